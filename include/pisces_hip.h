@@ -1,0 +1,275 @@
+/*
+ * pisces_hip.h — C ABI of libpisceship.so: the MI355X (gfx950) pileup-and-likelihood
+ * engine that sits behind Pisces' ICandidateVariantFinder / IStateManager / IAlleleCaller.
+ *
+ * Conventions (mirror the only P/Invoke precedent in the reference,
+ * src/lib/Common.IO/FileCompression.cs:10-35): cdecl, every function returns int32
+ * (0 = ok, <0 = error, see PISCES_E_*), plain pointers + sizes, caller-owned buffers that
+ * are only read/written for the duration of the call, opaque handle owning all device
+ * memory.  No function throws or aborts; pisces_hip_last_error() returns the message the
+ * C# shim turns into an exception (caught per job at
+ * src/lib/Pisces.Processing/Logic/BaseGenomeProcessor.cs:121-128).
+ *
+ * Each entry point cites the reference interface member it replaces.
+ */
+#ifndef PISCES_HIP_H
+#define PISCES_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PISCES_HIP_ABI_VERSION 1
+
+/* ---- error codes -------------------------------------------------------- */
+#define PISCES_OK                 0
+#define PISCES_E_INVALID_ARG     -1  /* reference: ArgumentException (RegionStateManager.cs:363-364, RegionState.cs:315-316) */
+#define PISCES_E_BUFFER_TOO_SMALL -2 /* caller grows the output buffer and repeats the call */
+#define PISCES_E_DEVICE          -3  /* HIP runtime error, message in last_error */
+#define PISCES_E_UNMAPPED_BASE   -4  /* reference: RegionStateManager.cs:109-113 */
+#define PISCES_E_UNSUPPORTED     -5
+#define PISCES_E_STATE           -6  /* call protocol violated */
+
+/* ---- enums: numeric values are the reference's ------------------------- */
+/* src/lib/Pisces.Domain/Types/AlleleType.cs:3-11 */
+enum { PISCES_ALLELE_A = 0, PISCES_ALLELE_G = 1, PISCES_ALLELE_C = 2, PISCES_ALLELE_T = 3,
+       PISCES_ALLELE_N = 4, PISCES_ALLELE_DEL = 5, PISCES_NUM_ALLELE_TYPES = 6 };
+/* src/lib/Pisces.Domain/Types/DirectionType.cs:3-8 */
+enum { PISCES_DIR_FORWARD = 0, PISCES_DIR_REVERSE = 1, PISCES_DIR_STITCHED = 2, PISCES_NUM_DIRECTIONS = 3 };
+/* src/lib/Pisces.Domain/Types/CallType.cs:3-12 */
+enum { PISCES_CAT_SNV = 0, PISCES_CAT_INSERTION = 1, PISCES_CAT_DELETION = 2, PISCES_CAT_MNV = 3,
+       PISCES_CAT_REFERENCE = 4 };
+/* src/lib/Pisces.Domain/Types/Genotype.cs:3-18 */
+enum { PISCES_GT_HET_ALT1_ALT2 = 0, PISCES_GT_ALT12_LIKE_NOCALL = 1, PISCES_GT_HET_ALT_REF = 2,
+       PISCES_GT_HOM_ALT = 3, PISCES_GT_HOM_REF = 4, PISCES_GT_REF_LIKE_NOCALL = 5,
+       PISCES_GT_ALT_LIKE_NOCALL = 6, PISCES_GT_REF_AND_NOCALL = 7, PISCES_GT_ALT_AND_NOCALL = 8 };
+/* src/lib/Pisces.Domain/Types/FilterType.cs:3-19 — bit i of filter_bits = enum value i */
+enum { PISCES_FILTER_STRAND_BIAS = 0, PISCES_FILTER_POOL_BIAS = 1, PISCES_FILTER_AMPLICON_BIAS = 2,
+       PISCES_FILTER_LOW_VARIANT_QSCORE = 3, PISCES_FILTER_LOW_DEPTH = 4,
+       PISCES_FILTER_LOW_VARIANT_FREQUENCY = 5, PISCES_FILTER_LOW_GENOTYPE_QUALITY = 6,
+       PISCES_FILTER_INDEL_REPEAT_LENGTH = 7, PISCES_FILTER_MULTI_ALLELIC_SITE = 8,
+       PISCES_FILTER_RMXN = 9, PISCES_FILTER_FORCED_REPORT = 10, PISCES_FILTER_OFF_TARGET = 11,
+       PISCES_FILTER_NO_CALL = 12 };
+/* src/lib/Pisces.Domain/Types (StrandBiasModel): Poisson, Extended, Diploid */
+enum { PISCES_SB_POISSON = 0, PISCES_SB_EXTENDED = 1, PISCES_SB_DIPLOID = 2 };
+
+/* Anchor bins: NumAnchorIndexes = 2*trackedAnchorSize+1 (RegionStateManager.cs:30-31), default 5 -> 11 */
+#define PISCES_ANCHOR_SIZE   5
+#define PISCES_NUM_ANCHORS   11
+#define PISCES_COUNTS_PER_LOCUS (PISCES_NUM_ALLELE_TYPES * PISCES_NUM_DIRECTIONS * PISCES_NUM_ANCHORS) /* 198 */
+#define PISCES_FOLDED_PER_LOCUS (PISCES_NUM_ALLELE_TYPES * PISCES_NUM_DIRECTIONS)                      /* 18  */
+
+/* ---- packed observation tuple (4 bytes) ---------------------
+ * bit  0..14  locus-in-tile (15 bits)
+ * bit 15..18  anchor bin 0..10  (GetAnchorType, RegionStateManager.cs:83-116)
+ * bit 19..20  direction 0..2
+ * bit 21..23  raw allele code 0..5 (before the min-base-quality test)
+ * bit 24..31  base quality (deletion tuples carry 255: their quality gate,
+ *             CheckDeletionQuality, was applied when the read was expanded)
+ * The kernel applies "qual < minBQ -> N" (RegionStateManager.cs:179-181). */
+#define PISCES_TUPLE_LOCUS_BITS 15
+#define PISCES_TUPLE_MAX_TILE   (1 << PISCES_TUPLE_LOCUS_BITS)
+#define PISCES_TUPLE_PACK(locus, anchor, dir, allele, qual) \
+    ((uint32_t)(locus) | ((uint32_t)(anchor) << 15) | ((uint32_t)(dir) << 19) | \
+     ((uint32_t)(allele) << 21) | ((uint32_t)(qual) << 24))
+#define PISCES_TUPLE_LOCUS(t)  ((t) & 0x7FFFu)
+#define PISCES_TUPLE_ANCHOR(t) (((t) >> 15) & 0xFu)
+#define PISCES_TUPLE_DIR(t)    (((t) >> 19) & 0x3u)
+#define PISCES_TUPLE_ALLELE(t) (((t) >> 21) & 0x7u)
+#define PISCES_TUPLE_QUAL(t)   ((t) >> 24)
+/* A tuple with all bits set is padding and is ignored by every kernel. */
+#define PISCES_TUPLE_PAD 0xFFFFFFFFu
+
+/* ---- configuration: VariantCallerConfig (src/exe/Pisces/Logic/VariantCalling/AlleleCaller.cs:266-291)
+ * + the state-manager/finder settings wired in Factory.cs:123-227.
+ * Defaults (pisces_hip_default_config) are the reference's
+ * (src/lib/Pisces.Domain/Options/VariantCallingParameters.cs:57-156). */
+typedef struct PiscesHipConfig {
+    int32_t abi_version;              /* PISCES_HIP_ABI_VERSION */
+    int32_t min_base_call_quality;    /* BamFilterParameters.MinimumBaseCallQuality, 20 */
+    int32_t noise_level;              /* NoiseLevelUsedForQScoring, = minBQ unless forced */
+    int32_t max_variant_qscore;       /* 100 */
+    int32_t min_variant_qscore;       /* 20 */
+    int32_t variant_qscore_filter;    /* VariantQscoreFilterThreshold, 30; -1 = null */
+    int32_t min_coverage;             /* MinCoverage, 10 */
+    int32_t low_depth_filter;         /* LowDepthFilter, 10; -1 = null */
+    int32_t min_genotype_qscore;      /* 0 */
+    int32_t max_genotype_qscore;      /* 100 */
+    int32_t low_gq_filter;            /* LowGTqFilter; -1 = null */
+    int32_t strand_bias_model;        /* PISCES_SB_EXTENDED */
+    int32_t filter_single_strand;     /* FilterSingleStrandVariants, 0 */
+    int32_t include_reference_calls;  /* gVCF, 1 */
+    int32_t emit_zero_coverage_refs;  /* 1 when an interval set is supplied (RegionState.cs:446) */
+    int32_t expect_stitched_reads;    /* IAlleleSource.ExpectStitchedReads */
+    int32_t tile_loci;                /* device tile, power of two <= 1024; 0 = default 64 */
+    int32_t block_size;               /* GlobalConstants.RegionSize, 1000 */
+    float   min_frequency;            /* MinFrequency, 0.01f */
+    float   variant_freq_filter;      /* VariantFreqFilter (MinimumFrequencyFilter), 0.01f; <0 = null */
+    float   genotype_min_freq_filter; /* SomaticGenotyper._minVariantFrequencyFilter, 0.01f */
+    float   target_lod_frequency;     /* TargetLODFrequency, 0.01f */
+    float   strand_bias_threshold;    /* StrandBiasFilterThreshold, 0.5f */
+    float   no_call_filter_threshold; /* NoCallFilterThreshold, 0.6f; <0 = null */
+    int32_t rmxn_max_repeat_length;   /* RMxNFilterMaxLengthRepeat, 5; <0 = filter off */
+    int32_t rmxn_min_repetitions;     /* RMxNFilterMinRepetitions, 9 */
+    float   rmxn_frequency_limit;     /* RMxNFilterFrequencyLimit, 0.35f */
+    int32_t reserved[3];
+} PiscesHipConfig;
+
+/* ---- one called allele (64 bytes; what CalledAllele carries to the VCF writer,
+ * src/lib/Pisces.Domain/Models/Alleles/CalledAllele.cs:7-140, VcfFormatter.cs:224) */
+typedef struct PiscesCalledAllele {
+    int32_t position;            /* ReferencePosition, 1-based */
+    int32_t total_coverage;      /* TotalCoverage */
+    int32_t allele_support;      /* AlleleSupport */
+    int32_t reference_support;   /* ReferenceSupport */
+    int32_t num_no_calls;        /* NumNoCalls */
+    int32_t coverage_by_dir[3];  /* EstimatedCoverageByDirection */
+    int32_t support_by_dir[3];   /* SupportByDirection */
+    int32_t variant_qscore;      /* VariantQscore */
+    double  strand_bias_score;   /* StrandBiasResults.BiasScore; GATKBiasScore = 10*log10 of it */
+    int32_t genotype_qscore;     /* GenotypeQscore */
+    uint16_t filter_bits;        /* bit i = FilterType i */
+    uint16_t info;               /* see PISCES_INFO_* */
+} PiscesCalledAllele;
+
+/* info: genotype[0..3] | category[4..6] | ref allele code[7..9] | alt allele code[10..12] |
+ *       BiasAcceptable[13] | VarPresentOnBothStrands[14] | CovPresentOnBothStrands[15]
+ * ref/alt codes are AlleleType values (single-base alleles).  For host-supplied spanning
+ * candidates the strings stay with the caller; alt code then holds PISCES_ALLELE_N. */
+#define PISCES_INFO_GENOTYPE(i)  ((i) & 0xF)
+#define PISCES_INFO_CATEGORY(i)  (((i) >> 4) & 0x7)
+#define PISCES_INFO_REF(i)       (((i) >> 7) & 0x7)
+#define PISCES_INFO_ALT(i)       (((i) >> 10) & 0x7)
+#define PISCES_INFO_SB_OK(i)     (((i) >> 13) & 1)
+#define PISCES_INFO_VAR_BOTH(i)  (((i) >> 14) & 1)
+#define PISCES_INFO_COV_BOTH(i)  (((i) >> 15) & 1)
+#define PISCES_INFO_PACK(gt, cat, ref, alt, sbok, varboth, covboth) \
+    ((uint16_t)((gt) | ((cat) << 4) | ((ref) << 7) | ((alt) << 10) | ((sbok) << 13) | \
+                ((varboth) << 14) | ((covboth) << 15)))
+
+/* ---- tile descriptor: a run of <= tile_loci consecutive reference positions ------------
+ * The unit of device work and of interval sharding.  Tiles of one call must
+ * not overlap; tuples [tuple_begin, tuple_end) of the tuple buffer belong to this tile. */
+typedef struct PiscesTile {
+    int32_t start_position;   /* 1-based position of locus 0 */
+    int32_t n_loci;           /* 1..tile_loci */
+    int64_t tuple_begin;
+    int64_t tuple_end;
+} PiscesTile;
+
+/* per-tile output directory entry written by the device */
+typedef struct PiscesTileResult {
+    int32_t record_begin;     /* index of the tile's first record in the record buffer */
+    int32_t n_records;        /* called alleles of this tile, sorted by (position, ref, alt) */
+    int32_t n_candidate_loci; /* positions with >= 1 called allele */
+    int32_t reserved;
+} PiscesTileResult;
+
+/* ---- a batch of reads, structure-of-arrays (what the C# shim pins per call) ------------
+ * replaces the Read object walked by FindCandidates/AddAlleleCounts
+ * (src/lib/Pisces.Domain/Models/Read.cs:74-96, 535-562). Reads must already have passed
+ * AlignmentSource.ShouldSkipRead (src/exe/Pisces/Logic/Alignment/AlignmentsSource.cs:84-92). */
+typedef struct PiscesReadBatch {
+    int32_t        n_reads;
+    const int32_t* position;      /* [n_reads] Read.Position (1-based) */
+    const uint8_t* flags;         /* [n_reads] bit0 = reverse strand */
+    const int32_t* cigar_offset;  /* [n_reads+1] into cigar_op / cigar_len */
+    const uint8_t* cigar_op;      /* 'M','I','D','S','N','=','X','H','P' */
+    const uint32_t* cigar_len;
+    const int32_t* seq_offset;    /* [n_reads+1] into bases / quals / directions */
+    const uint8_t* bases;         /* upper-case ASCII */
+    const uint8_t* quals;         /* phred */
+    const uint8_t* directions;    /* optional per-base DirectionType (stitched reads, XD tag); NULL = from flags */
+} PiscesReadBatch;
+
+/* ---- a candidate allele crossing the boundary (CandidateAllele.cs:8-49) ---- */
+typedef struct PiscesCandidate {
+    int32_t position;
+    int32_t category;             /* PISCES_CAT_* */
+    int32_t ref_len, alt_len;
+    int32_t support_by_dir[3];
+    int32_t well_anchored_by_dir[3];
+    uint8_t open_left, open_right;
+    uint8_t pad[2];
+    int64_t allele_offset;        /* ref bytes then alt bytes at this offset of the allele byte pool */
+} PiscesCandidate;
+
+typedef struct PiscesHip PiscesHip;
+
+/* ---- lifecycle ----------------------------------------------------------- */
+/* fills *cfg with the reference defaults */
+int32_t pisces_hip_default_config(PiscesHipConfig* cfg);
+/* Factory.CreateStateManager / CreateVariantCaller / CreateVariantFinder (Factory.cs:123,128,209):
+ * one handle per (BAM, chromosome) job; owns one HIP stream; no global mutable state. */
+int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip** out);
+int32_t pisces_hip_destroy(PiscesHip* h);
+const char* pisces_hip_last_error(const PiscesHip* h);   /* h may be NULL: message of the last failed create */
+int32_t pisces_hip_abi_version(void);
+
+/* ChrReference.Sequence (upper-cased whole chromosome, src/lib/Pisces.IO/Genome.cs:84-96).
+ * bases[i] is position i+1. Copied to the device. */
+int32_t pisces_hip_set_reference(PiscesHip* h, const uint8_t* upper_bases, int64_t length);
+
+/* ---- streaming surface: IStateManager -------------------------------------- */
+/* ICandidateVariantFinder.FindCandidates + IStateManager.AddCandidates + AddAlleleCounts
+ * (SmallVariantCaller.cs:88-98) for a batch of reads: expands reads to observation tuples,
+ * keeps MNV/indel candidates host-side, stages tuples for the device. */
+int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch);
+/* Pre-expanded observations for the block grid: positions[i] is the 1-based locus of tuples[i]
+ * (the tuple's locus field is ignored). */
+int32_t pisces_hip_add_observations(PiscesHip* h, const int32_t* positions, const uint32_t* tuples, int64_t n);
+/* IStateManager.GetCandidatesToProcess(upTo) + IAlleleCaller.Call + DoneProcessing
+ * (SmallVariantCaller.cs:157-189).  up_to_position < 0 = final flush (Call(null)).
+ * Writes called alleles sorted by (position, ref, alt) into out[0..capacity); *n_out = number
+ * produced.  Returns PISCES_E_BUFFER_TOO_SMALL (and *n_out = required) without consuming the
+ * batch when capacity is insufficient: grow and repeat. */
+int32_t pisces_hip_flush(PiscesHip* h, int32_t up_to_position, PiscesCalledAllele* out,
+                         int64_t capacity, int64_t* n_out);
+/* IAlleleSource.GetAlleleCount for a run of positions: out[n][6][3][11] int32
+ * (RegionState.cs:57); blocks never touched read as zero (RegionStateManager.cs:222-226). */
+int32_t pisces_hip_get_counts(PiscesHip* h, int32_t start_position, int32_t n, int32_t* out);
+/* IAlleleSource.AddGappedMnvRefCount (RegionStateManager.cs:74-81) */
+int32_t pisces_hip_add_gapped_mnv_ref(PiscesHip* h, const int32_t* positions, const int32_t* counts, int32_t n);
+/* host-side candidates (MNV / insertion / deletion) found so far with position <= up_to
+ * (IStateManager.GetCandidatesToProcess for the host collapser). alleles = byte pool. */
+int32_t pisces_hip_get_candidates(PiscesHip* h, int32_t up_to_position, PiscesCandidate* out,
+                                  int64_t capacity, int64_t* n_out, uint8_t* alleles,
+                                  int64_t allele_capacity, int64_t* allele_bytes);
+/* totals lines: {allelesCalled (IAlleleCaller.TotalNumCalled), variantsCollapsed, readsProcessed,
+ * observations} (SmallVariantCaller.cs:114-115) */
+int32_t pisces_hip_stats(PiscesHip* h, int64_t out[4]);
+
+/* ---- device-resident surface (bench / multi-GPU shards) --------------------
+ * All d_* pointers are device pointers on the handle's device; stream is a hipStream_t
+ * (NULL = the handle's own stream).  One launch: per tile, observation tuples -> LDS
+ * allele-count histogram -> coverage, Poisson q-score, strand bias, somatic genotype and
+ * filters for the reference allele and every SNV candidate -> 64-byte records.
+ * d_ref_bases[i] is the reference base of position ref_start_position+i.
+ * d_record_count is an int32 device counter that the call resets and the kernel bumps;
+ * d_tile_results[n_tiles] receives each tile's slice of d_records. Asynchronous. */
+int32_t pisces_hip_call_tiles(PiscesHip* h, const uint32_t* d_tuples, const PiscesTile* d_tiles,
+                              int32_t n_tiles, const uint8_t* d_ref_bases, int32_t ref_start_position,
+                              int64_t ref_length, PiscesCalledAllele* d_records, int32_t record_capacity,
+                              int32_t* d_record_count, PiscesTileResult* d_tile_results, void* stream);
+/* tuples -> anchor-resolved counts added into d_counts[n_tiles*tile_loci][6][3][11]
+ * (the IAlleleSource view for host-side collapsing / spanning coverage). Asynchronous. */
+int32_t pisces_hip_accumulate_tiles(PiscesHip* h, const uint32_t* d_tuples, const PiscesTile* d_tiles,
+                                    int32_t n_tiles, int32_t* d_counts, void* stream);
+/* waits for the handle's stream */
+int32_t pisces_hip_synchronize(PiscesHip* h);
+/* time of the last call_tiles / accumulate_tiles launch measured with HIP events on the
+ * launch stream, in milliseconds (valid after synchronize) */
+int32_t pisces_hip_last_kernel_ms(PiscesHip* h, float* ms);
+
+/* ---- host-side helpers (pure CPU, no device needed) -------------------------- */
+/* Expands reads to (position, tuple) observations exactly as AddAlleleCounts walks a read
+ * (RegionStateManager.cs:118-220).  Returns the number written or PISCES_E_BUFFER_TOO_SMALL. */
+int64_t pisces_hip_expand_reads(const PiscesReadBatch* batch, int32_t min_base_call_quality,
+                                int32_t* positions, uint32_t* tuples, int64_t capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PISCES_HIP_H */

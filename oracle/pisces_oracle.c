@@ -1,0 +1,1444 @@
+/*
+ * pisces_oracle.c — TEST INFRASTRUCTURE ONLY (see pisces_oracle.h).
+ * CPU restatement of the Pisces pileup-and-likelihood path.  Compile with
+ * -ffp-contract=off: the reference is C# double/float arithmetic without fused ops.
+ * Citations are relative to /root/reference/src.
+ */
+#include "pisces_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* =====================================================================================
+ * lib/Pisces.Calculators/stats/Poisson.cs  (in-repo incomplete gamma, Numerical-Recipes style)
+ * ===================================================================================== */
+static const double kEpsilon = 1.0E-20;      /* Poisson.cs:15 */
+static const double kFpmin = 1.0E-50;        /* :16 */
+static const double kLanczCutoff = 700.0;    /* :17 */
+#define kItmax 300                            /* :18 */
+
+/* Poisson.cs:106-120 */
+static double lanczos_approximation(double p)
+{
+    double x = p;
+    double tmp = x + 5.5;
+    tmp = tmp - (x + 0.5) * log(tmp);
+    double ser = 1.000000000190015 + 76.18009172947146 / (p + 1.0);
+    ser -= 86.50532032941678 / (p + 2.0);
+    ser += 24.01409824083091 / (p + 3.0);
+    ser -= 1.231739572450155 / (p + 4.0);
+    ser += 0.001208650973866179 / (p + 5.0);
+    ser -= 5.395239384953E-06 / (p + 6.0);
+    return (log(2.506628274631001 * ser / x) - tmp);
+}
+
+/* Poisson.cs:125-128 */
+static double stirling_approximation(double n)
+{
+    return (0.5 * log(2.0 * M_PI) + (0.5 + n) * log(n) - n);
+}
+
+/* Poisson.cs:49-74 */
+static double gamma_continued_fraction(double a, double x, double g)
+{
+    double b = x + 1.0 - a;
+    double c = 1.0 / kFpmin;
+    double d = 1.0 / b;
+    double h = d;
+    int i;
+    for (i = 1; i <= kItmax; i++) {
+        double an = i * (a - i);
+        b += 2.0;
+        d = an * d + b;
+        if (fabs(d) < kFpmin) d = kFpmin;
+        c = b + an / c;
+        if (fabs(c) < kFpmin) c = kFpmin;
+        d = 1.0 / d;
+        double del = d * c;
+        h *= del;
+        if (fabs(del - 1.0) < kEpsilon) break;
+    }
+    if (i > kItmax) return -1.0;
+    return exp(a * log(x) - x - g) * h;
+}
+
+/* Poisson.cs:76-101 */
+static double gamma_series(double a, double x, double g)
+{
+    double retval = -1.0;
+    if (x == 0.0) return 0.0;
+    if (x < 0.0) return retval;
+    double ap = a;
+    double sum = 1.0 / a;
+    double del = sum;
+    for (int i = 1; i <= kItmax; i++) {
+        ap += 1.0;
+        del *= x / ap;
+        sum += del;
+        if (fabs(del) < fabs(sum) * kEpsilon) {
+            retval = sum * exp(a * log(x) - x - g);
+            break;
+        }
+    }
+    return retval;
+}
+
+/* Poisson.cs:34-44 */
+static double incomplete_gamma_function(double a, double x)
+{
+    if ((x < 0) || (a <= 0)) return -1.0;
+    double g = (a >= kLanczCutoff ? stirling_approximation(a) : lanczos_approximation(a));
+    if (x >= a + 1.0) return gamma_continued_fraction(a, x, g);
+    if ((g = gamma_series(a, x, g)) < 0) return g;
+    return 1.0 - g;
+}
+
+/* Poisson.cs:26-29 */
+double orc_poisson_cdf(double num_occurrences, double expected)
+{
+    return incomplete_gamma_function((double)(int)(num_occurrences + 1.0), expected);
+}
+
+/* stats/MathOperations.cs:7-10: Math.Pow(10, -1 * q / 10f) with q double -> double division */
+double orc_q_to_p(double q) { return pow(10.0, -1 * q / (double)10.0f); }
+/* stats/MathOperations.cs:12-15 */
+double orc_p_to_q(double p) { return (-10 * log10(p)); }
+
+/* =====================================================================================
+ * MathNet.Numerics 4.5.1 (NuGet; lib/Pisces.Calculators/Pisces.Calculators.csproj:24) —
+ * restated from the published algorithm: SpecialFunctions.GammaLn (Lanczos, g = 10.900511,
+ * 11 terms), GammaLowerRegularized (Cephes igam/igamc), Poisson.CumulativeDistribution and
+ * ProbabilityLn.  Call sites: VariantQualityCalculator.cs:36,38,47.
+ * ===================================================================================== */
+static const double kGammaDk[11] = {
+    2.48574089138753565546e-5, 1.05142378581721974210, -3.45687097222016235469,
+    4.51227709466894823700, -2.98285225323576655721, 1.05639711577126713077,
+    -1.95428773191645869583e-1, 1.70970543404441224307e-2, -5.71926117404305781283e-4,
+    4.63399473359905636708e-6, -2.71994908488607703910e-9};
+static const double kGammaR = 10.900511;
+static const double kLogTwoSqrtEOverPi = 0.6207822376352452223455184457816472122518527279025978;
+static const double kLnPi = 1.1447298858494001741434273513530587116472948129153;
+
+double orc_mathnet_gamma_ln(double z)
+{
+    if (z < 0.5) {
+        double s = kGammaDk[0];
+        for (int i = 1; i <= 10; i++) s += kGammaDk[i] / (i - z);
+        return kLnPi - log(sin(M_PI * z)) - log(s) - kLogTwoSqrtEOverPi -
+               ((0.5 - z) * log((0.5 - z + kGammaR) / M_E));
+    } else {
+        double s = kGammaDk[0];
+        for (int i = 1; i <= 10; i++) s += kGammaDk[i] / (z + i - 1.0);
+        return log(s) + kLogTwoSqrtEOverPi + ((z - 0.5) * log((z - 0.5 + kGammaR) / M_E));
+    }
+}
+
+static double mathnet_factorial_ln(int x)
+{
+    /* SpecialFunctions.FactorialLn: cache of 171 factorials built by repeated multiplication */
+    static double cache[171];
+    static int init = 0;
+    if (!init) {
+        cache[0] = 1.0;
+        for (int i = 1; i < 171; i++) cache[i] = cache[i - 1] * i;
+        init = 1;
+    }
+    if (x <= 1) return 0.0;
+    if (x < 171) return log(cache[x]);
+    return orc_mathnet_gamma_ln(x + 1.0);
+}
+
+static int almost_zero(double v) { return fabs(v) < 1e-15; }
+
+double orc_mathnet_gamma_lower_regularized(double a, double x)
+{
+    const double epsilon = 0.000000000000001;
+    const double big = 4503599627370496.0;
+    const double bigInv = 2.22044604925031308085e-16;
+
+    if (almost_zero(a)) {
+        if (almost_zero(x)) return NAN;
+        return 1.0;
+    }
+    if (almost_zero(x)) return 0.0;
+
+    double ax = (a * log(x)) - x - orc_mathnet_gamma_ln(a);
+    if (ax < -709.78271289338399) return a < x ? 1.0 : 0.0;
+
+    if (x <= 1 || x <= a) {
+        double r2 = a, c2 = 1, ans2 = 1;
+        do {
+            r2 = r2 + 1;
+            c2 = c2 * x / r2;
+            ans2 += c2;
+        } while ((c2 / ans2) > epsilon);
+        return exp(ax) * ans2 / a;
+    }
+
+    int c = 0;
+    double y = 1 - a;
+    double z = x + y + 1;
+    double p3 = 1, q3 = x, p2 = x + 1, q2 = z * x;
+    double ans = p2 / q2;
+    double error;
+    do {
+        c++;
+        y += 1;
+        z += 2;
+        double yc = y * c;
+        double p = (p2 * z) - (p3 * yc);
+        double q = (q2 * z) - (q3 * yc);
+        if (q != 0) {
+            double nextans = p / q;
+            error = fabs((ans - nextans) / nextans);
+            ans = nextans;
+        } else {
+            error = 1;
+        }
+        p3 = p2; p2 = p; q3 = q2; q2 = q;
+        if (fabs(p) > big) {
+            p3 *= bigInv; p2 *= bigInv; q3 *= bigInv; q2 *= bigInv;
+        }
+    } while (error > epsilon);
+    return 1.0 - (exp(ax) * ans);
+}
+
+/* Poisson.CumulativeDistribution(x) = 1 - GammaLowerRegularized(x + 1, lambda) */
+double orc_mathnet_poisson_cdf(double lambda, double x)
+{
+    return 1.0 - orc_mathnet_gamma_lower_regularized(x + 1, lambda);
+}
+/* Poisson.ProbabilityLn(k) = -lambda + k ln(lambda) - FactorialLn(k) */
+double orc_mathnet_poisson_ln_pmf(double lambda, int32_t k)
+{
+    return -lambda + (k * log(lambda)) - mathnet_factorial_ln(k);
+}
+
+/* =====================================================================================
+ * lib/Pisces.Calculators/VariantQualityCalculator.cs
+ * ===================================================================================== */
+/* :67-74 */
+double orc_assign_pvalue(int32_t observed, int32_t coverage, int32_t nl)
+{
+    double errorRate = orc_q_to_p(nl);
+    if (observed == 0) return 1.0;
+    return (1 - orc_poisson_cdf(observed - 1.0, coverage * errorRate));
+}
+
+/* :27-52 */
+double orc_raw_poisson_qscore(int32_t callCount, int32_t coverage, int32_t nl)
+{
+    double errorRate = orc_q_to_p(nl);
+    double callCountMinusOne = callCount - 1;
+    double callCountDouble = callCount;
+    double lambda = errorRate * coverage;
+    double pValue = 1 - orc_mathnet_poisson_cdf(lambda, callCountMinusOne);
+    if (pValue > 0) {
+        return orc_p_to_q(pValue);
+    } else {
+        double A = orc_mathnet_poisson_ln_pmf(lambda, (int)callCountMinusOne);
+        double correction = (callCountDouble - lambda) / callCountDouble;
+        double qScore = -10.0 * (A - log(2.0 * correction)) / log(10.0);
+        return qScore;
+    }
+}
+
+/* :54-65; Math.Round = banker's rounding = rint() in the default FP environment */
+int32_t orc_poisson_qscore(int32_t callCount, int32_t coverage, int32_t nl, int32_t maxQ)
+{
+    if ((callCount <= 0) || (coverage <= 0)) return 0;
+    double rawQ = orc_raw_poisson_qscore(callCount, coverage, nl);
+    double qScore = fmin((double)maxQ, rawQ);
+    qScore = fmax(qScore, 0);
+    return (int32_t)rint(qScore);
+}
+
+/* =====================================================================================
+ * lib/Pisces.Calculators/StrandBiasCalculator.cs
+ * ===================================================================================== */
+/* PopulateStats :175-231 (Poisson / Extended models; Diploid is out of scope) */
+static void sb_create_stats(OrcSbStats* st, double support, double coverage, double noiseFreq,
+                            double minDetectableSNP, int32_t model)
+{
+    if (model != PISCES_SB_DIPLOID) minDetectableSNP = noiseFreq; /* CreateStats :141-142 */
+    st->frequency = support / coverage;                           /* StrandBiasStats ctor */
+    st->support = support;
+    st->coverage = coverage;
+    if (coverage == 0) st->frequency = 0;
+    st->chance_false_neg = st->chance_false_pos = st->chance_var_freq_gt_zero = 0;
+
+    if (st->support == 0) {
+        if (model == PISCES_SB_POISSON) {
+            st->chance_false_pos = 1;
+            st->chance_var_freq_gt_zero = 0;
+            st->chance_false_neg = 0;
+        } else {
+            st->chance_var_freq_gt_zero = pow(1 - minDetectableSNP, st->coverage);
+            st->chance_false_pos = 1 - st->chance_var_freq_gt_zero;
+            st->chance_false_neg = st->chance_var_freq_gt_zero;
+        }
+    } else {
+        st->chance_var_freq_gt_zero = fmax(0, orc_poisson_cdf(st->support - 1, st->coverage * noiseFreq));
+        st->chance_false_pos = fmax(0, 1 - st->chance_var_freq_gt_zero);
+        st->chance_false_neg = fmax(0, orc_poisson_cdf(st->support, st->coverage * minDetectableSNP));
+    }
+}
+
+/* CalculateStrandBiasResults :21-72, AssignBiasScore :89-105 */
+void orc_strand_bias(const int32_t cov[3], const int32_t sup[3], int32_t qNoise, double minVariantFreq,
+                     double acceptance, int32_t model, OrcBiasResults* r)
+{
+    int forwardSupport = sup[PISCES_DIR_FORWARD], forwardCoverage = cov[PISCES_DIR_FORWARD];
+    int reverseSupport = sup[PISCES_DIR_REVERSE], reverseCoverage = cov[PISCES_DIR_REVERSE];
+    int stitchedSupport = sup[PISCES_DIR_STITCHED], stitchedCoverage = cov[PISCES_DIR_STITCHED];
+
+    /* Math.Pow(10, -1*qNoise/10f): int / float -> float exponent */
+    double errorRate = pow(10.0, (double)((float)(-1 * qNoise) / 10.0f));
+
+    sb_create_stats(&r->overall, forwardSupport + reverseSupport + stitchedSupport,
+                    forwardCoverage + reverseCoverage + stitchedCoverage, errorRate, minVariantFreq, model);
+    sb_create_stats(&r->forward, forwardSupport + stitchedSupport / 2, forwardCoverage + stitchedCoverage / 2,
+                    errorRate, minVariantFreq, model);
+    sb_create_stats(&r->reverse, reverseSupport + stitchedSupport / 2, reverseCoverage + stitchedCoverage / 2,
+                    errorRate, minVariantFreq, model);
+    sb_create_stats(&r->stitched, stitchedSupport, stitchedCoverage, errorRate, minVariantFreq, model);
+
+    double forwardBias = (r->forward.chance_var_freq_gt_zero * r->reverse.chance_false_pos) /
+                         r->overall.chance_var_freq_gt_zero;
+    double reverseBias = (r->reverse.chance_var_freq_gt_zero * r->forward.chance_false_pos) /
+                         r->overall.chance_var_freq_gt_zero;
+    if (r->overall.chance_var_freq_gt_zero == 0) {
+        forwardBias = 1;
+        reverseBias = 1;
+    }
+    /* Math.Max: NaN-propagating; operands here are never NaN after the guard above */
+    double p = forwardBias > reverseBias ? forwardBias : reverseBias;
+    r->bias_score = p;
+    r->gatk_bias_score = 10 * log10(p);
+    r->cov_present_on_both = ((r->forward.coverage > 0) && (r->reverse.coverage > 0));
+    r->var_present_on_both = ((r->forward.support > 0) && (r->reverse.support > 0));
+    if (!r->cov_present_on_both) {
+        r->bias_score = 0;
+        r->gatk_bias_score = -INFINITY;
+    }
+    r->bias_acceptable = (r->bias_score < acceptance);
+}
+
+/* =====================================================================================
+ * lib/Pisces.Genotyping/Somatic
+ * ===================================================================================== */
+/* CalledAllele.Frequency / RefFrequency (CalledAllele.cs:49-52,121-124): float32 */
+static float frequency_f(int32_t support, int32_t coverage)
+{
+    if (coverage == 0) return 0.0f;
+    float f = (float)support / (float)coverage;
+    return f < 1.0f ? f : 1.0f;
+}
+
+/* SomaticGenotyper.CalculateSomaticGenotype :65-100 */
+int32_t orc_somatic_genotype(int32_t category, int32_t totalCoverage, int32_t alleleSupport,
+                             int32_t referenceSupport, float minFrequencyFilter, int32_t minDepthToGenotype)
+{
+    if (totalCoverage < minDepthToGenotype)
+        return (category == PISCES_CAT_REFERENCE) ? PISCES_GT_REF_LIKE_NOCALL : PISCES_GT_ALT_LIKE_NOCALL;
+    float freq = frequency_f(alleleSupport, totalCoverage);
+    if (category != PISCES_CAT_REFERENCE) {
+        float refFreq = frequency_f(referenceSupport, totalCoverage);
+        if (refFreq < minFrequencyFilter) {
+            if ((1 - freq) > minFrequencyFilter) return PISCES_GT_ALT_AND_NOCALL;
+            return PISCES_GT_HOM_ALT;
+        }
+        return PISCES_GT_HET_ALT_REF;
+    } else {
+        if (freq < minFrequencyFilter) return PISCES_GT_REF_LIKE_NOCALL;
+        if ((1 - freq) > minFrequencyFilter) return PISCES_GT_REF_AND_NOCALL;
+    }
+    return PISCES_GT_HOM_REF;
+}
+
+/* SomaticGenotypeQualityCalculator.Compute :10-48 */
+int32_t orc_somatic_gq(int32_t genotype, int32_t variantQ, int32_t totalCoverage, int32_t alleleSupport,
+                       float targetLod, int32_t minGQ, int32_t maxGQ)
+{
+    double rawQ = variantQ;
+    int isNoCall = (genotype == PISCES_GT_ALT12_LIKE_NOCALL || genotype == PISCES_GT_ALT_LIKE_NOCALL ||
+                    genotype == PISCES_GT_REF_LIKE_NOCALL || genotype == 11 /* HemizygousNoCall */);
+    if ((totalCoverage == 0) || isNoCall) return minGQ;
+    if ((genotype == PISCES_GT_HOM_REF) || (genotype == PISCES_GT_HOM_ALT)) {
+        double p1 = orc_q_to_p(variantQ);
+        float nonAlleleObservationsF = (1.0f - frequency_f(alleleSupport, totalCoverage)) * (float)totalCoverage;
+        float expectedNonAllelObservationsF = targetLod * (float)totalCoverage;
+        if (nonAlleleObservationsF >= expectedNonAllelObservationsF) return minGQ;
+        double p2 = orc_poisson_cdf(nonAlleleObservationsF, expectedNonAllelObservationsF);
+        rawQ = orc_p_to_q(p1 + p2);
+    }
+    double qScore = fmin((double)maxGQ, rawQ);
+    qScore = fmax(qScore, (double)minGQ);
+    return (int32_t)rint(qScore);
+}
+
+/* =====================================================================================
+ * Read geometry: Read.cs:535-562 (UpdatePositionMap), BamCommon.cs:119,560-585
+ * ===================================================================================== */
+static int op_is_ref_span(uint8_t t) { return t == 'M' || t == 'D' || t == 'N' || t == '=' || t == 'X'; }
+static int op_is_read_span(uint8_t t) { return t == 'M' || t == 'I' || t == 'S' || t == '=' || t == 'X'; }
+
+static int32_t read_ref_span(const OrcRead* r)
+{
+    int32_t n = 0;
+    for (int i = 0; i < r->n_cigar; i++)
+        if (op_is_ref_span(r->cigar_op[i])) n += (int32_t)r->cigar_len[i];
+    return n;
+}
+/* Read.EndPosition = BamAlignment.EndPosition + 1 = Position(1-based) + refSpan - 1 (Read.cs:88-91) */
+static int32_t read_end_position(const OrcRead* r) { return r->position + read_ref_span(r) - 1; }
+
+static void build_position_map(const OrcRead* r, int32_t* posmap)
+{
+    if (r->posmap_override) {
+        memcpy(posmap, r->posmap_override, sizeof(int32_t) * (size_t)r->read_len);
+        return;
+    }
+    for (int i = 0; i < r->read_len; i++) posmap[i] = -1;
+    int readIndex = 0;
+    int referencePosition = r->position;
+    for (int c = 0; c < r->n_cigar; c++) {
+        int readSpan = op_is_read_span(r->cigar_op[c]);
+        int refSpan = op_is_ref_span(r->cigar_op[c]);
+        for (uint32_t k = 0; k < r->cigar_len[c]; k++) {
+            if (readSpan) {
+                if (readIndex < r->read_len) posmap[readIndex] = refSpan ? referencePosition++ : -1;
+                readIndex++;
+            } else if (refSpan) {
+                referencePosition++;
+            }
+        }
+    }
+}
+
+static int32_t read_dir(const OrcRead* r, int idx)
+{
+    if (r->dirs) return r->dirs[idx];
+    return r->is_reverse ? PISCES_DIR_REVERSE : PISCES_DIR_FORWARD; /* Read.cs:394-401 */
+}
+
+/* CigarExtensions.HasOperationAtOpIndex (Utility/CigarExtensions.cs:38-44) */
+static int has_op_at(const OrcRead* r, int index, uint8_t type, int fromEnd)
+{
+    int opIndex = fromEnd ? r->n_cigar - index - 1 : index;
+    return r->n_cigar > opIndex && opIndex >= 0 && r->cigar_op[opIndex] == type;
+}
+
+/* AlleleHelper.GetAlleleType (Utility/AlleleHelper.cs:13-32) */
+static int32_t allele_type_of(uint8_t c)
+{
+    switch (c) {
+    case 'A': return PISCES_ALLELE_A;
+    case 'C': return PISCES_ALLELE_C;
+    case 'G': return PISCES_ALLELE_G;
+    case 'T': return PISCES_ALLELE_T;
+    default: return PISCES_ALLELE_N;
+    }
+}
+
+/* CandidateVariantFinder.CheckDeletionQuality :294-320 */
+int32_t orc_check_deletion_quality(const OrcRead* r, int32_t opStartIndexInRead, int32_t minBQ)
+{
+    if (r->read_len == 0) return 0;
+    int after = (opStartIndexInRead < r->read_len) ? r->quals[opStartIndexInRead] : r->quals[opStartIndexInRead - 1];
+    int before = after;
+    if (opStartIndexInRead > 0) before = r->quals[opStartIndexInRead - 1];
+    return (before >= minBQ) && (after >= minBQ);
+}
+
+/* =====================================================================================
+ * lib/Pisces.Processing/RegionState
+ * ===================================================================================== */
+struct OrcState {
+    int32_t start_position, n_loci, min_bq, num_anchor_types, n_anchor_idx, track_open_ended;
+    int32_t* counts;   /* [n_loci][6][3][n_anchor_idx]  RegionState.cs:57 */
+    double* sumq;      /* RegionState.cs:61 */
+    int32_t* gapped;   /* RegionState.cs:58 */
+    int32_t* cand_head;
+    int32_t* cand_tail;
+    OrcCandidate* cands;
+    int32_t n_cands, cap_cands;
+};
+
+OrcState* orc_state_create(int32_t start, int32_t n_loci, int32_t min_bq, int32_t num_anchor_types,
+                           int32_t track_open_ended)
+{
+    OrcState* s = (OrcState*)calloc(1, sizeof(OrcState));
+    s->start_position = start;
+    s->n_loci = n_loci;
+    s->min_bq = min_bq;
+    s->num_anchor_types = num_anchor_types;
+    s->n_anchor_idx = num_anchor_types * 2 + 1;
+    s->track_open_ended = track_open_ended;
+    size_t per = (size_t)6 * 3 * (size_t)s->n_anchor_idx;
+    s->counts = (int32_t*)calloc((size_t)n_loci * per, sizeof(int32_t));
+    s->sumq = (double*)calloc((size_t)n_loci * per, sizeof(double));
+    s->gapped = (int32_t*)calloc((size_t)n_loci, sizeof(int32_t));
+    s->cand_head = (int32_t*)malloc(sizeof(int32_t) * (size_t)n_loci);
+    s->cand_tail = (int32_t*)malloc(sizeof(int32_t) * (size_t)n_loci);
+    for (int i = 0; i < n_loci; i++) s->cand_head[i] = s->cand_tail[i] = -1;
+    return s;
+}
+
+void orc_state_destroy(OrcState* s)
+{
+    if (!s) return;
+    free(s->counts); free(s->sumq); free(s->gapped); free(s->cand_head); free(s->cand_tail); free(s->cands);
+    free(s);
+}
+
+const int32_t* orc_counts_ptr(const OrcState* s) { return s->counts; }
+int32_t orc_num_anchor_indexes(const OrcState* s) { return s->n_anchor_idx; }
+
+static inline size_t cidx(const OrcState* s, int32_t pos, int allele, int dir, int anchor)
+{
+    return (((size_t)(pos - s->start_position) * 6 + (size_t)allele) * 3 + (size_t)dir) * (size_t)s->n_anchor_idx +
+           (size_t)anchor;
+}
+static inline int in_region(const OrcState* s, int32_t pos)
+{
+    return pos >= s->start_position && pos < s->start_position + s->n_loci;
+}
+
+/* RegionState.AddAlleleCount :225-231 (positions outside the oracle's dense window are dropped,
+ * the analogue of a block nobody asks for) */
+static void add_allele_count(OrcState* s, int32_t pos, int allele, int dir, int anchor)
+{
+    if (in_region(s, pos)) s->counts[cidx(s, pos, allele, dir, anchor)]++;
+}
+static void add_base_quality(OrcState* s, int32_t pos, int allele, int dir, double q, int anchor)
+{
+    if (in_region(s, pos)) s->sumq[cidx(s, pos, allele, dir, anchor)] += q;
+}
+
+/* RegionStateManager.GetAnchorType :83-116; returns -1 where the reference throws */
+static int get_anchor_type(const OrcState* s, int alignmentEndPosition, int basePosition, int alignmentStartPosition)
+{
+    int leftAnchor = basePosition - alignmentStartPosition;
+    int rightAnchor = alignmentEndPosition - basePosition;
+    int minAnchor;
+    if (leftAnchor >= rightAnchor) {
+        if (rightAnchor >= s->num_anchor_types) return s->num_anchor_types; /* WellAnchoredIndex */
+        minAnchor = s->n_anchor_idx - rightAnchor - 1;
+    } else {
+        if (leftAnchor >= s->num_anchor_types) return s->num_anchor_types;
+        minAnchor = leftAnchor;
+    }
+    if (minAnchor < 0) return -1;
+    return minAnchor;
+}
+
+/* RegionStateManager.AddAlleleCounts :118-220 */
+int32_t orc_add_allele_counts(OrcState* s, const OrcRead* r)
+{
+    int32_t stack_map[512];
+    int32_t* posmap = r->read_len <= 512 ? stack_map : (int32_t*)malloc(sizeof(int32_t) * (size_t)r->read_len);
+    build_position_map(r, posmap);
+    int32_t rc = 0;
+
+    int lastPosition = r->position - 1;
+    int deletionLength = 0;
+    int lengthBeforeDeletion = r->read_len;
+    int endsInDeletion = has_op_at(r, 0, 'D', 1);
+    int endsInDeletionBeforeSoftclip = has_op_at(r, 1, 'D', 1) && has_op_at(r, 0, 'S', 1);
+    if (endsInDeletion || endsInDeletionBeforeSoftclip) {
+        deletionLength = (int)(endsInDeletionBeforeSoftclip ? r->cigar_len[r->n_cigar - 2] : r->cigar_len[r->n_cigar - 1]);
+        lengthBeforeDeletion = (int)(endsInDeletionBeforeSoftclip ? r->read_len - (int)r->cigar_len[r->n_cigar - 1] : r->read_len);
+    }
+    int positionMapLength = r->read_len;
+    int alignmentEndPosition = read_end_position(r);
+    int alignmentStartPosition = r->position;
+    int nAnchorIdx = s->n_anchor_idx;
+
+    for (int positionMapIndex = 0; positionMapIndex < positionMapLength; positionMapIndex++) {
+        int directionType = read_dir(r, positionMapIndex);
+
+        if ((endsInDeletionBeforeSoftclip) && positionMapIndex == lengthBeforeDeletion) {
+            if (orc_check_deletion_quality(r, positionMapIndex, s->min_bq)) {
+                for (int j = 1; j < deletionLength + 1; j++) {
+                    int anchorIndex = nAnchorIdx - 1;
+                    add_allele_count(s, j + lastPosition, PISCES_ALLELE_DEL, directionType, anchorIndex);
+                }
+            }
+        }
+
+        int position = posmap[positionMapIndex];
+        if (position == -1) continue;
+
+        int anchorType = get_anchor_type(s, alignmentEndPosition, position, alignmentStartPosition);
+        if (anchorType < 0) { rc = PISCES_E_UNMAPPED_BASE; goto done; }
+
+        if (orc_check_deletion_quality(r, positionMapIndex, s->min_bq)) {
+            for (int j = lastPosition + 1; j < position; j++)
+                add_allele_count(s, j, PISCES_ALLELE_DEL, directionType, anchorType);
+        }
+
+        int alleleType = allele_type_of(r->bases[positionMapIndex]);
+        if (r->quals[positionMapIndex] < s->min_bq) alleleType = PISCES_ALLELE_N;
+
+        add_allele_count(s, position, alleleType, directionType, anchorType);
+
+        /* Math.Pow(10, -1 * (int)q / 10f) :191 — int / float -> float exponent */
+        double bq = pow(10.0, (double)((float)(-1 * (int)r->quals[positionMapIndex]) / 10.0f));
+        add_base_quality(s, position, alleleType, directionType, bq, anchorType);
+        lastPosition = position;
+    }
+
+    if (endsInDeletion) {
+        if (orc_check_deletion_quality(r, r->read_len - 1, s->min_bq)) {
+            for (int j = 1; j < deletionLength + 1; j++) {
+                int directionType = read_dir(r, r->read_len - 1);
+                int anchorIndex = nAnchorIdx - 1;
+                add_allele_count(s, j + lastPosition, PISCES_ALLELE_DEL, directionType, anchorIndex);
+            }
+        }
+    }
+done:
+    if (posmap != stack_map) free(posmap);
+    return rc;
+}
+
+/* AlleleCountHelper.GetAnchorAdjustedAlleleCount :21-85 (generic over int / double storage) */
+#define ANCHOR_ADJUSTED(TYPE, ARR)                                                                        \
+    int wellAnchoredIndex = s->num_anchor_types, numAnchorIndexes = s->n_anchor_idx;                      \
+    int trueMinAnchor = wellAnchoredIndex < minAnchor ? wellAnchoredIndex : minAnchor;                    \
+    int initialMaxAnchor = wellAnchoredIndex;                                                             \
+    if (maxAnchor >= 0) {                                                                                 \
+        if (maxAnchor >= wellAnchoredIndex) initialMaxAnchor = wellAnchoredIndex - 1;                     \
+        if (maxAnchor < wellAnchoredIndex) initialMaxAnchor = maxAnchor;                                  \
+    }                                                                                                     \
+    TYPE totCount = 0;                                                                                    \
+    if (fromEnd) {                                                                                        \
+        for (int i = trueMinAnchor; i <= initialMaxAnchor; i++)                                           \
+            totCount += ARR[cidx(s, position, allele, dir, numAnchorIndexes - i - 1)];                    \
+        if (maxAnchor < 0)                                                                                \
+            for (int i = symmetric ? trueMinAnchor : 0; i < initialMaxAnchor; i++)                        \
+                totCount += ARR[cidx(s, position, allele, dir, i)];                                       \
+    } else {                                                                                              \
+        for (int i = trueMinAnchor; i <= initialMaxAnchor; i++)                                           \
+            totCount += ARR[cidx(s, position, allele, dir, i)];                                           \
+        if (maxAnchor < 0)                                                                                \
+            for (int i = initialMaxAnchor + 1; i < (symmetric ? numAnchorIndexes - trueMinAnchor : numAnchorIndexes); i++) \
+                totCount += ARR[cidx(s, position, allele, dir, i)];                                       \
+    }                                                                                                     \
+    return totCount;
+
+/* RegionStateManager.GetAlleleCount :222-226: no block -> 0 */
+int32_t orc_get_allele_count(const OrcState* s, int32_t position, int32_t allele, int32_t dir, int32_t minAnchor,
+                             int32_t maxAnchor, int32_t fromEnd, int32_t symmetric)
+{
+    if (!in_region(s, position)) return 0;
+    ANCHOR_ADJUSTED(int32_t, s->counts)
+}
+double orc_get_sum_base_quality(const OrcState* s, int32_t position, int32_t allele, int32_t dir, int32_t minAnchor,
+                                int32_t maxAnchor, int32_t fromEnd, int32_t symmetric)
+{
+    if (!in_region(s, position)) return 0;
+    ANCHOR_ADJUSTED(double, s->sumq)
+}
+
+void orc_add_gapped_mnv_ref(OrcState* s, int32_t position, int32_t count)
+{
+    if (in_region(s, position)) s->gapped[position - s->start_position] += count;
+}
+static int32_t get_gapped_mnv_ref(const OrcState* s, int32_t position)
+{
+    return in_region(s, position) ? s->gapped[position - s->start_position] : 0;
+}
+
+/* CandidateAllele.Equals (CandidateAllele.cs:58-68) */
+static int candidate_equals(const OrcCandidate* a, const OrcCandidate* b)
+{
+    return a->position == b->position && strcmp(a->alt, b->alt) == 0 && a->category == b->category &&
+           strcmp(a->ref, b->ref) == 0;
+}
+
+/* RegionState.AddCandidate :94-174 */
+int32_t orc_add_candidate(OrcState* s, const OrcCandidate* c)
+{
+    if (c->category == PISCES_CAT_REFERENCE) return PISCES_E_INVALID_ARG;
+    if (!in_region(s, c->position)) return PISCES_E_INVALID_ARG;
+    int li = c->position - s->start_position;
+    for (int i = s->cand_head[li]; i >= 0; i = s->cands[i].next) {
+        OrcCandidate* e = &s->cands[i];
+        int match = candidate_equals(e, c);
+        if (match && s->track_open_ended) match = (e->open_left == c->open_left && e->open_right == c->open_right);
+        if (match) {
+            for (int d = 0; d < 3; d++) {
+                e->support_by_dir[d] += c->support_by_dir[d];
+                e->well_anchored_by_dir[d] += c->well_anchored_by_dir[d];
+            }
+            return 0;
+        }
+    }
+    if (s->n_cands == s->cap_cands) {
+        s->cap_cands = s->cap_cands ? s->cap_cands * 2 : 64;
+        s->cands = (OrcCandidate*)realloc(s->cands, sizeof(OrcCandidate) * (size_t)s->cap_cands);
+    }
+    int id = s->n_cands++;
+    s->cands[id] = *c;
+    s->cands[id].next = -1;
+    if (s->cand_tail[li] >= 0) s->cands[s->cand_tail[li]].next = id;
+    else s->cand_head[li] = id;
+    s->cand_tail[li] = id;
+    return 0;
+}
+
+int32_t orc_num_candidates(const OrcState* s) { return s->n_cands; }
+
+int32_t orc_get_candidates(const OrcState* s, OrcCandidate* out, int32_t capacity)
+{
+    int n = 0;
+    for (int li = 0; li < s->n_loci; li++)
+        for (int i = s->cand_head[li]; i >= 0; i = s->cands[i].next) {
+            if (n < capacity) out[n] = s->cands[i];
+            n++;
+        }
+    return n;
+}
+
+/* =====================================================================================
+ * lib/Pisces.Domain/Logic/CandidateVariantFinder.cs
+ * ===================================================================================== */
+typedef struct FinderCtx {
+    const OrcRead* r;
+    const uint8_t* ref;
+    int64_t ref_len;
+    int min_bq, max_mnv, max_gap, call_mnvs, anchor_size;
+    OrcCandidate* out;
+    int n, cap;
+    int overflow;
+} FinderCtx;
+
+/* GetSupportDirection :396-445 (the stitched-deletion branch via CigarDirections, :417-420,
+ * needs the XD tag's expanded map; reads carrying one supply per-base dirs and take the
+ * fallback branch, which is what the reference does when CigarDirections == null). */
+static int get_support_direction(const FinderCtx* f, int category, int length, int startIndexInRead)
+{
+    const OrcRead* r = f->r;
+    if (category == PISCES_CAT_SNV || category == PISCES_CAT_REFERENCE) return read_dir(r, startIndexInRead);
+    int leftAnchorIndex = startIndexInRead - 1;
+    int rightAnchorIndex = category == PISCES_CAT_DELETION ? startIndexInRead : startIndexInRead + length;
+    int lastIndex = r->read_len - 1;
+    if (rightAnchorIndex == 0) return read_dir(r, rightAnchorIndex);
+    if (leftAnchorIndex == lastIndex) return read_dir(r, lastIndex);
+    if (leftAnchorIndex == rightAnchorIndex - 1) {
+        int startDirection = read_dir(r, leftAnchorIndex);
+        int endDirection = read_dir(r, rightAnchorIndex);
+        return startDirection == PISCES_DIR_STITCHED ? endDirection : startDirection;
+    }
+    int direction = PISCES_DIR_FORWARD;
+    for (int i = leftAnchorIndex + 1; i < rightAnchorIndex; i++) {
+        direction = read_dir(r, i);
+        if (direction == PISCES_DIR_STITCHED) return PISCES_DIR_STITCHED;
+    }
+    return direction;
+}
+
+static int allele_length(int category, const char* ref, const char* alt)
+{
+    /* BaseAllele.Length (BaseAllele.cs:26-46) */
+    switch (category) {
+    case PISCES_CAT_MNV:
+    case PISCES_CAT_SNV: return (int)strlen(alt);
+    case PISCES_CAT_INSERTION: return (int)strlen(alt) - 1;
+    case PISCES_CAT_DELETION: return (int)strlen(ref) - 1;
+    default: return (int)strlen(ref);
+    }
+}
+
+/* CandidateVariantFinder.Create :334-387 */
+static OrcCandidate* finder_create(FinderCtx* f, int category, int coordinate, const char* ref, int ref_n,
+                                   const char* alt, int alt_n, int startIndexInRead)
+{
+    if (f->n >= f->cap || ref_n >= ORC_MAX_ALLELE || alt_n >= ORC_MAX_ALLELE) { f->overflow = 1; return NULL; }
+    OrcCandidate* c = &f->out[f->n++];
+    memset(c, 0, sizeof(*c));
+    c->position = coordinate;
+    c->category = category;
+    memcpy(c->ref, ref, (size_t)ref_n); c->ref[ref_n] = 0;
+    memcpy(c->alt, alt, (size_t)alt_n); c->alt[alt_n] = 0;
+    c->next = -1;
+    int dir = get_support_direction(f, category, allele_length(category, c->ref, c->alt), startIndexInRead);
+    c->support_by_dir[dir]++;
+    int endPos = read_end_position(f->r);
+    int a1 = coordinate - f->r->position, a2 = endPos - coordinate;
+    int anchor = a1 < a2 ? a1 : a2;
+    int lim = (f->anchor_size - 1) < (alt_n - 1) ? (f->anchor_size - 1) : (alt_n - 1);
+    if (anchor > lim) c->well_anchored_by_dir[dir]++;
+    return c;
+}
+
+/* FlushVariant :183-203 */
+static void flush_variant(FinderCtx* f, int variantStartIndexInRead, int variantStartIndexInReference,
+                          int variantLengthSoFar, int interveningRefLengthSoFar, int openLeft, int openRight)
+{
+    if (interveningRefLengthSoFar >= 1) {
+        variantLengthSoFar -= interveningRefLengthSoFar;
+        openRight = 0;
+    }
+    if (variantLengthSoFar >= 1) {
+        int cat = variantLengthSoFar > 1 ? PISCES_CAT_MNV : PISCES_CAT_SNV;
+        OrcCandidate* c = finder_create(f, cat, variantStartIndexInReference + 1,
+                                        (const char*)f->ref + variantStartIndexInReference, variantLengthSoFar,
+                                        (const char*)f->r->bases + variantStartIndexInRead, variantLengthSoFar,
+                                        variantStartIndexInRead);
+        if (c) { c->open_left = openLeft; c->open_right = openRight; }
+    }
+}
+
+/* ShouldBuildUpMNV :170-181 */
+static int should_build_up_mnv(const FinderCtx* f, int mnvLengthSoFar, int interveningRefLengthSoFar, int refCallNext)
+{
+    if (!f->call_mnvs) return 0;
+    if (refCallNext && mnvLengthSoFar == 0) return 0;
+    if ((mnvLengthSoFar + 1) > f->max_mnv) return 0;
+    if ((interveningRefLengthSoFar + (refCallNext ? 1 : 0)) > f->max_gap) return 0;
+    return 1;
+}
+
+/* ExtractSnvsFromOperation :90-168 */
+static void extract_snvs(FinderCtx* f, int opStartIndexInRead, uint32_t operationLength, int opStartIndexInReference)
+{
+    const OrcRead* r = f->r;
+    int variantLengthSoFar = 0, interveningRefLengthSoFar = 0, openLeft = 0;
+    for (int i = 0; i < (int)operationLength; i++) {
+        int qualityGoodEnough = r->quals[opStartIndexInRead + i] >= f->min_bq;
+        uint8_t readBase = r->bases[opStartIndexInRead + i];
+        if (opStartIndexInReference + i >= f->ref_len) break;
+        uint8_t refBase = f->ref[opStartIndexInReference + i];
+        int atEndOfOperation = i == ((int)operationLength - 1);
+        int startingMnvAtEndOfOperation = (atEndOfOperation && variantLengthSoFar == 0);
+
+        if ((allele_type_of(readBase) == PISCES_ALLELE_N) || (allele_type_of(refBase) == PISCES_ALLELE_N) || !qualityGoodEnough) {
+            flush_variant(f, opStartIndexInRead + i - variantLengthSoFar, opStartIndexInReference + i - variantLengthSoFar,
+                          variantLengthSoFar, interveningRefLengthSoFar, openLeft, 1);
+            variantLengthSoFar = 0; interveningRefLengthSoFar = 0; openLeft = 1;
+        } else if (refBase == readBase) {
+            if (should_build_up_mnv(f, variantLengthSoFar, interveningRefLengthSoFar, 1) && !startingMnvAtEndOfOperation) {
+                variantLengthSoFar++; interveningRefLengthSoFar++;
+            } else {
+                flush_variant(f, opStartIndexInRead + i - variantLengthSoFar, opStartIndexInReference + i - variantLengthSoFar,
+                              variantLengthSoFar, interveningRefLengthSoFar, openLeft, 0);
+                variantLengthSoFar = 0; interveningRefLengthSoFar = 0; openLeft = 0;
+            }
+        } else {
+            if (should_build_up_mnv(f, variantLengthSoFar, interveningRefLengthSoFar, 0) && !startingMnvAtEndOfOperation) {
+                variantLengthSoFar++; interveningRefLengthSoFar = 0;
+            } else {
+                flush_variant(f, opStartIndexInRead + i - variantLengthSoFar, opStartIndexInReference + i - variantLengthSoFar,
+                              variantLengthSoFar, interveningRefLengthSoFar, openLeft, 0);
+                variantLengthSoFar = 1; interveningRefLengthSoFar = 0; openLeft = 0;
+            }
+        }
+    }
+    flush_variant(f, opStartIndexInRead + (int)operationLength - variantLengthSoFar,
+                  opStartIndexInReference + (int)operationLength - variantLengthSoFar, variantLengthSoFar,
+                  interveningRefLengthSoFar, openLeft, 0);
+}
+
+/* ExtractInsertionFromOperation :234-260 */
+static void extract_insertion(FinderCtx* f, int opStartIndexInRead, uint32_t operationLength, int opStartIndexInReference)
+{
+    if (opStartIndexInReference - 1 >= f->ref_len || opStartIndexInReference == 0) return;
+    int n = (int)operationLength;
+    if (n + 1 >= ORC_MAX_ALLELE) { f->overflow = 1; return; }
+    char alt[ORC_MAX_ALLELE];
+    alt[0] = (char)f->ref[opStartIndexInReference - 1];
+    memcpy(alt + 1, f->r->bases + opStartIndexInRead, (size_t)n);
+    if (!(f->r->quals[opStartIndexInRead] >= f->min_bq)) return;
+    finder_create(f, PISCES_CAT_INSERTION, opStartIndexInReference, (const char*)f->ref + opStartIndexInReference - 1, 1,
+                  alt, n + 1, opStartIndexInRead);
+}
+
+/* ExtractDeletionFromOperation :262-292 */
+static void extract_deletion(FinderCtx* f, int opStartIndexInRead, uint32_t operationLength, int opStartIndexInReference)
+{
+    if ((int64_t)opStartIndexInReference + (int64_t)operationLength >= f->ref_len) return;
+    if (opStartIndexInReference - 1 < 0) return; /* C# Substring(-1, ..) would throw; reads never start with D at ref index 0 */
+    if (!orc_check_deletion_quality(f->r, opStartIndexInRead, f->min_bq)) return;
+    finder_create(f, PISCES_CAT_DELETION, opStartIndexInReference, (const char*)f->ref + opStartIndexInReference - 1,
+                  (int)operationLength + 1, (const char*)f->ref + opStartIndexInReference - 1, 1, opStartIndexInRead);
+}
+
+/* PositionMap.MaxPosition */
+static int posmap_max(const int32_t* posmap, int n)
+{
+    int m = -1;
+    for (int i = 0; i < n; i++) if (posmap[i] > m) m = posmap[i];
+    return m;
+}
+
+/* ProcessCigarOps :36-83, Annotate :496-553 */
+int32_t orc_find_candidates(const OrcRead* r, const uint8_t* ref, int64_t ref_len, int32_t min_bq, int32_t max_mnv,
+                            int32_t max_gap, int32_t call_mnvs, int32_t anchor_size, OrcCandidate* out, int32_t cap)
+{
+    FinderCtx f = {r, ref, ref_len, min_bq, max_mnv, max_gap, call_mnvs, anchor_size, out, 0, cap, 0};
+    int startIndexInRead = 0;
+    int startIndexInReference = r->position - 1;
+    for (int c = 0; c < r->n_cigar; c++) {
+        uint8_t t = r->cigar_op[c];
+        uint32_t len = r->cigar_len[c];
+        switch (t) {
+        case 'S': break;
+        case 'M': extract_snvs(&f, startIndexInRead, len, startIndexInReference); break;
+        case 'I': extract_insertion(&f, startIndexInRead, len, startIndexInReference); break;
+        case 'D': extract_deletion(&f, startIndexInRead, len, startIndexInReference); break;
+        default: break;
+        }
+        if (op_is_read_span(t)) startIndexInRead += (int)len;
+        if (op_is_ref_span(t)) startIndexInReference += (int)len;
+    }
+    if (f.overflow) return PISCES_E_BUFFER_TOO_SMALL;
+    if (f.n == 0) return 0;
+
+    /* Annotate */
+    int fi = 0, li = r->n_cigar - 1;
+    if (r->cigar_op[fi] == 'S') fi = 1;
+    if (r->cigar_op[li] == 'S') li = r->n_cigar - 2;
+    if (fi >= r->n_cigar || li < 0) return f.n;
+    int32_t stack_map[512];
+    int32_t* posmap = r->read_len <= 512 ? stack_map : (int32_t*)malloc(sizeof(int32_t) * (size_t)r->read_len);
+    build_position_map(r, posmap);
+    int maxPosition = posmap_max(posmap, r->read_len);
+    if (posmap != stack_map) free(posmap);
+    if (maxPosition == -1) maxPosition = r->position - 1;
+    uint8_t firstOp = r->cigar_op[fi], lastOp = r->cigar_op[li];
+    for (int i = 0; i < f.n; i++) {
+        OrcCandidate* c = &out[i];
+        int isSnvMnv = (c->category == PISCES_CAT_MNV || c->category == PISCES_CAT_SNV);
+        switch (firstOp) {
+        case 'M': if (c->position == r->position && isSnvMnv) c->open_left = 1; break;
+        case 'I': if (c->position == r->position - 1 && c->category == PISCES_CAT_INSERTION) c->open_left = 1; break;
+        case 'D': if (c->position == r->position - 1 && c->category == PISCES_CAT_DELETION) c->open_left = 1; break;
+        default: break;
+        }
+        switch (lastOp) {
+        case 'M': if (c->position + (int)strlen(c->alt) - 1 == maxPosition && isSnvMnv) c->open_right = 1; break;
+        case 'I': if (c->position == maxPosition && c->category == PISCES_CAT_INSERTION) c->open_right = 1; break;
+        case 'D': if (c->position == maxPosition && c->category == PISCES_CAT_DELETION) c->open_right = 1; break;
+        default: break;
+        }
+    }
+    return f.n;
+}
+
+/* =====================================================================================
+ * lib/Pisces.Calculators/CoverageCalculator.cs
+ * ===================================================================================== */
+static const int kCoverageContributing[5] = {PISCES_ALLELE_A, PISCES_ALLELE_C, PISCES_ALLELE_G, PISCES_ALLELE_T,
+                                              PISCES_ALLELE_DEL}; /* Constants.cs:41-44 */
+
+/* CalculateSinglePoint :49-98 */
+static void coverage_single_point(OrcCalled* a, const OrcState* s)
+{
+    int refType = allele_type_of((uint8_t)a->ref[0]); /* AlleleHelper.GetAlleleType(string) needs length 1 */
+    for (int direction = 0; direction < 3; direction++) {
+        for (int k = 0; k < 5; k++) {
+            int alleleType = kCoverageContributing[k];
+            a->coverage_by_dir[direction] += orc_get_allele_count(s, a->position, alleleType, direction, 0, -1, 0, 0);
+            a->sum_of_base_quality += orc_get_sum_base_quality(s, a->position, alleleType, direction, 0, -1, 0, 0);
+            if (alleleType != refType) continue;
+            a->reference_support += orc_get_allele_count(s, a->position, alleleType, direction, 0, -1, 0, 0);
+        }
+        a->total_coverage += a->coverage_by_dir[direction];
+        a->confident_start += a->coverage_by_dir[direction];
+        a->confident_end += a->coverage_by_dir[direction];
+        a->num_no_calls += orc_get_allele_count(s, a->position, PISCES_ALLELE_N, direction, 0, -1, 0, 0);
+    }
+    int gappedRefCounts = get_gapped_mnv_ref(s, a->position);
+    if (a->category == PISCES_CAT_SNV) {
+        int v = a->reference_support - gappedRefCounts;
+        a->reference_support = v > 0 ? v : 0;
+    } else if (a->category == PISCES_CAT_REFERENCE) {
+        int v = a->allele_support - gappedRefCounts;
+        a->allele_support = v > 0 ? v : 0;
+    }
+}
+
+/* RedistributeStitchedCoverage :324-331 */
+static void redistribute_stitched(int dataPoint[3])
+{
+    int stitchedCoverage = dataPoint[PISCES_DIR_STITCHED];
+    dataPoint[PISCES_DIR_FORWARD] += (int)ceilf((float)stitchedCoverage / 2);
+    dataPoint[PISCES_DIR_REVERSE] += (int)floorf((float)stitchedCoverage / 2);
+    dataPoint[PISCES_DIR_STITCHED] = 0;
+}
+
+/* CalculateSpanning :162-321 */
+static void coverage_spanning(OrcCalled* a, const OrcState* s, int startPointPosition, int endPointPosition,
+                              int presumeAnchoredForExactCov, int considerAnchorInformation)
+{
+    int startPointCoverage[3] = {0, 0, 0}, endPointCoverage[3] = {0, 0, 0};
+    float exactTotalCoverage = 0.0f;
+    int confidentCoverageLeft = 0, confidentCoverageRight = 0, suspiciousCoverageLeft = 0, suspiciousCoverageRight = 0;
+    int firstBase = PISCES_ALLELE_N, lastBase = PISCES_ALLELE_N;
+    int bePickyAboutAnchors = considerAnchorInformation && a->category == PISCES_CAT_INSERTION;
+    int alleleLength = allele_length(a->category, a->ref, a->alt);
+    if (bePickyAboutAnchors) {
+        firstBase = allele_type_of((uint8_t)a->alt[1]);
+        lastBase = allele_type_of((uint8_t)a->alt[strlen(a->alt) - 1]);
+    }
+    int startPointCoverageUnanchored[3] = {0, 0, 0}, endPointCoverageUnanchored[3] = {0, 0, 0};
+    double unanchoredCoverageStartQuality = 0, unanchoredCoverageEndQuality = 0;
+    int unanchoredSupport = a->allele_support - a->well_anchored_support;
+
+    for (int directionIndex = 0; directionIndex < 3; directionIndex++) {
+        for (int k = 0; k < 5; k++) {
+            int alleleType = kCoverageContributing[k];
+            int anchoredCoverageOnlyEnd = bePickyAboutAnchors && alleleType == firstBase;
+            int anchoredCoverageOnlyStart = bePickyAboutAnchors && alleleType == lastBase;
+            int minAnchorEnd = anchoredCoverageOnlyEnd ? alleleLength : 0;
+            int minAnchorStart = anchoredCoverageOnlyStart ? alleleLength : 0;
+
+            int startCov = orc_get_allele_count(s, startPointPosition, alleleType, directionIndex, minAnchorStart, -1, 0, 0);
+            startPointCoverage[directionIndex] += startCov;
+            int endCov = orc_get_allele_count(s, endPointPosition, alleleType, directionIndex, minAnchorEnd, -1, 1, 0);
+            endPointCoverage[directionIndex] += endCov;
+            confidentCoverageLeft += startCov;
+            confidentCoverageRight += endCov;
+            a->sum_of_base_quality += orc_get_sum_base_quality(s, startPointPosition, alleleType, directionIndex, minAnchorStart, -1, 0, 0);
+            a->sum_of_base_quality += orc_get_sum_base_quality(s, endPointPosition, alleleType, directionIndex, minAnchorEnd, -1, 1, 0);
+
+            if (bePickyAboutAnchors && unanchoredSupport > 0) {
+                if (minAnchorStart > 0) {
+                    int u = orc_get_allele_count(s, startPointPosition, alleleType, directionIndex, 0, minAnchorStart - 1, 0, 0);
+                    startPointCoverageUnanchored[directionIndex] += u;
+                    suspiciousCoverageLeft += u;
+                    unanchoredCoverageStartQuality += orc_get_sum_base_quality(s, startPointPosition, alleleType, directionIndex, 0, minAnchorStart - 1, 0, 0);
+                }
+                if (minAnchorEnd > 0) {
+                    int u = orc_get_allele_count(s, endPointPosition, alleleType, directionIndex, 0, minAnchorEnd - 1, 1, 0);
+                    endPointCoverageUnanchored[directionIndex] += u;
+                    suspiciousCoverageRight += u;
+                    /* reference reads startPointPosition here (:254) — reproduced */
+                    unanchoredCoverageEndQuality += orc_get_sum_base_quality(s, startPointPosition, alleleType, directionIndex, 0, minAnchorEnd - 1, 1, 0);
+                }
+            }
+        }
+    }
+
+    if (bePickyAboutAnchors) {
+        float trulyAnchoredCoverage = (((confidentCoverageLeft - suspiciousCoverageRight) +
+                                        (confidentCoverageRight - suspiciousCoverageLeft)) / 2.0f);
+        float anchoredVariantFreq = trulyAnchoredCoverage <= 0 ? 0 : (float)a->well_anchored_support / trulyAnchoredCoverage;
+        int totalSuspiciousCoverage = suspiciousCoverageLeft + suspiciousCoverageRight;
+        float unanchoredVariantFreq = totalSuspiciousCoverage == 0 ? 0 : unanchoredSupport / ((float)totalSuspiciousCoverage);
+        /* Math.Max(0, anchoredVariantFreq == 0 ? 1 : Math.Min(1, unanchoredVariantFreq / anchoredVariantFreq)) in float */
+        float w = anchoredVariantFreq == 0 ? 1.0f : fminf(1.0f, unanchoredVariantFreq / anchoredVariantFreq);
+        if (!(w > 0.0f)) w = 0.0f;
+        double variantSpecificUnanchoredWeight = w;
+        a->unanchored_weight = variantSpecificUnanchoredWeight;
+        for (int d = 0; d < 3; d++) {
+            startPointCoverage[d] += (int)(startPointCoverageUnanchored[d] * variantSpecificUnanchoredWeight);
+            endPointCoverage[d] += (int)(endPointCoverageUnanchored[d] * variantSpecificUnanchoredWeight);
+            a->sum_of_base_quality += unanchoredCoverageStartQuality * variantSpecificUnanchoredWeight;
+            a->sum_of_base_quality += unanchoredCoverageEndQuality * variantSpecificUnanchoredWeight;
+        }
+    }
+
+    redistribute_stitched(startPointCoverage);
+    redistribute_stitched(endPointCoverage);
+
+    for (int d = 0; d < 2; d++) {
+        float exactCoverageForDir = presumeAnchoredForExactCov
+            ? (startPointCoverage[d] + endPointCoverage[d]) / 2.0f
+            : (float)(startPointCoverage[d] < endPointCoverage[d] ? startPointCoverage[d] : endPointCoverage[d]);
+        a->coverage_by_dir[d] = (int)exactCoverageForDir;
+        exactTotalCoverage += exactCoverageForDir;
+    }
+    a->total_coverage = (int)exactTotalCoverage;
+    int rs = a->total_coverage - a->allele_support;
+    a->reference_support = rs > 0 ? rs : 0;
+    a->suspicious_start = suspiciousCoverageLeft;
+    a->confident_start = confidentCoverageLeft;
+    a->suspicious_end = suspiciousCoverageRight;
+    a->confident_end = confidentCoverageRight;
+}
+
+/* Compute :19-47 */
+void orc_coverage_compute(OrcCalled* a, const OrcState* s, int32_t considerAnchors, int32_t expectStitched)
+{
+    int len = allele_length(a->category, a->ref, a->alt);
+    switch (a->category) {
+    case PISCES_CAT_REFERENCE: coverage_single_point(a, s); break;
+    case PISCES_CAT_DELETION: coverage_spanning(a, s, a->position + 1, a->position + len, 1, considerAnchors); break;
+    case PISCES_CAT_MNV: coverage_spanning(a, s, a->position, a->position + len - 1, 1, considerAnchors); break;
+    case PISCES_CAT_INSERTION: coverage_spanning(a, s, a->position, a->position + 1, expectStitched, considerAnchors); break;
+    default: coverage_single_point(a, s); break;
+    }
+}
+
+/* AlleleHelper.Map(CandidateAllele) :51-85 */
+void orc_called_from_candidate(OrcCalled* v, const OrcCandidate* c)
+{
+    memset(v, 0, sizeof(*v));
+    v->position = c->position;
+    v->category = c->category;
+    strcpy(v->ref, c->ref);
+    strcpy(v->alt, c->alt);
+    for (int d = 0; d < 3; d++) {
+        v->support_by_dir[d] = c->support_by_dir[d];
+        v->well_anchored_by_dir[d] = c->well_anchored_by_dir[d];
+        v->allele_support += c->support_by_dir[d];
+        v->well_anchored_support += c->well_anchored_by_dir[d];
+    }
+    /* CalledAllele(AlleleCategory) ctor, CalledAllele.cs:142-155 */
+    v->genotype = (c->category == PISCES_CAT_REFERENCE) ? PISCES_GT_HOM_REF : PISCES_GT_HET_ALT_REF;
+}
+
+/* RMxNCalculator.ComputeRMxNLengthForIndel (RMxNCalculator.cs:50-94) */
+static int rmxn_length_for_indel(int variantPosition, const char* variantBases, int length, const uint8_t* ref,
+                                 int64_t ref_len, int maxRepeatUnitLength)
+{
+    int maxRepeatsFound = 0;
+    int lo = length - (maxRepeatUnitLength < length ? maxRepeatUnitLength : length);
+    for (int pass = 0; pass < 2; pass++) {
+        for (int i = lo; i < length; i++) {
+            int blen = length - i;
+            const char* bookend = pass == 0 ? variantBases : variantBases + i;
+            int64_t backPeekPosition = variantPosition;
+            while (1) {
+                int64_t nb = backPeekPosition - blen;
+                if (nb < 0) break;
+                if (nb + blen > ref_len || memcmp(bookend, ref + nb, (size_t)blen) != 0) break;
+                backPeekPosition = nb;
+            }
+            int repeatCount = 0;
+            int64_t currentPosition = backPeekPosition;
+            while (1) {
+                if (currentPosition + blen > ref_len) break;
+                if (memcmp(bookend, ref + currentPosition, (size_t)blen) != 0) break;
+                repeatCount++;
+                currentPosition += blen;
+            }
+            if (repeatCount > maxRepeatsFound) maxRepeatsFound = repeatCount;
+        }
+    }
+    return maxRepeatsFound;
+}
+
+/* RMxNCalculator.ShouldFilter :19-38 with the default settings 5 x 9 @ 0.35f
+ * (VariantCallingParameters.cs:76-80) carried in the config */
+static int rmxn_should_filter(const OrcCalled* a, const uint8_t* ref, int64_t ref_len, const PiscesHipConfig* cfg)
+{
+    const int maxLen = cfg->rmxn_max_repeat_length, minRep = cfg->rmxn_min_repetitions;
+    const float freqLimit = cfg->rmxn_frequency_limit;
+    if (!ref || maxLen < 0) return 0;
+    if (frequency_f(a->allele_support, a->total_coverage) >= freqLimit) return 0;
+    int c1, c2 = 2147483647;
+    if (a->category == PISCES_CAT_INSERTION) {
+        c1 = rmxn_length_for_indel(a->position, a->alt + 1, (int)strlen(a->alt) - 1, ref, ref_len, maxLen);
+    } else if (a->category == PISCES_CAT_DELETION) {
+        c1 = rmxn_length_for_indel(a->position, a->ref + 1, (int)strlen(a->ref) - 1, ref, ref_len, maxLen);
+    } else {
+        int rl = (int)strlen(a->ref), al = (int)strlen(a->alt);
+        c1 = rmxn_length_for_indel(a->position - 1, a->ref, rl, ref, ref_len, maxLen);
+        int i1 = rmxn_length_for_indel(a->position + rl - 1, a->alt, al, ref, ref_len, maxLen);
+        int i2 = rmxn_length_for_indel(a->position - 1, a->alt, al, ref, ref_len, maxLen);
+        c2 = i1 > i2 ? i1 : i2;
+    }
+    return (c1 < c2 ? c1 : c2) >= minRep;
+}
+
+static const uint8_t* g_rmxn_ref = NULL; /* set per orc_call_all; oracle is single-threaded per call */
+static int64_t g_rmxn_ref_len = 0;
+
+/* AlleleCaller.ProcessVariant :208-234 + AlleleProcessor.Process/ApplyFilters (AlleleProcessor.cs:16-71) */
+void orc_process_variant(OrcCalled* v, const OrcState* s, const PiscesHipConfig* cfg)
+{
+    /* coverage accumulates with += : re-processing a variant double counts, like the reference does
+     * for MNVs (AlleleCaller.cs:74,111); callers reset what they need. */
+    orc_coverage_compute(v, s, /*considerAnchorInformation: TrackedAnchorSize > 0*/ s->num_anchor_types > 0,
+                         cfg->expect_stitched_reads);
+
+    if (v->allele_support > 0) {
+        /* VariantQualityCalculator.Compute :11-24 (NoiseModel.Flat) */
+        v->noise_level_applied = cfg->noise_level;
+        if (v->total_coverage == 0) v->variant_qscore = 0;
+        else v->variant_qscore = orc_poisson_qscore(v->allele_support, v->total_coverage, cfg->noise_level, cfg->max_variant_qscore);
+        orc_strand_bias(v->coverage_by_dir, v->support_by_dir, cfg->noise_level, (double)cfg->min_frequency,
+                        (double)cfg->strand_bias_threshold, cfg->strand_bias_model, &v->sb);
+        v->has_sb = 1;
+    }
+
+    /* SetFractionNoCalls CalledAllele.cs:107-114 */
+    float allReads = (float)(v->total_coverage + v->num_no_calls);
+    v->fraction_no_calls = allReads == 0 ? 0.0f : ((float)v->num_no_calls / allReads);
+
+    /* ApplyFilters :25-71 */
+    v->filters = 0;
+    if (cfg->low_depth_filter >= 0 && v->total_coverage < cfg->low_depth_filter) v->filters |= 1u << PISCES_FILTER_LOW_DEPTH;
+    if (cfg->variant_qscore_filter >= 0 && v->variant_qscore < cfg->variant_qscore_filter && (v->total_coverage != 0))
+        v->filters |= 1u << PISCES_FILTER_LOW_VARIANT_QSCORE;
+    if (v->category != PISCES_CAT_REFERENCE) {
+        if (cfg->no_call_filter_threshold >= 0 && v->fraction_no_calls > cfg->no_call_filter_threshold)
+            v->filters |= 1u << PISCES_FILTER_NO_CALL;
+        int biasAcceptable = v->has_sb ? v->sb.bias_acceptable : 0; /* new BiasResults(): false */
+        int varBoth = v->has_sb ? v->sb.var_present_on_both : 0;
+        if (!biasAcceptable || (cfg->filter_single_strand && !varBoth)) v->filters |= 1u << PISCES_FILTER_STRAND_BIAS;
+        if (rmxn_should_filter(v, g_rmxn_ref, g_rmxn_ref_len, cfg)) v->filters |= 1u << PISCES_FILTER_RMXN;
+        if (cfg->variant_freq_filter >= 0 && frequency_f(v->allele_support, v->total_coverage) < cfg->variant_freq_filter)
+            v->filters |= 1u << PISCES_FILTER_LOW_VARIANT_FREQUENCY;
+        if (cfg->expect_stitched_reads && strchr(v->alt, 'N')) v->filters |= 1u << PISCES_FILTER_STRAND_BIAS;
+    }
+}
+
+/* AlleleCaller.IsCallable :236-258 */
+static int is_callable(const OrcCalled* a, const PiscesHipConfig* cfg, int64_t* totalNumCalled)
+{
+    if (a->category == PISCES_CAT_REFERENCE) { (*totalNumCalled)++; return 1; }
+    if (a->total_coverage < cfg->min_coverage && !cfg->include_reference_calls) return 0;
+    if (a->total_coverage != 0 && frequency_f(a->allele_support, a->total_coverage) < cfg->min_frequency) return 0;
+    if (a->variant_qscore < cfg->min_variant_qscore) return 0;
+    (*totalNumCalled)++;
+    return 1;
+}
+
+static int called_cmp(const void* pa, const void* pb)
+{
+    const OrcCalled* a = (const OrcCalled*)pa;
+    const OrcCalled* b = (const OrcCalled*)pb;
+    if (a->position != b->position) return a->position < b->position ? -1 : 1;
+    int r = strcmp(a->ref, b->ref);
+    return r ? r : strcmp(a->alt, b->alt);
+}
+
+static void to_record(PiscesCalledAllele* o, const OrcCalled* v)
+{
+    memset(o, 0, sizeof(*o));
+    o->position = v->position;
+    o->total_coverage = v->total_coverage;
+    o->allele_support = v->allele_support;
+    o->reference_support = v->reference_support;
+    o->num_no_calls = v->num_no_calls;
+    for (int d = 0; d < 3; d++) { o->coverage_by_dir[d] = v->coverage_by_dir[d]; o->support_by_dir[d] = v->support_by_dir[d]; }
+    o->variant_qscore = v->variant_qscore;
+    o->strand_bias_score = v->has_sb ? v->sb.bias_score : 0.0;
+    o->genotype_qscore = v->genotype_qscore;
+    o->filter_bits = (uint16_t)v->filters;
+    int single = (strlen(v->ref) == 1 && strlen(v->alt) == 1);
+    int refc = allele_type_of((uint8_t)v->ref[0]);
+    int altc = single ? allele_type_of((uint8_t)v->alt[0]) : PISCES_ALLELE_N;
+    o->info = PISCES_INFO_PACK(v->genotype, v->category, refc, altc, v->has_sb ? v->sb.bias_acceptable : 0,
+                               v->has_sb ? v->sb.var_present_on_both : 0, v->has_sb ? v->sb.cov_present_on_both : 0);
+}
+
+/* AlleleCaller.CallForPositions :60-141 (no collapser, no MNV reallocation, no forced alleles)
+ * over RegionState.GetAllCandidates :383-453. */
+int64_t orc_call_all(OrcState* s, const uint8_t* ref_bases, int64_t ref_len, const PiscesHipConfig* cfg,
+                     PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out, int64_t* total_num_called)
+{
+    g_rmxn_ref = ref_bases;
+    g_rmxn_ref_len = ref_len;
+    int64_t totalNumCalled = 0;
+    int64_t n = 0, cap = 1024;
+    OrcCalled* called = (OrcCalled*)malloc(sizeof(OrcCalled) * (size_t)cap);
+    OrcCalled v;
+
+#define PUSH_IF_CALLED()                                                            \
+    do {                                                                            \
+        orc_process_variant(&v, s, cfg);                                            \
+        if (is_callable(&v, cfg, &totalNumCalled)) {                                \
+            if (n == cap) { cap *= 2; called = (OrcCalled*)realloc(called, sizeof(OrcCalled) * (size_t)cap); } \
+            called[n++] = v;                                                        \
+        }                                                                           \
+    } while (0)
+
+    for (int li = 0; li < s->n_loci; li++)
+        for (int i = s->cand_head[li]; i >= 0; i = s->cands[i].next) {
+            orc_called_from_candidate(&v, &s->cands[i]);
+            PUSH_IF_CALLED();
+        }
+
+    if (cfg->include_reference_calls && ref_bases) {
+        for (int li = 0; li < s->n_loci; li++) {
+            int position = s->start_position + li;
+            if (position > ref_len) break;
+            uint8_t refBase = ref_bases[position - 1];
+            int refBaseIndex = allele_type_of(refBase);
+            OrcCandidate rc;
+            memset(&rc, 0, sizeof(rc));
+            rc.position = position;
+            rc.category = PISCES_CAT_REFERENCE;
+            rc.ref[0] = rc.alt[0] = (char)refBase;
+            int totalSupport = 0;
+            for (int at = 0; at < 6; at++)
+                for (int d = 0; d < 3; d++) {
+                    int count = 0;
+                    for (int an = 0; an < s->n_anchor_idx; an++) count += s->counts[cidx(s, position, at, d, an)];
+                    if (at == refBaseIndex) rc.support_by_dir[d] = count;
+                    totalSupport += count;
+                }
+            if (cfg->emit_zero_coverage_refs || totalSupport > 0) {
+                orc_called_from_candidate(&v, &rc);
+                PUSH_IF_CALLED();
+            }
+        }
+    }
+#undef PUSH_IF_CALLED
+
+    /* SortedList by position; per position sort by (ref, alt) :172-176. Stable enough: keys are unique
+     * unless open-ended twins survive (only with track_open_ended). */
+    qsort(called, (size_t)n, sizeof(OrcCalled), called_cmp);
+
+    /* ComputeGenotypeAndFilterAllele :143-177 per position */
+    int64_t w = 0;
+    for (int64_t i = 0; i < n;) {
+        int64_t j = i;
+        int anyNonRef = 0;
+        while (j < n && called[j].position == called[i].position) { if (called[j].category != PISCES_CAT_REFERENCE) anyNonRef = 1; j++; }
+        for (int64_t k = i; k < j; k++) {
+            if (anyNonRef && called[k].category == PISCES_CAT_REFERENCE) continue;
+            OrcCalled* a = &called[k];
+            a->genotype = orc_somatic_genotype(a->category, a->total_coverage, a->allele_support, a->reference_support,
+                                               cfg->genotype_min_freq_filter, cfg->min_coverage);
+            a->genotype_qscore = orc_somatic_gq(a->genotype, a->variant_qscore, a->total_coverage, a->allele_support,
+                                                cfg->target_lod_frequency, cfg->min_genotype_qscore, cfg->max_genotype_qscore);
+            if (cfg->low_gq_filter >= 0 && (float)a->genotype_qscore < (float)cfg->low_gq_filter)
+                a->filters |= 1u << PISCES_FILTER_LOW_GENOTYPE_QUALITY;
+            if (w != k) called[w] = called[k];
+            w++;
+        }
+        i = j;
+    }
+    n = w;
+    if (total_num_called) *total_num_called = totalNumCalled;
+    if (n > capacity) { free(called); return -n; }
+    for (int64_t i = 0; i < n; i++) {
+        to_record(&out[i], &called[i]);
+        if (full_out) full_out[i] = called[i];
+    }
+    free(called);
+    return n;
+}
+
+/* =====================================================================================
+ * Whole path: SmallVariantCaller.Execute (exe/Pisces/Logic/SmallVariantCaller.cs:79-116).
+ * One dense window instead of 1000-locus blocks: without collapser / MNV spill-over the
+ * block schedule (RegionStateManager.cs:283-334) only changes WHEN alleles are emitted.
+ * ===================================================================================== */
+static int64_t count_candidate_loci(const PiscesCalledAllele* out, int64_t n)
+{
+    int64_t loci = 0;
+    for (int64_t i = 0; i < n; i++)
+        if (i == 0 || out[i].position != out[i - 1].position) loci++;
+    return loci;
+}
+
+int64_t orc_run_reads(const PiscesReadBatch* b, const uint8_t* ref_bases, int64_t ref_len, int32_t region_start,
+                      int32_t region_loci, const PiscesHipConfig* cfg, PiscesCalledAllele* out, int64_t capacity,
+                      int64_t* n_candidate_loci)
+{
+    OrcState* s = orc_state_create(region_start, region_loci, cfg->min_base_call_quality, PISCES_ANCHOR_SIZE, 0);
+    OrcCandidate cands[256];
+    for (int i = 0; i < b->n_reads; i++) {
+        OrcRead r;
+        r.position = b->position[i];
+        r.n_cigar = b->cigar_offset[i + 1] - b->cigar_offset[i];
+        r.cigar_op = b->cigar_op + b->cigar_offset[i];
+        r.cigar_len = b->cigar_len + b->cigar_offset[i];
+        r.read_len = b->seq_offset[i + 1] - b->seq_offset[i];
+        r.bases = b->bases + b->seq_offset[i];
+        r.quals = b->quals + b->seq_offset[i];
+        r.dirs = b->directions ? b->directions + b->seq_offset[i] : NULL;
+        r.is_reverse = b->flags[i] & 1;
+        r.posmap_override = NULL;
+        /* FindCandidates -> AddCandidates -> AddAlleleCounts (SmallVariantCaller.cs:92-98) */
+        int nc = orc_find_candidates(&r, ref_bases, ref_len, cfg->min_base_call_quality, 3, 1, 0, PISCES_ANCHOR_SIZE,
+                                     cands, 256);
+        for (int k = 0; k < nc; k++)
+            if (cands[k].position >= region_start && cands[k].position < region_start + region_loci)
+                orc_add_candidate(s, &cands[k]);
+        int rc = orc_add_allele_counts(s, &r);
+        if (rc) { orc_state_destroy(s); return rc; }
+    }
+    int64_t n = orc_call_all(s, ref_bases, ref_len, cfg, out, capacity, NULL, NULL);
+    orc_state_destroy(s);
+    if (n >= 0 && n_candidate_loci) *n_candidate_loci = count_candidate_loci(out, n);
+    return n;
+}
+
+int64_t orc_run_observations(const int32_t* positions, const uint32_t* tuples, int64_t n_obs, const uint8_t* ref_bases,
+                             int64_t ref_len, int32_t region_start, int32_t region_loci, const PiscesHipConfig* cfg,
+                             PiscesCalledAllele* out, int64_t capacity, int64_t* n_candidate_loci)
+{
+    OrcState* s = orc_state_create(region_start, region_loci, cfg->min_base_call_quality, PISCES_ANCHOR_SIZE, 0);
+    static const char kBase[6] = {'A', 'G', 'C', 'T', 'N', 'D'};
+    for (int64_t i = 0; i < n_obs; i++) {
+        uint32_t t = tuples[i];
+        if (t == PISCES_TUPLE_PAD) continue;
+        int pos = positions[i];
+        int allele = (int)PISCES_TUPLE_ALLELE(t), dir = (int)PISCES_TUPLE_DIR(t), anchor = (int)PISCES_TUPLE_ANCHOR(t);
+        int qual = (int)PISCES_TUPLE_QUAL(t);
+        int raw = allele;
+        /* RegionStateManager.cs:179-181 */
+        if (allele < PISCES_ALLELE_N && qual < cfg->min_base_call_quality) allele = PISCES_ALLELE_N;
+        add_allele_count(s, pos, allele, dir, anchor);
+        /* the SNV candidate this observation implies (CandidateVariantFinder.cs:97-160, callMNVs off) */
+        if (in_region(s, pos) && allele < PISCES_ALLELE_N && pos <= ref_len) {
+            uint8_t rb = ref_bases[pos - 1];
+            int rt = allele_type_of(rb);
+            if (rt != PISCES_ALLELE_N && rt != allele) {
+                OrcCandidate c;
+                memset(&c, 0, sizeof(c));
+                c.position = pos;
+                c.category = PISCES_CAT_SNV;
+                c.ref[0] = (char)rb;
+                c.alt[0] = kBase[raw];
+                c.support_by_dir[dir] = 1;
+                c.well_anchored_by_dir[dir] = (anchor != 0 && anchor != PISCES_NUM_ANCHORS - 1);
+                c.next = -1;
+                orc_add_candidate(s, &c);
+            }
+        }
+    }
+    int64_t n = orc_call_all(s, ref_bases, ref_len, cfg, out, capacity, NULL, NULL);
+    orc_state_destroy(s);
+    if (n >= 0 && n_candidate_loci) *n_candidate_loci = count_candidate_loci(out, n);
+    return n;
+}
+
+/* VariantCallingParameters.cs:57-156 defaults after Validate() */
+void orc_default_config(PiscesHipConfig* c)
+{
+    memset(c, 0, sizeof(*c));
+    c->abi_version = PISCES_HIP_ABI_VERSION;
+    c->min_base_call_quality = 20;
+    c->noise_level = 20;
+    c->max_variant_qscore = 100;
+    c->min_variant_qscore = 20;
+    c->variant_qscore_filter = 30;
+    c->min_coverage = 10;
+    c->low_depth_filter = 10;
+    c->min_genotype_qscore = 0;
+    c->max_genotype_qscore = 100;
+    c->low_gq_filter = -1;
+    c->strand_bias_model = PISCES_SB_EXTENDED;
+    c->filter_single_strand = 0;
+    c->include_reference_calls = 1;
+    c->emit_zero_coverage_refs = 0;
+    c->expect_stitched_reads = 0;
+    c->tile_loci = 64;
+    c->block_size = 1000;
+    c->min_frequency = 0.01f;
+    c->variant_freq_filter = 0.01f;
+    c->genotype_min_freq_filter = 0.01f;
+    c->target_lod_frequency = 0.01f;
+    c->strand_bias_threshold = 0.5f;
+    c->no_call_filter_threshold = 0.6f;
+    c->rmxn_max_repeat_length = 5;
+    c->rmxn_min_repetitions = 9;
+    c->rmxn_frequency_limit = 0.35f;
+}

@@ -1,0 +1,158 @@
+/*
+ * pisces_oracle.h — TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C, FP contraction off) of the reference's per-locus
+ * pileup-and-likelihood path (Illumina/Pisces v5.2.11, C#).  It exists to check the
+ * HIP path; nothing in the product (pisces_amd/, libpisceship.so) may link, import or
+ * call it.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
+ *
+ * Parity pinning: the reference cannot be compiled or run here (no dotnet/mono), so the
+ * restatement is pinned by the reference's own known-answer tests, transcribed as
+ * fixtures under tests/golden/ (see tests/golden/README.md for file:line of each).
+ * MathNet.Numerics 4.5.1 (NuGet dependency, not in /root/reference) is restated from its
+ * published algorithm (Cephes igam/igamc + Lanczos GammaLn) and pinned by
+ * QualityCalculatorTests.cs:65-75.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference/src).
+ */
+#ifndef PISCES_ORACLE_H
+#define PISCES_ORACLE_H
+
+#include <stdint.h>
+#include "../include/pisces_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_ALLELE 320
+
+typedef struct OrcRead {
+    int32_t position;            /* Read.Position (1-based) */
+    int32_t n_cigar;
+    const uint8_t* cigar_op;
+    const uint32_t* cigar_len;
+    int32_t read_len;
+    const uint8_t* bases;
+    const uint8_t* quals;
+    const uint8_t* dirs;         /* per-base DirectionType or NULL */
+    int32_t is_reverse;
+    const int32_t* posmap_override; /* tests poke PositionMap directly; NULL = from CIGAR */
+} OrcRead;
+
+typedef struct OrcCandidate {
+    int32_t position;
+    int32_t category;
+    char ref[ORC_MAX_ALLELE];
+    char alt[ORC_MAX_ALLELE];
+    int32_t support_by_dir[3];
+    int32_t well_anchored_by_dir[3];
+    int32_t open_left, open_right;
+    int32_t next;                /* per-locus chain inside OrcState */
+} OrcCandidate;
+
+/* StrandBiasStats / BiasResults (lib/Pisces.Domain/Models/StrandBiasStats.cs) */
+typedef struct OrcSbStats {
+    double chance_false_neg, chance_false_pos, chance_var_freq_gt_zero, coverage, frequency, support;
+} OrcSbStats;
+typedef struct OrcBiasResults {
+    double bias_score, gatk_bias_score;
+    int32_t bias_acceptable, var_present_on_both, cov_present_on_both;
+    OrcSbStats forward, reverse, overall, stitched;
+} OrcBiasResults;
+
+/* full CalledAllele working set (superset of the 64-byte record) */
+typedef struct OrcCalled {
+    int32_t position, category;
+    char ref[ORC_MAX_ALLELE], alt[ORC_MAX_ALLELE];
+    int32_t support_by_dir[3], well_anchored_by_dir[3];
+    int32_t allele_support, well_anchored_support;
+    int32_t total_coverage, reference_support, num_no_calls;
+    int32_t coverage_by_dir[3];
+    int32_t confident_start, confident_end, suspicious_start, suspicious_end;
+    double unanchored_weight;
+    double sum_of_base_quality;
+    int32_t variant_qscore, noise_level_applied;
+    float fraction_no_calls;
+    OrcBiasResults sb;
+    int32_t has_sb;
+    uint32_t filters;
+    int32_t genotype, genotype_qscore;
+} OrcCalled;
+
+typedef struct OrcState OrcState;
+
+/* ---- math (lib/Pisces.Calculators/stats) ---- */
+double orc_poisson_cdf(double num_occurrences, double expected);           /* stats/Poisson.cs:26 */
+double orc_q_to_p(double q);                                               /* stats/MathOperations.cs:7 */
+double orc_p_to_q(double p);                                               /* stats/MathOperations.cs:12 */
+double orc_mathnet_gamma_ln(double z);                                     /* MathNet SpecialFunctions.GammaLn */
+double orc_mathnet_gamma_lower_regularized(double a, double x);            /* MathNet SpecialFunctions.GammaLowerRegularized */
+double orc_mathnet_poisson_cdf(double lambda, double x);                   /* MathNet Poisson.CumulativeDistribution */
+double orc_mathnet_poisson_ln_pmf(double lambda, int32_t k);               /* MathNet Poisson.ProbabilityLn */
+
+/* ---- calculators ---- */
+double  orc_assign_pvalue(int32_t call_count, int32_t coverage, int32_t nl);              /* VariantQualityCalculator.cs:67-74 */
+double  orc_raw_poisson_qscore(int32_t call_count, int32_t coverage, int32_t nl);          /* :27-52 */
+int32_t orc_poisson_qscore(int32_t call_count, int32_t coverage, int32_t nl, int32_t max_q);/* :54-65 */
+void    orc_strand_bias(const int32_t cov_by_dir[3], const int32_t sup_by_dir[3], int32_t q_noise,
+                        double min_variant_freq, double acceptance, int32_t model, OrcBiasResults* out); /* StrandBiasCalculator.cs:21-72 */
+int32_t orc_somatic_genotype(int32_t category, int32_t total_coverage, int32_t allele_support,
+                             int32_t reference_support, float min_freq_filter, int32_t min_depth); /* SomaticGenotyper.cs:65-100 */
+int32_t orc_somatic_gq(int32_t genotype, int32_t variant_q, int32_t total_coverage, int32_t allele_support,
+                       float target_lod, int32_t min_gq, int32_t max_gq);                  /* SomaticGenotypeQualityCalculator.cs:10-48 */
+
+/* ---- region state (lib/Pisces.Processing/RegionState) ---- */
+OrcState* orc_state_create(int32_t start_position, int32_t n_loci, int32_t min_bq,
+                           int32_t num_anchor_types, int32_t track_open_ended);
+void      orc_state_destroy(OrcState* s);
+int32_t   orc_add_allele_counts(OrcState* s, const OrcRead* r);            /* RegionStateManager.cs:118-220 */
+int32_t   orc_get_allele_count(const OrcState* s, int32_t position, int32_t allele, int32_t dir,
+                               int32_t min_anchor, int32_t max_anchor /* -1 = null */, int32_t from_end,
+                               int32_t symmetric);                          /* AlleleCountHelper.cs:21-85 */
+double    orc_get_sum_base_quality(const OrcState* s, int32_t position, int32_t allele, int32_t dir,
+                               int32_t min_anchor, int32_t max_anchor, int32_t from_end, int32_t symmetric);
+const int32_t* orc_counts_ptr(const OrcState* s);                           /* [n_loci][6][3][n_anchor_idx] */
+int32_t   orc_num_anchor_indexes(const OrcState* s);
+void      orc_add_gapped_mnv_ref(OrcState* s, int32_t position, int32_t count);
+int32_t   orc_add_candidate(OrcState* s, const OrcCandidate* c);            /* RegionState.cs:94-174 */
+int32_t   orc_num_candidates(const OrcState* s);
+int32_t   orc_get_candidates(const OrcState* s, OrcCandidate* out, int32_t capacity); /* position order */
+
+/* ---- candidate finder (lib/Pisces.Domain/Logic/CandidateVariantFinder.cs) ---- */
+int32_t orc_find_candidates(const OrcRead* r, const uint8_t* ref_bases, int64_t ref_len,
+                            int32_t min_bq, int32_t max_mnv_len, int32_t max_gap, int32_t call_mnvs,
+                            int32_t anchor_size, OrcCandidate* out, int32_t capacity); /* :31-83 */
+int32_t orc_check_deletion_quality(const OrcRead* r, int32_t op_start_index, int32_t min_bq); /* :294-320 */
+
+/* ---- coverage + caller ---- */
+void    orc_coverage_compute(OrcCalled* allele, const OrcState* s, int32_t consider_anchors,
+                             int32_t expect_stitched);                      /* CoverageCalculator.cs:19-47 */
+void    orc_called_from_candidate(OrcCalled* out, const OrcCandidate* c);   /* AlleleHelper.Map, AlleleHelper.cs:51-85 */
+void    orc_process_variant(OrcCalled* v, const OrcState* s, const PiscesHipConfig* cfg); /* AlleleCaller.cs:208-234 */
+/* AlleleCaller.CallForPositions (AlleleCaller.cs:60-141) without collapser / MNV reallocation,
+ * over every candidate in the state plus (gVCF) a Reference candidate per position
+ * (RegionState.GetAllCandidates, RegionState.cs:383-453).  Sorted output; returns count or
+ * -(needed) when capacity is too small. */
+int64_t orc_call_all(OrcState* s, const uint8_t* ref_bases, int64_t ref_len, const PiscesHipConfig* cfg,
+                     PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out /* optional, same capacity */,
+                     int64_t* total_num_called);
+
+/* ---- whole path on a read batch: the CPU baseline (SmallVariantCaller.Execute loop,
+ * exe/Pisces/Logic/SmallVariantCaller.cs:79-116) ---- */
+int64_t orc_run_reads(const PiscesReadBatch* batch, const uint8_t* ref_bases, int64_t ref_len,
+                      int32_t region_start, int32_t region_loci, const PiscesHipConfig* cfg,
+                      PiscesCalledAllele* out, int64_t capacity, int64_t* n_candidate_loci);
+/* same, from packed observations (position, tuple) instead of reads */
+int64_t orc_run_observations(const int32_t* positions, const uint32_t* tuples, int64_t n_obs,
+                      const uint8_t* ref_bases, int64_t ref_len, int32_t region_start, int32_t region_loci,
+                      const PiscesHipConfig* cfg, PiscesCalledAllele* out, int64_t capacity,
+                      int64_t* n_candidate_loci);
+
+void orc_default_config(PiscesHipConfig* cfg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,284 @@
+"""ctypes / numpy mirrors of include/pisces_hip.h (the C ABI of libpisceship.so).
+
+Field order and widths must match the header exactly; tests/test_abi.py checks the
+sizes against the compiled library.
+"""
+import ctypes as C
+
+import numpy as np
+
+ABI_VERSION = 1
+
+# error codes
+OK = 0
+E_INVALID_ARG = -1
+E_BUFFER_TOO_SMALL = -2
+E_DEVICE = -3
+E_UNMAPPED_BASE = -4
+E_UNSUPPORTED = -5
+E_STATE = -6
+
+# src/lib/Pisces.Domain/Types/AlleleType.cs:3-11
+ALLELE_A, ALLELE_G, ALLELE_C, ALLELE_T, ALLELE_N, ALLELE_DEL = range(6)
+ALLELE_OF_BASE = {"A": ALLELE_A, "G": ALLELE_G, "C": ALLELE_C, "T": ALLELE_T, "N": ALLELE_N}
+BASE_OF_ALLELE = "AGCTND"
+# src/lib/Pisces.Domain/Types/DirectionType.cs:3-8
+DIR_FORWARD, DIR_REVERSE, DIR_STITCHED = range(3)
+# src/lib/Pisces.Domain/Types/CallType.cs:3-12
+CAT_SNV, CAT_INSERTION, CAT_DELETION, CAT_MNV, CAT_REFERENCE = range(5)
+# src/lib/Pisces.Domain/Types/Genotype.cs:3-18
+(GT_HET_ALT1_ALT2, GT_ALT12_LIKE_NOCALL, GT_HET_ALT_REF, GT_HOM_ALT, GT_HOM_REF, GT_REF_LIKE_NOCALL,
+ GT_ALT_LIKE_NOCALL, GT_REF_AND_NOCALL, GT_ALT_AND_NOCALL) = range(9)
+GT_STRING = {GT_HET_ALT_REF: "0/1", GT_HOM_ALT: "1/1", GT_HOM_REF: "0/0", GT_REF_LIKE_NOCALL: "./.",
+             GT_ALT_LIKE_NOCALL: "./.", GT_REF_AND_NOCALL: "0/.", GT_ALT_AND_NOCALL: "1/."}
+# src/lib/Pisces.Domain/Types/FilterType.cs:3-19
+(FILTER_STRAND_BIAS, FILTER_POOL_BIAS, FILTER_AMPLICON_BIAS, FILTER_LOW_VARIANT_QSCORE, FILTER_LOW_DEPTH,
+ FILTER_LOW_VARIANT_FREQUENCY, FILTER_LOW_GENOTYPE_QUALITY, FILTER_INDEL_REPEAT_LENGTH,
+ FILTER_MULTI_ALLELIC_SITE, FILTER_RMXN, FILTER_FORCED_REPORT, FILTER_OFF_TARGET, FILTER_NO_CALL) = range(13)
+SB_POISSON, SB_EXTENDED, SB_DIPLOID = range(3)
+
+ANCHOR_SIZE = 5
+NUM_ANCHORS = 11
+COUNTS_PER_LOCUS = 6 * 3 * NUM_ANCHORS
+TUPLE_PAD = 0xFFFFFFFF
+
+
+def tuple_pack(locus, anchor, direction, allele, qual):
+    """PISCES_TUPLE_PACK; works on ints and numpy arrays."""
+    if isinstance(locus, np.ndarray):
+        return (locus.astype(np.uint32) | (np.asarray(anchor).astype(np.uint32) << np.uint32(15))
+                | (np.asarray(direction).astype(np.uint32) << np.uint32(19))
+                | (np.asarray(allele).astype(np.uint32) << np.uint32(21))
+                | (np.asarray(qual).astype(np.uint32) << np.uint32(24)))
+    return (locus | (anchor << 15) | (direction << 19) | (allele << 21) | (qual << 24)) & 0xFFFFFFFF
+
+
+class PiscesHipConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("min_base_call_quality", C.c_int32),
+        ("noise_level", C.c_int32),
+        ("max_variant_qscore", C.c_int32),
+        ("min_variant_qscore", C.c_int32),
+        ("variant_qscore_filter", C.c_int32),
+        ("min_coverage", C.c_int32),
+        ("low_depth_filter", C.c_int32),
+        ("min_genotype_qscore", C.c_int32),
+        ("max_genotype_qscore", C.c_int32),
+        ("low_gq_filter", C.c_int32),
+        ("strand_bias_model", C.c_int32),
+        ("filter_single_strand", C.c_int32),
+        ("include_reference_calls", C.c_int32),
+        ("emit_zero_coverage_refs", C.c_int32),
+        ("expect_stitched_reads", C.c_int32),
+        ("tile_loci", C.c_int32),
+        ("block_size", C.c_int32),
+        ("min_frequency", C.c_float),
+        ("variant_freq_filter", C.c_float),
+        ("genotype_min_freq_filter", C.c_float),
+        ("target_lod_frequency", C.c_float),
+        ("strand_bias_threshold", C.c_float),
+        ("no_call_filter_threshold", C.c_float),
+        ("rmxn_max_repeat_length", C.c_int32),
+        ("rmxn_min_repetitions", C.c_int32),
+        ("rmxn_frequency_limit", C.c_float),
+        ("reserved", C.c_int32 * 3),
+    ]
+
+
+def default_config(**overrides):
+    """Reference defaults after VariantCallingParameters.Validate()
+    (src/lib/Pisces.Domain/Options/VariantCallingParameters.cs:57-156)."""
+    c = PiscesHipConfig()
+    c.abi_version = ABI_VERSION
+    c.min_base_call_quality = 20
+    c.noise_level = 20
+    c.max_variant_qscore = 100
+    c.min_variant_qscore = 20
+    c.variant_qscore_filter = 30
+    c.min_coverage = 10
+    c.low_depth_filter = 10
+    c.min_genotype_qscore = 0
+    c.max_genotype_qscore = 100
+    c.low_gq_filter = -1
+    c.strand_bias_model = SB_EXTENDED
+    c.filter_single_strand = 0
+    c.include_reference_calls = 1
+    c.emit_zero_coverage_refs = 0
+    c.expect_stitched_reads = 0
+    c.tile_loci = 64
+    c.block_size = 1000
+    c.min_frequency = 0.01
+    c.variant_freq_filter = 0.01
+    c.genotype_min_freq_filter = 0.01
+    c.target_lod_frequency = 0.01
+    c.strand_bias_threshold = 0.5
+    c.no_call_filter_threshold = 0.6
+    c.rmxn_max_repeat_length = 5
+    c.rmxn_min_repetitions = 9
+    c.rmxn_frequency_limit = 0.35
+    for k, v in overrides.items():
+        if not hasattr(c, k):
+            raise AttributeError(f"PiscesHipConfig has no field {k!r}")
+        setattr(c, k, v)
+    return c
+
+
+CALLED_ALLELE_DTYPE = np.dtype([
+    ("position", "<i4"),
+    ("total_coverage", "<i4"),
+    ("allele_support", "<i4"),
+    ("reference_support", "<i4"),
+    ("num_no_calls", "<i4"),
+    ("coverage_by_dir", "<i4", (3,)),
+    ("support_by_dir", "<i4", (3,)),
+    ("variant_qscore", "<i4"),
+    ("strand_bias_score", "<f8"),
+    ("genotype_qscore", "<i4"),
+    ("filter_bits", "<u2"),
+    ("info", "<u2"),
+], align=True)
+assert CALLED_ALLELE_DTYPE.itemsize == 64
+
+TILE_DTYPE = np.dtype([("start_position", "<i4"), ("n_loci", "<i4"), ("tuple_begin", "<i8"), ("tuple_end", "<i8")],
+                      align=True)
+assert TILE_DTYPE.itemsize == 24
+TILE_RESULT_DTYPE = np.dtype([("record_begin", "<i4"), ("n_records", "<i4"), ("n_candidate_loci", "<i4"),
+                              ("reserved", "<i4")], align=True)
+assert TILE_RESULT_DTYPE.itemsize == 16
+
+
+def info_genotype(info):
+    return info & 0xF
+
+
+def info_category(info):
+    return (info >> 4) & 0x7
+
+
+def info_ref(info):
+    return (info >> 7) & 0x7
+
+
+def info_alt(info):
+    return (info >> 10) & 0x7
+
+
+def info_sb_ok(info):
+    return (info >> 13) & 1
+
+
+def info_var_both(info):
+    return (info >> 14) & 1
+
+
+def info_cov_both(info):
+    return (info >> 15) & 1
+
+
+class PiscesReadBatch(C.Structure):
+    _fields_ = [
+        ("n_reads", C.c_int32),
+        ("position", C.POINTER(C.c_int32)),
+        ("flags", C.POINTER(C.c_uint8)),
+        ("cigar_offset", C.POINTER(C.c_int32)),
+        ("cigar_op", C.POINTER(C.c_uint8)),
+        ("cigar_len", C.POINTER(C.c_uint32)),
+        ("seq_offset", C.POINTER(C.c_int32)),
+        ("bases", C.POINTER(C.c_uint8)),
+        ("quals", C.POINTER(C.c_uint8)),
+        ("directions", C.POINTER(C.c_uint8)),
+    ]
+
+
+class PiscesCandidate(C.Structure):
+    _fields_ = [
+        ("position", C.c_int32),
+        ("category", C.c_int32),
+        ("ref_len", C.c_int32),
+        ("alt_len", C.c_int32),
+        ("support_by_dir", C.c_int32 * 3),
+        ("well_anchored_by_dir", C.c_int32 * 3),
+        ("open_left", C.c_uint8),
+        ("open_right", C.c_uint8),
+        ("pad", C.c_uint8 * 2),
+        ("allele_offset", C.c_int64),
+    ]
+
+
+def _ptr(arr, ctype):
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+class ReadBatch:
+    """Structure-of-arrays read batch (what the C# shim pins per call). Keeps the numpy
+    arrays alive next to the ctypes view."""
+
+    def __init__(self, reads):
+        """reads: iterable of dicts {pos, cigar:[(op,len)], seq:str|bytes, quals:bytes|list,
+        reverse:bool, dirs:optional list}."""
+        reads = list(reads)
+        n = len(reads)
+        self.position = np.array([r["pos"] for r in reads], dtype=np.int32).reshape(n)
+        self.flags = np.array([1 if r.get("reverse") else 0 for r in reads], dtype=np.uint8).reshape(n)
+        cig_off = [0]
+        ops, lens = [], []
+        seq_off = [0]
+        bases, quals, dirs = [], [], []
+        any_dirs = any(r.get("dirs") is not None for r in reads)
+        for r in reads:
+            for op, ln in r["cigar"]:
+                ops.append(ord(op))
+                lens.append(ln)
+            cig_off.append(len(ops))
+            s = r["seq"].encode() if isinstance(r["seq"], str) else bytes(r["seq"])
+            q = bytes(r["quals"])
+            assert len(s) == len(q), "sequence / quality length mismatch"
+            bases.append(np.frombuffer(s, dtype=np.uint8))
+            quals.append(np.frombuffer(q, dtype=np.uint8))
+            if any_dirs:
+                d = r.get("dirs")
+                if d is None:
+                    d = [DIR_REVERSE if r.get("reverse") else DIR_FORWARD] * len(s)
+                dirs.append(np.array(d, dtype=np.uint8))
+            seq_off.append(seq_off[-1] + len(s))
+        self.cigar_offset = np.array(cig_off, dtype=np.int32)
+        self.cigar_op = np.array(ops, dtype=np.uint8)
+        self.cigar_len = np.array(lens, dtype=np.uint32)
+        self.seq_offset = np.array(seq_off, dtype=np.int32)
+        self.bases = np.concatenate(bases) if bases else np.zeros(0, np.uint8)
+        self.quals = np.concatenate(quals) if quals else np.zeros(0, np.uint8)
+        self.directions = np.concatenate(dirs) if any_dirs and dirs else None
+        self._finish(n)
+
+    @classmethod
+    def from_arrays(cls, position, flags, cigar_offset, cigar_op, cigar_len, seq_offset, bases, quals,
+                    directions=None):
+        self = cls.__new__(cls)
+        self.position = np.ascontiguousarray(position, np.int32)
+        self.flags = np.ascontiguousarray(flags, np.uint8)
+        self.cigar_offset = np.ascontiguousarray(cigar_offset, np.int32)
+        self.cigar_op = np.ascontiguousarray(cigar_op, np.uint8)
+        self.cigar_len = np.ascontiguousarray(cigar_len, np.uint32)
+        self.seq_offset = np.ascontiguousarray(seq_offset, np.int32)
+        self.bases = np.ascontiguousarray(bases, np.uint8)
+        self.quals = np.ascontiguousarray(quals, np.uint8)
+        self.directions = None if directions is None else np.ascontiguousarray(directions, np.uint8)
+        self._finish(len(self.position))
+        return self
+
+    def _finish(self, n):
+        b = PiscesReadBatch()
+        b.n_reads = n
+        b.position = _ptr(self.position, C.c_int32)
+        b.flags = _ptr(self.flags, C.c_uint8)
+        b.cigar_offset = _ptr(self.cigar_offset, C.c_int32)
+        b.cigar_op = _ptr(self.cigar_op, C.c_uint8)
+        b.cigar_len = _ptr(self.cigar_len, C.c_uint32)
+        b.seq_offset = _ptr(self.seq_offset, C.c_int32)
+        b.bases = _ptr(self.bases, C.c_uint8)
+        b.quals = _ptr(self.quals, C.c_uint8)
+        b.directions = _ptr(self.directions, C.c_uint8) if self.directions is not None else None
+        self.c = b
+        self.n_reads = n
+        self.n_bases = int(self.seq_offset[-1]) if n else 0

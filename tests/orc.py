@@ -1,0 +1,291 @@
+"""ctypes view of oracle/libpiscesoracle.so — TEST INFRASTRUCTURE (the CPU restatement of the
+reference path).  Product code never imports this module."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from pisces_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORC_MAX_ALLELE = 320
+
+
+class OrcRead(C.Structure):
+    _fields_ = [
+        ("position", C.c_int32),
+        ("n_cigar", C.c_int32),
+        ("cigar_op", C.POINTER(C.c_uint8)),
+        ("cigar_len", C.POINTER(C.c_uint32)),
+        ("read_len", C.c_int32),
+        ("bases", C.POINTER(C.c_uint8)),
+        ("quals", C.POINTER(C.c_uint8)),
+        ("dirs", C.POINTER(C.c_uint8)),
+        ("is_reverse", C.c_int32),
+        ("posmap_override", C.POINTER(C.c_int32)),
+    ]
+
+
+class OrcCandidate(C.Structure):
+    _fields_ = [
+        ("position", C.c_int32),
+        ("category", C.c_int32),
+        ("ref", C.c_char * ORC_MAX_ALLELE),
+        ("alt", C.c_char * ORC_MAX_ALLELE),
+        ("support_by_dir", C.c_int32 * 3),
+        ("well_anchored_by_dir", C.c_int32 * 3),
+        ("open_left", C.c_int32),
+        ("open_right", C.c_int32),
+        ("next", C.c_int32),
+    ]
+
+
+class OrcSbStats(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("chance_false_neg", "chance_false_pos", "chance_var_freq_gt_zero",
+                                          "coverage", "frequency", "support")]
+
+
+class OrcBiasResults(C.Structure):
+    _fields_ = [
+        ("bias_score", C.c_double),
+        ("gatk_bias_score", C.c_double),
+        ("bias_acceptable", C.c_int32),
+        ("var_present_on_both", C.c_int32),
+        ("cov_present_on_both", C.c_int32),
+        ("forward", OrcSbStats),
+        ("reverse", OrcSbStats),
+        ("overall", OrcSbStats),
+        ("stitched", OrcSbStats),
+    ]
+
+
+class OrcCalled(C.Structure):
+    _fields_ = [
+        ("position", C.c_int32), ("category", C.c_int32),
+        ("ref", C.c_char * ORC_MAX_ALLELE), ("alt", C.c_char * ORC_MAX_ALLELE),
+        ("support_by_dir", C.c_int32 * 3), ("well_anchored_by_dir", C.c_int32 * 3),
+        ("allele_support", C.c_int32), ("well_anchored_support", C.c_int32),
+        ("total_coverage", C.c_int32), ("reference_support", C.c_int32), ("num_no_calls", C.c_int32),
+        ("coverage_by_dir", C.c_int32 * 3),
+        ("confident_start", C.c_int32), ("confident_end", C.c_int32),
+        ("suspicious_start", C.c_int32), ("suspicious_end", C.c_int32),
+        ("unanchored_weight", C.c_double),
+        ("sum_of_base_quality", C.c_double),
+        ("variant_qscore", C.c_int32), ("noise_level_applied", C.c_int32),
+        ("fraction_no_calls", C.c_float),
+        ("sb", OrcBiasResults),
+        ("has_sb", C.c_int32),
+        ("filters", C.c_uint32),
+        ("genotype", C.c_int32), ("genotype_qscore", C.c_int32),
+    ]
+
+
+def _load():
+    so = os.path.join(ROOT, "oracle", "libpiscesoracle.so")
+    src = os.path.join(ROOT, "oracle", "pisces_oracle.c")
+    if not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(so) < os.path.getmtime(src)):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    L = C.CDLL(so)
+    d, i32, i64, f32 = C.c_double, C.c_int32, C.c_int64, C.c_float
+    P = C.POINTER
+    sig = {
+        "orc_poisson_cdf": (d, [d, d]),
+        "orc_q_to_p": (d, [d]),
+        "orc_p_to_q": (d, [d]),
+        "orc_mathnet_gamma_ln": (d, [d]),
+        "orc_mathnet_gamma_lower_regularized": (d, [d, d]),
+        "orc_mathnet_poisson_cdf": (d, [d, d]),
+        "orc_mathnet_poisson_ln_pmf": (d, [d, i32]),
+        "orc_assign_pvalue": (d, [i32, i32, i32]),
+        "orc_raw_poisson_qscore": (d, [i32, i32, i32]),
+        "orc_poisson_qscore": (i32, [i32, i32, i32, i32]),
+        "orc_strand_bias": (None, [P(i32), P(i32), i32, d, d, i32, P(OrcBiasResults)]),
+        "orc_somatic_genotype": (i32, [i32, i32, i32, i32, f32, i32]),
+        "orc_somatic_gq": (i32, [i32, i32, i32, i32, f32, i32, i32]),
+        "orc_state_create": (C.c_void_p, [i32, i32, i32, i32, i32]),
+        "orc_state_destroy": (None, [C.c_void_p]),
+        "orc_add_allele_counts": (i32, [C.c_void_p, P(OrcRead)]),
+        "orc_get_allele_count": (i32, [C.c_void_p, i32, i32, i32, i32, i32, i32, i32]),
+        "orc_get_sum_base_quality": (d, [C.c_void_p, i32, i32, i32, i32, i32, i32, i32]),
+        "orc_counts_ptr": (P(i32), [C.c_void_p]),
+        "orc_num_anchor_indexes": (i32, [C.c_void_p]),
+        "orc_add_gapped_mnv_ref": (None, [C.c_void_p, i32, i32]),
+        "orc_add_candidate": (i32, [C.c_void_p, P(OrcCandidate)]),
+        "orc_num_candidates": (i32, [C.c_void_p]),
+        "orc_get_candidates": (i32, [C.c_void_p, P(OrcCandidate), i32]),
+        "orc_find_candidates": (i32, [P(OrcRead), P(C.c_uint8), i64, i32, i32, i32, i32, i32, P(OrcCandidate), i32]),
+        "orc_check_deletion_quality": (i32, [P(OrcRead), i32, i32]),
+        "orc_coverage_compute": (None, [P(OrcCalled), C.c_void_p, i32, i32]),
+        "orc_called_from_candidate": (None, [P(OrcCalled), P(OrcCandidate)]),
+        "orc_process_variant": (None, [P(OrcCalled), C.c_void_p, P(_abi.PiscesHipConfig)]),
+        "orc_call_all": (i64, [C.c_void_p, P(C.c_uint8), i64, P(_abi.PiscesHipConfig), C.c_void_p, i64, P(OrcCalled),
+                               P(i64)]),
+        "orc_run_reads": (i64, [P(_abi.PiscesReadBatch), P(C.c_uint8), i64, i32, i32, P(_abi.PiscesHipConfig),
+                                C.c_void_p, i64, P(i64)]),
+        "orc_run_observations": (i64, [P(i32), P(C.c_uint32), i64, P(C.c_uint8), i64, i32, i32,
+                                       P(_abi.PiscesHipConfig), C.c_void_p, i64, P(i64)]),
+        "orc_default_config": (None, [P(_abi.PiscesHipConfig)]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    return L
+
+
+lib = _load()
+
+
+def make_read(pos, seq, cigar=None, quals=None, qual_all=30, reverse=False, dirs=None, posmap=None):
+    """ReadTestHelper.CreateRead (src/test/TestUtilities/ReadTestHelper.cs:156-173): default Q30, <len>M."""
+    seq_b = np.frombuffer(seq.encode(), dtype=np.uint8).copy()
+    n = len(seq_b)
+    if cigar is None:
+        cigar = [("M", n)]
+    elif isinstance(cigar, str):
+        cigar = parse_cigar(cigar)
+    ops = np.array([ord(o) for o, _ in cigar], dtype=np.uint8)
+    lens = np.array([l for _, l in cigar], dtype=np.uint32)
+    q = np.array(quals if quals is not None else [qual_all] * n, dtype=np.uint8)
+    keep = [seq_b, ops, lens, q]
+    r = OrcRead()
+    r.position = pos
+    r.n_cigar = len(cigar)
+    r.cigar_op = ops.ctypes.data_as(C.POINTER(C.c_uint8))
+    r.cigar_len = lens.ctypes.data_as(C.POINTER(C.c_uint32))
+    r.read_len = n
+    r.bases = seq_b.ctypes.data_as(C.POINTER(C.c_uint8))
+    r.quals = q.ctypes.data_as(C.POINTER(C.c_uint8))
+    if dirs is not None:
+        da = np.array(dirs, dtype=np.uint8)
+        keep.append(da)
+        r.dirs = da.ctypes.data_as(C.POINTER(C.c_uint8))
+    r.is_reverse = 1 if reverse else 0
+    if posmap is not None:
+        pm = np.array(posmap, dtype=np.int32)
+        keep.append(pm)
+        r.posmap_override = pm.ctypes.data_as(C.POINTER(C.c_int32))
+    r._keep = keep
+    return r
+
+
+def parse_cigar(s):
+    out, num = [], ""
+    for ch in s:
+        if ch.isdigit():
+            num += ch
+        else:
+            out.append((ch, int(num)))
+            num = ""
+    return out
+
+
+class State:
+    """Dense-window RegionStateManager of the oracle."""
+
+    def __init__(self, start, n_loci, min_bq=20, anchor_size=5, track_open_ended=False):
+        self.h = lib.orc_state_create(start, n_loci, min_bq, anchor_size, 1 if track_open_ended else 0)
+        self.start, self.n_loci = start, n_loci
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.orc_state_destroy(self.h)
+            self.h = None
+
+    def add_allele_counts(self, read):
+        return lib.orc_add_allele_counts(self.h, C.byref(read))
+
+    def get_allele_count(self, pos, allele, direction, min_anchor=0, max_anchor=-1, from_end=False, symmetric=False):
+        return lib.orc_get_allele_count(self.h, pos, allele, direction, min_anchor, max_anchor, int(from_end),
+                                        int(symmetric))
+
+    def counts(self):
+        na = lib.orc_num_anchor_indexes(self.h)
+        p = lib.orc_counts_ptr(self.h)
+        return np.ctypeslib.as_array(p, shape=(self.n_loci, 6, 3, na)).copy()
+
+    def set_count(self, pos, allele, direction, anchor, value):
+        na = lib.orc_num_anchor_indexes(self.h)
+        p = lib.orc_counts_ptr(self.h)
+        a = np.ctypeslib.as_array(p, shape=(self.n_loci, 6, 3, na))
+        a[pos - self.start, allele, direction, anchor] = value
+
+    def add_candidate(self, cand):
+        return lib.orc_add_candidate(self.h, C.byref(cand))
+
+    def candidates(self):
+        n = lib.orc_num_candidates(self.h)
+        arr = (OrcCandidate * max(n, 1))()
+        lib.orc_get_candidates(self.h, arr, n)
+        return [arr[i] for i in range(n)]
+
+    def call_all(self, ref_bases, cfg, want_full=False):
+        ref = np.frombuffer(ref_bases if isinstance(ref_bases, bytes) else ref_bases.encode(), dtype=np.uint8)
+        cap = self.n_loci * 5 + 16
+        out = np.zeros(cap, dtype=_abi.CALLED_ALLELE_DTYPE)
+        full = (OrcCalled * cap)() if want_full else None
+        total = C.c_int64(0)
+        n = lib.orc_call_all(self.h, ref.ctypes.data_as(C.POINTER(C.c_uint8)), len(ref), C.byref(cfg),
+                             out.ctypes.data, cap, full, C.byref(total))
+        assert n >= 0, n
+        if want_full:
+            return out[:n], [full[i] for i in range(n)], total.value
+        return out[:n]
+
+
+def make_candidate(pos, category, ref, alt, support=(0, 0, 0), well_anchored=(0, 0, 0), open_left=False,
+                   open_right=False):
+    c = OrcCandidate()
+    c.position = pos
+    c.category = category
+    c.ref = ref.encode()
+    c.alt = alt.encode()
+    for i in range(3):
+        c.support_by_dir[i] = support[i]
+        c.well_anchored_by_dir[i] = well_anchored[i]
+    c.open_left = int(open_left)
+    c.open_right = int(open_right)
+    c.next = -1
+    return c
+
+
+def strand_bias(cov, sup, q_noise=20, min_vf=0.01, acceptance=0.5, model=_abi.SB_EXTENDED):
+    r = OrcBiasResults()
+    lib.orc_strand_bias((C.c_int32 * 3)(*cov), (C.c_int32 * 3)(*sup), q_noise, min_vf, acceptance, model, C.byref(r))
+    return r
+
+
+def find_candidates(read, ref, min_bq=20, max_mnv=3, max_gap=1, call_mnvs=False, anchor_size=5):
+    refa = np.frombuffer(ref.encode() if isinstance(ref, str) else ref, dtype=np.uint8)
+    out = (OrcCandidate * 256)()
+    n = lib.orc_find_candidates(C.byref(read), refa.ctypes.data_as(C.POINTER(C.c_uint8)), len(refa), min_bq, max_mnv,
+                                max_gap, int(call_mnvs), anchor_size, out, 256)
+    assert n >= 0, n
+    return [out[i] for i in range(n)]
+
+
+def run_observations(positions, tuples, ref, region_start, region_loci, cfg):
+    positions = np.ascontiguousarray(positions, np.int32)
+    tuples = np.ascontiguousarray(tuples, np.uint32)
+    refa = np.ascontiguousarray(ref, np.uint8)
+    cap = region_loci * 5 + 16
+    out = np.zeros(cap, dtype=_abi.CALLED_ALLELE_DTYPE)
+    nloci = C.c_int64(0)
+    n = lib.orc_run_observations(positions.ctypes.data_as(C.POINTER(C.c_int32)),
+                                 tuples.ctypes.data_as(C.POINTER(C.c_uint32)), len(tuples),
+                                 refa.ctypes.data_as(C.POINTER(C.c_uint8)), len(refa), region_start, region_loci,
+                                 C.byref(cfg), out.ctypes.data, cap, C.byref(nloci))
+    assert n >= 0, n
+    return out[:n], nloci.value
+
+
+def run_reads(batch, ref, region_start, region_loci, cfg):
+    refa = np.ascontiguousarray(ref, np.uint8)
+    cap = region_loci * 5 + 16
+    out = np.zeros(cap, dtype=_abi.CALLED_ALLELE_DTYPE)
+    nloci = C.c_int64(0)
+    n = lib.orc_run_reads(C.byref(batch.c), refa.ctypes.data_as(C.POINTER(C.c_uint8)), len(refa), region_start,
+                          region_loci, C.byref(cfg), out.ctypes.data, cap, C.byref(nloci))
+    assert n >= 0, n
+    return out[:n], nloci.value

@@ -1,0 +1,324 @@
+"""Pins oracle/ (the CPU restatement of the reference path) against the reference's own
+known-answer tables (tests/golden/*.json, transcribed from the xUnit tests cited there)."""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from pisces_amd import _abi
+from tests import orc
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+INT_MAX = 2**31 - 1
+
+
+def load(name):
+    with open(os.path.join(G, name)) as f:
+        return json.load(f)
+
+
+GT = {"HeterozygousAlt1Alt2": 0, "Alt12LikeNoCall": 1, "HeterozygousAltRef": 2, "HomozygousAlt": 3, "HomozygousRef": 4,
+      "RefLikeNoCall": 5, "AltLikeNoCall": 6, "RefAndNoCall": 7, "AltAndNoCall": 8}
+ALLELE = {"A": 0, "G": 1, "C": 2, "T": 3, "N": 4, "D": 5}
+DIR = {"F": 0, "R": 1, "S": 2}
+
+
+# ---------------------------------------------------------------- q-score (MathNet boundary)
+def test_variant_qscore_table():
+    g = load("qscore.json")
+    nl = g["noise_level"]
+    for row in g["compute"]:
+        assert orc.lib.orc_poisson_qscore(row["support"], row["coverage"], nl, INT_MAX) == row["q"], row
+        assert orc.lib.orc_poisson_qscore(row["support"], row["coverage"], nl, 100) == min(100, row["q"]), row
+
+
+def test_assign_pvalue_table():
+    g = load("qscore.json")
+    for row in g["assign_pvalue"]:
+        p = orc.lib.orc_assign_pvalue(row["support"], row["coverage"], 20)
+        assert round(abs(p - row["p"]), row["decimals"]) == 0, (row, p)  # xUnit Assert.Equal(a, b, precision)
+        assert orc.lib.orc_poisson_qscore(row["support"], row["coverage"], 20, 100) == row["final_q_cap100"]
+
+
+def test_qscore_cap_and_bad_input():
+    g = load("qscore.json")
+    c = g["cap"]
+    assert orc.lib.orc_poisson_qscore(c["support"], c["coverage"], 20, 1000) == c["uncapped"]
+    assert orc.lib.orc_poisson_qscore(c["support"], c["coverage"], 20, c["max_q_below"]) == c["max_q_below"]
+    for k, cov, nl in g["bad_input"]:
+        assert orc.lib.orc_poisson_qscore(k, cov, nl, 100) == 0
+
+
+def test_excel_truth_depth500_and_raw_q():
+    g = load("qscore.json")
+    for row in g["excel_depth500"]:
+        p = orc.lib.orc_assign_pvalue(row["support"], 500, 20)
+        assert abs(p - row["p"]) < 5e-5
+        assert abs(orc.lib.orc_p_to_q(p) - row["q"]) < 5e-5
+    r = g["raw_q_depth10000"]
+    raw = orc.lib.orc_raw_poisson_qscore(r["support"], r["coverage"], 20)
+    assert abs(raw - r["raw_q"]) < 5e-5
+    assert (r["chernoff_q"] - raw) / r["chernoff_q"] <= 0.03
+
+
+def test_mathnet_restatement_against_scipy():
+    """Cross-check of the restated MathNet functions (only possible where scipy exists)."""
+    sp = pytest.importorskip("scipy.special")
+    for a, x in [(1, 0.5), (5, 1.0), (25, 5.0), (10, 2.0), (3, 7.5), (250, 50.0), (40, 60.0), (700, 650.0)]:
+        got = orc.lib.orc_mathnet_gamma_lower_regularized(a, x)
+        assert got == pytest.approx(float(sp.gammainc(a, x)), rel=1e-12, abs=1e-300)
+    for z in [0.7, 1.0, 2.5, 10.0, 171.0, 495.0, 9995.0]:
+        assert orc.lib.orc_mathnet_gamma_ln(z) == pytest.approx(float(sp.gammaln(z)), rel=1e-13, abs=1e-13)
+    for k, lam in [(0, 1.0), (4, 5.0), (24, 5.0), (249, 50.0)]:
+        assert orc.lib.orc_poisson_cdf(k, lam) == pytest.approx(float(sp.pdtr(k, lam)), rel=1e-10)
+
+
+# ---------------------------------------------------------------- strand bias
+def test_strand_bias_somatic_rows():
+    g = load("strand_bias.json")
+    for row in g["somatic_extended"]:
+        r = orc.strand_bias(row["cov"], row["sup"], row["q_noise"], row["min_vf"], row["thr"], _abi.SB_EXTENDED)
+        if row["gatk"] == "-inf":
+            assert r.bias_score == 0 and r.gatk_bias_score == -math.inf
+        else:
+            assert round(abs(r.bias_score - row["bias"]), row["decimals"]) == 0
+            assert round(abs(r.gatk_bias_score - row["gatk"]), row["decimals"]) == 0
+        assert bool(r.bias_acceptable) == row["acceptable"]
+    f = g["forced_poisson"]
+    r = orc.strand_bias(f["cov"], f["sup"], f["q_noise"], f["min_vf"], f["thr"], _abi.SB_POISSON)
+    assert r.bias_score == 1.0 and r.gatk_bias_score == 0
+
+
+def _execute_sb(f, r, s, q=20, thr=0.5, model=_abi.SB_POISSON):
+    # the reference's ExecuteTest harness (StrandBiasCalculatorTests.cs:363-393)
+    sup = [int(f[0] * f[1]), int(r[0] * r[1]), int(s[0] * s[1])]
+    return orc.strand_bias([f[1], r[1], s[1]], sup, q, 0.01, thr, model)
+
+
+def test_strand_bias_both_strand_flags():
+    g = load("strand_bias.json")
+    for row in g["both_strands_poisson"]:
+        # the reference builds the frequencies as float32 (0.1f, ...)
+        f = (float(np.float32(row["f"][0])), row["f"][1])
+        r = (float(np.float32(row["r"][0])), row["r"][1])
+        s = (float(np.float32(row["s"][0])), row["s"][1])
+        res = _execute_sb(f, r, s)
+        assert bool(res.var_present_on_both) == row["var"], row
+        assert bool(res.cov_present_on_both) == row["cov"], row
+
+
+def test_strand_bias_threshold_sweeps():
+    g = load("strand_bias.json")
+    h = g["happy_path_poisson"]
+    for rev_depth in range(h["rev_depth_range"][0], h["rev_depth_range"][1]):
+        res = _execute_sb((h["fwd_freq"], h["fwd_depth"]), (h["rev_freq"], rev_depth),
+                          (h["stitched_freq"], h["stitched_depth"]))
+        if rev_depth == 0:
+            assert res.bias_acceptable
+        else:
+            assert not res.bias_acceptable
+            thr = float(np.float32(res.bias_score + 0.00001))
+            assert _execute_sb((h["fwd_freq"], h["fwd_depth"]), (h["rev_freq"], rev_depth),
+                               (h["stitched_freq"], h["stitched_depth"]), 20, thr).bias_acceptable
+    v = g["varying_coverage_poisson"]
+    ff = 0.01
+    while ff < 0.10:
+        for fc in range(v["fwd_cov"][0], v["fwd_cov"][1] + 1, v["fwd_cov"][2]):
+            assert _execute_sb((ff, fc), tuple(v["rev"]), tuple(v["stitched"])).bias_acceptable
+        ff += 0.01
+
+
+# ---------------------------------------------------------------- somatic genotype / GQ
+def test_somatic_genotype_scenarios():
+    g = load("somatic_genotype.json")
+    pv = g["passing_variant"]
+    for row in g["genotype_cases"]:
+        cov = row["total_coverage"]
+        if row["is_reference"]:
+            cat, sup, refsup = _abi.CAT_REFERENCE, pv["reference"]["allele_support"], 0
+        else:
+            refsup = int(np.float32(row["ref_frequency"]) * np.float32(cov))  # (int)(refFrequency * totalCoverage)
+            cat, sup = _abi.CAT_SNV, cov - refsup
+        gt = orc.lib.orc_somatic_genotype(cat, cov, sup, refsup, g["genotype_min_freq_filter"], g["genotype_min_depth"])
+        assert gt == GT[row["genotype"]], row
+
+
+def test_somatic_gq_table():
+    g = load("somatic_genotype.json")["gq"]
+    depth = g["depth"]
+    for case in g["cases"]:
+        for freq, exp in zip(case["freqs"], case["expected"]):
+            gt = GT[case["genotype"]]
+            support = int(depth * freq)
+            if case["genotype"] in ("HomozygousRef", "RefAndNoCall"):
+                support = int(depth * (1.0 - freq))
+            got = orc.lib.orc_somatic_gq(gt, g["variant_q"], depth, support, case["lod"], g["min_gq"], g["max_gq"])
+            assert got == exp, (case["genotype"], case["lod"], freq, got, exp)
+
+
+# ---------------------------------------------------------------- region state
+def _mk(rd, default_q):
+    dirs = None
+    if "dirs" in rd:
+        dirs = [DIR[rd["dirs"]]] * len(rd["seq"])
+    posmap = None
+    if "posmap_unmapped_index" in rd:
+        posmap = [rd["pos"] + i for i in range(len(rd["seq"]))]
+        posmap[rd["posmap_unmapped_index"]] = -1
+    return orc.make_read(rd["pos"], rd["seq"], cigar=rd.get("cigar"), quals=rd.get("quals"),
+                         qual_all=rd.get("qual", default_q), dirs=dirs, posmap=posmap)
+
+
+def test_add_and_get_allele_counts():
+    g = load("region_state.json")["add_and_get"]
+    st = orc.State(900, 300, min_bq=g["min_quality"])
+    for rd in g["reads"]:
+        assert st.add_allele_counts(_mk(rd, g["min_quality"])) == 0
+    for pos, a, d, n in g["expect"]:
+        assert st.get_allele_count(pos, ALLELE[a], DIR[d]) == n, (pos, a, d)
+    assert st.add_allele_counts(_mk(g["then_read"], g["min_quality"])) == 0
+    for pos, a, d, n in g["expect_after"]:
+        assert st.get_allele_count(pos, ALLELE[a], DIR[d]) == n, (pos, a, d)
+
+
+def test_poor_quality_and_terminal_deletions():
+    g = load("region_state.json")["poor_qual_deletions"]
+    for sc in g["scenarios"]:
+        st = orc.State(900, 300, min_bq=g["min_quality"])
+        for rd in sc["reads"]:
+            assert st.add_allele_counts(_mk(rd, 30)) == 0
+        for e in sc["expect_ranges"]:
+            for pos in range(e["from"], e["to"] + 1):
+                assert st.get_allele_count(pos, ALLELE[e["allele"]], DIR[e["dir"]]) == e["count"], (sc["name"], pos, e)
+
+
+def test_anchor_adjusted_counts():
+    g = load("region_state.json")["anchor_adjusted"]
+    st = orc.State(1, 10)
+    for anchor, v in g["matrix"].items():
+        st.set_count(2, _abi.ALLELE_A, _abi.DIR_FORWARD, int(anchor), v)
+    for c in g["cases"]:
+        got = st.get_allele_count(2, _abi.ALLELE_A, _abi.DIR_FORWARD, c["min"], -1 if c["max"] is None else c["max"],
+                                  c["from_end"], c["symmetric"])
+        assert got == c["expect"], c
+
+
+def test_anchor_bins_of_a_read():
+    """GetAnchorType (RegionStateManager.cs:83-116): left side 0..4, well anchored 5, right side 6..10,
+    ties go right."""
+    st = orc.State(100, 40)
+    st.add_allele_counts(orc.make_read(100, "A" * 12))
+    c = st.counts()
+    bins = [int(np.argmax(c[i, _abi.ALLELE_A, 0])) for i in range(12)]
+    assert bins == [0, 1, 2, 3, 4, 5, 5, 6, 7, 8, 9, 10]
+    st = orc.State(100, 40)
+    st.add_allele_counts(orc.make_read(100, "A" * 5))
+    c = st.counts()
+    assert [int(np.argmax(c[i, _abi.ALLELE_A, 0])) for i in range(5)] == [0, 1, 8, 9, 10]
+
+
+# ---------------------------------------------------------------- coverage + filters
+def test_coverage_point_happy_path():
+    g = load("coverage.json")["point"]
+    st = orc.State(1, 10)
+    for row in g["counts"]:
+        for d, v in enumerate(row["by_dir"]):
+            st.set_count(g["variant"]["pos"], ALLELE[row["allele"]], d, 5, v)
+    v = g["variant"]
+    cand = orc.make_candidate(v["pos"], _abi.CAT_SNV, v["ref"], v["alt"], support=(v["support"], 0, 0))
+    called = orc.OrcCalled()
+    orc.lib.orc_called_from_candidate(C.byref(called), C.byref(cand))
+    orc.lib.orc_coverage_compute(C.byref(called), st.h, 1, 0)
+    assert list(called.coverage_by_dir) == g["expect_cov_by_dir"]
+    assert called.total_coverage == g["expect_total"]
+    assert called.reference_support == g["expect_ref_support"]
+
+
+def test_fraction_no_calls():
+    g = load("filters.json")
+    cfg = _abi.default_config()
+    rows = g["fraction_no_calls"] + [dict(total_coverage=g["happy_path"]["total_coverage"],
+                                          num_no_calls=g["happy_path"]["num_no_calls"],
+                                          expect=g["happy_path"]["expect_fraction"])]
+    for row in rows:
+        st = orc.State(1, 4)
+        st.set_count(1, _abi.ALLELE_T, 0, 5, row["total_coverage"])  # coverage lands on T, no-calls on N
+        st.set_count(1, _abi.ALLELE_N, 0, 5, row["num_no_calls"])
+        cand = orc.make_candidate(1, _abi.CAT_SNV, "A", "T", support=(min(10, row["total_coverage"]), 0, 0))
+        called = orc.OrcCalled()
+        orc.lib.orc_called_from_candidate(C.byref(called), C.byref(cand))
+        orc.lib.orc_process_variant(C.byref(called), st.h, C.byref(cfg))
+        assert called.fraction_no_calls == np.float32(row["expect"])
+
+
+# ---------------------------------------------------------------- candidate finder
+def test_finder_snv_basics_and_open_ends():
+    ref = "ACGTACGTACGTACGTACGT"
+    rd = orc.make_read(3, "GTACGAAC")  # ref[2:10] = GTACGTAC -> T>A at pos 8, fully anchored
+    c = orc.find_candidates(rd, ref)
+    assert [(x.position, x.ref, x.alt, x.category) for x in c] == [(8, b"T", b"A", _abi.CAT_SNV)]
+    assert (c[0].open_left, c[0].open_right) == (0, 0)
+    assert list(c[0].support_by_dir) == [1, 0, 0] and list(c[0].well_anchored_by_dir) == [1, 0, 0]
+    # mismatch on the first / last aligned base is open ended (Annotate, CandidateVariantFinder.cs:514-541)
+    rd = orc.make_read(3, "TTACGTAG")
+    c = orc.find_candidates(rd, ref)
+    assert [(x.position, x.open_left, x.open_right) for x in c] == [(3, 1, 0), (10, 0, 1)]
+    assert list(c[0].well_anchored_by_dir) == [0, 0, 0]
+    # a mismatch before a low-quality base is open on the right (:110-118); a low-quality mismatch is no candidate
+    rd = orc.make_read(3, "GTACGAAC", quals=[30, 30, 30, 30, 30, 30, 10, 30])
+    c = orc.find_candidates(rd, ref)
+    assert [(x.position, x.open_left, x.open_right) for x in c] == [(8, 0, 1)]
+    rd = orc.make_read(3, "GTACGAAC", quals=[30, 30, 30, 30, 30, 10, 30, 30])
+    assert orc.find_candidates(rd, ref) == []
+
+
+def test_finder_indels():
+    ref = "ACGTACGTACGTACGTACGT"
+    rd = orc.make_read(3, "GTACCCGTAC", cigar="4M2I4M")
+    c = orc.find_candidates(rd, ref)
+    assert [(x.position, x.ref, x.alt, x.category) for x in c] == [(6, b"C", b"CCC", _abi.CAT_INSERTION)]
+    rd = orc.make_read(3, "GTACAC", cigar="4M2D2M")  # deletes GT at 7,8
+    c = orc.find_candidates(rd, ref)
+    assert [(x.position, x.ref, x.alt, x.category) for x in c] == [(6, b"CGT", b"C", _abi.CAT_DELETION)]
+
+
+def test_mnv_build_up():
+    ref = "ACGTACGTACGTACGTACGT"
+    rd = orc.make_read(3, "GTTGGTAC")  # AC->TG at 5,6
+    c = orc.find_candidates(rd, ref, call_mnvs=True, max_mnv=3, max_gap=1)
+    assert [(x.position, x.ref, x.alt, x.category) for x in c] == [(5, b"AC", b"TG", _abi.CAT_MNV)]
+    c = orc.find_candidates(rd, ref, call_mnvs=False)
+    assert [(x.position, x.ref, x.alt) for x in c] == [(5, b"A", b"T"), (6, b"C", b"G")]
+
+
+# ---------------------------------------------------------------- caller flow
+def test_call_all_simple_snv_gvcf():
+    """Depth-100 pileup with a 20 % SNV: reference rows everywhere, the SNV replaces the reference row at its
+    locus (AlleleCaller.cs:146-147), genotypes 0/0 and 0/1."""
+    ref = "ACGTACGTACGTACGTACGTACGTACGTAC"
+    st = orc.State(1, 30)
+    cfg = _abi.default_config()
+    for i in range(100):
+        seq = list(ref[4:24])
+        if i < 20:
+            seq[8] = "G" if ref[12] != "G" else "T"  # position 13
+        rd = orc.make_read(5, "".join(seq), reverse=(i % 2 == 1))
+        for c in orc.find_candidates(rd, ref):
+            st.add_candidate(c)
+        st.add_allele_counts(rd)
+    out = st.call_all(ref, cfg)
+    assert len(out) == 20
+    assert list(out["position"]) == list(range(5, 25))
+    row = out[out["position"] == 13][0]
+    assert _abi.info_category(row["info"]) == _abi.CAT_SNV
+    assert row["allele_support"] == 20 and row["total_coverage"] == 100 and row["reference_support"] == 80
+    assert row["variant_qscore"] == 100 and _abi.info_genotype(row["info"]) == _abi.GT_HET_ALT_REF
+    assert row["filter_bits"] == 0
+    others = out[out["position"] != 13]
+    assert (others["total_coverage"] == 100).all() and (others["allele_support"] == 100).all()
+    assert all(_abi.info_genotype(i) == _abi.GT_HOM_REF for i in others["info"])
+    # GQ of a 0/0 call: PtoQ(QtoP(100) + Poisson.Cdf(0, 0.01*100)) = -10 log10(e^-1) = 4.34 -> 4
+    assert (others["genotype_qscore"] == 4).all()
