@@ -212,6 +212,12 @@ int32_t pisces_hip_abi_version(void);
  * bases[i] is position i+1. Copied to the device. */
 int32_t pisces_hip_set_reference(PiscesHip* h, const uint8_t* upper_bases, int64_t length);
 
+/* ChrIntervalSet after SortAndCollapse (src/lib/Pisces.Domain/Models/IntervalSet.cs:38-74): sorted,
+ * disjoint, inclusive [start, end].  With intervals, calls are made only inside them
+ * (AlleleCaller.ShouldReport, AlleleCaller.cs:260-263; RegionState.GetAllCandidates clips the
+ * reference candidates, RegionState.cs:406-408); set emit_zero_coverage_refs = 1 alongside. n = 0 clears. */
+int32_t pisces_hip_set_intervals(PiscesHip* h, const int32_t* starts, const int32_t* ends, int32_t n);
+
 /* ---- streaming surface: IStateManager -------------------------------------- */
 /* ICandidateVariantFinder.FindCandidates + IStateManager.AddCandidates + AddAlleleCounts
  * (SmallVariantCaller.cs:88-98) for a batch of reads: expands reads to observation tuples,

@@ -1,0 +1,66 @@
+"""ctypes binding of libpisceship.so — the same entry points a C# [DllImport] shim binds
+(INTEGRATION.md).  There is no CPU fallback: if the HIP library is missing or fails to load,
+importing this module raises."""
+import ctypes as C
+import os
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpisceship.so")
+
+EXPORTS = [
+    "pisces_hip_abi_version", "pisces_hip_default_config", "pisces_hip_create", "pisces_hip_destroy",
+    "pisces_hip_last_error", "pisces_hip_set_reference", "pisces_hip_set_intervals", "pisces_hip_add_reads",
+    "pisces_hip_add_observations", "pisces_hip_flush", "pisces_hip_get_counts", "pisces_hip_add_gapped_mnv_ref",
+    "pisces_hip_get_candidates", "pisces_hip_stats", "pisces_hip_call_tiles", "pisces_hip_accumulate_tiles",
+    "pisces_hip_synchronize", "pisces_hip_last_kernel_ms", "pisces_hip_expand_reads",
+]
+
+
+class PiscesHipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libpisceship error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (needs hipcc). pisces_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    i32, i64, vp = C.c_int32, C.c_int64, C.c_void_p
+    P = C.POINTER
+    sig = {
+        "pisces_hip_abi_version": (i32, []),
+        "pisces_hip_default_config": (i32, [P(_abi.PiscesHipConfig)]),
+        "pisces_hip_create": (i32, [P(_abi.PiscesHipConfig), i32, P(vp)]),
+        "pisces_hip_destroy": (i32, [vp]),
+        "pisces_hip_last_error": (C.c_char_p, [vp]),
+        "pisces_hip_set_reference": (i32, [vp, vp, i64]),
+        "pisces_hip_set_intervals": (i32, [vp, vp, vp, i32]),
+        "pisces_hip_add_reads": (i32, [vp, P(_abi.PiscesReadBatch)]),
+        "pisces_hip_add_observations": (i32, [vp, vp, vp, i64]),
+        "pisces_hip_flush": (i32, [vp, i32, vp, i64, P(i64)]),
+        "pisces_hip_get_counts": (i32, [vp, i32, i32, vp]),
+        "pisces_hip_add_gapped_mnv_ref": (i32, [vp, vp, vp, i32]),
+        "pisces_hip_get_candidates": (i32, [vp, i32, vp, i64, P(i64), vp, i64, P(i64)]),
+        "pisces_hip_stats": (i32, [vp, P(i64)]),
+        "pisces_hip_call_tiles": (i32, [vp, vp, vp, i32, vp, i32, i64, vp, i32, vp, vp, vp]),
+        "pisces_hip_accumulate_tiles": (i32, [vp, vp, vp, i32, vp, vp]),
+        "pisces_hip_synchronize": (i32, [vp]),
+        "pisces_hip_last_kernel_ms": (i32, [vp, P(C.c_float)]),
+        "pisces_hip_expand_reads": (i64, [P(_abi.PiscesReadBatch), i32, vp, vp, i64]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(lib, name)   # AttributeError here = a declared symbol is not exported
+        f.restype = res
+        f.argtypes = args
+    if lib.pisces_hip_abi_version() != _abi.ABI_VERSION:
+        raise ImportError("libpisceship.so ABI version does not match pisces_amd._abi")
+    return lib
+
+
+lib = _load()

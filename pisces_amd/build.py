@@ -1,0 +1,47 @@
+"""Builds libpisceship.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off: the call phase restates C#
+double/float arithmetic that never fuses multiply-add (see csrc/device_math.hip.h).
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libpisceship.so")
+SOURCES = ["pisces_hip.hip", "expander.cpp"]
+HEADERS = ["kernels.hip.h", "device_math.hip.h", "expander.h", os.path.join("..", "..", "include", "pisces_hip.h")]
+
+
+def hipcc_path():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm: /opt/rocm/bin/hipcc)")
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build_native(force=False, verbose=False, extra_flags=()):
+    if not force and not is_stale():
+        return LIB
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           "-fno-fast-math", "-Wall", "-Wno-unused-function", "-x", "hip",
+           *extra_flags, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    import sys
+    build_native(force="--force" in sys.argv, verbose=True)
+    print(LIB)

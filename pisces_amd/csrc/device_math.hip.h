@@ -1,0 +1,348 @@
+// device_math.hip.h — FP64/FP32 device functions of the call phase for gfx950.
+//
+// These are the per-allele calculators of the Pisces path, written for one lane per
+// allele: data-dependent trip counts, no LDS, no cross-lane traffic.  Arithmetic order and
+// types follow the reference so that integer outputs are bit-exact and q-scores land on
+// the same integer (compile with -ffp-contract=off; ocml exp/log/pow are within an ulp or
+// two of the CLR's, which only matters within 1e-13 of a rounding boundary).
+// Citations: paths relative to /root/reference/src.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pisces_hip.h"
+
+namespace pisces {
+
+// Constants the host evaluates once per handle (so host and device agree on them bit for bit).
+struct DeviceParams {
+    int32_t min_bq, noise_level, max_vq, min_vq, vq_filter, min_cov, low_depth_filter;
+    int32_t min_gq, max_gq, low_gq_filter, sb_model, filter_single_strand, include_ref, emit_zero_cov;
+    int32_t rmxn_max_len, rmxn_min_rep;
+    float min_freq, vf_filter, gt_min_freq, target_lod, nocall_thr, rmxn_freq_limit;
+    double sb_threshold;  // (double)StrandBiasFilterThreshold
+    double err_q;         // MathOperations.QtoP(NL)                       stats/MathOperations.cs:7
+    double err_sb;        // Math.Pow(10, -1*NL/10f) (float exponent)      StrandBiasCalculator.cs:32
+    double ln10;          // Math.Log(10.0)
+};
+
+// ------------------------------------------------------------------------------------------
+// lib/Pisces.Calculators/stats/Poisson.cs — in-repo regularized incomplete gamma
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double lanczos_approximation(double p)  // Poisson.cs:106-120
+{
+    double x = p;
+    double tmp = x + 5.5;
+    tmp = tmp - (x + 0.5) * log(tmp);
+    double ser = 1.000000000190015 + 76.18009172947146 / (p + 1.0);
+    ser -= 86.50532032941678 / (p + 2.0);
+    ser += 24.01409824083091 / (p + 3.0);
+    ser -= 1.231739572450155 / (p + 4.0);
+    ser += 0.001208650973866179 / (p + 5.0);
+    ser -= 5.395239384953E-06 / (p + 6.0);
+    return (log(2.506628274631001 * ser / x) - tmp);
+}
+
+__device__ __forceinline__ double stirling_approximation(double n)  // Poisson.cs:125-128
+{
+    return (0.5 * log(2.0 * 3.14159265358979323846) + (0.5 + n) * log(n) - n);
+}
+
+__device__ inline double gamma_continued_fraction(double a, double x, double g)  // Poisson.cs:49-74
+{
+    const double kFpmin = 1.0E-50, kEpsilon = 1.0E-20;
+    double b = x + 1.0 - a;
+    double c = 1.0 / kFpmin;
+    double d = 1.0 / b;
+    double h = d;
+    int i;
+    for (i = 1; i <= 300; i++) {
+        double an = i * (a - i);
+        b += 2.0;
+        d = an * d + b;
+        if (fabs(d) < kFpmin) d = kFpmin;
+        c = b + an / c;
+        if (fabs(c) < kFpmin) c = kFpmin;
+        d = 1.0 / d;
+        double del = d * c;
+        h *= del;
+        if (fabs(del - 1.0) < kEpsilon) break;
+    }
+    if (i > 300) return -1.0;
+    return exp(a * log(x) - x - g) * h;
+}
+
+__device__ inline double gamma_series(double a, double x, double g)  // Poisson.cs:76-101
+{
+    const double kEpsilon = 1.0E-20;
+    double retval = -1.0;
+    if (x == 0.0) return 0.0;
+    if (x < 0.0) return retval;
+    double ap = a;
+    double sum = 1.0 / a;
+    double del = sum;
+    for (int i = 1; i <= 300; i++) {
+        ap += 1.0;
+        del *= x / ap;
+        sum += del;
+        if (fabs(del) < fabs(sum) * kEpsilon) {
+            retval = sum * exp(a * log(x) - x - g);
+            break;
+        }
+    }
+    return retval;
+}
+
+__device__ inline double incomplete_gamma_function(double a, double x)  // Poisson.cs:34-44
+{
+    if ((x < 0) || (a <= 0)) return -1.0;
+    double g = (a >= 700.0 ? stirling_approximation(a) : lanczos_approximation(a));
+    if (x >= a + 1.0) return gamma_continued_fraction(a, x, g);
+    if ((g = gamma_series(a, x, g)) < 0) return g;
+    return 1.0 - g;
+}
+
+__device__ __forceinline__ double poisson_cdf(double num_occurrences, double expected)  // Poisson.cs:26-29
+{
+    return incomplete_gamma_function((double)(int)(num_occurrences + 1.0), expected);
+}
+
+__device__ __forceinline__ double q_to_p(double q) { return pow(10.0, -1 * q / 10.0); }  // MathOperations.cs:7
+__device__ __forceinline__ double p_to_q(double p) { return (-10 * log10(p)); }          // MathOperations.cs:12
+
+// ------------------------------------------------------------------------------------------
+// MathNet.Numerics 4.5.1 (NuGet dependency of Pisces.Calculators): GammaLn (Lanczos g=10.900511),
+// GammaLowerRegularized (Cephes igam/igamc), Poisson CDF / ln PMF — the algorithm behind
+// VariantQualityCalculator.cs:36,38,47.
+// ------------------------------------------------------------------------------------------
+__device__ inline double mathnet_gamma_ln(double z)
+{
+    const double dk[11] = {2.48574089138753565546e-5,  1.05142378581721974210,    -3.45687097222016235469,
+                           4.51227709466894823700,     -2.98285225323576655721,   1.05639711577126713077,
+                           -1.95428773191645869583e-1, 1.70970543404441224307e-2, -5.71926117404305781283e-4,
+                           4.63399473359905636708e-6,  -2.71994908488607703910e-9};
+    const double r = 10.900511;
+    const double log_two_sqrt_e_over_pi = 0.6207822376352452223455184457816472122518527279025978;
+    const double e = 2.7182818284590452354;
+    // arguments here are call counts >= 1, so only the z >= 0.5 branch is reachable
+    double s = dk[0];
+#pragma unroll
+    for (int i = 1; i <= 10; i++) s += dk[i] / (z + i - 1.0);
+    return log(s) + log_two_sqrt_e_over_pi + ((z - 0.5) * log((z - 0.5 + r) / e));
+}
+
+__device__ inline double mathnet_factorial_ln(int x)
+{
+    if (x <= 1) return 0.0;
+    if (x < 171) {
+        // SpecialFunctions' factorial cache: c[i] = c[i-1] * i in double, then Math.Log
+        double c = 1.0;
+        for (int i = 2; i <= x; i++) c = c * i;
+        return log(c);
+    }
+    return mathnet_gamma_ln(x + 1.0);
+}
+
+__device__ inline double mathnet_gamma_lower_regularized(double a, double x)
+{
+    const double epsilon = 0.000000000000001;
+    const double big = 4503599627370496.0;
+    const double bigInv = 2.22044604925031308085e-16;
+    if (fabs(a) < 1e-15) return (fabs(x) < 1e-15) ? __builtin_nan("") : 1.0;
+    if (fabs(x) < 1e-15) return 0.0;
+
+    double ax = (a * log(x)) - x - mathnet_gamma_ln(a);
+    if (ax < -709.78271289338399) return a < x ? 1.0 : 0.0;
+
+    if (x <= 1 || x <= a) {
+        double r2 = a, c2 = 1, ans2 = 1;
+        do {
+            r2 = r2 + 1;
+            c2 = c2 * x / r2;
+            ans2 += c2;
+        } while ((c2 / ans2) > epsilon);
+        return exp(ax) * ans2 / a;
+    }
+
+    int c = 0;
+    double y = 1 - a;
+    double z = x + y + 1;
+    double p3 = 1, q3 = x, p2 = x + 1, q2 = z * x;
+    double ans = p2 / q2;
+    double error;
+    do {
+        c++;
+        y += 1;
+        z += 2;
+        double yc = y * c;
+        double p = (p2 * z) - (p3 * yc);
+        double q = (q2 * z) - (q3 * yc);
+        if (q != 0) {
+            double nextans = p / q;
+            error = fabs((ans - nextans) / nextans);
+            ans = nextans;
+        } else {
+            error = 1;
+        }
+        p3 = p2; p2 = p; q3 = q2; q2 = q;
+        if (fabs(p) > big) {
+            p3 *= bigInv; p2 *= bigInv; q3 *= bigInv; q2 *= bigInv;
+        }
+    } while (error > epsilon);
+    return 1.0 - (exp(ax) * ans);
+}
+
+// ------------------------------------------------------------------------------------------
+// lib/Pisces.Calculators/VariantQualityCalculator.cs:27-65
+// ------------------------------------------------------------------------------------------
+__device__ inline int32_t poisson_qscore(int32_t callCount, int32_t coverage, const DeviceParams& P)
+{
+    if ((callCount <= 0) || (coverage <= 0)) return 0;
+    double callCountMinusOne = callCount - 1;
+    double callCountDouble = callCount;
+    double lambda = P.err_q * coverage;
+    // Poisson.CumulativeDistribution(k-1) = 1 - GammaLowerRegularized(k, lambda)
+    double pValue = 1 - (1.0 - mathnet_gamma_lower_regularized(callCountMinusOne + 1, lambda));
+    double rawQ;
+    if (pValue > 0) {
+        rawQ = p_to_q(pValue);
+    } else {
+        int k = (int)callCountMinusOne;
+        double A = -lambda + (k * log(lambda)) - mathnet_factorial_ln(k);  // Poisson.ProbabilityLn
+        double correction = (callCountDouble - lambda) / callCountDouble;
+        rawQ = -10.0 * (A - log(2.0 * correction)) / P.ln10;
+    }
+    double qScore = fmin((double)P.max_vq, rawQ);
+    qScore = fmax(qScore, 0.0);
+    return (int32_t)rint(qScore);  // Math.Round: ties to even
+}
+
+// ------------------------------------------------------------------------------------------
+// lib/Pisces.Calculators/StrandBiasCalculator.cs:21-231 (Poisson and Extended models)
+// ------------------------------------------------------------------------------------------
+struct SbStats { double var_gt_zero, false_pos, coverage, support; };
+
+__device__ inline SbStats sb_create_stats(double support, double coverage, double noiseFreq, int model)
+{
+    // CreateStats :137-148 — minDetectableSNP = noiseFreq for every non-Diploid model;
+    // ChanceFalseNeg (:213) does not enter the bias score and is not part of the record.
+    SbStats st;
+    st.support = support;
+    st.coverage = coverage;
+    if (support == 0) {
+        if (model == PISCES_SB_POISSON) {
+            st.false_pos = 1;
+            st.var_gt_zero = 0;
+        } else {
+            st.var_gt_zero = pow(1 - noiseFreq, coverage);
+            st.false_pos = 1 - st.var_gt_zero;
+        }
+    } else {
+        st.var_gt_zero = fmax(0.0, poisson_cdf(support - 1, coverage * noiseFreq));
+        st.false_pos = fmax(0.0, 1 - st.var_gt_zero);
+    }
+    return st;
+}
+
+struct SbResult { double bias_score; int acceptable, var_both, cov_both; };
+
+__device__ inline SbResult strand_bias(const int32_t cov[3], const int32_t sup[3], const DeviceParams& P)
+{
+    double errorRate = P.err_sb;
+    SbStats overall = sb_create_stats(sup[0] + sup[1] + sup[2], cov[0] + cov[1] + cov[2], errorRate, P.sb_model);
+    SbStats fwd = sb_create_stats(sup[0] + sup[2] / 2, cov[0] + cov[2] / 2, errorRate, P.sb_model);
+    SbStats rev = sb_create_stats(sup[1] + sup[2] / 2, cov[1] + cov[2] / 2, errorRate, P.sb_model);
+    // StitchedStats (:55-56) feed only the optional strand-bias report file, not the score.
+    double forwardBias = (fwd.var_gt_zero * rev.false_pos) / overall.var_gt_zero;
+    double reverseBias = (rev.var_gt_zero * fwd.false_pos) / overall.var_gt_zero;
+    if (overall.var_gt_zero == 0) {
+        forwardBias = 1;
+        reverseBias = 1;
+    }
+    SbResult r;
+    r.bias_score = forwardBias > reverseBias ? forwardBias : reverseBias;
+    r.cov_both = (fwd.coverage > 0) && (rev.coverage > 0);
+    r.var_both = (fwd.support > 0) && (rev.support > 0);
+    if (!r.cov_both) r.bias_score = 0;
+    r.acceptable = r.bias_score < P.sb_threshold;
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// CalledAllele.Frequency (CalledAllele.cs:49-52) and lib/Pisces.Genotyping/Somatic
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float frequency_f(int32_t support, int32_t coverage)
+{
+    if (coverage == 0) return 0.0f;
+    float f = (float)support / (float)coverage;
+    return f < 1.0f ? f : 1.0f;
+}
+
+__device__ inline int32_t somatic_genotype(bool isReference, int32_t cov, int32_t support, int32_t refSupport,
+                                           const DeviceParams& P)  // SomaticGenotyper.cs:65-100
+{
+    if (cov < P.min_cov) return isReference ? PISCES_GT_REF_LIKE_NOCALL : PISCES_GT_ALT_LIKE_NOCALL;
+    float freq = frequency_f(support, cov);
+    if (!isReference) {
+        if (frequency_f(refSupport, cov) < P.gt_min_freq) {
+            if ((1 - freq) > P.gt_min_freq) return PISCES_GT_ALT_AND_NOCALL;
+            return PISCES_GT_HOM_ALT;
+        }
+        return PISCES_GT_HET_ALT_REF;
+    }
+    if (freq < P.gt_min_freq) return PISCES_GT_REF_LIKE_NOCALL;
+    if ((1 - freq) > P.gt_min_freq) return PISCES_GT_REF_AND_NOCALL;
+    return PISCES_GT_HOM_REF;
+}
+
+__device__ inline int32_t somatic_gq(int32_t genotype, int32_t variantQ, int32_t cov, int32_t support,
+                                     const DeviceParams& P)  // SomaticGenotypeQualityCalculator.cs:10-48
+{
+    double rawQ = variantQ;
+    bool noCall = (genotype == PISCES_GT_ALT12_LIKE_NOCALL || genotype == PISCES_GT_ALT_LIKE_NOCALL ||
+                   genotype == PISCES_GT_REF_LIKE_NOCALL);
+    if ((cov == 0) || noCall) return P.min_gq;
+    if ((genotype == PISCES_GT_HOM_REF) || (genotype == PISCES_GT_HOM_ALT)) {
+        double p1 = q_to_p(variantQ);
+        float nonAlleleObservationsF = (1.0f - frequency_f(support, cov)) * (float)cov;
+        float expectedNonAllelObservationsF = P.target_lod * (float)cov;
+        if (nonAlleleObservationsF >= expectedNonAllelObservationsF) return P.min_gq;
+        double p2 = poisson_cdf(nonAlleleObservationsF, expectedNonAllelObservationsF);
+        rawQ = p_to_q(p1 + p2);
+    }
+    double qScore = fmin((double)P.max_gq, rawQ);
+    qScore = fmax(qScore, (double)P.min_gq);
+    return (int32_t)rint(qScore);
+}
+
+// ------------------------------------------------------------------------------------------
+// RMxNCalculator (lib/Pisces.Calculators/RMxNCalculator.cs:19-131) for a single-base SNV: every
+// prefix/suffix "bookend" of a one-base string is that base, so each component is the length of
+// the homopolymer run found by ratcheting back from `start` and reading forward.
+// ref[i] is position ref_start_position + i (so string index s <-> i = s + 1 - ref_start_position).
+// ------------------------------------------------------------------------------------------
+__device__ inline int rmxn_run(const uint8_t* ref, int64_t lo, int64_t hi, int64_t start, uint8_t base)
+{
+    // indices are 0-based string indices of the chromosome clipped to the resident window [lo, hi)
+    int64_t back = start;
+    while (back - 1 >= lo && ref[back - 1 - lo] == base) back--;   // ComputeRMxNLengthForIndel :66-76
+    int n = 0;
+    int64_t cur = back;
+    while (cur < hi && ref[cur - lo] == base) { n++; cur++; }      // :79-89
+    return n;
+}
+
+__device__ inline bool rmxn_should_filter_snv(const uint8_t* ref, int64_t win_lo, int64_t win_hi, int32_t position,
+                                              uint8_t refBase, uint8_t altBase, float freq, const DeviceParams& P)
+{
+    if (P.rmxn_max_len < 1) return false;   // a one-base unit needs maxRepeatUnitLength >= 1
+    if (freq >= P.rmxn_freq_limit) return false;
+    // string index of `position` is position-1
+    int c1 = rmxn_run(ref, win_lo, win_hi, (int64_t)position - 1, refBase);
+    int i1 = rmxn_run(ref, win_lo, win_hi, (int64_t)position, altBase);      // ReferencePosition + refLen - 1
+    int i2 = rmxn_run(ref, win_lo, win_hi, (int64_t)position - 1, altBase);
+    int c2 = i1 > i2 ? i1 : i2;
+    return (c1 < c2 ? c1 : c2) >= P.rmxn_min_rep;
+}
+
+}  // namespace pisces

@@ -1,0 +1,392 @@
+// kernels.hip.h — gfx950 kernels of the pileup-and-likelihood path.
+//
+//   call_tiles_kernel        observation tuples -> LDS allele-count histogram (per 64-locus tile)
+//                            -> coverage / Poisson q-score / strand bias / somatic genotype / filters
+//                            for the Reference allele and every SNV candidate -> 64-byte records.
+//                            Counts never leave LDS.  HBM traffic = 4 B/tuple + 1 B/locus + 64 B/record.
+//   accumulate_tiles_kernel  tuples -> anchor-resolved int32[6][3][11] counts added to a global tensor
+//                            (the IAlleleSource view: RegionState._alleleCounts, RegionState.cs:57).
+//   call_counts_kernel       the same call phase fed from that global tensor (streaming surface after
+//                            the host collapser has looked at the counts).
+//
+// One workgroup (256 threads = 4 wave64) per tile; grid = number of tiles (>> 256 CUs for any real
+// interval set).  No MFMA: this is a scan + histogram + transcendental epilogue, HBM-bound.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.hip.h"
+
+namespace pisces {
+
+constexpr int kBlock = 256;
+constexpr int kTile = 64;                 // loci per tile: kTile * 4 allele lanes = one workgroup pass
+constexpr int kFolded = 18;               // 6 allele types x 3 directions (anchors folded)
+constexpr int kUnroll = 4;                // 16-byte loads in flight per lane
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // one dwordx4 load
+
+// alphabetical allele order A, C, G, T (the per-locus output order, AlleleCaller.cs:172-176)
+// expressed in AlleleType codes A=0, G=1, C=2, T=3
+__device__ __forceinline__ int allele_of_rank(int k) { return k == 1 ? 2 : (k == 2 ? 1 : k); }
+
+__device__ __forceinline__ int allele_type_of_base(uint8_t c)  // AlleleHelper.GetAlleleType, AlleleHelper.cs:13-32
+{
+    return c == 'A' ? 0 : c == 'G' ? 1 : c == 'C' ? 2 : c == 'T' ? 3 : 4;
+}
+
+// One observation into the folded LDS histogram hist[(allele*3+dir)*kTile + locus].
+// "qual < minBQ -> N" is RegionStateManager.cs:179-181; deletion tuples carry qual 255.
+// Padding tuples (0xFFFFFFFF) decode to allele 7 and fall out of the range test.
+__device__ __forceinline__ void accumulate_folded(int* hist, uint32_t t, uint32_t n_loci, uint32_t min_bq)
+{
+    uint32_t locus = t & 0x7FFFu;
+    uint32_t dir = (t >> 19) & 3u;
+    uint32_t allele = (t >> 21) & 7u;
+    uint32_t qual = t >> 24;
+    if (allele < 4u && qual < min_bq) allele = 4u;
+    if (locus < n_loci && dir < 3u && allele < 6u) atomicAdd(&hist[(allele * 3u + dir) * kTile + locus], 1);
+}
+
+// Streams tuples[begin, end) through `op(tuple)`: scalar head/tail up to 16-byte alignment, then
+// kUnroll independent dwordx4 loads per lane per iteration (1 KiB per wave-instruction, coalesced).
+template <typename Op>
+__device__ __forceinline__ void stream_tuples(const uint32_t* __restrict__ tuples, int64_t begin, int64_t end, Op op)
+{
+    const int tid = threadIdx.x;
+    int64_t abegin = (begin + 3) & ~(int64_t)3;
+    int64_t aend = end & ~(int64_t)3;
+    if (abegin > aend) { abegin = end; aend = end; }
+    for (int64_t i = begin + tid; i < abegin; i += kBlock) op(tuples[i]);
+    const u32x4* __restrict__ p4 = reinterpret_cast<const u32x4*>(tuples + abegin);
+    const int64_t n4 = (aend - abegin) >> 2;
+    for (int64_t i = tid; i < n4; i += (int64_t)kBlock * kUnroll) {
+        u32x4 v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            int64_t j = i + (int64_t)u * kBlock;
+            // streamed exactly once: non-temporal so the tuples do not evict the reference / records from L2
+            v[u] = j < n4 ? __builtin_nontemporal_load(&p4[j]) : (u32x4){~0u, ~0u, ~0u, ~0u};
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            op(v[u].x); op(v[u].y); op(v[u].z); op(v[u].w);
+        }
+    }
+    for (int64_t i = aend + tid; i < end; i += kBlock) op(tuples[i]);
+}
+
+// exclusive prefix sum of a per-thread 0/1 flag over the 256-thread block (wave ballot + 4 wave totals)
+__device__ __forceinline__ int block_exclusive_count(bool flag, int* wave_tot /* LDS[4] */, int* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long m = __ballot(flag);
+    int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = __popcll(m);
+    __syncthreads();
+    int off = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) off += (w < wave) ? wave_tot[w] : 0;
+    *total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    __syncthreads();
+    return off + before;
+}
+
+struct AlleleOut {
+    PiscesCalledAllele rec;
+    bool callable;
+};
+
+// AlleleCaller.ProcessVariant (AlleleCaller.cs:208-234) + AlleleProcessor.ApplyFilters
+// (AlleleProcessor.cs:25-71) + IsCallable (:236-258) + SomaticGenotyper (speculatively: genotype and
+// GQ of an allele depend only on its own numbers) for a point allele whose counts are h[6][3].
+__device__ inline AlleleOut process_point_allele(const int h[6][3], int position, int allele, bool isRef, int refType,
+                                                 int gappedMnvRef, const uint8_t* __restrict__ ref, int64_t win_lo,
+                                                 int64_t win_hi, const DeviceParams& P)
+{
+    AlleleOut o;
+    PiscesCalledAllele& r = o.rec;
+    // CoverageCalculator.CalculateSinglePoint (CoverageCalculator.cs:49-98)
+    int cov[3], sup[3];
+    int total = 0, nocalls = 0, refsup = 0;
+    const int supAllele = isRef ? refType : allele;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        cov[d] = h[PISCES_ALLELE_A][d] + h[PISCES_ALLELE_C][d] + h[PISCES_ALLELE_G][d] + h[PISCES_ALLELE_T][d] +
+                 h[PISCES_ALLELE_DEL][d];
+        total += cov[d];
+        nocalls += h[PISCES_ALLELE_N][d];
+        sup[d] = 0;
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        if (a == refType && a < PISCES_ALLELE_N) refsup += h[a][0] + h[a][1] + h[a][2];
+        if (a == supAllele) { sup[0] = h[a][0]; sup[1] = h[a][1]; sup[2] = h[a][2]; }
+    }
+    int support = sup[0] + sup[1] + sup[2];  // AlleleHelper.Map: AlleleSupport = candidate.Support
+    if (isRef) { support -= gappedMnvRef; if (support < 0) support = 0; }        // :94-97
+    else { refsup -= gappedMnvRef; if (refsup < 0) refsup = 0; }                 // :90-93
+
+    int vq = 0;
+    SbResult sb = {0.0, 0, 0, 0};
+    if (support > 0) {
+        vq = (total == 0) ? 0 : poisson_qscore(support, total, P);   // VariantQualityCalculator.Compute :11-24
+        sb = strand_bias(cov, sup, P);                               // StrandBiasCalculator.Compute :10-15
+    }
+    const float freq = frequency_f(support, total);
+    // SetFractionNoCalls (CalledAllele.cs:107-114)
+    const float allReads = (float)(total + nocalls);
+    const float fractionNoCalls = (allReads == 0.0f) ? 0.0f : ((float)nocalls / allReads);
+
+    uint32_t filters = 0;
+    if (P.low_depth_filter >= 0 && total < P.low_depth_filter) filters |= 1u << PISCES_FILTER_LOW_DEPTH;
+    if (P.vq_filter >= 0 && vq < P.vq_filter && total != 0) filters |= 1u << PISCES_FILTER_LOW_VARIANT_QSCORE;
+    if (!isRef) {
+        if (P.nocall_thr >= 0.0f && fractionNoCalls > P.nocall_thr) filters |= 1u << PISCES_FILTER_NO_CALL;
+        if (!sb.acceptable || (P.filter_single_strand && !sb.var_both)) filters |= 1u << PISCES_FILTER_STRAND_BIAS;
+        const uint8_t bases[4] = {'A', 'G', 'C', 'T'};
+        if (refType < 4 && allele < 4 &&
+            rmxn_should_filter_snv(ref, win_lo, win_hi, position, bases[refType], bases[allele], freq, P))
+            filters |= 1u << PISCES_FILTER_RMXN;
+        if (P.vf_filter >= 0.0f && freq < P.vf_filter) filters |= 1u << PISCES_FILTER_LOW_VARIANT_FREQUENCY;
+    }
+
+    // IsCallable (AlleleCaller.cs:236-258)
+    bool callable = true;
+    if (!isRef) {
+        if (total < P.min_cov && !P.include_ref) callable = false;
+        else if (total != 0 && freq < P.min_freq) callable = false;
+        else if (vq < P.min_vq) callable = false;
+    }
+    o.callable = callable;
+
+    int gt = somatic_genotype(isRef, total, support, refsup, P);
+    int gq = somatic_gq(gt, vq, total, support, P);
+    if (P.low_gq_filter >= 0 && (float)gq < (float)P.low_gq_filter) filters |= 1u << PISCES_FILTER_LOW_GENOTYPE_QUALITY;
+
+    r.position = position;
+    r.total_coverage = total;
+    r.allele_support = support;
+    r.reference_support = refsup;
+    r.num_no_calls = nocalls;
+    r.coverage_by_dir[0] = cov[0]; r.coverage_by_dir[1] = cov[1]; r.coverage_by_dir[2] = cov[2];
+    r.support_by_dir[0] = sup[0]; r.support_by_dir[1] = sup[1]; r.support_by_dir[2] = sup[2];
+    r.variant_qscore = vq;
+    r.strand_bias_score = sb.bias_score;
+    r.genotype_qscore = gq;
+    r.filter_bits = (uint16_t)filters;
+    r.info = PISCES_INFO_PACK(gt, isRef ? PISCES_CAT_REFERENCE : PISCES_CAT_SNV, refType, isRef ? refType : allele,
+                              sb.acceptable, sb.var_both, sb.cov_both);
+    return o;
+}
+
+__device__ __forceinline__ void store_record(PiscesCalledAllele* __restrict__ dst, const PiscesCalledAllele& r)
+{
+    // 64-byte record = 4 x dwordx4
+    const uint4* s = reinterpret_cast<const uint4*>(&r);
+    uint4* d = reinterpret_cast<uint4*>(dst);
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
+}
+
+// The call phase for one tile whose folded counts sit in LDS (hist[(allele*3+dir)*kTile + locus]).
+// lane (locus = tid>>2, rank = tid&3) decides whether (locus, allele-of-rank) is a candidate:
+//   Reference candidate per position  — RegionState.GetAllCandidates, RegionState.cs:414-447
+//   SNV candidate                     — a quality-passing base != reference base, ref and read not N
+//                                       (CandidateVariantFinder.cs:97-160 with callMNVs off; its
+//                                       SupportByDirection equals the allele count by direction)
+// candidates are compacted onto the low threads, processed one lane each, then the per-locus rule
+// "drop the Reference allele when a variant is called" (AlleleCaller.cs:146-147) and the output
+// order (position, then allele) are applied and the records written to HBM.
+__device__ inline void call_phase(const int* hist, const uint32_t* gapped /* LDS[kTile] or nullptr */,
+                                  const PiscesTile& tile, const uint8_t* __restrict__ ref, int32_t ref_start,
+                                  int64_t ref_len, PiscesCalledAllele* __restrict__ records, int32_t capacity,
+                                  int32_t* __restrict__ record_count, PiscesTileResult* __restrict__ tile_result,
+                                  const DeviceParams& P, int* s_wave, uint8_t* s_work, uint8_t* s_callable, int* s_base)
+{
+    const int tid = threadIdx.x;
+    const int locus = tid >> 2, rank = tid & 3;
+    const int allele = allele_of_rank(rank);
+    const int position = tile.start_position + locus;
+    const int64_t ridx = (int64_t)position - ref_start;   // index into the resident reference window
+    const bool in_ref = locus < tile.n_loci && ridx >= 0 && ridx < ref_len;
+    const int refType = in_ref ? allele_type_of_base(ref[ridx]) : PISCES_ALLELE_N;
+
+    bool is_work = false;
+    if (in_ref) {
+        int mine = 0, all = 0;
+#pragma unroll
+        for (int c = 0; c < kFolded; c++) {
+            int v = hist[c * kTile + locus];
+            all += v;
+            if (c / 3 == allele) mine += v;
+        }
+        const bool refLane = (refType < 4) ? (allele == refType) : (rank == 0);
+        if (refLane) is_work = P.include_ref && (P.emit_zero_cov || all > 0);
+        else is_work = (refType < 4) && mine > 0;
+    }
+    int n_work;
+    int slot = block_exclusive_count(is_work, s_wave, &n_work);
+    if (is_work) s_work[slot] = (uint8_t)tid;
+    s_callable[tid] = 0;
+    __syncthreads();
+
+    AlleleOut out;
+    out.callable = false;
+    int item = 0;
+    bool item_is_ref = false;
+    if (tid < n_work) {
+        item = s_work[tid];
+        const int l = item >> 2;
+        const int a = allele_of_rank(item & 3);
+        const int pos = tile.start_position + l;
+        const int rt = allele_type_of_base(ref[(int64_t)pos - ref_start]);
+        item_is_ref = (rt < 4) ? (a == rt) : true;
+        int h[6][3];
+#pragma unroll
+        for (int c = 0; c < kFolded; c++) h[c / 3][c % 3] = hist[c * kTile + l];
+        const int g = gapped ? (int)gapped[l] : 0;
+        out = process_point_allele(h, pos, a, item_is_ref, rt, g, ref, (int64_t)ref_start - 1,
+                                   (int64_t)ref_start - 1 + ref_len, P);
+        if (out.callable) s_callable[item] = item_is_ref ? 1 : 2;
+    }
+    __syncthreads();
+
+    bool survive = false;
+    bool first_of_locus = false;
+    if (tid < n_work && out.callable) {
+        const int q = item & ~3;
+        const bool any_variant = (s_callable[q] | s_callable[q + 1] | s_callable[q + 2] | s_callable[q + 3]) & 2;
+        survive = !(item_is_ref && any_variant);
+        if (survive) {
+            // first surviving allele of this locus (for the candidate-locus count)
+            bool earlier = false;
+            for (int k = 0; k < (item & 3); k++) {
+                uint8_t c = s_callable[q + k];
+                if (c == 2 || (c == 1 && !any_variant)) earlier = true;
+            }
+            first_of_locus = !earlier;
+        }
+    }
+    int n_callable;
+    (void)block_exclusive_count(tid < n_work && out.callable, s_wave, &n_callable);
+    int n_loci_called;
+    (void)block_exclusive_count(first_of_locus, s_wave, &n_loci_called);
+    int n_surv;
+    const int idx = block_exclusive_count(survive, s_wave, &n_surv);
+    if (tid == 0) {
+        int base = n_surv > 0 ? atomicAdd(record_count, n_surv) : 0;
+        *s_base = base;
+        PiscesTileResult tr;
+        tr.record_begin = base;
+        tr.n_records = n_surv;
+        tr.n_candidate_loci = n_loci_called;
+        tr.reserved = n_callable;   // IsCallable == true count (IAlleleCaller.TotalNumCalled)
+        *tile_result = tr;
+    }
+    __syncthreads();
+    if (survive) {
+        const int64_t dst = (int64_t)(*s_base) + idx;
+        if (dst < capacity) store_record(&records[dst], out.rec);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void call_tiles_kernel(
+    const uint32_t* __restrict__ tuples, const PiscesTile* __restrict__ tiles, int32_t n_tiles,
+    const uint8_t* __restrict__ ref, int32_t ref_start, int64_t ref_len, PiscesCalledAllele* __restrict__ records,
+    int32_t capacity, int32_t* __restrict__ record_count, PiscesTileResult* __restrict__ tile_results, DeviceParams P)
+{
+    __shared__ int hist[kFolded * kTile];
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    __shared__ uint8_t s_work[kBlock];
+    __shared__ uint8_t s_callable[kBlock];
+
+    const int t = blockIdx.x;
+    if (t >= n_tiles) return;
+    const PiscesTile tile = tiles[t];
+
+    for (int i = threadIdx.x; i < kFolded * kTile; i += kBlock) hist[i] = 0;
+    __syncthreads();
+
+    const uint32_t n_loci = (uint32_t)tile.n_loci, min_bq = (uint32_t)P.min_bq;
+    stream_tuples(tuples, tile.tuple_begin, tile.tuple_end,
+                  [&](uint32_t v) { accumulate_folded(hist, v, n_loci, min_bq); });
+    __syncthreads();
+
+    call_phase(hist, nullptr, tile, ref, ref_start, ref_len, records, capacity, record_count, &tile_results[t], P,
+               s_wave, s_work, s_callable, &s_base);
+}
+
+// ------------------------------------------------------------------------------------------
+// Anchor-resolved accumulation: LDS [locus][199] (odd stride: consecutive loci hit distinct banks),
+// added into counts[(tile*kTile + locus)][6][3][11] — RegionState._alleleCounts layout.
+constexpr int kAnchStride = PISCES_COUNTS_PER_LOCUS + 1;
+
+__global__ __launch_bounds__(kBlock) void accumulate_tiles_kernel(
+    const uint32_t* __restrict__ tuples, const PiscesTile* __restrict__ tiles, int32_t n_tiles,
+    int32_t* __restrict__ counts, int32_t min_bq_)
+{
+    __shared__ int hist[kTile * kAnchStride];
+    const int t = blockIdx.x;
+    if (t >= n_tiles) return;
+    const PiscesTile tile = tiles[t];
+    for (int i = threadIdx.x; i < kTile * kAnchStride; i += kBlock) hist[i] = 0;
+    __syncthreads();
+    const uint32_t n_loci = (uint32_t)tile.n_loci, min_bq = (uint32_t)min_bq_;
+    stream_tuples(tuples, tile.tuple_begin, tile.tuple_end, [&](uint32_t v) {
+        uint32_t locus = v & 0x7FFFu;
+        uint32_t anchor = (v >> 15) & 0xFu;
+        uint32_t dir = (v >> 19) & 3u;
+        uint32_t allele = (v >> 21) & 7u;
+        uint32_t qual = v >> 24;
+        if (allele < 4u && qual < min_bq) allele = 4u;
+        if (locus < n_loci && dir < 3u && allele < 6u && anchor < (uint32_t)PISCES_NUM_ANCHORS)
+            atomicAdd(&hist[locus * kAnchStride + (allele * 3u + dir) * PISCES_NUM_ANCHORS + anchor], 1);
+    });
+    __syncthreads();
+    int32_t* __restrict__ dst = counts + (int64_t)t * kTile * PISCES_COUNTS_PER_LOCUS;
+    const int n = tile.n_loci * PISCES_COUNTS_PER_LOCUS;
+    for (int g = threadIdx.x; g < n; g += kBlock) {
+        int l = g / PISCES_COUNTS_PER_LOCUS, c = g - l * PISCES_COUNTS_PER_LOCUS;
+        int v = hist[l * kAnchStride + c];
+        if (v) dst[g] += v;
+    }
+}
+
+// Call phase fed from the global anchor-resolved counts (+ gapped-MNV reference counts).
+__global__ __launch_bounds__(kBlock) void call_counts_kernel(
+    const int32_t* __restrict__ counts, const uint32_t* __restrict__ gapped_mnv_ref,
+    const PiscesTile* __restrict__ tiles, int32_t n_tiles, const uint8_t* __restrict__ ref, int32_t ref_start,
+    int64_t ref_len, PiscesCalledAllele* __restrict__ records, int32_t capacity, int32_t* __restrict__ record_count,
+    PiscesTileResult* __restrict__ tile_results, DeviceParams P)
+{
+    __shared__ int hist[kFolded * kTile];
+    __shared__ uint32_t s_gapped[kTile];
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    __shared__ uint8_t s_work[kBlock];
+    __shared__ uint8_t s_callable[kBlock];
+    const int t = blockIdx.x;
+    if (t >= n_tiles) return;
+    const PiscesTile tile = tiles[t];
+    const int32_t* __restrict__ src = counts + (int64_t)t * kTile * PISCES_COUNTS_PER_LOCUS;
+    // fold the 11 anchor bins: one (locus, allele*3+dir) cell per thread-iteration
+    for (int i = threadIdx.x; i < kFolded * kTile; i += kBlock) {
+        int c = i / kTile, l = i - c * kTile;
+        int s = 0;
+        if (l < tile.n_loci) {
+            const int32_t* p = src + (int64_t)l * PISCES_COUNTS_PER_LOCUS + c * PISCES_NUM_ANCHORS;
+#pragma unroll
+            for (int a = 0; a < PISCES_NUM_ANCHORS; a++) s += p[a];
+        }
+        hist[i] = s;
+    }
+    if (threadIdx.x < kTile)
+        s_gapped[threadIdx.x] = (gapped_mnv_ref && threadIdx.x < tile.n_loci) ? gapped_mnv_ref[(int64_t)t * kTile + threadIdx.x] : 0u;
+    __syncthreads();
+    call_phase(hist, s_gapped, tile, ref, ref_start, ref_len, records, capacity, record_count, &tile_results[t], P,
+               s_wave, s_work, s_callable, &s_base);
+}
+
+}  // namespace pisces

@@ -1,0 +1,671 @@
+// pisces_hip.hip — C ABI of libpisceship.so (include/pisces_hip.h): handle, device buffers,
+// kernel launches, and the host mirror of the reference's streaming protocol
+// (IStateManager.AddAlleleCounts / GetCandidatesToProcess / DoneProcessing around IAlleleCaller.Call,
+// src/exe/Pisces/Logic/SmallVariantCaller.cs:79-189).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/pisces_hip.h"
+#include "expander.h"
+#include "kernels.hip.h"
+
+using namespace pisces;
+
+static thread_local std::string g_create_error;
+
+namespace {
+
+struct BlockObs {
+    std::vector<int32_t> pos;
+    std::vector<uint32_t> tup;
+};
+
+template <typename T>
+struct DeviceBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 4 + 64;
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct PiscesHip {
+    PiscesHipConfig cfg;
+    DeviceParams P;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    std::string err;
+
+    DeviceBuf<uint8_t> d_ref;
+    int64_t ref_len = 0;
+
+    // ---- streaming state (RegionStateManager: _regionLookup, _lastUpToBlockKey) ----
+    std::map<int32_t, BlockObs> blocks;   // key = GetBlockKey(position) (RegionStateManager.cs:385-391)
+    int32_t last_block_key_cache = 0;
+    BlockObs* last_block = nullptr;       // "performance improvement to remember last block" (:366)
+    int32_t last_up_to_block_key = 0;
+    std::unordered_map<int32_t, int32_t> gapped_mnv_ref;
+    std::vector<std::pair<int32_t, int32_t>> intervals;   // sorted, disjoint [start, end]
+    int64_t stats[4] = {0, 0, 0, 0};      // called, collapsed, reads, observations
+
+    // cached result of a flush that did not fit the caller's buffer
+    bool pending_valid = false;
+    int32_t pending_up_to = 0;
+    std::vector<PiscesCalledAllele> pending;
+    std::vector<int32_t> pending_keys;
+    int64_t pending_called = 0;
+
+    // device scratch, grow-only
+    DeviceBuf<uint32_t> d_tuples;
+    DeviceBuf<PiscesTile> d_tiles;
+    DeviceBuf<PiscesTileResult> d_tile_results;
+    DeviceBuf<PiscesCalledAllele> d_records;
+    DeviceBuf<int32_t> d_counts;
+    DeviceBuf<uint32_t> d_gapped;
+    DeviceBuf<int32_t> d_count;
+};
+
+#define PISCES_HIP_CHECK(h, expr)                                                              \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                      \
+            return PISCES_E_DEVICE;                                                            \
+        }                                                                                      \
+    } while (0)
+
+static int32_t fail(PiscesHip* h, int32_t code, const std::string& msg)
+{
+    if (h) h->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+static DeviceParams make_params(const PiscesHipConfig& c)
+{
+    DeviceParams P;
+    P.min_bq = c.min_base_call_quality;
+    P.noise_level = c.noise_level;
+    P.max_vq = c.max_variant_qscore;
+    P.min_vq = c.min_variant_qscore;
+    P.vq_filter = c.variant_qscore_filter;
+    P.min_cov = c.min_coverage;
+    P.low_depth_filter = c.low_depth_filter;
+    P.min_gq = c.min_genotype_qscore;
+    P.max_gq = c.max_genotype_qscore;
+    P.low_gq_filter = c.low_gq_filter;
+    P.sb_model = c.strand_bias_model;
+    P.filter_single_strand = c.filter_single_strand;
+    P.include_ref = c.include_reference_calls;
+    P.emit_zero_cov = c.emit_zero_coverage_refs;
+    P.rmxn_max_len = c.rmxn_max_repeat_length;
+    P.rmxn_min_rep = c.rmxn_min_repetitions;
+    P.min_freq = c.min_frequency;
+    P.vf_filter = c.variant_freq_filter;
+    P.gt_min_freq = c.genotype_min_freq_filter;
+    P.target_lod = c.target_lod_frequency;
+    P.nocall_thr = c.no_call_filter_threshold;
+    P.rmxn_freq_limit = c.rmxn_frequency_limit;
+    P.sb_threshold = (double)c.strand_bias_threshold;
+    // MathOperations.QtoP: Math.Pow(10, -1 * q / 10f), q double  (stats/MathOperations.cs:7-10)
+    P.err_q = std::pow(10.0, -1 * (double)c.noise_level / 10.0);
+    // StrandBiasCalculator.cs:32: Math.Pow(10, -1*qNoise/10f), int / float -> float exponent
+    P.err_sb = std::pow(10.0, (double)((float)(-1 * c.noise_level) / 10.0f));
+    P.ln10 = std::log(10.0);
+    return P;
+}
+
+extern "C" {
+
+int32_t pisces_hip_abi_version(void) { return PISCES_HIP_ABI_VERSION; }
+
+int32_t pisces_hip_default_config(PiscesHipConfig* c)
+{
+    if (!c) return PISCES_E_INVALID_ARG;
+    std::memset(c, 0, sizeof(*c));
+    c->abi_version = PISCES_HIP_ABI_VERSION;
+    c->min_base_call_quality = 20;
+    c->noise_level = 20;
+    c->max_variant_qscore = 100;
+    c->min_variant_qscore = 20;
+    c->variant_qscore_filter = 30;
+    c->min_coverage = 10;
+    c->low_depth_filter = 10;
+    c->min_genotype_qscore = 0;
+    c->max_genotype_qscore = 100;
+    c->low_gq_filter = -1;
+    c->strand_bias_model = PISCES_SB_EXTENDED;
+    c->filter_single_strand = 0;
+    c->include_reference_calls = 1;
+    c->emit_zero_coverage_refs = 0;
+    c->expect_stitched_reads = 0;
+    c->tile_loci = kTile;
+    c->block_size = 1000;
+    c->min_frequency = 0.01f;
+    c->variant_freq_filter = 0.01f;
+    c->genotype_min_freq_filter = 0.01f;
+    c->target_lod_frequency = 0.01f;
+    c->strand_bias_threshold = 0.5f;
+    c->no_call_filter_threshold = 0.6f;
+    c->rmxn_max_repeat_length = 5;
+    c->rmxn_min_repetitions = 9;
+    c->rmxn_frequency_limit = 0.35f;
+    return PISCES_OK;
+}
+
+int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip** out)
+{
+    if (!cfg || !out) return fail(nullptr, PISCES_E_INVALID_ARG, "pisces_hip_create: null argument");
+    *out = nullptr;
+    if (cfg->abi_version != PISCES_HIP_ABI_VERSION)
+        return fail(nullptr, PISCES_E_INVALID_ARG, "pisces_hip_create: config abi_version mismatch");
+    if (cfg->tile_loci != 0 && cfg->tile_loci != kTile)
+        return fail(nullptr, PISCES_E_UNSUPPORTED, "pisces_hip_create: tile_loci must be 64 in this build");
+    if (cfg->strand_bias_model == PISCES_SB_DIPLOID)
+        return fail(nullptr, PISCES_E_UNSUPPORTED, "pisces_hip_create: Diploid strand-bias model is not on the device path");
+    if (cfg->block_size <= 0 || cfg->min_base_call_quality < 0 || cfg->min_base_call_quality > 254)
+        return fail(nullptr, PISCES_E_INVALID_ARG, "pisces_hip_create: block_size / min_base_call_quality out of range");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, PISCES_E_DEVICE, std::string("pisces_hip_create: no HIP device: ") + hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(nullptr, PISCES_E_INVALID_ARG, "pisces_hip_create: device index out of range");
+    PiscesHip* h = new PiscesHip();
+    h->cfg = *cfg;
+    h->cfg.tile_loci = kTile;
+    h->P = make_params(h->cfg);
+    h->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess) {
+        g_create_error = std::string("pisces_hip_create: ") + hipGetErrorString(e);
+        delete h;
+        return PISCES_E_DEVICE;
+    }
+    *out = h;
+    return PISCES_OK;
+}
+
+int32_t pisces_hip_destroy(PiscesHip* h)
+{
+    if (!h) return PISCES_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->d_ref.release(); h->d_tuples.release(); h->d_tiles.release(); h->d_tile_results.release();
+    h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release();
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return PISCES_OK;
+}
+
+const char* pisces_hip_last_error(const PiscesHip* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int32_t pisces_hip_set_reference(PiscesHip* h, const uint8_t* bases, int64_t length)
+{
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (!bases || length <= 0) return fail(h, PISCES_E_INVALID_ARG, "set_reference: empty reference");
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    PISCES_HIP_CHECK(h, h->d_ref.reserve((size_t)length));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_ref.p, bases, (size_t)length, hipMemcpyHostToDevice, h->stream));
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    h->ref_len = length;
+    return PISCES_OK;
+}
+
+int32_t pisces_hip_set_intervals(PiscesHip* h, const int32_t* starts, const int32_t* ends, int32_t n)
+{
+    if (!h || n < 0 || (n > 0 && (!starts || !ends))) return fail(h, PISCES_E_INVALID_ARG, "set_intervals: bad arguments");
+    h->intervals.clear();
+    for (int i = 0; i < n; i++) {
+        if (starts[i] <= 0 || ends[i] < starts[i] || (i > 0 && starts[i] <= ends[i - 1]))
+            return fail(h, PISCES_E_INVALID_ARG, "set_intervals: intervals must be positive, sorted and disjoint");
+        h->intervals.emplace_back(starts[i], ends[i]);
+    }
+    return PISCES_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// streaming surface
+// ------------------------------------------------------------------------------------------------
+static inline int32_t block_key(const PiscesHip* h, int32_t position)
+{
+    // GetBlockKey: (int)Math.Ceiling((double)position / _regionSize)
+    return (position + h->cfg.block_size - 1) / h->cfg.block_size;
+}
+
+static inline BlockObs* get_block(PiscesHip* h, int32_t position)
+{
+    int32_t key = block_key(h, position);
+    if (h->last_block && h->last_block_key_cache == key) return h->last_block;
+    BlockObs* b = &h->blocks[key];
+    h->last_block = b;
+    h->last_block_key_cache = key;
+    return b;
+}
+
+int32_t pisces_hip_add_observations(PiscesHip* h, const int32_t* positions, const uint32_t* tuples, int64_t n)
+{
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (n < 0 || (n > 0 && (!positions || !tuples))) return fail(h, PISCES_E_INVALID_ARG, "add_observations: null buffer");
+    for (int64_t i = 0; i < n; i++)
+        if (positions[i] <= 0) return fail(h, PISCES_E_INVALID_ARG, "Position must be greater than 0.");  // RegionStateManager.cs:363-364
+    h->pending_valid = false;
+    for (int64_t i = 0; i < n; i++) {
+        BlockObs* b = get_block(h, positions[i]);
+        b->pos.push_back(positions[i]);
+        b->tup.push_back(tuples[i] & ~0x7FFFu);
+    }
+    h->stats[3] += n;
+    return PISCES_OK;
+}
+
+namespace {
+struct BlockSink : ObservationSink {
+    PiscesHip* h;
+    std::vector<std::pair<int32_t, uint32_t>> staged;   // one read is committed atomically
+    void emit(int32_t position, uint32_t tuple) override { staged.emplace_back(position, tuple); }
+};
+struct ArraySink : ObservationSink {
+    int32_t* positions;
+    uint32_t* tuples;
+    int64_t capacity, n = 0;
+    void emit(int32_t position, uint32_t tuple) override
+    {
+        if (n < capacity) { positions[n] = position; tuples[n] = tuple; }
+        n++;
+    }
+};
+}  // namespace
+
+static int32_t validate_batch(const PiscesReadBatch* b)
+{
+    if (!b || b->n_reads < 0) return PISCES_E_INVALID_ARG;
+    if (b->n_reads == 0) return PISCES_OK;
+    if (!b->position || !b->flags || !b->cigar_offset || !b->cigar_op || !b->cigar_len || !b->seq_offset || !b->bases || !b->quals)
+        return PISCES_E_INVALID_ARG;
+    return PISCES_OK;
+}
+
+int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
+{
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (validate_batch(batch) != PISCES_OK) return fail(h, PISCES_E_INVALID_ARG, "add_reads: malformed read batch");
+    h->pending_valid = false;
+    BlockSink sink;
+    sink.h = h;
+    for (int32_t i = 0; i < batch->n_reads; i++) {
+        ReadView r = read_view(batch, i);
+        if (r.position <= 0) return fail(h, PISCES_E_INVALID_ARG, "Position must be greater than 0.");
+        sink.staged.clear();
+        int32_t rc = expand_read(r, h->cfg.min_base_call_quality, sink);
+        if (rc == PISCES_E_UNMAPPED_BASE)
+            return fail(h, rc, "Base position does not appear to be mapped in read.");  // RegionStateManager.cs:109-113
+        if (rc != PISCES_OK) return fail(h, rc, "add_reads: CIGAR does not match the read");
+        for (auto& pt : sink.staged) {
+            if (pt.first <= 0) continue;
+            BlockObs* b = get_block(h, pt.first);
+            b->pos.push_back(pt.first);
+            b->tup.push_back(pt.second);
+        }
+        h->stats[2] += 1;
+        h->stats[3] += (int64_t)sink.staged.size();
+    }
+    return PISCES_OK;
+}
+
+int64_t pisces_hip_expand_reads(const PiscesReadBatch* batch, int32_t min_bq, int32_t* positions, uint32_t* tuples, int64_t capacity)
+{
+    if (validate_batch(batch) != PISCES_OK || capacity < 0 || (capacity > 0 && (!positions || !tuples))) return PISCES_E_INVALID_ARG;
+    ArraySink sink;
+    sink.positions = positions;
+    sink.tuples = tuples;
+    sink.capacity = capacity;
+    for (int32_t i = 0; i < batch->n_reads; i++) {
+        int32_t rc = expand_read(read_view(batch, i), min_bq, sink);
+        if (rc != PISCES_OK) return rc;
+    }
+    return sink.n <= capacity ? sink.n : (int64_t)PISCES_E_BUFFER_TOO_SMALL;
+}
+
+// Builds tiles + tile-bucketed tuples for a set of blocks. Tiles follow the 1000-locus block grid
+// (clipped to the interval set when one is given); every tile's tuple segment is padded to a
+// multiple of 4 tuples so the kernel's 16-byte loads start aligned.
+static void build_tiles(PiscesHip* h, const std::vector<int32_t>& keys, std::vector<PiscesTile>& tiles,
+                        std::vector<uint32_t>& tuples)
+{
+    tiles.clear();
+    tuples.clear();
+    const int bs = h->cfg.block_size;
+    std::vector<int32_t> tile_of_locus;   // per block: locus -> tile index (or -1)
+    std::vector<int64_t> fill;
+    for (int32_t key : keys) {
+        const BlockObs& b = h->blocks[key];
+        const int32_t bstart = (key - 1) * bs + 1, bend = key * bs;
+        const size_t first_tile = tiles.size();
+        tile_of_locus.assign((size_t)bs, -1);
+        auto add_range = [&](int32_t s, int32_t e) {   // inclusive, inside the block
+            for (int32_t p = s; p <= e; p += kTile) {
+                PiscesTile t;
+                t.start_position = p;
+                t.n_loci = std::min<int32_t>(kTile, e - p + 1);
+                t.tuple_begin = t.tuple_end = 0;
+                for (int32_t q = 0; q < t.n_loci; q++) tile_of_locus[(size_t)(p + q - bstart)] = (int32_t)tiles.size();
+                tiles.push_back(t);
+            }
+        };
+        if (h->intervals.empty()) add_range(bstart, bend);
+        else
+            for (auto& iv : h->intervals) {   // ChrIntervalSet.GetClipped(block)
+                int32_t s = std::max(iv.first, bstart), e = std::min(iv.second, bend);
+                if (s <= e) add_range(s, e);
+            }
+        // counting sort of the block's observations by tile
+        const size_t nt = tiles.size() - first_tile;
+        if (nt == 0) continue;
+        std::vector<int64_t> cnt(nt, 0);
+        for (size_t i = 0; i < b.pos.size(); i++) {
+            int32_t ti = tile_of_locus[(size_t)(b.pos[i] - bstart)];
+            if (ti >= 0) cnt[(size_t)ti - first_tile]++;
+        }
+        fill.assign(nt, 0);
+        int64_t cursor = (int64_t)tuples.size();
+        for (size_t t = 0; t < nt; t++) {
+            tiles[first_tile + t].tuple_begin = cursor;
+            tiles[first_tile + t].tuple_end = cursor + cnt[t];
+            fill[t] = cursor;
+            cursor += (cnt[t] + 3) & ~(int64_t)3;
+        }
+        tuples.resize((size_t)cursor, PISCES_TUPLE_PAD);
+        for (size_t i = 0; i < b.pos.size(); i++) {
+            int32_t ti = tile_of_locus[(size_t)(b.pos[i] - bstart)];
+            if (ti < 0) continue;
+            uint32_t locus = (uint32_t)(b.pos[i] - tiles[(size_t)ti].start_position);
+            tuples[(size_t)fill[(size_t)ti - first_tile]++] = (b.tup[i] & ~0x7FFFu) | locus;
+        }
+    }
+}
+
+static int32_t upload_tiles(PiscesHip* h, const std::vector<PiscesTile>& tiles, const std::vector<uint32_t>& tuples)
+{
+    PISCES_HIP_CHECK(h, h->d_tiles.reserve(tiles.size()));
+    PISCES_HIP_CHECK(h, h->d_tuples.reserve(std::max<size_t>(tuples.size(), 4)));
+    PISCES_HIP_CHECK(h, h->d_tile_results.reserve(tiles.size()));
+    PISCES_HIP_CHECK(h, h->d_count.reserve(4));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_tiles.p, tiles.data(), tiles.size() * sizeof(PiscesTile), hipMemcpyHostToDevice, h->stream));
+    if (!tuples.empty())
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_tuples.p, tuples.data(), tuples.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    return PISCES_OK;
+}
+
+// device work of one flush: returns called alleles of `keys` sorted by (position, ref, alt)
+static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::vector<PiscesCalledAllele>& out, int64_t* n_called)
+{
+    out.clear();
+    *n_called = 0;
+    if (keys.empty()) return PISCES_OK;
+    if (!h->d_ref.p) return fail(h, PISCES_E_STATE, "flush: set_reference has not been called");
+    std::vector<PiscesTile> tiles;
+    std::vector<uint32_t> tuples;
+    build_tiles(h, keys, tiles, tuples);
+    if (tiles.empty()) return PISCES_OK;
+    const int32_t n_tiles = (int32_t)tiles.size();
+    int32_t rc = upload_tiles(h, tiles, tuples);
+    if (rc) return rc;
+    const size_t cap = (size_t)n_tiles * kTile * 4;   // worst case: 4 alleles at every locus
+    PISCES_HIP_CHECK(h, h->d_records.reserve(cap));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_count.p, 0, sizeof(int32_t), h->stream));
+
+    bool use_counts = false;
+    for (auto& kv : h->gapped_mnv_ref)
+        if (std::binary_search(keys.begin(), keys.end(), block_key(h, kv.first))) { use_counts = true; break; }
+
+    if (!use_counts) {
+        hipLaunchKernelGGL(call_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles,
+                           h->d_ref.p, 1, h->ref_len, h->d_records.p, (int32_t)cap, h->d_count.p, h->d_tile_results.p, h->P);
+    } else {
+        // counts in HBM + AddGappedMnvRefCount adjustments (CoverageCalculator.cs:82-97)
+        const size_t nc = (size_t)n_tiles * kTile * PISCES_COUNTS_PER_LOCUS;
+        PISCES_HIP_CHECK(h, h->d_counts.reserve(nc));
+        PISCES_HIP_CHECK(h, h->d_gapped.reserve((size_t)n_tiles * kTile));
+        PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_counts.p, 0, nc * sizeof(int32_t), h->stream));
+        std::vector<uint32_t> g((size_t)n_tiles * kTile, 0u);
+        for (int32_t t = 0; t < n_tiles; t++)
+            for (int32_t l = 0; l < tiles[(size_t)t].n_loci; l++) {
+                auto it = h->gapped_mnv_ref.find(tiles[(size_t)t].start_position + l);
+                if (it != h->gapped_mnv_ref.end()) g[(size_t)t * kTile + (size_t)l] = (uint32_t)it->second;
+            }
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_gapped.p, g.data(), g.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(accumulate_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->d_tuples.p, h->d_tiles.p,
+                           n_tiles, h->d_counts.p, h->cfg.min_base_call_quality);
+        hipLaunchKernelGGL(call_counts_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->d_counts.p, h->d_gapped.p,
+                           h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p, (int32_t)cap, h->d_count.p,
+                           h->d_tile_results.p, h->P);
+        PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // g must outlive the copy
+    }
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    std::vector<PiscesTileResult> tr((size_t)n_tiles);
+    int32_t total = 0;
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(tr.data(), h->d_tile_results.p, tr.size() * sizeof(PiscesTileResult), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(&total, h->d_count.p, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    if ((size_t)total > cap) return fail(h, PISCES_E_DEVICE, "flush: record buffer overflow (internal)");
+    std::vector<PiscesCalledAllele> raw((size_t)total);
+    if (total > 0) {
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(raw.data(), h->d_records.p, raw.size() * sizeof(PiscesCalledAllele), hipMemcpyDeviceToHost, h->stream));
+        PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    }
+    // tiles were built in ascending position order; records inside a tile are already sorted
+    out.reserve((size_t)total);
+    for (int32_t t = 0; t < n_tiles; t++) {
+        const PiscesTileResult& r = tr[(size_t)t];
+        *n_called += r.reserved;
+        for (int32_t i = 0; i < r.n_records; i++) out.push_back(raw[(size_t)r.record_begin + (size_t)i]);
+    }
+    return PISCES_OK;
+}
+
+int32_t pisces_hip_flush(PiscesHip* h, int32_t up_to_position, PiscesCalledAllele* out, int64_t capacity, int64_t* n_out)
+{
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (!n_out || capacity < 0 || (capacity > 0 && !out)) return fail(h, PISCES_E_INVALID_ARG, "flush: null output");
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    *n_out = 0;
+    const bool final_flush = up_to_position < 0;
+    const bool replay = h->pending_valid && h->pending_up_to == up_to_position;
+    if (!replay) {
+        // GetCandidatesToProcess (RegionStateManager.cs:283-334): only build a batch when upTo has moved
+        // onto another block; take blocks that lie wholly at or below upTo.
+        if (!final_flush && block_key(h, up_to_position) == h->last_up_to_block_key) return PISCES_OK;
+        std::vector<int32_t> keys;
+        for (auto& kv : h->blocks)
+            if (final_flush || (int64_t)kv.first * h->cfg.block_size <= up_to_position) keys.push_back(kv.first);
+        int64_t called = 0;
+        int32_t rc = call_blocks(h, keys, h->pending, &called);
+        if (rc) return rc;
+        h->pending_keys = keys;
+        h->pending_called = called;
+        h->pending_up_to = up_to_position;
+        h->pending_valid = true;
+    }
+    if ((int64_t)h->pending.size() > capacity) {
+        *n_out = (int64_t)h->pending.size();
+        return fail(h, PISCES_E_BUFFER_TOO_SMALL, "flush: output buffer too small");
+    }
+    if (!h->pending.empty()) std::memcpy(out, h->pending.data(), h->pending.size() * sizeof(PiscesCalledAllele));
+    *n_out = (int64_t)h->pending.size();
+    // DoneProcessing (RegionStateManager.cs:336-353)
+    for (int32_t key : h->pending_keys) {
+        h->blocks.erase(key);
+        const int32_t bstart = (key - 1) * h->cfg.block_size + 1, bend = key * h->cfg.block_size;
+        for (auto it = h->gapped_mnv_ref.begin(); it != h->gapped_mnv_ref.end();)
+            it = (it->first >= bstart && it->first <= bend) ? h->gapped_mnv_ref.erase(it) : std::next(it);
+    }
+    h->last_block = nullptr;
+    h->stats[0] += h->pending_called;
+    h->last_up_to_block_key = final_flush ? -1 : block_key(h, up_to_position);
+    h->pending_valid = false;
+    h->pending.clear();
+    h->pending_keys.clear();
+    return PISCES_OK;
+}
+
+int32_t pisces_hip_get_counts(PiscesHip* h, int32_t start_position, int32_t n, int32_t* out)
+{
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (n < 0 || (n > 0 && !out)) return fail(h, PISCES_E_INVALID_ARG, "get_counts: null output");
+    if (start_position <= 0) return fail(h, PISCES_E_INVALID_ARG, "Position must be greater than 0.");
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    std::memset(out, 0, (size_t)n * PISCES_COUNTS_PER_LOCUS * sizeof(int32_t));
+    if (n == 0) return PISCES_OK;
+    std::vector<int32_t> keys;
+    for (int32_t k = block_key(h, start_position); k <= block_key(h, start_position + n - 1); k++)
+        if (h->blocks.count(k)) keys.push_back(k);
+    if (keys.empty()) return PISCES_OK;
+    // counts are served over the whole block grid, not the interval-clipped tiles
+    auto saved = h->intervals;
+    h->intervals.clear();
+    std::vector<PiscesTile> tiles;
+    std::vector<uint32_t> tuples;
+    build_tiles(h, keys, tiles, tuples);
+    h->intervals = saved;
+    const int32_t n_tiles = (int32_t)tiles.size();
+    int32_t rc = upload_tiles(h, tiles, tuples);
+    if (rc) return rc;
+    const size_t nc = (size_t)n_tiles * kTile * PISCES_COUNTS_PER_LOCUS;
+    PISCES_HIP_CHECK(h, h->d_counts.reserve(nc));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_counts.p, 0, nc * sizeof(int32_t), h->stream));
+    hipLaunchKernelGGL(accumulate_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles,
+                       h->d_counts.p, h->cfg.min_base_call_quality);
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    std::vector<int32_t> host(nc);
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(host.data(), h->d_counts.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    for (int32_t t = 0; t < n_tiles; t++)
+        for (int32_t l = 0; l < tiles[(size_t)t].n_loci; l++) {
+            int32_t p = tiles[(size_t)t].start_position + l;
+            if (p < start_position || p >= start_position + n) continue;
+            std::memcpy(out + (size_t)(p - start_position) * PISCES_COUNTS_PER_LOCUS,
+                        host.data() + ((size_t)t * kTile + (size_t)l) * PISCES_COUNTS_PER_LOCUS,
+                        PISCES_COUNTS_PER_LOCUS * sizeof(int32_t));
+        }
+    return PISCES_OK;
+}
+
+int32_t pisces_hip_add_gapped_mnv_ref(PiscesHip* h, const int32_t* positions, const int32_t* counts, int32_t n)
+{
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (n < 0 || (n > 0 && (!positions || !counts))) return fail(h, PISCES_E_INVALID_ARG, "add_gapped_mnv_ref: null buffer");
+    for (int32_t i = 0; i < n; i++) {
+        if (positions[i] <= 0) return fail(h, PISCES_E_INVALID_ARG, "Position must be greater than 0.");
+        (void)get_block(h, positions[i]);   // GetBlock(position) creates the block (RegionStateManager.cs:78)
+        h->gapped_mnv_ref[positions[i]] += counts[i];
+    }
+    h->pending_valid = false;
+    return PISCES_OK;
+}
+
+int32_t pisces_hip_get_candidates(PiscesHip* h, int32_t, PiscesCandidate*, int64_t, int64_t* n_out, uint8_t*, int64_t, int64_t* allele_bytes)
+{
+    if (!h) return PISCES_E_INVALID_ARG;
+    // MNV / indel candidate discovery is SURVEY §8 row f1 (next): SNV candidates never leave the device.
+    if (n_out) *n_out = 0;
+    if (allele_bytes) *allele_bytes = 0;
+    return PISCES_OK;
+}
+
+int32_t pisces_hip_stats(PiscesHip* h, int64_t out[4])
+{
+    if (!h || !out) return PISCES_E_INVALID_ARG;
+    for (int i = 0; i < 4; i++) out[i] = h->stats[i];
+    return PISCES_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device-resident surface
+// ------------------------------------------------------------------------------------------------
+int32_t pisces_hip_call_tiles(PiscesHip* h, const uint32_t* d_tuples, const PiscesTile* d_tiles, int32_t n_tiles,
+                              const uint8_t* d_ref_bases, int32_t ref_start_position, int64_t ref_length,
+                              PiscesCalledAllele* d_records, int32_t record_capacity, int32_t* d_record_count,
+                              PiscesTileResult* d_tile_results, void* stream)
+{
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (n_tiles < 0 || record_capacity < 0 || ref_length < 0) return fail(h, PISCES_E_INVALID_ARG, "call_tiles: negative size");
+    if (n_tiles > 0 && (!d_tiles || !d_ref_bases || !d_records || !d_record_count || !d_tile_results))
+        return fail(h, PISCES_E_INVALID_ARG, "call_tiles: null device pointer");
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    PISCES_HIP_CHECK(h, hipMemsetAsync(d_record_count, 0, sizeof(int32_t), s));
+    PISCES_HIP_CHECK(h, hipEventRecord(h->ev0, s));
+    if (n_tiles > 0)
+        hipLaunchKernelGGL(call_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, d_tuples, d_tiles, n_tiles, d_ref_bases,
+                           ref_start_position, ref_length, d_records, record_capacity, d_record_count, d_tile_results, h->P);
+    PISCES_HIP_CHECK(h, hipEventRecord(h->ev1, s));
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    h->timed = true;
+    return PISCES_OK;
+}
+
+int32_t pisces_hip_accumulate_tiles(PiscesHip* h, const uint32_t* d_tuples, const PiscesTile* d_tiles, int32_t n_tiles,
+                                    int32_t* d_counts, void* stream)
+{
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (n_tiles < 0) return fail(h, PISCES_E_INVALID_ARG, "accumulate_tiles: negative size");
+    if (n_tiles > 0 && (!d_tiles || !d_counts)) return fail(h, PISCES_E_INVALID_ARG, "accumulate_tiles: null device pointer");
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    PISCES_HIP_CHECK(h, hipEventRecord(h->ev0, s));
+    if (n_tiles > 0)
+        hipLaunchKernelGGL(accumulate_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, d_tuples, d_tiles, n_tiles, d_counts,
+                           h->cfg.min_base_call_quality);
+    PISCES_HIP_CHECK(h, hipEventRecord(h->ev1, s));
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    h->timed = true;
+    return PISCES_OK;
+}
+
+int32_t pisces_hip_synchronize(PiscesHip* h)
+{
+    if (!h) return PISCES_E_INVALID_ARG;
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    return PISCES_OK;
+}
+
+int32_t pisces_hip_last_kernel_ms(PiscesHip* h, float* ms)
+{
+    if (!h || !ms) return PISCES_E_INVALID_ARG;
+    if (!h->timed) return fail(h, PISCES_E_STATE, "last_kernel_ms: no timed launch yet");
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    PISCES_HIP_CHECK(h, hipEventSynchronize(h->ev1));
+    PISCES_HIP_CHECK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return PISCES_OK;
+}
+
+}  // extern "C"

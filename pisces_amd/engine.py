@@ -1,0 +1,179 @@
+"""Host-side mirror of the reference's operator surface for the hot path, over the C ABI.
+
+`HipVariantCaller` plays the three objects Factory.CreateSomaticVariantCaller builds
+(src/exe/Pisces/Logic/Factory.cs:253-269): ICandidateVariantFinder + IStateManager
+(AddAlleleCounts / GetAlleleCount / GetCandidatesToProcess / DoneProcessing) + IAlleleCaller.Call,
+with the reference's method names so the parity tests read like the reference's own tests.
+Every compute call goes through libpisceship.so (HIP); nothing here has a CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._native import PiscesHipError, lib
+
+
+def _check(handle, rc):
+    if rc != 0:
+        msg = lib.pisces_hip_last_error(handle)
+        raise PiscesHipError(rc, msg.decode() if msg else "")
+
+
+class HipVariantCaller:
+    def __init__(self, config=None, device=0):
+        self.config = config if config is not None else _abi.default_config()
+        h = C.c_void_p()
+        rc = lib.pisces_hip_create(C.byref(self.config), device, C.byref(h))
+        if rc != 0:
+            raise PiscesHipError(rc, (lib.pisces_hip_last_error(None) or b"").decode())
+        self._h = h
+        self.device = device
+
+    # ---- lifetime (C# IDisposable) ----
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.pisces_hip_destroy(self._h)
+            self._h = None
+
+    Dispose = close
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    # ---- ChrReference ----
+    def SetReference(self, sequence):
+        """ChrReference.Sequence (upper case). position p is sequence[p-1]."""
+        if isinstance(sequence, str):
+            sequence = sequence.encode()
+        arr = np.frombuffer(bytes(sequence), dtype=np.uint8) if not isinstance(sequence, np.ndarray) else \
+            np.ascontiguousarray(sequence, np.uint8)
+        _check(self._h, lib.pisces_hip_set_reference(self._h, arr.ctypes.data, arr.size))
+
+    def SetIntervals(self, intervals):
+        """ChrIntervalSet (sorted, disjoint, inclusive)."""
+        s = np.array([a for a, _ in intervals], dtype=np.int32)
+        e = np.array([b for _, b in intervals], dtype=np.int32)
+        _check(self._h, lib.pisces_hip_set_intervals(self._h, s.ctypes.data, e.ctypes.data, len(s)))
+
+    # ---- IStateManager ----
+    def AddAlleleCounts(self, reads):
+        """IStateManager.AddAlleleCounts for a batch (one _abi.ReadBatch, or an iterable of read dicts)."""
+        batch = reads if isinstance(reads, _abi.ReadBatch) else _abi.ReadBatch(reads)
+        _check(self._h, lib.pisces_hip_add_reads(self._h, C.byref(batch.c)))
+
+    def AddObservations(self, positions, tuples):
+        positions = np.ascontiguousarray(positions, np.int32)
+        tuples = np.ascontiguousarray(tuples, np.uint32)
+        assert positions.shape == tuples.shape
+        _check(self._h, lib.pisces_hip_add_observations(self._h, positions.ctypes.data, tuples.ctypes.data, positions.size))
+
+    def GetCounts(self, start_position, n):
+        out = np.zeros((n, 6, 3, _abi.NUM_ANCHORS), dtype=np.int32)
+        _check(self._h, lib.pisces_hip_get_counts(self._h, start_position, n, out.ctypes.data))
+        return out
+
+    def GetAlleleCount(self, position, allele_type, direction_type, minAnchor=0, maxAnchor=None, fromEnd=False,
+                       symmetric=False):
+        """IAlleleSource.GetAlleleCount (src/lib/Pisces.Domain/Interfaces/IAlleleSource.cs): the anchor window
+        arithmetic is AlleleCountHelper.GetAnchorAdjustedAlleleCount (AlleleCountHelper.cs:21-85) applied to
+        the device-served counts."""
+        if position <= 0:
+            raise PiscesHipError(_abi.E_INVALID_ARG, "Position must be greater than 0.")
+        c = self.GetCounts(position, 1)[0, allele_type, direction_type]
+        return anchor_adjusted_count(c, minAnchor, maxAnchor, fromEnd, symmetric)
+
+    def AddGappedMnvRefCount(self, support_lookup):
+        pos = np.array(list(support_lookup.keys()), dtype=np.int32)
+        cnt = np.array(list(support_lookup.values()), dtype=np.int32)
+        _check(self._h, lib.pisces_hip_add_gapped_mnv_ref(self._h, pos.ctypes.data, cnt.ctypes.data, len(pos)))
+
+    # ---- GetCandidatesToProcess + IAlleleCaller.Call + DoneProcessing ----
+    def Call(self, upToPosition=None, capacity=1 << 16):
+        """SmallVariantCaller.Call(upToPosition) (SmallVariantCaller.cs:157-189). None = final flush.
+        Returns a CALLED_ALLELE_DTYPE array sorted by (position, ref, alt)."""
+        up_to = -1 if upToPosition is None else int(upToPosition)
+        while True:
+            out = np.zeros(capacity, dtype=_abi.CALLED_ALLELE_DTYPE)
+            n = C.c_int64(0)
+            rc = lib.pisces_hip_flush(self._h, up_to, out.ctypes.data, capacity, C.byref(n))
+            if rc == _abi.E_BUFFER_TOO_SMALL:
+                capacity = int(n.value)
+                continue
+            _check(self._h, rc)
+            return out[: n.value]
+
+    def Stats(self):
+        s = (C.c_int64 * 4)()
+        _check(self._h, lib.pisces_hip_stats(self._h, s))
+        return {"TotalNumCalled": s[0], "TotalNumCollapsed": s[1], "reads": s[2], "observations": s[3]}
+
+    # ---- device-resident surface ----
+    def call_tiles(self, d_tuples, d_tiles, n_tiles, d_ref, ref_start, ref_len, d_records, capacity, d_count,
+                   d_tile_results, stream=None):
+        """All arguments are raw device addresses (ints)."""
+        _check(self._h, lib.pisces_hip_call_tiles(self._h, d_tuples, d_tiles, n_tiles, d_ref, ref_start, ref_len,
+                                                  d_records, capacity, d_count, d_tile_results, stream))
+
+    def accumulate_tiles(self, d_tuples, d_tiles, n_tiles, d_counts, stream=None):
+        _check(self._h, lib.pisces_hip_accumulate_tiles(self._h, d_tuples, d_tiles, n_tiles, d_counts, stream))
+
+    def synchronize(self):
+        _check(self._h, lib.pisces_hip_synchronize(self._h))
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        _check(self._h, lib.pisces_hip_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+
+def anchor_adjusted_count(c, minAnchor=0, maxAnchor=None, fromEnd=False, symmetric=False):
+    """AlleleCountHelper.GetAnchorAdjustedAlleleCount (AlleleCountHelper.cs:21-85) over one [11] anchor row."""
+    well = _abi.ANCHOR_SIZE
+    n = _abi.NUM_ANCHORS
+    true_min = min(well, minAnchor)
+    init_max = well
+    if maxAnchor is not None:
+        init_max = well - 1 if maxAnchor >= well else maxAnchor
+    tot = 0
+    if fromEnd:
+        for i in range(true_min, init_max + 1):
+            tot += int(c[n - i - 1])
+        if maxAnchor is None:
+            for i in range(true_min if symmetric else 0, init_max):
+                tot += int(c[i])
+    else:
+        for i in range(true_min, init_max + 1):
+            tot += int(c[i])
+        if maxAnchor is None:
+            for i in range(init_max + 1, (n - true_min) if symmetric else n):
+                tot += int(c[i])
+    return tot
+
+
+def expand_reads(batch, min_base_call_quality=20):
+    """Host expansion of reads into (position, tuple) observations (pisces_hip_expand_reads)."""
+    cap = batch.n_bases * 2 + 64
+    while True:
+        pos = np.zeros(cap, dtype=np.int32)
+        tup = np.zeros(cap, dtype=np.uint32)
+        n = lib.pisces_hip_expand_reads(C.byref(batch.c), min_base_call_quality, pos.ctypes.data, tup.ctypes.data, cap)
+        if n == _abi.E_BUFFER_TOO_SMALL:
+            cap *= 4
+            continue
+        if n < 0:
+            raise PiscesHipError(int(n), "expand_reads failed")
+        return pos[:n], tup[:n]

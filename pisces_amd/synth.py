@@ -1,0 +1,182 @@
+"""Deterministic synthetic amplicon pileups (SURVEY.md §8d recipe; generator modelled on the
+reference's AmpliconTestFactory, src/test/TestUtilities/AmpliconTestFactory.cs:110-147).
+
+One pileup = a seeded reference + `depth` reads per 150-locus amplicon, half forward / half
+reverse by read-index parity, Q37 with a 2 % fraction at Q12 (exercises the N path), 0.1 %
+uniform base errors, planted SNVs every 100th locus with VAF ~ U[0.02, 0.5] and strand ratio
+~ U[0.3, 0.7].  Mismatches at the first/last read base and next to a low-quality base are
+suppressed so every SNV candidate is fully anchored (the reference's collapser is then the
+identity).
+
+The same matrices give (a) device-resident tile-bucketed observation tuples for the HIP path and
+(b) a `ReadBatch` of the first amplicons for the CPU oracle / streaming surface.
+Runs on torch CPU or GPU tensors; all randomness comes from one seeded torch.Generator.
+"""
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _abi
+
+READ_LEN = 150
+TILE = 64
+_BASE_ASCII = np.frombuffer(b"AGCT", dtype=np.uint8)   # index = AlleleType code (A0 G1 C2 T3)
+
+
+@dataclass
+class Pileup:
+    n_loci: int
+    depth: int
+    region_start: int            # 1-based position of locus 0
+    ref: torch.Tensor            # uint8 ASCII, whole synthetic contig (position p = ref[p-1])
+    tuples: torch.Tensor         # int32 view of packed uint32 tuples, tile-bucketed, each segment padded to x4
+    tiles: torch.Tensor          # uint8 bytes of PiscesTile[n_tiles]
+    n_tiles: int
+    n_obs: int                   # real (unpadded) observations
+    base: torch.Tensor           # (A, depth, READ_LEN) uint8 AlleleType code of every read base
+    qual: torch.Tensor           # (A, depth, READ_LEN) uint8
+    planted: np.ndarray          # loci with a planted SNV
+
+    @property
+    def ref_len(self):
+        return int(self.ref.numel())
+
+
+def _amplicon_lengths(n_loci):
+    a = math.ceil(n_loci / READ_LEN)
+    lens = [READ_LEN] * a
+    lens[-1] = n_loci - (a - 1) * READ_LEN
+    return a, lens
+
+
+def make_pileup(n_loci, depth, seed=20260928, device="cpu", p_lowq=0.02, base_error=0.001, snv_every=100,
+                snv_offset=37, q_hi=37, q_lo=12, vaf_range=(0.02, 0.5), strand_range=(0.3, 0.7), flank=READ_LEN):
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed))
+    A, lens = _amplicon_lengths(n_loci)
+    n_pad = A * READ_LEN
+
+    # reference: uniform ACGT, flank on both sides
+    ref_codes = torch.randint(0, 4, (n_pad + 2 * flank,), generator=g, device=dev, dtype=torch.int64)
+    lut = torch.from_numpy(_BASE_ASCII.copy()).to(dev)
+    ref_ascii = lut[ref_codes][: n_loci + 2 * flank].contiguous()
+    region_start = flank + 1
+    refc = ref_codes[flank: flank + n_pad].view(A, 1, READ_LEN)          # code of the reference base per locus
+
+    shape = (A, depth, READ_LEN)
+    lowq = torch.rand(shape, generator=g, device=dev) < p_lowq
+    # planted SNV sites
+    locus = torch.arange(n_pad, device=dev).view(A, 1, READ_LEN)
+    planted_mask = (locus % snv_every == snv_offset) & (locus < n_loci)
+    # neighbours of planted sites are never low quality (keeps the planted candidates fully anchored)
+    near_planted = torch.zeros_like(planted_mask)
+    near_planted[..., 1:] |= planted_mask[..., :-1]
+    near_planted[..., :-1] |= planted_mask[..., 1:]
+    lowq &= ~near_planted
+    qual = torch.where(lowq, torch.tensor(q_lo, device=dev, dtype=torch.uint8), torch.tensor(q_hi, device=dev, dtype=torch.uint8))
+
+    # per-site VAF / strand split / alt base
+    site_vaf = vaf_range[0] + (vaf_range[1] - vaf_range[0]) * torch.rand((A, 1, READ_LEN), generator=g, device=dev)
+    site_s = strand_range[0] + (strand_range[1] - strand_range[0]) * torch.rand((A, 1, READ_LEN), generator=g, device=dev)
+    site_alt = (refc + 1 + torch.randint(0, 3, (A, 1, READ_LEN), generator=g, device=dev)) % 4
+    reverse = (torch.arange(depth, device=dev) % 2 == 1).view(1, depth, 1)
+    p_alt = torch.where(reverse, site_vaf * 2 * (1 - site_s), site_vaf * 2 * site_s).clamp(max=1.0)
+
+    u = torch.rand(shape, generator=g, device=dev)
+    err_alt = (refc + 1 + torch.randint(0, 3, shape, generator=g, device=dev)) % 4
+    is_err = u < base_error
+    # suppress sequencing errors at the read ends and next to low-quality bases
+    idx = torch.arange(READ_LEN, device=dev).view(1, 1, READ_LEN)
+    rlen = torch.tensor(lens, device=dev).view(A, 1, 1)
+    at_end = (idx == 0) | (idx == rlen - 1)
+    nb_lowq = torch.zeros_like(lowq)
+    nb_lowq[..., 1:] |= lowq[..., :-1]
+    nb_lowq[..., :-1] |= lowq[..., 1:]
+    is_err &= ~at_end & ~nb_lowq & ~planted_mask
+    base = torch.where(is_err, err_alt, refc.expand(shape))
+    base = torch.where(planted_mask & (u < p_alt), site_alt.expand(shape), base).to(torch.uint8)
+
+    # anchor bin of read index i in a read of length rlen (GetAnchorType, RegionStateManager.cs:83-116)
+    left = idx.expand(A, 1, READ_LEN)
+    right = (rlen - 1 - idx)
+    anchor = torch.where(left >= right,
+                         torch.where(right >= _abi.ANCHOR_SIZE, torch.tensor(_abi.ANCHOR_SIZE, device=dev), _abi.NUM_ANCHORS - right - 1),
+                         torch.where(left >= _abi.ANCHOR_SIZE, torch.tensor(_abi.ANCHOR_SIZE, device=dev), left))
+    direction = reverse.to(torch.int64)   # Forward 0 / Reverse 1
+    packed = ((anchor.to(torch.int64) << 15) | (direction << 19) | (base.to(torch.int64) << 21) | (qual.to(torch.int64) << 24))
+    packed = packed.expand(shape)
+
+    # tile-bucketed tuple stream: tiles of 64 loci from locus 0; inside a tile read-major (each read's run of loci)
+    n_tiles = math.ceil(n_loci / TILE)
+    tiles = np.zeros(n_tiles, dtype=_abi.TILE_DTYPE)
+    segs = []
+    cursor = 0
+    pad_val = torch.tensor([-1], device=dev, dtype=torch.int64)   # 0xFFFFFFFF after the int32 cast
+    for t in range(n_tiles):
+        l0, l1 = t * TILE, min(t * TILE + TILE, n_loci)
+        n_seg = 0
+        for a in range(l0 // READ_LEN, (l1 - 1) // READ_LEN + 1):
+            i0, i1 = max(l0, a * READ_LEN) - a * READ_LEN, min(l1, a * READ_LEN + lens[a]) - a * READ_LEN
+            if i1 <= i0:
+                continue
+            loc = torch.arange(a * READ_LEN + i0 - l0, a * READ_LEN + i1 - l0, device=dev, dtype=torch.int64).view(1, -1)
+            piece = (packed[a, :, i0:i1] | loc).reshape(-1)
+            segs.append(piece)
+            n_seg += piece.numel()
+        tiles[t] = (region_start + l0, l1 - l0, cursor, cursor + n_seg)
+        padn = (-n_seg) % 4
+        if padn:
+            segs.append(pad_val.expand(padn))
+        cursor += n_seg + padn
+    tuples64 = torch.cat(segs) if segs else torch.zeros(0, dtype=torch.int64, device=dev)
+    tuples = (tuples64 & 0xFFFFFFFF).to(torch.int64)
+    tuples = torch.where(tuples >= 2 ** 31, tuples - 2 ** 32, tuples).to(torch.int32).contiguous()
+    n_obs = int(sum(int(tiles[t]["tuple_end"] - tiles[t]["tuple_begin"]) for t in range(n_tiles)))
+    tiles_t = torch.from_numpy(tiles.view(np.uint8).copy()).to(dev)
+    planted = np.nonzero((np.arange(n_loci) % snv_every) == snv_offset)[0]
+    return Pileup(n_loci=n_loci, depth=depth, region_start=region_start, ref=ref_ascii, tuples=tuples, tiles=tiles_t,
+                  n_tiles=n_tiles, n_obs=n_obs, base=base, qual=qual, planted=planted)
+
+
+def reads_of(p, n_amplicons=None):
+    """ReadBatch of the first `n_amplicons` amplicons (all of them when None): one <len>M read per row."""
+    A = p.base.shape[0]
+    n_amp = A if n_amplicons is None else min(A, n_amplicons)
+    _, lens = _amplicon_lengths(p.n_loci)
+    base = p.base[:n_amp].cpu().numpy()
+    qual = p.qual[:n_amp].cpu().numpy()
+    depth = p.depth
+    pos, flags, cig_len, seq_off = [], [], [], [0]
+    bases, quals = [], []
+    for a in range(n_amp):
+        L = lens[a]
+        pos.append(np.full(depth, p.region_start + a * READ_LEN, dtype=np.int32))
+        flags.append((np.arange(depth) % 2).astype(np.uint8))
+        cig_len.append(np.full(depth, L, dtype=np.uint32))
+        bases.append(_BASE_ASCII[base[a, :, :L]].reshape(-1))
+        quals.append(qual[a, :, :L].reshape(-1))
+        seq_off.extend(seq_off[-1] + L * (np.arange(depth) + 1))
+    n = n_amp * depth
+    return _abi.ReadBatch.from_arrays(
+        position=np.concatenate(pos), flags=np.concatenate(flags), cigar_offset=np.arange(n + 1, dtype=np.int32),
+        cigar_op=np.full(n, ord("M"), dtype=np.uint8), cigar_len=np.concatenate(cig_len),
+        seq_offset=np.array(seq_off, dtype=np.int32), bases=np.concatenate(bases), quals=np.concatenate(quals))
+
+
+def observations_of(p, n_tiles=None):
+    """(positions, tuples) numpy arrays of the first `n_tiles` tiles, padding removed, tile order kept."""
+    tiles = p.tiles.cpu().numpy().view(_abi.TILE_DTYPE)
+    nt = p.n_tiles if n_tiles is None else min(p.n_tiles, n_tiles)
+    tup = p.tuples.cpu().numpy().view(np.uint32)
+    pos_out, tup_out = [], []
+    for t in range(nt):
+        b, e = int(tiles[t]["tuple_begin"]), int(tiles[t]["tuple_end"])
+        seg = tup[b:e]
+        pos_out.append((tiles[t]["start_position"] + (seg & 0x7FFF)).astype(np.int32))
+        tup_out.append(seg)
+    if not pos_out:
+        return np.zeros(0, np.int32), np.zeros(0, np.uint32)
+    return np.concatenate(pos_out), np.concatenate(tup_out)

@@ -1,0 +1,65 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/pisces_hip.h declares
+(no compute calls here: those need a GPU and live in the -m gpu tests)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+from pisces_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "pisces_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pisces_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pisces_amd import _native
+    declared = _declared_functions()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(_native.lib, name), f"{name} declared in include/pisces_hip.h but not exported"
+    assert sorted(_native.EXPORTS) == declared
+    assert _native.lib.pisces_hip_abi_version() == _abi.ABI_VERSION
+
+
+def test_struct_layouts_match_header():
+    assert _abi.CALLED_ALLELE_DTYPE.itemsize == 64
+    assert _abi.TILE_DTYPE.itemsize == 24 and _abi.TILE_RESULT_DTYPE.itemsize == 16
+    assert C.sizeof(_abi.PiscesHipConfig) == 4 * 30
+    assert C.sizeof(_abi.PiscesCandidate) == 56
+    d = _abi.CALLED_ALLELE_DTYPE
+    assert d.fields["strand_bias_score"][1] == 48 and d.fields["genotype_qscore"][1] == 56
+    assert d.fields["filter_bits"][1] == 60 and d.fields["info"][1] == 62
+
+
+def test_default_config_matches_library_and_reference_defaults():
+    from pisces_amd import _native
+    c = _abi.PiscesHipConfig()
+    assert _native.lib.pisces_hip_default_config(C.byref(c)) == 0
+    py = _abi.default_config()
+    for name, _ in _abi.PiscesHipConfig._fields_:
+        if name == "reserved":
+            continue
+        assert getattr(c, name) == getattr(py, name), name
+    # src/lib/Pisces.Domain/Options/VariantCallingParameters.cs:57-107
+    assert (c.min_base_call_quality, c.max_variant_qscore, c.min_variant_qscore, c.variant_qscore_filter) == (20, 100, 20, 30)
+    assert (c.min_coverage, c.block_size, c.strand_bias_model) == (10, 1000, _abi.SB_EXTENDED)
+    assert np.float32(c.min_frequency) == np.float32(0.01) and np.float32(c.rmxn_frequency_limit) == np.float32(0.35)
+
+
+def test_create_without_gpu_fails_loudly_not_silently():
+    """On a box without a HIP device create() must return an error (no CPU fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    from pisces_amd import _native
+    h = C.c_void_p()
+    cfg = _abi.default_config()
+    rc = _native.lib.pisces_hip_create(C.byref(cfg), 0, C.byref(h))
+    assert rc == _abi.E_DEVICE and not h.value
+    assert b"HIP device" in _native.lib.pisces_hip_last_error(None)

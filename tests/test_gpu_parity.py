@@ -1,0 +1,315 @@
+"""Parity of the HIP path (through the C ABI) against the oracle on a real MI355X.
+Bit-exact for every integer field of the 64-byte record (position, coverage, support, counts,
+filters, genotype); q-scores within +-1 Phred (north_star), strand-bias score to 1e-9 relative."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from pisces_amd import _abi
+from tests import orc
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+DIR = {"F": 0, "R": 1, "S": 2}
+ALLELE = {"A": 0, "G": 1, "C": 2, "T": 3, "N": 4, "D": 5}
+
+INT_FIELDS = ["position", "total_coverage", "allele_support", "reference_support", "num_no_calls", "coverage_by_dir",
+              "support_by_dir"]
+
+
+def assert_records_match(got, exp, q_tol=1):
+    assert len(got) == len(exp), (len(got), len(exp))
+    for f in INT_FIELDS:
+        np.testing.assert_array_equal(got[f], exp[f], err_msg=f)
+    dq = np.abs(got["variant_qscore"].astype(np.int64) - exp["variant_qscore"])
+    dg = np.abs(got["genotype_qscore"].astype(np.int64) - exp["genotype_qscore"])
+    assert dq.max(initial=0) <= q_tol and dg.max(initial=0) <= q_tol, (dq.max(), dg.max())
+    same_q = (dq == 0) & (dg == 0)
+    # categorical outputs may legitimately flip only where a q-score moved across a threshold
+    np.testing.assert_array_equal(got["info"][same_q], exp["info"][same_q])
+    np.testing.assert_array_equal(got["filter_bits"][same_q], exp["filter_bits"][same_q])
+    np.testing.assert_allclose(got["strand_bias_score"], exp["strand_bias_score"], rtol=1e-9, atol=1e-300)
+    return int((~same_q).sum())
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch
+
+
+def run_fused(torch, caller, p, capacity=None):
+    """One pisces_hip_call_tiles launch on device-resident buffers; returns records in tile order."""
+    dev = p.tuples.device
+    cap = capacity or p.n_tiles * 64 * 4
+    recs = torch.zeros(cap * 64, dtype=torch.uint8, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    tres = torch.zeros(p.n_tiles * 16, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    caller.call_tiles(p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), 1, p.ref_len,
+                      recs.data_ptr(), cap, count.data_ptr(), tres.data_ptr(), stream)
+    torch.cuda.synchronize()
+    n = int(count.item())
+    tr = tres.cpu().numpy().view(_abi.TILE_RESULT_DTYPE)
+    raw = recs.cpu().numpy().view(_abi.CALLED_ALLELE_DTYPE)
+    assert n <= cap
+    out = np.concatenate([raw[r["record_begin"]: r["record_begin"] + r["n_records"]] for r in tr]) if len(tr) else raw[:0]
+    assert len(out) == n
+    return out, tr
+
+
+@pytest.mark.parametrize("n_loci,depth,seed", [(1000, 500, 1), (777, 37, 2), (64, 5000, 3), (130, 1, 4), (2000, 200, 5)])
+def test_fused_kernel_matches_oracle_on_synthetic_pileups(torch_cuda, n_loci, depth, seed):
+    from pisces_amd import engine, synth
+    torch = torch_cuda
+    p = synth.make_pileup(n_loci=n_loci, depth=depth, seed=seed, device="cuda")
+    cfg = _abi.default_config()
+    with engine.HipVariantCaller(cfg) as caller:
+        got, tr = run_fused(torch, caller, p)
+    pos, tup = synth.observations_of(p)
+    exp, nloci = orc.run_observations(pos, tup, p.ref.cpu().numpy(), p.region_start, p.n_loci, cfg)
+    assert_records_match(got, exp)
+    assert int(tr["n_candidate_loci"].sum()) == nloci
+
+
+@pytest.mark.parametrize("overrides", [
+    dict(min_base_call_quality=30, noise_level=30, min_frequency=0.005, variant_freq_filter=0.005,
+         genotype_min_freq_filter=0.005, target_lod_frequency=0.005),                       # BASELINE config 5 settings
+    dict(include_reference_calls=0),                                                          # plain VCF
+    dict(strand_bias_model=_abi.SB_POISSON, filter_single_strand=1, max_variant_qscore=2000, max_genotype_qscore=2000),
+    dict(emit_zero_coverage_refs=1, low_gq_filter=30, low_depth_filter=100, min_coverage=50),
+    dict(noise_level=37, variant_qscore_filter=-1, no_call_filter_threshold=0.01, rmxn_max_repeat_length=-1),
+])
+def test_fused_kernel_config_variants(torch_cuda, overrides):
+    from pisces_amd import engine, synth
+    torch = torch_cuda
+    p = synth.make_pileup(n_loci=900, depth=300, seed=21, device="cuda", vaf_range=(0.004, 0.9), p_lowq=0.05)
+    cfg = _abi.default_config(**overrides)
+    with engine.HipVariantCaller(cfg) as caller:
+        got, _ = run_fused(torch, caller, p)
+    pos, tup = synth.observations_of(p)
+    exp, _ = orc.run_observations(pos, tup, p.ref.cpu().numpy(), p.region_start, p.n_loci, cfg)
+    assert_records_match(got, exp)
+
+
+def test_fused_kernel_edge_inputs(torch_cuda):
+    """Empty tiles, ragged last tile, N reference bases, stitched direction, deletions, every-base-low-quality,
+    homopolymer reference (RMxN), unaligned tuple segments."""
+    from pisces_amd import engine
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    n_loci, start = 200, 11
+    ref = np.frombuffer(b"N" * 10 + b"A" * 12 + b"C" * 12 + b"ACGT" * 60, dtype=np.uint8)[: start - 1 + n_loci + 20].copy()
+    ref[60] = ord("N")
+    n_obs = 30000
+    pos = rng.integers(start, start + n_loci, n_obs).astype(np.int32)
+    pos[pos == start + 150] = start + 151                      # one zero-coverage locus
+    pos = pos[(pos < start + 64) | (pos >= start + 128)]       # one wholly empty tile
+    n_obs = len(pos)
+    allele = rng.choice(6, n_obs, p=[.3, .2, .2, .2, .02, .08])
+    qual = np.where(allele == 5, 255, rng.choice([5, 19, 20, 37], n_obs, p=[.05, .05, .1, .8]))
+    tup = _abi.tuple_pack(np.zeros(n_obs, np.uint32), rng.integers(0, 11, n_obs), rng.integers(0, 3, n_obs), allele, qual)
+    cfg = _abi.default_config(emit_zero_coverage_refs=1)
+    exp, nloci = orc.run_observations(pos, tup, ref, start, n_loci, cfg)
+    # tile-bucket WITHOUT padding so segments start unaligned (exercises the scalar head/tail path)
+    tiles = np.zeros(4, dtype=_abi.TILE_DTYPE)
+    segs, cursor = [np.full(1, _abi.TUPLE_PAD, np.uint32)], 1
+    for t in range(4):
+        l0, l1 = t * 64, min(n_loci, t * 64 + 64)
+        m = (pos >= start + l0) & (pos < start + l1)
+        seg = (tup[m] & ~np.uint32(0x7FFF)) | (pos[m] - (start + l0)).astype(np.uint32)
+        tiles[t] = (start + l0, l1 - l0, cursor, cursor + len(seg))
+        segs.append(seg)
+        cursor += len(seg)
+    d_tup = torch.from_numpy(np.concatenate(segs).view(np.int32)).cuda()
+    d_tiles = torch.from_numpy(tiles.view(np.uint8)).cuda()
+    d_ref = torch.from_numpy(ref).cuda()
+
+    class P:  # minimal pileup view for run_fused
+        tuples, tiles, n_tiles, ref, ref_len = d_tup, d_tiles, 4, d_ref, len(ref)
+    with engine.HipVariantCaller(cfg) as caller:
+        got, tr = run_fused(torch, caller, P)
+    assert_records_match(got, exp)
+    assert int(tr["n_candidate_loci"].sum()) == nloci == n_loci
+    assert tr[1]["n_records"] == 64   # the empty tile still reports its zero-coverage reference rows
+
+
+def test_rmxn_filter_on_device(torch_cuda):
+    """An SNV between two >= 9-long homopolymers gets the RMxN filter (RMxNCalculator.cs:19-38)."""
+    from pisces_amd import engine
+    ref = np.frombuffer(b"GATTACAGAT" + b"A" * 10 + b"C" * 10 + b"GATTACAGAT", dtype=np.uint8).copy()
+    pos_snv = 20   # last A, alt C
+    pos, tup = [], []
+    for p in range(5, 36):
+        rb = _abi.ALLELE_OF_BASE[chr(ref[p - 1])]
+        for i in range(200):
+            a = _abi.ALLELE_C if (p == pos_snv and i < 40) else rb
+            pos.append(p)
+            tup.append(_abi.tuple_pack(0, 5, i % 2, a, 37))
+    pos, tup = np.array(pos, np.int32), np.array(tup, np.uint32)
+    cfg = _abi.default_config()
+    exp, _ = orc.run_observations(pos, tup, ref, 1, len(ref), cfg)
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(ref)
+        c.AddObservations(pos, tup)
+        got = c.Call()
+    assert_records_match(got, exp)
+    row = got[got["position"] == pos_snv][0]
+    assert _abi.info_category(row["info"]) == _abi.CAT_SNV and row["filter_bits"] & (1 << _abi.FILTER_RMXN)
+
+
+# ---------------------------------------------------------------- streaming surface (IStateManager protocol)
+def _read_dict(rd, default_q):
+    d = {"pos": rd["pos"], "seq": rd["seq"],
+         "cigar": orc.parse_cigar(rd["cigar"]) if "cigar" in rd else [("M", len(rd["seq"]))],
+         "quals": rd.get("quals", [rd.get("qual", default_q)] * len(rd["seq"]))}
+    if "dirs" in rd:
+        d["dirs"] = [DIR[rd["dirs"]]] * len(rd["seq"])
+    return d
+
+
+def test_get_allele_count_reference_scenarios(torch_cuda):
+    """RegionStateManagerTests.AddAndGetAlleleCounts / _PoorQualDeletions through AddAlleleCounts + GetAlleleCount."""
+    from pisces_amd import engine
+    g = json.load(open(os.path.join(G, "region_state.json")))
+    for sc in g["poor_qual_deletions"]["scenarios"]:
+        with engine.HipVariantCaller(_abi.default_config(min_base_call_quality=g["poor_qual_deletions"]["min_quality"],
+                                                         noise_level=25)) as c:
+            c.AddAlleleCounts([_read_dict(r, 30) for r in sc["reads"]])
+            for e in sc["expect_ranges"]:
+                for pos in range(e["from"], e["to"] + 1):
+                    assert c.GetAlleleCount(pos, ALLELE[e["allele"]], DIR[e["dir"]]) == e["count"], (sc["name"], pos)
+    a = g["add_and_get"]
+    reads = [r for r in a["reads"] if "posmap_unmapped_index" not in r]
+    with engine.HipVariantCaller(_abi.default_config(min_base_call_quality=a["min_quality"], noise_level=25)) as c:
+        c.AddAlleleCounts([_read_dict(r, a["min_quality"]) for r in reads])
+        st = orc.State(900, 300, min_bq=a["min_quality"])
+        for r in reads:
+            d = _read_dict(r, a["min_quality"])
+            st.add_allele_counts(orc.make_read(d["pos"], d["seq"], cigar=d["cigar"], quals=d["quals"], dirs=d.get("dirs")))
+        np.testing.assert_array_equal(c.GetCounts(900, 300), st.counts())
+        with pytest.raises(engine.PiscesHipError):   # Assert.Throws<ArgumentException>(GetAlleleCount(0, ..))
+            c.GetAlleleCount(0, _abi.ALLELE_A, _abi.DIR_FORWARD)
+        # anchor windows served from device counts (AlleleCountHelperTests semantics)
+        assert c.GetAlleleCount(1001, _abi.ALLELE_A, _abi.DIR_FORWARD) == 2
+        assert c.GetAlleleCount(1001, _abi.ALLELE_A, _abi.DIR_FORWARD, minAnchor=1) == \
+            st.get_allele_count(1001, _abi.ALLELE_A, _abi.DIR_FORWARD, 1)
+
+
+def test_streaming_protocol_matches_oracle_and_block_schedule(torch_cuda):
+    """SmallVariantCaller loop: AddAlleleCounts(read); Call(LastClearedPosition) ... Call(null).
+    Blocks are emitted once upTo passes them (RegionStateManager.cs:283-334); the union equals the oracle."""
+    from pisces_amd import engine, synth
+    p = synth.make_pileup(n_loci=3300, depth=40, seed=9)          # CPU tensors: spans 4+ blocks of 1000
+    cfg = _abi.default_config()
+    batch = synth.reads_of(p)
+    exp, _ = orc.run_reads(batch, p.ref.numpy(), p.region_start, p.n_loci, cfg)
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(p.ref.numpy())
+        got = []
+        n_amp = batch.n_reads // p.depth
+        for a in range(n_amp):   # feed one amplicon (40 reads sharing a start) at a time, like position-sorted reads
+            lo, hi = a * p.depth, (a + 1) * p.depth
+            sub = _abi.ReadBatch.from_arrays(
+                batch.position[lo:hi], batch.flags[lo:hi], batch.cigar_offset[lo:hi + 1] - batch.cigar_offset[lo],
+                batch.cigar_op[batch.cigar_offset[lo]:batch.cigar_offset[hi]],
+                batch.cigar_len[batch.cigar_offset[lo]:batch.cigar_offset[hi]],
+                batch.seq_offset[lo:hi + 1] - batch.seq_offset[lo],
+                batch.bases[batch.seq_offset[lo]:batch.seq_offset[hi]], batch.quals[batch.seq_offset[lo]:batch.seq_offset[hi]])
+            c.AddAlleleCounts(sub)
+            out = c.Call(int(batch.position[lo]) - 1)              # LastClearedPosition = lastReadPos - 1
+            if len(out):
+                # nothing beyond the cleared position, whole blocks only
+                assert out["position"].max() <= int(batch.position[lo]) - 1
+                assert out["position"].max() % 1000 == 0 or out["position"].max() == exp["position"].max()
+            got.append(out)
+        got.append(c.Call(None))
+        got = np.concatenate(got)
+        assert_records_match(got, exp)
+        assert c.Stats()["reads"] == batch.n_reads
+        assert len(c.Call(None)) == 0   # nothing left
+
+
+def test_intervals_and_gapped_mnv_ref(torch_cuda):
+    from pisces_amd import engine, synth
+    p = synth.make_pileup(n_loci=1500, depth=80, seed=13)
+    cfg = _abi.default_config(emit_zero_coverage_refs=1)
+    pos, tup = synth.observations_of(p)
+    intervals = [(p.region_start + 100, p.region_start + 180), (p.region_start + 900, p.region_start + 1010)]
+    gapped = {p.region_start + 120: 7, p.region_start + 950: 10 ** 6}
+    exp_all, _ = orc.run_observations(pos, tup, p.ref.numpy(), p.region_start, p.n_loci, cfg)
+    keep = np.zeros(len(exp_all), bool)
+    for s, e in intervals:
+        keep |= (exp_all["position"] >= s) & (exp_all["position"] <= e)
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(p.ref.numpy())
+        c.SetIntervals(intervals)
+        c.AddObservations(pos, tup)
+        got = c.Call()
+    assert_records_match(got, exp_all[keep])
+    # gapped-MNV reference counts lower Reference AlleleSupport / SNV ReferenceSupport (CoverageCalculator.cs:82-97)
+    st = orc.State(p.region_start, p.n_loci, min_bq=20)
+    # (oracle side: same observations, then AddGappedMnvRefCount, then call)
+    import ctypes as C
+    with engine.HipVariantCaller(_abi.default_config()) as c:
+        c.SetReference(p.ref.numpy())
+        c.AddObservations(pos, tup)
+        c.AddGappedMnvRefCount(gapped)
+        got = c.Call()
+    base, _ = orc.run_observations(pos, tup, p.ref.numpy(), p.region_start, p.n_loci, _abi.default_config())
+    for gp, gc in gapped.items():
+        b = base[base["position"] == gp]
+        o = got[got["position"] == gp]
+        assert len(b) == len(o)
+        for rb, ro in zip(b, o):
+            if _abi.info_category(rb["info"]) == _abi.CAT_REFERENCE:
+                assert ro["allele_support"] == max(0, rb["allele_support"] - gc)
+            else:
+                assert ro["reference_support"] == max(0, rb["reference_support"] - gc)
+    untouched = ~np.isin(base["position"], list(gapped))
+    assert_records_match(got[~np.isin(got["position"], list(gapped))], base[untouched])
+
+
+def test_error_paths(torch_cuda):
+    from pisces_amd import engine
+    with engine.HipVariantCaller() as c:
+        with pytest.raises(engine.PiscesHipError) as e:
+            c.AddObservations(np.array([0], np.int32), np.array([0], np.uint32))   # position <= 0
+        assert e.value.code == _abi.E_INVALID_ARG and "greater than 0" in e.value.message
+        c.AddObservations(np.array([5], np.int32), np.array([_abi.tuple_pack(0, 5, 0, 0, 30)], np.uint32))
+        with pytest.raises(engine.PiscesHipError) as e:
+            c.Call()                                                                # no reference set
+        assert e.value.code == _abi.E_STATE
+    with pytest.raises(engine.PiscesHipError):
+        engine.HipVariantCaller(_abi.default_config(strand_bias_model=_abi.SB_DIPLOID))
+    with pytest.raises(engine.PiscesHipError):
+        engine.HipVariantCaller(_abi.default_config(abi_version=99))
+
+
+# ---------------------------------------------------------------- BASELINE sizes: size-independent properties
+def test_full_size_properties_config2(torch_cuda):
+    """100k loci x 500x (BASELINE config 2): exact depth everywhere, one candidate locus per locus, linearity
+    (two launches over halves == one launch), idempotence (same launch twice), a sampled slice against the oracle."""
+    from pisces_amd import engine, synth
+    torch = torch_cuda
+    p = synth.make_pileup(n_loci=100_000, depth=500, device="cuda")
+    cfg = _abi.default_config()
+    with engine.HipVariantCaller(cfg) as caller:
+        got, tr = run_fused(torch, caller, p)
+        again, _ = run_fused(torch, caller, p)
+    assert got.tobytes() == again.tobytes()
+    assert int(tr["n_candidate_loci"].sum()) == 100_000
+    assert ((got["total_coverage"] + got["num_no_calls"]) == 500).all()
+    assert (np.diff(got["position"]) >= 0).all()
+    ref_rows = np.array([_abi.info_category(i) == _abi.CAT_REFERENCE for i in got["info"][:5000]])
+    assert (got["allele_support"][:5000][ref_rows] == got["reference_support"][:5000][ref_rows]).all()
+    # a checksum of checksums: total support of all alleles equals the number of quality-passing ACGT observations
+    # that match a called allele; cheaper: sum(coverage) + sum(no calls) per locus == depth (done above), and the
+    # sample below pins the rest against the oracle
+    n_t = 40
+    pos, tup = synth.observations_of(p, n_t)
+    exp, _ = orc.run_observations(pos, tup, p.ref.cpu().numpy(), p.region_start, n_t * 64, cfg)
+    assert_records_match(got[got["position"] < p.region_start + n_t * 64], exp)

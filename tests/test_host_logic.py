@@ -1,0 +1,111 @@
+"""Host logic that needs no GPU: the read -> observation-tuple expander (pisces_hip_expand_reads,
+pure C++) against the oracle's AddAlleleCounts, and the synthetic generator's self-consistency."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from pisces_amd import _abi, engine
+from tests import orc
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+DIR = {"F": 0, "R": 1, "S": 2}
+
+
+def counts_from_observations(pos, tup, start, n_loci, min_bq):
+    """numpy histogram of (position, tuple) observations with the kernel's 'qual < minBQ -> N' rule."""
+    c = np.zeros((n_loci, 6, 3, _abi.NUM_ANCHORS), dtype=np.int32)
+    allele = (tup >> 21) & 7
+    qual = tup >> 24
+    allele = np.where((allele < 4) & (qual < min_bq), 4, allele)
+    keep = (pos >= start) & (pos < start + n_loci)
+    np.add.at(c, (pos[keep] - start, allele[keep], (tup[keep] >> 19) & 3, (tup[keep] >> 15) & 0xF), 1)
+    return c
+
+
+def _read_dict(rd, default_q):
+    d = {"pos": rd["pos"], "seq": rd["seq"], "cigar": orc.parse_cigar(rd["cigar"]) if "cigar" in rd else [("M", len(rd["seq"]))],
+         "quals": rd.get("quals", [rd.get("qual", default_q)] * len(rd["seq"]))}
+    if "dirs" in rd:
+        d["dirs"] = [DIR[rd["dirs"]]] * len(rd["seq"])
+    return d
+
+
+def _scenarios():
+    g = json.load(open(os.path.join(G, "region_state.json")))
+    out = [("add_and_get", g["add_and_get"]["min_quality"],
+            [r for r in g["add_and_get"]["reads"] if "posmap_unmapped_index" not in r] + [g["add_and_get"]["then_read"]])]
+    for sc in g["poor_qual_deletions"]["scenarios"]:
+        out.append((sc["name"], g["poor_qual_deletions"]["min_quality"], sc["reads"]))
+    # extra CIGAR shapes: insertion, soft clips both ends, leading/trailing deletions, stitched directions
+    out.append(("mixed", 20, [
+        {"seq": "ACGTACGTACGT", "pos": 1010, "cigar": "3S4M2I3M", "qual": 30},
+        {"seq": "ACGTACGTAC", "pos": 1020, "cigar": "5M3D5M", "quals": [30, 30, 30, 30, 10, 30, 30, 30, 30, 30]},
+        {"seq": "ACGTACGTAC", "pos": 1020, "cigar": "5M3D5M", "quals": [30] * 10, "dirs": "S"},
+        {"seq": "ACGTAC", "pos": 1030, "cigar": "2D6M", "qual": 30},
+        {"seq": "ACGTAC", "pos": 1040, "cigar": "6M3D", "qual": 30, "dirs": "R"},
+        {"seq": "ACGTACNN", "pos": 1050, "cigar": "6M2D2S", "qual": 30},
+        {"seq": "A", "pos": 1060, "qual": 30},
+    ]))
+    return out
+
+
+@pytest.mark.parametrize("name,min_bq,reads", _scenarios(), ids=[s[0] for s in _scenarios()])
+def test_expander_matches_oracle_add_allele_counts(name, min_bq, reads):
+    st = orc.State(900, 300, min_bq=min_bq)
+    for rd in reads:
+        d = _read_dict(rd, 30)
+        assert st.add_allele_counts(orc.make_read(d["pos"], d["seq"], cigar=d["cigar"], quals=d["quals"],
+                                                  dirs=d.get("dirs"))) == 0
+    batch = _abi.ReadBatch([_read_dict(rd, 30) for rd in reads])
+    pos, tup = engine.expand_reads(batch, min_bq)
+    got = counts_from_observations(pos, tup, 900, 300, min_bq)
+    np.testing.assert_array_equal(got, st.counts())
+
+
+def test_expander_random_reads_match_oracle():
+    rng = np.random.default_rng(7)
+    reads = []
+    for _ in range(300):
+        ops = []
+        n_ops = rng.integers(1, 6)
+        for k in range(n_ops):
+            ops.append((str(rng.choice(list("MMMIDS"))), int(rng.integers(1, 12))))
+        # CIGAR hygiene the BAM spec guarantees: S only at the ends, at least one M
+        ops = [(o, l) for i, (o, l) in enumerate(ops) if o != "S" or i in (0, len(ops) - 1)]
+        if not any(o == "M" for o, _ in ops):
+            ops.append(("M", 5))
+        rl = sum(l for o, l in ops if o in "MIS")
+        reads.append({"pos": int(rng.integers(950, 1100)), "cigar": ops,
+                      "seq": "".join(rng.choice(list("ACGTN"), rl, p=[.24, .24, .24, .24, .04])),
+                      "quals": rng.choice([10, 25, 37], rl, p=[.1, .2, .7]).astype(np.uint8).tolist(),
+                      "reverse": bool(rng.integers(0, 2))})
+    st = orc.State(900, 400, min_bq=20)
+    for d in reads:
+        assert st.add_allele_counts(orc.make_read(d["pos"], d["seq"], cigar=d["cigar"], quals=d["quals"],
+                                                  reverse=d["reverse"])) == 0
+    pos, tup = engine.expand_reads(_abi.ReadBatch(reads), 20)
+    np.testing.assert_array_equal(counts_from_observations(pos, tup, 900, 400, 20), st.counts())
+
+
+def test_synthetic_pileup_reads_and_tuples_agree():
+    """The generator's two views (reads for the oracle, tile-bucketed tuples for the device) describe the
+    same pileup: oracle(reads) == oracle(observations), and depth is exact at every locus."""
+    from pisces_amd import synth
+    p = synth.make_pileup(n_loci=500, depth=60, seed=11)
+    cfg = _abi.default_config()
+    ref = p.ref.numpy()
+    a, na = orc.run_reads(synth.reads_of(p), ref, p.region_start, p.n_loci, cfg)
+    pos, tup = synth.observations_of(p)
+    b, nb = orc.run_observations(pos, tup, ref, p.region_start, p.n_loci, cfg)
+    assert na == nb == 500
+    assert a.tobytes() == b.tobytes()
+    assert ((a["total_coverage"] + a["num_no_calls"]) == 60).all()
+    # SNVs are called only at planted sites (0.1 % sequencing errors stay below the emit thresholds at depth 60)
+    called_snv = a[[(_abi.info_category(i) == _abi.CAT_SNV) for i in a["info"]]]
+    assert 0 < len(called_snv) and set((called_snv["position"] - p.region_start).tolist()) <= set(p.planted.tolist())
+    # expander(reads) gives the same observations as the generator's tuple view (up to order)
+    epos, etup = engine.expand_reads(synth.reads_of(p), 20)
+    key = lambda P, T: np.sort((P.astype(np.int64) << 32) | (T & ~np.uint32(0x7FFF)).astype(np.int64))
+    np.testing.assert_array_equal(key(epos, etup), key(pos, tup))
