@@ -25,7 +25,22 @@ class PiscesHipError(RuntimeError):
         self.message = message
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7, looked up by file name
+    from torch/lib).  Device pointers and streams cross between torch and this library, so both must sit on
+    ONE HIP runtime: load torch's copy first, then libpisceship.so's NEEDED libamdhip64.so.7 resolves to it
+    by SONAME.  Without torch (the C# host) the system ROCm runtime is used."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def _load():
+    _share_hip_runtime_with_torch()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python -c 'import __graft_entry__ as g; "

@@ -128,10 +128,10 @@ def test_fused_kernel_edge_inputs(torch_cuda):
     d_tiles = torch.from_numpy(tiles.view(np.uint8)).cuda()
     d_ref = torch.from_numpy(ref).cuda()
 
-    class P:  # minimal pileup view for run_fused
-        tuples, tiles, n_tiles, ref, ref_len = d_tup, d_tiles, 4, d_ref, len(ref)
+    from types import SimpleNamespace
+    view = SimpleNamespace(tuples=d_tup, tiles=d_tiles, n_tiles=4, ref=d_ref, ref_len=len(ref))
     with engine.HipVariantCaller(cfg) as caller:
-        got, tr = run_fused(torch, caller, P)
+        got, tr = run_fused(torch, caller, view)
     assert_records_match(got, exp)
     assert int(tr["n_candidate_loci"].sum()) == nloci == n_loci
     assert tr[1]["n_records"] == 64   # the empty tile still reports its zero-coverage reference rows
