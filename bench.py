@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py — candidate loci/s of the pileup-and-likelihood hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step is ONE pass of the hot path (pisces_hip_call_tiles: observation tuples -> LDS allele-count
+histograms -> coverage / Poisson q-score / strand bias / somatic genotype / filters -> 64-byte called-allele
+records) over one synthetic batch of BASELINE.json config 2: 100 000 loci x 500x amplicon pileup, SNV-only,
+gVCF on, reference defaults.  Inputs are resident in HBM when the timed region starts.  Batches rotate through
+a ring of distinct pileups whose total size exceeds the 256 MiB Infinity Cache, so every step streams from HBM.
+Loci shard by interval across ranks (weak scaling: every rank owns its own 100k-locus shard per step); the only
+collective is one RCCL all-reduce of the int64[4] per-chromosome summary at the end of the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable
+N_LOCI = 100_000
+DEPTH = 500
+RING_BATCHES = 6        # 6 x ~200 MB of tuples > 256 MiB Infinity Cache
+BASE_SEED = 20260928
+
+
+def algorithmic_bytes(n_obs, n_loci, n_records):
+    """4 B per observation tuple + 1 reference byte per locus + 64 B per called-allele record."""
+    return 4 * n_obs + n_loci + 64 * n_records
+
+
+def cpu_baseline(torch, pileup, cfg, budget_s=20.0):
+    """The oracle (CPU restatement of the reference C# path: per read FindCandidates -> AddCandidates ->
+    AddAlleleCounts, then AlleleCaller over every locus) timed single-threaded — the reference runs one thread
+    per (BAM, chromosome) — on a bounded sample of the same workload."""
+    from pisces_amd import synth
+    from tests import orc   # the oracle is test infrastructure; here it is only the thing being timed
+    ref = pileup.ref.cpu().numpy()
+    # probe with 4 amplicons (600 loci) to size a ~budget_s sample
+    probe = synth.reads_of(pileup, 4)
+    t0 = time.perf_counter()
+    orc.run_reads(probe, ref, pileup.region_start, 4 * synth.READ_LEN, cfg)
+    dt = max(time.perf_counter() - t0, 1e-4)
+    n_amp_total = pileup.base.shape[0]
+    n_amp = int(min(n_amp_total, max(4, budget_s / (dt / 4))))
+    batch = synth.reads_of(pileup, n_amp)
+    n_loci = min(pileup.n_loci, n_amp * synth.READ_LEN)
+    est = dt / 4 * n_amp
+    repeats = int(max(1, min(20, round(0.6 * budget_s / max(est, 1e-3)))))   # whole batch is only seconds: repeat it
+    t0 = time.perf_counter()
+    loci = 0
+    for _ in range(repeats):
+        _, n = orc.run_reads(batch, ref, pileup.region_start, n_loci, cfg)
+        loci += n
+    dt = time.perf_counter() - t0
+    return {"value": loci / dt, "unit": "candidate loci/s", "cores": 1, "kind": "port",
+            "sample": f"first {n_loci} loci x {pileup.depth}x of batch 0 ({batch.n_reads} reads) x {repeats} passes, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--loci", type=int, default=N_LOCI)
+    ap.add_argument("--depth", type=int, default=DEPTH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from pisces_amd import _abi, engine, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    if world != args.gpus:
+        if rank == 0 and args.gpus != 1:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cfg = _abi.default_config()
+    caller = engine.HipVariantCaller(cfg, device=local_rank)
+
+    # ---- inputs, resident in HBM: RING_BATCHES distinct pileups of this rank's interval shard ----
+    ring = [synth.make_pileup(args.loci, args.depth, seed=BASE_SEED + 1000 * rank + b, device=dev) for b in range(RING_BATCHES)]
+    for p in ring:
+        p.base = p.base if p is ring[0] else None   # keep the read matrices of batch 0 only (CPU baseline sample)
+        p.qual = p.qual if p is ring[0] else None
+    torch.cuda.empty_cache()
+    n_tiles = ring[0].n_tiles
+    cap = n_tiles * 64 * 2
+    records = torch.zeros(cap * 64, dtype=torch.uint8, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    tile_results = torch.zeros(n_tiles * 16, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step(i):
+        p = ring[i % RING_BATCHES]
+        caller.call_tiles(p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), 1, p.ref_len,
+                          records.data_ptr(), cap, count.data_ptr(), tile_results.data_ptr(), stream.cuda_stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize(dev)
+    caller.device_totals(reset=True)
+    caller.set_timing(True)
+
+    # ---- timed region: exactly K steps, bracketed by barrier + synchronize ----
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize(dev)
+    totals = caller.device_totals()
+    summary = torch.tensor([totals["records"], totals["candidate_loci"], totals["called"], totals["tiles"]],
+                           dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(summary, op=dist.ReduceOp.SUM)   # the per-chromosome summary reduce (RCCL over xGMI)
+    torch.cuda.synchronize(dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    kernel_ms_total, launches = caller.kernel_time()
+    caller.set_timing(False)
+
+    # ---- sanity on the last step's output (outside the timed region) ----
+    n_rec_last = int(count.item())
+    tr = tile_results.cpu().numpy().view(_abi.TILE_RESULT_DTYPE)
+    assert n_rec_last <= cap and int(tr["n_records"].sum()) == n_rec_last
+    assert int(tr["n_candidate_loci"].sum()) == args.loci, "every covered locus must be a candidate locus in gVCF mode"
+
+    total_records, total_loci = int(summary[0].item()), int(summary[1].item())
+    value = total_loci / elapsed
+    if rank == 0:
+        # roofline of the dominant (only) kernel: algorithmic bytes per launch / mean kernel duration from HIP
+        # events recorded on the launch stream around each call_tiles_kernel launch
+        n_obs = float(np.mean([p.n_obs for p in ring]))
+        rec_per_launch = totals["records"] / max(args.steps, 1)
+        bytes_per_launch = algorithmic_bytes(n_obs, args.loci, rec_per_launch)
+        kernel_ms = kernel_ms_total / max(launches, 1)
+        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):   # written from separate rocprofv3 --pmc passes of this same command
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("loci") == args.loci and tj.get("depth") == args.depth:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "candidate loci/s at 500x depth",
+            "value": value,
+            "unit": "candidate loci/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32 counts + f64 likelihoods",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE config 2: synthetic {args.loci} loci x {args.depth}x amplicon pileup, SNV-only, "
+                                   "gVCF, per GPU per step; device-resident packed tuples",
+                       "loci_per_gpu_per_step": args.loci, "depth": args.depth, "observations_per_step": int(n_obs),
+                       "records_per_step": rec_per_launch, "ring_batches": RING_BATCHES,
+                       "parallelism": f"interval-shard x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "call_tiles_kernel", "kernel_ms": kernel_ms, "launches_timed": launches,
+                         "algorithmic_bytes_per_launch": bytes_per_launch},
+        }
+        if not args.no_cpu_baseline and world >= 1:
+            out["cpu_baseline"] = cpu_baseline(torch, ring[0], cfg)
+        print(json.dumps(out), flush=True)
+    caller.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

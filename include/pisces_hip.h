@@ -263,6 +263,16 @@ int32_t pisces_hip_call_tiles(PiscesHip* h, const uint32_t* d_tuples, const Pisc
  * (the IAlleleSource view for host-side collapsing / spanning coverage). Asynchronous. */
 int32_t pisces_hip_accumulate_tiles(PiscesHip* h, const uint32_t* d_tuples, const PiscesTile* d_tiles,
                                     int32_t n_tiles, int32_t* d_counts, void* stream);
+/* Device-side running totals bumped by every call_tiles launch of this handle:
+ * {records written, candidate loci, IsCallable==true alleles (IAlleleCaller.TotalNumCalled), tiles}.
+ * Synchronizes the handle's stream; reset != 0 zeroes them afterwards.  This is the per-chromosome
+ * summary a multi-GPU job all-reduces (SmallVariantCaller.cs:114-115 totals line). */
+int32_t pisces_hip_device_totals(PiscesHip* h, int64_t out[4], int32_t reset);
+/* Per-launch kernel timing with HIP events recorded on the launch stream around the kernel only.
+ * enable != 0 starts a fresh measurement window (up to 4096 launches are kept). */
+int32_t pisces_hip_set_timing(PiscesHip* h, int32_t enable);
+/* Sum of the kernel durations (ms) and number of launches recorded since set_timing(1). Waits for them. */
+int32_t pisces_hip_kernel_time(PiscesHip* h, double* total_ms, int64_t* launches);
 /* waits for the handle's stream */
 int32_t pisces_hip_synchronize(PiscesHip* h);
 /* time of the last call_tiles / accumulate_tiles launch measured with HIP events on the

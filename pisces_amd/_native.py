@@ -14,7 +14,8 @@ EXPORTS = [
     "pisces_hip_last_error", "pisces_hip_set_reference", "pisces_hip_set_intervals", "pisces_hip_add_reads",
     "pisces_hip_add_observations", "pisces_hip_flush", "pisces_hip_get_counts", "pisces_hip_add_gapped_mnv_ref",
     "pisces_hip_get_candidates", "pisces_hip_stats", "pisces_hip_call_tiles", "pisces_hip_accumulate_tiles",
-    "pisces_hip_synchronize", "pisces_hip_last_kernel_ms", "pisces_hip_expand_reads",
+    "pisces_hip_synchronize", "pisces_hip_last_kernel_ms", "pisces_hip_expand_reads", "pisces_hip_device_totals",
+    "pisces_hip_set_timing", "pisces_hip_kernel_time",
 ]
 
 
@@ -68,6 +69,9 @@ def _load():
         "pisces_hip_synchronize": (i32, [vp]),
         "pisces_hip_last_kernel_ms": (i32, [vp, P(C.c_float)]),
         "pisces_hip_expand_reads": (i64, [P(_abi.PiscesReadBatch), i32, vp, vp, i64]),
+        "pisces_hip_device_totals": (i32, [vp, P(i64), i32]),
+        "pisces_hip_set_timing": (i32, [vp, i32]),
+        "pisces_hip_kernel_time": (i32, [vp, P(C.c_double), P(i64)]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)   # AttributeError here = a declared symbol is not exported

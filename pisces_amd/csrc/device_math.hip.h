@@ -24,6 +24,7 @@ struct DeviceParams {
     double err_q;         // MathOperations.QtoP(NL)                       stats/MathOperations.cs:7
     double err_sb;        // Math.Pow(10, -1*NL/10f) (float exponent)      StrandBiasCalculator.cs:32
     double ln10;          // Math.Log(10.0)
+    unsigned long long* totals;  // device int64[4] running totals of the handle, or nullptr
 };
 
 // ------------------------------------------------------------------------------------------

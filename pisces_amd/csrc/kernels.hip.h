@@ -282,6 +282,12 @@ __device__ inline void call_phase(const int* hist, const uint32_t* gapped /* LDS
         tr.n_candidate_loci = n_loci_called;
         tr.reserved = n_callable;   // IsCallable == true count (IAlleleCaller.TotalNumCalled)
         *tile_result = tr;
+        if (P.totals) {
+            atomicAdd(&P.totals[0], (unsigned long long)n_surv);
+            atomicAdd(&P.totals[1], (unsigned long long)n_loci_called);
+            atomicAdd(&P.totals[2], (unsigned long long)n_callable);
+            atomicAdd(&P.totals[3], 1ull);
+        }
     }
     __syncthreads();
     if (survive) {

@@ -23,6 +23,8 @@ static thread_local std::string g_create_error;
 
 namespace {
 
+constexpr int64_t kTimingRing = 4096;
+
 struct BlockObs {
     std::vector<int32_t> pos;
     std::vector<uint32_t> tup;
@@ -60,6 +62,11 @@ struct PiscesHip {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    // per-launch timing window (pisces_hip_set_timing / pisces_hip_kernel_time)
+    std::vector<hipEvent_t> ring;   // pairs: [2i] start, [2i+1] stop
+    bool timing = false;
+    int64_t ring_used = 0;
+    DeviceBuf<unsigned long long> d_totals;
     std::string err;
 
     DeviceBuf<uint8_t> d_ref;
@@ -138,6 +145,7 @@ static DeviceParams make_params(const PiscesHipConfig& c)
     // StrandBiasCalculator.cs:32: Math.Pow(10, -1*qNoise/10f), int / float -> float exponent
     P.err_sb = std::pow(10.0, (double)((float)(-1 * c.noise_level) / 10.0f));
     P.ln10 = std::log(10.0);
+    P.totals = nullptr;
     return P;
 }
 
@@ -179,6 +187,8 @@ int32_t pisces_hip_default_config(PiscesHipConfig* c)
     return PISCES_OK;
 }
 
+int32_t pisces_hip_destroy(PiscesHip* h);
+
 int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip** out)
 {
     if (!cfg || !out) return fail(nullptr, PISCES_E_INVALID_ARG, "pisces_hip_create: null argument");
@@ -207,6 +217,13 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         delete h;
         return PISCES_E_DEVICE;
     }
+    if ((e = h->d_totals.reserve(4)) != hipSuccess || (e = hipMemsetAsync(h->d_totals.p, 0, 4 * sizeof(unsigned long long), h->stream)) != hipSuccess ||
+        (e = hipStreamSynchronize(h->stream)) != hipSuccess) {
+        g_create_error = std::string("pisces_hip_create: ") + hipGetErrorString(e);
+        pisces_hip_destroy(h);
+        return PISCES_E_DEVICE;
+    }
+    h->P.totals = h->d_totals.p;
     *out = h;
     return PISCES_OK;
 }
@@ -217,7 +234,8 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_ref.release(); h->d_tuples.release(); h->d_tiles.release(); h->d_tile_results.release();
-    h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release();
+    h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release(); h->d_totals.release();
+    for (hipEvent_t ev : h->ring) (void)hipEventDestroy(ev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -622,11 +640,18 @@ int32_t pisces_hip_call_tiles(PiscesHip* h, const uint32_t* d_tuples, const Pisc
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     PISCES_HIP_CHECK(h, hipMemsetAsync(d_record_count, 0, sizeof(int32_t), s));
-    PISCES_HIP_CHECK(h, hipEventRecord(h->ev0, s));
+    hipEvent_t e0 = h->ev0, e1 = h->ev1;
+    if (h->timing) {
+        const size_t slot = (size_t)(h->ring_used % kTimingRing);
+        e0 = h->ring[2 * slot];
+        e1 = h->ring[2 * slot + 1];
+        h->ring_used++;
+    }
+    PISCES_HIP_CHECK(h, hipEventRecord(e0, s));
     if (n_tiles > 0)
         hipLaunchKernelGGL(call_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, d_tuples, d_tiles, n_tiles, d_ref_bases,
                            ref_start_position, ref_length, d_records, record_capacity, d_record_count, d_tile_results, h->P);
-    PISCES_HIP_CHECK(h, hipEventRecord(h->ev1, s));
+    PISCES_HIP_CHECK(h, hipEventRecord(e1, s));
     PISCES_HIP_CHECK(h, hipGetLastError());
     h->timed = true;
     return PISCES_OK;
@@ -650,6 +675,48 @@ int32_t pisces_hip_accumulate_tiles(PiscesHip* h, const uint32_t* d_tuples, cons
     return PISCES_OK;
 }
 
+int32_t pisces_hip_device_totals(PiscesHip* h, int64_t out[4], int32_t reset)
+{
+    if (!h || !out) return PISCES_E_INVALID_ARG;
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    PISCES_HIP_CHECK(h, hipDeviceSynchronize());   // launches may sit on caller-supplied streams
+    unsigned long long host[4];
+    PISCES_HIP_CHECK(h, hipMemcpy(host, h->d_totals.p, sizeof(host), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; i++) out[i] = (int64_t)host[i];
+    if (reset) PISCES_HIP_CHECK(h, hipMemset(h->d_totals.p, 0, sizeof(host)));
+    return PISCES_OK;
+}
+
+int32_t pisces_hip_set_timing(PiscesHip* h, int32_t enable)
+{
+    if (!h) return PISCES_E_INVALID_ARG;
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    if (enable && h->ring.empty()) {
+        h->ring.resize((size_t)(2 * kTimingRing), nullptr);
+        for (auto& ev : h->ring) PISCES_HIP_CHECK(h, hipEventCreate(&ev));
+    }
+    h->timing = enable != 0;
+    h->ring_used = 0;
+    return PISCES_OK;
+}
+
+int32_t pisces_hip_kernel_time(PiscesHip* h, double* total_ms, int64_t* launches)
+{
+    if (!h || !total_ms || !launches) return PISCES_E_INVALID_ARG;
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    const int64_t n = std::min<int64_t>(h->ring_used, kTimingRing);
+    double sum = 0.0;
+    for (int64_t i = 0; i < n; i++) {
+        float ms = 0.f;
+        PISCES_HIP_CHECK(h, hipEventSynchronize(h->ring[(size_t)(2 * i + 1)]));
+        PISCES_HIP_CHECK(h, hipEventElapsedTime(&ms, h->ring[(size_t)(2 * i)], h->ring[(size_t)(2 * i + 1)]));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = n;
+    return PISCES_OK;
+}
+
 int32_t pisces_hip_synchronize(PiscesHip* h)
 {
     if (!h) return PISCES_E_INVALID_ARG;
@@ -661,7 +728,7 @@ int32_t pisces_hip_synchronize(PiscesHip* h)
 int32_t pisces_hip_last_kernel_ms(PiscesHip* h, float* ms)
 {
     if (!h || !ms) return PISCES_E_INVALID_ARG;
-    if (!h->timed) return fail(h, PISCES_E_STATE, "last_kernel_ms: no timed launch yet");
+    if (!h->timed || h->timing) return fail(h, PISCES_E_STATE, "last_kernel_ms: no timed launch yet (or a timing window is open: use kernel_time)");
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     PISCES_HIP_CHECK(h, hipEventSynchronize(h->ev1));
     PISCES_HIP_CHECK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));

@@ -131,6 +131,21 @@ class HipVariantCaller:
     def accumulate_tiles(self, d_tuples, d_tiles, n_tiles, d_counts, stream=None):
         _check(self._h, lib.pisces_hip_accumulate_tiles(self._h, d_tuples, d_tiles, n_tiles, d_counts, stream))
 
+    def device_totals(self, reset=False):
+        """{records, candidate_loci, called (IAlleleCaller.TotalNumCalled), tiles} summed over call_tiles launches."""
+        s = (C.c_int64 * 4)()
+        _check(self._h, lib.pisces_hip_device_totals(self._h, s, 1 if reset else 0))
+        return {"records": s[0], "candidate_loci": s[1], "called": s[2], "tiles": s[3]}
+
+    def set_timing(self, enable=True):
+        _check(self._h, lib.pisces_hip_set_timing(self._h, 1 if enable else 0))
+
+    def kernel_time(self):
+        """(total_ms, launches) of the kernels launched since set_timing(True), from HIP events on the launch stream."""
+        ms, n = C.c_double(0), C.c_int64(0)
+        _check(self._h, lib.pisces_hip_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def synchronize(self):
         _check(self._h, lib.pisces_hip_synchronize(self._h))
 
