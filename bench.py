@@ -105,16 +105,15 @@ def main():
         p.qual = p.qual if p is ring[0] else None
     torch.cuda.empty_cache()
     n_tiles = ring[0].n_tiles
-    cap = n_tiles * 64 * 2
+    cap = n_tiles * 256   # fixed 256-slot stride per tile: no allocation atomics, deterministic placement
     records = torch.zeros(cap * 64, dtype=torch.uint8, device=dev)
-    count = torch.zeros(1, dtype=torch.int32, device=dev)
     tile_results = torch.zeros(n_tiles * 16, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev)
 
     def step(i):
         p = ring[i % RING_BATCHES]
         caller.call_tiles(p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), 1, p.ref_len,
-                          records.data_ptr(), cap, count.data_ptr(), tile_results.data_ptr(), stream.cuda_stream)
+                          records.data_ptr(), cap, None, tile_results.data_ptr(), stream.cuda_stream)
 
     def barrier():
         if world > 1:
@@ -149,9 +148,8 @@ def main():
     caller.set_timing(False)
 
     # ---- sanity on the last step's output (outside the timed region) ----
-    n_rec_last = int(count.item())
     tr = tile_results.cpu().numpy().view(_abi.TILE_RESULT_DTYPE)
-    assert n_rec_last <= cap and int(tr["n_records"].sum()) == n_rec_last
+    assert int(tr["n_records"].sum()) * args.steps == totals["records"]
     assert int(tr["n_candidate_loci"].sum()) == args.loci, "every covered locus must be a candidate locus in gVCF mode"
 
     total_records, total_loci = int(summary[0].item()), int(summary[1].item())

@@ -253,8 +253,11 @@ int32_t pisces_hip_stats(PiscesHip* h, int64_t out[4]);
  * allele-count histogram -> coverage, Poisson q-score, strand bias, somatic genotype and
  * filters for the reference allele and every SNV candidate -> 64-byte records.
  * d_ref_bases[i] is the reference base of position ref_start_position+i.
- * d_record_count is an int32 device counter that the call resets and the kernel bumps;
- * d_tile_results[n_tiles] receives each tile's slice of d_records. Asynchronous. */
+ * d_tile_results[n_tiles] receives each tile's slice of d_records (record_begin, n_records).
+ * Record placement: d_record_count == NULL -> tile t owns the fixed slots [256*t, 256*t+256)
+ * (record_capacity >= 256*n_tiles; no atomics, bit-reproducible placement; the fast path);
+ * d_record_count != NULL -> compact buffer, slices handed out through that int32 device counter
+ * (reset by the call, one returning atomic per tile). Asynchronous. */
 int32_t pisces_hip_call_tiles(PiscesHip* h, const uint32_t* d_tuples, const PiscesTile* d_tiles,
                               int32_t n_tiles, const uint8_t* d_ref_bases, int32_t ref_start_position,
                               int64_t ref_length, PiscesCalledAllele* d_records, int32_t record_capacity,

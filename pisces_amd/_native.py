@@ -7,7 +7,8 @@ import os
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpisceship.so")
+# PISCES_HIP_LIB points at a development build of the same library (kernel experiments); default = in-tree product
+LIB_PATH = os.environ.get("PISCES_HIP_LIB") or os.path.join(_HERE, "libpisceship.so")
 
 EXPORTS = [
     "pisces_hip_abi_version", "pisces_hip_default_config", "pisces_hip_create", "pisces_hip_destroy",

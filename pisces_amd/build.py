@@ -28,7 +28,15 @@ def is_stale():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build_native(force=False, verbose=False, extra_flags=()):
+def build_native(force=False, verbose=False, extra_flags=(), out=None):
+    """out != None builds a development variant (e.g. an ablation) next to the product library."""
+    global LIB
+    if out is not None:
+        saved, LIB = LIB, out
+        try:
+            return build_native(force=True, verbose=verbose, extra_flags=extra_flags)
+        finally:
+            LIB = saved
     if not force and not is_stale():
         return LIB
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",

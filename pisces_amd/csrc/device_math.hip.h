@@ -25,6 +25,8 @@ struct DeviceParams {
     double err_sb;        // Math.Pow(10, -1*NL/10f) (float exponent)      StrandBiasCalculator.cs:32
     double ln10;          // Math.Log(10.0)
     unsigned long long* totals;  // device int64[4] running totals of the handle, or nullptr
+    const double* q_to_p_lut;    // MathOperations.QtoP(q) for integer q in [0, q_to_p_n), evaluated on the host
+    int32_t q_to_p_n;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -108,7 +110,28 @@ __device__ __forceinline__ double poisson_cdf(double num_occurrences, double exp
     return incomplete_gamma_function((double)(int)(num_occurrences + 1.0), expected);
 }
 
+// Same value as poisson_cdf, bit for bit, with an exact early-out for the dominant case of the strand-bias
+// statistics (a well-supported allele against the noise rate): when 2x <= a the series branch is taken and
+// converges (every ratio x/(a+i) < 1/2, so |del| < |sum|*1e-20 within 70 of the 300 iterations), its sum is
+// < 2/a <= 2, and lgamma(a) >= (a-1/2)ln a - a + ln sqrt(2 pi) (also true of the Lanczos / Stirling forms the
+// reference uses, to 1e-9).  So if E = a ln x - x - [(a-1/2)ln a - a + 0.9189385] < -40 the series value is
+// < 2e^(-39.9) < 2^-54 and the reference's `1.0 - g` rounds to exactly 1.0.
+__device__ inline double poisson_cdf_sb(double num_occurrences, double expected)
+{
+    const double a = (double)(int)(num_occurrences + 1.0), x = expected;
+    if (x > 0.0 && a >= 1.0 && 2.0 * x <= a) {
+        const double E = a * log(x) - x - ((a - 0.5) * log(a) - a + 0.9189385);
+        if (E < -40.0) return 1.0;
+    }
+    return incomplete_gamma_function(a, x);
+}
+
+
 __device__ __forceinline__ double q_to_p(double q) { return pow(10.0, -1 * q / 10.0); }  // MathOperations.cs:7
+__device__ __forceinline__ double q_to_p_int(int q, const DeviceParams& P)
+{
+    return (P.q_to_p_lut && q >= 0 && q < P.q_to_p_n) ? P.q_to_p_lut[q] : q_to_p((double)q);
+}
 __device__ __forceinline__ double p_to_q(double p) { return (-10 * log10(p)); }          // MathOperations.cs:12
 
 // ------------------------------------------------------------------------------------------
@@ -144,15 +167,18 @@ __device__ inline double mathnet_factorial_ln(int x)
     return mathnet_gamma_ln(x + 1.0);
 }
 
-__device__ inline double mathnet_gamma_lower_regularized(double a, double x)
+__device__ inline double mathnet_gamma_lower_regularized(double a, double x, double* gamma_ln_a)
 {
     const double epsilon = 0.000000000000001;
     const double big = 4503599627370496.0;
     const double bigInv = 2.22044604925031308085e-16;
+    *gamma_ln_a = __builtin_nan("");
     if (fabs(a) < 1e-15) return (fabs(x) < 1e-15) ? __builtin_nan("") : 1.0;
     if (fabs(x) < 1e-15) return 0.0;
 
-    double ax = (a * log(x)) - x - mathnet_gamma_ln(a);
+    const double gl = mathnet_gamma_ln(a);
+    *gamma_ln_a = gl;
+    double ax = (a * log(x)) - x - gl;
     if (ax < -709.78271289338399) return a < x ? 1.0 : 0.0;
 
     if (x <= 1 || x <= a) {
@@ -203,13 +229,15 @@ __device__ inline int32_t poisson_qscore(int32_t callCount, int32_t coverage, co
     double callCountDouble = callCount;
     double lambda = P.err_q * coverage;
     // Poisson.CumulativeDistribution(k-1) = 1 - GammaLowerRegularized(k, lambda)
-    double pValue = 1 - (1.0 - mathnet_gamma_lower_regularized(callCountMinusOne + 1, lambda));
+    double gamma_ln_k;   // GammaLn(k) from the CDF; FactorialLn(k-1) = GammaLn(k) is the same evaluation
+    double pValue = 1 - (1.0 - mathnet_gamma_lower_regularized(callCountMinusOne + 1, lambda, &gamma_ln_k));
     double rawQ;
     if (pValue > 0) {
         rawQ = p_to_q(pValue);
     } else {
         int k = (int)callCountMinusOne;
-        double A = -lambda + (k * log(lambda)) - mathnet_factorial_ln(k);  // Poisson.ProbabilityLn
+        const double fl = (k >= 171 && gamma_ln_k == gamma_ln_k) ? gamma_ln_k : mathnet_factorial_ln(k);
+        double A = -lambda + (k * log(lambda)) - fl;  // Poisson.ProbabilityLn
         double correction = (callCountDouble - lambda) / callCountDouble;
         rawQ = -10.0 * (A - log(2.0 * correction)) / P.ln10;
     }
@@ -239,7 +267,7 @@ __device__ inline SbStats sb_create_stats(double support, double coverage, doubl
             st.false_pos = 1 - st.var_gt_zero;
         }
     } else {
-        st.var_gt_zero = fmax(0.0, poisson_cdf(support - 1, coverage * noiseFreq));
+        st.var_gt_zero = fmax(0.0, poisson_cdf_sb(support - 1, coverage * noiseFreq));
         st.false_pos = fmax(0.0, 1 - st.var_gt_zero);
     }
     return st;

@@ -23,6 +23,9 @@ constexpr int kBlock = 256;
 constexpr int kTile = 64;                 // loci per tile: kTile * 4 allele lanes = one workgroup pass
 constexpr int kFolded = 18;               // 6 allele types x 3 directions (anchors folded)
 constexpr int kUnroll = 4;                // 16-byte loads in flight per lane
+constexpr int kSlotsPerTile = 4 * kTile;  // worst case: four alleles called at every locus
+constexpr int kTotalShards = 64;          // running-total shards (one 128-byte line each)
+constexpr int kTotalStride = 16;          // in 8-byte words
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // one dwordx4 load
 
@@ -92,100 +95,100 @@ __device__ __forceinline__ int block_exclusive_count(bool flag, int* wave_tot /*
     return off + before;
 }
 
-struct AlleleOut {
-    PiscesCalledAllele rec;
-    bool callable;
+// ---- the call phase: one lane per candidate allele ------------------------------------------
+// PMC showed the call phase VALU-issue-bound (FP64 at 4 cycles per wave-instruction), so the layout that
+// minimises wave-instructions wins: candidates compacted onto the low lanes, one lane runs one allele
+// start to finish, and everything that cannot change the output is skipped:
+//  * IsCallable (AlleleCaller.cs:236-258) tests coverage and frequency BEFORE the q-score, so a variant
+//    candidate below MinFrequency (every sequencing-error allele at depth) is rejected on integer/float32
+//    arithmetic alone, and one below MinVariantQscore right after its q-score; rejected alleles never reach
+//    the strand-bias / genotype math because their CalledAllele is dropped by the reference too;
+//  * the strand-bias tails of a well-supported allele are exactly 1.0 (poisson_cdf_sb).
+
+struct PointCounts {
+    int cov[3], sup[3];
+    int total, nocalls, refsup, support;
 };
 
-// AlleleCaller.ProcessVariant (AlleleCaller.cs:208-234) + AlleleProcessor.ApplyFilters
-// (AlleleProcessor.cs:25-71) + IsCallable (:236-258) + SomaticGenotyper (speculatively: genotype and
-// GQ of an allele depend only on its own numbers) for a point allele whose counts are h[6][3].
-__device__ inline AlleleOut process_point_allele(const int h[6][3], int position, int allele, bool isRef, int refType,
-                                                 int gappedMnvRef, const uint8_t* __restrict__ ref, int64_t win_lo,
-                                                 int64_t win_hi, const DeviceParams& P)
+// CoverageCalculator.CalculateSinglePoint (CoverageCalculator.cs:49-98) from the folded counts of one locus
+__device__ __forceinline__ PointCounts point_counts(const int* hist, int l, int allele, bool isRef, int refType, int gapped)
 {
-    AlleleOut o;
-    PiscesCalledAllele& r = o.rec;
-    // CoverageCalculator.CalculateSinglePoint (CoverageCalculator.cs:49-98)
-    int cov[3], sup[3];
-    int total = 0, nocalls = 0, refsup = 0;
+    PointCounts c;
+    int h[6][3];
+#pragma unroll
+    for (int k = 0; k < kFolded; k++) h[k / 3][k % 3] = hist[k * kTile + l];
+    c.total = 0; c.nocalls = 0; c.refsup = 0;
     const int supAllele = isRef ? refType : allele;
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-        cov[d] = h[PISCES_ALLELE_A][d] + h[PISCES_ALLELE_C][d] + h[PISCES_ALLELE_G][d] + h[PISCES_ALLELE_T][d] +
-                 h[PISCES_ALLELE_DEL][d];
-        total += cov[d];
-        nocalls += h[PISCES_ALLELE_N][d];
-        sup[d] = 0;
+        c.cov[d] = h[PISCES_ALLELE_A][d] + h[PISCES_ALLELE_C][d] + h[PISCES_ALLELE_G][d] + h[PISCES_ALLELE_T][d] +
+                   h[PISCES_ALLELE_DEL][d];
+        c.total += c.cov[d];
+        c.nocalls += h[PISCES_ALLELE_N][d];
+        c.sup[d] = 0;
     }
 #pragma unroll
     for (int a = 0; a < 6; a++) {
-        if (a == refType && a < PISCES_ALLELE_N) refsup += h[a][0] + h[a][1] + h[a][2];
-        if (a == supAllele) { sup[0] = h[a][0]; sup[1] = h[a][1]; sup[2] = h[a][2]; }
+        if (a == refType && a < PISCES_ALLELE_N) c.refsup += h[a][0] + h[a][1] + h[a][2];
+        if (a == supAllele) { c.sup[0] = h[a][0]; c.sup[1] = h[a][1]; c.sup[2] = h[a][2]; }
     }
-    int support = sup[0] + sup[1] + sup[2];  // AlleleHelper.Map: AlleleSupport = candidate.Support
-    if (isRef) { support -= gappedMnvRef; if (support < 0) support = 0; }        // :94-97
-    else { refsup -= gappedMnvRef; if (refsup < 0) refsup = 0; }                 // :90-93
+    c.support = c.sup[0] + c.sup[1] + c.sup[2];   // AlleleHelper.Map: AlleleSupport = candidate.Support
+    if (isRef) { c.support -= gapped; if (c.support < 0) c.support = 0; }    // CoverageCalculator.cs:94-97
+    else { c.refsup -= gapped; if (c.refsup < 0) c.refsup = 0; }             // :90-93
+    return c;
+}
 
+// AlleleCaller.ProcessVariant (AlleleCaller.cs:208-234) + AlleleProcessor.ApplyFilters (AlleleProcessor.cs:25-71)
+// + IsCallable + SomaticGenotyper for one point allele. Returns false (record untouched) when the reference
+// would drop the allele.
+__device__ inline bool process_point_allele(const PointCounts& c, int pos, int a, bool isRef, int rt,
+                                             const uint8_t* __restrict__ ref, int64_t win_lo, int64_t win_hi,
+                                             const DeviceParams& P, PiscesCalledAllele& r)
+{
+    const float freq = frequency_f(c.support, c.total);
+    if (!isRef) {   // IsCallable, the tests that precede the q-score
+        if (c.total < P.min_cov && !P.include_ref) return false;
+        if (c.total != 0 && freq < P.min_freq) return false;
+    }
     int vq = 0;
-    SbResult sb = {0.0, 0, 0, 0};
-    if (support > 0) {
-        vq = (total == 0) ? 0 : poisson_qscore(support, total, P);   // VariantQualityCalculator.Compute :11-24
-        sb = strand_bias(cov, sup, P);                               // StrandBiasCalculator.Compute :10-15
-    }
-    const float freq = frequency_f(support, total);
-    // SetFractionNoCalls (CalledAllele.cs:107-114)
-    const float allReads = (float)(total + nocalls);
-    const float fractionNoCalls = (allReads == 0.0f) ? 0.0f : ((float)nocalls / allReads);
+    if (c.support > 0 && c.total != 0) vq = poisson_qscore(c.support, c.total, P);   // VariantQualityCalculator.Compute :11-24
+    if (!isRef && vq < P.min_vq) return false;
 
+    SbResult sb = {0.0, 0, 0, 0};
+    if (c.support > 0) sb = strand_bias(c.cov, c.sup, P);                            // StrandBiasCalculator.Compute :10-15
+
+    // SetFractionNoCalls (CalledAllele.cs:107-114) + ApplyFilters
+    const float allReads = (float)(c.total + c.nocalls);
+    const float fractionNoCalls = (allReads == 0.0f) ? 0.0f : ((float)c.nocalls / allReads);
     uint32_t filters = 0;
-    if (P.low_depth_filter >= 0 && total < P.low_depth_filter) filters |= 1u << PISCES_FILTER_LOW_DEPTH;
-    if (P.vq_filter >= 0 && vq < P.vq_filter && total != 0) filters |= 1u << PISCES_FILTER_LOW_VARIANT_QSCORE;
+    if (P.low_depth_filter >= 0 && c.total < P.low_depth_filter) filters |= 1u << PISCES_FILTER_LOW_DEPTH;
+    if (P.vq_filter >= 0 && vq < P.vq_filter && c.total != 0) filters |= 1u << PISCES_FILTER_LOW_VARIANT_QSCORE;
     if (!isRef) {
         if (P.nocall_thr >= 0.0f && fractionNoCalls > P.nocall_thr) filters |= 1u << PISCES_FILTER_NO_CALL;
         if (!sb.acceptable || (P.filter_single_strand && !sb.var_both)) filters |= 1u << PISCES_FILTER_STRAND_BIAS;
         const uint8_t bases[4] = {'A', 'G', 'C', 'T'};
-        if (refType < 4 && allele < 4 &&
-            rmxn_should_filter_snv(ref, win_lo, win_hi, position, bases[refType], bases[allele], freq, P))
+        if (rt < 4 && a < 4 && rmxn_should_filter_snv(ref, win_lo, win_hi, pos, bases[rt], bases[a], freq, P))
             filters |= 1u << PISCES_FILTER_RMXN;
         if (P.vf_filter >= 0.0f && freq < P.vf_filter) filters |= 1u << PISCES_FILTER_LOW_VARIANT_FREQUENCY;
     }
-
-    // IsCallable (AlleleCaller.cs:236-258)
-    bool callable = true;
-    if (!isRef) {
-        if (total < P.min_cov && !P.include_ref) callable = false;
-        else if (total != 0 && freq < P.min_freq) callable = false;
-        else if (vq < P.min_vq) callable = false;
-    }
-    o.callable = callable;
-
-    int gt = somatic_genotype(isRef, total, support, refsup, P);
-    int gq = somatic_gq(gt, vq, total, support, P);
+    const int gt = somatic_genotype(isRef, c.total, c.support, c.refsup, P);
+    const int gq = somatic_gq(gt, vq, c.total, c.support, P);
     if (P.low_gq_filter >= 0 && (float)gq < (float)P.low_gq_filter) filters |= 1u << PISCES_FILTER_LOW_GENOTYPE_QUALITY;
 
-    r.position = position;
-    r.total_coverage = total;
-    r.allele_support = support;
-    r.reference_support = refsup;
-    r.num_no_calls = nocalls;
-    r.coverage_by_dir[0] = cov[0]; r.coverage_by_dir[1] = cov[1]; r.coverage_by_dir[2] = cov[2];
-    r.support_by_dir[0] = sup[0]; r.support_by_dir[1] = sup[1]; r.support_by_dir[2] = sup[2];
+    r.position = pos;
+    r.total_coverage = c.total;
+    r.allele_support = c.support;
+    r.reference_support = c.refsup;
+    r.num_no_calls = c.nocalls;
+    r.coverage_by_dir[0] = c.cov[0]; r.coverage_by_dir[1] = c.cov[1]; r.coverage_by_dir[2] = c.cov[2];
+    r.support_by_dir[0] = c.sup[0]; r.support_by_dir[1] = c.sup[1]; r.support_by_dir[2] = c.sup[2];
     r.variant_qscore = vq;
     r.strand_bias_score = sb.bias_score;
     r.genotype_qscore = gq;
     r.filter_bits = (uint16_t)filters;
-    r.info = PISCES_INFO_PACK(gt, isRef ? PISCES_CAT_REFERENCE : PISCES_CAT_SNV, refType, isRef ? refType : allele,
-                              sb.acceptable, sb.var_both, sb.cov_both);
-    return o;
-}
-
-__device__ __forceinline__ void store_record(PiscesCalledAllele* __restrict__ dst, const PiscesCalledAllele& r)
-{
-    // 64-byte record = 4 x dwordx4
-    const uint4* s = reinterpret_cast<const uint4*>(&r);
-    uint4* d = reinterpret_cast<uint4*>(dst);
-    d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
+    r.info = PISCES_INFO_PACK(gt, isRef ? PISCES_CAT_REFERENCE : PISCES_CAT_SNV, rt, isRef ? rt : a, sb.acceptable, sb.var_both,
+                              sb.cov_both);
+    return true;
 }
 
 // The call phase for one tile whose folded counts sit in LDS (hist[(allele*3+dir)*kTile + locus]).
@@ -194,9 +197,9 @@ __device__ __forceinline__ void store_record(PiscesCalledAllele* __restrict__ ds
 //   SNV candidate                     — a quality-passing base != reference base, ref and read not N
 //                                       (CandidateVariantFinder.cs:97-160 with callMNVs off; its
 //                                       SupportByDirection equals the allele count by direction)
-// candidates are compacted onto the low threads, processed one lane each, then the per-locus rule
-// "drop the Reference allele when a variant is called" (AlleleCaller.cs:146-147) and the output
-// order (position, then allele) are applied and the records written to HBM.
+// candidates are compacted onto the low threads (at most 4*kTile = kBlock of them), processed one lane each,
+// then the per-locus rule "drop the Reference allele when a variant is called" (AlleleCaller.cs:146-147)
+// and the output order (position, then allele) are applied and the records written to HBM.
 __device__ inline void call_phase(const int* hist, const uint32_t* gapped /* LDS[kTile] or nullptr */,
                                   const PiscesTile& tile, const uint8_t* __restrict__ ref, int32_t ref_start,
                                   int64_t ref_len, PiscesCalledAllele* __restrict__ records, int32_t capacity,
@@ -204,34 +207,34 @@ __device__ inline void call_phase(const int* hist, const uint32_t* gapped /* LDS
                                   const DeviceParams& P, int* s_wave, uint8_t* s_work, uint8_t* s_callable, int* s_base)
 {
     const int tid = threadIdx.x;
-    const int locus = tid >> 2, rank = tid & 3;
-    const int allele = allele_of_rank(rank);
-    const int position = tile.start_position + locus;
-    const int64_t ridx = (int64_t)position - ref_start;   // index into the resident reference window
-    const bool in_ref = locus < tile.n_loci && ridx >= 0 && ridx < ref_len;
-    const int refType = in_ref ? allele_type_of_base(ref[ridx]) : PISCES_ALLELE_N;
-
-    bool is_work = false;
-    if (in_ref) {
-        int mine = 0, all = 0;
-#pragma unroll
-        for (int c = 0; c < kFolded; c++) {
-            int v = hist[c * kTile + locus];
-            all += v;
-            if (c / 3 == allele) mine += v;
-        }
-        const bool refLane = (refType < 4) ? (allele == refType) : (rank == 0);
-        if (refLane) is_work = P.include_ref && (P.emit_zero_cov || all > 0);
-        else is_work = (refType < 4) && mine > 0;
-    }
     int n_work;
-    int slot = block_exclusive_count(is_work, s_wave, &n_work);
-    if (is_work) s_work[slot] = (uint8_t)tid;
-    s_callable[tid] = 0;
+    {
+        const int locus = tid >> 2, rank = tid & 3;
+        const int allele = allele_of_rank(rank);
+        const int64_t ridx = (int64_t)tile.start_position + locus - ref_start;   // index into the reference window
+        const bool in_ref = locus < tile.n_loci && ridx >= 0 && ridx < ref_len;
+        const int refType = in_ref ? allele_type_of_base(ref[ridx]) : PISCES_ALLELE_N;
+        bool is_work = false;
+        if (in_ref) {
+            int mine = 0, all = 0;
+#pragma unroll
+            for (int c = 0; c < kFolded; c++) {
+                int v = hist[c * kTile + locus];
+                all += v;
+                if (c / 3 == allele) mine += v;
+            }
+            const bool refLane = (refType < 4) ? (allele == refType) : (rank == 0);
+            if (refLane) is_work = P.include_ref && (P.emit_zero_cov || all > 0);
+            else is_work = (refType < 4) && mine > 0;
+        }
+        int slot = block_exclusive_count(is_work, s_wave, &n_work);
+        if (is_work) s_work[slot] = (uint8_t)tid;
+        s_callable[tid] = 0;
+    }
     __syncthreads();
 
-    AlleleOut out;
-    out.callable = false;
+    PiscesCalledAllele rec;
+    bool callable = false;
     int item = 0;
     bool item_is_ref = false;
     if (tid < n_work) {
@@ -241,40 +244,36 @@ __device__ inline void call_phase(const int* hist, const uint32_t* gapped /* LDS
         const int pos = tile.start_position + l;
         const int rt = allele_type_of_base(ref[(int64_t)pos - ref_start]);
         item_is_ref = (rt < 4) ? (a == rt) : true;
-        int h[6][3];
-#pragma unroll
-        for (int c = 0; c < kFolded; c++) h[c / 3][c % 3] = hist[c * kTile + l];
-        const int g = gapped ? (int)gapped[l] : 0;
-        out = process_point_allele(h, pos, a, item_is_ref, rt, g, ref, (int64_t)ref_start - 1,
-                                   (int64_t)ref_start - 1 + ref_len, P);
-        if (out.callable) s_callable[item] = item_is_ref ? 1 : 2;
+        const PointCounts c = point_counts(hist, l, a, item_is_ref, rt, gapped ? (int)gapped[l] : 0);
+        callable = process_point_allele(c, pos, a, item_is_ref, rt, ref, (int64_t)ref_start - 1,
+                                        (int64_t)ref_start - 1 + ref_len, P, rec);
+        if (callable) s_callable[item] = item_is_ref ? 1 : 2;
     }
     __syncthreads();
 
-    bool survive = false;
-    bool first_of_locus = false;
-    if (tid < n_work && out.callable) {
+    bool survive = false, first_of_locus = false;
+    if (callable) {
         const int q = item & ~3;
         const bool any_variant = (s_callable[q] | s_callable[q + 1] | s_callable[q + 2] | s_callable[q + 3]) & 2;
         survive = !(item_is_ref && any_variant);
         if (survive) {
-            // first surviving allele of this locus (for the candidate-locus count)
-            bool earlier = false;
+            bool earlier = false;   // an earlier surviving allele at this locus?
             for (int k = 0; k < (item & 3); k++) {
-                uint8_t c = s_callable[q + k];
-                if (c == 2 || (c == 1 && !any_variant)) earlier = true;
+                uint8_t cc = s_callable[q + k];
+                if (cc == 2 || (cc == 1 && !any_variant)) earlier = true;
             }
             first_of_locus = !earlier;
         }
     }
-    int n_callable;
-    (void)block_exclusive_count(tid < n_work && out.callable, s_wave, &n_callable);
-    int n_loci_called;
+    int n_callable, n_loci_called, n_surv;
+    (void)block_exclusive_count(callable, s_wave, &n_callable);
     (void)block_exclusive_count(first_of_locus, s_wave, &n_loci_called);
-    int n_surv;
     const int idx = block_exclusive_count(survive, s_wave, &n_surv);
     if (tid == 0) {
-        int base = n_surv > 0 ? atomicAdd(record_count, n_surv) : 0;
+        // record placement: fixed 256-slot stride per tile (no atomics, deterministic), or — when the caller
+        // wants a compact buffer — one returning atomic per tile on a shared counter (same-address global
+        // atomics serialize in L2 at ~12 ns each: measurable at thousands of tiles per launch)
+        int base = record_count ? (n_surv > 0 ? atomicAdd(record_count, n_surv) : 0) : (int)blockIdx.x * kSlotsPerTile;
         *s_base = base;
         PiscesTileResult tr;
         tr.record_begin = base;
@@ -283,16 +282,22 @@ __device__ inline void call_phase(const int* hist, const uint32_t* gapped /* LDS
         tr.reserved = n_callable;   // IsCallable == true count (IAlleleCaller.TotalNumCalled)
         *tile_result = tr;
         if (P.totals) {
-            atomicAdd(&P.totals[0], (unsigned long long)n_surv);
-            atomicAdd(&P.totals[1], (unsigned long long)n_loci_called);
-            atomicAdd(&P.totals[2], (unsigned long long)n_callable);
-            atomicAdd(&P.totals[3], 1ull);
+            // running totals, sharded over kTotalShards cache lines so the adds do not serialize on one L2 line
+            unsigned long long* tt = P.totals + (size_t)(blockIdx.x % kTotalShards) * kTotalStride;
+            atomicAdd(&tt[0], (unsigned long long)n_surv);
+            atomicAdd(&tt[1], (unsigned long long)n_loci_called);
+            atomicAdd(&tt[2], (unsigned long long)n_callable);
+            atomicAdd(&tt[3], 1ull);
         }
     }
     __syncthreads();
     if (survive) {
         const int64_t dst = (int64_t)(*s_base) + idx;
-        if (dst < capacity) store_record(&records[dst], out.rec);
+        if (dst < capacity) {
+            const uint4* sp = reinterpret_cast<const uint4*>(&rec);
+            uint4* dp = reinterpret_cast<uint4*>(&records[dst]);
+            dp[0] = sp[0]; dp[1] = sp[1]; dp[2] = sp[2]; dp[3] = sp[3];
+        }
     }
 }
 
@@ -316,12 +321,23 @@ __global__ __launch_bounds__(kBlock) void call_tiles_kernel(
     __syncthreads();
 
     const uint32_t n_loci = (uint32_t)tile.n_loci, min_bq = (uint32_t)P.min_bq;
+#if defined(PISCES_ABLATE) && PISCES_ABLATE == 2
+    // development ablation: loads only (no LDS atomics, no call phase)
+    uint32_t acc = 0;
+    stream_tuples(tuples, tile.tuple_begin, tile.tuple_end, [&](uint32_t v) { acc ^= v; });
+    if (acc == 0x12345u) hist[threadIdx.x] = (int)(n_loci + min_bq);
+#else
     stream_tuples(tuples, tile.tuple_begin, tile.tuple_end,
                   [&](uint32_t v) { accumulate_folded(hist, v, n_loci, min_bq); });
+#endif
     __syncthreads();
-
+#if defined(PISCES_ABLATE) && PISCES_ABLATE >= 1
+    // development ablation: no call phase
+    if (threadIdx.x == 0) { PiscesTileResult tr = {0, 0, hist[5], 0}; tile_results[t] = tr; }
+#else
     call_phase(hist, nullptr, tile, ref, ref_start, ref_len, records, capacity, record_count, &tile_results[t], P,
                s_wave, s_work, s_callable, &s_base);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

@@ -67,6 +67,7 @@ struct PiscesHip {
     bool timing = false;
     int64_t ring_used = 0;
     DeviceBuf<unsigned long long> d_totals;
+    DeviceBuf<double> d_qlut;
     std::string err;
 
     DeviceBuf<uint8_t> d_ref;
@@ -146,6 +147,8 @@ static DeviceParams make_params(const PiscesHipConfig& c)
     P.err_sb = std::pow(10.0, (double)((float)(-1 * c.noise_level) / 10.0f));
     P.ln10 = std::log(10.0);
     P.totals = nullptr;
+    P.q_to_p_lut = nullptr;
+    P.q_to_p_n = 0;
     return P;
 }
 
@@ -217,13 +220,28 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         delete h;
         return PISCES_E_DEVICE;
     }
-    if ((e = h->d_totals.reserve(4)) != hipSuccess || (e = hipMemsetAsync(h->d_totals.p, 0, 4 * sizeof(unsigned long long), h->stream)) != hipSuccess ||
+    if ((e = h->d_totals.reserve((size_t)kTotalShards * kTotalStride)) != hipSuccess ||
+        (e = hipMemsetAsync(h->d_totals.p, 0, (size_t)kTotalShards * kTotalStride * sizeof(unsigned long long), h->stream)) != hipSuccess ||
         (e = hipStreamSynchronize(h->stream)) != hipSuccess) {
         g_create_error = std::string("pisces_hip_create: ") + hipGetErrorString(e);
         pisces_hip_destroy(h);
         return PISCES_E_DEVICE;
     }
     h->P.totals = h->d_totals.p;
+    {
+        // MathOperations.QtoP(q) = Math.Pow(10, -1 * q / 10f) for every integer q-score the caller can produce
+        const int n = std::min(std::max(h->cfg.max_variant_qscore, 0), 4095) + 1;
+        std::vector<double> lut((size_t)n);
+        for (int q = 0; q < n; q++) lut[(size_t)q] = std::pow(10.0, -1 * (double)q / 10.0);
+        if ((e = h->d_qlut.reserve((size_t)n)) != hipSuccess ||
+            (e = hipMemcpy(h->d_qlut.p, lut.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) {
+            g_create_error = std::string("pisces_hip_create: ") + hipGetErrorString(e);
+            pisces_hip_destroy(h);
+            return PISCES_E_DEVICE;
+        }
+        h->P.q_to_p_lut = h->d_qlut.p;
+        h->P.q_to_p_n = n;
+    }
     *out = h;
     return PISCES_OK;
 }
@@ -234,7 +252,7 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_ref.release(); h->d_tuples.release(); h->d_tiles.release(); h->d_tile_results.release();
-    h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release(); h->d_totals.release();
+    h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release(); h->d_totals.release(); h->d_qlut.release();
     for (hipEvent_t ev : h->ring) (void)hipEventDestroy(ev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -456,9 +474,8 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
     const int32_t n_tiles = (int32_t)tiles.size();
     int32_t rc = upload_tiles(h, tiles, tuples);
     if (rc) return rc;
-    const size_t cap = (size_t)n_tiles * kTile * 4;   // worst case: 4 alleles at every locus
+    const size_t cap = (size_t)n_tiles * kSlotsPerTile;   // strided record layout: 256 slots per tile
     PISCES_HIP_CHECK(h, h->d_records.reserve(cap));
-    PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_count.p, 0, sizeof(int32_t), h->stream));
 
     bool use_counts = false;
     for (auto& kv : h->gapped_mnv_ref)
@@ -466,7 +483,7 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
 
     if (!use_counts) {
         hipLaunchKernelGGL(call_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles,
-                           h->d_ref.p, 1, h->ref_len, h->d_records.p, (int32_t)cap, h->d_count.p, h->d_tile_results.p, h->P);
+                           h->d_ref.p, 1, h->ref_len, h->d_records.p, (int32_t)cap, (int32_t*)nullptr, h->d_tile_results.p, h->P);
     } else {
         // counts in HBM + AddGappedMnvRefCount adjustments (CoverageCalculator.cs:82-97)
         const size_t nc = (size_t)n_tiles * kTile * PISCES_COUNTS_PER_LOCUS;
@@ -483,29 +500,30 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
         hipLaunchKernelGGL(accumulate_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->d_tuples.p, h->d_tiles.p,
                            n_tiles, h->d_counts.p, h->cfg.min_base_call_quality);
         hipLaunchKernelGGL(call_counts_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->d_counts.p, h->d_gapped.p,
-                           h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p, (int32_t)cap, h->d_count.p,
+                           h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p, (int32_t)cap, (int32_t*)nullptr,
                            h->d_tile_results.p, h->P);
         PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // g must outlive the copy
     }
     PISCES_HIP_CHECK(h, hipGetLastError());
     std::vector<PiscesTileResult> tr((size_t)n_tiles);
-    int32_t total = 0;
     PISCES_HIP_CHECK(h, hipMemcpyAsync(tr.data(), h->d_tile_results.p, tr.size() * sizeof(PiscesTileResult), hipMemcpyDeviceToHost, h->stream));
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(&total, h->d_count.p, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
-    if ((size_t)total > cap) return fail(h, PISCES_E_DEVICE, "flush: record buffer overflow (internal)");
-    std::vector<PiscesCalledAllele> raw((size_t)total);
-    if (total > 0) {
-        PISCES_HIP_CHECK(h, hipMemcpyAsync(raw.data(), h->d_records.p, raw.size() * sizeof(PiscesCalledAllele), hipMemcpyDeviceToHost, h->stream));
-        PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
-    }
-    // tiles were built in ascending position order; records inside a tile are already sorted
-    out.reserve((size_t)total);
+    // tiles were built in ascending position order; records inside a tile are already sorted, so the
+    // tile-ordered gather is the (position, ref, alt) order of AlleleCaller.Call
+    size_t total = 0;
+    for (auto& r : tr) total += (size_t)r.n_records;
+    out.resize(total);
+    size_t w = 0;
     for (int32_t t = 0; t < n_tiles; t++) {
         const PiscesTileResult& r = tr[(size_t)t];
         *n_called += r.reserved;
-        for (int32_t i = 0; i < r.n_records; i++) out.push_back(raw[(size_t)r.record_begin + (size_t)i]);
+        if (r.n_records > 0) {
+            PISCES_HIP_CHECK(h, hipMemcpyAsync(out.data() + w, h->d_records.p + r.record_begin,
+                                               (size_t)r.n_records * sizeof(PiscesCalledAllele), hipMemcpyDeviceToHost, h->stream));
+            w += (size_t)r.n_records;
+        }
     }
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     return PISCES_OK;
 }
 
@@ -635,11 +653,13 @@ int32_t pisces_hip_call_tiles(PiscesHip* h, const uint32_t* d_tuples, const Pisc
 {
     if (!h) return PISCES_E_INVALID_ARG;
     if (n_tiles < 0 || record_capacity < 0 || ref_length < 0) return fail(h, PISCES_E_INVALID_ARG, "call_tiles: negative size");
-    if (n_tiles > 0 && (!d_tiles || !d_ref_bases || !d_records || !d_record_count || !d_tile_results))
+    if (n_tiles > 0 && (!d_tiles || !d_ref_bases || !d_records || !d_tile_results))
         return fail(h, PISCES_E_INVALID_ARG, "call_tiles: null device pointer");
+    if (!d_record_count && (int64_t)record_capacity < (int64_t)n_tiles * kSlotsPerTile)
+        return fail(h, PISCES_E_BUFFER_TOO_SMALL, "call_tiles: strided record layout needs record_capacity >= 256 * n_tiles");
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-    PISCES_HIP_CHECK(h, hipMemsetAsync(d_record_count, 0, sizeof(int32_t), s));
+    if (d_record_count) PISCES_HIP_CHECK(h, hipMemsetAsync(d_record_count, 0, sizeof(int32_t), s));
     hipEvent_t e0 = h->ev0, e1 = h->ev1;
     if (h->timing) {
         const size_t slot = (size_t)(h->ring_used % kTimingRing);
@@ -680,9 +700,12 @@ int32_t pisces_hip_device_totals(PiscesHip* h, int64_t out[4], int32_t reset)
     if (!h || !out) return PISCES_E_INVALID_ARG;
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     PISCES_HIP_CHECK(h, hipDeviceSynchronize());   // launches may sit on caller-supplied streams
-    unsigned long long host[4];
+    unsigned long long host[kTotalShards * kTotalStride];
     PISCES_HIP_CHECK(h, hipMemcpy(host, h->d_totals.p, sizeof(host), hipMemcpyDeviceToHost));
-    for (int i = 0; i < 4; i++) out[i] = (int64_t)host[i];
+    for (int i = 0; i < 4; i++) {
+        out[i] = 0;
+        for (int sh = 0; sh < kTotalShards; sh++) out[i] += (int64_t)host[sh * kTotalStride + i];
+    }
     if (reset) PISCES_HIP_CHECK(h, hipMemset(h->d_totals.p, 0, sizeof(host)));
     return PISCES_OK;
 }

@@ -41,23 +41,31 @@ def torch_cuda():
     return torch
 
 
-def run_fused(torch, caller, p, capacity=None):
-    """One pisces_hip_call_tiles launch on device-resident buffers; returns records in tile order."""
+def run_fused(torch, caller, p, compact=False):
+    """One pisces_hip_call_tiles launch on device-resident buffers; returns records in tile order.
+    compact=False: fixed 256-slot stride per tile (no atomics); compact=True: atomic slice allocation."""
     dev = p.tuples.device
-    cap = capacity or p.n_tiles * 64 * 4
+    cap = p.n_tiles * 256
     recs = torch.zeros(cap * 64, dtype=torch.uint8, device=dev)
     count = torch.zeros(1, dtype=torch.int32, device=dev)
     tres = torch.zeros(p.n_tiles * 16, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     caller.call_tiles(p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), 1, p.ref_len,
-                      recs.data_ptr(), cap, count.data_ptr(), tres.data_ptr(), stream)
+                      recs.data_ptr(), cap, count.data_ptr() if compact else None, tres.data_ptr(), stream)
     torch.cuda.synchronize()
-    n = int(count.item())
     tr = tres.cpu().numpy().view(_abi.TILE_RESULT_DTYPE)
     raw = recs.cpu().numpy().view(_abi.CALLED_ALLELE_DTYPE)
-    assert n <= cap
     out = np.concatenate([raw[r["record_begin"]: r["record_begin"] + r["n_records"]] for r in tr]) if len(tr) else raw[:0]
-    assert len(out) == n
+    if compact:
+        assert len(out) == int(count.item())
+        assert sorted(tr["record_begin"][tr["n_records"] > 0].tolist()) == \
+            np.cumsum(np.r_[0, np.sort(tr["n_records"][tr["n_records"] > 0])])[:0].tolist() or True
+        # slices tile the compact buffer exactly
+        order = np.argsort(tr["record_begin"], kind="stable")
+        nz = tr[order][tr[order]["n_records"] > 0]
+        assert (nz["record_begin"][1:] == nz["record_begin"][:-1] + nz["n_records"][:-1]).all()
+    else:
+        assert (tr["record_begin"] == np.arange(len(tr)) * 256).all()
     return out, tr
 
 
@@ -69,10 +77,14 @@ def test_fused_kernel_matches_oracle_on_synthetic_pileups(torch_cuda, n_loci, de
     cfg = _abi.default_config()
     with engine.HipVariantCaller(cfg) as caller:
         got, tr = run_fused(torch, caller, p)
+        got_c, tr_c = run_fused(torch, caller, p, compact=True)
+        totals = caller.device_totals()
     pos, tup = synth.observations_of(p)
     exp, nloci = orc.run_observations(pos, tup, p.ref.cpu().numpy(), p.region_start, p.n_loci, cfg)
     assert_records_match(got, exp)
+    assert got.tobytes() == got_c.tobytes()
     assert int(tr["n_candidate_loci"].sum()) == nloci
+    assert totals["records"] == 2 * len(exp) and totals["candidate_loci"] == 2 * nloci and totals["tiles"] == 2 * p.n_tiles
 
 
 @pytest.mark.parametrize("overrides", [
