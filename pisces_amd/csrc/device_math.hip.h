@@ -120,8 +120,9 @@ __device__ inline double poisson_cdf_sb(double num_occurrences, double expected)
 {
     const double a = (double)(int)(num_occurrences + 1.0), x = expected;
     if (x > 0.0 && a >= 1.0 && 2.0 * x <= a) {
-        const double E = a * log(x) - x - ((a - 0.5) * log(a) - a + 0.9189385);
-        if (E < -40.0) return 1.0;
+        // E = -a ln(a/x) + a - x + ln(a)/2 - 0.9189..., and ln(a)/2 < 10.75 for any int32 count:
+        // one logarithm decides E < -40
+        if (a * (log(a / x) - 1.0) + x > 51.0) return 1.0;
     }
     return incomplete_gamma_function(a, x);
 }
@@ -228,6 +229,16 @@ __device__ inline int32_t poisson_qscore(int32_t callCount, int32_t coverage, co
     double callCountMinusOne = callCount - 1;
     double callCountDouble = callCount;
     double lambda = P.err_q * coverage;
+    // Exact early-out at the cap (the dominant case: a well-supported allele, MaximumVariantQScore = 100).
+    // With k-1 >= e*lambda and k >= 2*lambda both the true tail P(X >= k) <= (e lambda/k)^k and the value the
+    // reference's log-space branch uses, pmf(k-1) * k/(2(k-lambda)) <= (e lambda/(k-1))^(k-1), are bounded by
+    // B = (e lambda/(k-1))^(k-1).  If B <= 10^-((cap+1)/10) (cap <= 110 so that B <= 7.9e-12 dwarfs the 2^-53
+    // cancellation error of `1 - CDF`), either branch yields rawQ >= cap + 0.5 and the clamp returns cap.
+    if (P.max_vq <= 110 && callCount >= 3 && callCountDouble >= 2.0 * lambda) {
+        const double km1 = callCountMinusOne;
+        if (km1 * (log(km1 / lambda) - 1.0) >= ((double)P.max_vq + 1.0) * 0.23025850929940458 + 1e-3)
+            return P.max_vq;
+    }
     // Poisson.CumulativeDistribution(k-1) = 1 - GammaLowerRegularized(k, lambda)
     double gamma_ln_k;   // GammaLn(k) from the CDF; FactorialLn(k-1) = GammaLn(k) is the same evaluation
     double pValue = 1 - (1.0 - mathnet_gamma_lower_regularized(callCountMinusOne + 1, lambda, &gamma_ln_k));

@@ -151,11 +151,15 @@ __device__ inline bool process_point_allele(const PointCounts& c, int pos, int a
         if (c.total != 0 && freq < P.min_freq) return false;
     }
     int vq = 0;
+#if !(defined(PISCES_ABLATE_MATH) && PISCES_ABLATE_MATH == 5)
     if (c.support > 0 && c.total != 0) vq = poisson_qscore(c.support, c.total, P);   // VariantQualityCalculator.Compute :11-24
+#endif
     if (!isRef && vq < P.min_vq) return false;
 
     SbResult sb = {0.0, 0, 0, 0};
+#if !(defined(PISCES_ABLATE_MATH) && PISCES_ABLATE_MATH == 4)
     if (c.support > 0) sb = strand_bias(c.cov, c.sup, P);                            // StrandBiasCalculator.Compute :10-15
+#endif
 
     // SetFractionNoCalls (CalledAllele.cs:107-114) + ApplyFilters
     const float allReads = (float)(c.total + c.nocalls);
@@ -172,7 +176,11 @@ __device__ inline bool process_point_allele(const PointCounts& c, int pos, int a
         if (P.vf_filter >= 0.0f && freq < P.vf_filter) filters |= 1u << PISCES_FILTER_LOW_VARIANT_FREQUENCY;
     }
     const int gt = somatic_genotype(isRef, c.total, c.support, c.refsup, P);
+#if !(defined(PISCES_ABLATE_MATH) && PISCES_ABLATE_MATH == 3)
     const int gq = somatic_gq(gt, vq, c.total, c.support, P);
+#else
+    const int gq = vq;
+#endif
     if (P.low_gq_filter >= 0 && (float)gq < (float)P.low_gq_filter) filters |= 1u << PISCES_FILTER_LOW_GENOTYPE_QUALITY;
 
     r.position = pos;
@@ -207,14 +215,17 @@ __device__ inline void call_phase(const int* hist, const uint32_t* gapped /* LDS
                                   const DeviceParams& P, int* s_wave, uint8_t* s_work, uint8_t* s_callable, int* s_base)
 {
     const int tid = threadIdx.x;
-    int n_work;
+    // Two work lists so that a wave is not held hostage by one divergent lane: Reference candidates (at most
+    // one per locus, a cheap uniform path) are compacted onto threads 0..63 = wave 0, variant candidates
+    // (rare, long data-dependent path) onto threads 64.. = waves 1-3.  s_work[thread] = key = 4*locus + rank.
+    int n_ref, n_var;
     {
         const int locus = tid >> 2, rank = tid & 3;
         const int allele = allele_of_rank(rank);
         const int64_t ridx = (int64_t)tile.start_position + locus - ref_start;   // index into the reference window
         const bool in_ref = locus < tile.n_loci && ridx >= 0 && ridx < ref_len;
         const int refType = in_ref ? allele_type_of_base(ref[ridx]) : PISCES_ALLELE_N;
-        bool is_work = false;
+        bool is_ref_work = false, is_var_work = false;
         if (in_ref) {
             int mine = 0, all = 0;
 #pragma unroll
@@ -224,11 +235,13 @@ __device__ inline void call_phase(const int* hist, const uint32_t* gapped /* LDS
                 if (c / 3 == allele) mine += v;
             }
             const bool refLane = (refType < 4) ? (allele == refType) : (rank == 0);
-            if (refLane) is_work = P.include_ref && (P.emit_zero_cov || all > 0);
-            else is_work = (refType < 4) && mine > 0;
+            if (refLane) is_ref_work = P.include_ref && (P.emit_zero_cov || all > 0);
+            else is_var_work = (refType < 4) && mine > 0;
         }
-        int slot = block_exclusive_count(is_work, s_wave, &n_work);
-        if (is_work) s_work[slot] = (uint8_t)tid;
+        const int rslot = block_exclusive_count(is_ref_work, s_wave, &n_ref);
+        const int vslot = block_exclusive_count(is_var_work, s_wave, &n_var);
+        if (is_ref_work) s_work[rslot] = (uint8_t)tid;
+        if (is_var_work) s_work[kTile + vslot] = (uint8_t)tid;
         s_callable[tid] = 0;
     }
     __syncthreads();
@@ -237,13 +250,13 @@ __device__ inline void call_phase(const int* hist, const uint32_t* gapped /* LDS
     bool callable = false;
     int item = 0;
     bool item_is_ref = false;
-    if (tid < n_work) {
+    if (tid < n_ref || (tid >= kTile && tid - kTile < n_var)) {
         item = s_work[tid];
         const int l = item >> 2;
         const int a = allele_of_rank(item & 3);
         const int pos = tile.start_position + l;
         const int rt = allele_type_of_base(ref[(int64_t)pos - ref_start]);
-        item_is_ref = (rt < 4) ? (a == rt) : true;
+        item_is_ref = tid < kTile;
         const PointCounts c = point_counts(hist, l, a, item_is_ref, rt, gapped ? (int)gapped[l] : 0);
         callable = process_point_allele(c, pos, a, item_is_ref, rt, ref, (int64_t)ref_start - 1,
                                         (int64_t)ref_start - 1 + ref_len, P, rec);
@@ -251,24 +264,31 @@ __device__ inline void call_phase(const int* hist, const uint32_t* gapped /* LDS
     }
     __syncthreads();
 
-    bool survive = false, first_of_locus = false;
-    if (callable) {
-        const int q = item & ~3;
-        const bool any_variant = (s_callable[q] | s_callable[q + 1] | s_callable[q + 2] | s_callable[q + 3]) & 2;
-        survive = !(item_is_ref && any_variant);
-        if (survive) {
-            bool earlier = false;   // an earlier surviving allele at this locus?
-            for (int k = 0; k < (item & 3); k++) {
-                uint8_t cc = s_callable[q + k];
-                if (cc == 2 || (cc == 1 && !any_variant)) earlier = true;
+    // per-locus pruning (AlleleCaller.cs:146-147) in key order: thread t looks at key t
+    bool key_survives = false, key_first = false, key_callable = false;
+    {
+        const uint8_t mine = s_callable[tid];
+        key_callable = mine != 0;
+        if (key_callable) {
+            const int q = tid & ~3;
+            const bool any_variant = (s_callable[q] | s_callable[q + 1] | s_callable[q + 2] | s_callable[q + 3]) & 2;
+            key_survives = !(mine == 1 && any_variant);
+            if (key_survives) {
+                bool earlier = false;   // an earlier surviving allele at this locus?
+                for (int k = 0; k < (tid & 3); k++) {
+                    uint8_t cc = s_callable[q + k];
+                    if (cc == 2 || (cc == 1 && !any_variant)) earlier = true;
+                }
+                key_first = !earlier;
             }
-            first_of_locus = !earlier;
         }
     }
     int n_callable, n_loci_called, n_surv;
-    (void)block_exclusive_count(callable, s_wave, &n_callable);
-    (void)block_exclusive_count(first_of_locus, s_wave, &n_loci_called);
-    const int idx = block_exclusive_count(survive, s_wave, &n_surv);
+    (void)block_exclusive_count(key_callable, s_wave, &n_callable);
+    (void)block_exclusive_count(key_first, s_wave, &n_loci_called);
+    const int key_idx = block_exclusive_count(key_survives, s_wave, &n_surv);
+    // hand each surviving key its output index (position, then allele order); 0xFF = dropped
+    s_work[tid] = key_survives ? (uint8_t)key_idx : (uint8_t)0xFF;   // n_surv <= 4*64 but idx 255 needs key 255 surviving with 255 before it: impossible (refs are pruned)
     if (tid == 0) {
         // record placement: fixed 256-slot stride per tile (no atomics, deterministic), or — when the caller
         // wants a compact buffer — one returning atomic per tile on a shared counter (same-address global
@@ -291,8 +311,8 @@ __device__ inline void call_phase(const int* hist, const uint32_t* gapped /* LDS
         }
     }
     __syncthreads();
-    if (survive) {
-        const int64_t dst = (int64_t)(*s_base) + idx;
+    if (callable && s_work[item] != 0xFF) {
+        const int64_t dst = (int64_t)(*s_base) + s_work[item];
         if (dst < capacity) {
             const uint4* sp = reinterpret_cast<const uint4*>(&rec);
             uint4* dp = reinterpret_cast<uint4*>(&records[dst]);
