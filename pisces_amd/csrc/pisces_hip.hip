@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -68,6 +69,8 @@ struct PiscesHip {
     int64_t ring_used = 0;
     DeviceBuf<unsigned long long> d_totals;
     DeviceBuf<double> d_qlut;
+    int n_cus = 256;
+    int kernel_variant = 0;   // 0 = one workgroup per tile (default), 1 = software-pipelined persistent kernel (experimental)
     std::string err;
 
     DeviceBuf<uint8_t> d_ref;
@@ -228,6 +231,12 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         return PISCES_E_DEVICE;
     }
     h->P.totals = h->d_totals.p;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cus = prop.multiProcessorCount;
+        const char* kv = getenv("PISCES_HIP_KERNEL");   // development switch: "pipelined" selects the persistent kernel
+        if (kv && std::string(kv) == "pipelined") h->kernel_variant = 1;
+    }
     {
         // MathOperations.QtoP(q) = Math.Pow(10, -1 * q / 10f) for every integer q-score the caller can produce
         const int n = std::min(std::max(h->cfg.max_variant_qscore, 0), 4095) + 1;
@@ -448,6 +457,22 @@ static void build_tiles(PiscesHip* h, const std::vector<int32_t>& keys, std::vec
     }
 }
 
+// launches the fused tuples -> histogram -> call kernel on stream s
+static void launch_call_tiles(PiscesHip* h, hipStream_t s, const uint32_t* d_tuples, const PiscesTile* d_tiles, int32_t n_tiles,
+                              const uint8_t* d_ref, int32_t ref_start, int64_t ref_len, PiscesCalledAllele* d_records,
+                              int32_t cap, int32_t* d_count, PiscesTileResult* d_tr)
+{
+    if (h->kernel_variant == 1) {
+        // persistent grid: 4 workgroups of 5 waves per CU, each walking tiles blockIdx.x, +grid, ...
+        const int grid = std::min<int64_t>(n_tiles, (int64_t)h->n_cus * 4);
+        hipLaunchKernelGGL(call_tiles_pipelined_kernel, dim3((unsigned)grid), dim3(kPipeBlock), 0, s, d_tuples, d_tiles, n_tiles, d_ref,
+                           ref_start, ref_len, d_records, cap, d_count, d_tr, h->P);
+    } else {
+        hipLaunchKernelGGL(call_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, d_tuples, d_tiles, n_tiles, d_ref, ref_start,
+                           ref_len, d_records, cap, d_count, d_tr, h->P);
+    }
+}
+
 static int32_t upload_tiles(PiscesHip* h, const std::vector<PiscesTile>& tiles, const std::vector<uint32_t>& tuples)
 {
     PISCES_HIP_CHECK(h, h->d_tiles.reserve(tiles.size()));
@@ -482,8 +507,8 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
         if (std::binary_search(keys.begin(), keys.end(), block_key(h, kv.first))) { use_counts = true; break; }
 
     if (!use_counts) {
-        hipLaunchKernelGGL(call_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles,
-                           h->d_ref.p, 1, h->ref_len, h->d_records.p, (int32_t)cap, (int32_t*)nullptr, h->d_tile_results.p, h->P);
+        launch_call_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p, (int32_t)cap,
+                          nullptr, h->d_tile_results.p);
     } else {
         // counts in HBM + AddGappedMnvRefCount adjustments (CoverageCalculator.cs:82-97)
         const size_t nc = (size_t)n_tiles * kTile * PISCES_COUNTS_PER_LOCUS;
@@ -669,8 +694,8 @@ int32_t pisces_hip_call_tiles(PiscesHip* h, const uint32_t* d_tuples, const Pisc
     }
     PISCES_HIP_CHECK(h, hipEventRecord(e0, s));
     if (n_tiles > 0)
-        hipLaunchKernelGGL(call_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, d_tuples, d_tiles, n_tiles, d_ref_bases,
-                           ref_start_position, ref_length, d_records, record_capacity, d_record_count, d_tile_results, h->P);
+        launch_call_tiles(h, s, d_tuples, d_tiles, n_tiles, d_ref_bases, ref_start_position, ref_length, d_records, record_capacity,
+                          d_record_count, d_tile_results);
     PISCES_HIP_CHECK(h, hipEventRecord(e1, s));
     PISCES_HIP_CHECK(h, hipGetLastError());
     h->timed = true;
