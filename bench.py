@@ -78,7 +78,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from pisces_amd import _abi, engine, synth
+    from pisces_amd import _abi, engine, shard, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -135,8 +135,7 @@ def main():
     totals = caller.device_totals()
     summary = torch.tensor([totals["records"], totals["candidate_loci"], totals["called"], totals["tiles"]],
                            dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.all_reduce(summary, op=dist.ReduceOp.SUM)   # the per-chromosome summary reduce (RCCL over xGMI)
+    shard.reduce_summary(summary)   # the per-chromosome summary reduce: one all-reduce(sum) of int64[4] (RCCL over xGMI)
     torch.cuda.synchronize(dev)
     barrier()
     elapsed = time.perf_counter() - t0

@@ -1,0 +1,78 @@
+// HipFactory.cs — the injection point: subclass Pisces' Factory and override the three protected virtual
+// Create* hooks (src/exe/Pisces/Logic/Factory.cs:123,128,209), exactly as the reference's own test double
+// MockFactoryWithDefaults does (src/test/Pisces.Tests/MockBehaviors/MockFactoryWithDefaults.cs:36-49).
+// Program.ProgramExecution (src/exe/Pisces/Program.cs:39) is the single `new Factory(...)` site to switch.
+// Source only (no dotnet toolchain in the build image).
+using System;
+using System.Collections.Generic;
+using Pisces.Domain.Interfaces;
+using Pisces.Domain.Models;
+using Pisces.Domain.Models.Alleles;
+using Pisces.Domain.Options;
+using Pisces.Interfaces;
+using Pisces.Processing.Interfaces;
+
+namespace Pisces.Hip
+{
+    public class HipFactory : Pisces.Logic.Factory
+    {
+        private HipEngine _engine;   // one per (BAM, chromosome) job, created in CreateStateManager
+
+        public HipFactory(PiscesApplicationOptions options) : base(options) { }
+
+        // The finder's SNV candidates are implied by the device counts; MNV/indel discovery stays with the
+        // reference finder until SURVEY §8 row f1 lands, so the base finder is kept and its SNVs are ignored
+        // by HipStateManager.AddCandidates.
+        protected override ICandidateVariantFinder CreateVariantFinder() { return base.CreateVariantFinder(); }
+
+        protected override IStateManager CreateStateManager(ChrIntervalSet intervalSet, bool expectStitchedReads = false,
+            bool expectCollapsedReads = true)
+        {
+            _engine = new HipEngine(HipEngine.ConfigFrom(_options, expectStitchedReads, intervalSet != null), device: 0);
+            if (intervalSet != null) _engine.SetIntervals(intervalSet);
+            return new HipStateManager(_engine);
+        }
+
+        protected override IAlleleCaller CreateVariantCaller(ChrReference chrReference, ChrIntervalSet intervalSet,
+            IAlignmentSource alignmentSource, HashSet<Tuple<string, int, string, string>> forceGtAlleles = null)
+        {
+            return new HipAlleleCaller(() => _engine, chrReference);
+        }
+    }
+
+    /// IStateManager over the native handle: AddAlleleCounts batches reads into a pinned SoA and calls
+    /// pisces_hip_add_reads; GetCandidatesToProcess returns a batch token carrying upToPosition;
+    /// DoneProcessing is a no-op (the native flush already retired the blocks); GetAlleleCount is served by
+    /// pisces_hip_get_counts + the AlleleCountHelper window arithmetic (kept in C#, it is 40 lines of ints).
+    public class HipStateManager : IStateManager
+    {
+        private readonly HipEngine _e;
+        public HipStateManager(HipEngine e) { _e = e; }
+        public void AddAlleleCounts(Read read) { _e.StageRead(read); }                       // copies out: the Read object is reused (AlignmentsSource.cs:21,61)
+        public void AddCandidates(IEnumerable<CandidateAllele> candidates) { _e.KeepNonSnvCandidates(candidates); }
+        public ICandidateBatch GetCandidatesToProcess(int? upToPosition, ChrReference chrReference = null,
+            HashSet<Tuple<string, int, string, string>> forcedGtAlleles = null)
+        { _e.FlushStagedReads(chrReference); return new HipBatch(upToPosition); }
+        public void DoneProcessing(ICandidateBatch batch) { }
+        public int GetAlleleCount(int position, Pisces.Domain.Types.AlleleType a, Pisces.Domain.Types.DirectionType d,
+            int minAnchor = 0, int? maxAnchor = null, bool fromEnd = false, bool symmetric = false)
+        { return _e.GetAlleleCount(position, (int)a, (int)d, minAnchor, maxAnchor, fromEnd, symmetric); }
+        public void AddGappedMnvRefCount(Dictionary<int, int> lookup) { _e.AddGappedMnvRefCount(lookup); }
+        // remaining IAlleleSource members (GetSumOfAlleleBaseQualities, GetCollapsedReadCount, ...) return the
+        // RegionStateManager defaults (0 / ExpectStitchedReads) — they feed only NoiseModel.Window / collapsed BAMs.
+        public bool ExpectStitchedReads { get { return _e.ExpectStitchedReads; } }
+        /* ... */
+    }
+
+    /// IAlleleCaller: Call(batch, source) = pisces_hip_flush(upTo) -> PiscesCalledAllele[] -> CalledAllele objects
+    /// in a SortedList<int, List<CalledAllele>> (already sorted by position, then ref/alt).
+    public class HipAlleleCaller : IAlleleCaller
+    {
+        private readonly Func<HipEngine> _engine; private readonly ChrReference _chr;
+        public HipAlleleCaller(Func<HipEngine> engine, ChrReference chr) { _engine = engine; _chr = chr; }
+        public int TotalNumCollapsed { get { return 0; } }
+        public int TotalNumCalled { get { return (int)_engine().Stats()[0]; } }
+        public SortedList<int, List<CalledAllele>> Call(ICandidateBatch batch, IAlleleSource source)
+        { return _engine().Flush(((HipBatch)batch).UpToPosition, _chr); }
+    }
+}
