@@ -77,22 +77,31 @@ __device__ inline double gamma_continued_fraction(double a, double x, double g) 
 
 __device__ inline double gamma_series(double a, double x, double g)  // Poisson.cs:76-101
 {
+    // Same operations in the same order as the reference loop; only the scheduling differs: the quotients
+    // x / (a + i) do not depend on the running term, so four of them are formed together (independent FP64
+    // division sequences overlap in the pipeline) and then consumed one by one with the reference's
+    // convergence test after each.  a is an integer-valued double here, so a + i is exactly the
+    // reference's repeatedly incremented `ap`.
     const double kEpsilon = 1.0E-20;
     double retval = -1.0;
     if (x == 0.0) return 0.0;
     if (x < 0.0) return retval;
-    double ap = a;
     double sum = 1.0 / a;
     double del = sum;
-    for (int i = 1; i <= 300; i++) {
-        ap += 1.0;
-        del *= x / ap;
-        sum += del;
-        if (fabs(del) < fabs(sum) * kEpsilon) {
-            retval = sum * exp(a * log(x) - x - g);
-            break;
-        }
+    bool done = false;
+    for (int i = 1; i <= 300 && !done; i += 4) {
+        const double ap0 = a + (double)i;
+        const double q0 = x / ap0, q1 = x / (ap0 + 1.0), q2 = x / (ap0 + 2.0), q3 = x / (ap0 + 3.0);
+        del *= q0; sum += del;
+        if (fabs(del) < fabs(sum) * kEpsilon) { done = true; break; }
+        del *= q1; sum += del;
+        if (fabs(del) < fabs(sum) * kEpsilon) { done = true; break; }
+        del *= q2; sum += del;
+        if (fabs(del) < fabs(sum) * kEpsilon) { done = true; break; }
+        del *= q3; sum += del;
+        if (fabs(del) < fabs(sum) * kEpsilon) { done = true; break; }
     }
+    if (done) retval = sum * exp(a * log(x) - x - g);
     return retval;
 }
 
@@ -110,6 +119,9 @@ __device__ __forceinline__ double poisson_cdf(double num_occurrences, double exp
     return incomplete_gamma_function((double)(int)(num_occurrences + 1.0), expected);
 }
 
+// ln(r) >= ilogb(r) * ln 2 for r >= 1: a logarithm-free lower bound (one v_frexp_exp) for the early-out tests
+__device__ __forceinline__ double ln_lower_bound(double r) { return (double)ilogb(r) * 0.6931471805; }
+
 // Same value as poisson_cdf, bit for bit, with an exact early-out for the dominant case of the strand-bias
 // statistics (a well-supported allele against the noise rate): when 2x <= a the series branch is taken and
 // converges (every ratio x/(a+i) < 1/2, so |del| < |sum|*1e-20 within 70 of the 300 iterations), its sum is
@@ -122,7 +134,9 @@ __device__ inline double poisson_cdf_sb(double num_occurrences, double expected)
     if (x > 0.0 && a >= 1.0 && 2.0 * x <= a) {
         // E = -a ln(a/x) + a - x + ln(a)/2 - 0.9189..., and ln(a)/2 < 10.75 for any int32 count:
         // one logarithm decides E < -40
-        if (a * (log(a / x) - 1.0) + x > 51.0) return 1.0;
+        const double r = a / x;
+        if (a * (ln_lower_bound(r) - 1.0) + x > 51.0) return 1.0;   // usual case: decided without a logarithm
+        if (a * (log(r) - 1.0) + x > 51.0) return 1.0;
     }
     return incomplete_gamma_function(a, x);
 }
@@ -236,8 +250,10 @@ __device__ inline int32_t poisson_qscore(int32_t callCount, int32_t coverage, co
     // cancellation error of `1 - CDF`), either branch yields rawQ >= cap + 0.5 and the clamp returns cap.
     if (P.max_vq <= 110 && callCount >= 3 && callCountDouble >= 2.0 * lambda) {
         const double km1 = callCountMinusOne;
-        if (km1 * (log(km1 / lambda) - 1.0) >= ((double)P.max_vq + 1.0) * 0.23025850929940458 + 1e-3)
-            return P.max_vq;
+        const double need = ((double)P.max_vq + 1.0) * 0.23025850929940458 + 1e-3;
+        const double r = km1 / lambda;
+        if (km1 * (ln_lower_bound(r) - 1.0) >= need) return P.max_vq;   // usual case: decided without a logarithm
+        if (km1 * (log(r) - 1.0) >= need) return P.max_vq;
     }
     // Poisson.CumulativeDistribution(k-1) = 1 - GammaLowerRegularized(k, lambda)
     double gamma_ln_k;   // GammaLn(k) from the CDF; FactorialLn(k-1) = GammaLn(k) is the same evaluation
@@ -286,12 +302,17 @@ __device__ inline SbStats sb_create_stats(double support, double coverage, doubl
 
 struct SbResult { double bias_score; int acceptable, var_both, cov_both; };
 
-__device__ inline SbResult strand_bias(const int32_t cov[3], const int32_t sup[3], const DeviceParams& P)
+// which: 0 overall (F+R+S), 1 forward (F + S/2), 2 reverse (R + S/2); the stitched halves use integer division (:36-41)
+__device__ __forceinline__ SbStats sb_stats_of(int which, const int32_t cov[3], const int32_t sup[3], const DeviceParams& P)
 {
-    double errorRate = P.err_sb;
-    SbStats overall = sb_create_stats(sup[0] + sup[1] + sup[2], cov[0] + cov[1] + cov[2], errorRate, P.sb_model);
-    SbStats fwd = sb_create_stats(sup[0] + sup[2] / 2, cov[0] + cov[2] / 2, errorRate, P.sb_model);
-    SbStats rev = sb_create_stats(sup[1] + sup[2] / 2, cov[1] + cov[2] / 2, errorRate, P.sb_model);
+    const int s = which == 0 ? sup[0] + sup[1] + sup[2] : (which == 1 ? sup[0] + sup[2] / 2 : sup[1] + sup[2] / 2);
+    const int c = which == 0 ? cov[0] + cov[1] + cov[2] : (which == 1 ? cov[0] + cov[2] / 2 : cov[1] + cov[2] / 2);
+    return sb_create_stats((double)s, (double)c, P.err_sb, P.sb_model);
+}
+
+// AssignBiasScore (:89-105) + the both-strands rules (:57-69) from the three statistics
+__device__ __forceinline__ SbResult sb_combine(const SbStats& overall, const SbStats& fwd, const SbStats& rev, const DeviceParams& P)
+{
     // StitchedStats (:55-56) feed only the optional strand-bias report file, not the score.
     double forwardBias = (fwd.var_gt_zero * rev.false_pos) / overall.var_gt_zero;
     double reverseBias = (rev.var_gt_zero * fwd.false_pos) / overall.var_gt_zero;
@@ -306,6 +327,12 @@ __device__ inline SbResult strand_bias(const int32_t cov[3], const int32_t sup[3
     if (!r.cov_both) r.bias_score = 0;
     r.acceptable = r.bias_score < P.sb_threshold;
     return r;
+}
+
+__device__ inline SbResult strand_bias(const int32_t cov[3], const int32_t sup[3], const DeviceParams& P)
+{
+    const SbStats overall = sb_stats_of(0, cov, sup, P), fwd = sb_stats_of(1, cov, sup, P), rev = sb_stats_of(2, cov, sup, P);
+    return sb_combine(overall, fwd, rev, P);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -381,6 +408,31 @@ __device__ inline bool rmxn_should_filter_snv(const uint8_t* ref, int64_t win_lo
     int c1 = rmxn_run(ref, win_lo, win_hi, (int64_t)position - 1, refBase);
     int i1 = rmxn_run(ref, win_lo, win_hi, (int64_t)position, altBase);      // ReferencePosition + refLen - 1
     int i2 = rmxn_run(ref, win_lo, win_hi, (int64_t)position - 1, altBase);
+    int c2 = i1 > i2 ? i1 : i2;
+    return (c1 < c2 ? c1 : c2) >= P.rmxn_min_rep;
+}
+
+// The same scan over a window of the reference staged in LDS: win[j] is string index win_lo + j, j in [0, n).
+// A run clipped by the window edge is at least kRefMargin long, so comparing against rmxn_min_rep <= kRefMargin
+// gives the reference's decision.
+__device__ inline int rmxn_run_lds(const uint8_t* win, int n, int start, uint8_t base)
+{
+    int back = start;
+    while (back - 1 >= 0 && win[back - 1] == base) back--;
+    int cnt = 0;
+    int cur = back;
+    while (cur < n && win[cur] == base) { cnt++; cur++; }
+    return cnt;
+}
+
+__device__ inline bool rmxn_should_filter_snv_lds(const uint8_t* win, int n, int idx /* window index of the SNV */,
+                                                  uint8_t refBase, uint8_t altBase, float freq, const DeviceParams& P)
+{
+    if (P.rmxn_max_len < 1) return false;
+    if (freq >= P.rmxn_freq_limit) return false;
+    int c1 = rmxn_run_lds(win, n, idx, refBase);
+    int i1 = rmxn_run_lds(win, n, idx + 1, altBase);
+    int i2 = rmxn_run_lds(win, n, idx, altBase);
     int c2 = i1 > i2 ? i1 : i2;
     return (c1 < c2 ? c1 : c2) >= P.rmxn_min_rep;
 }

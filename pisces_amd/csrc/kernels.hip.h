@@ -26,6 +26,9 @@ constexpr int kUnroll = 4;                // 16-byte loads in flight per lane
 constexpr int kSlotsPerTile = 4 * kTile;  // worst case: four alleles called at every locus
 constexpr int kTotalShards = 64;          // running-total shards (one 128-byte line each)
 constexpr int kTotalStride = 16;          // in 8-byte words
+constexpr int kRefMargin = 32;            // reference bases staged in LDS on each side of a tile (RMxN scan reach)
+constexpr int kRefWin = kTile + 2 * kRefMargin;
+constexpr int kQLutLds = 128;             // QtoP(q), q < 128, staged in LDS (no global load inside the call phase)
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // one dwordx4 load
 
@@ -138,29 +141,21 @@ __device__ __forceinline__ PointCounts point_counts(const int* hist, int l, int 
     return c;
 }
 
-// AlleleCaller.ProcessVariant (AlleleCaller.cs:208-234) + AlleleProcessor.ApplyFilters (AlleleProcessor.cs:25-71)
-// + IsCallable + SomaticGenotyper for one point allele. Returns false (record untouched) when the reference
-// would drop the allele.
-__device__ inline bool process_point_allele(const PointCounts& c, int pos, int a, bool isRef, int rt,
-                                             const uint8_t* __restrict__ ref, int64_t win_lo, int64_t win_hi,
-                                             const DeviceParams& P, PiscesCalledAllele& r)
+// IsCallable (AlleleCaller.cs:236-258), the tests that precede the q-score: coverage, then frequency.
+__device__ __forceinline__ bool variant_passes_frequency(const PointCounts& c, const DeviceParams& P)
+{
+    if (c.total < P.min_cov && !P.include_ref) return false;
+    if (c.total != 0 && frequency_f(c.support, c.total) < P.min_freq) return false;
+    return true;
+}
+
+// Everything of AlleleCaller.ProcessVariant (AlleleCaller.cs:208-234) after the q-score and the strand-bias
+// statistics: AlleleProcessor.ApplyFilters (AlleleProcessor.cs:25-71), SomaticGenotyper, record packing.
+__device__ inline void finish_allele(const PointCounts& c, int pos, int a, bool isRef, int rt, int vq, const SbResult& sb,
+                                     const uint8_t* __restrict__ ref, int64_t win_lo, int64_t win_hi, const DeviceParams& P,
+                                     PiscesCalledAllele& r, const uint8_t* s_refwin, int s_refidx)
 {
     const float freq = frequency_f(c.support, c.total);
-    if (!isRef) {   // IsCallable, the tests that precede the q-score
-        if (c.total < P.min_cov && !P.include_ref) return false;
-        if (c.total != 0 && freq < P.min_freq) return false;
-    }
-    int vq = 0;
-#if !(defined(PISCES_ABLATE_MATH) && PISCES_ABLATE_MATH == 5)
-    if (c.support > 0 && c.total != 0) vq = poisson_qscore(c.support, c.total, P);   // VariantQualityCalculator.Compute :11-24
-#endif
-    if (!isRef && vq < P.min_vq) return false;
-
-    SbResult sb = {0.0, 0, 0, 0};
-#if !(defined(PISCES_ABLATE_MATH) && PISCES_ABLATE_MATH == 4)
-    if (c.support > 0) sb = strand_bias(c.cov, c.sup, P);                            // StrandBiasCalculator.Compute :10-15
-#endif
-
     // SetFractionNoCalls (CalledAllele.cs:107-114) + ApplyFilters
     const float allReads = (float)(c.total + c.nocalls);
     const float fractionNoCalls = (allReads == 0.0f) ? 0.0f : ((float)c.nocalls / allReads);
@@ -171,8 +166,14 @@ __device__ inline bool process_point_allele(const PointCounts& c, int pos, int a
         if (P.nocall_thr >= 0.0f && fractionNoCalls > P.nocall_thr) filters |= 1u << PISCES_FILTER_NO_CALL;
         if (!sb.acceptable || (P.filter_single_strand && !sb.var_both)) filters |= 1u << PISCES_FILTER_STRAND_BIAS;
         const uint8_t bases[4] = {'A', 'G', 'C', 'T'};
-        if (rt < 4 && a < 4 && rmxn_should_filter_snv(ref, win_lo, win_hi, pos, bases[rt], bases[a], freq, P))
-            filters |= 1u << PISCES_FILTER_RMXN;
+        if (rt < 4 && a < 4) {
+            // the reference window of the tile sits in LDS (global byte loads are dependent multi-microsecond
+            // round trips while the chip is streaming); fall back to HBM only for an RMxN reach beyond the margin
+            const bool hit = (s_refwin && P.rmxn_min_rep <= kRefMargin)
+                                 ? rmxn_should_filter_snv_lds(s_refwin, kRefWin, s_refidx, bases[rt], bases[a], freq, P)
+                                 : rmxn_should_filter_snv(ref, win_lo, win_hi, pos, bases[rt], bases[a], freq, P);
+            if (hit) filters |= 1u << PISCES_FILTER_RMXN;
+        }
         if (P.vf_filter >= 0.0f && freq < P.vf_filter) filters |= 1u << PISCES_FILTER_LOW_VARIANT_FREQUENCY;
     }
     const int gt = somatic_genotype(isRef, c.total, c.support, c.refsup, P);
@@ -196,6 +197,25 @@ __device__ inline bool process_point_allele(const PointCounts& c, int pos, int a
     r.filter_bits = (uint16_t)filters;
     r.info = PISCES_INFO_PACK(gt, isRef ? PISCES_CAT_REFERENCE : PISCES_CAT_SNV, rt, isRef ? rt : a, sb.acceptable, sb.var_both,
                               sb.cov_both);
+}
+
+// One lane, one allele, start to finish. Returns false (record untouched) when the reference would drop the allele.
+__device__ inline bool process_point_allele(const PointCounts& c, int pos, int a, bool isRef, int rt,
+                                             const uint8_t* __restrict__ ref, int64_t win_lo, int64_t win_hi,
+                                             const DeviceParams& P, PiscesCalledAllele& r,
+                                             const uint8_t* s_refwin = nullptr, int s_refidx = 0)
+{
+    if (!isRef && !variant_passes_frequency(c, P)) return false;
+    int vq = 0;
+#if !(defined(PISCES_ABLATE_MATH) && PISCES_ABLATE_MATH == 5)
+    if (c.support > 0 && c.total != 0) vq = poisson_qscore(c.support, c.total, P);   // VariantQualityCalculator.Compute :11-24
+#endif
+    if (!isRef && vq < P.min_vq) return false;
+    SbResult sb = {0.0, 0, 0, 0};
+#if !(defined(PISCES_ABLATE_MATH) && PISCES_ABLATE_MATH == 4)
+    if (c.support > 0) sb = strand_bias(c.cov, c.sup, P);                            // StrandBiasCalculator.Compute :10-15
+#endif
+    finish_allele(c, pos, a, isRef, rt, vq, sb, ref, win_lo, win_hi, P, r, s_refwin, s_refidx);
     return true;
 }
 
@@ -215,6 +235,10 @@ __device__ inline void call_phase(const int* hist, const uint32_t* gapped /* LDS
                                   const DeviceParams& P, int* s_wave, uint8_t* s_work, uint8_t* s_callable, int* s_base)
 {
     const int tid = threadIdx.x;
+#ifdef PISCES_TIMING
+    __shared__ long long s_dbg[8];
+    if (tid == 0) s_dbg[0] = clock64();
+#endif
     // Two work lists so that a wave is not held hostage by one divergent lane: Reference candidates (at most
     // one per locus, a cheap uniform path) are compacted onto threads 0..63 = wave 0, variant candidates
     // (rare, long data-dependent path) onto threads 64.. = waves 1-3.  s_work[thread] = key = 4*locus + rank.
@@ -246,6 +270,9 @@ __device__ inline void call_phase(const int* hist, const uint32_t* gapped /* LDS
     }
     __syncthreads();
 
+#ifdef PISCES_TIMING
+    if (tid == 0) s_dbg[1] = clock64();
+#endif
     PiscesCalledAllele rec;
     bool callable = false;
     int item = 0;
@@ -262,7 +289,14 @@ __device__ inline void call_phase(const int* hist, const uint32_t* gapped /* LDS
                                         (int64_t)ref_start - 1 + ref_len, P, rec);
         if (callable) s_callable[item] = item_is_ref ? 1 : 2;
     }
+#ifdef PISCES_TIMING
+    if (tid == 0) s_dbg[2] = clock64();     // wave 0 (Reference lanes) done
+    if (tid == 64) s_dbg[4] = clock64();    // wave 1 (variant lanes) done
+#endif
     __syncthreads();
+#ifdef PISCES_TIMING
+    if (tid == 0) s_dbg[3] = clock64();
+#endif
 
     // per-locus pruning (AlleleCaller.cs:146-147) in key order: thread t looks at key t
     bool key_survives = false, key_first = false, key_callable = false;
@@ -319,25 +353,237 @@ __device__ inline void call_phase(const int* hist, const uint32_t* gapped /* LDS
             dp[0] = sp[0]; dp[1] = sp[1]; dp[2] = sp[2]; dp[3] = sp[3];
         }
     }
+#ifdef PISCES_TIMING
+    __syncthreads();
+    if (tid == 0) {
+        const long long now = clock64();
+        tile_result->n_records = (int)(s_dbg[1] - s_dbg[0]);          // detection + compaction
+        tile_result->n_candidate_loci = (int)(s_dbg[2] - s_dbg[1]);   // Reference lanes (wave 0)
+        tile_result->reserved = (int)(now - s_dbg[0]);                // whole call phase
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void call_tiles_kernel(
+// The hot kernel.  One workgroup per tile; four waves stream the tile's tuples into the LDS histogram, then
+// waves 2 and 3 retire (their wave slots go to the next workgroup, whose streaming overlaps this tile's FP64
+// call phase), wave 1 calls the variant candidates and wave 0 the Reference candidates, lane = locus.
+// Measured on config 2: with all four waves held through a block-wide call phase the launch ran stream and
+// call phases in lock-step across the chip (HBM idle ~30 us of 74); per-tile stamps: stream 45 k cycles,
+// call 23 k of which 13 k Reference lanes, 10 k compaction / block barriers / waiting on the variant wave.
+__device__ __forceinline__ int wave_exclusive_sum(int v, int* total)
+{
+    const int lane = threadIdx.x & 63;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    *total = __shfl(x, 63, 64);
+    return x - v;
+}
+
+__device__ __forceinline__ void copy_record(PiscesCalledAllele* dst, const PiscesCalledAllele* src)
+{
+    const uint4* sp = reinterpret_cast<const uint4*>(src);
+    uint4* dp = reinterpret_cast<uint4*>(dst);
+    dp[0] = sp[0]; dp[1] = sp[1]; dp[2] = sp[2]; dp[3] = sp[3];
+}
+
+// The call phase, lane = locus, one role per wave (wave-uniform code, no divergence between roles):
+//   wave 0  Reference candidate of the locus, start to finish
+//   wave 1  variant candidates: variant q-score            (then assembles the variant records)
+//   wave 2  variant candidates: strand-bias overall + forward statistics
+//   wave 3  variant candidates: strand-bias reverse statistics
+// A called SNV is ~5 k dependent FP64 instructions on one lane (measured p99 26 us per tile with one variant
+// wave against 6 us for the Reference wave); its q-score and three strand-bias tails are independent, so they
+// run on three SIMDs at once and meet in LDS.
+struct VarScratch {
+    int vq[kTile * 4];
+    double ov_var[kTile * 4], fw_var[kTile * 4], fw_fp[kTile * 4], rv_var[kTile * 4], rv_fp[kTile * 4];
+};
+
+__device__ inline void call_four_waves(const int* hist, const uint32_t* gapped, const PiscesTile& tile, int tile_index,
+                                       const uint8_t* __restrict__ ref, int32_t ref_start, int64_t ref_len,
+                                       PiscesCalledAllele* __restrict__ records, int32_t capacity,
+                                       int32_t* __restrict__ record_count, PiscesTileResult* __restrict__ tile_result,
+                                       const DeviceParams& P, PiscesCalledAllele* s_rec, uint8_t* s_mask,
+                                       const uint8_t* s_refwin /* LDS[kRefWin], 0 = outside the reference */,
+                                       VarScratch* vs)
+{
+    const int wave = threadIdx.x >> 6;
+    const int l = threadIdx.x & 63;
+    const int pos = tile.start_position + l;
+    const uint8_t refb = s_refwin[kRefMargin + l];
+    const bool in_ref = l < tile.n_loci && refb != 0;
+    const int rt = in_ref ? allele_type_of_base(refb) : PISCES_ALLELE_N;
+    const int64_t win_lo = (int64_t)ref_start - 1, win_hi = win_lo + ref_len;
+    const int g = gapped ? (int)gapped[l] : 0;
+
+    PiscesCalledAllele rec;      // wave 0: this locus' Reference record
+    bool ref_emitted = false;
+    if (wave == 0) {
+        // Reference candidate (RegionState.GetAllCandidates, RegionState.cs:414-447)
+        if (in_ref && P.include_ref) {
+            int all = 0;
+#pragma unroll
+            for (int c = 0; c < kFolded; c++) all += hist[c * kTile + l];
+            if (P.emit_zero_cov || all > 0) {
+                const int a = (rt < 4) ? rt : PISCES_ALLELE_N;
+                const PointCounts c = point_counts(hist, l, a, true, rt, g);
+                (void)process_point_allele(c, pos, a, true, rt, ref, win_lo, win_hi, P, rec, s_refwin, kRefMargin + l);
+                ref_emitted = true;
+            }
+        }
+    } else if (in_ref && rt < 4) {
+        // variant candidates (CandidateVariantFinder.cs:97-160, callMNVs off): quality-passing base != ref base
+        for (int k = 0; k < 4; k++) {
+            const int a = allele_of_rank(k);
+            if (a == rt) continue;
+            if (hist[(a * 3 + 0) * kTile + l] + hist[(a * 3 + 1) * kTile + l] + hist[(a * 3 + 2) * kTile + l] == 0) continue;
+            const PointCounts c = point_counts(hist, l, a, false, rt, g);
+            if (!variant_passes_frequency(c, P)) continue;
+            const int slot = l * 4 + k;
+            if (wave == 1) {
+                vs->vq[slot] = (c.support > 0 && c.total != 0) ? poisson_qscore(c.support, c.total, P) : 0;
+            } else if (c.support > 0) {
+                if (wave == 2) {
+                    const SbStats ov = sb_stats_of(0, c.cov, c.sup, P), fw = sb_stats_of(1, c.cov, c.sup, P);
+                    vs->ov_var[slot] = ov.var_gt_zero;
+                    vs->fw_var[slot] = fw.var_gt_zero;
+                    vs->fw_fp[slot] = fw.false_pos;
+                } else {
+                    const SbStats rv = sb_stats_of(2, c.cov, c.sup, P);
+                    vs->rv_var[slot] = rv.var_gt_zero;
+                    vs->rv_fp[slot] = rv.false_pos;
+                }
+            }
+        }
+    }
+    __syncthreads();   // four waves
+    if (wave >= 2) return;
+    if (wave == 1) {
+        uint32_t mask = 0;
+        if (in_ref && rt < 4) {
+            for (int k = 0; k < 4; k++) {
+                const int a = allele_of_rank(k);
+                if (a == rt) continue;
+                if (hist[(a * 3 + 0) * kTile + l] + hist[(a * 3 + 1) * kTile + l] + hist[(a * 3 + 2) * kTile + l] == 0) continue;
+                const PointCounts c = point_counts(hist, l, a, false, rt, g);
+                if (!variant_passes_frequency(c, P)) continue;
+                const int slot = l * 4 + k;
+                const int vq = vs->vq[slot];
+                if (vq < P.min_vq) continue;                                   // IsCallable, last test
+                SbResult sb = {0.0, 0, 0, 0};
+                if (c.support > 0) {
+                    SbStats ov, fw, rv;
+                    ov.var_gt_zero = vs->ov_var[slot];
+                    fw.var_gt_zero = vs->fw_var[slot]; fw.false_pos = vs->fw_fp[slot];
+                    rv.var_gt_zero = vs->rv_var[slot]; rv.false_pos = vs->rv_fp[slot];
+                    const int s2 = c.sup[2] / 2, c2 = c.cov[2] / 2;
+                    fw.coverage = c.cov[0] + c2; fw.support = c.sup[0] + s2;
+                    rv.coverage = c.cov[1] + c2; rv.support = c.sup[1] + s2;
+                    ov.false_pos = 0; ov.coverage = 0; ov.support = 0;
+                    sb = sb_combine(ov, fw, rv, P);
+                }
+                PiscesCalledAllele r;
+                finish_allele(c, pos, a, false, rt, vq, sb, ref, win_lo, win_hi, P, r, s_refwin, kRefMargin + l);
+                copy_record(&s_rec[slot], &r);
+                mask |= 1u << k;
+            }
+        }
+        s_mask[l] = (uint8_t)mask;
+    }
+    __syncthreads();   // waves 0 and 1
+    if (wave == 1) return;
+
+    // per-locus pruning (AlleleCaller.cs:146-147), output order (position, then allele), write-out
+    const uint32_t vmask = s_mask[l];
+    const int mine = vmask ? __popc(vmask) : (ref_emitted ? 1 : 0);
+    const int n_callable = __popc(vmask) + (ref_emitted ? 1 : 0);   // IsCallable is always true for a Reference allele
+    int n_surv, n_call_total;
+    const int excl = wave_exclusive_sum(mine, &n_surv);
+    (void)wave_exclusive_sum(n_callable, &n_call_total);
+    const int n_loci_called = __popcll(__ballot(mine > 0));
+    int base = 0;
+    if (l == 0) {
+        // record placement: fixed 256-slot stride per tile (no atomics, deterministic) or a compact buffer
+        // handed out by one returning atomic per tile
+        base = record_count ? (n_surv > 0 ? atomicAdd(record_count, n_surv) : 0) : tile_index * kSlotsPerTile;
+        PiscesTileResult tr;
+        tr.record_begin = base;
+        tr.n_records = n_surv;
+        tr.n_candidate_loci = n_loci_called;
+        tr.reserved = n_call_total;   // IAlleleCaller.TotalNumCalled contribution
+        *tile_result = tr;
+        if (P.totals) {
+            // running totals, sharded over kTotalShards cache lines so the adds do not serialize on one L2 line
+            unsigned long long* tt = P.totals + (size_t)(tile_index % kTotalShards) * kTotalStride;
+            atomicAdd(&tt[0], (unsigned long long)n_surv);
+            atomicAdd(&tt[1], (unsigned long long)n_loci_called);
+            atomicAdd(&tt[2], (unsigned long long)n_call_total);
+            atomicAdd(&tt[3], 1ull);
+        }
+    }
+    base = __shfl(base, 0, 64);
+    if (vmask) {
+        int j = 0;
+        for (int k = 0; k < 4; k++) {
+            if (!(vmask & (1u << k))) continue;
+            const int64_t dst = (int64_t)base + excl + j;
+            j++;
+            if (dst < capacity) copy_record(&records[dst], &s_rec[l * 4 + k]);
+        }
+    } else if (ref_emitted) {
+        const int64_t dst = (int64_t)base + excl;
+        if (dst < capacity) copy_record(&records[dst], &rec);
+    }
+}
+
+__global__ __launch_bounds__(kBlock, 5) void call_tiles_kernel(
     const uint32_t* __restrict__ tuples, const PiscesTile* __restrict__ tiles, int32_t n_tiles,
     const uint8_t* __restrict__ ref, int32_t ref_start, int64_t ref_len, PiscesCalledAllele* __restrict__ records,
-    int32_t capacity, int32_t* __restrict__ record_count, PiscesTileResult* __restrict__ tile_results, DeviceParams P)
+    int32_t capacity, int32_t* __restrict__ record_count, PiscesTileResult* __restrict__ tile_results, DeviceParams P,
+    int32_t* __restrict__ gate, int32_t gate_epoch, int32_t gate_width)
 {
+    __shared__ __attribute__((aligned(16))) PiscesCalledAllele s_rec[kTile * 4];
     __shared__ int hist[kFolded * kTile];
-    __shared__ int s_wave[4];
-    __shared__ int s_base;
-    __shared__ uint8_t s_work[kBlock];
-    __shared__ uint8_t s_callable[kBlock];
+    __shared__ uint8_t s_mask[kTile];
+    __shared__ uint8_t s_refwin[kRefWin];
+    __shared__ VarScratch s_var;
+    __shared__ double s_qlut[kQLutLds];
 
     const int t = blockIdx.x;
     if (t >= n_tiles) return;
     const PiscesTile tile = tiles[t];
-
+#ifdef PISCES_TIMING
+    const long long tc0 = wall_clock64();   // 100 MHz, chip-global
+#endif
     for (int i = threadIdx.x; i < kFolded * kTile; i += kBlock) hist[i] = 0;
+    if (threadIdx.x < kRefWin) {
+        // the tile's reference bases (+ margin for the RMxN scan) into LDS now, under the stream
+        const int64_t ri = (int64_t)tile.start_position - kRefMargin + threadIdx.x - ref_start;
+        s_refwin[threadIdx.x] = (ri >= 0 && ri < ref_len) ? ref[ri] : (uint8_t)0;
+    } else if (threadIdx.x >= 128 && threadIdx.x < 128 + kQLutLds) {
+        const int q = threadIdx.x - 128;
+        s_qlut[q] = (P.q_to_p_lut && q < P.q_to_p_n) ? P.q_to_p_lut[q] : q_to_p((double)q);
+    }
+    P.q_to_p_lut = s_qlut;   // generic pointer to LDS from here on
+    P.q_to_p_n = kQLutLds;
+    // Streaming window: tile t starts streaming once tile t - gate_width has finished streaming.  ~1300 waves with
+    // 4 KiB in flight saturate HBM; letting every resident workgroup stream at once only makes all of them finish
+    // together and then run their FP64 call phases together with HBM idle.  The window spreads the call phases
+    // under the stream of later tiles.  It is a throttle, not a correctness dependency: the wait is bounded and a
+    // workgroup proceeds regardless (dispatch order is observed, not guaranteed, to follow blockIdx).
+    if (gate_width > 0 && t >= gate_width) {
+        if (threadIdx.x == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(&gate[t - gate_width], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gate_epoch &&
+                   ++spins < 20000)
+                __builtin_amdgcn_s_sleep(4);
+        }
+    }
     __syncthreads();
 
     const uint32_t n_loci = (uint32_t)tile.n_loci, min_bq = (uint32_t)P.min_bq;
@@ -351,12 +597,26 @@ __global__ __launch_bounds__(kBlock) void call_tiles_kernel(
                   [&](uint32_t v) { accumulate_folded(hist, v, n_loci, min_bq); });
 #endif
     __syncthreads();
+    if (gate_width > 0 && threadIdx.x == 0)
+        __hip_atomic_store(&gate[t], gate_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #if defined(PISCES_ABLATE) && PISCES_ABLATE >= 1
     // development ablation: no call phase
     if (threadIdx.x == 0) { PiscesTileResult tr = {0, 0, hist[5], 0}; tile_results[t] = tr; }
 #else
-    call_phase(hist, nullptr, tile, ref, ref_start, ref_len, records, capacity, record_count, &tile_results[t], P,
-               s_wave, s_work, s_callable, &s_base);
+#ifdef PISCES_TIMING
+    const long long tc1 = wall_clock64();
+#endif
+    call_four_waves(hist, nullptr, tile, t, ref, ref_start, ref_len, records, capacity, record_count, &tile_results[t], P,
+                    s_rec, s_mask, s_refwin, &s_var);
+#ifdef PISCES_TIMING
+    if (threadIdx.x == 0) {   // development instrumentation: shader-clock stamps in the tile directory
+        const long long tc2 = wall_clock64();
+        tile_results[t].record_begin = (int)(tc1 - tc0);             // stream (10 ns ticks)
+        tile_results[t].n_records = 0;
+        tile_results[t].n_candidate_loci = 0;
+        tile_results[t].reserved = (int)(tc2 - tc1);                 // call end
+    }
+#endif
 #endif
 }
 
@@ -374,19 +634,6 @@ __global__ __launch_bounds__(kBlock) void call_tiles_kernel(
 // wave prefix sum and written as 64-byte rows.
 constexpr int kStreamWaves = 4;
 constexpr int kPipeBlock = (kStreamWaves + 1) * 64;
-
-__device__ __forceinline__ int wave_exclusive_sum(int v, int* total)
-{
-    const int lane = threadIdx.x & 63;
-    int x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-    }
-    *total = __shfl(x, 63, 64);
-    return x - v;
-}
 
 // One wave, lane = locus. hist: folded counts of the tile; s_rec: LDS staging [kTile][4] records.
 __device__ inline void call_wave(const int* hist, const uint32_t* gapped, const PiscesTile& tile, int tile_index,

@@ -70,6 +70,9 @@ struct PiscesHip {
     DeviceBuf<unsigned long long> d_totals;
     DeviceBuf<double> d_qlut;
     int n_cus = 256;
+    DeviceBuf<int32_t> d_gate;
+    int32_t gate_epoch = 0;
+    int gate_width = 0;
     int kernel_variant = 0;   // 0 = one workgroup per tile (default), 1 = software-pipelined persistent kernel (experimental)
     std::string err;
 
@@ -236,6 +239,8 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cus = prop.multiProcessorCount;
         const char* kv = getenv("PISCES_HIP_KERNEL");   // development switch: "pipelined" selects the persistent kernel
         if (kv && std::string(kv) == "pipelined") h->kernel_variant = 1;
+        const char* gw = getenv("PISCES_HIP_GATE");   // development: streaming window width in tiles (0 = off)
+        if (gw) h->gate_width = atoi(gw);
     }
     {
         // MathOperations.QtoP(q) = Math.Pow(10, -1 * q / 10f) for every integer q-score the caller can produce
@@ -261,7 +266,7 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_ref.release(); h->d_tuples.release(); h->d_tiles.release(); h->d_tile_results.release();
-    h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release(); h->d_totals.release(); h->d_qlut.release();
+    h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release(); h->d_totals.release(); h->d_qlut.release(); h->d_gate.release();
     for (hipEvent_t ev : h->ring) (void)hipEventDestroy(ev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -468,8 +473,16 @@ static void launch_call_tiles(PiscesHip* h, hipStream_t s, const uint32_t* d_tup
         hipLaunchKernelGGL(call_tiles_pipelined_kernel, dim3((unsigned)grid), dim3(kPipeBlock), 0, s, d_tuples, d_tiles, n_tiles, d_ref,
                            ref_start, ref_len, d_records, cap, d_count, d_tr, h->P);
     } else {
+        int gw = h->gate_width;
+        if (gw > 0) {
+            if (h->d_gate.cap < (size_t)n_tiles) {
+                (void)hipStreamSynchronize(s);
+                if (h->d_gate.reserve((size_t)n_tiles) != hipSuccess || hipMemset(h->d_gate.p, 0, h->d_gate.cap * sizeof(int32_t)) != hipSuccess) gw = 0;
+            }
+            h->gate_epoch = h->gate_epoch == 0x7FFFFFFF ? 1 : h->gate_epoch + 1;
+        }
         hipLaunchKernelGGL(call_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, d_tuples, d_tiles, n_tiles, d_ref, ref_start,
-                           ref_len, d_records, cap, d_count, d_tr, h->P);
+                           ref_len, d_records, cap, d_count, d_tr, h->P, gw > 0 ? h->d_gate.p : nullptr, h->gate_epoch, gw);
     }
 }
 
