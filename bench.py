@@ -67,8 +67,8 @@ def cpu_baseline(torch, pileup, cfg, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--loci", type=int, default=N_LOCI)
     ap.add_argument("--depth", type=int, default=DEPTH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -83,17 +83,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    if world != args.gpus:
-        if rank == 0 and args.gpus != 1:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch N>1 with torch.distributed.run", file=sys.stderr)
 
     cfg = _abi.default_config()
     caller = engine.HipVariantCaller(cfg, device=local_rank)
@@ -193,7 +191,7 @@ def main():
                          "kernel": "call_tiles_kernel", "kernel_ms": kernel_ms, "launches_timed": launches,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
-        if not args.no_cpu_baseline and world >= 1:
+        if not args.no_cpu_baseline and world == 1:   # timed on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(torch, ring[0], cfg)
         print(json.dumps(out), flush=True)
     caller.close()

@@ -220,8 +220,9 @@ int32_t pisces_hip_set_intervals(PiscesHip* h, const int32_t* starts, const int3
 
 /* ---- streaming surface: IStateManager -------------------------------------- */
 /* ICandidateVariantFinder.FindCandidates + IStateManager.AddCandidates + AddAlleleCounts
- * (SmallVariantCaller.cs:88-98) for a batch of reads: expands reads to observation tuples,
- * keeps MNV/indel candidates host-side, stages tuples for the device. */
+ * (SmallVariantCaller.cs:88-98) for a batch of reads: expands reads to observation tuples and stages them
+ * for the device; finds and merges insertion / deletion candidates host-side (needs set_reference first;
+ * without a reference only the AddAlleleCounts half runs). */
 int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch);
 /* Pre-expanded observations for the block grid: positions[i] is the 1-based locus of tuples[i]
  * (the tuple's locus field is ignored). */
@@ -233,13 +234,20 @@ int32_t pisces_hip_add_observations(PiscesHip* h, const int32_t* positions, cons
  * batch when capacity is insufficient: grow and repeat. */
 int32_t pisces_hip_flush(PiscesHip* h, int32_t up_to_position, PiscesCalledAllele* out,
                          int64_t capacity, int64_t* n_out);
+/* The same call, also returning the allele strings of the called insertions / deletions:
+ * cand_index_out[i] (capacity entries, may be NULL) is -1 for Reference / SNV rows (their alleles are the
+ * info base codes) or the index into cand_out of row i's candidate; alleles_out receives ref then alt bytes of each
+ * candidate at cand_out[j].allele_offset. PISCES_E_BUFFER_TOO_SMALL if any buffer is short (counts reported). */
+int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAllele* out, int64_t capacity, int64_t* n_out,
+                            int32_t* cand_index_out, PiscesCandidate* cand_out, int64_t cand_capacity, int64_t* n_cand,
+                            uint8_t* alleles_out, int64_t allele_capacity, int64_t* allele_bytes);
 /* IAlleleSource.GetAlleleCount for a run of positions: out[n][6][3][11] int32
  * (RegionState.cs:57); blocks never touched read as zero (RegionStateManager.cs:222-226). */
 int32_t pisces_hip_get_counts(PiscesHip* h, int32_t start_position, int32_t n, int32_t* out);
 /* IAlleleSource.AddGappedMnvRefCount (RegionStateManager.cs:74-81) */
 int32_t pisces_hip_add_gapped_mnv_ref(PiscesHip* h, const int32_t* positions, const int32_t* counts, int32_t n);
-/* host-side candidates (MNV / insertion / deletion) found so far with position <= up_to
- * (IStateManager.GetCandidatesToProcess for the host collapser). alleles = byte pool. */
+/* host-side candidates (insertion / deletion) found so far with position <= up_to (< 0 = all)
+ * (IStateManager.GetCandidatesToProcess for the host collapser). alleles = byte pool; out may be NULL to count. */
 int32_t pisces_hip_get_candidates(PiscesHip* h, int32_t up_to_position, PiscesCandidate* out,
                                   int64_t capacity, int64_t* n_out, uint8_t* alleles,
                                   int64_t allele_capacity, int64_t* allele_bytes);
@@ -287,6 +295,13 @@ int32_t pisces_hip_last_kernel_ms(PiscesHip* h, float* ms);
  * (RegionStateManager.cs:118-220).  Returns the number written or PISCES_E_BUFFER_TOO_SMALL. */
 int64_t pisces_hip_expand_reads(const PiscesReadBatch* batch, int32_t min_base_call_quality,
                                 int32_t* positions, uint32_t* tuples, int64_t capacity);
+
+/* ICandidateVariantFinder.FindCandidates restricted to insertions and deletions
+ * (CandidateVariantFinder.cs:234-292, Create :334-345, Annotate :496-553), one entry per read event, unmerged,
+ * in read order. ref[i] is position i+1. Returns the count or PISCES_E_BUFFER_TOO_SMALL. */
+int64_t pisces_hip_find_indel_candidates(const PiscesReadBatch* batch, const uint8_t* ref, int64_t ref_len,
+                                         int32_t min_base_call_quality, PiscesCandidate* out, int64_t capacity,
+                                         uint8_t* alleles, int64_t allele_capacity, int64_t* allele_bytes);
 
 #ifdef __cplusplus
 }

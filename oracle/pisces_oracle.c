@@ -1337,9 +1337,20 @@ static int64_t count_candidate_loci(const PiscesCalledAllele* out, int64_t n)
     return loci;
 }
 
+int64_t orc_run_reads_full(const PiscesReadBatch* b, const uint8_t* ref_bases, int64_t ref_len, int32_t region_start,
+                           int32_t region_loci, const PiscesHipConfig* cfg, PiscesCalledAllele* out, int64_t capacity,
+                           int64_t* n_candidate_loci, OrcCalled* full_out, int64_t* total_num_called);
+
 int64_t orc_run_reads(const PiscesReadBatch* b, const uint8_t* ref_bases, int64_t ref_len, int32_t region_start,
                       int32_t region_loci, const PiscesHipConfig* cfg, PiscesCalledAllele* out, int64_t capacity,
                       int64_t* n_candidate_loci)
+{
+    return orc_run_reads_full(b, ref_bases, ref_len, region_start, region_loci, cfg, out, capacity, n_candidate_loci, NULL, NULL);
+}
+
+int64_t orc_run_reads_full(const PiscesReadBatch* b, const uint8_t* ref_bases, int64_t ref_len, int32_t region_start,
+                           int32_t region_loci, const PiscesHipConfig* cfg, PiscesCalledAllele* out, int64_t capacity,
+                           int64_t* n_candidate_loci, OrcCalled* full_out, int64_t* total_num_called)
 {
     OrcState* s = orc_state_create(region_start, region_loci, cfg->min_base_call_quality, PISCES_ANCHOR_SIZE, 0);
     OrcCandidate cands[256];
@@ -1364,7 +1375,7 @@ int64_t orc_run_reads(const PiscesReadBatch* b, const uint8_t* ref_bases, int64_
         int rc = orc_add_allele_counts(s, &r);
         if (rc) { orc_state_destroy(s); return rc; }
     }
-    int64_t n = orc_call_all(s, ref_bases, ref_len, cfg, out, capacity, NULL, NULL);
+    int64_t n = orc_call_all(s, ref_bases, ref_len, cfg, out, capacity, full_out, total_num_called);
     orc_state_destroy(s);
     if (n >= 0 && n_candidate_loci) *n_candidate_loci = count_candidate_loci(out, n);
     return n;

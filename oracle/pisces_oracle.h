@@ -144,6 +144,10 @@ int64_t orc_call_all(OrcState* s, const uint8_t* ref_bases, int64_t ref_len, con
 int64_t orc_run_reads(const PiscesReadBatch* batch, const uint8_t* ref_bases, int64_t ref_len,
                       int32_t region_start, int32_t region_loci, const PiscesHipConfig* cfg,
                       PiscesCalledAllele* out, int64_t capacity, int64_t* n_candidate_loci);
+int64_t orc_run_reads_full(const PiscesReadBatch* batch, const uint8_t* ref_bases, int64_t ref_len,
+                      int32_t region_start, int32_t region_loci, const PiscesHipConfig* cfg,
+                      PiscesCalledAllele* out, int64_t capacity, int64_t* n_candidate_loci,
+                      OrcCalled* full_out /* optional: allele strings etc. */, int64_t* total_num_called);
 /* same, from packed observations (position, tuple) instead of reads */
 int64_t orc_run_observations(const int32_t* positions, const uint32_t* tuples, int64_t n_obs,
                       const uint8_t* ref_bases, int64_t ref_len, int32_t region_start, int32_t region_loci,

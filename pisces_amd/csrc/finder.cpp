@@ -1,0 +1,123 @@
+// finder.cpp — insertion / deletion candidate discovery on the host (see finder.h).
+#include "finder.h"
+
+#include <algorithm>
+
+namespace pisces {
+
+static inline bool op_is_ref_span(uint8_t t) { return t == 'M' || t == 'D' || t == 'N' || t == '=' || t == 'X'; }
+static inline bool op_is_read_span(uint8_t t) { return t == 'M' || t == 'I' || t == 'S' || t == '=' || t == 'X'; }
+
+static inline int dir_at(const ReadView& r, int i)
+{
+    return r.dirs ? r.dirs[i] : (r.is_reverse ? PISCES_DIR_REVERSE : PISCES_DIR_FORWARD);
+}
+
+// CandidateVariantFinder.GetSupportDirection :396-445 for insertions / deletions. Reads that carry per-base
+// directions (stitched, XD tag) take the branch the reference takes when CigarDirections == null (:422-428).
+static int support_direction(const ReadView& r, int category, int length, int startIndexInRead)
+{
+    const int leftAnchorIndex = startIndexInRead - 1;
+    const int rightAnchorIndex = category == PISCES_CAT_DELETION ? startIndexInRead : startIndexInRead + length;
+    const int lastIndex = r.read_len - 1;
+    if (rightAnchorIndex == 0) return dir_at(r, rightAnchorIndex);
+    if (leftAnchorIndex == lastIndex) return dir_at(r, lastIndex);
+    if (leftAnchorIndex == rightAnchorIndex - 1) {
+        const int startDirection = dir_at(r, leftAnchorIndex), endDirection = dir_at(r, rightAnchorIndex);
+        return startDirection == PISCES_DIR_STITCHED ? endDirection : startDirection;
+    }
+    int direction = PISCES_DIR_FORWARD;
+    for (int i = leftAnchorIndex + 1; i < rightAnchorIndex; i++) {
+        direction = dir_at(r, i);
+        if (direction == PISCES_DIR_STITCHED) return PISCES_DIR_STITCHED;
+    }
+    return direction;
+}
+
+// CandidateVariantFinder.CheckDeletionQuality :294-320
+static bool deletion_quality_ok(const ReadView& r, int opStartIndexInRead, int minBQ)
+{
+    if (r.read_len == 0) return false;
+    const int after = (opStartIndexInRead < r.read_len) ? r.quals[opStartIndexInRead] : r.quals[opStartIndexInRead - 1];
+    int before = after;
+    if (opStartIndexInRead > 0) before = r.quals[opStartIndexInRead - 1];
+    return before >= minBQ && after >= minBQ;
+}
+
+void find_indel_candidates(const ReadView& r, const uint8_t* ref, int64_t ref_len, int32_t minBQ, int32_t anchorSize,
+                           std::vector<HostCandidate>& out)
+{
+    const size_t first = out.size();
+    int refSpan = 0;
+    for (int c = 0; c < r.n_cigar; c++)
+        if (op_is_ref_span(r.cigar_op[c])) refSpan += (int)r.cigar_len[c];
+    const int endPosition = r.position + refSpan - 1;   // Read.EndPosition
+
+    // CandidateVariantFinder.Create :334-345
+    auto create = [&](int category, int coordinate, std::string refAllele, std::string altAllele, int startIndexInRead) {
+        HostCandidate c;
+        c.position = coordinate;
+        c.category = category;
+        const int length = category == PISCES_CAT_INSERTION ? (int)altAllele.size() - 1 : (int)refAllele.size() - 1;
+        const int dir = support_direction(r, category, length, startIndexInRead);
+        c.support_by_dir[dir]++;
+        const int anchor = std::min(coordinate - r.position, endPosition - coordinate);
+        if (anchor > std::min(anchorSize - 1, (int)altAllele.size() - 1)) c.well_anchored_by_dir[dir]++;
+        c.ref = std::move(refAllele);
+        c.alt = std::move(altAllele);
+        out.push_back(std::move(c));
+    };
+
+    int startIndexInRead = 0;
+    int startIndexInReference = r.position - 1;
+    for (int ci = 0; ci < r.n_cigar; ci++) {   // ProcessCigarOps :36-83
+        const uint8_t t = r.cigar_op[ci];
+        const int len = (int)r.cigar_len[ci];
+        if (t == 'I') {   // ExtractInsertionFromOperation :234-260
+            if (!(startIndexInReference - 1 >= ref_len || startIndexInReference == 0) && startIndexInRead + len <= r.read_len &&
+                r.quals[startIndexInRead] >= minBQ) {
+                std::string refAllele(1, (char)ref[startIndexInReference - 1]);
+                std::string altAllele = refAllele + std::string((const char*)r.bases + startIndexInRead, (size_t)len);
+                create(PISCES_CAT_INSERTION, startIndexInReference, refAllele, altAllele, startIndexInRead);
+            }
+        } else if (t == 'D') {   // ExtractDeletionFromOperation :262-292
+            if (!((int64_t)startIndexInReference + len >= ref_len) && startIndexInReference >= 1 &&
+                deletion_quality_ok(r, startIndexInRead, minBQ)) {
+                std::string refAllele((const char*)ref + startIndexInReference - 1, (size_t)len + 1);
+                std::string altAllele(1, (char)ref[startIndexInReference - 1]);
+                create(PISCES_CAT_DELETION, startIndexInReference, refAllele, altAllele, startIndexInRead);
+            }
+        }
+        if (op_is_read_span(t)) startIndexInRead += len;
+        if (op_is_ref_span(t)) startIndexInReference += len;
+    }
+    if (out.size() == first || r.n_cigar == 0) return;
+
+    // Annotate :496-553 — open-endedness only at the unclipped ends of the read
+    int fi = 0, li = r.n_cigar - 1;
+    if (r.cigar_op[fi] == 'S') fi = 1;
+    if (r.cigar_op[li] == 'S') li = r.n_cigar - 2;
+    if (fi >= r.n_cigar || li < 0) return;
+    // PositionMap.MaxPosition: the last mapped read base
+    int maxPosition = -1;
+    {
+        int refPos = r.position, lastMapped = -1;
+        for (int c = 0; c < r.n_cigar; c++) {
+            const bool rs = op_is_read_span(r.cigar_op[c]), fs = op_is_ref_span(r.cigar_op[c]);
+            if (rs && fs) lastMapped = refPos + (int)r.cigar_len[c] - 1;
+            if (fs) refPos += (int)r.cigar_len[c];
+        }
+        maxPosition = lastMapped;
+    }
+    if (maxPosition == -1) maxPosition = r.position - 1;
+    const uint8_t firstOp = r.cigar_op[fi], lastOp = r.cigar_op[li];
+    for (size_t i = first; i < out.size(); i++) {
+        HostCandidate& c = out[i];
+        if (firstOp == 'I' && c.position == r.position - 1 && c.category == PISCES_CAT_INSERTION) c.open_left = true;
+        if (firstOp == 'D' && c.position == r.position - 1 && c.category == PISCES_CAT_DELETION) c.open_left = true;
+        if (lastOp == 'I' && c.position == maxPosition && c.category == PISCES_CAT_INSERTION) c.open_right = true;
+        if (lastOp == 'D' && c.position == maxPosition && c.category == PISCES_CAT_DELETION) c.open_right = true;
+    }
+}
+
+}  // namespace pisces

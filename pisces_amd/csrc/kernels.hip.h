@@ -843,3 +843,214 @@ __global__ __launch_bounds__(kBlock) void call_counts_kernel(
 }
 
 }  // namespace pisces
+
+// ==========================================================================================
+// Spanning candidates (insertions / deletions found by the host finder): CoverageCalculator.CalculateSpanning
+// (lib/Pisces.Calculators/CoverageCalculator.cs:162-321) from the anchor-resolved counts in HBM, then the same
+// q-score / strand-bias / filter / genotype chain.  One lane per candidate; these are rare (a handful per block).
+// ==========================================================================================
+namespace pisces {
+
+struct DevCandidate {
+    int32_t position, category, ref_len, alt_len;
+    int32_t sup[3];
+    int32_t anch[3];
+    int32_t first_base, last_base;   // AlleleType of AlternateAllele[1] / [last] (insertions, :180-186)
+    int64_t start_idx, end_idx;      // locus index of the start / end point in the counts tensor, -1 = no block (count 0)
+    int32_t allele_off;              // ref bytes then alt bytes in the allele pool
+    int32_t pad;
+};
+
+// AlleleCountHelper.GetAnchorAdjustedAlleleCount (lib/Pisces.Processing/RegionState/AlleleCountHelper.cs:21-85)
+// over one [11] row; maxAnchor < 0 = null; symmetric is never set on this path
+__device__ inline int anchor_adjusted_count(const int32_t* __restrict__ row, int minAnchor, int maxAnchor, bool fromEnd)
+{
+    const int wellAnchoredIndex = PISCES_ANCHOR_SIZE, numAnchorIndexes = PISCES_NUM_ANCHORS;
+    const int trueMinAnchor = wellAnchoredIndex < minAnchor ? wellAnchoredIndex : minAnchor;
+    int initialMaxAnchor = wellAnchoredIndex;
+    if (maxAnchor >= 0) {
+        if (maxAnchor >= wellAnchoredIndex) initialMaxAnchor = wellAnchoredIndex - 1;
+        if (maxAnchor < wellAnchoredIndex) initialMaxAnchor = maxAnchor;
+    }
+    int tot = 0;
+    if (fromEnd) {
+        for (int i = trueMinAnchor; i <= initialMaxAnchor; i++) tot += row[numAnchorIndexes - i - 1];
+        if (maxAnchor < 0)
+            for (int i = 0; i < initialMaxAnchor; i++) tot += row[i];
+    } else {
+        for (int i = trueMinAnchor; i <= initialMaxAnchor; i++) tot += row[i];
+        if (maxAnchor < 0)
+            for (int i = initialMaxAnchor + 1; i < numAnchorIndexes; i++) tot += row[i];
+    }
+    return tot;
+}
+
+__device__ inline int get_allele_count(const int32_t* __restrict__ counts, int64_t idx, int allele, int dir, int minAnchor,
+                                       int maxAnchor, bool fromEnd)
+{
+    if (idx < 0) return 0;   // RegionStateManager.GetAlleleCount: no block -> 0 (RegionStateManager.cs:222-226)
+    return anchor_adjusted_count(counts + idx * PISCES_COUNTS_PER_LOCUS + (allele * 3 + dir) * PISCES_NUM_ANCHORS, minAnchor,
+                                 maxAnchor, fromEnd);
+}
+
+// RMxNCalculator.ComputeRMxNLengthForIndel (lib/Pisces.Calculators/RMxNCalculator.cs:50-94); ref[i] = string index i
+__device__ inline int rmxn_length_for_indel(int variantPosition, const uint8_t* __restrict__ bases, int length,
+                                            const uint8_t* __restrict__ ref, int64_t ref_len, int maxRepeatUnitLength)
+{
+    int maxRepeatsFound = 0;
+    const int lo = length - (maxRepeatUnitLength < length ? maxRepeatUnitLength : length);
+    for (int pass = 0; pass < 2; pass++) {       // prefixes, then suffixes
+        for (int i = lo; i < length; i++) {
+            const int blen = length - i;
+            const uint8_t* bookend = pass == 0 ? bases : bases + i;
+            auto matches = [&](int64_t at) {
+                for (int k = 0; k < blen; k++)
+                    if (ref[at + k] != bookend[k]) return false;
+                return true;
+            };
+            int64_t backPeekPosition = variantPosition;
+            while (true) {
+                const int64_t nb = backPeekPosition - blen;
+                if (nb < 0) break;
+                if (nb + blen > ref_len || !matches(nb)) break;
+                backPeekPosition = nb;
+            }
+            int repeatCount = 0;
+            int64_t currentPosition = backPeekPosition;
+            while (true) {
+                if (currentPosition + blen > ref_len) break;
+                if (!matches(currentPosition)) break;
+                repeatCount++;
+                currentPosition += blen;
+            }
+            if (repeatCount > maxRepeatsFound) maxRepeatsFound = repeatCount;
+        }
+    }
+    return maxRepeatsFound;
+}
+
+__global__ __launch_bounds__(64) void call_spanning_kernel(
+    const DevCandidate* __restrict__ cands, int32_t n, const int32_t* __restrict__ counts, const uint8_t* __restrict__ alleles,
+    const uint8_t* __restrict__ ref, int64_t ref_len /* ref[i] = position i+1 */, int32_t expect_stitched,
+    PiscesCalledAllele* __restrict__ out, uint8_t* __restrict__ callable_out, DeviceParams P)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const DevCandidate c = cands[i];
+    const int length = c.category == PISCES_CAT_INSERTION ? c.alt_len - 1 : c.ref_len - 1;   // BaseAllele.Length
+    const int support = c.sup[0] + c.sup[1] + c.sup[2];
+    const int wellAnchored = c.anch[0] + c.anch[1] + c.anch[2];
+    const bool presumeAnchoredForExactCov = c.category == PISCES_CAT_INSERTION ? (expect_stitched != 0) : true;   // :31-41
+    const bool bePicky = c.category == PISCES_CAT_INSERTION;   // considerAnchorInformation (TrackedAnchorSize 5 > 0), :179
+
+    int startPointCoverage[3] = {0, 0, 0}, endPointCoverage[3] = {0, 0, 0};
+    int startUnanch[3] = {0, 0, 0}, endUnanch[3] = {0, 0, 0};
+    int confidentLeft = 0, confidentRight = 0, suspiciousLeft = 0, suspiciousRight = 0;
+    const int unanchoredSupport = support - wellAnchored;
+    const int cca[5] = {PISCES_ALLELE_A, PISCES_ALLELE_C, PISCES_ALLELE_G, PISCES_ALLELE_T, PISCES_ALLELE_DEL};
+    for (int d = 0; d < 3; d++) {
+        for (int k = 0; k < 5; k++) {
+            const int at = cca[k];
+            const int minAnchorEnd = (bePicky && at == c.first_base) ? length : 0;
+            const int minAnchorStart = (bePicky && at == c.last_base) ? length : 0;
+            const int sc = get_allele_count(counts, c.start_idx, at, d, minAnchorStart, -1, false);
+            const int ec = get_allele_count(counts, c.end_idx, at, d, minAnchorEnd, -1, true);
+            startPointCoverage[d] += sc;
+            endPointCoverage[d] += ec;
+            confidentLeft += sc;
+            confidentRight += ec;
+            if (bePicky && unanchoredSupport > 0) {
+                if (minAnchorStart > 0) {
+                    const int u = get_allele_count(counts, c.start_idx, at, d, 0, minAnchorStart - 1, false);
+                    startUnanch[d] += u;
+                    suspiciousLeft += u;
+                }
+                if (minAnchorEnd > 0) {
+                    const int u = get_allele_count(counts, c.end_idx, at, d, 0, minAnchorEnd - 1, true);
+                    endUnanch[d] += u;
+                    suspiciousRight += u;
+                }
+            }
+        }
+    }
+    if (bePicky) {   // :261-293, float32 arithmetic as written
+        const float trulyAnchoredCoverage = (((confidentLeft - suspiciousRight) + (confidentRight - suspiciousLeft)) / 2.0f);
+        const float anchoredVariantFreq = trulyAnchoredCoverage <= 0 ? 0.0f : (float)wellAnchored / trulyAnchoredCoverage;
+        const int totalSuspicious = suspiciousLeft + suspiciousRight;
+        const float unanchoredVariantFreq = totalSuspicious == 0 ? 0.0f : unanchoredSupport / ((float)totalSuspicious);
+        float w = anchoredVariantFreq == 0 ? 1.0f : fminf(1.0f, unanchoredVariantFreq / anchoredVariantFreq);
+        if (!(w > 0.0f)) w = 0.0f;
+        const double weight = w;
+        for (int d = 0; d < 3; d++) {
+            startPointCoverage[d] += (int)(startUnanch[d] * weight);
+            endPointCoverage[d] += (int)(endUnanch[d] * weight);
+        }
+    }
+    // RedistributeStitchedCoverage :324-331
+    startPointCoverage[0] += (int)ceilf((float)startPointCoverage[2] / 2);
+    startPointCoverage[1] += (int)floorf((float)startPointCoverage[2] / 2);
+    endPointCoverage[0] += (int)ceilf((float)endPointCoverage[2] / 2);
+    endPointCoverage[1] += (int)floorf((float)endPointCoverage[2] / 2);
+    int cov[3] = {0, 0, 0};
+    float exactTotalCoverage = 0.0f;
+    for (int d = 0; d < 2; d++) {
+        const float e = presumeAnchoredForExactCov
+                            ? (startPointCoverage[d] + endPointCoverage[d]) / 2.0f
+                            : (float)(startPointCoverage[d] < endPointCoverage[d] ? startPointCoverage[d] : endPointCoverage[d]);
+        cov[d] = (int)e;
+        exactTotalCoverage += e;
+    }
+    const int total = (int)exactTotalCoverage;
+    int refsup = total - support;
+    if (refsup < 0) refsup = 0;
+
+    // ProcessVariant (AlleleCaller.cs:208-234)
+    int vq = 0;
+    SbResult sb = {0.0, 0, 0, 0};
+    if (support > 0) {
+        if (total != 0) vq = poisson_qscore(support, total, P);
+        sb = strand_bias(cov, c.sup, P);
+    }
+    const float freq = frequency_f(support, total);
+    uint32_t filters = 0;   // NumNoCalls stays 0 for spanning alleles -> FractionNoCalls 0
+    if (P.low_depth_filter >= 0 && total < P.low_depth_filter) filters |= 1u << PISCES_FILTER_LOW_DEPTH;
+    if (P.vq_filter >= 0 && vq < P.vq_filter && total != 0) filters |= 1u << PISCES_FILTER_LOW_VARIANT_QSCORE;
+    if (!sb.acceptable || (P.filter_single_strand && !sb.var_both)) filters |= 1u << PISCES_FILTER_STRAND_BIAS;
+    if (P.rmxn_max_len >= 0 && !(freq >= P.rmxn_freq_limit)) {   // RMxNCalculator.ShouldFilter :19-38
+        const uint8_t* vb = alleles + c.allele_off + (c.category == PISCES_CAT_INSERTION ? c.ref_len + 1 : 1);
+        const int c1 = rmxn_length_for_indel(c.position, vb, length, ref, ref_len, P.rmxn_max_len);
+        if (c1 >= P.rmxn_min_rep) filters |= 1u << PISCES_FILTER_RMXN;
+    }
+    if (P.vf_filter >= 0.0f && freq < P.vf_filter) filters |= 1u << PISCES_FILTER_LOW_VARIANT_FREQUENCY;
+    if (expect_stitched) {   // AlleleProcessor.cs:64-68
+        for (int k = 0; k < c.alt_len; k++)
+            if (alleles[c.allele_off + c.ref_len + k] == 'N') filters |= 1u << PISCES_FILTER_STRAND_BIAS;
+    }
+    bool callable = true;   // IsCallable (AlleleCaller.cs:236-258)
+    if (total < P.min_cov && !P.include_ref) callable = false;
+    else if (total != 0 && freq < P.min_freq) callable = false;
+    else if (vq < P.min_vq) callable = false;
+
+    const int gt = somatic_genotype(false, total, support, refsup, P);
+    const int gq = somatic_gq(gt, vq, total, support, P);
+    if (P.low_gq_filter >= 0 && (float)gq < (float)P.low_gq_filter) filters |= 1u << PISCES_FILTER_LOW_GENOTYPE_QUALITY;
+
+    PiscesCalledAllele r;
+    r.position = c.position;
+    r.total_coverage = total;
+    r.allele_support = support;
+    r.reference_support = refsup;
+    r.num_no_calls = 0;
+    r.coverage_by_dir[0] = cov[0]; r.coverage_by_dir[1] = cov[1]; r.coverage_by_dir[2] = 0;
+    r.support_by_dir[0] = c.sup[0]; r.support_by_dir[1] = c.sup[1]; r.support_by_dir[2] = c.sup[2];
+    r.variant_qscore = vq;
+    r.strand_bias_score = sb.bias_score;
+    r.genotype_qscore = gq;
+    r.filter_bits = (uint16_t)filters;
+    const int rt = allele_type_of_base(alleles[c.allele_off]);
+    r.info = PISCES_INFO_PACK(gt, c.category, rt, PISCES_ALLELE_N, sb.acceptable, sb.var_both, sb.cov_both);
+    out[i] = r;
+    callable_out[i] = callable ? 1 : 0;
+}
+
+}  // namespace pisces

@@ -16,6 +16,7 @@
 
 #include "../../include/pisces_hip.h"
 #include "expander.h"
+#include "finder.h"
 #include "kernels.hip.h"
 
 using namespace pisces;
@@ -29,6 +30,11 @@ constexpr int64_t kTimingRing = 4096;
 struct BlockObs {
     std::vector<int32_t> pos;
     std::vector<uint32_t> tup;
+    // insertion / deletion candidates of the block (RegionState._candidateVariantsLookup), merged by
+    // CandidateAllele.Equals (position, category, ref, alt) — the collapse-off rule of RegionState.AddCandidate
+    std::vector<HostCandidate> cands;
+    std::unordered_map<std::string, size_t> cand_index;
+    int32_t max_allele_endpoint = 0;   // RegionState.MaxAlleleEndpoint
 };
 
 template <typename T>
@@ -77,7 +83,12 @@ struct PiscesHip {
     std::string err;
 
     DeviceBuf<uint8_t> d_ref;
+    std::vector<uint8_t> h_ref;   // host copy for the indel candidate finder
     int64_t ref_len = 0;
+    DeviceBuf<DevCandidate> d_cands;
+    DeviceBuf<uint8_t> d_alleles;
+    DeviceBuf<PiscesCalledAllele> d_cand_records;
+    DeviceBuf<uint8_t> d_cand_callable;
 
     // ---- streaming state (RegionStateManager: _regionLookup, _lastUpToBlockKey) ----
     std::map<int32_t, BlockObs> blocks;   // key = GetBlockKey(position) (RegionStateManager.cs:385-391)
@@ -92,6 +103,8 @@ struct PiscesHip {
     bool pending_valid = false;
     int32_t pending_up_to = 0;
     std::vector<PiscesCalledAllele> pending;
+    std::vector<int32_t> pending_cand_index;        // per record: index into pending_cands, -1 for Reference / SNV rows
+    std::vector<HostCandidate> pending_cands;       // called insertion / deletion candidates (their allele strings)
     std::vector<int32_t> pending_keys;
     int64_t pending_called = 0;
 
@@ -267,6 +280,7 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_ref.release(); h->d_tuples.release(); h->d_tiles.release(); h->d_tile_results.release();
     h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release(); h->d_totals.release(); h->d_qlut.release(); h->d_gate.release();
+    h->d_cands.release(); h->d_alleles.release(); h->d_cand_records.release(); h->d_cand_callable.release();
     for (hipEvent_t ev : h->ring) (void)hipEventDestroy(ev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -285,6 +299,7 @@ int32_t pisces_hip_set_reference(PiscesHip* h, const uint8_t* bases, int64_t len
     PISCES_HIP_CHECK(h, h->d_ref.reserve((size_t)length));
     PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_ref.p, bases, (size_t)length, hipMemcpyHostToDevice, h->stream));
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    h->h_ref.assign(bases, bases + length);
     h->ref_len = length;
     return PISCES_OK;
 }
@@ -370,9 +385,37 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
     h->pending_valid = false;
     BlockSink sink;
     sink.h = h;
+    std::vector<HostCandidate> found;
     for (int32_t i = 0; i < batch->n_reads; i++) {
         ReadView r = read_view(batch, i);
         if (r.position <= 0) return fail(h, PISCES_E_INVALID_ARG, "Position must be greater than 0.");
+        // ICandidateVariantFinder.FindCandidates + IStateManager.AddCandidates (SmallVariantCaller.cs:92-96) for the
+        // candidates the device counts do not imply: insertions and deletions
+        bool has_indel = false;
+        for (int c = 0; c < r.n_cigar; c++) has_indel |= (r.cigar_op[c] == 'I' || r.cigar_op[c] == 'D');
+        if (has_indel && !h->h_ref.empty()) {   // without a reference only the IStateManager half (allele counts) runs
+            found.clear();
+            find_indel_candidates(r, h->h_ref.data(), h->ref_len, h->cfg.min_base_call_quality, PISCES_ANCHOR_SIZE, found);
+            for (auto& cnd : found) {
+                if (cnd.position <= 0) continue;
+                BlockObs* b = get_block(h, cnd.position);
+                std::string key = std::to_string(cnd.position) + "|" + std::to_string(cnd.category) + "|" + cnd.ref + ">" + cnd.alt;
+                auto it = b->cand_index.find(key);
+                if (it == b->cand_index.end()) {
+                    b->cand_index.emplace(std::move(key), b->cands.size());
+                    b->cands.push_back(cnd);
+                } else {
+                    HostCandidate& e = b->cands[it->second];
+                    for (int d = 0; d < 3; d++) {
+                        e.support_by_dir[d] += cnd.support_by_dir[d];
+                        e.well_anchored_by_dir[d] += cnd.well_anchored_by_dir[d];
+                    }
+                }
+                // RegionState.UpdateMaxPosition (RegionState.cs:205-223)
+                const int32_t other_end = cnd.category == PISCES_CAT_DELETION ? cnd.position + (int32_t)cnd.ref.size() : cnd.position + 1;
+                if (other_end > b->max_allele_endpoint) b->max_allele_endpoint = other_end;
+            }
+        }
         sink.staged.clear();
         int32_t rc = expand_read(r, h->cfg.min_base_call_quality, sink);
         if (rc == PISCES_E_UNMAPPED_BASE)
@@ -402,6 +445,38 @@ int64_t pisces_hip_expand_reads(const PiscesReadBatch* batch, int32_t min_bq, in
         if (rc != PISCES_OK) return rc;
     }
     return sink.n <= capacity ? sink.n : (int64_t)PISCES_E_BUFFER_TOO_SMALL;
+}
+
+int64_t pisces_hip_find_indel_candidates(const PiscesReadBatch* batch, const uint8_t* ref, int64_t ref_len, int32_t min_bq,
+                                         PiscesCandidate* out, int64_t capacity, uint8_t* alleles, int64_t allele_capacity,
+                                         int64_t* allele_bytes)
+{
+    if (validate_batch(batch) != PISCES_OK || !ref || ref_len <= 0 || capacity < 0 || (capacity > 0 && !out)) return PISCES_E_INVALID_ARG;
+    std::vector<HostCandidate> found;
+    for (int32_t i = 0; i < batch->n_reads; i++)
+        find_indel_candidates(read_view(batch, i), ref, ref_len, min_bq, PISCES_ANCHOR_SIZE, found);
+    int64_t bytes = 0;
+    for (size_t i = 0; i < found.size(); i++) {
+        const HostCandidate& c = found[i];
+        const int64_t need = (int64_t)(c.ref.size() + c.alt.size());
+        if ((int64_t)i < capacity && (!alleles || bytes + need <= allele_capacity)) {
+            PiscesCandidate& o = out[i];
+            std::memset(&o, 0, sizeof(o));
+            o.position = c.position; o.category = c.category;
+            o.ref_len = (int32_t)c.ref.size(); o.alt_len = (int32_t)c.alt.size();
+            for (int d = 0; d < 3; d++) { o.support_by_dir[d] = c.support_by_dir[d]; o.well_anchored_by_dir[d] = c.well_anchored_by_dir[d]; }
+            o.open_left = c.open_left; o.open_right = c.open_right;
+            o.allele_offset = bytes;
+            if (alleles) {
+                std::memcpy(alleles + bytes, c.ref.data(), c.ref.size());
+                std::memcpy(alleles + bytes + c.ref.size(), c.alt.data(), c.alt.size());
+            }
+        }
+        bytes += need;
+    }
+    if (allele_bytes) *allele_bytes = bytes;
+    if ((int64_t)found.size() > capacity || (alleles && bytes > allele_capacity)) return PISCES_E_BUFFER_TOO_SMALL;
+    return (int64_t)found.size();
 }
 
 // Builds tiles + tile-bucketed tuples for a set of blocks. Tiles follow the 1000-locus block grid
@@ -565,12 +640,128 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
     return PISCES_OK;
 }
 
-int32_t pisces_hip_flush(PiscesHip* h, int32_t up_to_position, PiscesCalledAllele* out, int64_t capacity, int64_t* n_out)
+// IAlleleCaller.Call for the host-found insertion / deletion candidates of `keys`: anchor-resolved counts of every
+// block a candidate touches -> call_spanning_kernel -> callable candidates with their records.
+static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, std::vector<PiscesCalledAllele>& recs,
+                             std::vector<HostCandidate>& called, int64_t* n_called)
+{
+    recs.clear();
+    called.clear();
+    std::vector<const HostCandidate*> cands;
+    for (int32_t key : keys)
+        for (auto& c : h->blocks[key].cands) cands.push_back(&c);
+    if (cands.empty()) return PISCES_OK;
+    const int bs = h->cfg.block_size;
+    // start / end points (CoverageCalculator.Compute :27-41)
+    auto endpoints = [](const HostCandidate& c, int32_t& sp, int32_t& ep) {
+        if (c.category == PISCES_CAT_DELETION) { sp = c.position + 1; ep = c.position + (int32_t)c.ref.size() - 1; }
+        else { sp = c.position; ep = c.position + 1; }
+    };
+    std::vector<int32_t> bkeys;
+    for (auto* c : cands) {
+        int32_t sp, ep;
+        endpoints(*c, sp, ep);
+        for (int32_t p : {sp, ep}) {
+            const int32_t k = block_key(h, p);
+            if (p > 0 && h->blocks.count(k)) bkeys.push_back(k);
+        }
+    }
+    std::sort(bkeys.begin(), bkeys.end());
+    bkeys.erase(std::unique(bkeys.begin(), bkeys.end()), bkeys.end());
+    // counts over the whole block grid of those blocks (not the interval-clipped tiles)
+    auto saved = h->intervals;
+    h->intervals.clear();
+    std::vector<PiscesTile> tiles;
+    std::vector<uint32_t> tuples;
+    build_tiles(h, bkeys, tiles, tuples);
+    h->intervals = saved;
+    const int32_t n_tiles = (int32_t)tiles.size();
+    const int tiles_per_block = (bs + kTile - 1) / kTile;
+    auto locus_index = [&](int32_t p) -> int64_t {
+        if (p <= 0) return -1;
+        const int32_t k = block_key(h, p);
+        auto it = std::lower_bound(bkeys.begin(), bkeys.end(), k);
+        if (it == bkeys.end() || *it != k) return -1;
+        const int64_t bi = it - bkeys.begin();
+        const int32_t off = p - ((k - 1) * bs + 1);
+        return (bi * tiles_per_block + off / kTile) * kTile + off % kTile;
+    };
+    if (n_tiles > 0) {
+        int32_t rc = upload_tiles(h, tiles, tuples);
+        if (rc) return rc;
+        const size_t nc = (size_t)n_tiles * kTile * PISCES_COUNTS_PER_LOCUS;
+        PISCES_HIP_CHECK(h, h->d_counts.reserve(nc));
+        PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_counts.p, 0, nc * sizeof(int32_t), h->stream));
+        hipLaunchKernelGGL(accumulate_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles,
+                           h->d_counts.p, h->cfg.min_base_call_quality);
+    } else {
+        PISCES_HIP_CHECK(h, h->d_counts.reserve(PISCES_COUNTS_PER_LOCUS));
+    }
+    std::vector<DevCandidate> dc(cands.size());
+    std::vector<uint8_t> pool;
+    auto atype = [](char ch) { return ch == 'A' ? 0 : ch == 'G' ? 1 : ch == 'C' ? 2 : ch == 'T' ? 3 : 4; };
+    for (size_t i = 0; i < cands.size(); i++) {
+        const HostCandidate& c = *cands[i];
+        DevCandidate& d = dc[i];
+        std::memset(&d, 0, sizeof(d));
+        d.position = c.position;
+        d.category = c.category;
+        d.ref_len = (int32_t)c.ref.size();
+        d.alt_len = (int32_t)c.alt.size();
+        for (int k = 0; k < 3; k++) { d.sup[k] = c.support_by_dir[k]; d.anch[k] = c.well_anchored_by_dir[k]; }
+        d.first_base = d.last_base = PISCES_ALLELE_N;
+        if (c.category == PISCES_CAT_INSERTION && c.alt.size() >= 2) {
+            d.first_base = atype(c.alt[1]);
+            d.last_base = atype(c.alt[c.alt.size() - 1]);
+        }
+        int32_t sp, ep;
+        endpoints(c, sp, ep);
+        d.start_idx = locus_index(sp);
+        d.end_idx = locus_index(ep);
+        d.allele_off = (int32_t)pool.size();
+        pool.insert(pool.end(), c.ref.begin(), c.ref.end());
+        pool.insert(pool.end(), c.alt.begin(), c.alt.end());
+    }
+    const int32_t n = (int32_t)dc.size();
+    PISCES_HIP_CHECK(h, h->d_cands.reserve(dc.size()));
+    PISCES_HIP_CHECK(h, h->d_alleles.reserve(pool.size() + 16));
+    PISCES_HIP_CHECK(h, h->d_cand_records.reserve(dc.size()));
+    PISCES_HIP_CHECK(h, h->d_cand_callable.reserve(dc.size()));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_cands.p, dc.data(), dc.size() * sizeof(DevCandidate), hipMemcpyHostToDevice, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_alleles.p, pool.data(), pool.size(), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(call_spanning_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, h->d_cands.p, n, h->d_counts.p,
+                       h->d_alleles.p, h->d_ref.p, h->ref_len, h->cfg.expect_stitched_reads, h->d_cand_records.p, h->d_cand_callable.p, h->P);
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    std::vector<PiscesCalledAllele> raw(dc.size());
+    std::vector<uint8_t> callable(dc.size());
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(raw.data(), h->d_cand_records.p, raw.size() * sizeof(PiscesCalledAllele), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(callable.data(), h->d_cand_callable.p, callable.size(), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < dc.size(); i++) {
+        if (!callable[i]) continue;
+        // ShouldReport (AlleleCaller.cs:260-263): inside the interval set
+        if (!h->intervals.empty()) {
+            bool inside = false;
+            for (auto& iv : h->intervals) inside |= (cands[i]->position >= iv.first && cands[i]->position <= iv.second);
+            if (!inside) { (*n_called)++; continue; }
+        }
+        (*n_called)++;
+        recs.push_back(raw[i]);
+        called.push_back(*cands[i]);
+    }
+    return PISCES_OK;
+}
+
+int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAllele* out, int64_t capacity, int64_t* n_out,
+                            int32_t* cand_index_out, PiscesCandidate* cand_out, int64_t cand_capacity, int64_t* n_cand,
+                            uint8_t* alleles_out, int64_t allele_capacity, int64_t* allele_bytes)
 {
     if (!h) return PISCES_E_INVALID_ARG;
     if (!n_out || capacity < 0 || (capacity > 0 && !out)) return fail(h, PISCES_E_INVALID_ARG, "flush: null output");
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     *n_out = 0;
+    if (n_cand) *n_cand = 0;
+    if (allele_bytes) *allele_bytes = 0;
     const bool final_flush = up_to_position < 0;
     const bool replay = h->pending_valid && h->pending_up_to == up_to_position;
     if (!replay) {
@@ -578,21 +769,81 @@ int32_t pisces_hip_flush(PiscesHip* h, int32_t up_to_position, PiscesCalledAllel
         // onto another block; take blocks that lie wholly at or below upTo.
         if (!final_flush && block_key(h, up_to_position) == h->last_up_to_block_key) return PISCES_OK;
         std::vector<int32_t> keys;
-        for (auto& kv : h->blocks)
-            if (final_flush || (int64_t)kv.first * h->cfg.block_size <= up_to_position) keys.push_back(kv.first);
+        for (auto& kv : h->blocks) {   // std::map: ascending keys
+            if (!(final_flush || (int64_t)kv.first * h->cfg.block_size <= up_to_position)) continue;
+            // a block whose spanning alleles reach past upTo is held, and so is everything after it (:304-308)
+            if (!final_flush && kv.second.max_allele_endpoint > up_to_position) break;
+            keys.push_back(kv.first);
+        }
         int64_t called = 0;
-        int32_t rc = call_blocks(h, keys, h->pending, &called);
+        std::vector<PiscesCalledAllele> point_recs, span_recs;
+        std::vector<HostCandidate> span_cands;
+        int32_t rc = call_blocks(h, keys, point_recs, &called);
         if (rc) return rc;
+        rc = call_spanning(h, keys, span_recs, span_cands, &called);
+        if (rc) return rc;
+        // per locus: drop the Reference row when a variant is reported there (AlleleCaller.cs:146-147), then order by
+        // position, reference allele, alternate allele (:172-176; ordinal order of upper-case ASCII allele strings)
+        h->pending.clear();
+        h->pending_cand_index.clear();
+        h->pending_cands = span_cands;
+        if (span_recs.empty()) {
+            h->pending = std::move(point_recs);
+            h->pending_cand_index.assign(h->pending.size(), -1);
+        } else {
+            struct Row { const PiscesCalledAllele* r; int32_t ci; std::string ref, alt; };
+            static const char kBase[6] = {'A', 'G', 'C', 'T', 'N', 'D'};
+            std::vector<Row> rows;
+            std::vector<int32_t> variant_pos;
+            for (auto& r : span_recs) variant_pos.push_back(r.position);
+            std::sort(variant_pos.begin(), variant_pos.end());
+            for (auto& r : point_recs) {
+                const bool is_ref = PISCES_INFO_CATEGORY(r.info) == PISCES_CAT_REFERENCE;
+                if (is_ref && std::binary_search(variant_pos.begin(), variant_pos.end(), r.position)) continue;
+                rows.push_back({&r, -1, std::string(1, kBase[PISCES_INFO_REF(r.info)]), std::string(1, kBase[PISCES_INFO_ALT(r.info)])});
+            }
+            for (size_t i = 0; i < span_recs.size(); i++) rows.push_back({&span_recs[i], (int32_t)i, span_cands[i].ref, span_cands[i].alt});
+            std::stable_sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) {
+                if (a.r->position != b.r->position) return a.r->position < b.r->position;
+                if (a.ref != b.ref) return a.ref < b.ref;
+                return a.alt < b.alt;
+            });
+            for (auto& row : rows) { h->pending.push_back(*row.r); h->pending_cand_index.push_back(row.ci); }
+        }
         h->pending_keys = keys;
         h->pending_called = called;
         h->pending_up_to = up_to_position;
         h->pending_valid = true;
     }
-    if ((int64_t)h->pending.size() > capacity) {
+    int64_t pool_bytes = 0;
+    for (auto& c : h->pending_cands) pool_bytes += (int64_t)(c.ref.size() + c.alt.size());
+    if (n_cand) *n_cand = (int64_t)h->pending_cands.size();
+    if (allele_bytes) *allele_bytes = pool_bytes;
+    const bool cand_too_small = cand_out && ((int64_t)h->pending_cands.size() > cand_capacity || (alleles_out && pool_bytes > allele_capacity));
+    if ((int64_t)h->pending.size() > capacity || cand_too_small) {
         *n_out = (int64_t)h->pending.size();
         return fail(h, PISCES_E_BUFFER_TOO_SMALL, "flush: output buffer too small");
     }
     if (!h->pending.empty()) std::memcpy(out, h->pending.data(), h->pending.size() * sizeof(PiscesCalledAllele));
+    if (cand_index_out && !h->pending.empty()) std::memcpy(cand_index_out, h->pending_cand_index.data(), h->pending.size() * sizeof(int32_t));
+    if (cand_out) {
+        int64_t off = 0;
+        for (size_t i = 0; i < h->pending_cands.size(); i++) {
+            const HostCandidate& c = h->pending_cands[i];
+            PiscesCandidate& o = cand_out[i];
+            std::memset(&o, 0, sizeof(o));
+            o.position = c.position; o.category = c.category;
+            o.ref_len = (int32_t)c.ref.size(); o.alt_len = (int32_t)c.alt.size();
+            for (int d = 0; d < 3; d++) { o.support_by_dir[d] = c.support_by_dir[d]; o.well_anchored_by_dir[d] = c.well_anchored_by_dir[d]; }
+            o.open_left = c.open_left; o.open_right = c.open_right;
+            o.allele_offset = off;
+            if (alleles_out) {
+                std::memcpy(alleles_out + off, c.ref.data(), c.ref.size());
+                std::memcpy(alleles_out + off + c.ref.size(), c.alt.data(), c.alt.size());
+            }
+            off += (int64_t)(c.ref.size() + c.alt.size());
+        }
+    }
     *n_out = (int64_t)h->pending.size();
     // DoneProcessing (RegionStateManager.cs:336-353)
     for (int32_t key : h->pending_keys) {
@@ -606,8 +857,15 @@ int32_t pisces_hip_flush(PiscesHip* h, int32_t up_to_position, PiscesCalledAllel
     h->last_up_to_block_key = final_flush ? -1 : block_key(h, up_to_position);
     h->pending_valid = false;
     h->pending.clear();
+    h->pending_cand_index.clear();
+    h->pending_cands.clear();
     h->pending_keys.clear();
     return PISCES_OK;
+}
+
+int32_t pisces_hip_flush(PiscesHip* h, int32_t up_to_position, PiscesCalledAllele* out, int64_t capacity, int64_t* n_out)
+{
+    return pisces_hip_flush_ex(h, up_to_position, out, capacity, n_out, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr);
 }
 
 int32_t pisces_hip_get_counts(PiscesHip* h, int32_t start_position, int32_t n, int32_t* out)
@@ -665,12 +923,35 @@ int32_t pisces_hip_add_gapped_mnv_ref(PiscesHip* h, const int32_t* positions, co
     return PISCES_OK;
 }
 
-int32_t pisces_hip_get_candidates(PiscesHip* h, int32_t, PiscesCandidate*, int64_t, int64_t* n_out, uint8_t*, int64_t, int64_t* allele_bytes)
+int32_t pisces_hip_get_candidates(PiscesHip* h, int32_t up_to_position, PiscesCandidate* out, int64_t capacity, int64_t* n_out,
+                                  uint8_t* alleles, int64_t allele_capacity, int64_t* allele_bytes)
 {
-    if (!h) return PISCES_E_INVALID_ARG;
-    // MNV / indel candidate discovery is SURVEY §8 row f1 (next): SNV candidates never leave the device.
-    if (n_out) *n_out = 0;
-    if (allele_bytes) *allele_bytes = 0;
+    if (!h || !n_out) return PISCES_E_INVALID_ARG;
+    // the insertion / deletion candidates collected so far (SNV candidates never leave the device; MNV discovery
+    // is SURVEY section 8 row f1)
+    int64_t n = 0, bytes = 0;
+    for (auto& kv : h->blocks)
+        for (auto& c : kv.second.cands) {
+            if (up_to_position >= 0 && c.position > up_to_position) continue;
+            if (out && n < capacity && (!alleles || bytes + (int64_t)(c.ref.size() + c.alt.size()) <= allele_capacity)) {
+                PiscesCandidate& o = out[n];
+                std::memset(&o, 0, sizeof(o));
+                o.position = c.position; o.category = c.category;
+                o.ref_len = (int32_t)c.ref.size(); o.alt_len = (int32_t)c.alt.size();
+                for (int d = 0; d < 3; d++) { o.support_by_dir[d] = c.support_by_dir[d]; o.well_anchored_by_dir[d] = c.well_anchored_by_dir[d]; }
+                o.open_left = c.open_left; o.open_right = c.open_right;
+                o.allele_offset = bytes;
+                if (alleles) {
+                    std::memcpy(alleles + bytes, c.ref.data(), c.ref.size());
+                    std::memcpy(alleles + bytes + c.ref.size(), c.alt.data(), c.alt.size());
+                }
+            }
+            n++;
+            bytes += (int64_t)(c.ref.size() + c.alt.size());
+        }
+    *n_out = n;
+    if (allele_bytes) *allele_bytes = bytes;
+    if (out && (n > capacity || (alleles && bytes > allele_capacity))) return fail(h, PISCES_E_BUFFER_TOO_SMALL, "get_candidates: buffer too small");
     return PISCES_OK;
 }
 

@@ -116,6 +116,54 @@ class HipVariantCaller:
             _check(self._h, rc)
             return out[: n.value]
 
+    def CallWithAlleles(self, upToPosition=None, capacity=1 << 16):
+        """Call() that also returns the (ref, alt) allele strings of every row: Reference / SNV rows from the record's
+        base codes, insertion / deletion rows from the candidate the library found (pisces_hip_flush_ex)."""
+        up_to = -1 if upToPosition is None else int(upToPosition)
+        cand_cap, pool_cap = 1024, 1 << 16
+        while True:
+            out = np.zeros(capacity, dtype=_abi.CALLED_ALLELE_DTYPE)
+            idx = np.zeros(capacity, dtype=np.int32)
+            cands = (_abi.PiscesCandidate * cand_cap)()
+            pool = np.zeros(pool_cap, dtype=np.uint8)
+            n, nc, nb = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+            rc = lib.pisces_hip_flush_ex(self._h, up_to, out.ctypes.data, capacity, C.byref(n), idx.ctypes.data, cands, cand_cap,
+                                         C.byref(nc), pool.ctypes.data, pool_cap, C.byref(nb))
+            if rc == _abi.E_BUFFER_TOO_SMALL:
+                capacity = max(capacity, int(n.value))
+                cand_cap = max(cand_cap, int(nc.value))
+                pool_cap = max(pool_cap, int(nb.value))
+                continue
+            _check(self._h, rc)
+            recs = out[: n.value]
+            alleles = []
+            for r, ci in zip(recs, idx[: n.value]):
+                if ci < 0:
+                    alleles.append((_abi.BASE_OF_ALLELE[_abi.info_ref(r["info"])], _abi.BASE_OF_ALLELE[_abi.info_alt(r["info"])]))
+                else:
+                    c = cands[ci]
+                    o = c.allele_offset
+                    alleles.append((bytes(pool[o: o + c.ref_len]).decode(), bytes(pool[o + c.ref_len: o + c.ref_len + c.alt_len]).decode()))
+            return recs, alleles
+
+    def GetCandidates(self, upToPosition=None):
+        """The insertion / deletion candidates held by the state manager: list of dicts."""
+        up_to = -1 if upToPosition is None else int(upToPosition)
+        n, nb = C.c_int64(0), C.c_int64(0)
+        _check(self._h, lib.pisces_hip_get_candidates(self._h, up_to, None, 0, C.byref(n), None, 0, C.byref(nb)))
+        cands = (_abi.PiscesCandidate * max(1, n.value))()
+        pool = np.zeros(max(1, nb.value), dtype=np.uint8)
+        _check(self._h, lib.pisces_hip_get_candidates(self._h, up_to, cands, n.value, C.byref(n), pool.ctypes.data, nb.value, C.byref(nb)))
+        out = []
+        for i in range(n.value):
+            c = cands[i]
+            o = c.allele_offset
+            out.append({"position": c.position, "category": c.category, "ref": bytes(pool[o: o + c.ref_len]).decode(),
+                        "alt": bytes(pool[o + c.ref_len: o + c.ref_len + c.alt_len]).decode(),
+                        "support_by_dir": list(c.support_by_dir), "well_anchored_by_dir": list(c.well_anchored_by_dir),
+                        "open_left": bool(c.open_left), "open_right": bool(c.open_right)})
+        return out
+
     def Stats(self):
         s = (C.c_int64 * 4)()
         _check(self._h, lib.pisces_hip_stats(self._h, s))
@@ -192,3 +240,30 @@ def expand_reads(batch, min_base_call_quality=20):
         if n < 0:
             raise PiscesHipError(int(n), "expand_reads failed")
         return pos[:n], tup[:n]
+
+
+def find_indel_candidates(batch, ref, min_base_call_quality=20):
+    """Host finder for insertions / deletions (pisces_hip_find_indel_candidates): list of dicts in read order."""
+    refa = np.ascontiguousarray(np.frombuffer(ref, dtype=np.uint8) if isinstance(ref, (bytes, bytearray)) else ref, np.uint8)
+    cap, pool_cap = 4096, 1 << 18
+    while True:
+        cands = (_abi.PiscesCandidate * cap)()
+        pool = np.zeros(pool_cap, dtype=np.uint8)
+        nb = C.c_int64(0)
+        n = lib.pisces_hip_find_indel_candidates(C.byref(batch.c), refa.ctypes.data, refa.size, min_base_call_quality, cands, cap,
+                                                 pool.ctypes.data, pool_cap, C.byref(nb))
+        if n == _abi.E_BUFFER_TOO_SMALL:
+            cap *= 4
+            pool_cap = max(pool_cap * 4, int(nb.value))
+            continue
+        if n < 0:
+            raise PiscesHipError(int(n), "find_indel_candidates failed")
+        out = []
+        for i in range(n):
+            c = cands[i]
+            o = c.allele_offset
+            out.append({"position": c.position, "category": c.category, "ref": bytes(pool[o: o + c.ref_len]).decode(),
+                        "alt": bytes(pool[o + c.ref_len: o + c.ref_len + c.alt_len]).decode(),
+                        "support_by_dir": list(c.support_by_dir), "well_anchored_by_dir": list(c.well_anchored_by_dir),
+                        "open_left": bool(c.open_left), "open_right": bool(c.open_right)})
+        return out

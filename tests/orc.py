@@ -123,6 +123,8 @@ def _load():
                                P(i64)]),
         "orc_run_reads": (i64, [P(_abi.PiscesReadBatch), P(C.c_uint8), i64, i32, i32, P(_abi.PiscesHipConfig),
                                 C.c_void_p, i64, P(i64)]),
+        "orc_run_reads_full": (i64, [P(_abi.PiscesReadBatch), P(C.c_uint8), i64, i32, i32, P(_abi.PiscesHipConfig),
+                                     C.c_void_p, i64, P(i64), P(OrcCalled), P(i64)]),
         "orc_run_observations": (i64, [P(i32), P(C.c_uint32), i64, P(C.c_uint8), i64, i32, i32,
                                        P(_abi.PiscesHipConfig), C.c_void_p, i64, P(i64)]),
         "orc_default_config": (None, [P(_abi.PiscesHipConfig)]),
@@ -289,3 +291,16 @@ def run_reads(batch, ref, region_start, region_loci, cfg):
                           region_loci, C.byref(cfg), out.ctypes.data, cap, C.byref(nloci))
     assert n >= 0, n
     return out[:n], nloci.value
+
+
+def run_reads_full(batch, ref, region_start, region_loci, cfg):
+    """run_reads + the full CalledAllele working set (allele strings) + TotalNumCalled."""
+    refa = np.ascontiguousarray(ref, np.uint8)
+    cap = region_loci * 5 + 16
+    out = np.zeros(cap, dtype=_abi.CALLED_ALLELE_DTYPE)
+    full = (OrcCalled * cap)()
+    nloci, total = C.c_int64(0), C.c_int64(0)
+    n = lib.orc_run_reads_full(C.byref(batch.c), refa.ctypes.data_as(C.POINTER(C.c_uint8)), len(refa), region_start,
+                               region_loci, C.byref(cfg), out.ctypes.data, cap, C.byref(nloci), full, C.byref(total))
+    assert n >= 0, n
+    return out[:n], [(full[i].ref.decode(), full[i].alt.decode()) for i in range(n)], nloci.value, total.value

@@ -325,3 +325,87 @@ def test_full_size_properties_config2(torch_cuda):
     pos, tup = synth.observations_of(p, n_t)
     exp, _ = orc.run_observations(pos, tup, p.ref.cpu().numpy(), p.region_start, n_t * 64, cfg)
     assert_records_match(got[got["position"] < p.region_start + n_t * 64], exp)
+
+
+# ---------------------------------------------------------------- insertions / deletions (host finder + spanning coverage on the device)
+def _indel_reads(rng, ref, start, depth, plan, read_len=150, p_lowq=0.02):
+    """`depth` reads of one amplicon at `start`; plan = list of (offset_in_read, kind 'D'|'I', length, fraction)."""
+    reads = []
+    for i in range(depth):
+        ops, seq, ref_off = [], [], 0
+        cursor = 0   # offset in amplicon (reference coordinates, 0-based from start)
+        events = sorted([e for e in plan if rng.random() < e[3]], key=lambda e: e[0])
+        for off, kind, ln, _ in events:
+            if off <= cursor:
+                continue
+            ops.append(("M", off - cursor))
+            seq.append(ref[start - 1 + cursor: start - 1 + off])
+            cursor = off
+            if kind == "D":
+                ops.append(("D", ln))
+                cursor += ln
+            else:
+                ops.append(("I", ln))
+                seq.append(bytes(rng.choice(list(b"ACGT"), ln).astype(np.uint8)))
+        tail = read_len - sum(l for o, l in ops if o in "MI")
+        if tail > 0:
+            ops.append(("M", tail))
+            seq.append(ref[start - 1 + cursor: start - 1 + cursor + tail])
+        s = b"".join(seq)
+        q = np.where(rng.random(len(s)) < p_lowq, 12, 37).astype(np.uint8)
+        reads.append({"pos": start, "cigar": ops, "seq": s.decode(), "quals": q.tolist(), "reverse": bool(i % 2)})
+    return reads
+
+
+def test_indels_match_oracle_with_allele_strings(torch_cuda):
+    from pisces_amd import engine
+    rng = np.random.default_rng(42)
+    ref = bytes(rng.choice(list(b"ACGT"), 1400).astype(np.uint8))
+    ref = ref[:300] + b"A" * 12 + ref[312:]          # a homopolymer: deletions inside it get the RMxN filter
+    reads = []
+    reads += _indel_reads(rng, ref, 101, 80, [(40, "D", 3, 0.3), (90, "I", 2, 0.25), (3, "I", 1, 0.2), (140, "D", 5, 0.2)])
+    reads += _indel_reads(rng, ref, 251, 80, [(52, "D", 2, 0.4), (100, "I", 6, 0.1), (100, "D", 1, 0.1)])
+    reads += _indel_reads(rng, ref, 401, 60, [(75, "D", 10, 0.5)])
+    reads += _indel_reads(rng, ref, 930, 70, [(68, "D", 7, 0.35), (20, "I", 3, 0.3)])   # deletion across the 1000 block edge
+    batch = _abi.ReadBatch(reads)
+    refa = np.frombuffer(ref, dtype=np.uint8)
+    for overrides in (dict(), dict(include_reference_calls=0), dict(min_frequency=0.3, variant_freq_filter=0.3)):
+        cfg = _abi.default_config(**overrides)
+        exp, exp_alleles, _, exp_called = orc.run_reads_full(batch, refa, 1, len(ref), cfg)
+        with engine.HipVariantCaller(cfg) as c:
+            c.SetReference(refa)
+            c.AddAlleleCounts(batch)
+            cands = c.GetCandidates()
+            got, got_alleles = c.CallWithAlleles()
+            assert c.Stats()["TotalNumCalled"] == exp_called
+        assert any(x["category"] == _abi.CAT_DELETION for x in cands) and any(x["category"] == _abi.CAT_INSERTION for x in cands)
+        assert_records_match(got, exp)
+        assert got_alleles == exp_alleles
+        cats = {int(_abi.info_category(i)) for i in got["info"]}
+        if not overrides:
+            assert {_abi.CAT_DELETION, _abi.CAT_INSERTION, _abi.CAT_SNV, _abi.CAT_REFERENCE} >= cats >= {_abi.CAT_DELETION, _abi.CAT_INSERTION}
+            rmxn_rows = [(r, a) for r, a in zip(got, got_alleles)
+                         if _abi.info_category(r["info"]) == _abi.CAT_DELETION and 295 <= r["position"] <= 312]
+    # the deletion inside the A homopolymer carries the RMxN filter (and the oracle agrees: filter_bits matched above)
+    assert rmxn_rows and all(r["filter_bits"] & (1 << _abi.FILTER_RMXN) for r, _ in rmxn_rows)
+
+
+def test_spanning_alleles_hold_their_block(torch_cuda):
+    """A block whose deletion reaches past upTo is not emitted (RegionStateManager.cs:304-308)."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(3)
+    ref = bytes(rng.choice(list(b"ACGT"), 2400).astype(np.uint8))
+    reads = _indel_reads(rng, ref, 930, 50, [(68, "D", 7, 0.5)])     # deletion 998..1004, anchor 997, endpoint 1005
+    batch = _abi.ReadBatch(reads)
+    refa = np.frombuffer(ref, dtype=np.uint8)
+    cfg = _abi.default_config()
+    exp, exp_alleles, _, _ = orc.run_reads_full(batch, refa, 1, len(ref), cfg)
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(refa)
+        c.AddAlleleCounts(batch)
+        assert len(c.Call(1001)) == 0          # block 1 is held: MaxAlleleEndpoint 1005 > 1001
+        out2, al2 = c.CallWithAlleles(2001)    # entering block 3: blocks 1 and 2 are released together
+        rest, al3 = c.CallWithAlleles(None)
+    got = np.concatenate([out2, rest])
+    assert_records_match(got, exp)
+    assert al2 + al3 == exp_alleles

@@ -109,3 +109,36 @@ def test_synthetic_pileup_reads_and_tuples_agree():
     epos, etup = engine.expand_reads(synth.reads_of(p), 20)
     key = lambda P, T: np.sort((P.astype(np.int64) << 32) | (T & ~np.uint32(0x7FFF)).astype(np.int64))
     np.testing.assert_array_equal(key(epos, etup), key(pos, tup))
+
+
+def test_indel_finder_matches_oracle_finder():
+    """pisces_hip_find_indel_candidates (host C++) vs the oracle's CandidateVariantFinder restatement, per read:
+    coordinates, alleles, support direction, well-anchored support and open-end flags of every insertion / deletion."""
+    rng = np.random.default_rng(11)
+    ref = bytes(rng.choice(list(b"ACGT"), 600).astype(np.uint8))
+    reads = []
+    for _ in range(400):
+        ops = []
+        for k in range(int(rng.integers(1, 6))):
+            ops.append((str(rng.choice(list("MMMIDS"))), int(rng.integers(1, 9))))
+        ops = [(o, l) for i, (o, l) in enumerate(ops) if o != "S" or i in (0, len(ops) - 1)]
+        if not any(o == "M" for o, _ in ops):
+            ops.insert(len(ops) // 2, ("M", 4))
+        rl = sum(l for o, l in ops if o in "MIS")
+        stitched = rng.random() < 0.3
+        reads.append({"pos": int(rng.integers(20, 500)), "cigar": ops,
+                      "seq": "".join(rng.choice(list("ACGT"), rl)),
+                      "quals": rng.choice([10, 25, 37], rl, p=[.15, .15, .7]).astype(np.uint8).tolist(),
+                      "reverse": bool(rng.integers(0, 2)),
+                      "dirs": rng.choice([0, 1, 2], rl).tolist() if stitched else None})
+    got = engine.find_indel_candidates(_abi.ReadBatch(reads), ref, 20)
+    exp = []
+    for d in reads:
+        rd = orc.make_read(d["pos"], d["seq"], cigar=d["cigar"], quals=d["quals"], reverse=d["reverse"], dirs=d["dirs"])
+        for c in orc.find_candidates(rd, ref.decode()):
+            if c.category in (_abi.CAT_INSERTION, _abi.CAT_DELETION):
+                exp.append({"position": c.position, "category": c.category, "ref": c.ref.decode(), "alt": c.alt.decode(),
+                            "support_by_dir": list(c.support_by_dir), "well_anchored_by_dir": list(c.well_anchored_by_dir),
+                            "open_left": bool(c.open_left), "open_right": bool(c.open_right)})
+    assert len(exp) > 100
+    assert got == exp
