@@ -103,15 +103,15 @@ def main():
         p.qual = p.qual if p is ring[0] else None
     torch.cuda.empty_cache()
     n_tiles = ring[0].n_tiles
-    cap = n_tiles * 256   # fixed 256-slot stride per tile: no allocation atomics, deterministic placement
+    cap = n_tiles * _abi.SLOTS_PER_TILE   # slot layout (include/pisces_hip.h PiscesTileResult): no allocation atomics
     records = torch.zeros(cap * 64, dtype=torch.uint8, device=dev)
-    tile_results = torch.zeros(n_tiles * 16, dtype=torch.uint8, device=dev)
+    tile_results = torch.zeros(n_tiles * _abi.TILE_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev)
 
     def step(i):
         p = ring[i % RING_BATCHES]
         caller.call_tiles(p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), 1, p.ref_len,
-                          records.data_ptr(), cap, None, tile_results.data_ptr(), stream.cuda_stream)
+                          records.data_ptr(), cap, tile_results.data_ptr(), stream.cuda_stream)
 
     def barrier():
         if world > 1:

@@ -159,12 +159,17 @@ typedef struct PiscesTile {
     int64_t tuple_end;
 } PiscesTile;
 
-/* per-tile output directory entry written by the device */
+/* per-tile output directory entry written by the device (48 bytes).
+ * The record of (locus l of the tile, allele of alphabetical rank k in A,C,G,T) lives in slot
+ * record_begin + 4*l + k of the record buffer; bit (4*l + k) of valid[] says whether that slot holds a called
+ * allele.  Walking the valid slots in ascending order yields the tile's alleles sorted by (position, ref, alt);
+ * a Reference allele sits at the rank of its base and is not marked valid when a variant is called at its locus. */
 typedef struct PiscesTileResult {
-    int32_t record_begin;     /* index of the tile's first record in the record buffer */
-    int32_t n_records;        /* called alleles of this tile, sorted by (position, ref, alt) */
+    int32_t record_begin;     /* 256 * tile index */
+    int32_t n_records;        /* number of valid slots */
     int32_t n_candidate_loci; /* positions with >= 1 called allele */
-    int32_t reserved;
+    int32_t n_called;         /* alleles for which IsCallable was true (IAlleleCaller.TotalNumCalled) */
+    uint32_t valid[8];        /* 256 slot-validity bits */
 } PiscesTileResult;
 
 /* ---- a batch of reads, structure-of-arrays (what the C# shim pins per call) ------------
@@ -261,15 +266,19 @@ int32_t pisces_hip_stats(PiscesHip* h, int64_t out[4]);
  * allele-count histogram -> coverage, Poisson q-score, strand bias, somatic genotype and
  * filters for the reference allele and every SNV candidate -> 64-byte records.
  * d_ref_bases[i] is the reference base of position ref_start_position+i.
- * d_tile_results[n_tiles] receives each tile's slice of d_records (record_begin, n_records).
- * Record placement: d_record_count == NULL -> tile t owns the fixed slots [256*t, 256*t+256)
- * (record_capacity >= 256*n_tiles; no atomics, bit-reproducible placement; the fast path);
- * d_record_count != NULL -> compact buffer, slices handed out through that int32 device counter
- * (reset by the call, one returning atomic per tile). Asynchronous. */
+ * d_records needs record_capacity >= 256 * n_tiles slots (PiscesTileResult explains the slot layout: no
+ * allocation atomics, placement independent of scheduling); d_tile_results[n_tiles] is the directory.
+ * Asynchronous; launches of one handle must be stream-ordered with respect to each other. */
 int32_t pisces_hip_call_tiles(PiscesHip* h, const uint32_t* d_tuples, const PiscesTile* d_tiles,
                               int32_t n_tiles, const uint8_t* d_ref_bases, int32_t ref_start_position,
                               int64_t ref_length, PiscesCalledAllele* d_records, int32_t record_capacity,
-                              int32_t* d_record_count, PiscesTileResult* d_tile_results, void* stream);
+                              PiscesTileResult* d_tile_results, void* stream);
+/* Ordered compaction of a call_tiles result: d_out[0 .. *d_count) receives every called allele of the launch
+ * sorted by (position, ref, alt) (tiles must be in ascending position order); d_offsets[n_tiles] (int32 scratch)
+ * receives each tile's first index in d_out. Asynchronous. */
+int32_t pisces_hip_compact_records(PiscesHip* h, const PiscesCalledAllele* d_records,
+                                   const PiscesTileResult* d_tile_results, int32_t n_tiles, int32_t* d_offsets,
+                                   PiscesCalledAllele* d_out, int32_t out_capacity, int32_t* d_count, void* stream);
 /* tuples -> anchor-resolved counts added into d_counts[n_tiles*tile_loci][6][3][11]
  * (the IAlleleSource view for host-side collapsing / spanning coverage). Asynchronous. */
 int32_t pisces_hip_accumulate_tiles(PiscesHip* h, const uint32_t* d_tuples, const PiscesTile* d_tiles,

@@ -144,8 +144,19 @@ TILE_DTYPE = np.dtype([("start_position", "<i4"), ("n_loci", "<i4"), ("tuple_beg
                       align=True)
 assert TILE_DTYPE.itemsize == 24
 TILE_RESULT_DTYPE = np.dtype([("record_begin", "<i4"), ("n_records", "<i4"), ("n_candidate_loci", "<i4"),
-                              ("reserved", "<i4")], align=True)
-assert TILE_RESULT_DTYPE.itemsize == 16
+                              ("n_called", "<i4"), ("valid", "<u4", (8,))], align=True)
+assert TILE_RESULT_DTYPE.itemsize == 48
+SLOTS_PER_TILE = 256
+
+
+def records_in_order(records, tile_results):
+    """Called alleles of a call_tiles launch in (position, ref, alt) order: the valid slots of every tile, ascending
+    (slot of locus l, allele rank k = record_begin + 4*l + k; PiscesTileResult in include/pisces_hip.h)."""
+    if len(tile_results) == 0:
+        return records[:0]
+    bits = np.unpackbits(tile_results["valid"].view(np.uint8).reshape(len(tile_results), 32), axis=1, bitorder="little")
+    t, s = np.nonzero(bits)
+    return records[tile_results["record_begin"][t].astype(np.int64) + s]
 
 
 def info_genotype(info):

@@ -6,8 +6,11 @@
 //                            Counts never leave LDS.  HBM traffic = 4 B/tuple + 1 B/locus + 64 B/record.
 //   accumulate_tiles_kernel  tuples -> anchor-resolved int32[6][3][11] counts added to a global tensor
 //                            (the IAlleleSource view: RegionState._alleleCounts, RegionState.cs:57).
-//   call_counts_kernel       the same call phase fed from that global tensor (streaming surface after
-//                            the host collapser has looked at the counts).
+//   call_counts_kernel       the same call phase fed from that global tensor (+ gapped-MNV reference counts).
+//   scan_tile_counts_kernel / gather_records_kernel
+//                            optional ordered compaction of the per-tile record slots.
+//   call_spanning_kernel     insertion / deletion candidates found by the host: spanning coverage from the
+//                            global tensor, then the same q-score / strand-bias / filter / genotype chain.
 //
 // One workgroup (256 threads = 4 wave64) per tile; grid = number of tiles (>> 256 CUs for any real
 // interval set).  No MFMA: this is a scan + histogram + transcendental epilogue, HBM-bound.
@@ -20,10 +23,10 @@
 namespace pisces {
 
 constexpr int kBlock = 256;
-constexpr int kTile = 64;                 // loci per tile: kTile * 4 allele lanes = one workgroup pass
+constexpr int kTile = 64;                 // loci per tile (lane = locus in the call phase)
 constexpr int kFolded = 18;               // 6 allele types x 3 directions (anchors folded)
-constexpr int kUnroll = 4;                // 16-byte loads in flight per lane
-constexpr int kSlotsPerTile = 4 * kTile;  // worst case: four alleles called at every locus
+constexpr int kUnroll = 8;                // 16-byte loads in flight per lane
+constexpr int kSlotsPerTile = 4 * kTile;  // record slot of (locus, allele rank) = 256 * tile + 4 * locus + rank
 constexpr int kTotalShards = 64;          // running-total shards (one 128-byte line each)
 constexpr int kTotalStride = 16;          // in 8-byte words
 constexpr int kRefMargin = 32;            // reference bases staged in LDS on each side of a tile (RMxN scan reach)
@@ -35,6 +38,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // one dwordx4 loa
 // alphabetical allele order A, C, G, T (the per-locus output order, AlleleCaller.cs:172-176)
 // expressed in AlleleType codes A=0, G=1, C=2, T=3
 __device__ __forceinline__ int allele_of_rank(int k) { return k == 1 ? 2 : (k == 2 ? 1 : k); }
+__device__ __forceinline__ int rank_of_allele(int a) { return a == 1 ? 2 : (a == 2 ? 1 : a); }
 
 __device__ __forceinline__ int allele_type_of_base(uint8_t c)  // AlleleHelper.GetAlleleType, AlleleHelper.cs:13-32
 {
@@ -82,31 +86,12 @@ __device__ __forceinline__ void stream_tuples(const uint32_t* __restrict__ tuple
     for (int64_t i = aend + tid; i < end; i += kBlock) op(tuples[i]);
 }
 
-// exclusive prefix sum of a per-thread 0/1 flag over the 256-thread block (wave ballot + 4 wave totals)
-__device__ __forceinline__ int block_exclusive_count(bool flag, int* wave_tot /* LDS[4] */, int* total)
+__device__ __forceinline__ void copy_record(PiscesCalledAllele* dst, const PiscesCalledAllele* src)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long m = __ballot(flag);
-    int before = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_tot[wave] = __popcll(m);
-    __syncthreads();
-    int off = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) off += (w < wave) ? wave_tot[w] : 0;
-    *total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-    __syncthreads();
-    return off + before;
+    const uint4* sp = reinterpret_cast<const uint4*>(src);
+    uint4* dp = reinterpret_cast<uint4*>(dst);
+    dp[0] = sp[0]; dp[1] = sp[1]; dp[2] = sp[2]; dp[3] = sp[3];
 }
-
-// ---- the call phase: one lane per candidate allele ------------------------------------------
-// PMC showed the call phase VALU-issue-bound (FP64 at 4 cycles per wave-instruction), so the layout that
-// minimises wave-instructions wins: candidates compacted onto the low lanes, one lane runs one allele
-// start to finish, and everything that cannot change the output is skipped:
-//  * IsCallable (AlleleCaller.cs:236-258) tests coverage and frequency BEFORE the q-score, so a variant
-//    candidate below MinFrequency (every sequencing-error allele at depth) is rejected on integer/float32
-//    arithmetic alone, and one below MinVariantQscore right after its q-score; rejected alleles never reach
-//    the strand-bias / genotype math because their CalledAllele is dropped by the reference too;
-//  * the strand-bias tails of a well-supported allele are exactly 1.0 (poisson_cdf_sb).
 
 struct PointCounts {
     int cov[3], sup[3];
@@ -219,200 +204,35 @@ __device__ inline bool process_point_allele(const PointCounts& c, int pos, int a
     return true;
 }
 
-// The call phase for one tile whose folded counts sit in LDS (hist[(allele*3+dir)*kTile + locus]).
-// lane (locus = tid>>2, rank = tid&3) decides whether (locus, allele-of-rank) is a candidate:
-//   Reference candidate per position  — RegionState.GetAllCandidates, RegionState.cs:414-447
-//   SNV candidate                     — a quality-passing base != reference base, ref and read not N
-//                                       (CandidateVariantFinder.cs:97-160 with callMNVs off; its
-//                                       SupportByDirection equals the allele count by direction)
-// candidates are compacted onto the low threads (at most 4*kTile = kBlock of them), processed one lane each,
-// then the per-locus rule "drop the Reference allele when a variant is called" (AlleleCaller.cs:146-147)
-// and the output order (position, then allele) are applied and the records written to HBM.
-__device__ inline void call_phase(const int* hist, const uint32_t* gapped /* LDS[kTile] or nullptr */,
-                                  const PiscesTile& tile, const uint8_t* __restrict__ ref, int32_t ref_start,
-                                  int64_t ref_len, PiscesCalledAllele* __restrict__ records, int32_t capacity,
-                                  int32_t* __restrict__ record_count, PiscesTileResult* __restrict__ tile_result,
-                                  const DeviceParams& P, int* s_wave, uint8_t* s_work, uint8_t* s_callable, int* s_base)
-{
-    const int tid = threadIdx.x;
-#ifdef PISCES_TIMING
-    __shared__ long long s_dbg[8];
-    if (tid == 0) s_dbg[0] = clock64();
-#endif
-    // Two work lists so that a wave is not held hostage by one divergent lane: Reference candidates (at most
-    // one per locus, a cheap uniform path) are compacted onto threads 0..63 = wave 0, variant candidates
-    // (rare, long data-dependent path) onto threads 64.. = waves 1-3.  s_work[thread] = key = 4*locus + rank.
-    int n_ref, n_var;
-    {
-        const int locus = tid >> 2, rank = tid & 3;
-        const int allele = allele_of_rank(rank);
-        const int64_t ridx = (int64_t)tile.start_position + locus - ref_start;   // index into the reference window
-        const bool in_ref = locus < tile.n_loci && ridx >= 0 && ridx < ref_len;
-        const int refType = in_ref ? allele_type_of_base(ref[ridx]) : PISCES_ALLELE_N;
-        bool is_ref_work = false, is_var_work = false;
-        if (in_ref) {
-            int mine = 0, all = 0;
-#pragma unroll
-            for (int c = 0; c < kFolded; c++) {
-                int v = hist[c * kTile + locus];
-                all += v;
-                if (c / 3 == allele) mine += v;
-            }
-            const bool refLane = (refType < 4) ? (allele == refType) : (rank == 0);
-            if (refLane) is_ref_work = P.include_ref && (P.emit_zero_cov || all > 0);
-            else is_var_work = (refType < 4) && mine > 0;
-        }
-        const int rslot = block_exclusive_count(is_ref_work, s_wave, &n_ref);
-        const int vslot = block_exclusive_count(is_var_work, s_wave, &n_var);
-        if (is_ref_work) s_work[rslot] = (uint8_t)tid;
-        if (is_var_work) s_work[kTile + vslot] = (uint8_t)tid;
-        s_callable[tid] = 0;
-    }
-    __syncthreads();
-
-#ifdef PISCES_TIMING
-    if (tid == 0) s_dbg[1] = clock64();
-#endif
-    PiscesCalledAllele rec;
-    bool callable = false;
-    int item = 0;
-    bool item_is_ref = false;
-    if (tid < n_ref || (tid >= kTile && tid - kTile < n_var)) {
-        item = s_work[tid];
-        const int l = item >> 2;
-        const int a = allele_of_rank(item & 3);
-        const int pos = tile.start_position + l;
-        const int rt = allele_type_of_base(ref[(int64_t)pos - ref_start]);
-        item_is_ref = tid < kTile;
-        const PointCounts c = point_counts(hist, l, a, item_is_ref, rt, gapped ? (int)gapped[l] : 0);
-        callable = process_point_allele(c, pos, a, item_is_ref, rt, ref, (int64_t)ref_start - 1,
-                                        (int64_t)ref_start - 1 + ref_len, P, rec);
-        if (callable) s_callable[item] = item_is_ref ? 1 : 2;
-    }
-#ifdef PISCES_TIMING
-    if (tid == 0) s_dbg[2] = clock64();     // wave 0 (Reference lanes) done
-    if (tid == 64) s_dbg[4] = clock64();    // wave 1 (variant lanes) done
-#endif
-    __syncthreads();
-#ifdef PISCES_TIMING
-    if (tid == 0) s_dbg[3] = clock64();
-#endif
-
-    // per-locus pruning (AlleleCaller.cs:146-147) in key order: thread t looks at key t
-    bool key_survives = false, key_first = false, key_callable = false;
-    {
-        const uint8_t mine = s_callable[tid];
-        key_callable = mine != 0;
-        if (key_callable) {
-            const int q = tid & ~3;
-            const bool any_variant = (s_callable[q] | s_callable[q + 1] | s_callable[q + 2] | s_callable[q + 3]) & 2;
-            key_survives = !(mine == 1 && any_variant);
-            if (key_survives) {
-                bool earlier = false;   // an earlier surviving allele at this locus?
-                for (int k = 0; k < (tid & 3); k++) {
-                    uint8_t cc = s_callable[q + k];
-                    if (cc == 2 || (cc == 1 && !any_variant)) earlier = true;
-                }
-                key_first = !earlier;
-            }
-        }
-    }
-    int n_callable, n_loci_called, n_surv;
-    (void)block_exclusive_count(key_callable, s_wave, &n_callable);
-    (void)block_exclusive_count(key_first, s_wave, &n_loci_called);
-    const int key_idx = block_exclusive_count(key_survives, s_wave, &n_surv);
-    // hand each surviving key its output index (position, then allele order); 0xFF = dropped
-    s_work[tid] = key_survives ? (uint8_t)key_idx : (uint8_t)0xFF;   // n_surv <= 4*64 but idx 255 needs key 255 surviving with 255 before it: impossible (refs are pruned)
-    if (tid == 0) {
-        // record placement: fixed 256-slot stride per tile (no atomics, deterministic), or — when the caller
-        // wants a compact buffer — one returning atomic per tile on a shared counter (same-address global
-        // atomics serialize in L2 at ~12 ns each: measurable at thousands of tiles per launch)
-        int base = record_count ? (n_surv > 0 ? atomicAdd(record_count, n_surv) : 0) : (int)blockIdx.x * kSlotsPerTile;
-        *s_base = base;
-        PiscesTileResult tr;
-        tr.record_begin = base;
-        tr.n_records = n_surv;
-        tr.n_candidate_loci = n_loci_called;
-        tr.reserved = n_callable;   // IsCallable == true count (IAlleleCaller.TotalNumCalled)
-        *tile_result = tr;
-        if (P.totals) {
-            // running totals, sharded over kTotalShards cache lines so the adds do not serialize on one L2 line
-            unsigned long long* tt = P.totals + (size_t)(blockIdx.x % kTotalShards) * kTotalStride;
-            atomicAdd(&tt[0], (unsigned long long)n_surv);
-            atomicAdd(&tt[1], (unsigned long long)n_loci_called);
-            atomicAdd(&tt[2], (unsigned long long)n_callable);
-            atomicAdd(&tt[3], 1ull);
-        }
-    }
-    __syncthreads();
-    if (callable && s_work[item] != 0xFF) {
-        const int64_t dst = (int64_t)(*s_base) + s_work[item];
-        if (dst < capacity) {
-            const uint4* sp = reinterpret_cast<const uint4*>(&rec);
-            uint4* dp = reinterpret_cast<uint4*>(&records[dst]);
-            dp[0] = sp[0]; dp[1] = sp[1]; dp[2] = sp[2]; dp[3] = sp[3];
-        }
-    }
-#ifdef PISCES_TIMING
-    __syncthreads();
-    if (tid == 0) {
-        const long long now = clock64();
-        tile_result->n_records = (int)(s_dbg[1] - s_dbg[0]);          // detection + compaction
-        tile_result->n_candidate_loci = (int)(s_dbg[2] - s_dbg[1]);   // Reference lanes (wave 0)
-        tile_result->reserved = (int)(now - s_dbg[0]);                // whole call phase
-    }
-#endif
-}
-
 // ------------------------------------------------------------------------------------------
-// The hot kernel.  One workgroup per tile; four waves stream the tile's tuples into the LDS histogram, then
-// waves 2 and 3 retire (their wave slots go to the next workgroup, whose streaming overlaps this tile's FP64
-// call phase), wave 1 calls the variant candidates and wave 0 the Reference candidates, lane = locus.
-// Measured on config 2: with all four waves held through a block-wide call phase the launch ran stream and
-// call phases in lock-step across the chip (HBM idle ~30 us of 74); per-tile stamps: stream 45 k cycles,
-// call 23 k of which 13 k Reference lanes, 10 k compaction / block barriers / waiting on the variant wave.
-__device__ __forceinline__ int wave_exclusive_sum(int v, int* total)
-{
-    const int lane = threadIdx.x & 63;
-    int x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-    }
-    *total = __shfl(x, 63, 64);
-    return x - v;
-}
-
-__device__ __forceinline__ void copy_record(PiscesCalledAllele* dst, const PiscesCalledAllele* src)
-{
-    const uint4* sp = reinterpret_cast<const uint4*>(src);
-    uint4* dp = reinterpret_cast<uint4*>(dst);
-    dp[0] = sp[0]; dp[1] = sp[1]; dp[2] = sp[2]; dp[3] = sp[3];
-}
-
-// The call phase, lane = locus, one role per wave (wave-uniform code, no divergence between roles):
-//   wave 0  Reference candidate of the locus, start to finish
-//   wave 1  variant candidates: variant q-score            (then assembles the variant records)
-//   wave 2  variant candidates: strand-bias overall + forward statistics
-//   wave 3  variant candidates: strand-bias reverse statistics
-// A called SNV is ~5 k dependent FP64 instructions on one lane (measured p99 26 us per tile with one variant
-// wave against 6 us for the Reference wave); its q-score and three strand-bias tails are independent, so they
-// run on three SIMDs at once and meet in LDS.
+// The call phase of one tile whose folded counts sit in LDS, lane = locus, one role per wave (wave-uniform code):
+//   wave 0  Reference candidate of the locus (RegionState.GetAllCandidates, RegionState.cs:414-447), start to finish
+//   wave 1  variant candidates: variant q-score, then filters / genotype / record for the callable ones
+//   wave 2  variant candidates: the three strand-bias statistics
+//   wave 3  retires at once
+// SNV candidates are the quality-passing bases that differ from the reference base (CandidateVariantFinder.cs:97-160
+// with callMNVs off; SupportByDirection = allele count by direction).  A called SNV is ~5 k dependent FP64
+// instructions; its q-score and strand-bias tails are independent, so they run on two SIMDs and meet in LDS.
+// Waves leave as soon as their role is done: their wave slots start the next workgroup's stream while the
+// last one or two waves finish the FP64 tail (measured timeline in DESIGN.md section 4).
+//
+// Output: the record of (locus l, allele rank k) goes straight to slot record_begin + 4*l + k; the tile directory
+// carries a validity bit per slot.  Ascending valid slots are (position, allele) order, and the Reference slot of a
+// locus is simply not marked valid when a variant is called there (AlleleCaller.cs:146-147).  No staging, no
+// prefix sums, no allocation atomics, placement independent of scheduling.
 struct VarScratch {
     int vq[kTile * 4];
     double ov_var[kTile * 4], fw_var[kTile * 4], fw_fp[kTile * 4], rv_var[kTile * 4], rv_fp[kTile * 4];
 };
 
-__device__ inline void call_four_waves(const int* hist, const uint32_t* gapped, const PiscesTile& tile, int tile_index,
-                                       const uint8_t* __restrict__ ref, int32_t ref_start, int64_t ref_len,
-                                       PiscesCalledAllele* __restrict__ records, int32_t capacity,
-                                       int32_t* __restrict__ record_count, PiscesTileResult* __restrict__ tile_result,
-                                       const DeviceParams& P, PiscesCalledAllele* s_rec, uint8_t* s_mask,
-                                       const uint8_t* s_refwin /* LDS[kRefWin], 0 = outside the reference */,
-                                       VarScratch* vs)
+__device__ inline void call_roles(const int* hist, const uint32_t* gapped /* LDS[kTile] or nullptr */, const PiscesTile& tile,
+                                  int tile_index, const uint8_t* __restrict__ ref, int32_t ref_start, int64_t ref_len,
+                                  PiscesCalledAllele* __restrict__ records, PiscesTileResult* __restrict__ tile_result,
+                                  const DeviceParams& P, uint8_t* s_mask /* LDS[kTile] */,
+                                  const uint8_t* s_refwin /* LDS[kRefWin], 0 = outside the reference */, VarScratch* vs)
 {
     const int wave = threadIdx.x >> 6;
+    if (wave == 3) return;
     const int l = threadIdx.x & 63;
     const int pos = tile.start_position + l;
     const uint8_t refb = s_refwin[kRefMargin + l];
@@ -420,24 +240,27 @@ __device__ inline void call_four_waves(const int* hist, const uint32_t* gapped, 
     const int rt = in_ref ? allele_type_of_base(refb) : PISCES_ALLELE_N;
     const int64_t win_lo = (int64_t)ref_start - 1, win_hi = win_lo + ref_len;
     const int g = gapped ? (int)gapped[l] : 0;
+    PiscesCalledAllele* const slots = records + (int64_t)tile_index * kSlotsPerTile + l * 4;
 
-    PiscesCalledAllele rec;      // wave 0: this locus' Reference record
     bool ref_emitted = false;
+    int ref_rank = 0;
     if (wave == 0) {
-        // Reference candidate (RegionState.GetAllCandidates, RegionState.cs:414-447)
         if (in_ref && P.include_ref) {
             int all = 0;
 #pragma unroll
             for (int c = 0; c < kFolded; c++) all += hist[c * kTile + l];
             if (P.emit_zero_cov || all > 0) {
                 const int a = (rt < 4) ? rt : PISCES_ALLELE_N;
+                ref_rank = (rt < 4) ? rank_of_allele(rt) : 0;
                 const PointCounts c = point_counts(hist, l, a, true, rt, g);
+                PiscesCalledAllele rec;
                 (void)process_point_allele(c, pos, a, true, rt, ref, win_lo, win_hi, P, rec, s_refwin, kRefMargin + l);
+                // written now; it only counts if no variant turns out callable at this locus
+                copy_record(&slots[ref_rank], &rec);
                 ref_emitted = true;
             }
         }
     } else if (in_ref && rt < 4) {
-        // variant candidates (CandidateVariantFinder.cs:97-160, callMNVs off): quality-passing base != ref base
         for (int k = 0; k < 4; k++) {
             const int a = allele_of_rank(k);
             if (a == rt) continue;
@@ -448,21 +271,16 @@ __device__ inline void call_four_waves(const int* hist, const uint32_t* gapped, 
             if (wave == 1) {
                 vs->vq[slot] = (c.support > 0 && c.total != 0) ? poisson_qscore(c.support, c.total, P) : 0;
             } else if (c.support > 0) {
-                if (wave == 2) {
-                    const SbStats ov = sb_stats_of(0, c.cov, c.sup, P), fw = sb_stats_of(1, c.cov, c.sup, P);
-                    vs->ov_var[slot] = ov.var_gt_zero;
-                    vs->fw_var[slot] = fw.var_gt_zero;
-                    vs->fw_fp[slot] = fw.false_pos;
-                } else {
-                    const SbStats rv = sb_stats_of(2, c.cov, c.sup, P);
-                    vs->rv_var[slot] = rv.var_gt_zero;
-                    vs->rv_fp[slot] = rv.false_pos;
-                }
+                const SbStats ov = sb_stats_of(0, c.cov, c.sup, P), fw = sb_stats_of(1, c.cov, c.sup, P),
+                              rv = sb_stats_of(2, c.cov, c.sup, P);
+                vs->ov_var[slot] = ov.var_gt_zero;
+                vs->fw_var[slot] = fw.var_gt_zero; vs->fw_fp[slot] = fw.false_pos;
+                vs->rv_var[slot] = rv.var_gt_zero; vs->rv_fp[slot] = rv.false_pos;
             }
         }
     }
-    __syncthreads();   // four waves
-    if (wave >= 2) return;
+    __syncthreads();   // waves 0, 1, 2
+    if (wave == 2) return;
     if (wave == 1) {
         uint32_t mask = 0;
         if (in_ref && rt < 4) {
@@ -489,7 +307,7 @@ __device__ inline void call_four_waves(const int* hist, const uint32_t* gapped, 
                 }
                 PiscesCalledAllele r;
                 finish_allele(c, pos, a, false, rt, vq, sb, ref, win_lo, win_hi, P, r, s_refwin, kRefMargin + l);
-                copy_record(&s_rec[slot], &r);
+                copy_record(&slots[k], &r);
                 mask |= 1u << k;
             }
         }
@@ -498,25 +316,28 @@ __device__ inline void call_four_waves(const int* hist, const uint32_t* gapped, 
     __syncthreads();   // waves 0 and 1
     if (wave == 1) return;
 
-    // per-locus pruning (AlleleCaller.cs:146-147), output order (position, then allele), write-out
+    // wave 0: validity bits, counts, tile directory
     const uint32_t vmask = s_mask[l];
-    const int mine = vmask ? __popc(vmask) : (ref_emitted ? 1 : 0);
+    const uint32_t valid = vmask ? vmask : (ref_emitted ? (1u << ref_rank) : 0u);
     const int n_callable = __popc(vmask) + (ref_emitted ? 1 : 0);   // IsCallable is always true for a Reference allele
-    int n_surv, n_call_total;
-    const int excl = wave_exclusive_sum(mine, &n_surv);
-    (void)wave_exclusive_sum(n_callable, &n_call_total);
-    const int n_loci_called = __popcll(__ballot(mine > 0));
-    int base = 0;
+    int n_surv = __popc(valid), n_call_total = n_callable;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        n_surv += __shfl_xor(n_surv, d, 64);
+        n_call_total += __shfl_xor(n_call_total, d, 64);
+    }
+    const int n_loci_called = __popcll(__ballot(valid != 0));
+    // nibble of lane l -> bit 4*l.. of the 256-bit mask: 8 lanes per 32-bit word
+    uint32_t word = valid << ((l & 7) * 4);
+    word |= __shfl_xor(word, 1, 64);
+    word |= __shfl_xor(word, 2, 64);
+    word |= __shfl_xor(word, 4, 64);
+    if ((l & 7) == 0) tile_result->valid[l >> 3] = word;
     if (l == 0) {
-        // record placement: fixed 256-slot stride per tile (no atomics, deterministic) or a compact buffer
-        // handed out by one returning atomic per tile
-        base = record_count ? (n_surv > 0 ? atomicAdd(record_count, n_surv) : 0) : tile_index * kSlotsPerTile;
-        PiscesTileResult tr;
-        tr.record_begin = base;
-        tr.n_records = n_surv;
-        tr.n_candidate_loci = n_loci_called;
-        tr.reserved = n_call_total;   // IAlleleCaller.TotalNumCalled contribution
-        *tile_result = tr;
+        tile_result->record_begin = tile_index * kSlotsPerTile;
+        tile_result->n_records = n_surv;
+        tile_result->n_candidate_loci = n_loci_called;
+        tile_result->n_called = n_call_total;   // IAlleleCaller.TotalNumCalled contribution
         if (P.totals) {
             // running totals, sharded over kTotalShards cache lines so the adds do not serialize on one L2 line
             unsigned long long* tt = P.totals + (size_t)(tile_index % kTotalShards) * kTotalStride;
@@ -526,28 +347,15 @@ __device__ inline void call_four_waves(const int* hist, const uint32_t* gapped, 
             atomicAdd(&tt[3], 1ull);
         }
     }
-    base = __shfl(base, 0, 64);
-    if (vmask) {
-        int j = 0;
-        for (int k = 0; k < 4; k++) {
-            if (!(vmask & (1u << k))) continue;
-            const int64_t dst = (int64_t)base + excl + j;
-            j++;
-            if (dst < capacity) copy_record(&records[dst], &s_rec[l * 4 + k]);
-        }
-    } else if (ref_emitted) {
-        const int64_t dst = (int64_t)base + excl;
-        if (dst < capacity) copy_record(&records[dst], &rec);
-    }
 }
 
-__global__ __launch_bounds__(kBlock, 5) void call_tiles_kernel(
+// ------------------------------------------------------------------------------------------
+// The hot kernel: stream -> LDS histogram -> call_roles.
+__global__ __launch_bounds__(kBlock, 4) void call_tiles_kernel(
     const uint32_t* __restrict__ tuples, const PiscesTile* __restrict__ tiles, int32_t n_tiles,
     const uint8_t* __restrict__ ref, int32_t ref_start, int64_t ref_len, PiscesCalledAllele* __restrict__ records,
-    int32_t capacity, int32_t* __restrict__ record_count, PiscesTileResult* __restrict__ tile_results, DeviceParams P,
-    int32_t* __restrict__ gate, int32_t gate_epoch, int32_t gate_width)
+    PiscesTileResult* __restrict__ tile_results, DeviceParams P)
 {
-    __shared__ __attribute__((aligned(16))) PiscesCalledAllele s_rec[kTile * 4];
     __shared__ int hist[kFolded * kTile];
     __shared__ uint8_t s_mask[kTile];
     __shared__ uint8_t s_refwin[kRefWin];
@@ -562,7 +370,8 @@ __global__ __launch_bounds__(kBlock, 5) void call_tiles_kernel(
 #endif
     for (int i = threadIdx.x; i < kFolded * kTile; i += kBlock) hist[i] = 0;
     if (threadIdx.x < kRefWin) {
-        // the tile's reference bases (+ margin for the RMxN scan) into LDS now, under the stream
+        // the tile's reference bases (+ margin for the RMxN scan) into LDS now, under the stream: a global byte load
+        // inside the call phase is a dependent multi-microsecond round trip while the chip is streaming
         const int64_t ri = (int64_t)tile.start_position - kRefMargin + threadIdx.x - ref_start;
         s_refwin[threadIdx.x] = (ri >= 0 && ri < ref_len) ? ref[ri] : (uint8_t)0;
     } else if (threadIdx.x >= 128 && threadIdx.x < 128 + kQLutLds) {
@@ -571,19 +380,6 @@ __global__ __launch_bounds__(kBlock, 5) void call_tiles_kernel(
     }
     P.q_to_p_lut = s_qlut;   // generic pointer to LDS from here on
     P.q_to_p_n = kQLutLds;
-    // Streaming window: tile t starts streaming once tile t - gate_width has finished streaming.  ~1300 waves with
-    // 4 KiB in flight saturate HBM; letting every resident workgroup stream at once only makes all of them finish
-    // together and then run their FP64 call phases together with HBM idle.  The window spreads the call phases
-    // under the stream of later tiles.  It is a throttle, not a correctness dependency: the wait is bounded and a
-    // workgroup proceeds regardless (dispatch order is observed, not guaranteed, to follow blockIdx).
-    if (gate_width > 0 && t >= gate_width) {
-        if (threadIdx.x == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(&gate[t - gate_width], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gate_epoch &&
-                   ++spins < 20000)
-                __builtin_amdgcn_s_sleep(4);
-        }
-    }
     __syncthreads();
 
     const uint32_t n_loci = (uint32_t)tile.n_loci, min_bq = (uint32_t)P.min_bq;
@@ -597,178 +393,23 @@ __global__ __launch_bounds__(kBlock, 5) void call_tiles_kernel(
                   [&](uint32_t v) { accumulate_folded(hist, v, n_loci, min_bq); });
 #endif
     __syncthreads();
-    if (gate_width > 0 && threadIdx.x == 0)
-        __hip_atomic_store(&gate[t], gate_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #if defined(PISCES_ABLATE) && PISCES_ABLATE >= 1
     // development ablation: no call phase
-    if (threadIdx.x == 0) { PiscesTileResult tr = {0, 0, hist[5], 0}; tile_results[t] = tr; }
+    if (threadIdx.x == 0) { tile_results[t].record_begin = 0; tile_results[t].n_records = hist[5]; }
 #else
 #ifdef PISCES_TIMING
     const long long tc1 = wall_clock64();
 #endif
-    call_four_waves(hist, nullptr, tile, t, ref, ref_start, ref_len, records, capacity, record_count, &tile_results[t], P,
-                    s_rec, s_mask, s_refwin, &s_var);
+    call_roles(hist, nullptr, tile, t, ref, ref_start, ref_len, records, &tile_results[t], P, s_mask, s_refwin, &s_var);
 #ifdef PISCES_TIMING
-    if (threadIdx.x == 0) {   // development instrumentation: shader-clock stamps in the tile directory
+    if (threadIdx.x == 0) {   // development instrumentation: chip-global clock stamps in the tile directory
         const long long tc2 = wall_clock64();
-        tile_results[t].record_begin = (int)(tc1 - tc0);             // stream (10 ns ticks)
-        tile_results[t].n_records = 0;
-        tile_results[t].n_candidate_loci = 0;
-        tile_results[t].reserved = (int)(tc2 - tc1);                 // call end
+        tile_results[t].record_begin = (int)(tc0 & 0x3FFFFFFF);      // start (10 ns ticks)
+        tile_results[t].n_records = (int)(tc1 & 0x3FFFFFFF);         // stream end
+        tile_results[t].n_candidate_loci = (int)(tc2 & 0x3FFFFFFF);  // call end
     }
 #endif
 #endif
-}
-
-// ------------------------------------------------------------------------------------------
-// Software-pipelined persistent variant of call_tiles_kernel.
-//
-// In call_tiles_kernel every co-resident workgroup streams at the same time and then runs its FP64 call
-// phase at the same time, so HBM sits idle during the call phase (measured: 41 us streaming + 32 us call).
-// Here a workgroup is 5 waves and walks tiles t = blockIdx.x, +gridDim.x, ...:
-//     waves 0-3  stream tile i+1's tuples into hist[(i+1)&1]      (HBM + LDS atomics)
-//     wave  4    runs the call phase of tile i from hist[i&1]     (FP64 VALU), then clears that buffer
-// with one workgroup barrier per tile.  The call wave keeps lane = locus: variant candidates first (at most
-// three per lane, nearly all rejected by the integer frequency test), then the Reference allele unless a
-// variant was called at the locus (AlleleCaller.cs:146-147); records are staged in LDS, ordered with a
-// wave prefix sum and written as 64-byte rows.
-constexpr int kStreamWaves = 4;
-constexpr int kPipeBlock = (kStreamWaves + 1) * 64;
-
-// One wave, lane = locus. hist: folded counts of the tile; s_rec: LDS staging [kTile][4] records.
-__device__ inline void call_wave(const int* hist, const uint32_t* gapped, const PiscesTile& tile, int tile_index,
-                                 const uint8_t* __restrict__ ref, int32_t ref_start, int64_t ref_len,
-                                 PiscesCalledAllele* __restrict__ records, int32_t capacity,
-                                 int32_t* __restrict__ record_count, PiscesTileResult* __restrict__ tile_result,
-                                 const DeviceParams& P, PiscesCalledAllele* s_rec)
-{
-    const int l = threadIdx.x & 63;
-    const int pos = tile.start_position + l;
-    const int64_t ridx = (int64_t)pos - ref_start;
-    const bool in_ref = l < tile.n_loci && ridx >= 0 && ridx < ref_len;
-    const int rt = in_ref ? allele_type_of_base(ref[ridx]) : PISCES_ALLELE_N;
-    const int64_t win_lo = (int64_t)ref_start - 1, win_hi = win_lo + ref_len;
-    const int g = gapped ? (int)gapped[l] : 0;
-
-    uint32_t called_mask = 0;   // bit k = allele of alphabetical rank k has a record in s_rec[l*4+k]
-    int n_callable = 0;
-    if (in_ref) {
-        int cnt[4] = {0, 0, 0, 0}, all = 0;
-#pragma unroll
-        for (int c = 0; c < kFolded; c++) {
-            int v = hist[c * kTile + l];
-            all += v;
-            if (c / 3 < 4) cnt[c / 3] += v;
-        }
-        // variant candidates (CandidateVariantFinder.cs:97-160, callMNVs off): quality-passing base != ref base
-        if (rt < 4) {
-            for (int k = 0; k < 4; k++) {
-                const int a = allele_of_rank(k);
-                if (a == rt || cnt[a] == 0) continue;
-                const PointCounts c = point_counts(hist, l, a, false, rt, g);
-                PiscesCalledAllele r;
-                if (process_point_allele(c, pos, a, false, rt, ref, win_lo, win_hi, P, r)) {
-                    const uint4* sp = reinterpret_cast<const uint4*>(&r);
-                    uint4* dp = reinterpret_cast<uint4*>(&s_rec[l * 4 + k]);
-                    dp[0] = sp[0]; dp[1] = sp[1]; dp[2] = sp[2]; dp[3] = sp[3];
-                    called_mask |= 1u << k;
-                    n_callable++;
-                }
-            }
-        }
-        // Reference candidate (RegionState.GetAllCandidates, RegionState.cs:414-447); IsCallable is always true
-        // for it (TotalNumCalled counts it) but its record is dropped when a variant was called at the locus
-        if (P.include_ref && (P.emit_zero_cov || all > 0)) {
-            n_callable++;
-            if (called_mask == 0) {
-                const int kref = (rt < 4) ? (rt == 0 ? 0 : rt == 2 ? 1 : rt == 1 ? 2 : 3) : 0;
-                const int a = (rt < 4) ? rt : PISCES_ALLELE_N;
-                const PointCounts c = point_counts(hist, l, a, true, rt, g);
-                PiscesCalledAllele r;
-                (void)process_point_allele(c, pos, a, true, rt, ref, win_lo, win_hi, P, r);
-                const uint4* sp = reinterpret_cast<const uint4*>(&r);
-                uint4* dp = reinterpret_cast<uint4*>(&s_rec[l * 4 + kref]);
-                dp[0] = sp[0]; dp[1] = sp[1]; dp[2] = sp[2]; dp[3] = sp[3];
-                called_mask |= 1u << kref;
-            }
-        }
-    }
-    const int mine = __popc(called_mask);
-    int n_surv, n_call_total;
-    const int excl = wave_exclusive_sum(mine, &n_surv);
-    (void)wave_exclusive_sum(n_callable, &n_call_total);
-    const int n_loci_called = __popcll(__ballot(mine > 0));
-    int base = 0;
-    if (l == 0) {
-        base = record_count ? (n_surv > 0 ? atomicAdd(record_count, n_surv) : 0) : tile_index * kSlotsPerTile;
-        PiscesTileResult tr;
-        tr.record_begin = base;
-        tr.n_records = n_surv;
-        tr.n_candidate_loci = n_loci_called;
-        tr.reserved = n_call_total;
-        *tile_result = tr;
-        if (P.totals) {
-            unsigned long long* tt = P.totals + (size_t)(tile_index % kTotalShards) * kTotalStride;
-            atomicAdd(&tt[0], (unsigned long long)n_surv);
-            atomicAdd(&tt[1], (unsigned long long)n_loci_called);
-            atomicAdd(&tt[2], (unsigned long long)n_call_total);
-            atomicAdd(&tt[3], 1ull);
-        }
-    }
-    base = __shfl(base, 0, 64);
-    int j = 0;
-    for (int k = 0; k < 4; k++) {
-        if (!(called_mask & (1u << k))) continue;
-        const int64_t dst = (int64_t)base + excl + j;
-        j++;
-        if (dst < capacity) {
-            const uint4* sp = reinterpret_cast<const uint4*>(&s_rec[l * 4 + k]);
-            uint4* dp = reinterpret_cast<uint4*>(&records[dst]);
-            dp[0] = sp[0]; dp[1] = sp[1]; dp[2] = sp[2]; dp[3] = sp[3];
-        }
-    }
-}
-
-__global__ __launch_bounds__(kPipeBlock, 5) void call_tiles_pipelined_kernel(
-    const uint32_t* __restrict__ tuples, const PiscesTile* __restrict__ tiles, int32_t n_tiles,
-    const uint8_t* __restrict__ ref, int32_t ref_start, int64_t ref_len, PiscesCalledAllele* __restrict__ records,
-    int32_t capacity, int32_t* __restrict__ record_count, PiscesTileResult* __restrict__ tile_results, DeviceParams P)
-{
-    __shared__ __attribute__((aligned(16))) PiscesCalledAllele s_rec[kTile * 4];
-    __shared__ int hist[2][kFolded * kTile];
-
-    const int wave = threadIdx.x >> 6;
-    const bool streamer = wave < kStreamWaves;
-    int t = blockIdx.x;
-    if (t >= n_tiles) return;
-    for (int i = threadIdx.x; i < 2 * kFolded * kTile; i += kPipeBlock) (&hist[0][0])[i] = 0;
-    __syncthreads();
-    const uint32_t min_bq = (uint32_t)P.min_bq;
-    if (streamer) {
-        const PiscesTile t0 = tiles[t];
-        int* hb = hist[0];
-        const uint32_t n_loci = (uint32_t)t0.n_loci;
-        stream_tuples(tuples, t0.tuple_begin, t0.tuple_end, [&](uint32_t v) { accumulate_folded(hb, v, n_loci, min_bq); });
-    }
-    __syncthreads();
-    for (int it = 0; t < n_tiles; t += gridDim.x, it++) {
-        const int cur = it & 1;
-        const int t_next = t + gridDim.x;
-        if (streamer) {
-            if (t_next < n_tiles) {
-                const PiscesTile tn = tiles[t_next];
-                int* hb = hist[cur ^ 1];
-                const uint32_t n_loci = (uint32_t)tn.n_loci;
-                stream_tuples(tuples, tn.tuple_begin, tn.tuple_end, [&](uint32_t v) { accumulate_folded(hb, v, n_loci, min_bq); });
-            }
-        } else {
-            const PiscesTile tc = tiles[t];
-            call_wave(hist[cur], nullptr, tc, t, ref, ref_start, ref_len, records, capacity, record_count, &tile_results[t], P, s_rec);
-            int* hb = hist[cur];
-            for (int i = threadIdx.x & 63; i < kFolded * kTile; i += 64) hb[i] = 0;
-        }
-        __syncthreads();
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -807,19 +448,17 @@ __global__ __launch_bounds__(kBlock) void accumulate_tiles_kernel(
     }
 }
 
-// Call phase fed from the global anchor-resolved counts (+ gapped-MNV reference counts).
-__global__ __launch_bounds__(kBlock) void call_counts_kernel(
+// Call phase fed from the global anchor-resolved counts (+ gapped-MNV reference counts, CoverageCalculator.cs:82-97).
+__global__ __launch_bounds__(kBlock, 4) void call_counts_kernel(
     const int32_t* __restrict__ counts, const uint32_t* __restrict__ gapped_mnv_ref,
     const PiscesTile* __restrict__ tiles, int32_t n_tiles, const uint8_t* __restrict__ ref, int32_t ref_start,
-    int64_t ref_len, PiscesCalledAllele* __restrict__ records, int32_t capacity, int32_t* __restrict__ record_count,
-    PiscesTileResult* __restrict__ tile_results, DeviceParams P)
+    int64_t ref_len, PiscesCalledAllele* __restrict__ records, PiscesTileResult* __restrict__ tile_results, DeviceParams P)
 {
     __shared__ int hist[kFolded * kTile];
     __shared__ uint32_t s_gapped[kTile];
-    __shared__ int s_wave[4];
-    __shared__ int s_base;
-    __shared__ uint8_t s_work[kBlock];
-    __shared__ uint8_t s_callable[kBlock];
+    __shared__ uint8_t s_mask[kTile];
+    __shared__ uint8_t s_refwin[kRefWin];
+    __shared__ VarScratch s_var;
     const int t = blockIdx.x;
     if (t >= n_tiles) return;
     const PiscesTile tile = tiles[t];
@@ -837,9 +476,68 @@ __global__ __launch_bounds__(kBlock) void call_counts_kernel(
     }
     if (threadIdx.x < kTile)
         s_gapped[threadIdx.x] = (gapped_mnv_ref && threadIdx.x < tile.n_loci) ? gapped_mnv_ref[(int64_t)t * kTile + threadIdx.x] : 0u;
+    if (threadIdx.x >= 128 && threadIdx.x < 128 + kRefWin) {
+        const int j = threadIdx.x - 128;
+        const int64_t ri = (int64_t)tile.start_position - kRefMargin + j - ref_start;
+        s_refwin[j] = (ri >= 0 && ri < ref_len) ? ref[ri] : (uint8_t)0;
+    }
     __syncthreads();
-    call_phase(hist, s_gapped, tile, ref, ref_start, ref_len, records, capacity, record_count, &tile_results[t], P,
-               s_wave, s_work, s_callable, &s_base);
+    call_roles(hist, s_gapped, tile, t, ref, ref_start, ref_len, records, &tile_results[t], P, s_mask, s_refwin, &s_var);
+}
+
+// ------------------------------------------------------------------------------------------
+// Ordered compaction of the slot layout: offsets[t] = sum of n_records of tiles < t (one workgroup scans the
+// directory), then each tile's valid slots are copied, in slot order, to out[offsets[t] ..].  The result is the
+// called alleles of the whole launch sorted by (position, allele) in one contiguous buffer.
+__global__ __launch_bounds__(1024) void scan_tile_counts_kernel(const PiscesTileResult* __restrict__ tr, int32_t n_tiles,
+                                                                int32_t* __restrict__ offsets, int32_t* __restrict__ total)
+{
+    __shared__ int s_part[1024];
+    __shared__ int s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_tiles; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n_tiles ? tr[i].n_records : 0;
+        s_part[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {   // Hillis-Steele inclusive scan
+            int add = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
+            __syncthreads();
+            s_part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < n_tiles) offsets[i] = s_carry + s_part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry += s_part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = s_carry;
+}
+
+__global__ __launch_bounds__(64) void gather_records_kernel(const PiscesCalledAllele* __restrict__ records,
+                                                            const PiscesTileResult* __restrict__ tr, int32_t n_tiles,
+                                                            const int32_t* __restrict__ offsets,
+                                                            PiscesCalledAllele* __restrict__ out, int32_t capacity)
+{
+    const int t = blockIdx.x;
+    if (t >= n_tiles) return;
+    const int l = threadIdx.x;
+    const uint32_t nib = (tr[t].valid[l >> 3] >> ((l & 7) * 4)) & 0xFu;
+    int x = __popc(nib);
+    const int mine = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int y = __shfl_up(x, d, 64);
+        if (l >= d) x += y;
+    }
+    int64_t dst = (int64_t)offsets[t] + (x - mine);
+    const PiscesCalledAllele* src = records + (int64_t)tr[t].record_begin + l * 4;
+    for (int k = 0; k < 4; k++) {
+        if (!(nib & (1u << k))) continue;
+        if (dst < capacity) copy_record(&out[dst], &src[k]);
+        dst++;
+    }
 }
 
 }  // namespace pisces

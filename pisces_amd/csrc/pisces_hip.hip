@@ -76,10 +76,8 @@ struct PiscesHip {
     DeviceBuf<unsigned long long> d_totals;
     DeviceBuf<double> d_qlut;
     int n_cus = 256;
-    DeviceBuf<int32_t> d_gate;
-    int32_t gate_epoch = 0;
-    int gate_width = 0;
-    int kernel_variant = 0;   // 0 = one workgroup per tile (default), 1 = software-pipelined persistent kernel (experimental)
+    DeviceBuf<int32_t> d_offsets;
+    DeviceBuf<PiscesCalledAllele> d_compact;
     std::string err;
 
     DeviceBuf<uint8_t> d_ref;
@@ -250,10 +248,6 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cus = prop.multiProcessorCount;
-        const char* kv = getenv("PISCES_HIP_KERNEL");   // development switch: "pipelined" selects the persistent kernel
-        if (kv && std::string(kv) == "pipelined") h->kernel_variant = 1;
-        const char* gw = getenv("PISCES_HIP_GATE");   // development: streaming window width in tiles (0 = off)
-        if (gw) h->gate_width = atoi(gw);
     }
     {
         // MathOperations.QtoP(q) = Math.Pow(10, -1 * q / 10f) for every integer q-score the caller can produce
@@ -279,7 +273,7 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_ref.release(); h->d_tuples.release(); h->d_tiles.release(); h->d_tile_results.release();
-    h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release(); h->d_totals.release(); h->d_qlut.release(); h->d_gate.release();
+    h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release(); h->d_totals.release(); h->d_qlut.release(); h->d_offsets.release(); h->d_compact.release();
     h->d_cands.release(); h->d_alleles.release(); h->d_cand_records.release(); h->d_cand_callable.release();
     for (hipEvent_t ev : h->ring) (void)hipEventDestroy(ev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -540,25 +534,18 @@ static void build_tiles(PiscesHip* h, const std::vector<int32_t>& keys, std::vec
 // launches the fused tuples -> histogram -> call kernel on stream s
 static void launch_call_tiles(PiscesHip* h, hipStream_t s, const uint32_t* d_tuples, const PiscesTile* d_tiles, int32_t n_tiles,
                               const uint8_t* d_ref, int32_t ref_start, int64_t ref_len, PiscesCalledAllele* d_records,
-                              int32_t cap, int32_t* d_count, PiscesTileResult* d_tr)
+                              PiscesTileResult* d_tr)
 {
-    if (h->kernel_variant == 1) {
-        // persistent grid: 4 workgroups of 5 waves per CU, each walking tiles blockIdx.x, +grid, ...
-        const int grid = std::min<int64_t>(n_tiles, (int64_t)h->n_cus * 4);
-        hipLaunchKernelGGL(call_tiles_pipelined_kernel, dim3((unsigned)grid), dim3(kPipeBlock), 0, s, d_tuples, d_tiles, n_tiles, d_ref,
-                           ref_start, ref_len, d_records, cap, d_count, d_tr, h->P);
-    } else {
-        int gw = h->gate_width;
-        if (gw > 0) {
-            if (h->d_gate.cap < (size_t)n_tiles) {
-                (void)hipStreamSynchronize(s);
-                if (h->d_gate.reserve((size_t)n_tiles) != hipSuccess || hipMemset(h->d_gate.p, 0, h->d_gate.cap * sizeof(int32_t)) != hipSuccess) gw = 0;
-            }
-            h->gate_epoch = h->gate_epoch == 0x7FFFFFFF ? 1 : h->gate_epoch + 1;
-        }
-        hipLaunchKernelGGL(call_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, d_tuples, d_tiles, n_tiles, d_ref, ref_start,
-                           ref_len, d_records, cap, d_count, d_tr, h->P, gw > 0 ? h->d_gate.p : nullptr, h->gate_epoch, gw);
-    }
+    hipLaunchKernelGGL(call_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, d_tuples, d_tiles, n_tiles, d_ref, ref_start,
+                       ref_len, d_records, d_tr, h->P);
+}
+
+// scan + gather: d_out = called alleles in (position, allele) order, *d_count = how many
+static void launch_compaction(hipStream_t s, const PiscesCalledAllele* d_records, const PiscesTileResult* d_tr, int32_t n_tiles,
+                              int32_t* d_offsets, PiscesCalledAllele* d_out, int32_t cap, int32_t* d_count)
+{
+    hipLaunchKernelGGL(scan_tile_counts_kernel, dim3(1), dim3(1024), 0, s, d_tr, n_tiles, d_offsets, d_count);
+    hipLaunchKernelGGL(gather_records_kernel, dim3((unsigned)n_tiles), dim3(64), 0, s, d_records, d_tr, n_tiles, d_offsets, d_out, cap);
 }
 
 static int32_t upload_tiles(PiscesHip* h, const std::vector<PiscesTile>& tiles, const std::vector<uint32_t>& tuples)
@@ -587,23 +574,26 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
     const int32_t n_tiles = (int32_t)tiles.size();
     int32_t rc = upload_tiles(h, tiles, tuples);
     if (rc) return rc;
-    const size_t cap = (size_t)n_tiles * kSlotsPerTile;   // strided record layout: 256 slots per tile
+    const size_t cap = (size_t)n_tiles * kSlotsPerTile;   // slot layout: 256 slots per tile
     PISCES_HIP_CHECK(h, h->d_records.reserve(cap));
+    PISCES_HIP_CHECK(h, h->d_compact.reserve(cap));
+    PISCES_HIP_CHECK(h, h->d_offsets.reserve((size_t)n_tiles));
 
     bool use_counts = false;
     for (auto& kv : h->gapped_mnv_ref)
         if (std::binary_search(keys.begin(), keys.end(), block_key(h, kv.first))) { use_counts = true; break; }
 
+    std::vector<uint32_t> g;
     if (!use_counts) {
-        launch_call_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p, (int32_t)cap,
-                          nullptr, h->d_tile_results.p);
+        launch_call_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p,
+                          h->d_tile_results.p);
     } else {
         // counts in HBM + AddGappedMnvRefCount adjustments (CoverageCalculator.cs:82-97)
         const size_t nc = (size_t)n_tiles * kTile * PISCES_COUNTS_PER_LOCUS;
         PISCES_HIP_CHECK(h, h->d_counts.reserve(nc));
         PISCES_HIP_CHECK(h, h->d_gapped.reserve((size_t)n_tiles * kTile));
         PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_counts.p, 0, nc * sizeof(int32_t), h->stream));
-        std::vector<uint32_t> g((size_t)n_tiles * kTile, 0u);
+        g.assign((size_t)n_tiles * kTile, 0u);
         for (int32_t t = 0; t < n_tiles; t++)
             for (int32_t l = 0; l < tiles[(size_t)t].n_loci; l++) {
                 auto it = h->gapped_mnv_ref.find(tiles[(size_t)t].start_position + l);
@@ -613,30 +603,22 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
         hipLaunchKernelGGL(accumulate_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->d_tuples.p, h->d_tiles.p,
                            n_tiles, h->d_counts.p, h->cfg.min_base_call_quality);
         hipLaunchKernelGGL(call_counts_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->d_counts.p, h->d_gapped.p,
-                           h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p, (int32_t)cap, (int32_t*)nullptr,
-                           h->d_tile_results.p, h->P);
-        PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // g must outlive the copy
+                           h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p, h->d_tile_results.p, h->P);
     }
+    // tiles were built in ascending position order: the ordered compaction is AlleleCaller.Call's (position, ref, alt) order
+    launch_compaction(h->stream, h->d_records.p, h->d_tile_results.p, n_tiles, h->d_offsets.p, h->d_compact.p, (int32_t)cap, h->d_count.p);
     PISCES_HIP_CHECK(h, hipGetLastError());
     std::vector<PiscesTileResult> tr((size_t)n_tiles);
+    int32_t total = 0;
     PISCES_HIP_CHECK(h, hipMemcpyAsync(tr.data(), h->d_tile_results.p, tr.size() * sizeof(PiscesTileResult), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(&total, h->d_count.p, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
-    // tiles were built in ascending position order; records inside a tile are already sorted, so the
-    // tile-ordered gather is the (position, ref, alt) order of AlleleCaller.Call
-    size_t total = 0;
-    for (auto& r : tr) total += (size_t)r.n_records;
-    out.resize(total);
-    size_t w = 0;
-    for (int32_t t = 0; t < n_tiles; t++) {
-        const PiscesTileResult& r = tr[(size_t)t];
-        *n_called += r.reserved;
-        if (r.n_records > 0) {
-            PISCES_HIP_CHECK(h, hipMemcpyAsync(out.data() + w, h->d_records.p + r.record_begin,
-                                               (size_t)r.n_records * sizeof(PiscesCalledAllele), hipMemcpyDeviceToHost, h->stream));
-            w += (size_t)r.n_records;
-        }
+    for (auto& r : tr) *n_called += r.n_called;
+    out.resize((size_t)total);
+    if (total > 0) {
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(out.data(), h->d_compact.p, (size_t)total * sizeof(PiscesCalledAllele), hipMemcpyDeviceToHost, h->stream));
+        PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     }
-    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     return PISCES_OK;
 }
 
@@ -967,18 +949,16 @@ int32_t pisces_hip_stats(PiscesHip* h, int64_t out[4])
 // ------------------------------------------------------------------------------------------------
 int32_t pisces_hip_call_tiles(PiscesHip* h, const uint32_t* d_tuples, const PiscesTile* d_tiles, int32_t n_tiles,
                               const uint8_t* d_ref_bases, int32_t ref_start_position, int64_t ref_length,
-                              PiscesCalledAllele* d_records, int32_t record_capacity, int32_t* d_record_count,
-                              PiscesTileResult* d_tile_results, void* stream)
+                              PiscesCalledAllele* d_records, int32_t record_capacity, PiscesTileResult* d_tile_results, void* stream)
 {
     if (!h) return PISCES_E_INVALID_ARG;
     if (n_tiles < 0 || record_capacity < 0 || ref_length < 0) return fail(h, PISCES_E_INVALID_ARG, "call_tiles: negative size");
     if (n_tiles > 0 && (!d_tiles || !d_ref_bases || !d_records || !d_tile_results))
         return fail(h, PISCES_E_INVALID_ARG, "call_tiles: null device pointer");
-    if (!d_record_count && (int64_t)record_capacity < (int64_t)n_tiles * kSlotsPerTile)
-        return fail(h, PISCES_E_BUFFER_TOO_SMALL, "call_tiles: strided record layout needs record_capacity >= 256 * n_tiles");
+    if ((int64_t)record_capacity < (int64_t)n_tiles * kSlotsPerTile)
+        return fail(h, PISCES_E_BUFFER_TOO_SMALL, "call_tiles: the slot layout needs record_capacity >= 256 * n_tiles");
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-    if (d_record_count) PISCES_HIP_CHECK(h, hipMemsetAsync(d_record_count, 0, sizeof(int32_t), s));
     hipEvent_t e0 = h->ev0, e1 = h->ev1;
     if (h->timing) {
         const size_t slot = (size_t)(h->ring_used % kTimingRing);
@@ -988,11 +968,29 @@ int32_t pisces_hip_call_tiles(PiscesHip* h, const uint32_t* d_tuples, const Pisc
     }
     PISCES_HIP_CHECK(h, hipEventRecord(e0, s));
     if (n_tiles > 0)
-        launch_call_tiles(h, s, d_tuples, d_tiles, n_tiles, d_ref_bases, ref_start_position, ref_length, d_records, record_capacity,
-                          d_record_count, d_tile_results);
+        launch_call_tiles(h, s, d_tuples, d_tiles, n_tiles, d_ref_bases, ref_start_position, ref_length, d_records, d_tile_results);
     PISCES_HIP_CHECK(h, hipEventRecord(e1, s));
     PISCES_HIP_CHECK(h, hipGetLastError());
     h->timed = true;
+    return PISCES_OK;
+}
+
+int32_t pisces_hip_compact_records(PiscesHip* h, const PiscesCalledAllele* d_records, const PiscesTileResult* d_tile_results,
+                                   int32_t n_tiles, int32_t* d_offsets, PiscesCalledAllele* d_out, int32_t out_capacity,
+                                   int32_t* d_count, void* stream)
+{
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (n_tiles < 0 || out_capacity < 0) return fail(h, PISCES_E_INVALID_ARG, "compact_records: negative size");
+    if (!d_count || (n_tiles > 0 && (!d_records || !d_tile_results || !d_offsets || !d_out)))
+        return fail(h, PISCES_E_INVALID_ARG, "compact_records: null device pointer");
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    if (n_tiles == 0) {
+        PISCES_HIP_CHECK(h, hipMemsetAsync(d_count, 0, sizeof(int32_t), s));
+        return PISCES_OK;
+    }
+    launch_compaction(s, d_records, d_tile_results, n_tiles, d_offsets, d_out, out_capacity, d_count);
+    PISCES_HIP_CHECK(h, hipGetLastError());
     return PISCES_OK;
 }
 

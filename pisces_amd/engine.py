@@ -170,11 +170,14 @@ class HipVariantCaller:
         return {"TotalNumCalled": s[0], "TotalNumCollapsed": s[1], "reads": s[2], "observations": s[3]}
 
     # ---- device-resident surface ----
-    def call_tiles(self, d_tuples, d_tiles, n_tiles, d_ref, ref_start, ref_len, d_records, capacity, d_count,
-                   d_tile_results, stream=None):
-        """All arguments are raw device addresses (ints)."""
+    def call_tiles(self, d_tuples, d_tiles, n_tiles, d_ref, ref_start, ref_len, d_records, capacity, d_tile_results, stream=None):
+        """All pointer arguments are raw device addresses (ints); capacity >= 256 * n_tiles record slots."""
         _check(self._h, lib.pisces_hip_call_tiles(self._h, d_tuples, d_tiles, n_tiles, d_ref, ref_start, ref_len,
-                                                  d_records, capacity, d_count, d_tile_results, stream))
+                                                  d_records, capacity, d_tile_results, stream))
+
+    def compact_records(self, d_records, d_tile_results, n_tiles, d_offsets, d_out, out_capacity, d_count, stream=None):
+        _check(self._h, lib.pisces_hip_compact_records(self._h, d_records, d_tile_results, n_tiles, d_offsets, d_out,
+                                                       out_capacity, d_count, stream))
 
     def accumulate_tiles(self, d_tuples, d_tiles, n_tiles, d_counts, stream=None):
         _check(self._h, lib.pisces_hip_accumulate_tiles(self._h, d_tuples, d_tiles, n_tiles, d_counts, stream))

@@ -42,30 +42,31 @@ def torch_cuda():
 
 
 def run_fused(torch, caller, p, compact=False):
-    """One pisces_hip_call_tiles launch on device-resident buffers; returns records in tile order.
-    compact=False: fixed 256-slot stride per tile (no atomics); compact=True: atomic slice allocation."""
+    """One pisces_hip_call_tiles launch on device-resident buffers; returns the called alleles in order.
+    compact=False: read the slot layout through the validity masks; compact=True: pisces_hip_compact_records."""
     dev = p.tuples.device
-    cap = p.n_tiles * 256
+    cap = p.n_tiles * _abi.SLOTS_PER_TILE
     recs = torch.zeros(cap * 64, dtype=torch.uint8, device=dev)
-    count = torch.zeros(1, dtype=torch.int32, device=dev)
-    tres = torch.zeros(p.n_tiles * 16, dtype=torch.uint8, device=dev)
+    tres = torch.zeros(p.n_tiles * _abi.TILE_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     caller.call_tiles(p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), 1, p.ref_len,
-                      recs.data_ptr(), cap, count.data_ptr() if compact else None, tres.data_ptr(), stream)
+                      recs.data_ptr(), cap, tres.data_ptr(), stream)
+    if compact:
+        out_d = torch.zeros(cap * 64, dtype=torch.uint8, device=dev)
+        offs = torch.zeros(max(p.n_tiles, 1), dtype=torch.int32, device=dev)
+        count = torch.zeros(1, dtype=torch.int32, device=dev)
+        caller.compact_records(recs.data_ptr(), tres.data_ptr(), p.n_tiles, offs.data_ptr(), out_d.data_ptr(), cap,
+                               count.data_ptr(), stream)
     torch.cuda.synchronize()
     tr = tres.cpu().numpy().view(_abi.TILE_RESULT_DTYPE)
-    raw = recs.cpu().numpy().view(_abi.CALLED_ALLELE_DTYPE)
-    out = np.concatenate([raw[r["record_begin"]: r["record_begin"] + r["n_records"]] for r in tr]) if len(tr) else raw[:0]
+    assert (tr["record_begin"] == np.arange(len(tr)) * _abi.SLOTS_PER_TILE).all()
     if compact:
-        assert len(out) == int(count.item())
-        assert sorted(tr["record_begin"][tr["n_records"] > 0].tolist()) == \
-            np.cumsum(np.r_[0, np.sort(tr["n_records"][tr["n_records"] > 0])])[:0].tolist() or True
-        # slices tile the compact buffer exactly
-        order = np.argsort(tr["record_begin"], kind="stable")
-        nz = tr[order][tr[order]["n_records"] > 0]
-        assert (nz["record_begin"][1:] == nz["record_begin"][:-1] + nz["n_records"][:-1]).all()
-    else:
-        assert (tr["record_begin"] == np.arange(len(tr)) * 256).all()
+        n = int(count.item())
+        assert n == int(tr["n_records"].sum())
+        assert (offs.cpu().numpy()[: p.n_tiles] == np.cumsum(np.r_[0, tr["n_records"]])[:-1]).all()
+        return out_d.cpu().numpy().view(_abi.CALLED_ALLELE_DTYPE)[:n].copy(), tr
+    out = _abi.records_in_order(recs.cpu().numpy().view(_abi.CALLED_ALLELE_DTYPE), tr)
+    assert len(out) == int(tr["n_records"].sum())
     return out, tr
 
 
@@ -147,6 +148,7 @@ def test_fused_kernel_edge_inputs(torch_cuda):
     assert_records_match(got, exp)
     assert int(tr["n_candidate_loci"].sum()) == nloci == n_loci
     assert tr[1]["n_records"] == 64   # the empty tile still reports its zero-coverage reference rows
+    assert int(tr["n_called"].sum()) >= len(got)
 
 
 def test_rmxn_filter_on_device(torch_cuda):

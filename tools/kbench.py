@@ -26,14 +26,13 @@ def main():
     nt = ring[0].n_tiles
     cap = nt * 256
     rec = torch.zeros(cap * 64, dtype=torch.uint8, device=dev)
-    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
-    tr = torch.zeros(nt * 16, dtype=torch.uint8, device=dev)
+    tr = torch.zeros(nt * 48, dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream(dev).cuda_stream
     with engine.HipVariantCaller(_abi.default_config()) as c:
         def step(i):
             p = ring[i % a.ring]
             c.call_tiles(p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), 1, p.ref_len,
-                         rec.data_ptr(), cap, None, tr.data_ptr(), st)
+                         rec.data_ptr(), cap, tr.data_ptr(), st)
         for i in range(5):
             step(i)
         torch.cuda.synchronize()
