@@ -242,6 +242,22 @@ __device__ inline void call_roles(const int* hist, const uint32_t* gapped /* LDS
     const int g = gapped ? (int)gapped[l] : 0;
     PiscesCalledAllele* const slots = records + (int64_t)tile_index * kSlotsPerTile + l * 4;
 
+    // Which variant candidates of this locus survive the integer / float32 half of IsCallable (coverage, frequency)?
+    // Every wave evaluates the same data, so the "no variant work in this tile" decision is wave-uniform across the
+    // workgroup: waves 1 and 2 then retire at once and wave 0 never meets a barrier.
+    uint32_t pass_mask = 0;
+    if (in_ref && rt < 4) {
+        for (int k = 0; k < 4; k++) {
+            const int a = allele_of_rank(k);
+            if (a == rt) continue;
+            if (hist[(a * 3 + 0) * kTile + l] + hist[(a * 3 + 1) * kTile + l] + hist[(a * 3 + 2) * kTile + l] == 0) continue;
+            const PointCounts c = point_counts(hist, l, a, false, rt, g);
+            if (variant_passes_frequency(c, P)) pass_mask |= 1u << k;
+        }
+    }
+    const bool tile_has_variants = __ballot(pass_mask != 0) != 0ull;
+    if (!tile_has_variants && wave != 0) return;
+
     bool ref_emitted = false;
     int ref_rank = 0;
     if (wave == 0) {
@@ -260,13 +276,11 @@ __device__ inline void call_roles(const int* hist, const uint32_t* gapped /* LDS
                 ref_emitted = true;
             }
         }
-    } else if (in_ref && rt < 4) {
+    } else {
         for (int k = 0; k < 4; k++) {
+            if (!(pass_mask & (1u << k))) continue;
             const int a = allele_of_rank(k);
-            if (a == rt) continue;
-            if (hist[(a * 3 + 0) * kTile + l] + hist[(a * 3 + 1) * kTile + l] + hist[(a * 3 + 2) * kTile + l] == 0) continue;
             const PointCounts c = point_counts(hist, l, a, false, rt, g);
-            if (!variant_passes_frequency(c, P)) continue;
             const int slot = l * 4 + k;
             if (wave == 1) {
                 vs->vq[slot] = (c.support > 0 && c.total != 0) ? poisson_qscore(c.support, c.total, P) : 0;
@@ -279,20 +293,19 @@ __device__ inline void call_roles(const int* hist, const uint32_t* gapped /* LDS
             }
         }
     }
-    __syncthreads();   // waves 0, 1, 2
-    if (wave == 2) return;
-    if (wave == 1) {
-        uint32_t mask = 0;
-        if (in_ref && rt < 4) {
+    uint32_t vmask = 0;
+    if (tile_has_variants) {
+        __syncthreads();   // waves 0, 1, 2
+        if (wave == 2) return;
+        if (wave == 1) {
+            uint32_t mask = 0;
             for (int k = 0; k < 4; k++) {
+                if (!(pass_mask & (1u << k))) continue;
                 const int a = allele_of_rank(k);
-                if (a == rt) continue;
-                if (hist[(a * 3 + 0) * kTile + l] + hist[(a * 3 + 1) * kTile + l] + hist[(a * 3 + 2) * kTile + l] == 0) continue;
-                const PointCounts c = point_counts(hist, l, a, false, rt, g);
-                if (!variant_passes_frequency(c, P)) continue;
                 const int slot = l * 4 + k;
                 const int vq = vs->vq[slot];
                 if (vq < P.min_vq) continue;                                   // IsCallable, last test
+                const PointCounts c = point_counts(hist, l, a, false, rt, g);
                 SbResult sb = {0.0, 0, 0, 0};
                 if (c.support > 0) {
                     SbStats ov, fw, rv;
@@ -310,14 +323,14 @@ __device__ inline void call_roles(const int* hist, const uint32_t* gapped /* LDS
                 copy_record(&slots[k], &r);
                 mask |= 1u << k;
             }
+            s_mask[l] = (uint8_t)mask;
         }
-        s_mask[l] = (uint8_t)mask;
+        __syncthreads();   // waves 0 and 1
+        if (wave == 1) return;
+        vmask = s_mask[l];
     }
-    __syncthreads();   // waves 0 and 1
-    if (wave == 1) return;
 
     // wave 0: validity bits, counts, tile directory
-    const uint32_t vmask = s_mask[l];
     const uint32_t valid = vmask ? vmask : (ref_emitted ? (1u << ref_rank) : 0u);
     const int n_callable = __popc(vmask) + (ref_emitted ? 1 : 0);   // IsCallable is always true for a Reference allele
     int n_surv = __popc(valid), n_call_total = n_callable;

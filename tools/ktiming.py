@@ -29,3 +29,6 @@ r1, r2 = t0 < 5, t0 >= 5
 for name, m in (("round 1", r1), ("round 2", r2)):
     if m.any():
         print(f"{name}: n={int(m.sum())} stream dur p10/p50/p90: {np.round(np.percentile((t1 - t0)[m], [10, 50, 90]), 1)}  call dur p10/p50/p90: {np.round(np.percentile((t2 - t1)[m], [10, 50, 90]), 1)}")
+v = t["valid"].astype(np.int64) / 100.0
+for i, name in enumerate(("wave0 reference lanes", "wait waves 1,2", "wait wave 1 assembly", "tail (masks, directory)")):
+    print(f"{name:26s} us p10/p50/p90/p99: {np.round(np.percentile(v[:, i], [10, 50, 90, 99]), 2)}")
