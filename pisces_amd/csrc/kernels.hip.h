@@ -426,6 +426,178 @@ __global__ __launch_bounds__(kBlock, 4) void call_tiles_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Software-pipelined persistent form of the hot kernel.  A workgroup walks tiles b, b+G, b+2G, ...:
+//   waves 1-3 stream tile i+1 into hist[(i+1)&1]   |   wave 0 runs the whole call phase of tile i from hist[i&1]
+// with one workgroup barrier per tile, so exactly one call phase per workgroup (the last) is not covered by
+// streaming.  call_tiles_kernel exposes one call phase per tile per scheduling round instead (measured timeline,
+// DESIGN.md section 4).
+constexpr int kStreamThreads = kBlock - 64;
+
+template <typename Op>
+__device__ __forceinline__ void stream_tuples_part(const uint32_t* __restrict__ tuples, int64_t begin, int64_t end, int tid,
+                                                   int nthreads, Op op)
+{
+    int64_t abegin = (begin + 3) & ~(int64_t)3;
+    int64_t aend = end & ~(int64_t)3;
+    if (abegin > aend) { abegin = end; aend = end; }
+    for (int64_t i = begin + tid; i < abegin; i += nthreads) op(tuples[i]);
+    const u32x4* __restrict__ p4 = reinterpret_cast<const u32x4*>(tuples + abegin);
+    const int64_t n4 = (aend - abegin) >> 2;
+    for (int64_t i = tid; i < n4; i += (int64_t)nthreads * kUnroll) {
+        u32x4 v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            int64_t j = i + (int64_t)u * nthreads;
+            v[u] = j < n4 ? __builtin_nontemporal_load(&p4[j]) : (u32x4){~0u, ~0u, ~0u, ~0u};
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            op(v[u].x); op(v[u].y); op(v[u].z); op(v[u].w);
+        }
+    }
+    for (int64_t i = aend + tid; i < end; i += nthreads) op(tuples[i]);
+}
+
+// The whole call phase of one tile on one wave (lane = locus): variant candidates first, then the Reference
+// candidate unless a variant was called at the locus.
+__device__ inline void call_one_wave(const int* hist, const PiscesTile& tile, int tile_index, const uint8_t* __restrict__ ref,
+                                     int32_t ref_start, int64_t ref_len, PiscesCalledAllele* __restrict__ records,
+                                     PiscesTileResult* __restrict__ tile_result, const DeviceParams& P, const uint8_t* s_refwin)
+{
+    const int l = threadIdx.x & 63;
+    const int pos = tile.start_position + l;
+    const uint8_t refb = s_refwin[kRefMargin + l];
+    const bool in_ref = l < tile.n_loci && refb != 0;
+    const int rt = in_ref ? allele_type_of_base(refb) : PISCES_ALLELE_N;
+    const int64_t win_lo = (int64_t)ref_start - 1, win_hi = win_lo + ref_len;
+    PiscesCalledAllele* const slots = records + (int64_t)tile_index * kSlotsPerTile + l * 4;
+
+    uint32_t vmask = 0;
+    if (in_ref && rt < 4) {
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {
+            const int a = allele_of_rank(k);
+            if (a == rt) continue;
+            if (hist[(a * 3 + 0) * kTile + l] + hist[(a * 3 + 1) * kTile + l] + hist[(a * 3 + 2) * kTile + l] == 0) continue;
+            const PointCounts c = point_counts(hist, l, a, false, rt, 0);
+            if (!variant_passes_frequency(c, P)) continue;
+            const int vq = (c.support > 0 && c.total != 0) ? poisson_qscore(c.support, c.total, P) : 0;
+            if (vq < P.min_vq) continue;
+            SbResult sb = {0.0, 0, 0, 0};
+            if (c.support > 0) sb = strand_bias(c.cov, c.sup, P);
+            PiscesCalledAllele r;
+            finish_allele(c, pos, a, false, rt, vq, sb, ref, win_lo, win_hi, P, r, s_refwin, kRefMargin + l);
+            copy_record(&slots[k], &r);
+            vmask |= 1u << k;
+        }
+    }
+    bool ref_emitted = false;
+    int ref_rank = 0;
+    if (in_ref && P.include_ref) {
+        int all = 0;
+#pragma unroll
+        for (int c = 0; c < kFolded; c++) all += hist[c * kTile + l];
+        if (P.emit_zero_cov || all > 0) {
+            ref_emitted = true;
+            ref_rank = (rt < 4) ? rank_of_allele(rt) : 0;
+            if (vmask == 0) {   // its record is dropped anyway when a variant is called here (AlleleCaller.cs:146-147)
+                const int a = (rt < 4) ? rt : PISCES_ALLELE_N;
+                const PointCounts c = point_counts(hist, l, a, true, rt, 0);
+                const int vq = (c.support > 0 && c.total != 0) ? poisson_qscore(c.support, c.total, P) : 0;
+                SbResult sb = {0.0, 0, 0, 0};
+                if (c.support > 0) sb = strand_bias(c.cov, c.sup, P);
+                PiscesCalledAllele r;
+                finish_allele(c, pos, a, true, rt, vq, sb, ref, win_lo, win_hi, P, r, s_refwin, kRefMargin + l);
+                copy_record(&slots[ref_rank], &r);
+            }
+        }
+    }
+    const uint32_t valid = vmask ? vmask : (ref_emitted ? (1u << ref_rank) : 0u);
+    int n_surv = __popc(valid), n_call_total = __popc(vmask) + (ref_emitted ? 1 : 0);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        n_surv += __shfl_xor(n_surv, d, 64);
+        n_call_total += __shfl_xor(n_call_total, d, 64);
+    }
+    const int n_loci_called = __popcll(__ballot(valid != 0));
+    uint32_t word = valid << ((l & 7) * 4);
+    word |= __shfl_xor(word, 1, 64);
+    word |= __shfl_xor(word, 2, 64);
+    word |= __shfl_xor(word, 4, 64);
+    if ((l & 7) == 0) tile_result->valid[l >> 3] = word;
+    if (l == 0) {
+        tile_result->record_begin = tile_index * kSlotsPerTile;
+        tile_result->n_records = n_surv;
+        tile_result->n_candidate_loci = n_loci_called;
+        tile_result->n_called = n_call_total;
+        if (P.totals) {
+            unsigned long long* tt = P.totals + (size_t)(tile_index % kTotalShards) * kTotalStride;
+            atomicAdd(&tt[0], (unsigned long long)n_surv);
+            atomicAdd(&tt[1], (unsigned long long)n_loci_called);
+            atomicAdd(&tt[2], (unsigned long long)n_call_total);
+            atomicAdd(&tt[3], 1ull);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock, 4) void call_tiles_pipelined_kernel(
+    const uint32_t* __restrict__ tuples, const PiscesTile* __restrict__ tiles, int32_t n_tiles,
+    const uint8_t* __restrict__ ref, int32_t ref_start, int64_t ref_len, PiscesCalledAllele* __restrict__ records,
+    PiscesTileResult* __restrict__ tile_results, DeviceParams P)
+{
+    __shared__ int hist[2][kFolded * kTile];
+    __shared__ uint8_t s_refwin[2][kRefWin];
+    __shared__ double s_qlut[kQLutLds];
+
+    const int wave = threadIdx.x >> 6;
+    int t = blockIdx.x;
+    if (t >= n_tiles) return;
+    for (int i = threadIdx.x; i < 2 * kFolded * kTile; i += kBlock) (&hist[0][0])[i] = 0;
+    if (threadIdx.x >= 128 && threadIdx.x < 128 + kQLutLds) {
+        const int q = threadIdx.x - 128;
+        s_qlut[q] = (P.q_to_p_lut && q < P.q_to_p_n) ? P.q_to_p_lut[q] : q_to_p((double)q);
+    }
+    P.q_to_p_lut = s_qlut;
+    P.q_to_p_n = kQLutLds;
+    const uint32_t min_bq = (uint32_t)P.min_bq;
+    auto stage_ref = [&](const PiscesTile& tl, uint8_t* win, int tid) {
+        if (tid < kRefWin) {
+            const int64_t ri = (int64_t)tl.start_position - kRefMargin + tid - ref_start;
+            win[tid] = (ri >= 0 && ri < ref_len) ? ref[ri] : (uint8_t)0;
+        }
+    };
+    __syncthreads();
+    {   // prologue: all four waves stream the first tile
+        const PiscesTile t0 = tiles[t];
+        stage_ref(t0, s_refwin[0], threadIdx.x);
+        int* hb = hist[0];
+        const uint32_t n_loci = (uint32_t)t0.n_loci;
+        stream_tuples(tuples, t0.tuple_begin, t0.tuple_end, [&](uint32_t v) { accumulate_folded(hb, v, n_loci, min_bq); });
+    }
+    __syncthreads();
+    for (int it = 0; t < n_tiles; t += gridDim.x, it++) {
+        const int cur = it & 1;
+        const int t_next = t + gridDim.x;
+        if (wave != 0) {
+            if (t_next < n_tiles) {
+                const PiscesTile tn = tiles[t_next];
+                stage_ref(tn, s_refwin[cur ^ 1], threadIdx.x - 64);
+                int* hb = hist[cur ^ 1];
+                const uint32_t n_loci = (uint32_t)tn.n_loci;
+                stream_tuples_part(tuples, tn.tuple_begin, tn.tuple_end, threadIdx.x - 64, kStreamThreads,
+                                   [&](uint32_t v) { accumulate_folded(hb, v, n_loci, min_bq); });
+            }
+        } else {
+            const PiscesTile tc = tiles[t];
+            call_one_wave(hist[cur], tc, t, ref, ref_start, ref_len, records, &tile_results[t], P, s_refwin[cur]);
+            int* hb = hist[cur];
+            for (int i = threadIdx.x; i < kFolded * kTile; i += 64) hb[i] = 0;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Anchor-resolved accumulation: LDS [locus][199] (odd stride: consecutive loci hit distinct banks),
 // added into counts[(tile*kTile + locus)][6][3][11] — RegionState._alleleCounts layout.
 constexpr int kAnchStride = PISCES_COUNTS_PER_LOCUS + 1;

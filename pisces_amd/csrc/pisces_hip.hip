@@ -78,6 +78,8 @@ struct PiscesHip {
     int n_cus = 256;
     DeviceBuf<int32_t> d_offsets;
     DeviceBuf<PiscesCalledAllele> d_compact;
+    int kernel_variant = 0;    // 0 = one workgroup per tile, 1 = persistent software-pipelined kernel
+    int pipeline_depth = 0;    // tiles per workgroup for variant 1 (0 = fill 4 workgroups per CU)
     std::string err;
 
     DeviceBuf<uint8_t> d_ref;
@@ -248,6 +250,11 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cus = prop.multiProcessorCount;
+        const char* kv = getenv("PISCES_HIP_KERNEL");   // development switch between the two forms of the hot kernel
+        if (kv && std::string(kv) == "pipelined") h->kernel_variant = 1;
+        if (kv && std::string(kv) == "block") h->kernel_variant = 0;
+        const char* pd = getenv("PISCES_HIP_DEPTH");
+        if (pd) h->pipeline_depth = atoi(pd);
     }
     {
         // MathOperations.QtoP(q) = Math.Pow(10, -1 * q / 10f) for every integer q-score the caller can produce
@@ -536,6 +543,15 @@ static void launch_call_tiles(PiscesHip* h, hipStream_t s, const uint32_t* d_tup
                               const uint8_t* d_ref, int32_t ref_start, int64_t ref_len, PiscesCalledAllele* d_records,
                               PiscesTileResult* d_tr)
 {
+    if (h->kernel_variant == 1) {
+        // persistent software-pipelined form: 4 workgroups per CU walking tiles b, b+G, ...
+        int64_t grid = (int64_t)h->n_cus * 4;
+        if (h->pipeline_depth > 0) grid = ((int64_t)n_tiles + h->pipeline_depth - 1) / h->pipeline_depth;
+        grid = std::max<int64_t>(1, std::min<int64_t>(grid, n_tiles));
+        hipLaunchKernelGGL(call_tiles_pipelined_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, d_tuples, d_tiles, n_tiles, d_ref,
+                           ref_start, ref_len, d_records, d_tr, h->P);
+        return;
+    }
     hipLaunchKernelGGL(call_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, d_tuples, d_tiles, n_tiles, d_ref, ref_start,
                        ref_len, d_records, d_tr, h->P);
 }
