@@ -38,6 +38,26 @@ namespace Pisces.Hip
         public int* SeqOffset; public byte* Bases; public byte* Quals; public byte* Directions;
     }
 
+    [StructLayout(LayoutKind.Sequential, Size = 56)]
+    public struct PiscesCandidate
+    {
+        public int Position, Category, RefLen, AltLen;
+        public int SupF, SupR, SupS, AnchoredF, AnchoredR, AnchoredS;
+        public byte OpenLeft, OpenRight, Pad0, Pad1;
+        public long AlleleOffset;   // ref bytes then alt bytes in the allele pool
+    }
+
+    // device-resident surface: tile descriptor and per-tile result directory entry (slot layout, pisces_hip.h)
+    [StructLayout(LayoutKind.Sequential, Size = 24)]
+    public struct PiscesTile { public int StartPosition, NLoci; public long TupleBegin, TupleEnd; }
+
+    [StructLayout(LayoutKind.Sequential, Size = 48)]
+    public unsafe struct PiscesTileResult
+    {
+        public int RecordBegin, NRecords, NCandidateLoci, NCalled;
+        public fixed uint Valid[8];
+    }
+
     internal static unsafe class NativeMethods
     {
         private const string Lib = "pisceship";   // libpisceship.so next to Pisces.dll (like libFileCompression.so)
@@ -51,6 +71,15 @@ namespace Pisces.Hip
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_set_intervals(IntPtr handle, int[] starts, int[] ends, int n);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_add_reads(IntPtr handle, ref PiscesReadBatch batch);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_flush(IntPtr handle, int upToPosition, [Out] PiscesCalledAllele[] output, long capacity, out long nOut);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_flush_ex(IntPtr handle, int upToPosition, [Out] PiscesCalledAllele[] output, long capacity, out long nOut, [Out] int[] candIndex, [Out] PiscesCandidate[] cands, long candCapacity, out long nCand, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_get_candidates(IntPtr handle, int upToPosition, [Out] PiscesCandidate[] cands, long capacity, out long nOut, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern long pisces_hip_find_indel_candidates(ref PiscesReadBatch batch, byte[] reference, long refLen, int minBaseCallQuality, [Out] PiscesCandidate[] cands, long capacity, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
+        // device-resident surface (raw device pointers + hipStream_t as IntPtr)
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_call_tiles(IntPtr handle, IntPtr dTuples, IntPtr dTiles, int nTiles, IntPtr dRefBases, int refStartPosition, long refLength, IntPtr dRecords, int recordCapacity, IntPtr dTileResults, IntPtr stream);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_compact_records(IntPtr handle, IntPtr dRecords, IntPtr dTileResults, int nTiles, IntPtr dOffsets, IntPtr dOut, int outCapacity, IntPtr dCount, IntPtr stream);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_accumulate_tiles(IntPtr handle, IntPtr dTuples, IntPtr dTiles, int nTiles, IntPtr dCounts, IntPtr stream);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_device_totals(IntPtr handle, [Out] long[] totals4, int reset);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_synchronize(IntPtr handle);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_get_counts(IntPtr handle, int startPosition, int n, [Out] int[] counts);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_add_gapped_mnv_ref(IntPtr handle, int[] positions, int[] counts, int n);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_stats(IntPtr handle, [Out] long[] stats4);
