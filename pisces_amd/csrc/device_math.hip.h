@@ -27,6 +27,11 @@ struct DeviceParams {
     unsigned long long* totals;  // device int64[4] running totals of the handle, or nullptr
     const double* q_to_p_lut;    // MathOperations.QtoP(q) for integer q in [0, q_to_p_n), evaluated on the host
     int32_t q_to_p_n;
+    // Memo of the genotype-quality tail: gq_tail[a * gq_tail_cov + cov] = incomplete_gamma_function(a, target_lod * cov)
+    // for a in [1, gq_tail_a), cov in [0, gq_tail_cov), filled once per handle BY THE DEVICE with the very function
+    // the call phase would run (build_gq_tail_kernel), so a hit is bit-identical to the evaluation it replaces.
+    const double* gq_tail;
+    int32_t gq_tail_a, gq_tail_cov;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -89,6 +94,16 @@ __device__ inline double gamma_series(double a, double x, double g)  // Poisson.
     double sum = 1.0 / a;
     double del = sum;
     bool done = false;
+#if defined(PISCES_SERIES_ILP) && PISCES_SERIES_ILP == 2
+    for (int i = 1; i <= 300 && !done; i += 2) {
+        const double ap0 = a + (double)i;
+        const double q0 = x / ap0, q1 = x / (ap0 + 1.0);
+        del *= q0; sum += del;
+        if (fabs(del) < fabs(sum) * kEpsilon) { done = true; break; }
+        del *= q1; sum += del;
+        if (fabs(del) < fabs(sum) * kEpsilon) { done = true; break; }
+    }
+#else
     for (int i = 1; i <= 300 && !done; i += 4) {
         const double ap0 = a + (double)i;
         const double q0 = x / ap0, q1 = x / (ap0 + 1.0), q2 = x / (ap0 + 2.0), q3 = x / (ap0 + 3.0);
@@ -101,6 +116,7 @@ __device__ inline double gamma_series(double a, double x, double g)  // Poisson.
         del *= q3; sum += del;
         if (fabs(del) < fabs(sum) * kEpsilon) { done = true; break; }
     }
+#endif
     if (done) retval = sum * exp(a * log(x) - x - g);
     return retval;
 }
@@ -362,24 +378,49 @@ __device__ inline int32_t somatic_genotype(bool isReference, int32_t cov, int32_
     return PISCES_GT_HOM_REF;
 }
 
-__device__ inline int32_t somatic_gq(int32_t genotype, int32_t variantQ, int32_t cov, int32_t support,
-                                     const DeviceParams& P)  // SomaticGenotypeQualityCalculator.cs:10-48
+// The Poisson tail of SomaticGenotypeQualityCalculator.cs:30-41 for a hom-ref / hom-alt call: a pure function of
+// (coverage, support, targetLODFrequency).  `skip` = the reference returns MinGenotypeQScore before using it.
+struct GqTail { double p2; bool used, floor; };
+__device__ __forceinline__ GqTail somatic_gq_tail(int32_t genotype, int32_t cov, int32_t support, const DeviceParams& P)
+{
+    GqTail t = {0.0, false, false};
+    if (cov == 0) return t;
+    if ((genotype == PISCES_GT_HOM_REF) || (genotype == PISCES_GT_HOM_ALT)) {
+        const float nonAlleleObservationsF = (1.0f - frequency_f(support, cov)) * (float)cov;
+        const float expectedNonAllelObservationsF = P.target_lod * (float)cov;
+        t.used = true;
+        if (nonAlleleObservationsF >= expectedNonAllelObservationsF) { t.floor = true; return t; }
+        const int ai = (int)((double)nonAlleleObservationsF + 1.0);   // Poisson.Cdf's (int)(numOccurrences + 1)
+        if (P.gq_tail && ai >= 1 && ai < P.gq_tail_a && cov < P.gq_tail_cov)
+            t.p2 = P.gq_tail[(size_t)ai * (size_t)P.gq_tail_cov + (size_t)cov];
+        else
+            t.p2 = poisson_cdf(nonAlleleObservationsF, expectedNonAllelObservationsF);
+    }
+    return t;
+}
+
+__device__ __forceinline__ int32_t somatic_gq_finish(int32_t genotype, int32_t variantQ, int32_t cov, const GqTail& t,
+                                                     const DeviceParams& P)  // SomaticGenotypeQualityCalculator.cs:10-48
 {
     double rawQ = variantQ;
     bool noCall = (genotype == PISCES_GT_ALT12_LIKE_NOCALL || genotype == PISCES_GT_ALT_LIKE_NOCALL ||
                    genotype == PISCES_GT_REF_LIKE_NOCALL);
     if ((cov == 0) || noCall) return P.min_gq;
-    if ((genotype == PISCES_GT_HOM_REF) || (genotype == PISCES_GT_HOM_ALT)) {
-        double p1 = q_to_p(variantQ);
-        float nonAlleleObservationsF = (1.0f - frequency_f(support, cov)) * (float)cov;
-        float expectedNonAllelObservationsF = P.target_lod * (float)cov;
-        if (nonAlleleObservationsF >= expectedNonAllelObservationsF) return P.min_gq;
-        double p2 = poisson_cdf(nonAlleleObservationsF, expectedNonAllelObservationsF);
-        rawQ = p_to_q(p1 + p2);
+    if (t.used) {
+        if (t.floor) return P.min_gq;
+        double p1 = q_to_p_int(variantQ, P);
+        rawQ = p_to_q(p1 + t.p2);
     }
     double qScore = fmin((double)P.max_gq, rawQ);
     qScore = fmax(qScore, (double)P.min_gq);
     return (int32_t)rint(qScore);
+}
+
+__device__ inline int32_t somatic_gq(int32_t genotype, int32_t variantQ, int32_t cov, int32_t support,
+                                     const DeviceParams& P)
+{
+    const GqTail t = somatic_gq_tail(genotype, cov, support, P);
+    return somatic_gq_finish(genotype, variantQ, cov, t, P);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -31,6 +31,8 @@ constexpr int kTotalShards = 64;          // running-total shards (one 128-byte 
 constexpr int kTotalStride = 16;          // in 8-byte words
 constexpr int kRefMargin = 32;            // reference bases staged in LDS on each side of a tile (RMxN scan reach)
 constexpr int kRefWin = kTile + 2 * kRefMargin;
+constexpr int kWaveRow = kTile + 1;       // wave-kernel histogram row; column kTile collects out-of-range loci (padding tuples)
+constexpr int kWaveRows = 32;             // row = the tuple's 5-bit allele:direction field as it is
 constexpr int kQLutLds = 128;             // QtoP(q), q < 128, staged in LDS (no global load inside the call phase)
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // one dwordx4 load
@@ -56,6 +58,19 @@ __device__ __forceinline__ void accumulate_folded(int* hist, uint32_t t, uint32_
     uint32_t qual = t >> 24;
     if (allele < 4u && qual < min_bq) allele = 4u;
     if (locus < n_loci && dir < 3u && allele < 6u) atomicAdd(&hist[(allele * 3u + dir) * kTile + locus], 1);
+}
+
+// Wave-kernel form: row = bits 19..23 of the tuple (allele:direction), column = min(locus, kTile).  Invalid
+// allele / direction codes and out-of-range loci land in rows / a column nobody reads, so the loop has no branch and
+// no exec masking: 9 VALU + 1 DS instruction per observation.  "qual < minBQ -> N" for A/C/G/T is
+// max(row, 16 + direction): rows of alleles 0..3 are below row 16 + d, N stays, a deletion (row 20 + d) stays.
+__device__ __forceinline__ void accumulate_wave(int* hist, uint32_t t, uint32_t min_bq_shifted)
+{
+    const uint32_t locus = min(t & 0x7FFFu, (uint32_t)kTile);
+    const uint32_t row = (t >> 19) & 31u;
+    const uint32_t low = max(row, (row & 3u) | 16u);
+    const uint32_t r = (t < min_bq_shifted) ? low : row;   // qual is the top byte: qual < minBQ <=> t < minBQ << 24
+    atomicAdd(&hist[r * kWaveRow + locus], 1);
 }
 
 // Streams tuples[begin, end) through `op(tuple)`: scalar head/tail up to 16-byte alignment, then
@@ -88,6 +103,9 @@ __device__ __forceinline__ void stream_tuples(const uint32_t* __restrict__ tuple
 
 __device__ __forceinline__ void copy_record(PiscesCalledAllele* dst, const PiscesCalledAllele* src)
 {
+#ifdef PISCES_ABLATE_STORE
+    if (src->position != -12345) return;   // development ablation: no record stores
+#endif
     const uint4* sp = reinterpret_cast<const uint4*>(src);
     uint4* dp = reinterpret_cast<uint4*>(dst);
     dp[0] = sp[0]; dp[1] = sp[1]; dp[2] = sp[2]; dp[3] = sp[3];
@@ -98,13 +116,30 @@ struct PointCounts {
     int total, nocalls, refsup, support;
 };
 
+// LDS layouts of the folded histogram: count of (allele a, direction d) at locus l
+struct HistBlock {   // call_tiles_kernel / call_counts_kernel: 18 rows of kTile
+    static __device__ __forceinline__ int idx(int a, int d, int l) { return (a * 3 + d) * kTile + l; }
+};
+struct HistWave {    // call_tiles_wave_kernel: no validity test in the streaming loop (unused rows / column absorb)
+    static __device__ __forceinline__ int idx(int a, int d, int l) { return (a * 4 + d) * kWaveRow + l; }
+};
+
+struct LocusCounts { int h[6][3]; };
+
+template <typename H = HistBlock>
+__device__ __forceinline__ LocusCounts load_counts(const int* hist, int l)
+{
+    LocusCounts lc;
+#pragma unroll
+    for (int k = 0; k < kFolded; k++) lc.h[k / 3][k % 3] = hist[H::idx(k / 3, k % 3, l)];
+    return lc;
+}
+
 // CoverageCalculator.CalculateSinglePoint (CoverageCalculator.cs:49-98) from the folded counts of one locus
-__device__ __forceinline__ PointCounts point_counts(const int* hist, int l, int allele, bool isRef, int refType, int gapped)
+__device__ __forceinline__ PointCounts point_counts_of(const LocusCounts& lc, int allele, bool isRef, int refType, int gapped)
 {
     PointCounts c;
-    int h[6][3];
-#pragma unroll
-    for (int k = 0; k < kFolded; k++) h[k / 3][k % 3] = hist[k * kTile + l];
+    const int (&h)[6][3] = lc.h;
     c.total = 0; c.nocalls = 0; c.refsup = 0;
     const int supAllele = isRef ? refType : allele;
 #pragma unroll
@@ -126,6 +161,12 @@ __device__ __forceinline__ PointCounts point_counts(const int* hist, int l, int 
     return c;
 }
 
+template <typename H = HistBlock>
+__device__ __forceinline__ PointCounts point_counts(const int* hist, int l, int allele, bool isRef, int refType, int gapped)
+{
+    return point_counts_of(load_counts<H>(hist, l), allele, isRef, refType, gapped);
+}
+
 // IsCallable (AlleleCaller.cs:236-258), the tests that precede the q-score: coverage, then frequency.
 __device__ __forceinline__ bool variant_passes_frequency(const PointCounts& c, const DeviceParams& P)
 {
@@ -138,7 +179,8 @@ __device__ __forceinline__ bool variant_passes_frequency(const PointCounts& c, c
 // statistics: AlleleProcessor.ApplyFilters (AlleleProcessor.cs:25-71), SomaticGenotyper, record packing.
 __device__ inline void finish_allele(const PointCounts& c, int pos, int a, bool isRef, int rt, int vq, const SbResult& sb,
                                      const uint8_t* __restrict__ ref, int64_t win_lo, int64_t win_hi, const DeviceParams& P,
-                                     PiscesCalledAllele& r, const uint8_t* s_refwin, int s_refidx)
+                                     PiscesCalledAllele& r, const uint8_t* s_refwin, int s_refidx,
+                                     const GqTail* pre_tail = nullptr)
 {
     const float freq = frequency_f(c.support, c.total);
     // SetFractionNoCalls (CalledAllele.cs:107-114) + ApplyFilters
@@ -162,8 +204,8 @@ __device__ inline void finish_allele(const PointCounts& c, int pos, int a, bool 
         if (P.vf_filter >= 0.0f && freq < P.vf_filter) filters |= 1u << PISCES_FILTER_LOW_VARIANT_FREQUENCY;
     }
     const int gt = somatic_genotype(isRef, c.total, c.support, c.refsup, P);
-#if !(defined(PISCES_ABLATE_MATH) && PISCES_ABLATE_MATH == 3)
-    const int gq = somatic_gq(gt, vq, c.total, c.support, P);
+#if !(defined(PISCES_ABLATE_MATH) && (PISCES_ABLATE_MATH == 3 || PISCES_ABLATE_MATH == 9))
+    const int gq = pre_tail ? somatic_gq_finish(gt, vq, c.total, *pre_tail, P) : somatic_gq(gt, vq, c.total, c.support, P);
 #else
     const int gq = vq;
 #endif
@@ -188,19 +230,19 @@ __device__ inline void finish_allele(const PointCounts& c, int pos, int a, bool 
 __device__ inline bool process_point_allele(const PointCounts& c, int pos, int a, bool isRef, int rt,
                                              const uint8_t* __restrict__ ref, int64_t win_lo, int64_t win_hi,
                                              const DeviceParams& P, PiscesCalledAllele& r,
-                                             const uint8_t* s_refwin = nullptr, int s_refidx = 0)
+                                             const uint8_t* s_refwin = nullptr, int s_refidx = 0, const GqTail* pre_tail = nullptr)
 {
     if (!isRef && !variant_passes_frequency(c, P)) return false;
     int vq = 0;
-#if !(defined(PISCES_ABLATE_MATH) && PISCES_ABLATE_MATH == 5)
+#if !(defined(PISCES_ABLATE_MATH) && (PISCES_ABLATE_MATH == 5 || PISCES_ABLATE_MATH == 9))
     if (c.support > 0 && c.total != 0) vq = poisson_qscore(c.support, c.total, P);   // VariantQualityCalculator.Compute :11-24
 #endif
     if (!isRef && vq < P.min_vq) return false;
     SbResult sb = {0.0, 0, 0, 0};
-#if !(defined(PISCES_ABLATE_MATH) && PISCES_ABLATE_MATH == 4)
+#if !(defined(PISCES_ABLATE_MATH) && (PISCES_ABLATE_MATH == 4 || PISCES_ABLATE_MATH == 9))
     if (c.support > 0) sb = strand_bias(c.cov, c.sup, P);                            // StrandBiasCalculator.Compute :10-15
 #endif
-    finish_allele(c, pos, a, isRef, rt, vq, sb, ref, win_lo, win_hi, P, r, s_refwin, s_refidx);
+    finish_allele(c, pos, a, isRef, rt, vq, sb, ref, win_lo, win_hi, P, r, s_refwin, s_refidx, pre_tail);
     return true;
 }
 
@@ -283,8 +325,16 @@ __device__ inline void call_roles(const int* hist, const uint32_t* gapped /* LDS
             const PointCounts c = point_counts(hist, l, a, false, rt, g);
             const int slot = l * 4 + k;
             if (wave == 1) {
+#if defined(PISCES_ABLATE_MATH) && (PISCES_ABLATE_MATH == 9 || PISCES_ABLATE_MATH == 6)
+                vs->vq[slot] = 100;
+#else
                 vs->vq[slot] = (c.support > 0 && c.total != 0) ? poisson_qscore(c.support, c.total, P) : 0;
+#endif
+#if defined(PISCES_ABLATE_MATH) && (PISCES_ABLATE_MATH == 9 || PISCES_ABLATE_MATH == 7)
+            } else if (c.support < 0) {
+#else
             } else if (c.support > 0) {
+#endif
                 const SbStats ov = sb_stats_of(0, c.cov, c.sup, P), fw = sb_stats_of(1, c.cov, c.sup, P),
                               rv = sb_stats_of(2, c.cov, c.sup, P);
                 vs->ov_var[slot] = ov.var_gt_zero;
@@ -426,175 +476,384 @@ __global__ __launch_bounds__(kBlock, 4) void call_tiles_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Software-pipelined persistent form of the hot kernel.  A workgroup walks tiles b, b+G, b+2G, ...:
-//   waves 1-3 stream tile i+1 into hist[(i+1)&1]   |   wave 0 runs the whole call phase of tile i from hist[i&1]
-// with one workgroup barrier per tile, so exactly one call phase per workgroup (the last) is not covered by
-// streaming.  call_tiles_kernel exposes one call phase per tile per scheduling round instead (measured timeline,
-// DESIGN.md section 4).
-constexpr int kStreamThreads = kBlock - 64;
+// Wave-per-tile form of the hot kernel: one wave64 owns one tile from its first tuple to its directory entry.
+//
+// Why: a tile is a fixed-latency chain (stream ~130 KB, then a call phase of dependent FP64 work).  With four waves
+// per tile only 1024 tiles are resident (128 VGPRs), a BASELINE-config-2 launch (1563 tiles) runs as two lock-step
+// rounds and exposes two call phases (measured timeline).  One wave per tile makes every tile of
+// such a launch resident at once (4096 wave slots), needs no workgroup barrier, and lets larger launches interleave
+// freely.  The call phase is arranged so that the single wave never runs the same long function twice in a row:
+//   1. Reference candidate of every locus (lane = locus).  Its q-score and strand-bias tails are the provable
+//      early-outs, its genotype-quality tail comes from the handle's memo table (DeviceParams::gq_tail).
+//   2. variant q-scores, lane = locus, one converged pass per allele rank that has a candidate in the tile.
+//   3. strand bias of the callable variants, lane = (variant, statistic): the three Poisson tails of a variant are
+//      independent, so they run side by side on three lanes instead of one after the other.
+//   4. filters / genotype / record of the callable variants, lane = locus again.
+#ifndef PISCES_WAVE_UNROLL
+#define PISCES_WAVE_UNROLL 8
+#endif
+#ifndef PISCES_WAVE_OCC
+#define PISCES_WAVE_OCC 3    // waves per SIMD the one-wave-per-tile form is compiled for (168 VGPRs)
+#endif
+#ifndef PISCES_WAVE2_OCC
+#define PISCES_WAVE2_OCC 4   // two waves per tile: 8 tiles per CU resident, 2048 on the chip
+#endif
+constexpr int kWaveUnroll = PISCES_WAVE_UNROLL;   // 16-byte loads per lane per batch; two batches are in flight
+constexpr int kPairsPerRound = 21;   // 21 variants x 3 statistics = 63 lanes
+constexpr int kPairsPerSuper = 3 * kPairsPerRound;   // candidates whose statistics are held in LDS at a time
 
-template <typename Op>
-__device__ __forceinline__ void stream_tuples_part(const uint32_t* __restrict__ tuples, int64_t begin, int64_t end, int tid,
-                                                   int nthreads, Op op)
+// One wave streams tuples[begin, end) through op(): two register batches of kWaveUnroll dwordx4 loads per lane in
+// ping-pong, so that the loads of the next batch are in flight while the current one is decoded (a lone wave has no
+// neighbour to hide its decode time behind).
+template <int NW, typename Op>
+__device__ __forceinline__ void stream_tuples_wave(const uint32_t* __restrict__ tuples, int64_t begin, int64_t end, int lane, int wid,
+                                                   Op op)
 {
     int64_t abegin = (begin + 3) & ~(int64_t)3;
     int64_t aend = end & ~(int64_t)3;
     if (abegin > aend) { abegin = end; aend = end; }
-    for (int64_t i = begin + tid; i < abegin; i += nthreads) op(tuples[i]);
+    const int tid = wid * 64 + lane;
+    for (int64_t i = begin + tid; i < abegin; i += 64 * NW) op(tuples[i]);
     const u32x4* __restrict__ p4 = reinterpret_cast<const u32x4*>(tuples + abegin);
-    const int64_t n4 = (aend - abegin) >> 2;
-    for (int64_t i = tid; i < n4; i += (int64_t)nthreads * kUnroll) {
-        u32x4 v[kUnroll];
+    const uint32_t n4 = (uint32_t)((aend - abegin) >> 2);   // a tile's segment is < 2^32 dwordx4
+    constexpr uint32_t kBatch = 64u * kWaveUnroll;
+    // wave-uniform loop control in scalar registers: a divergent-looking `break` would put the loop exit on the latch
+    // path, and the waitcnt pass would then drain the batch in flight at every loop header
+    const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((n4 + kBatch - 1) / kBatch));   // batches wid, wid + NW, ...
+    u32x4 cur[kWaveUnroll], nxt[kWaveUnroll];
+    // every load is unconditional (index clamped into the segment) so that the batches stay straight-line code and
+    // the waits are counted, not drained; only the last, partial batch masks its out-of-range lanes afterwards
+    auto load = [&](u32x4* v, uint32_t b) {
 #pragma unroll
-        for (int u = 0; u < kUnroll; u++) {
-            int64_t j = i + (int64_t)u * nthreads;
-            v[u] = j < n4 ? __builtin_nontemporal_load(&p4[j]) : (u32x4){~0u, ~0u, ~0u, ~0u};
+        for (int u = 0; u < kWaveUnroll; u++) {
+            const uint32_t j = min(b * kBatch + (uint32_t)u * 64u + (uint32_t)lane, n4 - 1u);
+            // streamed exactly once: non-temporal so the tuples do not evict the reference / records from L2
+            v[u] = __builtin_nontemporal_load(&p4[j]);
         }
+    };
+    auto consume = [&](const u32x4* v) {
 #pragma unroll
-        for (int u = 0; u < kUnroll; u++) {
-            op(v[u].x); op(v[u].y); op(v[u].z); op(v[u].w);
+        for (int u = 0; u < kWaveUnroll; u++) { op(v[u].x); op(v[u].y); op(v[u].z); op(v[u].w); }
+    };
+    if ((uint32_t)wid < nb) {
+        uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane(wid);
+        const uint32_t m = (nb - b + NW - 1) / NW;   // this wave's batches
+        load(cur, b);
+        // explicit ping-pong over pairs of batches with a trip count known up front: no register copy between the
+        // halves (it would wait for the batch in flight) and no mid-loop exit (its latch path would make the waitcnt
+        // pass drain the batch in flight at every loop header)
+        for (uint32_t p = (m - 1) / 2; p > 0; p--) {
+            load(nxt, b + NW);
+            __builtin_amdgcn_sched_barrier(0);   // keep the next batch's loads ahead of this batch's decode
+            consume(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            load(cur, b + 2 * NW);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            b += 2 * NW;
         }
+        if (((m - 1) & 1u) != 0) {
+            load(nxt, b + NW);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(cur);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < kWaveUnroll; u++) cur[u] = nxt[u];
+            b += NW;
+        }
+        if (b == nb - 1 && (n4 % kBatch)) {
+#pragma unroll
+            for (int u = 0; u < kWaveUnroll; u++)
+                if (b * kBatch + (uint32_t)u * 64u + (uint32_t)lane >= n4) cur[u] = (u32x4){~0u, ~0u, ~0u, ~0u};
+        }
+        consume(cur);
     }
-    for (int64_t i = aend + tid; i < end; i += nthreads) op(tuples[i]);
+    for (int64_t i = aend + tid; i < end; i += 64 * NW) op(tuples[i]);
 }
 
-// The whole call phase of one tile on one wave (lane = locus): variant candidates first, then the Reference
-// candidate unless a variant was called at the locus.
-__device__ inline void call_one_wave(const int* hist, const PiscesTile& tile, int tile_index, const uint8_t* __restrict__ ref,
-                                     int32_t ref_start, int64_t ref_len, PiscesCalledAllele* __restrict__ records,
-                                     PiscesTileResult* __restrict__ tile_result, const DeviceParams& P, const uint8_t* s_refwin)
+// LDS traffic of ONE wave is processed in order; the fence keeps the compiler from moving it and drains lgkmcnt
+__device__ __forceinline__ void wave_lds_sync()
 {
-    const int l = threadIdx.x & 63;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct WaveScratch {
+    int vq[kTile * 4];                       // variant q-score of (locus, rank)
+    uint8_t pair_l[64], pair_k[64];          // the variant candidates in flight
+    double sb_var[kPairsPerSuper][3], sb_fp[kPairsPerSuper][3];
+};
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_OCC) void call_tiles_wave_kernel(
+    const uint32_t* __restrict__ tuples, const PiscesTile* __restrict__ tiles, int32_t n_tiles,
+    const uint8_t* __restrict__ ref, int32_t ref_start, int64_t ref_len, PiscesCalledAllele* __restrict__ records,
+    PiscesTileResult* __restrict__ tile_results, DeviceParams P)
+{
+    __shared__ int hist[kWaveRows * kWaveRow];
+    __shared__ uint8_t s_refwin[kRefWin];
+    __shared__ double s_qlut[kQLutLds];
+    __shared__ WaveScratch ws;
+    __shared__ uint8_t s_vmask[kTile];
+
+    const int t = blockIdx.x;
+    if (t >= n_tiles) return;
+    const int l = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const PiscesTile tile = tiles[t];
+#ifdef PISCES_TIMING
+    const long long tc0 = wall_clock64();
+#endif
+    for (int i = threadIdx.x; i < kWaveRows * kWaveRow; i += 64 * NW) hist[i] = 0;
+    for (int i = threadIdx.x; i < kRefWin; i += 64 * NW) {
+        const int64_t ri = (int64_t)tile.start_position - kRefMargin + i - ref_start;
+        s_refwin[i] = (ri >= 0 && ri < ref_len) ? ref[ri] : (uint8_t)0;
+    }
+    for (int q = threadIdx.x; q < kQLutLds; q += 64 * NW) s_qlut[q] = (P.q_to_p_lut && q < P.q_to_p_n) ? P.q_to_p_lut[q] : q_to_p((double)q);
+    P.q_to_p_lut = s_qlut;
+    P.q_to_p_n = kQLutLds;
+    __syncthreads();
+
+    {
+        const uint32_t min_bq_shifted = (uint32_t)min(max(P.min_bq, 0), 255) << 24;
+#if defined(PISCES_ABLATE) && PISCES_ABLATE == 2
+        uint32_t acc = 0;   // development ablation: loads only
+        stream_tuples_wave<NW>(tuples, tile.tuple_begin, tile.tuple_end, l, wid, [&](uint32_t v) { acc ^= v; });
+        if (acc == 0x12345u) hist[l] = (int)min_bq_shifted;
+#elif defined(PISCES_ABLATE) && PISCES_ABLATE == 3
+        uint32_t acc = 0;   // development ablation: loads + decode, no LDS atomics
+        stream_tuples_wave<NW>(tuples, tile.tuple_begin, tile.tuple_end, l, wid, [&](uint32_t t) {
+            const uint32_t locus = min(t & 0x7FFFu, (uint32_t)kTile);
+            const uint32_t row = (t >> 19) & 31u;
+            const uint32_t low = max(row, (row & 3u) | 16u);
+            const uint32_t r = (t < min_bq_shifted) ? low : row;
+            acc += r * kWaveRow + locus; });
+        if (acc == 0x12345u) hist[l] = (int)min_bq_shifted;
+#else
+        stream_tuples_wave<NW>(tuples, tile.tuple_begin, tile.tuple_end, l, wid, [&](uint32_t v) { accumulate_wave(hist, v, min_bq_shifted); });
+#endif
+    }
+    __syncthreads();
+#if defined(PISCES_ABLATE) && PISCES_ABLATE >= 1
+    if (threadIdx.x == 0) { tile_results[t].record_begin = 0; tile_results[t].n_records = hist[5 + l]; }
+    return;
+#endif
+#ifdef PISCES_TIMING
+    const long long tc1 = wall_clock64();
+#endif
+
+    // ---- call phase ----
     const int pos = tile.start_position + l;
     const uint8_t refb = s_refwin[kRefMargin + l];
     const bool in_ref = l < tile.n_loci && refb != 0;
     const int rt = in_ref ? allele_type_of_base(refb) : PISCES_ALLELE_N;
     const int64_t win_lo = (int64_t)ref_start - 1, win_hi = win_lo + ref_len;
-    PiscesCalledAllele* const slots = records + (int64_t)tile_index * kSlotsPerTile + l * 4;
+    PiscesCalledAllele* const slots = records + (int64_t)t * kSlotsPerTile + l * 4;
 
-    uint32_t vmask = 0;
+    // the locus' 18 folded counts, once, into registers
+    const LocusCounts lc = load_counts<HistWave>(hist, l);
+    // Reference candidate first: its genotype-quality tail is one dependent global load from the handle's memo table,
+    // issued here so that it is back by the time the Reference pass wants it
+    const bool want_ref = in_ref && P.include_ref;
+    const int ref_a = (rt < 4) ? rt : PISCES_ALLELE_N;
+    const PointCounts ref_c = point_counts_of(lc, ref_a, true, rt, 0);
+    GqTail ref_tail = {0.0, false, false};
+    if (want_ref) ref_tail = somatic_gq_tail(somatic_genotype(true, ref_c.total, ref_c.support, ref_c.refsup, P), ref_c.total, ref_c.support, P);
+
+    // variant candidates that survive the integer / float32 half of IsCallable (AlleleCaller.cs:236-258)
+    uint32_t pass_mask = 0;
     if (in_ref && rt < 4) {
-#pragma unroll 1
+#pragma unroll
         for (int k = 0; k < 4; k++) {
             const int a = allele_of_rank(k);
             if (a == rt) continue;
-            if (hist[(a * 3 + 0) * kTile + l] + hist[(a * 3 + 1) * kTile + l] + hist[(a * 3 + 2) * kTile + l] == 0) continue;
-            const PointCounts c = point_counts(hist, l, a, false, rt, 0);
-            if (!variant_passes_frequency(c, P)) continue;
-            const int vq = (c.support > 0 && c.total != 0) ? poisson_qscore(c.support, c.total, P) : 0;
-            if (vq < P.min_vq) continue;
-            SbResult sb = {0.0, 0, 0, 0};
-            if (c.support > 0) sb = strand_bias(c.cov, c.sup, P);
-            PiscesCalledAllele r;
-            finish_allele(c, pos, a, false, rt, vq, sb, ref, win_lo, win_hi, P, r, s_refwin, kRefMargin + l);
-            copy_record(&slots[k], &r);
-            vmask |= 1u << k;
+            if (lc.h[a][0] + lc.h[a][1] + lc.h[a][2] == 0) continue;
+            const PointCounts c = point_counts_of(lc, a, false, rt, 0);
+            if (variant_passes_frequency(c, P)) pass_mask |= 1u << k;
         }
     }
+#ifdef PISCES_TIMING
+    const long long tcA = wall_clock64();
+    long long tcB = tcA, tcC = tcA, tcD = tcA;
+#endif
+    // With two waves per tile, wave 0 takes the Reference candidates and then the variant q-scores while wave 1 takes
+    // the strand-bias statistics; they meet in LDS for the assembly.  "No variant candidate in this tile" is the same
+    // ballot in both waves, so wave 1 can simply leave.  With one wave per tile the same code runs in sequence.
+    const bool any_variant = __ballot(pass_mask != 0) != 0ull;
+    const bool ref_wave = wid == 0, sb_wave = wid == NW - 1;
+    if (!ref_wave && !any_variant) return;
+
+    // variant candidates of the tile numbered rank-major from ballots (scalar work, identical in both waves)
+    uint32_t pidx = 0;   // this lane's candidate numbers, 8 bits per allele rank
+    int total = 0;
+    if (any_variant) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long bk = __ballot((pass_mask >> k) & 1u);
+            const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bk, 0u));
+            if ((pass_mask >> k) & 1u) pidx |= (uint32_t)(total + below) << (8 * k);
+            total += __popcll(bk);
+        }
+    }
+
     bool ref_emitted = false;
     int ref_rank = 0;
-    if (in_ref && P.include_ref) {
-        int all = 0;
-#pragma unroll
-        for (int c = 0; c < kFolded; c++) all += hist[c * kTile + l];
-        if (P.emit_zero_cov || all > 0) {
-            ref_emitted = true;
-            ref_rank = (rt < 4) ? rank_of_allele(rt) : 0;
-            if (vmask == 0) {   // its record is dropped anyway when a variant is called here (AlleleCaller.cs:146-147)
-                const int a = (rt < 4) ? rt : PISCES_ALLELE_N;
-                const PointCounts c = point_counts(hist, l, a, true, rt, 0);
-                const int vq = (c.support > 0 && c.total != 0) ? poisson_qscore(c.support, c.total, P) : 0;
-                SbResult sb = {0.0, 0, 0, 0};
-                if (c.support > 0) sb = strand_bias(c.cov, c.sup, P);
-                PiscesCalledAllele r;
-                finish_allele(c, pos, a, true, rt, vq, sb, ref, win_lo, win_hi, P, r, s_refwin, kRefMargin + l);
-                copy_record(&slots[ref_rank], &r);
+    if (ref_wave) {
+        // 1. Reference candidate (RegionState.GetAllCandidates, RegionState.cs:414-447); written now, it only counts if
+        //    no variant turns out callable at the locus (AlleleCaller.cs:146-147)
+        if (want_ref) {
+            const int all = ref_c.total + ref_c.nocalls;
+            if (P.emit_zero_cov || all > 0) {
+                ref_rank = (rt < 4) ? rank_of_allele(rt) : 0;
+                PiscesCalledAllele rec;
+                (void)process_point_allele(ref_c, pos, ref_a, true, rt, ref, win_lo, win_hi, P, rec, s_refwin, kRefMargin + l, &ref_tail);
+                copy_record(&slots[ref_rank], &rec);
+                ref_emitted = true;
             }
         }
+#ifdef PISCES_TIMING
+        tcB = wall_clock64();
+        tcC = tcB; tcD = tcB;
+#endif
+        // 2. variant q-scores (VariantQualityCalculator.Compute :11-24), one converged pass per allele rank in use
+        if (any_variant) {
+            wave_lds_sync();   // the counts are re-read from LDS here rather than held in registers across the Reference pass
+            const LocusCounts lv = load_counts<HistWave>(hist, l);
+#pragma unroll 1
+            for (int k = 0; k < 4; k++) {
+                if (!(pass_mask & (1u << k))) continue;
+                const PointCounts c = point_counts_of(lv, allele_of_rank(k), false, rt, 0);
+                ws.vq[l * 4 + k] = (c.support > 0 && c.total != 0) ? poisson_qscore(c.support, c.total, P) : 0;
+            }
+        }
+#ifdef PISCES_TIMING
+        tcC = wall_clock64();
+        tcD = tcC;
+#endif
     }
-    const uint32_t valid = vmask ? vmask : (ref_emitted ? (1u << ref_rank) : 0u);
-    int n_surv = __popc(valid), n_call_total = __popc(vmask) + (ref_emitted ? 1 : 0);
+
+    uint32_t vmask = 0;
+    if (any_variant) {
+        for (int sbase = 0; sbase < total; sbase += kPairsPerSuper) {
+            const int n_here = min(kPairsPerSuper, total - sbase);
+            if (sb_wave) {
+                // 3. strand-bias statistics, lane = (candidate, statistic)
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        n_surv += __shfl_xor(n_surv, d, 64);
-        n_call_total += __shfl_xor(n_call_total, d, 64);
+                for (int k = 0; k < 4; k++) {
+                    const int p = (int)((pidx >> (8 * k)) & 255u) - sbase;
+                    if (((pass_mask >> k) & 1u) && p >= 0 && p < kPairsPerSuper) { ws.pair_l[p] = (uint8_t)l; ws.pair_k[p] = (uint8_t)k; }
+                }
+                wave_lds_sync();
+#pragma unroll 1
+                for (int r = 0; r * kPairsPerRound < n_here; r++) {
+                    const int p = r * kPairsPerRound + l / 3, which = l % 3;
+                    if (l < 3 * kPairsPerRound && p < n_here) {
+                        const int pl = ws.pair_l[p], pk = ws.pair_k[p];
+                        const int prt = allele_type_of_base(s_refwin[kRefMargin + pl]);
+                        const PointCounts c = point_counts<HistWave>(hist, pl, allele_of_rank(pk), false, prt, 0);
+                        const SbStats st = sb_stats_of(which, c.cov, c.sup, P);
+                        ws.sb_var[p][which] = st.var_gt_zero;
+                        ws.sb_fp[p][which] = st.false_pos;
+                    }
+                }
+            }
+            if (NW > 1) __syncthreads(); else wave_lds_sync();   // q-scores and strand-bias statistics meet
+            if (sb_wave) {
+                // 4. IsCallable's last test, then filters / genotype / record of the callable variants, lane = locus
+                const LocusCounts la = load_counts<HistWave>(hist, l);   // re-read (after the fence above), not held
+#pragma unroll 1
+                for (int k = 0; k < 4; k++) {
+                    if (!(pass_mask & (1u << k))) continue;
+                    const int p = (int)((pidx >> (8 * k)) & 255u) - sbase;
+                    if (p < 0 || p >= kPairsPerSuper) continue;
+                    const int vq = ws.vq[l * 4 + k];
+                    if (vq < P.min_vq) continue;
+                    const int a = allele_of_rank(k);
+                    const PointCounts c = point_counts_of(la, a, false, rt, 0);
+                    SbStats ov, fw, rv;
+                    ov.var_gt_zero = ws.sb_var[p][0]; ov.false_pos = ws.sb_fp[p][0];
+                    fw.var_gt_zero = ws.sb_var[p][1]; fw.false_pos = ws.sb_fp[p][1];
+                    rv.var_gt_zero = ws.sb_var[p][2]; rv.false_pos = ws.sb_fp[p][2];
+                    const int s2 = c.sup[2] / 2, c2 = c.cov[2] / 2;
+                    fw.coverage = c.cov[0] + c2; fw.support = c.sup[0] + s2;
+                    rv.coverage = c.cov[1] + c2; rv.support = c.sup[1] + s2;
+                    ov.coverage = 0; ov.support = 0;
+                    const SbResult sb = sb_combine(ov, fw, rv, P);
+                    PiscesCalledAllele r;
+                    finish_allele(c, pos, a, false, rt, vq, sb, ref, win_lo, win_hi, P, r, s_refwin, kRefMargin + l);
+                    copy_record(&slots[k], &r);
+                    vmask |= 1u << k;
+                }
+            }
+            if (sbase + kPairsPerSuper < total) {   // before the scratch of this round is overwritten
+                if (NW > 1) __syncthreads(); else wave_lds_sync();
+            }
+        }
+        if (NW > 1) {
+            if (sb_wave) s_vmask[l] = (uint8_t)vmask;
+            __syncthreads();
+            if (!ref_wave) return;
+            vmask = s_vmask[l];
+        }
     }
+#ifdef PISCES_TIMING
+    tcD = wall_clock64();
+#endif
+
+    // validity bits, counts, tile directory
+    const uint32_t valid = vmask ? vmask : (ref_emitted ? (1u << ref_rank) : 0u);
+    // counts from ballots (scalar) instead of cross-lane reductions
+    int n_surv = 0, n_var = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        n_surv += __popcll(__ballot((valid >> k) & 1u));
+        n_var += __popcll(__ballot((vmask >> k) & 1u));
+    }
+    const int n_call_total = n_var + __popcll(__ballot(ref_emitted));   // IsCallable is always true for a Reference allele
     const int n_loci_called = __popcll(__ballot(valid != 0));
+    // nibble of lane l -> bits 4*(l&7).. of word l>>3 of the 256-bit mask
     uint32_t word = valid << ((l & 7) * 4);
     word |= __shfl_xor(word, 1, 64);
     word |= __shfl_xor(word, 2, 64);
     word |= __shfl_xor(word, 4, 64);
+    PiscesTileResult* const tile_result = &tile_results[t];
     if ((l & 7) == 0) tile_result->valid[l >> 3] = word;
     if (l == 0) {
-        tile_result->record_begin = tile_index * kSlotsPerTile;
+        tile_result->record_begin = t * kSlotsPerTile;
         tile_result->n_records = n_surv;
         tile_result->n_candidate_loci = n_loci_called;
-        tile_result->n_called = n_call_total;
+        tile_result->n_called = n_call_total;   // IAlleleCaller.TotalNumCalled contribution
         if (P.totals) {
-            unsigned long long* tt = P.totals + (size_t)(tile_index % kTotalShards) * kTotalStride;
+            unsigned long long* tt = P.totals + (size_t)(t % kTotalShards) * kTotalStride;
             atomicAdd(&tt[0], (unsigned long long)n_surv);
             atomicAdd(&tt[1], (unsigned long long)n_loci_called);
             atomicAdd(&tt[2], (unsigned long long)n_call_total);
             atomicAdd(&tt[3], 1ull);
         }
+#ifdef PISCES_TIMING
+        const long long tc2 = wall_clock64();
+        tile_result->record_begin = (int)(tc0 & 0x3FFFFFFF);
+        tile_result->n_records = (int)(tc1 & 0x3FFFFFFF);
+        tile_result->n_candidate_loci = (int)(tc2 & 0x3FFFFFFF);
+        tile_result->n_called = (int)__builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
+        tile_result->valid[0] = __builtin_amdgcn_s_getreg(63508);        // HW_REG_XCC_ID
+        tile_result->valid[1] = (uint32_t)(tcA - tc1);   // pass mask
+        tile_result->valid[2] = (uint32_t)(tcB - tcA);   // Reference pass
+        tile_result->valid[3] = (uint32_t)(tcC - tcB);   // variant q-scores
+        tile_result->valid[4] = (uint32_t)(tcD - tcC);   // strand-bias items + assembly
+        tile_result->valid[5] = (uint32_t)(tc2 - tcD);   // directory
+#endif
     }
 }
 
-__global__ __launch_bounds__(kBlock, 4) void call_tiles_pipelined_kernel(
-    const uint32_t* __restrict__ tuples, const PiscesTile* __restrict__ tiles, int32_t n_tiles,
-    const uint8_t* __restrict__ ref, int32_t ref_start, int64_t ref_len, PiscesCalledAllele* __restrict__ records,
-    PiscesTileResult* __restrict__ tile_results, DeviceParams P)
+// fills DeviceParams::gq_tail with the function the call phase would evaluate (bit-identical by construction)
+__global__ void build_gq_tail_kernel(double* __restrict__ table, int32_t n_a, int32_t n_cov, float target_lod)
 {
-    __shared__ int hist[2][kFolded * kTile];
-    __shared__ uint8_t s_refwin[2][kRefWin];
-    __shared__ double s_qlut[kQLutLds];
-
-    const int wave = threadIdx.x >> 6;
-    int t = blockIdx.x;
-    if (t >= n_tiles) return;
-    for (int i = threadIdx.x; i < 2 * kFolded * kTile; i += kBlock) (&hist[0][0])[i] = 0;
-    if (threadIdx.x >= 128 && threadIdx.x < 128 + kQLutLds) {
-        const int q = threadIdx.x - 128;
-        s_qlut[q] = (P.q_to_p_lut && q < P.q_to_p_n) ? P.q_to_p_lut[q] : q_to_p((double)q);
-    }
-    P.q_to_p_lut = s_qlut;
-    P.q_to_p_n = kQLutLds;
-    const uint32_t min_bq = (uint32_t)P.min_bq;
-    auto stage_ref = [&](const PiscesTile& tl, uint8_t* win, int tid) {
-        if (tid < kRefWin) {
-            const int64_t ri = (int64_t)tl.start_position - kRefMargin + tid - ref_start;
-            win[tid] = (ri >= 0 && ri < ref_len) ? ref[ri] : (uint8_t)0;
-        }
-    };
-    __syncthreads();
-    {   // prologue: all four waves stream the first tile
-        const PiscesTile t0 = tiles[t];
-        stage_ref(t0, s_refwin[0], threadIdx.x);
-        int* hb = hist[0];
-        const uint32_t n_loci = (uint32_t)t0.n_loci;
-        stream_tuples(tuples, t0.tuple_begin, t0.tuple_end, [&](uint32_t v) { accumulate_folded(hb, v, n_loci, min_bq); });
-    }
-    __syncthreads();
-    for (int it = 0; t < n_tiles; t += gridDim.x, it++) {
-        const int cur = it & 1;
-        const int t_next = t + gridDim.x;
-        if (wave != 0) {
-            if (t_next < n_tiles) {
-                const PiscesTile tn = tiles[t_next];
-                stage_ref(tn, s_refwin[cur ^ 1], threadIdx.x - 64);
-                int* hb = hist[cur ^ 1];
-                const uint32_t n_loci = (uint32_t)tn.n_loci;
-                stream_tuples_part(tuples, tn.tuple_begin, tn.tuple_end, threadIdx.x - 64, kStreamThreads,
-                                   [&](uint32_t v) { accumulate_folded(hb, v, n_loci, min_bq); });
-            }
-        } else {
-            const PiscesTile tc = tiles[t];
-            call_one_wave(hist[cur], tc, t, ref, ref_start, ref_len, records, &tile_results[t], P, s_refwin[cur]);
-            int* hb = hist[cur];
-            for (int i = threadIdx.x; i < kFolded * kTile; i += 64) hb[i] = 0;
-        }
-        __syncthreads();
-    }
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_a * n_cov) return;
+    const int a = (int)(i / n_cov), cov = (int)(i % n_cov);
+    const float expectedF = target_lod * (float)cov;
+    table[i] = a >= 1 ? incomplete_gamma_function((double)a, (double)expectedF) : -1.0;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -75,11 +75,13 @@ struct PiscesHip {
     int64_t ring_used = 0;
     DeviceBuf<unsigned long long> d_totals;
     DeviceBuf<double> d_qlut;
+    DeviceBuf<double> d_gq_tail;   // memo of the genotype-quality Poisson tail (DeviceParams::gq_tail)
     int n_cus = 256;
     DeviceBuf<int32_t> d_offsets;
     DeviceBuf<PiscesCalledAllele> d_compact;
-    int kernel_variant = 0;    // 0 = one workgroup per tile, 1 = persistent software-pipelined kernel
-    int pipeline_depth = 0;    // tiles per workgroup for variant 1 (0 = fill 4 workgroups per CU)
+    int kernel_variant = 4;    // 4 = auto (two waves per tile while every tile of the launch is resident at once, else one),
+                               // 2 = one wave per tile, 3 = two waves per tile, 0 = one 4-wave workgroup per tile
+    int lds_pad = 0;           // development: extra dynamic LDS per workgroup (occupancy experiments)
     std::string err;
 
     DeviceBuf<uint8_t> d_ref;
@@ -168,6 +170,9 @@ static DeviceParams make_params(const PiscesHipConfig& c)
     P.totals = nullptr;
     P.q_to_p_lut = nullptr;
     P.q_to_p_n = 0;
+    P.gq_tail = nullptr;
+    P.gq_tail_a = 0;
+    P.gq_tail_cov = 0;
     return P;
 }
 
@@ -251,10 +256,11 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cus = prop.multiProcessorCount;
         const char* kv = getenv("PISCES_HIP_KERNEL");   // development switch between the two forms of the hot kernel
-        if (kv && std::string(kv) == "pipelined") h->kernel_variant = 1;
+        if (kv && std::string(kv) == "wave") h->kernel_variant = 2;
+        if (kv && std::string(kv) == "wave2") h->kernel_variant = 3;
+        if (kv && std::string(kv) == "auto") h->kernel_variant = 4;
         if (kv && std::string(kv) == "block") h->kernel_variant = 0;
-        const char* pd = getenv("PISCES_HIP_DEPTH");
-        if (pd) h->pipeline_depth = atoi(pd);
+        if (const char* lp = getenv("PISCES_HIP_LDS_PAD")) h->lds_pad = atoi(lp);
     }
     {
         // MathOperations.QtoP(q) = Math.Pow(10, -1 * q / 10f) for every integer q-score the caller can produce
@@ -270,6 +276,25 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         h->P.q_to_p_lut = h->d_qlut.p;
         h->P.q_to_p_n = n;
     }
+    if (!getenv("PISCES_HIP_NO_GQ_TABLE")) {
+        // genotype-quality tail memo, evaluated on the device by the function it stands in for
+        const int32_t n_a = 32, n_cov = 8192;
+        if ((e = h->d_gq_tail.reserve((size_t)n_a * n_cov)) != hipSuccess) {
+            g_create_error = std::string("pisces_hip_create: ") + hipGetErrorString(e);
+            pisces_hip_destroy(h);
+            return PISCES_E_DEVICE;
+        }
+        hipLaunchKernelGGL(build_gq_tail_kernel, dim3((unsigned)((n_a * n_cov + 255) / 256)), dim3(256), 0, h->stream, h->d_gq_tail.p,
+                           n_a, n_cov, h->P.target_lod);
+        if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(h->stream)) != hipSuccess) {
+            g_create_error = std::string("pisces_hip_create: ") + hipGetErrorString(e);
+            pisces_hip_destroy(h);
+            return PISCES_E_DEVICE;
+        }
+        h->P.gq_tail = h->d_gq_tail.p;
+        h->P.gq_tail_a = n_a;
+        h->P.gq_tail_cov = n_cov;
+    }
     *out = h;
     return PISCES_OK;
 }
@@ -280,7 +305,7 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_ref.release(); h->d_tuples.release(); h->d_tiles.release(); h->d_tile_results.release();
-    h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release(); h->d_totals.release(); h->d_qlut.release(); h->d_offsets.release(); h->d_compact.release();
+    h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release(); h->d_totals.release(); h->d_qlut.release(); h->d_gq_tail.release(); h->d_offsets.release(); h->d_compact.release();
     h->d_cands.release(); h->d_alleles.release(); h->d_cand_records.release(); h->d_cand_callable.release();
     for (hipEvent_t ev : h->ring) (void)hipEventDestroy(ev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -543,17 +568,22 @@ static void launch_call_tiles(PiscesHip* h, hipStream_t s, const uint32_t* d_tup
                               const uint8_t* d_ref, int32_t ref_start, int64_t ref_len, PiscesCalledAllele* d_records,
                               PiscesTileResult* d_tr)
 {
-    if (h->kernel_variant == 1) {
-        // persistent software-pipelined form: 4 workgroups per CU walking tiles b, b+G, ...
-        int64_t grid = (int64_t)h->n_cus * 4;
-        if (h->pipeline_depth > 0) grid = ((int64_t)n_tiles + h->pipeline_depth - 1) / h->pipeline_depth;
-        grid = std::max<int64_t>(1, std::min<int64_t>(grid, n_tiles));
-        hipLaunchKernelGGL(call_tiles_pipelined_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, d_tuples, d_tiles, n_tiles, d_ref,
-                           ref_start, ref_len, d_records, d_tr, h->P);
+    if (h->kernel_variant >= 2 && h->cfg.min_base_call_quality <= 255) {   // the wave forms compare the quality byte in place
+        // Two waves per tile shorten the call phase (Reference / q-score work and the strand-bias statistics run side by
+        // side) and pay for it in registers (128 VGPRs for 8 tiles per CU).  That wins while the whole launch is
+        // resident at once and the call phase of the last tiles is exposed; beyond that tiles interleave on their own
+        // and one wave per tile (168 VGPRs, no spills) streams better.
+        const bool two = h->kernel_variant == 3 || (h->kernel_variant == 4 && (int64_t)n_tiles <= (int64_t)h->n_cus * 8);
+        if (!two)
+            hipLaunchKernelGGL(call_tiles_wave_kernel<1>, dim3((unsigned)n_tiles), dim3(64), (size_t)h->lds_pad, s, d_tuples, d_tiles,
+                               n_tiles, d_ref, ref_start, ref_len, d_records, d_tr, h->P);
+        else
+            hipLaunchKernelGGL(call_tiles_wave_kernel<2>, dim3((unsigned)n_tiles), dim3(128), (size_t)h->lds_pad, s, d_tuples, d_tiles,
+                               n_tiles, d_ref, ref_start, ref_len, d_records, d_tr, h->P);
         return;
     }
-    hipLaunchKernelGGL(call_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, d_tuples, d_tiles, n_tiles, d_ref, ref_start,
-                       ref_len, d_records, d_tr, h->P);
+    hipLaunchKernelGGL(call_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), (size_t)h->lds_pad, s, d_tuples, d_tiles, n_tiles, d_ref,
+                       ref_start, ref_len, d_records, d_tr, h->P);
 }
 
 // scan + gather: d_out = called alleles in (position, allele) order, *d_count = how many

@@ -88,6 +88,29 @@ def test_fused_kernel_matches_oracle_on_synthetic_pileups(torch_cuda, n_loci, de
     assert totals["records"] == 2 * len(exp) and totals["candidate_loci"] == 2 * nloci and totals["tiles"] == 2 * p.n_tiles
 
 
+@pytest.mark.parametrize("form", ["block", "wave", "wave2", "auto"])
+@pytest.mark.parametrize("kw", [
+    dict(n_loci=1500, depth=400, seed=11),                                     # BASELINE-like: one planted SNV per 100 loci
+    dict(n_loci=700, depth=250, seed=12, snv_every=3, snv_offset=1, vaf_range=(0.01, 0.9)),  # ~21 variant candidates per tile
+    dict(n_loci=500, depth=150, seed=13, base_error=0.09, snv_every=5, snv_offset=2),        # every error allele is a candidate: ~190 per tile
+])
+def test_every_form_of_the_hot_kernel_matches_oracle(torch_cuda, monkeypatch, form, kw):
+    """The three forms of the hot kernel (one 4-wave workgroup / one wave / two waves per tile; `auto` is the product
+    default) on pileups that exercise one, several and more-than-one-LDS-round of variant candidates per tile."""
+    from pisces_amd import engine, synth
+    torch = torch_cuda
+    monkeypatch.setenv("PISCES_HIP_KERNEL", form)
+    p = synth.make_pileup(device="cuda", **kw)
+    cfg = _abi.default_config()
+    with engine.HipVariantCaller(cfg) as caller:
+        got, tr = run_fused(torch, caller, p)
+    pos, tup = synth.observations_of(p)
+    exp, nloci = orc.run_observations(pos, tup, p.ref.cpu().numpy(), p.region_start, p.n_loci, cfg)
+    assert_records_match(got, exp)
+    assert int(tr["n_candidate_loci"].sum()) == nloci
+    assert int((_abi.info_category(got["info"]) == _abi.CAT_SNV).sum()) > 0
+
+
 @pytest.mark.parametrize("overrides", [
     dict(min_base_call_quality=30, noise_level=30, min_frequency=0.005, variant_freq_filter=0.005,
          genotype_min_freq_filter=0.005, target_lod_frequency=0.005),                       # BASELINE config 5 settings

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development: per-tile phase timing of call_tiles_kernel (needs the -DPISCES_TIMING build)."""
+"""Development: per-tile phase timing of the hot kernel (needs the -DPISCES_TIMING build)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -25,10 +25,28 @@ for name, v in (("start", t0), ("stream end", t1), ("call end", t2), ("stream du
 print("t(us)   streaming  calling")
 for g in np.arange(0, t2.max() + 1, 4.0):
     print(f"{g:6.0f} {int(((t0 <= g) & (t1 > g)).sum()):9d} {int(((t1 <= g) & (t2 > g)).sum()):8d}")
-r1, r2 = t0 < 5, t0 >= 5
-for name, m in (("round 1", r1), ("round 2", r2)):
-    if m.any():
-        print(f"{name}: n={int(m.sum())} stream dur p10/p50/p90: {np.round(np.percentile((t1 - t0)[m], [10, 50, 90]), 1)}  call dur p10/p50/p90: {np.round(np.percentile((t2 - t1)[m], [10, 50, 90]), 1)}")
+hw = t["n_called"].astype(np.int64) & 0xFFFFFFFF
+xcc = t["valid"][:, 0].astype(np.int64) & 0xF
+cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 7; simd = (hw >> 4) & 3
+cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+u, inv, cnt = np.unique(cuid, return_inverse=True, return_counts=True)
+print(f"distinct CUs used: {len(u)}; tiles per CU min/median/max: {cnt.min()} {int(np.median(cnt))} {cnt.max()}; XCC counts {np.bincount(xcc)}")
+print("tiles/CU histogram:", dict(zip(*np.unique(cnt, return_counts=True))))
+per = cnt[inv]
+for n in np.unique(per):
+    m = per == n
+    print(f"  tiles on CUs with {n} tiles: n={int(m.sum())} stream dur p50 {np.percentile((t1-t0)[m],50):.1f} p90 {np.percentile((t1-t0)[m],90):.1f}; call dur p50 {np.percentile((t2-t1)[m],50):.1f}")
+sid = cuid * 4 + simd
+us, invs, cnts = np.unique(sid, return_inverse=True, return_counts=True)
+pers = cnts[invs]
+for n in np.unique(pers):
+    m = pers == n
+    print(f"  tiles on SIMDs with {n} tile-waves(0): n={int(m.sum())} stream dur p50 {np.percentile((t1-t0)[m],50):.1f} p90 {np.percentile((t1-t0)[m],90):.1f}")
 v = t["valid"].astype(np.int64) / 100.0
-for i, name in enumerate(("wave0 reference lanes", "wait waves 1,2", "wait wave 1 assembly", "tail (masks, directory)")):
-    print(f"{name:26s} us p10/p50/p90/p99: {np.round(np.percentile(v[:, i], [10, 50, 90, 99]), 2)}")
+hasvar = v[:, 3] > 0.005
+print(f"tiles with variant work: {int(hasvar.sum())} of {nt}")
+for i, name in ((1, "pass mask"), (2, "Reference pass"), (3, "variant q-scores"), (4, "SB items + assembly"), (5, "directory")):
+    print(f"{name:22s} us p10/p50/p90/max  all: {np.round(np.percentile(v[:, i], [10, 50, 90, 100]), 2)}   variant tiles: {np.round(np.percentile(v[hasvar, i], [10, 50, 90, 100]), 2) if hasvar.any() else ''}")
+for i, name in ((6, "  scan + publish"), (7, "  SB items")):
+    print(f"{name:22s} us p10/p50/p90/max  variant tiles: {np.round(np.percentile(v[hasvar, i], [10, 50, 90, 100]), 2)}")
+print(f"{'  assembly':22s} us p10/p50/p90/max  variant tiles: {np.round(np.percentile((v[:,4]-v[:,6]-v[:,7])[hasvar], [10, 50, 90, 100]), 2)}")
