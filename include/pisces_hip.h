@@ -288,15 +288,16 @@ int32_t pisces_hip_accumulate_tiles(PiscesHip* h, const uint32_t* d_tuples, cons
  * Synchronizes the handle's stream; reset != 0 zeroes them afterwards.  This is the per-chromosome
  * summary a multi-GPU job all-reduces (SmallVariantCaller.cs:114-115 totals line). */
 int32_t pisces_hip_device_totals(PiscesHip* h, int64_t out[4], int32_t reset);
-/* Per-launch kernel timing with HIP events recorded on the launch stream around the kernel only.
- * enable != 0 starts a fresh measurement window (up to 4096 launches are kept). */
+/* Kernel timing with HIP events bound to the kernel's own dispatch on the launch stream (start and stop events of
+ * hipExtLaunchKernel).  Off by default.
+ * enable = n > 0 starts a fresh measurement window in which every n-th call_tiles / accumulate_tiles launch is timed
+ * (up to 4096 timed launches are kept); enable = 0 ends it. */
 int32_t pisces_hip_set_timing(PiscesHip* h, int32_t enable);
-/* Sum of the kernel durations (ms) and number of launches recorded since set_timing(1). Waits for them. */
+/* Sum of the timed kernel durations (ms) and number of timed launches since set_timing(n). Waits for them. */
 int32_t pisces_hip_kernel_time(PiscesHip* h, double* total_ms, int64_t* launches);
 /* waits for the handle's stream */
 int32_t pisces_hip_synchronize(PiscesHip* h);
-/* time of the last call_tiles / accumulate_tiles launch measured with HIP events on the
- * launch stream, in milliseconds (valid after synchronize) */
+/* duration of the most recent timed launch of the current window, in milliseconds (PISCES_E_STATE when timing is off) */
 int32_t pisces_hip_last_kernel_ms(PiscesHip* h, float* ms);
 
 /* ---- host-side helpers (pure CPU, no device needed) -------------------------- */

@@ -181,7 +181,13 @@ __device__ inline double mathnet_gamma_ln(double z)
     const double e = 2.7182818284590452354;
     // arguments here are call counts >= 1, so only the z >= 0.5 branch is reachable
     double s = dk[0];
+#if defined(PISCES_GAMMALN_UNROLL) && PISCES_GAMMALN_UNROLL == 1
+#pragma unroll 1
+#elif defined(PISCES_GAMMALN_UNROLL) && PISCES_GAMMALN_UNROLL == 2
+#pragma unroll 2
+#else
 #pragma unroll
+#endif
     for (int i = 1; i <= 10; i++) s += dk[i] / (z + i - 1.0);
     return log(s) + log_two_sqrt_e_over_pi + ((z - 0.5) * log((z - 0.5 + r) / e));
 }
@@ -347,7 +353,14 @@ __device__ __forceinline__ SbResult sb_combine(const SbStats& overall, const SbS
 
 __device__ inline SbResult strand_bias(const int32_t cov[3], const int32_t sup[3], const DeviceParams& P)
 {
-    const SbStats overall = sb_stats_of(0, cov, sup, P), fwd = sb_stats_of(1, cov, sup, P), rev = sb_stats_of(2, cov, sup, P);
+    // the three evaluations are independent; interleaving them costs ~3x the registers of one (scratch spills at the
+    // 128-VGPR forms of the kernel) and buys nothing on the usual early-out path, so keep them apart
+    const SbStats overall = sb_stats_of(0, cov, sup, P);
+    __builtin_amdgcn_sched_barrier(0);
+    const SbStats fwd = sb_stats_of(1, cov, sup, P);
+    __builtin_amdgcn_sched_barrier(0);
+    const SbStats rev = sb_stats_of(2, cov, sup, P);
+    __builtin_amdgcn_sched_barrier(0);
     return sb_combine(overall, fwd, rev, P);
 }
 
@@ -378,6 +391,13 @@ __device__ inline int32_t somatic_genotype(bool isReference, int32_t cov, int32_
     return PISCES_GT_HOM_REF;
 }
 
+// The memo miss path (coverage or count beyond the table, or no table): the same evaluation, kept out of line so that
+// its registers are not part of every caller's budget (it was the VGPR peak of the whole call phase).
+__device__ __noinline__ double poisson_cdf_out_of_line(double num_occurrences, double expected)
+{
+    return poisson_cdf(num_occurrences, expected);
+}
+
 // The Poisson tail of SomaticGenotypeQualityCalculator.cs:30-41 for a hom-ref / hom-alt call: a pure function of
 // (coverage, support, targetLODFrequency).  `skip` = the reference returns MinGenotypeQScore before using it.
 struct GqTail { double p2; bool used, floor; };
@@ -394,7 +414,7 @@ __device__ __forceinline__ GqTail somatic_gq_tail(int32_t genotype, int32_t cov,
         if (P.gq_tail && ai >= 1 && ai < P.gq_tail_a && cov < P.gq_tail_cov)
             t.p2 = P.gq_tail[(size_t)ai * (size_t)P.gq_tail_cov + (size_t)cov];
         else
-            t.p2 = poisson_cdf(nonAlleleObservationsF, expectedNonAllelObservationsF);
+            t.p2 = poisson_cdf_out_of_line(nonAlleleObservationsF, expectedNonAllelObservationsF);
     }
     return t;
 }

@@ -717,12 +717,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
 #endif
         // 2. variant q-scores (VariantQualityCalculator.Compute :11-24), one converged pass per allele rank in use
         if (any_variant) {
-            wave_lds_sync();   // the counts are re-read from LDS here rather than held in registers across the Reference pass
-            const LocusCounts lv = load_counts<HistWave>(hist, l);
 #pragma unroll 1
             for (int k = 0; k < 4; k++) {
                 if (!(pass_mask & (1u << k))) continue;
-                const PointCounts c = point_counts_of(lv, allele_of_rank(k), false, rt, 0);
+                const PointCounts c = point_counts<HistWave>(hist, l, allele_of_rank(k), false, rt, 0);   // re-read, not held
                 ws.vq[l * 4 + k] = (c.support > 0 && c.total != 0) ? poisson_qscore(c.support, c.total, P) : 0;
             }
         }
@@ -760,7 +758,6 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
             if (NW > 1) __syncthreads(); else wave_lds_sync();   // q-scores and strand-bias statistics meet
             if (sb_wave) {
                 // 4. IsCallable's last test, then filters / genotype / record of the callable variants, lane = locus
-                const LocusCounts la = load_counts<HistWave>(hist, l);   // re-read (after the fence above), not held
 #pragma unroll 1
                 for (int k = 0; k < 4; k++) {
                     if (!(pass_mask & (1u << k))) continue;
@@ -769,7 +766,8 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
                     const int vq = ws.vq[l * 4 + k];
                     if (vq < P.min_vq) continue;
                     const int a = allele_of_rank(k);
-                    const PointCounts c = point_counts_of(la, a, false, rt, 0);
+                    // counts re-read from LDS per candidate: 18 registers held across this loop were spilled at 128 VGPRs
+                    const PointCounts c = point_counts<HistWave>(hist, l, a, false, rt, 0);
                     SbStats ov, fw, rv;
                     ov.var_gt_zero = ws.sb_var[p][0]; ov.false_pos = ws.sb_fp[p][0];
                     fw.var_gt_zero = ws.sb_var[p][1]; fw.false_pos = ws.sb_fp[p][1];

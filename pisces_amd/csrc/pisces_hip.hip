@@ -3,6 +3,7 @@
 // (IStateManager.AddAlleleCounts / GetCandidatesToProcess / DoneProcessing around IAlleleCaller.Call,
 // src/exe/Pisces/Logic/SmallVariantCaller.cs:79-189).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -68,11 +69,11 @@ struct PiscesHip {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
     // per-launch timing window (pisces_hip_set_timing / pisces_hip_kernel_time)
     std::vector<hipEvent_t> ring;   // pairs: [2i] start, [2i+1] stop
-    bool timing = false;
+    int32_t timing = 0;        // 0 = off (no events are recorded), n > 0 = every n-th launch is bracketed by events
     int64_t ring_used = 0;
+    int64_t launches_seen = 0;
     DeviceBuf<unsigned long long> d_totals;
     DeviceBuf<double> d_qlut;
     DeviceBuf<double> d_gq_tail;   // memo of the genotype-quality Poisson tail (DeviceParams::gq_tail)
@@ -564,10 +565,13 @@ static void build_tiles(PiscesHip* h, const std::vector<int32_t>& keys, std::vec
 }
 
 // launches the fused tuples -> histogram -> call kernel on stream s
+// e0 / e1 (optional): HIP events bound to the dispatch itself (hipExtLaunchKernel): their timestamps are the kernel's own
+// start and end, not the arrival of separate marker packets before and after it.
 static void launch_call_tiles(PiscesHip* h, hipStream_t s, const uint32_t* d_tuples, const PiscesTile* d_tiles, int32_t n_tiles,
                               const uint8_t* d_ref, int32_t ref_start, int64_t ref_len, PiscesCalledAllele* d_records,
-                              PiscesTileResult* d_tr)
+                              PiscesTileResult* d_tr, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
 {
+    const uint32_t lds = (uint32_t)h->lds_pad;
     if (h->kernel_variant >= 2 && h->cfg.min_base_call_quality <= 255) {   // the wave forms compare the quality byte in place
         // Two waves per tile shorten the call phase (Reference / q-score work and the strand-bias statistics run side by
         // side) and pay for it in registers (128 VGPRs for 8 tiles per CU).  That wins while the whole launch is
@@ -575,15 +579,15 @@ static void launch_call_tiles(PiscesHip* h, hipStream_t s, const uint32_t* d_tup
         // and one wave per tile (168 VGPRs, no spills) streams better.
         const bool two = h->kernel_variant == 3 || (h->kernel_variant == 4 && (int64_t)n_tiles <= (int64_t)h->n_cus * 8);
         if (!two)
-            hipLaunchKernelGGL(call_tiles_wave_kernel<1>, dim3((unsigned)n_tiles), dim3(64), (size_t)h->lds_pad, s, d_tuples, d_tiles,
-                               n_tiles, d_ref, ref_start, ref_len, d_records, d_tr, h->P);
+            hipExtLaunchKernelGGL(call_tiles_wave_kernel<1>, dim3((unsigned)n_tiles), dim3(64), lds, s, e0, e1, 0u, d_tuples, d_tiles,
+                                  n_tiles, d_ref, ref_start, ref_len, d_records, d_tr, h->P);
         else
-            hipLaunchKernelGGL(call_tiles_wave_kernel<2>, dim3((unsigned)n_tiles), dim3(128), (size_t)h->lds_pad, s, d_tuples, d_tiles,
-                               n_tiles, d_ref, ref_start, ref_len, d_records, d_tr, h->P);
+            hipExtLaunchKernelGGL(call_tiles_wave_kernel<2>, dim3((unsigned)n_tiles), dim3(128), lds, s, e0, e1, 0u, d_tuples, d_tiles,
+                                  n_tiles, d_ref, ref_start, ref_len, d_records, d_tr, h->P);
         return;
     }
-    hipLaunchKernelGGL(call_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), (size_t)h->lds_pad, s, d_tuples, d_tiles, n_tiles, d_ref,
-                       ref_start, ref_len, d_records, d_tr, h->P);
+    hipExtLaunchKernelGGL(call_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), lds, s, e0, e1, 0u, d_tuples, d_tiles, n_tiles, d_ref,
+                          ref_start, ref_len, d_records, d_tr, h->P);
 }
 
 // scan + gather: d_out = called alleles in (position, allele) order, *d_count = how many
@@ -1005,19 +1009,22 @@ int32_t pisces_hip_call_tiles(PiscesHip* h, const uint32_t* d_tuples, const Pisc
         return fail(h, PISCES_E_BUFFER_TOO_SMALL, "call_tiles: the slot layout needs record_capacity >= 256 * n_tiles");
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-    hipEvent_t e0 = h->ev0, e1 = h->ev1;
-    if (h->timing) {
+    // events only when asked for (pisces_hip_set_timing): an event record is a queue packet of its own, and two of them
+    // per launch cost a few microseconds between back-to-back launches
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->timing > 0 && (h->launches_seen++ % h->timing) == 0) {
         const size_t slot = (size_t)(h->ring_used % kTimingRing);
         e0 = h->ring[2 * slot];
         e1 = h->ring[2 * slot + 1];
         h->ring_used++;
     }
-    PISCES_HIP_CHECK(h, hipEventRecord(e0, s));
-    if (n_tiles > 0)
-        launch_call_tiles(h, s, d_tuples, d_tiles, n_tiles, d_ref_bases, ref_start_position, ref_length, d_records, d_tile_results);
-    PISCES_HIP_CHECK(h, hipEventRecord(e1, s));
+    if (n_tiles > 0) {
+        launch_call_tiles(h, s, d_tuples, d_tiles, n_tiles, d_ref_bases, ref_start_position, ref_length, d_records, d_tile_results, e0, e1);
+    } else if (e0) {
+        PISCES_HIP_CHECK(h, hipEventRecord(e0, s));
+        PISCES_HIP_CHECK(h, hipEventRecord(e1, s));
+    }
     PISCES_HIP_CHECK(h, hipGetLastError());
-    h->timed = true;
     return PISCES_OK;
 }
 
@@ -1048,13 +1055,21 @@ int32_t pisces_hip_accumulate_tiles(PiscesHip* h, const uint32_t* d_tuples, cons
     if (n_tiles > 0 && (!d_tiles || !d_counts)) return fail(h, PISCES_E_INVALID_ARG, "accumulate_tiles: null device pointer");
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-    PISCES_HIP_CHECK(h, hipEventRecord(h->ev0, s));
-    if (n_tiles > 0)
-        hipLaunchKernelGGL(accumulate_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, d_tuples, d_tiles, n_tiles, d_counts,
-                           h->cfg.min_base_call_quality);
-    PISCES_HIP_CHECK(h, hipEventRecord(h->ev1, s));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->timing > 0 && (h->launches_seen++ % h->timing) == 0) {
+        const size_t slot = (size_t)(h->ring_used % kTimingRing);
+        e0 = h->ring[2 * slot];
+        e1 = h->ring[2 * slot + 1];
+        h->ring_used++;
+    }
+    if (n_tiles > 0) {
+        hipExtLaunchKernelGGL(accumulate_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0u, s, e0, e1, 0u, d_tuples, d_tiles, n_tiles,
+                              d_counts, h->cfg.min_base_call_quality);
+    } else if (e0) {
+        PISCES_HIP_CHECK(h, hipEventRecord(e0, s));
+        PISCES_HIP_CHECK(h, hipEventRecord(e1, s));
+    }
     PISCES_HIP_CHECK(h, hipGetLastError());
-    h->timed = true;
     return PISCES_OK;
 }
 
@@ -1081,8 +1096,9 @@ int32_t pisces_hip_set_timing(PiscesHip* h, int32_t enable)
         h->ring.resize((size_t)(2 * kTimingRing), nullptr);
         for (auto& ev : h->ring) PISCES_HIP_CHECK(h, hipEventCreate(&ev));
     }
-    h->timing = enable != 0;
+    h->timing = enable > 0 ? enable : 0;
     h->ring_used = 0;
+    h->launches_seen = 0;
     return PISCES_OK;
 }
 
@@ -1114,10 +1130,12 @@ int32_t pisces_hip_synchronize(PiscesHip* h)
 int32_t pisces_hip_last_kernel_ms(PiscesHip* h, float* ms)
 {
     if (!h || !ms) return PISCES_E_INVALID_ARG;
-    if (!h->timed || h->timing) return fail(h, PISCES_E_STATE, "last_kernel_ms: no timed launch yet (or a timing window is open: use kernel_time)");
+    if (h->timing <= 0 || h->ring_used == 0)
+        return fail(h, PISCES_E_STATE, "last_kernel_ms: no timed launch (pisces_hip_set_timing first)");
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
-    PISCES_HIP_CHECK(h, hipEventSynchronize(h->ev1));
-    PISCES_HIP_CHECK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    const size_t slot = (size_t)((h->ring_used - 1) % kTimingRing);
+    PISCES_HIP_CHECK(h, hipEventSynchronize(h->ring[2 * slot + 1]));
+    PISCES_HIP_CHECK(h, hipEventElapsedTime(ms, h->ring[2 * slot], h->ring[2 * slot + 1]));
     return PISCES_OK;
 }
 

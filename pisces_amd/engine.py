@@ -189,7 +189,8 @@ class HipVariantCaller:
         return {"records": s[0], "candidate_loci": s[1], "called": s[2], "tiles": s[3]}
 
     def set_timing(self, enable=True):
-        _check(self._h, lib.pisces_hip_set_timing(self._h, 1 if enable else 0))
+        """enable = True / n > 0: time every launch / every n-th launch with HIP events; False / 0: off (default)."""
+        _check(self._h, lib.pisces_hip_set_timing(self._h, int(enable)))
 
     def kernel_time(self):
         """(total_ms, launches) of the kernels launched since set_timing(True), from HIP events on the launch stream."""

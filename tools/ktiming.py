@@ -11,6 +11,7 @@ nt = p.n_tiles; cap = nt * 256
 rec = torch.zeros(cap * 64, dtype=torch.uint8, device=dev)
 tr = torch.zeros(nt * 48, dtype=torch.uint8, device=dev)
 with engine.HipVariantCaller(_abi.default_config()) as c:
+    c.set_timing(True)
     for _ in range(3):
         c.call_tiles(p.tuples.data_ptr(), p.tiles.data_ptr(), nt, p.ref.data_ptr(), 1, p.ref_len, rec.data_ptr(), cap, tr.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
