@@ -648,7 +648,13 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
     const bool in_ref = l < tile.n_loci && refb != 0;
     const int rt = in_ref ? allele_type_of_base(refb) : PISCES_ALLELE_N;
     const int64_t win_lo = (int64_t)ref_start - 1, win_hi = win_lo + ref_len;
-    PiscesCalledAllele* const slots = records + (int64_t)t * kSlotsPerTile + l * 4;
+    // The record slot address is formed where it is used, from an opaque copy of the lane number: as one per-lane pointer
+    // it is live from here to the last store and was the register allocator's first pick for a scratch spill.
+    auto slot_of = [&](int k) {
+        int lf = l;
+        asm volatile("" : "+v"(lf));
+        return records + ((int64_t)t * kSlotsPerTile + lf * 4 + k);
+    };
 
     // the locus' 18 folded counts, once, into registers
     const LocusCounts lc = load_counts<HistWave>(hist, l);
@@ -707,7 +713,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
                 ref_rank = (rt < 4) ? rank_of_allele(rt) : 0;
                 PiscesCalledAllele rec;
                 (void)process_point_allele(ref_c, pos, ref_a, true, rt, ref, win_lo, win_hi, P, rec, s_refwin, kRefMargin + l, &ref_tail);
-                copy_record(&slots[ref_rank], &rec);
+                copy_record(slot_of(ref_rank), &rec);
                 ref_emitted = true;
             }
         }
@@ -779,7 +785,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
                     const SbResult sb = sb_combine(ov, fw, rv, P);
                     PiscesCalledAllele r;
                     finish_allele(c, pos, a, false, rt, vq, sb, ref, win_lo, win_hi, P, r, s_refwin, kRefMargin + l);
-                    copy_record(&slots[k], &r);
+                    copy_record(slot_of(k), &r);
                     vmask |= 1u << k;
                 }
             }
