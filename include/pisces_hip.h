@@ -295,6 +295,9 @@ int32_t pisces_hip_device_totals(PiscesHip* h, int64_t out[4], int32_t reset);
 int32_t pisces_hip_set_timing(PiscesHip* h, int32_t enable);
 /* Sum of the timed kernel durations (ms) and number of timed launches since set_timing(n). Waits for them. */
 int32_t pisces_hip_kernel_time(PiscesHip* h, double* total_ms, int64_t* launches);
+/* Streaming-read bandwidth of the handle's device, GB/s: best of `reps` timed passes of a kernel that only reads `nbytes`
+ * with the hot kernel's load pattern.  Reported beside the spec peak in bench.py; allocates and frees nbytes. */
+int32_t pisces_hip_probe_read_bandwidth(PiscesHip* h, int64_t nbytes, int32_t reps, double* gb_per_s);
 /* waits for the handle's stream */
 int32_t pisces_hip_synchronize(PiscesHip* h);
 /* duration of the most recent timed launch of the current window, in milliseconds (PISCES_E_STATE when timing is off) */

@@ -1453,3 +1453,36 @@ void orc_default_config(PiscesHipConfig* c)
     c->rmxn_min_repetitions = 9;
     c->rmxn_frequency_limit = 0.35f;
 }
+
+
+/* ---- interval shards on host threads: the -threadbychr analogue of the reference (one job thread per chromosome,
+ * BaseGenomeProcessor.cs:49-71, JobManager.cs:70-73), used only as bench.py's threaded CPU baseline ---- */
+#include <pthread.h>
+
+static void* orc_shard_main(void* arg)
+{
+    OrcShardJob* j = (OrcShardJob*)arg;
+    j->n_out = 0;
+    j->n_loci = 0;
+    for (int32_t p = 0; p < j->passes; p++) {
+        int64_t nl = 0;
+        int64_t n = orc_run_reads(j->batch, j->ref_bases, j->ref_len, j->region_start, j->region_loci, j->cfg, j->out, j->capacity, &nl);
+        if (n < 0) { j->n_out = n; return NULL; }
+        j->n_out = n;
+        j->n_loci += nl;
+    }
+    return NULL;
+}
+
+int32_t orc_run_reads_sharded(OrcShardJob* jobs, int32_t n_jobs)
+{
+    pthread_t* th = (pthread_t*)calloc((size_t)(n_jobs > 0 ? n_jobs : 1), sizeof(pthread_t));
+    int32_t started = 0, rc = 0;
+    for (; started < n_jobs; started++)
+        if (pthread_create(&th[started], NULL, orc_shard_main, &jobs[started]) != 0) { rc = -1; break; }
+    for (int32_t i = 0; i < started; i++) pthread_join(th[i], NULL);
+    free(th);
+    for (int32_t i = 0; i < n_jobs && rc == 0; i++)
+        if (jobs[i].n_out < 0) rc = -2;
+    return rc;
+}

@@ -154,6 +154,22 @@ int64_t orc_run_observations(const int32_t* positions, const uint32_t* tuples, i
                       const PiscesHipConfig* cfg, PiscesCalledAllele* out, int64_t capacity,
                       int64_t* n_candidate_loci);
 
+/* interval shards, one host thread each (bench.py's threaded CPU baseline); every job has its own output buffer */
+typedef struct OrcShardJob {
+    const PiscesReadBatch* batch;
+    const uint8_t* ref_bases;
+    int64_t ref_len;
+    int32_t region_start, region_loci;
+    const PiscesHipConfig* cfg;
+    PiscesCalledAllele* out;
+    int64_t capacity;
+    int32_t passes;
+    int32_t pad;
+    int64_t n_out;    /* records of the last pass, or < 0 on error */
+    int64_t n_loci;   /* candidate loci summed over the passes */
+} OrcShardJob;
+int32_t orc_run_reads_sharded(OrcShardJob* jobs, int32_t n_jobs);
+
 void orc_default_config(PiscesHipConfig* cfg);
 
 #ifdef __cplusplus

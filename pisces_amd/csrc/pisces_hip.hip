@@ -1119,6 +1119,30 @@ int32_t pisces_hip_kernel_time(PiscesHip* h, double* total_ms, int64_t* launches
     return PISCES_OK;
 }
 
+int32_t pisces_hip_probe_read_bandwidth(PiscesHip* h, int64_t nbytes, int32_t reps, double* gb_per_s)
+{
+    if (!h || !gb_per_s || nbytes < (1 << 20) || reps < 1) return fail(h, PISCES_E_INVALID_ARG, "probe_read_bandwidth: bad arguments");
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    DeviceBuf<uint32_t> buf;
+    PISCES_HIP_CHECK(h, buf.reserve((size_t)(nbytes / 4) + 4));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(buf.p, 0x5A, (size_t)nbytes, h->stream));
+    const int64_t n4 = nbytes / 16;
+    const unsigned grid = (unsigned)std::min<int64_t>((n4 + 2047) / 2048, (int64_t)h->n_cus * 32);
+    hipLaunchKernelGGL(read_probe_kernel, dim3(grid), dim3(256), 0, h->stream, (const u32x4*)buf.p, n4, buf.p + nbytes / 4);   // warm-up
+    double best = 0.0;
+    for (int r = 0; r < reps; r++) {
+        hipExtLaunchKernelGGL(read_probe_kernel, dim3(grid), dim3(256), 0u, h->stream, h->ev0, h->ev1, 0u, (const u32x4*)buf.p, n4,
+                              buf.p + nbytes / 4);
+        PISCES_HIP_CHECK(h, hipEventSynchronize(h->ev1));
+        float ms = 0.f;
+        PISCES_HIP_CHECK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        if (ms > 0.f) best = std::max(best, (double)nbytes / ((double)ms * 1e-3) / 1e9);
+    }
+    buf.release();
+    *gb_per_s = best;
+    return PISCES_OK;
+}
+
 int32_t pisces_hip_synchronize(PiscesHip* h)
 {
     if (!h) return PISCES_E_INVALID_ARG;

@@ -198,6 +198,12 @@ class HipVariantCaller:
         _check(self._h, lib.pisces_hip_kernel_time(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def probe_read_bandwidth(self, nbytes=1 << 30, reps=6):
+        """GB/s of a plain streaming read on this device (context for the roofline fraction)."""
+        g = C.c_double(0)
+        _check(self._h, lib.pisces_hip_probe_read_bandwidth(self._h, nbytes, reps, C.byref(g)))
+        return g.value
+
     def synchronize(self):
         _check(self._h, lib.pisces_hip_synchronize(self._h))
 

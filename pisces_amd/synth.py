@@ -141,19 +141,21 @@ def make_pileup(n_loci, depth, seed=20260928, device="cpu", p_lowq=0.02, base_er
                   n_tiles=n_tiles, n_obs=n_obs, base=base, qual=qual, planted=planted)
 
 
-def reads_of(p, n_amplicons=None):
-    """ReadBatch of the first `n_amplicons` amplicons (all of them when None): one <len>M read per row."""
+def reads_of(p, n_amplicons=None, first_amplicon=0):
+    """ReadBatch of `n_amplicons` amplicons starting at `first_amplicon` (all of them when None): one <len>M read per row."""
     A = p.base.shape[0]
-    n_amp = A if n_amplicons is None else min(A, n_amplicons)
+    first_amplicon = min(first_amplicon, A)
+    n_amp = A - first_amplicon if n_amplicons is None else min(A - first_amplicon, n_amplicons)
     _, lens = _amplicon_lengths(p.n_loci)
-    base = p.base[:n_amp].cpu().numpy()
-    qual = p.qual[:n_amp].cpu().numpy()
+    lens = lens[first_amplicon:]
+    base = p.base[first_amplicon:first_amplicon + n_amp].cpu().numpy()
+    qual = p.qual[first_amplicon:first_amplicon + n_amp].cpu().numpy()
     depth = p.depth
     pos, flags, cig_len, seq_off = [], [], [], [0]
     bases, quals = [], []
     for a in range(n_amp):
         L = lens[a]
-        pos.append(np.full(depth, p.region_start + a * READ_LEN, dtype=np.int32))
+        pos.append(np.full(depth, p.region_start + (first_amplicon + a) * READ_LEN, dtype=np.int32))
         flags.append((np.arange(depth) % 2).astype(np.uint8))
         cig_len.append(np.full(depth, L, dtype=np.uint32))
         bases.append(_BASE_ASCII[base[a, :, :L]].reshape(-1))

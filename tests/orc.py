@@ -81,6 +81,13 @@ class OrcCalled(C.Structure):
     ]
 
 
+class OrcShardJob(C.Structure):
+    _fields_ = [("batch", C.POINTER(_abi.PiscesReadBatch)), ("ref_bases", C.POINTER(C.c_uint8)), ("ref_len", C.c_int64),
+                ("region_start", C.c_int32), ("region_loci", C.c_int32), ("cfg", C.POINTER(_abi.PiscesHipConfig)),
+                ("out", C.c_void_p), ("capacity", C.c_int64), ("passes", C.c_int32), ("pad", C.c_int32),
+                ("n_out", C.c_int64), ("n_loci", C.c_int64)]
+
+
 def _load():
     so = os.path.join(ROOT, "oracle", "libpiscesoracle.so")
     src = os.path.join(ROOT, "oracle", "pisces_oracle.c")
@@ -128,6 +135,7 @@ def _load():
         "orc_run_observations": (i64, [P(i32), P(C.c_uint32), i64, P(C.c_uint8), i64, i32, i32,
                                        P(_abi.PiscesHipConfig), C.c_void_p, i64, P(i64)]),
         "orc_default_config": (None, [P(_abi.PiscesHipConfig)]),
+        "orc_run_reads_sharded": (i32, [P(OrcShardJob), i32]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -304,3 +312,24 @@ def run_reads_full(batch, ref, region_start, region_loci, cfg):
                                region_loci, C.byref(cfg), out.ctypes.data, cap, C.byref(nloci), full, C.byref(total))
     assert n >= 0, n
     return out[:n], [(full[i].ref.decode(), full[i].alt.decode()) for i in range(n)], nloci.value, total.value
+
+
+def run_reads_sharded(shards, ref, cfg, passes=1):
+    """shards: list of (ReadBatch, region_start, region_loci); one host thread per shard inside the oracle library.
+    Returns (list of record arrays in shard order, candidate loci summed over shards and passes)."""
+    refa = np.ascontiguousarray(ref, np.uint8)
+    jobs = (OrcShardJob * len(shards))()
+    outs = []
+    for j, (b, start, loci) in zip(jobs, shards):
+        cap = loci * 5 + 16
+        out = np.zeros(cap, dtype=_abi.CALLED_ALLELE_DTYPE)
+        outs.append(out)
+        j.batch = C.pointer(b.c)
+        j.ref_bases = refa.ctypes.data_as(C.POINTER(C.c_uint8))
+        j.ref_len = len(refa)
+        j.region_start, j.region_loci = start, loci
+        j.cfg = C.pointer(cfg)
+        j.out, j.capacity, j.passes = out.ctypes.data, cap, passes
+    rc = lib.orc_run_reads_sharded(jobs, len(shards))
+    assert rc == 0, rc
+    return [o[: j.n_out].copy() for o, j in zip(outs, jobs)], int(sum(j.n_loci for j in jobs))

@@ -142,3 +142,19 @@ def test_indel_finder_matches_oracle_finder():
                             "open_left": bool(c.open_left), "open_right": bool(c.open_right)})
     assert len(exp) > 100
     assert got == exp
+
+
+def test_interval_shards_concatenate_to_the_whole():
+    """loci shard by interval with no exchange — the oracle over amplicon shards, concatenated in shard order,
+    is the oracle over the whole region (what bench.py's threaded CPU baseline and the multi-GPU host rely on)."""
+    from pisces_amd import synth
+    p = synth.make_pileup(900, 30, seed=3)
+    cfg = _abi.default_config()
+    ref = p.ref.cpu().numpy()
+    whole, n = orc.run_reads(synth.reads_of(p), ref, p.region_start, p.n_loci, cfg)
+    parts = []
+    for a0 in range(0, 6, 2):
+        b = synth.reads_of(p, 2, first_amplicon=a0)
+        r, _ = orc.run_reads(b, ref, p.region_start + a0 * synth.READ_LEN, 2 * synth.READ_LEN, cfg)
+        parts.append(r)
+    assert n == 900 and np.concatenate(parts).tobytes() == whole.tobytes()
