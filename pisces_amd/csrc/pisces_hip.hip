@@ -19,6 +19,7 @@
 #include "expander.h"
 #include "finder.h"
 #include "kernels.hip.h"
+#include "stream_kernels.hip.h"
 
 using namespace pisces;
 
@@ -28,9 +29,7 @@ namespace {
 
 constexpr int64_t kTimingRing = 4096;
 
-struct BlockObs {
-    std::vector<int32_t> pos;
-    std::vector<uint32_t> tup;
+struct BlockObs {   // the block's observations live in the device log (PiscesHip::d_log_*)
     // insertion / deletion candidates of the block (RegionState._candidateVariantsLookup), merged by
     // CandidateAllele.Equals (position, category, ref, alt) — the collapse-off rule of RegionState.AddCandidate
     std::vector<HostCandidate> cands;
@@ -51,6 +50,24 @@ struct DeviceBuf {
         size_t want = n + n / 4 + 64;
         hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
         if (e == hipSuccess) cap = want;
+        return e;
+    }
+    // grow keeping the first n_keep elements (device-to-device copy on `stream`)
+    hipError_t grow_keep(size_t n, size_t n_keep, hipStream_t stream)
+    {
+        if (n <= cap) return hipSuccess;
+        T* old = p;
+        size_t want = n + n / 2 + 1024;
+        T* fresh = nullptr;
+        hipError_t e = hipMalloc((void**)&fresh, want * sizeof(T));
+        if (e != hipSuccess) return e;
+        if (old && n_keep > 0) {
+            e = hipMemcpyAsync(fresh, old, std::min(n_keep, cap) * sizeof(T), hipMemcpyDeviceToDevice, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        }
+        if (old) (void)hipFree(old);
+        p = fresh;
+        cap = want;
         return e;
     }
     void release()
@@ -110,6 +127,21 @@ struct PiscesHip {
     std::vector<HostCandidate> pending_cands;       // called insertion / deletion candidates (their allele strings)
     std::vector<int32_t> pending_keys;
     int64_t pending_called = 0;
+
+    // observation log on the device: (position, tuple) of every allele-count increment of the blocks not yet flushed,
+    // appended by expand_reads_kernel / pisces_hip_add_observations, bucketed by tile at flush time
+    DeviceBuf<int32_t> d_log_pos[2];
+    DeviceBuf<uint32_t> d_log_tup[2];
+    int log_cur = 0;
+    DeviceBuf<unsigned long long> d_log_n;   // [0], [1]: entries in log 0 / 1; [2]: entries ever appended
+    int64_t log_ub = 0;                      // host upper bound of the entries in the current log
+    DeviceBuf<int32_t> d_flags;              // [0] log overflow
+    DeviceBuf<uint8_t> d_stage;              // device copy of the packed read batch
+    uint8_t* h_stage = nullptr;              // pinned staging buffer
+    size_t h_stage_cap = 0;
+    DeviceBuf<int32_t> d_bucket;             // BucketMap tables
+    DeviceBuf<unsigned int> d_tile_cnt;
+    DeviceBuf<long long> d_total;
 
     // device scratch, grow-only
     DeviceBuf<uint32_t> d_tuples;
@@ -277,6 +309,13 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         h->P.q_to_p_lut = h->d_qlut.p;
         h->P.q_to_p_n = n;
     }
+    if ((e = h->d_log_n.reserve(4)) != hipSuccess || (e = h->d_flags.reserve(4)) != hipSuccess ||
+        (e = hipMemset(h->d_log_n.p, 0, 4 * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMemset(h->d_flags.p, 0, 4 * sizeof(int32_t))) != hipSuccess) {
+        g_create_error = std::string("pisces_hip_create: ") + hipGetErrorString(e);
+        pisces_hip_destroy(h);
+        return PISCES_E_DEVICE;
+    }
     if (!getenv("PISCES_HIP_NO_GQ_TABLE")) {
         // genotype-quality tail memo, evaluated on the device by the function it stands in for
         const int32_t n_a = 32, n_cov = 8192;
@@ -307,6 +346,10 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_ref.release(); h->d_tuples.release(); h->d_tiles.release(); h->d_tile_results.release();
     h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release(); h->d_totals.release(); h->d_qlut.release(); h->d_gq_tail.release(); h->d_offsets.release(); h->d_compact.release();
+    for (int i = 0; i < 2; i++) { h->d_log_pos[i].release(); h->d_log_tup[i].release(); }
+    h->d_log_n.release(); h->d_flags.release(); h->d_stage.release(); h->d_bucket.release(); h->d_tile_cnt.release(); h->d_total.release();
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
+    h->h_stage = nullptr;
     h->d_cands.release(); h->d_alleles.release(); h->d_cand_records.release(); h->d_cand_callable.release();
     for (hipEvent_t ev : h->ring) (void)hipEventDestroy(ev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -362,6 +405,50 @@ static inline BlockObs* get_block(PiscesHip* h, int32_t position)
     return b;
 }
 
+// room for `extra` more log entries (the log keeps its content when it grows)
+static int32_t log_reserve(PiscesHip* h, int64_t extra)
+{
+    const size_t need = (size_t)(h->log_ub + extra);
+    const int c = h->log_cur;
+    PISCES_HIP_CHECK(h, h->d_log_pos[c].grow_keep(need, (size_t)h->log_ub, h->stream));
+    PISCES_HIP_CHECK(h, h->d_log_tup[c].grow_keep(need, (size_t)h->log_ub, h->stream));
+    return PISCES_OK;
+}
+
+static int32_t stage_reserve(PiscesHip* h, size_t bytes)
+{
+    if (bytes > h->h_stage_cap) {
+        if (h->h_stage) (void)hipHostFree(h->h_stage);
+        h->h_stage = nullptr;
+        h->h_stage_cap = 0;
+        const size_t want = bytes + bytes / 2 + 4096;
+        PISCES_HIP_CHECK(h, hipHostMalloc((void**)&h->h_stage, want, hipHostMallocDefault));
+        h->h_stage_cap = want;
+    }
+    PISCES_HIP_CHECK(h, h->d_stage.reserve(bytes));
+    return PISCES_OK;
+}
+
+namespace pisces {
+// host-expanded observations: copied behind the current end of the log (which no other kernel moves meanwhile: launches of
+// one handle are stream-ordered), then the end is moved by log_bump_kernel
+__global__ __launch_bounds__(256) void log_append_kernel(const int32_t* __restrict__ src_pos, const uint32_t* __restrict__ src_tup, int64_t n,
+                                                         int32_t* __restrict__ log_pos, uint32_t* __restrict__ log_tup,
+                                                         const unsigned long long* __restrict__ log_n)
+{
+    const unsigned long long base = *log_n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        log_pos[base + (unsigned long long)i] = src_pos[i];
+        log_tup[base + (unsigned long long)i] = src_tup[i] & ~0x7FFFu;
+    }
+}
+__global__ void log_bump_kernel(unsigned long long* __restrict__ log_n, unsigned long long* __restrict__ appended, int64_t n)
+{
+    *log_n += (unsigned long long)n;
+    *appended += (unsigned long long)n;
+}
+}  // namespace pisces
+
 int32_t pisces_hip_add_observations(PiscesHip* h, const int32_t* positions, const uint32_t* tuples, int64_t n)
 {
     if (!h) return PISCES_E_INVALID_ARG;
@@ -369,21 +456,29 @@ int32_t pisces_hip_add_observations(PiscesHip* h, const int32_t* positions, cons
     for (int64_t i = 0; i < n; i++)
         if (positions[i] <= 0) return fail(h, PISCES_E_INVALID_ARG, "Position must be greater than 0.");  // RegionStateManager.cs:363-364
     h->pending_valid = false;
-    for (int64_t i = 0; i < n; i++) {
-        BlockObs* b = get_block(h, positions[i]);
-        b->pos.push_back(positions[i]);
-        b->tup.push_back(tuples[i] & ~0x7FFFu);
-    }
-    h->stats[3] += n;
+    if (n == 0) return PISCES_OK;
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    for (int64_t i = 0; i < n; i++) (void)get_block(h, positions[i]);
+    int32_t rc = log_reserve(h, n);
+    if (rc) return rc;
+    const size_t bytes = (size_t)n * 8;
+    rc = stage_reserve(h, bytes);
+    if (rc) return rc;
+    std::memcpy(h->h_stage, positions, (size_t)n * 4);
+    std::memcpy(h->h_stage + (size_t)n * 4, tuples, (size_t)n * 4);
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_stage.p, h->h_stage, bytes, hipMemcpyHostToDevice, h->stream));
+    const int c = h->log_cur;
+    hipLaunchKernelGGL(log_append_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, h->stream,
+                       (const int32_t*)h->d_stage.p, (const uint32_t*)(h->d_stage.p + (size_t)n * 4), n, h->d_log_pos[c].p, h->d_log_tup[c].p,
+                       h->d_log_n.p + c);
+    hipLaunchKernelGGL(log_bump_kernel, dim3(1), dim3(1), 0, h->stream, h->d_log_n.p + c, h->d_log_n.p + 2, n);
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // the pinned staging buffer is reused by the next call
+    h->log_ub += n;
     return PISCES_OK;
 }
 
 namespace {
-struct BlockSink : ObservationSink {
-    PiscesHip* h;
-    std::vector<std::pair<int32_t, uint32_t>> staged;   // one read is committed atomically
-    void emit(int32_t position, uint32_t tuple) override { staged.emplace_back(position, tuple); }
-};
 struct ArraySink : ObservationSink {
     int32_t* positions;
     uint32_t* tuples;
@@ -410,19 +505,43 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
     if (!h) return PISCES_E_INVALID_ARG;
     if (validate_batch(batch) != PISCES_OK) return fail(h, PISCES_E_INVALID_ARG, "add_reads: malformed read batch");
     h->pending_valid = false;
-    BlockSink sink;
-    sink.h = h;
+    if (batch->n_reads == 0) return PISCES_OK;
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    const int32_t nr = batch->n_reads;
+    const int32_t minBQ = h->cfg.min_base_call_quality;
+    // ---- host pass over the CIGARs only (never over the bases): argument checks of the reference's walk, the insertion /
+    // deletion candidates, the blocks the read touches, and an upper bound of its observations ----
+    auto op_ref = [](uint8_t t) { return t == 'M' || t == 'D' || t == 'N' || t == '=' || t == 'X'; };
+    auto op_read = [](uint8_t t) { return t == 'M' || t == 'I' || t == 'S' || t == '=' || t == 'X'; };
     std::vector<HostCandidate> found;
-    for (int32_t i = 0; i < batch->n_reads; i++) {
+    int64_t ub = 0;
+    for (int32_t i = 0; i < nr; i++) {
         ReadView r = read_view(batch, i);
         if (r.position <= 0) return fail(h, PISCES_E_INVALID_ARG, "Position must be greater than 0.");
+        if (r.read_len < 0 || r.n_cigar < 0) return fail(h, PISCES_E_INVALID_ARG, "add_reads: malformed read batch");
+        int64_t read_span = 0, ref_span = 0;
+        bool has_indel = false;
+        for (int c = 0; c < r.n_cigar; c++) {
+            const uint8_t t = r.cigar_op[c];
+            if (op_read(t)) read_span += r.cigar_len[c];
+            if (op_ref(t)) ref_span += r.cigar_len[c];
+            has_indel |= (t == 'I' || t == 'D');
+        }
+        if (read_span > r.read_len) return fail(h, PISCES_E_INVALID_ARG, "add_reads: CIGAR does not match the read");
+        if (r.dirs)
+            for (int k = 0; k < r.read_len; k++)
+                if (r.dirs[k] > 2) return fail(h, PISCES_E_INVALID_ARG, "add_reads: CIGAR does not match the read");
+        ub += (int64_t)r.read_len + ref_span;
+    }
+    for (int32_t i = 0; i < nr; i++) {
+        ReadView r = read_view(batch, i);
         // ICandidateVariantFinder.FindCandidates + IStateManager.AddCandidates (SmallVariantCaller.cs:92-96) for the
         // candidates the device counts do not imply: insertions and deletions
         bool has_indel = false;
         for (int c = 0; c < r.n_cigar; c++) has_indel |= (r.cigar_op[c] == 'I' || r.cigar_op[c] == 'D');
         if (has_indel && !h->h_ref.empty()) {   // without a reference only the IStateManager half (allele counts) runs
             found.clear();
-            find_indel_candidates(r, h->h_ref.data(), h->ref_len, h->cfg.min_base_call_quality, PISCES_ANCHOR_SIZE, found);
+            find_indel_candidates(r, h->h_ref.data(), h->ref_len, minBQ, PISCES_ANCHOR_SIZE, found);
             for (auto& cnd : found) {
                 if (cnd.position <= 0) continue;
                 BlockObs* b = get_block(h, cnd.position);
@@ -443,20 +562,86 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
                 if (other_end > b->max_allele_endpoint) b->max_allele_endpoint = other_end;
             }
         }
-        sink.staged.clear();
-        int32_t rc = expand_read(r, h->cfg.min_base_call_quality, sink);
-        if (rc == PISCES_E_UNMAPPED_BASE)
-            return fail(h, rc, "Base position does not appear to be mapped in read.");  // RegionStateManager.cs:109-113
-        if (rc != PISCES_OK) return fail(h, rc, "add_reads: CIGAR does not match the read");
-        for (auto& pt : sink.staged) {
-            if (pt.first <= 0) continue;
-            BlockObs* b = get_block(h, pt.first);
-            b->pos.push_back(pt.first);
-            b->tup.push_back(pt.second);
+        // GetBlock(position) for every position that receives a count (RegionStateManager.cs:361-383): the runs of mapped
+        // bases always do; a gap (deletion / skip) does when its flanking qualities pass CheckDeletionQuality
+        {
+            auto touch = [&](int64_t from, int64_t to) {   // inclusive
+                if (to < 1) return;
+                if (from < 1) from = 1;
+                for (int32_t k = block_key(h, (int32_t)from); k <= block_key(h, (int32_t)to); k++) (void)get_block(h, (k - 1) * h->cfg.block_size + 1);
+            };
+            auto delq = [&](int idx) {
+                if (r.read_len == 0) return false;
+                const int after = idx < r.read_len ? r.quals[idx] : r.quals[idx - 1];
+                const int before = idx > 0 ? r.quals[idx - 1] : after;
+                return before >= minBQ && after >= minBQ;
+            };
+            int64_t rp = r.position, last_mapped = (int64_t)r.position - 1;
+            int ri = 0;
+            for (int c = 0; c < r.n_cigar; c++) {
+                const uint8_t t = r.cigar_op[c];
+                const int64_t len = r.cigar_len[c];
+                if (op_read(t) && op_ref(t) && len > 0) {
+                    if (rp > last_mapped + 1 && ri < r.read_len && delq(ri)) touch(last_mapped + 1, rp - 1);
+                    touch(rp, rp + len - 1);
+                    last_mapped = rp + len - 1;
+                }
+                if (op_ref(t)) rp += len;
+                if (op_read(t)) ri += (int)len;
+            }
+            const int nc = r.n_cigar;
+            const bool ends_del = nc >= 1 && r.cigar_op[nc - 1] == 'D';
+            const bool ends_del_soft = nc >= 2 && r.cigar_op[nc - 2] == 'D' && r.cigar_op[nc - 1] == 'S';
+            if (ends_del && r.read_len > 0 && delq(r.read_len - 1)) touch(last_mapped + 1, last_mapped + r.cigar_len[nc - 1]);
+            if (ends_del_soft) {
+                const int idx = r.read_len - (int)r.cigar_len[nc - 1];
+                if (idx >= 0 && idx < r.read_len && delq(idx)) touch(last_mapped + 1, last_mapped + r.cigar_len[nc - 2]);
+            }
         }
         h->stats[2] += 1;
-        h->stats[3] += (int64_t)sink.staged.size();
     }
+
+    // ---- the read batch crosses PCIe once, packed; the walk runs on the device (expand_reads_kernel) ----
+    const size_t n_cig = (size_t)batch->cigar_offset[nr], n_seq = (size_t)batch->seq_offset[nr];
+    auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    size_t off_pos = 0, off_flags = align16(off_pos + (size_t)nr * 4), off_coff = align16(off_flags + (size_t)nr),
+           off_cop = align16(off_coff + ((size_t)nr + 1) * 4), off_clen = align16(off_cop + n_cig),
+           off_soff = align16(off_clen + n_cig * 4), off_bases = align16(off_soff + ((size_t)nr + 1) * 4),
+           off_quals = align16(off_bases + n_seq), off_dirs = align16(off_quals + n_seq),
+           total = align16(off_dirs + (batch->directions ? n_seq : 0));
+    int32_t rc = stage_reserve(h, total);
+    if (rc) return rc;
+    rc = log_reserve(h, ub);
+    if (rc) return rc;
+    uint8_t* st = h->h_stage;
+    std::memcpy(st + off_pos, batch->position, (size_t)nr * 4);
+    std::memcpy(st + off_flags, batch->flags, (size_t)nr);
+    std::memcpy(st + off_coff, batch->cigar_offset, ((size_t)nr + 1) * 4);
+    std::memcpy(st + off_cop, batch->cigar_op, n_cig);
+    std::memcpy(st + off_clen, batch->cigar_len, n_cig * 4);
+    std::memcpy(st + off_soff, batch->seq_offset, ((size_t)nr + 1) * 4);
+    std::memcpy(st + off_bases, batch->bases, n_seq);
+    std::memcpy(st + off_quals, batch->quals, n_seq);
+    if (batch->directions) std::memcpy(st + off_dirs, batch->directions, n_seq);
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_stage.p, st, total, hipMemcpyHostToDevice, h->stream));
+    DevReadBatch db;
+    const uint8_t* d = h->d_stage.p;
+    db.position = (const int32_t*)(d + off_pos);
+    db.flags = d + off_flags;
+    db.cigar_offset = (const int32_t*)(d + off_coff);
+    db.cigar_op = d + off_cop;
+    db.cigar_len = (const uint32_t*)(d + off_clen);
+    db.seq_offset = (const int32_t*)(d + off_soff);
+    db.bases = d + off_bases;
+    db.quals = d + off_quals;
+    db.dirs = batch->directions ? d + off_dirs : nullptr;
+    db.n_reads = nr;
+    const int c = h->log_cur;
+    hipLaunchKernelGGL(expand_reads_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, h->stream, db, minBQ, h->d_log_pos[c].p,
+                       h->d_log_tup[c].p, h->d_log_n.p + c, (unsigned long long)h->d_log_pos[c].cap, h->d_flags.p, h->d_log_n.p + 2);
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // the pinned staging buffer is reused by the next call
+    h->log_ub += ub;
     return PISCES_OK;
 }
 
@@ -509,59 +694,132 @@ int64_t pisces_hip_find_indel_candidates(const PiscesReadBatch* batch, const uin
 // Builds tiles + tile-bucketed tuples for a set of blocks. Tiles follow the 1000-locus block grid
 // (clipped to the interval set when one is given); every tile's tuple segment is padded to a
 // multiple of 4 tuples so the kernel's 16-byte loads start aligned.
-static void build_tiles(PiscesHip* h, const std::vector<int32_t>& keys, std::vector<PiscesTile>& tiles,
-                        std::vector<uint32_t>& tuples)
+// Tile geometry of the blocks `keys` (ascending): the 64-locus grid of each block, clipped to the interval set when `clip`
+// (ChrIntervalSet.GetClipped).  tile_of_locus (per key, block_size entries, relative to the key's first tile) is filled only
+// when the grid is irregular, i.e. when intervals clip it.
+static void tile_geometry(PiscesHip* h, const std::vector<int32_t>& keys, bool clip, std::vector<PiscesTile>& tiles,
+                          std::vector<int32_t>& first_tile, std::vector<int32_t>& tol)
 {
     tiles.clear();
-    tuples.clear();
+    first_tile.clear();
+    tol.clear();
     const int bs = h->cfg.block_size;
-    std::vector<int32_t> tile_of_locus;   // per block: locus -> tile index (or -1)
-    std::vector<int64_t> fill;
-    for (int32_t key : keys) {
-        const BlockObs& b = h->blocks[key];
+    const bool irregular = clip && !h->intervals.empty();
+    if (irregular) tol.assign(keys.size() * (size_t)bs, -1);
+    for (size_t ki = 0; ki < keys.size(); ki++) {
+        const int32_t key = keys[ki];
         const int32_t bstart = (key - 1) * bs + 1, bend = key * bs;
-        const size_t first_tile = tiles.size();
-        tile_of_locus.assign((size_t)bs, -1);
+        const size_t first = tiles.size();
+        first_tile.push_back((int32_t)first);
         auto add_range = [&](int32_t s, int32_t e) {   // inclusive, inside the block
             for (int32_t p = s; p <= e; p += kTile) {
                 PiscesTile t;
                 t.start_position = p;
                 t.n_loci = std::min<int32_t>(kTile, e - p + 1);
                 t.tuple_begin = t.tuple_end = 0;
-                for (int32_t q = 0; q < t.n_loci; q++) tile_of_locus[(size_t)(p + q - bstart)] = (int32_t)tiles.size();
+                if (irregular)
+                    for (int32_t q = 0; q < t.n_loci; q++) tol[ki * (size_t)bs + (size_t)(p + q - bstart)] = (int32_t)(tiles.size() - first);
                 tiles.push_back(t);
             }
         };
-        if (h->intervals.empty()) add_range(bstart, bend);
+        if (!irregular) add_range(bstart, bend);
         else
-            for (auto& iv : h->intervals) {   // ChrIntervalSet.GetClipped(block)
+            for (auto& iv : h->intervals) {
                 int32_t s = std::max(iv.first, bstart), e = std::min(iv.second, bend);
                 if (s <= e) add_range(s, e);
             }
-        // counting sort of the block's observations by tile
-        const size_t nt = tiles.size() - first_tile;
-        if (nt == 0) continue;
-        std::vector<int64_t> cnt(nt, 0);
-        for (size_t i = 0; i < b.pos.size(); i++) {
-            int32_t ti = tile_of_locus[(size_t)(b.pos[i] - bstart)];
-            if (ti >= 0) cnt[(size_t)ti - first_tile]++;
-        }
-        fill.assign(nt, 0);
-        int64_t cursor = (int64_t)tuples.size();
-        for (size_t t = 0; t < nt; t++) {
-            tiles[first_tile + t].tuple_begin = cursor;
-            tiles[first_tile + t].tuple_end = cursor + cnt[t];
-            fill[t] = cursor;
-            cursor += (cnt[t] + 3) & ~(int64_t)3;
-        }
-        tuples.resize((size_t)cursor, PISCES_TUPLE_PAD);
-        for (size_t i = 0; i < b.pos.size(); i++) {
-            int32_t ti = tile_of_locus[(size_t)(b.pos[i] - bstart)];
-            if (ti < 0) continue;
-            uint32_t locus = (uint32_t)(b.pos[i] - tiles[(size_t)ti].start_position);
-            tuples[(size_t)fill[(size_t)ti - first_tile]++] = (b.tup[i] & ~0x7FFFu) | locus;
-        }
     }
+}
+
+// uploads the BucketMap tables of `keys` and returns the device view
+static int32_t upload_bucket_map(PiscesHip* h, const std::vector<int32_t>& keys, const std::vector<int32_t>& first_tile,
+                                 const std::vector<int32_t>& tol, BucketMap* m)
+{
+    const int32_t kmin = keys.front(), kmax = keys.back();
+    const size_t n_slot = (size_t)(kmax - kmin + 1);
+    std::vector<int32_t> host(n_slot + keys.size() + tol.size(), -1);
+    for (size_t i = 0; i < keys.size(); i++) host[(size_t)(keys[i] - kmin)] = (int32_t)i;
+    std::copy(first_tile.begin(), first_tile.end(), host.begin() + (std::ptrdiff_t)n_slot);
+    std::copy(tol.begin(), tol.end(), host.begin() + (std::ptrdiff_t)(n_slot + keys.size()));
+    PISCES_HIP_CHECK(h, h->d_bucket.reserve(host.size()));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_bucket.p, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // `host` goes out of scope
+    m->key_slot = h->d_bucket.p;
+    m->first_tile = h->d_bucket.p + n_slot;
+    m->tile_of_locus = tol.empty() ? nullptr : h->d_bucket.p + n_slot + keys.size();
+    m->key_min = kmin;
+    m->key_max = kmax;
+    m->block_size = h->cfg.block_size;
+    return PISCES_OK;
+}
+
+static unsigned log_grid(const PiscesHip* h)
+{
+    const int64_t waves = (h->log_ub + 63) / 64;
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>((waves + 3) / 4, (int64_t)h->n_cus * 16));
+}
+
+// The observations of the blocks `keys`, bucketed by tile into h->d_tuples with the segments in h->d_tiles (device side of
+// what a counting sort on the host used to do).  The log itself is left as it is.  `tiles` receives the geometry.
+static int32_t bucket_blocks(PiscesHip* h, const std::vector<int32_t>& keys, bool clip, std::vector<PiscesTile>& tiles)
+{
+    std::vector<int32_t> first_tile, tol;
+    tile_geometry(h, keys, clip, tiles, first_tile, tol);
+    if (tiles.empty()) return PISCES_OK;
+    const int32_t n_tiles = (int32_t)tiles.size();
+    BucketMap m;
+    int32_t rc = upload_bucket_map(h, keys, first_tile, tol, &m);
+    if (rc) return rc;
+    PISCES_HIP_CHECK(h, h->d_tiles.reserve(tiles.size()));
+    PISCES_HIP_CHECK(h, h->d_tile_results.reserve(tiles.size()));
+    PISCES_HIP_CHECK(h, h->d_count.reserve(4));
+    PISCES_HIP_CHECK(h, h->d_tile_cnt.reserve(tiles.size()));
+    PISCES_HIP_CHECK(h, h->d_total.reserve(2));
+    const size_t tup_ub = (size_t)h->log_ub + 3 * tiles.size() + 4;
+    PISCES_HIP_CHECK(h, h->d_tuples.reserve(tup_ub));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_tiles.p, tiles.data(), tiles.size() * sizeof(PiscesTile), hipMemcpyHostToDevice, h->stream));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_tile_cnt.p, 0, tiles.size() * sizeof(unsigned int), h->stream));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_tuples.p, 0xFF, tup_ub * sizeof(uint32_t), h->stream));   // PISCES_TUPLE_PAD in the padding
+    const int c = h->log_cur;
+    if (h->log_ub > 0) {
+        hipLaunchKernelGGL(bucket_count_kernel, dim3(log_grid(h)), dim3(256), 0, h->stream, h->d_log_pos[c].p, h->d_log_n.p + c, m,
+                           h->d_tile_cnt.p);
+    }
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_tiles.p, n_tiles, h->d_tile_cnt.p, h->d_total.p);
+    if (h->log_ub > 0) {
+        hipLaunchKernelGGL(bucket_scatter_kernel, dim3(log_grid(h)), dim3(256), 0, h->stream, h->d_log_pos[c].p, h->d_log_tup[c].p,
+                           h->d_log_n.p + c, m, h->d_tiles.p, h->d_tile_cnt.p, h->d_tuples.p);
+    }
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    // the map tables (h->d_bucket) are reused by the next bucketing: finish before returning
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    return PISCES_OK;
+}
+
+// DoneProcessing for the observation log: the entries of `keys` leave, the rest moves to the other log buffer
+static int32_t drop_blocks(PiscesHip* h, const std::vector<int32_t>& keys)
+{
+    if (keys.empty() || h->log_ub == 0) return PISCES_OK;
+    std::vector<int32_t> first_tile(keys.size(), 0), tol;
+    BucketMap m;
+    int32_t rc = upload_bucket_map(h, keys, first_tile, tol, &m);
+    if (rc) return rc;
+    const int c = h->log_cur, o = c ^ 1;
+    PISCES_HIP_CHECK(h, h->d_log_pos[o].reserve((size_t)h->log_ub));
+    PISCES_HIP_CHECK(h, h->d_log_tup[o].reserve((size_t)h->log_ub));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_log_n.p + o, 0, sizeof(unsigned long long), h->stream));
+    hipLaunchKernelGGL(log_drop_kernel, dim3(log_grid(h)), dim3(256), 0, h->stream, h->d_log_pos[c].p, h->d_log_tup[c].p, h->d_log_n.p + c, m,
+                       h->d_log_pos[o].p, h->d_log_tup[o].p, h->d_log_n.p + o);
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    unsigned long long kept = 0;
+    int32_t flags[1] = {0};
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(&kept, h->d_log_n.p + o, sizeof(kept), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(flags, h->d_flags.p, sizeof(flags), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    if (flags[0]) return fail(h, PISCES_E_DEVICE, "observation log overflow (internal sizing error)");
+    h->log_cur = o;
+    h->log_ub = (int64_t)kept;
+    return PISCES_OK;
 }
 
 // launches the fused tuples -> histogram -> call kernel on stream s
@@ -598,18 +856,6 @@ static void launch_compaction(hipStream_t s, const PiscesCalledAllele* d_records
     hipLaunchKernelGGL(gather_records_kernel, dim3((unsigned)n_tiles), dim3(64), 0, s, d_records, d_tr, n_tiles, d_offsets, d_out, cap);
 }
 
-static int32_t upload_tiles(PiscesHip* h, const std::vector<PiscesTile>& tiles, const std::vector<uint32_t>& tuples)
-{
-    PISCES_HIP_CHECK(h, h->d_tiles.reserve(tiles.size()));
-    PISCES_HIP_CHECK(h, h->d_tuples.reserve(std::max<size_t>(tuples.size(), 4)));
-    PISCES_HIP_CHECK(h, h->d_tile_results.reserve(tiles.size()));
-    PISCES_HIP_CHECK(h, h->d_count.reserve(4));
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_tiles.p, tiles.data(), tiles.size() * sizeof(PiscesTile), hipMemcpyHostToDevice, h->stream));
-    if (!tuples.empty())
-        PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_tuples.p, tuples.data(), tuples.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-    return PISCES_OK;
-}
-
 // device work of one flush: returns called alleles of `keys` sorted by (position, ref, alt)
 static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::vector<PiscesCalledAllele>& out, int64_t* n_called)
 {
@@ -618,12 +864,10 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
     if (keys.empty()) return PISCES_OK;
     if (!h->d_ref.p) return fail(h, PISCES_E_STATE, "flush: set_reference has not been called");
     std::vector<PiscesTile> tiles;
-    std::vector<uint32_t> tuples;
-    build_tiles(h, keys, tiles, tuples);
+    int32_t rc = bucket_blocks(h, keys, true, tiles);
+    if (rc) return rc;
     if (tiles.empty()) return PISCES_OK;
     const int32_t n_tiles = (int32_t)tiles.size();
-    int32_t rc = upload_tiles(h, tiles, tuples);
-    if (rc) return rc;
     const size_t cap = (size_t)n_tiles * kSlotsPerTile;   // slot layout: 256 slots per tile
     PISCES_HIP_CHECK(h, h->d_records.reserve(cap));
     PISCES_HIP_CHECK(h, h->d_compact.reserve(cap));
@@ -701,12 +945,11 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, std
     std::sort(bkeys.begin(), bkeys.end());
     bkeys.erase(std::unique(bkeys.begin(), bkeys.end()), bkeys.end());
     // counts over the whole block grid of those blocks (not the interval-clipped tiles)
-    auto saved = h->intervals;
-    h->intervals.clear();
     std::vector<PiscesTile> tiles;
-    std::vector<uint32_t> tuples;
-    build_tiles(h, bkeys, tiles, tuples);
-    h->intervals = saved;
+    if (!bkeys.empty()) {
+        int32_t rcb = bucket_blocks(h, bkeys, false, tiles);
+        if (rcb) return rcb;
+    }
     const int32_t n_tiles = (int32_t)tiles.size();
     const int tiles_per_block = (bs + kTile - 1) / kTile;
     auto locus_index = [&](int32_t p) -> int64_t {
@@ -719,8 +962,6 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, std
         return (bi * tiles_per_block + off / kTile) * kTile + off % kTile;
     };
     if (n_tiles > 0) {
-        int32_t rc = upload_tiles(h, tiles, tuples);
-        if (rc) return rc;
         const size_t nc = (size_t)n_tiles * kTile * PISCES_COUNTS_PER_LOCUS;
         PISCES_HIP_CHECK(h, h->d_counts.reserve(nc));
         PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_counts.p, 0, nc * sizeof(int32_t), h->stream));
@@ -878,6 +1119,10 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
     }
     *n_out = (int64_t)h->pending.size();
     // DoneProcessing (RegionStateManager.cs:336-353)
+    {
+        int32_t rcd = drop_blocks(h, h->pending_keys);
+        if (rcd) return rcd;
+    }
     for (int32_t key : h->pending_keys) {
         h->blocks.erase(key);
         const int32_t bstart = (key - 1) * h->cfg.block_size + 1, bend = key * h->cfg.block_size;
@@ -913,15 +1158,10 @@ int32_t pisces_hip_get_counts(PiscesHip* h, int32_t start_position, int32_t n, i
         if (h->blocks.count(k)) keys.push_back(k);
     if (keys.empty()) return PISCES_OK;
     // counts are served over the whole block grid, not the interval-clipped tiles
-    auto saved = h->intervals;
-    h->intervals.clear();
     std::vector<PiscesTile> tiles;
-    std::vector<uint32_t> tuples;
-    build_tiles(h, keys, tiles, tuples);
-    h->intervals = saved;
-    const int32_t n_tiles = (int32_t)tiles.size();
-    int32_t rc = upload_tiles(h, tiles, tuples);
+    int32_t rc = bucket_blocks(h, keys, false, tiles);
     if (rc) return rc;
+    const int32_t n_tiles = (int32_t)tiles.size();
     const size_t nc = (size_t)n_tiles * kTile * PISCES_COUNTS_PER_LOCUS;
     PISCES_HIP_CHECK(h, h->d_counts.reserve(nc));
     PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_counts.p, 0, nc * sizeof(int32_t), h->stream));
@@ -991,6 +1231,11 @@ int32_t pisces_hip_stats(PiscesHip* h, int64_t out[4])
 {
     if (!h || !out) return PISCES_E_INVALID_ARG;
     for (int i = 0; i < 4; i++) out[i] = h->stats[i];
+    unsigned long long appended = 0;   // observations: counted where they are made, on the device
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpy(&appended, h->d_log_n.p + 2, sizeof(appended), hipMemcpyDeviceToHost));
+    out[3] = (int64_t)appended;
     return PISCES_OK;
 }
 

@@ -434,3 +434,44 @@ def test_spanning_alleles_hold_their_block(torch_cuda):
     got = np.concatenate([out2, rest])
     assert_records_match(got, exp)
     assert al2 + al3 == exp_alleles
+
+
+def test_device_read_walk_matches_oracle_on_random_cigars(torch_cuda):
+    """SURVEY 8 row f1: pisces_hip_add_reads walks the reads ON THE DEVICE (expand_reads_kernel) into the observation log;
+    the anchor-resolved counts it serves (IAlleleSource.GetAlleleCount over pisces_hip_get_counts) must equal the oracle's
+    AddAlleleCounts (RegionStateManager.cs:118-220) for arbitrary CIGARs: insertions, deletions, soft clips at either end,
+    terminal deletions, N bases, low qualities, stitched per-base directions, reads longer than one wave."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(23)
+    reads = []
+    for i in range(600):
+        ops = []
+        for _ in range(int(rng.integers(1, 7))):
+            ops.append((str(rng.choice(list("MMMIDSN"))), int(rng.integers(1, 40 if i % 7 == 0 else 12))))
+        ops = [(o, l) for k, (o, l) in enumerate(ops) if o != "S" or k in (0, len(ops) - 1)]
+        if not any(o == "M" for o, _ in ops):
+            ops.append(("M", 5))
+        if i % 11 == 0:
+            ops.append(("D", int(rng.integers(1, 6))))          # read ends in a deletion
+        if i % 13 == 0:
+            ops += [("D", int(rng.integers(1, 6))), ("S", int(rng.integers(1, 5)))]   # ... before a soft clip
+        rl = sum(l for o, l in ops if o in "MIS")
+        rd = {"pos": int(rng.integers(940, 1150)), "cigar": ops,
+              "seq": "".join(rng.choice(list("ACGTN"), rl, p=[.24, .24, .24, .24, .04])),
+              "quals": rng.choice([10, 25, 37], rl, p=[.15, .2, .65]).astype(np.uint8).tolist(),
+              "reverse": bool(rng.integers(0, 2))}
+        if i % 5 == 0:
+            rd["dirs"] = rng.integers(0, 3, rl).astype(np.uint8).tolist()
+        reads.append(rd)
+    st = orc.State(900, 2200, min_bq=20)
+    for d in reads:
+        assert st.add_allele_counts(orc.make_read(d["pos"], d["seq"], cigar=d["cigar"], quals=d["quals"], reverse=d["reverse"],
+                                                  dirs=d.get("dirs"))) == 0
+    with engine.HipVariantCaller(_abi.default_config()) as c:
+        for k in range(0, len(reads), 97):                        # several add_reads calls: the log grows and keeps its content
+            c.AddAlleleCounts(_abi.ReadBatch(reads[k:k + 97]))
+        got = c.GetCounts(900, 2200)
+        n_obs = c.Stats()["observations"]
+    exp = st.counts()
+    np.testing.assert_array_equal(got.reshape(exp.shape), exp)
+    assert n_obs == int(exp.sum())
