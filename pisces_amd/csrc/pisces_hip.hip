@@ -133,13 +133,15 @@ struct PiscesHip {
     DeviceBuf<int32_t> d_log_pos[2];
     DeviceBuf<uint32_t> d_log_tup[2];
     int log_cur = 0;
-    DeviceBuf<unsigned long long> d_log_n;   // [0], [1]: entries in log 0 / 1; [2]: entries ever appended
-    int64_t log_ub = 0;                      // host upper bound of the entries in the current log
+    DeviceBuf<unsigned long long> d_log_n;   // [0], [1]: entries kept by the last drop into log 0 / 1; [2]: observations ever made
+    int64_t log_ub = 0;                      // entries of the current log, holes included (slots are reserved on the host)
+    std::vector<long long> read_slots;
     DeviceBuf<int32_t> d_flags;              // [0] log overflow
     DeviceBuf<uint8_t> d_stage;              // device copy of the packed read batch
     uint8_t* h_stage = nullptr;              // pinned staging buffer
     size_t h_stage_cap = 0;
     DeviceBuf<int32_t> d_bucket;             // BucketMap tables
+    std::vector<int32_t> bucket_host;
     DeviceBuf<unsigned int> d_tile_cnt;
     DeviceBuf<long long> d_total;
 
@@ -430,22 +432,16 @@ static int32_t stage_reserve(PiscesHip* h, size_t bytes)
 }
 
 namespace pisces {
-// host-expanded observations: copied behind the current end of the log (which no other kernel moves meanwhile: launches of
-// one handle are stream-ordered), then the end is moved by log_bump_kernel
+// host-expanded observations: copied behind the current end of the log (its size is host-known: slots are reserved on the host)
 __global__ __launch_bounds__(256) void log_append_kernel(const int32_t* __restrict__ src_pos, const uint32_t* __restrict__ src_tup, int64_t n,
-                                                         int32_t* __restrict__ log_pos, uint32_t* __restrict__ log_tup,
-                                                         const unsigned long long* __restrict__ log_n)
+                                                         int32_t* __restrict__ log_pos, uint32_t* __restrict__ log_tup, long long base,
+                                                         unsigned long long* __restrict__ appended)
 {
-    const unsigned long long base = *log_n;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        log_pos[base + (unsigned long long)i] = src_pos[i];
-        log_tup[base + (unsigned long long)i] = src_tup[i] & ~0x7FFFu;
+        log_pos[base + i] = src_pos[i];
+        log_tup[base + i] = src_tup[i] & ~0x7FFFu;
     }
-}
-__global__ void log_bump_kernel(unsigned long long* __restrict__ log_n, unsigned long long* __restrict__ appended, int64_t n)
-{
-    *log_n += (unsigned long long)n;
-    *appended += (unsigned long long)n;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(appended, (unsigned long long)n);
 }
 }  // namespace pisces
 
@@ -470,8 +466,7 @@ int32_t pisces_hip_add_observations(PiscesHip* h, const int32_t* positions, cons
     const int c = h->log_cur;
     hipLaunchKernelGGL(log_append_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, h->stream,
                        (const int32_t*)h->d_stage.p, (const uint32_t*)(h->d_stage.p + (size_t)n * 4), n, h->d_log_pos[c].p, h->d_log_tup[c].p,
-                       h->d_log_n.p + c);
-    hipLaunchKernelGGL(log_bump_kernel, dim3(1), dim3(1), 0, h->stream, h->d_log_n.p + c, h->d_log_n.p + 2, n);
+                       (long long)h->log_ub, h->d_log_n.p + 2);
     PISCES_HIP_CHECK(h, hipGetLastError());
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // the pinned staging buffer is reused by the next call
     h->log_ub += n;
@@ -515,24 +510,26 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
     auto op_read = [](uint8_t t) { return t == 'M' || t == 'I' || t == 'S' || t == '=' || t == 'X'; };
     std::vector<HostCandidate> found;
     int64_t ub = 0;
+    std::vector<long long>& slots = h->read_slots;   // log slots reserved per read: [slots[i], slots[i + 1])
+    slots.resize((size_t)nr + 1);
     for (int32_t i = 0; i < nr; i++) {
         ReadView r = read_view(batch, i);
+        slots[(size_t)i] = (long long)(h->log_ub + ub);
         if (r.position <= 0) return fail(h, PISCES_E_INVALID_ARG, "Position must be greater than 0.");
         if (r.read_len < 0 || r.n_cigar < 0) return fail(h, PISCES_E_INVALID_ARG, "add_reads: malformed read batch");
         int64_t read_span = 0, ref_span = 0;
-        bool has_indel = false;
         for (int c = 0; c < r.n_cigar; c++) {
             const uint8_t t = r.cigar_op[c];
             if (op_read(t)) read_span += r.cigar_len[c];
-            if (op_ref(t)) ref_span += r.cigar_len[c];
-            has_indel |= (t == 'I' || t == 'D');
+            if (op_ref(t)) ref_span += r.cigar_len[c];   // mapped bases + every gap: one observation each at most
         }
         if (read_span > r.read_len) return fail(h, PISCES_E_INVALID_ARG, "add_reads: CIGAR does not match the read");
         if (r.dirs)
             for (int k = 0; k < r.read_len; k++)
                 if (r.dirs[k] > 2) return fail(h, PISCES_E_INVALID_ARG, "add_reads: CIGAR does not match the read");
-        ub += (int64_t)r.read_len + ref_span;
+        ub += ref_span;
     }
+    slots[(size_t)nr] = (long long)(h->log_ub + ub);
     for (int32_t i = 0; i < nr; i++) {
         ReadView r = read_view(batch, i);
         // ICandidateVariantFinder.FindCandidates + IStateManager.AddCandidates (SmallVariantCaller.cs:92-96) for the
@@ -608,7 +605,7 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
            off_cop = align16(off_coff + ((size_t)nr + 1) * 4), off_clen = align16(off_cop + n_cig),
            off_soff = align16(off_clen + n_cig * 4), off_bases = align16(off_soff + ((size_t)nr + 1) * 4),
            off_quals = align16(off_bases + n_seq), off_dirs = align16(off_quals + n_seq),
-           total = align16(off_dirs + (batch->directions ? n_seq : 0));
+           off_slots = align16(off_dirs + (batch->directions ? n_seq : 0)), total = align16(off_slots + ((size_t)nr + 1) * 8);
     int32_t rc = stage_reserve(h, total);
     if (rc) return rc;
     rc = log_reserve(h, ub);
@@ -623,6 +620,7 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
     std::memcpy(st + off_bases, batch->bases, n_seq);
     std::memcpy(st + off_quals, batch->quals, n_seq);
     if (batch->directions) std::memcpy(st + off_dirs, batch->directions, n_seq);
+    std::memcpy(st + off_slots, slots.data(), ((size_t)nr + 1) * 8);
     PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_stage.p, st, total, hipMemcpyHostToDevice, h->stream));
     DevReadBatch db;
     const uint8_t* d = h->d_stage.p;
@@ -637,8 +635,8 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
     db.dirs = batch->directions ? d + off_dirs : nullptr;
     db.n_reads = nr;
     const int c = h->log_cur;
-    hipLaunchKernelGGL(expand_reads_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, h->stream, db, minBQ, h->d_log_pos[c].p,
-                       h->d_log_tup[c].p, h->d_log_n.p + c, (unsigned long long)h->d_log_pos[c].cap, h->d_flags.p, h->d_log_n.p + 2);
+    hipLaunchKernelGGL(expand_reads_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, h->stream, db, (const long long*)(d + off_slots),
+                       minBQ, h->d_log_pos[c].p, h->d_log_tup[c].p, h->d_log_n.p + 2);
     PISCES_HIP_CHECK(h, hipGetLastError());
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // the pinned staging buffer is reused by the next call
     h->log_ub += ub;
@@ -737,13 +735,14 @@ static int32_t upload_bucket_map(PiscesHip* h, const std::vector<int32_t>& keys,
 {
     const int32_t kmin = keys.front(), kmax = keys.back();
     const size_t n_slot = (size_t)(kmax - kmin + 1);
-    std::vector<int32_t> host(n_slot + keys.size() + tol.size(), -1);
+    std::vector<int32_t>& host = h->bucket_host;   // member: alive until the copy below has been consumed
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // ... and not rewritten while an earlier copy is still in flight
+    host.assign(n_slot + keys.size() + tol.size(), -1);
     for (size_t i = 0; i < keys.size(); i++) host[(size_t)(keys[i] - kmin)] = (int32_t)i;
     std::copy(first_tile.begin(), first_tile.end(), host.begin() + (std::ptrdiff_t)n_slot);
     std::copy(tol.begin(), tol.end(), host.begin() + (std::ptrdiff_t)(n_slot + keys.size()));
     PISCES_HIP_CHECK(h, h->d_bucket.reserve(host.size()));
     PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_bucket.p, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // `host` goes out of scope
     m->key_slot = h->d_bucket.p;
     m->first_tile = h->d_bucket.p + n_slot;
     m->tile_of_locus = tol.empty() ? nullptr : h->d_bucket.p + n_slot + keys.size();
@@ -753,11 +752,7 @@ static int32_t upload_bucket_map(PiscesHip* h, const std::vector<int32_t>& keys,
     return PISCES_OK;
 }
 
-static unsigned log_grid(const PiscesHip* h)
-{
-    const int64_t waves = (h->log_ub + 63) / 64;
-    return (unsigned)std::max<int64_t>(1, std::min<int64_t>((waves + 3) / 4, (int64_t)h->n_cus * 16));
-}
+static unsigned log_grid(const PiscesHip* h) { return (unsigned)std::max<int64_t>(1, (h->log_ub + kLogChunk - 1) / kLogChunk); }
 
 // The observations of the blocks `keys`, bucketed by tile into h->d_tuples with the segments in h->d_tiles (device side of
 // what a counting sort on the host used to do).  The log itself is left as it is.  `tiles` receives the geometry.
@@ -782,18 +777,16 @@ static int32_t bucket_blocks(PiscesHip* h, const std::vector<int32_t>& keys, boo
     PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_tuples.p, 0xFF, tup_ub * sizeof(uint32_t), h->stream));   // PISCES_TUPLE_PAD in the padding
     const int c = h->log_cur;
     if (h->log_ub > 0) {
-        hipLaunchKernelGGL(bucket_count_kernel, dim3(log_grid(h)), dim3(256), 0, h->stream, h->d_log_pos[c].p, h->d_log_n.p + c, m,
+        hipLaunchKernelGGL(bucket_count_kernel, dim3(log_grid(h)), dim3(256), 0, h->stream, h->d_log_pos[c].p, (long long)h->log_ub, m,
                            h->d_tile_cnt.p);
     }
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_tiles.p, n_tiles, h->d_tile_cnt.p, h->d_total.p);
     if (h->log_ub > 0) {
         hipLaunchKernelGGL(bucket_scatter_kernel, dim3(log_grid(h)), dim3(256), 0, h->stream, h->d_log_pos[c].p, h->d_log_tup[c].p,
-                           h->d_log_n.p + c, m, h->d_tiles.p, h->d_tile_cnt.p, h->d_tuples.p);
+                           (long long)h->log_ub, m, h->d_tiles.p, h->d_tile_cnt.p, h->d_tuples.p);
     }
     PISCES_HIP_CHECK(h, hipGetLastError());
-    // the map tables (h->d_bucket) are reused by the next bucketing: finish before returning
-    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
-    return PISCES_OK;
+    return PISCES_OK;   // everything else of the handle is ordered behind this on h->stream
 }
 
 // DoneProcessing for the observation log: the entries of `keys` leave, the rest moves to the other log buffer
@@ -808,15 +801,12 @@ static int32_t drop_blocks(PiscesHip* h, const std::vector<int32_t>& keys)
     PISCES_HIP_CHECK(h, h->d_log_pos[o].reserve((size_t)h->log_ub));
     PISCES_HIP_CHECK(h, h->d_log_tup[o].reserve((size_t)h->log_ub));
     PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_log_n.p + o, 0, sizeof(unsigned long long), h->stream));
-    hipLaunchKernelGGL(log_drop_kernel, dim3(log_grid(h)), dim3(256), 0, h->stream, h->d_log_pos[c].p, h->d_log_tup[c].p, h->d_log_n.p + c, m,
-                       h->d_log_pos[o].p, h->d_log_tup[o].p, h->d_log_n.p + o);
+    hipLaunchKernelGGL(log_drop_kernel, dim3(log_grid(h)), dim3(256), 0, h->stream, h->d_log_pos[c].p, h->d_log_tup[c].p, (long long)h->log_ub,
+                       m, h->d_log_pos[o].p, h->d_log_tup[o].p, h->d_log_n.p + o);
     PISCES_HIP_CHECK(h, hipGetLastError());
     unsigned long long kept = 0;
-    int32_t flags[1] = {0};
     PISCES_HIP_CHECK(h, hipMemcpyAsync(&kept, h->d_log_n.p + o, sizeof(kept), hipMemcpyDeviceToHost, h->stream));
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(flags, h->d_flags.p, sizeof(flags), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
-    if (flags[0]) return fail(h, PISCES_E_DEVICE, "observation log overflow (internal sizing error)");
     h->log_cur = o;
     h->log_ub = (int64_t)kept;
     return PISCES_OK;

@@ -67,133 +67,144 @@ __device__ __forceinline__ int wave_exclusive_scan(int v, int lane, int* total)
 
 // One wave per read, lane = read index within a chunk of 64 bases.  Follows expander.cpp (the host form, checked against
 // the oracle's AddAlleleCounts) observation for observation; positions <= 0 are not logged, as there.
-__global__ __launch_bounds__(256) void expand_reads_kernel(DevReadBatch b, int32_t min_bq, int32_t* __restrict__ log_pos,
-                                                           uint32_t* __restrict__ log_tup, unsigned long long* __restrict__ log_n,
-                                                           unsigned long long log_cap, int32_t* __restrict__ overflow,
+// Every read owns the log slots [read_slot[r], read_slot[r + 1]) reserved by the host from its CIGAR (mapped bases + gap
+// lengths, an upper bound that is exact unless a deletion fails its quality test): no atomics on the log — same-address
+// global atomics from 8 XCDs cost ~25-200 ns EACH and were the whole run time of the first version of this kernel.
+// Slots a read does not use are written as position 0 ("hole"), which every consumer skips.
+__global__ __launch_bounds__(256) void expand_reads_kernel(DevReadBatch b, const long long* __restrict__ read_slot, int32_t min_bq,
+                                                           int32_t* __restrict__ log_pos, uint32_t* __restrict__ log_tup,
                                                            unsigned long long* __restrict__ appended)
 {
-    const int lane = threadIdx.x & 63;
-    const int r = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    if (r >= b.n_reads) return;
-    const int pos0 = b.position[r];
-    const int c0 = b.cigar_offset[r], nc = b.cigar_offset[r + 1] - c0;
-    const int s0 = b.seq_offset[r], n = b.seq_offset[r + 1] - s0;
-    const uint32_t read_dir = (b.flags[r] & 1) ? PISCES_DIR_REVERSE : PISCES_DIR_FORWARD;
-    const uint8_t* const ops = b.cigar_op + c0;
-    const uint32_t* const lens = b.cigar_len + c0;
-    const uint8_t* const quals = b.quals + s0;
-    const uint8_t* const bases = b.bases + s0;
-    const uint8_t* const dirs = b.dirs ? b.dirs + s0 : nullptr;
-    if (n <= 0) return;
+    __shared__ unsigned int s_emitted[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
+    int emitted = 0;
+    if (r < b.n_reads) {
+        const int pos0 = b.position[r];
+        const int c0 = b.cigar_offset[r], nc = b.cigar_offset[r + 1] - c0;
+        const int s0 = b.seq_offset[r], n = b.seq_offset[r + 1] - s0;
+        const uint32_t read_dir = (b.flags[r] & 1) ? PISCES_DIR_REVERSE : PISCES_DIR_FORWARD;
+        const uint8_t* const ops = b.cigar_op + c0;
+        const uint32_t* const lens = b.cigar_len + c0;
+        const uint8_t* const quals = b.quals + s0;
+        const uint8_t* const bases = b.bases + s0;
+        const uint8_t* const dirs = b.dirs ? b.dirs + s0 : nullptr;
+        const long long slot0 = read_slot[r], slot1 = read_slot[r + 1];
 
-    int refSpan = 0, lastMappedOverall = pos0 - 1;
-    {
-        int rp = pos0;
-        for (int c = 0; c < nc; c++) {
-            const uint8_t t = ops[c];
-            const int len = (int)lens[c];
-            if (dev_op_ref_span(t)) {
-                refSpan += len;
-                if (dev_op_read_span(t) && len > 0) lastMappedOverall = rp + len - 1;
-                rp += len;
-            }
-        }
-    }
-    const bool endsInDel = nc >= 1 && ops[nc - 1] == 'D';
-    const bool endsInDelSoft = nc >= 2 && ops[nc - 2] == 'D' && ops[nc - 1] == 'S';
-    int delLen = 0, lengthBeforeDeletion = n;
-    if (endsInDel || endsInDelSoft) {
-        delLen = (int)(endsInDelSoft ? lens[nc - 2] : lens[nc - 1]);
-        lengthBeforeDeletion = endsInDelSoft ? n - (int)lens[nc - 1] : n;
-    }
-    const int alignmentEnd = pos0 + refSpan - 1;
-    auto delq_ok = [&](int i) {   // CandidateVariantFinder.CheckDeletionQuality (:294-320), i < n
-        const int after = quals[i], before = i > 0 ? quals[i - 1] : after;
-        return before >= min_bq && after >= min_bq;
-    };
-
-    for (int base0 = 0; base0 < n; base0 += 64) {
-        const int i = base0 + lane;
-        const bool active = i < n;
-        // Read.UpdatePositionMap (Read.cs:535-562) for index i, plus the position of the last mapped base before it
-        int p = -1, lp = pos0 - 1;
+        int refSpan = 0, lastMappedOverall = pos0 - 1;
         {
-            int ri = 0, rp = pos0, lastm = pos0 - 1;
+            int rp = pos0;
             for (int c = 0; c < nc; c++) {
                 const uint8_t t = ops[c];
                 const int len = (int)lens[c];
-                const bool rs = dev_op_read_span(t), fs = dev_op_ref_span(t);
-                if (rs) {
-                    if (active && i >= ri && i < ri + len) {
-                        if (fs) { p = rp + (i - ri); lp = (i == ri) ? lastm : p - 1; }
-                        else lp = lastm;
-                    }
-                    if (fs && len > 0) { lastm = rp + len - 1; rp += len; }
-                    ri += len;
-                } else if (fs) {
+                if (dev_op_ref_span(t)) {
+                    refSpan += len;
+                    if (dev_op_read_span(t) && len > 0) lastMappedOverall = rp + len - 1;
                     rp += len;
                 }
             }
         }
-        const uint32_t dir = active ? (dirs ? (uint32_t)dirs[i] : read_dir) : 0u;
-        const bool dq = active && delq_ok(i);
-        // what this lane emits, in the host walk's order: terminal deletion before a soft clip, gap deletions, the base,
-        // terminal deletion at the read end
-        int n_soft = 0, n_gap = 0, n_base = 0, n_end = 0;
-        int soft_first = 0, gap_first = 0, end_first = 0;
-        if (active) {
-            if (endsInDelSoft && i == lengthBeforeDeletion && dq) {
-                soft_first = max(lp + 1, 1);
-                n_soft = max(0, lp + delLen - soft_first + 1);
+        const bool endsInDel = nc >= 1 && ops[nc - 1] == 'D';
+        const bool endsInDelSoft = nc >= 2 && ops[nc - 2] == 'D' && ops[nc - 1] == 'S';
+        int delLen = 0, lengthBeforeDeletion = n;
+        if (endsInDel || endsInDelSoft) {
+            delLen = (int)(endsInDelSoft ? lens[nc - 2] : lens[nc - 1]);
+            lengthBeforeDeletion = endsInDelSoft ? n - (int)lens[nc - 1] : n;
+        }
+        const int alignmentEnd = pos0 + refSpan - 1;
+        auto delq_ok = [&](int i) {   // CandidateVariantFinder.CheckDeletionQuality (:294-320), i < n
+            const int after = quals[i], before = i > 0 ? quals[i - 1] : after;
+            return before >= min_bq && after >= min_bq;
+        };
+
+        long long w0 = slot0;   // next free slot of this read (wave-uniform)
+        for (int base0 = 0; base0 < n; base0 += 64) {
+            const int i = base0 + lane;
+            const bool active = i < n;
+            // Read.UpdatePositionMap (Read.cs:535-562) for index i, plus the position of the last mapped base before it
+            int p = -1, lp = pos0 - 1;
+            {
+                int ri = 0, rp = pos0, lastm = pos0 - 1;
+                for (int c = 0; c < nc; c++) {
+                    const uint8_t t = ops[c];
+                    const int len = (int)lens[c];
+                    const bool rs = dev_op_read_span(t), fs = dev_op_ref_span(t);
+                    if (rs) {
+                        if (active && i >= ri && i < ri + len) {
+                            if (fs) { p = rp + (i - ri); lp = (i == ri) ? lastm : p - 1; }
+                            else lp = lastm;
+                        }
+                        if (fs && len > 0) { lastm = rp + len - 1; rp += len; }
+                        ri += len;
+                    } else if (fs) {
+                        rp += len;
+                    }
+                }
+            }
+            const uint32_t dir = active ? (dirs ? (uint32_t)dirs[i] : read_dir) : 0u;
+            const bool dq = active && delq_ok(i);
+            // what this lane emits, in the host walk's order: terminal deletion before a soft clip, gap deletions, the base,
+            // terminal deletion at the read end
+            int n_soft = 0, n_gap = 0, n_base = 0, n_end = 0;
+            int soft_first = 0, gap_first = 0, end_first = 0;
+            if (active) {
+                if (endsInDelSoft && i == lengthBeforeDeletion && dq) {
+                    soft_first = max(lp + 1, 1);
+                    n_soft = max(0, lp + delLen - soft_first + 1);
+                }
+                if (p != -1) {
+                    if (dq) {
+                        gap_first = max(lp + 1, 1);
+                        n_gap = max(0, p - 1 - gap_first + 1);
+                    }
+                    n_base = p > 0 ? 1 : 0;
+                }
+                if (endsInDel && i == n - 1 && dq) {
+                    end_first = max(lastMappedOverall + 1, 1);
+                    n_end = max(0, lastMappedOverall + delLen - end_first + 1);
+                }
+            }
+            const int cnt = n_soft + n_gap + n_base + n_end;
+            int total;
+            const int excl = wave_exclusive_scan(cnt, lane, &total);
+            if (total == 0) continue;
+            long long w = w0 + excl;
+            const bool fits = w0 + total <= slot1;   // always, by the host's bound; never write outside the read's slots
+            w0 += total;
+            if (!fits) continue;
+            emitted += cnt;
+            const uint32_t lastAnchor = PISCES_NUM_ANCHORS - 1;
+            for (int k = 0; k < n_soft; k++, w++) {
+                log_pos[w] = soft_first + k;
+                log_tup[w] = PISCES_TUPLE_PACK(0, lastAnchor, dir, PISCES_ALLELE_DEL, 255);
             }
             if (p != -1) {
-                if (dq) {
-                    gap_first = max(lp + 1, 1);
-                    n_gap = max(0, p - 1 - gap_first + 1);
+                const uint32_t anchor = dev_anchor_type(alignmentEnd, p, pos0);
+                for (int k = 0; k < n_gap; k++, w++) {
+                    log_pos[w] = gap_first + k;
+                    log_tup[w] = PISCES_TUPLE_PACK(0, anchor, dir, PISCES_ALLELE_DEL, 255);
                 }
-                n_base = p > 0 ? 1 : 0;
+                if (n_base) {
+                    log_pos[w] = p;
+                    log_tup[w] = PISCES_TUPLE_PACK(0, anchor, dir, dev_allele_type(bases[i]), (uint32_t)quals[i]);
+                    w++;
+                }
             }
-            if (endsInDel && i == n - 1 && dq) {
-                end_first = max(lastMappedOverall + 1, 1);
-                n_end = max(0, lastMappedOverall + delLen - end_first + 1);
-            }
-        }
-        const int cnt = n_soft + n_gap + n_base + n_end;
-        int total;
-        const int excl = wave_exclusive_scan(cnt, lane, &total);
-        if (total == 0) continue;
-        unsigned long long base = 0;
-        if (lane == 0) {
-            base = atomicAdd(log_n, (unsigned long long)total);
-            atomicAdd(appended, (unsigned long long)total);
-        }
-        base = ((unsigned long long)__shfl((int)(base >> 32), 0, 64) << 32) | (unsigned int)__shfl((int)(base & 0xFFFFFFFFull), 0, 64);
-        if (base + (unsigned long long)total > log_cap) {
-            if (lane == 0) *overflow = 1;
-            continue;
-        }
-        unsigned long long w = base + (unsigned long long)excl;
-        const uint32_t lastAnchor = PISCES_NUM_ANCHORS - 1;
-        for (int k = 0; k < n_soft; k++, w++) {
-            log_pos[w] = soft_first + k;
-            log_tup[w] = PISCES_TUPLE_PACK(0, lastAnchor, dir, PISCES_ALLELE_DEL, 255);
-        }
-        if (p != -1) {
-            const uint32_t anchor = dev_anchor_type(alignmentEnd, p, pos0);
-            for (int k = 0; k < n_gap; k++, w++) {
-                log_pos[w] = gap_first + k;
-                log_tup[w] = PISCES_TUPLE_PACK(0, anchor, dir, PISCES_ALLELE_DEL, 255);
-            }
-            if (n_base) {
-                log_pos[w] = p;
-                log_tup[w] = PISCES_TUPLE_PACK(0, anchor, dir, dev_allele_type(bases[i]), (uint32_t)quals[i]);
-                w++;
+            for (int k = 0; k < n_end; k++, w++) {
+                log_pos[w] = end_first + k;
+                log_tup[w] = PISCES_TUPLE_PACK(0, lastAnchor, dir, PISCES_ALLELE_DEL, 255);
             }
         }
-        for (int k = 0; k < n_end; k++, w++) {
-            log_pos[w] = end_first + k;
-            log_tup[w] = PISCES_TUPLE_PACK(0, lastAnchor, dir, PISCES_ALLELE_DEL, 255);
-        }
+        for (long long w = min(w0, slot1) + lane; w < slot1; w += 64) log_pos[w] = 0;   // holes
+    }
+    // observations made (IStateManager statistics): one global atomic per workgroup
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) emitted += __shfl_xor(emitted, d, 64);
+    if (lane == 0) s_emitted[wave] = (unsigned int)emitted;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int t = s_emitted[0] + s_emitted[1] + s_emitted[2] + s_emitted[3];
+        if (t) atomicAdd(appended, (unsigned long long)t);
     }
 }
 
@@ -218,41 +229,55 @@ __device__ __forceinline__ int32_t bucket_tile_of(const BucketMap& m, int32_t po
     return rel < 0 ? -1 : m.first_tile[slot] + rel;
 }
 
-// Consecutive log entries mostly fall into the same tile (a read's run of loci): one atomic per run of equal tiles in a
-// wave instead of one per entry.  Returns the reserved base for this lane's run (valid in every lane of the run) and the
-// lane's offset inside it.
-__device__ __forceinline__ int64_t reserve_runs(int32_t ti, int lane, unsigned int* counters, int* offset_in_run)
+// A workgroup owns kLogChunk consecutive log entries.  Consecutive entries are a read's run of loci, i.e. a handful of tiles,
+// so counts and fill cursors are privatized in LDS over the tile range [tmin, tmin + kLocalTiles) of the chunk and the
+// global counters see one atomic per (workgroup, tile) instead of one per entry or per wave (same-address global atomics
+// across XCDs serialize at ~0.1-0.2 us each on this part).
+constexpr int kLogChunk = 4096;
+constexpr int kLogPerThread = kLogChunk / 256;
+constexpr int kLocalTiles = 1024;
+
+__device__ __forceinline__ int chunk_min_tile(const int32_t (&ti)[kLogPerThread], int* s_tmin)
 {
-    const int32_t prev = __shfl_up(ti, 1, 64);
-    const bool head = lane == 0 || prev != ti;
-    const unsigned long long heads = __ballot(head);
-    // head lane of this lane's run = highest set bit of heads at or below lane
-    const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
-    const int head_lane = 63 - __clzll(below);
-    // run length = distance from the head to the next head (or 64)
-    const unsigned long long above = heads & ~((head_lane == 63) ? ~0ull : ((1ull << (head_lane + 1)) - 1ull));
-    const int next_head = above ? __ffsll((long long)above) - 1 : 64;
-    const int run_len = next_head - head_lane;
-    unsigned int base = 0;
-    if (head && ti >= 0) base = atomicAdd(&counters[ti], (unsigned int)run_len);
-    base = (unsigned int)__shfl((int)base, head_lane, 64);
-    *offset_in_run = lane - head_lane;
-    return (int64_t)base;
+    int tmin = 0x7FFFFFFF;
+#pragma unroll
+    for (int k = 0; k < kLogPerThread; k++)
+        if (ti[k] >= 0) tmin = min(tmin, ti[k]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) tmin = min(tmin, __shfl_xor(tmin, d, 64));
+    if ((threadIdx.x & 63) == 0) atomicMin(s_tmin, tmin);
+    __syncthreads();
+    return *s_tmin;
 }
 
-__global__ __launch_bounds__(256) void bucket_count_kernel(const int32_t* __restrict__ log_pos, const unsigned long long* __restrict__ log_n,
-                                                           BucketMap m, unsigned int* __restrict__ tile_count)
+__global__ __launch_bounds__(256) void bucket_count_kernel(const int32_t* __restrict__ log_pos, long long n, BucketMap m,
+                                                           unsigned int* __restrict__ tile_count)
 {
-    const int lane = threadIdx.x & 63;
-    const unsigned long long n = *log_n;
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    const unsigned long long first = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    for (unsigned long long base = first - lane; base < n; base += stride) {   // whole waves stay in the loop together
-        const unsigned long long i = base + lane;
-        const int32_t ti = i < n ? bucket_tile_of(m, log_pos[i]) : -1;
-        int off;
-        (void)reserve_runs(ti, lane, tile_count, &off);
+    __shared__ unsigned int s_cnt[kLocalTiles];
+    __shared__ int s_tmin;
+    const long long start = (long long)blockIdx.x * kLogChunk;
+    if (start >= n) return;
+    if (threadIdx.x == 0) s_tmin = 0x7FFFFFFF;
+    for (int d = threadIdx.x; d < kLocalTiles; d += 256) s_cnt[d] = 0;
+    __syncthreads();
+    int32_t ti[kLogPerThread];
+#pragma unroll
+    for (int k = 0; k < kLogPerThread; k++) {
+        const long long i = start + (long long)k * 256 + threadIdx.x;
+        ti[k] = i < n ? bucket_tile_of(m, log_pos[i]) : -1;
     }
+    const int tmin = chunk_min_tile(ti, &s_tmin);
+    if (tmin == 0x7FFFFFFF) return;
+#pragma unroll
+    for (int k = 0; k < kLogPerThread; k++) {
+        if (ti[k] < 0) continue;
+        const int d = ti[k] - tmin;
+        if (d < kLocalTiles) atomicAdd(&s_cnt[d], 1u);
+        else atomicAdd(&tile_count[ti[k]], 1u);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < kLocalTiles; d += 256)
+        if (s_cnt[d]) atomicAdd(&tile_count[tmin + d], s_cnt[d]);
 }
 
 // one workgroup: exclusive scan of the padded tile counts; fills the tile segments and resets the counters to cursors
@@ -285,65 +310,103 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(PiscesTile* __restric
 }
 
 __global__ __launch_bounds__(256) void bucket_scatter_kernel(const int32_t* __restrict__ log_pos, const uint32_t* __restrict__ log_tup,
-                                                             const unsigned long long* __restrict__ log_n, BucketMap m,
-                                                             const PiscesTile* __restrict__ tiles, unsigned int* __restrict__ tile_fill,
-                                                             uint32_t* __restrict__ tuples)
+                                                             long long n, BucketMap m, const PiscesTile* __restrict__ tiles,
+                                                             unsigned int* __restrict__ tile_fill, uint32_t* __restrict__ tuples)
 {
-    const int lane = threadIdx.x & 63;
-    const unsigned long long n = *log_n;
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    const unsigned long long first = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    for (unsigned long long base = first - lane; base < n; base += stride) {
-        const unsigned long long i = base + lane;
-        int32_t pos = 0;
-        uint32_t tup = 0;
-        int32_t ti = -1;
-        if (i < n) {
-            pos = log_pos[i];
-            tup = log_tup[i];
-            ti = bucket_tile_of(m, pos);
+    __shared__ unsigned int s_cnt[kLocalTiles];
+    __shared__ long long s_dst[kLocalTiles];    // tuples index of this workgroup's first entry of the tile
+    __shared__ int s_start[kLocalTiles];        // start_position of the tile
+    __shared__ int s_tmin;
+    const long long start = (long long)blockIdx.x * kLogChunk;
+    if (start >= n) return;
+    if (threadIdx.x == 0) s_tmin = 0x7FFFFFFF;
+    for (int d = threadIdx.x; d < kLocalTiles; d += 256) s_cnt[d] = 0;
+    __syncthreads();
+    int32_t ti[kLogPerThread], pos[kLogPerThread];
+    uint32_t tup[kLogPerThread];
+#pragma unroll
+    for (int k = 0; k < kLogPerThread; k++) {
+        const long long i = start + (long long)k * 256 + threadIdx.x;
+        pos[k] = i < n ? log_pos[i] : 0;
+        tup[k] = i < n ? log_tup[i] : 0u;
+        ti[k] = i < n ? bucket_tile_of(m, pos[k]) : -1;
+    }
+    const int tmin = chunk_min_tile(ti, &s_tmin);
+    if (tmin == 0x7FFFFFFF) return;
+#pragma unroll
+    for (int k = 0; k < kLogPerThread; k++)
+        if (ti[k] >= 0 && ti[k] - tmin < kLocalTiles) atomicAdd(&s_cnt[ti[k] - tmin], 1u);
+    __syncthreads();
+    for (int d = threadIdx.x; d < kLocalTiles; d += 256) {
+        if (s_cnt[d]) {
+            const PiscesTile t = tiles[tmin + d];
+            s_dst[d] = t.tuple_begin + (long long)atomicAdd(&tile_fill[tmin + d], s_cnt[d]);
+            s_start[d] = t.start_position;
+            s_cnt[d] = 0;   // now the local cursor
         }
-        int off;
-        const int64_t run_base = reserve_runs(ti, lane, tile_fill, &off);
-        if (ti >= 0) {
-            const PiscesTile t = tiles[ti];
-            const uint32_t locus = (uint32_t)(pos - t.start_position);
-            tuples[t.tuple_begin + run_base + off] = (tup & ~0x7FFFu) | locus;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kLogPerThread; k++) {
+        if (ti[k] < 0) continue;
+        const int d = ti[k] - tmin;
+        long long dst;
+        int start_position;
+        if (d < kLocalTiles) {
+            dst = s_dst[d] + (long long)atomicAdd(&s_cnt[d], 1u);
+            start_position = s_start[d];
+        } else {
+            const PiscesTile t = tiles[ti[k]];
+            dst = t.tuple_begin + (long long)atomicAdd(&tile_fill[ti[k]], 1u);
+            start_position = t.start_position;
         }
+        tuples[dst] = (tup[k] & ~0x7FFFu) | (uint32_t)(pos[k] - start_position);
     }
 }
 
-// DoneProcessing (RegionStateManager.cs:336-353): entries of the blocks in `m` are dropped, the rest is kept (order inside
-// a wave is kept, across waves it is not defined)
-__global__ __launch_bounds__(256) void log_drop_kernel(const int32_t* __restrict__ log_pos, const uint32_t* __restrict__ log_tup,
-                                                       const unsigned long long* __restrict__ log_n, BucketMap m,
-                                                       int32_t* __restrict__ out_pos, uint32_t* __restrict__ out_tup,
+// DoneProcessing (RegionStateManager.cs:336-353): entries of the blocks in `m` and holes are dropped, the rest is kept
+// (one global atomic per workgroup; the order of the kept entries across workgroups is not defined)
+__global__ __launch_bounds__(256) void log_drop_kernel(const int32_t* __restrict__ log_pos, const uint32_t* __restrict__ log_tup, long long n,
+                                                       BucketMap m, int32_t* __restrict__ out_pos, uint32_t* __restrict__ out_tup,
                                                        unsigned long long* __restrict__ out_n)
 {
-    const int lane = threadIdx.x & 63;
-    const unsigned long long n = *log_n;
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    const unsigned long long first = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    for (unsigned long long base = first - lane; base < n; base += stride) {
-        const unsigned long long i = base + lane;
-        int32_t pos = 0;
-        uint32_t tup = 0;
+    __shared__ unsigned int s_wave[4];
+    __shared__ unsigned long long s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long start = (long long)blockIdx.x * kLogChunk;
+    if (start >= n) return;
+    int32_t pos[kLogPerThread];
+    uint32_t tup[kLogPerThread];
+    unsigned int keep_bits = 0, mine = 0;
+#pragma unroll
+    for (int k = 0; k < kLogPerThread; k++) {
+        const long long i = start + (long long)k * 256 + threadIdx.x;
+        pos[k] = i < n ? log_pos[i] : 0;
+        tup[k] = i < n ? log_tup[i] : 0u;
         bool keep = false;
-        if (i < n) {
-            pos = log_pos[i];
-            tup = log_tup[i];
-            const int32_t key = (pos + m.block_size - 1) / m.block_size;
+        if (pos[k] > 0) {
+            const int32_t key = (pos[k] + m.block_size - 1) / m.block_size;
             keep = !(key >= m.key_min && key <= m.key_max && m.key_slot[key - m.key_min] >= 0);
         }
-        const unsigned long long mask = __ballot(keep);
-        if (mask == 0ull) continue;
-        unsigned long long wbase = 0;
-        if (lane == 0) wbase = atomicAdd(out_n, (unsigned long long)__popcll(mask));
-        wbase = ((unsigned long long)__shfl((int)(wbase >> 32), 0, 64) << 32) | (unsigned int)__shfl((int)(wbase & 0xFFFFFFFFull), 0, 64);
-        if (keep) {
-            const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-            out_pos[wbase + rank] = pos;
-            out_tup[wbase + rank] = tup;
+        if (keep) { keep_bits |= 1u << k; mine++; }
+    }
+    int total;
+    const int excl = wave_exclusive_scan((int)mine, lane, &total);
+    if (lane == 0) s_wave[wave] = (unsigned int)total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int t = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        s_base = t ? atomicAdd(out_n, (unsigned long long)t) : 0ull;
+    }
+    __syncthreads();
+    unsigned long long w = s_base + (unsigned long long)excl;
+    for (int q = 0; q < wave; q++) w += s_wave[q];
+#pragma unroll
+    for (int k = 0; k < kLogPerThread; k++) {
+        if (keep_bits & (1u << k)) {
+            out_pos[w] = pos[k];
+            out_tup[w] = tup[k];
+            w++;
         }
     }
 }
