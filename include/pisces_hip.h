@@ -225,9 +225,11 @@ int32_t pisces_hip_set_intervals(PiscesHip* h, const int32_t* starts, const int3
 
 /* ---- streaming surface: IStateManager -------------------------------------- */
 /* ICandidateVariantFinder.FindCandidates + IStateManager.AddCandidates + AddAlleleCounts
- * (SmallVariantCaller.cs:88-98) for a batch of reads: expands reads to observation tuples and stages them
- * for the device; finds and merges insertion / deletion candidates host-side (needs set_reference first;
- * without a reference only the AddAlleleCounts half runs). */
+ * (SmallVariantCaller.cs:88-98) for a batch of reads.  The batch crosses PCIe once, packed (2 bytes per base), and the
+ * read walk of AddAlleleCounts (RegionStateManager.cs:118-220) runs on the device into an observation log in HBM; the
+ * host only reads the CIGARs: argument checks, the blocks a read touches, and the insertion / deletion candidates
+ * (needs set_reference first; without a reference only the AddAlleleCounts half runs).  The whole batch is checked
+ * before any of it is committed. */
 int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch);
 /* Pre-expanded observations for the block grid: positions[i] is the 1-based locus of tuples[i]
  * (the tuple's locus field is ignored). */
