@@ -475,3 +475,15 @@ def test_device_read_walk_matches_oracle_on_random_cigars(torch_cuda):
     exp = st.counts()
     np.testing.assert_array_equal(got.reshape(exp.shape), exp)
     assert n_obs == int(exp.sum())
+
+
+def test_committed_fixture_without_the_oracle(torch_cuda):
+    """The streaming surface against tests/golden/synthetic_small.npz: committed inputs, committed expected records."""
+    from pisces_amd import engine
+    z = np.load(os.path.join(G, "synthetic_small.npz"))
+    exp = z["expected"].view(_abi.CALLED_ALLELE_DTYPE)
+    with engine.HipVariantCaller(_abi.default_config()) as c:
+        c.SetReference(z["ref"])
+        c.AddObservations(z["positions"], z["tuples"])
+        got = c.Call(None)
+    assert_records_match(got, exp)

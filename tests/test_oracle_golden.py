@@ -322,3 +322,79 @@ def test_call_all_simple_snv_gvcf():
     assert all(_abi.info_genotype(i) == _abi.GT_HOM_REF for i in others["info"])
     # GQ of a 0/0 call: PtoQ(QtoP(100) + Poisson.Cdf(0, 0.01*100)) = -10 log10(e^-1) = 4.34 -> 4
     assert (others["genotype_qscore"] == 4).all()
+
+
+# ---------------------------------------------------------------- spanning coverage (insertions / deletions / MNVs)
+_CAT = {"Snv": _abi.CAT_SNV, "Insertion": _abi.CAT_INSERTION, "Deletion": _abi.CAT_DELETION, "Mnv": _abi.CAT_MNV,
+        "Reference": _abi.CAT_REFERENCE}
+
+
+def _stage_counts(case, taken_ref=0):
+    st = orc.State(1, 16)
+    for row in case["counts"]:
+        a = ALLELE[row["allele"]]
+        if "dirs" in row:
+            for d, v in enumerate(row["dirs"]):
+                st.set_count(row["coord"], a, d, 5, v)
+        else:
+            for d, per in enumerate(row["anchors"]):
+                for anchor, v in per.items():
+                    st.set_count(row["coord"], a, d, int(anchor), v)
+    if taken_ref:
+        orc.lib.orc_add_gapped_mnv_ref(st.h, case["allele"]["pos"], taken_ref)
+    return st
+
+
+def _compute(case, support, well_anchored, consider_anchor):
+    st = _stage_counts(case, case.get("taken_ref", 0))
+    v = case["allele"]
+    cand = orc.make_candidate(v["pos"], _CAT[v["category"]], v["ref"], v["alt"], support=(0, 0, support),
+                              well_anchored=(0, 0, well_anchored))
+    called = orc.OrcCalled()
+    orc.lib.orc_called_from_candidate(C.byref(called), C.byref(cand))
+    orc.lib.orc_coverage_compute(C.byref(called), st.h, 1 if consider_anchor else 0, 0)
+    return called
+
+
+@pytest.mark.parametrize("case", load("coverage_spanning.json")["cases"], ids=lambda c: c["name"])
+def test_coverage_calculator_reference_cases(case):
+    """CoverageCalculatorTests.ComputeCoverage_* through the reference's own harness (ComputeCoverageTest): anchors ignored,
+    then for insertions anchor-aware with fully anchored, fully unanchored and half-and-half support."""
+    exp_dir, exp_total = case["by_dir"], case["total"]
+    check_aux = case.get("check_aux", True)
+    cat = case["allele"]["category"]
+
+    def check(called, by_dir, total, weight):
+        assert called.total_coverage == total
+        assert list(called.coverage_by_dir)[: len(by_dir)] == by_dir
+        if check_aux:
+            if cat == "Reference":
+                assert called.allele_support == case.get("snv_ref", 0)
+            elif cat == "Snv":
+                assert called.reference_support == case.get("snv_ref", 0)
+            else:
+                assert called.reference_support == total - called.allele_support
+        assert called.unanchored_weight == weight
+
+    c = _compute(case, 5, 5, False)
+    check(c, exp_dir, exp_total, 0.0)
+    if "expect_ref_support" in case:
+        assert c.reference_support == case["expect_ref_support"]
+    if cat != "Insertion":
+        return
+    suspicious = case.get("suspicious", 0)
+    aware = case.get("by_dir_anchor_aware")
+    check(_compute(case, 5, 5, True), aware if aware is not None else exp_dir,
+          sum(aware) if aware is not None else exp_total - suspicious, 0.0)
+    check(_compute(case, 5, 0, True), exp_dir, exp_total, 1.0)
+    from_unanchored = np.float32(suspicious) * np.float32(0.5)
+    total_support = int(from_unanchored + np.float32(0.5) * np.float32(exp_total - suspicious))
+    check(_compute(case, total_support, int(total_support - from_unanchored), True), exp_dir, exp_total, 1.0 if suspicious > 0 else 0.0)
+
+
+def test_synthetic_fixture_is_what_the_oracle_produces():
+    """tests/golden/synthetic_small.npz (made by tests/golden/make_synthetic_golden.py) is reproducible."""
+    z = np.load(os.path.join(G, "synthetic_small.npz"))
+    cfg = _abi.default_config()
+    exp, nloci = orc.run_observations(z["positions"], z["tuples"], z["ref"], int(z["region_start"]), int(z["n_loci"]), cfg)
+    assert exp.tobytes() == z["expected"].tobytes() and nloci == int(z["n_candidate_loci"])
