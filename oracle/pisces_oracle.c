@@ -1235,10 +1235,12 @@ static void to_record(PiscesCalledAllele* o, const OrcCalled* v)
                                v->has_sb ? v->sb.var_present_on_both : 0, v->has_sb ? v->sb.cov_present_on_both : 0);
 }
 
-/* AlleleCaller.CallForPositions :60-141 (no collapser, no MNV reallocation, no forced alleles)
- * over RegionState.GetAllCandidates :383-453. */
-int64_t orc_call_all(OrcState* s, const uint8_t* ref_bases, int64_t ref_len, const PiscesHipConfig* cfg,
-                     PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out, int64_t* total_num_called)
+/* AlleleCaller.CallForPositions :60-141 (no collapser, no MNV reallocation, no forced alleles) over an explicit batch of
+ * candidates (ICandidateBatch.GetCandidates): ProcessVariant + IsCallable per candidate, then per position the
+ * reference pruning, genotype, LowGQ filter and the (ref, alt) order of ComputeGenotypeAndFilterAllele :143-177. */
+int64_t orc_call_candidates(OrcState* s, const OrcCandidate* list, int64_t n_list, const uint8_t* ref_bases, int64_t ref_len,
+                            const PiscesHipConfig* cfg, PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out,
+                            int64_t* total_num_called)
 {
     g_rmxn_ref = ref_bases;
     g_rmxn_ref_len = ref_len;
@@ -1246,48 +1248,14 @@ int64_t orc_call_all(OrcState* s, const uint8_t* ref_bases, int64_t ref_len, con
     int64_t n = 0, cap = 1024;
     OrcCalled* called = (OrcCalled*)malloc(sizeof(OrcCalled) * (size_t)cap);
     OrcCalled v;
-
-#define PUSH_IF_CALLED()                                                            \
-    do {                                                                            \
-        orc_process_variant(&v, s, cfg);                                            \
-        if (is_callable(&v, cfg, &totalNumCalled)) {                                \
-            if (n == cap) { cap *= 2; called = (OrcCalled*)realloc(called, sizeof(OrcCalled) * (size_t)cap); } \
-            called[n++] = v;                                                        \
-        }                                                                           \
-    } while (0)
-
-    for (int li = 0; li < s->n_loci; li++)
-        for (int i = s->cand_head[li]; i >= 0; i = s->cands[i].next) {
-            orc_called_from_candidate(&v, &s->cands[i]);
-            PUSH_IF_CALLED();
-        }
-
-    if (cfg->include_reference_calls && ref_bases) {
-        for (int li = 0; li < s->n_loci; li++) {
-            int position = s->start_position + li;
-            if (position > ref_len) break;
-            uint8_t refBase = ref_bases[position - 1];
-            int refBaseIndex = allele_type_of(refBase);
-            OrcCandidate rc;
-            memset(&rc, 0, sizeof(rc));
-            rc.position = position;
-            rc.category = PISCES_CAT_REFERENCE;
-            rc.ref[0] = rc.alt[0] = (char)refBase;
-            int totalSupport = 0;
-            for (int at = 0; at < 6; at++)
-                for (int d = 0; d < 3; d++) {
-                    int count = 0;
-                    for (int an = 0; an < s->n_anchor_idx; an++) count += s->counts[cidx(s, position, at, d, an)];
-                    if (at == refBaseIndex) rc.support_by_dir[d] = count;
-                    totalSupport += count;
-                }
-            if (cfg->emit_zero_coverage_refs || totalSupport > 0) {
-                orc_called_from_candidate(&v, &rc);
-                PUSH_IF_CALLED();
-            }
+    for (int64_t i = 0; i < n_list; i++) {
+        orc_called_from_candidate(&v, &list[i]);
+        orc_process_variant(&v, s, cfg);
+        if (is_callable(&v, cfg, &totalNumCalled)) {
+            if (n == cap) { cap *= 2; called = (OrcCalled*)realloc(called, sizeof(OrcCalled) * (size_t)cap); }
+            called[n++] = v;
         }
     }
-#undef PUSH_IF_CALLED
 
     /* SortedList by position; per position sort by (ref, alt) :172-176. Stable enough: keys are unique
      * unless open-ended twins survive (only with track_open_ended). */
@@ -1322,6 +1290,45 @@ int64_t orc_call_all(OrcState* s, const uint8_t* ref_bases, int64_t ref_len, con
     }
     free(called);
     return n;
+}
+
+/* The same over RegionState.GetAllCandidates :383-453: every candidate of the state plus (gVCF) a Reference candidate per
+ * position with support = the reference base's counts by direction. */
+int64_t orc_call_all(OrcState* s, const uint8_t* ref_bases, int64_t ref_len, const PiscesHipConfig* cfg,
+                     PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out, int64_t* total_num_called)
+{
+    int64_t n = 0, cap = (int64_t)s->n_cands + 64;
+    OrcCandidate* list = (OrcCandidate*)malloc(sizeof(OrcCandidate) * (size_t)cap);
+    for (int li = 0; li < s->n_loci; li++)
+        for (int i = s->cand_head[li]; i >= 0; i = s->cands[i].next) list[n++] = s->cands[i];
+    if (cfg->include_reference_calls && ref_bases) {
+        for (int li = 0; li < s->n_loci; li++) {
+            int position = s->start_position + li;
+            if (position > ref_len) break;
+            uint8_t refBase = ref_bases[position - 1];
+            int refBaseIndex = allele_type_of(refBase);
+            OrcCandidate rc;
+            memset(&rc, 0, sizeof(rc));
+            rc.position = position;
+            rc.category = PISCES_CAT_REFERENCE;
+            rc.ref[0] = rc.alt[0] = (char)refBase;
+            int totalSupport = 0;
+            for (int at = 0; at < 6; at++)
+                for (int d = 0; d < 3; d++) {
+                    int count = 0;
+                    for (int an = 0; an < s->n_anchor_idx; an++) count += s->counts[cidx(s, position, at, d, an)];
+                    if (at == refBaseIndex) rc.support_by_dir[d] = count;
+                    totalSupport += count;
+                }
+            if (cfg->emit_zero_coverage_refs || totalSupport > 0) {
+                if (n == cap) { cap *= 2; list = (OrcCandidate*)realloc(list, sizeof(OrcCandidate) * (size_t)cap); }
+                list[n++] = rc;
+            }
+        }
+    }
+    int64_t r = orc_call_candidates(s, list, n, ref_bases, ref_len, cfg, out, capacity, full_out, total_num_called);
+    free(list);
+    return r;
 }
 
 /* =====================================================================================

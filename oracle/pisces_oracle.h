@@ -139,6 +139,11 @@ int64_t orc_call_all(OrcState* s, const uint8_t* ref_bases, int64_t ref_len, con
                      PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out /* optional, same capacity */,
                      int64_t* total_num_called);
 
+/* the same call over an explicit batch of candidates (ICandidateBatch.GetCandidates; Reference candidates allowed) */
+int64_t orc_call_candidates(OrcState* s, const OrcCandidate* list, int64_t n_list, const uint8_t* ref_bases, int64_t ref_len,
+                            const PiscesHipConfig* cfg, PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out,
+                            int64_t* total_num_called);
+
 /* ---- whole path on a read batch: the CPU baseline (SmallVariantCaller.Execute loop,
  * exe/Pisces/Logic/SmallVariantCaller.cs:79-116) ---- */
 int64_t orc_run_reads(const PiscesReadBatch* batch, const uint8_t* ref_bases, int64_t ref_len,

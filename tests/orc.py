@@ -128,6 +128,8 @@ def _load():
         "orc_process_variant": (None, [P(OrcCalled), C.c_void_p, P(_abi.PiscesHipConfig)]),
         "orc_call_all": (i64, [C.c_void_p, P(C.c_uint8), i64, P(_abi.PiscesHipConfig), C.c_void_p, i64, P(OrcCalled),
                                P(i64)]),
+        "orc_call_candidates": (i64, [C.c_void_p, P(OrcCandidate), i64, P(C.c_uint8), i64, P(_abi.PiscesHipConfig), C.c_void_p, i64,
+                                      P(OrcCalled), P(i64)]),
         "orc_run_reads": (i64, [P(_abi.PiscesReadBatch), P(C.c_uint8), i64, i32, i32, P(_abi.PiscesHipConfig),
                                 C.c_void_p, i64, P(i64)]),
         "orc_run_reads_full": (i64, [P(_abi.PiscesReadBatch), P(C.c_uint8), i64, i32, i32, P(_abi.PiscesHipConfig),
@@ -242,6 +244,20 @@ class State:
         if want_full:
             return out[:n], [full[i] for i in range(n)], total.value
         return out[:n]
+
+
+def call_candidates(state, cands, cfg, ref_bases=b""):
+    """AlleleCaller.Call over an explicit candidate batch; returns (records, full OrcCalled list, TotalNumCalled)."""
+    ref = np.frombuffer(ref_bases, dtype=np.uint8) if len(ref_bases) else np.zeros(1, np.uint8)
+    arr = (OrcCandidate * max(len(cands), 1))(*cands)
+    cap = len(cands) + 16
+    out = np.zeros(cap, dtype=_abi.CALLED_ALLELE_DTYPE)
+    full = (OrcCalled * cap)()
+    total = C.c_int64(0)
+    n = lib.orc_call_candidates(state.h, arr, len(cands), ref.ctypes.data_as(C.POINTER(C.c_uint8)), len(ref_bases), C.byref(cfg),
+                                out.ctypes.data, cap, full, C.byref(total))
+    assert n >= 0, n
+    return out[:n], [full[i] for i in range(n)], total.value
 
 
 def make_candidate(pos, category, ref, alt, support=(0, 0, 0), well_anchored=(0, 0, 0), open_left=False,

@@ -398,3 +398,32 @@ def test_synthetic_fixture_is_what_the_oracle_produces():
     cfg = _abi.default_config()
     exp, nloci = orc.run_observations(z["positions"], z["tuples"], z["ref"], int(z["region_start"]), int(z["n_loci"]), cfg)
     assert exp.tobytes() == z["expected"].tobytes() and nloci == int(z["n_candidate_loci"])
+
+
+# ---------------------------------------------------------------- AlleleCaller matrix (IsCallable, reference pruning)
+@pytest.mark.parametrize("sc", load("caller_matrix.json")["scenarios"], ids=lambda s: s["name"])
+def test_allele_caller_matrix(sc):
+    g = load("caller_matrix.json")
+    ov = {k: v for k, v in sc["config"].items() if k in ("max_variant_qscore", "noise_level", "min_coverage", "include_reference_calls",
+                                                          "min_variant_qscore", "min_frequency", "low_gq_filter", "max_genotype_qscore")}
+    if "min_frequency_num" in sc["config"]:
+        ov["min_frequency"] = float(np.float32(sc["config"]["min_frequency_num"]) / np.float32(sc["config"]["min_frequency_den"]))
+    if "min_variant_qscore_from" in sc["config"]:
+        f = sc["config"]["min_variant_qscore_from"]
+        ov["min_variant_qscore"] = orc.lib.orc_poisson_qscore(f["support"], f["coverage"], 20, 100) + f["plus"]
+    cfg = _abi.default_config(rmxn_max_repeat_length=-1, variant_qscore_filter=-1, low_depth_filter=-1, variant_freq_filter=-1.0,
+                              no_call_filter_threshold=-1.0, **ov)
+    st = orc.State(1, 600)
+    for pos_s, mult in g["counts_per_allele_direction"].items():
+        for a in range(6):
+            for d in range(3):
+                st.set_count(int(pos_s), a, d, 5, mult)
+    names = sc["candidates"]
+    cands = [orc.make_candidate(g["candidates"][n]["pos"], _CAT[g["candidates"][n]["category"]], g["candidates"][n]["ref"],
+                                g["candidates"][n]["alt"], support=tuple(g["candidates"][n]["support"])) for n in names]
+    recs, full, _ = orc.call_candidates(st, cands, cfg)
+    # MatchVariants (VariantCallerTests.cs:776-789): position, alleles, type (the chromosome label is not part of the state)
+    def key(c):
+        return (c["pos"], c["ref"], c["alt"], _CAT[c["category"]], sum(c["support"]))
+    got = sorted((f.position, f.ref.decode(), f.alt.decode(), f.category, f.allele_support) for f in full)
+    assert got == sorted(key(g["candidates"][n]) for n in sc["called"])
