@@ -158,3 +158,31 @@ def test_interval_shards_concatenate_to_the_whole():
         r, _ = orc.run_reads(b, ref, p.region_start + a0 * synth.READ_LEN, 2 * synth.READ_LEN, cfg)
         parts.append(r)
     assert n == 900 and np.concatenate(parts).tobytes() == whole.tobytes()
+
+
+def test_library_indel_finder_on_the_reference_cases():
+    """pisces_hip_find_indel_candidates (finder.cpp, what pisces_hip_add_reads runs per read) on the reference's DeletionTests /
+    InsertionTests known answers (tests/golden/finder_cases.json); SNV expectations of those cases belong to the device counts."""
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "finder_cases.json")))
+    cat = {"Insertion": _abi.CAT_INSERTION, "Deletion": _abi.CAT_DELETION}
+    n_checked = 0
+    for case in g["cases"]:
+        if not case["read"]:
+            continue
+        start = 101
+        ops = orc.parse_cigar(case["cigar"])
+        clip = ops[0][1] if ops and ops[0][0] == "S" else 0
+        ref = ("N" * (start - 1 - clip) + case["ref_under_read"] + "NNNNN").encode()
+        batch = _abi.ReadBatch([{"pos": start, "cigar": ops, "seq": case["read"], "quals": case["quals"], "reverse": False}])
+        got = sorted(engine.find_indel_candidates(batch, ref, g["min_base_call_quality"]), key=lambda c: c["position"])
+        exp = [e for e in case["expected"] if e["type"] in cat] if case["expected_count"] else []
+        assert len(got) == len(exp), (case["cigar"], case["quals"], got)
+        for c, e in zip(got, exp):
+            assert (c["position"] - start, c["ref"], c["alt"], c["category"]) == (e["coord"], e["ref"], e["alt"], cat[e["type"]])
+            if e["open_left"] is not None:
+                assert c["open_left"] == e["open_left"]
+            if e["open_right"] is not None:
+                assert c["open_right"] == e["open_right"]
+            n_checked += 1
+    assert n_checked >= 30

@@ -427,3 +427,35 @@ def test_allele_caller_matrix(sc):
         return (c["pos"], c["ref"], c["alt"], _CAT[c["category"]], sum(c["support"]))
     got = sorted((f.position, f.ref.decode(), f.alt.decode(), f.category, f.allele_support) for f in full)
     assert got == sorted(key(g["candidates"][n]) for n in sc["called"])
+
+
+# ---------------------------------------------------------------- candidate finder: the reference's deletion / insertion cases
+_FINDER = load("finder_cases.json")
+_TYPE = {"Snv": _abi.CAT_SNV, "Insertion": _abi.CAT_INSERTION, "Deletion": _abi.CAT_DELETION, "Mnv": _abi.CAT_MNV}
+
+
+def _finder_case_inputs(case, start=101):
+    ops = orc.parse_cigar(case["cigar"])
+    clip = ops[0][1] if ops and ops[0][0] == "S" else 0
+    ref = "N" * (start - 1 - clip) + case["ref_under_read"] + "NNNNN"      # CandidateVariantsTest ctor, VariantFinderTests.cs:28-41
+    return start, ops, ref
+
+
+@pytest.mark.parametrize("case", _FINDER["cases"], ids=lambda c: "%s-%s-%s-%d-%d" % (c["test"][:3], c["cigar"], "".join(map(str, c["quals"][:8])), c["max_mnv_length"], c["max_gap"]))
+def test_finder_reference_cases_oracle(case):
+    start, ops, ref = _finder_case_inputs(case)
+    if not case["read"]:
+        pytest.skip("read without bases (5D): Read construction itself is outside the finder")
+    rd = orc.make_read(start, case["read"], cigar=ops, quals=case["quals"])
+    got = sorted(orc.find_candidates(rd, ref, min_bq=_FINDER["min_base_call_quality"], max_mnv=case["max_mnv_length"],
+                                     max_gap=case["max_gap"], call_mnvs=_FINDER["call_mnvs"]), key=lambda c: c.position)
+    assert len(got) == case["expected_count"]
+    if not got:
+        return
+    assert len(got) == len(case["expected"])
+    for c, e in zip(got, case["expected"]):
+        assert (c.position - start, c.ref.decode(), c.alt.decode(), c.category) == (e["coord"], e["ref"], e["alt"], _TYPE[e["type"]])
+        if e["open_left"] is not None:
+            assert bool(c.open_left) == e["open_left"]
+        if e["open_right"] is not None:
+            assert bool(c.open_right) == e["open_right"]
