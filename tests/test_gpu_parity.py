@@ -487,3 +487,28 @@ def test_committed_fixture_without_the_oracle(torch_cuda):
         c.AddObservations(z["positions"], z["tuples"])
         got = c.Call(None)
     assert_records_match(got, exp)
+
+
+def test_streaming_surface_equals_device_resident_surface_at_size(torch_cuda):
+    """The two surfaces of the boundary on the same pileup (20 000 loci x 500x, 66 700 reads): reads walked on the device, block by
+    block through add_reads / flush as SmallVariantCaller drives them, must give exactly the records of one call_tiles launch over
+    the pre-bucketed tuples (tile order inside the observation log is not defined, the counts are)."""
+    from pisces_amd import engine, synth
+    torch = torch_cuda
+    p = synth.make_pileup(n_loci=20_000, depth=500, seed=77, device="cuda")
+    cfg = _abi.default_config()
+    with engine.HipVariantCaller(cfg) as caller:
+        resident, _ = run_fused(torch, caller, p)
+    p.base, p.qual = p.base.cpu(), p.qual.cpu()
+    A = p.base.shape[0]
+    streamed = []
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(p.ref.cpu().numpy())
+        for a0 in range(0, A, 5):
+            c.AddAlleleCounts(synth.reads_of(p, 5, first_amplicon=a0))
+            streamed.append(c.Call(p.region_start + a0 * synth.READ_LEN - 1))
+        streamed.append(c.Call(None))
+        stats = c.Stats()
+    streamed = np.concatenate(streamed)
+    assert streamed.tobytes() == resident.tobytes()
+    assert stats["reads"] == A * 500 and stats["observations"] == p.n_obs
