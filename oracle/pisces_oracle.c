@@ -1235,6 +1235,155 @@ static void to_record(PiscesCalledAllele* o, const OrcCalled* v)
                                v->has_sb ? v->sb.var_present_on_both : 0, v->has_sb ? v->sb.cov_present_on_both : 0);
 }
 
+/* =====================================================================================
+ * exe/Pisces/Logic/VariantCalling/VariantCollapser.cs
+ * ===================================================================================== */
+static int cand_length(const OrcCandidate* c) { return allele_length(c->category, c->ref, c->alt); }
+static int cand_support(const OrcCandidate* c) { return c->support_by_dir[0] + c->support_by_dir[1] + c->support_by_dir[2]; }
+static int cand_fully_anchored(const OrcCandidate* c) { return !c->open_left && !c->open_right; }
+
+/* CanCollapse :119-174 */
+static int can_collapse(const OrcCandidate* toCollapse, const OrcCandidate* potentialMatch)
+{
+    const int ti = toCollapse->category == PISCES_CAT_INSERTION, pi = potentialMatch->category == PISCES_CAT_INSERTION;
+    const int td = toCollapse->category == PISCES_CAT_DELETION, pd = potentialMatch->category == PISCES_CAT_DELETION;
+    if ((ti && !pi) || (!ti && pi) || (td && !pd) || (!td && pd) || cand_length(toCollapse) > cand_length(potentialMatch) ||
+        (cand_fully_anchored(toCollapse) && !cand_fully_anchored(potentialMatch)))
+        return 0;
+    const char* tb = td ? toCollapse->ref : toCollapse->alt;
+    const char* pb = pd ? potentialMatch->ref : potentialMatch->alt;
+    const int tl = (int)strlen(tb), pl = (int)strlen(pb);
+    if (cand_fully_anchored(toCollapse) && cand_fully_anchored(potentialMatch)) return candidate_equals(toCollapse, potentialMatch);
+    if (td) {
+        if (toCollapse->open_right) return potentialMatch->position + 1 == toCollapse->position + 1;
+        return potentialMatch->position + pl - 1 == toCollapse->position + tl - 1;
+    }
+    if (toCollapse->open_right) return potentialMatch->position == toCollapse->position && pl >= tl && strncmp(pb, tb, (size_t)tl) == 0;
+    if (ti) {
+        /* anchored on right: Substring(pl - tl + 1) == toCollapseBases.Substring(1); throws (never reached in practice) when negative */
+        if (potentialMatch->position + 1 != toCollapse->position + 1) return 0;
+        return pl - tl + 1 >= 0 && strcmp(pb + (pl - tl + 1), tb + 1) == 0;
+    }
+    const int tal = (int)strlen(toCollapse->alt), pal = (int)strlen(potentialMatch->alt);
+    return potentialMatch->position + pal - 1 == toCollapse->position + tal - 1 && pal >= tal &&
+           strcmp(potentialMatch->alt + (pal - tal), toCollapse->alt) == 0;
+}
+
+/* Frequency of a candidate: AlleleHelper.Map + CoverageCalculator.Compute + CalledAllele.Frequency (:196-207) */
+static float cand_frequency(const OrcCandidate* c, const OrcState* src, int considerAnchors, int expectStitched)
+{
+    OrcCalled v;
+    orc_called_from_candidate(&v, c);
+    orc_coverage_compute(&v, src, considerAnchors, expectStitched);
+    return frequency_f(v.allele_support, v.total_coverage);
+}
+
+typedef struct { const OrcCandidate* c; float freq; int idx; } MatchRow;
+
+/* IComparer<CandidateAllele>.Compare :214-244 (no known variants on this path) */
+static int match_cmp(const void* pa, const void* pb)
+{
+    const MatchRow* a = (const MatchRow*)pa;
+    const MatchRow* b = (const MatchRow*)pb;
+    const int fa = cand_fully_anchored(a->c), fb = cand_fully_anchored(b->c);
+    if (fa && !fb) return -1;
+    if (!fa && fb) return 1;
+    const int la = cand_length(a->c), lb = cand_length(b->c);
+    if (la != lb) return la > lb ? -1 : 1;
+    if (fabsf(a->freq - b->freq) > 0.0f) return a->freq > b->freq ? -1 : 1;
+    if (a->c->position != b->c->position) return a->c->position < b->c->position ? -1 : 1;
+    int r = strcmp(a->c->alt, b->c->alt);
+    if (r != 0) return r;
+    return a->idx - b->idx;   /* List.Sort is unstable there; input order keeps this deterministic */
+}
+
+typedef struct { int idx; int len, both, either, sup, openr, openl; const char* ref; const char* alt; } OrderRow;
+/* OrderByDescending(Length).ThenByDescending(both open).ThenByDescending(either open).ThenBy(ref).ThenBy(alt).ThenBy(Support)
+ * .ThenBy(OpenOnRight).ThenBy(OpenOnLeft) :41-46 (stable) */
+static int order_cmp(const void* pa, const void* pb)
+{
+    const OrderRow* a = (const OrderRow*)pa;
+    const OrderRow* b = (const OrderRow*)pb;
+    if (a->len != b->len) return a->len > b->len ? -1 : 1;
+    if (a->both != b->both) return a->both > b->both ? -1 : 1;
+    if (a->either != b->either) return a->either > b->either ? -1 : 1;
+    int r = strcmp(a->ref, b->ref);
+    if (r) return r;
+    r = strcmp(a->alt, b->alt);
+    if (r) return r;
+    if (a->sup != b->sup) return a->sup < b->sup ? -1 : 1;
+    if (a->openr != b->openr) return a->openr < b->openr ? -1 : 1;
+    if (a->openl != b->openl) return a->openl < b->openl ? -1 : 1;
+    return a->idx - b->idx;
+}
+
+/* VariantCollapser.Collapse :31-79.  cands[0..n) is edited in place (collapsed entries removed, order kept); returns the new
+ * count.  Candidates past max_cleared_position (>= 0) that could not be collapsed are moved to added_back (source.AddCandidates). */
+int32_t orc_collapse(OrcCandidate* cands, int32_t n, const OrcState* src, float freq_threshold, float freq_ratio_threshold,
+                     int32_t exclude_mnvs, int32_t consider_anchors, int32_t expect_stitched, int32_t max_cleared_position,
+                     int32_t* n_collapsed, OrcCandidate* added_back, int32_t* n_added_back)
+{
+    uint8_t* removed = (uint8_t*)calloc((size_t)(n > 0 ? n : 1), 1);
+    OrderRow* order = (OrderRow*)malloc(sizeof(OrderRow) * (size_t)(n > 0 ? n : 1));
+    MatchRow* rows = (MatchRow*)malloc(sizeof(MatchRow) * (size_t)(n > 0 ? n : 1));
+    int no = 0, collapsed = 0;
+    for (int i = 0; i < n; i++) {
+        const OrcCandidate* c = &cands[i];
+        if (exclude_mnvs && c->category == PISCES_CAT_MNV) continue;
+        if (!(c->open_left || c->open_right)) continue;
+        OrderRow r = {i, cand_length(c), c->open_left && c->open_right, c->open_left || c->open_right, cand_support(c), c->open_right,
+                      c->open_left, c->ref, c->alt};
+        order[no++] = r;
+    }
+    qsort(order, (size_t)no, sizeof(OrderRow), order_cmp);
+    for (int k = 0; k < no; k++) {
+        OrcCandidate* toCollapse = &cands[order[k].idx];
+        int nm = 0;
+        for (int j = 0; j < n; j++) {
+            if (j == order[k].idx || removed[j]) continue;
+            if (exclude_mnvs && cands[j].category == PISCES_CAT_MNV) continue;
+            if (!can_collapse(toCollapse, &cands[j])) continue;
+            rows[nm].c = &cands[j];
+            rows[nm].idx = j;
+            rows[nm].freq = cand_frequency(&cands[j], src, consider_anchors, expect_stitched);
+            nm++;
+        }
+        if (nm == 0) continue;
+        const float toFreq = cand_frequency(toCollapse, src, consider_anchors, expect_stitched);
+        qsort(rows, (size_t)nm, sizeof(MatchRow), match_cmp);
+        int pick = -1;
+        for (int m = 0; m < nm && pick < 0; m++)
+            if (candidate_equals(rows[m].c, toCollapse) && cand_fully_anchored(rows[m].c)) pick = m;
+        for (int m = 0; m < nm && pick < 0; m++)
+            if (rows[m].freq >= freq_threshold && rows[m].freq / toFreq > freq_ratio_threshold) pick = m;
+        if (pick < 0) continue;
+        OrcCandidate* match = &cands[rows[pick].idx];
+        collapsed++;
+        for (int d = 0; d < 3; d++) {   /* Collapse :81-90 */
+            match->support_by_dir[d] += toCollapse->support_by_dir[d];
+            match->well_anchored_by_dir[d] += toCollapse->well_anchored_by_dir[d];
+        }
+        match->open_left = match->open_left && toCollapse->open_left;
+        match->open_right = match->open_right && toCollapse->open_right;
+        removed[order[k].idx] = 1;
+    }
+    int nab = 0;
+    if (max_cleared_position >= 0)
+        for (int i = 0; i < n; i++)
+            if (!removed[i] && cands[i].position > max_cleared_position && cands[i].category != PISCES_CAT_REFERENCE) {
+                if (added_back) added_back[nab] = cands[i];
+                nab++;
+                removed[i] = 1;
+            }
+    int w = 0;
+    for (int i = 0; i < n; i++)
+        if (!removed[i]) { if (w != i) cands[w] = cands[i]; w++; }
+    if (n_collapsed) *n_collapsed = collapsed;
+    if (n_added_back) *n_added_back = nab;
+    free(removed); free(order); free(rows);
+    return w;
+}
+
 /* AlleleCaller.CallForPositions :60-141 (no collapser, no MNV reallocation, no forced alleles) over an explicit batch of
  * candidates (ICandidateBatch.GetCandidates): ProcessVariant + IsCallable per candidate, then per position the
  * reference pruning, genotype, LowGQ filter and the (ref, alt) order of ComputeGenotypeAndFilterAllele :143-177. */

@@ -139,6 +139,12 @@ int64_t orc_call_all(OrcState* s, const uint8_t* ref_bases, int64_t ref_len, con
                      PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out /* optional, same capacity */,
                      int64_t* total_num_called);
 
+/* VariantCollapser.Collapse (exe/Pisces/Logic/VariantCalling/VariantCollapser.cs:31-79) on a candidate list, in place;
+ * returns the new count.  max_cleared_position < 0 = null. */
+int32_t orc_collapse(OrcCandidate* cands, int32_t n, const OrcState* src, float freq_threshold, float freq_ratio_threshold,
+                     int32_t exclude_mnvs, int32_t consider_anchors, int32_t expect_stitched, int32_t max_cleared_position,
+                     int32_t* n_collapsed, OrcCandidate* added_back, int32_t* n_added_back);
+
 /* the same call over an explicit batch of candidates (ICandidateBatch.GetCandidates; Reference candidates allowed) */
 int64_t orc_call_candidates(OrcState* s, const OrcCandidate* list, int64_t n_list, const uint8_t* ref_bases, int64_t ref_len,
                             const PiscesHipConfig* cfg, PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out,

@@ -130,6 +130,7 @@ def _load():
                                P(i64)]),
         "orc_call_candidates": (i64, [C.c_void_p, P(OrcCandidate), i64, P(C.c_uint8), i64, P(_abi.PiscesHipConfig), C.c_void_p, i64,
                                       P(OrcCalled), P(i64)]),
+        "orc_collapse": (i32, [P(OrcCandidate), i32, C.c_void_p, f32, f32, i32, i32, i32, i32, P(i32), P(OrcCandidate), P(i32)]),
         "orc_run_reads": (i64, [P(_abi.PiscesReadBatch), P(C.c_uint8), i64, i32, i32, P(_abi.PiscesHipConfig),
                                 C.c_void_p, i64, P(i64)]),
         "orc_run_reads_full": (i64, [P(_abi.PiscesReadBatch), P(C.c_uint8), i64, i32, i32, P(_abi.PiscesHipConfig),
@@ -258,6 +259,18 @@ def call_candidates(state, cands, cfg, ref_bases=b""):
                                 out.ctypes.data, cap, full, C.byref(total))
     assert n >= 0, n
     return out[:n], [full[i] for i in range(n)], total.value
+
+
+def collapse(state, cands, freq_threshold=0.0, freq_ratio_threshold=0.0, exclude_mnvs=False, consider_anchors=True, expect_stitched=False,
+             max_cleared_position=None):
+    """VariantCollapser.Collapse on a list of OrcCandidate; returns (collapsed list, TotalNumCollapsed, added back)."""
+    n = len(cands)
+    arr = (OrcCandidate * max(n, 1))(*cands)
+    back = (OrcCandidate * max(n, 1))()
+    nc, nb = C.c_int32(0), C.c_int32(0)
+    m = lib.orc_collapse(arr, n, state.h, freq_threshold, freq_ratio_threshold, int(exclude_mnvs), int(consider_anchors), int(expect_stitched),
+                         -1 if max_cleared_position is None else max_cleared_position, C.byref(nc), back, C.byref(nb))
+    return [arr[i] for i in range(m)], nc.value, [back[i] for i in range(nb.value)]
 
 
 def make_candidate(pos, category, ref, alt, support=(0, 0, 0), well_anchored=(0, 0, 0), open_left=False,

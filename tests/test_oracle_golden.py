@@ -459,3 +459,25 @@ def test_finder_reference_cases_oracle(case):
             assert bool(c.open_left) == e["open_left"]
         if e["open_right"] is not None:
             assert bool(c.open_right) == e["open_right"]
+
+
+# ---------------------------------------------------------------- VariantCollapser
+@pytest.mark.parametrize("case", load("collapser_cases.json")["cases"], ids=lambda c: c["name"])
+def test_variant_collapser_reference_cases(case):
+    st = orc.State(1, 64)
+    for pos in range(1, 40):                       # the mock allele source: every count is 1
+        for a in range(6):
+            for d in range(3):
+                for anchor in range(11):
+                    st.set_count(pos, a, d, anchor, 0)
+                st.set_count(pos, a, d, 5, 1)
+    def run(order):
+        cands = [orc.make_candidate(c["pos"], _CAT[c["category"]], c["ref"], c["alt"], support=(1, 0, 0), open_left=c["open_left"],
+                                    open_right=c["open_right"]) for c in order]
+        out, n_collapsed, _ = orc.collapse(st, cands)
+        assert len(out) == case["expected_count"]
+        assert n_collapsed == len(order) - case["expected_count"]
+        if case["expected_support_first"] is not None:
+            assert sum(out[0].support_by_dir) == case["expected_support_first"]
+    run(case["candidates"])
+    run(list(reversed(case["candidates"])))
