@@ -16,7 +16,8 @@ namespace Pisces.Hip
             NoCallFilterThreshold;
         public int RmxnMaxRepeatLength, RmxnMinRepetitions;
         public float RmxnFrequencyLimit;
-        public int Reserved0, Reserved1, Reserved2;
+        public int Collapse;
+        public float CollapseFreqThreshold, CollapseFreqRatioThreshold;
     }
 
     [StructLayout(LayoutKind.Sequential, Pack = 8, Size = 64)]

@@ -114,7 +114,10 @@ typedef struct PiscesHipConfig {
     int32_t rmxn_max_repeat_length;   /* RMxNFilterMaxLengthRepeat, 5; <0 = filter off */
     int32_t rmxn_min_repetitions;     /* RMxNFilterMinRepetitions, 9 */
     float   rmxn_frequency_limit;     /* RMxNFilterFrequencyLimit, 0.35f */
-    int32_t reserved[3];
+    int32_t collapse;                 /* PiscesApplicationOptions.Collapse (VariantCollapser on insertion / deletion candidates; SNV twins are
+                                         the device counts already); reference default true, see pisces_hip_default_config */
+    float   collapse_freq_threshold;        /* CollapseFreqThreshold, 0f */
+    float   collapse_freq_ratio_threshold;  /* CollapseFreqRatioThreshold, 0.5f */
 } PiscesHipConfig;
 
 /* ---- one called allele (64 bytes; what CalledAllele carries to the VCF writer,

@@ -1450,6 +1450,9 @@ int64_t orc_call_all(OrcState* s, const uint8_t* ref_bases, int64_t ref_len, con
     OrcCandidate* list = (OrcCandidate*)malloc(sizeof(OrcCandidate) * (size_t)cap);
     for (int li = 0; li < s->n_loci; li++)
         for (int i = s->cand_head[li]; i >= 0; i = s->cands[i].next) list[n++] = s->cands[i];
+    if (cfg->collapse)   /* AlleleCaller.Call :50-58: candidates = _collapser.Collapse(batch.GetCandidates(), source, MaxClearedPosition) */
+        n = orc_collapse(list, (int32_t)n, s, cfg->collapse_freq_threshold, cfg->collapse_freq_ratio_threshold, 0, 1,
+                         cfg->expect_stitched_reads, -1, NULL, NULL, NULL);
     if (cfg->include_reference_calls && ref_bases) {
         for (int li = 0; li < s->n_loci; li++) {
             int position = s->start_position + li;
@@ -1508,7 +1511,8 @@ int64_t orc_run_reads_full(const PiscesReadBatch* b, const uint8_t* ref_bases, i
                            int32_t region_loci, const PiscesHipConfig* cfg, PiscesCalledAllele* out, int64_t capacity,
                            int64_t* n_candidate_loci, OrcCalled* full_out, int64_t* total_num_called)
 {
-    OrcState* s = orc_state_create(region_start, region_loci, cfg->min_base_call_quality, PISCES_ANCHOR_SIZE, 0);
+    /* the state manager tracks open-ended candidates apart when the collapser is on (Factory.cs:209-227) */
+    OrcState* s = orc_state_create(region_start, region_loci, cfg->min_base_call_quality, PISCES_ANCHOR_SIZE, cfg->collapse ? 1 : 0);
     OrcCandidate cands[256];
     for (int i = 0; i < b->n_reads; i++) {
         OrcRead r;
@@ -1608,6 +1612,9 @@ void orc_default_config(PiscesHipConfig* c)
     c->rmxn_max_repeat_length = 5;
     c->rmxn_min_repetitions = 9;
     c->rmxn_frequency_limit = 0.35f;
+    c->collapse = 1;
+    c->collapse_freq_threshold = 0.0f;
+    c->collapse_freq_ratio_threshold = 0.5f;
 }
 
 

@@ -82,7 +82,9 @@ class PiscesHipConfig(C.Structure):
         ("rmxn_max_repeat_length", C.c_int32),
         ("rmxn_min_repetitions", C.c_int32),
         ("rmxn_frequency_limit", C.c_float),
-        ("reserved", C.c_int32 * 3),
+        ("collapse", C.c_int32),
+        ("collapse_freq_threshold", C.c_float),
+        ("collapse_freq_ratio_threshold", C.c_float),
     ]
 
 
@@ -117,6 +119,9 @@ def default_config(**overrides):
     c.rmxn_max_repeat_length = 5
     c.rmxn_min_repetitions = 9
     c.rmxn_frequency_limit = 0.35
+    c.collapse = 1
+    c.collapse_freq_threshold = 0.0
+    c.collapse_freq_ratio_threshold = 0.5
     for k, v in overrides.items():
         if not hasattr(c, k):
             raise AttributeError(f"PiscesHipConfig has no field {k!r}")

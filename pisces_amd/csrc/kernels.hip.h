@@ -1027,7 +1027,7 @@ struct DevCandidate {
 
 // AlleleCountHelper.GetAnchorAdjustedAlleleCount (lib/Pisces.Processing/RegionState/AlleleCountHelper.cs:21-85)
 // over one [11] row; maxAnchor < 0 = null; symmetric is never set on this path
-__device__ inline int anchor_adjusted_count(const int32_t* __restrict__ row, int minAnchor, int maxAnchor, bool fromEnd)
+__host__ __device__ inline int anchor_adjusted_count(const int32_t* __restrict__ row, int minAnchor, int maxAnchor, bool fromEnd)
 {
     const int wellAnchoredIndex = PISCES_ANCHOR_SIZE, numAnchorIndexes = PISCES_NUM_ANCHORS;
     const int trueMinAnchor = wellAnchoredIndex < minAnchor ? wellAnchoredIndex : minAnchor;
@@ -1049,7 +1049,7 @@ __device__ inline int anchor_adjusted_count(const int32_t* __restrict__ row, int
     return tot;
 }
 
-__device__ inline int get_allele_count(const int32_t* __restrict__ counts, int64_t idx, int allele, int dir, int minAnchor,
+__host__ __device__ inline int get_allele_count(const int32_t* __restrict__ counts, int64_t idx, int allele, int dir, int minAnchor,
                                        int maxAnchor, bool fromEnd)
 {
     if (idx < 0) return 0;   // RegionStateManager.GetAlleleCount: no block -> 0 (RegionStateManager.cs:222-226)
@@ -1093,14 +1093,12 @@ __device__ inline int rmxn_length_for_indel(int variantPosition, const uint8_t* 
     return maxRepeatsFound;
 }
 
-__global__ __launch_bounds__(64) void call_spanning_kernel(
-    const DevCandidate* __restrict__ cands, int32_t n, const int32_t* __restrict__ counts, const uint8_t* __restrict__ alleles,
-    const uint8_t* __restrict__ ref, int64_t ref_len /* ref[i] = position i+1 */, int32_t expect_stitched,
-    PiscesCalledAllele* __restrict__ out, uint8_t* __restrict__ callable_out, DeviceParams P)
+// CoverageCalculator.CalculateSpanning (CoverageCalculator.cs:162-321) for an insertion / deletion candidate over the
+// anchor-resolved counts tensor: coverage by direction, total coverage.  Host and device: the host-side collapser needs the
+// same number (CandidateAllele.Frequency) the device call uses.
+struct SpanningCoverage { int cov[3]; int total; };
+__host__ __device__ inline SpanningCoverage spanning_coverage(const DevCandidate& c, const int32_t* __restrict__ counts, int32_t expect_stitched)
 {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
-    const DevCandidate c = cands[i];
     const int length = c.category == PISCES_CAT_INSERTION ? c.alt_len - 1 : c.ref_len - 1;   // BaseAllele.Length
     const int support = c.sup[0] + c.sup[1] + c.sup[2];
     const int wellAnchored = c.anch[0] + c.anch[1] + c.anch[2];
@@ -1142,7 +1140,7 @@ __global__ __launch_bounds__(64) void call_spanning_kernel(
         const float anchoredVariantFreq = trulyAnchoredCoverage <= 0 ? 0.0f : (float)wellAnchored / trulyAnchoredCoverage;
         const int totalSuspicious = suspiciousLeft + suspiciousRight;
         const float unanchoredVariantFreq = totalSuspicious == 0 ? 0.0f : unanchoredSupport / ((float)totalSuspicious);
-        float w = anchoredVariantFreq == 0 ? 1.0f : fminf(1.0f, unanchoredVariantFreq / anchoredVariantFreq);
+        float w = anchoredVariantFreq == 0 ? 1.0f : ((unanchoredVariantFreq / anchoredVariantFreq) < 1.0f ? (unanchoredVariantFreq / anchoredVariantFreq) : 1.0f);
         if (!(w > 0.0f)) w = 0.0f;
         const double weight = w;
         for (int d = 0; d < 3; d++) {
@@ -1164,7 +1162,26 @@ __global__ __launch_bounds__(64) void call_spanning_kernel(
         cov[d] = (int)e;
         exactTotalCoverage += e;
     }
-    const int total = (int)exactTotalCoverage;
+    SpanningCoverage r;
+    r.cov[0] = cov[0]; r.cov[1] = cov[1]; r.cov[2] = cov[2];
+    r.total = (int)exactTotalCoverage;
+    return r;
+}
+
+
+__global__ __launch_bounds__(64) void call_spanning_kernel(
+    const DevCandidate* __restrict__ cands, int32_t n, const int32_t* __restrict__ counts, const uint8_t* __restrict__ alleles,
+    const uint8_t* __restrict__ ref, int64_t ref_len /* ref[i] = position i+1 */, int32_t expect_stitched,
+    PiscesCalledAllele* __restrict__ out, uint8_t* __restrict__ callable_out, DeviceParams P)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const DevCandidate c = cands[i];
+    const int length = c.category == PISCES_CAT_INSERTION ? c.alt_len - 1 : c.ref_len - 1;   // BaseAllele.Length
+    const int support = c.sup[0] + c.sup[1] + c.sup[2];
+    const SpanningCoverage sc = spanning_coverage(c, counts, expect_stitched);
+    const int cov[3] = {sc.cov[0], sc.cov[1], sc.cov[2]};
+    const int total = sc.total;
     int refsup = total - support;
     if (refsup < 0) refsup = 0;
 

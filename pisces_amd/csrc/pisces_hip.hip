@@ -127,6 +127,7 @@ struct PiscesHip {
     std::vector<HostCandidate> pending_cands;       // called insertion / deletion candidates (their allele strings)
     std::vector<int32_t> pending_keys;
     int64_t pending_called = 0;
+    int64_t pending_collapsed = 0;
 
     // observation log on the device: (position, tuple) of every allele-count increment of the blocks not yet flushed,
     // appended by expand_reads_kernel / pisces_hip_add_observations, bucketed by tile at flush time
@@ -246,6 +247,9 @@ int32_t pisces_hip_default_config(PiscesHipConfig* c)
     c->rmxn_max_repeat_length = 5;
     c->rmxn_min_repetitions = 9;
     c->rmxn_frequency_limit = 0.35f;
+    c->collapse = 1;
+    c->collapse_freq_threshold = 0.0f;
+    c->collapse_freq_ratio_threshold = 0.5f;
     return PISCES_OK;
 }
 
@@ -542,7 +546,9 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
             for (auto& cnd : found) {
                 if (cnd.position <= 0) continue;
                 BlockObs* b = get_block(h, cnd.position);
+                // RegionState.AddCandidate: with the collapser on (trackOpenEnded) open-ended candidates stay apart (RegionState.cs:114-137)
                 std::string key = std::to_string(cnd.position) + "|" + std::to_string(cnd.category) + "|" + cnd.ref + ">" + cnd.alt;
+                if (h->cfg.collapse) key += cnd.open_left ? (cnd.open_right ? "|LR" : "|L") : (cnd.open_right ? "|R" : "|");
                 auto it = b->cand_index.find(key);
                 if (it == b->cand_index.end()) {
                     b->cand_index.emplace(std::move(key), b->cands.size());
@@ -906,17 +912,123 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
     return PISCES_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// VariantCollapser.Collapse (exe/Pisces/Logic/VariantCalling/VariantCollapser.cs:31-79) for the insertion / deletion
+// candidates of a batch.  SNV candidates need no pass here: an open-ended SNV collapses into its anchored twin, and the
+// device counts are that sum already.  Frequencies come from the same spanning_coverage() the device call uses, over a host
+// copy of the anchor-resolved counts.
+// ------------------------------------------------------------------------------------------------
+namespace {
+inline int cand_length(const HostCandidate& c) { return c.category == PISCES_CAT_INSERTION ? (int)c.alt.size() - 1 : (int)c.ref.size() - 1; }
+inline int cand_support(const HostCandidate& c) { return c.support_by_dir[0] + c.support_by_dir[1] + c.support_by_dir[2]; }
+inline bool cand_fully_anchored(const HostCandidate& c) { return !c.open_left && !c.open_right; }
+inline bool cand_equals(const HostCandidate& a, const HostCandidate& b)
+{
+    return a.position == b.position && a.alt == b.alt && a.category == b.category && a.ref == b.ref;
+}
+// CanCollapse :119-174 (insertions and deletions)
+bool can_collapse(const HostCandidate& t, const HostCandidate& p)
+{
+    if (t.category != p.category || cand_length(t) > cand_length(p) || (cand_fully_anchored(t) && !cand_fully_anchored(p))) return false;
+    const bool del = t.category == PISCES_CAT_DELETION;
+    const std::string& tb = del ? t.ref : t.alt;
+    const std::string& pb = del ? p.ref : p.alt;
+    if (cand_fully_anchored(t) && cand_fully_anchored(p)) return cand_equals(t, p);
+    if (del) {
+        if (t.open_right) return p.position + 1 == t.position + 1;
+        return p.position + (int)pb.size() - 1 == t.position + (int)tb.size() - 1;
+    }
+    if (t.open_right) return p.position == t.position && pb.size() >= tb.size() && pb.compare(0, tb.size(), tb) == 0;
+    if (p.position + 1 != t.position + 1) return false;
+    if (pb.size() + 1 < tb.size()) return false;
+    return pb.compare(pb.size() - tb.size() + 1, std::string::npos, tb, 1, std::string::npos) == 0;
+}
+}  // namespace
+
+// cands is edited in place; freq(c) = CalledAllele.Frequency of the candidate against the current counts
+extern "C++" {
+template <typename FreqFn>
+static int64_t collapse_candidates(std::vector<HostCandidate>& cands, float freq_threshold, float freq_ratio_threshold, FreqFn freq)
+{
+    const size_t n = cands.size();
+    std::vector<uint8_t> removed(n, 0);
+    std::vector<size_t> order;
+    for (size_t i = 0; i < n; i++)
+        if (cands[i].open_left || cands[i].open_right) order.push_back(i);
+    // OrderByDescending(Length).ThenByDescending(both open).ThenByDescending(either).ThenBy(ref).ThenBy(alt).ThenBy(Support)
+    // .ThenBy(OpenOnRight).ThenBy(OpenOnLeft) :41-46
+    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+        const HostCandidate& a = cands[x];
+        const HostCandidate& b = cands[y];
+        if (cand_length(a) != cand_length(b)) return cand_length(a) > cand_length(b);
+        const bool ba = a.open_left && a.open_right, bb = b.open_left && b.open_right;
+        if (ba != bb) return ba;
+        if (a.ref != b.ref) return a.ref < b.ref;
+        if (a.alt != b.alt) return a.alt < b.alt;
+        if (cand_support(a) != cand_support(b)) return cand_support(a) < cand_support(b);
+        if (a.open_right != b.open_right) return !a.open_right;
+        if (a.open_left != b.open_left) return !a.open_left;
+        return false;
+    });
+    int64_t collapsed = 0;
+    struct Row { size_t idx; float f; };
+    std::vector<Row> rows;
+    for (size_t oi : order) {
+        HostCandidate& t = cands[oi];
+        rows.clear();
+        for (size_t j = 0; j < n; j++)
+            if (j != oi && !removed[j] && can_collapse(t, cands[j])) rows.push_back({j, freq(cands[j])});
+        if (rows.empty()) continue;
+        const float tf = freq(t);
+        // IComparer.Compare :214-244 (no known variants here); input order breaks the remaining ties
+        std::stable_sort(rows.begin(), rows.end(), [&](const Row& x, const Row& y) {
+            const HostCandidate& a = cands[x.idx];
+            const HostCandidate& b = cands[y.idx];
+            if (cand_fully_anchored(a) != cand_fully_anchored(b)) return cand_fully_anchored(a);
+            if (cand_length(a) != cand_length(b)) return cand_length(a) > cand_length(b);
+            if (std::fabs(x.f - y.f) > 0.0f) return x.f > y.f;
+            if (a.position != b.position) return a.position < b.position;
+            return a.alt < b.alt;
+        });
+        const Row* pick = nullptr;
+        for (auto& r : rows)
+            if (cand_equals(cands[r.idx], t) && cand_fully_anchored(cands[r.idx])) { pick = &r; break; }
+        if (!pick)
+            for (auto& r : rows)
+                if (r.f >= freq_threshold && r.f / tf > freq_ratio_threshold) { pick = &r; break; }
+        if (!pick) continue;
+        HostCandidate& m = cands[pick->idx];
+        collapsed++;
+        for (int d = 0; d < 3; d++) {   // Collapse :81-90
+            m.support_by_dir[d] += t.support_by_dir[d];
+            m.well_anchored_by_dir[d] += t.well_anchored_by_dir[d];
+        }
+        m.open_left = m.open_left && t.open_left;
+        m.open_right = m.open_right && t.open_right;
+        removed[oi] = 1;
+    }
+    size_t w = 0;
+    for (size_t i = 0; i < n; i++)
+        if (!removed[i]) { if (w != i) cands[w] = std::move(cands[i]); w++; }
+    cands.resize(w);
+    return collapsed;
+}
+}  // extern "C++"
+
 // IAlleleCaller.Call for the host-found insertion / deletion candidates of `keys`: anchor-resolved counts of every
 // block a candidate touches -> call_spanning_kernel -> callable candidates with their records.
 static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, std::vector<PiscesCalledAllele>& recs,
-                             std::vector<HostCandidate>& called, int64_t* n_called)
+                             std::vector<HostCandidate>& called, int64_t* n_called, int64_t* n_collapsed)
 {
     recs.clear();
     called.clear();
-    std::vector<const HostCandidate*> cands;
+    *n_collapsed = 0;
+    std::vector<HostCandidate> work;   // a copy: the blocks keep their candidates until DoneProcessing
     for (int32_t key : keys)
-        for (auto& c : h->blocks[key].cands) cands.push_back(&c);
-    if (cands.empty()) return PISCES_OK;
+        for (auto& c : h->blocks[key].cands) work.push_back(c);
+    if (work.empty()) return PISCES_OK;
+    std::vector<const HostCandidate*> cands;
+    for (auto& c : work) cands.push_back(&c);
     const int bs = h->cfg.block_size;
     // start / end points (CoverageCalculator.Compute :27-41)
     auto endpoints = [](const HostCandidate& c, int32_t& sp, int32_t& ep) {
@@ -960,9 +1072,46 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, std
     } else {
         PISCES_HIP_CHECK(h, h->d_counts.reserve(PISCES_COUNTS_PER_LOCUS));
     }
+    auto atype = [](char ch) { return ch == 'A' ? 0 : ch == 'G' ? 1 : ch == 'C' ? 2 : ch == 'T' ? 3 : 4; };
+    auto to_dev = [&](const HostCandidate& c, DevCandidate& d) {
+        std::memset(&d, 0, sizeof(d));
+        d.position = c.position;
+        d.category = c.category;
+        d.ref_len = (int32_t)c.ref.size();
+        d.alt_len = (int32_t)c.alt.size();
+        for (int k = 0; k < 3; k++) { d.sup[k] = c.support_by_dir[k]; d.anch[k] = c.well_anchored_by_dir[k]; }
+        d.first_base = d.last_base = PISCES_ALLELE_N;
+        if (c.category == PISCES_CAT_INSERTION && c.alt.size() >= 2) {
+            d.first_base = atype(c.alt[1]);
+            d.last_base = atype(c.alt[c.alt.size() - 1]);
+        }
+        int32_t sp, ep;
+        endpoints(c, sp, ep);
+        d.start_idx = locus_index(sp);
+        d.end_idx = locus_index(ep);
+    };
+    if (h->cfg.collapse) {
+        // the collapser's frequencies: host copy of the anchor-resolved counts of the touched blocks, same coverage function
+        std::vector<int32_t> host_counts((size_t)std::max(n_tiles, 1) * kTile * PISCES_COUNTS_PER_LOCUS, 0);
+        if (n_tiles > 0) {
+            PISCES_HIP_CHECK(h, hipMemcpyAsync(host_counts.data(), h->d_counts.p, host_counts.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+        }
+        const int32_t stitched = h->cfg.expect_stitched_reads;
+        *n_collapsed = collapse_candidates(work, h->cfg.collapse_freq_threshold, h->cfg.collapse_freq_ratio_threshold, [&](const HostCandidate& c) {
+            DevCandidate d;
+            to_dev(c, d);
+            const SpanningCoverage sc = spanning_coverage(d, host_counts.data(), stitched);
+            const int support = c.support_by_dir[0] + c.support_by_dir[1] + c.support_by_dir[2];
+            if (sc.total == 0) return 0.0f;                       // CalledAllele.Frequency (CalledAllele.cs:49-52)
+            const float f = (float)support / (float)sc.total;
+            return f < 1.0f ? f : 1.0f;
+        });
+        cands.clear();
+        for (auto& c : work) cands.push_back(&c);
+    }
     std::vector<DevCandidate> dc(cands.size());
     std::vector<uint8_t> pool;
-    auto atype = [](char ch) { return ch == 'A' ? 0 : ch == 'G' ? 1 : ch == 'C' ? 2 : ch == 'T' ? 3 : 4; };
     for (size_t i = 0; i < cands.size(); i++) {
         const HostCandidate& c = *cands[i];
         DevCandidate& d = dc[i];
@@ -1043,7 +1192,9 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
         std::vector<HostCandidate> span_cands;
         int32_t rc = call_blocks(h, keys, point_recs, &called);
         if (rc) return rc;
-        rc = call_spanning(h, keys, span_recs, span_cands, &called);
+        int64_t collapsed = 0;
+        rc = call_spanning(h, keys, span_recs, span_cands, &called, &collapsed);
+        h->pending_collapsed = collapsed;
         if (rc) return rc;
         // per locus: drop the Reference row when a variant is reported there (AlleleCaller.cs:146-147), then order by
         // position, reference allele, alternate allele (:172-176; ordinal order of upper-case ASCII allele strings)
@@ -1121,6 +1272,7 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
     }
     h->last_block = nullptr;
     h->stats[0] += h->pending_called;
+    h->stats[1] += h->pending_collapsed;
     h->last_up_to_block_key = final_flush ? -1 : block_key(h, up_to_position);
     h->pending_valid = false;
     h->pending.clear();

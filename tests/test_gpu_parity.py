@@ -512,3 +512,58 @@ def test_streaming_surface_equals_device_resident_surface_at_size(torch_cuda):
     streamed = np.concatenate(streamed)
     assert streamed.tobytes() == resident.tobytes()
     assert stats["reads"] == A * 500 and stats["observations"] == p.n_obs
+
+
+def test_collapser_on_open_ended_indels_matches_oracle(torch_cuda):
+    """with the collapser on (the reference default) reads that end inside an insertion, start inside it, end in
+    a deletion or start with one produce open-ended candidates, which VariantCollapser folds into the anchored candidate
+    (VariantCollapser.cs:31-174).  The library collapses its insertion / deletion candidates on the host with frequencies from the
+    device counts; SNV twins are the counts already.  Records, allele strings and TotalNumCalled against the oracle."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(5)
+    ref = bytes(rng.choice(list(b"ACGT"), 900).astype(np.uint8))
+    P, INS = 300, b"ACGTTGCA"      # insertion after position P
+    Q, DEL = 520, 6                # deletion of positions Q+1 .. Q+DEL
+    reads = []
+
+    def add(pos, ops, seq, i):
+        q = np.where(rng.random(len(seq)) < 0.01, 12, 37).astype(np.uint8)
+        reads.append({"pos": pos, "cigar": ops, "seq": seq.decode(), "quals": q.tolist(), "reverse": bool(i % 2)})
+
+    for i in range(60):            # plain coverage over both sites
+        add(P - 70, [("M", 150)], ref[P - 71: P + 79], i)
+        add(Q - 70, [("M", 150)], ref[Q - 71: Q + 79], i)
+    for i in range(40):            # the full insertion, anchored on both sides
+        add(P - 50, [("M", 51), ("I", len(INS)), ("M", 60)], ref[P - 51: P] + INS + ref[P: P + 60], i)
+    for i in range(16):            # reads that end inside the insertion (open on the right)
+        k = 3 + i % 4
+        add(P - 60, [("M", 61), ("I", k)], ref[P - 61: P] + INS[:k], i)
+    for i in range(16):            # reads that start inside the insertion (open on the left)
+        k = 3 + i % 4
+        add(P + 1, [("I", k), ("M", 80)], INS[len(INS) - k:] + ref[P: P + 80], i)
+    for i in range(40):            # the full deletion
+        add(Q - 50, [("M", 51), ("D", DEL), ("M", 60)], ref[Q - 51: Q] + ref[Q + DEL: Q + DEL + 60], i)
+    for i in range(12):            # reads that end in the deletion / start with it
+        add(Q - 60, [("M", 61), ("D", DEL)], ref[Q - 61: Q], i)
+        add(Q + DEL + 1, [("D", DEL), ("M", 70)], ref[Q + DEL: Q + DEL + 70], i)
+    batch = _abi.ReadBatch(reads)
+    refa = np.frombuffer(ref, dtype=np.uint8)
+    out = {}
+    for collapse in (0, 1):
+        cfg = _abi.default_config(collapse=collapse)
+        exp, exp_alleles, _, exp_called = orc.run_reads_full(batch, refa, 1, len(ref), cfg)
+        with engine.HipVariantCaller(cfg) as c:
+            c.SetReference(refa)
+            c.AddAlleleCounts(batch)
+            got, got_alleles = c.CallWithAlleles()
+            stats = c.Stats()
+        assert_records_match(got, exp)
+        assert got_alleles == exp_alleles
+        assert stats["TotalNumCalled"] == exp_called
+        out[collapse] = (got, got_alleles, stats)
+    # collapsing happened and changed the call set: fewer rows, more support on the anchored insertion
+    assert out[1][2]["TotalNumCollapsed"] > 0 and out[0][2]["TotalNumCollapsed"] == 0
+    full = ("%c" % ref[P - 1], ("%c" % ref[P - 1]) + INS.decode())
+    sup = {k: [int(r["allele_support"]) for r, a in zip(out[k][0], out[k][1]) if a == full and r["position"] == P] for k in (0, 1)}
+    assert sup[0] and sup[1] and sup[1][0] > sup[0][0]
+    assert len(out[1][0]) <= len(out[0][0])
