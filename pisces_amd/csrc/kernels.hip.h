@@ -615,6 +615,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
     __syncthreads();
 
     {
+        // single-round launches (NW = 2): streaming waves win the issue arbitration over waves in their call phase — the launch
+        // ends with the slowest tile, and a tile that is still streaming has its whole call phase ahead of it (+1.5-2.5 % there;
+        // with several rounds per launch it delays the calls that free wave slots and costs 1.4 %)
+        if (NW == 2) __builtin_amdgcn_s_setprio(3);
         const uint32_t min_bq_shifted = (uint32_t)min(max(P.min_bq, 0), 255) << 24;
 #if defined(PISCES_ABLATE) && PISCES_ABLATE == 2
         uint32_t acc = 0;   // development ablation: loads only
@@ -634,6 +638,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
 #endif
     }
     __syncthreads();
+    if (NW == 2) __builtin_amdgcn_s_setprio(0);
 #if defined(PISCES_ABLATE) && PISCES_ABLATE >= 1
     if (threadIdx.x == 0) { tile_results[t].record_begin = 0; tile_results[t].n_records = hist[5 + l]; }
     return;
