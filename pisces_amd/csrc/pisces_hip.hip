@@ -828,10 +828,10 @@ static void launch_call_tiles(PiscesHip* h, hipStream_t s, const uint32_t* d_tup
     const uint32_t lds = (uint32_t)h->lds_pad;
     if (h->kernel_variant >= 2 && h->cfg.min_base_call_quality <= 255) {   // the wave forms compare the quality byte in place
         // Two waves per tile shorten the call phase (Reference / q-score work and the strand-bias statistics run side by
-        // side) and pay for it in registers (128 VGPRs for 8 tiles per CU).  That wins while the whole launch is
-        // resident at once and the call phase of the last tiles is exposed; beyond that tiles interleave on their own
-        // and one wave per tile (168 VGPRs, no spills) streams better.
-        const bool two = h->kernel_variant == 3 || (h->kernel_variant == 4 && (int64_t)n_tiles <= (int64_t)h->n_cus * 8);
+        // side) and pay for it in registers (128 VGPRs for 8 tiles per CU).  Measured (tools/kbench.py, 500x): that wins up
+        // to ~8 k tiles per launch (56 % vs 49 % at 2048 tiles, 62 % vs 60 % at 8192); beyond that tiles interleave on their
+        // own and one wave per tile (no spills, 12 tiles per CU) streams better (68.5 % vs 66 % at 15 625 tiles).
+        const bool two = h->kernel_variant == 3 || (h->kernel_variant == 4 && (int64_t)n_tiles <= (int64_t)h->n_cus * 32);
         if (!two)
             hipExtLaunchKernelGGL(call_tiles_wave_kernel<1>, dim3((unsigned)n_tiles), dim3(64), lds, s, e0, e1, 0u, d_tuples, d_tiles,
                                   n_tiles, d_ref, ref_start, ref_len, d_records, d_tr, h->P);
