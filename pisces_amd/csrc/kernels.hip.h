@@ -961,15 +961,19 @@ __global__ __launch_bounds__(kBlock, 4) void call_counts_kernel(
 // directory), then each tile's valid slots are copied, in slot order, to out[offsets[t] ..].  The result is the
 // called alleles of the whole launch sorted by (position, allele) in one contiguous buffer.
 __global__ __launch_bounds__(1024) void scan_tile_counts_kernel(const PiscesTileResult* __restrict__ tr, int32_t n_tiles,
-                                                                int32_t* __restrict__ offsets, int32_t* __restrict__ total)
+                                                                int32_t* __restrict__ offsets, int32_t* __restrict__ total,
+                                                                int32_t* __restrict__ called_out /* optional */)
 {
     __shared__ int s_part[1024];
     __shared__ int s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
+    __shared__ int s_called;
+    if (threadIdx.x == 0) { s_carry = 0; s_called = 0; }
     __syncthreads();
+    int called = 0;   // IAlleleCaller.TotalNumCalled of the launch: total[1]
     for (int base = 0; base < n_tiles; base += 1024) {
         const int i = base + threadIdx.x;
         const int v = i < n_tiles ? tr[i].n_records : 0;
+        if (i < n_tiles) called += tr[i].n_called;
         s_part[threadIdx.x] = v;
         __syncthreads();
         for (int d = 1; d < 1024; d <<= 1) {   // Hillis-Steele inclusive scan
@@ -983,7 +987,12 @@ __global__ __launch_bounds__(1024) void scan_tile_counts_kernel(const PiscesTile
         if (threadIdx.x == 1023) s_carry += s_part[1023];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total = s_carry;
+    if (called) atomicAdd(&s_called, called);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *total = s_carry;
+        if (called_out) *called_out = s_called;
+    }
 }
 
 __global__ __launch_bounds__(64) void gather_records_kernel(const PiscesCalledAllele* __restrict__ records,

@@ -138,11 +138,22 @@ struct PiscesHip {
     int64_t log_ub = 0;                      // entries of the current log, holes included (slots are reserved on the host)
     std::vector<long long> read_slots;
     DeviceBuf<int32_t> d_flags;              // [0] log overflow
-    DeviceBuf<uint8_t> d_stage;              // device copy of the packed read batch
-    uint8_t* h_stage = nullptr;              // pinned staging buffer
-    size_t h_stage_cap = 0;
+    // staging of host input, double-buffered: a pinned host buffer, its device copy and an event that fires when the device
+    // work reading them is done — add_reads returns without waiting for its own expansion kernel
+    struct Stage {
+        DeviceBuf<uint8_t> d;
+        uint8_t* h = nullptr;
+        size_t h_cap = 0;
+        hipEvent_t done = nullptr;
+        bool in_flight = false;
+    } stage[2];
+    int stage_cur = 0;
+    uint8_t* h_stage = nullptr;              // = stage[stage_cur].h after stage_reserve
+    DeviceBuf<uint8_t> d_stage_alias;        // unused placeholder (kept empty)
     DeviceBuf<int32_t> d_bucket;             // BucketMap tables
     std::vector<int32_t> bucket_host;
+    uint8_t* h_dl = nullptr;                 // pinned download buffer of flush
+    size_t h_dl_cap = 0;
     DeviceBuf<unsigned int> d_tile_cnt;
     DeviceBuf<long long> d_total;
 
@@ -353,9 +364,17 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     h->d_ref.release(); h->d_tuples.release(); h->d_tiles.release(); h->d_tile_results.release();
     h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release(); h->d_totals.release(); h->d_qlut.release(); h->d_gq_tail.release(); h->d_offsets.release(); h->d_compact.release();
     for (int i = 0; i < 2; i++) { h->d_log_pos[i].release(); h->d_log_tup[i].release(); }
-    h->d_log_n.release(); h->d_flags.release(); h->d_stage.release(); h->d_bucket.release(); h->d_tile_cnt.release(); h->d_total.release();
-    if (h->h_stage) (void)hipHostFree(h->h_stage);
+    h->d_log_n.release(); h->d_flags.release(); h->d_bucket.release(); h->d_tile_cnt.release(); h->d_total.release();
+    for (auto& st : h->stage) {
+        st.d.release();
+        if (st.h) (void)hipHostFree(st.h);
+        st.h = nullptr;
+        if (st.done) (void)hipEventDestroy(st.done);
+        st.done = nullptr;
+    }
     h->h_stage = nullptr;
+    if (h->h_dl) (void)hipHostFree(h->h_dl);
+    h->h_dl = nullptr;
     h->d_cands.release(); h->d_alleles.release(); h->d_cand_records.release(); h->d_cand_callable.release();
     for (hipEvent_t ev : h->ring) (void)hipEventDestroy(ev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -421,19 +440,37 @@ static int32_t log_reserve(PiscesHip* h, int64_t extra)
     return PISCES_OK;
 }
 
+// next staging pair with room for `bytes`; waits only for the work that used THIS pair two calls ago
 static int32_t stage_reserve(PiscesHip* h, size_t bytes)
 {
-    if (bytes > h->h_stage_cap) {
-        if (h->h_stage) (void)hipHostFree(h->h_stage);
-        h->h_stage = nullptr;
-        h->h_stage_cap = 0;
-        const size_t want = bytes + bytes / 2 + 4096;
-        PISCES_HIP_CHECK(h, hipHostMalloc((void**)&h->h_stage, want, hipHostMallocDefault));
-        h->h_stage_cap = want;
+    h->stage_cur ^= 1;
+    PiscesHip::Stage& st = h->stage[h->stage_cur];
+    if (!st.done) PISCES_HIP_CHECK(h, hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+    if (st.in_flight) {
+        PISCES_HIP_CHECK(h, hipEventSynchronize(st.done));
+        st.in_flight = false;
     }
-    PISCES_HIP_CHECK(h, h->d_stage.reserve(bytes));
+    if (bytes > st.h_cap) {
+        if (st.h) (void)hipHostFree(st.h);
+        st.h = nullptr;
+        st.h_cap = 0;
+        const size_t want = bytes + bytes / 2 + 4096;
+        PISCES_HIP_CHECK(h, hipHostMalloc((void**)&st.h, want, hipHostMallocDefault));
+        st.h_cap = want;
+    }
+    PISCES_HIP_CHECK(h, st.d.reserve(bytes));
+    h->h_stage = st.h;
     return PISCES_OK;
 }
+// call after the last device operation that reads the current staging pair has been enqueued
+static int32_t stage_release(PiscesHip* h)
+{
+    PiscesHip::Stage& st = h->stage[h->stage_cur];
+    PISCES_HIP_CHECK(h, hipEventRecord(st.done, h->stream));
+    st.in_flight = true;
+    return PISCES_OK;
+}
+#define D_STAGE(h) ((h)->stage[(h)->stage_cur].d.p)
 
 namespace pisces {
 // host-expanded observations: copied behind the current end of the log (its size is host-known: slots are reserved on the host)
@@ -466,13 +503,13 @@ int32_t pisces_hip_add_observations(PiscesHip* h, const int32_t* positions, cons
     if (rc) return rc;
     std::memcpy(h->h_stage, positions, (size_t)n * 4);
     std::memcpy(h->h_stage + (size_t)n * 4, tuples, (size_t)n * 4);
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_stage.p, h->h_stage, bytes, hipMemcpyHostToDevice, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(D_STAGE(h), h->h_stage, bytes, hipMemcpyHostToDevice, h->stream));
     const int c = h->log_cur;
     hipLaunchKernelGGL(log_append_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, h->stream,
-                       (const int32_t*)h->d_stage.p, (const uint32_t*)(h->d_stage.p + (size_t)n * 4), n, h->d_log_pos[c].p, h->d_log_tup[c].p,
+                       (const int32_t*)D_STAGE(h), (const uint32_t*)(D_STAGE(h) + (size_t)n * 4), n, h->d_log_pos[c].p, h->d_log_tup[c].p,
                        (long long)h->log_ub, h->d_log_n.p + 2);
     PISCES_HIP_CHECK(h, hipGetLastError());
-    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // the pinned staging buffer is reused by the next call
+    { int32_t rcs = stage_release(h); if (rcs) return rcs; }
     h->log_ub += n;
     return PISCES_OK;
 }
@@ -627,9 +664,9 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
     std::memcpy(st + off_quals, batch->quals, n_seq);
     if (batch->directions) std::memcpy(st + off_dirs, batch->directions, n_seq);
     std::memcpy(st + off_slots, slots.data(), ((size_t)nr + 1) * 8);
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_stage.p, st, total, hipMemcpyHostToDevice, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(D_STAGE(h), st, total, hipMemcpyHostToDevice, h->stream));
     DevReadBatch db;
-    const uint8_t* d = h->d_stage.p;
+    const uint8_t* d = D_STAGE(h);
     db.position = (const int32_t*)(d + off_pos);
     db.flags = d + off_flags;
     db.cigar_offset = (const int32_t*)(d + off_coff);
@@ -644,7 +681,7 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
     hipLaunchKernelGGL(expand_reads_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, h->stream, db, (const long long*)(d + off_slots),
                        minBQ, h->d_log_pos[c].p, h->d_log_tup[c].p, h->d_log_n.p + 2);
     PISCES_HIP_CHECK(h, hipGetLastError());
-    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // the pinned staging buffer is reused by the next call
+    { int32_t rcs = stage_release(h); if (rcs) return rcs; }
     h->log_ub += ub;
     return PISCES_OK;
 }
@@ -846,9 +883,9 @@ static void launch_call_tiles(PiscesHip* h, hipStream_t s, const uint32_t* d_tup
 
 // scan + gather: d_out = called alleles in (position, allele) order, *d_count = how many
 static void launch_compaction(hipStream_t s, const PiscesCalledAllele* d_records, const PiscesTileResult* d_tr, int32_t n_tiles,
-                              int32_t* d_offsets, PiscesCalledAllele* d_out, int32_t cap, int32_t* d_count)
+                              int32_t* d_offsets, PiscesCalledAllele* d_out, int32_t cap, int32_t* d_count, int32_t* d_called = nullptr)
 {
-    hipLaunchKernelGGL(scan_tile_counts_kernel, dim3(1), dim3(1024), 0, s, d_tr, n_tiles, d_offsets, d_count);
+    hipLaunchKernelGGL(scan_tile_counts_kernel, dim3(1), dim3(1024), 0, s, d_tr, n_tiles, d_offsets, d_count, d_called);
     hipLaunchKernelGGL(gather_records_kernel, dim3((unsigned)n_tiles), dim3(64), 0, s, d_records, d_tr, n_tiles, d_offsets, d_out, cap);
 }
 
@@ -896,19 +933,35 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
                            h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p, h->d_tile_results.p, h->P);
     }
     // tiles were built in ascending position order: the ordered compaction is AlleleCaller.Call's (position, ref, alt) order
-    launch_compaction(h->stream, h->d_records.p, h->d_tile_results.p, n_tiles, h->d_offsets.p, h->d_compact.p, (int32_t)cap, h->d_count.p);
+    launch_compaction(h->stream, h->d_records.p, h->d_tile_results.p, n_tiles, h->d_offsets.p, h->d_compact.p, (int32_t)cap, h->d_count.p,
+                      h->d_count.p + 1);
     PISCES_HIP_CHECK(h, hipGetLastError());
-    std::vector<PiscesTileResult> tr((size_t)n_tiles);
-    int32_t total = 0;
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(tr.data(), h->d_tile_results.p, tr.size() * sizeof(PiscesTileResult), hipMemcpyDeviceToHost, h->stream));
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(&total, h->d_count.p, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    // one synchronisation in the usual case: the two counters and a speculative prefix of the sorted records (one per locus plus
+    // a quarter) come back together into pinned memory; a second copy only when more alleles were called than that
+    int64_t n_loci_total = 0;
+    for (auto& t : tiles) n_loci_total += t.n_loci;
+    const size_t spec = std::min<size_t>(cap, (size_t)(n_loci_total + n_loci_total / 4 + 64));
+    const size_t dl_bytes = 16 + cap * sizeof(PiscesCalledAllele);
+    if (dl_bytes > h->h_dl_cap) {
+        if (h->h_dl) (void)hipHostFree(h->h_dl);
+        h->h_dl = nullptr;
+        h->h_dl_cap = 0;
+        PISCES_HIP_CHECK(h, hipHostMalloc((void**)&h->h_dl, dl_bytes + dl_bytes / 2, hipHostMallocDefault));
+        h->h_dl_cap = dl_bytes + dl_bytes / 2;
+    }
+    int32_t* hdr = (int32_t*)h->h_dl;
+    PiscesCalledAllele* hrec = (PiscesCalledAllele*)(h->h_dl + 16);
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(hdr, h->d_count.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(hrec, h->d_compact.p, spec * sizeof(PiscesCalledAllele), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
-    for (auto& r : tr) *n_called += r.n_called;
-    out.resize((size_t)total);
-    if (total > 0) {
-        PISCES_HIP_CHECK(h, hipMemcpyAsync(out.data(), h->d_compact.p, (size_t)total * sizeof(PiscesCalledAllele), hipMemcpyDeviceToHost, h->stream));
+    const int32_t total = hdr[0];
+    *n_called += hdr[1];
+    if ((size_t)total > spec) {
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(hrec + spec, h->d_compact.p + spec, ((size_t)total - spec) * sizeof(PiscesCalledAllele),
+                                           hipMemcpyDeviceToHost, h->stream));
         PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     }
+    out.assign(hrec, hrec + total);
     return PISCES_OK;
 }
 
