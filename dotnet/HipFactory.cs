@@ -20,10 +20,12 @@ namespace Pisces.Hip
 
         public HipFactory(PiscesApplicationOptions options) : base(options) { }
 
-        // The finder's SNV candidates are implied by the device counts; MNV/indel discovery stays with the
-        // reference finder until SURVEY §8 row f1 lands, so the base finder is kept and its SNVs are ignored
-        // by HipStateManager.AddCandidates.
-        protected override ICandidateVariantFinder CreateVariantFinder() { return base.CreateVariantFinder(); }
+        // SNV candidates are implied by the device counts and insertion / deletion candidates are found by the library
+        // itself from the reads handed to pisces_hip_add_reads (finder.cpp), so with MNV calling off (the default) no
+        // managed finder runs: a finder that yields nothing keeps SmallVariantCaller's loop unchanged.  With -callmnvs
+        // the reference finder is kept for the MNV candidates (HipStateManager.AddCandidates ignores the rest).
+        protected override ICandidateVariantFinder CreateVariantFinder()
+        { return _options.VariantCallingParameters.CallMNVs ? base.CreateVariantFinder() : new NoCandidates(); }
 
         protected override IStateManager CreateStateManager(ChrIntervalSet intervalSet, bool expectStitchedReads = false,
             bool expectCollapsedReads = true)
@@ -38,6 +40,12 @@ namespace Pisces.Hip
         {
             return new HipAlleleCaller(() => _engine, chrReference);
         }
+    }
+
+    internal sealed class NoCandidates : ICandidateVariantFinder
+    {
+        private static readonly CandidateAllele[] None = new CandidateAllele[0];
+        public IEnumerable<CandidateAllele> FindCandidates(Read read, string refChromosome, string chromosomeName) { return None; }
     }
 
     /// IStateManager over the native handle: AddAlleleCounts batches reads into a pinned SoA and calls
@@ -64,13 +72,14 @@ namespace Pisces.Hip
         /* ... */
     }
 
-    /// IAlleleCaller: Call(batch, source) = pisces_hip_flush(upTo) -> PiscesCalledAllele[] -> CalledAllele objects
-    /// in a SortedList<int, List<CalledAllele>> (already sorted by position, then ref/alt).
+    /// IAlleleCaller: Call(batch, source) = pisces_hip_flush_ex(upTo) -> PiscesCalledAllele[] (+ the allele strings of the called
+    /// insertions / deletions) -> CalledAllele objects in a SortedList<int, List<CalledAllele>> (already sorted by position, then
+    /// ref/alt).  No managed VariantCollapser is passed down: PiscesHipConfig.Collapse = options.Collapse does it natively.
     public class HipAlleleCaller : IAlleleCaller
     {
         private readonly Func<HipEngine> _engine; private readonly ChrReference _chr;
         public HipAlleleCaller(Func<HipEngine> engine, ChrReference chr) { _engine = engine; _chr = chr; }
-        public int TotalNumCollapsed { get { return 0; } }
+        public int TotalNumCollapsed { get { return (int)_engine().Stats()[1]; } }   // the library collapses insertion / deletion candidates (PiscesHipConfig.Collapse)
         public int TotalNumCalled { get { return (int)_engine().Stats()[0]; } }
         public SortedList<int, List<CalledAllele>> Call(ICandidateBatch batch, IAlleleSource source)
         { return _engine().Flush(((HipBatch)batch).UpToPosition, _chr); }
