@@ -320,6 +320,19 @@ def test_error_paths(torch_cuda):
         with pytest.raises(engine.PiscesHipError) as e:
             c.Call()                                                                # no reference set
         assert e.value.code == _abi.E_STATE
+        # a malformed batch is rejected as a whole, before any of it is committed (argument errors of the reference's walk:
+        # RegionStateManager.cs:363-364 position, Read.ValidateCigar, DirectionType range)
+        good = {"pos": 20, "seq": "ACGTACGT", "cigar": [("M", 8)], "quals": [30] * 8, "reverse": False}
+        for bad, needle in (({"pos": 0, "seq": "ACGT", "cigar": [("M", 4)], "quals": [30] * 4, "reverse": False}, "greater than 0"),
+                            ({"pos": 9, "seq": "ACGT", "cigar": [("M", 3), ("I", 4)], "quals": [30] * 4, "reverse": False}, "CIGAR"),
+                            ({"pos": 9, "seq": "ACGT", "cigar": [("M", 4)], "quals": [30] * 4, "reverse": False, "dirs": [0, 1, 3, 0]}, "CIGAR")):
+            before = c.Stats()
+            with pytest.raises(engine.PiscesHipError) as e:
+                c.AddAlleleCounts(_abi.ReadBatch([good, bad]))
+            assert e.value.code == _abi.E_INVALID_ARG and needle in e.value.message
+            assert c.Stats() == before and c.GetCounts(20, 8).sum() == 0
+        c.AddAlleleCounts(_abi.ReadBatch([good]))
+        assert c.GetCounts(20, 8).sum() == 8 and c.Stats()["observations"] == 9 and c.Stats()["reads"] == 1
     with pytest.raises(engine.PiscesHipError):
         engine.HipVariantCaller(_abi.default_config(strand_bias_model=_abi.SB_DIPLOID))
     with pytest.raises(engine.PiscesHipError):
