@@ -491,7 +491,17 @@ __device__ inline bool rmxn_should_filter_snv_lds(const uint8_t* win, int n, int
 {
     if (P.rmxn_max_len < 1) return false;
     if (freq >= P.rmxn_freq_limit) return false;
+    // min(c1, c2) >= m  <=>  c1 >= m and c2 >= m: the reference-base run decides first, and almost always at once.  Its eight
+    // neighbours are read together (one LDS round trip instead of a dependent chain); a run that stays inside them is exact.
+    if (idx >= 4 && idx + 4 < n) {
+        const bool l1 = win[idx - 1] == refBase, l2 = win[idx - 2] == refBase, l3 = win[idx - 3] == refBase, l4 = win[idx - 4] == refBase;
+        const bool r1 = win[idx + 1] == refBase, r2 = win[idx + 2] == refBase, r3 = win[idx + 3] == refBase, r4 = win[idx + 4] == refBase;
+        const int left = !l1 ? 0 : !l2 ? 1 : !l3 ? 2 : !l4 ? 3 : 4;
+        const int right = !r1 ? 0 : !r2 ? 1 : !r3 ? 2 : !r4 ? 3 : 4;
+        if (left < 4 && right < 4 && 1 + left + right < P.rmxn_min_rep) return false;
+    }
     int c1 = rmxn_run_lds(win, n, idx, refBase);
+    if (c1 < P.rmxn_min_rep) return false;
     int i1 = rmxn_run_lds(win, n, idx + 1, altBase);
     int i2 = rmxn_run_lds(win, n, idx, altBase);
     int c2 = i1 > i2 ? i1 : i2;
