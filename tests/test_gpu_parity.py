@@ -580,3 +580,57 @@ def test_collapser_on_open_ended_indels_matches_oracle(torch_cuda):
     sup = {k: [int(r["allele_support"]) for r, a in zip(out[k][0], out[k][1]) if a == full and r["position"] == P] for k in (0, 1)}
     assert sup[0] and sup[1] and sup[1][0] > sup[0][0]
     assert len(out[1][0]) <= len(out[0][0])
+
+
+def test_streaming_mix_of_snvs_and_indels_across_blocks_matches_oracle(torch_cuda):
+    """BASELINE config 3 / 4 in the small (without MNV calling): 12 000 loci x 120x in 80 amplicons over 13 blocks, sequencing errors,
+    planted SNVs, and at ~every 1000th locus a deletion (1-10 bp) or an insertion (1-6 bp) in a third of the reads — some of them
+    next to block edges.  Fed block by block through add_reads / flush (device read walk, host finder + collapser, device
+    spanning calls, block hold rule) and compared with the oracle over the whole region: records, allele strings, totals."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(2026)
+    n_amp, depth, L = 80, 120, 150
+    ref = bytes(rng.choice(list(b"ACGT"), n_amp * L + 400).astype(np.uint8))
+    start0 = 101
+    reads, batches = [], []
+    for a in range(n_amp):
+        start = start0 + a * L
+        plan = []
+        if a % 7 == 3:
+            plan.append((int(rng.integers(20, 120)), "D", int(rng.integers(1, 11)), 0.35))
+        if a % 7 == 5:
+            plan.append((int(rng.integers(20, 120)), "I", int(rng.integers(1, 7)), 0.35))
+        if a % 13 == 6:
+            plan.append((146, "D", 6, 0.4))          # reaches into the next amplicon (and, for some, the next block)
+        amp = _indel_reads(rng, ref, start, depth, plan, read_len=L, p_lowq=0.03)
+        # planted SNV and sequencing errors on the M-only part of the reads
+        snv_off, snv_alt = int(rng.integers(5, 15)), "ACGT"[int(rng.integers(0, 4))]
+        for r in amp:
+            s = list(r["seq"])
+            if r["cigar"][0][0] == "M" and r["cigar"][0][1] > snv_off + 1 and rng.random() < 0.2:
+                s[snv_off] = snv_alt
+            for j in np.nonzero(rng.random(len(s)) < 0.002)[0]:
+                s[j] = "ACGT"[int(rng.integers(0, 4))]
+            r["seq"] = "".join(s)
+        batches.append((start, amp))
+        reads += amp
+    refa = np.frombuffer(ref, dtype=np.uint8)
+    cfg = _abi.default_config()
+    exp, exp_alleles, _, exp_called = orc.run_reads_full(_abi.ReadBatch(reads), refa, 1, len(ref), cfg)
+    got, got_alleles = [], []
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(refa)
+        for start, amp in batches:
+            c.AddAlleleCounts(_abi.ReadBatch(amp))
+            g, ga = c.CallWithAlleles(start - 1)
+            got.append(g); got_alleles += ga
+        g, ga = c.CallWithAlleles(None)
+        got.append(g); got_alleles += ga
+        stats = c.Stats()
+    got = np.concatenate(got)
+    assert_records_match(got, exp)
+    assert got_alleles == exp_alleles
+    assert stats["TotalNumCalled"] == exp_called and stats["reads"] == len(reads)
+    cats = [int(_abi.info_category(i)) for i in got["info"]]
+    assert cats.count(_abi.CAT_DELETION) >= 10 and cats.count(_abi.CAT_INSERTION) >= 5 and cats.count(_abi.CAT_SNV) >= 40
+    assert (np.diff(got["position"]) >= 0).all()
