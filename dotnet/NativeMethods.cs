@@ -7,6 +7,14 @@ using System.Runtime.InteropServices;
 namespace Pisces.Hip
 {
     [StructLayout(LayoutKind.Sequential)]
+    public struct PiscesVcfConfig   // include/pisces_hip.h PiscesVcfConfig; filled from VcfWriterConfig (VcfFileWriter.cs:264-330), -1 = null
+    {
+        public int VariantQualityFilter, RMxNMaxRepeatLength, RMxNMinRepetitions, NoiseLevel;
+        public int OutputStrandBiasAndNoiseLevel, OutputNoCallFraction;
+        public float MinFrequencyThreshold, FrequencyFilterThreshold;
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
     public struct PiscesHipConfig
     {
         public int AbiVersion, MinBaseCallQuality, NoiseLevel, MaxVariantQscore, MinVariantQscore, VariantQscoreFilter,
@@ -84,6 +92,14 @@ namespace Pisces.Hip
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_get_counts(IntPtr handle, int startPosition, int n, [Out] int[] counts);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_add_gapped_mnv_ref(IntPtr handle, int[] positions, int[] counts, int n);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_stats(IntPtr handle, [Out] long[] stats4);
+
+        // measurement helpers (bench / diagnostics)
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_set_timing(IntPtr handle, int everyNth);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_last_kernel_ms(IntPtr handle, out float ms);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_probe_read_bandwidth(IntPtr handle, long nBytes, int reps, out double gbPerSecond);
+        // VCF body lines straight from the records (what VcfFileWriter.WriteListOfColocatedAlleles writes per allele, Pisces.IO/VcfFileWriter.cs:206-262)
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_vcf_default_config(out PiscesVcfConfig cfg);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern long pisces_hip_format_vcf(ref PiscesVcfConfig cfg, [MarshalAs(UnmanagedType.LPStr)] string chrom, PiscesCalledAllele[] records, long n, int[] candIndex, PiscesCandidate[] cands, byte[] alleles, [Out] byte[] text, long capacity);
 
         public static void Check(IntPtr handle, int rc)
         {

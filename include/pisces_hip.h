@@ -321,6 +321,27 @@ int64_t pisces_hip_find_indel_candidates(const PiscesReadBatch* batch, const uin
                                          int32_t min_base_call_quality, PiscesCandidate* out, int64_t capacity,
                                          uint8_t* alleles, int64_t allele_capacity, int64_t* allele_bytes);
 
+/* ---- VCF body lines (pure CPU) ---------------------------------------
+ * What the writer needs of VcfWriterConfig (src/lib/Pisces.IO/VcfFileWriter.cs:264-330). */
+typedef struct PiscesVcfConfig {
+    int32_t variant_quality_filter;             /* VariantQualityFilterThreshold (names the q<N> filter); -1 = null */
+    int32_t rmxn_max_repeat_length;             /* RMxNFilterMaxLengthRepeat, names R<M>x<N>; -1 = null */
+    int32_t rmxn_min_repetitions;               /* RMxNFilterMinRepetitions */
+    int32_t noise_level;                        /* EstimatedBaseCallQuality = NoiseLevelUsedForQScoring (the NL field) */
+    int32_t output_strand_bias_and_noise_level; /* ShouldOutputStrandBiasAndNoiseLevel */
+    int32_t output_no_call_fraction;            /* ShouldOutputNoCallFraction (-reportnocalls) */
+    float   min_frequency_threshold;            /* MinFrequencyThreshold: sets the number of VF decimals */
+    float   frequency_filter_threshold;         /* FrequencyFilterThreshold; < 0 = null */
+} PiscesVcfConfig;
+int32_t pisces_hip_vcf_default_config(PiscesVcfConfig* cfg);
+/* One VCF body line per record, uncrushed (VcfFileWriter.WriteListOfColocatedAlleles, VcfFileWriter.cs:206-262 with
+ * VcfFormatter.cs:52-448): CHROM POS . REF ALT QUAL FILTER DP=<n> GT:GQ:AD:DP:VF[:NL:SB][:NC] <sample>.  cand_index / cands /
+ * alleles are what pisces_hip_flush_ex returned (may be NULL when no row is an insertion / deletion).  Returns the number of
+ * bytes of text; when that exceeds `capacity` nothing is written and the call is repeated with a larger buffer; < 0 = error. */
+int64_t pisces_hip_format_vcf(const PiscesVcfConfig* cfg, const char* chrom, const PiscesCalledAllele* recs, int64_t n,
+                              const int32_t* cand_index, const PiscesCandidate* cands, const uint8_t* alleles, char* out,
+                              int64_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

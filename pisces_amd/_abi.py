@@ -88,6 +88,12 @@ class PiscesHipConfig(C.Structure):
     ]
 
 
+class PiscesVcfConfig(C.Structure):
+    _fields_ = [("variant_quality_filter", C.c_int32), ("rmxn_max_repeat_length", C.c_int32), ("rmxn_min_repetitions", C.c_int32),
+                ("noise_level", C.c_int32), ("output_strand_bias_and_noise_level", C.c_int32), ("output_no_call_fraction", C.c_int32),
+                ("min_frequency_threshold", C.c_float), ("frequency_filter_threshold", C.c_float)]
+
+
 def default_config(**overrides):
     """Reference defaults after VariantCallingParameters.Validate()
     (src/lib/Pisces.Domain/Options/VariantCallingParameters.cs:57-156)."""

@@ -252,6 +252,45 @@ def expand_reads(batch, min_base_call_quality=20):
         return pos[:n], tup[:n]
 
 
+def format_vcf(chrom, records, vcf_config=None, alleles=None, **overrides):
+    """VCF body lines of `records` (pisces_hip_format_vcf).  alleles: the (ref, alt) string pairs CallWithAlleles returned, needed
+    for insertion / deletion rows; vcf_config: _abi.PiscesVcfConfig or None for the defaults (+ field overrides)."""
+    cfg = vcf_config
+    if cfg is None:
+        cfg = _abi.PiscesVcfConfig()
+        _check(None, lib.pisces_hip_vcf_default_config(C.byref(cfg)))
+    for k, v in overrides.items():
+        setattr(cfg, k, v)
+    recs = np.ascontiguousarray(records)
+    n = len(recs)
+    idx = cands = pool_arr = None
+    if alleles is not None:
+        idx_l, cand_l, pool = [], [], bytearray()
+        for (r, a) in alleles:
+            if len(r) == 1 and len(a) == 1:
+                idx_l.append(-1)
+                continue
+            c = _abi.PiscesCandidate()
+            c.ref_len, c.alt_len, c.allele_offset = len(r), len(a), len(pool)
+            pool += r.encode() + a.encode()
+            idx_l.append(len(cand_l))
+            cand_l.append(c)
+        idx = np.array(idx_l, dtype=np.int32)
+        cands = (_abi.PiscesCandidate * max(len(cand_l), 1))(*cand_l)
+        pool_arr = np.frombuffer(bytes(pool) + b"\0", dtype=np.uint8).copy()
+    cap = 256 * max(n, 1)
+    while True:
+        buf = C.create_string_buffer(cap)
+        need = lib.pisces_hip_format_vcf(C.byref(cfg), chrom.encode(), recs.ctypes.data if n else None, n,
+                                         idx.ctypes.data if idx is not None else None, cands, pool_arr.ctypes.data if pool_arr is not None else None,
+                                         buf, cap)
+        if need < 0:
+            raise PiscesHipError(int(need), "format_vcf failed")
+        if need <= cap:
+            return buf.raw[:need].decode()
+        cap = int(need)
+
+
 def find_indel_candidates(batch, ref, min_base_call_quality=20):
     """Host finder for insertions / deletions (pisces_hip_find_indel_candidates): list of dicts in read order."""
     refa = np.ascontiguousarray(np.frombuffer(ref, dtype=np.uint8) if isinstance(ref, (bytes, bytearray)) else ref, np.uint8)
