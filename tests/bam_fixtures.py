@@ -1,0 +1,43 @@
+"""The end-to-end fixtures made from the reference's own BAMs (tests/golden/extract_bam_fixture.py): reads, reference window, the VCF body
+lines Pisces wrote / its functional tests expect, and the options of the run that produced them."""
+import os
+
+import numpy as np
+
+from pisces_amd import _abi
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+# name -> (chromosome, PiscesHipConfig overrides, VCF writer overrides, intervals (absolute, inclusive) or None, which expected rows)
+# low_depth_filter = -1: the functional-test harness builds its options without VariantCallingParameters.Validate(), which is what
+# turns the null LowDepthFilter into MinimumCoverage (VariantCallingParameters.cs:134-141), so zero-coverage rows stay PASS there.
+CASES = {
+    # SimpleSnv, last Execute: gVCF over Sample_S1_negative.picard (SomaticVariantCallerFunctionalTests.cs:31-65)
+    "bam_chr19": dict(chrom="chr19", cfg=dict(low_depth_filter=-1, emit_zero_coverage_refs=1), vcf=dict(),
+                      intervals=[(3118880, 3118890), (3118942, 3118942)], mode="all"),
+    # Pisces_PhiX (BugGenomeTests.cs:87-178): NL 1000, minimum frequency 0.0001, minimum variant q-score 3; the seven SNVs are the whole
+    # expected variant set
+    "bam_phix": dict(chrom="phix", cfg=dict(low_depth_filter=-1, noise_level=1000, min_frequency=0.0001, min_variant_qscore=3),
+                     vcf=dict(noise_level=1000, min_frequency_threshold=0.0001), intervals=None, mode="variants"),
+    # ExecuteEdgeInsertion (:540-612): the whole gVCF of the run, 127 rows
+    "bam_edge_ins": dict(chrom="chr7", cfg=dict(low_depth_filter=-1), vcf=dict(), intervals=None, mode="all"),
+    # the deletion twin (:462-538): exactly one variant
+    "bam_edge_del": dict(chrom="chr7", cfg=dict(low_depth_filter=-1), vcf=dict(), intervals=None, mode="variant_alleles"),
+}
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    batch = _abi.ReadBatch.from_arrays(position=z["position"], flags=z["flags"], cigar_offset=z["cigar_offset"], cigar_op=z["cigar_op"],
+                                       cigar_len=z["cigar_len"], seq_offset=z["seq_offset"], bases=z["bases"], quals=z["quals"])
+    return z, batch
+
+
+def check_lines(case, lines, expected):
+    """lines: VCF body lines we produced for the run; expected: the fixture's rows."""
+    if case["mode"] == "all":
+        assert lines == expected
+    elif case["mode"] == "variants":
+        assert [l for l in lines if l.split("\t")[4] != "."] == expected
+    else:
+        assert ["\t".join(l.split("\t")[:5]) for l in lines if l.split("\t")[4] != "."] == expected

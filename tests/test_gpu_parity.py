@@ -634,3 +634,35 @@ def test_streaming_mix_of_snvs_and_indels_across_blocks_matches_oracle(torch_cud
     cats = [int(_abi.info_category(i)) for i in got["info"]]
     assert cats.count(_abi.CAT_DELETION) >= 10 and cats.count(_abi.CAT_INSERTION) >= 5 and cats.count(_abi.CAT_SNV) >= 40
     assert (np.diff(got["position"]) >= 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["bam_chr19", "bam_phix", "bam_edge_ins", "bam_edge_del"])
+def test_reference_bams_through_the_library_give_the_vcf_rows_pisces_wrote(torch_cuda, name):
+    """End to end on the device: the reads of the reference's own test BAMs through the streaming surface (device read walk, finder,
+    collapser, call kernels) and pisces_hip_format_vcf must reproduce the VCF body lines Pisces wrote for them byte for byte, and
+    the records must equal the oracle's (tests/bam_fixtures.py, tests/golden/extract_bam_fixture.py)."""
+    from pisces_amd import engine
+    from tests import bam_fixtures
+    case = bam_fixtures.CASES[name]
+    z, batch = bam_fixtures.load(name)
+    off = int(z["offset"])
+    cfg = _abi.default_config(**case["cfg"])
+    intervals = [(a - off, b - off) for a, b in case["intervals"]] if case["intervals"] else None
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(z["ref"])
+        if intervals:
+            c.SetIntervals(intervals)
+        c.AddAlleleCounts(batch)
+        got, got_alleles = c.CallWithAlleles()
+    exp, exp_alleles = [], []
+    for start, loci in ([(a, b - a + 1) for a, b in intervals] if intervals else [(1, len(z["ref"]))]):
+        r, a, _, _ = orc.run_reads_full(batch, z["ref"], start, loci, cfg)
+        exp.append(r)
+        exp_alleles += a
+    assert_records_match(got, np.concatenate(exp))
+    assert got_alleles == exp_alleles
+    got = got.copy()
+    got["position"] += off
+    text = engine.format_vcf(case["chrom"], got, alleles=got_alleles, **case["vcf"])
+    bam_fixtures.check_lines(case, text.rstrip("\n").split("\n") if text else [], [str(x) for x in z["expected_vcf"]])

@@ -481,3 +481,26 @@ def test_variant_collapser_reference_cases(case):
             assert sum(out[0].support_by_dir) == case["expected_support_first"]
     run(case["candidates"])
     run(list(reversed(case["candidates"])))
+
+
+# ---- end to end: the reference's own BAMs -> the VCF rows Pisces wrote for them -----------------------------------------------
+@pytest.mark.parametrize("name", ["bam_chr19", "bam_phix", "bam_edge_ins", "bam_edge_del"])
+def test_reference_bams_give_the_vcf_rows_pisces_wrote(name):
+    """Reads decoded from the reference's test BAMs (filtered as AlignmentSource does), run through the oracle with the options of
+    the functional test that owns the BAM, formatted by pisces_hip_format_vcf: the body lines must be the ones Pisces left in its
+    test-data VCFs / quotes in its tests, byte for byte (tests/bam_fixtures.py names each source)."""
+    from pisces_amd import engine
+    from tests import bam_fixtures
+    case = bam_fixtures.CASES[name]
+    z, batch = bam_fixtures.load(name)
+    off = int(z["offset"])
+    cfg = _abi.default_config(**case["cfg"])
+    regions = [(a - off, b - a + 1) for a, b in case["intervals"]] if case["intervals"] else [(1, len(z["ref"]))]
+    lines = []
+    for start, loci in regions:
+        recs, alleles, _, _ = orc.run_reads_full(batch, z["ref"], start, loci, cfg)
+        recs = recs.copy()
+        recs["position"] += off
+        text = engine.format_vcf(case["chrom"], recs, alleles=alleles, **case["vcf"])
+        lines += text.rstrip("\n").split("\n") if text else []
+    bam_fixtures.check_lines(case, lines, [str(x) for x in z["expected_vcf"]])
