@@ -20,6 +20,9 @@ import os
 import sys
 import time
 
+# Streams of independent batches only overlap when each has its own hardware queue; the ROCm runtime shares 4 per process by default.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -29,7 +32,10 @@ N_LOCI = 100_000
 DEPTH = 500
 RING_BATCHES = 6        # 6 x ~200 MB of tuples > 256 MiB Infinity Cache
 BASE_SEED = 20260928
-TIME_EVERY = 1
+TIME_EVERY = 1          # dispatch-bound HIP events on every launch of the timed region: costs ~5 us per step in `value`, but the
+                        # durations then are those rocprofv3 reports for the same command (sampling every 4th launch times kernels that
+                        # start the instant their predecessor ends: 54.6 us against rocprofv3's 52.7 us, profiles/r01_rocprofv3_summary.md)
+PIPELINE_STREAMS = 3    # the extra 'pipelined' figure: steps issued round-robin over this many HIP streams
 
 
 def algorithmic_bytes(n_obs, n_loci, n_records):
@@ -92,6 +98,8 @@ def main():
     ap.add_argument("--loci", type=int, default=N_LOCI)
     ap.add_argument("--depth", type=int, default=DEPTH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the extra multi-stream figure (profiling runs: its overlapped "
+                    "launches would mix into the per-kernel statistics of the timed region)")
     args = ap.parse_args()
 
     import numpy as np
@@ -126,7 +134,7 @@ def main():
     cap = n_tiles * _abi.SLOTS_PER_TILE   # slot layout (include/pisces_hip.h PiscesTileResult): no allocation atomics
     records = torch.zeros(cap * 64, dtype=torch.uint8, device=dev)
     tile_results = torch.zeros(n_tiles * _abi.TILE_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream(dev)
+    stream = torch.cuda.Stream(dev) if os.environ.get('BENCH_OWN_STREAM') else torch.cuda.current_stream(dev)
 
     def step(i):
         p = ring[i % RING_BATCHES]
@@ -172,6 +180,37 @@ def main():
 
     total_records, total_loci = int(summary[0].item()), int(summary[1].item())
     value = total_loci / elapsed
+
+    # ---- extra figure, outside the timed region: the same K steps issued round-robin over PIPELINE_STREAMS HIP streams (own output
+    # buffers).  Batches are independent, so the call phase at the end of one launch overlaps the streaming phase of the next, which a
+    # single in-order stream forbids; this is how a host with several blocks in flight drives the library.
+    pipelined_elapsed = None
+    if not args.no_pipelined:
+        p_streams = [torch.cuda.Stream(dev) for _ in range(PIPELINE_STREAMS)]
+        p_records = [records] + [torch.zeros_like(records) for _ in range(PIPELINE_STREAMS - 1)]
+        p_results = [tile_results] + [torch.zeros_like(tile_results) for _ in range(PIPELINE_STREAMS - 1)]
+
+        def pstep(i):
+            p, k = ring[i % RING_BATCHES], i % PIPELINE_STREAMS
+            caller.call_tiles(p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), 1, p.ref_len,
+                              p_records[k].data_ptr(), cap, p_results[k].data_ptr(), p_streams[k].cuda_stream)
+
+        for i in range(2 * PIPELINE_STREAMS):
+            pstep(i)
+        torch.cuda.synchronize(dev)
+        barrier()
+        tp0 = time.perf_counter()
+        for i in range(args.steps):
+            pstep(i)
+        torch.cuda.synchronize(dev)
+        barrier()
+        tp = torch.tensor([time.perf_counter() - tp0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+        pipelined_elapsed = float(tp.item())
+        for k in range(1, PIPELINE_STREAMS):   # every stream's last output equals a serial launch's (same batch -> same records)
+            trk = p_results[k].cpu().numpy().view(_abi.TILE_RESULT_DTYPE)
+            assert int(trk["n_candidate_loci"].sum()) == args.loci
     if rank == 0:
         # roofline of the dominant (only) kernel: algorithmic bytes per launch / mean kernel duration from HIP
         # events recorded on the launch stream around every TIME_EVERY-th launch of the timed region
@@ -215,6 +254,12 @@ def main():
         # context only (SURVEY 8d asks for the measured peak beside the spec one; frac stays against the spec peak):
         # a plain streaming read of 1 GiB with the kernel's own load pattern
         out["roofline"]["peak_measured_read"] = caller.probe_read_bandwidth(1 << 30, 6)
+        if pipelined_elapsed is not None:
+            p_ms = pipelined_elapsed / args.steps * 1e3
+            out["pipelined"] = {"streams": PIPELINE_STREAMS, "value": args.loci * world * args.steps / pipelined_elapsed,
+                                "unit": "candidate loci/s", "ms_per_step": p_ms,
+                                "hbm_frac": bytes_per_launch / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "note": "same steps over several HIP streams; not the contract's value, not a per-kernel roofline"}
         if not args.no_cpu_baseline and world == 1:   # timed on rank 0 at N=1 only
             out["cpu_baseline"], out["cpu_baseline_threads"] = cpu_baseline(torch, ring[0], cfg)
         print(json.dumps(out), flush=True)
