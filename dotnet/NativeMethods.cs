@@ -26,6 +26,7 @@ namespace Pisces.Hip
         public float RmxnFrequencyLimit;
         public int Collapse;
         public float CollapseFreqThreshold, CollapseFreqRatioThreshold;
+        public int CallMnvs, MaxMnvLength, MaxGapBetweenMnv;   // PiscesApplicationOptions.CallMNVs / MaxSizeMNV / MaxGapBetweenMNV
     }
 
     [StructLayout(LayoutKind.Sequential, Pack = 8, Size = 64)]

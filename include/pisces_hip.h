@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define PISCES_HIP_ABI_VERSION 1
+#define PISCES_HIP_ABI_VERSION 2
 
 /* ---- error codes -------------------------------------------------------- */
 #define PISCES_OK                 0
@@ -118,6 +118,10 @@ typedef struct PiscesHipConfig {
                                          the device counts already); reference default true, see pisces_hip_default_config */
     float   collapse_freq_threshold;        /* CollapseFreqThreshold, 0f */
     float   collapse_freq_ratio_threshold;  /* CollapseFreqRatioThreshold, 0.5f */
+    int32_t call_mnvs;                /* PiscesApplicationOptions.CallMNVs, 0: with it on, SNV / MNV candidates come from the read walk
+                                         (CandidateVariantFinder.cs:90-232), no longer from the allele counts */
+    int32_t max_mnv_length;           /* MaxSizeMNV, 3 */
+    int32_t max_gap_between_mnv;      /* MaxGapBetweenMNV, 1 */
 } PiscesHipConfig;
 
 /* ---- one called allele (64 bytes; what CalledAllele carries to the VCF writer,

@@ -6,6 +6,7 @@
  */
 #include "pisces_oracle.h"
 
+#include <ctype.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1384,26 +1385,297 @@ int32_t orc_collapse(OrcCandidate* cands, int32_t n, const OrcState* src, float 
     return w;
 }
 
-/* AlleleCaller.CallForPositions :60-141 (no collapser, no MNV reallocation, no forced alleles) over an explicit batch of
- * candidates (ICandidateBatch.GetCandidates): ProcessVariant + IsCallable per candidate, then per position the
+/* =====================================================================================
+ * exe/Pisces/Logic/VariantCalling/MnvReallocator.cs
+ * ===================================================================================== */
+typedef struct PtrList { OrcCalled** p; int64_t n, cap; } PtrList;
+static void pl_push(PtrList* l, OrcCalled* v)
+{
+    if (l->n == l->cap) { l->cap = l->cap ? l->cap * 2 : 16; l->p = (OrcCalled**)realloc(l->p, sizeof(OrcCalled*) * (size_t)l->cap); }
+    l->p[l->n++] = v;
+}
+static void pl_remove(PtrList* l, const OrcCalled* v)   /* List<T>.Remove: first element that is this object */
+{
+    for (int64_t i = 0; i < l->n; i++)
+        if (l->p[i] == v) { memmove(&l->p[i], &l->p[i + 1], sizeof(OrcCalled*) * (size_t)(l->n - i - 1)); l->n--; return; }
+}
+/* stable insertion sort (LINQ OrderBy is stable) */
+static void pl_sort(PtrList* l, int (*cmp)(const OrcCalled*, const OrcCalled*))
+{
+    for (int64_t i = 1; i < l->n; i++) {
+        OrcCalled* x = l->p[i];
+        int64_t j = i;
+        while (j > 0 && cmp(l->p[j - 1], x) > 0) { l->p[j] = l->p[j - 1]; j--; }
+        l->p[j] = x;
+    }
+}
+/* .OrderByDescending(alt.Length).ThenByDescending(AlleleSupport).ThenBy(alt).ThenBy(ref) :27 */
+static int overlap_order(const OrcCalled* a, const OrcCalled* b)
+{
+    int la = (int)strlen(a->alt), lb = (int)strlen(b->alt);
+    if (la != lb) return la > lb ? -1 : 1;
+    if (a->allele_support != b->allele_support) return a->allele_support > b->allele_support ? -1 : 1;
+    int r = strcmp(a->alt, b->alt);
+    return r ? r : strcmp(a->ref, b->ref);
+}
+/* .OrderBy(position) then the same keys :17 */
+static int failed_order(const OrcCalled* a, const OrcCalled* b)
+{
+    if (a->position != b->position) return a->position < b->position ? -1 : 1;
+    return overlap_order(a, b);
+}
+
+/* CreateVariant :151-168 */
+static OrcCalled* mnv_create_variant(int coordinate, int alleleSupport, const char* alt, int alt_n, const char* ref, int ref_n,
+                                     const int32_t* supportByDirection)
+{
+    OrcCalled* v = (OrcCalled*)calloc(1, sizeof(OrcCalled));
+    int same = (alt_n == ref_n);
+    for (int i = 0; same && i < alt_n; i++)
+        if (toupper((unsigned char)alt[i]) != toupper((unsigned char)ref[i])) same = 0;
+    v->category = same ? PISCES_CAT_REFERENCE : (alt_n > 1 ? PISCES_CAT_MNV : PISCES_CAT_SNV);
+    v->genotype = same ? PISCES_GT_HOM_REF : PISCES_GT_HET_ALT_REF;   /* CalledAllele() / CalledAllele(category) ctors */
+    v->position = coordinate;
+    v->allele_support = alleleSupport;
+    memcpy(v->alt, alt, (size_t)alt_n); v->alt[alt_n] = 0;
+    memcpy(v->ref, ref, (size_t)ref_n); v->ref[ref_n] = 0;
+    if (supportByDirection) for (int d = 0; d < 3; d++) v->support_by_dir[d] = supportByDirection[d];
+    return v;
+}
+
+/* BreakOffEdgeReferences :212-241 (one element) */
+static OrcCalled* mnv_break_off_edge_references(OrcCalled* allele)
+{
+    if (allele->category != PISCES_CAT_MNV) return allele;
+    int n = (int)strlen(allele->ref), leftAdjust = 0, rightAdjust = 0;
+    for (int i = 0; i < n; i++) { if (allele->ref[i] != allele->alt[i]) break; leftAdjust++; }
+    for (int i = 0; i < n; i++) { int k = n - 1 - i; if (allele->ref[k] != allele->alt[k]) break; rightAdjust++; }
+    int len = (int)strlen(allele->alt) - (leftAdjust + rightAdjust), rlen = n - (leftAdjust + rightAdjust);
+    OrcCalled* rest = mnv_create_variant(allele->position + leftAdjust, allele->allele_support, allele->alt + leftAdjust, len,
+                                         allele->ref + leftAdjust, rlen, allele->support_by_dir);
+    free(allele);
+    return rest;
+}
+
+/* CreateAllelesFromRemainder :170-210 */
+static void mnv_remainders(const OrcCalled* overlap, const OrcCalled* toReassign, PtrList* out)
+{
+    int overlapIndexInFailedMnv = overlap->position - toReassign->position;
+    int overlapAlleleLength = (int)strlen(overlap->alt);
+    int rightSideOverlap = overlapIndexInFailedMnv + overlapAlleleLength;
+    int altLen = (int)strlen(toReassign->alt);
+    PtrList tmp = {0};
+    if (altLen - rightSideOverlap > 0 && rightSideOverlap <= toReassign->position + altLen) {
+        OrcCalled* r = mnv_create_variant(toReassign->position + rightSideOverlap, toReassign->allele_support,
+                                          toReassign->alt + rightSideOverlap, altLen - rightSideOverlap,
+                                          toReassign->ref + rightSideOverlap, altLen - rightSideOverlap, toReassign->support_by_dir);
+        if (r->category != PISCES_CAT_REFERENCE) pl_push(&tmp, r); else free(r);
+    }
+    if (overlapIndexInFailedMnv > 0) {
+        OrcCalled* l = mnv_create_variant(toReassign->position, toReassign->allele_support, toReassign->alt, overlapIndexInFailedMnv,
+                                          toReassign->ref, overlapIndexInFailedMnv, toReassign->support_by_dir);
+        if (l->category != PISCES_CAT_REFERENCE) pl_push(&tmp, l); else free(l);
+    }
+    for (int64_t i = 0; i < tmp.n; i++) pl_push(out, mnv_break_off_edge_references(tmp.p[i]));
+    free(tmp.p);
+}
+
+/* IsPotentialOverlap :250-261 (one chromosome) */
+static int mnv_is_potential_overlap(const OrcCalled* callable, const OrcCalled* failed)
+{
+    int fl = (int)strlen(failed->alt), cl = (int)strlen(callable->alt);
+    return callable->position >= failed->position && callable->position <= failed->position + fl && cl <= fl &&
+           callable->position + cl <= failed->position + fl &&
+           (callable->category == PISCES_CAT_MNV || callable->category == PISCES_CAT_SNV || callable->category == PISCES_CAT_REFERENCE);
+}
+/* OverlapMatches :243-248 */
+static int mnv_overlap_matches(const OrcCalled* overlap, const OrcCalled* toReassign)
+{
+    int idx = overlap->position - toReassign->position, n = (int)strlen(overlap->alt);
+    return strncmp(overlap->alt, toReassign->alt + idx, (size_t)n) == 0;
+}
+
+/* ProcessOverlap :97-133 */
+static void mnv_process_overlap(int hasMax, int blockMaxPos, OrcCalled* overlap, OrcCalled* toReassign, PtrList* remainderAlleles,
+                                PtrList* outsideThisBlock)
+{
+    overlap->allele_support += toReassign->allele_support;
+    for (int d = 0; d < 3; d++) overlap->support_by_dir[d] += toReassign->support_by_dir[d];
+    pl_remove(remainderAlleles, toReassign);
+    PtrList remainders = {0};
+    mnv_remainders(overlap, toReassign, &remainders);
+    if (hasMax) {
+        if (overlap->position > blockMaxPos) { pl_remove(remainderAlleles, overlap); pl_push(outsideThisBlock, overlap); }
+        for (int64_t i = 0; i < remainders.n; i++) {
+            if (remainders.p[i]->position <= blockMaxPos) pl_push(remainderAlleles, remainders.p[i]);
+            else pl_push(outsideThisBlock, remainders.p[i]);
+        }
+    } else {
+        for (int64_t i = 0; i < remainders.n; i++) pl_push(remainderAlleles, remainders.p[i]);
+    }
+    free(remainders.p);
+}
+
+/* ReallocateFailedMnvs :12-95.  failed / callable hold heap OrcCalled objects; new objects are appended to callable or
+ * outsideThisBlock (which the caller maps back to candidates of the next block, AlleleCaller.cs:92-93).  The failed MNVs themselves
+ * stay owned by `failed`. */
+static void mnv_reallocate_failed(PtrList* failed, PtrList* callable, int hasMax, int blockMaxPos, PtrList* outsideThisBlock)
+{
+    PtrList ordered = {0};
+    for (int64_t i = 0; i < failed->n; i++) pl_push(&ordered, failed->p[i]);
+    pl_sort(&ordered, failed_order);
+    for (int64_t fi = 0; fi < ordered.n; fi++) {
+        PtrList remainderAlleles = {0};
+        pl_push(&remainderAlleles, ordered.p[fi]);
+        while (remainderAlleles.n > 0) {
+            OrcCalled* alleleToReassign = remainderAlleles.p[0];
+            PtrList overlaps = {0};
+            for (int64_t i = 0; i < callable->n; i++)
+                if (mnv_is_potential_overlap(callable->p[i], alleleToReassign)) pl_push(&overlaps, callable->p[i]);
+            pl_sort(&overlaps, overlap_order);   /* longest sub-MNVs first, support as tie-breaker */
+            OrcCalled* firstMatch = NULL;
+            int anyLongMatch = 0;
+            for (int64_t i = 0; i < overlaps.n; i++)
+                if (mnv_overlap_matches(overlaps.p[i], alleleToReassign)) {
+                    if (!firstMatch) firstMatch = overlaps.p[i];
+                    if (strlen(overlaps.p[i]->alt) > 1) anyLongMatch = 1;
+                }
+            free(overlaps.p);
+            int reallocated = 0;
+            if (hasMax) {
+                int altLen = (int)strlen(alleleToReassign->alt);
+                int distanceIntoNextBlock = alleleToReassign->position + (altLen - 1) - blockMaxPos;
+                if (distanceIntoNextBlock > 0 && !anyLongMatch) {
+                    if (alleleToReassign->position <= blockMaxPos) {
+                        /* peel off into the next block */
+                        int originalAlleleLength = (int)strlen(alleleToReassign->ref);
+                        OrcCalled* nextBlockVariant = mnv_create_variant(blockMaxPos + 1, 0,
+                            alleleToReassign->alt + (originalAlleleLength - distanceIntoNextBlock), distanceIntoNextBlock,
+                            alleleToReassign->ref + (originalAlleleLength - distanceIntoNextBlock), distanceIntoNextBlock, NULL);
+                        nextBlockVariant = mnv_break_off_edge_references(nextBlockVariant);
+                        mnv_process_overlap(hasMax, blockMaxPos, nextBlockVariant, alleleToReassign, &remainderAlleles, outsideThisBlock);
+                    } else {
+                        pl_remove(&remainderAlleles, alleleToReassign);
+                        pl_push(outsideThisBlock, alleleToReassign);
+                    }
+                    reallocated = 1;
+                }
+            }
+            if (!reallocated && firstMatch) {
+                mnv_process_overlap(hasMax, blockMaxPos, firstMatch, alleleToReassign, &remainderAlleles, outsideThisBlock);
+                reallocated = 1;
+            }
+            if (!reallocated) {
+                /* BreakDownToSingleNucCalls :135-149 */
+                int altLen = (int)strlen(alleleToReassign->alt);
+                for (int i = 0; i < altLen; i++) {
+                    OrcCalled* sn = mnv_create_variant(alleleToReassign->position + i, alleleToReassign->allele_support,
+                                                       alleleToReassign->alt + i, 1, alleleToReassign->ref + i, 1,
+                                                       alleleToReassign->support_by_dir);
+                    if (sn->category == PISCES_CAT_REFERENCE) { free(sn); continue; }
+                    if (hasMax && sn->position > blockMaxPos) pl_push(outsideThisBlock, sn);
+                    else pl_push(callable, sn);
+                }
+                pl_remove(&remainderAlleles, alleleToReassign);
+            }
+        }
+        free(remainderAlleles.p);
+    }
+    free(ordered.p);
+}
+
+/* test hook: MnvReallocator.ReallocateFailedMnvs over arrays.  callable[0..n_callable) is updated in place and grown (capacity
+ * cap_callable); outside[0..) receives the leftovers for the next block.  max_position < 0 = null.  Returns the new n_callable,
+ * *n_outside = number written. */
+int64_t orc_reallocate_failed_mnvs(const OrcCalled* failed, int64_t n_failed, OrcCalled* callable, int64_t n_callable, int64_t cap_callable,
+                                   int32_t max_position, OrcCalled* outside, int64_t cap_outside, int64_t* n_outside)
+{
+    PtrList f = {0}, c = {0}, o = {0};
+    for (int64_t i = 0; i < n_failed; i++) { OrcCalled* v = (OrcCalled*)malloc(sizeof(OrcCalled)); *v = failed[i]; pl_push(&f, v); }
+    for (int64_t i = 0; i < n_callable; i++) { OrcCalled* v = (OrcCalled*)malloc(sizeof(OrcCalled)); *v = callable[i]; pl_push(&c, v); }
+    mnv_reallocate_failed(&f, &c, max_position >= 0, max_position, &o);
+    int64_t nc = c.n, no = o.n;
+    for (int64_t i = 0; i < c.n && i < cap_callable; i++) callable[i] = *c.p[i];
+    for (int64_t i = 0; i < o.n && i < cap_outside; i++) outside[i] = *o.p[i];
+    if (n_outside) *n_outside = no;
+    /* objects may sit in several lists (a failed MNV that lies wholly in the next block is also in `outside`): free each once */
+    for (int64_t i = 0; i < o.n; i++) {
+        int dup = 0;
+        for (int64_t k = 0; k < f.n; k++) if (f.p[k] == o.p[i]) dup = 1;
+        for (int64_t k = 0; k < c.n; k++) if (c.p[k] == o.p[i]) dup = 1;
+        for (int64_t k = 0; k < i; k++) if (o.p[k] == o.p[i]) dup = 1;
+        if (!dup) free(o.p[i]);
+    }
+    for (int64_t i = 0; i < f.n; i++) free(f.p[i]);
+    for (int64_t i = 0; i < c.n; i++) free(c.p[i]);
+    free(f.p); free(c.p); free(o.p);
+    return nc;
+}
+
+/* AlleleCaller.CallForPositions :60-141 (collapser applied by the caller, no forced alleles) over an explicit batch of
+ * candidates (ICandidateBatch.GetCandidates): MNV candidates are processed first, the ones that are not callable are handed to
+ * MnvReallocator, what it pushes past max_cleared_position goes back to the state as candidates (the next block's), reference
+ * support taken by gapped MNVs is registered, then ProcessVariant + IsCallable per callable allele, and per position the
  * reference pruning, genotype, LowGQ filter and the (ref, alt) order of ComputeGenotypeAndFilterAllele :143-177. */
-int64_t orc_call_candidates(OrcState* s, const OrcCandidate* list, int64_t n_list, const uint8_t* ref_bases, int64_t ref_len,
-                            const PiscesHipConfig* cfg, PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out,
-                            int64_t* total_num_called)
+int64_t orc_call_candidates_max(OrcState* s, const OrcCandidate* list, int64_t n_list, const uint8_t* ref_bases, int64_t ref_len,
+                                const PiscesHipConfig* cfg, int32_t max_cleared_position, PiscesCalledAllele* out, int64_t capacity,
+                                OrcCalled* full_out, int64_t* total_num_called)
 {
     g_rmxn_ref = ref_bases;
     g_rmxn_ref_len = ref_len;
     int64_t totalNumCalled = 0;
-    int64_t n = 0, cap = 1024;
-    OrcCalled* called = (OrcCalled*)malloc(sizeof(OrcCalled) * (size_t)cap);
-    OrcCalled v;
+    PtrList callable = {0}, failedMnvs = {0}, outside = {0};
     for (int64_t i = 0; i < n_list; i++) {
-        orc_called_from_candidate(&v, &list[i]);
-        orc_process_variant(&v, s, cfg);
-        if (is_callable(&v, cfg, &totalNumCalled)) {
-            if (n == cap) { cap *= 2; called = (OrcCalled*)realloc(called, sizeof(OrcCalled) * (size_t)cap); }
-            called[n++] = v;
+        OrcCalled* v = (OrcCalled*)malloc(sizeof(OrcCalled));
+        orc_called_from_candidate(v, &list[i]);
+        if (v->category == PISCES_CAT_MNV) {
+            orc_process_variant(v, s, cfg);
+            if (is_callable(v, cfg, &totalNumCalled)) pl_push(&callable, v);
+            else pl_push(&failedMnvs, v);
+        } else {
+            pl_push(&callable, v);
         }
+    }
+    if (failedMnvs.n > 0) {
+        {   /* (PiscesApplicationOptions.UseMNVReallocation is declared but read nowhere: the caller always reallocates) */
+            mnv_reallocate_failed(&failedMnvs, &callable, max_cleared_position >= 0, max_cleared_position, &outside);
+            for (int64_t i = 0; i < outside.n; i++) {   /* source.AddCandidates(leftovers.Select(AlleleHelper.Map)) */
+                OrcCandidate c;
+                memset(&c, 0, sizeof(c));
+                c.position = outside.p[i]->position;
+                c.category = outside.p[i]->category;
+                strcpy(c.ref, outside.p[i]->ref);
+                strcpy(c.alt, outside.p[i]->alt);
+                for (int d = 0; d < 3; d++) c.support_by_dir[d] = outside.p[i]->support_by_dir[d];
+                if (c.category != PISCES_CAT_REFERENCE) (void)orc_add_candidate(s, &c);   /* outside the window: dropped */
+            }
+        }
+    }
+    /* GetRefSupportFromGappedMnvs :180-203 */
+    for (int64_t i = 0; i < callable.n; i++) {
+        const OrcCalled* a = callable.p[i];
+        if (a->category != PISCES_CAT_MNV) continue;
+        for (int k = 0; a->ref[k]; k++)
+            if (a->ref[k] == a->alt[k]) orc_add_gapped_mnv_ref(s, a->position + k, a->allele_support);
+    }
+
+    int64_t n = 0, cap = callable.n + 1;
+    OrcCalled* called = (OrcCalled*)malloc(sizeof(OrcCalled) * (size_t)cap);
+    for (int64_t i = 0; i < callable.n; i++) {
+        OrcCalled* v = callable.p[i];
+        orc_process_variant(v, s, cfg);
+        if (is_callable(v, cfg, &totalNumCalled)) called[n++] = *v;
+    }
+    {   /* free every object once */
+        for (int64_t i = 0; i < outside.n; i++) {
+            int dup = 0;
+            for (int64_t k = 0; k < failedMnvs.n && !dup; k++) dup = failedMnvs.p[k] == outside.p[i];
+            for (int64_t k = 0; k < i && !dup; k++) dup = outside.p[k] == outside.p[i];
+            if (!dup) free(outside.p[i]);
+        }
+        for (int64_t i = 0; i < failedMnvs.n; i++) free(failedMnvs.p[i]);
+        for (int64_t i = 0; i < callable.n; i++) free(callable.p[i]);
+        free(outside.p); free(failedMnvs.p); free(callable.p);
     }
 
     /* SortedList by position; per position sort by (ref, alt) :172-176. Stable enough: keys are unique
@@ -1439,6 +1711,15 @@ int64_t orc_call_candidates(OrcState* s, const OrcCandidate* list, int64_t n_lis
     }
     free(called);
     return n;
+}
+
+int64_t orc_call_candidates(OrcState* s, const OrcCandidate* list, int64_t n_list, const uint8_t* ref_bases, int64_t ref_len,
+                            const PiscesHipConfig* cfg, PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out,
+                            int64_t* total_num_called)
+{
+    /* one dense window = one block: MaxClearedPosition is its last position (RegionStateManager.cs:318-320) */
+    return orc_call_candidates_max(s, list, n_list, ref_bases, ref_len, cfg, s->start_position + s->n_loci - 1, out, capacity, full_out,
+                                   total_num_called);
 }
 
 /* The same over RegionState.GetAllCandidates :383-453: every candidate of the state plus (gVCF) a Reference candidate per
@@ -1527,8 +1808,8 @@ int64_t orc_run_reads_full(const PiscesReadBatch* b, const uint8_t* ref_bases, i
         r.is_reverse = b->flags[i] & 1;
         r.posmap_override = NULL;
         /* FindCandidates -> AddCandidates -> AddAlleleCounts (SmallVariantCaller.cs:92-98) */
-        int nc = orc_find_candidates(&r, ref_bases, ref_len, cfg->min_base_call_quality, 3, 1, 0, PISCES_ANCHOR_SIZE,
-                                     cands, 256);
+        int nc = orc_find_candidates(&r, ref_bases, ref_len, cfg->min_base_call_quality, cfg->max_mnv_length, cfg->max_gap_between_mnv,
+                                     cfg->call_mnvs, PISCES_ANCHOR_SIZE, cands, 256);
         for (int k = 0; k < nc; k++)
             if (cands[k].position >= region_start && cands[k].position < region_start + region_loci)
                 orc_add_candidate(s, &cands[k]);
@@ -1615,6 +1896,9 @@ void orc_default_config(PiscesHipConfig* c)
     c->collapse = 1;
     c->collapse_freq_threshold = 0.0f;
     c->collapse_freq_ratio_threshold = 0.5f;
+    c->call_mnvs = 0;
+    c->max_mnv_length = 3;
+    c->max_gap_between_mnv = 1;
 }
 
 

@@ -152,6 +152,9 @@ int64_t orc_call_candidates(OrcState* s, const OrcCandidate* list, int64_t n_lis
 
 /* ---- whole path on a read batch: the CPU baseline (SmallVariantCaller.Execute loop,
  * exe/Pisces/Logic/SmallVariantCaller.cs:79-116) ---- */
+/* MnvReallocator.ReallocateFailedMnvs over arrays (test hook; max_position < 0 = null) */
+int64_t orc_reallocate_failed_mnvs(const OrcCalled* failed, int64_t n_failed, OrcCalled* callable, int64_t n_callable, int64_t cap_callable,
+                                   int32_t max_position, OrcCalled* outside, int64_t cap_outside, int64_t* n_outside);
 int64_t orc_run_reads(const PiscesReadBatch* batch, const uint8_t* ref_bases, int64_t ref_len,
                       int32_t region_start, int32_t region_loci, const PiscesHipConfig* cfg,
                       PiscesCalledAllele* out, int64_t capacity, int64_t* n_candidate_loci);

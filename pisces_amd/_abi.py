@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # error codes
 OK = 0
@@ -85,6 +85,9 @@ class PiscesHipConfig(C.Structure):
         ("collapse", C.c_int32),
         ("collapse_freq_threshold", C.c_float),
         ("collapse_freq_ratio_threshold", C.c_float),
+        ("call_mnvs", C.c_int32),
+        ("max_mnv_length", C.c_int32),
+        ("max_gap_between_mnv", C.c_int32),
     ]
 
 
@@ -128,6 +131,9 @@ def default_config(**overrides):
     c.collapse = 1
     c.collapse_freq_threshold = 0.0
     c.collapse_freq_ratio_threshold = 0.5
+    c.call_mnvs = 0
+    c.max_mnv_length = 3
+    c.max_gap_between_mnv = 1
     for k, v in overrides.items():
         if not hasattr(c, k):
             raise AttributeError(f"PiscesHipConfig has no field {k!r}")

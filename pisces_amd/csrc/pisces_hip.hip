@@ -261,6 +261,9 @@ int32_t pisces_hip_default_config(PiscesHipConfig* c)
     c->collapse = 1;
     c->collapse_freq_threshold = 0.0f;
     c->collapse_freq_ratio_threshold = 0.5f;
+    c->call_mnvs = 0;
+    c->max_mnv_length = 3;
+    c->max_gap_between_mnv = 1;
     return PISCES_OK;
 }
 

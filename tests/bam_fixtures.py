@@ -23,6 +23,10 @@ CASES = {
     "bam_edge_ins": dict(chrom="chr7", cfg=dict(low_depth_filter=-1), vcf=dict(), intervals=None, mode="all"),
     # the deletion twin (:462-538): exactly one variant
     "bam_edge_del": dict(chrom="chr7", cfg=dict(low_depth_filter=-1), vcf=dict(), intervals=None, mode="variant_alleles"),
+    # BasicMnvTesting (:381-424): MNV calling on (MaxSizeMNV 15, MaxGapBetweenMNV 10), collapser off; exactly three variants, two of them
+    # MNVs that start at the same position
+    "bam_small_s1": dict(chrom="chr1", cfg=dict(low_depth_filter=-1, call_mnvs=1, max_mnv_length=15, max_gap_between_mnv=10, collapse=0),
+                         vcf=dict(), intervals=None, mode="variant_alleles"),
 }
 
 

@@ -164,6 +164,10 @@ EDGE_AMPLICON = ("GTTGGTCTTCTATTTTATGCGAATTCTTCTAAGATTCCCAGGTTATTTATCATAAGAATTAC
                  "TAATTTCTGGCACACATTACTTCAGGGGT")
 
 
+# mock chr1 of BasicMnvTesting (SomaticVariantCallerFunctionalTests.cs:391-398)
+SMALL_S1_CHR1 = "TTGTCAGTGCGCTTTTCCCAACACCACCTGCTCCGACCACCACCAGTTTGTACTCAGTCATTTCACACCAGCAAGAACCTGTTGGAAACCAGTAATCAGGGTTAATTGGCGGCG"
+
+
 def main(root):
     t = os.path.join(root, "src/test")
     # ExecuteEdgeInsertion (:540-612): edgeIns_S2.genome.vcf is the gVCF that run writes next to the BAM
@@ -177,6 +181,10 @@ def main(root):
     ref = "N" * 62 + EDGE_AMPLICON
     extract(root, "Pisces.Tests/TestData/edgeIndel_S2.bam", "chr7", None, (1, len(ref)), 0, ["chr7\t107\t.\tATTT\tA"], "bam_edge_del.npz",
             ref_literal=ref)
+    # BasicMnvTesting (:381-424): small_S1.bam on the test's mock chr1, MNV calling on (MaxSizeMNV 15, MaxGapBetweenMNV 10), collapser
+    # off; exactly these three variants
+    extract(root, "Pisces.Tests/TestData/small_S1.bam", "chr1", None, (1, len(SMALL_S1_CHR1)), 0,
+            ["chr1\t27\t.\tCC\tTT", "chr1\t27\t.\tCCTGCTCCG\tTTTGCTCCA", "chr1\t35\t.\tG\tA"], "bam_small_s1.npz", ref_literal=SMALL_S1_CHR1)
     # Sample_S1.genome.vcf is what the last run of SimpleSnv leaves behind (gVCF, Sample_S1_negative.picard: chr19:3118880-3118890);
     # the variant row comes from Chr17again.expected.genome.vcf (IntervalTestingWithMultipleSamples, same reads: Chr17again.bam ==
     # Chr17Chr19.bam, whose chr19 alignments are those of Sample_S1.bam)

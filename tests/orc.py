@@ -362,3 +362,29 @@ def run_reads_sharded(shards, ref, cfg, passes=1):
     rc = lib.orc_run_reads_sharded(jobs, len(shards))
     assert rc == 0, rc
     return [o[: j.n_out].copy() for o, j in zip(outs, jobs)], int(sum(j.n_loci for j in jobs))
+
+
+def reallocate_failed_mnvs(failed, callable_, max_position=None):
+    """MnvReallocator.ReallocateFailedMnvs on lists of dicts {position, ref, alt, support, dirs, category}; returns (callable, outside)."""
+    def mk(d):
+        v = OrcCalled()
+        v.position, v.category = d["position"], d["category"]
+        v.ref, v.alt = d["ref"].encode(), d["alt"].encode()
+        v.allele_support = d["support"]
+        for k in range(3):
+            v.support_by_dir[k] = d["dirs"][k]
+        return v
+
+    def un(v):
+        return {"position": v.position, "ref": v.ref.decode(), "alt": v.alt.decode(), "support": v.allele_support,
+                "dirs": [v.support_by_dir[k] for k in range(3)], "category": v.category}
+    cap = len(callable_) + 64 * max(len(failed), 1)
+    f = (OrcCalled * max(len(failed), 1))(*[mk(d) for d in failed])
+    c = (OrcCalled * cap)(*[mk(d) for d in callable_])
+    o = (OrcCalled * cap)()
+    no = C.c_int64(0)
+    lib.orc_reallocate_failed_mnvs.restype = C.c_int64
+    nc = lib.orc_reallocate_failed_mnvs(f, C.c_int64(len(failed)), c, C.c_int64(len(callable_)), C.c_int64(cap),
+                                        C.c_int32(-1 if max_position is None else max_position), o, C.c_int64(cap), C.byref(no))
+    assert nc <= cap and no.value <= cap
+    return [un(c[i]) for i in range(nc)], [un(o[i]) for i in range(no.value)]

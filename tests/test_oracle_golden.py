@@ -484,7 +484,7 @@ def test_variant_collapser_reference_cases(case):
 
 
 # ---- end to end: the reference's own BAMs -> the VCF rows Pisces wrote for them -----------------------------------------------
-@pytest.mark.parametrize("name", ["bam_chr19", "bam_phix", "bam_edge_ins", "bam_edge_del"])
+@pytest.mark.parametrize("name", ["bam_chr19", "bam_phix", "bam_edge_ins", "bam_edge_del", "bam_small_s1"])
 def test_reference_bams_give_the_vcf_rows_pisces_wrote(name):
     """Reads decoded from the reference's test BAMs (filtered as AlignmentSource does), run through the oracle with the options of
     the functional test that owns the BAM, formatted by pisces_hip_format_vcf: the body lines must be the ones Pisces left in its
@@ -504,3 +504,18 @@ def test_reference_bams_give_the_vcf_rows_pisces_wrote(name):
         text = engine.format_vcf(case["chrom"], recs, alleles=alleles, **case["vcf"])
         lines += text.rstrip("\n").split("\n") if text else []
     bam_fixtures.check_lines(case, lines, [str(x) for x in z["expected_vcf"]])
+
+
+# ---- MnvReallocator ------------------------------------------------------------------------------------
+def _norm(rows):
+    return sorted((r["position"], r["ref"], r["alt"], r["support"], tuple(r["dirs"]), r["category"]) for r in rows)
+
+
+@pytest.mark.parametrize("case", json.load(open(os.path.join(G, "mnv_reallocator_cases.json")))["cases"], ids=lambda c: c["name"][:40])
+def test_mnv_reallocator_cases(case):
+    got_callable, got_outside = orc.reallocate_failed_mnvs(case["failed"], case["callable"], case["max"])
+    if "expect_callable" in case:
+        assert _norm(got_callable) == _norm(case["expect_callable"])
+    for want in case.get("expect_callable_contains", []):
+        assert _norm(got_callable).count(_norm([want])[0]) == 1
+    assert _norm(got_outside) == _norm(case["expect_outside"])
