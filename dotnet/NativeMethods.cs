@@ -84,6 +84,7 @@ namespace Pisces.Hip
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_flush_ex(IntPtr handle, int upToPosition, [Out] PiscesCalledAllele[] output, long capacity, out long nOut, [Out] int[] candIndex, [Out] PiscesCandidate[] cands, long candCapacity, out long nCand, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_get_candidates(IntPtr handle, int upToPosition, [Out] PiscesCandidate[] cands, long capacity, out long nOut, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern long pisces_hip_find_indel_candidates(ref PiscesReadBatch batch, byte[] reference, long refLen, int minBaseCallQuality, [Out] PiscesCandidate[] cands, long capacity, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern long pisces_hip_find_candidates(ref PiscesReadBatch batch, byte[] reference, long refLen, int minBaseCallQuality, int snvsAndMnvs, int callMnvs, int maxMnvLength, int maxGapBetweenMnv, [Out] PiscesCandidate[] cands, long capacity, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
         // device-resident surface (raw device pointers + hipStream_t as IntPtr)
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_call_tiles(IntPtr handle, IntPtr dTuples, IntPtr dTiles, int nTiles, IntPtr dRefBases, int refStartPosition, long refLength, IntPtr dRecords, int recordCapacity, IntPtr dTileResults, IntPtr stream);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_compact_records(IntPtr handle, IntPtr dRecords, IntPtr dTileResults, int nTiles, IntPtr dOffsets, IntPtr dOut, int outCapacity, IntPtr dCount, IntPtr stream);

@@ -1,4 +1,4 @@
-// finder.cpp — insertion / deletion candidate discovery on the host (see finder.h).
+// finder.cpp — candidate discovery on the host (see finder.h): insertions / deletions always, SNVs / MNVs when MNV calling is on.
 #include "finder.h"
 
 #include <algorithm>
@@ -17,6 +17,7 @@ static inline int dir_at(const ReadView& r, int i)
 // directions (stitched, XD tag) take the branch the reference takes when CigarDirections == null (:422-428).
 static int support_direction(const ReadView& r, int category, int length, int startIndexInRead)
 {
+    if (category == PISCES_CAT_SNV || category == PISCES_CAT_REFERENCE) return dir_at(r, startIndexInRead);
     const int leftAnchorIndex = startIndexInRead - 1;
     const int rightAnchorIndex = category == PISCES_CAT_DELETION ? startIndexInRead : startIndexInRead + length;
     const int lastIndex = r.read_len - 1;
@@ -47,6 +48,14 @@ static bool deletion_quality_ok(const ReadView& r, int opStartIndexInRead, int m
 void find_indel_candidates(const ReadView& r, const uint8_t* ref, int64_t ref_len, int32_t minBQ, int32_t anchorSize,
                            std::vector<HostCandidate>& out)
 {
+    find_candidates(r, ref, ref_len, minBQ, anchorSize, false, false, 0, 0, out);
+}
+
+static inline int allele_code(uint8_t b) { return b == 'A' ? 0 : b == 'G' ? 1 : b == 'C' ? 2 : b == 'T' ? 3 : 4; }
+
+void find_candidates(const ReadView& r, const uint8_t* ref, int64_t ref_len, int32_t minBQ, int32_t anchorSize, bool snvs_and_mnvs,
+                     bool call_mnvs, int32_t max_mnv_length, int32_t max_gap, std::vector<HostCandidate>& out)
+{
     const size_t first = out.size();
     int refSpan = 0;
     for (int c = 0; c < r.n_cigar; c++)
@@ -58,7 +67,8 @@ void find_indel_candidates(const ReadView& r, const uint8_t* ref, int64_t ref_le
         HostCandidate c;
         c.position = coordinate;
         c.category = category;
-        const int length = category == PISCES_CAT_INSERTION ? (int)altAllele.size() - 1 : (int)refAllele.size() - 1;
+        const int length = category == PISCES_CAT_INSERTION ? (int)altAllele.size() - 1
+                           : category == PISCES_CAT_DELETION ? (int)refAllele.size() - 1 : (int)altAllele.size();   // BaseAllele.Length
         const int dir = support_direction(r, category, length, startIndexInRead);
         c.support_by_dir[dir]++;
         const int anchor = std::min(coordinate - r.position, endPosition - coordinate);
@@ -67,13 +77,71 @@ void find_indel_candidates(const ReadView& r, const uint8_t* ref, int64_t ref_le
         c.alt = std::move(altAllele);
         out.push_back(std::move(c));
     };
+    // FlushVariant :183-203
+    auto flush_variant = [&](int variantStartIndexInRead, int variantStartIndexInReference, int variantLengthSoFar,
+                             int interveningRefLengthSoFar, bool openLeft, bool openRight) {
+        if (interveningRefLengthSoFar >= 1) { variantLengthSoFar -= interveningRefLengthSoFar; openRight = false; }
+        if (variantLengthSoFar < 1) return;
+        create(variantLengthSoFar > 1 ? PISCES_CAT_MNV : PISCES_CAT_SNV, variantStartIndexInReference + 1,
+               std::string((const char*)ref + variantStartIndexInReference, (size_t)variantLengthSoFar),
+               std::string((const char*)r.bases + variantStartIndexInRead, (size_t)variantLengthSoFar), variantStartIndexInRead);
+        out.back().open_left = openLeft;
+        out.back().open_right = openRight;
+    };
+    // ShouldBuildUpMNV :170-181
+    auto should_build_up = [&](int mnvLengthSoFar, int interveningRefLengthSoFar, bool refCallNext) {
+        if (!call_mnvs) return false;
+        if (refCallNext && mnvLengthSoFar == 0) return false;
+        if (mnvLengthSoFar + 1 > max_mnv_length) return false;
+        if (interveningRefLengthSoFar + (refCallNext ? 1 : 0) > max_gap) return false;
+        return true;
+    };
+    // ExtractSnvsFromOperation :90-168
+    auto extract_snvs = [&](int opStartIndexInRead, int operationLength, int opStartIndexInReference) {
+        int variantLengthSoFar = 0, interveningRefLengthSoFar = 0;
+        bool openLeft = false;
+        for (int i = 0; i < operationLength; i++) {
+            if (opStartIndexInRead + i >= r.read_len) break;
+            const bool qualityGoodEnough = r.quals[opStartIndexInRead + i] >= minBQ;
+            const uint8_t readBase = r.bases[opStartIndexInRead + i];
+            if (opStartIndexInReference + i >= ref_len) break;
+            const uint8_t refBase = ref[opStartIndexInReference + i];
+            const bool atEndOfOperation = i == operationLength - 1;
+            const bool startingMnvAtEndOfOperation = atEndOfOperation && variantLengthSoFar == 0;
+            if (allele_code(readBase) == 4 || allele_code(refBase) == 4 || !qualityGoodEnough) {
+                flush_variant(opStartIndexInRead + i - variantLengthSoFar, opStartIndexInReference + i - variantLengthSoFar, variantLengthSoFar,
+                              interveningRefLengthSoFar, openLeft, true);
+                variantLengthSoFar = 0; interveningRefLengthSoFar = 0; openLeft = true;
+            } else if (refBase == readBase) {
+                if (should_build_up(variantLengthSoFar, interveningRefLengthSoFar, true) && !startingMnvAtEndOfOperation) {
+                    variantLengthSoFar++; interveningRefLengthSoFar++;
+                } else {
+                    flush_variant(opStartIndexInRead + i - variantLengthSoFar, opStartIndexInReference + i - variantLengthSoFar,
+                                  variantLengthSoFar, interveningRefLengthSoFar, openLeft, false);
+                    variantLengthSoFar = 0; interveningRefLengthSoFar = 0; openLeft = false;
+                }
+            } else {
+                if (should_build_up(variantLengthSoFar, interveningRefLengthSoFar, false) && !startingMnvAtEndOfOperation) {
+                    variantLengthSoFar++; interveningRefLengthSoFar = 0;
+                } else {
+                    flush_variant(opStartIndexInRead + i - variantLengthSoFar, opStartIndexInReference + i - variantLengthSoFar,
+                                  variantLengthSoFar, interveningRefLengthSoFar, openLeft, false);
+                    variantLengthSoFar = 1; interveningRefLengthSoFar = 0; openLeft = false;
+                }
+            }
+        }
+        flush_variant(opStartIndexInRead + operationLength - variantLengthSoFar, opStartIndexInReference + operationLength - variantLengthSoFar,
+                      variantLengthSoFar, interveningRefLengthSoFar, openLeft, false);
+    };
 
     int startIndexInRead = 0;
     int startIndexInReference = r.position - 1;
     for (int ci = 0; ci < r.n_cigar; ci++) {   // ProcessCigarOps :36-83
         const uint8_t t = r.cigar_op[ci];
         const int len = (int)r.cigar_len[ci];
-        if (t == 'I') {   // ExtractInsertionFromOperation :234-260
+        if (t == 'M' && snvs_and_mnvs) {
+            extract_snvs(startIndexInRead, len, startIndexInReference);
+        } else if (t == 'I') {   // ExtractInsertionFromOperation :234-260
             if (!(startIndexInReference - 1 >= ref_len || startIndexInReference == 0) && startIndexInRead + len <= r.read_len &&
                 r.quals[startIndexInRead] >= minBQ) {
                 std::string refAllele(1, (char)ref[startIndexInReference - 1]);
@@ -113,6 +181,9 @@ void find_indel_candidates(const ReadView& r, const uint8_t* ref, int64_t ref_le
     const uint8_t firstOp = r.cigar_op[fi], lastOp = r.cigar_op[li];
     for (size_t i = first; i < out.size(); i++) {
         HostCandidate& c = out[i];
+        const bool isSnvMnv = c.category == PISCES_CAT_SNV || c.category == PISCES_CAT_MNV;
+        if (firstOp == 'M' && c.position == r.position && isSnvMnv) c.open_left = true;
+        if (lastOp == 'M' && c.position + (int)c.alt.size() - 1 == maxPosition && isSnvMnv) c.open_right = true;
         if (firstOp == 'I' && c.position == r.position - 1 && c.category == PISCES_CAT_INSERTION) c.open_left = true;
         if (firstOp == 'D' && c.position == r.position - 1 && c.category == PISCES_CAT_DELETION) c.open_left = true;
         if (lastOp == 'I' && c.position == maxPosition && c.category == PISCES_CAT_INSERTION) c.open_right = true;

@@ -1,6 +1,7 @@
-// finder.h — host side of ICandidateVariantFinder.FindCandidates for the candidates that do NOT fall out of
-// the device allele counts: insertions and deletions (src/lib/Pisces.Domain/Logic/CandidateVariantFinder.cs:234-292).
-// SNV candidates are implied by the counts (callMNVs off, the reference default), so M operations are not walked.
+// finder.h — host side of ICandidateVariantFinder.FindCandidates (src/lib/Pisces.Domain/Logic/CandidateVariantFinder.cs:36-387,496-553).
+// With MNV calling off (the reference default) SNV candidates are implied by the device allele counts and only insertions and
+// deletions are discovered here (M operations are not walked); with it on, SNV and MNV candidates come from the M walk too
+// (ExtractSnvsFromOperation :90-232), because bases absorbed into an MNV are no SNV candidates.
 #pragma once
 #include <stdint.h>
 
@@ -13,7 +14,7 @@ namespace pisces {
 
 struct HostCandidate {
     int32_t position = 0;     // coordinate of the anchor base (one before the inserted / deleted bases)
-    int32_t category = 0;     // PISCES_CAT_INSERTION / PISCES_CAT_DELETION
+    int32_t category = 0;     // PISCES_CAT_*
     std::string ref, alt;
     int32_t support_by_dir[3] = {0, 0, 0};
     int32_t well_anchored_by_dir[3] = {0, 0, 0};
@@ -23,5 +24,10 @@ struct HostCandidate {
 // Appends the read's indel candidates. ref[i] is position i+1 of the chromosome (upper case).
 void find_indel_candidates(const ReadView& read, const uint8_t* ref, int64_t ref_len, int32_t min_base_call_quality,
                            int32_t well_anchored_anchor_size, std::vector<HostCandidate>& out);
+
+// The full walk: snvs_and_mnvs adds the candidates of the M operations; call_mnvs / max_mnv_length / max_gap are ShouldBuildUpMNV's.
+void find_candidates(const ReadView& read, const uint8_t* ref, int64_t ref_len, int32_t min_base_call_quality,
+                     int32_t well_anchored_anchor_size, bool snvs_and_mnvs, bool call_mnvs, int32_t max_mnv_length, int32_t max_gap,
+                     std::vector<HostCandidate>& out);
 
 }  // namespace pisces

@@ -703,14 +703,15 @@ int64_t pisces_hip_expand_reads(const PiscesReadBatch* batch, int32_t min_bq, in
     return sink.n <= capacity ? sink.n : (int64_t)PISCES_E_BUFFER_TOO_SMALL;
 }
 
-int64_t pisces_hip_find_indel_candidates(const PiscesReadBatch* batch, const uint8_t* ref, int64_t ref_len, int32_t min_bq,
-                                         PiscesCandidate* out, int64_t capacity, uint8_t* alleles, int64_t allele_capacity,
-                                         int64_t* allele_bytes)
+int64_t pisces_hip_find_candidates(const PiscesReadBatch* batch, const uint8_t* ref, int64_t ref_len, int32_t min_bq, int32_t snvs_and_mnvs,
+                                   int32_t call_mnvs, int32_t max_mnv_length, int32_t max_gap_between_mnv, PiscesCandidate* out,
+                                   int64_t capacity, uint8_t* alleles, int64_t allele_capacity, int64_t* allele_bytes)
 {
     if (validate_batch(batch) != PISCES_OK || !ref || ref_len <= 0 || capacity < 0 || (capacity > 0 && !out)) return PISCES_E_INVALID_ARG;
     std::vector<HostCandidate> found;
     for (int32_t i = 0; i < batch->n_reads; i++)
-        find_indel_candidates(read_view(batch, i), ref, ref_len, min_bq, PISCES_ANCHOR_SIZE, found);
+        find_candidates(read_view(batch, i), ref, ref_len, min_bq, PISCES_ANCHOR_SIZE, snvs_and_mnvs != 0, call_mnvs != 0, max_mnv_length,
+                        max_gap_between_mnv, found);
     int64_t bytes = 0;
     for (size_t i = 0; i < found.size(); i++) {
         const HostCandidate& c = found[i];
@@ -733,6 +734,13 @@ int64_t pisces_hip_find_indel_candidates(const PiscesReadBatch* batch, const uin
     if (allele_bytes) *allele_bytes = bytes;
     if ((int64_t)found.size() > capacity || (alleles && bytes > allele_capacity)) return PISCES_E_BUFFER_TOO_SMALL;
     return (int64_t)found.size();
+}
+
+int64_t pisces_hip_find_indel_candidates(const PiscesReadBatch* batch, const uint8_t* ref, int64_t ref_len, int32_t min_bq,
+                                         PiscesCandidate* out, int64_t capacity, uint8_t* alleles, int64_t allele_capacity,
+                                         int64_t* allele_bytes)
+{
+    return pisces_hip_find_candidates(batch, ref, ref_len, min_bq, 0, 0, 0, 0, out, capacity, alleles, allele_capacity, allele_bytes);
 }
 
 // Builds tiles + tile-bucketed tuples for a set of blocks. Tiles follow the 1000-locus block grid

@@ -293,20 +293,27 @@ def format_vcf(chrom, records, vcf_config=None, alleles=None, **overrides):
 
 def find_indel_candidates(batch, ref, min_base_call_quality=20):
     """Host finder for insertions / deletions (pisces_hip_find_indel_candidates): list of dicts in read order."""
+    return find_candidates(batch, ref, min_base_call_quality, snvs_and_mnvs=False)
+
+
+def find_candidates(batch, ref, min_base_call_quality=20, snvs_and_mnvs=True, call_mnvs=False, max_mnv_length=3, max_gap_between_mnv=1):
+    """The host finder (pisces_hip_find_candidates): insertions / deletions, and with snvs_and_mnvs the SNV / MNV candidates of the
+    M operations; list of dicts in read order."""
     refa = np.ascontiguousarray(np.frombuffer(ref, dtype=np.uint8) if isinstance(ref, (bytes, bytearray)) else ref, np.uint8)
     cap, pool_cap = 4096, 1 << 18
     while True:
         cands = (_abi.PiscesCandidate * cap)()
         pool = np.zeros(pool_cap, dtype=np.uint8)
         nb = C.c_int64(0)
-        n = lib.pisces_hip_find_indel_candidates(C.byref(batch.c), refa.ctypes.data, refa.size, min_base_call_quality, cands, cap,
-                                                 pool.ctypes.data, pool_cap, C.byref(nb))
+        n = lib.pisces_hip_find_candidates(C.byref(batch.c), refa.ctypes.data, refa.size, min_base_call_quality, int(snvs_and_mnvs),
+                                           int(call_mnvs), max_mnv_length, max_gap_between_mnv, cands, cap, pool.ctypes.data, pool_cap,
+                                           C.byref(nb))
         if n == _abi.E_BUFFER_TOO_SMALL:
             cap *= 4
             pool_cap = max(pool_cap * 4, int(nb.value))
             continue
         if n < 0:
-            raise PiscesHipError(int(n), "find_indel_candidates failed")
+            raise PiscesHipError(int(n), "find_candidates failed")
         out = []
         for i in range(n):
             c = cands[i]

@@ -186,3 +186,80 @@ def test_library_indel_finder_on_the_reference_cases():
                 assert c["open_right"] == e["open_right"]
             n_checked += 1
     assert n_checked >= 30
+
+
+def test_full_finder_matches_oracle_finder_with_mnvs():
+    """pisces_hip_find_candidates with the M walk on (what add_reads runs when call_mnvs is set) vs the oracle's finder, per read and
+    in read order: SNV / MNV / insertion / deletion candidates with alleles, direction, well-anchored support and open ends, for
+    several MaxSizeMNV / MaxGapBetweenMNV settings."""
+    rng = np.random.default_rng(23)
+    ref = bytes(rng.choice(list(b"ACGT"), 600).astype(np.uint8))
+    reads = []
+    for _ in range(300):
+        ops = []
+        for k in range(int(rng.integers(1, 5))):
+            ops.append((str(rng.choice(list("MMMMIDS"))), int(rng.integers(1, 30))))
+        ops = [(o, l) for i, (o, l) in enumerate(ops) if o != "S" or i in (0, len(ops) - 1)]
+        if not any(o == "M" for o, _ in ops):
+            ops.insert(len(ops) // 2, ("M", 12))
+        pos = int(rng.integers(20, 400))
+        seq, rp = [], pos
+        for o, l in ops:   # mostly the reference, with mismatches so that MNVs and gapped MNVs form
+            if o == "M":
+                seg = bytearray(ref[rp - 1: rp - 1 + l])
+                for i in range(len(seg)):
+                    if rng.random() < 0.25:
+                        seg[i] = int(rng.choice(list(b"ACGTN"), p=[.24, .24, .24, .24, .04]))
+                seq.append(bytes(seg).decode())
+                rp += l
+            elif o == "D":
+                rp += l
+            else:
+                seq.append("".join(rng.choice(list("ACGT"), l)))
+        seq = "".join(seq)
+        rl = len(seq)
+        stitched = rng.random() < 0.3
+        reads.append({"pos": pos, "cigar": ops, "seq": seq, "quals": rng.choice([10, 25, 37], rl, p=[.1, .15, .75]).astype(np.uint8).tolist(),
+                      "reverse": bool(rng.integers(0, 2)), "dirs": rng.choice([0, 1, 2], rl).tolist() if stitched else None})
+    for call_mnvs, max_len, max_gap in ((False, 3, 1), (True, 3, 1), (True, 15, 10), (True, 2, 0)):
+        got = engine.find_candidates(_abi.ReadBatch(reads), ref, 20, True, call_mnvs, max_len, max_gap)
+        exp = []
+        for d in reads:
+            rd = orc.make_read(d["pos"], d["seq"], cigar=d["cigar"], quals=d["quals"], reverse=d["reverse"], dirs=d["dirs"])
+            for c in orc.find_candidates(rd, ref.decode(), call_mnvs=call_mnvs, max_mnv=max_len, max_gap=max_gap):
+                exp.append({"position": c.position, "category": c.category, "ref": c.ref.decode(), "alt": c.alt.decode(),
+                            "support_by_dir": list(c.support_by_dir), "well_anchored_by_dir": list(c.well_anchored_by_dir),
+                            "open_left": bool(c.open_left), "open_right": bool(c.open_right)})
+        assert sum(e["category"] == _abi.CAT_MNV for e in exp) > (50 if call_mnvs else -1)
+        assert got == exp, (call_mnvs, max_len, max_gap)
+
+
+def test_library_full_finder_on_all_reference_cases():
+    """pisces_hip_find_candidates with callMNVs on, over all 106 reads of the reference's VariantFinderTests (SNV, MNV, deletion and
+    insertion suites, tests/golden/finder_cases.json): every expected candidate, nothing else."""
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "finder_cases.json")))
+    cat = {"Snv": _abi.CAT_SNV, "Mnv": _abi.CAT_MNV, "Insertion": _abi.CAT_INSERTION, "Deletion": _abi.CAT_DELETION}
+    n_checked = 0
+    for case in g["cases"]:
+        if not case["read"]:
+            continue
+        start = 101
+        ops = orc.parse_cigar(case["cigar"])
+        clip = ops[0][1] if ops and ops[0][0] == "S" else 0
+        ref = ("N" * (start - 1 - clip) + case["ref_under_read"] + "NNNNN").encode()
+        batch = _abi.ReadBatch([{"pos": start, "cigar": ops, "seq": case["read"], "quals": case["quals"], "reverse": False}])
+        got = engine.find_candidates(batch, ref, g["min_base_call_quality"], True, g["call_mnvs"], case["max_mnv_length"], case["max_gap"])
+        exp = case["expected"] if case["expected_count"] else []
+        assert len(got) == case["expected_count"], (case["cigar"], case["read"], got)
+        key = lambda c: (c["position"], c["category"], c["ref"], c["alt"])
+        got = sorted(got, key=key)
+        for e in exp:
+            m = [c for c in got if key(c) == (e["coord"] + start, cat[e["type"]], e["ref"], e["alt"])]
+            assert len(m) == 1, (case, got)
+            if e["open_left"] is not None:
+                assert m[0]["open_left"] == e["open_left"]
+            if e["open_right"] is not None:
+                assert m[0]["open_right"] == e["open_right"]
+            n_checked += 1
+    assert n_checked >= 90
