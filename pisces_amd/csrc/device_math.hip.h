@@ -32,6 +32,7 @@ struct DeviceParams {
     // the call phase would run (build_gq_tail_kernel), so a hit is bit-identical to the evaluation it replaces.
     const double* gq_tail;
     int32_t gq_tail_a, gq_tail_cov;
+    int32_t refs_only;   // MNV calling on: SNV candidates come from the read walk, the tile kernels emit Reference records only
 };
 
 // ------------------------------------------------------------------------------------------

@@ -288,7 +288,7 @@ __device__ inline void call_roles(const int* hist, const uint32_t* gapped /* LDS
     // Every wave evaluates the same data, so the "no variant work in this tile" decision is wave-uniform across the
     // workgroup: waves 1 and 2 then retire at once and wave 0 never meets a barrier.
     uint32_t pass_mask = 0;
-    if (in_ref && rt < 4) {
+    if (in_ref && rt < 4 && !P.refs_only) {
         for (int k = 0; k < 4; k++) {
             const int a = allele_of_rank(k);
             if (a == rt) continue;
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
 
     // variant candidates that survive the integer / float32 half of IsCallable (AlleleCaller.cs:236-258)
     uint32_t pass_mask = 0;
-    if (in_ref && rt < 4) {
+    if (in_ref && rt < 4 && !P.refs_only) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int a = allele_of_rank(k);
@@ -1036,7 +1036,7 @@ struct DevCandidate {
     int32_t first_base, last_base;   // AlleleType of AlternateAllele[1] / [last] (insertions, :180-186)
     int64_t start_idx, end_idx;      // locus index of the start / end point in the counts tensor, -1 = no block (count 0)
     int32_t allele_off;              // ref bytes then alt bytes in the allele pool
-    int32_t pad;
+    int32_t gapped;                  // GetGappedMnvRefCount at the position (SNV: off the reference support, Reference: off the support)
 };
 
 // AlleleCountHelper.GetAnchorAdjustedAlleleCount (lib/Pisces.Processing/RegionState/AlleleCountHelper.cs:21-85)
@@ -1107,13 +1107,13 @@ __device__ inline int rmxn_length_for_indel(int variantPosition, const uint8_t* 
     return maxRepeatsFound;
 }
 
-// CoverageCalculator.CalculateSpanning (CoverageCalculator.cs:162-321) for an insertion / deletion candidate over the
+// CoverageCalculator.CalculateSpanning (CoverageCalculator.cs:162-321) for an insertion / deletion / MNV candidate over the
 // anchor-resolved counts tensor: coverage by direction, total coverage.  Host and device: the host-side collapser needs the
 // same number (CandidateAllele.Frequency) the device call uses.
 struct SpanningCoverage { int cov[3]; int total; };
 __host__ __device__ inline SpanningCoverage spanning_coverage(const DevCandidate& c, const int32_t* __restrict__ counts, int32_t expect_stitched)
 {
-    const int length = c.category == PISCES_CAT_INSERTION ? c.alt_len - 1 : c.ref_len - 1;   // BaseAllele.Length
+    const int length = c.category == PISCES_CAT_INSERTION ? c.alt_len - 1 : c.category == PISCES_CAT_DELETION ? c.ref_len - 1 : c.alt_len;   // BaseAllele.Length
     const int support = c.sup[0] + c.sup[1] + c.sup[2];
     const int wellAnchored = c.anch[0] + c.anch[1] + c.anch[2];
     const bool presumeAnchoredForExactCov = c.category == PISCES_CAT_INSERTION ? (expect_stitched != 0) : true;   // :31-41
@@ -1183,6 +1183,23 @@ __host__ __device__ inline SpanningCoverage spanning_coverage(const DevCandidate
 }
 
 
+// TotalCoverage of a candidate of any category against the counts tensor (the collapser's frequencies, CandidateAllele -> CalledAllele
+// -> CoverageCalculator.Compute): point alleles sum the five coverage-contributing allele types over directions and anchors.
+__host__ __device__ inline int candidate_total_coverage(const DevCandidate& c, const int32_t* __restrict__ counts, int32_t expect_stitched)
+{
+    if (c.category == PISCES_CAT_SNV || c.category == PISCES_CAT_REFERENCE) {
+        const int cca[5] = {PISCES_ALLELE_A, PISCES_ALLELE_C, PISCES_ALLELE_G, PISCES_ALLELE_T, PISCES_ALLELE_DEL};
+        int total = 0;
+        for (int d = 0; d < 3; d++)
+            for (int k = 0; k < 5; k++) total += get_allele_count(counts, c.start_idx, cca[k], d, 0, -1, false);
+        return total;
+    }
+    return spanning_coverage(c, counts, expect_stitched).total;
+}
+
+// IAlleleCaller's ProcessVariant + IsCallable for host-supplied candidates (one lane each): insertions / deletions always; with MNV
+// calling on also the SNV and MNV candidates of the read walk and the Reference alleles that MNV reallocation touched
+// (AlleleCaller.cs:60-141).  Point alleles (SNV, Reference) go through the tile kernels' own process_point_allele.
 __global__ __launch_bounds__(64) void call_spanning_kernel(
     const DevCandidate* __restrict__ cands, int32_t n, const int32_t* __restrict__ counts, const uint8_t* __restrict__ alleles,
     const uint8_t* __restrict__ ref, int64_t ref_len /* ref[i] = position i+1 */, int32_t expect_stitched,
@@ -1191,7 +1208,37 @@ __global__ __launch_bounds__(64) void call_spanning_kernel(
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     const DevCandidate c = cands[i];
-    const int length = c.category == PISCES_CAT_INSERTION ? c.alt_len - 1 : c.ref_len - 1;   // BaseAllele.Length
+    if (c.category == PISCES_CAT_SNV || c.category == PISCES_CAT_REFERENCE) {
+        // CalculateSinglePoint :49-98 over the anchor-resolved counts; AlleleSupport is the candidate's (AlleleHelper.Map)
+        const bool isRef = c.category == PISCES_CAT_REFERENCE;
+        LocusCounts lc;
+        for (int a = 0; a < 6; a++)
+            for (int d = 0; d < 3; d++) lc.h[a][d] = get_allele_count(counts, c.start_idx, a, d, 0, -1, false);
+        const int rt = allele_type_of_base(alleles[c.allele_off]);
+        const int a = isRef ? rt : allele_type_of_base(alleles[c.allele_off + c.ref_len]);
+        PointCounts pc = point_counts_of(lc, a, isRef, rt, 0);
+        if (isRef) {   // the Reference candidate's own support (RegionState.cs:414-447) + what reallocated MNVs added to it
+            for (int d = 0; d < 3; d++) pc.sup[d] += c.sup[d];
+            pc.support = pc.sup[0] + pc.sup[1] + pc.sup[2] - c.gapped;
+            if (pc.support < 0) pc.support = 0;
+        } else {
+            for (int d = 0; d < 3; d++) pc.sup[d] = c.sup[d];
+            pc.support = c.sup[0] + c.sup[1] + c.sup[2];
+            pc.refsup -= c.gapped;
+            if (pc.refsup < 0) pc.refsup = 0;
+        }
+        PiscesCalledAllele r;
+        r.position = c.position; r.total_coverage = pc.total; r.allele_support = pc.support; r.reference_support = pc.refsup;
+        r.num_no_calls = pc.nocalls;
+        for (int d = 0; d < 3; d++) { r.coverage_by_dir[d] = pc.cov[d]; r.support_by_dir[d] = pc.sup[d]; }
+        r.variant_qscore = 0; r.strand_bias_score = 0.0; r.genotype_qscore = 0; r.filter_bits = 0;
+        r.info = PISCES_INFO_PACK(PISCES_GT_HET_ALT_REF, c.category, rt, a, 0, 0, 0);
+        const bool ok = process_point_allele(pc, c.position, a, isRef, rt, ref, 0, ref_len, P, r);
+        out[i] = r;
+        callable_out[i] = ok ? 1 : 0;
+        return;
+    }
+    const int length = c.category == PISCES_CAT_INSERTION ? c.alt_len - 1 : c.category == PISCES_CAT_DELETION ? c.ref_len - 1 : c.alt_len;
     const int support = c.sup[0] + c.sup[1] + c.sup[2];
     const SpanningCoverage sc = spanning_coverage(c, counts, expect_stitched);
     const int cov[3] = {sc.cov[0], sc.cov[1], sc.cov[2]};
@@ -1212,9 +1259,19 @@ __global__ __launch_bounds__(64) void call_spanning_kernel(
     if (P.vq_filter >= 0 && vq < P.vq_filter && total != 0) filters |= 1u << PISCES_FILTER_LOW_VARIANT_QSCORE;
     if (!sb.acceptable || (P.filter_single_strand && !sb.var_both)) filters |= 1u << PISCES_FILTER_STRAND_BIAS;
     if (P.rmxn_max_len >= 0 && !(freq >= P.rmxn_freq_limit)) {   // RMxNCalculator.ShouldFilter :19-38
-        const uint8_t* vb = alleles + c.allele_off + (c.category == PISCES_CAT_INSERTION ? c.ref_len + 1 : 1);
-        const int c1 = rmxn_length_for_indel(c.position, vb, length, ref, ref_len, P.rmxn_max_len);
-        if (c1 >= P.rmxn_min_rep) filters |= 1u << PISCES_FILTER_RMXN;
+        int c1, c2 = 2147483647;
+        if (c.category == PISCES_CAT_MNV) {   // :30-36: the reference allele's repeat against the alternate allele's at either end
+            const uint8_t* rb = alleles + c.allele_off;
+            const uint8_t* ab = alleles + c.allele_off + c.ref_len;
+            c1 = rmxn_length_for_indel(c.position - 1, rb, c.ref_len, ref, ref_len, P.rmxn_max_len);
+            const int i1 = rmxn_length_for_indel(c.position + c.ref_len - 1, ab, c.alt_len, ref, ref_len, P.rmxn_max_len);
+            const int i2 = rmxn_length_for_indel(c.position - 1, ab, c.alt_len, ref, ref_len, P.rmxn_max_len);
+            c2 = i1 > i2 ? i1 : i2;
+        } else {
+            const uint8_t* vb = alleles + c.allele_off + (c.category == PISCES_CAT_INSERTION ? c.ref_len + 1 : 1);
+            c1 = rmxn_length_for_indel(c.position, vb, length, ref, ref_len, P.rmxn_max_len);
+        }
+        if ((c1 < c2 ? c1 : c2) >= P.rmxn_min_rep) filters |= 1u << PISCES_FILTER_RMXN;
     }
     if (P.vf_filter >= 0.0f && freq < P.vf_filter) filters |= 1u << PISCES_FILTER_LOW_VARIANT_FREQUENCY;
     if (expect_stitched) {   // AlleleProcessor.cs:64-68

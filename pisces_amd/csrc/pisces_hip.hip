@@ -6,6 +6,9 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <array>
+#include <cctype>
+#include <memory>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -220,6 +223,7 @@ static DeviceParams make_params(const PiscesHipConfig& c)
     P.gq_tail = nullptr;
     P.gq_tail_a = 0;
     P.gq_tail_cov = 0;
+    P.refs_only = c.call_mnvs ? 1 : 0;
     return P;
 }
 
@@ -539,6 +543,31 @@ static int32_t validate_batch(const PiscesReadBatch* b)
     return PISCES_OK;
 }
 
+// IStateManager.AddCandidates -> RegionState.AddCandidate (RegionState.cs:94-174): merge by CandidateAllele.Equals, and with the
+// collapser on (trackOpenEnded) keep open-ended candidates apart (:114-137); UpdateMaxPosition (:205-223)
+static void add_candidate(PiscesHip* h, const HostCandidate& cnd)
+{
+    BlockObs* b = get_block(h, cnd.position);
+    std::string key = std::to_string(cnd.position) + "|" + std::to_string(cnd.category) + "|" + cnd.ref + ">" + cnd.alt;
+    if (h->cfg.collapse) key += cnd.open_left ? (cnd.open_right ? "|LR" : "|L") : (cnd.open_right ? "|R" : "|");
+    auto it = b->cand_index.find(key);
+    if (it == b->cand_index.end()) {
+        b->cand_index.emplace(std::move(key), b->cands.size());
+        b->cands.push_back(cnd);
+    } else {
+        HostCandidate& e = b->cands[it->second];
+        for (int d = 0; d < 3; d++) {
+            e.support_by_dir[d] += cnd.support_by_dir[d];
+            e.well_anchored_by_dir[d] += cnd.well_anchored_by_dir[d];
+        }
+    }
+    int32_t other_end = 0;
+    if (cnd.category == PISCES_CAT_DELETION) other_end = cnd.position + (int32_t)cnd.ref.size();
+    else if (cnd.category == PISCES_CAT_INSERTION) other_end = cnd.position + 1;
+    else if (cnd.category == PISCES_CAT_MNV) other_end = cnd.position + (int32_t)cnd.ref.size() - 1;
+    if (other_end > b->max_allele_endpoint) b->max_allele_endpoint = other_end;
+}
+
 int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
 {
     if (!h) return PISCES_E_INVALID_ARG;
@@ -578,31 +607,15 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
         ReadView r = read_view(batch, i);
         // ICandidateVariantFinder.FindCandidates + IStateManager.AddCandidates (SmallVariantCaller.cs:92-96) for the
         // candidates the device counts do not imply: insertions and deletions
-        bool has_indel = false;
-        for (int c = 0; c < r.n_cigar; c++) has_indel |= (r.cigar_op[c] == 'I' || r.cigar_op[c] == 'D');
-        if (has_indel && !h->h_ref.empty()) {   // without a reference only the IStateManager half (allele counts) runs
+        bool walk = h->cfg.call_mnvs != 0;   // MNV calling: SNV / MNV candidates come from the M operations too
+        for (int c = 0; c < r.n_cigar && !walk; c++) walk = (r.cigar_op[c] == 'I' || r.cigar_op[c] == 'D');
+        if (walk && !h->h_ref.empty()) {   // without a reference only the IStateManager half (allele counts) runs
             found.clear();
-            find_indel_candidates(r, h->h_ref.data(), h->ref_len, minBQ, PISCES_ANCHOR_SIZE, found);
+            find_candidates(r, h->h_ref.data(), h->ref_len, minBQ, PISCES_ANCHOR_SIZE, h->cfg.call_mnvs != 0, h->cfg.call_mnvs != 0,
+                            h->cfg.max_mnv_length, h->cfg.max_gap_between_mnv, found);
             for (auto& cnd : found) {
                 if (cnd.position <= 0) continue;
-                BlockObs* b = get_block(h, cnd.position);
-                // RegionState.AddCandidate: with the collapser on (trackOpenEnded) open-ended candidates stay apart (RegionState.cs:114-137)
-                std::string key = std::to_string(cnd.position) + "|" + std::to_string(cnd.category) + "|" + cnd.ref + ">" + cnd.alt;
-                if (h->cfg.collapse) key += cnd.open_left ? (cnd.open_right ? "|LR" : "|L") : (cnd.open_right ? "|R" : "|");
-                auto it = b->cand_index.find(key);
-                if (it == b->cand_index.end()) {
-                    b->cand_index.emplace(std::move(key), b->cands.size());
-                    b->cands.push_back(cnd);
-                } else {
-                    HostCandidate& e = b->cands[it->second];
-                    for (int d = 0; d < 3; d++) {
-                        e.support_by_dir[d] += cnd.support_by_dir[d];
-                        e.well_anchored_by_dir[d] += cnd.well_anchored_by_dir[d];
-                    }
-                }
-                // RegionState.UpdateMaxPosition (RegionState.cs:205-223)
-                const int32_t other_end = cnd.category == PISCES_CAT_DELETION ? cnd.position + (int32_t)cnd.ref.size() : cnd.position + 1;
-                if (other_end > b->max_allele_endpoint) b->max_allele_endpoint = other_end;
+                add_candidate(h, cnd);
             }
         }
         // GetBlock(position) for every position that receives a count (RegionStateManager.cs:361-383): the runs of mapped
@@ -903,8 +916,7 @@ static void launch_compaction(hipStream_t s, const PiscesCalledAllele* d_records
 // device work of one flush: returns called alleles of `keys` sorted by (position, ref, alt)
 static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::vector<PiscesCalledAllele>& out, int64_t* n_called)
 {
-    out.clear();
-    *n_called = 0;
+    out.clear();   // (*n_called accumulates: the caller zeroes it)
     if (keys.empty()) return PISCES_OK;
     if (!h->d_ref.p) return fail(h, PISCES_E_STATE, "flush: set_reference has not been called");
     std::vector<PiscesTile> tiles;
@@ -977,35 +989,178 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
 }
 
 // ------------------------------------------------------------------------------------------------
-// VariantCollapser.Collapse (exe/Pisces/Logic/VariantCalling/VariantCollapser.cs:31-79) for the insertion / deletion
-// candidates of a batch.  SNV candidates need no pass here: an open-ended SNV collapses into its anchored twin, and the
-// device counts are that sum already.  Frequencies come from the same spanning_coverage() the device call uses, over a host
-// copy of the anchor-resolved counts.
+// VariantCollapser.Collapse (exe/Pisces/Logic/VariantCalling/VariantCollapser.cs:31-79) for the host-side candidates of a batch:
+// insertions / deletions, and with MNV calling on the SNV / MNV candidates too.  With it off SNV candidates need no pass here: an
+// open-ended SNV collapses into its anchored twin, and the device counts are that sum already.  Frequencies come from the same
+// coverage functions the device call uses, over a host copy of the anchor-resolved counts.
 // ------------------------------------------------------------------------------------------------
 namespace {
-inline int cand_length(const HostCandidate& c) { return c.category == PISCES_CAT_INSERTION ? (int)c.alt.size() - 1 : (int)c.ref.size() - 1; }
+inline int cand_length(const HostCandidate& c)   // BaseAllele.Length
+{
+    return c.category == PISCES_CAT_INSERTION ? (int)c.alt.size() - 1 : c.category == PISCES_CAT_DELETION ? (int)c.ref.size() - 1 : (int)c.alt.size();
+}
 inline int cand_support(const HostCandidate& c) { return c.support_by_dir[0] + c.support_by_dir[1] + c.support_by_dir[2]; }
 inline bool cand_fully_anchored(const HostCandidate& c) { return !c.open_left && !c.open_right; }
 inline bool cand_equals(const HostCandidate& a, const HostCandidate& b)
 {
     return a.position == b.position && a.alt == b.alt && a.category == b.category && a.ref == b.ref;
 }
-// CanCollapse :119-174 (insertions and deletions)
+// CanCollapse :119-174
 bool can_collapse(const HostCandidate& t, const HostCandidate& p)
 {
-    if (t.category != p.category || cand_length(t) > cand_length(p) || (cand_fully_anchored(t) && !cand_fully_anchored(p))) return false;
-    const bool del = t.category == PISCES_CAT_DELETION;
-    const std::string& tb = del ? t.ref : t.alt;
-    const std::string& pb = del ? p.ref : p.alt;
+    const bool ti = t.category == PISCES_CAT_INSERTION, pi = p.category == PISCES_CAT_INSERTION;
+    const bool td = t.category == PISCES_CAT_DELETION, pd = p.category == PISCES_CAT_DELETION;
+    if (ti != pi || td != pd || cand_length(t) > cand_length(p) || (cand_fully_anchored(t) && !cand_fully_anchored(p))) return false;
+    const std::string& tb = td ? t.ref : t.alt;
+    const std::string& pb = pd ? p.ref : p.alt;
     if (cand_fully_anchored(t) && cand_fully_anchored(p)) return cand_equals(t, p);
-    if (del) {
+    if (td) {
         if (t.open_right) return p.position + 1 == t.position + 1;
         return p.position + (int)pb.size() - 1 == t.position + (int)tb.size() - 1;
     }
     if (t.open_right) return p.position == t.position && pb.size() >= tb.size() && pb.compare(0, tb.size(), tb) == 0;
-    if (p.position + 1 != t.position + 1) return false;
-    if (pb.size() + 1 < tb.size()) return false;
-    return pb.compare(pb.size() - tb.size() + 1, std::string::npos, tb, 1, std::string::npos) == 0;
+    if (ti) {
+        if (p.position + 1 != t.position + 1) return false;
+        if (pb.size() + 1 < tb.size()) return false;
+        return pb.compare(pb.size() - tb.size() + 1, std::string::npos, tb, 1, std::string::npos) == 0;
+    }
+    // SNV / MNV anchored on the right: same last position, the bases are a suffix
+    return p.position + (int)p.alt.size() - 1 == t.position + (int)t.alt.size() - 1 && p.alt.size() >= t.alt.size() &&
+           p.alt.compare(p.alt.size() - t.alt.size(), std::string::npos, t.alt) == 0;
+}
+
+// ---- MnvReallocator (exe/Pisces/Logic/VariantCalling/MnvReallocator.cs:12-261) over heap HostCandidate objects; AlleleSupport is the
+// sum of support_by_dir throughout (AlleleHelper.Map and every CreateVariant on this path keep the two in step) ----
+using CandPtr = HostCandidate*;
+struct MnvArena {   // owns every object the reallocation creates
+    std::vector<std::unique_ptr<HostCandidate>> objs;
+    CandPtr make(int32_t position, const std::string& alt, const std::string& ref, const int32_t* dirs)   // CreateVariant :151-168
+    {
+        objs.emplace_back(new HostCandidate());
+        CandPtr v = objs.back().get();
+        bool same = alt.size() == ref.size();
+        for (size_t i = 0; same && i < alt.size(); i++) same = std::toupper((unsigned char)alt[i]) == std::toupper((unsigned char)ref[i]);
+        v->category = same ? PISCES_CAT_REFERENCE : (alt.size() > 1 ? PISCES_CAT_MNV : PISCES_CAT_SNV);
+        v->position = position;
+        v->alt = alt;
+        v->ref = ref;
+        if (dirs) for (int d = 0; d < 3; d++) v->support_by_dir[d] = dirs[d];
+        return v;
+    }
+};
+inline void list_remove(std::vector<CandPtr>& l, CandPtr v)
+{
+    auto it = std::find(l.begin(), l.end(), v);
+    if (it != l.end()) l.erase(it);
+}
+inline bool overlap_before(CandPtr a, CandPtr b)   // OrderByDescending(alt.Length).ThenByDescending(AlleleSupport).ThenBy(alt).ThenBy(ref)
+{
+    if (a->alt.size() != b->alt.size()) return a->alt.size() > b->alt.size();
+    if (cand_support(*a) != cand_support(*b)) return cand_support(*a) > cand_support(*b);
+    if (a->alt != b->alt) return a->alt < b->alt;
+    return a->ref < b->ref;
+}
+CandPtr mnv_break_off_edge_references(MnvArena& arena, CandPtr allele)   // :212-241
+{
+    if (allele->category != PISCES_CAT_MNV) return allele;
+    const int n = (int)allele->ref.size();
+    int leftAdjust = 0, rightAdjust = 0;
+    for (int i = 0; i < n; i++) { if (allele->ref[(size_t)i] != allele->alt[(size_t)i]) break; leftAdjust++; }
+    for (int i = 0; i < n; i++) { const int k = n - 1 - i; if (allele->ref[(size_t)k] != allele->alt[(size_t)k]) break; rightAdjust++; }
+    return arena.make(allele->position + leftAdjust, allele->alt.substr((size_t)leftAdjust, allele->alt.size() - (size_t)(leftAdjust + rightAdjust)),
+                      allele->ref.substr((size_t)leftAdjust, allele->ref.size() - (size_t)(leftAdjust + rightAdjust)), allele->support_by_dir);
+}
+void mnv_process_overlap(MnvArena& arena, bool hasMax, int32_t blockMaxPos, CandPtr overlap, CandPtr toReassign, std::vector<CandPtr>& remainderAlleles,
+                         std::vector<CandPtr>& outsideThisBlock)   // :97-133
+{
+    for (int d = 0; d < 3; d++) overlap->support_by_dir[d] += toReassign->support_by_dir[d];
+    list_remove(remainderAlleles, toReassign);
+    // CreateAllelesFromRemainder :170-210
+    std::vector<CandPtr> remainders;
+    const int overlapIndexInFailedMnv = overlap->position - toReassign->position;
+    const int rightSideOverlap = overlapIndexInFailedMnv + (int)overlap->alt.size();
+    const int altLen = (int)toReassign->alt.size();
+    if (altLen - rightSideOverlap > 0 && rightSideOverlap <= toReassign->position + altLen) {
+        CandPtr r = arena.make(toReassign->position + rightSideOverlap, toReassign->alt.substr((size_t)rightSideOverlap),
+                               toReassign->ref.substr((size_t)rightSideOverlap, (size_t)(altLen - rightSideOverlap)), toReassign->support_by_dir);
+        if (r->category != PISCES_CAT_REFERENCE) remainders.push_back(r);
+    }
+    if (overlapIndexInFailedMnv > 0) {
+        CandPtr l = arena.make(toReassign->position, toReassign->alt.substr(0, (size_t)overlapIndexInFailedMnv),
+                               toReassign->ref.substr(0, (size_t)overlapIndexInFailedMnv), toReassign->support_by_dir);
+        if (l->category != PISCES_CAT_REFERENCE) remainders.push_back(l);
+    }
+    for (auto& r : remainders) r = mnv_break_off_edge_references(arena, r);
+    if (hasMax) {
+        if (overlap->position > blockMaxPos) { list_remove(remainderAlleles, overlap); outsideThisBlock.push_back(overlap); }
+        for (CandPtr r : remainders) (r->position <= blockMaxPos ? remainderAlleles : outsideThisBlock).push_back(r);
+    } else {
+        for (CandPtr r : remainders) remainderAlleles.push_back(r);
+    }
+}
+// ReallocateFailedMnvs :12-95
+void mnv_reallocate_failed(MnvArena& arena, const std::vector<CandPtr>& failed, std::vector<CandPtr>& callable, bool hasMax, int32_t blockMaxPos,
+                           std::vector<CandPtr>& outsideThisBlock)
+{
+    std::vector<CandPtr> ordered(failed);
+    std::stable_sort(ordered.begin(), ordered.end(), [](CandPtr a, CandPtr b) {
+        if (a->position != b->position) return a->position < b->position;
+        return overlap_before(a, b);
+    });
+    for (CandPtr failedMnv : ordered) {
+        std::vector<CandPtr> remainderAlleles{failedMnv};
+        while (!remainderAlleles.empty()) {
+            CandPtr alleleToReassign = remainderAlleles.front();
+            const int fl = (int)alleleToReassign->alt.size();
+            std::vector<CandPtr> overlaps;
+            for (CandPtr c : callable) {   // IsPotentialOverlap :250-261
+                const int cl = (int)c->alt.size();
+                if (c->position >= alleleToReassign->position && c->position <= alleleToReassign->position + fl && cl <= fl &&
+                    c->position + cl <= alleleToReassign->position + fl &&
+                    (c->category == PISCES_CAT_MNV || c->category == PISCES_CAT_SNV || c->category == PISCES_CAT_REFERENCE))
+                    overlaps.push_back(c);
+            }
+            std::stable_sort(overlaps.begin(), overlaps.end(), overlap_before);
+            CandPtr firstMatch = nullptr;
+            bool anyLongMatch = false;
+            for (CandPtr o : overlaps)   // OverlapMatches :243-248
+                if (alleleToReassign->alt.compare((size_t)(o->position - alleleToReassign->position), o->alt.size(), o->alt) == 0) {
+                    if (!firstMatch) firstMatch = o;
+                    if (o->alt.size() > 1) anyLongMatch = true;
+                }
+            bool reallocated = false;
+            if (hasMax) {
+                const int distanceIntoNextBlock = alleleToReassign->position + (fl - 1) - blockMaxPos;
+                if (distanceIntoNextBlock > 0 && !anyLongMatch) {
+                    if (alleleToReassign->position <= blockMaxPos) {   // peel off into the next block
+                        const int originalAlleleLength = (int)alleleToReassign->ref.size();
+                        CandPtr next = arena.make(blockMaxPos + 1, alleleToReassign->alt.substr((size_t)(originalAlleleLength - distanceIntoNextBlock), (size_t)distanceIntoNextBlock),
+                                                  alleleToReassign->ref.substr((size_t)(originalAlleleLength - distanceIntoNextBlock), (size_t)distanceIntoNextBlock), nullptr);
+                        next = mnv_break_off_edge_references(arena, next);
+                        mnv_process_overlap(arena, hasMax, blockMaxPos, next, alleleToReassign, remainderAlleles, outsideThisBlock);
+                    } else {
+                        list_remove(remainderAlleles, alleleToReassign);
+                        outsideThisBlock.push_back(alleleToReassign);
+                    }
+                    reallocated = true;
+                }
+            }
+            if (!reallocated && firstMatch) {
+                mnv_process_overlap(arena, hasMax, blockMaxPos, firstMatch, alleleToReassign, remainderAlleles, outsideThisBlock);
+                reallocated = true;
+            }
+            if (!reallocated) {   // BreakDownToSingleNucCalls :135-149
+                for (int i = 0; i < fl; i++) {
+                    CandPtr sn = arena.make(alleleToReassign->position + i, alleleToReassign->alt.substr((size_t)i, 1), alleleToReassign->ref.substr((size_t)i, 1),
+                                            alleleToReassign->support_by_dir);
+                    if (sn->category == PISCES_CAT_REFERENCE) continue;
+                    if (hasMax && sn->position > blockMaxPos) outsideThisBlock.push_back(sn);
+                    else callable.push_back(sn);
+                }
+                list_remove(remainderAlleles, alleleToReassign);
+            }
+        }
+    }
 }
 }  // namespace
 
@@ -1079,30 +1234,42 @@ static int64_t collapse_candidates(std::vector<HostCandidate>& cands, float freq
 }
 }  // extern "C++"
 
-// IAlleleCaller.Call for the host-found insertion / deletion candidates of `keys`: anchor-resolved counts of every
-// block a candidate touches -> call_spanning_kernel -> callable candidates with their records.
+// IAlleleCaller.Call for the host-found candidates of `keys` (AlleleCaller.CallForPositions :60-141): anchor-resolved counts of every
+// block a candidate touches -> collapser -> call_spanning_kernel -> callable candidates with their records.  With MNV calling on
+// the candidates include the SNVs / MNVs of the read walk: MNV candidates are processed first, the ones that are not callable go
+// through MnvReallocator on the host, leftovers past the last cleared block return to the state as candidates of the next block,
+// reference support taken by gapped MNVs is registered (it reaches the Reference records through call_blocks, which runs after
+// this), and every callable allele is processed again.  ref_overrides: Reference alleles that reallocation added support to
+// (they replace the tile kernels' Reference record of that position).
 static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, std::vector<PiscesCalledAllele>& recs,
-                             std::vector<HostCandidate>& called, int64_t* n_called, int64_t* n_collapsed)
+                             std::vector<HostCandidate>& called, int64_t* n_called, int64_t* n_collapsed,
+                             std::vector<PiscesCalledAllele>& ref_overrides)
 {
     recs.clear();
     called.clear();
+    ref_overrides.clear();
     *n_collapsed = 0;
+    const bool mnv_mode = h->cfg.call_mnvs != 0;
     std::vector<HostCandidate> work;   // a copy: the blocks keep their candidates until DoneProcessing
-    for (int32_t key : keys)
+    for (int32_t key : keys) {
+        // RegionState.GetAllCandidates walks _candidateVariantsLookup by position, each position in arrival order (RegionState.cs:388-391)
+        const size_t first = work.size();
         for (auto& c : h->blocks[key].cands) work.push_back(c);
+        std::stable_sort(work.begin() + (std::ptrdiff_t)first, work.end(), [](const HostCandidate& x, const HostCandidate& y) { return x.position < y.position; });
+    }
     if (work.empty()) return PISCES_OK;
-    std::vector<const HostCandidate*> cands;
-    for (auto& c : work) cands.push_back(&c);
     const int bs = h->cfg.block_size;
     // start / end points (CoverageCalculator.Compute :27-41)
     auto endpoints = [](const HostCandidate& c, int32_t& sp, int32_t& ep) {
         if (c.category == PISCES_CAT_DELETION) { sp = c.position + 1; ep = c.position + (int32_t)c.ref.size() - 1; }
-        else { sp = c.position; ep = c.position + 1; }
+        else if (c.category == PISCES_CAT_MNV) { sp = c.position; ep = c.position + (int32_t)c.alt.size() - 1; }
+        else if (c.category == PISCES_CAT_INSERTION) { sp = c.position; ep = c.position + 1; }
+        else { sp = c.position; ep = c.position; }
     };
     std::vector<int32_t> bkeys;
-    for (auto* c : cands) {
+    for (auto& c : work) {
         int32_t sp, ep;
-        endpoints(*c, sp, ep);
+        endpoints(c, sp, ep);
         for (int32_t p : {sp, ep}) {
             const int32_t k = block_key(h, p);
             if (p > 0 && h->blocks.count(k)) bkeys.push_back(k);
@@ -1137,6 +1304,10 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, std
         PISCES_HIP_CHECK(h, h->d_counts.reserve(PISCES_COUNTS_PER_LOCUS));
     }
     auto atype = [](char ch) { return ch == 'A' ? 0 : ch == 'G' ? 1 : ch == 'C' ? 2 : ch == 'T' ? 3 : 4; };
+    auto gapped_at = [&](int32_t p) {
+        auto it = h->gapped_mnv_ref.find(p);
+        return it == h->gapped_mnv_ref.end() ? 0 : it->second;
+    };
     auto to_dev = [&](const HostCandidate& c, DevCandidate& d) {
         std::memset(&d, 0, sizeof(d));
         d.position = c.position;
@@ -1153,77 +1324,173 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, std
         endpoints(c, sp, ep);
         d.start_idx = locus_index(sp);
         d.end_idx = locus_index(ep);
+        d.gapped = (c.category == PISCES_CAT_SNV || c.category == PISCES_CAT_REFERENCE) ? gapped_at(c.position) : 0;
     };
-    if (h->cfg.collapse) {
-        // the collapser's frequencies: host copy of the anchor-resolved counts of the touched blocks, same coverage function
-        std::vector<int32_t> host_counts((size_t)std::max(n_tiles, 1) * kTile * PISCES_COUNTS_PER_LOCUS, 0);
+    // the collapser's frequencies and the reallocator's Reference candidates read a host copy of the anchor-resolved counts
+    std::vector<int32_t> host_counts;
+    if (h->cfg.collapse || mnv_mode) {
+        host_counts.assign((size_t)std::max(n_tiles, 1) * kTile * PISCES_COUNTS_PER_LOCUS, 0);
         if (n_tiles > 0) {
             PISCES_HIP_CHECK(h, hipMemcpyAsync(host_counts.data(), h->d_counts.p, host_counts.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
             PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
         }
+    }
+    if (h->cfg.collapse) {
         const int32_t stitched = h->cfg.expect_stitched_reads;
         *n_collapsed = collapse_candidates(work, h->cfg.collapse_freq_threshold, h->cfg.collapse_freq_ratio_threshold, [&](const HostCandidate& c) {
             DevCandidate d;
             to_dev(c, d);
-            const SpanningCoverage sc = spanning_coverage(d, host_counts.data(), stitched);
+            const int total = candidate_total_coverage(d, host_counts.data(), stitched);
             const int support = c.support_by_dir[0] + c.support_by_dir[1] + c.support_by_dir[2];
-            if (sc.total == 0) return 0.0f;                       // CalledAllele.Frequency (CalledAllele.cs:49-52)
-            const float f = (float)support / (float)sc.total;
+            if (total == 0) return 0.0f;                       // CalledAllele.Frequency (CalledAllele.cs:49-52)
+            const float f = (float)support / (float)total;
             return f < 1.0f ? f : 1.0f;
         });
-        cands.clear();
-        for (auto& c : work) cands.push_back(&c);
+        // candidates past the last cleared position that could not be collapsed stay with their (held) blocks: this batch only holds
+        // candidates of cleared blocks, so there is nothing to hand back (VariantCollapser.cs:67-75)
     }
-    std::vector<DevCandidate> dc(cands.size());
-    std::vector<uint8_t> pool;
-    for (size_t i = 0; i < cands.size(); i++) {
-        const HostCandidate& c = *cands[i];
-        DevCandidate& d = dc[i];
-        std::memset(&d, 0, sizeof(d));
-        d.position = c.position;
-        d.category = c.category;
-        d.ref_len = (int32_t)c.ref.size();
-        d.alt_len = (int32_t)c.alt.size();
-        for (int k = 0; k < 3; k++) { d.sup[k] = c.support_by_dir[k]; d.anch[k] = c.well_anchored_by_dir[k]; }
-        d.first_base = d.last_base = PISCES_ALLELE_N;
-        if (c.category == PISCES_CAT_INSERTION && c.alt.size() >= 2) {
-            d.first_base = atype(c.alt[1]);
-            d.last_base = atype(c.alt[c.alt.size() - 1]);
+    // one device pass over a list of candidates: records + IsCallable
+    std::vector<PiscesCalledAllele> raw;
+    std::vector<uint8_t> callable;
+    auto device_pass = [&](const std::vector<const HostCandidate*>& list) -> int32_t {
+        std::vector<DevCandidate> dc(list.size());
+        std::vector<uint8_t> pool;
+        for (size_t i = 0; i < list.size(); i++) {
+            to_dev(*list[i], dc[i]);
+            dc[i].allele_off = (int32_t)pool.size();
+            pool.insert(pool.end(), list[i]->ref.begin(), list[i]->ref.end());
+            pool.insert(pool.end(), list[i]->alt.begin(), list[i]->alt.end());
         }
-        int32_t sp, ep;
-        endpoints(c, sp, ep);
-        d.start_idx = locus_index(sp);
-        d.end_idx = locus_index(ep);
-        d.allele_off = (int32_t)pool.size();
-        pool.insert(pool.end(), c.ref.begin(), c.ref.end());
-        pool.insert(pool.end(), c.alt.begin(), c.alt.end());
+        raw.assign(dc.size(), PiscesCalledAllele{});
+        callable.assign(dc.size(), 0);
+        if (dc.empty()) return PISCES_OK;
+        const int32_t n = (int32_t)dc.size();
+        PISCES_HIP_CHECK(h, h->d_cands.reserve(dc.size()));
+        PISCES_HIP_CHECK(h, h->d_alleles.reserve(pool.size() + 16));
+        PISCES_HIP_CHECK(h, h->d_cand_records.reserve(dc.size()));
+        PISCES_HIP_CHECK(h, h->d_cand_callable.reserve(dc.size()));
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_cands.p, dc.data(), dc.size() * sizeof(DevCandidate), hipMemcpyHostToDevice, h->stream));
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_alleles.p, pool.data(), pool.size(), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(call_spanning_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, h->d_cands.p, n, h->d_counts.p,
+                           h->d_alleles.p, h->d_ref.p, h->ref_len, h->cfg.expect_stitched_reads, h->d_cand_records.p, h->d_cand_callable.p, h->P);
+        PISCES_HIP_CHECK(h, hipGetLastError());
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(raw.data(), h->d_cand_records.p, raw.size() * sizeof(PiscesCalledAllele), hipMemcpyDeviceToHost, h->stream));
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(callable.data(), h->d_cand_callable.p, callable.size(), hipMemcpyDeviceToHost, h->stream));
+        PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+        return PISCES_OK;
+    };
+    auto inside_intervals = [&](int32_t position) {   // ShouldReport (AlleleCaller.cs:260-263)
+        if (h->intervals.empty()) return true;
+        for (auto& iv : h->intervals)
+            if (position >= iv.first && position <= iv.second) return true;
+        return false;
+    };
+
+    std::vector<const HostCandidate*> final_list;
+    MnvArena arena;
+    std::vector<CandPtr> callable_alleles;          // AlleleCaller's callableAlleles (non-Reference ones and touched Reference ones)
+    std::map<int32_t, CandPtr> touched_refs;         // Reference candidates created for the reallocator, by position
+    if (!mnv_mode) {
+        for (auto& c : work) final_list.push_back(&c);
+    } else {
+        // ---- MNV candidates first (AlleleCaller.cs:69-89)
+        std::vector<const HostCandidate*> mnvs;
+        for (auto& c : work)
+            if (c.category == PISCES_CAT_MNV) mnvs.push_back(&c);
+        int32_t rc1 = device_pass(mnvs);
+        if (rc1) return rc1;
+        std::vector<CandPtr> failed;
+        {
+            size_t mi = 0;
+            for (auto& c : work) {
+                if (c.category == PISCES_CAT_MNV) {
+                    if (callable[mi]) { callable_alleles.push_back(&c); (*n_called)++; }   // IsCallable counts every pass (_totalNumCalled)
+                    else failed.push_back(&c);
+                    mi++;
+                } else {
+                    callable_alleles.push_back(&c);
+                }
+            }
+        }
+        if (!failed.empty()) {
+            // Reference candidates of this batch that a failed MNV can reach: only those whose base equals the MNV's base there can
+            // match (OverlapMatches); their AlleleSupport (the reference base's counts) decides the order among one-base overlaps
+            const int32_t last_cleared = keys.back() * bs;
+            auto ref_candidate_exists = [&](int32_t p, int32_t (&sup)[3]) {
+                if (!h->cfg.include_reference_calls || p < 1 || p > h->ref_len || !inside_intervals(p)) return false;
+                if (!std::binary_search(keys.begin(), keys.end(), block_key(h, p))) return false;
+                const int64_t li = locus_index(p);
+                const int rb = atype((char)h->h_ref[(size_t)p - 1]);
+                int total = 0;
+                sup[0] = sup[1] = sup[2] = 0;
+                if (li >= 0)
+                    for (int at = 0; at < PISCES_NUM_ALLELE_TYPES; at++)
+                        for (int d = 0; d < 3; d++) {
+                            int cnt = 0;
+                            const int32_t* row = host_counts.data() + li * PISCES_COUNTS_PER_LOCUS + (at * 3 + d) * PISCES_NUM_ANCHORS;
+                            for (int an = 0; an < PISCES_NUM_ANCHORS; an++) cnt += row[an];
+                            if (at == rb) sup[d] = cnt;
+                            total += cnt;
+                        }
+                return h->cfg.emit_zero_coverage_refs != 0 || total > 0;   // RegionState.cs:446
+            };
+            for (CandPtr f : failed)
+                for (size_t k = 0; k < f->alt.size(); k++) {
+                    const int32_t p = f->position + (int32_t)k;
+                    if (f->alt[k] != f->ref[k] || touched_refs.count(p)) continue;
+                    int32_t sup[3];
+                    if (!ref_candidate_exists(p, sup)) continue;
+                    CandPtr rc = arena.make(p, std::string(1, f->ref[k]), std::string(1, f->ref[k]), sup);
+                    touched_refs[p] = rc;
+                }
+            // GetAllCandidates appends the Reference candidates after the variant candidates of a block: the order only matters for
+            // ties between alleles of equal length, support and bases, which Reference candidates (base == reference) cannot have with
+            // a variant; among themselves they are in position order
+            std::vector<CandPtr> ref_originals;
+            std::vector<std::array<int32_t, 3>> ref_before;
+            for (auto& kv : touched_refs) {
+                callable_alleles.push_back(kv.second);
+                ref_originals.push_back(kv.second);
+                ref_before.push_back({kv.second->support_by_dir[0], kv.second->support_by_dir[1], kv.second->support_by_dir[2]});
+            }
+            std::vector<CandPtr> outside;
+            mnv_reallocate_failed(arena, failed, callable_alleles, true, last_cleared, outside);
+            for (CandPtr o : outside)   // source.AddCandidates(leftovers.Select(AlleleHelper.Map)) :92-93
+                if (o->category != PISCES_CAT_REFERENCE && o->position > 0) {
+                    HostCandidate c = *o;
+                    c.well_anchored_by_dir[0] = c.well_anchored_by_dir[1] = c.well_anchored_by_dir[2] = 0;
+                    c.open_left = c.open_right = false;
+                    add_candidate(h, c);
+                }
+            // Reference candidates keep only what reallocation added: the kernel supplies their own counts
+            for (size_t i = 0; i < ref_originals.size(); i++)
+                for (int d = 0; d < 3; d++) ref_originals[i]->support_by_dir[d] -= ref_before[i][(size_t)d];
+        }
+        // GetRefSupportFromGappedMnvs :180-203 -> IAlleleSource.AddGappedMnvRefCount
+        for (CandPtr a : callable_alleles) {
+            if (a->category != PISCES_CAT_MNV) continue;
+            const int support = cand_support(*a);
+            for (size_t k = 0; k < a->ref.size() && k < a->alt.size(); k++)
+                if (a->ref[k] == a->alt[k]) h->gapped_mnv_ref[a->position + (int32_t)k] += support;
+        }
+        for (CandPtr a : callable_alleles) {
+            if (a->category == PISCES_CAT_REFERENCE && cand_support(*a) == 0) continue;   // untouched: the tile kernels' record stands
+            final_list.push_back(a);
+        }
     }
-    const int32_t n = (int32_t)dc.size();
-    PISCES_HIP_CHECK(h, h->d_cands.reserve(dc.size()));
-    PISCES_HIP_CHECK(h, h->d_alleles.reserve(pool.size() + 16));
-    PISCES_HIP_CHECK(h, h->d_cand_records.reserve(dc.size()));
-    PISCES_HIP_CHECK(h, h->d_cand_callable.reserve(dc.size()));
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_cands.p, dc.data(), dc.size() * sizeof(DevCandidate), hipMemcpyHostToDevice, h->stream));
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_alleles.p, pool.data(), pool.size(), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(call_spanning_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, h->d_cands.p, n, h->d_counts.p,
-                       h->d_alleles.p, h->d_ref.p, h->ref_len, h->cfg.expect_stitched_reads, h->d_cand_records.p, h->d_cand_callable.p, h->P);
-    PISCES_HIP_CHECK(h, hipGetLastError());
-    std::vector<PiscesCalledAllele> raw(dc.size());
-    std::vector<uint8_t> callable(dc.size());
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(raw.data(), h->d_cand_records.p, raw.size() * sizeof(PiscesCalledAllele), hipMemcpyDeviceToHost, h->stream));
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(callable.data(), h->d_cand_callable.p, callable.size(), hipMemcpyDeviceToHost, h->stream));
-    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
-    for (size_t i = 0; i < dc.size(); i++) {
+
+    int32_t rc2 = device_pass(final_list);
+    if (rc2) return rc2;
+    for (size_t i = 0; i < final_list.size(); i++) {
+        if (final_list[i]->category == PISCES_CAT_REFERENCE) {   // counted as called by the tile kernels already
+            ref_overrides.push_back(raw[i]);
+            continue;
+        }
         if (!callable[i]) continue;
-        // ShouldReport (AlleleCaller.cs:260-263): inside the interval set
-        if (!h->intervals.empty()) {
-            bool inside = false;
-            for (auto& iv : h->intervals) inside |= (cands[i]->position >= iv.first && cands[i]->position <= iv.second);
-            if (!inside) { (*n_called)++; continue; }
-        }
         (*n_called)++;
+        if (!inside_intervals(final_list[i]->position)) continue;
         recs.push_back(raw[i]);
-        called.push_back(*cands[i]);
+        called.push_back(*final_list[i]);
     }
     return PISCES_OK;
 }
@@ -1254,12 +1521,24 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
         int64_t called = 0;
         std::vector<PiscesCalledAllele> point_recs, span_recs;
         std::vector<HostCandidate> span_cands;
-        int32_t rc = call_blocks(h, keys, point_recs, &called);
-        if (rc) return rc;
+        // host-side candidates first: with MNV calling on they register the reference support that gapped MNVs take, which the
+        // Reference records of call_blocks must see (AlleleCaller.cs:95, CoverageCalculator.cs:82-97)
         int64_t collapsed = 0;
-        rc = call_spanning(h, keys, span_recs, span_cands, &called, &collapsed);
+        std::vector<PiscesCalledAllele> ref_overrides;
+        int32_t rc = call_spanning(h, keys, span_recs, span_cands, &called, &collapsed, ref_overrides);
         h->pending_collapsed = collapsed;
         if (rc) return rc;
+        rc = call_blocks(h, keys, point_recs, &called);
+        if (rc) return rc;
+        if (!ref_overrides.empty()) {   // Reference alleles that MNV reallocation added support to
+            std::map<int32_t, const PiscesCalledAllele*> by_pos;
+            for (auto& r : ref_overrides) by_pos[r.position] = &r;
+            for (auto& r : point_recs) {
+                if (PISCES_INFO_CATEGORY(r.info) != PISCES_CAT_REFERENCE) continue;
+                auto it = by_pos.find(r.position);
+                if (it != by_pos.end()) r = *it->second;
+            }
+        }
         // per locus: drop the Reference row when a variant is reported there (AlleleCaller.cs:146-147), then order by
         // position, reference allele, alternate allele (:172-176; ordinal order of upper-case ASCII allele strings)
         h->pending.clear();

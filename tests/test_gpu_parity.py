@@ -666,3 +666,133 @@ def test_reference_bams_through_the_library_give_the_vcf_rows_pisces_wrote(torch
     got["position"] += off
     text = engine.format_vcf(case["chrom"], got, alleles=got_alleles, **case["vcf"])
     bam_fixtures.check_lines(case, text.rstrip("\n").split("\n") if text else [], [str(x) for x in z["expected_vcf"]])
+
+
+def _mnv_reads(rng, ref, n_reads, read_len=100, region=(50, 1900), snv_rate=0.004):
+    """Reads with planted MNVs (some gapped), SNVs next to them, random errors that make failing MNV candidates, low-quality bases that
+    open candidates up, and a few indels."""
+    L = len(ref)
+    planted = []   # (position, alt string over consecutive reference positions, fraction)
+    p = region[0] + 20
+    while p < region[1] - 40:
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            alt = "".join(rng.choice([b for b in "ACGT" if b != chr(ref[p - 1 + i])]) for i in range(2))
+        elif kind == 1:
+            alt = "".join(rng.choice([b for b in "ACGT" if b != chr(ref[p - 1 + i])]) for i in range(3))
+        elif kind == 2:   # gapped: mismatch, reference, mismatch
+            alt = rng.choice([b for b in "ACGT" if b != chr(ref[p - 1])]) + chr(ref[p]) + rng.choice([b for b in "ACGT" if b != chr(ref[p + 1])])
+        else:
+            alt = str(rng.choice([b for b in "ACGT" if b != chr(ref[p - 1])]))
+        planted.append((p, alt, float(rng.choice([0.004, 0.03, 0.2, 0.6]))))
+        p += int(rng.integers(7, 40))
+    reads = []
+    for i in range(n_reads):
+        start = int(rng.integers(region[0], region[1] - read_len))
+        seq = bytearray(ref[start - 1: start - 1 + read_len])
+        for (pp, alt, frac) in planted:
+            if start <= pp and pp + len(alt) <= start + read_len and rng.random() < frac:
+                seq[pp - start: pp - start + len(alt)] = alt.encode()
+            elif start <= pp < start + read_len and rng.random() < frac * 0.3:   # partial: only the first base
+                seq[pp - start] = ord(alt[0])
+        for k in range(read_len):
+            if rng.random() < snv_rate:
+                seq[k] = int(rng.choice(list(b"ACGT")))
+        quals = np.where(rng.random(read_len) < 0.03, 12, 37).astype(np.uint8)
+        ops = [("M", read_len)]
+        s = bytes(seq).decode()
+        if rng.random() < 0.03:   # a deletion or an insertion in the middle
+            k = int(rng.integers(20, read_len - 20))
+            if rng.random() < 0.5:
+                ops = [("M", k), ("D", 3), ("M", read_len - k)]
+                s = s[:k] + bytes(ref[start - 1 + k + 3: start - 1 + read_len + 3]).decode()
+            else:
+                ops = [("M", k), ("I", 2), ("M", read_len - k - 2)]
+                s = s[:k] + "GA" + s[k: read_len - 2]
+        reads.append({"pos": start, "cigar": ops, "seq": s, "quals": quals.tolist(), "reverse": bool(i % 2)})
+    return reads
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("collapse", [0, 1])
+@pytest.mark.parametrize("mnv", [(3, 1), (6, 2)])
+def test_mnv_calling_matches_oracle(torch_cuda, collapse, mnv):
+    """SURVEY section 8 rows a4 / a10 / f2 with -callmnvs: SNV / MNV candidates from the read walk, MNV candidates processed first,
+    failed MNVs reallocated (MnvReallocator) to sub-MNVs / SNVs / Reference alleles, gapped-MNV reference counts, every callable allele
+    processed again.  Records, allele strings and TotalNumCalled against the oracle, whole region in one block grid flush."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(100 + 10 * collapse + mnv[0])
+    ref = bytes(rng.choice(list(b"ACGT"), 2000).astype(np.uint8))
+    reads = _mnv_reads(rng, ref, 3000)
+    batch = _abi.ReadBatch(reads)
+    refa = np.frombuffer(ref, dtype=np.uint8)
+    cfg = _abi.default_config(call_mnvs=1, max_mnv_length=mnv[0], max_gap_between_mnv=mnv[1], collapse=collapse, block_size=2000)
+    exp, exp_alleles, _, exp_called = orc.run_reads_full(batch, refa, 1, len(ref), cfg)
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(refa)
+        c.AddAlleleCounts(batch)
+        got, got_alleles = c.CallWithAlleles()
+        stats = c.Stats()
+    cats = (exp["info"] >> 4) & 7
+    assert (cats == _abi.CAT_MNV).sum() >= 5 and (cats == _abi.CAT_SNV).sum() >= 10
+    assert got_alleles == exp_alleles
+    assert_records_match(got, exp)
+    assert stats["TotalNumCalled"] == exp_called
+
+
+@pytest.mark.gpu
+def test_small_s1_bam_mnvs_through_the_library(torch_cuda):
+    """BasicMnvTesting (SomaticVariantCallerFunctionalTests.cs:381-424) on the device: small_S1.bam on the test's mock chr1 with MNV calling
+    on gives exactly the three expected variants, and the records equal the oracle's."""
+    from pisces_amd import engine
+    from tests import bam_fixtures
+    case = bam_fixtures.CASES["bam_small_s1"]
+    z, batch = bam_fixtures.load("bam_small_s1")
+    cfg = _abi.default_config(**case["cfg"])
+    exp, exp_alleles, _, exp_called = orc.run_reads_full(batch, z["ref"], 1, len(z["ref"]), cfg)
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(z["ref"])
+        c.AddAlleleCounts(batch)
+        got, got_alleles = c.CallWithAlleles()
+        stats = c.Stats()
+    assert got_alleles == exp_alleles
+    assert_records_match(got, exp)
+    assert stats["TotalNumCalled"] == exp_called
+    text = engine.format_vcf(case["chrom"], got, alleles=got_alleles)
+    bam_fixtures.check_lines(case, text.rstrip("\n").split("\n"), [str(x) for x in z["expected_vcf"]])
+
+
+@pytest.mark.gpu
+def test_mnv_calling_over_the_block_schedule(torch_cuda):
+    """MNV calling through the streaming block schedule (1000-locus blocks, flush per block as SmallVariantCaller does): blocks are
+    called one by one, each with its own reallocation, and the concatenation equals the oracle's single-window run as long as no MNV
+    candidate straddles a block edge (reads are kept 6 loci away from the edges here; straddling is MnvReallocator's block logic,
+    pinned on the CPU by the reference's BlockStraddling cases)."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(77)
+    ref = bytes(rng.choice(list(b"ACGT"), 3000).astype(np.uint8))
+    reads = []
+    for lo in (1, 1001, 2001):   # reads stay inside their block
+        reads += _mnv_reads(rng, ref, 1200, read_len=90, region=(lo + 6, lo + 993))
+    reads.sort(key=lambda r: r["pos"])
+    refa = np.frombuffer(ref, dtype=np.uint8)
+    cfg = _abi.default_config(call_mnvs=1)
+    exp, exp_alleles, _, exp_called = orc.run_reads_full(_abi.ReadBatch(reads), refa, 1, len(ref), cfg)
+    got, got_alleles = [], []
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(refa)
+        for i in range(0, len(reads), 400):
+            chunk = reads[i: i + 400]
+            c.AddAlleleCounts(_abi.ReadBatch(chunk))
+            r, a = c.CallWithAlleles(upToPosition=chunk[-1]["pos"] - 1)
+            got.append(r)
+            got_alleles += a
+        r, a = c.CallWithAlleles()
+        got.append(r)
+        got_alleles += a
+        stats = c.Stats()
+    got = np.concatenate(got)
+    assert sum(len(x) > 0 for x in [got]) and len(got) == len(exp)
+    assert got_alleles == exp_alleles
+    assert_records_match(got, exp)
+    assert stats["TotalNumCalled"] == exp_called
