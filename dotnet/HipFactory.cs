@@ -20,12 +20,10 @@ namespace Pisces.Hip
 
         public HipFactory(PiscesApplicationOptions options) : base(options) { }
 
-        // SNV candidates are implied by the device counts and insertion / deletion candidates are found by the library
-        // itself from the reads handed to pisces_hip_add_reads (finder.cpp), so with MNV calling off (the default) no
-        // managed finder runs: a finder that yields nothing keeps SmallVariantCaller's loop unchanged.  With -callmnvs
-        // the reference finder is kept for the MNV candidates (HipStateManager.AddCandidates ignores the rest).
-        protected override ICandidateVariantFinder CreateVariantFinder()
-        { return _options.VariantCallingParameters.CallMNVs ? base.CreateVariantFinder() : new NoCandidates(); }
+        // Candidates are found by the library itself from the reads handed to pisces_hip_add_reads (finder.cpp): insertions / deletions
+        // always, SNV / MNV candidates of the M walk when CallMNVs is set (PiscesHipConfig.call_mnvs); with it off SNV candidates are
+        // implied by the device counts.  No managed finder runs: a finder that yields nothing keeps SmallVariantCaller's loop unchanged.
+        protected override ICandidateVariantFinder CreateVariantFinder() { return new NoCandidates(); }
 
         protected override IStateManager CreateStateManager(ChrIntervalSet intervalSet, bool expectStitchedReads = false,
             bool expectCollapsedReads = true)
