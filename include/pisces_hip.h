@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define PISCES_HIP_ABI_VERSION 2
+#define PISCES_HIP_ABI_VERSION 3
 
 /* ---- error codes -------------------------------------------------------- */
 #define PISCES_OK                 0
@@ -54,6 +54,7 @@ enum { PISCES_FILTER_STRAND_BIAS = 0, PISCES_FILTER_POOL_BIAS = 1, PISCES_FILTER
        PISCES_FILTER_NO_CALL = 12 };
 /* src/lib/Pisces.Domain/Types (StrandBiasModel): Poisson, Extended, Diploid */
 enum { PISCES_SB_POISSON = 0, PISCES_SB_EXTENDED = 1, PISCES_SB_DIPLOID = 2 };
+enum { PISCES_NOISE_FLAT = 0, PISCES_NOISE_WINDOW = 1 };   /* Pisces.Domain/Types/ModelTypes.cs:13 */
 
 /* Anchor bins: NumAnchorIndexes = 2*trackedAnchorSize+1 (RegionStateManager.cs:30-31), default 5 -> 11 */
 #define PISCES_ANCHOR_SIZE   5
@@ -122,6 +123,9 @@ typedef struct PiscesHipConfig {
                                          (CandidateVariantFinder.cs:90-232), no longer from the allele counts */
     int32_t max_mnv_length;           /* MaxSizeMNV, 3 */
     int32_t max_gap_between_mnv;      /* MaxGapBetweenMNV, 1 */
+    int32_t noise_model;              /* VariantCallingParameters.NoiseModel: PISCES_NOISE_FLAT (default) or PISCES_NOISE_WINDOW, where the
+                                         variant q-score of an allele uses (int)PtoQ(SumOfBaseQuality / TotalCoverage) as its noise level
+                                         (AlleleCaller.cs:215-218, RegionStateManager.cs:191) */
 } PiscesHipConfig;
 
 /* ---- one called allele (64 bytes; what CalledAllele carries to the VCF writer,

@@ -1165,10 +1165,24 @@ void orc_process_variant(OrcCalled* v, const OrcState* s, const PiscesHipConfig*
                          cfg->expect_stitched_reads);
 
     if (v->allele_support > 0) {
-        /* VariantQualityCalculator.Compute :11-24 (NoiseModel.Flat) */
+        /* VariantQualityCalculator.Compute :11-24 */
+        if (cfg->noise_model == PISCES_NOISE_WINDOW) {
+            /* AlleleCaller.cs:215-218: (int)MathOperations.PtoQ(variant.SumOfBaseQuality / variant.TotalCoverage).  A mean error that
+             * is not a positive finite number (coverage made of deletions only: no base qualities) makes PtoQ +inf, the C# cast gives
+             * int.MinValue, QtoP of that +inf, and MathNet's Poisson(+inf).CumulativeDistribution is 0: p = 1, Q = 0. */
+            double mean = v->sum_of_base_quality / v->total_coverage;
+            if (v->total_coverage == 0 || !(mean > 0.0) || isinf(mean)) {
+                v->noise_level_applied = INT32_MIN;
+                v->variant_qscore = 0;
+            } else {
+                v->noise_level_applied = (int32_t)(-10.0 * log10(mean));
+                v->variant_qscore = orc_poisson_qscore(v->allele_support, v->total_coverage, v->noise_level_applied, cfg->max_variant_qscore);
+            }
+        } else {
         v->noise_level_applied = cfg->noise_level;
         if (v->total_coverage == 0) v->variant_qscore = 0;
         else v->variant_qscore = orc_poisson_qscore(v->allele_support, v->total_coverage, cfg->noise_level, cfg->max_variant_qscore);
+        }
         orc_strand_bias(v->coverage_by_dir, v->support_by_dir, cfg->noise_level, (double)cfg->min_frequency,
                         (double)cfg->strand_bias_threshold, cfg->strand_bias_model, &v->sb);
         v->has_sb = 1;
@@ -1899,6 +1913,7 @@ void orc_default_config(PiscesHipConfig* c)
     c->call_mnvs = 0;
     c->max_mnv_length = 3;
     c->max_gap_between_mnv = 1;
+    c->noise_model = PISCES_NOISE_FLAT;
 }
 
 

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # error codes
 OK = 0
@@ -88,6 +88,7 @@ class PiscesHipConfig(C.Structure):
         ("call_mnvs", C.c_int32),
         ("max_mnv_length", C.c_int32),
         ("max_gap_between_mnv", C.c_int32),
+        ("noise_model", C.c_int32),
     ]
 
 
@@ -134,6 +135,7 @@ def default_config(**overrides):
     c.call_mnvs = 0
     c.max_mnv_length = 3
     c.max_gap_between_mnv = 1
+    c.noise_model = 0
     for k, v in overrides.items():
         if not hasattr(c, k):
             raise AttributeError(f"PiscesHipConfig has no field {k!r}")

@@ -260,12 +260,13 @@ __device__ inline double mathnet_gamma_lower_regularized(double a, double x, dou
 // ------------------------------------------------------------------------------------------
 // lib/Pisces.Calculators/VariantQualityCalculator.cs:27-65
 // ------------------------------------------------------------------------------------------
-__device__ inline int32_t poisson_qscore(int32_t callCount, int32_t coverage, const DeviceParams& P)
+// err = MathOperations.QtoP(noise level): P.err_q with NoiseModel.Flat, the allele's own with NoiseModel.Window
+__device__ inline int32_t poisson_qscore_e(int32_t callCount, int32_t coverage, double err, const DeviceParams& P)
 {
     if ((callCount <= 0) || (coverage <= 0)) return 0;
     double callCountMinusOne = callCount - 1;
     double callCountDouble = callCount;
-    double lambda = P.err_q * coverage;
+    double lambda = err * coverage;
     // Exact early-out at the cap (the dominant case: a well-supported allele, MaximumVariantQScore = 100).
     // With k-1 >= e*lambda and k >= 2*lambda both the true tail P(X >= k) <= (e lambda/k)^k and the value the
     // reference's log-space branch uses, pmf(k-1) * k/(2(k-lambda)) <= (e lambda/(k-1))^(k-1), are bounded by
@@ -294,6 +295,20 @@ __device__ inline int32_t poisson_qscore(int32_t callCount, int32_t coverage, co
     double qScore = fmin((double)P.max_vq, rawQ);
     qScore = fmax(qScore, 0.0);
     return (int32_t)rint(qScore);  // Math.Round: ties to even
+}
+__device__ inline int32_t poisson_qscore(int32_t callCount, int32_t coverage, const DeviceParams& P)
+{
+    return poisson_qscore_e(callCount, coverage, P.err_q, P);
+}
+
+// NoiseModel.Window (AlleleCaller.cs:215-218): QtoP((int)PtoQ(SumOfBaseQuality / TotalCoverage)), or a negative value when the mean
+// error is not a positive finite number (the reference's arithmetic then ends in a q-score of 0; see oracle/pisces_oracle.c)
+__device__ inline double window_err(double sumOfBaseQuality, int totalCoverage, const DeviceParams& P)
+{
+    if (totalCoverage == 0) return -1.0;
+    const double mean = sumOfBaseQuality / (double)totalCoverage;
+    if (!(mean > 0.0) || isinf(mean)) return -1.0;
+    return q_to_p_int((int)p_to_q(mean), P);
 }
 
 // ------------------------------------------------------------------------------------------

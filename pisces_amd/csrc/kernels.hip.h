@@ -230,10 +230,14 @@ __device__ inline void finish_allele(const PointCounts& c, int pos, int a, bool 
 __device__ inline bool process_point_allele(const PointCounts& c, int pos, int a, bool isRef, int rt,
                                              const uint8_t* __restrict__ ref, int64_t win_lo, int64_t win_hi,
                                              const DeviceParams& P, PiscesCalledAllele& r,
-                                             const uint8_t* s_refwin = nullptr, int s_refidx = 0, const GqTail* pre_tail = nullptr)
+                                             const uint8_t* s_refwin = nullptr, int s_refidx = 0, const GqTail* pre_tail = nullptr,
+                                             const double* window_err_ = nullptr /* NoiseModel.Window: QtoP of the allele's noise level, < 0 = q-score 0 */)
 {
     if (!isRef && !variant_passes_frequency(c, P)) return false;
     int vq = 0;
+    if (window_err_) {
+        if (c.support > 0 && c.total != 0 && *window_err_ >= 0.0) vq = poisson_qscore_e(c.support, c.total, *window_err_, P);
+    } else
 #if !(defined(PISCES_ABLATE_MATH) && (PISCES_ABLATE_MATH == 5 || PISCES_ABLATE_MATH == 9))
     if (c.support > 0 && c.total != 0) vq = poisson_qscore(c.support, c.total, P);   // VariantQualityCalculator.Compute :11-24
 #endif
@@ -267,7 +271,7 @@ struct VarScratch {
     double ov_var[kTile * 4], fw_var[kTile * 4], fw_fp[kTile * 4], rv_var[kTile * 4], rv_fp[kTile * 4];
 };
 
-__device__ inline void call_roles(const int* hist, const uint32_t* gapped /* LDS[kTile] or nullptr */, const PiscesTile& tile,
+__device__ inline void call_roles(const int* hist, const uint32_t* gapped /* LDS[kTile] or nullptr */, const double* s_err /* LDS[kTile], NoiseModel.Window, or nullptr */, const PiscesTile& tile,
                                   int tile_index, const uint8_t* __restrict__ ref, int32_t ref_start, int64_t ref_len,
                                   PiscesCalledAllele* __restrict__ records, PiscesTileResult* __restrict__ tile_result,
                                   const DeviceParams& P, uint8_t* s_mask /* LDS[kTile] */,
@@ -312,7 +316,7 @@ __device__ inline void call_roles(const int* hist, const uint32_t* gapped /* LDS
                 ref_rank = (rt < 4) ? rank_of_allele(rt) : 0;
                 const PointCounts c = point_counts(hist, l, a, true, rt, g);
                 PiscesCalledAllele rec;
-                (void)process_point_allele(c, pos, a, true, rt, ref, win_lo, win_hi, P, rec, s_refwin, kRefMargin + l);
+                (void)process_point_allele(c, pos, a, true, rt, ref, win_lo, win_hi, P, rec, s_refwin, kRefMargin + l, nullptr, s_err ? &s_err[l] : nullptr);
                 // written now; it only counts if no variant turns out callable at this locus
                 copy_record(&slots[ref_rank], &rec);
                 ref_emitted = true;
@@ -328,7 +332,8 @@ __device__ inline void call_roles(const int* hist, const uint32_t* gapped /* LDS
 #if defined(PISCES_ABLATE_MATH) && (PISCES_ABLATE_MATH == 9 || PISCES_ABLATE_MATH == 6)
                 vs->vq[slot] = 100;
 #else
-                vs->vq[slot] = (c.support > 0 && c.total != 0) ? poisson_qscore(c.support, c.total, P) : 0;
+                vs->vq[slot] = !(c.support > 0 && c.total != 0) ? 0 : !s_err ? poisson_qscore(c.support, c.total, P)
+                               : s_err[l] >= 0.0 ? poisson_qscore_e(c.support, c.total, s_err[l], P) : 0;
 #endif
 #if defined(PISCES_ABLATE_MATH) && (PISCES_ABLATE_MATH == 9 || PISCES_ABLATE_MATH == 7)
             } else if (c.support < 0) {
@@ -463,7 +468,7 @@ __global__ __launch_bounds__(kBlock, 4) void call_tiles_kernel(
 #ifdef PISCES_TIMING
     const long long tc1 = wall_clock64();
 #endif
-    call_roles(hist, nullptr, tile, t, ref, ref_start, ref_len, records, &tile_results[t], P, s_mask, s_refwin, &s_var);
+    call_roles(hist, nullptr, nullptr, tile, t, ref, ref_start, ref_len, records, &tile_results[t], P, s_mask, s_refwin, &s_var);
 #ifdef PISCES_TIMING
     if (threadIdx.x == 0) {   // development instrumentation: chip-global clock stamps in the tile directory
         const long long tc2 = wall_clock64();
@@ -886,11 +891,45 @@ __global__ void build_gq_tail_kernel(double* __restrict__ table, int32_t n_a, in
 // ------------------------------------------------------------------------------------------
 // Anchor-resolved accumulation: LDS [locus][199] (odd stride: consecutive loci hit distinct banks),
 // added into counts[(tile*kTile + locus)][6][3][11] — RegionState._alleleCounts layout.
+// AlleleCountHelper.GetAnchorAdjustedAlleleCount (lib/Pisces.Processing/RegionState/AlleleCountHelper.cs:21-85) over one [11] row of
+// counts (int) or of base-quality sums (double, GetAnchorAdjustedTotalQuality: same walk, same order of additions); maxAnchor < 0 =
+// null; symmetric is never set on this path
+template <typename T, typename R>
+__host__ __device__ inline R anchor_adjusted(const T* __restrict__ row, int minAnchor, int maxAnchor, bool fromEnd)
+{
+    const int wellAnchoredIndex = PISCES_ANCHOR_SIZE, numAnchorIndexes = PISCES_NUM_ANCHORS;
+    const int trueMinAnchor = wellAnchoredIndex < minAnchor ? wellAnchoredIndex : minAnchor;
+    int initialMaxAnchor = wellAnchoredIndex;
+    if (maxAnchor >= 0) {
+        if (maxAnchor >= wellAnchoredIndex) initialMaxAnchor = wellAnchoredIndex - 1;
+        if (maxAnchor < wellAnchoredIndex) initialMaxAnchor = maxAnchor;
+    }
+    R tot = 0;
+    if (fromEnd) {
+        for (int i = trueMinAnchor; i <= initialMaxAnchor; i++) tot += row[numAnchorIndexes - i - 1];
+        if (maxAnchor < 0)
+            for (int i = 0; i < initialMaxAnchor; i++) tot += row[i];
+    } else {
+        for (int i = trueMinAnchor; i <= initialMaxAnchor; i++) tot += row[i];
+        if (maxAnchor < 0)
+            for (int i = initialMaxAnchor + 1; i < numAnchorIndexes; i++) tot += row[i];
+    }
+    return tot;
+}
+__host__ __device__ inline double get_base_quality_sum(const double* __restrict__ sumq, int64_t idx, int allele, int dir, int minAnchor,
+                                                       int maxAnchor, bool fromEnd)
+{
+    if (idx < 0) return 0.0;
+    return anchor_adjusted<double, double>(sumq + idx * PISCES_COUNTS_PER_LOCUS + (allele * 3 + dir) * PISCES_NUM_ANCHORS, minAnchor, maxAnchor,
+                                           fromEnd);
+}
+
 constexpr int kAnchStride = PISCES_COUNTS_PER_LOCUS + 1;
 
 __global__ __launch_bounds__(kBlock) void accumulate_tiles_kernel(
     const uint32_t* __restrict__ tuples, const PiscesTile* __restrict__ tiles, int32_t n_tiles,
-    int32_t* __restrict__ counts, int32_t min_bq_)
+    int32_t* __restrict__ counts, int32_t min_bq_, double* __restrict__ sumq = nullptr /* NoiseModel.Window: RegionState._sumOfAlleleBaseQualities */,
+    const double* __restrict__ bq_lut = nullptr /* [256] Math.Pow(10, -1 * (int)q / 10f), RegionStateManager.cs:191 */)
 {
     __shared__ int hist[kTile * kAnchStride];
     const int t = blockIdx.x;
@@ -906,8 +945,12 @@ __global__ __launch_bounds__(kBlock) void accumulate_tiles_kernel(
         uint32_t allele = (v >> 21) & 7u;
         uint32_t qual = v >> 24;
         if (allele < 4u && qual < min_bq) allele = 4u;
-        if (locus < n_loci && dir < 3u && allele < 6u && anchor < (uint32_t)PISCES_NUM_ANCHORS)
+        if (locus < n_loci && dir < 3u && allele < 6u && anchor < (uint32_t)PISCES_NUM_ANCHORS) {
             atomicAdd(&hist[locus * kAnchStride + (allele * 3u + dir) * PISCES_NUM_ANCHORS + anchor], 1);
+            // the quality of a base goes under its post-threshold allele type; only A/C/G/T are ever read back (CoverageCalculator.cs:62)
+            if (sumq && allele < 4u)
+                unsafeAtomicAdd(&sumq[((int64_t)t * kTile + locus) * PISCES_COUNTS_PER_LOCUS + (allele * 3u + dir) * PISCES_NUM_ANCHORS + anchor], bq_lut[qual]);
+        }
     });
     __syncthreads();
     int32_t* __restrict__ dst = counts + (int64_t)t * kTile * PISCES_COUNTS_PER_LOCUS;
@@ -923,10 +966,12 @@ __global__ __launch_bounds__(kBlock) void accumulate_tiles_kernel(
 __global__ __launch_bounds__(kBlock, 4) void call_counts_kernel(
     const int32_t* __restrict__ counts, const uint32_t* __restrict__ gapped_mnv_ref,
     const PiscesTile* __restrict__ tiles, int32_t n_tiles, const uint8_t* __restrict__ ref, int32_t ref_start,
-    int64_t ref_len, PiscesCalledAllele* __restrict__ records, PiscesTileResult* __restrict__ tile_results, DeviceParams P)
+    int64_t ref_len, PiscesCalledAllele* __restrict__ records, PiscesTileResult* __restrict__ tile_results, DeviceParams P,
+    const double* __restrict__ sumq = nullptr /* NoiseModel.Window */)
 {
     __shared__ int hist[kFolded * kTile];
     __shared__ uint32_t s_gapped[kTile];
+    __shared__ double s_err[kTile];
     __shared__ uint8_t s_mask[kTile];
     __shared__ uint8_t s_refwin[kRefWin];
     __shared__ VarScratch s_var;
@@ -953,7 +998,23 @@ __global__ __launch_bounds__(kBlock, 4) void call_counts_kernel(
         s_refwin[j] = (ri >= 0 && ri < ref_len) ? ref[ri] : (uint8_t)0;
     }
     __syncthreads();
-    call_roles(hist, s_gapped, tile, t, ref, ref_start, ref_len, records, &tile_results[t], P, s_mask, s_refwin, &s_var);
+    if (sumq && threadIdx.x < kTile) {
+        // CalculateSinglePoint :49-98: SumOfBaseQuality and TotalCoverage of a point allele of this locus, in the reference's order
+        const int l = threadIdx.x;
+        double sum = 0.0;
+        int total = 0;
+        if (l < tile.n_loci) {
+            const int cca[5] = {PISCES_ALLELE_A, PISCES_ALLELE_C, PISCES_ALLELE_G, PISCES_ALLELE_T, PISCES_ALLELE_DEL};
+            for (int d = 0; d < 3; d++)
+                for (int k = 0; k < 5; k++) {
+                    total += hist[HistBlock::idx(cca[k], d, l)];
+                    sum += get_base_quality_sum(sumq, (int64_t)t * kTile + l, cca[k], d, 0, -1, false);
+                }
+        }
+        s_err[l] = window_err(sum, total, P);
+    }
+    __syncthreads();
+    call_roles(hist, s_gapped, sumq ? s_err : nullptr, tile, t, ref, ref_start, ref_len, records, &tile_results[t], P, s_mask, s_refwin, &s_var);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1037,30 +1098,16 @@ struct DevCandidate {
     int64_t start_idx, end_idx;      // locus index of the start / end point in the counts tensor, -1 = no block (count 0)
     int32_t allele_off;              // ref bytes then alt bytes in the allele pool
     int32_t gapped;                  // GetGappedMnvRefCount at the position (SNV: off the reference support, Reference: off the support)
+    int32_t reprocessed;             // an MNV candidate on its second ProcessVariant (AlleleCaller.cs:74 then :111): CalledAllele.SumOfBaseQuality
+                                     // keeps what the first pass added (CoverageCalculator.cs:226-227 use +=), which NoiseModel.Window then sees twice
+    int32_t pad;
 };
 
 // AlleleCountHelper.GetAnchorAdjustedAlleleCount (lib/Pisces.Processing/RegionState/AlleleCountHelper.cs:21-85)
 // over one [11] row; maxAnchor < 0 = null; symmetric is never set on this path
 __host__ __device__ inline int anchor_adjusted_count(const int32_t* __restrict__ row, int minAnchor, int maxAnchor, bool fromEnd)
 {
-    const int wellAnchoredIndex = PISCES_ANCHOR_SIZE, numAnchorIndexes = PISCES_NUM_ANCHORS;
-    const int trueMinAnchor = wellAnchoredIndex < minAnchor ? wellAnchoredIndex : minAnchor;
-    int initialMaxAnchor = wellAnchoredIndex;
-    if (maxAnchor >= 0) {
-        if (maxAnchor >= wellAnchoredIndex) initialMaxAnchor = wellAnchoredIndex - 1;
-        if (maxAnchor < wellAnchoredIndex) initialMaxAnchor = maxAnchor;
-    }
-    int tot = 0;
-    if (fromEnd) {
-        for (int i = trueMinAnchor; i <= initialMaxAnchor; i++) tot += row[numAnchorIndexes - i - 1];
-        if (maxAnchor < 0)
-            for (int i = 0; i < initialMaxAnchor; i++) tot += row[i];
-    } else {
-        for (int i = trueMinAnchor; i <= initialMaxAnchor; i++) tot += row[i];
-        if (maxAnchor < 0)
-            for (int i = initialMaxAnchor + 1; i < numAnchorIndexes; i++) tot += row[i];
-    }
-    return tot;
+    return anchor_adjusted<int32_t, int>(row, minAnchor, maxAnchor, fromEnd);
 }
 
 __host__ __device__ inline int get_allele_count(const int32_t* __restrict__ counts, int64_t idx, int allele, int dir, int minAnchor,
@@ -1111,7 +1158,8 @@ __device__ inline int rmxn_length_for_indel(int variantPosition, const uint8_t* 
 // anchor-resolved counts tensor: coverage by direction, total coverage.  Host and device: the host-side collapser needs the
 // same number (CandidateAllele.Frequency) the device call uses.
 struct SpanningCoverage { int cov[3]; int total; };
-__host__ __device__ inline SpanningCoverage spanning_coverage(const DevCandidate& c, const int32_t* __restrict__ counts, int32_t expect_stitched)
+__host__ __device__ inline SpanningCoverage spanning_coverage(const DevCandidate& c, const int32_t* __restrict__ counts, int32_t expect_stitched,
+                                                             const double* __restrict__ sumq = nullptr, double* sum_of_base_quality = nullptr)
 {
     const int length = c.category == PISCES_CAT_INSERTION ? c.alt_len - 1 : c.category == PISCES_CAT_DELETION ? c.ref_len - 1 : c.alt_len;   // BaseAllele.Length
     const int support = c.sup[0] + c.sup[1] + c.sup[2];
@@ -1124,6 +1172,7 @@ __host__ __device__ inline SpanningCoverage spanning_coverage(const DevCandidate
     int confidentLeft = 0, confidentRight = 0, suspiciousLeft = 0, suspiciousRight = 0;
     const int unanchoredSupport = support - wellAnchored;
     const int cca[5] = {PISCES_ALLELE_A, PISCES_ALLELE_C, PISCES_ALLELE_G, PISCES_ALLELE_T, PISCES_ALLELE_DEL};
+    double sumQ = 0.0, unanchoredStartQ = 0.0, unanchoredEndQ = 0.0;   // SumOfBaseQuality :226-227,245,254 (NoiseModel.Window)
     for (int d = 0; d < 3; d++) {
         for (int k = 0; k < 5; k++) {
             const int at = cca[k];
@@ -1135,16 +1184,23 @@ __host__ __device__ inline SpanningCoverage spanning_coverage(const DevCandidate
             endPointCoverage[d] += ec;
             confidentLeft += sc;
             confidentRight += ec;
+            if (sumq) {
+                sumQ += get_base_quality_sum(sumq, c.start_idx, at, d, minAnchorStart, -1, false);
+                sumQ += get_base_quality_sum(sumq, c.end_idx, at, d, minAnchorEnd, -1, true);
+            }
             if (bePicky && unanchoredSupport > 0) {
                 if (minAnchorStart > 0) {
                     const int u = get_allele_count(counts, c.start_idx, at, d, 0, minAnchorStart - 1, false);
                     startUnanch[d] += u;
                     suspiciousLeft += u;
+                    if (sumq) unanchoredStartQ += get_base_quality_sum(sumq, c.start_idx, at, d, 0, minAnchorStart - 1, false);
                 }
                 if (minAnchorEnd > 0) {
                     const int u = get_allele_count(counts, c.end_idx, at, d, 0, minAnchorEnd - 1, true);
                     endUnanch[d] += u;
                     suspiciousRight += u;
+                    // the reference reads the START point here (CoverageCalculator.cs:254) - reproduced
+                    if (sumq) unanchoredEndQ += get_base_quality_sum(sumq, c.start_idx, at, d, 0, minAnchorEnd - 1, true);
                 }
             }
         }
@@ -1160,8 +1216,11 @@ __host__ __device__ inline SpanningCoverage spanning_coverage(const DevCandidate
         for (int d = 0; d < 3; d++) {
             startPointCoverage[d] += (int)(startUnanch[d] * weight);
             endPointCoverage[d] += (int)(endUnanch[d] * weight);
+            sumQ += unanchoredStartQ * weight;   // inside the direction loop in the reference too (:284-292)
+            sumQ += unanchoredEndQ * weight;
         }
     }
+    if (sum_of_base_quality) *sum_of_base_quality = sumQ;
     // RedistributeStitchedCoverage :324-331
     startPointCoverage[0] += (int)ceilf((float)startPointCoverage[2] / 2);
     startPointCoverage[1] += (int)floorf((float)startPointCoverage[2] / 2);
@@ -1203,7 +1262,8 @@ __host__ __device__ inline int candidate_total_coverage(const DevCandidate& c, c
 __global__ __launch_bounds__(64) void call_spanning_kernel(
     const DevCandidate* __restrict__ cands, int32_t n, const int32_t* __restrict__ counts, const uint8_t* __restrict__ alleles,
     const uint8_t* __restrict__ ref, int64_t ref_len /* ref[i] = position i+1 */, int32_t expect_stitched,
-    PiscesCalledAllele* __restrict__ out, uint8_t* __restrict__ callable_out, DeviceParams P)
+    PiscesCalledAllele* __restrict__ out, uint8_t* __restrict__ callable_out, DeviceParams P,
+    const double* __restrict__ sumq = nullptr /* NoiseModel.Window */)
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
@@ -1233,14 +1293,23 @@ __global__ __launch_bounds__(64) void call_spanning_kernel(
         for (int d = 0; d < 3; d++) { r.coverage_by_dir[d] = pc.cov[d]; r.support_by_dir[d] = pc.sup[d]; }
         r.variant_qscore = 0; r.strand_bias_score = 0.0; r.genotype_qscore = 0; r.filter_bits = 0;
         r.info = PISCES_INFO_PACK(PISCES_GT_HET_ALT_REF, c.category, rt, a, 0, 0, 0);
-        const bool ok = process_point_allele(pc, c.position, a, isRef, rt, ref, 0, ref_len, P, r);
+        double werr = 0.0;
+        if (sumq) {   // CalculateSinglePoint: SumOfBaseQuality over the five coverage-contributing allele types, directions outermost
+            const int cca[5] = {PISCES_ALLELE_A, PISCES_ALLELE_C, PISCES_ALLELE_G, PISCES_ALLELE_T, PISCES_ALLELE_DEL};
+            double sum = 0.0;
+            for (int d = 0; d < 3; d++)
+                for (int k = 0; k < 5; k++) sum += get_base_quality_sum(sumq, c.start_idx, cca[k], d, 0, -1, false);
+            werr = window_err(sum, pc.total, P);
+        }
+        const bool ok = process_point_allele(pc, c.position, a, isRef, rt, ref, 0, ref_len, P, r, nullptr, 0, nullptr, sumq ? &werr : nullptr);
         out[i] = r;
         callable_out[i] = ok ? 1 : 0;
         return;
     }
     const int length = c.category == PISCES_CAT_INSERTION ? c.alt_len - 1 : c.category == PISCES_CAT_DELETION ? c.ref_len - 1 : c.alt_len;
     const int support = c.sup[0] + c.sup[1] + c.sup[2];
-    const SpanningCoverage sc = spanning_coverage(c, counts, expect_stitched);
+    double sumQ = 0.0;
+    const SpanningCoverage sc = spanning_coverage(c, counts, expect_stitched, sumq, &sumQ);
     const int cov[3] = {sc.cov[0], sc.cov[1], sc.cov[2]};
     const int total = sc.total;
     int refsup = total - support;
@@ -1250,7 +1319,14 @@ __global__ __launch_bounds__(64) void call_spanning_kernel(
     int vq = 0;
     SbResult sb = {0.0, 0, 0, 0};
     if (support > 0) {
-        if (total != 0) vq = poisson_qscore(support, total, P);
+        if (total != 0) {
+            if (sumq) {
+                const double werr = window_err(c.reprocessed ? sumQ + sumQ : sumQ, total, P);
+                vq = werr >= 0.0 ? poisson_qscore_e(support, total, werr, P) : 0;
+            } else {
+                vq = poisson_qscore(support, total, P);
+            }
+        }
         sb = strand_bias(cov, c.sup, P);
     }
     const float freq = frequency_f(support, total);

@@ -96,6 +96,8 @@ struct PiscesHip {
     int64_t launches_seen = 0;
     DeviceBuf<unsigned long long> d_totals;
     DeviceBuf<double> d_qlut;
+    DeviceBuf<double> d_bq_lut;    // [256] Math.Pow(10, -1 * (int)q / 10f): what a base of quality q adds to the base-quality sums (NoiseModel.Window)
+    DeviceBuf<double> d_sumq;      // RegionState._sumOfAlleleBaseQualities of the tiles being called (NoiseModel.Window)
     DeviceBuf<double> d_gq_tail;   // memo of the genotype-quality Poisson tail (DeviceParams::gq_tail)
     int n_cus = 256;
     DeviceBuf<int32_t> d_offsets;
@@ -268,6 +270,7 @@ int32_t pisces_hip_default_config(PiscesHipConfig* c)
     c->call_mnvs = 0;
     c->max_mnv_length = 3;
     c->max_gap_between_mnv = 1;
+    c->noise_model = PISCES_NOISE_FLAT;
     return PISCES_OK;
 }
 
@@ -333,6 +336,17 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         h->P.q_to_p_lut = h->d_qlut.p;
         h->P.q_to_p_n = n;
     }
+    if (h->cfg.noise_model == PISCES_NOISE_WINDOW) {
+        // RegionStateManager.cs:191: Math.Pow(10, -1 * (int)quality / 10f) - int / float is a float32 quotient, promoted for Pow
+        std::vector<double> lut(256);
+        for (int q = 0; q < 256; q++) lut[(size_t)q] = std::pow(10.0, (double)((float)(-1 * q) / 10.0f));
+        if ((e = h->d_bq_lut.reserve(256)) != hipSuccess ||
+            (e = hipMemcpy(h->d_bq_lut.p, lut.data(), 256 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) {
+            g_create_error = std::string("pisces_hip_create: ") + hipGetErrorString(e);
+            pisces_hip_destroy(h);
+            return PISCES_E_DEVICE;
+        }
+    }
     if ((e = h->d_log_n.reserve(4)) != hipSuccess || (e = h->d_flags.reserve(4)) != hipSuccess ||
         (e = hipMemset(h->d_log_n.p, 0, 4 * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMemset(h->d_flags.p, 0, 4 * sizeof(int32_t))) != hipSuccess) {
@@ -369,7 +383,7 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_ref.release(); h->d_tuples.release(); h->d_tiles.release(); h->d_tile_results.release();
-    h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release(); h->d_totals.release(); h->d_qlut.release(); h->d_gq_tail.release(); h->d_offsets.release(); h->d_compact.release();
+    h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release(); h->d_totals.release(); h->d_qlut.release(); h->d_bq_lut.release(); h->d_sumq.release(); h->d_gq_tail.release(); h->d_offsets.release(); h->d_compact.release();
     for (int i = 0; i < 2; i++) { h->d_log_pos[i].release(); h->d_log_tup[i].release(); }
     h->d_log_n.release(); h->d_flags.release(); h->d_bucket.release(); h->d_tile_cnt.release(); h->d_total.release();
     for (auto& st : h->stage) {
@@ -887,6 +901,22 @@ static void launch_call_tiles(PiscesHip* h, hipStream_t s, const uint32_t* d_tup
                               PiscesTileResult* d_tr, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
 {
     const uint32_t lds = (uint32_t)h->lds_pad;
+    if (h->cfg.noise_model == PISCES_NOISE_WINDOW) {
+        // NoiseModel.Window needs the base-quality sums next to the counts, cell by cell (RegionState.cs:61): anchor-resolved counts and
+        // sums go to HBM (accumulate_tiles_kernel) and the call phase reads them back (call_counts_kernel).  Not the streaming-rate
+        // path; the reference's default is NoiseModel.Flat.
+        const size_t nc = (size_t)n_tiles * kTile * PISCES_COUNTS_PER_LOCUS;
+        if (h->d_counts.reserve(nc) != hipSuccess || h->d_sumq.reserve(nc) != hipSuccess) return;
+        (void)hipMemsetAsync(h->d_counts.p, 0, nc * sizeof(int32_t), s);
+        (void)hipMemsetAsync(h->d_sumq.p, 0, nc * sizeof(double), s);
+        if (e0) (void)hipEventRecord(e0, s);
+        hipLaunchKernelGGL(accumulate_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, d_tuples, d_tiles, n_tiles, h->d_counts.p,
+                           h->cfg.min_base_call_quality, h->d_sumq.p, h->d_bq_lut.p);
+        hipLaunchKernelGGL(call_counts_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, h->d_counts.p, (const uint32_t*)nullptr, d_tiles, n_tiles,
+                           d_ref, ref_start, ref_len, d_records, d_tr, h->P, h->d_sumq.p);
+        if (e1) (void)hipEventRecord(e1, s);
+        return;
+    }
     if (h->kernel_variant >= 2 && h->cfg.min_base_call_quality <= 255) {   // the wave forms compare the quality byte in place
         // Two waves per tile shorten the call phase (Reference / q-score work and the strand-bias statistics run side by
         // side) and pay for it in registers (128 VGPRs for 8 tiles per CU).  Measured (tools/kbench.py, 500x): that wins up
@@ -929,12 +959,13 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
     PISCES_HIP_CHECK(h, h->d_compact.reserve(cap));
     PISCES_HIP_CHECK(h, h->d_offsets.reserve((size_t)n_tiles));
 
+    const bool window = h->cfg.noise_model == PISCES_NOISE_WINDOW;
     bool use_counts = false;
     for (auto& kv : h->gapped_mnv_ref)
         if (std::binary_search(keys.begin(), keys.end(), block_key(h, kv.first))) { use_counts = true; break; }
 
     std::vector<uint32_t> g;
-    if (!use_counts) {
+    if (!use_counts && !window) {
         launch_call_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p,
                           h->d_tile_results.p);
     } else {
@@ -950,10 +981,16 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
                 if (it != h->gapped_mnv_ref.end()) g[(size_t)t * kTile + (size_t)l] = (uint32_t)it->second;
             }
         PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_gapped.p, g.data(), g.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+        if (window) {
+            PISCES_HIP_CHECK(h, h->d_sumq.reserve(nc));
+            PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_sumq.p, 0, nc * sizeof(double), h->stream));
+        }
         hipLaunchKernelGGL(accumulate_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->d_tuples.p, h->d_tiles.p,
-                           n_tiles, h->d_counts.p, h->cfg.min_base_call_quality);
+                           n_tiles, h->d_counts.p, h->cfg.min_base_call_quality, window ? h->d_sumq.p : (double*)nullptr,
+                           window ? h->d_bq_lut.p : (const double*)nullptr);
         hipLaunchKernelGGL(call_counts_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->d_counts.p, h->d_gapped.p,
-                           h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p, h->d_tile_results.p, h->P);
+                           h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p, h->d_tile_results.p, h->P,
+                           window ? h->d_sumq.p : (const double*)nullptr);
     }
     // tiles were built in ascending position order: the ordered compaction is AlleleCaller.Call's (position, ref, alt) order
     launch_compaction(h->stream, h->d_records.p, h->d_tile_results.p, n_tiles, h->d_offsets.p, h->d_compact.p, (int32_t)cap, h->d_count.p,
@@ -1250,6 +1287,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, std
     ref_overrides.clear();
     *n_collapsed = 0;
     const bool mnv_mode = h->cfg.call_mnvs != 0;
+    const bool window = h->cfg.noise_model == PISCES_NOISE_WINDOW;
     std::vector<HostCandidate> work;   // a copy: the blocks keep their candidates until DoneProcessing
     for (int32_t key : keys) {
         // RegionState.GetAllCandidates walks _candidateVariantsLookup by position, each position in arrival order (RegionState.cs:388-391)
@@ -1298,10 +1336,16 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, std
         const size_t nc = (size_t)n_tiles * kTile * PISCES_COUNTS_PER_LOCUS;
         PISCES_HIP_CHECK(h, h->d_counts.reserve(nc));
         PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_counts.p, 0, nc * sizeof(int32_t), h->stream));
+        if (window) {
+            PISCES_HIP_CHECK(h, h->d_sumq.reserve(nc));
+            PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_sumq.p, 0, nc * sizeof(double), h->stream));
+        }
         hipLaunchKernelGGL(accumulate_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles,
-                           h->d_counts.p, h->cfg.min_base_call_quality);
+                           h->d_counts.p, h->cfg.min_base_call_quality, window ? h->d_sumq.p : (double*)nullptr,
+                           window ? h->d_bq_lut.p : (const double*)nullptr);
     } else {
         PISCES_HIP_CHECK(h, h->d_counts.reserve(PISCES_COUNTS_PER_LOCUS));
+        if (window) PISCES_HIP_CHECK(h, h->d_sumq.reserve(PISCES_COUNTS_PER_LOCUS));
     }
     auto atype = [](char ch) { return ch == 'A' ? 0 : ch == 'G' ? 1 : ch == 'C' ? 2 : ch == 'T' ? 3 : 4; };
     auto gapped_at = [&](int32_t p) {
@@ -1352,11 +1396,14 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, std
     // one device pass over a list of candidates: records + IsCallable
     std::vector<PiscesCalledAllele> raw;
     std::vector<uint8_t> callable;
+    bool second_pass = false;   // MNV mode: the pass over every callable allele, after the MNV-only pass
     auto device_pass = [&](const std::vector<const HostCandidate*>& list) -> int32_t {
         std::vector<DevCandidate> dc(list.size());
         std::vector<uint8_t> pool;
         for (size_t i = 0; i < list.size(); i++) {
             to_dev(*list[i], dc[i]);
+            dc[i].reprocessed = (second_pass && list[i]->category == PISCES_CAT_MNV && !work.empty() && list[i] >= work.data() &&
+                                 list[i] < work.data() + work.size()) ? 1 : 0;
             dc[i].allele_off = (int32_t)pool.size();
             pool.insert(pool.end(), list[i]->ref.begin(), list[i]->ref.end());
             pool.insert(pool.end(), list[i]->alt.begin(), list[i]->alt.end());
@@ -1372,7 +1419,8 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, std
         PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_cands.p, dc.data(), dc.size() * sizeof(DevCandidate), hipMemcpyHostToDevice, h->stream));
         PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_alleles.p, pool.data(), pool.size(), hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(call_spanning_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, h->d_cands.p, n, h->d_counts.p,
-                           h->d_alleles.p, h->d_ref.p, h->ref_len, h->cfg.expect_stitched_reads, h->d_cand_records.p, h->d_cand_callable.p, h->P);
+                           h->d_alleles.p, h->d_ref.p, h->ref_len, h->cfg.expect_stitched_reads, h->d_cand_records.p, h->d_cand_callable.p, h->P,
+                           window ? h->d_sumq.p : (const double*)nullptr);
         PISCES_HIP_CHECK(h, hipGetLastError());
         PISCES_HIP_CHECK(h, hipMemcpyAsync(raw.data(), h->d_cand_records.p, raw.size() * sizeof(PiscesCalledAllele), hipMemcpyDeviceToHost, h->stream));
         PISCES_HIP_CHECK(h, hipMemcpyAsync(callable.data(), h->d_cand_callable.p, callable.size(), hipMemcpyDeviceToHost, h->stream));
@@ -1479,6 +1527,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, std
         }
     }
 
+    second_pass = mnv_mode;
     int32_t rc2 = device_pass(final_list);
     if (rc2) return rc2;
     for (size_t i = 0; i < final_list.size(); i++) {
@@ -1651,7 +1700,7 @@ int32_t pisces_hip_get_counts(PiscesHip* h, int32_t start_position, int32_t n, i
     PISCES_HIP_CHECK(h, h->d_counts.reserve(nc));
     PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_counts.p, 0, nc * sizeof(int32_t), h->stream));
     hipLaunchKernelGGL(accumulate_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles,
-                       h->d_counts.p, h->cfg.min_base_call_quality);
+                       h->d_counts.p, h->cfg.min_base_call_quality, (double*)nullptr, (const double*)nullptr);
     PISCES_HIP_CHECK(h, hipGetLastError());
     std::vector<int32_t> host(nc);
     PISCES_HIP_CHECK(h, hipMemcpyAsync(host.data(), h->d_counts.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
@@ -1794,7 +1843,7 @@ int32_t pisces_hip_accumulate_tiles(PiscesHip* h, const uint32_t* d_tuples, cons
     }
     if (n_tiles > 0) {
         hipExtLaunchKernelGGL(accumulate_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0u, s, e0, e1, 0u, d_tuples, d_tiles, n_tiles,
-                              d_counts, h->cfg.min_base_call_quality);
+                              d_counts, h->cfg.min_base_call_quality, (double*)nullptr, (const double*)nullptr);
     } else if (e0) {
         PISCES_HIP_CHECK(h, hipEventRecord(e0, s));
         PISCES_HIP_CHECK(h, hipEventRecord(e1, s));

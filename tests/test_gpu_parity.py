@@ -796,3 +796,39 @@ def test_mnv_calling_over_the_block_schedule(torch_cuda):
     assert got_alleles == exp_alleles
     assert_records_match(got, exp)
     assert stats["TotalNumCalled"] == exp_called
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("call_mnvs", [0, 1])
+def test_window_noise_model_matches_oracle(torch_cuda, call_mnvs):
+    """SURVEY section 8 row a3, NoiseModel.Window: the base-quality sums are accumulated on the device next to the counts (cell by cell,
+    FP64 atomics) and every allele's q-score uses (int)PtoQ(SumOfBaseQuality / TotalCoverage): SNVs, Reference alleles, insertions /
+    deletions (start + end point sums) and, with MNV calling on, MNVs.  Mixed base qualities, so no locus sits on an integer edge of
+    PtoQ (there the order of the FP64 additions, which the device does not reproduce, could decide); records against the oracle."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(300 + call_mnvs)
+    ref = bytes(rng.choice(list(b"ACGT"), 1500).astype(np.uint8))
+    reads = _mnv_reads(rng, ref, 2500, region=(40, 1450))
+    for i in range(160):   # a deletion of 701..703 and an insertion after 900, each in 80 reads
+        if i % 2:
+            reads.append({"pos": 660, "cigar": [("M", 41), ("D", 3), ("M", 50)], "seq": (ref[659:700] + ref[703:753]).decode(), "reverse": bool(i & 2)})
+        else:
+            reads.append({"pos": 860, "cigar": [("M", 41), ("I", 4), ("M", 50)], "seq": (ref[859:900] + b"TTGA" + ref[900:950]).decode(), "reverse": bool(i & 2)})
+    for r in reads:   # mixed qualities: 12 (below the threshold), 23, 30, 37, 41
+        r["quals"] = rng.choice([12, 23, 30, 37, 41], len(r["seq"]), p=[.04, .2, .2, .4, .16]).astype(np.uint8).tolist()
+    batch = _abi.ReadBatch(reads)
+    refa = np.frombuffer(ref, dtype=np.uint8)
+    cfg = _abi.default_config(noise_model=1, call_mnvs=call_mnvs, block_size=2000, max_variant_qscore=200)
+    exp, exp_alleles, _, exp_called = orc.run_reads_full(batch, refa, 1, len(ref), cfg)
+    flat, _, _, _ = orc.run_reads_full(batch, refa, 1, len(ref), _abi.default_config(call_mnvs=call_mnvs, block_size=2000, max_variant_qscore=200))
+    assert len(flat) != len(exp) or (flat["variant_qscore"] != exp["variant_qscore"]).any()   # the model matters on this input
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(refa)
+        c.AddAlleleCounts(batch)
+        got, got_alleles = c.CallWithAlleles()
+        stats = c.Stats()
+    cats = (exp["info"] >> 4) & 7
+    assert (cats == _abi.CAT_SNV).sum() >= 10 and ((cats == _abi.CAT_DELETION) | (cats == _abi.CAT_INSERTION)).sum() >= 1
+    assert got_alleles == exp_alleles
+    assert_records_match(got, exp)
+    assert stats["TotalNumCalled"] == exp_called

@@ -519,3 +519,27 @@ def test_mnv_reallocator_cases(case):
     for want in case.get("expect_callable_contains", []):
         assert _norm(got_callable).count(_norm([want])[0]) == 1
     assert _norm(got_outside) == _norm(case["expect_outside"])
+
+
+# ---- NoiseModel.Window ---------------------------------------------------------------------------------
+def test_window_noise_model_uses_the_mean_base_error_of_the_locus():
+    """AlleleCaller.cs:215-218 + RegionStateManager.cs:191: with NoiseModel.Window the q-score of an allele is computed at noise level
+    (int)PtoQ(sum of 10^(-(int)q/10f) over the passing A/C/G/T bases / TotalCoverage).  200 reads of Q30 bases, 14 of them with an SNV:
+    the mean error is 10^-3 -> noise level 29 or 30 (the quotient sits on the integer edge), well above the flat level of 20, so the
+    window q-score must equal the flat q-score computed at that noise level and exceed the flat-20 one."""
+    ref = b"ACGTACGTACGTACGTACGT" * 5
+    reads = []
+    for i in range(200):
+        seq = bytearray(ref[10:60])
+        if i < 14:
+            seq[20] = ord("T") if ref[30] != ord("T") else ord("G")
+        reads.append({"pos": 11, "cigar": [("M", 50)], "seq": bytes(seq).decode(), "quals": [30] * 50, "reverse": bool(i % 2)})
+    batch = _abi.ReadBatch(reads)
+    refa = np.frombuffer(ref, dtype=np.uint8)
+    def run(**kw):
+        recs, _ = orc.run_reads(batch, refa, 1, len(ref), _abi.default_config(max_variant_qscore=1000, **kw))
+        snv = recs[((recs["info"] >> 4) & 7) == _abi.CAT_SNV]
+        assert len(snv) == 1 and snv["position"][0] == 31
+        return int(snv["variant_qscore"][0])
+    flat20, window = run(), run(noise_model=1)
+    assert window in (run(noise_level=29), run(noise_level=30)) and window > flat20
