@@ -12,7 +12,11 @@ namespace Pisces.Hip
         public int VariantQualityFilter, RMxNMaxRepeatLength, RMxNMinRepetitions, NoiseLevel;
         public int OutputStrandBiasAndNoiseLevel, OutputNoCallFraction;
         public float MinFrequencyThreshold, FrequencyFilterThreshold;
+        public int Crush;   // !AllowMultipleVcfLinesPerLoci
     }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct PiscesVcfPadState { public int LastVariantPositionWritten, LastPaddedPosition, LastClearedIntervalIndex; }   // start at {0, 0, -1}
 
     [StructLayout(LayoutKind.Sequential)]
     public struct PiscesHipConfig
@@ -102,6 +106,8 @@ namespace Pisces.Hip
         // VCF body lines straight from the records (what VcfFileWriter.WriteListOfColocatedAlleles writes per allele, Pisces.IO/VcfFileWriter.cs:206-262)
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_vcf_default_config(out PiscesVcfConfig cfg);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern long pisces_hip_format_vcf(ref PiscesVcfConfig cfg, [MarshalAs(UnmanagedType.LPStr)] string chrom, PiscesCalledAllele[] records, long n, int[] candIndex, PiscesCandidate[] cands, byte[] alleles, [Out] byte[] text, long capacity);
+
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern long pisces_hip_format_vcf_padded(ref PiscesVcfConfig cfg, [MarshalAs(UnmanagedType.LPStr)] string chrom, PiscesCalledAllele[] records, long n, int[] candIndex, PiscesCandidate[] cands, byte[] alleles, byte[] referenceBases, long refLen, int[] intervalStarts, int[] intervalEnds, int nIntervals, ref PiscesVcfPadState state, int finish, [Out] byte[] text, long capacity);
 
         public static void Check(IntPtr handle, int rc)
         {

@@ -346,15 +346,30 @@ typedef struct PiscesVcfConfig {
     int32_t output_no_call_fraction;            /* ShouldOutputNoCallFraction (-reportnocalls) */
     float   min_frequency_threshold;            /* MinFrequencyThreshold: sets the number of VF decimals */
     float   frequency_filter_threshold;         /* FrequencyFilterThreshold; < 0 = null */
+    int32_t crush;                              /* !AllowMultipleVcfLinesPerLoci (-crushvcf): co-located alleles share one line */
 } PiscesVcfConfig;
 int32_t pisces_hip_vcf_default_config(PiscesVcfConfig* cfg);
-/* One VCF body line per record, uncrushed (VcfFileWriter.WriteListOfColocatedAlleles, VcfFileWriter.cs:206-262 with
- * VcfFormatter.cs:52-448): CHROM POS . REF ALT QUAL FILTER DP=<n> GT:GQ:AD:DP:VF[:NL:SB][:NC] <sample>.  cand_index / cands /
- * alleles are what pisces_hip_flush_ex returned (may be NULL when no row is an insertion / deletion).  Returns the number of
+/* One VCF body line per record, or with cfg->crush one per position (VcfFileWriter.WriteListOfColocatedAlleles, VcfFileWriter.cs:206-262
+ * with VcfFormatter.cs:52-495): CHROM POS . REF ALT QUAL FILTER DP=<n> GT:GQ:AD:DP:VF[:NL:SB][:NC] <sample>.  cand_index / cands /
+ * alleles are what pisces_hip_flush_ex returned (may be NULL when no row is an insertion / deletion / MNV).  Returns the number of
  * bytes of text; when that exceeds `capacity` nothing is written and the call is repeated with a larger buffer; < 0 = error. */
 int64_t pisces_hip_format_vcf(const PiscesVcfConfig* cfg, const char* chrom, const PiscesCalledAllele* recs, int64_t n,
                               const int32_t* cand_index, const PiscesCandidate* cands, const uint8_t* alleles, char* out,
                               int64_t capacity);
+/* The same with RegionMapper's padding (src/lib/Pisces.IO/RegionMapper.cs:31-84, VcfFileWriter.PadIfNeeded / WriteRemaining :124-172):
+ * positions of the interval set that no allele covers get a no-call row (./., LowDP, DP=0, NL = cfg->noise_level) before the next
+ * written position, and with `finish` up to the end of the last interval.  `state` carries the writer's and the mapper's cursors from
+ * one call to the next (zero-initialise, then {0, 0, -1}: see PiscesVcfPadState); it is only advanced when the text fitted. */
+typedef struct PiscesVcfPadState {
+    int32_t last_variant_position_written;   /* VcfFileWriter._lastVariantPositionWritten, starts at 0 */
+    int32_t last_padded_position;            /* RegionMapper._lastPaddedPosition, starts at 0 */
+    int32_t last_cleared_interval_index;     /* RegionMapper._lastClearedIntervalIndex, starts at -1 */
+} PiscesVcfPadState;
+int64_t pisces_hip_format_vcf_padded(const PiscesVcfConfig* cfg, const char* chrom, const PiscesCalledAllele* recs, int64_t n,
+                                     const int32_t* cand_index, const PiscesCandidate* cands, const uint8_t* alleles,
+                                     const uint8_t* ref_bases, int64_t ref_len, const int32_t* interval_starts,
+                                     const int32_t* interval_ends, int32_t n_intervals, PiscesVcfPadState* state, int32_t finish,
+                                     char* out, int64_t capacity);
 
 #ifdef __cplusplus
 }

@@ -95,7 +95,11 @@ class PiscesHipConfig(C.Structure):
 class PiscesVcfConfig(C.Structure):
     _fields_ = [("variant_quality_filter", C.c_int32), ("rmxn_max_repeat_length", C.c_int32), ("rmxn_min_repetitions", C.c_int32),
                 ("noise_level", C.c_int32), ("output_strand_bias_and_noise_level", C.c_int32), ("output_no_call_fraction", C.c_int32),
-                ("min_frequency_threshold", C.c_float), ("frequency_filter_threshold", C.c_float)]
+                ("min_frequency_threshold", C.c_float), ("frequency_filter_threshold", C.c_float), ("crush", C.c_int32)]
+
+
+class PiscesVcfPadState(C.Structure):
+    _fields_ = [("last_variant_position_written", C.c_int32), ("last_padded_position", C.c_int32), ("last_cleared_interval_index", C.c_int32)]
 
 
 def default_config(**overrides):

@@ -17,7 +17,7 @@ EXPORTS = [
     "pisces_hip_get_candidates", "pisces_hip_stats", "pisces_hip_call_tiles", "pisces_hip_accumulate_tiles",
     "pisces_hip_synchronize", "pisces_hip_last_kernel_ms", "pisces_hip_expand_reads", "pisces_hip_device_totals",
     "pisces_hip_set_timing", "pisces_hip_kernel_time", "pisces_hip_flush_ex", "pisces_hip_probe_read_bandwidth",
-    "pisces_hip_vcf_default_config", "pisces_hip_format_vcf", "pisces_hip_find_candidates",
+    "pisces_hip_vcf_default_config", "pisces_hip_format_vcf", "pisces_hip_format_vcf_padded", "pisces_hip_find_candidates",
     "pisces_hip_find_indel_candidates", "pisces_hip_compact_records",
 ]
 
@@ -82,6 +82,8 @@ def _load():
         "pisces_hip_probe_read_bandwidth": (i32, [vp, i64, i32, P(C.c_double)]),
         "pisces_hip_vcf_default_config": (i32, [P(_abi.PiscesVcfConfig)]),
         "pisces_hip_format_vcf": (i64, [P(_abi.PiscesVcfConfig), C.c_char_p, vp, i64, vp, vp, vp, vp, i64]),
+        "pisces_hip_format_vcf_padded": (i64, [P(_abi.PiscesVcfConfig), C.c_char_p, vp, i64, vp, vp, vp, vp, i64, vp, vp, i32,
+                                               P(_abi.PiscesVcfPadState), i32, vp, i64]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)   # AttributeError here = a declared symbol is not exported

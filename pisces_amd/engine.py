@@ -252,9 +252,16 @@ def expand_reads(batch, min_base_call_quality=20):
         return pos[:n], tup[:n]
 
 
-def format_vcf(chrom, records, vcf_config=None, alleles=None, **overrides):
-    """VCF body lines of `records` (pisces_hip_format_vcf).  alleles: the (ref, alt) string pairs CallWithAlleles returned, needed
-    for insertion / deletion rows; vcf_config: _abi.PiscesVcfConfig or None for the defaults (+ field overrides)."""
+def new_pad_state():
+    """Cursors of a VCF writer + RegionMapper pair at the start of a chromosome (PiscesVcfPadState)."""
+    return _abi.PiscesVcfPadState(0, 0, -1)
+
+
+def format_vcf(chrom, records, vcf_config=None, alleles=None, pad=None, **overrides):
+    """VCF body lines of `records` (pisces_hip_format_vcf[_padded]).  alleles: the (ref, alt) string pairs CallWithAlleles returned, needed
+    for insertion / deletion / MNV rows; vcf_config: _abi.PiscesVcfConfig or None for the defaults (+ field overrides, e.g. crush=1).
+    pad: dict(state=new_pad_state(), reference=bytes, intervals=[(start, end), ...], finish=bool) adds RegionMapper's no-call rows for
+    uncovered interval positions; the state object is advanced in place."""
     cfg = vcf_config
     if cfg is None:
         cfg = _abi.PiscesVcfConfig()
@@ -278,12 +285,22 @@ def format_vcf(chrom, records, vcf_config=None, alleles=None, **overrides):
         idx = np.array(idx_l, dtype=np.int32)
         cands = (_abi.PiscesCandidate * max(len(cand_l), 1))(*cand_l)
         pool_arr = np.frombuffer(bytes(pool) + b"\0", dtype=np.uint8).copy()
-    cap = 256 * max(n, 1)
+    refa = starts = ends = state = None
+    n_iv = finish = 0
+    if pad is not None:
+        refa = np.ascontiguousarray(np.frombuffer(pad["reference"], dtype=np.uint8) if isinstance(pad["reference"], (bytes, bytearray))
+                                    else pad["reference"], np.uint8)
+        starts = np.array([a for a, _ in pad["intervals"]], dtype=np.int32)
+        ends = np.array([b for _, b in pad["intervals"]], dtype=np.int32)
+        n_iv, finish, state = len(starts), int(bool(pad.get("finish"))), pad["state"]
+    cap = 256 * max(n, 1) + 128 * (int((ends - starts + 1).sum()) if pad is not None and n_iv else 0)
     while True:
-        buf = C.create_string_buffer(cap)
-        need = lib.pisces_hip_format_vcf(C.byref(cfg), chrom.encode(), recs.ctypes.data if n else None, n,
-                                         idx.ctypes.data if idx is not None else None, cands, pool_arr.ctypes.data if pool_arr is not None else None,
-                                         buf, cap)
+        buf = C.create_string_buffer(max(cap, 1))
+        need = lib.pisces_hip_format_vcf_padded(
+            C.byref(cfg), chrom.encode(), recs.ctypes.data if n else None, n, idx.ctypes.data if idx is not None else None, cands,
+            pool_arr.ctypes.data if pool_arr is not None else None, refa.ctypes.data if refa is not None else None,
+            refa.size if refa is not None else 0, starts.ctypes.data if n_iv else None, ends.ctypes.data if n_iv else None, n_iv,
+            C.byref(state) if state is not None else None, finish, buf, cap)
         if need < 0:
             raise PiscesHipError(int(need), "format_vcf failed")
         if need <= cap:

@@ -4,6 +4,8 @@
 import json
 import os
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -185,3 +187,50 @@ def test_lines_pisces_wrote_are_reproduced(spec):
         assert got == line + "\n", (got, line)
         checked += 1
     assert checked >= (7 * len(spec["lines"])) // 10, (checked, len(spec["lines"]))   # 85/116, 177/177, 39/39, 36/36, 89/90
+
+
+def test_crushed_and_padded_lines_of_the_writer_test():
+    """VcfFileWriterTests.TestDiploidStyleWithVariantsAndPadding (src/test/Pisces.IO.Tests/UnitTests/VcfFileWriterTests.cs:160-262): three
+    alleles (two of them co-located, 1/2), intervals 2-3, 6-8, 10-11 over a reference of C's, written in two calls and finished; the
+    body of VcfFileWriterTests_Crushed_Padded_expected.vcf, byte for byte."""
+    a = record(7, "C", "A", GT["1/1"], CAT_SNV, cov=5394, support=2387, ref_support=7, q=0, gq=0)
+    b = record(10, "A", "G", GT["1/2"], CAT_SNV, cov=5394, support=2387, ref_support=7, q=0, gq=0)
+    c = record(10, "A", "A", GT["1/2"], CAT_DEL, cov=5394, support=2000, ref_support=7, q=0, gq=0)
+    kw = dict(variant_quality_filter=20, min_frequency_threshold=0.007, frequency_filter_threshold=0.007, noise_level=23,
+              output_no_call_fraction=1, crush=1)
+    pad = dict(state=engine.new_pad_state(), reference=b"C" * 15, intervals=[(2, 3), (6, 8), (10, 11)])
+    text = engine.format_vcf("chr4", a, alleles=[("C", "A")], pad=pad, **kw)
+    text += engine.format_vcf("chr4", np.concatenate([b, c]), alleles=[("A", "G"), ("AA", "G")], pad=pad, **kw)
+    text += engine.format_vcf("chr4", np.zeros(0, dtype=_abi.CALLED_ALLELE_DTYPE), pad=dict(pad, finish=True), **kw)
+    want = [
+        "chr4\t2\t.\tC\t.\t0\tLowDP\tDP=0\tGT:GQ:AD:DP:VF:NL:SB:NC\t./.:0:0:0:0.0000:23:0.0000:0.0000",
+        "chr4\t3\t.\tC\t.\t0\tLowDP\tDP=0\tGT:GQ:AD:DP:VF:NL:SB:NC\t./.:0:0:0:0.0000:23:0.0000:0.0000",
+        "chr4\t6\t.\tC\t.\t0\tLowDP\tDP=0\tGT:GQ:AD:DP:VF:NL:SB:NC\t./.:0:0:0:0.0000:23:0.0000:0.0000",
+        "chr4\t7\t.\tC\tA\t0\tPASS\tDP=5394\tGT:GQ:AD:DP:VF:NL:SB:NC\t1/1:0:7,2387:5394:0.4425:23:0.0000:0.0000",
+        "chr4\t8\t.\tC\t.\t0\tLowDP\tDP=0\tGT:GQ:AD:DP:VF:NL:SB:NC\t./.:0:0:0:0.0000:23:0.0000:0.0000",
+        "chr4\t10\t.\tAA\tGA,G\t0\tPASS\tDP=5394\tGT:GQ:AD:DP:VF:NL:SB:NC\t1/2:0:2387,2000:5394:0.8133:23:0.0000:0.0000",
+        "chr4\t11\t.\tC\t.\t0\tLowDP\tDP=0\tGT:GQ:AD:DP:VF:NL:SB:NC\t./.:0:0:0:0.0000:23:0.0000:0.0000",
+    ]
+    assert text.rstrip("\n").split("\n") == want
+    assert (pad["state"].last_variant_position_written, pad["state"].last_padded_position) == (0, 11)
+
+
+def test_padding_needs_its_inputs_and_keeps_state_on_a_short_buffer():
+    r = record(7, "C", "A", GT["1/1"], CAT_SNV, cov=100, support=60, ref_support=40, q=100, gq=100)
+    st = engine.new_pad_state()
+    with pytest.raises(engine.PiscesHipError):   # state without a reference
+        cfg = _abi.PiscesVcfConfig()
+        engine.lib.pisces_hip_vcf_default_config(C.byref(cfg))
+        rc = engine.lib.pisces_hip_format_vcf_padded(C.byref(cfg), b"chr1", r.ctypes.data, 1, None, None, None, None, 0, None, None, 0,
+                                                     C.byref(st), 0, None, 0)
+        if rc < 0:
+            raise engine.PiscesHipError(int(rc), "invalid")
+    # a buffer that is too small reports the size and leaves the cursors alone
+    cfg = _abi.PiscesVcfConfig()
+    engine.lib.pisces_hip_vcf_default_config(C.byref(cfg))
+    ref = np.frombuffer(b"C" * 15, dtype=np.uint8)
+    starts, ends = np.array([2], dtype=np.int32), np.array([9], dtype=np.int32)
+    buf = C.create_string_buffer(8)
+    need = engine.lib.pisces_hip_format_vcf_padded(C.byref(cfg), b"chr1", r.ctypes.data, 1, None, None, None, ref.ctypes.data, 15,
+                                                   starts.ctypes.data, ends.ctypes.data, 1, C.byref(st), 1, buf, 8)
+    assert need > 8 and (st.last_variant_position_written, st.last_padded_position, st.last_cleared_interval_index) == (0, 0, -1)
