@@ -30,7 +30,8 @@ namespace Pisces.Hip
         public float RmxnFrequencyLimit;
         public int Collapse;
         public float CollapseFreqThreshold, CollapseFreqRatioThreshold;
-        public int CallMnvs, MaxMnvLength, MaxGapBetweenMnv, NoiseModel;   // PiscesApplicationOptions.CallMNVs / MaxSizeMNV / MaxGapBetweenMNV, VariantCallingParameters.NoiseModel (0 Flat, 1 Window)
+        public int CallMnvs, MaxMnvLength, MaxGapBetweenMnv, NoiseModel, Ploidy;
+        public float DiploidSnvMinorVF, DiploidSnvMajorVF, DiploidSnvSumVF, DiploidIndelMinorVF, DiploidIndelMajorVF, DiploidIndelSumVF;   // PiscesApplicationOptions.CallMNVs / MaxSizeMNV / MaxGapBetweenMNV, VariantCallingParameters.NoiseModel (0 Flat, 1 Window)
     }
 
     [StructLayout(LayoutKind.Sequential, Pack = 8, Size = 64)]

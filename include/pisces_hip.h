@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define PISCES_HIP_ABI_VERSION 3
+#define PISCES_HIP_ABI_VERSION 4
 
 /* ---- error codes -------------------------------------------------------- */
 #define PISCES_OK                 0
@@ -54,7 +54,8 @@ enum { PISCES_FILTER_STRAND_BIAS = 0, PISCES_FILTER_POOL_BIAS = 1, PISCES_FILTER
        PISCES_FILTER_NO_CALL = 12 };
 /* src/lib/Pisces.Domain/Types (StrandBiasModel): Poisson, Extended, Diploid */
 enum { PISCES_SB_POISSON = 0, PISCES_SB_EXTENDED = 1, PISCES_SB_DIPLOID = 2 };
-enum { PISCES_NOISE_FLAT = 0, PISCES_NOISE_WINDOW = 1 };   /* Pisces.Domain/Types/ModelTypes.cs:13 */
+enum { PISCES_NOISE_FLAT = 0, PISCES_NOISE_WINDOW = 1 };
+enum { PISCES_PLOIDY_SOMATIC = 0, PISCES_PLOIDY_DIPLOID = 1 };   /* PloidyModel.Somatic / DiploidByThresholding (Types/ModelTypes.cs) */   /* Pisces.Domain/Types/ModelTypes.cs:13 */
 
 /* Anchor bins: NumAnchorIndexes = 2*trackedAnchorSize+1 (RegionStateManager.cs:30-31), default 5 -> 11 */
 #define PISCES_ANCHOR_SIZE   5
@@ -126,6 +127,10 @@ typedef struct PiscesHipConfig {
     int32_t noise_model;              /* VariantCallingParameters.NoiseModel: PISCES_NOISE_FLAT (default) or PISCES_NOISE_WINDOW, where the
                                          variant q-score of an allele uses (int)PtoQ(SumOfBaseQuality / TotalCoverage) as its noise level
                                          (AlleleCaller.cs:215-218, RegionStateManager.cs:191) */
+    int32_t ploidy;                   /* PISCES_PLOIDY_SOMATIC (default) or PISCES_PLOIDY_DIPLOID: one genotype per locus from the variant
+                                         frequencies, alleles beyond the ploidy pruned (DiploidThresholdingGenotyper.cs:54-141) */
+    float   diploid_snv_params[3];    /* DiploidSNVThresholdingParameters {MinorVF, MajorVF, SumVFforMultiAllelicSite}: 0.20, 0.70, 0.80 */
+    float   diploid_indel_params[3];  /* DiploidINDELThresholdingParameters, same defaults */
 } PiscesHipConfig;
 
 /* ---- one called allele (64 bytes; what CalledAllele carries to the VCF writer,
@@ -156,6 +161,8 @@ typedef struct PiscesCalledAllele {
 #define PISCES_INFO_SB_OK(i)     (((i) >> 13) & 1)
 #define PISCES_INFO_VAR_BOTH(i)  (((i) >> 14) & 1)
 #define PISCES_INFO_COV_BOTH(i)  (((i) >> 15) & 1)
+/* filter_bits 14..15: CalledAllele.PhaseSetIndex of a diploid call (0 reference, 1 / 2 the variant alleles in frequency order) */
+#define PISCES_FILTERBITS_PHASE(f) (((f) >> 14) & 3)
 #define PISCES_INFO_PACK(gt, cat, ref, alt, sbok, varboth, covboth) \
     ((uint16_t)((gt) | ((cat) << 4) | ((ref) << 7) | ((alt) << 10) | ((sbok) << 13) | \
                 ((varboth) << 14) | ((covboth) << 15)))

@@ -263,7 +263,66 @@ int32_t orc_poisson_qscore(int32_t callCount, int32_t coverage, int32_t nl, int3
 /* =====================================================================================
  * lib/Pisces.Calculators/StrandBiasCalculator.cs
  * ===================================================================================== */
-/* PopulateStats :175-231 (Poisson / Extended models; Diploid is out of scope) */
+/* MathNet.Numerics 4.5.1 SpecialFunctions.BetaRegularized (Beta.cs): the continued fraction of Numerical Recipes' betacf with the
+ * symmetry transformation, eps = 2^-53 (Precision.DoublePrecision), fpmin = double.Epsilon / eps, at most 50000 rounds. */
+double orc_mathnet_beta_regularized(double a, double b, double x)
+{
+    const double bt = (x == 0.0 || x == 1.0) ? 0.0
+                      : exp(orc_mathnet_gamma_ln(a + b) - orc_mathnet_gamma_ln(a) - orc_mathnet_gamma_ln(b) + (a * log(x)) + (b * log(1.0 - x)));
+    const int symmetryTransformation = x >= (a + 1.0) / (a + b + 2.0);
+    const double eps = 1.1102230246251565e-16;
+    const double fpmin = 4.9406564584124654e-324 / eps;
+    if (symmetryTransformation) { x = 1.0 - x; double swap = a; a = b; b = swap; }
+    const double qab = a + b, qap = a + 1.0, qam = a - 1.0;
+    double c = 1.0, d = 1.0 - (qab * x / qap);
+    if (fabs(d) < fpmin) d = fpmin;
+    d = 1.0 / d;
+    double h = d;
+    for (int m = 1, m2 = 2; m <= 50000; m++, m2 += 2) {
+        double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+        d = 1.0 + (aa * d); if (fabs(d) < fpmin) d = fpmin;
+        c = 1.0 + (aa / c); if (fabs(c) < fpmin) c = fpmin;
+        d = 1.0 / d;
+        h *= d * c;
+        aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+        d = 1.0 + (aa * d); if (fabs(d) < fpmin) d = fpmin;
+        c = 1.0 + (aa / c); if (fabs(c) < fpmin) c = fpmin;
+        d = 1.0 / d;
+        const double del = d * c;
+        h *= del;
+        if (fabs(del - 1.0) <= eps) return symmetryTransformation ? 1.0 - (bt * h / a) : bt * h / a;
+    }
+    return symmetryTransformation ? 1.0 - (bt * h / a) : bt * h / a;
+}
+/* Binomial(p, n).CumulativeDistribution(x) (Distributions/Binomial.cs CDF): BetaRegularized(n - k, k + 1, 1 - p), k = floor(x) */
+double orc_mathnet_binomial_cdf(double p, int n, double x)
+{
+    if (x < 0.0) return 0.0;
+    if (x > n) return 1.0;
+    const double k = floor(x);
+    return orc_mathnet_beta_regularized(n - k, k + 1, 1 - p);
+}
+/* Binomial(p, n).ProbabilityLn(k) (PMFLn): BinomialLn(n, k) + k ln p + (n - k) ln(1 - p) */
+double orc_mathnet_binomial_lnpmf(double p, int n, int k)
+{
+    if (k < 0 || k > n) return -INFINITY;
+    if (p == 0.0) return k == 0 ? 0.0 : -INFINITY;
+    if (p == 1.0) return k == n ? 0.0 : -INFINITY;
+    const double binomialLn = mathnet_factorial_ln(n) - mathnet_factorial_ln(k) - mathnet_factorial_ln(n - k);
+    return binomialLn + (k * log(p)) + ((n - k) * log(1.0 - p));
+}
+
+/* PopulateDiploidStats :150-173 */
+void orc_sb_populate_diploid_stats(double support, double coverage, double minDetectableSNP, double out3[3] /* FN, FP, P(var > 0) */)
+{
+    const double frequency = coverage == 0 ? 0 : support / coverage;
+    if (frequency >= minDetectableSNP) { out3[0] = 1; out3[1] = 0; out3[2] = 1; return; }
+    out3[0] = fmax(orc_mathnet_binomial_cdf(minDetectableSNP, (int)coverage, support), 0);
+    out3[1] = fmax(0.0, 1 - orc_poisson_cdf(support, coverage * 0.1));
+    out3[2] = out3[0];
+}
+
+/* PopulateStats :175-231 */
 static void sb_create_stats(OrcSbStats* st, double support, double coverage, double noiseFreq,
                             double minDetectableSNP, int32_t model)
 {
@@ -284,6 +343,10 @@ static void sb_create_stats(OrcSbStats* st, double support, double coverage, dou
             st->chance_false_pos = 1 - st->chance_var_freq_gt_zero;
             st->chance_false_neg = st->chance_var_freq_gt_zero;
         }
+    } else if (model == PISCES_SB_DIPLOID) {
+        double o[3];
+        orc_sb_populate_diploid_stats(st->support, st->coverage, minDetectableSNP, o);
+        st->chance_false_neg = o[0]; st->chance_false_pos = o[1]; st->chance_var_freq_gt_zero = o[2];
     } else {
         st->chance_var_freq_gt_zero = fmax(0, orc_poisson_cdf(st->support - 1, st->coverage * noiseFreq));
         st->chance_false_pos = fmax(0, 1 - st->chance_var_freq_gt_zero);
@@ -361,6 +424,145 @@ int32_t orc_somatic_genotype(int32_t category, int32_t totalCoverage, int32_t al
         if ((1 - freq) > minFrequencyFilter) return PISCES_GT_REF_AND_NOCALL;
     }
     return PISCES_GT_HOM_REF;
+}
+
+/* =====================================================================================
+ * lib/Pisces.Genotyping/Thresholding (PloidyModel.DiploidByThresholding) + GenotypeCalculatorUtilities.cs
+ * ===================================================================================== */
+/* DiploidGenotypeQualityCalculator.Compute :12-105 */
+int32_t orc_diploid_gq(int32_t calledGT, int32_t totalCoverage, int32_t alleleSupport, int32_t minQScore, int32_t maxQScore)
+{
+    if (totalCoverage == 0) return minQScore;
+    const float noiseHomRef = 0.05f, noiseHomAlt = 0.075f, noiseHetAlt = 0.10f, expectedHetFreq = 0.40f;
+    const float depth = (float)totalCoverage;
+    const float frequency = frequency_f(alleleSupport, totalCoverage);
+    const double lamHomRef = (double)(noiseHomRef * depth), lamHomAlt = (double)(noiseHomAlt * depth);   /* float products, as written */
+    const int nonAlleleCalls = totalCoverage - alleleSupport > 0 ? totalCoverage - alleleSupport : 0;
+    double LnPofH0GT = 0, LnPofH1GT = 0;
+    switch (calledGT) {
+    case PISCES_GT_HOM_REF:
+        LnPofH0GT = orc_mathnet_poisson_ln_pmf(lamHomRef, nonAlleleCalls);
+        LnPofH1GT = orc_mathnet_binomial_lnpmf((double)expectedHetFreq, totalCoverage, nonAlleleCalls);
+        break;
+    case PISCES_GT_HOM_ALT:
+        LnPofH0GT = orc_mathnet_poisson_ln_pmf(lamHomAlt, nonAlleleCalls);
+        LnPofH1GT = orc_mathnet_binomial_lnpmf((double)expectedHetFreq, totalCoverage, alleleSupport);
+        break;
+    case PISCES_GT_HET_ALT1_ALT2:
+    case PISCES_GT_HET_ALT_REF: {
+        const int k = (int)(depth * frequency);
+        LnPofH0GT = orc_mathnet_binomial_lnpmf((double)expectedHetFreq, totalCoverage, k);
+        if (frequency >= 0.50) LnPofH1GT = orc_mathnet_binomial_lnpmf((double)(1 - noiseHetAlt), totalCoverage, k);
+        else LnPofH1GT = orc_mathnet_binomial_lnpmf((double)noiseHetAlt, totalCoverage, k);
+        break;
+    }
+    default: return minQScore;
+    }
+    /* (int)Math.Floor(...): a value outside int (or NaN) converts to int.MinValue */
+    const double v = floor(10.0 * 0.4342944819032518 * (LnPofH0GT - LnPofH1GT));
+    const int32_t qScore = (v > -2147483649.0 && v < 2147483648.0) ? (int32_t)v : INT32_MIN;
+    if ((LnPofH1GT <= (double)INT32_MIN) && (LnPofH0GT > LnPofH1GT)) return maxQScore;
+    if ((LnPofH0GT <= (double)INT32_MIN) && (LnPofH0GT < LnPofH1GT)) return minQScore;
+    const int32_t capped = qScore < maxQScore ? qScore : maxQScore;
+    return capped > minQScore ? capped : minQScore;
+}
+
+/* DiploidThresholdingGenotyper.SetGenotypes :54-75 + CalculateDiploidGenotype :77-103 over the alleles of one locus (already without
+ * pruned Reference rows).  Sets genotype, genotype q-score, phase set index and the MultiAllelicSite filter; prune[i] = 1 for the
+ * alleles the genotyper asks the caller to drop.  Returns the locus genotype. */
+int32_t orc_diploid_set_genotypes(OrcCalled* alleles, int n, const float snv[3], const float indel[3], int32_t minDepthToGenotype,
+                                  int32_t minGQ, int32_t maxGQ, int32_t* phase_set_index, uint8_t* prune)
+{
+    int order[64];
+    int nv = 0;
+    for (int i = 0; i < n; i++) prune[i] = 0;
+    /* FilterAndOrderAllelesByFrequency: variants at or above the SNV MinorVF, by descending frequency then (ref, alt) */
+    const double minFreqThreshold = (double)snv[0];
+    for (int i = 0; i < n && nv < 64; i++) {
+        if (alleles[i].category == PISCES_CAT_REFERENCE) continue;
+        if ((double)frequency_f(alleles[i].allele_support, alleles[i].total_coverage) >= minFreqThreshold) order[nv++] = i;
+        else prune[i] = 1;
+    }
+    for (int a = 1; a < nv; a++) {   /* stable insertion sort */
+        int x = order[a], b = a;
+        while (b > 0) {
+            const OrcCalled* p = &alleles[order[b - 1]];
+            const OrcCalled* q = &alleles[x];
+            const float fp = frequency_f(p->allele_support, p->total_coverage), fq = frequency_f(q->allele_support, q->total_coverage);
+            int after = 0;
+            if (fp != fq) after = fp < fq;
+            else { int r = strcmp(p->ref, q->ref); if (!r) r = strcmp(p->alt, q->alt); after = r > 0; }
+            if (!after) break;
+            order[b] = order[b - 1];
+            b--;
+        }
+        order[b] = x;
+    }
+    /* GetReferenceFrequency */
+    double referenceFrequency = 0;
+    if (n == 1) referenceFrequency = frequency_f(alleles[0].reference_support, alleles[0].total_coverage);
+    else if (n > 1) {
+        double refFrequencyCountBySNP = 0, indelFrequencyCount = 0;
+        int returned = 0;
+        for (int i = 0; i < n && !returned; i++) {
+            const float f = frequency_f(alleles[i].allele_support, alleles[i].total_coverage);
+            if (alleles[i].category == PISCES_CAT_REFERENCE) { referenceFrequency = f; returned = 1; break; }
+            if (alleles[i].category == PISCES_CAT_SNV) refFrequencyCountBySNP = frequency_f(alleles[i].reference_support, alleles[i].total_coverage);
+            else indelFrequencyCount += f;
+        }
+        if (!returned) referenceFrequency = fmax(refFrequencyCountBySNP - indelFrequencyCount, 0.0);
+    }
+    const int refExists = referenceFrequency >= (double)snv[0];
+    int depthIssue = 0;
+    for (int i = 0; i < n; i++) depthIssue |= alleles[i].total_coverage < minDepthToGenotype;
+    const float f0 = nv ? frequency_f(alleles[order[0]].allele_support, alleles[order[0]].total_coverage) : 0.0f;
+    const int refCall = nv == 0 || f0 < snv[0];
+    const float* par = (!refCall && alleles[order[0]].category != PISCES_CAT_SNV) ? indel : snv;   /* SelectParameters */
+    /* GetPreliminaryGenotype: 0 HomozygousRef, 1 HeterozygousAltRef, 2 HomozygousAlt */
+    int prelim = 0;
+    if (!refCall) prelim = (f0 >= par[0] && f0 <= par[1]) ? 1 : (f0 > par[1]) ? 2 : 0;
+    /* ConvertSimpleGenotypeToComplexGenotype */
+    int32_t gt;
+    if (depthIssue) gt = refCall ? PISCES_GT_REF_LIKE_NOCALL : PISCES_GT_ALT_LIKE_NOCALL;
+    else if (prelim == 0) {
+        if (!refExists) gt = PISCES_GT_REF_LIKE_NOCALL;
+        else {
+            const float first = frequency_f(alleles[0].allele_support, alleles[0].total_coverage);
+            gt = (alleles[0].category == PISCES_CAT_REFERENCE && (1 - first) > par[0]) ? PISCES_GT_REF_AND_NOCALL : PISCES_GT_HOM_REF;
+        }
+    } else if (prelim == 1) {
+        if (nv == 1) gt = refExists ? PISCES_GT_HET_ALT_REF : PISCES_GT_ALT_AND_NOCALL;
+        else {
+            /* CheckForTriAllelicIssue */
+            int fail;
+            if (alleles[order[nv - 1]].category != PISCES_CAT_SNV) fail = 0;
+            else if (refExists && ((double)f0 + referenceFrequency) < (double)par[2]) fail = 1;
+            else {
+                const float f1 = frequency_f(alleles[order[1]].allele_support, alleles[order[1]].total_coverage);
+                fail = (f0 + f1) < par[2];
+            }
+            if (fail) {
+                for (int i = 0; i < n; i++) alleles[i].filters |= 1u << PISCES_FILTER_MULTI_ALLELIC_SITE;   /* SetMultiAllelicFilter */
+                gt = refExists ? PISCES_GT_ALT_LIKE_NOCALL : PISCES_GT_ALT12_LIKE_NOCALL;
+            } else {
+                gt = refExists ? PISCES_GT_HET_ALT_REF : PISCES_GT_HET_ALT1_ALT2;
+            }
+        }
+    } else gt = PISCES_GT_HOM_ALT;
+    /* GetAllelesToPruneBasedOnGTCall */
+    int allowed = 0;
+    if (gt == PISCES_GT_ALT_AND_NOCALL || gt == PISCES_GT_ALT_LIKE_NOCALL || gt == PISCES_GT_HOM_ALT || gt == PISCES_GT_HET_ALT_REF) allowed = 1;
+    else if (gt == PISCES_GT_ALT12_LIKE_NOCALL || gt == PISCES_GT_HET_ALT1_ALT2) allowed = 2;
+    for (int k = allowed; k < nv; k++) prune[order[k]] = 1;
+    /* SetGenotypes: every allele gets the locus genotype, its own q-score, a phase set index in list order */
+    int phase = 1;
+    for (int i = 0; i < n; i++) {
+        alleles[i].genotype = gt;
+        alleles[i].genotype_qscore = orc_diploid_gq(gt, alleles[i].total_coverage, alleles[i].allele_support, minGQ, maxGQ);
+        if (alleles[i].category == PISCES_CAT_REFERENCE) phase_set_index[i] = 0;
+        else phase_set_index[i] = phase++;
+    }
+    return gt;
 }
 
 /* SomaticGenotypeQualityCalculator.Compute :10-48 */
@@ -1702,6 +1904,29 @@ int64_t orc_call_candidates_max(OrcState* s, const OrcCandidate* list, int64_t n
         int64_t j = i;
         int anyNonRef = 0;
         while (j < n && called[j].position == called[i].position) { if (called[j].category != PISCES_CAT_REFERENCE) anyNonRef = 1; j++; }
+        if (cfg->ploidy == PISCES_PLOIDY_DIPLOID) {
+            /* ComputeGenotypeAndFilterAllele :143-177 with the diploid genotyper: Reference rows leave when a variant is there, the
+             * genotyper names the alleles beyond the ploidy, LowGQ, (ref, alt) order (the list is sorted already) */
+            OrcCalled at[64];
+            int32_t phase[64];
+            uint8_t prune[64];
+            int m = 0;
+            for (int64_t k = i; k < j && m < 64; k++) {
+                if (anyNonRef && called[k].category == PISCES_CAT_REFERENCE) continue;
+                at[m++] = called[k];
+            }
+            orc_diploid_set_genotypes(at, m, cfg->diploid_snv_params, cfg->diploid_indel_params, cfg->min_coverage, cfg->min_genotype_qscore,
+                                      cfg->max_genotype_qscore, phase, prune);
+            for (int q = 0; q < m; q++) {
+                if (prune[q]) continue;
+                if (cfg->low_gq_filter >= 0 && (float)at[q].genotype_qscore < (float)cfg->low_gq_filter)
+                    at[q].filters |= 1u << PISCES_FILTER_LOW_GENOTYPE_QUALITY;
+                at[q].filters |= (uint32_t)phase[q] << 14;   /* PhaseSetIndex rides in filter_bits 14..15 */
+                called[w++] = at[q];
+            }
+            i = j;
+            continue;
+        }
         for (int64_t k = i; k < j; k++) {
             if (anyNonRef && called[k].category == PISCES_CAT_REFERENCE) continue;
             OrcCalled* a = &called[k];
@@ -1914,6 +2139,10 @@ void orc_default_config(PiscesHipConfig* c)
     c->max_mnv_length = 3;
     c->max_gap_between_mnv = 1;
     c->noise_model = PISCES_NOISE_FLAT;
+    c->ploidy = PISCES_PLOIDY_SOMATIC;
+    c->diploid_snv_params[0] = c->diploid_indel_params[0] = 0.20f;
+    c->diploid_snv_params[1] = c->diploid_indel_params[1] = 0.70f;
+    c->diploid_snv_params[2] = c->diploid_indel_params[2] = 0.80f;
 }
 
 

@@ -152,6 +152,15 @@ int64_t orc_call_candidates(OrcState* s, const OrcCandidate* list, int64_t n_lis
 
 /* ---- whole path on a read batch: the CPU baseline (SmallVariantCaller.Execute loop,
  * exe/Pisces/Logic/SmallVariantCaller.cs:79-116) ---- */
+/* MathNet.Numerics 4.5.1 Beta / Binomial and the diploid (germline) pieces: DiploidGenotypeQualityCalculator, DiploidThresholdingGenotyper,
+ * StrandBiasCalculator.PopulateDiploidStats */
+double orc_mathnet_beta_regularized(double a, double b, double x);
+double orc_mathnet_binomial_cdf(double p, int n, double x);
+double orc_mathnet_binomial_lnpmf(double p, int n, int k);
+void orc_sb_populate_diploid_stats(double support, double coverage, double minDetectableSNP, double out3[3]);
+int32_t orc_diploid_gq(int32_t calledGT, int32_t totalCoverage, int32_t alleleSupport, int32_t minQScore, int32_t maxQScore);
+int32_t orc_diploid_set_genotypes(OrcCalled* alleles, int n, const float snv[3], const float indel[3], int32_t minDepthToGenotype,
+                                  int32_t minGQ, int32_t maxGQ, int32_t* phase_set_index, uint8_t* prune);
 /* MnvReallocator.ReallocateFailedMnvs over arrays (test hook; max_position < 0 = null) */
 int64_t orc_reallocate_failed_mnvs(const OrcCalled* failed, int64_t n_failed, OrcCalled* callable, int64_t n_callable, int64_t cap_callable,
                                    int32_t max_position, OrcCalled* outside, int64_t cap_outside, int64_t* n_outside);

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # error codes
 OK = 0
@@ -89,6 +89,9 @@ class PiscesHipConfig(C.Structure):
         ("max_mnv_length", C.c_int32),
         ("max_gap_between_mnv", C.c_int32),
         ("noise_model", C.c_int32),
+        ("ploidy", C.c_int32),
+        ("diploid_snv_params", C.c_float * 3),
+        ("diploid_indel_params", C.c_float * 3),
     ]
 
 
@@ -140,10 +143,16 @@ def default_config(**overrides):
     c.max_mnv_length = 3
     c.max_gap_between_mnv = 1
     c.noise_model = 0
+    c.ploidy = 0
+    c.diploid_snv_params[:] = [0.20, 0.70, 0.80]
+    c.diploid_indel_params[:] = [0.20, 0.70, 0.80]
     for k, v in overrides.items():
         if not hasattr(c, k):
             raise AttributeError(f"PiscesHipConfig has no field {k!r}")
-        setattr(c, k, v)
+        if isinstance(v, (list, tuple)):
+            getattr(c, k)[:] = list(v)
+        else:
+            setattr(c, k, v)
     return c
 
 

@@ -271,6 +271,10 @@ int32_t pisces_hip_default_config(PiscesHipConfig* c)
     c->max_mnv_length = 3;
     c->max_gap_between_mnv = 1;
     c->noise_model = PISCES_NOISE_FLAT;
+    c->ploidy = PISCES_PLOIDY_SOMATIC;
+    c->diploid_snv_params[0] = c->diploid_indel_params[0] = 0.20f;
+    c->diploid_snv_params[1] = c->diploid_indel_params[1] = 0.70f;
+    c->diploid_snv_params[2] = c->diploid_indel_params[2] = 0.80f;
     return PISCES_OK;
 }
 

@@ -388,3 +388,36 @@ def reallocate_failed_mnvs(failed, callable_, max_position=None):
                                         C.c_int32(-1 if max_position is None else max_position), o, C.c_int64(cap), C.byref(no))
     assert nc <= cap and no.value <= cap
     return [un(c[i]) for i in range(nc)], [un(o[i]) for i in range(no.value)]
+
+
+# ---- diploid (germline) pieces ----
+lib.orc_diploid_gq.restype = C.c_int32
+lib.orc_diploid_gq.argtypes = [C.c_int32] * 5
+lib.orc_sb_populate_diploid_stats.restype = None
+lib.orc_sb_populate_diploid_stats.argtypes = [C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double)]
+lib.orc_diploid_set_genotypes.restype = C.c_int32
+
+
+def diploid_gq(genotype, total_coverage, allele_support, min_q=0, max_q=2147483647):
+    return lib.orc_diploid_gq(genotype, total_coverage, allele_support, min_q, max_q)
+
+
+def diploid_sb_stats(support, coverage, min_detectable):
+    out = (C.c_double * 3)()
+    lib.orc_sb_populate_diploid_stats(support, coverage, min_detectable, out)
+    return list(out)
+
+
+def diploid_set_genotypes(alleles, snv=(0.20, 0.70, 0.80), indel=(0.20, 0.70, 0.80), min_depth=100, min_gq=0, max_gq=0):
+    """alleles: list of dicts {category, ref, alt, support, coverage, ref_support}; returns (locus genotype, prune flags, per-allele
+    (genotype, gq, filters, phase))."""
+    n = len(alleles)
+    arr = (OrcCalled * max(n, 1))()
+    for i, d in enumerate(alleles):
+        arr[i].category = d["category"]
+        arr[i].ref, arr[i].alt = d["ref"].encode(), d["alt"].encode()
+        arr[i].allele_support, arr[i].total_coverage, arr[i].reference_support = d["support"], d["coverage"], d["ref_support"]
+    phase = (C.c_int32 * max(n, 1))()
+    prune = (C.c_uint8 * max(n, 1))()
+    gt = lib.orc_diploid_set_genotypes(arr, n, (C.c_float * 3)(*snv), (C.c_float * 3)(*indel), min_depth, min_gq, max_gq, phase, prune)
+    return gt, [int(prune[i]) for i in range(n)], [(arr[i].genotype, arr[i].genotype_qscore, arr[i].filters, phase[i]) for i in range(n)]

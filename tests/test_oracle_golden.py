@@ -543,3 +543,50 @@ def test_window_noise_model_uses_the_mean_base_error_of_the_locus():
         return int(snv["variant_qscore"][0])
     flat20, window = run(), run(noise_model=1)
     assert window in (run(noise_level=29), run(noise_level=30)) and window > flat20
+
+
+# ---- diploid (germline) genotyping, SURVEY section 8 row f4 ----------------------------------------------------------------------
+_DIPLOID = load("diploid_cases.json")
+_GT_CODE = {"HeterozygousAlt1Alt2": 0, "Alt12LikeNoCall": 1, "HeterozygousAltRef": 2, "HomozygousAlt": 3, "HomozygousRef": 4,
+            "RefLikeNoCall": 5, "AltLikeNoCall": 6, "RefAndNoCall": 7, "AltAndNoCall": 8}
+
+
+@pytest.mark.parametrize("case", _DIPLOID["genotype_scenarios"], ids=lambda c: "%s-%s-%s" % (c["genotype"], c["ref_freqs"], c["alt_freqs"]))
+def test_diploid_genotype_scenarios(case):
+    """GenotypeCalculatorTest.DiploidGenotypeScenarios through its harness (:107-147): float32 frequencies x coverage truncated to int."""
+    cov = case["coverage"]
+    alleles = []
+    ref_freq = 0.0
+    for rf in case["ref_freqs"]:
+        sup = int(np.float32(rf) * np.float32(cov))
+        alleles.append({"category": _abi.CAT_REFERENCE, "ref": "A", "alt": "A", "support": sup, "coverage": cov, "ref_support": sup})
+        ref_freq = float(np.float32(rf))
+    if ref_freq == 0:
+        ref_freq = 1.0 - float(np.sum(np.array(case["alt_freqs"], dtype=np.float32), dtype=np.float32))   # List<float>.Sum() is a float
+    for vf in case["alt_freqs"]:
+        alleles.append({"category": _abi.CAT_SNV, "ref": "A", "alt": "T", "support": int(np.float32(vf) * np.float32(cov)), "coverage": cov,
+                        "ref_support": int(ref_freq * cov)})
+    gt, prune, per = orc.diploid_set_genotypes(alleles, min_depth=_DIPLOID["min_depth_to_genotype"])
+    assert gt == _GT_CODE[case["genotype"]] and sum(prune) == case["prune"]
+    assert all(p[0] == gt for p in per)
+
+
+@pytest.mark.parametrize("table", _DIPLOID["genotype_qscores"], ids=lambda t: "%s-%d" % (t["genotype"], t["depth"]))
+def test_diploid_genotype_qscores(table):
+    """DiploidGenotypeQualityCalculatorTests (:16-96, :103-117) through TestCalculation (:124-134)."""
+    gt = _GT_CODE[table["genotype"]]
+    for f, want in zip(table["frequencies"], table["expected"]):
+        depth = float(table["depth"])
+        support = int(depth * f)
+        if table["genotype"] == "HomozygousRef":
+            support = int(depth * (1.0 - f))
+        assert orc.diploid_gq(gt, int(depth), support) == want, (table["genotype"], depth, f)
+
+
+def test_diploid_strand_bias_stats():
+    """StrandBiasCalculatorTests PopulateDiploidStats cases (:185-285), three decimals as the test asserts them."""
+    for c in _DIPLOID["diploid_sb_stats"]:
+        fn, fp, pv = orc.diploid_sb_stats(c["support"], c["coverage"], _DIPLOID["sb_threshold"])
+        for name, got in (("ChanceFalseNeg", fn), ("ChanceFalsePos", fp), ("ChanceVarFreqGreaterThanZero", pv)):
+            if name in c:
+                assert abs(got - c[name]) < 0.0005 + 1e-12, (c, name, got)
