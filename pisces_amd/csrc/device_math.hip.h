@@ -316,20 +316,69 @@ __device__ inline double window_err(double sumOfBaseQuality, int totalCoverage, 
 // ------------------------------------------------------------------------------------------
 struct SbStats { double var_gt_zero, false_pos, coverage, support; };
 
-__device__ inline SbStats sb_create_stats(double support, double coverage, double noiseFreq, int model)
+// MathNet.Numerics 4.5.1 SpecialFunctions.BetaRegularized (continued fraction with the symmetry transformation, eps = 2^-53, at most
+// 50000 rounds) and Binomial(p, n).CumulativeDistribution(x) = BetaRegularized(n - k, k + 1, 1 - p): the Diploid strand-bias model
+// (StrandBiasCalculator.cs:150-173).  Kept out of line: only germline runs reach it.
+__device__ __noinline__ double mathnet_beta_regularized(double a, double b, double x)
+{
+    const double bt = (x == 0.0 || x == 1.0) ? 0.0
+                      : exp(mathnet_gamma_ln(a + b) - mathnet_gamma_ln(a) - mathnet_gamma_ln(b) + (a * log(x)) + (b * log(1.0 - x)));
+    const bool symmetryTransformation = x >= (a + 1.0) / (a + b + 2.0);
+    const double eps = 1.1102230246251565e-16;
+    const double fpmin = 4.9406564584124654e-324 / eps;
+    if (symmetryTransformation) { x = 1.0 - x; const double swap = a; a = b; b = swap; }
+    const double qab = a + b, qap = a + 1.0, qam = a - 1.0;
+    double c = 1.0, d = 1.0 - (qab * x / qap);
+    if (fabs(d) < fpmin) d = fpmin;
+    d = 1.0 / d;
+    double h = d;
+    for (int m = 1, m2 = 2; m <= 50000; m++, m2 += 2) {
+        double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+        d = 1.0 + (aa * d); if (fabs(d) < fpmin) d = fpmin;
+        c = 1.0 + (aa / c); if (fabs(c) < fpmin) c = fpmin;
+        d = 1.0 / d;
+        h *= d * c;
+        aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+        d = 1.0 + (aa * d); if (fabs(d) < fpmin) d = fpmin;
+        c = 1.0 + (aa / c); if (fabs(c) < fpmin) c = fpmin;
+        d = 1.0 / d;
+        const double del = d * c;
+        h *= del;
+        if (fabs(del - 1.0) <= eps) break;
+    }
+    return symmetryTransformation ? 1.0 - (bt * h / a) : bt * h / a;
+}
+
+// kDiploidOk: the kernels of the streaming-rate path instantiate the Poisson / Extended models only; the Diploid model
+// (PopulateDiploidStats :150-173) is compiled into the counts-fed and candidate kernels, where germline configurations are routed.
+template <bool kDiploidOk = false>
+__device__ inline SbStats sb_create_stats(double support, double coverage, double noiseFreq, double minVariantFreq, int model)
 {
     // CreateStats :137-148 — minDetectableSNP = noiseFreq for every non-Diploid model;
     // ChanceFalseNeg (:213) does not enter the bias score and is not part of the record.
     SbStats st;
     st.support = support;
     st.coverage = coverage;
+    const double minDetectableSNP = (kDiploidOk && model == PISCES_SB_DIPLOID) ? minVariantFreq : noiseFreq;
     if (support == 0) {
         if (model == PISCES_SB_POISSON) {
             st.false_pos = 1;
             st.var_gt_zero = 0;
         } else {
-            st.var_gt_zero = pow(1 - noiseFreq, coverage);
+            st.var_gt_zero = pow(1 - minDetectableSNP, coverage);
             st.false_pos = 1 - st.var_gt_zero;
+        }
+    } else if (kDiploidOk && model == PISCES_SB_DIPLOID) {
+        const double frequency = coverage == 0 ? 0.0 : support / coverage;
+        if (frequency >= minDetectableSNP) {
+            st.var_gt_zero = 1;
+            st.false_pos = 0;
+        } else {
+            const int n = (int)coverage;
+            const double k = floor(support);
+            const double cdf = support < 0.0 ? 0.0 : support > n ? 1.0 : mathnet_beta_regularized(n - k, k + 1, 1 - minDetectableSNP);
+            st.var_gt_zero = fmax(cdf, 0.0);   // ChanceVarFreqGreaterThanZero = ChanceFalseNeg
+            st.false_pos = fmax(0.0, 1 - poisson_cdf_sb(support, coverage * 0.1));
         }
     } else {
         st.var_gt_zero = fmax(0.0, poisson_cdf_sb(support - 1, coverage * noiseFreq));
@@ -341,11 +390,12 @@ __device__ inline SbStats sb_create_stats(double support, double coverage, doubl
 struct SbResult { double bias_score; int acceptable, var_both, cov_both; };
 
 // which: 0 overall (F+R+S), 1 forward (F + S/2), 2 reverse (R + S/2); the stitched halves use integer division (:36-41)
+template <bool kDiploidOk = false>
 __device__ __forceinline__ SbStats sb_stats_of(int which, const int32_t cov[3], const int32_t sup[3], const DeviceParams& P)
 {
     const int s = which == 0 ? sup[0] + sup[1] + sup[2] : (which == 1 ? sup[0] + sup[2] / 2 : sup[1] + sup[2] / 2);
     const int c = which == 0 ? cov[0] + cov[1] + cov[2] : (which == 1 ? cov[0] + cov[2] / 2 : cov[1] + cov[2] / 2);
-    return sb_create_stats((double)s, (double)c, P.err_sb, P.sb_model);
+    return sb_create_stats<kDiploidOk>((double)s, (double)c, P.err_sb, (double)P.min_freq, P.sb_model);
 }
 
 // AssignBiasScore (:89-105) + the both-strands rules (:57-69) from the three statistics
@@ -367,15 +417,16 @@ __device__ __forceinline__ SbResult sb_combine(const SbStats& overall, const SbS
     return r;
 }
 
+template <bool kDiploidOk = false>
 __device__ inline SbResult strand_bias(const int32_t cov[3], const int32_t sup[3], const DeviceParams& P)
 {
     // the three evaluations are independent; interleaving them costs ~3x the registers of one (scratch spills at the
     // 128-VGPR forms of the kernel) and buys nothing on the usual early-out path, so keep them apart
-    const SbStats overall = sb_stats_of(0, cov, sup, P);
+    const SbStats overall = sb_stats_of<kDiploidOk>(0, cov, sup, P);
     __builtin_amdgcn_sched_barrier(0);
-    const SbStats fwd = sb_stats_of(1, cov, sup, P);
+    const SbStats fwd = sb_stats_of<kDiploidOk>(1, cov, sup, P);
     __builtin_amdgcn_sched_barrier(0);
-    const SbStats rev = sb_stats_of(2, cov, sup, P);
+    const SbStats rev = sb_stats_of<kDiploidOk>(2, cov, sup, P);
     __builtin_amdgcn_sched_barrier(0);
     return sb_combine(overall, fwd, rev, P);
 }

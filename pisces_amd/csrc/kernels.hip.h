@@ -227,6 +227,7 @@ __device__ inline void finish_allele(const PointCounts& c, int pos, int a, bool 
 }
 
 // One lane, one allele, start to finish. Returns false (record untouched) when the reference would drop the allele.
+template <bool kDiploidOk = false>
 __device__ inline bool process_point_allele(const PointCounts& c, int pos, int a, bool isRef, int rt,
                                              const uint8_t* __restrict__ ref, int64_t win_lo, int64_t win_hi,
                                              const DeviceParams& P, PiscesCalledAllele& r,
@@ -244,7 +245,7 @@ __device__ inline bool process_point_allele(const PointCounts& c, int pos, int a
     if (!isRef && vq < P.min_vq) return false;
     SbResult sb = {0.0, 0, 0, 0};
 #if !(defined(PISCES_ABLATE_MATH) && (PISCES_ABLATE_MATH == 4 || PISCES_ABLATE_MATH == 9))
-    if (c.support > 0) sb = strand_bias(c.cov, c.sup, P);                            // StrandBiasCalculator.Compute :10-15
+    if (c.support > 0) sb = strand_bias<kDiploidOk>(c.cov, c.sup, P);                // StrandBiasCalculator.Compute :10-15
 #endif
     finish_allele(c, pos, a, isRef, rt, vq, sb, ref, win_lo, win_hi, P, r, s_refwin, s_refidx, pre_tail);
     return true;
@@ -316,7 +317,7 @@ __device__ inline void call_roles(const int* hist, const uint32_t* gapped /* LDS
                 ref_rank = (rt < 4) ? rank_of_allele(rt) : 0;
                 const PointCounts c = point_counts(hist, l, a, true, rt, g);
                 PiscesCalledAllele rec;
-                (void)process_point_allele(c, pos, a, true, rt, ref, win_lo, win_hi, P, rec, s_refwin, kRefMargin + l, nullptr, s_err ? &s_err[l] : nullptr);
+                (void)process_point_allele<true>(c, pos, a, true, rt, ref, win_lo, win_hi, P, rec, s_refwin, kRefMargin + l, nullptr, s_err ? &s_err[l] : nullptr);
                 // written now; it only counts if no variant turns out callable at this locus
                 copy_record(&slots[ref_rank], &rec);
                 ref_emitted = true;
@@ -340,8 +341,8 @@ __device__ inline void call_roles(const int* hist, const uint32_t* gapped /* LDS
 #else
             } else if (c.support > 0) {
 #endif
-                const SbStats ov = sb_stats_of(0, c.cov, c.sup, P), fw = sb_stats_of(1, c.cov, c.sup, P),
-                              rv = sb_stats_of(2, c.cov, c.sup, P);
+                const SbStats ov = sb_stats_of<true>(0, c.cov, c.sup, P), fw = sb_stats_of<true>(1, c.cov, c.sup, P),
+                              rv = sb_stats_of<true>(2, c.cov, c.sup, P);
                 vs->ov_var[slot] = ov.var_gt_zero;
                 vs->fw_var[slot] = fw.var_gt_zero; vs->fw_fp[slot] = fw.false_pos;
                 vs->rv_var[slot] = rv.var_gt_zero; vs->rv_fp[slot] = rv.false_pos;
@@ -1301,7 +1302,7 @@ __global__ __launch_bounds__(64) void call_spanning_kernel(
                 for (int k = 0; k < 5; k++) sum += get_base_quality_sum(sumq, c.start_idx, cca[k], d, 0, -1, false);
             werr = window_err(sum, pc.total, P);
         }
-        const bool ok = process_point_allele(pc, c.position, a, isRef, rt, ref, 0, ref_len, P, r, nullptr, 0, nullptr, sumq ? &werr : nullptr);
+        const bool ok = process_point_allele<true>(pc, c.position, a, isRef, rt, ref, 0, ref_len, P, r, nullptr, 0, nullptr, sumq ? &werr : nullptr);
         out[i] = r;
         callable_out[i] = ok ? 1 : 0;
         return;
@@ -1327,7 +1328,7 @@ __global__ __launch_bounds__(64) void call_spanning_kernel(
                 vq = poisson_qscore(support, total, P);
             }
         }
-        sb = strand_bias(cov, c.sup, P);
+        sb = strand_bias<true>(cov, c.sup, P);
     }
     const float freq = frequency_f(support, total);
     uint32_t filters = 0;   // NumNoCalls stays 0 for spanning alleles -> FractionNoCalls 0

@@ -20,6 +20,7 @@
 
 #include "../../include/pisces_hip.h"
 #include "expander.h"
+#include "diploid.h"
 #include "finder.h"
 #include "kernels.hip.h"
 #include "stream_kernels.hip.h"
@@ -288,8 +289,9 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         return fail(nullptr, PISCES_E_INVALID_ARG, "pisces_hip_create: config abi_version mismatch");
     if (cfg->tile_loci != 0 && cfg->tile_loci != kTile)
         return fail(nullptr, PISCES_E_UNSUPPORTED, "pisces_hip_create: tile_loci must be 64 in this build");
-    if (cfg->strand_bias_model == PISCES_SB_DIPLOID)
-        return fail(nullptr, PISCES_E_UNSUPPORTED, "pisces_hip_create: Diploid strand-bias model is not on the device path");
+    if (cfg->strand_bias_model < PISCES_SB_POISSON || cfg->strand_bias_model > PISCES_SB_DIPLOID || cfg->ploidy < PISCES_PLOIDY_SOMATIC ||
+        cfg->ploidy > PISCES_PLOIDY_DIPLOID || cfg->noise_model < PISCES_NOISE_FLAT || cfg->noise_model > PISCES_NOISE_WINDOW)
+        return fail(nullptr, PISCES_E_INVALID_ARG, "pisces_hip_create: strand_bias_model / ploidy / noise_model out of range");
     if (cfg->block_size <= 0 || cfg->min_base_call_quality < 0 || cfg->min_base_call_quality > 254)
         return fail(nullptr, PISCES_E_INVALID_ARG, "pisces_hip_create: block_size / min_base_call_quality out of range");
     int ndev = 0;
@@ -921,7 +923,8 @@ static void launch_call_tiles(PiscesHip* h, hipStream_t s, const uint32_t* d_tup
         if (e1) (void)hipEventRecord(e1, s);
         return;
     }
-    if (h->kernel_variant >= 2 && h->cfg.min_base_call_quality <= 255) {   // the wave forms compare the quality byte in place
+    // (the Diploid strand-bias model is compiled into call_tiles_kernel / call_counts_kernel / call_spanning_kernel only)
+    if (h->kernel_variant >= 2 && h->cfg.min_base_call_quality <= 255 && h->cfg.strand_bias_model != PISCES_SB_DIPLOID) {   // the wave forms compare the quality byte in place
         // Two waves per tile shorten the call phase (Reference / q-score work and the strand-bias statistics run side by
         // side) and pay for it in registers (128 VGPRs for 8 tiles per CU).  Measured (tools/kbench.py, 500x): that wins up
         // to ~8 k tiles per launch (56 % vs 49 % at 2048 tiles, 62 % vs 60 % at 8192); beyond that tiles interleave on their
@@ -1597,7 +1600,8 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
         h->pending.clear();
         h->pending_cand_index.clear();
         h->pending_cands = span_cands;
-        if (span_recs.empty()) {
+        const bool diploid = h->cfg.ploidy == PISCES_PLOIDY_DIPLOID;
+        if (span_recs.empty() && !diploid) {
             h->pending = std::move(point_recs);
             h->pending_cand_index.assign(h->pending.size(), -1);
         } else {
@@ -1618,7 +1622,47 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
                 if (a.ref != b.ref) return a.ref < b.ref;
                 return a.alt < b.alt;
             });
-            for (auto& row : rows) { h->pending.push_back(*row.r); h->pending_cand_index.push_back(row.ci); }
+            if (!diploid) {
+                for (auto& row : rows) { h->pending.push_back(*row.r); h->pending_cand_index.push_back(row.ci); }
+            } else {
+                // ComputeGenotypeAndFilterAllele :143-177 with DiploidThresholdingGenotyper: one genotype per locus, alleles beyond the
+                // ploidy dropped, every kept allele gets its own diploid genotype q-score, LowGQ and MultiAllelicSite filters; the
+                // device's somatic genotype fields are replaced.  (Reference rows at variant loci are gone already, rows are in
+                // (ref, alt) order.)
+                std::vector<DiploidAllele> at;
+                for (size_t i = 0; i < rows.size();) {
+                    size_t j = i;
+                    while (j < rows.size() && rows[j].r->position == rows[i].r->position) j++;
+                    at.clear();
+                    for (size_t k = i; k < j; k++) {
+                        DiploidAllele a;
+                        a.category = PISCES_INFO_CATEGORY(rows[k].r->info);
+                        a.ref = rows[k].ref;
+                        a.alt = rows[k].alt;
+                        a.support = rows[k].r->allele_support;
+                        a.coverage = rows[k].r->total_coverage;
+                        a.ref_support = rows[k].r->reference_support;
+                        at.push_back(std::move(a));
+                    }
+                    (void)diploid_set_genotypes(at, h->cfg.diploid_snv_params, h->cfg.diploid_indel_params, h->cfg.min_coverage,
+                                                h->cfg.min_genotype_qscore, h->cfg.max_genotype_qscore);
+                    for (size_t k = i; k < j; k++) {
+                        const DiploidAllele& a = at[k - i];
+                        if (a.prune) continue;
+                        PiscesCalledAllele r = *rows[k].r;
+                        r.info = (uint16_t)((r.info & ~0xFu) | ((uint32_t)a.genotype & 0xFu));
+                        r.genotype_qscore = a.genotype_qscore;
+                        uint32_t fb = r.filter_bits & ~(1u << PISCES_FILTER_LOW_GENOTYPE_QUALITY) & 0x3FFFu;
+                        if (a.multi_allelic) fb |= 1u << PISCES_FILTER_MULTI_ALLELIC_SITE;
+                        if (h->cfg.low_gq_filter >= 0 && (float)a.genotype_qscore < (float)h->cfg.low_gq_filter) fb |= 1u << PISCES_FILTER_LOW_GENOTYPE_QUALITY;
+                        fb |= (uint32_t)(a.phase_set_index & 3) << 14;
+                        r.filter_bits = (uint16_t)fb;
+                        h->pending.push_back(r);
+                        h->pending_cand_index.push_back(rows[k].ci);
+                    }
+                    i = j;
+                }
+            }
         }
         h->pending_keys = keys;
         h->pending_called = called;
@@ -1790,6 +1834,8 @@ int32_t pisces_hip_call_tiles(PiscesHip* h, const uint32_t* d_tuples, const Pisc
         return fail(h, PISCES_E_INVALID_ARG, "call_tiles: null device pointer");
     if ((int64_t)record_capacity < (int64_t)n_tiles * kSlotsPerTile)
         return fail(h, PISCES_E_BUFFER_TOO_SMALL, "call_tiles: the slot layout needs record_capacity >= 256 * n_tiles");
+    if (h->cfg.ploidy == PISCES_PLOIDY_DIPLOID)
+        return fail(h, PISCES_E_STATE, "call_tiles: diploid genotyping is a per-locus pass of pisces_hip_flush (streaming surface)");
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     // events only when asked for (pisces_hip_set_timing): an event record is a queue packet of its own, and two of them

@@ -219,11 +219,13 @@ int64_t pisces_hip_format_vcf_padded(const PiscesVcfConfig* cfg, const char* chr
             gq = std::min(gq, recs[i].genotype_qscore);         // MergeGenotypeQScores :491-494
         }
         depth = std::max(depth, total_variant_reads);
-        // SetUncrushedReferenceAndAlt :434-448 (PhaseSetIndex is 0 on this path) / MergeCrushedReferenceAndAlt :450-482
+        // SetUncrushedReferenceAndAlt :434-448 (PhaseSetIndex: 1 / 2 for the variant alleles of a diploid call, 0 on the somatic path) /
+        // MergeCrushedReferenceAndAlt :450-482
+        const int phase = PISCES_FILTERBITS_PHASE(first.filter_bits);
         std::string ref_allele, alt_allele;
         if (g1 - g0 == 1) {
             if (!allele_strings(g0, ref_allele, alt_allele)) return PISCES_E_INVALID_ARG;
-            if (alt12) alt_allele = "<M>," + alt_allele;
+            if (alt12) alt_allele = phase == 1 ? alt_allele + ",<M>" : "<M>," + alt_allele;
         } else {
             std::vector<std::pair<std::string, std::string>> ra((size_t)(g1 - g0));
             for (int64_t i = g0; i < g1; i++) {
@@ -242,8 +244,11 @@ int64_t pisces_hip_format_vcf_padded(const PiscesVcfConfig* cfg, const char* chr
         // them (src/exe/Pisces/Logic/VariantCalling/AlleleProcessor.cs:25-71), alleles in order, first occurrence kept
         std::string filters;
         uint32_t seen = 0;
-        static const int kOrder[7] = {PISCES_FILTER_LOW_DEPTH, PISCES_FILTER_LOW_VARIANT_QSCORE, PISCES_FILTER_NO_CALL, PISCES_FILTER_STRAND_BIAS,
-                                      PISCES_FILTER_RMXN, PISCES_FILTER_LOW_VARIANT_FREQUENCY, PISCES_FILTER_LOW_GENOTYPE_QUALITY};
+        // (MultiAllelicSite is added by the diploid genotyper, GenotypeCalculatorUtilities.cs:139-145, after the processor's filters
+        // and before AlleleCaller's LowGQ)
+        static const int kOrder[8] = {PISCES_FILTER_LOW_DEPTH, PISCES_FILTER_LOW_VARIANT_QSCORE, PISCES_FILTER_NO_CALL, PISCES_FILTER_STRAND_BIAS,
+                                      PISCES_FILTER_RMXN, PISCES_FILTER_LOW_VARIANT_FREQUENCY, PISCES_FILTER_MULTI_ALLELIC_SITE,
+                                      PISCES_FILTER_LOW_GENOTYPE_QUALITY};
         for (int64_t i = g0; i < g1; i++)
             for (int f : kOrder) {
                 if (!(recs[i].filter_bits & (1u << f)) || (seen & (1u << f))) continue;
@@ -262,6 +267,7 @@ int64_t pisces_hip_format_vcf_padded(const PiscesVcfConfig* cfg, const char* chr
                     name = "R" + std::to_string(cfg->rmxn_max_repeat_length) + "x" + std::to_string(cfg->rmxn_min_repetitions);
                     break;
                 case PISCES_FILTER_LOW_VARIANT_FREQUENCY: name = "LowVariantFreq"; break;
+                case PISCES_FILTER_MULTI_ALLELIC_SITE: name = "MultiAllelicSite"; break;
                 default: name = "LowGQ"; break;
                 }
                 if (!filters.empty()) filters += ";";
@@ -279,7 +285,8 @@ int64_t pisces_hip_format_vcf_padded(const PiscesVcfConfig* cfg, const char* chr
                 for (int64_t i = g0; i < g1; i++) ad += (i > g0 ? "," : "") + std::to_string(recs[i].allele_support);
             } else {
                 const int other = depth - first.allele_support - first.reference_support;
-                ad = std::to_string(first.reference_support) + "," + std::to_string(other) + "," + std::to_string(first.allele_support);
+                ad = phase == 1 ? std::to_string(first.reference_support) + "," + std::to_string(first.allele_support) + "," + std::to_string(other)
+                                : std::to_string(first.reference_support) + "," + std::to_string(other) + "," + std::to_string(first.allele_support);
             }
             double sum = 0.0;   // SumMultipleVF
             for (int64_t i = g0; i < g1; i++) sum += (double)recs[i].allele_support / (double)depth;

@@ -45,7 +45,8 @@ def test_default_config_matches_library_and_reference_defaults():
     for name, _ in _abi.PiscesHipConfig._fields_:
         if name == "reserved":
             continue
-        assert getattr(c, name) == getattr(py, name), name
+        a, b = getattr(c, name), getattr(py, name)
+        assert (list(a) == list(b)) if hasattr(a, "__len__") else (a == b), name
     # src/lib/Pisces.Domain/Options/VariantCallingParameters.cs:57-107
     assert (c.min_base_call_quality, c.max_variant_qscore, c.min_variant_qscore, c.variant_qscore_filter) == (20, 100, 20, 30)
     assert (c.min_coverage, c.block_size, c.strand_bias_model) == (10, 1000, _abi.SB_EXTENDED)

@@ -334,7 +334,7 @@ def test_error_paths(torch_cuda):
         c.AddAlleleCounts(_abi.ReadBatch([good]))
         assert c.GetCounts(20, 8).sum() == 8 and c.Stats()["observations"] == 9 and c.Stats()["reads"] == 1
     with pytest.raises(engine.PiscesHipError):
-        engine.HipVariantCaller(_abi.default_config(strand_bias_model=_abi.SB_DIPLOID))
+        engine.HipVariantCaller(_abi.default_config(strand_bias_model=7))
     with pytest.raises(engine.PiscesHipError):
         engine.HipVariantCaller(_abi.default_config(abi_version=99))
 
@@ -829,6 +829,72 @@ def test_window_noise_model_matches_oracle(torch_cuda, call_mnvs):
         stats = c.Stats()
     cats = (exp["info"] >> 4) & 7
     assert (cats == _abi.CAT_SNV).sum() >= 10 and ((cats == _abi.CAT_DELETION) | (cats == _abi.CAT_INSERTION)).sum() >= 1
+    assert got_alleles == exp_alleles
+    assert_records_match(got, exp)
+    assert stats["TotalNumCalled"] == exp_called
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sb_model", [1, 2])   # Extended, Diploid
+def test_diploid_genotyping_matches_oracle(torch_cuda, sb_model):
+    """PloidyModel.DiploidByThresholding (one genotype per locus from the variant frequencies, alleles beyond
+    the ploidy pruned, diploid genotype q-scores, MultiAllelicSite / LowGQ filters, phase set index) and the Diploid strand-bias model,
+    on germline-like reads: het and hom SNVs, a het deletion, a tri-allelic site, a 1/2 site, sub-threshold alleles, a shallow stretch.
+    Records, allele strings and TotalNumCalled against the oracle."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(500 + sb_model)
+    ref = bytearray(rng.choice(list(b"ACGT"), 1600).astype(np.uint8))
+    def other(p, k=0):
+        return [b for b in b"ACGT" if b != ref[p - 1]][k]
+    planted = {}   # position -> list of (alt byte, cumulative fraction)
+    p = 60
+    kinds = ["het", "hom", "quarter", "tri", "alt12", "low"]
+    i = 0
+    while p < 1500:
+        k = kinds[i % len(kinds)]
+        planted[p] = {"het": [(other(p), 0.5)], "hom": [(other(p), 0.97)], "quarter": [(other(p), 0.27)],
+                      "tri": [(other(p), 0.3), (other(p, 1), 0.55), (other(p, 2), 0.8)], "alt12": [(other(p), 0.48), (other(p, 1), 0.97)],
+                      "low": [(other(p), 0.1)]}[k]
+        p += int(rng.integers(15, 40))
+        i += 1
+    reads = []
+    for n in range(2400):
+        shallow = n >= 2340                      # a stretch covered by only 60 reads: below MinimumCoverage on parts of it
+        start = int(rng.integers(1390, 1480)) if shallow else int(rng.integers(30, 1300))
+        L = 100
+        seq = bytearray(ref[start - 1: start - 1 + L])
+        for pos, alts in planted.items():
+            if start <= pos < start + L:
+                u = rng.random()
+                for alt, cum in alts:
+                    if u < cum:
+                        seq[pos - start] = alt
+                        break
+        for k in range(L):
+            if rng.random() < 0.002:
+                seq[k] = int(rng.choice(list(b"ACGT")))
+        ops, s = [("M", L)], bytes(seq).decode()
+        if start <= 720 and start + L > 745 and rng.random() < 0.45:   # a het deletion of 731..733
+            k = 730 - start + 1
+            ops = [("M", k), ("D", 3), ("M", L - k)]
+            s = s[:k] + bytes(ref[start - 1 + k + 3: start - 1 + L + 3]).decode()
+        reads.append({"pos": start, "cigar": ops, "seq": s, "quals": np.where(rng.random(L) < 0.02, 12, 37).astype(np.uint8).tolist(),
+                      "reverse": bool(n % 2)})
+    reads.sort(key=lambda r: r["pos"])
+    batch = _abi.ReadBatch(reads)
+    refa = np.frombuffer(bytes(ref), dtype=np.uint8)
+    cfg = _abi.default_config(ploidy=1, strand_bias_model=sb_model, min_frequency=0.2, variant_freq_filter=0.2, low_gq_filter=30,
+                              max_genotype_qscore=1000, block_size=2000)
+    exp, exp_alleles, _, exp_called = orc.run_reads_full(batch, refa, 1, len(ref), cfg)
+    gts = set((exp["info"] & 15).tolist())
+    assert {0, 2, 3, 4}.issubset(gts) and (6 in gts or 1 in gts), gts       # 1/2, 0/1, 1/1, 0/0 and a multi-allelic no-call
+    assert ((exp["filter_bits"] >> 8) & 1).any() and ((exp["filter_bits"] >> 14) == 2).any()
+    assert ((((exp["info"] >> 4) & 7) == _abi.CAT_DELETION)).any()
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(refa)
+        c.AddAlleleCounts(batch)
+        got, got_alleles = c.CallWithAlleles()
+        stats = c.Stats()
     assert got_alleles == exp_alleles
     assert_records_match(got, exp)
     assert stats["TotalNumCalled"] == exp_called

@@ -234,3 +234,17 @@ def test_padding_needs_its_inputs_and_keeps_state_on_a_short_buffer():
     need = engine.lib.pisces_hip_format_vcf_padded(C.byref(cfg), b"chr1", r.ctypes.data, 1, None, None, None, ref.ctypes.data, 15,
                                                    starts.ctypes.data, ends.ctypes.data, 1, C.byref(st), 1, buf, 8)
     assert need > 8 and (st.last_variant_position_written, st.last_padded_position, st.last_cleared_interval_index) == (0, 0, -1)
+
+
+def test_phase_set_index_orders_the_unspecified_allele_of_a_1_2_line():
+    """SetUncrushedReferenceAndAlt (VcfFormatter.cs:434-448) and GetAlleleCountString (:396-421): the first variant allele of a diploid 1/2
+    call (PhaseSetIndex 1, carried in filter_bits 14..15) prints ALT,<M> and ref,support,other; the second <M>,ALT and ref,other,support;
+    MultiAllelicSite keeps its place before LowGQ."""
+    a = record(10, "A", "G", GT["1/2"], CAT_SNV, cov=200, support=90, ref_support=5, q=100, gq=50)
+    b = record(10, "A", "T", GT["1/2"], CAT_SNV, cov=200, support=100, ref_support=5, q=100, gq=50)
+    a["filter_bits"] |= 1 << 14
+    b["filter_bits"] |= (2 << 14) | (1 << 8) | (1 << 6) | (1 << 0)
+    la = engine.format_vcf("chr1", a).rstrip("\n").split("\t")
+    lb = engine.format_vcf("chr1", b).rstrip("\n").split("\t")
+    assert la[4] == "G,<M>" and la[9].split(":")[2] == "5,90,105" and la[6] == "PASS"
+    assert lb[4] == "<M>,T" and lb[9].split(":")[2] == "5,95,100" and lb[6] == "SB;MultiAllelicSite;LowGQ"
