@@ -44,7 +44,8 @@ enum { PISCES_CAT_SNV = 0, PISCES_CAT_INSERTION = 1, PISCES_CAT_DELETION = 2, PI
 /* src/lib/Pisces.Domain/Types/Genotype.cs:3-18 */
 enum { PISCES_GT_HET_ALT1_ALT2 = 0, PISCES_GT_ALT12_LIKE_NOCALL = 1, PISCES_GT_HET_ALT_REF = 2,
        PISCES_GT_HOM_ALT = 3, PISCES_GT_HOM_REF = 4, PISCES_GT_REF_LIKE_NOCALL = 5,
-       PISCES_GT_ALT_LIKE_NOCALL = 6, PISCES_GT_REF_AND_NOCALL = 7, PISCES_GT_ALT_AND_NOCALL = 8 };
+       PISCES_GT_ALT_LIKE_NOCALL = 6, PISCES_GT_REF_AND_NOCALL = 7, PISCES_GT_ALT_AND_NOCALL = 8,
+       PISCES_GT_HEMI_REF = 9, PISCES_GT_HEMI_ALT = 10, PISCES_GT_HEMI_NOCALL = 11 /* PloidyModel.Haploid */ };
 /* src/lib/Pisces.Domain/Types/FilterType.cs:3-19 — bit i of filter_bits = enum value i */
 enum { PISCES_FILTER_STRAND_BIAS = 0, PISCES_FILTER_POOL_BIAS = 1, PISCES_FILTER_AMPLICON_BIAS = 2,
        PISCES_FILTER_LOW_VARIANT_QSCORE = 3, PISCES_FILTER_LOW_DEPTH = 4,
@@ -55,7 +56,8 @@ enum { PISCES_FILTER_STRAND_BIAS = 0, PISCES_FILTER_POOL_BIAS = 1, PISCES_FILTER
 /* src/lib/Pisces.Domain/Types (StrandBiasModel): Poisson, Extended, Diploid */
 enum { PISCES_SB_POISSON = 0, PISCES_SB_EXTENDED = 1, PISCES_SB_DIPLOID = 2 };
 enum { PISCES_NOISE_FLAT = 0, PISCES_NOISE_WINDOW = 1 };
-enum { PISCES_PLOIDY_SOMATIC = 0, PISCES_PLOIDY_DIPLOID = 1 };   /* PloidyModel.Somatic / DiploidByThresholding (Types/ModelTypes.cs) */   /* Pisces.Domain/Types/ModelTypes.cs:13 */
+enum { PISCES_PLOIDY_SOMATIC = 0, PISCES_PLOIDY_DIPLOID = 1, PISCES_PLOIDY_HAPLOID = 2 };   /* PloidyModel.Somatic / DiploidByThresholding /
+                                                                                         Haploid (Types/ModelTypes.cs) */   /* Pisces.Domain/Types/ModelTypes.cs:13 */
 
 /* Anchor bins: NumAnchorIndexes = 2*trackedAnchorSize+1 (RegionStateManager.cs:30-31), default 5 -> 11 */
 #define PISCES_ANCHOR_SIZE   5
@@ -127,8 +129,9 @@ typedef struct PiscesHipConfig {
     int32_t noise_model;              /* VariantCallingParameters.NoiseModel: PISCES_NOISE_FLAT (default) or PISCES_NOISE_WINDOW, where the
                                          variant q-score of an allele uses (int)PtoQ(SumOfBaseQuality / TotalCoverage) as its noise level
                                          (AlleleCaller.cs:215-218, RegionStateManager.cs:191) */
-    int32_t ploidy;                   /* PISCES_PLOIDY_SOMATIC (default) or PISCES_PLOIDY_DIPLOID: one genotype per locus from the variant
-                                         frequencies, alleles beyond the ploidy pruned (DiploidThresholdingGenotyper.cs:54-141) */
+    int32_t ploidy;                   /* PISCES_PLOIDY_SOMATIC (default), PISCES_PLOIDY_DIPLOID or PISCES_PLOIDY_HAPLOID: one genotype per locus from the
+                                         variant frequencies, alleles beyond the ploidy pruned (DiploidThresholdingGenotyper.cs:54-141,
+                                         HaploidGenotyper.cs:36-83, which takes MinorVF / MajorVF from the SNV parameters below) */
     float   diploid_snv_params[3];    /* DiploidSNVThresholdingParameters {MinorVF, MajorVF, SumVFforMultiAllelicSite}: 0.20, 0.70, 0.80 */
     float   diploid_indel_params[3];  /* DiploidINDELThresholdingParameters, same defaults */
 } PiscesHipConfig;

@@ -565,6 +565,83 @@ int32_t orc_diploid_set_genotypes(OrcCalled* alleles, int n, const float snv[3],
     return gt;
 }
 
+/* HaploidGenotypeQualityCalculator.Compute :10-59 */
+int32_t orc_haploid_gq(int32_t calledGT, int32_t totalCoverage, int32_t alleleSupport, int32_t minQScore, int32_t maxQScore)
+{
+    if (totalCoverage == 0) return minQScore;
+    const float noiseHomRef = 0.05f, noiseHomAlt = 0.075f, expectedHetFreq = 0.40f;
+    const float depth = (float)totalCoverage;
+    const int nonAlleleCalls = totalCoverage - alleleSupport > 0 ? totalCoverage - alleleSupport : 0;
+    double h0, h1;
+    if (calledGT == PISCES_GT_HEMI_REF) {
+        h0 = orc_mathnet_poisson_ln_pmf((double)(noiseHomRef * depth), nonAlleleCalls);
+        h1 = orc_mathnet_binomial_lnpmf((double)expectedHetFreq, totalCoverage, nonAlleleCalls);
+    } else if (calledGT == PISCES_GT_HEMI_ALT) {
+        h0 = orc_mathnet_poisson_ln_pmf((double)(noiseHomAlt * depth), nonAlleleCalls);
+        h1 = orc_mathnet_binomial_lnpmf((double)expectedHetFreq, totalCoverage, alleleSupport);
+    } else return minQScore;
+    const double v = floor(10.0 * 0.4342944819032518 * (h0 - h1));
+    const int32_t qScore = (v > -2147483649.0 && v < 2147483648.0) ? (int32_t)v : INT32_MIN;
+    const int32_t capped = qScore < maxQScore ? qScore : maxQScore;
+    return capped > minQScore ? capped : minQScore;
+}
+
+/* HaploidGenotyper.SetGenotypes :36-48 + CalculateHaploidGenotype :50-83 */
+int32_t orc_haploid_set_genotypes(OrcCalled* alleles, int n, float minorVF, float majorVF, int32_t minDepthToGenotype, int32_t minGQ,
+                                  int32_t maxGQ, uint8_t* prune)
+{
+    int order[64];
+    int nv = 0;
+    for (int i = 0; i < n; i++) prune[i] = 0;
+    for (int i = 0; i < n && nv < 64; i++) {
+        if (alleles[i].category == PISCES_CAT_REFERENCE) continue;
+        if ((double)frequency_f(alleles[i].allele_support, alleles[i].total_coverage) >= (double)minorVF) order[nv++] = i;
+        else prune[i] = 1;
+    }
+    for (int a = 1; a < nv; a++) {
+        int x = order[a], b = a;
+        while (b > 0) {
+            const OrcCalled* p = &alleles[order[b - 1]];
+            const OrcCalled* q = &alleles[x];
+            const float fp = frequency_f(p->allele_support, p->total_coverage), fq = frequency_f(q->allele_support, q->total_coverage);
+            int after;
+            if (fp != fq) after = fp < fq;
+            else { int r = strcmp(p->ref, q->ref); if (!r) r = strcmp(p->alt, q->alt); after = r > 0; }
+            if (!after) break;
+            order[b] = order[b - 1];
+            b--;
+        }
+        order[b] = x;
+    }
+    double referenceFrequency = 0;
+    if (n == 1) referenceFrequency = frequency_f(alleles[0].reference_support, alleles[0].total_coverage);
+    else if (n > 1) {
+        double refBySNP = 0, indelCount = 0;
+        int returned = 0;
+        for (int i = 0; i < n; i++) {
+            const float f = frequency_f(alleles[i].allele_support, alleles[i].total_coverage);
+            if (alleles[i].category == PISCES_CAT_REFERENCE) { referenceFrequency = f; returned = 1; break; }
+            if (alleles[i].category == PISCES_CAT_SNV) refBySNP = frequency_f(alleles[i].reference_support, alleles[i].total_coverage);
+            else indelCount += f;
+        }
+        if (!returned) referenceFrequency = fmax(refBySNP - indelCount, 0.0);
+    }
+    const int refExists = referenceFrequency >= (double)minorVF;
+    int depthIssue = 0;
+    for (int i = 0; i < n; i++) depthIssue |= alleles[i].total_coverage < minDepthToGenotype;
+    const float f0 = nv ? frequency_f(alleles[order[0]].allele_support, alleles[order[0]].total_coverage) : 0.0f;
+    const int refCall = nv == 0 || f0 < minorVF;
+    int32_t gt = PISCES_GT_HEMI_NOCALL;
+    if (!depthIssue && refCall && refExists && referenceFrequency > (double)majorVF) gt = PISCES_GT_HEMI_REF;
+    if (!depthIssue && !refCall && !refExists && f0 > majorVF) gt = PISCES_GT_HEMI_ALT;
+    for (int k = (gt == PISCES_GT_HEMI_ALT ? 1 : 0); k < nv; k++) prune[order[k]] = 1;
+    for (int i = 0; i < n; i++) {
+        alleles[i].genotype = gt;
+        alleles[i].genotype_qscore = orc_haploid_gq(gt, alleles[i].total_coverage, alleles[i].allele_support, minGQ, maxGQ);
+    }
+    return gt;
+}
+
 /* SomaticGenotypeQualityCalculator.Compute :10-48 */
 int32_t orc_somatic_gq(int32_t genotype, int32_t variantQ, int32_t totalCoverage, int32_t alleleSupport,
                        float targetLod, int32_t minGQ, int32_t maxGQ)
@@ -1904,7 +1981,7 @@ int64_t orc_call_candidates_max(OrcState* s, const OrcCandidate* list, int64_t n
         int64_t j = i;
         int anyNonRef = 0;
         while (j < n && called[j].position == called[i].position) { if (called[j].category != PISCES_CAT_REFERENCE) anyNonRef = 1; j++; }
-        if (cfg->ploidy == PISCES_PLOIDY_DIPLOID) {
+        if (cfg->ploidy == PISCES_PLOIDY_DIPLOID || cfg->ploidy == PISCES_PLOIDY_HAPLOID) {
             /* ComputeGenotypeAndFilterAllele :143-177 with the diploid genotyper: Reference rows leave when a variant is there, the
              * genotyper names the alleles beyond the ploidy, LowGQ, (ref, alt) order (the list is sorted already) */
             OrcCalled at[64];
@@ -1915,6 +1992,11 @@ int64_t orc_call_candidates_max(OrcState* s, const OrcCandidate* list, int64_t n
                 if (anyNonRef && called[k].category == PISCES_CAT_REFERENCE) continue;
                 at[m++] = called[k];
             }
+            if (cfg->ploidy == PISCES_PLOIDY_HAPLOID) {
+                orc_haploid_set_genotypes(at, m, cfg->diploid_snv_params[0], cfg->diploid_snv_params[1], cfg->min_coverage, cfg->min_genotype_qscore,
+                                          cfg->max_genotype_qscore, prune);
+                for (int q = 0; q < m; q++) phase[q] = 0;   /* HaploidGenotyper leaves PhaseSetIndex alone */
+            } else
             orc_diploid_set_genotypes(at, m, cfg->diploid_snv_params, cfg->diploid_indel_params, cfg->min_coverage, cfg->min_genotype_qscore,
                                       cfg->max_genotype_qscore, phase, prune);
             for (int q = 0; q < m; q++) {

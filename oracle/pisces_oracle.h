@@ -159,6 +159,9 @@ double orc_mathnet_binomial_cdf(double p, int n, double x);
 double orc_mathnet_binomial_lnpmf(double p, int n, int k);
 void orc_sb_populate_diploid_stats(double support, double coverage, double minDetectableSNP, double out3[3]);
 int32_t orc_diploid_gq(int32_t calledGT, int32_t totalCoverage, int32_t alleleSupport, int32_t minQScore, int32_t maxQScore);
+int32_t orc_haploid_gq(int32_t calledGT, int32_t totalCoverage, int32_t alleleSupport, int32_t minQScore, int32_t maxQScore);
+int32_t orc_haploid_set_genotypes(OrcCalled* alleles, int n, float minorVF, float majorVF, int32_t minDepthToGenotype, int32_t minGQ,
+                                  int32_t maxGQ, uint8_t* prune);
 int32_t orc_diploid_set_genotypes(OrcCalled* alleles, int n, const float snv[3], const float indel[3], int32_t minDepthToGenotype,
                                   int32_t minGQ, int32_t maxGQ, int32_t* phase_set_index, uint8_t* prune);
 /* MnvReallocator.ReallocateFailedMnvs over arrays (test hook; max_position < 0 = null) */

@@ -161,4 +161,63 @@ int32_t diploid_set_genotypes(std::vector<DiploidAllele>& alleles, const float s
     return gt;
 }
 
+int32_t haploid_set_genotypes(std::vector<DiploidAllele>& alleles, float minorVF, float majorVF, int32_t minDepthToGenotype, int32_t minGQ,
+                              int32_t maxGQ)
+{
+    const int n = (int)alleles.size();
+    auto freq = [&](int i) { return frequency_f(alleles[(size_t)i].support, alleles[(size_t)i].coverage); };
+    std::vector<int> order;
+    for (int i = 0; i < n; i++) {
+        alleles[(size_t)i].prune = false;
+        if (alleles[(size_t)i].category == PISCES_CAT_REFERENCE) continue;
+        if ((double)freq(i) >= (double)minorVF) order.push_back(i);
+        else alleles[(size_t)i].prune = true;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+        if (freq(x) != freq(y)) return freq(x) > freq(y);
+        if (alleles[(size_t)x].ref != alleles[(size_t)y].ref) return alleles[(size_t)x].ref < alleles[(size_t)y].ref;
+        return alleles[(size_t)x].alt < alleles[(size_t)y].alt;
+    });
+    const int nv = (int)order.size();
+    double referenceFrequency = 0;
+    if (n == 1) referenceFrequency = frequency_f(alleles[0].ref_support, alleles[0].coverage);
+    else if (n > 1) {
+        double refBySNP = 0, indelCount = 0;
+        bool returned = false;
+        for (int i = 0; i < n; i++) {
+            if (alleles[(size_t)i].category == PISCES_CAT_REFERENCE) { referenceFrequency = freq(i); returned = true; break; }
+            if (alleles[(size_t)i].category == PISCES_CAT_SNV) refBySNP = frequency_f(alleles[(size_t)i].ref_support, alleles[(size_t)i].coverage);
+            else indelCount += freq(i);
+        }
+        if (!returned) referenceFrequency = std::max(refBySNP - indelCount, 0.0);
+    }
+    const bool refExists = referenceFrequency >= (double)minorVF;
+    bool depthIssue = false;
+    for (int i = 0; i < n; i++) depthIssue |= alleles[(size_t)i].coverage < minDepthToGenotype;
+    const float f0 = nv ? freq(order[0]) : 0.0f;
+    const bool refCall = nv == 0 || f0 < minorVF;
+    int32_t gt = PISCES_GT_HEMI_NOCALL;
+    if (!depthIssue && refCall && refExists && referenceFrequency > (double)majorVF) gt = PISCES_GT_HEMI_REF;
+    if (!depthIssue && !refCall && !refExists && f0 > majorVF) gt = PISCES_GT_HEMI_ALT;
+    for (int k = gt == PISCES_GT_HEMI_ALT ? 1 : 0; k < nv; k++) alleles[(size_t)order[(size_t)k]].prune = true;
+    for (auto& a : alleles) {
+        a.genotype = gt;
+        a.phase_set_index = 0;
+        a.multi_allelic = false;
+        // HaploidGenotypeQualityCalculator.Compute
+        int32_t gq = minGQ;
+        if (a.coverage != 0 && (gt == PISCES_GT_HEMI_REF || gt == PISCES_GT_HEMI_ALT)) {
+            const float depth = (float)a.coverage;
+            const int nonAlleleCalls = std::max(a.coverage - a.support, 0);
+            const double h0 = poisson_ln_pmf((double)((gt == PISCES_GT_HEMI_REF ? 0.05f : 0.075f) * depth), nonAlleleCalls);
+            const double h1 = binomial_ln_pmf((double)0.40f, a.coverage, gt == PISCES_GT_HEMI_REF ? nonAlleleCalls : a.support);
+            const double v = std::floor(10.0 * 0.4342944819032518 * (h0 - h1));
+            const int32_t q = (v > -2147483649.0 && v < 2147483648.0) ? (int32_t)v : INT32_MIN;
+            gq = std::max(std::min(q, maxGQ), minGQ);
+        }
+        a.genotype_qscore = gq;
+    }
+    return gt;
+}
+
 }  // namespace pisces

@@ -27,4 +27,9 @@ int32_t diploid_genotype_qscore(int32_t genotype, int32_t total_coverage, int32_
 int32_t diploid_set_genotypes(std::vector<DiploidAllele>& alleles, const float snv[3], const float indel[3], int32_t min_depth_to_genotype,
                               int32_t min_gq, int32_t max_gq);
 
+// HaploidGenotyper.SetGenotypes (src/lib/Pisces.Genotyping/Haploid/HaploidGenotyper.cs:36-83) with HaploidGenotypeQualityCalculator
+// (:10-59); minor_vf / major_vf are the SNV thresholding parameters (GenotypeCreator.cs:21-22)
+int32_t haploid_set_genotypes(std::vector<DiploidAllele>& alleles, float minor_vf, float major_vf, int32_t min_depth_to_genotype, int32_t min_gq,
+                              int32_t max_gq);
+
 }  // namespace pisces

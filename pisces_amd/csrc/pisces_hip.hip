@@ -290,7 +290,7 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
     if (cfg->tile_loci != 0 && cfg->tile_loci != kTile)
         return fail(nullptr, PISCES_E_UNSUPPORTED, "pisces_hip_create: tile_loci must be 64 in this build");
     if (cfg->strand_bias_model < PISCES_SB_POISSON || cfg->strand_bias_model > PISCES_SB_DIPLOID || cfg->ploidy < PISCES_PLOIDY_SOMATIC ||
-        cfg->ploidy > PISCES_PLOIDY_DIPLOID || cfg->noise_model < PISCES_NOISE_FLAT || cfg->noise_model > PISCES_NOISE_WINDOW)
+        cfg->ploidy > PISCES_PLOIDY_HAPLOID || cfg->noise_model < PISCES_NOISE_FLAT || cfg->noise_model > PISCES_NOISE_WINDOW)
         return fail(nullptr, PISCES_E_INVALID_ARG, "pisces_hip_create: strand_bias_model / ploidy / noise_model out of range");
     if (cfg->block_size <= 0 || cfg->min_base_call_quality < 0 || cfg->min_base_call_quality > 254)
         return fail(nullptr, PISCES_E_INVALID_ARG, "pisces_hip_create: block_size / min_base_call_quality out of range");
@@ -1600,7 +1600,7 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
         h->pending.clear();
         h->pending_cand_index.clear();
         h->pending_cands = span_cands;
-        const bool diploid = h->cfg.ploidy == PISCES_PLOIDY_DIPLOID;
+        const bool diploid = h->cfg.ploidy == PISCES_PLOIDY_DIPLOID || h->cfg.ploidy == PISCES_PLOIDY_HAPLOID;   // per-locus genotypers
         if (span_recs.empty() && !diploid) {
             h->pending = std::move(point_recs);
             h->pending_cand_index.assign(h->pending.size(), -1);
@@ -1644,8 +1644,12 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
                         a.ref_support = rows[k].r->reference_support;
                         at.push_back(std::move(a));
                     }
-                    (void)diploid_set_genotypes(at, h->cfg.diploid_snv_params, h->cfg.diploid_indel_params, h->cfg.min_coverage,
-                                                h->cfg.min_genotype_qscore, h->cfg.max_genotype_qscore);
+                    if (h->cfg.ploidy == PISCES_PLOIDY_HAPLOID)
+                        (void)haploid_set_genotypes(at, h->cfg.diploid_snv_params[0], h->cfg.diploid_snv_params[1], h->cfg.min_coverage,
+                                                    h->cfg.min_genotype_qscore, h->cfg.max_genotype_qscore);
+                    else
+                        (void)diploid_set_genotypes(at, h->cfg.diploid_snv_params, h->cfg.diploid_indel_params, h->cfg.min_coverage,
+                                                    h->cfg.min_genotype_qscore, h->cfg.max_genotype_qscore);
                     for (size_t k = i; k < j; k++) {
                         const DiploidAllele& a = at[k - i];
                         if (a.prune) continue;
@@ -1834,8 +1838,8 @@ int32_t pisces_hip_call_tiles(PiscesHip* h, const uint32_t* d_tuples, const Pisc
         return fail(h, PISCES_E_INVALID_ARG, "call_tiles: null device pointer");
     if ((int64_t)record_capacity < (int64_t)n_tiles * kSlotsPerTile)
         return fail(h, PISCES_E_BUFFER_TOO_SMALL, "call_tiles: the slot layout needs record_capacity >= 256 * n_tiles");
-    if (h->cfg.ploidy == PISCES_PLOIDY_DIPLOID)
-        return fail(h, PISCES_E_STATE, "call_tiles: diploid genotyping is a per-locus pass of pisces_hip_flush (streaming surface)");
+    if (h->cfg.ploidy != PISCES_PLOIDY_SOMATIC)
+        return fail(h, PISCES_E_STATE, "call_tiles: diploid / haploid genotyping is a per-locus pass of pisces_hip_flush (streaming surface)");
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     // events only when asked for (pisces_hip_set_timing): an event record is a queue packet of its own, and two of them

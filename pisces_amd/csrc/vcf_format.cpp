@@ -101,6 +101,9 @@ const char* map_genotype(int gt)   // VcfFormatter.MapGenotype :184-216
     case PISCES_GT_ALT_LIKE_NOCALL: return "./.";
     case PISCES_GT_REF_AND_NOCALL: return "0/.";
     case PISCES_GT_ALT_AND_NOCALL: return "1/.";
+    case PISCES_GT_HEMI_ALT: return "1";
+    case PISCES_GT_HEMI_NOCALL: return ".";
+    case PISCES_GT_HEMI_REF: return "0";
     default: return "./.";
     }
 }
@@ -239,7 +242,8 @@ int64_t pisces_hip_format_vcf_padded(const PiscesVcfConfig* cfg, const char* chr
                 alt_allele += rep;
             }
         }
-        const bool ref_like_gt = gt == PISCES_GT_HOM_REF || gt == PISCES_GT_REF_LIKE_NOCALL || gt == PISCES_GT_REF_AND_NOCALL;
+        const bool ref_like_gt = gt == PISCES_GT_HOM_REF || gt == PISCES_GT_REF_LIKE_NOCALL || gt == PISCES_GT_REF_AND_NOCALL ||
+                                 gt == PISCES_GT_HEMI_NOCALL || gt == PISCES_GT_HEMI_REF;   // VcfFileWriter.cs:236-240
         // MapFilters / MapFilter :136-182 over MergeFilters :423-432: each allele's filters in the order AlleleProcessor.ApplyFilters adds
         // them (src/exe/Pisces/Logic/VariantCalling/AlleleProcessor.cs:25-71), alleles in order, first occurrence kept
         std::string filters;

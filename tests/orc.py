@@ -421,3 +421,18 @@ def diploid_set_genotypes(alleles, snv=(0.20, 0.70, 0.80), indel=(0.20, 0.70, 0.
     prune = (C.c_uint8 * max(n, 1))()
     gt = lib.orc_diploid_set_genotypes(arr, n, (C.c_float * 3)(*snv), (C.c_float * 3)(*indel), min_depth, min_gq, max_gq, phase, prune)
     return gt, [int(prune[i]) for i in range(n)], [(arr[i].genotype, arr[i].genotype_qscore, arr[i].filters, phase[i]) for i in range(n)]
+
+
+lib.orc_haploid_set_genotypes.restype = C.c_int32
+
+
+def haploid_set_genotypes(alleles, minor_vf=0.20, major_vf=0.70, min_depth=100, min_gq=0, max_gq=100):
+    n = len(alleles)
+    arr = (OrcCalled * max(n, 1))()
+    for i, d in enumerate(alleles):
+        arr[i].category = d["category"]
+        arr[i].ref, arr[i].alt = d["ref"].encode(), d["alt"].encode()
+        arr[i].allele_support, arr[i].total_coverage, arr[i].reference_support = d["support"], d["coverage"], d["ref_support"]
+    prune = (C.c_uint8 * max(n, 1))()
+    gt = lib.orc_haploid_set_genotypes(arr, n, C.c_float(minor_vf), C.c_float(major_vf), min_depth, min_gq, max_gq, prune)
+    return gt, [int(prune[i]) for i in range(n)], [(arr[i].genotype, arr[i].genotype_qscore) for i in range(n)]

@@ -835,10 +835,11 @@ def test_window_noise_model_matches_oracle(torch_cuda, call_mnvs):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sb_model", [1, 2])   # Extended, Diploid
-def test_diploid_genotyping_matches_oracle(torch_cuda, sb_model):
+@pytest.mark.parametrize("sb_model,ploidy", [(1, 1), (2, 1), (1, 2)])   # Extended / Diploid strand bias; diploid, diploid, haploid genotyper
+def test_diploid_genotyping_matches_oracle(torch_cuda, sb_model, ploidy):
     """PloidyModel.DiploidByThresholding (one genotype per locus from the variant frequencies, alleles beyond
-    the ploidy pruned, diploid genotype q-scores, MultiAllelicSite / LowGQ filters, phase set index) and the Diploid strand-bias model,
+    the ploidy pruned, diploid genotype q-scores, MultiAllelicSite / LowGQ filters, phase set index), PloidyModel.Haploid (hemizygous
+    calls, its own q-score) and the Diploid strand-bias model,
     on germline-like reads: het and hom SNVs, a het deletion, a tri-allelic site, a 1/2 site, sub-threshold alleles, a shallow stretch.
     Records, allele strings and TotalNumCalled against the oracle."""
     from pisces_amd import engine
@@ -883,13 +884,16 @@ def test_diploid_genotyping_matches_oracle(torch_cuda, sb_model):
     reads.sort(key=lambda r: r["pos"])
     batch = _abi.ReadBatch(reads)
     refa = np.frombuffer(bytes(ref), dtype=np.uint8)
-    cfg = _abi.default_config(ploidy=1, strand_bias_model=sb_model, min_frequency=0.2, variant_freq_filter=0.2, low_gq_filter=30,
+    cfg = _abi.default_config(ploidy=ploidy, strand_bias_model=sb_model, min_frequency=0.2, variant_freq_filter=0.2, low_gq_filter=30,
                               max_genotype_qscore=1000, block_size=2000)
     exp, exp_alleles, _, exp_called = orc.run_reads_full(batch, refa, 1, len(ref), cfg)
     gts = set((exp["info"] & 15).tolist())
-    assert {0, 2, 3, 4}.issubset(gts) and (6 in gts or 1 in gts), gts       # 1/2, 0/1, 1/1, 0/0 and a multi-allelic no-call
-    assert ((exp["filter_bits"] >> 8) & 1).any() and ((exp["filter_bits"] >> 14) == 2).any()
-    assert ((((exp["info"] >> 4) & 7) == _abi.CAT_DELETION)).any()
+    if ploidy == 1:
+        assert {0, 2, 3, 4}.issubset(gts) and (6 in gts or 1 in gts), gts       # 1/2, 0/1, 1/1, 0/0 and a multi-allelic no-call
+        assert ((exp["filter_bits"] >> 8) & 1).any() and ((exp["filter_bits"] >> 14) == 2).any()
+    else:
+        assert gts == {9, 10, 11}, gts                                          # HemizygousRef / Alt / NoCall (HaploidGenotyper)
+    assert ploidy == 2 or ((((exp["info"] >> 4) & 7) == _abi.CAT_DELETION)).any()   # (a het deletion is no hemizygous call)
     with engine.HipVariantCaller(cfg) as c:
         c.SetReference(refa)
         c.AddAlleleCounts(batch)

@@ -590,3 +590,22 @@ def test_diploid_strand_bias_stats():
         for name, got in (("ChanceFalseNeg", fn), ("ChanceFalsePos", fp), ("ChanceVarFreqGreaterThanZero", pv)):
             if name in c:
                 assert abs(got - c[name]) < 0.0005 + 1e-12, (c, name, got)
+
+
+@pytest.mark.parametrize("want,prune,ref_freq,alt_freqs,coverage", [
+    (9, 2, 0.80, [0.01, 0.01], 1000),     # HemizygousRefTest
+    (11, 2, 0.70, [0.01, 0.01], 1000),    # NoCallDueToRefMajorVf
+    (11, 2, 0.22, [0.75, 0.01], 1000),    # NoCallDueToRefMinorVf
+    (11, 2, 0.80, [0.01, 0.01], 10),      # NoCallDueToCoverge
+    (10, 1, 0.10, [0.75, 0.01], 1000),    # HemizygousAlt
+])
+def test_haploid_genotype_scenarios(want, prune, ref_freq, alt_freqs, coverage):
+    """HaploidGenotypeCalculatorTests.cs:59-96 through its harness (:20-57): minor / major VF 0.20 / 0.70, minimum depth 100; genotype
+    codes 9 / 10 / 11 = HemizygousRef / HemizygousAlt / HemizygousNoCall."""
+    sup = int(np.float32(ref_freq) * np.float32(coverage))
+    alleles = [{"category": _abi.CAT_REFERENCE, "ref": "A", "alt": "A", "support": sup, "coverage": coverage, "ref_support": sup}]
+    for vf in alt_freqs:
+        alleles.append({"category": _abi.CAT_SNV, "ref": "A", "alt": "T", "support": int(np.float32(vf) * np.float32(coverage)),
+                        "coverage": coverage, "ref_support": int(float(np.float32(ref_freq)) * coverage)})
+    gt, pr, per = orc.haploid_set_genotypes(alleles)
+    assert gt == want and sum(pr) == prune and all(p[0] == gt for p in per)
