@@ -902,7 +902,7 @@ static int32_t drop_blocks(PiscesHip* h, const std::vector<int32_t>& keys)
 // launches the fused tuples -> histogram -> call kernel on stream s
 // e0 / e1 (optional): HIP events bound to the dispatch itself (hipExtLaunchKernel): their timestamps are the kernel's own
 // start and end, not the arrival of separate marker packets before and after it.
-static void launch_call_tiles(PiscesHip* h, hipStream_t s, const uint32_t* d_tuples, const PiscesTile* d_tiles, int32_t n_tiles,
+static hipError_t launch_call_tiles(PiscesHip* h, hipStream_t s, const uint32_t* d_tuples, const PiscesTile* d_tiles, int32_t n_tiles,
                               const uint8_t* d_ref, int32_t ref_start, int64_t ref_len, PiscesCalledAllele* d_records,
                               PiscesTileResult* d_tr, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
 {
@@ -912,7 +912,9 @@ static void launch_call_tiles(PiscesHip* h, hipStream_t s, const uint32_t* d_tup
         // sums go to HBM (accumulate_tiles_kernel) and the call phase reads them back (call_counts_kernel).  Not the streaming-rate
         // path; the reference's default is NoiseModel.Flat.
         const size_t nc = (size_t)n_tiles * kTile * PISCES_COUNTS_PER_LOCUS;
-        if (h->d_counts.reserve(nc) != hipSuccess || h->d_sumq.reserve(nc) != hipSuccess) return;
+        hipError_t er = h->d_counts.reserve(nc);
+        if (er == hipSuccess) er = h->d_sumq.reserve(nc);
+        if (er != hipSuccess) return er;
         (void)hipMemsetAsync(h->d_counts.p, 0, nc * sizeof(int32_t), s);
         (void)hipMemsetAsync(h->d_sumq.p, 0, nc * sizeof(double), s);
         if (e0) (void)hipEventRecord(e0, s);
@@ -921,7 +923,7 @@ static void launch_call_tiles(PiscesHip* h, hipStream_t s, const uint32_t* d_tup
         hipLaunchKernelGGL(call_counts_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, h->d_counts.p, (const uint32_t*)nullptr, d_tiles, n_tiles,
                            d_ref, ref_start, ref_len, d_records, d_tr, h->P, h->d_sumq.p);
         if (e1) (void)hipEventRecord(e1, s);
-        return;
+        return hipSuccess;
     }
     // (the Diploid strand-bias model is compiled into call_tiles_kernel / call_counts_kernel / call_spanning_kernel only)
     if (h->kernel_variant >= 2 && h->cfg.min_base_call_quality <= 255 && h->cfg.strand_bias_model != PISCES_SB_DIPLOID) {   // the wave forms compare the quality byte in place
@@ -936,10 +938,11 @@ static void launch_call_tiles(PiscesHip* h, hipStream_t s, const uint32_t* d_tup
         else
             hipExtLaunchKernelGGL(call_tiles_wave_kernel<2>, dim3((unsigned)n_tiles), dim3(128), lds, s, e0, e1, 0u, d_tuples, d_tiles,
                                   n_tiles, d_ref, ref_start, ref_len, d_records, d_tr, h->P);
-        return;
+        return hipSuccess;
     }
     hipExtLaunchKernelGGL(call_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), lds, s, e0, e1, 0u, d_tuples, d_tiles, n_tiles, d_ref,
                           ref_start, ref_len, d_records, d_tr, h->P);
+    return hipSuccess;
 }
 
 // scan + gather: d_out = called alleles in (position, allele) order, *d_count = how many
@@ -973,8 +976,8 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
 
     std::vector<uint32_t> g;
     if (!use_counts && !window) {
-        launch_call_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p,
-                          h->d_tile_results.p);
+        PISCES_HIP_CHECK(h, launch_call_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p,
+                                              h->d_tile_results.p));
     } else {
         // counts in HBM + AddGappedMnvRefCount adjustments (CoverageCalculator.cs:82-97)
         const size_t nc = (size_t)n_tiles * kTile * PISCES_COUNTS_PER_LOCUS;
@@ -1852,7 +1855,7 @@ int32_t pisces_hip_call_tiles(PiscesHip* h, const uint32_t* d_tuples, const Pisc
         h->ring_used++;
     }
     if (n_tiles > 0) {
-        launch_call_tiles(h, s, d_tuples, d_tiles, n_tiles, d_ref_bases, ref_start_position, ref_length, d_records, d_tile_results, e0, e1);
+        PISCES_HIP_CHECK(h, launch_call_tiles(h, s, d_tuples, d_tiles, n_tiles, d_ref_bases, ref_start_position, ref_length, d_records, d_tile_results, e0, e1));
     } else if (e0) {
         PISCES_HIP_CHECK(h, hipEventRecord(e0, s));
         PISCES_HIP_CHECK(h, hipEventRecord(e1, s));
