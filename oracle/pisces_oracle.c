@@ -2045,19 +2045,27 @@ int64_t orc_call_candidates(OrcState* s, const OrcCandidate* list, int64_t n_lis
 
 /* The same over RegionState.GetAllCandidates :383-453: every candidate of the state plus (gVCF) a Reference candidate per
  * position with support = the reference base's counts by direction. */
-int64_t orc_call_all(OrcState* s, const uint8_t* ref_bases, int64_t ref_len, const PiscesHipConfig* cfg,
-                     PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out, int64_t* total_num_called)
+int64_t orc_call_range(OrcState* s, const uint8_t* ref_bases, int64_t ref_len, const PiscesHipConfig* cfg, int32_t first_position,
+                       int32_t last_position, PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out, int64_t* total_num_called)
 {
+    /* one batch of the block schedule: the candidates and Reference candidates of [first_position, last_position] (whole blocks),
+     * MaxClearedPosition = last_position (RegionStateManager.cs:283-334).  What the batch pushes past it (MNV leftovers) goes back to
+     * the state and is found by the next range; processed candidates are removed (DoneProcessing). */
     int64_t n = 0, cap = (int64_t)s->n_cands + 64;
     OrcCandidate* list = (OrcCandidate*)malloc(sizeof(OrcCandidate) * (size_t)cap);
-    for (int li = 0; li < s->n_loci; li++)
+    for (int li = 0; li < s->n_loci; li++) {
+        const int position = s->start_position + li;
+        if (position < first_position || position > last_position) continue;
         for (int i = s->cand_head[li]; i >= 0; i = s->cands[i].next) list[n++] = s->cands[i];
+        s->cand_head[li] = s->cand_tail[li] = -1;
+    }
     if (cfg->collapse)   /* AlleleCaller.Call :50-58: candidates = _collapser.Collapse(batch.GetCandidates(), source, MaxClearedPosition) */
         n = orc_collapse(list, (int32_t)n, s, cfg->collapse_freq_threshold, cfg->collapse_freq_ratio_threshold, 0, 1,
                          cfg->expect_stitched_reads, -1, NULL, NULL, NULL);
     if (cfg->include_reference_calls && ref_bases) {
         for (int li = 0; li < s->n_loci; li++) {
             int position = s->start_position + li;
+            if (position < first_position || position > last_position) continue;
             if (position > ref_len) break;
             uint8_t refBase = ref_bases[position - 1];
             int refBaseIndex = allele_type_of(refBase);
@@ -2080,9 +2088,16 @@ int64_t orc_call_all(OrcState* s, const uint8_t* ref_bases, int64_t ref_len, con
             }
         }
     }
-    int64_t r = orc_call_candidates(s, list, n, ref_bases, ref_len, cfg, out, capacity, full_out, total_num_called);
+    int64_t r = orc_call_candidates_max(s, list, n, ref_bases, ref_len, cfg, last_position, out, capacity, full_out, total_num_called);
     free(list);
     return r;
+}
+
+int64_t orc_call_all(OrcState* s, const uint8_t* ref_bases, int64_t ref_len, const PiscesHipConfig* cfg,
+                     PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out, int64_t* total_num_called)
+{
+    return orc_call_range(s, ref_bases, ref_len, cfg, s->start_position, s->start_position + s->n_loci - 1, out, capacity, full_out,
+                          total_num_called);
 }
 
 /* =====================================================================================
@@ -2140,6 +2155,48 @@ int64_t orc_run_reads_full(const PiscesReadBatch* b, const uint8_t* ref_bases, i
     int64_t n = orc_call_all(s, ref_bases, ref_len, cfg, out, capacity, full_out, total_num_called);
     orc_state_destroy(s);
     if (n >= 0 && n_candidate_loci) *n_candidate_loci = count_candidate_loci(out, n);
+    return n;
+}
+
+/* The same with the block schedule: every block of the cfg->block_size grid is its own batch, in order, each with MaxClearedPosition = its
+ * last position, as SmallVariantCaller drives the caller when reads arrive in position order and every block is flushed once the reads
+ * have moved past it.  Differs from the single window only where alleles interact across a block edge (MNV reallocation peels). */
+int64_t orc_run_reads_blocks(const PiscesReadBatch* b, const uint8_t* ref_bases, int64_t ref_len, int32_t region_start, int32_t region_loci,
+                             const PiscesHipConfig* cfg, PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out, int64_t* total_num_called)
+{
+    OrcState* s = orc_state_create(region_start, region_loci, cfg->min_base_call_quality, PISCES_ANCHOR_SIZE, cfg->collapse ? 1 : 0);
+    OrcCandidate cands[256];
+    for (int i = 0; i < b->n_reads; i++) {
+        OrcRead r;
+        r.position = b->position[i];
+        r.n_cigar = b->cigar_offset[i + 1] - b->cigar_offset[i];
+        r.cigar_op = b->cigar_op + b->cigar_offset[i];
+        r.cigar_len = b->cigar_len + b->cigar_offset[i];
+        r.read_len = b->seq_offset[i + 1] - b->seq_offset[i];
+        r.bases = b->bases + b->seq_offset[i];
+        r.quals = b->quals + b->seq_offset[i];
+        r.dirs = b->directions ? b->directions + b->seq_offset[i] : NULL;
+        r.is_reverse = b->flags[i] & 1;
+        r.posmap_override = NULL;
+        int nc = orc_find_candidates(&r, ref_bases, ref_len, cfg->min_base_call_quality, cfg->max_mnv_length, cfg->max_gap_between_mnv,
+                                     cfg->call_mnvs, PISCES_ANCHOR_SIZE, cands, 256);
+        for (int k = 0; k < nc; k++)
+            if (cands[k].position >= region_start && cands[k].position < region_start + region_loci) orc_add_candidate(s, &cands[k]);
+        int rc = orc_add_allele_counts(s, &r);
+        if (rc) { orc_state_destroy(s); return rc; }
+    }
+    const int bs = cfg->block_size;
+    int64_t n = 0, total = 0;
+    const int region_end = region_start + region_loci - 1;
+    for (int first = ((region_start - 1) / bs) * bs + 1; first <= region_end; first += bs) {
+        int64_t t = 0;
+        int64_t k = orc_call_range(s, ref_bases, ref_len, cfg, first, first + bs - 1, out + n, capacity - n, full_out ? full_out + n : NULL, &t);
+        if (k < 0) { orc_state_destroy(s); return k; }
+        n += k;
+        total += t;
+    }
+    if (total_num_called) *total_num_called = total;
+    orc_state_destroy(s);
     return n;
 }
 

@@ -167,6 +167,12 @@ int32_t orc_diploid_set_genotypes(OrcCalled* alleles, int n, const float snv[3],
 /* MnvReallocator.ReallocateFailedMnvs over arrays (test hook; max_position < 0 = null) */
 int64_t orc_reallocate_failed_mnvs(const OrcCalled* failed, int64_t n_failed, OrcCalled* callable, int64_t n_callable, int64_t cap_callable,
                                    int32_t max_position, OrcCalled* outside, int64_t cap_outside, int64_t* n_outside);
+/* one batch of the block schedule over whole blocks [first_position, last_position]; MaxClearedPosition = last_position */
+int64_t orc_call_range(OrcState* s, const uint8_t* ref_bases, int64_t ref_len, const PiscesHipConfig* cfg, int32_t first_position,
+                       int32_t last_position, PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out, int64_t* total_num_called);
+int64_t orc_call_candidates_max(OrcState* s, const OrcCandidate* list, int64_t n_list, const uint8_t* ref_bases, int64_t ref_len,
+                                const PiscesHipConfig* cfg, int32_t max_cleared_position, PiscesCalledAllele* out, int64_t capacity,
+                                OrcCalled* full_out, int64_t* total_num_called);
 int64_t orc_run_reads(const PiscesReadBatch* batch, const uint8_t* ref_bases, int64_t ref_len,
                       int32_t region_start, int32_t region_loci, const PiscesHipConfig* cfg,
                       PiscesCalledAllele* out, int64_t capacity, int64_t* n_candidate_loci);
@@ -174,6 +180,8 @@ int64_t orc_run_reads_full(const PiscesReadBatch* batch, const uint8_t* ref_base
                       int32_t region_start, int32_t region_loci, const PiscesHipConfig* cfg,
                       PiscesCalledAllele* out, int64_t capacity, int64_t* n_candidate_loci,
                       OrcCalled* full_out /* optional: allele strings etc. */, int64_t* total_num_called);
+int64_t orc_run_reads_blocks(const PiscesReadBatch* batch, const uint8_t* ref_bases, int64_t ref_len, int32_t region_start, int32_t region_loci,
+                             const PiscesHipConfig* cfg, PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out, int64_t* total_num_called);
 /* same, from packed observations (position, tuple) instead of reads */
 int64_t orc_run_observations(const int32_t* positions, const uint32_t* tuples, int64_t n_obs,
                       const uint8_t* ref_bases, int64_t ref_len, int32_t region_start, int32_t region_loci,

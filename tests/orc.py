@@ -436,3 +436,17 @@ def haploid_set_genotypes(alleles, minor_vf=0.20, major_vf=0.70, min_depth=100, 
     prune = (C.c_uint8 * max(n, 1))()
     gt = lib.orc_haploid_set_genotypes(arr, n, C.c_float(minor_vf), C.c_float(major_vf), min_depth, min_gq, max_gq, prune)
     return gt, [int(prune[i]) for i in range(n)], [(arr[i].genotype, arr[i].genotype_qscore) for i in range(n)]
+
+
+def run_reads_blocks(batch, ref, region_start, region_loci, cfg):
+    """run_reads_full with the block schedule (one batch per block of the cfg.block_size grid, MaxClearedPosition = its end)."""
+    refa = np.ascontiguousarray(ref, np.uint8)
+    cap = region_loci * 5 + 16
+    out = np.zeros(cap, dtype=_abi.CALLED_ALLELE_DTYPE)
+    full = (OrcCalled * cap)()
+    total = C.c_int64(0)
+    lib.orc_run_reads_blocks.restype = C.c_int64
+    n = lib.orc_run_reads_blocks(C.byref(batch.c), refa.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int64(len(refa)), C.c_int32(region_start),
+                                 C.c_int32(region_loci), C.byref(cfg), C.c_void_p(out.ctypes.data), C.c_int64(cap), full, C.byref(total))
+    assert n >= 0, n
+    return out[:n], [(full[i].ref.decode(), full[i].alt.decode()) for i in range(n)], total.value

@@ -902,3 +902,51 @@ def test_diploid_genotyping_matches_oracle(torch_cuda, sb_model, ploidy):
     assert got_alleles == exp_alleles
     assert_records_match(got, exp)
     assert stats["TotalNumCalled"] == exp_called
+
+
+@pytest.mark.gpu
+def test_mnvs_that_straddle_a_block_edge(torch_cuda):
+    """MnvReallocator's block logic on the device path: failed MNV candidates that reach past the last cleared block are peeled (the part
+    in the next block returns to the state as a candidate of that block, AlleleCaller.cs:91-93), callable ones are called from the
+    block they start in once the schedule has moved past their end (MaxAlleleEndpoint hold).  Low-frequency MNVs of length 3 planted across the
+    1000|1001 and 2000|2001 edges next to SNVs that only become callable with the peeled part; the oracle runs the same block schedule (orc_run_reads_blocks)."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(909)
+    ref = bytearray(rng.choice(list(b"ACGT"), 3000).astype(np.uint8))
+    def mut(p, n):
+        return "".join(chr([b for b in b"ACGT" if b != ref[p - 1 + i]][(i + p) % 3]) for i in range(n))
+    m999, m1998 = mut(999, 3), mut(1999, 3)
+    # fractions of the covering reads: the 1.2 % MNVs fail on their q-score, and so would the 1.2 % SNVs under their last base alone;
+    # together (the reallocated part crosses the block edge as a leftover candidate) they are called
+    planted = [(999, m999, 0.012), (1001, m999[2], 0.012), (1999, m1998, 0.012), (2001, m1998[2], 0.012), (500, mut(500, 3), 0.25),
+               (1040, mut(1040, 2), 0.2)]
+    reads = []
+    for n in range(4000):
+        start = int(rng.integers(900, 1080)) if n % 3 == 0 else int(rng.integers(1900, 2080)) if n % 3 == 1 else int(rng.integers(430, 560))
+        L = 100
+        seq = bytearray(ref[start - 1: start - 1 + L])
+        for (p, alt, frac) in planted:
+            if start <= p and p + len(alt) <= start + L and rng.random() < frac:
+                seq[p - start: p - start + len(alt)] = alt.encode()
+                break
+        reads.append({"pos": start, "cigar": [("M", L)], "seq": bytes(seq).decode(), "quals": [37] * L, "reverse": bool(n % 2)})
+    reads.sort(key=lambda r: r["pos"])
+    batch = _abi.ReadBatch(reads)
+    refa = np.frombuffer(bytes(ref), dtype=np.uint8)
+    cfg = _abi.default_config(call_mnvs=1, collapse=0)
+    exp, exp_alleles, exp_called = orc.run_reads_blocks(batch, refa, 1, len(ref), cfg)
+    called = {(int(r["position"]), a) for r, a in zip(exp, exp_alleles) if a[0] != a[1]}
+    assert (1001, (chr(ref[1000]), m999[2])) in called and (2001, (chr(ref[2000]), m1998[2])) in called   # SNVs that need the leftovers
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(refa)
+        c.AddAlleleCounts(batch)
+        got, got_alleles = [], []
+        for up_to in (1500, 2500, None):
+            r, a = c.CallWithAlleles(upToPosition=up_to)
+            got.append(r)
+            got_alleles += a
+        stats = c.Stats()
+    got = np.concatenate(got)
+    assert got_alleles == exp_alleles
+    assert_records_match(got, exp)
+    assert stats["TotalNumCalled"] == exp_called
