@@ -64,3 +64,9 @@ def test_create_without_gpu_fails_loudly_not_silently():
     rc = _native.lib.pisces_hip_create(C.byref(cfg), 0, C.byref(h))
     assert rc == _abi.E_DEVICE and not h.value
     assert b"HIP device" in _native.lib.pisces_hip_last_error(None)
+
+
+def test_graft_entry_build_succeeds():
+    """The driver's build check: __graft_entry__.build() compiles (or finds up to date) the HIP library and the oracle and imports the package."""
+    import __graft_entry__ as g
+    g.build()
