@@ -23,3 +23,52 @@ def reduce_summary(summary):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(summary, op=dist.ReduceOp.SUM)
     return summary
+
+
+def partition_intervals(intervals, world, block_size=1000, weights=None):
+    """contiguous shards of a sorted, disjoint interval set [(start, end)], inclusive, balanced by
+    sum(interval length x weight) (weight = expected depth; 1 when None).  Cuts fall on the block grid (multiples of block_size), so a
+    1000-locus block is never split between ranks and the block schedule of every shard is the single-GPU one; an interval that
+    straddles a cut is clipped on both sides.  Returns, per rank, (owned_lo, owned_hi, [clipped intervals]); ranks past the work get
+    (0, -1, []).  Concatenating the ranks' calls in rank order is genomic order."""
+    ivs = [(int(a), int(b)) for a, b in intervals]
+    assert all(a <= b for a, b in ivs) and all(x[1] < y[0] for x, y in zip(ivs, ivs[1:])), "intervals must be sorted and disjoint"
+    w = [1.0] * len(ivs) if weights is None else [float(x) for x in weights]
+    # weight per block of the grid
+    blocks = {}
+    for (a, b), wt in zip(ivs, w):
+        k = (a - 1) // block_size
+        while k * block_size + 1 <= b:
+            lo, hi = max(a, k * block_size + 1), min(b, (k + 1) * block_size)
+            blocks[k] = blocks.get(k, 0.0) + (hi - lo + 1) * wt
+            k += 1
+    keys = sorted(blocks)
+    total = sum(blocks.values())
+    out, i, acc = [], 0, 0.0
+    for r in range(world):
+        target = total * (r + 1) / world
+        first = i
+        while i < len(keys) and (acc + blocks[keys[i]] <= target + 1e-9 or i == first) and (len(keys) - i > world - 1 - r):
+            acc += blocks[keys[i]]
+            i += 1
+        if r == world - 1:
+            while i < len(keys):
+                acc += blocks[keys[i]]
+                i += 1
+        if first == i:
+            out.append((0, -1, []))
+            continue
+        lo, hi = keys[first] * block_size + 1, (keys[i - 1] + 1) * block_size
+        out.append((lo, hi, [(max(a, lo), min(b, hi)) for a, b in ivs if b >= lo and a <= hi]))
+    return out
+
+
+def reads_for_shard(read_starts, read_ends, owned_lo, owned_hi, halo):
+    """Indices of the reads a shard needs: every read overlapping [owned_lo - halo, owned_hi + halo] (halo = longest read span +
+    longest variant span; reads near a cut go to both sides, no inter-GPU exchange).  A read is COUNTED (Totals line) by the shard that
+    owns its start."""
+    import numpy as np
+    s, e = np.asarray(read_starts), np.asarray(read_ends)
+    need = (e >= owned_lo - halo) & (s <= owned_hi + halo)
+    owner = (s >= owned_lo) & (s <= owned_hi)
+    return np.nonzero(need)[0], owner[need]

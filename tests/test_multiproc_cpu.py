@@ -73,3 +73,51 @@ def test_tile_range_partition_properties():
             assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
             sizes = [b - a for a, b in ranges]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_interval_partition_is_block_aligned_balanced_and_complete():
+    ivs = [(150, 420), (980, 1310), (2500, 2790), (5001, 5600), (9100, 9200), (12000, 14050)]
+    for world in (1, 2, 3, 4, 8):
+        parts = shard.partition_intervals(ivs, world)
+        assert len(parts) == world
+        owned = [p for p in parts if p[1] >= p[0]]
+        assert all(lo % 1000 == 1 and hi % 1000 == 0 for lo, hi, _ in owned)               # cuts on the block grid
+        assert all(a[1] < b[0] for a, b in zip(owned, owned[1:]))                           # contiguous, ordered, disjoint
+        covered = sorted(iv for _, _, clipped in owned for iv in clipped)
+        loci = lambda L: sum(b - a + 1 for a, b in L)
+        assert loci(covered) == loci(ivs) and covered[0][0] == ivs[0][0] and covered[-1][1] == ivs[-1][1]
+        if world <= 4:
+            sizes = [loci(c) for _, _, c in owned]
+            assert max(sizes) <= 2 * (loci(ivs) / len(owned)) + 1000                          # within a block of balance
+    heavy = shard.partition_intervals([(1, 1000), (1001, 2000), (2001, 3000)], 2, weights=[10, 1, 1])
+    assert heavy[0][1] == 1000 and heavy[1][0] == 1001                                       # depth-weighted: the deep block stands alone
+
+
+def test_shards_with_halo_reads_reproduce_the_single_run():
+    """SURVEY 8e end to end on the CPU: reads near a cut are handed to both shards, each shard calls only the loci it owns, and the
+    rank-order concatenation is the unsharded result; every read is counted once (by the shard that owns its start)."""
+    from tests import orc
+    rng = np.random.default_rng(12)
+    ref = rng.choice(list(b"ACGT"), 4000).astype(np.uint8)
+    reads = []
+    for i in range(6000):
+        start = int(rng.integers(1, 3850))
+        seq = ref[start - 1: start - 1 + 120].copy()
+        for k in range(120):
+            if rng.random() < 0.01:
+                seq[k] = rng.choice(list(b"ACGT"))
+        reads.append({"pos": start, "cigar": [("M", 120)], "seq": bytes(seq).decode(), "quals": [37] * 120, "reverse": bool(i % 2)})
+    reads.sort(key=lambda r: r["pos"])
+    cfg = _abi.default_config()
+    whole, _ = orc.run_reads(_abi.ReadBatch(reads), ref, 1, 4000, cfg)
+    starts = np.array([r["pos"] for r in reads])
+    ends = starts + 119
+    parts = shard.partition_intervals([(1, 4000)], 3)
+    got, counted = [], 0
+    for lo, hi, clipped in parts:
+        idx, owner = shard.reads_for_shard(starts, ends, lo, hi, halo=130)
+        counted += int(owner.sum())
+        recs, _ = orc.run_reads(_abi.ReadBatch([reads[i] for i in idx]), ref, lo, hi - lo + 1, cfg)
+        got.append(recs)
+    assert counted == len(reads)
+    assert np.concatenate(got).tobytes() == whole.tobytes()
