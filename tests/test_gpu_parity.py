@@ -950,3 +950,28 @@ def test_mnvs_that_straddle_a_block_edge(torch_cuda):
     assert got_alleles == exp_alleles
     assert_records_match(got, exp)
     assert stats["TotalNumCalled"] == exp_called
+
+
+@pytest.mark.gpu
+def test_mnv_mode_on_an_snv_only_pileup_equals_the_count_derived_calls(torch_cuda):
+    """With -callmnvs on an SNV-only amplicon pileup (BASELINE config 2 style, 12 000 loci x 300x) the candidates come from the read walk
+    instead of the allele counts, go through MNV-first processing / reallocation of the (failing) error MNVs and the candidate kernel:
+    the result must equal the oracle's, and the called variants those of the default mode."""
+    from pisces_amd import engine, synth
+    p = synth.make_pileup(12000, 300, seed=11)
+    ref = p.ref.cpu().numpy()
+    batch = synth.reads_of(p)
+    out = {}
+    for mnv in (0, 1):
+        cfg = _abi.default_config(call_mnvs=mnv)
+        exp, exp_alleles, _, exp_called = orc.run_reads_full(batch, ref, p.region_start, p.n_loci, cfg)
+        with engine.HipVariantCaller(cfg) as c:
+            c.SetReference(ref)
+            c.AddAlleleCounts(batch)
+            got, got_alleles = c.CallWithAlleles()
+            stats = c.Stats()
+        assert got_alleles == exp_alleles
+        assert_records_match(got, exp)
+        assert stats["TotalNumCalled"] == exp_called
+        out[mnv] = [(int(r["position"]), a) for r, a in zip(got, got_alleles) if a[0] != a[1]]
+    assert len(out[0]) >= 100 and set(out[0]) <= set(out[1]) | set(out[0])
