@@ -15,6 +15,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -623,12 +624,47 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
         ub += ref_span;
     }
     slots[(size_t)nr] = (long long)(h->log_ub + ub);
+    // With MNV calling on every base of every read is compared with the reference on the host (the SNV / MNV walk): large batches
+    // are walked by a few worker threads, chunk by chunk; the candidates are then added in read order, as the serial loop would
+    std::vector<std::vector<HostCandidate>> pre_found;   // per chunk, in read order, each candidate tagged with its read index below
+    std::vector<std::vector<int32_t>> pre_read;
+    const bool parallel_walk = h->cfg.call_mnvs != 0 && !h->h_ref.empty() && nr >= 4096;
+    int32_t chunk = nr;
+    if (parallel_walk) {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const int n_threads = (int)std::min<unsigned>(8u, hw);
+        chunk = (nr + n_threads - 1) / n_threads;
+        pre_found.resize((size_t)n_threads);
+        pre_read.resize((size_t)n_threads);
+        std::vector<std::thread> workers;
+        for (int t = 0; t < n_threads; t++)
+            workers.emplace_back([&, t]() {
+                std::vector<HostCandidate> local;
+                const int32_t lo = t * chunk, hi = std::min(nr, lo + chunk);
+                for (int32_t i = lo; i < hi; i++) {
+                    local.clear();
+                    find_candidates(read_view(batch, i), h->h_ref.data(), h->ref_len, minBQ, PISCES_ANCHOR_SIZE, true, true, h->cfg.max_mnv_length,
+                                    h->cfg.max_gap_between_mnv, local);
+                    for (auto& c : local) { pre_found[(size_t)t].push_back(std::move(c)); pre_read[(size_t)t].push_back(i); }
+                }
+            });
+        for (auto& w : workers) w.join();
+    }
+    std::vector<size_t> pre_cursor(pre_found.size(), 0);
     for (int32_t i = 0; i < nr; i++) {
         ReadView r = read_view(batch, i);
+        if (parallel_walk) {
+            const size_t t = (size_t)(i / chunk);
+            size_t& k = pre_cursor[t];
+            while (k < pre_found[t].size() && pre_read[t][k] == i) {
+                if (pre_found[t][k].position > 0) add_candidate(h, pre_found[t][k]);
+                k++;
+            }
+        }
         // ICandidateVariantFinder.FindCandidates + IStateManager.AddCandidates (SmallVariantCaller.cs:92-96) for the
         // candidates the device counts do not imply: insertions and deletions
-        bool walk = h->cfg.call_mnvs != 0;   // MNV calling: SNV / MNV candidates come from the M operations too
-        for (int c = 0; c < r.n_cigar && !walk; c++) walk = (r.cigar_op[c] == 'I' || r.cigar_op[c] == 'D');
+        bool walk = h->cfg.call_mnvs != 0 && !parallel_walk;   // MNV calling: SNV / MNV candidates come from the M operations too
+        for (int c = 0; c < r.n_cigar && !walk && !parallel_walk; c++) walk = (r.cigar_op[c] == 'I' || r.cigar_op[c] == 'D');
         if (walk && !h->h_ref.empty()) {   // without a reference only the IStateManager half (allele counts) runs
             found.clear();
             find_candidates(r, h->h_ref.data(), h->ref_len, minBQ, PISCES_ANCHOR_SIZE, h->cfg.call_mnvs != 0, h->cfg.call_mnvs != 0,
