@@ -35,7 +35,7 @@ BASE_SEED = 20260928
 TIME_EVERY = 1          # dispatch-bound HIP events on every launch of the timed region: costs ~5 us per step in `value`, but the
                         # durations then are those rocprofv3 reports for the same command (sampling every 4th launch times kernels that
                         # start the instant their predecessor ends: 54.6 us against rocprofv3's 52.7 us, profiles/r01_rocprofv3_summary.md)
-PIPELINE_STREAMS = 3    # the extra 'pipelined' figure: steps issued round-robin over this many HIP streams
+PIPELINE_STREAMS = 3    # the extra 'pipelined' figure: pisces_hip_call_tiles_batched spreads the steps over its 3 lanes
 
 
 def algorithmic_bytes(n_obs, n_loci, n_records):
@@ -181,34 +181,37 @@ def main():
     total_records, total_loci = int(summary[0].item()), int(summary[1].item())
     value = total_loci / elapsed
 
-    # ---- extra figure, outside the timed region: the same K steps issued round-robin over PIPELINE_STREAMS HIP streams (own output
-    # buffers).  Batches are independent, so the call phase at the end of one launch overlaps the streaming phase of the next, which a
+    # ---- extra figure, outside the timed region: the same K steps handed to pisces_hip_call_tiles_batched in one call (own output
+    # buffers per lane).  Batches are independent, so the call phase at the end of one launch overlaps the streaming phase of the next, which a
     # single in-order stream forbids; this is how a host with several blocks in flight drives the library.
     pipelined_elapsed = None
     if not args.no_pipelined:
-        p_streams = [torch.cuda.Stream(dev) for _ in range(PIPELINE_STREAMS)]
+        # pisces_hip_call_tiles_batched spreads the launches over the handle's own HIP streams ("lanes"); every batch in flight needs its
+        # own output buffers
         p_records = [records] + [torch.zeros_like(records) for _ in range(PIPELINE_STREAMS - 1)]
         p_results = [tile_results] + [torch.zeros_like(tile_results) for _ in range(PIPELINE_STREAMS - 1)]
 
-        def pstep(i):
-            p, k = ring[i % RING_BATCHES], i % PIPELINE_STREAMS
-            caller.call_tiles(p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), 1, p.ref_len,
-                              p_records[k].data_ptr(), cap, p_results[k].data_ptr(), p_streams[k].cuda_stream)
+        def pbatches(first, n):
+            out = []
+            for i in range(first, first + n):
+                p, k = ring[i % RING_BATCHES], i % PIPELINE_STREAMS
+                out.append((p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), 1, p.ref_len, p_records[k].data_ptr(), cap,
+                            p_results[k].data_ptr()))
+            return out
 
-        for i in range(2 * PIPELINE_STREAMS):
-            pstep(i)
-        torch.cuda.synchronize(dev)
+        caller.call_tiles_batched(pbatches(0, 2 * PIPELINE_STREAMS))
+        caller.synchronize()
+        todo = pbatches(0, args.steps)
         barrier()
         tp0 = time.perf_counter()
-        for i in range(args.steps):
-            pstep(i)
-        torch.cuda.synchronize(dev)
+        caller.call_tiles_batched(todo)     # the same K steps, one call; complete after synchronize()
+        caller.synchronize()
         barrier()
         tp = torch.tensor([time.perf_counter() - tp0], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tp, op=dist.ReduceOp.MAX)
         pipelined_elapsed = float(tp.item())
-        for k in range(1, PIPELINE_STREAMS):   # every stream's last output equals a serial launch's (same batch -> same records)
+        for k in range(1, PIPELINE_STREAMS):   # every lane's last output equals a serial launch's (same batch -> same records)
             trk = p_results[k].cpu().numpy().view(_abi.TILE_RESULT_DTYPE)
             assert int(trk["n_candidate_loci"].sum()) == args.loci
     if rank == 0:

@@ -90,6 +90,9 @@ namespace Pisces.Hip
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_get_candidates(IntPtr handle, int upToPosition, [Out] PiscesCandidate[] cands, long capacity, out long nOut, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern long pisces_hip_find_indel_candidates(ref PiscesReadBatch batch, byte[] reference, long refLen, int minBaseCallQuality, [Out] PiscesCandidate[] cands, long capacity, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern long pisces_hip_find_candidates(ref PiscesReadBatch batch, byte[] reference, long refLen, int minBaseCallQuality, int snvsAndMnvs, int callMnvs, int maxMnvLength, int maxGapBetweenMnv, [Out] PiscesCandidate[] cands, long capacity, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
+        [StructLayout(LayoutKind.Sequential)]
+        public struct PiscesTileBatch { public IntPtr DTuples, DTiles; public int NTiles, RefStartPosition; public IntPtr DRefBases; public long RefLength; public IntPtr DRecords, DTileResults; public int RecordCapacity, Pad; }
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_call_tiles_batched(IntPtr handle, PiscesTileBatch[] batches, int nBatches, IntPtr stream);
         // device-resident surface (raw device pointers + hipStream_t as IntPtr)
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_call_tiles(IntPtr handle, IntPtr dTuples, IntPtr dTiles, int nTiles, IntPtr dRefBases, int refStartPosition, long refLength, IntPtr dRecords, int recordCapacity, IntPtr dTileResults, IntPtr stream);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_compact_records(IntPtr handle, IntPtr dRecords, IntPtr dTileResults, int nTiles, IntPtr dOffsets, IntPtr dOut, int outCapacity, IntPtr dCount, IntPtr stream);

@@ -296,6 +296,27 @@ int32_t pisces_hip_call_tiles(PiscesHip* h, const uint32_t* d_tuples, const Pisc
                               int32_t n_tiles, const uint8_t* d_ref_bases, int32_t ref_start_position,
                               int64_t ref_length, PiscesCalledAllele* d_records, int32_t record_capacity,
                               PiscesTileResult* d_tile_results, void* stream);
+/* Several independent batches at once: the launches are spread over the handle's own HIP streams ("lanes"), so that the call phase
+ * that ends one launch runs under the streaming phase of the next (at BASELINE config 2 a step takes ~37 us this way instead of ~52 us
+ * one after the other).  Every batch in flight needs its own d_records / d_tile_results.  Ordering is on the host: the call first
+ * waits for `stream` (NULL = nothing to wait for: the inputs are ready), returns once everything is enqueued, and the outputs are
+ * complete after pisces_hip_synchronize (a lane that has waited on another stream's event runs its later kernels ~5 us slower on
+ * this runtime, so no event fork / join).  The process should run with GPU_MAX_HW_QUEUES >= 8 so that each lane owns a hardware
+ * queue. */
+typedef struct PiscesTileBatch {
+    const uint32_t*     d_tuples;
+    const PiscesTile*   d_tiles;
+    int32_t             n_tiles;
+    int32_t             ref_start_position;
+    const uint8_t*      d_ref_bases;
+    int64_t             ref_length;
+    PiscesCalledAllele* d_records;
+    PiscesTileResult*   d_tile_results;
+    int32_t             record_capacity;
+    int32_t             pad;
+} PiscesTileBatch;
+int32_t pisces_hip_call_tiles_batched(PiscesHip* h, const PiscesTileBatch* batches, int32_t n_batches, void* stream);
+
 /* Ordered compaction of a call_tiles result: d_out[0 .. *d_count) receives every called allele of the launch
  * sorted by (position, ref, alt) (tiles must be in ascending position order); d_offsets[n_tiles] (int32 scratch)
  * receives each tile's first index in d_out. Asynchronous. */

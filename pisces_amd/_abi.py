@@ -95,6 +95,12 @@ class PiscesHipConfig(C.Structure):
     ]
 
 
+class PiscesTileBatch(C.Structure):
+    _fields_ = [("d_tuples", C.c_void_p), ("d_tiles", C.c_void_p), ("n_tiles", C.c_int32), ("ref_start_position", C.c_int32),
+                ("d_ref_bases", C.c_void_p), ("ref_length", C.c_int64), ("d_records", C.c_void_p), ("d_tile_results", C.c_void_p),
+                ("record_capacity", C.c_int32), ("pad", C.c_int32)]
+
+
 class PiscesVcfConfig(C.Structure):
     _fields_ = [("variant_quality_filter", C.c_int32), ("rmxn_max_repeat_length", C.c_int32), ("rmxn_min_repetitions", C.c_int32),
                 ("noise_level", C.c_int32), ("output_strand_bias_and_noise_level", C.c_int32), ("output_no_call_fraction", C.c_int32),

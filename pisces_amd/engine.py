@@ -175,6 +175,16 @@ class HipVariantCaller:
         _check(self._h, lib.pisces_hip_call_tiles(self._h, d_tuples, d_tiles, n_tiles, d_ref, ref_start, ref_len,
                                                   d_records, capacity, d_tile_results, stream))
 
+    def call_tiles_batched(self, batches, stream=None):
+        """pisces_hip_call_tiles_batched: batches = list of (d_tuples, d_tiles, n_tiles, d_ref, ref_start, ref_len, d_records, capacity,
+        d_tile_results) with per-batch output buffers; spread over the handle's lanes.  Waits for `stream` first when given; the outputs
+        are complete after synchronize()."""
+        arr = (_abi.PiscesTileBatch * max(len(batches), 1))()
+        for i, (tu, ti, n, rf, rs, rl, rec, cap, tr) in enumerate(batches):
+            arr[i].d_tuples, arr[i].d_tiles, arr[i].n_tiles, arr[i].ref_start_position = tu, ti, n, rs
+            arr[i].d_ref_bases, arr[i].ref_length, arr[i].d_records, arr[i].d_tile_results, arr[i].record_capacity = rf, rl, rec, tr, cap
+        _check(self._h, lib.pisces_hip_call_tiles_batched(self._h, arr, len(batches), stream))
+
     def compact_records(self, d_records, d_tile_results, n_tiles, d_offsets, d_out, out_capacity, d_count, stream=None):
         _check(self._h, lib.pisces_hip_compact_records(self._h, d_records, d_tile_results, n_tiles, d_offsets, d_out,
                                                        out_capacity, d_count, stream))

@@ -975,3 +975,40 @@ def test_mnv_mode_on_an_snv_only_pileup_equals_the_count_derived_calls(torch_cud
         assert stats["TotalNumCalled"] == exp_called
         out[mnv] = [(int(r["position"]), a) for r, a in zip(got, got_alleles) if a[0] != a[1]]
     assert len(out[0]) >= 100 and set(out[0]) <= set(out[1]) | set(out[0])
+
+
+@pytest.mark.gpu
+def test_batched_launches_equal_single_launches(torch_cuda):
+    """pisces_hip_call_tiles_batched (independent batches spread over the handle's HIP streams) gives every batch exactly the records of its
+    own pisces_hip_call_tiles launch, whatever runs beside it; argument errors come back before anything is launched."""
+    import torch
+    from pisces_amd import engine, synth
+    dev = torch.device("cuda", 0)
+    ps = [synth.make_pileup(3000 + 640 * i, 60 + 25 * i, seed=40 + i, device=dev) for i in range(5)]
+    with engine.HipVariantCaller(_abi.default_config()) as c:
+        outs, single = [], []
+        for p in ps:
+            cap = p.n_tiles * _abi.SLOTS_PER_TILE
+            rec = torch.zeros(cap * 64, dtype=torch.uint8, device=dev)
+            tr = torch.zeros(p.n_tiles * _abi.TILE_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            c.call_tiles(p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), 1, p.ref_len, rec.data_ptr(), cap, tr.data_ptr())
+            torch.cuda.synchronize()
+            trn = tr.cpu().numpy().view(_abi.TILE_RESULT_DTYPE)
+            single.append(_abi.records_in_order(rec.cpu().numpy().view(_abi.CALLED_ALLELE_DTYPE), trn).copy())
+            outs.append((torch.zeros_like(rec), torch.zeros_like(tr), cap))
+        batches = [(p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), 1, p.ref_len, o[0].data_ptr(), o[2], o[1].data_ptr())
+                   for p, o in zip(ps, outs)]
+        for _ in range(3):
+            c.call_tiles_batched(batches)
+        c.synchronize()
+        torch.cuda.synchronize()
+        for o, want in zip(outs, single):
+            trn = o[1].cpu().numpy().view(_abi.TILE_RESULT_DTYPE)
+            got = _abi.records_in_order(o[0].cpu().numpy().view(_abi.CALLED_ALLELE_DTYPE), trn)
+            assert got.tobytes() == want.tobytes()
+        bad = list(batches)
+        bad[2] = bad[2][:7] + (10,) + bad[2][8:]          # record capacity below 256 slots per tile
+        with pytest.raises(engine.PiscesHipError) as e:
+            c.call_tiles_batched(bad)
+        assert e.value.code == _abi.E_BUFFER_TOO_SMALL
+        c.call_tiles_batched([])
