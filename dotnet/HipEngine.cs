@@ -1,0 +1,228 @@
+// HipEngine.cs — the managed half of the drop-in: one native handle per (BAM, chromosome) job, the read staging buffers, the option ->
+// PiscesHipConfig mapping and the record -> CalledAllele conversion.  Source only: this image has no dotnet toolchain (INTEGRATION.md).
+// It is written against the reference's types (Pisces.Domain / Pisces.Interfaces, v5.2.11) and include/pisces_hip.h (ABI 4).
+using System;
+using System.Collections.Generic;
+using System.Runtime.InteropServices;
+using System.Text;
+using Pisces.Domain.Models;
+using Pisces.Domain.Models.Alleles;
+using Pisces.Domain.Options;
+using Pisces.Domain.Types;
+
+namespace Pisces.Hip
+{
+    internal sealed class HipBatch : Pisces.Interfaces.ICandidateBatch
+    {
+        public readonly int? UpToPosition;
+        public HipBatch(int? upTo) { UpToPosition = upTo; }
+        public bool HasCandidates { get { return true; } }                       // the native flush decides (block rule of RegionStateManager.cs:283-334)
+        public int? MaxClearedPosition { get; set; }
+        public List<Region> ClearedRegions { get; set; }
+        public List<CandidateAllele> GetCandidates() { return new List<CandidateAllele>(); }
+        public void Add(CandidateAllele candidate) { }
+        public void Add(IEnumerable<CandidateAllele> candidates) { }
+    }
+
+    public sealed class HipEngine : IDisposable
+    {
+        private IntPtr _h;
+        private readonly PiscesHipConfig _cfg;
+        private bool _referenceSet;
+        // staged reads (SoA, grown geometrically; handed to pisces_hip_add_reads when the caller asks for candidates)
+        private readonly List<int> _pos = new List<int>(), _cigOff = new List<int> { 0 }, _seqOff = new List<int> { 0 };
+        private readonly List<byte> _flags = new List<byte>(), _cigOp = new List<byte>(), _bases = new List<byte>(), _quals = new List<byte>(), _dirs = new List<byte>();
+        private readonly List<uint> _cigLen = new List<uint>();
+        private bool _anyStitched;
+        // BlocksPerFlush > 1 holds the native flush back until upTo has moved that many blocks on: records come out later, in the same
+        // order (the VCF writer does not care), and the per-flush latency (~0.26 ms) is paid once per group (DESIGN.md section 8)
+        public int BlocksPerFlush = 1;
+        private int _lastFlushedBlock = -1;
+
+        public bool ExpectStitchedReads { get { return _cfg.ExpectStitchedReads != 0; } }
+
+        /// Factory.CreateVariantCaller's VariantCallerConfig (Factory.cs:149-179) + the state-manager / finder settings (:123,209-227)
+        public static PiscesHipConfig ConfigFrom(PiscesApplicationOptions o, bool expectStitchedReads, bool hasIntervals)
+        {
+            PiscesHipConfig c;
+            NativeMethods.Check(IntPtr.Zero, NativeMethods.pisces_hip_default_config(out c));
+            var v = o.VariantCallingParameters;
+            c.MinBaseCallQuality = o.BamFilterParameters.MinimumBaseCallQuality;
+            c.NoiseLevel = v.NoiseLevelUsedForQScoring;
+            c.MaxVariantQscore = v.MaximumVariantQScore; c.MinVariantQscore = v.MinimumVariantQScore; c.VariantQscoreFilter = v.MinimumVariantQScoreFilter;
+            c.MinCoverage = v.MinimumCoverage; c.LowDepthFilter = v.LowDepthFilter ?? -1;
+            c.MinGenotypeQscore = v.MinimumGenotypeQScore; c.MaxGenotypeQscore = v.MaximumGenotypeQScore; c.LowGqFilter = v.LowGenotypeQualityFilter ?? -1;
+            c.StrandBiasModel = v.StrandBiasModel == StrandBiasModel.Poisson ? 0 : v.StrandBiasModel == StrandBiasModel.Extended ? 1 : 2;
+            c.StrandBiasThreshold = v.StrandBiasAcceptanceCriteria; c.FilterSingleStrand = v.FilterOutVariantsPresentOnlyOneStrand ? 1 : 0;
+            c.IncludeReferenceCalls = o.VcfWritingParameters.OutputGvcfFile ? 1 : 0;
+            c.EmitZeroCoverageRefs = hasIntervals ? 1 : 0;                         // RegionState.cs:446
+            c.ExpectStitchedReads = expectStitchedReads ? 1 : 0;
+            c.NoCallFilterThreshold = v.NoCallFilterThreshold; c.TargetLodFrequency = v.TargetLODFrequency;
+            c.RmxnMaxRepeatLength = v.RMxNFilterMaxLengthRepeat ?? -1; c.RmxnMinRepetitions = v.RMxNFilterMinRepetitions ?? -1; c.RmxnFrequencyLimit = v.RMxNFilterFrequencyLimit;
+            c.Collapse = o.Collapse ? 1 : 0; c.CollapseFreqThreshold = o.CollapseFreqThreshold; c.CollapseFreqRatioThreshold = o.CollapseFreqRatioThreshold;
+            c.CallMnvs = o.CallMNVs ? 1 : 0; c.MaxMnvLength = o.MaxSizeMNV; c.MaxGapBetweenMnv = o.MaxGapBetweenMNV;
+            c.NoiseModel = v.NoiseModel == NoiseModel.Window ? 1 : 0;
+            c.Ploidy = v.PloidyModel == PloidyModel.DiploidByThresholding ? 1 : v.PloidyModel == PloidyModel.Haploid ? 2 : 0;
+            var snv = v.DiploidSNVThresholdingParameters; var indel = v.DiploidINDELThresholdingParameters;
+            c.DiploidSnvMinorVF = snv.MinorVF; c.DiploidSnvMajorVF = snv.MajorVF; c.DiploidSnvSumVF = snv.SumVFforMultiAllelicSite;
+            c.DiploidIndelMinorVF = indel.MinorVF; c.DiploidIndelMajorVF = indel.MajorVF; c.DiploidIndelSumVF = indel.SumVFforMultiAllelicSite;
+            // MinFrequency / VariantFreqFilter come from the genotyper (Factory.cs:160,167; IGenotypeCalculator.MinVarFrequency[Filter])
+            float minVarFrequency = c.Ploidy == 0 ? v.MinimumFrequency : snv.MinorVF;
+            c.MinFrequency = minVarFrequency;
+            c.VariantFreqFilter = Math.Max(v.MinimumFrequencyFilter, minVarFrequency);   // SetMinFreqFilter
+            c.GenotypeMinFreqFilter = c.VariantFreqFilter;
+            return c;
+        }
+
+        public HipEngine(PiscesHipConfig cfg, int device)
+        {
+            _cfg = cfg;
+            var c = cfg;
+            NativeMethods.Check(IntPtr.Zero, NativeMethods.pisces_hip_create(ref c, device, out _h));
+        }
+
+        public void SetIntervals(ChrIntervalSet set)
+        {
+            var s = new int[set.Intervals.Count]; var e = new int[set.Intervals.Count];
+            for (int i = 0; i < s.Length; i++) { s[i] = set.Intervals[i].StartPosition; e[i] = set.Intervals[i].EndPosition; }
+            NativeMethods.Check(_h, NativeMethods.pisces_hip_set_intervals(_h, s, e, s.Length));
+        }
+
+        /// IStateManager.AddAlleleCounts: copy the read out (the Read object is reused by the source, AlignmentsSource.cs:21,61)
+        public void StageRead(Read read)
+        {
+            _pos.Add(read.Position);
+            _flags.Add((byte)(read.BamAlignment.IsReverseStrand() ? 1 : 0));
+            foreach (var op in read.CigarData) { _cigOp.Add((byte)op.Type); _cigLen.Add(op.Length); }
+            _cigOff.Add(_cigOp.Count);
+            _bases.AddRange(Encoding.ASCII.GetBytes(read.Sequence));
+            _quals.AddRange(read.Qualities);
+            var map = read.SequencedBaseDirectionMap;                               // per-base DirectionType (stitched reads: XD tag)
+            for (int i = 0; i < map.Length; i++) { _dirs.Add((byte)map[i]); _anyStitched |= map[i] == DirectionType.Stitched; }
+            _seqOff.Add(_bases.Count);
+        }
+
+        /// with MNV calling off the library finds every candidate itself; nothing of the managed finder's output is needed
+        public void KeepNonSnvCandidates(IEnumerable<CandidateAllele> candidates) { }
+
+        public unsafe void FlushStagedReads(ChrReference chrReference)
+        {
+            if (!_referenceSet && chrReference != null)
+            {
+                var bytes = Encoding.ASCII.GetBytes(chrReference.Sequence);         // upper case already (Genome.cs:84-96)
+                NativeMethods.Check(_h, NativeMethods.pisces_hip_set_reference(_h, bytes, bytes.LongLength));
+                _referenceSet = true;
+            }
+            if (_pos.Count == 0) return;
+            int[] pos = _pos.ToArray(), cigOff = _cigOff.ToArray(), seqOff = _seqOff.ToArray();
+            byte[] flags = _flags.ToArray(), cigOp = _cigOp.ToArray(), bases = _bases.ToArray(), quals = _quals.ToArray(), dirs = _dirs.ToArray();
+            uint[] cigLen = _cigLen.ToArray();
+            fixed (int* pPos = pos, pCo = cigOff, pSo = seqOff)
+            fixed (byte* pF = flags, pOp = cigOp, pB = bases, pQ = quals, pD = dirs)
+            fixed (uint* pLen = cigLen)
+            {
+                var b = new PiscesReadBatch { NReads = pos.Length, Position = pPos, Flags = pF, CigarOffset = pCo, CigarOp = pOp, CigarLen = pLen,
+                                              SeqOffset = pSo, Bases = pB, Quals = pQ, Directions = _anyStitched ? pD : null };
+                NativeMethods.Check(_h, NativeMethods.pisces_hip_add_reads(_h, ref b));
+            }
+            _pos.Clear(); _flags.Clear(); _cigOp.Clear(); _cigLen.Clear(); _bases.Clear(); _quals.Clear(); _dirs.Clear();
+            _cigOff.Clear(); _cigOff.Add(0); _seqOff.Clear(); _seqOff.Add(0); _anyStitched = false;
+        }
+
+        /// IAlleleCaller.Call: pisces_hip_flush_ex, growing the buffers on PISCES_E_BUFFER_TOO_SMALL (the batch stays intact until it fits)
+        public SortedList<int, List<CalledAllele>> Flush(int? upToPosition, ChrReference chr)
+        {
+            var result = new SortedList<int, List<CalledAllele>>();
+            int upTo = upToPosition ?? -1;
+            if (upToPosition.HasValue && BlocksPerFlush > 1)
+            {
+                int block = (upTo - 1) / _cfg.BlockSize;
+                if (block < _lastFlushedBlock + BlocksPerFlush) return result;
+                _lastFlushedBlock = block;
+            }
+            var recs = new PiscesCalledAllele[1 << 14]; var idx = new int[recs.Length];
+            var cands = new PiscesCandidate[1 << 10]; var pool = new byte[1 << 16];
+            long n, nc, nb; int rc;
+            while ((rc = NativeMethods.pisces_hip_flush_ex(_h, upTo, recs, recs.LongLength, out n, idx, cands, cands.LongLength, out nc, pool, pool.LongLength, out nb)) == -2)
+            {
+                if (n > recs.LongLength) { recs = new PiscesCalledAllele[n + n / 2]; idx = new int[recs.Length]; }
+                if (nc > cands.LongLength) cands = new PiscesCandidate[nc + nc / 2];
+                if (nb > pool.LongLength) pool = new byte[nb + nb / 2];
+            }
+            NativeMethods.Check(_h, rc);
+            const string baseOf = "AGCTND";
+            for (long i = 0; i < n; i++)
+            {
+                var r = recs[i];
+                var category = (AlleleCategory)((r.Info >> 4) & 7);   // the native codes follow Pisces.Domain.Types.AlleleCategory
+                string refAllele, altAllele;
+                if (idx[i] >= 0)
+                {
+                    var c = cands[idx[i]];
+                    refAllele = Encoding.ASCII.GetString(pool, (int)c.AlleleOffset, c.RefLen);
+                    altAllele = Encoding.ASCII.GetString(pool, (int)c.AlleleOffset + c.RefLen, c.AltLen);
+                }
+                else { refAllele = baseOf[(r.Info >> 7) & 7].ToString(); altAllele = baseOf[(r.Info >> 10) & 7].ToString(); }
+                var a = new CalledAllele(category)
+                {
+                    Chromosome = chr.Name, ReferencePosition = r.Position, ReferenceAllele = refAllele, AlternateAllele = altAllele,
+                    TotalCoverage = r.TotalCoverage, AlleleSupport = r.AlleleSupport, ReferenceSupport = r.ReferenceSupport, NumNoCalls = r.NumNoCalls,
+                    VariantQscore = r.VariantQscore, GenotypeQscore = r.GenotypeQscore, Genotype = MapGenotype(r.Info & 15),
+                    NoiseLevelApplied = r.AlleleSupport > 0 ? _cfg.NoiseLevel : 0, PhaseSetIndex = (r.FilterBits >> 14) & 3
+                };
+                a.EstimatedCoverageByDirection = new[] { r.CovF, r.CovR, r.CovS };
+                a.SupportByDirection = new[] { r.SupF, r.SupR, r.SupS };
+                a.SetFractionNoCalls();
+                a.StrandBiasResults.BiasScore = r.StrandBiasScore;
+                a.StrandBiasResults.GATKBiasScore = r.AlleleSupport > 0 ? 10 * Math.Log10(r.StrandBiasScore) : 0;   // MathOperations.PtoGATKBiasScale
+                a.StrandBiasResults.BiasAcceptable = ((r.Info >> 13) & 1) != 0;
+                a.StrandBiasResults.VarPresentOnBothStrands = ((r.Info >> 14) & 1) != 0;
+                a.StrandBiasResults.CovPresentOnBothStrands = ((r.Info >> 15) & 1) != 0;
+                foreach (var f in FilterOrder) if ((r.FilterBits & (1 << (int)f.Item1)) != 0) a.AddFilter(f.Item2);
+                List<CalledAllele> at;
+                if (!result.TryGetValue(r.Position, out at)) { at = new List<CalledAllele>(); result.Add(r.Position, at); }
+                at.Add(a);                                              // rows arrive sorted by position, then (ref, alt)
+            }
+            return result;
+        }
+
+        // native filter bit -> FilterType, in the order AlleleProcessor / the genotyper / AlleleCaller add them
+        private static readonly Tuple<int, FilterType>[] FilterOrder = {
+            Tuple.Create(4, FilterType.LowDepth), Tuple.Create(3, FilterType.LowVariantQscore), Tuple.Create(12, FilterType.NoCall),
+            Tuple.Create(0, FilterType.StrandBias), Tuple.Create(9, FilterType.RMxN), Tuple.Create(5, FilterType.LowVariantFrequency),
+            Tuple.Create(8, FilterType.MultiAllelicSite), Tuple.Create(6, FilterType.LowGenotypeQuality) };
+
+        private static Genotype MapGenotype(int code)   // PISCES_GT_* (include/pisces_hip.h)
+        {
+            switch (code)
+            {
+                case 0: return Genotype.HeterozygousAlt1Alt2; case 1: return Genotype.Alt12LikeNoCall; case 2: return Genotype.HeterozygousAltRef;
+                case 3: return Genotype.HomozygousAlt; case 4: return Genotype.HomozygousRef; case 5: return Genotype.RefLikeNoCall;
+                case 6: return Genotype.AltLikeNoCall; case 7: return Genotype.RefAndNoCall; case 8: return Genotype.AltAndNoCall;
+                case 9: return Genotype.HemizygousRef; case 10: return Genotype.HemizygousAlt; default: return Genotype.HemizygousNoCall;
+            }
+        }
+
+        /// IAlleleSource.GetAlleleCount: the anchor-resolved counts of one position + AlleleCountHelper.GetAnchorAdjustedAlleleCount
+        public int GetAlleleCount(int position, int allele, int direction, int minAnchor, int? maxAnchor, bool fromEnd, bool symmetric)
+        {
+            var flat = new int[6 * 3 * 11];
+            NativeMethods.Check(_h, NativeMethods.pisces_hip_get_counts(_h, position, 1, flat));
+            var counts = new int[1, 6, 3, 11];                                  // RegionState._alleleCounts layout for one position
+            Buffer.BlockCopy(flat, 0, counts, 0, flat.Length * sizeof(int));
+            return Pisces.Processing.RegionState.AlleleCountHelper.GetAnchorAdjustedAlleleCount(minAnchor, fromEnd, 5, 11, counts, 0, allele, direction,
+                5, maxAnchor, symmetric);                                       // (AlleleCountHelper.cs:21-85, TrackedAnchorSize 5)
+        }
+
+        public void AddGappedMnvRefCount(Dictionary<int, int> lookup)
+        {
+            var p = new int[lookup.Count]; var c = new int[lookup.Count]; int i = 0;
+            foreach (var kv in lookup) { p[i] = kv.Key; c[i++] = kv.Value; }
+            NativeMethods.Check(_h, NativeMethods.pisces_hip_add_gapped_mnv_ref(_h, p, c, p.Length));
+        }
+
+        public long[] Stats() { var s = new long[4]; NativeMethods.Check(_h, NativeMethods.pisces_hip_stats(_h, s)); return s; }
+
+        public void Dispose() { if (_h != IntPtr.Zero) { NativeMethods.pisces_hip_destroy(_h); _h = IntPtr.Zero; } }
+    }
+}
