@@ -40,6 +40,7 @@ namespace Pisces.Hip
         private int _lastFlushedBlock = -1;
 
         public bool ExpectStitchedReads { get { return _cfg.ExpectStitchedReads != 0; } }
+        public int BlockKey(int position) { return (position - 1) / _cfg.BlockSize + 1; }   // RegionStateManager.GetBlockKey
 
         /// Factory.CreateVariantCaller's VariantCallerConfig (Factory.cs:149-179) + the state-manager / finder settings (:123,209-227)
         public static PiscesHipConfig ConfigFrom(PiscesApplicationOptions o, bool expectStitchedReads, bool hasIntervals)

@@ -56,9 +56,17 @@ namespace Pisces.Hip
         public HipStateManager(HipEngine e) { _e = e; }
         public void AddAlleleCounts(Read read) { _e.StageRead(read); }                       // copies out: the Read object is reused (AlignmentsSource.cs:21,61)
         public void AddCandidates(IEnumerable<CandidateAllele> candidates) { _e.KeepNonSnvCandidates(candidates); }
+        private int _lastUpToBlockKey = -1;
         public ICandidateBatch GetCandidatesToProcess(int? upToPosition, ChrReference chrReference = null,
             HashSet<Tuple<string, int, string, string>> forcedGtAlleles = null)
-        { _e.FlushStagedReads(chrReference); return new HipBatch(upToPosition); }
+        {
+            // RegionStateManager.cs:287-291: only make a batch when upTo has moved onto another block (SmallVariantCaller asks after every
+            // read); until then the reads just accumulate in the staging arrays and cross PCIe once per block
+            if (upToPosition.HasValue && _e.BlockKey(upToPosition.Value) == _lastUpToBlockKey) return null;
+            _lastUpToBlockKey = upToPosition.HasValue ? _e.BlockKey(upToPosition.Value) : -1;
+            _e.FlushStagedReads(chrReference);
+            return new HipBatch(upToPosition);
+        }
         public void DoneProcessing(ICandidateBatch batch) { }
         public int GetAlleleCount(int position, Pisces.Domain.Types.AlleleType a, Pisces.Domain.Types.DirectionType d,
             int minAnchor = 0, int? maxAnchor = null, bool fromEnd = false, bool symmetric = false)
