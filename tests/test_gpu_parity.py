@@ -1012,3 +1012,57 @@ def test_batched_launches_equal_single_launches(torch_cuda):
             c.call_tiles_batched(bad)
         assert e.value.code == _abi.E_BUFFER_TOO_SMALL
         c.call_tiles_batched([])
+
+
+@pytest.mark.gpu
+def test_random_configuration_matrix_matches_oracle(torch_cuda):
+    """Forty random combinations of the modes (MNV calling, collapser, noise model, ploidy, strand-bias model, thresholds, gVCF on / off,
+    intervals) on one read set with SNVs, MNVs, an insertion and a deletion: the device path against the oracle, every field."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(2024)
+    ref = bytes(rng.choice(list(b"ACGT"), 1300).astype(np.uint8))
+    reads = _mnv_reads(rng, ref, 2200, region=(30, 1250))
+    for i in range(120):
+        if i % 2:
+            reads.append({"pos": 560, "cigar": [("M", 41), ("D", 2), ("M", 50)], "seq": (ref[559:600] + ref[602:652]).decode(), "reverse": bool(i & 2)})
+        else:
+            reads.append({"pos": 760, "cigar": [("M", 41), ("I", 3), ("M", 50)], "seq": (ref[759:800] + b"GAT" + ref[800:850]).decode(), "reverse": bool(i & 2)})
+    for r in reads:
+        r["quals"] = rng.choice([12, 23, 30, 37, 41], len(r["seq"]), p=[.03, .15, .2, .45, .17]).astype(np.uint8).tolist()
+    reads.sort(key=lambda r: r["pos"])
+    batch = _abi.ReadBatch(reads)
+    refa = np.frombuffer(ref, dtype=np.uint8)
+    checked = 0
+    for trial in range(40):
+        ploidy = int(rng.choice([0, 0, 1, 2]))
+        kw = dict(call_mnvs=int(rng.integers(0, 2)), collapse=int(rng.integers(0, 2)), noise_model=int(rng.integers(0, 2)), ploidy=ploidy,
+                  strand_bias_model=int(rng.choice([0, 1, 2])), include_reference_calls=int(rng.integers(0, 2)),
+                  min_frequency=float(rng.choice([0.005, 0.01, 0.05])) if ploidy == 0 else 0.2,
+                  min_variant_qscore=int(rng.choice([10, 20, 30])), max_variant_qscore=int(rng.choice([100, 500])),
+                  filter_single_strand=int(rng.integers(0, 2)), low_gq_filter=int(rng.choice([-1, 30])), block_size=2000,
+                  max_mnv_length=int(rng.choice([2, 3, 5])), max_gap_between_mnv=int(rng.choice([0, 1, 2])),
+                  variant_qscore_filter=int(rng.choice([20, 30, 60])))
+        kw["variant_freq_filter"] = kw["min_frequency"]
+        intervals = [(100, 400), (520, 900), (1000, 1100)] if rng.random() < 0.3 else None
+        if intervals:
+            kw["emit_zero_coverage_refs"] = 1
+        cfg = _abi.default_config(**kw)
+        # the reference calls every candidate of the block (MNV reallocation included) and applies the intervals only when it
+        # reports (AlleleCaller.ShouldReport :260-263), so the expectation is the whole region filtered by interval
+        exp, exp_alleles, _, _ = orc.run_reads_full(batch, refa, 1, len(ref), cfg)
+        if intervals:
+            keep = np.zeros(len(exp), dtype=bool)
+            for (a, b) in intervals:
+                keep |= (exp["position"] >= a) & (exp["position"] <= b)
+            exp_alleles = [al for al, k in zip(exp_alleles, keep) if k]
+            exp = exp[keep]
+        with engine.HipVariantCaller(cfg) as c:
+            c.SetReference(refa)
+            if intervals:
+                c.SetIntervals(intervals)
+            c.AddAlleleCounts(batch)
+            got, got_alleles = c.CallWithAlleles()
+        assert got_alleles == exp_alleles, (trial, kw, intervals)
+        assert_records_match(got, exp)
+        checked += 1
+    assert checked == 40
