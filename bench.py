@@ -114,7 +114,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # the collectives also run at world size 1 when launched by torch.distributed.run (exercises the RCCL path on a 1-GPU box)
+    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
@@ -142,7 +144,7 @@ def main():
                           records.data_ptr(), cap, tile_results.data_ptr(), stream.cuda_stream)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for i in range(args.warmup):
@@ -167,7 +169,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     kernel_ms_total, launches = caller.kernel_time()
@@ -208,7 +210,7 @@ def main():
         caller.synchronize()
         barrier()
         tp = torch.tensor([time.perf_counter() - tp0], dtype=torch.float64, device=dev)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(tp, op=dist.ReduceOp.MAX)
         pipelined_elapsed = float(tp.item())
         for k in range(1, PIPELINE_STREAMS):   # every lane's last output equals a serial launch's (same batch -> same records)
@@ -267,7 +269,7 @@ def main():
             out["cpu_baseline"], out["cpu_baseline_threads"] = cpu_baseline(torch, ring[0], cfg)
         print(json.dumps(out), flush=True)
     caller.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
