@@ -31,9 +31,9 @@ namespace Pisces.Hip
         private bool _referenceSet;
         // staged reads (SoA, grown geometrically; handed to pisces_hip_add_reads when the caller asks for candidates)
         private readonly List<int> _pos = new List<int>(), _cigOff = new List<int> { 0 }, _seqOff = new List<int> { 0 };
-        private readonly List<byte> _flags = new List<byte>(), _cigOp = new List<byte>(), _bases = new List<byte>(), _quals = new List<byte>(), _dirs = new List<byte>();
+        private readonly List<byte> _flags = new List<byte>(), _cigOp = new List<byte>(), _bases = new List<byte>(), _quals = new List<byte>(), _dirs = new List<byte>(), _delDirs = new List<byte>();
         private readonly List<uint> _cigLen = new List<uint>();
-        private bool _anyStitched;
+        private bool _anyStitched, _anyDelDirs;
         // BlocksPerFlush > 1 holds the native flush back until upTo has moved that many blocks on: records come out later, in the same
         // order (the VCF writer does not care), and the per-flush latency (~0.26 ms) is paid once per group (DESIGN.md section 8)
         public int BlocksPerFlush = 1;
@@ -94,7 +94,18 @@ namespace Pisces.Hip
         {
             _pos.Add(read.Position);
             _flags.Add((byte)(read.BamAlignment.IsReverseStrand() ? 1 : 0));
-            foreach (var op in read.CigarData) { _cigOp.Add((byte)op.Type); _cigLen.Add(op.Length); }
+            // directions inside deletions (CandidateVariantFinder.GetDeletionDirectionForStitchedRead reads them from the expanded XD map)
+            var expanded = read.CigarDirections != null && read.CigarDirections.Directions.Count > 0 ? read.CigarDirections.Expand() : null;
+            int e = 0;
+            foreach (var op in read.CigarData)
+            {
+                _cigOp.Add((byte)op.Type); _cigLen.Add(op.Length);
+                bool tracked = expanded != null && op.Type == 'D' && op.Length > 0 && e + (int)op.Length <= expanded.Count;
+                _delDirs.Add(tracked ? (byte)expanded[e] : (byte)255);
+                _delDirs.Add(tracked ? (byte)expanded[e + (int)op.Length - 1] : (byte)255);
+                _anyDelDirs |= tracked;
+                e += (int)op.Length;
+            }
             _cigOff.Add(_cigOp.Count);
             _bases.AddRange(Encoding.ASCII.GetBytes(read.Sequence));
             _quals.AddRange(read.Qualities);
@@ -116,17 +127,18 @@ namespace Pisces.Hip
             }
             if (_pos.Count == 0) return;
             int[] pos = _pos.ToArray(), cigOff = _cigOff.ToArray(), seqOff = _seqOff.ToArray();
-            byte[] flags = _flags.ToArray(), cigOp = _cigOp.ToArray(), bases = _bases.ToArray(), quals = _quals.ToArray(), dirs = _dirs.ToArray();
+            byte[] flags = _flags.ToArray(), cigOp = _cigOp.ToArray(), bases = _bases.ToArray(), quals = _quals.ToArray(), dirs = _dirs.ToArray(), delDirs = _delDirs.ToArray();
             uint[] cigLen = _cigLen.ToArray();
             fixed (int* pPos = pos, pCo = cigOff, pSo = seqOff)
-            fixed (byte* pF = flags, pOp = cigOp, pB = bases, pQ = quals, pD = dirs)
+            fixed (byte* pF = flags, pOp = cigOp, pB = bases, pQ = quals, pD = dirs, pDd = delDirs)
             fixed (uint* pLen = cigLen)
             {
                 var b = new PiscesReadBatch { NReads = pos.Length, Position = pPos, Flags = pF, CigarOffset = pCo, CigarOp = pOp, CigarLen = pLen,
-                                              SeqOffset = pSo, Bases = pB, Quals = pQ, Directions = _anyStitched ? pD : null };
+                                              SeqOffset = pSo, Bases = pB, Quals = pQ, Directions = _anyStitched ? pD : null,
+                                              DeletionDirections = _anyDelDirs ? pDd : null };
                 NativeMethods.Check(_h, NativeMethods.pisces_hip_add_reads(_h, ref b));
             }
-            _pos.Clear(); _flags.Clear(); _cigOp.Clear(); _cigLen.Clear(); _bases.Clear(); _quals.Clear(); _dirs.Clear();
+            _pos.Clear(); _flags.Clear(); _cigOp.Clear(); _cigLen.Clear(); _bases.Clear(); _quals.Clear(); _dirs.Clear(); _delDirs.Clear(); _anyDelDirs = false;
             _cigOff.Clear(); _cigOff.Add(0); _seqOff.Clear(); _seqOff.Add(0); _anyStitched = false;
         }
 

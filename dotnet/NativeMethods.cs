@@ -51,6 +51,7 @@ namespace Pisces.Hip
         public int NReads;
         public int* Position; public byte* Flags; public int* CigarOffset; public byte* CigarOp; public uint* CigarLen;
         public int* SeqOffset; public byte* Bases; public byte* Quals; public byte* Directions;
+        public byte* DeletionDirections;   // 2 per CIGAR op: first / last deleted base of a D op in CigarDirections.Expand(), 255 = untracked
     }
 
     [StructLayout(LayoutKind.Sequential, Size = 56)]

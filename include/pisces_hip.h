@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define PISCES_HIP_ABI_VERSION 4
+#define PISCES_HIP_ABI_VERSION 5
 
 /* ---- error codes -------------------------------------------------------- */
 #define PISCES_OK                 0
@@ -208,7 +208,13 @@ typedef struct PiscesReadBatch {
     const uint8_t* bases;         /* upper-case ASCII */
     const uint8_t* quals;         /* phred */
     const uint8_t* directions;    /* optional per-base DirectionType (stitched reads, XD tag); NULL = from flags */
+    const uint8_t* deletion_directions; /* optional, 2 bytes per CIGAR op (indexed like cigar_op): for a 'D' op the DirectionType of
+                                     * its first and of its last deleted base in Read.CigarDirections.Expand() (the XD tag covers
+                                     * deleted bases too) - what GetDeletionDirectionForStitchedRead reads,
+                                     * CandidateVariantFinder.cs:417-420, 468-487; 255 = this read tracks no directions inside
+                                     * deletions (CigarDirections == null, :422-428); ignored for other ops.  NULL = 255 throughout */
 } PiscesReadBatch;
+#define PISCES_DIR_UNTRACKED 255
 
 /* ---- a candidate allele crossing the boundary (CandidateAllele.cs:8-49) ---- */
 typedef struct PiscesCandidate {

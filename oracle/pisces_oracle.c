@@ -1001,9 +1001,33 @@ typedef struct FinderCtx {
     int overflow;
 } FinderCtx;
 
-/* GetSupportDirection :396-445 (the stitched-deletion branch via CigarDirections, :417-420,
- * needs the XD tag's expanded map; reads carrying one supply per-base dirs and take the
- * fallback branch, which is what the reference does when CigarDirections == null). */
+/* Read.SequencedIndexesToExpandedIndexes (Read.cs:432-476), one index: the position of sequenced base idx in the expanded CIGAR */
+static int sequenced_index_to_expanded(const OrcRead* r, int idx)
+{
+    int extendedIndex = 0, sequencedBaseIndex = 0;
+    for (int c = 0; c < r->n_cigar; c++)
+        for (uint32_t k = 0; k < r->cigar_len[c]; k++, extendedIndex++)
+            if (op_is_read_span(r->cigar_op[c])) {
+                if (sequencedBaseIndex == idx) return extendedIndex;
+                sequencedBaseIndex++;
+            }
+    return -1;
+}
+
+/* GetDeletionDirectionForStitchedRead :468-487: the directions one step inside the deletion from either anchor, read from the
+ * expanded direction map.  -1 where the reference throws (indexes outside the map). */
+int32_t orc_deletion_direction_for_stitched_read(const OrcRead* r, int32_t leftAnchorIndexInSequencedRead, int32_t rightAnchorIndexInSequencedRead)
+{
+    int first = sequenced_index_to_expanded(r, leftAnchorIndexInSequencedRead) + 1;
+    int last = sequenced_index_to_expanded(r, rightAnchorIndexInSequencedRead) - 1;
+    if (first >= 0 && first < r->n_expanded && last >= 0 && last < r->n_expanded) {
+        int startDirection = r->expanded_dirs[first], endDirection = r->expanded_dirs[last];
+        return startDirection == PISCES_DIR_STITCHED ? endDirection : startDirection;
+    }
+    return -1;
+}
+
+/* GetSupportDirection :396-445 */
 static int get_support_direction(const FinderCtx* f, int category, int length, int startIndexInRead)
 {
     const OrcRead* r = f->r;
@@ -1014,6 +1038,10 @@ static int get_support_direction(const FinderCtx* f, int category, int length, i
     if (rightAnchorIndex == 0) return read_dir(r, rightAnchorIndex);
     if (leftAnchorIndex == lastIndex) return read_dir(r, lastIndex);
     if (leftAnchorIndex == rightAnchorIndex - 1) {
+        if (r->expanded_dirs) {
+            int d = orc_deletion_direction_for_stitched_read(r, leftAnchorIndex, rightAnchorIndex);
+            if (d >= 0 && d <= 2) return d;
+        }
         int startDirection = read_dir(r, leftAnchorIndex);
         int endDirection = read_dir(r, rightAnchorIndex);
         return startDirection == PISCES_DIR_STITCHED ? endDirection : startDirection;
@@ -2117,6 +2145,54 @@ int64_t orc_run_reads_full(const PiscesReadBatch* b, const uint8_t* ref_bases, i
                            int32_t region_loci, const PiscesHipConfig* cfg, PiscesCalledAllele* out, int64_t capacity,
                            int64_t* n_candidate_loci, OrcCalled* full_out, int64_t* total_num_called);
 
+/* One read of a batch as the oracle's Read.  A batch that tracks directions inside deletions (deletion_directions) is turned back
+ * into the expanded direction map the reference reads them from: sequenced bases carry their own direction, a deletion its first /
+ * last pair (first direction up to the last base, which takes the second). */
+static void read_from_batch(const PiscesReadBatch* b, int i, OrcRead* r, uint8_t** expanded, int64_t* expanded_cap)
+{
+    r->position = b->position[i];
+    r->n_cigar = b->cigar_offset[i + 1] - b->cigar_offset[i];
+    r->cigar_op = b->cigar_op + b->cigar_offset[i];
+    r->cigar_len = b->cigar_len + b->cigar_offset[i];
+    r->read_len = b->seq_offset[i + 1] - b->seq_offset[i];
+    r->bases = b->bases + b->seq_offset[i];
+    r->quals = b->quals + b->seq_offset[i];
+    r->dirs = b->directions ? b->directions + b->seq_offset[i] : NULL;
+    r->is_reverse = b->flags[i] & 1;
+    r->posmap_override = NULL;
+    r->expanded_dirs = NULL;
+    r->n_expanded = 0;
+    if (!b->deletion_directions) return;
+    const uint8_t* dd = b->deletion_directions + 2 * (size_t)b->cigar_offset[i];
+    int tracked = 0;
+    int64_t total = 0;
+    for (int c = 0; c < r->n_cigar; c++) {
+        total += r->cigar_len[c];
+        if (r->cigar_op[c] == 'D' && dd[2 * c] != PISCES_DIR_UNTRACKED) tracked = 1;
+    }
+    if (!tracked) return;
+    if (total > *expanded_cap) {
+        free(*expanded);
+        *expanded_cap = total * 2;
+        *expanded = (uint8_t*)malloc((size_t)*expanded_cap);
+    }
+    int64_t e = 0;
+    int seq = 0;
+    for (int c = 0; c < r->n_cigar; c++)
+        for (uint32_t k = 0; k < r->cigar_len[c]; k++, e++) {
+            if (op_is_read_span(r->cigar_op[c])) {
+                (*expanded)[e] = seq < r->read_len ? (uint8_t)read_dir(r, seq) : (uint8_t)PISCES_DIR_FORWARD;
+                seq++;
+            } else if (r->cigar_op[c] == 'D') {
+                (*expanded)[e] = k + 1 == r->cigar_len[c] ? dd[2 * c + 1] : dd[2 * c];
+            } else {
+                (*expanded)[e] = PISCES_DIR_UNTRACKED;
+            }
+        }
+    r->expanded_dirs = *expanded;
+    r->n_expanded = (int32_t)total;
+}
+
 int64_t orc_run_reads(const PiscesReadBatch* b, const uint8_t* ref_bases, int64_t ref_len, int32_t region_start,
                       int32_t region_loci, const PiscesHipConfig* cfg, PiscesCalledAllele* out, int64_t capacity,
                       int64_t* n_candidate_loci)
@@ -2131,18 +2207,11 @@ int64_t orc_run_reads_full(const PiscesReadBatch* b, const uint8_t* ref_bases, i
     /* the state manager tracks open-ended candidates apart when the collapser is on (Factory.cs:209-227) */
     OrcState* s = orc_state_create(region_start, region_loci, cfg->min_base_call_quality, PISCES_ANCHOR_SIZE, cfg->collapse ? 1 : 0);
     OrcCandidate cands[256];
+    uint8_t* expanded = NULL;
+    int64_t expanded_cap = 0;
     for (int i = 0; i < b->n_reads; i++) {
         OrcRead r;
-        r.position = b->position[i];
-        r.n_cigar = b->cigar_offset[i + 1] - b->cigar_offset[i];
-        r.cigar_op = b->cigar_op + b->cigar_offset[i];
-        r.cigar_len = b->cigar_len + b->cigar_offset[i];
-        r.read_len = b->seq_offset[i + 1] - b->seq_offset[i];
-        r.bases = b->bases + b->seq_offset[i];
-        r.quals = b->quals + b->seq_offset[i];
-        r.dirs = b->directions ? b->directions + b->seq_offset[i] : NULL;
-        r.is_reverse = b->flags[i] & 1;
-        r.posmap_override = NULL;
+        read_from_batch(b, i, &r, &expanded, &expanded_cap);
         /* FindCandidates -> AddCandidates -> AddAlleleCounts (SmallVariantCaller.cs:92-98) */
         int nc = orc_find_candidates(&r, ref_bases, ref_len, cfg->min_base_call_quality, cfg->max_mnv_length, cfg->max_gap_between_mnv,
                                      cfg->call_mnvs, PISCES_ANCHOR_SIZE, cands, 256);
@@ -2150,8 +2219,9 @@ int64_t orc_run_reads_full(const PiscesReadBatch* b, const uint8_t* ref_bases, i
             if (cands[k].position >= region_start && cands[k].position < region_start + region_loci)
                 orc_add_candidate(s, &cands[k]);
         int rc = orc_add_allele_counts(s, &r);
-        if (rc) { orc_state_destroy(s); return rc; }
+        if (rc) { free(expanded); orc_state_destroy(s); return rc; }
     }
+    free(expanded);
     int64_t n = orc_call_all(s, ref_bases, ref_len, cfg, out, capacity, full_out, total_num_called);
     orc_state_destroy(s);
     if (n >= 0 && n_candidate_loci) *n_candidate_loci = count_candidate_loci(out, n);
@@ -2166,25 +2236,19 @@ int64_t orc_run_reads_blocks(const PiscesReadBatch* b, const uint8_t* ref_bases,
 {
     OrcState* s = orc_state_create(region_start, region_loci, cfg->min_base_call_quality, PISCES_ANCHOR_SIZE, cfg->collapse ? 1 : 0);
     OrcCandidate cands[256];
+    uint8_t* expanded = NULL;
+    int64_t expanded_cap = 0;
     for (int i = 0; i < b->n_reads; i++) {
         OrcRead r;
-        r.position = b->position[i];
-        r.n_cigar = b->cigar_offset[i + 1] - b->cigar_offset[i];
-        r.cigar_op = b->cigar_op + b->cigar_offset[i];
-        r.cigar_len = b->cigar_len + b->cigar_offset[i];
-        r.read_len = b->seq_offset[i + 1] - b->seq_offset[i];
-        r.bases = b->bases + b->seq_offset[i];
-        r.quals = b->quals + b->seq_offset[i];
-        r.dirs = b->directions ? b->directions + b->seq_offset[i] : NULL;
-        r.is_reverse = b->flags[i] & 1;
-        r.posmap_override = NULL;
+        read_from_batch(b, i, &r, &expanded, &expanded_cap);
         int nc = orc_find_candidates(&r, ref_bases, ref_len, cfg->min_base_call_quality, cfg->max_mnv_length, cfg->max_gap_between_mnv,
                                      cfg->call_mnvs, PISCES_ANCHOR_SIZE, cands, 256);
         for (int k = 0; k < nc; k++)
             if (cands[k].position >= region_start && cands[k].position < region_start + region_loci) orc_add_candidate(s, &cands[k]);
         int rc = orc_add_allele_counts(s, &r);
-        if (rc) { orc_state_destroy(s); return rc; }
+        if (rc) { free(expanded); orc_state_destroy(s); return rc; }
     }
+    free(expanded);
     const int bs = cfg->block_size;
     int64_t n = 0, total = 0;
     const int region_end = region_start + region_loci - 1;

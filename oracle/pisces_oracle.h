@@ -39,6 +39,9 @@ typedef struct OrcRead {
     const uint8_t* dirs;         /* per-base DirectionType or NULL */
     int32_t is_reverse;
     const int32_t* posmap_override; /* tests poke PositionMap directly; NULL = from CIGAR */
+    const uint8_t* expanded_dirs;   /* Read.CigarDirections.Expand(): one DirectionType per base of the expanded CIGAR (deleted bases
+                                     * included); NULL = CigarDirections == null */
+    int32_t n_expanded;
 } OrcRead;
 
 typedef struct OrcCandidate {
@@ -125,6 +128,7 @@ int32_t orc_find_candidates(const OrcRead* r, const uint8_t* ref_bases, int64_t 
                             int32_t min_bq, int32_t max_mnv_len, int32_t max_gap, int32_t call_mnvs,
                             int32_t anchor_size, OrcCandidate* out, int32_t capacity); /* :31-83 */
 int32_t orc_check_deletion_quality(const OrcRead* r, int32_t op_start_index, int32_t min_bq); /* :294-320 */
+int32_t orc_deletion_direction_for_stitched_read(const OrcRead* r, int32_t left_anchor_index, int32_t right_anchor_index); /* :468-487 */
 
 /* ---- coverage + caller ---- */
 void    orc_coverage_compute(OrcCalled* allele, const OrcState* s, int32_t consider_anchors,

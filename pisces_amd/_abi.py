@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # error codes
 OK = 0
@@ -237,6 +237,7 @@ class PiscesReadBatch(C.Structure):
         ("bases", C.POINTER(C.c_uint8)),
         ("quals", C.POINTER(C.c_uint8)),
         ("directions", C.POINTER(C.c_uint8)),
+        ("deletion_directions", C.POINTER(C.c_uint8)),
     ]
 
 
@@ -255,6 +256,32 @@ class PiscesCandidate(C.Structure):
     ]
 
 
+DIR_UNTRACKED = 255
+_READ_SPAN_OPS = "MIS=X"
+
+
+def directions_from_xd(xd, cigar):
+    """The two direction inputs of a stitched read from its XD tag (e.g. "3F4S3R", one direction per base of the EXPANDED CIGAR, deleted
+    bases included): (dirs, del_dirs).  dirs = Read.CreateSequencedBaseDirectionMap (Read.cs:664-682): the directions of the read-span
+    bases.  del_dirs = per CIGAR op, for a 'D' op the directions of its first and last deleted base (what
+    GetDeletionDirectionForStitchedRead reads, CandidateVariantFinder.cs:468-487), (255, 255) for the other ops."""
+    expanded, num = [], ""
+    for ch in xd:
+        if ch.isdigit():
+            num += ch
+        else:
+            expanded += [{"F": DIR_FORWARD, "R": DIR_REVERSE, "S": DIR_STITCHED}[ch]] * int(num)
+            num = ""
+    dirs, del_dirs, e = [], [], 0
+    for op, ln in cigar:
+        seg = expanded[e:e + ln]
+        e += ln
+        if op in _READ_SPAN_OPS:
+            dirs += seg
+        del_dirs.append((seg[0], seg[-1]) if op == "D" and seg else (DIR_UNTRACKED, DIR_UNTRACKED))
+    return dirs, del_dirs
+
+
 def _ptr(arr, ctype):
     return arr.ctypes.data_as(C.POINTER(ctype))
 
@@ -265,7 +292,7 @@ class ReadBatch:
 
     def __init__(self, reads):
         """reads: iterable of dicts {pos, cigar:[(op,len)], seq:str|bytes, quals:bytes|list,
-        reverse:bool, dirs:optional list}."""
+        reverse:bool, dirs:optional list, del_dirs:optional list of (first, last) per CIGAR op, or xd:"3F4S3R" for both}."""
         reads = list(reads)
         n = len(reads)
         self.position = np.array([r["pos"] for r in reads], dtype=np.int32).reshape(n)
@@ -274,12 +301,20 @@ class ReadBatch:
         ops, lens = [], []
         seq_off = [0]
         bases, quals, dirs = [], [], []
+        for r in reads:
+            if r.get("xd") is not None and r.get("dirs") is None:
+                r["dirs"], r["del_dirs"] = directions_from_xd(r["xd"], r["cigar"])
         any_dirs = any(r.get("dirs") is not None for r in reads)
+        any_del = any(r.get("del_dirs") is not None for r in reads)
+        del_dirs = []
         for r in reads:
             for op, ln in r["cigar"]:
                 ops.append(ord(op))
                 lens.append(ln)
             cig_off.append(len(ops))
+            if any_del:
+                dd = r.get("del_dirs")
+                del_dirs += [tuple(x) for x in dd] if dd is not None else [(DIR_UNTRACKED, DIR_UNTRACKED)] * len(r["cigar"])
             s = r["seq"].encode() if isinstance(r["seq"], str) else bytes(r["seq"])
             q = bytes(r["quals"])
             assert len(s) == len(q), "sequence / quality length mismatch"
@@ -298,11 +333,12 @@ class ReadBatch:
         self.bases = np.concatenate(bases) if bases else np.zeros(0, np.uint8)
         self.quals = np.concatenate(quals) if quals else np.zeros(0, np.uint8)
         self.directions = np.concatenate(dirs) if any_dirs and dirs else None
+        self.deletion_directions = np.array(del_dirs, dtype=np.uint8).reshape(-1) if any_del else None
         self._finish(n)
 
     @classmethod
     def from_arrays(cls, position, flags, cigar_offset, cigar_op, cigar_len, seq_offset, bases, quals,
-                    directions=None):
+                    directions=None, deletion_directions=None):
         self = cls.__new__(cls)
         self.position = np.ascontiguousarray(position, np.int32)
         self.flags = np.ascontiguousarray(flags, np.uint8)
@@ -313,6 +349,7 @@ class ReadBatch:
         self.bases = np.ascontiguousarray(bases, np.uint8)
         self.quals = np.ascontiguousarray(quals, np.uint8)
         self.directions = None if directions is None else np.ascontiguousarray(directions, np.uint8)
+        self.deletion_directions = None if deletion_directions is None else np.ascontiguousarray(deletion_directions, np.uint8).reshape(-1)
         self._finish(len(self.position))
         return self
 
@@ -328,6 +365,9 @@ class ReadBatch:
         b.bases = _ptr(self.bases, C.c_uint8)
         b.quals = _ptr(self.quals, C.c_uint8)
         b.directions = _ptr(self.directions, C.c_uint8) if self.directions is not None else None
+        dd = getattr(self, "deletion_directions", None)
+        assert dd is None or len(dd) == 2 * len(self.cigar_op), "deletion_directions: two bytes per CIGAR op"
+        b.deletion_directions = _ptr(dd, C.c_uint8) if dd is not None else None
         self.c = b
         self.n_reads = n
         self.n_bases = int(self.seq_offset[-1]) if n else 0

@@ -135,6 +135,7 @@ ReadView read_view(const PiscesReadBatch* b, int32_t i)
     r.bases = b->bases + b->seq_offset[i];
     r.quals = b->quals + b->seq_offset[i];
     r.dirs = b->directions ? b->directions + b->seq_offset[i] : nullptr;
+    r.del_dirs = b->deletion_directions ? b->deletion_directions + 2 * (size_t)b->cigar_offset[i] : nullptr;
     r.is_reverse = b->flags[i] & 1;
     return r;
 }

@@ -17,6 +17,7 @@ struct ReadView {
     const uint8_t* bases;
     const uint8_t* quals;
     const uint8_t* dirs;   // per-base DirectionType or nullptr
+    const uint8_t* del_dirs = nullptr;   // 2 per CIGAR op (first / last deleted base of a D op, 255 = untracked) or nullptr
     int32_t is_reverse;
 };
 

@@ -13,9 +13,9 @@ static inline int dir_at(const ReadView& r, int i)
     return r.dirs ? r.dirs[i] : (r.is_reverse ? PISCES_DIR_REVERSE : PISCES_DIR_FORWARD);
 }
 
-// CandidateVariantFinder.GetSupportDirection :396-445 for insertions / deletions. Reads that carry per-base
-// directions (stitched, XD tag) take the branch the reference takes when CigarDirections == null (:422-428).
-static int support_direction(const ReadView& r, int category, int length, int startIndexInRead)
+// CandidateVariantFinder.GetSupportDirection :396-445. A deletion of a read whose XD tag tracks directions inside deletions
+// (ReadView::del_dirs) takes GetDeletionDirectionForStitchedRead :468-487: the directions of its first and last deleted base.
+static int support_direction(const ReadView& r, int category, int length, int startIndexInRead, int cigarIndex)
 {
     if (category == PISCES_CAT_SNV || category == PISCES_CAT_REFERENCE) return dir_at(r, startIndexInRead);
     const int leftAnchorIndex = startIndexInRead - 1;
@@ -24,6 +24,10 @@ static int support_direction(const ReadView& r, int category, int length, int st
     if (rightAnchorIndex == 0) return dir_at(r, rightAnchorIndex);
     if (leftAnchorIndex == lastIndex) return dir_at(r, lastIndex);
     if (leftAnchorIndex == rightAnchorIndex - 1) {
+        if (r.del_dirs && cigarIndex >= 0 && r.del_dirs[2 * cigarIndex] != PISCES_DIR_UNTRACKED) {
+            const int startDirection = r.del_dirs[2 * cigarIndex], endDirection = r.del_dirs[2 * cigarIndex + 1];
+            return startDirection == PISCES_DIR_STITCHED ? endDirection : startDirection;
+        }
         const int startDirection = dir_at(r, leftAnchorIndex), endDirection = dir_at(r, rightAnchorIndex);
         return startDirection == PISCES_DIR_STITCHED ? endDirection : startDirection;
     }
@@ -63,13 +67,13 @@ void find_candidates(const ReadView& r, const uint8_t* ref, int64_t ref_len, int
     const int endPosition = r.position + refSpan - 1;   // Read.EndPosition
 
     // CandidateVariantFinder.Create :334-345
-    auto create = [&](int category, int coordinate, std::string refAllele, std::string altAllele, int startIndexInRead) {
+    auto create = [&](int category, int coordinate, std::string refAllele, std::string altAllele, int startIndexInRead, int cigarIndex = -1) {
         HostCandidate c;
         c.position = coordinate;
         c.category = category;
         const int length = category == PISCES_CAT_INSERTION ? (int)altAllele.size() - 1
                            : category == PISCES_CAT_DELETION ? (int)refAllele.size() - 1 : (int)altAllele.size();   // BaseAllele.Length
-        const int dir = support_direction(r, category, length, startIndexInRead);
+        const int dir = support_direction(r, category, length, startIndexInRead, cigarIndex);
         c.support_by_dir[dir]++;
         const int anchor = std::min(coordinate - r.position, endPosition - coordinate);
         if (anchor > std::min(anchorSize - 1, (int)altAllele.size() - 1)) c.well_anchored_by_dir[dir]++;
@@ -153,7 +157,7 @@ void find_candidates(const ReadView& r, const uint8_t* ref, int64_t ref_len, int
                 deletion_quality_ok(r, startIndexInRead, minBQ)) {
                 std::string refAllele((const char*)ref + startIndexInReference - 1, (size_t)len + 1);
                 std::string altAllele(1, (char)ref[startIndexInReference - 1]);
-                create(PISCES_CAT_DELETION, startIndexInReference, refAllele, altAllele, startIndexInRead);
+                create(PISCES_CAT_DELETION, startIndexInReference, refAllele, altAllele, startIndexInRead, ci);
             }
         }
         if (op_is_read_span(t)) startIndexInRead += len;

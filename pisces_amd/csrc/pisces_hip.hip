@@ -626,6 +626,12 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
         if (r.dirs)
             for (int k = 0; k < r.read_len; k++)
                 if (r.dirs[k] > 2) return fail(h, PISCES_E_INVALID_ARG, "add_reads: CIGAR does not match the read");
+        if (r.del_dirs)
+            for (int c = 0; c < r.n_cigar; c++)
+                if (r.cigar_op[c] == 'D')
+                    for (int k = 0; k < 2; k++)
+                        if (r.del_dirs[2 * c + k] > 2 && r.del_dirs[2 * c + k] != PISCES_DIR_UNTRACKED)
+                            return fail(h, PISCES_E_INVALID_ARG, "add_reads: deletion_directions holds a value that is no DirectionType");
         ub += ref_span;
     }
     slots[(size_t)nr] = (long long)(h->log_ub + ub);

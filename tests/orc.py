@@ -24,6 +24,8 @@ class OrcRead(C.Structure):
         ("dirs", C.POINTER(C.c_uint8)),
         ("is_reverse", C.c_int32),
         ("posmap_override", C.POINTER(C.c_int32)),
+        ("expanded_dirs", C.POINTER(C.c_uint8)),
+        ("n_expanded", C.c_int32),
     ]
 
 
@@ -123,6 +125,7 @@ def _load():
         "orc_get_candidates": (i32, [C.c_void_p, P(OrcCandidate), i32]),
         "orc_find_candidates": (i32, [P(OrcRead), P(C.c_uint8), i64, i32, i32, i32, i32, i32, P(OrcCandidate), i32]),
         "orc_check_deletion_quality": (i32, [P(OrcRead), i32, i32]),
+        "orc_deletion_direction_for_stitched_read": (i32, [P(OrcRead), i32, i32]),
         "orc_coverage_compute": (None, [P(OrcCalled), C.c_void_p, i32, i32]),
         "orc_called_from_candidate": (None, [P(OrcCalled), P(OrcCandidate)]),
         "orc_process_variant": (None, [P(OrcCalled), C.c_void_p, P(_abi.PiscesHipConfig)]),
@@ -150,7 +153,7 @@ def _load():
 lib = _load()
 
 
-def make_read(pos, seq, cigar=None, quals=None, qual_all=30, reverse=False, dirs=None, posmap=None):
+def make_read(pos, seq, cigar=None, quals=None, qual_all=30, reverse=False, dirs=None, posmap=None, expanded_dirs=None):
     """ReadTestHelper.CreateRead (src/test/TestUtilities/ReadTestHelper.cs:156-173): default Q30, <len>M."""
     seq_b = np.frombuffer(seq.encode(), dtype=np.uint8).copy()
     n = len(seq_b)
@@ -175,6 +178,11 @@ def make_read(pos, seq, cigar=None, quals=None, qual_all=30, reverse=False, dirs
         keep.append(da)
         r.dirs = da.ctypes.data_as(C.POINTER(C.c_uint8))
     r.is_reverse = 1 if reverse else 0
+    if expanded_dirs is not None:   # Read.CigarDirections.Expand()
+        ea = np.array(expanded_dirs, dtype=np.uint8)
+        keep.append(ea)
+        r.expanded_dirs = ea.ctypes.data_as(C.POINTER(C.c_uint8))
+        r.n_expanded = len(ea)
     if posmap is not None:
         pm = np.array(posmap, dtype=np.int32)
         keep.append(pm)

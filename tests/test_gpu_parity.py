@@ -1066,3 +1066,45 @@ def test_random_configuration_matrix_matches_oracle(torch_cuda):
         assert_records_match(got, exp)
         checked += 1
     assert checked == 40
+
+
+@pytest.mark.gpu
+def test_stitched_reads_with_deletions_use_the_expanded_direction_map(torch_cuda):
+    """Stitched reads (XD tag) whose deletion sits on the forward / stitched / reverse boundaries: the candidate's support direction
+    comes from the directions INSIDE the deletion (PiscesReadBatch.deletion_directions; GetDeletionDirectionForStitchedRead
+    CandidateVariantFinder.cs:468-487), so the deletion's support by direction and its strand bias differ from the anchor rule's."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(5)
+    ref = bytes(rng.choice(list(b"ACGT"), 500).astype(np.uint8))
+    reads = []
+    for k in range(300):
+        start = 100 + int(rng.integers(0, 40))
+        left = 200 - start + 1        # start..200 aligned, 201..203 deleted in every carrier
+        carrier = k % 3 != 0
+        cigar = [("M", left), ("D", 3), ("M", 60)] if carrier else [("M", left + 63)]
+        seq = (ref[start - 1:200] + ref[203:263]) if carrier else ref[start - 1:start - 1 + left + 63]
+        n_exp = sum(l for _, l in cigar)
+        a = int(rng.integers(left - 4, left + 6))          # the stitched region starts around the deletion ...
+        b = a + int(rng.integers(0, 8))                    # ... and may end inside or after it
+        reads.append({"pos": start, "cigar": cigar, "seq": seq.decode(), "quals": [35] * len(seq),
+                      "xd": f"{a}F{b - a}S{n_exp - b}R" if b > a else f"{a}F{n_exp - a}R"})
+    reads.sort(key=lambda r: r["pos"])
+    batch = _abi.ReadBatch(reads)
+    refa = np.frombuffer(ref, dtype=np.uint8)
+    kw = dict(include_reference_calls=0, min_frequency=0.01, variant_freq_filter=0.01)
+    cfg = _abi.default_config(**kw)
+    exp, exp_alleles, _, _ = orc.run_reads_full(batch, refa, 1, len(ref), cfg)
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(refa)
+        c.AddAlleleCounts(batch)
+        got, got_alleles = c.CallWithAlleles()
+    assert got_alleles == exp_alleles
+    assert_records_match(got, exp)
+    dele = got[[_abi.info_category(i) == _abi.CAT_DELETION for i in got["info"]]]
+    assert len(dele) == 1 and dele[0]["position"] == 200 and dele[0]["allele_support"] == 200
+    # the same reads without the map: the anchor rule gives other per-direction supports
+    plain = _abi.ReadBatch.from_arrays(batch.position, batch.flags, batch.cigar_offset, batch.cigar_op, batch.cigar_len, batch.seq_offset,
+                                       batch.bases, batch.quals, directions=batch.directions)
+    old, _, _, _ = orc.run_reads_full(plain, refa, 1, len(ref), cfg)
+    old_del = old[[_abi.info_category(i) == _abi.CAT_DELETION for i in old["info"]]]
+    assert list(old_del[0]["support_by_dir"]) != list(dele[0]["support_by_dir"])

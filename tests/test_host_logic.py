@@ -263,3 +263,73 @@ def test_library_full_finder_on_all_reference_cases():
                 assert m[0]["open_right"] == e["open_right"]
             n_checked += 1
     assert n_checked >= 90
+
+
+def _xd_of(expanded):
+    out, i = "", 0
+    while i < len(expanded):
+        j = i
+        while j < len(expanded) and expanded[j] == expanded[i]:
+            j += 1
+        out += f"{j - i}{'FRS'[expanded[i]]}"
+        i = j
+    return out
+
+
+def test_library_finder_stitched_deletion_directions():
+    """The deletion direction of stitched reads through the C-ABI (PiscesReadBatch.deletion_directions, filled from the XD tag by
+    _abi.directions_from_xd as the C# shim fills it from CigarDirections.Expand()): the reference's 14 scenarios, then random stitched
+    reads with deletions against the oracle's literal GetDeletionDirectionForStitchedRead on the expanded map."""
+    import json
+    doc = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "support_direction_deletion_cases.json")))
+    code = {"Forward": _abi.DIR_FORWARD, "Reverse": _abi.DIR_REVERSE, "Stitched": _abi.DIR_STITCHED}
+    rd = doc["read"]
+    ref = b"ATCG" * 5
+    reads = [{"pos": rd["position"], "cigar": orc.parse_cigar(rd["cigar"]), "seq": rd["sequence"], "quals": [30] * len(rd["sequence"]),
+              "xd": f'{c["num_forward"]}F{c["num_stitched"]}S{c["num_reverse"]}R'} for c in doc["cases"]]
+    got = engine.find_indel_candidates(_abi.ReadBatch(reads), ref, 20)
+    assert len(got) == len(doc["cases"])
+    for g, c in zip(got, doc["cases"]):
+        want = [0, 0, 0]
+        want[code[c["expected"]]] = 1
+        assert g["category"] == _abi.CAT_DELETION and g["support_by_dir"] == want, c["name"]
+
+    rng = np.random.default_rng(77)
+    ref = bytes(rng.choice(list(b"ACGT"), 700).astype(np.uint8))
+    reads, exp = [], []
+    for k in range(500):
+        ops = [("M", int(rng.integers(1, 12)))]
+        for _ in range(int(rng.integers(1, 4))):
+            ops.append((str(rng.choice(list("DDI"))), int(rng.integers(1, 7))))
+            ops.append(("M", int(rng.integers(1, 12))))
+        if rng.random() < 0.2:
+            ops.insert(0, ("S", 3))
+        n_exp = sum(l for _, l in ops)
+        # F.. S.. R.. with random cut points, as a stitcher writes the XD tag
+        a, b = sorted(rng.integers(0, n_exp + 1, 2).tolist())
+        expanded = [0] * a + [2] * (b - a) + [1] * (n_exp - b)
+        rl = sum(l for o, l in ops if o in "MIS")
+        d = {"pos": int(rng.integers(20, 600)), "cigar": ops, "seq": "".join(rng.choice(list("ACGT"), rl)),
+             "quals": rng.choice([10, 25, 37], rl, p=[.1, .2, .7]).astype(np.uint8).tolist()}
+        tracked = rng.random() < 0.8   # the rest: reads without CigarDirections in the same batch
+        sequenced, e = [], 0
+        for o, l in ops:
+            if o in "MIS":
+                sequenced += expanded[e:e + l]
+            e += l
+        if tracked:
+            d["xd"] = _xd_of(expanded)
+        else:
+            d["dirs"] = sequenced
+        reads.append(d)
+        r = orc.make_read(d["pos"], d["seq"], cigar=ops, quals=d["quals"], dirs=sequenced, expanded_dirs=expanded if tracked else None)
+        for c in orc.find_candidates(r, ref.decode()):
+            if c.category in (_abi.CAT_INSERTION, _abi.CAT_DELETION):
+                exp.append({"position": c.position, "category": c.category, "ref": c.ref.decode(), "alt": c.alt.decode(),
+                            "support_by_dir": list(c.support_by_dir), "well_anchored_by_dir": list(c.well_anchored_by_dir),
+                            "open_left": bool(c.open_left), "open_right": bool(c.open_right)})
+    batch = _abi.ReadBatch(reads)
+    assert batch.deletion_directions is not None and (batch.deletion_directions != 255).any() and (batch.deletion_directions == 255).any()
+    got = engine.find_indel_candidates(batch, ref, 20)
+    assert sum(g["category"] == _abi.CAT_DELETION for g in got) > 200
+    assert got == exp

@@ -609,3 +609,29 @@ def test_haploid_genotype_scenarios(want, prune, ref_freq, alt_freqs, coverage):
                         "coverage": coverage, "ref_support": int(float(np.float32(ref_freq)) * coverage)})
     gt, pr, per = orc.haploid_set_genotypes(alleles)
     assert gt == want and sum(pr) == prune and all(p[0] == gt for p in per)
+
+
+def test_stitched_deletion_support_direction_scenarios():
+    """GetSupportDirection for a deletion inside a stitched read (CigarDirections != null -> GetDeletionDirectionForStitchedRead,
+    CandidateVariantFinder.cs:417-420, 468-487): the reference's 14 RunDeletionScenarios."""
+    doc = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "support_direction_deletion_cases.json")))
+    code = {"Forward": _abi.DIR_FORWARD, "Reverse": _abi.DIR_REVERSE, "Stitched": _abi.DIR_STITCHED}
+    rd = doc["read"]
+    start, dl = rd["variant_start_in_read"], rd["deletion_length"]
+    ref = "ATCG" * 5
+    old_method_differs = 0
+    for case in doc["cases"]:
+        expanded = ([_abi.DIR_FORWARD] * case["num_forward"] + [_abi.DIR_STITCHED] * case["num_stitched"] + [_abi.DIR_REVERSE] * case["num_reverse"])
+        sequenced = expanded[:start] + expanded[start + dl:]   # PiscesSupportDirectionTestSetup.GetCoverageDirections :45-59
+        read = orc.make_read(rd["position"], rd["sequence"], cigar=rd["cigar"], dirs=sequenced, expanded_dirs=expanded)
+        assert orc.lib.orc_deletion_direction_for_stitched_read(read, start - 1, start) == code[case["expected"]], case["name"]
+        dels = [c for c in orc.find_candidates(read, ref) if c.category == _abi.CAT_DELETION]
+        assert len(dels) == 1 and dels[0].position == 3
+        want = [0, 0, 0]
+        want[code[case["expected"]]] = 1
+        assert list(dels[0].support_by_dir) == want, case["name"]
+        # without the expanded map the same read takes the anchor-direction fallback (:422-428)
+        plain = orc.make_read(rd["position"], rd["sequence"], cigar=rd["cigar"], dirs=sequenced)
+        old = [c for c in orc.find_candidates(plain, ref) if c.category == _abi.CAT_DELETION][0]
+        old_method_differs += list(old.support_by_dir) != want
+    assert old_method_differs >= 2   # the scenarios do tell the two branches apart
