@@ -1108,3 +1108,48 @@ def test_stitched_reads_with_deletions_use_the_expanded_direction_map(torch_cuda
     old, _, _, _ = orc.run_reads_full(plain, refa, 1, len(ref), cfg)
     old_del = old[[_abi.info_category(i) == _abi.CAT_DELETION for i in old["info"]]]
     assert list(old_del[0]["support_by_dir"]) != list(dele[0]["support_by_dir"])
+
+
+@pytest.mark.gpu
+def test_concurrent_handles_on_threads_share_nothing(torch_cuda):
+    """-threadbychr: several SmallVariantCallers (one handle each) run at once on raw threads of one process (JobManager.cs:70-73).
+    Six threads, each with its own handle, configuration (somatic / MNV + collapser / Window / diploid) and reads, three rounds each:
+    every thread's records equal the oracle's for ITS job (no global mutable state in the library; ctypes releases the GIL)."""
+    import threading
+    from pisces_amd import engine
+    modes = [dict(), dict(call_mnvs=1, collapse=1), dict(noise_model=1), dict(ploidy=1, min_frequency=0.2, variant_freq_filter=0.2),
+             dict(call_mnvs=1, max_mnv_length=5, max_gap_between_mnv=2), dict(include_reference_calls=0, strand_bias_model=1)]
+    jobs = []
+    for j, kw in enumerate(modes):
+        rng = np.random.default_rng(900 + j)
+        ref = bytes(rng.choice(list(b"ACGT"), 1500).astype(np.uint8))
+        reads = _mnv_reads(rng, ref, 1500 + 200 * j, region=(30, 1400))
+        reads.sort(key=lambda r: r["pos"])
+        batch = _abi.ReadBatch(reads)
+        refa = np.frombuffer(ref, dtype=np.uint8)
+        cfg = _abi.default_config(block_size=2000, **kw)
+        exp, exp_alleles, _, _ = orc.run_reads_full(batch, refa, 1, len(ref), cfg)
+        jobs.append((cfg, refa, batch, exp, exp_alleles))
+    errors = []
+    start = threading.Barrier(len(jobs))
+
+    def run(j):
+        try:
+            cfg, refa, batch, exp, exp_alleles = jobs[j]
+            start.wait()
+            for _ in range(3):
+                with engine.HipVariantCaller(cfg) as c:
+                    c.SetReference(refa)
+                    c.AddAlleleCounts(batch)
+                    got, got_alleles = c.CallWithAlleles()
+                assert got_alleles == exp_alleles
+                assert_records_match(got, exp)
+        except BaseException as e:   # noqa: BLE001 - reported by the main thread
+            errors.append((j, repr(e)[:400]))
+
+    threads = [threading.Thread(target=run, args=(j,)) for j in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
