@@ -511,15 +511,14 @@ constexpr int kPairsPerSuper = 3 * kPairsPerRound;   // candidates whose statist
 // One wave streams tuples[begin, end) through op(): two register batches of kWaveUnroll dwordx4 loads per lane in
 // ping-pong, so that the loads of the next batch are in flight while the current one is decoded (a lone wave has no
 // neighbour to hide its decode time behind).
-template <int NW, typename Op>
+template <int NW, typename Op, typename Pre>
 __device__ __forceinline__ void stream_tuples_wave(const uint32_t* __restrict__ tuples, int64_t begin, int64_t end, int lane, int wid,
-                                                   Op op)
+                                                   Op op, Pre pre)
 {
     int64_t abegin = (begin + 3) & ~(int64_t)3;
     int64_t aend = end & ~(int64_t)3;
     if (abegin > aend) { abegin = end; aend = end; }
     const int tid = wid * 64 + lane;
-    for (int64_t i = begin + tid; i < abegin; i += 64 * NW) op(tuples[i]);
     const u32x4* __restrict__ p4 = reinterpret_cast<const u32x4*>(tuples + abegin);
     const uint32_t n4 = (uint32_t)((aend - abegin) >> 2);   // a tile's segment is < 2^32 dwordx4
     constexpr uint32_t kBatch = 64u * kWaveUnroll;
@@ -541,10 +540,23 @@ __device__ __forceinline__ void stream_tuples_wave(const uint32_t* __restrict__ 
 #pragma unroll
         for (int u = 0; u < kWaveUnroll; u++) { op(v[u].x); op(v[u].y); op(v[u].z); op(v[u].w); }
     };
-    if ((uint32_t)wid < nb) {
+    // the first batch is requested before pre() (the workgroup's LDS set-up and its barrier): it is in flight while the histogram
+    // is cleared and the reference window arrives, instead of one memory latency after them
+    // (single-round launches, NW = 2: 51.5 -> 50.4 us at config 2; the one-wave form of multi-round launches shows no difference
+    // beyond run-to-run noise and keeps the set-up first)
+    const bool streams = (uint32_t)wid < nb;
+    if (NW == 2) {
+        if (streams) load(cur, (uint32_t)__builtin_amdgcn_readfirstlane(wid));
+        __builtin_amdgcn_sched_barrier(0);
+        pre();
+    } else {
+        pre();
+        if (streams) load(cur, (uint32_t)__builtin_amdgcn_readfirstlane(wid));
+    }
+    for (int64_t i = begin + tid; i < abegin; i += 64 * NW) op(tuples[i]);
+    if (streams) {
         uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane(wid);
         const uint32_t m = (nb - b + NW - 1) / NW;   // this wave's batches
-        load(cur, b);
         // explicit ping-pong over pairs of batches with a trip count known up front: no register copy between the
         // halves (it would wait for the batch in flight) and no mid-loop exit (its latch path would make the waitcnt
         // pass drain the batch in flight at every loop header)
@@ -610,15 +622,19 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
 #ifdef PISCES_TIMING
     const long long tc0 = wall_clock64();
 #endif
-    for (int i = threadIdx.x; i < kWaveRows * kWaveRow; i += 64 * NW) hist[i] = 0;
-    for (int i = threadIdx.x; i < kRefWin; i += 64 * NW) {
-        const int64_t ri = (int64_t)tile.start_position - kRefMargin + i - ref_start;
-        s_refwin[i] = (ri >= 0 && ri < ref_len) ? ref[ri] : (uint8_t)0;
-    }
-    for (int q = threadIdx.x; q < kQLutLds; q += 64 * NW) s_qlut[q] = (P.q_to_p_lut && q < P.q_to_p_n) ? P.q_to_p_lut[q] : q_to_p((double)q);
+    const double* const g_qlut = P.q_to_p_lut;
+    const int g_qlut_n = P.q_to_p_n;
+    auto setup = [&]() {
+        for (int i = threadIdx.x; i < kWaveRows * kWaveRow; i += 64 * NW) hist[i] = 0;
+        for (int i = threadIdx.x; i < kRefWin; i += 64 * NW) {
+            const int64_t ri = (int64_t)tile.start_position - kRefMargin + i - ref_start;
+            s_refwin[i] = (ri >= 0 && ri < ref_len) ? ref[ri] : (uint8_t)0;
+        }
+        for (int q = threadIdx.x; q < kQLutLds; q += 64 * NW) s_qlut[q] = (g_qlut && q < g_qlut_n) ? g_qlut[q] : q_to_p((double)q);
+        __syncthreads();
+    };
     P.q_to_p_lut = s_qlut;
     P.q_to_p_n = kQLutLds;
-    __syncthreads();
 
     {
         // single-round launches (NW = 2): streaming waves win the issue arbitration over waves in their call phase — the launch
@@ -628,7 +644,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
         const uint32_t min_bq_shifted = (uint32_t)min(max(P.min_bq, 0), 255) << 24;
 #if defined(PISCES_ABLATE) && PISCES_ABLATE == 2
         uint32_t acc = 0;   // development ablation: loads only
-        stream_tuples_wave<NW>(tuples, tile.tuple_begin, tile.tuple_end, l, wid, [&](uint32_t v) { acc ^= v; });
+        stream_tuples_wave<NW>(tuples, tile.tuple_begin, tile.tuple_end, l, wid, [&](uint32_t v) { acc ^= v; }, setup);
         if (acc == 0x12345u) hist[l] = (int)min_bq_shifted;
 #elif defined(PISCES_ABLATE) && PISCES_ABLATE == 3
         uint32_t acc = 0;   // development ablation: loads + decode, no LDS atomics
@@ -637,10 +653,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
             const uint32_t row = (t >> 19) & 31u;
             const uint32_t low = max(row, (row & 3u) | 16u);
             const uint32_t r = (t < min_bq_shifted) ? low : row;
-            acc += r * kWaveRow + locus; });
+            acc += r * kWaveRow + locus; }, setup);
         if (acc == 0x12345u) hist[l] = (int)min_bq_shifted;
 #else
-        stream_tuples_wave<NW>(tuples, tile.tuple_begin, tile.tuple_end, l, wid, [&](uint32_t v) { accumulate_wave(hist, v, min_bq_shifted); });
+        stream_tuples_wave<NW>(tuples, tile.tuple_begin, tile.tuple_end, l, wid, [&](uint32_t v) { accumulate_wave(hist, v, min_bq_shifted); }, setup);
 #endif
     }
     __syncthreads();
