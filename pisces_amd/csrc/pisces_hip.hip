@@ -15,6 +15,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -743,11 +744,56 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
     std::memcpy(st + off_cop, batch->cigar_op, n_cig);
     std::memcpy(st + off_clen, batch->cigar_len, n_cig * 4);
     std::memcpy(st + off_soff, batch->seq_offset, ((size_t)nr + 1) * 4);
-    std::memcpy(st + off_bases, batch->bases, n_seq);
-    std::memcpy(st + off_quals, batch->quals, n_seq);
-    if (batch->directions) std::memcpy(st + off_dirs, batch->directions, n_seq);
     std::memcpy(st + off_slots, slots.data(), ((size_t)nr + 1) * 8);
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(D_STAGE(h), st, total, hipMemcpyHostToDevice, h->stream));
+    {
+        // bases / qualities / directions are the bulk (2-3 bytes per aligned base).  Small batches: one copy into the pinned buffer,
+        // one transfer.  Large ones: slices of 8 MB, each copied by a few threads and handed to the DMA engine as soon as it is
+        // complete, so that the host copy of slice k+1 runs under the PCIe transfer of slice k.
+        struct Seg { size_t dst; const uint8_t* src; size_t len; };
+        const Seg segs[3] = {{off_bases, batch->bases, n_seq}, {off_quals, batch->quals, n_seq},
+                             {off_dirs, batch->directions, batch->directions ? n_seq : 0}};
+        const size_t bulk = 2 * n_seq + (batch->directions ? n_seq : 0);
+        constexpr size_t kSlice = (size_t)8 << 20;
+        if (bulk < 2 * kSlice) {
+            for (const Seg& g : segs) if (g.len) std::memcpy(st + g.dst, g.src, g.len);
+            PISCES_HIP_CHECK(h, hipMemcpyAsync(D_STAGE(h), st, total, hipMemcpyHostToDevice, h->stream));
+        } else {
+            // everything outside the bulk first (the descriptors before it, the slot table after it)
+            PISCES_HIP_CHECK(h, hipMemcpyAsync(D_STAGE(h), st, off_bases, hipMemcpyHostToDevice, h->stream));
+            PISCES_HIP_CHECK(h, hipMemcpyAsync(D_STAGE(h) + off_slots, st + off_slots, total - off_slots, hipMemcpyHostToDevice, h->stream));
+            struct Slice { size_t dst; const uint8_t* src; size_t len; };
+            std::vector<Slice> slices;
+            for (const Seg& g : segs)
+                for (size_t o = 0; o < g.len; o += kSlice) slices.push_back({g.dst + o, g.src + o, std::min(kSlice, g.len - o)});
+            const int n_threads = (int)std::min<size_t>(4, std::max<unsigned>(1u, std::thread::hardware_concurrency()));
+            std::vector<std::atomic<int>> parts_done(slices.size());
+            for (auto& a : parts_done) a.store(0, std::memory_order_relaxed);
+            auto worker = [&](int w) {
+                for (size_t k = 0; k < slices.size(); k++) {
+                    const size_t per = (slices[k].len + (size_t)n_threads - 1) / (size_t)n_threads, lo = std::min(slices[k].len, per * (size_t)w),
+                                 hi = std::min(slices[k].len, lo + per);
+                    if (hi > lo) std::memcpy(st + slices[k].dst + lo, slices[k].src + lo, hi - lo);
+                    parts_done[k].fetch_add(1, std::memory_order_release);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int w = 1; w < n_threads; w++) pool.emplace_back(worker, w);
+            hipError_t first_error = hipSuccess;
+            {
+                // this thread copies its share of a slice, then waits for the others' and enqueues the transfer
+                for (size_t k = 0; k < slices.size(); k++) {
+                    const size_t per = (slices[k].len + (size_t)n_threads - 1) / (size_t)n_threads, hi = std::min(slices[k].len, per);
+                    if (hi) std::memcpy(st + slices[k].dst, slices[k].src, hi);
+                    parts_done[k].fetch_add(1, std::memory_order_release);
+                    while (parts_done[k].load(std::memory_order_acquire) < n_threads) std::this_thread::yield();
+                    if (first_error == hipSuccess)
+                        first_error = hipMemcpyAsync(D_STAGE(h) + slices[k].dst, st + slices[k].dst, slices[k].len, hipMemcpyHostToDevice, h->stream);
+                }
+            }
+            for (auto& t : pool) t.join();
+            PISCES_HIP_CHECK(h, first_error);
+        }
+    }
     DevReadBatch db;
     const uint8_t* d = D_STAGE(h);
     db.position = (const int32_t*)(d + off_pos);

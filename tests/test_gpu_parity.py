@@ -525,6 +525,19 @@ def test_streaming_surface_equals_device_resident_surface_at_size(torch_cuda):
     streamed = np.concatenate(streamed)
     assert streamed.tobytes() == resident.tobytes()
     assert stats["reads"] == A * 500 and stats["observations"] == p.n_obs
+    # the whole pileup in ONE add_reads call: 20 MB of bases + qualities, staged in slices by worker threads under the PCIe transfer
+    # (stitched per-base directions ride along as a third bulk array)
+    whole = synth.reads_of(p, A, first_amplicon=0)
+    assert 2 * whole.n_bases >= (16 << 20)
+    dirs = np.where(np.repeat(whole.flags & 1, np.diff(whole.seq_offset)) == 1, _abi.DIR_REVERSE, _abi.DIR_FORWARD).astype(np.uint8)
+    with_dirs = _abi.ReadBatch.from_arrays(whole.position, whole.flags, whole.cigar_offset, whole.cigar_op, whole.cigar_len, whole.seq_offset,
+                                           whole.bases, whole.quals, directions=dirs)
+    for batch in (whole, with_dirs):
+        with engine.HipVariantCaller(cfg) as c:
+            c.SetReference(p.ref.cpu().numpy())
+            c.AddAlleleCounts(batch)
+            once = c.Call(None)
+        assert once.tobytes() == resident.tobytes()
 
 
 def test_collapser_on_open_ended_indels_matches_oracle(torch_cuda):
