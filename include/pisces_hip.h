@@ -408,6 +408,30 @@ int64_t pisces_hip_format_vcf_padded(const PiscesVcfConfig* cfg, const char* chr
                                      const int32_t* interval_ends, int32_t n_intervals, PiscesVcfPadState* state, int32_t finish,
                                      char* out, int64_t capacity);
 
+/* ---- BGZF inflate on the device (the stage upstream of the read batch) ------------------------------------
+ * A BAM file is a chain of BGZF blocks, gzip members of <= 64 KiB whose 'BC' extra subfield holds the block size; each is an
+ * independent DEFLATE stream.  Replaces BamReader.ReadBlock's per-block call into the native zlib binding
+ * (src/lib/Alignment.IO/BamReader.cs:603-645 -> SafeNativeMethods.UncompressBlock, src/lib/Common.IO/FileCompression.cs:14-16):
+ * the host walks the block headers (pisces_hip_bgzf_scan), the device inflates every block of the table at once, one lane per block. */
+typedef struct PiscesBgzfBlock {
+    int64_t  in_offset;    /* first byte of the DEFLATE payload in the file bytes */
+    int64_t  out_offset;   /* where the block's bytes go in the inflated stream (running sum of ISIZE) */
+    int32_t  in_length;    /* payload bytes (block size - header - 8 trailer bytes) */
+    int32_t  out_length;   /* ISIZE */
+    uint32_t crc32;        /* CRC-32 of the inflated bytes, from the trailer */
+    int32_t  reserved;
+} PiscesBgzfBlock;
+/* Host: the block table of file[0, n_bytes).  Returns the number of blocks (the empty end-of-file block included); fills at most
+ * `capacity` of them; *inflated_bytes = sum of ISIZE.  PISCES_E_INVALID_ARG: not a BGZF block chain (bad magic, no BC subfield, a
+ * block running past the end - what BamReader.ReadBlock throws InvalidDataException for). */
+int64_t pisces_hip_bgzf_scan(const uint8_t* file, int64_t n_bytes, PiscesBgzfBlock* blocks, int64_t capacity, int64_t* inflated_bytes);
+/* Device: inflates blocks[0, n_blocks) of the file bytes into out (host memory, out_capacity >= the blocks' last out_offset +
+ * out_length).  check_crc: the trailer CRC-32s are verified on the host afterwards.  PISCES_E_INVALID_ARG with the index of the first
+ * bad block in the message when a stream is corrupt (UncompressBlock < 0 -> ReadBlock returns -1).  kernel_ms (optional): the inflate
+ * kernel's own duration. */
+int32_t pisces_hip_bgzf_inflate(PiscesHip* h, const uint8_t* file, int64_t n_bytes, const PiscesBgzfBlock* blocks, int64_t n_blocks,
+                                uint8_t* out, int64_t out_capacity, int32_t check_crc, float* kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -241,6 +241,17 @@ class PiscesReadBatch(C.Structure):
     ]
 
 
+class PiscesBgzfBlock(C.Structure):
+    _fields_ = [
+        ("in_offset", C.c_int64),
+        ("out_offset", C.c_int64),
+        ("in_length", C.c_int32),
+        ("out_length", C.c_int32),
+        ("crc32", C.c_uint32),
+        ("reserved", C.c_int32),
+    ]
+
+
 class PiscesCandidate(C.Structure):
     _fields_ = [
         ("position", C.c_int32),

@@ -16,6 +16,7 @@
 #include <map>
 #include <string>
 #include <atomic>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -26,6 +27,7 @@
 #include "finder.h"
 #include "kernels.hip.h"
 #include "stream_kernels.hip.h"
+#include "bgzf_kernels.hip.h"
 
 using namespace pisces;
 
@@ -2105,6 +2107,117 @@ int32_t pisces_hip_probe_read_bandwidth(PiscesHip* h, int64_t nbytes, int32_t re
     }
     buf.release();
     *gb_per_s = best;
+    return PISCES_OK;
+}
+
+// ---- BGZF (row f4, upstream of the read batch) ----
+int64_t pisces_hip_bgzf_scan(const uint8_t* file, int64_t n_bytes, PiscesBgzfBlock* blocks, int64_t capacity, int64_t* inflated_bytes)
+{
+    if (!file || n_bytes < 0 || capacity < 0 || (capacity > 0 && !blocks)) return PISCES_E_INVALID_ARG;
+    int64_t pos = 0, n = 0, out = 0;
+    while (pos < n_bytes) {
+        // gzip member header (RFC 1952) with FEXTRA; BamConstants.BlockHeaderLength = 18 is the XLEN = 6 case (BamCommon.cs:989)
+        if (pos + 12 > n_bytes) return PISCES_E_INVALID_ARG;
+        const uint8_t* b = file + pos;
+        if (b[0] != 31 || b[1] != 139 || b[2] != 8 || !(b[3] & 4)) return PISCES_E_INVALID_ARG;
+        const int64_t xlen = b[10] | ((int64_t)b[11] << 8);
+        if (pos + 12 + xlen > n_bytes) return PISCES_E_INVALID_ARG;
+        int64_t bsize = -1;
+        for (int64_t x = 0; x + 4 <= xlen;) {   // the BC subfield: total block size - 1 (BamReader.cs:622)
+            const uint8_t* f = b + 12 + x;
+            const int64_t slen = f[2] | ((int64_t)f[3] << 8);
+            if (f[0] == 'B' && f[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = (f[4] | ((int64_t)f[5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        const int64_t header = 12 + xlen;
+        if (bsize < header + 8 || pos + bsize > n_bytes) return PISCES_E_INVALID_ARG;
+        const uint8_t* tr = b + bsize - 8;
+        PiscesBgzfBlock blk;
+        blk.in_offset = pos + header;
+        blk.in_length = (int32_t)(bsize - header - 8);
+        blk.crc32 = tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+        const uint32_t isize = tr[4] | ((uint32_t)tr[5] << 8) | ((uint32_t)tr[6] << 16) | ((uint32_t)tr[7] << 24);
+        if (isize > 65536u) return PISCES_E_INVALID_ARG;   // BgzfCommon.MaxBlockSize
+        blk.out_length = (int32_t)isize;
+        blk.out_offset = out;
+        blk.reserved = 0;
+        if (n < capacity) blocks[n] = blk;
+        n++;
+        out += isize;
+        pos += bsize;
+    }
+    if (inflated_bytes) *inflated_bytes = out;
+    return n;
+}
+
+static uint32_t crc32_of(const uint8_t* p, size_t n)
+{
+    static uint32_t table[8][256];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; i++)
+            for (int t = 1; t < 8; t++) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xFF];
+    });
+    uint32_t c = 0xFFFFFFFFu;
+    while (n >= 8) {   // slicing-by-8
+        const uint32_t lo = (p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)) ^ c;
+        c = table[7][lo & 0xFF] ^ table[6][(lo >> 8) & 0xFF] ^ table[5][(lo >> 16) & 0xFF] ^ table[4][lo >> 24] ^ table[3][p[4]] ^
+            table[2][p[5]] ^ table[1][p[6]] ^ table[0][p[7]];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) c = table[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+
+int32_t pisces_hip_bgzf_inflate(PiscesHip* h, const uint8_t* file, int64_t n_bytes, const PiscesBgzfBlock* blocks, int64_t n_blocks,
+                                uint8_t* out, int64_t out_capacity, int32_t check_crc, float* kernel_ms)
+{
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (!file || n_bytes <= 0 || n_blocks < 0 || (n_blocks > 0 && !blocks) || out_capacity < 0) return fail(h, PISCES_E_INVALID_ARG, "bgzf_inflate: bad arguments");
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (n_blocks == 0) return PISCES_OK;
+    int64_t out_bytes = 0;
+    for (int64_t i = 0; i < n_blocks; i++) {
+        const PiscesBgzfBlock& b = blocks[i];
+        if (b.in_offset < 0 || b.in_length < 0 || b.in_offset + b.in_length > n_bytes || b.out_offset < 0 || b.out_length < 0 ||
+            b.out_length > 65536 || b.out_offset + b.out_length > out_capacity)
+            return fail(h, PISCES_E_INVALID_ARG, "bgzf_inflate: block " + std::to_string(i) + " lies outside the file bytes or the output buffer");
+        out_bytes = std::max(out_bytes, b.out_offset + b.out_length);
+    }
+    if (out_bytes > 0 && !out) return fail(h, PISCES_E_INVALID_ARG, "bgzf_inflate: bad arguments");
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    DeviceBuf<uint8_t> d_in, d_out;
+    DeviceBuf<PiscesBgzfBlock> d_blocks;
+    DeviceBuf<int32_t> d_status;
+    PISCES_HIP_CHECK(h, d_in.reserve((size_t)n_bytes));
+    PISCES_HIP_CHECK(h, d_out.reserve((size_t)std::max<int64_t>(out_bytes, 1)));
+    PISCES_HIP_CHECK(h, d_blocks.reserve((size_t)n_blocks));
+    PISCES_HIP_CHECK(h, d_status.reserve((size_t)n_blocks));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(d_in.p, file, (size_t)n_bytes, hipMemcpyHostToDevice, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(d_blocks.p, blocks, (size_t)n_blocks * sizeof(PiscesBgzfBlock), hipMemcpyHostToDevice, h->stream));
+    hipExtLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)((n_blocks + 63) / 64)), dim3(64), 0u, h->stream, h->ev0, h->ev1, 0u,
+                          (const uint8_t*)d_in.p, (const PiscesBgzfBlock*)d_blocks.p, n_blocks, d_out.p, d_status.p);
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    std::vector<int32_t> status((size_t)n_blocks);
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(status.data(), d_status.p, status.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    if (out_bytes > 0) PISCES_HIP_CHECK(h, hipMemcpyAsync(out, d_out.p, (size_t)out_bytes, hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    if (kernel_ms) PISCES_HIP_CHECK(h, hipEventElapsedTime(kernel_ms, h->ev0, h->ev1));
+    d_in.release(); d_out.release(); d_blocks.release(); d_status.release();
+    for (int64_t i = 0; i < n_blocks; i++)
+        if (status[(size_t)i] != 0)
+            return fail(h, PISCES_E_INVALID_ARG, "bgzf_inflate: block " + std::to_string(i) + " is not a valid DEFLATE stream of its ISIZE (code " +
+                                                     std::to_string(status[(size_t)i]) + ")");
+    if (check_crc)
+        for (int64_t i = 0; i < n_blocks; i++)
+            if (crc32_of(out + blocks[i].out_offset, (size_t)blocks[i].out_length) != blocks[i].crc32)
+                return fail(h, PISCES_E_INVALID_ARG, "bgzf_inflate: CRC-32 mismatch in block " + std::to_string(i));
     return PISCES_OK;
 }
 

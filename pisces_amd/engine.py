@@ -222,6 +222,17 @@ class HipVariantCaller:
         _check(self._h, lib.pisces_hip_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
 
+    def bgzf_inflate(self, file_bytes, check_crc=True):
+        """Row f4 (upstream): every BGZF block of `file_bytes` (a BAM file or a region of one) inflated on the device, one lane per
+        block (BamReader.ReadBlock -> UncompressBlock, BamReader.cs:603-645).  Returns (inflated bytes, block table, kernel ms)."""
+        data = np.frombuffer(bytes(file_bytes), dtype=np.uint8)
+        blocks, total = bgzf_scan(data)
+        out = np.zeros(max(total, 1), dtype=np.uint8)
+        ms = C.c_float(0)
+        _check(self._h, lib.pisces_hip_bgzf_inflate(self._h, data.ctypes.data, data.size, blocks, len(blocks), out.ctypes.data, total,
+                                                    1 if check_crc else 0, C.byref(ms)))
+        return out[:total].tobytes(), blocks, ms.value
+
 
 def anchor_adjusted_count(c, minAnchor=0, maxAnchor=None, fromEnd=False, symmetric=False):
     """AlleleCountHelper.GetAnchorAdjustedAlleleCount (AlleleCountHelper.cs:21-85) over one [11] anchor row."""
@@ -321,6 +332,19 @@ def format_vcf(chrom, records, vcf_config=None, alleles=None, pad=None, **overri
 def find_indel_candidates(batch, ref, min_base_call_quality=20):
     """Host finder for insertions / deletions (pisces_hip_find_indel_candidates): list of dicts in read order."""
     return find_candidates(batch, ref, min_base_call_quality, snvs_and_mnvs=False)
+
+
+def bgzf_scan(file_bytes):
+    """pisces_hip_bgzf_scan: the BGZF block table of the file bytes (host); returns (ctypes array of PiscesBgzfBlock, inflated size)."""
+    data = file_bytes if isinstance(file_bytes, np.ndarray) else np.frombuffer(bytes(file_bytes), dtype=np.uint8)
+    total = C.c_int64(0)
+    n = lib.pisces_hip_bgzf_scan(data.ctypes.data, data.size, None, 0, C.byref(total))
+    if n < 0:
+        raise PiscesHipError(int(n), "not a chain of BGZF blocks")
+    blocks = (_abi.PiscesBgzfBlock * max(int(n), 1))()
+    n2 = lib.pisces_hip_bgzf_scan(data.ctypes.data, data.size, blocks, n, C.byref(total))
+    assert n2 == n
+    return (_abi.PiscesBgzfBlock * int(n)).from_buffer(blocks) if n else (_abi.PiscesBgzfBlock * 0)(), int(total.value)
 
 
 def find_candidates(batch, ref, min_base_call_quality=20, snvs_and_mnvs=True, call_mnvs=False, max_mnv_length=3, max_gap_between_mnv=1):

@@ -1,0 +1,122 @@
+"""SURVEY row f4 (upstream stage): BGZF inflate on the device.  The checker is zlib (RFC 1951's reference implementation, Python's
+stdlib binding - test infrastructure like oracle/): every block the device inflates must equal zlib's bytes for the same payload.
+Fixtures: BAM files the reference's own tests hold (tests/golden/bams/, data only)."""
+import gzip
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from pisces_amd import _abi, engine
+
+BAMS = os.path.join(os.path.dirname(__file__), "golden", "bams")
+NAMES = sorted(f for f in os.listdir(BAMS) if f.endswith(".bam"))
+
+
+def python_block_table(data):
+    """BGZF block walk restated in Python (SAM spec 4.1; BamReader.ReadBlock reads BSIZE at byte 16 of the 18-byte header)."""
+    out, pos, total = [], 0, 0
+    while pos < len(data):
+        assert data[pos:pos + 4] == b"\x1f\x8b\x08\x04"
+        xlen = struct.unpack_from("<H", data, pos + 10)[0]
+        extra = data[pos + 12: pos + 12 + xlen]
+        bsize, x = None, 0
+        while x + 4 <= len(extra):
+            slen = struct.unpack_from("<H", extra, x + 2)[0]
+            if extra[x:x + 2] == b"BC":
+                bsize = struct.unpack_from("<H", extra, x + 4)[0] + 1
+            x += 4 + slen
+        crc, isize = struct.unpack_from("<II", data, pos + bsize - 8)
+        out.append((pos + 12 + xlen, bsize - 12 - xlen - 8, total, isize, crc))
+        total += isize
+        pos += bsize
+    return out, total
+
+
+def make_bgzf(chunks, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
+    """chunks of <= 65280 bytes -> BGZF members + the empty end-of-file block."""
+    out = bytearray()
+    for chunk in list(chunks) + [b""]:
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+        payload = co.compress(chunk) + co.flush()
+        bsize = 18 + len(payload) + 8
+        assert bsize <= 65536 + 26
+        out += b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+        out += payload + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))
+    return bytes(out)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_block_table_of_the_reference_bams(name):
+    data = open(os.path.join(BAMS, name), "rb").read()
+    blocks, total = engine.bgzf_scan(data)
+    exp, exp_total = python_block_table(data)
+    assert total == exp_total and len(blocks) == len(exp) and len(exp) >= 2
+    for b, e in zip(blocks, exp):
+        assert (b.in_offset, b.in_length, b.out_offset, b.out_length, b.crc32) == e
+    assert blocks[len(blocks) - 1].out_length == 0   # the end-of-file marker block
+    # the checker itself agrees with the gzip reader on these files
+    assert sum(len(zlib.decompress(data[o:o + n], -15)) for o, n, *_ in exp) == len(gzip.decompress(data)) == total
+
+
+def test_scan_rejects_what_is_not_bgzf():
+    data = open(os.path.join(BAMS, NAMES[0]), "rb").read()
+    for bad in (data[:-1], b"BAM\x01" + data, data[:10], gzip.compress(b"plain gzip has no BC field")):
+        with pytest.raises(engine.PiscesHipError):
+            engine.bgzf_scan(bad)
+    blocks, total = engine.bgzf_scan(b"")
+    assert len(blocks) == 0 and total == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_device_inflate_of_the_reference_bams_equals_zlib(name):
+    data = open(os.path.join(BAMS, name), "rb").read()
+    with engine.HipVariantCaller(_abi.default_config()) as c:
+        got, blocks, ms = c.bgzf_inflate(data)
+    exp = b"".join(zlib.decompress(data[b.in_offset:b.in_offset + b.in_length], -15) for b in blocks)
+    assert got == exp and got == gzip.decompress(data)
+    assert got[:4] == b"BAM\x01" and ms > 0
+
+
+@pytest.mark.gpu
+def test_device_inflate_on_synthetic_streams(tmp_path):
+    """Stored / fixed / dynamic blocks, every compression level, runs (distance 1), maximum-size blocks, empty blocks, several DEFLATE
+    blocks in one member; a corrupt payload and a wrong CRC are reported, not returned."""
+    rng = np.random.default_rng(3)
+    text = bytes(rng.choice(list(b"ACGTN\n\t0123456789"), 400_000, p=[.2, .2, .2, .2, .02, .02, .02] + [.014] * 10).astype(np.uint8))
+    noise = rng.integers(0, 256, 200_000, dtype=np.uint8).tobytes()
+    runs = b"".join(bytes([int(v)]) * int(n) for v, n in zip(rng.integers(0, 256, 400), rng.integers(1, 600, 400)))
+    cases = []
+    for level in (0, 1, 6, 9):
+        for src in (text, noise, runs):
+            cases.append(make_bgzf([src[i:i + 65280] for i in range(0, len(src), 65280)], level))
+    cases.append(make_bgzf([text[:65280]], 6, zlib.Z_FIXED))
+    cases.append(make_bgzf([text[:3000]], 6, zlib.Z_HUFFMAN_ONLY))
+    cases.append(make_bgzf([b"", b"A", b"", text[:17], b"\0" * 65280]))
+    # a member whose stream holds several DEFLATE blocks (sync flushes add empty stored blocks in between)
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    parts = co.compress(text[:20000]) + co.flush(zlib.Z_FULL_FLUSH) + co.compress(noise[:3000]) + co.flush(zlib.Z_SYNC_FLUSH) + co.compress(runs[:9000]) + co.flush()
+    chunk = text[:20000] + noise[:3000] + runs[:9000]
+    multi = (b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 18 + len(parts) + 8 - 1) + parts +
+             struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+    cases.append(multi + make_bgzf([]))
+    with engine.HipVariantCaller(_abi.default_config()) as c:
+        for data in cases:
+            got, blocks, _ = c.bgzf_inflate(data)
+            assert got == gzip.decompress(data)
+        good = bytearray(cases[4])
+        blocks, _ = engine.bgzf_scan(bytes(good))
+        bad = bytearray(good)
+        o = blocks[1].in_offset
+        bad[o: o + 40] = bytes(40)   # block 1's stream: garbage
+        with pytest.raises(engine.PiscesHipError, match="block 1"):
+            c.bgzf_inflate(bytes(bad))
+        bad = bytearray(good)
+        bad[blocks[0].in_offset + blocks[0].in_length] ^= 0xFF   # first CRC byte of block 0
+        with pytest.raises(engine.PiscesHipError, match="CRC-32 mismatch in block 0"):
+            c.bgzf_inflate(bytes(bad))
+        got, _, _ = c.bgzf_inflate(bytes(bad), check_crc=False)
+        assert got == gzip.decompress(bytes(good))
