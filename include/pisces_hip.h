@@ -412,7 +412,7 @@ int64_t pisces_hip_format_vcf_padded(const PiscesVcfConfig* cfg, const char* chr
  * A BAM file is a chain of BGZF blocks, gzip members of <= 64 KiB whose 'BC' extra subfield holds the block size; each is an
  * independent DEFLATE stream.  Replaces BamReader.ReadBlock's per-block call into the native zlib binding
  * (src/lib/Alignment.IO/BamReader.cs:603-645 -> SafeNativeMethods.UncompressBlock, src/lib/Common.IO/FileCompression.cs:14-16):
- * the host walks the block headers (pisces_hip_bgzf_scan), the device inflates every block of the table at once, one lane per block. */
+ * the host walks the block headers (pisces_hip_bgzf_scan), the device inflates every block of the table at once, one wave per block. */
 typedef struct PiscesBgzfBlock {
     int64_t  in_offset;    /* first byte of the DEFLATE payload in the file bytes */
     int64_t  out_offset;   /* where the block's bytes go in the inflated stream (running sum of ISIZE) */

@@ -2195,13 +2195,14 @@ int32_t pisces_hip_bgzf_inflate(PiscesHip* h, const uint8_t* file, int64_t n_byt
     DeviceBuf<uint8_t> d_in, d_out;
     DeviceBuf<PiscesBgzfBlock> d_blocks;
     DeviceBuf<int32_t> d_status;
-    PISCES_HIP_CHECK(h, d_in.reserve((size_t)n_bytes));
+    PISCES_HIP_CHECK(h, d_in.reserve((size_t)n_bytes + 16));   // the bit reader loads whole words: a few bytes past a block's payload
+    PISCES_HIP_CHECK(h, hipMemsetAsync(d_in.p + n_bytes, 0, 16, h->stream));
     PISCES_HIP_CHECK(h, d_out.reserve((size_t)std::max<int64_t>(out_bytes, 1)));
     PISCES_HIP_CHECK(h, d_blocks.reserve((size_t)n_blocks));
     PISCES_HIP_CHECK(h, d_status.reserve((size_t)n_blocks));
     PISCES_HIP_CHECK(h, hipMemcpyAsync(d_in.p, file, (size_t)n_bytes, hipMemcpyHostToDevice, h->stream));
     PISCES_HIP_CHECK(h, hipMemcpyAsync(d_blocks.p, blocks, (size_t)n_blocks * sizeof(PiscesBgzfBlock), hipMemcpyHostToDevice, h->stream));
-    hipExtLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)((n_blocks + 63) / 64)), dim3(64), 0u, h->stream, h->ev0, h->ev1, 0u,
+    hipExtLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)n_blocks), dim3(64), 0u, h->stream, h->ev0, h->ev1, 0u,
                           (const uint8_t*)d_in.p, (const PiscesBgzfBlock*)d_blocks.p, n_blocks, d_out.p, d_status.p);
     PISCES_HIP_CHECK(h, hipGetLastError());
     std::vector<int32_t> status((size_t)n_blocks);

@@ -223,7 +223,7 @@ class HipVariantCaller:
         return ms.value
 
     def bgzf_inflate(self, file_bytes, check_crc=True):
-        """Row f4 (upstream): every BGZF block of `file_bytes` (a BAM file or a region of one) inflated on the device, one lane per
+        """Row f4 (upstream): every BGZF block of `file_bytes` (a BAM file or a region of one) inflated on the device, one wave per
         block (BamReader.ReadBlock -> UncompressBlock, BamReader.cs:603-645).  Returns (inflated bytes, block table, kernel ms)."""
         data = np.frombuffer(bytes(file_bytes), dtype=np.uint8)
         blocks, total = bgzf_scan(data)
