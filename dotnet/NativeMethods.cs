@@ -54,6 +54,15 @@ namespace Pisces.Hip
         public byte* DeletionDirections;   // 2 per CIGAR op: first / last deleted base of a D op in CigarDirections.Expand(), 255 = untracked
     }
 
+    [StructLayout(LayoutKind.Sequential, Size = 32)]
+    public struct PiscesBgzfBlock
+    {
+        public long InOffset, OutOffset;
+        public int InLength, OutLength;
+        public uint Crc32;
+        public int Reserved;
+    }
+
     [StructLayout(LayoutKind.Sequential, Size = 56)]
     public struct PiscesCandidate
     {
@@ -107,6 +116,9 @@ namespace Pisces.Hip
         // measurement helpers (bench / diagnostics)
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_set_timing(IntPtr handle, int everyNth);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_last_kernel_ms(IntPtr handle, out float ms);
+        // BGZF: the batched counterpart of Common.IO.SafeNativeMethods.UncompressBlock (FileCompression.cs:14-16)
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern long pisces_hip_bgzf_scan(byte[] file, long nBytes, [Out] PiscesBgzfBlock[] blocks, long capacity, out long inflatedBytes);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_bgzf_inflate(IntPtr handle, byte[] file, long nBytes, PiscesBgzfBlock[] blocks, long nBlocks, [Out] byte[] output, long outCapacity, int checkCrc, out float kernelMs);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_probe_read_bandwidth(IntPtr handle, long nBytes, int reps, out double gbPerSecond);
         // VCF body lines straight from the records (what VcfFileWriter.WriteListOfColocatedAlleles writes per allele, Pisces.IO/VcfFileWriter.cs:206-262)
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_vcf_default_config(out PiscesVcfConfig cfg);

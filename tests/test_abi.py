@@ -32,6 +32,7 @@ def test_struct_layouts_match_header():
     assert _abi.TILE_DTYPE.itemsize == 24 and _abi.TILE_RESULT_DTYPE.itemsize == 48
     assert C.sizeof(_abi.PiscesHipConfig) == 4 * 41
     assert C.sizeof(_abi.PiscesCandidate) == 56
+    assert C.sizeof(_abi.PiscesBgzfBlock) == 32
     d = _abi.CALLED_ALLELE_DTYPE
     assert d.fields["strand_bias_score"][1] == 48 and d.fields["genotype_qscore"][1] == 56
     assert d.fields["filter_bits"][1] == 60 and d.fields["info"][1] == 62
