@@ -2185,8 +2185,8 @@ int32_t pisces_hip_bgzf_inflate(PiscesHip* h, const uint8_t* file, int64_t n_byt
     int64_t out_bytes = 0;
     for (int64_t i = 0; i < n_blocks; i++) {
         const PiscesBgzfBlock& b = blocks[i];
-        if (b.in_offset < 0 || b.in_length < 0 || b.in_offset + b.in_length > n_bytes || b.out_offset < 0 || b.out_length < 0 ||
-            b.out_length > 65536 || b.out_offset + b.out_length > out_capacity)
+        if (b.in_offset < 0 || b.in_length < 0 || b.in_length > 65536 || b.in_offset + b.in_length > n_bytes || b.out_offset < 0 ||
+            b.out_length < 0 || b.out_length > 65536 || b.out_offset + b.out_length > out_capacity)   // BgzfCommon.MaxBlockSize both ways
             return fail(h, PISCES_E_INVALID_ARG, "bgzf_inflate: block " + std::to_string(i) + " lies outside the file bytes or the output buffer");
         out_bytes = std::max(out_bytes, b.out_offset + b.out_length);
     }

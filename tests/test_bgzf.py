@@ -120,3 +120,40 @@ def test_device_inflate_on_synthetic_streams(tmp_path):
             c.bgzf_inflate(bytes(bad))
         got, _, _ = c.bgzf_inflate(bytes(bad), check_crc=False)
         assert got == gzip.decompress(bytes(good))
+
+
+@pytest.mark.gpu
+def test_device_inflate_survives_corrupted_streams():
+    """300 mutated copies of valid members (bit flips, zeroed and randomised stretches, truncated payloads with the table left as it
+    was): every call returns - with an error naming a block, or with exactly zlib's bytes when the damage missed the stream - and the
+    next call on the same handle still works.  (The decoder's loops are bounded by ISIZE and by the payload length.)"""
+    rng = np.random.default_rng(11)
+    text = bytes(rng.choice(list(b"ACGT\n0123456789"), 150_000).astype(np.uint8))
+    base = [make_bgzf([text[i:i + 50_000] for i in range(0, len(text), 50_000)], lvl, st)
+            for lvl, st in ((6, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (0, zlib.Z_DEFAULT_STRATEGY))]
+    errors = same = 0
+    with engine.HipVariantCaller(_abi.default_config()) as c:
+        for trial in range(300):
+            good = base[trial % len(base)]
+            blocks, _ = engine.bgzf_scan(good)
+            b = blocks[int(rng.integers(0, len(blocks) - 1))]
+            bad = bytearray(good)
+            kind = trial % 3
+            at = b.in_offset + int(rng.integers(0, max(b.in_length - 8, 1)))
+            if kind == 0:
+                bad[at] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1:
+                n = int(rng.integers(1, 64))
+                bad[at:at + n] = rng.integers(0, 256, n, dtype=np.uint8).tobytes()[: len(bad[at:at + n])]
+            else:
+                bad[at:b.in_offset + b.in_length] = bytes(b.in_offset + b.in_length - at)
+            try:
+                got, _, _ = c.bgzf_inflate(bytes(bad))
+                assert got == gzip.decompress(good)
+                same += 1
+            except engine.PiscesHipError as e:
+                assert "block" in str(e)
+                errors += 1
+        got, _, _ = c.bgzf_inflate(base[0])
+        assert got == text
+    assert errors > 250 and errors + same == 300
