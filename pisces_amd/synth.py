@@ -172,7 +172,8 @@ def observations_of(p, n_tiles=None):
     """(positions, tuples) numpy arrays of the first `n_tiles` tiles, padding removed, tile order kept."""
     tiles = p.tiles.cpu().numpy().view(_abi.TILE_DTYPE)
     nt = p.n_tiles if n_tiles is None else min(p.n_tiles, n_tiles)
-    tup = p.tuples.cpu().numpy().view(np.uint32)
+    hi = int(tiles[nt - 1]["tuple_end"]) if nt > 0 else 0   # only the tiles asked for leave the device
+    tup = p.tuples[:hi].cpu().numpy().view(np.uint32)
     pos_out, tup_out = [], []
     for t in range(nt):
         b, e = int(tiles[t]["tuple_begin"]), int(tiles[t]["tuple_end"])

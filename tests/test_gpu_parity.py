@@ -365,6 +365,41 @@ def test_full_size_properties_config2(torch_cuda):
     assert_records_match(got[got["position"] < p.region_start + n_t * 64], exp)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_loci,depth,synth_kw,cfg_kw", [
+    (1_000_000, 2000, {}, {}),                                                             # BASELINE config 3 size (SNV-only pileup)
+    (3_750_000, 200, {}, {}),                                                              # config 4: one GPU's eighth of 30 M loci x 200x
+    (100_000, 5000, dict(vaf_range=(0.005, 0.005)),                                        # config 5: 0.5 % VAF at 5000x, gVCF, filters on
+     dict(min_frequency=0.002, variant_freq_filter=0.002, noise_level=35)),                 # -nl 35: 25 of 5000 reads stand out of 1.6 expected errors
+], ids=["config3_1Mx2000", "config4_shard_3.75Mx200", "config5_100kx5000_lowvaf"])
+def test_full_size_properties_other_baseline_configs(torch_cuda, n_loci, depth, synth_kw, cfg_kw):
+    """The other BASELINE sizes through size-independent properties: idempotence (the same launch twice, byte for byte), exact depth at
+    every locus, one candidate locus per locus, sortedness, planted low-frequency variants found, and the first 640 loci against the oracle."""
+    from pisces_amd import engine, synth
+    torch = torch_cuda
+    p = synth.make_pileup(n_loci=n_loci, depth=depth, seed=5, device="cuda", **synth_kw)
+    p.base = p.qual = None
+    torch.cuda.empty_cache()
+    cfg = _abi.default_config(**cfg_kw)
+    with engine.HipVariantCaller(cfg) as caller:
+        got, tr = run_fused(torch, caller, p)
+        again, _ = run_fused(torch, caller, p)
+    assert got.tobytes() == again.tobytes()
+    assert int(tr["n_candidate_loci"].sum()) == n_loci
+    assert ((got["total_coverage"] + got["num_no_calls"]) == depth).all()
+    assert (np.diff(got["position"]) >= 0).all()
+    cats = (got["info"] >> 4) & 7
+    n_planted = len(p.planted)
+    found = np.isin(got["position"][cats == _abi.CAT_SNV] - p.region_start, p.planted.cpu().numpy() if hasattr(p.planted, "cpu") else p.planted)
+    assert found.sum() >= 0.9 * n_planted, (int(found.sum()), n_planted)
+    n_t = 10
+    pos, tup = synth.observations_of(p, n_t)
+    exp, _ = orc.run_observations(pos, tup, p.ref.cpu().numpy(), p.region_start, n_t * 64, cfg)
+    assert_records_match(got[got["position"] < p.region_start + n_t * 64], exp)
+    del p
+    torch.cuda.empty_cache()
+
+
 # ---------------------------------------------------------------- insertions / deletions (host finder + spanning coverage on the device)
 def _indel_reads(rng, ref, start, depth, plan, read_len=150, p_lowq=0.02):
     """`depth` reads of one amplicon at `start`; plan = list of (offset_in_read, kind 'D'|'I', length, fraction)."""
