@@ -1,6 +1,6 @@
 """SURVEY row f4 (upstream stage): BGZF inflate on the device.  The checker is zlib (RFC 1951's reference implementation, Python's
 stdlib binding - test infrastructure like oracle/): every block the device inflates must equal zlib's bytes for the same payload.
-Fixtures: BAM files the reference's own tests hold (tests/golden/bams/, data only)."""
+Fixtures: the bytes of four BAM files the reference's own tests hold (tests/golden/bgzf_fixtures.npz, data only)."""
 import gzip
 import os
 import struct
@@ -11,8 +11,12 @@ import pytest
 
 from pisces_amd import _abi, engine
 
-BAMS = os.path.join(os.path.dirname(__file__), "golden", "bams")
-NAMES = sorted(f for f in os.listdir(BAMS) if f.endswith(".bam"))
+_FIXTURES = np.load(os.path.join(os.path.dirname(__file__), "golden", "bgzf_fixtures.npz"))
+NAMES = sorted(_FIXTURES.files)
+
+
+def bam_bytes(name):
+    return _FIXTURES[name].tobytes()
 
 
 def python_block_table(data):
@@ -50,7 +54,7 @@ def make_bgzf(chunks, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
 
 @pytest.mark.parametrize("name", NAMES)
 def test_block_table_of_the_reference_bams(name):
-    data = open(os.path.join(BAMS, name), "rb").read()
+    data = bam_bytes(name)
     blocks, total = engine.bgzf_scan(data)
     exp, exp_total = python_block_table(data)
     assert total == exp_total and len(blocks) == len(exp) and len(exp) >= 2
@@ -62,7 +66,7 @@ def test_block_table_of_the_reference_bams(name):
 
 
 def test_scan_rejects_what_is_not_bgzf():
-    data = open(os.path.join(BAMS, NAMES[0]), "rb").read()
+    data = bam_bytes(NAMES[0])
     for bad in (data[:-1], b"BAM\x01" + data, data[:10], gzip.compress(b"plain gzip has no BC field")):
         with pytest.raises(engine.PiscesHipError):
             engine.bgzf_scan(bad)
@@ -73,7 +77,7 @@ def test_scan_rejects_what_is_not_bgzf():
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", NAMES)
 def test_device_inflate_of_the_reference_bams_equals_zlib(name):
-    data = open(os.path.join(BAMS, name), "rb").read()
+    data = bam_bytes(name)
     with engine.HipVariantCaller(_abi.default_config()) as c:
         got, blocks, ms = c.bgzf_inflate(data)
     exp = b"".join(zlib.decompress(data[b.in_offset:b.in_offset + b.in_length], -15) for b in blocks)
