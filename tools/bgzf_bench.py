@@ -32,6 +32,9 @@ def main():
         got, blocks, ms = c.bgzf_inflate(data, check_crc=False)
         got, blocks, ms = c.bgzf_inflate(data, check_crc=False)
         t0 = time.perf_counter()
+        c.bgzf_inflate(data, check_crc=False)
+        wall_nocrc = time.perf_counter() - t0
+        t0 = time.perf_counter()
         got2, _, _ = c.bgzf_inflate(data, check_crc=True)
         wall = time.perf_counter() - t0
     assert got == src
@@ -40,7 +43,7 @@ def main():
     nb = sum(len(zlib.decompress(data[b.in_offset:b.in_offset + b.in_length], -15)) for b in sample)
     cpu = nb / (time.perf_counter() - t0)
     print(f"bgzf inflate: {len(src)/1e6:.0f} MB inflated from {len(data)/1e6:.0f} MB in {len(blocks)} blocks: kernel {ms:.2f} ms = "
-          f"{len(src)/ms/1e6:.2f} GB/s inflated; call incl. PCIe both ways + CRC check {wall*1e3:.0f} ms; zlib on one core {cpu/1e6:.0f} MB/s")
+          f"{len(src)/ms/1e6:.2f} GB/s inflated; call incl. PCIe both ways {wall_nocrc*1e3:.0f} ms, with the CRC check {wall*1e3:.0f} ms; zlib on one core {cpu/1e6:.0f} MB/s")
 
 
 if __name__ == "__main__":
