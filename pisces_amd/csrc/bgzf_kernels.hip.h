@@ -54,7 +54,10 @@ __device__ __forceinline__ void inflate_refill(InflateStream& s)
         // in bounds; consuming bits that lie past the payload is the error
         if (s.in_pos >= s.in_len + 8) { s.err = s.err ? s.err : kInflateInputExhausted; return; }
         const uint8_t* p = s.in + s.in_pos;
-        const uint32_t w = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+        // every lane loads the same word; telling the compiler so keeps the bit buffer and all that follows from it (symbols, lengths,
+        // the branches on them) in scalar registers and scalar branches instead of 64-wide copies under exec masks
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane(
+            (int)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)));
         s.bitbuf |= (uint64_t)w << s.bitcnt;
         s.bitcnt += 32;
         s.in_pos += 4;
@@ -89,7 +92,7 @@ __device__ __forceinline__ void wave_lds_fence()
 __device__ __forceinline__ int inflate_decode(InflateStream& s, const HuffmanTable& h)
 {
     inflate_refill(s);
-    const uint32_t e = h.lut[(uint32_t)s.bitbuf & (kLutSize - 1)];
+    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)h.lut[(uint32_t)s.bitbuf & (kLutSize - 1)]);
     if (e) {
         const int n = (int)(e & 15u);
         s.bitbuf >>= n;
@@ -101,11 +104,11 @@ __device__ __forceinline__ int inflate_decode(InflateStream& s, const HuffmanTab
     for (int len = 1; len <= 15; len++) {
         code |= (int)(bits & 1u);
         bits >>= 1;
-        const int count = h.count[len];
+        const int count = __builtin_amdgcn_readfirstlane((int)h.count[len]);
         if (code - count < first) {
             s.bitbuf >>= len;
             s.bitcnt -= len;
-            return h.symbol[index + (code - first)];
+            return __builtin_amdgcn_readfirstlane((int)h.symbol[index + (code - first)]);
         }
         index += count;
         first += count;
