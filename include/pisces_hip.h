@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define PISCES_HIP_ABI_VERSION 5
+#define PISCES_HIP_ABI_VERSION 6
 
 /* ---- error codes -------------------------------------------------------- */
 #define PISCES_OK                 0
@@ -66,23 +66,39 @@ enum { PISCES_PLOIDY_SOMATIC = 0, PISCES_PLOIDY_DIPLOID = 1, PISCES_PLOIDY_HAPLO
 #define PISCES_FOLDED_PER_LOCUS (PISCES_NUM_ALLELE_TYPES * PISCES_NUM_DIRECTIONS)                      /* 18  */
 
 /* ---- packed observation tuple (4 bytes) ---------------------
- * bit  0..14  locus-in-tile (15 bits)
- * bit 15..18  anchor bin 0..10  (GetAnchorType, RegionStateManager.cs:83-116)
- * bit 19..20  direction 0..2
- * bit 21..23  raw allele code 0..5 (before the min-base-quality test)
+ * Laid out so that the hot kernel's LDS counter address is a mask of the tuple: bits 2..12 are the byte
+ * offset of the (allele, direction, column) counter in a [32 rows][64 columns] int32 histogram.
+ * bit  0..1   zero
+ * bit  2..7   column = PISCES_TUPLE_COLUMN(locus-in-tile, direction): a bank-spreading bijection of the locus
+ *             (0..63).  A dwordx4 load hands each lane four consecutive loci of a read, so one LDS instruction sees the
+ *             loci c + 4q of a few reads: the column puts q in the low four bank bits and the direction parity in
+ *             the fifth, so a forward and a reverse read of the same loci never meet on a bank.
+ * bit  8..9   direction 0..2
+ * bit 10..12  raw allele code 0..5 (before the min-base-quality test)
+ * bit 13..16  anchor bin 0..10  (GetAnchorType, RegionStateManager.cs:83-116)
+ * bit 17..23  zero
  * bit 24..31  base quality (deletion tuples carry 255: their quality gate,
  *             CheckDeletionQuality, was applied when the read was expanded)
- * The kernel applies "qual < minBQ -> N" (RegionStateManager.cs:179-181). */
-#define PISCES_TUPLE_LOCUS_BITS 15
-#define PISCES_TUPLE_MAX_TILE   (1 << PISCES_TUPLE_LOCUS_BITS)
+ * The kernel applies "qual < minBQ -> N" (RegionStateManager.cs:179-181).
+ * A tile has at most 64 loci, so every column value is a locus of the tile: no tuple can address memory outside its
+ * tile's histogram; allele codes 6, 7 and direction 3 select rows nobody reads. */
+#define PISCES_TUPLE_MAX_TILE   64
+#define PISCES_TUPLE_COLUMN(locus, dir) \
+    (((((uint32_t)(locus) >> 2) & 15u) | (((uint32_t)(locus) & 3u) << 4)) ^ (((uint32_t)(dir) & 1u) << 4))
 #define PISCES_TUPLE_PACK(locus, anchor, dir, allele, qual) \
-    ((uint32_t)(locus) | ((uint32_t)(anchor) << 15) | ((uint32_t)(dir) << 19) | \
-     ((uint32_t)(allele) << 21) | ((uint32_t)(qual) << 24))
-#define PISCES_TUPLE_LOCUS(t)  ((t) & 0x7FFFu)
-#define PISCES_TUPLE_ANCHOR(t) (((t) >> 15) & 0xFu)
-#define PISCES_TUPLE_DIR(t)    (((t) >> 19) & 0x3u)
-#define PISCES_TUPLE_ALLELE(t) (((t) >> 21) & 0x7u)
+    ((PISCES_TUPLE_COLUMN(locus, dir) << 2) | ((uint32_t)(dir) << 8) | ((uint32_t)(allele) << 10) | \
+     ((uint32_t)(anchor) << 13) | ((uint32_t)(qual) << 24))
+#define PISCES_TUPLE_DIR(t)    (((t) >> 8) & 0x3u)
+#define PISCES_TUPLE_ALLELE(t) (((t) >> 10) & 0x7u)
+#define PISCES_TUPLE_ANCHOR(t) (((t) >> 13) & 0xFu)
 #define PISCES_TUPLE_QUAL(t)   ((t) >> 24)
+#define PISCES_TUPLE_COL(t)    (((t) >> 2) & 63u)
+/* inverse of PISCES_TUPLE_COLUMN */
+#define PISCES_TUPLE_LOCUS_OF(col, dir) \
+    ((((((uint32_t)(col)) ^ (((uint32_t)(dir) & 1u) << 4)) & 15u) << 2) | ((((uint32_t)(col)) ^ (((uint32_t)(dir) & 1u) << 4)) >> 4))
+#define PISCES_TUPLE_LOCUS(t)  PISCES_TUPLE_LOCUS_OF(PISCES_TUPLE_COL(t), PISCES_TUPLE_DIR(t))
+/* the tuple with another locus (same observation) */
+#define PISCES_TUPLE_WITH_LOCUS(t, locus) (((t) & ~0xFCu) | (PISCES_TUPLE_COLUMN(locus, PISCES_TUPLE_DIR(t)) << 2))
 /* A tuple with all bits set is padding and is ignored by every kernel. */
 #define PISCES_TUPLE_PAD 0xFFFFFFFFu
 

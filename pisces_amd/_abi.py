@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # error codes
 OK = 0
@@ -43,14 +43,36 @@ COUNTS_PER_LOCUS = 6 * 3 * NUM_ANCHORS
 TUPLE_PAD = 0xFFFFFFFF
 
 
+def tuple_column(locus, direction):
+    """PISCES_TUPLE_COLUMN: the bank-spreading bijection of the locus-in-tile (include/pisces_hip.h)."""
+    return ((((locus >> 2) & 15) | ((locus & 3) << 4)) ^ ((direction & 1) << 4))
+
+
 def tuple_pack(locus, anchor, direction, allele, qual):
-    """PISCES_TUPLE_PACK; works on ints and numpy arrays."""
+    """PISCES_TUPLE_PACK; works on ints, numpy arrays and torch tensors."""
     if isinstance(locus, np.ndarray):
-        return (locus.astype(np.uint32) | (np.asarray(anchor).astype(np.uint32) << np.uint32(15))
-                | (np.asarray(direction).astype(np.uint32) << np.uint32(19))
-                | (np.asarray(allele).astype(np.uint32) << np.uint32(21))
-                | (np.asarray(qual).astype(np.uint32) << np.uint32(24)))
-    return (locus | (anchor << 15) | (direction << 19) | (allele << 21) | (qual << 24)) & 0xFFFFFFFF
+        locus, anchor, direction, allele, qual = (np.asarray(x).astype(np.uint32) for x in (locus, anchor, direction, allele, qual))
+        return ((tuple_column(locus, direction) << np.uint32(2)) | (direction << np.uint32(8)) | (allele << np.uint32(10))
+                | (anchor << np.uint32(13)) | (qual << np.uint32(24)))
+    v = (tuple_column(locus, direction) << 2) | (direction << 8) | (allele << 10) | (anchor << 13) | (qual << 24)
+    return v & 0xFFFFFFFF if isinstance(v, int) else v
+
+
+def tuple_fields(t):
+    """(locus, anchor, direction, allele, qual) of packed tuples (numpy uint32 array or int)."""
+    if isinstance(t, np.ndarray):
+        t = t.astype(np.uint32)
+    col, d = (t >> 2) & 63, (t >> 8) & 3
+    c = col ^ ((d & 1) << 4)
+    locus = ((c & 15) << 2) | (c >> 4)
+    return locus, (t >> 13) & 15, d, (t >> 10) & 7, t >> 24
+
+
+def tuple_with_locus(t, locus):
+    """PISCES_TUPLE_WITH_LOCUS on numpy uint32 arrays."""
+    t = np.asarray(t).astype(np.uint32)
+    locus = np.asarray(locus).astype(np.uint32)
+    return (t & ~np.uint32(0xFC)) | (tuple_column(locus, (t >> np.uint32(8)) & np.uint32(3)) << np.uint32(2))
 
 
 class PiscesHipConfig(C.Structure):

@@ -30,23 +30,18 @@ def is_stale():
 
 def build_native(force=False, verbose=False, extra_flags=(), out=None):
     """out != None builds a development variant (e.g. an ablation) next to the product library."""
-    global LIB
-    if out is not None:
-        saved, LIB = LIB, out
-        try:
-            return build_native(force=True, verbose=verbose, extra_flags=extra_flags)
-        finally:
-            LIB = saved
-    if not force and not is_stale():
-        return LIB
+    lib = LIB if out is None else out
+    if out is None and not force and not is_stale():
+        return lib
+    tmp = f"{lib}.{os.getpid()}.tmp"
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
            "-fno-fast-math", "-Wall", "-Wno-unused-function", "-x", "hip",
-           *extra_flags, *[os.path.join(CSRC, s) for s in SOURCES], "-lpthread", "-o", LIB + ".tmp"]
+           *extra_flags, *[os.path.join(CSRC, s) for s in SOURCES], "-lpthread", "-o", tmp]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(tmp, lib)
+    return lib
 
 
 if __name__ == "__main__":

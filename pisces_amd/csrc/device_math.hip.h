@@ -33,6 +33,17 @@ struct DeviceParams {
     const double* gq_tail;
     int32_t gq_tail_a, gq_tail_cov;
     int32_t refs_only;   // MNV calling on: SNV candidates come from the read walk, the tile kernels emit Reference records only
+    // Memo tables of the call phase, all filled once per handle BY THE DEVICE with the very functions they stand in for
+    // (build_call_tables_kernel), so a hit is bit-identical to the evaluation it replaces; `tab_cov` columns (coverage) each:
+    //   vq_tab[k * tab_cov + cov]  = poisson_qscore(k, cov)                                    1 <= k < vq_tab_k   (NoiseModel.Flat)
+    //   sb_tab[k * tab_cov + cov]  = fmax(0, poisson_cdf_sb(k - 1, cov * err_sb))              1 <= k < sb_tab_k   (ChanceVarFreqGreaterThanZero)
+    //   sb0_tab[cov]               = pow(1 - err_sb, cov)                                      support == 0, Extended model
+    //   gq_cap[a * gq_tail_cov + cov] = the hom-ref / hom-alt genotype q-score of an allele whose variant q-score is max_vq
+    const int16_t* vq_tab;
+    const double* sb_tab;
+    const double* sb0_tab;
+    const int16_t* gq_cap;
+    int32_t vq_tab_k, sb_tab_k, tab_cov;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -261,7 +272,8 @@ __device__ inline double mathnet_gamma_lower_regularized(double a, double x, dou
 // lib/Pisces.Calculators/VariantQualityCalculator.cs:27-65
 // ------------------------------------------------------------------------------------------
 // err = MathOperations.QtoP(noise level): P.err_q with NoiseModel.Flat, the allele's own with NoiseModel.Window
-__device__ inline int32_t poisson_qscore_e(int32_t callCount, int32_t coverage, double err, const DeviceParams& P)
+struct QParams { int32_t max_vq; double ln10; };
+__device__ inline int32_t poisson_qscore_core(int32_t callCount, int32_t coverage, double err, const QParams P)
 {
     if ((callCount <= 0) || (coverage <= 0)) return 0;
     double callCountMinusOne = callCount - 1;
@@ -296,9 +308,35 @@ __device__ inline int32_t poisson_qscore_e(int32_t callCount, int32_t coverage, 
     qScore = fmax(qScore, 0.0);
     return (int32_t)rint(qScore);  // Math.Round: ties to even
 }
+__device__ inline int32_t poisson_qscore_e(int32_t callCount, int32_t coverage, double err, const DeviceParams& P)
+{
+    const QParams q = {P.max_vq, P.ln10};
+    return poisson_qscore_core(callCount, coverage, err, q);
+}
 __device__ inline int32_t poisson_qscore(int32_t callCount, int32_t coverage, const DeviceParams& P)
 {
     return poisson_qscore_e(callCount, coverage, P.err_q, P);
+}
+// ln(a / x) >= (ilogb(a) - ilogb(x) - 1) ln 2 for a >= x > 0: the logarithm-free bound of ln_lower_bound without the division
+__device__ __forceinline__ double ln_ratio_lower_bound(double a, double x) { return (double)(ilogb(a) - ilogb(x) - 1) * 0.6931471805; }
+
+// poisson_qscore for the streaming-rate kernel (NoiseModel.Flat): the memo table; beyond the table the cap early-out of
+// poisson_qscore_core in a division-free form (a weaker bound of the same quantity, so still a proof).  false = neither
+// decides: the caller evaluates the long way (a cold path shared by every miss of the tile).
+__device__ __forceinline__ bool poisson_qscore_try(int32_t callCount, int32_t coverage, const DeviceParams& P, int32_t& vq)
+{
+    if ((callCount <= 0) || (coverage <= 0)) { vq = 0; return true; }
+    if (P.vq_tab && callCount < P.vq_tab_k && coverage < P.tab_cov) {
+        vq = P.vq_tab[(size_t)callCount * (size_t)P.tab_cov + (size_t)coverage];
+        return true;
+    }
+    const double lambda = P.err_q * coverage;
+    if (P.max_vq <= 110 && callCount >= 3 && (double)callCount >= 2.0 * lambda) {
+        const double km1 = callCount - 1;
+        const double need = ((double)P.max_vq + 1.0) * 0.23025850929940458 + 1e-3;
+        if (km1 * (ln_ratio_lower_bound(km1, lambda) - 1.0) >= need) { vq = P.max_vq; return true; }
+    }
+    return false;
 }
 
 // NoiseModel.Window (AlleleCaller.cs:215-218): QtoP((int)PtoQ(SumOfBaseQuality / TotalCoverage)), or a negative value when the mean
@@ -508,6 +546,130 @@ __device__ inline int32_t somatic_gq(int32_t genotype, int32_t variantQ, int32_t
 {
     const GqTail t = somatic_gq_tail(genotype, cov, support, P);
     return somatic_gq_finish(genotype, variantQ, cov, t, P);
+}
+
+// ------------------------------------------------------------------------------------------
+// Table-first forms of the strand-bias statistics and the genotype q-score for the streaming-rate kernel.  Every table is filled
+// by the device with the function it stands in for (build_*_kernel in kernels.hip.h), keyed by the integer counts the function is
+// called with.  Each returns false when neither a table nor a provable early-out decides (count or coverage beyond the table):
+// the caller then takes the allele through the long evaluation, a cold path shared by every miss of the tile.
+// ------------------------------------------------------------------------------------------
+// CreateStats / PopulateStats (:137-231) for the Poisson and Extended models, integer support and coverage
+__device__ __forceinline__ bool sb_stats_try(int32_t support, int32_t coverage, const DeviceParams& P, SbStats& st)
+{
+    st.support = (double)support;
+    st.coverage = (double)coverage;
+    if (support == 0) {
+        if (P.sb_model == PISCES_SB_POISSON) {
+            st.false_pos = 1;
+            st.var_gt_zero = 0;
+            return true;
+        }
+        if (!(P.sb0_tab && coverage >= 0 && coverage < P.tab_cov)) return false;
+        st.var_gt_zero = P.sb0_tab[coverage];
+        st.false_pos = 1 - st.var_gt_zero;
+        return true;
+    }
+    if (P.sb_tab && support > 0 && support < P.sb_tab_k && coverage >= 0 && coverage < P.tab_cov) {
+        st.var_gt_zero = P.sb_tab[(size_t)support * (size_t)P.tab_cov + (size_t)coverage];
+    } else {
+        // poisson_cdf_sb's proof of "exactly 1.0" with ln(a / x) bounded from below without the division
+        const double a = (double)support, x = (double)coverage * P.err_sb;
+        if (!(x > 0.0 && 2.0 * x <= a && a * (ln_ratio_lower_bound(a, x) - 1.0) + x > 51.0)) return false;
+        st.var_gt_zero = 1.0;
+    }
+    st.false_pos = fmax(0.0, 1 - st.var_gt_zero);
+    return true;
+}
+
+__device__ __forceinline__ bool strand_bias_try(const int32_t cov[3], const int32_t sup[3], const DeviceParams& P, double& bias_score,
+                                                int& acceptable, int& var_both, int& cov_both)
+{
+    const int s2 = sup[2] / 2, c2 = cov[2] / 2;   // the stitched halves use integer division (:36-41)
+    const int sf = sup[0] + s2, sr = sup[1] + s2, cf = cov[0] + c2, cr = cov[1] + c2;
+    SbStats overall, fwd, rev;
+    const bool ok0 = sb_stats_try(sup[0] + sup[1] + sup[2], cov[0] + cov[1] + cov[2], P, overall);
+    const bool ok1 = sb_stats_try(sf, cf, P, fwd);
+    const bool ok2 = sb_stats_try(sr, cr, P, rev);
+    // AssignBiasScore (:89-105) + the both-strands rules (:57-69), as sb_combine; with both products exactly +0 the quotients are
+    // (x * 0) / y = 0 for finite x >= 0, y > 0 — no division needed
+    double forwardBias = 0.0, reverseBias = 0.0;
+    if (!(fwd.false_pos == 0.0 && rev.false_pos == 0.0 && overall.var_gt_zero > 0.0)) {
+        forwardBias = (fwd.var_gt_zero * rev.false_pos) / overall.var_gt_zero;
+        reverseBias = (rev.var_gt_zero * fwd.false_pos) / overall.var_gt_zero;
+        if (overall.var_gt_zero == 0) {
+            forwardBias = 1;
+            reverseBias = 1;
+        }
+    }
+    double score = forwardBias > reverseBias ? forwardBias : reverseBias;
+    cov_both = (cf > 0) && (cr > 0);
+    var_both = (sf > 0) && (sr > 0);
+    if (!cov_both) score = 0;
+    bias_score = score;
+    acceptable = score < P.sb_threshold;
+    return ok0 && ok1 && ok2;
+}
+
+// SomaticGenotypeQualityCalculator.Compute (:10-48).  somatic_gq_index = the memo index of a hom-ref / hom-alt call (or -1), so that
+// a caller can issue the load of P.gq_cap[index] ahead of time.
+__device__ __forceinline__ int32_t somatic_gq_index(int32_t genotype, int32_t cov, int32_t support, const DeviceParams& P)
+{
+    if (cov == 0 || !((genotype == PISCES_GT_HOM_REF) || (genotype == PISCES_GT_HOM_ALT))) return -1;
+    const float nonAlleleObservationsF = (1.0f - frequency_f(support, cov)) * (float)cov;
+    const float expectedNonAllelObservationsF = P.target_lod * (float)cov;
+    if (nonAlleleObservationsF >= expectedNonAllelObservationsF) return -1;
+    const int ai = (int)((double)nonAlleleObservationsF + 1.0);   // Poisson.Cdf's (int)(numOccurrences + 1)
+    if (ai >= 1 && ai < P.gq_tail_a && cov < P.gq_tail_cov) return ai * P.gq_tail_cov + cov;
+    return -1;
+}
+__device__ __forceinline__ bool somatic_gq_try(int32_t genotype, int32_t variantQ, int32_t cov, int32_t support, const DeviceParams& P,
+                                               int32_t gq_index, int32_t gq_cap_value /* P.gq_cap[gq_index] when gq_index >= 0 */, int32_t& gq)
+{
+    const bool noCall = (genotype == PISCES_GT_ALT12_LIKE_NOCALL || genotype == PISCES_GT_ALT_LIKE_NOCALL || genotype == PISCES_GT_REF_LIKE_NOCALL);
+    if ((cov == 0) || noCall) { gq = P.min_gq; return true; }
+    if ((genotype == PISCES_GT_HOM_REF) || (genotype == PISCES_GT_HOM_ALT)) {
+        if (gq_index >= 0 && variantQ == P.max_vq && P.gq_cap) { gq = gq_cap_value; return true; }
+        const float nonAlleleObservationsF = (1.0f - frequency_f(support, cov)) * (float)cov;
+        const float expectedNonAllelObservationsF = P.target_lod * (float)cov;
+        if (nonAlleleObservationsF >= expectedNonAllelObservationsF) { gq = P.min_gq; return true; }
+        return false;   // a logarithm of QtoP(variantQ) + tail: the long way
+    }
+    double qScore = fmin((double)P.max_gq, (double)variantQ);
+    qScore = fmax(qScore, (double)P.min_gq);
+    gq = (int32_t)rint(qScore);
+    return true;
+}
+
+// Out-of-line leaves of the wave kernel's cold path (an allele beyond the memo tables): the evaluations the tables were filled
+// with, as calls, so that neither their registers nor their code weigh on the call phase proper.
+__device__ __noinline__ int32_t poisson_qscore_out_of_line(int32_t callCount, int32_t coverage, double err, int32_t max_vq, double ln10)
+{
+    const QParams q = {max_vq, ln10};
+    return poisson_qscore_core(callCount, coverage, err, q);
+}
+struct SbPair { double var_gt_zero, false_pos; };
+__device__ __noinline__ SbPair sb_stats_out_of_line(double support, double coverage, double noiseFreq, int model)
+{
+    const SbStats st = sb_create_stats<false>(support, coverage, noiseFreq, 0.0, model);
+    SbPair p = {st.var_gt_zero, st.false_pos};
+    return p;
+}
+__device__ inline SbResult strand_bias_out_of_line(const int32_t cov[3], const int32_t sup[3], const DeviceParams& P)
+{
+    const int s2 = sup[2] / 2, c2 = cov[2] / 2;
+    SbStats st[3];
+#pragma unroll 1
+    for (int which = 0; which < 3; which++) {
+        const int s = which == 0 ? sup[0] + sup[1] + sup[2] : (which == 1 ? sup[0] + s2 : sup[1] + s2);
+        const int c = which == 0 ? cov[0] + cov[1] + cov[2] : (which == 1 ? cov[0] + c2 : cov[1] + c2);
+        const SbPair p = sb_stats_out_of_line((double)s, (double)c, P.err_sb, P.sb_model);
+        st[which].var_gt_zero = p.var_gt_zero;
+        st[which].false_pos = p.false_pos;
+        st[which].support = (double)s;
+        st[which].coverage = (double)c;
+    }
+    return sb_combine(st[0], st[1], st[2], P);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -31,8 +31,9 @@ constexpr int kTotalShards = 64;          // running-total shards (one 128-byte 
 constexpr int kTotalStride = 16;          // in 8-byte words
 constexpr int kRefMargin = 32;            // reference bases staged in LDS on each side of a tile (RMxN scan reach)
 constexpr int kRefWin = kTile + 2 * kRefMargin;
-constexpr int kWaveRow = kTile + 1;       // wave-kernel histogram row; column kTile collects out-of-range loci (padding tuples)
-constexpr int kWaveRows = 32;             // row = the tuple's 5-bit allele:direction field as it is
+constexpr int kWaveRows = 32;             // wave-kernel histogram row = the tuple's 5-bit allele:direction field as it is
+constexpr int kWaveRow = kTile;           // 64 columns (PISCES_TUPLE_COLUMN): the LDS bank of a counter depends on its column only
+constexpr int kWaveRegion = kWaveRows * kWaveRow;   // counters per region; two regions: quality-passing bases, low-quality bases
 constexpr int kQLutLds = 128;             // QtoP(q), q < 128, staged in LDS (no global load inside the call phase)
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // one dwordx4 load
@@ -52,25 +53,25 @@ __device__ __forceinline__ int allele_type_of_base(uint8_t c)  // AlleleHelper.G
 // Padding tuples (0xFFFFFFFF) decode to allele 7 and fall out of the range test.
 __device__ __forceinline__ void accumulate_folded(int* hist, uint32_t t, uint32_t n_loci, uint32_t min_bq)
 {
-    uint32_t locus = t & 0x7FFFu;
-    uint32_t dir = (t >> 19) & 3u;
-    uint32_t allele = (t >> 21) & 7u;
-    uint32_t qual = t >> 24;
+    uint32_t locus = PISCES_TUPLE_LOCUS(t);
+    uint32_t dir = PISCES_TUPLE_DIR(t);
+    uint32_t allele = PISCES_TUPLE_ALLELE(t);
+    uint32_t qual = PISCES_TUPLE_QUAL(t);
     if (allele < 4u && qual < min_bq) allele = 4u;
     if (locus < n_loci && dir < 3u && allele < 6u) atomicAdd(&hist[(allele * 3u + dir) * kTile + locus], 1);
 }
 
-// Wave-kernel form: row = bits 19..23 of the tuple (allele:direction), column = min(locus, kTile).  Invalid
-// allele / direction codes and out-of-range loci land in rows / a column nobody reads, so the loop has no branch and
-// no exec masking: 9 VALU + 1 DS instruction per observation.  "qual < minBQ -> N" for A/C/G/T is
-// max(row, 16 + direction): rows of alleles 0..3 are below row 16 + d, N stays, a deletion (row 20 + d) stays.
+// Wave-kernel form.  The tuple is laid out for this (include/pisces_hip.h): bits 2..12 ARE the byte offset of the (allele, direction,
+// column) counter in a [32][64] int32 region, so an observation is 3 VALU + 1 DS instruction: one compare-and-select for "qual <
+// minBQ" (RegionStateManager.cs:179-181; it picks the second region, whose counts the call phase adds to N, or to the deletion
+// count for a deletion tuple, exactly where the remapped allele would have gone), one and-or for the address, ds_add_u32.  No
+// branch, no exec masking, no range test: six column bits cannot leave the tile, padding tuples (all ones) and invalid allele /
+// direction codes select rows nobody reads.
 __device__ __forceinline__ void accumulate_wave(int* hist, uint32_t t, uint32_t min_bq_shifted)
 {
-    const uint32_t locus = min(t & 0x7FFFu, (uint32_t)kTile);
-    const uint32_t row = (t >> 19) & 31u;
-    const uint32_t low = max(row, (row & 3u) | 16u);
-    const uint32_t r = (t < min_bq_shifted) ? low : row;   // qual is the top byte: qual < minBQ <=> t < minBQ << 24
-    atomicAdd(&hist[r * kWaveRow + locus], 1);
+    const uint32_t region = (t < min_bq_shifted) ? (uint32_t)(kWaveRegion * sizeof(int)) : 0u;   // qual is the top byte: qual < minBQ <=> t < minBQ << 24
+    const uint32_t off = (t & 0x1FFCu) | region;
+    atomicAdd(reinterpret_cast<int*>(reinterpret_cast<char*>(hist) + off), 1);
 }
 
 // Streams tuples[begin, end) through `op(tuple)`: scalar head/tail up to 16-byte alignment, then
@@ -101,14 +102,20 @@ __device__ __forceinline__ void stream_tuples(const uint32_t* __restrict__ tuple
     for (int64_t i = aend + tid; i < end; i += kBlock) op(tuples[i]);
 }
 
+// The record goes out as four dwordx4 stores assembled from its fields in registers.  (Copying it as uint4 words through a pointer
+// keeps the whole record a stack object: fields stored to scratch, read back, then stored to HBM — a dependent scratch round trip in
+// front of every record while the chip is streaming.)
 __device__ __forceinline__ void copy_record(PiscesCalledAllele* dst, const PiscesCalledAllele* src)
 {
 #ifdef PISCES_ABLATE_STORE
     if (src->position != -12345) return;   // development ablation: no record stores
 #endif
-    const uint4* sp = reinterpret_cast<const uint4*>(src);
+    const unsigned long long sb = (unsigned long long)__double_as_longlong(src->strand_bias_score);
     uint4* dp = reinterpret_cast<uint4*>(dst);
-    dp[0] = sp[0]; dp[1] = sp[1]; dp[2] = sp[2]; dp[3] = sp[3];
+    dp[0] = make_uint4((uint32_t)src->position, (uint32_t)src->total_coverage, (uint32_t)src->allele_support, (uint32_t)src->reference_support);
+    dp[1] = make_uint4((uint32_t)src->num_no_calls, (uint32_t)src->coverage_by_dir[0], (uint32_t)src->coverage_by_dir[1], (uint32_t)src->coverage_by_dir[2]);
+    dp[2] = make_uint4((uint32_t)src->support_by_dir[0], (uint32_t)src->support_by_dir[1], (uint32_t)src->support_by_dir[2], (uint32_t)src->variant_qscore);
+    dp[3] = make_uint4((uint32_t)sb, (uint32_t)(sb >> 32), (uint32_t)src->genotype_qscore, (uint32_t)src->filter_bits | ((uint32_t)src->info << 16));
 }
 
 struct PointCounts {
@@ -120,8 +127,8 @@ struct PointCounts {
 struct HistBlock {   // call_tiles_kernel / call_counts_kernel: 18 rows of kTile
     static __device__ __forceinline__ int idx(int a, int d, int l) { return (a * 3 + d) * kTile + l; }
 };
-struct HistWave {    // call_tiles_wave_kernel: no validity test in the streaming loop (unused rows / column absorb)
-    static __device__ __forceinline__ int idx(int a, int d, int l) { return (a * 4 + d) * kWaveRow + l; }
+struct HistWave {    // call_tiles_wave_kernel: counter of (allele a, direction d) at locus l in the quality-passing region
+    static __device__ __forceinline__ int idx(int a, int d, int l) { return (a * 4 + d) * kWaveRow + (int)PISCES_TUPLE_COLUMN(l, d); }
 };
 
 struct LocusCounts { int h[6][3]; };
@@ -132,6 +139,23 @@ __device__ __forceinline__ LocusCounts load_counts(const int* hist, int l)
     LocusCounts lc;
 #pragma unroll
     for (int k = 0; k < kFolded; k++) lc.h[k / 3][k % 3] = hist[H::idx(k / 3, k % 3, l)];
+    return lc;
+}
+
+// the wave kernel's two regions folded into the reference's counts: a low-quality A/C/G/T/N base is an N, a deletion stays one
+__device__ __forceinline__ LocusCounts load_counts_wave(const int* hist, int l)
+{
+    LocusCounts lc;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        int low = 0;
+#pragma unroll
+        for (int a = 0; a < 5; a++) low += hist[kWaveRegion + HistWave::idx(a, d, l)];
+#pragma unroll
+        for (int a = 0; a < 4; a++) lc.h[a][d] = hist[HistWave::idx(a, d, l)];
+        lc.h[PISCES_ALLELE_N][d] = hist[HistWave::idx(PISCES_ALLELE_N, d, l)] + low;
+        lc.h[PISCES_ALLELE_DEL][d] = hist[HistWave::idx(PISCES_ALLELE_DEL, d, l)] + hist[kWaveRegion + HistWave::idx(PISCES_ALLELE_DEL, d, l)];
+    }
     return lc;
 }
 
@@ -177,10 +201,12 @@ __device__ __forceinline__ bool variant_passes_frequency(const PointCounts& c, c
 
 // Everything of AlleleCaller.ProcessVariant (AlleleCaller.cs:208-234) after the q-score and the strand-bias
 // statistics: AlleleProcessor.ApplyFilters (AlleleProcessor.cs:25-71), SomaticGenotyper, record packing.
-__device__ inline void finish_allele(const PointCounts& c, int pos, int a, bool isRef, int rt, int vq, const SbResult& sb,
+struct GqPre { int32_t idx, val; };   // memo index of the genotype q-score (somatic_gq_index) and P.gq_cap[idx], fetched ahead by the caller
+template <bool kMemo = false>   // kMemo: table-first forms only; false = a table missed, the record is not made (the caller takes the long way)
+__device__ inline bool finish_allele(const PointCounts& c, int pos, int a, bool isRef, int rt, int vq, const SbResult& sb,
                                      const uint8_t* __restrict__ ref, int64_t win_lo, int64_t win_hi, const DeviceParams& P,
                                      PiscesCalledAllele& r, const uint8_t* s_refwin, int s_refidx,
-                                     const GqTail* pre_tail = nullptr)
+                                     const GqTail* pre_tail = nullptr, const GqPre* pre_gq = nullptr)
 {
     const float freq = frequency_f(c.support, c.total);
     // SetFractionNoCalls (CalledAllele.cs:107-114) + ApplyFilters
@@ -192,23 +218,31 @@ __device__ inline void finish_allele(const PointCounts& c, int pos, int a, bool 
     if (!isRef) {
         if (P.nocall_thr >= 0.0f && fractionNoCalls > P.nocall_thr) filters |= 1u << PISCES_FILTER_NO_CALL;
         if (!sb.acceptable || (P.filter_single_strand && !sb.var_both)) filters |= 1u << PISCES_FILTER_STRAND_BIAS;
-        const uint8_t bases[4] = {'A', 'G', 'C', 'T'};
+        // base letter of an allele code (A0 G1 C2 T3) from a packed constant: a local array indexed at run time would live in scratch
+        auto base_of = [](int code) { return (uint8_t)((0x54434741u >> (8 * code)) & 0xFFu); };
         if (rt < 4 && a < 4) {
             // the reference window of the tile sits in LDS (global byte loads are dependent multi-microsecond
             // round trips while the chip is streaming); fall back to HBM only for an RMxN reach beyond the margin
             const bool hit = (s_refwin && P.rmxn_min_rep <= kRefMargin)
-                                 ? rmxn_should_filter_snv_lds(s_refwin, kRefWin, s_refidx, bases[rt], bases[a], freq, P)
-                                 : rmxn_should_filter_snv(ref, win_lo, win_hi, pos, bases[rt], bases[a], freq, P);
+                                 ? rmxn_should_filter_snv_lds(s_refwin, kRefWin, s_refidx, base_of(rt), base_of(a), freq, P)
+                                 : rmxn_should_filter_snv(ref, win_lo, win_hi, pos, base_of(rt), base_of(a), freq, P);
             if (hit) filters |= 1u << PISCES_FILTER_RMXN;
         }
         if (P.vf_filter >= 0.0f && freq < P.vf_filter) filters |= 1u << PISCES_FILTER_LOW_VARIANT_FREQUENCY;
     }
     const int gt = somatic_genotype(isRef, c.total, c.support, c.refsup, P);
-#if !(defined(PISCES_ABLATE_MATH) && (PISCES_ABLATE_MATH == 3 || PISCES_ABLATE_MATH == 9))
-    const int gq = pre_tail ? somatic_gq_finish(gt, vq, c.total, *pre_tail, P) : somatic_gq(gt, vq, c.total, c.support, P);
-#else
-    const int gq = vq;
-#endif
+    int gq;
+    if (kMemo) {
+        GqPre g;
+        if (pre_gq) g = *pre_gq;
+        else {
+            g.idx = somatic_gq_index(gt, c.total, c.support, P);
+            g.val = (g.idx >= 0 && P.gq_cap) ? (int32_t)P.gq_cap[g.idx] : 0;
+        }
+        if (!somatic_gq_try(gt, vq, c.total, c.support, P, g.idx, g.val, gq)) return false;
+    } else {
+        gq = pre_tail ? somatic_gq_finish(gt, vq, c.total, *pre_tail, P) : somatic_gq(gt, vq, c.total, c.support, P);
+    }
     if (P.low_gq_filter >= 0 && (float)gq < (float)P.low_gq_filter) filters |= 1u << PISCES_FILTER_LOW_GENOTYPE_QUALITY;
 
     r.position = pos;
@@ -224,6 +258,7 @@ __device__ inline void finish_allele(const PointCounts& c, int pos, int a, bool 
     r.filter_bits = (uint16_t)filters;
     r.info = PISCES_INFO_PACK(gt, isRef ? PISCES_CAT_REFERENCE : PISCES_CAT_SNV, rt, isRef ? rt : a, sb.acceptable, sb.var_both,
                               sb.cov_both);
+    return true;
 }
 
 // One lane, one allele, start to finish. Returns false (record untouched) when the reference would drop the allele.
@@ -505,8 +540,6 @@ __global__ __launch_bounds__(kBlock, 4) void call_tiles_kernel(
 #define PISCES_WAVE2_OCC 4   // two waves per tile: 8 tiles per CU resident, 2048 on the chip
 #endif
 constexpr int kWaveUnroll = PISCES_WAVE_UNROLL;   // 16-byte loads per lane per batch; two batches are in flight
-constexpr int kPairsPerRound = 21;   // 21 variants x 3 statistics = 63 lanes
-constexpr int kPairsPerSuper = 3 * kPairsPerRound;   // candidates whose statistics are held in LDS at a time
 
 // One wave streams tuples[begin, end) through op(): two register batches of kWaveUnroll dwordx4 loads per lane in
 // ping-pong, so that the loads of the next batch are in flight while the current one is decoded (a lone wave has no
@@ -597,22 +630,43 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
-struct WaveScratch {
-    int vq[kTile * 4];                       // variant q-score of (locus, rank)
-    uint8_t pair_l[64], pair_k[64];          // the variant candidates in flight
-    double sb_var[kPairsPerSuper][3], sb_fp[kPairsPerSuper][3];
-};
+// Cold path of the wave kernel: alleles whose count or coverage lies beyond the memo tables go through the evaluations the tables
+// were filled with (out-of-line leaves, device_math.hip.h), counts re-read from LDS: it runs after the fast pass, when almost nothing
+// is live.  slow: bit 4 = the Reference candidate, bits 0..3 = variant ranks; returns the variant ranks that were called.
+__device__ __forceinline__ uint32_t slow_alleles(const int* hist, const uint8_t* s_refwin, uint32_t slow, int l, int pos, int rt, int ref_rank,
+                                                 const uint8_t* __restrict__ ref, int64_t win_lo, int64_t win_hi, PiscesCalledAllele* slots,
+                                                 const DeviceParams& P)
+{
+    uint32_t called = 0;
+    const int ref_a = (rt < 4) ? rt : PISCES_ALLELE_N;
+#pragma unroll 1
+    for (int k = 0; k < 5; k++) {
+        if (!((slow >> k) & 1u)) continue;
+        const bool isRef = k == 4;
+        const int a = isRef ? ref_a : allele_of_rank(k);
+        const LocusCounts lc = load_counts_wave(hist, l);
+        const PointCounts c = point_counts_of(lc, a, isRef, rt, 0);
+        int vq = 0;
+        if (c.support > 0 && c.total != 0) vq = poisson_qscore_out_of_line(c.support, c.total, P.err_q, P.max_vq, P.ln10);
+        if (!isRef && vq < P.min_vq) continue;
+        SbResult sb = {0.0, 0, 0, 0};
+        if (c.support > 0) sb = strand_bias_out_of_line(c.cov, c.sup, P);
+        PiscesCalledAllele r;
+        (void)finish_allele<false>(c, pos, a, isRef, rt, vq, sb, ref, win_lo, win_hi, P, r, s_refwin, kRefMargin + l);
+        copy_record(&slots[isRef ? ref_rank : k], &r);
+        if (!isRef) called |= 1u << k;
+    }
+    return called;
+}
 
 template <int NW>
 __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_OCC) void call_tiles_wave_kernel(
     const uint32_t* __restrict__ tuples, const PiscesTile* __restrict__ tiles, int32_t n_tiles,
     const uint8_t* __restrict__ ref, int32_t ref_start, int64_t ref_len, PiscesCalledAllele* __restrict__ records,
-    PiscesTileResult* __restrict__ tile_results, DeviceParams P)
+    PiscesTileResult* __restrict__ tile_results, DeviceParams P, const DeviceParams* __restrict__ Pd /* the same in device memory, for the cold path */)
 {
-    __shared__ int hist[kWaveRows * kWaveRow];
+    __shared__ __attribute__((aligned(16))) int hist[2 * kWaveRegion];   // 16 KiB: [region][allele:direction row][column]
     __shared__ uint8_t s_refwin[kRefWin];
-    __shared__ double s_qlut[kQLutLds];
-    __shared__ WaveScratch ws;
     __shared__ uint8_t s_vmask[kTile];
 
     const int t = blockIdx.x;
@@ -622,38 +676,24 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
 #ifdef PISCES_TIMING
     const long long tc0 = wall_clock64();
 #endif
-    const double* const g_qlut = P.q_to_p_lut;
-    const int g_qlut_n = P.q_to_p_n;
     auto setup = [&]() {
-        for (int i = threadIdx.x; i < kWaveRows * kWaveRow; i += 64 * NW) hist[i] = 0;
+        int4* h4 = reinterpret_cast<int4*>(hist);
+        for (int i = threadIdx.x; i < 2 * kWaveRegion / 4; i += 64 * NW) h4[i] = make_int4(0, 0, 0, 0);
         for (int i = threadIdx.x; i < kRefWin; i += 64 * NW) {
             const int64_t ri = (int64_t)tile.start_position - kRefMargin + i - ref_start;
             s_refwin[i] = (ri >= 0 && ri < ref_len) ? ref[ri] : (uint8_t)0;
         }
-        for (int q = threadIdx.x; q < kQLutLds; q += 64 * NW) s_qlut[q] = (g_qlut && q < g_qlut_n) ? g_qlut[q] : q_to_p((double)q);
         __syncthreads();
     };
-    P.q_to_p_lut = s_qlut;
-    P.q_to_p_n = kQLutLds;
 
     {
         // single-round launches (NW = 2): streaming waves win the issue arbitration over waves in their call phase — the launch
-        // ends with the slowest tile, and a tile that is still streaming has its whole call phase ahead of it (+1.5-2.5 % there;
-        // with several rounds per launch it delays the calls that free wave slots and costs 1.4 %)
+        // ends with the slowest tile, and a tile that is still streaming has its whole call phase ahead of it
         if (NW == 2) __builtin_amdgcn_s_setprio(3);
         const uint32_t min_bq_shifted = (uint32_t)min(max(P.min_bq, 0), 255) << 24;
 #if defined(PISCES_ABLATE) && PISCES_ABLATE == 2
         uint32_t acc = 0;   // development ablation: loads only
         stream_tuples_wave<NW>(tuples, tile.tuple_begin, tile.tuple_end, l, wid, [&](uint32_t v) { acc ^= v; }, setup);
-        if (acc == 0x12345u) hist[l] = (int)min_bq_shifted;
-#elif defined(PISCES_ABLATE) && PISCES_ABLATE == 3
-        uint32_t acc = 0;   // development ablation: loads + decode, no LDS atomics
-        stream_tuples_wave<NW>(tuples, tile.tuple_begin, tile.tuple_end, l, wid, [&](uint32_t t) {
-            const uint32_t locus = min(t & 0x7FFFu, (uint32_t)kTile);
-            const uint32_t row = (t >> 19) & 31u;
-            const uint32_t low = max(row, (row & 3u) | 16u);
-            const uint32_t r = (t < min_bq_shifted) ? low : row;
-            acc += r * kWaveRow + locus; }, setup);
         if (acc == 0x12345u) hist[l] = (int)min_bq_shifted;
 #else
         stream_tuples_wave<NW>(tuples, tile.tuple_begin, tile.tuple_end, l, wid, [&](uint32_t v) { accumulate_wave(hist, v, min_bq_shifted); }, setup);
@@ -669,166 +709,83 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
     const long long tc1 = wall_clock64();
 #endif
 
-    // ---- call phase ----
+    // ---- call phase: lane = locus; with two waves per tile wave 0 makes the Reference records and the tile directory, wave 1 the
+    // variant records, and they meet once in LDS (a variant called at a locus drops its Reference record, AlleleCaller.cs:146-147).
+    // Every FP64 tail comes from the handle's memo tables (DeviceParams), keyed by the integer counts: no incomplete gamma,
+    // no logarithm and no division chain runs here unless a count lies beyond the tables (out-of-line evaluation then). ----
     const int pos = tile.start_position + l;
     const uint8_t refb = s_refwin[kRefMargin + l];
     const bool in_ref = l < tile.n_loci && refb != 0;
     const int rt = in_ref ? allele_type_of_base(refb) : PISCES_ALLELE_N;
     const int64_t win_lo = (int64_t)ref_start - 1, win_hi = win_lo + ref_len;
-    // The record slot address is formed where it is used, from an opaque copy of the lane number: as one per-lane pointer
-    // it is live from here to the last store and was the register allocator's first pick for a scratch spill.
-    auto slot_of = [&](int k) {
-        int lf = l;
-        asm volatile("" : "+v"(lf));
-        return records + ((int64_t)t * kSlotsPerTile + lf * 4 + k);
+    auto slot_of = [&](int k) { return records + ((int64_t)t * kSlotsPerTile + l * 4 + k); };
+    const LocusCounts lc = load_counts_wave(hist, l);
+    const bool ref_wave = wid == 0, var_wave = wid == NW - 1;
+
+    // One allele through the table-first forms; false = a table missed (the record is not made)
+    auto fast_allele = [&](const PointCounts& c, int a, bool isRef, PiscesCalledAllele& rec, const GqPre* g) -> bool {
+        int vq = 0;
+        if (c.support > 0 && c.total != 0 && !poisson_qscore_try(c.support, c.total, P, vq)) return false;   // VariantQualityCalculator.Compute :11-24
+        if (!isRef && vq < P.min_vq) return true;                                                             // IsCallable, last test: not callable, nothing to make
+        double sb_score = 0.0;
+        int sb_ok = 0, sb_var = 0, sb_cov = 0;
+        if (c.support > 0 && !strand_bias_try(c.cov, c.sup, P, sb_score, sb_ok, sb_var, sb_cov)) return false;   // StrandBiasCalculator.Compute :10-15
+        const SbResult sb = {sb_score, sb_ok, sb_var, sb_cov};
+        if (!finish_allele<true>(c, pos, a, isRef, rt, vq, sb, ref, win_lo, win_hi, P, rec, s_refwin, kRefMargin + l, nullptr, g)) return false;
+        return true;
     };
-
-    // the locus' 18 folded counts, once, into registers
-    const LocusCounts lc = load_counts<HistWave>(hist, l);
-    // Reference candidate first: its genotype-quality tail is one dependent global load from the handle's memo table,
-    // issued here so that it is back by the time the Reference pass wants it
-    const bool want_ref = in_ref && P.include_ref;
+    bool ref_emitted = false;
+    int ref_rank = 0;
+    uint32_t slow = 0;    // alleles of this lane that need the long evaluation: bit 4 = Reference, bits 0..3 = variant ranks
+    uint32_t vmask = 0;
     const int ref_a = (rt < 4) ? rt : PISCES_ALLELE_N;
-    const PointCounts ref_c = point_counts_of(lc, ref_a, true, rt, 0);
-    GqTail ref_tail = {0.0, false, false};
-    if (want_ref) ref_tail = somatic_gq_tail(somatic_genotype(true, ref_c.total, ref_c.support, ref_c.refsup, P), ref_c.total, ref_c.support, P);
-
-    // variant candidates that survive the integer / float32 half of IsCallable (AlleleCaller.cs:236-258)
-    uint32_t pass_mask = 0;
-    if (in_ref && rt < 4 && !P.refs_only) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int a = allele_of_rank(k);
-            if (a == rt) continue;
-            if (lc.h[a][0] + lc.h[a][1] + lc.h[a][2] == 0) continue;
-            const PointCounts c = point_counts_of(lc, a, false, rt, 0);
-            if (variant_passes_frequency(c, P)) pass_mask |= 1u << k;
+    if (ref_wave) {
+        // Reference candidate (RegionState.GetAllCandidates, RegionState.cs:414-447); written now, it only counts if no variant turns
+        // out callable at the locus
+        const PointCounts c = point_counts_of(lc, ref_a, true, rt, 0);
+        if (in_ref && P.include_ref && (P.emit_zero_cov || c.total + c.nocalls > 0)) {
+            // the genotype q-score is one dependent load from the memo table: issue it first
+            GqPre g;
+            g.idx = somatic_gq_index(somatic_genotype(true, c.total, c.support, c.refsup, P), c.total, c.support, P);
+            g.val = (g.idx >= 0 && P.gq_cap) ? (int32_t)P.gq_cap[g.idx] : 0;
+            ref_rank = (rt < 4) ? rank_of_allele(rt) : 0;
+            ref_emitted = true;
+            PiscesCalledAllele rec;
+            if (fast_allele(c, ref_a, true, rec, &g)) copy_record(slot_of(ref_rank), &rec);
+            else slow |= 16u;
         }
     }
 #ifdef PISCES_TIMING
     const long long tcA = wall_clock64();
-    long long tcB = tcA, tcC = tcA, tcD = tcA;
 #endif
-    // With two waves per tile, wave 0 takes the Reference candidates and then the variant q-scores while wave 1 takes
-    // the strand-bias statistics; they meet in LDS for the assembly.  "No variant candidate in this tile" is the same
-    // ballot in both waves, so wave 1 can simply leave.  With one wave per tile the same code runs in sequence.
-    const bool any_variant = __ballot(pass_mask != 0) != 0ull;
-    const bool ref_wave = wid == 0, sb_wave = wid == NW - 1;
-    if (!ref_wave && !any_variant) return;
-
-    // variant candidates of the tile numbered rank-major from ballots (scalar work, identical in both waves)
-    uint32_t pidx = 0;   // this lane's candidate numbers, 8 bits per allele rank
-    int total = 0;
-    if (any_variant) {
-#pragma unroll
+    if (var_wave && in_ref && rt < 4 && !P.refs_only) {
+        // SNV candidates: quality-passing bases that differ from the reference base (CandidateVariantFinder.cs:97-160 with MNV
+        // calling off); IsCallable (AlleleCaller.cs:236-258) in its own order: coverage, frequency, q-score
+#pragma unroll 1
         for (int k = 0; k < 4; k++) {
-            const unsigned long long bk = __ballot((pass_mask >> k) & 1u);
-            const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bk, 0u));
-            if ((pass_mask >> k) & 1u) pidx |= (uint32_t)(total + below) << (8 * k);
-            total += __popcll(bk);
+            const int a = allele_of_rank(k);
+            if (a == rt) continue;
+            const PointCounts c = point_counts_of(lc, a, false, rt, 0);   // (selects over the unrolled allele loop: no run-time index into the counts)
+            if (c.support == 0) continue;
+            if (!variant_passes_frequency(c, P)) continue;
+            PiscesCalledAllele r;
+            r.position = 0;
+            if (!fast_allele(c, a, false, r, nullptr)) { slow |= 1u << k; continue; }
+            if (r.position == 0) continue;   // not callable
+            copy_record(slot_of(k), &r);
+            vmask |= 1u << k;
         }
     }
-
-    bool ref_emitted = false;
-    int ref_rank = 0;
-    if (ref_wave) {
-        // 1. Reference candidate (RegionState.GetAllCandidates, RegionState.cs:414-447); written now, it only counts if
-        //    no variant turns out callable at the locus (AlleleCaller.cs:146-147)
-        if (want_ref) {
-            const int all = ref_c.total + ref_c.nocalls;
-            if (P.emit_zero_cov || all > 0) {
-                ref_rank = (rt < 4) ? rank_of_allele(rt) : 0;
-                PiscesCalledAllele rec;
-                (void)process_point_allele(ref_c, pos, ref_a, true, rt, ref, win_lo, win_hi, P, rec, s_refwin, kRefMargin + l, &ref_tail);
-                copy_record(slot_of(ref_rank), &rec);
-                ref_emitted = true;
-            }
-        }
-#ifdef PISCES_TIMING
-        tcB = wall_clock64();
-        tcC = tcB; tcD = tcB;
-#endif
-        // 2. variant q-scores (VariantQualityCalculator.Compute :11-24), one converged pass per allele rank in use
-        if (any_variant) {
-#pragma unroll 1
-            for (int k = 0; k < 4; k++) {
-                if (!(pass_mask & (1u << k))) continue;
-                const PointCounts c = point_counts<HistWave>(hist, l, allele_of_rank(k), false, rt, 0);   // re-read, not held
-                ws.vq[l * 4 + k] = (c.support > 0 && c.total != 0) ? poisson_qscore(c.support, c.total, P) : 0;
-            }
-        }
-#ifdef PISCES_TIMING
-        tcC = wall_clock64();
-        tcD = tcC;
-#endif
-    }
-
-    uint32_t vmask = 0;
-    if (any_variant) {
-        for (int sbase = 0; sbase < total; sbase += kPairsPerSuper) {
-            const int n_here = min(kPairsPerSuper, total - sbase);
-            if (sb_wave) {
-                // 3. strand-bias statistics, lane = (candidate, statistic)
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int p = (int)((pidx >> (8 * k)) & 255u) - sbase;
-                    if (((pass_mask >> k) & 1u) && p >= 0 && p < kPairsPerSuper) { ws.pair_l[p] = (uint8_t)l; ws.pair_k[p] = (uint8_t)k; }
-                }
-                wave_lds_sync();
-#pragma unroll 1
-                for (int r = 0; r * kPairsPerRound < n_here; r++) {
-                    const int p = r * kPairsPerRound + l / 3, which = l % 3;
-                    if (l < 3 * kPairsPerRound && p < n_here) {
-                        const int pl = ws.pair_l[p], pk = ws.pair_k[p];
-                        const int prt = allele_type_of_base(s_refwin[kRefMargin + pl]);
-                        const PointCounts c = point_counts<HistWave>(hist, pl, allele_of_rank(pk), false, prt, 0);
-                        const SbStats st = sb_stats_of(which, c.cov, c.sup, P);
-                        ws.sb_var[p][which] = st.var_gt_zero;
-                        ws.sb_fp[p][which] = st.false_pos;
-                    }
-                }
-            }
-            if (NW > 1) __syncthreads(); else wave_lds_sync();   // q-scores and strand-bias statistics meet
-            if (sb_wave) {
-                // 4. IsCallable's last test, then filters / genotype / record of the callable variants, lane = locus
-#pragma unroll 1
-                for (int k = 0; k < 4; k++) {
-                    if (!(pass_mask & (1u << k))) continue;
-                    const int p = (int)((pidx >> (8 * k)) & 255u) - sbase;
-                    if (p < 0 || p >= kPairsPerSuper) continue;
-                    const int vq = ws.vq[l * 4 + k];
-                    if (vq < P.min_vq) continue;
-                    const int a = allele_of_rank(k);
-                    // counts re-read from LDS per candidate: 18 registers held across this loop were spilled at 128 VGPRs
-                    const PointCounts c = point_counts<HistWave>(hist, l, a, false, rt, 0);
-                    SbStats ov, fw, rv;
-                    ov.var_gt_zero = ws.sb_var[p][0]; ov.false_pos = ws.sb_fp[p][0];
-                    fw.var_gt_zero = ws.sb_var[p][1]; fw.false_pos = ws.sb_fp[p][1];
-                    rv.var_gt_zero = ws.sb_var[p][2]; rv.false_pos = ws.sb_fp[p][2];
-                    const int s2 = c.sup[2] / 2, c2 = c.cov[2] / 2;
-                    fw.coverage = c.cov[0] + c2; fw.support = c.sup[0] + s2;
-                    rv.coverage = c.cov[1] + c2; rv.support = c.sup[1] + s2;
-                    ov.coverage = 0; ov.support = 0;
-                    const SbResult sb = sb_combine(ov, fw, rv, P);
-                    PiscesCalledAllele r;
-                    finish_allele(c, pos, a, false, rt, vq, sb, ref, win_lo, win_hi, P, r, s_refwin, kRefMargin + l);
-                    copy_record(slot_of(k), &r);
-                    vmask |= 1u << k;
-                }
-            }
-            if (sbase + kPairsPerSuper < total) {   // before the scratch of this round is overwritten
-                if (NW > 1) __syncthreads(); else wave_lds_sync();
-            }
-        }
-        if (NW > 1) {
-            if (sb_wave) s_vmask[l] = (uint8_t)vmask;
-            __syncthreads();
-            if (!ref_wave) return;
-            vmask = s_vmask[l];
-        }
+    if (__builtin_expect(__ballot(slow != 0) != 0ull, 0))
+        vmask |= slow_alleles(hist, s_refwin, slow, l, pos, rt, ref_rank, ref, win_lo, win_hi, records + ((int64_t)t * kSlotsPerTile + l * 4), P);
+    if (NW > 1) {
+        if (var_wave) s_vmask[l] = (uint8_t)vmask;
+        __syncthreads();
+        if (!ref_wave) return;
+        vmask = s_vmask[l];
     }
 #ifdef PISCES_TIMING
-    tcD = wall_clock64();
+    const long long tcB = wall_clock64();
 #endif
 
     // validity bits, counts, tile directory
@@ -868,13 +825,41 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
         tile_result->n_candidate_loci = (int)(tc2 & 0x3FFFFFFF);
         tile_result->n_called = (int)__builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
         tile_result->valid[0] = __builtin_amdgcn_s_getreg(63508);        // HW_REG_XCC_ID
-        tile_result->valid[1] = (uint32_t)(tcA - tc1);   // pass mask
-        tile_result->valid[2] = (uint32_t)(tcB - tcA);   // Reference pass
-        tile_result->valid[3] = (uint32_t)(tcC - tcB);   // variant q-scores
-        tile_result->valid[4] = (uint32_t)(tcD - tcC);   // strand-bias items + assembly
-        tile_result->valid[5] = (uint32_t)(tc2 - tcD);   // directory
+        tile_result->valid[1] = 0;
+        tile_result->valid[2] = (uint32_t)(tcA - tc1);   // counts + Reference pass
+        tile_result->valid[3] = (uint32_t)(tcB - tcA);   // variants + meeting
+        tile_result->valid[4] = 0;
+        tile_result->valid[5] = (uint32_t)(tc2 - tcB);   // directory
 #endif
     }
+}
+
+// The handle's memo tables (DeviceParams), filled with the very functions the call phase would otherwise run.
+__global__ __launch_bounds__(256) void build_vq_tab_kernel(int16_t* __restrict__ tab, int32_t n_k, int32_t n_cov, DeviceParams P)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_k * n_cov) return;
+    tab[i] = (int16_t)poisson_qscore((int32_t)(i / n_cov), (int32_t)(i % n_cov), P);
+}
+__global__ __launch_bounds__(256) void build_sb_tab_kernel(double* __restrict__ tab, double* __restrict__ tab0, int32_t n_k, int32_t n_cov, DeviceParams P)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_k * n_cov) return;
+    const int k = (int)(i / n_cov), cov = (int)(i % n_cov);
+    // sb_create_stats with support >= 1 (Poisson / Extended): Math.Max(0, Poisson.Cdf(support - 1, coverage * noiseFreq))
+    tab[i] = k >= 1 ? fmax(0.0, poisson_cdf_sb((double)k - 1, (double)cov * P.err_sb)) : 0.0;
+    if (k == 0) tab0[cov] = pow(1 - P.err_sb, (double)cov);   // support == 0, Extended model
+}
+__global__ __launch_bounds__(256) void build_gq_cap_kernel(int16_t* __restrict__ tab, const double* __restrict__ gq_tail, int32_t n_a, int32_t n_cov, DeviceParams P)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_a * n_cov) return;
+    // somatic_gq_finish for a hom-ref / hom-alt call whose variant q-score is the cap
+    if (i < n_cov) { tab[i] = 0; return; }   // row a = 0 is never addressed
+    double rawQ = p_to_q(q_to_p_int(P.max_vq, P) + gq_tail[i]);
+    double qScore = fmin((double)P.max_gq, rawQ);
+    qScore = fmax(qScore, (double)P.min_gq);
+    tab[i] = (int16_t)rint(qScore);
 }
 
 // streaming-read probe: the hot kernel's load pattern (non-temporal dwordx4, 8 per lane in flight) and nothing else
@@ -956,10 +941,10 @@ __global__ __launch_bounds__(kBlock) void accumulate_tiles_kernel(
     __syncthreads();
     const uint32_t n_loci = (uint32_t)tile.n_loci, min_bq = (uint32_t)min_bq_;
     stream_tuples(tuples, tile.tuple_begin, tile.tuple_end, [&](uint32_t v) {
-        uint32_t locus = v & 0x7FFFu;
-        uint32_t anchor = (v >> 15) & 0xFu;
-        uint32_t dir = (v >> 19) & 3u;
-        uint32_t allele = (v >> 21) & 7u;
+        uint32_t locus = PISCES_TUPLE_LOCUS(v);
+        uint32_t anchor = PISCES_TUPLE_ANCHOR(v);
+        uint32_t dir = PISCES_TUPLE_DIR(v);
+        uint32_t allele = PISCES_TUPLE_ALLELE(v);
         uint32_t qual = v >> 24;
         if (allele < 4u && qual < min_bq) allele = 4u;
         if (locus < n_loci && dir < 3u && allele < 6u && anchor < (uint32_t)PISCES_NUM_ANCHORS) {

@@ -107,6 +107,11 @@ struct PiscesHip {
     DeviceBuf<double> d_bq_lut;    // [256] Math.Pow(10, -1 * (int)q / 10f): what a base of quality q adds to the base-quality sums (NoiseModel.Window)
     DeviceBuf<double> d_sumq;      // RegionState._sumOfAlleleBaseQualities of the tiles being called (NoiseModel.Window)
     DeviceBuf<double> d_gq_tail;   // memo of the genotype-quality Poisson tail (DeviceParams::gq_tail)
+    DeviceBuf<int16_t> d_vq_tab;   // memo tables of the call phase (DeviceParams::vq_tab / sb_tab / sb0_tab / gq_cap)
+    DeviceBuf<double> d_sb_tab;
+    DeviceBuf<double> d_sb0_tab;
+    DeviceBuf<int16_t> d_gq_cap;
+    DeviceBuf<DeviceParams> d_params;   // device copy of P (what the wave kernel's out-of-line cold path reads instead of a by-value copy)
     int n_cus = 256;
     DeviceBuf<int32_t> d_offsets;
     DeviceBuf<PiscesCalledAllele> d_compact;
@@ -234,6 +239,11 @@ static DeviceParams make_params(const PiscesHipConfig& c)
     P.gq_tail_a = 0;
     P.gq_tail_cov = 0;
     P.refs_only = c.call_mnvs ? 1 : 0;
+    P.vq_tab = nullptr;
+    P.sb_tab = nullptr;
+    P.sb0_tab = nullptr;
+    P.gq_cap = nullptr;
+    P.vq_tab_k = P.sb_tab_k = P.tab_cov = 0;
     return P;
 }
 
@@ -386,6 +396,42 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         h->P.gq_tail_a = n_a;
         h->P.gq_tail_cov = n_cov;
     }
+    if (!getenv("PISCES_HIP_NO_CALL_TABLES") && h->cfg.noise_model == PISCES_NOISE_FLAT && h->cfg.strand_bias_model != PISCES_SB_DIPLOID &&
+        h->cfg.max_variant_qscore <= 32767 && h->cfg.max_genotype_qscore <= 32767 && h->cfg.min_genotype_qscore >= -32768) {
+        // Memo tables of the streaming-rate kernel's call phase, filled by the device with the functions they stand in for
+        // (bit-identical by construction): variant q-score and strand-bias tail by (support, coverage), the support-0 power by
+        // coverage, the capped genotype q-score by (non-allele observations, coverage).  ~22 MB and ~1 ms per handle.
+        const int32_t n_k = 256, n_cov = 8192;
+        if ((e = h->d_vq_tab.reserve((size_t)n_k * n_cov)) != hipSuccess || (e = h->d_sb_tab.reserve((size_t)n_k * n_cov)) != hipSuccess ||
+            (e = h->d_sb0_tab.reserve((size_t)n_cov)) != hipSuccess ||
+            (h->P.gq_tail && (e = h->d_gq_cap.reserve((size_t)h->P.gq_tail_a * h->P.gq_tail_cov)) != hipSuccess)) {
+            g_create_error = std::string("pisces_hip_create: ") + hipGetErrorString(e);
+            pisces_hip_destroy(h);
+            return PISCES_E_DEVICE;
+        }
+        const unsigned nb = (unsigned)(((size_t)n_k * n_cov + 255) / 256);
+        hipLaunchKernelGGL(build_vq_tab_kernel, dim3(nb), dim3(256), 0, h->stream, h->d_vq_tab.p, n_k, n_cov, h->P);
+        hipLaunchKernelGGL(build_sb_tab_kernel, dim3(nb), dim3(256), 0, h->stream, h->d_sb_tab.p, h->d_sb0_tab.p, n_k, n_cov, h->P);
+        if (h->P.gq_tail)
+            hipLaunchKernelGGL(build_gq_cap_kernel, dim3((unsigned)((h->P.gq_tail_a * h->P.gq_tail_cov + 255) / 256)), dim3(256), 0, h->stream,
+                               h->d_gq_cap.p, h->P.gq_tail, h->P.gq_tail_a, h->P.gq_tail_cov, h->P);
+        if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(h->stream)) != hipSuccess) {
+            g_create_error = std::string("pisces_hip_create: ") + hipGetErrorString(e);
+            pisces_hip_destroy(h);
+            return PISCES_E_DEVICE;
+        }
+        h->P.vq_tab = h->d_vq_tab.p;
+        h->P.sb_tab = h->d_sb_tab.p;
+        h->P.sb0_tab = h->d_sb0_tab.p;
+        h->P.gq_cap = h->P.gq_tail ? h->d_gq_cap.p : nullptr;
+        h->P.vq_tab_k = h->P.sb_tab_k = n_k;
+        h->P.tab_cov = n_cov;
+    }
+    if ((e = h->d_params.reserve(1)) != hipSuccess || (e = hipMemcpy(h->d_params.p, &h->P, sizeof(DeviceParams), hipMemcpyHostToDevice)) != hipSuccess) {
+        g_create_error = std::string("pisces_hip_create: ") + hipGetErrorString(e);
+        pisces_hip_destroy(h);
+        return PISCES_E_DEVICE;
+    }
     *out = h;
     return PISCES_OK;
 }
@@ -396,7 +442,7 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_ref.release(); h->d_tuples.release(); h->d_tiles.release(); h->d_tile_results.release();
-    h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release(); h->d_totals.release(); h->d_qlut.release(); h->d_bq_lut.release(); h->d_sumq.release(); h->d_gq_tail.release(); h->d_offsets.release(); h->d_compact.release();
+    h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release(); h->d_totals.release(); h->d_qlut.release(); h->d_bq_lut.release(); h->d_sumq.release(); h->d_gq_tail.release(); h->d_vq_tab.release(); h->d_sb_tab.release(); h->d_sb0_tab.release(); h->d_gq_cap.release(); h->d_params.release(); h->d_offsets.release(); h->d_compact.release();
     for (int i = 0; i < 2; i++) { h->d_log_pos[i].release(); h->d_log_tup[i].release(); }
     h->d_log_n.release(); h->d_flags.release(); h->d_bucket.release(); h->d_tile_cnt.release(); h->d_total.release();
     for (auto& st : h->stage) {
@@ -516,7 +562,7 @@ __global__ __launch_bounds__(256) void log_append_kernel(const int32_t* __restri
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         log_pos[base + i] = src_pos[i];
-        log_tup[base + i] = src_tup[i] & ~0x7FFFu;
+        log_tup[base + i] = src_tup[i] & ~0xFCu;   // the column is set from the position when the log is bucketed
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(appended, (unsigned long long)n);
 }
@@ -1029,10 +1075,10 @@ static hipError_t launch_call_tiles(PiscesHip* h, hipStream_t s, const uint32_t*
         const bool two = h->kernel_variant == 3 || (h->kernel_variant == 4 && (int64_t)n_tiles <= (int64_t)h->n_cus * 32);
         if (!two)
             hipExtLaunchKernelGGL(call_tiles_wave_kernel<1>, dim3((unsigned)n_tiles), dim3(64), lds, s, e0, e1, 0u, d_tuples, d_tiles,
-                                  n_tiles, d_ref, ref_start, ref_len, d_records, d_tr, h->P);
+                                  n_tiles, d_ref, ref_start, ref_len, d_records, d_tr, h->P, (const DeviceParams*)h->d_params.p);
         else
             hipExtLaunchKernelGGL(call_tiles_wave_kernel<2>, dim3((unsigned)n_tiles), dim3(128), lds, s, e0, e1, 0u, d_tuples, d_tiles,
-                                  n_tiles, d_ref, ref_start, ref_len, d_records, d_tr, h->P);
+                                  n_tiles, d_ref, ref_start, ref_len, d_records, d_tr, h->P, (const DeviceParams*)h->d_params.p);
         return hipSuccess;
     }
     hipExtLaunchKernelGGL(call_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), lds, s, e0, e1, 0u, d_tuples, d_tiles, n_tiles, d_ref,

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(const int32_t* __re
             dst = t.tuple_begin + (long long)atomicAdd(&tile_fill[ti[k]], 1u);
             start_position = t.start_position;
         }
-        tuples[dst] = (tup[k] & ~0x7FFFu) | (uint32_t)(pos[k] - start_position);
+        tuples[dst] = PISCES_TUPLE_WITH_LOCUS(tup[k], (uint32_t)(pos[k] - start_position));
     }
 }
 

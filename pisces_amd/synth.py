@@ -52,7 +52,9 @@ def _amplicon_lengths(n_loci):
 
 
 def make_pileup(n_loci, depth, seed=20260928, device="cpu", p_lowq=0.02, base_error=0.001, snv_every=100,
-                snv_offset=37, q_hi=37, q_lo=12, vaf_range=(0.02, 0.5), strand_range=(0.3, 0.7), flank=READ_LEN):
+                snv_offset=37, q_hi=37, q_lo=12, vaf_range=(0.02, 0.5), strand_range=(0.3, 0.7), flank=READ_LEN, tile=TILE):
+    """`tile` = loci per tile of the bucketed tuple stream (<= 64; the kernels take any PiscesTile.n_loci <= 64)."""
+    assert 1 <= tile <= TILE
     dev = torch.device(device)
     g = torch.Generator(device=dev)
     g.manual_seed(int(seed))
@@ -106,24 +108,27 @@ def make_pileup(n_loci, depth, seed=20260928, device="cpu", p_lowq=0.02, base_er
                          torch.where(right >= _abi.ANCHOR_SIZE, torch.tensor(_abi.ANCHOR_SIZE, device=dev), _abi.NUM_ANCHORS - right - 1),
                          torch.where(left >= _abi.ANCHOR_SIZE, torch.tensor(_abi.ANCHOR_SIZE, device=dev), left))
     direction = reverse.to(torch.int64)   # Forward 0 / Reverse 1
-    packed = ((anchor.to(torch.int64) << 15) | (direction << 19) | (base.to(torch.int64) << 21) | (qual.to(torch.int64) << 24))
+    # PISCES_TUPLE_PACK without the column (the locus-in-tile enters per tile below)
+    packed = ((direction << 8) | (base.to(torch.int64) << 10) | (anchor.to(torch.int64) << 13) | (qual.to(torch.int64) << 24))
     packed = packed.expand(shape)
+    dir_bit4 = (direction & 1) << 4
 
     # tile-bucketed tuple stream: tiles of 64 loci from locus 0; inside a tile read-major (each read's run of loci)
-    n_tiles = math.ceil(n_loci / TILE)
+    n_tiles = math.ceil(n_loci / tile)
     tiles = np.zeros(n_tiles, dtype=_abi.TILE_DTYPE)
     segs = []
     cursor = 0
     pad_val = torch.tensor([-1], device=dev, dtype=torch.int64)   # 0xFFFFFFFF after the int32 cast
     for t in range(n_tiles):
-        l0, l1 = t * TILE, min(t * TILE + TILE, n_loci)
+        l0, l1 = t * tile, min(t * tile + tile, n_loci)
         n_seg = 0
         for a in range(l0 // READ_LEN, (l1 - 1) // READ_LEN + 1):
             i0, i1 = max(l0, a * READ_LEN) - a * READ_LEN, min(l1, a * READ_LEN + lens[a]) - a * READ_LEN
             if i1 <= i0:
                 continue
             loc = torch.arange(a * READ_LEN + i0 - l0, a * READ_LEN + i1 - l0, device=dev, dtype=torch.int64).view(1, -1)
-            piece = (packed[a, :, i0:i1] | loc).reshape(-1)
+            col = (((loc >> 2) & 15) | ((loc & 3) << 4)) ^ dir_bit4[0]          # PISCES_TUPLE_COLUMN(locus, direction)
+            piece = (packed[a, :, i0:i1] | (col << 2)).reshape(-1)
             segs.append(piece)
             n_seg += piece.numel()
         tiles[t] = (region_start + l0, l1 - l0, cursor, cursor + n_seg)
@@ -178,7 +183,7 @@ def observations_of(p, n_tiles=None):
     for t in range(nt):
         b, e = int(tiles[t]["tuple_begin"]), int(tiles[t]["tuple_end"])
         seg = tup[b:e]
-        pos_out.append((tiles[t]["start_position"] + (seg & 0x7FFF)).astype(np.int32))
+        pos_out.append((tiles[t]["start_position"] + _abi.tuple_fields(seg)[0]).astype(np.int32))
         tup_out.append(seg)
     if not pos_out:
         return np.zeros(0, np.int32), np.zeros(0, np.uint32)

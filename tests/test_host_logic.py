@@ -16,11 +16,10 @@ DIR = {"F": 0, "R": 1, "S": 2}
 def counts_from_observations(pos, tup, start, n_loci, min_bq):
     """numpy histogram of (position, tuple) observations with the kernel's 'qual < minBQ -> N' rule."""
     c = np.zeros((n_loci, 6, 3, _abi.NUM_ANCHORS), dtype=np.int32)
-    allele = (tup >> 21) & 7
-    qual = tup >> 24
+    _, anchor, direction, allele, qual = _abi.tuple_fields(tup)
     allele = np.where((allele < 4) & (qual < min_bq), 4, allele)
     keep = (pos >= start) & (pos < start + n_loci)
-    np.add.at(c, (pos[keep] - start, allele[keep], (tup[keep] >> 19) & 3, (tup[keep] >> 15) & 0xF), 1)
+    np.add.at(c, (pos[keep] - start, allele[keep], direction[keep], anchor[keep]), 1)
     return c
 
 
@@ -107,7 +106,7 @@ def test_synthetic_pileup_reads_and_tuples_agree():
     assert 0 < len(called_snv) and set((called_snv["position"] - p.region_start).tolist()) <= set(p.planted.tolist())
     # expander(reads) gives the same observations as the generator's tuple view (up to order)
     epos, etup = engine.expand_reads(synth.reads_of(p), 20)
-    key = lambda P, T: np.sort((P.astype(np.int64) << 32) | (T & ~np.uint32(0x7FFF)).astype(np.int64))
+    key = lambda P, T: np.sort((P.astype(np.int64) << 32) | (T & ~np.uint32(0xFC)).astype(np.int64))
     np.testing.assert_array_equal(key(epos, etup), key(pos, tup))
 
 

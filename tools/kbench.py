@@ -15,11 +15,12 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--ring", type=int, default=4)
     ap.add_argument("--tag", default="")
+    ap.add_argument("--tile", type=int, default=64, help="loci per tile of the synthetic tuple stream")
     a = ap.parse_args()
     import torch
     from pisces_amd import _abi, engine, synth
     dev = torch.device("cuda", 0)
-    ring = [synth.make_pileup(a.loci, a.depth, seed=100 + b, device=dev) for b in range(a.ring)]
+    ring = [synth.make_pileup(a.loci, a.depth, seed=100 + b, device=dev, tile=a.tile) for b in range(a.ring)]
     for p in ring:
         p.base = p.qual = None
     torch.cuda.empty_cache()
@@ -33,6 +34,7 @@ def main():
             p = ring[i % a.ring]
             c.call_tiles(p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), 1, p.ref_len,
                          rec.data_ptr(), cap, tr.data_ptr(), st)
+        torch.cuda.synchronize()
         for i in range(5):
             step(i)
         torch.cuda.synchronize()
@@ -43,7 +45,7 @@ def main():
         ms, n = c.kernel_time()
     k = ms / n
     nb = 4 * ring[0].n_obs + a.loci + 64 * a.loci
-    print(f"{a.tag or os.environ.get('PISCES_HIP_LIB', 'product')}: loci={a.loci} depth={a.depth} kernel={k*1e3:.1f} us  "
+    print(f"{a.tag or os.environ.get('PISCES_HIP_LIB', 'product')}: loci={a.loci} depth={a.depth} tile={a.tile} kernel={k*1e3:.1f} us  "
           f"{nb / (k * 1e-3) / 1e9:.0f} GB/s algorithmic ({nb / (k * 1e-3) / 8e12 * 100:.1f}% of 8 TB/s)  "
           f"{a.loci / (k * 1e-3) / 1e9:.2f} G loci/s", flush=True)
 
