@@ -1121,10 +1121,14 @@ static void extract_snvs(FinderCtx* f, int opStartIndexInRead, uint32_t operatio
 {
     const OrcRead* r = f->r;
     int variantLengthSoFar = 0, interveningRefLengthSoFar = 0, openLeft = 0;
+    /* An M operation that runs past the end of the contig stops there (:103-104).  The reference then flushes a pending variant
+     * from `operationLength`, i.e. from indices beyond both strings, and Substring throws; here the flush uses the bases actually
+     * walked (n_done), so the pending variant comes out at its own coordinates and nothing is read out of range. */
+    int n_done = (int)operationLength;
     for (int i = 0; i < (int)operationLength; i++) {
         int qualityGoodEnough = r->quals[opStartIndexInRead + i] >= f->min_bq;
         uint8_t readBase = r->bases[opStartIndexInRead + i];
-        if (opStartIndexInReference + i >= f->ref_len) break;
+        if (opStartIndexInReference + i >= f->ref_len) { n_done = i; break; }
         uint8_t refBase = f->ref[opStartIndexInReference + i];
         int atEndOfOperation = i == ((int)operationLength - 1);
         int startingMnvAtEndOfOperation = (atEndOfOperation && variantLengthSoFar == 0);
@@ -1151,8 +1155,8 @@ static void extract_snvs(FinderCtx* f, int opStartIndexInRead, uint32_t operatio
             }
         }
     }
-    flush_variant(f, opStartIndexInRead + (int)operationLength - variantLengthSoFar,
-                  opStartIndexInReference + (int)operationLength - variantLengthSoFar, variantLengthSoFar,
+    flush_variant(f, opStartIndexInRead + n_done - variantLengthSoFar,
+                  opStartIndexInReference + n_done - variantLengthSoFar, variantLengthSoFar,
                   interveningRefLengthSoFar, openLeft, 0);
 }
 

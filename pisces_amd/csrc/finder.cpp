@@ -104,11 +104,14 @@ void find_candidates(const ReadView& r, const uint8_t* ref, int64_t ref_len, int
     auto extract_snvs = [&](int opStartIndexInRead, int operationLength, int opStartIndexInReference) {
         int variantLengthSoFar = 0, interveningRefLengthSoFar = 0;
         bool openLeft = false;
+        // An M operation that runs past the contig end stops there; the pending variant is flushed from the bases actually walked
+        // (the reference flushes from operationLength and its Substring throws): nothing is read beyond the reference.
+        int n_done = operationLength;
         for (int i = 0; i < operationLength; i++) {
-            if (opStartIndexInRead + i >= r.read_len) break;
+            if (opStartIndexInRead + i >= r.read_len) { n_done = i; break; }
             const bool qualityGoodEnough = r.quals[opStartIndexInRead + i] >= minBQ;
             const uint8_t readBase = r.bases[opStartIndexInRead + i];
-            if (opStartIndexInReference + i >= ref_len) break;
+            if (opStartIndexInReference + i >= ref_len) { n_done = i; break; }
             const uint8_t refBase = ref[opStartIndexInReference + i];
             const bool atEndOfOperation = i == operationLength - 1;
             const bool startingMnvAtEndOfOperation = atEndOfOperation && variantLengthSoFar == 0;
@@ -134,7 +137,7 @@ void find_candidates(const ReadView& r, const uint8_t* ref, int64_t ref_len, int
                 }
             }
         }
-        flush_variant(opStartIndexInRead + operationLength - variantLengthSoFar, opStartIndexInReference + operationLength - variantLengthSoFar,
+        flush_variant(opStartIndexInRead + n_done - variantLengthSoFar, opStartIndexInReference + n_done - variantLengthSoFar,
                       variantLengthSoFar, interveningRefLengthSoFar, openLeft, false);
     };
 

@@ -49,6 +49,10 @@ template <typename T>
 struct DeviceBuf {
     T* p = nullptr;
     size_t cap = 0;
+    DeviceBuf() = default;
+    DeviceBuf(const DeviceBuf&) = delete;
+    DeviceBuf& operator=(const DeviceBuf&) = delete;
+    ~DeviceBuf() { release(); }   // a local buffer is freed on every early return
     hipError_t reserve(size_t n)
     {
         if (n <= cap) return hipSuccess;
@@ -615,6 +619,11 @@ static int32_t validate_batch(const PiscesReadBatch* b)
     if (b->n_reads == 0) return PISCES_OK;
     if (!b->position || !b->flags || !b->cigar_offset || !b->cigar_op || !b->cigar_len || !b->seq_offset || !b->bases || !b->quals)
         return PISCES_E_INVALID_ARG;
+    // BAM stores an operation length in 28 bits; anything larger would overflow the int arithmetic of the read walks
+    const int64_t n_ops = (int64_t)b->cigar_offset[b->n_reads] - (int64_t)b->cigar_offset[0];
+    if (n_ops < 0) return PISCES_E_INVALID_ARG;
+    for (int64_t c = b->cigar_offset[0]; c < (int64_t)b->cigar_offset[b->n_reads]; c++)
+        if (b->cigar_len[c] > 0x0FFFFFFFu) return PISCES_E_INVALID_ARG;
     return PISCES_OK;
 }
 
@@ -672,6 +681,7 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
             if (op_ref(t)) ref_span += r.cigar_len[c];   // mapped bases + every gap: one observation each at most
         }
         if (read_span > r.read_len) return fail(h, PISCES_E_INVALID_ARG, "add_reads: CIGAR does not match the read");
+        if ((int64_t)r.position + ref_span > 0x7FFFFFFFll) return fail(h, PISCES_E_INVALID_ARG, "add_reads: read runs past position 2^31 - 1");
         if (r.dirs)
             for (int k = 0; k < r.read_len; k++)
                 if (r.dirs[k] > 2) return fail(h, PISCES_E_INVALID_ARG, "add_reads: CIGAR does not match the read");
@@ -883,9 +893,13 @@ int64_t pisces_hip_find_candidates(const PiscesReadBatch* batch, const uint8_t* 
 {
     if (validate_batch(batch) != PISCES_OK || !ref || ref_len <= 0 || capacity < 0 || (capacity > 0 && !out)) return PISCES_E_INVALID_ARG;
     std::vector<HostCandidate> found;
-    for (int32_t i = 0; i < batch->n_reads; i++)
-        find_candidates(read_view(batch, i), ref, ref_len, min_bq, PISCES_ANCHOR_SIZE, snvs_and_mnvs != 0, call_mnvs != 0, max_mnv_length,
-                        max_gap_between_mnv, found);
+    try {
+        for (int32_t i = 0; i < batch->n_reads; i++)
+            find_candidates(read_view(batch, i), ref, ref_len, min_bq, PISCES_ANCHOR_SIZE, snvs_and_mnvs != 0, call_mnvs != 0, max_mnv_length,
+                            max_gap_between_mnv, found);
+    } catch (...) {   // nothing crosses the C ABI as an exception
+        return PISCES_E_INVALID_ARG;
+    }
     int64_t bytes = 0;
     for (size_t i = 0; i < found.size(); i++) {
         const HostCandidate& c = found[i];

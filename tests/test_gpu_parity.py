@@ -1,6 +1,6 @@
 """Parity of the HIP path (through the C ABI) against the oracle on a real MI355X.
 Bit-exact for every integer field of the 64-byte record (position, coverage, support, counts,
-filters, genotype); q-scores within +-1 Phred (north_star), strand-bias score to 1e-9 relative."""
+filters, genotype) and for the q-scores (north_star allows +-1 Phred; none is used), strand-bias score to 1e-9 relative."""
 import json
 import os
 
@@ -19,19 +19,24 @@ INT_FIELDS = ["position", "total_coverage", "allele_support", "reference_support
               "support_by_dir"]
 
 
-def assert_records_match(got, exp, q_tol=1):
+def assert_records_match(got, exp, q_tol=0):
+    """Every field exact by default (what is observed: the device restates the C# arithmetic operation by operation).  With q_tol = 1
+    (north_star's +-1 Phred) a q-score may move by one on at most 0.1 % of the rows, and on those rows only what a threshold crossing
+    explains may differ: the LowVariantQscore / LowGQ filter bits."""
     assert len(got) == len(exp), (len(got), len(exp))
     for f in INT_FIELDS:
         np.testing.assert_array_equal(got[f], exp[f], err_msg=f)
     dq = np.abs(got["variant_qscore"].astype(np.int64) - exp["variant_qscore"])
     dg = np.abs(got["genotype_qscore"].astype(np.int64) - exp["genotype_qscore"])
     assert dq.max(initial=0) <= q_tol and dg.max(initial=0) <= q_tol, (dq.max(), dg.max())
-    same_q = (dq == 0) & (dg == 0)
-    # categorical outputs may legitimately flip only where a q-score moved across a threshold
-    np.testing.assert_array_equal(got["info"][same_q], exp["info"][same_q])
-    np.testing.assert_array_equal(got["filter_bits"][same_q], exp["filter_bits"][same_q])
+    moved = (dq != 0) | (dg != 0)
+    assert int(moved.sum()) <= len(got) // 1000, (int(moved.sum()), len(got))
+    np.testing.assert_array_equal(got["info"], exp["info"])
+    q_bits = np.uint16((1 << 3) | (1 << 6))   # FilterType.LowVariantQscore, LowGenotypeQuality
+    np.testing.assert_array_equal(got["filter_bits"][~moved], exp["filter_bits"][~moved])
+    np.testing.assert_array_equal(got["filter_bits"][moved] & ~q_bits, exp["filter_bits"][moved] & ~q_bits)
     np.testing.assert_allclose(got["strand_bias_score"], exp["strand_bias_score"], rtol=1e-9, atol=1e-300)
-    return int((~same_q).sum())
+    return int(moved.sum())
 
 
 @pytest.fixture(scope="module")

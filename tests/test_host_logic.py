@@ -233,6 +233,26 @@ def test_full_finder_matches_oracle_finder_with_mnvs():
         assert got == exp, (call_mnvs, max_len, max_gap)
 
 
+def test_finder_read_overhanging_the_contig_end():
+    """An M operation that runs past the end of the reference (circular contigs: PhiX, chrM): the walk stops at the last reference
+    base and a pending mismatch comes out at its own coordinates — the reference's flush reads from `operationLength` there and
+    Substring throws (CandidateVariantFinder.cs:103-104,162-165).  Library == oracle, nothing is read beyond the reference."""
+    ref = b"ACGTACGTAC"   # 10 bases
+    for call_mnvs in (False, True):
+        for seq in ("GTAC" + "TGCATG", "GTAA" + "TGCATG", "GTGG" + "TGCATG"):   # read at 7: M walk over 7..10, then 6 bases of overhang
+            reads = [{"pos": 7, "cigar": [("M", 10)], "seq": seq, "quals": [37] * 10, "reverse": False, "dirs": None}]
+            got = engine.find_candidates(_abi.ReadBatch(reads), ref, 20, True, call_mnvs, 3, 1)
+            rd = orc.make_read(7, seq, cigar=[("M", 10)], quals=[37] * 10)
+            exp = [{"position": c.position, "category": c.category, "ref": c.ref.decode(), "alt": c.alt.decode(),
+                    "support_by_dir": list(c.support_by_dir), "well_anchored_by_dir": list(c.well_anchored_by_dir),
+                    "open_left": bool(c.open_left), "open_right": bool(c.open_right)}
+                   for c in orc.find_candidates(rd, ref.decode(), call_mnvs=call_mnvs, max_mnv=3, max_gap=1)]
+            assert got == exp, (call_mnvs, seq)
+            assert all(1 <= e["position"] and e["position"] + len(e["ref"]) - 1 <= len(ref) for e in got), got
+            if seq.startswith("GTAA"):
+                assert [(e["position"], e["ref"], e["alt"]) for e in got] == [(10, "C", "A")]
+
+
 def test_library_full_finder_on_all_reference_cases():
     """pisces_hip_find_candidates with callMNVs on, over all 106 reads of the reference's VariantFinderTests (SNV, MNV, deletion and
     insertion suites, tests/golden/finder_cases.json): every expected candidate, nothing else."""
