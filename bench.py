@@ -43,6 +43,31 @@ def algorithmic_bytes(n_obs, n_loci, n_records):
     return 4 * n_obs + n_loci + 64 * n_records
 
 
+def host_cpu():
+    """(model name, physical cores, hardware threads) of the box from /proc/cpuinfo."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    threads = os.cpu_count() or 1
+    return model, (len(cores) or threads), threads
+
+
 def cpu_baseline(torch, pileup, cfg, budget_s=14.0):
     """The oracle (CPU restatement of the reference C# path: per read FindCandidates -> AddCandidates ->
     AddAlleleCounts, then AlleleCaller over every locus) on a bounded sample of the same workload.
@@ -69,15 +94,16 @@ def cpu_baseline(torch, pileup, cfg, budget_s=14.0):
         _, n = orc.run_reads(batch, ref, pileup.region_start, n_loci, cfg)
         loci += n
     dt1 = time.perf_counter() - t0
-    single = {"value": loci / dt1, "unit": "candidate loci/s", "cores": 1, "kind": "port",
+    model, phys_cores, hw_threads = host_cpu()
+    single = {"value": loci / dt1, "unit": "candidate loci/s", "cores": 1, "kind": "port", "cpu": model,
               "sample": f"first {n_loci} loci x {pileup.depth}x of batch 0 ({batch.n_reads} reads) x {repeats} passes, {dt1:.1f} s"}
 
     # interval shards, one thread each (ctypes releases the GIL inside the oracle)
-    cores = os.cpu_count() or 1
+    cores = phys_cores   # one thread per physical core, not per hardware thread
     shards = []
     for idx in np.array_split(np.arange(n_amp_total), min(cores, n_amp_total)):
         a0, na = int(idx[0]), len(idx)
-        b = synth.reads_of(pileup, na, first_amplicon=a0)
+        b = synth.reads_of(pileup, na, first_amplicon=pileup.first_amplicon + a0)
         start = pileup.region_start + a0 * synth.READ_LEN
         nl = min(pileup.n_loci - a0 * synth.READ_LEN, na * synth.READ_LEN)
         shards.append((b, start, nl))
@@ -85,9 +111,41 @@ def cpu_baseline(torch, pileup, cfg, budget_s=14.0):
     t0 = time.perf_counter()
     _, loci_n = orc.run_reads_sharded(shards, ref, cfg, passes=passes)   # pthreads inside the oracle library
     dtn = time.perf_counter() - t0
-    multi = {"value": loci_n / dtn, "unit": "candidate loci/s", "cores": len(shards), "kind": "port",
+    multi = {"value": loci_n / dtn, "unit": "candidate loci/s", "cores": len(shards), "kind": "port", "cpu": model,
+             "physical_cores": phys_cores, "hardware_threads": hw_threads,
              "sample": f"batch 0 ({pileup.n_loci} loci x {pileup.depth}x) in {len(shards)} interval shards, one thread each, x {passes} passes, {dtn:.1f} s"}
     return single, multi
+
+
+def end_to_end(pileup, cfg, engine, loci=30_000):
+    """the end-to-end rate of the drop-in boundary (the streaming surface the C# shim drives), host buffers in,
+    called alleles out, H2D / D2H and every host pass included: reads of the first `loci` loci of batch 0 through
+    pisces_hip_add_reads + pisces_hip_flush, (a) one pair per 1000-locus block as SmallVariantCaller.Execute does, (b) 30 blocks per
+    pair (HipEngine.BlocksPerFlush).  This is the figure comparable to `cpu_baseline` (same scope: reads -> called alleles)."""
+    from pisces_amd import synth
+    ref = pileup.ref.cpu().numpy()
+    n_amp_total = pileup.base.shape[0]
+    n_amp = min(n_amp_total, max(7, loci // synth.READ_LEN))
+    out = {}
+    for label, per_call in (("per_block", 7), ("batched_30_blocks", 200)):   # 7 amplicons = 1050 loci: one block of reads per call
+        batches = [(a0, synth.reads_of(pileup, min(per_call, n_amp - a0), first_amplicon=pileup.first_amplicon + a0)) for a0 in range(0, n_amp, per_call)]
+        n_loci = min(pileup.n_loci, n_amp * synth.READ_LEN)
+        best = None
+        for rep in range(3):   # the first pass of a handle pays for its pinned staging buffers
+            with engine.HipVariantCaller(cfg) as c:
+                c.SetReference(ref)
+                n_rec = 0
+                t0 = time.perf_counter()
+                for a0, b in batches:
+                    c.AddAlleleCounts(b)
+                    n_rec += len(c.Call(pileup.region_start + a0 * synth.READ_LEN - 1, capacity=1 << 18))   # LastClearedPosition
+                n_rec += len(c.Call(None, capacity=1 << 18))
+                dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        out[label] = {"value": n_loci / best, "unit": "candidate loci/s", "seconds": best, "loci": n_loci, "records": n_rec,
+                      "add_reads_flush_pairs": len(batches), "reads": int(sum(b.n_reads for _, b in batches))}
+    out["scope"] = "host read buffers -> pisces_hip_add_reads -> pisces_hip_flush -> host records (PCIe both ways, best of 3 handles)"
+    return out
 
 
 def main():
@@ -98,6 +156,7 @@ def main():
     ap.add_argument("--loci", type=int, default=N_LOCI)
     ap.add_argument("--depth", type=int, default=DEPTH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shard-check", action="store_true", help="skip the on-device check of one cut of the interval partition")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra multi-stream figure (profiling runs: its overlapped "
                     "launches would mix into the per-kernel statistics of the timed region)")
     args = ap.parse_args()
@@ -126,10 +185,24 @@ def main():
     cfg = _abi.default_config()
     caller = engine.HipVariantCaller(cfg, device=local_rank)
 
-    # ---- inputs, resident in HBM: RING_BATCHES distinct pileups of this rank's interval shard ----
-    ring = [synth.make_pileup(args.loci, args.depth, seed=BASE_SEED + 1000 * rank + b, device=dev) for b in range(RING_BATCHES)]
+    # ---- the job: ONE interval set of world x args.loci loci (amplicon intervals of 150 loci), partitioned by interval across the
+    # ranks (contiguous shards balanced by length x depth, cuts on the 1000-locus block grid).  Weak scaling: the set grows
+    # with the number of GPUs, every rank owns ~args.loci loci.  At world size 1 the single shard is BASELINE config 2 itself. ----
+    total_loci = args.loci * world
+    origin = synth.READ_LEN + 1                                      # position of locus 0 (the generator's flank comes first)
+    n_amp = -(-total_loci // synth.READ_LEN)
+    intervals = [(origin + a * synth.READ_LEN, origin + min((a + 1) * synth.READ_LEN, total_loci) - 1) for a in range(n_amp)]
+    parts = shard.partition_intervals(intervals, world, block_size=cfg.block_size, weights=[args.depth] * len(intervals))
+    own_lo, own_hi, own_intervals = parts[rank]
+    assert own_hi >= own_lo, "more ranks than blocks"
+    own_lo, own_hi = max(own_lo, intervals[0][0]), min(own_hi, intervals[-1][1])
+    first_locus, my_loci = own_lo - origin, own_hi - own_lo + 1
+
+    # ---- inputs, resident in HBM: RING_BATCHES distinct pileups of the whole set, this rank making only its own shard of each ----
+    ring = [synth.make_pileup(my_loci, args.depth, seed=BASE_SEED + b, device=dev, first_locus=first_locus, total_loci=total_loci)
+            for b in range(RING_BATCHES)]
     for p in ring:
-        p.base = p.base if p is ring[0] else None   # keep the read matrices of batch 0 only (CPU baseline sample)
+        p.base = p.base if p is ring[0] else None   # keep the read matrices of batch 0 only (CPU baseline / end-to-end sample)
         p.qual = p.qual if p is ring[0] else None
     torch.cuda.empty_cache()
     n_tiles = ring[0].n_tiles
@@ -140,7 +213,7 @@ def main():
 
     def step(i):
         p = ring[i % RING_BATCHES]
-        caller.call_tiles(p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), 1, p.ref_len,
+        caller.call_tiles(p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), p.ref_start, p.ref_len,
                           records.data_ptr(), cap, tile_results.data_ptr(), stream.cuda_stream)
 
     def barrier():
@@ -178,10 +251,51 @@ def main():
     # ---- sanity on the last step's output (outside the timed region) ----
     tr = tile_results.cpu().numpy().view(_abi.TILE_RESULT_DTYPE)
     assert int(tr["n_records"].sum()) * args.steps == totals["records"]
-    assert int(tr["n_candidate_loci"].sum()) == args.loci, "every covered locus must be a candidate locus in gVCF mode"
+    assert int(tr["n_candidate_loci"].sum()) == my_loci, "every covered locus must be a candidate locus in gVCF mode"
 
-    total_records, total_loci = int(summary[0].item()), int(summary[1].item())
-    value = total_loci / elapsed
+    total_records, sum_loci = int(summary[0].item()), int(summary[1].item())
+    assert sum_loci == total_loci * args.steps, (sum_loci, total_loci, args.steps)   # the shards cover the interval set exactly once
+    value = sum_loci / elapsed
+
+    # ---- the same summary through the C ABI (pisces_hip_reduce_summary: RCCL bound by the library, what a host without torch
+    # calls), outside the timed region and not fatal: the timed region keeps torch.distributed's communicator ----
+    c_abi_reduce = None
+    if world > 1:
+        try:
+            ids = [engine.HipVariantCaller.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            caller.comm_init(ids[0], rank, world)
+            red = caller.reduce_summary([totals["records"], totals["candidate_loci"], totals["called"], totals["tiles"]])
+            c_abi_reduce = {"ok": red == [int(x) for x in summary.tolist()], "summary": red}
+        except Exception as e:   # noqa: BLE001
+            c_abi_reduce = {"ok": False, "error": str(e)[:200]}
+
+    # ---- one cut of the partition checked on the device (outside the timed region): the two sides of this rank's cut, each called by
+    # its own handle from the reads shard.reads_for_shard hands it (halo reads on both sides), concatenate to the unsharded window ----
+    shard_check = None
+    if not args.no_shard_check:
+        bs = cfg.block_size
+        if world > 1:
+            cut = own_lo if rank > 0 else own_hi + 1
+        else:
+            cut = shard.partition_intervals(intervals, 2, block_size=bs)[1][0]   # where a second rank would start
+        w_lo, w_hi = max(cut - bs, intervals[0][0]), min(cut + bs - 1, intervals[-1][1])
+        g_lo = max(w_lo - origin - synth.READ_LEN, 0)
+        g_hi = min(w_hi - origin + synth.READ_LEN, total_loci - 1)
+        wp = synth.make_pileup(g_hi - g_lo + 1, args.depth, seed=BASE_SEED, device=dev, first_locus=g_lo, total_loci=total_loci)
+        rb = synth.reads_of(wp)
+        arrays = (rb.position, rb.flags, rb.cigar_offset, rb.cigar_op, rb.cigar_len, rb.seq_offset, rb.bases, rb.quals)
+        ref_slice = wp.ref.cpu().numpy()
+        ref_full = np.full(wp.ref_start - 1 + len(ref_slice), ord("N"), dtype=np.uint8)
+        ref_full[wp.ref_start - 1:] = ref_slice
+        n_rec, n_counted = shard.verify_cut(lambda: engine.HipVariantCaller(cfg, device=local_rank), ref_full, arrays, w_lo, cut, w_hi,
+                                            halo=synth.READ_LEN + 10)
+        ok = torch.tensor([1], dtype=torch.int64, device=dev)
+        if use_dist:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        shard_check = {"cut": int(cut), "window": [int(w_lo), int(w_hi)], "records": int(n_rec), "reads": int(n_counted),
+                       "ranks_ok": int(ok.item()) == 1, "what": "two handles fed by shard.reads_for_shard == one handle, byte for byte"}
+        del wp
 
     # ---- extra figure, outside the timed region: the same K steps handed to pisces_hip_call_tiles_batched in one call (own output
     # buffers per lane).  Batches are independent, so the call phase at the end of one launch overlaps the streaming phase of the next, which a
@@ -197,7 +311,7 @@ def main():
             out = []
             for i in range(first, first + n):
                 p, k = ring[i % RING_BATCHES], i % PIPELINE_STREAMS
-                out.append((p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), 1, p.ref_len, p_records[k].data_ptr(), cap,
+                out.append((p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), p.ref_start, p.ref_len, p_records[k].data_ptr(), cap,
                             p_results[k].data_ptr()))
             return out
 
@@ -215,13 +329,13 @@ def main():
         pipelined_elapsed = float(tp.item())
         for k in range(1, PIPELINE_STREAMS):   # every lane's last output equals a serial launch's (same batch -> same records)
             trk = p_results[k].cpu().numpy().view(_abi.TILE_RESULT_DTYPE)
-            assert int(trk["n_candidate_loci"].sum()) == args.loci
+            assert int(trk["n_candidate_loci"].sum()) == my_loci
     if rank == 0:
         # roofline of the dominant (only) kernel: algorithmic bytes per launch / mean kernel duration from HIP
         # events recorded on the launch stream around every TIME_EVERY-th launch of the timed region
         n_obs = float(np.mean([p.n_obs for p in ring]))
         rec_per_launch = totals["records"] / max(args.steps, 1)
-        bytes_per_launch = algorithmic_bytes(n_obs, args.loci, rec_per_launch)
+        bytes_per_launch = algorithmic_bytes(n_obs, my_loci, rec_per_launch)
         kernel_ms = kernel_ms_total / max(launches, 1)
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
         traffic = None
@@ -250,6 +364,7 @@ def main():
                                    "gVCF, per GPU per step; device-resident packed tuples",
                        "loci_per_gpu_per_step": args.loci, "depth": args.depth, "observations_per_step": int(n_obs),
                        "records_per_step": rec_per_launch, "ring_batches": RING_BATCHES,
+                       "interval_set": {"loci": total_loci, "intervals": len(intervals), "rank0_shard": [int(own_lo), int(own_hi)]},
                        "parallelism": f"interval-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -261,11 +376,16 @@ def main():
         out["roofline"]["peak_measured_read"] = caller.probe_read_bandwidth(1 << 30, 6)
         if pipelined_elapsed is not None:
             p_ms = pipelined_elapsed / args.steps * 1e3
-            out["pipelined"] = {"streams": PIPELINE_STREAMS, "value": args.loci * world * args.steps / pipelined_elapsed,
+            out["pipelined"] = {"streams": PIPELINE_STREAMS, "value": total_loci * args.steps / pipelined_elapsed,
                                 "unit": "candidate loci/s", "ms_per_step": p_ms,
                                 "hbm_frac": bytes_per_launch / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "note": "same steps over several HIP streams; not the contract's value, not a per-kernel roofline"}
+        if shard_check is not None:
+            out["shard_check"] = shard_check
+        if c_abi_reduce is not None:
+            out["c_abi_reduce"] = c_abi_reduce
         if not args.no_cpu_baseline and world == 1:   # timed on rank 0 at N=1 only
+            out["end_to_end"] = end_to_end(ring[0], cfg, engine)
             out["cpu_baseline"], out["cpu_baseline_threads"] = cpu_baseline(torch, ring[0], cfg)
         print(json.dumps(out), flush=True)
     caller.close()

@@ -305,6 +305,22 @@ int32_t pisces_hip_get_candidates(PiscesHip* h, int32_t up_to_position, PiscesCa
  * observations} (SmallVariantCaller.cs:114-115) */
 int32_t pisces_hip_stats(PiscesHip* h, int64_t out[4]);
 
+/* ---- multi-GPU: the per-chromosome summary across interval shards --------------------------------------------------
+ * Loci shard by genomic interval, one process (or one handle) per GPU, no data-path exchange; the only collective is the sum of
+ * the int64[4] totals above over the shards (the reference concatenates per-chromosome jobs and prints their totals,
+ * src/lib/Pisces.Processing/Logic/BaseGenomeProcessor.cs:40-90, SmallVariantCaller.cs:114-115).  RCCL over xGMI, bound at run time
+ * (librccl is loaded when comm_init is first called, so a single-GPU host needs no RCCL):
+ *   rank 0:      pisces_hip_comm_unique_id(id)            -> hands the 128 bytes to the other processes (file, pipe, MPI, ...)
+ *   every rank:  pisces_hip_comm_init(h, id, rank, world) -> ncclCommInitRank on the handle's device
+ *   every rank:  pisces_hip_reduce_summary(h, totals)     -> one ncclAllReduce(sum) of int64[4] on the handle's stream, in place
+ * Without a communicator (never initialised, or world == 1) reduce_summary leaves `inout` as it is.  Handles of ONE process on
+ * several GPUs can simply add their pisces_hip_stats on the host. */
+#define PISCES_COMM_ID_BYTES 128
+int32_t pisces_hip_comm_unique_id(uint8_t* id_out, int32_t capacity);
+int32_t pisces_hip_comm_init(PiscesHip* h, const uint8_t* id, int32_t rank, int32_t world);
+int32_t pisces_hip_reduce_summary(PiscesHip* h, int64_t inout[4]);
+int32_t pisces_hip_comm_destroy(PiscesHip* h);
+
 /* ---- device-resident surface (bench / multi-GPU shards) --------------------
  * All d_* pointers are device pointers on the handle's device; stream is a hipStream_t
  * (NULL = the handle's own stream).  One launch: per tile, observation tuples -> LDS

@@ -19,6 +19,7 @@ EXPORTS = [
     "pisces_hip_set_timing", "pisces_hip_kernel_time", "pisces_hip_flush_ex", "pisces_hip_probe_read_bandwidth",
     "pisces_hip_vcf_default_config", "pisces_hip_format_vcf", "pisces_hip_format_vcf_padded", "pisces_hip_find_candidates", "pisces_hip_call_tiles_batched",
     "pisces_hip_find_indel_candidates", "pisces_hip_compact_records", "pisces_hip_bgzf_scan", "pisces_hip_bgzf_inflate",
+    "pisces_hip_comm_unique_id", "pisces_hip_comm_init", "pisces_hip_reduce_summary", "pisces_hip_comm_destroy",
 ]
 
 
@@ -73,6 +74,10 @@ def _load():
         "pisces_hip_add_gapped_mnv_ref": (i32, [vp, vp, vp, i32]),
         "pisces_hip_get_candidates": (i32, [vp, i32, vp, i64, P(i64), vp, i64, P(i64)]),
         "pisces_hip_stats": (i32, [vp, P(i64)]),
+        "pisces_hip_comm_unique_id": (i32, [vp, i32]),
+        "pisces_hip_comm_init": (i32, [vp, vp, i32, i32]),
+        "pisces_hip_reduce_summary": (i32, [vp, P(i64)]),
+        "pisces_hip_comm_destroy": (i32, [vp]),
         "pisces_hip_call_tiles": (i32, [vp, vp, vp, i32, vp, i32, i64, vp, i32, vp, vp]),
         "pisces_hip_compact_records": (i32, [vp, vp, vp, i32, vp, vp, i32, vp, vp]),
         "pisces_hip_accumulate_tiles": (i32, [vp, vp, vp, i32, vp, vp]),

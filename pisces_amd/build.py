@@ -36,7 +36,7 @@ def build_native(force=False, verbose=False, extra_flags=(), out=None):
     tmp = f"{lib}.{os.getpid()}.tmp"
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
            "-fno-fast-math", "-Wall", "-Wno-unused-function", "-x", "hip",
-           *extra_flags, *[os.path.join(CSRC, s) for s in SOURCES], "-lpthread", "-o", tmp]
+           *extra_flags, *[os.path.join(CSRC, s) for s in SOURCES], "-lpthread", "-ldl", "-o", tmp]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -4,6 +4,7 @@
 // src/exe/Pisces/Logic/SmallVariantCaller.cs:79-189).
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <array>
@@ -117,6 +118,9 @@ struct PiscesHip {
     DeviceBuf<int16_t> d_gq_cap;
     DeviceBuf<DeviceParams> d_params;   // device copy of P (what the wave kernel's out-of-line cold path reads instead of a by-value copy)
     int n_cus = 256;
+    void* comm = nullptr;           // ncclComm_t of the summary reduce (pisces_hip_comm_init), or nullptr
+    int comm_world = 1;
+    DeviceBuf<long long> d_summary;
     DeviceBuf<int32_t> d_offsets;
     DeviceBuf<PiscesCalledAllele> d_compact;
     int kernel_variant = 4;    // 4 = auto (two waves per tile while every tile of the launch is resident at once, else one),
@@ -445,6 +449,8 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     if (!h) return PISCES_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)pisces_hip_comm_destroy(h);
+    h->d_summary.release();
     h->d_ref.release(); h->d_tuples.release(); h->d_tiles.release(); h->d_tile_results.release();
     h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release(); h->d_totals.release(); h->d_qlut.release(); h->d_bq_lut.release(); h->d_sumq.release(); h->d_gq_tail.release(); h->d_vq_tab.release(); h->d_sb_tab.release(); h->d_sb0_tab.release(); h->d_gq_cap.release(); h->d_params.release(); h->d_offsets.release(); h->d_compact.release();
     for (int i = 0; i < 2; i++) { h->d_log_pos[i].release(); h->d_log_tup[i].release(); }
@@ -2294,6 +2300,102 @@ int32_t pisces_hip_bgzf_inflate(PiscesHip* h, const uint8_t* file, int64_t n_byt
         if (first_bad.load() < n_blocks)
             return fail(h, PISCES_E_INVALID_ARG, "bgzf_inflate: CRC-32 mismatch in block " + std::to_string(first_bad.load()));
     }
+    return PISCES_OK;
+}
+
+// ---- RCCL, bound at run time: the library itself does not link librccl (a single-GPU host never loads it) ----
+struct RcclId { char internal[PISCES_COMM_ID_BYTES]; };   // ncclUniqueId
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, /* ncclUniqueId by value */ RcclId, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+}  // namespace
+static Rccl* rccl()
+{
+    static std::mutex mu;
+    static Rccl r;
+    std::lock_guard<std::mutex> lock(mu);
+    if (r.lib) return &r;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) return nullptr;
+    r.GetUniqueId = (int (*)(void*))dlsym(r.lib, "ncclGetUniqueId");
+    r.CommInitRank = (int (*)(void**, int, RcclId, int))dlsym(r.lib, "ncclCommInitRank");
+    r.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(r.lib, "ncclAllReduce");
+    r.CommDestroy = (int (*)(void*))dlsym(r.lib, "ncclCommDestroy");
+    r.GetErrorString = (const char* (*)(int))dlsym(r.lib, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy) { dlclose(r.lib); r.lib = nullptr; return nullptr; }
+    return &r;
+}
+static std::string rccl_error(Rccl* r, int code)
+{
+    return std::string("RCCL: ") + ((r && r->GetErrorString) ? r->GetErrorString(code) : "error") + " (" + std::to_string(code) + ")";
+}
+
+int32_t pisces_hip_comm_unique_id(uint8_t* id_out, int32_t capacity)
+{
+    if (!id_out || capacity < PISCES_COMM_ID_BYTES) return fail(nullptr, PISCES_E_INVALID_ARG, "comm_unique_id: the id needs 128 bytes");
+    Rccl* r = rccl();
+    if (!r) return fail(nullptr, PISCES_E_DEVICE, "comm_unique_id: librccl could not be loaded");
+    RcclId id;
+    std::memset(&id, 0, sizeof(id));
+    const int rc = r->GetUniqueId(&id);
+    if (rc != 0) return fail(nullptr, PISCES_E_DEVICE, rccl_error(r, rc));
+    std::memcpy(id_out, id.internal, PISCES_COMM_ID_BYTES);
+    return PISCES_OK;
+}
+
+int32_t pisces_hip_comm_init(PiscesHip* h, const uint8_t* id, int32_t rank, int32_t world)
+{
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (!id || world < 1 || rank < 0 || rank >= world) return fail(h, PISCES_E_INVALID_ARG, "comm_init: rank / world out of range");
+    if (h->comm) return fail(h, PISCES_E_STATE, "comm_init: the handle already has a communicator");
+    Rccl* r = rccl();
+    if (!r) return fail(h, PISCES_E_DEVICE, "comm_init: librccl could not be loaded");
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    PISCES_HIP_CHECK(h, h->d_summary.reserve(4));
+    RcclId uid;
+    std::memcpy(uid.internal, id, PISCES_COMM_ID_BYTES);
+    void* comm = nullptr;
+    const int rc = r->CommInitRank(&comm, world, uid, rank);
+    if (rc != 0) return fail(h, PISCES_E_DEVICE, rccl_error(r, rc));
+    h->comm = comm;
+    h->comm_world = world;
+    return PISCES_OK;
+}
+
+int32_t pisces_hip_reduce_summary(PiscesHip* h, int64_t inout[4])
+{
+    if (!h || !inout) return PISCES_E_INVALID_ARG;
+    if (!h->comm) return PISCES_OK;   // one shard: the sum is the value
+    Rccl* r = rccl();
+    if (!r) return fail(h, PISCES_E_DEVICE, "reduce_summary: librccl could not be loaded");
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    long long v[4] = {inout[0], inout[1], inout[2], inout[3]};
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_summary.p, v, sizeof(v), hipMemcpyHostToDevice, h->stream));
+    const int rc = r->AllReduce(h->d_summary.p, h->d_summary.p, 4, /* ncclInt64 */ 4, /* ncclSum */ 0, h->comm, h->stream);
+    if (rc != 0) return fail(h, PISCES_E_DEVICE, rccl_error(r, rc));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(v, h->d_summary.p, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 4; i++) inout[i] = v[i];
+    return PISCES_OK;
+}
+
+int32_t pisces_hip_comm_destroy(PiscesHip* h)
+{
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (!h->comm) return PISCES_OK;
+    Rccl* r = rccl();
+    if (r) (void)r->CommDestroy(h->comm);
+    h->comm = nullptr;
+    h->comm_world = 1;
     return PISCES_OK;
 }
 

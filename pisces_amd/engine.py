@@ -164,6 +164,26 @@ class HipVariantCaller:
                         "open_left": bool(c.open_left), "open_right": bool(c.open_right)})
         return out
 
+    # ---- multi-GPU summary (one process per GPU): RCCL bound at run time by the library ----
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL id made by rank 0 and handed to the other processes."""
+        buf = (C.c_uint8 * 128)()
+        rc = lib.pisces_hip_comm_unique_id(buf, 128)
+        if rc != 0:
+            raise PiscesHipError(rc, (lib.pisces_hip_last_error(None) or b"").decode(errors="replace"))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _check(self._h, lib.pisces_hip_comm_init(self._h, buf, int(rank), int(world)))
+
+    def reduce_summary(self, values):
+        """In-place sum over the ranks of the int64[4] summary (identity without a communicator)."""
+        v = (C.c_int64 * 4)(*[int(x) for x in values])
+        _check(self._h, lib.pisces_hip_reduce_summary(self._h, v))
+        return [int(x) for x in v]
+
     def Stats(self):
         s = (C.c_int64 * 4)()
         _check(self._h, lib.pisces_hip_stats(self._h, s))

@@ -72,3 +72,55 @@ def reads_for_shard(read_starts, read_ends, owned_lo, owned_hi, halo):
     need = (e >= owned_lo - halo) & (s <= owned_hi + halo)
     owner = (s >= owned_lo) & (s <= owned_hi)
     return np.nonzero(need)[0], owner[need]
+
+
+def read_batch_subset(batch_arrays, idx):
+    """ReadBatch of the reads `idx` of arrays made by reads_as_arrays (fixed-length single-M reads are not assumed)."""
+    from . import _abi
+    import numpy as np
+    pos, flags, cig_off, cig_op, cig_len, seq_off, bases, quals = batch_arrays
+    idx = np.asarray(idx, dtype=np.int64)
+    n = len(idx)
+    ncig = (cig_off[idx + 1] - cig_off[idx]).astype(np.int64)
+    nseq = (seq_off[idx + 1] - seq_off[idx]).astype(np.int64)
+    new_cig_off = np.concatenate([[0], np.cumsum(ncig)]).astype(np.int32)
+    new_seq_off = np.concatenate([[0], np.cumsum(nseq)]).astype(np.int32)
+    cig_idx = np.concatenate([np.arange(cig_off[i], cig_off[i + 1]) for i in idx]) if n else np.zeros(0, np.int64)
+    seq_idx = np.concatenate([np.arange(seq_off[i], seq_off[i + 1]) for i in idx]) if n else np.zeros(0, np.int64)
+    return _abi.ReadBatch.from_arrays(position=pos[idx], flags=flags[idx], cigar_offset=new_cig_off, cigar_op=cig_op[cig_idx],
+                                      cigar_len=cig_len[cig_idx], seq_offset=new_seq_off, bases=bases[seq_idx], quals=quals[seq_idx])
+
+
+def verify_cut(make_caller, ref_full, batch_arrays, window_lo, cut, window_hi, halo):
+    """One cut of an interval partition on the device, against the unsharded run of the same window: the loci
+    [window_lo, cut - 1] and [cut, window_hi] called by two handles, each fed the reads reads_for_shard gives it (halo reads go to both)
+    and reporting only the loci it owns, must concatenate to what one handle calls for [window_lo, window_hi] from all the reads.
+    make_caller() -> a fresh HipVariantCaller; batch_arrays: the position-sorted reads as numpy arrays (ReadBatch.from_arrays order).
+    Returns (records, reads counted by their owners) and raises AssertionError on any difference."""
+    import numpy as np
+    pos, flags, cig_off, cig_op, cig_len, seq_off, bases, quals = batch_arrays
+    starts = pos.astype(np.int64)
+    span = np.zeros(len(pos), dtype=np.int64)
+    refspan = np.isin(cig_op, np.frombuffer(b"MDN=X", dtype=np.uint8))
+    np.add.at(span, np.repeat(np.arange(len(pos)), np.diff(cig_off)), np.where(refspan, cig_len, 0).astype(np.int64))
+    ends = starts + np.maximum(span, 1) - 1
+
+    def run(lo, hi, idx):
+        with make_caller() as c:
+            c.SetReference(ref_full)
+            c.SetIntervals([(int(lo), int(hi))])
+            if len(idx):
+                c.AddAlleleCounts(read_batch_subset(batch_arrays, idx))
+            return c.Call(None, capacity=1 << 17)
+
+    whole = run(window_lo, window_hi, np.arange(len(pos)))
+    parts, counted = [], 0
+    for lo, hi in ((window_lo, cut - 1), (cut, window_hi)):
+        idx, owner = reads_for_shard(starts, ends, lo, hi, halo)
+        counted += int(owner.sum())
+        parts.append(run(lo, hi, idx))
+    got = np.concatenate(parts)
+    assert got.tobytes() == whole.tobytes(), "sharded halves differ from the unsharded window"
+    in_window = int(((starts >= window_lo) & (starts <= window_hi)).sum())
+    assert counted == in_window, (counted, in_window)
+    return len(whole), counted

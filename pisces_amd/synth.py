@@ -25,19 +25,28 @@ TILE = 64
 _BASE_ASCII = np.frombuffer(b"AGCT", dtype=np.uint8)   # index = AlleleType code (A0 G1 C2 T3)
 
 
+CHUNK_AMPLICONS = 32    # generation unit: every chunk of amplicons draws from its own seeded stream, so that any locus range of a
+                        # (possibly very large) global pileup can be made without making the rest — what an interval shard does
+
+
 @dataclass
 class Pileup:
     n_loci: int
     depth: int
-    region_start: int            # 1-based position of locus 0
-    ref: torch.Tensor            # uint8 ASCII, whole synthetic contig (position p = ref[p-1])
+    region_start: int            # 1-based position of locus 0 of THIS pileup (= flank + 1 + first_locus)
+    ref: torch.Tensor            # uint8 ASCII; ref[i] is position ref_start + i (the whole contig when the pileup starts at locus 0)
     tuples: torch.Tensor         # int32 view of packed uint32 tuples, tile-bucketed, each segment padded to x4
     tiles: torch.Tensor          # uint8 bytes of PiscesTile[n_tiles]
     n_tiles: int
     n_obs: int                   # real (unpadded) observations
-    base: torch.Tensor           # (A, depth, READ_LEN) uint8 AlleleType code of every read base
+    base: torch.Tensor           # (A, depth, READ_LEN) uint8 AlleleType code of every read base, amplicons first_amplicon ..
     qual: torch.Tensor           # (A, depth, READ_LEN) uint8
-    planted: np.ndarray          # loci with a planted SNV
+    planted: np.ndarray          # loci (relative to region_start) with a planted SNV
+    ref_start: int = 1           # 1-based position of ref[0]
+    first_locus: int = 0         # global locus index of locus 0 of this pileup
+    first_amplicon: int = 0      # global index of base[0] / qual[0]
+    total_loci: int = 0          # loci of the global pileup this one is a range of
+    flank: int = READ_LEN
 
     @property
     def ref_len(self):
@@ -51,84 +60,124 @@ def _amplicon_lengths(n_loci):
     return a, lens
 
 
+def _chunk_generator(seed, chunk, dev):
+    g = torch.Generator(device=dev)
+    g.manual_seed((int(seed) * 1_000_003 + int(chunk) + 1) % (2 ** 63))
+    return g
+
+
 def make_pileup(n_loci, depth, seed=20260928, device="cpu", p_lowq=0.02, base_error=0.001, snv_every=100,
-                snv_offset=37, q_hi=37, q_lo=12, vaf_range=(0.02, 0.5), strand_range=(0.3, 0.7), flank=READ_LEN, tile=TILE):
-    """`tile` = loci per tile of the bucketed tuple stream (<= 64; the kernels take any PiscesTile.n_loci <= 64)."""
+                snv_offset=37, q_hi=37, q_lo=12, vaf_range=(0.02, 0.5), strand_range=(0.3, 0.7), flank=READ_LEN, tile=TILE,
+                first_locus=0, total_loci=None):
+    """Loci [first_locus, first_locus + n_loci) of a global pileup of `total_loci` loci (default: the whole pileup, n_loci from 0).
+    `tile` = loci per tile of the bucketed tuple stream (<= 64; the kernels take any PiscesTile.n_loci <= 64).  Every chunk of
+    CHUNK_AMPLICONS amplicons has its own seeded stream: a range made on its own equals the same range of the whole."""
     assert 1 <= tile <= TILE
     dev = torch.device(device)
-    g = torch.Generator(device=dev)
-    g.manual_seed(int(seed))
-    A, lens = _amplicon_lengths(n_loci)
-    n_pad = A * READ_LEN
-
-    # reference: uniform ACGT, flank on both sides
-    ref_codes = torch.randint(0, 4, (n_pad + 2 * flank,), generator=g, device=dev, dtype=torch.int64)
+    total_loci = first_locus + n_loci if total_loci is None else int(total_loci)
+    assert 0 <= first_locus and first_locus + n_loci <= total_loci and n_loci > 0
+    A_total, lens_total = _amplicon_lengths(total_loci)
+    a0, a1 = first_locus // READ_LEN, (first_locus + n_loci - 1) // READ_LEN          # amplicons this range touches
+    ga0, ga1 = max(a0 - 1, 0), min(a1 + 1, A_total - 1)                                # + a neighbour each side for the reference margin
+    c0, c1 = ga0 // CHUNK_AMPLICONS, ga1 // CHUNK_AMPLICONS
     lut = torch.from_numpy(_BASE_ASCII.copy()).to(dev)
-    ref_ascii = lut[ref_codes][: n_loci + 2 * flank].contiguous()
-    region_start = flank + 1
-    refc = ref_codes[flank: flank + n_pad].view(A, 1, READ_LEN)          # code of the reference base per locus
-
-    shape = (A, depth, READ_LEN)
-    lowq = torch.rand(shape, generator=g, device=dev) < p_lowq
-    # planted SNV sites
-    locus = torch.arange(n_pad, device=dev).view(A, 1, READ_LEN)
-    planted_mask = (locus % snv_every == snv_offset) & (locus < n_loci)
-    # neighbours of planted sites are never low quality (keeps the planted candidates fully anchored)
-    near_planted = torch.zeros_like(planted_mask)
-    near_planted[..., 1:] |= planted_mask[..., :-1]
-    near_planted[..., :-1] |= planted_mask[..., 1:]
-    lowq &= ~near_planted
-    qual = torch.where(lowq, torch.tensor(q_lo, device=dev, dtype=torch.uint8), torch.tensor(q_hi, device=dev, dtype=torch.uint8))
-
-    # per-site VAF / strand split / alt base
-    site_vaf = vaf_range[0] + (vaf_range[1] - vaf_range[0]) * torch.rand((A, 1, READ_LEN), generator=g, device=dev)
-    site_s = strand_range[0] + (strand_range[1] - strand_range[0]) * torch.rand((A, 1, READ_LEN), generator=g, device=dev)
-    site_alt = (refc + 1 + torch.randint(0, 3, (A, 1, READ_LEN), generator=g, device=dev)) % 4
+    low_t, hi_t = torch.tensor(q_lo, device=dev, dtype=torch.uint8), torch.tensor(q_hi, device=dev, dtype=torch.uint8)
     reverse = (torch.arange(depth, device=dev) % 2 == 1).view(1, depth, 1)
-    p_alt = torch.where(reverse, site_vaf * 2 * (1 - site_s), site_vaf * 2 * site_s).clamp(max=1.0)
-
-    u = torch.rand(shape, generator=g, device=dev)
-    err_alt = (refc + 1 + torch.randint(0, 3, shape, generator=g, device=dev)) % 4
-    is_err = u < base_error
-    # suppress sequencing errors at the read ends and next to low-quality bases
     idx = torch.arange(READ_LEN, device=dev).view(1, 1, READ_LEN)
-    rlen = torch.tensor(lens, device=dev).view(A, 1, 1)
-    at_end = (idx == 0) | (idx == rlen - 1)
-    nb_lowq = torch.zeros_like(lowq)
-    nb_lowq[..., 1:] |= lowq[..., :-1]
-    nb_lowq[..., :-1] |= lowq[..., 1:]
-    is_err &= ~at_end & ~nb_lowq & ~planted_mask
-    base = torch.where(is_err, err_alt, refc.expand(shape))
-    base = torch.where(planted_mask & (u < p_alt), site_alt.expand(shape), base).to(torch.uint8)
+    refc_parts, base_parts, qual_parts = [], [], []
+    for c in range(c0, c1 + 1):
+        g = _chunk_generator(seed, c, dev)
+        ca0 = c * CHUNK_AMPLICONS
+        A = min(CHUNK_AMPLICONS, A_total - ca0)
+        shape = (A, depth, READ_LEN)
+        n_chunk = A * READ_LEN
+        ref_codes = torch.randint(0, 4, (n_chunk,), generator=g, device=dev, dtype=torch.int64)
+        refc = ref_codes.view(A, 1, READ_LEN)                                         # code of the reference base per locus
+        lowq = torch.rand(shape, generator=g, device=dev) < p_lowq
+        locus = (ca0 * READ_LEN + torch.arange(n_chunk, device=dev)).view(A, 1, READ_LEN)    # global locus index
+        planted_mask = (locus % snv_every == snv_offset) & (locus < total_loci)
+        # neighbours of planted sites are never low quality (keeps the planted candidates fully anchored)
+        near_planted = torch.zeros_like(planted_mask)
+        near_planted[..., 1:] |= planted_mask[..., :-1]
+        near_planted[..., :-1] |= planted_mask[..., 1:]
+        lowq &= ~near_planted
+        qual = torch.where(lowq, low_t, hi_t)
+        # per-site VAF / strand split / alt base
+        site_vaf = vaf_range[0] + (vaf_range[1] - vaf_range[0]) * torch.rand((A, 1, READ_LEN), generator=g, device=dev)
+        site_s = strand_range[0] + (strand_range[1] - strand_range[0]) * torch.rand((A, 1, READ_LEN), generator=g, device=dev)
+        site_alt = (refc + 1 + torch.randint(0, 3, (A, 1, READ_LEN), generator=g, device=dev)) % 4
+        p_alt = torch.where(reverse, site_vaf * 2 * (1 - site_s), site_vaf * 2 * site_s).clamp(max=1.0)
+        u = torch.rand(shape, generator=g, device=dev)
+        err_alt = (refc + 1 + torch.randint(0, 3, shape, generator=g, device=dev)) % 4
+        is_err = u < base_error
+        # suppress sequencing errors at the read ends and next to low-quality bases
+        rlen = torch.tensor(lens_total[ca0:ca0 + A], device=dev).view(A, 1, 1)
+        at_end = (idx == 0) | (idx == rlen - 1)
+        nb_lowq = torch.zeros_like(lowq)
+        nb_lowq[..., 1:] |= lowq[..., :-1]
+        nb_lowq[..., :-1] |= lowq[..., 1:]
+        is_err &= ~at_end & ~nb_lowq & ~planted_mask
+        base = torch.where(is_err, err_alt, refc.expand(shape))
+        base = torch.where(planted_mask & (u < p_alt), site_alt.expand(shape), base).to(torch.uint8)
+        lo_a, hi_a = max(ga0, ca0) - ca0, min(ga1, ca0 + A - 1) - ca0 + 1            # the amplicons of this chunk that are wanted
+        refc_parts.append(ref_codes[lo_a * READ_LEN: hi_a * READ_LEN])
+        ka0, ka1 = max(a0, ca0) - ca0, min(a1, ca0 + A - 1) - ca0 + 1
+        if ka1 > ka0:
+            base_parts.append(base[ka0:ka1])
+            qual_parts.append(qual[ka0:ka1])
+        del lowq, u, err_alt, is_err, base, qual
+    base = torch.cat(base_parts) if len(base_parts) > 1 else base_parts[0]
+    qual = torch.cat(qual_parts) if len(qual_parts) > 1 else qual_parts[0]
+    A = a1 - a0 + 1
+    lens = lens_total[a0:a1 + 1]
+
+    # reference: the flank before locus 0 and after the last locus from their own stream; positions: locus L <-> flank + 1 + L
+    gf = _chunk_generator(seed, -1, dev)
+    flank_codes = torch.randint(0, 4, (2 * flank,), generator=gf, device=dev, dtype=torch.int64)
+    ref_codes = torch.cat(refc_parts)                                                  # loci [ga0 * READ_LEN, (ga1 + 1) * READ_LEN)
+    ref_lo_locus = ga0 * READ_LEN
+    ref_hi_locus = min((ga1 + 1) * READ_LEN, total_loci)
+    ref_codes = ref_codes[: ref_hi_locus - ref_lo_locus]
+    pieces, ref_start = [ref_codes], flank + 1 + ref_lo_locus
+    if ga0 == 0:
+        pieces.insert(0, flank_codes[:flank])
+        ref_start = 1
+    if ga1 == A_total - 1:
+        pieces.append(flank_codes[flank:])
+    ref_ascii = lut[torch.cat(pieces)].contiguous()
+    region_start = flank + 1 + first_locus
 
     # anchor bin of read index i in a read of length rlen (GetAnchorType, RegionStateManager.cs:83-116)
+    rlen = torch.tensor(lens, device=dev).view(A, 1, 1)
     left = idx.expand(A, 1, READ_LEN)
     right = (rlen - 1 - idx)
     anchor = torch.where(left >= right,
                          torch.where(right >= _abi.ANCHOR_SIZE, torch.tensor(_abi.ANCHOR_SIZE, device=dev), _abi.NUM_ANCHORS - right - 1),
                          torch.where(left >= _abi.ANCHOR_SIZE, torch.tensor(_abi.ANCHOR_SIZE, device=dev), left))
     direction = reverse.to(torch.int64)   # Forward 0 / Reverse 1
+    shape = (A, depth, READ_LEN)
     # PISCES_TUPLE_PACK without the column (the locus-in-tile enters per tile below)
     packed = ((direction << 8) | (base.to(torch.int64) << 10) | (anchor.to(torch.int64) << 13) | (qual.to(torch.int64) << 24))
     packed = packed.expand(shape)
     dir_bit4 = (direction & 1) << 4
 
-    # tile-bucketed tuple stream: tiles of 64 loci from locus 0; inside a tile read-major (each read's run of loci)
+    # tile-bucketed tuple stream: tiles from locus 0 of this pileup; inside a tile read-major (each read's run of loci)
     n_tiles = math.ceil(n_loci / tile)
     tiles = np.zeros(n_tiles, dtype=_abi.TILE_DTYPE)
     segs = []
     cursor = 0
     pad_val = torch.tensor([-1], device=dev, dtype=torch.int64)   # 0xFFFFFFFF after the int32 cast
     for t in range(n_tiles):
-        l0, l1 = t * tile, min(t * tile + tile, n_loci)
+        l0, l1 = t * tile, min(t * tile + tile, n_loci)            # loci of this pileup
+        g0, g1 = first_locus + l0, first_locus + l1               # global loci
         n_seg = 0
-        for a in range(l0 // READ_LEN, (l1 - 1) // READ_LEN + 1):
-            i0, i1 = max(l0, a * READ_LEN) - a * READ_LEN, min(l1, a * READ_LEN + lens[a]) - a * READ_LEN
+        for a in range(g0 // READ_LEN, (g1 - 1) // READ_LEN + 1):
+            i0, i1 = max(g0, a * READ_LEN) - a * READ_LEN, min(g1, a * READ_LEN + lens_total[a]) - a * READ_LEN
             if i1 <= i0:
                 continue
-            loc = torch.arange(a * READ_LEN + i0 - l0, a * READ_LEN + i1 - l0, device=dev, dtype=torch.int64).view(1, -1)
+            loc = torch.arange(a * READ_LEN + i0 - g0, a * READ_LEN + i1 - g0, device=dev, dtype=torch.int64).view(1, -1)
             col = (((loc >> 2) & 15) | ((loc & 3) << 4)) ^ dir_bit4[0]          # PISCES_TUPLE_COLUMN(locus, direction)
-            piece = (packed[a, :, i0:i1] | (col << 2)).reshape(-1)
+            piece = (packed[a - a0, :, i0:i1] | (col << 2)).reshape(-1)
             segs.append(piece)
             n_seg += piece.numel()
         tiles[t] = (region_start + l0, l1 - l0, cursor, cursor + n_seg)
@@ -141,26 +190,31 @@ def make_pileup(n_loci, depth, seed=20260928, device="cpu", p_lowq=0.02, base_er
     tuples = torch.where(tuples >= 2 ** 31, tuples - 2 ** 32, tuples).to(torch.int32).contiguous()
     n_obs = int(sum(int(tiles[t]["tuple_end"] - tiles[t]["tuple_begin"]) for t in range(n_tiles)))
     tiles_t = torch.from_numpy(tiles.view(np.uint8).copy()).to(dev)
-    planted = np.nonzero((np.arange(n_loci) % snv_every) == snv_offset)[0]
+    gl = np.arange(first_locus, first_locus + n_loci)
+    planted = np.nonzero((gl % snv_every) == snv_offset)[0]
     return Pileup(n_loci=n_loci, depth=depth, region_start=region_start, ref=ref_ascii, tuples=tuples, tiles=tiles_t,
-                  n_tiles=n_tiles, n_obs=n_obs, base=base, qual=qual, planted=planted)
+                  n_tiles=n_tiles, n_obs=n_obs, base=base, qual=qual, planted=planted, ref_start=ref_start, first_locus=first_locus,
+                  first_amplicon=a0, total_loci=total_loci, flank=flank)
 
 
-def reads_of(p, n_amplicons=None, first_amplicon=0):
-    """ReadBatch of `n_amplicons` amplicons starting at `first_amplicon` (all of them when None): one <len>M read per row."""
+def reads_of(p, n_amplicons=None, first_amplicon=None):
+    """ReadBatch of `n_amplicons` amplicons starting at the GLOBAL amplicon index `first_amplicon` (default: the pileup's first; all of
+    them when n_amplicons is None): one <len>M read per row.  An amplicon the pileup's locus range only touches comes whole."""
     A = p.base.shape[0]
-    first_amplicon = min(first_amplicon, A)
-    n_amp = A - first_amplicon if n_amplicons is None else min(A - first_amplicon, n_amplicons)
-    _, lens = _amplicon_lengths(p.n_loci)
-    lens = lens[first_amplicon:]
-    base = p.base[first_amplicon:first_amplicon + n_amp].cpu().numpy()
-    qual = p.qual[first_amplicon:first_amplicon + n_amp].cpu().numpy()
+    first_amplicon = p.first_amplicon if first_amplicon is None else first_amplicon
+    k0 = min(max(first_amplicon - p.first_amplicon, 0), A)
+    n_amp = A - k0 if n_amplicons is None else min(A - k0, n_amplicons)
+    _, lens_total = _amplicon_lengths(p.total_loci or (p.first_locus + p.n_loci))
+    lens = lens_total[p.first_amplicon + k0:]
+    base = p.base[k0:k0 + n_amp].cpu().numpy()
+    qual = p.qual[k0:k0 + n_amp].cpu().numpy()
     depth = p.depth
+    origin = p.flank + 1   # position of global locus 0
     pos, flags, cig_len, seq_off = [], [], [], [0]
     bases, quals = [], []
     for a in range(n_amp):
         L = lens[a]
-        pos.append(np.full(depth, p.region_start + (first_amplicon + a) * READ_LEN, dtype=np.int32))
+        pos.append(np.full(depth, origin + (p.first_amplicon + k0 + a) * READ_LEN, dtype=np.int32))
         flags.append((np.arange(depth) % 2).astype(np.uint8))
         cig_len.append(np.full(depth, L, dtype=np.uint32))
         bases.append(_BASE_ASCII[base[a, :, :L]].reshape(-1))

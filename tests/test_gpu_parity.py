@@ -46,7 +46,7 @@ def torch_cuda():
     return torch
 
 
-def run_fused(torch, caller, p, compact=False):
+def run_fused(torch, caller, p, compact=False, ref_start=1):
     """One pisces_hip_call_tiles launch on device-resident buffers; returns the called alleles in order.
     compact=False: read the slot layout through the validity masks; compact=True: pisces_hip_compact_records."""
     dev = p.tuples.device
@@ -57,7 +57,7 @@ def run_fused(torch, caller, p, compact=False):
     # torch's default stream has the null handle, which the library reads as "the handle's own (non-blocking) stream": the fills
     # above must be complete before the launch or they race with the tile directory writes of the first workgroups
     torch.cuda.synchronize()
-    caller.call_tiles(p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), 1, p.ref_len,
+    caller.call_tiles(p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), ref_start, p.ref_len,
                       recs.data_ptr(), cap, tres.data_ptr(), stream)
     if compact:
         out_d = torch.zeros(cap * 64, dtype=torch.uint8, device=dev)
@@ -544,6 +544,65 @@ def test_committed_fixture_without_the_oracle(torch_cuda):
         c.AddObservations(z["positions"], z["tuples"])
         got = c.Call(None)
     assert_records_match(got, exp)
+
+
+def test_two_interval_shards_on_one_gpu_equal_the_unsharded_run(torch_cuda):
+    """SURVEY 8e on the device: ONE interval set partitioned by shard.partition_intervals; each shard is made on its own (only its
+    locus range of the global pileup), called by its own handle, and the rank-order concatenation is the unsharded launch byte for
+    byte, with summaries that add up (what bench.py does across GPUs).  Then the cut itself through the streaming surface: two handles
+    fed by shard.reads_for_shard (halo reads on both sides) against one handle (shard.verify_cut)."""
+    from pisces_amd import engine, shard, synth
+    torch = torch_cuda
+    total, depth, seed = 12_300, 120, 31
+    origin = synth.READ_LEN + 1
+    n_amp = -(-total // synth.READ_LEN)
+    intervals = [(origin + a * synth.READ_LEN, origin + min((a + 1) * synth.READ_LEN, total) - 1) for a in range(n_amp)]
+    cfg = _abi.default_config()
+    whole_p = synth.make_pileup(total, depth, seed=seed, device="cuda")
+    with engine.HipVariantCaller(cfg) as c:
+        whole, tr_w = run_fused(torch, c, whole_p)
+    for world in (2, 3):
+        parts = shard.partition_intervals(intervals, world, block_size=cfg.block_size)
+        got, n_rec, n_loci = [], 0, 0
+        for lo, hi, clipped in parts:
+            lo, hi = max(lo, intervals[0][0]), min(hi, intervals[-1][1])
+            p = synth.make_pileup(hi - lo + 1, depth, seed=seed, device="cuda", first_locus=lo - origin, total_loci=total)
+            with engine.HipVariantCaller(cfg) as c:
+                recs, tr = run_fused(torch, c, p, ref_start=p.ref_start)
+            assert recs["position"].min() >= lo and recs["position"].max() <= hi
+            got.append(recs)
+            n_rec += int(tr["n_records"].sum())
+            n_loci += int(tr["n_candidate_loci"].sum())
+        assert np.concatenate(got).tobytes() == whole.tobytes(), world
+        assert n_rec == int(tr_w["n_records"].sum()) and n_loci == total
+    # the cut of the 2-way partition through the streaming surface
+    cut = shard.partition_intervals(intervals, 2, block_size=cfg.block_size)[1][0]
+    g_lo, g_hi = cut - 1000 - origin - synth.READ_LEN, cut + 999 - origin + synth.READ_LEN
+    wp = synth.make_pileup(g_hi - g_lo + 1, depth, seed=seed, device="cuda", first_locus=g_lo, total_loci=total)
+    rb = synth.reads_of(wp)
+    arrays = (rb.position, rb.flags, rb.cigar_offset, rb.cigar_op, rb.cigar_len, rb.seq_offset, rb.bases, rb.quals)
+    ref_slice = wp.ref.cpu().numpy()
+    ref_full = np.full(wp.ref_start - 1 + len(ref_slice), ord("N"), dtype=np.uint8)
+    ref_full[wp.ref_start - 1:] = ref_slice
+    n, counted = shard.verify_cut(lambda: engine.HipVariantCaller(cfg), ref_full, arrays, cut - 1000, cut, cut + 999, halo=synth.READ_LEN + 10)
+    assert n == 2000 and counted > 0
+    # ... and those window records are the unsharded launch's
+    m = (whole["position"] >= cut - 1000) & (whole["position"] <= cut + 999)
+    assert int(m.sum()) == n
+
+
+def test_summary_reduce_through_the_c_abi(torch_cuda):
+    """pisces_hip_comm_unique_id / comm_init / reduce_summary / comm_destroy (RCCL bound at run time): on a one-GPU box the communicator
+    has one rank and the all-reduce returns the totals as they are; without a communicator the call is the identity."""
+    from pisces_amd import engine
+    with engine.HipVariantCaller(_abi.default_config()) as c:
+        assert c.reduce_summary([1, 2, 3, 4]) == [1, 2, 3, 4]
+        uid = engine.HipVariantCaller.comm_unique_id()
+        assert len(uid) == 128 and any(uid)
+        c.comm_init(uid, 0, 1)
+        assert c.reduce_summary([5, 1 << 40, 7, 8]) == [5, 1 << 40, 7, 8]
+        with pytest.raises(Exception):
+            c.comm_init(uid, 0, 1)   # one communicator per handle
 
 
 def test_streaming_surface_equals_device_resident_surface_at_size(torch_cuda):
