@@ -235,10 +235,11 @@ def main():
         step(args.warmup + i)
     torch.cuda.synchronize(dev)
     totals = caller.device_totals()
-    summary = torch.tensor([totals["records"], totals["candidate_loci"], totals["called"], totals["tiles"]],
-                           dtype=torch.int64, device=dev)
-    shard.reduce_summary(summary)   # the per-chromosome summary reduce: one all-reduce(sum) of int64[4] (RCCL over xGMI)
-    torch.cuda.synchronize(dev)
+    summary = torch.tensor([totals["records"], totals["candidate_loci"], totals["called"], totals["tiles"]], dtype=torch.int64)
+    if use_dist:
+        summary = summary.to(dev)
+        shard.reduce_summary(summary)   # the per-chromosome summary reduce: one all-reduce(sum) of int64[4] (RCCL over xGMI)
+        torch.cuda.synchronize(dev)
     barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)

@@ -65,6 +65,54 @@ def test_interval_sharding_two_ranks_matches_single():
     assert blob == exp.tobytes()      # shard-order concatenation == genomic order == the unsharded result
 
 
+def _worker_intervals(rank, world, port, total, depth, q):
+    """bench.py's N > 1 path on CPU: ONE interval set partitioned by shard.partition_intervals, every rank making only its own locus
+    range of the global pileup and calling it (oracle as the stand-in compute), then the summary all-reduce."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pisces_amd import synth
+    from tests import orc
+    origin = synth.READ_LEN + 1
+    n_amp = -(-total // synth.READ_LEN)
+    intervals = [(origin + a * synth.READ_LEN, origin + min((a + 1) * synth.READ_LEN, total) - 1) for a in range(n_amp)]
+    lo, hi, _ = shard.partition_intervals(intervals, world, block_size=1000)[rank]
+    lo, hi = max(lo, intervals[0][0]), min(hi, intervals[-1][1])
+    p = synth.make_pileup(hi - lo + 1, depth, seed=78, first_locus=lo - origin, total_loci=total)
+    pos, tup = synth.observations_of(p)
+    ref = p.ref.numpy()
+    ref_full = np.full(p.ref_start - 1 + len(ref), ord("N"), dtype=np.uint8)
+    ref_full[p.ref_start - 1:] = ref
+    out, nloci = orc.run_observations(pos, tup, ref_full, p.region_start, p.n_loci, _abi.default_config())
+    summary = shard.reduce_summary(torch.tensor([len(out), nloci, len(pos), p.n_tiles], dtype=torch.int64))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, out.tobytes())
+    if rank == 0:
+        q.put((summary.tolist(), b"".join(gathered)))
+    dist.destroy_process_group()
+
+
+def test_interval_set_partitioned_across_two_ranks_matches_single():
+    from pisces_amd import synth
+    from tests import orc
+    total, depth = 3300, 24
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_intervals, args=(r, 2, port, total, depth, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    summary, blob = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    p = synth.make_pileup(total, depth, seed=78)
+    pos, tup = synth.observations_of(p)
+    exp, nloci = orc.run_observations(pos, tup, p.ref.numpy(), p.region_start, total, _abi.default_config())
+    assert summary[:3] == [len(exp), nloci, len(pos)]
+    assert blob == exp.tobytes()      # rank-order concatenation of the shards == the unsharded result
+
+
 def test_tile_range_partition_properties():
     for n in (0, 1, 7, 64, 1563):
         for w in (1, 2, 3, 4, 8):
