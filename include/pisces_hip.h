@@ -398,11 +398,18 @@ int64_t pisces_hip_find_indel_candidates(const PiscesReadBatch* batch, const uin
                                          int32_t min_base_call_quality, PiscesCandidate* out, int64_t capacity,
                                          uint8_t* alleles, int64_t allele_capacity, int64_t* allele_bytes);
 /* The whole of CandidateVariantFinder.FindCandidates (CandidateVariantFinder.cs:36-387,496-553): with snvs_and_mnvs the M operations are
- * walked too (ExtractSnvsFromOperation :90-232; call_mnvs / max_mnv_length / max_gap_between_mnv are ShouldBuildUpMNV's :170-181).  This is
- * what pisces_hip_add_reads runs per read when PiscesHipConfig.call_mnvs is set.  Same outputs as above. */
+ * walked too (ExtractSnvsFromOperation :90-232; call_mnvs / max_mnv_length / max_gap_between_mnv are ShouldBuildUpMNV's :170-181).
+ * Same outputs as above.  Host form of the walk (no handle, no device); pisces_hip_add_reads runs the device form below. */
 int64_t pisces_hip_find_candidates(const PiscesReadBatch* batch, const uint8_t* ref, int64_t ref_len, int32_t min_base_call_quality,
                                    int32_t snvs_and_mnvs, int32_t call_mnvs, int32_t max_mnv_length, int32_t max_gap_between_mnv,
                                    PiscesCandidate* out, int64_t capacity, uint8_t* alleles, int64_t allele_capacity, int64_t* allele_bytes);
+/* The same walk on the handle's device (find_count_kernel / find_emit_kernel: one lane per read), against the reference given to
+ * pisces_hip_set_reference and with the handle's minimum base quality: the candidate discovery pisces_hip_add_reads enqueues for
+ * every batch, here with its records returned per read event, unmerged, in read order — what the parity tests compare with
+ * the reference's own finder cases.  Same outputs and return values as pisces_hip_find_candidates. */
+int64_t pisces_hip_find_candidates_device(PiscesHip* h, const PiscesReadBatch* batch, int32_t snvs_and_mnvs, int32_t call_mnvs,
+                                          int32_t max_mnv_length, int32_t max_gap_between_mnv, PiscesCandidate* out, int64_t capacity,
+                                          uint8_t* alleles, int64_t allele_capacity, int64_t* allele_bytes);
 
 /* ---- VCF body lines (pure CPU) ---------------------------------------
  * What the writer needs of VcfWriterConfig (src/lib/Pisces.IO/VcfFileWriter.cs:264-330). */

@@ -1,7 +1,7 @@
-// finder.h — host side of ICandidateVariantFinder.FindCandidates (src/lib/Pisces.Domain/Logic/CandidateVariantFinder.cs:36-387,496-553).
-// With MNV calling off (the reference default) SNV candidates are implied by the device allele counts and only insertions and
-// deletions are discovered here (M operations are not walked); with it on, SNV and MNV candidates come from the M walk too
-// (ExtractSnvsFromOperation :90-232), because bases absorbed into an MNV are no SNV candidates.
+// finder.h — ICandidateVariantFinder.FindCandidates (src/lib/Pisces.Domain/Logic/CandidateVariantFinder.cs:36-387,496-553) as host
+// calls; the walk itself is finder_walk.h (one source for the host and the device).  With MNV calling off (the reference default) SNV
+// candidates are implied by the device allele counts and only insertions and deletions are discovered (M operations are not
+// walked); with it on, SNV and MNV candidates come from the M walk too, because bases absorbed into an MNV are no SNV candidates.
 #pragma once
 #include <stdint.h>
 
@@ -29,5 +29,10 @@ void find_indel_candidates(const ReadView& read, const uint8_t* ref, int64_t ref
 void find_candidates(const ReadView& read, const uint8_t* ref, int64_t ref_len, int32_t min_base_call_quality,
                      int32_t well_anchored_anchor_size, bool snvs_and_mnvs, bool call_mnvs, int32_t max_mnv_length, int32_t max_gap,
                      std::vector<HostCandidate>& out);
+
+struct FoundCandidate;
+// REF / ALT strings of a record of the walk (finder_walk.h); read_bases = the read's bases from FoundCandidate::start_in_read on
+void candidate_strings(const FoundCandidate& c, const uint8_t* ref, const uint8_t* read_bases, std::string& ref_allele, std::string& alt_allele);
+HostCandidate host_candidate_of(const FoundCandidate& c, const uint8_t* ref, const uint8_t* read_bases);
 
 }  // namespace pisces

@@ -28,6 +28,7 @@
 #include "finder.h"
 #include "kernels.hip.h"
 #include "stream_kernels.hip.h"
+#include "finder_kernels.hip.h"
 #include "bgzf_kernels.hip.h"
 
 using namespace pisces;
@@ -163,6 +164,7 @@ struct PiscesHip {
     DeviceBuf<unsigned long long> d_log_n;   // [0], [1]: entries kept by the last drop into log 0 / 1; [2]: observations ever made
     int64_t log_ub = 0;                      // entries of the current log, holes included (slots are reserved on the host)
     std::vector<long long> read_slots;
+    std::vector<int32_t> found_slots_host;   // first candidate-record slot of every read of the batch being added
     DeviceBuf<int32_t> d_flags;              // [0] log overflow
     // staging of host input, double-buffered: a pinned host buffer, its device copy and an event that fires when the device
     // work reading them is done — add_reads returns without waiting for its own expansion kernel
@@ -182,6 +184,20 @@ struct PiscesHip {
     size_t h_dl_cap = 0;
     DeviceBuf<unsigned int> d_tile_cnt;
     DeviceBuf<long long> d_total;
+
+    // candidate discovery on the device (finder_kernels.hip.h): records of the last add_reads, picked up when they are needed
+    DeviceBuf<DevFound> d_found;
+    DeviceBuf<uint8_t> d_found_pool;
+    DeviceBuf<int32_t> d_found_slots, d_found_pool_first;
+    DeviceBuf<unsigned int> d_found_misc;    // [0] pool cursor, [1] overflow flag
+    DeviceBuf<long long> d_found_totals;
+    struct FoundPending {
+        uint8_t* h = nullptr;                // pinned: DevFound[n_slots], then the pool bytes, then misc[2]
+        size_t h_cap = 0;
+        hipEvent_t done = nullptr;
+        bool in_flight = false;
+        int64_t n_slots = 0, pool_bytes = 0;
+    } found;
 
     // device scratch, grow-only
     DeviceBuf<uint32_t> d_tuples;
@@ -208,6 +224,8 @@ static int32_t fail(PiscesHip* h, int32_t code, const std::string& msg)
     else g_create_error = msg;
     return code;
 }
+
+static int32_t consume_found(PiscesHip* h);
 
 static DeviceParams make_params(const PiscesHipConfig& c)
 {
@@ -465,6 +483,12 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     h->h_stage = nullptr;
     if (h->h_dl) (void)hipHostFree(h->h_dl);
     h->h_dl = nullptr;
+    if (h->found.h) (void)hipHostFree(h->found.h);
+    h->found.h = nullptr;
+    if (h->found.done) (void)hipEventDestroy(h->found.done);
+    h->found.done = nullptr;
+    h->d_found.release(); h->d_found_pool.release(); h->d_found_slots.release(); h->d_found_pool_first.release();
+    h->d_found_misc.release(); h->d_found_totals.release();
     h->d_cands.release(); h->d_alleles.release(); h->d_cand_records.release(); h->d_cand_callable.release();
     for (hipEvent_t ev : h->ring) (void)hipEventDestroy(ev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -483,6 +507,8 @@ int32_t pisces_hip_set_reference(PiscesHip* h, const uint8_t* bases, int64_t len
     if (!h) return PISCES_E_INVALID_ARG;
     if (!bases || length <= 0) return fail(h, PISCES_E_INVALID_ARG, "set_reference: empty reference");
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    { int32_t rcf = consume_found(h); if (rcf) return rcf; }   // candidates found against the previous reference take their strings from it
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     PISCES_HIP_CHECK(h, h->d_ref.reserve((size_t)length));
     PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_ref.p, bases, (size_t)length, hipMemcpyHostToDevice, h->stream));
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
@@ -658,6 +684,26 @@ static void add_candidate(PiscesHip* h, const HostCandidate& cnd)
     if (other_end > b->max_allele_endpoint) b->max_allele_endpoint = other_end;
 }
 
+// The candidates the device found for the last add_reads (find_emit_kernel), merged into their blocks in read order:
+// IStateManager.AddCandidates (SmallVariantCaller.cs:92-96).  Called before anything that looks at the candidates.
+static int32_t consume_found(PiscesHip* h)
+{
+    if (!h->found.in_flight) return PISCES_OK;
+    h->found.in_flight = false;
+    PISCES_HIP_CHECK(h, hipEventSynchronize(h->found.done));
+    const DevFound* recs = (const DevFound*)h->found.h;
+    const uint8_t* pool = h->found.h + (size_t)h->found.n_slots * sizeof(DevFound);
+    const unsigned int* misc = (const unsigned int*)(pool + (((size_t)h->found.pool_bytes + 15) & ~(size_t)15));
+    if (misc[1] != 0) return fail(h, PISCES_E_DEVICE, "add_reads: the candidate records of the device did not fit their reservation");
+    for (int64_t i = 0; i < h->found.n_slots; i++) {
+        const DevFound& f = recs[i];
+        if (f.c.category == kFoundHole) continue;
+        const uint8_t* bases = f.pool_offset >= 0 ? pool + f.pool_offset : f.alt;
+        add_candidate(h, host_candidate_of(f.c, h->h_ref.data(), bases));
+    }
+    return PISCES_OK;
+}
+
 int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
 {
     if (!h) return PISCES_E_INVALID_ARG;
@@ -665,13 +711,13 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
     h->pending_valid = false;
     if (batch->n_reads == 0) return PISCES_OK;
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    { int32_t rcf = consume_found(h); if (rcf) return rcf; }
     const int32_t nr = batch->n_reads;
     const int32_t minBQ = h->cfg.min_base_call_quality;
     // ---- host pass over the CIGARs only (never over the bases): argument checks of the reference's walk, the insertion /
     // deletion candidates, the blocks the read touches, and an upper bound of its observations ----
     auto op_ref = [](uint8_t t) { return t == 'M' || t == 'D' || t == 'N' || t == '=' || t == 'X'; };
     auto op_read = [](uint8_t t) { return t == 'M' || t == 'I' || t == 'S' || t == '=' || t == 'X'; };
-    std::vector<HostCandidate> found;
     int64_t ub = 0;
     std::vector<long long>& slots = h->read_slots;   // log slots reserved per read: [slots[i], slots[i + 1])
     slots.resize((size_t)nr + 1);
@@ -700,56 +746,23 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
         ub += ref_span;
     }
     slots[(size_t)nr] = (long long)(h->log_ub + ub);
-    // With MNV calling on every base of every read is compared with the reference on the host (the SNV / MNV walk): large batches
-    // are walked by a few worker threads, chunk by chunk; the candidates are then added in read order, as the serial loop would
-    std::vector<std::vector<HostCandidate>> pre_found;   // per chunk, in read order, each candidate tagged with its read index below
-    std::vector<std::vector<int32_t>> pre_read;
-    const bool parallel_walk = h->cfg.call_mnvs != 0 && !h->h_ref.empty() && nr >= 4096;
-    int32_t chunk = nr;
-    if (parallel_walk) {
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        const int n_threads = (int)std::min<unsigned>(8u, hw);
-        chunk = (nr + n_threads - 1) / n_threads;
-        pre_found.resize((size_t)n_threads);
-        pre_read.resize((size_t)n_threads);
-        std::vector<std::thread> workers;
-        for (int t = 0; t < n_threads; t++)
-            workers.emplace_back([&, t]() {
-                std::vector<HostCandidate> local;
-                const int32_t lo = t * chunk, hi = std::min(nr, lo + chunk);
-                for (int32_t i = lo; i < hi; i++) {
-                    local.clear();
-                    find_candidates(read_view(batch, i), h->h_ref.data(), h->ref_len, minBQ, PISCES_ANCHOR_SIZE, true, true, h->cfg.max_mnv_length,
-                                    h->cfg.max_gap_between_mnv, local);
-                    for (auto& c : local) { pre_found[(size_t)t].push_back(std::move(c)); pre_read[(size_t)t].push_back(i); }
-                }
-            });
-        for (auto& w : workers) w.join();
-    }
-    std::vector<size_t> pre_cursor(pre_found.size(), 0);
+    // ICandidateVariantFinder.FindCandidates + IStateManager.AddCandidates (SmallVariantCaller.cs:92-96) run on the device
+    // (find_emit_kernel, enqueued behind the read walk below).  With MNV calling off only insertions and deletions are discovered
+    // (SNV candidates are implied by the allele counts): the host reserves one record slot per I / D operation here, from the CIGAR
+    // alone; with it on the device counts its candidates itself.
+    const bool find_on_device = !h->h_ref.empty();   // without a reference only the IStateManager half (allele counts) runs
+    std::vector<int32_t>& fslots = h->found_slots_host;
+    fslots.assign((size_t)nr + 1, 0);
+    int64_t found_slots = 0, found_pool = 0;
     for (int32_t i = 0; i < nr; i++) {
         ReadView r = read_view(batch, i);
-        if (parallel_walk) {
-            const size_t t = (size_t)(i / chunk);
-            size_t& k = pre_cursor[t];
-            while (k < pre_found[t].size() && pre_read[t][k] == i) {
-                if (pre_found[t][k].position > 0) add_candidate(h, pre_found[t][k]);
-                k++;
+        fslots[(size_t)i] = (int32_t)found_slots;
+        if (find_on_device && !h->cfg.call_mnvs)
+            for (int c = 0; c < r.n_cigar; c++) {
+                if (r.cigar_op[c] == 'I' || r.cigar_op[c] == 'D') found_slots++;
+                if (r.cigar_op[c] == 'I' && r.cigar_len[c] > (uint32_t)kFoundInline) found_pool += r.cigar_len[c];
             }
-        }
-        // ICandidateVariantFinder.FindCandidates + IStateManager.AddCandidates (SmallVariantCaller.cs:92-96) for the
-        // candidates the device counts do not imply: insertions and deletions
-        bool walk = h->cfg.call_mnvs != 0 && !parallel_walk;   // MNV calling: SNV / MNV candidates come from the M operations too
-        for (int c = 0; c < r.n_cigar && !walk && !parallel_walk; c++) walk = (r.cigar_op[c] == 'I' || r.cigar_op[c] == 'D');
-        if (walk && !h->h_ref.empty()) {   // without a reference only the IStateManager half (allele counts) runs
-            found.clear();
-            find_candidates(r, h->h_ref.data(), h->ref_len, minBQ, PISCES_ANCHOR_SIZE, h->cfg.call_mnvs != 0, h->cfg.call_mnvs != 0,
-                            h->cfg.max_mnv_length, h->cfg.max_gap_between_mnv, found);
-            for (auto& cnd : found) {
-                if (cnd.position <= 0) continue;
-                add_candidate(h, cnd);
-            }
-        }
+        if (found_slots > 0x7FFFFFF0ll || found_pool > 0x7FFFFFF0ll) return fail(h, PISCES_E_INVALID_ARG, "add_reads: too many insertions / deletions in one batch");
         // GetBlock(position) for every position that receives a count (RegionStateManager.cs:361-383): the runs of mapped
         // bases always do; a gap (deletion / skip) does when its flanking qualities pass CheckDeletionQuality
         {
@@ -788,6 +801,7 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
         }
         h->stats[2] += 1;
     }
+    fslots[(size_t)nr] = (int32_t)found_slots;
 
     // ---- the read batch crosses PCIe once, packed; the walk runs on the device (expand_reads_kernel) ----
     const size_t n_cig = (size_t)batch->cigar_offset[nr], n_seq = (size_t)batch->seq_offset[nr];
@@ -796,7 +810,8 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
            off_cop = align16(off_coff + ((size_t)nr + 1) * 4), off_clen = align16(off_cop + n_cig),
            off_soff = align16(off_clen + n_cig * 4), off_bases = align16(off_soff + ((size_t)nr + 1) * 4),
            off_quals = align16(off_bases + n_seq), off_dirs = align16(off_quals + n_seq),
-           off_slots = align16(off_dirs + (batch->directions ? n_seq : 0)), total = align16(off_slots + ((size_t)nr + 1) * 8);
+           off_slots = align16(off_dirs + (batch->directions ? n_seq : 0)), off_fslots = align16(off_slots + ((size_t)nr + 1) * 8),
+           off_deldirs = align16(off_fslots + ((size_t)nr + 1) * 4), total = align16(off_deldirs + (batch->deletion_directions ? 2 * n_cig : 0));
     int32_t rc = stage_reserve(h, total);
     if (rc) return rc;
     rc = log_reserve(h, ub);
@@ -809,6 +824,8 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
     std::memcpy(st + off_clen, batch->cigar_len, n_cig * 4);
     std::memcpy(st + off_soff, batch->seq_offset, ((size_t)nr + 1) * 4);
     std::memcpy(st + off_slots, slots.data(), ((size_t)nr + 1) * 8);
+    std::memcpy(st + off_fslots, fslots.data(), ((size_t)nr + 1) * 4);
+    if (batch->deletion_directions) std::memcpy(st + off_deldirs, batch->deletion_directions, 2 * n_cig);
     {
         // bases / qualities / directions are the bulk (2-3 bytes per aligned base).  Small batches: one copy into the pinned buffer,
         // one transfer.  Large ones: slices of 8 MB, each copied by a few threads and handed to the DMA engine as soon as it is
@@ -874,6 +891,62 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
     hipLaunchKernelGGL(expand_reads_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, h->stream, db, (const long long*)(d + off_slots),
                        minBQ, h->d_log_pos[c].p, h->d_log_tup[c].p, h->d_log_n.p + 2);
     PISCES_HIP_CHECK(h, hipGetLastError());
+    if (find_on_device && (h->cfg.call_mnvs || found_slots > 0)) {
+        const uint8_t* d_deldirs = batch->deletion_directions ? d + off_deldirs : nullptr;
+        const FinderParams FP = {minBQ, PISCES_ANCHOR_SIZE, h->cfg.call_mnvs ? 1 : 0, h->cfg.call_mnvs ? 1 : 0, h->cfg.max_mnv_length,
+                                 h->cfg.max_gap_between_mnv};
+        const unsigned grid = (unsigned)((nr + 255) / 256);
+        PISCES_HIP_CHECK(h, h->d_found_misc.reserve(4));
+        PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_found_misc.p, 0, 4 * sizeof(unsigned int), h->stream));
+        const int32_t* d_slots = (const int32_t*)(d + off_fslots);
+        const int32_t* d_pool_first = nullptr;
+        if (h->cfg.call_mnvs) {
+            // count, scan (one more element than reads: the last one receives the total), then size the record buffer
+            PISCES_HIP_CHECK(h, h->d_found_slots.reserve((size_t)nr + 1));
+            PISCES_HIP_CHECK(h, h->d_found_pool_first.reserve((size_t)nr + 1));
+            PISCES_HIP_CHECK(h, h->d_found_totals.reserve(2));
+            PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_found_slots.p + nr, 0, sizeof(int32_t), h->stream));
+            PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_found_pool_first.p + nr, 0, sizeof(int32_t), h->stream));
+            hipLaunchKernelGGL(find_count_kernel, dim3(grid), dim3(256), 0, h->stream, db, d_deldirs, (const uint8_t*)h->d_ref.p, h->ref_len, FP,
+                               h->d_found_slots.p, h->d_found_pool_first.p);
+            hipLaunchKernelGGL(found_scan_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_found_slots.p, h->d_found_pool_first.p, nr + 1,
+                               h->d_found_totals.p);
+            long long totals[2] = {0, 0};
+            PISCES_HIP_CHECK(h, hipMemcpyAsync(totals, h->d_found_totals.p, sizeof(totals), hipMemcpyDeviceToHost, h->stream));
+            PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+            if (totals[0] > 0x7FFFFFF0ll || totals[1] > 0x7FFFFFF0ll) return fail(h, PISCES_E_INVALID_ARG, "add_reads: too many candidates in one batch");
+            found_slots = totals[0];
+            found_pool = totals[1];
+            d_slots = h->d_found_slots.p;
+            d_pool_first = h->d_found_pool_first.p;
+        }
+        if (found_slots > 0) {
+            PISCES_HIP_CHECK(h, h->d_found.reserve((size_t)found_slots));
+            PISCES_HIP_CHECK(h, h->d_found_pool.reserve((size_t)found_pool + 16));
+            hipLaunchKernelGGL(find_emit_kernel, dim3(grid), dim3(256), 0, h->stream, db, d_deldirs, (const uint8_t*)h->d_ref.p, h->ref_len, FP, d_slots,
+                               d_pool_first, h->d_found.p, h->d_found_pool.p, h->d_found_misc.p, (int32_t)found_pool, (int32_t*)(h->d_found_misc.p + 1));
+            PISCES_HIP_CHECK(h, hipGetLastError());
+            // records + pool + {cursor, overflow} come back into pinned memory; consume_found waits for them when they are needed
+            const size_t rec_bytes = (size_t)found_slots * sizeof(DevFound), pool_al = ((size_t)found_pool + 15) & ~(size_t)15;
+            const size_t need = rec_bytes + pool_al + 16;
+            if (need > h->found.h_cap) {
+                if (h->found.h) (void)hipHostFree(h->found.h);
+                h->found.h = nullptr;
+                h->found.h_cap = 0;
+                PISCES_HIP_CHECK(h, hipHostMalloc((void**)&h->found.h, need + need / 2, hipHostMallocDefault));
+                h->found.h_cap = need + need / 2;
+            }
+            if (!h->found.done) PISCES_HIP_CHECK(h, hipEventCreateWithFlags(&h->found.done, hipEventDisableTiming));
+            PISCES_HIP_CHECK(h, hipMemcpyAsync(h->found.h, h->d_found.p, rec_bytes, hipMemcpyDeviceToHost, h->stream));
+            if (found_pool > 0)
+                PISCES_HIP_CHECK(h, hipMemcpyAsync(h->found.h + rec_bytes, h->d_found_pool.p, (size_t)found_pool, hipMemcpyDeviceToHost, h->stream));
+            PISCES_HIP_CHECK(h, hipMemcpyAsync(h->found.h + rec_bytes + pool_al, h->d_found_misc.p, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+            PISCES_HIP_CHECK(h, hipEventRecord(h->found.done, h->stream));
+            h->found.n_slots = found_slots;
+            h->found.pool_bytes = found_pool;
+            h->found.in_flight = true;
+        }
+    }
     { int32_t rcs = stage_release(h); if (rcs) return rcs; }
     h->log_ub += ub;
     return PISCES_OK;
@@ -928,6 +1001,115 @@ int64_t pisces_hip_find_candidates(const PiscesReadBatch* batch, const uint8_t* 
     if (allele_bytes) *allele_bytes = bytes;
     if ((int64_t)found.size() > capacity || (alleles && bytes > allele_capacity)) return PISCES_E_BUFFER_TOO_SMALL;
     return (int64_t)found.size();
+}
+
+static int64_t export_candidates(const std::vector<HostCandidate>& found, PiscesCandidate* out, int64_t capacity, uint8_t* alleles,
+                                 int64_t allele_capacity, int64_t* allele_bytes)
+{
+    int64_t bytes = 0;
+    for (size_t i = 0; i < found.size(); i++) {
+        const HostCandidate& c = found[i];
+        const int64_t need = (int64_t)(c.ref.size() + c.alt.size());
+        if ((int64_t)i < capacity && (!alleles || bytes + need <= allele_capacity)) {
+            PiscesCandidate& o = out[i];
+            std::memset(&o, 0, sizeof(o));
+            o.position = c.position; o.category = c.category;
+            o.ref_len = (int32_t)c.ref.size(); o.alt_len = (int32_t)c.alt.size();
+            for (int d = 0; d < 3; d++) { o.support_by_dir[d] = c.support_by_dir[d]; o.well_anchored_by_dir[d] = c.well_anchored_by_dir[d]; }
+            o.open_left = c.open_left; o.open_right = c.open_right;
+            o.allele_offset = bytes;
+            if (alleles) {
+                std::memcpy(alleles + bytes, c.ref.data(), c.ref.size());
+                std::memcpy(alleles + bytes + c.ref.size(), c.alt.data(), c.alt.size());
+            }
+        }
+        bytes += need;
+    }
+    if (allele_bytes) *allele_bytes = bytes;
+    if ((int64_t)found.size() > capacity || (alleles && bytes > allele_capacity)) return PISCES_E_BUFFER_TOO_SMALL;
+    return (int64_t)found.size();
+}
+
+int64_t pisces_hip_find_candidates_device(PiscesHip* h, const PiscesReadBatch* batch, int32_t snvs_and_mnvs, int32_t call_mnvs,
+                                          int32_t max_mnv_length, int32_t max_gap_between_mnv, PiscesCandidate* out, int64_t capacity,
+                                          uint8_t* alleles, int64_t allele_capacity, int64_t* allele_bytes)
+{
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (validate_batch(batch) != PISCES_OK || capacity < 0 || (capacity > 0 && !out)) return fail(h, PISCES_E_INVALID_ARG, "find_candidates_device: malformed arguments");
+    if (h->h_ref.empty()) return fail(h, PISCES_E_STATE, "find_candidates_device: set_reference has not been called");
+    if (allele_bytes) *allele_bytes = 0;
+    if (batch->n_reads == 0) return 0;
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    const int32_t nr = batch->n_reads;
+    for (int32_t i = 0; i < nr; i++) {
+        const ReadView r = read_view(batch, i);
+        int64_t read_span = 0;
+        for (int c = 0; c < r.n_cigar; c++)
+            if (r.cigar_op[c] == 'M' || r.cigar_op[c] == 'I' || r.cigar_op[c] == 'S' || r.cigar_op[c] == '=' || r.cigar_op[c] == 'X') read_span += r.cigar_len[c];
+        if (r.position <= 0 || r.read_len < 0 || read_span > r.read_len) return fail(h, PISCES_E_INVALID_ARG, "find_candidates_device: CIGAR does not match the read");
+    }
+    // the batch on the device (local buffers: this entry is a test / tooling surface, not the streaming path)
+    const size_t n_cig = (size_t)batch->cigar_offset[nr], n_seq = (size_t)batch->seq_offset[nr];
+    DeviceBuf<int32_t> d_pos, d_coff, d_soff, d_cnt, d_pool_first;
+    DeviceBuf<uint8_t> d_flags, d_cop, d_bases, d_quals, d_dirs, d_deldirs, d_pool;
+    DeviceBuf<uint32_t> d_clen;
+    DeviceBuf<long long> d_totals;
+    DeviceBuf<unsigned int> d_misc;
+    DeviceBuf<DevFound> d_out;
+    auto up = [&](auto& buf, const void* src, size_t n_elems, size_t elem) -> hipError_t {
+        hipError_t e = buf.reserve(std::max<size_t>(n_elems, 1));
+        if (e != hipSuccess || n_elems == 0) return e;
+        return hipMemcpyAsync(buf.p, src, n_elems * elem, hipMemcpyHostToDevice, h->stream);
+    };
+    PISCES_HIP_CHECK(h, up(d_pos, batch->position, (size_t)nr, 4));
+    PISCES_HIP_CHECK(h, up(d_flags, batch->flags, (size_t)nr, 1));
+    PISCES_HIP_CHECK(h, up(d_coff, batch->cigar_offset, (size_t)nr + 1, 4));
+    PISCES_HIP_CHECK(h, up(d_cop, batch->cigar_op, n_cig, 1));
+    PISCES_HIP_CHECK(h, up(d_clen, batch->cigar_len, n_cig, 4));
+    PISCES_HIP_CHECK(h, up(d_soff, batch->seq_offset, (size_t)nr + 1, 4));
+    PISCES_HIP_CHECK(h, up(d_bases, batch->bases, n_seq, 1));
+    PISCES_HIP_CHECK(h, up(d_quals, batch->quals, n_seq, 1));
+    if (batch->directions) PISCES_HIP_CHECK(h, up(d_dirs, batch->directions, n_seq, 1));
+    if (batch->deletion_directions) PISCES_HIP_CHECK(h, up(d_deldirs, batch->deletion_directions, 2 * n_cig, 1));
+    DevReadBatch db;
+    db.position = d_pos.p; db.flags = d_flags.p; db.cigar_offset = d_coff.p; db.cigar_op = d_cop.p; db.cigar_len = d_clen.p;
+    db.seq_offset = d_soff.p; db.bases = d_bases.p; db.quals = d_quals.p; db.dirs = batch->directions ? d_dirs.p : nullptr; db.n_reads = nr;
+    const uint8_t* dd = batch->deletion_directions ? d_deldirs.p : nullptr;
+    const FinderParams FP = {h->cfg.min_base_call_quality, PISCES_ANCHOR_SIZE, snvs_and_mnvs ? 1 : 0, call_mnvs ? 1 : 0, max_mnv_length, max_gap_between_mnv};
+    const unsigned grid = (unsigned)((nr + 255) / 256);
+    PISCES_HIP_CHECK(h, d_cnt.reserve((size_t)nr + 1));
+    PISCES_HIP_CHECK(h, d_pool_first.reserve((size_t)nr + 1));
+    PISCES_HIP_CHECK(h, d_totals.reserve(2));
+    PISCES_HIP_CHECK(h, d_misc.reserve(4));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(d_misc.p, 0, 4 * sizeof(unsigned int), h->stream));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(d_cnt.p + nr, 0, sizeof(int32_t), h->stream));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(d_pool_first.p + nr, 0, sizeof(int32_t), h->stream));
+    hipLaunchKernelGGL(find_count_kernel, dim3(grid), dim3(256), 0, h->stream, db, dd, (const uint8_t*)h->d_ref.p, h->ref_len, FP, d_cnt.p, d_pool_first.p);
+    hipLaunchKernelGGL(found_scan_kernel, dim3(1), dim3(1024), 0, h->stream, d_cnt.p, d_pool_first.p, nr + 1, d_totals.p);
+    long long totals[2] = {0, 0};
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(totals, d_totals.p, sizeof(totals), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    std::vector<HostCandidate> found;
+    if (totals[0] > 0) {
+        PISCES_HIP_CHECK(h, d_out.reserve((size_t)totals[0]));
+        PISCES_HIP_CHECK(h, d_pool.reserve((size_t)totals[1] + 16));
+        hipLaunchKernelGGL(find_emit_kernel, dim3(grid), dim3(256), 0, h->stream, db, dd, (const uint8_t*)h->d_ref.p, h->ref_len, FP, (const int32_t*)d_cnt.p,
+                           (const int32_t*)d_pool_first.p, d_out.p, d_pool.p, d_misc.p, (int32_t)totals[1], (int32_t*)(d_misc.p + 1));
+        PISCES_HIP_CHECK(h, hipGetLastError());
+        std::vector<DevFound> recs((size_t)totals[0]);
+        std::vector<uint8_t> pool((size_t)totals[1] + 1);
+        unsigned int misc[2] = {0, 0};
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(recs.data(), d_out.p, recs.size() * sizeof(DevFound), hipMemcpyDeviceToHost, h->stream));
+        if (totals[1] > 0) PISCES_HIP_CHECK(h, hipMemcpyAsync(pool.data(), d_pool.p, (size_t)totals[1], hipMemcpyDeviceToHost, h->stream));
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(misc, d_misc.p, sizeof(misc), hipMemcpyDeviceToHost, h->stream));
+        PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+        if (misc[1]) return fail(h, PISCES_E_DEVICE, "find_candidates_device: record reservation exceeded");
+        for (const DevFound& f : recs) {
+            if (f.c.category == kFoundHole) continue;
+            found.push_back(host_candidate_of(f.c, h->h_ref.data(), f.pool_offset >= 0 ? pool.data() + f.pool_offset : f.alt));
+        }
+    }
+    return export_candidates(found, out, capacity, alleles, allele_capacity, allele_bytes);
 }
 
 int64_t pisces_hip_find_indel_candidates(const PiscesReadBatch* batch, const uint8_t* ref, int64_t ref_len, int32_t min_bq,
@@ -1725,6 +1907,7 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
     *n_out = 0;
     if (n_cand) *n_cand = 0;
     if (allele_bytes) *allele_bytes = 0;
+    { int32_t rcf = consume_found(h); if (rcf) return rcf; }
     const bool final_flush = up_to_position < 0;
     const bool replay = h->pending_valid && h->pending_up_to == up_to_position;
     if (!replay) {
@@ -1949,8 +2132,9 @@ int32_t pisces_hip_get_candidates(PiscesHip* h, int32_t up_to_position, PiscesCa
                                   uint8_t* alleles, int64_t allele_capacity, int64_t* allele_bytes)
 {
     if (!h || !n_out) return PISCES_E_INVALID_ARG;
-    // the insertion / deletion candidates collected so far (SNV candidates never leave the device; MNV discovery
-    // is SURVEY section 8 row f1)
+    // the candidates collected so far: insertions / deletions, and with MNV calling on the SNVs / MNVs of the read walk (with it
+    // off SNV candidates never leave the device: they are the allele counts)
+    { int32_t rcf = consume_found(h); if (rcf) return rcf; }
     int64_t n = 0, bytes = 0;
     for (auto& kv : h->blocks)
         for (auto& c : kv.second.cands) {

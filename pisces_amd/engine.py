@@ -184,6 +184,25 @@ class HipVariantCaller:
         _check(self._h, lib.pisces_hip_reduce_summary(self._h, v))
         return [int(x) for x in v]
 
+    def FindCandidates(self, reads, snvs_and_mnvs=True, call_mnvs=False, max_mnv_length=3, max_gap_between_mnv=1):
+        """ICandidateVariantFinder.FindCandidates on the device (pisces_hip_find_candidates_device: the kernels pisces_hip_add_reads
+        enqueues), against the reference given to SetReference: list of dicts per read event, unmerged, in read order."""
+        batch = reads if isinstance(reads, _abi.ReadBatch) else _abi.ReadBatch(reads)
+        cap, pool_cap = 4096, 1 << 18
+        while True:
+            cands = (_abi.PiscesCandidate * cap)()
+            pool = np.zeros(pool_cap, dtype=np.uint8)
+            nb = C.c_int64(0)
+            n = lib.pisces_hip_find_candidates_device(self._h, C.byref(batch.c), int(snvs_and_mnvs), int(call_mnvs), max_mnv_length,
+                                                      max_gap_between_mnv, cands, cap, pool.ctypes.data, pool_cap, C.byref(nb))
+            if n == _abi.E_BUFFER_TOO_SMALL:
+                cap *= 4
+                pool_cap = max(pool_cap * 4, int(nb.value))
+                continue
+            if n < 0:
+                _check(self._h, int(n))
+            return _candidate_dicts(cands, pool, n)
+
     def Stats(self):
         s = (C.c_int64 * 4)()
         _check(self._h, lib.pisces_hip_stats(self._h, s))
@@ -367,6 +386,18 @@ def bgzf_scan(file_bytes):
     return (_abi.PiscesBgzfBlock * int(n)).from_buffer(blocks) if n else (_abi.PiscesBgzfBlock * 0)(), int(total.value)
 
 
+def _candidate_dicts(cands, pool, n):
+    out = []
+    for i in range(n):
+        c = cands[i]
+        o = c.allele_offset
+        out.append({"position": c.position, "category": c.category, "ref": bytes(pool[o: o + c.ref_len]).decode(),
+                    "alt": bytes(pool[o + c.ref_len: o + c.ref_len + c.alt_len]).decode(),
+                    "support_by_dir": list(c.support_by_dir), "well_anchored_by_dir": list(c.well_anchored_by_dir),
+                    "open_left": bool(c.open_left), "open_right": bool(c.open_right)})
+    return out
+
+
 def find_candidates(batch, ref, min_base_call_quality=20, snvs_and_mnvs=True, call_mnvs=False, max_mnv_length=3, max_gap_between_mnv=1):
     """The host finder (pisces_hip_find_candidates): insertions / deletions, and with snvs_and_mnvs the SNV / MNV candidates of the
     M operations; list of dicts in read order."""
@@ -385,12 +416,4 @@ def find_candidates(batch, ref, min_base_call_quality=20, snvs_and_mnvs=True, ca
             continue
         if n < 0:
             raise PiscesHipError(int(n), "find_candidates failed")
-        out = []
-        for i in range(n):
-            c = cands[i]
-            o = c.allele_offset
-            out.append({"position": c.position, "category": c.category, "ref": bytes(pool[o: o + c.ref_len]).decode(),
-                        "alt": bytes(pool[o + c.ref_len: o + c.ref_len + c.alt_len]).decode(),
-                        "support_by_dir": list(c.support_by_dir), "well_anchored_by_dir": list(c.well_anchored_by_dir),
-                        "open_left": bool(c.open_left), "open_right": bool(c.open_right)})
-        return out
+        return _candidate_dicts(cands, pool, n)

@@ -605,6 +605,115 @@ def test_summary_reduce_through_the_c_abi(torch_cuda):
             c.comm_init(uid, 0, 1)   # one communicator per handle
 
 
+def _cand_dicts_oracle(reads, ref, call_mnvs, max_len, max_gap, snvs=True):
+    exp = []
+    for d in reads:
+        rd = orc.make_read(d["pos"], d["seq"], cigar=d["cigar"], quals=d["quals"], reverse=d.get("reverse", False), dirs=d.get("dirs"))
+        for c in orc.find_candidates(rd, ref.decode() if isinstance(ref, bytes) else ref, call_mnvs=call_mnvs, max_mnv=max_len, max_gap=max_gap):
+            if not snvs and c.category in (_abi.CAT_SNV, _abi.CAT_MNV):
+                continue
+            exp.append({"position": c.position, "category": c.category, "ref": c.ref.decode(), "alt": c.alt.decode(),
+                        "support_by_dir": list(c.support_by_dir), "well_anchored_by_dir": list(c.well_anchored_by_dir),
+                        "open_left": bool(c.open_left), "open_right": bool(c.open_right)})
+    return exp
+
+
+def test_device_finder_on_the_reference_finder_cases(torch_cuda):
+    """Row f1: candidate discovery on the DEVICE (find_count_kernel / find_emit_kernel through pisces_hip_find_candidates_device, the
+    kernels pisces_hip_add_reads enqueues) over all 106 reads of the reference's VariantFinderTests (tests/golden/finder_cases.json:
+    SNV, MNV, deletion and insertion suites): every expected candidate with its open ends, nothing else, and equal to the oracle's
+    finder field by field."""
+    from pisces_amd import engine
+    g = json.load(open(os.path.join(G, "finder_cases.json")))
+    cat = {"Snv": _abi.CAT_SNV, "Mnv": _abi.CAT_MNV, "Insertion": _abi.CAT_INSERTION, "Deletion": _abi.CAT_DELETION}
+    n_checked = n_reads = 0
+    for case in g["cases"]:
+        if not case["read"]:
+            continue
+        start = 101
+        ops = orc.parse_cigar(case["cigar"])
+        clip = ops[0][1] if ops and ops[0][0] == "S" else 0
+        ref = ("N" * (start - 1 - clip) + case["ref_under_read"] + "NNNNN").encode()
+        rd = {"pos": start, "cigar": ops, "seq": case["read"], "quals": case["quals"], "reverse": False}
+        cfg = _abi.default_config(min_base_call_quality=g["min_base_call_quality"])
+        with engine.HipVariantCaller(cfg) as c:
+            c.SetReference(ref)
+            got = c.FindCandidates(_abi.ReadBatch([rd]), True, g["call_mnvs"], case["max_mnv_length"], case["max_gap"])
+        n_reads += 1
+        assert got == _cand_dicts_oracle([rd], ref, g["call_mnvs"], case["max_mnv_length"], case["max_gap"]), case
+        assert len(got) == case["expected_count"], (case["cigar"], case["read"], got)
+        key = lambda x: (x["position"], x["category"], x["ref"], x["alt"])
+        for e in (case["expected"] if case["expected_count"] else []):
+            m = [x for x in got if key(x) == (e["coord"] + start, cat[e["type"]], e["ref"], e["alt"])]
+            assert len(m) == 1, (case, got)
+            if e["open_left"] is not None:
+                assert m[0]["open_left"] == e["open_left"]
+            if e["open_right"] is not None:
+                assert m[0]["open_right"] == e["open_right"]
+            n_checked += 1
+    assert n_reads >= 100 and n_checked >= 90
+
+
+def test_device_finder_deletion_directions_and_random_reads(torch_cuda):
+    """The 14 RunDeletionScenarios reads (support direction of a deletion inside a stitched read, deletion_directions from the XD tag)
+    on the device finder, then 500 random reads (insertions, deletions, soft clips, mismatches, N bases, low qualities, stitched
+    directions, long insertions that go through the byte pool) against the oracle's finder for four MNV settings, in one batch each:
+    records in read order, field by field."""
+    from pisces_amd import engine
+    doc = json.load(open(os.path.join(G, "support_direction_deletion_cases.json")))
+    code = {"Forward": _abi.DIR_FORWARD, "Reverse": _abi.DIR_REVERSE, "Stitched": _abi.DIR_STITCHED}
+    rd = doc["read"]
+    reads = [{"pos": rd["position"], "cigar": orc.parse_cigar(rd["cigar"]), "seq": rd["sequence"], "quals": [30] * len(rd["sequence"]),
+              "xd": f'{c["num_forward"]}F{c["num_stitched"]}S{c["num_reverse"]}R'} for c in doc["cases"]]
+    with engine.HipVariantCaller(_abi.default_config()) as c:
+        c.SetReference(b"ATCG" * 5)
+        got = c.FindCandidates(_abi.ReadBatch(reads), False)
+    assert len(got) == len(doc["cases"]) == 14
+    for x, case in zip(got, doc["cases"]):
+        want = [0, 0, 0]
+        want[code[case["expected"]]] = 1
+        assert x["category"] == _abi.CAT_DELETION and x["support_by_dir"] == want, case["name"]
+    rng = np.random.default_rng(2026)
+    ref = bytes(rng.choice(list(b"ACGT"), 700).astype(np.uint8))
+    reads = []
+    for _ in range(500):
+        ops = []
+        for k in range(int(rng.integers(1, 5))):
+            o = str(rng.choice(list("MMMMIDS")))
+            ops.append((o, int(rng.integers(33, 60)) if (o == "I" and rng.random() < 0.1) else int(rng.integers(1, 30))))
+        ops = [(o, l) for i, (o, l) in enumerate(ops) if o != "S" or i in (0, len(ops) - 1)]
+        if not any(o == "M" for o, _ in ops):
+            ops.insert(len(ops) // 2, ("M", 12))
+        pos = int(rng.integers(20, 500))
+        seq, rp = [], pos
+        for o, l in ops:
+            if o == "M":
+                seg = bytearray(ref[rp - 1: rp - 1 + l])
+                seg += bytes(rng.choice(list(b"ACGT"), l - len(seg)).astype(np.uint8)) if len(seg) < l else b""
+                for i in range(len(seg)):
+                    if rng.random() < 0.25:
+                        seg[i] = int(rng.choice(list(b"ACGTN"), p=[.24, .24, .24, .24, .04]))
+                seq.append(bytes(seg).decode())
+                rp += l
+            elif o == "D":
+                rp += l
+            else:
+                seq.append("".join(rng.choice(list("ACGT"), l)))
+        seq = "".join(seq)
+        rl = len(seq)
+        stitched = rng.random() < 0.3
+        reads.append({"pos": pos, "cigar": ops, "seq": seq, "quals": rng.choice([10, 25, 37], rl, p=[.1, .15, .75]).astype(np.uint8).tolist(),
+                      "reverse": bool(rng.integers(0, 2)), "dirs": rng.choice([0, 1, 2], rl).tolist() if stitched else None})
+    with engine.HipVariantCaller(_abi.default_config()) as c:
+        c.SetReference(ref)
+        for snvs, call_mnvs, max_len, max_gap in ((False, False, 3, 1), (True, False, 3, 1), (True, True, 3, 1), (True, True, 40, 10), (True, True, 2, 0)):
+            got = c.FindCandidates(_abi.ReadBatch(reads), snvs, call_mnvs, max_len, max_gap)
+            exp = _cand_dicts_oracle(reads, ref, call_mnvs, max_len, max_gap, snvs=snvs)
+            assert len(exp) > 100
+            assert got == exp, (snvs, call_mnvs, max_len, max_gap)
+            assert any(len(x["alt"]) > 33 for x in got)   # the byte pool was exercised
+
+
 def test_streaming_surface_equals_device_resident_surface_at_size(torch_cuda):
     """The two surfaces of the boundary on the same pileup (20 000 loci x 500x, 66 700 reads): reads walked on the device, block by
     block through add_reads / flush as SmallVariantCaller drives them, must give exactly the records of one call_tiles launch over
