@@ -181,7 +181,7 @@ namespace Pisces.Hip
                     Chromosome = chr.Name, ReferencePosition = r.Position, ReferenceAllele = refAllele, AlternateAllele = altAllele,
                     TotalCoverage = r.TotalCoverage, AlleleSupport = r.AlleleSupport, ReferenceSupport = r.ReferenceSupport, NumNoCalls = r.NumNoCalls,
                     VariantQscore = r.VariantQscore, GenotypeQscore = r.GenotypeQscore, Genotype = MapGenotype(r.Info & 15),
-                    NoiseLevelApplied = r.AlleleSupport > 0 ? _cfg.NoiseLevel : 0, PhaseSetIndex = (r.FilterBits >> 14) & 3
+                    NoiseLevelApplied = r.NoiseLevel == short.MinValue ? int.MinValue : r.NoiseLevel, PhaseSetIndex = (r.FilterBits >> 14) & 3
                 };
                 a.EstimatedCoverageByDirection = new[] { r.CovF, r.CovR, r.CovS };
                 a.SupportByDirection = new[] { r.SupF, r.SupR, r.SupS };
@@ -226,6 +226,30 @@ namespace Pisces.Hip
             return Pisces.Processing.RegionState.AlleleCountHelper.GetAnchorAdjustedAlleleCount(minAnchor, fromEnd, 5, 11, counts, 0, allele, direction,
                 5, maxAnchor, symmetric);                                       // (AlleleCountHelper.cs:21-85, TrackedAnchorSize 5)
         }
+
+        /// IAlleleSource.GetSumOfAlleleBaseQualities: the base-quality sums of one position + AlleleCountHelper.GetAnchorAdjustedTotalQuality
+        public double GetSumOfAlleleBaseQualities(int position, int allele, int direction, int minAnchor, int? maxAnchor, bool fromEnd, bool symmetric)
+        {
+            var flat = new double[6 * 3 * 11];
+            NativeMethods.Check(_h, NativeMethods.pisces_hip_get_base_quality_sums(_h, position, 1, flat));
+            var sums = new double[1, 6, 3, 11];                                 // RegionState._sumOfAlleleBaseQualities layout for one position
+            Buffer.BlockCopy(flat, 0, sums, 0, flat.Length * sizeof(double));
+            return Pisces.Processing.RegionState.AlleleCountHelper.GetAnchorAdjustedTotalQuality(minAnchor, fromEnd, 5, 11, sums, 0, allele, direction,
+                5, maxAnchor, symmetric);                                       // (AlleleCountHelper.cs:87-166)
+        }
+
+        public int GetGappedMnvRefCount(int position)
+        {
+            int count;
+            NativeMethods.Check(_h, NativeMethods.pisces_hip_get_gapped_mnv_ref(_h, position, out count));
+            return count;
+        }
+
+        /// The per-chromosome totals summed over the interval shards of a multi-GPU job (one process per GPU; SmallVariantCaller.cs:114-115):
+        /// InitSummaryReduce once per handle with the id rank 0 made (MakeSummaryReduceId), then ReduceSummary(Stats()).
+        public static byte[] MakeSummaryReduceId() { var id = new byte[128]; NativeMethods.Check(IntPtr.Zero, NativeMethods.pisces_hip_comm_unique_id(id, id.Length)); return id; }
+        public void InitSummaryReduce(byte[] id, int rank, int world) { NativeMethods.Check(_h, NativeMethods.pisces_hip_comm_init(_h, id, rank, world)); }
+        public long[] ReduceSummary(long[] totals4) { NativeMethods.Check(_h, NativeMethods.pisces_hip_reduce_summary(_h, totals4)); return totals4; }
 
         public void AddGappedMnvRefCount(Dictionary<int, int> lookup)
         {

@@ -20,9 +20,9 @@ namespace Pisces.Hip
 
         public HipFactory(PiscesApplicationOptions options) : base(options) { }
 
-        // Candidates are found by the library itself from the reads handed to pisces_hip_add_reads (finder.cpp): insertions / deletions
-        // always, SNV / MNV candidates of the M walk when CallMNVs is set (PiscesHipConfig.call_mnvs); with it off SNV candidates are
-        // implied by the device counts.  No managed finder runs: a finder that yields nothing keeps SmallVariantCaller's loop unchanged.
+        // Candidates are found by the library itself, on the device, from the reads handed to pisces_hip_add_reads (find_emit_kernel):
+        // insertions / deletions always, SNV / MNV candidates of the M walk when CallMNVs is set (PiscesHipConfig.call_mnvs); with it off SNV
+        // candidates are implied by the device counts.  No managed finder runs: a finder that yields nothing keeps SmallVariantCaller's loop unchanged.
         protected override ICandidateVariantFinder CreateVariantFinder() { return new NoCandidates(); }
 
         protected override IStateManager CreateStateManager(ChrIntervalSet intervalSet, bool expectStitchedReads = false,
@@ -72,10 +72,20 @@ namespace Pisces.Hip
             int minAnchor = 0, int? maxAnchor = null, bool fromEnd = false, bool symmetric = false)
         { return _e.GetAlleleCount(position, (int)a, (int)d, minAnchor, maxAnchor, fromEnd, symmetric); }
         public void AddGappedMnvRefCount(Dictionary<int, int> lookup) { _e.AddGappedMnvRefCount(lookup); }
-        // remaining IAlleleSource members (GetSumOfAlleleBaseQualities, GetCollapsedReadCount, ...) return the
-        // RegionStateManager defaults (0 / ExpectStitchedReads) — they feed only NoiseModel.Window / collapsed BAMs.
+        public int GetGappedMnvRefCount(int position) { return _e.GetGappedMnvRefCount(position); }
+        public double GetSumOfAlleleBaseQualities(int position, Pisces.Domain.Types.AlleleType a, Pisces.Domain.Types.DirectionType d,
+            int minAnchor = 0, int? maxAnchor = null, bool fromEnd = false, bool symmetric = false)
+        { return _e.GetSumOfAlleleBaseQualities(position, (int)a, (int)d, minAnchor, maxAnchor, fromEnd, symmetric); }
+        // Read-collapsing (UMI) counts are kept by CollapsedRegionStateManager only, for BAMs made by the read collapser
+        // (CollapedRegionStateManager.cs:33); RegionStateManager itself returns 0 (RegionStateManager.cs: the virtual no-op
+        // AddCollapsedReadCount), and so does this state manager: Factory.CreateStateManager is asked for the plain one here.
+        public int GetCollapsedReadCount(int position, Pisces.Domain.Types.ReadCollapsedType type) { return 0; }
+        // Consumers: ExactCoverageCalculator (only with the exact-coverage option, which HipAlleleCaller does not run) and the amplicon-bias
+        // calculator (off by default; AmpliconBiasFilterThreshold null).  The native path carries neither, as RegionStateManager
+        // carries none without an amplicon-tagged BAM.
+        public List<ReadCoverageSummary> GetSpanningReadSummaries(int startPosition, int endPosition) { return new List<ReadCoverageSummary>(); }
+        public AmpliconCounts GetCoverageByAmplicon(int position) { return AmpliconCounts.GetEmptyAmpliconCounts(); }
         public bool ExpectStitchedReads { get { return _e.ExpectStitchedReads; } }
-        /* ... */
     }
 
     /// IAlleleCaller: Call(batch, source) = pisces_hip_flush_ex(upTo) -> PiscesCalledAllele[] (+ the allele strings of the called

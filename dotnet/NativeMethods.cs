@@ -41,7 +41,8 @@ namespace Pisces.Hip
         public int CovF, CovR, CovS, SupF, SupR, SupS;
         public int VariantQscore;
         public double StrandBiasScore;
-        public int GenotypeQscore;
+        public short GenotypeQscore;
+        public short NoiseLevel;   // CalledAllele.NoiseLevelApplied; -32768 = int.MinValue (the C# cast of a non-finite PtoQ)
         public ushort FilterBits, Info;
     }
 
@@ -111,6 +112,14 @@ namespace Pisces.Hip
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_synchronize(IntPtr handle);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_get_counts(IntPtr handle, int startPosition, int n, [Out] int[] counts);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_add_gapped_mnv_ref(IntPtr handle, int[] positions, int[] counts, int n);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_get_gapped_mnv_ref(IntPtr handle, int position, out int count);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_get_base_quality_sums(IntPtr handle, int startPosition, int n, [Out] double[] sums);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern long pisces_hip_find_candidates_device(IntPtr handle, ref PiscesReadBatch batch, int snvsAndMnvs, int callMnvs, int maxMnvLength, int maxGapBetweenMnv, [Out] PiscesCandidate[] cands, long capacity, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
+        // multi-GPU summary (one process per GPU): RCCL is bound by the library at run time
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_comm_unique_id([Out] byte[] id128, int capacity);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_comm_init(IntPtr handle, byte[] id128, int rank, int world);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_reduce_summary(IntPtr handle, [In, Out] long[] totals4);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_comm_destroy(IntPtr handle);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_stats(IntPtr handle, [Out] long[] stats4);
 
         // measurement helpers (bench / diagnostics)

@@ -164,7 +164,11 @@ typedef struct PiscesCalledAllele {
     int32_t support_by_dir[3];   /* SupportByDirection */
     int32_t variant_qscore;      /* VariantQscore */
     double  strand_bias_score;   /* StrandBiasResults.BiasScore; GATKBiasScore = 10*log10 of it */
-    int32_t genotype_qscore;     /* GenotypeQscore */
+    int16_t genotype_qscore;     /* GenotypeQscore */
+    int16_t noise_level;         /* NoiseLevelApplied: set where the q-score is computed (VariantQualityCalculator.cs:13), so 0 for an
+                                    allele without support; the configured level with NoiseModel.Flat, (int)PtoQ(SumOfBaseQuality /
+                                    TotalCoverage) with NoiseModel.Window (AlleleCaller.cs:215-218); -32768 stands for int.MinValue (the
+                                    C# cast of a non-finite PtoQ) */
     uint16_t filter_bits;        /* bit i = FilterType i */
     uint16_t info;               /* see PISCES_INFO_* */
 } PiscesCalledAllele;
@@ -294,6 +298,12 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
 /* IAlleleSource.GetAlleleCount for a run of positions: out[n][6][3][11] int32
  * (RegionState.cs:57); blocks never touched read as zero (RegionStateManager.cs:222-226). */
 int32_t pisces_hip_get_counts(PiscesHip* h, int32_t start_position, int32_t n, int32_t* out);
+/* IAlleleSource.GetSumOfAlleleBaseQualities (src/lib/Pisces.Domain/Interfaces/IAlleleSource.cs:16; RegionState.cs:61,233-239): the
+ * base-quality sums double[n][6][3][11] of [start_position, start_position + n), same layout and rules as pisces_hip_get_counts (the
+ * caller applies the anchor window, AlleleCountHelper.GetAnchorAdjustedTotalQuality).  Served by any handle, not only NoiseModel.Window. */
+int32_t pisces_hip_get_base_quality_sums(PiscesHip* h, int32_t start_position, int32_t n, double* out);
+/* IAlleleSource.GetGappedMnvRefCount (IAlleleSource.cs:19): what pisces_hip_add_gapped_mnv_ref registered for the position, else 0 */
+int32_t pisces_hip_get_gapped_mnv_ref(PiscesHip* h, int32_t position, int32_t* count);
 /* IAlleleSource.AddGappedMnvRefCount (RegionStateManager.cs:74-81) */
 int32_t pisces_hip_add_gapped_mnv_ref(PiscesHip* h, const int32_t* positions, const int32_t* counts, int32_t n);
 /* host-side candidates (insertion / deletion) found so far with position <= up_to (< 0 = all)
@@ -423,6 +433,9 @@ typedef struct PiscesVcfConfig {
     float   min_frequency_threshold;            /* MinFrequencyThreshold: sets the number of VF decimals */
     float   frequency_filter_threshold;         /* FrequencyFilterThreshold; < 0 = null */
     int32_t crush;                              /* !AllowMultipleVcfLinesPerLoci (-crushvcf): co-located alleles share one line */
+    int32_t noise_level_from_records;           /* 1: the NL column is the record's noise_level (CalledAllele.NoiseLevelApplied: records made by
+                                                   this library, exact with NoiseModel.Window too); 0: noise_level above for every allele
+                                                   with support (records assembled elsewhere) */
 } PiscesVcfConfig;
 int32_t pisces_hip_vcf_default_config(PiscesVcfConfig* cfg);
 /* One VCF body line per record, or with cfg->crush one per position (VcfFileWriter.WriteListOfColocatedAlleles, VcfFileWriter.cs:206-262

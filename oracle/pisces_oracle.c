@@ -1552,7 +1552,8 @@ static void to_record(PiscesCalledAllele* o, const OrcCalled* v)
     for (int d = 0; d < 3; d++) { o->coverage_by_dir[d] = v->coverage_by_dir[d]; o->support_by_dir[d] = v->support_by_dir[d]; }
     o->variant_qscore = v->variant_qscore;
     o->strand_bias_score = v->has_sb ? v->sb.bias_score : 0.0;
-    o->genotype_qscore = v->genotype_qscore;
+    o->genotype_qscore = (int16_t)v->genotype_qscore;
+    o->noise_level = v->noise_level_applied == INT32_MIN ? INT16_MIN : (int16_t)v->noise_level_applied;
     o->filter_bits = (uint16_t)v->filters;
     int single = (strlen(v->ref) == 1 && strlen(v->alt) == 1);
     int refc = allele_type_of((uint8_t)v->ref[0]);

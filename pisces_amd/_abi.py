@@ -126,7 +126,8 @@ class PiscesTileBatch(C.Structure):
 class PiscesVcfConfig(C.Structure):
     _fields_ = [("variant_quality_filter", C.c_int32), ("rmxn_max_repeat_length", C.c_int32), ("rmxn_min_repetitions", C.c_int32),
                 ("noise_level", C.c_int32), ("output_strand_bias_and_noise_level", C.c_int32), ("output_no_call_fraction", C.c_int32),
-                ("min_frequency_threshold", C.c_float), ("frequency_filter_threshold", C.c_float), ("crush", C.c_int32)]
+                ("min_frequency_threshold", C.c_float), ("frequency_filter_threshold", C.c_float), ("crush", C.c_int32),
+                ("noise_level_from_records", C.c_int32)]
 
 
 class PiscesVcfPadState(C.Structure):
@@ -194,7 +195,8 @@ CALLED_ALLELE_DTYPE = np.dtype([
     ("support_by_dir", "<i4", (3,)),
     ("variant_qscore", "<i4"),
     ("strand_bias_score", "<f8"),
-    ("genotype_qscore", "<i4"),
+    ("genotype_qscore", "<i2"),
+    ("noise_level", "<i2"),
     ("filter_bits", "<u2"),
     ("info", "<u2"),
 ], align=True)

@@ -339,15 +339,24 @@ __device__ __forceinline__ bool poisson_qscore_try(int32_t callCount, int32_t co
     return false;
 }
 
-// NoiseModel.Window (AlleleCaller.cs:215-218): QtoP((int)PtoQ(SumOfBaseQuality / TotalCoverage)), or a negative value when the mean
-// error is not a positive finite number (the reference's arithmetic then ends in a q-score of 0; see oracle/pisces_oracle.c)
+// NoiseModel.Window (AlleleCaller.cs:215-218): the allele's noise level (int)PtoQ(SumOfBaseQuality / TotalCoverage), or kNoLevel when
+// the mean error is not a positive finite number (the C# cast then gives int.MinValue and the reference's arithmetic ends in a
+// q-score of 0; see oracle/pisces_oracle.c), and QtoP of it (negative for kNoLevel).
+constexpr int32_t kNoLevel = (int32_t)0x80000000;
+__device__ inline int32_t window_level(double sumOfBaseQuality, int totalCoverage)
+{
+    if (totalCoverage == 0) return kNoLevel;
+    const double mean = sumOfBaseQuality / (double)totalCoverage;
+    if (!(mean > 0.0) || isinf(mean)) return kNoLevel;
+    return (int32_t)p_to_q(mean);
+}
+__device__ inline double window_err_of_level(int32_t level, const DeviceParams& P) { return level == kNoLevel ? -1.0 : q_to_p_int(level, P); }
 __device__ inline double window_err(double sumOfBaseQuality, int totalCoverage, const DeviceParams& P)
 {
-    if (totalCoverage == 0) return -1.0;
-    const double mean = sumOfBaseQuality / (double)totalCoverage;
-    if (!(mean > 0.0) || isinf(mean)) return -1.0;
-    return q_to_p_int((int)p_to_q(mean), P);
+    return window_err_of_level(window_level(sumOfBaseQuality, totalCoverage), P);
 }
+// CalledAllele.NoiseLevelApplied as the 64-byte record carries it
+__device__ __forceinline__ int16_t noise_level_field(int32_t level) { return level == kNoLevel ? (int16_t)-32768 : (int16_t)level; }
 
 // ------------------------------------------------------------------------------------------
 // lib/Pisces.Calculators/StrandBiasCalculator.cs:21-231 (Poisson and Extended models)

@@ -115,7 +115,7 @@ __device__ __forceinline__ void copy_record(PiscesCalledAllele* dst, const Pisce
     dp[0] = make_uint4((uint32_t)src->position, (uint32_t)src->total_coverage, (uint32_t)src->allele_support, (uint32_t)src->reference_support);
     dp[1] = make_uint4((uint32_t)src->num_no_calls, (uint32_t)src->coverage_by_dir[0], (uint32_t)src->coverage_by_dir[1], (uint32_t)src->coverage_by_dir[2]);
     dp[2] = make_uint4((uint32_t)src->support_by_dir[0], (uint32_t)src->support_by_dir[1], (uint32_t)src->support_by_dir[2], (uint32_t)src->variant_qscore);
-    dp[3] = make_uint4((uint32_t)sb, (uint32_t)(sb >> 32), (uint32_t)src->genotype_qscore, (uint32_t)src->filter_bits | ((uint32_t)src->info << 16));
+    dp[3] = make_uint4((uint32_t)sb, (uint32_t)(sb >> 32), (uint32_t)(uint16_t)src->genotype_qscore | ((uint32_t)(uint16_t)src->noise_level << 16), (uint32_t)src->filter_bits | ((uint32_t)src->info << 16));
 }
 
 struct PointCounts {
@@ -206,7 +206,8 @@ template <bool kMemo = false>   // kMemo: table-first forms only; false = a tabl
 __device__ inline bool finish_allele(const PointCounts& c, int pos, int a, bool isRef, int rt, int vq, const SbResult& sb,
                                      const uint8_t* __restrict__ ref, int64_t win_lo, int64_t win_hi, const DeviceParams& P,
                                      PiscesCalledAllele& r, const uint8_t* s_refwin, int s_refidx,
-                                     const GqTail* pre_tail = nullptr, const GqPre* pre_gq = nullptr)
+                                     const GqTail* pre_tail = nullptr, const GqPre* pre_gq = nullptr,
+                                     const int32_t* window_level_ = nullptr /* NoiseModel.Window: the allele's own noise level */)
 {
     const float freq = frequency_f(c.support, c.total);
     // SetFractionNoCalls (CalledAllele.cs:107-114) + ApplyFilters
@@ -254,7 +255,9 @@ __device__ inline bool finish_allele(const PointCounts& c, int pos, int a, bool 
     r.support_by_dir[0] = c.sup[0]; r.support_by_dir[1] = c.sup[1]; r.support_by_dir[2] = c.sup[2];
     r.variant_qscore = vq;
     r.strand_bias_score = sb.bias_score;
-    r.genotype_qscore = gq;
+    r.genotype_qscore = (int16_t)gq;
+    // NoiseLevelApplied is assigned where the q-score is computed (VariantQualityCalculator.cs:13): alleles with support only
+    r.noise_level = c.support > 0 ? (window_level_ ? noise_level_field(*window_level_) : (int16_t)P.noise_level) : (int16_t)0;
     r.filter_bits = (uint16_t)filters;
     r.info = PISCES_INFO_PACK(gt, isRef ? PISCES_CAT_REFERENCE : PISCES_CAT_SNV, rt, isRef ? rt : a, sb.acceptable, sb.var_both,
                               sb.cov_both);
@@ -267,12 +270,13 @@ __device__ inline bool process_point_allele(const PointCounts& c, int pos, int a
                                              const uint8_t* __restrict__ ref, int64_t win_lo, int64_t win_hi,
                                              const DeviceParams& P, PiscesCalledAllele& r,
                                              const uint8_t* s_refwin = nullptr, int s_refidx = 0, const GqTail* pre_tail = nullptr,
-                                             const double* window_err_ = nullptr /* NoiseModel.Window: QtoP of the allele's noise level, < 0 = q-score 0 */)
+                                             const int32_t* window_level_ = nullptr /* NoiseModel.Window: the allele's own noise level (kNoLevel = q-score 0) */)
 {
     if (!isRef && !variant_passes_frequency(c, P)) return false;
     int vq = 0;
-    if (window_err_) {
-        if (c.support > 0 && c.total != 0 && *window_err_ >= 0.0) vq = poisson_qscore_e(c.support, c.total, *window_err_, P);
+    if (window_level_) {
+        const double werr = window_err_of_level(*window_level_, P);
+        if (c.support > 0 && c.total != 0 && werr >= 0.0) vq = poisson_qscore_e(c.support, c.total, werr, P);
     } else
 #if !(defined(PISCES_ABLATE_MATH) && (PISCES_ABLATE_MATH == 5 || PISCES_ABLATE_MATH == 9))
     if (c.support > 0 && c.total != 0) vq = poisson_qscore(c.support, c.total, P);   // VariantQualityCalculator.Compute :11-24
@@ -282,7 +286,7 @@ __device__ inline bool process_point_allele(const PointCounts& c, int pos, int a
 #if !(defined(PISCES_ABLATE_MATH) && (PISCES_ABLATE_MATH == 4 || PISCES_ABLATE_MATH == 9))
     if (c.support > 0) sb = strand_bias<kDiploidOk>(c.cov, c.sup, P);                // StrandBiasCalculator.Compute :10-15
 #endif
-    finish_allele(c, pos, a, isRef, rt, vq, sb, ref, win_lo, win_hi, P, r, s_refwin, s_refidx, pre_tail);
+    finish_allele(c, pos, a, isRef, rt, vq, sb, ref, win_lo, win_hi, P, r, s_refwin, s_refidx, pre_tail, nullptr, window_level_);
     return true;
 }
 
@@ -307,7 +311,7 @@ struct VarScratch {
     double ov_var[kTile * 4], fw_var[kTile * 4], fw_fp[kTile * 4], rv_var[kTile * 4], rv_fp[kTile * 4];
 };
 
-__device__ inline void call_roles(const int* hist, const uint32_t* gapped /* LDS[kTile] or nullptr */, const double* s_err /* LDS[kTile], NoiseModel.Window, or nullptr */, const PiscesTile& tile,
+__device__ inline void call_roles(const int* hist, const uint32_t* gapped /* LDS[kTile] or nullptr */, const int32_t* s_lvl /* LDS[kTile]: NoiseModel.Window noise level of the locus' point alleles, or nullptr */, const PiscesTile& tile,
                                   int tile_index, const uint8_t* __restrict__ ref, int32_t ref_start, int64_t ref_len,
                                   PiscesCalledAllele* __restrict__ records, PiscesTileResult* __restrict__ tile_result,
                                   const DeviceParams& P, uint8_t* s_mask /* LDS[kTile] */,
@@ -352,7 +356,7 @@ __device__ inline void call_roles(const int* hist, const uint32_t* gapped /* LDS
                 ref_rank = (rt < 4) ? rank_of_allele(rt) : 0;
                 const PointCounts c = point_counts(hist, l, a, true, rt, g);
                 PiscesCalledAllele rec;
-                (void)process_point_allele<true>(c, pos, a, true, rt, ref, win_lo, win_hi, P, rec, s_refwin, kRefMargin + l, nullptr, s_err ? &s_err[l] : nullptr);
+                (void)process_point_allele<true>(c, pos, a, true, rt, ref, win_lo, win_hi, P, rec, s_refwin, kRefMargin + l, nullptr, s_lvl ? &s_lvl[l] : nullptr);
                 // written now; it only counts if no variant turns out callable at this locus
                 copy_record(&slots[ref_rank], &rec);
                 ref_emitted = true;
@@ -368,8 +372,8 @@ __device__ inline void call_roles(const int* hist, const uint32_t* gapped /* LDS
 #if defined(PISCES_ABLATE_MATH) && (PISCES_ABLATE_MATH == 9 || PISCES_ABLATE_MATH == 6)
                 vs->vq[slot] = 100;
 #else
-                vs->vq[slot] = !(c.support > 0 && c.total != 0) ? 0 : !s_err ? poisson_qscore(c.support, c.total, P)
-                               : s_err[l] >= 0.0 ? poisson_qscore_e(c.support, c.total, s_err[l], P) : 0;
+                vs->vq[slot] = !(c.support > 0 && c.total != 0) ? 0 : !s_lvl ? poisson_qscore(c.support, c.total, P)
+                               : s_lvl[l] != kNoLevel ? poisson_qscore_e(c.support, c.total, window_err_of_level(s_lvl[l], P), P) : 0;
 #endif
 #if defined(PISCES_ABLATE_MATH) && (PISCES_ABLATE_MATH == 9 || PISCES_ABLATE_MATH == 7)
             } else if (c.support < 0) {
@@ -410,7 +414,7 @@ __device__ inline void call_roles(const int* hist, const uint32_t* gapped /* LDS
                     sb = sb_combine(ov, fw, rv, P);
                 }
                 PiscesCalledAllele r;
-                finish_allele(c, pos, a, false, rt, vq, sb, ref, win_lo, win_hi, P, r, s_refwin, kRefMargin + l);
+                finish_allele(c, pos, a, false, rt, vq, sb, ref, win_lo, win_hi, P, r, s_refwin, kRefMargin + l, nullptr, nullptr, s_lvl ? &s_lvl[l] : nullptr);
                 copy_record(&slots[k], &r);
                 mask |= 1u << k;
             }
@@ -973,7 +977,7 @@ __global__ __launch_bounds__(kBlock, 4) void call_counts_kernel(
 {
     __shared__ int hist[kFolded * kTile];
     __shared__ uint32_t s_gapped[kTile];
-    __shared__ double s_err[kTile];
+    __shared__ int32_t s_lvl[kTile];
     __shared__ uint8_t s_mask[kTile];
     __shared__ uint8_t s_refwin[kRefWin];
     __shared__ VarScratch s_var;
@@ -1013,10 +1017,10 @@ __global__ __launch_bounds__(kBlock, 4) void call_counts_kernel(
                     sum += get_base_quality_sum(sumq, (int64_t)t * kTile + l, cca[k], d, 0, -1, false);
                 }
         }
-        s_err[l] = window_err(sum, total, P);
+        s_lvl[l] = window_level(sum, total);
     }
     __syncthreads();
-    call_roles(hist, s_gapped, sumq ? s_err : nullptr, tile, t, ref, ref_start, ref_len, records, &tile_results[t], P, s_mask, s_refwin, &s_var);
+    call_roles(hist, s_gapped, sumq ? s_lvl : nullptr, tile, t, ref, ref_start, ref_len, records, &tile_results[t], P, s_mask, s_refwin, &s_var);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1293,17 +1297,17 @@ __global__ __launch_bounds__(64) void call_spanning_kernel(
         r.position = c.position; r.total_coverage = pc.total; r.allele_support = pc.support; r.reference_support = pc.refsup;
         r.num_no_calls = pc.nocalls;
         for (int d = 0; d < 3; d++) { r.coverage_by_dir[d] = pc.cov[d]; r.support_by_dir[d] = pc.sup[d]; }
-        r.variant_qscore = 0; r.strand_bias_score = 0.0; r.genotype_qscore = 0; r.filter_bits = 0;
+        r.variant_qscore = 0; r.strand_bias_score = 0.0; r.genotype_qscore = 0; r.noise_level = 0; r.filter_bits = 0;
         r.info = PISCES_INFO_PACK(PISCES_GT_HET_ALT_REF, c.category, rt, a, 0, 0, 0);
-        double werr = 0.0;
+        int32_t wlevel = kNoLevel;
         if (sumq) {   // CalculateSinglePoint: SumOfBaseQuality over the five coverage-contributing allele types, directions outermost
             const int cca[5] = {PISCES_ALLELE_A, PISCES_ALLELE_C, PISCES_ALLELE_G, PISCES_ALLELE_T, PISCES_ALLELE_DEL};
             double sum = 0.0;
             for (int d = 0; d < 3; d++)
                 for (int k = 0; k < 5; k++) sum += get_base_quality_sum(sumq, c.start_idx, cca[k], d, 0, -1, false);
-            werr = window_err(sum, pc.total, P);
+            wlevel = window_level(sum, pc.total);
         }
-        const bool ok = process_point_allele<true>(pc, c.position, a, isRef, rt, ref, 0, ref_len, P, r, nullptr, 0, nullptr, sumq ? &werr : nullptr);
+        const bool ok = process_point_allele<true>(pc, c.position, a, isRef, rt, ref, 0, ref_len, P, r, nullptr, 0, nullptr, sumq ? &wlevel : nullptr);
         out[i] = r;
         callable_out[i] = ok ? 1 : 0;
         return;
@@ -1319,15 +1323,16 @@ __global__ __launch_bounds__(64) void call_spanning_kernel(
 
     // ProcessVariant (AlleleCaller.cs:208-234)
     int vq = 0;
+    int16_t noise_level = 0;   // NoiseLevelApplied: assigned with the q-score, i.e. for alleles with support
     SbResult sb = {0.0, 0, 0, 0};
     if (support > 0) {
-        if (total != 0) {
-            if (sumq) {
-                const double werr = window_err(c.reprocessed ? sumQ + sumQ : sumQ, total, P);
-                vq = werr >= 0.0 ? poisson_qscore_e(support, total, werr, P) : 0;
-            } else {
-                vq = poisson_qscore(support, total, P);
-            }
+        noise_level = (int16_t)P.noise_level;
+        if (sumq) {
+            const int32_t level = window_level(c.reprocessed ? sumQ + sumQ : sumQ, total);
+            noise_level = noise_level_field(level);
+            if (total != 0 && level != kNoLevel) vq = poisson_qscore_e(support, total, window_err_of_level(level, P), P);
+        } else if (total != 0) {
+            vq = poisson_qscore(support, total, P);
         }
         sb = strand_bias<true>(cov, c.sup, P);
     }
@@ -1375,7 +1380,8 @@ __global__ __launch_bounds__(64) void call_spanning_kernel(
     r.support_by_dir[0] = c.sup[0]; r.support_by_dir[1] = c.sup[1]; r.support_by_dir[2] = c.sup[2];
     r.variant_qscore = vq;
     r.strand_bias_score = sb.bias_score;
-    r.genotype_qscore = gq;
+    r.genotype_qscore = (int16_t)gq;
+    r.noise_level = noise_level;
     r.filter_bits = (uint16_t)filters;
     const int rt = allele_type_of_base(alleles[c.allele_off]);
     r.info = PISCES_INFO_PACK(gt, c.category, rt, PISCES_ALLELE_N, sb.acceptable, sb.var_both, sb.cov_both);

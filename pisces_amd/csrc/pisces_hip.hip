@@ -2115,6 +2115,62 @@ int32_t pisces_hip_get_counts(PiscesHip* h, int32_t start_position, int32_t n, i
     return PISCES_OK;
 }
 
+// IAlleleSource.GetSumOfAlleleBaseQualities (RegionState._sumOfAlleleBaseQualities, RegionState.cs:61,233-239): the cells of
+// [start_position, start_position + n), layout as pisces_hip_get_counts, accumulated on the device next to the counts from the
+// observation log (Math.Pow(10, -(int)q / 10f) per base under its post-threshold allele, RegionStateManager.cs:191).  The order of the
+// FP64 additions is the device's (atomic order), not the read order: equal to the reference's sums to rounding.
+int32_t pisces_hip_get_base_quality_sums(PiscesHip* h, int32_t start_position, int32_t n, double* out)
+{
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (n < 0 || (n > 0 && !out)) return fail(h, PISCES_E_INVALID_ARG, "get_base_quality_sums: null output");
+    if (start_position <= 0) return fail(h, PISCES_E_INVALID_ARG, "Position must be greater than 0.");
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    std::memset(out, 0, (size_t)n * PISCES_COUNTS_PER_LOCUS * sizeof(double));
+    if (n == 0) return PISCES_OK;
+    std::vector<int32_t> keys;
+    for (int32_t k = block_key(h, start_position); k <= block_key(h, start_position + n - 1); k++)
+        if (h->blocks.count(k)) keys.push_back(k);
+    if (keys.empty()) return PISCES_OK;
+    if (!h->d_bq_lut.p) {   // made at create only for NoiseModel.Window; any handle can serve the sums
+        std::vector<double> lut(256);
+        for (int q = 0; q < 256; q++) lut[(size_t)q] = std::pow(10.0, (double)((float)(-1 * q) / 10.0f));
+        PISCES_HIP_CHECK(h, h->d_bq_lut.reserve(256));
+        PISCES_HIP_CHECK(h, hipMemcpy(h->d_bq_lut.p, lut.data(), 256 * sizeof(double), hipMemcpyHostToDevice));
+    }
+    std::vector<PiscesTile> tiles;
+    int32_t rc = bucket_blocks(h, keys, false, tiles);
+    if (rc) return rc;
+    const int32_t n_tiles = (int32_t)tiles.size();
+    const size_t nc = (size_t)n_tiles * kTile * PISCES_COUNTS_PER_LOCUS;
+    PISCES_HIP_CHECK(h, h->d_counts.reserve(nc));
+    PISCES_HIP_CHECK(h, h->d_sumq.reserve(nc));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_counts.p, 0, nc * sizeof(int32_t), h->stream));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_sumq.p, 0, nc * sizeof(double), h->stream));
+    hipLaunchKernelGGL(accumulate_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles,
+                       h->d_counts.p, h->cfg.min_base_call_quality, h->d_sumq.p, (const double*)h->d_bq_lut.p);
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    std::vector<double> host(nc);
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(host.data(), h->d_sumq.p, nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    for (int32_t t = 0; t < n_tiles; t++)
+        for (int32_t l = 0; l < tiles[(size_t)t].n_loci; l++) {
+            int32_t p = tiles[(size_t)t].start_position + l;
+            if (p < start_position || p >= start_position + n) continue;
+            std::memcpy(out + (size_t)(p - start_position) * PISCES_COUNTS_PER_LOCUS,
+                        host.data() + ((size_t)t * kTile + (size_t)l) * PISCES_COUNTS_PER_LOCUS, PISCES_COUNTS_PER_LOCUS * sizeof(double));
+        }
+    return PISCES_OK;
+}
+
+// IAlleleSource.GetGappedMnvRefCount (RegionStateManager.cs: the lookup AddGappedMnvRefCount fills)
+int32_t pisces_hip_get_gapped_mnv_ref(PiscesHip* h, int32_t position, int32_t* count)
+{
+    if (!h || !count) return PISCES_E_INVALID_ARG;
+    auto it = h->gapped_mnv_ref.find(position);
+    *count = it == h->gapped_mnv_ref.end() ? 0 : it->second;
+    return PISCES_OK;
+}
+
 int32_t pisces_hip_add_gapped_mnv_ref(PiscesHip* h, const int32_t* positions, const int32_t* counts, int32_t n)
 {
     if (!h) return PISCES_E_INVALID_ARG;

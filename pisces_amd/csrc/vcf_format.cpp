@@ -121,6 +121,7 @@ int32_t pisces_hip_vcf_default_config(PiscesVcfConfig* c)
     c->rmxn_min_repetitions = 9;
     c->noise_level = 20;
     c->output_strand_bias_and_noise_level = 1;
+    c->noise_level_from_records = 0;
     c->output_no_call_fraction = 0;
     c->min_frequency_threshold = 0.01f;
     c->frequency_filter_threshold = 0.01f;
@@ -219,7 +220,7 @@ int64_t pisces_hip_format_vcf_padded(const PiscesVcfConfig* cfg, const char* chr
             depth = std::max(depth, recs[i].total_coverage);
             total_variant_reads += recs[i].allele_support;
             qual = std::min(qual, recs[i].variant_qscore);      // MergeVariantQScores :486-489
-            gq = std::min(gq, recs[i].genotype_qscore);         // MergeGenotypeQScores :491-494
+            gq = std::min(gq, (int)recs[i].genotype_qscore);         // MergeGenotypeQScores :491-494
         }
         depth = std::max(depth, total_variant_reads);
         // SetUncrushedReferenceAndAlt :434-448 (PhaseSetIndex: 1 / 2 for the variant alleles of a diploid call, 0 on the somatic path) /
@@ -303,7 +304,8 @@ int64_t pisces_hip_format_vcf_padded(const PiscesVcfConfig* cfg, const char* chr
         if (cfg->output_strand_bias_and_noise_level) {
             // NoiseLevelApplied is set where the q-score is computed (VariantQualityCalculator.cs:13), i.e. for support > 0;
             // BiasResults.GATKBiasScore = 10 log10(BiasScore) (MathOperations.PtoGATKBiasScale), default 0 when never computed
-            const int nl = first.allele_support > 0 ? cfg->noise_level : 0;
+            const long long nl = cfg->noise_level_from_records ? (first.noise_level == INT16_MIN ? (long long)INT32_MIN : (long long)first.noise_level)
+                                                               : (first.allele_support > 0 ? cfg->noise_level : 0);
             double gatk = first.allele_support > 0 ? 10.0 * std::log10(first.strand_bias_score) : 0.0;
             gatk = std::min(std::max(-100.0, gatk), 0.0);
             sample += ":" + std::to_string(nl) + ":" + fmt_double(gatk, 4);

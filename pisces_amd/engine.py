@@ -86,6 +86,17 @@ class HipVariantCaller:
         _check(self._h, lib.pisces_hip_get_counts(self._h, start_position, n, out.ctypes.data))
         return out
 
+    def GetBaseQualitySums(self, start_position, n):
+        """RegionState._sumOfAlleleBaseQualities of [start_position, start_position + n): double[n][6][3][11]."""
+        out = np.zeros((n, 6, 3, _abi.NUM_ANCHORS), dtype=np.float64)
+        _check(self._h, lib.pisces_hip_get_base_quality_sums(self._h, int(start_position), int(n), out.ctypes.data))
+        return out
+
+    def GetGappedMnvRefCount(self, position):
+        v = C.c_int32(0)
+        _check(self._h, lib.pisces_hip_get_gapped_mnv_ref(self._h, int(position), C.byref(v)))
+        return int(v.value)
+
     def GetAlleleCount(self, position, allele_type, direction_type, minAnchor=0, maxAnchor=None, fromEnd=False,
                        symmetric=False):
         """IAlleleSource.GetAlleleCount (src/lib/Pisces.Domain/Interfaces/IAlleleSource.cs): the anchor window

@@ -32,6 +32,7 @@ def assert_records_match(got, exp, q_tol=0):
     moved = (dq != 0) | (dg != 0)
     assert int(moved.sum()) <= len(got) // 1000, (int(moved.sum()), len(got))
     np.testing.assert_array_equal(got["info"], exp["info"])
+    np.testing.assert_array_equal(got["noise_level"], exp["noise_level"])   # CalledAllele.NoiseLevelApplied
     q_bits = np.uint16((1 << 3) | (1 << 6))   # FilterType.LowVariantQscore, LowGenotypeQuality
     np.testing.assert_array_equal(got["filter_bits"][~moved], exp["filter_bits"][~moved])
     np.testing.assert_array_equal(got["filter_bits"][moved] & ~q_bits, exp["filter_bits"][moved] & ~q_bits)
@@ -714,6 +715,36 @@ def test_device_finder_deletion_directions_and_random_reads(torch_cuda):
             assert any(len(x["alt"]) > 33 for x in got)   # the byte pool was exercised
 
 
+def test_flush_into_a_buffer_that_is_too_small_is_repeatable(torch_cuda):
+    """SURVEY 8b ownership rule: output buffers are caller-allocated; pisces_hip_flush returns PISCES_E_BUFFER_TOO_SMALL (-2) with the
+    needed count when the batch does not fit, changes nothing, and the repeated call with a larger buffer returns the identical batch
+    (the blocks are retired only then).  Checked mid-stream and at the final flush, with insertions / deletions in the batch."""
+    import ctypes as C
+    from pisces_amd import engine, synth
+    from pisces_amd._native import lib
+    p = synth.make_pileup(2300, 60, seed=17)
+    reads = synth.reads_of(p)
+    ref = p.ref.cpu().numpy()
+    cfg = _abi.default_config()
+    with engine.HipVariantCaller(cfg) as a, engine.HipVariantCaller(cfg) as b:
+        for c in (a, b):
+            c.SetReference(ref)
+            c.AddAlleleCounts(reads)
+        for up_to in (p.region_start + 1500, None):
+            want = a.Call(up_to, capacity=1 << 16)
+            assert len(want) > 900
+            n = C.c_int64(0)
+            small = np.zeros(10, dtype=_abi.CALLED_ALLELE_DTYPE)
+            for cap in (0, 10, len(want) - 1):
+                rc = lib.pisces_hip_flush(b.handle, -1 if up_to is None else up_to, small.ctypes.data, min(cap, 10), C.byref(n))
+                assert rc == _abi.E_BUFFER_TOO_SMALL and n.value == len(want), (rc, n.value, len(want))
+            out = np.zeros(len(want), dtype=_abi.CALLED_ALLELE_DTYPE)
+            rc = lib.pisces_hip_flush(b.handle, -1 if up_to is None else up_to, out.ctypes.data, len(out), C.byref(n))
+            assert rc == 0 and n.value == len(want)
+            assert out.tobytes() == want.tobytes()
+        assert a.Stats() == b.Stats()
+
+
 def test_streaming_surface_equals_device_resident_surface_at_size(torch_cuda):
     """The two surfaces of the boundary on the same pileup (20 000 loci x 500x, 66 700 reads): reads walked on the device, block by
     block through add_reads / flush as SmallVariantCaller drives them, must give exactly the records of one call_tiles launch over
@@ -889,7 +920,7 @@ def test_reference_bams_through_the_library_give_the_vcf_rows_pisces_wrote(torch
     assert got_alleles == exp_alleles
     got = got.copy()
     got["position"] += off
-    text = engine.format_vcf(case["chrom"], got, alleles=got_alleles, **case["vcf"])
+    text = engine.format_vcf(case["chrom"], got, alleles=got_alleles, noise_level_from_records=1, **case["vcf"])
     bam_fixtures.check_lines(case, text.rstrip("\n").split("\n") if text else [], [str(x) for x in z["expected_vcf"]])
 
 

@@ -501,7 +501,7 @@ def test_reference_bams_give_the_vcf_rows_pisces_wrote(name):
         recs, alleles, _, _ = orc.run_reads_full(batch, z["ref"], start, loci, cfg)
         recs = recs.copy()
         recs["position"] += off
-        text = engine.format_vcf(case["chrom"], recs, alleles=alleles, **case["vcf"])
+        text = engine.format_vcf(case["chrom"], recs, alleles=alleles, noise_level_from_records=1, **case["vcf"])
         lines += text.rstrip("\n").split("\n") if text else []
     bam_fixtures.check_lines(case, lines, [str(x) for x in z["expected_vcf"]])
 
