@@ -68,7 +68,7 @@ def _chunk_generator(seed, chunk, dev):
 
 def make_pileup(n_loci, depth, seed=20260928, device="cpu", p_lowq=0.02, base_error=0.001, snv_every=100,
                 snv_offset=37, q_hi=37, q_lo=12, vaf_range=(0.02, 0.5), strand_range=(0.3, 0.7), flank=READ_LEN, tile=TILE,
-                first_locus=0, total_loci=None):
+                first_locus=0, total_loci=None, with_tuples=True):
     """Loci [first_locus, first_locus + n_loci) of a global pileup of `total_loci` loci (default: the whole pileup, n_loci from 0).
     `tile` = loci per tile of the bucketed tuple stream (<= 64; the kernels take any PiscesTile.n_loci <= 64).  Every chunk of
     CHUNK_AMPLICONS amplicons has its own seeded stream: a range made on its own equals the same range of the whole."""
@@ -161,6 +161,11 @@ def make_pileup(n_loci, depth, seed=20260928, device="cpu", p_lowq=0.02, base_er
     packed = packed.expand(shape)
     dir_bit4 = (direction & 1) << 4
 
+    if not with_tuples:   # reads only (reads_of / mixed_reads): no packed tuple stream
+        gl = np.arange(first_locus, first_locus + n_loci)
+        return Pileup(n_loci=n_loci, depth=depth, region_start=region_start, ref=ref_ascii, tuples=None, tiles=None, n_tiles=0, n_obs=0,
+                      base=base, qual=qual, planted=np.nonzero((gl % snv_every) == snv_offset)[0], ref_start=ref_start,
+                      first_locus=first_locus, first_amplicon=a0, total_loci=total_loci, flank=flank)
     # tile-bucketed tuple stream: tiles from locus 0 of this pileup; inside a tile read-major (each read's run of loci)
     n_tiles = math.ceil(n_loci / tile)
     tiles = np.zeros(n_tiles, dtype=_abi.TILE_DTYPE)
@@ -195,6 +200,20 @@ def make_pileup(n_loci, depth, seed=20260928, device="cpu", p_lowq=0.02, base_er
     return Pileup(n_loci=n_loci, depth=depth, region_start=region_start, ref=ref_ascii, tuples=tuples, tiles=tiles_t,
                   n_tiles=n_tiles, n_obs=n_obs, base=base, qual=qual, planted=planted, ref_start=ref_start, first_locus=first_locus,
                   first_amplicon=a0, total_loci=total_loci, flank=flank)
+
+
+def reference_of(total_loci, seed, flank=READ_LEN, device="cpu"):
+    """The whole contig of a global pileup (position p = result[p - 1]) without making the pileup: the reference bases are the first
+    draw of every chunk's stream.  `device` must be the device the pileups are made on (CPU and GPU generators differ)."""
+    A_total, _ = _amplicon_lengths(total_loci)
+    dev = torch.device(device)
+    parts = []
+    for c in range((A_total + CHUNK_AMPLICONS - 1) // CHUNK_AMPLICONS):
+        A = min(CHUNK_AMPLICONS, A_total - c * CHUNK_AMPLICONS)
+        parts.append(torch.randint(0, 4, (A * READ_LEN,), generator=_chunk_generator(seed, c, dev), device=dev, dtype=torch.int64))
+    codes = torch.cat(parts)[:total_loci]
+    fl = torch.randint(0, 4, (2 * flank,), generator=_chunk_generator(seed, -1, dev), device=dev, dtype=torch.int64)
+    return _BASE_ASCII[torch.cat([fl[:flank], codes, fl[flank:]]).cpu().numpy()]
 
 
 def reads_of(p, n_amplicons=None, first_amplicon=None):
@@ -242,3 +261,98 @@ def observations_of(p, n_tiles=None):
     if not pos_out:
         return np.zeros(0, np.int32), np.zeros(0, np.uint32)
     return np.concatenate(pos_out), np.concatenate(tup_out)
+
+
+# ---- BASELINE config 3: SNV + MNV + small indels ---------------------------------------------------------------
+MNV_OFFSET, DEL_OFFSET, INS_OFFSET = 40, 60, 80   # read index of the planted event inside its amplicon
+
+
+def mixed_event_of(a):
+    """The event planted in (global) amplicon `a`: None, or (kind, offset, length, vaf) with kind 'M' (an MNV of 2-3 bases), 'D' (a
+    deletion of 1-10 bases) or 'I' (an insertion of 1-6 bases).  One amplicon in 13 carries each kind: about one MNV, one deletion
+    and one insertion per 1950 loci; every locus keeps the SNVs and errors of make_pileup."""
+    k = a % 13
+    vaf = 0.05 + 0.30 * ((a * 2654435761) % 1000) / 1000.0
+    if k == 3:
+        return ("M", MNV_OFFSET, 2 + a % 2, vaf)
+    if k == 7:
+        return ("D", DEL_OFFSET, 1 + (a * 7) % 10, vaf)
+    if k == 11:
+        return ("I", INS_OFFSET, 1 + (a * 5) % 6, vaf)
+    return None
+
+
+def mixed_reads(p, seed=0):
+    """The reads of pileup `p` (whole amplicons only) with mixed_event_of's events planted: MNV carriers get the variant bases, deletion
+    carriers the CIGAR xM dD yM, insertion carriers xM iI yM (inserted bases at Q37).  Returns (ReadBatch, planted) where planted is a
+    list of (kind, position, ref, alt) in VCF form (anchor base included for insertions / deletions)."""
+    A = p.base.shape[0]
+    _, lens_total = _amplicon_lengths(p.total_loci or (p.first_locus + p.n_loci))
+    base = p.base.cpu().numpy()
+    qual = p.qual.cpu().numpy()
+    ref = p.ref.cpu().numpy()
+    origin = p.flank + 1
+    depth = p.depth
+    rev = (np.arange(depth) % 2).astype(np.uint8)
+    pos_l, flag_l, cop_l, clen_l, ncig_l, seq_l, q_l, slen_l, planted = [], [], [], [], [], [], [], [], []
+    code_of = {ord("A"): 0, ord("G"): 1, ord("C"): 2, ord("T"): 3}
+    for k in range(A):
+        a = p.first_amplicon + k
+        L = lens_total[a]
+        start = origin + a * READ_LEN
+        rows = _BASE_ASCII[base[k, :, :L]]            # (depth, L) ASCII
+        qs = qual[k, :, :L]
+        ev = mixed_event_of(a) if L == READ_LEN else None
+        rng = np.random.default_rng((seed * 1_000_003 + a) % (2 ** 63))
+        carriers = np.zeros(depth, dtype=bool)
+        if ev is not None:
+            carriers = rng.random(depth) < ev[3]
+        refrow = ref[start - p.ref_start: start - p.ref_start + L]
+        if ev is not None and ev[0] == "M":
+            off, n = ev[1], ev[2]
+            alt = _BASE_ASCII[(np.array([code_of[int(c)] for c in refrow[off:off + n]]) + 1 + np.arange(n)) % 4]
+            rows = rows.copy()
+            qs = qs.copy()
+            rows[np.ix_(carriers, np.arange(off, off + n))] = alt
+            qs[np.ix_(carriers, np.arange(off - 1, off + n + 1))] = 37     # clean flanks: the MNV is fully anchored in every carrier
+            planted.append(("M", start + off, bytes(refrow[off:off + n]).decode(), bytes(alt).decode()))
+        if ev is None or ev[0] == "M":
+            pos_l.append(np.full(depth, start, np.int32)); flag_l.append(rev)
+            cop_l.append(np.full(depth, ord("M"), np.uint8)); clen_l.append(np.full(depth, L, np.uint32)); ncig_l.append(np.ones(depth, np.int64))
+            seq_l.append(rows.reshape(-1)); q_l.append(qs.reshape(-1)); slen_l.append(np.full(depth, L, np.int64))
+            continue
+        off, n = ev[1], ev[2]
+        nc = int(carriers.sum())
+        keep = ~carriers
+        # non-carriers: <L>M
+        pos_l.append(np.full(depth, start, np.int32)); flag_l.append(np.concatenate([rev[keep], rev[carriers]]))
+        ops = np.full(int(keep.sum()) + 3 * nc, ord("M"), np.uint8)
+        lens = np.full(int(keep.sum()) + 3 * nc, L, np.uint32)
+        if ev[0] == "D":
+            ops[int(keep.sum()) + 1::3] = ord("D")
+            lens[int(keep.sum())::3] = off; lens[int(keep.sum()) + 1::3] = n; lens[int(keep.sum()) + 2::3] = L - off - n
+            crow = np.concatenate([rows[carriers][:, :off], rows[carriers][:, off + n:]], axis=1)
+            cq = np.concatenate([qs[carriers][:, :off], qs[carriers][:, off + n:]], axis=1)
+            cq[:, off - 1:off + 1] = 37                                     # both flanks pass CheckDeletionQuality
+            planted.append(("D", start + off - 1, bytes(refrow[off - 1:off + n]).decode(), chr(refrow[off - 1])))
+            clen = L - n
+        else:
+            ops[int(keep.sum()) + 1::3] = ord("I")
+            lens[int(keep.sum())::3] = off; lens[int(keep.sum()) + 1::3] = n; lens[int(keep.sum()) + 2::3] = L - off
+            ins = _BASE_ASCII[rng.integers(0, 4, n)]
+            crow = np.concatenate([rows[carriers][:, :off], np.tile(ins, (nc, 1)), rows[carriers][:, off:]], axis=1)
+            cq = np.concatenate([qs[carriers][:, :off], np.full((nc, n), 37, np.uint8), qs[carriers][:, off:]], axis=1)
+            planted.append(("I", start + off - 1, chr(refrow[off - 1]), chr(refrow[off - 1]) + bytes(ins).decode()))
+            clen = L + n
+        cop_l.append(ops); clen_l.append(lens)
+        ncig_l.append(np.concatenate([np.ones(int(keep.sum()), np.int64), np.full(nc, 3, np.int64)]))
+        seq_l.append(np.concatenate([rows[keep].reshape(-1), crow.reshape(-1)]))
+        q_l.append(np.concatenate([qs[keep].reshape(-1), cq.reshape(-1)]))
+        slen_l.append(np.concatenate([np.full(int(keep.sum()), L, np.int64), np.full(nc, clen, np.int64)]))
+    ncig = np.concatenate(ncig_l)
+    slen = np.concatenate(slen_l)
+    batch = _abi.ReadBatch.from_arrays(
+        position=np.concatenate(pos_l), flags=np.concatenate(flag_l), cigar_offset=np.concatenate([[0], np.cumsum(ncig)]).astype(np.int32),
+        cigar_op=np.concatenate(cop_l), cigar_len=np.concatenate(clen_l), seq_offset=np.concatenate([[0], np.cumsum(slen)]).astype(np.int32),
+        bases=np.concatenate(seq_l), quals=np.concatenate(q_l))
+    return batch, planted

@@ -379,9 +379,12 @@ def test_full_size_properties_config2(torch_cuda):
 @pytest.mark.parametrize("n_loci,depth,synth_kw,cfg_kw", [
     (1_000_000, 2000, {}, {}),                                                             # BASELINE config 3 size (SNV-only pileup)
     (3_750_000, 200, {}, {}),                                                              # config 4: one GPU's eighth of 30 M loci x 200x
-    (100_000, 5000, dict(vaf_range=(0.005, 0.005)),                                        # config 5: 0.5 % VAF at 5000x, gVCF, filters on
-     dict(min_frequency=0.002, variant_freq_filter=0.002, noise_level=35)),                 # -nl 35: 25 of 5000 reads stand out of 1.6 expected errors
-], ids=["config3_1Mx2000", "config4_shard_3.75Mx200", "config5_100kx5000_lowvaf"])
+    (100_000, 5000, dict(vaf_range=(0.005, 0.005)),                                        # 0.5 % VAF at 5000x, gVCF, filters on, with a noise level
+     dict(min_frequency=0.002, variant_freq_filter=0.002, noise_level=35)),                 # (-nl 35) at which every planted variant stands out
+    (100_000, 5000, dict(vaf_range=(0.005, 0.005), snv_every=50, snv_offset=17, q_lo=12),  # BASELINE config 5 as SURVEY 8d states it: -minbq 30 => NL 30,
+     dict(min_base_call_quality=30, noise_level=30, min_frequency=0.005, variant_freq_filter=0.005,   # -minvf 0.005, -sbfilter 0.5, -vqfilter 30, gVCF;
+          strand_bias_threshold=0.5, variant_qscore_filter=30)),                                     # 25 expected reads per site: about half clear 0.5 %
+], ids=["config3_1Mx2000", "config4_shard_3.75Mx200", "config5_100kx5000_lowvaf_nl35", "config5_100kx5000_as_stated"])
 def test_full_size_properties_other_baseline_configs(torch_cuda, n_loci, depth, synth_kw, cfg_kw):
     """The other BASELINE sizes through size-independent properties: idempotence (the same launch twice, byte for byte), exact depth at
     every locus, one candidate locus per locus, sortedness, planted low-frequency variants found, and the first 640 loci against the oracle."""
@@ -401,7 +404,9 @@ def test_full_size_properties_other_baseline_configs(torch_cuda, n_loci, depth, 
     cats = (got["info"] >> 4) & 7
     n_planted = len(p.planted)
     found = np.isin(got["position"][cats == _abi.CAT_SNV] - p.region_start, p.planted.cpu().numpy() if hasattr(p.planted, "cpu") else p.planted)
-    assert found.sum() >= 0.9 * n_planted, (int(found.sum()), n_planted)
+    # at exactly 0.5 % VAF against a 0.5 % emit threshold a planted site is called when its sampled support reaches the threshold: about half
+    min_found = 0.3 if cfg_kw.get("min_frequency", 0) >= 0.005 else 0.9
+    assert found.sum() >= min_found * n_planted, (int(found.sum()), n_planted)
     n_t = 10
     pos, tup = synth.observations_of(p, n_t)
     exp, _ = orc.run_observations(pos, tup, p.ref.cpu().numpy(), p.region_start, n_t * 64, cfg)
@@ -732,7 +737,7 @@ def test_flush_into_a_buffer_that_is_too_small_is_repeatable(torch_cuda):
             c.AddAlleleCounts(reads)
         for up_to in (p.region_start + 1500, None):
             want = a.Call(up_to, capacity=1 << 16)
-            assert len(want) > 900
+            assert len(want) > 500
             n = C.c_int64(0)
             small = np.zeros(10, dtype=_abi.CALLED_ALLELE_DTYPE)
             for cap in (0, 10, len(want) - 1):
@@ -743,6 +748,67 @@ def test_flush_into_a_buffer_that_is_too_small_is_repeatable(torch_cuda):
             assert rc == 0 and n.value == len(want)
             assert out.tobytes() == want.tobytes()
         assert a.Stats() == b.Stats()
+
+
+@pytest.mark.parametrize("n_loci,depth", [(1_000_000, 2000)], ids=["config3_1Mx2000_snv_mnv_indel"])
+def test_full_size_config3_mix_through_the_streaming_surface(torch_cuda, n_loci, depth):
+    """BASELINE config 3 with its real mix at full size: 1 M loci x 2000x, SNVs + MNVs (2-3 bases) + deletions (1-10) + insertions
+    (1-6), MNV calling on (-callmnvs true -maxmnvlength 3 -maxgapbetweenmnv 1), reads walked, candidates found (find_emit_kernel),
+    collapsed, reallocated and called through pisces_hip_add_reads / pisces_hip_flush.  Properties over the whole run: sorted output,
+    exact depth at every point record, every planted MNV / deletion / insertion called at its position, reads counted once; and the
+    first two blocks, flushed block by block as SmallVariantCaller does, against the oracle running the same schedule (records and
+    allele strings)."""
+    from pisces_amd import engine, synth
+    seed, chunk = 33, 200
+    cfg = _abi.default_config(call_mnvs=1, max_mnv_length=3, max_gap_between_mnv=1)
+    n_amp = n_loci // synth.READ_LEN
+    n_loci = n_amp * synth.READ_LEN
+    ref = synth.reference_of(n_loci, seed, device="cuda")
+    origin = synth.READ_LEN + 1
+    recs, planted, n_reads = [], [], 0
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(ref)
+        # the first 14 amplicons (2100 loci) block by block, against the oracle
+        p = synth.make_pileup(14 * synth.READ_LEN, depth, seed=seed, device="cuda", first_locus=0, total_loci=n_loci, with_tuples=False)
+        batch, pl = synth.mixed_reads(p, seed)
+        planted += pl
+        n_reads += batch.n_reads
+        c.AddAlleleCounts(batch)
+        head, head_alleles = [], []
+        for up_to in (1000, 2000):
+            r, a = c.CallWithAlleles(up_to, capacity=1 << 14)
+            head.append(r)
+            head_alleles += a
+        head = np.concatenate(head)
+        exp, exp_alleles, _ = orc.run_reads_blocks(batch, ref, 1, 2100 + origin, cfg)
+        keep = exp["position"] <= 2000
+        assert int(keep.sum()) == len(head) > 1800
+        assert head_alleles == [x for x, k in zip(exp_alleles, keep) if k]
+        assert_records_match(head, exp[keep])
+        recs.append(head)
+        for a0 in range(14, n_amp, chunk):
+            na = min(chunk, n_amp - a0)
+            p = synth.make_pileup(na * synth.READ_LEN, depth, seed=seed, device="cuda", first_locus=a0 * synth.READ_LEN, total_loci=n_loci,
+                                  with_tuples=False)
+            batch, pl = synth.mixed_reads(p, seed)
+            planted += pl
+            n_reads += batch.n_reads
+            c.AddAlleleCounts(batch)
+            recs.append(c.Call(origin + a0 * synth.READ_LEN - 1, capacity=1 << 19))
+            del p, batch
+        recs.append(c.Call(None, capacity=1 << 19))
+        stats = c.Stats()
+    got = np.concatenate(recs)
+    assert stats["reads"] == n_reads
+    assert (np.diff(got["position"]) >= 0).all()
+    cats = (got["info"] >> 4) & 7
+    point = (cats == _abi.CAT_SNV) | (cats == _abi.CAT_REFERENCE)
+    assert ((got["total_coverage"] + got["num_no_calls"])[point] == depth).all()
+    assert len(np.unique(got["position"])) == n_loci   # every locus of the region is a candidate locus
+    for kind, cat in (("M", _abi.CAT_MNV), ("D", _abi.CAT_DELETION), ("I", _abi.CAT_INSERTION)):
+        want = np.array(sorted(pos for k, pos, _, _ in planted if k == kind))
+        have = np.unique(got["position"][cats == cat])
+        assert len(want) > 400 and np.isin(want, have).mean() >= 0.99, (kind, len(want), int(np.isin(want, have).sum()))
 
 
 def test_streaming_surface_equals_device_resident_surface_at_size(torch_cuda):
