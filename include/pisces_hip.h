@@ -484,6 +484,24 @@ int64_t pisces_hip_bgzf_scan(const uint8_t* file, int64_t n_bytes, PiscesBgzfBlo
 int32_t pisces_hip_bgzf_inflate(PiscesHip* h, const uint8_t* file, int64_t n_bytes, const PiscesBgzfBlock* blocks, int64_t n_blocks,
                                 uint8_t* out, int64_t out_capacity, int32_t check_crc, float* kernel_ms);
 
+/* ---- BAM records cut on the device (the rest of row f4): the compressed file is the only thing that crosses PCIe --------------------
+ * pisces_hip_bam_decode: the BGZF blocks of `file` are inflated into HBM (as above, without the copy back), the BAM record chain is cut
+ * there (no serial pass: every byte offset of a 32 KiB chunk is tried as a record start and pointer jumping finds where each chain
+ * leaves the chunk), AlignmentSource.ShouldSkipRead (src/exe/Pisces/Logic/Alignment/AlignmentsSource.cs:84-92: unmapped, secondary,
+ * optionally improper pairs and duplicates, MAPQ below the minimum, no CIGAR) drops what the reference drops, and the alignments of
+ * reference sequence `ref_id` are decoded into the PiscesReadBatch arrays in device memory, in file order — what BamReader.GetNextAlignment
+ * (src/lib/Alignment.IO/BamReader.cs:137) + Read's constructor do per record on the host.  counts = {reads kept, reads of the chromosome
+ * skipped, CIGAR operations, bases}.  Records longer than 32 KiB (long reads) are reported as a broken chain.
+ * pisces_hip_bam_fetch: the decoded batch to host arrays sized from `counts` (any pointer may be NULL) — for inspection and tests.
+ * pisces_hip_add_decoded_reads: pisces_hip_add_reads for the decoded batch without its bases and qualities leaving the device: the
+ * host reads back positions and CIGARs only (for the block bookkeeping), the read walk and the candidate discovery run where the
+ * bases are. */
+int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes, const PiscesBgzfBlock* blocks, int64_t n_blocks, int32_t ref_id,
+                              int32_t min_map_quality, int32_t skip_duplicates, int32_t only_proper_pairs, int64_t counts[4]);
+int32_t pisces_hip_bam_fetch(PiscesHip* h, int32_t* position, uint8_t* flags, int32_t* cigar_offset, uint8_t* cigar_op, uint32_t* cigar_len,
+                             int32_t* seq_offset, uint8_t* bases, uint8_t* quals);
+int32_t pisces_hip_add_decoded_reads(PiscesHip* h);
+
 #ifdef __cplusplus
 }
 #endif

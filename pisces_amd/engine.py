@@ -283,6 +283,32 @@ class HipVariantCaller:
                                                     1 if check_crc else 0, C.byref(ms)))
         return out[:total].tobytes(), blocks, ms.value
 
+    def bam_decode(self, file_bytes, ref_id, min_map_quality=1, skip_duplicates=True, only_proper_pairs=False):
+        """Row f4: a BAM file (bytes) inflated and cut into records on the device; the alignments of reference sequence `ref_id` that
+        AlignmentSource.ShouldSkipRead keeps become a device-resident read batch.  Returns {reads, skipped, cigar_ops, bases}."""
+        data = np.frombuffer(bytes(file_bytes), dtype=np.uint8)
+        blocks, _ = bgzf_scan(data)
+        counts = (C.c_int64 * 4)()
+        _check(self._h, lib.pisces_hip_bam_decode(self._h, data.ctypes.data, data.size, blocks, len(blocks), int(ref_id), int(min_map_quality),
+                                                  int(bool(skip_duplicates)), int(bool(only_proper_pairs)), counts))
+        self._bam_counts = {"reads": counts[0], "skipped": counts[1], "cigar_ops": counts[2], "bases": counts[3]}
+        return dict(self._bam_counts)
+
+    def bam_fetch(self):
+        """The decoded batch as host arrays (dict with the PiscesReadBatch field names)."""
+        n = self._bam_counts
+        out = {"position": np.zeros(n["reads"], np.int32), "flags": np.zeros(n["reads"], np.uint8),
+               "cigar_offset": np.zeros(n["reads"] + 1, np.int32), "cigar_op": np.zeros(n["cigar_ops"], np.uint8),
+               "cigar_len": np.zeros(n["cigar_ops"], np.uint32), "seq_offset": np.zeros(n["reads"] + 1, np.int32),
+               "bases": np.zeros(n["bases"], np.uint8), "quals": np.zeros(n["bases"], np.uint8)}
+        _check(self._h, lib.pisces_hip_bam_fetch(self._h, *[out[k].ctypes.data for k in ("position", "flags", "cigar_offset", "cigar_op",
+                                                                                       "cigar_len", "seq_offset", "bases", "quals")]))
+        return out
+
+    def AddDecodedReads(self):
+        """AddAlleleCounts + FindCandidates for the batch bam_decode left on the device (bases and qualities never come back)."""
+        _check(self._h, lib.pisces_hip_add_decoded_reads(self._h))
+
 
 def anchor_adjusted_count(c, minAnchor=0, maxAnchor=None, fromEnd=False, symmetric=False):
     """AlleleCountHelper.GetAnchorAdjustedAlleleCount (AlleleCountHelper.cs:21-85) over one [11] anchor row."""

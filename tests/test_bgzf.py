@@ -161,3 +161,95 @@ def test_device_inflate_survives_corrupted_streams():
         got, _, _ = c.bgzf_inflate(base[0])
         assert got == text
     assert errors > 250 and errors + same == 300
+
+
+# ---------------------------------------------------------------- BAM records cut on the device (rest of row f4)
+def _bam_reads_reference(file_bytes):
+    """The reads of a BAM file by a plain host reader (the minimal BGZF / BAM reader of tests/golden/extract_bam_fixture.py)."""
+    import importlib.util
+    import tempfile
+    spec = importlib.util.spec_from_file_location("extract_bam_fixture", os.path.join(os.path.dirname(__file__), "golden", "extract_bam_fixture.py"))
+    xb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(xb)
+    with tempfile.NamedTemporaryFile(suffix=".bam") as f:
+        f.write(bytes(file_bytes))
+        f.flush()
+        return xb.read_bam(f.name)
+
+
+def _kept(reads, chrom, min_mapq=1, skip_dups=True):
+    """AlignmentSource.ShouldSkipRead (AlignmentsSource.cs:84-92) as extract_bam_fixture.extract applies it"""
+    keep = []
+    for r in reads:
+        if r["ref"] != chrom:
+            continue
+        if (r["flag"] & 0x4) or (r["flag"] & 0x100) or (skip_dups and (r["flag"] & 0x400)) or r["mapq"] < min_mapq or not r["cigar"]:
+            continue
+        keep.append(r)
+    return keep
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,chrom", [("PhiX_S3", "phix"), ("Sample_S1", "chr19"), ("small_S1", "chr1"), ("Ins_L3_var12_S12", None)])
+def test_bam_records_are_cut_on_the_device(name, chrom):
+    """pisces_hip_bam_decode on four BAM files of the reference's tests: the device-built read batch (record chain cut by pointer
+    jumping, ShouldSkipRead, 4-bit bases / CIGAR words / qualities decoded by bam_decode_kernel) equals, array by array, what a
+    plain host reader makes of the same bytes, for every reference sequence of the file and for two filter settings."""
+    import torch
+    assert torch.cuda.is_available()
+    from pisces_amd import engine
+    data = _FIXTURES[name]
+    refs, reads = _bam_reads_reference(data)
+    chroms = [chrom] if chrom else sorted({r["ref"] for r in reads if r["ref"] is not None})[:3]
+    n_checked = 0
+    with engine.HipVariantCaller(_abi.default_config()) as c:
+        for ch in chroms:
+            for min_mapq, skip_dups in ((1, True), (0, False)):
+                keep = _kept(reads, ch, min_mapq, skip_dups)
+                counts = c.bam_decode(data, refs.index(ch), min_mapq, skip_dups)
+                assert counts["reads"] == len(keep)
+                assert counts["reads"] + counts["skipped"] == sum(1 for r in reads if r["ref"] == ch)
+                got = c.bam_fetch()
+                np.testing.assert_array_equal(got["position"], np.array([r["pos"] for r in keep], np.int32))
+                np.testing.assert_array_equal(got["flags"], np.array([1 if r["flag"] & 0x10 else 0 for r in keep], np.uint8))
+                ops = [(ord(o), l) for r in keep for o, l in r["cigar"]]
+                np.testing.assert_array_equal(got["cigar_op"], np.array([o for o, _ in ops], np.uint8))
+                np.testing.assert_array_equal(got["cigar_len"], np.array([l for _, l in ops], np.uint32))
+                np.testing.assert_array_equal(got["cigar_offset"], np.cumsum([0] + [len(r["cigar"]) for r in keep]).astype(np.int32))
+                np.testing.assert_array_equal(got["seq_offset"], np.cumsum([0] + [len(r["seq"]) for r in keep]).astype(np.int32))
+                assert got["bases"].tobytes() == "".join(r["seq"] for r in keep).encode()
+                assert got["quals"].tobytes() == b"".join(r["qual"].tobytes() for r in keep)
+                n_checked += len(keep)
+    assert n_checked > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,bam", [("bam_phix", "PhiX_S3"), ("bam_small_s1", "small_S1")])
+def test_bam_bytes_to_vcf_rows_without_the_reads_leaving_the_device(name, bam):
+    """The whole upstream path on the device: compressed BAM bytes in (the only bulk PCIe traffic), BGZF inflate, records cut and
+    decoded, read walk + candidate discovery straight from the decoded batch (pisces_hip_add_decoded_reads), calls, VCF text — the
+    body lines Pisces wrote for these BAMs, and the records of the host-fed path on the same reads."""
+    import torch
+    assert torch.cuda.is_available()
+    from pisces_amd import engine
+    from tests import bam_fixtures
+    case = bam_fixtures.CASES[name]
+    z, batch = bam_fixtures.load(name)
+    assert int(z["offset"]) == 0
+    data = _FIXTURES[bam]
+    refs, _ = _bam_reads_reference(data)
+    cfg = _abi.default_config(**case["cfg"])
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(z["ref"])
+        counts = c.bam_decode(data, refs.index(case["chrom"]))
+        assert counts["reads"] == batch.n_reads
+        c.AddDecodedReads()
+        got, got_alleles = c.CallWithAlleles()
+        stats = c.Stats()
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(z["ref"])
+        c.AddAlleleCounts(batch)
+        want, want_alleles = c.CallWithAlleles()
+    assert got.tobytes() == want.tobytes() and got_alleles == want_alleles and stats["reads"] == batch.n_reads
+    text = engine.format_vcf(case["chrom"], got, alleles=got_alleles, noise_level_from_records=1, **case["vcf"])
+    bam_fixtures.check_lines(case, text.rstrip("\n").split("\n") if text else [], [str(x) for x in z["expected_vcf"]])
