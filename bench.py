@@ -131,9 +131,9 @@ def end_to_end(pileup, cfg, engine, loci=30_000):
         batches = [(a0, synth.reads_of(pileup, min(per_call, n_amp - a0), first_amplicon=pileup.first_amplicon + a0)) for a0 in range(0, n_amp, per_call)]
         n_loci = min(pileup.n_loci, n_amp * synth.READ_LEN)
         best = None
-        for rep in range(3):   # the first pass of a handle pays for its pinned staging buffers
-            with engine.HipVariantCaller(cfg) as c:
-                c.SetReference(ref)
+        with engine.HipVariantCaller(cfg) as c:   # one handle, as one (BAM, chromosome) job has: the first pass pays for its pinned staging
+            c.SetReference(ref)                    # and device buffers (grow-only), the later ones are the steady state
+            for rep in range(4):
                 n_rec = 0
                 t0 = time.perf_counter()
                 for a0, b in batches:
@@ -141,10 +141,11 @@ def end_to_end(pileup, cfg, engine, loci=30_000):
                     n_rec += len(c.Call(pileup.region_start + a0 * synth.READ_LEN - 1, capacity=1 << 18))   # LastClearedPosition
                 n_rec += len(c.Call(None, capacity=1 << 18))
                 dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
+                if rep > 0:
+                    best = dt if best is None else min(best, dt)
         out[label] = {"value": n_loci / best, "unit": "candidate loci/s", "seconds": best, "loci": n_loci, "records": n_rec,
                       "add_reads_flush_pairs": len(batches), "reads": int(sum(b.n_reads for _, b in batches))}
-    out["scope"] = "host read buffers -> pisces_hip_add_reads -> pisces_hip_flush -> host records (PCIe both ways, best of 3 handles)"
+    out["scope"] = "host read buffers -> pisces_hip_add_reads -> pisces_hip_flush -> host records (PCIe both ways; one handle, best of 3 passes after a warm-up pass)"
     return out
 
 

@@ -155,6 +155,8 @@ struct PiscesHip {
     std::vector<HostCandidate> pending_cands;       // called insertion / deletion candidates (their allele strings)
     std::vector<int32_t> pending_keys;
     int64_t pending_called = 0;
+    bool pending_dropped = false;            // the flushed blocks' log entries are already gone from the other log buffer (kept entries there)
+    unsigned long long pending_kept = 0;
     int64_t pending_collapsed = 0;
 
     // observation log on the device: (position, tuple) of every allele-count increment of the blocks not yet flushed,
@@ -180,7 +182,9 @@ struct PiscesHip {
     uint8_t* h_stage = nullptr;              // = stage[stage_cur].h after stage_reserve
     DeviceBuf<uint8_t> d_stage_alias;        // unused placeholder (kept empty)
     DeviceBuf<int32_t> d_bucket;             // BucketMap tables
-    std::vector<int32_t> bucket_host;
+    std::vector<int32_t> bucket_host[4];
+    int bucket_host_next = 0;
+    uint64_t uploads_since_sync = 0;
     uint8_t* h_dl = nullptr;                 // pinned download buffer of flush
     size_t h_dl_cap = 0;
     DeviceBuf<unsigned int> d_tile_cnt;
@@ -1197,8 +1201,10 @@ static int32_t upload_bucket_map(PiscesHip* h, const std::vector<int32_t>& keys,
 {
     const int32_t kmin = keys.front(), kmax = keys.back();
     const size_t n_slot = (size_t)(kmax - kmin + 1);
-    std::vector<int32_t>& host = h->bucket_host;   // member: alive until the copy below has been consumed
-    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // ... and not rewritten while an earlier copy is still in flight
+    // the source of an asynchronous copy must stay untouched until the copy has left: a flush uploads at most three maps before its
+    // one synchronisation, so a ring of four staging vectors never rewrites one that is still in flight
+    std::vector<int32_t>& host = h->bucket_host[h->bucket_host_next];
+    h->bucket_host_next = (h->bucket_host_next + 1) % 4;
     host.assign(n_slot + keys.size() + tol.size(), -1);
     for (size_t i = 0; i < keys.size(); i++) host[(size_t)(keys[i] - kmin)] = (int32_t)i;
     std::copy(first_tile.begin(), first_tile.end(), host.begin() + (std::ptrdiff_t)n_slot);
@@ -1251,10 +1257,11 @@ static int32_t bucket_blocks(PiscesHip* h, const std::vector<int32_t>& keys, boo
     return PISCES_OK;   // everything else of the handle is ordered behind this on h->stream
 }
 
-// DoneProcessing for the observation log: the entries of `keys` leave, the rest moves to the other log buffer
-static int32_t drop_blocks(PiscesHip* h, const std::vector<int32_t>& keys)
+// DoneProcessing for the observation log: the entries of `keys` leave, the rest moves to the OTHER log buffer.  enqueue_drop only
+// enqueues (the current log is left as it is, so a flush that has to be repeated loses nothing); commit_drop makes the other buffer
+// the log once the number of entries it kept is known on the host.
+static int32_t enqueue_drop(PiscesHip* h, const std::vector<int32_t>& keys)
 {
-    if (keys.empty() || h->log_ub == 0) return PISCES_OK;
     std::vector<int32_t> first_tile(keys.size(), 0), tol;
     BucketMap m;
     int32_t rc = upload_bucket_map(h, keys, first_tile, tol, &m);
@@ -1266,11 +1273,22 @@ static int32_t drop_blocks(PiscesHip* h, const std::vector<int32_t>& keys)
     hipLaunchKernelGGL(log_drop_kernel, dim3(log_grid(h)), dim3(256), 0, h->stream, h->d_log_pos[c].p, h->d_log_tup[c].p, (long long)h->log_ub,
                        m, h->d_log_pos[o].p, h->d_log_tup[o].p, h->d_log_n.p + o);
     PISCES_HIP_CHECK(h, hipGetLastError());
-    unsigned long long kept = 0;
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(&kept, h->d_log_n.p + o, sizeof(kept), hipMemcpyDeviceToHost, h->stream));
-    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
-    h->log_cur = o;
+    return PISCES_OK;
+}
+static void commit_drop(PiscesHip* h, unsigned long long kept)
+{
+    h->log_cur ^= 1;
     h->log_ub = (int64_t)kept;
+}
+static int32_t drop_blocks(PiscesHip* h, const std::vector<int32_t>& keys)
+{
+    if (keys.empty() || h->log_ub == 0) return PISCES_OK;
+    int32_t rc = enqueue_drop(h, keys);
+    if (rc) return rc;
+    unsigned long long kept = 0;
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(&kept, h->d_log_n.p + (h->log_cur ^ 1), sizeof(kept), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    commit_drop(h, kept);
     return PISCES_OK;
 }
 
@@ -1329,9 +1347,11 @@ static void launch_compaction(hipStream_t s, const PiscesCalledAllele* d_records
 }
 
 // device work of one flush: returns called alleles of `keys` sorted by (position, ref, alt)
-static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::vector<PiscesCalledAllele>& out, int64_t* n_called)
+static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::vector<PiscesCalledAllele>& out, int64_t* n_called,
+                           bool with_drop = false, bool* dropped = nullptr, unsigned long long* kept = nullptr)
 {
     out.clear();   // (*n_called accumulates: the caller zeroes it)
+    if (dropped) *dropped = false;
     if (keys.empty()) return PISCES_OK;
     if (!h->d_ref.p) return fail(h, PISCES_E_STATE, "flush: set_reference has not been called");
     std::vector<PiscesTile> tiles;
@@ -1386,6 +1406,12 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
     int64_t n_loci_total = 0;
     for (auto& t : tiles) n_loci_total += t.n_loci;
     const size_t spec = std::min<size_t>(cap, (size_t)(n_loci_total + n_loci_total / 4 + 64));
+    // DoneProcessing's kernel rides in the same submission (it only writes the OTHER log buffer): one synchronisation per flush
+    const bool drop_now = with_drop && h->log_ub > 0;
+    if (drop_now) {
+        int32_t rcd = enqueue_drop(h, keys);
+        if (rcd) return rcd;
+    }
     const size_t dl_bytes = 16 + cap * sizeof(PiscesCalledAllele);
     if (dl_bytes > h->h_dl_cap) {
         if (h->h_dl) (void)hipHostFree(h->h_dl);
@@ -1397,10 +1423,16 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
     int32_t* hdr = (int32_t*)h->h_dl;
     PiscesCalledAllele* hrec = (PiscesCalledAllele*)(h->h_dl + 16);
     PISCES_HIP_CHECK(h, hipMemcpyAsync(hdr, h->d_count.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    if (drop_now)
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(hdr + 2, h->d_log_n.p + (h->log_cur ^ 1), sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipMemcpyAsync(hrec, h->d_compact.p, spec * sizeof(PiscesCalledAllele), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     const int32_t total = hdr[0];
     *n_called += hdr[1];
+    if (drop_now) {
+        if (dropped) *dropped = true;
+        if (kept) std::memcpy(kept, hdr + 2, sizeof(unsigned long long));
+    }
     if ((size_t)total > spec) {
         PISCES_HIP_CHECK(h, hipMemcpyAsync(hrec + spec, h->d_compact.p + spec, ((size_t)total - spec) * sizeof(PiscesCalledAllele),
                                            hipMemcpyDeviceToHost, h->stream));
@@ -1963,7 +1995,8 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
         int32_t rc = call_spanning(h, keys, span_recs, span_cands, &called, &collapsed, ref_overrides);
         h->pending_collapsed = collapsed;
         if (rc) return rc;
-        rc = call_blocks(h, keys, point_recs, &called);
+        h->pending_dropped = false;
+        rc = call_blocks(h, keys, point_recs, &called, true, &h->pending_dropped, &h->pending_kept);
         if (rc) return rc;
         if (!ref_overrides.empty()) {   // Reference alleles that MNV reallocation added support to
             std::map<int32_t, const PiscesCalledAllele*> by_pos;
@@ -2082,8 +2115,12 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
         }
     }
     *n_out = (int64_t)h->pending.size();
-    // DoneProcessing (RegionStateManager.cs:336-353)
-    {
+    // DoneProcessing (RegionStateManager.cs:336-353): the log entries of the flushed blocks left with call_blocks' submission when
+    // there was one; what remains is to make that buffer the log
+    if (h->pending_dropped) {
+        commit_drop(h, h->pending_kept);
+        h->pending_dropped = false;
+    } else {
         int32_t rcd = drop_blocks(h, h->pending_keys);
         if (rcd) return rcd;
     }

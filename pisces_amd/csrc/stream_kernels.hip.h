@@ -233,7 +233,10 @@ __device__ __forceinline__ int32_t bucket_tile_of(const BucketMap& m, int32_t po
 // so counts and fill cursors are privatized in LDS over the tile range [tmin, tmin + kLocalTiles) of the chunk and the
 // global counters see one atomic per (workgroup, tile) instead of one per entry or per wave (same-address global atomics
 // across XCDs serialize at ~0.1-0.2 us each on this part).
-constexpr int kLogChunk = 4096;
+#ifndef PISCES_LOG_CHUNK
+#define PISCES_LOG_CHUNK 4096
+#endif
+constexpr int kLogChunk = PISCES_LOG_CHUNK;
 constexpr int kLogPerThread = kLogChunk / 256;
 constexpr int kLocalTiles = 1024;
 
