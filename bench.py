@@ -200,7 +200,8 @@ def main():
     first_locus, my_loci = own_lo - origin, own_hi - own_lo + 1
 
     # ---- inputs, resident in HBM: RING_BATCHES distinct pileups of the whole set, this rank making only its own shard of each ----
-    ring = [synth.make_pileup(my_loci, args.depth, seed=BASE_SEED + b, device=dev, first_locus=first_locus, total_loci=total_loci)
+    tile_loci = caller.balanced_tile_loci(my_loci)   # every CU gets the same number of tiles (100 000 loci: 56 -> 1786 tiles, 7 per CU)
+    ring = [synth.make_pileup(my_loci, args.depth, seed=BASE_SEED + b, device=dev, first_locus=first_locus, total_loci=total_loci, tile=tile_loci)
             for b in range(RING_BATCHES)]
     for p in ring:
         p.base = p.base if p is ring[0] else None   # keep the read matrices of batch 0 only (CPU baseline / end-to-end sample)
@@ -365,7 +366,7 @@ def main():
             "config": {"workload": f"BASELINE config 2: synthetic {args.loci} loci x {args.depth}x amplicon pileup, SNV-only, "
                                    "gVCF, per GPU per step; device-resident packed tuples",
                        "loci_per_gpu_per_step": args.loci, "depth": args.depth, "observations_per_step": int(n_obs),
-                       "records_per_step": rec_per_launch, "ring_batches": RING_BATCHES,
+                       "records_per_step": rec_per_launch, "ring_batches": RING_BATCHES, "tile_loci": tile_loci, "tiles_per_step": n_tiles,
                        "interval_set": {"loci": total_loci, "intervals": len(intervals), "rank0_shard": [int(own_lo), int(own_hi)]},
                        "parallelism": f"interval-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -340,6 +340,10 @@ int32_t pisces_hip_comm_destroy(PiscesHip* h);
  * d_records needs record_capacity >= 256 * n_tiles slots (PiscesTileResult explains the slot layout: no
  * allocation atomics, placement independent of scheduling); d_tile_results[n_tiles] is the directory.
  * Asynchronous; launches of one handle must be stream-ordered with respect to each other. */
+/* The tile size (<= 64 loci) at which a launch over n_loci contiguous loci loads every CU of the handle's device equally: a launch
+ * that is resident at once ends with the CU that holds the most tiles (100 000 loci: 56, i.e. 1786 tiles = 7 per CU, instead of 1563
+ * tiles of 64 = 6 or 7 per CU).  64 for launches of many rounds.  A hint for whoever buckets tuples by tile. */
+int32_t pisces_hip_balanced_tile_loci(PiscesHip* h, int64_t n_loci);
 int32_t pisces_hip_call_tiles(PiscesHip* h, const uint32_t* d_tuples, const PiscesTile* d_tiles,
                               int32_t n_tiles, const uint8_t* d_ref_bases, int32_t ref_start_position,
                               int64_t ref_length, PiscesCalledAllele* d_records, int32_t record_capacity,

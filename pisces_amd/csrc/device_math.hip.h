@@ -327,7 +327,7 @@ __device__ __forceinline__ bool poisson_qscore_try(int32_t callCount, int32_t co
 {
     if ((callCount <= 0) || (coverage <= 0)) { vq = 0; return true; }
     if (P.vq_tab && callCount < P.vq_tab_k && coverage < P.tab_cov) {
-        vq = P.vq_tab[(size_t)callCount * (size_t)P.tab_cov + (size_t)coverage];
+        vq = P.vq_tab[(uint32_t)callCount * (uint32_t)P.tab_cov + (uint32_t)coverage];   // (tables hold < 2^31 entries: 32-bit index arithmetic)
         return true;
     }
     const double lambda = P.err_q * coverage;
@@ -580,7 +580,7 @@ __device__ __forceinline__ bool sb_stats_try(int32_t support, int32_t coverage, 
         return true;
     }
     if (P.sb_tab && support > 0 && support < P.sb_tab_k && coverage >= 0 && coverage < P.tab_cov) {
-        st.var_gt_zero = P.sb_tab[(size_t)support * (size_t)P.tab_cov + (size_t)coverage];
+        st.var_gt_zero = P.sb_tab[(uint32_t)support * (uint32_t)P.tab_cov + (uint32_t)coverage];
     } else {
         // poisson_cdf_sb's proof of "exactly 1.0" with ln(a / x) bounded from below without the division
         const double a = (double)support, x = (double)coverage * P.err_sb;

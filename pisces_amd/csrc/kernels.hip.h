@@ -693,7 +693,9 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
     {
         // single-round launches (NW = 2): streaming waves win the issue arbitration over waves in their call phase — the launch
         // ends with the slowest tile, and a tile that is still streaming has its whole call phase ahead of it
+#ifndef PISCES_NO_PRIO
         if (NW == 2) __builtin_amdgcn_s_setprio(3);
+#endif
         const uint32_t min_bq_shifted = (uint32_t)min(max(P.min_bq, 0), 255) << 24;
 #if defined(PISCES_ABLATE) && PISCES_ABLATE == 2
         uint32_t acc = 0;   // development ablation: loads only

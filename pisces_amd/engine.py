@@ -225,6 +225,10 @@ class HipVariantCaller:
         _check(self._h, lib.pisces_hip_call_tiles(self._h, d_tuples, d_tiles, n_tiles, d_ref, ref_start, ref_len,
                                                   d_records, capacity, d_tile_results, stream))
 
+    def balanced_tile_loci(self, n_loci):
+        """Tile size (<= 64) that gives every CU the same number of tiles for a launch over n_loci loci (pisces_hip_balanced_tile_loci)."""
+        return int(lib.pisces_hip_balanced_tile_loci(self._h, int(n_loci)))
+
     def call_tiles_batched(self, batches, stream=None):
         """pisces_hip_call_tiles_batched: batches = list of (d_tuples, d_tiles, n_tiles, d_ref, ref_start, ref_len, d_records, capacity,
         d_tile_results) with per-batch output buffers; spread over the handle's lanes.  Waits for `stream` first when given; the outputs

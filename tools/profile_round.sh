@@ -1,28 +1,53 @@
 #!/bin/bash
-# Collects what profiles/ holds for a round, on the GPU box:  bash tools/profile_round.sh r01
-# (1) un-profiled bench line, (2) rocprofv3 kernel-trace stats of the same command, (3) PMC HBM traffic in separate passes.
+# Collects what profiles/ holds for a round, on the GPU box:  bash tools/profile_round.sh r02
+# (1) un-profiled bench line, (2) rocprofv3 kernel-trace stats of the same command, (3) PMC HBM traffic in separate passes (counters
+# restricted to the hot kernel: the synthetic generator's thousands of small torch kernels are not instrumented), (4) SQ / LDS counters
+# of the hot kernel, (5) the streaming surface's and the BGZF / BAM kernels' statistics and counters.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $REPO
-timeout 600 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
-tail -1 $OUT/bench_n1.json
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python bench.py --no-cpu-baseline --no-pipelined --no-shard-check > $OUT/bench_prof.log 2>&1
+PROF_FLAGS="--no-cpu-baseline --no-pipelined --no-shard-check"
+timeout 900 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
+tail -1 $OUT/bench_n1.json | cut -c1-400
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python bench.py $PROF_FLAGS > $OUT/bench_prof.log 2>&1
 find /tmp/prof_$TAG -name "*kernel_stats.csv" -exec cp {} $OUT/bench_kernel_stats.csv \;
-for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $C --kernel-trace --kernel-include-regex call_tiles --output-format csv -d /tmp/pmc_${TAG}_$C -o pmc -- python bench.py --no-cpu-baseline --no-pipelined --no-shard-check --steps 12 --warmup 2 > $OUT/pmc_$C.log 2>&1
-  f=$(find /tmp/pmc_${TAG}_$C -name "*counter_collection.csv" | head -1)
-  python - "$f" $C <<'PY' | tee $OUT/pmc_$C.txt
-import sys, csv, collections
+grep call_tiles $OUT/bench_kernel_stats.csv | sed 's/.*)",//'
+pmc() {   # pmc <name> <kernel regex> <counters...> -- <command...>
+  local name=$1 regex=$2; shift 2
+  local counters=()
+  while [ "$1" != "--" ]; do counters+=("$1"); shift; done; shift
+  rm -rf /tmp/pmc_$name
+  timeout 300 rocprofv3 --pmc "${counters[@]}" --kernel-trace --kernel-include-regex "$regex" --output-format csv -d /tmp/pmc_$name -o pmc -- "$@" > $OUT/pmc_$name.log 2>&1
+  f=$(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1)
+  python - "$f" "$regex" <<'PY' | tee $OUT/pmc_$name.txt
+import sys, csv, collections, re
 acc = collections.defaultdict(list)
-for r in csv.DictReader(open(sys.argv[1])):
-    if 'call_tiles' in r['Kernel_Name']:
-        acc[(r['Kernel_Name'][:60], r['Counter_Name'])].append(float(r['Counter_Value']))
-for k, v in acc.items():
+try:
+    for r in csv.DictReader(open(sys.argv[1])):
+        if re.search(sys.argv[2], r['Kernel_Name']):
+            acc[(r['Kernel_Name'].split('(')[0][-60:], r['Counter_Name'])].append(float(r['Counter_Value']))
+except Exception as e:
+    print("no counter file:", e)
+for k, v in sorted(acc.items()):
     print(k[0], k[1], "mean per dispatch", sum(v) / len(v), "n", len(v))
 PY
-done
-head -5 $OUT/bench_kernel_stats.csv
+}
+pmc FETCH_SIZE call_tiles FETCH_SIZE -- python bench.py $PROF_FLAGS --steps 12 --warmup 2
+pmc WRITE_SIZE call_tiles WRITE_SIZE -- python bench.py $PROF_FLAGS --steps 12 --warmup 2
+pmc sq_lds call_tiles SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS -- python bench.py $PROF_FLAGS --steps 12 --warmup 2
+pmc sq_wave call_tiles SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -- python bench.py $PROF_FLAGS --steps 12 --warmup 2
+# streaming surface + device finder + BGZF / BAM kernels
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_stream -o s -- python tools/hostfed_bench.py > $OUT/hostfed.log 2>&1
+find /tmp/prof_${TAG}_stream -name "*kernel_stats.csv" -exec cp {} $OUT/streaming_kernel_stats.csv \;
+grep "host-fed" $OUT/hostfed.log | tail -1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_bam -o s -- python tools/bam_bench.py 400000 > $OUT/bam_bench.log 2>&1
+find /tmp/prof_${TAG}_bam -name "*kernel_stats.csv" -exec cp {} $OUT/bam_kernel_stats.csv \;
+grep "bam decode" $OUT/bam_bench.log | tail -1
+timeout 300 python tools/bgzf_bench.py 256 2>&1 | grep "bgzf inflate" | tee $OUT/bgzf_bench.txt
+pmc bgzf_mem bgzf_inflate FETCH_SIZE -- python tools/bgzf_bench.py 256
+pmc bgzf_sq bgzf_inflate SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -- python tools/bgzf_bench.py 256
+pmc bgzf_lds bgzf_inflate SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -- python tools/bgzf_bench.py 256
