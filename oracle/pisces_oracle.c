@@ -749,6 +749,9 @@ struct OrcState {
     int32_t* cand_tail;
     OrcCandidate* cands;
     int32_t n_cands, cap_cands;
+    /* the block grid of RegionStateManager over the window, when a schedule is run (orc_track_blocks): MaxAlleleEndpoint per block */
+    int32_t block_size, first_block_key, n_blocks, next_block_key, last_up_to_block_key, have_last_up_to;
+    int32_t* max_allele_endpoint;
 };
 
 OrcState* orc_state_create(int32_t start, int32_t n_loci, int32_t min_bq, int32_t num_anchor_types,
@@ -775,6 +778,7 @@ void orc_state_destroy(OrcState* s)
 {
     if (!s) return;
     free(s->counts); free(s->sumq); free(s->gapped); free(s->cand_head); free(s->cand_tail); free(s->cands);
+    free(s->max_allele_endpoint);
     free(s);
 }
 
@@ -945,11 +949,30 @@ static int candidate_equals(const OrcCandidate* a, const OrcCandidate* b)
 }
 
 /* RegionState.AddCandidate :94-174 */
+/* Blocks of block_size positions, block k = [(k-1)*block_size + 1, k*block_size] (RegionStateManager.GetBlockKey :404-407); call before
+ * candidates are added.  Every block of the window counts as existing. */
+void orc_track_blocks(OrcState* s, int32_t block_size)
+{
+    s->block_size = block_size;
+    s->first_block_key = (s->start_position - 1) / block_size + 1;
+    s->n_blocks = (s->start_position + s->n_loci - 2) / block_size + 1 - s->first_block_key + 1;
+    free(s->max_allele_endpoint);
+    s->max_allele_endpoint = (int32_t*)calloc((size_t)s->n_blocks, sizeof(int32_t));
+}
+
 int32_t orc_add_candidate(OrcState* s, const OrcCandidate* c)
 {
     if (c->category == PISCES_CAT_REFERENCE) return PISCES_E_INVALID_ARG;
     if (!in_region(s, c->position)) return PISCES_E_INVALID_ARG;
     int li = c->position - s->start_position;
+    if (s->block_size > 0) {   /* RegionState.UpdateMaxPosition :203-223 (before the merge, for every candidate handed in) */
+        int otherEnd = 0;
+        if (c->category == PISCES_CAT_DELETION) otherEnd = c->position + (int)strlen(c->ref);
+        else if (c->category == PISCES_CAT_INSERTION) otherEnd = c->position + 1;
+        else if (c->category == PISCES_CAT_MNV) otherEnd = c->position + (int)strlen(c->ref) - 1;
+        int32_t* m = &s->max_allele_endpoint[(c->position - 1) / s->block_size + 1 - s->first_block_key];
+        if (otherEnd > *m) *m = otherEnd;
+    }
     for (int i = s->cand_head[li]; i >= 0; i = s->cands[i].next) {
         OrcCandidate* e = &s->cands[i];
         int match = candidate_equals(e, c);
@@ -2076,25 +2099,121 @@ int64_t orc_call_candidates(OrcState* s, const OrcCandidate* list, int64_t n_lis
                                    total_num_called);
 }
 
+/* CandidateBatch of GetCandidatesToProcess (RegionStateManager.cs:283-334) for cleared blocks [first_position, last_position]: their
+ * candidates by position, each position in arrival order (RegionState.GetAllCandidates :388-391; they stay in the state until
+ * DoneProcessing), and with up_to_position >= 0, open-ended tracking on and an allele of those blocks reaching past last_position, the
+ * collapsable SNV / MNV candidates of the blocks that start in (last_position, up_to_position], which leave the state
+ * (AddCollapsableFromOtherBlocks :441-457, RegionState.ExtractCollapsable :470-490).  Returns the count. */
+int32_t orc_batch_candidates(OrcState* s, int32_t first_position, int32_t last_position, int32_t up_to_position, OrcCandidate* out,
+                             int32_t capacity, int32_t* from_other_blocks)
+{
+    int32_t n = 0;
+    if (from_other_blocks) *from_other_blocks = 0;
+    for (int li = 0; li < s->n_loci; li++) {
+        const int position = s->start_position + li;
+        if (position < first_position || position > last_position) continue;
+        for (int i = s->cand_head[li]; i >= 0; i = s->cands[i].next) { if (n < capacity) out[n] = s->cands[i]; n++; }
+    }
+    if (!(up_to_position >= 0 && s->track_open_ended && s->block_size > 0)) return n;
+    int maxEndpoint = 0;   /* blocks.Max(b => b.MaxAlleleEndpoint) :321 */
+    for (int k = (first_position - 1) / s->block_size + 1; k <= (last_position - 1) / s->block_size + 1; k++)
+        if (k >= s->first_block_key && k < s->first_block_key + s->n_blocks && s->max_allele_endpoint[k - s->first_block_key] > maxEndpoint)
+            maxEndpoint = s->max_allele_endpoint[k - s->first_block_key];
+    if (maxEndpoint <= last_position) return n;
+    const int lastOfThose = ((up_to_position - 1) / s->block_size + 1) * s->block_size;   /* end of the block that holds upTo */
+    for (int li = 0; li < s->n_loci; li++) {
+        const int position = s->start_position + li;
+        if (position <= last_position || position > lastOfThose) continue;
+        int prev = -1;
+        for (int i = s->cand_head[li]; i >= 0;) {
+            OrcCandidate* c = &s->cands[i];
+            const int next = c->next;
+            if (c->position + (int)strlen(c->alt) - 1 <= up_to_position && !c->open_right &&
+                (c->category == PISCES_CAT_MNV || c->category == PISCES_CAT_SNV)) {
+                if (n < capacity) out[n] = *c;
+                n++;
+                if (from_other_blocks) *from_other_blocks = 1;
+                if (prev >= 0) s->cands[prev].next = next; else s->cand_head[li] = next;   /* lookup.Remove(collapsable) */
+                if (s->cand_tail[li] == i) s->cand_tail[li] = prev;
+            } else {
+                prev = i;
+            }
+            i = next;
+        }
+    }
+    return n;
+}
+
+/* Which blocks GetCandidatesToProcess(upToPosition) clears (RegionStateManager.cs:283-334; up_to_position < 0 = null, the final batch).
+ * Returns -1: no batch (upTo is still in the block of the previous call); 0: a batch without cleared blocks; 1: blocks
+ * [*first_position, *last_position].  Every block of the window from the first one not yet done counts as existing. */
+int32_t orc_next_batch(OrcState* s, int32_t up_to_position, int32_t* first_position, int32_t* last_position)
+{
+    const int bs = s->block_size;
+    const int final_batch = up_to_position < 0;
+    if (s->next_block_key < s->first_block_key) s->next_block_key = s->first_block_key;
+    if (!final_batch) {
+        const int key = (up_to_position - 1) / bs + 1;   /* GetBlockKey :404-407 */
+        if (s->have_last_up_to && key == s->last_up_to_block_key) return -1;
+        s->last_up_to_block_key = key;
+        s->have_last_up_to = 1;
+    } else {
+        s->have_last_up_to = 0;
+    }
+    int last_key = s->next_block_key - 1;
+    for (int k = s->next_block_key; k < s->first_block_key + s->n_blocks; k++) {
+        if (!final_batch && (int64_t)k * bs > up_to_position) break;                                          /* keys.Where(k * size <= upTo) */
+        if (!final_batch && s->max_allele_endpoint[k - s->first_block_key] > up_to_position) break;          /* a held block, and all after it */
+        last_key = k;
+    }
+    if (last_key < s->next_block_key) return 0;
+    *first_position = (s->next_block_key - 1) * bs + 1;
+    *last_position = last_key * bs;
+    return 1;
+}
+
+/* DoneProcessing :336-360 for the blocks up to last_position */
+void orc_done_processing(OrcState* s, int32_t last_position)
+{
+    for (int li = 0; li < s->n_loci; li++)
+        if (s->start_position + li <= last_position) s->cand_head[li] = s->cand_tail[li] = -1;
+    const int key = (last_position - 1) / s->block_size + 1;
+    if (key + 1 > s->next_block_key) s->next_block_key = key + 1;
+}
+
 /* The same over RegionState.GetAllCandidates :383-453: every candidate of the state plus (gVCF) a Reference candidate per
  * position with support = the reference base's counts by direction. */
 int64_t orc_call_range(OrcState* s, const uint8_t* ref_bases, int64_t ref_len, const PiscesHipConfig* cfg, int32_t first_position,
                        int32_t last_position, PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out, int64_t* total_num_called)
 {
+    return orc_call_range_up_to(s, ref_bases, ref_len, cfg, first_position, last_position, -1, out, capacity, full_out, total_num_called);
+}
+
+/* up_to_position >= 0: a batch made while reads are still arriving (GetCandidatesToProcess(upToPosition)); when an allele of the cleared
+ * blocks reaches past last_position the collapsable candidates of the following blocks join it (AddCollapsableFromOtherBlocks). */
+int64_t orc_call_range_up_to(OrcState* s, const uint8_t* ref_bases, int64_t ref_len, const PiscesHipConfig* cfg, int32_t first_position,
+                             int32_t last_position, int32_t up_to_position, PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out,
+                             int64_t* total_num_called)
+{
     /* one batch of the block schedule: the candidates and Reference candidates of [first_position, last_position] (whole blocks),
      * MaxClearedPosition = last_position (RegionStateManager.cs:283-334).  What the batch pushes past it (MNV leftovers) goes back to
      * the state and is found by the next range; processed candidates are removed (DoneProcessing). */
-    int64_t n = 0, cap = (int64_t)s->n_cands + 64;
+    int64_t cap = (int64_t)s->n_cands + 64;
     OrcCandidate* list = (OrcCandidate*)malloc(sizeof(OrcCandidate) * (size_t)cap);
-    for (int li = 0; li < s->n_loci; li++) {
+    int32_t from_other_blocks = 0;
+    int64_t n = orc_batch_candidates(s, first_position, last_position, up_to_position, list, (int32_t)cap, &from_other_blocks);
+    for (int li = 0; li < s->n_loci; li++) {   /* DoneProcessing :336-360 (what the batch hands back goes to later blocks) */
         const int position = s->start_position + li;
-        if (position < first_position || position > last_position) continue;
-        for (int i = s->cand_head[li]; i >= 0; i = s->cands[i].next) list[n++] = s->cands[i];
-        s->cand_head[li] = s->cand_tail[li] = -1;
+        if (position >= first_position && position <= last_position) s->cand_head[li] = s->cand_tail[li] = -1;
     }
-    if (cfg->collapse)   /* AlleleCaller.Call :50-58: candidates = _collapser.Collapse(batch.GetCandidates(), source, MaxClearedPosition) */
+    if (cfg->collapse) {   /* AlleleCaller.Call :50-58: candidates = _collapser.Collapse(batch.GetCandidates(), source, MaxClearedPosition) */
+        OrcCandidate* back = from_other_blocks ? (OrcCandidate*)malloc(sizeof(OrcCandidate) * (size_t)(n > 0 ? n : 1)) : NULL;
+        int32_t n_back = 0;
         n = orc_collapse(list, (int32_t)n, s, cfg->collapse_freq_threshold, cfg->collapse_freq_ratio_threshold, 0, 1,
-                         cfg->expect_stitched_reads, -1, NULL, NULL, NULL);
+                         cfg->expect_stitched_reads, from_other_blocks ? last_position : -1, NULL, back, &n_back);
+        for (int i = 0; i < n_back; i++) orc_add_candidate(s, &back[i]);   /* source.AddCandidates(notClearedVariants) :67-75 */
+        free(back);
+    }
     if (cfg->include_reference_calls && ref_bases) {
         for (int li = 0; li < s->n_loci; li++) {
             int position = s->start_position + li;
@@ -2263,6 +2382,46 @@ int64_t orc_run_reads_blocks(const PiscesReadBatch* b, const uint8_t* ref_bases,
         if (k < 0) { orc_state_destroy(s); return k; }
         n += k;
         total += t;
+    }
+    if (total_num_called) *total_num_called = total;
+    orc_state_destroy(s);
+    return n;
+}
+
+/* SmallVariantCaller's loop with the reads given first and then a list of upToPosition values, the last batch being the final one
+ * (GetCandidatesToProcess(null)): RegionStateManager.GetCandidatesToProcess :283-334 decides which blocks each batch clears.  Every
+ * block of the window exists (the window is dense); a batch is skipped while upTo stays in the block of the previous call. */
+int64_t orc_run_reads_schedule(const PiscesReadBatch* b, const uint8_t* ref_bases, int64_t ref_len, int32_t region_start, int32_t region_loci,
+                               const PiscesHipConfig* cfg, const int32_t* up_to_positions, int32_t n_up_to, PiscesCalledAllele* out,
+                               int64_t capacity, OrcCalled* full_out, int64_t* total_num_called)
+{
+    OrcState* s = orc_state_create(region_start, region_loci, cfg->min_base_call_quality, PISCES_ANCHOR_SIZE, cfg->collapse ? 1 : 0);
+    orc_track_blocks(s, cfg->block_size);
+    OrcCandidate cands[256];
+    uint8_t* expanded = NULL;
+    int64_t expanded_cap = 0;
+    for (int i = 0; i < b->n_reads; i++) {
+        OrcRead r;
+        read_from_batch(b, i, &r, &expanded, &expanded_cap);
+        int nc = orc_find_candidates(&r, ref_bases, ref_len, cfg->min_base_call_quality, cfg->max_mnv_length, cfg->max_gap_between_mnv,
+                                     cfg->call_mnvs, PISCES_ANCHOR_SIZE, cands, 256);
+        for (int k = 0; k < nc; k++)
+            if (cands[k].position >= region_start && cands[k].position < region_start + region_loci) orc_add_candidate(s, &cands[k]);
+        int rc = orc_add_allele_counts(s, &r);
+        if (rc) { free(expanded); orc_state_destroy(s); return rc; }
+    }
+    free(expanded);
+    int64_t n = 0, total = 0;
+    for (int u = 0; u <= n_up_to; u++) {
+        const int upTo = u == n_up_to ? -1 : up_to_positions[u];
+        int32_t first = 0, last = 0;
+        if (orc_next_batch(s, upTo, &first, &last) != 1) continue;
+        int64_t t = 0;
+        int64_t k = orc_call_range_up_to(s, ref_bases, ref_len, cfg, first, last, upTo, out + n, capacity - n, full_out ? full_out + n : NULL, &t);
+        if (k < 0) { orc_state_destroy(s); return k; }
+        n += k;
+        total += t;
+        orc_done_processing(s, last);
     }
     if (total_num_called) *total_num_called = total;
     orc_state_destroy(s);

@@ -186,6 +186,17 @@ int64_t orc_run_reads_full(const PiscesReadBatch* batch, const uint8_t* ref_base
                       OrcCalled* full_out /* optional: allele strings etc. */, int64_t* total_num_called);
 int64_t orc_run_reads_blocks(const PiscesReadBatch* batch, const uint8_t* ref_bases, int64_t ref_len, int32_t region_start, int32_t region_loci,
                              const PiscesHipConfig* cfg, PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out, int64_t* total_num_called);
+void    orc_track_blocks(OrcState* s, int32_t block_size);                  /* RegionState.MaxAlleleEndpoint per block, RegionState.cs:203-223 */
+int32_t orc_batch_candidates(OrcState* s, int32_t first_position, int32_t last_position, int32_t up_to_position, OrcCandidate* out,
+                             int32_t capacity, int32_t* from_other_blocks);   /* RegionStateManager.cs:283-334, 441-457; RegionState.cs:470-490 */
+int32_t orc_next_batch(OrcState* s, int32_t up_to_position, int32_t* first_position, int32_t* last_position);   /* RegionStateManager.cs:283-334 */
+void    orc_done_processing(OrcState* s, int32_t last_position);           /* RegionStateManager.cs:336-360 */
+int64_t orc_call_range_up_to(OrcState* s, const uint8_t* ref_bases, int64_t ref_len, const PiscesHipConfig* cfg, int32_t first_position,
+                             int32_t last_position, int32_t up_to_position, PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out,
+                             int64_t* total_num_called);                    /* + AddCollapsableFromOtherBlocks, RegionStateManager.cs:321-324,441-457 */
+int64_t orc_run_reads_schedule(const PiscesReadBatch* batch, const uint8_t* ref_bases, int64_t ref_len, int32_t region_start, int32_t region_loci,
+                               const PiscesHipConfig* cfg, const int32_t* up_to_positions, int32_t n_up_to, PiscesCalledAllele* out,
+                               int64_t capacity, OrcCalled* full_out, int64_t* total_num_called);   /* RegionStateManager.cs:283-334 */
 /* same, from packed observations (position, tuple) instead of reads */
 int64_t orc_run_observations(const int32_t* positions, const uint32_t* tuples, int64_t n_obs,
                       const uint8_t* ref_bases, int64_t ref_len, int32_t region_start, int32_t region_loci,

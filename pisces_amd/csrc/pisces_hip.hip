@@ -1695,7 +1695,7 @@ static int64_t collapse_candidates(std::vector<HostCandidate>& cands, float freq
 // reference support taken by gapped MNVs is registered (it reaches the Reference records through call_blocks, which runs after
 // this), and every callable allele is processed again.  ref_overrides: Reference alleles that reallocation added support to
 // (they replace the tile kernels' Reference record of that position).
-static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, std::vector<PiscesCalledAllele>& recs,
+static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int32_t up_to_position, std::vector<PiscesCalledAllele>& recs,
                              std::vector<HostCandidate>& called, int64_t* n_called, int64_t* n_collapsed,
                              std::vector<PiscesCalledAllele>& ref_overrides)
 {
@@ -1712,8 +1712,36 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, std
         for (auto& c : h->blocks[key].cands) work.push_back(c);
         std::stable_sort(work.begin() + (std::ptrdiff_t)first, work.end(), [](const HostCandidate& x, const HostCandidate& y) { return x.position < y.position; });
     }
-    if (work.empty()) return PISCES_OK;
     const int bs = h->cfg.block_size;
+    // AddCollapsableFromOtherBlocks (RegionStateManager.cs:321-324, 441-457): when an allele of the cleared blocks reaches past the last
+    // cleared position and the collapser is on, the SNV / MNV candidates of the held blocks up to upTo that end at or before upTo and are
+    // not open on the right (RegionState.ExtractCollapsable :470-490) leave their blocks and join this batch, where candidates of the
+    // cleared blocks may collapse into them; whatever of them is left after collapsing goes back to the state (below)
+    int32_t max_cleared = -1;
+    if (!keys.empty() && up_to_position >= 0 && h->cfg.collapse) {
+        int32_t max_endpoint = 0;
+        for (int32_t key : keys) max_endpoint = std::max(max_endpoint, h->blocks[key].max_allele_endpoint);
+        if (max_endpoint > keys.back() * bs) {
+            max_cleared = keys.back() * bs;
+            for (auto& kv : h->blocks) {   // ascending block order
+                const int32_t start = (kv.first - 1) * bs + 1;
+                if (start <= max_cleared || start > up_to_position) continue;
+                std::vector<HostCandidate> kept;
+                const size_t first = work.size();
+                for (auto& c : kv.second.cands) {
+                    const bool collapsable = (c.category == PISCES_CAT_MNV || c.category == PISCES_CAT_SNV) && !c.open_right &&
+                                             c.position + (int32_t)c.alt.size() - 1 <= up_to_position;
+                    (collapsable ? work : kept).push_back(c);
+                }
+                if (work.size() == first) continue;
+                std::stable_sort(work.begin() + (std::ptrdiff_t)first, work.end(), [](const HostCandidate& x, const HostCandidate& y) { return x.position < y.position; });
+                kv.second.cands.clear();   // (MaxAlleleEndpoint keeps its value: RegionState never lowers it)
+                kv.second.cand_index.clear();
+                for (auto& c : kept) add_candidate(h, c);
+            }
+        }
+    }
+    if (work.empty()) return PISCES_OK;
     // start / end points (CoverageCalculator.Compute :27-41)
     auto endpoints = [](const HostCandidate& c, int32_t& sp, int32_t& ep) {
         if (c.category == PISCES_CAT_DELETION) { sp = c.position + 1; ep = c.position + (int32_t)c.ref.size() - 1; }
@@ -1807,8 +1835,18 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, std
             const float f = (float)support / (float)total;
             return f < 1.0f ? f : 1.0f;
         });
-        // candidates past the last cleared position that could not be collapsed stay with their (held) blocks: this batch only holds
-        // candidates of cleared blocks, so there is nothing to hand back (VariantCollapser.cs:67-75)
+        // candidates past the last cleared position that could not be collapsed return to the state (VariantCollapser.cs:67-75): only the
+        // ones AddCollapsableFromOtherBlocks brought in can lie there
+        if (max_cleared >= 0) {
+            size_t w = 0;
+            for (size_t i = 0; i < work.size(); i++) {
+                if (work[i].position > max_cleared && work[i].category != PISCES_CAT_REFERENCE) { add_candidate(h, work[i]); continue; }
+                if (w != i) work[w] = std::move(work[i]);
+                w++;
+            }
+            work.resize(w);
+            if (work.empty()) return PISCES_OK;
+        }
     }
     // one device pass over a list of candidates: records + IsCallable
     std::vector<PiscesCalledAllele> raw;
@@ -1992,7 +2030,7 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
         // Reference records of call_blocks must see (AlleleCaller.cs:95, CoverageCalculator.cs:82-97)
         int64_t collapsed = 0;
         std::vector<PiscesCalledAllele> ref_overrides;
-        int32_t rc = call_spanning(h, keys, span_recs, span_cands, &called, &collapsed, ref_overrides);
+        int32_t rc = call_spanning(h, keys, final_flush ? -1 : up_to_position, span_recs, span_cands, &called, &collapsed, ref_overrides);
         h->pending_collapsed = collapsed;
         if (rc) return rc;
         h->pending_dropped = false;

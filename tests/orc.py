@@ -142,6 +142,10 @@ def _load():
                                        P(_abi.PiscesHipConfig), C.c_void_p, i64, P(i64)]),
         "orc_default_config": (None, [P(_abi.PiscesHipConfig)]),
         "orc_run_reads_sharded": (i32, [P(OrcShardJob), i32]),
+        "orc_track_blocks": (None, [C.c_void_p, i32]),
+        "orc_next_batch": (i32, [C.c_void_p, i32, P(i32), P(i32)]),
+        "orc_batch_candidates": (i32, [C.c_void_p, i32, i32, i32, P(OrcCandidate), i32, P(i32)]),
+        "orc_done_processing": (None, [C.c_void_p, i32]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -240,6 +244,26 @@ class State:
         arr = (OrcCandidate * max(n, 1))()
         lib.orc_get_candidates(self.h, arr, n)
         return [arr[i] for i in range(n)]
+
+    def track_blocks(self, block_size=1000):
+        lib.orc_track_blocks(self.h, C.c_int32(block_size))
+
+    def next_batch(self, up_to):
+        """GetCandidatesToProcess's block choice: None (no batch), () (a batch without cleared blocks) or (first, last) positions."""
+        first, last = C.c_int32(0), C.c_int32(0)
+        rc = lib.orc_next_batch(self.h, C.c_int32(-1 if up_to is None else up_to), C.byref(first), C.byref(last))
+        return None if rc < 0 else () if rc == 0 else (first.value, last.value)
+
+    def batch_candidates(self, first, last, up_to):
+        cap = lib.orc_num_candidates(self.h) + 1
+        arr = (OrcCandidate * cap)()
+        other = C.c_int32(0)
+        n = lib.orc_batch_candidates(self.h, C.c_int32(first), C.c_int32(last), C.c_int32(-1 if up_to is None else up_to), arr, C.c_int32(cap),
+                                     C.byref(other))
+        return [arr[i] for i in range(n)], bool(other.value)
+
+    def done_processing(self, last):
+        lib.orc_done_processing(self.h, C.c_int32(last))
 
     def call_all(self, ref_bases, cfg, want_full=False):
         ref = np.frombuffer(ref_bases if isinstance(ref_bases, bytes) else ref_bases.encode(), dtype=np.uint8)
@@ -456,5 +480,22 @@ def run_reads_blocks(batch, ref, region_start, region_loci, cfg):
     lib.orc_run_reads_blocks.restype = C.c_int64
     n = lib.orc_run_reads_blocks(C.byref(batch.c), refa.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int64(len(refa)), C.c_int32(region_start),
                                  C.c_int32(region_loci), C.byref(cfg), C.c_void_p(out.ctypes.data), C.c_int64(cap), full, C.byref(total))
+    assert n >= 0, n
+    return out[:n], [(full[i].ref.decode(), full[i].alt.decode()) for i in range(n)], total.value
+
+
+def run_reads_schedule(batch, ref, region_start, region_loci, cfg, up_to_positions):
+    """run_reads_full with GetCandidatesToProcess(upTo) for every upTo of the list and then the final batch (RegionStateManager.cs:283-334,
+    with AddCollapsableFromOtherBlocks)."""
+    refa = np.ascontiguousarray(ref, np.uint8)
+    cap = region_loci * 5 + 16
+    out = np.zeros(cap, dtype=_abi.CALLED_ALLELE_DTYPE)
+    full = (OrcCalled * cap)()
+    total = C.c_int64(0)
+    ups = np.ascontiguousarray(up_to_positions, np.int32)
+    lib.orc_run_reads_schedule.restype = C.c_int64
+    n = lib.orc_run_reads_schedule(C.byref(batch.c), refa.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int64(len(refa)), C.c_int32(region_start),
+                                   C.c_int32(region_loci), C.byref(cfg), ups.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int32(len(ups)),
+                                   C.c_void_p(out.ctypes.data), C.c_int64(cap), full, C.byref(total))
     assert n >= 0, n
     return out[:n], [(full[i].ref.decode(), full[i].alt.decode()) for i in range(n)], total.value

@@ -1475,3 +1475,64 @@ def test_concurrent_handles_on_threads_share_nothing(torch_cuda):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def _cross_block_collapse_case(seed=4242):
+    """Reads over the 1000|1001 and 2000|2001 block edges: three-base MNVs at 999 and 1999 at 30 %, reads that begin on the second or third
+    base of them (their part of the MNV is an open-left candidate: a two-base MNV of the same block, an SNV of the NEXT block), SNVs at
+    1020 / 1050 / 1600 and an MNV at 2040 some of whose reads begin on them (open-left candidates with nothing to collapse into)."""
+    rng = np.random.default_rng(seed)
+    ref = bytearray(rng.choice(list(b"ACGT"), 3200).astype(np.uint8))
+    def mut(p, n):
+        return "".join(chr([b for b in b"ACGT" if b != ref[p - 1 + i]][(i + p) % 3]) for i in range(n))
+    planted = [(999, mut(999, 3), 0.30), (1999, mut(1999, 3), 0.30), (1020, mut(1020, 1), 0.25), (1600, mut(1600, 1), 0.25),
+               (1050, mut(1050, 1), 0.3), (2040, mut(2040, 2), 0.25)]
+    reads, L = [], 100
+    for n in range(5000):
+        k = n % 5
+        if k == 0: start = int(rng.integers(905, 999))
+        elif k == 1: start = int(rng.choice([1000, 1001, 1050, 1020]))
+        elif k == 2: start = int(rng.integers(1905, 1999))
+        elif k == 3: start = int(rng.choice([2000, 2001, 2040, 2041]))
+        else: start = int(rng.integers(1400, 1700))
+        seq = bytearray(ref[start - 1: start - 1 + L])
+        for (p, alt, frac) in planted:
+            lo, hi = max(p, start), min(p + len(alt), start + L)
+            if lo < hi and rng.random() < frac:   # the part of the allele the read covers
+                seq[lo - start: hi - start] = alt[lo - p: hi - p].encode()
+        reads.append({"pos": start, "cigar": [("M", L)], "seq": bytes(seq).decode(), "quals": [37] * L, "reverse": bool(n % 2)})
+    reads.sort(key=lambda r: r["pos"])
+    return ref, reads, planted
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("schedule", [(1500, 2600), (1003, 2002), (1001, 1500, 2001, 2999, 3100)])
+def test_collapsable_candidates_of_the_next_block_join_the_batch(torch_cuda, schedule):
+    """AddCollapsableFromOtherBlocks (RegionStateManager.cs:321-324, 441-457) in pisces_hip_flush_ex: with the collapser and MNV calling on,
+    a batch whose MNV reaches past its last cleared position takes the collapsable SNV / MNV candidates of the held blocks up to upTo;
+    the open-left SNV that is the last base of the MNV (a candidate of the next block) collapses into it, candidates that do not collapse
+    return to their block and are called with it.  The oracle runs the same upTo schedule (orc_run_reads_schedule); without the step the
+    MNVs would keep 400 instead of 482 supporting reads and their last bases would be called as SNVs of their own."""
+    from pisces_amd import engine
+    ref, reads, planted = _cross_block_collapse_case()
+    batch = _abi.ReadBatch(reads)
+    refa = np.frombuffer(bytes(ref), dtype=np.uint8)
+    cfg = _abi.default_config(call_mnvs=1, collapse=1)
+    exp, exp_alleles, exp_called = orc.run_reads_schedule(batch, refa, 1, len(ref), cfg, list(schedule))
+    plain, plain_alleles, _ = orc.run_reads_blocks(batch, refa, 1, len(ref), cfg)
+    support = lambda recs, alleles, p, n: [int(r["allele_support"]) for r, a in zip(recs, alleles) if int(r["position"]) == p and len(a[1]) == n and a[0] != a[1]]
+    if schedule[0] > 1001:   # (upTo = 1001 first: block 1 clears with nothing of block 2 at or below upTo but the SNV at 1001 itself)
+        assert support(exp, exp_alleles, 999, 3)[0] > support(plain, plain_alleles, 999, 3)[0]   # the step matters on this input
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(refa)
+        c.AddAlleleCounts(batch)
+        got, got_alleles = [], []
+        for up_to in tuple(schedule) + (None,):
+            r, a = c.CallWithAlleles(upToPosition=up_to)
+            got.append(r)
+            got_alleles += a
+        stats = c.Stats()
+    got = np.concatenate(got)
+    assert got_alleles == exp_alleles
+    assert_records_match(got, exp)
+    assert stats["TotalNumCalled"] == exp_called

@@ -635,3 +635,85 @@ def test_stitched_deletion_support_direction_scenarios():
         old = [c for c in orc.find_candidates(plain, ref) if c.category == _abi.CAT_DELETION][0]
         old_method_differs += list(old.support_by_dir) != want
     assert old_method_differs >= 2   # the scenarios do tell the two branches apart
+
+
+@pytest.mark.parametrize("track_open_ended", [True, False])
+def test_batches_and_collapsable_candidates_of_later_blocks(track_open_ended):
+    """RegionStateManagerTests.AddAndGetCandidates (Pisces.Processing.Tests/UnitTests/RegionStateManagerTests.cs:27-122), the same
+    candidates and the same sequence of GetCandidatesToProcess calls: a batch only when upTo has moved onto another block, only blocks
+    that lie wholly below upTo, a block held while one of its alleles reaches past upTo, and — with open-ended tracking on — the
+    collapsable SNV / MNV candidates of the following blocks pulled into a batch whose alleles reach past its last position."""
+    SNV, MNV, DEL = _abi.CAT_SNV, _abi.CAT_MNV, _abi.CAT_DELETION
+    st = orc.State(1, 6000, track_open_ended=track_open_ended)
+    st.track_blocks(1000)
+    cands = [
+        (1, SNV, "A", "T", False), (998, DEL, "AT", "A", False), (1000, SNV, "A", "T", False),
+        (1001, SNV, "A", "T", False), (1001, SNV, "A", "G", False),
+        (3000, MNV, "ATCC", "GAGG", False),            # spans blocks
+        (3001, DEL, "AT", "A", False),                 # not collapsable
+        (3002, SNV, "T", "A", False),                  # collapsable
+        (3003, SNV, "G", "C", True),                   # open on the right: not collapsable
+        (3002, MNV, "TA", "GA", False),                # collapsable
+        (3001, MNV, "TACGG", "GAGAA", False),          # ends past upTo
+        (5005, MNV, "AC", "TT", False),
+    ]
+    for (p, cat, r, a, open_right) in cands:
+        assert st.add_candidate(orc.make_candidate(p, cat, r, a, support=(1, 0, 0), open_right=open_right)) == 0
+    key = lambda c: (c.position, c.category, c.ref.decode(), c.alt.decode())
+    def batch(up_to):
+        b = st.next_batch(up_to)
+        if not b:
+            return b, None
+        got, _ = st.batch_candidates(b[0], b[1], up_to)
+        return b, sorted(key(c) for c in got)
+    want = lambda pred: sorted((p, cat, r, a) for (p, cat, r, a, o) in cands if pred(p, cat, r, a, o))
+    collapsable = lambda p, cat, r, a, o: cat in (SNV, MNV) and p + len(a) - 1 <= 3003 and not o
+
+    assert batch(1) == ((), None)                       # first time: a batch, nothing cleared
+    assert batch(1000) == (None, None)                  # upTo has not left its block: no batch
+    b, got = batch(1002)
+    assert b == (1, 1000) and got == want(lambda p, *_: p <= 1000)
+    st.done_processing(b[1])
+    b, got = batch(2001)
+    assert b == (1001, 2000) and got == want(lambda p, *_: p == 1001)
+    st.done_processing(b[1])
+    b, got = batch(3003)                                # the MNV at 3000 ends at 3003: block 3 clears and reaches into block 4
+    assert b == (2001, 3000)
+    assert got == want(lambda p, cat, r, a, o: p > 1001 and (p <= 3000 or (track_open_ended and collapsable(p, cat, r, a, o))))
+    # not done: the next batch holds the same blocks again, without what was extracted
+    b, got = batch(4001)
+    assert b == (2001, 4000)
+    assert got == want(lambda p, cat, r, a, o: 1001 < p < 4000 and (p != 3002 or not track_open_ended))
+    b, got = batch(None)
+    assert b == (2001, 6000)
+    assert got == want(lambda p, cat, r, a, o: p > 1001 and (p != 3002 or not track_open_ended))
+    st.done_processing(b[1])
+    assert batch(None) == ((), None)                    # an empty state is fine
+
+
+def test_schedule_collapses_the_open_left_base_of_the_next_block_into_the_mnv():
+    """The oracle's upTo schedule on the cross-block case of the GPU test: an MNV that starts in a cleared block takes the support of
+    the open-left SNV that is its last base and lives in the next block (VariantCollapser's end-anchored match); with one batch per
+    block and no look-ahead that SNV is called on its own."""
+    from tests.test_gpu_parity import _cross_block_collapse_case
+    ref, reads, planted = _cross_block_collapse_case()
+    batch = _abi.ReadBatch(reads)
+    refa = np.frombuffer(bytes(ref), dtype=np.uint8)
+    cfg = _abi.default_config(call_mnvs=1, collapse=1)
+    ahead = orc.run_reads_schedule(batch, refa, 1, len(ref), cfg, [1500, 2600])
+    plain = orc.run_reads_blocks(batch, refa, 1, len(ref), cfg)
+    rows = lambda x: {(int(r["position"]), a): int(r["allele_support"]) for r, a in zip(x[0], x[1]) if a[0] != a[1]}
+    ra, rp = rows(ahead), rows(plain)
+    for p in (999, 1999):
+        mnv = (p, (bytes(ref[p - 1:p + 2]).decode(), planted[0 if p == 999 else 1][1]))
+        tail = (p + 2, (chr(ref[p + 1]), mnv[1][1][2]))
+        assert tail in rp and tail not in ra
+        assert ra[mnv] == rp[mnv] + rp[tail]
+    # candidates that were looked at and did not collapse are called with their own block, unchanged
+    for p in (1020, 1050, 1600, 2040):
+        same = [k for k in ra if k[0] == p]
+        assert same and all(ra[k] == rp[k] for k in same)
+    # a schedule that never looks ahead (upTo at the block ends) gives the per-block result
+    flat = orc.run_reads_schedule(batch, refa, 1, len(ref), _abi.default_config(call_mnvs=1, collapse=0), [1500, 2600])
+    flat_blocks = orc.run_reads_blocks(batch, refa, 1, len(ref), _abi.default_config(call_mnvs=1, collapse=0))
+    assert rows(flat) == rows(flat_blocks)
