@@ -45,7 +45,8 @@ enum { PISCES_CAT_SNV = 0, PISCES_CAT_INSERTION = 1, PISCES_CAT_DELETION = 2, PI
 enum { PISCES_GT_HET_ALT1_ALT2 = 0, PISCES_GT_ALT12_LIKE_NOCALL = 1, PISCES_GT_HET_ALT_REF = 2,
        PISCES_GT_HOM_ALT = 3, PISCES_GT_HOM_REF = 4, PISCES_GT_REF_LIKE_NOCALL = 5,
        PISCES_GT_ALT_LIKE_NOCALL = 6, PISCES_GT_REF_AND_NOCALL = 7, PISCES_GT_ALT_AND_NOCALL = 8,
-       PISCES_GT_HEMI_REF = 9, PISCES_GT_HEMI_ALT = 10, PISCES_GT_HEMI_NOCALL = 11 /* PloidyModel.Haploid */ };
+       PISCES_GT_HEMI_REF = 9, PISCES_GT_HEMI_ALT = 10, PISCES_GT_HEMI_NOCALL = 11 /* PloidyModel.Haploid */,
+       PISCES_GT_OTHERS = 12 /* a forced allele next to other variants, DiploidLocusProcessor.cs:36-38 */ };
 /* src/lib/Pisces.Domain/Types/FilterType.cs:3-19 — bit i of filter_bits = enum value i */
 enum { PISCES_FILTER_STRAND_BIAS = 0, PISCES_FILTER_POOL_BIAS = 1, PISCES_FILTER_AMPLICON_BIAS = 2,
        PISCES_FILTER_LOW_VARIANT_QSCORE = 3, PISCES_FILTER_LOW_DEPTH = 4,

@@ -752,6 +752,9 @@ struct OrcState {
     /* the block grid of RegionStateManager over the window, when a schedule is run (orc_track_blocks): MaxAlleleEndpoint per block */
     int32_t block_size, first_block_key, n_blocks, next_block_key, last_up_to_block_key, have_last_up_to;
     int32_t* max_allele_endpoint;
+    /* forced genotyping alleles (-forcedalleles): sorted by position; [0, n_forced_added) have been handed in as candidates */
+    OrcCandidate* forced;
+    int32_t n_forced, n_forced_added;
 };
 
 OrcState* orc_state_create(int32_t start, int32_t n_loci, int32_t min_bq, int32_t num_anchor_types,
@@ -779,6 +782,7 @@ void orc_state_destroy(OrcState* s)
     if (!s) return;
     free(s->counts); free(s->sumq); free(s->gapped); free(s->cand_head); free(s->cand_tail); free(s->cands);
     free(s->max_allele_endpoint);
+    free(s->forced);
     free(s);
 }
 
@@ -995,6 +999,49 @@ int32_t orc_add_candidate(OrcState* s, const OrcCandidate* c)
     if (s->cand_tail[li] >= 0) s->cands[s->cand_tail[li]].next = id;
     else s->cand_head[li] = id;
     s->cand_tail[li] = id;
+    return 0;
+}
+
+/* The forced alleles of this chromosome (Factory.SelectForcedAllele, Factory.cs:270-286; SmallVariantCaller.CreateForcedAllelePos :49-77):
+ * (position, ref, alt) with the category of SmallVariantCaller.GetAlleleCategory :141-150, kept in position order (a SortedList), alleles
+ * of one position in the order given. */
+void orc_set_forced_alleles(OrcState* s, const OrcCandidate* list, int32_t n)
+{
+    free(s->forced);
+    s->forced = (OrcCandidate*)calloc((size_t)(n > 0 ? n : 1), sizeof(OrcCandidate));
+    s->n_forced = n;
+    s->n_forced_added = 0;
+    for (int i = 0; i < n; i++) {
+        OrcCandidate c;
+        memset(&c, 0, sizeof(c));
+        c.position = list[i].position;
+        strcpy(c.ref, list[i].ref);
+        strcpy(c.alt, list[i].alt);
+        const size_t rl = strlen(c.ref), al = strlen(c.alt);
+        c.category = (rl == 1 && al == 1) ? PISCES_CAT_SNV : rl == al ? PISCES_CAT_MNV : rl > al ? PISCES_CAT_DELETION : PISCES_CAT_INSERTION;
+        c.next = -1;
+        int k = i;   /* stable insertion by position */
+        while (k > 0 && s->forced[k - 1].position > c.position) { s->forced[k] = s->forced[k - 1]; k--; }
+        s->forced[k] = c;
+    }
+}
+
+/* SmallVariantCaller.AddForcedAlleleAsCandidate :118-132: the forced alleles up to upToPosition (< 0 = null: all that are left) become
+ * candidates without support (IStateManager.AddCandidates), once */
+void orc_add_forced_as_candidates(OrcState* s, int32_t up_to_position)
+{
+    while (s->n_forced_added < s->n_forced) {
+        const OrcCandidate* c = &s->forced[s->n_forced_added];
+        if (up_to_position >= 0 && c->position > up_to_position) break;
+        (void)orc_add_candidate(s, c);
+        s->n_forced_added++;
+    }
+}
+
+static int is_forced_allele(const OrcState* s, const OrcCalled* a)   /* AlleleCaller.IsForcedAllele :179-184 */
+{
+    for (int i = 0; i < s->n_forced; i++)
+        if (s->forced[i].position == a->position && strcmp(s->forced[i].ref, a->ref) == 0 && strcmp(s->forced[i].alt, a->alt) == 0) return 1;
     return 0;
 }
 
@@ -1961,7 +2008,30 @@ int64_t orc_reallocate_failed_mnvs(const OrcCalled* failed, int64_t n_failed, Or
     return nc;
 }
 
-/* AlleleCaller.CallForPositions :60-141 (collapser applied by the caller, no forced alleles) over an explicit batch of
+/* DiploidLocusProcessor.Process (exe/Pisces/Logic/VariantCalling/DiploidLocusProcessor.cs:13-52) over the alleles of one position: a
+ * forced allele (ForcedReport filter) takes the genotype the other alleles imply, every allele the smallest genotype q-score of the others */
+void orc_diploid_locus_process(OrcCalled* at, int32_t n)
+{
+    int anyForced = 0, anyOther = 0, isRef = 0, isNoCall = 0, minGq = 0;
+    for (int k = 0; k < n; k++) {
+        if ((at[k].filters >> PISCES_FILTER_FORCED_REPORT) & 1u) { anyForced = 1; continue; }
+        const int g = at[k].genotype;
+        if (at[k].category == PISCES_CAT_REFERENCE) isRef = 1;
+        if (g == PISCES_GT_ALT12_LIKE_NOCALL || g == PISCES_GT_ALT_LIKE_NOCALL || g == PISCES_GT_HEMI_NOCALL || g == PISCES_GT_REF_LIKE_NOCALL)
+            isNoCall = 1;   /* CalledAllele.IsNocall, CalledAllele.cs:54-62 */
+        if (!anyOther || at[k].genotype_qscore < minGq) minGq = at[k].genotype_qscore;
+        anyOther = 1;
+    }
+    if (!anyForced) return;
+    if (!anyOther) isNoCall = 1;
+    const int genotype = isNoCall ? PISCES_GT_ALT_LIKE_NOCALL : isRef ? PISCES_GT_HOM_REF : PISCES_GT_OTHERS;
+    for (int k = 0; k < n; k++) {
+        if ((at[k].filters >> PISCES_FILTER_FORCED_REPORT) & 1u) at[k].genotype = genotype;
+        at[k].genotype_qscore = anyOther ? minGq : 0;
+    }
+}
+
+/* AlleleCaller.CallForPositions :60-141 (collapser applied by the caller; forced alleles: orc_set_forced_alleles) over an explicit batch of
  * candidates (ICandidateBatch.GetCandidates): MNV candidates are processed first, the ones that are not callable are handed to
  * MnvReallocator, what it pushes past max_cleared_position goes back to the state as candidates (the next block's), reference
  * support taken by gapped MNVs is registered, then ProcessVariant + IsCallable per callable allele, and per position the
@@ -2008,13 +2078,23 @@ int64_t orc_call_candidates_max(OrcState* s, const OrcCandidate* list, int64_t n
             if (a->ref[k] == a->alt[k]) orc_add_gapped_mnv_ref(s, a->position + k, a->allele_support);
     }
 
+    /* a failed MNV that is a forced allele is reported all the same: back among the callable alleles (:98-107) */
+    int64_t n_spiked = 0;
+    for (int64_t i = 0; i < failedMnvs.n; i++)
+        if (is_forced_allele(s, failedMnvs.p[i])) { pl_push(&callable, failedMnvs.p[i]); n_spiked++; }
+
     int64_t n = 0, cap = callable.n + 1;
     OrcCalled* called = (OrcCalled*)malloc(sizeof(OrcCalled) * (size_t)cap);
     for (int64_t i = 0; i < callable.n; i++) {
         OrcCalled* v = callable.p[i];
         orc_process_variant(v, s, cfg);
-        if (is_callable(v, cfg, &totalNumCalled)) called[n++] = *v;
+        /* :109-131.  (ShouldReport: the window is the interval; forced alleles are inside the intervals by Factory.SelectForcedAllele.)
+         * IsCallable runs once in each condition, and counts a callable forced allele twice in TotalNumCalled. */
+        const int forced = s->n_forced > 0 && is_forced_allele(s, v);
+        if (forced && !is_callable(v, cfg, &totalNumCalled)) v->filters |= 1u << PISCES_FILTER_FORCED_REPORT;   /* IsForcedToReport */
+        if (is_callable(v, cfg, &totalNumCalled) || forced) called[n++] = *v;
     }
+    callable.n -= n_spiked;   /* (owned by failedMnvs) */
     {   /* free every object once */
         for (int64_t i = 0; i < outside.n; i++) {
             int dup = 0;
@@ -2031,54 +2111,69 @@ int64_t orc_call_candidates_max(OrcState* s, const OrcCandidate* list, int64_t n
      * unless open-ended twins survive (only with track_open_ended). */
     qsort(called, (size_t)n, sizeof(OrcCalled), called_cmp);
 
-    /* ComputeGenotypeAndFilterAllele :143-177 per position */
+    /* ComputeGenotypeAndFilterAllele :143-177 per position, then ILocusProcessor.Process */
+#define FORCED_TO_REPORT(a) (((a).filters >> PISCES_FILTER_FORCED_REPORT) & 1u)
+    const int per_locus_genotyper = cfg->ploidy == PISCES_PLOIDY_DIPLOID || cfg->ploidy == PISCES_PLOIDY_HAPLOID;
     int64_t w = 0;
     for (int64_t i = 0; i < n;) {
         int64_t j = i;
-        int anyNonRef = 0;
-        while (j < n && called[j].position == called[i].position) { if (called[j].category != PISCES_CAT_REFERENCE) anyNonRef = 1; j++; }
-        if (cfg->ploidy == PISCES_PLOIDY_DIPLOID || cfg->ploidy == PISCES_PLOIDY_HAPLOID) {
-            /* ComputeGenotypeAndFilterAllele :143-177 with the diploid genotyper: Reference rows leave when a variant is there, the
-             * genotyper names the alleles beyond the ploidy, LowGQ, (ref, alt) order (the list is sorted already) */
-            OrcCalled at[64];
-            int32_t phase[64];
-            uint8_t prune[64];
-            int m = 0;
-            for (int64_t k = i; k < j && m < 64; k++) {
-                if (anyNonRef && called[k].category == PISCES_CAT_REFERENCE) continue;
-                at[m++] = called[k];
-            }
-            if (cfg->ploidy == PISCES_PLOIDY_HAPLOID) {
-                orc_haploid_set_genotypes(at, m, cfg->diploid_snv_params[0], cfg->diploid_snv_params[1], cfg->min_coverage, cfg->min_genotype_qscore,
-                                          cfg->max_genotype_qscore, prune);
-                for (int q = 0; q < m; q++) phase[q] = 0;   /* HaploidGenotyper leaves PhaseSetIndex alone */
-            } else
-            orc_diploid_set_genotypes(at, m, cfg->diploid_snv_params, cfg->diploid_indel_params, cfg->min_coverage, cfg->min_genotype_qscore,
-                                      cfg->max_genotype_qscore, phase, prune);
-            for (int q = 0; q < m; q++) {
-                if (prune[q]) continue;
-                if (cfg->low_gq_filter >= 0 && (float)at[q].genotype_qscore < (float)cfg->low_gq_filter)
-                    at[q].filters |= 1u << PISCES_FILTER_LOW_GENOTYPE_QUALITY;
-                at[q].filters |= (uint32_t)phase[q] << 14;   /* PhaseSetIndex rides in filter_bits 14..15 */
-                called[w++] = at[q];
-            }
-            i = j;
-            continue;
+        int anyNonRef = 0;   /* a variant that is not there only because it was forced */
+        while (j < n && called[j].position == called[i].position) {
+            if (called[j].category != PISCES_CAT_REFERENCE && !FORCED_TO_REPORT(called[j])) anyNonRef = 1;
+            j++;
         }
-        for (int64_t k = i; k < j; k++) {
+        OrcCalled at[64];   /* allelesAtPosition, Reference rows pruned */
+        int m = 0;
+        for (int64_t k = i; k < j && m < 64; k++) {
             if (anyNonRef && called[k].category == PISCES_CAT_REFERENCE) continue;
-            OrcCalled* a = &called[k];
-            a->genotype = orc_somatic_genotype(a->category, a->total_coverage, a->allele_support, a->reference_support,
-                                               cfg->genotype_min_freq_filter, cfg->min_coverage);
-            a->genotype_qscore = orc_somatic_gq(a->genotype, a->variant_qscore, a->total_coverage, a->allele_support,
-                                                cfg->target_lod_frequency, cfg->min_genotype_qscore, cfg->max_genotype_qscore);
-            if (cfg->low_gq_filter >= 0 && (float)a->genotype_qscore < (float)cfg->low_gq_filter)
-                a->filters |= 1u << PISCES_FILTER_LOW_GENOTYPE_QUALITY;
-            if (w != k) called[w] = called[k];
-            w++;
+            at[m++] = called[k];
         }
+        uint8_t prune[64] = {0};
+        int32_t phase[64] = {0};
+        if (per_locus_genotyper) {
+            /* the genotyper sees the alleles that were not forced in, and names the ones beyond the ploidy */
+            OrcCalled sub[64];
+            int idx[64], ms = 0;
+            uint8_t sub_prune[64];
+            int32_t sub_phase[64];
+            for (int q = 0; q < m; q++)
+                if (!FORCED_TO_REPORT(at[q])) { idx[ms] = q; sub[ms++] = at[q]; }
+            if (cfg->ploidy == PISCES_PLOIDY_HAPLOID) {
+                orc_haploid_set_genotypes(sub, ms, cfg->diploid_snv_params[0], cfg->diploid_snv_params[1], cfg->min_coverage, cfg->min_genotype_qscore,
+                                          cfg->max_genotype_qscore, sub_prune);
+                for (int q = 0; q < ms; q++) sub_phase[q] = 0;   /* HaploidGenotyper leaves PhaseSetIndex alone */
+            } else {
+                orc_diploid_set_genotypes(sub, ms, cfg->diploid_snv_params, cfg->diploid_indel_params, cfg->min_coverage, cfg->min_genotype_qscore,
+                                          cfg->max_genotype_qscore, sub_phase, sub_prune);
+            }
+            for (int q = 0; q < ms; q++) {
+                at[idx[q]] = sub[q];
+                phase[idx[q]] = sub_phase[q];
+                /* a forced allele stays even when the genotyper would drop it :155-163 */
+                prune[idx[q]] = sub_prune[q] && !(s->n_forced > 0 && is_forced_allele(s, &sub[q]));
+            }
+        } else {
+            for (int q = 0; q < m; q++) {
+                OrcCalled* a = &at[q];
+                if (FORCED_TO_REPORT(*a)) continue;
+                a->genotype = orc_somatic_genotype(a->category, a->total_coverage, a->allele_support, a->reference_support,
+                                                   cfg->genotype_min_freq_filter, cfg->min_coverage);
+                a->genotype_qscore = orc_somatic_gq(a->genotype, a->variant_qscore, a->total_coverage, a->allele_support,
+                                                    cfg->target_lod_frequency, cfg->min_genotype_qscore, cfg->max_genotype_qscore);
+            }
+        }
+        const int64_t w0 = w;
+        for (int q = 0; q < m; q++) {
+            if (prune[q]) continue;
+            if (cfg->low_gq_filter >= 0 && (float)at[q].genotype_qscore < (float)cfg->low_gq_filter)
+                at[q].filters |= 1u << PISCES_FILTER_LOW_GENOTYPE_QUALITY;
+            at[q].filters |= (uint32_t)phase[q] << 14;   /* PhaseSetIndex rides in filter_bits 14..15 */
+            called[w++] = at[q];
+        }
+        if (cfg->ploidy == PISCES_PLOIDY_DIPLOID) orc_diploid_locus_process(called + w0, (int32_t)(w - w0));   /* Factory.cs:145-147: the diploid model only */
         i = j;
     }
+#undef FORCED_TO_REPORT
     n = w;
     if (total_num_called) *total_num_called = totalNumCalled;
     if (n > capacity) { free(called); return -n; }
@@ -2198,6 +2293,7 @@ int64_t orc_call_range_up_to(OrcState* s, const uint8_t* ref_bases, int64_t ref_
     /* one batch of the block schedule: the candidates and Reference candidates of [first_position, last_position] (whole blocks),
      * MaxClearedPosition = last_position (RegionStateManager.cs:283-334).  What the batch pushes past it (MNV leftovers) goes back to
      * the state and is found by the next range; processed candidates are removed (DoneProcessing). */
+    orc_add_forced_as_candidates(s, up_to_position);   /* SmallVariantCaller.cs:101-108: before Call(upTo) */
     int64_t cap = (int64_t)s->n_cands + 64;
     OrcCandidate* list = (OrcCandidate*)malloc(sizeof(OrcCandidate) * (size_t)cap);
     int32_t from_other_blocks = 0;
@@ -2214,11 +2310,20 @@ int64_t orc_call_range_up_to(OrcState* s, const uint8_t* ref_bases, int64_t ref_
         for (int i = 0; i < n_back; i++) orc_add_candidate(s, &back[i]);   /* source.AddCandidates(notClearedVariants) :67-75 */
         free(back);
     }
-    if (cfg->include_reference_calls && ref_bases) {
+    /* RegionState.GetAllCandidates :393-450: Reference candidates over the block (gVCF; the window stands for the intervals), or — not a
+     * gVCF, forced alleles given — at the positions of the forced alleles (CreateIntervalsFromAllels :455-468), there with or without
+     * coverage (IntervalsInUse != null) */
+    const int refs_at_forced_only = !cfg->include_reference_calls && s->n_forced > 0;
+    if ((cfg->include_reference_calls || refs_at_forced_only) && ref_bases) {
         for (int li = 0; li < s->n_loci; li++) {
             int position = s->start_position + li;
             if (position < first_position || position > last_position) continue;
             if (position > ref_len) break;
+            if (refs_at_forced_only) {
+                int here = 0;
+                for (int f = 0; f < s->n_forced && !here; f++) here = s->forced[f].position == position;
+                if (!here) continue;
+            }
             uint8_t refBase = ref_bases[position - 1];
             int refBaseIndex = allele_type_of(refBase);
             OrcCandidate rc;
@@ -2234,7 +2339,7 @@ int64_t orc_call_range_up_to(OrcState* s, const uint8_t* ref_bases, int64_t ref_
                     if (at == refBaseIndex) rc.support_by_dir[d] = count;
                     totalSupport += count;
                 }
-            if (cfg->emit_zero_coverage_refs || totalSupport > 0) {
+            if (cfg->emit_zero_coverage_refs || refs_at_forced_only || totalSupport > 0) {
                 if (n == cap) { cap *= 2; list = (OrcCandidate*)realloc(list, sizeof(OrcCandidate) * (size_t)cap); }
                 list[n++] = rc;
             }
@@ -2392,11 +2497,12 @@ int64_t orc_run_reads_blocks(const PiscesReadBatch* b, const uint8_t* ref_bases,
  * (GetCandidatesToProcess(null)): RegionStateManager.GetCandidatesToProcess :283-334 decides which blocks each batch clears.  Every
  * block of the window exists (the window is dense); a batch is skipped while upTo stays in the block of the previous call. */
 int64_t orc_run_reads_schedule(const PiscesReadBatch* b, const uint8_t* ref_bases, int64_t ref_len, int32_t region_start, int32_t region_loci,
-                               const PiscesHipConfig* cfg, const int32_t* up_to_positions, int32_t n_up_to, PiscesCalledAllele* out,
-                               int64_t capacity, OrcCalled* full_out, int64_t* total_num_called)
+                               const PiscesHipConfig* cfg, const int32_t* up_to_positions, int32_t n_up_to, const OrcCandidate* forced,
+                               int32_t n_forced, PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out, int64_t* total_num_called)
 {
     OrcState* s = orc_state_create(region_start, region_loci, cfg->min_base_call_quality, PISCES_ANCHOR_SIZE, cfg->collapse ? 1 : 0);
     orc_track_blocks(s, cfg->block_size);
+    if (n_forced > 0) orc_set_forced_alleles(s, forced, n_forced);
     OrcCandidate cands[256];
     uint8_t* expanded = NULL;
     int64_t expanded_cap = 0;
@@ -2415,6 +2521,7 @@ int64_t orc_run_reads_schedule(const PiscesReadBatch* b, const uint8_t* ref_base
     for (int u = 0; u <= n_up_to; u++) {
         const int upTo = u == n_up_to ? -1 : up_to_positions[u];
         int32_t first = 0, last = 0;
+        orc_add_forced_as_candidates(s, upTo);
         if (orc_next_batch(s, upTo, &first, &last) != 1) continue;
         int64_t t = 0;
         int64_t k = orc_call_range_up_to(s, ref_bases, ref_len, cfg, first, last, upTo, out + n, capacity - n, full_out ? full_out + n : NULL, &t);

@@ -195,8 +195,12 @@ int64_t orc_call_range_up_to(OrcState* s, const uint8_t* ref_bases, int64_t ref_
                              int32_t last_position, int32_t up_to_position, PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out,
                              int64_t* total_num_called);                    /* + AddCollapsableFromOtherBlocks, RegionStateManager.cs:321-324,441-457 */
 int64_t orc_run_reads_schedule(const PiscesReadBatch* batch, const uint8_t* ref_bases, int64_t ref_len, int32_t region_start, int32_t region_loci,
-                               const PiscesHipConfig* cfg, const int32_t* up_to_positions, int32_t n_up_to, PiscesCalledAllele* out,
-                               int64_t capacity, OrcCalled* full_out, int64_t* total_num_called);   /* RegionStateManager.cs:283-334 */
+                               const PiscesHipConfig* cfg, const int32_t* up_to_positions, int32_t n_up_to, const OrcCandidate* forced,
+                               int32_t n_forced, PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out,
+                               int64_t* total_num_called);                  /* RegionStateManager.cs:283-334; forced alleles: SmallVariantCaller.cs:49-77,118-150 */
+void    orc_diploid_locus_process(OrcCalled* alleles_at_position, int32_t n);             /* DiploidLocusProcessor.cs:13-52 */
+void    orc_set_forced_alleles(OrcState* s, const OrcCandidate* list, int32_t n);       /* Factory.cs:56-96,270-286 */
+void    orc_add_forced_as_candidates(OrcState* s, int32_t up_to_position);              /* SmallVariantCaller.cs:118-132 */
 /* same, from packed observations (position, tuple) instead of reads */
 int64_t orc_run_observations(const int32_t* positions, const uint32_t* tuples, int64_t n_obs,
                       const uint8_t* ref_bases, int64_t ref_len, int32_t region_start, int32_t region_loci,

@@ -28,7 +28,7 @@ DIR_FORWARD, DIR_REVERSE, DIR_STITCHED = range(3)
 CAT_SNV, CAT_INSERTION, CAT_DELETION, CAT_MNV, CAT_REFERENCE = range(5)
 # src/lib/Pisces.Domain/Types/Genotype.cs:3-18
 (GT_HET_ALT1_ALT2, GT_ALT12_LIKE_NOCALL, GT_HET_ALT_REF, GT_HOM_ALT, GT_HOM_REF, GT_REF_LIKE_NOCALL,
- GT_ALT_LIKE_NOCALL, GT_REF_AND_NOCALL, GT_ALT_AND_NOCALL) = range(9)
+ GT_ALT_LIKE_NOCALL, GT_REF_AND_NOCALL, GT_ALT_AND_NOCALL, GT_HEMI_REF, GT_HEMI_ALT, GT_HEMI_NOCALL, GT_OTHERS) = range(13)
 GT_STRING = {GT_HET_ALT_REF: "0/1", GT_HOM_ALT: "1/1", GT_HOM_REF: "0/0", GT_REF_LIKE_NOCALL: "./.",
              GT_ALT_LIKE_NOCALL: "./.", GT_REF_AND_NOCALL: "0/.", GT_ALT_AND_NOCALL: "1/."}
 # src/lib/Pisces.Domain/Types/FilterType.cs:3-19

@@ -104,6 +104,7 @@ const char* map_genotype(int gt)   // VcfFormatter.MapGenotype :184-216
     case PISCES_GT_HEMI_ALT: return "1";
     case PISCES_GT_HEMI_NOCALL: return ".";
     case PISCES_GT_HEMI_REF: return "0";
+    case PISCES_GT_OTHERS: return "2/2";
     default: return "./.";
     }
 }
@@ -213,6 +214,8 @@ int64_t pisces_hip_format_vcf_padded(const PiscesVcfConfig* cfg, const char* chr
         const int gt = PISCES_INFO_GENOTYPE(first.info);
         const bool is_ref = PISCES_INFO_CATEGORY(first.info) == PISCES_CAT_REFERENCE;
         const bool alt12 = gt == PISCES_GT_HET_ALT1_ALT2 || gt == PISCES_GT_ALT12_LIKE_NOCALL;
+        const bool others = gt == PISCES_GT_OTHERS;   // a forced allele beside the called ones (DiploidLocusProcessor.cs:36-38)
+        const bool forced_to_report = (first.filter_bits >> PISCES_FILTER_FORCED_REPORT) & 1u;   // CalledAllele.IsForcedToReport
         // GetDepthCountInt :373-394
         int depth = is_ref ? first.reference_support : first.reference_support + first.allele_support;
         int total_variant_reads = 0, qual = first.variant_qscore, gq = first.genotype_qscore;
@@ -229,7 +232,7 @@ int64_t pisces_hip_format_vcf_padded(const PiscesVcfConfig* cfg, const char* chr
         std::string ref_allele, alt_allele;
         if (g1 - g0 == 1) {
             if (!allele_strings(g0, ref_allele, alt_allele)) return PISCES_E_INVALID_ARG;
-            if (alt12) alt_allele = phase == 1 ? alt_allele + ",<M>" : "<M>," + alt_allele;
+            if (alt12 || others) alt_allele = (phase == 1 || others) ? alt_allele + ",<M>" : "<M>," + alt_allele;
         } else {
             std::vector<std::pair<std::string, std::string>> ra((size_t)(g1 - g0));
             for (int64_t i = g0; i < g1; i++) {
@@ -250,10 +253,10 @@ int64_t pisces_hip_format_vcf_padded(const PiscesVcfConfig* cfg, const char* chr
         std::string filters;
         uint32_t seen = 0;
         // (MultiAllelicSite is added by the diploid genotyper, GenotypeCalculatorUtilities.cs:139-145, after the processor's filters
-        // and before AlleleCaller's LowGQ)
-        static const int kOrder[8] = {PISCES_FILTER_LOW_DEPTH, PISCES_FILTER_LOW_VARIANT_QSCORE, PISCES_FILTER_NO_CALL, PISCES_FILTER_STRAND_BIAS,
-                                      PISCES_FILTER_RMXN, PISCES_FILTER_LOW_VARIANT_FREQUENCY, PISCES_FILTER_MULTI_ALLELIC_SITE,
-                                      PISCES_FILTER_LOW_GENOTYPE_QUALITY};
+        // and before AlleleCaller's LowGQ; ForcedReport by AlleleCaller.cs:112-116, after the processor's filters and before the genotyper)
+        static const int kOrder[9] = {PISCES_FILTER_LOW_DEPTH, PISCES_FILTER_LOW_VARIANT_QSCORE, PISCES_FILTER_NO_CALL, PISCES_FILTER_STRAND_BIAS,
+                                      PISCES_FILTER_RMXN, PISCES_FILTER_LOW_VARIANT_FREQUENCY, PISCES_FILTER_FORCED_REPORT,
+                                      PISCES_FILTER_MULTI_ALLELIC_SITE, PISCES_FILTER_LOW_GENOTYPE_QUALITY};
         for (int64_t i = g0; i < g1; i++)
             for (int f : kOrder) {
                 if (!(recs[i].filter_bits & (1u << f)) || (seen & (1u << f))) continue;
@@ -272,6 +275,7 @@ int64_t pisces_hip_format_vcf_padded(const PiscesVcfConfig* cfg, const char* chr
                     name = "R" + std::to_string(cfg->rmxn_max_repeat_length) + "x" + std::to_string(cfg->rmxn_min_repetitions);
                     break;
                 case PISCES_FILTER_LOW_VARIANT_FREQUENCY: name = "LowVariantFreq"; break;
+                case PISCES_FILTER_FORCED_REPORT: name = "ForcedReport"; break;
                 case PISCES_FILTER_MULTI_ALLELIC_SITE: name = "MultiAllelicSite"; break;
                 default: name = "LowGQ"; break;
                 }
@@ -285,17 +289,21 @@ int64_t pisces_hip_format_vcf_padded(const PiscesVcfConfig* cfg, const char* chr
         if (is_ref) {
             ad = std::to_string(first.allele_support);
             vf = first.total_coverage == 0 ? fmt_single(0.0f, freq_decimals) : fmt_single(1.0f - freq, freq_decimals);
-        } else if (alt12) {
+        } else if (alt12 || others) {
             if (g1 - g0 > 1) {
                 for (int64_t i = g0; i < g1; i++) ad += (i > g0 ? "," : "") + std::to_string(recs[i].allele_support);
             } else {
                 const int other = depth - first.allele_support - first.reference_support;
-                ad = phase == 1 ? std::to_string(first.reference_support) + "," + std::to_string(first.allele_support) + "," + std::to_string(other)
+                ad = (phase == 1 || others) ? std::to_string(first.reference_support) + "," + std::to_string(first.allele_support) + "," + std::to_string(other)
                                 : std::to_string(first.reference_support) + "," + std::to_string(other) + "," + std::to_string(first.allele_support);
             }
-            double sum = 0.0;   // SumMultipleVF
-            for (int64_t i = g0; i < g1; i++) sum += (double)recs[i].allele_support / (double)depth;
-            vf = fmt_double(sum, freq_decimals);
+            if (others) {   // GetFrequencyString :341 names the 1/2 genotypes only
+                vf = fmt_single(freq, freq_decimals);
+            } else {
+                double sum = 0.0;   // SumMultipleVF
+                for (int64_t i = g0; i < g1; i++) sum += (double)recs[i].allele_support / (double)depth;
+                vf = fmt_double(sum, freq_decimals);
+            }
         } else {
             ad = std::to_string(first.reference_support) + "," + std::to_string(first.allele_support);
             vf = fmt_single(freq, freq_decimals);
@@ -316,7 +324,7 @@ int64_t pisces_hip_format_vcf_padded(const PiscesVcfConfig* cfg, const char* chr
             sample += ":" + fmt_single(nc, 4);
         }
         text += chrom;
-        text += "\t" + std::to_string(first.position) + "\t.\t" + ref_allele + "\t" + (ref_like_gt ? std::string(".") : alt_allele) + "\t" +
+        text += "\t" + std::to_string(first.position) + "\t.\t" + ref_allele + "\t" + ((ref_like_gt && !forced_to_report) ? std::string(".") : alt_allele) + "\t" +
                 std::to_string(qual) + "\t" + filters + "\tDP=" + std::to_string(depth) + "\t" + format + "\t" + sample + "\n";
         st.last_variant_position_written = first.position;
         g0 = g1;

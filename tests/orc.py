@@ -484,18 +484,34 @@ def run_reads_blocks(batch, ref, region_start, region_loci, cfg):
     return out[:n], [(full[i].ref.decode(), full[i].alt.decode()) for i in range(n)], total.value
 
 
-def run_reads_schedule(batch, ref, region_start, region_loci, cfg, up_to_positions):
+def run_reads_schedule(batch, ref, region_start, region_loci, cfg, up_to_positions, forced=()):
     """run_reads_full with GetCandidatesToProcess(upTo) for every upTo of the list and then the final batch (RegionStateManager.cs:283-334,
-    with AddCollapsableFromOtherBlocks)."""
+    with AddCollapsableFromOtherBlocks); forced = [(position, ref, alt)] forced genotyping alleles of the chromosome."""
     refa = np.ascontiguousarray(ref, np.uint8)
     cap = region_loci * 5 + 16
     out = np.zeros(cap, dtype=_abi.CALLED_ALLELE_DTYPE)
     full = (OrcCalled * cap)()
     total = C.c_int64(0)
     ups = np.ascontiguousarray(up_to_positions, np.int32)
+    fa = (OrcCandidate * max(len(forced), 1))(*[make_candidate(p, 0, r, a) for (p, r, a) in forced])   # (the oracle derives the category)
+    cap += len(forced)
+    out = np.zeros(cap, dtype=_abi.CALLED_ALLELE_DTYPE)
+    full = (OrcCalled * cap)()
     lib.orc_run_reads_schedule.restype = C.c_int64
     n = lib.orc_run_reads_schedule(C.byref(batch.c), refa.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int64(len(refa)), C.c_int32(region_start),
                                    C.c_int32(region_loci), C.byref(cfg), ups.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int32(len(ups)),
-                                   C.c_void_p(out.ctypes.data), C.c_int64(cap), full, C.byref(total))
+                                   fa, C.c_int32(len(forced)), C.c_void_p(out.ctypes.data), C.c_int64(cap), full, C.byref(total))
     assert n >= 0, n
     return out[:n], [(full[i].ref.decode(), full[i].alt.decode()) for i in range(n)], total.value
+
+
+def diploid_locus_process(alleles):
+    """DiploidLocusProcessor.Process on [{category, genotype, gq, forced}]; returns [(genotype, gq)]."""
+    n = len(alleles)
+    arr = (OrcCalled * max(n, 1))()
+    for i, d in enumerate(alleles):
+        arr[i].category, arr[i].genotype, arr[i].genotype_qscore = d["category"], d["genotype"], d["gq"]
+        arr[i].filters = (1 << _abi.FILTER_FORCED_REPORT) | (1 << _abi.FILTER_LOW_DEPTH) if d.get("forced") else 0
+    lib.orc_diploid_locus_process.restype = None
+    lib.orc_diploid_locus_process(arr, C.c_int32(n))
+    return [(arr[i].genotype, arr[i].genotype_qscore) for i in range(n)]

@@ -717,3 +717,55 @@ def test_schedule_collapses_the_open_left_base_of_the_next_block_into_the_mnv():
     flat = orc.run_reads_schedule(batch, refa, 1, len(ref), _abi.default_config(call_mnvs=1, collapse=0), [1500, 2600])
     flat_blocks = orc.run_reads_blocks(batch, refa, 1, len(ref), _abi.default_config(call_mnvs=1, collapse=0))
     assert rows(flat) == rows(flat_blocks)
+
+
+# ---- forced genotyping (-forcedalleles): ForcedGTFxnlTest.RunForcedGT ------------------------------------------------------------
+FORCED_GT = load("forced_gt.json")
+
+
+@pytest.mark.parametrize("run", ["noisy", "forced1", "forced2"])
+def test_forced_gt_functional_test_vcfs(run):
+    """ForcedGTFxnlTest.RunForcedGT (ForcedGTFxnlTest.cs:10-124) on PhiX_S3.bam: -c 2 -minbq 10 -minvf 0.00001 -nl 40 -callMNVs
+    -maxmnvlength 10 -maxgapbetweenmnv 5 -ncfilter 1, first without forced alleles (-minvq 1), then with the nine alleles of
+    PhiX_S3.forcedGTInput.vcf (-minvq 1: three of them are not in the reads and come out as ForcedReport rows without support), then
+    with -minvq 20 (the noise-level MNVs among them fail, are reallocated AND reported; Reference rows stay beside forced rows).
+    The oracle runs the reads of the BAM through the block schedule; pisces_hip_format_vcf writes the rows: byte for byte the body
+    lines of PhiX_S3.noisy.vcf / Forced1.vcf / Forced2.vcf (the files hold the first 76 positions)."""
+    from pisces_amd import engine
+    from tests import bam_fixtures
+    r = FORCED_GT["runs"][run]
+    z, batch = bam_fixtures.load("bam_phix")
+    cfg = _abi.default_config(**forced_gt_config(r["min_variant_qscore"]))
+    forced = [tuple(f) for f in FORCED_GT["forced"]] if r["forced"] else []
+    recs, alleles, _ = orc.run_reads_schedule(batch, z["ref"], 1, len(z["ref"]), cfg, [1500, 2500, 3500, 4500], forced=forced)
+    text = engine.format_vcf("phix", recs, alleles=alleles, noise_level_from_records=1, noise_level=40, min_frequency_threshold=0.00001)
+    last = int(r["lines"][-1].split("\t")[1])
+    got = [l for l in text.rstrip("\n").split("\n") if int(l.split("\t")[1]) <= last]
+    assert got == r["lines"]
+
+
+def forced_gt_config(min_variant_qscore):
+    # (-minvf also sets the frequency filter, the genotyper's frequency and the LOD target: VariantCallingParameters.cs:134-156; the
+    # functional-test harness skips Validate(), which leaves LowDepthFilter null: see tests/bam_fixtures.py)
+    return dict(low_depth_filter=-1, min_coverage=2, min_base_call_quality=10, min_variant_qscore=min_variant_qscore, min_frequency=0.00001,
+                variant_freq_filter=0.00001, genotype_min_freq_filter=0.00001, target_lod_frequency=0.00001, noise_level=40, call_mnvs=1,
+                max_mnv_length=10, max_gap_between_mnv=5, no_call_filter_threshold=1.0)
+
+
+def test_diploid_locus_processor_cases():
+    """DiploidLocusProcessorTests.cs:11-125, the four cases: a forced allele at a reference site, at a no-call site, beside a
+    heterozygous call, and the genotype q-score of the whole position = the smallest of the alleles that were not forced."""
+    SNV, INS, REF = _abi.CAT_SNV, _abi.CAT_INSERTION, _abi.CAT_REFERENCE
+    forced = dict(category=SNV, genotype=_abi.GT_ALT_LIKE_NOCALL, gq=10, forced=True)
+    got = orc.diploid_locus_process([forced, dict(category=REF, genotype=_abi.GT_HOM_REF, gq=100)])
+    assert got[0] == (_abi.GT_HOM_REF, 100)
+    got = orc.diploid_locus_process([forced, dict(category=INS, genotype=_abi.GT_ALT_LIKE_NOCALL, gq=20)])
+    assert got[0] == (_abi.GT_ALT_LIKE_NOCALL, 20)
+    got = orc.diploid_locus_process([forced, dict(category=INS, genotype=_abi.GT_HET_ALT_REF, gq=40)])
+    assert got[0] == (_abi.GT_OTHERS, 40)
+    got = orc.diploid_locus_process([forced, dict(category=INS, genotype=_abi.GT_HET_ALT1_ALT2, gq=40),
+                                     dict(category=INS, genotype=_abi.GT_HET_ALT1_ALT2, gq=100)])
+    assert [g[1] for g in got] == [40, 40, 40] and got[0][0] == _abi.GT_OTHERS
+    # no forced allele: nothing changes (Process returns early)
+    assert orc.diploid_locus_process([dict(category=INS, genotype=_abi.GT_HET_ALT_REF, gq=40), dict(category=SNV, genotype=_abi.GT_HOM_ALT, gq=7)]) == \
+        [(_abi.GT_HET_ALT_REF, 40), (_abi.GT_HOM_ALT, 7)]
