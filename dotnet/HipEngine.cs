@@ -114,8 +114,49 @@ namespace Pisces.Hip
             _seqOff.Add(_bases.Count);
         }
 
-        /// with MNV calling off the library finds every candidate itself; nothing of the managed finder's output is needed
-        public void KeepNonSnvCandidates(IEnumerable<CandidateAllele> candidates) { }
+        /// IStateManager.AddCandidates: the library finds the candidates of the reads itself (NoCandidates is the managed finder), so what
+        /// arrives here is what the caller makes on its own: the forced alleles of SmallVariantCaller.AddForcedAlleleAsCandidate
+        /// (SmallVariantCaller.cs:118-139).  They go to the state through pisces_hip_add_candidates (ahead of the reads still staged: a
+        /// forced allele carries no support, so its place among the candidates of a position decides nothing).
+        public void AddCandidates(IEnumerable<CandidateAllele> candidates)
+        {
+            var list = new List<CandidateAllele>(candidates);
+            if (list.Count == 0) return;
+            PiscesCandidate[] c; byte[] pool;
+            Pack(list.ConvertAll(a => Tuple.Create(a.ReferencePosition, a.ReferenceAllele, a.AlternateAllele)), list, out c, out pool);
+            NativeMethods.Check(_h, NativeMethods.pisces_hip_add_candidates(_h, c, c.LongLength, pool, pool.LongLength));
+        }
+
+        /// AlleleCaller.AddForcedGtAlleles (Factory.cs:187) + RegionState's reference rows at forced positions: the (chr, pos, ref, alt) set
+        /// Factory.SelectForcedAllele picked for this chromosome.  After SetIntervals, before the first flush.
+        public void SetForcedAlleles(HashSet<Tuple<string, int, string, string>> forced)
+        {
+            if (forced == null || forced.Count == 0) return;
+            var triples = new List<Tuple<int, string, string>>();
+            foreach (var f in forced) triples.Add(Tuple.Create(f.Item2, f.Item3, f.Item4));
+            PiscesCandidate[] c; byte[] pool;
+            Pack(triples, null, out c, out pool);
+            NativeMethods.Check(_h, NativeMethods.pisces_hip_set_forced_alleles(_h, c, c.LongLength, pool, pool.LongLength));
+        }
+
+        private static void Pack(List<Tuple<int, string, string>> alleles, List<CandidateAllele> full, out PiscesCandidate[] c, out byte[] pool)
+        {
+            c = new PiscesCandidate[alleles.Count];
+            var bytes = new List<byte>();
+            for (int i = 0; i < c.Length; i++)
+            {
+                c[i].Position = alleles[i].Item1; c[i].RefLen = alleles[i].Item2.Length; c[i].AltLen = alleles[i].Item3.Length;
+                c[i].AlleleOffset = bytes.Count;
+                bytes.AddRange(Encoding.ASCII.GetBytes(alleles[i].Item2)); bytes.AddRange(Encoding.ASCII.GetBytes(alleles[i].Item3));
+                if (full == null) continue;
+                var a = full[i];
+                c[i].Category = a.Type == AlleleCategory.Snv ? 0 : a.Type == AlleleCategory.Insertion ? 1 : a.Type == AlleleCategory.Deletion ? 2 : 3;   // PISCES_CAT_*
+                c[i].SupF = a.SupportByDirection[0]; c[i].SupR = a.SupportByDirection[1]; c[i].SupS = a.SupportByDirection[2];
+                c[i].AnchoredF = a.WellAnchoredSupportByDirection[0]; c[i].AnchoredR = a.WellAnchoredSupportByDirection[1]; c[i].AnchoredS = a.WellAnchoredSupportByDirection[2];
+                c[i].OpenLeft = (byte)(a.OpenOnLeft ? 1 : 0); c[i].OpenRight = (byte)(a.OpenOnRight ? 1 : 0);
+            }
+            pool = bytes.ToArray();
+        }
 
         public unsafe void FlushStagedReads(ChrReference chrReference)
         {

@@ -17,6 +17,7 @@ namespace Pisces.Hip
     public class HipFactory : Pisces.Logic.Factory
     {
         private HipEngine _engine;   // one per (BAM, chromosome) job, created in CreateStateManager
+        private HashSet<Tuple<string, int, string, string>> _forcedGtAlleles;   // of that job (Factory.cs:260-262 makes the caller first)
 
         public HipFactory(PiscesApplicationOptions options) : base(options) { }
 
@@ -30,12 +31,14 @@ namespace Pisces.Hip
         {
             _engine = new HipEngine(HipEngine.ConfigFrom(_options, expectStitchedReads, intervalSet != null), device: 0);
             if (intervalSet != null) _engine.SetIntervals(intervalSet);
+            _engine.SetForcedAlleles(_forcedGtAlleles);   // -forcedalleles: ForcedReport rows, reference rows at forced positions
             return new HipStateManager(_engine);
         }
 
         protected override IAlleleCaller CreateVariantCaller(ChrReference chrReference, ChrIntervalSet intervalSet,
             IAlignmentSource alignmentSource, HashSet<Tuple<string, int, string, string>> forceGtAlleles = null)
         {
+            _forcedGtAlleles = forceGtAlleles;
             return new HipAlleleCaller(() => _engine, chrReference);
         }
     }
@@ -55,7 +58,9 @@ namespace Pisces.Hip
         private readonly HipEngine _e;
         public HipStateManager(HipEngine e) { _e = e; }
         public void AddAlleleCounts(Read read) { _e.StageRead(read); }                       // copies out: the Read object is reused (AlignmentsSource.cs:21,61)
-        public void AddCandidates(IEnumerable<CandidateAllele> candidates) { _e.KeepNonSnvCandidates(candidates); }
+        // SmallVariantCaller hands the forced alleles in here itself (AddForcedAlleleAsCandidate); the library also adds them at flush
+        // time from pisces_hip_set_forced_alleles, and a second copy without support merges into the first (RegionState.AddCandidate)
+        public void AddCandidates(IEnumerable<CandidateAllele> candidates) { _e.AddCandidates(candidates); }
         private int _lastUpToBlockKey = -1;
         public ICandidateBatch GetCandidatesToProcess(int? upToPosition, ChrReference chrReference = null,
             HashSet<Tuple<string, int, string, string>> forcedGtAlleles = null)

@@ -312,6 +312,20 @@ int32_t pisces_hip_add_gapped_mnv_ref(PiscesHip* h, const int32_t* positions, co
 int32_t pisces_hip_get_candidates(PiscesHip* h, int32_t up_to_position, PiscesCandidate* out,
                                   int64_t capacity, int64_t* n_out, uint8_t* alleles,
                                   int64_t allele_capacity, int64_t* allele_bytes);
+/* IStateManager.AddCandidates (src/lib/Pisces.Domain/Interfaces/IStateManager.cs; RegionStateManager.cs:83-116) for candidates the caller
+ * brings itself: merged with the candidates the library finds in the reads by RegionState.AddCandidate's rules (RegionState.cs:94-174).
+ * cands[i].allele_offset / ref_len / alt_len index `alleles` (ref bytes then alt bytes), as pisces_hip_get_candidates writes them. */
+int32_t pisces_hip_add_candidates(PiscesHip* h, const PiscesCandidate* cands, int64_t n, const uint8_t* alleles, int64_t allele_bytes);
+/* Forced genotyping (-forcedalleles; Factory.GetForcedAlleles :56-96 + SelectForcedAllele :270-286, src/exe/Pisces/Logic/Factory.cs): the
+ * alleles of this chromosome that are reported whatever the reads say.  Only position and the allele strings are read (the category
+ * is SmallVariantCaller.GetAlleleCategory's, SmallVariantCaller.cs:141-150); alleles equal to the reference, with an ALT outside
+ * A/C/G/T or outside the intervals of pisces_hip_set_intervals are dropped as the reference drops them.  From then on every flush first
+ * adds the forced alleles up to upTo as candidates without support (AddForcedAlleleAsCandidate :118-132), reports a forced allele that
+ * is not callable with PISCES_FILTER_FORCED_REPORT, genotype 0/1 and genotype q-score 0 (AlleleCaller.cs:98-131, 143-170), keeps the
+ * Reference row beside it, and when include_reference_calls is off makes Reference rows at the forced positions
+ * (RegionState.GetAllCandidates :393-450).  With the diploid model DiploidLocusProcessor's rules apply (PISCES_GT_OTHERS).  Call it
+ * after pisces_hip_set_intervals and before the first flush. */
+int32_t pisces_hip_set_forced_alleles(PiscesHip* h, const PiscesCandidate* alleles_of, int64_t n, const uint8_t* alleles, int64_t allele_bytes);
 /* totals lines: {allelesCalled (IAlleleCaller.TotalNumCalled), variantsCollapsed, readsProcessed,
  * observations} (SmallVariantCaller.cs:114-115) */
 int32_t pisces_hip_stats(PiscesHip* h, int64_t out[4]);

@@ -265,14 +265,19 @@ __device__ inline bool finish_allele(const PointCounts& c, int pos, int a, bool 
 }
 
 // One lane, one allele, start to finish. Returns false (record untouched) when the reference would drop the allele.
-template <bool kDiploidOk = false>
+// kFinishAnyway: the record is made even then (a forced allele is reported whether it is callable or not, AlleleCaller.cs:109-131).
+template <bool kDiploidOk = false, bool kFinishAnyway = false>
 __device__ inline bool process_point_allele(const PointCounts& c, int pos, int a, bool isRef, int rt,
                                              const uint8_t* __restrict__ ref, int64_t win_lo, int64_t win_hi,
                                              const DeviceParams& P, PiscesCalledAllele& r,
                                              const uint8_t* s_refwin = nullptr, int s_refidx = 0, const GqTail* pre_tail = nullptr,
                                              const int32_t* window_level_ = nullptr /* NoiseModel.Window: the allele's own noise level (kNoLevel = q-score 0) */)
 {
-    if (!isRef && !variant_passes_frequency(c, P)) return false;
+    bool callable = true;
+    if (!isRef && !variant_passes_frequency(c, P)) {
+        if (!kFinishAnyway) return false;
+        callable = false;
+    }
     int vq = 0;
     if (window_level_) {
         const double werr = window_err_of_level(*window_level_, P);
@@ -281,13 +286,16 @@ __device__ inline bool process_point_allele(const PointCounts& c, int pos, int a
 #if !(defined(PISCES_ABLATE_MATH) && (PISCES_ABLATE_MATH == 5 || PISCES_ABLATE_MATH == 9))
     if (c.support > 0 && c.total != 0) vq = poisson_qscore(c.support, c.total, P);   // VariantQualityCalculator.Compute :11-24
 #endif
-    if (!isRef && vq < P.min_vq) return false;
+    if (!isRef && vq < P.min_vq) {
+        if (!kFinishAnyway) return false;
+        callable = false;
+    }
     SbResult sb = {0.0, 0, 0, 0};
 #if !(defined(PISCES_ABLATE_MATH) && (PISCES_ABLATE_MATH == 4 || PISCES_ABLATE_MATH == 9))
     if (c.support > 0) sb = strand_bias<kDiploidOk>(c.cov, c.sup, P);                // StrandBiasCalculator.Compute :10-15
 #endif
     finish_allele(c, pos, a, isRef, rt, vq, sb, ref, win_lo, win_hi, P, r, s_refwin, s_refidx, pre_tail, nullptr, window_level_);
-    return true;
+    return callable;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1309,7 +1317,7 @@ __global__ __launch_bounds__(64) void call_spanning_kernel(
                 for (int k = 0; k < 5; k++) sum += get_base_quality_sum(sumq, c.start_idx, cca[k], d, 0, -1, false);
             wlevel = window_level(sum, pc.total);
         }
-        const bool ok = process_point_allele<true>(pc, c.position, a, isRef, rt, ref, 0, ref_len, P, r, nullptr, 0, nullptr, sumq ? &wlevel : nullptr);
+        const bool ok = process_point_allele<true, true>(pc, c.position, a, isRef, rt, ref, 0, ref_len, P, r, nullptr, 0, nullptr, sumq ? &wlevel : nullptr);
         out[i] = r;
         callable_out[i] = ok ? 1 : 0;
         return;

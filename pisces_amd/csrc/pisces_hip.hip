@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <string>
 #include <atomic>
 #include <mutex>
@@ -144,6 +145,12 @@ struct PiscesHip {
     BlockObs* last_block = nullptr;       // "performance improvement to remember last block" (:366)
     int32_t last_up_to_block_key = 0;
     std::unordered_map<int32_t, int32_t> gapped_mnv_ref;
+    // forced genotyping alleles of this chromosome (pisces_hip_set_forced_alleles), in position order; the first n_forced_added have
+    // been handed to the state as candidates (SmallVariantCaller.AddForcedAlleleAsCandidate)
+    std::vector<HostCandidate> forced;
+    size_t n_forced_added = 0;
+    std::set<std::string> forced_keys;        // position|ref>alt (AlleleCaller.IsForcedAllele)
+    std::set<int32_t> forced_positions;       // RegionState.CreateIntervalsFromAllels
     std::vector<std::pair<int32_t, int32_t>> intervals;   // sorted, disjoint [start, end]
     int64_t stats[4] = {0, 0, 0, 0};      // called, collapsed, reads, observations
 
@@ -706,6 +713,95 @@ static void add_candidate(PiscesHip* h, const HostCandidate& cnd)
     else if (cnd.category == PISCES_CAT_INSERTION) other_end = cnd.position + 1;
     else if (cnd.category == PISCES_CAT_MNV) other_end = cnd.position + (int32_t)cnd.ref.size() - 1;
     if (other_end > b->max_allele_endpoint) b->max_allele_endpoint = other_end;
+}
+
+static std::string forced_key(int32_t position, const std::string& ref, const std::string& alt)
+{
+    return std::to_string(position) + "|" + ref + ">" + alt;
+}
+static bool is_forced_allele(const PiscesHip* h, const HostCandidate& c)   // AlleleCaller.IsForcedAllele (AlleleCaller.cs:179-184)
+{
+    return !h->forced_keys.empty() && h->forced_keys.count(forced_key(c.position, c.ref, c.alt)) != 0;
+}
+
+static int32_t host_candidates_of(PiscesHip* h, const PiscesCandidate* cands, int64_t n, const uint8_t* alleles, int64_t allele_bytes,
+                                  std::vector<HostCandidate>& out, const char* what)
+{
+    if (n < 0 || (n > 0 && (!cands || !alleles))) return fail(h, PISCES_E_INVALID_ARG, std::string(what) + ": null input");
+    for (int64_t i = 0; i < n; i++) {
+        const PiscesCandidate& c = cands[i];
+        if (c.position <= 0 || c.ref_len <= 0 || c.alt_len <= 0 || c.allele_offset < 0 || c.allele_offset + c.ref_len + c.alt_len > allele_bytes ||
+            c.category < PISCES_CAT_SNV || c.category > PISCES_CAT_MNV)
+            return fail(h, PISCES_E_INVALID_ARG, std::string(what) + ": bad candidate");
+        HostCandidate hc;
+        hc.position = c.position;
+        hc.category = c.category;
+        hc.ref.assign((const char*)alleles + c.allele_offset, (size_t)c.ref_len);
+        hc.alt.assign((const char*)alleles + c.allele_offset + c.ref_len, (size_t)c.alt_len);
+        for (int d = 0; d < 3; d++) { hc.support_by_dir[d] = c.support_by_dir[d]; hc.well_anchored_by_dir[d] = c.well_anchored_by_dir[d]; }
+        hc.open_left = c.open_left != 0;
+        hc.open_right = c.open_right != 0;
+        out.push_back(std::move(hc));
+    }
+    return PISCES_OK;
+}
+
+// IStateManager.AddCandidates (IStateManager.cs; RegionStateManager.cs:83-116) for candidates the caller brings itself
+int32_t pisces_hip_add_candidates(PiscesHip* h, const PiscesCandidate* cands, int64_t n, const uint8_t* alleles, int64_t allele_bytes)
+{
+    if (!h) return PISCES_E_INVALID_ARG;
+    { int32_t rcf = consume_found(h); if (rcf) return rcf; }   // keep the arrival order: what the reads gave so far comes first
+    std::vector<HostCandidate> list;
+    int32_t rc = host_candidates_of(h, cands, n, alleles, allele_bytes, list, "add_candidates");
+    if (rc) return rc;
+    for (auto& c : list) add_candidate(h, c);
+    return PISCES_OK;
+}
+
+// -forcedalleles (Factory.GetForcedAlleles :56-96, SelectForcedAllele :270-286; SmallVariantCaller.CreateForcedAllelePos :49-77): the
+// alleles to report whatever the reads say.  Categories are SmallVariantCaller.GetAlleleCategory's (:141-150), support is ignored.
+int32_t pisces_hip_set_forced_alleles(PiscesHip* h, const PiscesCandidate* cands, int64_t n, const uint8_t* alleles, int64_t allele_bytes)
+{
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (h->n_forced_added > 0) return fail(h, PISCES_E_INVALID_ARG, "set_forced_alleles: some forced alleles are candidates already");
+    std::vector<HostCandidate> list;
+    int32_t rc = host_candidates_of(h, cands, n, alleles, allele_bytes, list, "set_forced_alleles");
+    if (rc) return rc;
+    h->forced.clear();
+    h->forced_keys.clear();
+    h->forced_positions.clear();
+    for (auto& c : list) {
+        // IsValidAlt :88-96
+        if (c.ref == c.alt) continue;
+        bool acgt = true;
+        for (char ch : c.alt) acgt = acgt && (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T');
+        if (!acgt) continue;
+        if (!h->intervals.empty()) {   // SelectForcedAllele: inside the intervals only
+            bool inside = false;
+            for (auto& iv : h->intervals) inside = inside || (c.position >= iv.first && c.position <= iv.second);
+            if (!inside) continue;
+        }
+        c.category = (c.ref.size() == 1 && c.alt.size() == 1) ? PISCES_CAT_SNV : c.ref.size() == c.alt.size() ? PISCES_CAT_MNV
+                     : c.ref.size() > c.alt.size() ? PISCES_CAT_DELETION : PISCES_CAT_INSERTION;
+        for (int d = 0; d < 3; d++) c.support_by_dir[d] = c.well_anchored_by_dir[d] = 0;
+        c.open_left = c.open_right = false;
+        if (!h->forced_keys.insert(forced_key(c.position, c.ref, c.alt)).second) continue;   // a HashSet
+        h->forced_positions.insert(c.position);
+        h->forced.push_back(c);
+    }
+    std::stable_sort(h->forced.begin(), h->forced.end(), [](const HostCandidate& a, const HostCandidate& b) { return a.position < b.position; });
+    return PISCES_OK;
+}
+
+// SmallVariantCaller.AddForcedAlleleAsCandidate :118-132, before GetCandidatesToProcess(upTo)
+static void add_forced_as_candidates(PiscesHip* h, int32_t up_to_position)
+{
+    while (h->n_forced_added < h->forced.size()) {
+        const HostCandidate& c = h->forced[h->n_forced_added];
+        if (up_to_position >= 0 && c.position > up_to_position) break;
+        add_candidate(h, c);
+        h->n_forced_added++;
+    }
 }
 
 // Candidate discovery for a read batch that is on the device (find_count / found_scan / find_emit kernels), enqueued on the handle's
@@ -1817,11 +1913,26 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
     };
     // the collapser's frequencies and the reallocator's Reference candidates read a host copy of the anchor-resolved counts
     std::vector<int32_t> host_counts;
-    if (h->cfg.collapse || mnv_mode) {
+    const bool have_forced = !h->forced.empty();
+    if (h->cfg.collapse || mnv_mode || have_forced) {
         host_counts.assign((size_t)std::max(n_tiles, 1) * kTile * PISCES_COUNTS_PER_LOCUS, 0);
         if (n_tiles > 0) {
             PISCES_HIP_CHECK(h, hipMemcpyAsync(host_counts.data(), h->d_counts.p, host_counts.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
             PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+        }
+    }
+    if (!mnv_mode && have_forced) {
+        // MNV calling off: SNV candidates are the allele counts and never reach the host, so a forced SNV (added without support) takes
+        // the support the merged candidate of the reference has: the reads that show the base at or above the quality threshold
+        for (auto& c : work) {
+            if (c.category != PISCES_CAT_SNV || cand_support(c) != 0 || !is_forced_allele(h, c)) continue;
+            const int64_t li = locus_index(c.position);
+            const int at = atype(c.alt[0]);
+            if (li < 0 || at >= 4) continue;
+            for (int d = 0; d < 3; d++) {
+                const int32_t* row = host_counts.data() + li * PISCES_COUNTS_PER_LOCUS + (at * 3 + d) * PISCES_NUM_ANCHORS;
+                for (int an = 0; an < PISCES_NUM_ANCHORS; an++) c.support_by_dir[d] += row[an];
+            }
         }
     }
     if (h->cfg.collapse) {
@@ -1920,7 +2031,9 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
             // match (OverlapMatches); their AlleleSupport (the reference base's counts) decides the order among one-base overlaps
             const int32_t last_cleared = keys.back() * bs;
             auto ref_candidate_exists = [&](int32_t p, int32_t (&sup)[3]) {
-                if (!h->cfg.include_reference_calls || p < 1 || p > h->ref_len || !inside_intervals(p)) return false;
+                // (not a gVCF: Reference candidates exist at the positions of the forced alleles only, RegionState.cs:393-396)
+                const bool forced_here = !h->cfg.include_reference_calls && h->forced_positions.count(p) != 0;
+                if (!(h->cfg.include_reference_calls || forced_here) || p < 1 || p > h->ref_len || !inside_intervals(p)) return false;
                 if (!std::binary_search(keys.begin(), keys.end(), block_key(h, p))) return false;
                 const int64_t li = locus_index(p);
                 const int rb = atype((char)h->h_ref[(size_t)p - 1]);
@@ -1935,7 +2048,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
                             if (at == rb) sup[d] = cnt;
                             total += cnt;
                         }
-                return h->cfg.emit_zero_coverage_refs != 0 || total > 0;   // RegionState.cs:446
+                return h->cfg.emit_zero_coverage_refs != 0 || forced_here || total > 0;   // RegionState.cs:446
             };
             for (CandPtr f : failed)
                 for (size_t k = 0; k < f->alt.size(); k++) {
@@ -1976,9 +2089,27 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
             for (size_t k = 0; k < a->ref.size() && k < a->alt.size(); k++)
                 if (a->ref[k] == a->alt[k]) h->gapped_mnv_ref[a->position + (int32_t)k] += support;
         }
+        // a failed MNV that is a forced allele is reported all the same (AlleleCaller.cs:98-107)
+        if (have_forced)
+            for (CandPtr f : failed)
+                if (is_forced_allele(h, *f)) callable_alleles.push_back(f);
         for (CandPtr a : callable_alleles) {
             if (a->category == PISCES_CAT_REFERENCE && cand_support(*a) == 0) continue;   // untouched: the tile kernels' record stands
             final_list.push_back(a);
+        }
+    }
+    // not a gVCF, forced alleles given: Reference candidates at the forced positions of the cleared blocks, with or without coverage
+    // (RegionState.GetAllCandidates :393-450 with CreateIntervalsFromAllels); the candidate kernel makes their records from the counts
+    if (have_forced && !h->cfg.include_reference_calls) {
+        static const int32_t kNone[3] = {0, 0, 0};
+        for (int32_t p : h->forced_positions) {
+            if (p < 1 || p > h->ref_len || !inside_intervals(p) || !std::binary_search(keys.begin(), keys.end(), block_key(h, p))) continue;
+            if (touched_refs.count(p)) {
+                if (cand_support(*touched_refs[p]) != 0) continue;   // in the list already, with what reallocation added
+            } else {
+                touched_refs[p] = arena.make(p, std::string(1, (char)h->h_ref[(size_t)p - 1]), std::string(1, (char)h->h_ref[(size_t)p - 1]), kNone);
+            }
+            final_list.push_back(touched_refs[p]);
         }
     }
 
@@ -1986,14 +2117,31 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
     int32_t rc2 = device_pass(final_list);
     if (rc2) return rc2;
     for (size_t i = 0; i < final_list.size(); i++) {
-        if (final_list[i]->category == PISCES_CAT_REFERENCE) {   // counted as called by the tile kernels already
+        if (final_list[i]->category == PISCES_CAT_REFERENCE) {   // counted as called by the tile kernels already (gVCF)
             ref_overrides.push_back(raw[i]);
             continue;
         }
-        if (!callable[i]) continue;
-        (*n_called)++;
-        if (!inside_intervals(final_list[i]->position)) continue;
-        recs.push_back(raw[i]);
+        // AlleleCaller.cs:109-131: a forced allele is reported whether it is callable or not; IsCallable runs once in the test for
+        // IsForcedToReport and once in the test for reporting, and counts a callable forced allele twice in TotalNumCalled
+        const bool forced = have_forced && is_forced_allele(h, *final_list[i]);
+        const bool reportable = callable[i] && inside_intervals(final_list[i]->position);
+        if (callable[i]) (*n_called) += forced ? 2 : 1;
+        if (forced && !mnv_mode && final_list[i]->category == PISCES_CAT_SNV && reportable) {   // MNV calling off: the tile kernels report it,
+            (*n_called)--;                                                                        // and have counted it once
+            continue;
+        }
+        if (!reportable && !forced) continue;
+        PiscesCalledAllele r = raw[i];
+        if (forced && !reportable) {
+            // IsForcedToReport: the ForcedReport filter, and no genotyper sees the allele (:150): the genotype of a new CalledAllele
+            // (CalledAllele.cs:151) and genotype q-score 0, against which AlleleCaller's LowGQ filter is taken (:166-170)
+            uint32_t fb = (r.filter_bits | (1u << PISCES_FILTER_FORCED_REPORT)) & ~(1u << PISCES_FILTER_LOW_GENOTYPE_QUALITY);
+            if (h->cfg.low_gq_filter >= 0 && 0.0f < (float)h->cfg.low_gq_filter) fb |= 1u << PISCES_FILTER_LOW_GENOTYPE_QUALITY;
+            r.filter_bits = (uint16_t)fb;
+            r.info = (uint16_t)((r.info & ~0xFu) | (uint32_t)PISCES_GT_HET_ALT_REF);
+            r.genotype_qscore = 0;
+        }
+        recs.push_back(r);
         called.push_back(*final_list[i]);
     }
     return PISCES_OK;
@@ -2015,6 +2163,7 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
     if (!replay) {
         // GetCandidatesToProcess (RegionStateManager.cs:283-334): only build a batch when upTo has moved
         // onto another block; take blocks that lie wholly at or below upTo.
+        add_forced_as_candidates(h, final_flush ? -1 : up_to_position);   // SmallVariantCaller.cs:101-108: before Call(upTo)
         if (!final_flush && block_key(h, up_to_position) == h->last_up_to_block_key) return PISCES_OK;
         std::vector<int32_t> keys;
         for (auto& kv : h->blocks) {   // std::map: ascending keys
@@ -2042,8 +2191,12 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
             for (auto& r : point_recs) {
                 if (PISCES_INFO_CATEGORY(r.info) != PISCES_CAT_REFERENCE) continue;
                 auto it = by_pos.find(r.position);
-                if (it != by_pos.end()) r = *it->second;
+                if (it != by_pos.end()) { r = *it->second; by_pos.erase(it); }
             }
+            // not a gVCF: the Reference alleles at forced positions have no tile-kernel record to replace; they are rows (and calls,
+            // AlleleCaller.IsCallable) of their own
+            if (!h->cfg.include_reference_calls)
+                for (auto& kv : by_pos) { point_recs.push_back(*kv.second); called++; }
         }
         // per locus: drop the Reference row when a variant is reported there (AlleleCaller.cs:146-147), then order by
         // position, reference allele, alternate allele (:172-176; ordinal order of upper-case ASCII allele strings)
@@ -2051,15 +2204,21 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
         h->pending_cand_index.clear();
         h->pending_cands = span_cands;
         const bool diploid = h->cfg.ploidy == PISCES_PLOIDY_DIPLOID || h->cfg.ploidy == PISCES_PLOIDY_HAPLOID;   // per-locus genotypers
-        if (span_recs.empty() && !diploid) {
+        if (span_recs.empty() && !diploid && h->forced.empty()) {
             h->pending = std::move(point_recs);
             h->pending_cand_index.assign(h->pending.size(), -1);
         } else {
             struct Row { const PiscesCalledAllele* r; int32_t ci; std::string ref, alt; };
             static const char kBase[6] = {'A', 'G', 'C', 'T', 'N', 'D'};
             std::vector<Row> rows;
+            // (a variant that is only there because it was forced prunes nothing: AlleleCaller.cs:146)
+            auto forced_to_report = [](const PiscesCalledAllele& r) { return ((r.filter_bits >> PISCES_FILTER_FORCED_REPORT) & 1u) != 0; };
             std::vector<int32_t> variant_pos;
-            for (auto& r : span_recs) variant_pos.push_back(r.position);
+            for (auto& r : span_recs)
+                if (!forced_to_report(r)) variant_pos.push_back(r.position);
+            if (!h->forced.empty())   // forced alleles given: Reference rows can come from the candidate kernel, beside the tile kernels' SNV rows
+                for (auto& r : point_recs)
+                    if (PISCES_INFO_CATEGORY(r.info) != PISCES_CAT_REFERENCE) variant_pos.push_back(r.position);
             std::sort(variant_pos.begin(), variant_pos.end());
             for (auto& r : point_recs) {
                 const bool is_ref = PISCES_INFO_CATEGORY(r.info) == PISCES_CAT_REFERENCE;
@@ -2080,11 +2239,14 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
                 // device's somatic genotype fields are replaced.  (Reference rows at variant loci are gone already, rows are in
                 // (ref, alt) order.)
                 std::vector<DiploidAllele> at;
+                std::vector<size_t> at_row;
                 for (size_t i = 0; i < rows.size();) {
                     size_t j = i;
                     while (j < rows.size() && rows[j].r->position == rows[i].r->position) j++;
                     at.clear();
+                    at_row.clear();
                     for (size_t k = i; k < j; k++) {
+                        if (forced_to_report(*rows[k].r)) continue;   // the genotyper does not see alleles that are only there because they were forced (:150)
                         DiploidAllele a;
                         a.category = PISCES_INFO_CATEGORY(rows[k].r->info);
                         a.ref = rows[k].ref;
@@ -2093,6 +2255,7 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
                         a.coverage = rows[k].r->total_coverage;
                         a.ref_support = rows[k].r->reference_support;
                         at.push_back(std::move(a));
+                        at_row.push_back(k);
                     }
                     if (h->cfg.ploidy == PISCES_PLOIDY_HAPLOID)
                         (void)haploid_set_genotypes(at, h->cfg.diploid_snv_params[0], h->cfg.diploid_snv_params[1], h->cfg.min_coverage,
@@ -2100,19 +2263,48 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
                     else
                         (void)diploid_set_genotypes(at, h->cfg.diploid_snv_params, h->cfg.diploid_indel_params, h->cfg.min_coverage,
                                                     h->cfg.min_genotype_qscore, h->cfg.max_genotype_qscore);
+                    const size_t first_out = h->pending.size();
+                    size_t ai = 0;
                     for (size_t k = i; k < j; k++) {
-                        const DiploidAllele& a = at[k - i];
-                        if (a.prune) continue;
                         PiscesCalledAllele r = *rows[k].r;
-                        r.info = (uint16_t)((r.info & ~0xFu) | ((uint32_t)a.genotype & 0xFu));
-                        r.genotype_qscore = a.genotype_qscore;
-                        uint32_t fb = r.filter_bits & ~(1u << PISCES_FILTER_LOW_GENOTYPE_QUALITY) & 0x3FFFu;
-                        if (a.multi_allelic) fb |= 1u << PISCES_FILTER_MULTI_ALLELIC_SITE;
-                        if (h->cfg.low_gq_filter >= 0 && (float)a.genotype_qscore < (float)h->cfg.low_gq_filter) fb |= 1u << PISCES_FILTER_LOW_GENOTYPE_QUALITY;
-                        fb |= (uint32_t)(a.phase_set_index & 3) << 14;
-                        r.filter_bits = (uint16_t)fb;
+                        if (ai < at_row.size() && at_row[ai] == k) {
+                            const DiploidAllele& a = at[ai++];
+                            // an allele beyond the ploidy goes, unless it is a forced allele (:155-163)
+                            if (a.prune && !(!h->forced_keys.empty() && h->forced_keys.count(forced_key(r.position, rows[k].ref, rows[k].alt)))) continue;
+                            r.info = (uint16_t)((r.info & ~0xFu) | ((uint32_t)a.genotype & 0xFu));
+                            r.genotype_qscore = a.genotype_qscore;
+                            uint32_t fb = r.filter_bits & ~(1u << PISCES_FILTER_LOW_GENOTYPE_QUALITY) & 0x3FFFu;
+                            if (a.multi_allelic) fb |= 1u << PISCES_FILTER_MULTI_ALLELIC_SITE;
+                            if (h->cfg.low_gq_filter >= 0 && (float)a.genotype_qscore < (float)h->cfg.low_gq_filter) fb |= 1u << PISCES_FILTER_LOW_GENOTYPE_QUALITY;
+                            fb |= (uint32_t)(a.phase_set_index & 3) << 14;
+                            r.filter_bits = (uint16_t)fb;
+                        }
                         h->pending.push_back(r);
                         h->pending_cand_index.push_back(rows[k].ci);
+                    }
+                    if (h->cfg.ploidy == PISCES_PLOIDY_DIPLOID && !h->forced.empty()) {
+                        // DiploidLocusProcessor.Process (DiploidLocusProcessor.cs:13-52): a forced allele takes the genotype the other alleles of
+                        // the position imply, every allele the smallest genotype q-score among those others
+                        bool any_forced = false, any_other = false, is_ref = false, is_no_call = false;
+                        int min_gq = 0;
+                        for (size_t q = first_out; q < h->pending.size(); q++) {
+                            const PiscesCalledAllele& r = h->pending[q];
+                            if (forced_to_report(r)) { any_forced = true; continue; }
+                            const int g = PISCES_INFO_GENOTYPE(r.info);
+                            if (PISCES_INFO_CATEGORY(r.info) == PISCES_CAT_REFERENCE) is_ref = true;
+                            if (g == PISCES_GT_ALT12_LIKE_NOCALL || g == PISCES_GT_ALT_LIKE_NOCALL || g == PISCES_GT_HEMI_NOCALL || g == PISCES_GT_REF_LIKE_NOCALL) is_no_call = true;
+                            if (!any_other || r.genotype_qscore < min_gq) min_gq = r.genotype_qscore;
+                            any_other = true;
+                        }
+                        if (any_forced) {
+                            if (!any_other) is_no_call = true;
+                            const uint32_t genotype = is_no_call ? PISCES_GT_ALT_LIKE_NOCALL : is_ref ? PISCES_GT_HOM_REF : PISCES_GT_OTHERS;
+                            for (size_t q = first_out; q < h->pending.size(); q++) {
+                                PiscesCalledAllele& r = h->pending[q];
+                                if (forced_to_report(r)) r.info = (uint16_t)((r.info & ~0xFu) | genotype);
+                                r.genotype_qscore = (int16_t)(any_other ? min_gq : 0);
+                            }
+                        }
                     }
                     i = j;
                 }

@@ -175,6 +175,35 @@ class HipVariantCaller:
                         "open_left": bool(c.open_left), "open_right": bool(c.open_right)})
         return out
 
+    @staticmethod
+    def _candidate_arrays(items):
+        """[(position, ref, alt)] or [dict(position, category, ref, alt, support_by_dir, ...)] -> (PiscesCandidate[], allele pool)."""
+        arr = (_abi.PiscesCandidate * max(1, len(items)))()
+        pool = bytearray()
+        for i, it in enumerate(items):
+            d = it if isinstance(it, dict) else {"position": it[0], "ref": it[1], "alt": it[2]}
+            c = arr[i]
+            c.position, c.category = int(d["position"]), int(d.get("category", 0))
+            c.ref_len, c.alt_len = len(d["ref"]), len(d["alt"])
+            for k in range(3):
+                c.support_by_dir[k] = int(d.get("support_by_dir", (0, 0, 0))[k])
+                c.well_anchored_by_dir[k] = int(d.get("well_anchored_by_dir", (0, 0, 0))[k])
+            c.open_left, c.open_right = int(bool(d.get("open_left", False))), int(bool(d.get("open_right", False)))
+            c.allele_offset = len(pool)
+            pool += d["ref"].encode() + d["alt"].encode()
+        return arr, np.frombuffer(bytes(pool) or b"\0", dtype=np.uint8).copy(), len(pool)
+
+    def AddCandidates(self, candidates):
+        """IStateManager.AddCandidates for candidates the caller brings itself (dicts as GetCandidates returns them)."""
+        arr, pool, nb = self._candidate_arrays(list(candidates))
+        _check(self._h, lib.pisces_hip_add_candidates(self._h, arr, len(candidates), pool.ctypes.data, nb))
+
+    def SetForcedAlleles(self, alleles):
+        """-forcedalleles: [(position, ref, alt)] of this chromosome (AlleleCaller.AddForcedGtAlleles + SmallVariantCaller's forced
+        candidates).  After SetIntervals, before the first Call."""
+        arr, pool, nb = self._candidate_arrays(list(alleles))
+        _check(self._h, lib.pisces_hip_set_forced_alleles(self._h, arr, len(alleles), pool.ctypes.data, nb))
+
     # ---- multi-GPU summary (one process per GPU): RCCL bound at run time by the library ----
     @staticmethod
     def comm_unique_id():

@@ -1536,3 +1536,107 @@ def test_collapsable_candidates_of_the_next_block_join_the_batch(torch_cuda, sch
     assert got_alleles == exp_alleles
     assert_records_match(got, exp)
     assert stats["TotalNumCalled"] == exp_called
+
+
+# ---- forced genotyping alleles (-forcedalleles) ------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("run", ["noisy", "forced1", "forced2"])
+def test_forced_gt_functional_test_vcfs_on_the_device_path(torch_cuda, run):
+    """ForcedGTFxnlTest.RunForcedGT through libpisceship: the reads of PhiX_S3.bam, the options of the three runs, the nine forced
+    alleles of the test's input VCF (pisces_hip_set_forced_alleles), flushed block by block as the reads pass; the records equal the
+    oracle's and pisces_hip_format_vcf writes the body lines of PhiX_S3.noisy.vcf / Forced1.vcf / Forced2.vcf byte for byte."""
+    from pisces_amd import engine
+    from tests import bam_fixtures
+    from tests.test_oracle_golden import FORCED_GT, forced_gt_config
+    r = FORCED_GT["runs"][run]
+    z, batch = bam_fixtures.load("bam_phix")
+    cfg = _abi.default_config(**forced_gt_config(r["min_variant_qscore"]))
+    forced = [tuple(f) for f in FORCED_GT["forced"]] if r["forced"] else []
+    schedule = [1500, 2500, 3500, 4500]
+    exp, exp_alleles, exp_called = orc.run_reads_schedule(batch, z["ref"], 1, len(z["ref"]), cfg, schedule, forced=forced)
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(z["ref"])
+        if forced:
+            c.SetForcedAlleles(forced)
+        c.AddAlleleCounts(batch)
+        got, got_alleles = [], []
+        for up_to in schedule + [None]:
+            rr, a = c.CallWithAlleles(upToPosition=up_to)
+            got.append(rr)
+            got_alleles += a
+        stats = c.Stats()
+    got = np.concatenate(got)
+    assert got_alleles == exp_alleles
+    assert_records_match(got, exp)
+    assert stats["TotalNumCalled"] == exp_called
+    text = engine.format_vcf("phix", got, alleles=got_alleles, noise_level_from_records=1, noise_level=40, min_frequency_threshold=0.00001)
+    last = int(r["lines"][-1].split("\t")[1])
+    assert [l for l in text.rstrip("\n").split("\n") if int(l.split("\t")[1]) <= last] == r["lines"]
+
+
+def _forced_case(seed=77):
+    """300x reads over 600 loci with SNVs at 100 (30 %), 200 (2 %: below the frequency cut) and a 3-base deletion after 300 (20 %); forced
+    alleles: the three of them, an SNV nobody has (150), another base at 100, an insertion nobody has (250), an MNV nobody has (400), a
+    position without reads (590), and one outside the reference window's intervals when intervals are given."""
+    rng = np.random.default_rng(seed)
+    ref = bytearray(rng.choice(list(b"ACGT"), 640).astype(np.uint8))
+    other = lambda p, k=0: chr([b for b in b"ACGT" if b != ref[p - 1]][k])
+    reads, L = [], 80
+    for n in range(1800):
+        start = int(rng.integers(1, 480))
+        seq = bytearray(ref[start - 1: start - 1 + L])
+        cigar = [("M", L)]
+        u = rng.random()
+        if start <= 100 < start + L and u < 0.30:
+            seq[100 - start] = ord(other(100))
+        if start <= 200 < start + L and u > 0.98:
+            seq[200 - start] = ord(other(200))
+        if start + 5 <= 300 and 304 + 5 <= start + L and 0.4 < u < 0.6:   # deletion of 301..303, anchor base 300
+            k = 300 - start + 1
+            seq = seq[:k] + bytearray(ref[303: 303 + L - k])
+            cigar = [("M", k), ("D", 3), ("M", L - k)]
+        reads.append({"pos": start, "cigar": cigar, "seq": bytes(seq).decode(), "quals": [35] * L, "reverse": bool(n % 2)})
+    reads.sort(key=lambda r: r["pos"])
+    refs = lambda p, n: bytes(ref[p - 1: p - 1 + n]).decode()
+    forced = [(100, refs(100, 1), other(100)), (100, refs(100, 1), other(100, 1)), (150, refs(150, 1), other(150)), (200, refs(200, 1), other(200)),
+              (300, refs(300, 4), refs(300, 1)), (250, refs(250, 1), refs(250, 1) + "ACG"), (400, refs(400, 3), other(400) + other(401) + other(402)),
+              (590, refs(590, 1), other(590))]
+    return ref, reads, forced
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["somatic_gvcf", "somatic_vcf", "mnv_vcf", "diploid_gvcf", "diploid_vcf", "low_gq"])
+def test_forced_alleles_against_the_oracle(torch_cuda, mode):
+    """Forced alleles on the default path (MNV calling off: SNVs are the device counts, a forced SNV takes its support from them), with
+    and without Reference rows (gVCF on: the Reference row of the tile kernels stays beside a ForcedReport row; off: Reference rows at
+    the forced positions only, RegionState.cs:393-450), with MNV calling on, with the diploid genotyper (DiploidLocusProcessor: forced
+    alleles take the genotype the others imply, PISCES_GT_OTHERS beside a heterozygous call) and with the LowGQ filter (a forced row
+    has genotype q-score 0).  Records, allele strings, TotalNumCalled and the VCF text equal the oracle's."""
+    from pisces_amd import engine
+    ref, reads, forced = _forced_case()
+    batch = _abi.ReadBatch(reads)
+    refa = np.frombuffer(bytes(ref), dtype=np.uint8)
+    over = dict(somatic_gvcf=dict(), somatic_vcf=dict(include_reference_calls=0), mnv_vcf=dict(include_reference_calls=0, call_mnvs=1, collapse=0),
+                diploid_gvcf=dict(ploidy=1), diploid_vcf=dict(ploidy=1, include_reference_calls=0),
+                low_gq=dict(low_gq_filter=20))[mode]
+    cfg = _abi.default_config(block_size=250, **over)
+    schedule = [260, 520]
+    exp, exp_alleles, exp_called = orc.run_reads_schedule(batch, refa, 1, len(ref), cfg, schedule, forced=forced)
+    forced_rows = [(int(r["position"]), a) for r, a in zip(exp, exp_alleles) if (int(r["filter_bits"]) >> _abi.FILTER_FORCED_REPORT) & 1]
+    assert len(forced_rows) >= 5 and (100, forced[0][1:]) not in forced_rows   # the real SNV at 100 is called, not forced
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(refa)
+        c.SetForcedAlleles(forced)
+        c.AddAlleleCounts(batch)
+        got, got_alleles = [], []
+        for up_to in schedule + [None]:
+            rr, a = c.CallWithAlleles(upToPosition=up_to)
+            got.append(rr)
+            got_alleles += a
+        stats = c.Stats()
+    got = np.concatenate(got)
+    assert got_alleles == exp_alleles
+    assert_records_match(got, exp)
+    assert stats["TotalNumCalled"] == exp_called
+    fmt = lambda recs, alleles: engine.format_vcf("chrF", recs, alleles=alleles, noise_level_from_records=1)
+    assert fmt(got, got_alleles) == fmt(exp, exp_alleles)
