@@ -1,19 +1,27 @@
 // kernels.hip.h — gfx950 kernels of the pileup-and-likelihood path.
 //
-//   call_tiles_kernel        observation tuples -> LDS allele-count histogram (per 64-locus tile)
-//                            -> coverage / Poisson q-score / strand bias / somatic genotype / filters
-//                            for the Reference allele and every SNV candidate -> 64-byte records.
-//                            Counts never leave LDS.  HBM traffic = 4 B/tuple + 1 B/locus + 64 B/record.
-//   accumulate_tiles_kernel  tuples -> anchor-resolved int32[6][3][11] counts added to a global tensor
-//                            (the IAlleleSource view: RegionState._alleleCounts, RegionState.cs:57).
+//   call_tiles_wave_kernel<NW>  THE HOT KERNEL: one tile (<= 64 loci) per wave, NW waves per workgroup.  Observation tuples stream in
+//                            as 16-byte loads; the tuple IS the LDS address of its counter (3 VALU + 1 ds_add per observation, two
+//                            [32][64] int32 regions: quality-passing / low-quality bases); the call phase — coverage, Poisson
+//                            q-score, strand bias, somatic genotype, filters for the Reference allele and every SNV candidate —
+//                            reads memo tables first (DeviceParams::vq_tab / sb_tab / gq_cap, filled by the functions they stand for)
+//                            and falls into the full FP64 functions only on a miss.  Counts never leave LDS.
+//                            HBM traffic = 4 B/tuple + 1 B/locus + 64 B/record.
+//   call_tiles_kernel        the earlier form (one 4-wave workgroup per tile, roles per wave); germline / Window configurations
+//   accumulate_tiles_kernel  tuples -> anchor-resolved int32[6][3][11] counts (+ base-quality sums) added to a global tensor
+//                            (the IAlleleSource view: RegionState._alleleCounts / _sumOfAlleleBaseQualities, RegionState.cs:57,61).
 //   call_counts_kernel       the same call phase fed from that global tensor (+ gapped-MNV reference counts).
 //   scan_tile_counts_kernel / gather_records_kernel
 //                            optional ordered compaction of the per-tile record slots.
-//   call_spanning_kernel     insertion / deletion candidates found by the host: spanning coverage from the
-//                            global tensor, then the same q-score / strand-bias / filter / genotype chain.
+//   call_spanning_kernel     candidates with allele strings (insertions, deletions, MNVs; SNV / Reference alleles of the MNV path and
+//                            forced alleles): spanning coverage from the global tensor, then the same q-score / strand-bias /
+//                            filter / genotype chain; records are made for alleles that are not callable too (forced alleles).
+//   build_*_kernel           the memo tables, once per handle.
 //
-// One workgroup (256 threads = 4 wave64) per tile; grid = number of tiles (>> 256 CUs for any real
-// interval set).  No MFMA: this is a scan + histogram + transcendental epilogue, HBM-bound.
+// Grid = number of tiles / NW (>> 256 CUs for any real interval set; pisces_hip_balanced_tile_loci picks the tile size that gives every
+// CU the same number of tiles).  No MFMA: this is a scan + histogram + transcendental epilogue, HBM-bound.
+// The read walk, the bucketing and candidate discovery are in stream_kernels.hip.h / finder_kernels.hip.h, BGZF / BAM in
+// bgzf_kernels.hip.h / bam_kernels.hip.h.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
