@@ -31,6 +31,7 @@ extern "C" {
 #define PISCES_E_UNMAPPED_BASE   -4  /* reference: RegionStateManager.cs:109-113 */
 #define PISCES_E_UNSUPPORTED     -5
 #define PISCES_E_STATE           -6  /* call protocol violated */
+#define PISCES_E_INTERNAL        -7  /* an exception inside the library (e.g. out of host memory): caught at the boundary, message in last_error */
 
 /* ---- enums: numeric values are the reference's ------------------------- */
 /* src/lib/Pisces.Domain/Types/AlleleType.cs:3-11 */

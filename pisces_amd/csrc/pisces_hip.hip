@@ -304,12 +304,27 @@ static DeviceParams make_params(const PiscesHipConfig& c)
     return P;
 }
 
+// Nothing crosses the C ABI as an exception: every exported entry runs inside this guard (std::bad_alloc from a host vector,
+// std::length_error from a string built on caller data, ...) and reports PISCES_E_INTERNAL with the message in last_error.
+template <typename R, typename F>
+static R abi_guard(PiscesHip* h, F&& body)
+{
+    try {
+        return body();
+    } catch (const std::exception& e) {
+        return (R)fail(h, PISCES_E_INTERNAL, std::string("exception inside the library: ") + e.what());
+    } catch (...) {
+        return (R)fail(h, PISCES_E_INTERNAL, "unknown exception inside the library");
+    }
+}
+
 extern "C" {
 
 int32_t pisces_hip_abi_version(void) { return PISCES_HIP_ABI_VERSION; }
 
 int32_t pisces_hip_default_config(PiscesHipConfig* c)
 {
+    return abi_guard<int32_t>((PiscesHip*)nullptr, [&]() -> int32_t {
     if (!c) return PISCES_E_INVALID_ARG;
     std::memset(c, 0, sizeof(*c));
     c->abi_version = PISCES_HIP_ABI_VERSION;
@@ -351,12 +366,14 @@ int32_t pisces_hip_default_config(PiscesHipConfig* c)
     c->diploid_snv_params[1] = c->diploid_indel_params[1] = 0.70f;
     c->diploid_snv_params[2] = c->diploid_indel_params[2] = 0.80f;
     return PISCES_OK;
+    });
 }
 
 int32_t pisces_hip_destroy(PiscesHip* h);
 
 int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip** out)
 {
+    return abi_guard<int32_t>((PiscesHip*)nullptr, [&]() -> int32_t {
     if (!cfg || !out) return fail(nullptr, PISCES_E_INVALID_ARG, "pisces_hip_create: null argument");
     *out = nullptr;
     if (cfg->abi_version != PISCES_HIP_ABI_VERSION)
@@ -491,10 +508,12 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
     }
     *out = h;
     return PISCES_OK;
+    });
 }
 
 int32_t pisces_hip_destroy(PiscesHip* h)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -529,12 +548,14 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return PISCES_OK;
+    });
 }
 
 const char* pisces_hip_last_error(const PiscesHip* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 int32_t pisces_hip_set_reference(PiscesHip* h, const uint8_t* bases, int64_t length)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (!bases || length <= 0) return fail(h, PISCES_E_INVALID_ARG, "set_reference: empty reference");
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
@@ -546,10 +567,12 @@ int32_t pisces_hip_set_reference(PiscesHip* h, const uint8_t* bases, int64_t len
     h->h_ref.assign(bases, bases + length);
     h->ref_len = length;
     return PISCES_OK;
+    });
 }
 
 int32_t pisces_hip_set_intervals(PiscesHip* h, const int32_t* starts, const int32_t* ends, int32_t n)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h || n < 0 || (n > 0 && (!starts || !ends))) return fail(h, PISCES_E_INVALID_ARG, "set_intervals: bad arguments");
     h->intervals.clear();
     for (int i = 0; i < n; i++) {
@@ -558,6 +581,7 @@ int32_t pisces_hip_set_intervals(PiscesHip* h, const int32_t* starts, const int3
         h->intervals.emplace_back(starts[i], ends[i]);
     }
     return PISCES_OK;
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -637,6 +661,7 @@ __global__ __launch_bounds__(256) void log_append_kernel(const int32_t* __restri
 
 int32_t pisces_hip_add_observations(PiscesHip* h, const int32_t* positions, const uint32_t* tuples, int64_t n)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (n < 0 || (n > 0 && (!positions || !tuples))) return fail(h, PISCES_E_INVALID_ARG, "add_observations: null buffer");
     for (int64_t i = 0; i < n; i++)
@@ -661,6 +686,7 @@ int32_t pisces_hip_add_observations(PiscesHip* h, const int32_t* positions, cons
     { int32_t rcs = stage_release(h); if (rcs) return rcs; }
     h->log_ub += n;
     return PISCES_OK;
+    });
 }
 
 namespace {
@@ -749,6 +775,7 @@ static int32_t host_candidates_of(PiscesHip* h, const PiscesCandidate* cands, in
 // IStateManager.AddCandidates (IStateManager.cs; RegionStateManager.cs:83-116) for candidates the caller brings itself
 int32_t pisces_hip_add_candidates(PiscesHip* h, const PiscesCandidate* cands, int64_t n, const uint8_t* alleles, int64_t allele_bytes)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     { int32_t rcf = consume_found(h); if (rcf) return rcf; }   // keep the arrival order: what the reads gave so far comes first
     std::vector<HostCandidate> list;
@@ -756,12 +783,14 @@ int32_t pisces_hip_add_candidates(PiscesHip* h, const PiscesCandidate* cands, in
     if (rc) return rc;
     for (auto& c : list) add_candidate(h, c);
     return PISCES_OK;
+    });
 }
 
 // -forcedalleles (Factory.GetForcedAlleles :56-96, SelectForcedAllele :270-286; SmallVariantCaller.CreateForcedAllelePos :49-77): the
 // alleles to report whatever the reads say.  Categories are SmallVariantCaller.GetAlleleCategory's (:141-150), support is ignored.
 int32_t pisces_hip_set_forced_alleles(PiscesHip* h, const PiscesCandidate* cands, int64_t n, const uint8_t* alleles, int64_t allele_bytes)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (h->n_forced_added > 0) return fail(h, PISCES_E_INVALID_ARG, "set_forced_alleles: some forced alleles are candidates already");
     std::vector<HostCandidate> list;
@@ -791,6 +820,7 @@ int32_t pisces_hip_set_forced_alleles(PiscesHip* h, const PiscesCandidate* cands
     }
     std::stable_sort(h->forced.begin(), h->forced.end(), [](const HostCandidate& a, const HostCandidate& b) { return a.position < b.position; });
     return PISCES_OK;
+    });
 }
 
 // SmallVariantCaller.AddForcedAlleleAsCandidate :118-132, before GetCandidatesToProcess(upTo)
@@ -889,6 +919,7 @@ static int32_t consume_found(PiscesHip* h)
 
 int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (validate_batch(batch) != PISCES_OK) return fail(h, PISCES_E_INVALID_ARG, "add_reads: malformed read batch");
     h->pending_valid = false;
@@ -1082,10 +1113,12 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
     { int32_t rcs = stage_release(h); if (rcs) return rcs; }
     h->log_ub += ub;
     return PISCES_OK;
+    });
 }
 
 int64_t pisces_hip_expand_reads(const PiscesReadBatch* batch, int32_t min_bq, int32_t* positions, uint32_t* tuples, int64_t capacity)
 {
+    return abi_guard<int64_t>((PiscesHip*)nullptr, [&]() -> int64_t {
     if (validate_batch(batch) != PISCES_OK || capacity < 0 || (capacity > 0 && (!positions || !tuples))) return PISCES_E_INVALID_ARG;
     ArraySink sink;
     sink.positions = positions;
@@ -1096,12 +1129,14 @@ int64_t pisces_hip_expand_reads(const PiscesReadBatch* batch, int32_t min_bq, in
         if (rc != PISCES_OK) return rc;
     }
     return sink.n <= capacity ? sink.n : (int64_t)PISCES_E_BUFFER_TOO_SMALL;
+    });
 }
 
 int64_t pisces_hip_find_candidates(const PiscesReadBatch* batch, const uint8_t* ref, int64_t ref_len, int32_t min_bq, int32_t snvs_and_mnvs,
                                    int32_t call_mnvs, int32_t max_mnv_length, int32_t max_gap_between_mnv, PiscesCandidate* out,
                                    int64_t capacity, uint8_t* alleles, int64_t allele_capacity, int64_t* allele_bytes)
 {
+    return abi_guard<int64_t>((PiscesHip*)nullptr, [&]() -> int64_t {
     if (validate_batch(batch) != PISCES_OK || !ref || ref_len <= 0 || capacity < 0 || (capacity > 0 && !out)) return PISCES_E_INVALID_ARG;
     std::vector<HostCandidate> found;
     try {
@@ -1133,6 +1168,7 @@ int64_t pisces_hip_find_candidates(const PiscesReadBatch* batch, const uint8_t* 
     if (allele_bytes) *allele_bytes = bytes;
     if ((int64_t)found.size() > capacity || (alleles && bytes > allele_capacity)) return PISCES_E_BUFFER_TOO_SMALL;
     return (int64_t)found.size();
+    });
 }
 
 static int64_t export_candidates(const std::vector<HostCandidate>& found, PiscesCandidate* out, int64_t capacity, uint8_t* alleles,
@@ -1166,6 +1202,7 @@ int64_t pisces_hip_find_candidates_device(PiscesHip* h, const PiscesReadBatch* b
                                           int32_t max_mnv_length, int32_t max_gap_between_mnv, PiscesCandidate* out, int64_t capacity,
                                           uint8_t* alleles, int64_t allele_capacity, int64_t* allele_bytes)
 {
+    return abi_guard<int64_t>(h, [&]() -> int64_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (validate_batch(batch) != PISCES_OK || capacity < 0 || (capacity > 0 && !out)) return fail(h, PISCES_E_INVALID_ARG, "find_candidates_device: malformed arguments");
     if (h->h_ref.empty()) return fail(h, PISCES_E_STATE, "find_candidates_device: set_reference has not been called");
@@ -1242,13 +1279,16 @@ int64_t pisces_hip_find_candidates_device(PiscesHip* h, const PiscesReadBatch* b
         }
     }
     return export_candidates(found, out, capacity, alleles, allele_capacity, allele_bytes);
+    });
 }
 
 int64_t pisces_hip_find_indel_candidates(const PiscesReadBatch* batch, const uint8_t* ref, int64_t ref_len, int32_t min_bq,
                                          PiscesCandidate* out, int64_t capacity, uint8_t* alleles, int64_t allele_capacity,
                                          int64_t* allele_bytes)
 {
+    return abi_guard<int64_t>((PiscesHip*)nullptr, [&]() -> int64_t {
     return pisces_hip_find_candidates(batch, ref, ref_len, min_bq, 0, 0, 0, 0, out, capacity, alleles, allele_capacity, allele_bytes);
+    });
 }
 
 // Builds tiles + tile-bucketed tuples for a set of blocks. Tiles follow the 1000-locus block grid
@@ -2151,6 +2191,7 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
                             int32_t* cand_index_out, PiscesCandidate* cand_out, int64_t cand_capacity, int64_t* n_cand,
                             uint8_t* alleles_out, int64_t allele_capacity, int64_t* allele_bytes)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (!n_out || capacity < 0 || (capacity > 0 && !out)) return fail(h, PISCES_E_INVALID_ARG, "flush: null output");
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
@@ -2370,15 +2411,19 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
     h->pending_cands.clear();
     h->pending_keys.clear();
     return PISCES_OK;
+    });
 }
 
 int32_t pisces_hip_flush(PiscesHip* h, int32_t up_to_position, PiscesCalledAllele* out, int64_t capacity, int64_t* n_out)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     return pisces_hip_flush_ex(h, up_to_position, out, capacity, n_out, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr);
+    });
 }
 
 int32_t pisces_hip_get_counts(PiscesHip* h, int32_t start_position, int32_t n, int32_t* out)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (n < 0 || (n > 0 && !out)) return fail(h, PISCES_E_INVALID_ARG, "get_counts: null output");
     if (start_position <= 0) return fail(h, PISCES_E_INVALID_ARG, "Position must be greater than 0.");
@@ -2412,6 +2457,7 @@ int32_t pisces_hip_get_counts(PiscesHip* h, int32_t start_position, int32_t n, i
                         PISCES_COUNTS_PER_LOCUS * sizeof(int32_t));
         }
     return PISCES_OK;
+    });
 }
 
 // IAlleleSource.GetSumOfAlleleBaseQualities (RegionState._sumOfAlleleBaseQualities, RegionState.cs:61,233-239): the cells of
@@ -2420,6 +2466,7 @@ int32_t pisces_hip_get_counts(PiscesHip* h, int32_t start_position, int32_t n, i
 // FP64 additions is the device's (atomic order), not the read order: equal to the reference's sums to rounding.
 int32_t pisces_hip_get_base_quality_sums(PiscesHip* h, int32_t start_position, int32_t n, double* out)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (n < 0 || (n > 0 && !out)) return fail(h, PISCES_E_INVALID_ARG, "get_base_quality_sums: null output");
     if (start_position <= 0) return fail(h, PISCES_E_INVALID_ARG, "Position must be greater than 0.");
@@ -2459,19 +2506,23 @@ int32_t pisces_hip_get_base_quality_sums(PiscesHip* h, int32_t start_position, i
                         host.data() + ((size_t)t * kTile + (size_t)l) * PISCES_COUNTS_PER_LOCUS, PISCES_COUNTS_PER_LOCUS * sizeof(double));
         }
     return PISCES_OK;
+    });
 }
 
 // IAlleleSource.GetGappedMnvRefCount (RegionStateManager.cs: the lookup AddGappedMnvRefCount fills)
 int32_t pisces_hip_get_gapped_mnv_ref(PiscesHip* h, int32_t position, int32_t* count)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h || !count) return PISCES_E_INVALID_ARG;
     auto it = h->gapped_mnv_ref.find(position);
     *count = it == h->gapped_mnv_ref.end() ? 0 : it->second;
     return PISCES_OK;
+    });
 }
 
 int32_t pisces_hip_add_gapped_mnv_ref(PiscesHip* h, const int32_t* positions, const int32_t* counts, int32_t n)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (n < 0 || (n > 0 && (!positions || !counts))) return fail(h, PISCES_E_INVALID_ARG, "add_gapped_mnv_ref: null buffer");
     for (int32_t i = 0; i < n; i++) {
@@ -2481,11 +2532,13 @@ int32_t pisces_hip_add_gapped_mnv_ref(PiscesHip* h, const int32_t* positions, co
     }
     h->pending_valid = false;
     return PISCES_OK;
+    });
 }
 
 int32_t pisces_hip_get_candidates(PiscesHip* h, int32_t up_to_position, PiscesCandidate* out, int64_t capacity, int64_t* n_out,
                                   uint8_t* alleles, int64_t allele_capacity, int64_t* allele_bytes)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h || !n_out) return PISCES_E_INVALID_ARG;
     // the candidates collected so far: insertions / deletions, and with MNV calling on the SNVs / MNVs of the read walk (with it
     // off SNV candidates never leave the device: they are the allele counts)
@@ -2514,10 +2567,12 @@ int32_t pisces_hip_get_candidates(PiscesHip* h, int32_t up_to_position, PiscesCa
     if (allele_bytes) *allele_bytes = bytes;
     if (out && (n > capacity || (alleles && bytes > allele_capacity))) return fail(h, PISCES_E_BUFFER_TOO_SMALL, "get_candidates: buffer too small");
     return PISCES_OK;
+    });
 }
 
 int32_t pisces_hip_stats(PiscesHip* h, int64_t out[4])
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h || !out) return PISCES_E_INVALID_ARG;
     for (int i = 0; i < 4; i++) out[i] = h->stats[i];
     unsigned long long appended = 0;   // observations: counted where they are made, on the device
@@ -2526,6 +2581,7 @@ int32_t pisces_hip_stats(PiscesHip* h, int64_t out[4])
     PISCES_HIP_CHECK(h, hipMemcpy(&appended, h->d_log_n.p + 2, sizeof(appended), hipMemcpyDeviceToHost));
     out[3] = (int64_t)appended;
     return PISCES_OK;
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2535,6 +2591,7 @@ int32_t pisces_hip_call_tiles(PiscesHip* h, const uint32_t* d_tuples, const Pisc
                               const uint8_t* d_ref_bases, int32_t ref_start_position, int64_t ref_length,
                               PiscesCalledAllele* d_records, int32_t record_capacity, PiscesTileResult* d_tile_results, void* stream)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (n_tiles < 0 || record_capacity < 0 || ref_length < 0) return fail(h, PISCES_E_INVALID_ARG, "call_tiles: negative size");
     if (n_tiles > 0 && (!d_tiles || !d_ref_bases || !d_records || !d_tile_results))
@@ -2562,6 +2619,7 @@ int32_t pisces_hip_call_tiles(PiscesHip* h, const uint32_t* d_tuples, const Pisc
     }
     PISCES_HIP_CHECK(h, hipGetLastError());
     return PISCES_OK;
+    });
 }
 
 // Tile size for a launch of n_loci contiguous loci that keeps every CU equally loaded.  The hot kernel is HBM-bound and a CU streams
@@ -2571,16 +2629,19 @@ int32_t pisces_hip_call_tiles(PiscesHip* h, const uint32_t* d_tuples, const Pisc
 // run in many rounds and balance themselves: 64.
 int32_t pisces_hip_balanced_tile_loci(PiscesHip* h, int64_t n_loci)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h || n_loci <= 0) return kTile;
     const int64_t cus = std::max(1, h->n_cus);
     const int64_t per_cu = (n_loci + (int64_t)kTile * cus - 1) / ((int64_t)kTile * cus);   // tiles per CU at 64 loci
     if (per_cu > 8) return kTile;
     const int64_t n_tiles = per_cu * cus;
     return (int32_t)std::min<int64_t>(kTile, (n_loci + n_tiles - 1) / n_tiles);
+    });
 }
 
 int32_t pisces_hip_call_tiles_batched(PiscesHip* h, const PiscesTileBatch* batches, int32_t n_batches, void* stream)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (n_batches < 0 || (n_batches > 0 && !batches)) return fail(h, PISCES_E_INVALID_ARG, "call_tiles_batched: null batch list");
     if (h->cfg.ploidy != PISCES_PLOIDY_SOMATIC)
@@ -2613,12 +2674,14 @@ int32_t pisces_hip_call_tiles_batched(PiscesHip* h, const PiscesTileBatch* batch
     }
     PISCES_HIP_CHECK(h, hipGetLastError());
     return PISCES_OK;
+    });
 }
 
 int32_t pisces_hip_compact_records(PiscesHip* h, const PiscesCalledAllele* d_records, const PiscesTileResult* d_tile_results,
                                    int32_t n_tiles, int32_t* d_offsets, PiscesCalledAllele* d_out, int32_t out_capacity,
                                    int32_t* d_count, void* stream)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (n_tiles < 0 || out_capacity < 0) return fail(h, PISCES_E_INVALID_ARG, "compact_records: negative size");
     if (!d_count || (n_tiles > 0 && (!d_records || !d_tile_results || !d_offsets || !d_out)))
@@ -2632,11 +2695,13 @@ int32_t pisces_hip_compact_records(PiscesHip* h, const PiscesCalledAllele* d_rec
     launch_compaction(s, d_records, d_tile_results, n_tiles, d_offsets, d_out, out_capacity, d_count);
     PISCES_HIP_CHECK(h, hipGetLastError());
     return PISCES_OK;
+    });
 }
 
 int32_t pisces_hip_accumulate_tiles(PiscesHip* h, const uint32_t* d_tuples, const PiscesTile* d_tiles, int32_t n_tiles,
                                     int32_t* d_counts, void* stream)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (n_tiles < 0) return fail(h, PISCES_E_INVALID_ARG, "accumulate_tiles: negative size");
     if (n_tiles > 0 && (!d_tiles || !d_counts)) return fail(h, PISCES_E_INVALID_ARG, "accumulate_tiles: null device pointer");
@@ -2658,10 +2723,12 @@ int32_t pisces_hip_accumulate_tiles(PiscesHip* h, const uint32_t* d_tuples, cons
     }
     PISCES_HIP_CHECK(h, hipGetLastError());
     return PISCES_OK;
+    });
 }
 
 int32_t pisces_hip_device_totals(PiscesHip* h, int64_t out[4], int32_t reset)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h || !out) return PISCES_E_INVALID_ARG;
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     PISCES_HIP_CHECK(h, hipDeviceSynchronize());   // launches may sit on caller-supplied streams
@@ -2673,10 +2740,12 @@ int32_t pisces_hip_device_totals(PiscesHip* h, int64_t out[4], int32_t reset)
     }
     if (reset) PISCES_HIP_CHECK(h, hipMemset(h->d_totals.p, 0, sizeof(host)));
     return PISCES_OK;
+    });
 }
 
 int32_t pisces_hip_set_timing(PiscesHip* h, int32_t enable)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     if (enable && h->ring.empty()) {
@@ -2687,10 +2756,12 @@ int32_t pisces_hip_set_timing(PiscesHip* h, int32_t enable)
     h->ring_used = 0;
     h->launches_seen = 0;
     return PISCES_OK;
+    });
 }
 
 int32_t pisces_hip_kernel_time(PiscesHip* h, double* total_ms, int64_t* launches)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h || !total_ms || !launches) return PISCES_E_INVALID_ARG;
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     const int64_t n = std::min<int64_t>(h->ring_used, kTimingRing);
@@ -2704,10 +2775,12 @@ int32_t pisces_hip_kernel_time(PiscesHip* h, double* total_ms, int64_t* launches
     *total_ms = sum;
     *launches = n;
     return PISCES_OK;
+    });
 }
 
 int32_t pisces_hip_probe_read_bandwidth(PiscesHip* h, int64_t nbytes, int32_t reps, double* gb_per_s)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h || !gb_per_s || nbytes < (1 << 20) || reps < 1) return fail(h, PISCES_E_INVALID_ARG, "probe_read_bandwidth: bad arguments");
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     DeviceBuf<uint32_t> buf;
@@ -2728,11 +2801,13 @@ int32_t pisces_hip_probe_read_bandwidth(PiscesHip* h, int64_t nbytes, int32_t re
     buf.release();
     *gb_per_s = best;
     return PISCES_OK;
+    });
 }
 
 // ---- BGZF (row f4, upstream of the read batch) ----
 int64_t pisces_hip_bgzf_scan(const uint8_t* file, int64_t n_bytes, PiscesBgzfBlock* blocks, int64_t capacity, int64_t* inflated_bytes)
 {
+    return abi_guard<int64_t>((PiscesHip*)nullptr, [&]() -> int64_t {
     if (!file || n_bytes < 0 || capacity < 0 || (capacity > 0 && !blocks)) return PISCES_E_INVALID_ARG;
     int64_t pos = 0, n = 0, out = 0;
     while (pos < n_bytes) {
@@ -2768,6 +2843,7 @@ int64_t pisces_hip_bgzf_scan(const uint8_t* file, int64_t n_bytes, PiscesBgzfBlo
     }
     if (inflated_bytes) *inflated_bytes = out;
     return n;
+    });
 }
 
 static uint32_t crc32_of(const uint8_t* p, size_t n)
@@ -2798,6 +2874,7 @@ static uint32_t crc32_of(const uint8_t* p, size_t n)
 int32_t pisces_hip_bgzf_inflate(PiscesHip* h, const uint8_t* file, int64_t n_bytes, const PiscesBgzfBlock* blocks, int64_t n_blocks,
                                 uint8_t* out, int64_t out_capacity, int32_t check_crc, float* kernel_ms)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (!file || n_bytes <= 0 || n_blocks < 0 || (n_blocks > 0 && !blocks) || out_capacity < 0) return fail(h, PISCES_E_INVALID_ARG, "bgzf_inflate: bad arguments");
     if (kernel_ms) *kernel_ms = 0.f;
@@ -2855,12 +2932,14 @@ int32_t pisces_hip_bgzf_inflate(PiscesHip* h, const uint8_t* file, int64_t n_byt
             return fail(h, PISCES_E_INVALID_ARG, "bgzf_inflate: CRC-32 mismatch in block " + std::to_string(first_bad.load()));
     }
     return PISCES_OK;
+    });
 }
 
 // ---- BAM bytes -> read batch on the device (row f4): only the compressed file crosses PCIe -------------------------------
 int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes, const PiscesBgzfBlock* blocks, int64_t n_blocks, int32_t ref_id,
                               int32_t min_map_quality, int32_t skip_duplicates, int32_t only_proper_pairs, int64_t counts[4])
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (!file || n_bytes <= 0 || n_blocks <= 0 || !blocks) return fail(h, PISCES_E_INVALID_ARG, "bam_decode: bad arguments");
     h->bam.valid = false;
@@ -2944,11 +3023,13 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
     B.valid = true;
     if (counts) { counts[0] = B.n_reads; counts[1] = B.n_skipped; counts[2] = B.n_ops; counts[3] = B.n_bases; }
     return PISCES_OK;
+    });
 }
 
 int32_t pisces_hip_bam_fetch(PiscesHip* h, int32_t* position, uint8_t* flags, int32_t* cigar_offset, uint8_t* cigar_op, uint32_t* cigar_len,
                              int32_t* seq_offset, uint8_t* bases, uint8_t* quals)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (!h->bam.valid) return fail(h, PISCES_E_STATE, "bam_fetch: no decoded batch (pisces_hip_bam_decode first)");
     auto& B = h->bam;
@@ -2967,6 +3048,7 @@ int32_t pisces_hip_bam_fetch(PiscesHip* h, int32_t* position, uint8_t* flags, in
     PISCES_HIP_CHECK(h, down(quals, B.quals.p, nb));
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     return PISCES_OK;
+    });
 }
 
 // IStateManager.AddAlleleCounts + FindCandidates for the decoded batch: the bases and qualities stay on the device; the host sees
@@ -2974,6 +3056,7 @@ int32_t pisces_hip_bam_fetch(PiscesHip* h, int32_t* position, uint8_t* flags, in
 // (log slots, candidate-record slots, the blocks every read touches).
 int32_t pisces_hip_add_decoded_reads(PiscesHip* h)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (!h->bam.valid) return fail(h, PISCES_E_STATE, "add_decoded_reads: no decoded batch (pisces_hip_bam_decode first)");
     auto& B = h->bam;
@@ -3077,6 +3160,7 @@ int32_t pisces_hip_add_decoded_reads(PiscesHip* h)
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     h->log_ub += ub;
     return PISCES_OK;
+    });
 }
 
 // ---- RCCL, bound at run time: the library itself does not link librccl (a single-GPU host never loads it) ----
@@ -3117,6 +3201,7 @@ static std::string rccl_error(Rccl* r, int code)
 
 int32_t pisces_hip_comm_unique_id(uint8_t* id_out, int32_t capacity)
 {
+    return abi_guard<int32_t>((PiscesHip*)nullptr, [&]() -> int32_t {
     if (!id_out || capacity < PISCES_COMM_ID_BYTES) return fail(nullptr, PISCES_E_INVALID_ARG, "comm_unique_id: the id needs 128 bytes");
     Rccl* r = rccl();
     if (!r) return fail(nullptr, PISCES_E_DEVICE, "comm_unique_id: librccl could not be loaded");
@@ -3126,10 +3211,12 @@ int32_t pisces_hip_comm_unique_id(uint8_t* id_out, int32_t capacity)
     if (rc != 0) return fail(nullptr, PISCES_E_DEVICE, rccl_error(r, rc));
     std::memcpy(id_out, id.internal, PISCES_COMM_ID_BYTES);
     return PISCES_OK;
+    });
 }
 
 int32_t pisces_hip_comm_init(PiscesHip* h, const uint8_t* id, int32_t rank, int32_t world)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (!id || world < 1 || rank < 0 || rank >= world) return fail(h, PISCES_E_INVALID_ARG, "comm_init: rank / world out of range");
     if (h->comm) return fail(h, PISCES_E_STATE, "comm_init: the handle already has a communicator");
@@ -3145,10 +3232,12 @@ int32_t pisces_hip_comm_init(PiscesHip* h, const uint8_t* id, int32_t rank, int3
     h->comm = comm;
     h->comm_world = world;
     return PISCES_OK;
+    });
 }
 
 int32_t pisces_hip_reduce_summary(PiscesHip* h, int64_t inout[4])
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h || !inout) return PISCES_E_INVALID_ARG;
     if (!h->comm) return PISCES_OK;   // one shard: the sum is the value
     Rccl* r = rccl();
@@ -3162,10 +3251,12 @@ int32_t pisces_hip_reduce_summary(PiscesHip* h, int64_t inout[4])
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < 4; i++) inout[i] = v[i];
     return PISCES_OK;
+    });
 }
 
 int32_t pisces_hip_comm_destroy(PiscesHip* h)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (!h->comm) return PISCES_OK;
     Rccl* r = rccl();
@@ -3173,20 +3264,24 @@ int32_t pisces_hip_comm_destroy(PiscesHip* h)
     h->comm = nullptr;
     h->comm_world = 1;
     return PISCES_OK;
+    });
 }
 
 int32_t pisces_hip_synchronize(PiscesHip* h)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     for (int k = 0; k < PiscesHip::kLanes; k++)
         if (h->lane[k]) PISCES_HIP_CHECK(h, hipStreamSynchronize(h->lane[k]));
     return PISCES_OK;
+    });
 }
 
 int32_t pisces_hip_last_kernel_ms(PiscesHip* h, float* ms)
 {
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h || !ms) return PISCES_E_INVALID_ARG;
     if (h->timing <= 0 || h->ring_used == 0)
         return fail(h, PISCES_E_STATE, "last_kernel_ms: no timed launch (pisces_hip_set_timing first)");
@@ -3195,6 +3290,7 @@ int32_t pisces_hip_last_kernel_ms(PiscesHip* h, float* ms)
     PISCES_HIP_CHECK(h, hipEventSynchronize(h->ring[2 * slot + 1]));
     PISCES_HIP_CHECK(h, hipEventElapsedTime(ms, h->ring[2 * slot], h->ring[2 * slot + 1]));
     return PISCES_OK;
+    });
 }
 
 }  // extern "C"

@@ -136,6 +136,8 @@ int64_t pisces_hip_format_vcf_padded(const PiscesVcfConfig* cfg, const char* chr
                                      const int32_t* interval_ends, int32_t n_intervals, PiscesVcfPadState* state, int32_t finish,
                                      char* out, int64_t capacity)
 {
+    try {   // nothing crosses the C ABI as an exception (std::bad_alloc from the text buffer, ...)
+    return [&]() -> int64_t {
     if (!cfg || !chrom || n < 0 || (n > 0 && !recs) || capacity < 0 || (capacity > 0 && !out)) return PISCES_E_INVALID_ARG;
     const bool pad = state != nullptr;
     if (pad && (n_intervals < 0 || (n_intervals > 0 && (!interval_starts || !interval_ends)) || !ref_bases || ref_len < 0)) return PISCES_E_INVALID_ARG;
@@ -340,6 +342,10 @@ int64_t pisces_hip_format_vcf_padded(const PiscesVcfConfig* cfg, const char* chr
         if (pad) *state = st;
     }
     return need;   // > capacity: nothing was written and the state is unchanged, call again with a buffer of this size
+    }();
+    } catch (...) {
+        return PISCES_E_INTERNAL;
+    }
 }
 
 int64_t pisces_hip_format_vcf(const PiscesVcfConfig* cfg, const char* chrom, const PiscesCalledAllele* recs, int64_t n,

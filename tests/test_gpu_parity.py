@@ -1640,3 +1640,66 @@ def test_forced_alleles_against_the_oracle(torch_cuda, mode):
     assert stats["TotalNumCalled"] == exp_called
     fmt = lambda recs, alleles: engine.format_vcf("chrF", recs, alleles=alleles, noise_level_from_records=1)
     assert fmt(got, got_alleles) == fmt(exp, exp_alleles)
+
+
+@pytest.mark.gpu
+def test_random_configuration_matrix_with_schedules_and_forced_alleles(torch_cuda):
+    """Forty more random mode combinations, this time over a block schedule (400-locus blocks, random upTo positions: held blocks, MNV
+    leftovers crossing block edges, collapsable candidates of later blocks) and with random forced alleles (present in the reads or
+    not; SNVs, MNVs, insertions, deletions; some at positions without coverage): records, allele strings and TotalNumCalled against
+    the oracle running the same schedule."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(31337)
+    ref = bytes(rng.choice(list(b"ACGT"), 1700).astype(np.uint8))
+    reads = _mnv_reads(rng, ref, 2600, region=(30, 1500))
+    for i in range(160):
+        if i % 2:
+            reads.append({"pos": 760, "cigar": [("M", 41), ("D", 2), ("M", 50)], "seq": (ref[759:800] + ref[802:852]).decode(), "reverse": bool(i & 2)})
+        else:
+            reads.append({"pos": 1160, "cigar": [("M", 41), ("I", 3), ("M", 50)], "seq": (ref[1159:1200] + b"GAT" + ref[1200:1250]).decode(), "reverse": bool(i & 2)})
+    for r in reads:
+        r["quals"] = rng.choice([12, 23, 30, 37, 41], len(r["seq"]), p=[.03, .15, .2, .45, .17]).astype(np.uint8).tolist()
+    reads.sort(key=lambda r: r["pos"])
+    batch = _abi.ReadBatch(reads)
+    refa = np.frombuffer(ref, dtype=np.uint8)
+    other = lambda p, k=0: chr([b for b in b"ACGT" if b != ref[p - 1]][k % 3])
+    refs = lambda p, n: ref[p - 1: p - 1 + n].decode()
+    for trial in range(40):
+        ploidy = int(rng.choice([0, 0, 1, 2]))
+        kw = dict(call_mnvs=int(rng.integers(0, 2)), collapse=int(rng.integers(0, 2)), noise_model=int(rng.integers(0, 2)), ploidy=ploidy,
+                  strand_bias_model=int(rng.choice([0, 1, 2])), include_reference_calls=int(rng.integers(0, 2)),
+                  min_frequency=float(rng.choice([0.005, 0.01, 0.05])) if ploidy == 0 else 0.2,
+                  min_variant_qscore=int(rng.choice([10, 20, 30])), low_gq_filter=int(rng.choice([-1, 30])), block_size=400,
+                  max_mnv_length=int(rng.choice([2, 3, 5])), max_gap_between_mnv=int(rng.choice([0, 1, 2])))
+        kw["variant_freq_filter"] = kw["min_frequency"]
+        cfg = _abi.default_config(**kw)
+        schedule = sorted(int(x) for x in rng.integers(200, 1690, int(rng.integers(1, 6))))
+        forced = []
+        for _ in range(int(rng.integers(0, 9))):
+            p = int(rng.integers(5, 1650))
+            kind = int(rng.integers(0, 4))
+            if kind == 0: forced.append((p, refs(p, 1), other(p, int(rng.integers(0, 3)))))
+            elif kind == 1:
+                n = int(rng.integers(2, 4))
+                forced.append((p, refs(p, n), "".join(other(p + i, i) for i in range(n))))
+            elif kind == 2: forced.append((p, refs(p, 1), refs(p, 1) + "ACGT"[: int(rng.integers(1, 4))]))
+            else: forced.append((p, refs(p, 1 + int(rng.integers(1, 4))), refs(p, 1)))
+        if rng.random() < 0.5:
+            forced += [(760, refs(760, 3), refs(760, 1)), (1160, refs(1160, 1), refs(1160, 1) + "GAT")]   # the planted deletion / insertion
+        forced = list(dict.fromkeys(forced))
+        exp, exp_alleles, exp_called = orc.run_reads_schedule(batch, refa, 1, len(ref), cfg, schedule, forced=forced)
+        with engine.HipVariantCaller(cfg) as c:
+            c.SetReference(refa)
+            if forced:
+                c.SetForcedAlleles(forced)
+            c.AddAlleleCounts(batch)
+            got, got_alleles = [], []
+            for up_to in schedule + [None]:
+                rr, a = c.CallWithAlleles(upToPosition=up_to)
+                got.append(rr)
+                got_alleles += a
+            stats = c.Stats()
+        got = np.concatenate(got)
+        assert got_alleles == exp_alleles, (trial, kw, schedule, forced)
+        assert_records_match(got, exp)
+        assert stats["TotalNumCalled"] == exp_called, (trial, kw, schedule, forced)
