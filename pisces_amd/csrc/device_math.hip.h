@@ -650,6 +650,118 @@ __device__ __forceinline__ bool somatic_gq_try(int32_t genotype, int32_t variant
     return true;
 }
 
+// ------------------------------------------------------------------------------------------
+// The same table-first forms with every table entry an allele can need requested AT ONCE (one memory round trip instead of a
+// chain of five to eight: in the call phase of the streaming kernel a dependent global load queues behind the CU's streaming loads
+// and costs a microsecond).  The addresses depend on the integer counts only; an entry that is out of range is requested at
+// index 0 and ignored.  The decisions and the values are those of poisson_qscore_try / sb_stats_try / somatic_gq_try.
+// ------------------------------------------------------------------------------------------
+struct AlleleTables {
+    int32_t vq;            // P.vq_tab[support][coverage]
+    double sb[3];          // overall / forward / reverse: P.sb_tab[support][coverage], or P.sb0_tab[coverage] when support == 0
+    int32_t gq_cap;        // P.gq_cap[gq_idx]
+    int32_t gq_idx;        // somatic_gq_index (-1 = none)
+    uint32_t have;         // bit 0: vq, bits 1..3: sb[0..2]
+};
+__device__ __forceinline__ bool tables_complete(const DeviceParams& P) { return P.vq_tab && P.sb_tab && P.sb0_tab && P.gq_cap; }
+
+__device__ __forceinline__ AlleleTables request_allele_tables(bool isRef, int32_t support, int32_t total, int32_t refsup, const int32_t cov[3],
+                                                              const int32_t sup[3], const DeviceParams& P)
+{
+    AlleleTables t;
+    const uint32_t tab_cov = (uint32_t)P.tab_cov;
+    const bool vq_in = support > 0 && total > 0 && support < P.vq_tab_k && total < P.tab_cov;
+    const int16_t vq_v = P.vq_tab[vq_in ? (uint32_t)support * tab_cov + (uint32_t)total : 0u];
+    const int s2 = sup[2] / 2, c2 = cov[2] / 2;
+    const int ss[3] = {sup[0] + sup[1] + sup[2], sup[0] + s2, sup[1] + s2};
+    const int cc[3] = {cov[0] + cov[1] + cov[2], cov[0] + c2, cov[1] + c2};
+    double sb_v[3];
+    uint32_t have = vq_in ? 1u : 0u;
+#pragma unroll
+    for (int w = 0; w < 3; w++) {
+        const bool zero = ss[w] == 0;
+        const bool in = zero ? (P.sb_model != PISCES_SB_POISSON && cc[w] >= 0 && cc[w] < P.tab_cov)
+                             : (ss[w] > 0 && ss[w] < P.sb_tab_k && cc[w] >= 0 && cc[w] < P.tab_cov);
+        const double* base = zero ? P.sb0_tab : P.sb_tab;
+        const uint32_t idx = in ? (zero ? (uint32_t)cc[w] : (uint32_t)ss[w] * tab_cov + (uint32_t)cc[w]) : 0u;
+        sb_v[w] = base[idx];
+        have |= in ? (2u << w) : 0u;
+    }
+    t.gq_idx = somatic_gq_index(somatic_genotype(isRef, total, support, refsup, P), total, support, P);
+    const int16_t gq_v = P.gq_cap[t.gq_idx >= 0 ? t.gq_idx : 0];
+    t.vq = vq_v;
+    t.sb[0] = sb_v[0]; t.sb[1] = sb_v[1]; t.sb[2] = sb_v[2];
+    t.gq_cap = gq_v;
+    t.have = have;
+    return t;
+}
+
+__device__ __forceinline__ bool poisson_qscore_try(int32_t callCount, int32_t coverage, const DeviceParams& P, const AlleleTables& t, int32_t& vq)
+{
+    if ((callCount <= 0) || (coverage <= 0)) { vq = 0; return true; }
+    if (t.have & 1u) { vq = t.vq; return true; }
+    const double lambda = P.err_q * coverage;
+    if (P.max_vq <= 110 && callCount >= 3 && (double)callCount >= 2.0 * lambda) {
+        const double km1 = callCount - 1;
+        const double need = ((double)P.max_vq + 1.0) * 0.23025850929940458 + 1e-3;
+        if (km1 * (ln_ratio_lower_bound(km1, lambda) - 1.0) >= need) { vq = P.max_vq; return true; }
+    }
+    return false;
+}
+
+__device__ __forceinline__ bool sb_stats_try(int32_t support, int32_t coverage, const DeviceParams& P, bool have, double value, SbStats& st)
+{
+    st.support = (double)support;
+    st.coverage = (double)coverage;
+    if (support == 0) {
+        if (P.sb_model == PISCES_SB_POISSON) {
+            st.false_pos = 1;
+            st.var_gt_zero = 0;
+            return true;
+        }
+        if (!have) return false;
+        st.var_gt_zero = value;
+        st.false_pos = 1 - st.var_gt_zero;
+        return true;
+    }
+    if (have) {
+        st.var_gt_zero = value;
+    } else {
+        const double a = (double)support, x = (double)coverage * P.err_sb;
+        if (!(x > 0.0 && 2.0 * x <= a && a * (ln_ratio_lower_bound(a, x) - 1.0) + x > 51.0)) return false;
+        st.var_gt_zero = 1.0;
+    }
+    st.false_pos = fmax(0.0, 1 - st.var_gt_zero);
+    return true;
+}
+
+__device__ __forceinline__ bool strand_bias_try(const int32_t cov[3], const int32_t sup[3], const DeviceParams& P, const AlleleTables& t,
+                                                double& bias_score, int& acceptable, int& var_both, int& cov_both)
+{
+    const int s2 = sup[2] / 2, c2 = cov[2] / 2;   // the stitched halves use integer division (:36-41)
+    const int sf = sup[0] + s2, sr = sup[1] + s2, cf = cov[0] + c2, cr = cov[1] + c2;
+    SbStats overall, fwd, rev;
+    const bool ok0 = sb_stats_try(sup[0] + sup[1] + sup[2], cov[0] + cov[1] + cov[2], P, (t.have & 2u) != 0, t.sb[0], overall);
+    const bool ok1 = sb_stats_try(sf, cf, P, (t.have & 4u) != 0, t.sb[1], fwd);
+    const bool ok2 = sb_stats_try(sr, cr, P, (t.have & 8u) != 0, t.sb[2], rev);
+    double forwardBias = 0.0, reverseBias = 0.0;
+    if (!(fwd.false_pos == 0.0 && rev.false_pos == 0.0 && overall.var_gt_zero > 0.0)) {
+        forwardBias = (fwd.var_gt_zero * rev.false_pos) / overall.var_gt_zero;
+        reverseBias = (rev.var_gt_zero * fwd.false_pos) / overall.var_gt_zero;
+        if (overall.var_gt_zero == 0) {
+            forwardBias = 1;
+            reverseBias = 1;
+        }
+    }
+    double score = forwardBias > reverseBias ? forwardBias : reverseBias;
+    cov_both = (cf > 0) && (cr > 0);
+    var_both = (sf > 0) && (sr > 0);
+    if (!cov_both) score = 0;
+    bias_score = score;
+    acceptable = score < P.sb_threshold;
+    return ok0 && ok1 && ok2;
+}
+
 // Out-of-line leaves of the wave kernel's cold path (an allele beyond the memo tables): the evaluations the tables were filled
 // with, as calls, so that neither their registers nor their code weigh on the call phase proper.
 __device__ __noinline__ int32_t poisson_qscore_out_of_line(int32_t callCount, int32_t coverage, double err, int32_t max_vq, double ln10)

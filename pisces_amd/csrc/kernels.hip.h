@@ -679,58 +679,18 @@ __device__ __forceinline__ uint32_t slow_alleles(const int* hist, const uint8_t*
     return called;
 }
 
+// The call phase of one tile whose histogram sits in LDS: lane = locus.  NW = 2: the two waves of the tile's workgroup share it (wave 0
+// makes the Reference records and the tile directory, wave 1 the variant records; they meet once in LDS).  NW = 1: one wave does all of it.
 template <int NW>
-__global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_OCC) void call_tiles_wave_kernel(
-    const uint32_t* __restrict__ tuples, const PiscesTile* __restrict__ tiles, int32_t n_tiles,
-    const uint8_t* __restrict__ ref, int32_t ref_start, int64_t ref_len, PiscesCalledAllele* __restrict__ records,
-    PiscesTileResult* __restrict__ tile_results, DeviceParams P, const DeviceParams* __restrict__ Pd /* the same in device memory, for the cold path */)
+__device__ __forceinline__ void call_phase_wave(const int* hist, const uint8_t* s_refwin, uint8_t* s_vmask, const PiscesTile& tile, const int t,
+                                                const int l, const int wid, const uint8_t* __restrict__ ref, const int32_t ref_start,
+                                                const int64_t ref_len, PiscesCalledAllele* __restrict__ records,
+                                                PiscesTileResult* __restrict__ tile_results, const DeviceParams& P
+#ifdef PISCES_TIMING
+                                                , const long long tc0, const long long tc1
+#endif
+                                                )
 {
-    __shared__ __attribute__((aligned(16))) int hist[2 * kWaveRegion];   // 16 KiB: [region][allele:direction row][column]
-    __shared__ uint8_t s_refwin[kRefWin];
-    __shared__ uint8_t s_vmask[kTile];
-
-    const int t = blockIdx.x;
-    if (t >= n_tiles) return;
-    const int l = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const PiscesTile tile = tiles[t];
-#ifdef PISCES_TIMING
-    const long long tc0 = wall_clock64();
-#endif
-    auto setup = [&]() {
-        int4* h4 = reinterpret_cast<int4*>(hist);
-        for (int i = threadIdx.x; i < 2 * kWaveRegion / 4; i += 64 * NW) h4[i] = make_int4(0, 0, 0, 0);
-        for (int i = threadIdx.x; i < kRefWin; i += 64 * NW) {
-            const int64_t ri = (int64_t)tile.start_position - kRefMargin + i - ref_start;
-            s_refwin[i] = (ri >= 0 && ri < ref_len) ? ref[ri] : (uint8_t)0;
-        }
-        __syncthreads();
-    };
-
-    {
-        // single-round launches (NW = 2): streaming waves win the issue arbitration over waves in their call phase — the launch
-        // ends with the slowest tile, and a tile that is still streaming has its whole call phase ahead of it
-#ifndef PISCES_NO_PRIO
-        if (NW == 2) __builtin_amdgcn_s_setprio(3);
-#endif
-        const uint32_t min_bq_shifted = (uint32_t)min(max(P.min_bq, 0), 255) << 24;
-#if defined(PISCES_ABLATE) && PISCES_ABLATE == 2
-        uint32_t acc = 0;   // development ablation: loads only
-        stream_tuples_wave<NW>(tuples, tile.tuple_begin, tile.tuple_end, l, wid, [&](uint32_t v) { acc ^= v; }, setup);
-        if (acc == 0x12345u) hist[l] = (int)min_bq_shifted;
-#else
-        stream_tuples_wave<NW>(tuples, tile.tuple_begin, tile.tuple_end, l, wid, [&](uint32_t v) { accumulate_wave(hist, v, min_bq_shifted); }, setup);
-#endif
-    }
-    __syncthreads();
-    if (NW == 2) __builtin_amdgcn_s_setprio(0);
-#if defined(PISCES_ABLATE) && PISCES_ABLATE >= 1
-    if (threadIdx.x == 0) { tile_results[t].record_begin = 0; tile_results[t].n_records = hist[5 + l]; }
-    return;
-#endif
-#ifdef PISCES_TIMING
-    const long long tc1 = wall_clock64();
-#endif
-
     // ---- call phase: lane = locus; with two waves per tile wave 0 makes the Reference records and the tile directory, wave 1 the
     // variant records, and they meet once in LDS (a variant called at a locus drops its Reference record, AlleleCaller.cs:146-147).
     // Every FP64 tail comes from the handle's memo tables (DeviceParams), keyed by the integer counts: no incomplete gamma,
@@ -744,16 +704,21 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
     const LocusCounts lc = load_counts_wave(hist, l);
     const bool ref_wave = wid == 0, var_wave = wid == NW - 1;
 
-    // One allele through the table-first forms; false = a table missed (the record is not made)
-    auto fast_allele = [&](const PointCounts& c, int a, bool isRef, PiscesCalledAllele& rec, const GqPre* g) -> bool {
+    // One allele through the table-first forms; false = a table missed (the record is not made).  With the handle's tables in place
+    // (always, for the configurations routed here) every entry the allele can need is requested up front: one round trip.
+    const bool tabs = tables_complete(P);
+    auto fast_allele = [&](const PointCounts& c, int a, bool isRef, PiscesCalledAllele& rec) -> bool {
         int vq = 0;
-        if (c.support > 0 && c.total != 0 && !poisson_qscore_try(c.support, c.total, P, vq)) return false;   // VariantQualityCalculator.Compute :11-24
-        if (!isRef && vq < P.min_vq) return true;                                                             // IsCallable, last test: not callable, nothing to make
         double sb_score = 0.0;
         int sb_ok = 0, sb_var = 0, sb_cov = 0;
-        if (c.support > 0 && !strand_bias_try(c.cov, c.sup, P, sb_score, sb_ok, sb_var, sb_cov)) return false;   // StrandBiasCalculator.Compute :10-15
+        if (!tabs) return false;   // (a handle without tables: everything takes the long way)
+        const AlleleTables tb = request_allele_tables(isRef, c.support, c.total, c.refsup, c.cov, c.sup, P);
+        if (c.support > 0 && c.total != 0 && !poisson_qscore_try(c.support, c.total, P, tb, vq)) return false;   // VariantQualityCalculator.Compute :11-24
+        if (!isRef && vq < P.min_vq) return true;                                                                 // IsCallable, last test: not callable, nothing to make
+        if (c.support > 0 && !strand_bias_try(c.cov, c.sup, P, tb, sb_score, sb_ok, sb_var, sb_cov)) return false;   // StrandBiasCalculator.Compute :10-15
+        const GqPre g = {tb.gq_idx, tb.gq_cap};
         const SbResult sb = {sb_score, sb_ok, sb_var, sb_cov};
-        if (!finish_allele<true>(c, pos, a, isRef, rt, vq, sb, ref, win_lo, win_hi, P, rec, s_refwin, kRefMargin + l, nullptr, g)) return false;
+        if (!finish_allele<true>(c, pos, a, isRef, rt, vq, sb, ref, win_lo, win_hi, P, rec, s_refwin, kRefMargin + l, nullptr, &g)) return false;
         return true;
     };
     bool ref_emitted = false;
@@ -766,14 +731,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
         // out callable at the locus
         const PointCounts c = point_counts_of(lc, ref_a, true, rt, 0);
         if (in_ref && P.include_ref && (P.emit_zero_cov || c.total + c.nocalls > 0)) {
-            // the genotype q-score is one dependent load from the memo table: issue it first
-            GqPre g;
-            g.idx = somatic_gq_index(somatic_genotype(true, c.total, c.support, c.refsup, P), c.total, c.support, P);
-            g.val = (g.idx >= 0 && P.gq_cap) ? (int32_t)P.gq_cap[g.idx] : 0;
             ref_rank = (rt < 4) ? rank_of_allele(rt) : 0;
             ref_emitted = true;
             PiscesCalledAllele rec;
-            if (fast_allele(c, ref_a, true, rec, &g)) copy_record(slot_of(ref_rank), &rec);
+            if (fast_allele(c, ref_a, true, rec)) copy_record(slot_of(ref_rank), &rec);
             else slow |= 16u;
         }
     }
@@ -792,7 +753,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
             if (!variant_passes_frequency(c, P)) continue;
             PiscesCalledAllele r;
             r.position = 0;
-            if (!fast_allele(c, a, false, r, nullptr)) { slow |= 1u << k; continue; }
+            if (!fast_allele(c, a, false, r)) { slow |= 1u << k; continue; }
             if (r.position == 0) continue;   // not callable
             copy_record(slot_of(k), &r);
             vmask |= 1u << k;
@@ -800,7 +761,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
     }
     if (__builtin_expect(__ballot(slow != 0) != 0ull, 0))
         vmask |= slow_alleles(hist, s_refwin, slow, l, pos, rt, ref_rank, ref, win_lo, win_hi, records + ((int64_t)t * kSlotsPerTile + l * 4), P);
-    if (NW > 1) {
+    if (NW == 2) {
         if (var_wave) s_vmask[l] = (uint8_t)vmask;
         __syncthreads();
         if (!ref_wave) return;
@@ -854,6 +815,65 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
         tile_result->valid[5] = (uint32_t)(tc2 - tcB);   // directory
 #endif
     }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_OCC) void call_tiles_wave_kernel(
+    const uint32_t* __restrict__ tuples, const PiscesTile* __restrict__ tiles, int32_t n_tiles,
+    const uint8_t* __restrict__ ref, int32_t ref_start, int64_t ref_len, PiscesCalledAllele* __restrict__ records,
+    PiscesTileResult* __restrict__ tile_results, DeviceParams P, const DeviceParams* __restrict__ Pd /* the same in device memory, for the cold path */)
+{
+    __shared__ __attribute__((aligned(16))) int hist[2 * kWaveRegion];   // 16 KiB: [region][allele:direction row][column]
+    __shared__ uint8_t s_refwin[kRefWin];
+    __shared__ uint8_t s_vmask[kTile];
+
+    const int t = blockIdx.x;
+    if (t >= n_tiles) return;
+    const int l = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const PiscesTile tile = tiles[t];
+#ifdef PISCES_TIMING
+    const long long tc0 = wall_clock64();
+#endif
+    auto setup = [&]() {
+        int4* h4 = reinterpret_cast<int4*>(hist);
+        for (int i = threadIdx.x; i < 2 * kWaveRegion / 4; i += 64 * NW) h4[i] = make_int4(0, 0, 0, 0);
+        for (int i = threadIdx.x; i < kRefWin; i += 64 * NW) {
+            const int64_t ri = (int64_t)tile.start_position - kRefMargin + i - ref_start;
+            s_refwin[i] = (ri >= 0 && ri < ref_len) ? ref[ri] : (uint8_t)0;
+        }
+        __syncthreads();
+    };
+
+    {
+        // single-round launches (NW = 2): streaming waves win the issue arbitration over waves in their call phase — the launch
+        // ends with the slowest tile, and a tile that is still streaming has its whole call phase ahead of it
+#ifndef PISCES_NO_PRIO
+        if (NW == 2) __builtin_amdgcn_s_setprio(3);
+#endif
+        const uint32_t min_bq_shifted = (uint32_t)min(max(P.min_bq, 0), 255) << 24;
+#if defined(PISCES_ABLATE) && PISCES_ABLATE == 2
+        uint32_t acc = 0;   // development ablation: loads only
+        stream_tuples_wave<NW>(tuples, tile.tuple_begin, tile.tuple_end, l, wid, [&](uint32_t v) { acc ^= v; }, setup);
+        if (acc == 0x12345u) hist[l] = (int)min_bq_shifted;
+#else
+        stream_tuples_wave<NW>(tuples, tile.tuple_begin, tile.tuple_end, l, wid, [&](uint32_t v) { accumulate_wave(hist, v, min_bq_shifted); }, setup);
+#endif
+    }
+    __syncthreads();
+    if (NW == 2) __builtin_amdgcn_s_setprio(0);
+#if defined(PISCES_ABLATE) && PISCES_ABLATE >= 1
+    if (threadIdx.x == 0) { tile_results[t].record_begin = 0; tile_results[t].n_records = hist[5 + l]; }
+    return;
+#endif
+#ifdef PISCES_TIMING
+    const long long tc1 = wall_clock64();
+#endif
+
+    call_phase_wave<NW>(hist, s_refwin, s_vmask, tile, t, l, wid, ref, ref_start, ref_len, records, tile_results, P
+#ifdef PISCES_TIMING
+                        , tc0, tc1
+#endif
+                        );
 }
 
 // The handle's memo tables (DeviceParams), filled with the very functions the call phase would otherwise run.
