@@ -33,34 +33,67 @@ enum : int32_t {
 // canonical bit-by-bit walk as the fall-back for longer codes.  Output goes straight to HBM; a copy waits for the wave's outstanding
 // stores first (its source bytes may be among them).  LDS per wave is 5 KB, so a CU holds as many waves as it has slots for and a
 // file's thousands of blocks are all in flight: the serial chains hide one another's latency.
-constexpr int kLutBits = 10;
-constexpr int kLutSize = 1 << kLutBits;
+
+// The payload reaches the bit buffer through a window in LDS: kInWindow bytes of the file copied by all 64 lanes at once (16 bytes a
+// lane per load instruction), so that topping up the bit buffer is an LDS read (~100 cycles) and not a global load on the decode's
+// dependent chain (a microsecond while the chip is busy: with a few thousand blocks in flight that wait was most of a symbol's time).
+constexpr int kInWindow = 2048;   // bytes; the window starts on a 16-byte boundary of the file copy
 
 struct InflateStream {
-    const uint8_t* in;
-    int32_t in_len, in_pos;   // in_pos: next byte to load into the bit buffer
+    const uint8_t* in;        // first byte of the payload
+    int32_t in_len, in_pos;   // in_pos: next byte to load into the bit buffer, relative to `in`; in + in_pos is 4-byte aligned
     uint64_t bitbuf;
     int32_t bitcnt;
     uint8_t* out;
     int32_t out_len, out_pos;
     int32_t err;
     int lane;
+    uint32_t* window;         // LDS [kInWindow / 4]
+    int32_t win_pos;          // in_pos of the window's first byte (or a value that no in_pos lies in)
 };
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
 
 __device__ __forceinline__ void inflate_refill(InflateStream& s)
 {
     if (s.bitcnt <= 32) {
-        // the file bytes continue past the payload (trailer, next header; the device copy is padded), so the load itself is always
+        // the file bytes continue past the payload (trailer, next header; the device copy is padded), so the loads themselves are always
         // in bounds; consuming bits that lie past the payload is the error
         if (s.in_pos >= s.in_len + 8) { s.err = s.err ? s.err : kInflateInputExhausted; return; }
-        const uint8_t* p = s.in + s.in_pos;
-        // every lane loads the same word; telling the compiler so keeps the bit buffer and all that follows from it (symbols, lengths,
+        if ((uint32_t)(s.in_pos - s.win_pos) >= (uint32_t)kInWindow) {
+            // slide the window: it starts at the 16-byte boundary at or below in_pos
+            const int32_t skew = (int32_t)((uintptr_t)(s.in + s.in_pos) & 15u);
+            s.win_pos = s.in_pos - skew;
+            const uint4* src = reinterpret_cast<const uint4*>(s.in + s.win_pos);
+            uint4* dst = reinterpret_cast<uint4*>(s.window);
+            wave_lds_fence();   // (earlier reads of the window are done)
+#pragma unroll
+            for (int k = 0; k < kInWindow / 16 / 64; k++) dst[k * 64 + s.lane] = src[k * 64 + s.lane];
+            wave_lds_fence();
+        }
+        // every lane reads the same word; telling the compiler so keeps the bit buffer and all that follows from it (symbols, lengths,
         // the branches on them) in scalar registers and scalar branches instead of 64-wide copies under exec masks
-        const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane(
-            (int)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)));
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.window[(uint32_t)(s.in_pos - s.win_pos) >> 2]);
         s.bitbuf |= (uint64_t)w << s.bitcnt;
         s.bitcnt += 32;
         s.in_pos += 4;
+    }
+}
+
+// puts the bit buffer at byte `pos` of the payload (the start of the stream, the byte after a stored block)
+__device__ __forceinline__ void inflate_seek(InflateStream& s, int32_t pos)
+{
+    const int32_t skew = (int32_t)((uintptr_t)(s.in + pos) & 3u);
+    s.in_pos = pos - skew;
+    s.bitbuf = 0;
+    s.bitcnt = 0;
+    if (skew) {
+        inflate_refill(s);
+        if (s.bitcnt >= 8 * skew) { s.bitbuf >>= 8 * skew; s.bitcnt -= 8 * skew; }
     }
 }
 
@@ -79,49 +112,79 @@ __device__ __forceinline__ bool inflate_overran(const InflateStream& s) { return
 struct HuffmanTable {
     int16_t* count;    // [16] codes of each length
     int16_t* symbol;   // symbols in canonical code order
-    uint16_t* lut;     // [kLutSize] (symbol << 4) | length for codes of <= kLutBits bits, 0 = longer code
+    uint32_t* lut;     // [1 << lut_bits], indexed by the next bits of the stream; 0 = a code longer than lut_bits (canonical walk)
+    int lut_bits;
 };
+// What a table entry holds depends on what the code is for:
+//   kPlainCode (the code-length code): (symbol << 4) | code length
+//   kLengthCode (literals and lengths): bits 0-3 = bits to consume, bits 4-5 = n literals (1..3: the codes of up to three literals
+//       that fit into lut_bits together, bytes in bits 8-15 / 16-23 / 24-31), else bit 6 = end of block, bit 7 = a length code with
+//       its base in bits 8-16 and its number of extra bits in bits 17-19 (neither bit: an invalid symbol)
+//   kDistanceCode: bits 0-3 = bits to consume, bits 4-7 = extra bits, bits 8-22 = base, bit 31 = a valid distance symbol
+// A run of quality bytes (a handful of symbols, 2-3 bit codes) is then three bytes per look-up, and a length or distance needs no
+// table of bases: the look-up is the one dependent LDS read per step of the serial chain.
+enum { kPlainCode = 0, kLengthCode = 1, kDistanceCode = 2 };
+constexpr int kLenLutBits = 10, kDistLutBits = 9;
 
-__device__ __forceinline__ void wave_lds_fence()
-{
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-}
+__device__ const int16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__device__ const int16_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__device__ const int16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145,
+                                          8193, 12289, 16385, 24577};
+__device__ const int16_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__device__ const uint8_t kCodeLengthOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-// canonical code: the codes of one length are consecutive integers, shorter codes first (RFC 1951 3.2.2)
-__device__ __forceinline__ int inflate_decode(InflateStream& s, const HuffmanTable& h)
+// canonical code: the codes of one length are consecutive integers, shorter codes first (RFC 1951 3.2.2).  The bit-by-bit walk over
+// `bits` (first bit of the stream lowest), at most max_len of them: the symbol and its code length, or length 0 when no code ends there.
+__device__ __forceinline__ int inflate_walk(const HuffmanTable& h, uint32_t bits, int max_len, int& symbol)
 {
-    inflate_refill(s);
-    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)h.lut[(uint32_t)s.bitbuf & (kLutSize - 1)]);
-    if (e) {
-        const int n = (int)(e & 15u);
-        s.bitbuf >>= n;
-        s.bitcnt -= n;
-        return (int)(e >> 4);
-    }
     int code = 0, first = 0, index = 0;
-    uint32_t bits = (uint32_t)s.bitbuf;
-    for (int len = 1; len <= 15; len++) {
+    for (int len = 1; len <= max_len; len++) {
         code |= (int)(bits & 1u);
         bits >>= 1;
-        const int count = __builtin_amdgcn_readfirstlane((int)h.count[len]);
+        const int count = h.count[len];
         if (code - count < first) {
-            s.bitbuf >>= len;
-            s.bitcnt -= len;
-            return __builtin_amdgcn_readfirstlane((int)h.symbol[index + (code - first)]);
+            symbol = h.symbol[index + (code - first)];
+            return len;
         }
         index += count;
         first += count;
         first <<= 1;
         code <<= 1;
     }
-    s.err = kInflateBadSymbol;
-    return -1;
+    return 0;
+}
+
+__device__ __forceinline__ void inflate_consume(InflateStream& s, int n)
+{
+    s.bitbuf >>= n;
+    s.bitcnt -= n;
+}
+
+// a code that is longer than the table's index: the walk, with the state kept scalar
+__device__ __forceinline__ int inflate_decode_long(InflateStream& s, const HuffmanTable& h)
+{
+    int symbol = 0;
+    const int len = __builtin_amdgcn_readfirstlane(inflate_walk(h, (uint32_t)s.bitbuf, 15, symbol));
+    if (len == 0) { s.err = kInflateBadSymbol; return -1; }
+    inflate_consume(s, len);
+    return __builtin_amdgcn_readfirstlane(symbol);
+}
+
+// one symbol of a kPlainCode table
+__device__ __forceinline__ int inflate_decode(InflateStream& s, const HuffmanTable& h)
+{
+    inflate_refill(s);
+    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)h.lut[(uint32_t)s.bitbuf & ((1u << h.lut_bits) - 1u)]);
+    if (e) {
+        inflate_consume(s, (int)(e & 15u));
+        return (int)(e >> 4);
+    }
+    return inflate_decode_long(s, h);
 }
 
 // returns 0 for a complete code, > 0 for an incomplete one (that many codes unused), < 0 when over-subscribed.  Lane 0 counts and
 // sorts (serial), all lanes fill the look-up table.
-__device__ inline int inflate_construct(const InflateStream& s, HuffmanTable& h, const int16_t* length, int n, int16_t* offs /* [16] LDS */)
+__device__ inline int inflate_construct(const InflateStream& s, HuffmanTable& h, const int16_t* length, int n, int16_t* offs /* [16] LDS */, int kind)
 {
     if (s.lane == 0) {
         for (int len = 0; len <= 15; len++) h.count[len] = 0;
@@ -132,79 +195,151 @@ __device__ inline int inflate_construct(const InflateStream& s, HuffmanTable& h,
             if (length[sym] != 0) h.symbol[offs[length[sym]]++] = (int16_t)sym;   // offs[len] ends as the END of that length's run
     }
     wave_lds_fence();
-    int left = 1, total = 0;
+    int left = 1;
     for (int len = 1; len <= 15; len++) {
         left <<= 1;
         left -= h.count[len];
-        total += h.count[len];
         if (left < 0) break;
     }
-    for (int k = s.lane; k < kLutSize; k += 64) h.lut[k] = 0;
-    wave_lds_fence();
-    if (left >= 0 && h.count[0] != n) {
-        // entry i of symbol[] has length len where run_begin(len) <= i < run_end(len), code = first_code(len) + i - run_begin(len)
-        for (int i = s.lane; i < total; i += 64) {
-            int len = 1, begin = 0, code0 = 0;
-            while (len <= 15 && i >= begin + h.count[len]) { code0 = (code0 + h.count[len]) << 1; begin += h.count[len]; len++; }
-            if (len <= kLutBits) {
-                const uint32_t code = (uint32_t)(code0 + (i - begin));
-                const uint32_t rev = __brev(code) >> (32 - len);   // the stream carries a code's most significant bit first
-                const uint16_t e = (uint16_t)(((uint32_t)h.symbol[i] << 4) | (uint32_t)len);
-                for (uint32_t k = rev; k < (uint32_t)kLutSize; k += 1u << len) h.lut[k] = e;
+    const bool usable = left >= 0 && h.count[0] != n;
+    const int size = 1 << h.lut_bits;
+    for (int i = s.lane; i < size; i += 64) {
+        uint32_t e = 0;
+        int sym = 0;
+        const int len = usable ? inflate_walk(h, (uint32_t)i, h.lut_bits, sym) : 0;
+        if (len) {
+            if (kind == kPlainCode) {
+                e = ((uint32_t)sym << 4) | (uint32_t)len;
+            } else if (kind == kDistanceCode) {
+                e = (uint32_t)len;
+                if (sym < 30) e |= ((uint32_t)kDistExtra[sym] << 4) | ((uint32_t)kDistBase[sym] << 8) | 0x80000000u;
+            } else if (sym < 256) {
+                // up to three literals whose codes fit into the index together
+                int used = len, n_lit = 1;
+                e = (uint32_t)sym << 8;
+                while (n_lit < 3 && used < h.lut_bits) {
+                    int next = 0;
+                    const int l = inflate_walk(h, (uint32_t)i >> used, h.lut_bits - used, next);
+                    if (l == 0 || next >= 256) break;
+                    e |= (uint32_t)next << (8 + 8 * n_lit);
+                    used += l;
+                    n_lit++;
+                }
+                e |= (uint32_t)used | ((uint32_t)n_lit << 4);
+            } else if (sym == 256) {
+                e = (uint32_t)len | 0x40u;
+            } else {
+                e = (uint32_t)len;
+                if (sym <= 285) e |= 0x80u | ((uint32_t)kLenBase[sym - 257] << 8) | ((uint32_t)kLenExtra[sym - 257] << 17);
             }
         }
+        h.lut[i] = e;
     }
     wave_lds_fence();
     if (h.count[0] == n) return 0;   // no codes: complete, but decoding will fail
     return left;
 }
 
-__device__ const int16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__device__ const int16_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__device__ const int16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145,
-                                          8193, 12289, 16385, 24577};
-__device__ const int16_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
-__device__ const uint8_t kCodeLengthOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-
-// literals and length / distance pairs until the end-of-block code (RFC 1951 3.2.3, 3.2.5)
+// literals and length / distance pairs until the end-of-block code (RFC 1951 3.2.3, 3.2.5).
+// The decode is a serial chain per block and the CU's scalar issue is what the waves share (the decoder state is scalar), so the loop
+// is written for few steps and few instructions per byte: one table look-up yields up to three literals, or a length with its base and
+// extra-bit count, or a distance likewise; a literal is parked in the lane whose index is its place in the current run and a run goes
+// out with ONE store instruction, lane k writing byte k, when a match, the end of the block or the 62nd literal arrives; the test that
+// the stream has not run past its payload is made where a block ends, not per symbol (the bit buffer cannot read outside the padded
+// device copy: inflate_refill), and a decode error surfaces at the next symbol that is not a literal or at the output bound.
 __device__ inline void inflate_codes(InflateStream& s, const HuffmanTable& lencode, const HuffmanTable& distcode)
 {
+    uint32_t run = 0;   // lane k: the k-th literal of the pending run
+    int n_run = 0;      // literals pending (wave-uniform); they belong at out[out_pos - n_run, out_pos)
+    auto flush = [&]() {
+        if (n_run) {
+#ifndef PISCES_INFLATE_ABLATE_LIT
+            if (s.lane < n_run) s.out[s.out_pos - n_run + s.lane] = (uint8_t)run;
+#endif
+            n_run = 0;
+        }
+    };
+    const uint32_t lmask = (1u << lencode.lut_bits) - 1u, dmask = (1u << distcode.lut_bits) - 1u;
     for (;;) {
-        int symbol = inflate_decode(s, lencode);
-        if (s.err) return;
-        if (symbol < 256) {
-            if (s.out_pos >= s.out_len) { s.err = kInflateOutputOverflow; return; }
-            if (s.lane == 0) s.out[s.out_pos] = (uint8_t)symbol;
-            s.out_pos++;
-        } else if (symbol == 256) {
-            return;
+        inflate_refill(s);
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)lencode.lut[(uint32_t)s.bitbuf & lmask]);
+        const int n_lit = (int)((e >> 4) & 3u);
+        if (n_lit) {
+            if (s.out_pos + n_lit > s.out_len) { s.err = s.err ? s.err : kInflateOutputOverflow; break; }
+            const uint32_t k = (uint32_t)(s.lane - n_run);
+            run = k < (uint32_t)n_lit ? (e >> (8u + 8u * k)) & 255u : run;
+            n_run += n_lit;
+            s.out_pos += n_lit;
+            inflate_consume(s, (int)(e & 15u));
+            if (n_run > 61) flush();
+            continue;
+        }
+        int len;
+        if (e) {
+            inflate_consume(s, (int)(e & 15u));
+            flush();
+            if (s.err) return;
+            if (e & 0x40u) {   // end of block
+                if (inflate_overran(s)) s.err = kInflateInputExhausted;
+                return;
+            }
+            if (!(e & 0x80u)) { s.err = kInflateBadSymbol; return; }
+            len = (int)((e >> 8) & 0x1FFu) + (int)inflate_bits(s, (int)((e >> 17) & 7u));
         } else {
+            int symbol = inflate_decode_long(s, lencode);
+            if ((uint32_t)symbol < 256u) {
+                if (s.out_pos >= s.out_len) { s.err = s.err ? s.err : kInflateOutputOverflow; break; }
+                run = s.lane == n_run ? (uint32_t)symbol : run;
+                n_run++;
+                s.out_pos++;
+                if (n_run > 61) flush();
+                continue;
+            }
+            flush();
+            if (s.err) return;
+            if (symbol == 256) {
+                if (inflate_overran(s)) s.err = kInflateInputExhausted;
+                return;
+            }
             symbol -= 257;
             if (symbol >= 29) { s.err = kInflateBadSymbol; return; }
-            const int len = kLenBase[symbol] + (int)inflate_bits(s, kLenExtra[symbol]);
-            symbol = inflate_decode(s, distcode);
+            len = kLenBase[symbol] + (int)inflate_bits(s, kLenExtra[symbol]);
+        }
+        inflate_refill(s);
+        const uint32_t ed = (uint32_t)__builtin_amdgcn_readfirstlane((int)distcode.lut[(uint32_t)s.bitbuf & dmask]);
+        int dist;
+        if (ed) {
+            inflate_consume(s, (int)(ed & 15u));
+            if (!(ed >> 31)) { s.err = kInflateBadSymbol; return; }
+            dist = (int)((ed >> 8) & 0x7FFFu) + (int)inflate_bits(s, (int)((ed >> 4) & 15u));
+        } else {
+            const int symbol = inflate_decode_long(s, distcode);
             if (s.err) return;
             if (symbol >= 30) { s.err = kInflateBadSymbol; return; }
-            const int dist = kDistBase[symbol] + (int)inflate_bits(s, kDistExtra[symbol]);
-            if (s.err) return;
-            if (dist > s.out_pos) { s.err = kInflateDistanceTooFar; return; }
-            if (s.out_pos + len > s.out_len) { s.err = kInflateOutputOverflow; return; }
-            // the source bytes may still be on their way to memory (this wave's own earlier stores)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            // every source byte lies before out_pos, also when the pair overlaps itself (dist < len: a run of period dist)
-            const uint8_t* src = s.out + s.out_pos - dist;
-            uint8_t* dst = s.out + s.out_pos;
-            for (int k = s.lane; k < len; k += 64) dst[k] = src[dist >= len ? k : k % dist];
-            s.out_pos += len;
+            dist = kDistBase[symbol] + (int)inflate_bits(s, kDistExtra[symbol]);
         }
-        if (inflate_overran(s)) { s.err = kInflateInputExhausted; return; }
+        if (s.err) return;
+        if (dist > s.out_pos) { s.err = kInflateDistanceTooFar; return; }
+        if (s.out_pos + len > s.out_len) { s.err = kInflateOutputOverflow; return; }
+        // the source bytes may still be on their way to memory (this wave's own earlier stores)
+#ifndef PISCES_INFLATE_ABLATE_COPY
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+        // every source byte lies before out_pos, also when the pair overlaps itself (dist < len: a run of period dist)
+        const uint8_t* src = s.out + s.out_pos - dist;
+        uint8_t* dst = s.out + s.out_pos;
+#ifndef PISCES_INFLATE_ABLATE_COPY
+        for (int k = s.lane; k < len; k += 64) dst[k] = src[dist >= len ? k : k % dist];
+#endif
+        s.out_pos += len;
     }
+    flush();
 }
 
-// LDS workspace of a wave, in int16 units
-constexpr int kInflateTableWords = 16 + 288 + 16 + 30 + 320 + 16 + 2 * kLutSize;
-__device__ inline void inflate_stream(InflateStream& s, int16_t* tables)
+// LDS workspace of a wave: the small tables in int16 units, and the two look-up tables
+constexpr int kInflateTableWords = 16 + 288 + 16 + 30 + 320 + 16;
+__device__ inline void inflate_stream(InflateStream& s, int16_t* tables, uint32_t* llut, uint32_t* dlut)
 {
     int16_t* const lcount = tables;
     int16_t* const lsymbol = lcount + 16;
@@ -212,9 +347,7 @@ __device__ inline void inflate_stream(InflateStream& s, int16_t* tables)
     int16_t* const dsymbol = dcount + 16;
     int16_t* const lengths = dsymbol + 30;
     int16_t* const offs = lengths + 320;
-    uint16_t* const llut = (uint16_t*)(offs + 16);
-    uint16_t* const dlut = llut + kLutSize;
-    HuffmanTable lencode = {lcount, lsymbol, llut}, distcode = {dcount, dsymbol, dlut};
+    HuffmanTable lencode = {lcount, lsymbol, llut, kLenLutBits}, distcode = {dcount, dsymbol, dlut, kDistLutBits};
     int last;
     do {
         last = (int)inflate_bits(s, 1);
@@ -233,16 +366,14 @@ __device__ inline void inflate_stream(InflateStream& s, int16_t* tables)
             if (s.out_pos + (int32_t)len > s.out_len) { s.err = kInflateOutputOverflow; return; }
             for (int32_t k = s.lane; k < (int32_t)len; k += 64) s.out[s.out_pos + k] = s.in[from + k];
             s.out_pos += (int32_t)len;
-            s.in_pos = from + (int32_t)len;
-            s.bitbuf = 0;
-            s.bitcnt = 0;
+            inflate_seek(s, from + (int32_t)len);
         } else if (type == 1) {   // fixed code (RFC 1951 3.2.6)
             for (int sym = s.lane; sym < 288; sym += 64) lengths[sym] = (int16_t)(sym < 144 ? 8 : sym < 256 ? 9 : sym < 280 ? 7 : 8);
             wave_lds_fence();
-            (void)inflate_construct(s, lencode, lengths, 288, offs);
+            (void)inflate_construct(s, lencode, lengths, 288, offs, kLengthCode);
             for (int sym = s.lane; sym < 30; sym += 64) lengths[sym] = 5;
             wave_lds_fence();
-            (void)inflate_construct(s, distcode, lengths, 30, offs);
+            (void)inflate_construct(s, distcode, lengths, 30, offs, kDistanceCode);
             inflate_codes(s, lencode, distcode);
         } else if (type == 2) {   // dynamic code (RFC 1951 3.2.7)
             const int nlen = (int)inflate_bits(s, 5) + 257, ndist = (int)inflate_bits(s, 5) + 1, ncode = (int)inflate_bits(s, 4) + 4;
@@ -254,7 +385,7 @@ __device__ inline void inflate_stream(InflateStream& s, int16_t* tables)
             }
             if (s.err) return;
             wave_lds_fence();
-            if (inflate_construct(s, lencode, lengths, 19, offs) != 0) { s.err = kInflateBadCodeLengths; return; }   // the code-length code is complete
+            if (inflate_construct(s, lencode, lengths, 19, offs, kPlainCode) != 0) { s.err = kInflateBadCodeLengths; return; }   // the code-length code is complete
             int index = 0, prev = 0;
             while (index < nlen + ndist) {
                 int symbol = inflate_decode(s, lencode);
@@ -286,9 +417,9 @@ __device__ inline void inflate_stream(InflateStream& s, int16_t* tables)
             }
             wave_lds_fence();
             if (lengths[256] == 0) { s.err = kInflateBadCodeLengths; return; }   // no end-of-block code
-            int e = inflate_construct(s, lencode, lengths, nlen, offs);
+            int e = inflate_construct(s, lencode, lengths, nlen, offs, kLengthCode);
             if (e && (e < 0 || nlen != lencode.count[0] + lencode.count[1])) { s.err = kInflateBadCodeLengths; return; }   // incomplete only as a single code
-            e = inflate_construct(s, distcode, lengths + nlen, ndist, offs);
+            e = inflate_construct(s, distcode, lengths + nlen, ndist, offs, kDistanceCode);
             if (e && (e < 0 || ndist != distcode.count[0] + distcode.count[1])) { s.err = kInflateBadCodeLengths; return; }
             inflate_codes(s, lencode, distcode);
         } else {
@@ -299,11 +430,13 @@ __device__ inline void inflate_stream(InflateStream& s, int16_t* tables)
     if (s.out_pos != s.out_len) s.err = kInflateLengthMismatch;
 }
 
-// in: the file bytes as they are (the device copy carries 16 spare bytes behind the last one); blocks: payload offset / length and
+// in: the file bytes as they are (the device copy carries a window (kInWindow + 32 bytes) of slack behind the last one); blocks: payload offset / length and
 // output offset / length (ISIZE) per block.
 __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restrict__ in, const PiscesBgzfBlock* __restrict__ blocks, int64_t n_blocks,
                                                           uint8_t* out, int32_t* __restrict__ status)
 {
+    __shared__ __attribute__((aligned(16))) uint32_t window[kInWindow / 4];
+    __shared__ uint32_t llut[1 << kLenLutBits], dlut[1 << kDistLutBits];
     __shared__ int16_t tables[kInflateTableWords];
     const int64_t i = (int64_t)blockIdx.x;
     if (i >= n_blocks) return;
@@ -311,15 +444,15 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
     InflateStream s;
     s.in = in + b.in_offset;
     s.in_len = b.in_length;
-    s.in_pos = 0;
-    s.bitbuf = 0;
-    s.bitcnt = 0;
+    s.window = window;
+    s.win_pos = -2 * kInWindow;
     s.out = out + b.out_offset;
     s.out_len = b.out_length;
     s.out_pos = 0;
     s.err = kInflateOk;
     s.lane = (int)threadIdx.x;
-    inflate_stream(s, tables);
+    inflate_seek(s, 0);
+    inflate_stream(s, tables, llut, dlut);
     if (threadIdx.x == 0) status[i] = s.err;
 }
 
