@@ -50,6 +50,7 @@ struct InflateStream {
     int lane;
     uint32_t* window;         // LDS [kInWindow / 4]
     int32_t win_pos;          // in_pos of the window's first byte (or a value that no in_pos lies in)
+    int32_t safe_pos;         // every output byte below it has reached memory (the wave's stores were waited for)
 };
 
 __device__ __forceinline__ void wave_lds_fence()
@@ -261,19 +262,22 @@ __device__ inline void inflate_codes(InflateStream& s, const HuffmanTable& lenco
     };
     const uint32_t lmask = (1u << lencode.lut_bits) - 1u, dmask = (1u << distcode.lut_bits) - 1u;
     for (;;) {
-        inflate_refill(s);
-        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)lencode.lut[(uint32_t)s.bitbuf & lmask]);
-        const int n_lit = (int)((e >> 4) & 3u);
-        if (n_lit) {
-            if (s.out_pos + n_lit > s.out_len) { s.err = s.err ? s.err : kInflateOutputOverflow; break; }
+        // literal runs: the loop the decode spends most of its steps in, kept to one exit so that it stays a tight loop
+        uint32_t e;
+        int n_lit;
+        for (;;) {
+            inflate_refill(s);
+            e = (uint32_t)__builtin_amdgcn_readfirstlane((int)lencode.lut[(uint32_t)s.bitbuf & lmask]);
+            n_lit = (int)((e >> 4) & 3u);
+            if (n_lit == 0 || s.out_pos + n_lit > s.out_len) break;
             const uint32_t k = (uint32_t)(s.lane - n_run);
             run = k < (uint32_t)n_lit ? (e >> (8u + 8u * k)) & 255u : run;
             n_run += n_lit;
             s.out_pos += n_lit;
             inflate_consume(s, (int)(e & 15u));
             if (n_run > 61) flush();
-            continue;
         }
+        if (n_lit) { s.err = s.err ? s.err : kInflateOutputOverflow; break; }
         int len;
         if (e) {
             inflate_consume(s, (int)(e & 15u));
@@ -321,16 +325,22 @@ __device__ inline void inflate_codes(InflateStream& s, const HuffmanTable& lenco
         if (s.err) return;
         if (dist > s.out_pos) { s.err = kInflateDistanceTooFar; return; }
         if (s.out_pos + len > s.out_len) { s.err = kInflateOutputOverflow; return; }
-        // the source bytes may still be on their way to memory (this wave's own earlier stores)
 #ifndef PISCES_INFLATE_ABLATE_COPY
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#endif
+        // the source bytes may still be on their way to memory (this wave's own earlier stores): wait for the stores only when the source
+        // reaches into what was written since the last wait
+        if (s.out_pos - dist + (dist >= len ? len : dist) > s.safe_pos) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            s.safe_pos = s.out_pos;
+        }
         // every source byte lies before out_pos, also when the pair overlaps itself (dist < len: a run of period dist)
         const uint8_t* src = s.out + s.out_pos - dist;
         uint8_t* dst = s.out + s.out_pos;
-#ifndef PISCES_INFLATE_ABLATE_COPY
-        for (int k = s.lane; k < len; k += 64) dst[k] = src[dist >= len ? k : k % dist];
+        if (dist >= len) {
+            for (int k = s.lane; k < len; k += 64) dst[k] = src[k];
+        } else {
+            for (int k = s.lane; k < len; k += 64) dst[k] = src[k % dist];
+        }
 #endif
         s.out_pos += len;
     }
@@ -445,6 +455,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
     s.in = in + b.in_offset;
     s.in_len = b.in_length;
     s.window = window;
+    s.safe_pos = 0;
     s.win_pos = -2 * kInWindow;
     s.out = out + b.out_offset;
     s.out_len = b.out_length;
