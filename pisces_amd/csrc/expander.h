@@ -23,7 +23,6 @@ struct ReadView {
 
 // receives (position, tuple-with-locus-0) pairs in read order
 struct ObservationSink {
-    std::vector<int32_t> scratch;   // position map of the read being walked
     virtual void emit(int32_t position, uint32_t tuple) = 0;
     virtual ~ObservationSink() {}
 };

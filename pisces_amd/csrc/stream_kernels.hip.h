@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include "../../include/pisces_hip.h"
+#include "read_walk.h"
 
 namespace pisces {
 
@@ -32,27 +33,6 @@ struct DevReadBatch {
     int32_t n_reads;
 };
 
-__device__ __forceinline__ bool dev_op_ref_span(uint8_t t) { return t == 'M' || t == 'D' || t == 'N' || t == '=' || t == 'X'; }
-__device__ __forceinline__ bool dev_op_read_span(uint8_t t) { return t == 'M' || t == 'I' || t == 'S' || t == '=' || t == 'X'; }
-
-// AlleleHelper.GetAlleleType (AlleleHelper.cs:13-32)
-__device__ __forceinline__ uint32_t dev_allele_type(uint8_t c)
-{
-    return c == 'A' ? PISCES_ALLELE_A : c == 'C' ? PISCES_ALLELE_C : c == 'G' ? PISCES_ALLELE_G : c == 'T' ? PISCES_ALLELE_T : PISCES_ALLELE_N;
-}
-
-// RegionStateManager.GetAnchorType :83-116 with numAnchorTypes = 5 (positions here always lie inside the read's span)
-__device__ __forceinline__ uint32_t dev_anchor_type(int alignmentEnd, int basePosition, int alignmentStart)
-{
-    const int leftAnchor = basePosition - alignmentStart, rightAnchor = alignmentEnd - basePosition;
-    if (leftAnchor >= rightAnchor) {
-        if (rightAnchor >= PISCES_ANCHOR_SIZE) return PISCES_ANCHOR_SIZE;
-        return (uint32_t)max(PISCES_NUM_ANCHORS - rightAnchor - 1, 0);
-    }
-    if (leftAnchor >= PISCES_ANCHOR_SIZE) return PISCES_ANCHOR_SIZE;
-    return (uint32_t)max(leftAnchor, 0);
-}
-
 __device__ __forceinline__ int wave_exclusive_scan(int v, int lane, int* total)
 {
     int incl = v;
@@ -65,8 +45,8 @@ __device__ __forceinline__ int wave_exclusive_scan(int v, int lane, int* total)
     return incl - v;
 }
 
-// One wave per read, lane = read index within a chunk of 64 bases.  Follows expander.cpp (the host form, checked against
-// the oracle's AddAlleleCounts) observation for observation; positions <= 0 are not logged, as there.
+// One wave per read, lane = base within a chunk of 64 bases: every lane asks read_walk.h what its base adds (the same function the
+// host form loops over), a wave scan turns the counts into log slots.  Positions <= 0 are not logged.
 // Every read owns the log slots [read_slot[r], read_slot[r + 1]) reserved by the host from its CIGAR (mapped bases + gap
 // lengths, an upper bound that is exact unless a deletion fails its quality test): no atomics on the log — same-address
 // global atomics from 8 XCDs cost ~25-200 ns EACH and were the whole run time of the first version of this kernel.
@@ -80,91 +60,27 @@ __global__ __launch_bounds__(256) void expand_reads_kernel(DevReadBatch b, const
     const int r = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
     int emitted = 0;
     if (r < b.n_reads) {
-        const int pos0 = b.position[r];
-        const int c0 = b.cigar_offset[r], nc = b.cigar_offset[r + 1] - c0;
-        const int s0 = b.seq_offset[r], n = b.seq_offset[r + 1] - s0;
+        const int c0 = b.cigar_offset[r], s0 = b.seq_offset[r];
+        const ReadShape shape = read_shape(b.position[r], b.seq_offset[r + 1] - s0, b.cigar_offset[r + 1] - c0, b.cigar_op + c0, b.cigar_len + c0);
+        const int n = shape.n;
         const uint32_t read_dir = (b.flags[r] & 1) ? PISCES_DIR_REVERSE : PISCES_DIR_FORWARD;
-        const uint8_t* const ops = b.cigar_op + c0;
-        const uint32_t* const lens = b.cigar_len + c0;
         const uint8_t* const quals = b.quals + s0;
         const uint8_t* const bases = b.bases + s0;
         const uint8_t* const dirs = b.dirs ? b.dirs + s0 : nullptr;
         const long long slot0 = read_slot[r], slot1 = read_slot[r + 1];
-
-        int refSpan = 0, lastMappedOverall = pos0 - 1;
-        {
-            int rp = pos0;
-            for (int c = 0; c < nc; c++) {
-                const uint8_t t = ops[c];
-                const int len = (int)lens[c];
-                if (dev_op_ref_span(t)) {
-                    refSpan += len;
-                    if (dev_op_read_span(t) && len > 0) lastMappedOverall = rp + len - 1;
-                    rp += len;
-                }
-            }
-        }
-        const bool endsInDel = nc >= 1 && ops[nc - 1] == 'D';
-        const bool endsInDelSoft = nc >= 2 && ops[nc - 2] == 'D' && ops[nc - 1] == 'S';
-        int delLen = 0, lengthBeforeDeletion = n;
-        if (endsInDel || endsInDelSoft) {
-            delLen = (int)(endsInDelSoft ? lens[nc - 2] : lens[nc - 1]);
-            lengthBeforeDeletion = endsInDelSoft ? n - (int)lens[nc - 1] : n;
-        }
-        const int alignmentEnd = pos0 + refSpan - 1;
-        auto delq_ok = [&](int i) {   // CandidateVariantFinder.CheckDeletionQuality (:294-320), i < n
-            const int after = quals[i], before = i > 0 ? quals[i - 1] : after;
-            return before >= min_bq && after >= min_bq;
-        };
+        const uint32_t lastAnchor = PISCES_NUM_ANCHORS - 1;
 
         long long w0 = slot0;   // next free slot of this read (wave-uniform)
         for (int base0 = 0; base0 < n; base0 += 64) {
             const int i = base0 + lane;
             const bool active = i < n;
-            // Read.UpdatePositionMap (Read.cs:535-562) for index i, plus the position of the last mapped base before it
-            int p = -1, lp = pos0 - 1;
-            {
-                int ri = 0, rp = pos0, lastm = pos0 - 1;
-                for (int c = 0; c < nc; c++) {
-                    const uint8_t t = ops[c];
-                    const int len = (int)lens[c];
-                    const bool rs = dev_op_read_span(t), fs = dev_op_ref_span(t);
-                    if (rs) {
-                        if (active && i >= ri && i < ri + len) {
-                            if (fs) { p = rp + (i - ri); lp = (i == ri) ? lastm : p - 1; }
-                            else lp = lastm;
-                        }
-                        if (fs && len > 0) { lastm = rp + len - 1; rp += len; }
-                        ri += len;
-                    } else if (fs) {
-                        rp += len;
-                    }
-                }
-            }
+            BaseWalk bw;
+            bw.position = -1; bw.anchor = 0;
+            bw.n_soft = bw.n_gap = bw.n_base = bw.n_end = 0;
+            bw.soft_first = bw.gap_first = bw.end_first = 0;
+            if (active) bw = walk_base(shape, i, quals, min_bq);
             const uint32_t dir = active ? (dirs ? (uint32_t)dirs[i] : read_dir) : 0u;
-            const bool dq = active && delq_ok(i);
-            // what this lane emits, in the host walk's order: terminal deletion before a soft clip, gap deletions, the base,
-            // terminal deletion at the read end
-            int n_soft = 0, n_gap = 0, n_base = 0, n_end = 0;
-            int soft_first = 0, gap_first = 0, end_first = 0;
-            if (active) {
-                if (endsInDelSoft && i == lengthBeforeDeletion && dq) {
-                    soft_first = max(lp + 1, 1);
-                    n_soft = max(0, lp + delLen - soft_first + 1);
-                }
-                if (p != -1) {
-                    if (dq) {
-                        gap_first = max(lp + 1, 1);
-                        n_gap = max(0, p - 1 - gap_first + 1);
-                    }
-                    n_base = p > 0 ? 1 : 0;
-                }
-                if (endsInDel && i == n - 1 && dq) {
-                    end_first = max(lastMappedOverall + 1, 1);
-                    n_end = max(0, lastMappedOverall + delLen - end_first + 1);
-                }
-            }
-            const int cnt = n_soft + n_gap + n_base + n_end;
+            const int cnt = bw.n_soft + bw.n_gap + bw.n_base + bw.n_end;
             int total;
             const int excl = wave_exclusive_scan(cnt, lane, &total);
             if (total == 0) continue;
@@ -173,25 +89,24 @@ __global__ __launch_bounds__(256) void expand_reads_kernel(DevReadBatch b, const
             w0 += total;
             if (!fits) continue;
             emitted += cnt;
-            const uint32_t lastAnchor = PISCES_NUM_ANCHORS - 1;
-            for (int k = 0; k < n_soft; k++, w++) {
-                log_pos[w] = soft_first + k;
+            for (int k = 0; k < bw.n_soft; k++, w++) {
+                log_pos[w] = bw.soft_first + k;
                 log_tup[w] = PISCES_TUPLE_PACK(0, lastAnchor, dir, PISCES_ALLELE_DEL, 255);
             }
-            if (p != -1) {
-                const uint32_t anchor = dev_anchor_type(alignmentEnd, p, pos0);
-                for (int k = 0; k < n_gap; k++, w++) {
-                    log_pos[w] = gap_first + k;
+            if (bw.position != -1) {
+                const uint32_t anchor = (uint32_t)(bw.anchor < 0 ? 0 : bw.anchor);   // (inside the alignment the anchor is never negative)
+                for (int k = 0; k < bw.n_gap; k++, w++) {
+                    log_pos[w] = bw.gap_first + k;
                     log_tup[w] = PISCES_TUPLE_PACK(0, anchor, dir, PISCES_ALLELE_DEL, 255);
                 }
-                if (n_base) {
-                    log_pos[w] = p;
-                    log_tup[w] = PISCES_TUPLE_PACK(0, anchor, dir, dev_allele_type(bases[i]), (uint32_t)quals[i]);
+                if (bw.n_base) {
+                    log_pos[w] = bw.position;
+                    log_tup[w] = PISCES_TUPLE_PACK(0, anchor, dir, walk_allele_type(bases[i]), (uint32_t)quals[i]);
                     w++;
                 }
             }
-            for (int k = 0; k < n_end; k++, w++) {
-                log_pos[w] = end_first + k;
+            for (int k = 0; k < bw.n_end; k++, w++) {
+                log_pos[w] = bw.end_first + k;
                 log_tup[w] = PISCES_TUPLE_PACK(0, lastAnchor, dir, PISCES_ALLELE_DEL, 255);
             }
         }
