@@ -287,7 +287,10 @@ int32_t pisces_hip_add_observations(PiscesHip* h, const int32_t* positions, cons
  * (SmallVariantCaller.cs:157-189).  up_to_position < 0 = final flush (Call(null)).
  * Writes called alleles sorted by (position, ref, alt) into out[0..capacity); *n_out = number
  * produced.  Returns PISCES_E_BUFFER_TOO_SMALL (and *n_out = required) without consuming the
- * batch when capacity is insufficient: grow and repeat. */
+ * batch when capacity is insufficient: grow and repeat.  The batch is made at that point (what AlleleCaller.Call hands back to the state
+ * — MNV leftovers, candidates that did not collapse — has been handed back) and waits for the repeated call: until then every entry that
+ * would change the state (add_reads, add_observations, add_candidates, add_decoded_reads, add_gapped_mnv_ref, a flush with another
+ * up_to_position) returns PISCES_E_STATE. */
 int32_t pisces_hip_flush(PiscesHip* h, int32_t up_to_position, PiscesCalledAllele* out,
                          int64_t capacity, int64_t* n_out);
 /* The same call, also returning the allele strings of the called insertions / deletions:

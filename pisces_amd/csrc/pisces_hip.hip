@@ -258,6 +258,17 @@ static int32_t fail(PiscesHip* h, int32_t code, const std::string& msg)
 
 static int32_t consume_found(PiscesHip* h);
 
+// A flush that reported PISCES_E_BUFFER_TOO_SMALL has made its batch (collapsed candidates, MNV leftovers handed to later blocks, ...)
+// and keeps it until the caller repeats the call with buffers that hold it.  Until then the state must not move: every entry that
+// would change it refuses.
+static int32_t refuse_while_batch_is_open(PiscesHip* h, const char* what);
+
+static int32_t refuse_while_batch_is_open(PiscesHip* h, const char* what)
+{
+    if (!h->pending_valid) return PISCES_OK;
+    return fail(h, PISCES_E_STATE, std::string(what) + ": a flush reported PISCES_E_BUFFER_TOO_SMALL; repeat it with larger buffers first");
+}
+
 static DeviceParams make_params(const PiscesHipConfig& c)
 {
     DeviceParams P;
@@ -666,7 +677,7 @@ int32_t pisces_hip_add_observations(PiscesHip* h, const int32_t* positions, cons
     if (n < 0 || (n > 0 && (!positions || !tuples))) return fail(h, PISCES_E_INVALID_ARG, "add_observations: null buffer");
     for (int64_t i = 0; i < n; i++)
         if (positions[i] <= 0) return fail(h, PISCES_E_INVALID_ARG, "Position must be greater than 0.");  // RegionStateManager.cs:363-364
-    h->pending_valid = false;
+    { int32_t rcp = refuse_while_batch_is_open(h, "add_observations"); if (rcp) return rcp; }
     if (n == 0) return PISCES_OK;
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     for (int64_t i = 0; i < n; i++) (void)get_block(h, positions[i]);
@@ -777,6 +788,7 @@ int32_t pisces_hip_add_candidates(PiscesHip* h, const PiscesCandidate* cands, in
 {
     return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
+    { int32_t rcp = refuse_while_batch_is_open(h, "add_candidates"); if (rcp) return rcp; }
     { int32_t rcf = consume_found(h); if (rcf) return rcf; }   // keep the arrival order: what the reads gave so far comes first
     std::vector<HostCandidate> list;
     int32_t rc = host_candidates_of(h, cands, n, alleles, allele_bytes, list, "add_candidates");
@@ -922,7 +934,7 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
     return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (validate_batch(batch) != PISCES_OK) return fail(h, PISCES_E_INVALID_ARG, "add_reads: malformed read batch");
-    h->pending_valid = false;
+    { int32_t rcp = refuse_while_batch_is_open(h, "add_reads"); if (rcp) return rcp; }
     if (batch->n_reads == 0) return PISCES_OK;
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     { int32_t rcf = consume_found(h); if (rcf) return rcf; }
@@ -2202,6 +2214,7 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
     const bool final_flush = up_to_position < 0;
     const bool replay = h->pending_valid && h->pending_up_to == up_to_position;
     if (!replay) {
+        { int32_t rcp = refuse_while_batch_is_open(h, "flush (another upToPosition)"); if (rcp) return rcp; }
         // GetCandidatesToProcess (RegionStateManager.cs:283-334): only build a batch when upTo has moved
         // onto another block; take blocks that lie wholly at or below upTo.
         add_forced_as_candidates(h, final_flush ? -1 : up_to_position);   // SmallVariantCaller.cs:101-108: before Call(upTo)
@@ -2525,12 +2538,12 @@ int32_t pisces_hip_add_gapped_mnv_ref(PiscesHip* h, const int32_t* positions, co
     return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (n < 0 || (n > 0 && (!positions || !counts))) return fail(h, PISCES_E_INVALID_ARG, "add_gapped_mnv_ref: null buffer");
+    { int32_t rcp = refuse_while_batch_is_open(h, "add_gapped_mnv_ref"); if (rcp) return rcp; }
     for (int32_t i = 0; i < n; i++) {
         if (positions[i] <= 0) return fail(h, PISCES_E_INVALID_ARG, "Position must be greater than 0.");
         (void)get_block(h, positions[i]);   // GetBlock(position) creates the block (RegionStateManager.cs:78)
         h->gapped_mnv_ref[positions[i]] += counts[i];
     }
-    h->pending_valid = false;
     return PISCES_OK;
     });
 }
@@ -3061,7 +3074,7 @@ int32_t pisces_hip_add_decoded_reads(PiscesHip* h)
     if (!h->bam.valid) return fail(h, PISCES_E_STATE, "add_decoded_reads: no decoded batch (pisces_hip_bam_decode first)");
     auto& B = h->bam;
     if (B.min_bq != h->cfg.min_base_call_quality) return fail(h, PISCES_E_STATE, "add_decoded_reads: decoded with another minimum base quality");
-    h->pending_valid = false;
+    { int32_t rcp = refuse_while_batch_is_open(h, "add_decoded_reads"); if (rcp) return rcp; }
     const int32_t nr = (int32_t)B.n_reads;
     if (nr == 0) return PISCES_OK;
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));

@@ -567,8 +567,9 @@ def test_two_interval_shards_on_one_gpu_equal_the_unsharded_run(torch_cuda):
     whole_p = synth.make_pileup(total, depth, seed=seed, device="cuda")
     with engine.HipVariantCaller(cfg) as c:
         whole, tr_w = run_fused(torch, c, whole_p)
-    for world in (2, 3):
+    for world in (2, 3, 8):   # (8: BASELINE config 4's rank count)
         parts = shard.partition_intervals(intervals, world, block_size=cfg.block_size)
+        assert len(parts) == world and all(hi >= lo for lo, hi, _ in parts)
         got, n_rec, n_loci = [], 0, 0
         for lo, hi, clipped in parts:
             lo, hi = max(lo, intervals[0][0]), min(hi, intervals[-1][1])
@@ -743,6 +744,12 @@ def test_flush_into_a_buffer_that_is_too_small_is_repeatable(torch_cuda):
             for cap in (0, 10, len(want) - 1):
                 rc = lib.pisces_hip_flush(b.handle, -1 if up_to is None else up_to, small.ctypes.data, min(cap, 10), C.byref(n))
                 assert rc == _abi.E_BUFFER_TOO_SMALL and n.value == len(want), (rc, n.value, len(want))
+            # the batch is made and waits for its buffers: until it is taken nothing may move the state
+            with pytest.raises(Exception) as e:
+                b.AddAlleleCounts(reads)
+            assert e.value.code == _abi.E_STATE
+            rc = lib.pisces_hip_flush(b.handle, 7 if up_to is None else -1, small.ctypes.data, 10, C.byref(n))
+            assert rc == _abi.E_STATE
             out = np.zeros(len(want), dtype=_abi.CALLED_ALLELE_DTYPE)
             rc = lib.pisces_hip_flush(b.handle, -1 if up_to is None else up_to, out.ctypes.data, len(out), C.byref(n))
             assert rc == 0 and n.value == len(want)
