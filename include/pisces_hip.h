@@ -305,7 +305,8 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
 int32_t pisces_hip_get_counts(PiscesHip* h, int32_t start_position, int32_t n, int32_t* out);
 /* IAlleleSource.GetSumOfAlleleBaseQualities (src/lib/Pisces.Domain/Interfaces/IAlleleSource.cs:16; RegionState.cs:61,233-239): the
  * base-quality sums double[n][6][3][11] of [start_position, start_position + n), same layout and rules as pisces_hip_get_counts (the
- * caller applies the anchor window, AlleleCountHelper.GetAnchorAdjustedTotalQuality).  Served by any handle, not only NoiseModel.Window. */
+ * caller applies the anchor window, AlleleCountHelper.GetAnchorAdjustedTotalQuality).  Served by any handle, not only NoiseModel.Window.
+ * The device accumulates in fixed point: each cell is the true sum rounded once, identical from run to run. */
 int32_t pisces_hip_get_base_quality_sums(PiscesHip* h, int32_t start_position, int32_t n, double* out);
 /* IAlleleSource.GetGappedMnvRefCount (IAlleleSource.cs:19): what pisces_hip_add_gapped_mnv_ref registered for the position, else 0 */
 int32_t pisces_hip_get_gapped_mnv_ref(PiscesHip* h, int32_t position, int32_t* count);

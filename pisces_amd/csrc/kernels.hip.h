@@ -970,10 +970,27 @@ __host__ __device__ inline double get_base_quality_sum(const double* __restrict_
 
 constexpr int kAnchStride = PISCES_COUNTS_PER_LOCUS + 1;
 
+// The base-quality sums are accumulated in FIXED POINT: what a base of quality q adds, Math.Pow(10, -1 * (int)q / 10f)
+// (RegionStateManager.cs:191), is cut at 2^-76 and carried as two 38-bit halves that go to two 64-bit integer counters of the cell.
+// Integer addition does not care about the order the atomics arrive in, so the sums are the same bits from run to run (FP64 atomics in
+// arrival order were not), and exact to 2^-76 per term; finish_quality_sums_kernel turns a cell's pair into the double the call
+// phase and pisces_hip_get_base_quality_sums read.  (The reference adds doubles in read order; its result and this one are both within
+// n * 2^-53 relative of the true sum, which is what SURVEY promises for this mode.)
+constexpr int kSumqHalfBits = 38;
+__global__ __launch_bounds__(256) void finish_quality_sums_kernel(const unsigned long long* __restrict__ fix, double* __restrict__ sumq, int64_t n_cells)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cells) return;
+    const unsigned long long hi = fix[2 * i], lo = fix[2 * i + 1];
+    const unsigned long long hi_total = hi + (lo >> kSumqHalfBits), lo_rest = lo & ((1ull << kSumqHalfBits) - 1ull);
+    sumq[i] = (double)hi_total * 0x1p-38 + (double)lo_rest * 0x1p-76;
+}
+
 __global__ __launch_bounds__(kBlock) void accumulate_tiles_kernel(
     const uint32_t* __restrict__ tuples, const PiscesTile* __restrict__ tiles, int32_t n_tiles,
-    int32_t* __restrict__ counts, int32_t min_bq_, double* __restrict__ sumq = nullptr /* NoiseModel.Window: RegionState._sumOfAlleleBaseQualities */,
-    const double* __restrict__ bq_lut = nullptr /* [256] Math.Pow(10, -1 * (int)q / 10f), RegionStateManager.cs:191 */)
+    int32_t* __restrict__ counts, int32_t min_bq_,
+    unsigned long long* __restrict__ sumq = nullptr /* NoiseModel.Window: RegionState._sumOfAlleleBaseQualities, two fixed-point halves per cell */,
+    const ulonglong2* __restrict__ bq_lut = nullptr /* [256] the halves of Math.Pow(10, -1 * (int)q / 10f) */)
 {
     __shared__ int hist[kTile * kAnchStride];
     const int t = blockIdx.x;
@@ -992,8 +1009,12 @@ __global__ __launch_bounds__(kBlock) void accumulate_tiles_kernel(
         if (locus < n_loci && dir < 3u && allele < 6u && anchor < (uint32_t)PISCES_NUM_ANCHORS) {
             atomicAdd(&hist[locus * kAnchStride + (allele * 3u + dir) * PISCES_NUM_ANCHORS + anchor], 1);
             // the quality of a base goes under its post-threshold allele type; only A/C/G/T are ever read back (CoverageCalculator.cs:62)
-            if (sumq && allele < 4u)
-                unsafeAtomicAdd(&sumq[((int64_t)t * kTile + locus) * PISCES_COUNTS_PER_LOCUS + (allele * 3u + dir) * PISCES_NUM_ANCHORS + anchor], bq_lut[qual]);
+            if (sumq && allele < 4u) {
+                const ulonglong2 add = bq_lut[qual];
+                unsigned long long* cell = &sumq[2 * (((int64_t)t * kTile + locus) * PISCES_COUNTS_PER_LOCUS + (allele * 3u + dir) * PISCES_NUM_ANCHORS + anchor)];
+                atomicAdd(cell, add.x);
+                atomicAdd(cell + 1, add.y);
+            }
         }
     });
     __syncthreads();

@@ -112,8 +112,9 @@ struct PiscesHip {
     int64_t launches_seen = 0;
     DeviceBuf<unsigned long long> d_totals;
     DeviceBuf<double> d_qlut;
-    DeviceBuf<double> d_bq_lut;    // [256] Math.Pow(10, -1 * (int)q / 10f): what a base of quality q adds to the base-quality sums (NoiseModel.Window)
-    DeviceBuf<double> d_sumq;      // RegionState._sumOfAlleleBaseQualities of the tiles being called (NoiseModel.Window)
+    DeviceBuf<ulonglong2> d_bq_lut;   // [256] Math.Pow(10, -1 * (int)q / 10f) in fixed point (two 38-bit halves): what a base of quality q adds to the sums
+    DeviceBuf<unsigned long long> d_sumq_fix;   // the cells' fixed-point accumulators (accumulate_tiles_kernel)
+    DeviceBuf<double> d_sumq;      // RegionState._sumOfAlleleBaseQualities of the tiles being called (NoiseModel.Window), made from them
     DeviceBuf<double> d_gq_tail;   // memo of the genotype-quality Poisson tail (DeviceParams::gq_tail)
     DeviceBuf<int16_t> d_vq_tab;   // memo tables of the call phase (DeviceParams::vq_tab / sb_tab / sb0_tab / gq_cap)
     DeviceBuf<double> d_sb_tab;
@@ -267,6 +268,46 @@ static int32_t refuse_while_batch_is_open(PiscesHip* h, const char* what)
 {
     if (!h->pending_valid) return PISCES_OK;
     return fail(h, PISCES_E_STATE, std::string(what) + ": a flush reported PISCES_E_BUFFER_TOO_SMALL; repeat it with larger buffers first");
+}
+
+// [256] what a base of quality q adds to the base-quality sums, RegionStateManager.cs:191: Math.Pow(10, -1 * (int)quality / 10f) (int /
+// float is a float32 quotient, promoted for Pow), as the two 38-bit halves of its value cut at 2^-76 (kernels.hip.h)
+static hipError_t ensure_quality_lut(PiscesHip* h)
+{
+    if (h->d_bq_lut.p) return hipSuccess;
+    std::vector<ulonglong2> lut(256);
+    for (int q = 0; q < 256; q++) {
+        const double x = std::pow(10.0, (double)((float)(-1 * q) / 10.0f));   // in (0, 1]
+        int e2 = 0;
+        const double m = std::frexp(x, &e2);                                    // x = m * 2^e2, m in [0.5, 1)
+        const unsigned long long mant = (unsigned long long)std::ldexp(m, 53);  // 53-bit integer
+        const int shift = e2 - 53 + 2 * kSumqHalfBits;                          // x * 2^76 = mant * 2^shift
+        const unsigned __int128 v = shift >= 0 ? (unsigned __int128)mant << shift : (shift > -64 ? (unsigned __int128)mant >> (-shift) : (unsigned __int128)0);
+        lut[(size_t)q].x = (unsigned long long)(v >> kSumqHalfBits);
+        lut[(size_t)q].y = (unsigned long long)(v & (((unsigned __int128)1 << kSumqHalfBits) - 1));
+    }
+    hipError_t e = h->d_bq_lut.reserve(256);
+    if (e == hipSuccess) e = hipMemcpy(h->d_bq_lut.p, lut.data(), 256 * sizeof(ulonglong2), hipMemcpyHostToDevice);
+    return e;
+}
+
+// tuples of `n_tiles` tiles -> anchor-resolved counts in d_counts (and, with_sums, the base-quality sums in d_sumq), on stream s
+static hipError_t accumulate_tiles(PiscesHip* h, hipStream_t s, const uint32_t* d_tuples, const PiscesTile* d_tiles, int32_t n_tiles, bool with_sums)
+{
+    const size_t nc = (size_t)n_tiles * kTile * PISCES_COUNTS_PER_LOCUS;
+    hipError_t e = h->d_counts.reserve(nc);
+    if (e == hipSuccess && with_sums) e = h->d_sumq.reserve(nc);
+    if (e == hipSuccess && with_sums) e = h->d_sumq_fix.reserve(2 * nc);
+    if (e == hipSuccess && with_sums) e = ensure_quality_lut(h);
+    if (e != hipSuccess) return e;
+    (void)hipMemsetAsync(h->d_counts.p, 0, nc * sizeof(int32_t), s);
+    if (with_sums) (void)hipMemsetAsync(h->d_sumq_fix.p, 0, 2 * nc * sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(accumulate_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, d_tuples, d_tiles, n_tiles, h->d_counts.p,
+                       h->cfg.min_base_call_quality, with_sums ? h->d_sumq_fix.p : (unsigned long long*)nullptr,
+                       with_sums ? (const ulonglong2*)h->d_bq_lut.p : (const ulonglong2*)nullptr);
+    if (with_sums)
+        hipLaunchKernelGGL(finish_quality_sums_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, h->d_sumq_fix.p, h->d_sumq.p, (int64_t)nc);
+    return hipGetLastError();
 }
 
 static DeviceParams make_params(const PiscesHipConfig& c)
@@ -445,11 +486,7 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         h->P.q_to_p_n = n;
     }
     if (h->cfg.noise_model == PISCES_NOISE_WINDOW) {
-        // RegionStateManager.cs:191: Math.Pow(10, -1 * (int)quality / 10f) - int / float is a float32 quotient, promoted for Pow
-        std::vector<double> lut(256);
-        for (int q = 0; q < 256; q++) lut[(size_t)q] = std::pow(10.0, (double)((float)(-1 * q) / 10.0f));
-        if ((e = h->d_bq_lut.reserve(256)) != hipSuccess ||
-            (e = hipMemcpy(h->d_bq_lut.p, lut.data(), 256 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) {
+        if ((e = ensure_quality_lut(h)) != hipSuccess) {
             g_create_error = std::string("pisces_hip_create: ") + hipGetErrorString(e);
             pisces_hip_destroy(h);
             return PISCES_E_DEVICE;
@@ -531,7 +568,7 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     (void)pisces_hip_comm_destroy(h);
     h->d_summary.release();
     h->d_ref.release(); h->d_tuples.release(); h->d_tiles.release(); h->d_tile_results.release();
-    h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release(); h->d_totals.release(); h->d_qlut.release(); h->d_bq_lut.release(); h->d_sumq.release(); h->d_gq_tail.release(); h->d_vq_tab.release(); h->d_sb_tab.release(); h->d_sb0_tab.release(); h->d_gq_cap.release(); h->d_params.release(); h->d_offsets.release(); h->d_compact.release();
+    h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release(); h->d_totals.release(); h->d_qlut.release(); h->d_bq_lut.release(); h->d_sumq_fix.release(); h->d_sumq.release(); h->d_gq_tail.release(); h->d_vq_tab.release(); h->d_sb_tab.release(); h->d_sb0_tab.release(); h->d_gq_cap.release(); h->d_params.release(); h->d_offsets.release(); h->d_compact.release();
     for (int i = 0; i < 2; i++) { h->d_log_pos[i].release(); h->d_log_tup[i].release(); }
     h->d_log_n.release(); h->d_flags.release(); h->d_bucket.release(); h->d_tile_cnt.release(); h->d_total.release();
     for (auto& st : h->stage) {
@@ -1452,15 +1489,9 @@ static hipError_t launch_call_tiles(PiscesHip* h, hipStream_t s, const uint32_t*
         // NoiseModel.Window needs the base-quality sums next to the counts, cell by cell (RegionState.cs:61): anchor-resolved counts and
         // sums go to HBM (accumulate_tiles_kernel) and the call phase reads them back (call_counts_kernel).  Not the streaming-rate
         // path; the reference's default is NoiseModel.Flat.
-        const size_t nc = (size_t)n_tiles * kTile * PISCES_COUNTS_PER_LOCUS;
-        hipError_t er = h->d_counts.reserve(nc);
-        if (er == hipSuccess) er = h->d_sumq.reserve(nc);
-        if (er != hipSuccess) return er;
-        (void)hipMemsetAsync(h->d_counts.p, 0, nc * sizeof(int32_t), s);
-        (void)hipMemsetAsync(h->d_sumq.p, 0, nc * sizeof(double), s);
         if (e0) (void)hipEventRecord(e0, s);
-        hipLaunchKernelGGL(accumulate_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, d_tuples, d_tiles, n_tiles, h->d_counts.p,
-                           h->cfg.min_base_call_quality, h->d_sumq.p, h->d_bq_lut.p);
+        hipError_t er = accumulate_tiles(h, s, d_tuples, d_tiles, n_tiles, true);
+        if (er != hipSuccess) return er;
         hipLaunchKernelGGL(call_counts_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, h->d_counts.p, (const uint32_t*)nullptr, d_tiles, n_tiles,
                            d_ref, ref_start, ref_len, d_records, d_tr, h->P, h->d_sumq.p);
         if (e1) (void)hipEventRecord(e1, s);
@@ -1534,13 +1565,7 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
                 if (it != h->gapped_mnv_ref.end()) g[(size_t)t * kTile + (size_t)l] = (uint32_t)it->second;
             }
         PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_gapped.p, g.data(), g.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-        if (window) {
-            PISCES_HIP_CHECK(h, h->d_sumq.reserve(nc));
-            PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_sumq.p, 0, nc * sizeof(double), h->stream));
-        }
-        hipLaunchKernelGGL(accumulate_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->d_tuples.p, h->d_tiles.p,
-                           n_tiles, h->d_counts.p, h->cfg.min_base_call_quality, window ? h->d_sumq.p : (double*)nullptr,
-                           window ? h->d_bq_lut.p : (const double*)nullptr);
+        PISCES_HIP_CHECK(h, accumulate_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, window));
         hipLaunchKernelGGL(call_counts_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->d_counts.p, h->d_gapped.p,
                            h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p, h->d_tile_results.p, h->P,
                            window ? h->d_sumq.p : (const double*)nullptr);
@@ -1926,16 +1951,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         return (bi * tiles_per_block + off / kTile) * kTile + off % kTile;
     };
     if (n_tiles > 0) {
-        const size_t nc = (size_t)n_tiles * kTile * PISCES_COUNTS_PER_LOCUS;
-        PISCES_HIP_CHECK(h, h->d_counts.reserve(nc));
-        PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_counts.p, 0, nc * sizeof(int32_t), h->stream));
-        if (window) {
-            PISCES_HIP_CHECK(h, h->d_sumq.reserve(nc));
-            PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_sumq.p, 0, nc * sizeof(double), h->stream));
-        }
-        hipLaunchKernelGGL(accumulate_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles,
-                           h->d_counts.p, h->cfg.min_base_call_quality, window ? h->d_sumq.p : (double*)nullptr,
-                           window ? h->d_bq_lut.p : (const double*)nullptr);
+        PISCES_HIP_CHECK(h, accumulate_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, window));
     } else {
         PISCES_HIP_CHECK(h, h->d_counts.reserve(PISCES_COUNTS_PER_LOCUS));
         if (window) PISCES_HIP_CHECK(h, h->d_sumq.reserve(PISCES_COUNTS_PER_LOCUS));
@@ -2453,11 +2469,7 @@ int32_t pisces_hip_get_counts(PiscesHip* h, int32_t start_position, int32_t n, i
     if (rc) return rc;
     const int32_t n_tiles = (int32_t)tiles.size();
     const size_t nc = (size_t)n_tiles * kTile * PISCES_COUNTS_PER_LOCUS;
-    PISCES_HIP_CHECK(h, h->d_counts.reserve(nc));
-    PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_counts.p, 0, nc * sizeof(int32_t), h->stream));
-    hipLaunchKernelGGL(accumulate_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles,
-                       h->d_counts.p, h->cfg.min_base_call_quality, (double*)nullptr, (const double*)nullptr);
-    PISCES_HIP_CHECK(h, hipGetLastError());
+    PISCES_HIP_CHECK(h, accumulate_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, false));
     std::vector<int32_t> host(nc);
     PISCES_HIP_CHECK(h, hipMemcpyAsync(host.data(), h->d_counts.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
@@ -2475,8 +2487,8 @@ int32_t pisces_hip_get_counts(PiscesHip* h, int32_t start_position, int32_t n, i
 
 // IAlleleSource.GetSumOfAlleleBaseQualities (RegionState._sumOfAlleleBaseQualities, RegionState.cs:61,233-239): the cells of
 // [start_position, start_position + n), layout as pisces_hip_get_counts, accumulated on the device next to the counts from the
-// observation log (Math.Pow(10, -(int)q / 10f) per base under its post-threshold allele, RegionStateManager.cs:191).  The order of the
-// FP64 additions is the device's (atomic order), not the read order: equal to the reference's sums to rounding.
+// observation log (Math.Pow(10, -(int)q / 10f) per base under its post-threshold allele, RegionStateManager.cs:191) in fixed point:
+// the true sum rounded once, the same bits from run to run; the reference adds doubles in read order, equal to rounding.
 int32_t pisces_hip_get_base_quality_sums(PiscesHip* h, int32_t start_position, int32_t n, double* out)
 {
     return abi_guard<int32_t>(h, [&]() -> int32_t {
@@ -2490,24 +2502,12 @@ int32_t pisces_hip_get_base_quality_sums(PiscesHip* h, int32_t start_position, i
     for (int32_t k = block_key(h, start_position); k <= block_key(h, start_position + n - 1); k++)
         if (h->blocks.count(k)) keys.push_back(k);
     if (keys.empty()) return PISCES_OK;
-    if (!h->d_bq_lut.p) {   // made at create only for NoiseModel.Window; any handle can serve the sums
-        std::vector<double> lut(256);
-        for (int q = 0; q < 256; q++) lut[(size_t)q] = std::pow(10.0, (double)((float)(-1 * q) / 10.0f));
-        PISCES_HIP_CHECK(h, h->d_bq_lut.reserve(256));
-        PISCES_HIP_CHECK(h, hipMemcpy(h->d_bq_lut.p, lut.data(), 256 * sizeof(double), hipMemcpyHostToDevice));
-    }
     std::vector<PiscesTile> tiles;
     int32_t rc = bucket_blocks(h, keys, false, tiles);
     if (rc) return rc;
     const int32_t n_tiles = (int32_t)tiles.size();
     const size_t nc = (size_t)n_tiles * kTile * PISCES_COUNTS_PER_LOCUS;
-    PISCES_HIP_CHECK(h, h->d_counts.reserve(nc));
-    PISCES_HIP_CHECK(h, h->d_sumq.reserve(nc));
-    PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_counts.p, 0, nc * sizeof(int32_t), h->stream));
-    PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_sumq.p, 0, nc * sizeof(double), h->stream));
-    hipLaunchKernelGGL(accumulate_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles,
-                       h->d_counts.p, h->cfg.min_base_call_quality, h->d_sumq.p, (const double*)h->d_bq_lut.p);
-    PISCES_HIP_CHECK(h, hipGetLastError());
+    PISCES_HIP_CHECK(h, accumulate_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, true));   // (any handle can serve the sums, not only NoiseModel.Window)
     std::vector<double> host(nc);
     PISCES_HIP_CHECK(h, hipMemcpyAsync(host.data(), h->d_sumq.p, nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
@@ -2729,7 +2729,7 @@ int32_t pisces_hip_accumulate_tiles(PiscesHip* h, const uint32_t* d_tuples, cons
     }
     if (n_tiles > 0) {
         hipExtLaunchKernelGGL(accumulate_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0u, s, e0, e1, 0u, d_tuples, d_tiles, n_tiles,
-                              d_counts, h->cfg.min_base_call_quality, (double*)nullptr, (const double*)nullptr);
+                              d_counts, h->cfg.min_base_call_quality, (unsigned long long*)nullptr, (const ulonglong2*)nullptr);
     } else if (e0) {
         PISCES_HIP_CHECK(h, hipEventRecord(e0, s));
         PISCES_HIP_CHECK(h, hipEventRecord(e1, s));

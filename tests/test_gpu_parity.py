@@ -1131,9 +1131,10 @@ def test_mnv_calling_over_the_block_schedule(torch_cuda):
 @pytest.mark.parametrize("call_mnvs", [0, 1])
 def test_window_noise_model_matches_oracle(torch_cuda, call_mnvs):
     """SURVEY section 8 row a3, NoiseModel.Window: the base-quality sums are accumulated on the device next to the counts (cell by cell,
-    FP64 atomics) and every allele's q-score uses (int)PtoQ(SumOfBaseQuality / TotalCoverage): SNVs, Reference alleles, insertions /
-    deletions (start + end point sums) and, with MNV calling on, MNVs.  Mixed base qualities, so no locus sits on an integer edge of
-    PtoQ (there the order of the FP64 additions, which the device does not reproduce, could decide); records against the oracle."""
+    fixed-point integer atomics) and every allele's q-score uses (int)PtoQ(SumOfBaseQuality / TotalCoverage): SNVs, Reference alleles,
+    insertions / deletions (start + end point sums) and, with MNV calling on, MNVs.  Mixed base qualities, so no locus sits on an integer
+    edge of PtoQ (there the order of the reference's FP64 additions, which no parallel sum reproduces, could decide); records against the
+    oracle."""
     from pisces_amd import engine
     rng = np.random.default_rng(300 + call_mnvs)
     ref = bytes(rng.choice(list(b"ACGT"), 1500).astype(np.uint8))
@@ -1710,3 +1711,64 @@ def test_random_configuration_matrix_with_schedules_and_forced_alleles(torch_cud
         assert got_alleles == exp_alleles, (trial, kw, schedule, forced)
         assert_records_match(got, exp)
         assert stats["TotalNumCalled"] == exp_called, (trial, kw, schedule, forced)
+
+
+@pytest.mark.gpu
+def test_base_quality_sums_are_exact_and_the_same_from_run_to_run(torch_cuda):
+    """IAlleleSource.GetSumOfAlleleBaseQualities (pisces_hip_get_base_quality_sums; RegionState._sumOfAlleleBaseQualities): the sums are
+    accumulated in fixed point (integer atomics, two 38-bit halves per cell), so they are the same bits whatever order the device adds
+    in — two handles, several rounds — and they are the true sum of Math.Pow(10, -(int)q / 10f) over the cell's bases to the last place
+    (checked against exact rational arithmetic); the oracle's read-order double sums agree to rounding.  Low-quality bases count under N,
+    whose sums nobody reads; cells of A/C/G/T are compared."""
+    from fractions import Fraction
+    from pisces_amd import engine
+    rng = np.random.default_rng(77)
+    ref = bytes(rng.choice(list(b"ACGT"), 400).astype(np.uint8))
+    reads = []
+    for n in range(3000):
+        start = int(rng.integers(1, 290))
+        seq = bytearray(ref[start - 1: start + 99])
+        for k in range(100):
+            if rng.random() < 0.02:
+                seq[k] = rng.choice(list(b"ACGT"))
+        reads.append({"pos": start, "cigar": [("M", 100)], "seq": bytes(seq).decode(), "reverse": bool(n % 2),
+                      "quals": rng.choice([2, 12, 23, 30, 37, 41], 100, p=[.02, .04, .2, .2, .38, .16]).astype(np.uint8).tolist()})
+    batch = _abi.ReadBatch(reads)
+    refa = np.frombuffer(ref, dtype=np.uint8)
+    cfg = _abi.default_config(noise_model=1)
+    runs = []
+    for rep in range(3):
+        with engine.HipVariantCaller(cfg) as c:
+            c.SetReference(refa)
+            c.AddAlleleCounts(batch)
+            runs.append((c.GetBaseQualitySums(1, 390).copy(), None))
+    assert runs[0][0].tobytes() == runs[1][0].tobytes() == runs[2][0].tobytes()
+    sums = runs[0][0]                                                    # [390][6][3][11]
+    # exact: per (position, allele, direction) over all anchors, from the reads themselves
+    term = {q: Fraction(float(np.float64(10.0) ** np.float64(np.float32(-q) / np.float32(10.0)))) for q in (2, 12, 23, 30, 37, 41)}
+    want = {}
+    code = {ord("A"): 0, ord("G"): 1, ord("C"): 2, ord("T"): 3}
+    for r in reads:
+        d = 1 if r["reverse"] else 0
+        for k, (b, q) in enumerate(zip(r["seq"].encode(), r["quals"])):
+            if q < 20:
+                continue                                              # counted under N
+            key = (r["pos"] + k, code[b], d)
+            want[key] = want.get(key, Fraction(0)) + term[q]
+    checked = 0
+    for (p, a, d), exact in want.items():
+        if p > 390:
+            continue
+        got = float(sums[p - 1, a, d].sum())                            # the anchors of one cell group add up to the per-direction sum
+        assert abs(Fraction(got) - exact) <= Fraction(np.spacing(float(exact))) * 8, (p, a, d, got, float(exact))
+        checked += 1
+    assert checked > 1500
+    # the oracle's state (doubles added in read order) agrees to rounding
+    st = orc.State(1, 400, min_bq=20, track_open_ended=False)
+    for r in reads:
+        assert st.add_allele_counts(orc.make_read(r["pos"], r["seq"], quals=r["quals"], reverse=r["reverse"])) == 0
+    for p in range(1, 391, 7):
+        for a in range(4):
+            for d in range(2):
+                o = orc.lib.orc_get_sum_base_quality(st.h, p, a, d, 0, -1, 0, 0)
+                assert float(sums[p - 1, a, d].sum()) == pytest.approx(o, rel=1e-12, abs=1e-18)
