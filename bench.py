@@ -172,6 +172,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    # development only: PISCES_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and the process group on gloo, so that the N > 1 code path
+    # (partition, shard check across a real cut, summary reduce) can be exercised on a one-GPU box; the numbers of such a run mean nothing
+    one_device = os.environ.get("PISCES_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # the collectives also run at world size 1 when launched by torch.distributed.run (exercises the RCCL path on a 1-GPU box)
@@ -179,7 +184,10 @@ def main():
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if one_device:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
     if world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch N>1 with torch.distributed.run", file=sys.stderr)
 
