@@ -268,19 +268,6 @@ def main():
     assert sum_loci == total_loci * args.steps, (sum_loci, total_loci, args.steps)   # the shards cover the interval set exactly once
     value = sum_loci / elapsed
 
-    # ---- the same summary through the C ABI (pisces_hip_reduce_summary: RCCL bound by the library, what a host without torch
-    # calls), outside the timed region and not fatal: the timed region keeps torch.distributed's communicator ----
-    c_abi_reduce = None
-    if world > 1:
-        try:
-            ids = [engine.HipVariantCaller.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            caller.comm_init(ids[0], rank, world)
-            red = caller.reduce_summary([totals["records"], totals["candidate_loci"], totals["called"], totals["tiles"]])
-            c_abi_reduce = {"ok": red == [int(x) for x in summary.tolist()], "summary": red}
-        except Exception as e:   # noqa: BLE001
-            c_abi_reduce = {"ok": False, "error": str(e)[:200]}
-
     # ---- one cut of the partition checked on the device (outside the timed region): the two sides of this rank's cut, each called by
     # its own handle from the reads shard.reads_for_shard hands it (halo reads on both sides), concatenate to the unsharded window ----
     shard_check = None
@@ -341,6 +328,30 @@ def main():
         for k in range(1, PIPELINE_STREAMS):   # every lane's last output equals a serial launch's (same batch -> same records)
             trk = p_results[k].cpu().numpy().view(_abi.TILE_RESULT_DTYPE)
             assert int(trk["n_candidate_loci"].sum()) == my_loci
+    # ---- the same summary through the C ABI (pisces_hip_reduce_summary: RCCL bound by the library, what a host without torch
+    # calls), outside the timed region, after every torch collective of this run, and not fatal: it runs on a side thread with a time
+    # limit, so that a communicator that cannot be set up on some node costs this field and not the bench line ----
+    c_abi_reduce, c_abi_hung = None, False
+    if world > 1:
+        import threading
+        box = {}
+
+        def through_the_c_abi():
+            try:
+                ids = [engine.HipVariantCaller.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                caller.comm_init(ids[0], rank, world)
+                red = caller.reduce_summary([totals["records"], totals["candidate_loci"], totals["called"], totals["tiles"]])
+                box["r"] = {"ok": red == [int(x) for x in summary.tolist()], "summary": red}
+            except Exception as e:   # noqa: BLE001
+                box["r"] = {"ok": False, "error": str(e)[:200]}
+
+        th = threading.Thread(target=through_the_c_abi, daemon=True)
+        th.start()
+        th.join(90.0)
+        c_abi_hung = th.is_alive()
+        c_abi_reduce = box.get("r", {"ok": False, "error": "no answer within 90 s"})
+
     if rank == 0:
         # roofline of the dominant (only) kernel: algorithmic bytes per launch / mean kernel duration from HIP
         # events recorded on the launch stream around every TIME_EVERY-th launch of the timed region
@@ -399,6 +410,9 @@ def main():
             out["end_to_end"] = end_to_end(ring[0], cfg, engine)
             out["cpu_baseline"], out["cpu_baseline_threads"] = cpu_baseline(torch, ring[0], cfg)
         print(json.dumps(out), flush=True)
+    if c_abi_hung:   # a side thread sits in a communicator that never came up: nothing more to do in this process
+        sys.stdout.flush()
+        os._exit(0)
     caller.close()
     if use_dist:
         dist.barrier()
