@@ -194,8 +194,13 @@ struct PiscesHip {
     int bucket_host_next = 0;
     uint64_t uploads_since_sync = 0;
     uint8_t* h_dl = nullptr;                 // pinned download buffer of flush
+    // pinned arena of the small uploads of a flush (bucket tables, tile geometry, gapped-MNV counts): a copy from pageable memory makes
+    // the host wait until the stream has caught up, i.e. it serialises the flush's enqueueing with the device; from pinned memory it is
+    // asynchronous.  Bump-allocated, rewound when the stream is known to be idle (every flush ends with a synchronisation).
+    uint8_t* h_meta = nullptr;
+    size_t h_meta_cap = 0, h_meta_used = 0;
     size_t h_dl_cap = 0;
-    DeviceBuf<unsigned int> d_tile_cnt;
+    bool drop_counter_cleared = false;   // d_log_n[log_cur ^ 1] was zeroed by the last bucket_scan_kernel and not used since
     DeviceBuf<long long> d_total;
 
     // candidate discovery on the device (finder_kernels.hip.h): records of the last add_reads, picked up when they are needed
@@ -570,7 +575,7 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     h->d_ref.release(); h->d_tuples.release(); h->d_tiles.release(); h->d_tile_results.release();
     h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release(); h->d_totals.release(); h->d_qlut.release(); h->d_bq_lut.release(); h->d_sumq_fix.release(); h->d_sumq.release(); h->d_gq_tail.release(); h->d_vq_tab.release(); h->d_sb_tab.release(); h->d_sb0_tab.release(); h->d_gq_cap.release(); h->d_params.release(); h->d_offsets.release(); h->d_compact.release();
     for (int i = 0; i < 2; i++) { h->d_log_pos[i].release(); h->d_log_tup[i].release(); }
-    h->d_log_n.release(); h->d_flags.release(); h->d_bucket.release(); h->d_tile_cnt.release(); h->d_total.release();
+    h->d_log_n.release(); h->d_flags.release(); h->d_bucket.release(); h->d_total.release();
     for (auto& st : h->stage) {
         st.d.release();
         if (st.h) (void)hipHostFree(st.h);
@@ -581,6 +586,8 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     h->h_stage = nullptr;
     if (h->h_dl) (void)hipHostFree(h->h_dl);
     h->h_dl = nullptr;
+    if (h->h_meta) (void)hipHostFree(h->h_meta);
+    h->h_meta = nullptr;
     if (h->found.h) (void)hipHostFree(h->found.h);
     h->found.h = nullptr;
     if (h->found.done) (void)hipEventDestroy(h->found.done);
@@ -662,6 +669,31 @@ static int32_t log_reserve(PiscesHip* h, int64_t extra)
 }
 
 // next staging pair with room for `bytes`; waits only for the work that used THIS pair two calls ago
+// enqueues dst[0, bytes) = src[0, bytes) (device <- host) on h->stream through the pinned arena
+static int32_t meta_upload(PiscesHip* h, void* dst, const void* src, size_t bytes)
+{
+    if (bytes == 0) return PISCES_OK;
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (h->h_meta_used + need > h->h_meta_cap) {
+        // copies out of the arena may be in flight: drain, rewind, and grow if this one upload is larger than the arena (rare)
+        PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+        h->h_meta_used = 0;
+        if (need > h->h_meta_cap) {
+            const size_t want = std::max<size_t>(need * 2, (size_t)1 << 20);
+            if (h->h_meta) (void)hipHostFree(h->h_meta);
+            h->h_meta = nullptr;
+            h->h_meta_cap = 0;
+            PISCES_HIP_CHECK(h, hipHostMalloc((void**)&h->h_meta, want, hipHostMallocDefault));
+            h->h_meta_cap = want;
+        }
+    }
+    uint8_t* at = h->h_meta + h->h_meta_used;
+    h->h_meta_used += need;
+    std::memcpy(at, src, bytes);
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(dst, at, bytes, hipMemcpyHostToDevice, h->stream));
+    return PISCES_OK;
+}
+
 static int32_t stage_reserve(PiscesHip* h, size_t bytes)
 {
     h->stage_cur ^= 1;
@@ -1381,8 +1413,10 @@ static void tile_geometry(PiscesHip* h, const std::vector<int32_t>& keys, bool c
 }
 
 // uploads the BucketMap tables of `keys` and returns the device view
+// (n_zero_tail > 0: that many zeroed 32-bit words ride behind the tables in the same transfer — the tile counters of the bucketing —
+// and *zero_tail receives their device address)
 static int32_t upload_bucket_map(PiscesHip* h, const std::vector<int32_t>& keys, const std::vector<int32_t>& first_tile,
-                                 const std::vector<int32_t>& tol, BucketMap* m)
+                                 const std::vector<int32_t>& tol, BucketMap* m, size_t n_zero_tail = 0, unsigned int** zero_tail = nullptr)
 {
     const int32_t kmin = keys.front(), kmax = keys.back();
     const size_t n_slot = (size_t)(kmax - kmin + 1);
@@ -1390,12 +1424,15 @@ static int32_t upload_bucket_map(PiscesHip* h, const std::vector<int32_t>& keys,
     // one synchronisation, so a ring of four staging vectors never rewrites one that is still in flight
     std::vector<int32_t>& host = h->bucket_host[h->bucket_host_next];
     h->bucket_host_next = (h->bucket_host_next + 1) % 4;
-    host.assign(n_slot + keys.size() + tol.size(), -1);
+    const size_t n_tables = n_slot + keys.size() + tol.size();
+    host.assign(n_tables, -1);
     for (size_t i = 0; i < keys.size(); i++) host[(size_t)(keys[i] - kmin)] = (int32_t)i;
     std::copy(first_tile.begin(), first_tile.end(), host.begin() + (std::ptrdiff_t)n_slot);
     std::copy(tol.begin(), tol.end(), host.begin() + (std::ptrdiff_t)(n_slot + keys.size()));
+    host.resize(n_tables + n_zero_tail, 0);
     PISCES_HIP_CHECK(h, h->d_bucket.reserve(host.size()));
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_bucket.p, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    if (zero_tail) *zero_tail = (unsigned int*)(h->d_bucket.p + n_tables);
+    { int32_t rcu = meta_upload(h, h->d_bucket.p, host.data(), host.size() * sizeof(int32_t)); if (rcu) return rcu; }
     m->key_slot = h->d_bucket.p;
     m->first_tile = h->d_bucket.p + n_slot;
     m->tile_of_locus = tol.empty() ? nullptr : h->d_bucket.p + n_slot + keys.size();
@@ -1415,28 +1452,32 @@ static int32_t bucket_blocks(PiscesHip* h, const std::vector<int32_t>& keys, boo
     tile_geometry(h, keys, clip, tiles, first_tile, tol);
     if (tiles.empty()) return PISCES_OK;
     const int32_t n_tiles = (int32_t)tiles.size();
+    // Every stream operation of a flush costs ~4.5 us whatever its size (a 1000-locus block's whole flush is ~130 us of device time), so
+    // there are as few as can be: the tile counters arrive zeroed behind the bucket tables, the drop's counter is cleared by the scan,
+    // and the tuple buffer is not filled at all (a tile's segment is padded to a multiple of four tuples only so that the next segment
+    // starts aligned: no kernel reads past tuple_end).
     BucketMap m;
-    int32_t rc = upload_bucket_map(h, keys, first_tile, tol, &m);
+    unsigned int* tile_cnt = nullptr;
+    int32_t rc = upload_bucket_map(h, keys, first_tile, tol, &m, tiles.size(), &tile_cnt);
     if (rc) return rc;
     PISCES_HIP_CHECK(h, h->d_tiles.reserve(tiles.size()));
     PISCES_HIP_CHECK(h, h->d_tile_results.reserve(tiles.size()));
     PISCES_HIP_CHECK(h, h->d_count.reserve(4));
-    PISCES_HIP_CHECK(h, h->d_tile_cnt.reserve(tiles.size()));
     PISCES_HIP_CHECK(h, h->d_total.reserve(2));
     const size_t tup_ub = (size_t)h->log_ub + 3 * tiles.size() + 4;
     PISCES_HIP_CHECK(h, h->d_tuples.reserve(tup_ub));
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_tiles.p, tiles.data(), tiles.size() * sizeof(PiscesTile), hipMemcpyHostToDevice, h->stream));
-    PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_tile_cnt.p, 0, tiles.size() * sizeof(unsigned int), h->stream));
-    PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_tuples.p, 0xFF, tup_ub * sizeof(uint32_t), h->stream));   // PISCES_TUPLE_PAD in the padding
+    { int32_t rcu = meta_upload(h, h->d_tiles.p, tiles.data(), tiles.size() * sizeof(PiscesTile)); if (rcu) return rcu; }
     const int c = h->log_cur;
     if (h->log_ub > 0) {
         hipLaunchKernelGGL(bucket_count_kernel, dim3(log_grid(h)), dim3(256), 0, h->stream, h->d_log_pos[c].p, (long long)h->log_ub, m,
-                           h->d_tile_cnt.p);
+                           tile_cnt);
     }
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_tiles.p, n_tiles, h->d_tile_cnt.p, h->d_total.p);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_tiles.p, n_tiles, tile_cnt, h->d_total.p,
+                       h->d_log_n.p + (c ^ 1));
+    h->drop_counter_cleared = true;   // (by the scan above: enqueue_drop of the same submission needs no fill)
     if (h->log_ub > 0) {
         hipLaunchKernelGGL(bucket_scatter_kernel, dim3(log_grid(h)), dim3(256), 0, h->stream, h->d_log_pos[c].p, h->d_log_tup[c].p,
-                           (long long)h->log_ub, m, h->d_tiles.p, h->d_tile_cnt.p, h->d_tuples.p);
+                           (long long)h->log_ub, m, h->d_tiles.p, tile_cnt, h->d_tuples.p);
     }
     PISCES_HIP_CHECK(h, hipGetLastError());
     return PISCES_OK;   // everything else of the handle is ordered behind this on h->stream
@@ -1454,7 +1495,8 @@ static int32_t enqueue_drop(PiscesHip* h, const std::vector<int32_t>& keys)
     const int c = h->log_cur, o = c ^ 1;
     PISCES_HIP_CHECK(h, h->d_log_pos[o].reserve((size_t)h->log_ub));
     PISCES_HIP_CHECK(h, h->d_log_tup[o].reserve((size_t)h->log_ub));
-    PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_log_n.p + o, 0, sizeof(unsigned long long), h->stream));
+    if (!h->drop_counter_cleared) PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_log_n.p + o, 0, sizeof(unsigned long long), h->stream));
+    h->drop_counter_cleared = false;
     hipLaunchKernelGGL(log_drop_kernel, dim3(log_grid(h)), dim3(256), 0, h->stream, h->d_log_pos[c].p, h->d_log_tup[c].p, (long long)h->log_ub,
                        m, h->d_log_pos[o].p, h->d_log_tup[o].p, h->d_log_n.p + o);
     PISCES_HIP_CHECK(h, hipGetLastError());
@@ -1564,7 +1606,7 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
                 auto it = h->gapped_mnv_ref.find(tiles[(size_t)t].start_position + l);
                 if (it != h->gapped_mnv_ref.end()) g[(size_t)t * kTile + (size_t)l] = (uint32_t)it->second;
             }
-        PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_gapped.p, g.data(), g.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+        { int32_t rcu = meta_upload(h, h->d_gapped.p, g.data(), g.size() * sizeof(uint32_t)); if (rcu) return rcu; }
         PISCES_HIP_CHECK(h, accumulate_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, window));
         hipLaunchKernelGGL(call_counts_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->d_counts.p, h->d_gapped.p,
                            h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p, h->d_tile_results.p, h->P,
@@ -1600,6 +1642,7 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
         PISCES_HIP_CHECK(h, hipMemcpyAsync(hdr + 2, h->d_log_n.p + (h->log_cur ^ 1), sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipMemcpyAsync(hrec, h->d_compact.p, spec * sizeof(PiscesCalledAllele), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    h->h_meta_used = 0;   // the stream is idle: nothing reads the arena any more
     const int32_t total = hdr[0];
     *n_called += hdr[1];
     if (drop_now) {
