@@ -113,14 +113,21 @@ class HipVariantCaller:
         _check(self._h, lib.pisces_hip_add_gapped_mnv_ref(self._h, pos.ctypes.data, cnt.ctypes.data, len(pos)))
 
     # ---- GetCandidatesToProcess + IAlleleCaller.Call + DoneProcessing ----
-    def Call(self, upToPosition=None, capacity=1 << 16):
+    def Call(self, upToPosition=None, capacity=1 << 16, reuse_buffer=False):
         """SmallVariantCaller.Call(upToPosition) (SmallVariantCaller.cs:157-189). None = final flush.
-        Returns a CALLED_ALLELE_DTYPE array sorted by (position, ref, alt)."""
+        Returns a CALLED_ALLELE_DTYPE array sorted by (position, ref, alt).  reuse_buffer: the rows are a view into a buffer the engine
+        keeps from call to call (valid until the next Call), as a host that owns its output buffer works; the default hands
+        out a fresh array every time."""
         up_to = -1 if upToPosition is None else int(upToPosition)
         while True:
-            out = np.zeros(capacity, dtype=_abi.CALLED_ALLELE_DTYPE)
+            if reuse_buffer:
+                out = getattr(self, "_flush_out", None)
+                if out is None or len(out) < capacity:
+                    out = self._flush_out = np.zeros(capacity, dtype=_abi.CALLED_ALLELE_DTYPE)
+            else:
+                out = np.zeros(capacity, dtype=_abi.CALLED_ALLELE_DTYPE)
             n = C.c_int64(0)
-            rc = lib.pisces_hip_flush(self._h, up_to, out.ctypes.data, capacity, C.byref(n))
+            rc = lib.pisces_hip_flush(self._h, up_to, out.ctypes.data, len(out), C.byref(n))
             if rc == _abi.E_BUFFER_TOO_SMALL:
                 capacity = int(n.value)
                 continue
