@@ -668,7 +668,6 @@ static int32_t log_reserve(PiscesHip* h, int64_t extra)
     return PISCES_OK;
 }
 
-// next staging pair with room for `bytes`; waits only for the work that used THIS pair two calls ago
 // enqueues dst[0, bytes) = src[0, bytes) (device <- host) on h->stream through the pinned arena
 static int32_t meta_upload(PiscesHip* h, void* dst, const void* src, size_t bytes)
 {
@@ -694,6 +693,7 @@ static int32_t meta_upload(PiscesHip* h, void* dst, const void* src, size_t byte
     return PISCES_OK;
 }
 
+// next staging pair with room for `bytes`; waits only for the work that used THIS pair two calls ago
 static int32_t stage_reserve(PiscesHip* h, size_t bytes)
 {
     h->stage_cur ^= 1;
@@ -1041,6 +1041,79 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
         ub += ref_span;
     }
     slots[(size_t)nr] = (long long)(h->log_ub + ub);
+    // ---- the read batch crosses PCIe once, packed; the walk runs on the device (expand_reads_kernel).  The transfer is started
+    // BEFORE the second host pass over the CIGARs (block bookkeeping, candidate slots): that pass runs under it, and only its small
+    // table of candidate slots follows in a transfer of its own ----
+    const size_t n_cig = (size_t)batch->cigar_offset[nr], n_seq = (size_t)batch->seq_offset[nr];
+    auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    size_t off_pos = 0, off_flags = align16(off_pos + (size_t)nr * 4), off_coff = align16(off_flags + (size_t)nr),
+           off_cop = align16(off_coff + ((size_t)nr + 1) * 4), off_clen = align16(off_cop + n_cig),
+           off_soff = align16(off_clen + n_cig * 4), off_bases = align16(off_soff + ((size_t)nr + 1) * 4),
+           off_quals = align16(off_bases + n_seq), off_dirs = align16(off_quals + n_seq),
+           off_slots = align16(off_dirs + (batch->directions ? n_seq : 0)), off_deldirs = align16(off_slots + ((size_t)nr + 1) * 8),
+           off_fslots = align16(off_deldirs + (batch->deletion_directions ? 2 * n_cig : 0)), total = align16(off_fslots + ((size_t)nr + 1) * 4);
+    int32_t rc = stage_reserve(h, total);
+    if (rc) return rc;
+    rc = log_reserve(h, ub);
+    if (rc) return rc;
+    uint8_t* st = h->h_stage;
+    std::memcpy(st + off_pos, batch->position, (size_t)nr * 4);
+    std::memcpy(st + off_flags, batch->flags, (size_t)nr);
+    std::memcpy(st + off_coff, batch->cigar_offset, ((size_t)nr + 1) * 4);
+    std::memcpy(st + off_cop, batch->cigar_op, n_cig);
+    std::memcpy(st + off_clen, batch->cigar_len, n_cig * 4);
+    std::memcpy(st + off_soff, batch->seq_offset, ((size_t)nr + 1) * 4);
+    std::memcpy(st + off_slots, slots.data(), ((size_t)nr + 1) * 8);
+    if (batch->deletion_directions) std::memcpy(st + off_deldirs, batch->deletion_directions, 2 * n_cig);
+    {
+        // bases / qualities / directions are the bulk (2-3 bytes per aligned base).  Small batches: one copy into the pinned buffer,
+        // one transfer.  Large ones: slices of 8 MB, each copied by a few threads and handed to the DMA engine as soon as it is
+        // complete, so that the host copy of slice k+1 runs under the PCIe transfer of slice k.
+        struct Seg { size_t dst; const uint8_t* src; size_t len; };
+        const Seg segs[3] = {{off_bases, batch->bases, n_seq}, {off_quals, batch->quals, n_seq},
+                             {off_dirs, batch->directions, batch->directions ? n_seq : 0}};
+        const size_t bulk = 2 * n_seq + (batch->directions ? n_seq : 0);
+        constexpr size_t kSlice = (size_t)8 << 20;
+        if (bulk < 2 * kSlice) {
+            for (const Seg& g : segs) if (g.len) std::memcpy(st + g.dst, g.src, g.len);
+            PISCES_HIP_CHECK(h, hipMemcpyAsync(D_STAGE(h), st, off_fslots, hipMemcpyHostToDevice, h->stream));
+        } else {
+            // everything outside the bulk first (the descriptors before it, the slot table after it)
+            PISCES_HIP_CHECK(h, hipMemcpyAsync(D_STAGE(h), st, off_bases, hipMemcpyHostToDevice, h->stream));
+            PISCES_HIP_CHECK(h, hipMemcpyAsync(D_STAGE(h) + off_slots, st + off_slots, off_fslots - off_slots, hipMemcpyHostToDevice, h->stream));
+            struct Slice { size_t dst; const uint8_t* src; size_t len; };
+            std::vector<Slice> slices;
+            for (const Seg& g : segs)
+                for (size_t o = 0; o < g.len; o += kSlice) slices.push_back({g.dst + o, g.src + o, std::min(kSlice, g.len - o)});
+            const int n_threads = (int)std::min<size_t>(4, std::max<unsigned>(1u, std::thread::hardware_concurrency()));
+            std::vector<std::atomic<int>> parts_done(slices.size());
+            for (auto& a : parts_done) a.store(0, std::memory_order_relaxed);
+            auto worker = [&](int w) {
+                for (size_t k = 0; k < slices.size(); k++) {
+                    const size_t per = (slices[k].len + (size_t)n_threads - 1) / (size_t)n_threads, lo = std::min(slices[k].len, per * (size_t)w),
+                                 hi = std::min(slices[k].len, lo + per);
+                    if (hi > lo) std::memcpy(st + slices[k].dst + lo, slices[k].src + lo, hi - lo);
+                    parts_done[k].fetch_add(1, std::memory_order_release);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int w = 1; w < n_threads; w++) pool.emplace_back(worker, w);
+            hipError_t first_error = hipSuccess;
+            {
+                // this thread copies its share of a slice, then waits for the others' and enqueues the transfer
+                for (size_t k = 0; k < slices.size(); k++) {
+                    const size_t per = (slices[k].len + (size_t)n_threads - 1) / (size_t)n_threads, hi = std::min(slices[k].len, per);
+                    if (hi) std::memcpy(st + slices[k].dst, slices[k].src, hi);
+                    parts_done[k].fetch_add(1, std::memory_order_release);
+                    while (parts_done[k].load(std::memory_order_acquire) < n_threads) std::this_thread::yield();
+                    if (first_error == hipSuccess)
+                        first_error = hipMemcpyAsync(D_STAGE(h) + slices[k].dst, st + slices[k].dst, slices[k].len, hipMemcpyHostToDevice, h->stream);
+                }
+            }
+            for (auto& t : pool) t.join();
+            PISCES_HIP_CHECK(h, first_error);
+        }
+    }
     // ICandidateVariantFinder.FindCandidates + IStateManager.AddCandidates (SmallVariantCaller.cs:92-96) run on the device
     // (find_emit_kernel, enqueued behind the read walk below).  With MNV calling off only insertions and deletions are discovered
     // (SNV candidates are implied by the allele counts): the host reserves one record slot per I / D operation here, from the CIGAR
@@ -1057,7 +1130,10 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
                 if (r.cigar_op[c] == 'I' || r.cigar_op[c] == 'D') found_slots++;
                 if (r.cigar_op[c] == 'I' && r.cigar_len[c] > (uint32_t)kFoundInline) found_pool += r.cigar_len[c];
             }
-        if (found_slots > 0x7FFFFFF0ll || found_pool > 0x7FFFFFF0ll) return fail(h, PISCES_E_INVALID_ARG, "add_reads: too many insertions / deletions in one batch");
+        if (found_slots > 0x7FFFFFF0ll || found_pool > 0x7FFFFFF0ll) {
+            (void)stage_release(h);   // (the batch's transfer is in flight out of the staging pair)
+            return fail(h, PISCES_E_INVALID_ARG, "add_reads: too many insertions / deletions in one batch");
+        }
         // GetBlock(position) for every position that receives a count (RegionStateManager.cs:361-383): the runs of mapped
         // bases always do; a gap (deletion / skip) does when its flanking qualities pass CheckDeletionQuality
         {
@@ -1098,78 +1174,8 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
     }
     fslots[(size_t)nr] = (int32_t)found_slots;
 
-    // ---- the read batch crosses PCIe once, packed; the walk runs on the device (expand_reads_kernel) ----
-    const size_t n_cig = (size_t)batch->cigar_offset[nr], n_seq = (size_t)batch->seq_offset[nr];
-    auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    size_t off_pos = 0, off_flags = align16(off_pos + (size_t)nr * 4), off_coff = align16(off_flags + (size_t)nr),
-           off_cop = align16(off_coff + ((size_t)nr + 1) * 4), off_clen = align16(off_cop + n_cig),
-           off_soff = align16(off_clen + n_cig * 4), off_bases = align16(off_soff + ((size_t)nr + 1) * 4),
-           off_quals = align16(off_bases + n_seq), off_dirs = align16(off_quals + n_seq),
-           off_slots = align16(off_dirs + (batch->directions ? n_seq : 0)), off_fslots = align16(off_slots + ((size_t)nr + 1) * 8),
-           off_deldirs = align16(off_fslots + ((size_t)nr + 1) * 4), total = align16(off_deldirs + (batch->deletion_directions ? 2 * n_cig : 0));
-    int32_t rc = stage_reserve(h, total);
-    if (rc) return rc;
-    rc = log_reserve(h, ub);
-    if (rc) return rc;
-    uint8_t* st = h->h_stage;
-    std::memcpy(st + off_pos, batch->position, (size_t)nr * 4);
-    std::memcpy(st + off_flags, batch->flags, (size_t)nr);
-    std::memcpy(st + off_coff, batch->cigar_offset, ((size_t)nr + 1) * 4);
-    std::memcpy(st + off_cop, batch->cigar_op, n_cig);
-    std::memcpy(st + off_clen, batch->cigar_len, n_cig * 4);
-    std::memcpy(st + off_soff, batch->seq_offset, ((size_t)nr + 1) * 4);
-    std::memcpy(st + off_slots, slots.data(), ((size_t)nr + 1) * 8);
     std::memcpy(st + off_fslots, fslots.data(), ((size_t)nr + 1) * 4);
-    if (batch->deletion_directions) std::memcpy(st + off_deldirs, batch->deletion_directions, 2 * n_cig);
-    {
-        // bases / qualities / directions are the bulk (2-3 bytes per aligned base).  Small batches: one copy into the pinned buffer,
-        // one transfer.  Large ones: slices of 8 MB, each copied by a few threads and handed to the DMA engine as soon as it is
-        // complete, so that the host copy of slice k+1 runs under the PCIe transfer of slice k.
-        struct Seg { size_t dst; const uint8_t* src; size_t len; };
-        const Seg segs[3] = {{off_bases, batch->bases, n_seq}, {off_quals, batch->quals, n_seq},
-                             {off_dirs, batch->directions, batch->directions ? n_seq : 0}};
-        const size_t bulk = 2 * n_seq + (batch->directions ? n_seq : 0);
-        constexpr size_t kSlice = (size_t)8 << 20;
-        if (bulk < 2 * kSlice) {
-            for (const Seg& g : segs) if (g.len) std::memcpy(st + g.dst, g.src, g.len);
-            PISCES_HIP_CHECK(h, hipMemcpyAsync(D_STAGE(h), st, total, hipMemcpyHostToDevice, h->stream));
-        } else {
-            // everything outside the bulk first (the descriptors before it, the slot table after it)
-            PISCES_HIP_CHECK(h, hipMemcpyAsync(D_STAGE(h), st, off_bases, hipMemcpyHostToDevice, h->stream));
-            PISCES_HIP_CHECK(h, hipMemcpyAsync(D_STAGE(h) + off_slots, st + off_slots, total - off_slots, hipMemcpyHostToDevice, h->stream));
-            struct Slice { size_t dst; const uint8_t* src; size_t len; };
-            std::vector<Slice> slices;
-            for (const Seg& g : segs)
-                for (size_t o = 0; o < g.len; o += kSlice) slices.push_back({g.dst + o, g.src + o, std::min(kSlice, g.len - o)});
-            const int n_threads = (int)std::min<size_t>(4, std::max<unsigned>(1u, std::thread::hardware_concurrency()));
-            std::vector<std::atomic<int>> parts_done(slices.size());
-            for (auto& a : parts_done) a.store(0, std::memory_order_relaxed);
-            auto worker = [&](int w) {
-                for (size_t k = 0; k < slices.size(); k++) {
-                    const size_t per = (slices[k].len + (size_t)n_threads - 1) / (size_t)n_threads, lo = std::min(slices[k].len, per * (size_t)w),
-                                 hi = std::min(slices[k].len, lo + per);
-                    if (hi > lo) std::memcpy(st + slices[k].dst + lo, slices[k].src + lo, hi - lo);
-                    parts_done[k].fetch_add(1, std::memory_order_release);
-                }
-            };
-            std::vector<std::thread> pool;
-            for (int w = 1; w < n_threads; w++) pool.emplace_back(worker, w);
-            hipError_t first_error = hipSuccess;
-            {
-                // this thread copies its share of a slice, then waits for the others' and enqueues the transfer
-                for (size_t k = 0; k < slices.size(); k++) {
-                    const size_t per = (slices[k].len + (size_t)n_threads - 1) / (size_t)n_threads, hi = std::min(slices[k].len, per);
-                    if (hi) std::memcpy(st + slices[k].dst, slices[k].src, hi);
-                    parts_done[k].fetch_add(1, std::memory_order_release);
-                    while (parts_done[k].load(std::memory_order_acquire) < n_threads) std::this_thread::yield();
-                    if (first_error == hipSuccess)
-                        first_error = hipMemcpyAsync(D_STAGE(h) + slices[k].dst, st + slices[k].dst, slices[k].len, hipMemcpyHostToDevice, h->stream);
-                }
-            }
-            for (auto& t : pool) t.join();
-            PISCES_HIP_CHECK(h, first_error);
-        }
-    }
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(D_STAGE(h) + off_fslots, st + off_fslots, total - off_fslots, hipMemcpyHostToDevice, h->stream));
     DevReadBatch db;
     const uint8_t* d = D_STAGE(h);
     db.position = (const int32_t*)(d + off_pos);
