@@ -150,6 +150,30 @@ def end_to_end(pileup, cfg, engine, loci=30_000):
         out[label] = {"value": n_loci / best, "unit": "candidate loci/s", "seconds": best, "loci": n_loci, "records": n_rec,
                       "add_reads_flush_pairs": len(batches), "reads": int(sum(b.n_reads for _, b in batches))}
     out["scope"] = "host read buffers -> pisces_hip_add_reads -> pisces_hip_flush -> host records (PCIe both ways; one handle, best of 3 passes after a warm-up pass)"
+    # (c) the same reads as the bytes of a BAM file (BGZF, zlib level 6): inflated, cut into records, filtered, walked and called on the
+    # device (pisces_hip_bam_decode -> pisces_hip_add_decoded_reads -> pisces_hip_flush); only the compressed bytes cross PCIe
+    try:
+        from tools.bam_bench import bam_of_read_batch
+        from tools.bgzf_bench import make_bgzf
+        rb = synth.reads_of(pileup, n_amp, first_amplicon=pileup.first_amplicon)
+        data = make_bgzf(bam_of_read_batch(rb), 6)
+        best = None
+        with engine.HipVariantCaller(cfg) as c:
+            c.SetReference(ref)
+            for rep in range(4):
+                t0 = time.perf_counter()
+                counts = c.bam_decode(data, 0)
+                c.AddDecodedReads()
+                n_rec = len(c.Call(None, capacity=1 << 18, reuse_buffer=True))
+                dt = time.perf_counter() - t0
+                if rep > 0:
+                    best = dt if best is None else min(best, dt)
+        assert counts["reads"] == rb.n_reads and n_rec == out["batched_30_blocks"]["records"], (counts, n_rec)
+        out["from_bam_bytes"] = {"value": n_loci / best, "unit": "candidate loci/s", "seconds": best, "loci": n_loci, "records": n_rec,
+                                 "reads": int(rb.n_reads), "compressed_bytes": len(data),
+                                 "scope": "BGZF-compressed BAM bytes on the host -> inflate, record cut, ShouldSkipRead, read walk, calls on the device -> host records"}
+    except Exception as e:   # noqa: BLE001  (an extra figure: it must not cost the bench line)
+        out["from_bam_bytes"] = {"error": str(e)[:200]}
     return out
 
 

@@ -40,6 +40,47 @@ def make_bam(n_reads, read_len=150, seed=3):
     return hdr + rec.tobytes()
 
 
+def bam_of_read_batch(rb, chrom=b"chr1", chrom_len=250_000_000):
+    """An uncompressed BAM stream (header + records) of a pisces_amd._abi.ReadBatch whose reads all have the CIGAR <len>M (the
+    synthetic amplicon reads): what samtools would write for them, mapping quality 60, no tags."""
+    n = rb.n_reads
+    seq_off = np.asarray(rb.seq_offset)
+    lens = np.diff(seq_off)
+    read_len = int(lens[0])
+    assert (lens == read_len).all() and (np.diff(np.asarray(rb.cigar_offset)) == 1).all() and (np.asarray(rb.cigar_op) == ord("M")).all()
+    hdr = b"BAM\x01" + struct.pack("<i", 0) + struct.pack("<i", 1) + struct.pack("<i", len(chrom) + 1) + chrom + b"\0" + struct.pack("<i", chrom_len)
+    name = b"read/0000000\0"
+    fixed = 32 + len(name) + 4 + (read_len + 1) // 2 + read_len
+    rec = np.zeros((n, 4 + fixed), dtype=np.uint8)
+
+    def put32(col, v):
+        rec[:, col:col + 4] = np.asarray(v, dtype="<i4").reshape(-1, 1).view(np.uint8).reshape(-1, 4) if np.ndim(v) else np.frombuffer(struct.pack("<i", v), np.uint8)
+
+    put32(0, fixed)
+    put32(4, 0)
+    put32(8, np.asarray(rb.position, dtype=np.int32) - 1)   # BAM positions are 0-based
+    rec[:, 12] = len(name)
+    rec[:, 13] = 60
+    rec[:, 16:18] = np.frombuffer(struct.pack("<H", 1), np.uint8)
+    flags = np.where(np.asarray(rb.flags) & 1, 16, 0).astype("<u2")
+    rec[:, 18:20] = flags.reshape(-1, 1).view(np.uint8).reshape(-1, 2)
+    put32(20, read_len)
+    put32(24, -1); put32(28, -1); put32(32, 0)
+    rec[:, 36:36 + len(name)] = np.frombuffer(name, np.uint8)
+    c0 = 36 + len(name)
+    rec[:, c0:c0 + 4] = np.frombuffer(struct.pack("<I", (read_len << 4) | 0), np.uint8)
+    code = np.full(256, 15, dtype=np.uint8)
+    for ch, v in ((b"A", 1), (b"C", 2), (b"G", 4), (b"T", 8)):
+        code[ch[0]] = v
+    codes = code[np.asarray(rb.bases).reshape(n, read_len)]
+    if read_len % 2:
+        codes = np.concatenate([codes, np.zeros((n, 1), np.uint8)], axis=1)
+    rec[:, c0 + 4:c0 + 4 + (read_len + 1) // 2] = (codes[:, 0::2] << 4) | codes[:, 1::2]
+    q0 = c0 + 4 + (read_len + 1) // 2
+    rec[:, q0:q0 + read_len] = np.asarray(rb.quals).reshape(n, read_len)
+    return hdr + rec.tobytes()
+
+
 def main():
     from pisces_amd import _abi, engine
     n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 400_000
