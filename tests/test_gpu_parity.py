@@ -347,6 +347,27 @@ def test_error_paths(torch_cuda):
         engine.HipVariantCaller(_abi.default_config(strand_bias_model=7))
     with pytest.raises(engine.PiscesHipError):
         engine.HipVariantCaller(_abi.default_config(abi_version=99))
+    # candidates and forced alleles the caller brings: malformed entries are refused, invalid forced alleles dropped as Factory drops them
+    with engine.HipVariantCaller() as c:
+        c.SetReference(np.frombuffer(b"ACGT" * 600, dtype=np.uint8))
+        for bad in ({"position": 0, "category": 0, "ref": "A", "alt": "C"}, {"position": 5, "category": 9, "ref": "A", "alt": "C"},
+                    {"position": 5, "category": 0, "ref": "", "alt": "C"}):
+            with pytest.raises(engine.PiscesHipError) as e:
+                c.AddCandidates([bad])
+            assert e.value.code == _abi.E_INVALID_ARG
+        assert c.GetCandidates() == []
+        c.AddCandidates([{"position": 9, "category": _abi.CAT_DELETION, "ref": "ACG", "alt": "A", "support_by_dir": (3, 2, 0)}] * 2)
+        got = c.GetCandidates()
+        assert len(got) == 1 and got[0]["support_by_dir"] == [6, 4, 0] and (got[0]["ref"], got[0]["alt"]) == ("ACG", "A")   # merged (RegionState.AddCandidate)
+        # ref == alt and an ALT outside A/C/G/T are no forced alleles (Factory.IsValidAlt); duplicates count once (a HashSet)
+        c.SetForcedAlleles([(30, "G", "G"), (31, "T", "N"), (32, "A", "C"), (32, "A", "C"), (33, "AC", "A")])
+        c.AddAlleleCounts(_abi.ReadBatch([{"pos": 20, "seq": "TACGTACGTACGTACGTACG", "cigar": [("M", 20)], "quals": [30] * 20, "reverse": False}]))
+        recs, alleles = c.CallWithAlleles()
+        forced_rows = [(int(r["position"]), a) for r, a in zip(recs, alleles) if (int(r["filter_bits"]) >> _abi.FILTER_FORCED_REPORT) & 1]
+        assert forced_rows == [(32, ("A", "C")), (33, ("AC", "A"))]
+        with pytest.raises(engine.PiscesHipError) as e:
+            c.SetForcedAlleles([(40, "A", "C")])        # after forced alleles became candidates: refused
+        assert e.value.code == _abi.E_INVALID_ARG
 
 
 # ---------------------------------------------------------------- BASELINE sizes: size-independent properties
