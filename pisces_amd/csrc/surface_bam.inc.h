@@ -1,0 +1,362 @@
+// surface_bam.inc.h — part of pisces_hip.hip (included there, inside its extern "C" block; not a translation unit of its own).
+// Row f4 behind the C ABI: BGZF block table and inflate, BAM bytes -> device-resident read batch, pisces_hip_add_decoded_reads.
+
+// ---- BGZF (row f4, upstream of the read batch) ----
+int64_t pisces_hip_bgzf_scan(const uint8_t* file, int64_t n_bytes, PiscesBgzfBlock* blocks, int64_t capacity, int64_t* inflated_bytes)
+{
+    return abi_guard<int64_t>((PiscesHip*)nullptr, [&]() -> int64_t {
+    if (!file || n_bytes < 0 || capacity < 0 || (capacity > 0 && !blocks)) return PISCES_E_INVALID_ARG;
+    int64_t pos = 0, n = 0, out = 0;
+    while (pos < n_bytes) {
+        // gzip member header (RFC 1952) with FEXTRA; BamConstants.BlockHeaderLength = 18 is the XLEN = 6 case (BamCommon.cs:989)
+        if (pos + 12 > n_bytes) return PISCES_E_INVALID_ARG;
+        const uint8_t* b = file + pos;
+        if (b[0] != 31 || b[1] != 139 || b[2] != 8 || !(b[3] & 4)) return PISCES_E_INVALID_ARG;
+        const int64_t xlen = b[10] | ((int64_t)b[11] << 8);
+        if (pos + 12 + xlen > n_bytes) return PISCES_E_INVALID_ARG;
+        int64_t bsize = -1;
+        for (int64_t x = 0; x + 4 <= xlen;) {   // the BC subfield: total block size - 1 (BamReader.cs:622)
+            const uint8_t* f = b + 12 + x;
+            const int64_t slen = f[2] | ((int64_t)f[3] << 8);
+            if (f[0] == 'B' && f[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = (f[4] | ((int64_t)f[5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        const int64_t header = 12 + xlen;
+        if (bsize < header + 8 || pos + bsize > n_bytes) return PISCES_E_INVALID_ARG;
+        const uint8_t* tr = b + bsize - 8;
+        PiscesBgzfBlock blk;
+        blk.in_offset = pos + header;
+        blk.in_length = (int32_t)(bsize - header - 8);
+        blk.crc32 = tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+        const uint32_t isize = tr[4] | ((uint32_t)tr[5] << 8) | ((uint32_t)tr[6] << 16) | ((uint32_t)tr[7] << 24);
+        if (isize > 65536u) return PISCES_E_INVALID_ARG;   // BgzfCommon.MaxBlockSize
+        blk.out_length = (int32_t)isize;
+        blk.out_offset = out;
+        blk.reserved = 0;
+        if (n < capacity) blocks[n] = blk;
+        n++;
+        out += isize;
+        pos += bsize;
+    }
+    if (inflated_bytes) *inflated_bytes = out;
+    return n;
+    });
+}
+
+static uint32_t crc32_of(const uint8_t* p, size_t n)
+{
+    static uint32_t table[8][256];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; i++)
+            for (int t = 1; t < 8; t++) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xFF];
+    });
+    uint32_t c = 0xFFFFFFFFu;
+    while (n >= 8) {   // slicing-by-8
+        const uint32_t lo = (p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)) ^ c;
+        c = table[7][lo & 0xFF] ^ table[6][(lo >> 8) & 0xFF] ^ table[5][(lo >> 16) & 0xFF] ^ table[4][lo >> 24] ^ table[3][p[4]] ^
+            table[2][p[5]] ^ table[1][p[6]] ^ table[0][p[7]];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) c = table[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+
+int32_t pisces_hip_bgzf_inflate(PiscesHip* h, const uint8_t* file, int64_t n_bytes, const PiscesBgzfBlock* blocks, int64_t n_blocks,
+                                uint8_t* out, int64_t out_capacity, int32_t check_crc, float* kernel_ms)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (!file || n_bytes <= 0 || n_blocks < 0 || (n_blocks > 0 && !blocks) || out_capacity < 0) return fail(h, PISCES_E_INVALID_ARG, "bgzf_inflate: bad arguments");
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (n_blocks == 0) return PISCES_OK;
+    int64_t out_bytes = 0;
+    for (int64_t i = 0; i < n_blocks; i++) {
+        const PiscesBgzfBlock& b = blocks[i];
+        if (b.in_offset < 0 || b.in_length < 0 || b.in_length > 65536 || b.in_offset + b.in_length > n_bytes || b.out_offset < 0 ||
+            b.out_length < 0 || b.out_length > 65536 || b.out_offset + b.out_length > out_capacity)   // BgzfCommon.MaxBlockSize both ways
+            return fail(h, PISCES_E_INVALID_ARG, "bgzf_inflate: block " + std::to_string(i) + " lies outside the file bytes or the output buffer");
+        out_bytes = std::max(out_bytes, b.out_offset + b.out_length);
+    }
+    if (out_bytes > 0 && !out) return fail(h, PISCES_E_INVALID_ARG, "bgzf_inflate: bad arguments");
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    DeviceBuf<uint8_t> d_in, d_out;
+    DeviceBuf<PiscesBgzfBlock> d_blocks;
+    DeviceBuf<int32_t> d_status;
+    PISCES_HIP_CHECK(h, d_in.reserve((size_t)n_bytes + kInWindow + 32));   // the bit reader's LDS window is filled in whole: up to a window past a block's payload
+    PISCES_HIP_CHECK(h, hipMemsetAsync(d_in.p + n_bytes, 0, 16, h->stream));
+    PISCES_HIP_CHECK(h, d_out.reserve((size_t)std::max<int64_t>(out_bytes, 1)));
+    PISCES_HIP_CHECK(h, d_blocks.reserve((size_t)n_blocks));
+    PISCES_HIP_CHECK(h, d_status.reserve((size_t)n_blocks));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(d_in.p, file, (size_t)n_bytes, hipMemcpyHostToDevice, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(d_blocks.p, blocks, (size_t)n_blocks * sizeof(PiscesBgzfBlock), hipMemcpyHostToDevice, h->stream));
+    hipExtLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)n_blocks), dim3(64), 0u, h->stream, h->ev0, h->ev1, 0u,
+                          (const uint8_t*)d_in.p, (const PiscesBgzfBlock*)d_blocks.p, n_blocks, d_out.p, d_status.p);
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    std::vector<int32_t> status((size_t)n_blocks);
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(status.data(), d_status.p, status.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    if (out_bytes > 0) PISCES_HIP_CHECK(h, hipMemcpyAsync(out, d_out.p, (size_t)out_bytes, hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    if (kernel_ms) PISCES_HIP_CHECK(h, hipEventElapsedTime(kernel_ms, h->ev0, h->ev1));
+    d_in.release(); d_out.release(); d_blocks.release(); d_status.release();
+    for (int64_t i = 0; i < n_blocks; i++)
+        if (status[(size_t)i] != 0)
+            return fail(h, PISCES_E_INVALID_ARG, "bgzf_inflate: block " + std::to_string(i) + " is not a valid DEFLATE stream of its ISIZE (code " +
+                                                     std::to_string(status[(size_t)i]) + ")");
+    if (check_crc) {
+        // blocks are independent: a few host threads share them for large tables (slicing-by-8 runs at ~2 GB/s per core)
+        (void)crc32_of(out, 0);   // the tables, once, before any thread needs them
+        const int n_threads = n_blocks >= 256 ? (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+        std::atomic<int64_t> first_bad(n_blocks);
+        auto check = [&](int w) {
+            for (int64_t i = w; i < n_blocks; i += n_threads)
+                if (crc32_of(out + blocks[i].out_offset, (size_t)blocks[i].out_length) != blocks[i].crc32) {
+                    int64_t cur = first_bad.load();
+                    while (i < cur && !first_bad.compare_exchange_weak(cur, i)) {}
+                }
+        };
+        std::vector<std::thread> pool;
+        for (int w = 1; w < n_threads; w++) pool.emplace_back(check, w);
+        check(0);
+        for (auto& t : pool) t.join();
+        if (first_bad.load() < n_blocks)
+            return fail(h, PISCES_E_INVALID_ARG, "bgzf_inflate: CRC-32 mismatch in block " + std::to_string(first_bad.load()));
+    }
+    return PISCES_OK;
+    });
+}
+
+// ---- BAM bytes -> read batch on the device (row f4): only the compressed file crosses PCIe -------------------------------
+int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes, const PiscesBgzfBlock* blocks, int64_t n_blocks, int32_t ref_id,
+                              int32_t min_map_quality, int32_t skip_duplicates, int32_t only_proper_pairs, int64_t counts[4])
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (!file || n_bytes <= 0 || n_blocks <= 0 || !blocks) return fail(h, PISCES_E_INVALID_ARG, "bam_decode: bad arguments");
+    h->bam.valid = false;
+    int64_t out_bytes = 0;
+    for (int64_t i = 0; i < n_blocks; i++) {
+        const PiscesBgzfBlock& b = blocks[i];
+        if (b.in_offset < 0 || b.in_length < 0 || b.in_length > 65536 || b.in_offset + b.in_length > n_bytes || b.out_offset < 0 ||
+            b.out_length < 0 || b.out_length > 65536)
+            return fail(h, PISCES_E_INVALID_ARG, "bam_decode: block " + std::to_string(i) + " lies outside the file bytes");
+        out_bytes = std::max(out_bytes, b.out_offset + b.out_length);
+    }
+    if (out_bytes <= 0 || out_bytes > 0x7FFFFFFF00ll) return fail(h, PISCES_E_INVALID_ARG, "bam_decode: empty or oversized stream");
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    auto& B = h->bam;
+    PISCES_HIP_CHECK(h, B.d_file.reserve((size_t)n_bytes + kInWindow + 32));
+    PISCES_HIP_CHECK(h, B.d_stream.reserve((size_t)out_bytes + 16));
+    PISCES_HIP_CHECK(h, B.d_blocks.reserve((size_t)n_blocks));
+    PISCES_HIP_CHECK(h, B.d_status.reserve((size_t)n_blocks));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(B.d_file.p + n_bytes, 0, 16, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(B.d_file.p, file, (size_t)n_bytes, hipMemcpyHostToDevice, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(B.d_blocks.p, blocks, (size_t)n_blocks * sizeof(PiscesBgzfBlock), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)n_blocks), dim3(64), 0, h->stream, (const uint8_t*)B.d_file.p,
+                       (const PiscesBgzfBlock*)B.d_blocks.p, n_blocks, B.d_stream.p, B.d_status.p);
+    // record boundaries without a serial pass over the bytes
+    const int64_t n_chunks = (out_bytes + kBamChunk - 1) / kBamChunk;
+    PISCES_HIP_CHECK(h, B.d_exits.reserve((size_t)out_bytes));
+    PISCES_HIP_CHECK(h, B.d_header.reserve(4));
+    PISCES_HIP_CHECK(h, B.d_entry.reserve((size_t)n_chunks));
+    PISCES_HIP_CHECK(h, B.d_bstatus.reserve(4));
+    PISCES_HIP_CHECK(h, B.d_n_reads.reserve((size_t)n_chunks + 1));
+    PISCES_HIP_CHECK(h, B.d_n_ops.reserve((size_t)n_chunks + 1));
+    PISCES_HIP_CHECK(h, B.d_n_bases.reserve((size_t)n_chunks + 1));
+    PISCES_HIP_CHECK(h, B.d_n_skipped.reserve((size_t)n_chunks + 1));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(B.d_bstatus.p, 0, 4 * sizeof(int32_t), h->stream));
+    const BamFilter F = {ref_id, min_map_quality, skip_duplicates, only_proper_pairs, h->cfg.min_base_call_quality};
+    hipLaunchKernelGGL(bam_header_kernel, dim3(1), dim3(1), 0, h->stream, (const uint8_t*)B.d_stream.p, out_bytes, B.d_header.p);
+    hipLaunchKernelGGL(bam_chain_kernel, dim3((unsigned)n_chunks), dim3(1024), 0, h->stream, (const uint8_t*)B.d_stream.p, out_bytes, B.d_exits.p);
+    hipLaunchKernelGGL(bam_entry_kernel, dim3(1), dim3(1), 0, h->stream, (const uint16_t*)B.d_exits.p, out_bytes, (const long long*)B.d_header.p,
+                       n_chunks, B.d_entry.p, B.d_bstatus.p);
+    hipLaunchKernelGGL(bam_count_kernel, dim3((unsigned)n_chunks), dim3(64), 0, h->stream, (const uint8_t*)B.d_stream.p, out_bytes,
+                       (const long long*)B.d_entry.p, F, B.d_n_reads.p, B.d_n_ops.p, B.d_n_bases.p, B.d_n_skipped.p);
+    hipLaunchKernelGGL(bam_scan3_kernel, dim3(1), dim3(1024), 0, h->stream, B.d_n_reads.p, B.d_n_ops.p, B.d_n_bases.p, (int32_t)n_chunks);
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    std::vector<int32_t> status((size_t)n_blocks), skipped((size_t)n_chunks);
+    int32_t totals[3] = {0, 0, 0}, bstatus[4] = {0, 0, 0, 0};
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(status.data(), B.d_status.p, status.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(skipped.data(), B.d_n_skipped.p, skipped.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(&totals[0], B.d_n_reads.p + n_chunks, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(&totals[1], B.d_n_ops.p + n_chunks, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(&totals[2], B.d_n_bases.p + n_chunks, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(bstatus, B.d_bstatus.p, sizeof(bstatus), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    for (int64_t i = 0; i < n_blocks; i++)
+        if (status[(size_t)i] != 0)
+            return fail(h, PISCES_E_INVALID_ARG, "bam_decode: block " + std::to_string(i) + " is not a valid DEFLATE stream of its ISIZE");
+    if (bstatus[0] == 1) return fail(h, PISCES_E_INVALID_ARG, "bam_decode: not a BAM stream (magic / header)");
+    if (bstatus[0] != 0)
+        return fail(h, PISCES_E_INVALID_ARG, "bam_decode: the record chain breaks in chunk " + std::to_string(bstatus[1]) +
+                                                 " (corrupt block_size, or a record longer than 32 KiB)");
+    B.n_reads = totals[0]; B.n_ops = totals[1]; B.n_bases = totals[2];
+    B.n_skipped = 0;
+    for (int32_t v : skipped) B.n_skipped += v;
+    B.min_bq = h->cfg.min_base_call_quality;
+    const size_t nr = (size_t)B.n_reads, no = (size_t)B.n_ops, nb = (size_t)B.n_bases;
+    PISCES_HIP_CHECK(h, B.position.reserve(nr + 1)); PISCES_HIP_CHECK(h, B.flags.reserve(nr + 1));
+    PISCES_HIP_CHECK(h, B.cigar_offset.reserve(nr + 1)); PISCES_HIP_CHECK(h, B.seq_offset.reserve(nr + 1));
+    PISCES_HIP_CHECK(h, B.read_quality.reserve(nr + 1));
+    PISCES_HIP_CHECK(h, B.cigar_op.reserve(no + 1)); PISCES_HIP_CHECK(h, B.cigar_len.reserve(no + 1)); PISCES_HIP_CHECK(h, B.op_quality.reserve(no + 1));
+    PISCES_HIP_CHECK(h, B.bases.reserve(nb + 16)); PISCES_HIP_CHECK(h, B.quals.reserve(nb + 16));
+    if (nr > 0)
+        hipLaunchKernelGGL(bam_decode_kernel, dim3((unsigned)n_chunks), dim3(64), 0, h->stream, (const uint8_t*)B.d_stream.p, out_bytes,
+                           (const long long*)B.d_entry.p, F, (const int32_t*)B.d_n_reads.p, (const int32_t*)B.d_n_ops.p, (const int32_t*)B.d_n_bases.p,
+                           B.position.p, B.flags.p, B.cigar_offset.p, B.cigar_op.p, B.cigar_len.p, B.seq_offset.p, B.bases.p, B.quals.p,
+                           B.op_quality.p, B.read_quality.p);
+    // the closing offsets
+    const int32_t end_ops = (int32_t)no, end_bases = (int32_t)nb;
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(B.cigar_offset.p + nr, &end_ops, sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(B.seq_offset.p + nr, &end_bases, sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    B.valid = true;
+    if (counts) { counts[0] = B.n_reads; counts[1] = B.n_skipped; counts[2] = B.n_ops; counts[3] = B.n_bases; }
+    return PISCES_OK;
+    });
+}
+
+int32_t pisces_hip_bam_fetch(PiscesHip* h, int32_t* position, uint8_t* flags, int32_t* cigar_offset, uint8_t* cigar_op, uint32_t* cigar_len,
+                             int32_t* seq_offset, uint8_t* bases, uint8_t* quals)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (!h->bam.valid) return fail(h, PISCES_E_STATE, "bam_fetch: no decoded batch (pisces_hip_bam_decode first)");
+    auto& B = h->bam;
+    const size_t nr = (size_t)B.n_reads, no = (size_t)B.n_ops, nb = (size_t)B.n_bases;
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    auto down = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+        return (dst && bytes) ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream) : hipSuccess;
+    };
+    PISCES_HIP_CHECK(h, down(position, B.position.p, nr * 4));
+    PISCES_HIP_CHECK(h, down(flags, B.flags.p, nr));
+    PISCES_HIP_CHECK(h, down(cigar_offset, B.cigar_offset.p, (nr + 1) * 4));
+    PISCES_HIP_CHECK(h, down(cigar_op, B.cigar_op.p, no));
+    PISCES_HIP_CHECK(h, down(cigar_len, B.cigar_len.p, no * 4));
+    PISCES_HIP_CHECK(h, down(seq_offset, B.seq_offset.p, (nr + 1) * 4));
+    PISCES_HIP_CHECK(h, down(bases, B.bases.p, nb));
+    PISCES_HIP_CHECK(h, down(quals, B.quals.p, nb));
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    return PISCES_OK;
+    });
+}
+
+// IStateManager.AddAlleleCounts + FindCandidates for the decoded batch: the bases and qualities stay on the device; the host sees
+// only positions and CIGARs (about 20 bytes per read), from which it makes what pisces_hip_add_reads makes from its own pass
+// (log slots, candidate-record slots, the blocks every read touches).
+int32_t pisces_hip_add_decoded_reads(PiscesHip* h)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (!h->bam.valid) return fail(h, PISCES_E_STATE, "add_decoded_reads: no decoded batch (pisces_hip_bam_decode first)");
+    auto& B = h->bam;
+    if (B.min_bq != h->cfg.min_base_call_quality) return fail(h, PISCES_E_STATE, "add_decoded_reads: decoded with another minimum base quality");
+    { int32_t rcp = refuse_while_batch_is_open(h, "add_decoded_reads"); if (rcp) return rcp; }
+    const int32_t nr = (int32_t)B.n_reads;
+    if (nr == 0) return PISCES_OK;
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    { int32_t rcf = consume_found(h); if (rcf) return rcf; }
+    const size_t no = (size_t)B.n_ops;
+    std::vector<int32_t> position((size_t)nr), coff((size_t)nr + 1), soff((size_t)nr + 1);
+    std::vector<uint8_t> cop(no), opq(no), rq((size_t)nr);
+    std::vector<uint32_t> clen(no);
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(position.data(), B.position.p, (size_t)nr * 4, hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(coff.data(), B.cigar_offset.p, ((size_t)nr + 1) * 4, hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(soff.data(), B.seq_offset.p, ((size_t)nr + 1) * 4, hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(cop.data(), B.cigar_op.p, no, hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(clen.data(), B.cigar_len.p, no * 4, hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(opq.data(), B.op_quality.p, no, hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(rq.data(), B.read_quality.p, (size_t)nr, hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    auto op_ref = [](uint8_t t) { return t == 'M' || t == 'D' || t == 'N' || t == '=' || t == 'X'; };
+    auto op_read = [](uint8_t t) { return t == 'M' || t == 'I' || t == 'S' || t == '=' || t == 'X'; };
+    const bool find_on_device = !h->h_ref.empty();
+    std::vector<long long>& slots = h->read_slots;
+    std::vector<int32_t>& fslots = h->found_slots_host;
+    slots.resize((size_t)nr + 1);
+    fslots.assign((size_t)nr + 1, 0);
+    int64_t ub = 0, found_slots = 0, found_pool = 0;
+    for (int32_t i = 0; i < nr; i++) {
+        const int c0 = coff[(size_t)i], nc = coff[(size_t)i + 1] - c0, read_len = soff[(size_t)i + 1] - soff[(size_t)i];
+        const uint8_t* ops = cop.data() + c0;
+        const uint32_t* lens = clen.data() + c0;
+        const uint8_t* oq = opq.data() + c0;
+        slots[(size_t)i] = (long long)(h->log_ub + ub);
+        fslots[(size_t)i] = (int32_t)found_slots;
+        if (position[(size_t)i] <= 0) return fail(h, PISCES_E_INVALID_ARG, "Position must be greater than 0.");
+        int64_t read_span = 0, ref_span = 0;
+        for (int c = 0; c < nc; c++) {
+            if (lens[c] > 0x0FFFFFFFu) return fail(h, PISCES_E_INVALID_ARG, "add_decoded_reads: CIGAR operation longer than 2^28 - 1");
+            if (op_read(ops[c])) read_span += lens[c];
+            if (op_ref(ops[c])) ref_span += lens[c];
+            if (find_on_device && !h->cfg.call_mnvs) {
+                if (ops[c] == 'I' || ops[c] == 'D') found_slots++;
+                if (ops[c] == 'I' && lens[c] > (uint32_t)kFoundInline) found_pool += lens[c];
+            }
+        }
+        if (read_span > read_len) return fail(h, PISCES_E_INVALID_ARG, "add_decoded_reads: CIGAR does not match the read");
+        if ((int64_t)position[(size_t)i] + ref_span > 0x7FFFFFFFll) return fail(h, PISCES_E_INVALID_ARG, "add_decoded_reads: read runs past position 2^31 - 1");
+        ub += ref_span;
+        // the blocks the read touches (GetBlock for every position that receives a count, RegionStateManager.cs:361-383), as in
+        // pisces_hip_add_reads, with CheckDeletionQuality taken from the bits the decode kernel left
+        auto touch = [&](int64_t from, int64_t to) {
+            if (to < 1) return;
+            if (from < 1) from = 1;
+            for (int32_t k = block_key(h, (int32_t)from); k <= block_key(h, (int32_t)to); k++) (void)get_block(h, (k - 1) * h->cfg.block_size + 1);
+        };
+        int64_t rp = position[(size_t)i], last_mapped = (int64_t)position[(size_t)i] - 1;
+        int ri = 0;
+        for (int c = 0; c < nc; c++) {
+            const uint8_t t = ops[c];
+            const int64_t len = lens[c];
+            if (op_read(t) && op_ref(t) && len > 0) {
+                if (rp > last_mapped + 1 && ri < read_len && oq[c]) touch(last_mapped + 1, rp - 1);
+                touch(rp, rp + len - 1);
+                last_mapped = rp + len - 1;
+            }
+            if (op_ref(t)) rp += len;
+            if (op_read(t)) ri += (int)len;
+        }
+        const bool ends_del = nc >= 1 && ops[nc - 1] == 'D';
+        const bool ends_del_soft = nc >= 2 && ops[nc - 2] == 'D' && ops[nc - 1] == 'S';
+        if (ends_del && read_len > 0 && rq[(size_t)i]) touch(last_mapped + 1, last_mapped + lens[nc - 1]);
+        if (ends_del_soft) {
+            const int idx = read_len - (int)lens[nc - 1];
+            if (idx >= 0 && idx < read_len && oq[nc - 1]) touch(last_mapped + 1, last_mapped + lens[nc - 2]);
+        }
+        h->stats[2] += 1;
+    }
+    slots[(size_t)nr] = (long long)(h->log_ub + ub);
+    fslots[(size_t)nr] = (int32_t)found_slots;
+    if (found_slots > 0x7FFFFFF0ll || found_pool > 0x7FFFFFF0ll) return fail(h, PISCES_E_INVALID_ARG, "add_decoded_reads: too many insertions / deletions in one batch");
+    int32_t rc = log_reserve(h, ub);
+    if (rc) return rc;
+    PISCES_HIP_CHECK(h, B.d_slots.reserve((size_t)nr + 1));
+    PISCES_HIP_CHECK(h, B.d_fslots.reserve((size_t)nr + 1));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(B.d_slots.p, slots.data(), ((size_t)nr + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(B.d_fslots.p, fslots.data(), ((size_t)nr + 1) * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    DevReadBatch db;
+    db.position = B.position.p; db.flags = B.flags.p; db.cigar_offset = B.cigar_offset.p; db.cigar_op = B.cigar_op.p; db.cigar_len = B.cigar_len.p;
+    db.seq_offset = B.seq_offset.p; db.bases = B.bases.p; db.quals = B.quals.p; db.dirs = nullptr; db.n_reads = nr;
+    const int c = h->log_cur;
+    hipLaunchKernelGGL(expand_reads_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, h->stream, db, (const long long*)B.d_slots.p,
+                       h->cfg.min_base_call_quality, h->d_log_pos[c].p, h->d_log_tup[c].p, h->d_log_n.p + 2);
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    if (find_on_device && (h->cfg.call_mnvs || found_slots > 0)) {
+        int32_t rcd = enqueue_candidate_discovery(h, db, nullptr, nr, (const int32_t*)B.d_fslots.p, found_slots, found_pool);
+        if (rcd) return rcd;
+    }
+    // slots / fslots on the host are reused by the next call: the copies above must have left first
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    h->log_ub += ub;
+    return PISCES_OK;
+    });
+}
+

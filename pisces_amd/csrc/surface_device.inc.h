@@ -1,0 +1,224 @@
+// surface_device.inc.h — part of pisces_hip.hip (included there, inside its extern "C" block; not a translation unit of its own).
+// The device-resident surface: pisces_hip_call_tiles[_batched], compaction, accumulation into a caller's tensor, totals, timing, the
+// streaming-read probe.
+
+// ------------------------------------------------------------------------------------------------
+// device-resident surface
+// ------------------------------------------------------------------------------------------------
+int32_t pisces_hip_call_tiles(PiscesHip* h, const uint32_t* d_tuples, const PiscesTile* d_tiles, int32_t n_tiles,
+                              const uint8_t* d_ref_bases, int32_t ref_start_position, int64_t ref_length,
+                              PiscesCalledAllele* d_records, int32_t record_capacity, PiscesTileResult* d_tile_results, void* stream)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (n_tiles < 0 || record_capacity < 0 || ref_length < 0) return fail(h, PISCES_E_INVALID_ARG, "call_tiles: negative size");
+    if (n_tiles > 0 && (!d_tiles || !d_ref_bases || !d_records || !d_tile_results))
+        return fail(h, PISCES_E_INVALID_ARG, "call_tiles: null device pointer");
+    if ((int64_t)record_capacity < (int64_t)n_tiles * kSlotsPerTile)
+        return fail(h, PISCES_E_BUFFER_TOO_SMALL, "call_tiles: the slot layout needs record_capacity >= 256 * n_tiles");
+    if (h->cfg.ploidy != PISCES_PLOIDY_SOMATIC)
+        return fail(h, PISCES_E_STATE, "call_tiles: diploid / haploid genotyping is a per-locus pass of pisces_hip_flush (streaming surface)");
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    // events only when asked for (pisces_hip_set_timing): an event record is a queue packet of its own, and two of them
+    // per launch cost a few microseconds between back-to-back launches
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->timing > 0 && (h->launches_seen++ % h->timing) == 0) {
+        const size_t slot = (size_t)(h->ring_used % kTimingRing);
+        e0 = h->ring[2 * slot];
+        e1 = h->ring[2 * slot + 1];
+        h->ring_used++;
+    }
+    if (n_tiles > 0) {
+        PISCES_HIP_CHECK(h, launch_call_tiles(h, s, d_tuples, d_tiles, n_tiles, d_ref_bases, ref_start_position, ref_length, d_records, d_tile_results, e0, e1));
+    } else if (e0) {
+        PISCES_HIP_CHECK(h, hipEventRecord(e0, s));
+        PISCES_HIP_CHECK(h, hipEventRecord(e1, s));
+    }
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    return PISCES_OK;
+    });
+}
+
+// Tile size for a launch of n_loci contiguous loci that keeps every CU equally loaded.  The hot kernel is HBM-bound and a CU streams
+// at most ~1/256 of the chip's bandwidth, so a launch ends with the CU that holds the most tiles: 1563 tiles of 64 loci leave 27 CUs
+// with 7 tiles and the rest with 6 (the launch takes 7/6.1 of the balanced time), 1786 tiles of 56 loci give every CU 7.  When the
+// whole launch is resident at once (up to 8 two-wave tiles per CU) the tile count is made a multiple of the CU count; larger launches
+// run in many rounds and balance themselves: 64.
+int32_t pisces_hip_balanced_tile_loci(PiscesHip* h, int64_t n_loci)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h || n_loci <= 0) return kTile;
+    const int64_t cus = std::max(1, h->n_cus);
+    const int64_t per_cu = (n_loci + (int64_t)kTile * cus - 1) / ((int64_t)kTile * cus);   // tiles per CU at 64 loci
+    if (per_cu > 8) return kTile;
+    const int64_t n_tiles = per_cu * cus;
+    return (int32_t)std::min<int64_t>(kTile, (n_loci + n_tiles - 1) / n_tiles);
+    });
+}
+
+int32_t pisces_hip_call_tiles_batched(PiscesHip* h, const PiscesTileBatch* batches, int32_t n_batches, void* stream)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (n_batches < 0 || (n_batches > 0 && !batches)) return fail(h, PISCES_E_INVALID_ARG, "call_tiles_batched: null batch list");
+    if (h->cfg.ploidy != PISCES_PLOIDY_SOMATIC)
+        return fail(h, PISCES_E_STATE, "call_tiles: diploid / haploid genotyping is a per-locus pass of pisces_hip_flush (streaming surface)");
+    if (h->cfg.noise_model == PISCES_NOISE_WINDOW)
+        return fail(h, PISCES_E_STATE, "call_tiles_batched: NoiseModel.Window calls through the handle's one counts tensor; use pisces_hip_call_tiles");
+    for (int32_t i = 0; i < n_batches; i++) {
+        const PiscesTileBatch& b = batches[i];
+        if (b.n_tiles < 0 || b.record_capacity < 0 || b.ref_length < 0) return fail(h, PISCES_E_INVALID_ARG, "call_tiles: negative size");
+        if (b.n_tiles > 0 && (!b.d_tiles || !b.d_ref_bases || !b.d_records || !b.d_tile_results))
+            return fail(h, PISCES_E_INVALID_ARG, "call_tiles: null device pointer");
+        if ((int64_t)b.record_capacity < (int64_t)b.n_tiles * kSlotsPerTile)
+            return fail(h, PISCES_E_BUFFER_TOO_SMALL, "call_tiles: the slot layout needs record_capacity >= 256 * n_tiles");
+    }
+    if (n_batches == 0) return PISCES_OK;
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    if (!h->lane[0])
+        for (int k = 0; k < PiscesHip::kLanes; k++) PISCES_HIP_CHECK(h, hipStreamCreateWithFlags(&h->lane[k], hipStreamNonBlocking));
+    // Ordering is on the host, not through HIP events: a lane that has waited on an event of another stream runs every later kernel
+    // ~5 us slower on this runtime (measured: 43 us per config-2 step with an event fork / join, 38 us without), which is most of
+    // what the lanes are for.  So: inputs must be complete on `stream` - the call waits for it here - and the outputs are complete
+    // after pisces_hip_synchronize.
+    const int lanes = std::min<int>(PiscesHip::kLanes, n_batches);
+    if (stream) PISCES_HIP_CHECK(h, hipStreamSynchronize((hipStream_t)stream));
+    for (int32_t i = 0; i < n_batches; i++) {
+        const PiscesTileBatch& b = batches[i];
+        if (b.n_tiles == 0) continue;
+        PISCES_HIP_CHECK(h, launch_call_tiles(h, h->lane[i % lanes], b.d_tuples, b.d_tiles, b.n_tiles, b.d_ref_bases, b.ref_start_position,
+                                              b.ref_length, b.d_records, b.d_tile_results));
+    }
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    return PISCES_OK;
+    });
+}
+
+int32_t pisces_hip_compact_records(PiscesHip* h, const PiscesCalledAllele* d_records, const PiscesTileResult* d_tile_results,
+                                   int32_t n_tiles, int32_t* d_offsets, PiscesCalledAllele* d_out, int32_t out_capacity,
+                                   int32_t* d_count, void* stream)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (n_tiles < 0 || out_capacity < 0) return fail(h, PISCES_E_INVALID_ARG, "compact_records: negative size");
+    if (!d_count || (n_tiles > 0 && (!d_records || !d_tile_results || !d_offsets || !d_out)))
+        return fail(h, PISCES_E_INVALID_ARG, "compact_records: null device pointer");
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    if (n_tiles == 0) {
+        PISCES_HIP_CHECK(h, hipMemsetAsync(d_count, 0, sizeof(int32_t), s));
+        return PISCES_OK;
+    }
+    launch_compaction(s, d_records, d_tile_results, n_tiles, d_offsets, d_out, out_capacity, d_count);
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    return PISCES_OK;
+    });
+}
+
+int32_t pisces_hip_accumulate_tiles(PiscesHip* h, const uint32_t* d_tuples, const PiscesTile* d_tiles, int32_t n_tiles,
+                                    int32_t* d_counts, void* stream)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (n_tiles < 0) return fail(h, PISCES_E_INVALID_ARG, "accumulate_tiles: negative size");
+    if (n_tiles > 0 && (!d_tiles || !d_counts)) return fail(h, PISCES_E_INVALID_ARG, "accumulate_tiles: null device pointer");
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->timing > 0 && (h->launches_seen++ % h->timing) == 0) {
+        const size_t slot = (size_t)(h->ring_used % kTimingRing);
+        e0 = h->ring[2 * slot];
+        e1 = h->ring[2 * slot + 1];
+        h->ring_used++;
+    }
+    if (n_tiles > 0) {
+        hipExtLaunchKernelGGL(accumulate_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0u, s, e0, e1, 0u, d_tuples, d_tiles, n_tiles,
+                              d_counts, h->cfg.min_base_call_quality, (unsigned long long*)nullptr, (const ulonglong2*)nullptr);
+    } else if (e0) {
+        PISCES_HIP_CHECK(h, hipEventRecord(e0, s));
+        PISCES_HIP_CHECK(h, hipEventRecord(e1, s));
+    }
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    return PISCES_OK;
+    });
+}
+
+int32_t pisces_hip_device_totals(PiscesHip* h, int64_t out[4], int32_t reset)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h || !out) return PISCES_E_INVALID_ARG;
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    PISCES_HIP_CHECK(h, hipDeviceSynchronize());   // launches may sit on caller-supplied streams
+    unsigned long long host[kTotalShards * kTotalStride];
+    PISCES_HIP_CHECK(h, hipMemcpy(host, h->d_totals.p, sizeof(host), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; i++) {
+        out[i] = 0;
+        for (int sh = 0; sh < kTotalShards; sh++) out[i] += (int64_t)host[sh * kTotalStride + i];
+    }
+    if (reset) PISCES_HIP_CHECK(h, hipMemset(h->d_totals.p, 0, sizeof(host)));
+    return PISCES_OK;
+    });
+}
+
+int32_t pisces_hip_set_timing(PiscesHip* h, int32_t enable)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    if (enable && h->ring.empty()) {
+        h->ring.resize((size_t)(2 * kTimingRing), nullptr);
+        for (auto& ev : h->ring) PISCES_HIP_CHECK(h, hipEventCreate(&ev));
+    }
+    h->timing = enable > 0 ? enable : 0;
+    h->ring_used = 0;
+    h->launches_seen = 0;
+    return PISCES_OK;
+    });
+}
+
+int32_t pisces_hip_kernel_time(PiscesHip* h, double* total_ms, int64_t* launches)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h || !total_ms || !launches) return PISCES_E_INVALID_ARG;
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    const int64_t n = std::min<int64_t>(h->ring_used, kTimingRing);
+    double sum = 0.0;
+    for (int64_t i = 0; i < n; i++) {
+        float ms = 0.f;
+        PISCES_HIP_CHECK(h, hipEventSynchronize(h->ring[(size_t)(2 * i + 1)]));
+        PISCES_HIP_CHECK(h, hipEventElapsedTime(&ms, h->ring[(size_t)(2 * i)], h->ring[(size_t)(2 * i + 1)]));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = n;
+    return PISCES_OK;
+    });
+}
+
+int32_t pisces_hip_probe_read_bandwidth(PiscesHip* h, int64_t nbytes, int32_t reps, double* gb_per_s)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h || !gb_per_s || nbytes < (1 << 20) || reps < 1) return fail(h, PISCES_E_INVALID_ARG, "probe_read_bandwidth: bad arguments");
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    DeviceBuf<uint32_t> buf;
+    PISCES_HIP_CHECK(h, buf.reserve((size_t)(nbytes / 4) + 4));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(buf.p, 0x5A, (size_t)nbytes, h->stream));
+    const int64_t n4 = nbytes / 16;
+    const unsigned grid = (unsigned)std::min<int64_t>((n4 + 2047) / 2048, (int64_t)h->n_cus * 32);
+    hipLaunchKernelGGL(read_probe_kernel, dim3(grid), dim3(256), 0, h->stream, (const u32x4*)buf.p, n4, buf.p + nbytes / 4);   // warm-up
+    double best = 0.0;
+    for (int r = 0; r < reps; r++) {
+        hipExtLaunchKernelGGL(read_probe_kernel, dim3(grid), dim3(256), 0u, h->stream, h->ev0, h->ev1, 0u, (const u32x4*)buf.p, n4,
+                              buf.p + nbytes / 4);
+        PISCES_HIP_CHECK(h, hipEventSynchronize(h->ev1));
+        float ms = 0.f;
+        PISCES_HIP_CHECK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        if (ms > 0.f) best = std::max(best, (double)nbytes / ((double)ms * 1e-3) / 1e9);
+    }
+    buf.release();
+    *gb_per_s = best;
+    return PISCES_OK;
+    });
+}
+

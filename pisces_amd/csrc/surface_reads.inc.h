@@ -1,0 +1,743 @@
+// surface_reads.inc.h — part of pisces_hip.hip (included there, inside its extern "C" block; not a translation unit of its own).
+// IStateManager.AddAlleleCounts / AddCandidates behind the C ABI: staging, pisces_hip_add_observations, candidates and forced alleles the
+// caller brings, candidate discovery on the device, pisces_hip_add_reads, and the host-only walks (pisces_hip_expand_reads, pisces_hip_find_*).
+
+// ------------------------------------------------------------------------------------------------
+// streaming surface
+// ------------------------------------------------------------------------------------------------
+static inline int32_t block_key(const PiscesHip* h, int32_t position)
+{
+    // GetBlockKey: (int)Math.Ceiling((double)position / _regionSize)
+    return (position + h->cfg.block_size - 1) / h->cfg.block_size;
+}
+
+static inline BlockObs* get_block(PiscesHip* h, int32_t position)
+{
+    int32_t key = block_key(h, position);
+    if (h->last_block && h->last_block_key_cache == key) return h->last_block;
+    BlockObs* b = &h->blocks[key];
+    h->last_block = b;
+    h->last_block_key_cache = key;
+    return b;
+}
+
+// room for `extra` more log entries (the log keeps its content when it grows)
+static int32_t log_reserve(PiscesHip* h, int64_t extra)
+{
+    const size_t need = (size_t)(h->log_ub + extra);
+    const int c = h->log_cur;
+    PISCES_HIP_CHECK(h, h->d_log_pos[c].grow_keep(need, (size_t)h->log_ub, h->stream));
+    PISCES_HIP_CHECK(h, h->d_log_tup[c].grow_keep(need, (size_t)h->log_ub, h->stream));
+    return PISCES_OK;
+}
+
+// enqueues dst[0, bytes) = src[0, bytes) (device <- host) on h->stream through the pinned arena
+static int32_t meta_upload(PiscesHip* h, void* dst, const void* src, size_t bytes)
+{
+    if (bytes == 0) return PISCES_OK;
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (h->h_meta_used + need > h->h_meta_cap) {
+        // copies out of the arena may be in flight: drain, rewind, and grow if this one upload is larger than the arena (rare)
+        PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+        h->h_meta_used = 0;
+        if (need > h->h_meta_cap) {
+            const size_t want = std::max<size_t>(need * 2, (size_t)1 << 20);
+            if (h->h_meta) (void)hipHostFree(h->h_meta);
+            h->h_meta = nullptr;
+            h->h_meta_cap = 0;
+            PISCES_HIP_CHECK(h, hipHostMalloc((void**)&h->h_meta, want, hipHostMallocDefault));
+            h->h_meta_cap = want;
+        }
+    }
+    uint8_t* at = h->h_meta + h->h_meta_used;
+    h->h_meta_used += need;
+    std::memcpy(at, src, bytes);
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(dst, at, bytes, hipMemcpyHostToDevice, h->stream));
+    return PISCES_OK;
+}
+
+// next staging pair with room for `bytes`; waits only for the work that used THIS pair two calls ago
+static int32_t stage_reserve(PiscesHip* h, size_t bytes)
+{
+    h->stage_cur ^= 1;
+    PiscesHip::Stage& st = h->stage[h->stage_cur];
+    if (!st.done) PISCES_HIP_CHECK(h, hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+    if (st.in_flight) {
+        PISCES_HIP_CHECK(h, hipEventSynchronize(st.done));
+        st.in_flight = false;
+    }
+    if (bytes > st.h_cap) {
+        if (st.h) (void)hipHostFree(st.h);
+        st.h = nullptr;
+        st.h_cap = 0;
+        const size_t want = bytes + bytes / 2 + 4096;
+        PISCES_HIP_CHECK(h, hipHostMalloc((void**)&st.h, want, hipHostMallocDefault));
+        st.h_cap = want;
+    }
+    PISCES_HIP_CHECK(h, st.d.reserve(bytes));
+    h->h_stage = st.h;
+    return PISCES_OK;
+}
+// call after the last device operation that reads the current staging pair has been enqueued
+static int32_t stage_release(PiscesHip* h)
+{
+    PiscesHip::Stage& st = h->stage[h->stage_cur];
+    PISCES_HIP_CHECK(h, hipEventRecord(st.done, h->stream));
+    st.in_flight = true;
+    return PISCES_OK;
+}
+#define D_STAGE(h) ((h)->stage[(h)->stage_cur].d.p)
+
+namespace pisces {
+// host-expanded observations: copied behind the current end of the log (its size is host-known: slots are reserved on the host)
+__global__ __launch_bounds__(256) void log_append_kernel(const int32_t* __restrict__ src_pos, const uint32_t* __restrict__ src_tup, int64_t n,
+                                                         int32_t* __restrict__ log_pos, uint32_t* __restrict__ log_tup, long long base,
+                                                         unsigned long long* __restrict__ appended)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        log_pos[base + i] = src_pos[i];
+        log_tup[base + i] = src_tup[i] & ~0xFCu;   // the column is set from the position when the log is bucketed
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(appended, (unsigned long long)n);
+}
+}  // namespace pisces
+
+int32_t pisces_hip_add_observations(PiscesHip* h, const int32_t* positions, const uint32_t* tuples, int64_t n)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (n < 0 || (n > 0 && (!positions || !tuples))) return fail(h, PISCES_E_INVALID_ARG, "add_observations: null buffer");
+    for (int64_t i = 0; i < n; i++)
+        if (positions[i] <= 0) return fail(h, PISCES_E_INVALID_ARG, "Position must be greater than 0.");  // RegionStateManager.cs:363-364
+    { int32_t rcp = refuse_while_batch_is_open(h, "add_observations"); if (rcp) return rcp; }
+    if (n == 0) return PISCES_OK;
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    for (int64_t i = 0; i < n; i++) (void)get_block(h, positions[i]);
+    int32_t rc = log_reserve(h, n);
+    if (rc) return rc;
+    const size_t bytes = (size_t)n * 8;
+    rc = stage_reserve(h, bytes);
+    if (rc) return rc;
+    std::memcpy(h->h_stage, positions, (size_t)n * 4);
+    std::memcpy(h->h_stage + (size_t)n * 4, tuples, (size_t)n * 4);
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(D_STAGE(h), h->h_stage, bytes, hipMemcpyHostToDevice, h->stream));
+    const int c = h->log_cur;
+    hipLaunchKernelGGL(log_append_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, h->stream,
+                       (const int32_t*)D_STAGE(h), (const uint32_t*)(D_STAGE(h) + (size_t)n * 4), n, h->d_log_pos[c].p, h->d_log_tup[c].p,
+                       (long long)h->log_ub, h->d_log_n.p + 2);
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    { int32_t rcs = stage_release(h); if (rcs) return rcs; }
+    h->log_ub += n;
+    return PISCES_OK;
+    });
+}
+
+namespace {
+struct ArraySink : ObservationSink {
+    int32_t* positions;
+    uint32_t* tuples;
+    int64_t capacity, n = 0;
+    void emit(int32_t position, uint32_t tuple) override
+    {
+        if (n < capacity) { positions[n] = position; tuples[n] = tuple; }
+        n++;
+    }
+};
+}  // namespace
+
+static int32_t validate_batch(const PiscesReadBatch* b)
+{
+    if (!b || b->n_reads < 0) return PISCES_E_INVALID_ARG;
+    if (b->n_reads == 0) return PISCES_OK;
+    if (!b->position || !b->flags || !b->cigar_offset || !b->cigar_op || !b->cigar_len || !b->seq_offset || !b->bases || !b->quals)
+        return PISCES_E_INVALID_ARG;
+    // BAM stores an operation length in 28 bits; anything larger would overflow the int arithmetic of the read walks
+    const int64_t n_ops = (int64_t)b->cigar_offset[b->n_reads] - (int64_t)b->cigar_offset[0];
+    if (n_ops < 0) return PISCES_E_INVALID_ARG;
+    for (int64_t c = b->cigar_offset[0]; c < (int64_t)b->cigar_offset[b->n_reads]; c++)
+        if (b->cigar_len[c] > 0x0FFFFFFFu) return PISCES_E_INVALID_ARG;
+    return PISCES_OK;
+}
+
+// IStateManager.AddCandidates -> RegionState.AddCandidate (RegionState.cs:94-174): merge by CandidateAllele.Equals, and with the
+// collapser on (trackOpenEnded) keep open-ended candidates apart (:114-137); UpdateMaxPosition (:205-223)
+static void add_candidate(PiscesHip* h, const HostCandidate& cnd)
+{
+    BlockObs* b = get_block(h, cnd.position);
+    std::string key = std::to_string(cnd.position) + "|" + std::to_string(cnd.category) + "|" + cnd.ref + ">" + cnd.alt;
+    if (h->cfg.collapse) key += cnd.open_left ? (cnd.open_right ? "|LR" : "|L") : (cnd.open_right ? "|R" : "|");
+    auto it = b->cand_index.find(key);
+    if (it == b->cand_index.end()) {
+        b->cand_index.emplace(std::move(key), b->cands.size());
+        b->cands.push_back(cnd);
+    } else {
+        HostCandidate& e = b->cands[it->second];
+        for (int d = 0; d < 3; d++) {
+            e.support_by_dir[d] += cnd.support_by_dir[d];
+            e.well_anchored_by_dir[d] += cnd.well_anchored_by_dir[d];
+        }
+    }
+    int32_t other_end = 0;
+    if (cnd.category == PISCES_CAT_DELETION) other_end = cnd.position + (int32_t)cnd.ref.size();
+    else if (cnd.category == PISCES_CAT_INSERTION) other_end = cnd.position + 1;
+    else if (cnd.category == PISCES_CAT_MNV) other_end = cnd.position + (int32_t)cnd.ref.size() - 1;
+    if (other_end > b->max_allele_endpoint) b->max_allele_endpoint = other_end;
+}
+
+static std::string forced_key(int32_t position, const std::string& ref, const std::string& alt)
+{
+    return std::to_string(position) + "|" + ref + ">" + alt;
+}
+static bool is_forced_allele(const PiscesHip* h, const HostCandidate& c)   // AlleleCaller.IsForcedAllele (AlleleCaller.cs:179-184)
+{
+    return !h->forced_keys.empty() && h->forced_keys.count(forced_key(c.position, c.ref, c.alt)) != 0;
+}
+
+static int32_t host_candidates_of(PiscesHip* h, const PiscesCandidate* cands, int64_t n, const uint8_t* alleles, int64_t allele_bytes,
+                                  std::vector<HostCandidate>& out, const char* what)
+{
+    if (n < 0 || (n > 0 && (!cands || !alleles))) return fail(h, PISCES_E_INVALID_ARG, std::string(what) + ": null input");
+    for (int64_t i = 0; i < n; i++) {
+        const PiscesCandidate& c = cands[i];
+        if (c.position <= 0 || c.ref_len <= 0 || c.alt_len <= 0 || c.allele_offset < 0 || c.allele_offset + c.ref_len + c.alt_len > allele_bytes ||
+            c.category < PISCES_CAT_SNV || c.category > PISCES_CAT_MNV)
+            return fail(h, PISCES_E_INVALID_ARG, std::string(what) + ": bad candidate");
+        HostCandidate hc;
+        hc.position = c.position;
+        hc.category = c.category;
+        hc.ref.assign((const char*)alleles + c.allele_offset, (size_t)c.ref_len);
+        hc.alt.assign((const char*)alleles + c.allele_offset + c.ref_len, (size_t)c.alt_len);
+        for (int d = 0; d < 3; d++) { hc.support_by_dir[d] = c.support_by_dir[d]; hc.well_anchored_by_dir[d] = c.well_anchored_by_dir[d]; }
+        hc.open_left = c.open_left != 0;
+        hc.open_right = c.open_right != 0;
+        out.push_back(std::move(hc));
+    }
+    return PISCES_OK;
+}
+
+// IStateManager.AddCandidates (IStateManager.cs; RegionStateManager.cs:83-116) for candidates the caller brings itself
+int32_t pisces_hip_add_candidates(PiscesHip* h, const PiscesCandidate* cands, int64_t n, const uint8_t* alleles, int64_t allele_bytes)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    { int32_t rcp = refuse_while_batch_is_open(h, "add_candidates"); if (rcp) return rcp; }
+    { int32_t rcf = consume_found(h); if (rcf) return rcf; }   // keep the arrival order: what the reads gave so far comes first
+    std::vector<HostCandidate> list;
+    int32_t rc = host_candidates_of(h, cands, n, alleles, allele_bytes, list, "add_candidates");
+    if (rc) return rc;
+    for (auto& c : list) add_candidate(h, c);
+    return PISCES_OK;
+    });
+}
+
+// -forcedalleles (Factory.GetForcedAlleles :56-96, SelectForcedAllele :270-286; SmallVariantCaller.CreateForcedAllelePos :49-77): the
+// alleles to report whatever the reads say.  Categories are SmallVariantCaller.GetAlleleCategory's (:141-150), support is ignored.
+int32_t pisces_hip_set_forced_alleles(PiscesHip* h, const PiscesCandidate* cands, int64_t n, const uint8_t* alleles, int64_t allele_bytes)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (h->n_forced_added > 0) return fail(h, PISCES_E_INVALID_ARG, "set_forced_alleles: some forced alleles are candidates already");
+    std::vector<HostCandidate> list;
+    int32_t rc = host_candidates_of(h, cands, n, alleles, allele_bytes, list, "set_forced_alleles");
+    if (rc) return rc;
+    h->forced.clear();
+    h->forced_keys.clear();
+    h->forced_positions.clear();
+    for (auto& c : list) {
+        // IsValidAlt :88-96
+        if (c.ref == c.alt) continue;
+        bool acgt = true;
+        for (char ch : c.alt) acgt = acgt && (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T');
+        if (!acgt) continue;
+        if (!h->intervals.empty()) {   // SelectForcedAllele: inside the intervals only
+            bool inside = false;
+            for (auto& iv : h->intervals) inside = inside || (c.position >= iv.first && c.position <= iv.second);
+            if (!inside) continue;
+        }
+        c.category = (c.ref.size() == 1 && c.alt.size() == 1) ? PISCES_CAT_SNV : c.ref.size() == c.alt.size() ? PISCES_CAT_MNV
+                     : c.ref.size() > c.alt.size() ? PISCES_CAT_DELETION : PISCES_CAT_INSERTION;
+        for (int d = 0; d < 3; d++) c.support_by_dir[d] = c.well_anchored_by_dir[d] = 0;
+        c.open_left = c.open_right = false;
+        if (!h->forced_keys.insert(forced_key(c.position, c.ref, c.alt)).second) continue;   // a HashSet
+        h->forced_positions.insert(c.position);
+        h->forced.push_back(c);
+    }
+    std::stable_sort(h->forced.begin(), h->forced.end(), [](const HostCandidate& a, const HostCandidate& b) { return a.position < b.position; });
+    return PISCES_OK;
+    });
+}
+
+// SmallVariantCaller.AddForcedAlleleAsCandidate :118-132, before GetCandidatesToProcess(upTo)
+static void add_forced_as_candidates(PiscesHip* h, int32_t up_to_position)
+{
+    while (h->n_forced_added < h->forced.size()) {
+        const HostCandidate& c = h->forced[h->n_forced_added];
+        if (up_to_position >= 0 && c.position > up_to_position) break;
+        add_candidate(h, c);
+        h->n_forced_added++;
+    }
+}
+
+// Candidate discovery for a read batch that is on the device (find_count / found_scan / find_emit kernels), enqueued on the handle's
+// stream; its records come back into pinned memory and are merged by consume_found when they are needed.  d_slots: the record slots
+// the host reserved per read from the CIGARs (MNV calling off), found_slots / found_pool their totals.
+static int32_t enqueue_candidate_discovery(PiscesHip* h, const DevReadBatch& db, const uint8_t* d_deldirs, int32_t nr, const int32_t* d_slots_in,
+                                           int64_t found_slots, int64_t found_pool)
+{
+    const int32_t minBQ = h->cfg.min_base_call_quality;
+    const int32_t* d_slots = d_slots_in;
+        const FinderParams FP = {minBQ, PISCES_ANCHOR_SIZE, h->cfg.call_mnvs ? 1 : 0, h->cfg.call_mnvs ? 1 : 0, h->cfg.max_mnv_length,
+                                 h->cfg.max_gap_between_mnv};
+        const unsigned grid = (unsigned)((nr + 255) / 256);
+        PISCES_HIP_CHECK(h, h->d_found_misc.reserve(4));
+        PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_found_misc.p, 0, 4 * sizeof(unsigned int), h->stream));
+        const int32_t* d_pool_first = nullptr;
+        if (h->cfg.call_mnvs) {
+            // count, scan (one more element than reads: the last one receives the total), then size the record buffer
+            PISCES_HIP_CHECK(h, h->d_found_slots.reserve((size_t)nr + 1));
+            PISCES_HIP_CHECK(h, h->d_found_pool_first.reserve((size_t)nr + 1));
+            PISCES_HIP_CHECK(h, h->d_found_totals.reserve(2));
+            PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_found_slots.p + nr, 0, sizeof(int32_t), h->stream));
+            PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_found_pool_first.p + nr, 0, sizeof(int32_t), h->stream));
+            hipLaunchKernelGGL(find_count_kernel, dim3(grid), dim3(256), 0, h->stream, db, d_deldirs, (const uint8_t*)h->d_ref.p, h->ref_len, FP,
+                               h->d_found_slots.p, h->d_found_pool_first.p);
+            hipLaunchKernelGGL(found_scan_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_found_slots.p, h->d_found_pool_first.p, nr + 1,
+                               h->d_found_totals.p);
+            long long totals[2] = {0, 0};
+            PISCES_HIP_CHECK(h, hipMemcpyAsync(totals, h->d_found_totals.p, sizeof(totals), hipMemcpyDeviceToHost, h->stream));
+            PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+            if (totals[0] > 0x7FFFFFF0ll || totals[1] > 0x7FFFFFF0ll) return fail(h, PISCES_E_INVALID_ARG, "add_reads: too many candidates in one batch");
+            found_slots = totals[0];
+            found_pool = totals[1];
+            d_slots = h->d_found_slots.p;
+            d_pool_first = h->d_found_pool_first.p;
+        }
+        if (found_slots > 0) {
+            PISCES_HIP_CHECK(h, h->d_found.reserve((size_t)found_slots));
+            PISCES_HIP_CHECK(h, h->d_found_pool.reserve((size_t)found_pool + 16));
+            hipLaunchKernelGGL(find_emit_kernel, dim3(grid), dim3(256), 0, h->stream, db, d_deldirs, (const uint8_t*)h->d_ref.p, h->ref_len, FP, d_slots,
+                               d_pool_first, h->d_found.p, h->d_found_pool.p, h->d_found_misc.p, (int32_t)found_pool, (int32_t*)(h->d_found_misc.p + 1));
+            PISCES_HIP_CHECK(h, hipGetLastError());
+            // records + pool + {cursor, overflow} come back into pinned memory; consume_found waits for them when they are needed
+            const size_t rec_bytes = (size_t)found_slots * sizeof(DevFound), pool_al = ((size_t)found_pool + 15) & ~(size_t)15;
+            const size_t need = rec_bytes + pool_al + 16;
+            if (need > h->found.h_cap) {
+                if (h->found.h) (void)hipHostFree(h->found.h);
+                h->found.h = nullptr;
+                h->found.h_cap = 0;
+                PISCES_HIP_CHECK(h, hipHostMalloc((void**)&h->found.h, need + need / 2, hipHostMallocDefault));
+                h->found.h_cap = need + need / 2;
+            }
+            if (!h->found.done) PISCES_HIP_CHECK(h, hipEventCreateWithFlags(&h->found.done, hipEventDisableTiming));
+            PISCES_HIP_CHECK(h, hipMemcpyAsync(h->found.h, h->d_found.p, rec_bytes, hipMemcpyDeviceToHost, h->stream));
+            if (found_pool > 0)
+                PISCES_HIP_CHECK(h, hipMemcpyAsync(h->found.h + rec_bytes, h->d_found_pool.p, (size_t)found_pool, hipMemcpyDeviceToHost, h->stream));
+            PISCES_HIP_CHECK(h, hipMemcpyAsync(h->found.h + rec_bytes + pool_al, h->d_found_misc.p, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+            PISCES_HIP_CHECK(h, hipEventRecord(h->found.done, h->stream));
+            h->found.n_slots = found_slots;
+            h->found.pool_bytes = found_pool;
+            h->found.in_flight = true;
+        }
+    return PISCES_OK;
+}
+
+// The candidates the device found for the last add_reads (find_emit_kernel), merged into their blocks in read order:
+// IStateManager.AddCandidates (SmallVariantCaller.cs:92-96).  Called before anything that looks at the candidates.
+static int32_t consume_found(PiscesHip* h)
+{
+    if (!h->found.in_flight) return PISCES_OK;
+    h->found.in_flight = false;
+    PISCES_HIP_CHECK(h, hipEventSynchronize(h->found.done));
+    const DevFound* recs = (const DevFound*)h->found.h;
+    const uint8_t* pool = h->found.h + (size_t)h->found.n_slots * sizeof(DevFound);
+    const unsigned int* misc = (const unsigned int*)(pool + (((size_t)h->found.pool_bytes + 15) & ~(size_t)15));
+    if (misc[1] != 0) return fail(h, PISCES_E_DEVICE, "add_reads: the candidate records of the device did not fit their reservation");
+    for (int64_t i = 0; i < h->found.n_slots; i++) {
+        const DevFound& f = recs[i];
+        if (f.c.category == kFoundHole) continue;
+        const uint8_t* bases = f.pool_offset >= 0 ? pool + f.pool_offset : f.alt;
+        add_candidate(h, host_candidate_of(f.c, h->h_ref.data(), bases));
+    }
+    return PISCES_OK;
+}
+
+int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (validate_batch(batch) != PISCES_OK) return fail(h, PISCES_E_INVALID_ARG, "add_reads: malformed read batch");
+    { int32_t rcp = refuse_while_batch_is_open(h, "add_reads"); if (rcp) return rcp; }
+    if (batch->n_reads == 0) return PISCES_OK;
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    { int32_t rcf = consume_found(h); if (rcf) return rcf; }
+    const int32_t nr = batch->n_reads;
+    const int32_t minBQ = h->cfg.min_base_call_quality;
+    // ---- host pass over the CIGARs only (never over the bases): argument checks of the reference's walk, the insertion /
+    // deletion candidates, the blocks the read touches, and an upper bound of its observations ----
+    auto op_ref = [](uint8_t t) { return t == 'M' || t == 'D' || t == 'N' || t == '=' || t == 'X'; };
+    auto op_read = [](uint8_t t) { return t == 'M' || t == 'I' || t == 'S' || t == '=' || t == 'X'; };
+    int64_t ub = 0;
+    std::vector<long long>& slots = h->read_slots;   // log slots reserved per read: [slots[i], slots[i + 1])
+    slots.resize((size_t)nr + 1);
+    for (int32_t i = 0; i < nr; i++) {
+        ReadView r = read_view(batch, i);
+        slots[(size_t)i] = (long long)(h->log_ub + ub);
+        if (r.position <= 0) return fail(h, PISCES_E_INVALID_ARG, "Position must be greater than 0.");
+        if (r.read_len < 0 || r.n_cigar < 0) return fail(h, PISCES_E_INVALID_ARG, "add_reads: malformed read batch");
+        int64_t read_span = 0, ref_span = 0;
+        for (int c = 0; c < r.n_cigar; c++) {
+            const uint8_t t = r.cigar_op[c];
+            if (op_read(t)) read_span += r.cigar_len[c];
+            if (op_ref(t)) ref_span += r.cigar_len[c];   // mapped bases + every gap: one observation each at most
+        }
+        if (read_span > r.read_len) return fail(h, PISCES_E_INVALID_ARG, "add_reads: CIGAR does not match the read");
+        if ((int64_t)r.position + ref_span > 0x7FFFFFFFll) return fail(h, PISCES_E_INVALID_ARG, "add_reads: read runs past position 2^31 - 1");
+        if (r.dirs)
+            for (int k = 0; k < r.read_len; k++)
+                if (r.dirs[k] > 2) return fail(h, PISCES_E_INVALID_ARG, "add_reads: CIGAR does not match the read");
+        if (r.del_dirs)
+            for (int c = 0; c < r.n_cigar; c++)
+                if (r.cigar_op[c] == 'D')
+                    for (int k = 0; k < 2; k++)
+                        if (r.del_dirs[2 * c + k] > 2 && r.del_dirs[2 * c + k] != PISCES_DIR_UNTRACKED)
+                            return fail(h, PISCES_E_INVALID_ARG, "add_reads: deletion_directions holds a value that is no DirectionType");
+        ub += ref_span;
+    }
+    slots[(size_t)nr] = (long long)(h->log_ub + ub);
+    // ---- the read batch crosses PCIe once, packed; the walk runs on the device (expand_reads_kernel).  The transfer is started
+    // BEFORE the second host pass over the CIGARs (block bookkeeping, candidate slots): that pass runs under it, and only its small
+    // table of candidate slots follows in a transfer of its own ----
+    const size_t n_cig = (size_t)batch->cigar_offset[nr], n_seq = (size_t)batch->seq_offset[nr];
+    auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    size_t off_pos = 0, off_flags = align16(off_pos + (size_t)nr * 4), off_coff = align16(off_flags + (size_t)nr),
+           off_cop = align16(off_coff + ((size_t)nr + 1) * 4), off_clen = align16(off_cop + n_cig),
+           off_soff = align16(off_clen + n_cig * 4), off_bases = align16(off_soff + ((size_t)nr + 1) * 4),
+           off_quals = align16(off_bases + n_seq), off_dirs = align16(off_quals + n_seq),
+           off_slots = align16(off_dirs + (batch->directions ? n_seq : 0)), off_deldirs = align16(off_slots + ((size_t)nr + 1) * 8),
+           off_fslots = align16(off_deldirs + (batch->deletion_directions ? 2 * n_cig : 0)), total = align16(off_fslots + ((size_t)nr + 1) * 4);
+    int32_t rc = stage_reserve(h, total);
+    if (rc) return rc;
+    rc = log_reserve(h, ub);
+    if (rc) return rc;
+    uint8_t* st = h->h_stage;
+    std::memcpy(st + off_pos, batch->position, (size_t)nr * 4);
+    std::memcpy(st + off_flags, batch->flags, (size_t)nr);
+    std::memcpy(st + off_coff, batch->cigar_offset, ((size_t)nr + 1) * 4);
+    std::memcpy(st + off_cop, batch->cigar_op, n_cig);
+    std::memcpy(st + off_clen, batch->cigar_len, n_cig * 4);
+    std::memcpy(st + off_soff, batch->seq_offset, ((size_t)nr + 1) * 4);
+    std::memcpy(st + off_slots, slots.data(), ((size_t)nr + 1) * 8);
+    if (batch->deletion_directions) std::memcpy(st + off_deldirs, batch->deletion_directions, 2 * n_cig);
+    {
+        // bases / qualities / directions are the bulk (2-3 bytes per aligned base).  Small batches: one copy into the pinned buffer,
+        // one transfer.  Large ones: slices of 8 MB, each copied by a few threads and handed to the DMA engine as soon as it is
+        // complete, so that the host copy of slice k+1 runs under the PCIe transfer of slice k.
+        struct Seg { size_t dst; const uint8_t* src; size_t len; };
+        const Seg segs[3] = {{off_bases, batch->bases, n_seq}, {off_quals, batch->quals, n_seq},
+                             {off_dirs, batch->directions, batch->directions ? n_seq : 0}};
+        const size_t bulk = 2 * n_seq + (batch->directions ? n_seq : 0);
+        constexpr size_t kSlice = (size_t)8 << 20;
+        if (bulk < 2 * kSlice) {
+            for (const Seg& g : segs) if (g.len) std::memcpy(st + g.dst, g.src, g.len);
+            PISCES_HIP_CHECK(h, hipMemcpyAsync(D_STAGE(h), st, off_fslots, hipMemcpyHostToDevice, h->stream));
+        } else {
+            // everything outside the bulk first (the descriptors before it, the slot table after it)
+            PISCES_HIP_CHECK(h, hipMemcpyAsync(D_STAGE(h), st, off_bases, hipMemcpyHostToDevice, h->stream));
+            PISCES_HIP_CHECK(h, hipMemcpyAsync(D_STAGE(h) + off_slots, st + off_slots, off_fslots - off_slots, hipMemcpyHostToDevice, h->stream));
+            struct Slice { size_t dst; const uint8_t* src; size_t len; };
+            std::vector<Slice> slices;
+            for (const Seg& g : segs)
+                for (size_t o = 0; o < g.len; o += kSlice) slices.push_back({g.dst + o, g.src + o, std::min(kSlice, g.len - o)});
+            const int n_threads = (int)std::min<size_t>(4, std::max<unsigned>(1u, std::thread::hardware_concurrency()));
+            std::vector<std::atomic<int>> parts_done(slices.size());
+            for (auto& a : parts_done) a.store(0, std::memory_order_relaxed);
+            auto worker = [&](int w) {
+                for (size_t k = 0; k < slices.size(); k++) {
+                    const size_t per = (slices[k].len + (size_t)n_threads - 1) / (size_t)n_threads, lo = std::min(slices[k].len, per * (size_t)w),
+                                 hi = std::min(slices[k].len, lo + per);
+                    if (hi > lo) std::memcpy(st + slices[k].dst + lo, slices[k].src + lo, hi - lo);
+                    parts_done[k].fetch_add(1, std::memory_order_release);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int w = 1; w < n_threads; w++) pool.emplace_back(worker, w);
+            hipError_t first_error = hipSuccess;
+            {
+                // this thread copies its share of a slice, then waits for the others' and enqueues the transfer
+                for (size_t k = 0; k < slices.size(); k++) {
+                    const size_t per = (slices[k].len + (size_t)n_threads - 1) / (size_t)n_threads, hi = std::min(slices[k].len, per);
+                    if (hi) std::memcpy(st + slices[k].dst, slices[k].src, hi);
+                    parts_done[k].fetch_add(1, std::memory_order_release);
+                    while (parts_done[k].load(std::memory_order_acquire) < n_threads) std::this_thread::yield();
+                    if (first_error == hipSuccess)
+                        first_error = hipMemcpyAsync(D_STAGE(h) + slices[k].dst, st + slices[k].dst, slices[k].len, hipMemcpyHostToDevice, h->stream);
+                }
+            }
+            for (auto& t : pool) t.join();
+            PISCES_HIP_CHECK(h, first_error);
+        }
+    }
+    // ICandidateVariantFinder.FindCandidates + IStateManager.AddCandidates (SmallVariantCaller.cs:92-96) run on the device
+    // (find_emit_kernel, enqueued behind the read walk below).  With MNV calling off only insertions and deletions are discovered
+    // (SNV candidates are implied by the allele counts): the host reserves one record slot per I / D operation here, from the CIGAR
+    // alone; with it on the device counts its candidates itself.
+    const bool find_on_device = !h->h_ref.empty();   // without a reference only the IStateManager half (allele counts) runs
+    std::vector<int32_t>& fslots = h->found_slots_host;
+    fslots.assign((size_t)nr + 1, 0);
+    int64_t found_slots = 0, found_pool = 0;
+    for (int32_t i = 0; i < nr; i++) {
+        ReadView r = read_view(batch, i);
+        fslots[(size_t)i] = (int32_t)found_slots;
+        if (find_on_device && !h->cfg.call_mnvs)
+            for (int c = 0; c < r.n_cigar; c++) {
+                if (r.cigar_op[c] == 'I' || r.cigar_op[c] == 'D') found_slots++;
+                if (r.cigar_op[c] == 'I' && r.cigar_len[c] > (uint32_t)kFoundInline) found_pool += r.cigar_len[c];
+            }
+        if (found_slots > 0x7FFFFFF0ll || found_pool > 0x7FFFFFF0ll) {
+            (void)stage_release(h);   // (the batch's transfer is in flight out of the staging pair)
+            return fail(h, PISCES_E_INVALID_ARG, "add_reads: too many insertions / deletions in one batch");
+        }
+        // GetBlock(position) for every position that receives a count (RegionStateManager.cs:361-383): the runs of mapped
+        // bases always do; a gap (deletion / skip) does when its flanking qualities pass CheckDeletionQuality
+        {
+            auto touch = [&](int64_t from, int64_t to) {   // inclusive
+                if (to < 1) return;
+                if (from < 1) from = 1;
+                for (int32_t k = block_key(h, (int32_t)from); k <= block_key(h, (int32_t)to); k++) (void)get_block(h, (k - 1) * h->cfg.block_size + 1);
+            };
+            auto delq = [&](int idx) {
+                if (r.read_len == 0) return false;
+                const int after = idx < r.read_len ? r.quals[idx] : r.quals[idx - 1];
+                const int before = idx > 0 ? r.quals[idx - 1] : after;
+                return before >= minBQ && after >= minBQ;
+            };
+            int64_t rp = r.position, last_mapped = (int64_t)r.position - 1;
+            int ri = 0;
+            for (int c = 0; c < r.n_cigar; c++) {
+                const uint8_t t = r.cigar_op[c];
+                const int64_t len = r.cigar_len[c];
+                if (op_read(t) && op_ref(t) && len > 0) {
+                    if (rp > last_mapped + 1 && ri < r.read_len && delq(ri)) touch(last_mapped + 1, rp - 1);
+                    touch(rp, rp + len - 1);
+                    last_mapped = rp + len - 1;
+                }
+                if (op_ref(t)) rp += len;
+                if (op_read(t)) ri += (int)len;
+            }
+            const int nc = r.n_cigar;
+            const bool ends_del = nc >= 1 && r.cigar_op[nc - 1] == 'D';
+            const bool ends_del_soft = nc >= 2 && r.cigar_op[nc - 2] == 'D' && r.cigar_op[nc - 1] == 'S';
+            if (ends_del && r.read_len > 0 && delq(r.read_len - 1)) touch(last_mapped + 1, last_mapped + r.cigar_len[nc - 1]);
+            if (ends_del_soft) {
+                const int idx = r.read_len - (int)r.cigar_len[nc - 1];
+                if (idx >= 0 && idx < r.read_len && delq(idx)) touch(last_mapped + 1, last_mapped + r.cigar_len[nc - 2]);
+            }
+        }
+        h->stats[2] += 1;
+    }
+    fslots[(size_t)nr] = (int32_t)found_slots;
+
+    std::memcpy(st + off_fslots, fslots.data(), ((size_t)nr + 1) * 4);
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(D_STAGE(h) + off_fslots, st + off_fslots, total - off_fslots, hipMemcpyHostToDevice, h->stream));
+    DevReadBatch db;
+    const uint8_t* d = D_STAGE(h);
+    db.position = (const int32_t*)(d + off_pos);
+    db.flags = d + off_flags;
+    db.cigar_offset = (const int32_t*)(d + off_coff);
+    db.cigar_op = d + off_cop;
+    db.cigar_len = (const uint32_t*)(d + off_clen);
+    db.seq_offset = (const int32_t*)(d + off_soff);
+    db.bases = d + off_bases;
+    db.quals = d + off_quals;
+    db.dirs = batch->directions ? d + off_dirs : nullptr;
+    db.n_reads = nr;
+    const int c = h->log_cur;
+    hipLaunchKernelGGL(expand_reads_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, h->stream, db, (const long long*)(d + off_slots),
+                       minBQ, h->d_log_pos[c].p, h->d_log_tup[c].p, h->d_log_n.p + 2);
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    if (find_on_device && (h->cfg.call_mnvs || found_slots > 0)) {
+        int32_t rcd = enqueue_candidate_discovery(h, db, batch->deletion_directions ? d + off_deldirs : nullptr, nr, (const int32_t*)(d + off_fslots),
+                                                  found_slots, found_pool);
+        if (rcd) return rcd;
+    }
+    { int32_t rcs = stage_release(h); if (rcs) return rcs; }
+    h->log_ub += ub;
+    return PISCES_OK;
+    });
+}
+
+int64_t pisces_hip_expand_reads(const PiscesReadBatch* batch, int32_t min_bq, int32_t* positions, uint32_t* tuples, int64_t capacity)
+{
+    return abi_guard<int64_t>((PiscesHip*)nullptr, [&]() -> int64_t {
+    if (validate_batch(batch) != PISCES_OK || capacity < 0 || (capacity > 0 && (!positions || !tuples))) return PISCES_E_INVALID_ARG;
+    ArraySink sink;
+    sink.positions = positions;
+    sink.tuples = tuples;
+    sink.capacity = capacity;
+    for (int32_t i = 0; i < batch->n_reads; i++) {
+        int32_t rc = expand_read(read_view(batch, i), min_bq, sink);
+        if (rc != PISCES_OK) return rc;
+    }
+    return sink.n <= capacity ? sink.n : (int64_t)PISCES_E_BUFFER_TOO_SMALL;
+    });
+}
+
+int64_t pisces_hip_find_candidates(const PiscesReadBatch* batch, const uint8_t* ref, int64_t ref_len, int32_t min_bq, int32_t snvs_and_mnvs,
+                                   int32_t call_mnvs, int32_t max_mnv_length, int32_t max_gap_between_mnv, PiscesCandidate* out,
+                                   int64_t capacity, uint8_t* alleles, int64_t allele_capacity, int64_t* allele_bytes)
+{
+    return abi_guard<int64_t>((PiscesHip*)nullptr, [&]() -> int64_t {
+    if (validate_batch(batch) != PISCES_OK || !ref || ref_len <= 0 || capacity < 0 || (capacity > 0 && !out)) return PISCES_E_INVALID_ARG;
+    std::vector<HostCandidate> found;
+    try {
+        for (int32_t i = 0; i < batch->n_reads; i++)
+            find_candidates(read_view(batch, i), ref, ref_len, min_bq, PISCES_ANCHOR_SIZE, snvs_and_mnvs != 0, call_mnvs != 0, max_mnv_length,
+                            max_gap_between_mnv, found);
+    } catch (...) {   // nothing crosses the C ABI as an exception
+        return PISCES_E_INVALID_ARG;
+    }
+    int64_t bytes = 0;
+    for (size_t i = 0; i < found.size(); i++) {
+        const HostCandidate& c = found[i];
+        const int64_t need = (int64_t)(c.ref.size() + c.alt.size());
+        if ((int64_t)i < capacity && (!alleles || bytes + need <= allele_capacity)) {
+            PiscesCandidate& o = out[i];
+            std::memset(&o, 0, sizeof(o));
+            o.position = c.position; o.category = c.category;
+            o.ref_len = (int32_t)c.ref.size(); o.alt_len = (int32_t)c.alt.size();
+            for (int d = 0; d < 3; d++) { o.support_by_dir[d] = c.support_by_dir[d]; o.well_anchored_by_dir[d] = c.well_anchored_by_dir[d]; }
+            o.open_left = c.open_left; o.open_right = c.open_right;
+            o.allele_offset = bytes;
+            if (alleles) {
+                std::memcpy(alleles + bytes, c.ref.data(), c.ref.size());
+                std::memcpy(alleles + bytes + c.ref.size(), c.alt.data(), c.alt.size());
+            }
+        }
+        bytes += need;
+    }
+    if (allele_bytes) *allele_bytes = bytes;
+    if ((int64_t)found.size() > capacity || (alleles && bytes > allele_capacity)) return PISCES_E_BUFFER_TOO_SMALL;
+    return (int64_t)found.size();
+    });
+}
+
+static int64_t export_candidates(const std::vector<HostCandidate>& found, PiscesCandidate* out, int64_t capacity, uint8_t* alleles,
+                                 int64_t allele_capacity, int64_t* allele_bytes)
+{
+    int64_t bytes = 0;
+    for (size_t i = 0; i < found.size(); i++) {
+        const HostCandidate& c = found[i];
+        const int64_t need = (int64_t)(c.ref.size() + c.alt.size());
+        if ((int64_t)i < capacity && (!alleles || bytes + need <= allele_capacity)) {
+            PiscesCandidate& o = out[i];
+            std::memset(&o, 0, sizeof(o));
+            o.position = c.position; o.category = c.category;
+            o.ref_len = (int32_t)c.ref.size(); o.alt_len = (int32_t)c.alt.size();
+            for (int d = 0; d < 3; d++) { o.support_by_dir[d] = c.support_by_dir[d]; o.well_anchored_by_dir[d] = c.well_anchored_by_dir[d]; }
+            o.open_left = c.open_left; o.open_right = c.open_right;
+            o.allele_offset = bytes;
+            if (alleles) {
+                std::memcpy(alleles + bytes, c.ref.data(), c.ref.size());
+                std::memcpy(alleles + bytes + c.ref.size(), c.alt.data(), c.alt.size());
+            }
+        }
+        bytes += need;
+    }
+    if (allele_bytes) *allele_bytes = bytes;
+    if ((int64_t)found.size() > capacity || (alleles && bytes > allele_capacity)) return PISCES_E_BUFFER_TOO_SMALL;
+    return (int64_t)found.size();
+}
+
+int64_t pisces_hip_find_candidates_device(PiscesHip* h, const PiscesReadBatch* batch, int32_t snvs_and_mnvs, int32_t call_mnvs,
+                                          int32_t max_mnv_length, int32_t max_gap_between_mnv, PiscesCandidate* out, int64_t capacity,
+                                          uint8_t* alleles, int64_t allele_capacity, int64_t* allele_bytes)
+{
+    return abi_guard<int64_t>(h, [&]() -> int64_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (validate_batch(batch) != PISCES_OK || capacity < 0 || (capacity > 0 && !out)) return fail(h, PISCES_E_INVALID_ARG, "find_candidates_device: malformed arguments");
+    if (h->h_ref.empty()) return fail(h, PISCES_E_STATE, "find_candidates_device: set_reference has not been called");
+    if (allele_bytes) *allele_bytes = 0;
+    if (batch->n_reads == 0) return 0;
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    const int32_t nr = batch->n_reads;
+    for (int32_t i = 0; i < nr; i++) {
+        const ReadView r = read_view(batch, i);
+        int64_t read_span = 0;
+        for (int c = 0; c < r.n_cigar; c++)
+            if (r.cigar_op[c] == 'M' || r.cigar_op[c] == 'I' || r.cigar_op[c] == 'S' || r.cigar_op[c] == '=' || r.cigar_op[c] == 'X') read_span += r.cigar_len[c];
+        if (r.position <= 0 || r.read_len < 0 || read_span > r.read_len) return fail(h, PISCES_E_INVALID_ARG, "find_candidates_device: CIGAR does not match the read");
+    }
+    // the batch on the device (local buffers: this entry is a test / tooling surface, not the streaming path)
+    const size_t n_cig = (size_t)batch->cigar_offset[nr], n_seq = (size_t)batch->seq_offset[nr];
+    DeviceBuf<int32_t> d_pos, d_coff, d_soff, d_cnt, d_pool_first;
+    DeviceBuf<uint8_t> d_flags, d_cop, d_bases, d_quals, d_dirs, d_deldirs, d_pool;
+    DeviceBuf<uint32_t> d_clen;
+    DeviceBuf<long long> d_totals;
+    DeviceBuf<unsigned int> d_misc;
+    DeviceBuf<DevFound> d_out;
+    auto up = [&](auto& buf, const void* src, size_t n_elems, size_t elem) -> hipError_t {
+        hipError_t e = buf.reserve(std::max<size_t>(n_elems, 1));
+        if (e != hipSuccess || n_elems == 0) return e;
+        return hipMemcpyAsync(buf.p, src, n_elems * elem, hipMemcpyHostToDevice, h->stream);
+    };
+    PISCES_HIP_CHECK(h, up(d_pos, batch->position, (size_t)nr, 4));
+    PISCES_HIP_CHECK(h, up(d_flags, batch->flags, (size_t)nr, 1));
+    PISCES_HIP_CHECK(h, up(d_coff, batch->cigar_offset, (size_t)nr + 1, 4));
+    PISCES_HIP_CHECK(h, up(d_cop, batch->cigar_op, n_cig, 1));
+    PISCES_HIP_CHECK(h, up(d_clen, batch->cigar_len, n_cig, 4));
+    PISCES_HIP_CHECK(h, up(d_soff, batch->seq_offset, (size_t)nr + 1, 4));
+    PISCES_HIP_CHECK(h, up(d_bases, batch->bases, n_seq, 1));
+    PISCES_HIP_CHECK(h, up(d_quals, batch->quals, n_seq, 1));
+    if (batch->directions) PISCES_HIP_CHECK(h, up(d_dirs, batch->directions, n_seq, 1));
+    if (batch->deletion_directions) PISCES_HIP_CHECK(h, up(d_deldirs, batch->deletion_directions, 2 * n_cig, 1));
+    DevReadBatch db;
+    db.position = d_pos.p; db.flags = d_flags.p; db.cigar_offset = d_coff.p; db.cigar_op = d_cop.p; db.cigar_len = d_clen.p;
+    db.seq_offset = d_soff.p; db.bases = d_bases.p; db.quals = d_quals.p; db.dirs = batch->directions ? d_dirs.p : nullptr; db.n_reads = nr;
+    const uint8_t* dd = batch->deletion_directions ? d_deldirs.p : nullptr;
+    const FinderParams FP = {h->cfg.min_base_call_quality, PISCES_ANCHOR_SIZE, snvs_and_mnvs ? 1 : 0, call_mnvs ? 1 : 0, max_mnv_length, max_gap_between_mnv};
+    const unsigned grid = (unsigned)((nr + 255) / 256);
+    PISCES_HIP_CHECK(h, d_cnt.reserve((size_t)nr + 1));
+    PISCES_HIP_CHECK(h, d_pool_first.reserve((size_t)nr + 1));
+    PISCES_HIP_CHECK(h, d_totals.reserve(2));
+    PISCES_HIP_CHECK(h, d_misc.reserve(4));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(d_misc.p, 0, 4 * sizeof(unsigned int), h->stream));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(d_cnt.p + nr, 0, sizeof(int32_t), h->stream));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(d_pool_first.p + nr, 0, sizeof(int32_t), h->stream));
+    hipLaunchKernelGGL(find_count_kernel, dim3(grid), dim3(256), 0, h->stream, db, dd, (const uint8_t*)h->d_ref.p, h->ref_len, FP, d_cnt.p, d_pool_first.p);
+    hipLaunchKernelGGL(found_scan_kernel, dim3(1), dim3(1024), 0, h->stream, d_cnt.p, d_pool_first.p, nr + 1, d_totals.p);
+    long long totals[2] = {0, 0};
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(totals, d_totals.p, sizeof(totals), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    std::vector<HostCandidate> found;
+    if (totals[0] > 0) {
+        PISCES_HIP_CHECK(h, d_out.reserve((size_t)totals[0]));
+        PISCES_HIP_CHECK(h, d_pool.reserve((size_t)totals[1] + 16));
+        hipLaunchKernelGGL(find_emit_kernel, dim3(grid), dim3(256), 0, h->stream, db, dd, (const uint8_t*)h->d_ref.p, h->ref_len, FP, (const int32_t*)d_cnt.p,
+                           (const int32_t*)d_pool_first.p, d_out.p, d_pool.p, d_misc.p, (int32_t)totals[1], (int32_t*)(d_misc.p + 1));
+        PISCES_HIP_CHECK(h, hipGetLastError());
+        std::vector<DevFound> recs((size_t)totals[0]);
+        std::vector<uint8_t> pool((size_t)totals[1] + 1);
+        unsigned int misc[2] = {0, 0};
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(recs.data(), d_out.p, recs.size() * sizeof(DevFound), hipMemcpyDeviceToHost, h->stream));
+        if (totals[1] > 0) PISCES_HIP_CHECK(h, hipMemcpyAsync(pool.data(), d_pool.p, (size_t)totals[1], hipMemcpyDeviceToHost, h->stream));
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(misc, d_misc.p, sizeof(misc), hipMemcpyDeviceToHost, h->stream));
+        PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+        if (misc[1]) return fail(h, PISCES_E_DEVICE, "find_candidates_device: record reservation exceeded");
+        for (const DevFound& f : recs) {
+            if (f.c.category == kFoundHole) continue;
+            found.push_back(host_candidate_of(f.c, h->h_ref.data(), f.pool_offset >= 0 ? pool.data() + f.pool_offset : f.alt));
+        }
+    }
+    return export_candidates(found, out, capacity, alleles, allele_capacity, allele_bytes);
+    });
+}
+
+int64_t pisces_hip_find_indel_candidates(const PiscesReadBatch* batch, const uint8_t* ref, int64_t ref_len, int32_t min_bq,
+                                         PiscesCandidate* out, int64_t capacity, uint8_t* alleles, int64_t allele_capacity,
+                                         int64_t* allele_bytes)
+{
+    return abi_guard<int64_t>((PiscesHip*)nullptr, [&]() -> int64_t {
+    return pisces_hip_find_candidates(batch, ref, ref_len, min_bq, 0, 0, 0, 0, out, capacity, alleles, allele_capacity, allele_bytes);
+    });
+}
+
