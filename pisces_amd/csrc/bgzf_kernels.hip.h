@@ -118,14 +118,17 @@ struct HuffmanTable {
 };
 // What a table entry holds depends on what the code is for:
 //   kPlainCode (the code-length code): (symbol << 4) | code length
-//   kLengthCode (literals and lengths): bits 0-3 = bits to consume, bits 4-5 = n literals (1..3: the codes of up to three literals
-//       that fit into lut_bits together, bytes in bits 8-15 / 16-23 / 24-31), else bit 6 = end of block, bit 7 = a length code with
-//       its base in bits 8-16 and its number of extra bits in bits 17-19 (neither bit: an invalid symbol)
+//   kLengthCode (literals and lengths): bits 0-6 = how far the walk over a group's literals moves on: a literal's code length (bits
+//       8-15 = the byte), 64 for everything else (which ends the walk: a group has 64 offsets).  Everything else: bits 20-23 = code
+//       length (0: the code is longer than the index), bit 28 = end of block, bit 7 = a length code with its base in bits 8-16 and its
+//       number of extra bits in bits 17-19 (a code length and neither bit: an invalid symbol)
 //   kDistanceCode: bits 0-3 = bits to consume, bits 4-7 = extra bits, bits 8-22 = base, bit 31 = a valid distance symbol
-// A run of quality bytes (a handful of symbols, 2-3 bit codes) is then three bytes per look-up, and a length or distance needs no
-// table of bases: the look-up is the one dependent LDS read per step of the serial chain.
+// A length or distance needs no table of bases: the look-up is all there is to a symbol.
 enum { kPlainCode = 0, kLengthCode = 1, kDistanceCode = 2 };
-constexpr int kLenLutBits = 10, kDistLutBits = 9;
+#ifndef PISCES_INFLATE_LEN_BITS
+#define PISCES_INFLATE_LEN_BITS 10
+#endif
+constexpr int kLenLutBits = PISCES_INFLATE_LEN_BITS, kDistLutBits = 9;
 
 __device__ const int16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __device__ const int16_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -205,7 +208,7 @@ __device__ inline int inflate_construct(const InflateStream& s, HuffmanTable& h,
     const bool usable = left >= 0 && h.count[0] != n;
     const int size = 1 << h.lut_bits;
     for (int i = s.lane; i < size; i += 64) {
-        uint32_t e = 0;
+        uint32_t e = kind == kLengthCode ? 0x40u : 0u;
         int sym = 0;
         const int len = usable ? inflate_walk(h, (uint32_t)i, h.lut_bits, sym) : 0;
         if (len) {
@@ -215,22 +218,11 @@ __device__ inline int inflate_construct(const InflateStream& s, HuffmanTable& h,
                 e = (uint32_t)len;
                 if (sym < 30) e |= ((uint32_t)kDistExtra[sym] << 4) | ((uint32_t)kDistBase[sym] << 8) | 0x80000000u;
             } else if (sym < 256) {
-                // up to three literals whose codes fit into the index together
-                int used = len, n_lit = 1;
-                e = (uint32_t)sym << 8;
-                while (n_lit < 3 && used < h.lut_bits) {
-                    int next = 0;
-                    const int l = inflate_walk(h, (uint32_t)i >> used, h.lut_bits - used, next);
-                    if (l == 0 || next >= 256) break;
-                    e |= (uint32_t)next << (8 + 8 * n_lit);
-                    used += l;
-                    n_lit++;
-                }
-                e |= (uint32_t)used | ((uint32_t)n_lit << 4);
+                e = ((uint32_t)sym << 8) | (uint32_t)len;   // a literal
             } else if (sym == 256) {
-                e = (uint32_t)len | 0x40u;
+                e = ((uint32_t)len << 20) | 0x40u | (1u << 28);
             } else {
-                e = (uint32_t)len;
+                e = ((uint32_t)len << 20) | 0x40u;
                 if (sym <= 285) e |= 0x80u | ((uint32_t)kLenBase[sym - 257] << 8) | ((uint32_t)kLenExtra[sym - 257] << 17);
             }
         }
@@ -242,98 +234,261 @@ __device__ inline int inflate_construct(const InflateStream& s, HuffmanTable& h,
 }
 
 // literals and length / distance pairs until the end-of-block code (RFC 1951 3.2.3, 3.2.5).
-// The decode is a serial chain per block and the CU's scalar issue is what the waves share (the decoder state is scalar), so the loop
-// is written for few steps and few instructions per byte: one table look-up yields up to three literals, or a length with its base and
-// extra-bit count, or a distance likewise; a literal is parked in the lane whose index is its place in the current run and a run goes
-// out with ONE store instruction, lane k writing byte k, when a match, the end of the block or the 62nd literal arrives; the test that
-// the stream has not run past its payload is made where a block ends, not per symbol (the bit buffer cannot read outside the padded
-// device copy: inflate_refill), and a decode error surfaces at the next symbol that is not a literal or at the output bound.
+//
+// Where a symbol starts is only known from the symbol before it, but what a symbol WOULD be if it started at a given bit is not: the
+// payload is taken in groups of 64 bits, and lane j of the wave decodes the symbol that would start at bit offset j of the group --
+// both tables looked up at that offset (one LDS read each for all 64 offsets: the stream bits of a group are three words every lane
+// shifts by its own offset), a length code's extra bits, and the distance that follows it, fetched from the lane at the offset where
+// the distance code would start (ds_bpermute).  Every lane then knows where the chain would go on from it (`nxt`), and the serial
+// part that is left is a walk over that one register: v_readlane at the offset the chain stands on, mark the lane, until the chain
+// leaves the group (four instructions a symbol, literal or length / distance pair alike).  The marked lanes then write the group's
+// output: literals with one store instruction (a byte's place is the number of marked literal lanes below it plus the lengths of the
+// marked pairs below it), the pairs one after the other with all lanes copying.  The next two groups are looked up while this one is
+// walked, so no table look-up waits on the dependent chain.  What the lanes cannot decode by themselves -- the end-of-block code, a
+// code longer than a table's index, an invalid symbol -- stops the walk and is taken by the scalar path below, from the same registers.
+struct BitGroup {
+    uint32_t raw;   // the 32 stream bits from this lane's offset on
+    uint32_t le;    // lencode.lut at those bits
+    uint32_t de;    // distcode.lut at those bits
+    uint32_t pk;    // the distance that would start here: bits 0-15 = distance, bits 16-20 = bits it takes (code + extra), bit 31 = valid
+};
+
+__device__ __forceinline__ uint64_t bitset64(uint64_t mask, int bit)   // mask | 1 << bit, both wave-uniform: one scalar instruction
+{
+    asm("s_bitset1_b64 %0, %1" : "+s"(mask) : "s"(bit));
+    return mask;
+}
+
+__device__ __forceinline__ uint32_t group_lane(uint32_t cur, uint32_t next, int off)   // off < 128, wave-uniform
+{
+    return off < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)cur, off) : (uint32_t)__builtin_amdgcn_readlane((int)next, off - 64);
+}
+
+constexpr int kWalkStop = 255;   // `nxt` of an offset whose symbol the lanes cannot decode
+
 __device__ inline void inflate_codes(InflateStream& s, const HuffmanTable& lencode, const HuffmanTable& distcode)
 {
-    uint32_t run = 0;   // lane k: the k-th literal of the pending run
-    int n_run = 0;      // literals pending (wave-uniform); they belong at out[out_pos - n_run, out_pos)
-    auto flush = [&]() {
-        if (n_run) {
-#ifndef PISCES_INFLATE_ABLATE_LIT
-            if (s.lane < n_run) s.out[s.out_pos - n_run + s.lane] = (uint8_t)run;
-#endif
-            n_run = 0;
+    // bit positions are counted from the 16-byte boundary at or below the payload's first byte; a group is 64 of them (two words)
+    const int32_t skew16 = (int32_t)((uintptr_t)s.in & 15u);
+    const int32_t start = s.in_pos * 8 - s.bitcnt + 8 * skew16;
+    int32_t G = start >> 6;
+    int pos = start & 63;
+    int32_t wb = s.win_pos + skew16;   // the window's first byte (a multiple of 16), counted from the same boundary
+    const uint32_t lmask = (1u << lencode.lut_bits) - 1u, dmask = (1u << distcode.lut_bits) - 1u;
+    const bool upper = s.lane >= 32;
+    const uint32_t shift = (uint32_t)s.lane & 31u;
+
+    // words [d_lo, d_hi] (counted from the boundary) are in the window afterwards
+    auto ensure = [&](int32_t d_lo, int32_t d_hi) {
+        if (d_lo * 4 < wb || d_hi * 4 + 4 > wb + kInWindow) {
+            wb = (d_lo * 4) & ~15;
+            const uint4* src = reinterpret_cast<const uint4*>(s.in - skew16 + wb);
+            uint4* dst = reinterpret_cast<uint4*>(s.window);
+            wave_lds_fence();
+#pragma unroll
+            for (int k = 0; k < kInWindow / 16 / 64; k++) dst[k * 64 + s.lane] = src[k * 64 + s.lane];
+            wave_lds_fence();
         }
     };
-    const uint32_t lmask = (1u << lencode.lut_bits) - 1u, dmask = (1u << distcode.lut_bits) - 1u;
-    for (;;) {
-        // literal runs: the loop the decode spends most of its steps in, kept to one exit so that it stays a tight loop
-        uint32_t e;
-        int n_lit;
-        for (;;) {
-            inflate_refill(s);
-            e = (uint32_t)__builtin_amdgcn_readfirstlane((int)lencode.lut[(uint32_t)s.bitbuf & lmask]);
-            n_lit = (int)((e >> 4) & 3u);
-            if (n_lit == 0 || s.out_pos + n_lit > s.out_len) break;
-            const uint32_t k = (uint32_t)(s.lane - n_run);
-            run = k < (uint32_t)n_lit ? (e >> (8u + 8u * k)) & 255u : run;
-            n_run += n_lit;
-            s.out_pos += n_lit;
-            inflate_consume(s, (int)(e & 15u));
-            if (n_run > 61) flush();
+    auto word = [&](int32_t d) { return s.window[d - (wb >> 2)]; };   // every lane the same word
+    auto uniform = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    auto make = [&](uint32_t w0, uint32_t w1, uint32_t w2) {
+        BitGroup g;
+        g.raw = __builtin_amdgcn_alignbit(upper ? w2 : w1, upper ? w1 : w0, shift);
+        g.le = lencode.lut[g.raw & lmask];
+        g.de = distcode.lut[g.raw & dmask];
+        g.pk = 0;
+        return g;
+    };
+    // (when the group's distance entries have arrived)
+    auto pack_distance = [&](BitGroup& g) {
+        const uint32_t dl = g.de & 15u, deb = (g.de >> 4) & 15u;
+        g.pk = (g.de & 0x80000000u) | ((dl + deb) << 16) | (((g.de >> 8) & 0x7FFFu) + ((g.raw >> dl) & ((1u << deb) - 1u)));
+    };
+
+    // the group the chain stands in (X), the two behind it (Y, Z), and the words of the one after those, asked for a group ahead
+    // (uniform, but left in vector registers until they are used)
+    ensure(2 * G, 2 * G + 8);
+    BitGroup X, Y, Z;
+    uint32_t last_w;
+    {
+        const uint32_t w0 = uniform(word(2 * G)), w1 = uniform(word(2 * G + 1)), w2 = uniform(word(2 * G + 2)), w3 = uniform(word(2 * G + 3)),
+                       w4 = uniform(word(2 * G + 4)), w5 = uniform(word(2 * G + 5)), w6 = uniform(word(2 * G + 6));
+        X = make(w0, w1, w2);
+        Y = make(w2, w3, w4);
+        Z = make(w4, w5, w6);
+        last_w = w6;
+    }
+    uint32_t pre1 = word(2 * G + 7), pre2 = word(2 * G + 8);
+    pack_distance(X);
+    pack_distance(Y);
+
+    // what every lane of X would decode at its offset
+    uint32_t nxt, mlen, mdist;
+    uint64_t lit_lanes, pair_lanes;
+    auto prepare = [&]() {
+        const uint32_t e = X.le;
+        const bool lit = !(e & 0x40u);
+        const uint32_t cl = (e >> 20) & 15u, eb = (e >> 17) & 7u;
+        mlen = ((e >> 8) & 0x1FFu) + ((X.raw >> cl) & ((1u << eb) - 1u));
+        const uint32_t t = (uint32_t)s.lane + cl + eb;   // where the distance code would start: in X or in Y
+        const uint32_t from_x = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((t & 63u) << 2), (int)X.pk),
+                       from_y = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((t & 63u) << 2), (int)Y.pk);
+        const uint32_t g = t < 64u ? from_x : from_y;
+        const bool pair = (e & 0x80u) && (g >> 31);
+        mdist = g & 0xFFFFu;
+        nxt = lit ? (uint32_t)s.lane + (e & 127u) : pair ? t + ((g >> 16) & 31u) : (uint32_t)kWalkStop;
+        lit_lanes = __builtin_amdgcn_ballot_w64(lit);
+        pair_lanes = __builtin_amdgcn_ballot_w64(pair);
+    };
+    prepare();
+
+    // the output of the lanes the chain went through
+    auto emit = [&](uint64_t chain) {
+        const uint64_t lits = chain & lit_lanes, pairs = chain & pair_lanes;
+        if (!(lits | pairs)) return;
+        uint32_t before = 0;   // lane k: the bytes the pairs below offset k write
+        int total = __builtin_popcountll(lits);
+        for (uint64_t mm = pairs; mm; mm &= mm - 1) {
+            const int m = __builtin_ctzll(mm);
+            const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)mlen, m);
+            before += s.lane > m ? len : 0u;
+            total += (int)len;
         }
-        if (n_lit) { s.err = s.err ? s.err : kInflateOutputOverflow; break; }
-        int len;
-        if (e) {
-            inflate_consume(s, (int)(e & 15u));
-            flush();
+        if (s.out_pos + total > s.out_len) { s.err = s.err ? s.err : kInflateOutputOverflow; return; }
+#ifndef PISCES_INFLATE_ABLATE_LIT
+        if ((lits >> s.lane) & 1u)
+            s.out[s.out_pos + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(lits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lits, 0u)) + (int)before] = (uint8_t)(X.le >> 8);
+#endif
+        int run = 0;
+        for (uint64_t mm = pairs; mm; mm &= mm - 1) {
+            const int m = __builtin_ctzll(mm);
+            const int len = __builtin_amdgcn_readlane((int)mlen, m), dist = __builtin_amdgcn_readlane((int)mdist, m);
+            const int at = s.out_pos + __builtin_popcountll(lits & ((1ull << m) - 1ull)) + run;
+            if (dist > at) { s.err = s.err ? s.err : kInflateDistanceTooFar; return; }
+#ifndef PISCES_INFLATE_ABLATE_COPY
+            // every source byte lies before `at`, also when the pair overlaps itself (dist < len: a run of period dist).  The bytes may
+            // be this wave's own stores of a moment ago: a wave's memory instructions reach the cache in program order, no wait is needed.
+            const uint8_t* src = s.out + at - dist;
+            uint8_t* dst = s.out + at;
+            if (dist >= len) {
+                for (int k = s.lane; k < len; k += 64) dst[k] = src[k];
+            } else {
+                for (int k = s.lane; k < len; k += 64) dst[k] = src[k % dist];
+            }
+#endif
+            run += len;
+        }
+        s.out_pos += total;
+    };
+    // the stream continues at bit `pos` of group G: hand it back to the bit buffer (block headers are read through it)
+    auto leave = [&]() {
+        const int32_t at = G * 64 + pos - 8 * skew16;
+        s.win_pos = wb - skew16;
+        if (at > s.in_len * 8) { s.err = s.err ? s.err : kInflateInputExhausted; return; }
+        inflate_seek(s, at >> 3);
+        (void)inflate_bits(s, at & 7);
+    };
+
+    for (;;) {
+        // the walk (four steps per turn of the loop: a step that leaves the group branches forward, the loop branches back once in four)
+        uint64_t chain = 0;
+        int at = pos;   // the offset of the last symbol the walk read
+        if (pos < 64) {   // (a length / distance pair can end beyond the next group's first offsets)
+            for (;;) {
+#define PISCES_WALK_STEP                               \
+    at = pos;                                          \
+    chain = bitset64(chain, pos);                      \
+    pos = __builtin_amdgcn_readlane((int)nxt, pos);    \
+    if (pos >= 64) break;
+                PISCES_WALK_STEP
+                PISCES_WALK_STEP
+                PISCES_WALK_STEP
+                PISCES_WALK_STEP
+#undef PISCES_WALK_STEP
+            }
+        }
+        if (pos != kWalkStop) {
+            // the chain has left the group
+            emit(chain);
             if (s.err) return;
-            if (e & 0x40u) {   // end of block
-                if (inflate_overran(s)) s.err = kInflateInputExhausted;
+            X = Y;
+            Y = Z;
+            G++;
+            pos -= 64;
+            if (G * 8 - skew16 > s.in_len + 16) { s.err = kInflateInputExhausted; return; }   // (a valid stream ends inside its payload)
+            const uint32_t w1 = uniform(pre1), w2 = uniform(pre2);
+            Z = make(last_w, w1, w2);
+            last_w = w2;
+            pack_distance(Y);
+            prepare();
+            ensure(2 * G + 7, 2 * G + 8);
+            pre1 = word(2 * G + 7);
+            pre2 = word(2 * G + 8);
+            continue;
+        }
+        // a symbol the lanes could not decode, at offset `at`
+        pos = at;
+        emit(chain & ~(1ull << pos));
+        if (s.err) return;
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)X.le, pos);
+        const uint32_t raw = (uint32_t)__builtin_amdgcn_readlane((int)X.raw, pos);
+        int len, t;   // t: where the distance code starts
+        const int cl = (int)((e >> 20) & 15u);
+        if (cl) {
+            if (e >> 28) {   // end of block
+                pos += cl;
+                leave();
                 return;
             }
             if (!(e & 0x80u)) { s.err = kInflateBadSymbol; return; }
-            len = (int)((e >> 8) & 0x1FFu) + (int)inflate_bits(s, (int)((e >> 17) & 7u));
-        } else {
-            int symbol = inflate_decode_long(s, lencode);
-            if ((uint32_t)symbol < 256u) {
-                if (s.out_pos >= s.out_len) { s.err = s.err ? s.err : kInflateOutputOverflow; break; }
-                run = s.lane == n_run ? (uint32_t)symbol : run;
-                n_run++;
+            const int eb = (int)((e >> 17) & 7u);
+            len = (int)((e >> 8) & 0x1FFu) + (int)((raw >> cl) & ((1u << eb) - 1u));
+            t = pos + cl + eb;
+        } else {   // a code longer than the table's index: the canonical walk over the bits at this offset
+            int symbol = 0;
+            const int wl = __builtin_amdgcn_readfirstlane(inflate_walk(lencode, raw, 15, symbol));
+            symbol = __builtin_amdgcn_readfirstlane(symbol);
+            if (wl == 0) { s.err = kInflateBadSymbol; return; }
+            if (symbol < 256) {
+                if (s.out_pos >= s.out_len) { s.err = kInflateOutputOverflow; return; }
+#ifndef PISCES_INFLATE_ABLATE_LIT
+                if (s.lane == 0) s.out[s.out_pos] = (uint8_t)symbol;
+#endif
                 s.out_pos++;
-                if (n_run > 61) flush();
+                pos += wl;
                 continue;
             }
-            flush();
-            if (s.err) return;
             if (symbol == 256) {
-                if (inflate_overran(s)) s.err = kInflateInputExhausted;
+                pos += wl;
+                leave();
                 return;
             }
             symbol -= 257;
             if (symbol >= 29) { s.err = kInflateBadSymbol; return; }
-            len = kLenBase[symbol] + (int)inflate_bits(s, kLenExtra[symbol]);
+            const int eb = kLenExtra[symbol];
+            len = kLenBase[symbol] + (int)((raw >> wl) & ((1u << eb) - 1u));
+            t = pos + wl + eb;
         }
-        inflate_refill(s);
-        const uint32_t ed = (uint32_t)__builtin_amdgcn_readfirstlane((int)distcode.lut[(uint32_t)s.bitbuf & dmask]);
+        const uint32_t ed = group_lane(X.de, Y.de, t), rawd = group_lane(X.raw, Y.raw, t);
         int dist;
         if (ed) {
-            inflate_consume(s, (int)(ed & 15u));
             if (!(ed >> 31)) { s.err = kInflateBadSymbol; return; }
-            dist = (int)((ed >> 8) & 0x7FFFu) + (int)inflate_bits(s, (int)((ed >> 4) & 15u));
+            const int dl = (int)(ed & 15u), deb = (int)((ed >> 4) & 15u);
+            dist = (int)((ed >> 8) & 0x7FFFu) + (int)((rawd >> dl) & ((1u << deb) - 1u));
+            pos = t + dl + deb;
         } else {
-            const int symbol = inflate_decode_long(s, distcode);
-            if (s.err) return;
-            if (symbol >= 30) { s.err = kInflateBadSymbol; return; }
-            dist = kDistBase[symbol] + (int)inflate_bits(s, kDistExtra[symbol]);
+            int symbol = 0;
+            const int dl = __builtin_amdgcn_readfirstlane(inflate_walk(distcode, rawd, 15, symbol));
+            symbol = __builtin_amdgcn_readfirstlane(symbol);
+            if (dl == 0 || symbol >= 30) { s.err = kInflateBadSymbol; return; }
+            const int deb = kDistExtra[symbol];
+            dist = kDistBase[symbol] + (int)((rawd >> dl) & ((1u << deb) - 1u));
+            pos = t + dl + deb;
         }
-        if (s.err) return;
         if (dist > s.out_pos) { s.err = kInflateDistanceTooFar; return; }
         if (s.out_pos + len > s.out_len) { s.err = kInflateOutputOverflow; return; }
 #ifndef PISCES_INFLATE_ABLATE_COPY
-        // the source bytes may still be on their way to memory (this wave's own earlier stores): wait for the stores only when the source
-        // reaches into what was written since the last wait
-        if (s.out_pos - dist + (dist >= len ? len : dist) > s.safe_pos) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            s.safe_pos = s.out_pos;
-        }
-        // every source byte lies before out_pos, also when the pair overlaps itself (dist < len: a run of period dist)
         const uint8_t* src = s.out + s.out_pos - dist;
         uint8_t* dst = s.out + s.out_pos;
         if (dist >= len) {
@@ -344,7 +499,6 @@ __device__ inline void inflate_codes(InflateStream& s, const HuffmanTable& lenco
 #endif
         s.out_pos += len;
     }
-    flush();
 }
 
 // LDS workspace of a wave: the small tables in int16 units, and the two look-up tables
@@ -440,7 +594,7 @@ __device__ inline void inflate_stream(InflateStream& s, int16_t* tables, uint32_
     if (s.out_pos != s.out_len) s.err = kInflateLengthMismatch;
 }
 
-// in: the file bytes as they are (the device copy carries a window (kInWindow + 32 bytes) of slack behind the last one); blocks: payload offset / length and
+// in: the file bytes as they are (the device copy carries a window (kInWindow + 256 bytes) of slack behind the last one); blocks: payload offset / length and
 // output offset / length (ISIZE) per block.
 __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restrict__ in, const PiscesBgzfBlock* __restrict__ blocks, int64_t n_blocks,
                                                           uint8_t* out, int32_t* __restrict__ status)

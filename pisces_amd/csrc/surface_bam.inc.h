@@ -89,7 +89,7 @@ int32_t pisces_hip_bgzf_inflate(PiscesHip* h, const uint8_t* file, int64_t n_byt
     DeviceBuf<uint8_t> d_in, d_out;
     DeviceBuf<PiscesBgzfBlock> d_blocks;
     DeviceBuf<int32_t> d_status;
-    PISCES_HIP_CHECK(h, d_in.reserve((size_t)n_bytes + kInWindow + 32));   // the bit reader's LDS window is filled in whole: up to a window past a block's payload
+    PISCES_HIP_CHECK(h, d_in.reserve((size_t)n_bytes + kInWindow + 256));   // the bit reader's LDS window is filled in whole: up to a window past a block's payload
     PISCES_HIP_CHECK(h, hipMemsetAsync(d_in.p + n_bytes, 0, 16, h->stream));
     PISCES_HIP_CHECK(h, d_out.reserve((size_t)std::max<int64_t>(out_bytes, 1)));
     PISCES_HIP_CHECK(h, d_blocks.reserve((size_t)n_blocks));
@@ -151,7 +151,7 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
     if (out_bytes <= 0 || out_bytes > 0x7FFFFFFF00ll) return fail(h, PISCES_E_INVALID_ARG, "bam_decode: empty or oversized stream");
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     auto& B = h->bam;
-    PISCES_HIP_CHECK(h, B.d_file.reserve((size_t)n_bytes + kInWindow + 32));
+    PISCES_HIP_CHECK(h, B.d_file.reserve((size_t)n_bytes + kInWindow + 256));
     PISCES_HIP_CHECK(h, B.d_stream.reserve((size_t)out_bytes + 16));
     PISCES_HIP_CHECK(h, B.d_blocks.reserve((size_t)n_blocks));
     PISCES_HIP_CHECK(h, B.d_status.reserve((size_t)n_blocks));
