@@ -3,9 +3,8 @@
 // A BAM file is a chain of BGZF blocks: gzip members of at most 64 KiB of payload, each an independent RFC 1951 DEFLATE stream
 // (BamReader.ReadBlock, src/lib/Alignment.IO/BamReader.cs:603-645, hands each to the native zlib binding UncompressBlock,
 // src/lib/Common.IO/FileCompression.cs:14-16).  Independent streams are the parallelism: one wave inflates one block, a
-// launch inflates every block of a file region.  Inside a block DEFLATE is serial (a code's position depends on every code
-// before it), so one lane walks it bit by bit with canonical-Huffman decoding from (count per length, symbols in code order)
-// tables in LDS; stored, fixed and dynamic blocks, any number of them per stream.
+// launch inflates every block of a file region.  Inside a block a code's position depends on every code before it; what the 64 lanes
+// share of that serial chain is described at inflate_codes.  Stored, fixed and dynamic blocks, any number of them per stream.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -26,13 +25,11 @@ enum : int32_t {
     kInflateLengthMismatch = 8,   // the stream ended before ISIZE bytes were produced
 };
 
-// ---- one wave per BGZF block, every lane carrying the same decoder state ----
-// DEFLATE is serial inside a stream, so the 64 lanes of the wave run the SAME decode (identical registers, broadcast LDS reads: no
-// divergence, no extra cost) and split what can be split: a length / distance pair is copied by all lanes at once, the decode tables
-// are filled by all lanes, and a literal is stored by lane 0.  Symbols are looked up in a 10-bit table in LDS (code, length) with the
-// canonical bit-by-bit walk as the fall-back for longer codes.  Output goes straight to HBM; a copy waits for the wave's outstanding
-// stores first (its source bytes may be among them).  LDS per wave is 5 KB, so a CU holds as many waves as it has slots for and a
-// file's thousands of blocks are all in flight: the serial chains hide one another's latency.
+// ---- one wave per BGZF block ----
+// Block headers and code lengths are read by all 64 lanes alike through one bit buffer (identical scalar registers, broadcast LDS
+// reads: no divergence), the decode tables are filled by all lanes, and the symbols themselves are decoded by the lanes side by side,
+// one bit offset each (inflate_codes).  Output goes straight to HBM.  ~9.5 KB of LDS per wave, so a CU holds as many waves as it has
+// slots for and a file's thousands of blocks are all in flight.
 
 // The payload reaches the bit buffer through a window in LDS: kInWindow bytes of the file copied by all 64 lanes at once (16 bytes a
 // lane per load instruction), so that topping up the bit buffer is an LDS read (~100 cycles) and not a global load on the decode's
@@ -50,7 +47,6 @@ struct InflateStream {
     int lane;
     uint32_t* window;         // LDS [kInWindow / 4]
     int32_t win_pos;          // in_pos of the window's first byte (or a value that no in_pos lies in)
-    int32_t safe_pos;         // every output byte below it has reached memory (the wave's stores were waited for)
 };
 
 __device__ __forceinline__ void wave_lds_fence()
@@ -186,26 +182,36 @@ __device__ __forceinline__ int inflate_decode(InflateStream& s, const HuffmanTab
     return inflate_decode_long(s, h);
 }
 
-// returns 0 for a complete code, > 0 for an incomplete one (that many codes unused), < 0 when over-subscribed.  Lane 0 counts and
-// sorts (serial), all lanes fill the look-up table.
-__device__ inline int inflate_construct(const InflateStream& s, HuffmanTable& h, const int16_t* length, int n, int16_t* offs /* [16] LDS */, int kind)
+// returns 0 for a complete code, > 0 for an incomplete one (that many codes unused), < 0 when over-subscribed.
+// The canonical order (shorter codes first, the symbols of one length in symbol order) without a serial pass: every lane holds the
+// lengths of symbols lane, lane + 64, ...; for each length in turn a ballot over each of those rows says which symbols have it, and a
+// symbol's place is the running count plus the number of such lanes below it.
+__device__ inline int inflate_construct(const InflateStream& s, HuffmanTable& h, const int16_t* length, int n, int kind)
 {
-    if (s.lane == 0) {
-        for (int len = 0; len <= 15; len++) h.count[len] = 0;
-        for (int sym = 0; sym < n; sym++) h.count[length[sym]]++;
-        offs[1] = 0;
-        for (int len = 1; len < 15; len++) offs[len + 1] = (int16_t)(offs[len] + h.count[len]);
-        for (int sym = 0; sym < n; sym++)
-            if (length[sym] != 0) h.symbol[offs[length[sym]]++] = (int16_t)sym;   // offs[len] ends as the END of that length's run
-    }
-    wave_lds_fence();
-    int left = 1;
+    constexpr int kRows = 5;   // 5 x 64 >= 288 literal / length symbols (the most a table has)
+    int v[kRows];
+#pragma unroll
+    for (int k = 0; k < kRows; k++) v[k] = s.lane + 64 * k < n ? (int)length[s.lane + 64 * k] : 0;
+    int base = 0, left = 1;
     for (int len = 1; len <= 15; len++) {
-        left <<= 1;
-        left -= h.count[len];
-        if (left < 0) break;
+        const int first = base;
+#pragma unroll
+        for (int k = 0; k < kRows; k++) {
+            if (64 * k >= n) break;
+            const bool mine = v[k] == len;
+            const uint64_t b = __builtin_amdgcn_ballot_w64(mine);
+            if (b) {
+                if (mine) h.symbol[base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u))] = (int16_t)(s.lane + 64 * k);
+                base += __builtin_popcountll(b);
+            }
+        }
+        if (s.lane == 0) h.count[len] = (int16_t)(base - first);
+        left = (left << 1) - (base - first);   // (negative stays negative: an over-subscribed code is known at the end as well)
+        if (left < -(1 << 20)) left = -(1 << 20);
     }
-    const bool usable = left >= 0 && h.count[0] != n;
+    if (s.lane == 0) h.count[0] = (int16_t)(n - base);
+    wave_lds_fence();
+    const bool usable = left >= 0 && base != 0;
     const int size = 1 << h.lut_bits;
     for (int i = s.lane; i < size; i += 64) {
         uint32_t e = kind == kLengthCode ? 0x40u : 0u;
@@ -229,7 +235,7 @@ __device__ inline int inflate_construct(const InflateStream& s, HuffmanTable& h,
         h.lut[i] = e;
     }
     wave_lds_fence();
-    if (h.count[0] == n) return 0;   // no codes: complete, but decoding will fail
+    if (base == 0) return 0;   // no codes: complete, but decoding will fail
     return left;
 }
 
@@ -502,7 +508,7 @@ __device__ inline void inflate_codes(InflateStream& s, const HuffmanTable& lenco
 }
 
 // LDS workspace of a wave: the small tables in int16 units, and the two look-up tables
-constexpr int kInflateTableWords = 16 + 288 + 16 + 30 + 320 + 16;
+constexpr int kInflateTableWords = 16 + 288 + 16 + 30 + 320;
 __device__ inline void inflate_stream(InflateStream& s, int16_t* tables, uint32_t* llut, uint32_t* dlut)
 {
     int16_t* const lcount = tables;
@@ -510,7 +516,6 @@ __device__ inline void inflate_stream(InflateStream& s, int16_t* tables, uint32_
     int16_t* const dcount = lsymbol + 288;
     int16_t* const dsymbol = dcount + 16;
     int16_t* const lengths = dsymbol + 30;
-    int16_t* const offs = lengths + 320;
     HuffmanTable lencode = {lcount, lsymbol, llut, kLenLutBits}, distcode = {dcount, dsymbol, dlut, kDistLutBits};
     int last;
     do {
@@ -534,10 +539,10 @@ __device__ inline void inflate_stream(InflateStream& s, int16_t* tables, uint32_
         } else if (type == 1) {   // fixed code (RFC 1951 3.2.6)
             for (int sym = s.lane; sym < 288; sym += 64) lengths[sym] = (int16_t)(sym < 144 ? 8 : sym < 256 ? 9 : sym < 280 ? 7 : 8);
             wave_lds_fence();
-            (void)inflate_construct(s, lencode, lengths, 288, offs, kLengthCode);
+            (void)inflate_construct(s, lencode, lengths, 288, kLengthCode);
             for (int sym = s.lane; sym < 30; sym += 64) lengths[sym] = 5;
             wave_lds_fence();
-            (void)inflate_construct(s, distcode, lengths, 30, offs, kDistanceCode);
+            (void)inflate_construct(s, distcode, lengths, 30, kDistanceCode);
             inflate_codes(s, lencode, distcode);
         } else if (type == 2) {   // dynamic code (RFC 1951 3.2.7)
             const int nlen = (int)inflate_bits(s, 5) + 257, ndist = (int)inflate_bits(s, 5) + 1, ncode = (int)inflate_bits(s, 4) + 4;
@@ -549,7 +554,7 @@ __device__ inline void inflate_stream(InflateStream& s, int16_t* tables, uint32_
             }
             if (s.err) return;
             wave_lds_fence();
-            if (inflate_construct(s, lencode, lengths, 19, offs, kPlainCode) != 0) { s.err = kInflateBadCodeLengths; return; }   // the code-length code is complete
+            if (inflate_construct(s, lencode, lengths, 19, kPlainCode) != 0) { s.err = kInflateBadCodeLengths; return; }   // the code-length code is complete
             int index = 0, prev = 0;
             while (index < nlen + ndist) {
                 int symbol = inflate_decode(s, lencode);
@@ -581,9 +586,9 @@ __device__ inline void inflate_stream(InflateStream& s, int16_t* tables, uint32_
             }
             wave_lds_fence();
             if (lengths[256] == 0) { s.err = kInflateBadCodeLengths; return; }   // no end-of-block code
-            int e = inflate_construct(s, lencode, lengths, nlen, offs, kLengthCode);
+            int e = inflate_construct(s, lencode, lengths, nlen, kLengthCode);
             if (e && (e < 0 || nlen != lencode.count[0] + lencode.count[1])) { s.err = kInflateBadCodeLengths; return; }   // incomplete only as a single code
-            e = inflate_construct(s, distcode, lengths + nlen, ndist, offs, kDistanceCode);
+            e = inflate_construct(s, distcode, lengths + nlen, ndist, kDistanceCode);
             if (e && (e < 0 || ndist != distcode.count[0] + distcode.count[1])) { s.err = kInflateBadCodeLengths; return; }
             inflate_codes(s, lencode, distcode);
         } else {
@@ -609,7 +614,6 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
     s.in = in + b.in_offset;
     s.in_len = b.in_length;
     s.window = window;
-    s.safe_pos = 0;
     s.win_pos = -2 * kInWindow;
     s.out = out + b.out_offset;
     s.out_len = b.out_length;
