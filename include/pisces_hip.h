@@ -516,6 +516,9 @@ int32_t pisces_hip_bgzf_inflate(PiscesHip* h, const uint8_t* file, int64_t n_byt
  * reference sequence `ref_id` are decoded into the PiscesReadBatch arrays in device memory, in file order — what BamReader.GetNextAlignment
  * (src/lib/Alignment.IO/BamReader.cs:137) + Read's constructor do per record on the host.  counts = {reads kept, reads of the chromosome
  * skipped, CIGAR operations, bases}.  Records longer than 32 KiB (long reads) are reported as a broken chain.
+ * Where the record chain enters each chunk is first taken, for all chunks at once, from the one exit that the live chains of the chunk
+ * before share, and every link checked; a file where that fails somewhere (records of several KiB, ...) gets the serial hop chunk to
+ * chunk instead.  pisces_hip_bam_chain_mode says which it was for the last decode (0 = all at once, 1 = serial hop): diagnostics.
  * pisces_hip_bam_fetch: the decoded batch to host arrays sized from `counts` (any pointer may be NULL) — for inspection and tests.
  * pisces_hip_add_decoded_reads: pisces_hip_add_reads for the decoded batch without its bases and qualities leaving the device: the
  * host reads back positions and CIGARs only (for the block bookkeeping), the read walk and the candidate discovery run where the
@@ -525,6 +528,7 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
 int32_t pisces_hip_bam_fetch(PiscesHip* h, int32_t* position, uint8_t* flags, int32_t* cigar_offset, uint8_t* cigar_op, uint32_t* cigar_len,
                              int32_t* seq_offset, uint8_t* bases, uint8_t* quals);
 int32_t pisces_hip_add_decoded_reads(PiscesHip* h);
+int32_t pisces_hip_bam_chain_mode(PiscesHip* h);
 
 #ifdef __cplusplus
 }

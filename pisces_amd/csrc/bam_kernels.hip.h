@@ -8,7 +8,14 @@
 //   bam_chain_kernel    per 32 KiB chunk, EVERY byte offset s is taken as a possible record start: next(s) = s + 4 + le32(s).  Pointer
 //                       jumping in LDS (next <- next o next, 10 rounds) turns that into "where does the chain from s leave the chunk"
 //                       for all 32768 offsets at once — no knowledge of the true starts needed.
-//   bam_entry_kernel    one thread hops chunk to chunk: entry(c + 1) = where the chain from entry(c) leaves chunk c (one load per chunk)
+//                       False chains die within a few records (a random word is no block_size), so the chains that are still alive
+//                       when they leave a chunk have all merged into the true one: the chunk also reports the exit that every live
+//                       chain from its first 4 KiB shares, when there is exactly one.
+//   bam_entry_guess_kernel / bam_entry_check_kernel   entry(c + 1) taken from that shared exit of chunk c, for all chunks at once, and
+//                       then every link checked against the pointers (entry(c + 1) must be where the chain from entry(c) leaves
+//                       chunk c: by induction from the header the entries are then the true ones)
+//   bam_entry_kernel    the fall-back when a chunk had no single shared exit or a link failed (long records, a first 4 KiB without a
+//                       record start): one thread hops chunk to chunk, one dependent load per chunk
 //   bam_count_kernel    one wave per chunk walks its records from the true entry: AlignmentSource.ShouldSkipRead, counts of kept reads,
 //                       CIGAR operations and bases -> (after a scan) every chunk's place in the read batch
 //   bam_decode_kernel   the same walk, all 64 lanes decoding each kept record into the SoA read batch the read walk takes
@@ -22,6 +29,7 @@ namespace pisces {
 constexpr int kBamChunk = 32768;               // bytes of the inflated stream per workgroup
 constexpr uint16_t kBamLeaves = 0x8000;        // pointer values >= this: the chain leaves the chunk, low 15 bits = bytes past its end
 constexpr uint16_t kBamBroken = 0xFFFF;        // no record can start here (size out of range, or its chain runs into such a place)
+constexpr int kBamGuessWindow = 4096;          // the first bytes of a chunk whose live chains vote for the chunk's exit
 constexpr int kBamMinRecord = 32;              // fixed fields of a record after block_size
 constexpr int kBamMaxRecord = kBamChunk - 8;   // a longer record would leave the chunk by more than 15 bits can say (long reads: not here)
 
@@ -61,10 +69,13 @@ __global__ void bam_header_kernel(const uint8_t* __restrict__ s, int64_t n, long
 }
 
 // exits[s] for every byte offset s of the stream: kBamLeaves | (bytes past the end of s's chunk) once the chain from s leaves its chunk
-__global__ __launch_bounds__(1024) void bam_chain_kernel(const uint8_t* __restrict__ s, int64_t n, uint16_t* __restrict__ exits)
+__global__ __launch_bounds__(1024) void bam_chain_kernel(const uint8_t* __restrict__ s, int64_t n, uint16_t* __restrict__ exits, uint32_t* __restrict__ shared_exit,
+                                                         const long long* __restrict__ header)
 {
     __shared__ uint8_t bytes[kBamChunk + 4];
     __shared__ uint16_t ptr[kBamChunk];
+    __shared__ uint32_t exit_lo, exit_hi;
+    if (threadIdx.x == 0) { exit_lo = 0xFFFFFFFFu; exit_hi = 0u; }
     const int64_t c0 = (int64_t)blockIdx.x * kBamChunk;
     const int len = (int)min((int64_t)kBamChunk, n - c0);
     for (int i = threadIdx.x; i < kBamChunk + 4; i += 1024) bytes[i] = (c0 + i < n) ? s[c0 + i] : (uint8_t)0;
@@ -91,13 +102,79 @@ __global__ __launch_bounds__(1024) void bam_chain_kernel(const uint8_t* __restri
         __syncthreads();
     }
     for (int i = threadIdx.x; i < len; i += 1024) exits[c0 + i] = ptr[i];
+    // the exit all live chains from the chunk's first kBamGuessWindow bytes share (0: none alive, or more than one exit); in the chunk
+    // the header ends in, the window starts at the first record
+    const long long first = header[2] == 0 ? header[0] : 0;
+    const int w0 = first >= c0 && first < c0 + len ? (int)(first - c0) : 0;
+    for (int i = w0 + threadIdx.x; i < min(len, w0 + kBamGuessWindow); i += 1024) {
+        const uint32_t v = ptr[i];
+        if (v >= kBamLeaves && v != kBamBroken) { atomicMin(&exit_lo, v); atomicMax(&exit_hi, v); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) shared_exit[blockIdx.x] = exit_lo == exit_hi ? exit_lo : 0u;
+}
+
+// entry[c] for every chunk at once, from the shared exit of the chunk before it (fallback[0] = 1 when some chunk has none)
+__global__ void bam_entry_guess_kernel(const uint32_t* __restrict__ shared_exit, int64_t n, const long long* __restrict__ header, int64_t n_chunks,
+                                       long long* __restrict__ entry, int32_t* __restrict__ status, int32_t* __restrict__ fallback)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    if (header[2] != 0) { if (c == 0) status[0] = 1; entry[c] = -1; return; }
+    const int64_t first = header[0], c_first = first / kBamChunk;
+    long long e = -1;
+    if (first < n) {
+        if (c == c_first) e = first;
+        else if (c > c_first) {
+            const uint32_t v = shared_exit[c - 1];
+            if (v == 0u) { atomicOr(fallback, 1); }
+            else {
+                const int64_t at = min(c * (int64_t)kBamChunk, n) + (int64_t)(v & 0x7FFFu);
+                if (at < n) {
+                    if (at / kBamChunk == c) e = at; else atomicOr(fallback, 1);
+                }
+            }
+        }
+    }
+    entry[c] = e;
+}
+
+// every link of the guessed entries against the pointers; fallback[0] = 1 on any doubt
+__global__ void bam_entry_check_kernel(const uint16_t* __restrict__ exits, int64_t n, const long long* __restrict__ header, int64_t n_chunks,
+                                       const long long* __restrict__ entry, int32_t* __restrict__ fallback)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks || header[2] != 0) return;
+    const int64_t first = header[0], c_first = first / kBamChunk;
+    if (first >= n) return;                   // no records at all: every entry is -1, nothing to check (the header alone is the stream)
+    if (c < c_first) return;
+    // where the chain from chunk k's entry leaves it (-1: not a live pointer)
+    auto link = [&](int64_t k) -> int64_t {
+        const uint16_t v = exits[entry[k]];
+        if (v == kBamBroken || v < kBamLeaves) return -1;
+        return min((k + 1) * (int64_t)kBamChunk, n) + (int64_t)(v & 0x7FFF);
+    };
+    const long long e = entry[c];
+    if (e < 0) {
+        // no record starts here: only the last chunk may say so, when the last record ends with the stream inside it
+        if (!(c == n_chunks - 1 && c > c_first && entry[c - 1] >= 0 && link(c - 1) == n)) atomicOr(fallback, 1);
+        return;
+    }
+    const int64_t at = link(c);
+    if (at < 0) { atomicOr(fallback, 1); return; }
+    if (at < n) {
+        if (c + 1 >= n_chunks || at != entry[c + 1]) atomicOr(fallback, 1);
+    } else if (at != n || (c + 1 < n_chunks && (c + 2 < n_chunks || entry[c + 1] != -1))) {
+        atomicOr(fallback, 1);                // (the serial pass reports how a chain ends that does not end with the stream)
+    }
 }
 
 // entry[c] = offset of the first record that STARTS in chunk c (-1: none); status[0] != 0 on a broken chain
 __global__ void bam_entry_kernel(const uint16_t* __restrict__ exits, int64_t n, const long long* __restrict__ header, int64_t n_chunks,
-                                 long long* __restrict__ entry, int32_t* __restrict__ status)
+                                 long long* __restrict__ entry, int32_t* __restrict__ status, const int32_t* __restrict__ fallback)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    if (fallback && fallback[0] == 0) return;   // the guessed entries passed every check
     for (int64_t c = 0; c < n_chunks; c++) entry[c] = -1;
     if (header[2] != 0) { status[0] = 1; return; }
     int64_t at = header[0];

@@ -223,6 +223,7 @@ struct PiscesHip {
         DeviceBuf<PiscesBgzfBlock> d_blocks;
         DeviceBuf<int32_t> d_status;
         DeviceBuf<uint16_t> d_exits;
+        DeviceBuf<uint32_t> d_shared_exit;
         DeviceBuf<long long> d_header, d_entry;
         DeviceBuf<int32_t> d_n_reads, d_n_ops, d_n_bases, d_n_skipped, d_bstatus;
         // the read batch
@@ -233,6 +234,7 @@ struct PiscesHip {
         DeviceBuf<int32_t> d_fslots;       // candidate-record slots of the reads
         int64_t n_reads = 0, n_ops = 0, n_bases = 0, n_skipped = 0;
         bool valid = false;
+        int32_t chain_mode = 0;   // 0: every chunk's entry guessed and checked; 1: the serial hop ran
         int32_t min_bq = 0;
     } bam;
 

@@ -165,6 +165,7 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
     PISCES_HIP_CHECK(h, B.d_exits.reserve((size_t)out_bytes));
     PISCES_HIP_CHECK(h, B.d_header.reserve(4));
     PISCES_HIP_CHECK(h, B.d_entry.reserve((size_t)n_chunks));
+    PISCES_HIP_CHECK(h, B.d_shared_exit.reserve((size_t)n_chunks));
     PISCES_HIP_CHECK(h, B.d_bstatus.reserve(4));
     PISCES_HIP_CHECK(h, B.d_n_reads.reserve((size_t)n_chunks + 1));
     PISCES_HIP_CHECK(h, B.d_n_ops.reserve((size_t)n_chunks + 1));
@@ -173,9 +174,15 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
     PISCES_HIP_CHECK(h, hipMemsetAsync(B.d_bstatus.p, 0, 4 * sizeof(int32_t), h->stream));
     const BamFilter F = {ref_id, min_map_quality, skip_duplicates, only_proper_pairs, h->cfg.min_base_call_quality};
     hipLaunchKernelGGL(bam_header_kernel, dim3(1), dim3(1), 0, h->stream, (const uint8_t*)B.d_stream.p, out_bytes, B.d_header.p);
-    hipLaunchKernelGGL(bam_chain_kernel, dim3((unsigned)n_chunks), dim3(1024), 0, h->stream, (const uint8_t*)B.d_stream.p, out_bytes, B.d_exits.p);
+    hipLaunchKernelGGL(bam_chain_kernel, dim3((unsigned)n_chunks), dim3(1024), 0, h->stream, (const uint8_t*)B.d_stream.p, out_bytes, B.d_exits.p,
+                       B.d_shared_exit.p, (const long long*)B.d_header.p);
+    // (d_bstatus[3]: some chunk needs the serial hop)
+    hipLaunchKernelGGL(bam_entry_guess_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, h->stream, (const uint32_t*)B.d_shared_exit.p,
+                       out_bytes, (const long long*)B.d_header.p, n_chunks, B.d_entry.p, B.d_bstatus.p, B.d_bstatus.p + 3);
+    hipLaunchKernelGGL(bam_entry_check_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, h->stream, (const uint16_t*)B.d_exits.p,
+                       out_bytes, (const long long*)B.d_header.p, n_chunks, (const long long*)B.d_entry.p, B.d_bstatus.p + 3);
     hipLaunchKernelGGL(bam_entry_kernel, dim3(1), dim3(1), 0, h->stream, (const uint16_t*)B.d_exits.p, out_bytes, (const long long*)B.d_header.p,
-                       n_chunks, B.d_entry.p, B.d_bstatus.p);
+                       n_chunks, B.d_entry.p, B.d_bstatus.p, (const int32_t*)(B.d_bstatus.p + 3));
     hipLaunchKernelGGL(bam_count_kernel, dim3((unsigned)n_chunks), dim3(64), 0, h->stream, (const uint8_t*)B.d_stream.p, out_bytes,
                        (const long long*)B.d_entry.p, F, B.d_n_reads.p, B.d_n_ops.p, B.d_n_bases.p, B.d_n_skipped.p);
     hipLaunchKernelGGL(bam_scan3_kernel, dim3(1), dim3(1024), 0, h->stream, B.d_n_reads.p, B.d_n_ops.p, B.d_n_bases.p, (int32_t)n_chunks);
@@ -196,6 +203,7 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
     if (bstatus[0] != 0)
         return fail(h, PISCES_E_INVALID_ARG, "bam_decode: the record chain breaks in chunk " + std::to_string(bstatus[1]) +
                                                  " (corrupt block_size, or a record longer than 32 KiB)");
+    B.chain_mode = bstatus[3] != 0 ? 1 : 0;
     B.n_reads = totals[0]; B.n_ops = totals[1]; B.n_bases = totals[2];
     B.n_skipped = 0;
     for (int32_t v : skipped) B.n_skipped += v;
@@ -220,6 +228,15 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
     B.valid = true;
     if (counts) { counts[0] = B.n_reads; counts[1] = B.n_skipped; counts[2] = B.n_ops; counts[3] = B.n_bases; }
     return PISCES_OK;
+    });
+}
+
+int32_t pisces_hip_bam_chain_mode(PiscesHip* h)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (!h->bam.valid) return fail(h, PISCES_E_STATE, "bam_chain_mode: no decoded batch (pisces_hip_bam_decode first)");
+    return h->bam.chain_mode;
     });
 }
 

@@ -332,7 +332,8 @@ class HipVariantCaller:
         _check(self._h, lib.pisces_hip_bam_decode(self._h, data.ctypes.data, data.size, blocks, len(blocks), int(ref_id), int(min_map_quality),
                                                   int(bool(skip_duplicates)), int(bool(only_proper_pairs)), counts))
         self._bam_counts = {"reads": counts[0], "skipped": counts[1], "cigar_ops": counts[2], "bases": counts[3]}
-        return dict(self._bam_counts)
+        mode = lib.pisces_hip_bam_chain_mode(self._h)
+        return dict(self._bam_counts, chain="guessed" if mode == 0 else "hopped")
 
     def bam_fetch(self):
         """The decoded batch as host arrays (dict with the PiscesReadBatch field names)."""

@@ -253,3 +253,67 @@ def test_bam_bytes_to_vcf_rows_without_the_reads_leaving_the_device(name, bam):
     assert got.tobytes() == want.tobytes() and got_alleles == want_alleles and stats["reads"] == batch.n_reads
     text = engine.format_vcf(case["chrom"], got, alleles=got_alleles, noise_level_from_records=1, **case["vcf"])
     bam_fixtures.check_lines(case, text.rstrip("\n").split("\n") if text else [], [str(x) for x in z["expected_vcf"]])
+
+
+def _synthetic_bam(read_lens, header_text=b"@HD\tVN:1.6\n", seed=5):
+    """An uncompressed BAM stream: header + one record per entry of read_lens (CIGAR <len>M, random bases / qualities)."""
+    rng = np.random.default_rng(seed)
+    out = bytearray(b"BAM\x01" + struct.pack("<i", len(header_text)) + header_text + struct.pack("<i", 1) + struct.pack("<i", 5) + b"chr1\0" +
+                    struct.pack("<i", 250_000_000))
+    pos = 1000
+    for i, n in enumerate(read_lens):
+        name = b"r%07d\0" % i
+        seq = rng.integers(0, 4, n)
+        packed = np.zeros((n + 1) // 2, np.uint8)
+        codes = np.array([1, 2, 4, 8], np.uint8)[seq]
+        packed[: n // 2] = (codes[0:n - n % 2:2] << 4) | codes[1::2]
+        if n % 2:
+            packed[-1] = codes[-1] << 4
+        qual = rng.integers(2, 42, n).astype(np.uint8)
+        body = struct.pack("<iiBBHHHiiii", 0, pos, len(name), 60, 4681, 1, 16 if i % 2 else 0, n, -1, -1, 0) + name + struct.pack("<I", (n << 4) | 0) + \
+            packed.tobytes() + qual.tobytes()
+        out += struct.pack("<i", len(body)) + body
+        pos += int(rng.integers(0, 3))
+    return bytes(out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["short_records", "long_header", "long_records", "last_record_straddles", "mixed"])
+def test_record_chain_is_cut_the_same_with_guessed_and_with_hopped_entries(case):
+    """bam_entry_guess_kernel / bam_entry_check_kernel take every chunk's entry from the shared exit of the chunk before it and fall back
+    to the serial hop when a chunk has none (records longer than the 4 KiB the guess looks at); a header that ends deep inside a chunk
+    and a last record that ends in a chunk of its own are taken without it: either way the read batch is what a plain host reader makes
+    of the bytes."""
+    import torch
+    assert torch.cuda.is_available()
+    rng = np.random.default_rng(11)
+    if case == "short_records":
+        lens, header = [150] * 3000, b"@HD\tVN:1.6\n"
+    elif case == "long_header":
+        lens, header = [150] * 2000, b"@HD\tVN:1.6\n" + b"".join(b"@CO\tline %06d of a long header\n" % i for i in range(2500))
+    elif case == "long_records":
+        lens, header = [int(x) for x in rng.integers(3000, 12000, 120)], b"@HD\tVN:1.6\n"
+    elif case == "last_record_straddles":
+        lens, header = [150] * 1000, b"@HD\tVN:1.6\n"
+    else:
+        lens, header = [int(x) for x in rng.choice([36, 150, 151, 250, 5000, 9000], 1500, p=[.2, .4, .2, .15, .03, .02])], b"@HD\tVN:1.6\n"
+    stream = _synthetic_bam(lens, header)
+    if case == "last_record_straddles":
+        # pad the header so that the last record begins a few bytes before a 32 KiB boundary and ends behind it
+        rec = 4 + 32 + 9 + 4 + 75 + 150
+        short = (32768 - (len(stream) - rec) % 32768 - 10) % 32768
+        stream = _synthetic_bam(lens, header + b"@CO\t" + b"x" * (short - 5) + b"\n")
+        assert (len(stream) - rec) % 32768 == 32768 - 10
+    data = make_bgzf([stream[i:i + 60000] for i in range(0, len(stream), 60000)])
+    refs, reads = _bam_reads_reference(data)
+    keep = _kept(reads, "chr1")
+    assert len(keep) == len(lens)
+    with engine.HipVariantCaller(_abi.default_config()) as c:
+        counts = c.bam_decode(data, 0)
+        assert counts["reads"] == len(keep)
+        assert counts["chain"] == ("guessed" if case in ("short_records", "long_header", "last_record_straddles") else "hopped"), counts
+        got = c.bam_fetch()
+    np.testing.assert_array_equal(got["position"], np.array([r["pos"] for r in keep], np.int32))
+    np.testing.assert_array_equal(got["seq_offset"], np.cumsum([0] + [len(r["seq"]) for r in keep]).astype(np.int32))
+    assert got["bases"].tobytes() == "".join(r["seq"] for r in keep).encode()
+    assert got["quals"].tobytes() == b"".join(r["qual"].tobytes() for r in keep)
