@@ -518,7 +518,8 @@ int32_t pisces_hip_bgzf_inflate(PiscesHip* h, const uint8_t* file, int64_t n_byt
  * skipped, CIGAR operations, bases}.  Records longer than 32 KiB (long reads) are reported as a broken chain.
  * Where the record chain enters each chunk is first taken, for all chunks at once, from the one exit that the live chains of the chunk
  * before share, and every link checked; a file where that fails somewhere (records of several KiB, ...) gets the serial hop chunk to
- * chunk instead.  pisces_hip_bam_chain_mode says which it was for the last decode (0 = all at once, 1 = serial hop): diagnostics.
+ * chunk instead.  pisces_hip_bam_chain_mode says which it was for the last decode (0 = all at once, 1 = serial hop): diagnostics
+ * (the environment variable PISCES_HIP_BAM_SERIAL_CHAIN=1 forces the serial hop).
  * pisces_hip_bam_fetch: the decoded batch to host arrays sized from `counts` (any pointer may be NULL) — for inspection and tests.
  * pisces_hip_add_decoded_reads: pisces_hip_add_reads for the decoded batch without its bases and qualities leaving the device: the
  * host reads back positions and CIGARs only (for the block bookkeeping), the read walk and the candidate discovery run where the

@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "finder_kernels.hip.h"   // kFoundInline
+
 namespace pisces {
 
 constexpr int kBamChunk = 32768;               // bytes of the inflated stream per workgroup
@@ -37,6 +39,7 @@ struct BamFilter {   // AlignmentSourceConfig + the chromosome being called
     int32_t ref_id;
     int32_t min_map_quality, skip_duplicates, only_proper_pairs;
     int32_t min_base_quality;   // for the deletion-quality bits of the read metadata
+    int32_t block_size;         // RegionStateManager's block grid: the decode marks the blocks every read touches
 };
 
 struct BamCounts { long long reads, cigar_ops, bases, records, skipped; };
@@ -47,11 +50,11 @@ __device__ __forceinline__ int32_t bam_le32(const uint8_t* __restrict__ p)
 }
 __device__ __forceinline__ uint32_t bam_le16(const uint8_t* __restrict__ p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
 
-// out[0] = offset of the first record, out[1] = n_ref, out[2] = status (0 ok)
-__global__ void bam_header_kernel(const uint8_t* __restrict__ s, int64_t n, long long* __restrict__ out)
+// out[0] = offset of the first record, out[1] = n_ref, out[2] = status (0 ok), out[3] = l_ref of reference sequence ref_id (0: no such)
+__global__ void bam_header_kernel(const uint8_t* __restrict__ s, int64_t n, long long* __restrict__ out, int32_t ref_id)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    out[0] = 0; out[1] = 0; out[2] = 1;
+    out[0] = 0; out[1] = 0; out[2] = 1; out[3] = 0;
     if (n < 12 || s[0] != 'B' || s[1] != 'A' || s[2] != 'M' || s[3] != 1) return;
     const int64_t l_text = bam_le32(s + 4);
     if (l_text < 0 || 8 + l_text + 4 > n) return;
@@ -63,6 +66,7 @@ __global__ void bam_header_kernel(const uint8_t* __restrict__ s, int64_t n, long
         if (p + 4 > n) return;
         const int64_t l_name = bam_le32(s + p);
         if (l_name < 0 || p + 4 + l_name + 4 > n) return;
+        if (i == ref_id) out[3] = bam_le32(s + p + 4 + l_name);
         p += 4 + l_name + 4;
     }
     out[0] = p; out[1] = n_ref; out[2] = 0;
@@ -106,34 +110,53 @@ __global__ __launch_bounds__(1024) void bam_chain_kernel(const uint8_t* __restri
     // the header ends in, the window starts at the first record
     const long long first = header[2] == 0 ? header[0] : 0;
     const int w0 = first >= c0 && first < c0 + len ? (int)(first - c0) : 0;
+    // (only starts that look like a record vote -- reference id inside the header's table, a block_size that holds its own fixed
+    // fields, name, CIGAR and bases: an integer field that merely reads like a block_size does not.  The pointers themselves stay
+    // as permissive as BamReader is: the vote decides nothing that the check of the links does not confirm.)
+    const long long n_ref = header[2] == 0 ? header[1] : 0;
     for (int i = w0 + threadIdx.x; i < min(len, w0 + kBamGuessWindow); i += 1024) {
         const uint32_t v = ptr[i];
+        if (i + 4 + kBamMinRecord > len) continue;
+        const int32_t bs = bam_le32(bytes + i), ref_id = bam_le32(bytes + i + 4), l_seq = bam_le32(bytes + i + 20);
+        const int l_name = bytes[i + 12], n_cigar = (int)bam_le16(bytes + i + 16);
+        if (ref_id < -1 || ref_id >= n_ref || l_name < 1 || l_seq < 0 || (long long)bs < 32ll + l_name + 4ll * n_cigar + (l_seq + 1ll) / 2 + l_seq) continue;
         if (v >= kBamLeaves && v != kBamBroken) { atomicMin(&exit_lo, v); atomicMax(&exit_hi, v); }
     }
     __syncthreads();
     if (threadIdx.x == 0) shared_exit[blockIdx.x] = exit_lo == exit_hi ? exit_lo : 0u;
 }
 
-// entry[c] for every chunk at once, from the shared exit of the chunk before it (fallback[0] = 1 when some chunk has none)
-__global__ void bam_entry_guess_kernel(const uint32_t* __restrict__ shared_exit, int64_t n, const long long* __restrict__ header, int64_t n_chunks,
-                                       long long* __restrict__ entry, int32_t* __restrict__ status, int32_t* __restrict__ fallback)
+// entry[c] for every chunk at once, from the shared exit of the chunk before it.  Where that chunk has none (two live chains with
+// different exits: a small integer field near the chunk's start that reads like a block_size), the thread goes back to the nearest
+// chunk whose entry is known and hops forward from there through the pointers (at most kBamGuessBack chunks; fallback[0] = 1 beyond).
+constexpr int kBamGuessBack = 64;
+__global__ void bam_entry_guess_kernel(const uint32_t* __restrict__ shared_exit, const uint16_t* __restrict__ exits, int64_t n,
+                                       const long long* __restrict__ header, int64_t n_chunks, long long* __restrict__ entry,
+                                       int32_t* __restrict__ status, int32_t* __restrict__ fallback)
 {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
     if (header[2] != 0) { if (c == 0) status[0] = 1; entry[c] = -1; return; }
     const int64_t first = header[0], c_first = first / kBamChunk;
     long long e = -1;
-    if (first < n) {
-        if (c == c_first) e = first;
-        else if (c > c_first) {
-            const uint32_t v = shared_exit[c - 1];
-            if (v == 0u) { atomicOr(fallback, 1); }
-            else {
-                const int64_t at = min(c * (int64_t)kBamChunk, n) + (int64_t)(v & 0x7FFFu);
-                if (at < n) {
-                    if (at / kBamChunk == c) e = at; else atomicOr(fallback, 1);
-                }
-            }
+    if (first < n && c >= c_first) {
+        // the nearest chunk at or before c whose entry does not depend on another chunk's
+        int64_t p = c;
+        while (p > c_first && shared_exit[p - 1] == 0u && c - p < kBamGuessBack) p--;
+        long long at;
+        if (p == c_first) at = first;
+        else if (shared_exit[p - 1] != 0u) at = min(p * (int64_t)kBamChunk, n) + (long long)(shared_exit[p - 1] & 0x7FFFu);
+        else { atomicOr(fallback, 1); at = -1; }
+        // forward through chunks p .. c - 1
+        for (int64_t k = p; at >= 0 && k < c; k++) {
+            if (at >= n || at / kBamChunk != k) { at = at >= n ? n : -1; break; }
+            const uint16_t v = exits[at];
+            if (v == kBamBroken || v < kBamLeaves) { at = -1; break; }
+            at = min((k + 1) * (int64_t)kBamChunk, n) + (long long)(v & 0x7FFF);
+        }
+        if (at < 0) atomicOr(fallback, 1);
+        else if (at < n) {
+            if (at / kBamChunk == c) e = at; else atomicOr(fallback, 1);
         }
     }
     entry[c] = e;
@@ -206,32 +229,75 @@ __device__ __forceinline__ bool bam_keep(const uint8_t* __restrict__ rec, const 
     return true;
 }
 
-// per chunk: {kept reads, CIGAR operations, bases, records of the chromosome that were skipped}
+// what pisces_hip_add_reads's host pass takes from a read's CIGAR, for the kept reads of the decoded batch: log slots (one per reference
+// position the read spans: an upper bound of its observations), candidate-record slots (one per insertion / deletion), bytes of
+// insertions too long for a record
+struct BamCigarSums { long long ref_span; int read_span, indels, pool; };
+__device__ __forceinline__ BamCigarSums bam_cigar_sums(const uint8_t* __restrict__ cig, int n_cigar)
+{
+    BamCigarSums t = {0, 0, 0, 0};
+    for (int k = 0; k < n_cigar; k++) {
+        const uint32_t v = (uint32_t)bam_le32(cig + 4 * k);
+        const uint32_t op = v & 0xFu, len = v >> 4;
+        if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) t.read_span += (int)len;    // M I S = X
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) t.ref_span += (long long)len;   // M D N = X
+        if (op == 1 || op == 2) t.indels++;
+        if (op == 1 && len > (uint32_t)kFoundInline) t.pool += (int)len;
+    }
+    return t;
+}
+
+// per chunk: {kept reads, CIGAR operations, bases, records of the chromosome that were skipped, log slots, candidate slots, pool bytes}.
+// Lane 0 walks the chunk's chain (one dependent load a record) and leaves the record offsets in LDS; the lanes then take a record each.
 __global__ __launch_bounds__(64) void bam_count_kernel(const uint8_t* __restrict__ s, int64_t n, const long long* __restrict__ entry,
                                                        BamFilter F, int32_t* __restrict__ n_reads, int32_t* __restrict__ n_ops,
-                                                       int32_t* __restrict__ n_bases, int32_t* __restrict__ n_skipped)
+                                                       int32_t* __restrict__ n_bases, int32_t* __restrict__ n_skipped,
+                                                       long long* __restrict__ n_span, int32_t* __restrict__ n_indels, int32_t* __restrict__ n_pool)
 {
+    __shared__ int32_t rec_at[kBamChunk / (4 + kBamMinRecord) + 2];   // relative to the chunk's first byte
+    __shared__ int32_t n_rec_s;
     const int64_t c = blockIdx.x;
-    if (threadIdx.x != 0) return;
-    int reads = 0, ops = 0, bases = 0, skipped = 0;
-    int64_t at = entry[c];
-    const int64_t chunk_end = min((c + 1) * (int64_t)kBamChunk, n);
-    while (at >= 0 && at < chunk_end) {
-        const int32_t bs = bam_le32(s + at);
-        const uint8_t* rec = s + at + 4;
+    const int64_t c0 = c * (int64_t)kBamChunk, chunk_end = min((c + 1) * (int64_t)kBamChunk, n);
+    if (threadIdx.x == 0) {
+        int k = 0;
+        int64_t at = entry[c];
+        while (at >= 0 && at < chunk_end) {
+            rec_at[k++] = (int32_t)(at - c0);
+            at += 4 + (int64_t)bam_le32(s + at);
+        }
+        n_rec_s = k;
+    }
+    __syncthreads();
+    const int n_rec = n_rec_s;
+    int reads = 0, ops = 0, bases = 0, skipped = 0, indels = 0, pool = 0;
+    long long span = 0;
+    for (int i = threadIdx.x; i < n_rec; i += 64) {
+        const uint8_t* rec = s + c0 + rec_at[i] + 4;
         if (bam_keep(rec, F)) {
+            const int n_cigar = (int)bam_le16(rec + 12);
             reads++;
-            ops += (int)bam_le16(rec + 12);
+            ops += n_cigar;
             bases += bam_le32(rec + 16);
+            const BamCigarSums t = bam_cigar_sums(rec + 32 + rec[8], n_cigar);
+            span += t.ref_span;
+            indels += t.indels;
+            pool += t.pool;
         } else if (bam_le32(rec) == F.ref_id) {
             skipped++;
         }
-        at += 4 + (int64_t)bs;
     }
-    n_reads[c] = reads; n_ops[c] = ops; n_bases[c] = bases; n_skipped[c] = skipped;
+    for (int d = 32; d >= 1; d >>= 1) {
+        reads += __shfl_down(reads, d, 64); ops += __shfl_down(ops, d, 64); bases += __shfl_down(bases, d, 64);
+        skipped += __shfl_down(skipped, d, 64); indels += __shfl_down(indels, d, 64); pool += __shfl_down(pool, d, 64);
+        span += __shfl_down(span, d, 64);
+    }
+    if (threadIdx.x == 0) {
+        n_reads[c] = reads; n_ops[c] = ops; n_bases[c] = bases; n_skipped[c] = skipped;
+        n_span[c] = span; n_indels[c] = indels; n_pool[c] = pool;
+    }
 }
 
-// in-place exclusive scans of three int32 arrays of n + 1 elements (the last receives the total) by one workgroup
+// in-place exclusive scans of up to three int32 arrays of n + 1 elements (the last receives the total) by one workgroup (d may be null)
 __global__ __launch_bounds__(1024) void bam_scan3_kernel(int32_t* __restrict__ a, int32_t* __restrict__ b, int32_t* __restrict__ d, int32_t n)
 {
     __shared__ long long sa[1024], sb[1024], sd[1024];
@@ -240,7 +306,7 @@ __global__ __launch_bounds__(1024) void bam_scan3_kernel(int32_t* __restrict__ a
     __syncthreads();
     for (int32_t start = 0; start < n; start += 1024) {
         const int32_t i = start + (int32_t)threadIdx.x;
-        const long long va = i < n ? a[i] : 0, vb = i < n ? b[i] : 0, vd = i < n ? d[i] : 0;
+        const long long va = i < n ? a[i] : 0, vb = i < n ? b[i] : 0, vd = (d && i < n) ? d[i] : 0;
         sa[threadIdx.x] = va; sb[threadIdx.x] = vb; sd[threadIdx.x] = vd;
         __syncthreads();
         for (int k = 1; k < 1024; k <<= 1) {
@@ -253,31 +319,72 @@ __global__ __launch_bounds__(1024) void bam_scan3_kernel(int32_t* __restrict__ a
         if (i < n) {
             a[i] = (int32_t)(base[0] + sa[threadIdx.x] - va);
             b[i] = (int32_t)(base[1] + sb[threadIdx.x] - vb);
-            d[i] = (int32_t)(base[2] + sd[threadIdx.x] - vd);
+            if (d) d[i] = (int32_t)(base[2] + sd[threadIdx.x] - vd);
         }
         __syncthreads();
         if (threadIdx.x == 1023) { base[0] += sa[1023]; base[1] += sb[1023]; base[2] += sd[1023]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { a[n] = (int32_t)base[0]; b[n] = (int32_t)base[1]; d[n] = (int32_t)base[2]; }
+    if (threadIdx.x == 0) { a[n] = (int32_t)base[0]; b[n] = (int32_t)base[1]; if (d) d[n] = (int32_t)base[2]; }
+}
+
+// the same for one array of 64-bit counts
+__global__ __launch_bounds__(1024) void bam_scan_ll_kernel(long long* __restrict__ a, int32_t n)
+{
+    __shared__ long long sa[1024];
+    __shared__ long long base;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int32_t start = 0; start < n; start += 1024) {
+        const int32_t i = start + (int32_t)threadIdx.x;
+        const long long va = i < n ? a[i] : 0;
+        sa[threadIdx.x] = va;
+        __syncthreads();
+        for (int k = 1; k < 1024; k <<= 1) {
+            long long xa = 0;
+            if ((int)threadIdx.x >= k) xa = sa[threadIdx.x - k];
+            __syncthreads();
+            sa[threadIdx.x] += xa;
+            __syncthreads();
+        }
+        if (i < n) a[i] = base + sa[threadIdx.x] - va;
+        __syncthreads();
+        if (threadIdx.x == 1023) base += sa[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a[n] = base;
 }
 
 // The read batch (the arrays PiscesReadBatch names), in file order.  read0 / op0 / base0: the scanned counts of bam_count_kernel.
 // op_quality[k] bit 0: CheckDeletionQuality at the read index where CIGAR operation k starts (both flanking qualities >= minBQ);
-// read_quality[r] bit 0: the same at the last read base — what the host needs to know which blocks a gap touches without the qualities.
+// read_quality[r] bit 0: the same at the last read base.
+// What pisces_hip_add_reads's host pass would make of the reads is made here as well, so that the batch can go into the handle's log
+// without coming back: slots[r] / fslots[r] (exclusive sums of the reads' log slots and candidate-record slots, span0 / indel0 being
+// the chunks' scanned sums), one bit per 1000-locus block a read touches (GetBlock for every position that receives a count,
+// RegionStateManager.cs:361-383: the aligned segments, and a gap or terminal deletion when CheckDeletionQuality lets it count), and
+// the first read the host pass would have refused (first_error = read index * 8 + code; codes below).
+enum { kBamReadPositionNotPositive = 1, kBamReadCigarLongerThanRead = 2, kBamReadPastInt32 = 3, kBamReadPastBlockMap = 4 };
 __global__ __launch_bounds__(64) void bam_decode_kernel(const uint8_t* __restrict__ s, int64_t n, const long long* __restrict__ entry, BamFilter F,
                                                         const int32_t* __restrict__ read0, const int32_t* __restrict__ op0,
                                                         const int32_t* __restrict__ base0, int32_t* __restrict__ position,
                                                         uint8_t* __restrict__ flags, int32_t* __restrict__ cigar_offset,
                                                         uint8_t* __restrict__ cigar_op, uint32_t* __restrict__ cigar_len,
                                                         int32_t* __restrict__ seq_offset, uint8_t* __restrict__ bases, uint8_t* __restrict__ quals,
-                                                        uint8_t* __restrict__ op_quality, uint8_t* __restrict__ read_quality)
+                                                        uint8_t* __restrict__ op_quality, uint8_t* __restrict__ read_quality,
+                                                        const long long* __restrict__ span0, const int32_t* __restrict__ indel0,
+                                                        long long* __restrict__ slots, int32_t* __restrict__ fslots,
+                                                        uint32_t* __restrict__ block_map, long long n_block_bits,
+                                                        unsigned long long* __restrict__ first_error)
 {
     const int64_t c = blockIdx.x;
     const int lane = threadIdx.x;
     int64_t at = entry[c];
     const int64_t chunk_end = min((c + 1) * (int64_t)kBamChunk, n);
     int r = read0[c], o = op0[c], b = base0[c];
+    long long slot = span0[c];
+    int fslot = indel0[c];
+    long long map_word = -1;      // lane 0: the word of the block map the chunk's reads are setting bits in (reads come sorted: one
+    uint32_t map_bits = 0;        // atomic a word instead of one a read)
     while (at >= 0 && at < chunk_end) {   // (wave-uniform: every lane follows the same chain)
         const int32_t bs = bam_le32(s + at);
         const uint8_t* rec = s + at + 4;
@@ -306,7 +413,25 @@ __global__ __launch_bounds__(64) void bam_decode_kernel(const uint8_t* __restric
                 quals[b + k] = ql[k];
             }
             if (lane == 0) {   // the CIGAR: a handful of operations, with the read index each one starts at
-                int ri = 0;
+                const long long pos1 = (long long)bam_le32(rec + 4) + 1;
+                int code = pos1 <= 0 ? kBamReadPositionNotPositive : 0;
+                auto touch = [&](long long from, long long to) {   // positions [from, to] receive counts
+                    if (to < 1) return;
+                    if (from < 1) from = 1;
+                    for (long long k = (from - 1) / F.block_size; k <= (to - 1) / F.block_size; k++) {
+                        if (k >= n_block_bits) { code = code ? code : kBamReadPastBlockMap; return; }
+                        if ((k >> 5) != map_word) {
+                            if (map_bits) atomicOr(block_map + map_word, map_bits);
+                            map_word = k >> 5;
+                            map_bits = 0;
+                        }
+                        map_bits |= 1u << (k & 31);
+                    }
+                };
+                int ri = 0, indels = 0;
+                long long rp = pos1, last_mapped = pos1 - 1;
+                uint8_t ok_last = 0;
+                uint32_t op_last = 99, len_last = 0, op_before = 99, len_before = 0;
                 for (int k = 0; k < n_cigar; k++) {
                     const uint32_t v = (uint32_t)bam_le32(cig + 4 * k);
                     const uint32_t op = v & 0xFu, len = v >> 4;
@@ -320,8 +445,36 @@ __global__ __launch_bounds__(64) void bam_decode_kernel(const uint8_t* __restric
                         ok = (before >= F.min_base_quality && after >= F.min_base_quality) ? 1 : 0;
                     }
                     op_quality[o + k] = ok;
-                    if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) ri += (int)len;
+                    const bool on_read = op == 0 || op == 1 || op == 4 || op == 7 || op == 8, on_ref = op == 0 || op == 2 || op == 3 || op == 7 || op == 8;
+                    if (!code && on_read && on_ref && len > 0) {
+                        if (rp > last_mapped + 1 && ri < l_seq && ok) touch(last_mapped + 1, rp - 1);   // the gap before this segment
+                        touch(rp, rp + (long long)len - 1);
+                        last_mapped = rp + (long long)len - 1;
+                    }
+                    if (on_ref) rp += (long long)len;
+                    if (on_read) ri += (int)len;
+                    if (op == 1 || op == 2) indels++;
+                    op_before = op_last; len_before = len_last;
+                    op_last = op; len_last = len; ok_last = ok;
                 }
+                if (!code && ri > l_seq) code = kBamReadCigarLongerThanRead;
+                if (!code && rp > 0x7FFFFFFFll) code = kBamReadPastInt32;
+                if (!code) {
+                    // a terminal deletion counts at the anchor of the read's end (RegionStateManager.cs:195-210), a deletion before a
+                    // terminal soft clip likewise
+                    const int lastq = l_seq > 0 ? ql[l_seq - 1] : 0, prevq = l_seq > 1 ? ql[l_seq - 2] : lastq;
+                    const bool end_ok = l_seq > 0 && lastq >= F.min_base_quality && prevq >= F.min_base_quality;
+                    if (op_last == 2 && l_seq > 0 && end_ok) touch(last_mapped + 1, last_mapped + (long long)len_last);
+                    if (n_cigar >= 2 && op_before == 2 && op_last == 4) {
+                        const int idx = l_seq - (int)len_last;
+                        if (idx >= 0 && idx < l_seq && ok_last) touch(last_mapped + 1, last_mapped + (long long)len_before);
+                    }
+                }
+                if (code) atomicMin(first_error, (unsigned long long)r * 8ull + (unsigned long long)code);
+                slots[r] = slot;
+                fslots[r] = fslot;
+                slot += rp - pos1;
+                fslot += indels;
             }
             r++;
             o += n_cigar;
@@ -329,6 +482,7 @@ __global__ __launch_bounds__(64) void bam_decode_kernel(const uint8_t* __restric
         }
         at += 4 + (int64_t)bs;
     }
+    if (lane == 0 && map_bits) atomicOr(block_map + map_word, map_bits);
 }
 
 }  // namespace pisces

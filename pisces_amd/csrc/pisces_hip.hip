@@ -225,7 +225,13 @@ struct PiscesHip {
         DeviceBuf<uint16_t> d_exits;
         DeviceBuf<uint32_t> d_shared_exit;
         DeviceBuf<long long> d_header, d_entry;
-        DeviceBuf<int32_t> d_n_reads, d_n_ops, d_n_bases, d_n_skipped, d_bstatus;
+        DeviceBuf<int32_t> d_n_reads, d_n_ops, d_n_bases, d_n_skipped, d_bstatus, d_n_indels, d_n_pool;
+        DeviceBuf<long long> d_n_span;
+        DeviceBuf<uint32_t> d_block_map;          // one bit per block of the chromosome: a kept read touches it
+        DeviceBuf<unsigned long long> d_first_error;
+        std::vector<uint32_t> block_map;          // its host copy
+        int64_t log_slots = 0, found_slots = 0, found_pool = 0;   // what the batch needs in the log / the candidate records
+        unsigned long long first_error = ~0ull;   // read index * 8 + code of the first read add_reads would refuse (all ones: none)
         // the read batch
         DeviceBuf<int32_t> position, cigar_offset, seq_offset;
         DeviceBuf<uint8_t> flags, cigar_op, bases, quals, op_quality, read_quality;

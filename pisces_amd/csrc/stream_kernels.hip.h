@@ -51,7 +51,8 @@ __device__ __forceinline__ int wave_exclusive_scan(int v, int lane, int* total)
 // lengths, an upper bound that is exact unless a deletion fails its quality test): no atomics on the log — same-address
 // global atomics from 8 XCDs cost ~25-200 ns EACH and were the whole run time of the first version of this kernel.
 // Slots a read does not use are written as position 0 ("hole"), which every consumer skips.
-__global__ __launch_bounds__(256) void expand_reads_kernel(DevReadBatch b, const long long* __restrict__ read_slot, int32_t min_bq,
+// (read_slot[r] + slot_base = the read's first slot in the log: a batch decoded on the device carries slots counted from 0)
+__global__ __launch_bounds__(256) void expand_reads_kernel(DevReadBatch b, const long long* __restrict__ read_slot, long long slot_base, int32_t min_bq,
                                                            int32_t* __restrict__ log_pos, uint32_t* __restrict__ log_tup,
                                                            unsigned long long* __restrict__ appended)
 {
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void expand_reads_kernel(DevReadBatch b, const
         const uint8_t* const quals = b.quals + s0;
         const uint8_t* const bases = b.bases + s0;
         const uint8_t* const dirs = b.dirs ? b.dirs + s0 : nullptr;
-        const long long slot0 = read_slot[r], slot1 = read_slot[r + 1];
+        const long long slot0 = read_slot[r] + slot_base, slot1 = read_slot[r + 1] + slot_base;
         const uint32_t lastAnchor = PISCES_NUM_ANCHORS - 1;
 
         long long w0 = slot0;   // next free slot of this read (wave-uniform)

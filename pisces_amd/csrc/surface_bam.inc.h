@@ -171,29 +171,45 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
     PISCES_HIP_CHECK(h, B.d_n_ops.reserve((size_t)n_chunks + 1));
     PISCES_HIP_CHECK(h, B.d_n_bases.reserve((size_t)n_chunks + 1));
     PISCES_HIP_CHECK(h, B.d_n_skipped.reserve((size_t)n_chunks + 1));
+    PISCES_HIP_CHECK(h, B.d_n_span.reserve((size_t)n_chunks + 1));
+    PISCES_HIP_CHECK(h, B.d_n_indels.reserve((size_t)n_chunks + 1));
+    PISCES_HIP_CHECK(h, B.d_n_pool.reserve((size_t)n_chunks + 1));
+    PISCES_HIP_CHECK(h, B.d_first_error.reserve(1));
     PISCES_HIP_CHECK(h, hipMemsetAsync(B.d_bstatus.p, 0, 4 * sizeof(int32_t), h->stream));
-    const BamFilter F = {ref_id, min_map_quality, skip_duplicates, only_proper_pairs, h->cfg.min_base_call_quality};
-    hipLaunchKernelGGL(bam_header_kernel, dim3(1), dim3(1), 0, h->stream, (const uint8_t*)B.d_stream.p, out_bytes, B.d_header.p);
+    {   // diagnostics: PISCES_HIP_BAM_SERIAL_CHAIN=1 takes the serial hop whatever the guesses say (the two must agree: tests)
+        const char* force = std::getenv("PISCES_HIP_BAM_SERIAL_CHAIN");
+        if (force && force[0] == '1') PISCES_HIP_CHECK(h, hipMemsetAsync(B.d_bstatus.p + 3, 1, 1, h->stream));
+    }
+    const BamFilter F = {ref_id, min_map_quality, skip_duplicates, only_proper_pairs, h->cfg.min_base_call_quality, h->cfg.block_size};
+    hipLaunchKernelGGL(bam_header_kernel, dim3(1), dim3(1), 0, h->stream, (const uint8_t*)B.d_stream.p, out_bytes, B.d_header.p, ref_id);
     hipLaunchKernelGGL(bam_chain_kernel, dim3((unsigned)n_chunks), dim3(1024), 0, h->stream, (const uint8_t*)B.d_stream.p, out_bytes, B.d_exits.p,
                        B.d_shared_exit.p, (const long long*)B.d_header.p);
     // (d_bstatus[3]: some chunk needs the serial hop)
     hipLaunchKernelGGL(bam_entry_guess_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, h->stream, (const uint32_t*)B.d_shared_exit.p,
-                       out_bytes, (const long long*)B.d_header.p, n_chunks, B.d_entry.p, B.d_bstatus.p, B.d_bstatus.p + 3);
+                       (const uint16_t*)B.d_exits.p, out_bytes, (const long long*)B.d_header.p, n_chunks, B.d_entry.p, B.d_bstatus.p, B.d_bstatus.p + 3);
     hipLaunchKernelGGL(bam_entry_check_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, h->stream, (const uint16_t*)B.d_exits.p,
                        out_bytes, (const long long*)B.d_header.p, n_chunks, (const long long*)B.d_entry.p, B.d_bstatus.p + 3);
     hipLaunchKernelGGL(bam_entry_kernel, dim3(1), dim3(1), 0, h->stream, (const uint16_t*)B.d_exits.p, out_bytes, (const long long*)B.d_header.p,
                        n_chunks, B.d_entry.p, B.d_bstatus.p, (const int32_t*)(B.d_bstatus.p + 3));
     hipLaunchKernelGGL(bam_count_kernel, dim3((unsigned)n_chunks), dim3(64), 0, h->stream, (const uint8_t*)B.d_stream.p, out_bytes,
-                       (const long long*)B.d_entry.p, F, B.d_n_reads.p, B.d_n_ops.p, B.d_n_bases.p, B.d_n_skipped.p);
+                       (const long long*)B.d_entry.p, F, B.d_n_reads.p, B.d_n_ops.p, B.d_n_bases.p, B.d_n_skipped.p, B.d_n_span.p, B.d_n_indels.p,
+                       B.d_n_pool.p);
     hipLaunchKernelGGL(bam_scan3_kernel, dim3(1), dim3(1024), 0, h->stream, B.d_n_reads.p, B.d_n_ops.p, B.d_n_bases.p, (int32_t)n_chunks);
+    hipLaunchKernelGGL(bam_scan3_kernel, dim3(1), dim3(1024), 0, h->stream, B.d_n_indels.p, B.d_n_pool.p, (int32_t*)nullptr, (int32_t)n_chunks);
+    hipLaunchKernelGGL(bam_scan_ll_kernel, dim3(1), dim3(1024), 0, h->stream, B.d_n_span.p, (int32_t)n_chunks);
     PISCES_HIP_CHECK(h, hipGetLastError());
     std::vector<int32_t> status((size_t)n_blocks), skipped((size_t)n_chunks);
-    int32_t totals[3] = {0, 0, 0}, bstatus[4] = {0, 0, 0, 0};
+    int32_t totals[5] = {0, 0, 0, 0, 0}, bstatus[4] = {0, 0, 0, 0};
+    long long span_total = 0, header[4] = {0, 0, 0, 0};
     PISCES_HIP_CHECK(h, hipMemcpyAsync(status.data(), B.d_status.p, status.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipMemcpyAsync(skipped.data(), B.d_n_skipped.p, skipped.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipMemcpyAsync(&totals[0], B.d_n_reads.p + n_chunks, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipMemcpyAsync(&totals[1], B.d_n_ops.p + n_chunks, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipMemcpyAsync(&totals[2], B.d_n_bases.p + n_chunks, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(&totals[3], B.d_n_indels.p + n_chunks, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(&totals[4], B.d_n_pool.p + n_chunks, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(&span_total, B.d_n_span.p + n_chunks, sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(header, B.d_header.p, sizeof(header), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipMemcpyAsync(bstatus, B.d_bstatus.p, sizeof(bstatus), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     for (int64_t i = 0; i < n_blocks; i++)
@@ -205,6 +221,7 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
                                                  " (corrupt block_size, or a record longer than 32 KiB)");
     B.chain_mode = bstatus[3] != 0 ? 1 : 0;
     B.n_reads = totals[0]; B.n_ops = totals[1]; B.n_bases = totals[2];
+    B.found_slots = totals[3]; B.found_pool = totals[4]; B.log_slots = span_total;
     B.n_skipped = 0;
     for (int32_t v : skipped) B.n_skipped += v;
     B.min_bq = h->cfg.min_base_call_quality;
@@ -214,15 +231,31 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
     PISCES_HIP_CHECK(h, B.read_quality.reserve(nr + 1));
     PISCES_HIP_CHECK(h, B.cigar_op.reserve(no + 1)); PISCES_HIP_CHECK(h, B.cigar_len.reserve(no + 1)); PISCES_HIP_CHECK(h, B.op_quality.reserve(no + 1));
     PISCES_HIP_CHECK(h, B.bases.reserve(nb + 16)); PISCES_HIP_CHECK(h, B.quals.reserve(nb + 16));
+    PISCES_HIP_CHECK(h, B.d_slots.reserve(nr + 1)); PISCES_HIP_CHECK(h, B.d_fslots.reserve(nr + 1));
+    // the blocks of the chromosome (its length from the header, and room for reads that hang over its end), one bit each
+    const long long l_ref = std::min<long long>(std::max<long long>(header[3], 0), 0x7FFFFFFFll);
+    const long long n_block_bits = std::min<long long>(l_ref + 70000, 0x7FFFFFFFll - h->cfg.block_size) / h->cfg.block_size + 1;
+    const size_t map_words = (size_t)((n_block_bits + 31) / 32);
+    PISCES_HIP_CHECK(h, B.d_block_map.reserve(map_words));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(B.d_block_map.p, 0, map_words * sizeof(uint32_t), h->stream));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(B.d_first_error.p, 0xFF, sizeof(unsigned long long), h->stream));
     if (nr > 0)
         hipLaunchKernelGGL(bam_decode_kernel, dim3((unsigned)n_chunks), dim3(64), 0, h->stream, (const uint8_t*)B.d_stream.p, out_bytes,
                            (const long long*)B.d_entry.p, F, (const int32_t*)B.d_n_reads.p, (const int32_t*)B.d_n_ops.p, (const int32_t*)B.d_n_bases.p,
                            B.position.p, B.flags.p, B.cigar_offset.p, B.cigar_op.p, B.cigar_len.p, B.seq_offset.p, B.bases.p, B.quals.p,
-                           B.op_quality.p, B.read_quality.p);
+                           B.op_quality.p, B.read_quality.p, (const long long*)B.d_n_span.p, (const int32_t*)B.d_n_indels.p, B.d_slots.p,
+                           B.d_fslots.p, B.d_block_map.p, n_block_bits, B.d_first_error.p);
     // the closing offsets
-    const int32_t end_ops = (int32_t)no, end_bases = (int32_t)nb;
+    const int32_t end_ops = (int32_t)no, end_bases = (int32_t)nb, end_fslots = (int32_t)B.found_slots;
+    const long long end_slots = B.log_slots;
     PISCES_HIP_CHECK(h, hipMemcpyAsync(B.cigar_offset.p + nr, &end_ops, sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     PISCES_HIP_CHECK(h, hipMemcpyAsync(B.seq_offset.p + nr, &end_bases, sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(B.d_fslots.p + nr, &end_fslots, sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(B.d_slots.p + nr, &end_slots, sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    B.block_map.assign(map_words, 0u);
+    B.first_error = ~0ull;
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(B.block_map.data(), B.d_block_map.p, map_words * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(&B.first_error, B.d_first_error.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipGetLastError());
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     B.valid = true;
@@ -265,9 +298,10 @@ int32_t pisces_hip_bam_fetch(PiscesHip* h, int32_t* position, uint8_t* flags, in
     });
 }
 
-// IStateManager.AddAlleleCounts + FindCandidates for the decoded batch: the bases and qualities stay on the device; the host sees
-// only positions and CIGARs (about 20 bytes per read), from which it makes what pisces_hip_add_reads makes from its own pass
-// (log slots, candidate-record slots, the blocks every read touches).
+// IStateManager.AddAlleleCounts + FindCandidates for the decoded batch: nothing of it comes back to the host.  What pisces_hip_add_reads
+// takes from a pass over the reads' CIGARs (log slots, candidate-record slots, the blocks every read touches, the reads it refuses)
+// the decode kernel has made where the reads are; the host creates the blocks from a bit map and enqueues the read walk and the
+// candidate discovery.
 int32_t pisces_hip_add_decoded_reads(PiscesHip* h)
 {
     return abi_guard<int32_t>(h, [&]() -> int32_t {
@@ -280,99 +314,37 @@ int32_t pisces_hip_add_decoded_reads(PiscesHip* h)
     if (nr == 0) return PISCES_OK;
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     { int32_t rcf = consume_found(h); if (rcf) return rcf; }
-    const size_t no = (size_t)B.n_ops;
-    std::vector<int32_t> position((size_t)nr), coff((size_t)nr + 1), soff((size_t)nr + 1);
-    std::vector<uint8_t> cop(no), opq(no), rq((size_t)nr);
-    std::vector<uint32_t> clen(no);
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(position.data(), B.position.p, (size_t)nr * 4, hipMemcpyDeviceToHost, h->stream));
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(coff.data(), B.cigar_offset.p, ((size_t)nr + 1) * 4, hipMemcpyDeviceToHost, h->stream));
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(soff.data(), B.seq_offset.p, ((size_t)nr + 1) * 4, hipMemcpyDeviceToHost, h->stream));
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(cop.data(), B.cigar_op.p, no, hipMemcpyDeviceToHost, h->stream));
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(clen.data(), B.cigar_len.p, no * 4, hipMemcpyDeviceToHost, h->stream));
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(opq.data(), B.op_quality.p, no, hipMemcpyDeviceToHost, h->stream));
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(rq.data(), B.read_quality.p, (size_t)nr, hipMemcpyDeviceToHost, h->stream));
-    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
-    auto op_ref = [](uint8_t t) { return t == 'M' || t == 'D' || t == 'N' || t == '=' || t == 'X'; };
-    auto op_read = [](uint8_t t) { return t == 'M' || t == 'I' || t == 'S' || t == '=' || t == 'X'; };
-    const bool find_on_device = !h->h_ref.empty();
-    std::vector<long long>& slots = h->read_slots;
-    std::vector<int32_t>& fslots = h->found_slots_host;
-    slots.resize((size_t)nr + 1);
-    fslots.assign((size_t)nr + 1, 0);
-    int64_t ub = 0, found_slots = 0, found_pool = 0;
-    for (int32_t i = 0; i < nr; i++) {
-        const int c0 = coff[(size_t)i], nc = coff[(size_t)i + 1] - c0, read_len = soff[(size_t)i + 1] - soff[(size_t)i];
-        const uint8_t* ops = cop.data() + c0;
-        const uint32_t* lens = clen.data() + c0;
-        const uint8_t* oq = opq.data() + c0;
-        slots[(size_t)i] = (long long)(h->log_ub + ub);
-        fslots[(size_t)i] = (int32_t)found_slots;
-        if (position[(size_t)i] <= 0) return fail(h, PISCES_E_INVALID_ARG, "Position must be greater than 0.");
-        int64_t read_span = 0, ref_span = 0;
-        for (int c = 0; c < nc; c++) {
-            if (lens[c] > 0x0FFFFFFFu) return fail(h, PISCES_E_INVALID_ARG, "add_decoded_reads: CIGAR operation longer than 2^28 - 1");
-            if (op_read(ops[c])) read_span += lens[c];
-            if (op_ref(ops[c])) ref_span += lens[c];
-            if (find_on_device && !h->cfg.call_mnvs) {
-                if (ops[c] == 'I' || ops[c] == 'D') found_slots++;
-                if (ops[c] == 'I' && lens[c] > (uint32_t)kFoundInline) found_pool += lens[c];
-            }
+    if (B.first_error != ~0ull) {
+        const std::string read = " (read " + std::to_string((long long)(B.first_error >> 3)) + " of the decoded batch)";
+        switch ((int)(B.first_error & 7ull)) {
+            case kBamReadPositionNotPositive: return fail(h, PISCES_E_INVALID_ARG, "Position must be greater than 0." + read);
+            case kBamReadCigarLongerThanRead: return fail(h, PISCES_E_INVALID_ARG, "add_decoded_reads: CIGAR does not match the read" + read);
+            case kBamReadPastInt32: return fail(h, PISCES_E_INVALID_ARG, "add_decoded_reads: read runs past position 2^31 - 1" + read);
+            default: return fail(h, PISCES_E_INVALID_ARG, "add_decoded_reads: read runs far past the end of its reference sequence" + read);
         }
-        if (read_span > read_len) return fail(h, PISCES_E_INVALID_ARG, "add_decoded_reads: CIGAR does not match the read");
-        if ((int64_t)position[(size_t)i] + ref_span > 0x7FFFFFFFll) return fail(h, PISCES_E_INVALID_ARG, "add_decoded_reads: read runs past position 2^31 - 1");
-        ub += ref_span;
-        // the blocks the read touches (GetBlock for every position that receives a count, RegionStateManager.cs:361-383), as in
-        // pisces_hip_add_reads, with CheckDeletionQuality taken from the bits the decode kernel left
-        auto touch = [&](int64_t from, int64_t to) {
-            if (to < 1) return;
-            if (from < 1) from = 1;
-            for (int32_t k = block_key(h, (int32_t)from); k <= block_key(h, (int32_t)to); k++) (void)get_block(h, (k - 1) * h->cfg.block_size + 1);
-        };
-        int64_t rp = position[(size_t)i], last_mapped = (int64_t)position[(size_t)i] - 1;
-        int ri = 0;
-        for (int c = 0; c < nc; c++) {
-            const uint8_t t = ops[c];
-            const int64_t len = lens[c];
-            if (op_read(t) && op_ref(t) && len > 0) {
-                if (rp > last_mapped + 1 && ri < read_len && oq[c]) touch(last_mapped + 1, rp - 1);
-                touch(rp, rp + len - 1);
-                last_mapped = rp + len - 1;
-            }
-            if (op_ref(t)) rp += len;
-            if (op_read(t)) ri += (int)len;
-        }
-        const bool ends_del = nc >= 1 && ops[nc - 1] == 'D';
-        const bool ends_del_soft = nc >= 2 && ops[nc - 2] == 'D' && ops[nc - 1] == 'S';
-        if (ends_del && read_len > 0 && rq[(size_t)i]) touch(last_mapped + 1, last_mapped + lens[nc - 1]);
-        if (ends_del_soft) {
-            const int idx = read_len - (int)lens[nc - 1];
-            if (idx >= 0 && idx < read_len && oq[nc - 1]) touch(last_mapped + 1, last_mapped + lens[nc - 2]);
-        }
-        h->stats[2] += 1;
     }
-    slots[(size_t)nr] = (long long)(h->log_ub + ub);
-    fslots[(size_t)nr] = (int32_t)found_slots;
+    const bool find_on_device = !h->h_ref.empty();
+    const int64_t found_slots = (find_on_device && !h->cfg.call_mnvs) ? B.found_slots : 0, found_pool = (find_on_device && !h->cfg.call_mnvs) ? B.found_pool : 0;
     if (found_slots > 0x7FFFFFF0ll || found_pool > 0x7FFFFFF0ll) return fail(h, PISCES_E_INVALID_ARG, "add_decoded_reads: too many insertions / deletions in one batch");
-    int32_t rc = log_reserve(h, ub);
+    // the blocks the reads touch (GetBlock, RegionStateManager.cs:361-383)
+    for (size_t w = 0; w < B.block_map.size(); w++)
+        for (uint32_t bits = B.block_map[w]; bits; bits &= bits - 1)
+            (void)get_block(h, (int32_t)(((int64_t)w * 32 + __builtin_ctz(bits)) * h->cfg.block_size + 1));
+    h->stats[2] += nr;
+    int32_t rc = log_reserve(h, B.log_slots);
     if (rc) return rc;
-    PISCES_HIP_CHECK(h, B.d_slots.reserve((size_t)nr + 1));
-    PISCES_HIP_CHECK(h, B.d_fslots.reserve((size_t)nr + 1));
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(B.d_slots.p, slots.data(), ((size_t)nr + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream));
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(B.d_fslots.p, fslots.data(), ((size_t)nr + 1) * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     DevReadBatch db;
     db.position = B.position.p; db.flags = B.flags.p; db.cigar_offset = B.cigar_offset.p; db.cigar_op = B.cigar_op.p; db.cigar_len = B.cigar_len.p;
     db.seq_offset = B.seq_offset.p; db.bases = B.bases.p; db.quals = B.quals.p; db.dirs = nullptr; db.n_reads = nr;
     const int c = h->log_cur;
     hipLaunchKernelGGL(expand_reads_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, h->stream, db, (const long long*)B.d_slots.p,
-                       h->cfg.min_base_call_quality, h->d_log_pos[c].p, h->d_log_tup[c].p, h->d_log_n.p + 2);
+                       (long long)h->log_ub, h->cfg.min_base_call_quality, h->d_log_pos[c].p, h->d_log_tup[c].p, h->d_log_n.p + 2);
     PISCES_HIP_CHECK(h, hipGetLastError());
     if (find_on_device && (h->cfg.call_mnvs || found_slots > 0)) {
         int32_t rcd = enqueue_candidate_discovery(h, db, nullptr, nr, (const int32_t*)B.d_fslots.p, found_slots, found_pool);
         if (rcd) return rcd;
     }
-    // slots / fslots on the host are reused by the next call: the copies above must have left first
-    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
-    h->log_ub += ub;
+    h->log_ub += B.log_slots;
     return PISCES_OK;
     });
 }

@@ -552,7 +552,7 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
     db.dirs = batch->directions ? d + off_dirs : nullptr;
     db.n_reads = nr;
     const int c = h->log_cur;
-    hipLaunchKernelGGL(expand_reads_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, h->stream, db, (const long long*)(d + off_slots),
+    hipLaunchKernelGGL(expand_reads_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, h->stream, db, (const long long*)(d + off_slots), 0ll,
                        minBQ, h->d_log_pos[c].p, h->d_log_tup[c].p, h->d_log_n.p + 2);
     PISCES_HIP_CHECK(h, hipGetLastError());
     if (find_on_device && (h->cfg.call_mnvs || found_slots > 0)) {

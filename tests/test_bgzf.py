@@ -308,12 +308,19 @@ def test_record_chain_is_cut_the_same_with_guessed_and_with_hopped_entries(case)
     refs, reads = _bam_reads_reference(data)
     keep = _kept(reads, "chr1")
     assert len(keep) == len(lens)
-    with engine.HipVariantCaller(_abi.default_config()) as c:
-        counts = c.bam_decode(data, 0)
-        assert counts["reads"] == len(keep)
-        assert counts["chain"] == ("guessed" if case in ("short_records", "long_header", "last_record_straddles") else "hopped"), counts
-        got = c.bam_fetch()
-    np.testing.assert_array_equal(got["position"], np.array([r["pos"] for r in keep], np.int32))
-    np.testing.assert_array_equal(got["seq_offset"], np.cumsum([0] + [len(r["seq"]) for r in keep]).astype(np.int32))
-    assert got["bases"].tobytes() == "".join(r["seq"] for r in keep).encode()
-    assert got["quals"].tobytes() == b"".join(r["qual"].tobytes() for r in keep)
+    modes = []
+    for force in ("0", "1"):
+        os.environ["PISCES_HIP_BAM_SERIAL_CHAIN"] = force
+        try:
+            with engine.HipVariantCaller(_abi.default_config()) as c:
+                counts = c.bam_decode(data, 0)
+                assert counts["reads"] == len(keep)
+                modes.append(counts["chain"])
+                got = c.bam_fetch()
+        finally:
+            os.environ.pop("PISCES_HIP_BAM_SERIAL_CHAIN", None)
+        np.testing.assert_array_equal(got["position"], np.array([r["pos"] for r in keep], np.int32))
+        np.testing.assert_array_equal(got["seq_offset"], np.cumsum([0] + [len(r["seq"]) for r in keep]).astype(np.int32))
+        assert got["bases"].tobytes() == "".join(r["seq"] for r in keep).encode()
+        assert got["quals"].tobytes() == b"".join(r["qual"].tobytes() for r in keep)
+    assert modes[1] == "hopped" and (modes[0] == "guessed" or case in ("long_records", "mixed")), modes

@@ -29,7 +29,7 @@ def main():
             recs = c.Call(None, capacity=1 << 20, reuse_buffer=True)
             t4 = time.perf_counter()
             print(f"rep {rep}: {n_reads} reads, {len(stream)/1e6:.0f} MB from {len(data)/1e6:.0f} MB: scan {1e3*(t1-t0):.2f} ms, bam_decode (incl. its own scan) "
-                  f"{1e3*(t2-t1):.2f} ms, add_decoded_reads {1e3*(t3-t2):.2f} ms, flush {1e3*(t4-t3):.2f} ms ({len(recs)} records)", flush=True)
+                  f"{1e3*(t2-t1):.2f} ms, add_decoded_reads {1e3*(t3-t2):.2f} ms, flush {1e3*(t4-t3):.2f} ms ({len(recs)} records; record chain {counts['chain']})", flush=True)
         assert counts["reads"] == n_reads
 
 
