@@ -194,6 +194,8 @@ struct PiscesHip {
     int bucket_host_next = 0;
     uint64_t uploads_since_sync = 0;
     uint8_t* h_dl = nullptr;                 // pinned download buffer of flush
+    const PiscesCalledAllele* pending_view = nullptr;   // the pending records when they are the download buffer's as they came (no host-side
+    size_t pending_view_n = 0;                          // candidates, genotyper or forced alleles to merge in): no copy into `pending`
     // pinned arena of the small uploads of a flush (bucket tables, tile geometry, gapped-MNV counts): a copy from pageable memory makes
     // the host wait until the stream has caught up, i.e. it serialises the flush's enqueueing with the device; from pinned memory it is
     // asynchronous.  Bump-allocated, rewound when the stream is known to be idle (every flush ends with a synchronisation).

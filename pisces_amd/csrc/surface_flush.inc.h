@@ -199,10 +199,14 @@ static void launch_compaction(hipStream_t s, const PiscesCalledAllele* d_records
 }
 
 // device work of one flush: returns called alleles of `keys` sorted by (position, ref, alt)
+// as_view: the records are not copied into `out`; h->pending_view points at them in the pinned download buffer (valid until the next
+// call_blocks)
 static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::vector<PiscesCalledAllele>& out, int64_t* n_called,
-                           bool with_drop = false, bool* dropped = nullptr, unsigned long long* kept = nullptr)
+                           bool with_drop = false, bool* dropped = nullptr, unsigned long long* kept = nullptr, bool as_view = false)
 {
     out.clear();   // (*n_called accumulates: the caller zeroes it)
+    h->pending_view = nullptr;
+    h->pending_view_n = 0;
     if (dropped) *dropped = false;
     if (keys.empty()) return PISCES_OK;
     if (!h->d_ref.p) return fail(h, PISCES_E_STATE, "flush: set_reference has not been called");
@@ -285,7 +289,8 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
                                            hipMemcpyDeviceToHost, h->stream));
         PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     }
-    out.assign(hrec, hrec + total);
+    if (as_view) { h->pending_view = hrec; h->pending_view_n = (size_t)total; }
+    else out.assign(hrec, hrec + total);
     return PISCES_OK;
 }
 
@@ -927,7 +932,10 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
         h->pending_collapsed = collapsed;
         if (rc) return rc;
         h->pending_dropped = false;
-        rc = call_blocks(h, keys, point_recs, &called, true, &h->pending_dropped, &h->pending_kept);
+        const bool diploid = h->cfg.ploidy == PISCES_PLOIDY_DIPLOID || h->cfg.ploidy == PISCES_PLOIDY_HAPLOID;   // per-locus genotypers
+        // nothing to merge into the tile kernels' records: they go from the download buffer straight to the caller
+        const bool plain = span_recs.empty() && !diploid && h->forced.empty() && ref_overrides.empty();
+        rc = call_blocks(h, keys, point_recs, &called, true, &h->pending_dropped, &h->pending_kept, plain);
         if (rc) return rc;
         if (!ref_overrides.empty()) {   // Reference alleles that MNV reallocation added support to
             std::map<int32_t, const PiscesCalledAllele*> by_pos;
@@ -947,8 +955,9 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
         h->pending.clear();
         h->pending_cand_index.clear();
         h->pending_cands = span_cands;
-        const bool diploid = h->cfg.ploidy == PISCES_PLOIDY_DIPLOID || h->cfg.ploidy == PISCES_PLOIDY_HAPLOID;   // per-locus genotypers
-        if (span_recs.empty() && !diploid && h->forced.empty()) {
+        if (plain) {
+            h->pending_cand_index.assign(h->pending_view_n, -1);
+        } else if (span_recs.empty() && !diploid && h->forced.empty()) {
             h->pending = std::move(point_recs);
             h->pending_cand_index.assign(h->pending.size(), -1);
         } else {
@@ -1064,12 +1073,14 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
     if (n_cand) *n_cand = (int64_t)h->pending_cands.size();
     if (allele_bytes) *allele_bytes = pool_bytes;
     const bool cand_too_small = cand_out && ((int64_t)h->pending_cands.size() > cand_capacity || (alleles_out && pool_bytes > allele_capacity));
-    if ((int64_t)h->pending.size() > capacity || cand_too_small) {
-        *n_out = (int64_t)h->pending.size();
+    const PiscesCalledAllele* const pending_data = h->pending_view ? h->pending_view : h->pending.data();
+    const size_t pending_n = h->pending_view ? h->pending_view_n : h->pending.size();
+    if ((int64_t)pending_n > capacity || cand_too_small) {
+        *n_out = (int64_t)pending_n;
         return fail(h, PISCES_E_BUFFER_TOO_SMALL, "flush: output buffer too small");
     }
-    if (!h->pending.empty()) std::memcpy(out, h->pending.data(), h->pending.size() * sizeof(PiscesCalledAllele));
-    if (cand_index_out && !h->pending.empty()) std::memcpy(cand_index_out, h->pending_cand_index.data(), h->pending.size() * sizeof(int32_t));
+    if (pending_n) std::memcpy(out, pending_data, pending_n * sizeof(PiscesCalledAllele));
+    if (cand_index_out && pending_n) std::memcpy(cand_index_out, h->pending_cand_index.data(), pending_n * sizeof(int32_t));
     if (cand_out) {
         int64_t off = 0;
         for (size_t i = 0; i < h->pending_cands.size(); i++) {
@@ -1088,7 +1099,7 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
             off += (int64_t)(c.ref.size() + c.alt.size());
         }
     }
-    *n_out = (int64_t)h->pending.size();
+    *n_out = (int64_t)pending_n;
     // DoneProcessing (RegionStateManager.cs:336-353): the log entries of the flushed blocks left with call_blocks' submission when
     // there was one; what remains is to make that buffer the log
     if (h->pending_dropped) {
@@ -1109,6 +1120,8 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
     h->stats[1] += h->pending_collapsed;
     h->last_up_to_block_key = final_flush ? -1 : block_key(h, up_to_position);
     h->pending_valid = false;
+    h->pending_view = nullptr;
+    h->pending_view_n = 0;
     h->pending.clear();
     h->pending_cand_index.clear();
     h->pending_cands.clear();
