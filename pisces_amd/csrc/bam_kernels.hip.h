@@ -252,7 +252,8 @@ __device__ __forceinline__ BamCigarSums bam_cigar_sums(const uint8_t* __restrict
 __global__ __launch_bounds__(64) void bam_count_kernel(const uint8_t* __restrict__ s, int64_t n, const long long* __restrict__ entry,
                                                        BamFilter F, int32_t* __restrict__ n_reads, int32_t* __restrict__ n_ops,
                                                        int32_t* __restrict__ n_bases, int32_t* __restrict__ n_skipped,
-                                                       long long* __restrict__ n_span, int32_t* __restrict__ n_indels, int32_t* __restrict__ n_pool)
+                                                       long long* __restrict__ n_span, int32_t* __restrict__ n_indels, int32_t* __restrict__ n_pool,
+                                                       int32_t* __restrict__ status)
 {
     __shared__ int32_t rec_at[kBamChunk / (4 + kBamMinRecord) + 2];   // relative to the chunk's first byte
     __shared__ int32_t n_rec_s;
@@ -273,6 +274,15 @@ __global__ __launch_bounds__(64) void bam_count_kernel(const uint8_t* __restrict
     long long span = 0;
     for (int i = threadIdx.x; i < n_rec; i += 64) {
         const uint8_t* rec = s + c0 + rec_at[i] + 4;
+        {
+            // a record must hold what its own fields announce (name, CIGAR, packed bases, qualities): everything behind this kernel
+            // reads those arrays by these lengths
+            const long long bs = bam_le32(rec - 4), l_seq = bam_le32(rec + 16);
+            if (l_seq < 0 || rec[8] < 1 || 32ll + rec[8] + 4ll * (long long)bam_le16(rec + 12) + (l_seq + 1) / 2 + l_seq > bs) {
+                if (atomicCAS(status, 0, 4) == 0) status[1] = (int32_t)c;
+                continue;
+            }
+        }
         if (bam_keep(rec, F)) {
             const int n_cigar = (int)bam_le16(rec + 12);
             reads++;

@@ -193,7 +193,7 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
                        n_chunks, B.d_entry.p, B.d_bstatus.p, (const int32_t*)(B.d_bstatus.p + 3));
     hipLaunchKernelGGL(bam_count_kernel, dim3((unsigned)n_chunks), dim3(64), 0, h->stream, (const uint8_t*)B.d_stream.p, out_bytes,
                        (const long long*)B.d_entry.p, F, B.d_n_reads.p, B.d_n_ops.p, B.d_n_bases.p, B.d_n_skipped.p, B.d_n_span.p, B.d_n_indels.p,
-                       B.d_n_pool.p);
+                       B.d_n_pool.p, B.d_bstatus.p);
     hipLaunchKernelGGL(bam_scan3_kernel, dim3(1), dim3(1024), 0, h->stream, B.d_n_reads.p, B.d_n_ops.p, B.d_n_bases.p, (int32_t)n_chunks);
     hipLaunchKernelGGL(bam_scan3_kernel, dim3(1), dim3(1024), 0, h->stream, B.d_n_indels.p, B.d_n_pool.p, (int32_t*)nullptr, (int32_t)n_chunks);
     hipLaunchKernelGGL(bam_scan_ll_kernel, dim3(1), dim3(1024), 0, h->stream, B.d_n_span.p, (int32_t)n_chunks);
@@ -216,6 +216,8 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
         if (status[(size_t)i] != 0)
             return fail(h, PISCES_E_INVALID_ARG, "bam_decode: block " + std::to_string(i) + " is not a valid DEFLATE stream of its ISIZE");
     if (bstatus[0] == 1) return fail(h, PISCES_E_INVALID_ARG, "bam_decode: not a BAM stream (magic / header)");
+    if (bstatus[0] == 4)
+        return fail(h, PISCES_E_INVALID_ARG, "bam_decode: a record in chunk " + std::to_string(bstatus[1]) + " is shorter than its name, CIGAR and bases");
     if (bstatus[0] != 0)
         return fail(h, PISCES_E_INVALID_ARG, "bam_decode: the record chain breaks in chunk " + std::to_string(bstatus[1]) +
                                                  " (corrupt block_size, or a record longer than 32 KiB)");

@@ -324,3 +324,47 @@ def test_record_chain_is_cut_the_same_with_guessed_and_with_hopped_entries(case)
         assert got["bases"].tobytes() == "".join(r["seq"] for r in keep).encode()
         assert got["quals"].tobytes() == b"".join(r["qual"].tobytes() for r in keep)
     assert modes[1] == "hopped" and (modes[0] == "guessed" or case in ("long_records", "mixed")), modes
+
+
+@pytest.mark.gpu
+def test_bam_decode_survives_corrupted_records():
+    """Bytes of the inflated BAM stream overwritten at random (block sizes, field lengths, CIGAR counts): pisces_hip_bam_decode either
+    refuses the stream with a message, or gives the reads a plain host reader makes of the same bytes — it never reads outside the
+    stream (a record must hold what its fields announce before any kernel takes its arrays by those lengths)."""
+    import torch
+    assert torch.cuda.is_available()
+    rng = np.random.default_rng(23)
+    good = _synthetic_bam([150] * 400 + [36, 5000, 151] * 20)
+    refused = same = 0
+    with engine.HipVariantCaller(_abi.default_config()) as c:
+        for trial in range(80):
+            bad = bytearray(good)
+            for _ in range(int(rng.integers(1, 4))):
+                at = int(rng.integers(60, len(bad) - 8))
+                kind = trial % 4
+                if kind == 0:
+                    bad[at] = int(rng.integers(0, 256))
+                elif kind == 1:
+                    bad[at:at + 4] = struct.pack("<i", int(rng.integers(-5, 70000)))
+                elif kind == 2:
+                    bad[at:at + 4] = struct.pack("<I", int(rng.integers(0, 2**32)))
+                else:
+                    bad[at:at + 2] = struct.pack("<H", int(rng.integers(0, 65536)))
+            stream = bytes(bad)
+            data = make_bgzf([stream[i:i + 60000] for i in range(0, len(stream), 60000)])
+            try:
+                counts = c.bam_decode(data, 0)
+            except engine.PiscesHipError as e:
+                assert "bam_decode" in str(e)
+                refused += 1
+                continue
+            got = c.bam_fetch()
+            try:
+                refs, reads = _bam_reads_reference(data)
+                keep = _kept(reads, "chr1")
+            except Exception:
+                continue   # the plain reader gave up on a stream the device took: nothing to compare with
+            if counts["reads"] == len(keep):
+                np.testing.assert_array_equal(got["position"], np.array([r["pos"] for r in keep], np.int32))
+                same += 1
+    assert refused + same > 40 and same > 5, (refused, same)
