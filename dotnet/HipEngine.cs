@@ -167,18 +167,18 @@ namespace Pisces.Hip
                 _referenceSet = true;
             }
             if (_pos.Count == 0) return;
-            int[] pos = _pos.ToArray(), cigOff = _cigOff.ToArray(), seqOff = _seqOff.ToArray();
-            byte[] flags = _flags.ToArray(), cigOp = _cigOp.ToArray(), bases = _bases.ToArray(), quals = _quals.ToArray(), dirs = _dirs.ToArray(), delDirs = _delDirs.ToArray();
-            uint[] cigLen = _cigLen.ToArray();
-            fixed (int* pPos = pos, pCo = cigOff, pSo = seqOff)
-            fixed (byte* pF = flags, pOp = cigOp, pB = bases, pQ = quals, pD = dirs, pDd = delDirs)
-            fixed (uint* pLen = cigLen)
-            {
-                var b = new PiscesReadBatch { NReads = pos.Length, Position = pPos, Flags = pF, CigarOffset = pCo, CigarOp = pOp, CigarLen = pLen,
-                                              SeqOffset = pSo, Bases = pB, Quals = pQ, Directions = _anyStitched ? pD : null,
-                                              DeletionDirections = _anyDelDirs ? pDd : null };
-                NativeMethods.Check(_h, NativeMethods.pisces_hip_add_reads(_h, ref b));
-            }
+            // the staged lists go straight into the library's pinned staging buffer (pisces_hip_stage_reads): one copy, the one a managed
+            // host has to make anyway, and pisces_hip_add_reads sends the batch as it lies
+            var v = new PiscesReadBatch();
+            NativeMethods.Check(_h, NativeMethods.pisces_hip_stage_reads(_h, _pos.Count, _cigOp.Count, _bases.Count, _anyStitched ? 1 : 0, _anyDelDirs ? 1 : 0, ref v));
+            for (int i = 0; i < _pos.Count; i++) { v.Position[i] = _pos[i]; v.Flags[i] = _flags[i]; }
+            for (int i = 0; i < _cigOff.Count; i++) v.CigarOffset[i] = _cigOff[i];
+            for (int i = 0; i < _seqOff.Count; i++) v.SeqOffset[i] = _seqOff[i];
+            for (int i = 0; i < _cigOp.Count; i++) { v.CigarOp[i] = _cigOp[i]; v.CigarLen[i] = _cigLen[i]; }
+            for (int i = 0; i < _bases.Count; i++) { v.Bases[i] = _bases[i]; v.Quals[i] = _quals[i]; }
+            if (_anyStitched) for (int i = 0; i < _dirs.Count; i++) v.Directions[i] = _dirs[i];
+            if (_anyDelDirs) for (int i = 0; i < _delDirs.Count; i++) v.DeletionDirections[i] = _delDirs[i];
+            NativeMethods.Check(_h, NativeMethods.pisces_hip_add_reads(_h, ref v));
             _pos.Clear(); _flags.Clear(); _cigOp.Clear(); _cigLen.Clear(); _bases.Clear(); _quals.Clear(); _dirs.Clear(); _delDirs.Clear(); _anyDelDirs = false;
             _cigOff.Clear(); _cigOff.Add(0); _seqOff.Clear(); _seqOff.Add(0); _anyStitched = false;
         }

@@ -96,6 +96,8 @@ namespace Pisces.Hip
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_set_reference(IntPtr handle, byte[] upperBases, long length);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_set_intervals(IntPtr handle, int[] starts, int[] ends, int n);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_add_reads(IntPtr handle, ref PiscesReadBatch batch);
+        /// the arrays of a batch inside the handle's pinned staging buffer: fill them, then pisces_hip_add_reads(views) sends them as they lie
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_stage_reads(IntPtr handle, int nReads, long nCigarOps, long nBases, int withDirections, int withDeletionDirections, ref PiscesReadBatch views);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_flush(IntPtr handle, int upToPosition, [Out] PiscesCalledAllele[] output, long capacity, out long nOut);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_flush_ex(IntPtr handle, int upToPosition, [Out] PiscesCalledAllele[] output, long capacity, out long nOut, [Out] int[] candIndex, [Out] PiscesCandidate[] cands, long candCapacity, out long nCand, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_get_candidates(IntPtr handle, int upToPosition, [Out] PiscesCandidate[] cands, long capacity, out long nOut, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);

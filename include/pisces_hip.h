@@ -280,6 +280,14 @@ int32_t pisces_hip_set_intervals(PiscesHip* h, const int32_t* starts, const int3
  * (needs set_reference first; without a reference only the AddAlleleCounts half runs).  The whole batch is checked
  * before any of it is committed. */
 int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch);
+/* The arrays of a batch of n_reads reads (n_cigar_ops CIGAR operations, n_bases bases in all) inside the handle's pinned staging
+ * buffer: `views` receives pointers the caller may WRITE through (the const of PiscesReadBatch's members is for add_reads).  A host
+ * that marshals its reads anyway (the C# shim packs Read objects into arrays) fills them -- cigar_offset[n_reads] and
+ * seq_offset[n_reads] included -- and hands `views` to pisces_hip_add_reads, which then sends the batch as it lies instead of
+ * copying it into that buffer first (the copy is the larger part of pisces_hip_add_reads for a large batch).  The views are valid
+ * until the next call on the handle that is not pisces_hip_add_reads(views). */
+int32_t pisces_hip_stage_reads(PiscesHip* h, int32_t n_reads, int64_t n_cigar_ops, int64_t n_bases, int32_t with_directions,
+                               int32_t with_deletion_directions, PiscesReadBatch* views);
 /* Pre-expanded observations for the block grid: positions[i] is the 1-based locus of tuples[i]
  * (the tuple's locus field is ignored). */
 int32_t pisces_hip_add_observations(PiscesHip* h, const int32_t* positions, const uint32_t* tuples, int64_t n);

@@ -193,6 +193,7 @@ struct PiscesHip {
     std::vector<int32_t> bucket_host[4];
     int bucket_host_next = 0;
     uint64_t uploads_since_sync = 0;
+    size_t staged_total = 0;                 // bytes pisces_hip_stage_reads laid out in the current staging buffer (0: nothing staged)
     uint8_t* h_dl = nullptr;                 // pinned download buffer of flush
     const PiscesCalledAllele* pending_view = nullptr;   // the pending records when they are the download buffer's as they came (no host-side
     size_t pending_view_n = 0;                          // candidates, genotyper or forced alleles to merge in): no copy into `pending`

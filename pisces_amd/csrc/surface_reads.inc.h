@@ -361,6 +361,61 @@ static int32_t consume_found(PiscesHip* h)
     return PISCES_OK;
 }
 
+// where the arrays of a read batch lie in the staging pair (host pinned + device copy): the batch crosses PCIe packed, in one piece
+struct StageLayout {
+    size_t off_pos, off_flags, off_coff, off_cop, off_clen, off_soff, off_bases, off_quals, off_dirs, off_slots, off_deldirs, off_fslots, total;
+};
+static StageLayout stage_layout(size_t nr, size_t n_cig, size_t n_seq, bool with_dirs, bool with_deldirs)
+{
+    auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    StageLayout L;
+    L.off_pos = 0;
+    L.off_flags = align16(L.off_pos + nr * 4);
+    L.off_coff = align16(L.off_flags + nr);
+    L.off_cop = align16(L.off_coff + (nr + 1) * 4);
+    L.off_clen = align16(L.off_cop + n_cig);
+    L.off_soff = align16(L.off_clen + n_cig * 4);
+    L.off_bases = align16(L.off_soff + (nr + 1) * 4);
+    L.off_quals = align16(L.off_bases + n_seq);
+    L.off_dirs = align16(L.off_quals + n_seq);
+    L.off_slots = align16(L.off_dirs + (with_dirs ? n_seq : 0));
+    L.off_deldirs = align16(L.off_slots + (nr + 1) * 8);
+    L.off_fslots = align16(L.off_deldirs + (with_deldirs ? 2 * n_cig : 0));
+    L.total = align16(L.off_fslots + (nr + 1) * 4);
+    return L;
+}
+
+// The arrays of a batch of n_reads reads inside the handle's pinned staging buffer: a host that marshals its reads anyway (the C#
+// shim packs Read objects into arrays) writes them here and pisces_hip_add_reads sends them as they lie, without a copy of its own.
+int32_t pisces_hip_stage_reads(PiscesHip* h, int32_t n_reads, int64_t n_cigar_ops, int64_t n_bases, int32_t with_directions,
+                               int32_t with_deletion_directions, PiscesReadBatch* views)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (!views || n_reads < 0 || n_cigar_ops < 0 || n_bases < 0 || n_cigar_ops > 0x7FFFFFFFll || n_bases > 0x7FFFFFFFll)
+        return fail(h, PISCES_E_INVALID_ARG, "stage_reads: bad arguments");
+    { int32_t rcp = refuse_while_batch_is_open(h, "stage_reads"); if (rcp) return rcp; }
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    const StageLayout L = stage_layout((size_t)n_reads, (size_t)n_cigar_ops, (size_t)n_bases, with_directions != 0, with_deletion_directions != 0);
+    int32_t rc = stage_reserve(h, L.total);
+    if (rc) return rc;
+    h->staged_total = L.total;
+    uint8_t* st = h->h_stage;
+    views->n_reads = n_reads;
+    views->position = (const int32_t*)(st + L.off_pos);
+    views->flags = st + L.off_flags;
+    views->cigar_offset = (const int32_t*)(st + L.off_coff);
+    views->cigar_op = st + L.off_cop;
+    views->cigar_len = (const uint32_t*)(st + L.off_clen);
+    views->seq_offset = (const int32_t*)(st + L.off_soff);
+    views->bases = st + L.off_bases;
+    views->quals = st + L.off_quals;
+    views->directions = with_directions ? st + L.off_dirs : nullptr;
+    views->deletion_directions = with_deletion_directions ? st + L.off_deldirs : nullptr;
+    return PISCES_OK;
+    });
+}
+
 int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
 {
     return abi_guard<int32_t>(h, [&]() -> int32_t {
@@ -408,37 +463,39 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
     // BEFORE the second host pass over the CIGARs (block bookkeeping, candidate slots): that pass runs under it, and only its small
     // table of candidate slots follows in a transfer of its own ----
     const size_t n_cig = (size_t)batch->cigar_offset[nr], n_seq = (size_t)batch->seq_offset[nr];
-    auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    size_t off_pos = 0, off_flags = align16(off_pos + (size_t)nr * 4), off_coff = align16(off_flags + (size_t)nr),
-           off_cop = align16(off_coff + ((size_t)nr + 1) * 4), off_clen = align16(off_cop + n_cig),
-           off_soff = align16(off_clen + n_cig * 4), off_bases = align16(off_soff + ((size_t)nr + 1) * 4),
-           off_quals = align16(off_bases + n_seq), off_dirs = align16(off_quals + n_seq),
-           off_slots = align16(off_dirs + (batch->directions ? n_seq : 0)), off_deldirs = align16(off_slots + ((size_t)nr + 1) * 8),
-           off_fslots = align16(off_deldirs + (batch->deletion_directions ? 2 * n_cig : 0)), total = align16(off_fslots + ((size_t)nr + 1) * 4);
-    int32_t rc = stage_reserve(h, total);
+    const StageLayout L = stage_layout((size_t)nr, n_cig, n_seq, batch->directions != nullptr, batch->deletion_directions != nullptr);
+    const size_t off_pos = L.off_pos, off_flags = L.off_flags, off_coff = L.off_coff, off_cop = L.off_cop, off_clen = L.off_clen, off_soff = L.off_soff,
+                 off_bases = L.off_bases, off_quals = L.off_quals, off_dirs = L.off_dirs, off_slots = L.off_slots, off_deldirs = L.off_deldirs,
+                 off_fslots = L.off_fslots, total = L.total;
+    // a batch that pisces_hip_stage_reads laid out lies in the staging buffer already: nothing to reserve, nothing to copy
+    const bool staged = h->staged_total == total && h->h_stage && (const uint8_t*)batch->position == h->h_stage + off_pos &&
+                        batch->bases == h->h_stage + off_bases && batch->quals == h->h_stage + off_quals;
+    h->staged_total = 0;
+    int32_t rc = staged ? PISCES_OK : stage_reserve(h, total);
     if (rc) return rc;
     rc = log_reserve(h, ub);
     if (rc) return rc;
     uint8_t* st = h->h_stage;
-    std::memcpy(st + off_pos, batch->position, (size_t)nr * 4);
-    std::memcpy(st + off_flags, batch->flags, (size_t)nr);
-    std::memcpy(st + off_coff, batch->cigar_offset, ((size_t)nr + 1) * 4);
-    std::memcpy(st + off_cop, batch->cigar_op, n_cig);
-    std::memcpy(st + off_clen, batch->cigar_len, n_cig * 4);
-    std::memcpy(st + off_soff, batch->seq_offset, ((size_t)nr + 1) * 4);
+    auto place = [](uint8_t* dst, const void* src, size_t n) { if (n && (const void*)dst != src) std::memcpy(dst, src, n); };
+    place(st + off_pos, batch->position, (size_t)nr * 4);
+    place(st + off_flags, batch->flags, (size_t)nr);
+    place(st + off_coff, batch->cigar_offset, ((size_t)nr + 1) * 4);
+    place(st + off_cop, batch->cigar_op, n_cig);
+    place(st + off_clen, batch->cigar_len, n_cig * 4);
+    place(st + off_soff, batch->seq_offset, ((size_t)nr + 1) * 4);
     std::memcpy(st + off_slots, slots.data(), ((size_t)nr + 1) * 8);
-    if (batch->deletion_directions) std::memcpy(st + off_deldirs, batch->deletion_directions, 2 * n_cig);
+    if (batch->deletion_directions) place(st + off_deldirs, batch->deletion_directions, 2 * n_cig);
     {
         // bases / qualities / directions are the bulk (2-3 bytes per aligned base).  Small batches: one copy into the pinned buffer,
         // one transfer.  Large ones: slices of 8 MB, each copied by a few threads and handed to the DMA engine as soon as it is
-        // complete, so that the host copy of slice k+1 runs under the PCIe transfer of slice k.
+        // complete, so that the host copy of slice k+1 runs under the PCIe transfer of slice k.  A staged batch: one transfer.
         struct Seg { size_t dst; const uint8_t* src; size_t len; };
         const Seg segs[3] = {{off_bases, batch->bases, n_seq}, {off_quals, batch->quals, n_seq},
                              {off_dirs, batch->directions, batch->directions ? n_seq : 0}};
         const size_t bulk = 2 * n_seq + (batch->directions ? n_seq : 0);
         constexpr size_t kSlice = (size_t)8 << 20;
-        if (bulk < 2 * kSlice) {
-            for (const Seg& g : segs) if (g.len) std::memcpy(st + g.dst, g.src, g.len);
+        if (staged || bulk < 2 * kSlice) {
+            for (const Seg& g : segs) place(st + g.dst, g.src, g.len);
             PISCES_HIP_CHECK(h, hipMemcpyAsync(D_STAGE(h), st, off_fslots, hipMemcpyHostToDevice, h->stream));
         } else {
             // everything outside the bulk first (the descriptors before it, the slot table after it)

@@ -75,6 +75,29 @@ class HipVariantCaller:
         batch = reads if isinstance(reads, _abi.ReadBatch) else _abi.ReadBatch(reads)
         _check(self._h, lib.pisces_hip_add_reads(self._h, C.byref(batch.c)))
 
+    def StageReads(self, reads):
+        """pisces_hip_stage_reads: the arrays of `reads` (an _abi.ReadBatch) written into the handle's pinned staging buffer, as a host
+        that marshals its reads straight into it would leave them; returns the batch to hand to AddAlleleCounts (valid until the next
+        call on the handle that is not that AddAlleleCounts)."""
+        b = reads if isinstance(reads, _abi.ReadBatch) else _abi.ReadBatch(reads)
+        views = _abi.PiscesReadBatch()
+        dd = getattr(b, "deletion_directions", None)
+        _check(self._h, lib.pisces_hip_stage_reads(self._h, b.n_reads, len(b.cigar_op), b.n_bases, 1 if b.directions is not None else 0,
+                                                   1 if dd is not None else 0, C.byref(views)))
+
+        def fill(ptr, arr):
+            if arr is not None and arr.size:
+                C.memmove(ptr, arr.ctypes.data, arr.nbytes)
+
+        fill(views.position, b.position); fill(views.flags, b.flags); fill(views.cigar_offset, b.cigar_offset)
+        fill(views.cigar_op, b.cigar_op); fill(views.cigar_len, b.cigar_len); fill(views.seq_offset, b.seq_offset)
+        fill(views.bases, b.bases); fill(views.quals, b.quals); fill(views.directions, b.directions); fill(views.deletion_directions, dd)
+        staged = _abi.ReadBatch.__new__(_abi.ReadBatch)
+        staged.c = views
+        staged.n_reads = b.n_reads
+        staged.n_bases = b.n_bases
+        return staged
+
     def AddObservations(self, positions, tuples):
         positions = np.ascontiguousarray(positions, np.int32)
         tuples = np.ascontiguousarray(tuples, np.uint32)

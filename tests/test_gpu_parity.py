@@ -875,6 +875,22 @@ def test_streaming_surface_equals_device_resident_surface_at_size(torch_cuda):
             c.AddAlleleCounts(batch)
             once = c.Call(None)
         assert once.tobytes() == resident.tobytes()
+        # the same batch written by the caller into the library's pinned staging buffer (pisces_hip_stage_reads): sent as it lies
+        with engine.HipVariantCaller(cfg) as c:
+            c.SetReference(p.ref.cpu().numpy())
+            c.AddAlleleCounts(c.StageReads(batch))
+            once = c.Call(None)
+        assert once.tobytes() == resident.tobytes()
+    # staged and plain batches in turn, block by block
+    streamed = []
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(p.ref.cpu().numpy())
+        for k, a0 in enumerate(range(0, A, 5)):
+            b = synth.reads_of(p, 5, first_amplicon=a0)
+            c.AddAlleleCounts(c.StageReads(b) if k % 3 != 2 else b)
+            streamed.append(c.Call(p.region_start + a0 * synth.READ_LEN - 1))
+        streamed.append(c.Call(None))
+    assert np.concatenate(streamed).tobytes() == resident.tobytes()
 
 
 def test_collapser_on_open_ended_indels_matches_oracle(torch_cuda):
