@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "../../include/pisces_hip.h"
 #include "read_walk.h"
 
@@ -52,14 +54,18 @@ __device__ __forceinline__ int wave_exclusive_scan(int v, int lane, int* total)
 // global atomics from 8 XCDs cost ~25-200 ns EACH and were the whole run time of the first version of this kernel.
 // Slots a read does not use are written as position 0 ("hole"), which every consumer skips.
 // (read_slot[r] + slot_base = the read's first slot in the log: a batch decoded on the device carries slots counted from 0)
+// A wave takes reads_per_wave reads one after the other (expand_reads_grid: 1 for a block's worth of reads, more for large batches, so
+// that the one statistics atomic a workgroup makes at its end -- same address for all of them -- stays a few thousand a launch: at one
+// per four reads it was the whole run time of a 400 000-read launch).
 __global__ __launch_bounds__(256) void expand_reads_kernel(DevReadBatch b, const long long* __restrict__ read_slot, long long slot_base, int32_t min_bq,
                                                            int32_t* __restrict__ log_pos, uint32_t* __restrict__ log_tup,
-                                                           unsigned long long* __restrict__ appended)
+                                                           unsigned long long* __restrict__ appended, int32_t reads_per_wave)
 {
     __shared__ unsigned int s_emitted[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
     int emitted = 0;
+    for (int rr = 0; rr < reads_per_wave; rr++) {
+    const int r = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 4 + wave) * reads_per_wave + rr));
     if (r < b.n_reads) {
         const int c0 = b.cigar_offset[r], s0 = b.seq_offset[r];
         const ReadShape shape = read_shape(b.position[r], b.seq_offset[r + 1] - s0, b.cigar_offset[r + 1] - c0, b.cigar_op + c0, b.cigar_len + c0);
@@ -70,6 +76,20 @@ __global__ __launch_bounds__(256) void expand_reads_kernel(DevReadBatch b, const
         const uint8_t* const dirs = b.dirs ? b.dirs + s0 : nullptr;
         const long long slot0 = read_slot[r] + slot_base, slot1 = read_slot[r + 1] + slot_base;
         const uint32_t lastAnchor = PISCES_NUM_ANCHORS - 1;
+        if (shape.nc == 1 && walk_op_read_span(shape.ops[0]) && walk_op_ref_span(shape.ops[0]) && (int)shape.lens[0] == n && shape.pos0 >= 1 &&
+            slot1 - slot0 >= n) {
+            // one aligned segment and nothing else (most reads): base i sits on position pos0 + i and closes no gap, so it owns slot i
+            // of the read -- no walk over the CIGAR per base, no scan
+            for (int i = lane; i < n; i += 64) {
+                const int p = shape.pos0 + i;
+                const uint32_t dir = dirs ? (uint32_t)dirs[i] : read_dir;
+                log_pos[slot0 + i] = p;
+                log_tup[slot0 + i] = PISCES_TUPLE_PACK(0, (uint32_t)walk_anchor_type(shape.alignment_end, p, shape.pos0), dir, walk_allele_type(bases[i]),
+                                                       (uint32_t)quals[i]);
+                emitted++;
+            }
+            for (long long w = slot0 + n + lane; w < slot1; w += 64) log_pos[w] = 0;   // holes (none, by the host's bound)
+        } else {
 
         long long w0 = slot0;   // next free slot of this read (wave-uniform)
         for (int base0 = 0; base0 < n; base0 += 64) {
@@ -112,6 +132,8 @@ __global__ __launch_bounds__(256) void expand_reads_kernel(DevReadBatch b, const
             }
         }
         for (long long w = min(w0, slot1) + lane; w < slot1; w += 64) log_pos[w] = 0;   // holes
+        }
+    }
     }
     // observations made (IStateManager statistics): one global atomic per workgroup
 #pragma unroll
@@ -122,6 +144,14 @@ __global__ __launch_bounds__(256) void expand_reads_kernel(DevReadBatch b, const
         const unsigned int t = s_emitted[0] + s_emitted[1] + s_emitted[2] + s_emitted[3];
         if (t) atomicAdd(appended, (unsigned long long)t);
     }
+}
+
+// reads a wave takes / workgroups of a launch over n_reads reads
+inline int32_t expand_reads_per_wave(int64_t n_reads) { return (int32_t)std::min<int64_t>(16, std::max<int64_t>(1, n_reads / 16384)); }
+inline unsigned expand_reads_grid(int64_t n_reads)
+{
+    const int64_t per_group = 4 * (int64_t)expand_reads_per_wave(n_reads);
+    return (unsigned)((n_reads + per_group - 1) / per_group);
 }
 
 // ---- bucketing of the log by tile --------------------------------------------------------------------------------

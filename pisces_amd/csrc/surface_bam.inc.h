@@ -339,8 +339,8 @@ int32_t pisces_hip_add_decoded_reads(PiscesHip* h)
     db.position = B.position.p; db.flags = B.flags.p; db.cigar_offset = B.cigar_offset.p; db.cigar_op = B.cigar_op.p; db.cigar_len = B.cigar_len.p;
     db.seq_offset = B.seq_offset.p; db.bases = B.bases.p; db.quals = B.quals.p; db.dirs = nullptr; db.n_reads = nr;
     const int c = h->log_cur;
-    hipLaunchKernelGGL(expand_reads_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, h->stream, db, (const long long*)B.d_slots.p,
-                       (long long)h->log_ub, h->cfg.min_base_call_quality, h->d_log_pos[c].p, h->d_log_tup[c].p, h->d_log_n.p + 2);
+    hipLaunchKernelGGL(expand_reads_kernel, dim3(expand_reads_grid(nr)), dim3(256), 0, h->stream, db, (const long long*)B.d_slots.p,
+                       (long long)h->log_ub, h->cfg.min_base_call_quality, h->d_log_pos[c].p, h->d_log_tup[c].p, h->d_log_n.p + 2, expand_reads_per_wave(nr));
     PISCES_HIP_CHECK(h, hipGetLastError());
     if (find_on_device && (h->cfg.call_mnvs || found_slots > 0)) {
         int32_t rcd = enqueue_candidate_discovery(h, db, nullptr, nr, (const int32_t*)B.d_fslots.p, found_slots, found_pool);

@@ -609,8 +609,8 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
     db.dirs = batch->directions ? d + off_dirs : nullptr;
     db.n_reads = nr;
     const int c = h->log_cur;
-    hipLaunchKernelGGL(expand_reads_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, h->stream, db, (const long long*)(d + off_slots), 0ll,
-                       minBQ, h->d_log_pos[c].p, h->d_log_tup[c].p, h->d_log_n.p + 2);
+    hipLaunchKernelGGL(expand_reads_kernel, dim3(expand_reads_grid(nr)), dim3(256), 0, h->stream, db, (const long long*)(d + off_slots), 0ll,
+                       minBQ, h->d_log_pos[c].p, h->d_log_tup[c].p, h->d_log_n.p + 2, expand_reads_per_wave(nr));
     PISCES_HIP_CHECK(h, hipGetLastError());
     if (find_on_device && (h->cfg.call_mnvs || found_slots > 0)) {
         int32_t rcd = enqueue_candidate_discovery(h, db, batch->deletion_directions ? d + off_deldirs : nullptr, nr, (const int32_t*)(d + off_fslots),

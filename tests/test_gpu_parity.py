@@ -1358,11 +1358,14 @@ def test_batched_launches_equal_single_launches(torch_cuda):
             cap = p.n_tiles * _abi.SLOTS_PER_TILE
             rec = torch.zeros(cap * 64, dtype=torch.uint8, device=dev)
             tr = torch.zeros(p.n_tiles * _abi.TILE_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()   # (torch fills on its own stream, the library launches on the handle's: the fills must have landed)
             c.call_tiles(p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), 1, p.ref_len, rec.data_ptr(), cap, tr.data_ptr())
+            c.synchronize()
             torch.cuda.synchronize()
             trn = tr.cpu().numpy().view(_abi.TILE_RESULT_DTYPE)
             single.append(_abi.records_in_order(rec.cpu().numpy().view(_abi.CALLED_ALLELE_DTYPE), trn).copy())
             outs.append((torch.zeros_like(rec), torch.zeros_like(tr), cap))
+        torch.cuda.synchronize()
         batches = [(p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), 1, p.ref_len, o[0].data_ptr(), o[2], o[1].data_ptr())
                    for p, o in zip(ps, outs)]
         for _ in range(3):
