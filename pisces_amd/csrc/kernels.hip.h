@@ -35,7 +35,10 @@ constexpr int kTile = 64;                 // loci per tile (lane = locus in the 
 constexpr int kFolded = 18;               // 6 allele types x 3 directions (anchors folded)
 constexpr int kUnroll = 8;                // 16-byte loads in flight per lane
 constexpr int kSlotsPerTile = 4 * kTile;  // record slot of (locus, allele rank) = 256 * tile + 4 * locus + rank
-constexpr int kTotalShards = 64;          // running-total shards (one 128-byte line each)
+#ifndef PISCES_TOTAL_SHARDS
+#define PISCES_TOTAL_SHARDS 64
+#endif
+constexpr int kTotalShards = PISCES_TOTAL_SHARDS;   // running-total shards (one 128-byte line each)
 constexpr int kTotalStride = 16;          // in 8-byte words
 constexpr int kRefMargin = 32;            // reference bases staged in LDS on each side of a tile (RMxN scan reach)
 constexpr int kRefWin = kTile + 2 * kRefMargin;

@@ -150,13 +150,13 @@ int32_t pisces_hip_device_totals(PiscesHip* h, int64_t out[4], int32_t reset)
     if (!h || !out) return PISCES_E_INVALID_ARG;
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     PISCES_HIP_CHECK(h, hipDeviceSynchronize());   // launches may sit on caller-supplied streams
-    unsigned long long host[kTotalShards * kTotalStride];
-    PISCES_HIP_CHECK(h, hipMemcpy(host, h->d_totals.p, sizeof(host), hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> host((size_t)kTotalShards * kTotalStride);
+    PISCES_HIP_CHECK(h, hipMemcpy(host.data(), h->d_totals.p, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (int i = 0; i < 4; i++) {
         out[i] = 0;
         for (int sh = 0; sh < kTotalShards; sh++) out[i] += (int64_t)host[sh * kTotalStride + i];
     }
-    if (reset) PISCES_HIP_CHECK(h, hipMemset(h->d_totals.p, 0, sizeof(host)));
+    if (reset) PISCES_HIP_CHECK(h, hipMemset(h->d_totals.p, 0, host.size() * sizeof(unsigned long long)));
     return PISCES_OK;
     });
 }
