@@ -156,21 +156,37 @@ inline unsigned expand_reads_grid(int64_t n_reads)
 
 // ---- bucketing of the log by tile --------------------------------------------------------------------------------
 struct BucketMap {
-    const int32_t* key_slot;      // [key_max - key_min + 1] -> slot of a block being bucketed, or -1
-    const int32_t* first_tile;    // [slots] first tile of the block
-    const int32_t* tile_of_locus; // [slots * block_size] tile index relative to first_tile, or -1; nullptr = regular 64-locus grid
+    const int32_t* key_slot;        // [key_max - key_min + 1] -> slot of a block being bucketed, or -1
+    const int32_t* key_first_tile;  // [key_max - key_min + 1] -> first tile of that block, or -1 (key_slot and first_tile in one look-up)
+    const int32_t* first_tile;      // [slots] first tile of the block
+    const int32_t* tile_of_locus;   // [slots * block_size] tile index relative to first_tile, or -1; nullptr = regular 64-locus grid
     int32_t key_min, key_max, block_size;
+    double inv_block_size;          // 1 / block_size: the block of a position without an integer division per log entry
 };
+
+// GetBlockKey (RegionStateManager.cs:385-391): ceil(pos / block_size) for pos >= 1, exactly (the product is corrected by its remainder)
+__device__ __forceinline__ int32_t bucket_key_of(const BucketMap& m, int32_t pos)
+{
+    const long long n = (long long)pos + m.block_size - 1;   // (64 bits: positions reach 2^31 - 1)
+    int32_t q = (int32_t)((double)n * m.inv_block_size);
+    const long long r = n - (long long)q * m.block_size;
+    q += r >= m.block_size ? 1 : r < 0 ? -1 : 0;
+    return q;
+}
 
 // tile of a position, or -1 (block not in this bucketing, or locus outside the interval set)
 __device__ __forceinline__ int32_t bucket_tile_of(const BucketMap& m, int32_t pos)
 {
-    const int32_t key = (pos + m.block_size - 1) / m.block_size;   // GetBlockKey (RegionStateManager.cs:385-391)
-    if (pos <= 0 || key < m.key_min || key > m.key_max) return -1;
+    if (pos <= 0) return -1;
+    const int32_t key = bucket_key_of(m, pos);
+    if (key < m.key_min || key > m.key_max) return -1;
+    const int32_t off = pos - ((key - 1) * m.block_size + 1);
+    if (!m.tile_of_locus) {
+        const int32_t first = m.key_first_tile[key - m.key_min];
+        return first < 0 ? -1 : first + off / 64;
+    }
     const int32_t slot = m.key_slot[key - m.key_min];
     if (slot < 0) return -1;
-    const int32_t off = pos - ((key - 1) * m.block_size + 1);
-    if (!m.tile_of_locus) return m.first_tile[slot] + off / 64;
     const int32_t rel = m.tile_of_locus[(int64_t)slot * m.block_size + off];
     return rel < 0 ? -1 : m.first_tile[slot] + rel;
 }
@@ -337,7 +353,7 @@ __global__ __launch_bounds__(256) void log_drop_kernel(const int32_t* __restrict
         tup[k] = i < n ? log_tup[i] : 0u;
         bool keep = false;
         if (pos[k] > 0) {
-            const int32_t key = (pos[k] + m.block_size - 1) / m.block_size;
+            const int32_t key = bucket_key_of(m, pos[k]);
             keep = !(key >= m.key_min && key <= m.key_max && m.key_slot[key - m.key_min] >= 0);
         }
         if (keep) { keep_bits |= 1u << k; mine++; }

@@ -55,18 +55,23 @@ static int32_t upload_bucket_map(PiscesHip* h, const std::vector<int32_t>& keys,
     // one synchronisation, so a ring of four staging vectors never rewrites one that is still in flight
     std::vector<int32_t>& host = h->bucket_host[h->bucket_host_next];
     h->bucket_host_next = (h->bucket_host_next + 1) % 4;
-    const size_t n_tables = n_slot + keys.size() + tol.size();
+    const size_t n_tables = 2 * n_slot + keys.size() + tol.size();   // key_slot, key_first_tile, first_tile, tile_of_locus
     host.assign(n_tables, -1);
-    for (size_t i = 0; i < keys.size(); i++) host[(size_t)(keys[i] - kmin)] = (int32_t)i;
-    std::copy(first_tile.begin(), first_tile.end(), host.begin() + (std::ptrdiff_t)n_slot);
-    std::copy(tol.begin(), tol.end(), host.begin() + (std::ptrdiff_t)(n_slot + keys.size()));
+    for (size_t i = 0; i < keys.size(); i++) {
+        host[(size_t)(keys[i] - kmin)] = (int32_t)i;
+        host[n_slot + (size_t)(keys[i] - kmin)] = first_tile[i];
+    }
+    std::copy(first_tile.begin(), first_tile.end(), host.begin() + (std::ptrdiff_t)(2 * n_slot));
+    std::copy(tol.begin(), tol.end(), host.begin() + (std::ptrdiff_t)(2 * n_slot + keys.size()));
     host.resize(n_tables + n_zero_tail, 0);
     PISCES_HIP_CHECK(h, h->d_bucket.reserve(host.size()));
     if (zero_tail) *zero_tail = (unsigned int*)(h->d_bucket.p + n_tables);
     { int32_t rcu = meta_upload(h, h->d_bucket.p, host.data(), host.size() * sizeof(int32_t)); if (rcu) return rcu; }
     m->key_slot = h->d_bucket.p;
-    m->first_tile = h->d_bucket.p + n_slot;
-    m->tile_of_locus = tol.empty() ? nullptr : h->d_bucket.p + n_slot + keys.size();
+    m->key_first_tile = h->d_bucket.p + n_slot;
+    m->first_tile = h->d_bucket.p + 2 * n_slot;
+    m->tile_of_locus = tol.empty() ? nullptr : h->d_bucket.p + 2 * n_slot + keys.size();
+    m->inv_block_size = 1.0 / (double)h->cfg.block_size;
     m->key_min = kmin;
     m->key_max = kmax;
     m->block_size = h->cfg.block_size;
