@@ -149,6 +149,39 @@ def end_to_end(pileup, cfg, engine, loci=30_000):
                     best = dt if best is None else min(best, dt)
         out[label] = {"value": n_loci / best, "unit": "candidate loci/s", "seconds": best, "loci": n_loci, "records": n_rec,
                       "add_reads_flush_pairs": len(batches), "reads": int(sum(b.n_reads for _, b in batches))}
+    # (a') block by block through the flush PAIR (pisces_hip_flush_begin / pisces_hip_flush_end): the device works on block k while the
+    # host adds the reads of block k + 1; the alleles of block k are taken before block k + 1 is flushed.  Same calls otherwise.
+    try:
+        per_block = [(a0, synth.reads_of(pileup, min(7, n_amp - a0), first_amplicon=pileup.first_amplicon + a0)) for a0 in range(0, n_amp, 7)]
+        for label, stage in (("per_block_pair", False), ("per_block_pair_staged", True)):
+            best = None
+            with engine.HipVariantCaller(cfg) as c:
+                c.SetReference(ref)
+                for rep in range(4):
+                    n_rec = 0
+                    dt = 0.0
+                    pending = False
+                    for a0, b in per_block:
+                        staged = c.StageReads(b) if stage else b       # (filling the staging buffer: the caller's marshalling, not timed)
+                        t0 = time.perf_counter()
+                        c.AddAlleleCounts(staged)
+                        if pending:
+                            n_rec += len(c.CallEnd(capacity=1 << 18, reuse_buffer=True))
+                        c.CallBegin(pileup.region_start + a0 * synth.READ_LEN - 1)
+                        pending = True
+                        dt += time.perf_counter() - t0
+                    t0 = time.perf_counter()
+                    n_rec += len(c.CallEnd(capacity=1 << 18, reuse_buffer=True))
+                    c.CallBegin(None)
+                    n_rec += len(c.CallEnd(capacity=1 << 18, reuse_buffer=True))
+                    dt += time.perf_counter() - t0
+                    if rep > 0:
+                        best = dt if best is None else min(best, dt)
+            assert n_rec == out["per_block"]["records"], (n_rec, out["per_block"]["records"])
+            out[label] = {"value": n_loci / best, "unit": "candidate loci/s", "seconds": best, "loci": n_loci, "records": n_rec,
+                          "add_reads_flush_pairs": len(per_block)}
+    except Exception as e:   # noqa: BLE001
+        out["per_block_pair"] = {"error": str(e)[:200]}
     # (b') the 30-block pairs with the reads written by the caller straight into the library's pinned staging buffer
     # (pisces_hip_stage_reads: what a host that marshals its reads anyway does; filling the buffer is that marshalling and is not
     # timed, as making the read arrays is not timed in (a) and (b)): pisces_hip_add_reads then sends the batch without a copy of its own

@@ -308,6 +308,19 @@ int32_t pisces_hip_flush(PiscesHip* h, int32_t up_to_position, PiscesCalledAllel
 int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAllele* out, int64_t capacity, int64_t* n_out,
                             int32_t* cand_index_out, PiscesCandidate* cand_out, int64_t cand_capacity, int64_t* n_cand,
                             uint8_t* alleles_out, int64_t allele_capacity, int64_t* allele_bytes);
+/* The flush as a pair, for a host that wants the device to work on block k while it prepares block k + 1:
+ * pisces_hip_flush_begin(upTo) does what pisces_hip_flush does up to the point where it would wait for the device and commits
+ * DoneProcessing (the flushed blocks are gone, the observation log is the compacted one); pisces_hip_flush_end waits for what is
+ * still in flight and returns the same alleles pisces_hip_flush would have returned (PISCES_E_BUFFER_TOO_SMALL with *n_out = the
+ * count needed: repeat flush_end with a larger buffer, nothing is lost).  Between the two the caller may stage and add the next
+ * reads (pisces_hip_stage_reads, pisces_hip_add_reads, pisces_hip_add_observations, pisces_hip_bam_decode +
+ * pisces_hip_add_decoded_reads) and read counts; pisces_hip_flush[_ex] and another pisces_hip_flush_begin return PISCES_E_STATE
+ * until flush_end has been called.  A batch that needs the host between its device passes (insertion / deletion / MNV candidates,
+ * forced alleles, the diploid / haploid genotypers, NoiseModel.Window, gapped-MNV reference counts) is flushed synchronously inside
+ * flush_begin; flush_end returns it all the same (records only: use pisces_hip_flush_ex where the candidates' allele strings are
+ * needed). */
+int32_t pisces_hip_flush_begin(PiscesHip* h, int32_t up_to_position);
+int32_t pisces_hip_flush_end(PiscesHip* h, PiscesCalledAllele* out, int64_t capacity, int64_t* n_out);
 /* IAlleleSource.GetAlleleCount for a run of positions: out[n][6][3][11] int32
  * (RegionState.cs:57); blocks never touched read as zero (RegionStateManager.cs:222-226). */
 int32_t pisces_hip_get_counts(PiscesHip* h, int32_t start_position, int32_t n, int32_t* out);

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("PISCES_HIP_LIB") or os.path.join(_HERE, "libpisceship
 
 EXPORTS = [
     "pisces_hip_abi_version", "pisces_hip_default_config", "pisces_hip_create", "pisces_hip_destroy",
-    "pisces_hip_last_error", "pisces_hip_set_reference", "pisces_hip_set_intervals", "pisces_hip_add_reads", "pisces_hip_stage_reads",
+    "pisces_hip_last_error", "pisces_hip_set_reference", "pisces_hip_set_intervals", "pisces_hip_add_reads", "pisces_hip_stage_reads", "pisces_hip_flush_begin", "pisces_hip_flush_end",
     "pisces_hip_add_observations", "pisces_hip_flush", "pisces_hip_get_counts", "pisces_hip_add_gapped_mnv_ref",
     "pisces_hip_get_candidates", "pisces_hip_stats", "pisces_hip_call_tiles", "pisces_hip_accumulate_tiles",
     "pisces_hip_synchronize", "pisces_hip_last_kernel_ms", "pisces_hip_expand_reads", "pisces_hip_device_totals",
@@ -64,6 +64,8 @@ def _load():
         "pisces_hip_set_intervals": (i32, [vp, vp, vp, i32]),
         "pisces_hip_add_reads": (i32, [vp, P(_abi.PiscesReadBatch)]),
         "pisces_hip_stage_reads": (i32, [vp, i32, i64, i64, i32, i32, P(_abi.PiscesReadBatch)]),
+        "pisces_hip_flush_begin": (i32, [vp, i32]),
+        "pisces_hip_flush_end": (i32, [vp, vp, i64, P(i64)]),
         "pisces_hip_add_observations": (i32, [vp, vp, vp, i64]),
         "pisces_hip_flush": (i32, [vp, i32, vp, i64, P(i64)]),
         "pisces_hip_flush_ex": (i32, [vp, i32, vp, i64, P(i64), vp, vp, i64, P(i64), vp, i64, P(i64)]),

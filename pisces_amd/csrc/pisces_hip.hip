@@ -193,6 +193,21 @@ struct PiscesHip {
     std::vector<int32_t> bucket_host[4];
     int bucket_host_next = 0;
     uint64_t uploads_since_sync = 0;
+    // pisces_hip_flush_begin / pisces_hip_flush_end: a flush whose device work is in flight while the host goes on (add_reads of the
+    // next batch), or whose results are ready and wait to be taken
+    struct AsyncFlush {
+        int state = 0;                         // 0 none, 1 in flight, 2 results ready
+        hipEvent_t done = nullptr;
+        bool dropped = false;                  // the log was compacted behind the calls: [kept, bound) of the new log are holes
+        int64_t bound = 0;
+        int32_t* hdr = nullptr;                // {records, called, kept (8 bytes)} in the pinned download buffer
+        PiscesCalledAllele* hrec = nullptr;
+        size_t spec = 0;                       // records that come back with the header; more only with a second copy
+        const PiscesCalledAllele* data = nullptr;   // state 2: the results
+        size_t n = 0;
+        std::vector<PiscesCalledAllele> owned; // state 2, when the flush had to run synchronously (host-side candidates, genotypers, ...)
+    } async;
+    int64_t log_known_holes = 0;             // slots of the log that the last asynchronous drop left as holes (0 after any other drop)
     size_t staged_total = 0;                 // bytes pisces_hip_stage_reads laid out in the current staging buffer (0: nothing staged)
     uint8_t* h_dl = nullptr;                 // pinned download buffer of flush
     const PiscesCalledAllele* pending_view = nullptr;   // the pending records when they are the download buffer's as they came (no host-side
@@ -595,6 +610,8 @@ int32_t pisces_hip_destroy(PiscesHip* h)
         st.done = nullptr;
     }
     h->h_stage = nullptr;
+    if (h->async.done) (void)hipEventDestroy(h->async.done);
+    h->async.done = nullptr;
     if (h->h_dl) (void)hipHostFree(h->h_dl);
     h->h_dl = nullptr;
     if (h->h_meta) (void)hipHostFree(h->h_meta);

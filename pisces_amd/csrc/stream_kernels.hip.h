@@ -245,6 +245,14 @@ __global__ __launch_bounds__(256) void bucket_count_kernel(const int32_t* __rest
         if (s_cnt[d]) atomicAdd(&tile_count[tmin + d], s_cnt[d]);
 }
 
+// after a drop whose count the host does not wait for: the slots [*kept, bound) of the new log become holes, so that `bound` (which
+// the host knows) can be the log's length
+__global__ __launch_bounds__(256) void log_fill_holes_kernel(int32_t* __restrict__ log_pos, const unsigned long long* __restrict__ kept, long long bound)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < bound && i >= (long long)*kept) log_pos[i] = 0;
+}
+
 // one workgroup: exclusive scan of the padded tile counts; fills the tile segments and resets the counters to cursors
 // (zero_me: a counter a later kernel of the same submission starts from — log_drop_kernel's kept count — cleared here instead of by
 // a fill of its own: every operation of a flush costs ~4.5 us of stream time whatever its size)

@@ -122,7 +122,7 @@ static int32_t bucket_blocks(PiscesHip* h, const std::vector<int32_t>& keys, boo
 // DoneProcessing for the observation log: the entries of `keys` leave, the rest moves to the OTHER log buffer.  enqueue_drop only
 // enqueues (the current log is left as it is, so a flush that has to be repeated loses nothing); commit_drop makes the other buffer
 // the log once the number of entries it kept is known on the host.
-static int32_t enqueue_drop(PiscesHip* h, const std::vector<int32_t>& keys)
+static int32_t enqueue_drop(PiscesHip* h, const std::vector<int32_t>& keys, int64_t hole_bound = -1)
 {
     std::vector<int32_t> first_tile(keys.size(), 0), tol;
     BucketMap m;
@@ -135,6 +135,9 @@ static int32_t enqueue_drop(PiscesHip* h, const std::vector<int32_t>& keys)
     h->drop_counter_cleared = false;
     hipLaunchKernelGGL(log_drop_kernel, dim3(log_grid(h)), dim3(256), 0, h->stream, h->d_log_pos[c].p, h->d_log_tup[c].p, (long long)h->log_ub,
                        m, h->d_log_pos[o].p, h->d_log_tup[o].p, h->d_log_n.p + o);
+    if (hole_bound > 0)   // (pisces_hip_flush_begin: the host will not wait for the count; the new log is hole_bound slots long, the rest holes)
+        hipLaunchKernelGGL(log_fill_holes_kernel, dim3((unsigned)((hole_bound + 255) / 256)), dim3(256), 0, h->stream, h->d_log_pos[o].p,
+                           (const unsigned long long*)(h->d_log_n.p + o), (long long)hole_bound);
     PISCES_HIP_CHECK(h, hipGetLastError());
     return PISCES_OK;
 }
@@ -142,6 +145,7 @@ static void commit_drop(PiscesHip* h, unsigned long long kept)
 {
     h->log_cur ^= 1;
     h->log_ub = (int64_t)kept;
+    h->log_known_holes = 0;
 }
 static int32_t drop_blocks(PiscesHip* h, const std::vector<int32_t>& keys)
 {
@@ -204,15 +208,21 @@ static void launch_compaction(hipStream_t s, const PiscesCalledAllele* d_records
 }
 
 // device work of one flush: returns called alleles of `keys` sorted by (position, ref, alt)
-// as_view: the records are not copied into `out`; h->pending_view points at them in the pinned download buffer (valid until the next
-// call_blocks)
-static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::vector<PiscesCalledAllele>& out, int64_t* n_called,
-                           bool with_drop = false, bool* dropped = nullptr, unsigned long long* kept = nullptr, bool as_view = false)
+// The device work of one flush in two halves: everything up to the copies into the pinned download buffer is enqueued by
+// call_blocks_enqueue; call_blocks_finish reads what came back once the stream (or an event behind the copies) has been waited for.
+struct CallBlocksInFlight {
+    bool active = false;       // false: nothing was enqueued (no blocks, no tiles)
+    bool drop_now = false;
+    int32_t* hdr = nullptr;
+    PiscesCalledAllele* hrec = nullptr;
+    size_t spec = 0;
+};
+// hole_bound >= 0 (asynchronous flush): the compacted log is made hole_bound slots long (see enqueue_drop)
+static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& keys, bool with_drop, int64_t hole_bound, CallBlocksInFlight* st)
 {
-    out.clear();   // (*n_called accumulates: the caller zeroes it)
+    *st = CallBlocksInFlight();
     h->pending_view = nullptr;
     h->pending_view_n = 0;
-    if (dropped) *dropped = false;
     if (keys.empty()) return PISCES_OK;
     if (!h->d_ref.p) return fail(h, PISCES_E_STATE, "flush: set_reference has not been called");
     std::vector<PiscesTile> tiles;
@@ -264,7 +274,7 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
     // DoneProcessing's kernel rides in the same submission (it only writes the OTHER log buffer): one synchronisation per flush
     const bool drop_now = with_drop && h->log_ub > 0;
     if (drop_now) {
-        int32_t rcd = enqueue_drop(h, keys);
+        int32_t rcd = enqueue_drop(h, keys, hole_bound);
         if (rcd) return rcd;
     }
     const size_t dl_bytes = 16 + cap * sizeof(PiscesCalledAllele);
@@ -281,21 +291,48 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
     if (drop_now)
         PISCES_HIP_CHECK(h, hipMemcpyAsync(hdr + 2, h->d_log_n.p + (h->log_cur ^ 1), sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipMemcpyAsync(hrec, h->d_compact.p, spec * sizeof(PiscesCalledAllele), hipMemcpyDeviceToHost, h->stream));
-    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
-    h->h_meta_used = 0;   // the stream is idle: nothing reads the arena any more
-    const int32_t total = hdr[0];
-    *n_called += hdr[1];
-    if (drop_now) {
-        if (dropped) *dropped = true;
-        if (kept) std::memcpy(kept, hdr + 2, sizeof(unsigned long long));
-    }
-    if ((size_t)total > spec) {
-        PISCES_HIP_CHECK(h, hipMemcpyAsync(hrec + spec, h->d_compact.p + spec, ((size_t)total - spec) * sizeof(PiscesCalledAllele),
+    st->active = true;
+    st->drop_now = drop_now;
+    st->hdr = hdr;
+    st->hrec = hrec;
+    st->spec = spec;
+    return PISCES_OK;
+}
+// (after the wait) total: the records; they lie in st.hrec, all of them
+static int32_t call_blocks_finish(PiscesHip* h, const CallBlocksInFlight& st, int32_t* total, int64_t* n_called, unsigned long long* kept)
+{
+    *total = 0;
+    if (!st.active) return PISCES_OK;
+    *total = st.hdr[0];
+    *n_called += st.hdr[1];
+    if (st.drop_now && kept) std::memcpy(kept, st.hdr + 2, sizeof(unsigned long long));
+    if ((size_t)*total > st.spec) {
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(st.hrec + st.spec, h->d_compact.p + st.spec, ((size_t)*total - st.spec) * sizeof(PiscesCalledAllele),
                                            hipMemcpyDeviceToHost, h->stream));
         PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     }
-    if (as_view) { h->pending_view = hrec; h->pending_view_n = (size_t)total; }
-    else out.assign(hrec, hrec + total);
+    return PISCES_OK;
+}
+
+// device work of one flush: returns called alleles of `keys` sorted by (position, ref, alt)
+// as_view: the records are not copied into `out`; h->pending_view points at them in the pinned download buffer (valid until the next
+// call_blocks)
+static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::vector<PiscesCalledAllele>& out, int64_t* n_called,
+                           bool with_drop = false, bool* dropped = nullptr, unsigned long long* kept = nullptr, bool as_view = false)
+{
+    out.clear();   // (*n_called accumulates: the caller zeroes it)
+    if (dropped) *dropped = false;
+    CallBlocksInFlight st;
+    int32_t rc = call_blocks_enqueue(h, keys, with_drop, -1, &st);
+    if (rc || !st.active) return rc;
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    h->h_meta_used = 0;   // the stream is idle: nothing reads the arena any more
+    int32_t total = 0;
+    rc = call_blocks_finish(h, st, &total, n_called, kept);
+    if (rc) return rc;
+    if (st.drop_now && dropped) *dropped = true;
+    if (as_view) { h->pending_view = st.hrec; h->pending_view_n = (size_t)total; }
+    else out.assign(st.hrec, st.hrec + total);
     return PISCES_OK;
 }
 
@@ -910,6 +947,7 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
     *n_out = 0;
     if (n_cand) *n_cand = 0;
     if (allele_bytes) *allele_bytes = 0;
+    if (h->async.state != 0) return fail(h, PISCES_E_STATE, "flush: pisces_hip_flush_begin is waiting for its pisces_hip_flush_end");
     { int32_t rcf = consume_found(h); if (rcf) return rcf; }
     const bool final_flush = up_to_position < 0;
     const bool replay = h->pending_valid && h->pending_up_to == up_to_position;
@@ -1139,6 +1177,130 @@ int32_t pisces_hip_flush(PiscesHip* h, int32_t up_to_position, PiscesCalledAllel
 {
     return abi_guard<int32_t>(h, [&]() -> int32_t {
     return pisces_hip_flush_ex(h, up_to_position, out, capacity, n_out, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr);
+    });
+}
+
+// ---- the flush as a pair: the device works on block k while the host prepares block k + 1 ---------------------------------------
+// pisces_hip_flush_begin does what pisces_hip_flush does up to the point where it would wait for the device, and commits the state
+// (DoneProcessing: the flushed blocks are gone, the log is the compacted one); pisces_hip_flush_end waits for what is still in flight
+// and hands the alleles over.  Between the two the caller may add the next reads (pisces_hip_stage_reads / pisces_hip_add_reads /
+// pisces_hip_add_observations / pisces_hip_add_decoded_reads): the compaction's entry count, which the host has not seen yet, is
+// replaced by a bound -- the compacted log is made that long, holes behind the kept entries -- so appending needs nothing from the
+// device.  A batch that needs the host between its device passes (host-side candidates: insertions, deletions, MNVs; forced alleles;
+// the per-locus genotypers; NoiseModel.Window; gapped-MNV reference counts) is flushed synchronously inside begin, and end returns it.
+int32_t pisces_hip_flush_begin(PiscesHip* h, int32_t up_to_position)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (h->async.state != 0) return fail(h, PISCES_E_STATE, "flush_begin: the flush before this one has not been taken (pisces_hip_flush_end)");
+    { int32_t rcp = refuse_while_batch_is_open(h, "flush_begin"); if (rcp) return rcp; }
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    { int32_t rcf = consume_found(h); if (rcf) return rcf; }
+    const bool final_flush = up_to_position < 0;
+    auto& A = h->async;
+    // the batch GetCandidatesToProcess would build (as pisces_hip_flush_ex)
+    std::vector<int32_t> keys;
+    const bool same_block = !final_flush && block_key(h, up_to_position) == h->last_up_to_block_key;
+    bool plain = h->forced.empty() && h->cfg.ploidy != PISCES_PLOIDY_DIPLOID && h->cfg.ploidy != PISCES_PLOIDY_HAPLOID &&
+                 h->cfg.noise_model != PISCES_NOISE_WINDOW;
+    if (!same_block)
+        for (auto& kv : h->blocks) {
+            if (!(final_flush || (int64_t)kv.first * h->cfg.block_size <= up_to_position)) continue;
+            if (!final_flush && kv.second.max_allele_endpoint > up_to_position) break;
+            keys.push_back(kv.first);
+            if (!kv.second.cands.empty()) plain = false;
+        }
+    for (auto& kv : h->gapped_mnv_ref)
+        if (std::binary_search(keys.begin(), keys.end(), block_key(h, kv.first))) { plain = false; break; }
+    if (!plain) {
+        // the synchronous flush, its alleles kept for pisces_hip_flush_end
+        A.owned.resize(std::max<size_t>(A.owned.size(), 1024));
+        for (;;) {
+            int64_t n = 0;
+            const int32_t rc = pisces_hip_flush_ex(h, up_to_position, A.owned.data(), (int64_t)A.owned.size(), &n, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr);
+            if (rc == PISCES_E_BUFFER_TOO_SMALL) { A.owned.resize((size_t)n); continue; }
+            if (rc) return rc;
+            A.data = A.owned.data();
+            A.n = (size_t)n;
+            break;
+        }
+        A.state = 2;
+        return PISCES_OK;
+    }
+    if (!A.done) PISCES_HIP_CHECK(h, hipEventCreateWithFlags(&A.done, hipEventDisableTiming));
+    if (same_block) { A.data = nullptr; A.n = 0; A.state = 2; return PISCES_OK; }
+    // what the compacted log can hold at most: the entries that are not known holes
+    const int64_t bound = std::max<int64_t>(0, h->log_ub - h->log_known_holes);
+    CallBlocksInFlight st;
+    int32_t rc = call_blocks_enqueue(h, keys, true, bound, &st);
+    if (rc) return rc;
+    if (st.active) PISCES_HIP_CHECK(h, hipEventRecord(A.done, h->stream));
+    // DoneProcessing, now: the blocks leave, the other log buffer is the log, `bound` slots long
+    if (st.active && st.drop_now) {
+        h->log_cur ^= 1;
+        h->log_ub = bound;
+        h->log_known_holes = bound;   // until the kept count is known every slot may be a hole (pisces_hip_flush_end corrects this)
+    } else if (!st.active) {
+        // no tiles: nothing was launched; the log entries of these blocks (if any) leave the ordinary way
+        int32_t rcd = drop_blocks(h, keys);
+        if (rcd) return rcd;
+    }
+    for (int32_t key : keys) {
+        h->blocks.erase(key);
+        const int32_t bstart = (key - 1) * h->cfg.block_size + 1, bend = key * h->cfg.block_size;
+        for (auto it = h->gapped_mnv_ref.begin(); it != h->gapped_mnv_ref.end();)
+            it = (it->first >= bstart && it->first <= bend) ? h->gapped_mnv_ref.erase(it) : std::next(it);
+    }
+    h->last_block = nullptr;
+    h->last_up_to_block_key = final_flush ? -1 : block_key(h, up_to_position);
+    A.dropped = st.active && st.drop_now;
+    A.bound = bound;
+    A.hdr = st.hdr;
+    A.hrec = st.hrec;
+    A.spec = st.spec;
+    A.data = nullptr;
+    A.n = 0;
+    A.state = st.active ? 1 : 2;
+    return PISCES_OK;
+    });
+}
+
+int32_t pisces_hip_flush_end(PiscesHip* h, PiscesCalledAllele* out, int64_t capacity, int64_t* n_out)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (!n_out || capacity < 0 || (capacity > 0 && !out)) return fail(h, PISCES_E_INVALID_ARG, "flush_end: null output");
+    *n_out = 0;
+    auto& A = h->async;
+    if (A.state == 0) return fail(h, PISCES_E_STATE, "flush_end: no pisces_hip_flush_begin before it");
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    if (A.state == 1) {
+        PISCES_HIP_CHECK(h, hipEventSynchronize(A.done));
+        h->h_meta_used = 0;   // (only a flush uploads through the arena, and this one's uploads lie before the event)
+        CallBlocksInFlight st;
+        st.active = true; st.drop_now = A.dropped; st.hdr = A.hdr; st.hrec = A.hrec; st.spec = A.spec;
+        int32_t total = 0;
+        int64_t called = 0;
+        unsigned long long kept = 0;
+        int32_t rc = call_blocks_finish(h, st, &total, &called, &kept);
+        if (rc) return rc;
+        // the holes the drop left are the bound minus what it kept; entries appended since lie behind the bound
+        if (A.dropped) h->log_known_holes = A.bound - (int64_t)kept;
+        h->stats[0] += called;
+        A.data = A.hrec;
+        A.n = (size_t)total;
+        A.state = 2;
+    }
+    if ((int64_t)A.n > capacity) {
+        *n_out = (int64_t)A.n;
+        return fail(h, PISCES_E_BUFFER_TOO_SMALL, "flush_end: output buffer too small");
+    }
+    if (A.n) std::memcpy(out, A.data, A.n * sizeof(PiscesCalledAllele));
+    *n_out = (int64_t)A.n;
+    A.state = 0;
+    A.data = nullptr;
+    A.n = 0;
+    return PISCES_OK;
     });
 }
 

@@ -157,6 +157,28 @@ class HipVariantCaller:
             _check(self._h, rc)
             return out[: n.value]
 
+    def CallBegin(self, upToPosition=None):
+        """pisces_hip_flush_begin: the flush enqueued, DoneProcessing committed; the alleles come with CallEnd.  In between the next
+        reads may be staged and added."""
+        _check(self._h, lib.pisces_hip_flush_begin(self._h, -1 if upToPosition is None else int(upToPosition)))
+
+    def CallEnd(self, capacity=1 << 16, reuse_buffer=False):
+        """pisces_hip_flush_end: the alleles of the flush CallBegin started (the rows Call would have returned)."""
+        while True:
+            if reuse_buffer:
+                out = getattr(self, "_flush_out", None)
+                if out is None or len(out) < capacity:
+                    out = self._flush_out = np.zeros(capacity, dtype=_abi.CALLED_ALLELE_DTYPE)
+            else:
+                out = np.zeros(capacity, dtype=_abi.CALLED_ALLELE_DTYPE)
+            n = C.c_int64(0)
+            rc = lib.pisces_hip_flush_end(self._h, out.ctypes.data, len(out), C.byref(n))
+            if rc == _abi.E_BUFFER_TOO_SMALL:
+                capacity = int(n.value)
+                continue
+            _check(self._h, rc)
+            return out[: n.value]
+
     def CallWithAlleles(self, upToPosition=None, capacity=1 << 16):
         """Call() that also returns the (ref, alt) allele strings of every row: Reference / SNV rows from the record's
         base codes, insertion / deletion rows from the candidate the library found (pisces_hip_flush_ex)."""

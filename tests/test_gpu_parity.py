@@ -1,6 +1,7 @@
 """Parity of the HIP path (through the C ABI) against the oracle on a real MI355X.
 Bit-exact for every integer field of the 64-byte record (position, coverage, support, counts,
 filters, genotype) and for the q-scores (north_star allows +-1 Phred; none is used), strand-bias score to 1e-9 relative."""
+import ctypes as C
 import json
 import os
 
@@ -1812,3 +1813,84 @@ def test_base_quality_sums_are_exact_and_the_same_from_run_to_run(torch_cuda):
             for d in range(2):
                 o = orc.lib.orc_get_sum_base_quality(st.h, p, a, d, 0, -1, 0, 0)
                 assert float(sums[p - 1, a, d].sum()) == pytest.approx(o, rel=1e-12, abs=1e-18)
+
+
+def test_flush_pair_gives_what_flush_gives_while_the_next_reads_are_added(torch_cuda):
+    """pisces_hip_flush_begin / pisces_hip_flush_end: the same alleles, call by call, as pisces_hip_flush in SmallVariantCaller's loop,
+    with the next block's reads staged and added between begin and end (the compacted log is a bound long, holes behind what it kept);
+    the state entries that must wait say so; a batch with host-side candidates (a deletion) is flushed synchronously inside begin."""
+    from pisces_amd import engine, synth
+    p = synth.make_pileup(n_loci=6300, depth=60, seed=19)
+    cfg = _abi.default_config()
+    A = p.base.shape[0]
+    ref = p.ref.numpy()
+    per_call = 3   # amplicons per add_reads: blocks end in the middle of some calls, so entries are kept across flushes
+    want = []
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(ref)
+        for a0 in range(0, A, per_call):
+            c.AddAlleleCounts(synth.reads_of(p, min(per_call, A - a0), first_amplicon=a0))
+            want.append(c.Call(p.region_start + a0 * synth.READ_LEN - 1).copy())
+        want.append(c.Call(None).copy())
+        want_stats = c.Stats()
+    for staged in (False, True):
+        got = []
+        with engine.HipVariantCaller(cfg) as c:
+            c.SetReference(ref)
+            pending = False
+            for k, a0 in enumerate(range(0, A, per_call)):
+                b = synth.reads_of(p, min(per_call, A - a0), first_amplicon=a0)
+                c.AddAlleleCounts(c.StageReads(b) if staged else b)      # (between begin and end of the flush before)
+                if pending:
+                    if k == 2:   # what has to wait says so, and nothing is lost by asking
+                        with pytest.raises(engine.PiscesHipError) as e:
+                            c.Call(None)
+                        assert e.value.code == _abi.E_STATE
+                        with pytest.raises(engine.PiscesHipError) as e:
+                            c.CallBegin(None)
+                        assert e.value.code == _abi.E_STATE
+                        n = C.c_int64(0)
+                        small = np.zeros(1, dtype=_abi.CALLED_ALLELE_DTYPE)
+                        from pisces_amd._native import lib
+                        rc = lib.pisces_hip_flush_end(c.handle, small.ctypes.data, 0, C.byref(n))
+                        assert (rc == _abi.E_BUFFER_TOO_SMALL and n.value == len(want[k - 1])) or (rc == 0 and len(want[k - 1]) == 0)
+                        if rc == 0:
+                            got.append(small[:0])
+                            pending = False
+                    if pending:
+                        got.append(c.CallEnd().copy())
+                c.CallBegin(p.region_start + a0 * synth.READ_LEN - 1)
+                pending = True
+            got.append(c.CallEnd().copy())
+            c.CallBegin(None)
+            got.append(c.CallEnd().copy())
+            with pytest.raises(engine.PiscesHipError) as e:
+                c.CallEnd()
+            assert e.value.code == _abi.E_STATE
+            stats = c.Stats()
+            assert len(c.Call(None)) == 0
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert g.tobytes() == w.tobytes()
+        assert stats == want_stats
+    # host-side candidates: a deletion in some reads -> the pair must give what the plain flush gives
+    rng = np.random.default_rng(2)
+    refb = bytes(rng.choice(list(b"ACGT"), 2600).astype(np.uint8))
+    reads = []
+    for i in range(120):
+        s = 900 + (i % 7) * 3
+        if i % 3 == 0:
+            reads.append({"pos": s, "cigar": [("M", 60), ("D", 4), ("M", 60)], "seq": (refb[s - 1:s + 59] + refb[s + 63:s + 123]).decode(), "quals": [37] * 120, "reverse": bool(i % 2)})
+        else:
+            reads.append({"pos": s, "cigar": [("M", 124)], "seq": refb[s - 1:s + 123].decode(), "quals": [37] * 124, "reverse": bool(i % 2)})
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(refb)
+        c.AddAlleleCounts(reads)
+        plain_way = c.Call(None).copy()
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(refb)
+        c.AddAlleleCounts(reads)
+        c.CallBegin(None)
+        pair_way = c.CallEnd().copy()
+    assert len(plain_way) > 0 and pair_way.tobytes() == plain_way.tobytes()
+    assert any(_abi.info_category(int(r["info"])) == _abi.CAT_DELETION for r in plain_way)
