@@ -1873,6 +1873,23 @@ def test_flush_pair_gives_what_flush_gives_while_the_next_reads_are_added(torch_
         for g, w in zip(got, want):
             assert g.tobytes() == w.tobytes()
         assert stats == want_stats
+    # the pair and the plain flush in turn on one handle (the log keeps holes behind a pair's compaction; a plain flush squeezes them out)
+    got = []
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(ref)
+        c.SetIntervals([(p.region_start, p.region_start + p.n_loci - 1)])
+        for k, a0 in enumerate(range(0, A, per_call)):
+            c.AddAlleleCounts(synth.reads_of(p, min(per_call, A - a0), first_amplicon=a0))
+            up_to = p.region_start + a0 * synth.READ_LEN - 1
+            if k % 3 == 0:
+                got.append(c.Call(up_to).copy())
+            else:
+                c.CallBegin(up_to)
+                if k % 3 == 1:
+                    _ = c.GetCounts(p.region_start + a0 * synth.READ_LEN, 4)   # (reading counts between begin and end is allowed)
+                got.append(c.CallEnd().copy())
+        got.append(c.Call(None).copy())
+    assert np.concatenate(got).tobytes() == np.concatenate(want).tobytes()
     # host-side candidates: a deletion in some reads -> the pair must give what the plain flush gives
     rng = np.random.default_rng(2)
     refb = bytes(rng.choice(list(b"ACGT"), 2600).astype(np.uint8))
