@@ -542,9 +542,11 @@ int32_t pisces_hip_bgzf_inflate(PiscesHip* h, const uint8_t* file, int64_t n_byt
  * chunk instead.  pisces_hip_bam_chain_mode says which it was for the last decode (0 = all at once, 1 = serial hop): diagnostics
  * (the environment variable PISCES_HIP_BAM_SERIAL_CHAIN=1 forces the serial hop).
  * pisces_hip_bam_fetch: the decoded batch to host arrays sized from `counts` (any pointer may be NULL) — for inspection and tests.
- * pisces_hip_add_decoded_reads: pisces_hip_add_reads for the decoded batch without its bases and qualities leaving the device: the
- * host reads back positions and CIGARs only (for the block bookkeeping), the read walk and the candidate discovery run where the
- * bases are. */
+ * pisces_hip_add_decoded_reads: pisces_hip_add_reads for the decoded batch without anything of it leaving the device: what
+ * pisces_hip_add_reads takes from a host pass over the CIGARs (log slots, candidate-record slots, the blocks every read touches, the
+ * reads it refuses: position <= 0, a CIGAR longer than the read, a read past 2^31 - 1 or far past the end of its reference sequence)
+ * the decode has made where the reads are (the blocks as a bit map that came back with `counts`); the call enqueues the read walk and
+ * the candidate discovery and returns without waiting. */
 int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes, const PiscesBgzfBlock* blocks, int64_t n_blocks, int32_t ref_id,
                               int32_t min_map_quality, int32_t skip_duplicates, int32_t only_proper_pairs, int64_t counts[4]);
 int32_t pisces_hip_bam_fetch(PiscesHip* h, int32_t* position, uint8_t* flags, int32_t* cigar_offset, uint8_t* cigar_op, uint32_t* cigar_len,
