@@ -368,3 +368,54 @@ def test_bam_decode_survives_corrupted_records():
                 np.testing.assert_array_equal(got["position"], np.array([r["pos"] for r in keep], np.int32))
                 same += 1
     assert refused + same > 40 and same > 5, (refused, same)
+
+
+@pytest.mark.gpu
+def test_device_inflate_fuzz_against_zlib():
+    """A few thousand BGZF members of random make -- alphabet size, run structure, repeats at short and long distances, every zlib
+    level and strategy (default, filtered, Huffman only, RLE, fixed codes), lengths from 0 to the 65 280 bytes a member may hold --
+    inflated on the device in a handful of launches and compared with zlib byte for byte.  (The decoder takes the payload in groups
+    of 64 bit offsets with the next two groups looked up ahead: members of every length put block ends, long codes and length /
+    distance pairs at every offset of a group.)"""
+    import torch
+    assert torch.cuda.is_available()
+    rng = np.random.default_rng(77)
+    strategies = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED]
+
+    def payload():
+        kind = int(rng.integers(0, 6))
+        n = int(rng.choice([0, 1, 2, 3, 7, 64, 257, 1000, 5000, 20000, 65280])) if rng.random() < 0.5 else int(rng.integers(0, 65281))
+        if kind == 0:      # small alphabet (quality strings)
+            return bytes(rng.integers(33, 33 + int(rng.integers(1, 8)), n, dtype=np.uint8))
+        if kind == 1:      # all byte values, skewed: codes longer than the look-up tables' indexes
+            p = 1.0 / (np.arange(256) + 1.0) ** float(rng.uniform(0.5, 2.5))
+            return bytes(rng.choice(256, n, p=p / p.sum()).astype(np.uint8))
+        if kind == 2:      # runs (distance 1 and short periods)
+            out = bytearray()
+            while len(out) < n:
+                out += bytes(rng.integers(0, 256, int(rng.integers(1, 5)), dtype=np.uint8)) * int(rng.integers(1, 400))
+            return bytes(out[:n])
+        if kind == 3:      # records with a shared prefix (repeats at a fixed distance, as BAM records have)
+            rec = bytes(rng.integers(0, 256, int(rng.integers(8, 60)), dtype=np.uint8))
+            out = bytearray()
+            while len(out) < n:
+                out += rec + bytes(rng.integers(0, 256, int(rng.integers(4, 300)), dtype=np.uint8))
+            return bytes(out[:n])
+        if kind == 4:      # long-distance repeats
+            base = bytes(rng.integers(0, 256, int(rng.integers(100, 30000)), dtype=np.uint8))
+            return (base * (n // max(len(base), 1) + 1))[:n]
+        return bytes(rng.integers(0, 256, n, dtype=np.uint8))   # noise
+
+    with engine.HipVariantCaller(_abi.default_config()) as c:
+        for launch in range(6):
+            members, want = [], []
+            for _ in range(400):
+                src = payload()
+                level = int(rng.integers(1, 10))
+                strategy = strategies[int(rng.integers(0, len(strategies)))]
+                members.append(make_bgzf([src], level, strategy)[:-28])   # (without the empty end-of-file member make_bgzf appends)
+                want.append(src)
+            data = b"".join(members) + make_bgzf([])
+            got, blocks, _ = c.bgzf_inflate(data)
+            assert len(blocks) == len(members) + 1
+            assert got == b"".join(want)
