@@ -396,6 +396,82 @@ __device__ inline void inflate_codes(InflateStream& s, const HuffmanTable& lenco
         (void)inflate_bits(s, at & 7);
     };
 
+    // a symbol the lanes could not decode, at offset `at` of X (the chain so far: `chain`); true = the block is over (end-of-block code,
+    // or an error)
+    auto special = [&](uint64_t chain, int at) -> bool {
+        pos = at;
+        emit(chain & ~(1ull << pos));
+        if (s.err) return true;
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)X.le, pos);
+        const uint32_t raw = (uint32_t)__builtin_amdgcn_readlane((int)X.raw, pos);
+        int len, t;   // t: where the distance code starts
+        const int cl = (int)((e >> 20) & 15u);
+        if (cl) {
+            if (e >> 28) {   // end of block
+                pos += cl;
+                leave();
+                return true;
+            }
+            if (!(e & 0x80u)) { s.err = kInflateBadSymbol; return true; }
+            const int eb = (int)((e >> 17) & 7u);
+            len = (int)((e >> 8) & 0x1FFu) + (int)((raw >> cl) & ((1u << eb) - 1u));
+            t = pos + cl + eb;
+        } else {   // a code longer than the table's index: the canonical walk over the bits at this offset
+            int symbol = 0;
+            const int wl = __builtin_amdgcn_readfirstlane(inflate_walk(lencode, raw, 15, symbol));
+            symbol = __builtin_amdgcn_readfirstlane(symbol);
+            if (wl == 0) { s.err = kInflateBadSymbol; return true; }
+            if (symbol < 256) {
+                if (s.out_pos >= s.out_len) { s.err = kInflateOutputOverflow; return true; }
+#ifndef PISCES_INFLATE_ABLATE_LIT
+                if (s.lane == 0) s.out[s.out_pos] = (uint8_t)symbol;
+#endif
+                s.out_pos++;
+                pos += wl;
+                return false;
+            }
+            if (symbol == 256) {
+                pos += wl;
+                leave();
+                return true;
+            }
+            symbol -= 257;
+            if (symbol >= 29) { s.err = kInflateBadSymbol; return true; }
+            const int eb = kLenExtra[symbol];
+            len = kLenBase[symbol] + (int)((raw >> wl) & ((1u << eb) - 1u));
+            t = pos + wl + eb;
+        }
+        const uint32_t ed = group_lane(X.de, Y.de, t), rawd = group_lane(X.raw, Y.raw, t);
+        int dist;
+        if (ed) {
+            if (!(ed >> 31)) { s.err = kInflateBadSymbol; return true; }
+            const int dl = (int)(ed & 15u), deb = (int)((ed >> 4) & 15u);
+            dist = (int)((ed >> 8) & 0x7FFFu) + (int)((rawd >> dl) & ((1u << deb) - 1u));
+            pos = t + dl + deb;
+        } else {
+            int symbol = 0;
+            const int dl = __builtin_amdgcn_readfirstlane(inflate_walk(distcode, rawd, 15, symbol));
+            symbol = __builtin_amdgcn_readfirstlane(symbol);
+            if (dl == 0 || symbol >= 30) { s.err = kInflateBadSymbol; return true; }
+            const int deb = kDistExtra[symbol];
+            dist = kDistBase[symbol] + (int)((rawd >> dl) & ((1u << deb) - 1u));
+            pos = t + dl + deb;
+        }
+        if (dist > s.out_pos) { s.err = kInflateDistanceTooFar; return true; }
+        if (s.out_pos + len > s.out_len) { s.err = kInflateOutputOverflow; return true; }
+#ifndef PISCES_INFLATE_ABLATE_COPY
+        const uint8_t* src = s.out + s.out_pos - dist;
+        uint8_t* dst = s.out + s.out_pos;
+        if (dist >= len) {
+            for (int k = s.lane; k < len; k += 64) dst[k] = src[k];
+        } else {
+            for (int k = s.lane; k < len; k += 64) dst[k] = src[k % dist];
+        }
+#endif
+        s.out_pos += len;
+        return false;
+    };
+
     for (;;) {
         // the walk (four steps per turn of the loop: a step that leaves the group branches forward, the loop branches back once in four)
         uint64_t chain = 0;
@@ -431,79 +507,9 @@ __device__ inline void inflate_codes(InflateStream& s, const HuffmanTable& lenco
             ensure(2 * G + 7, 2 * G + 8);
             pre1 = word(2 * G + 7);
             pre2 = word(2 * G + 8);
-            continue;
+        } else if (special(chain, at)) {
+            return;
         }
-        // a symbol the lanes could not decode, at offset `at`
-        pos = at;
-        emit(chain & ~(1ull << pos));
-        if (s.err) return;
-        const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)X.le, pos);
-        const uint32_t raw = (uint32_t)__builtin_amdgcn_readlane((int)X.raw, pos);
-        int len, t;   // t: where the distance code starts
-        const int cl = (int)((e >> 20) & 15u);
-        if (cl) {
-            if (e >> 28) {   // end of block
-                pos += cl;
-                leave();
-                return;
-            }
-            if (!(e & 0x80u)) { s.err = kInflateBadSymbol; return; }
-            const int eb = (int)((e >> 17) & 7u);
-            len = (int)((e >> 8) & 0x1FFu) + (int)((raw >> cl) & ((1u << eb) - 1u));
-            t = pos + cl + eb;
-        } else {   // a code longer than the table's index: the canonical walk over the bits at this offset
-            int symbol = 0;
-            const int wl = __builtin_amdgcn_readfirstlane(inflate_walk(lencode, raw, 15, symbol));
-            symbol = __builtin_amdgcn_readfirstlane(symbol);
-            if (wl == 0) { s.err = kInflateBadSymbol; return; }
-            if (symbol < 256) {
-                if (s.out_pos >= s.out_len) { s.err = kInflateOutputOverflow; return; }
-#ifndef PISCES_INFLATE_ABLATE_LIT
-                if (s.lane == 0) s.out[s.out_pos] = (uint8_t)symbol;
-#endif
-                s.out_pos++;
-                pos += wl;
-                continue;
-            }
-            if (symbol == 256) {
-                pos += wl;
-                leave();
-                return;
-            }
-            symbol -= 257;
-            if (symbol >= 29) { s.err = kInflateBadSymbol; return; }
-            const int eb = kLenExtra[symbol];
-            len = kLenBase[symbol] + (int)((raw >> wl) & ((1u << eb) - 1u));
-            t = pos + wl + eb;
-        }
-        const uint32_t ed = group_lane(X.de, Y.de, t), rawd = group_lane(X.raw, Y.raw, t);
-        int dist;
-        if (ed) {
-            if (!(ed >> 31)) { s.err = kInflateBadSymbol; return; }
-            const int dl = (int)(ed & 15u), deb = (int)((ed >> 4) & 15u);
-            dist = (int)((ed >> 8) & 0x7FFFu) + (int)((rawd >> dl) & ((1u << deb) - 1u));
-            pos = t + dl + deb;
-        } else {
-            int symbol = 0;
-            const int dl = __builtin_amdgcn_readfirstlane(inflate_walk(distcode, rawd, 15, symbol));
-            symbol = __builtin_amdgcn_readfirstlane(symbol);
-            if (dl == 0 || symbol >= 30) { s.err = kInflateBadSymbol; return; }
-            const int deb = kDistExtra[symbol];
-            dist = kDistBase[symbol] + (int)((rawd >> dl) & ((1u << deb) - 1u));
-            pos = t + dl + deb;
-        }
-        if (dist > s.out_pos) { s.err = kInflateDistanceTooFar; return; }
-        if (s.out_pos + len > s.out_len) { s.err = kInflateOutputOverflow; return; }
-#ifndef PISCES_INFLATE_ABLATE_COPY
-        const uint8_t* src = s.out + s.out_pos - dist;
-        uint8_t* dst = s.out + s.out_pos;
-        if (dist >= len) {
-            for (int k = s.lane; k < len; k += 64) dst[k] = src[k];
-        } else {
-            for (int k = s.lane; k < len; k += 64) dst[k] = src[k % dist];
-        }
-#endif
-        s.out_pos += len;
     }
 }
 
