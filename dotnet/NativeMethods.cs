@@ -99,6 +99,10 @@ namespace Pisces.Hip
         /// the arrays of a batch inside the handle's pinned staging buffer: fill them, then pisces_hip_add_reads(views) sends them as they lie
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_stage_reads(IntPtr handle, int nReads, long nCigarOps, long nBases, int withDirections, int withDeletionDirections, ref PiscesReadBatch views);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_flush(IntPtr handle, int upToPosition, [Out] PiscesCalledAllele[] output, long capacity, out long nOut);
+        /// the flush as a pair: begin enqueues it and commits DoneProcessing, end waits and returns the alleles pisces_hip_flush would have
+        /// returned; the next reads may be staged and added in between (the device works on block k while the host marshals block k + 1)
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_flush_begin(IntPtr handle, int upToPosition);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_flush_end(IntPtr handle, [Out] PiscesCalledAllele[] output, long capacity, out long nOut);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_flush_ex(IntPtr handle, int upToPosition, [Out] PiscesCalledAllele[] output, long capacity, out long nOut, [Out] int[] candIndex, [Out] PiscesCandidate[] cands, long candCapacity, out long nCand, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_get_candidates(IntPtr handle, int upToPosition, [Out] PiscesCandidate[] cands, long capacity, out long nOut, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_add_candidates(IntPtr handle, PiscesCandidate[] cands, long n, byte[] alleles, long alleleBytes);
