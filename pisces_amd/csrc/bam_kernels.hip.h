@@ -5,9 +5,9 @@
 // The inflated stream stays in HBM.  A BAM record is [block_size:int32][block_size bytes]; where a record starts is only known
 // from the one before it, a serial chain over the whole file.  It is cut without a serial pass over the bytes:
 //   bam_header_kernel   the header (magic, text, reference names) -> offset of the first record
-//   bam_chain_kernel    per 32 KiB chunk, EVERY byte offset s is taken as a possible record start: next(s) = s + 4 + le32(s).  Pointer
-//                       jumping in LDS (next <- next o next, 10 rounds) turns that into "where does the chain from s leave the chunk"
-//                       for all 32768 offsets at once — no knowledge of the true starts needed.
+//   bam_chain_kernel    per 32 KiB chunk, every byte offset s of its first 4 KiB is taken as a possible record start and its chain
+//                       (next(s) = s + 4 + le32(s)) followed through the chunk in LDS: "where does the chain from s leave the chunk",
+//                       with no knowledge of the true starts.
 //                       False chains die within a few records (a random word is no block_size), so the chains that are still alive
 //                       when they leave a chunk have all merged into the true one: the chunk also reports the exit that every live
 //                       chain from its first 4 KiB shares, when there is exactly one.
@@ -72,63 +72,89 @@ __global__ void bam_header_kernel(const uint8_t* __restrict__ s, int64_t n, long
     out[0] = p; out[1] = n_ref; out[2] = 0;
 }
 
-// exits[s] for every byte offset s of the stream: kBamLeaves | (bytes past the end of s's chunk) once the chain from s leaves its chunk
-__global__ __launch_bounds__(1024) void bam_chain_kernel(const uint8_t* __restrict__ s, int64_t n, uint16_t* __restrict__ exits, uint32_t* __restrict__ shared_exit,
-                                                         const long long* __restrict__ header)
+// The first offset of chunk c whose chain is followed (the window of kBamGuessWindow offsets starts there): the chunk's first byte, or
+// the first record in the chunk the header ends in.
+__device__ __forceinline__ int bam_window_start(int64_t c, const long long* __restrict__ header)
 {
-    __shared__ uint8_t bytes[kBamChunk + 4];
-    __shared__ uint16_t ptr[kBamChunk];
+    const long long first = header[2] == 0 ? header[0] : 0;
+    return first / kBamChunk == c ? (int)(first - c * (long long)kBamChunk) : 0;
+}
+
+// where the chain from stream offset `at` leaves its chunk: kBamLeaves | bytes past the chunk's end, kBamBroken, or kBamOutside when
+// `at` does not lie in its chunk's window (the table only holds the window's offsets)
+constexpr uint16_t kBamOutside = 0x7FFF;
+__device__ __forceinline__ uint16_t bam_exit_of(const uint16_t* __restrict__ exits, int64_t at, const long long* __restrict__ header)
+{
+    const int64_t c = at / kBamChunk;
+    const int i = (int)(at - c * kBamChunk) - bam_window_start(c, header);
+    if (i < 0 || i >= kBamGuessWindow) return kBamOutside;
+    return exits[c * kBamGuessWindow + i];
+}
+
+// one hop of a chain inside the stream: the offset behind the record at `at`, or -1 when no record can start there
+__device__ __forceinline__ int64_t bam_next_record(const uint8_t* __restrict__ s, int64_t n, int64_t at)
+{
+    if (at + 4 > n) return -1;
+    const int32_t bs = bam_le32(s + at);
+    if (bs < kBamMinRecord || bs > kBamMaxRecord || at + 4 + bs > n) return -1;
+    return at + 4 + bs;
+}
+
+// exits[c * kBamGuessWindow + k]: where the chain from offset k of chunk c's window leaves the chunk -- kBamLeaves | (bytes past the
+// chunk's end), or kBamBroken.  Every offset of the window is taken as a possible record start (next(s) = s + 4 + le32(s)) and
+// followed through the chunk's bytes in LDS; false chains die within a few hops (a random word is no block_size), the true chain is
+// ~170 hops of 188-byte records.  The chunk also reports the exit all its live, record-like starts share (shared_exit).
+__global__ __launch_bounds__(256) void bam_chain_kernel(const uint8_t* __restrict__ s, int64_t n, uint16_t* __restrict__ exits, uint32_t* __restrict__ shared_exit,
+                                                        const long long* __restrict__ header)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t bytes[kBamChunk + 16];
     __shared__ uint32_t exit_lo, exit_hi;
     if (threadIdx.x == 0) { exit_lo = 0xFFFFFFFFu; exit_hi = 0u; }
-    const int64_t c0 = (int64_t)blockIdx.x * kBamChunk;
+    const int64_t c = blockIdx.x, c0 = c * (int64_t)kBamChunk;
     const int len = (int)min((int64_t)kBamChunk, n - c0);
-    for (int i = threadIdx.x; i < kBamChunk + 4; i += 1024) bytes[i] = (c0 + i < n) ? s[c0 + i] : (uint8_t)0;
+    // the chunk and the four bytes behind it (a block_size that starts in the chunk's last bytes), 16 bytes a thread and load where
+    // the whole 16 lie inside the stream's buffer (it carries 16 bytes of slack), bytes otherwise
+    for (int i = threadIdx.x * 16; i < kBamChunk + 16; i += 256 * 16) {
+        if (c0 + i + 16 <= n + 16) *reinterpret_cast<uint4*>(bytes + i) = *reinterpret_cast<const uint4*>(s + c0 + i);
+        else for (int k = 0; k < 16; k++) bytes[i + k] = 0;
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < kBamChunk; i += 1024) {
+    const int w0 = bam_window_start(c, header);
+    const long long n_ref = header[2] == 0 ? header[1] : 0;
+    for (int k = threadIdx.x; k < kBamGuessWindow; k += 256) {
+        const int i = w0 + k;
         uint16_t v = kBamBroken;
-        if (i < len && c0 + i + 4 <= n) {
-            const int32_t bs = bam_le32(bytes + i);
-            if (bs >= kBamMinRecord && bs <= kBamMaxRecord) {
-                const int64_t nxt = (int64_t)i + 4 + bs;          // relative to the chunk
-                if (c0 + nxt <= n) v = nxt < len ? (uint16_t)nxt : (uint16_t)(kBamLeaves | (uint16_t)(nxt - len));
+        if (i < len) {
+            int at = i;
+            for (;;) {   // (at most 32768 / 36 = 910 hops)
+                if (c0 + at + 4 > n) break;
+                const int32_t bs = bam_le32(bytes + at);
+                if (bs < kBamMinRecord || bs > kBamMaxRecord || c0 + at + 4 + (int64_t)bs > n) break;
+                const int nxt = at + 4 + bs;
+                if (nxt >= len) { v = (uint16_t)(kBamLeaves | (uint16_t)(nxt - len)); break; }
+                at = nxt;
+            }
+            // the vote: only starts that look like a record (reference id inside the header's table, a block_size that holds its own
+            // fixed fields, name, CIGAR and bases: an integer field that merely reads like a block_size does not).  The chains
+            // themselves stay as permissive as BamReader is: the vote decides nothing that the check of the links does not confirm.
+            if (v != kBamBroken && i + 4 + kBamMinRecord <= len) {
+                const int32_t bs = bam_le32(bytes + i), ref_id = bam_le32(bytes + i + 4), l_seq = bam_le32(bytes + i + 20);
+                const int l_name = bytes[i + 12], n_cigar = (int)bam_le16(bytes + i + 16);
+                if (ref_id >= -1 && ref_id < n_ref && l_name >= 1 && l_seq >= 0 && (long long)bs >= 32ll + l_name + 4ll * n_cigar + (l_seq + 1ll) / 2 + l_seq) {
+                    atomicMin(&exit_lo, (uint32_t)v);
+                    atomicMax(&exit_hi, (uint32_t)v);
+                }
             }
         }
-        ptr[i] = v;
+        exits[c * kBamGuessWindow + k] = v;
     }
     __syncthreads();
-    // a chain inside one chunk has at most 32768 / 36 = 910 hops: ten doublings reach its end (in-place updates only ever move a
-    // pointer further along its own chain)
-    for (int round = 0; round < 10; round++) {
-        for (int i = threadIdx.x; i < len; i += 1024) {
-            const uint16_t v = ptr[i];
-            if (v < kBamLeaves) ptr[i] = ptr[v];
-        }
-        __syncthreads();
-    }
-    for (int i = threadIdx.x; i < len; i += 1024) exits[c0 + i] = ptr[i];
-    // the exit all live chains from the chunk's first kBamGuessWindow bytes share (0: none alive, or more than one exit); in the chunk
-    // the header ends in, the window starts at the first record
-    const long long first = header[2] == 0 ? header[0] : 0;
-    const int w0 = first >= c0 && first < c0 + len ? (int)(first - c0) : 0;
-    // (only starts that look like a record vote -- reference id inside the header's table, a block_size that holds its own fixed
-    // fields, name, CIGAR and bases: an integer field that merely reads like a block_size does not.  The pointers themselves stay
-    // as permissive as BamReader is: the vote decides nothing that the check of the links does not confirm.)
-    const long long n_ref = header[2] == 0 ? header[1] : 0;
-    for (int i = w0 + threadIdx.x; i < min(len, w0 + kBamGuessWindow); i += 1024) {
-        const uint32_t v = ptr[i];
-        if (i + 4 + kBamMinRecord > len) continue;
-        const int32_t bs = bam_le32(bytes + i), ref_id = bam_le32(bytes + i + 4), l_seq = bam_le32(bytes + i + 20);
-        const int l_name = bytes[i + 12], n_cigar = (int)bam_le16(bytes + i + 16);
-        if (ref_id < -1 || ref_id >= n_ref || l_name < 1 || l_seq < 0 || (long long)bs < 32ll + l_name + 4ll * n_cigar + (l_seq + 1ll) / 2 + l_seq) continue;
-        if (v >= kBamLeaves && v != kBamBroken) { atomicMin(&exit_lo, v); atomicMax(&exit_hi, v); }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) shared_exit[blockIdx.x] = exit_lo == exit_hi ? exit_lo : 0u;
+    if (threadIdx.x == 0) shared_exit[c] = exit_lo == exit_hi ? exit_lo : 0u;   // (0: none alive, or more than one exit)
 }
 
 // entry[c] for every chunk at once, from the shared exit of the chunk before it.  Where that chunk has none (two live chains with
-// different exits: a small integer field near the chunk's start that reads like a block_size), the thread goes back to the nearest
-// chunk whose entry is known and hops forward from there through the pointers (at most kBamGuessBack chunks; fallback[0] = 1 beyond).
+// different exits), the thread goes back to the nearest chunk whose entry is known and hops forward from there through the table (at
+// most kBamGuessBack chunks; fallback[0] = 1 beyond, or when a hop starts outside its chunk's window).
 constexpr int kBamGuessBack = 64;
 __global__ void bam_entry_guess_kernel(const uint32_t* __restrict__ shared_exit, const uint16_t* __restrict__ exits, int64_t n,
                                        const long long* __restrict__ header, int64_t n_chunks, long long* __restrict__ entry,
@@ -150,7 +176,7 @@ __global__ void bam_entry_guess_kernel(const uint32_t* __restrict__ shared_exit,
         // forward through chunks p .. c - 1
         for (int64_t k = p; at >= 0 && k < c; k++) {
             if (at >= n || at / kBamChunk != k) { at = at >= n ? n : -1; break; }
-            const uint16_t v = exits[at];
+            const uint16_t v = bam_exit_of(exits, at, header);
             if (v == kBamBroken || v < kBamLeaves) { at = -1; break; }
             at = min((k + 1) * (int64_t)kBamChunk, n) + (long long)(v & 0x7FFF);
         }
@@ -162,7 +188,7 @@ __global__ void bam_entry_guess_kernel(const uint32_t* __restrict__ shared_exit,
     entry[c] = e;
 }
 
-// every link of the guessed entries against the pointers; fallback[0] = 1 on any doubt
+// every link of the guessed entries against the table; fallback[0] = 1 on any doubt
 __global__ void bam_entry_check_kernel(const uint16_t* __restrict__ exits, int64_t n, const long long* __restrict__ header, int64_t n_chunks,
                                        const long long* __restrict__ entry, int32_t* __restrict__ fallback)
 {
@@ -171,9 +197,9 @@ __global__ void bam_entry_check_kernel(const uint16_t* __restrict__ exits, int64
     const int64_t first = header[0], c_first = first / kBamChunk;
     if (first >= n) return;                   // no records at all: every entry is -1, nothing to check (the header alone is the stream)
     if (c < c_first) return;
-    // where the chain from chunk k's entry leaves it (-1: not a live pointer)
+    // where the chain from chunk k's entry leaves it (-1: not a live pointer, or an entry outside the window)
     auto link = [&](int64_t k) -> int64_t {
-        const uint16_t v = exits[entry[k]];
+        const uint16_t v = bam_exit_of(exits, entry[k], header);
         if (v == kBamBroken || v < kBamLeaves) return -1;
         return min((k + 1) * (int64_t)kBamChunk, n) + (int64_t)(v & 0x7FFF);
     };
@@ -192,9 +218,11 @@ __global__ void bam_entry_check_kernel(const uint16_t* __restrict__ exits, int64
     }
 }
 
-// entry[c] = offset of the first record that STARTS in chunk c (-1: none); status[0] != 0 on a broken chain
-__global__ void bam_entry_kernel(const uint16_t* __restrict__ exits, int64_t n, const long long* __restrict__ header, int64_t n_chunks,
-                                 long long* __restrict__ entry, int32_t* __restrict__ status, const int32_t* __restrict__ fallback)
+// The fall-back: entry[c] = offset of the first record that STARTS in chunk c (-1: none), hopping chunk to chunk from the end of the
+// header; status[0] != 0 on a broken chain.  A hop is one look-up when the entry lies in its chunk's window, and a walk over the
+// chunk's records otherwise (long records: few to a chunk).
+__global__ void bam_entry_kernel(const uint8_t* __restrict__ s, const uint16_t* __restrict__ exits, int64_t n, const long long* __restrict__ header,
+                                 int64_t n_chunks, long long* __restrict__ entry, int32_t* __restrict__ status, const int32_t* __restrict__ fallback)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     if (fallback && fallback[0] == 0) return;   // the guessed entries passed every check
@@ -204,10 +232,15 @@ __global__ void bam_entry_kernel(const uint16_t* __restrict__ exits, int64_t n, 
     while (at < n) {
         const int64_t c = at / kBamChunk;
         entry[c] = at;
-        const uint16_t v = exits[at];
-        if (v == kBamBroken || v < kBamLeaves) { status[0] = 2; status[1] = (int32_t)c; return; }   // (after ten doublings every live pointer leaves)
         const int64_t chunk_end = min((c + 1) * (int64_t)kBamChunk, n);
-        at = chunk_end + (v & 0x7FFF);
+        const uint16_t v = bam_exit_of(exits, at, header);
+        if (v == kBamOutside) {
+            while (at >= 0 && at < chunk_end) at = bam_next_record(s, n, at);
+            if (at < 0) { status[0] = 2; status[1] = (int32_t)c; return; }
+        } else {
+            if (v == kBamBroken || v < kBamLeaves) { status[0] = 2; status[1] = (int32_t)c; return; }
+            at = chunk_end + (v & 0x7FFF);
+        }
     }
     if (at != n) { status[0] = 3; }
 }

@@ -162,7 +162,7 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
                        (const PiscesBgzfBlock*)B.d_blocks.p, n_blocks, B.d_stream.p, B.d_status.p);
     // record boundaries without a serial pass over the bytes
     const int64_t n_chunks = (out_bytes + kBamChunk - 1) / kBamChunk;
-    PISCES_HIP_CHECK(h, B.d_exits.reserve((size_t)out_bytes));
+    PISCES_HIP_CHECK(h, B.d_exits.reserve((size_t)n_chunks * kBamGuessWindow));
     PISCES_HIP_CHECK(h, B.d_header.reserve(4));
     PISCES_HIP_CHECK(h, B.d_entry.reserve((size_t)n_chunks));
     PISCES_HIP_CHECK(h, B.d_shared_exit.reserve((size_t)n_chunks));
@@ -182,14 +182,14 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
     }
     const BamFilter F = {ref_id, min_map_quality, skip_duplicates, only_proper_pairs, h->cfg.min_base_call_quality, h->cfg.block_size};
     hipLaunchKernelGGL(bam_header_kernel, dim3(1), dim3(1), 0, h->stream, (const uint8_t*)B.d_stream.p, out_bytes, B.d_header.p, ref_id);
-    hipLaunchKernelGGL(bam_chain_kernel, dim3((unsigned)n_chunks), dim3(1024), 0, h->stream, (const uint8_t*)B.d_stream.p, out_bytes, B.d_exits.p,
+    hipLaunchKernelGGL(bam_chain_kernel, dim3((unsigned)n_chunks), dim3(256), 0, h->stream, (const uint8_t*)B.d_stream.p, out_bytes, B.d_exits.p,
                        B.d_shared_exit.p, (const long long*)B.d_header.p);
     // (d_bstatus[3]: some chunk needs the serial hop)
     hipLaunchKernelGGL(bam_entry_guess_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, h->stream, (const uint32_t*)B.d_shared_exit.p,
                        (const uint16_t*)B.d_exits.p, out_bytes, (const long long*)B.d_header.p, n_chunks, B.d_entry.p, B.d_bstatus.p, B.d_bstatus.p + 3);
     hipLaunchKernelGGL(bam_entry_check_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, h->stream, (const uint16_t*)B.d_exits.p,
                        out_bytes, (const long long*)B.d_header.p, n_chunks, (const long long*)B.d_entry.p, B.d_bstatus.p + 3);
-    hipLaunchKernelGGL(bam_entry_kernel, dim3(1), dim3(1), 0, h->stream, (const uint16_t*)B.d_exits.p, out_bytes, (const long long*)B.d_header.p,
+    hipLaunchKernelGGL(bam_entry_kernel, dim3(1), dim3(1), 0, h->stream, (const uint8_t*)B.d_stream.p, (const uint16_t*)B.d_exits.p, out_bytes, (const long long*)B.d_header.p,
                        n_chunks, B.d_entry.p, B.d_bstatus.p, (const int32_t*)(B.d_bstatus.p + 3));
     hipLaunchKernelGGL(bam_count_kernel, dim3((unsigned)n_chunks), dim3(64), 0, h->stream, (const uint8_t*)B.d_stream.p, out_bytes,
                        (const long long*)B.d_entry.p, F, B.d_n_reads.p, B.d_n_ops.p, B.d_n_bases.p, B.d_n_skipped.p, B.d_n_span.p, B.d_n_indels.p,
