@@ -531,8 +531,8 @@ int32_t pisces_hip_bgzf_inflate(PiscesHip* h, const uint8_t* file, int64_t n_byt
 
 /* ---- BAM records cut on the device (the rest of row f4): the compressed file is the only thing that crosses PCIe --------------------
  * pisces_hip_bam_decode: the BGZF blocks of `file` are inflated into HBM (as above, without the copy back), the BAM record chain is cut
- * there (no serial pass: every byte offset of a 32 KiB chunk is tried as a record start and pointer jumping finds where each chain
- * leaves the chunk), AlignmentSource.ShouldSkipRead (src/exe/Pisces/Logic/Alignment/AlignmentsSource.cs:84-92: unmapped, secondary,
+ * there (no serial pass: every byte offset of the first 4 KiB of a 32 KiB chunk is tried as a record start and its chain followed
+ * to where it leaves the chunk), AlignmentSource.ShouldSkipRead (src/exe/Pisces/Logic/Alignment/AlignmentsSource.cs:84-92: unmapped, secondary,
  * optionally improper pairs and duplicates, MAPQ below the minimum, no CIGAR) drops what the reference drops, and the alignments of
  * reference sequence `ref_id` are decoded into the PiscesReadBatch arrays in device memory, in file order — what BamReader.GetNextAlignment
  * (src/lib/Alignment.IO/BamReader.cs:137) + Read's constructor do per record on the host.  counts = {reads kept, reads of the chromosome
