@@ -362,16 +362,17 @@ __device__ inline void inflate_codes(InflateStream& s, const HuffmanTable& lenco
             total += (int)len;
         }
         if (s.out_pos + total > s.out_len) { s.err = s.err ? s.err : kInflateOutputOverflow; return; }
+        // where this lane's symbol writes: the bytes of the marked literals and pairs below it behind out_pos
+        const int place = s.out_pos + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(lits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lits, 0u)) + (int)before;
 #ifndef PISCES_INFLATE_ABLATE_LIT
-        if ((lits >> s.lane) & 1u)
-            s.out[s.out_pos + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(lits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lits, 0u)) + (int)before] = (uint8_t)(X.le >> 8);
+        if ((lits >> s.lane) & 1u) s.out[place] = (uint8_t)(X.le >> 8);
 #endif
-        int run = 0;
+        // a distance that reaches in front of the output (checked for all pairs at once)
+        if (__builtin_amdgcn_ballot_w64(((pairs >> s.lane) & 1u) && (int)mdist > place)) { s.err = s.err ? s.err : kInflateDistanceTooFar; return; }
         for (uint64_t mm = pairs; mm; mm &= mm - 1) {
             const int m = __builtin_ctzll(mm);
             const int len = __builtin_amdgcn_readlane((int)mlen, m), dist = __builtin_amdgcn_readlane((int)mdist, m);
-            const int at = s.out_pos + __builtin_popcountll(lits & ((1ull << m) - 1ull)) + run;
-            if (dist > at) { s.err = s.err ? s.err : kInflateDistanceTooFar; return; }
+            const int at = __builtin_amdgcn_readlane(place, m);
 #ifndef PISCES_INFLATE_ABLATE_COPY
             // every source byte lies before `at`, also when the pair overlaps itself (dist < len: a run of period dist).  The bytes may
             // be this wave's own stores of a moment ago: a wave's memory instructions reach the cache in program order, no wait is needed.
@@ -383,7 +384,6 @@ __device__ inline void inflate_codes(InflateStream& s, const HuffmanTable& lenco
                 for (int k = s.lane; k < len; k += 64) dst[k] = src[k % dist];
             }
 #endif
-            run += len;
         }
         s.out_pos += total;
     };
