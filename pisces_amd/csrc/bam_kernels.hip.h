@@ -407,7 +407,7 @@ __global__ __launch_bounds__(1024) void bam_scan_ll_kernel(long long* __restrict
 // RegionStateManager.cs:361-383: the aligned segments, and a gap or terminal deletion when CheckDeletionQuality lets it count), and
 // the first read the host pass would have refused (first_error = read index * 8 + code; codes below).
 enum { kBamReadPositionNotPositive = 1, kBamReadCigarLongerThanRead = 2, kBamReadPastInt32 = 3, kBamReadPastBlockMap = 4 };
-__global__ __launch_bounds__(64) void bam_decode_kernel(const uint8_t* __restrict__ s, int64_t n, const long long* __restrict__ entry, BamFilter F,
+__global__ __launch_bounds__(256) void bam_decode_kernel(const uint8_t* __restrict__ s, int64_t n, const long long* __restrict__ entry, BamFilter F,
                                                         const int32_t* __restrict__ read0, const int32_t* __restrict__ op0,
                                                         const int32_t* __restrict__ base0, int32_t* __restrict__ position,
                                                         uint8_t* __restrict__ flags, int32_t* __restrict__ cigar_offset,
@@ -419,19 +419,62 @@ __global__ __launch_bounds__(64) void bam_decode_kernel(const uint8_t* __restric
                                                         uint32_t* __restrict__ block_map, long long n_block_bits,
                                                         unsigned long long* __restrict__ first_error)
 {
+    // Lane 0 walks the chunk's chain (one dependent load a record) and leaves the record offsets in LDS; the threads then take a record
+    // each for what the records add to the batch's arrays (an exclusive scan over the chunk's records gives every record its place);
+    // the four waves then decode a record each, in turn.
+    __shared__ int32_t rec_at[kBamChunk / (4 + kBamMinRecord) + 2];   // relative to the chunk's first byte
+    __shared__ int32_t rec_r[kBamChunk / (4 + kBamMinRecord) + 2], rec_o[kBamChunk / (4 + kBamMinRecord) + 2], rec_b[kBamChunk / (4 + kBamMinRecord) + 2],
+        rec_f[kBamChunk / (4 + kBamMinRecord) + 2];
+    __shared__ long long rec_s[kBamChunk / (4 + kBamMinRecord) + 2];
+    __shared__ int32_t n_rec_s;
     const int64_t c = blockIdx.x;
-    const int lane = threadIdx.x;
-    int64_t at = entry[c];
-    const int64_t chunk_end = min((c + 1) * (int64_t)kBamChunk, n);
-    int r = read0[c], o = op0[c], b = base0[c];
-    long long slot = span0[c];
-    int fslot = indel0[c];
-    long long map_word = -1;      // lane 0: the word of the block map the chunk's reads are setting bits in (reads come sorted: one
-    uint32_t map_bits = 0;        // atomic a word instead of one a read)
-    while (at >= 0 && at < chunk_end) {   // (wave-uniform: every lane follows the same chain)
-        const int32_t bs = bam_le32(s + at);
-        const uint8_t* rec = s + at + 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t c0 = c * (int64_t)kBamChunk, chunk_end = min((c + 1) * (int64_t)kBamChunk, n);
+    if (threadIdx.x == 0) {
+        int k = 0;
+        int64_t at = entry[c];
+        while (at >= 0 && at < chunk_end) {
+            rec_at[k++] = (int32_t)(at - c0);
+            at += 4 + (int64_t)bam_le32(s + at);
+        }
+        n_rec_s = k;
+    }
+    __syncthreads();
+    const int n_rec = n_rec_s;
+    // what each record adds: 1 read (0 when it is not kept: rec_r then marks it), CIGAR operations, bases, log slots, candidate slots
+    for (int i = threadIdx.x; i < n_rec; i += 256) {
+        const uint8_t* rec = s + c0 + rec_at[i] + 4;
+        int keep = 0, ops = 0, nb = 0, ind = 0;
+        long long span = 0;
         if (bam_keep(rec, F)) {
+            keep = 1;
+            ops = (int)bam_le16(rec + 12);
+            nb = bam_le32(rec + 16);
+            const BamCigarSums t = bam_cigar_sums(rec + 32 + rec[8], ops);
+            span = t.ref_span;
+            ind = t.indels;
+        }
+        rec_r[i] = keep; rec_o[i] = ops; rec_b[i] = nb; rec_f[i] = ind; rec_s[i] = span;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {   // (at most 910 records: a serial scan of five counters is a few microseconds)
+        int r = read0[c], o = op0[c], b = base0[c], f = indel0[c];
+        long long sl = span0[c];
+        for (int i = 0; i < n_rec; i++) {
+            const int keep = rec_r[i], ops = rec_o[i], nb = rec_b[i], ind = rec_f[i];
+            const long long span = rec_s[i];
+            rec_r[i] = keep ? r : -1; rec_o[i] = o; rec_b[i] = b; rec_f[i] = f; rec_s[i] = sl;
+            r += keep; o += ops; b += nb; f += ind; sl += span;
+        }
+    }
+    __syncthreads();
+    long long map_word = -1;      // lane 0 of each wave: the word of the block map its reads are setting bits in (reads come sorted:
+    uint32_t map_bits = 0;        // one atomic a word instead of one a read)
+    for (int rec_i = wave; rec_i < n_rec; rec_i += 4) {   // (wave-uniform)
+        const int r = rec_r[rec_i], o = rec_o[rec_i], b = rec_b[rec_i], fslot = rec_f[rec_i];
+        const long long slot = rec_s[rec_i];
+        const uint8_t* rec = s + c0 + rec_at[rec_i] + 4;
+        if (r >= 0) {   // (a kept record: AlignmentSource.ShouldSkipRead was applied when the records were counted above)
             const int l_name = rec[8], n_cigar = (int)bam_le16(rec + 12), l_seq = bam_le32(rec + 16);
             const uint32_t flag = bam_le16(rec + 14);
             const uint8_t* cig = rec + 32 + l_name;
@@ -471,7 +514,7 @@ __global__ __launch_bounds__(64) void bam_decode_kernel(const uint8_t* __restric
                         map_bits |= 1u << (k & 31);
                     }
                 };
-                int ri = 0, indels = 0;
+                int ri = 0;
                 long long rp = pos1, last_mapped = pos1 - 1;
                 uint8_t ok_last = 0;
                 uint32_t op_last = 99, len_last = 0, op_before = 99, len_before = 0;
@@ -496,7 +539,6 @@ __global__ __launch_bounds__(64) void bam_decode_kernel(const uint8_t* __restric
                     }
                     if (on_ref) rp += (long long)len;
                     if (on_read) ri += (int)len;
-                    if (op == 1 || op == 2) indels++;
                     op_before = op_last; len_before = len_last;
                     op_last = op; len_last = len; ok_last = ok;
                 }
@@ -516,14 +558,8 @@ __global__ __launch_bounds__(64) void bam_decode_kernel(const uint8_t* __restric
                 if (code) atomicMin(first_error, (unsigned long long)r * 8ull + (unsigned long long)code);
                 slots[r] = slot;
                 fslots[r] = fslot;
-                slot += rp - pos1;
-                fslot += indels;
             }
-            r++;
-            o += n_cigar;
-            b += l_seq;
         }
-        at += 4 + (int64_t)bs;
     }
     if (lane == 0 && map_bits) atomicOr(block_map + map_word, map_bits);
 }

@@ -242,7 +242,7 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
     PISCES_HIP_CHECK(h, hipMemsetAsync(B.d_block_map.p, 0, map_words * sizeof(uint32_t), h->stream));
     PISCES_HIP_CHECK(h, hipMemsetAsync(B.d_first_error.p, 0xFF, sizeof(unsigned long long), h->stream));
     if (nr > 0)
-        hipLaunchKernelGGL(bam_decode_kernel, dim3((unsigned)n_chunks), dim3(64), 0, h->stream, (const uint8_t*)B.d_stream.p, out_bytes,
+        hipLaunchKernelGGL(bam_decode_kernel, dim3((unsigned)n_chunks), dim3(256), 0, h->stream, (const uint8_t*)B.d_stream.p, out_bytes,
                            (const long long*)B.d_entry.p, F, (const int32_t*)B.d_n_reads.p, (const int32_t*)B.d_n_ops.p, (const int32_t*)B.d_n_bases.p,
                            B.position.p, B.flags.p, B.cigar_offset.p, B.cigar_op.p, B.cigar_len.p, B.seq_offset.p, B.bases.p, B.quals.p,
                            B.op_quality.p, B.read_quality.p, (const long long*)B.d_n_span.p, (const int32_t*)B.d_n_indels.p, B.d_slots.p,
