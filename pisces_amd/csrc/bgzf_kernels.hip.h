@@ -369,6 +369,27 @@ __device__ inline void inflate_codes(InflateStream& s, const HuffmanTable& lenco
 #endif
         // a distance that reaches in front of the output (checked for all pairs at once)
         if (__builtin_amdgcn_ballot_w64(((pairs >> s.lane) & 1u) && (int)mdist > place)) { s.err = s.err ? s.err : kInflateDistanceTooFar; return; }
+        // The pairs of most groups copy a few bytes each from output that older groups wrote: when no source reaches into this group's
+        // own output and the pairs' bytes are 64 at most, lane k takes byte k of them all -- one load and one store for the group's
+        // pairs, no loop, branch or exec mask per pair.
+        const int pair_bytes = total - __builtin_popcountll(lits);
+        const bool is_pair = (pairs >> s.lane) & 1u;
+        if (pairs && pair_bytes <= 64 && !__builtin_amdgcn_ballot_w64(is_pair && place - (int)mdist + (int)mlen > s.out_pos)) {
+            int src_at = 0, dst_at = 0, start = 0;
+            for (uint64_t mm = pairs; mm; mm &= mm - 1) {
+                const int m = __builtin_ctzll(mm);
+                const int len = __builtin_amdgcn_readlane((int)mlen, m), dist = __builtin_amdgcn_readlane((int)mdist, m);
+                const int at = __builtin_amdgcn_readlane(place, m);
+                const int k = s.lane - start;
+                const bool mine = (uint32_t)k < (uint32_t)len;
+                dst_at = mine ? at + k : dst_at;
+                src_at = mine ? at - dist + k : src_at;
+                start += len;
+            }
+#ifndef PISCES_INFLATE_ABLATE_COPY
+            if (s.lane < pair_bytes) s.out[dst_at] = s.out[src_at];
+#endif
+        } else
         for (uint64_t mm = pairs; mm; mm &= mm - 1) {
             const int m = __builtin_ctzll(mm);
             const int len = __builtin_amdgcn_readlane((int)mlen, m), dist = __builtin_amdgcn_readlane((int)mdist, m);
