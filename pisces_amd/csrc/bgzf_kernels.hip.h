@@ -28,13 +28,17 @@ enum : int32_t {
 // ---- one wave per BGZF block ----
 // Block headers and code lengths are read by all 64 lanes alike through one bit buffer (identical scalar registers, broadcast LDS
 // reads: no divergence), the decode tables are filled by all lanes, and the symbols themselves are decoded by the lanes side by side,
-// one bit offset each (inflate_codes).  Output goes straight to HBM.  ~9.5 KB of LDS per wave, so a CU holds as many waves as it has
+// one bit offset each (inflate_codes).  Output goes straight to HBM.  ~8.5 KB of LDS per wave, so a CU holds as many waves as it has
 // slots for and a file's thousands of blocks are all in flight.
 
 // The payload reaches the bit buffer through a window in LDS: kInWindow bytes of the file copied by all 64 lanes at once (16 bytes a
 // lane per load instruction), so that topping up the bit buffer is an LDS read (~100 cycles) and not a global load on the decode's
 // dependent chain (a microsecond while the chip is busy: with a few thousand blocks in flight that wait was most of a symbol's time).
-constexpr int kInWindow = 2048;   // bytes; the window starts on a 16-byte boundary of the file copy
+#ifndef PISCES_INFLATE_WINDOW
+#define PISCES_INFLATE_WINDOW 1024
+#endif
+constexpr int kInWindow = PISCES_INFLATE_WINDOW;   // bytes; the window starts on a 16-byte boundary of the file copy
+static_assert(kInWindow % 1024 == 0 && kInWindow >= 1024, "the window is filled 16 bytes a lane at a time by 64 lanes");
 
 struct InflateStream {
     const uint8_t* in;        // first byte of the payload
