@@ -128,7 +128,10 @@ enum { kPlainCode = 0, kLengthCode = 1, kDistanceCode = 2 };
 #ifndef PISCES_INFLATE_LEN_BITS
 #define PISCES_INFLATE_LEN_BITS 10
 #endif
-constexpr int kLenLutBits = PISCES_INFLATE_LEN_BITS, kDistLutBits = 9;
+#ifndef PISCES_INFLATE_DIST_BITS
+#define PISCES_INFLATE_DIST_BITS 9
+#endif
+constexpr int kLenLutBits = PISCES_INFLATE_LEN_BITS, kDistLutBits = PISCES_INFLATE_DIST_BITS;
 
 __device__ const int16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __device__ const int16_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
