@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define PISCES_HIP_ABI_VERSION 6
+#define PISCES_HIP_ABI_VERSION 7
 
 /* ---- error codes -------------------------------------------------------- */
 #define PISCES_OK                 0
@@ -352,8 +352,10 @@ int32_t pisces_hip_add_candidates(PiscesHip* h, const PiscesCandidate* cands, in
  * (RegionState.GetAllCandidates :393-450).  With the diploid model DiploidLocusProcessor's rules apply (PISCES_GT_OTHERS).  Call it
  * after pisces_hip_set_intervals and before the first flush. */
 int32_t pisces_hip_set_forced_alleles(PiscesHip* h, const PiscesCandidate* alleles_of, int64_t n, const uint8_t* alleles, int64_t allele_bytes);
-/* totals lines: {allelesCalled (IAlleleCaller.TotalNumCalled), variantsCollapsed, readsProcessed,
- * observations} (SmallVariantCaller.cs:114-115) */
+/* totals lines: {allelesCalled (IAlleleCaller.TotalNumCalled), variantsCollapsed, readsProcessed, readsSkipped}
+ * (SmallVariantCaller.cs:114-115; readsSkipped = AlignmentSource's count of the reads ShouldSkipRead dropped, AlignmentsSource.cs:63,84-92:
+ * the reads pisces_hip_bam_decode dropped from the batches that pisces_hip_add_decoded_reads added; reads a host hands over through
+ * pisces_hip_add_reads have passed that filter already).  This is the vector pisces_hip_reduce_summary adds up over the interval shards. */
 int32_t pisces_hip_stats(PiscesHip* h, int64_t out[4]);
 
 /* ---- multi-GPU: the per-chromosome summary across interval shards --------------------------------------------------

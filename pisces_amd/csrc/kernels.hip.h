@@ -142,6 +142,11 @@ struct HistWave {    // call_tiles_wave_kernel: counter of (allele a, direction 
     static __device__ __forceinline__ int idx(int a, int d, int l) { return (a * 4 + d) * kWaveRow + (int)PISCES_TUPLE_COLUMN(l, d); }
 };
 
+struct HistLinear {  // call_store_tiles_kernel (store_kernels.hip.h): the same rows, column = locus (lane = locus when a read is added: no two lanes of
+                     // an instruction share a bank)
+    static __device__ __forceinline__ int idx(int a, int d, int l) { return (a * 4 + d) * kWaveRow + l; }
+};
+
 struct LocusCounts { int h[6][3]; };
 
 template <typename H = HistBlock>
@@ -154,6 +159,7 @@ __device__ __forceinline__ LocusCounts load_counts(const int* hist, int l)
 }
 
 // the wave kernel's two regions folded into the reference's counts: a low-quality A/C/G/T/N base is an N, a deletion stays one
+template <typename HistWave = pisces::HistWave>
 __device__ __forceinline__ LocusCounts load_counts_wave(const int* hist, int l)
 {
     LocusCounts lc;
@@ -656,6 +662,7 @@ __device__ __forceinline__ void wave_lds_sync()
 // Cold path of the wave kernel: alleles whose count or coverage lies beyond the memo tables go through the evaluations the tables
 // were filled with (out-of-line leaves, device_math.hip.h), counts re-read from LDS: it runs after the fast pass, when almost nothing
 // is live.  slow: bit 4 = the Reference candidate, bits 0..3 = variant ranks; returns the variant ranks that were called.
+template <typename H = HistWave>
 __device__ __forceinline__ uint32_t slow_alleles(const int* hist, const uint8_t* s_refwin, uint32_t slow, int l, int pos, int rt, int ref_rank,
                                                  const uint8_t* __restrict__ ref, int64_t win_lo, int64_t win_hi, PiscesCalledAllele* slots,
                                                  const DeviceParams& P)
@@ -667,7 +674,7 @@ __device__ __forceinline__ uint32_t slow_alleles(const int* hist, const uint8_t*
         if (!((slow >> k) & 1u)) continue;
         const bool isRef = k == 4;
         const int a = isRef ? ref_a : allele_of_rank(k);
-        const LocusCounts lc = load_counts_wave(hist, l);
+        const LocusCounts lc = load_counts_wave<H>(hist, l);
         const PointCounts c = point_counts_of(lc, a, isRef, rt, 0);
         int vq = 0;
         if (c.support > 0 && c.total != 0) vq = poisson_qscore_out_of_line(c.support, c.total, P.err_q, P.max_vq, P.ln10);
@@ -684,7 +691,7 @@ __device__ __forceinline__ uint32_t slow_alleles(const int* hist, const uint8_t*
 
 // The call phase of one tile whose histogram sits in LDS: lane = locus.  NW = 2: the two waves of the tile's workgroup share it (wave 0
 // makes the Reference records and the tile directory, wave 1 the variant records; they meet once in LDS).  NW = 1: one wave does all of it.
-template <int NW>
+template <int NW, typename H = HistWave>
 __device__ __forceinline__ void call_phase_wave(const int* hist, const uint8_t* s_refwin, uint8_t* s_vmask, const PiscesTile& tile, const int t,
                                                 const int l, const int wid, const uint8_t* __restrict__ ref, const int32_t ref_start,
                                                 const int64_t ref_len, PiscesCalledAllele* __restrict__ records,
@@ -704,7 +711,7 @@ __device__ __forceinline__ void call_phase_wave(const int* hist, const uint8_t* 
     const int rt = in_ref ? allele_type_of_base(refb) : PISCES_ALLELE_N;
     const int64_t win_lo = (int64_t)ref_start - 1, win_hi = win_lo + ref_len;
     auto slot_of = [&](int k) { return records + ((int64_t)t * kSlotsPerTile + l * 4 + k); };
-    const LocusCounts lc = load_counts_wave(hist, l);
+    const LocusCounts lc = load_counts_wave<H>(hist, l);
     const bool ref_wave = wid == 0, var_wave = wid == NW - 1;
 
     // One allele through the table-first forms; false = a table missed (the record is not made).  With the handle's tables in place
@@ -763,7 +770,7 @@ __device__ __forceinline__ void call_phase_wave(const int* hist, const uint8_t* 
         }
     }
     if (__builtin_expect(__ballot(slow != 0) != 0ull, 0))
-        vmask |= slow_alleles(hist, s_refwin, slow, l, pos, rt, ref_rank, ref, win_lo, win_hi, records + ((int64_t)t * kSlotsPerTile + l * 4), P);
+        vmask |= slow_alleles<H>(hist, s_refwin, slow, l, pos, rt, ref_rank, ref, win_lo, win_hi, records + ((int64_t)t * kSlotsPerTile + l * 4), P);
     if (NW == 2) {
         if (var_wave) s_vmask[l] = (uint8_t)vmask;
         __syncthreads();

@@ -29,6 +29,7 @@
 #include "finder.h"
 #include "kernels.hip.h"
 #include "stream_kernels.hip.h"
+#include "store_kernels.hip.h"
 #include "finder_kernels.hip.h"
 #include "bgzf_kernels.hip.h"
 #include "bam_kernels.hip.h"
@@ -92,6 +93,30 @@ struct DeviceBuf {
         p = nullptr;
         cap = 0;
     }
+    void swap(DeviceBuf& o)
+    {
+        std::swap(p, o.p);
+        std::swap(cap, o.cap);
+    }
+};
+
+// One segment of the read store (store_kernels.hip.h): reads in position order with their descriptors.  Three ways to own the bytes:
+// a batch uploaded in one piece (`blob`, laid out as the staging buffer is; the views point into it), a decoded BAM batch (the decode's
+// own arrays moved in), or the OPEN segment that small batches are appended to (its arrays grow).
+struct ReadSegment {
+    DeviceBuf<uint8_t> blob;
+    DeviceBuf<uint8_t> bases, quals, dirs, cop;
+    DeviceBuf<uint32_t> clen;
+    DeviceBuf<ReadDesc> desc;
+    DeviceBuf<ReadExt> ext;
+    DeviceBuf<int32_t> state;
+    const uint8_t *v_bases = nullptr, *v_quals = nullptr, *v_dirs = nullptr, *v_cop = nullptr;
+    const uint32_t* v_clen = nullptr;
+    int64_t n_reads = 0, n_bases = 0, n_ops = 0;
+    int64_t n_floored = 0;     // reads that were there at the last flush ...
+    int32_t floor = 0;         // ... have their positions below this counted already (DoneProcessing of the blocks below it)
+    int32_t max_key = 0;       // highest block any of its reads touches: the segment is dropped once no block up to it is left
+    bool open = false;         // accepts appended batches
 };
 
 }  // namespace
@@ -153,7 +178,7 @@ struct PiscesHip {
     std::set<std::string> forced_keys;        // position|ref>alt (AlleleCaller.IsForcedAllele)
     std::set<int32_t> forced_positions;       // RegionState.CreateIntervalsFromAllels
     std::vector<std::pair<int32_t, int32_t>> intervals;   // sorted, disjoint [start, end]
-    int64_t stats[4] = {0, 0, 0, 0};      // called, collapsed, reads, observations
+    int64_t stats[4] = {0, 0, 0, 0};      // called, collapsed, reads processed, reads skipped
 
     // cached result of a flush that did not fit the caller's buffer
     bool pending_valid = false;
@@ -258,9 +283,17 @@ struct PiscesHip {
         DeviceBuf<int32_t> d_fslots;       // candidate-record slots of the reads
         int64_t n_reads = 0, n_ops = 0, n_bases = 0, n_skipped = 0;
         bool valid = false;
+        bool moved = false;       // the batch's byte arrays went to the read store (pisces_hip_add_decoded_reads)
         int32_t chain_mode = 0;   // 0: every chunk's entry guessed and checked; 1: the serial hop ran
         int32_t min_bq = 0;
     } bam;
+
+    // the read store (store_kernels.hip.h): the reads of the blocks not yet flushed stay in HBM as they came, a flush calls from them
+    std::vector<std::unique_ptr<ReadSegment>> segments, segment_pool;
+    int read_path = 1;                        // 1: read store (default); 0: observation log (PISCES_HIP_READ_PATH=log: the earlier chain, kept for comparison)
+    size_t store_direct_bytes = (size_t)256 << 10;   // a batch of at least this many bytes becomes a segment of its own (no copy); smaller ones are appended to the open segment
+    size_t store_seal_bytes = (size_t)4 << 20;       // the open segment stops accepting batches at this size
+    std::vector<int32_t> touched_keys;
 
     // device scratch, grow-only
     DeviceBuf<uint32_t> d_tuples;
@@ -323,7 +356,10 @@ static hipError_t ensure_quality_lut(PiscesHip* h)
 }
 
 // tuples of `n_tiles` tiles -> anchor-resolved counts in d_counts (and, with_sums, the base-quality sums in d_sumq), on stream s
-static hipError_t accumulate_tiles(PiscesHip* h, hipStream_t s, const uint32_t* d_tuples, const PiscesTile* d_tiles, int32_t n_tiles, bool with_sums)
+static void store_view(const PiscesHip* h, StoreView* V);
+// with_store: the reads of the handle's read store are walked as well (the streaming surface; the device-resident surface passes false)
+static hipError_t accumulate_tiles(PiscesHip* h, hipStream_t s, const uint32_t* d_tuples, const PiscesTile* d_tiles, int32_t n_tiles, bool with_sums,
+                                   bool with_store = false)
 {
     const size_t nc = (size_t)n_tiles * kTile * PISCES_COUNTS_PER_LOCUS;
     hipError_t e = h->d_counts.reserve(nc);
@@ -333,6 +369,13 @@ static hipError_t accumulate_tiles(PiscesHip* h, hipStream_t s, const uint32_t* 
     if (e != hipSuccess) return e;
     (void)hipMemsetAsync(h->d_counts.p, 0, nc * sizeof(int32_t), s);
     if (with_sums) (void)hipMemsetAsync(h->d_sumq_fix.p, 0, 2 * nc * sizeof(unsigned long long), s);
+    if (with_store && h->read_path == 1) {
+        StoreView V;
+        store_view(h, &V);
+        hipLaunchKernelGGL(accumulate_store_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, V, d_tuples, d_tiles, n_tiles, h->d_counts.p,
+                           h->cfg.min_base_call_quality, with_sums ? h->d_sumq_fix.p : (unsigned long long*)nullptr,
+                           with_sums ? (const ulonglong2*)h->d_bq_lut.p : (const ulonglong2*)nullptr);
+    } else
     hipLaunchKernelGGL(accumulate_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, d_tuples, d_tiles, n_tiles, h->d_counts.p,
                        h->cfg.min_base_call_quality, with_sums ? h->d_sumq_fix.p : (unsigned long long*)nullptr,
                        with_sums ? (const ulonglong2*)h->d_bq_lut.p : (const ulonglong2*)nullptr);
@@ -501,6 +544,10 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         if (kv && std::string(kv) == "auto") h->kernel_variant = 4;
         if (kv && std::string(kv) == "block") h->kernel_variant = 0;
         if (const char* lp = getenv("PISCES_HIP_LDS_PAD")) h->lds_pad = atoi(lp);
+        const char* rp = getenv("PISCES_HIP_READ_PATH");   // "log": reads are expanded into the observation log and bucketed at flush time (the earlier chain)
+        if (rp && std::string(rp) == "log") h->read_path = 0;
+        if (const char* v = getenv("PISCES_HIP_STORE_DIRECT_BYTES")) h->store_direct_bytes = (size_t)std::max(0ll, atoll(v));
+        if (const char* v = getenv("PISCES_HIP_STORE_SEAL_BYTES")) h->store_seal_bytes = (size_t)std::max(0ll, atoll(v));
     }
     {
         // MathOperations.QtoP(q) = Math.Pow(10, -1 * q / 10f) for every integer q-score the caller can produce
@@ -623,6 +670,8 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     h->d_found.release(); h->d_found_pool.release(); h->d_found_slots.release(); h->d_found_pool_first.release();
     h->d_found_misc.release(); h->d_found_totals.release();
     h->d_cands.release(); h->d_alleles.release(); h->d_cand_records.release(); h->d_cand_callable.release();
+    h->segments.clear();
+    h->segment_pool.clear();
     for (hipEvent_t ev : h->ring) (void)hipEventDestroy(ev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -668,6 +717,8 @@ int32_t pisces_hip_set_intervals(PiscesHip* h, const int32_t* starts, const int3
 }
 
 #include "surface_reads.inc.h"
+
+#include "surface_store.inc.h"
 
 #include "surface_flush.inc.h"
 

@@ -140,6 +140,7 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
     if (!h) return PISCES_E_INVALID_ARG;
     if (!file || n_bytes <= 0 || n_blocks <= 0 || !blocks) return fail(h, PISCES_E_INVALID_ARG, "bam_decode: bad arguments");
     h->bam.valid = false;
+    h->bam.moved = false;
     int64_t out_bytes = 0;
     for (int64_t i = 0; i < n_blocks; i++) {
         const PiscesBgzfBlock& b = blocks[i];
@@ -282,6 +283,7 @@ int32_t pisces_hip_bam_fetch(PiscesHip* h, int32_t* position, uint8_t* flags, in
     if (!h) return PISCES_E_INVALID_ARG;
     if (!h->bam.valid) return fail(h, PISCES_E_STATE, "bam_fetch: no decoded batch (pisces_hip_bam_decode first)");
     auto& B = h->bam;
+    if (B.moved) return fail(h, PISCES_E_STATE, "bam_fetch: the decoded batch has been added to the read store (fetch before pisces_hip_add_decoded_reads)");
     const size_t nr = (size_t)B.n_reads, no = (size_t)B.n_ops, nb = (size_t)B.n_bases;
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     auto down = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
@@ -310,6 +312,7 @@ int32_t pisces_hip_add_decoded_reads(PiscesHip* h)
     if (!h) return PISCES_E_INVALID_ARG;
     if (!h->bam.valid) return fail(h, PISCES_E_STATE, "add_decoded_reads: no decoded batch (pisces_hip_bam_decode first)");
     auto& B = h->bam;
+    if (B.moved) return fail(h, PISCES_E_STATE, "add_decoded_reads: the decoded batch has been added already");
     if (B.min_bq != h->cfg.min_base_call_quality) return fail(h, PISCES_E_STATE, "add_decoded_reads: decoded with another minimum base quality");
     { int32_t rcp = refuse_while_batch_is_open(h, "add_decoded_reads"); if (rcp) return rcp; }
     const int32_t nr = (int32_t)B.n_reads;
@@ -333,6 +336,8 @@ int32_t pisces_hip_add_decoded_reads(PiscesHip* h)
         for (uint32_t bits = B.block_map[w]; bits; bits &= bits - 1)
             (void)get_block(h, (int32_t)(((int64_t)w * 32 + __builtin_ctz(bits)) * h->cfg.block_size + 1));
     h->stats[2] += nr;
+    h->stats[3] += B.n_skipped;
+    if (h->read_path == 1) return add_decoded_reads_store(h, found_slots, found_pool, find_on_device);
     int32_t rc = log_reserve(h, B.log_slots);
     if (rc) return rc;
     DevReadBatch db;

@@ -88,6 +88,13 @@ static int32_t bucket_blocks(PiscesHip* h, const std::vector<int32_t>& keys, boo
     tile_geometry(h, keys, clip, tiles, first_tile, tol);
     if (tiles.empty()) return PISCES_OK;
     const int32_t n_tiles = (int32_t)tiles.size();
+    if (h->log_ub == 0) {
+        // nothing in the log (the reads are in the read store, or there are none): tiles without tuple segments, no bucketing
+        PISCES_HIP_CHECK(h, h->d_tiles.reserve(tiles.size()));
+        PISCES_HIP_CHECK(h, h->d_tile_results.reserve(tiles.size()));
+        PISCES_HIP_CHECK(h, h->d_count.reserve(4));
+        return meta_upload(h, h->d_tiles.p, tiles.data(), tiles.size() * sizeof(PiscesTile));
+    }
     // Every stream operation of a flush costs ~4.5 us whatever its size (a 1000-locus block's whole flush is ~130 us of device time), so
     // there are as few as can be: the tile counters arrive zeroed behind the bucket tables, the drop's counter is cleared by the scan,
     // and the tuple buffer is not filled at all (a tile's segment is padded to a multiple of four tuples only so that the next segment
@@ -241,7 +248,14 @@ static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& key
         if (std::binary_search(keys.begin(), keys.end(), block_key(h, kv.first))) { use_counts = true; break; }
 
     std::vector<uint32_t> g;
-    if (!use_counts && !window) {
+    // the read store calls through call_store_tiles_kernel; configurations that kernel is not compiled for (the Diploid strand-bias model,
+    // the 4-wave development form) go through the counts in HBM
+    const bool store = h->read_path == 1;
+    const bool store_fused = h->kernel_variant >= 2 && h->cfg.strand_bias_model != PISCES_SB_DIPLOID;
+    if (!use_counts && !window && store && store_fused) {
+        PISCES_HIP_CHECK(h, launch_call_store_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p,
+                                                    h->d_tile_results.p));
+    } else if (!use_counts && !window && !store) {
         PISCES_HIP_CHECK(h, launch_call_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p,
                                               h->d_tile_results.p));
     } else {
@@ -257,7 +271,7 @@ static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& key
                 if (it != h->gapped_mnv_ref.end()) g[(size_t)t * kTile + (size_t)l] = (uint32_t)it->second;
             }
         { int32_t rcu = meta_upload(h, h->d_gapped.p, g.data(), g.size() * sizeof(uint32_t)); if (rcu) return rcu; }
-        PISCES_HIP_CHECK(h, accumulate_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, window));
+        PISCES_HIP_CHECK(h, accumulate_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, window, true));
         hipLaunchKernelGGL(call_counts_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->d_counts.p, h->d_gapped.p,
                            h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p, h->d_tile_results.p, h->P,
                            window ? h->d_sumq.p : (const double*)nullptr);
@@ -672,7 +686,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         return (bi * tiles_per_block + off / kTile) * kTile + off % kTile;
     };
     if (n_tiles > 0) {
-        PISCES_HIP_CHECK(h, accumulate_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, window));
+        PISCES_HIP_CHECK(h, accumulate_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, window, true));
     } else {
         PISCES_HIP_CHECK(h, h->d_counts.reserve(PISCES_COUNTS_PER_LOCUS));
         if (window) PISCES_HIP_CHECK(h, h->d_sumq.reserve(PISCES_COUNTS_PER_LOCUS));
@@ -1159,6 +1173,7 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
             it = (it->first >= bstart && it->first <= bend) ? h->gapped_mnv_ref.erase(it) : std::next(it);
     }
     h->last_block = nullptr;
+    { int32_t rcs = store_commit_flush(h, h->pending_keys); if (rcs) return rcs; }
     h->stats[0] += h->pending_called;
     h->stats[1] += h->pending_collapsed;
     h->last_up_to_block_key = final_flush ? -1 : block_key(h, up_to_position);
@@ -1252,6 +1267,7 @@ int32_t pisces_hip_flush_begin(PiscesHip* h, int32_t up_to_position)
             it = (it->first >= bstart && it->first <= bend) ? h->gapped_mnv_ref.erase(it) : std::next(it);
     }
     h->last_block = nullptr;
+    { int32_t rcs = store_commit_flush(h, keys); if (rcs) return rcs; }
     h->last_up_to_block_key = final_flush ? -1 : block_key(h, up_to_position);
     A.dropped = st.active && st.drop_now;
     A.bound = bound;
@@ -1323,7 +1339,7 @@ int32_t pisces_hip_get_counts(PiscesHip* h, int32_t start_position, int32_t n, i
     if (rc) return rc;
     const int32_t n_tiles = (int32_t)tiles.size();
     const size_t nc = (size_t)n_tiles * kTile * PISCES_COUNTS_PER_LOCUS;
-    PISCES_HIP_CHECK(h, accumulate_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, false));
+    PISCES_HIP_CHECK(h, accumulate_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, false, true));
     std::vector<int32_t> host(nc);
     PISCES_HIP_CHECK(h, hipMemcpyAsync(host.data(), h->d_counts.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
@@ -1361,7 +1377,7 @@ int32_t pisces_hip_get_base_quality_sums(PiscesHip* h, int32_t start_position, i
     if (rc) return rc;
     const int32_t n_tiles = (int32_t)tiles.size();
     const size_t nc = (size_t)n_tiles * kTile * PISCES_COUNTS_PER_LOCUS;
-    PISCES_HIP_CHECK(h, accumulate_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, true));   // (any handle can serve the sums, not only NoiseModel.Window)
+    PISCES_HIP_CHECK(h, accumulate_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, true, true));   // (any handle can serve the sums, not only NoiseModel.Window)
     std::vector<double> host(nc);
     PISCES_HIP_CHECK(h, hipMemcpyAsync(host.data(), h->d_sumq.p, nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
@@ -1442,11 +1458,6 @@ int32_t pisces_hip_stats(PiscesHip* h, int64_t out[4])
     return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h || !out) return PISCES_E_INVALID_ARG;
     for (int i = 0; i < 4; i++) out[i] = h->stats[i];
-    unsigned long long appended = 0;   // observations: counted where they are made, on the device
-    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
-    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
-    PISCES_HIP_CHECK(h, hipMemcpy(&appended, h->d_log_n.p + 2, sizeof(appended), hipMemcpyDeviceToHost));
-    out[3] = (int64_t)appended;
     return PISCES_OK;
     });
 }

@@ -57,7 +57,7 @@ static int32_t meta_upload(PiscesHip* h, void* dst, const void* src, size_t byte
 }
 
 // next staging pair with room for `bytes`; waits only for the work that used THIS pair two calls ago
-static int32_t stage_reserve(PiscesHip* h, size_t bytes)
+static int32_t stage_reserve(PiscesHip* h, size_t bytes, bool with_device_half = true)
 {
     h->stage_cur ^= 1;
     PiscesHip::Stage& st = h->stage[h->stage_cur];
@@ -74,7 +74,7 @@ static int32_t stage_reserve(PiscesHip* h, size_t bytes)
         PISCES_HIP_CHECK(h, hipHostMalloc((void**)&st.h, want, hipHostMallocDefault));
         st.h_cap = want;
     }
-    PISCES_HIP_CHECK(h, st.d.reserve(bytes));
+    if (with_device_half) PISCES_HIP_CHECK(h, st.d.reserve(bytes));
     h->h_stage = st.h;
     return PISCES_OK;
 }
@@ -416,6 +416,8 @@ int32_t pisces_hip_stage_reads(PiscesHip* h, int32_t n_reads, int64_t n_cigar_op
     });
 }
 
+static int32_t add_reads_store(PiscesHip* h, const PiscesReadBatch* batch);
+
 int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
 {
     return abi_guard<int32_t>(h, [&]() -> int32_t {
@@ -425,9 +427,10 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
     if (batch->n_reads == 0) return PISCES_OK;
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     { int32_t rcf = consume_found(h); if (rcf) return rcf; }
+    if (h->read_path == 1) return add_reads_store(h, batch);
     const int32_t nr = batch->n_reads;
     const int32_t minBQ = h->cfg.min_base_call_quality;
-    // ---- host pass over the CIGARs only (never over the bases): argument checks of the reference's walk, the insertion /
+    // ---- (PISCES_HIP_READ_PATH=log: the observation-log chain) host pass over the CIGARs only (never over the bases): argument checks of the reference's walk, the insertion /
     // deletion candidates, the blocks the read touches, and an upper bound of its observations ----
     auto op_ref = [](uint8_t t) { return t == 'M' || t == 'D' || t == 'N' || t == '=' || t == 'X'; };
     auto op_read = [](uint8_t t) { return t == 'M' || t == 'I' || t == 'S' || t == '=' || t == 'X'; };

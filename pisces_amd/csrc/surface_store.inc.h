@@ -1,0 +1,467 @@
+// surface_store.inc.h — part of pisces_hip.hip (included there, inside its extern "C" block; not a translation unit of its own).
+// The read store behind pisces_hip_add_reads / pisces_hip_add_decoded_reads: the reads of the blocks that
+// are not flushed yet stay in HBM as they came (2 bytes per base + CIGAR), in SEGMENTS of position-sorted reads with a 16-byte
+// descriptor each (store_kernels.hip.h); pisces_hip_flush calls straight from them (call_store_tiles_kernel).  The host keeps, per
+// segment, how many reads it holds, which of them were there at the last flush (their positions below the flushed blocks' end are
+// counted already: DoneProcessing, RegionStateManager.cs:336-353, is a floor, not a compaction) and the highest block any of its reads
+// touches (the segment goes when no block up to it is left).
+
+static void store_view(const PiscesHip* h, StoreView* V)
+{
+    std::memset(V, 0, sizeof(*V));
+    int n = 0;
+    for (auto& sp : h->segments) {
+        const ReadSegment& g = *sp;
+        if (g.n_reads == 0 || n == kMaxSegments) continue;
+        SegmentView& v = V->seg[n++];
+        v.desc = g.desc.p;
+        v.ext = g.ext.p;
+        v.bases = g.v_bases;
+        v.quals = g.v_quals;
+        v.dirs = g.v_dirs;
+        v.cigar_op = g.v_cop;
+        v.cigar_len = g.v_clen;
+        v.state = g.state.p;
+        v.n_reads = (int32_t)g.n_reads;
+        v.n_floored = (int32_t)g.n_floored;
+        v.floor = g.floor;
+    }
+    V->n_segments = n;
+}
+
+static bool store_is_empty(const PiscesHip* h)
+{
+    for (auto& sp : h->segments)
+        if (sp->n_reads > 0) return false;
+    return true;
+}
+
+// a segment without reads, its state words zeroed on the handle's stream (buffers of a retired segment are reused)
+static int32_t store_new_segment(PiscesHip* h, std::unique_ptr<ReadSegment>* out)
+{
+    std::unique_ptr<ReadSegment> g;
+    if (!h->segment_pool.empty()) {
+        g = std::move(h->segment_pool.back());
+        h->segment_pool.pop_back();
+    } else {
+        g.reset(new ReadSegment());
+    }
+    g->n_reads = g->n_bases = g->n_ops = g->n_floored = 0;
+    g->floor = 0;
+    g->max_key = 0;
+    g->open = false;
+    g->v_bases = g->v_quals = g->v_dirs = g->v_cop = nullptr;
+    g->v_clen = nullptr;
+    PISCES_HIP_CHECK(h, g->state.reserve(4));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(g->state.p, 0, 4 * sizeof(int32_t), h->stream));
+    *out = std::move(g);
+    return PISCES_OK;
+}
+
+static void store_retire(PiscesHip* h, std::unique_ptr<ReadSegment> g)
+{
+    // (kernels that read the segment are ordered before whatever reuses its buffers: one stream)
+    if (h->segment_pool.size() < 4) h->segment_pool.push_back(std::move(g));
+}
+
+// DoneProcessing for the read store: the blocks `keys` (a prefix of the blocks there were) are gone.  Every read that is in the store
+// now has its positions up to the end of the last of them counted; segments none of whose reads touch a block that is left go.
+static int32_t store_commit_flush(PiscesHip* h, const std::vector<int32_t>& keys)
+{
+    if (h->read_path != 1 || keys.empty()) return PISCES_OK;
+    const int64_t floor64 = (int64_t)keys.back() * h->cfg.block_size + 1;
+    const int32_t floor = (int32_t)std::min<int64_t>(floor64, 0x7FFFFFFFll);
+    const bool none_left = h->blocks.empty();
+    const int32_t min_key = none_left ? 0 : h->blocks.begin()->first;
+    for (size_t i = 0; i < h->segments.size();) {
+        ReadSegment& g = *h->segments[i];
+        const bool dead = none_left || g.max_key < min_key;
+        if (dead && g.open) {
+            g.n_reads = g.n_bases = g.n_ops = g.n_floored = 0;
+            g.floor = 0;
+            g.max_key = 0;
+            g.v_dirs = nullptr;
+            PISCES_HIP_CHECK(h, hipMemsetAsync(g.state.p, 0, 4 * sizeof(int32_t), h->stream));
+            i++;
+        } else if (dead) {
+            store_retire(h, std::move(h->segments[i]));
+            h->segments.erase(h->segments.begin() + (std::ptrdiff_t)i);
+        } else {
+            g.n_floored = g.n_reads;
+            g.floor = std::max(g.floor, floor);
+            i++;
+        }
+    }
+    return PISCES_OK;
+}
+
+// the batch in the pinned staging buffer (laid out by L) -> device, in one piece or, when it is large, in slices whose host copies
+// run under the transfers of the slices before them
+static int32_t store_upload_batch(PiscesHip* h, const PiscesReadBatch* batch, const StageLayout& L, int32_t nr, size_t n_cig, size_t n_seq, bool staged,
+                                  const std::vector<int32_t>& fslots, uint8_t* d_dst)
+{
+    uint8_t* st = h->h_stage;
+    auto place = [](uint8_t* dst, const void* src, size_t n) { if (n && (const void*)dst != src) std::memcpy(dst, src, n); };
+    place(st + L.off_pos, batch->position, (size_t)nr * 4);
+    place(st + L.off_flags, batch->flags, (size_t)nr);
+    place(st + L.off_coff, batch->cigar_offset, ((size_t)nr + 1) * 4);
+    place(st + L.off_cop, batch->cigar_op, n_cig);
+    place(st + L.off_clen, batch->cigar_len, n_cig * 4);
+    place(st + L.off_soff, batch->seq_offset, ((size_t)nr + 1) * 4);
+    if (batch->deletion_directions) place(st + L.off_deldirs, batch->deletion_directions, 2 * n_cig);
+    std::memcpy(st + L.off_fslots, fslots.data(), ((size_t)nr + 1) * 4);
+    struct Seg { size_t dst; const uint8_t* src; size_t len; };
+    const Seg segs[3] = {{L.off_bases, batch->bases, n_seq}, {L.off_quals, batch->quals, n_seq}, {L.off_dirs, batch->directions, batch->directions ? n_seq : 0}};
+    const size_t bulk = 2 * n_seq + (batch->directions ? n_seq : 0);
+    constexpr size_t kSlice = (size_t)8 << 20;
+    if (staged || bulk < 2 * kSlice) {
+        for (const Seg& g : segs) place(st + g.dst, g.src, g.len);
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(d_dst, st, L.total, hipMemcpyHostToDevice, h->stream));
+        return PISCES_OK;
+    }
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(d_dst, st, L.off_bases, hipMemcpyHostToDevice, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(d_dst + L.off_slots, st + L.off_slots, L.total - L.off_slots, hipMemcpyHostToDevice, h->stream));
+    struct Slice { size_t dst; const uint8_t* src; size_t len; };
+    std::vector<Slice> slices;
+    for (const Seg& g : segs)
+        for (size_t o = 0; o < g.len; o += kSlice) slices.push_back({g.dst + o, g.src + o, std::min(kSlice, g.len - o)});
+    const int n_threads = (int)std::min<size_t>(4, std::max<unsigned>(1u, std::thread::hardware_concurrency()));
+    std::vector<std::atomic<int>> parts_done(slices.size());
+    for (auto& a : parts_done) a.store(0, std::memory_order_relaxed);
+    auto worker = [&](int w) {
+        for (size_t k = 0; k < slices.size(); k++) {
+            const size_t per = (slices[k].len + (size_t)n_threads - 1) / (size_t)n_threads, lo = std::min(slices[k].len, per * (size_t)w),
+                         hi = std::min(slices[k].len, lo + per);
+            if (hi > lo) std::memcpy(st + slices[k].dst + lo, slices[k].src + lo, hi - lo);
+            parts_done[k].fetch_add(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int w = 1; w < n_threads; w++) pool.emplace_back(worker, w);
+    hipError_t first_error = hipSuccess;
+    for (size_t k = 0; k < slices.size(); k++) {
+        const size_t per = (slices[k].len + (size_t)n_threads - 1) / (size_t)n_threads, hi = std::min(slices[k].len, per);
+        if (hi) std::memcpy(st + slices[k].dst, slices[k].src, hi);
+        parts_done[k].fetch_add(1, std::memory_order_release);
+        while (parts_done[k].load(std::memory_order_acquire) < n_threads) std::this_thread::yield();
+        if (first_error == hipSuccess)
+            first_error = hipMemcpyAsync(d_dst + slices[k].dst, st + slices[k].dst, slices[k].len, hipMemcpyHostToDevice, h->stream);
+    }
+    for (auto& t : pool) t.join();
+    PISCES_HIP_CHECK(h, first_error);
+    return PISCES_OK;
+}
+
+// Where a batch goes: a segment of its own (`direct`: its device arrays ARE the segment, nothing is copied) or the open segment (small
+// batches; their bytes are appended by segment_copy_kernel).  Only the last segment is ever open, and at most kMaxSegments - 1 are closed.
+struct StorePlace {
+    ReadSegment* seg = nullptr;
+    bool direct = false;
+    bool fresh = false;        // the segment was made for this batch (it leaves again if the batch fails)
+};
+static int32_t store_place_batch(PiscesHip* h, size_t bulk_bytes, StorePlace* out)
+{
+    ReadSegment* open = (!h->segments.empty() && h->segments.back()->open) ? h->segments.back().get() : nullptr;
+    const size_t n_closed = h->segments.size() - (open ? 1 : 0);
+    StorePlace pl;
+    if (bulk_bytes >= h->store_direct_bytes && n_closed < (size_t)kMaxSegments - 1) {
+        std::unique_ptr<ReadSegment> g;
+        { int32_t rc = store_new_segment(h, &g); if (rc) return rc; }
+        pl.seg = g.get();
+        pl.direct = true;
+        pl.fresh = true;
+        h->segments.insert(h->segments.end() - (open ? 1 : 0), std::move(g));   // (the open segment stays last)
+    } else if (open) {
+        pl.seg = open;
+    } else {
+        std::unique_ptr<ReadSegment> g;
+        { int32_t rc = store_new_segment(h, &g); if (rc) return rc; }
+        g->open = true;
+        pl.seg = g.get();
+        pl.fresh = true;
+        h->segments.push_back(std::move(g));
+    }
+    *out = pl;
+    return PISCES_OK;
+}
+static void store_unplace(PiscesHip* h, const StorePlace& pl)
+{
+    if (!pl.fresh) return;
+    for (size_t i = 0; i < h->segments.size(); i++)
+        if (h->segments[i].get() == pl.seg) {
+            store_retire(h, std::move(h->segments[i]));
+            h->segments.erase(h->segments.begin() + (std::ptrdiff_t)i);
+            return;
+        }
+}
+// the open segment closes once it is large (and a closed one more is allowed)
+static void store_maybe_seal(PiscesHip* h, ReadSegment* g)
+{
+    if (!g->open) return;
+    const size_t n_closed = h->segments.size() - 1;
+    if ((size_t)(2 * g->n_bases + 5 * g->n_ops) >= h->store_seal_bytes && n_closed < (size_t)kMaxSegments - 1) g->open = false;
+}
+
+// Appends the batch whose arrays (offsets relative to the batch) lie on the device at `src` to the segment: descriptors always, the
+// bytes only when the batch joins the open segment.
+struct StoreBatchArrays {
+    const int32_t* position;
+    const uint8_t* flags;
+    const int32_t* cigar_offset;
+    const uint8_t* cigar_op;
+    const uint32_t* cigar_len;
+    const int32_t* seq_offset;
+    const uint8_t* bases;
+    const uint8_t* quals;
+    const uint8_t* dirs;   // or nullptr
+};
+static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const StoreBatchArrays& A, int32_t nr, size_t n_cig, size_t n_seq)
+{
+    ReadSegment& g = *pl.seg;
+    if (g.n_reads + nr > 0x7FFFFF00ll) return fail(h, PISCES_E_INVALID_ARG, "add_reads: too many reads held at once");
+    ShapeArgs S;
+    S.position = A.position; S.flags = A.flags; S.cigar_offset = A.cigar_offset; S.cigar_op = A.cigar_op; S.cigar_len = A.cigar_len;
+    S.seq_offset = A.seq_offset;
+    S.n_reads = nr;
+    if (pl.direct) {
+        PISCES_HIP_CHECK(h, g.desc.reserve((size_t)nr));
+        PISCES_HIP_CHECK(h, g.ext.reserve((size_t)nr));
+        g.v_bases = A.bases; g.v_quals = A.quals; g.v_dirs = A.dirs; g.v_cop = A.cigar_op; g.v_clen = A.cigar_len;
+        S.n0 = 0; S.base0 = 0; S.ops0 = 0;
+    } else {
+        const size_t nb = (size_t)g.n_bases, no = (size_t)g.n_ops, n0 = (size_t)g.n_reads;
+        PISCES_HIP_CHECK(h, g.desc.grow_keep(n0 + (size_t)nr, n0, h->stream));
+        PISCES_HIP_CHECK(h, g.ext.grow_keep(n0 + (size_t)nr, n0, h->stream));
+        PISCES_HIP_CHECK(h, g.bases.grow_keep(nb + n_seq + 16, nb, h->stream));
+        PISCES_HIP_CHECK(h, g.quals.grow_keep(nb + n_seq + 16, nb, h->stream));
+        PISCES_HIP_CHECK(h, g.cop.grow_keep(no + n_cig + 16, no, h->stream));
+        PISCES_HIP_CHECK(h, g.clen.grow_keep(no + n_cig + 16, no, h->stream));
+        const bool tracks = g.v_dirs != nullptr;
+        const bool wants = A.dirs != nullptr || tracks;
+        if (wants) PISCES_HIP_CHECK(h, g.dirs.grow_keep(std::max(g.bases.cap, nb + n_seq + 16), tracks ? nb : 0, h->stream));
+        g.v_bases = g.bases.p; g.v_quals = g.quals.p; g.v_cop = g.cop.p; g.v_clen = g.clen.p;
+        g.v_dirs = wants ? g.dirs.p : nullptr;
+        CopyRanges C;
+        std::memset(&C, 0, sizeof(C));
+        C.dst[0] = g.bases.p + nb; C.src[0] = A.bases; C.n[0] = (int64_t)n_seq;
+        C.dst[1] = g.quals.p + nb; C.src[1] = A.quals; C.n[1] = (int64_t)n_seq;
+        C.dst[2] = g.cop.p + no; C.src[2] = A.cigar_op; C.n[2] = (int64_t)n_cig;
+        C.dst[3] = (uint8_t*)(g.clen.p + no); C.src[3] = (const uint8_t*)A.cigar_len; C.n[3] = (int64_t)n_cig * 4;
+        if (A.dirs) { C.dst[4] = g.dirs.p + nb; C.src[4] = A.dirs; C.n[4] = (int64_t)n_seq; }
+        const int64_t most = std::max<int64_t>((int64_t)n_seq, (int64_t)n_cig * 4);
+        if (most > 0)
+            hipLaunchKernelGGL(segment_copy_kernel, dim3((unsigned)std::min<int64_t>((most + 255) / 256, 2048)), dim3(256), 0, h->stream, C);
+        S.n0 = (int32_t)n0; S.base0 = (int64_t)nb; S.ops0 = (int64_t)no;
+        if (A.dirs && !tracks && n0 > 0)   // the reads the segment held before its first batch with directions
+            hipLaunchKernelGGL(segment_fill_dirs_kernel, dim3((unsigned)((n0 + 3) / 4)), dim3(256), 0, h->stream, (const ReadDesc*)g.desc.p,
+                               (const ReadExt*)g.ext.p, 0, (int32_t)n0, g.dirs.p);
+    }
+    S.desc = g.desc.p;
+    S.ext = g.ext.p;
+    S.state = g.state.p;
+    hipLaunchKernelGGL(read_shape_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, h->stream, S);
+    if (!pl.direct && !A.dirs && g.v_dirs)   // a batch without directions in a segment that tracks them
+        hipLaunchKernelGGL(segment_fill_dirs_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, h->stream, (const ReadDesc*)g.desc.p,
+                           (const ReadExt*)g.ext.p, S.n0, S.n0 + nr, g.dirs.p);
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    return PISCES_OK;
+}
+
+// pisces_hip_add_reads with the read store: ONE host pass over the CIGARs (argument checks of the reference's walk, the blocks the reads
+// touch, the candidate-record slots), the batch across PCIe once, descriptors and candidate discovery on the device.  Nothing of the
+// handle's state changes before the whole batch has been checked.
+static int32_t add_reads_store(PiscesHip* h, const PiscesReadBatch* batch)
+{
+    const int32_t nr = batch->n_reads;
+    const int32_t minBQ = h->cfg.min_base_call_quality;
+    const size_t n_cig = (size_t)batch->cigar_offset[nr], n_seq = (size_t)batch->seq_offset[nr];
+    const StageLayout L = stage_layout((size_t)nr, n_cig, n_seq, batch->directions != nullptr, batch->deletion_directions != nullptr);
+    const bool staged = h->staged_total == L.total && h->h_stage && (const uint8_t*)batch->position == h->h_stage + L.off_pos &&
+                        batch->bases == h->h_stage + L.off_bases && batch->quals == h->h_stage + L.off_quals;
+    h->staged_total = 0;
+    auto op_ref = [](uint8_t t) { return t == 'M' || t == 'D' || t == 'N' || t == '=' || t == 'X'; };
+    auto op_read = [](uint8_t t) { return t == 'M' || t == 'I' || t == 'S' || t == '=' || t == 'X'; };
+    const bool find_on_device = !h->h_ref.empty();   // without a reference only the IStateManager half (allele counts) runs
+    const bool count_indels = find_on_device && !h->cfg.call_mnvs;
+    std::vector<int32_t>& fslots = h->found_slots_host;
+    fslots.assign((size_t)nr + 1, 0);
+    std::vector<int32_t>& touched = h->touched_keys;
+    touched.clear();
+    int64_t found_slots = 0, found_pool = 0;
+    int32_t max_key = 0, last_touched = -1;
+    const int32_t bs = h->cfg.block_size;
+    for (int32_t i = 0; i < nr; i++) {
+        const ReadView r = read_view(batch, i);
+        fslots[(size_t)i] = (int32_t)found_slots;
+        if (r.position <= 0) return fail(h, PISCES_E_INVALID_ARG, "Position must be greater than 0.");
+        if (r.read_len < 0 || r.n_cigar < 0) return fail(h, PISCES_E_INVALID_ARG, "add_reads: malformed read batch");
+        auto touch = [&](int64_t from, int64_t to) {   // inclusive: GetBlock(position) for every position that receives a count (RegionStateManager.cs:361-383)
+            if (to < 1) return;
+            if (from < 1) from = 1;
+            for (int32_t k = block_key(h, (int32_t)from); k <= block_key(h, (int32_t)to); k++) {
+                if (k != last_touched) { touched.push_back(k); last_touched = k; }
+                max_key = std::max(max_key, k);
+            }
+        };
+        auto delq = [&](int idx) {   // CandidateVariantFinder.CheckDeletionQuality (CandidateVariantFinder.cs:294-320)
+            if (r.read_len == 0) return false;
+            const int after = idx < r.read_len ? r.quals[idx] : r.quals[idx - 1];
+            const int before = idx > 0 ? r.quals[idx - 1] : after;
+            return before >= minBQ && after >= minBQ;
+        };
+        int64_t read_span = 0, ref_span = 0;
+        for (int c = 0; c < r.n_cigar; c++) {
+            const uint8_t t = r.cigar_op[c];
+            if (op_read(t)) read_span += r.cigar_len[c];
+            if (op_ref(t)) ref_span += r.cigar_len[c];
+        }
+        if (read_span > r.read_len) return fail(h, PISCES_E_INVALID_ARG, "add_reads: CIGAR does not match the read");
+        if ((int64_t)r.position + ref_span > 0x7FFFFFFFll) return fail(h, PISCES_E_INVALID_ARG, "add_reads: read runs past position 2^31 - 1");
+        if (r.dirs)
+            for (int k = 0; k < r.read_len; k++)
+                if (r.dirs[k] > 2) return fail(h, PISCES_E_INVALID_ARG, "add_reads: CIGAR does not match the read");
+        int64_t rp = r.position, last_mapped = (int64_t)r.position - 1;
+        int ri = 0;
+        for (int c = 0; c < r.n_cigar; c++) {
+            const uint8_t t = r.cigar_op[c];
+            const int64_t len = r.cigar_len[c];
+            if (r.del_dirs && t == 'D')
+                for (int k = 0; k < 2; k++)
+                    if (r.del_dirs[2 * c + k] > 2 && r.del_dirs[2 * c + k] != PISCES_DIR_UNTRACKED)
+                        return fail(h, PISCES_E_INVALID_ARG, "add_reads: deletion_directions holds a value that is no DirectionType");
+            if (count_indels) {
+                if (t == 'I' || t == 'D') found_slots++;
+                if (t == 'I' && len > (int64_t)kFoundInline) found_pool += len;
+            }
+            if (op_read(t) && op_ref(t) && len > 0) {
+                if (rp > last_mapped + 1 && ri < r.read_len && delq(ri)) touch(last_mapped + 1, rp - 1);
+                touch(rp, rp + len - 1);
+                last_mapped = rp + len - 1;
+            }
+            if (op_ref(t)) rp += len;
+            if (op_read(t)) ri += (int)len;
+        }
+        const int nc = r.n_cigar;
+        const bool ends_del = nc >= 1 && r.cigar_op[nc - 1] == 'D';
+        const bool ends_del_soft = nc >= 2 && r.cigar_op[nc - 2] == 'D' && r.cigar_op[nc - 1] == 'S';
+        if (ends_del && r.read_len > 0 && delq(r.read_len - 1)) touch(last_mapped + 1, last_mapped + r.cigar_len[nc - 1]);
+        if (ends_del_soft) {
+            const int idx = r.read_len - (int)r.cigar_len[nc - 1];
+            if (idx >= 0 && idx < r.read_len && delq(idx)) touch(last_mapped + 1, last_mapped + r.cigar_len[nc - 2]);
+        }
+        if (found_slots > 0x7FFFFFF0ll || found_pool > 0x7FFFFFF0ll) return fail(h, PISCES_E_INVALID_ARG, "add_reads: too many insertions / deletions in one batch");
+    }
+    fslots[(size_t)nr] = (int32_t)found_slots;
+
+    // ---- where the batch goes, and across PCIe in one piece
+    const size_t bulk = 2 * n_seq + (batch->directions ? n_seq : 0) + 5 * n_cig;
+    StorePlace pl;
+    { int32_t rc = store_place_batch(h, bulk, &pl); if (rc) return rc; }
+    int32_t rc = staged ? PISCES_OK : stage_reserve(h, L.total, !pl.direct);
+    if (rc == PISCES_OK && pl.direct) {
+        hipError_t e = pl.seg->blob.reserve(L.total);
+        if (e != hipSuccess) rc = fail(h, PISCES_E_DEVICE, std::string("add_reads: ") + hipGetErrorString(e));
+    }
+    if (rc == PISCES_OK && !pl.direct && staged) {   // (stage_reads reserved the device half with the pinned one)
+        hipError_t e = h->stage[h->stage_cur].d.reserve(L.total);
+        if (e != hipSuccess) rc = fail(h, PISCES_E_DEVICE, std::string("add_reads: ") + hipGetErrorString(e));
+    }
+    if (rc) { store_unplace(h, pl); return rc; }
+    uint8_t* const d = pl.direct ? pl.seg->blob.p : D_STAGE(h);
+    rc = store_upload_batch(h, batch, L, nr, n_cig, n_seq, staged, fslots, d);
+    DevReadBatch db;
+    db.position = (const int32_t*)(d + L.off_pos);
+    db.flags = d + L.off_flags;
+    db.cigar_offset = (const int32_t*)(d + L.off_coff);
+    db.cigar_op = d + L.off_cop;
+    db.cigar_len = (const uint32_t*)(d + L.off_clen);
+    db.seq_offset = (const int32_t*)(d + L.off_soff);
+    db.bases = d + L.off_bases;
+    db.quals = d + L.off_quals;
+    db.dirs = batch->directions ? d + L.off_dirs : nullptr;
+    db.n_reads = nr;
+    if (rc == PISCES_OK) {
+        const StoreBatchArrays A = {db.position, db.flags, db.cigar_offset, db.cigar_op, db.cigar_len, db.seq_offset, db.bases, db.quals, db.dirs};
+        rc = store_append_arrays(h, pl, A, nr, n_cig, n_seq);
+    }
+    // ICandidateVariantFinder.FindCandidates + IStateManager.AddCandidates (SmallVariantCaller.cs:92-96) on the device, on the batch as it was uploaded
+    if (rc == PISCES_OK && find_on_device && (h->cfg.call_mnvs || found_slots > 0))
+        rc = enqueue_candidate_discovery(h, db, batch->deletion_directions ? d + L.off_deldirs : nullptr, nr, (const int32_t*)(d + L.off_fslots), found_slots,
+                                         found_pool);
+    { int32_t rcs = stage_release(h); if (rc == PISCES_OK) rc = rcs; }   // (transfers out of the pinned buffer may be in flight whatever happened after them)
+    if (rc) {
+        (void)hipStreamSynchronize(h->stream);
+        store_unplace(h, pl);
+        return rc;
+    }
+    // ---- commit
+    ReadSegment& g = *pl.seg;
+    g.n_reads += nr;
+    g.n_bases += (int64_t)n_seq;
+    g.n_ops += (int64_t)n_cig;
+    g.max_key = std::max(g.max_key, max_key);
+    store_maybe_seal(h, &g);
+    for (int32_t k : touched) (void)get_block(h, (k - 1) * bs + 1);
+    h->stats[2] += nr;
+    return PISCES_OK;
+}
+
+// pisces_hip_add_decoded_reads with the read store: a large decoded batch becomes a segment as it lies (its arrays change owner: the
+// decode's next batch gets the buffers of a retired segment), a small one joins the open segment.
+static int32_t add_decoded_reads_store(PiscesHip* h, int64_t found_slots, int64_t found_pool, bool find_on_device)
+{
+    auto& B = h->bam;
+    const int32_t nr = (int32_t)B.n_reads;
+    const size_t n_cig = (size_t)B.n_ops, n_seq = (size_t)B.n_bases;
+    int32_t max_key = 0;
+    for (size_t w = B.block_map.size(); w-- > 0;)
+        if (B.block_map[w]) { max_key = (int32_t)(w * 32 + (31 - (size_t)__builtin_clz(B.block_map[w]))) + 1; break; }
+    StorePlace pl;
+    { int32_t rc = store_place_batch(h, 2 * n_seq + 5 * n_cig, &pl); if (rc) return rc; }
+    ReadSegment& g = *pl.seg;
+    if (pl.direct) {
+        g.bases.swap(B.bases);
+        g.quals.swap(B.quals);
+        g.cop.swap(B.cigar_op);
+        g.clen.swap(B.cigar_len);
+        B.moved = true;
+    }
+    const StoreBatchArrays A = {B.position.p, B.flags.p, B.cigar_offset.p, pl.direct ? g.cop.p : B.cigar_op.p, pl.direct ? g.clen.p : B.cigar_len.p,
+                                B.seq_offset.p, pl.direct ? g.bases.p : B.bases.p, pl.direct ? g.quals.p : B.quals.p, nullptr};
+    int32_t rc = store_append_arrays(h, pl, A, nr, n_cig, n_seq);
+    if (rc == PISCES_OK && find_on_device && (h->cfg.call_mnvs || found_slots > 0)) {
+        DevReadBatch db;
+        db.position = A.position; db.flags = A.flags; db.cigar_offset = A.cigar_offset; db.cigar_op = A.cigar_op; db.cigar_len = A.cigar_len;
+        db.seq_offset = A.seq_offset; db.bases = A.bases; db.quals = A.quals; db.dirs = nullptr; db.n_reads = nr;
+        rc = enqueue_candidate_discovery(h, db, nullptr, nr, (const int32_t*)B.d_fslots.p, found_slots, found_pool);
+    }
+    if (rc) {
+        (void)hipStreamSynchronize(h->stream);
+        if (pl.direct) { g.bases.swap(B.bases); g.quals.swap(B.quals); g.cop.swap(B.cigar_op); g.clen.swap(B.cigar_len); B.moved = false; }
+        store_unplace(h, pl);
+        return rc;
+    }
+    g.n_reads += nr;
+    g.n_bases += (int64_t)n_seq;
+    g.n_ops += (int64_t)n_cig;
+    g.max_key = std::max(g.max_key, max_key);
+    store_maybe_seal(h, &g);
+    return PISCES_OK;
+}
+
+// the flush's kernel: reads of the store (+ the bucketed tuples of pisces_hip_add_observations) -> LDS histogram -> calls
+static hipError_t launch_call_store_tiles(PiscesHip* h, hipStream_t s, const uint32_t* d_tuples, const PiscesTile* d_tiles, int32_t n_tiles,
+                                          const uint8_t* d_ref, int32_t ref_start, int64_t ref_len, PiscesCalledAllele* d_records, PiscesTileResult* d_tr,
+                                          hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
+{
+    StoreView V;
+    store_view(h, &V);
+    const bool two = h->kernel_variant == 3 || (h->kernel_variant == 4 && (int64_t)n_tiles <= (int64_t)h->n_cus * 32);
+    if (two)
+        hipExtLaunchKernelGGL(call_store_tiles_kernel<2>, dim3((unsigned)n_tiles), dim3(128), 0u, s, e0, e1, 0u, V, d_tuples, d_tiles, n_tiles, d_ref, ref_start,
+                              ref_len, d_records, d_tr, h->P, (const DeviceParams*)h->d_params.p);
+    else
+        hipExtLaunchKernelGGL(call_store_tiles_kernel<1>, dim3((unsigned)n_tiles), dim3(64), 0u, s, e0, e1, 0u, V, d_tuples, d_tiles, n_tiles, d_ref, ref_start,
+                              ref_len, d_records, d_tr, h->P, (const DeviceParams*)h->d_params.p);
+    return hipGetLastError();
+}

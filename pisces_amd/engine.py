@@ -298,7 +298,8 @@ class HipVariantCaller:
     def Stats(self):
         s = (C.c_int64 * 4)()
         _check(self._h, lib.pisces_hip_stats(self._h, s))
-        return {"TotalNumCalled": s[0], "TotalNumCollapsed": s[1], "reads": s[2], "observations": s[3]}
+        # SmallVariantCaller.cs:114-115 / AlignmentsSource.cs:63: the vector a multi-GPU job adds up over its interval shards
+        return {"TotalNumCalled": s[0], "TotalNumCollapsed": s[1], "reads": s[2], "reads_skipped": s[3]}
 
     # ---- device-resident surface ----
     def call_tiles(self, d_tuples, d_tiles, n_tiles, d_ref, ref_start, ref_len, d_records, capacity, d_tile_results, stream=None):

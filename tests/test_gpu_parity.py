@@ -343,7 +343,7 @@ def test_error_paths(torch_cuda):
             assert e.value.code == _abi.E_INVALID_ARG and needle in e.value.message
             assert c.Stats() == before and c.GetCounts(20, 8).sum() == 0
         c.AddAlleleCounts(_abi.ReadBatch([good]))
-        assert c.GetCounts(20, 8).sum() == 8 and c.Stats()["observations"] == 9 and c.Stats()["reads"] == 1
+        assert c.GetCounts(20, 8).sum() == 8 and c.Stats()["reads"] == 1 and c.Stats()["reads_skipped"] == 0
     with pytest.raises(engine.PiscesHipError):
         engine.HipVariantCaller(_abi.default_config(strand_bias_model=7))
     with pytest.raises(engine.PiscesHipError):
@@ -556,10 +556,10 @@ def test_device_read_walk_matches_oracle_on_random_cigars(torch_cuda):
         for k in range(0, len(reads), 97):                        # several add_reads calls: the log grows and keeps its content
             c.AddAlleleCounts(_abi.ReadBatch(reads[k:k + 97]))
         got = c.GetCounts(900, 2200)
-        n_obs = c.Stats()["observations"]
+        n_reads = c.Stats()["reads"]
     exp = st.counts()
     np.testing.assert_array_equal(got.reshape(exp.shape), exp)
-    assert n_obs == int(exp.sum())
+    assert n_reads == len(reads)
 
 
 def test_committed_fixture_without_the_oracle(torch_cuda):
@@ -862,7 +862,7 @@ def test_streaming_surface_equals_device_resident_surface_at_size(torch_cuda):
         stats = c.Stats()
     streamed = np.concatenate(streamed)
     assert streamed.tobytes() == resident.tobytes()
-    assert stats["reads"] == A * 500 and stats["observations"] == p.n_obs
+    assert stats["reads"] == A * 500 and stats["reads_skipped"] == 0
     # the whole pileup in ONE add_reads call: 20 MB of bases + qualities, staged in slices by worker threads under the PCIe transfer
     # (stitched per-base directions ride along as a third bulk array)
     whole = synth.reads_of(p, A, first_amplicon=0)
