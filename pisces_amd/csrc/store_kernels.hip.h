@@ -17,9 +17,8 @@
 // Reads of a segment are in position order (a BAM is); a tile's reads are then the index range [first read that can still reach the
 // tile, first read that starts behind it), found by a 64-ary search over the descriptors (every lane probes one: 2-4 dependent loads).
 // A segment that turned out not to be sorted (state[0]) is scanned in whole: slow, still exact.
-// Lane = locus: for a read of one aligned run (soft clips allowed: most reads) lane l takes the base on locus l of the tile, one byte
-// load each for base and quality, one ds_add — 64 consecutive bytes per load instruction, no two lanes on one LDS bank.  Reads with
-// insertions, deletions or skips go through read_walk.h's per-base function (the walk the host form and the log path use).
+// A read of one aligned run (soft clips allowed: most reads) is taken sixteen lanes at a time, four bases a lane (walk_segment);
+// reads with insertions, deletions or skips go through read_walk.h's per-base function (the walk the host form and the log path use).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -45,7 +44,7 @@ constexpr uint32_t kDescLenMask = 0xFFFFFu;      // bases of the one aligned run
 constexpr uint32_t kDescComplex = 1u << 20;      // insertions / deletions / skips / anything but clips around one aligned run: general walk
 constexpr uint32_t kDescReverse = 1u << 21;      // flags bit 0 (direction of every base unless the segment tracks per-base directions)
 constexpr int kMaxSegments = 8;
-constexpr int kStateUnsorted = 0, kStateReach = 1;
+constexpr int kStateUnsorted = 0, kStateReach = 1, kStateComplex = 2;
 
 struct SegmentView {
     const ReadDesc* desc;
@@ -55,7 +54,8 @@ struct SegmentView {
     const uint8_t* dirs;          // per-base DirectionType of every read of the segment, or nullptr (direction = kDescReverse)
     const uint8_t* cigar_op;
     const uint32_t* cigar_len;
-    const int32_t* state;         // [kStateUnsorted] != 0: not in position order; [kStateReach]: longest reference span of a read
+    const int32_t* state;         // [kStateUnsorted] != 0: not in position order; [kStateReach]: longest reference span of a read;
+                                  // [kStateComplex] != 0: some read needs the general walk
     int32_t n_reads;
     int32_t n_floored;            // reads [0, n_floored) were there at the last flush: their positions below `floor` are counted already
     int32_t floor;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void read_shape_kernel(ShapeArgs A)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     int reach = 0;
-    bool unsorted = false;
+    bool unsorted = false, complex_read = false;
     if (r < A.n_reads) {
         const int c0 = A.cigar_offset[r], nc = A.cigar_offset[r + 1] - c0;
         const int s0 = A.seq_offset[r], n = A.seq_offset[r + 1] - s0;
@@ -125,16 +125,19 @@ __global__ __launch_bounds__(256) void read_shape_kernel(ShapeArgs A)
         e.n_bases = n;
         A.ext[A.n0 + r] = e;
         reach = (int)(ref_span > 0x7FFFFFFFll ? 0x7FFFFFFFll : ref_span);
+        complex_read = !simple;
         // position order, the batch's first read against the read before it in the segment (written by an earlier launch)
         if (r > 0) unsorted = A.position[r - 1] > pos0;
         else if (A.n0 > 0) unsorted = A.desc[A.n0 - 1].pos0 > pos0;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) reach = max(reach, __shfl_xor(reach, d, 64));
-    const bool any_unsorted = __ballot(unsorted) != 0ull;
+    const bool any_unsorted = __ballot(unsorted) != 0ull, any_complex = __ballot(complex_read) != 0ull;
     if ((threadIdx.x & 63) == 0) {
+        // (plain reads first: same-address atomics from the whole chip are what they cost, and after the first few waves none is needed)
         if (reach > A.state[kStateReach]) atomicMax(&A.state[kStateReach], reach);
-        if (any_unsorted) atomicOr(&A.state[kStateUnsorted], 1);
+        if (any_unsorted && A.state[kStateUnsorted] == 0) atomicOr(&A.state[kStateUnsorted], 1);
+        if (any_complex && A.state[kStateComplex] == 0) atomicOr(&A.state[kStateComplex], 1);
     }
 }
 
@@ -192,54 +195,16 @@ __device__ __forceinline__ long long readlane64(long long v, int lane_index)
     return ((long long)hi << 32) | (unsigned int)lo;
 }
 
-// The reads of one segment that can touch the tile [tile_start, tile_start + 64): simple reads eight at a time (their sixteen byte
-// loads are in flight together), lane = locus.  on_base(k-th read of the group: base, quality, direction, valid, pos0, aligned bases).
-// Then the complex reads of the same range, one at a time, through walk_base: on_obs(position, allele, direction, anchor, quality).
-constexpr int kReadGroup = 8;
-template <bool kDirs, typename OnBase, typename OnObs>
-__device__ __forceinline__ void walk_segment(const SegmentView& G, int tile_start, int min_bq, int lane, int wid, int n_waves, OnBase on_base, OnObs on_obs)
+// The reads of desc[lo, hi) with insertions / deletions / skips, one at a time: RegionStateManager.AddAlleleCounts base by base
+// (read_walk.h); on_obs(position, allele, direction, anchor, quality) for every observation inside the tile and at or above the floor.
+template <bool kDirs, typename OnObs>
+__device__ __forceinline__ void walk_segment_complex(const SegmentView& G, int lo, int hi, int tile_start, int min_bq, int lane, int wid, int n_waves, OnObs on_obs)
 {
-    if (G.n_reads <= 0) return;
     const int tile_end = tile_start + kTile - 1;
-    int lo = 0, hi = G.n_reads;
-    if (G.state[kStateUnsorted] == 0) {
-        const int reach = G.state[kStateReach];
-        const long long x_lo = (long long)tile_start - reach + 1;
-        lo = wave_lower_bound(G.desc, G.n_reads, (int)max(x_lo, -0x7FFFFFFFll), lane);
-        hi = tile_end == 0x7FFFFFFF ? G.n_reads : wave_lower_bound(G.desc, G.n_reads, tile_end + 1, lane);
-    }
-    lo = __builtin_amdgcn_readfirstlane(lo);
-    hi = __builtin_amdgcn_readfirstlane(hi);
-    const int locus_pos = tile_start + lane;
     for (int base = lo + wid * 64; base < hi; base += n_waves * 64) {
         const int cnt = min(64, hi - base);
         const ReadDesc d = G.desc[base + min(lane, cnt - 1)];
         unsigned long long complex_mask = __ballot(lane < cnt && (d.meta & kDescComplex));
-        for (int g0 = 0; g0 < cnt; g0 += kReadGroup) {
-            uint32_t bb[kReadGroup], qq[kReadGroup], dd[kReadGroup];
-            int p0[kReadGroup], nn[kReadGroup];
-            uint32_t ok = 0;
-#pragma unroll
-            for (int k = 0; k < kReadGroup; k++) {
-                const int u = min(g0 + k, cnt - 1);   // (a short last group repeats its last read with no bases)
-                const int pos0 = __builtin_amdgcn_readlane(d.pos0, u);
-                const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)d.meta, u);
-                const long long aoff = readlane64(d.aoff, u);
-                const int n = (g0 + k < cnt && !(meta & kDescComplex)) ? (int)(meta & kDescLenMask) : 0;
-                const int floor_pos = base + u < G.n_floored ? G.floor : 0;
-                const int i_min = max(floor_pos - pos0, 0);   // (floor <= 2^31 - 1, pos0 >= 1)
-                const int i = locus_pos - pos0;
-                if (i >= i_min && i < n) ok |= 1u << k;
-                const uint32_t ic = (uint32_t)min(max(i, 0), max(n - 1, 0));
-                bb[k] = (G.bases + aoff)[ic];
-                qq[k] = (G.quals + aoff)[ic];
-                dd[k] = kDirs ? (uint32_t)(G.dirs + aoff)[ic] : ((meta & kDescReverse) ? (uint32_t)PISCES_DIR_REVERSE : (uint32_t)PISCES_DIR_FORWARD);
-                p0[k] = pos0;
-                nn[k] = n;
-            }
-#pragma unroll
-            for (int k = 0; k < kReadGroup; k++) on_base(bb[k], qq[k], dd[k], (ok >> k) & 1u, p0[k], nn[k]);
-        }
         // the reads with insertions / deletions / skips: RegionStateManager.AddAlleleCounts base by base (read_walk.h)
         while (complex_mask) {
             const int u = __builtin_ctzll(complex_mask);
@@ -280,6 +245,268 @@ __device__ __forceinline__ void walk_segment(const SegmentView& G, int tile_star
     }
 }
 
+// four bytes at any address (gfx950 runs with unaligned global access enabled: one global_load_dword)
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ long long shfl64(long long v, int src_lane)
+{
+    const int lo = __shfl((int)(v & 0xFFFFFFFFll), src_lane, 64);
+    const int hi = __shfl((int)(v >> 32), src_lane, 64);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+// The reads of one segment that can touch the tile [tile_start, tile_start + 64).
+// Simple reads (one aligned run): a wave takes 64 descriptors with one load, then SIXTEEN reads at a time: lane (g, j) = (lane >> 4,
+// lane & 15) takes, of the reads 4u + g (u = 0..3), the four bases on the loci 4j .. 4j + 3 of the tile — one 4-byte load each for
+// bases and qualities (any alignment), 256 bytes per load instruction, eight (twelve with per-base directions) in flight per wave.
+// The four bytes are added in the order k = (s + g) & 3, s = 0..3: in step s the 64 lanes stand on 64 different loci, so a ds_add
+// never has two lanes on one bank, whatever the reads.  on_base(locus, base, quality, direction, valid, pos0, aligned bases).
+// Then the complex reads of the same descriptors, one at a time, through walk_base: on_obs(position, allele, direction, anchor, quality).
+// Bytes up to 3 before a read's first aligned base and up to 3 behind its last one are loaded (and not used): the segment's arrays
+// have that much room on both sides (kSegmentPad).
+constexpr int kSegmentPad = 64;
+template <bool kDirs, typename OnBase, typename OnObs>
+__device__ __forceinline__ void walk_segment(const SegmentView& G, int tile_start, int min_bq, int lane, int wid, int n_waves, OnBase on_base, OnObs on_obs)
+{
+    if (G.n_reads <= 0) return;
+    const int tile_end = tile_start + kTile - 1;
+    int lo = 0, hi = G.n_reads;
+    if (G.state[kStateUnsorted] == 0) {
+        const int reach = G.state[kStateReach];
+        const long long x_lo = (long long)tile_start - reach + 1;
+        lo = wave_lower_bound(G.desc, G.n_reads, (int)max(x_lo, -0x7FFFFFFFll), lane);
+        hi = tile_end == 0x7FFFFFFF ? G.n_reads : wave_lower_bound(G.desc, G.n_reads, tile_end + 1, lane);
+    }
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    const int g = lane >> 4, j4 = (lane & 15) * 4;
+    const int lane_pos = tile_start + j4;
+    // ---- simple reads.  Blocks of 64 descriptors (this wave takes the blocks wid, wid + n_waves, ...), four sub-chunks of sixteen reads
+    // a block; the loads of sub-chunk f + 1 are issued before sub-chunk f is added (explicit ping-pong over two register sets, every
+    // load unconditional with its index clamped, so that the loop body is straight-line code and the waits are counted, not drained).
+    struct Sub {
+        uint32_t bw[4], qw[4], dw[4];
+        int rel[4], lim[4], p0[4], nn[4];
+    };
+    const int n_blocks = (hi - lo + 63) >> 6;
+    const int my_blocks = (n_blocks - wid + n_waves - 1) / n_waves;
+    if (my_blocks > 0) {
+        auto block_base = [&](int b) { return lo + (wid + min(b, my_blocks - 1) * n_waves) * 64; };
+        auto load_desc = [&](int b) {
+            const int base = block_base(b);
+            return G.desc[base + min(lane, min(64, hi - base) - 1)];
+        };
+        // the loads of sub-chunk f (of this wave's sequence) from the descriptors d of its block
+        auto issue = [&](const ReadDesc& d, int f, Sub& S) {
+            const bool live = f < my_blocks * 4;
+            const int base = block_base(f >> 2), cnt = min(64, hi - base), q = f & 3;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int src = 16 * q + 4 * u + g;
+                const int srcl = min(src, cnt - 1);
+                const int pos0 = __shfl(d.pos0, srcl, 64);
+                const uint32_t meta = (uint32_t)__shfl((int)d.meta, srcl, 64);
+                const long long aoff = shfl64(d.aoff, srcl);
+                const int n = (live && src < cnt && !(meta & kDescComplex)) ? (int)(meta & kDescLenMask) : 0;
+                const int floor_pos = base + srcl < G.n_floored ? G.floor : 0;
+                const int i_min = max(floor_pos - pos0, 0);   // (floor <= 2^31 - 1, pos0 >= 1)
+                const int s0 = lane_pos - pos0;               // index, in the aligned run, of the base on the lane's first locus
+                S.lim[u] = max(n - i_min, 0);
+                S.rel[u] = s0 - i_min;                        // (may wrap when nothing is valid: the wrapped value is far above lim)
+#if defined(PISCES_STORE_ABLATE) && PISCES_STORE_ABLATE == 3
+                const long long at = (aoff + min(max(s0, -3), max((int)(meta & kDescComplex ? 0u : (meta & kDescLenMask)) - 1, -3))) & ~3ll;   // development ablation: aligned loads (wrong bytes)
+#else
+                const long long at = aoff + min(max(s0, -3), max((int)(meta & kDescComplex ? 0u : (meta & kDescLenMask)) - 1, -3));
+#endif
+                S.bw[u] = load_u32_unaligned(G.bases + at);
+                S.qw[u] = load_u32_unaligned(G.quals + at);
+                S.dw[u] = kDirs ? load_u32_unaligned(G.dirs + at)
+                                : ((meta & kDescReverse) ? (uint32_t)PISCES_DIR_REVERSE * 0x01010101u : (uint32_t)PISCES_DIR_FORWARD * 0x01010101u);
+                S.p0[u] = pos0;
+                S.nn[u] = n;
+            }
+        };
+        auto consume = [&](const Sub& S) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+#pragma unroll
+                for (int st = 0; st < 4; st++) {
+                    const int k = (st + g) & 3;
+                    const uint32_t sh = (uint32_t)k * 8u;
+                    on_base(j4 + k, (S.bw[u] >> sh) & 0xFFu, (S.qw[u] >> sh) & 0xFFu, (S.dw[u] >> sh) & 0xFFu,
+                            (uint32_t)(S.rel[u] + k) < (uint32_t)S.lim[u], S.p0[u], S.nn[u]);
+                }
+            }
+        };
+        const int n_f = my_blocks * 4;
+        ReadDesc dc = load_desc(0), dn = load_desc(1);
+        Sub A, B;
+        issue(dc, 0, A);
+        for (int f = 0; f < n_f; f += 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue(dc, f + 1, B);                  // (same block as f: four sub-chunks a block)
+            __builtin_amdgcn_sched_barrier(0);
+            consume(A);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool next_block = (f & 3) == 2;
+            ReadDesc da;
+            da.pos0 = next_block ? dn.pos0 : dc.pos0;
+            da.meta = next_block ? dn.meta : dc.meta;
+            da.aoff = next_block ? dn.aoff : dc.aoff;
+            dn = load_desc(((f + 2) >> 2) + 1);   // (the same descriptors again three times out of four: straight-line code)
+            issue(da, f + 2, A);                  // (past the end: a repeat of the last sub-chunk with nothing valid)
+            dc = da;
+            __builtin_amdgcn_sched_barrier(0);
+            consume(B);
+        }
+    }
+    // ---- the reads with insertions / deletions / skips (if the segment has any)
+    if (G.state[kStateComplex] == 0) return;
+    walk_segment_complex<kDirs>(G, lo, hi, tile_start, min_bq, lane, wid, n_waves, on_obs);
+}
+
+// ---- the flush kernel's own form of the walk over simple reads -------------------------------------------------------------------
+// The general form above hands every base to a callback (18 VALU instructions a base with the histogram update of the call kernel:
+// 37.5 M a launch at BASELINE config 2, 4 cycles each — the kernel was VALU-bound at 3 x the tuple kernel's time).  Here the four
+// bases of a loaded word are classified TOGETHER into one byte each, the ROW of the histogram the base counts in:
+//     row = low-quality << 5 | allele << 2 | direction          (24 = a row nobody reads: the base is not on the read / below the floor)
+//   * allele: v_perm_b32 looks up, by the low three bits of every base, the letter those bits stand for (A C G T have 1 3 7 4) and its
+//     AlleleType; a base that is not exactly that letter is an N (AlleleHelper.GetAlleleType, AlleleHelper.cs:13-32)
+//   * low quality: one subtraction on all four qualities (RegionStateManager.cs:179-181: quality < minBQ; minBQ <= 127 here)
+//   * on the read: one mask from the lane's first / last valid byte (v_bfm_b32), applied with v_bfi_b32
+// and an observation is then ONE v_perm_b32 (row byte and column byte -> LDS address) and one ds_add_u32.  Lane (g, j) adds its four
+// bytes in the order (s + g) & 3 (the word is rotated by 8 g once), so the 64 lanes of an instruction stand on 64 different loci.
+struct ReadTrim {   // a descriptor with the floor applied: what is left of the read, per lane of a 64-read block
+    int32_t pos, end;     // first position still to count, one past the last
+    uint32_t aoff;        // index of the base on `pos` in the segment's arrays, + kSegmentPad
+    uint32_t dir4;        // the read's direction in every byte
+};
+template <bool kDirs, typename OnObs>
+__device__ __forceinline__ void walk_segment_fast(const SegmentView& G, int tile_start, uint32_t min_bq, int lane, int wid, int n_waves, char* hbytes,
+                                                  OnObs on_obs)
+{
+    if (G.n_reads <= 0) return;
+    const int tile_end = tile_start + kTile - 1;
+    int lo = 0, hi = G.n_reads;
+    if (G.state[kStateUnsorted] == 0) {
+        const int reach = G.state[kStateReach];
+        const long long x_lo = (long long)tile_start - reach + 1;
+        lo = wave_lower_bound(G.desc, G.n_reads, (int)max(x_lo, -0x7FFFFFFFll), lane);
+        hi = tile_end == 0x7FFFFFFF ? G.n_reads : wave_lower_bound(G.desc, G.n_reads, tile_end + 1, lane);
+    }
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    const int g = lane >> 4, j4 = (lane & 15) * 4;
+    const int lane_pos = tile_start + j4;
+    const uint32_t rot = (uint32_t)g * 8u;
+    // byte s of colreg: LDS byte offset, inside a row, of the locus this lane stands on in step s
+    uint32_t colreg = 0;
+#pragma unroll
+    for (int st = 0; st < 4; st++) colreg |= (uint32_t)((j4 + ((st + g) & 3)) * (int)sizeof(int)) << (8 * st);
+    const uint32_t qk4 = (0x7Fu + min(min_bq, 127u)) * 0x01010101u;
+    const uint8_t* const bases = G.bases - kSegmentPad;
+    const uint8_t* const quals = G.quals - kSegmentPad;
+    const uint8_t* const dirs = kDirs ? G.dirs - kSegmentPad : nullptr;
+    const int n_blocks = (hi - lo + 63) >> 6;
+    const int my_blocks = (n_blocks - wid + n_waves - 1) / n_waves;
+    if (my_blocks > 0) {
+        struct Sub { uint32_t bw[4], qw[4], dw[4], mask[4]; };
+        auto block_base = [&](int b) { return lo + (wid + min(b, my_blocks - 1) * n_waves) * 64; };
+        auto load_trim = [&](int b) {
+            const int base = block_base(b), cnt = min(64, hi - base);
+            const ReadDesc d = G.desc[base + min(lane, cnt - 1)];
+            const int n = (lane < cnt && !(d.meta & kDescComplex)) ? (int)(d.meta & kDescLenMask) : 0;
+            const int floor_pos = base + lane < G.n_floored ? G.floor : 0;
+            ReadTrim t;
+            t.pos = max(d.pos0, floor_pos);                  // (pos0 >= 1)
+            const int cut = t.pos - d.pos0;                  // bases below the floor
+            t.end = t.pos + max(n - min(cut, n), 0);
+            t.aoff = (uint32_t)d.aoff + (uint32_t)min(cut, n) + (uint32_t)kSegmentPad;
+            t.dir4 = (d.meta & kDescReverse) ? (uint32_t)PISCES_DIR_REVERSE * 0x01010101u : (uint32_t)PISCES_DIR_FORWARD * 0x01010101u;
+            return t;
+        };
+        auto issue = [&](const ReadTrim& t, int f, Sub& S) {
+            const uint32_t live = f < my_blocks * 4 ? 0xFFFFFFFFu : 0u;
+            const int q = f & 3;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int src = 16 * q + 4 * u + g;
+                const int pos = __shfl(t.pos, src, 64), end = __shfl(t.end, src, 64);
+                const uint32_t aoff = (uint32_t)__shfl((int)t.aoff, src, 64);
+                const int da = pos - lane_pos, de = end - lane_pos;            // the lane's bytes a .. e - 1 are on the read
+                const int a = min(max(da, 0), 4), e = min(max(de, 0), 4);
+                const uint32_t width = (uint32_t)min((e - a) * 8, 31);         // (a full word: 31 bits; bit 31 is no row bit)
+                S.mask[u] = ((((1u << width) - 1u) << ((uint32_t)a * 8u)) & live);
+                const uint32_t at = aoff + (uint32_t)(a < e ? -da : 0);       // (a word that is not on the read at all: the read's first)
+#if defined(PISCES_STORE_ABLATE) && PISCES_STORE_ABLATE == 3
+                S.bw[u] = load_u32_unaligned(bases + (at & ~3u));
+                S.qw[u] = load_u32_unaligned(quals + (at & ~3u));
+#else
+                S.bw[u] = load_u32_unaligned(bases + at);
+                S.qw[u] = load_u32_unaligned(quals + at);
+#endif
+                S.dw[u] = kDirs ? load_u32_unaligned(dirs + at) : (uint32_t)__shfl((int)t.dir4, src, 64);
+            }
+        };
+        auto consume = [&](const Sub& S) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t bw = S.bw[u], qw = S.qw[u];
+                // allele << 2 of every base
+                const uint32_t idx4 = bw & 0x07070707u;
+                const uint32_t letter4 = __builtin_amdgcn_perm(0x47000054u, 0x43004101u, idx4);   // what the low three bits stand for
+                const uint32_t code4 = __builtin_amdgcn_perm(0x0410100Cu, 0x08100010u, idx4);     // its AlleleType << 2 (N for the rest)
+                const uint32_t x4 = bw ^ letter4;                                                   // a zero byte: the base IS that letter
+                const uint32_t nz = (((x4 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x4) & 0x80808080u;
+                const uint32_t nzff = (nz - (nz >> 7)) | nz;                                       // 0xFF where it is not
+                const uint32_t allele4 = (nzff & 0x10101010u) | (~nzff & code4);
+                // quality < minBQ: bit 7 of (0x7F + minBQ) - (q & 0x7F) is set iff (q & 0x7F) < minBQ; a quality >= 128 is never low
+                const uint32_t low4 = ~qw & (qk4 - (qw & 0x7F7F7F7Fu));
+                uint32_t row4 = ((low4 >> 2) & 0x20202020u) | allele4 | S.dw[u];
+                row4 = (S.mask[u] & row4) | (~S.mask[u] & 0x18181818u);
+#if defined(PISCES_STORE_ABLATE) && PISCES_STORE_ABLATE == 2
+                if (row4 == 0x12345u) *reinterpret_cast<volatile int*>(hbytes) = 1;   // development ablation: no histogram update
+                continue;
+#endif
+                row4 = __builtin_amdgcn_alignbit(row4, row4, rot);
+                atomicAdd(reinterpret_cast<int*>(hbytes + __builtin_amdgcn_perm(row4, colreg, 0x0C0C0400u)), 1);
+                atomicAdd(reinterpret_cast<int*>(hbytes + __builtin_amdgcn_perm(row4, colreg, 0x0C0C0501u)), 1);
+                atomicAdd(reinterpret_cast<int*>(hbytes + __builtin_amdgcn_perm(row4, colreg, 0x0C0C0602u)), 1);
+                atomicAdd(reinterpret_cast<int*>(hbytes + __builtin_amdgcn_perm(row4, colreg, 0x0C0C0703u)), 1);
+            }
+        };
+        const int n_f = my_blocks * 4;
+        ReadTrim tc = load_trim(0), tn = load_trim(1);
+        Sub A, B;
+        issue(tc, 0, A);
+        for (int f = 0; f < n_f; f += 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue(tc, f + 1, B);                  // (same block as f: four sub-chunks a block)
+            __builtin_amdgcn_sched_barrier(0);
+            consume(A);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool next_block = (f & 3) == 2;
+            ReadTrim ta;
+            ta.pos = next_block ? tn.pos : tc.pos;
+            ta.end = next_block ? tn.end : tc.end;
+            ta.aoff = next_block ? tn.aoff : tc.aoff;
+            ta.dir4 = next_block ? tn.dir4 : tc.dir4;
+            tn = load_trim(((f + 2) >> 2) + 1);   // (the same descriptors again three times out of four: straight-line code)
+            issue(ta, f + 2, A);                  // (past the end: a repeat of the last sub-chunk with nothing valid)
+            tc = ta;
+            __builtin_amdgcn_sched_barrier(0);
+            consume(B);
+        }
+    }
+    // ---- the reads with insertions / deletions / skips (if the segment has any): the general walk's second half
+    if (G.state[kStateComplex] == 0) return;
+    walk_segment_complex<kDirs>(G, lo, hi, tile_start, (int)min_bq, lane, wid, n_waves, on_obs);
+}
+
 template <typename OnBase, typename OnObs>
 __device__ __forceinline__ void walk_store(const StoreView& S, int tile_start, int min_bq, int lane, int wid, int n_waves, OnBase on_base, OnObs on_obs)
 {
@@ -306,6 +533,16 @@ __device__ __forceinline__ uint32_t allele_row_bytes(uint32_t c)
             : c == 'T' ? (uint32_t)PISCES_ALLELE_T : (uint32_t)PISCES_ALLELE_N) * (4u * kWaveRow * (uint32_t)sizeof(int));
 }
 
+// the same without a table: ((c >> 1) & 3) tells A, C, T, G apart (0, 1, 2, 3); the letter that index stands for is compared with c.
+// (A look-up in LDS put a dependent LDS round trip in front of every ds_add: 74 of the kernel's first 91 us.)
+__device__ __forceinline__ uint32_t allele_row_bytes_of_base(uint32_t c)
+{
+    const uint32_t t8 = (c << 2) & 0x18u;                  // 8 * ((c >> 1) & 3)
+    const uint32_t letter = (0x47544341u >> t8) & 0xFFu;   // 'A', 'C', 'T', 'G'
+    const uint32_t code = (0x01030200u >> t8) & 0xFFu;     // AlleleType of that letter: A 0, C 2, T 3, G 1
+    return (c == letter ? code : (uint32_t)PISCES_ALLELE_N) * (4u * kWaveRow * (uint32_t)sizeof(int));
+}
+
 template <int NW>
 __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_OCC) void call_store_tiles_kernel(
     StoreView S, const uint32_t* __restrict__ tuples, const PiscesTile* __restrict__ tiles, int32_t n_tiles, const uint8_t* __restrict__ ref,
@@ -315,12 +552,18 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
     __shared__ __attribute__((aligned(16))) int hist[2 * kWaveRegion];   // [region: quality-passing / low-quality][allele * 4 + direction][locus]
     __shared__ uint8_t s_refwin[kRefWin];
     __shared__ uint8_t s_vmask[kTile];
-    __shared__ uint16_t s_row[256];   // allele_row_bytes by read base
 
     if ((int)blockIdx.x >= n_tiles) return;
+#ifdef PISCES_STORE_NO_SWIZZLE
+    const int t = (int)blockIdx.x;
+#else
     const int t = xcd_tile_of_block((int)blockIdx.x, n_tiles);
-    const int l = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#endif
+    const int l = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const PiscesTile tile = tiles[t];
+#if defined(PISCES_STORE_ABLATE) && PISCES_STORE_ABLATE == 4
+    if (tile.n_loci > 0) { if (threadIdx.x == 0) { tile_results[t].record_begin = 0; tile_results[t].n_records = 0; tile_results[t].n_called = 0; tile_results[t].n_candidate_loci = 0; } return; }   // development ablation: nothing
+#endif
     {
         int4* h4 = reinterpret_cast<int4*>(hist);
         for (int i = threadIdx.x; i < 2 * kWaveRegion / 4; i += 64 * NW) h4[i] = make_int4(0, 0, 0, 0);
@@ -328,10 +571,9 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
             const int64_t ri = (int64_t)tile.start_position - kRefMargin + i - ref_start;
             s_refwin[i] = (ri >= 0 && ri < ref_len) ? ref[ri] : (uint8_t)0;
         }
-        for (int i = threadIdx.x; i < 256; i += 64 * NW) s_row[i] = (uint16_t)allele_row_bytes((uint32_t)i);
         __syncthreads();
     }
-    const uint32_t min_bq = (uint32_t)min(max(P.min_bq, 0), 255);
+    const uint32_t min_bq = (uint32_t)min(max(P.min_bq, 0), 127);   // (the host routes larger thresholds through the counts in HBM)
     char* const hbytes = reinterpret_cast<char*>(hist);
     constexpr uint32_t kRegionBytes = (uint32_t)(kWaveRegion * sizeof(int));
     // pre-expanded observations (pisces_hip_add_observations), bucketed by tile: "qual < minBQ -> the low-quality region" as accumulate_wave
@@ -343,18 +585,21 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
                                              (uint32_t)HistLinear::idx((int)allele, (int)dir, (int)PISCES_TUPLE_LOCUS(v)) * (uint32_t)sizeof(int)), 1);
     }
     // the reads
-    const uint32_t lane_bytes = (uint32_t)l * (uint32_t)sizeof(int);
-    walk_store(S, tile.start_position, (int)min_bq, l, wid, NW,
-               [&](uint32_t base, uint32_t qual, uint32_t dir, uint32_t valid, int, int) {
-                   const uint32_t off = (uint32_t)s_row[base] + ((qual < min_bq) ? kRegionBytes : 0u) + dir * (uint32_t)(kWaveRow * sizeof(int)) + lane_bytes;
-                   if (valid) atomicAdd(reinterpret_cast<int*>(hbytes + off), 1);
-               },
-               [&](int position, uint32_t allele, uint32_t dir, int, uint32_t qual) {
-                   const uint32_t off = ((qual < min_bq) ? kRegionBytes : 0u) +
-                                        (uint32_t)HistLinear::idx((int)allele, (int)dir, position - tile.start_position) * (uint32_t)sizeof(int);
-                   atomicAdd(reinterpret_cast<int*>(hbytes + off), 1);
-               });
+    auto on_obs = [&](int position, uint32_t allele, uint32_t dir, int, uint32_t qual) {
+        const uint32_t off = ((qual < min_bq) ? kRegionBytes : 0u) +
+                             (uint32_t)HistLinear::idx((int)allele, (int)dir, position - tile.start_position) * (uint32_t)sizeof(int);
+        atomicAdd(reinterpret_cast<int*>(hbytes + off), 1);
+    };
+    for (int sg = 0; sg < S.n_segments; sg++) {
+        const SegmentView& G = S.seg[sg];
+        if (G.dirs) walk_segment_fast<true>(G, tile.start_position, min_bq, l, wid, NW, hbytes, on_obs);
+        else walk_segment_fast<false>(G, tile.start_position, min_bq, l, wid, NW, hbytes, on_obs);
+    }
     __syncthreads();
+#if defined(PISCES_STORE_ABLATE) && (PISCES_STORE_ABLATE == 1 || PISCES_STORE_ABLATE == 2 || PISCES_STORE_ABLATE >= 5)
+    if (threadIdx.x == 0) { tile_results[t].record_begin = 0; tile_results[t].n_records = hist[5 + l] & 0; tile_results[t].n_called = 0; tile_results[t].n_candidate_loci = 0; }   // development ablation: no call phase
+    return;
+#endif
     call_phase_wave<NW, HistLinear>(hist, s_refwin, s_vmask, tile, t, l, wid, ref, ref_start, ref_len, records, tile_results, P
 #ifdef PISCES_TIMING
                                     , 0ll, 0ll
@@ -391,13 +636,13 @@ __global__ __launch_bounds__(kBlock) void accumulate_store_tiles_kernel(StoreVie
         const uint32_t v = tuples[i];
         add(PISCES_TUPLE_LOCUS(v), PISCES_TUPLE_ALLELE(v), PISCES_TUPLE_DIR(v), PISCES_TUPLE_ANCHOR(v), v >> 24);
     }
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     walk_store(S, tile.start_position, (int)min_bq, lane, wid, kBlock / 64,
-               [&](uint32_t base, uint32_t qual, uint32_t dir, uint32_t valid, int pos0, int n_aligned) {
+               [&](int locus, uint32_t base, uint32_t qual, uint32_t dir, bool valid, int pos0, int n_aligned) {
                    if (!valid) return;
                    // GetAnchorType (RegionStateManager.cs:83-116); EndPosition of a read of one aligned run = pos0 + run - 1
-                   const int anchor = walk_anchor_type(pos0 + n_aligned - 1, tile.start_position + lane, pos0);
-                   add((uint32_t)lane, walk_allele_type((uint8_t)base), dir, (uint32_t)(anchor < 0 ? 0 : anchor), qual);
+                   const int anchor = walk_anchor_type(pos0 + n_aligned - 1, tile.start_position + locus, pos0);
+                   add((uint32_t)locus, walk_allele_type((uint8_t)base), dir, (uint32_t)(anchor < 0 ? 0 : anchor), qual);
                },
                [&](int position, uint32_t allele, uint32_t dir, int anchor, uint32_t qual) {
                    add((uint32_t)(position - tile.start_position), allele, dir, (uint32_t)anchor, qual);

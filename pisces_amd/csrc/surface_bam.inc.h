@@ -233,7 +233,8 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
     PISCES_HIP_CHECK(h, B.cigar_offset.reserve(nr + 1)); PISCES_HIP_CHECK(h, B.seq_offset.reserve(nr + 1));
     PISCES_HIP_CHECK(h, B.read_quality.reserve(nr + 1));
     PISCES_HIP_CHECK(h, B.cigar_op.reserve(no + 1)); PISCES_HIP_CHECK(h, B.cigar_len.reserve(no + 1)); PISCES_HIP_CHECK(h, B.op_quality.reserve(no + 1));
-    PISCES_HIP_CHECK(h, B.bases.reserve(nb + 16)); PISCES_HIP_CHECK(h, B.quals.reserve(nb + 16));
+    // (kSegmentPad bytes in front of the bases and the qualities: a batch that becomes a segment of the read store as it lies)
+    PISCES_HIP_CHECK(h, B.bases.reserve(nb + 16 + 2 * kSegmentPad)); PISCES_HIP_CHECK(h, B.quals.reserve(nb + 16 + 2 * kSegmentPad));
     PISCES_HIP_CHECK(h, B.d_slots.reserve(nr + 1)); PISCES_HIP_CHECK(h, B.d_fslots.reserve(nr + 1));
     // the blocks of the chromosome (its length from the header, and room for reads that hang over its end), one bit each
     const long long l_ref = std::min<long long>(std::max<long long>(header[3], 0), 0x7FFFFFFFll);
@@ -245,7 +246,7 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
     if (nr > 0)
         hipLaunchKernelGGL(bam_decode_kernel, dim3((unsigned)n_chunks), dim3(256), 0, h->stream, (const uint8_t*)B.d_stream.p, out_bytes,
                            (const long long*)B.d_entry.p, F, (const int32_t*)B.d_n_reads.p, (const int32_t*)B.d_n_ops.p, (const int32_t*)B.d_n_bases.p,
-                           B.position.p, B.flags.p, B.cigar_offset.p, B.cigar_op.p, B.cigar_len.p, B.seq_offset.p, B.bases.p, B.quals.p,
+                           B.position.p, B.flags.p, B.cigar_offset.p, B.cigar_op.p, B.cigar_len.p, B.seq_offset.p, B.bases.p + kSegmentPad, B.quals.p + kSegmentPad,
                            B.op_quality.p, B.read_quality.p, (const long long*)B.d_n_span.p, (const int32_t*)B.d_n_indels.p, B.d_slots.p,
                            B.d_fslots.p, B.d_block_map.p, n_block_bits, B.d_first_error.p);
     // the closing offsets
@@ -295,8 +296,8 @@ int32_t pisces_hip_bam_fetch(PiscesHip* h, int32_t* position, uint8_t* flags, in
     PISCES_HIP_CHECK(h, down(cigar_op, B.cigar_op.p, no));
     PISCES_HIP_CHECK(h, down(cigar_len, B.cigar_len.p, no * 4));
     PISCES_HIP_CHECK(h, down(seq_offset, B.seq_offset.p, (nr + 1) * 4));
-    PISCES_HIP_CHECK(h, down(bases, B.bases.p, nb));
-    PISCES_HIP_CHECK(h, down(quals, B.quals.p, nb));
+    PISCES_HIP_CHECK(h, down(bases, B.bases.p + kSegmentPad, nb));
+    PISCES_HIP_CHECK(h, down(quals, B.quals.p + kSegmentPad, nb));
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     return PISCES_OK;
     });
@@ -342,7 +343,7 @@ int32_t pisces_hip_add_decoded_reads(PiscesHip* h)
     if (rc) return rc;
     DevReadBatch db;
     db.position = B.position.p; db.flags = B.flags.p; db.cigar_offset = B.cigar_offset.p; db.cigar_op = B.cigar_op.p; db.cigar_len = B.cigar_len.p;
-    db.seq_offset = B.seq_offset.p; db.bases = B.bases.p; db.quals = B.quals.p; db.dirs = nullptr; db.n_reads = nr;
+    db.seq_offset = B.seq_offset.p; db.bases = B.bases.p + kSegmentPad; db.quals = B.quals.p + kSegmentPad; db.dirs = nullptr; db.n_reads = nr;
     const int c = h->log_cur;
     hipLaunchKernelGGL(expand_reads_kernel, dim3(expand_reads_grid(nr)), dim3(256), 0, h->stream, db, (const long long*)B.d_slots.p,
                        (long long)h->log_ub, h->cfg.min_base_call_quality, h->d_log_pos[c].p, h->d_log_tup[c].p, h->d_log_n.p + 2, expand_reads_per_wave(nr));

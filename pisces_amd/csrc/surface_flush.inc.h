@@ -251,7 +251,7 @@ static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& key
     // the read store calls through call_store_tiles_kernel; configurations that kernel is not compiled for (the Diploid strand-bias model,
     // the 4-wave development form) go through the counts in HBM
     const bool store = h->read_path == 1;
-    const bool store_fused = h->kernel_variant >= 2 && h->cfg.strand_bias_model != PISCES_SB_DIPLOID;
+    const bool store_fused = h->kernel_variant >= 2 && h->cfg.strand_bias_model != PISCES_SB_DIPLOID && h->cfg.min_base_call_quality <= 127;
     if (!use_counts && !window && store && store_fused) {
         PISCES_HIP_CHECK(h, launch_call_store_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p,
                                                     h->d_tile_results.p));

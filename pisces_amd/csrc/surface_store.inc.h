@@ -230,31 +230,35 @@ static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const Sto
         S.n0 = 0; S.base0 = 0; S.ops0 = 0;
     } else {
         const size_t nb = (size_t)g.n_bases, no = (size_t)g.n_ops, n0 = (size_t)g.n_reads;
+        constexpr size_t kPad = (size_t)kSegmentPad;   // room on both sides of the byte arrays (walk_segment loads whole words around a read's ends)
         PISCES_HIP_CHECK(h, g.desc.grow_keep(n0 + (size_t)nr, n0, h->stream));
         PISCES_HIP_CHECK(h, g.ext.grow_keep(n0 + (size_t)nr, n0, h->stream));
-        PISCES_HIP_CHECK(h, g.bases.grow_keep(nb + n_seq + 16, nb, h->stream));
-        PISCES_HIP_CHECK(h, g.quals.grow_keep(nb + n_seq + 16, nb, h->stream));
+        PISCES_HIP_CHECK(h, g.bases.grow_keep(nb + n_seq + 2 * kPad, nb + kPad, h->stream));
+        PISCES_HIP_CHECK(h, g.quals.grow_keep(nb + n_seq + 2 * kPad, nb + kPad, h->stream));
         PISCES_HIP_CHECK(h, g.cop.grow_keep(no + n_cig + 16, no, h->stream));
         PISCES_HIP_CHECK(h, g.clen.grow_keep(no + n_cig + 16, no, h->stream));
         const bool tracks = g.v_dirs != nullptr;
         const bool wants = A.dirs != nullptr || tracks;
-        if (wants) PISCES_HIP_CHECK(h, g.dirs.grow_keep(std::max(g.bases.cap, nb + n_seq + 16), tracks ? nb : 0, h->stream));
-        g.v_bases = g.bases.p; g.v_quals = g.quals.p; g.v_cop = g.cop.p; g.v_clen = g.clen.p;
-        g.v_dirs = wants ? g.dirs.p : nullptr;
+        if (wants) PISCES_HIP_CHECK(h, g.dirs.grow_keep(std::max(g.bases.cap, nb + n_seq + 2 * kPad), tracks ? nb + kPad : 0, h->stream));
+        g.v_bases = g.bases.p + kPad; g.v_quals = g.quals.p + kPad; g.v_cop = g.cop.p; g.v_clen = g.clen.p;
+        g.v_dirs = wants ? g.dirs.p + kPad : nullptr;
+        uint8_t* const w_bases = g.bases.p + kPad;
+        uint8_t* const w_quals = g.quals.p + kPad;
+        uint8_t* const w_dirs = wants ? g.dirs.p + kPad : nullptr;
         CopyRanges C;
         std::memset(&C, 0, sizeof(C));
-        C.dst[0] = g.bases.p + nb; C.src[0] = A.bases; C.n[0] = (int64_t)n_seq;
-        C.dst[1] = g.quals.p + nb; C.src[1] = A.quals; C.n[1] = (int64_t)n_seq;
+        C.dst[0] = w_bases + nb; C.src[0] = A.bases; C.n[0] = (int64_t)n_seq;
+        C.dst[1] = w_quals + nb; C.src[1] = A.quals; C.n[1] = (int64_t)n_seq;
         C.dst[2] = g.cop.p + no; C.src[2] = A.cigar_op; C.n[2] = (int64_t)n_cig;
         C.dst[3] = (uint8_t*)(g.clen.p + no); C.src[3] = (const uint8_t*)A.cigar_len; C.n[3] = (int64_t)n_cig * 4;
-        if (A.dirs) { C.dst[4] = g.dirs.p + nb; C.src[4] = A.dirs; C.n[4] = (int64_t)n_seq; }
+        if (A.dirs) { C.dst[4] = w_dirs + nb; C.src[4] = A.dirs; C.n[4] = (int64_t)n_seq; }
         const int64_t most = std::max<int64_t>((int64_t)n_seq, (int64_t)n_cig * 4);
         if (most > 0)
             hipLaunchKernelGGL(segment_copy_kernel, dim3((unsigned)std::min<int64_t>((most + 255) / 256, 2048)), dim3(256), 0, h->stream, C);
         S.n0 = (int32_t)n0; S.base0 = (int64_t)nb; S.ops0 = (int64_t)no;
         if (A.dirs && !tracks && n0 > 0)   // the reads the segment held before its first batch with directions
             hipLaunchKernelGGL(segment_fill_dirs_kernel, dim3((unsigned)((n0 + 3) / 4)), dim3(256), 0, h->stream, (const ReadDesc*)g.desc.p,
-                               (const ReadExt*)g.ext.p, 0, (int32_t)n0, g.dirs.p);
+                               (const ReadExt*)g.ext.p, 0, (int32_t)n0, w_dirs);
     }
     S.desc = g.desc.p;
     S.ext = g.ext.p;
@@ -262,7 +266,7 @@ static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const Sto
     hipLaunchKernelGGL(read_shape_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, h->stream, S);
     if (!pl.direct && !A.dirs && g.v_dirs)   // a batch without directions in a segment that tracks them
         hipLaunchKernelGGL(segment_fill_dirs_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, h->stream, (const ReadDesc*)g.desc.p,
-                           (const ReadExt*)g.ext.p, S.n0, S.n0 + nr, g.dirs.p);
+                           (const ReadExt*)g.ext.p, S.n0, S.n0 + nr, const_cast<uint8_t*>(g.v_dirs));
     PISCES_HIP_CHECK(h, hipGetLastError());
     return PISCES_OK;
 }
@@ -426,8 +430,9 @@ static int32_t add_decoded_reads_store(PiscesHip* h, int64_t found_slots, int64_
         g.clen.swap(B.cigar_len);
         B.moved = true;
     }
+    // (the decode leaves kSegmentPad bytes in front of the bases and the qualities)
     const StoreBatchArrays A = {B.position.p, B.flags.p, B.cigar_offset.p, pl.direct ? g.cop.p : B.cigar_op.p, pl.direct ? g.clen.p : B.cigar_len.p,
-                                B.seq_offset.p, pl.direct ? g.bases.p : B.bases.p, pl.direct ? g.quals.p : B.quals.p, nullptr};
+                                B.seq_offset.p, (pl.direct ? g.bases.p : B.bases.p) + kSegmentPad, (pl.direct ? g.quals.p : B.quals.p) + kSegmentPad, nullptr};
     int32_t rc = store_append_arrays(h, pl, A, nr, n_cig, n_seq);
     if (rc == PISCES_OK && find_on_device && (h->cfg.call_mnvs || found_slots > 0)) {
         DevReadBatch db;
