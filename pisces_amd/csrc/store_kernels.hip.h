@@ -188,6 +188,32 @@ __device__ __forceinline__ int wave_lower_bound(const ReadDesc* __restrict__ des
     return a;
 }
 
+// Both ends of a tile's read range in the same rounds: lanes 0-31 look for the first read at or behind x_lo, lanes 32-63 for the first
+// at or behind x_hi (32 probes each a round: as many rounds as one 64-ary search for the segment sizes that occur, half the latency of two).
+__device__ __forceinline__ void wave_lower_bound2(const ReadDesc* __restrict__ desc, int n, int x_lo, int x_hi, int lane, int* lo_out, int* hi_out)
+{
+    const int half = lane >> 5, sub = lane & 31;
+    const int x = half ? x_hi : x_lo;
+    int a = 0, b = n;   // (per half; the same in all lanes of a half)
+    bool more = n > 0;
+    while (__ballot(more) != 0ull) {
+        const int step = max((b - a + 31) >> 5, 1);
+        const long long idx = (long long)a + (long long)(sub + 1) * step - 1;
+        const int v = (more && idx < b) ? desc[idx].pos0 : 0x7FFFFFFF;
+        const unsigned long long below = __ballot(more && idx < b && v < x);
+        const int c = __popc((unsigned int)(half ? (below >> 32) : (below & 0xFFFFFFFFull)));
+        const long long na = (long long)a + (long long)c * step;
+        const long long nb = na + step - 1;
+        if (more) {
+            a = (int)min(na, (long long)b);
+            b = (int)max(min(nb, (long long)b), (long long)a);
+        }
+        more = b > a;
+    }
+    *lo_out = __builtin_amdgcn_readlane(a, 0);
+    *hi_out = __builtin_amdgcn_readlane(a, 32);
+}
+
 __device__ __forceinline__ long long readlane64(long long v, int lane_index)
 {
     const int lo = __builtin_amdgcn_readlane((int)(v & 0xFFFFFFFFll), lane_index);
@@ -278,11 +304,8 @@ __device__ __forceinline__ void walk_segment(const SegmentView& G, int tile_star
     if (G.state[kStateUnsorted] == 0) {
         const int reach = G.state[kStateReach];
         const long long x_lo = (long long)tile_start - reach + 1;
-        lo = wave_lower_bound(G.desc, G.n_reads, (int)max(x_lo, -0x7FFFFFFFll), lane);
-        hi = tile_end == 0x7FFFFFFF ? G.n_reads : wave_lower_bound(G.desc, G.n_reads, tile_end + 1, lane);
+        wave_lower_bound2(G.desc, G.n_reads, (int)max(x_lo, -0x7FFFFFFFll), tile_end == 0x7FFFFFFF ? 0x7FFFFFFF : tile_end + 1, lane, &lo, &hi);
     }
-    lo = __builtin_amdgcn_readfirstlane(lo);
-    hi = __builtin_amdgcn_readfirstlane(hi);
     const int g = lane >> 4, j4 = (lane & 15) * 4;
     const int lane_pos = tile_start + j4;
     // ---- simple reads.  Blocks of 64 descriptors (this wave takes the blocks wid, wid + n_waves, ...), four sub-chunks of sixteen reads
@@ -387,7 +410,7 @@ struct ReadTrim {   // a descriptor with the floor applied: what is left of the 
 };
 template <bool kDirs, typename OnObs>
 __device__ __forceinline__ void walk_segment_fast(const SegmentView& G, int tile_start, uint32_t min_bq, int lane, int wid, int n_waves, char* hbytes,
-                                                  OnObs on_obs)
+                                                  OnObs on_obs, long long* stamps = nullptr /* development: PISCES_STORE_TIMING */)
 {
     if (G.n_reads <= 0) return;
     const int tile_end = tile_start + kTile - 1;
@@ -395,18 +418,22 @@ __device__ __forceinline__ void walk_segment_fast(const SegmentView& G, int tile
     if (G.state[kStateUnsorted] == 0) {
         const int reach = G.state[kStateReach];
         const long long x_lo = (long long)tile_start - reach + 1;
-        lo = wave_lower_bound(G.desc, G.n_reads, (int)max(x_lo, -0x7FFFFFFFll), lane);
-        hi = tile_end == 0x7FFFFFFF ? G.n_reads : wave_lower_bound(G.desc, G.n_reads, tile_end + 1, lane);
+        wave_lower_bound2(G.desc, G.n_reads, (int)max(x_lo, -0x7FFFFFFFll), tile_end == 0x7FFFFFFF ? 0x7FFFFFFF : tile_end + 1, lane, &lo, &hi);
     }
-    lo = __builtin_amdgcn_readfirstlane(lo);
-    hi = __builtin_amdgcn_readfirstlane(hi);
+#ifdef PISCES_STORE_TIMING
+    if (stamps) { stamps[0] = wall_clock64(); stamps[1] = hi - lo; }
+#endif
     const int g = lane >> 4, j4 = (lane & 15) * 4;
     const int lane_pos = tile_start + j4;
-    const uint32_t rot = (uint32_t)g * 8u;
-    // byte s of colreg: LDS byte offset, inside a row, of the locus this lane stands on in step s
-    uint32_t colreg = 0;
+    // byte s of colreg: LDS byte offset, inside a row, of the locus this lane stands on in step s (its byte (s + g) & 3);
+    // sel[s]: the v_perm selector that makes that step's LDS address out of the word of rows and colreg
+    uint32_t colreg = 0, sel[4];
 #pragma unroll
-    for (int st = 0; st < 4; st++) colreg |= (uint32_t)((j4 + ((st + g) & 3)) * (int)sizeof(int)) << (8 * st);
+    for (int st = 0; st < 4; st++) {
+        const int k = (st + g) & 3;
+        colreg |= (uint32_t)((j4 + k) * (int)sizeof(int)) << (8 * st);
+        sel[st] = 0x0C0C0000u | ((uint32_t)(4 + k) << 8) | (uint32_t)st;
+    }
     const uint32_t qk4 = (0x7Fu + min(min_bq, 127u)) * 0x01010101u;
     const uint8_t* const bases = G.bases - kSegmentPad;
     const uint8_t* const quals = G.quals - kSegmentPad;
@@ -452,31 +479,46 @@ __device__ __forceinline__ void walk_segment_fast(const SegmentView& G, int tile
                 S.dw[u] = kDirs ? load_u32_unaligned(dirs + at) : (uint32_t)__shfl((int)t.dir4, src, 64);
             }
         };
+        // the rows of the four bases of a word.  Fast form: the letter the low three bits stand for (A C G T N) is taken at its word; a base
+        // that is none of these letters shows in `other` (returned or-ed over the words) and the exact form is taken then.
+        auto rows_of = [&](uint32_t bw, uint32_t qw, uint32_t dw, uint32_t mask, uint32_t& other) {
+            const uint32_t idx4 = bw & 0x07070707u;
+            const uint32_t letter4 = __builtin_amdgcn_perm(0x474E0054u, 0x43004101u, idx4);   // 1 A, 3 C, 4 T, 6 N, 7 G
+            const uint32_t code4 = __builtin_amdgcn_perm(0x0410100Cu, 0x08100010u, idx4);     // AlleleType << 2 (N for the rest)
+            other |= (bw ^ letter4) & mask;
+            // quality < minBQ: bit 7 of (0x7F + minBQ) - (q & 0x7F) is set iff (q & 0x7F) < minBQ; a quality >= 128 is never low
+            const uint32_t low4 = ~qw & (qk4 - (qw & 0x7F7F7F7Fu));
+            const uint32_t row4 = ((low4 >> 2) & 0x20202020u) | code4 | dw;
+            return (mask & row4) | (~mask & 0x18181818u);
+        };
+        auto rows_of_exact = [&](uint32_t bw, uint32_t qw, uint32_t dw, uint32_t mask) {   // any byte: what is not exactly A C G T is an N
+            const uint32_t idx4 = bw & 0x07070707u;
+            const uint32_t letter4 = __builtin_amdgcn_perm(0x47000054u, 0x43004101u, idx4);
+            const uint32_t code4 = __builtin_amdgcn_perm(0x0410100Cu, 0x08100010u, idx4);
+            const uint32_t x4 = bw ^ letter4;                                                   // a zero byte: the base IS that letter
+            const uint32_t nz = (((x4 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x4) & 0x80808080u;
+            const uint32_t nzff = (nz - (nz >> 7)) | nz;                                       // 0xFF where it is not
+            const uint32_t allele4 = (nzff & 0x10101010u) | (~nzff & code4);
+            const uint32_t low4 = ~qw & (qk4 - (qw & 0x7F7F7F7Fu));
+            const uint32_t row4 = ((low4 >> 2) & 0x20202020u) | allele4 | dw;
+            return (mask & row4) | (~mask & 0x18181818u);
+        };
         auto consume = [&](const Sub& S) {
+            uint32_t row4[4], other = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) row4[u] = rows_of(S.bw[u], S.qw[u], S.dw[u], S.mask[u], other);
+            if (__builtin_expect(__ballot(other != 0) != 0ull, 0)) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) row4[u] = rows_of_exact(S.bw[u], S.qw[u], S.dw[u], S.mask[u]);
+            }
+#if defined(PISCES_STORE_ABLATE) && PISCES_STORE_ABLATE == 2
+            if ((row4[0] ^ row4[1] ^ row4[2] ^ row4[3]) == 0x12345u) *reinterpret_cast<volatile int*>(hbytes) = 1;   // development ablation: no histogram update
+            return;
+#endif
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const uint32_t bw = S.bw[u], qw = S.qw[u];
-                // allele << 2 of every base
-                const uint32_t idx4 = bw & 0x07070707u;
-                const uint32_t letter4 = __builtin_amdgcn_perm(0x47000054u, 0x43004101u, idx4);   // what the low three bits stand for
-                const uint32_t code4 = __builtin_amdgcn_perm(0x0410100Cu, 0x08100010u, idx4);     // its AlleleType << 2 (N for the rest)
-                const uint32_t x4 = bw ^ letter4;                                                   // a zero byte: the base IS that letter
-                const uint32_t nz = (((x4 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x4) & 0x80808080u;
-                const uint32_t nzff = (nz - (nz >> 7)) | nz;                                       // 0xFF where it is not
-                const uint32_t allele4 = (nzff & 0x10101010u) | (~nzff & code4);
-                // quality < minBQ: bit 7 of (0x7F + minBQ) - (q & 0x7F) is set iff (q & 0x7F) < minBQ; a quality >= 128 is never low
-                const uint32_t low4 = ~qw & (qk4 - (qw & 0x7F7F7F7Fu));
-                uint32_t row4 = ((low4 >> 2) & 0x20202020u) | allele4 | S.dw[u];
-                row4 = (S.mask[u] & row4) | (~S.mask[u] & 0x18181818u);
-#if defined(PISCES_STORE_ABLATE) && PISCES_STORE_ABLATE == 2
-                if (row4 == 0x12345u) *reinterpret_cast<volatile int*>(hbytes) = 1;   // development ablation: no histogram update
-                continue;
-#endif
-                row4 = __builtin_amdgcn_alignbit(row4, row4, rot);
-                atomicAdd(reinterpret_cast<int*>(hbytes + __builtin_amdgcn_perm(row4, colreg, 0x0C0C0400u)), 1);
-                atomicAdd(reinterpret_cast<int*>(hbytes + __builtin_amdgcn_perm(row4, colreg, 0x0C0C0501u)), 1);
-                atomicAdd(reinterpret_cast<int*>(hbytes + __builtin_amdgcn_perm(row4, colreg, 0x0C0C0602u)), 1);
-                atomicAdd(reinterpret_cast<int*>(hbytes + __builtin_amdgcn_perm(row4, colreg, 0x0C0C0703u)), 1);
+#pragma unroll
+                for (int st = 0; st < 4; st++) atomicAdd(reinterpret_cast<int*>(hbytes + __builtin_amdgcn_perm(row4[u], colreg, sel[st])), 1);
             }
         };
         const int n_f = my_blocks * 4;
@@ -561,6 +603,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
 #endif
     const int l = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const PiscesTile tile = tiles[t];
+#ifdef PISCES_STORE_TIMING
+    const long long tc0 = wall_clock64();   // 100 MHz, chip-global
+    long long stamps[2] = {0, 0};
+#endif
 #if defined(PISCES_STORE_ABLATE) && PISCES_STORE_ABLATE == 4
     if (tile.n_loci > 0) { if (threadIdx.x == 0) { tile_results[t].record_begin = 0; tile_results[t].n_records = 0; tile_results[t].n_called = 0; tile_results[t].n_candidate_loci = 0; } return; }   // development ablation: nothing
 #endif
@@ -592,9 +638,17 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
     };
     for (int sg = 0; sg < S.n_segments; sg++) {
         const SegmentView& G = S.seg[sg];
+#ifdef PISCES_STORE_TIMING
+        if (G.dirs) walk_segment_fast<true>(G, tile.start_position, min_bq, l, wid, NW, hbytes, on_obs, stamps);
+        else walk_segment_fast<false>(G, tile.start_position, min_bq, l, wid, NW, hbytes, on_obs, stamps);
+#else
         if (G.dirs) walk_segment_fast<true>(G, tile.start_position, min_bq, l, wid, NW, hbytes, on_obs);
         else walk_segment_fast<false>(G, tile.start_position, min_bq, l, wid, NW, hbytes, on_obs);
+#endif
     }
+#ifdef PISCES_STORE_TIMING
+    const long long tc_walk = wall_clock64();
+#endif
     __syncthreads();
 #if defined(PISCES_STORE_ABLATE) && (PISCES_STORE_ABLATE == 1 || PISCES_STORE_ABLATE == 2 || PISCES_STORE_ABLATE >= 5)
     if (threadIdx.x == 0) { tile_results[t].record_begin = 0; tile_results[t].n_records = hist[5 + l] & 0; tile_results[t].n_called = 0; tile_results[t].n_candidate_loci = 0; }   // development ablation: no call phase
@@ -605,6 +659,19 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
                                     , 0ll, 0ll
 #endif
                                     );
+#ifdef PISCES_STORE_TIMING
+    if (threadIdx.x == 0) {   // development instrumentation: chip-global clock stamps in the tile directory (the records are not usable then)
+        const long long tc_end = wall_clock64();
+        int* tr = reinterpret_cast<int*>(&records[(int64_t)t * kSlotsPerTile + kSlotsPerTile - 1]);   // the tile's last record slot (a T variant on locus 63, if there was one, is lost)
+        tr[0] = (int)(tc0 & 0x3FFFFFFF);
+        tr[1] = (int)(stamps[0] & 0x3FFFFFFF);      // search done (first segment)
+        tr[2] = (int)(tc_walk & 0x3FFFFFFF);
+        tr[3] = (int)(tc_end & 0x3FFFFFFF);
+        tr[4] = (int)stamps[1];                     // reads in the tile's range
+        tr[5] = (int)__builtin_amdgcn_s_getreg(63492);    // HW_REG_HW_ID
+        tr[6] = (int)__builtin_amdgcn_s_getreg(63508);    // HW_REG_XCC_ID
+    }
+#endif
 }
 
 // The same walk into the anchor-resolved tensor (RegionState._alleleCounts, RegionState.cs:57) and, with sumq, the base-quality sums

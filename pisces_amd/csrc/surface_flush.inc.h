@@ -341,6 +341,14 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
     if (rc || !st.active) return rc;
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     h->h_meta_used = 0;   // the stream is idle: nothing reads the arena any more
+#ifdef PISCES_STORE_TIMING
+    if (const char* path = getenv("PISCES_HIP_DUMP_TILE_RESULTS")) {   // development: the kernel's clock stamps (tools/store_timing.py)
+        std::vector<PiscesCalledAllele> tr(h->d_tile_results.cap);   // every tile's last record slot: the stamps
+        (void)hipMemcpy2D(tr.data(), sizeof(PiscesCalledAllele), h->d_records.p + (kSlotsPerTile - 1), (size_t)kSlotsPerTile * sizeof(PiscesCalledAllele),
+                          sizeof(PiscesCalledAllele), std::min(tr.size(), h->d_records.cap / kSlotsPerTile), hipMemcpyDeviceToHost);
+        if (FILE* fp = fopen(path, "wb")) { fwrite(tr.data(), sizeof(PiscesCalledAllele), tr.size(), fp); fclose(fp); }
+    }
+#endif
     int32_t total = 0;
     rc = call_blocks_finish(h, st, &total, n_called, kept);
     if (rc) return rc;

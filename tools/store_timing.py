@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Development: per-tile phase timing of call_store_tiles_kernel (needs a -DPISCES_STORE_TIMING build in PISCES_HIP_LIB)."""
+import os, sys, tempfile
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+path = os.path.join(tempfile.gettempdir(), "store_tr.bin")
+os.environ["PISCES_HIP_DUMP_TILE_RESULTS"] = path
+from pisces_amd import _abi, engine, synth
+loci = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+p = synth.make_pileup(loci, 500, seed=7)
+whole = synth.reads_of(p, p.base.shape[0], first_amplicon=0)
+with engine.HipVariantCaller(_abi.default_config()) as c:
+    c.SetReference(p.ref.cpu().numpy())
+    for rep in range(3):
+        c.AddAlleleCounts(whole)
+        try:
+            c.Call(None, capacity=4 * loci)
+        except Exception as e:   # (the records are not usable in a timing build)
+            print("flush:", e)
+nt = (loci + 999) // 1000 * 16
+t = np.fromfile(path, dtype=np.int32).reshape(-1, 16)[:nt]
+t0, ts, tw, te = (t[:, k].astype(np.int64) for k in range(4))
+base = t0.min()
+t0, ts, tw, te = ((x - base) / 100.0 for x in (t0, ts, tw, te))
+nreads = t[:, 4].astype(np.int64)
+print(f"tiles {nt}; span {te.max():.1f} us; reads in range p10/p50/p90/max {np.percentile(nreads, [10, 50, 90, 100])}")
+for name, v in (("start", t0), ("search done", ts - t0), ("walk dur", tw - ts), ("call dur", te - tw), ("end", te)):
+    print(f"{name:12s} us  min/p10/p50/p90/p99/max:", np.round(np.percentile(v, [0, 10, 50, 90, 99, 100]), 1))
+for lo, hi in ((0, 600), (600, 2000)):
+    m = (nreads >= lo) & (nreads < hi)
+    if m.any():
+        print(f"tiles with {lo}-{hi} reads: n={int(m.sum())} walk dur p50 {np.percentile((tw - ts)[m], 50):.1f} p90 {np.percentile((tw - ts)[m], 90):.1f} us; per 16 reads p50 {np.percentile(((tw - ts) / np.maximum(nreads, 1) * 16)[m], 50) * 1000:.0f} ns")
+print("t(us)  searching  walking  calling")
+for g in np.arange(0, te.max() + 1, 4.0):
+    print(f"{g:6.0f} {int(((t0 <= g) & (ts > g)).sum()):9d} {int(((ts <= g) & (tw > g)).sum()):8d} {int(((tw <= g) & (te > g)).sum()):8d}")
