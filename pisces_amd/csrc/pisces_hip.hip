@@ -109,7 +109,7 @@ struct ReadSegment {
     DeviceBuf<uint32_t> clen;
     DeviceBuf<ReadDesc> desc;
     DeviceBuf<ReadExt> ext;
-    DeviceBuf<int32_t> state;
+    int32_t* state = nullptr;    // its four state words on the device (a slot of PiscesHip::state_pool, zero when handed out)
     const uint8_t *v_bases = nullptr, *v_quals = nullptr, *v_dirs = nullptr, *v_cop = nullptr;
     const uint32_t* v_clen = nullptr;
     int64_t n_reads = 0, n_bases = 0, n_ops = 0;
@@ -294,6 +294,10 @@ struct PiscesHip {
     size_t store_direct_bytes = (size_t)256 << 10;   // a batch of at least this many bytes becomes a segment of its own (no copy); smaller ones are appended to the open segment
     size_t store_seal_bytes = (size_t)4 << 20;       // the open segment stops accepting batches at this size
     std::vector<int32_t> touched_keys;
+    // state words of the segments: slots of buffers that were zeroed in one piece (a fill per new segment is a stream operation per add_reads)
+    std::vector<std::unique_ptr<DeviceBuf<int32_t>>> state_pool;
+    size_t state_slots_used = 0;
+    int store_waves = 0;                      // development: waves per tile of call_store_tiles_kernel (PISCES_HIP_STORE_WAVES; 0 = by launch size)
 
     // device scratch, grow-only
     DeviceBuf<uint32_t> d_tuples;
@@ -547,6 +551,7 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         const char* rp = getenv("PISCES_HIP_READ_PATH");   // "log": reads are expanded into the observation log and bucketed at flush time (the earlier chain)
         if (rp && std::string(rp) == "log") h->read_path = 0;
         if (const char* v = getenv("PISCES_HIP_STORE_DIRECT_BYTES")) h->store_direct_bytes = (size_t)std::max(0ll, atoll(v));
+        if (const char* v = getenv("PISCES_HIP_STORE_WAVES")) h->store_waves = atoi(v);
         if (const char* v = getenv("PISCES_HIP_STORE_SEAL_BYTES")) h->store_seal_bytes = (size_t)std::max(0ll, atoll(v));
     }
     {
@@ -672,6 +677,7 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     h->d_cands.release(); h->d_alleles.release(); h->d_cand_records.release(); h->d_cand_callable.release();
     h->segments.clear();
     h->segment_pool.clear();
+    h->state_pool.clear();
     for (hipEvent_t ev : h->ring) (void)hipEventDestroy(ev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);

@@ -559,6 +559,21 @@ __device__ __forceinline__ void walk_store(const StoreView& S, int tile_start, i
     }
 }
 
+// The tiles of a run of consecutive blocks with no interval clipping, by value: tile t is the (t % tiles_per_block)-th 64-locus tile of
+// block first_key + t / tiles_per_block (GetBlockKey grid, RegionStateManager.cs:385-391).  A flush of such a run uploads no geometry.
+struct RegularTiles {
+    int32_t first_key, block_size, tiles_per_block, pad;
+};
+__device__ __forceinline__ PiscesTile regular_tile(const RegularTiles& R, int t)
+{
+    const int b = t / R.tiles_per_block, i = t - b * R.tiles_per_block;
+    PiscesTile tile;
+    tile.start_position = (R.first_key - 1 + b) * R.block_size + 1 + i * kTile;
+    tile.n_loci = min(kTile, R.block_size - i * kTile);
+    tile.tuple_begin = tile.tuple_end = 0;
+    return tile;
+}
+
 // consecutive tiles on one XCD (workgroups go round the 8 XCDs in dispatch order): neighbouring tiles read the same reads — their
 // lines are then in that XCD's L2 the second time
 __device__ __forceinline__ int xcd_tile_of_block(int b, int n)
@@ -585,11 +600,15 @@ __device__ __forceinline__ uint32_t allele_row_bytes_of_base(uint32_t c)
     return (c == letter ? code : (uint32_t)PISCES_ALLELE_N) * (4u * kWaveRow * (uint32_t)sizeof(int));
 }
 
+// NW waves walk a tile's reads (blocks of 64 descriptors in turn).  A launch that fills the chip anyway takes 2 (or 1 beyond ~8 k tiles);
+// a launch of a few tiles — one 1000-locus block of the streaming protocol is 16 — takes 8, so that a tile's ~700 reads are eleven
+// blocks side by side and not six one after the other per wave.  The call phase is the wave kernel's: wave 0 the Reference records and
+// the directory, the last wave the variant records; the other waves are done when the histogram is.
 template <int NW>
 __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_OCC) void call_store_tiles_kernel(
-    StoreView S, const uint32_t* __restrict__ tuples, const PiscesTile* __restrict__ tiles, int32_t n_tiles, const uint8_t* __restrict__ ref,
-    int32_t ref_start, int64_t ref_len, PiscesCalledAllele* __restrict__ records, PiscesTileResult* __restrict__ tile_results, DeviceParams P,
-    const DeviceParams* __restrict__ Pd)
+    StoreView S, const uint32_t* __restrict__ tuples, const PiscesTile* __restrict__ tiles /* or nullptr: R */, RegularTiles R, int32_t n_tiles,
+    const uint8_t* __restrict__ ref, int32_t ref_start, int64_t ref_len, PiscesCalledAllele* __restrict__ records,
+    PiscesTileResult* __restrict__ tile_results, DeviceParams P, const DeviceParams* __restrict__ Pd)
 {
     __shared__ __attribute__((aligned(16))) int hist[2 * kWaveRegion];   // [region: quality-passing / low-quality][allele * 4 + direction][locus]
     __shared__ uint8_t s_refwin[kRefWin];
@@ -602,7 +621,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
     const int t = xcd_tile_of_block((int)blockIdx.x, n_tiles);
 #endif
     const int l = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const PiscesTile tile = tiles[t];
+    const PiscesTile tile = tiles ? tiles[t] : regular_tile(R, t);
 #ifdef PISCES_STORE_TIMING
     const long long tc0 = wall_clock64();   // 100 MHz, chip-global
     long long stamps[2] = {0, 0};
@@ -654,7 +673,8 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
     if (threadIdx.x == 0) { tile_results[t].record_begin = 0; tile_results[t].n_records = hist[5 + l] & 0; tile_results[t].n_called = 0; tile_results[t].n_candidate_loci = 0; }   // development ablation: no call phase
     return;
 #endif
-    call_phase_wave<NW, HistLinear>(hist, s_refwin, s_vmask, tile, t, l, wid, ref, ref_start, ref_len, records, tile_results, P
+    if (NW > 2 && wid != 0 && wid != NW - 1) return;
+    call_phase_wave<(NW == 1 ? 1 : 2), HistLinear>(hist, s_refwin, s_vmask, tile, t, l, NW == 1 ? 0 : (wid == NW - 1 ? 1 : 0), ref, ref_start, ref_len, records, tile_results, P
 #ifdef PISCES_TIMING
                                     , 0ll, 0ll
 #endif
@@ -672,6 +692,52 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
         tr[6] = (int)__builtin_amdgcn_s_getreg(63508);    // HW_REG_XCC_ID
     }
 #endif
+}
+
+// Ordered compaction of a small launch (<= 64 tiles: the blocks of one flush of the streaming protocol) in ONE workgroup: the scan of
+// the tiles' record counts, then every wave copies the valid slots of its tiles in order (scan_tile_counts_kernel + gather_records_kernel
+// for any number of tiles are two launches and a separate copy of the counts).  out[0] is a header {records, alleles called}: the
+// records start at out[1], so that header and records come back in one transfer.
+__global__ __launch_bounds__(1024) void compact_small_kernel(const PiscesCalledAllele* __restrict__ records, const PiscesTileResult* __restrict__ tr,
+                                                             int32_t n_tiles, PiscesCalledAllele* __restrict__ out, int32_t capacity)
+{
+    __shared__ int s_off[64];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (w == 0) {
+        const int v = l < n_tiles ? tr[l].n_records : 0;
+        int called = l < n_tiles ? tr[l].n_called : 0;
+        int x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d, 64);
+            if (l >= d) x += y;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) called += __shfl_xor(called, d, 64);
+        s_off[l] = x - v;
+        if (l == 63) {
+            int4* hdr = reinterpret_cast<int4*>(out);
+            hdr[0] = make_int4(x, called, 0, 0);
+        }
+    }
+    __syncthreads();
+    for (int t = w; t < n_tiles; t += 16) {
+        const uint32_t nib = (tr[t].valid[l >> 3] >> ((l & 7) * 4)) & 0xFu;
+        int x = __popc(nib);
+        const int mine = x;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d, 64);
+            if (l >= d) x += y;
+        }
+        int64_t dst = (int64_t)s_off[t] + (x - mine);
+        const PiscesCalledAllele* src = records + (int64_t)tr[t].record_begin + l * 4;
+        for (int k = 0; k < 4; k++) {
+            if (!(nib & (1u << k))) continue;
+            if (dst < capacity) copy_record(&out[1 + dst], &src[k]);
+            dst++;
+        }
+    }
 }
 
 // The same walk into the anchor-resolved tensor (RegionState._alleleCounts, RegionState.cs:57) and, with sumq, the base-quality sums

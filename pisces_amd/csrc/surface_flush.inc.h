@@ -232,29 +232,47 @@ static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& key
     h->pending_view_n = 0;
     if (keys.empty()) return PISCES_OK;
     if (!h->d_ref.p) return fail(h, PISCES_E_STATE, "flush: set_reference has not been called");
-    std::vector<PiscesTile> tiles;
-    int32_t rc = bucket_blocks(h, keys, true, tiles);
-    if (rc) return rc;
-    if (tiles.empty()) return PISCES_OK;
-    const int32_t n_tiles = (int32_t)tiles.size();
-    const size_t cap = (size_t)n_tiles * kSlotsPerTile;   // slot layout: 256 slots per tile
-    PISCES_HIP_CHECK(h, h->d_records.reserve(cap));
-    PISCES_HIP_CHECK(h, h->d_compact.reserve(cap));
-    PISCES_HIP_CHECK(h, h->d_offsets.reserve((size_t)n_tiles));
-
     const bool window = h->cfg.noise_model == PISCES_NOISE_WINDOW;
     bool use_counts = false;
     for (auto& kv : h->gapped_mnv_ref)
         if (std::binary_search(keys.begin(), keys.end(), block_key(h, kv.first))) { use_counts = true; break; }
-
-    std::vector<uint32_t> g;
     // the read store calls through call_store_tiles_kernel; configurations that kernel is not compiled for (the Diploid strand-bias model,
-    // the 4-wave development form) go through the counts in HBM
+    // the 4-wave development form, a quality threshold above 127) go through the counts in HBM
     const bool store = h->read_path == 1;
     const bool store_fused = h->kernel_variant >= 2 && h->cfg.strand_bias_model != PISCES_SB_DIPLOID && h->cfg.min_base_call_quality <= 127;
-    if (!use_counts && !window && store && store_fused) {
-        PISCES_HIP_CHECK(h, launch_call_store_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p,
-                                                    h->d_tile_results.p));
+    const bool fused = !use_counts && !window && store && store_fused;
+    // A run of consecutive blocks that no interval set clips, nothing in the observation log: the tile geometry goes to the kernel by
+    // value (RegularTiles) — no geometry is made on the host and none uploaded
+    const int bs = h->cfg.block_size;
+    const int tiles_per_block = (bs + kTile - 1) / kTile;
+    const bool regular = fused && h->log_ub == 0 && h->intervals.empty() && (int64_t)keys.back() - keys.front() + 1 == (int64_t)keys.size() &&
+                         (int64_t)keys.size() * tiles_per_block < 0x7FFFFF00ll / kSlotsPerTile;
+    std::vector<PiscesTile> tiles;
+    int32_t n_tiles = 0;
+    int64_t n_loci_total = 0;
+    RegularTiles R = {0, bs, tiles_per_block, 0};
+    if (regular) {
+        R.first_key = keys.front();
+        n_tiles = (int32_t)(keys.size() * (size_t)tiles_per_block);
+        n_loci_total = (int64_t)keys.size() * bs;
+        PISCES_HIP_CHECK(h, h->d_tile_results.reserve((size_t)n_tiles));
+        PISCES_HIP_CHECK(h, h->d_count.reserve(4));
+    } else {
+        int32_t rc = bucket_blocks(h, keys, true, tiles);
+        if (rc) return rc;
+        if (tiles.empty()) return PISCES_OK;
+        n_tiles = (int32_t)tiles.size();
+        for (auto& t : tiles) n_loci_total += t.n_loci;
+    }
+    const size_t cap = (size_t)n_tiles * kSlotsPerTile;   // slot layout: 256 slots per tile
+    PISCES_HIP_CHECK(h, h->d_records.reserve(cap));
+    PISCES_HIP_CHECK(h, h->d_compact.reserve(cap + 1));   // ([0]: the header of a small launch's compaction)
+    PISCES_HIP_CHECK(h, h->d_offsets.reserve((size_t)n_tiles));
+
+    std::vector<uint32_t> g;
+    if (fused) {
+        PISCES_HIP_CHECK(h, launch_call_store_tiles(h, h->stream, regular ? nullptr : h->d_tuples.p, regular ? nullptr : h->d_tiles.p, R, n_tiles, h->d_ref.p, 1,
+                                                    h->ref_len, h->d_records.p, h->d_tile_results.p));
     } else if (!use_counts && !window && !store) {
         PISCES_HIP_CHECK(h, launch_call_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p,
                                               h->d_tile_results.p));
@@ -276,14 +294,19 @@ static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& key
                            h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p, h->d_tile_results.p, h->P,
                            window ? h->d_sumq.p : (const double*)nullptr);
     }
-    // tiles were built in ascending position order: the ordered compaction is AlleleCaller.Call's (position, ref, alt) order
-    launch_compaction(h->stream, h->d_records.p, h->d_tile_results.p, n_tiles, h->d_offsets.p, h->d_compact.p, (int32_t)cap, h->d_count.p,
-                      h->d_count.p + 1);
+    // tiles were built in ascending position order: the ordered compaction is AlleleCaller.Call's (position, ref, alt) order.
+    // The sorted records lie behind one header slot in d_compact.  A launch of up to 64 tiles (the blocks of one flush of the streaming
+    // protocol) is compacted by ONE workgroup that also writes {records, called} into the header slot: one kernel, one transfer back.
+    const bool small = n_tiles <= 64;
+    if (small)
+        hipLaunchKernelGGL(compact_small_kernel, dim3(1), dim3(1024), 0, h->stream, (const PiscesCalledAllele*)h->d_records.p,
+                           (const PiscesTileResult*)h->d_tile_results.p, n_tiles, h->d_compact.p, (int32_t)cap);
+    else
+        launch_compaction(h->stream, h->d_records.p, h->d_tile_results.p, n_tiles, h->d_offsets.p, h->d_compact.p + 1, (int32_t)cap, h->d_count.p,
+                          h->d_count.p + 1);
     PISCES_HIP_CHECK(h, hipGetLastError());
     // one synchronisation in the usual case: the two counters and a speculative prefix of the sorted records (one per locus plus
     // a quarter) come back together into pinned memory; a second copy only when more alleles were called than that
-    int64_t n_loci_total = 0;
-    for (auto& t : tiles) n_loci_total += t.n_loci;
     const size_t spec = std::min<size_t>(cap, (size_t)(n_loci_total + n_loci_total / 4 + 64));
     // DoneProcessing's kernel rides in the same submission (it only writes the OTHER log buffer): one synchronisation per flush
     const bool drop_now = with_drop && h->log_ub > 0;
@@ -291,7 +314,7 @@ static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& key
         int32_t rcd = enqueue_drop(h, keys, hole_bound);
         if (rcd) return rcd;
     }
-    const size_t dl_bytes = 16 + cap * sizeof(PiscesCalledAllele);
+    const size_t dl_bytes = (cap + 1) * sizeof(PiscesCalledAllele);
     if (dl_bytes > h->h_dl_cap) {
         if (h->h_dl) (void)hipHostFree(h->h_dl);
         h->h_dl = nullptr;
@@ -299,12 +322,17 @@ static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& key
         PISCES_HIP_CHECK(h, hipHostMalloc((void**)&h->h_dl, dl_bytes + dl_bytes / 2, hipHostMallocDefault));
         h->h_dl_cap = dl_bytes + dl_bytes / 2;
     }
+    // the pinned download buffer mirrors d_compact: a header slot {records, called, kept (8 bytes)}, then the records
     int32_t* hdr = (int32_t*)h->h_dl;
-    PiscesCalledAllele* hrec = (PiscesCalledAllele*)(h->h_dl + 16);
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(hdr, h->d_count.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    PiscesCalledAllele* hrec = (PiscesCalledAllele*)h->h_dl + 1;
+    if (small) {
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(hdr, h->d_compact.p, (spec + 1) * sizeof(PiscesCalledAllele), hipMemcpyDeviceToHost, h->stream));
+    } else {
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(hdr, h->d_count.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(hrec, h->d_compact.p + 1, spec * sizeof(PiscesCalledAllele), hipMemcpyDeviceToHost, h->stream));
+    }
     if (drop_now)
         PISCES_HIP_CHECK(h, hipMemcpyAsync(hdr + 2, h->d_log_n.p + (h->log_cur ^ 1), sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(hrec, h->d_compact.p, spec * sizeof(PiscesCalledAllele), hipMemcpyDeviceToHost, h->stream));
     st->active = true;
     st->drop_now = drop_now;
     st->hdr = hdr;
@@ -321,7 +349,7 @@ static int32_t call_blocks_finish(PiscesHip* h, const CallBlocksInFlight& st, in
     *n_called += st.hdr[1];
     if (st.drop_now && kept) std::memcpy(kept, st.hdr + 2, sizeof(unsigned long long));
     if ((size_t)*total > st.spec) {
-        PISCES_HIP_CHECK(h, hipMemcpyAsync(st.hrec + st.spec, h->d_compact.p + st.spec, ((size_t)*total - st.spec) * sizeof(PiscesCalledAllele),
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(st.hrec + st.spec, h->d_compact.p + 1 + st.spec, ((size_t)*total - st.spec) * sizeof(PiscesCalledAllele),
                                            hipMemcpyDeviceToHost, h->stream));
         PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     }

@@ -21,7 +21,7 @@ static void store_view(const PiscesHip* h, StoreView* V)
         v.dirs = g.v_dirs;
         v.cigar_op = g.v_cop;
         v.cigar_len = g.v_clen;
-        v.state = g.state.p;
+        v.state = g.state;
         v.n_reads = (int32_t)g.n_reads;
         v.n_floored = (int32_t)g.n_floored;
         v.floor = g.floor;
@@ -36,7 +36,23 @@ static bool store_is_empty(const PiscesHip* h)
     return true;
 }
 
-// a segment without reads, its state words zeroed on the handle's stream (buffers of a retired segment are reused)
+// four zeroed state words on the device
+constexpr size_t kStateSlotsPerBuffer = 1024;
+static int32_t store_state_slot(PiscesHip* h, int32_t** out)
+{
+    if (h->state_pool.empty() || h->state_slots_used == kStateSlotsPerBuffer) {
+        std::unique_ptr<DeviceBuf<int32_t>> b(new DeviceBuf<int32_t>());
+        PISCES_HIP_CHECK(h, b->reserve(4 * kStateSlotsPerBuffer));
+        PISCES_HIP_CHECK(h, hipMemsetAsync(b->p, 0, 4 * kStateSlotsPerBuffer * sizeof(int32_t), h->stream));
+        // (earlier buffers stay: segments that are alive point into them; 16 KB per 1024 segments)
+        h->state_pool.push_back(std::move(b));
+        h->state_slots_used = 0;
+    }
+    *out = h->state_pool.back()->p + 4 * h->state_slots_used++;
+    return PISCES_OK;
+}
+
+// a segment without reads (buffers of a retired segment are reused)
 static int32_t store_new_segment(PiscesHip* h, std::unique_ptr<ReadSegment>* out)
 {
     std::unique_ptr<ReadSegment> g;
@@ -52,8 +68,7 @@ static int32_t store_new_segment(PiscesHip* h, std::unique_ptr<ReadSegment>* out
     g->open = false;
     g->v_bases = g->v_quals = g->v_dirs = g->v_cop = nullptr;
     g->v_clen = nullptr;
-    PISCES_HIP_CHECK(h, g->state.reserve(4));
-    PISCES_HIP_CHECK(h, hipMemsetAsync(g->state.p, 0, 4 * sizeof(int32_t), h->stream));
+    { int32_t rc = store_state_slot(h, &g->state); if (rc) return rc; }
     *out = std::move(g);
     return PISCES_OK;
 }
@@ -81,7 +96,7 @@ static int32_t store_commit_flush(PiscesHip* h, const std::vector<int32_t>& keys
             g.floor = 0;
             g.max_key = 0;
             g.v_dirs = nullptr;
-            PISCES_HIP_CHECK(h, hipMemsetAsync(g.state.p, 0, 4 * sizeof(int32_t), h->stream));
+            { int32_t rc = store_state_slot(h, &g.state); if (rc) return rc; }
             i++;
         } else if (dead) {
             store_retire(h, std::move(h->segments[i]));
@@ -97,8 +112,9 @@ static int32_t store_commit_flush(PiscesHip* h, const std::vector<int32_t>& keys
 
 // the batch in the pinned staging buffer (laid out by L) -> device, in one piece or, when it is large, in slices whose host copies
 // run under the transfers of the slices before them
+// (everything but the table of candidate-record slots, which the pass over the CIGARs makes while this is on its way)
 static int32_t store_upload_batch(PiscesHip* h, const PiscesReadBatch* batch, const StageLayout& L, int32_t nr, size_t n_cig, size_t n_seq, bool staged,
-                                  const std::vector<int32_t>& fslots, uint8_t* d_dst)
+                                  uint8_t* d_dst)
 {
     uint8_t* st = h->h_stage;
     auto place = [](uint8_t* dst, const void* src, size_t n) { if (n && (const void*)dst != src) std::memcpy(dst, src, n); };
@@ -109,18 +125,17 @@ static int32_t store_upload_batch(PiscesHip* h, const PiscesReadBatch* batch, co
     place(st + L.off_clen, batch->cigar_len, n_cig * 4);
     place(st + L.off_soff, batch->seq_offset, ((size_t)nr + 1) * 4);
     if (batch->deletion_directions) place(st + L.off_deldirs, batch->deletion_directions, 2 * n_cig);
-    std::memcpy(st + L.off_fslots, fslots.data(), ((size_t)nr + 1) * 4);
     struct Seg { size_t dst; const uint8_t* src; size_t len; };
     const Seg segs[3] = {{L.off_bases, batch->bases, n_seq}, {L.off_quals, batch->quals, n_seq}, {L.off_dirs, batch->directions, batch->directions ? n_seq : 0}};
     const size_t bulk = 2 * n_seq + (batch->directions ? n_seq : 0);
     constexpr size_t kSlice = (size_t)8 << 20;
     if (staged || bulk < 2 * kSlice) {
         for (const Seg& g : segs) place(st + g.dst, g.src, g.len);
-        PISCES_HIP_CHECK(h, hipMemcpyAsync(d_dst, st, L.total, hipMemcpyHostToDevice, h->stream));
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(d_dst, st, L.off_fslots, hipMemcpyHostToDevice, h->stream));
         return PISCES_OK;
     }
     PISCES_HIP_CHECK(h, hipMemcpyAsync(d_dst, st, L.off_bases, hipMemcpyHostToDevice, h->stream));
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(d_dst + L.off_slots, st + L.off_slots, L.total - L.off_slots, hipMemcpyHostToDevice, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(d_dst + L.off_slots, st + L.off_slots, L.off_fslots - L.off_slots, hipMemcpyHostToDevice, h->stream));
     struct Slice { size_t dst; const uint8_t* src; size_t len; };
     std::vector<Slice> slices;
     for (const Seg& g : segs)
@@ -262,7 +277,7 @@ static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const Sto
     }
     S.desc = g.desc.p;
     S.ext = g.ext.p;
-    S.state = g.state.p;
+    S.state = g.state;
     hipLaunchKernelGGL(read_shape_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, h->stream, S);
     if (!pl.direct && !A.dirs && g.v_dirs)   // a batch without directions in a segment that tracks them
         hipLaunchKernelGGL(segment_fill_dirs_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, h->stream, (const ReadDesc*)g.desc.p,
@@ -271,9 +286,9 @@ static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const Sto
     return PISCES_OK;
 }
 
-// pisces_hip_add_reads with the read store: ONE host pass over the CIGARs (argument checks of the reference's walk, the blocks the reads
-// touch, the candidate-record slots), the batch across PCIe once, descriptors and candidate discovery on the device.  Nothing of the
-// handle's state changes before the whole batch has been checked.
+// pisces_hip_add_reads with the read store: the batch goes across PCIe once, in one piece, and ONE host pass over the CIGARs runs while it
+// is on its way (argument checks of the reference's walk, the blocks the reads touch, the candidate-record slots); descriptors and
+// candidate discovery are made on the device.  Nothing of the handle's state changes before the whole batch has been checked.
 static int32_t add_reads_store(PiscesHip* h, const PiscesReadBatch* batch)
 {
     const int32_t nr = batch->n_reads;
@@ -283,6 +298,26 @@ static int32_t add_reads_store(PiscesHip* h, const PiscesReadBatch* batch)
     const bool staged = h->staged_total == L.total && h->h_stage && (const uint8_t*)batch->position == h->h_stage + L.off_pos &&
                         batch->bases == h->h_stage + L.off_bases && batch->quals == h->h_stage + L.off_quals;
     h->staged_total = 0;
+    for (int32_t i = 0; i < nr; i++)   // (what the upload itself relies on)
+        if (batch->cigar_offset[i + 1] < batch->cigar_offset[i] || batch->seq_offset[i + 1] < batch->seq_offset[i])
+            return fail(h, PISCES_E_INVALID_ARG, "add_reads: malformed read batch");
+    // ---- where the batch goes, and across PCIe in one piece
+    const size_t bulk = 2 * n_seq + (batch->directions ? n_seq : 0) + 5 * n_cig;
+    StorePlace pl;
+    { int32_t rc = store_place_batch(h, bulk, &pl); if (rc) return rc; }
+    int32_t rc = staged ? PISCES_OK : stage_reserve(h, L.total, !pl.direct);
+    if (rc == PISCES_OK && pl.direct) {
+        hipError_t e = pl.seg->blob.reserve(L.total);
+        if (e != hipSuccess) rc = fail(h, PISCES_E_DEVICE, std::string("add_reads: ") + hipGetErrorString(e));
+    }
+    if (rc == PISCES_OK && !pl.direct && staged) {   // (stage_reads reserved the device half with the pinned one)
+        hipError_t e = h->stage[h->stage_cur].d.reserve(L.total);
+        if (e != hipSuccess) rc = fail(h, PISCES_E_DEVICE, std::string("add_reads: ") + hipGetErrorString(e));
+    }
+    if (rc) { store_unplace(h, pl); return rc; }
+    uint8_t* const d = pl.direct ? pl.seg->blob.p : D_STAGE(h);
+    rc = store_upload_batch(h, batch, L, nr, n_cig, n_seq, staged, d);
+    // ---- the pass over the CIGARs, under the transfer
     auto op_ref = [](uint8_t t) { return t == 'M' || t == 'D' || t == 'N' || t == '=' || t == 'X'; };
     auto op_read = [](uint8_t t) { return t == 'M' || t == 'I' || t == 'S' || t == '=' || t == 'X'; };
     const bool find_on_device = !h->h_ref.empty();   // without a reference only the IStateManager half (allele counts) runs
@@ -292,21 +327,37 @@ static int32_t add_reads_store(PiscesHip* h, const PiscesReadBatch* batch)
     std::vector<int32_t>& touched = h->touched_keys;
     touched.clear();
     int64_t found_slots = 0, found_pool = 0;
-    int32_t max_key = 0, last_touched = -1;
+    int32_t max_key = 0;
     const int32_t bs = h->cfg.block_size;
-    for (int32_t i = 0; i < nr; i++) {
+    int64_t in_lo = 1, in_hi = 0;   // positions of the block touched last: a read inside it needs no division
+    const char* bad = nullptr;
+    auto touch = [&](int64_t from, int64_t to) {   // inclusive: GetBlock(position) for every position that receives a count (RegionStateManager.cs:361-383)
+        if (to < 1) return;
+        if (from < 1) from = 1;
+        if (from >= in_lo && to <= in_hi) return;
+        const int32_t k0 = block_key(h, (int32_t)from), k1 = block_key(h, (int32_t)to);
+        for (int32_t k = k0; k <= k1; k++) {
+            if (touched.empty() || touched.back() != k) touched.push_back(k);
+            max_key = std::max(max_key, k);
+        }
+        in_lo = (int64_t)(k1 - 1) * bs + 1;
+        in_hi = (int64_t)k1 * bs;
+    };
+    for (int32_t i = 0; i < nr && rc == PISCES_OK && !bad; i++) {
         const ReadView r = read_view(batch, i);
         fslots[(size_t)i] = (int32_t)found_slots;
-        if (r.position <= 0) return fail(h, PISCES_E_INVALID_ARG, "Position must be greater than 0.");
-        if (r.read_len < 0 || r.n_cigar < 0) return fail(h, PISCES_E_INVALID_ARG, "add_reads: malformed read batch");
-        auto touch = [&](int64_t from, int64_t to) {   // inclusive: GetBlock(position) for every position that receives a count (RegionStateManager.cs:361-383)
-            if (to < 1) return;
-            if (from < 1) from = 1;
-            for (int32_t k = block_key(h, (int32_t)from); k <= block_key(h, (int32_t)to); k++) {
-                if (k != last_touched) { touched.push_back(k); last_touched = k; }
-                max_key = std::max(max_key, k);
-            }
-        };
+        if (r.position <= 0) { bad = "Position must be greater than 0."; break; }
+        if (r.read_len < 0 || r.n_cigar < 0) { bad = "add_reads: malformed read batch"; break; }
+        if (r.dirs)
+            for (int k = 0; k < r.read_len; k++)
+                if (r.dirs[k] > 2) { bad = "add_reads: CIGAR does not match the read"; break; }
+        if (r.n_cigar == 1 && (r.cigar_op[0] == 'M' || r.cigar_op[0] == '=' || r.cigar_op[0] == 'X')) {   // one aligned run: most reads
+            const int64_t len = r.cigar_len[0];
+            if (len > r.read_len) { bad = "add_reads: CIGAR does not match the read"; break; }
+            if ((int64_t)r.position + len > 0x7FFFFFFFll) { bad = "add_reads: read runs past position 2^31 - 1"; break; }
+            if (len > 0) touch(r.position, r.position + len - 1);
+            continue;
+        }
         auto delq = [&](int idx) {   // CandidateVariantFinder.CheckDeletionQuality (CandidateVariantFinder.cs:294-320)
             if (r.read_len == 0) return false;
             const int after = idx < r.read_len ? r.quals[idx] : r.quals[idx - 1];
@@ -319,20 +370,16 @@ static int32_t add_reads_store(PiscesHip* h, const PiscesReadBatch* batch)
             if (op_read(t)) read_span += r.cigar_len[c];
             if (op_ref(t)) ref_span += r.cigar_len[c];
         }
-        if (read_span > r.read_len) return fail(h, PISCES_E_INVALID_ARG, "add_reads: CIGAR does not match the read");
-        if ((int64_t)r.position + ref_span > 0x7FFFFFFFll) return fail(h, PISCES_E_INVALID_ARG, "add_reads: read runs past position 2^31 - 1");
-        if (r.dirs)
-            for (int k = 0; k < r.read_len; k++)
-                if (r.dirs[k] > 2) return fail(h, PISCES_E_INVALID_ARG, "add_reads: CIGAR does not match the read");
+        if (read_span > r.read_len) { bad = "add_reads: CIGAR does not match the read"; break; }
+        if ((int64_t)r.position + ref_span > 0x7FFFFFFFll) { bad = "add_reads: read runs past position 2^31 - 1"; break; }
         int64_t rp = r.position, last_mapped = (int64_t)r.position - 1;
         int ri = 0;
-        for (int c = 0; c < r.n_cigar; c++) {
+        for (int c = 0; c < r.n_cigar && !bad; c++) {
             const uint8_t t = r.cigar_op[c];
             const int64_t len = r.cigar_len[c];
             if (r.del_dirs && t == 'D')
                 for (int k = 0; k < 2; k++)
-                    if (r.del_dirs[2 * c + k] > 2 && r.del_dirs[2 * c + k] != PISCES_DIR_UNTRACKED)
-                        return fail(h, PISCES_E_INVALID_ARG, "add_reads: deletion_directions holds a value that is no DirectionType");
+                    if (r.del_dirs[2 * c + k] > 2 && r.del_dirs[2 * c + k] != PISCES_DIR_UNTRACKED) bad = "add_reads: deletion_directions holds a value that is no DirectionType";
             if (count_indels) {
                 if (t == 'I' || t == 'D') found_slots++;
                 if (t == 'I' && len > (int64_t)kFoundInline) found_pool += len;
@@ -353,26 +400,10 @@ static int32_t add_reads_store(PiscesHip* h, const PiscesReadBatch* batch)
             const int idx = r.read_len - (int)r.cigar_len[nc - 1];
             if (idx >= 0 && idx < r.read_len && delq(idx)) touch(last_mapped + 1, last_mapped + r.cigar_len[nc - 2]);
         }
-        if (found_slots > 0x7FFFFFF0ll || found_pool > 0x7FFFFFF0ll) return fail(h, PISCES_E_INVALID_ARG, "add_reads: too many insertions / deletions in one batch");
+        if (found_slots > 0x7FFFFFF0ll || found_pool > 0x7FFFFFF0ll) bad = "add_reads: too many insertions / deletions in one batch";
     }
     fslots[(size_t)nr] = (int32_t)found_slots;
-
-    // ---- where the batch goes, and across PCIe in one piece
-    const size_t bulk = 2 * n_seq + (batch->directions ? n_seq : 0) + 5 * n_cig;
-    StorePlace pl;
-    { int32_t rc = store_place_batch(h, bulk, &pl); if (rc) return rc; }
-    int32_t rc = staged ? PISCES_OK : stage_reserve(h, L.total, !pl.direct);
-    if (rc == PISCES_OK && pl.direct) {
-        hipError_t e = pl.seg->blob.reserve(L.total);
-        if (e != hipSuccess) rc = fail(h, PISCES_E_DEVICE, std::string("add_reads: ") + hipGetErrorString(e));
-    }
-    if (rc == PISCES_OK && !pl.direct && staged) {   // (stage_reads reserved the device half with the pinned one)
-        hipError_t e = h->stage[h->stage_cur].d.reserve(L.total);
-        if (e != hipSuccess) rc = fail(h, PISCES_E_DEVICE, std::string("add_reads: ") + hipGetErrorString(e));
-    }
-    if (rc) { store_unplace(h, pl); return rc; }
-    uint8_t* const d = pl.direct ? pl.seg->blob.p : D_STAGE(h);
-    rc = store_upload_batch(h, batch, L, nr, n_cig, n_seq, staged, fslots, d);
+    if (rc == PISCES_OK && bad) rc = fail(h, PISCES_E_INVALID_ARG, bad);
     DevReadBatch db;
     db.position = (const int32_t*)(d + L.off_pos);
     db.flags = d + L.off_flags;
@@ -389,9 +420,14 @@ static int32_t add_reads_store(PiscesHip* h, const PiscesReadBatch* batch)
         rc = store_append_arrays(h, pl, A, nr, n_cig, n_seq);
     }
     // ICandidateVariantFinder.FindCandidates + IStateManager.AddCandidates (SmallVariantCaller.cs:92-96) on the device, on the batch as it was uploaded
-    if (rc == PISCES_OK && find_on_device && (h->cfg.call_mnvs || found_slots > 0))
-        rc = enqueue_candidate_discovery(h, db, batch->deletion_directions ? d + L.off_deldirs : nullptr, nr, (const int32_t*)(d + L.off_fslots), found_slots,
-                                         found_pool);
+    if (rc == PISCES_OK && find_on_device && (h->cfg.call_mnvs || found_slots > 0)) {
+        std::memcpy(h->h_stage + L.off_fslots, fslots.data(), ((size_t)nr + 1) * 4);
+        hipError_t e = hipMemcpyAsync(d + L.off_fslots, h->h_stage + L.off_fslots, L.total - L.off_fslots, hipMemcpyHostToDevice, h->stream);
+        if (e != hipSuccess) rc = fail(h, PISCES_E_DEVICE, std::string("add_reads: ") + hipGetErrorString(e));
+        if (rc == PISCES_OK)
+            rc = enqueue_candidate_discovery(h, db, batch->deletion_directions ? d + L.off_deldirs : nullptr, nr, (const int32_t*)(d + L.off_fslots), found_slots,
+                                             found_pool);
+    }
     { int32_t rcs = stage_release(h); if (rc == PISCES_OK) rc = rcs; }   // (transfers out of the pinned buffer may be in flight whatever happened after them)
     if (rc) {
         (void)hipStreamSynchronize(h->stream);
@@ -455,18 +491,23 @@ static int32_t add_decoded_reads_store(PiscesHip* h, int64_t found_slots, int64_
 }
 
 // the flush's kernel: reads of the store (+ the bucketed tuples of pisces_hip_add_observations) -> LDS histogram -> calls
-static hipError_t launch_call_store_tiles(PiscesHip* h, hipStream_t s, const uint32_t* d_tuples, const PiscesTile* d_tiles, int32_t n_tiles,
-                                          const uint8_t* d_ref, int32_t ref_start, int64_t ref_len, PiscesCalledAllele* d_records, PiscesTileResult* d_tr,
+static hipError_t launch_call_store_tiles(PiscesHip* h, hipStream_t s, const uint32_t* d_tuples, const PiscesTile* d_tiles /* or nullptr: R */,
+                                          const RegularTiles& R, int32_t n_tiles, const uint8_t* d_ref, int32_t ref_start, int64_t ref_len, PiscesCalledAllele* d_records, PiscesTileResult* d_tr,
                                           hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
 {
     StoreView V;
     store_view(h, &V);
-    const bool two = h->kernel_variant == 3 || (h->kernel_variant == 4 && (int64_t)n_tiles <= (int64_t)h->n_cus * 32);
-    if (two)
-        hipExtLaunchKernelGGL(call_store_tiles_kernel<2>, dim3((unsigned)n_tiles), dim3(128), 0u, s, e0, e1, 0u, V, d_tuples, d_tiles, n_tiles, d_ref, ref_start,
-                              ref_len, d_records, d_tr, h->P, (const DeviceParams*)h->d_params.p);
-    else
-        hipExtLaunchKernelGGL(call_store_tiles_kernel<1>, dim3((unsigned)n_tiles), dim3(64), 0u, s, e0, e1, 0u, V, d_tuples, d_tiles, n_tiles, d_ref, ref_start,
-                              ref_len, d_records, d_tr, h->P, (const DeviceParams*)h->d_params.p);
+    // waves per tile: enough of them that a small launch still puts its reads on many SIMDs (see the kernel)
+    int nw = h->store_waves;
+    if (nw == 0) nw = h->kernel_variant == 2 ? 1 : h->kernel_variant == 3 ? 2 : (int64_t)n_tiles * 8 <= (int64_t)h->n_cus * 8 ? 8 : (int64_t)n_tiles * 4 <= (int64_t)h->n_cus * 12 ? 4
+                      : (int64_t)n_tiles <= (int64_t)h->n_cus * 32 ? 2 : 1;
+#define PISCES_LAUNCH_STORE(NW)                                                                                                                     \
+    hipExtLaunchKernelGGL(call_store_tiles_kernel<NW>, dim3((unsigned)n_tiles), dim3(64 * NW), 0u, s, e0, e1, 0u, V, d_tuples, d_tiles, R, n_tiles, d_ref, \
+                          ref_start, ref_len, d_records, d_tr, h->P, (const DeviceParams*)h->d_params.p)
+    if (nw >= 8) PISCES_LAUNCH_STORE(8);
+    else if (nw >= 4) PISCES_LAUNCH_STORE(4);
+    else if (nw >= 2) PISCES_LAUNCH_STORE(2);
+    else PISCES_LAUNCH_STORE(1);
+#undef PISCES_LAUNCH_STORE
     return hipGetLastError();
 }

@@ -159,7 +159,7 @@ lib = _load()
 
 def make_read(pos, seq, cigar=None, quals=None, qual_all=30, reverse=False, dirs=None, posmap=None, expanded_dirs=None):
     """ReadTestHelper.CreateRead (src/test/TestUtilities/ReadTestHelper.cs:156-173): default Q30, <len>M."""
-    seq_b = np.frombuffer(seq.encode(), dtype=np.uint8).copy()
+    seq_b = np.frombuffer(seq.encode() if isinstance(seq, str) else bytes(seq), dtype=np.uint8).copy()   # (bytes: any base value)
     n = len(seq_b)
     if cigar is None:
         cigar = [("M", n)]

@@ -1,0 +1,265 @@
+"""The read store of the streaming surface (pisces_amd/csrc/store_kernels.hip.h, surface_store.inc.h):
+pisces_hip_add_reads keeps the reads in HBM and pisces_hip_flush calls straight from them.  Checked here against the oracle
+(RegionStateManager.AddAlleleCounts, RegionStateManager.cs:118-220; SmallVariantCaller's block schedule, SmallVariantCaller.cs:88-189)
+and against the earlier chain (PISCES_HIP_READ_PATH=log: observation log + bucketing), record for record, byte for byte — through
+every way a batch can join the store (a segment of its own, appended to the open segment, more batches than segments), with the
+floor that DoneProcessing (RegionStateManager.cs:336-353) leaves behind, with reads out of position order, with bases that are no
+A C G T N, and with a quality threshold the fused kernel is not compiled for."""
+import contextlib
+import os
+
+import numpy as np
+import pytest
+
+from pisces_amd import _abi
+from tests import orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch
+
+
+@contextlib.contextmanager
+def env(**kv):
+    """Environment switches the library reads when a handle is created."""
+    old = {k: os.environ.get(k) for k in kv}
+    for k, v in kv.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = str(v)
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+STORE_MODES = {
+    "default": {},
+    "every batch its own segment": {"PISCES_HIP_STORE_DIRECT_BYTES": 0},
+    "every batch appended to the open segment": {"PISCES_HIP_STORE_DIRECT_BYTES": 1 << 40, "PISCES_HIP_STORE_SEAL_BYTES": 1 << 40},
+    "open segment closed after every batch": {"PISCES_HIP_STORE_DIRECT_BYTES": 1 << 40, "PISCES_HIP_STORE_SEAL_BYTES": 1},
+}
+
+
+def random_reads(rng, n, lo, hi, exotic=False, with_dirs=True, sort=True):
+    """Reads with arbitrary CIGARs (insertions, deletions, skips, soft / hard clips, pads, terminal deletions), N bases, low qualities,
+    stitched per-base directions; exotic: bases that are no A C G T N (IUPAC codes, lower case, '=', NUL, 0xFF)."""
+    letters = list(b"ACGTN") + (list(b"RYKMacgtn=.*") + [0, 255, 0x44, 0x4B, 0x51] if exotic else [])
+    p = np.array([.235] * 4 + [.03] + ([.03 / 17] * 17 if exotic else []))
+    p = p / p.sum()
+    reads = []
+    for i in range(n):
+        kind = i % 4
+        if kind == 0:     # one aligned run
+            ops = [("M", int(rng.integers(20, 160)))]
+        elif kind == 1:   # clips around one aligned run, split in = / X, pads and hard clips
+            ops = [("H", 3)] * int(rng.integers(0, 2)) + [("S", int(rng.integers(1, 9)))] * int(rng.integers(0, 2))
+            ops += [("=", int(rng.integers(5, 60))), ("X", 1), ("P", 2), ("M", int(rng.integers(5, 60)))]
+            ops += [("S", int(rng.integers(1, 9)))] * int(rng.integers(0, 2)) + [("H", 2)] * int(rng.integers(0, 2))
+        else:             # anything
+            ops = [(str(rng.choice(list("MMMIDSN"))), int(rng.integers(1, 30))) for _ in range(int(rng.integers(1, 7)))]
+            ops = [(o, l) for k, (o, l) in enumerate(ops) if o != "S" or k in (0, len(ops) - 1)]
+            if not any(o == "M" for o, _ in ops):
+                ops.append(("M", 5))
+            if i % 11 == 0:
+                ops.append(("D", int(rng.integers(1, 6))))
+            if i % 13 == 0:
+                ops += [("D", int(rng.integers(1, 6))), ("S", int(rng.integers(1, 5)))]
+        rl = sum(l for o, l in ops if o in "MIS=X")
+        rd = {"pos": int(rng.integers(lo, hi)), "cigar": ops, "seq": bytes(rng.choice(letters, rl, p=p).astype(np.uint8)),
+              "quals": rng.choice([10, 25, 37, 200], rl, p=[.15, .2, .63, .02]).astype(np.uint8).tolist(), "reverse": bool(rng.integers(0, 2))}
+        if with_dirs and i % 5 == 0:
+            rd["dirs"] = rng.integers(0, 3, rl).astype(np.uint8).tolist()
+        reads.append(rd)
+    if sort:
+        reads.sort(key=lambda r: r["pos"])
+    return reads
+
+
+def oracle_counts(reads, start, n_loci, min_bq=20):
+    st = orc.State(start, n_loci, min_bq=min_bq)
+    for d in reads:
+        assert st.add_allele_counts(orc.make_read(d["pos"], d["seq"], cigar=d["cigar"],
+                                                  quals=d["quals"], reverse=d["reverse"], dirs=d.get("dirs"))) == 0
+    return st.counts()
+
+
+@pytest.mark.parametrize("mode", list(STORE_MODES))
+@pytest.mark.parametrize("sort", [True, False], ids=["sorted", "unsorted"])
+def test_counts_from_the_store_equal_the_oracle(torch_cuda, mode, sort):
+    """IAlleleSource.GetAlleleCount served from the read store (accumulate_store_tiles_kernel) == the oracle's AddAlleleCounts, for
+    arbitrary CIGARs and bases, however the batches joined the store and whether or not they came in position order (a segment that is
+    not sorted is scanned in whole)."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(5)
+    reads = random_reads(rng, 700, 940, 1900, exotic=True, sort=sort)
+    exp = oracle_counts(reads, 900, 2300)
+    with env(PISCES_HIP_READ_PATH=None, **STORE_MODES[mode]):
+        with engine.HipVariantCaller(_abi.default_config()) as c:
+            for k in range(0, len(reads), 53):     # 14 batches: more than the store has segments
+                c.AddAlleleCounts(_abi.ReadBatch(reads[k:k + 53]))
+            got = c.GetCounts(900, 2300)
+            assert c.Stats()["reads"] == len(reads)
+    np.testing.assert_array_equal(got.reshape(exp.shape), exp)
+
+
+def _schedule_run(reads_batches, ref, cfg, ups, environ):
+    """add_reads batch k, then flush(ups[k]); a final flush at the end.  Returns records, allele strings, stats."""
+    from pisces_amd import engine
+    recs, alleles = [], []
+    with env(**environ):
+        with engine.HipVariantCaller(cfg) as c:
+            c.SetReference(ref)
+            for batch, up in zip(reads_batches, ups):
+                c.AddAlleleCounts(batch)
+                if up is not None:
+                    r, a = c.CallWithAlleles(up, capacity=1 << 14)
+                    recs.append(r)
+                    alleles += a
+            r, a = c.CallWithAlleles(None, capacity=1 << 14)
+            recs.append(r)
+            alleles += a
+            stats = c.Stats()
+    return np.concatenate(recs), alleles, stats
+
+
+@pytest.mark.parametrize("mode", list(STORE_MODES))
+@pytest.mark.parametrize("call_mnvs", [0, 1], ids=["snv_indel", "mnv"])
+def test_block_schedule_from_the_store_equals_the_log_chain_and_the_oracle(torch_cuda, mode, call_mnvs):
+    """SmallVariantCaller's protocol over four blocks, reads arriving in position order in batches that straddle block edges: after a
+    flush the reads that reach into blocks still held stay in the store with the flushed positions floored (nothing is counted twice,
+    nothing is lost).  Records and allele strings must equal what the observation-log chain gives, byte for byte, and the oracle
+    running the same schedule."""
+    rng = np.random.default_rng(17 + call_mnvs)
+    ref = np.frombuffer(bytes(rng.choice(list(b"ACGT"), 4400).astype(np.uint8)), dtype=np.uint8)
+    reads = []
+    for i in range(2600):
+        pos = int(rng.integers(60, 3900))
+        ln = int(rng.integers(60, 151))
+        seq = bytearray(ref[pos - 1:pos - 1 + ln].tobytes())
+        ops = [("M", ln)]
+        for k in range(len(seq)):
+            if rng.random() < 0.004:
+                seq[k] = rng.choice(list(b"ACGT"))
+        site = pos // 97 * 97 + 50     # shared variant sites: SNVs, 2-base MNVs, deletions, insertions
+        off = site - pos
+        if 8 <= off < ln - 12:
+            kind = (site // 97) % 4
+            take = rng.random() < 0.35
+            if take and kind == 0:
+                seq[off] = ord("ACGT"[("ACGT".index(chr(ref[site - 1])) + 1) % 4])
+            elif take and kind == 1:
+                for d in (0, 1):
+                    seq[off + d] = ord("ACGT"[("ACGT".index(chr(ref[site - 1 + d])) + 2) % 4])
+            elif take and kind == 2:
+                dl = 1 + (site // 97) % 5
+                ops = [("M", off), ("D", dl), ("M", ln - off)]
+            elif take and kind == 3:
+                il = 1 + (site // 97) % 4
+                seq[off:off] = bytes(rng.choice(list(b"ACGT"), il).astype(np.uint8))
+                ops = [("M", off), ("I", il), ("M", ln - off)]
+        if rng.random() < 0.2:
+            clip = int(rng.integers(1, 6))
+            seq = bytearray(rng.choice(list(b"ACGT"), clip).astype(np.uint8).tobytes()) + seq
+            ops = [("S", clip)] + ops
+        rl = sum(l for o, l in ops if o in "MIS")
+        reads.append({"pos": pos, "cigar": ops, "seq": bytes(seq[:rl]), "quals": rng.choice([12, 30, 38], rl, p=[.04, .3, .66]).astype(np.uint8).tolist(),
+                      "reverse": bool(rng.integers(0, 2))})
+    reads.sort(key=lambda r: r["pos"])
+    cfg = _abi.default_config(call_mnvs=call_mnvs, max_mnv_length=3, max_gap_between_mnv=1)
+    # batches of ~330 reads; after each one the caller has seen reads up to the last one's position
+    batches, ups = [], []
+    for k in range(0, len(reads), 330):
+        part = reads[k:k + 330]
+        batches.append(_abi.ReadBatch(part))
+        ups.append(part[-1]["pos"] - 1)
+    got, got_alleles, stats = _schedule_run(batches, ref, cfg, ups, dict(PISCES_HIP_READ_PATH=None, **STORE_MODES[mode]))
+    want, want_alleles, want_stats = _schedule_run(batches, ref, cfg, ups, dict(PISCES_HIP_READ_PATH="log"))
+    assert got.tobytes() == want.tobytes() and got_alleles == want_alleles
+    assert stats == want_stats and stats["reads"] == len(reads)
+    exp, exp_alleles, total = orc.run_reads_schedule(_abi.ReadBatch(reads), ref, 1, len(ref), cfg, ups)
+    assert len(exp) == len(got) > 3000 and exp_alleles == got_alleles
+    for f in ("position", "total_coverage", "allele_support", "reference_support", "num_no_calls", "coverage_by_dir", "support_by_dir", "filter_bits",
+              "info", "variant_qscore", "genotype_qscore"):
+        assert (got[f] == exp[f]).all(), f
+    assert stats["TotalNumCalled"] == total
+
+
+def test_thresholds_the_fused_kernel_is_not_compiled_for(torch_cuda):
+    """minBQ above 127 (the fused kernel compares seven bits) goes through the counts in HBM: same records as the log chain."""
+    rng = np.random.default_rng(2)
+    ref = np.frombuffer(bytes(rng.choice(list(b"ACGT"), 2300).astype(np.uint8)), dtype=np.uint8)
+    reads = []
+    for i in range(500):
+        pos = int(rng.integers(10, 2000))
+        ln = 100
+        reads.append({"pos": pos, "cigar": [("M", ln)], "seq": ref[pos - 1:pos - 1 + ln].tobytes(),
+                      "quals": rng.choice([100, 160, 250], ln).astype(np.uint8).tolist(), "reverse": bool(i & 1)})
+    reads.sort(key=lambda r: r["pos"])
+    cfg = _abi.default_config(min_base_call_quality=150, noise_level=20)
+    got, _, _ = _schedule_run([_abi.ReadBatch(reads)], ref, cfg, [None], dict(PISCES_HIP_READ_PATH=None))
+    want, _, _ = _schedule_run([_abi.ReadBatch(reads)], ref, cfg, [None], dict(PISCES_HIP_READ_PATH="log"))
+    assert got.tobytes() == want.tobytes() and len(got) > 2000
+    assert (got["num_no_calls"] > 0).any() and (got["total_coverage"] > 0).any()
+
+
+@pytest.mark.parametrize("n_loci,depth", [(100_000, 500)], ids=["config2_100kx500"])
+def test_config2_at_full_size_store_equals_log_chain_and_oracle_slice(torch_cuda, n_loci, depth):
+    """BASELINE config 2 (100 000 loci x 500x, 333 500 reads) through pisces_hip_add_reads / pisces_hip_flush: the read store and the
+    observation-log chain give the same bytes, in one batch and block by block; the first 2 000 loci equal the oracle."""
+    from pisces_amd import engine, synth
+    p = synth.make_pileup(n_loci=n_loci, depth=depth, seed=11)
+    ref = p.ref.cpu().numpy()
+    cfg = _abi.default_config()
+    A = p.base.shape[0]
+    whole = synth.reads_of(p, A, first_amplicon=0)
+    out = {}
+    for path in ("store", "log"):
+        with env(PISCES_HIP_READ_PATH=None if path == "store" else "log"):
+            with engine.HipVariantCaller(cfg) as c:
+                c.SetReference(ref)
+                c.AddAlleleCounts(whole)
+                one = c.Call(None, capacity=2 * n_loci)
+                parts = []
+                for a0 in range(0, A, 7):     # ~ one 1000-locus block of reads per call, as SmallVariantCaller feeds them
+                    c.AddAlleleCounts(synth.reads_of(p, 7, first_amplicon=a0))
+                    parts.append(c.Call(p.region_start + a0 * synth.READ_LEN - 1, capacity=1 << 13))
+                parts.append(c.Call(None, capacity=1 << 13))
+                out[path] = (one, np.concatenate(parts))
+    assert out["store"][0].tobytes() == out["log"][0].tobytes() and len(out["store"][0]) >= n_loci
+    assert out["store"][1].tobytes() == out["log"][1].tobytes()
+    assert out["store"][0].tobytes() == out["store"][1].tobytes()
+    head = synth.reads_of(p, 14, first_amplicon=0)
+    exp, _ = orc.run_reads(head, ref, p.region_start, 2000, cfg)
+    got = out["store"][0]
+    got = got[got["position"] < p.region_start + 2000]
+    assert got.tobytes() == exp.tobytes()
+
+
+def test_config3_mix_store_equals_log_chain(torch_cuda):
+    """BASELINE config 3's mix (SNVs, MNVs, deletions, insertions at 2000x, MNV calling on) over 30 amplicons, block by block: the read
+    store and the log chain give the same records and allele strings (the full size runs in test_gpu_parity.py; this is the A / B)."""
+    from pisces_amd import synth
+    seed, depth, n_amp = 33, 2000, 30
+    cfg = _abi.default_config(call_mnvs=1, max_mnv_length=3, max_gap_between_mnv=1)
+    n_loci = n_amp * synth.READ_LEN
+    ref = synth.reference_of(n_loci, seed, device="cuda")
+    p = synth.make_pileup(n_loci, depth, seed=seed, device="cuda", first_locus=0, total_loci=n_loci, with_tuples=False)
+    batch, planted = synth.mixed_reads(p, seed)
+    ups = [1000, 2000, 3000, 4000]
+    got, got_alleles, stats = _schedule_run([batch] + [_abi.ReadBatch([])] * 3, ref, cfg, ups, dict(PISCES_HIP_READ_PATH=None))
+    want, want_alleles, want_stats = _schedule_run([batch] + [_abi.ReadBatch([])] * 3, ref, cfg, ups, dict(PISCES_HIP_READ_PATH="log"))
+    assert got.tobytes() == want.tobytes() and got_alleles == want_alleles and stats == want_stats
+    cats = (got["info"] >> 4) & 7
+    assert len(planted) >= 5 and (cats == _abi.CAT_MNV).any() and (cats == _abi.CAT_DELETION).any() and (cats == _abi.CAT_INSERTION).any()
