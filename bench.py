@@ -237,6 +237,101 @@ def end_to_end(pileup, cfg, engine, loci=30_000):
     return out
 
 
+def end_to_end_full(pileup, cfg, engine, torch):
+    """The streaming surface on ALL of the configuration the metric is quoted on (BASELINE config 2: 100 000 loci x 500x = 333 500 reads
+    of batch 0), not a 30 000-locus sample: in one add_reads + flush, and block by block as SmallVariantCaller drives it
+    (SmallVariantCaller.cs:88-112,157-189).  The flush's kernel is timed with HIP events bound to its dispatch: `roofline_streaming` is
+    the read store's kernel against the bytes the reads -> records path has to move (2 B per aligned base + 64 B per record)."""
+    import numpy as np
+    from pisces_amd import synth
+    ref = pileup.ref.cpu().numpy()
+    n_amp = pileup.base.shape[0]
+    whole = synth.reads_of(pileup, n_amp, first_amplicon=pileup.first_amplicon)
+    n_bases = int(whole.n_bases)
+    out, roof = {}, None
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(ref)
+        best, n_rec = None, 0
+        for rep in range(5):
+            if rep == 1:
+                c.set_timing(1)
+                c.HostTime(reset=True)
+            t0 = time.perf_counter()
+            c.AddAlleleCounts(whole)
+            n_rec = len(c.Call(None, capacity=1 << 18, reuse_buffer=True))
+            dt = time.perf_counter() - t0
+            if rep > 0:
+                best = dt if best is None else min(best, dt)
+        kernel_ms_total, launches = c.kernel_time()
+        c.set_timing(False)
+        ht = c.HostTime(reset=True)
+        out["one_batch"] = {"value": pileup.n_loci / best, "unit": "candidate loci/s", "seconds": best, "loci": pileup.n_loci, "reads": int(whole.n_reads),
+                            "records": n_rec, "host_ms_per_flush": ht["host_ms_per_flush"]}
+        if launches:
+            kernel_ms = kernel_ms_total / launches
+            nbytes = 2.0 * n_bases + 64.0 * n_rec
+            achieved = nbytes / (kernel_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": "pisces::call_store_tiles_kernel", "kernel_ms": kernel_ms, "launches_timed": int(launches),
+                    "algorithmic_bytes_per_launch": nbytes,
+                    "what": "reads in HBM (1 B base + 1 B quality per aligned base) -> LDS histogram -> 64-byte records, one launch per flush; "
+                            "the kernel is VALU-issue-bound (DESIGN.md section 3.10), not HBM-bound"}
+        per_block = [(a0, synth.reads_of(pileup, min(7, n_amp - a0), first_amplicon=pileup.first_amplicon + a0)) for a0 in range(0, n_amp, 7)]
+        best = None
+        for rep in range(3):
+            if rep == 1:
+                c.HostTime(reset=True)
+            n_rec = 0
+            t0 = time.perf_counter()
+            for a0, b in per_block:
+                c.AddAlleleCounts(b)
+                n_rec += len(c.Call(pileup.region_start + a0 * synth.READ_LEN - 1, capacity=1 << 18, reuse_buffer=True))
+            n_rec += len(c.Call(None, capacity=1 << 18, reuse_buffer=True))
+            dt = time.perf_counter() - t0
+            if rep > 0:
+                best = dt if best is None else min(best, dt)
+        ht = c.HostTime(reset=True)
+        out["per_block"] = {"value": pileup.n_loci / best, "unit": "candidate loci/s", "seconds": best, "loci": pileup.n_loci, "records": n_rec,
+                            "add_reads_flush_pairs": len(per_block), "host_ms_per_flush": ht["host_ms_per_flush"],
+                            "host_ms_per_add_reads": ht["add_reads_s"] / max(2 * len(per_block), 1) * 1e3}
+    # BASELINE config 3's mix (SNV + MNV + deletions + insertions at 2000x, MNV calling on) block by block: the flushes whose host half is
+    # not empty (candidate merge, VariantCollapser, MnvReallocator between the device passes)
+    try:
+        seed, depth, amps = 33, 2000, 40
+        cfg3 = _abi_config(call_mnvs=1, max_mnv_length=3, max_gap_between_mnv=1)
+        n_loci = amps * synth.READ_LEN
+        ref3 = synth.reference_of(n_loci, seed, device="cuda")
+        p3 = synth.make_pileup(n_loci, depth, seed=seed, device="cuda", first_locus=0, total_loci=n_loci, with_tuples=False)
+        batch, planted = synth.mixed_reads(p3, seed)
+        with engine.HipVariantCaller(cfg3) as c:
+            c.SetReference(ref3)
+            best = None
+            for rep in range(3):
+                if rep == 1:
+                    c.HostTime(reset=True)
+                t0 = time.perf_counter()
+                c.AddAlleleCounts(batch)
+                n_rec = 0
+                for up_to in range(1000, n_loci, 1000):
+                    n_rec += len(c.Call(up_to, capacity=1 << 16, reuse_buffer=True))
+                n_rec += len(c.Call(None, capacity=1 << 16, reuse_buffer=True))
+                dt = time.perf_counter() - t0
+                if rep > 0:
+                    best = dt if best is None else min(best, dt)
+            ht = c.HostTime(reset=True)
+        out["config3_mix_sample"] = {"value": n_loci / best, "unit": "candidate loci/s", "seconds": best, "loci": n_loci, "depth": depth, "reads": int(batch.n_reads),
+                                     "records": n_rec, "planted_events": len(planted), "flushes": ht["flushes"] // 2,
+                                     "host_ms_per_flush": ht["host_ms_per_flush"], "device_wait_ms_per_flush": ht["flush_wait_s"] / max(ht["flushes"], 1) * 1e3}
+    except Exception as e:   # noqa: BLE001
+        out["config3_mix_sample"] = {"error": str(e)[:200]}
+    return out, roof
+
+
+def _abi_config(**kw):
+    from pisces_amd import _abi
+    return _abi.default_config(**kw)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -245,6 +340,7 @@ def main():
     ap.add_argument("--loci", type=int, default=N_LOCI)
     ap.add_argument("--depth", type=int, default=DEPTH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the streaming-surface figures (host reads -> records)")
     ap.add_argument("--no-shard-check", action="store_true", help="skip the on-device check of one cut of the interval partition")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra multi-stream figure (profiling runs: its overlapped "
                     "launches would mix into the per-kernel statistics of the timed region)")
@@ -494,8 +590,13 @@ def main():
             out["shard_check"] = shard_check
         if c_abi_reduce is not None:
             out["c_abi_reduce"] = c_abi_reduce
-        if not args.no_cpu_baseline and world == 1:   # timed on rank 0 at N=1 only
+        if not args.no_end_to_end and world == 1:     # the drop-in boundary's own rates, rank 0 at N=1 only
             out["end_to_end"] = end_to_end(ring[0], cfg, engine)
+            try:
+                out["end_to_end_full"], out["roofline_streaming"] = end_to_end_full(ring[0], cfg, engine, torch)
+            except Exception as e:   # noqa: BLE001  (extra figures: they must not cost the bench line)
+                out["end_to_end_full"] = {"error": str(e)[:200]}
+        if not args.no_cpu_baseline and world == 1:   # timed on rank 0 at N=1 only
             out["cpu_baseline"], out["cpu_baseline_threads"] = cpu_baseline(torch, ring[0], cfg)
         print(json.dumps(out), flush=True)
     if c_abi_hung:   # a side thread sits in a communicator that never came up: nothing more to do in this process

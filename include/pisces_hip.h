@@ -358,6 +358,13 @@ int32_t pisces_hip_set_forced_alleles(PiscesHip* h, const PiscesCandidate* allel
  * pisces_hip_add_reads have passed that filter already).  This is the vector pisces_hip_reduce_summary adds up over the interval shards. */
 int32_t pisces_hip_stats(PiscesHip* h, int64_t out[4]);
 
+/* Where the host's time went inside the streaming surface since the handle was made (or since the last call with reset != 0), seconds:
+ * {pisces_hip_add_reads / pisces_hip_add_decoded_reads, pisces_hip_flush / _flush_ex / _flush_begin / _flush_end in all, of that waiting
+ * for the device (stream / event synchronisation), number of flushes that made a batch}.  (flush - waiting) / flushes is the serial host
+ * work per flush: block bookkeeping, candidate merge, VariantCollapser, MnvReallocator, the diploid genotyper, record assembly
+ * (what runs on one core of the host next to the device; IAlleleCaller.Call's host half, AlleleCaller.cs:60-141). */
+int32_t pisces_hip_host_time(PiscesHip* h, double out[4], int32_t reset);
+
 /* ---- multi-GPU: the per-chromosome summary across interval shards --------------------------------------------------
  * Loci shard by genomic interval, one process (or one handle) per GPU, no data-path exchange; the only collective is the sum of
  * the int64[4] totals above over the shards (the reference concatenates per-chromosome jobs and prints their totals,

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <set>
 #include <string>
@@ -179,6 +180,8 @@ struct PiscesHip {
     std::set<int32_t> forced_positions;       // RegionState.CreateIntervalsFromAllels
     std::vector<std::pair<int32_t, int32_t>> intervals;   // sorted, disjoint [start, end]
     int64_t stats[4] = {0, 0, 0, 0};      // called, collapsed, reads processed, reads skipped
+    bool in_flush_begin = false;
+    double host_time[4] = {0, 0, 0, 0};   // pisces_hip_host_time: seconds in add_reads, in flush, of that waiting for the device; flushes
 
     // cached result of a flush that did not fit the caller's buffer
     bool pending_valid = false;
@@ -316,6 +319,26 @@ struct PiscesHip {
             (h)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                      \
             return PISCES_E_DEVICE;                                                            \
         }                                                                                      \
+    } while (0)
+
+static inline double now_seconds()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+// adds the time a scope took to one of PiscesHip::host_time's counters
+struct HostTimer {
+    double* into;
+    double t0;
+    explicit HostTimer(double* p) : into(p), t0(now_seconds()) {}
+    ~HostTimer() { if (into) *into += now_seconds() - t0; }
+};
+// waits inside a flush are accounted apart from the host's own work
+#define PISCES_TIMED_WAIT(h, expr)                                      \
+    do {                                                                \
+        HostTimer _w(&(h)->host_time[2]);                               \
+        PISCES_HIP_CHECK(h, expr);                                      \
     } while (0)
 
 static int32_t fail(PiscesHip* h, int32_t code, const std::string& msg)

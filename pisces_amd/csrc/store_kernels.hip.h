@@ -694,49 +694,43 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
 #endif
 }
 
-// Ordered compaction of a small launch (<= 64 tiles: the blocks of one flush of the streaming protocol) in ONE workgroup: the scan of
-// the tiles' record counts, then every wave copies the valid slots of its tiles in order (scan_tile_counts_kernel + gather_records_kernel
-// for any number of tiles are two launches and a separate copy of the counts).  out[0] is a header {records, alleles called}: the
-// records start at out[1], so that header and records come back in one transfer.
-__global__ __launch_bounds__(1024) void compact_small_kernel(const PiscesCalledAllele* __restrict__ records, const PiscesTileResult* __restrict__ tr,
-                                                             int32_t n_tiles, PiscesCalledAllele* __restrict__ out, int32_t capacity)
+// Ordered compaction of a small launch (<= 64 tiles: the blocks of one flush of the streaming protocol): one wave per tile; every
+// wave scans the 64 record counts itself (no second kernel, no barrier) and copies the valid slots of its tile in order.  out[0] is a
+// header {records, alleles called}, the records start at out[1] — and `out` may be PINNED HOST MEMORY: the sorted records of a block
+// (~64 KB) then cross PCIe as the kernel's own stores, and the flush has no copy operation behind its kernels at all
+// (scan_tile_counts_kernel + gather_records_kernel + two copies for any number of tiles are four stream operations).
+__global__ __launch_bounds__(64) void compact_small_kernel(const PiscesCalledAllele* __restrict__ records, const PiscesTileResult* __restrict__ tr,
+                                                           int32_t n_tiles, PiscesCalledAllele* __restrict__ out, int32_t capacity)
 {
-    __shared__ int s_off[64];
-    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (w == 0) {
-        const int v = l < n_tiles ? tr[l].n_records : 0;
-        int called = l < n_tiles ? tr[l].n_called : 0;
-        int x = v;
+    const int l = threadIdx.x, t = blockIdx.x;
+    const int v = l < n_tiles ? tr[l].n_records : 0;
+    int incl = v;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int y = __shfl_up(x, d, 64);
-            if (l >= d) x += y;
-        }
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(incl, d, 64);
+        if (l >= d) incl += y;
+    }
+    const int my_off = __shfl(incl - v, t, 64);
+    if (t == 0) {
+        int called = l < n_tiles ? tr[l].n_called : 0;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) called += __shfl_xor(called, d, 64);
-        s_off[l] = x - v;
-        if (l == 63) {
-            int4* hdr = reinterpret_cast<int4*>(out);
-            hdr[0] = make_int4(x, called, 0, 0);
-        }
+        if (l == 63) reinterpret_cast<int4*>(out)[0] = make_int4(incl, called, 0, 0);
     }
-    __syncthreads();
-    for (int t = w; t < n_tiles; t += 16) {
-        const uint32_t nib = (tr[t].valid[l >> 3] >> ((l & 7) * 4)) & 0xFu;
-        int x = __popc(nib);
-        const int mine = x;
+    const uint32_t nib = (tr[t].valid[l >> 3] >> ((l & 7) * 4)) & 0xFu;
+    int x = __popc(nib);
+    const int mine = x;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int y = __shfl_up(x, d, 64);
-            if (l >= d) x += y;
-        }
-        int64_t dst = (int64_t)s_off[t] + (x - mine);
-        const PiscesCalledAllele* src = records + (int64_t)tr[t].record_begin + l * 4;
-        for (int k = 0; k < 4; k++) {
-            if (!(nib & (1u << k))) continue;
-            if (dst < capacity) copy_record(&out[1 + dst], &src[k]);
-            dst++;
-        }
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d, 64);
+        if (l >= d) x += y;
+    }
+    int64_t dst = (int64_t)my_off + (x - mine);
+    const PiscesCalledAllele* src = records + (int64_t)tr[t].record_begin + l * 4;
+    for (int k = 0; k < 4; k++) {
+        if (!(nib & (1u << k))) continue;
+        if (dst < capacity) copy_record(&out[1 + dst], &src[k]);
+        dst++;
     }
 }
 

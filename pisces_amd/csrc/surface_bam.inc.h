@@ -312,6 +312,7 @@ int32_t pisces_hip_add_decoded_reads(PiscesHip* h)
     return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (!h->bam.valid) return fail(h, PISCES_E_STATE, "add_decoded_reads: no decoded batch (pisces_hip_bam_decode first)");
+    HostTimer timer(&h->host_time[0]);
     auto& B = h->bam;
     if (B.moved) return fail(h, PISCES_E_STATE, "add_decoded_reads: the decoded batch has been added already");
     if (B.min_bq != h->cfg.min_base_call_quality) return fail(h, PISCES_E_STATE, "add_decoded_reads: decoded with another minimum base quality");

@@ -271,8 +271,16 @@ static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& key
 
     std::vector<uint32_t> g;
     if (fused) {
+        // (pisces_hip_set_timing: the dispatch's own start / stop events, as for pisces_hip_call_tiles)
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (h->timing > 0 && (h->launches_seen++ % h->timing) == 0) {
+            const size_t slot = (size_t)(h->ring_used % kTimingRing);
+            e0 = h->ring[2 * slot];
+            e1 = h->ring[2 * slot + 1];
+            h->ring_used++;
+        }
         PISCES_HIP_CHECK(h, launch_call_store_tiles(h, h->stream, regular ? nullptr : h->d_tuples.p, regular ? nullptr : h->d_tiles.p, R, n_tiles, h->d_ref.p, 1,
-                                                    h->ref_len, h->d_records.p, h->d_tile_results.p));
+                                                    h->ref_len, h->d_records.p, h->d_tile_results.p, e0, e1));
     } else if (!use_counts && !window && !store) {
         PISCES_HIP_CHECK(h, launch_call_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p,
                                               h->d_tile_results.p));
@@ -295,27 +303,17 @@ static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& key
                            window ? h->d_sumq.p : (const double*)nullptr);
     }
     // tiles were built in ascending position order: the ordered compaction is AlleleCaller.Call's (position, ref, alt) order.
-    // The sorted records lie behind one header slot in d_compact.  A launch of up to 64 tiles (the blocks of one flush of the streaming
-    // protocol) is compacted by ONE workgroup that also writes {records, called} into the header slot: one kernel, one transfer back.
+    // The sorted records lie behind one header slot {records, called}.  A launch of up to 64 tiles (the blocks of one flush of the
+    // streaming protocol) is compacted by one kernel that writes header and records into the pinned download buffer itself.
     const bool small = n_tiles <= 64;
-    if (small)
-        hipLaunchKernelGGL(compact_small_kernel, dim3(1), dim3(1024), 0, h->stream, (const PiscesCalledAllele*)h->d_records.p,
-                           (const PiscesTileResult*)h->d_tile_results.p, n_tiles, h->d_compact.p, (int32_t)cap);
-    else
-        launch_compaction(h->stream, h->d_records.p, h->d_tile_results.p, n_tiles, h->d_offsets.p, h->d_compact.p + 1, (int32_t)cap, h->d_count.p,
-                          h->d_count.p + 1);
-    PISCES_HIP_CHECK(h, hipGetLastError());
     // one synchronisation in the usual case: the two counters and a speculative prefix of the sorted records (one per locus plus
     // a quarter) come back together into pinned memory; a second copy only when more alleles were called than that
-    const size_t spec = std::min<size_t>(cap, (size_t)(n_loci_total + n_loci_total / 4 + 64));
+    const size_t spec = small ? cap : std::min<size_t>(cap, (size_t)(n_loci_total + n_loci_total / 4 + 64));
     // DoneProcessing's kernel rides in the same submission (it only writes the OTHER log buffer): one synchronisation per flush
     const bool drop_now = with_drop && h->log_ub > 0;
-    if (drop_now) {
-        int32_t rcd = enqueue_drop(h, keys, hole_bound);
-        if (rcd) return rcd;
-    }
     const size_t dl_bytes = (cap + 1) * sizeof(PiscesCalledAllele);
     if (dl_bytes > h->h_dl_cap) {
+        if (h->async.state == 1) PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // (never: a flush in flight owns the buffer; flush_begin refuses)
         if (h->h_dl) (void)hipHostFree(h->h_dl);
         h->h_dl = nullptr;
         h->h_dl_cap = 0;
@@ -326,10 +324,19 @@ static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& key
     int32_t* hdr = (int32_t*)h->h_dl;
     PiscesCalledAllele* hrec = (PiscesCalledAllele*)h->h_dl + 1;
     if (small) {
-        PISCES_HIP_CHECK(h, hipMemcpyAsync(hdr, h->d_compact.p, (spec + 1) * sizeof(PiscesCalledAllele), hipMemcpyDeviceToHost, h->stream));
+        // straight into the pinned buffer (host memory the device can write): the kernel's stores are the transfer
+        hipLaunchKernelGGL(compact_small_kernel, dim3((unsigned)n_tiles), dim3(64), 0, h->stream, (const PiscesCalledAllele*)h->d_records.p,
+                           (const PiscesTileResult*)h->d_tile_results.p, n_tiles, (PiscesCalledAllele*)h->h_dl, (int32_t)cap);
     } else {
+        launch_compaction(h->stream, h->d_records.p, h->d_tile_results.p, n_tiles, h->d_offsets.p, h->d_compact.p + 1, (int32_t)cap, h->d_count.p,
+                          h->d_count.p + 1);
         PISCES_HIP_CHECK(h, hipMemcpyAsync(hdr, h->d_count.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         PISCES_HIP_CHECK(h, hipMemcpyAsync(hrec, h->d_compact.p + 1, spec * sizeof(PiscesCalledAllele), hipMemcpyDeviceToHost, h->stream));
+    }
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    if (drop_now) {
+        int32_t rcd = enqueue_drop(h, keys, hole_bound);
+        if (rcd) return rcd;
     }
     if (drop_now)
         PISCES_HIP_CHECK(h, hipMemcpyAsync(hdr + 2, h->d_log_n.p + (h->log_cur ^ 1), sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
@@ -367,7 +374,7 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
     CallBlocksInFlight st;
     int32_t rc = call_blocks_enqueue(h, keys, with_drop, -1, &st);
     if (rc || !st.active) return rc;
-    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    PISCES_TIMED_WAIT(h, hipStreamSynchronize(h->stream));
     h->h_meta_used = 0;   // the stream is idle: nothing reads the arena any more
 #ifdef PISCES_STORE_TIMING
     if (const char* path = getenv("PISCES_HIP_DUMP_TILE_RESULTS")) {   // development: the kernel's clock stamps (tools/store_timing.py)
@@ -757,7 +764,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         host_counts.assign((size_t)std::max(n_tiles, 1) * kTile * PISCES_COUNTS_PER_LOCUS, 0);
         if (n_tiles > 0) {
             PISCES_HIP_CHECK(h, hipMemcpyAsync(host_counts.data(), h->d_counts.p, host_counts.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-            PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+            PISCES_TIMED_WAIT(h, hipStreamSynchronize(h->stream));
         }
     }
     if (!mnv_mode && have_forced) {
@@ -829,7 +836,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         PISCES_HIP_CHECK(h, hipGetLastError());
         PISCES_HIP_CHECK(h, hipMemcpyAsync(raw.data(), h->d_cand_records.p, raw.size() * sizeof(PiscesCalledAllele), hipMemcpyDeviceToHost, h->stream));
         PISCES_HIP_CHECK(h, hipMemcpyAsync(callable.data(), h->d_cand_callable.p, callable.size(), hipMemcpyDeviceToHost, h->stream));
-        PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+        PISCES_TIMED_WAIT(h, hipStreamSynchronize(h->stream));
         return PISCES_OK;
     };
     auto inside_intervals = [&](int32_t position) {   // ShouldReport (AlleleCaller.cs:260-263)
@@ -993,6 +1000,7 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
     return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (!n_out || capacity < 0 || (capacity > 0 && !out)) return fail(h, PISCES_E_INVALID_ARG, "flush: null output");
+    HostTimer timer(h->in_flush_begin ? nullptr : &h->host_time[1]);   // (flush_begin times the synchronous flush it may run itself)
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     *n_out = 0;
     if (n_cand) *n_cand = 0;
@@ -1156,6 +1164,7 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
                 }
             }
         }
+        if (!keys.empty()) h->host_time[3] += 1.0;
         h->pending_keys = keys;
         h->pending_called = called;
         h->pending_up_to = up_to_position;
@@ -1244,6 +1253,8 @@ int32_t pisces_hip_flush_begin(PiscesHip* h, int32_t up_to_position)
     return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (h->async.state != 0) return fail(h, PISCES_E_STATE, "flush_begin: the flush before this one has not been taken (pisces_hip_flush_end)");
+    HostTimer timer(&h->host_time[1]);
+    struct InBegin { bool& f; explicit InBegin(bool& x) : f(x) { f = true; } ~InBegin() { f = false; } } in_begin(h->in_flush_begin);
     { int32_t rcp = refuse_while_batch_is_open(h, "flush_begin"); if (rcp) return rcp; }
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     { int32_t rcf = consume_found(h); if (rcf) return rcf; }
@@ -1286,6 +1297,7 @@ int32_t pisces_hip_flush_begin(PiscesHip* h, int32_t up_to_position)
     int32_t rc = call_blocks_enqueue(h, keys, true, bound, &st);
     if (rc) return rc;
     if (st.active) PISCES_HIP_CHECK(h, hipEventRecord(A.done, h->stream));
+    if (!keys.empty()) h->host_time[3] += 1.0;
     // DoneProcessing, now: the blocks leave, the other log buffer is the log, `bound` slots long
     if (st.active && st.drop_now) {
         h->log_cur ^= 1;
@@ -1325,9 +1337,10 @@ int32_t pisces_hip_flush_end(PiscesHip* h, PiscesCalledAllele* out, int64_t capa
     *n_out = 0;
     auto& A = h->async;
     if (A.state == 0) return fail(h, PISCES_E_STATE, "flush_end: no pisces_hip_flush_begin before it");
+    HostTimer timer(&h->host_time[1]);
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     if (A.state == 1) {
-        PISCES_HIP_CHECK(h, hipEventSynchronize(A.done));
+        PISCES_TIMED_WAIT(h, hipEventSynchronize(A.done));
         h->h_meta_used = 0;   // (only a flush uploads through the arena, and this one's uploads lie before the event)
         CallBlocksInFlight st;
         st.active = true; st.drop_now = A.dropped; st.hdr = A.hdr; st.hrec = A.hrec; st.spec = A.spec;
@@ -1485,6 +1498,17 @@ int32_t pisces_hip_get_candidates(PiscesHip* h, int32_t up_to_position, PiscesCa
     *n_out = n;
     if (allele_bytes) *allele_bytes = bytes;
     if (out && (n > capacity || (alleles && bytes > allele_capacity))) return fail(h, PISCES_E_BUFFER_TOO_SMALL, "get_candidates: buffer too small");
+    return PISCES_OK;
+    });
+}
+
+int32_t pisces_hip_host_time(PiscesHip* h, double out[4], int32_t reset)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h || !out) return PISCES_E_INVALID_ARG;
+    for (int i = 0; i < 4; i++) out[i] = h->host_time[i];
+    if (reset)
+        for (int i = 0; i < 4; i++) h->host_time[i] = 0.0;
     return PISCES_OK;
     });
 }

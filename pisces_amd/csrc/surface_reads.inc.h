@@ -347,7 +347,7 @@ static int32_t consume_found(PiscesHip* h)
 {
     if (!h->found.in_flight) return PISCES_OK;
     h->found.in_flight = false;
-    PISCES_HIP_CHECK(h, hipEventSynchronize(h->found.done));
+    PISCES_TIMED_WAIT(h, hipEventSynchronize(h->found.done));
     const DevFound* recs = (const DevFound*)h->found.h;
     const uint8_t* pool = h->found.h + (size_t)h->found.n_slots * sizeof(DevFound);
     const unsigned int* misc = (const unsigned int*)(pool + (((size_t)h->found.pool_bytes + 15) & ~(size_t)15));
@@ -422,6 +422,7 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
 {
     return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
+    HostTimer timer(&h->host_time[0]);
     if (validate_batch(batch) != PISCES_OK) return fail(h, PISCES_E_INVALID_ARG, "add_reads: malformed read batch");
     { int32_t rcp = refuse_while_batch_is_open(h, "add_reads"); if (rcp) return rcp; }
     if (batch->n_reads == 0) return PISCES_OK;

@@ -499,12 +499,13 @@ static hipError_t launch_call_store_tiles(PiscesHip* h, hipStream_t s, const uin
     store_view(h, &V);
     // waves per tile: enough of them that a small launch still puts its reads on many SIMDs (see the kernel)
     int nw = h->store_waves;
-    if (nw == 0) nw = h->kernel_variant == 2 ? 1 : h->kernel_variant == 3 ? 2 : (int64_t)n_tiles * 8 <= (int64_t)h->n_cus * 8 ? 8 : (int64_t)n_tiles * 4 <= (int64_t)h->n_cus * 12 ? 4
-                      : (int64_t)n_tiles <= (int64_t)h->n_cus * 32 ? 2 : 1;
+    if (nw == 0) nw = h->kernel_variant == 2 ? 1 : h->kernel_variant == 3 ? 2 : (int64_t)n_tiles * 4 <= (int64_t)h->n_cus ? 16 : (int64_t)n_tiles <= (int64_t)h->n_cus ? 8
+                      : (int64_t)n_tiles * 4 <= (int64_t)h->n_cus * 12 ? 4 : (int64_t)n_tiles <= (int64_t)h->n_cus * 32 ? 2 : 1;
 #define PISCES_LAUNCH_STORE(NW)                                                                                                                     \
     hipExtLaunchKernelGGL(call_store_tiles_kernel<NW>, dim3((unsigned)n_tiles), dim3(64 * NW), 0u, s, e0, e1, 0u, V, d_tuples, d_tiles, R, n_tiles, d_ref, \
                           ref_start, ref_len, d_records, d_tr, h->P, (const DeviceParams*)h->d_params.p)
-    if (nw >= 8) PISCES_LAUNCH_STORE(8);
+    if (nw >= 16) PISCES_LAUNCH_STORE(16);
+    else if (nw >= 8) PISCES_LAUNCH_STORE(8);
     else if (nw >= 4) PISCES_LAUNCH_STORE(4);
     else if (nw >= 2) PISCES_LAUNCH_STORE(2);
     else PISCES_LAUNCH_STORE(1);

@@ -301,6 +301,14 @@ class HipVariantCaller:
         # SmallVariantCaller.cs:114-115 / AlignmentsSource.cs:63: the vector a multi-GPU job adds up over its interval shards
         return {"TotalNumCalled": s[0], "TotalNumCollapsed": s[1], "reads": s[2], "reads_skipped": s[3]}
 
+    def HostTime(self, reset=False):
+        """pisces_hip_host_time: where the host's time went inside the streaming surface."""
+        t = (C.c_double * 4)()
+        _check(self._h, lib.pisces_hip_host_time(self._h, t, 1 if reset else 0))
+        flushes = int(t[3])
+        return {"add_reads_s": t[0], "flush_s": t[1], "flush_wait_s": t[2], "flushes": flushes,
+                "host_ms_per_flush": (t[1] - t[2]) / flushes * 1e3 if flushes else 0.0}
+
     # ---- device-resident surface ----
     def call_tiles(self, d_tuples, d_tiles, n_tiles, d_ref, ref_start, ref_len, d_records, capacity, d_tile_results, stream=None):
         """All pointer arguments are raw device addresses (ints); capacity >= 256 * n_tiles record slots."""

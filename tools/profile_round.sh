@@ -10,7 +10,7 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $REPO
-PROF_FLAGS="--no-cpu-baseline --no-pipelined --no-shard-check"
+PROF_FLAGS="--no-cpu-baseline --no-end-to-end --no-pipelined --no-shard-check"
 timeout 900 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 tail -1 $OUT/bench_n1.json | cut -c1-400
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python bench.py $PROF_FLAGS > $OUT/bench_prof.log 2>&1
