@@ -47,7 +47,10 @@ struct BlockObs {   // the block's observations live in the device log (PiscesHi
     // insertion / deletion candidates of the block (RegionState._candidateVariantsLookup), merged by
     // CandidateAllele.Equals (position, category, ref, alt) — the collapse-off rule of RegionState.AddCandidate
     std::vector<HostCandidate> cands;
-    std::unordered_map<std::string, size_t> cand_index;
+    // hash of (position, category, ref, alt[, open ends]) -> index of the first candidate with that hash; cand_next chains the (rare)
+    // candidates that share a hash.  (A std::string key per record was 200 ns of every candidate record the device sends back.)
+    std::unordered_map<uint64_t, uint32_t> cand_index;
+    std::vector<uint32_t> cand_next;
     int32_t max_allele_endpoint = 0;   // RegionState.MaxAlleleEndpoint
 };
 
@@ -110,11 +113,12 @@ struct ReadSegment {
     DeviceBuf<uint32_t> clen;
     DeviceBuf<ReadDesc> desc;
     DeviceBuf<ReadExt> ext;
+    DeviceBuf<ReadDesc> frag;    // one per CIGAR operation: what the flush kernel walks
     int32_t* state = nullptr;    // its four state words on the device (a slot of PiscesHip::state_pool, zero when handed out)
     const uint8_t *v_bases = nullptr, *v_quals = nullptr, *v_dirs = nullptr, *v_cop = nullptr;
     const uint32_t* v_clen = nullptr;
     int64_t n_reads = 0, n_bases = 0, n_ops = 0;
-    int64_t n_floored = 0;     // reads that were there at the last flush ...
+    int64_t n_floored = 0, n_floored_ops = 0;   // reads / CIGAR operations that were there at the last flush ...
     int32_t floor = 0;         // ... have their positions below this counted already (DoneProcessing of the blocks below it)
     int32_t max_key = 0;       // highest block any of its reads touches: the segment is dropped once no block up to it is left
     bool open = false;         // accepts appended batches
@@ -165,6 +169,8 @@ struct PiscesHip {
     DeviceBuf<uint8_t> d_alleles;
     DeviceBuf<PiscesCalledAllele> d_cand_records;
     DeviceBuf<uint8_t> d_cand_callable;
+    int32_t* h_counts = nullptr;           // pinned: the anchor-resolved counts of a batch's blocks for the collapser / reallocator (a copy into
+    size_t h_counts_cap = 0;               // pageable memory is staged by the runtime and blocks: 0.6 ms a flush of 0.8 MB)
 
     // ---- streaming state (RegionStateManager: _regionLookup, _lastUpToBlockKey) ----
     std::map<int32_t, BlockObs> blocks;   // key = GetBlockKey(position) (RegionStateManager.cs:385-391)
@@ -181,6 +187,8 @@ struct PiscesHip {
     std::vector<std::pair<int32_t, int32_t>> intervals;   // sorted, disjoint [start, end]
     int64_t stats[4] = {0, 0, 0, 0};      // called, collapsed, reads processed, reads skipped
     bool in_flush_begin = false;
+    double prof[12] = {0};                 // development (PISCES_HIP_HOST_PROFILE=1): host seconds by phase of a flush, printed when the handle goes
+    bool prof_on = false;
     double host_time[4] = {0, 0, 0, 0};   // pisces_hip_host_time: seconds in add_reads, in flush, of that waiting for the device; flushes
 
     // cached result of a flush that did not fit the caller's buffer
@@ -399,7 +407,7 @@ static hipError_t accumulate_tiles(PiscesHip* h, hipStream_t s, const uint32_t* 
     if (with_store && h->read_path == 1) {
         StoreView V;
         store_view(h, &V);
-        hipLaunchKernelGGL(accumulate_store_tiles_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, V, d_tuples, d_tiles, n_tiles, h->d_counts.p,
+        hipLaunchKernelGGL(accumulate_store_tiles_kernel, dim3((unsigned)n_tiles), dim3(n_tiles <= 2 * h->n_cus ? 1024 : kBlock), 0, s, V, d_tuples, d_tiles, n_tiles, h->d_counts.p,
                            h->cfg.min_base_call_quality, with_sums ? h->d_sumq_fix.p : (unsigned long long*)nullptr,
                            with_sums ? (const ulonglong2*)h->d_bq_lut.p : (const ulonglong2*)nullptr);
     } else
@@ -571,6 +579,7 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         if (kv && std::string(kv) == "auto") h->kernel_variant = 4;
         if (kv && std::string(kv) == "block") h->kernel_variant = 0;
         if (const char* lp = getenv("PISCES_HIP_LDS_PAD")) h->lds_pad = atoi(lp);
+        h->prof_on = getenv("PISCES_HIP_HOST_PROFILE") != nullptr;
         const char* rp = getenv("PISCES_HIP_READ_PATH");   // "log": reads are expanded into the observation log and bucketed at flush time (the earlier chain)
         if (rp && std::string(rp) == "log") h->read_path = 0;
         if (const char* v = getenv("PISCES_HIP_STORE_DIRECT_BYTES")) h->store_direct_bytes = (size_t)std::max(0ll, atoll(v));
@@ -669,6 +678,11 @@ int32_t pisces_hip_destroy(PiscesHip* h)
 {
     return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_OK;
+    if (h->prof_on) {
+        static const char* names[12] = {"consume_found", "spanning: candidates of the batch", "spanning: counts to the host", "collapse", "device pass (MNVs)",
+                                        "reallocate", "device pass (all)", "call_blocks", "row merge / genotypers", "copy out + DoneProcessing", "", ""};
+        for (int i = 0; i < 10; i++) fprintf(stderr, "pisces_hip host profile: %-36s %9.3f ms\n", names[i], h->prof[i] * 1e3);
+    }
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)pisces_hip_comm_destroy(h);
@@ -691,6 +705,8 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     h->h_dl = nullptr;
     if (h->h_meta) (void)hipHostFree(h->h_meta);
     h->h_meta = nullptr;
+    if (h->h_counts) (void)hipHostFree(h->h_counts);
+    h->h_counts = nullptr;
     if (h->found.h) (void)hipHostFree(h->found.h);
     h->found.h = nullptr;
     if (h->found.done) (void)hipEventDestroy(h->found.done);

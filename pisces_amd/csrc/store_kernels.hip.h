@@ -43,11 +43,26 @@ static_assert(sizeof(ReadDesc) == 16 && sizeof(ReadExt) == 16, "descriptor layou
 constexpr uint32_t kDescLenMask = 0xFFFFFu;      // bases of the one aligned run (simple reads)
 constexpr uint32_t kDescComplex = 1u << 20;      // insertions / deletions / skips / anything but clips around one aligned run: general walk
 constexpr uint32_t kDescReverse = 1u << 21;      // flags bit 0 (direction of every base unless the segment tracks per-base directions)
+constexpr uint32_t kDescGeneric = 1u << 22;      // a read whose fragments do not fit their fields (below): the flush kernel walks it base by base
+// FRAGMENTS: what the flush kernel walks.  One 16-byte ReadDesc per CIGAR operation, in read order (so: in position order of the READS,
+// pos0 = the read's position is the sort key of every one of them):
+//   M = X        the operation's bases: length in meta, first base at aoff, first position at pos0 + delta
+//   D N          the deleted positions, if the gap passes CandidateVariantFinder.CheckDeletionQuality at the base that closes it
+//                (RegionStateManager.cs:131-176; a deletion at the read's end or before its final soft clip: :143-154, :199-213)
+//   I S H P      nothing (length 0)
+// aoff's top 16 bits hold delta (a read that needs more, or an operation of 2^20 positions or more, is kDescGeneric: its fragments are
+// empty and the read goes through read_walk.h).  So a read with an insertion is two aligned fragments, one with a deletion two aligned
+// fragments and a deletion fragment: the fast path takes them all.
+constexpr uint32_t kFragDeletion = 1u << 20;
+constexpr int kFragDirShift = 22;                // DirectionType of a deletion fragment's positions (the base that closes the gap), 2 bits
+constexpr int kFragDeltaShift = 48;
+constexpr long long kFragAoffMask = (1ll << kFragDeltaShift) - 1;
 constexpr int kMaxSegments = 8;
-constexpr int kStateUnsorted = 0, kStateReach = 1, kStateComplex = 2;
+constexpr int kStateUnsorted = 0, kStateReach = 1, kStateComplex = 2, kStateFrags = 3;   // [kStateFrags]: bit 0 some read is kDescGeneric, bit 1 some deletion fragment
 
 struct SegmentView {
-    const ReadDesc* desc;
+    const ReadDesc* frag;         // one per CIGAR operation (see above)
+    const ReadDesc* desc;         // one per read
     const ReadExt* ext;
     const uint8_t* bases;
     const uint8_t* quals;
@@ -59,6 +74,7 @@ struct SegmentView {
     int32_t n_reads;
     int32_t n_floored;            // reads [0, n_floored) were there at the last flush: their positions below `floor` are counted already
     int32_t floor;
+    int32_t n_frags, n_floored_frags;   // the same for the fragments
     int32_t pad;
 };
 struct StoreView {
@@ -80,6 +96,10 @@ struct ShapeArgs {
     int64_t base0, ops0;   // index of its first base / first CIGAR operation in the segment's arrays
     ReadDesc* desc;
     ReadExt* ext;
+    ReadDesc* frag;        // [ops0 + ...]: the fragments
+    const uint8_t* quals;  // the batch's qualities / per-base directions (or nullptr), indexed by seq_offset: what a deletion fragment is gated by
+    const uint8_t* dirs;
+    int32_t min_bq;
     int32_t* state;
 };
 
@@ -87,7 +107,7 @@ __global__ __launch_bounds__(256) void read_shape_kernel(ShapeArgs A)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     int reach = 0;
-    bool unsorted = false, complex_read = false;
+    bool unsorted = false, complex_read = false, generic_read = false, has_del = false;
     if (r < A.n_reads) {
         const int c0 = A.cigar_offset[r], nc = A.cigar_offset[r + 1] - c0;
         const int s0 = A.seq_offset[r], n = A.seq_offset[r + 1] - s0;
@@ -126,6 +146,81 @@ __global__ __launch_bounds__(256) void read_shape_kernel(ShapeArgs A)
         A.ext[A.n0 + r] = e;
         reach = (int)(ref_span > 0x7FFFFFFFll ? 0x7FFFFFFFll : ref_span);
         complex_read = !simple;
+        // ---- the fragments, one per operation
+        bool generic = ref_span > 0xFFFFll;   // (delta of a later fragment would not fit)
+        for (int c = 0; c < nc; c++) generic = generic || A.cigar_len[c0 + c] > kDescLenMask;
+        if (generic) {
+            d.meta |= kDescGeneric;
+            A.desc[A.n0 + r] = d;
+        }
+        const uint8_t* const quals = A.quals + s0;
+        const uint32_t rev = (A.flags[r] & 1) ? kDescReverse : 0u;
+        auto dq = [&](int i) {   // CandidateVariantFinder.CheckDeletionQuality (CandidateVariantFinder.cs:294-320) at base i < n
+            const int after = quals[i], before = i > 0 ? quals[i - 1] : after;
+            return before >= A.min_bq && after >= A.min_bq;
+        };
+        auto dir_at = [&](int i) { return A.dirs ? (uint32_t)A.dirs[s0 + i] : (rev ? (uint32_t)PISCES_DIR_REVERSE : (uint32_t)PISCES_DIR_FORWARD); };
+        const bool ends_in_del = nc >= 1 && A.cigar_op[c0 + nc - 1] == 'D';
+        const bool ends_in_del_soft = nc >= 2 && A.cigar_op[c0 + nc - 2] == 'D' && A.cigar_op[c0 + nc - 1] == 'S';
+        int ri = 0;
+        long long rp = pos0, last_mapped = (long long)pos0 - 1;
+        for (int c = 0; c < nc; c++) {
+            const uint8_t t = A.cigar_op[c0 + c];
+            const int len = (int)A.cigar_len[c0 + c];
+            ReadDesc f;
+            f.pos0 = pos0;
+            f.meta = rev;
+            f.aoff = A.base0 + s0;
+            if (!generic && len > 0) {
+                if (t == 'M' || t == '=' || t == 'X') {
+                    const int have = max(min(len, n - ri), 0);   // (a CIGAR that runs past the read is refused before it gets here)
+                    f.meta |= (uint32_t)have;
+                    f.aoff = (A.base0 + s0 + ri) | ((rp - pos0) << kFragDeltaShift);
+                } else if (t == 'D' || t == 'N') {
+                    // the base that closes the gap: the first base of the next aligned operation (insertions and clips in between
+                    // move the index, not the position); without one, only a deletion at the read's end counts, by its own rules
+                    int idx = -1, first = (int)(rp - pos0), count = len;
+                    uint32_t dir = 0;
+                    {
+                        int rj = ri;
+                        for (int k = c + 1; k < nc && idx < 0; k++) {
+                            const uint8_t tk = A.cigar_op[c0 + k];
+                            const int lk = (int)A.cigar_len[c0 + k];
+                            if ((tk == 'M' || tk == '=' || tk == 'X') && lk > 0) idx = rj;
+                            else if (walk_op_read_span(tk)) rj += lk;
+                        }
+                    }
+                    bool counted = false;
+                    if (idx >= 0 && idx < n) {
+                        counted = dq(idx);
+                        dir = dir_at(idx);
+                    } else if (t == 'D' && c == nc - 1 && ends_in_del && n > 0) {           // :199-213: the deleted positions follow the last mapped base
+                        counted = dq(n - 1);
+                        dir = dir_at(n - 1);
+                        first = (int)(last_mapped + 1 - pos0);
+                    } else if (t == 'D' && c == nc - 2 && ends_in_del_soft) {              // :143-154
+                        const int at = n - (int)A.cigar_len[c0 + nc - 1];
+                        if (at >= 0 && at < n) {
+                            counted = dq(at);
+                            dir = dir_at(at);
+                            first = (int)(last_mapped + 1 - pos0);
+                        }
+                    }
+                    if (counted && first >= 0 && first <= 0xFFFF) {
+                        f.meta = rev | kFragDeletion | (uint32_t)count | (dir << kFragDirShift);
+                        f.aoff = (A.base0 + s0) | ((long long)first << kFragDeltaShift);
+                        has_del = true;
+                    }
+                }
+            }
+            A.frag[A.ops0 + c0 + c] = f;
+            if (walk_op_ref_span(t)) {
+                if (walk_op_read_span(t) && len > 0) last_mapped = rp + len - 1;
+                rp += len;
+            }
+            if (walk_op_read_span(t)) ri += len;
+        }
+        generic_read = generic;
         // position order, the batch's first read against the read before it in the segment (written by an earlier launch)
         if (r > 0) unsorted = A.position[r - 1] > pos0;
         else if (A.n0 > 0) unsorted = A.desc[A.n0 - 1].pos0 > pos0;
@@ -133,11 +228,13 @@ __global__ __launch_bounds__(256) void read_shape_kernel(ShapeArgs A)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) reach = max(reach, __shfl_xor(reach, d, 64));
     const bool any_unsorted = __ballot(unsorted) != 0ull, any_complex = __ballot(complex_read) != 0ull;
+    const int frag_bits = (__ballot(generic_read) != 0ull ? 1 : 0) | (__ballot(has_del) != 0ull ? 2 : 0);
     if ((threadIdx.x & 63) == 0) {
         // (plain reads first: same-address atomics from the whole chip are what they cost, and after the first few waves none is needed)
         if (reach > A.state[kStateReach]) atomicMax(&A.state[kStateReach], reach);
         if (any_unsorted && A.state[kStateUnsorted] == 0) atomicOr(&A.state[kStateUnsorted], 1);
         if (any_complex && A.state[kStateComplex] == 0) atomicOr(&A.state[kStateComplex], 1);
+        if (frag_bits & ~A.state[kStateFrags]) atomicOr(&A.state[kStateFrags], frag_bits);
     }
 }
 
@@ -224,13 +321,14 @@ __device__ __forceinline__ long long readlane64(long long v, int lane_index)
 // The reads of desc[lo, hi) with insertions / deletions / skips, one at a time: RegionStateManager.AddAlleleCounts base by base
 // (read_walk.h); on_obs(position, allele, direction, anchor, quality) for every observation inside the tile and at or above the floor.
 template <bool kDirs, typename OnObs>
-__device__ __forceinline__ void walk_segment_complex(const SegmentView& G, int lo, int hi, int tile_start, int min_bq, int lane, int wid, int n_waves, OnObs on_obs)
+__device__ __forceinline__ void walk_segment_complex(const SegmentView& G, int lo, int hi, int tile_start, int min_bq, int lane, int wid, int n_waves, OnObs on_obs,
+                                                     uint32_t which = kDescComplex /* the reads to take: kDescComplex, or kDescGeneric for the flush kernel */)
 {
     const int tile_end = tile_start + kTile - 1;
     for (int base = lo + wid * 64; base < hi; base += n_waves * 64) {
         const int cnt = min(64, hi - base);
         const ReadDesc d = G.desc[base + min(lane, cnt - 1)];
-        unsigned long long complex_mask = __ballot(lane < cnt && (d.meta & kDescComplex));
+        unsigned long long complex_mask = __ballot(lane < cnt && (d.meta & which));
         // the reads with insertions / deletions / skips: RegionStateManager.AddAlleleCounts base by base (read_walk.h)
         while (complex_mask) {
             const int u = __builtin_ctzll(complex_mask);
@@ -238,10 +336,19 @@ __device__ __forceinline__ void walk_segment_complex(const SegmentView& G, int l
             const int r = base + u;
             const int pos0 = __builtin_amdgcn_readlane(d.pos0, u);
             const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)d.meta, u);
-            const long long aoff = readlane64(d.aoff, u);
+            long long aoff = readlane64(d.aoff, u);
             const ReadExt e = G.ext[r];
             const ReadShape shape = read_shape(pos0, e.n_bases, e.n_cigar, G.cigar_op + e.cig_off, G.cigar_len + e.cig_off);
             if (pos0 > tile_end || (long long)pos0 + shape.ref_span - 1 < tile_start) continue;
+            if (!(meta & kDescComplex)) {   // (a read of one aligned run keeps the index of its first ALIGNED base: back to its first base)
+                int lead = 0;
+                for (int c = 0; c < e.n_cigar; c++) {
+                    const uint8_t t = G.cigar_op[e.cig_off + c];
+                    if (t == 'S') lead += (int)G.cigar_len[e.cig_off + c];
+                    else if (t != 'H' && t != 'P') break;
+                }
+                aoff -= lead;
+            }
             const int floor_pos = r < G.n_floored ? G.floor : 0;
             const int p_lo = max(tile_start, max(floor_pos, 1)), p_hi = tile_end;
             const uint8_t* const quals = G.quals + aoff;
@@ -412,14 +519,13 @@ template <bool kDirs, typename OnObs>
 __device__ __forceinline__ void walk_segment_fast(const SegmentView& G, int tile_start, uint32_t min_bq, int lane, int wid, int n_waves, char* hbytes,
                                                   OnObs on_obs, long long* stamps = nullptr /* development: PISCES_STORE_TIMING */)
 {
-    if (G.n_reads <= 0) return;
+    if (G.n_frags <= 0) return;
     const int tile_end = tile_start + kTile - 1;
-    int lo = 0, hi = G.n_reads;
-    if (G.state[kStateUnsorted] == 0) {
-        const int reach = G.state[kStateReach];
-        const long long x_lo = (long long)tile_start - reach + 1;
-        wave_lower_bound2(G.desc, G.n_reads, (int)max(x_lo, -0x7FFFFFFFll), tile_end == 0x7FFFFFFF ? 0x7FFFFFFF : tile_end + 1, lane, &lo, &hi);
-    }
+    const bool sorted = G.state[kStateUnsorted] == 0;
+    const int reach = G.state[kStateReach];
+    const int x_lo = (int)max((long long)tile_start - reach + 1, -0x7FFFFFFFll), x_hi = tile_end == 0x7FFFFFFF ? 0x7FFFFFFF : tile_end + 1;
+    int lo = 0, hi = G.n_frags;
+    if (sorted) wave_lower_bound2(G.frag, G.n_frags, x_lo, x_hi, lane, &lo, &hi);
 #ifdef PISCES_STORE_TIMING
     if (stamps) { stamps[0] = wall_clock64(); stamps[1] = hi - lo; }
 #endif
@@ -445,14 +551,15 @@ __device__ __forceinline__ void walk_segment_fast(const SegmentView& G, int tile
         auto block_base = [&](int b) { return lo + (wid + min(b, my_blocks - 1) * n_waves) * 64; };
         auto load_trim = [&](int b) {
             const int base = block_base(b), cnt = min(64, hi - base);
-            const ReadDesc d = G.desc[base + min(lane, cnt - 1)];
-            const int n = (lane < cnt && !(d.meta & kDescComplex)) ? (int)(d.meta & kDescLenMask) : 0;
-            const int floor_pos = base + lane < G.n_floored ? G.floor : 0;
+            const ReadDesc d = G.frag[base + min(lane, cnt - 1)];
+            const int n = (lane < cnt && !(d.meta & kFragDeletion)) ? (int)(d.meta & kDescLenMask) : 0;
+            const int floor_pos = base + lane < G.n_floored_frags ? G.floor : 0;
+            const int first = d.pos0 + (int)(d.aoff >> kFragDeltaShift);   // the fragment's first position
             ReadTrim t;
-            t.pos = max(d.pos0, floor_pos);                  // (pos0 >= 1)
-            const int cut = t.pos - d.pos0;                  // bases below the floor
+            t.pos = max(first, floor_pos);
+            const int cut = t.pos - first;                   // positions below the floor
             t.end = t.pos + max(n - min(cut, n), 0);
-            t.aoff = (uint32_t)d.aoff + (uint32_t)min(cut, n) + (uint32_t)kSegmentPad;
+            t.aoff = (uint32_t)(d.aoff & kFragAoffMask) + (uint32_t)min(cut, n) + (uint32_t)kSegmentPad;
             t.dir4 = (d.meta & kDescReverse) ? (uint32_t)PISCES_DIR_REVERSE * 0x01010101u : (uint32_t)PISCES_DIR_FORWARD * 0x01010101u;
             return t;
         };
@@ -544,9 +651,34 @@ __device__ __forceinline__ void walk_segment_fast(const SegmentView& G, int tile
             consume(B);
         }
     }
-    // ---- the reads with insertions / deletions / skips (if the segment has any): the general walk's second half
-    if (G.state[kStateComplex] == 0) return;
-    walk_segment_complex<kDirs>(G, lo, hi, tile_start, (int)min_bq, lane, wid, n_waves, on_obs);
+    const int frag_bits = G.state[kStateFrags];
+    // ---- the deletion fragments of the range (if the segment has any): lane = locus; a gap's positions count as deletions in the
+    // direction of the base that closed it, whatever their own quality (RegionStateManager.cs:170-176)
+    if (frag_bits & 2) {
+        for (int base = lo + wid * 64; base < hi; base += n_waves * 64) {
+            const int cnt = min(64, hi - base);
+            const ReadDesc d = G.frag[base + min(lane, cnt - 1)];
+            unsigned long long dels = __ballot(lane < cnt && (d.meta & kFragDeletion));
+            while (dels) {
+                const int u = __builtin_ctzll(dels);
+                dels &= dels - 1;
+                const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)d.meta, u);
+                const int first = __builtin_amdgcn_readlane(d.pos0, u) + (int)(readlane64(d.aoff, u) >> kFragDeltaShift);
+                const int count = (int)(meta & kDescLenMask);
+                const int floor_pos = base + u < G.n_floored_frags ? G.floor : 0;
+                const uint32_t dir = kDirs ? (meta >> kFragDirShift) & 3u : ((meta & kDescReverse) ? (uint32_t)PISCES_DIR_REVERSE : (uint32_t)PISCES_DIR_FORWARD);
+                const int p = tile_start + lane;
+                if (p >= max(first, floor_pos) && p - first < count)
+                    atomicAdd(reinterpret_cast<int*>(hbytes) + HistLinear::idx(PISCES_ALLELE_DEL, (int)dir, lane), 1);
+            }
+        }
+    }
+    // ---- reads whose fragments did not fit their fields: base by base, as the general walk takes reads with insertions / deletions
+    if (frag_bits & 1) {
+        int rlo = 0, rhi = G.n_reads;
+        if (sorted) wave_lower_bound2(G.desc, G.n_reads, x_lo, x_hi, lane, &rlo, &rhi);
+        walk_segment_complex<kDirs>(G, rlo, rhi, tile_start, (int)min_bq, lane, wid, n_waves, on_obs, kDescGeneric);
+    }
 }
 
 template <typename OnBase, typename OnObs>
@@ -736,7 +868,8 @@ __global__ __launch_bounds__(64) void compact_small_kernel(const PiscesCalledAll
 
 // The same walk into the anchor-resolved tensor (RegionState._alleleCounts, RegionState.cs:57) and, with sumq, the base-quality sums
 // (RegionState._sumOfAlleleBaseQualities :61): what accumulate_tiles_kernel makes of tuples, here from the reads (and the tuples).
-__global__ __launch_bounds__(kBlock) void accumulate_store_tiles_kernel(StoreView S, const uint32_t* __restrict__ tuples, const PiscesTile* __restrict__ tiles,
+// (256 threads a tile for launches that fill the chip, 1024 for the few tiles of one flush of the streaming protocol)
+__global__ __launch_bounds__(1024) void accumulate_store_tiles_kernel(StoreView S, const uint32_t* __restrict__ tuples, const PiscesTile* __restrict__ tiles,
                                                                         int32_t n_tiles, int32_t* __restrict__ counts, int32_t min_bq_,
                                                                         unsigned long long* __restrict__ sumq, const ulonglong2* __restrict__ bq_lut)
 {
@@ -744,7 +877,7 @@ __global__ __launch_bounds__(kBlock) void accumulate_store_tiles_kernel(StoreVie
     const int t = blockIdx.x;
     if (t >= n_tiles) return;
     const PiscesTile tile = tiles[t];
-    for (int i = threadIdx.x; i < kTile * kAnchStride; i += kBlock) hist[i] = 0;
+    for (int i = threadIdx.x; i < kTile * kAnchStride; i += (int)blockDim.x) hist[i] = 0;
     __syncthreads();
     const uint32_t n_loci = (uint32_t)tile.n_loci, min_bq = (uint32_t)min_bq_;
     auto add = [&](uint32_t locus, uint32_t allele, uint32_t dir, uint32_t anchor, uint32_t qual) {
@@ -759,12 +892,12 @@ __global__ __launch_bounds__(kBlock) void accumulate_store_tiles_kernel(StoreVie
             }
         }
     };
-    for (int64_t i = tile.tuple_begin + threadIdx.x; i < tile.tuple_end; i += kBlock) {
+    for (int64_t i = tile.tuple_begin + threadIdx.x; i < tile.tuple_end; i += (int64_t)blockDim.x) {
         const uint32_t v = tuples[i];
         add(PISCES_TUPLE_LOCUS(v), PISCES_TUPLE_ALLELE(v), PISCES_TUPLE_DIR(v), PISCES_TUPLE_ANCHOR(v), v >> 24);
     }
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    walk_store(S, tile.start_position, (int)min_bq, lane, wid, kBlock / 64,
+    walk_store(S, tile.start_position, (int)min_bq, lane, wid, (int)blockDim.x / 64,
                [&](int locus, uint32_t base, uint32_t qual, uint32_t dir, bool valid, int pos0, int n_aligned) {
                    if (!valid) return;
                    // GetAnchorType (RegionStateManager.cs:83-116); EndPosition of a read of one aligned run = pos0 + run - 1
@@ -777,7 +910,7 @@ __global__ __launch_bounds__(kBlock) void accumulate_store_tiles_kernel(StoreVie
     __syncthreads();
     int32_t* __restrict__ dst = counts + (int64_t)t * kTile * PISCES_COUNTS_PER_LOCUS;
     const int n = tile.n_loci * PISCES_COUNTS_PER_LOCUS;
-    for (int g = threadIdx.x; g < n; g += kBlock) {
+    for (int g = threadIdx.x; g < n; g += (int)blockDim.x) {
         const int lo = g / PISCES_COUNTS_PER_LOCUS, c = g - lo * PISCES_COUNTS_PER_LOCUS;
         const int v = hist[lo * kAnchStride + c];
         if (v) dst[g] += v;

@@ -656,6 +656,8 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
     *n_collapsed = 0;
     const bool mnv_mode = h->cfg.call_mnvs != 0;
     const bool window = h->cfg.noise_model == PISCES_NOISE_WINDOW;
+    std::unique_ptr<HostTimer> prof(new HostTimer(h->prof_on ? &h->prof[1] : nullptr));
+    auto phase = [&](int i) { prof.reset(); prof.reset(new HostTimer(h->prof_on ? &h->prof[i] : nullptr)); };
     std::vector<HostCandidate> work;   // a copy: the blocks keep their candidates until DoneProcessing
     for (int32_t key : keys) {
         // RegionState.GetAllCandidates walks _candidateVariantsLookup by position, each position in arrival order (RegionState.cs:388-391)
@@ -688,6 +690,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
                 std::stable_sort(work.begin() + (std::ptrdiff_t)first, work.end(), [](const HostCandidate& x, const HostCandidate& y) { return x.position < y.position; });
                 kv.second.cands.clear();   // (MaxAlleleEndpoint keeps its value: RegionState never lowers it)
                 kv.second.cand_index.clear();
+                kv.second.cand_next.clear();
                 for (auto& c : kept) add_candidate(h, c);
             }
         }
@@ -711,6 +714,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
     }
     std::sort(bkeys.begin(), bkeys.end());
     bkeys.erase(std::unique(bkeys.begin(), bkeys.end()), bkeys.end());
+    phase(2);
     // counts over the whole block grid of those blocks (not the interval-clipped tiles)
     std::vector<PiscesTile> tiles;
     if (!bkeys.empty()) {
@@ -758,15 +762,26 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         d.gapped = (c.category == PISCES_CAT_SNV || c.category == PISCES_CAT_REFERENCE) ? gapped_at(c.position) : 0;
     };
     // the collapser's frequencies and the reallocator's Reference candidates read a host copy of the anchor-resolved counts
-    std::vector<int32_t> host_counts;
     const bool have_forced = !h->forced.empty();
+    const int32_t* host_counts_p = nullptr;
     if (h->cfg.collapse || mnv_mode || have_forced) {
-        host_counts.assign((size_t)std::max(n_tiles, 1) * kTile * PISCES_COUNTS_PER_LOCUS, 0);
-        if (n_tiles > 0) {
-            PISCES_HIP_CHECK(h, hipMemcpyAsync(host_counts.data(), h->d_counts.p, host_counts.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-            PISCES_TIMED_WAIT(h, hipStreamSynchronize(h->stream));
+        const size_t n_counts = (size_t)std::max(n_tiles, 1) * kTile * PISCES_COUNTS_PER_LOCUS;
+        if (n_counts > h->h_counts_cap) {
+            if (h->h_counts) (void)hipHostFree(h->h_counts);
+            h->h_counts = nullptr;
+            h->h_counts_cap = 0;
+            PISCES_HIP_CHECK(h, hipHostMalloc((void**)&h->h_counts, (n_counts + n_counts / 2) * sizeof(int32_t), hipHostMallocDefault));
+            h->h_counts_cap = n_counts + n_counts / 2;
         }
+        if (n_tiles > 0) {
+            PISCES_HIP_CHECK(h, hipMemcpyAsync(h->h_counts, h->d_counts.p, n_counts * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            PISCES_TIMED_WAIT(h, hipStreamSynchronize(h->stream));
+        } else {
+            std::memset(h->h_counts, 0, n_counts * sizeof(int32_t));
+        }
+        host_counts_p = h->h_counts;
     }
+    struct { const int32_t* p; const int32_t* data() const { return p; } } host_counts = {host_counts_p};
     if (!mnv_mode && have_forced) {
         // MNV calling off: SNV candidates are the allele counts and never reach the host, so a forced SNV (added without support) takes
         // the support the merged candidate of the reference has: the reads that show the base at or above the quality threshold
@@ -781,6 +796,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
             }
         }
     }
+    phase(3);
     if (h->cfg.collapse) {
         const int32_t stitched = h->cfg.expect_stitched_reads;
         *n_collapsed = collapse_candidates(work, h->cfg.collapse_freq_threshold, h->cfg.collapse_freq_ratio_threshold, [&](const HostCandidate& c) {
@@ -846,6 +862,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         return false;
     };
 
+    phase(4);
     std::vector<const HostCandidate*> final_list;
     MnvArena arena;
     std::vector<CandPtr> callable_alleles;          // AlleleCaller's callableAlleles (non-Reference ones and touched Reference ones)
@@ -859,6 +876,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
             if (c.category == PISCES_CAT_MNV) mnvs.push_back(&c);
         int32_t rc1 = device_pass(mnvs);
         if (rc1) return rc1;
+        phase(5);
         std::vector<CandPtr> failed;
         {
             size_t mi = 0;
@@ -959,6 +977,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         }
     }
 
+    phase(6);
     second_pass = mnv_mode;
     int32_t rc2 = device_pass(final_list);
     if (rc2) return rc2;
@@ -1033,11 +1052,14 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
         h->pending_collapsed = collapsed;
         if (rc) return rc;
         h->pending_dropped = false;
+        std::unique_ptr<HostTimer> prof(new HostTimer(h->prof_on ? &h->prof[7] : nullptr));
         const bool diploid = h->cfg.ploidy == PISCES_PLOIDY_DIPLOID || h->cfg.ploidy == PISCES_PLOIDY_HAPLOID;   // per-locus genotypers
         // nothing to merge into the tile kernels' records: they go from the download buffer straight to the caller
         const bool plain = span_recs.empty() && !diploid && h->forced.empty() && ref_overrides.empty();
         rc = call_blocks(h, keys, point_recs, &called, true, &h->pending_dropped, &h->pending_kept, plain);
         if (rc) return rc;
+        prof.reset();
+        prof.reset(new HostTimer(h->prof_on ? &h->prof[8] : nullptr));
         if (!ref_overrides.empty()) {   // Reference alleles that MNV reallocation added support to
             std::map<int32_t, const PiscesCalledAllele*> by_pos;
             for (auto& r : ref_overrides) by_pos[r.position] = &r;
@@ -1170,6 +1192,7 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
         h->pending_up_to = up_to_position;
         h->pending_valid = true;
     }
+    HostTimer prof_out(h->prof_on ? &h->prof[9] : nullptr);
     int64_t pool_bytes = 0;
     for (auto& c : h->pending_cands) pool_bytes += (int64_t)(c.ref.size() + c.alt.size());
     if (n_cand) *n_cand = (int64_t)h->pending_cands.size();

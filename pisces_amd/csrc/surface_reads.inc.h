@@ -161,20 +161,44 @@ static int32_t validate_batch(const PiscesReadBatch* b)
 
 // IStateManager.AddCandidates -> RegionState.AddCandidate (RegionState.cs:94-174): merge by CandidateAllele.Equals, and with the
 // collapser on (trackOpenEnded) keep open-ended candidates apart (:114-137); UpdateMaxPosition (:205-223)
+static inline uint64_t candidate_hash(const HostCandidate& c, bool with_open_ends)
+{
+    uint64_t x = 0xcbf29ce484222325ull;   // FNV-1a over the fields CandidateAllele.Equals compares
+    auto mix = [&](uint64_t v) { x = (x ^ v) * 0x100000001b3ull; };
+    mix((uint32_t)c.position);
+    mix((uint32_t)c.category | (with_open_ends ? ((uint32_t)c.open_left << 8) | ((uint32_t)c.open_right << 9) | 0x10000u : 0u));
+    for (char ch : c.ref) mix((uint8_t)ch);
+    mix(0x3Eu);
+    for (char ch : c.alt) mix((uint8_t)ch);
+    return x;
+}
 static void add_candidate(PiscesHip* h, const HostCandidate& cnd)
 {
     BlockObs* b = get_block(h, cnd.position);
-    std::string key = std::to_string(cnd.position) + "|" + std::to_string(cnd.category) + "|" + cnd.ref + ">" + cnd.alt;
-    if (h->cfg.collapse) key += cnd.open_left ? (cnd.open_right ? "|LR" : "|L") : (cnd.open_right ? "|R" : "|");
+    const bool track_open = h->cfg.collapse != 0;
+    const uint64_t key = candidate_hash(cnd, track_open);
+    auto same = [&](const HostCandidate& e) {
+        return e.position == cnd.position && e.category == cnd.category && e.ref == cnd.ref && e.alt == cnd.alt &&
+               (!track_open || (e.open_left == cnd.open_left && e.open_right == cnd.open_right));
+    };
+    HostCandidate* found = nullptr;
     auto it = b->cand_index.find(key);
-    if (it == b->cand_index.end()) {
-        b->cand_index.emplace(std::move(key), b->cands.size());
+    uint32_t last = 0xFFFFFFFFu;
+    if (it != b->cand_index.end())
+        for (uint32_t i = it->second; i != 0xFFFFFFFFu; i = b->cand_next[i]) {
+            if (same(b->cands[i])) { found = &b->cands[i]; break; }
+            last = i;
+        }
+    if (!found) {
+        const uint32_t idx = (uint32_t)b->cands.size();
         b->cands.push_back(cnd);
+        b->cand_next.push_back(0xFFFFFFFFu);
+        if (last != 0xFFFFFFFFu) b->cand_next[last] = idx;
+        else b->cand_index.emplace(key, idx);
     } else {
-        HostCandidate& e = b->cands[it->second];
         for (int d = 0; d < 3; d++) {
-            e.support_by_dir[d] += cnd.support_by_dir[d];
-            e.well_anchored_by_dir[d] += cnd.well_anchored_by_dir[d];
+            found->support_by_dir[d] += cnd.support_by_dir[d];
+            found->well_anchored_by_dir[d] += cnd.well_anchored_by_dir[d];
         }
     }
     int32_t other_end = 0;
@@ -346,6 +370,7 @@ static int32_t enqueue_candidate_discovery(PiscesHip* h, const DevReadBatch& db,
 static int32_t consume_found(PiscesHip* h)
 {
     if (!h->found.in_flight) return PISCES_OK;
+    HostTimer prof(h->prof_on ? &h->prof[0] : nullptr);
     h->found.in_flight = false;
     PISCES_TIMED_WAIT(h, hipEventSynchronize(h->found.done));
     const DevFound* recs = (const DevFound*)h->found.h;

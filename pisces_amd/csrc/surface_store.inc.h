@@ -14,6 +14,7 @@ static void store_view(const PiscesHip* h, StoreView* V)
         const ReadSegment& g = *sp;
         if (g.n_reads == 0 || n == kMaxSegments) continue;
         SegmentView& v = V->seg[n++];
+        v.frag = g.frag.p;
         v.desc = g.desc.p;
         v.ext = g.ext.p;
         v.bases = g.v_bases;
@@ -25,6 +26,8 @@ static void store_view(const PiscesHip* h, StoreView* V)
         v.n_reads = (int32_t)g.n_reads;
         v.n_floored = (int32_t)g.n_floored;
         v.floor = g.floor;
+        v.n_frags = (int32_t)g.n_ops;
+        v.n_floored_frags = (int32_t)g.n_floored_ops;
     }
     V->n_segments = n;
 }
@@ -62,7 +65,7 @@ static int32_t store_new_segment(PiscesHip* h, std::unique_ptr<ReadSegment>* out
     } else {
         g.reset(new ReadSegment());
     }
-    g->n_reads = g->n_bases = g->n_ops = g->n_floored = 0;
+    g->n_reads = g->n_bases = g->n_ops = g->n_floored = g->n_floored_ops = 0;
     g->floor = 0;
     g->max_key = 0;
     g->open = false;
@@ -92,7 +95,7 @@ static int32_t store_commit_flush(PiscesHip* h, const std::vector<int32_t>& keys
         ReadSegment& g = *h->segments[i];
         const bool dead = none_left || g.max_key < min_key;
         if (dead && g.open) {
-            g.n_reads = g.n_bases = g.n_ops = g.n_floored = 0;
+            g.n_reads = g.n_bases = g.n_ops = g.n_floored = g.n_floored_ops = 0;
             g.floor = 0;
             g.max_key = 0;
             g.v_dirs = nullptr;
@@ -103,6 +106,7 @@ static int32_t store_commit_flush(PiscesHip* h, const std::vector<int32_t>& keys
             h->segments.erase(h->segments.begin() + (std::ptrdiff_t)i);
         } else {
             g.n_floored = g.n_reads;
+            g.n_floored_ops = g.n_ops;
             g.floor = std::max(g.floor, floor);
             i++;
         }
@@ -233,7 +237,7 @@ struct StoreBatchArrays {
 static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const StoreBatchArrays& A, int32_t nr, size_t n_cig, size_t n_seq)
 {
     ReadSegment& g = *pl.seg;
-    if (g.n_reads + nr > 0x7FFFFF00ll) return fail(h, PISCES_E_INVALID_ARG, "add_reads: too many reads held at once");
+    if (g.n_reads + nr > 0x7FFFFF00ll || g.n_ops + (int64_t)n_cig > 0x7FFFFF00ll) return fail(h, PISCES_E_INVALID_ARG, "add_reads: too many reads held at once");
     ShapeArgs S;
     S.position = A.position; S.flags = A.flags; S.cigar_offset = A.cigar_offset; S.cigar_op = A.cigar_op; S.cigar_len = A.cigar_len;
     S.seq_offset = A.seq_offset;
@@ -241,6 +245,7 @@ static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const Sto
     if (pl.direct) {
         PISCES_HIP_CHECK(h, g.desc.reserve((size_t)nr));
         PISCES_HIP_CHECK(h, g.ext.reserve((size_t)nr));
+        PISCES_HIP_CHECK(h, g.frag.reserve(n_cig + 1));
         g.v_bases = A.bases; g.v_quals = A.quals; g.v_dirs = A.dirs; g.v_cop = A.cigar_op; g.v_clen = A.cigar_len;
         S.n0 = 0; S.base0 = 0; S.ops0 = 0;
     } else {
@@ -248,6 +253,7 @@ static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const Sto
         constexpr size_t kPad = (size_t)kSegmentPad;   // room on both sides of the byte arrays (walk_segment loads whole words around a read's ends)
         PISCES_HIP_CHECK(h, g.desc.grow_keep(n0 + (size_t)nr, n0, h->stream));
         PISCES_HIP_CHECK(h, g.ext.grow_keep(n0 + (size_t)nr, n0, h->stream));
+        PISCES_HIP_CHECK(h, g.frag.grow_keep(no + n_cig + 1, no, h->stream));
         PISCES_HIP_CHECK(h, g.bases.grow_keep(nb + n_seq + 2 * kPad, nb + kPad, h->stream));
         PISCES_HIP_CHECK(h, g.quals.grow_keep(nb + n_seq + 2 * kPad, nb + kPad, h->stream));
         PISCES_HIP_CHECK(h, g.cop.grow_keep(no + n_cig + 16, no, h->stream));
@@ -277,6 +283,10 @@ static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const Sto
     }
     S.desc = g.desc.p;
     S.ext = g.ext.p;
+    S.frag = g.frag.p;
+    S.quals = A.quals;
+    S.dirs = A.dirs;
+    S.min_bq = h->cfg.min_base_call_quality;
     S.state = g.state;
     hipLaunchKernelGGL(read_shape_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, h->stream, S);
     if (!pl.direct && !A.dirs && g.v_dirs)   // a batch without directions in a segment that tracks them

@@ -196,6 +196,30 @@ def test_block_schedule_from_the_store_equals_the_log_chain_and_the_oracle(torch
     assert stats["TotalNumCalled"] == total
 
 
+@pytest.mark.parametrize("mode", ["default", "every batch appended to the open segment"])
+def test_any_cigar_through_the_fused_kernel_equals_the_log_chain(torch_cuda, mode):
+    """The flush kernel takes a read as the FRAGMENTS the shape kernel cuts it into (one per CIGAR operation: aligned runs, and gaps as
+    deletion fragments gated by CheckDeletionQuality at the base that closes them, RegionStateManager.cs:131-213); a read whose
+    fragments do not fit their fields (a skip of 70 000 positions) goes base by base.  Records over four blocks, flushed in two steps,
+    must equal the observation-log chain's (whose read walk is read_walk.h's per-base function) byte for byte."""
+    rng = np.random.default_rng(41)
+    ref = np.frombuffer(bytes(rng.choice(list(b"ACGT"), 76000).astype(np.uint8)), dtype=np.uint8)
+    reads = random_reads(rng, 1500, 20, 3800, exotic=True)
+    for k in range(6):   # reads that skip far ahead: one fragment's offset does not fit, the read is walked base by base
+        ln = 40 + k
+        reads.append({"pos": 300 + 500 * k, "cigar": [("M", 20), ("N", 70000 + k), ("M", ln - 20)],
+                      "seq": bytes(rng.choice(list(b"ACGT"), ln).astype(np.uint8)), "quals": [37] * ln, "reverse": bool(k & 1)})
+    reads.sort(key=lambda r: r["pos"])
+    cfg = _abi.default_config(min_coverage=1, low_depth_filter=1)
+    batches = [_abi.ReadBatch(reads[:800]), _abi.ReadBatch(reads[800:])]
+    ups = [reads[799]["pos"] - 1, 3000]
+    got, got_alleles, stats = _schedule_run(batches, ref, cfg, ups, dict(PISCES_HIP_READ_PATH=None, **STORE_MODES[mode]))
+    want, want_alleles, want_stats = _schedule_run(batches, ref, cfg, ups, dict(PISCES_HIP_READ_PATH="log"))
+    assert len(got) == len(want) > 3000
+    assert got.tobytes() == want.tobytes() and got_alleles == want_alleles and stats == want_stats
+    assert (got["position"] > 70000).any()        # the far ends of the skipping reads were called
+
+
 def test_thresholds_the_fused_kernel_is_not_compiled_for(torch_cuda):
     """minBQ above 127 (the fused kernel compares seven bits) goes through the counts in HBM: same records as the log chain."""
     rng = np.random.default_rng(2)
