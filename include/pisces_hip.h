@@ -272,6 +272,13 @@ int32_t pisces_hip_set_reference(PiscesHip* h, const uint8_t* upper_bases, int64
  * reference candidates, RegionState.cs:406-408); set emit_zero_coverage_refs = 1 alongside. n = 0 clears. */
 int32_t pisces_hip_set_intervals(PiscesHip* h, const int32_t* starts, const int32_t* ends, int32_t n);
 
+/* Interval sharding: the positions [lo, hi] this handle OWNS.  A shard is fed the reads that overlap its range plus
+ * a halo, so that counts and spanning alleles at its edges are complete; candidates the halo reads bring that lie outside the range
+ * belong to the neighbouring shard: they are neither reported nor counted in IAlleleCaller.TotalNumCalled here, so that the shards'
+ * totals add up to the unsharded job's (the reference has no such notion: one job per chromosome, BaseGenomeProcessor.cs:40-90).
+ * Default: everything.  Give the shard's own intervals to pisces_hip_set_intervals as well. */
+int32_t pisces_hip_set_owned_range(PiscesHip* h, int32_t lo, int32_t hi);
+
 /* ---- streaming surface: IStateManager -------------------------------------- */
 /* ICandidateVariantFinder.FindCandidates + IStateManager.AddCandidates + AddAlleleCounts
  * (SmallVariantCaller.cs:88-98) for a batch of reads.  The batch crosses PCIe once, packed (2 bytes per base), and the

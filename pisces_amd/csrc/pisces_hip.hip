@@ -185,6 +185,7 @@ struct PiscesHip {
     std::set<std::string> forced_keys;        // position|ref>alt (AlleleCaller.IsForcedAllele)
     std::set<int32_t> forced_positions;       // RegionState.CreateIntervalsFromAllels
     std::vector<std::pair<int32_t, int32_t>> intervals;   // sorted, disjoint [start, end]
+    int32_t own_lo = 1, own_hi = 0x7FFFFFFF;              // pisces_hip_set_owned_range
     int64_t stats[4] = {0, 0, 0, 0};      // called, collapsed, reads processed, reads skipped
     bool in_flush_begin = false;
     double prof[12] = {0};                 // development (PISCES_HIP_HOST_PROFILE=1): host seconds by phase of a flush, printed when the handle goes
@@ -757,6 +758,16 @@ int32_t pisces_hip_set_intervals(PiscesHip* h, const int32_t* starts, const int3
             return fail(h, PISCES_E_INVALID_ARG, "set_intervals: intervals must be positive, sorted and disjoint");
         h->intervals.emplace_back(starts[i], ends[i]);
     }
+    return PISCES_OK;
+    });
+}
+
+int32_t pisces_hip_set_owned_range(PiscesHip* h, int32_t lo, int32_t hi)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h || lo < 1 || hi < lo) return fail(h, PISCES_E_INVALID_ARG, "set_owned_range: bad range");
+    h->own_lo = lo;
+    h->own_hi = hi;
     return PISCES_OK;
     });
 }

@@ -855,7 +855,9 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         PISCES_TIMED_WAIT(h, hipStreamSynchronize(h->stream));
         return PISCES_OK;
     };
+    auto owned = [&](int32_t position) { return position >= h->own_lo && position <= h->own_hi; };   // (interval sharding: pisces_hip_set_owned_range)
     auto inside_intervals = [&](int32_t position) {   // ShouldReport (AlleleCaller.cs:260-263)
+        if (!owned(position)) return false;
         if (h->intervals.empty()) return true;
         for (auto& iv : h->intervals)
             if (position >= iv.first && position <= iv.second) return true;
@@ -882,7 +884,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
             size_t mi = 0;
             for (auto& c : work) {
                 if (c.category == PISCES_CAT_MNV) {
-                    if (callable[mi]) { callable_alleles.push_back(&c); (*n_called)++; }   // IsCallable counts every pass (_totalNumCalled)
+                    if (callable[mi]) { callable_alleles.push_back(&c); if (owned(c.position)) (*n_called)++; }   // IsCallable counts every pass (_totalNumCalled)
                     else failed.push_back(&c);
                     mi++;
                 } else {
@@ -990,7 +992,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         // IsForcedToReport and once in the test for reporting, and counts a callable forced allele twice in TotalNumCalled
         const bool forced = have_forced && is_forced_allele(h, *final_list[i]);
         const bool reportable = callable[i] && inside_intervals(final_list[i]->position);
-        if (callable[i]) (*n_called) += forced ? 2 : 1;
+        if (callable[i] && owned(final_list[i]->position)) (*n_called) += forced ? 2 : 1;
         if (forced && !mnv_mode && final_list[i]->category == PISCES_CAT_SNV && reportable) {   // MNV calling off: the tile kernels report it,
             (*n_called)--;                                                                        // and have counted it once
             continue;

@@ -69,6 +69,10 @@ class HipVariantCaller:
         e = np.array([b for _, b in intervals], dtype=np.int32)
         _check(self._h, lib.pisces_hip_set_intervals(self._h, s.ctypes.data, e.ctypes.data, len(s)))
 
+    def SetOwnedRange(self, lo, hi):
+        """pisces_hip_set_owned_range: the positions this shard owns (candidates of its halo reads outside them are the neighbour's)."""
+        _check(self._h, lib.pisces_hip_set_owned_range(self._h, int(lo), int(hi)))
+
     # ---- IStateManager ----
     def AddAlleleCounts(self, reads):
         """IStateManager.AddAlleleCounts for a batch (one _abi.ReadBatch, or an iterable of read dicts)."""

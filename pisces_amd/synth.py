@@ -267,10 +267,14 @@ def observations_of(p, n_tiles=None):
 MNV_OFFSET, DEL_OFFSET, INS_OFFSET = 40, 60, 80   # read index of the planted event inside its amplicon
 
 
-def mixed_event_of(a):
+def mixed_event_of(a, sparse=1):
     """The event planted in (global) amplicon `a`: None, or (kind, offset, length, vaf) with kind 'M' (an MNV of 2-3 bases), 'D' (a
     deletion of 1-10 bases) or 'I' (an insertion of 1-6 bases).  One amplicon in 13 carries each kind: about one MNV, one deletion
-    and one insertion per 1950 loci; every locus keeps the SNVs and errors of make_pileup."""
+    and one insertion per 1950 loci; every locus keeps the SNVs and errors of make_pileup.  sparse = 10: a tenth of that density
+    (BASELINE config 4)."""
+    if a % sparse:
+        return None
+    a //= sparse
     k = a % 13
     vaf = 0.05 + 0.30 * ((a * 2654435761) % 1000) / 1000.0
     if k == 3:
@@ -282,10 +286,10 @@ def mixed_event_of(a):
     return None
 
 
-def mixed_reads(p, seed=0):
+def mixed_reads(p, seed=0, sparse=1, kinds="MDI"):
     """The reads of pileup `p` (whole amplicons only) with mixed_event_of's events planted: MNV carriers get the variant bases, deletion
     carriers the CIGAR xM dD yM, insertion carriers xM iI yM (inserted bases at Q37).  Returns (ReadBatch, planted) where planted is a
-    list of (kind, position, ref, alt) in VCF form (anchor base included for insertions / deletions)."""
+    list of (kind, position, ref, alt) in VCF form (anchor base included for insertions / deletions).  kinds: the event kinds to plant."""
     A = p.base.shape[0]
     _, lens_total = _amplicon_lengths(p.total_loci or (p.first_locus + p.n_loci))
     base = p.base.cpu().numpy()
@@ -302,7 +306,9 @@ def mixed_reads(p, seed=0):
         start = origin + a * READ_LEN
         rows = _BASE_ASCII[base[k, :, :L]]            # (depth, L) ASCII
         qs = qual[k, :, :L]
-        ev = mixed_event_of(a) if L == READ_LEN else None
+        ev = mixed_event_of(a, sparse) if L == READ_LEN else None
+        if ev is not None and ev[0] not in kinds:
+            ev = None
         rng = np.random.default_rng((seed * 1_000_003 + a) % (2 ** 63))
         carriers = np.zeros(depth, dtype=bool)
         if ev is not None:

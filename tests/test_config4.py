@@ -1,0 +1,80 @@
+"""BASELINE config 4 as SURVEY.md section 8d states it, on ONE GPU: 30 M loci x 200x over 200 000 intervals of 150 bp on 24 contigs,
+SNVs + small insertions / deletions at a tenth of config 3's density, the interval set cut 8 ways (shard.partition_intervals over the
+contigs laid end to end) and the eight shards run in turn, every (contig, range) piece on a handle of its own with halo reads
+(shard.reads_for_shard), outputs concatenated in order.  Three contigs that a cut falls in are ALSO run unsharded, and the sharded
+output must equal that byte for byte (records and allele strings); every contig is held to size-independent properties; the
+per-piece totals add up to the unsharded ones (the vector pisces_hip_reduce_summary adds over the GPUs of a node).
+Reference: one job per chromosome, outputs concatenated (BaseGenomeProcessor.cs:40-90, GenomeProcessor.cs:156-186)."""
+import numpy as np
+import pytest
+
+from pisces_amd import _abi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch
+
+
+def test_config4_as_stated_eight_shards_in_turn_on_one_gpu(torch_cuda):
+    from pisces_amd import config4, engine
+    depth, world = 200, 8
+    sizes = config4.contig_intervals(200_000)
+    assert sum(sizes) == 200_000 and len(sizes) == 24 and sum(sizes) * config4.INTERVAL == 30_000_000
+    cfg = _abi.default_config(emit_zero_coverage_refs=1)
+    shards = config4.partition(sizes, world, block_size=cfg.block_size, depth=depth)
+    assert len(shards) == world and all(shards)
+    pieces_of = {}
+    for r, pieces in enumerate(shards):
+        for c, lo, hi in pieces:
+            pieces_of.setdefault(c, []).append((r, lo, hi))
+    cut_contigs = [c for c, pc in pieces_of.items() if len(pc) > 1]
+    assert len(cut_contigs) >= 3, cut_contigs             # an 8-way cut of 24 unequal contigs falls inside contigs
+    verify = set(cut_contigs[:2] + cut_contigs[-1:])
+    shard_loci = np.zeros(world, dtype=np.int64)
+    totals = np.zeros(4, dtype=np.int64)
+    n_reads_total = n_loci_total = 0
+    for c, n_iv in enumerate(sizes):
+        job = config4.make_contig(c, n_iv, depth=depth)
+        n_reads_total += job["batch"].n_reads
+        got, got_alleles, counted, called = [], [], 0, 0
+        for r, lo, hi in pieces_of[c]:
+            recs, alleles, stats, owned = config4.run_piece(engine, cfg, job, lo, hi)
+            got.append(recs)
+            got_alleles += alleles
+            counted += owned
+            called += stats["TotalNumCalled"]
+            shard_loci[r] += len(np.unique(recs["position"]))
+            totals += np.array([stats["TotalNumCalled"], stats["TotalNumCollapsed"], owned, stats["reads_skipped"]])
+        got = np.concatenate(got)
+        # ---- properties, every contig
+        assert counted == job["batch"].n_reads                                   # every read counted by exactly one piece
+        assert (np.diff(got["position"]) >= 0).all()
+        covered = np.unique(got["position"])
+        expect = (job["starts"].astype(np.int64)[:, None] + np.arange(config4.INTERVAL)[None, :]).reshape(-1)
+        assert np.array_equal(covered, expect)                                   # every locus of every interval is a candidate locus, nothing outside
+        n_loci_total += len(covered)
+        cats = (got["info"] >> 4) & 7
+        point = (cats == _abi.CAT_SNV) | (cats == _abi.CAT_REFERENCE)
+        near_indel = np.zeros(len(got), dtype=bool)
+        for kind, pos, ref, alt in job["planted"]:
+            near_indel |= (got["position"] >= pos) & (got["position"] <= pos + max(len(ref), len(alt)) + 1)
+        assert ((got["total_coverage"] + got["num_no_calls"])[point & ~near_indel] == depth).all()
+        for kind, cat in (("D", _abi.CAT_DELETION), ("I", _abi.CAT_INSERTION)):
+            want = np.array(sorted(pos for k, pos, _, _ in job["planted"] if k == kind))
+            have = np.unique(got["position"][cats == cat])
+            assert len(want) == 0 or np.isin(want, have).mean() >= 0.95, (c, kind, len(want), int(np.isin(want, have).sum()))
+        # ---- the unsharded contig, byte for byte
+        if c in verify:
+            whole, whole_alleles, wstats, _ = config4.run_piece(engine, cfg, job)
+            assert got.tobytes() == whole.tobytes() and got_alleles == whole_alleles, c
+            assert called == wstats["TotalNumCalled"] and wstats["reads"] == job["batch"].n_reads
+        del job, got
+    assert n_loci_total == 30_000_000 and n_reads_total == 200_000 * depth
+    assert totals[2] == n_reads_total and totals[3] == 0
+    assert shard_loci.sum() == n_loci_total and shard_loci.min() > 0.8 * shard_loci.mean()   # the cut is balanced
