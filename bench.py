@@ -332,6 +332,75 @@ def _abi_config(**kw):
     return _abi.default_config(**kw)
 
 
+def run_config4(args):
+    """BASELINE config 4 as SURVEY 8d states it (30 M loci x 200x, 200 000 intervals on 24 contigs, SNV + indel, cut 8 ways by interval):
+    `python bench.py --config 4`.  One process: the eight shards run in turn on cuda:0 (per-shard loci/s printed; `value` = loci / the sum
+    of the shards' times: what ONE GPU does with the whole set).  Under torch.distributed.run with N ranks: rank r takes the shards
+    r, r + N, ... on its own GPU, the totals are all-reduced (RCCL) and `value` = loci / the slowest rank's time.  Timed: the streaming
+    surface per (contig, range) piece — set_reference, set_intervals, add_reads in stretches, flushes — host reads in, host records out;
+    making the synthetic contigs is not timed."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from pisces_amd import _abi, config4, engine
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    use_dist = world > 1
+    if use_dist:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    depth, n_shards = 200, 8
+    sizes = config4.contig_intervals(200_000)
+    cfg = _abi.default_config(emit_zero_coverage_refs=1)
+    shards = config4.partition(sizes, n_shards, block_size=cfg.block_size, depth=depth)
+    mine = [r for r in range(n_shards) if r % world == rank]
+    need = sorted({c for r in mine for c, _, _ in shards[r]})
+    t_shard = {r: 0.0 for r in mine}
+    loci_shard = {r: 0 for r in mine}
+    totals = np.zeros(4, dtype=np.int64)
+    for c in need:
+        job = config4.make_contig(c, sizes[c], depth=depth, device=f"cuda:{local_rank}")
+        for r in mine:
+            for cc, lo, hi in shards[r]:
+                if cc != c:
+                    continue
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                recs, _, stats, owned = config4.run_piece(engine, cfg, job, lo, hi, device=local_rank, with_alleles=False)
+                t_shard[r] += time.perf_counter() - t0
+                loci_shard[r] += int(len(np.unique(recs["position"])))
+                totals += np.array([stats["TotalNumCalled"], stats["TotalNumCollapsed"], owned, stats["reads_skipped"]])
+        del job
+    elapsed = sum(t_shard.values())
+    summary = torch.tensor(totals.tolist() + [sum(loci_shard.values())], dtype=torch.int64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(summary, op=dist.ReduceOp.SUM)   # the per-chromosome totals over the shards (RCCL over xGMI)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        loci = int(summary[4].item())
+        out = {"metric": "candidate loci/s at 200x depth, interval-sharded (BASELINE config 4)", "value": loci / float(t.item()), "unit": "candidate loci/s",
+               "n_gpus": world, "steps": 1, "warmup": 0, "ms_per_step": float(t.item()) * 1e3, "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "int32 counts + f64 likelihoods", "data": "synthetic",
+               "config": {"workload": "BASELINE config 4: 30 M loci x 200x over 200 000 intervals of 150 bp on 24 contigs, SNV + indel at 1/10 of config 3's "
+                                      "density, cut 8 ways by interval; streaming surface (host reads in, host records out), shards "
+                                      + ("in turn on one GPU" if world == 1 else f"over {world} GPUs"),
+                          "loci": loci, "reads": int(summary[2].item()), "intervals": 200_000, "contigs": 24, "shards": n_shards},
+               "totals": {"allelesCalled": int(summary[0].item()), "variantsCollapsed": int(summary[1].item()), "readsProcessed": int(summary[2].item()),
+                          "readsSkipped": int(summary[3].item())},
+               "shards_rank0": [{"shard": r, "pieces": len(shards[r]), "loci": loci_shard[r], "seconds": t_shard[r], "loci_per_s": loci_shard[r] / t_shard[r]}
+                                for r in mine]}
+        assert loci == 30_000_000 and out["totals"]["readsProcessed"] == 200_000 * depth
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -344,7 +413,10 @@ def main():
     ap.add_argument("--no-shard-check", action="store_true", help="skip the on-device check of one cut of the interval partition")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra multi-stream figure (profiling runs: its overlapped "
                     "launches would mix into the per-kernel statistics of the timed region)")
+    ap.add_argument("--config", type=int, default=2, help="2 (default): the configuration the metric is quoted on; 4: BASELINE config 4 as stated")
     args = ap.parse_args()
+    if args.config == 4:
+        return run_config4(args)
 
     import numpy as np
     import torch

@@ -98,7 +98,7 @@ def read_batch_range(arrays, i0, i1):
                                       cigar_len=cig_len[c0:c1], seq_offset=seq_off[i0:i1 + 1] - s0, bases=bases[s0:s1], quals=quals[s0:s1])
 
 
-def run_piece(engine, cfg, job, lo=None, hi=None, halo=synth.READ_LEN + 16, device=0, chunk_reads=400_000):
+def run_piece(engine, cfg, job, lo=None, hi=None, halo=synth.READ_LEN + 16, device=0, chunk_reads=400_000, with_alleles=True):
     """One (contig, owned range) job on one handle: set_reference, set_intervals (clipped to the range), the reads
     shard.reads_for_shard gives it, one final flush.  lo / hi None: the whole contig.  Returns (records, alleles, stats, reads counted:
     a read is counted by the piece that owns its start)."""
@@ -121,10 +121,10 @@ def run_piece(engine, cfg, job, lo=None, hi=None, halo=synth.READ_LEN + 16, devi
                 b = min(a + chunk_reads, i1)
                 c.AddAlleleCounts(read_batch_range(job["arrays"], a, b))
                 if b < i1:
-                    r, al = c.CallWithAlleles(int(pos[b]) - 1, capacity=1 << 20)
+                    r, al = c.CallWithAlleles(int(pos[b]) - 1, capacity=1 << 20) if with_alleles else (c.Call(int(pos[b]) - 1, capacity=1 << 20), [])
                     recs.append(r)
                     alleles += al
-        r, al = c.CallWithAlleles(None, capacity=1 << 20)
+        r, al = c.CallWithAlleles(None, capacity=1 << 20) if with_alleles else (c.Call(None, capacity=1 << 20), [])
         recs.append(r)
         alleles += al
         stats = c.Stats()

@@ -35,11 +35,15 @@ static void tile_geometry(PiscesHip* h, const std::vector<int32_t>& keys, bool c
             }
         };
         if (!irregular) add_range(bstart, bend);
-        else
-            for (auto& iv : h->intervals) {
-                int32_t s = std::max(iv.first, bstart), e = std::min(iv.second, bend);
+        else {
+            // (sorted, disjoint intervals: the first one that ends at or behind the block's start, then on while they start inside it)
+            auto it = std::lower_bound(h->intervals.begin(), h->intervals.end(), bstart,
+                                       [](const std::pair<int32_t, int32_t>& iv, int32_t p) { return iv.second < p; });
+            for (; it != h->intervals.end() && it->first <= bend; ++it) {
+                int32_t s = std::max(it->first, bstart), e = std::min(it->second, bend);
                 if (s <= e) add_range(s, e);
             }
+        }
     }
 }
 
@@ -859,9 +863,9 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
     auto inside_intervals = [&](int32_t position) {   // ShouldReport (AlleleCaller.cs:260-263)
         if (!owned(position)) return false;
         if (h->intervals.empty()) return true;
-        for (auto& iv : h->intervals)
-            if (position >= iv.first && position <= iv.second) return true;
-        return false;
+        auto it = std::lower_bound(h->intervals.begin(), h->intervals.end(), position,
+                                   [](const std::pair<int32_t, int32_t>& iv, int32_t p) { return iv.second < p; });
+        return it != h->intervals.end() && it->first <= position;
     };
 
     phase(4);
