@@ -569,6 +569,13 @@ int32_t pisces_hip_bam_fetch(PiscesHip* h, int32_t* position, uint8_t* flags, in
                              int32_t* seq_offset, uint8_t* bases, uint8_t* quals);
 int32_t pisces_hip_add_decoded_reads(PiscesHip* h);
 int32_t pisces_hip_bam_chain_mode(PiscesHip* h);
+/* Stitched reads (the Stitcher's XD tag, one DirectionType per base of the expanded CIGAR; Read.CigarDirections / SequencedBaseDirectionMap,
+ * src/lib/Pisces.Domain/Models/Read.cs:340-400, 664-682): when a record of the decoded chromosome carries the tag, the decode makes
+ * PiscesReadBatch.directions (per base; reads without the tag: their strand's direction) and .deletion_directions (two per CIGAR
+ * operation) for the batch, and pisces_hip_add_decoded_reads counts and discovers candidates with them.  This entry copies them to the
+ * host (either pointer may be NULL): returns 1 when the batch has them, 0 when no read of it was stitched, < 0 on error.  A malformed tag
+ * (CigarDirection's "Unexpected format in direction string") makes pisces_hip_add_decoded_reads refuse the batch. */
+int32_t pisces_hip_bam_fetch_directions(PiscesHip* h, uint8_t* directions, uint8_t* deletion_directions);
 
 #ifdef __cplusplus
 }

@@ -245,6 +245,38 @@ __global__ void bam_entry_kernel(const uint8_t* __restrict__ s, const uint16_t* 
     if (at != n) { status[0] = 3; }
 }
 
+// The value of the string tag t0 t1 (type 'Z') in a record's auxiliary fields [p, end): its first character and its length, or nullptr
+// (BamAlignment.GetStringTag; SAM specification 4.2.4 for the value types that are skipped over).
+__device__ inline const uint8_t* bam_find_string_tag(const uint8_t* p, const uint8_t* end, uint8_t t0, uint8_t t1, int* length)
+{
+    while (p + 3 <= end) {
+        const uint8_t a = p[0], b = p[1], ty = p[2];
+        p += 3;
+        if (ty == 'Z' || ty == 'H') {
+            const uint8_t* q = p;
+            while (q < end && *q) q++;
+            if (a == t0 && b == t1 && ty == 'Z') { *length = (int)(q - p); return p; }
+            p = q + 1;
+        } else if (ty == 'A' || ty == 'c' || ty == 'C') p += 1;
+        else if (ty == 's' || ty == 'S') p += 2;
+        else if (ty == 'i' || ty == 'I' || ty == 'f') p += 4;
+        else if (ty == 'B') {
+            if (p + 5 > end) return nullptr;
+            const uint8_t sub = p[0];
+            const long long count = (uint32_t)bam_le32(p + 1);
+            const int size = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+            if (count * size > end - (p + 5)) return nullptr;
+            p += 5 + count * size;
+        } else return nullptr;   // not a value type: the fields end here
+    }
+    return nullptr;
+}
+__device__ __forceinline__ const uint8_t* bam_aux_of(const uint8_t* rec)   // rec points behind block_size
+{
+    const int l_name = rec[8], n_cigar = (int)bam_le16(rec + 12), l_seq = bam_le32(rec + 16);
+    return rec + 32 + l_name + 4 * n_cigar + (l_seq + 1) / 2 + l_seq;
+}
+
 __device__ __forceinline__ bool bam_keep(const uint8_t* __restrict__ rec, const BamFilter& F)
 {
     // rec points behind block_size: refID, pos, l_read_name, mapq, bin, n_cigar_op, flag, l_seq, ...
@@ -318,6 +350,8 @@ __global__ __launch_bounds__(64) void bam_count_kernel(const uint8_t* __restrict
         }
         if (bam_keep(rec, F)) {
             const int n_cigar = (int)bam_le16(rec + 12);
+            int xd_len = 0;
+            if (!status[2] && bam_find_string_tag(bam_aux_of(rec), rec + bam_le32(rec - 4), 'X', 'D', &xd_len)) status[2] = 1;   // stitched reads: the batch gets per-base directions
             reads++;
             ops += n_cigar;
             bases += bam_le32(rec + 16);
@@ -341,7 +375,10 @@ __global__ __launch_bounds__(64) void bam_count_kernel(const uint8_t* __restrict
 }
 
 // in-place exclusive scans of up to three int32 arrays of n + 1 elements (the last receives the total) by one workgroup (d may be null)
-__global__ __launch_bounds__(1024) void bam_scan3_kernel(int32_t* __restrict__ a, int32_t* __restrict__ b, int32_t* __restrict__ d, int32_t n)
+// (totals64, optional: the three totals as they are, for the host to refuse a batch whose counts do not fit 31 bits before any of the
+// wrapped 32-bit values is used as a size)
+__global__ __launch_bounds__(1024) void bam_scan3_kernel(int32_t* __restrict__ a, int32_t* __restrict__ b, int32_t* __restrict__ d, int32_t n,
+                                                         long long* __restrict__ totals64 = nullptr)
 {
     __shared__ long long sa[1024], sb[1024], sd[1024];
     __shared__ long long base[3];
@@ -368,7 +405,10 @@ __global__ __launch_bounds__(1024) void bam_scan3_kernel(int32_t* __restrict__ a
         if (threadIdx.x == 1023) { base[0] += sa[1023]; base[1] += sb[1023]; base[2] += sd[1023]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { a[n] = (int32_t)base[0]; b[n] = (int32_t)base[1]; if (d) d[n] = (int32_t)base[2]; }
+    if (threadIdx.x == 0) {
+        a[n] = (int32_t)base[0]; b[n] = (int32_t)base[1]; if (d) d[n] = (int32_t)base[2];
+        if (totals64) { totals64[0] = base[0]; totals64[1] = base[1]; totals64[2] = base[2]; }
+    }
 }
 
 // the same for one array of 64-bit counts
@@ -406,7 +446,8 @@ __global__ __launch_bounds__(1024) void bam_scan_ll_kernel(long long* __restrict
 // the chunks' scanned sums), one bit per 1000-locus block a read touches (GetBlock for every position that receives a count,
 // RegionStateManager.cs:361-383: the aligned segments, and a gap or terminal deletion when CheckDeletionQuality lets it count), and
 // the first read the host pass would have refused (first_error = read index * 8 + code; codes below).
-enum { kBamReadPositionNotPositive = 1, kBamReadCigarLongerThanRead = 2, kBamReadPastInt32 = 3, kBamReadPastBlockMap = 4 };
+enum { kBamReadPositionNotPositive = 1, kBamReadCigarLongerThanRead = 2, kBamReadPastInt32 = 3, kBamReadPastBlockMap = 4, kBamReadBadDirectionTag = 5 };
+constexpr int kBamMaxDirectionRuns = 64;   // runs of an XD tag ("3F4S3R": three); a tag with more is refused (kBamReadBadDirectionTag)
 __global__ __launch_bounds__(256) void bam_decode_kernel(const uint8_t* __restrict__ s, int64_t n, const long long* __restrict__ entry, BamFilter F,
                                                         const int32_t* __restrict__ read0, const int32_t* __restrict__ op0,
                                                         const int32_t* __restrict__ base0, int32_t* __restrict__ position,
@@ -417,8 +458,13 @@ __global__ __launch_bounds__(256) void bam_decode_kernel(const uint8_t* __restri
                                                         const long long* __restrict__ span0, const int32_t* __restrict__ indel0,
                                                         long long* __restrict__ slots, int32_t* __restrict__ fslots,
                                                         uint32_t* __restrict__ block_map, long long n_block_bits,
-                                                        unsigned long long* __restrict__ first_error)
+                                                        unsigned long long* __restrict__ first_error,
+                                                        uint8_t* __restrict__ dirs /* per base, or nullptr: no read of the batch has an XD tag */,
+                                                        uint8_t* __restrict__ del_dirs /* two per CIGAR operation, or nullptr */)
 {
+    // per wave: the XD tag of the record being decoded as (end in the expanded CIGAR, DirectionType) runs (CigarDirection, CigarDirection.cs:19-41)
+    __shared__ int32_t xd_end[4][kBamMaxDirectionRuns];
+    __shared__ uint8_t xd_dir[4][kBamMaxDirectionRuns];
     // Lane 0 walks the chunk's chain (one dependent load a record) and leaves the record offsets in LDS; the threads then take a record
     // each for what the records add to the batch's arrays (an exclusive scan over the chunk's records gives every record its place);
     // the four waves then decode a record each, in turn.
@@ -488,7 +534,62 @@ __global__ __launch_bounds__(256) void bam_decode_kernel(const uint8_t* __restri
                 const int lastq = l_seq > 0 ? ql[l_seq - 1] : 0, prevq = l_seq > 1 ? ql[l_seq - 2] : lastq;
                 read_quality[r] = (l_seq > 0 && lastq >= F.min_base_quality && prevq >= F.min_base_quality) ? 1 : 0;
             }
+            // ---- stitched reads (Read.SequencedBaseDirectionMap / CigarDirections, Read.cs:340-400, 664-682): the XD tag gives a
+            // DirectionType per base of the EXPANDED CIGAR (deleted bases included); without the tag every base has the strand's
+            int n_runs = -1;   // -1: no XD tag
+            if (dirs) {
+                wave_lds_sync();   // (the record before this one is done with the runs)
+                int xd_bad = 0;
+                if (lane == 0) {
+                    int xd_len = 0;
+                    const uint8_t* xd = bam_find_string_tag(ql + l_seq, rec + bam_le32(rec - 4), 'X', 'D', &xd_len);
+                    if (xd) {
+                        int runs = 0, num = 0, end = 0, digits = 0;
+                        for (int k = 0; k < xd_len && !xd_bad; k++) {
+                            const uint8_t ch = xd[k];
+                            if (ch >= '0' && ch <= '9') { num = num * 10 + (ch - '0'); digits++; continue; }
+                            const int d = ch == 'F' ? PISCES_DIR_FORWARD : ch == 'R' ? PISCES_DIR_REVERSE : ch == 'S' ? PISCES_DIR_STITCHED : -1;
+                            if (d < 0 || digits == 0 || runs == kBamMaxDirectionRuns) { xd_bad = 1; break; }   // (DirectionHelper.GetDirection / int.Parse throw)
+                            end += num;
+                            xd_end[wave][runs] = end;
+                            xd_dir[wave][runs] = (uint8_t)d;
+                            runs++;
+                            num = 0;
+                            digits = 0;
+                        }
+                        if (digits) xd_bad = 1;   // (CigarDirection: "Unexpected format in direction string")
+                        n_runs = runs;
+                        if (xd_bad) atomicMin(first_error, (unsigned long long)r * 8ull + (unsigned long long)kBamReadBadDirectionTag);
+                    }
+                }
+                n_runs = __shfl(n_runs, 0, 64);
+                wave_lds_sync();   // (lane 0's runs are in LDS for the other lanes)
+            }
+            auto direction_at = [&](int expanded_index) -> uint8_t {   // (bases the tag does not reach keep DirectionType's default)
+                for (int j = 0; j < n_runs; j++)
+                    if (expanded_index < xd_end[wave][j]) return xd_dir[wave][j];
+                return (uint8_t)PISCES_DIR_FORWARD;
+            };
             for (int k = lane; k < l_seq; k += 64) {
+                if (dirs) {
+                    uint8_t d = (flag & 0x10) ? PISCES_DIR_REVERSE : PISCES_DIR_FORWARD;
+                    if (n_runs >= 0) {
+                        // the base's index in the expanded CIGAR: every operation takes its length there, the read-span ones hold the bases
+                        int e = 0, ri = 0, ex = -1;
+                        for (int c = 0; c < n_cigar && ex < 0; c++) {
+                            const uint32_t v = (uint32_t)bam_le32(cig + 4 * c);
+                            const uint32_t op = v & 0xFu;
+                            const int len = (int)(v >> 4);
+                            if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) {
+                                if (k < ri + len) ex = e + (k - ri);
+                                ri += len;
+                            }
+                            e += len;
+                        }
+                        d = ex >= 0 ? direction_at(ex) : (uint8_t)PISCES_DIR_FORWARD;
+                    }
+                    dirs[b + k] = d;
+                }
                 const uint32_t nib = (seq[k >> 1] >> ((k & 1) ? 0 : 4)) & 0xFu;
                 // "=ACMGRSVTWYHKDBN" (SAM specification 4.2.3; BamReader decodes with the same table), eight letters per constant
                 const unsigned long long hi = 0x4E42444B48595754ull;   // T W Y H K D B N
@@ -514,7 +615,7 @@ __global__ __launch_bounds__(256) void bam_decode_kernel(const uint8_t* __restri
                         map_bits |= 1u << (k & 31);
                     }
                 };
-                int ri = 0;
+                int ri = 0, expanded = 0;
                 long long rp = pos1, last_mapped = pos1 - 1;
                 uint8_t ok_last = 0;
                 uint32_t op_last = 99, len_last = 0, op_before = 99, len_before = 0;
@@ -525,6 +626,12 @@ __global__ __launch_bounds__(256) void bam_decode_kernel(const uint8_t* __restri
                                            : op == 6 ? 'P' : op == 7 ? '=' : op == 8 ? 'X' : '?';
                     cigar_op[o + k] = letter;
                     cigar_len[o + k] = len;
+                    if (del_dirs) {   // a deletion's first and last deleted base (GetDeletionDirectionForStitchedRead, CandidateVariantFinder.cs:468-487)
+                        const bool tracked = n_runs >= 0 && op == 2 && len > 0;
+                        del_dirs[2 * (size_t)(o + k)] = tracked ? direction_at(expanded) : (uint8_t)PISCES_DIR_UNTRACKED;
+                        del_dirs[2 * (size_t)(o + k) + 1] = tracked ? direction_at(expanded + (int)len - 1) : (uint8_t)PISCES_DIR_UNTRACKED;
+                    }
+                    expanded += (int)len;
                     uint8_t ok = 0;
                     if (l_seq > 0) {
                         const int after = ri < l_seq ? ql[ri] : ql[l_seq - 1], before = ri > 0 ? ql[min(ri, l_seq) - 1] : after;
@@ -542,7 +649,7 @@ __global__ __launch_bounds__(256) void bam_decode_kernel(const uint8_t* __restri
                     op_before = op_last; len_before = len_last;
                     op_last = op; len_last = len; ok_last = ok;
                 }
-                if (!code && ri > l_seq) code = kBamReadCigarLongerThanRead;
+                if (!code && ri != l_seq) code = kBamReadCigarLongerThanRead;   // Read.ValidateCigar (Read.cs:603): the CIGAR's read span is the sequence length
                 if (!code && rp > 0x7FFFFFFFll) code = kBamReadPastInt32;
                 if (!code) {
                     // a terminal deletion counts at the anchor of the read's end (RegionStateManager.cs:195-210), a deletion before a

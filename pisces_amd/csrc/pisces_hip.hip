@@ -289,7 +289,9 @@ struct PiscesHip {
         unsigned long long first_error = ~0ull;   // read index * 8 + code of the first read add_reads would refuse (all ones: none)
         // the read batch
         DeviceBuf<int32_t> position, cigar_offset, seq_offset;
-        DeviceBuf<uint8_t> flags, cigar_op, bases, quals, op_quality, read_quality;
+        DeviceBuf<uint8_t> flags, cigar_op, bases, quals, op_quality, read_quality, dirs, del_dirs;
+        DeviceBuf<long long> d_totals64;
+        bool has_dirs = false;    // some read of the batch carries an XD tag (a stitched read): `dirs` / `del_dirs` are made
         DeviceBuf<uint32_t> cigar_len;
         DeviceBuf<long long> d_slots;      // log slots of the reads (pisces_hip_add_decoded_reads)
         DeviceBuf<int32_t> d_fslots;       // candidate-record slots of the reads

@@ -147,7 +147,11 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
         if (b.in_offset < 0 || b.in_length < 0 || b.in_length > 65536 || b.in_offset + b.in_length > n_bytes || b.out_offset < 0 ||
             b.out_length < 0 || b.out_length > 65536)
             return fail(h, PISCES_E_INVALID_ARG, "bam_decode: block " + std::to_string(i) + " lies outside the file bytes");
-        out_bytes = std::max(out_bytes, b.out_offset + b.out_length);
+        // the inflated stream is parsed as ONE run of BAM records: the blocks must tile it in order (what pisces_hip_bgzf_scan makes);
+        // a gap would be parsed as records, overlapping blocks would race in the inflate
+        if (b.out_offset != out_bytes)
+            return fail(h, PISCES_E_INVALID_ARG, "bam_decode: block " + std::to_string(i) + " does not start where the block before it ends in the inflated stream");
+        out_bytes = b.out_offset + b.out_length;
     }
     if (out_bytes <= 0 || out_bytes > 0x7FFFFFFF00ll) return fail(h, PISCES_E_INVALID_ARG, "bam_decode: empty or oversized stream");
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
@@ -176,6 +180,7 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
     PISCES_HIP_CHECK(h, B.d_n_indels.reserve((size_t)n_chunks + 1));
     PISCES_HIP_CHECK(h, B.d_n_pool.reserve((size_t)n_chunks + 1));
     PISCES_HIP_CHECK(h, B.d_first_error.reserve(1));
+    PISCES_HIP_CHECK(h, B.d_totals64.reserve(8));
     PISCES_HIP_CHECK(h, hipMemsetAsync(B.d_bstatus.p, 0, 4 * sizeof(int32_t), h->stream));
     {   // diagnostics: PISCES_HIP_BAM_SERIAL_CHAIN=1 takes the serial hop whatever the guesses say (the two must agree: tests)
         const char* force = std::getenv("PISCES_HIP_BAM_SERIAL_CHAIN");
@@ -195,13 +200,13 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
     hipLaunchKernelGGL(bam_count_kernel, dim3((unsigned)n_chunks), dim3(64), 0, h->stream, (const uint8_t*)B.d_stream.p, out_bytes,
                        (const long long*)B.d_entry.p, F, B.d_n_reads.p, B.d_n_ops.p, B.d_n_bases.p, B.d_n_skipped.p, B.d_n_span.p, B.d_n_indels.p,
                        B.d_n_pool.p, B.d_bstatus.p);
-    hipLaunchKernelGGL(bam_scan3_kernel, dim3(1), dim3(1024), 0, h->stream, B.d_n_reads.p, B.d_n_ops.p, B.d_n_bases.p, (int32_t)n_chunks);
-    hipLaunchKernelGGL(bam_scan3_kernel, dim3(1), dim3(1024), 0, h->stream, B.d_n_indels.p, B.d_n_pool.p, (int32_t*)nullptr, (int32_t)n_chunks);
+    hipLaunchKernelGGL(bam_scan3_kernel, dim3(1), dim3(1024), 0, h->stream, B.d_n_reads.p, B.d_n_ops.p, B.d_n_bases.p, (int32_t)n_chunks, B.d_totals64.p);
+    hipLaunchKernelGGL(bam_scan3_kernel, dim3(1), dim3(1024), 0, h->stream, B.d_n_indels.p, B.d_n_pool.p, (int32_t*)nullptr, (int32_t)n_chunks, B.d_totals64.p + 3);
     hipLaunchKernelGGL(bam_scan_ll_kernel, dim3(1), dim3(1024), 0, h->stream, B.d_n_span.p, (int32_t)n_chunks);
     PISCES_HIP_CHECK(h, hipGetLastError());
     std::vector<int32_t> status((size_t)n_blocks), skipped((size_t)n_chunks);
     int32_t totals[5] = {0, 0, 0, 0, 0}, bstatus[4] = {0, 0, 0, 0};
-    long long span_total = 0, header[4] = {0, 0, 0, 0};
+    long long span_total = 0, header[4] = {0, 0, 0, 0}, totals64[6] = {0, 0, 0, 0, 0, 0};
     PISCES_HIP_CHECK(h, hipMemcpyAsync(status.data(), B.d_status.p, status.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipMemcpyAsync(skipped.data(), B.d_n_skipped.p, skipped.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipMemcpyAsync(&totals[0], B.d_n_reads.p + n_chunks, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
@@ -212,6 +217,7 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
     PISCES_HIP_CHECK(h, hipMemcpyAsync(&span_total, B.d_n_span.p + n_chunks, sizeof(long long), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipMemcpyAsync(header, B.d_header.p, sizeof(header), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipMemcpyAsync(bstatus, B.d_bstatus.p, sizeof(bstatus), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(totals64, B.d_totals64.p, sizeof(totals64), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     for (int64_t i = 0; i < n_blocks; i++)
         if (status[(size_t)i] != 0)
@@ -222,7 +228,12 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
     if (bstatus[0] != 0)
         return fail(h, PISCES_E_INVALID_ARG, "bam_decode: the record chain breaks in chunk " + std::to_string(bstatus[1]) +
                                                  " (corrupt block_size, or a record longer than 32 KiB)");
+    // (the kernels index the batch with 32-bit offsets: a chromosome with more goes through in several regions)
+    for (int k = 0; k < 5; k++)
+        if (totals64[k] > 0x7FFFFFF0ll || span_total < 0)
+            return fail(h, PISCES_E_INVALID_ARG, "bam_decode: more than 2^31 reads, CIGAR operations, bases or candidate slots in one call: decode the file in regions");
     B.chain_mode = bstatus[3] != 0 ? 1 : 0;
+    B.has_dirs = bstatus[2] != 0;
     B.n_reads = totals[0]; B.n_ops = totals[1]; B.n_bases = totals[2];
     B.found_slots = totals[3]; B.found_pool = totals[4]; B.log_slots = span_total;
     B.n_skipped = 0;
@@ -236,6 +247,10 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
     // (kSegmentPad bytes in front of the bases and the qualities: a batch that becomes a segment of the read store as it lies)
     PISCES_HIP_CHECK(h, B.bases.reserve(nb + 16 + 2 * kSegmentPad)); PISCES_HIP_CHECK(h, B.quals.reserve(nb + 16 + 2 * kSegmentPad));
     PISCES_HIP_CHECK(h, B.d_slots.reserve(nr + 1)); PISCES_HIP_CHECK(h, B.d_fslots.reserve(nr + 1));
+    if (B.has_dirs) {   // some read is stitched (XD tag): per-base directions for all, the directions inside deletions for the finder
+        PISCES_HIP_CHECK(h, B.dirs.reserve(nb + 16 + 2 * kSegmentPad));
+        PISCES_HIP_CHECK(h, B.del_dirs.reserve(2 * no + 2));
+    }
     // the blocks of the chromosome (its length from the header, and room for reads that hang over its end), one bit each
     const long long l_ref = std::min<long long>(std::max<long long>(header[3], 0), 0x7FFFFFFFll);
     const long long n_block_bits = std::min<long long>(l_ref + 70000, 0x7FFFFFFFll - h->cfg.block_size) / h->cfg.block_size + 1;
@@ -248,7 +263,8 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
                            (const long long*)B.d_entry.p, F, (const int32_t*)B.d_n_reads.p, (const int32_t*)B.d_n_ops.p, (const int32_t*)B.d_n_bases.p,
                            B.position.p, B.flags.p, B.cigar_offset.p, B.cigar_op.p, B.cigar_len.p, B.seq_offset.p, B.bases.p + kSegmentPad, B.quals.p + kSegmentPad,
                            B.op_quality.p, B.read_quality.p, (const long long*)B.d_n_span.p, (const int32_t*)B.d_n_indels.p, B.d_slots.p,
-                           B.d_fslots.p, B.d_block_map.p, n_block_bits, B.d_first_error.p);
+                           B.d_fslots.p, B.d_block_map.p, n_block_bits, B.d_first_error.p, B.has_dirs ? B.dirs.p + kSegmentPad : (uint8_t*)nullptr,
+                           B.has_dirs ? B.del_dirs.p : (uint8_t*)nullptr);
     // the closing offsets
     const int32_t end_ops = (int32_t)no, end_bases = (int32_t)nb, end_fslots = (int32_t)B.found_slots;
     const long long end_slots = B.log_slots;
@@ -307,6 +323,22 @@ int32_t pisces_hip_bam_fetch(PiscesHip* h, int32_t* position, uint8_t* flags, in
 // takes from a pass over the reads' CIGARs (log slots, candidate-record slots, the blocks every read touches, the reads it refuses)
 // the decode kernel has made where the reads are; the host creates the blocks from a bit map and enqueues the read walk and the
 // candidate discovery.
+int32_t pisces_hip_bam_fetch_directions(PiscesHip* h, uint8_t* directions, uint8_t* deletion_directions)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (!h->bam.valid) return fail(h, PISCES_E_STATE, "bam_fetch_directions: no decoded batch (pisces_hip_bam_decode first)");
+    auto& B = h->bam;
+    if (B.moved) return fail(h, PISCES_E_STATE, "bam_fetch_directions: the decoded batch has been added to the read store");
+    if (!B.has_dirs) return 0;
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    if (directions && B.n_bases) PISCES_HIP_CHECK(h, hipMemcpyAsync(directions, B.dirs.p + kSegmentPad, (size_t)B.n_bases, hipMemcpyDeviceToHost, h->stream));
+    if (deletion_directions && B.n_ops) PISCES_HIP_CHECK(h, hipMemcpyAsync(deletion_directions, B.del_dirs.p, 2 * (size_t)B.n_ops, hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    return 1;
+    });
+}
+
 int32_t pisces_hip_add_decoded_reads(PiscesHip* h)
 {
     return abi_guard<int32_t>(h, [&]() -> int32_t {
@@ -327,6 +359,7 @@ int32_t pisces_hip_add_decoded_reads(PiscesHip* h)
             case kBamReadPositionNotPositive: return fail(h, PISCES_E_INVALID_ARG, "Position must be greater than 0." + read);
             case kBamReadCigarLongerThanRead: return fail(h, PISCES_E_INVALID_ARG, "add_decoded_reads: CIGAR does not match the read" + read);
             case kBamReadPastInt32: return fail(h, PISCES_E_INVALID_ARG, "add_decoded_reads: read runs past position 2^31 - 1" + read);
+            case kBamReadBadDirectionTag: return fail(h, PISCES_E_INVALID_ARG, "add_decoded_reads: unexpected format in a direction string (XD tag)" + read);
             default: return fail(h, PISCES_E_INVALID_ARG, "add_decoded_reads: read runs far past the end of its reference sequence" + read);
         }
     }
@@ -344,13 +377,14 @@ int32_t pisces_hip_add_decoded_reads(PiscesHip* h)
     if (rc) return rc;
     DevReadBatch db;
     db.position = B.position.p; db.flags = B.flags.p; db.cigar_offset = B.cigar_offset.p; db.cigar_op = B.cigar_op.p; db.cigar_len = B.cigar_len.p;
-    db.seq_offset = B.seq_offset.p; db.bases = B.bases.p + kSegmentPad; db.quals = B.quals.p + kSegmentPad; db.dirs = nullptr; db.n_reads = nr;
+    db.seq_offset = B.seq_offset.p; db.bases = B.bases.p + kSegmentPad; db.quals = B.quals.p + kSegmentPad;
+    db.dirs = B.has_dirs ? B.dirs.p + kSegmentPad : nullptr; db.n_reads = nr;
     const int c = h->log_cur;
     hipLaunchKernelGGL(expand_reads_kernel, dim3(expand_reads_grid(nr)), dim3(256), 0, h->stream, db, (const long long*)B.d_slots.p,
                        (long long)h->log_ub, h->cfg.min_base_call_quality, h->d_log_pos[c].p, h->d_log_tup[c].p, h->d_log_n.p + 2, expand_reads_per_wave(nr));
     PISCES_HIP_CHECK(h, hipGetLastError());
     if (find_on_device && (h->cfg.call_mnvs || found_slots > 0)) {
-        int32_t rcd = enqueue_candidate_discovery(h, db, nullptr, nr, (const int32_t*)B.d_fslots.p, found_slots, found_pool);
+        int32_t rcd = enqueue_candidate_discovery(h, db, B.has_dirs ? B.del_dirs.p : nullptr, nr, (const int32_t*)B.d_fslots.p, found_slots, found_pool);
         if (rcd) return rcd;
     }
     h->log_ub += B.log_slots;

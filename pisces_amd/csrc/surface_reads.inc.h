@@ -474,7 +474,7 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
             if (op_read(t)) read_span += r.cigar_len[c];
             if (op_ref(t)) ref_span += r.cigar_len[c];   // mapped bases + every gap: one observation each at most
         }
-        if (read_span > r.read_len) return fail(h, PISCES_E_INVALID_ARG, "add_reads: CIGAR does not match the read");
+        if (r.n_cigar > 0 && read_span != r.read_len) return fail(h, PISCES_E_INVALID_ARG, "add_reads: CIGAR does not match the read");   // Read.ValidateCigar (Read.cs:603-605)
         if ((int64_t)r.position + ref_span > 0x7FFFFFFFll) return fail(h, PISCES_E_INVALID_ARG, "add_reads: read runs past position 2^31 - 1");
         if (r.dirs)
             for (int k = 0; k < r.read_len; k++)
@@ -640,11 +640,11 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
     const int c = h->log_cur;
     hipLaunchKernelGGL(expand_reads_kernel, dim3(expand_reads_grid(nr)), dim3(256), 0, h->stream, db, (const long long*)(d + off_slots), 0ll,
                        minBQ, h->d_log_pos[c].p, h->d_log_tup[c].p, h->d_log_n.p + 2, expand_reads_per_wave(nr));
-    PISCES_HIP_CHECK(h, hipGetLastError());
+    { hipError_t el = hipGetLastError(); if (el != hipSuccess) { (void)stage_release(h); return fail(h, PISCES_E_DEVICE, std::string("add_reads: ") + hipGetErrorString(el)); } }
     if (find_on_device && (h->cfg.call_mnvs || found_slots > 0)) {
         int32_t rcd = enqueue_candidate_discovery(h, db, batch->deletion_directions ? d + off_deldirs : nullptr, nr, (const int32_t*)(d + off_fslots),
                                                   found_slots, found_pool);
-        if (rcd) return rcd;
+        if (rcd) { (void)stage_release(h); return rcd; }   // (transfers out of the staging pair are in flight)
     }
     { int32_t rcs = stage_release(h); if (rcs) return rcs; }
     h->log_ub += ub;

@@ -363,7 +363,7 @@ static int32_t add_reads_store(PiscesHip* h, const PiscesReadBatch* batch)
                 if (r.dirs[k] > 2) { bad = "add_reads: CIGAR does not match the read"; break; }
         if (r.n_cigar == 1 && (r.cigar_op[0] == 'M' || r.cigar_op[0] == '=' || r.cigar_op[0] == 'X')) {   // one aligned run: most reads
             const int64_t len = r.cigar_len[0];
-            if (len > r.read_len) { bad = "add_reads: CIGAR does not match the read"; break; }
+            if (len != r.read_len) { bad = "add_reads: CIGAR does not match the read"; break; }   // Read.ValidateCigar (Read.cs:603-605)
             if ((int64_t)r.position + len > 0x7FFFFFFFll) { bad = "add_reads: read runs past position 2^31 - 1"; break; }
             if (len > 0) touch(r.position, r.position + len - 1);
             continue;
@@ -380,7 +380,7 @@ static int32_t add_reads_store(PiscesHip* h, const PiscesReadBatch* batch)
             if (op_read(t)) read_span += r.cigar_len[c];
             if (op_ref(t)) ref_span += r.cigar_len[c];
         }
-        if (read_span > r.read_len) { bad = "add_reads: CIGAR does not match the read"; break; }
+        if (r.n_cigar > 0 && read_span != r.read_len) { bad = "add_reads: CIGAR does not match the read"; break; }   // Read.ValidateCigar (Read.cs:603-605)
         if ((int64_t)r.position + ref_span > 0x7FFFFFFFll) { bad = "add_reads: read runs past position 2^31 - 1"; break; }
         int64_t rp = r.position, last_mapped = (int64_t)r.position - 1;
         int ri = 0;
@@ -474,21 +474,23 @@ static int32_t add_decoded_reads_store(PiscesHip* h, int64_t found_slots, int64_
         g.quals.swap(B.quals);
         g.cop.swap(B.cigar_op);
         g.clen.swap(B.cigar_len);
+        if (B.has_dirs) g.dirs.swap(B.dirs);
         B.moved = true;
     }
     // (the decode leaves kSegmentPad bytes in front of the bases and the qualities)
     const StoreBatchArrays A = {B.position.p, B.flags.p, B.cigar_offset.p, pl.direct ? g.cop.p : B.cigar_op.p, pl.direct ? g.clen.p : B.cigar_len.p,
-                                B.seq_offset.p, (pl.direct ? g.bases.p : B.bases.p) + kSegmentPad, (pl.direct ? g.quals.p : B.quals.p) + kSegmentPad, nullptr};
+                                B.seq_offset.p, (pl.direct ? g.bases.p : B.bases.p) + kSegmentPad, (pl.direct ? g.quals.p : B.quals.p) + kSegmentPad,
+                                B.has_dirs ? (pl.direct ? g.dirs.p : B.dirs.p) + kSegmentPad : nullptr};
     int32_t rc = store_append_arrays(h, pl, A, nr, n_cig, n_seq);
     if (rc == PISCES_OK && find_on_device && (h->cfg.call_mnvs || found_slots > 0)) {
         DevReadBatch db;
         db.position = A.position; db.flags = A.flags; db.cigar_offset = A.cigar_offset; db.cigar_op = A.cigar_op; db.cigar_len = A.cigar_len;
-        db.seq_offset = A.seq_offset; db.bases = A.bases; db.quals = A.quals; db.dirs = nullptr; db.n_reads = nr;
-        rc = enqueue_candidate_discovery(h, db, nullptr, nr, (const int32_t*)B.d_fslots.p, found_slots, found_pool);
+        db.seq_offset = A.seq_offset; db.bases = A.bases; db.quals = A.quals; db.dirs = A.dirs; db.n_reads = nr;
+        rc = enqueue_candidate_discovery(h, db, B.has_dirs ? B.del_dirs.p : nullptr, nr, (const int32_t*)B.d_fslots.p, found_slots, found_pool);
     }
     if (rc) {
         (void)hipStreamSynchronize(h->stream);
-        if (pl.direct) { g.bases.swap(B.bases); g.quals.swap(B.quals); g.cop.swap(B.cigar_op); g.clen.swap(B.cigar_len); B.moved = false; }
+        if (pl.direct) { g.bases.swap(B.bases); g.quals.swap(B.quals); g.cop.swap(B.cigar_op); g.clen.swap(B.cigar_len); if (B.has_dirs) g.dirs.swap(B.dirs); B.moved = false; }
         store_unplace(h, pl);
         return rc;
     }

@@ -393,6 +393,15 @@ class HipVariantCaller:
         mode = lib.pisces_hip_bam_chain_mode(self._h)
         return dict(self._bam_counts, chain="guessed" if mode == 0 else "hopped")
 
+    def bam_fetch_directions(self):
+        """(directions, deletion_directions) of the decoded batch — made when some read of it carries the Stitcher's XD tag — or None."""
+        n = self._bam_counts
+        dirs, dd = np.zeros(n["bases"], np.uint8), np.zeros(2 * n["cigar_ops"], np.uint8)
+        rc = lib.pisces_hip_bam_fetch_directions(self._h, dirs.ctypes.data, dd.ctypes.data)
+        if rc < 0:
+            _check(self._h, rc)
+        return (dirs, dd) if rc == 1 else None
+
     def bam_fetch(self):
         """The decoded batch as host arrays (dict with the PiscesReadBatch field names)."""
         n = self._bam_counts

@@ -75,7 +75,7 @@ def read_bam(path):
         q += l_seq
         tags = b[q:p + 4 + block_size]
         reads.append(dict(ref=refs[ref_id] if ref_id >= 0 else None, pos=pos + 1, mapq=mapq, flag=flag, cigar=cigar, seq=seq, qual=qual,
-                          name=name, has_xd=b"XDZ" in tags))
+                          name=name, has_xd=b"XDZ" in tags, tags=bytes(tags)))
         p += 4 + block_size
     return refs, reads
 

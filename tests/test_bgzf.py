@@ -419,3 +419,138 @@ def test_device_inflate_fuzz_against_zlib():
             got, blocks, _ = c.bgzf_inflate(data)
             assert len(blocks) == len(members) + 1
             assert got == b"".join(want)
+
+
+# ---------------------------------------------------------------- stitched reads (XD tag) through the BAM surface
+def _string_tag(tags, name):
+    """BamAlignment.GetStringTag on a record's auxiliary bytes (SAM specification 4.2.4)."""
+    p, size = 0, {ord("A"): 1, ord("c"): 1, ord("C"): 1, ord("s"): 2, ord("S"): 2, ord("i"): 4, ord("I"): 4, ord("f"): 4}
+    while p + 3 <= len(tags):
+        tag, ty = tags[p:p + 2], tags[p + 2]
+        p += 3
+        if ty in (ord("Z"), ord("H")):
+            q = tags.index(b"\0", p)
+            if tag == name and ty == ord("Z"):
+                return tags[p:q].decode()
+            p = q + 1
+        elif ty == ord("B"):
+            sub, count = tags[p], int.from_bytes(tags[p + 1:p + 5], "little")
+            p += 5 + count * size[sub]
+        else:
+            p += size[ty]
+    return None
+
+
+def _expected_directions(keep):
+    """PiscesReadBatch.directions / deletion_directions of reads parsed on the host: Read.SequencedBaseDirectionMap from the XD tag
+    (Read.cs:340-400, 664-682; _abi.directions_from_xd), the strand's direction for a read without the tag."""
+    dirs, dd = [], []
+    for r in keep:
+        xd = _string_tag(r["tags"], b"XD")
+        if xd is None:
+            dirs += [_abi.DIR_REVERSE if r["flag"] & 0x10 else _abi.DIR_FORWARD] * len(r["seq"])
+            dd += [_abi.DIR_UNTRACKED] * (2 * len(r["cigar"]))
+        else:
+            d, e = _abi.directions_from_xd(xd, r["cigar"])
+            dirs += list(d) + [_abi.DIR_FORWARD] * (len(r["seq"]) - len(d))
+            dd += [x for pair in e for x in pair]
+    return np.array(dirs, np.uint8), np.array(dd, np.uint8)
+
+
+def _stitched_synthetic_bam(rng, n_reads=400, bad_read=None):
+    """A BAM whose reads carry XD tags (stitched pairs: F / S / R runs over the expanded CIGAR, deletions included) between other
+    auxiliary fields of every value type; a third of the reads carry no XD tag.  bad_read: that read's tag is malformed."""
+    import struct
+    hdr = b"BAM\x01" + struct.pack("<i", 0) + struct.pack("<i", 1) + struct.pack("<i", 5) + b"chr1\0" + struct.pack("<i", 1_000_000)
+    code = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+    out, pos = [hdr], 500
+    for i in range(n_reads):
+        pos += int(rng.integers(0, 8))
+        ops = [("M", int(rng.integers(20, 60)))]
+        if i % 3 == 1:
+            ops += [("D", int(rng.integers(1, 7))), ("M", int(rng.integers(10, 40)))]
+        if i % 3 == 2:
+            ops = [("S", 3)] + ops + [("I", int(rng.integers(1, 5))), ("M", int(rng.integers(10, 40)))]
+        l_seq = sum(l for o, l in ops if o in "MIS")
+        span = sum(l for o, l in ops)
+        seq = "".join(rng.choice(list("ACGT"), l_seq))
+        qual = rng.choice([12, 30, 38], l_seq, p=[.05, .3, .65]).astype(np.uint8).tobytes()
+        aux = b"NMC" + bytes([int(rng.integers(0, 5))]) + b"ZBBs" + struct.pack("<i", 3) + struct.pack("<3h", 1, -2, 3) + b"MDZ" + b"12A3\0" + b"ASi" + struct.pack("<i", 77)
+        if i % 3 != 0:
+            a = int(rng.integers(1, span // 2))
+            b = int(rng.integers(1, span - a)) if span - a > 1 else 0
+            xd = f"{a}F" + (f"{span - a - b}S" if span - a - b > 0 else "") + (f"{b}R" if b > 0 else "")
+            if bad_read == i:
+                xd = f"{a}F7"                                  # digits without a direction
+            aux += b"XDZ" + xd.encode() + b"\0" + b"XRZFR\0"
+        aux += b"XZf" + struct.pack("<f", 1.5)
+        name = b"r%05d\0" % i
+        cig = b"".join(struct.pack("<I", (l << 4) | "MIDNSHP=X".index(o)) for o, l in ops)
+        packed = bytearray((l_seq + 1) // 2)
+        for k, ch in enumerate(seq):
+            packed[k >> 1] |= code[ch] << (4 if k % 2 == 0 else 0)
+        flag = 16 if i % 2 else 0
+        body = struct.pack("<iiBBHHHiiii", 0, pos - 1, len(name), 60, 0, len(ops), flag, l_seq, -1, -1, 0) + name + cig + bytes(packed) + qual + aux
+        out.append(struct.pack("<i", len(body)) + body)
+    return _bgzf_of(b"".join(out))
+
+
+def _bgzf_of(stream, chunk=60000):
+    return make_bgzf([stream[i:i + chunk] for i in range(0, len(stream), chunk)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["reference fixture", "synthetic"])
+def test_stitched_reads_through_the_bam_surface(which):
+    """A stitched BAM (the Stitcher's XD tag: one DirectionType per base of the expanded CIGAR) through pisces_hip_bam_decode +
+    pisces_hip_add_decoded_reads: the per-base directions and the directions inside deletions the device makes of the tags equal
+    Read.SequencedBaseDirectionMap / CigarDirections restated on the host, and counts, candidates and records equal the host-fed
+    path's with the same direction maps (DirectionType.Stitched columns included)."""
+    import torch
+    assert torch.cuda.is_available()
+    from pisces_amd import engine
+    if which == "reference fixture":
+        data = np.load(os.path.join(os.path.dirname(__file__), "golden", "bam_stitched.npz"))["collapsed_test_stitched"].tobytes()
+        chrom = "chr1"
+    else:
+        data, chrom = _stitched_synthetic_bam(np.random.default_rng(8)), "chr1"
+    refs, reads = _bam_reads_reference(data)
+    keep = _kept(reads, chrom)
+    assert keep and any(_string_tag(r["tags"], b"XD") for r in keep)
+    want_dirs, want_dd = _expected_directions(keep)
+    lo, hi = min(r["pos"] for r in keep), max(r["pos"] + 400 for r in keep)
+    ref = np.frombuffer(bytes(np.random.default_rng(1).choice(list(b"ACGT"), hi + 100).astype(np.uint8)), dtype=np.uint8)
+    cfg = _abi.default_config(expect_stitched_reads=1, min_coverage=1, low_depth_filter=1)
+    batch = _abi.ReadBatch([{"pos": r["pos"], "cigar": r["cigar"], "seq": r["seq"], "quals": r["qual"].tolist(), "reverse": bool(r["flag"] & 0x10),
+                             "xd": _string_tag(r["tags"], b"XD")} for r in keep])
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(ref)
+        counts = c.bam_decode(data, refs.index(chrom))
+        assert counts["reads"] == len(keep)
+        got = c.bam_fetch_directions()
+        assert got is not None
+        np.testing.assert_array_equal(got[0], want_dirs)
+        np.testing.assert_array_equal(got[1], want_dd)
+        c.AddDecodedReads()
+        got_counts = c.GetCounts(lo, hi - lo)
+        got_recs, got_alleles = c.CallWithAlleles()
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(ref)
+        c.AddAlleleCounts(batch)
+        want_counts = c.GetCounts(lo, hi - lo)
+        want_recs, want_alleles = c.CallWithAlleles()
+    np.testing.assert_array_equal(got_counts, want_counts)
+    assert got_counts.reshape(-1, 6, 3, 11)[:, :, _abi.DIR_STITCHED, :].sum() > 0
+    assert got_recs.tobytes() == want_recs.tobytes() and got_alleles == want_alleles and len(got_recs) > 100
+    if which == "synthetic":   # a malformed tag is refused as CigarDirection's constructor refuses it (CigarDirection.cs:37-40)
+        bad = _stitched_synthetic_bam(np.random.default_rng(8), bad_read=7)
+        with engine.HipVariantCaller(cfg) as c:
+            c.SetReference(ref)
+            c.bam_decode(bad, 0)
+            with pytest.raises(engine.PiscesHipError) as e:
+                c.AddDecodedReads()
+            assert e.value.code == _abi.E_INVALID_ARG and "direction string" in e.value.message
+        plain = _synthetic_bam([100] * 50)   # no XD tag anywhere: no direction arrays are made
+        with engine.HipVariantCaller(cfg) as c:
+            c.bam_decode(_bgzf_of(bytes(plain)), 0)
+            assert c.bam_fetch_directions() is None
