@@ -36,9 +36,9 @@ N_LOCI = 100_000
 DEPTH = 500
 RING_BATCHES = 6        # 6 x ~200 MB of tuples > 256 MiB Infinity Cache
 BASE_SEED = 20260928
-TIME_EVERY = 1          # dispatch-bound HIP events on every launch of the timed region: costs ~5 us per step in `value`, but the
-                        # durations then are those rocprofv3 reports for the same command (sampling every 4th launch times kernels that
-                        # start the instant their predecessor ends: 54.6 us against rocprofv3's 52.7 us, profiles/r01_rocprofv3_summary.md)
+TIME_EVERY = 1          # the second pass (below) puts dispatch-bound HIP events on every launch: the durations then are those rocprofv3
+                        # reports for the same command.  The timed region itself carries no per-launch events (they cost 5-10 us of every
+                        # step: rounds 1-2 quoted `value` with them in) — one HIP event in front of it and one behind it on the launch stream
 PIPELINE_STREAMS = 3    # the extra 'pipelined' figure: pisces_hip_call_tiles_batched spreads the steps over its 3 lanes
 
 
@@ -490,16 +490,17 @@ def main():
         step(i)
     torch.cuda.synchronize(dev)
     caller.device_totals(reset=True)
-    caller.set_timing(TIME_EVERY)   # HIP events around every TIME_EVERY-th launch of the timed region (sampling keeps the
-                                    # event packets from stretching every step)
 
     # ---- timed region: exactly K steps, bracketed by barrier + synchronize ----
     barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
+    caller.mark(0, stream.cuda_stream)     # HIP events on the stream the kernel is launched on (torch.cuda.Event would see torch's only)
     for i in range(args.steps):
         step(args.warmup + i)
+    caller.mark(1, stream.cuda_stream)
     torch.cuda.synchronize(dev)
+    caller.synchronize()
     totals = caller.device_totals()
     summary = torch.tensor([totals["records"], totals["candidate_loci"], totals["called"], totals["tiles"]], dtype=torch.int64)
     if use_dist:
@@ -512,8 +513,17 @@ def main():
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    span_ms = caller.marked_ms() / args.steps    # HIP events over the timed region: the kernel's launches back to back
+
+    # ---- the same K launches once more, every one with the HIP events of its own dispatch (hipExtLaunchKernel start / stop): the
+    # kernel's duration as rocprofv3 reports it.  Outside the timed region: the events put 5-10 us between launches. ----
+    caller.set_timing(TIME_EVERY)
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize(dev)
     kernel_ms_total, launches = caller.kernel_time()
     caller.set_timing(False)
+    caller.device_totals(reset=True)
 
     # ---- sanity on the last step's output (outside the timed region) ----
     tr = tile_results.cpu().numpy().view(_abi.TILE_RESULT_DTYPE)
@@ -615,14 +625,17 @@ def main():
         rec_per_launch = totals["records"] / max(args.steps, 1)
         bytes_per_launch = algorithmic_bytes(n_obs, my_loci, rec_per_launch)
         kernel_ms = kernel_ms_total / max(launches, 1)
+        # `achieved`: against the kernel's own duration (the events of its dispatch, second pass: what rocprofv3's kernel statistics of this
+        # command say); timed_region_ms_per_launch is the timed region's two events / K, gaps between launches included
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_run = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):   # written from separate rocprofv3 --pmc passes of this same command
             try:
                 tj = json.load(open(tpath))
                 if tj.get("loci") == args.loci and tj.get("depth") == args.depth:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_run = tj.get("run")
             except Exception:
                 traffic = None
         out = {
@@ -647,11 +660,17 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "pisces::call_tiles_wave_kernel", "kernel_ms": kernel_ms, "launches_timed": launches,
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
+                         "timed_region_ms_per_launch": span_ms, "frac_timed_region": bytes_per_launch / (span_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "how": "kernel_ms: the K launches of the timed region launched once more, each with the HIP events of its own dispatch "
+                                "(hipExtLaunchKernel start / stop: the duration rocprofv3 reports; those events put 5-10 us between launches, so "
+                                "the timed region carries none); timed_region_ms_per_launch: one HIP event in front of and one behind the K "
+                                "launches of the timed region on the launch stream, / K (gaps between launches included)"},
         }
         # context only (SURVEY 8d asks for the measured peak beside the spec one; frac stays against the spec peak):
         # a plain streaming read of 1 GiB with the kernel's own load pattern
         out["roofline"]["peak_measured_read"] = caller.probe_read_bandwidth(1 << 30, 6)
+        out["roofline"]["traffic_from"] = traffic_run   # the rocprofv3 --pmc passes of tools/profile_round.sh the figure was collected in (not this run)
         if pipelined_elapsed is not None:
             p_ms = pipelined_elapsed / args.steps * 1e3
             out["pipelined"] = {"streams": PIPELINE_STREAMS, "value": total_loci * args.steps / pipelined_elapsed,

@@ -426,6 +426,15 @@ typedef struct PiscesTileBatch {
 } PiscesTileBatch;
 int32_t pisces_hip_call_tiles_batched(PiscesHip* h, const PiscesTileBatch* batches, int32_t n_batches, void* stream);
 
+/* The same launches as ONE HIP graph: pisces_hip_call_tiles_graph_build captures the n_batches launches (in order, on one stream: what
+ * pisces_hip_call_tiles n_batches times does) into a graph the handle keeps and returns its id; pisces_hip_call_tiles_graph_launch replays
+ * it on `stream` (NULL = the handle's) with one submission — the launches then follow each other at the device's own pace instead of the
+ * host's (a launch call per step leaves ~10 us between 38 us kernels at BASELINE config 2).  With pisces_hip_set_timing(n) in force when
+ * the graph is built, every n-th launch is bracketed by event records inside the graph, read back by pisces_hip_kernel_time after a
+ * replay.  The buffers named by `batches` must stay where they are while the graph is in use; graphs go with the handle. */
+int32_t pisces_hip_call_tiles_graph_build(PiscesHip* h, const PiscesTileBatch* batches, int32_t n_batches, int32_t* graph_id);
+int32_t pisces_hip_call_tiles_graph_launch(PiscesHip* h, int32_t graph_id, void* stream);
+
 /* Ordered compaction of a call_tiles result: d_out[0 .. *d_count) receives every called allele of the launch
  * sorted by (position, ref, alt) (tiles must be in ascending position order); d_offsets[n_tiles] (int32 scratch)
  * receives each tile's first index in d_out. Asynchronous. */
@@ -446,6 +455,12 @@ int32_t pisces_hip_device_totals(PiscesHip* h, int64_t out[4], int32_t reset);
  * enable = n > 0 starts a fresh measurement window in which every n-th call_tiles / accumulate_tiles launch is timed
  * (up to 4096 timed launches are kept); enable = 0 ends it. */
 int32_t pisces_hip_set_timing(PiscesHip* h, int32_t enable);
+/* A span on the launch stream: pisces_hip_mark(h, 0, stream) before the first of a run of launches, pisces_hip_mark(h, 1, stream) behind the
+ * last (HIP events on `stream`, NULL = the handle's own stream: the stream the launches go to); pisces_hip_marked_ms waits for the
+ * second mark and returns the time between the two.  Two event records for any number of launches: what bench.py brackets its timed
+ * region with (events of every dispatch, pisces_hip_set_timing, put 5-10 us between launches). */
+int32_t pisces_hip_mark(PiscesHip* h, int32_t which, void* stream);
+int32_t pisces_hip_marked_ms(PiscesHip* h, float* ms);
 /* Sum of the timed kernel durations (ms) and number of timed launches since set_timing(n). Waits for them. */
 int32_t pisces_hip_kernel_time(PiscesHip* h, double* total_ms, int64_t* launches);
 /* Streaming-read bandwidth of the handle's device, GB/s: best of `reps` timed passes of a kernel that only reads `nbytes`

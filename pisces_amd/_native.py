@@ -20,7 +20,7 @@ EXPORTS = [
     "pisces_hip_vcf_default_config", "pisces_hip_format_vcf", "pisces_hip_format_vcf_padded", "pisces_hip_find_candidates", "pisces_hip_call_tiles_batched",
     "pisces_hip_find_indel_candidates", "pisces_hip_compact_records", "pisces_hip_bgzf_scan", "pisces_hip_bgzf_inflate",
     "pisces_hip_balanced_tile_loci", "pisces_hip_bam_decode", "pisces_hip_bam_fetch", "pisces_hip_bam_chain_mode", "pisces_hip_add_decoded_reads", "pisces_hip_find_candidates_device", "pisces_hip_get_base_quality_sums", "pisces_hip_get_gapped_mnv_ref", "pisces_hip_comm_unique_id", "pisces_hip_comm_init", "pisces_hip_reduce_summary", "pisces_hip_comm_destroy",
-    "pisces_hip_add_candidates", "pisces_hip_set_forced_alleles", "pisces_hip_host_time", "pisces_hip_set_owned_range", "pisces_hip_bam_fetch_directions",
+    "pisces_hip_add_candidates", "pisces_hip_set_forced_alleles", "pisces_hip_host_time", "pisces_hip_set_owned_range", "pisces_hip_bam_fetch_directions", "pisces_hip_call_tiles_graph_build", "pisces_hip_call_tiles_graph_launch", "pisces_hip_mark", "pisces_hip_marked_ms",
 ]
 
 
@@ -91,6 +91,10 @@ def _load():
         "pisces_hip_host_time": (i32, [vp, P(C.c_double), i32]),
         "pisces_hip_set_owned_range": (i32, [vp, i32, i32]),
         "pisces_hip_bam_fetch_directions": (i32, [vp, vp, vp]),
+        "pisces_hip_call_tiles_graph_build": (i32, [vp, P(_abi.PiscesTileBatch), i32, P(i32)]),
+        "pisces_hip_call_tiles_graph_launch": (i32, [vp, i32, vp]),
+        "pisces_hip_mark": (i32, [vp, i32, vp]),
+        "pisces_hip_marked_ms": (i32, [vp, P(C.c_float)]),
         "pisces_hip_comm_unique_id": (i32, [vp, i32]),
         "pisces_hip_comm_init": (i32, [vp, vp, i32, i32]),
         "pisces_hip_reduce_summary": (i32, [vp, P(i64)]),

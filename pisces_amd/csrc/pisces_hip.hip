@@ -311,6 +311,8 @@ struct PiscesHip {
     // state words of the segments: slots of buffers that were zeroed in one piece (a fill per new segment is a stream operation per add_reads)
     std::vector<std::unique_ptr<DeviceBuf<int32_t>>> state_pool;
     size_t state_slots_used = 0;
+    std::vector<hipGraphExec_t> graphs;       // pisces_hip_call_tiles_graph_build
+    std::vector<hipGraph_t> graph_defs;
     int store_waves = 0;                      // development: waves per tile of call_store_tiles_kernel (PISCES_HIP_STORE_WAVES; 0 = by launch size)
 
     // device scratch, grow-only
@@ -720,6 +722,8 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     h->segments.clear();
     h->segment_pool.clear();
     h->state_pool.clear();
+    for (hipGraphExec_t g : h->graphs) (void)hipGraphExecDestroy(g);
+    for (hipGraph_t g : h->graph_defs) (void)hipGraphDestroy(g);
     for (hipEvent_t ev : h->ring) (void)hipEventDestroy(ev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);

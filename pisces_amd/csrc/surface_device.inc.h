@@ -95,6 +95,70 @@ int32_t pisces_hip_call_tiles_batched(PiscesHip* h, const PiscesTileBatch* batch
     });
 }
 
+// The launches of pisces_hip_call_tiles as one HIP graph (stream capture of the very launch path, so the graph holds what a plain call
+// would have launched: kernel form and geometry chosen by launch_call_tiles).
+int32_t pisces_hip_call_tiles_graph_build(PiscesHip* h, const PiscesTileBatch* batches, int32_t n_batches, int32_t* graph_id)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h || !graph_id) return PISCES_E_INVALID_ARG;
+    if (n_batches <= 0 || !batches) return fail(h, PISCES_E_INVALID_ARG, "call_tiles_graph_build: null batch list");
+    if (h->cfg.ploidy != PISCES_PLOIDY_SOMATIC || h->cfg.noise_model == PISCES_NOISE_WINDOW)
+        return fail(h, PISCES_E_STATE, "call_tiles_graph_build: the somatic, NoiseModel.Flat configuration only (see pisces_hip_call_tiles)");
+    for (int32_t i = 0; i < n_batches; i++) {
+        const PiscesTileBatch& b = batches[i];
+        if (b.n_tiles <= 0 || b.record_capacity < 0 || b.ref_length < 0 || !b.d_tiles || !b.d_ref_bases || !b.d_records || !b.d_tile_results)
+            return fail(h, PISCES_E_INVALID_ARG, "call_tiles_graph_build: bad batch");
+        if ((int64_t)b.record_capacity < (int64_t)b.n_tiles * kSlotsPerTile)
+            return fail(h, PISCES_E_BUFFER_TOO_SMALL, "call_tiles: the slot layout needs record_capacity >= 256 * n_tiles");
+    }
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    hipGraph_t graph = nullptr;
+    PISCES_HIP_CHECK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    hipError_t e = hipSuccess;
+    for (int32_t i = 0; i < n_batches && e == hipSuccess; i++) {
+        const PiscesTileBatch& b = batches[i];
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (h->timing > 0 && (h->launches_seen++ % h->timing) == 0 && h->ring_used < kTimingRing) {
+            const size_t slot = (size_t)h->ring_used;
+            e0 = h->ring[2 * slot];
+            e1 = h->ring[2 * slot + 1];
+            h->ring_used++;
+        }
+        // (event records of a capture become event-record nodes: the stamps are taken when the replay reaches them)
+        if (e0) e = hipEventRecord(e0, h->stream);
+        if (e == hipSuccess)
+            e = launch_call_tiles(h, h->stream, b.d_tuples, b.d_tiles, b.n_tiles, b.d_ref_bases, b.ref_start_position, b.ref_length, b.d_records,
+                                  b.d_tile_results);
+        if (e == hipSuccess && e1) e = hipEventRecord(e1, h->stream);
+    }
+    const hipError_t ec = hipStreamEndCapture(h->stream, &graph);
+    if (e == hipSuccess) e = ec;
+    if (e == hipSuccess) e = hipGetLastError();
+    hipGraphExec_t exec = nullptr;
+    if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return fail(h, PISCES_E_DEVICE, std::string("call_tiles_graph_build: ") + hipGetErrorString(e));
+    }
+    h->graph_defs.push_back(graph);
+    h->graphs.push_back(exec);
+    *graph_id = (int32_t)h->graphs.size() - 1;
+    return PISCES_OK;
+    });
+}
+
+int32_t pisces_hip_call_tiles_graph_launch(PiscesHip* h, int32_t graph_id, void* stream)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (graph_id < 0 || (size_t)graph_id >= h->graphs.size()) return fail(h, PISCES_E_INVALID_ARG, "call_tiles_graph_launch: no such graph");
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    PISCES_HIP_CHECK(h, hipGraphLaunch(h->graphs[(size_t)graph_id], stream ? (hipStream_t)stream : h->stream));
+    return PISCES_OK;
+    });
+}
+
 int32_t pisces_hip_compact_records(PiscesHip* h, const PiscesCalledAllele* d_records, const PiscesTileResult* d_tile_results,
                                    int32_t n_tiles, int32_t* d_offsets, PiscesCalledAllele* d_out, int32_t out_capacity,
                                    int32_t* d_count, void* stream)
@@ -157,6 +221,27 @@ int32_t pisces_hip_device_totals(PiscesHip* h, int64_t out[4], int32_t reset)
         for (int sh = 0; sh < kTotalShards; sh++) out[i] += (int64_t)host[sh * kTotalStride + i];
     }
     if (reset) PISCES_HIP_CHECK(h, hipMemset(h->d_totals.p, 0, host.size() * sizeof(unsigned long long)));
+    return PISCES_OK;
+    });
+}
+
+int32_t pisces_hip_mark(PiscesHip* h, int32_t which, void* stream)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h || which < 0 || which > 1) return PISCES_E_INVALID_ARG;
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    PISCES_HIP_CHECK(h, hipEventRecord(which ? h->ev1 : h->ev0, stream ? (hipStream_t)stream : h->stream));
+    return PISCES_OK;
+    });
+}
+
+int32_t pisces_hip_marked_ms(PiscesHip* h, float* ms)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h || !ms) return PISCES_E_INVALID_ARG;
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    PISCES_HIP_CHECK(h, hipEventSynchronize(h->ev1));
+    PISCES_HIP_CHECK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
     return PISCES_OK;
     });
 }

@@ -197,9 +197,16 @@ static hipError_t launch_call_tiles(PiscesHip* h, hipStream_t s, const uint32_t*
         // to ~8 k tiles per launch (56 % vs 49 % at 2048 tiles, 62 % vs 60 % at 8192); beyond that tiles interleave on their
         // own and one wave per tile (no spills, 12 tiles per CU) streams better (68.5 % vs 66 % at 15 625 tiles).
         const bool two = h->kernel_variant == 3 || (h->kernel_variant == 4 && (int64_t)n_tiles <= (int64_t)h->n_cus * 32);
-        if (!two)
+        // (without events the plain launch: it is what a stream capture records as a kernel node)
+        if (!two && !e0 && !e1)
+            hipLaunchKernelGGL(call_tiles_wave_kernel<1>, dim3((unsigned)n_tiles), dim3(64), lds, s, d_tuples, d_tiles, n_tiles, d_ref, ref_start, ref_len,
+                               d_records, d_tr, h->P, (const DeviceParams*)h->d_params.p);
+        else if (!two)
             hipExtLaunchKernelGGL(call_tiles_wave_kernel<1>, dim3((unsigned)n_tiles), dim3(64), lds, s, e0, e1, 0u, d_tuples, d_tiles,
                                   n_tiles, d_ref, ref_start, ref_len, d_records, d_tr, h->P, (const DeviceParams*)h->d_params.p);
+        else if (!e0 && !e1)
+            hipLaunchKernelGGL(call_tiles_wave_kernel<2>, dim3((unsigned)n_tiles), dim3(128), lds, s, d_tuples, d_tiles, n_tiles, d_ref, ref_start, ref_len,
+                               d_records, d_tr, h->P, (const DeviceParams*)h->d_params.p);
         else
             hipExtLaunchKernelGGL(call_tiles_wave_kernel<2>, dim3((unsigned)n_tiles), dim3(128), lds, s, e0, e1, 0u, d_tuples, d_tiles,
                                   n_tiles, d_ref, ref_start, ref_len, d_records, d_tr, h->P, (const DeviceParams*)h->d_params.p);

@@ -333,6 +333,19 @@ class HipVariantCaller:
             arr[i].d_ref_bases, arr[i].ref_length, arr[i].d_records, arr[i].d_tile_results, arr[i].record_capacity = rf, rl, rec, tr, cap
         _check(self._h, lib.pisces_hip_call_tiles_batched(self._h, arr, len(batches), stream))
 
+    def call_tiles_graph_build(self, batches):
+        """pisces_hip_call_tiles_graph_build: the launches of `batches` (as call_tiles_batched takes them), in order, as one HIP graph."""
+        arr = (_abi.PiscesTileBatch * max(len(batches), 1))()
+        for i, (tu, ti, n, rf, rs, rl, rec, cap, tr) in enumerate(batches):
+            arr[i].d_tuples, arr[i].d_tiles, arr[i].n_tiles, arr[i].ref_start_position = tu, ti, n, rs
+            arr[i].d_ref_bases, arr[i].ref_length, arr[i].d_records, arr[i].d_tile_results, arr[i].record_capacity = rf, rl, rec, tr, cap
+        gid = C.c_int32(-1)
+        _check(self._h, lib.pisces_hip_call_tiles_graph_build(self._h, arr, len(batches), C.byref(gid)))
+        return gid.value
+
+    def call_tiles_graph_launch(self, graph_id, stream=None):
+        _check(self._h, lib.pisces_hip_call_tiles_graph_launch(self._h, int(graph_id), stream))
+
     def compact_records(self, d_records, d_tile_results, n_tiles, d_offsets, d_out, out_capacity, d_count, stream=None):
         _check(self._h, lib.pisces_hip_compact_records(self._h, d_records, d_tile_results, n_tiles, d_offsets, d_out,
                                                        out_capacity, d_count, stream))
@@ -345,6 +358,15 @@ class HipVariantCaller:
         s = (C.c_int64 * 4)()
         _check(self._h, lib.pisces_hip_device_totals(self._h, s, 1 if reset else 0))
         return {"records": s[0], "candidate_loci": s[1], "called": s[2], "tiles": s[3]}
+
+    def mark(self, which, stream=None):
+        """pisces_hip_mark: an event on the launch stream in front of (0) / behind (1) a run of launches."""
+        _check(self._h, lib.pisces_hip_mark(self._h, int(which), stream))
+
+    def marked_ms(self):
+        ms = C.c_float(0)
+        _check(self._h, lib.pisces_hip_marked_ms(self._h, C.byref(ms)))
+        return ms.value
 
     def set_timing(self, enable=True):
         """enable = True / n > 0: time every launch / every n-th launch with HIP events; False / 0: off (default)."""
