@@ -404,9 +404,10 @@ class HipVariantCaller:
         return out[:total].tobytes(), blocks, ms.value
 
     def bam_decode(self, file_bytes, ref_id, min_map_quality=1, skip_duplicates=True, only_proper_pairs=False):
-        """Row f4: a BAM file (bytes) inflated and cut into records on the device; the alignments of reference sequence `ref_id` that
-        AlignmentSource.ShouldSkipRead keeps become a device-resident read batch.  Returns {reads, skipped, cigar_ops, bases}."""
-        data = np.frombuffer(bytes(file_bytes), dtype=np.uint8)
+        """Row f4: a BAM file (bytes, or the array bam_stage returned) inflated and cut into records on the device; the alignments of
+        reference sequence `ref_id` that AlignmentSource.ShouldSkipRead keeps become a device-resident read batch.  Returns {reads,
+        skipped, cigar_ops, bases}."""
+        data = file_bytes if isinstance(file_bytes, np.ndarray) else np.frombuffer(bytes(file_bytes), dtype=np.uint8)
         blocks, _ = bgzf_scan(data)
         counts = (C.c_int64 * 4)()
         _check(self._h, lib.pisces_hip_bam_decode(self._h, data.ctypes.data, data.size, blocks, len(blocks), int(ref_id), int(min_map_quality),
