@@ -186,24 +186,54 @@ namespace Pisces.Hip
         /// IAlleleCaller.Call: pisces_hip_flush_ex, growing the buffers on PISCES_E_BUFFER_TOO_SMALL (the batch stays intact until it fits)
         public SortedList<int, List<CalledAllele>> Flush(int? upToPosition, ChrReference chr)
         {
-            var result = new SortedList<int, List<CalledAllele>>();
             int upTo = upToPosition ?? -1;
-            if (upToPosition.HasValue && BlocksPerFlush > 1)
-            {
-                int block = (upTo - 1) / _cfg.BlockSize;
-                if (block < _lastFlushedBlock + BlocksPerFlush) return result;
-                _lastFlushedBlock = block;
-            }
-            var recs = new PiscesCalledAllele[1 << 14]; var idx = new int[recs.Length];
-            var cands = new PiscesCandidate[1 << 10]; var pool = new byte[1 << 16];
+            if (HeldBack(upToPosition)) return new SortedList<int, List<CalledAllele>>();
+            return Take(chr, (PiscesCalledAllele[] recs, out long n, int[] idx, PiscesCandidate[] cands, out long nc, byte[] pool, out long nb) =>
+                NativeMethods.pisces_hip_flush_ex(_h, upTo, recs, recs.LongLength, out n, idx, cands, cands.LongLength, out nc, pool, pool.LongLength, out nb));
+        }
+
+        /// The flush as a pair (pisces_hip_flush_begin / pisces_hip_flush_end_ex): FlushBegin enqueues the device work of the batch and
+        /// commits DoneProcessing; the host goes on staging the reads of the next block; FlushEnd hands over the alleles.  False when the
+        /// flush is held back (BlocksPerFlush) and nothing was begun.
+        public bool FlushBegin(int? upToPosition)
+        {
+            if (HeldBack(upToPosition)) return false;
+            NativeMethods.Check(_h, NativeMethods.pisces_hip_flush_begin(_h, upToPosition ?? -1));
+            return true;
+        }
+
+        public SortedList<int, List<CalledAllele>> FlushEnd(ChrReference chr)
+        {
+            return Take(chr, (PiscesCalledAllele[] recs, out long n, int[] idx, PiscesCandidate[] cands, out long nc, byte[] pool, out long nb) =>
+                NativeMethods.pisces_hip_flush_end_ex(_h, recs, recs.LongLength, out n, idx, cands, cands.LongLength, out nc, pool, pool.LongLength, out nb));
+        }
+
+        private bool HeldBack(int? upToPosition)
+        {
+            if (!upToPosition.HasValue || BlocksPerFlush <= 1) return false;
+            int block = (upToPosition.Value - 1) / _cfg.BlockSize;
+            if (block < _lastFlushedBlock + BlocksPerFlush) return true;
+            _lastFlushedBlock = block;
+            return false;
+        }
+
+        private delegate int FlushEntry(PiscesCalledAllele[] recs, out long n, int[] idx, PiscesCandidate[] cands, out long nc, byte[] pool, out long nb);
+        // the output buffers live with the engine: a block's worth of rows is a few hundred KB, and the flush is called once per block
+        private PiscesCalledAllele[] _recs = new PiscesCalledAllele[1 << 14]; private int[] _idx = new int[1 << 14];
+        private PiscesCandidate[] _cands = new PiscesCandidate[1 << 10]; private byte[] _pool = new byte[1 << 16];
+
+        private SortedList<int, List<CalledAllele>> Take(ChrReference chr, FlushEntry entry)
+        {
+            var result = new SortedList<int, List<CalledAllele>>();
             long n, nc, nb; int rc;
-            while ((rc = NativeMethods.pisces_hip_flush_ex(_h, upTo, recs, recs.LongLength, out n, idx, cands, cands.LongLength, out nc, pool, pool.LongLength, out nb)) == -2)
+            while ((rc = entry(_recs, out n, _idx, _cands, out nc, _pool, out nb)) == -2)
             {
-                if (n > recs.LongLength) { recs = new PiscesCalledAllele[n + n / 2]; idx = new int[recs.Length]; }
-                if (nc > cands.LongLength) cands = new PiscesCandidate[nc + nc / 2];
-                if (nb > pool.LongLength) pool = new byte[nb + nb / 2];
+                if (n > _recs.LongLength) { _recs = new PiscesCalledAllele[n + n / 2]; _idx = new int[_recs.Length]; }
+                if (nc > _cands.LongLength) _cands = new PiscesCandidate[nc + nc / 2];
+                if (nb > _pool.LongLength) _pool = new byte[nb + nb / 2];
             }
             NativeMethods.Check(_h, rc);
+            var recs = _recs; var idx = _idx; var cands = _cands; var pool = _pool;
             const string baseOf = "AGCTND";
             for (long i = 0; i < n; i++)
             {
@@ -299,6 +329,39 @@ namespace Pisces.Hip
             NativeMethods.Check(_h, NativeMethods.pisces_hip_add_gapped_mnv_ref(_h, p, c, p.Length));
         }
 
+        /// The BAM surface: one chromosome's records from the compressed file bytes to counts and candidates without the reads leaving
+        /// the device (pisces_hip_bgzf_scan -> pisces_hip_bam_decode -> pisces_hip_add_decoded_reads).  What AlignmentSource + BamReader +
+        /// the AddAlleleCounts loop do per read (AlignmentsSource.cs:33-92, BamReader.cs:287-420, SmallVariantCaller.cs:88-98) for a whole
+        /// batch; returns {records of the chromosome, reads kept, bases, CIGAR operations}.  `file` = a run of whole BGZF blocks (the
+        /// blocks of one chromosome from the .bai's chunk list, or the file).
+        public long[] AddBamBlocks(byte[] file, int refId, ChrReference chrReference, int minMapQuality, bool skipDuplicates, bool onlyProperPairs)
+        {
+            if (!_referenceSet && chrReference != null)
+            {
+                var bytes = Encoding.ASCII.GetBytes(chrReference.Sequence);
+                NativeMethods.Check(_h, NativeMethods.pisces_hip_set_reference(_h, bytes, bytes.LongLength));
+                _referenceSet = true;
+            }
+            long inflated;
+            long nBlocks = NativeMethods.pisces_hip_bgzf_scan(file, file.LongLength, null, 0, out inflated);   // the count; fills at most `capacity` entries
+            if (nBlocks < 0) throw new System.IO.InvalidDataException("not a chain of BGZF blocks (" + nBlocks + ")");   // BamReader.ReadBlock's InvalidDataException
+            var blocks = new PiscesBgzfBlock[Math.Max(1, nBlocks)];
+            nBlocks = NativeMethods.pisces_hip_bgzf_scan(file, file.LongLength, blocks, blocks.LongLength, out inflated);
+            var counts = new long[4];
+            NativeMethods.Check(_h, NativeMethods.pisces_hip_bam_decode(_h, file, file.LongLength, blocks, nBlocks, refId, minMapQuality, skipDuplicates ? 1 : 0, onlyProperPairs ? 1 : 0, counts));
+            NativeMethods.Check(_h, NativeMethods.pisces_hip_add_decoded_reads(_h));
+            return counts;
+        }
+
+        /// one interval shard of a chromosome: calls and totals only inside [lo, hi] (the reads of the halo still feed the counts)
+        public void SetOwnedRange(int lo, int hi) { NativeMethods.Check(_h, NativeMethods.pisces_hip_set_owned_range(_h, lo, hi)); }
+
+        /// host seconds spent inside the library: {adding reads, flushes, of those waiting for the device, number of flushes}
+        public double[] HostTime(bool reset = false) { var t = new double[4]; NativeMethods.Check(_h, NativeMethods.pisces_hip_host_time(_h, t, reset ? 1 : 0)); return t; }
+
+        public static int DeviceCount() { int n = NativeMethods.pisces_hip_device_count(); if (n <= 0) throw new Exception("libpisceship: no HIP device (" + n + ")"); return n; }
+
+        /// {allelesCalled, variantsCollapsed, readsProcessed, readsSkipped}
         public long[] Stats() { var s = new long[4]; NativeMethods.Check(_h, NativeMethods.pisces_hip_stats(_h, s)); return s; }
 
         public void Dispose() { if (_h != IntPtr.Zero) { NativeMethods.pisces_hip_destroy(_h); _h = IntPtr.Zero; } }

@@ -21,6 +21,15 @@ namespace Pisces.Hip
 
         public HipFactory(PiscesApplicationOptions options) : base(options) { }
 
+        private static int _jobsMade = -1;   // across the factory instances of the process (one per BAM, Program.cs:39)
+        private static int NextDevice()
+        {
+            var pinned = Environment.GetEnvironmentVariable("PISCES_HIP_DEVICE");
+            int device;
+            if (!string.IsNullOrEmpty(pinned) && int.TryParse(pinned, out device)) return device;
+            return (int)((uint)System.Threading.Interlocked.Increment(ref _jobsMade) % (uint)HipEngine.DeviceCount());
+        }
+
         // Candidates are found by the library itself, on the device, from the reads handed to pisces_hip_add_reads (find_emit_kernel):
         // insertions / deletions always, SNV / MNV candidates of the M walk when CallMNVs is set (PiscesHipConfig.call_mnvs); with it off SNV
         // candidates are implied by the device counts.  No managed finder runs: a finder that yields nothing keeps SmallVariantCaller's loop unchanged.
@@ -29,7 +38,10 @@ namespace Pisces.Hip
         protected override IStateManager CreateStateManager(ChrIntervalSet intervalSet, bool expectStitchedReads = false,
             bool expectCollapsedReads = true)
         {
-            _engine = new HipEngine(HipEngine.ConfigFrom(_options, expectStitchedReads, intervalSet != null), device: 0);
+            // one handle per (BAM, chromosome) job.  With -threadbychr the jobs of a BAM run on a thread pool (BaseGenomeProcessor.cs:40-90,
+            // JobManager.cs:70-73): job j takes device j % count, so that the jobs spread over the GPUs of the node (each handle owns its
+            // own HIP stream and buffers; handles share nothing).  PISCES_HIP_DEVICE pins one device (a process per GPU, as bench.py runs).
+            _engine = new HipEngine(HipEngine.ConfigFrom(_options, expectStitchedReads, intervalSet != null), NextDevice());
             if (intervalSet != null) _engine.SetIntervals(intervalSet);
             _engine.SetForcedAlleles(_forcedGtAlleles);   // -forcedalleles: ForcedReport rows, reference rows at forced positions
             return new HipStateManager(_engine);
@@ -39,7 +51,8 @@ namespace Pisces.Hip
             IAlignmentSource alignmentSource, HashSet<Tuple<string, int, string, string>> forceGtAlleles = null)
         {
             _forcedGtAlleles = forceGtAlleles;
-            return new HipAlleleCaller(() => _engine, chrReference);
+            // the flush as a pair unless PISCES_HIP_SYNC_FLUSH is set: the device calls block k while the managed side stages block k + 1
+            return new HipAlleleCaller(() => _engine, chrReference, Environment.GetEnvironmentVariable("PISCES_HIP_SYNC_FLUSH") == null);
         }
     }
 
@@ -93,16 +106,36 @@ namespace Pisces.Hip
         public bool ExpectStitchedReads { get { return _e.ExpectStitchedReads; } }
     }
 
-    /// IAlleleCaller: Call(batch, source) = pisces_hip_flush_ex(upTo) -> PiscesCalledAllele[] (+ the allele strings of the called
+    /// IAlleleCaller: Call(batch, source) = the native flush of upTo -> PiscesCalledAllele[] (+ the allele strings of the called
     /// insertions / deletions) -> CalledAllele objects in a SortedList<int, List<CalledAllele>> (already sorted by position, then
     /// ref/alt).  No managed VariantCollapser is passed down: PiscesHipConfig.Collapse = options.Collapse does it natively.
+    ///
+    /// Pipelined (the default): Call(k) begins the flush of batch k (pisces_hip_flush_begin: the device work is enqueued, DoneProcessing
+    /// committed) and returns the alleles of batch k - 1 (pisces_hip_flush_end_ex), so the device works on block k while
+    /// SmallVariantCaller's loop reads and stages the reads of block k + 1 (SmallVariantCaller.cs:88-104).  The final Call(null) returns
+    /// what is outstanding and its own batch.  The VCF writer sees the same alleles in the same order (batches are disjoint, ascending
+    /// runs of positions; SmallVariantCaller.cs:170-178 writes whatever Call returns), one block later.
     public class HipAlleleCaller : IAlleleCaller
     {
-        private readonly Func<HipEngine> _engine; private readonly ChrReference _chr;
-        public HipAlleleCaller(Func<HipEngine> engine, ChrReference chr) { _engine = engine; _chr = chr; }
+        private readonly Func<HipEngine> _engine; private readonly ChrReference _chr; private readonly bool _pipelined;
+        private bool _inFlight;
+        public HipAlleleCaller(Func<HipEngine> engine, ChrReference chr, bool pipelined = true) { _engine = engine; _chr = chr; _pipelined = pipelined; }
         public int TotalNumCollapsed { get { return (int)_engine().Stats()[1]; } }   // the library collapses insertion / deletion candidates (PiscesHipConfig.Collapse)
-        public int TotalNumCalled { get { return (int)_engine().Stats()[0]; } }
+        public int TotalNumCalled { get { return (int)_engine().Stats()[0]; } }      // (read after the final Call: nothing is in flight then)
         public SortedList<int, List<CalledAllele>> Call(ICandidateBatch batch, IAlleleSource source)
-        { return _engine().Flush(((HipBatch)batch).UpToPosition, _chr); }
+        {
+            var upTo = ((HipBatch)batch).UpToPosition;
+            var e = _engine();
+            if (!_pipelined) return e.Flush(upTo, _chr);
+            var ready = _inFlight ? e.FlushEnd(_chr) : new SortedList<int, List<CalledAllele>>();
+            _inFlight = false;
+            if (upTo.HasValue) { _inFlight = e.FlushBegin(upTo); return ready; }
+            foreach (var kv in e.Flush(null, _chr))              // the last batch: positions above everything returned so far
+            {
+                List<CalledAllele> at;
+                if (ready.TryGetValue(kv.Key, out at)) at.AddRange(kv.Value); else ready.Add(kv.Key, kv.Value);
+            }
+            return ready;
+        }
     }
 }

@@ -92,6 +92,10 @@ namespace Pisces.Hip
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_default_config(out PiscesHipConfig cfg);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_create(ref PiscesHipConfig cfg, int device, out IntPtr handle);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_destroy(IntPtr handle);
+        /// the HIP devices of this process; job j of a -threadbychr run takes device j % count (HipFactory)
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_device_count();
+        /// the positions this handle reports calls and totals for, when it is one interval shard of a chromosome (halo reads beyond it only feed the counts)
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_set_owned_range(IntPtr handle, int lo, int hi);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern IntPtr pisces_hip_last_error(IntPtr handle);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_set_reference(IntPtr handle, byte[] upperBases, long length);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_set_intervals(IntPtr handle, int[] starts, int[] ends, int n);
@@ -103,6 +107,8 @@ namespace Pisces.Hip
         /// returned; the next reads may be staged and added in between (the device works on block k while the host marshals block k + 1)
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_flush_begin(IntPtr handle, int upToPosition);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_flush_end(IntPtr handle, [Out] PiscesCalledAllele[] output, long capacity, out long nOut);
+        /// flush_end with pisces_hip_flush_ex's candidate outputs (what a host that writes VCF rows takes the allele strings from)
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_flush_end_ex(IntPtr handle, [Out] PiscesCalledAllele[] output, long capacity, out long nOut, [Out] int[] candIndex, [Out] PiscesCandidate[] cands, long candCapacity, out long nCand, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_flush_ex(IntPtr handle, int upToPosition, [Out] PiscesCalledAllele[] output, long capacity, out long nOut, [Out] int[] candIndex, [Out] PiscesCandidate[] cands, long candCapacity, out long nCand, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_get_candidates(IntPtr handle, int upToPosition, [Out] PiscesCandidate[] cands, long capacity, out long nOut, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_add_candidates(IntPtr handle, PiscesCandidate[] cands, long n, byte[] alleles, long alleleBytes);
@@ -128,11 +134,37 @@ namespace Pisces.Hip
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_comm_init(IntPtr handle, byte[] id128, int rank, int world);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_reduce_summary(IntPtr handle, [In, Out] long[] totals4);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_comm_destroy(IntPtr handle);
+        /// {allelesCalled, variantsCollapsed, readsProcessed, readsSkipped} (SmallVariantCaller.cs:114-115, AlignmentsSource.cs:63)
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_stats(IntPtr handle, [Out] long[] stats4);
+        /// host seconds inside the library: {add_reads / add_decoded_reads, flushes, of those waiting for the device, flushes counted}
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_host_time(IntPtr handle, [Out] double[] out4, int reset);
+
+        // the BAM surface: BamReader.GetNextAlignment + AlignmentSource's filters + Read construction for one chromosome's records
+        // (src/lib/Alignment.IO/Sequencing/BamReader.cs:287-420, Pisces.Processing/Logic/AlignmentsSource.cs:33-92), on the device, from the
+        // compressed file bytes.  counts4 = {records of the chromosome, reads kept, bases, CIGAR operations}.
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_bam_decode(IntPtr handle, byte[] file, long nBytes, PiscesBgzfBlock[] blocks, long nBlocks, int refId, int minMapQuality, int skipDuplicates, int onlyProperPairs, [Out] long[] counts4);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_bam_decode(IntPtr handle, IntPtr file, long nBytes, PiscesBgzfBlock[] blocks, long nBlocks, int refId, int minMapQuality, int skipDuplicates, int onlyProperPairs, [Out] long[] counts4);   // (a memory-mapped file)
+        /// the decoded batch to the host, array by array (any may be null): for hosts that want the Read objects as well
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_bam_fetch(IntPtr handle, [Out] int[] position, [Out] byte[] flags, [Out] int[] cigarOffset, [Out] byte[] cigarOp, [Out] uint[] cigarLen, [Out] int[] seqOffset, [Out] byte[] bases, [Out] byte[] quals);
+        /// 1: the batch has stitched reads (XD tags) and their per-base / per-deletion directions were copied out; 0: none
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_bam_fetch_directions(IntPtr handle, [Out] byte[] directions, [Out] byte[] deletionDirections);
+        /// IStateManager.AddAlleleCounts + the candidate finder for every read of the decoded batch, without the reads leaving the device
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_add_decoded_reads(IntPtr handle);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_bam_chain_mode(IntPtr handle);
 
         // measurement helpers (bench / diagnostics)
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_set_timing(IntPtr handle, int everyNth);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_last_kernel_ms(IntPtr handle, out float ms);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_kernel_time(IntPtr handle, out double totalMs, out long launches);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_mark(IntPtr handle, int which, IntPtr stream);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_marked_ms(IntPtr handle, out float ms);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_balanced_tile_loci(IntPtr handle, long nLoci);
+        // a run of call_tiles launches captured once (hipGraph) and replayed
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_call_tiles_graph_build(IntPtr handle, PiscesTileBatch[] batches, int nBatches, out int graphId);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_call_tiles_graph_launch(IntPtr handle, int graphId, IntPtr stream);
+        // observations a host expanded itself (pisces_hip_expand_reads is the host-side walk of RegionStateManager.AddAlleleCounts)
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_add_observations(IntPtr handle, int[] positions, uint[] tuples, long n);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern long pisces_hip_expand_reads(ref PiscesReadBatch batch, int minBaseCallQuality, [Out] int[] positions, [Out] uint[] tuples, long capacity);
         // BGZF: the batched counterpart of Common.IO.SafeNativeMethods.UncompressBlock (FileCompression.cs:14-16)
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern long pisces_hip_bgzf_scan(byte[] file, long nBytes, [Out] PiscesBgzfBlock[] blocks, long capacity, out long inflatedBytes);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_bgzf_inflate(IntPtr handle, byte[] file, long nBytes, PiscesBgzfBlock[] blocks, long nBlocks, [Out] byte[] output, long outCapacity, int checkCrc, out float kernelMs);

@@ -258,6 +258,10 @@ int32_t pisces_hip_default_config(PiscesHipConfig* cfg);
 /* Factory.CreateStateManager / CreateVariantCaller / CreateVariantFinder (Factory.cs:123,128,209):
  * one handle per (BAM, chromosome) job; owns one HIP stream; no global mutable state. */
 int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip** out);
+/* The number of HIP devices this process sees (what `device` above ranges over), or PISCES_E_DEVICE.  With -threadbychr the reference
+ * runs its (BAM, chromosome) jobs on a thread pool (src/lib/Pisces.Processing/Logic/BaseGenomeProcessor.cs:40-90, JobManager.cs:70-73):
+ * a host gives job j the device j % count, handles on different devices share nothing. */
+int32_t pisces_hip_device_count(void);
 int32_t pisces_hip_destroy(PiscesHip* h);
 const char* pisces_hip_last_error(const PiscesHip* h);   /* h may be NULL: message of the last failed create */
 int32_t pisces_hip_abi_version(void);
@@ -324,10 +328,14 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
  * pisces_hip_add_decoded_reads) and read counts; pisces_hip_flush[_ex] and another pisces_hip_flush_begin return PISCES_E_STATE
  * until flush_end has been called.  A batch that needs the host between its device passes (insertion / deletion / MNV candidates,
  * forced alleles, the diploid / haploid genotypers, NoiseModel.Window, gapped-MNV reference counts) is flushed synchronously inside
- * flush_begin; flush_end returns it all the same (records only: use pisces_hip_flush_ex where the candidates' allele strings are
- * needed). */
+ * flush_begin; flush_end returns it all the same (pisces_hip_flush_end_ex: with the candidates' allele strings). */
 int32_t pisces_hip_flush_begin(PiscesHip* h, int32_t up_to_position);
 int32_t pisces_hip_flush_end(PiscesHip* h, PiscesCalledAllele* out, int64_t capacity, int64_t* n_out);
+/* pisces_hip_flush_end with pisces_hip_flush_ex's candidate outputs (same meaning, same PISCES_E_BUFFER_TOO_SMALL protocol: all three
+ * counts are reported, repeat with larger buffers).  A flush that needed no host-side candidates returns cand_index -1 everywhere. */
+int32_t pisces_hip_flush_end_ex(PiscesHip* h, PiscesCalledAllele* out, int64_t capacity, int64_t* n_out, int32_t* cand_index_out,
+                                PiscesCandidate* cand_out, int64_t cand_capacity, int64_t* n_cand, uint8_t* alleles_out,
+                                int64_t allele_capacity, int64_t* allele_bytes);
 /* IAlleleSource.GetAlleleCount for a run of positions: out[n][6][3][11] int32
  * (RegionState.cs:57); blocks never touched read as zero (RegionStateManager.cs:222-226). */
 int32_t pisces_hip_get_counts(PiscesHip* h, int32_t start_position, int32_t n, int32_t* out);

@@ -243,6 +243,10 @@ struct PiscesHip {
         const PiscesCalledAllele* data = nullptr;   // state 2: the results
         size_t n = 0;
         std::vector<PiscesCalledAllele> owned; // state 2, when the flush had to run synchronously (host-side candidates, genotypers, ...)
+        std::vector<int32_t> owned_index;      // ... and what pisces_hip_flush_ex returns beside the records (pisces_hip_flush_end_ex)
+        std::vector<PiscesCandidate> owned_cands;
+        std::vector<uint8_t> owned_alleles;
+        size_t n_cands = 0, n_allele_bytes = 0;
     } async;
     int64_t log_known_holes = 0;             // slots of the log that the last asynchronous drop left as holes (0 after any other drop)
     size_t staged_total = 0;                 // bytes pisces_hip_stage_reads laid out in the current staging buffer (0: nothing staged)
@@ -536,6 +540,14 @@ int32_t pisces_hip_default_config(PiscesHipConfig* c)
 }
 
 int32_t pisces_hip_destroy(PiscesHip* h);
+
+int32_t pisces_hip_device_count(void)
+{
+    int ndev = 0;
+    const hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess) { g_create_error = std::string("pisces_hip_device_count: ") + hipGetErrorString(e); return PISCES_E_DEVICE; }
+    return ndev;
+}
 
 int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip** out)
 {

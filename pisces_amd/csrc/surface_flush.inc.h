@@ -1312,14 +1312,26 @@ int32_t pisces_hip_flush_begin(PiscesHip* h, int32_t up_to_position)
         if (std::binary_search(keys.begin(), keys.end(), block_key(h, kv.first))) { plain = false; break; }
     if (!plain) {
         // the synchronous flush, its alleles kept for pisces_hip_flush_end
+        // (with the candidates of its insertion / deletion / MNV rows and their allele strings, for pisces_hip_flush_end_ex)
         A.owned.resize(std::max<size_t>(A.owned.size(), 1024));
+        A.owned_index.resize(A.owned.size());
+        A.owned_cands.resize(std::max<size_t>(A.owned_cands.size(), 64));
+        A.owned_alleles.resize(std::max<size_t>(A.owned_alleles.size(), 4096));
         for (;;) {
-            int64_t n = 0;
-            const int32_t rc = pisces_hip_flush_ex(h, up_to_position, A.owned.data(), (int64_t)A.owned.size(), &n, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr);
-            if (rc == PISCES_E_BUFFER_TOO_SMALL) { A.owned.resize((size_t)n); continue; }
+            int64_t n = 0, nc = 0, nb = 0;
+            const int32_t rc = pisces_hip_flush_ex(h, up_to_position, A.owned.data(), (int64_t)A.owned.size(), &n, A.owned_index.data(), A.owned_cands.data(),
+                                                   (int64_t)A.owned_cands.size(), &nc, A.owned_alleles.data(), (int64_t)A.owned_alleles.size(), &nb);
+            if (rc == PISCES_E_BUFFER_TOO_SMALL) {
+                if ((size_t)n > A.owned.size()) { A.owned.resize((size_t)n); A.owned_index.resize((size_t)n); }
+                if ((size_t)nc > A.owned_cands.size()) A.owned_cands.resize((size_t)nc);
+                if ((size_t)nb > A.owned_alleles.size()) A.owned_alleles.resize((size_t)nb);
+                continue;
+            }
             if (rc) return rc;
             A.data = A.owned.data();
             A.n = (size_t)n;
+            A.n_cands = (size_t)nc;
+            A.n_allele_bytes = (size_t)nb;
             break;
         }
         A.state = 2;
@@ -1367,10 +1379,22 @@ int32_t pisces_hip_flush_begin(PiscesHip* h, int32_t up_to_position)
 
 int32_t pisces_hip_flush_end(PiscesHip* h, PiscesCalledAllele* out, int64_t capacity, int64_t* n_out)
 {
+    return pisces_hip_flush_end_ex(h, out, capacity, n_out, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr);
+}
+
+// flush_end with what pisces_hip_flush_ex returns beside the records: the candidate of every insertion / deletion / MNV row and the
+// allele strings.  A flush that ran on the device alone has none (every row is a Reference or SNV row: cand_index -1).
+int32_t pisces_hip_flush_end_ex(PiscesHip* h, PiscesCalledAllele* out, int64_t capacity, int64_t* n_out, int32_t* cand_index_out, PiscesCandidate* cand_out,
+                                int64_t cand_capacity, int64_t* n_cand, uint8_t* alleles_out, int64_t allele_capacity, int64_t* allele_bytes)
+{
     return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (!n_out || capacity < 0 || (capacity > 0 && !out)) return fail(h, PISCES_E_INVALID_ARG, "flush_end: null output");
+    if (cand_capacity < 0 || allele_capacity < 0 || (cand_capacity > 0 && !cand_out) || (allele_capacity > 0 && !alleles_out))
+        return fail(h, PISCES_E_INVALID_ARG, "flush_end_ex: null candidate output");
     *n_out = 0;
+    if (n_cand) *n_cand = 0;
+    if (allele_bytes) *allele_bytes = 0;
     auto& A = h->async;
     if (A.state == 0) return fail(h, PISCES_E_STATE, "flush_end: no pisces_hip_flush_begin before it");
     HostTimer timer(&h->host_time[1]);
@@ -1392,15 +1416,30 @@ int32_t pisces_hip_flush_end(PiscesHip* h, PiscesCalledAllele* out, int64_t capa
         A.n = (size_t)total;
         A.state = 2;
     }
-    if ((int64_t)A.n > capacity) {
+    const bool want_cands = cand_out || alleles_out || n_cand || allele_bytes;
+    if ((int64_t)A.n > capacity || (want_cands && ((int64_t)A.n_cands > cand_capacity || (int64_t)A.n_allele_bytes > allele_capacity))) {
         *n_out = (int64_t)A.n;
+        if (n_cand) *n_cand = (int64_t)A.n_cands;
+        if (allele_bytes) *allele_bytes = (int64_t)A.n_allele_bytes;
         return fail(h, PISCES_E_BUFFER_TOO_SMALL, "flush_end: output buffer too small");
     }
     if (A.n) std::memcpy(out, A.data, A.n * sizeof(PiscesCalledAllele));
+    if (cand_index_out) {
+        if (A.n_cands || A.data == A.owned.data()) { if (A.n) std::memcpy(cand_index_out, A.owned_index.data(), A.n * sizeof(int32_t)); }
+        else std::fill(cand_index_out, cand_index_out + A.n, -1);
+    }
+    if (want_cands) {
+        if (A.n_cands) std::memcpy(cand_out, A.owned_cands.data(), A.n_cands * sizeof(PiscesCandidate));
+        if (A.n_allele_bytes) std::memcpy(alleles_out, A.owned_alleles.data(), A.n_allele_bytes);
+        if (n_cand) *n_cand = (int64_t)A.n_cands;
+        if (allele_bytes) *allele_bytes = (int64_t)A.n_allele_bytes;
+    }
     *n_out = (int64_t)A.n;
     A.state = 0;
     A.data = nullptr;
     A.n = 0;
+    A.n_cands = 0;
+    A.n_allele_bytes = 0;
     return PISCES_OK;
     });
 }

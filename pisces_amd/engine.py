@@ -187,6 +187,14 @@ class HipVariantCaller:
         """Call() that also returns the (ref, alt) allele strings of every row: Reference / SNV rows from the record's
         base codes, insertion / deletion rows from the candidate the library found (pisces_hip_flush_ex)."""
         up_to = -1 if upToPosition is None else int(upToPosition)
+        return self._rows_with_alleles(lambda *outputs: lib.pisces_hip_flush_ex(self._h, up_to, *outputs), capacity)
+
+    def CallEndWithAlleles(self, capacity=1 << 16):
+        """CallEnd() with the allele strings (pisces_hip_flush_end_ex): what CallWithAlleles would have returned for the flush
+        CallBegin started."""
+        return self._rows_with_alleles(lambda *outputs: lib.pisces_hip_flush_end_ex(self._h, *outputs), capacity)
+
+    def _rows_with_alleles(self, entry, capacity):
         cand_cap, pool_cap = 1024, 1 << 16
         while True:
             out = np.zeros(capacity, dtype=_abi.CALLED_ALLELE_DTYPE)
@@ -194,8 +202,7 @@ class HipVariantCaller:
             cands = (_abi.PiscesCandidate * cand_cap)()
             pool = np.zeros(pool_cap, dtype=np.uint8)
             n, nc, nb = C.c_int64(0), C.c_int64(0), C.c_int64(0)
-            rc = lib.pisces_hip_flush_ex(self._h, up_to, out.ctypes.data, capacity, C.byref(n), idx.ctypes.data, cands, cand_cap,
-                                         C.byref(nc), pool.ctypes.data, pool_cap, C.byref(nb))
+            rc = entry(out.ctypes.data, capacity, C.byref(n), idx.ctypes.data, cands, cand_cap, C.byref(nc), pool.ctypes.data, pool_cap, C.byref(nb))
             if rc == _abi.E_BUFFER_TOO_SMALL:
                 capacity = max(capacity, int(n.value))
                 cand_cap = max(cand_cap, int(nc.value))
@@ -439,6 +446,14 @@ class HipVariantCaller:
     def AddDecodedReads(self):
         """AddAlleleCounts + FindCandidates for the batch bam_decode left on the device (bases and qualities never come back)."""
         _check(self._h, lib.pisces_hip_add_decoded_reads(self._h))
+
+
+def device_count():
+    """pisces_hip_device_count: the HIP devices of this process (a -threadbychr host gives job j the device j % count)."""
+    n = lib.pisces_hip_device_count()
+    if n < 0:
+        raise PiscesHipError(n, "pisces_hip_device_count: no HIP runtime / device")
+    return int(n)
 
 
 def anchor_adjusted_count(c, minAnchor=0, maxAnchor=None, fromEnd=False, symmetric=False):

@@ -27,6 +27,30 @@ def test_library_exports_every_declared_symbol():
     assert _native.lib.pisces_hip_abi_version() == _abi.ABI_VERSION
 
 
+def _split_args(arglist):
+    arglist = arglist.strip()
+    return [] if arglist in ("", "void") else [a.strip() for a in arglist.split(",")]
+
+
+def test_managed_bindings_cover_the_header():
+    """dotnet/NativeMethods.cs (the [DllImport]s a maintainer of the reference adds) cannot be compiled in this image: keep it
+    honest against the header at least -- every declared entry bound, with as many arguments as the C declaration has."""
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "pisces_hip.h")).read(), flags=re.S)
+    c_args = {m.group(1): len(_split_args(m.group(2))) for m in re.finditer(r"\b(pisces_hip_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S)}
+    assert sorted(c_args) == _declared_functions()
+    cs = open(os.path.join(ROOT, "dotnet", "NativeMethods.cs")).read()
+    cs = re.sub(r"//[^\n]*", "", cs)
+    bound = {}
+    for m in re.finditer(r"\[DllImport\(Lib[^\]]*\)\]\s*public static extern \w+ (pisces_hip_[a-z0-9_]+)\(([^;]*)\);", cs):
+        args = re.sub(r"\[[^\]]*\]", "", m.group(2))   # [Out], [MarshalAs(...)]
+        bound.setdefault(m.group(1), set()).add(len(_split_args(args)))
+    missing = sorted(set(c_args) - set(bound))
+    assert not missing, f"declared in include/pisces_hip.h, no [DllImport] in dotnet/NativeMethods.cs: {missing}"
+    assert not set(bound) - set(c_args), f"[DllImport]s of entries the header does not declare: {sorted(set(bound) - set(c_args))}"
+    for name, counts in bound.items():   # (overloads bind one entry twice: byte[] and IntPtr for the file bytes)
+        assert counts == {c_args[name]}, f"{name}: {c_args[name]} arguments in the header, {sorted(counts)} in NativeMethods.cs"
+
+
 def test_struct_layouts_match_header():
     assert _abi.CALLED_ALLELE_DTYPE.itemsize == 64
     assert _abi.TILE_DTYPE.itemsize == 24 and _abi.TILE_RESULT_DTYPE.itemsize == 48

@@ -1911,3 +1911,31 @@ def test_flush_pair_gives_what_flush_gives_while_the_next_reads_are_added(torch_
         pair_way = c.CallEnd().copy()
     assert len(plain_way) > 0 and pair_way.tobytes() == plain_way.tobytes()
     assert any(_abi.info_category(int(r["info"])) == _abi.CAT_DELETION for r in plain_way)
+    # ... and with the allele strings (pisces_hip_flush_end_ex = pisces_hip_flush_ex): what a host that writes VCF rows needs
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(refb)
+        c.AddAlleleCounts(reads)
+        plain_recs, plain_alleles = c.CallWithAlleles(None)
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(refb)
+        c.AddAlleleCounts(reads)
+        c.CallBegin(None)
+        pair_recs, pair_alleles = c.CallEndWithAlleles(capacity=8)   # (too small on purpose: the counts come back and the call repeats)
+    assert pair_recs.tobytes() == plain_recs.tobytes() and pair_alleles == plain_alleles
+    assert any(len(r) == 5 and len(a) == 1 for r, a in pair_alleles)   # the 4-base deletion's strings
+    # a flush that ran on the device alone: every row's alleles come from its base codes
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(refb)
+        c.AddAlleleCounts([r for r in reads if len(r["cigar"]) == 1])
+        c.CallBegin(None)
+        pair_recs, pair_alleles = c.CallEndWithAlleles()
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(refb)
+        c.AddAlleleCounts([r for r in reads if len(r["cigar"]) == 1])
+        plain_recs, plain_alleles = c.CallWithAlleles(None)
+    assert len(pair_recs) > 0 and pair_recs.tobytes() == plain_recs.tobytes() and pair_alleles == plain_alleles
+
+
+@pytest.mark.gpu
+def test_device_count():
+    assert engine.device_count() >= 1
