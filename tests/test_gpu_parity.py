@@ -1937,5 +1937,6 @@ def test_flush_pair_gives_what_flush_gives_while_the_next_reads_are_added(torch_
 
 
 @pytest.mark.gpu
-def test_device_count():
+def test_device_count(torch_cuda):
+    from pisces_amd import engine
     assert engine.device_count() >= 1

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Collects what profiles/ holds for a round, on the GPU box:  bash tools/profile_round.sh r02
+# Collects what profiles/ holds for a round, on the GPU box:  bash tools/profile_round.sh r03
 # (1) un-profiled bench line, (2) rocprofv3 kernel-trace stats of the same command, (3) PMC HBM traffic in separate passes (counters
 # restricted to the hot kernel: the synthetic generator's thousands of small torch kernels are not instrumented), (4) SQ / LDS counters
 # of the hot kernel, (5) the streaming surface's and the BGZF / BAM kernels' statistics and counters.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
@@ -51,3 +51,41 @@ timeout 300 python tools/bgzf_bench.py 256 2>&1 | grep "bgzf inflate" | tee $OUT
 pmc bgzf_mem bgzf_inflate FETCH_SIZE -- python tools/bgzf_bench.py 256
 pmc bgzf_sq bgzf_inflate SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -- python tools/bgzf_bench.py 256
 pmc bgzf_lds bgzf_inflate SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -- python tools/bgzf_bench.py 256
+# the streaming surface's device chain on the whole of config 2 in one add_reads + flush: the read store (fused reads -> LDS histogram ->
+# calls kernel) and, for the A/B, the observation log chain it replaced
+for path in store log; do
+  PISCES_HIP_READ_PATH=$path timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_$path -o s -- python tools/store_bench.py > $OUT/store_bench_$path.log 2>&1
+  find /tmp/prof_${TAG}_$path -name "*kernel_stats.csv" -exec cp {} $OUT/store_${path}_kernel_stats.csv \;
+  grep "store_bench" $OUT/store_bench_$path.log | tail -1
+done
+pmc store_fetch call_store_tiles FETCH_SIZE -- python tools/store_bench.py
+pmc store_write call_store_tiles WRITE_SIZE -- python tools/store_bench.py
+pmc store_sq call_store_tiles SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -- python tools/store_bench.py
+pmc store_lds call_store_tiles SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU -- python tools/store_bench.py
+# BASELINE config 3's mix (2000x, SNV + insertion / deletion / MNV candidates), flushed block by block
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_c3 -o s -- python tools/config3_host_profile.py 40 > $OUT/config3.log 2>&1
+find /tmp/prof_${TAG}_c3 -name "*kernel_stats.csv" -exec cp {} $OUT/config3_kernel_stats.csv \;
+grep "rep 2" $OUT/config3.log
+# HBM traffic of the hot kernel per launch, for bench.py's roofline.traffic: FETCH_SIZE / WRITE_SIZE come in KiB; on gfx950 FETCH_SIZE
+# reports half the bytes of a wide coalesced streaming read (16 B per lane: this kernel's loads), so it is doubled (MI355X_MICROARCH.md, HBM)
+python - $OUT $TAG <<'PY'
+import json, re, sys, time
+out, tag = sys.argv[1], sys.argv[2]
+def mean(name):
+    for line in open(f"{out}/pmc_{name}.txt"):
+        m = re.search(r"call_tiles\S* " + name + r" mean per dispatch ([0-9.e+]+)", line)
+        if m:
+            return float(m.group(1))
+    return None
+f, w = mean("FETCH_SIZE"), mean("WRITE_SIZE")
+line = json.loads(open(f"{out}/bench_n1.json").read().strip().splitlines()[-1])
+if f and w:
+    prev = json.load(open("profiles/traffic.json"))
+    corr = prev.get("fetch_correction", 2.0)
+    t = {"loci": line["config"]["loci_per_gpu_per_step"], "depth": line["config"]["depth"], "tile_loci": line["config"]["tile_loci"],
+         "hbm_bytes_per_launch": f * 1024 * corr + w * 1024, "fetch_size_kib_raw": f, "fetch_correction": corr, "write_size_kib_raw": w,
+         "kernel": "pisces::call_tiles_wave_kernel", "run": f"{tag} {time.strftime('%Y-%m-%d %H:%M:%S')} tools/profile_round.sh",
+         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-include-regex call_tiles, separate passes over bench.py (tools/profile_round.sh)"}
+    json.dump(t, open(f"{out}/traffic.json", "w"), indent=1)
+    print("traffic.json:", t["hbm_bytes_per_launch"], "bytes per launch; algorithmic", line["roofline"]["algorithmic_bytes_per_launch"])
+PY
