@@ -932,6 +932,25 @@ __global__ __launch_bounds__(256) void read_probe_kernel(const u32x4* __restrict
     if (acc == 0x9E3779B9u) *sink = acc;
 }
 
+// the same with the read store kernel's loads: one dword a lane (256 bytes a wave instruction), eight in flight.  Only for calibrating
+// FETCH_SIZE on that width (PISCES_HIP_PROBE_DWORD=1; tools/fetch_calibration.py).
+__global__ __launch_bounds__(256) void read_probe_dword_kernel(const uint32_t* __restrict__ p, int64_t n, uint32_t* __restrict__ sink)
+{
+    uint32_t acc = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x * 8 + threadIdx.x; i < n; i += stride) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int64_t j = i + (int64_t)u * blockDim.x;
+            v[u] = j < n ? p[j] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc ^= v[u];
+    }
+    if (acc == 0x9E3779B9u) *sink = acc;
+}
+
 // fills DeviceParams::gq_tail with the function the call phase would evaluate (bit-identical by construction)
 __global__ void build_gq_tail_kernel(double* __restrict__ table, int32_t n_a, int32_t n_cov, float target_lod)
 {

@@ -291,6 +291,23 @@ int32_t pisces_hip_probe_read_bandwidth(PiscesHip* h, int64_t nbytes, int32_t re
     PISCES_HIP_CHECK(h, hipMemsetAsync(buf.p, 0x5A, (size_t)nbytes, h->stream));
     const int64_t n4 = nbytes / 16;
     const unsigned grid = (unsigned)std::min<int64_t>((n4 + 2047) / 2048, (int64_t)h->n_cus * 32);
+    {   // calibration of the FETCH_SIZE counter on the read store kernel's load width (tools/fetch_calibration.py): dword loads instead
+        const char* dw = std::getenv("PISCES_HIP_PROBE_DWORD");
+        if (dw && dw[0] == '1') {
+            double best = 0.0;
+            for (int r = 0; r <= reps; r++) {
+                hipExtLaunchKernelGGL(read_probe_dword_kernel, dim3((unsigned)h->n_cus * 32), dim3(256), 0u, h->stream, h->ev0, h->ev1, 0u, (const uint32_t*)buf.p,
+                                      nbytes / 4, buf.p + nbytes / 4);
+                PISCES_HIP_CHECK(h, hipEventSynchronize(h->ev1));
+                float ms = 0.f;
+                PISCES_HIP_CHECK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+                if (r > 0 && ms > 0.f) best = std::max(best, (double)nbytes / ((double)ms * 1e-3) / 1e9);
+            }
+            buf.release();
+            *gb_per_s = best;
+            return PISCES_OK;
+        }
+    }
     hipLaunchKernelGGL(read_probe_kernel, dim3(grid), dim3(256), 0, h->stream, (const u32x4*)buf.p, n4, buf.p + nbytes / 4);   // warm-up
     double best = 0.0;
     for (int r = 0; r < reps; r++) {
