@@ -271,7 +271,15 @@ def end_to_end_full(pileup, cfg, engine, torch):
             kernel_ms = kernel_ms_total / launches
             nbytes = 2.0 * n_bases + 64.0 * n_rec
             achieved = nbytes / (kernel_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            traffic, traffic_run = None, None
+            try:   # separate rocprofv3 --pmc passes over tools/store_bench.py (the same one-batch flush), tools/profile_round.sh
+                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("streaming", {})
+                if tj.get("loci") == pileup.n_loci and tj.get("depth") == pileup.depth:
+                    traffic, traffic_run = tj.get("hbm_bytes_per_launch"), tj.get("run")
+            except Exception:   # noqa: BLE001
+                pass
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_from": traffic_run,
                     "kernel": "pisces::call_store_tiles_kernel", "kernel_ms": kernel_ms, "launches_timed": int(launches),
                     "algorithmic_bytes_per_launch": nbytes,
                     "what": "reads in HBM (1 B base + 1 B quality per aligned base) -> LDS histogram -> 64-byte records, one launch per flush; "
@@ -294,6 +302,32 @@ def end_to_end_full(pileup, cfg, engine, torch):
         out["per_block"] = {"value": pileup.n_loci / best, "unit": "candidate loci/s", "seconds": best, "loci": pileup.n_loci, "records": n_rec,
                             "add_reads_flush_pairs": len(per_block), "host_ms_per_flush": ht["host_ms_per_flush"],
                             "host_ms_per_add_reads": ht["add_reads_s"] / max(2 * len(per_block), 1) * 1e3}
+        # the same 96 blocks through the flush pair, as dotnet/HipFactory.cs drives the library (HipAlleleCaller.Call = FlushEnd of block k - 1,
+        # FlushBegin of block k), and with the caller's reads written into the pinned staging buffer (HipEngine.FlushStagedReads)
+        want_records = n_rec
+        for label, stage in (("per_block_pair", False), ("per_block_pair_staged", True)):
+            best = None
+            for rep in range(3):
+                n_rec, dt, pending = 0, 0.0, False
+                for a0, b in per_block:
+                    staged = c.StageReads(b) if stage else b       # (filling the staging buffer: the caller's marshalling, not timed)
+                    t0 = time.perf_counter()
+                    c.AddAlleleCounts(staged)
+                    if pending:
+                        n_rec += len(c.CallEnd(capacity=1 << 18, reuse_buffer=True))
+                    c.CallBegin(pileup.region_start + a0 * synth.READ_LEN - 1)
+                    pending = True
+                    dt += time.perf_counter() - t0
+                t0 = time.perf_counter()
+                n_rec += len(c.CallEnd(capacity=1 << 18, reuse_buffer=True))
+                c.CallBegin(None)
+                n_rec += len(c.CallEnd(capacity=1 << 18, reuse_buffer=True))
+                dt += time.perf_counter() - t0
+                if rep > 0:
+                    best = dt if best is None else min(best, dt)
+            assert n_rec == want_records, (n_rec, want_records)
+            out[label] = {"value": pileup.n_loci / best, "unit": "candidate loci/s", "seconds": best, "loci": pileup.n_loci, "records": n_rec,
+                          "add_reads_flush_pairs": len(per_block)}
     # BASELINE config 3's mix (SNV + MNV + deletions + insertions at 2000x, MNV calling on) block by block: the flushes whose host half is
     # not empty (candidate merge, VariantCollapser, MnvReallocator between the device passes)
     try:
@@ -309,6 +343,7 @@ def end_to_end_full(pileup, cfg, engine, torch):
             for rep in range(3):
                 if rep == 1:
                     c.HostTime(reset=True)
+                    c.TransferBytes(reset=True)
                 t0 = time.perf_counter()
                 c.AddAlleleCounts(batch)
                 n_rec = 0
@@ -319,12 +354,48 @@ def end_to_end_full(pileup, cfg, engine, torch):
                 if rep > 0:
                     best = dt if best is None else min(best, dt)
             ht = c.HostTime(reset=True)
-        out["config3_mix_sample"] = {"value": n_loci / best, "unit": "candidate loci/s", "seconds": best, "loci": n_loci, "depth": depth, "reads": int(batch.n_reads),
+            tb = c.TransferBytes(reset=True)
+        per_flush = max(ht["flushes"], 1)
+        out["config3_mix_sample"] = {"pcie_bytes_per_flush": {k: v / per_flush for k, v in tb.items()},"value": n_loci / best, "unit": "candidate loci/s", "seconds": best, "loci": n_loci, "depth": depth, "reads": int(batch.n_reads),
                                      "records": n_rec, "planted_events": len(planted), "flushes": ht["flushes"] // 2,
                                      "host_ms_per_flush": ht["host_ms_per_flush"], "device_wait_ms_per_flush": ht["flush_wait_s"] / max(ht["flushes"], 1) * 1e3}
     except Exception as e:   # noqa: BLE001
         out["config3_mix_sample"] = {"error": str(e)[:200]}
     return out, roof
+
+
+def from_large_bam(cfg, engine, reads=400_000, copies=7):
+    """the BAM surface on a file of >= 256 MB: 2.8 M reads of 150 bases drawn from a random reference with 0.5 % wrong
+    bases (tools/bam_bench.make_bam), BGZF at zlib level 1 (~330 MB), through pisces_hip_bam_decode -> pisces_hip_add_decoded_reads ->
+    flush; only the compressed bytes cross PCIe on the way in.  Generation (~20 s of numpy and zlib) is not timed."""
+    import numpy as np
+    from tools.bam_bench import make_bam
+    from tools.bgzf_bench import make_bgzf
+    stream, ref = make_bam(reads, copies=copies, from_reference=True)
+    data = make_bgzf(stream, 1)
+    out = {"reads": reads * copies, "compressed_bytes": len(data), "inflated_bytes": len(stream)}
+    del stream
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(ref)
+        for label in ("view", "copy"):
+            best, n_rec, n_loci = None, 0, 0
+            for rep in range(3):
+                t0 = time.perf_counter()
+                counts = c.bam_decode(data, 0)
+                c.AddDecodedReads()
+                recs = c.CallView(None) if label == "view" else c.Call(None, capacity=1 << 22, reuse_buffer=True)
+                dt = time.perf_counter() - t0
+                n_rec = len(recs)
+                if rep == 0:
+                    n_loci = int(len(np.unique(recs["position"])))
+                else:
+                    best = dt if best is None else min(best, dt)
+            assert counts["reads"] == reads * copies, counts
+            out[label] = {"value": n_loci / best, "unit": "candidate loci/s", "seconds": best, "loci": n_loci, "records": n_rec,
+                          "compressed_GB_per_s": len(data) / best / 1e9}
+    out["scope"] = ("BGZF-compressed BAM bytes on the host -> inflate, record cut, ShouldSkipRead, read store, calls on the device -> records on the host; "
+                    "view: read in place in the library's pinned buffer (pisces_hip_flush_view), copy: copied into the caller's array (pisces_hip_flush)")
+    return out
 
 
 def _abi_config(**kw):
@@ -410,6 +481,7 @@ def main():
     ap.add_argument("--depth", type=int, default=DEPTH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the streaming-surface figures (host reads -> records)")
+    ap.add_argument("--no-large-bam", action="store_true", help="skip the 330 MB BAM figure of end_to_end_full (~20 s to make the file)")
     ap.add_argument("--no-shard-check", action="store_true", help="skip the on-device check of one cut of the interval partition")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra multi-stream figure (profiling runs: its overlapped "
                     "launches would mix into the per-kernel statistics of the timed region)")
@@ -687,6 +759,11 @@ def main():
                 out["end_to_end_full"], out["roofline_streaming"] = end_to_end_full(ring[0], cfg, engine, torch)
             except Exception as e:   # noqa: BLE001  (extra figures: they must not cost the bench line)
                 out["end_to_end_full"] = {"error": str(e)[:200]}
+            if not args.no_large_bam:
+                try:
+                    out["end_to_end_full"]["from_bam_bytes_large"] = from_large_bam(cfg, engine)
+                except Exception as e:   # noqa: BLE001
+                    out["end_to_end_full"]["from_bam_bytes_large"] = {"error": str(e)[:200]}
         if not args.no_cpu_baseline and world == 1:   # timed on rank 0 at N=1 only
             out["cpu_baseline"], out["cpu_baseline_threads"] = cpu_baseline(torch, ring[0], cfg)
         print(json.dumps(out), flush=True)

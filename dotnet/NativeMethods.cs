@@ -109,6 +109,9 @@ namespace Pisces.Hip
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_flush_end(IntPtr handle, [Out] PiscesCalledAllele[] output, long capacity, out long nOut);
         /// flush_end with pisces_hip_flush_ex's candidate outputs (what a host that writes VCF rows takes the allele strings from)
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_flush_end_ex(IntPtr handle, [Out] PiscesCalledAllele[] output, long capacity, out long nOut, [Out] int[] candIndex, [Out] PiscesCandidate[] cands, long candCapacity, out long nCand, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
+        /// the flushes without the copy: the rows where they lie (pinned memory of the handle), valid until the next flush on the handle
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_flush_view(IntPtr handle, int upToPosition, out PiscesCalledAllele* rows, out long nRows, out int* candIndex, out PiscesCandidate* cands, out long nCand, out byte* alleles, out long alleleBytes);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_flush_end_view(IntPtr handle, out PiscesCalledAllele* rows, out long nRows);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_flush_ex(IntPtr handle, int upToPosition, [Out] PiscesCalledAllele[] output, long capacity, out long nOut, [Out] int[] candIndex, [Out] PiscesCandidate[] cands, long candCapacity, out long nCand, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_get_candidates(IntPtr handle, int upToPosition, [Out] PiscesCandidate[] cands, long capacity, out long nOut, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_add_candidates(IntPtr handle, PiscesCandidate[] cands, long n, byte[] alleles, long alleleBytes);
@@ -137,6 +140,8 @@ namespace Pisces.Hip
         /// {allelesCalled, variantsCollapsed, readsProcessed, readsSkipped} (SmallVariantCaller.cs:114-115, AlignmentsSource.cs:63)
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_stats(IntPtr handle, [Out] long[] stats4);
         /// host seconds inside the library: {add_reads / add_decoded_reads, flushes, of those waiting for the device, flushes counted}
+        /// bytes over PCIe: {host -> device reads / file bytes, device -> host records, candidate records, allele counts}
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_transfer_bytes(IntPtr handle, [Out] long[] out4, int reset);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_host_time(IntPtr handle, [Out] double[] out4, int reset);
 
         // the BAM surface: BamReader.GetNextAlignment + AlignmentSource's filters + Read construction for one chromosome's records

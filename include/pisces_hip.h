@@ -336,6 +336,14 @@ int32_t pisces_hip_flush_end(PiscesHip* h, PiscesCalledAllele* out, int64_t capa
 int32_t pisces_hip_flush_end_ex(PiscesHip* h, PiscesCalledAllele* out, int64_t capacity, int64_t* n_out, int32_t* cand_index_out,
                                 PiscesCandidate* cand_out, int64_t cand_capacity, int64_t* n_cand, uint8_t* alleles_out,
                                 int64_t allele_capacity, int64_t* allele_bytes);
+/* The flushes without the copy into the caller's array, for a host that reads the rows where they lie (a managed host marshals them into
+ * its own objects anyway; 2.8 M rows are 179 MB): *rows points at *n_rows called alleles in memory of the handle — for a batch the device
+ * called alone, the pinned host buffer the last kernel wrote them to — valid until the next pisces_hip_flush* / pisces_hip_flush_begin on the
+ * handle.  cand_index / cands / alleles (any may be NULL) as pisces_hip_flush_ex returns them; *cand_index is NULL when no row has a
+ * candidate (every row is a Reference or SNV row).  No PISCES_E_BUFFER_TOO_SMALL: nothing is copied. */
+int32_t pisces_hip_flush_view(PiscesHip* h, int32_t up_to_position, const PiscesCalledAllele** rows, int64_t* n_rows, const int32_t** cand_index,
+                              const PiscesCandidate** cands, int64_t* n_cand, const uint8_t** alleles, int64_t* allele_bytes);
+int32_t pisces_hip_flush_end_view(PiscesHip* h, const PiscesCalledAllele** rows, int64_t* n_rows);
 /* IAlleleSource.GetAlleleCount for a run of positions: out[n][6][3][11] int32
  * (RegionState.cs:57); blocks never touched read as zero (RegionStateManager.cs:222-226). */
 int32_t pisces_hip_get_counts(PiscesHip* h, int32_t start_position, int32_t n, int32_t* out);
@@ -379,6 +387,10 @@ int32_t pisces_hip_stats(PiscesHip* h, int64_t out[4]);
  * work per flush: block bookkeeping, candidate merge, VariantCollapser, MnvReallocator, the diploid genotyper, record assembly
  * (what runs on one core of the host next to the device; IAlleleCaller.Call's host half, AlleleCaller.cs:60-141). */
 int32_t pisces_hip_host_time(PiscesHip* h, double out[4], int32_t reset);
+/* Bytes that crossed PCIe for this handle since the last reset: {host -> device: read batches as handed to pisces_hip_add_reads, or the
+ * compressed file bytes and block table of pisces_hip_bam_decode; device -> host: called-allele records; device -> host: the candidate
+ * records of the device finder (64 B per read event + long ALT alleles); device -> host: allele counts for the collapser / reallocator}. */
+int32_t pisces_hip_transfer_bytes(PiscesHip* h, int64_t out[4], int32_t reset);
 
 /* ---- multi-GPU: the per-chromosome summary across interval shards --------------------------------------------------
  * Loci shard by genomic interval, one process (or one handle) per GPU, no data-path exchange; the only collective is the sum of

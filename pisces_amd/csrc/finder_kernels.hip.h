@@ -46,6 +46,53 @@ __device__ __forceinline__ ReadView dev_read_view(const DevReadBatch& b, const u
     return v;
 }
 
+// The bases of an M operation four at a time: one dword each of read bases, qualities and reference bases (any alignment: gfx950 runs
+// with unaligned global access on), the next word's loads issued before the state machine works through the current one — two
+// register sets in turn, straight-line code, every load unconditional with its address pulled back inside the arrays at the
+// operation's end (a guarded load becomes a branch with a wait for everything outstanding at the join, a register copy of a loaded
+// value a wait where it stands).  With one lane per read the byte-wise walk is a chain of dependent loads: 450 a read of 150 bases,
+// 215-230 us for 80 000 reads whatever the arithmetic.
+struct WordBases {
+    struct Word { uint32_t b, q, f; int sh; };   // sh: bits to shift right (the word was loaded `sh / 8` bytes early, at the end of the arrays)
+    template <typename Step>
+    __device__ __forceinline__ static void for_each(const ReadView& r, const uint8_t* ref, int op_read0, int op_ref0, int n, Step& step)
+    {
+        const uint8_t* pb = r.bases + op_read0; const uint8_t* pq = r.quals + op_read0; const uint8_t* pf = ref + op_ref0;
+        if (n < 4) {   // (the arrays are only known to hold n bytes from here)
+            for (int i = 0; i < n; i++) step(i, pb[i], pf[i], pq[i]);
+            return;
+        }
+        const int n_words = (n + 3) >> 2;
+        auto load = [&](int w, Word& W) {
+            const int o = 4 * min(w, n_words - 1), oc = min(o, n - 4);
+            __builtin_memcpy(&W.b, pb + oc, 4);
+            __builtin_memcpy(&W.q, pq + oc, 4);
+            __builtin_memcpy(&W.f, pf + oc, 4);
+            W.sh = 8 * (o - oc);
+        };
+        auto walk = [&](int w, const Word& W) {
+            const uint32_t b = W.b >> W.sh, q = W.q >> W.sh, f = W.f >> W.sh;
+#pragma unroll 1
+            for (int k = 0; k < 4; k++) {
+                const int i = 4 * w + k;
+                if (i < n) step(i, (uint8_t)(b >> (8 * k)), (uint8_t)(f >> (8 * k)), (uint8_t)(q >> (8 * k)));
+            }
+        };
+        Word A, B;
+        load(0, A);
+        for (int w = 0; w < n_words; w += 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            load(w + 1, B);
+            __builtin_amdgcn_sched_barrier(0);
+            walk(w, A);
+            __builtin_amdgcn_sched_barrier(0);
+            load(w + 2, A);
+            __builtin_amdgcn_sched_barrier(0);
+            if (w + 1 < n_words) walk(w + 1, B);
+        }
+    }
+};
+
 __device__ __forceinline__ bool found_needs_pool(const FoundCandidate& c)
 {
     return c.category != PISCES_CAT_DELETION && c.length > kFoundInline;
@@ -64,41 +111,50 @@ __global__ __launch_bounds__(256) void find_count_kernel(DevReadBatch b, const u
         n++;
         if (found_needs_pool(c)) bytes += c.length;
     };
-    walk::walk_read(v, ref, ref_len, P, count);
+    walk::walk_read<WordBases>(v, ref, ref_len, P, count);
     n_found[r] = n;
     n_pool[r] = bytes;
 }
 
-// in-place exclusive scans of two int32 arrays by one workgroup; totals[0], totals[1] = the sums
+// in-place exclusive scans of two int32 arrays by one workgroup; totals[0], totals[1] = the sums.  Every wave owns a contiguous sixteenth
+// of the arrays: it adds its part up, the sixteen sums are exchanged once through LDS, and the wave then scans its part 64 entries at a
+// time with lane shuffles — one barrier in all (the first form scanned 1024 entries a round through LDS, twenty barriers a round:
+// 228 us for 80 000 reads; this one 77 us: twelve dependent lane shuffles a round, 79 rounds a wave).
 __global__ __launch_bounds__(1024) void found_scan_kernel(int32_t* __restrict__ a, int32_t* __restrict__ b, int32_t n, long long* __restrict__ totals)
 {
-    __shared__ long long s_a[1024], s_b[1024];
-    __shared__ long long s_base[2];
-    if (threadIdx.x == 0) { s_base[0] = 0; s_base[1] = 0; }
+    __shared__ long long s_tot[2][16];
+    const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6;
+    const int per = (((n + 15) / 16) + 63) & ~63;
+    const int lo = min(w * per, n), hi = min(lo + per, n);
+    long long sa = 0, sb = 0;
+    for (int i = lo + lane; i < hi; i += 64) { sa += a[i]; sb += b[i]; }
+    for (int d = 32; d; d >>= 1) { sa += __shfl_xor(sa, d); sb += __shfl_xor(sb, d); }
+    if (lane == 0) { s_tot[0][w] = sa; s_tot[1][w] = sb; }
     __syncthreads();
-    for (int32_t start = 0; start < n; start += 1024) {
-        const int32_t i = start + (int32_t)threadIdx.x;
-        const long long va = i < n ? a[i] : 0, vb = i < n ? b[i] : 0;
-        s_a[threadIdx.x] = va;
-        s_b[threadIdx.x] = vb;
-        __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {
-            long long xa = 0, xb = 0;
-            if ((int)threadIdx.x >= d) { xa = s_a[threadIdx.x - d]; xb = s_b[threadIdx.x - d]; }
-            __syncthreads();
-            s_a[threadIdx.x] += xa;
-            s_b[threadIdx.x] += xb;
-            __syncthreads();
+    long long base_a = 0, base_b = 0;
+    for (int k = 0; k < w; k++) { base_a += s_tot[0][k]; base_b += s_tot[1][k]; }
+    int na = lo + lane < hi ? a[lo + lane] : 0, nb = lo + lane < hi ? b[lo + lane] : 0;
+    for (int start = lo; start < hi; start += 64) {
+        const int i = start + lane;
+        const int va = na, vb = nb;
+        // (the next 64 entries are requested before this round's are stored: a load behind a store to the same array is not moved up by
+        // the compiler, and every round would be a full memory round trip)
+        na = i + 64 < hi ? a[i + 64] : 0;
+        nb = i + 64 < hi ? b[i + 64] : 0;
+        int xa = va, xb = vb;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int ya = __shfl_up(xa, d), yb = __shfl_up(xb, d);
+            if (lane >= d) { xa += ya; xb += yb; }
         }
-        if (i < n) {
-            a[i] = (int32_t)(s_base[0] + s_a[threadIdx.x] - va);
-            b[i] = (int32_t)(s_base[1] + s_b[threadIdx.x] - vb);
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) { s_base[0] += s_a[1023]; s_base[1] += s_b[1023]; }
-        __syncthreads();
+        if (i < hi) { a[i] = (int32_t)(base_a + xa - va); b[i] = (int32_t)(base_b + xb - vb); }
+        base_a += __shfl(xa, 63);
+        base_b += __shfl(xb, 63);
     }
-    if (threadIdx.x == 0) { totals[0] = s_base[0]; totals[1] = s_base[1]; }
+    if (threadIdx.x == 0) {
+        long long ta = 0, tb = 0;
+        for (int k = 0; k < 16; k++) { ta += s_tot[0][k]; tb += s_tot[1][k]; }
+        totals[0] = ta; totals[1] = tb;
+    }
 }
 
 // slot_first[r] = first record slot of read r, slot_end = slot_first[r + 1] (host-made or scanned); pool_first[r] = first pool byte of
@@ -140,7 +196,7 @@ __global__ __launch_bounds__(256) void find_emit_kernel(DevReadBatch b, const ui
         for (int k = 0; k < kFoundInline; k++) f.alt[k] = (k < n_alt && n_alt <= kFoundInline) ? src[k] : (uint8_t)0;
         out[slot++] = f;
     };
-    walk::walk_read(v, ref, ref_len, P, write);
+    walk::walk_read<WordBases>(v, ref, ref_len, P, write);
     for (; slot < slot_end; slot++) {   // reserved, unused: a hole
         DevFound f = {};
         f.c.category = kFoundHole;

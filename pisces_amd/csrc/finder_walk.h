@@ -139,11 +139,23 @@ PISCES_HD inline void finish_candidate(const ReadView& r, const ReadFrame& f, co
     emit(c);
 }
 
+// Where the bases of an M operation come from: step(i, read base, reference base, quality) for i = 0 .. n - 1 (n bases of the operation
+// lie on the read and on the contig).  One byte at a time here; the device kernels take them four at a time, the next word requested
+// while the state machine works through the current one (WordBases, finder_kernels.hip.h).
+struct ByteBases {
+    template <typename Step>
+    PISCES_HD static void for_each(const ReadView& r, const uint8_t* ref, int op_read0, int op_ref0, int n, Step& step)
+    {
+        const uint8_t* pb = r.bases + op_read0; const uint8_t* pq = r.quals + op_read0; const uint8_t* pf = ref + op_ref0;
+        for (int i = 0; i < n; i++) step(i, pb[i], pf[i], pq[i]);
+    }
+};
+
 // The M-operation state machine (ExtractSnvsFromOperation :90-168 with ShouldBuildUpMNV :170-181 and FlushVariant :183-203).
 // `run` = bases of the variant being built, trailing reference matches included; `tail` = those trailing matches, which are
 // given back when the variant is closed; a variant that was closed by a base that cannot be called (N, low quality) is open on
 // that side.  A walk that reaches the end of the contig (or of the read) closes the pending variant where it stopped.
-template <typename Emit>
+template <typename Src, typename Emit>
 PISCES_HD inline void walk_match_op(const ReadView& r, const ReadFrame& f, const uint8_t* ref, int64_t ref_len, const FinderParams& P,
                                     int op_read0, int op_len, int op_ref0, Emit& emit)
 {
@@ -163,11 +175,13 @@ PISCES_HD inline void walk_match_op(const ReadView& r, const ReadFrame& f, const
         if (run + 1 > P.max_mnv_length) return false;
         return tail + (matches ? 1 : 0) <= P.max_gap;
     };
-    int walked = op_len;
-    for (int i = 0; i < op_len; i++) {
-        if (op_read0 + i >= r.read_len || (int64_t)op_ref0 + i >= ref_len) { walked = i; break; }
-        const uint8_t rb = r.bases[op_read0 + i], fb = ref[op_ref0 + i];
-        const bool callable = is_acgt(rb) && is_acgt(fb) && r.quals[op_read0 + i] >= P.min_bq;
+    // the bases of the operation that lie on the read and on the contig (the walk stops at the end of either)
+    int64_t lim = op_len;
+    if ((int64_t)r.read_len - op_read0 < lim) lim = (int64_t)r.read_len - op_read0;
+    if (ref_len - (int64_t)op_ref0 < lim) lim = ref_len - (int64_t)op_ref0;
+    const int walked = lim < 0 ? 0 : (int)lim;
+    auto step = [&](int i, uint8_t rb, uint8_t fb, uint8_t q) {
+        const bool callable = is_acgt(rb) && is_acgt(fb) && q >= P.min_bq;
         const bool alone_on_last_base = i == op_len - 1 && run == 0;   // no MNV is started on the last base of an operation
         if (!callable) {
             close(i, true);
@@ -179,12 +193,13 @@ PISCES_HD inline void walk_match_op(const ReadView& r, const ReadFrame& f, const
             if (may_grow(false) && !alone_on_last_base) { run++; tail = 0; }
             else { close(i, false); run = 1; tail = 0; open_left = false; }
         }
-    }
+    };
+    Src::for_each(r, ref, op_read0, op_ref0, walked, step);
     close(walked, false);
 }
 
 // ProcessCigarOps :36-83: every candidate of one read, in the reference's order of discovery
-template <typename Emit>
+template <typename Src = ByteBases, typename Emit>
 PISCES_HD inline void walk_read(const ReadView& r, const uint8_t* ref, int64_t ref_len, const FinderParams& P, Emit& emit)
 {
     const ReadFrame f = frame_of(r);
@@ -193,7 +208,7 @@ PISCES_HD inline void walk_read(const ReadView& r, const uint8_t* ref, int64_t r
         const uint8_t t = r.cigar_op[ci];
         const int len = (int)r.cigar_len[ci];
         if (t == 'M') {
-            if (P.snvs_and_mnvs) walk_match_op(r, f, ref, ref_len, P, in_read, len, in_ref, emit);
+            if (P.snvs_and_mnvs) walk_match_op<Src>(r, f, ref, ref_len, P, in_read, len, in_ref, emit);
         } else if (t == 'I') {   // ExtractInsertionFromOperation :234-260: anchored on the base before, gated on the first inserted base
             const bool off_contig = (int64_t)in_ref - 1 >= ref_len || in_ref == 0;
             if (!off_contig && in_read < r.read_len && in_read + len <= r.read_len && r.quals[in_read] >= P.min_bq)

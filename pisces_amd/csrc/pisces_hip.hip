@@ -190,6 +190,7 @@ struct PiscesHip {
     bool in_flush_begin = false;
     double prof[12] = {0};                 // development (PISCES_HIP_HOST_PROFILE=1): host seconds by phase of a flush, printed when the handle goes
     bool prof_on = false;
+    int64_t pcie[4] = {0, 0, 0, 0};          // pisces_hip_transfer_bytes: H2D reads / file bytes, D2H records, D2H candidate records, D2H counts
     double host_time[4] = {0, 0, 0, 0};   // pisces_hip_host_time: seconds in add_reads, in flush, of that waiting for the device; flushes
 
     // cached result of a flush that did not fit the caller's buffer
@@ -248,6 +249,15 @@ struct PiscesHip {
         std::vector<uint8_t> owned_alleles;
         size_t n_cands = 0, n_allele_bytes = 0;
     } async;
+    struct FlushView {                        // pisces_hip_flush_view: what the last flush handed out in place
+        bool wanted = false;
+        const PiscesCalledAllele* data = nullptr;
+        size_t n = 0;
+        std::vector<PiscesCalledAllele> rows;  // the merged rows of a batch with host-side candidates (otherwise data points into h_dl)
+        std::vector<int32_t> index;
+        std::vector<PiscesCandidate> cands;
+        std::vector<uint8_t> alleles;
+    } view;
     int64_t log_known_holes = 0;             // slots of the log that the last asynchronous drop left as holes (0 after any other drop)
     size_t staged_total = 0;                 // bytes pisces_hip_stage_reads laid out in the current staging buffer (0: nothing staged)
     uint8_t* h_dl = nullptr;                 // pinned download buffer of flush
@@ -416,7 +426,9 @@ static hipError_t accumulate_tiles(PiscesHip* h, hipStream_t s, const uint32_t* 
     if (with_store && h->read_path == 1) {
         StoreView V;
         store_view(h, &V);
-        hipLaunchKernelGGL(accumulate_store_tiles_kernel, dim3((unsigned)n_tiles), dim3(n_tiles <= 2 * h->n_cus ? 1024 : kBlock), 0, s, V, d_tuples, d_tiles, n_tiles, h->d_counts.p,
+        // a launch of few tiles: several workgroups a tile, so that ~2 workgroups a CU exist (the kernel)
+        const int split = (int)std::min<int64_t>(16, std::max<int64_t>(1, 2 * (int64_t)h->n_cus / std::max(n_tiles, 1)));
+        hipLaunchKernelGGL(accumulate_store_tiles_kernel, dim3((unsigned)n_tiles, (unsigned)split), dim3(kBlock), 0, s, V, d_tuples, d_tiles, n_tiles, h->d_counts.p,
                            h->cfg.min_base_call_quality, with_sums ? h->d_sumq_fix.p : (unsigned long long*)nullptr,
                            with_sums ? (const ulonglong2*)h->d_bq_lut.p : (const ulonglong2*)nullptr);
     } else

@@ -50,13 +50,15 @@ constexpr uint32_t kDescGeneric = 1u << 22;      // a read whose fragments do no
 //   D N          the deleted positions, if the gap passes CandidateVariantFinder.CheckDeletionQuality at the base that closes it
 //                (RegionStateManager.cs:131-176; a deletion at the read's end or before its final soft clip: :143-154, :199-213)
 //   I S H P      nothing (length 0)
-// aoff's top 16 bits hold delta (a read that needs more, or an operation of 2^20 positions or more, is kDescGeneric: its fragments are
-// empty and the read goes through read_walk.h).  So a read with an insertion is two aligned fragments, one with a deletion two aligned
+// aoff's top 16 bits hold delta, the 16 below them the read's reference span - 1 (a read that needs more, an operation of 2^20 positions
+// or more, or two gaps with no aligned base between them, is kDescGeneric: its fragments are empty and the read goes through read_walk.h).  So a read with an insertion is two aligned fragments, one with a deletion two aligned
 // fragments and a deletion fragment: the fast path takes them all.
 constexpr uint32_t kFragDeletion = 1u << 20;
 constexpr int kFragDirShift = 22;                // DirectionType of a deletion fragment's positions (the base that closes the gap), 2 bits
 constexpr int kFragDeltaShift = 48;
-constexpr long long kFragAoffMask = (1ll << kFragDeltaShift) - 1;
+constexpr long long kFragAoffMask = 0xFFFFFFFFll;   // bits 0..31: the offset (a segment's bases stay below 4 GB)
+constexpr int kFragSpanShift = 32;               // bits 32..47: Read.EndPosition - Read.Position of the fragment's read (GetAnchorType needs both ends)
+constexpr uint32_t kFragTerminal = 1u << 24;     // a deletion at the read's end / before its final soft clip: its positions count in anchor bin 10
 constexpr int kMaxSegments = 8;
 constexpr int kStateUnsorted = 0, kStateReach = 1, kStateComplex = 2, kStateFrags = 3;   // [kStateFrags]: bit 0 some read is kDescGeneric, bit 1 some deletion fragment
 
@@ -115,12 +117,14 @@ __global__ __launch_bounds__(256) void read_shape_kernel(ShapeArgs A)
         // one aligned run between clips?  phases: 0 leading clips, 1 the run (M = X), 2 trailing clips; H / P span nothing
         int phase = 0, lead = 0;
         long long run = 0, ref_span = 0;
-        bool simple = true;
+        bool simple = true, prev_gap = false, gap_chain = false;
         for (int c = 0; c < nc; c++) {
             const uint8_t t = A.cigar_op[c0 + c];
             const long long len = A.cigar_len[c0 + c];
             if (walk_op_ref_span(t)) ref_span += len;
+            if (t == 'D' || t == 'N') { gap_chain = gap_chain || prev_gap; prev_gap = true; }
             if (t == 'M' || t == '=' || t == 'X') {
+                prev_gap = false;
                 if (phase == 2) simple = false;
                 phase = 1;
                 run += len;
@@ -147,7 +151,8 @@ __global__ __launch_bounds__(256) void read_shape_kernel(ShapeArgs A)
         reach = (int)(ref_span > 0x7FFFFFFFll ? 0x7FFFFFFFll : ref_span);
         complex_read = !simple;
         // ---- the fragments, one per operation
-        bool generic = ref_span > 0xFFFFll;   // (delta of a later fragment would not fit)
+        bool generic = ref_span > 0xFFFFll || gap_chain;   // (delta of a later fragment would not fit; the base that closes a gap would not sit right behind it)
+        const long long span16 = (ref_span > 0 ? ref_span - 1 : 0) << kFragSpanShift;
         for (int c = 0; c < nc; c++) generic = generic || A.cigar_len[c0 + c] > kDescLenMask;
         if (generic) {
             d.meta |= kDescGeneric;
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(256) void read_shape_kernel(ShapeArgs A)
                 if (t == 'M' || t == '=' || t == 'X') {
                     const int have = max(min(len, n - ri), 0);   // (a CIGAR that runs past the read is refused before it gets here)
                     f.meta |= (uint32_t)have;
-                    f.aoff = (A.base0 + s0 + ri) | ((rp - pos0) << kFragDeltaShift);
+                    f.aoff = (A.base0 + s0 + ri) | span16 | ((rp - pos0) << kFragDeltaShift);
                 } else if (t == 'D' || t == 'N') {
                     // the base that closes the gap: the first base of the next aligned operation (insertions and clips in between
                     // move the index, not the position); without one, only a deletion at the read's end counts, by its own rules
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(256) void read_shape_kernel(ShapeArgs A)
                             else if (walk_op_read_span(tk)) rj += lk;
                         }
                     }
-                    bool counted = false;
+                    bool counted = false, terminal = false;
                     if (idx >= 0 && idx < n) {
                         counted = dq(idx);
                         dir = dir_at(idx);
@@ -198,17 +203,19 @@ __global__ __launch_bounds__(256) void read_shape_kernel(ShapeArgs A)
                         counted = dq(n - 1);
                         dir = dir_at(n - 1);
                         first = (int)(last_mapped + 1 - pos0);
+                        terminal = true;
                     } else if (t == 'D' && c == nc - 2 && ends_in_del_soft) {              // :143-154
                         const int at = n - (int)A.cigar_len[c0 + nc - 1];
                         if (at >= 0 && at < n) {
                             counted = dq(at);
                             dir = dir_at(at);
                             first = (int)(last_mapped + 1 - pos0);
+                            terminal = true;
                         }
                     }
                     if (counted && first >= 0 && first <= 0xFFFF) {
-                        f.meta = rev | kFragDeletion | (uint32_t)count | (dir << kFragDirShift);
-                        f.aoff = (A.base0 + s0) | ((long long)first << kFragDeltaShift);
+                        f.meta = rev | kFragDeletion | (uint32_t)count | (dir << kFragDirShift) | (terminal ? kFragTerminal : 0u);
+                        f.aoff = (A.base0 + s0) | span16 | ((long long)first << kFragDeltaShift);
                         has_del = true;
                     }
                 }
@@ -405,14 +412,12 @@ constexpr int kSegmentPad = 64;
 template <bool kDirs, typename OnBase, typename OnObs>
 __device__ __forceinline__ void walk_segment(const SegmentView& G, int tile_start, int min_bq, int lane, int wid, int n_waves, OnBase on_base, OnObs on_obs)
 {
-    if (G.n_reads <= 0) return;
+    if (G.n_frags <= 0) return;
     const int tile_end = tile_start + kTile - 1;
-    int lo = 0, hi = G.n_reads;
-    if (G.state[kStateUnsorted] == 0) {
-        const int reach = G.state[kStateReach];
-        const long long x_lo = (long long)tile_start - reach + 1;
-        wave_lower_bound2(G.desc, G.n_reads, (int)max(x_lo, -0x7FFFFFFFll), tile_end == 0x7FFFFFFF ? 0x7FFFFFFF : tile_end + 1, lane, &lo, &hi);
-    }
+    const bool sorted = G.state[kStateUnsorted] == 0;
+    const int x_lo = (int)max((long long)tile_start - G.state[kStateReach] + 1, -0x7FFFFFFFll), x_hi = tile_end == 0x7FFFFFFF ? 0x7FFFFFFF : tile_end + 1;
+    int lo = 0, hi = G.n_frags;
+    if (sorted) wave_lower_bound2(G.frag, G.n_frags, x_lo, x_hi, lane, &lo, &hi);
     const int g = lane >> 4, j4 = (lane & 15) * 4;
     const int lane_pos = tile_start + j4;
     // ---- simple reads.  Blocks of 64 descriptors (this wave takes the blocks wid, wid + n_waves, ...), four sub-chunks of sixteen reads
@@ -428,7 +433,7 @@ __device__ __forceinline__ void walk_segment(const SegmentView& G, int tile_star
         auto block_base = [&](int b) { return lo + (wid + min(b, my_blocks - 1) * n_waves) * 64; };
         auto load_desc = [&](int b) {
             const int base = block_base(b);
-            return G.desc[base + min(lane, min(64, hi - base) - 1)];
+            return G.frag[base + min(lane, min(64, hi - base) - 1)];
         };
         // the loads of sub-chunk f (of this wave's sequence) from the descriptors d of its block
         auto issue = [&](const ReadDesc& d, int f, Sub& S) {
@@ -441,23 +446,21 @@ __device__ __forceinline__ void walk_segment(const SegmentView& G, int tile_star
                 const int pos0 = __shfl(d.pos0, srcl, 64);
                 const uint32_t meta = (uint32_t)__shfl((int)d.meta, srcl, 64);
                 const long long aoff = shfl64(d.aoff, srcl);
-                const int n = (live && src < cnt && !(meta & kDescComplex)) ? (int)(meta & kDescLenMask) : 0;
-                const int floor_pos = base + srcl < G.n_floored ? G.floor : 0;
-                const int i_min = max(floor_pos - pos0, 0);   // (floor <= 2^31 - 1, pos0 >= 1)
-                const int s0 = lane_pos - pos0;               // index, in the aligned run, of the base on the lane's first locus
+                const int len = (meta & kFragDeletion) ? 0 : (int)(meta & kDescLenMask);   // (deletion fragments: their own pass below)
+                const int n = (live && src < cnt) ? len : 0;
+                const int first = pos0 + (int)(aoff >> kFragDeltaShift);                   // the fragment's first position
+                const int floor_pos = base + srcl < G.n_floored_frags ? G.floor : 0;
+                const int i_min = max(floor_pos - first, 0);  // (floor <= 2^31 - 1, first >= 1)
+                const int s0 = lane_pos - first;              // index, in the aligned run, of the base on the lane's first locus
                 S.lim[u] = max(n - i_min, 0);
                 S.rel[u] = s0 - i_min;                        // (may wrap when nothing is valid: the wrapped value is far above lim)
-#if defined(PISCES_STORE_ABLATE) && PISCES_STORE_ABLATE == 3
-                const long long at = (aoff + min(max(s0, -3), max((int)(meta & kDescComplex ? 0u : (meta & kDescLenMask)) - 1, -3))) & ~3ll;   // development ablation: aligned loads (wrong bytes)
-#else
-                const long long at = aoff + min(max(s0, -3), max((int)(meta & kDescComplex ? 0u : (meta & kDescLenMask)) - 1, -3));
-#endif
+                const long long at = (aoff & kFragAoffMask) + min(max(s0, -3), max(len - 1, -3));
                 S.bw[u] = load_u32_unaligned(G.bases + at);
                 S.qw[u] = load_u32_unaligned(G.quals + at);
                 S.dw[u] = kDirs ? load_u32_unaligned(G.dirs + at)
                                 : ((meta & kDescReverse) ? (uint32_t)PISCES_DIR_REVERSE * 0x01010101u : (uint32_t)PISCES_DIR_FORWARD * 0x01010101u);
-                S.p0[u] = pos0;
-                S.nn[u] = n;
+                S.p0[u] = pos0;                                               // the READ's ends, for GetAnchorType: Position and
+                S.nn[u] = (int)((aoff >> kFragSpanShift) & 0xFFFF) + 1;       // EndPosition - Position + 1
             }
         };
         auto consume = [&](const Sub& S) {
@@ -494,9 +497,37 @@ __device__ __forceinline__ void walk_segment(const SegmentView& G, int tile_star
             consume(B);
         }
     }
-    // ---- the reads with insertions / deletions / skips (if the segment has any)
-    if (G.state[kStateComplex] == 0) return;
-    walk_segment_complex<kDirs>(G, lo, hi, tile_start, min_bq, lane, wid, n_waves, on_obs);
+    const int frag_bits = G.state[kStateFrags];
+    // ---- the deletion fragments of the range: lane = locus.  A gap's positions count as deletions in the direction and in the anchor
+    // bin of the base that closes it (the first base behind the gap); a deletion at the read's end or before its final soft clip counts
+    // in the last bin (RegionStateManager.cs:143-154, 170-176, 199-213)
+    if (frag_bits & 2) {
+        for (int base = lo + wid * 64; base < hi; base += n_waves * 64) {
+            const int cnt = min(64, hi - base);
+            const ReadDesc d = G.frag[base + min(lane, cnt - 1)];
+            unsigned long long dels = __ballot(lane < cnt && (d.meta & kFragDeletion));
+            while (dels) {
+                const int u = __builtin_ctzll(dels);
+                dels &= dels - 1;
+                const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)d.meta, u);
+                const int pos0 = __builtin_amdgcn_readlane(d.pos0, u);
+                const long long aoff = readlane64(d.aoff, u);
+                const int first = pos0 + (int)(aoff >> kFragDeltaShift), count = (int)(meta & kDescLenMask);
+                const int floor_pos = base + u < G.n_floored_frags ? G.floor : 0;
+                const uint32_t dir = kDirs ? (meta >> kFragDirShift) & 3u : ((meta & kDescReverse) ? (uint32_t)PISCES_DIR_REVERSE : (uint32_t)PISCES_DIR_FORWARD);
+                const int anchor = (meta & kFragTerminal) ? PISCES_NUM_ANCHORS - 1
+                                                          : walk_anchor_type(pos0 + (int)((aoff >> kFragSpanShift) & 0xFFFF), first + count, pos0);
+                const int p = tile_start + lane;
+                if (p >= max(max(first, floor_pos), 1) && p - first < count) on_obs(p, (uint32_t)PISCES_ALLELE_DEL, dir, anchor, 0xFFu);
+            }
+        }
+    }
+    // ---- reads whose fragments did not fit their fields: base by base (read_walk.h)
+    if (frag_bits & 1) {
+        int rlo = 0, rhi = G.n_reads;
+        if (sorted) wave_lower_bound2(G.desc, G.n_reads, x_lo, x_hi, lane, &rlo, &rhi);
+        walk_segment_complex<kDirs>(G, rlo, rhi, tile_start, min_bq, lane, wid, n_waves, on_obs, kDescGeneric);
+    }
 }
 
 // ---- the flush kernel's own form of the walk over simple reads -------------------------------------------------------------------
@@ -868,7 +899,9 @@ __global__ __launch_bounds__(64) void compact_small_kernel(const PiscesCalledAll
 
 // The same walk into the anchor-resolved tensor (RegionState._alleleCounts, RegionState.cs:57) and, with sumq, the base-quality sums
 // (RegionState._sumOfAlleleBaseQualities :61): what accumulate_tiles_kernel makes of tuples, here from the reads (and the tuples).
-// (256 threads a tile for launches that fill the chip, 1024 for the few tiles of one flush of the streaming protocol)
+// gridDim.y workgroups share a tile (each takes every gridDim.y-th block of 64 fragments into a histogram of its own and adds what it
+// counted to the tensor with global atomics): the few tiles of one flush of the streaming protocol — 16 for a 1000-locus block, ~2 850
+// reads each at 2000x — are then spread over the chip instead of sixteen CUs (281 us a block with one workgroup of 1024 threads a tile).
 __global__ __launch_bounds__(1024) void accumulate_store_tiles_kernel(StoreView S, const uint32_t* __restrict__ tuples, const PiscesTile* __restrict__ tiles,
                                                                         int32_t n_tiles, int32_t* __restrict__ counts, int32_t min_bq_,
                                                                         unsigned long long* __restrict__ sumq, const ulonglong2* __restrict__ bq_lut)
@@ -892,12 +925,13 @@ __global__ __launch_bounds__(1024) void accumulate_store_tiles_kernel(StoreView 
             }
         }
     };
-    for (int64_t i = tile.tuple_begin + threadIdx.x; i < tile.tuple_end; i += (int64_t)blockDim.x) {
+    const int sub = (int)blockIdx.y, n_sub = (int)gridDim.y;
+    for (int64_t i = tile.tuple_begin + (int64_t)sub * blockDim.x + threadIdx.x; i < tile.tuple_end; i += (int64_t)blockDim.x * n_sub) {
         const uint32_t v = tuples[i];
         add(PISCES_TUPLE_LOCUS(v), PISCES_TUPLE_ALLELE(v), PISCES_TUPLE_DIR(v), PISCES_TUPLE_ANCHOR(v), v >> 24);
     }
-    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    walk_store(S, tile.start_position, (int)min_bq, lane, wid, (int)blockDim.x / 64,
+    const int lane = threadIdx.x & 63, waves = (int)blockDim.x / 64, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * n_sub + sub;
+    walk_store(S, tile.start_position, (int)min_bq, lane, wid, waves * n_sub,
                [&](int locus, uint32_t base, uint32_t qual, uint32_t dir, bool valid, int pos0, int n_aligned) {
                    if (!valid) return;
                    // GetAnchorType (RegionStateManager.cs:83-116); EndPosition of a read of one aligned run = pos0 + run - 1
@@ -913,7 +947,9 @@ __global__ __launch_bounds__(1024) void accumulate_store_tiles_kernel(StoreView 
     for (int g = threadIdx.x; g < n; g += (int)blockDim.x) {
         const int lo = g / PISCES_COUNTS_PER_LOCUS, c = g - lo * PISCES_COUNTS_PER_LOCUS;
         const int v = hist[lo * kAnchStride + c];
-        if (v) dst[g] += v;
+        if (!v) continue;
+        if (n_sub > 1) atomicAdd(dst + g, v);
+        else dst[g] += v;
     }
 }
 

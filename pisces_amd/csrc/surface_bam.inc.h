@@ -167,6 +167,7 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
     // of one launch: the launches did not overlap the transfers on this runtime, and one launch per slice on ONE stream serialises at
     // 4.5 ms a launch, the time one block takes one wave.)
     PISCES_HIP_CHECK(h, hipMemcpyAsync(B.d_file.p, file, (size_t)n_bytes, hipMemcpyHostToDevice, h->stream));
+    h->pcie[0] += n_bytes + n_blocks * (int64_t)sizeof(PiscesBgzfBlock);
     hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)n_blocks), dim3(64), 0, h->stream, (const uint8_t*)B.d_file.p,
                        (const PiscesBgzfBlock*)B.d_blocks.p, n_blocks, B.d_stream.p, B.d_status.p);
     // record boundaries without a serial pass over the bytes

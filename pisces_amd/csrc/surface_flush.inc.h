@@ -364,6 +364,7 @@ static int32_t call_blocks_finish(PiscesHip* h, const CallBlocksInFlight& st, in
     *total = 0;
     if (!st.active) return PISCES_OK;
     *total = st.hdr[0];
+    h->pcie[1] += (int64_t)*total * (int64_t)sizeof(PiscesCalledAllele) + 16;
     *n_called += st.hdr[1];
     if (st.drop_now && kept) std::memcpy(kept, st.hdr + 2, sizeof(unsigned long long));
     if ((size_t)*total > st.spec) {
@@ -785,6 +786,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
             h->h_counts_cap = n_counts + n_counts / 2;
         }
         if (n_tiles > 0) {
+            h->pcie[3] += (int64_t)(n_counts * sizeof(int32_t));
             PISCES_HIP_CHECK(h, hipMemcpyAsync(h->h_counts, h->d_counts.p, n_counts * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
             PISCES_TIMED_WAIT(h, hipStreamSynchronize(h->stream));
         } else {
@@ -861,6 +863,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
                            h->d_alleles.p, h->d_ref.p, h->ref_len, h->cfg.expect_stitched_reads, h->d_cand_records.p, h->d_cand_callable.p, h->P,
                            window ? h->d_sumq.p : (const double*)nullptr);
         PISCES_HIP_CHECK(h, hipGetLastError());
+        h->pcie[1] += (int64_t)(raw.size() * (sizeof(PiscesCalledAllele) + 1));
         PISCES_HIP_CHECK(h, hipMemcpyAsync(raw.data(), h->d_cand_records.p, raw.size() * sizeof(PiscesCalledAllele), hipMemcpyDeviceToHost, h->stream));
         PISCES_HIP_CHECK(h, hipMemcpyAsync(callable.data(), h->d_cand_callable.p, callable.size(), hipMemcpyDeviceToHost, h->stream));
         PISCES_TIMED_WAIT(h, hipStreamSynchronize(h->stream));
@@ -1211,14 +1214,28 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
     if (n_cand) *n_cand = (int64_t)h->pending_cands.size();
     if (allele_bytes) *allele_bytes = pool_bytes;
     const bool cand_too_small = cand_out && ((int64_t)h->pending_cands.size() > cand_capacity || (alleles_out && pool_bytes > allele_capacity));
-    const PiscesCalledAllele* const pending_data = h->pending_view ? h->pending_view : h->pending.data();
+    const PiscesCalledAllele* pending_data = h->pending_view ? h->pending_view : h->pending.data();
     const size_t pending_n = h->pending_view ? h->pending_view_n : h->pending.size();
+    auto& W = h->view;
+    if (W.wanted) {
+        // pisces_hip_flush_view: the rows are handed out where they lie — the pinned download buffer as the kernels wrote it, or the
+        // merged rows, which then move into a vector that lives until the next flush
+        if (!h->pending_view) { W.rows.swap(h->pending); pending_data = W.rows.data(); }
+        W.index.swap(h->pending_cand_index);
+        W.cands.resize(h->pending_cands.size());
+        W.alleles.resize((size_t)pool_bytes);
+        cand_out = W.cands.data();
+        alleles_out = W.alleles.data();
+        W.data = pending_data;
+        W.n = pending_n;
+    } else {
     if ((int64_t)pending_n > capacity || cand_too_small) {
         *n_out = (int64_t)pending_n;
         return fail(h, PISCES_E_BUFFER_TOO_SMALL, "flush: output buffer too small");
     }
     if (pending_n) std::memcpy(out, pending_data, pending_n * sizeof(PiscesCalledAllele));
     if (cand_index_out && pending_n) std::memcpy(cand_index_out, h->pending_cand_index.data(), pending_n * sizeof(int32_t));
+    }
     if (cand_out) {
         int64_t off = 0;
         for (size_t i = 0; i < h->pending_cands.size(); i++) {
@@ -1265,6 +1282,61 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
     h->pending_cand_index.clear();
     h->pending_cands.clear();
     h->pending_keys.clear();
+    return PISCES_OK;
+    });
+}
+
+// The flush without the copy into a caller's array: the rows (and, for insertion / deletion / MNV rows, candidate index, candidates and
+// allele strings) stay in memory of the handle — for a batch the device called alone that is the pinned buffer the last kernel wrote
+// them to — and the caller reads them there until the next flush.
+int32_t pisces_hip_flush_view(PiscesHip* h, int32_t up_to_position, const PiscesCalledAllele** rows, int64_t* n_rows, const int32_t** cand_index,
+                              const PiscesCandidate** cands, int64_t* n_cand, const uint8_t** alleles, int64_t* allele_bytes)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (!rows || !n_rows) return fail(h, PISCES_E_INVALID_ARG, "flush_view: null output");
+    *rows = nullptr; *n_rows = 0;
+    auto& W = h->view;
+    struct Wanted { bool& f; explicit Wanted(bool& x) : f(x) { f = true; } ~Wanted() { f = false; } } wanted(W.wanted);
+    W.data = nullptr; W.n = 0;
+    int64_t n = 0, nc = 0, nb = 0;
+    PiscesCandidate none;   // (a non-null candidate output makes the flush fill W.cands / W.alleles)
+    const int32_t rc = pisces_hip_flush_ex(h, up_to_position, nullptr, 0, &n, nullptr, &none, 0, &nc, nullptr, 0, &nb);
+    if (rc) return rc;
+    *rows = W.data;
+    *n_rows = (int64_t)W.n;
+    // a batch the device called alone has no index (every row is a Reference or SNV row): NULL then
+    if (cand_index) *cand_index = W.index.size() == W.n && W.n ? W.index.data() : nullptr;
+    if (cands) *cands = W.cands.empty() ? nullptr : W.cands.data();
+    if (n_cand) *n_cand = (int64_t)W.cands.size();
+    if (alleles) *alleles = W.alleles.empty() ? nullptr : W.alleles.data();
+    if (allele_bytes) *allele_bytes = (int64_t)W.alleles.size();
+    return PISCES_OK;
+    });
+}
+
+// pisces_hip_flush_end the same way: the rows where pisces_hip_flush_begin's work left them
+int32_t pisces_hip_flush_end_view(PiscesHip* h, const PiscesCalledAllele** rows, int64_t* n_rows)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    if (!rows || !n_rows) return fail(h, PISCES_E_INVALID_ARG, "flush_end_view: null output");
+    *rows = nullptr; *n_rows = 0;
+    auto& A = h->async;
+    if (A.state == 0) return fail(h, PISCES_E_STATE, "flush_end_view: no pisces_hip_flush_begin before it");
+    if (A.state == 1) {   // wait as pisces_hip_flush_end does: a call with no room for rows completes the flush and reports the count
+        int64_t need = 0;
+        const int32_t rc = pisces_hip_flush_end(h, nullptr, 0, &need);
+        if (rc == PISCES_OK) return PISCES_OK;   // no rows at all
+        if (rc != PISCES_E_BUFFER_TOO_SMALL) return rc;
+    }
+    *rows = A.data;
+    *n_rows = (int64_t)A.n;
+    A.state = 0;
+    A.data = nullptr;
+    A.n = 0;
+    A.n_cands = 0;
+    A.n_allele_bytes = 0;
     return PISCES_OK;
     });
 }
@@ -1584,6 +1656,17 @@ int32_t pisces_hip_host_time(PiscesHip* h, double out[4], int32_t reset)
     for (int i = 0; i < 4; i++) out[i] = h->host_time[i];
     if (reset)
         for (int i = 0; i < 4; i++) h->host_time[i] = 0.0;
+    return PISCES_OK;
+    });
+}
+
+int32_t pisces_hip_transfer_bytes(PiscesHip* h, int64_t out[4], int32_t reset)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h || !out) return PISCES_E_INVALID_ARG;
+    for (int i = 0; i < 4; i++) out[i] = h->pcie[i];
+    if (reset)
+        for (int i = 0; i < 4; i++) h->pcie[i] = 0;
     return PISCES_OK;
     });
 }

@@ -353,6 +353,7 @@ static int32_t enqueue_candidate_discovery(PiscesHip* h, const DevReadBatch& db,
                 h->found.h_cap = need + need / 2;
             }
             if (!h->found.done) PISCES_HIP_CHECK(h, hipEventCreateWithFlags(&h->found.done, hipEventDisableTiming));
+            h->pcie[2] += (int64_t)rec_bytes + found_pool;
             PISCES_HIP_CHECK(h, hipMemcpyAsync(h->found.h, h->d_found.p, rec_bytes, hipMemcpyDeviceToHost, h->stream));
             if (found_pool > 0)
                 PISCES_HIP_CHECK(h, hipMemcpyAsync(h->found.h + rec_bytes, h->d_found_pool.p, (size_t)found_pool, hipMemcpyDeviceToHost, h->stream));
@@ -453,6 +454,10 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
     if (batch->n_reads == 0) return PISCES_OK;
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     { int32_t rcf = consume_found(h); if (rcf) return rcf; }
+    {   // what crosses PCIe for this batch (pisces_hip_transfer_bytes): the arrays as they are handed over
+        const int64_t n_ops = batch->cigar_offset[batch->n_reads], n_bases = batch->seq_offset[batch->n_reads];
+        h->pcie[0] += (int64_t)batch->n_reads * 13 + 8 + n_ops * (batch->deletion_directions ? 7 : 5) + n_bases * (batch->directions ? 3 : 2);
+    }
     if (h->read_path == 1) return add_reads_store(h, batch);
     const int32_t nr = batch->n_reads;
     const int32_t minBQ = h->cfg.min_base_call_quality;

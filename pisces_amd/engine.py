@@ -161,6 +161,26 @@ class HipVariantCaller:
             _check(self._h, rc)
             return out[: n.value]
 
+    def CallView(self, upToPosition=None):
+        """pisces_hip_flush_view: Call() whose rows are NOT copied — the array aliases memory of the handle (the pinned buffer the device
+        wrote the records to) and is valid until the next Call* on this caller."""
+        rows, n = C.c_void_p(), C.c_int64(0)
+        _check(self._h, lib.pisces_hip_flush_view(self._h, -1 if upToPosition is None else int(upToPosition), C.byref(rows), C.byref(n), None, None, None, None, None))
+        return self._rows_at(rows, n.value)
+
+    def CallEndView(self):
+        """pisces_hip_flush_end_view: CallEnd() without the copy (valid until the next Call* / CallBegin)."""
+        rows, n = C.c_void_p(), C.c_int64(0)
+        _check(self._h, lib.pisces_hip_flush_end_view(self._h, C.byref(rows), C.byref(n)))
+        return self._rows_at(rows, n.value)
+
+    @staticmethod
+    def _rows_at(rows, n):
+        if not n:
+            return np.zeros(0, dtype=_abi.CALLED_ALLELE_DTYPE)
+        buf = (C.c_uint8 * (n * _abi.CALLED_ALLELE_DTYPE.itemsize)).from_address(rows.value)
+        return np.frombuffer(buf, dtype=_abi.CALLED_ALLELE_DTYPE, count=n)
+
     def CallBegin(self, upToPosition=None):
         """pisces_hip_flush_begin: the flush enqueued, DoneProcessing committed; the alleles come with CallEnd.  In between the next
         reads may be staged and added."""
@@ -319,6 +339,12 @@ class HipVariantCaller:
         flushes = int(t[3])
         return {"add_reads_s": t[0], "flush_s": t[1], "flush_wait_s": t[2], "flushes": flushes,
                 "host_ms_per_flush": (t[1] - t[2]) / flushes * 1e3 if flushes else 0.0}
+
+    def TransferBytes(self, reset=False):
+        """pisces_hip_transfer_bytes: what crossed PCIe for this caller since the last reset."""
+        b = (C.c_int64 * 4)()
+        _check(self._h, lib.pisces_hip_transfer_bytes(self._h, b, 1 if reset else 0))
+        return {"h2d_reads": int(b[0]), "d2h_records": int(b[1]), "d2h_candidates": int(b[2]), "d2h_counts": int(b[3])}
 
     # ---- device-resident surface ----
     def call_tiles(self, d_tuples, d_tiles, n_tiles, d_ref, ref_start, ref_len, d_records, capacity, d_tile_results, stream=None):

@@ -1940,3 +1940,61 @@ def test_flush_pair_gives_what_flush_gives_while_the_next_reads_are_added(torch_
 def test_device_count(torch_cuda):
     from pisces_amd import engine
     assert engine.device_count() >= 1
+
+
+@pytest.mark.gpu
+def test_flush_views_hand_out_the_rows_the_copying_flushes_return(torch_cuda):
+    """pisces_hip_flush_view / pisces_hip_flush_end_view: the same rows as pisces_hip_flush / pisces_hip_flush_end, read where they lie."""
+    import ctypes as C
+    from pisces_amd import _native, engine, synth
+    cfg = _abi.default_config()
+    p = synth.make_pileup(6000, 300, seed=5)
+    ref = p.ref.cpu().numpy()
+    A = p.base.shape[0]
+    whole = synth.reads_of(p, A, first_amplicon=0)
+    half = A // 2
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(ref)
+        c.AddAlleleCounts(whole)
+        want = [c.Call(p.region_start + half * synth.READ_LEN - 1).copy(), c.Call(None).copy()]
+    assert len(want[0]) > 0 and len(want[1]) > 0
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(ref)
+        c.AddAlleleCounts(whole)
+        got0 = c.CallView(p.region_start + half * synth.READ_LEN - 1).copy()      # (the view dies with the next flush: copy before it)
+        c.CallBegin(None)
+        got1 = c.CallEndView().copy()
+        assert len(c.CallView(None)) == 0                                           # nothing left
+    assert got0.tobytes() == want[0].tobytes() and got1.tobytes() == want[1].tobytes()
+    # a batch with host-side candidates (a deletion): the merged rows, the candidate index and the allele strings through the view
+    rng = np.random.default_rng(2)
+    refb = bytes(rng.choice(list(b"ACGT"), 2600).astype(np.uint8))
+    reads = []
+    for i in range(90):
+        s = 900 + (i % 7) * 3
+        if i % 3 == 0:
+            reads.append({"pos": s, "cigar": [("M", 60), ("D", 4), ("M", 60)], "seq": (refb[s - 1:s + 59] + refb[s + 63:s + 123]).decode(), "quals": [37] * 120, "reverse": bool(i % 2)})
+        else:
+            reads.append({"pos": s, "cigar": [("M", 124)], "seq": refb[s - 1:s + 123].decode(), "quals": [37] * 124, "reverse": bool(i % 2)})
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(refb)
+        c.AddAlleleCounts(reads)
+        want_recs, want_alleles = c.CallWithAlleles(None)
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(refb)
+        c.AddAlleleCounts(reads)
+        rows, n, idx, cands, nc, pool, nb = C.c_void_p(), C.c_int64(0), C.c_void_p(), C.c_void_p(), C.c_int64(0), C.c_void_p(), C.c_int64(0)
+        rc = _native.lib.pisces_hip_flush_view(c._h, -1, C.byref(rows), C.byref(n), C.byref(idx), C.byref(cands), C.byref(nc), C.byref(pool), C.byref(nb))
+        assert rc == 0 and n.value == len(want_recs) and nc.value >= 1 and idx.value and cands.value and pool.value
+        got = np.frombuffer((C.c_uint8 * (64 * n.value)).from_address(rows.value), dtype=_abi.CALLED_ALLELE_DTYPE).copy()
+        index = np.frombuffer((C.c_int32 * n.value).from_address(idx.value), dtype=np.int32).copy()
+        cand = (_abi.PiscesCandidate * nc.value).from_address(cands.value)
+        text = bytes((C.c_uint8 * nb.value).from_address(pool.value))
+        got_alleles = []
+        for r, ci in zip(got, index):
+            if ci < 0:
+                got_alleles.append((_abi.BASE_OF_ALLELE[_abi.info_ref(r["info"])], _abi.BASE_OF_ALLELE[_abi.info_alt(r["info"])]))
+            else:
+                o = cand[ci].allele_offset
+                got_alleles.append((text[o:o + cand[ci].ref_len].decode(), text[o + cand[ci].ref_len:o + cand[ci].ref_len + cand[ci].alt_len].decode()))
+    assert got.tobytes() == want_recs.tobytes() and got_alleles == want_alleles

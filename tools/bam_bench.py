@@ -9,7 +9,12 @@ import numpy as np
 from tools.bgzf_bench import make_bgzf
 
 
-def make_bam(n_reads, read_len=150, seed=3):
+def make_bam(n_reads, read_len=150, seed=3, copies=1, from_reference=False):
+    """header + n_reads * copies records; copies > 1: the same reads again, each copy moved behind the one before it on the chromosome
+    (only the position bytes differ: random bases and qualities are what takes the time to make, and DEFLATE's 32 KiB window does not
+    see from one copy into the next).  from_reference: the reads are windows of a random reference with 0.5 % substituted bases (a BAM
+    of a sample that looks like its genome: about one called allele a locus) instead of random bases (every base a mismatch), and the
+    reference comes back with the bytes: (stream, reference letters, 1-based)."""
     rng = np.random.default_rng(seed)
     hdr = b"BAM\x01" + struct.pack("<i", 0) + struct.pack("<i", 1) + struct.pack("<i", 5) + b"chr1\0" + struct.pack("<i", 250_000_000)
     name = b"read/0000000\0"
@@ -33,11 +38,27 @@ def make_bam(n_reads, read_len=150, seed=3):
     rec[:, 36:36 + len(name)] = np.frombuffer(name, np.uint8)
     c0 = 36 + len(name)
     rec[:, c0:c0 + 4] = np.frombuffer(struct.pack("<I", (read_len << 4) | 0), np.uint8)
-    codes = np.array([1, 2, 4, 8], dtype=np.uint8)[rng.integers(0, 4, (n_reads, read_len))]
+    fixed_span = n_reads // 3 + 2000 + read_len + 1     # positions lie in [1000, 1000 + n_reads // 3 + 1000)
+    reference = None
+    if from_reference:
+        unit = rng.integers(0, 4, fixed_span).astype(np.uint8)
+        letters = unit[(pos[:, None] - 1000) + np.arange(read_len)[None, :]]
+        wrong = rng.random((n_reads, read_len)) < 0.005
+        letters = np.where(wrong, (letters + rng.integers(1, 4, (n_reads, read_len))) & 3, letters).astype(np.uint8)
+        codes = np.array([1, 2, 4, 8], dtype=np.uint8)[letters]
+        reference = np.frombuffer(b"ACGT", np.uint8)[np.concatenate([rng.integers(0, 4, 1000).astype(np.uint8), np.tile(unit, copies), rng.integers(0, 4, 1000).astype(np.uint8)])]
+    else:
+        codes = np.array([1, 2, 4, 8], dtype=np.uint8)[rng.integers(0, 4, (n_reads, read_len))]
     rec[:, c0 + 4:c0 + 4 + read_len // 2] = (codes[:, 0::2] << 4) | codes[:, 1::2]
     q0 = c0 + 4 + (read_len + 1) // 2
     rec[:, q0:q0 + read_len] = rng.choice(np.array([12, 23, 30, 37, 41], dtype=np.uint8), (n_reads, read_len), p=[.03, .12, .2, .45, .2])
-    return hdr + rec.tobytes()
+    if copies == 1 and not from_reference:
+        return hdr + rec.tobytes()
+    parts, span = [hdr], (fixed_span if from_reference else int(pos[-1]) - 1000 + read_len + 1)
+    for k in range(copies):
+        put32(8, pos + k * span)
+        parts.append(rec.tobytes())
+    return (b"".join(parts), reference) if from_reference else b"".join(parts)
 
 
 def bam_of_read_batch(rb, chrom=b"chr1", chrom_len=250_000_000):

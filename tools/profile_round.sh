@@ -86,6 +86,15 @@ if f and w:
          "hbm_bytes_per_launch": f * 1024 * corr + w * 1024, "fetch_size_kib_raw": f, "fetch_correction": corr, "write_size_kib_raw": w,
          "kernel": "pisces::call_tiles_wave_kernel", "run": f"{tag} {time.strftime('%Y-%m-%d %H:%M:%S')} tools/profile_round.sh",
          "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-include-regex call_tiles, separate passes over bench.py (tools/profile_round.sh)"}
+    sf, sw = None, None
+    for name, key in (("store_fetch", "FETCH_SIZE"), ("store_write", "WRITE_SIZE")):
+        for ln in open(f"{out}/pmc_{name}.txt"):
+            m = re.search(r"call_store_tiles\S* " + key + r" mean per dispatch ([0-9.e+]+)", ln)
+            if m:
+                sf, sw = (float(m.group(1)), sw) if key == "FETCH_SIZE" else (sf, float(m.group(1)))
+    if sf and sw:   # tools/store_bench.py's one-batch flush of the same configuration (4 B / lane loads: the same x 2, tools/fetch_calibration.py)
+        t["streaming"] = {"kernel": "pisces::call_store_tiles_kernel<2>", "loci": t["loci"], "depth": t["depth"], "fetch_size_kib_raw": sf, "fetch_correction": corr,
+                          "write_size_kib_raw": sw, "hbm_bytes_per_launch": sf * 1024 * corr + sw * 1024, "run": t["run"] + " (pmc_store_fetch / pmc_store_write over tools/store_bench.py)"}
     json.dump(t, open(f"{out}/traffic.json", "w"), indent=1)
     print("traffic.json:", t["hbm_bytes_per_launch"], "bytes per launch; algorithmic", line["roofline"]["algorithmic_bytes_per_launch"])
 PY
