@@ -364,10 +364,12 @@ def end_to_end_full(pileup, cfg, engine, torch):
     return out, roof
 
 
-def from_large_bam(cfg, engine, reads=400_000, copies=7):
-    """the BAM surface on a file of >= 256 MB: 2.8 M reads of 150 bases drawn from a random reference with 0.5 % wrong
-    bases (tools/bam_bench.make_bam), BGZF at zlib level 1 (~330 MB), through pisces_hip_bam_decode -> pisces_hip_add_decoded_reads ->
-    flush; only the compressed bytes cross PCIe on the way in.  Generation (~20 s of numpy and zlib) is not timed."""
+def from_large_bam(cfg, engine, reads=400_000, copies=9):
+    """the BAM surface on a file of >= 256 MB: 3.6 M reads of 150 bases drawn from a random reference with 0.5 % wrong
+    bases at ~450x (tools/bam_bench.make_bam), BGZF at zlib level 1 (1.0 GB inflated, ~265 MB compressed: position-sorted reads of one
+    locus repeat each other inside DEFLATE's window, as in a real high-depth BAM), through pisces_hip_bam_decode ->
+    pisces_hip_add_decoded_reads -> flush; only the compressed bytes cross PCIe on the way in.  Generation (~25 s of numpy and zlib) is
+    not timed."""
     import numpy as np
     from tools.bam_bench import make_bam
     from tools.bgzf_bench import make_bgzf
@@ -481,7 +483,7 @@ def main():
     ap.add_argument("--depth", type=int, default=DEPTH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the streaming-surface figures (host reads -> records)")
-    ap.add_argument("--no-large-bam", action="store_true", help="skip the 330 MB BAM figure of end_to_end_full (~20 s to make the file)")
+    ap.add_argument("--no-large-bam", action="store_true", help="skip the 265 MB BAM figure of end_to_end_full (~25 s to make the file)")
     ap.add_argument("--no-shard-check", action="store_true", help="skip the on-device check of one cut of the interval partition")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra multi-stream figure (profiling runs: its overlapped "
                     "launches would mix into the per-kernel statistics of the timed region)")

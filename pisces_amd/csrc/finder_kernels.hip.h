@@ -206,4 +206,127 @@ __global__ __launch_bounds__(256) void find_emit_kernel(DevReadBatch b, const ui
     }
 }
 
+// ---- RegionState.AddCandidate for the records of one batch, on the device ------------------------------------------------------
+// find_emit_kernel leaves one record per read event; the reference merges equal candidates as they arrive (RegionState.cs:94-160: same
+// position, type, alleles — and, when open ends are tracked, the same open ends — add their support and well-anchored support by
+// direction; a position's candidates stay in order of first arrival).  Here the records of a batch are merged before they cross PCIe:
+//   found_merge_kernel    lane = record.  Lanes of a wave that hold the same candidate are added up first (the reads that carry a
+//                         variant are neighbours in read order, so most of a variant's ~VAF x depth records meet in a few waves); every
+//                         distinct candidate of the wave then goes to an open-addressing table of record indices — the first to claim a
+//                         slot owns the group, the others compare against the owner's record (the full key, no hash trust) and add
+//                         their sums to the owner's accumulators, with the smallest record index of the group (= first arrival)
+//   found_gather_kernel   the owners, each as the record of its group's FIRST arrival (whose open ends the merged candidate keeps
+//                         when open ends are not part of the identity) with the group's sums, straight into pinned host memory
+// The host puts the groups back into order of first arrival and merges them into the blocks (candidates of earlier batches included).
+struct DevMerged {   // 96 bytes
+    DevFound f;
+    int32_t sup[3], anch[3];
+    int32_t first;       // record index of the group's first arrival
+    int32_t pad;
+};
+static_assert(sizeof(DevMerged) == 96, "DevMerged is 96 bytes");
+constexpr int kMergeAcc = 8;   // int32 per record: sup[3], anch[3], 0x7FFFFFFF - first (atomicMax), owner flag
+
+__device__ __forceinline__ int found_alt_len(const FoundCandidate& c) { return c.category == PISCES_CAT_DELETION ? 0 : c.length; }
+__device__ __forceinline__ const uint8_t* found_alt_bytes(const DevFound& f, const uint8_t* pool)
+{
+    return found_alt_len(f.c) > kFoundInline ? pool + f.pool_offset : f.alt;
+}
+// CandidateAllele.Equals as RegionState.AddCandidate uses it: the REF allele follows from (position, category, length)
+__device__ __forceinline__ bool found_same_key(const DevFound& a, const DevFound& b, const uint8_t* pool, int track_open)
+{
+    if (a.c.position != b.c.position || a.c.category != b.c.category || a.c.length != b.c.length) return false;
+    if (track_open && (a.c.open_left != b.c.open_left || a.c.open_right != b.c.open_right)) return false;
+    const int n = found_alt_len(a.c);
+    if (n > kFoundInline && (a.pool_offset < 0 || b.pool_offset < 0)) return false;   // (a long allele that did not fit the pool: overflow is reported anyway)
+    const uint8_t* pa = found_alt_bytes(a, pool);
+    const uint8_t* pb = found_alt_bytes(b, pool);
+    for (int k = 0; k < n; k++)
+        if (pa[k] != pb[k]) return false;
+    return true;
+}
+__device__ __forceinline__ uint64_t found_key_hash(const DevFound& f, const uint8_t* pool, int track_open)
+{
+    uint64_t x = 0xcbf29ce484222325ull;
+    auto mix = [&](uint64_t v) { x = (x ^ v) * 0x100000001b3ull; x ^= x >> 29; };
+    mix((uint32_t)f.c.position);
+    mix((uint32_t)f.c.category | ((uint32_t)f.c.length << 8));
+    if (track_open) mix(0x100u | (uint32_t)f.c.open_left | ((uint32_t)f.c.open_right << 1));
+    const int n = found_alt_len(f.c);
+    if (n <= kFoundInline || f.pool_offset >= 0) {
+        const uint8_t* p = found_alt_bytes(f, pool);
+        for (int k = 0; k < n; k++) mix(p[k]);
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(256) void found_merge_kernel(const DevFound* __restrict__ rec, int32_t n, const uint8_t* __restrict__ pool,
+                                                          int32_t* __restrict__ tab, uint32_t cap_mask, int32_t* __restrict__ acc, int32_t track_open)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    DevFound f = {};
+    bool live = false;
+    if (i < n) {
+        f = rec[i];
+        live = f.c.category != kFoundHole;
+    }
+    const uint64_t key = live ? found_key_hash(f, pool, track_open) : 0ull;
+    const int dir = live ? (int)f.c.dir : 3, anchored = live && f.c.well_anchored;
+    // ---- the wave's records of one candidate, added up in the lowest lane that holds it
+    int sup[3] = {0, 0, 0}, anch[3] = {0, 0, 0};
+    bool leader = false;
+    unsigned long long todo = __ballot(live);
+    while (todo) {
+        const int l0 = __builtin_ctzll(todo);
+        const uint64_t k0 = ((uint64_t)(uint32_t)__shfl((int)(key >> 32), l0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)key, l0, 64);
+        const int j = __shfl(i, l0, 64);
+        bool same = ((todo >> lane) & 1ull) && key == k0;
+        if (same && lane != l0) same = found_same_key(f, rec[j], pool, track_open);
+        const unsigned long long grp = __ballot(same);
+        const int s0 = __popcll(__ballot(same && dir == 0)), s1 = __popcll(__ballot(same && dir == 1)), s2 = __popcll(__ballot(same && dir == 2));
+        const int a0 = __popcll(__ballot(same && anchored && dir == 0)), a1 = __popcll(__ballot(same && anchored && dir == 1)),
+                  a2 = __popcll(__ballot(same && anchored && dir == 2));
+        if (lane == l0) { leader = true; sup[0] = s0; sup[1] = s1; sup[2] = s2; anch[0] = a0; anch[1] = a1; anch[2] = a2; }
+        todo &= ~grp;
+    }
+    if (!leader) return;
+    // ---- the table: the first record to claim a slot owns its group
+    uint32_t at = (uint32_t)(key ^ (key >> 31)) & cap_mask;
+    int owner;
+    for (;;) {
+        const int cur = atomicCAS(&tab[at], -1, i);
+        if (cur == -1) { owner = i; break; }
+        if (found_same_key(f, rec[cur], pool, track_open)) { owner = cur; break; }
+        at = (at + 1) & cap_mask;
+    }
+    int32_t* a = acc + (int64_t)owner * kMergeAcc;
+    for (int d = 0; d < 3; d++) {
+        if (sup[d]) atomicAdd(a + d, sup[d]);
+        if (anch[d]) atomicAdd(a + 3 + d, anch[d]);
+    }
+    atomicMax(a + 6, 0x7FFFFFFF - i);        // (lanes of a wave hold ascending record indices: the leader's is the smallest of its records)
+    if (owner == i) a[7] = 1;
+}
+
+// out: pinned host memory, out[0 .. *cursor) on return (any order: the host sorts by `first`)
+__global__ __launch_bounds__(256) void found_gather_kernel(const DevFound* __restrict__ rec, int32_t n, const int32_t* __restrict__ acc,
+                                                           DevMerged* __restrict__ out, unsigned int* __restrict__ cursor)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const int32_t* a = acc + (int64_t)min(i, n - 1) * kMergeAcc;
+    const bool owner = i < n && a[7] == 1;
+    const unsigned long long owners = __ballot(owner);
+    if (!owners) return;
+    unsigned int base = 0;
+    if (lane == __builtin_ctzll(owners)) base = atomicAdd(cursor, (unsigned int)__popcll(owners));
+    base = (unsigned int)__shfl((int)base, __builtin_ctzll(owners), 64);
+    if (!owner) return;
+    DevMerged m;
+    m.first = 0x7FFFFFFF - a[6];
+    m.f = rec[m.first];
+    for (int d = 0; d < 3; d++) { m.sup[d] = a[d]; m.anch[d] = a[3 + d]; }
+    m.pad = 0;
+    out[base + (unsigned int)__popcll(owners & ((1ull << lane) - 1ull))] = m;
+}
+
 }  // namespace pisces

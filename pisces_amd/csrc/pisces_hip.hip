@@ -278,12 +278,16 @@ struct PiscesHip {
     DeviceBuf<int32_t> d_found_slots, d_found_pool_first;
     DeviceBuf<unsigned int> d_found_misc;    // [0] pool cursor, [1] overflow flag
     DeviceBuf<long long> d_found_totals;
+    DeviceBuf<int32_t> d_merge_tab, d_merge_acc;   // found_merge_kernel: the table of group owners, the accumulators (kMergeAcc int32 a record)
+    int device_merge = -1;                   // PISCES_HIP_DEVICE_MERGE: 0 the records come back one per read event, 1 merged whatever their number, -1 (default) merged from 2048 records up
     struct FoundPending {
-        uint8_t* h = nullptr;                // pinned: DevFound[n_slots], then the pool bytes, then misc[2]
+        bool merged = false;                 // h holds DevMerged[misc[2]] (any order) instead of DevFound[n_slots]
+        uint8_t* h = nullptr;                // pinned: DevFound[n_slots] (or room for DevMerged[n_slots]), then the pool bytes, then misc[3]
         size_t h_cap = 0;
         hipEvent_t done = nullptr;
         bool in_flight = false;
         int64_t n_slots = 0, pool_bytes = 0;
+        std::vector<int32_t> order;          // consume_found: group of each first-arrival record index
     } found;
 
     // BAM decode on the device (bam_kernels.hip.h): file bytes -> inflated stream -> read batch, all handle-owned and grow-only
@@ -613,6 +617,7 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         if (rp && std::string(rp) == "log") h->read_path = 0;
         if (const char* v = getenv("PISCES_HIP_STORE_DIRECT_BYTES")) h->store_direct_bytes = (size_t)std::max(0ll, atoll(v));
         if (const char* v = getenv("PISCES_HIP_STORE_WAVES")) h->store_waves = atoi(v);
+        if (const char* v = getenv("PISCES_HIP_DEVICE_MERGE")) h->device_merge = atoi(v) != 0 ? 1 : 0;   // the A/B of tests/test_read_store.py
         if (const char* v = getenv("PISCES_HIP_STORE_SEAL_BYTES")) h->store_seal_bytes = (size_t)std::max(0ll, atoll(v));
     }
     {
@@ -741,6 +746,7 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     if (h->found.done) (void)hipEventDestroy(h->found.done);
     h->found.done = nullptr;
     h->d_found.release(); h->d_found_pool.release(); h->d_found_slots.release(); h->d_found_pool_first.release();
+    h->d_merge_tab.release(); h->d_merge_acc.release();
     h->d_found_misc.release(); h->d_found_totals.release();
     h->d_cands.release(); h->d_alleles.release(); h->d_cand_records.release(); h->d_cand_callable.release();
     h->segments.clear();

@@ -342,8 +342,9 @@ static int32_t enqueue_candidate_discovery(PiscesHip* h, const DevReadBatch& db,
             hipLaunchKernelGGL(find_emit_kernel, dim3(grid), dim3(256), 0, h->stream, db, d_deldirs, (const uint8_t*)h->d_ref.p, h->ref_len, FP, d_slots,
                                d_pool_first, h->d_found.p, h->d_found_pool.p, h->d_found_misc.p, (int32_t)found_pool, (int32_t*)(h->d_found_misc.p + 1));
             PISCES_HIP_CHECK(h, hipGetLastError());
-            // records + pool + {cursor, overflow} come back into pinned memory; consume_found waits for them when they are needed
-            const size_t rec_bytes = (size_t)found_slots * sizeof(DevFound), pool_al = ((size_t)found_pool + 15) & ~(size_t)15;
+            // records + pool + {cursor, overflow, merged groups} come back into pinned memory; consume_found waits for them when they are needed
+            const bool merge = h->device_merge == 1 || (h->device_merge < 0 && found_slots >= 2048);
+            const size_t rec_bytes = (size_t)found_slots * (merge ? sizeof(DevMerged) : sizeof(DevFound)), pool_al = ((size_t)found_pool + 15) & ~(size_t)15;
             const size_t need = rec_bytes + pool_al + 16;
             if (need > h->found.h_cap) {
                 if (h->found.h) (void)hipHostFree(h->found.h);
@@ -353,11 +354,29 @@ static int32_t enqueue_candidate_discovery(PiscesHip* h, const DevReadBatch& db,
                 h->found.h_cap = need + need / 2;
             }
             if (!h->found.done) PISCES_HIP_CHECK(h, hipEventCreateWithFlags(&h->found.done, hipEventDisableTiming));
+            if (merge) {
+                // RegionState.AddCandidate on the device (found_merge_kernel / found_gather_kernel): one record a candidate crosses PCIe, as the
+                // gather kernel's own stores into the pinned buffer
+                size_t cap = 1024;
+                while (cap < 2 * (size_t)found_slots) cap <<= 1;
+                PISCES_HIP_CHECK(h, h->d_merge_tab.reserve(cap));
+                PISCES_HIP_CHECK(h, h->d_merge_acc.reserve((size_t)found_slots * kMergeAcc));
+                PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_merge_tab.p, 0xFF, cap * sizeof(int32_t), h->stream));
+                PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_merge_acc.p, 0, (size_t)found_slots * kMergeAcc * sizeof(int32_t), h->stream));
+                const unsigned mgrid = (unsigned)((found_slots + 255) / 256);
+                hipLaunchKernelGGL(found_merge_kernel, dim3(mgrid), dim3(256), 0, h->stream, (const DevFound*)h->d_found.p, (int32_t)found_slots,
+                                   (const uint8_t*)h->d_found_pool.p, h->d_merge_tab.p, (uint32_t)(cap - 1), h->d_merge_acc.p, h->cfg.collapse != 0 ? 1 : 0);
+                hipLaunchKernelGGL(found_gather_kernel, dim3(mgrid), dim3(256), 0, h->stream, (const DevFound*)h->d_found.p, (int32_t)found_slots,
+                                   (const int32_t*)h->d_merge_acc.p, (DevMerged*)h->found.h, h->d_found_misc.p + 2);
+                PISCES_HIP_CHECK(h, hipGetLastError());
+            } else {
             h->pcie[2] += (int64_t)rec_bytes + found_pool;
             PISCES_HIP_CHECK(h, hipMemcpyAsync(h->found.h, h->d_found.p, rec_bytes, hipMemcpyDeviceToHost, h->stream));
+            }
+            h->found.merged = merge;
             if (found_pool > 0)
                 PISCES_HIP_CHECK(h, hipMemcpyAsync(h->found.h + rec_bytes, h->d_found_pool.p, (size_t)found_pool, hipMemcpyDeviceToHost, h->stream));
-            PISCES_HIP_CHECK(h, hipMemcpyAsync(h->found.h + rec_bytes + pool_al, h->d_found_misc.p, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+            PISCES_HIP_CHECK(h, hipMemcpyAsync(h->found.h + rec_bytes + pool_al, h->d_found_misc.p, 3 * sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
             PISCES_HIP_CHECK(h, hipEventRecord(h->found.done, h->stream));
             h->found.n_slots = found_slots;
             h->found.pool_bytes = found_pool;
@@ -375,9 +394,32 @@ static int32_t consume_found(PiscesHip* h)
     h->found.in_flight = false;
     PISCES_TIMED_WAIT(h, hipEventSynchronize(h->found.done));
     const DevFound* recs = (const DevFound*)h->found.h;
-    const uint8_t* pool = h->found.h + (size_t)h->found.n_slots * sizeof(DevFound);
+    const uint8_t* pool = h->found.h + (size_t)h->found.n_slots * (h->found.merged ? sizeof(DevMerged) : sizeof(DevFound));
     const unsigned int* misc = (const unsigned int*)(pool + (((size_t)h->found.pool_bytes + 15) & ~(size_t)15));
     if (misc[1] != 0) return fail(h, PISCES_E_DEVICE, "add_reads: the candidate records of the device did not fit their reservation");
+    if (h->found.merged) {
+        // the groups in order of first arrival (a position's candidates keep that order, RegionState.cs:104-123): their first records'
+        // indices are distinct numbers below n_slots
+        const DevMerged* groups = (const DevMerged*)h->found.h;
+        const int64_t n_groups = (int64_t)misc[2];
+        if (n_groups > h->found.n_slots) return fail(h, PISCES_E_DEVICE, "add_reads: the merged candidate records of the device are inconsistent");
+        h->pcie[2] += n_groups * (int64_t)sizeof(DevMerged) + h->found.pool_bytes;
+        std::vector<int32_t>& order = h->found.order;
+        order.assign((size_t)h->found.n_slots, -1);
+        for (int64_t k = 0; k < n_groups; k++) {
+            const int32_t first = groups[k].first;
+            if (first < 0 || first >= h->found.n_slots || order[(size_t)first] != -1) return fail(h, PISCES_E_DEVICE, "add_reads: the merged candidate records of the device are inconsistent");
+            order[(size_t)first] = (int32_t)k;
+        }
+        for (int64_t i = 0; i < h->found.n_slots; i++) {
+            if (order[(size_t)i] < 0) continue;
+            const DevMerged& m = groups[order[(size_t)i]];
+            HostCandidate c = host_candidate_of(m.f.c, h->h_ref.data(), m.f.pool_offset >= 0 ? pool + m.f.pool_offset : m.f.alt);
+            for (int d = 0; d < 3; d++) { c.support_by_dir[d] = m.sup[d]; c.well_anchored_by_dir[d] = m.anch[d]; }
+            add_candidate(h, c);
+        }
+        return PISCES_OK;
+    }
     for (int64_t i = 0; i < h->found.n_slots; i++) {
         const DevFound& f = recs[i];
         if (f.c.category == kFoundHole) continue;

@@ -287,3 +287,52 @@ def test_config3_mix_store_equals_log_chain(torch_cuda):
     assert got.tobytes() == want.tobytes() and got_alleles == want_alleles and stats == want_stats
     cats = (got["info"] >> 4) & 7
     assert len(planted) >= 5 and (cats == _abi.CAT_MNV).any() and (cats == _abi.CAT_DELETION).any() and (cats == _abi.CAT_INSERTION).any()
+
+
+@pytest.mark.parametrize("collapse", [1, 0], ids=["open ends tracked", "open ends not part of the identity"])
+def test_candidates_merged_on_the_device_equal_the_host_merge(torch_cuda, collapse):
+    """RegionState.AddCandidate for the records of a batch on the device (found_merge_kernel / found_gather_kernel) against the host merge
+    of one record per read event (PISCES_HIP_DEVICE_MERGE=1 / =0): the candidates the state holds (support and well-anchored support by
+    direction, open ends, order of first arrival) and, after the flushes, records, allele strings and totals — on BASELINE config 3's
+    mix (hundreds of reads per planted variant, thousands of single-read error candidates) and on random reads with long insertions
+    (ALT alleles beyond the inline 32 bases live in the byte pool), with the collapser on (open ends are part of a candidate's identity)
+    and off (a merged candidate keeps the open ends of its first arrival)."""
+    from pisces_amd import engine, synth
+    seed, depth, n_amp = 35, 1500, 14
+    cfg = _abi.default_config(call_mnvs=1, max_mnv_length=3, max_gap_between_mnv=1, collapse=collapse)
+    n_loci = n_amp * synth.READ_LEN
+    ref = synth.reference_of(n_loci, seed, device="cuda")
+    p = synth.make_pileup(n_loci, depth, seed=seed, device="cuda", first_locus=0, total_loci=n_loci, with_tuples=False)
+    batch, planted = synth.mixed_reads(p, seed)
+    rng = np.random.default_rng(5)
+    refb = ref.cpu().numpy() if hasattr(ref, "cpu") else np.asarray(ref)
+    extra = []
+    for i in range(400):   # reads with an insertion of 20-50 bases (a few distinct ones, so that they merge) and soft clips
+        pos = 50 + 61 * int(rng.integers(0, 20))
+        ins = bytes(np.random.default_rng(int(rng.integers(0, 3))).choice(list(b"ACGT"), int(rng.integers(0, 2)) * 30 + 20).astype(np.uint8))
+        left, right = 40, int(rng.integers(20, 70))
+        seq = bytes(refb[pos - 1:pos - 1 + left]) + ins + bytes(refb[pos - 1 + left:pos - 1 + left + right])
+        extra.append({"pos": pos, "cigar": [("M", left), ("I", len(ins)), ("M", right)], "seq": seq, "quals": [37] * len(seq), "reverse": bool(i % 2)})
+    extra.sort(key=lambda r: r["pos"])
+    extra = _abi.ReadBatch(extra)
+    ups = [1000, None]
+    results = []
+    for merge in (1, 0):
+        with env(PISCES_HIP_DEVICE_MERGE=merge):
+            with engine.HipVariantCaller(cfg) as c:
+                c.SetReference(ref)
+                c.AddAlleleCounts(batch)
+                c.AddAlleleCounts(extra)                      # (a second batch: its groups merge into the candidates of the first)
+                cands = c.GetCandidates(None)
+                recs, alleles = [], []
+                for up in ups:
+                    r, a = c.CallWithAlleles(up, capacity=1 << 14)
+                    recs.append(r)
+                    alleles += a
+                pcie = c.TransferBytes()
+                results.append((cands, np.concatenate(recs), alleles, c.Stats(), pcie))
+    (cm, rm, am, sm, pm), (ch, rh, ah, sh, ph) = results
+    assert len(cm) > 1000 and cm == ch                       # same candidates, same order, same sums
+    assert any(len(c["alt"]) > 33 for c in cm) and any(sum(c["support_by_dir"]) > 100 for c in cm)
+    assert rm.tobytes() == rh.tobytes() and am == ah and sm == sh
+    assert pm["d2h_candidates"] < ph["d2h_candidates"]      # fewer bytes back: one record a candidate, not one a read event
