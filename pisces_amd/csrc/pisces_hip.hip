@@ -266,6 +266,8 @@ struct PiscesHip {
     // pinned arena of the small uploads of a flush (bucket tables, tile geometry, gapped-MNV counts): a copy from pageable memory makes
     // the host wait until the stream has caught up, i.e. it serialises the flush's enqueueing with the device; from pinned memory it is
     // asynchronous.  Bump-allocated, rewound when the stream is known to be idle (every flush ends with a synchronisation).
+    uint8_t* h_cand_dl = nullptr;            // pinned: records + IsCallable of a call_spanning_kernel pass
+    size_t h_cand_dl_cap = 0;
     uint8_t* h_meta = nullptr;
     size_t h_meta_cap = 0, h_meta_used = 0;
     size_t h_dl_cap = 0;
@@ -737,6 +739,8 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     h->async.done = nullptr;
     if (h->h_dl) (void)hipHostFree(h->h_dl);
     h->h_dl = nullptr;
+    if (h->h_cand_dl) (void)hipHostFree(h->h_cand_dl);
+    h->h_cand_dl = nullptr;
     if (h->h_meta) (void)hipHostFree(h->h_meta);
     h->h_meta = nullptr;
     if (h->h_counts) (void)hipHostFree(h->h_counts);

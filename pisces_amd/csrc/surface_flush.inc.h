@@ -857,16 +857,28 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         PISCES_HIP_CHECK(h, h->d_alleles.reserve(pool.size() + 16));
         PISCES_HIP_CHECK(h, h->d_cand_records.reserve(dc.size()));
         PISCES_HIP_CHECK(h, h->d_cand_callable.reserve(dc.size()));
-        PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_cands.p, dc.data(), dc.size() * sizeof(DevCandidate), hipMemcpyHostToDevice, h->stream));
-        PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_alleles.p, pool.data(), pool.size(), hipMemcpyHostToDevice, h->stream));
+        // (through the pinned arena and into a pinned buffer: a transfer from or to pageable memory is staged by the runtime, and the host
+        // waits for it)
+        { int32_t rcu = meta_upload(h, h->d_cands.p, dc.data(), dc.size() * sizeof(DevCandidate)); if (rcu) return rcu; }
+        { int32_t rcu = meta_upload(h, h->d_alleles.p, pool.data(), pool.size()); if (rcu) return rcu; }
         hipLaunchKernelGGL(call_spanning_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, h->d_cands.p, n, h->d_counts.p,
                            h->d_alleles.p, h->d_ref.p, h->ref_len, h->cfg.expect_stitched_reads, h->d_cand_records.p, h->d_cand_callable.p, h->P,
                            window ? h->d_sumq.p : (const double*)nullptr);
         PISCES_HIP_CHECK(h, hipGetLastError());
         h->pcie[1] += (int64_t)(raw.size() * (sizeof(PiscesCalledAllele) + 1));
-        PISCES_HIP_CHECK(h, hipMemcpyAsync(raw.data(), h->d_cand_records.p, raw.size() * sizeof(PiscesCalledAllele), hipMemcpyDeviceToHost, h->stream));
-        PISCES_HIP_CHECK(h, hipMemcpyAsync(callable.data(), h->d_cand_callable.p, callable.size(), hipMemcpyDeviceToHost, h->stream));
+        const size_t rec_bytes = raw.size() * sizeof(PiscesCalledAllele), need = rec_bytes + callable.size();
+        if (need > h->h_cand_dl_cap) {
+            if (h->h_cand_dl) (void)hipHostFree(h->h_cand_dl);
+            h->h_cand_dl = nullptr;
+            h->h_cand_dl_cap = 0;
+            PISCES_HIP_CHECK(h, hipHostMalloc((void**)&h->h_cand_dl, need + need / 2, hipHostMallocDefault));
+            h->h_cand_dl_cap = need + need / 2;
+        }
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(h->h_cand_dl, h->d_cand_records.p, rec_bytes, hipMemcpyDeviceToHost, h->stream));
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(h->h_cand_dl + rec_bytes, h->d_cand_callable.p, callable.size(), hipMemcpyDeviceToHost, h->stream));
         PISCES_TIMED_WAIT(h, hipStreamSynchronize(h->stream));
+        std::memcpy(raw.data(), h->h_cand_dl, rec_bytes);
+        std::memcpy(callable.data(), h->h_cand_dl + rec_bytes, callable.size());
         return PISCES_OK;
     };
     auto owned = [&](int32_t position) { return position >= h->own_lo && position <= h->own_hi; };   // (interval sharding: pisces_hip_set_owned_range)
