@@ -183,16 +183,17 @@ namespace Pisces.Hip
             _cigOff.Clear(); _cigOff.Add(0); _seqOff.Clear(); _seqOff.Add(0); _anyStitched = false;
         }
 
-        /// IAlleleCaller.Call: pisces_hip_flush_ex, growing the buffers on PISCES_E_BUFFER_TOO_SMALL (the batch stays intact until it fits)
-        public SortedList<int, List<CalledAllele>> Flush(int? upToPosition, ChrReference chr)
+        /// IAlleleCaller.Call: pisces_hip_flush_view — the rows are read where the library left them (for a batch the device called alone:
+        /// the pinned buffer its last kernel wrote them to), straight into CalledAllele objects; no intermediate managed arrays
+        public unsafe SortedList<int, List<CalledAllele>> Flush(int? upToPosition, ChrReference chr)
         {
-            int upTo = upToPosition ?? -1;
             if (HeldBack(upToPosition)) return new SortedList<int, List<CalledAllele>>();
-            return Take(chr, (PiscesCalledAllele[] recs, out long n, int[] idx, PiscesCandidate[] cands, out long nc, byte[] pool, out long nb) =>
-                NativeMethods.pisces_hip_flush_ex(_h, upTo, recs, recs.LongLength, out n, idx, cands, cands.LongLength, out nc, pool, pool.LongLength, out nb));
+            PiscesCalledAllele* rows; int* idx; PiscesCandidate* cands; byte* pool; long n, nc, nb;
+            NativeMethods.Check(_h, NativeMethods.pisces_hip_flush_view(_h, upToPosition ?? -1, out rows, out n, out idx, out cands, out nc, out pool, out nb));
+            return ToCalledAlleles(chr, rows, n, idx, cands, pool);
         }
 
-        /// The flush as a pair (pisces_hip_flush_begin / pisces_hip_flush_end_ex): FlushBegin enqueues the device work of the batch and
+        /// The flush as a pair (pisces_hip_flush_begin / pisces_hip_flush_end_view): FlushBegin enqueues the device work of the batch and
         /// commits DoneProcessing; the host goes on staging the reads of the next block; FlushEnd hands over the alleles.  False when the
         /// flush is held back (BlocksPerFlush) and nothing was begun.
         public bool FlushBegin(int? upToPosition)
@@ -202,10 +203,11 @@ namespace Pisces.Hip
             return true;
         }
 
-        public SortedList<int, List<CalledAllele>> FlushEnd(ChrReference chr)
+        public unsafe SortedList<int, List<CalledAllele>> FlushEnd(ChrReference chr)
         {
-            return Take(chr, (PiscesCalledAllele[] recs, out long n, int[] idx, PiscesCandidate[] cands, out long nc, byte[] pool, out long nb) =>
-                NativeMethods.pisces_hip_flush_end_ex(_h, recs, recs.LongLength, out n, idx, cands, cands.LongLength, out nc, pool, pool.LongLength, out nb));
+            PiscesCalledAllele* rows; int* idx; PiscesCandidate* cands; byte* pool; long n, nc, nb;
+            NativeMethods.Check(_h, NativeMethods.pisces_hip_flush_end_view(_h, out rows, out n, out idx, out cands, out nc, out pool, out nb));
+            return ToCalledAlleles(chr, rows, n, idx, cands, pool);
         }
 
         private bool HeldBack(int? upToPosition)
@@ -217,34 +219,21 @@ namespace Pisces.Hip
             return false;
         }
 
-        private delegate int FlushEntry(PiscesCalledAllele[] recs, out long n, int[] idx, PiscesCandidate[] cands, out long nc, byte[] pool, out long nb);
-        // the output buffers live with the engine: a block's worth of rows is a few hundred KB, and the flush is called once per block
-        private PiscesCalledAllele[] _recs = new PiscesCalledAllele[1 << 14]; private int[] _idx = new int[1 << 14];
-        private PiscesCandidate[] _cands = new PiscesCandidate[1 << 10]; private byte[] _pool = new byte[1 << 16];
-
-        private SortedList<int, List<CalledAllele>> Take(ChrReference chr, FlushEntry entry)
+        /// rows (valid until the next flush on the handle) -> CalledAllele objects; idx == null: no row has a candidate (Reference / SNV rows only)
+        private static unsafe SortedList<int, List<CalledAllele>> ToCalledAlleles(ChrReference chr, PiscesCalledAllele* recs, long n, int* idx, PiscesCandidate* cands, byte* pool)
         {
             var result = new SortedList<int, List<CalledAllele>>();
-            long n, nc, nb; int rc;
-            while ((rc = entry(_recs, out n, _idx, _cands, out nc, _pool, out nb)) == -2)
-            {
-                if (n > _recs.LongLength) { _recs = new PiscesCalledAllele[n + n / 2]; _idx = new int[_recs.Length]; }
-                if (nc > _cands.LongLength) _cands = new PiscesCandidate[nc + nc / 2];
-                if (nb > _pool.LongLength) _pool = new byte[nb + nb / 2];
-            }
-            NativeMethods.Check(_h, rc);
-            var recs = _recs; var idx = _idx; var cands = _cands; var pool = _pool;
             const string baseOf = "AGCTND";
             for (long i = 0; i < n; i++)
             {
                 var r = recs[i];
                 var category = (AlleleCategory)((r.Info >> 4) & 7);   // the native codes follow Pisces.Domain.Types.AlleleCategory
                 string refAllele, altAllele;
-                if (idx[i] >= 0)
+                if (idx != null && idx[i] >= 0)
                 {
                     var c = cands[idx[i]];
-                    refAllele = Encoding.ASCII.GetString(pool, (int)c.AlleleOffset, c.RefLen);
-                    altAllele = Encoding.ASCII.GetString(pool, (int)c.AlleleOffset + c.RefLen, c.AltLen);
+                    refAllele = Encoding.ASCII.GetString(pool + c.AlleleOffset, c.RefLen);
+                    altAllele = Encoding.ASCII.GetString(pool + c.AlleleOffset + c.RefLen, c.AltLen);
                 }
                 else { refAllele = baseOf[(r.Info >> 7) & 7].ToString(); altAllele = baseOf[(r.Info >> 10) & 7].ToString(); }
                 var a = new CalledAllele(category)

@@ -111,7 +111,7 @@ namespace Pisces.Hip
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_flush_end_ex(IntPtr handle, [Out] PiscesCalledAllele[] output, long capacity, out long nOut, [Out] int[] candIndex, [Out] PiscesCandidate[] cands, long candCapacity, out long nCand, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
         /// the flushes without the copy: the rows where they lie (pinned memory of the handle), valid until the next flush on the handle
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_flush_view(IntPtr handle, int upToPosition, out PiscesCalledAllele* rows, out long nRows, out int* candIndex, out PiscesCandidate* cands, out long nCand, out byte* alleles, out long alleleBytes);
-        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_flush_end_view(IntPtr handle, out PiscesCalledAllele* rows, out long nRows);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_flush_end_view(IntPtr handle, out PiscesCalledAllele* rows, out long nRows, out int* candIndex, out PiscesCandidate* cands, out long nCand, out byte* alleles, out long alleleBytes);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_flush_ex(IntPtr handle, int upToPosition, [Out] PiscesCalledAllele[] output, long capacity, out long nOut, [Out] int[] candIndex, [Out] PiscesCandidate[] cands, long candCapacity, out long nCand, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_get_candidates(IntPtr handle, int upToPosition, [Out] PiscesCandidate[] cands, long capacity, out long nOut, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_add_candidates(IntPtr handle, PiscesCandidate[] cands, long n, byte[] alleles, long alleleBytes);

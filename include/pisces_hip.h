@@ -343,7 +343,8 @@ int32_t pisces_hip_flush_end_ex(PiscesHip* h, PiscesCalledAllele* out, int64_t c
  * candidate (every row is a Reference or SNV row).  No PISCES_E_BUFFER_TOO_SMALL: nothing is copied. */
 int32_t pisces_hip_flush_view(PiscesHip* h, int32_t up_to_position, const PiscesCalledAllele** rows, int64_t* n_rows, const int32_t** cand_index,
                               const PiscesCandidate** cands, int64_t* n_cand, const uint8_t** alleles, int64_t* allele_bytes);
-int32_t pisces_hip_flush_end_view(PiscesHip* h, const PiscesCalledAllele** rows, int64_t* n_rows);
+int32_t pisces_hip_flush_end_view(PiscesHip* h, const PiscesCalledAllele** rows, int64_t* n_rows, const int32_t** cand_index,
+                                  const PiscesCandidate** cands, int64_t* n_cand, const uint8_t** alleles, int64_t* allele_bytes);
 /* IAlleleSource.GetAlleleCount for a run of positions: out[n][6][3][11] int32
  * (RegionState.cs:57); blocks never touched read as zero (RegionStateManager.cs:222-226). */
 int32_t pisces_hip_get_counts(PiscesHip* h, int32_t start_position, int32_t n, int32_t* out);

@@ -70,7 +70,7 @@ def _load():
         "pisces_hip_flush_end_ex": (i32, [vp, vp, i64, P(i64), vp, vp, i64, P(i64), vp, i64, P(i64)]),
         "pisces_hip_device_count": (i32, []),
         "pisces_hip_flush_view": (i32, [vp, i32, P(vp), P(i64), P(vp), P(vp), P(i64), P(vp), P(i64)]),
-        "pisces_hip_flush_end_view": (i32, [vp, P(vp), P(i64)]),
+        "pisces_hip_flush_end_view": (i32, [vp, P(vp), P(i64), P(vp), P(vp), P(i64), P(vp), P(i64)]),
         "pisces_hip_transfer_bytes": (i32, [vp, P(i64), i32]),
         "pisces_hip_add_observations": (i32, [vp, vp, vp, i64]),
         "pisces_hip_flush": (i32, [vp, i32, vp, i64, P(i64)]),

@@ -1328,7 +1328,8 @@ int32_t pisces_hip_flush_view(PiscesHip* h, int32_t up_to_position, const Pisces
 }
 
 // pisces_hip_flush_end the same way: the rows where pisces_hip_flush_begin's work left them
-int32_t pisces_hip_flush_end_view(PiscesHip* h, const PiscesCalledAllele** rows, int64_t* n_rows)
+int32_t pisces_hip_flush_end_view(PiscesHip* h, const PiscesCalledAllele** rows, int64_t* n_rows, const int32_t** cand_index, const PiscesCandidate** cands,
+                                  int64_t* n_cand, const uint8_t** alleles, int64_t* allele_bytes)
 {
     return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
@@ -1344,6 +1345,13 @@ int32_t pisces_hip_flush_end_view(PiscesHip* h, const PiscesCalledAllele** rows,
     }
     *rows = A.data;
     *n_rows = (int64_t)A.n;
+    // (a flush that ran inside flush_begin, with host-side candidates: its index, candidates and allele strings are kept with its rows)
+    const bool with_cands = A.n && A.data == A.owned.data();
+    if (cand_index) *cand_index = with_cands ? A.owned_index.data() : nullptr;
+    if (cands) *cands = A.n_cands ? A.owned_cands.data() : nullptr;
+    if (n_cand) *n_cand = (int64_t)A.n_cands;
+    if (alleles) *alleles = A.n_allele_bytes ? A.owned_alleles.data() : nullptr;
+    if (allele_bytes) *allele_bytes = (int64_t)A.n_allele_bytes;
     A.state = 0;
     A.data = nullptr;
     A.n = 0;

@@ -171,7 +171,7 @@ class HipVariantCaller:
     def CallEndView(self):
         """pisces_hip_flush_end_view: CallEnd() without the copy (valid until the next Call* / CallBegin)."""
         rows, n = C.c_void_p(), C.c_int64(0)
-        _check(self._h, lib.pisces_hip_flush_end_view(self._h, C.byref(rows), C.byref(n)))
+        _check(self._h, lib.pisces_hip_flush_end_view(self._h, C.byref(rows), C.byref(n), None, None, None, None, None))
         return self._rows_at(rows, n.value)
 
     @staticmethod

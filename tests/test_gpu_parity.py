@@ -1998,3 +1998,25 @@ def test_flush_views_hand_out_the_rows_the_copying_flushes_return(torch_cuda):
                 o = cand[ci].allele_offset
                 got_alleles.append((text[o:o + cand[ci].ref_len].decode(), text[o + cand[ci].ref_len:o + cand[ci].ref_len + cand[ci].alt_len].decode()))
     assert got.tobytes() == want_recs.tobytes() and got_alleles == want_alleles
+    # the pair the same way: pisces_hip_flush_end_view hands out the index, candidates and allele strings of a batch that was flushed inside flush_begin
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(refb)
+        c.AddAlleleCounts(reads)
+        c.CallBegin(None)
+        rows, n, idx, cands, nc, pool, nb = C.c_void_p(), C.c_int64(0), C.c_void_p(), C.c_void_p(), C.c_int64(0), C.c_void_p(), C.c_int64(0)
+        rc = _native.lib.pisces_hip_flush_end_view(c._h, C.byref(rows), C.byref(n), C.byref(idx), C.byref(cands), C.byref(nc), C.byref(pool), C.byref(nb))
+        assert rc == 0 and n.value == len(want_recs) and nc.value >= 1 and idx.value and cands.value and pool.value
+        got = np.frombuffer((C.c_uint8 * (64 * n.value)).from_address(rows.value), dtype=_abi.CALLED_ALLELE_DTYPE).copy()
+        index = np.frombuffer((C.c_int32 * n.value).from_address(idx.value), dtype=np.int32).copy()
+        cand = (_abi.PiscesCandidate * nc.value).from_address(cands.value)
+        text = bytes((C.c_uint8 * nb.value).from_address(pool.value))
+        pair_alleles = []
+        for r, ci in zip(got, index):
+            if ci < 0:
+                pair_alleles.append((_abi.BASE_OF_ALLELE[_abi.info_ref(r["info"])], _abi.BASE_OF_ALLELE[_abi.info_alt(r["info"])]))
+            else:
+                o = cand[ci].allele_offset
+                pair_alleles.append((text[o:o + cand[ci].ref_len].decode(), text[o + cand[ci].ref_len:o + cand[ci].ref_len + cand[ci].alt_len].decode()))
+        assert got.tobytes() == want_recs.tobytes() and pair_alleles == want_alleles
+        rc = _native.lib.pisces_hip_flush_end_view(c._h, C.byref(rows), C.byref(n), None, None, None, None, None)
+        assert rc == _abi.E_STATE        # no flush_begin before it
