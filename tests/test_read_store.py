@@ -336,3 +336,36 @@ def test_candidates_merged_on_the_device_equal_the_host_merge(torch_cuda, collap
     assert any(len(c["alt"]) > 33 for c in cm) and any(sum(c["support_by_dir"]) > 100 for c in cm)
     assert rm.tobytes() == rh.tobytes() and am == ah and sm == sh
     assert pm["d2h_candidates"] < ph["d2h_candidates"]      # fewer bytes back: one record a candidate, not one a read event
+
+
+def test_config5_depth_through_the_read_store_equals_log_chain_and_oracle(torch_cuda):
+    """BASELINE config 5's settings (-minbq 30 => NL 30, -minvf 0.005, -sbfilter 0.5, -vqfilter 30, gVCF) at its depth (5000x, planted
+    0.5 % VAF SNVs every 50 loci) from READS: 6 000 loci = 200 000 reads through pisces_hip_add_reads / pisces_hip_flush block by block —
+    ~7 000 reads a tile in the fused kernel, counts of 5 000 a cell, a quality threshold above the default — against the observation-log
+    chain (same bytes) and the oracle (first 1 000 loci)."""
+    from pisces_amd import engine, synth
+    n_loci, depth = 6000, 5000
+    p = synth.make_pileup(n_loci=n_loci, depth=depth, seed=23, vaf_range=(0.005, 0.005), snv_every=50, snv_offset=17, q_lo=12)
+    ref = p.ref.cpu().numpy()
+    cfg = _abi.default_config(min_base_call_quality=30, noise_level=30, min_frequency=0.005, variant_freq_filter=0.005,
+                              genotype_min_freq_filter=0.005, target_lod_frequency=0.005, strand_bias_threshold=0.5, variant_qscore_filter=30)
+    A = p.base.shape[0]
+    out = {}
+    for path in ("store", "log"):
+        with env(PISCES_HIP_READ_PATH=None if path == "store" else "log"):
+            with engine.HipVariantCaller(cfg) as c:
+                c.SetReference(ref)
+                parts = []
+                for a0 in range(0, A, 7):
+                    c.AddAlleleCounts(synth.reads_of(p, min(7, A - a0), first_amplicon=a0))
+                    parts.append(c.Call(p.region_start + a0 * synth.READ_LEN - 1, capacity=1 << 13))
+                parts.append(c.Call(None, capacity=1 << 13))
+                out[path] = np.concatenate(parts)
+    got = out["store"]
+    assert got.tobytes() == out["log"].tobytes() and len(got) >= n_loci
+    assert (got["total_coverage"] + got["num_no_calls"]).max() == depth
+    cats = (got["info"] >> 4) & 7
+    assert (cats == _abi.CAT_SNV).sum() >= 20                     # about half of the 120 planted sites clear 0.5 %
+    head = synth.reads_of(p, 7, first_amplicon=0)
+    exp, _ = orc.run_reads(head, ref, p.region_start, 1000, cfg)
+    assert got[got["position"] < p.region_start + 1000].tobytes() == exp.tobytes()
