@@ -474,6 +474,87 @@ def run_config4(args):
         dist.destroy_process_group()
 
 
+def run_stream_config(args):
+    """BASELINE configs 3 and 5 as SURVEY 8d states them, from READS through the streaming surface (`python bench.py --config 3 | 5`):
+      3: 1 M loci x 2000x = 13.3 M reads, SNVs + MNVs (2-3 bases) + deletions (1-10) + insertions (1-6), -callmnvs true -maxmnvlength 3
+         -maxgapbetweenmnv 1, gVCF;
+      5: 100 000 loci x 5000x = 3.3 M reads, planted 0.5 % VAF SNVs, -minbq 30 (=> NL 30) -minvf 0.005 -sbfilter 0.5 -vqfilter 30, gVCF.
+    The amplicons are handed over in stretches (pisces_hip_add_reads, then pisces_hip_flush up to the stretch's last cleared position),
+    host reads in, host records out; making the synthetic reads (torch, on the device) is not timed.  N ranks: rank r takes the r-th
+    contiguous range of amplicons (amplicons do not overlap: no halo), totals all-reduced, `value` = loci / the slowest rank's time."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from pisces_amd import _abi, engine, synth
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    use_dist = world > 1
+    if use_dist:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    if args.config == 3:
+        n_loci_all, depth, seed, stretch = 1_000_000, 2000, 33, 200
+        cfg = _abi.default_config(call_mnvs=1, max_mnv_length=3, max_gap_between_mnv=1)
+        synth_kw = {}
+        what = ("BASELINE config 3: 1 M loci x 2000x, SNV + MNV (2-3) + deletions (1-10) + insertions (1-6), MNV calling on, gVCF; "
+                "streaming surface from reads (device read store, device candidate discovery and merge, collapser, reallocator, candidate kernel)")
+    else:
+        n_loci_all, depth, seed, stretch = 100_000, 5000, 23, 40
+        cfg = _abi.default_config(min_base_call_quality=30, noise_level=30, min_frequency=0.005, variant_freq_filter=0.005, genotype_min_freq_filter=0.005,
+                                  target_lod_frequency=0.005, strand_bias_threshold=0.5, variant_qscore_filter=30)
+        synth_kw = dict(vaf_range=(0.005, 0.005), snv_every=50, snv_offset=17, q_lo=12)
+        what = "BASELINE config 5: 100 000 loci x 5000x, 0.5 % VAF SNVs, -minbq 30 (NL 30) -minvf 0.005 -sbfilter 0.5 -vqfilter 30, gVCF; streaming surface from reads"
+    n_amp_all = n_loci_all // synth.READ_LEN
+    n_loci_all = n_amp_all * synth.READ_LEN
+    a_lo, a_hi = rank * n_amp_all // world, (rank + 1) * n_amp_all // world
+    ref = synth.reference_of(n_loci_all, seed, device=f"cuda:{local_rank}")
+    origin = synth.READ_LEN + 1
+    elapsed, n_rec, n_reads, host = 0.0, 0, 0, None
+    with engine.HipVariantCaller(cfg, device=local_rank) as c:
+        c.SetReference(ref)
+        for a0 in range(a_lo, a_hi, stretch):
+            na = min(stretch, a_hi - a0)
+            p = synth.make_pileup(na * synth.READ_LEN, depth, seed=seed, device=f"cuda:{local_rank}", first_locus=a0 * synth.READ_LEN, total_loci=n_loci_all,
+                                  with_tuples=False, **synth_kw)
+            batch = synth.mixed_reads(p, seed)[0] if args.config == 3 else synth.reads_of(p, na, first_amplicon=a0)
+            n_reads += int(batch.n_reads)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            c.AddAlleleCounts(batch)
+            n_rec += len(c.CallView(origin + (a0 + na) * synth.READ_LEN - 1 if a0 + na < a_hi else None))
+            elapsed += time.perf_counter() - t0
+            del p, batch
+        stats = c.Stats()
+        host = c.HostTime()
+        pcie = c.TransferBytes()
+    loci_mine = (a_hi - a_lo) * synth.READ_LEN
+    summary = torch.tensor([stats["TotalNumCalled"], stats["TotalNumCollapsed"], stats["reads"], stats["reads_skipped"], loci_mine, n_rec], dtype=torch.int64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(summary, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        loci = int(summary[4].item())
+        out = {"metric": f"candidate loci/s at {depth}x depth from reads (BASELINE config {args.config})", "value": loci / float(t.item()), "unit": "candidate loci/s",
+               "n_gpus": world, "steps": 1, "warmup": 0, "ms_per_step": float(t.item()) * 1e3, "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "int32 counts + f64 likelihoods", "data": "synthetic",
+               "config": {"workload": what, "loci": loci, "depth": depth, "reads": int(summary[2].item()), "amplicons_per_add_reads": stretch,
+                          "parallelism": f"amplicon ranges x{world}"},
+               "totals": {"allelesCalled": int(summary[0].item()), "variantsCollapsed": int(summary[1].item()), "readsProcessed": int(summary[2].item()),
+                          "readsSkipped": int(summary[3].item()), "records": int(summary[5].item())},
+               "rank0": {"host_seconds_in_add_reads": host["add_reads_s"], "host_seconds_in_flushes": host["flush_s"], "of_those_waiting_for_the_device": host["flush_wait_s"],
+                         "flushes": host["flushes"], "pcie_bytes": pcie}}
+        assert out["totals"]["readsProcessed"] == n_reads or use_dist
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -487,10 +568,14 @@ def main():
     ap.add_argument("--no-shard-check", action="store_true", help="skip the on-device check of one cut of the interval partition")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra multi-stream figure (profiling runs: its overlapped "
                     "launches would mix into the per-kernel statistics of the timed region)")
-    ap.add_argument("--config", type=int, default=2, help="2 (default): the configuration the metric is quoted on; 4: BASELINE config 4 as stated")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
+                    help="2 (default): the configuration the metric is quoted on; 3 / 5: BASELINE configs 3 / 5 as stated, from reads through the "
+                         "streaming surface; 4: BASELINE config 4 as stated")
     args = ap.parse_args()
     if args.config == 4:
         return run_config4(args)
+    if args.config in (3, 5):
+        return run_stream_config(args)
 
     import numpy as np
     import torch
