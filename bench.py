@@ -142,8 +142,8 @@ def end_to_end(pileup, cfg, engine, loci=30_000):
                 t0 = time.perf_counter()
                 for a0, b in batches:
                     c.AddAlleleCounts(b)
-                    n_rec += len(c.Call(pileup.region_start + a0 * synth.READ_LEN - 1, capacity=1 << 18, reuse_buffer=True))   # LastClearedPosition
-                n_rec += len(c.Call(None, capacity=1 << 18, reuse_buffer=True))   # (the host keeps its output buffer, as HipEngine.Flush does)
+                    n_rec += len(c.CallView(pileup.region_start + a0 * synth.READ_LEN - 1))   # LastClearedPosition
+                n_rec += len(c.CallView(None))   # (the rows are read in place, as HipEngine.Flush reads them)
                 dt = time.perf_counter() - t0
                 if rep > 0:
                     best = dt if best is None else min(best, dt)
@@ -166,14 +166,14 @@ def end_to_end(pileup, cfg, engine, loci=30_000):
                         t0 = time.perf_counter()
                         c.AddAlleleCounts(staged)
                         if pending:
-                            n_rec += len(c.CallEnd(capacity=1 << 18, reuse_buffer=True))
+                            n_rec += len(c.CallEndView())
                         c.CallBegin(pileup.region_start + a0 * synth.READ_LEN - 1)
                         pending = True
                         dt += time.perf_counter() - t0
                     t0 = time.perf_counter()
-                    n_rec += len(c.CallEnd(capacity=1 << 18, reuse_buffer=True))
+                    n_rec += len(c.CallEndView())
                     c.CallBegin(None)
-                    n_rec += len(c.CallEnd(capacity=1 << 18, reuse_buffer=True))
+                    n_rec += len(c.CallEndView())
                     dt += time.perf_counter() - t0
                     if rep > 0:
                         best = dt if best is None else min(best, dt)
@@ -196,10 +196,10 @@ def end_to_end(pileup, cfg, engine, loci=30_000):
                     staged = c.StageReads(b)
                     t0 = time.perf_counter()
                     c.AddAlleleCounts(staged)
-                    n_rec += len(c.Call(pileup.region_start + a0 * synth.READ_LEN - 1, capacity=1 << 18, reuse_buffer=True))
+                    n_rec += len(c.CallView(pileup.region_start + a0 * synth.READ_LEN - 1))
                     dt += time.perf_counter() - t0
                 t0 = time.perf_counter()
-                n_rec += len(c.Call(None, capacity=1 << 18, reuse_buffer=True))
+                n_rec += len(c.CallView(None))
                 dt += time.perf_counter() - t0
                 if rep > 0:
                     best = dt if best is None else min(best, dt)
@@ -209,7 +209,8 @@ def end_to_end(pileup, cfg, engine, loci=30_000):
                                             "(pisces_hip_stage_reads; filling it is the caller's marshalling, not timed)"}
     except Exception as e:   # noqa: BLE001
         out["staged_30_blocks"] = {"error": str(e)[:200]}
-    out["scope"] = "host read buffers -> pisces_hip_add_reads -> pisces_hip_flush -> host records (PCIe both ways; one handle, best of 3 passes after a warm-up pass)"
+    out["scope"] = ("host read buffers -> pisces_hip_add_reads -> pisces_hip_flush_view / _flush_end_view -> records in host memory (the library's pinned buffer, "
+                    "read in place as dotnet/HipEngine.cs reads them; PCIe both ways; one handle, best of 3 passes after a warm-up pass)")
     # (c) the same reads as the bytes of a BAM file (BGZF, zlib level 6): inflated, cut into records, filtered, walked and called on the
     # device (pisces_hip_bam_decode -> pisces_hip_add_decoded_reads -> pisces_hip_flush); only the compressed bytes cross PCIe
     try:
@@ -224,7 +225,7 @@ def end_to_end(pileup, cfg, engine, loci=30_000):
                 t0 = time.perf_counter()
                 counts = c.bam_decode(data, 0)
                 c.AddDecodedReads()
-                n_rec = len(c.Call(None, capacity=1 << 18, reuse_buffer=True))
+                n_rec = len(c.CallView(None))
                 dt = time.perf_counter() - t0
                 if rep > 0:
                     best = dt if best is None else min(best, dt)
@@ -258,7 +259,7 @@ def end_to_end_full(pileup, cfg, engine, torch):
                 c.HostTime(reset=True)
             t0 = time.perf_counter()
             c.AddAlleleCounts(whole)
-            n_rec = len(c.Call(None, capacity=1 << 18, reuse_buffer=True))
+            n_rec = len(c.CallView(None))
             dt = time.perf_counter() - t0
             if rep > 0:
                 best = dt if best is None else min(best, dt)
@@ -293,8 +294,8 @@ def end_to_end_full(pileup, cfg, engine, torch):
             t0 = time.perf_counter()
             for a0, b in per_block:
                 c.AddAlleleCounts(b)
-                n_rec += len(c.Call(pileup.region_start + a0 * synth.READ_LEN - 1, capacity=1 << 18, reuse_buffer=True))
-            n_rec += len(c.Call(None, capacity=1 << 18, reuse_buffer=True))
+                n_rec += len(c.CallView(pileup.region_start + a0 * synth.READ_LEN - 1))
+            n_rec += len(c.CallView(None))
             dt = time.perf_counter() - t0
             if rep > 0:
                 best = dt if best is None else min(best, dt)
@@ -314,14 +315,14 @@ def end_to_end_full(pileup, cfg, engine, torch):
                     t0 = time.perf_counter()
                     c.AddAlleleCounts(staged)
                     if pending:
-                        n_rec += len(c.CallEnd(capacity=1 << 18, reuse_buffer=True))
+                        n_rec += len(c.CallEndView())
                     c.CallBegin(pileup.region_start + a0 * synth.READ_LEN - 1)
                     pending = True
                     dt += time.perf_counter() - t0
                 t0 = time.perf_counter()
-                n_rec += len(c.CallEnd(capacity=1 << 18, reuse_buffer=True))
+                n_rec += len(c.CallEndView())
                 c.CallBegin(None)
-                n_rec += len(c.CallEnd(capacity=1 << 18, reuse_buffer=True))
+                n_rec += len(c.CallEndView())
                 dt += time.perf_counter() - t0
                 if rep > 0:
                     best = dt if best is None else min(best, dt)
@@ -348,8 +349,8 @@ def end_to_end_full(pileup, cfg, engine, torch):
                 c.AddAlleleCounts(batch)
                 n_rec = 0
                 for up_to in range(1000, n_loci, 1000):
-                    n_rec += len(c.Call(up_to, capacity=1 << 16, reuse_buffer=True))
-                n_rec += len(c.Call(None, capacity=1 << 16, reuse_buffer=True))
+                    n_rec += len(c.CallView(up_to))
+                n_rec += len(c.CallView(None))
                 dt = time.perf_counter() - t0
                 if rep > 0:
                     best = dt if best is None else min(best, dt)
