@@ -98,10 +98,11 @@ def read_batch_range(arrays, i0, i1):
                                       cigar_len=cig_len[c0:c1], seq_offset=seq_off[i0:i1 + 1] - s0, bases=bases[s0:s1], quals=quals[s0:s1])
 
 
-def run_piece(engine, cfg, job, lo=None, hi=None, halo=synth.READ_LEN + 16, device=0, chunk_reads=400_000, with_alleles=True):
+def run_piece(engine, cfg, job, lo=None, hi=None, halo=synth.READ_LEN + 16, device=0, chunk_reads=400_000, with_alleles=True, keep_records=True):
     """One (contig, owned range) job on one handle: set_reference, set_intervals (clipped to the range), the reads
     shard.reads_for_shard gives it, one final flush.  lo / hi None: the whole contig.  Returns (records, alleles, stats, reads counted:
-    a read is counted by the piece that owns its start)."""
+    a read is counted by the piece that owns its start).  keep_records=False (bench.py): the rows are looked at where they lie
+    (pisces_hip_flush_view) and only counted — `records` is then {"n": rows, "loci": distinct positions}."""
     starts, ends = job["starts"], job["ends"]
     pos = job["arrays"][0].astype(np.int64)
     if lo is None:
@@ -110,6 +111,19 @@ def run_piece(engine, cfg, job, lo=None, hi=None, halo=synth.READ_LEN + 16, devi
     ivs = list(zip(np.maximum(starts[keep], lo).tolist(), np.minimum(ends[keep], hi).tolist()))
     idx, owner = shard.reads_for_shard(pos, job["read_end"], lo, hi, halo)
     recs, alleles = [], []
+    n_rows = n_loci = 0
+    last_position = [0]
+
+    def count(view):   # rows arrive in position order, flush after flush
+        nonlocal n_rows, n_loci
+        if len(view):
+            p = view["position"]
+            n_rows += len(view)
+            n_loci += int((np.diff(p) != 0).sum()) + (1 if int(p[0]) != last_position[0] else 0)
+            last_position[0] = int(p[-1])
+        return view[:0]
+
+    take = (lambda view: view.copy()) if keep_records else count
     with engine.HipVariantCaller(cfg, device=device) as c:
         c.SetReference(job["ref"])
         c.SetIntervals(ivs)
@@ -121,11 +135,14 @@ def run_piece(engine, cfg, job, lo=None, hi=None, halo=synth.READ_LEN + 16, devi
                 b = min(a + chunk_reads, i1)
                 c.AddAlleleCounts(read_batch_range(job["arrays"], a, b))
                 if b < i1:
-                    r, al = c.CallWithAlleles(int(pos[b]) - 1, capacity=1 << 20) if with_alleles else (c.Call(int(pos[b]) - 1, capacity=1 << 20), [])
+                    r, al = c.CallWithAlleles(int(pos[b]) - 1, capacity=1 << 20) if with_alleles else (take(c.CallView(int(pos[b]) - 1)), [])
                     recs.append(r)
                     alleles += al
-        r, al = c.CallWithAlleles(None, capacity=1 << 20) if with_alleles else (c.Call(None, capacity=1 << 20), [])
+        r, al = c.CallWithAlleles(None, capacity=1 << 20) if with_alleles else (take(c.CallView(None)), [])   # (rows read in place; kept by copying them once)
         recs.append(r)
         alleles += al
         stats = c.Stats()
+        stats["host_time"] = c.HostTime()
+    if not keep_records:
+        return {"n": n_rows, "loci": n_loci}, alleles, stats, int(owner.sum())
     return np.concatenate(recs), alleles, stats, int(owner.sum())
