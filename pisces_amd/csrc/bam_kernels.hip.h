@@ -44,11 +44,20 @@ struct BamFilter {   // AlignmentSourceConfig + the chromosome being called
 
 struct BamCounts { long long reads, cigar_ops, bases, records, skipped; };
 
+// little-endian fields at any byte offset: ONE load each (gfx950 runs with unaligned access enabled; four byte loads and three shifts
+// per field were most of what the record kernels issued)
 __device__ __forceinline__ int32_t bam_le32(const uint8_t* __restrict__ p)
 {
-    return (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24));
+    int32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
 }
-__device__ __forceinline__ uint32_t bam_le16(const uint8_t* __restrict__ p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+__device__ __forceinline__ uint32_t bam_le16(const uint8_t* __restrict__ p)
+{
+    uint16_t v;
+    __builtin_memcpy(&v, p, 2);
+    return v;
+}
 
 // out[0] = offset of the first record, out[1] = n_ref, out[2] = status (0 ok), out[3] = l_ref of reference sequence ref_id (0: no such)
 __global__ void bam_header_kernel(const uint8_t* __restrict__ s, int64_t n, long long* __restrict__ out, int32_t ref_id)
