@@ -35,6 +35,26 @@ namespace Pisces.Hip
         // candidates are implied by the device counts.  No managed finder runs: a finder that yields nothing keeps SmallVariantCaller's loop unchanged.
         protected override ICandidateVariantFinder CreateVariantFinder() { return new NoCandidates(); }
 
+        // PISCES_HIP_BAM_SURFACE=1: the reads of the job never become Read objects.  The alignment source hands the compressed file bytes to
+        // the library (inflate, record cut, AlignmentSource's filters, XD tags, read store, candidate discovery: all on the device) the first
+        // time SmallVariantCaller asks for a read, and then reports the end of the file; the loop of SmallVariantCaller.Execute
+        // (SmallVariantCaller.cs:88-104) falls through to its final Call(), which flushes everything.  The managed extractor is opened
+        // once for what only the BAM header says (stitched / collapsed source, reference order).
+        protected override IAlignmentSource CreateAlignmentSource(ChrReference chrReference, string bamFilePath, bool commandLineSaysStitched,
+            List<string> chrsToProcess = null)
+        {
+            if (Environment.GetEnvironmentVariable("PISCES_HIP_BAM_SURFACE") != "1")
+                return base.CreateAlignmentSource(chrReference, bamFilePath, commandLineSaysStitched, chrsToProcess);
+            bool stitched, collapsed; int refId;
+            using (var extractor = new Pisces.IO.BamFileAlignmentExtractor(bamFilePath, commandLineSaysStitched, chrReference.Name))
+            {
+                stitched = extractor.SourceIsStitched; collapsed = extractor.SourceIsCollapsed;
+                refId = extractor.SourceReferenceList.IndexOf(chrReference.Name);
+            }
+            var f = _options.BamFilterParameters;
+            return new HipBamSource(() => _engine, bamFilePath, refId, chrReference, f.MinimumMapQuality, f.RemoveDuplicates, f.OnlyUseProperPairs, stitched, collapsed);
+        }
+
         protected override IStateManager CreateStateManager(ChrIntervalSet intervalSet, bool expectStitchedReads = false,
             bool expectCollapsedReads = true)
         {
@@ -54,6 +74,35 @@ namespace Pisces.Hip
             // the flush as a pair unless PISCES_HIP_SYNC_FLUSH is set: the device calls block k while the managed side stages block k + 1
             return new HipAlleleCaller(() => _engine, chrReference, Environment.GetEnvironmentVariable("PISCES_HIP_SYNC_FLUSH") == null);
         }
+    }
+
+    /// IAlignmentSource over the library's BAM surface: no Read ever reaches the managed side (HipFactory.CreateAlignmentSource).
+    /// The whole file is handed over and the library keeps the records of refId (a production reader would hand over the chromosome's
+    /// chunks from the .bai instead of the file).
+    internal sealed class HipBamSource : IAlignmentSource
+    {
+        private readonly Func<HipEngine> _engine; private readonly string _path; private readonly int _refId; private readonly ChrReference _chr;
+        private readonly int _minMapQuality; private readonly bool _skipDuplicates, _onlyProperPairs;
+        private bool _handedOver;
+        public HipBamSource(Func<HipEngine> engine, string path, int refId, ChrReference chr, int minMapQuality, bool skipDuplicates, bool onlyProperPairs,
+            bool stitched, bool collapsed)
+        {
+            _engine = engine; _path = path; _refId = refId; _chr = chr; _minMapQuality = minMapQuality; _skipDuplicates = skipDuplicates;
+            _onlyProperPairs = onlyProperPairs; SourceIsStitched = stitched; SourceIsCollapsed = collapsed;
+        }
+        public Read GetNextRead()
+        {
+            if (!_handedOver && _refId >= 0)
+            {
+                _handedOver = true;
+                // {records of the chromosome, reads kept, bases, CIGAR operations}; the skipped reads are in HipEngine.Stats()[3]
+                _engine().AddBamBlocks(System.IO.File.ReadAllBytes(_path), _refId, _chr, _minMapQuality, _skipDuplicates, _onlyProperPairs);
+            }
+            return null;   // end of file: SmallVariantCaller goes on to its final Call()
+        }
+        public int? LastClearedPosition { get { return null; } }
+        public bool SourceIsStitched { get; private set; }
+        public bool SourceIsCollapsed { get; private set; }
     }
 
     internal sealed class NoCandidates : ICandidateVariantFinder
