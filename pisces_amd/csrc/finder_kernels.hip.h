@@ -117,14 +117,16 @@ __global__ __launch_bounds__(256) void find_count_kernel(DevReadBatch b, const u
 }
 
 // in-place exclusive scans of two int32 arrays by one workgroup; totals[0], totals[1] = the sums.  Every wave owns a contiguous sixteenth
-// of the arrays: it adds its part up, the sixteen sums are exchanged once through LDS, and the wave then scans its part 64 entries at a
-// time with lane shuffles — one barrier in all (the first form scanned 1024 entries a round through LDS, twenty barriers a round:
-// 228 us for 80 000 reads; this one 77 us: twelve dependent lane shuffles a round, 79 rounds a wave).
+// of the arrays: it adds its part up, the sixteen sums are exchanged once through LDS (the only barrier), and the wave then scans its
+// part 512 entries a round: a lane takes eight neighbours (scanned in registers), the lanes' sums go through one shuffle scan.
+// (The first form scanned 1024 entries a round through LDS, twenty barriers a round: 228 us for 80 000 reads; one entry a lane and
+// round, twelve dependent shuffles for 64 entries: 77 us.)
 __global__ __launch_bounds__(1024) void found_scan_kernel(int32_t* __restrict__ a, int32_t* __restrict__ b, int32_t n, long long* __restrict__ totals)
 {
     __shared__ long long s_tot[2][16];
+    constexpr int kPer = 8;
     const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6;
-    const int per = (((n + 15) / 16) + 63) & ~63;
+    const int per = (((n + 15) / 16) + 64 * kPer - 1) / (64 * kPer) * (64 * kPer);
     const int lo = min(w * per, n), hi = min(lo + per, n);
     long long sa = 0, sb = 0;
     for (int i = lo + lane; i < hi; i += 64) { sa += a[i]; sb += b[i]; }
@@ -133,20 +135,45 @@ __global__ __launch_bounds__(1024) void found_scan_kernel(int32_t* __restrict__ 
     __syncthreads();
     long long base_a = 0, base_b = 0;
     for (int k = 0; k < w; k++) { base_a += s_tot[0][k]; base_b += s_tot[1][k]; }
-    int na = lo + lane < hi ? a[lo + lane] : 0, nb = lo + lane < hi ? b[lo + lane] : 0;
-    for (int start = lo; start < hi; start += 64) {
-        const int i = start + lane;
-        const int va = na, vb = nb;
-        // (the next 64 entries are requested before this round's are stored: a load behind a store to the same array is not moved up by
-        // the compiler, and every round would be a full memory round trip)
-        na = i + 64 < hi ? a[i + 64] : 0;
-        nb = i + 64 < hi ? b[i + 64] : 0;
-        int xa = va, xb = vb;
+    for (int start = lo; start < hi; start += 64 * kPer) {
+        const int i0 = start + lane * kPer;
+        int va[kPer], vb[kPer];
+        int ta = 0, tb = 0;   // the lane's eight entries: their values, then exclusive sums inside the lane
+        const bool whole = start + 64 * kPer <= hi;   // (wave-uniform; the arrays and `start` are 16-byte aligned: two dwordx4 loads a lane)
+        if (whole) {
+            const int4 a0 = *reinterpret_cast<const int4*>(a + i0), a1 = *reinterpret_cast<const int4*>(a + i0 + 4);
+            const int4 b0 = *reinterpret_cast<const int4*>(b + i0), b1 = *reinterpret_cast<const int4*>(b + i0 + 4);
+            va[0] = a0.x; va[1] = a0.y; va[2] = a0.z; va[3] = a0.w; va[4] = a1.x; va[5] = a1.y; va[6] = a1.z; va[7] = a1.w;
+            vb[0] = b0.x; vb[1] = b0.y; vb[2] = b0.z; vb[3] = b0.w; vb[4] = b1.x; vb[5] = b1.y; vb[6] = b1.z; vb[7] = b1.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < kPer; k++) {
+                va[k] = i0 + k < hi ? a[i0 + k] : 0;
+                vb[k] = i0 + k < hi ? b[i0 + k] : 0;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+            const int xa = va[k], xb = vb[k];
+            va[k] = ta; vb[k] = tb;
+            ta += xa; tb += xb;
+        }
+        int xa = ta, xb = tb;   // inclusive scan of the lanes' sums
         for (int d = 1; d < 64; d <<= 1) {
             const int ya = __shfl_up(xa, d), yb = __shfl_up(xb, d);
             if (lane >= d) { xa += ya; xb += yb; }
         }
-        if (i < hi) { a[i] = (int32_t)(base_a + xa - va); b[i] = (int32_t)(base_b + xb - vb); }
+        const long long la = base_a + xa - ta, lb = base_b + xb - tb;
+        if (whole) {
+            *reinterpret_cast<int4*>(a + i0) = make_int4((int)(la + va[0]), (int)(la + va[1]), (int)(la + va[2]), (int)(la + va[3]));
+            *reinterpret_cast<int4*>(a + i0 + 4) = make_int4((int)(la + va[4]), (int)(la + va[5]), (int)(la + va[6]), (int)(la + va[7]));
+            *reinterpret_cast<int4*>(b + i0) = make_int4((int)(lb + vb[0]), (int)(lb + vb[1]), (int)(lb + vb[2]), (int)(lb + vb[3]));
+            *reinterpret_cast<int4*>(b + i0 + 4) = make_int4((int)(lb + vb[4]), (int)(lb + vb[5]), (int)(lb + vb[6]), (int)(lb + vb[7]));
+        } else {
+#pragma unroll
+            for (int k = 0; k < kPer; k++)
+                if (i0 + k < hi) { a[i0 + k] = (int32_t)(la + va[k]); b[i0 + k] = (int32_t)(lb + vb[k]); }
+        }
         base_a += __shfl(xa, 63);
         base_b += __shfl(xb, 63);
     }

@@ -180,19 +180,23 @@ PISCES_HD inline void walk_match_op(const ReadView& r, const ReadFrame& f, const
     if ((int64_t)r.read_len - op_read0 < lim) lim = (int64_t)r.read_len - op_read0;
     if (ref_len - (int64_t)op_ref0 < lim) lim = ref_len - (int64_t)op_ref0;
     const int walked = lim < 0 ? 0 : (int)lim;
+    // One base: what happens to the variant being built is decided first (selects), the variant is closed in ONE place — on the device
+    // a wave pays for every branch any of its 64 reads takes, and three copies of the closing code in three branches were most of
+    // what a step cost.
     auto step = [&](int i, uint8_t rb, uint8_t fb, uint8_t q) {
         const bool callable = is_acgt(rb) && is_acgt(fb) && q >= P.min_bq;
         const bool alone_on_last_base = i == op_len - 1 && run == 0;   // no MNV is started on the last base of an operation
-        if (!callable) {
-            close(i, true);
-            run = 0; tail = 0; open_left = true;
-        } else if (rb == fb) {
-            if (may_grow(true) && !alone_on_last_base) { run++; tail++; }
-            else { close(i, false); run = 0; tail = 0; open_left = false; }
-        } else {
-            if (may_grow(false) && !alone_on_last_base) { run++; tail = 0; }
-            else { close(i, false); run = 1; tail = 0; open_left = false; }
+        const bool matches = rb == fb;
+        const bool grows = callable && may_grow(matches) && !alone_on_last_base;
+        if (grows) {
+            run++;
+            tail = matches ? tail + 1 : 0;
+            return;
         }
+        close(i, !callable);   // (a base that cannot be called leaves the variant open on that side)
+        run = (callable && !matches) ? 1 : 0;
+        tail = 0;
+        open_left = !callable;
     };
     Src::for_each(r, ref, op_read0, op_ref0, walked, step);
     close(walked, false);
