@@ -685,6 +685,11 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
     std::unique_ptr<HostTimer> prof(new HostTimer(h->prof_on ? &h->prof[1] : nullptr));
     auto phase = [&](int i) { prof.reset(); prof.reset(new HostTimer(h->prof_on ? &h->prof[i] : nullptr)); };
     std::vector<HostCandidate> work;   // a copy: the blocks keep their candidates until DoneProcessing
+    {
+        size_t total = 0;
+        for (int32_t key : keys) total += h->blocks[key].cands.size();
+        work.reserve(total);
+    }
     for (int32_t key : keys) {
         // RegionState.GetAllCandidates walks _candidateVariantsLookup by position, each position in arrival order (RegionState.cs:388-391)
         const size_t first = work.size();
