@@ -78,3 +78,16 @@ def test_config4_as_stated_eight_shards_in_turn_on_one_gpu(torch_cuda):
     assert n_loci_total == 30_000_000 and n_reads_total == 200_000 * depth
     assert totals[2] == n_reads_total and totals[3] == 0
     assert shard_loci.sum() == n_loci_total and shard_loci.min() > 0.8 * shard_loci.mean()   # the cut is balanced
+
+
+def test_run_piece_counts_rows_in_place_as_it_would_keep_them(torch_cuda):
+    """config4.run_piece(keep_records=False) — what bench.py --config 4 times: the rows are looked at where they lie (pisces_hip_flush_view)
+    and only counted — reports the rows and distinct positions of the records it would have returned."""
+    from pisces_amd import config4, engine
+    cfg = _abi.default_config(emit_zero_coverage_refs=1)
+    job = config4.make_contig(5, 400, depth=60)
+    recs, _, stats, owned = config4.run_piece(engine, cfg, job, with_alleles=False, chunk_reads=7000)
+    counted, _, stats2, owned2 = config4.run_piece(engine, cfg, job, with_alleles=False, keep_records=False, chunk_reads=7000)
+    assert counted == {"n": len(recs), "loci": len(np.unique(recs["position"]))} and len(recs) >= 400 * config4.INTERVAL
+    assert owned == owned2 == job["batch"].n_reads
+    assert {k: v for k, v in stats.items() if k != "host_time"} == {k: v for k, v in stats2.items() if k != "host_time"}
