@@ -274,9 +274,14 @@ def end_to_end_full(pileup, cfg, engine, torch):
             achieved = nbytes / (kernel_ms * 1e-3) / 1e9
             traffic, traffic_run = None, None
             try:   # separate rocprofv3 --pmc passes over tools/store_bench.py (the same one-batch flush), tools/profile_round.sh
-                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("streaming", {})
+                from pisces_amd import build as native_build
+                whole_file = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+                tj = whole_file.get("streaming", {})
                 if tj.get("loci") == pileup.n_loci and tj.get("depth") == pileup.depth:
-                    traffic, traffic_run = tj.get("hbm_bytes_per_launch"), tj.get("run")
+                    if whole_file.get("source_hash") == native_build.source_hash():   # (collected on these kernels)
+                        traffic, traffic_run = tj.get("hbm_bytes_per_launch"), tj.get("run")
+                    else:
+                        traffic_run = "stale: profiles/traffic.json was collected on other sources (%s)" % tj.get("run")
             except Exception:   # noqa: BLE001
                 pass
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -797,9 +802,14 @@ def main():
         if os.path.exists(tpath):   # written from separate rocprofv3 --pmc passes of this same command
             try:
                 tj = json.load(open(tpath))
+                from pisces_amd import build as native_build
                 if tj.get("loci") == args.loci and tj.get("depth") == args.depth:
-                    traffic = tj.get("hbm_bytes_per_launch")
-                    traffic_run = tj.get("run")
+                    # the figure is only printed for the kernels it was collected on: the file carries the hash of the library's sources
+                    if tj.get("source_hash") == native_build.source_hash():
+                        traffic = tj.get("hbm_bytes_per_launch")
+                        traffic_run = tj.get("run")
+                    else:
+                        traffic_run = "stale: profiles/traffic.json was collected on other sources (%s); re-run tools/profile_round.sh" % tj.get("run")
             except Exception:
                 traffic = None
         out = {

@@ -13,6 +13,7 @@ namespace Pisces.Hip
         public int OutputStrandBiasAndNoiseLevel, OutputNoCallFraction;
         public float MinFrequencyThreshold, FrequencyFilterThreshold;
         public int Crush;   // !AllowMultipleVcfLinesPerLoci
+        public int NoiseLevelFromRecords;   // 1: the NL column is the record's NoiseLevelApplied (records made by this library)
     }
 
     [StructLayout(LayoutKind.Sequential)]

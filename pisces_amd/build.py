@@ -28,11 +28,28 @@ def is_stale():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
+def source_hash():
+    """sha1 over every source and header the library is built from: what a committed measurement (profiles/traffic.json) is stamped with,
+    so that a figure collected on other kernels is recognised as stale whatever the files' mtimes say."""
+    import hashlib
+    hsh = hashlib.sha1()
+    for f in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, f), "rb") as fp:
+            hsh.update(f.encode() + b"\0" + fp.read())
+    return hsh.hexdigest()
+
+
+LAST_BUILD = {"mode": None, "seconds": 0.0}   # what the last build_native of the product library did: "rebuilt" or "reused"
+
+
 def build_native(force=False, verbose=False, extra_flags=(), out=None):
     """out != None builds a development variant (e.g. an ablation) next to the product library."""
+    import time
     lib = LIB if out is None else out
     if out is None and not force and not is_stale():
+        LAST_BUILD.update(mode="reused", seconds=0.0)
         return lib
+    t0 = time.time()
     tmp = f"{lib}.{os.getpid()}.tmp"
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
            "-fno-fast-math", "-Wall", "-Wno-unused-function", "-x", "hip",
@@ -41,6 +58,8 @@ def build_native(force=False, verbose=False, extra_flags=(), out=None):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     os.replace(tmp, lib)
+    if out is None:
+        LAST_BUILD.update(mode="rebuilt", seconds=time.time() - t0)
     return lib
 
 

@@ -318,6 +318,7 @@ struct PiscesHip {
         int64_t n_reads = 0, n_ops = 0, n_bases = 0, n_skipped = 0;
         bool valid = false;
         bool moved = false;       // the batch's byte arrays went to the read store (pisces_hip_add_decoded_reads)
+        bool added = false;       // pisces_hip_add_decoded_reads took the batch (moved or copied): it is not added twice
         int32_t chain_mode = 0;   // 0: every chunk's entry guessed and checked; 1: the serial hop ran
         int32_t min_bq = 0;
     } bam;

@@ -58,7 +58,10 @@ constexpr int kFragDirShift = 22;                // DirectionType of a deletion 
 constexpr int kFragDeltaShift = 48;
 constexpr long long kFragAoffMask = 0xFFFFFFFFll;   // bits 0..31: the offset (a segment's bases stay below 4 GB)
 constexpr int kFragSpanShift = 32;               // bits 32..47: Read.EndPosition - Read.Position of the fragment's read (GetAnchorType needs both ends)
-constexpr uint32_t kFragTerminal = 1u << 24;     // a deletion at the read's end / before its final soft clip: its positions count in anchor bin 10
+constexpr uint32_t kFragTerminal = 1u << 24;
+// delta lives in the TOP 16 bits of the signed aoff: taken unsigned (an arithmetic shift would make 0x8000.. a negative offset, e.g. the
+// second aligned run of 20M40000N30M)
+__host__ __device__ __forceinline__ int frag_delta(long long aoff) { return (int)((unsigned long long)aoff >> 48); }     // a deletion at the read's end / before its final soft clip: its positions count in anchor bin 10
 constexpr int kMaxSegments = 8;
 constexpr int kStateUnsorted = 0, kStateReach = 1, kStateComplex = 2, kStateFrags = 3;   // [kStateFrags]: bit 0 some read is kDescGeneric, bit 1 some deletion fragment
 
@@ -448,7 +451,7 @@ __device__ __forceinline__ void walk_segment(const SegmentView& G, int tile_star
                 const long long aoff = shfl64(d.aoff, srcl);
                 const int len = (meta & kFragDeletion) ? 0 : (int)(meta & kDescLenMask);   // (deletion fragments: their own pass below)
                 const int n = (live && src < cnt) ? len : 0;
-                const int first = pos0 + (int)(aoff >> kFragDeltaShift);                   // the fragment's first position
+                const int first = pos0 + frag_delta(aoff);                   // the fragment's first position
                 const int floor_pos = base + srcl < G.n_floored_frags ? G.floor : 0;
                 const int i_min = max(floor_pos - first, 0);  // (floor <= 2^31 - 1, first >= 1)
                 const int s0 = lane_pos - first;              // index, in the aligned run, of the base on the lane's first locus
@@ -512,7 +515,7 @@ __device__ __forceinline__ void walk_segment(const SegmentView& G, int tile_star
                 const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)d.meta, u);
                 const int pos0 = __builtin_amdgcn_readlane(d.pos0, u);
                 const long long aoff = readlane64(d.aoff, u);
-                const int first = pos0 + (int)(aoff >> kFragDeltaShift), count = (int)(meta & kDescLenMask);
+                const int first = pos0 + frag_delta(aoff), count = (int)(meta & kDescLenMask);
                 const int floor_pos = base + u < G.n_floored_frags ? G.floor : 0;
                 const uint32_t dir = kDirs ? (meta >> kFragDirShift) & 3u : ((meta & kDescReverse) ? (uint32_t)PISCES_DIR_REVERSE : (uint32_t)PISCES_DIR_FORWARD);
                 const int anchor = (meta & kFragTerminal) ? PISCES_NUM_ANCHORS - 1
@@ -585,7 +588,7 @@ __device__ __forceinline__ void walk_segment_fast(const SegmentView& G, int tile
             const ReadDesc d = G.frag[base + min(lane, cnt - 1)];
             const int n = (lane < cnt && !(d.meta & kFragDeletion)) ? (int)(d.meta & kDescLenMask) : 0;
             const int floor_pos = base + lane < G.n_floored_frags ? G.floor : 0;
-            const int first = d.pos0 + (int)(d.aoff >> kFragDeltaShift);   // the fragment's first position
+            const int first = d.pos0 + frag_delta(d.aoff);   // the fragment's first position
             ReadTrim t;
             t.pos = max(first, floor_pos);
             const int cut = t.pos - first;                   // positions below the floor
@@ -694,7 +697,7 @@ __device__ __forceinline__ void walk_segment_fast(const SegmentView& G, int tile
                 const int u = __builtin_ctzll(dels);
                 dels &= dels - 1;
                 const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)d.meta, u);
-                const int first = __builtin_amdgcn_readlane(d.pos0, u) + (int)(readlane64(d.aoff, u) >> kFragDeltaShift);
+                const int first = __builtin_amdgcn_readlane(d.pos0, u) + frag_delta(readlane64(d.aoff, u));
                 const int count = (int)(meta & kDescLenMask);
                 const int floor_pos = base + u < G.n_floored_frags ? G.floor : 0;
                 const uint32_t dir = kDirs ? (meta >> kFragDirShift) & 3u : ((meta & kDescReverse) ? (uint32_t)PISCES_DIR_REVERSE : (uint32_t)PISCES_DIR_FORWARD);

@@ -141,6 +141,7 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
     if (!file || n_bytes <= 0 || n_blocks <= 0 || !blocks) return fail(h, PISCES_E_INVALID_ARG, "bam_decode: bad arguments");
     h->bam.valid = false;
     h->bam.moved = false;
+    h->bam.added = false;
     int64_t out_bytes = 0;
     for (int64_t i = 0; i < n_blocks; i++) {
         const PiscesBgzfBlock& b = blocks[i];
@@ -351,7 +352,7 @@ int32_t pisces_hip_add_decoded_reads(PiscesHip* h)
     if (!h->bam.valid) return fail(h, PISCES_E_STATE, "add_decoded_reads: no decoded batch (pisces_hip_bam_decode first)");
     HostTimer timer(&h->host_time[0]);
     auto& B = h->bam;
-    if (B.moved) return fail(h, PISCES_E_STATE, "add_decoded_reads: the decoded batch has been added already");
+    if (B.moved || B.added) return fail(h, PISCES_E_STATE, "add_decoded_reads: the decoded batch has been added already");
     if (B.min_bq != h->cfg.min_base_call_quality) return fail(h, PISCES_E_STATE, "add_decoded_reads: decoded with another minimum base quality");
     { int32_t rcp = refuse_while_batch_is_open(h, "add_decoded_reads"); if (rcp) return rcp; }
     const int32_t nr = (int32_t)B.n_reads;
@@ -371,13 +372,21 @@ int32_t pisces_hip_add_decoded_reads(PiscesHip* h)
     const bool find_on_device = !h->h_ref.empty();
     const int64_t found_slots = (find_on_device && !h->cfg.call_mnvs) ? B.found_slots : 0, found_pool = (find_on_device && !h->cfg.call_mnvs) ? B.found_pool : 0;
     if (found_slots > 0x7FFFFFF0ll || found_pool > 0x7FFFFFF0ll) return fail(h, PISCES_E_INVALID_ARG, "add_decoded_reads: too many insertions / deletions in one batch");
-    // the blocks the reads touch (GetBlock, RegionStateManager.cs:361-383)
-    for (size_t w = 0; w < B.block_map.size(); w++)
-        for (uint32_t bits = B.block_map[w]; bits; bits &= bits - 1)
-            (void)get_block(h, (int32_t)(((int64_t)w * 32 + __builtin_ctz(bits)) * h->cfg.block_size + 1));
-    h->stats[2] += nr;
-    h->stats[3] += B.n_skipped;
-    if (h->read_path == 1) return add_decoded_reads_store(h, found_slots, found_pool, find_on_device);
+    // commit: the blocks the reads touch (GetBlock, RegionStateManager.cs:361-383) and the totals — only once the batch is in the store / the log
+    // (a failed add leaves neither empty blocks nor readsProcessed / readsSkipped that pisces_hip_reduce_summary would add up)
+    auto commit = [&]() {
+        for (size_t w = 0; w < B.block_map.size(); w++)
+            for (uint32_t bits = B.block_map[w]; bits; bits &= bits - 1)
+                (void)get_block(h, (int32_t)(((int64_t)w * 32 + __builtin_ctz(bits)) * h->cfg.block_size + 1));
+        h->stats[2] += nr;
+        h->stats[3] += B.n_skipped;
+        B.added = true;   // consumed: a second add of the same decoded batch is refused, whichever way it went into the store
+    };
+    if (h->read_path == 1) {
+        const int32_t rcs = add_decoded_reads_store(h, found_slots, found_pool, find_on_device);
+        if (rcs == PISCES_OK) commit();
+        return rcs;
+    }
     int32_t rc = log_reserve(h, B.log_slots);
     if (rc) return rc;
     DevReadBatch db;
@@ -393,6 +402,7 @@ int32_t pisces_hip_add_decoded_reads(PiscesHip* h)
         if (rcd) return rcd;
     }
     h->log_ub += B.log_slots;
+    commit();
     return PISCES_OK;
     });
 }

@@ -1397,6 +1397,12 @@ int32_t pisces_hip_flush_end_view(PiscesHip* h, const PiscesCalledAllele** rows,
     if (!h) return PISCES_E_INVALID_ARG;
     if (!rows || !n_rows) return fail(h, PISCES_E_INVALID_ARG, "flush_end_view: null output");
     *rows = nullptr; *n_rows = 0;
+    // (every optional output is defined on every successful return, as pisces_hip_flush_view leaves them)
+    if (cand_index) *cand_index = nullptr;
+    if (cands) *cands = nullptr;
+    if (n_cand) *n_cand = 0;
+    if (alleles) *alleles = nullptr;
+    if (allele_bytes) *allele_bytes = 0;
     auto& A = h->async;
     if (A.state == 0) return fail(h, PISCES_E_STATE, "flush_end_view: no pisces_hip_flush_begin before it");
     if (A.state == 1) {   // wait as pisces_hip_flush_end does: a call with no room for rows completes the flush and reports the count
@@ -1404,6 +1410,7 @@ int32_t pisces_hip_flush_end_view(PiscesHip* h, const PiscesCalledAllele** rows,
         const int32_t rc = pisces_hip_flush_end(h, nullptr, 0, &need);
         if (rc == PISCES_OK) return PISCES_OK;   // no rows at all
         if (rc != PISCES_E_BUFFER_TOO_SMALL) return rc;
+        h->err.clear();   // (the probe's "buffer too small" is not an error of this call)
     }
     *rows = A.data;
     *n_rows = (int64_t)A.n;

@@ -238,6 +238,9 @@ static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const Sto
 {
     ReadSegment& g = *pl.seg;
     if (g.n_reads + nr > 0x7FFFFF00ll || g.n_ops + (int64_t)n_cig > 0x7FFFFF00ll) return fail(h, PISCES_E_INVALID_ARG, "add_reads: too many reads held at once");
+    // a fragment keeps the offset of its first base in 32 bits (kFragAoffMask): a segment's bases stay below 4 GB
+    if ((unsigned long long)g.n_bases + n_seq + 2ull * kSegmentPad > 0xFFFFFFFFull)
+        return fail(h, PISCES_E_INVALID_ARG, "add_reads: more than 4 GB of bases in one segment of the read store (flush, or hand the reads over in smaller batches)");
     ShapeArgs S;
     S.position = A.position; S.flags = A.flags; S.cigar_offset = A.cigar_offset; S.cigar_op = A.cigar_op; S.cigar_len = A.cigar_len;
     S.seq_offset = A.seq_offset;

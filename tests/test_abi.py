@@ -51,6 +51,77 @@ def test_managed_bindings_cover_the_header():
         assert counts == {c_args[name]}, f"{name}: {c_args[name]} arguments in the header, {sorted(counts)} in NativeMethods.cs"
 
 
+_C_SIZES = {"int32_t": 4, "uint32_t": 4, "float": 4, "double": 8, "int16_t": 2, "uint16_t": 2, "uint8_t": 1, "int8_t": 1, "int64_t": 8, "uint64_t": 8}
+_CS_SIZES = {"int": 4, "uint": 4, "float": 4, "double": 8, "short": 2, "ushort": 2, "byte": 1, "sbyte": 1, "long": 8, "ulong": 8, "IntPtr": 8}
+
+
+def _c_struct_fields(text):
+    """{struct name: [size of every primitive field in declaration order]} of the header (arrays flattened, pointers 8 bytes)."""
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"typedef struct (\w+)\s*\{(.*?)\}\s*\1\s*;", text, flags=re.S):
+        sizes = []
+        for decl in m.group(2).split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            dm = re.match(r"(?:const\s+)?(\w+)\s*(\*?)\s*(.+)$", decl, flags=re.S)
+            assert dm, decl
+            ctype, star, names = dm.group(1), dm.group(2), dm.group(3)
+            for name in names.split(","):
+                name = name.strip()
+                ptr = bool(star) or name.startswith("*")
+                am = re.search(r"\[(\d+)\]", name)
+                n = int(am.group(1)) if am else 1
+                if ptr:
+                    sizes += [8] * n
+                elif ctype in out:          # a struct by value
+                    sizes += out[ctype] * n
+                else:
+                    sizes += [_C_SIZES[ctype]] * n
+        out[m.group(1)] = sizes
+    return out
+
+
+def _cs_struct_fields(text):
+    text = re.sub(r"//[^\n]*", "", text)
+    out = {}
+    for m in re.finditer(r"public (?:unsafe )?struct (\w+)\s*\{(.*?)\}", text, flags=re.S):
+        sizes = []
+        for decl in m.group(2).split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            dm = re.match(r"public\s+(fixed\s+)?(\w+)\s*(\*?)\s*(.+)$", decl, flags=re.S)
+            assert dm, decl
+            fixed, cstype, star, names = dm.group(1), dm.group(2), dm.group(3), dm.group(4)
+            for name in names.split(","):
+                name = name.strip()
+                if fixed:
+                    sizes += [_CS_SIZES[cstype]] * int(re.search(r"\[(\d+)\]", name).group(1))
+                elif star:
+                    sizes.append(8)
+                else:
+                    sizes.append(_CS_SIZES[cstype])
+        out[m.group(1)] = sizes
+    return out
+
+
+def test_managed_structs_have_the_headers_fields_in_order():
+    """The [StructLayout(Sequential)] structs of dotnet/NativeMethods.cs against include/pisces_hip.h, field by field: the same number of
+    primitive fields, of the same widths, in the same order (a managed struct that lost a field, or has two swapped, marshals garbage
+    without any error — nothing compiles the C# here)."""
+    c = _c_struct_fields(open(os.path.join(ROOT, "include", "pisces_hip.h")).read())
+    cs = _cs_struct_fields(open(os.path.join(ROOT, "dotnet", "NativeMethods.cs")).read())
+    must = {"PiscesHipConfig", "PiscesCalledAllele", "PiscesReadBatch", "PiscesCandidate", "PiscesVcfConfig", "PiscesVcfPadState", "PiscesBgzfBlock",
+            "PiscesTile", "PiscesTileResult"}
+    assert must <= set(c) and must <= set(cs), (sorted(must - set(c)), sorted(must - set(cs)))
+    for name in sorted(set(c) & set(cs)):
+        assert cs[name] == c[name], f"{name}: header field widths {c[name]}, NativeMethods.cs {cs[name]}"
+    # and the header against the ctypes mirror the tests drive the library with
+    assert sum(c["PiscesHipConfig"]) == C.sizeof(_abi.PiscesHipConfig) and sum(c["PiscesCandidate"]) + 2 * 0 <= C.sizeof(_abi.PiscesCandidate)
+
+
 def test_struct_layouts_match_header():
     assert _abi.CALLED_ALLELE_DTYPE.itemsize == 64
     assert _abi.TILE_DTYPE.itemsize == 24 and _abi.TILE_RESULT_DTYPE.itemsize == 48

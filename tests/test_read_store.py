@@ -220,6 +220,37 @@ def test_any_cigar_through_the_fused_kernel_equals_the_log_chain(torch_cuda, mod
     assert (got["position"] > 70000).any()        # the far ends of the skipping reads were called
 
 
+@pytest.mark.parametrize("gap_op", ["N", "D"])
+def test_fragment_behind_a_gap_of_forty_thousand_positions(torch_cuda, gap_op):
+    """A later fragment's offset from the read's position sits in the top 16 bits of the descriptor's signed 64-bit field: offsets of
+    0x8000 .. 0xFFFF (a skip or a deletion of 33-65 thousand positions inside a read whose span still fits 16 bits) must come out
+    unsigned — 20M40000N30M is two aligned runs 40 020 positions apart, not one run 25 516 positions BEFORE the read.  Counts
+    (accumulate_store_tiles_kernel) against the oracle, records (call_store_tiles_kernel) against the log chain."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(77)
+    ref = np.frombuffer(bytes(rng.choice(list(b"ACGT"), 66000).astype(np.uint8)), dtype=np.uint8)
+    reads = []
+    for k in range(40):   # gaps from 32 700 to 65 400 positions: both sides of 0x8000, all inside a 16-bit span
+        gap, ln = 32700 + 838 * k, 50
+        reads.append({"pos": 100 + 3 * k, "cigar": [("M", 20), (gap_op, gap), ("M", ln - 20)],
+                      "seq": bytes(rng.choice(list(b"ACGT"), ln).astype(np.uint8)), "quals": [37] * ln, "reverse": bool(k & 1)})
+    reads.sort(key=lambda r: r["pos"])
+    assert all(sum(l for o, l in r["cigar"] if o in "MDN") <= 0xFFFF for r in reads)
+    exp = oracle_counts(reads, 1, 66000)
+    cfg = _abi.default_config(min_coverage=1, low_depth_filter=1)
+    with env(PISCES_HIP_READ_PATH=None):
+        with engine.HipVariantCaller(cfg) as c:
+            c.AddAlleleCounts(_abi.ReadBatch(reads))
+            lo = 100 + 20 + 32700 - 5
+            got = c.GetCounts(lo, 33500)
+    np.testing.assert_array_equal(got.reshape(33500, -1), exp.reshape(66000, -1)[lo - 1:lo - 1 + 33500])
+    assert got.sum() > 0
+    got_r, _, stats = _schedule_run([_abi.ReadBatch(reads)], ref, cfg, [None], dict(PISCES_HIP_READ_PATH=None))
+    want_r, _, want_stats = _schedule_run([_abi.ReadBatch(reads)], ref, cfg, [None], dict(PISCES_HIP_READ_PATH="log"))
+    assert got_r.tobytes() == want_r.tobytes() and stats == want_stats
+    assert (got_r["position"] > 40000).any()
+
+
 def test_thresholds_the_fused_kernel_is_not_compiled_for(torch_cuda):
     """minBQ above 127 (the fused kernel compares seven bits) goes through the counts in HBM: same records as the log chain."""
     rng = np.random.default_rng(2)

@@ -69,7 +69,8 @@ grep "rep 2" $OUT/config3.log
 # HBM traffic of the hot kernel per launch, for bench.py's roofline.traffic: FETCH_SIZE / WRITE_SIZE come in KiB; on gfx950 FETCH_SIZE
 # reports half the bytes of a wide coalesced streaming read (16 B per lane: this kernel's loads), so it is doubled (MI355X_MICROARCH.md, HBM)
 python - $OUT $TAG <<'PY'
-import json, re, sys, time
+import json, os, re, sys, time
+sys.path.insert(0, os.getcwd())
 out, tag = sys.argv[1], sys.argv[2]
 def mean(name):
     for line in open(f"{out}/pmc_{name}.txt"):
@@ -85,6 +86,7 @@ if f and w:
     t = {"loci": line["config"]["loci_per_gpu_per_step"], "depth": line["config"]["depth"], "tile_loci": line["config"]["tile_loci"],
          "hbm_bytes_per_launch": f * 1024 * corr + w * 1024, "fetch_size_kib_raw": f, "fetch_correction": corr, "write_size_kib_raw": w,
          "kernel": "pisces::call_tiles_wave_kernel", "run": f"{tag} {time.strftime('%Y-%m-%d %H:%M:%S')} tools/profile_round.sh",
+         "source_hash": __import__("pisces_amd.build", fromlist=["x"]).source_hash(),
          "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-include-regex call_tiles, separate passes over bench.py (tools/profile_round.sh)"}
     sf, sw = None, None
     for name, key in (("store_fetch", "FETCH_SIZE"), ("store_write", "WRITE_SIZE")):
