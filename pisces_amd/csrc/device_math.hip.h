@@ -44,7 +44,20 @@ struct DeviceParams {
     const double* sb0_tab;
     const int16_t* gq_cap;
     int32_t vq_tab_k, sb_tab_k, tab_cov;
+    // MNV calling on, split form (surface_flush.inc.h): SNV candidates are the allele counts — as with MNV calling off — everywhere but on
+    // the DIRTY loci, where candidates of the read walk decide (an MNV candidate spans the locus and has taken bases out of the SNVs there,
+    // an open-ended SNV candidate sits on it, a failed MNV's leftovers landed on it, ...): there the tile kernels emit the Reference
+    // record only and the variants come from the candidate kernel.  Bit (position - dirty_first) of dirty_bits; nullptr: no locus is dirty.
+    const uint32_t* dirty_bits;
+    int32_t dirty_first, dirty_n;
 };
+
+__device__ __forceinline__ bool locus_is_dirty(const DeviceParams& P, int pos)
+{
+    if (!P.dirty_bits) return false;
+    const unsigned rel = (unsigned)(pos - P.dirty_first);
+    return rel < (unsigned)P.dirty_n && ((P.dirty_bits[rel >> 5] >> (rel & 31u)) & 1u) != 0u;
+}
 
 // ------------------------------------------------------------------------------------------
 // lib/Pisces.Calculators/stats/Poisson.cs — in-repo regularized incomplete gamma

@@ -19,6 +19,10 @@ struct HostCandidate {
     int32_t support_by_dir[3] = {0, 0, 0};
     int32_t well_anchored_by_dir[3] = {0, 0, 0};
     bool open_left = false, open_right = false;
+    // bookkeeping of the streaming surface (surface_reads.inc.h): order of first arrival (RegionState.AddCandidate keeps a position's
+    // candidates in that order, RegionState.cs:104-123), and whether every read event behind the candidate came from the device's read walk
+    uint64_t stamp = 0;
+    bool from_reads = false;
 };
 
 // Appends the read's indel candidates. ref[i] is position i+1 of the chromosome (upper case).

@@ -95,7 +95,7 @@ struct WordBases {
 
 __device__ __forceinline__ bool found_needs_pool(const FoundCandidate& c)
 {
-    return c.category != PISCES_CAT_DELETION && c.length > kFoundInline;
+    return c.category != PISCES_CAT_DELETION && c.category != kFoundSpanMark && c.length > kFoundInline;
 }
 
 __global__ __launch_bounds__(256) void find_count_kernel(DevReadBatch b, const uint8_t* __restrict__ del_dirs, const uint8_t* __restrict__ ref,
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void find_emit_kernel(DevReadBatch b, const ui
         f.c = c;
         f.read = r;
         f.pool_offset = -1;
-        const int n_alt = c.category == PISCES_CAT_DELETION ? 0 : c.length;
+        const int n_alt = (c.category == PISCES_CAT_DELETION || c.category == kFoundSpanMark) ? 0 : c.length;
         const uint8_t* src = v.bases + c.start_in_read;
         if (n_alt > kFoundInline) {
             int at;
@@ -254,7 +254,7 @@ struct DevMerged {   // 96 bytes
 static_assert(sizeof(DevMerged) == 96, "DevMerged is 96 bytes");
 constexpr int kMergeAcc = 8;   // int32 per record: sup[3], anch[3], 0x7FFFFFFF - first (atomicMax), owner flag
 
-__device__ __forceinline__ int found_alt_len(const FoundCandidate& c) { return c.category == PISCES_CAT_DELETION ? 0 : c.length; }
+__device__ __forceinline__ int found_alt_len(const FoundCandidate& c) { return (c.category == PISCES_CAT_DELETION || c.category == kFoundSpanMark) ? 0 : c.length; }
 __device__ __forceinline__ const uint8_t* found_alt_bytes(const DevFound& f, const uint8_t* pool)
 {
     return found_alt_len(f.c) > kFoundInline ? pool + f.pool_offset : f.alt;
@@ -354,6 +354,136 @@ __global__ __launch_bounds__(256) void found_gather_kernel(const DevFound* __res
     for (int d = 0; d < 3; d++) { m.sup[d] = a[d]; m.anch[d] = a[3 + d]; }
     m.pad = 0;
     out[base + (unsigned int)__popcll(owners & ((1ull << lane) - 1ull))] = m;
+}
+
+// ---- MNV calling on, split form: where a batch's merged groups go ----------------------------------------------------------------
+// With MNV calling on every mismatch of every read is an SNV candidate of the read walk (bases an MNV candidate took are not): ~1.5
+// groups a locus at 2000x, nearly all of them fully anchored SNVs of one or two reads that are never called.  The host needs a
+// candidate object only where the read walk's candidates differ from what the allele counts say (surface_flush.inc.h, the dirty loci),
+// so the groups part here:
+//   fully anchored SNV groups ("plain")  -> the SNV STORE in device memory (SnvGroup, 40 bytes), where they stay until their block is
+//                                           flushed; a flush takes the ones on dirty loci (snv_store_sweep_kernel) and drops the rest
+//   everything else                      -> pinned host memory as before (DevMerged): MNVs, insertions, deletions, open-ended SNVs when
+//                                           open ends are tracked, X-operation span marks
+struct SnvGroup {
+    int32_t position;
+    uint8_t alt;          // the read base (ASCII); the reference base is the chromosome's
+    uint8_t pad[3];
+    int32_t sup[3], anch[3];
+    uint32_t first;       // (batch, first): order of first arrival (RegionState.cs:104-123 keeps a position's candidates in that order)
+    uint32_t batch;
+};
+static_assert(sizeof(SnvGroup) == 40, "SnvGroup is 40 bytes");
+
+__device__ __forceinline__ bool found_is_plain_snv(const FoundCandidate& c, int track_open)
+{
+    return c.category == PISCES_CAT_SNV && !(track_open && (c.open_left || c.open_right));
+}
+
+// cursors: [2] groups written to out_host, [3] groups appended to the store (this batch); store_n: the store's running count (device)
+__global__ __launch_bounds__(256) void found_gather_split_kernel(const DevFound* __restrict__ rec, int32_t n, const int32_t* __restrict__ acc,
+                                                                 DevMerged* __restrict__ out_host, unsigned int* __restrict__ cursors,
+                                                                 SnvGroup* __restrict__ store, unsigned int* __restrict__ store_n, uint32_t store_capacity,
+                                                                 uint32_t batch, int32_t track_open)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const int32_t* a = acc + (int64_t)min(i, n - 1) * kMergeAcc;
+    const bool owner = i < n && a[7] == 1;
+    if (__ballot(owner) == 0ull) return;
+    int32_t first = 0;
+    DevFound f = {};
+    if (owner) {
+        first = 0x7FFFFFFF - a[6];
+        f = rec[first];
+    }
+    const bool plain = owner && found_is_plain_snv(f.c, track_open);
+    const bool other = owner && !plain;
+    const unsigned long long plains = __ballot(plain), others = __ballot(other);
+    unsigned int base_p = 0, base_o = 0;
+    if (plains) {
+        const int l0 = __builtin_ctzll(plains);
+        if (lane == l0) { base_p = atomicAdd(store_n, (unsigned int)__popcll(plains)); atomicAdd(cursors + 3, (unsigned int)__popcll(plains)); }
+        base_p = (unsigned int)__shfl((int)base_p, l0, 64);
+    }
+    if (others) {
+        const int l0 = __builtin_ctzll(others);
+        if (lane == l0) base_o = atomicAdd(cursors + 2, (unsigned int)__popcll(others));
+        base_o = (unsigned int)__shfl((int)base_o, l0, 64);
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (plain) {
+        const unsigned int at = base_p + (unsigned int)__popcll(plains & below);
+        if (at < store_capacity) {
+            SnvGroup g;
+            g.position = f.c.position;
+            g.alt = f.alt[0];
+            g.pad[0] = g.pad[1] = g.pad[2] = 0;
+            for (int d = 0; d < 3; d++) { g.sup[d] = a[d]; g.anch[d] = a[3 + d]; }
+            g.first = (uint32_t)first;
+            g.batch = batch;
+            store[at] = g;
+        } else {
+            atomicExch(cursors + 1, 1u);   // (the reservation is the batch's record count: cannot happen; reported as an overflow)
+        }
+    }
+    if (other) {
+        DevMerged m;
+        m.first = first;
+        m.f = f;
+        for (int d = 0; d < 3; d++) { m.sup[d] = a[d]; m.anch[d] = a[3 + d]; }
+        m.pad = 0;
+        out_host[base_o + (unsigned int)__popcll(others & below)] = m;
+    }
+}
+
+// A flush over the SNV store: the groups on dirty loci (bit (position - bm_first) of bm) go to pinned host memory, the groups of the
+// flushed positions [1, drop_hi] that are not dirty are dropped (the tile kernels call those SNVs from the counts), the rest is kept,
+// compacted into the other buffer.  counts_out: [0] selected, [1] kept (zeroed before the launch).
+__global__ __launch_bounds__(256) void snv_store_sweep_kernel(const SnvGroup* __restrict__ in, const unsigned int* __restrict__ n_in, const uint32_t* __restrict__ bm,
+                                                              int32_t bm_first, int32_t bm_n, int32_t drop_hi, SnvGroup* __restrict__ selected,
+                                                              uint32_t selected_capacity, SnvGroup* __restrict__ kept, unsigned int* __restrict__ counts_out)
+{
+    const unsigned int n = *n_in;
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    SnvGroup g = {};
+    bool sel = false, keep = false;
+    if (i < n) {
+        g = in[i];
+        const unsigned rel = (unsigned)(g.position - bm_first);
+        sel = bm && rel < (unsigned)bm_n && ((bm[rel >> 5] >> (rel & 31u)) & 1u);
+        keep = !sel && g.position > drop_hi;
+    }
+    const unsigned long long sels = __ballot(sel), keeps = __ballot(keep);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (sels) {
+        unsigned int base = 0;
+        const int l0 = __builtin_ctzll(sels);
+        if (lane == l0) base = atomicAdd(counts_out, (unsigned int)__popcll(sels));
+        base = (unsigned int)__shfl((int)base, l0, 64);
+        const unsigned int at = base + (unsigned int)__popcll(sels & below);
+        if (sel && at < selected_capacity) selected[at] = g;
+    }
+    if (keeps) {
+        unsigned int base = 0;
+        const int l0 = __builtin_ctzll(keeps);
+        if (lane == l0) base = atomicAdd(counts_out + 1, (unsigned int)__popcll(keeps));
+        base = (unsigned int)__shfl((int)base, l0, 64);
+        if (keep) kept[base + (unsigned int)__popcll(keeps & below)] = g;
+    }
+}
+
+// rows[k][198] = counts[idx[k]][198] (a negative index: zeros): the anchor-resolved counts of the few loci the collapser's frequencies and
+// the reallocator's Reference candidates read on the host (the tensor itself stays on the device)
+__global__ __launch_bounds__(256) void gather_count_rows_kernel(const int32_t* __restrict__ counts, const long long* __restrict__ idx, int32_t n_rows,
+                                                                int32_t* __restrict__ rows)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t k = g / PISCES_COUNTS_PER_LOCUS;
+    if (k >= n_rows) return;
+    const int c = (int)(g - k * PISCES_COUNTS_PER_LOCUS);
+    const long long li = idx[k];
+    rows[g] = li >= 0 ? counts[li * PISCES_COUNTS_PER_LOCUS + c] : 0;
 }
 
 }  // namespace pisces

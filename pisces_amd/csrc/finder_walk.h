@@ -36,7 +36,13 @@ struct FinderParams {
     int32_t min_bq, anchor_size;
     int32_t snvs_and_mnvs;   // walk the M operations (MNV calling on); off: insertions and deletions only
     int32_t call_mnvs, max_mnv_length, max_gap;
+    int32_t mark_x_spans;    // the streaming surface's split form of MNV calling: every X operation leaves a span mark (below)
 };
+
+// Not a candidate: the positions of an X operation (position, length).  ProcessCigarOps (:44-71) walks M operations only, so the bases of
+// an X operation are allele counts without SNV candidates; the flush takes the loci of such a span from the read walk's candidates
+// instead of from the counts (surface_flush.inc.h, the dirty loci).  '=' bases equal the reference: they make no candidate either way.
+constexpr uint8_t kFoundSpanMark = 0x40;
 
 namespace walk {
 
@@ -226,6 +232,18 @@ PISCES_HD inline void walk_read(const ReadView& r, const uint8_t* ref, int64_t r
             }
             if ((int64_t)in_ref + len < ref_len && in_ref >= 1 && flanks_ok)
                 finish_candidate(r, f, P, PISCES_CAT_DELETION, in_ref, in_ref - 1, in_read, len, 1, ci, false, false, emit);
+        }
+        else if (t == 'X' && P.mark_x_spans && len > 0) {
+            FoundCandidate c;
+            c.position = in_ref + 1;
+            c.ref_index = in_ref;
+            c.start_in_read = in_read;
+            c.length = len;
+            c.category = kFoundSpanMark;
+            c.dir = 0;
+            c.well_anchored = c.open_left = c.open_right = 0;
+            c.pad[0] = c.pad[1] = c.pad[2] = 0;
+            emit(c);
         }
         if (spans_read(t)) in_read += len;
         if (spans_ref(t)) in_ref += len;

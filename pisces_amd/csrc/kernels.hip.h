@@ -357,7 +357,7 @@ __device__ inline void call_roles(const int* hist, const uint32_t* gapped /* LDS
     // Every wave evaluates the same data, so the "no variant work in this tile" decision is wave-uniform across the
     // workgroup: waves 1 and 2 then retire at once and wave 0 never meets a barrier.
     uint32_t pass_mask = 0;
-    if (in_ref && rt < 4 && !P.refs_only) {
+    if (in_ref && rt < 4 && !P.refs_only && !locus_is_dirty(P, pos)) {
         for (int k = 0; k < 4; k++) {
             const int a = allele_of_rank(k);
             if (a == rt) continue;
@@ -711,6 +711,7 @@ __device__ __forceinline__ void call_phase_wave(const int* hist, const uint8_t* 
     const int rt = in_ref ? allele_type_of_base(refb) : PISCES_ALLELE_N;
     const int64_t win_lo = (int64_t)ref_start - 1, win_hi = win_lo + ref_len;
     auto slot_of = [&](int k) { return records + ((int64_t)t * kSlotsPerTile + l * 4 + k); };
+    const bool dirty = locus_is_dirty(P, pos);   // (one dword per 32 loci, requested before the counts are read)
     const LocusCounts lc = load_counts_wave<H>(hist, l);
     const bool ref_wave = wid == 0, var_wave = wid == NW - 1;
 
@@ -751,7 +752,7 @@ __device__ __forceinline__ void call_phase_wave(const int* hist, const uint8_t* 
 #ifdef PISCES_TIMING
     const long long tcA = wall_clock64();
 #endif
-    if (var_wave && in_ref && rt < 4 && !P.refs_only) {
+    if (var_wave && in_ref && rt < 4 && !P.refs_only && !dirty) {
         // SNV candidates: quality-passing bases that differ from the reference base (CandidateVariantFinder.cs:97-160 with MNV
         // calling off); IsCallable (AlleleCaller.cs:236-258) in its own order: coverage, frequency, q-score
 #pragma unroll 1

@@ -52,6 +52,7 @@ struct BlockObs {   // the block's observations live in the device log (PiscesHi
     std::unordered_map<uint64_t, uint32_t> cand_index;
     std::vector<uint32_t> cand_next;
     int32_t max_allele_endpoint = 0;   // RegionState.MaxAlleleEndpoint
+    std::vector<std::pair<int32_t, int32_t>> x_spans;   // positions of the X operations of the block's reads (MNV calling on, split form): dirty loci
 };
 
 template <typename T>
@@ -290,7 +291,26 @@ struct PiscesHip {
         bool in_flight = false;
         int64_t n_slots = 0, pool_bytes = 0;
         std::vector<int32_t> order;          // consume_found: group of each first-arrival record index
+        uint32_t batch = 0;                  // the batch's sequence number (arrival stamps)
+        bool split = false;                  // the plain SNV groups went to the SNV store (misc[3] of them)
     } found;
+
+    // MNV calling on, SPLIT FORM (surface_flush.inc.h): the fully anchored SNV groups of the read walk stay in device memory (the SNV store,
+    // finder_kernels.hip.h) until their block is flushed; the tile kernels call SNVs from the allele counts everywhere but on the dirty loci
+    bool mnv_split = false;
+    DeviceBuf<SnvGroup> d_snv[2];
+    int snv_cur = 0;
+    DeviceBuf<unsigned int> d_snv_n;          // [0], [1]: groups in d_snv[0] / [1]; [2], [3]: a sweep's {selected, kept}
+    int64_t snv_ub = 0;                       // groups in d_snv[snv_cur], an upper bound while a batch's gather is in flight
+    DeviceBuf<SnvGroup> d_snv_sel;
+    SnvGroup* h_snv_sel = nullptr;            // pinned: {selected, kept} counts (16 bytes), then the first kSnvSpec selected groups
+    DeviceBuf<uint32_t> d_dirty;
+    std::vector<uint32_t> dirty_host;
+    uint32_t batch_seq = 0, host_seq = 0;     // arrival stamps: (batch_seq << 32) | record index, host-side additions behind the batch's records
+    DeviceBuf<long long> d_row_idx;           // gather_count_rows_kernel
+    DeviceBuf<int32_t> d_rows;
+    std::unordered_map<int64_t, int32_t> row_of_locus;
+    int64_t split_stats[4] = {0, 0, 0, 0};    // development: groups appended to the store, selected by flushes, dropped, flushes that swept
 
     // BAM decode on the device (bam_kernels.hip.h): file bytes -> inflated stream -> read batch, all handle-owned and grow-only
     struct BamState {
@@ -490,6 +510,8 @@ static DeviceParams make_params(const PiscesHipConfig& c)
     P.sb0_tab = nullptr;
     P.gq_cap = nullptr;
     P.vq_tab_k = P.sb_tab_k = P.tab_cov = 0;
+    P.dirty_bits = nullptr;
+    P.dirty_first = P.dirty_n = 0;
     return P;
 }
 
@@ -621,6 +643,10 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         if (const char* v = getenv("PISCES_HIP_STORE_DIRECT_BYTES")) h->store_direct_bytes = (size_t)std::max(0ll, atoll(v));
         if (const char* v = getenv("PISCES_HIP_STORE_WAVES")) h->store_waves = atoi(v);
         if (const char* v = getenv("PISCES_HIP_DEVICE_MERGE")) h->device_merge = atoi(v) != 0 ? 1 : 0;   // the A/B of tests/test_read_store.py
+        // MNV calling on: the split form, unless the candidate records are asked to come back unmerged (PISCES_HIP_DEVICE_MERGE=0: the
+        // earlier form, every candidate an object on the host, the tile kernels Reference records only) or PISCES_HIP_MNV_SPLIT=0
+        h->mnv_split = h->cfg.call_mnvs != 0 && h->device_merge != 0;
+        if (const char* v = getenv("PISCES_HIP_MNV_SPLIT")) h->mnv_split = h->mnv_split && atoi(v) != 0;
         if (const char* v = getenv("PISCES_HIP_STORE_SEAL_BYTES")) h->store_seal_bytes = (size_t)std::max(0ll, atoll(v));
     }
     {
@@ -752,6 +778,9 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     h->found.done = nullptr;
     h->d_found.release(); h->d_found_pool.release(); h->d_found_slots.release(); h->d_found_pool_first.release();
     h->d_merge_tab.release(); h->d_merge_acc.release();
+    h->d_snv[0].release(); h->d_snv[1].release(); h->d_snv_n.release(); h->d_snv_sel.release(); h->d_dirty.release(); h->d_row_idx.release(); h->d_rows.release();
+    if (h->h_snv_sel) (void)hipHostFree(h->h_snv_sel);
+    h->h_snv_sel = nullptr;
     h->d_found_misc.release(); h->d_found_totals.release();
     h->d_cands.release(); h->d_alleles.release(); h->d_cand_records.release(); h->d_cand_callable.release();
     h->segments.clear();

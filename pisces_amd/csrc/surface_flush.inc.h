@@ -665,6 +665,202 @@ static int64_t collapse_candidates(std::vector<HostCandidate>& cands, float freq
 }
 }  // extern "C++"
 
+// ------------------------------------------------------------------------------------------------
+// MNV calling on, SPLIT FORM.  With -callmnvs every mismatch of every read is an SNV candidate of the read walk
+// (CandidateVariantFinder.cs:90-168) — ~1.5 merged candidates a locus at 2000x, nearly all of them single-read errors that are never
+// called — and the reference calls SNVs from those candidates because a base that an MNV candidate took is no SNV candidate any more.
+// Where no such thing happened the candidate IS the allele count: support by direction = the quality-passing bases that show the allele,
+// which is what the tile kernels call SNVs from when MNV calling is off.  So a flush parts the loci of its blocks:
+//   DIRTY loci   an MNV candidate spans the locus; an open-ended SNV / MNV candidate sits on it (the collapser may move its support); a
+//                candidate the host added itself lies there (what a failed MNV left for the next block, a caller's candidate); an X
+//                operation of some read covers it (counted, but no candidate: ProcessCigarOps walks M operations only); it lies outside
+//                the interval set (calls there are counted, not reported).  There every candidate goes the way it always went: host
+//                objects, collapser, reallocator, candidate kernel — the SNV groups of those loci are taken from the device's SNV store
+//                (snv_store_sweep_kernel), and the tile kernels emit the Reference record only (DeviceParams::dirty_bits).
+//   the rest     SNVs from the allele counts in the tile kernels, as with MNV calling off; their groups in the store are dropped unseen.
+// The host's work per flush follows the dirty loci (hundreds a block at most), not the candidates (thousands).
+// ------------------------------------------------------------------------------------------------
+constexpr size_t kSnvSpec = 4096;   // selected groups that come back with the sweep's counts; more only with a second copy
+
+static inline bool candidate_is_plain_snv(const PiscesHip* h, const HostCandidate& c)
+{
+    return c.category == PISCES_CAT_SNV && c.from_reads && !(h->cfg.collapse != 0 && (c.open_left || c.open_right));
+}
+static inline bool split_dirty_at(const PiscesHip* h, int32_t p)
+{
+    const int64_t rel = (int64_t)p - h->P.dirty_first;
+    if (!h->P.dirty_bits || rel < 0 || rel >= h->P.dirty_n) return false;
+    return ((h->dirty_host[(size_t)(rel >> 5)] >> (rel & 31)) & 1u) != 0u;
+}
+
+// One pass over the SNV store: groups on set bits of `bm` (device, or nullptr) -> `selected`; groups at or below drop_hi are dropped; the
+// rest is kept (compacted into the other buffer).  Waits for the device.
+static int32_t snv_store_sweep(PiscesHip* h, const uint32_t* d_bm, int32_t bm_first, int32_t bm_n, int32_t drop_hi, std::vector<SnvGroup>& selected)
+{
+    selected.clear();
+    if (h->snv_ub <= 0) return PISCES_OK;
+    const int c = h->snv_cur, o = c ^ 1;
+    PISCES_HIP_CHECK(h, h->d_snv[o].reserve((size_t)h->snv_ub));
+    PISCES_HIP_CHECK(h, h->d_snv_sel.reserve((size_t)h->snv_ub));
+    if (!h->h_snv_sel) PISCES_HIP_CHECK(h, hipHostMalloc((void**)&h->h_snv_sel, 16 + kSnvSpec * sizeof(SnvGroup), hipHostMallocDefault));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_snv_n.p + 2, 0, 2 * sizeof(unsigned int), h->stream));
+    hipLaunchKernelGGL(snv_store_sweep_kernel, dim3((unsigned)((h->snv_ub + 255) / 256)), dim3(256), 0, h->stream, (const SnvGroup*)h->d_snv[c].p,
+                       (const unsigned int*)(h->d_snv_n.p + c), d_bm, bm_first, bm_n, drop_hi, h->d_snv_sel.p, (uint32_t)std::min<size_t>(h->d_snv_sel.cap, 0xFFFFFFF0u),
+                       h->d_snv[o].p, h->d_snv_n.p + 2);
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    // the kept count becomes the other buffer's count; the counts and a first stretch of the selected groups come back together
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(h->d_snv_n.p + o, h->d_snv_n.p + 3, sizeof(unsigned int), hipMemcpyDeviceToDevice, h->stream));
+    unsigned int* counts = (unsigned int*)h->h_snv_sel;
+    SnvGroup* first = (SnvGroup*)((uint8_t*)h->h_snv_sel + 16);
+    const size_t spec = std::min<size_t>(kSnvSpec, (size_t)h->snv_ub);
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(counts, h->d_snv_n.p + 2, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+    if (d_bm) PISCES_HIP_CHECK(h, hipMemcpyAsync(first, h->d_snv_sel.p, spec * sizeof(SnvGroup), hipMemcpyDeviceToHost, h->stream));
+    PISCES_TIMED_WAIT(h, hipStreamSynchronize(h->stream));
+    const size_t n_sel = counts[0], n_kept = counts[1];
+    if ((int64_t)(n_sel + n_kept) > h->snv_ub) return fail(h, PISCES_E_DEVICE, "flush: the SNV store's counts are inconsistent");
+    selected.resize(n_sel);
+    if (n_sel) std::memcpy(selected.data(), first, std::min(n_sel, spec) * sizeof(SnvGroup));
+    if (n_sel > spec) {
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(selected.data() + spec, h->d_snv_sel.p + spec, (n_sel - spec) * sizeof(SnvGroup), hipMemcpyDeviceToHost, h->stream));
+        PISCES_TIMED_WAIT(h, hipStreamSynchronize(h->stream));
+    }
+    h->pcie[2] += (int64_t)(n_sel * sizeof(SnvGroup)) + 16;
+    h->split_stats[1] += (int64_t)n_sel;
+    h->split_stats[2] += h->snv_ub - (int64_t)n_sel - (int64_t)n_kept;
+    h->split_stats[3] += 1;
+    h->snv_cur = o;
+    h->snv_ub = (int64_t)n_kept;
+    return PISCES_OK;
+}
+
+// The dirty loci of the batch `keys` (and, when alleles of the cleared blocks reach past the last cleared position, of the held blocks up
+// to upTo whose candidates AddCollapsableFromOtherBlocks will bring in), as a bit map on host and device; the SNV groups on them join
+// their blocks' candidates; DeviceParams is set for the tile kernels of this flush.  split_restore() undoes the latter.
+static void split_restore(PiscesHip* h)
+{
+    h->P.dirty_bits = nullptr;
+    h->P.dirty_first = h->P.dirty_n = 0;
+    h->P.refs_only = h->cfg.call_mnvs ? 1 : 0;
+}
+static int32_t split_prepare(PiscesHip* h, const std::vector<int32_t>& keys, int32_t up_to_position)
+{
+    split_restore(h);
+    if (!h->mnv_split) return PISCES_OK;
+    h->P.refs_only = 0;
+    if (keys.empty()) return PISCES_OK;
+    const int bs = h->cfg.block_size;
+    const int64_t lo = (int64_t)(keys.front() - 1) * bs + 1, hi = (int64_t)keys.back() * bs;
+    int64_t hi_bm = hi;
+    bool add_collapsable = false;
+    if (up_to_position >= 0 && h->cfg.collapse) {   // (the condition of call_spanning's AddCollapsableFromOtherBlocks step)
+        int32_t max_endpoint = 0;
+        for (int32_t key : keys) max_endpoint = std::max(max_endpoint, h->blocks[key].max_allele_endpoint);
+        if ((int64_t)max_endpoint > hi) { add_collapsable = true; hi_bm = std::max<int64_t>(hi, up_to_position); }
+    }
+    const int64_t n = hi_bm - lo + 1;
+    if (n > 0x7FFFFF00ll) return fail(h, PISCES_E_UNSUPPORTED, "flush: the blocks of one batch span more than 2^31 positions");
+    std::vector<uint32_t>& bm = h->dirty_host;
+    bm.assign((size_t)((n + 31) / 32), 0u);
+    bool any = false;
+    auto mark = [&](int64_t a, int64_t b) {   // inclusive positions
+        a = std::max(a, lo); b = std::min(b, hi_bm);
+        if (a > b) return;
+        any = true;
+        int64_t i = a - lo;
+        const int64_t e = b - lo;
+        while (i <= e) {
+            const int64_t w = i >> 5;
+            const int s0 = (int)(i & 31), s1 = (int)std::min<int64_t>(31, e - (w << 5));
+            bm[(size_t)w] |= (s1 == 31 ? 0xFFFFFFFFu : ((1u << (s1 + 1)) - 1u)) & ~((1u << s0) - 1u);
+            i = (w + 1) << 5;
+        }
+    };
+    const bool track_open = h->cfg.collapse != 0;
+    // A span that reaches past the last flushed position stays dirty for the block it reaches into: the candidate goes with this batch, the
+    // bases it took (an MNV across a block edge) stay in that block's counts.  (Only blocks that exist: no reads, nothing counted.)
+    auto carry = [&](int64_t a, int64_t b) {
+        a = std::max(a, hi + 1);
+        b = std::min<int64_t>(b, 0x7FFFFFFFll);
+        if (a > b) return;
+        for (int32_t k = block_key(h, (int32_t)a); k <= block_key(h, (int32_t)b); k++) {
+            auto it = h->blocks.find(k);
+            if (it != h->blocks.end()) it->second.x_spans.emplace_back((int32_t)a, (int32_t)b);
+        }
+    };
+    auto mark_candidate = [&](const HostCandidate& c, bool of_the_batch) {
+        if (c.category != PISCES_CAT_SNV && c.category != PISCES_CAT_MNV) return;   // (insertions and deletions touch no point allele)
+        const bool interesting = c.category == PISCES_CAT_MNV || !c.from_reads || (track_open && (c.open_left || c.open_right));
+        if (!interesting) return;
+        const int64_t end = (int64_t)c.position + (int64_t)std::max<size_t>(c.alt.size(), c.ref.size()) - 1;
+        mark(c.position, end);
+        if (of_the_batch) carry(c.position, end);
+    };
+    if (!h->forced.empty()) {
+        mark(lo, hi);   // forced alleles: every candidate of the batch is an object on the host, as before
+    } else {
+        for (int32_t key : keys) {
+            const BlockObs& b = h->blocks[key];
+            for (auto& c : b.cands) mark_candidate(c, true);
+            for (auto& sp : b.x_spans) mark(sp.first, sp.second);   // (a span lies with every block it touches already)
+        }
+        if (!h->intervals.empty()) {   // outside the intervals a callable allele is counted and not reported (AlleleCaller.cs:236-263): the candidate path's rule
+            int64_t at = lo;
+            auto it = std::lower_bound(h->intervals.begin(), h->intervals.end(), (int32_t)lo, [](const std::pair<int32_t, int32_t>& iv, int32_t p) { return iv.second < p; });
+            for (; it != h->intervals.end() && it->first <= hi; ++it) {
+                if (it->first > at) mark(at, (int64_t)it->first - 1);
+                at = std::max<int64_t>(at, (int64_t)it->second + 1);
+            }
+            if (at <= hi) mark(at, hi);
+        }
+    }
+    if (add_collapsable)
+        for (auto& kv : h->blocks) {
+            const int64_t start = (int64_t)(kv.first - 1) * bs + 1;
+            if (start <= hi || start > up_to_position) continue;
+            for (auto& c : kv.second.cands) {
+                const bool collapsable = (c.category == PISCES_CAT_MNV || c.category == PISCES_CAT_SNV) && !c.open_right &&
+                                         c.position + (int32_t)c.alt.size() - 1 <= up_to_position;
+                if (collapsable) mark_candidate(c, false);
+            }
+        }
+    // the device's copy of the map, and the groups on its set bits
+    if (any) {
+        PISCES_HIP_CHECK(h, h->d_dirty.reserve(bm.size()));
+        { int32_t rcu = meta_upload(h, h->d_dirty.p, bm.data(), bm.size() * sizeof(uint32_t)); if (rcu) return rcu; }
+    }
+    std::vector<SnvGroup> selected;
+    if (h->snv_ub > 0) {
+        int32_t rcs = snv_store_sweep(h, any ? h->d_dirty.p : (const uint32_t*)nullptr, (int32_t)lo, (int32_t)n, (int32_t)std::min<int64_t>(hi, 0x7FFFFFFFll), selected);
+        if (rcs) return rcs;
+    }
+    if (!selected.empty()) {
+        std::vector<int32_t> touched;
+        for (const SnvGroup& g : selected) {
+            if (g.position < 1 || (int64_t)g.position > h->ref_len) continue;
+            HostCandidate c;
+            c.position = g.position;
+            c.category = PISCES_CAT_SNV;
+            c.ref.assign(1, (char)h->h_ref[(size_t)g.position - 1]);
+            c.alt.assign(1, (char)g.alt);
+            for (int d = 0; d < 3; d++) { c.support_by_dir[d] = g.sup[d]; c.well_anchored_by_dir[d] = g.anch[d]; }
+            c.stamp = ((uint64_t)g.batch << 32) | (uint64_t)g.first;
+            c.from_reads = true;
+            add_candidate(h, c);
+            touched.push_back(block_key(h, g.position));
+        }
+        std::sort(touched.begin(), touched.end());
+        touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+        for (int32_t k : touched) reorder_block_candidates(h, &h->blocks[k]);
+        h->last_block = nullptr;
+    }
+    if (any) {
+        h->P.dirty_bits = h->d_dirty.p;
+        h->P.dirty_first = (int32_t)lo;
+        h->P.dirty_n = (int32_t)n;
+    }
+    return PISCES_OK;
+}
+
 // IAlleleCaller.Call for the host-found candidates of `keys` (AlleleCaller.CallForPositions :60-141): anchor-resolved counts of every
 // block a candidate touches -> collapser -> call_spanning_kernel -> callable candidates with their records.  With MNV calling on
 // the candidates include the SNVs / MNVs of the read walk: MNV candidates are processed first, the ones that are not callable go
@@ -693,7 +889,11 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
     for (int32_t key : keys) {
         // RegionState.GetAllCandidates walks _candidateVariantsLookup by position, each position in arrival order (RegionState.cs:388-391)
         const size_t first = work.size();
-        for (auto& c : h->blocks[key].cands) work.push_back(c);
+        for (auto& c : h->blocks[key].cands) {
+            // (split form of MNV calling: a fully anchored SNV of the read walk on a locus that is not dirty is the tile kernels' to call)
+            if (h->mnv_split && candidate_is_plain_snv(h, c) && !split_dirty_at(h, c.position)) continue;
+            work.push_back(c);
+        }
         std::stable_sort(work.begin() + (std::ptrdiff_t)first, work.end(), [](const HostCandidate& x, const HostCandidate& y) { return x.position < y.position; });
     }
     const int bs = h->cfg.block_size;
@@ -792,11 +992,37 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         d.end_idx = locus_index(ep);
         d.gapped = (c.category == PISCES_CAT_SNV || c.category == PISCES_CAT_REFERENCE) ? gapped_at(c.position) : 0;
     };
-    // the collapser's frequencies and the reallocator's Reference candidates read a host copy of the anchor-resolved counts
+    // The collapser's frequencies and the reallocator's Reference candidates read anchor-resolved counts on the host: the ROWS of the few
+    // loci they can look at (gather_count_rows_kernel), never the tensor — every start / end point when some candidate is open-ended (the
+    // collapser's candidates: CandidateAllele.Frequency of the open-ended one and of what it may join), the positions an MNV candidate
+    // spans (a failed one's Reference candidates, MnvReallocator.cs:12-98), a forced SNV's position.
     const bool have_forced = !h->forced.empty();
     const int32_t* host_counts_p = nullptr;
-    if (h->cfg.collapse || mnv_mode || have_forced) {
-        const size_t n_counts = (size_t)std::max(n_tiles, 1) * kTile * PISCES_COUNTS_PER_LOCUS;
+    std::unordered_map<int64_t, int32_t>& row_of = h->row_of_locus;
+    row_of.clear();
+    bool rows_missing = false;
+    auto row_index = [&](int64_t li) -> int64_t {
+        if (li < 0) return -1;
+        auto it = row_of.find(li);
+        if (it == row_of.end()) { rows_missing = true; return -1; }
+        return it->second;
+    };
+    {
+        bool any_open = false;
+        if (h->cfg.collapse)
+            for (auto& c : work) any_open = any_open || c.open_left || c.open_right;
+        std::vector<long long> need;
+        auto want = [&](int32_t p) { const int64_t li = locus_index(p); if (li >= 0) need.push_back(li); };
+        for (auto& c : work) {
+            int32_t sp, ep;
+            endpoints(c, sp, ep);
+            if (mnv_mode && c.category == PISCES_CAT_MNV)
+                for (int32_t p = sp; p <= ep; p++) want(p);
+            else if (any_open || (have_forced && c.category == PISCES_CAT_SNV)) { want(sp); want(ep); }
+        }
+        std::sort(need.begin(), need.end());
+        need.erase(std::unique(need.begin(), need.end()), need.end());
+        const size_t n_rows = need.size(), n_counts = std::max<size_t>(n_rows, 1) * PISCES_COUNTS_PER_LOCUS;
         if (n_counts > h->h_counts_cap) {
             if (h->h_counts) (void)hipHostFree(h->h_counts);
             h->h_counts = nullptr;
@@ -804,12 +1030,17 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
             PISCES_HIP_CHECK(h, hipHostMalloc((void**)&h->h_counts, (n_counts + n_counts / 2) * sizeof(int32_t), hipHostMallocDefault));
             h->h_counts_cap = n_counts + n_counts / 2;
         }
-        if (n_tiles > 0) {
-            h->pcie[3] += (int64_t)(n_counts * sizeof(int32_t));
-            PISCES_HIP_CHECK(h, hipMemcpyAsync(h->h_counts, h->d_counts.p, n_counts * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        if (n_rows > 0 && n_tiles > 0) {
+            for (size_t k = 0; k < n_rows; k++) row_of.emplace(need[k], (int32_t)k);
+            PISCES_HIP_CHECK(h, h->d_row_idx.reserve(n_rows));
+            PISCES_HIP_CHECK(h, h->d_rows.reserve(n_rows * PISCES_COUNTS_PER_LOCUS));
+            { int32_t rcu = meta_upload(h, h->d_row_idx.p, need.data(), n_rows * sizeof(long long)); if (rcu) return rcu; }
+            hipLaunchKernelGGL(gather_count_rows_kernel, dim3((unsigned)((n_rows * PISCES_COUNTS_PER_LOCUS + 255) / 256)), dim3(256), 0, h->stream,
+                               (const int32_t*)h->d_counts.p, (const long long*)h->d_row_idx.p, (int32_t)n_rows, h->d_rows.p);
+            PISCES_HIP_CHECK(h, hipGetLastError());
+            h->pcie[3] += (int64_t)(n_rows * PISCES_COUNTS_PER_LOCUS * sizeof(int32_t));
+            PISCES_HIP_CHECK(h, hipMemcpyAsync(h->h_counts, h->d_rows.p, n_rows * PISCES_COUNTS_PER_LOCUS * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
             PISCES_TIMED_WAIT(h, hipStreamSynchronize(h->stream));
-        } else {
-            std::memset(h->h_counts, 0, n_counts * sizeof(int32_t));
         }
         host_counts_p = h->h_counts;
     }
@@ -819,7 +1050,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         // the support the merged candidate of the reference has: the reads that show the base at or above the quality threshold
         for (auto& c : work) {
             if (c.category != PISCES_CAT_SNV || cand_support(c) != 0 || !is_forced_allele(h, c)) continue;
-            const int64_t li = locus_index(c.position);
+            const int64_t li = row_index(locus_index(c.position));
             const int at = atype(c.alt[0]);
             if (li < 0 || at >= 4) continue;
             for (int d = 0; d < 3; d++) {
@@ -834,6 +1065,8 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         *n_collapsed = collapse_candidates(work, h->cfg.collapse_freq_threshold, h->cfg.collapse_freq_ratio_threshold, [&](const HostCandidate& c) {
             DevCandidate d;
             to_dev(c, d);
+            d.start_idx = row_index(d.start_idx);   // (rows of the gathered loci, not of the tensor)
+            d.end_idx = row_index(d.end_idx);
             const int total = candidate_total_coverage(d, host_counts.data(), stitched);
             const int support = c.support_by_dir[0] + c.support_by_dir[1] + c.support_by_dir[2];
             if (total == 0) return 0.0f;                       // CalledAllele.Frequency (CalledAllele.cs:49-52)
@@ -845,7 +1078,11 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         if (max_cleared >= 0) {
             size_t w = 0;
             for (size_t i = 0; i < work.size(); i++) {
-                if (work[i].position > max_cleared && work[i].category != PISCES_CAT_REFERENCE) { add_candidate(h, work[i]); continue; }
+                if (work[i].position > max_cleared && work[i].category != PISCES_CAT_REFERENCE) {
+                    work[i].stamp = next_host_stamp(h);   // (AddCandidates appends it to its position's list again)
+                    add_candidate(h, work[i]);
+                    continue;
+                }
                 if (w != i) work[w] = std::move(work[i]);
                 w++;
             }
@@ -946,7 +1183,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
                 const bool forced_here = !h->cfg.include_reference_calls && h->forced_positions.count(p) != 0;
                 if (!(h->cfg.include_reference_calls || forced_here) || p < 1 || p > h->ref_len || !inside_intervals(p)) return false;
                 if (!std::binary_search(keys.begin(), keys.end(), block_key(h, p))) return false;
-                const int64_t li = locus_index(p);
+                const int64_t li = row_index(locus_index(p));
                 const int rb = atype((char)h->h_ref[(size_t)p - 1]);
                 int total = 0;
                 sup[0] = sup[1] = sup[2] = 0;
@@ -987,6 +1224,8 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
                     HostCandidate c = *o;
                     c.well_anchored_by_dir[0] = c.well_anchored_by_dir[1] = c.well_anchored_by_dir[2] = 0;
                     c.open_left = c.open_right = false;
+                    c.stamp = next_host_stamp(h);
+                    c.from_reads = false;   // (support that reallocation moved: no longer what the allele counts say)
                     add_candidate(h, c);
                 }
             // Reference candidates keep only what reallocation added: the kernel supplies their own counts
@@ -1024,6 +1263,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         }
     }
 
+    if (rows_missing) return fail(h, PISCES_E_INTERNAL, "flush: a candidate's counts were not among the rows fetched for the batch");
     phase(6);
     second_pass = mnv_mode;
     int32_t rc2 = device_pass(final_list);
@@ -1091,6 +1331,9 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
         int64_t called = 0;
         std::vector<PiscesCalledAllele> point_recs, span_recs;
         std::vector<HostCandidate> span_cands;
+        // MNV calling on, split form: the dirty loci of the batch, the SNV groups on them, the tile kernels' parameters for this flush
+        struct SplitGuard { PiscesHip* h; ~SplitGuard() { split_restore(h); } } split_guard{h};
+        { int32_t rcs = split_prepare(h, keys, final_flush ? -1 : up_to_position); if (rcs) return rcs; }
         // host-side candidates first: with MNV calling on they register the reference support that gapped MNVs take, which the
         // Reference records of call_blocks must see (AlleleCaller.cs:95, CoverageCalculator.cs:82-97)
         int64_t collapsed = 0;
@@ -1103,10 +1346,90 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
         const bool diploid = h->cfg.ploidy == PISCES_PLOIDY_DIPLOID || h->cfg.ploidy == PISCES_PLOIDY_HAPLOID;   // per-locus genotypers
         // nothing to merge into the tile kernels' records: they go from the download buffer straight to the caller
         const bool plain = span_recs.empty() && !diploid && h->forced.empty() && ref_overrides.empty();
-        rc = call_blocks(h, keys, point_recs, &called, true, &h->pending_dropped, &h->pending_kept, plain);
+        // the tile kernels' rows are read where the last kernel left them (pinned memory) unless a per-locus genotyper or forced alleles rework them
+        const bool fast_merge = !plain && !diploid && h->forced.empty();
+        rc = call_blocks(h, keys, point_recs, &called, true, &h->pending_dropped, &h->pending_kept, plain || fast_merge);
         if (rc) return rc;
         prof.reset();
         prof.reset(new HostTimer(h->prof_on ? &h->prof[8] : nullptr));
+        if (fast_merge) {
+            // The candidate kernel's rows (a handful per block) go into the tile kernels' rows (position, ref, alt order, one per locus and
+            // more): where each belongs is found by bisection, the rows between two such places are copied in one piece.  Three kinds of
+            // places: a candidate row goes in FRONT of a row; a Reference row goes because a variant of the candidate kernel is reported on its
+            // position (AlleleCaller.cs:146-147); a Reference row is replaced by the one MNV reallocation added support to.
+            static const char kBaseF[6] = {'A', 'G', 'C', 'T', 'N', 'D'};
+            const PiscesCalledAllele* const P = h->pending_view;
+            const size_t np = h->pending_view_n;
+            auto first_at = [&](int32_t position) {   // first row at or behind the position
+                size_t a = 0, b = np;
+                while (a < b) { const size_t m = (a + b) >> 1; if (P[m].position < position) a = m + 1; else b = m; }
+                return a;
+            };
+            struct SRow { const PiscesCalledAllele* r; int32_t ci; const std::string* ref; const std::string* alt; };
+            std::vector<SRow> rows;
+            rows.reserve(span_recs.size());
+            for (size_t i = 0; i < span_recs.size(); i++) rows.push_back({&span_recs[i], (int32_t)i, &span_cands[i].ref, &span_cands[i].alt});
+            std::stable_sort(rows.begin(), rows.end(), [](const SRow& a, const SRow& b) {
+                if (a.r->position != b.r->position) return a.r->position < b.r->position;
+                if (*a.ref != *b.ref) return *a.ref < *b.ref;
+                return *a.alt < *b.alt;
+            });
+            auto point_first = [&](const PiscesCalledAllele& p, const SRow& sr) {   // true: p goes before sr (or they are equal): one-base alleles against strings
+                const char pr = kBaseF[PISCES_INFO_REF(p.info)], pa = kBaseF[PISCES_INFO_ALT(p.info)];
+                const int cr = sr.ref->empty() ? 1 : (pr != (*sr.ref)[0] ? (pr < (*sr.ref)[0] ? -1 : 1) : (sr.ref->size() > 1 ? -1 : 0));
+                if (cr != 0) return cr < 0;
+                const int ca = sr.alt->empty() ? 1 : (pa != (*sr.alt)[0] ? (pa < (*sr.alt)[0] ? -1 : 1) : (sr.alt->size() > 1 ? -1 : 0));
+                return ca <= 0;
+            };
+            struct Ev { size_t idx; int kind; const PiscesCalledAllele* row; int32_t ci; };   // kind 0: insert in front of idx, 1: drop idx, 2: replace idx
+            std::vector<Ev> evs;
+            evs.reserve(rows.size() * 2 + ref_overrides.size());
+            int32_t last_dropped = -1;
+            for (auto& sr : rows) {
+                size_t i = first_at(sr.r->position);
+                while (i < np && P[i].position == sr.r->position && point_first(P[i], sr)) i++;
+                evs.push_back({i, 0, sr.r, sr.ci});
+                const bool forced_row = ((sr.r->filter_bits >> PISCES_FILTER_FORCED_REPORT) & 1u) != 0;
+                if (!forced_row && sr.r->position != last_dropped) {
+                    last_dropped = sr.r->position;
+                    for (size_t k = first_at(sr.r->position); k < np && P[k].position == sr.r->position; k++)
+                        if (PISCES_INFO_CATEGORY(P[k].info) == PISCES_CAT_REFERENCE) evs.push_back({k, 1, nullptr, -1});
+                }
+            }
+            for (auto& ov : ref_overrides)
+                for (size_t k = first_at(ov.position); k < np && P[k].position == ov.position; k++)
+                    if (PISCES_INFO_CATEGORY(P[k].info) == PISCES_CAT_REFERENCE) { evs.push_back({k, 2, &ov, -1}); break; }
+            std::stable_sort(evs.begin(), evs.end(), [](const Ev& a, const Ev& b) { return a.idx != b.idx ? a.idx < b.idx : a.kind < b.kind; });
+            h->pending.clear();
+            h->pending_cand_index.clear();
+            h->pending.reserve(np + rows.size());
+            h->pending_cand_index.reserve(np + rows.size());
+            size_t cur = 0;
+            auto copy_to = [&](size_t end) {
+                if (end > cur) {
+                    h->pending.insert(h->pending.end(), P + cur, P + end);
+                    h->pending_cand_index.insert(h->pending_cand_index.end(), end - cur, -1);
+                    cur = end;
+                }
+            };
+            for (size_t e = 0; e < evs.size(); e++) {
+                const Ev& ev = evs[e];
+                copy_to(ev.idx);
+                if (ev.kind == 0) { h->pending.push_back(*ev.row); h->pending_cand_index.push_back(ev.ci); continue; }
+                if (cur != ev.idx) continue;                       // (the row is gone already: dropped and replaced at once)
+                if (ev.kind == 2) {
+                    // a Reference row that a variant of its position removes is not brought back by its replacement
+                    bool dropped = false;
+                    for (size_t q = e; q-- > 0 && evs[q].idx == ev.idx;) dropped = dropped || evs[q].kind == 1;
+                    if (!dropped) { h->pending.push_back(*ev.row); h->pending_cand_index.push_back(-1); }
+                }
+                cur = ev.idx + 1;
+            }
+            copy_to(np);
+            h->pending_view = nullptr;
+            h->pending_view_n = 0;
+            h->pending_cands = span_cands;
+        } else {
         if (!ref_overrides.empty()) {   // Reference alleles that MNV reallocation added support to
             std::map<int32_t, const PiscesCalledAllele*> by_pos;
             for (auto& r : ref_overrides) by_pos[r.position] = &r;
@@ -1276,6 +1599,7 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
             }
             }
         }
+        }   // (!fast_merge)
         if (!keys.empty()) h->host_time[3] += 1.0;
         h->pending_keys = keys;
         h->pending_called = called;
@@ -1467,8 +1791,11 @@ int32_t pisces_hip_flush_begin(PiscesHip* h, int32_t up_to_position)
             if (!(final_flush || (int64_t)kv.first * h->cfg.block_size <= up_to_position)) continue;
             if (!final_flush && kv.second.max_allele_endpoint > up_to_position) break;
             keys.push_back(kv.first);
-            if (!kv.second.cands.empty()) plain = false;
+            if (!kv.second.cands.empty() || !kv.second.x_spans.empty()) plain = false;
         }
+    // MNV calling on, split form: a batch without dirty loci is the tile kernels' alone (SNVs from the allele counts); off-interval loci are
+    // dirty, and a store that has grown large is swept by a synchronous flush (the groups of flushed blocks leave it there)
+    if (h->mnv_split && (!h->intervals.empty() || h->snv_ub > (4ll << 20))) plain = false;
     for (auto& kv : h->gapped_mnv_ref)
         if (std::binary_search(keys.begin(), keys.end(), block_key(h, kv.first))) { plain = false; break; }
     if (!plain) {
@@ -1503,7 +1830,9 @@ int32_t pisces_hip_flush_begin(PiscesHip* h, int32_t up_to_position)
     // what the compacted log can hold at most: the entries that are not known holes
     const int64_t bound = std::max<int64_t>(0, h->log_ub - h->log_known_holes);
     CallBlocksInFlight st;
+    if (h->mnv_split) h->P.refs_only = 0;   // (no dirty locus in this batch: every SNV is the allele counts')
     int32_t rc = call_blocks_enqueue(h, keys, true, bound, &st);
+    split_restore(h);
     if (rc) return rc;
     if (st.active) PISCES_HIP_CHECK(h, hipEventRecord(A.done, h->stream));
     if (!keys.empty()) h->host_time[3] += 1.0;
@@ -1711,9 +2040,54 @@ int32_t pisces_hip_get_candidates(PiscesHip* h, int32_t up_to_position, PiscesCa
     // the candidates collected so far: insertions / deletions, and with MNV calling on the SNVs / MNVs of the read walk (with it
     // off SNV candidates never leave the device: they are the allele counts)
     { int32_t rcf = consume_found(h); if (rcf) return rcf; }
+    // MNV calling on, split form: the fully anchored SNV groups of the read walk are in the device's SNV store.  They are read (and stay
+    // where they are) and every block's candidates are listed as the state holds them: equal candidates merged, in order of first arrival.
+    std::map<int32_t, std::vector<HostCandidate>> merged_blocks;
+    if (h->mnv_split && h->snv_ub > 0) {
+        PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+        unsigned int n_store = 0;
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(&n_store, h->d_snv_n.p + h->snv_cur, sizeof(n_store), hipMemcpyDeviceToHost, h->stream));
+        PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+        std::vector<SnvGroup> groups(n_store);
+        if (n_store) {
+            PISCES_HIP_CHECK(h, hipMemcpyAsync(groups.data(), h->d_snv[h->snv_cur].p, (size_t)n_store * sizeof(SnvGroup), hipMemcpyDeviceToHost, h->stream));
+            PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+        }
+        const bool track_open = h->cfg.collapse != 0;
+        for (const SnvGroup& g : groups) {
+            if (g.position < 1 || (int64_t)g.position > h->ref_len) continue;
+            const int32_t key = block_key(h, g.position);
+            auto it = merged_blocks.find(key);
+            if (it == merged_blocks.end()) {
+                it = merged_blocks.emplace(key, std::vector<HostCandidate>()).first;
+                auto bi = h->blocks.find(key);
+                if (bi != h->blocks.end()) it->second = bi->second.cands;
+            }
+            HostCandidate c;
+            c.position = g.position;
+            c.category = PISCES_CAT_SNV;
+            c.ref.assign(1, (char)h->h_ref[(size_t)g.position - 1]);
+            c.alt.assign(1, (char)g.alt);
+            for (int d = 0; d < 3; d++) { c.support_by_dir[d] = g.sup[d]; c.well_anchored_by_dir[d] = g.anch[d]; }
+            c.stamp = ((uint64_t)g.batch << 32) | (uint64_t)g.first;
+            c.from_reads = true;
+            HostCandidate* same = nullptr;
+            for (auto& e : it->second)   // (a listing for inspection: a scan of the block's candidates per group is fine)
+                if (e.position == c.position && e.category == c.category && e.ref == c.ref && e.alt == c.alt &&
+                    (!track_open || (!e.open_left && !e.open_right))) { same = &e; break; }
+            if (same) {
+                for (int d = 0; d < 3; d++) { same->support_by_dir[d] += c.support_by_dir[d]; same->well_anchored_by_dir[d] += c.well_anchored_by_dir[d]; }
+                same->stamp = std::min(same->stamp, c.stamp);
+            } else {
+                it->second.push_back(c);
+            }
+        }
+        for (auto& kv : merged_blocks)
+            std::stable_sort(kv.second.begin(), kv.second.end(), [](const HostCandidate& x, const HostCandidate& y) { return x.stamp < y.stamp; });
+    }
     int64_t n = 0, bytes = 0;
     for (auto& kv : h->blocks)
-        for (auto& c : kv.second.cands) {
+        for (auto& c : (merged_blocks.count(kv.first) ? merged_blocks[kv.first] : kv.second.cands)) {
             if (up_to_position >= 0 && c.position > up_to_position) continue;
             if (out && n < capacity && (!alleles || bytes + (int64_t)(c.ref.size() + c.alt.size()) <= allele_capacity)) {
                 PiscesCandidate& o = out[n];

@@ -172,6 +172,29 @@ static inline uint64_t candidate_hash(const HostCandidate& c, bool with_open_end
     for (char ch : c.alt) mix((uint8_t)ch);
     return x;
 }
+// arrival stamp of a candidate the host adds itself (pisces_hip_add_candidates, forced alleles, what AlleleCaller.Call hands back to the
+// state): behind every record of the batches added so far, before the next batch's
+static uint64_t next_host_stamp(PiscesHip* h) { return ((uint64_t)h->batch_seq << 32) | 0x80000000ull | (uint64_t)(h->host_seq++ & 0x7FFFFFFFu); }
+
+// the block's candidates back in order of first arrival (after candidates with earlier stamps were added late: the SNV groups a flush
+// takes from the device store), and the hash index over them rebuilt
+static inline uint64_t candidate_hash(const HostCandidate& c, bool with_open_ends);
+static void reorder_block_candidates(PiscesHip* h, BlockObs* b)
+{
+    std::stable_sort(b->cands.begin(), b->cands.end(), [](const HostCandidate& x, const HostCandidate& y) { return x.stamp < y.stamp; });
+    const bool track_open = h->cfg.collapse != 0;
+    b->cand_index.clear();
+    b->cand_next.assign(b->cands.size(), 0xFFFFFFFFu);
+    for (uint32_t i = 0; i < (uint32_t)b->cands.size(); i++) {
+        const uint64_t key = candidate_hash(b->cands[i], track_open);
+        auto it = b->cand_index.find(key);
+        if (it == b->cand_index.end()) { b->cand_index.emplace(key, i); continue; }
+        uint32_t j = it->second;
+        while (b->cand_next[j] != 0xFFFFFFFFu) j = b->cand_next[j];
+        b->cand_next[j] = i;
+    }
+}
+
 static void add_candidate(PiscesHip* h, const HostCandidate& cnd)
 {
     BlockObs* b = get_block(h, cnd.position);
@@ -200,6 +223,8 @@ static void add_candidate(PiscesHip* h, const HostCandidate& cnd)
             found->support_by_dir[d] += cnd.support_by_dir[d];
             found->well_anchored_by_dir[d] += cnd.well_anchored_by_dir[d];
         }
+        found->stamp = std::min(found->stamp, cnd.stamp);                // (the candidate keeps the place of its first arrival)
+        found->from_reads = found->from_reads && cnd.from_reads;
     }
     int32_t other_end = 0;
     if (cnd.category == PISCES_CAT_DELETION) other_end = cnd.position + (int32_t)cnd.ref.size();
@@ -249,7 +274,7 @@ int32_t pisces_hip_add_candidates(PiscesHip* h, const PiscesCandidate* cands, in
     std::vector<HostCandidate> list;
     int32_t rc = host_candidates_of(h, cands, n, alleles, allele_bytes, list, "add_candidates");
     if (rc) return rc;
-    for (auto& c : list) add_candidate(h, c);
+    for (auto& c : list) { c.stamp = next_host_stamp(h); c.from_reads = false; add_candidate(h, c); }
     return PISCES_OK;
     });
 }
@@ -297,7 +322,10 @@ static void add_forced_as_candidates(PiscesHip* h, int32_t up_to_position)
     while (h->n_forced_added < h->forced.size()) {
         const HostCandidate& c = h->forced[h->n_forced_added];
         if (up_to_position >= 0 && c.position > up_to_position) break;
-        add_candidate(h, c);
+        HostCandidate fc = c;
+        fc.stamp = next_host_stamp(h);
+        fc.from_reads = false;
+        add_candidate(h, fc);
         h->n_forced_added++;
     }
 }
@@ -311,7 +339,12 @@ static int32_t enqueue_candidate_discovery(PiscesHip* h, const DevReadBatch& db,
     const int32_t minBQ = h->cfg.min_base_call_quality;
     const int32_t* d_slots = d_slots_in;
         const FinderParams FP = {minBQ, PISCES_ANCHOR_SIZE, h->cfg.call_mnvs ? 1 : 0, h->cfg.call_mnvs ? 1 : 0, h->cfg.max_mnv_length,
-                                 h->cfg.max_gap_between_mnv};
+                                 h->cfg.max_gap_between_mnv, h->mnv_split ? 1 : 0};
+        // (arrival stamps: this batch's records come behind everything the host added so far)
+        h->batch_seq++;
+        h->host_seq = 0;
+        h->found.batch = h->batch_seq;
+        h->found.split = false;
         const unsigned grid = (unsigned)((nr + 255) / 256);
         PISCES_HIP_CHECK(h, h->d_found_misc.reserve(4));
         PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_found_misc.p, 0, 4 * sizeof(unsigned int), h->stream));
@@ -343,7 +376,7 @@ static int32_t enqueue_candidate_discovery(PiscesHip* h, const DevReadBatch& db,
                                d_pool_first, h->d_found.p, h->d_found_pool.p, h->d_found_misc.p, (int32_t)found_pool, (int32_t*)(h->d_found_misc.p + 1));
             PISCES_HIP_CHECK(h, hipGetLastError());
             // records + pool + {cursor, overflow, merged groups} come back into pinned memory; consume_found waits for them when they are needed
-            const bool merge = h->device_merge == 1 || (h->device_merge < 0 && found_slots >= 2048);
+            const bool merge = h->mnv_split || h->device_merge == 1 || (h->device_merge < 0 && found_slots >= 2048);
             const size_t rec_bytes = (size_t)found_slots * (merge ? sizeof(DevMerged) : sizeof(DevFound)), pool_al = ((size_t)found_pool + 15) & ~(size_t)15;
             const size_t need = rec_bytes + pool_al + 16;
             if (need > h->found.h_cap) {
@@ -366,6 +399,20 @@ static int32_t enqueue_candidate_discovery(PiscesHip* h, const DevReadBatch& db,
                 const unsigned mgrid = (unsigned)((found_slots + 255) / 256);
                 hipLaunchKernelGGL(found_merge_kernel, dim3(mgrid), dim3(256), 0, h->stream, (const DevFound*)h->d_found.p, (int32_t)found_slots,
                                    (const uint8_t*)h->d_found_pool.p, h->d_merge_tab.p, (uint32_t)(cap - 1), h->d_merge_acc.p, h->cfg.collapse != 0 ? 1 : 0);
+                if (h->mnv_split) {
+                    // the fully anchored SNV groups stay on the device (the SNV store); everything else goes to the host as before
+                    if (!h->d_snv_n.p) {
+                        PISCES_HIP_CHECK(h, h->d_snv_n.reserve(4));
+                        PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_snv_n.p, 0, 4 * sizeof(unsigned int), h->stream));
+                    }
+                    PISCES_HIP_CHECK(h, h->d_snv[h->snv_cur].grow_keep((size_t)(h->snv_ub + found_slots), (size_t)h->snv_ub, h->stream));
+                    hipLaunchKernelGGL(found_gather_split_kernel, dim3(mgrid), dim3(256), 0, h->stream, (const DevFound*)h->d_found.p, (int32_t)found_slots,
+                                       (const int32_t*)h->d_merge_acc.p, (DevMerged*)h->found.h, h->d_found_misc.p, h->d_snv[h->snv_cur].p,
+                                       h->d_snv_n.p + h->snv_cur, (uint32_t)std::min<size_t>(h->d_snv[h->snv_cur].cap, 0xFFFFFFF0u), h->batch_seq,
+                                       h->cfg.collapse != 0 ? 1 : 0);
+                    h->snv_ub += found_slots;   // (an upper bound until the batch's counts are in: consume_found)
+                    h->found.split = true;
+                } else
                 hipLaunchKernelGGL(found_gather_kernel, dim3(mgrid), dim3(256), 0, h->stream, (const DevFound*)h->d_found.p, (int32_t)found_slots,
                                    (const int32_t*)h->d_merge_acc.p, (DevMerged*)h->found.h, h->d_found_misc.p + 2);
                 PISCES_HIP_CHECK(h, hipGetLastError());
@@ -376,7 +423,7 @@ static int32_t enqueue_candidate_discovery(PiscesHip* h, const DevReadBatch& db,
             h->found.merged = merge;
             if (found_pool > 0)
                 PISCES_HIP_CHECK(h, hipMemcpyAsync(h->found.h + rec_bytes, h->d_found_pool.p, (size_t)found_pool, hipMemcpyDeviceToHost, h->stream));
-            PISCES_HIP_CHECK(h, hipMemcpyAsync(h->found.h + rec_bytes + pool_al, h->d_found_misc.p, 3 * sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+            PISCES_HIP_CHECK(h, hipMemcpyAsync(h->found.h + rec_bytes + pool_al, h->d_found_misc.p, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
             PISCES_HIP_CHECK(h, hipEventRecord(h->found.done, h->stream));
             h->found.n_slots = found_slots;
             h->found.pool_bytes = found_pool;
@@ -403,6 +450,11 @@ static int32_t consume_found(PiscesHip* h)
         const DevMerged* groups = (const DevMerged*)h->found.h;
         const int64_t n_groups = (int64_t)misc[2];
         if (n_groups > h->found.n_slots) return fail(h, PISCES_E_DEVICE, "add_reads: the merged candidate records of the device are inconsistent");
+        if (h->found.split) {   // the plain SNV groups of the batch are in the SNV store: its size is exact again
+            if ((int64_t)misc[3] + n_groups > h->found.n_slots) return fail(h, PISCES_E_DEVICE, "add_reads: the merged candidate records of the device are inconsistent");
+            h->snv_ub -= h->found.n_slots - (int64_t)misc[3];
+            h->split_stats[0] += (int64_t)misc[3];
+        }
         h->pcie[2] += n_groups * (int64_t)sizeof(DevMerged) + h->found.pool_bytes;
         std::vector<int32_t>& order = h->found.order;
         order.assign((size_t)h->found.n_slots, -1);
@@ -414,8 +466,15 @@ static int32_t consume_found(PiscesHip* h)
         for (int64_t i = 0; i < h->found.n_slots; i++) {
             if (order[(size_t)i] < 0) continue;
             const DevMerged& m = groups[order[(size_t)i]];
+            if (m.f.c.category == kFoundSpanMark) {   // the positions of an X operation: no candidate, dirty loci of their blocks (surface_flush.inc.h)
+                for (int32_t k = block_key(h, m.f.c.position); k <= block_key(h, m.f.c.position + m.f.c.length - 1); k++)
+                    get_block(h, (k - 1) * h->cfg.block_size + 1)->x_spans.emplace_back(m.f.c.position, m.f.c.position + m.f.c.length - 1);
+                continue;
+            }
             HostCandidate c = host_candidate_of(m.f.c, h->h_ref.data(), m.f.pool_offset >= 0 ? pool + m.f.pool_offset : m.f.alt);
             for (int d = 0; d < 3; d++) { c.support_by_dir[d] = m.sup[d]; c.well_anchored_by_dir[d] = m.anch[d]; }
+            c.stamp = ((uint64_t)h->found.batch << 32) | (uint64_t)(uint32_t)i;
+            c.from_reads = true;
             add_candidate(h, c);
         }
         return PISCES_OK;
@@ -424,7 +483,10 @@ static int32_t consume_found(PiscesHip* h)
         const DevFound& f = recs[i];
         if (f.c.category == kFoundHole) continue;
         const uint8_t* bases = f.pool_offset >= 0 ? pool + f.pool_offset : f.alt;
-        add_candidate(h, host_candidate_of(f.c, h->h_ref.data(), bases));
+        HostCandidate c = host_candidate_of(f.c, h->h_ref.data(), bases);
+        c.stamp = ((uint64_t)h->found.batch << 32) | (uint64_t)(uint32_t)i;
+        c.from_reads = true;
+        add_candidate(h, c);
     }
     return PISCES_OK;
 }

@@ -242,8 +242,8 @@ def test_fragment_behind_a_gap_of_forty_thousand_positions(torch_cuda, gap_op):
         with engine.HipVariantCaller(cfg) as c:
             c.AddAlleleCounts(_abi.ReadBatch(reads))
             lo = 100 + 20 + 32700 - 5
-            got = c.GetCounts(lo, 33500)
-    np.testing.assert_array_equal(got.reshape(33500, -1), exp.reshape(66000, -1)[lo - 1:lo - 1 + 33500])
+            got = c.GetCounts(lo, 33000)
+    np.testing.assert_array_equal(got.reshape(33000, -1), exp.reshape(66000, -1)[lo - 1:lo - 1 + 33000])
     assert got.sum() > 0
     got_r, _, stats = _schedule_run([_abi.ReadBatch(reads)], ref, cfg, [None], dict(PISCES_HIP_READ_PATH=None))
     want_r, _, want_stats = _schedule_run([_abi.ReadBatch(reads)], ref, cfg, [None], dict(PISCES_HIP_READ_PATH="log"))
