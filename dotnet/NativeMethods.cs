@@ -101,6 +101,8 @@ namespace Pisces.Hip
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_set_reference(IntPtr handle, byte[] upperBases, long length);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_set_intervals(IntPtr handle, int[] starts, int[] ends, int n);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_add_reads(IntPtr handle, ref PiscesReadBatch batch);
+        /// the same for a batch whose arrays lie in device memory already (every pointer of the struct a device pointer)
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_add_device_reads(IntPtr handle, ref PiscesReadBatch deviceBatch, long nCigarOps, long nBases);
         /// the arrays of a batch inside the handle's pinned staging buffer: fill them, then pisces_hip_add_reads(views) sends them as they lie
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_stage_reads(IntPtr handle, int nReads, long nCigarOps, long nBases, int withDirections, int withDeletionDirections, ref PiscesReadBatch views);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_flush(IntPtr handle, int upToPosition, [Out] PiscesCalledAllele[] output, long capacity, out long nOut);

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define PISCES_HIP_ABI_VERSION 7
+#define PISCES_HIP_ABI_VERSION 8
 
 /* ---- error codes -------------------------------------------------------- */
 #define PISCES_OK                 0
@@ -299,6 +299,15 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch);
  * until the next call on the handle that is not pisces_hip_add_reads(views). */
 int32_t pisces_hip_stage_reads(PiscesHip* h, int32_t n_reads, int64_t n_cigar_ops, int64_t n_bases, int32_t with_directions,
                                int32_t with_deletion_directions, PiscesReadBatch* views);
+/* pisces_hip_add_reads for a batch that lies in DEVICE memory of the handle's device already: every pointer of `device_batch` is a device
+ * pointer (the struct itself is host memory), n_cigar_ops = cigar_offset[n_reads] and n_bases = seq_offset[n_reads] (which the host
+ * cannot read).  What an upstream stage on the device hands over — a decoder, an aligner, the bench's generator — and the form in which
+ * the reads -> records rate of the device is measured (inputs resident in HBM when the timed region starts).  The arrays must
+ * be complete when the call is made (synchronise the stream that made them) and are copied: the caller may reuse them when the call
+ * returns.  The checks pisces_hip_add_reads makes in a host pass over the CIGARs (Read.ValidateCigar, Read.cs:603-605; position > 0,
+ * RegionStateManager.cs:363-364; the blocks a read touches, :361-383) run on the device (read_prepare_kernel); same refusals, same
+ * messages, the state unchanged when a read is refused. */
+int32_t pisces_hip_add_device_reads(PiscesHip* h, const PiscesReadBatch* device_batch, int64_t n_cigar_ops, int64_t n_bases);
 /* Pre-expanded observations for the block grid: positions[i] is the 1-based locus of tuples[i]
  * (the tuple's locus field is ignored). */
 int32_t pisces_hip_add_observations(PiscesHip* h, const int32_t* positions, const uint32_t* tuples, int64_t n);

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # error codes
 OK = 0

@@ -355,6 +355,9 @@ struct PiscesHip {
     std::vector<hipGraphExec_t> graphs;       // pisces_hip_call_tiles_graph_build
     std::vector<hipGraph_t> graph_defs;
     int store_waves = 0;                      // development: waves per tile of call_store_tiles_kernel (PISCES_HIP_STORE_WAVES; 0 = by launch size)
+    int device_checks = -1;                   // PISCES_HIP_DEVICE_CHECKS: 1 every host batch is checked on the device (read_prepare_kernel), 0 none, -1 (default) from 65 536 reads up
+    bool prep_map_clean = false;              // the block map of read_prepare_kernel is all zero
+    DeviceBuf<uint32_t> d_prep_map;
 
     // device scratch, grow-only
     DeviceBuf<uint32_t> d_tuples;
@@ -648,6 +651,7 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         h->mnv_split = h->cfg.call_mnvs != 0 && h->device_merge != 0;
         if (const char* v = getenv("PISCES_HIP_MNV_SPLIT")) h->mnv_split = h->mnv_split && atoi(v) != 0;
         if (const char* v = getenv("PISCES_HIP_STORE_SEAL_BYTES")) h->store_seal_bytes = (size_t)std::max(0ll, atoll(v));
+        if (const char* v = getenv("PISCES_HIP_DEVICE_CHECKS")) h->device_checks = atoi(v) != 0 ? 1 : 0;
     }
     {
         // MathOperations.QtoP(q) = Math.Pow(10, -1 * q / 10f) for every integer q-score the caller can produce
@@ -745,6 +749,9 @@ int32_t pisces_hip_destroy(PiscesHip* h)
         static const char* names[12] = {"consume_found", "spanning: candidates of the batch", "spanning: counts to the host", "collapse", "device pass (MNVs)",
                                         "reallocate", "device pass (all)", "call_blocks", "row merge / genotypers", "copy out + DoneProcessing", "", ""};
         for (int i = 0; i < 10; i++) fprintf(stderr, "pisces_hip host profile: %-36s %9.3f ms\n", names[i], h->prof[i] * 1e3);
+        if (h->mnv_split)
+            fprintf(stderr, "pisces_hip split form: %lld SNV groups into the store, %lld taken by flushes (dirty loci), %lld dropped unseen, %lld sweeps\n",
+                    (long long)h->split_stats[0], (long long)h->split_stats[1], (long long)h->split_stats[2], (long long)h->split_stats[3]);
     }
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -778,6 +785,7 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     h->found.done = nullptr;
     h->d_found.release(); h->d_found_pool.release(); h->d_found_slots.release(); h->d_found_pool_first.release();
     h->d_merge_tab.release(); h->d_merge_acc.release();
+    h->d_prep_map.release();
     h->d_snv[0].release(); h->d_snv[1].release(); h->d_snv_n.release(); h->d_snv_sel.release(); h->d_dirty.release(); h->d_row_idx.release(); h->d_rows.release();
     if (h->h_snv_sel) (void)hipHostFree(h->h_snv_sel);
     h->h_snv_sel = nullptr;

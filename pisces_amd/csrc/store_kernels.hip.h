@@ -248,6 +248,155 @@ __global__ __launch_bounds__(256) void read_shape_kernel(ShapeArgs A)
     }
 }
 
+// What pisces_hip_add_reads takes from a pass over the reads' CIGARs, for a batch that is in device memory (a batch handed over there,
+// pisces_hip_add_device_reads, or a large host batch behind its upload): the argument checks of the reference's walk (Read.ValidateCigar,
+// Read.cs:603-605; RegionStateManager.cs:363-364), one bit per block a read touches (GetBlock for every position that receives a count,
+// RegionStateManager.cs:361-383: aligned runs, and gaps / terminal deletions that pass CheckDeletionQuality), and — MNV calling off —
+// the candidate-record slots of every read (one per I / D operation).  One lane per read.
+enum { kPrepPositionNotPositive = 1, kPrepMalformed = 2, kPrepCigarMismatch = 3, kPrepPastInt32 = 4, kPrepBadDeletionDirection = 5, kPrepBadDirection = 6 };
+struct PrepareArgs {
+    const int32_t* position;
+    const int32_t* cigar_offset;
+    const uint8_t* cigar_op;
+    const uint32_t* cigar_len;
+    const int32_t* seq_offset;
+    const uint8_t* quals;
+    const uint8_t* del_dirs;            // two per CIGAR operation, or nullptr
+    int32_t n_reads, min_bq, block_size, count_indels;
+    int64_t n_ops_total, n_bases_total;
+    uint32_t* block_bits;               // bit k: block key k is touched
+    int64_t n_block_bits;
+    int32_t* n_found;                   // [n_reads + 1] (count_indels): candidate records / pool bytes of every read, scanned afterwards
+    int32_t* n_pool;
+    unsigned long long* first_error;    // read index * 8 + code of the first read that is refused (atomicMin; all ones: none)
+    int32_t* key_span;                  // [0] lowest, [1] highest block key touched
+};
+// bits [a, b] of the block map; a bit that is set already (seen through a load that goes past this XCD's L2, where a stale line would
+// show zero for the rest of the launch) costs no atomic: same-address atomics from eight XCDs serialise at 0.1-0.2 us each
+__device__ __forceinline__ void set_keys(const PrepareArgs& A, int64_t a, int64_t b)
+{
+    for (int64_t k = a; k <= b; k++) {
+        if (k >= A.n_block_bits) continue;   // (cannot be: the map covers every int32 position)
+        const uint32_t bit = 1u << (k & 31);
+        uint32_t* const w = &A.block_bits[k >> 5];
+        if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(w, bit);
+    }
+}
+__device__ __forceinline__ long long prep_shfl64(long long v, int src_lane)
+{
+    const int lo = __shfl((int)(v & 0xFFFFFFFFll), src_lane, 64);
+    const int hi = __shfl((int)(v >> 32), src_lane, 64);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+__global__ __launch_bounds__(256) void read_prepare_kernel(PrepareArgs A)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    int k_lo = 0x7FFFFFFF, k_hi = 0;
+    int64_t run_a = 1, run_b = 0;   // the run of keys this read touches (empty)
+    if (r < A.n_reads) {
+        int code = 0;
+        const int64_t c0 = A.cigar_offset[r], c1 = A.cigar_offset[r + 1], s0 = A.seq_offset[r], s1 = A.seq_offset[r + 1];
+        const int32_t pos0 = A.position[r];
+        const int64_t nc = c1 - c0, n = s1 - s0;
+        int found = 0, pool = 0;
+        if (c0 < 0 || c1 < c0 || c1 > A.n_ops_total || s0 < 0 || s1 < s0 || s1 > A.n_bases_total) code = kPrepMalformed;
+        else if (pos0 <= 0) code = kPrepPositionNotPositive;
+        if (!code) {
+            const uint8_t* const quals = A.quals + s0;
+            auto delq = [&](int64_t idx) {   // CandidateVariantFinder.CheckDeletionQuality (CandidateVariantFinder.cs:294-320)
+                if (n == 0) return false;
+                const int after = idx < n ? quals[idx] : quals[idx - 1];
+                const int before = idx > 0 ? quals[idx - 1] : after;
+                return before >= A.min_bq && after >= A.min_bq;
+            };
+            // The keys a read touches are nearly always ONE run [run_a, run_b] (a read inside a block: one key); it is set behind the walk,
+            // once per wave for all lanes that hold the same run.  A read whose keys have a hole (a skip across untouched blocks) sets the
+            // run it leaves at once.
+            auto touch = [&](int64_t from, int64_t to) {   // inclusive
+                if (to < 1) return;
+                if (from < 1) from = 1;
+                const int64_t a = (from + A.block_size - 1) / A.block_size, b = (to + A.block_size - 1) / A.block_size;   // GetBlockKey
+                if (run_b < run_a) { run_a = a; run_b = b; }
+                else if (a <= run_b + 1 && b >= run_a - 1) { run_a = min(run_a, a); run_b = max(run_b, b); }
+                else { set_keys(A, run_a, run_b); run_a = a; run_b = b; }
+                k_lo = min(k_lo, (int)a);
+                k_hi = max(k_hi, (int)min(b, (int64_t)0x7FFFFFFF));
+            };
+            int64_t read_span = 0, ref_span = 0;
+            bool bad_del_dir = false;
+            for (int64_t c = 0; c < nc && !code; c++) {
+                const uint8_t t = A.cigar_op[c0 + c];
+                const uint32_t len = A.cigar_len[c0 + c];
+                if (len > 0x0FFFFFFFu) code = kPrepMalformed;   // (BAM keeps an operation's length in 28 bits)
+                if (walk_op_read_span(t)) read_span += len;
+                if (walk_op_ref_span(t)) ref_span += len;
+                if (A.del_dirs && t == 'D')
+                    for (int k = 0; k < 2; k++) {
+                        const uint8_t d = A.del_dirs[2 * (c0 + c) + k];
+                        if (d > 2 && d != PISCES_DIR_UNTRACKED) bad_del_dir = true;
+                    }
+                if (A.count_indels) {
+                    if (t == 'I' || t == 'D') found++;
+                    if (t == 'I' && len > 32u) pool += (int)len;   // (kFoundInline)
+                }
+            }
+            if (!code && nc > 0 && read_span != n) code = kPrepCigarMismatch;               // Read.ValidateCigar (Read.cs:603-605)
+            if (!code && (int64_t)pos0 + ref_span > 0x7FFFFFFFll) code = kPrepPastInt32;
+            if (!code && bad_del_dir) code = kPrepBadDeletionDirection;
+            if (!code) {
+                int64_t rp = pos0, last_mapped = (int64_t)pos0 - 1, ri = 0;
+                for (int64_t c = 0; c < nc; c++) {
+                    const uint8_t t = A.cigar_op[c0 + c];
+                    const int64_t len = A.cigar_len[c0 + c];
+                    if (walk_op_read_span(t) && walk_op_ref_span(t) && len > 0) {
+                        if (rp > last_mapped + 1 && ri < n && delq(ri)) touch(last_mapped + 1, rp - 1);
+                        touch(rp, rp + len - 1);
+                        last_mapped = rp + len - 1;
+                    }
+                    if (walk_op_ref_span(t)) rp += len;
+                    if (walk_op_read_span(t)) ri += len;
+                }
+                const bool ends_del = nc >= 1 && A.cigar_op[c0 + nc - 1] == 'D';
+                const bool ends_del_soft = nc >= 2 && A.cigar_op[c0 + nc - 2] == 'D' && A.cigar_op[c0 + nc - 1] == 'S';
+                if (ends_del && n > 0 && delq(n - 1)) touch(last_mapped + 1, last_mapped + (int64_t)A.cigar_len[c0 + nc - 1]);
+                if (ends_del_soft) {
+                    const int64_t idx = n - (int64_t)A.cigar_len[c0 + nc - 1];
+                    if (idx >= 0 && idx < n && delq(idx)) touch(last_mapped + 1, last_mapped + (int64_t)A.cigar_len[c0 + nc - 2]);
+                }
+            }
+        }
+        if (A.n_found) { A.n_found[r] = code ? 0 : found; A.n_pool[r] = code ? 0 : pool; }
+        if (code) atomicMin(A.first_error, (unsigned long long)r * 8ull + (unsigned long long)code);
+    }
+    {   // the lanes' runs, each distinct one set by one lane (reads come in position order: a wave holds one or two)
+        unsigned long long todo = __ballot(run_b >= run_a);
+        const int lane = threadIdx.x & 63;
+        while (todo) {
+            const int l0 = __builtin_ctzll(todo);
+            const long long a0 = prep_shfl64((long long)run_a, l0), b0 = prep_shfl64((long long)run_b, l0);
+            const unsigned long long same = __ballot(run_b >= run_a && run_a == a0 && run_b == b0);
+            if (lane == l0) set_keys(A, a0, b0);
+            todo &= ~same;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        k_lo = min(k_lo, __shfl_xor(k_lo, d, 64));
+        k_hi = max(k_hi, __shfl_xor(k_hi, d, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && k_hi > 0) {
+        if (k_lo < __hip_atomic_load(&A.key_span[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&A.key_span[0], k_lo);
+        if (k_hi > __hip_atomic_load(&A.key_span[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&A.key_span[1], k_hi);
+    }
+}
+// per-base directions: a value that is no DirectionType makes the batch unusable (add_reads: "CIGAR does not match the read")
+__global__ __launch_bounds__(256) void check_directions_kernel(const uint8_t* __restrict__ dirs, int64_t n, unsigned long long* __restrict__ first_error)
+{
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) bad = bad || dirs[i] > 2;
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicMin(first_error, (unsigned long long)kPrepBadDirection);
+}
+
 // small batches: their bytes join the open segment (up to five ranges in one launch; byte-wise: destinations are not aligned)
 struct CopyRanges {
     uint8_t* dst[5];

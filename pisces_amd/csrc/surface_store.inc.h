@@ -299,6 +299,148 @@ static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const Sto
     return PISCES_OK;
 }
 
+// The checks and the bookkeeping of a batch whose arrays lie on the device at d (laid out by L), made THERE (read_prepare_kernel): what
+// add_reads_store's host pass over the CIGARs makes for a batch that came from the host.  Two small waits (the verdict and the span of
+// touched blocks; then that span's bits).  found_slots / found_pool: the candidate-record slots (MNV calling off), scanned in place at
+// d + L.off_fslots.
+static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& L, int32_t nr, size_t n_cig, size_t n_seq, bool has_dirs, bool has_deldirs,
+                                   bool count_indels, int64_t* found_slots, int64_t* found_pool, std::vector<int32_t>& touched, int32_t* max_key)
+{
+    *found_slots = *found_pool = 0;
+    *max_key = 0;
+    touched.clear();
+    const int32_t bs = h->cfg.block_size;
+    const int64_t n_block_bits = (0x7FFFFFFFll + bs - 1) / bs + 2;
+    if (n_block_bits > (1ll << 27)) return fail(h, PISCES_E_UNSUPPORTED, "add_reads: a batch on the device needs a block size of 16 positions or more");
+    const size_t map_words = (size_t)((n_block_bits + 31) / 32);
+    auto& B = h->bam;   // (the block map and the first-error word of the BAM surface: the same roles)
+    PISCES_HIP_CHECK(h, h->d_prep_map.reserve(map_words + 4));
+    PISCES_HIP_CHECK(h, B.d_first_error.reserve(1));
+    PISCES_HIP_CHECK(h, B.d_totals64.reserve(8));
+    PISCES_HIP_CHECK(h, h->d_found_pool_first.reserve((size_t)nr + 1));
+    PISCES_HIP_CHECK(h, h->d_found_totals.reserve(2));
+    int32_t* const d_span = (int32_t*)(h->d_prep_map.p + map_words);   // [0] lowest, [1] highest key
+    // (the map is zero outside the span of the last batch that used it: only that span is cleared again, below; first use: all of it)
+    if (!h->prep_map_clean) {
+        PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_prep_map.p, 0, map_words * sizeof(uint32_t), h->stream));
+        h->prep_map_clean = true;
+    }
+    const int32_t span_init[2] = {0x7FFFFFFF, 0};
+    { int32_t rcu = meta_upload(h, d_span, span_init, sizeof(span_init)); if (rcu) return rcu; }
+    PISCES_HIP_CHECK(h, hipMemsetAsync(B.d_first_error.p, 0xFF, sizeof(unsigned long long), h->stream));
+    PrepareArgs A;
+    A.position = (const int32_t*)(d + L.off_pos);
+    A.cigar_offset = (const int32_t*)(d + L.off_coff);
+    A.cigar_op = d + L.off_cop;
+    A.cigar_len = (const uint32_t*)(d + L.off_clen);
+    A.seq_offset = (const int32_t*)(d + L.off_soff);
+    A.quals = d + L.off_quals;
+    A.del_dirs = has_deldirs ? d + L.off_deldirs : nullptr;
+    A.n_reads = nr; A.min_bq = h->cfg.min_base_call_quality; A.block_size = bs; A.count_indels = count_indels ? 1 : 0;
+    A.n_ops_total = (int64_t)n_cig; A.n_bases_total = (int64_t)n_seq;
+    A.block_bits = h->d_prep_map.p; A.n_block_bits = n_block_bits;
+    A.n_found = count_indels ? (int32_t*)(d + L.off_fslots) : nullptr;
+    A.n_pool = count_indels ? h->d_found_pool_first.p : nullptr;
+    A.first_error = B.d_first_error.p;
+    A.key_span = d_span;
+    if (count_indels) {
+        PISCES_HIP_CHECK(h, hipMemsetAsync(d + L.off_fslots + (size_t)nr * 4, 0, sizeof(int32_t), h->stream));
+        PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_found_pool_first.p + nr, 0, sizeof(int32_t), h->stream));
+    }
+    hipLaunchKernelGGL(read_prepare_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, h->stream, A);
+    if (has_dirs && n_seq > 0)
+        hipLaunchKernelGGL(check_directions_kernel, dim3((unsigned)std::min<size_t>((n_seq + 255) / 256, 4096)), dim3(256), 0, h->stream,
+                           (const uint8_t*)(d + L.off_dirs), (int64_t)n_seq, B.d_first_error.p);
+    if (count_indels)
+        hipLaunchKernelGGL(found_scan_kernel, dim3(1), dim3(1024), 0, h->stream, (int32_t*)(d + L.off_fslots), h->d_found_pool_first.p, nr + 1, h->d_found_totals.p);
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    unsigned long long first_error = ~0ull;
+    int32_t span[2] = {0x7FFFFFFF, 0};
+    long long totals[2] = {0, 0};
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(&first_error, B.d_first_error.p, sizeof(first_error), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(span, d_span, sizeof(span), hipMemcpyDeviceToHost, h->stream));
+    if (count_indels) PISCES_HIP_CHECK(h, hipMemcpyAsync(totals, h->d_found_totals.p, sizeof(totals), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    h->h_meta_used = 0;
+    // the touched blocks: the bits of [span[0], span[1]], which are cleared again behind the copy
+    std::vector<uint32_t> words;
+    if (span[1] >= span[0] && span[1] > 0) {
+        const size_t w0 = (size_t)span[0] >> 5, w1 = (size_t)span[1] >> 5;
+        words.resize(w1 - w0 + 1);
+        PISCES_HIP_CHECK(h, hipMemcpyAsync(words.data(), h->d_prep_map.p + w0, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_prep_map.p + w0, 0, words.size() * sizeof(uint32_t), h->stream));
+        PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+        for (size_t w = 0; w < words.size(); w++)
+            for (uint32_t bits = words[w]; bits; bits &= bits - 1) touched.push_back((int32_t)((w0 + w) * 32 + (size_t)__builtin_ctz(bits)));
+        if (!touched.empty()) *max_key = touched.back();
+    }
+    if (first_error != ~0ull) {
+        const std::string read = " (read " + std::to_string((long long)(first_error >> 3)) + " of the batch)";
+        switch ((int)(first_error & 7ull)) {
+            case kPrepPositionNotPositive: return fail(h, PISCES_E_INVALID_ARG, "Position must be greater than 0." + read);
+            case kPrepMalformed: return fail(h, PISCES_E_INVALID_ARG, "add_reads: malformed read batch" + read);
+            case kPrepPastInt32: return fail(h, PISCES_E_INVALID_ARG, "add_reads: read runs past position 2^31 - 1" + read);
+            case kPrepBadDeletionDirection: return fail(h, PISCES_E_INVALID_ARG, "add_reads: deletion_directions holds a value that is no DirectionType" + read);
+            default: return fail(h, PISCES_E_INVALID_ARG, "add_reads: CIGAR does not match the read" + ((first_error & 7ull) == kPrepBadDirection ? std::string() : read));
+        }
+    }
+    if (totals[0] > 0x7FFFFFF0ll || totals[1] > 0x7FFFFFF0ll) return fail(h, PISCES_E_INVALID_ARG, "add_reads: too many insertions / deletions in one batch");
+    *found_slots = totals[0];
+    *found_pool = totals[1];
+    return PISCES_OK;
+}
+
+// The tail of every add into the read store, once the batch's arrays lie on the device at d and its checks are in (rc_in: their verdict):
+// descriptors and fragments (read_shape_kernel), candidate discovery, and — only now — the handle's state.  fslots_host: the candidate-record
+// slots the host pass made (uploaded here), or nullptr when they were made on the device.
+static int32_t store_finish_add(PiscesHip* h, StorePlace& pl, int32_t rc, uint8_t* d, const StageLayout& L, int32_t nr, size_t n_cig, size_t n_seq, bool has_dirs,
+                                bool has_deldirs, bool find_on_device, int64_t found_slots, int64_t found_pool, const int32_t* fslots_host,
+                                const std::vector<int32_t>& touched, int32_t max_key)
+{
+    const int32_t bs = h->cfg.block_size;
+    DevReadBatch db;
+    db.position = (const int32_t*)(d + L.off_pos);
+    db.flags = d + L.off_flags;
+    db.cigar_offset = (const int32_t*)(d + L.off_coff);
+    db.cigar_op = d + L.off_cop;
+    db.cigar_len = (const uint32_t*)(d + L.off_clen);
+    db.seq_offset = (const int32_t*)(d + L.off_soff);
+    db.bases = d + L.off_bases;
+    db.quals = d + L.off_quals;
+    db.dirs = has_dirs ? d + L.off_dirs : nullptr;
+    db.n_reads = nr;
+    if (rc == PISCES_OK) {
+        const StoreBatchArrays A = {db.position, db.flags, db.cigar_offset, db.cigar_op, db.cigar_len, db.seq_offset, db.bases, db.quals, db.dirs};
+        rc = store_append_arrays(h, pl, A, nr, n_cig, n_seq);
+    }
+    // ICandidateVariantFinder.FindCandidates + IStateManager.AddCandidates (SmallVariantCaller.cs:92-96) on the device, on the batch as it lies there
+    if (rc == PISCES_OK && find_on_device && (h->cfg.call_mnvs || found_slots > 0)) {
+        if (fslots_host) {
+            std::memcpy(h->h_stage + L.off_fslots, fslots_host, ((size_t)nr + 1) * 4);
+            hipError_t e = hipMemcpyAsync(d + L.off_fslots, h->h_stage + L.off_fslots, L.total - L.off_fslots, hipMemcpyHostToDevice, h->stream);
+            if (e != hipSuccess) rc = fail(h, PISCES_E_DEVICE, std::string("add_reads: ") + hipGetErrorString(e));
+        }
+        if (rc == PISCES_OK)
+            rc = enqueue_candidate_discovery(h, db, has_deldirs ? d + L.off_deldirs : nullptr, nr, (const int32_t*)(d + L.off_fslots), found_slots, found_pool);
+    }
+    { int32_t rcs = stage_release(h); if (rc == PISCES_OK) rc = rcs; }   // (transfers out of the pinned buffer may be in flight whatever happened after them)
+    if (rc) {
+        (void)hipStreamSynchronize(h->stream);
+        store_unplace(h, pl);
+        return rc;
+    }
+    // ---- commit
+    ReadSegment& g = *pl.seg;
+    g.n_reads += nr;
+    g.n_bases += (int64_t)n_seq;
+    g.n_ops += (int64_t)n_cig;
+    g.max_key = std::max(g.max_key, max_key);
+    store_maybe_seal(h, &g);
+    for (int32_t k : touched) (void)get_block(h, (k - 1) * bs + 1);
+    h->stats[2] += nr;
+    return PISCES_OK;
+}
+
 // pisces_hip_add_reads with the read store: the batch goes across PCIe once, in one piece, and ONE host pass over the CIGARs runs while it
 // is on its way (argument checks of the reference's walk, the blocks the reads touch, the candidate-record slots); descriptors and
 // candidate discovery are made on the device.  Nothing of the handle's state changes before the whole batch has been checked.
@@ -330,17 +472,24 @@ static int32_t add_reads_store(PiscesHip* h, const PiscesReadBatch* batch)
     if (rc) { store_unplace(h, pl); return rc; }
     uint8_t* const d = pl.direct ? pl.seg->blob.p : D_STAGE(h);
     rc = store_upload_batch(h, batch, L, nr, n_cig, n_seq, staged, d);
-    // ---- the pass over the CIGARs, under the transfer
-    auto op_ref = [](uint8_t t) { return t == 'M' || t == 'D' || t == 'N' || t == '=' || t == 'X'; };
-    auto op_read = [](uint8_t t) { return t == 'M' || t == 'I' || t == 'S' || t == '=' || t == 'X'; };
     const bool find_on_device = !h->h_ref.empty();   // without a reference only the IStateManager half (allele counts) runs
     const bool count_indels = find_on_device && !h->cfg.call_mnvs;
     std::vector<int32_t>& fslots = h->found_slots_host;
-    fslots.assign((size_t)nr + 1, 0);
     std::vector<int32_t>& touched = h->touched_keys;
     touched.clear();
     int64_t found_slots = 0, found_pool = 0;
     int32_t max_key = 0;
+    // A large batch: the checks and the bookkeeping run on the device behind the upload (read_prepare_kernel) — a host pass over tens of
+    // millions of CIGARs is a second of one core, longer than the transfer it used to hide under.  (PISCES_HIP_DEVICE_CHECKS=0 / 1 forces either.)
+    const bool checked_on_device = h->device_checks == 1 || (h->device_checks < 0 && nr >= (1 << 16));
+    if (checked_on_device) {
+        if (rc == PISCES_OK) rc = store_device_checks(h, d, L, nr, n_cig, n_seq, batch->directions != nullptr, batch->deletion_directions != nullptr, count_indels,
+                                                      &found_slots, &found_pool, touched, &max_key);
+    } else {
+    // ---- the pass over the CIGARs, under the transfer
+    auto op_ref = [](uint8_t t) { return t == 'M' || t == 'D' || t == 'N' || t == '=' || t == 'X'; };
+    auto op_read = [](uint8_t t) { return t == 'M' || t == 'I' || t == 'S' || t == '=' || t == 'X'; };
+    fslots.assign((size_t)nr + 1, 0);
     const int32_t bs = h->cfg.block_size;
     int64_t in_lo = 1, in_hi = 0;   // positions of the block touched last: a read inside it needs no division
     const char* bad = nullptr;
@@ -417,46 +566,64 @@ static int32_t add_reads_store(PiscesHip* h, const PiscesReadBatch* batch)
     }
     fslots[(size_t)nr] = (int32_t)found_slots;
     if (rc == PISCES_OK && bad) rc = fail(h, PISCES_E_INVALID_ARG, bad);
-    DevReadBatch db;
-    db.position = (const int32_t*)(d + L.off_pos);
-    db.flags = d + L.off_flags;
-    db.cigar_offset = (const int32_t*)(d + L.off_coff);
-    db.cigar_op = d + L.off_cop;
-    db.cigar_len = (const uint32_t*)(d + L.off_clen);
-    db.seq_offset = (const int32_t*)(d + L.off_soff);
-    db.bases = d + L.off_bases;
-    db.quals = d + L.off_quals;
-    db.dirs = batch->directions ? d + L.off_dirs : nullptr;
-    db.n_reads = nr;
-    if (rc == PISCES_OK) {
-        const StoreBatchArrays A = {db.position, db.flags, db.cigar_offset, db.cigar_op, db.cigar_len, db.seq_offset, db.bases, db.quals, db.dirs};
-        rc = store_append_arrays(h, pl, A, nr, n_cig, n_seq);
+    }   // (the host's pass over the CIGARs)
+    return store_finish_add(h, pl, rc, d, L, nr, n_cig, n_seq, batch->directions != nullptr, batch->deletion_directions != nullptr, find_on_device, found_slots,
+                            found_pool, checked_on_device ? nullptr : fslots.data(), touched, max_key);
+}
+
+// pisces_hip_add_reads for a batch in device memory: its arrays are copied into the segment's blob (or, for a small batch, the staging
+// buffer's device half) in the layout an uploaded batch has, and everything else is add_reads_store's with the checks made on the device.
+int32_t pisces_hip_add_device_reads(PiscesHip* h, const PiscesReadBatch* batch, int64_t n_cigar_ops, int64_t n_bases)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    HostTimer timer(&h->host_time[0]);
+    if (!batch || batch->n_reads < 0 || n_cigar_ops < 0 || n_bases < 0 || n_cigar_ops > 0x7FFFFFF0ll || n_bases > 0x7FFFFFF0ll)
+        return fail(h, PISCES_E_INVALID_ARG, "add_device_reads: malformed read batch");
+    { int32_t rcp = refuse_while_batch_is_open(h, "add_device_reads"); if (rcp) return rcp; }
+    const int32_t nr = batch->n_reads;
+    if (nr == 0) return PISCES_OK;
+    if (!batch->position || !batch->flags || !batch->cigar_offset || !batch->cigar_op || !batch->cigar_len || !batch->seq_offset || !batch->bases || !batch->quals)
+        return fail(h, PISCES_E_INVALID_ARG, "add_device_reads: malformed read batch");
+    if (h->read_path != 1) return fail(h, PISCES_E_UNSUPPORTED, "add_device_reads: the observation-log chain (PISCES_HIP_READ_PATH=log) takes host batches only");
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    { int32_t rcf = consume_found(h); if (rcf) return rcf; }
+    const size_t n_cig = (size_t)n_cigar_ops, n_seq = (size_t)n_bases;
+    const bool has_dirs = batch->directions != nullptr, has_deldirs = batch->deletion_directions != nullptr;
+    const StageLayout L = stage_layout((size_t)nr, n_cig, n_seq, has_dirs, has_deldirs);
+    h->staged_total = 0;
+    StorePlace pl;
+    { int32_t rc = store_place_batch(h, 2 * n_seq + (has_dirs ? n_seq : 0) + 5 * n_cig, &pl); if (rc) return rc; }
+    int32_t rc = stage_reserve(h, pl.direct ? 64 : L.total, !pl.direct);   // (the pair's event orders the reuse of its device half; a segment's blob needs none of it)
+    if (rc == PISCES_OK && pl.direct) {
+        hipError_t e = pl.seg->blob.reserve(L.total);
+        if (e != hipSuccess) rc = fail(h, PISCES_E_DEVICE, std::string("add_device_reads: ") + hipGetErrorString(e));
     }
-    // ICandidateVariantFinder.FindCandidates + IStateManager.AddCandidates (SmallVariantCaller.cs:92-96) on the device, on the batch as it was uploaded
-    if (rc == PISCES_OK && find_on_device && (h->cfg.call_mnvs || found_slots > 0)) {
-        std::memcpy(h->h_stage + L.off_fslots, fslots.data(), ((size_t)nr + 1) * 4);
-        hipError_t e = hipMemcpyAsync(d + L.off_fslots, h->h_stage + L.off_fslots, L.total - L.off_fslots, hipMemcpyHostToDevice, h->stream);
-        if (e != hipSuccess) rc = fail(h, PISCES_E_DEVICE, std::string("add_reads: ") + hipGetErrorString(e));
-        if (rc == PISCES_OK)
-            rc = enqueue_candidate_discovery(h, db, batch->deletion_directions ? d + L.off_deldirs : nullptr, nr, (const int32_t*)(d + L.off_fslots), found_slots,
-                                             found_pool);
-    }
-    { int32_t rcs = stage_release(h); if (rc == PISCES_OK) rc = rcs; }   // (transfers out of the pinned buffer may be in flight whatever happened after them)
-    if (rc) {
-        (void)hipStreamSynchronize(h->stream);
-        store_unplace(h, pl);
-        return rc;
-    }
-    // ---- commit
-    ReadSegment& g = *pl.seg;
-    g.n_reads += nr;
-    g.n_bases += (int64_t)n_seq;
-    g.n_ops += (int64_t)n_cig;
-    g.max_key = std::max(g.max_key, max_key);
-    store_maybe_seal(h, &g);
-    for (int32_t k : touched) (void)get_block(h, (k - 1) * bs + 1);
-    h->stats[2] += nr;
-    return PISCES_OK;
+    if (rc) { store_unplace(h, pl); return rc; }
+    uint8_t* const d = pl.direct ? pl.seg->blob.p : D_STAGE(h);
+    auto d2d = [&](size_t off, const void* src, size_t bytes) -> hipError_t {
+        return bytes ? hipMemcpyAsync(d + off, src, bytes, hipMemcpyDeviceToDevice, h->stream) : hipSuccess;
+    };
+    hipError_t e = d2d(L.off_pos, batch->position, (size_t)nr * 4);
+    if (e == hipSuccess) e = d2d(L.off_flags, batch->flags, (size_t)nr);
+    if (e == hipSuccess) e = d2d(L.off_coff, batch->cigar_offset, ((size_t)nr + 1) * 4);
+    if (e == hipSuccess) e = d2d(L.off_cop, batch->cigar_op, n_cig);
+    if (e == hipSuccess) e = d2d(L.off_clen, batch->cigar_len, n_cig * 4);
+    if (e == hipSuccess) e = d2d(L.off_soff, batch->seq_offset, ((size_t)nr + 1) * 4);
+    if (e == hipSuccess) e = d2d(L.off_bases, batch->bases, n_seq);
+    if (e == hipSuccess) e = d2d(L.off_quals, batch->quals, n_seq);
+    if (e == hipSuccess && has_dirs) e = d2d(L.off_dirs, batch->directions, n_seq);
+    if (e == hipSuccess && has_deldirs) e = d2d(L.off_deldirs, batch->deletion_directions, 2 * n_cig);
+    if (e != hipSuccess) rc = fail(h, PISCES_E_DEVICE, std::string("add_device_reads: ") + hipGetErrorString(e));
+    const bool find_on_device = !h->h_ref.empty();
+    const bool count_indels = find_on_device && !h->cfg.call_mnvs;
+    std::vector<int32_t>& touched = h->touched_keys;
+    touched.clear();
+    int64_t found_slots = 0, found_pool = 0;
+    int32_t max_key = 0;
+    if (rc == PISCES_OK) rc = store_device_checks(h, d, L, nr, n_cig, n_seq, has_dirs, has_deldirs, count_indels, &found_slots, &found_pool, touched, &max_key);
+    return store_finish_add(h, pl, rc, d, L, nr, n_cig, n_seq, has_dirs, has_deldirs, find_on_device, found_slots, found_pool, nullptr, touched, max_key);
+    });
 }
 
 // pisces_hip_add_decoded_reads with the read store: a large decoded batch becomes a segment as it lies (its arrays change owner: the

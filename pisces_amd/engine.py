@@ -20,6 +20,41 @@ def _check(handle, rc):
         raise PiscesHipError(rc, msg.decode() if msg else "")
 
 
+class DeviceReadBatch:
+    """A PiscesReadBatch whose arrays are torch tensors in device memory (what pisces_hip_add_device_reads takes): position / cigar_offset /
+    seq_offset int32, flags / cigar_op / bases / quals (/ directions / deletion_directions) uint8, cigar_len int32 holding the uint32 bits."""
+
+    def __init__(self, position, flags, cigar_offset, cigar_op, cigar_len, seq_offset, bases, quals, directions=None, deletion_directions=None,
+                 n_ops=None, n_bases=None):
+        import torch
+        self.torch = torch
+        self.tensors = dict(position=position, flags=flags, cigar_offset=cigar_offset, cigar_op=cigar_op, cigar_len=cigar_len, seq_offset=seq_offset,
+                            bases=bases, quals=quals, directions=directions, deletion_directions=deletion_directions)
+        for k, t in self.tensors.items():
+            assert t is None or (t.is_cuda and t.is_contiguous()), k
+        self.n_reads = int(position.numel())
+        self.n_ops = int(cigar_op.numel()) if n_ops is None else int(n_ops)
+        self.n_bases = int(bases.numel()) if n_bases is None else int(n_bases)
+        c = _abi.PiscesReadBatch()
+        c.n_reads = self.n_reads
+        for k, t in self.tensors.items():
+            setattr(c, k, C.cast(C.c_void_p(t.data_ptr() if t is not None else 0), type(getattr(c, k))))
+        self.c = c
+
+    @classmethod
+    def from_host(cls, batch, device="cuda:0"):
+        import torch
+        up = lambda a, dt=None: None if a is None else torch.from_numpy(np.ascontiguousarray(a if dt is None else a.view(dt))).to(device)
+        # (an empty tensor has no storage to point at: one spare element keeps every pointer valid)
+        pad = lambda t: t if t is None or t.numel() else torch.zeros(1, dtype=t.dtype, device=device)
+        return cls(pad(up(batch.position)), pad(up(batch.flags)), pad(up(batch.cigar_offset)), pad(up(batch.cigar_op)), pad(up(batch.cigar_len, np.int32)),
+                   pad(up(batch.seq_offset)), pad(up(batch.bases)), pad(up(batch.quals)), pad(up(batch.directions)),
+                   pad(up(getattr(batch, "deletion_directions", None))), n_ops=len(batch.cigar_op), n_bases=len(batch.bases))
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.tensors["position"].device)
+
+
 class HipVariantCaller:
     def __init__(self, config=None, device=0):
         self.config = config if config is not None else _abi.default_config()
@@ -78,6 +113,14 @@ class HipVariantCaller:
         """IStateManager.AddAlleleCounts for a batch (one _abi.ReadBatch, or an iterable of read dicts)."""
         batch = reads if isinstance(reads, _abi.ReadBatch) else _abi.ReadBatch(reads)
         _check(self._h, lib.pisces_hip_add_reads(self._h, C.byref(batch.c)))
+
+    def AddDeviceReads(self, reads):
+        """pisces_hip_add_device_reads: IStateManager.AddAlleleCounts for a batch that lies in device memory.  `reads`: a DeviceReadBatch
+        (torch tensors on the handle's device), or an _abi.ReadBatch whose arrays are copied there first (test plumbing)."""
+        b = reads if isinstance(reads, DeviceReadBatch) else DeviceReadBatch.from_host(reads if isinstance(reads, _abi.ReadBatch) else _abi.ReadBatch(reads),
+                                                                                       f"cuda:{self.device}")
+        b.synchronize()
+        _check(self._h, lib.pisces_hip_add_device_reads(self._h, C.byref(b.c), b.n_ops, b.n_bases))
 
     def StageReads(self, reads):
         """pisces_hip_stage_reads: the arrays of `reads` (an _abi.ReadBatch) written into the handle's pinned staging buffer, as a host

@@ -400,3 +400,79 @@ def test_config5_depth_through_the_read_store_equals_log_chain_and_oracle(torch_
     head = synth.reads_of(p, 7, first_amplicon=0)
     exp, _ = orc.run_reads(head, ref, p.region_start, 1000, cfg)
     assert got[got["position"] < p.region_start + 1000].tobytes() == exp.tobytes()
+
+
+# ---- reads handed over in device memory (pisces_hip_add_device_reads) and the checks of a batch made on the device ----------------------
+@pytest.mark.parametrize("call_mnvs", [0, 1], ids=["snv_indel", "mnv"])
+@pytest.mark.parametrize("mode", ["default", "every batch appended to the open segment"])
+def test_reads_handed_over_in_device_memory(torch_cuda, mode, call_mnvs):
+    """pisces_hip_add_device_reads == pisces_hip_add_reads: the same reads (arbitrary CIGARs, per-base directions, N bases, low qualities),
+    in three batches with a flush between them, once from host arrays and once from tensors in device memory — the records, the allele
+    strings and the totals are the same bytes; so are they when a host batch is checked on the device (PISCES_HIP_DEVICE_CHECKS=1:
+    read_prepare_kernel instead of the host's pass over the CIGARs)."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(91 + call_mnvs)
+    ref = np.frombuffer(bytes(rng.choice(list(b"ACGT"), 4600).astype(np.uint8)), dtype=np.uint8)
+    reads = random_reads(rng, 1800, 30, 4100, exotic=False)
+    for r in reads[::3]:   # reads that look like their reference (with a few mismatches), so that calls are made
+        ln = len(r["seq"])
+        if r["cigar"] == [("M", ln)]:
+            seq = bytearray(ref[r["pos"] - 1:r["pos"] - 1 + ln].tobytes())
+            for k in range(ln):
+                if rng.random() < 0.02:
+                    seq[k] = int(rng.choice(list(b"ACGT")))
+            r["seq"] = bytes(seq)
+    cfg = _abi.default_config(min_coverage=1, low_depth_filter=1, call_mnvs=call_mnvs)
+    cuts = [0, 700, 1300, len(reads)]
+    ups = [reads[699]["pos"] - 1, reads[1299]["pos"] - 1, None]
+
+    def run(how, environ):
+        recs, alleles = [], []
+        with env(PISCES_HIP_READ_PATH=None, **environ):
+            with engine.HipVariantCaller(cfg) as c:
+                c.SetReference(ref)
+                for k, up in enumerate(ups):
+                    batch = _abi.ReadBatch(reads[cuts[k]:cuts[k + 1]])
+                    (c.AddDeviceReads if how == "device" else c.AddAlleleCounts)(batch)
+                    r, a = c.CallWithAlleles(up, capacity=1 << 15)
+                    recs.append(r)
+                    alleles += a
+                stats = c.Stats()
+        return np.concatenate(recs), alleles, stats
+    want = run("host", dict(PISCES_HIP_DEVICE_CHECKS=0, **STORE_MODES[mode]))
+    assert len(want[0]) > 3000
+    for how, environ in (("device", STORE_MODES[mode]), ("host", dict(PISCES_HIP_DEVICE_CHECKS=1, **STORE_MODES[mode]))):
+        got = run(how, environ)
+        assert got[0].tobytes() == want[0].tobytes() and got[1] == want[1] and got[2] == want[2], (how, environ)
+
+
+def test_checks_on_the_device_refuse_what_the_host_pass_refuses(torch_cuda):
+    """A batch in device memory (and a host batch with PISCES_HIP_DEVICE_CHECKS=1) is refused as a whole for the reasons the host's pass over
+    the CIGARs refuses one — position <= 0 (RegionStateManager.cs:363-364), a CIGAR that does not span the read (Read.ValidateCigar,
+    Read.cs:603-605), a read past 2^31 - 1, a per-base direction or a deletion direction that is no DirectionType — with the same code and
+    message, the state untouched; the reads in front of the bad one included."""
+    from pisces_amd import engine
+    good = {"pos": 20, "seq": "ACGTACGT", "cigar": [("M", 8)], "quals": [30] * 8, "reverse": False}
+    bads = (({"pos": 0, "seq": "ACGT", "cigar": [("M", 4)], "quals": [30] * 4, "reverse": False}, "greater than 0"),
+            ({"pos": 9, "seq": "ACGT", "cigar": [("M", 3), ("I", 4)], "quals": [30] * 4, "reverse": False}, "CIGAR does not match"),
+            ({"pos": 9, "seq": "ACGT", "cigar": [("M", 2)], "quals": [30] * 4, "reverse": False}, "CIGAR does not match"),
+            ({"pos": 2 ** 31 - 3, "seq": "ACGT", "cigar": [("M", 4)], "quals": [30] * 4, "reverse": False}, "2^31"),
+            ({"pos": 9, "seq": "ACGT", "cigar": [("M", 4)], "quals": [30] * 4, "reverse": False, "dirs": [0, 1, 3, 0]}, "CIGAR does not match"),
+            ({"pos": 9, "seq": "ACGT", "cigar": [("M", 2), ("D", 2), ("M", 2)], "quals": [30] * 4, "reverse": False, "del_dirs": [(255, 255), (7, 0), (255, 255)]},
+             "deletion_directions"))
+    for how in ("device", "host checked on the device"):
+        with env(PISCES_HIP_READ_PATH=None, PISCES_HIP_DEVICE_CHECKS=1):
+            with engine.HipVariantCaller() as c:
+                add = c.AddDeviceReads if how == "device" else c.AddAlleleCounts
+                for bad, needle in bads:
+                    before = c.Stats()
+                    with pytest.raises(engine.PiscesHipError) as e:
+                        add(_abi.ReadBatch([good, bad]))
+                    assert e.value.code == _abi.E_INVALID_ARG and needle in e.value.message, (how, needle, e.value.message)
+                    assert c.Stats() == before and c.GetCounts(20, 8).sum() == 0
+                add(_abi.ReadBatch([good]))
+                assert c.GetCounts(20, 8).sum() == 8 and c.Stats()["reads"] == 1
+                # two terminal cases of the block bookkeeping: a read across a block edge, and one far away
+                add(_abi.ReadBatch([{"pos": 996, "seq": "ACGTACGT", "cigar": [("M", 8)], "quals": [30] * 8, "reverse": True},
+                                    {"pos": 5_000_001, "seq": "ACGT", "cigar": [("M", 4)], "quals": [30] * 4, "reverse": False}]))
+                assert c.GetCounts(996, 8).sum() == 8 and c.GetCounts(5_000_001, 4).sum() == 4 and c.Stats()["reads"] == 3
