@@ -50,6 +50,10 @@ struct DeviceParams {
     // record only and the variants come from the candidate kernel.  Bit (position - dirty_first) of dirty_bits; nullptr: no locus is dirty.
     const uint32_t* dirty_bits;
     int32_t dirty_first, dirty_n;
+    // The folded counts int32[position - folded_first][6][3] of every locus the launch walks (anchor bins added up, low-quality bases
+    // under N: what the call phase itself reads), for the candidate kernel of the same flush; nullptr: not wanted.
+    int32_t* folded_out;
+    int32_t folded_first, folded_n;
 };
 
 __device__ __forceinline__ bool locus_is_dirty(const DeviceParams& P, int pos)

@@ -475,15 +475,20 @@ __global__ __launch_bounds__(256) void snv_store_sweep_kernel(const SnvGroup* __
 
 // rows[k][198] = counts[idx[k]][198] (a negative index: zeros): the anchor-resolved counts of the few loci the collapser's frequencies and
 // the reallocator's Reference candidates read on the host (the tensor itself stays on the device)
-__global__ __launch_bounds__(256) void gather_count_rows_kernel(const int32_t* __restrict__ counts, const long long* __restrict__ idx, int32_t n_rows,
-                                                                int32_t* __restrict__ rows)
+// (an index <= -2 names a locus of the FOLDED counts, kernels.hip.h CountsView: its 18 sums go to the well-anchored bin of their cells —
+// whoever reads such a row adds up all bins of a cell)
+__global__ __launch_bounds__(256) void gather_count_rows_kernel(const int32_t* __restrict__ counts, const int32_t* __restrict__ folded,
+                                                                const long long* __restrict__ idx, int32_t n_rows, int32_t* __restrict__ rows)
 {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t k = g / PISCES_COUNTS_PER_LOCUS;
     if (k >= n_rows) return;
     const int c = (int)(g - k * PISCES_COUNTS_PER_LOCUS);
     const long long li = idx[k];
-    rows[g] = li >= 0 ? counts[li * PISCES_COUNTS_PER_LOCUS + c] : 0;
+    int v = 0;
+    if (li >= 0) v = counts[li * PISCES_COUNTS_PER_LOCUS + c];
+    else if (li <= -2 && folded && c % PISCES_NUM_ANCHORS == PISCES_ANCHOR_SIZE) v = folded[(-(li + 2)) * PISCES_FOLDED_PER_LOCUS + c / PISCES_NUM_ANCHORS];
+    rows[g] = v;
 }
 
 }  // namespace pisces

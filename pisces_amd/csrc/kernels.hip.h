@@ -714,6 +714,16 @@ __device__ __forceinline__ void call_phase_wave(const int* hist, const uint8_t* 
     const bool dirty = locus_is_dirty(P, pos);   // (one dword per 32 loci, requested before the counts are read)
     const LocusCounts lc = load_counts_wave<H>(hist, l);
     const bool ref_wave = wid == 0, var_wave = wid == NW - 1;
+    if (P.folded_out && ref_wave && l < tile.n_loci) {   // the locus' 18 counts for the candidate kernel of this flush
+        const unsigned rel = (unsigned)(pos - P.folded_first);
+        if (rel < (unsigned)P.folded_n) {
+            int32_t* const dst = P.folded_out + (size_t)rel * PISCES_FOLDED_PER_LOCUS;
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int d = 0; d < 3; d++) dst[a * 3 + d] = lc.h[a][d];
+        }
+    }
 
     // One allele through the table-first forms; false = a table missed (the record is not made).  With the handle's tables in place
     // (always, for the configurations routed here) every entry the allele can need is requested up front: one round trip.
@@ -1205,11 +1215,24 @@ __host__ __device__ inline int anchor_adjusted_count(const int32_t* __restrict__
     return anchor_adjusted<int32_t, int>(row, minAnchor, maxAnchor, fromEnd);
 }
 
-__host__ __device__ inline int get_allele_count(const int32_t* __restrict__ counts, int64_t idx, int allele, int dir, int minAnchor,
+// Where a candidate's counts come from: the anchor-resolved tensor int32[locus][6][3][11] (accumulate_store_tiles_kernel), or — for
+// point alleles, MNVs and deletions, which add up all eleven anchor bins of a cell anyway (only an insertion's coverage looks at the bins,
+// CoverageCalculator.cs:179-259) — the FOLDED counts int32[locus][6][3] that the flush's tile kernel leaves behind for every locus it
+// walks (DeviceParams::folded_out): no second walk over the reads for them.  A locus index >= 0 is the tensor's, -1 is "no block"
+// (RegionStateManager.GetAlleleCount -> 0, RegionStateManager.cs:222-226), <= -2 is the folded array's, kept as -(index + 2).
+struct CountsView {
+    const int32_t* tensor;
+    const int32_t* folded;
+    __host__ __device__ CountsView(const int32_t* t, const int32_t* f = nullptr) : tensor(t), folded(f) {}
+};
+__host__ __device__ inline int64_t folded_locus(int64_t index) { return -(index + 2); }
+
+__host__ __device__ inline int get_allele_count(const CountsView counts, int64_t idx, int allele, int dir, int minAnchor,
                                        int maxAnchor, bool fromEnd)
 {
-    if (idx < 0) return 0;   // RegionStateManager.GetAlleleCount: no block -> 0 (RegionStateManager.cs:222-226)
-    return anchor_adjusted_count(counts + idx * PISCES_COUNTS_PER_LOCUS + (allele * 3 + dir) * PISCES_NUM_ANCHORS, minAnchor,
+    if (idx == -1) return 0;   // RegionStateManager.GetAlleleCount: no block -> 0 (RegionStateManager.cs:222-226)
+    if (idx < -1) return counts.folded ? counts.folded[folded_locus(idx) * PISCES_FOLDED_PER_LOCUS + allele * 3 + dir] : 0;   // (all anchors: minAnchor 0, no maxAnchor)
+    return anchor_adjusted_count(counts.tensor + idx * PISCES_COUNTS_PER_LOCUS + (allele * 3 + dir) * PISCES_NUM_ANCHORS, minAnchor,
                                  maxAnchor, fromEnd);
 }
 
@@ -1253,7 +1276,7 @@ __device__ inline int rmxn_length_for_indel(int variantPosition, const uint8_t* 
 // anchor-resolved counts tensor: coverage by direction, total coverage.  Host and device: the host-side collapser needs the
 // same number (CandidateAllele.Frequency) the device call uses.
 struct SpanningCoverage { int cov[3]; int total; };
-__host__ __device__ inline SpanningCoverage spanning_coverage(const DevCandidate& c, const int32_t* __restrict__ counts, int32_t expect_stitched,
+__host__ __device__ inline SpanningCoverage spanning_coverage(const DevCandidate& c, const CountsView counts, int32_t expect_stitched,
                                                              const double* __restrict__ sumq = nullptr, double* sum_of_base_quality = nullptr)
 {
     const int length = c.category == PISCES_CAT_INSERTION ? c.alt_len - 1 : c.category == PISCES_CAT_DELETION ? c.ref_len - 1 : c.alt_len;   // BaseAllele.Length
@@ -1339,7 +1362,7 @@ __host__ __device__ inline SpanningCoverage spanning_coverage(const DevCandidate
 
 // TotalCoverage of a candidate of any category against the counts tensor (the collapser's frequencies, CandidateAllele -> CalledAllele
 // -> CoverageCalculator.Compute): point alleles sum the five coverage-contributing allele types over directions and anchors.
-__host__ __device__ inline int candidate_total_coverage(const DevCandidate& c, const int32_t* __restrict__ counts, int32_t expect_stitched)
+__host__ __device__ inline int candidate_total_coverage(const DevCandidate& c, const CountsView counts, int32_t expect_stitched)
 {
     if (c.category == PISCES_CAT_SNV || c.category == PISCES_CAT_REFERENCE) {
         const int cca[5] = {PISCES_ALLELE_A, PISCES_ALLELE_C, PISCES_ALLELE_G, PISCES_ALLELE_T, PISCES_ALLELE_DEL};
@@ -1355,14 +1378,15 @@ __host__ __device__ inline int candidate_total_coverage(const DevCandidate& c, c
 // calling on also the SNV and MNV candidates of the read walk and the Reference alleles that MNV reallocation touched
 // (AlleleCaller.cs:60-141).  Point alleles (SNV, Reference) go through the tile kernels' own process_point_allele.
 __global__ __launch_bounds__(64) void call_spanning_kernel(
-    const DevCandidate* __restrict__ cands, int32_t n, const int32_t* __restrict__ counts, const uint8_t* __restrict__ alleles,
+    const DevCandidate* __restrict__ cands, int32_t n, const int32_t* __restrict__ counts_tensor, const uint8_t* __restrict__ alleles,
     const uint8_t* __restrict__ ref, int64_t ref_len /* ref[i] = position i+1 */, int32_t expect_stitched,
     PiscesCalledAllele* __restrict__ out, uint8_t* __restrict__ callable_out, DeviceParams P,
-    const double* __restrict__ sumq = nullptr /* NoiseModel.Window */)
+    const double* __restrict__ sumq = nullptr /* NoiseModel.Window */, const int32_t* __restrict__ counts_folded = nullptr)
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     const DevCandidate c = cands[i];
+    const CountsView counts(counts_tensor, counts_folded);
     if (c.category == PISCES_CAT_SNV || c.category == PISCES_CAT_REFERENCE) {
         // CalculateSinglePoint :49-98 over the anchor-resolved counts; AlleleSupport is the candidate's (AlleleHelper.Map)
         const bool isRef = c.category == PISCES_CAT_REFERENCE;

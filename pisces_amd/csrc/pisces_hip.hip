@@ -307,6 +307,9 @@ struct PiscesHip {
     DeviceBuf<uint32_t> d_dirty;
     std::vector<uint32_t> dirty_host;
     uint32_t batch_seq = 0, host_seq = 0;     // arrival stamps: (batch_seq << 32) | record index, host-side additions behind the batch's records
+    DeviceBuf<int32_t> d_folded;              // the folded counts the flush's tile kernel leaves for the candidate kernel (DeviceParams::folded_out)
+    struct { bool valid = false; int32_t lo = 0, hi = 0; } fold;   // the positions d_folded holds (the tile kernels of this flush went first)
+    DeviceBuf<PiscesTile> d_span_tiles;       // the 64-locus tiles whose anchor-resolved counts the candidate kernel reads (call_spanning)
     DeviceBuf<long long> d_row_idx;           // gather_count_rows_kernel
     DeviceBuf<int32_t> d_rows;
     std::unordered_map<int64_t, int32_t> row_of_locus;
@@ -515,6 +518,8 @@ static DeviceParams make_params(const PiscesHipConfig& c)
     P.vq_tab_k = P.sb_tab_k = P.tab_cov = 0;
     P.dirty_bits = nullptr;
     P.dirty_first = P.dirty_n = 0;
+    P.folded_out = nullptr;
+    P.folded_first = P.folded_n = 0;
     return P;
 }
 
@@ -785,7 +790,7 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     h->found.done = nullptr;
     h->d_found.release(); h->d_found_pool.release(); h->d_found_slots.release(); h->d_found_pool_first.release();
     h->d_merge_tab.release(); h->d_merge_acc.release();
-    h->d_prep_map.release();
+    h->d_prep_map.release(); h->d_folded.release(); h->d_span_tiles.release();
     h->d_snv[0].release(); h->d_snv[1].release(); h->d_snv_n.release(); h->d_snv_sel.release(); h->d_dirty.release(); h->d_row_idx.release(); h->d_rows.release();
     if (h->h_snv_sel) (void)hipHostFree(h->h_snv_sel);
     h->h_snv_sel = nullptr;

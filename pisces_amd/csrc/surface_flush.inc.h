@@ -236,9 +236,12 @@ struct CallBlocksInFlight {
     size_t spec = 0;
 };
 // hole_bound >= 0 (asynchronous flush): the compacted log is made hole_bound slots long (see enqueue_drop)
-static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& keys, bool with_drop, int64_t hole_bound, CallBlocksInFlight* st)
+// with_folded: the launch — when it is the fused kernel over a run of whole blocks — also leaves the folded counts of every locus it walks
+// in h->d_folded (h->fold says which positions), for the candidate kernel of the same flush
+static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& keys, bool with_drop, int64_t hole_bound, CallBlocksInFlight* st, bool with_folded = false)
 {
     *st = CallBlocksInFlight();
+    h->fold.valid = false;
     h->pending_view = nullptr;
     h->pending_view_n = 0;
     if (keys.empty()) return PISCES_OK;
@@ -290,8 +293,20 @@ static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& key
             e1 = h->ring[2 * slot + 1];
             h->ring_used++;
         }
-        PISCES_HIP_CHECK(h, launch_call_store_tiles(h, h->stream, regular ? nullptr : h->d_tuples.p, regular ? nullptr : h->d_tiles.p, R, n_tiles, h->d_ref.p, 1,
-                                                    h->ref_len, h->d_records.p, h->d_tile_results.p, e0, e1));
+        if (with_folded && regular) {
+            PISCES_HIP_CHECK(h, h->d_folded.reserve((size_t)n_loci_total * PISCES_FOLDED_PER_LOCUS));
+            h->P.folded_out = h->d_folded.p;
+            h->P.folded_first = (keys.front() - 1) * bs + 1;
+            h->P.folded_n = (int32_t)n_loci_total;
+            h->fold.valid = true;
+            h->fold.lo = h->P.folded_first;
+            h->fold.hi = h->P.folded_first + (int32_t)n_loci_total - 1;
+        }
+        const hipError_t el = launch_call_store_tiles(h, h->stream, regular ? nullptr : h->d_tuples.p, regular ? nullptr : h->d_tiles.p, R, n_tiles, h->d_ref.p, 1,
+                                                      h->ref_len, h->d_records.p, h->d_tile_results.p, e0, e1);
+        h->P.folded_out = nullptr;
+        h->P.folded_first = h->P.folded_n = 0;
+        PISCES_HIP_CHECK(h, el);
     } else if (!use_counts && !window && !store) {
         PISCES_HIP_CHECK(h, launch_call_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p,
                                               h->d_tile_results.p));
@@ -358,6 +373,19 @@ static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& key
     st->spec = spec;
     return PISCES_OK;
 }
+// Does a flush of `keys` go through the fused kernel over a run of whole blocks (call_blocks_enqueue's `fused && regular`)?  Then its
+// launch can go first and leave the folded counts for the candidate kernel.
+static bool fused_regular_applies(PiscesHip* h, const std::vector<int32_t>& keys)
+{
+    if (keys.empty() || !h->d_ref.p || h->cfg.noise_model == PISCES_NOISE_WINDOW || h->read_path != 1 || h->log_ub != 0 || !h->intervals.empty()) return false;
+    if (!(h->kernel_variant >= 2 && h->cfg.strand_bias_model != PISCES_SB_DIPLOID && h->cfg.min_base_call_quality <= 127)) return false;
+    for (auto& kv : h->gapped_mnv_ref)
+        if (std::binary_search(keys.begin(), keys.end(), block_key(h, kv.first))) return false;
+    const int tiles_per_block = (h->cfg.block_size + kTile - 1) / kTile;
+    return (int64_t)keys.back() - keys.front() + 1 == (int64_t)keys.size() && (int64_t)keys.size() * tiles_per_block < 0x7FFFFF00ll / kSlotsPerTile &&
+           (int64_t)keys.size() * h->cfg.block_size < (0x7FFFFF00ll / PISCES_FOLDED_PER_LOCUS);
+}
+
 // (after the wait) total: the records; they lie in st.hrec, all of them
 static int32_t call_blocks_finish(PiscesHip* h, const CallBlocksInFlight& st, int32_t* total, int64_t* n_called, unsigned long long* kept)
 {
@@ -868,9 +896,12 @@ static int32_t split_prepare(PiscesHip* h, const std::vector<int32_t>& keys, int
 // reference support taken by gapped MNVs is registered (it reaches the Reference records through call_blocks, which runs after
 // this), and every callable allele is processed again.  ref_overrides: Reference alleles that reallocation added support to
 // (they replace the tile kernels' Reference record of that position).
+// blocks_first: the tile kernels of this flush are enqueued already (their Reference records do not know the reference support that
+// gapped MNVs of THIS batch take: the Reference alleles of those positions come from here, as overrides), and h->fold says where their
+// folded counts lie.
 static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int32_t up_to_position, std::vector<PiscesCalledAllele>& recs,
                              std::vector<HostCandidate>& called, int64_t* n_called, int64_t* n_collapsed,
-                             std::vector<PiscesCalledAllele>& ref_overrides)
+                             std::vector<PiscesCalledAllele>& ref_overrides, bool blocks_first = false)
 {
     recs.clear();
     called.clear();
@@ -934,41 +965,86 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         else if (c.category == PISCES_CAT_INSERTION) { sp = c.position; ep = c.position + 1; }
         else { sp = c.position; ep = c.position; }
     };
-    std::vector<int32_t> bkeys;
+    // ---- where the candidates' counts come from (kernels.hip.h CountsView).  Point alleles, MNVs and deletions add up all anchor bins of a
+    // cell: when the flush's tile kernel has run over these blocks already it left exactly those sums for every locus (h->fold), and no
+    // second walk over the reads is needed for them.  What is left — insertions (their coverage looks at the bins), loci outside that
+    // launch (an allele that ends in a held block), or everything when the tile kernels come later — is accumulated into the tensor, for
+    // the 64-locus tiles those loci lie in only (the read store; with an observation log: the whole blocks, bucketed as they always were).
+    const bool have_forced = !h->forced.empty();
+    const bool fold_ok = blocks_first && h->fold.valid;
+    auto in_fold = [&](int32_t p) { return fold_ok && p >= h->fold.lo && p <= h->fold.hi; };
+    const bool sparse_tiles = h->read_path == 1 && h->log_ub == 0;
+    const int tiles_per_block = (bs + kTile - 1) / kTile;
+    auto tile_start_of = [&](int32_t p) { const int32_t b0 = (block_key(h, p) - 1) * bs + 1; return b0 + ((p - b0) / kTile) * kTile; };
+    std::vector<int32_t> need_pos;   // positions whose counts must be in the tensor
+    auto need = [&](int32_t p, bool may_fold) {
+        if (p > 0 && !(may_fold && in_fold(p)) && h->blocks.count(block_key(h, p))) need_pos.push_back(p);
+    };
     for (auto& c : work) {
         int32_t sp, ep;
         endpoints(c, sp, ep);
-        for (int32_t p : {sp, ep}) {
-            const int32_t k = block_key(h, p);
-            if (p > 0 && h->blocks.count(k)) bkeys.push_back(k);
+        const bool may_fold = c.category != PISCES_CAT_INSERTION;
+        if (c.category == PISCES_CAT_MNV) { for (int32_t p = sp; p <= ep; p++) need(p, true); }   // (and what reallocation makes of it: SNVs, Reference alleles)
+        else { need(sp, may_fold); need(ep, may_fold); }
+    }
+    if (have_forced)
+        for (int32_t p : h->forced_positions)
+            if (std::binary_search(keys.begin(), keys.end(), block_key(h, p))) need(p, true);
+    phase(2);
+    std::vector<PiscesTile> tiles;
+    std::vector<int32_t> bkeys, tile_starts;
+    if (sparse_tiles) {
+        for (int32_t p : need_pos) tile_starts.push_back(tile_start_of(p));
+        std::sort(tile_starts.begin(), tile_starts.end());
+        tile_starts.erase(std::unique(tile_starts.begin(), tile_starts.end()), tile_starts.end());
+        for (int32_t ts : tile_starts) {
+            PiscesTile t;
+            t.start_position = ts;
+            t.n_loci = std::min<int32_t>(kTile, block_key(h, ts) * bs - ts + 1);
+            t.tuple_begin = t.tuple_end = 0;
+            tiles.push_back(t);
+        }
+        if (!tiles.empty()) {
+            PISCES_HIP_CHECK(h, h->d_span_tiles.reserve(tiles.size()));
+            { int32_t rcu = meta_upload(h, h->d_span_tiles.p, tiles.data(), tiles.size() * sizeof(PiscesTile)); if (rcu) return rcu; }
+        }
+    } else {
+        for (int32_t p : need_pos) bkeys.push_back(block_key(h, p));
+        std::sort(bkeys.begin(), bkeys.end());
+        bkeys.erase(std::unique(bkeys.begin(), bkeys.end()), bkeys.end());
+        // counts over the whole block grid of those blocks (not the interval-clipped tiles)
+        if (!bkeys.empty()) {
+            int32_t rcb = bucket_blocks(h, bkeys, false, tiles);
+            if (rcb) return rcb;
         }
     }
-    std::sort(bkeys.begin(), bkeys.end());
-    bkeys.erase(std::unique(bkeys.begin(), bkeys.end()), bkeys.end());
-    phase(2);
-    // counts over the whole block grid of those blocks (not the interval-clipped tiles)
-    std::vector<PiscesTile> tiles;
-    if (!bkeys.empty()) {
-        int32_t rcb = bucket_blocks(h, bkeys, false, tiles);
-        if (rcb) return rcb;
-    }
     const int32_t n_tiles = (int32_t)tiles.size();
-    const int tiles_per_block = (bs + kTile - 1) / kTile;
-    auto locus_index = [&](int32_t p) -> int64_t {
+    const PiscesTile* const d_span_tiles = sparse_tiles ? h->d_span_tiles.p : h->d_tiles.p;
+    bool counts_missing = false;
+    auto locus_index = [&](int32_t p, bool may_fold = true) -> int64_t {
         if (p <= 0) return -1;
+        if (may_fold && in_fold(p)) return -((int64_t)(p - h->fold.lo) + 2);   // the folded counts of the tile kernels' launch
         const int32_t k = block_key(h, p);
+        if (!h->blocks.count(k)) return -1;   // no block: no counts (RegionStateManager.cs:222-226)
+        if (sparse_tiles) {
+            const int32_t ts = tile_start_of(p);
+            auto it = std::lower_bound(tile_starts.begin(), tile_starts.end(), ts);
+            if (it == tile_starts.end() || *it != ts) { counts_missing = true; return -1; }
+            return (int64_t)(it - tile_starts.begin()) * kTile + (p - ts);
+        }
         auto it = std::lower_bound(bkeys.begin(), bkeys.end(), k);
-        if (it == bkeys.end() || *it != k) return -1;
+        if (it == bkeys.end() || *it != k) { counts_missing = true; return -1; }
         const int64_t bi = it - bkeys.begin();
         const int32_t off = p - ((k - 1) * bs + 1);
         return (bi * tiles_per_block + off / kTile) * kTile + off % kTile;
     };
     if (n_tiles > 0) {
-        PISCES_HIP_CHECK(h, accumulate_tiles(h, h->stream, h->d_tuples.p, h->d_tiles.p, n_tiles, window, true));
+        PISCES_HIP_CHECK(h, accumulate_tiles(h, h->stream, h->d_tuples.p, d_span_tiles, n_tiles, window, true));
     } else {
         PISCES_HIP_CHECK(h, h->d_counts.reserve(PISCES_COUNTS_PER_LOCUS));
         if (window) PISCES_HIP_CHECK(h, h->d_sumq.reserve(PISCES_COUNTS_PER_LOCUS));
     }
+    const int32_t* const d_folded = fold_ok ? h->d_folded.p : (const int32_t*)nullptr;
     auto atype = [](char ch) { return ch == 'A' ? 0 : ch == 'G' ? 1 : ch == 'C' ? 2 : ch == 'T' ? 3 : 4; };
     auto gapped_at = [&](int32_t p) {
         auto it = h->gapped_mnv_ref.find(p);
@@ -988,21 +1064,21 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         }
         int32_t sp, ep;
         endpoints(c, sp, ep);
-        d.start_idx = locus_index(sp);
-        d.end_idx = locus_index(ep);
+        const bool may_fold = c.category != PISCES_CAT_INSERTION;
+        d.start_idx = locus_index(sp, may_fold);
+        d.end_idx = locus_index(ep, may_fold);
         d.gapped = (c.category == PISCES_CAT_SNV || c.category == PISCES_CAT_REFERENCE) ? gapped_at(c.position) : 0;
     };
     // The collapser's frequencies and the reallocator's Reference candidates read anchor-resolved counts on the host: the ROWS of the few
     // loci they can look at (gather_count_rows_kernel), never the tensor — every start / end point when some candidate is open-ended (the
     // collapser's candidates: CandidateAllele.Frequency of the open-ended one and of what it may join), the positions an MNV candidate
     // spans (a failed one's Reference candidates, MnvReallocator.cs:12-98), a forced SNV's position.
-    const bool have_forced = !h->forced.empty();
     const int32_t* host_counts_p = nullptr;
     std::unordered_map<int64_t, int32_t>& row_of = h->row_of_locus;
     row_of.clear();
     bool rows_missing = false;
     auto row_index = [&](int64_t li) -> int64_t {
-        if (li < 0) return -1;
+        if (li == -1) return -1;
         auto it = row_of.find(li);
         if (it == row_of.end()) { rows_missing = true; return -1; }
         return it->second;
@@ -1012,13 +1088,14 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         if (h->cfg.collapse)
             for (auto& c : work) any_open = any_open || c.open_left || c.open_right;
         std::vector<long long> need;
-        auto want = [&](int32_t p) { const int64_t li = locus_index(p); if (li >= 0) need.push_back(li); };
+        auto want = [&](int32_t p, bool may_fold) { const int64_t li = locus_index(p, may_fold); if (li != -1) need.push_back(li); };
         for (auto& c : work) {
             int32_t sp, ep;
             endpoints(c, sp, ep);
+            const bool may_fold = c.category != PISCES_CAT_INSERTION;
             if (mnv_mode && c.category == PISCES_CAT_MNV)
-                for (int32_t p = sp; p <= ep; p++) want(p);
-            else if (any_open || (have_forced && c.category == PISCES_CAT_SNV)) { want(sp); want(ep); }
+                for (int32_t p = sp; p <= ep; p++) want(p, true);
+            else if (any_open || (have_forced && c.category == PISCES_CAT_SNV)) { want(sp, may_fold); want(ep, may_fold); }
         }
         std::sort(need.begin(), need.end());
         need.erase(std::unique(need.begin(), need.end()), need.end());
@@ -1030,13 +1107,13 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
             PISCES_HIP_CHECK(h, hipHostMalloc((void**)&h->h_counts, (n_counts + n_counts / 2) * sizeof(int32_t), hipHostMallocDefault));
             h->h_counts_cap = n_counts + n_counts / 2;
         }
-        if (n_rows > 0 && n_tiles > 0) {
+        if (n_rows > 0) {
             for (size_t k = 0; k < n_rows; k++) row_of.emplace(need[k], (int32_t)k);
             PISCES_HIP_CHECK(h, h->d_row_idx.reserve(n_rows));
             PISCES_HIP_CHECK(h, h->d_rows.reserve(n_rows * PISCES_COUNTS_PER_LOCUS));
             { int32_t rcu = meta_upload(h, h->d_row_idx.p, need.data(), n_rows * sizeof(long long)); if (rcu) return rcu; }
             hipLaunchKernelGGL(gather_count_rows_kernel, dim3((unsigned)((n_rows * PISCES_COUNTS_PER_LOCUS + 255) / 256)), dim3(256), 0, h->stream,
-                               (const int32_t*)h->d_counts.p, (const long long*)h->d_row_idx.p, (int32_t)n_rows, h->d_rows.p);
+                               (const int32_t*)h->d_counts.p, d_folded, (const long long*)h->d_row_idx.p, (int32_t)n_rows, h->d_rows.p);
             PISCES_HIP_CHECK(h, hipGetLastError());
             h->pcie[3] += (int64_t)(n_rows * PISCES_COUNTS_PER_LOCUS * sizeof(int32_t));
             PISCES_HIP_CHECK(h, hipMemcpyAsync(h->h_counts, h->d_rows.p, n_rows * PISCES_COUNTS_PER_LOCUS * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
@@ -1119,7 +1196,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         { int32_t rcu = meta_upload(h, h->d_alleles.p, pool.data(), pool.size()); if (rcu) return rcu; }
         hipLaunchKernelGGL(call_spanning_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, h->d_cands.p, n, h->d_counts.p,
                            h->d_alleles.p, h->d_ref.p, h->ref_len, h->cfg.expect_stitched_reads, h->d_cand_records.p, h->d_cand_callable.p, h->P,
-                           window ? h->d_sumq.p : (const double*)nullptr);
+                           window ? h->d_sumq.p : (const double*)nullptr, d_folded);
         PISCES_HIP_CHECK(h, hipGetLastError());
         h->pcie[1] += (int64_t)(raw.size() * (sizeof(PiscesCalledAllele) + 1));
         const size_t rec_bytes = raw.size() * sizeof(PiscesCalledAllele), need = rec_bytes + callable.size();
@@ -1233,11 +1310,27 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
                 for (int d = 0; d < 3; d++) ref_originals[i]->support_by_dir[d] -= ref_before[i][(size_t)d];
         }
         // GetRefSupportFromGappedMnvs :180-203 -> IAlleleSource.AddGappedMnvRefCount
+        std::vector<int32_t> gapped_now;
         for (CandPtr a : callable_alleles) {
             if (a->category != PISCES_CAT_MNV) continue;
             const int support = cand_support(*a);
             for (size_t k = 0; k < a->ref.size() && k < a->alt.size(); k++)
-                if (a->ref[k] == a->alt[k]) h->gapped_mnv_ref[a->position + (int32_t)k] += support;
+                if (a->ref[k] == a->alt[k]) { h->gapped_mnv_ref[a->position + (int32_t)k] += support; gapped_now.push_back(a->position + (int32_t)k); }
+        }
+        // The tile kernels of this flush ran before these counts existed: the Reference allele of such a position (its support less what the
+        // gapped MNVs take, CoverageCalculator.cs:82-97) comes from the candidate kernel and replaces theirs.  (SNVs of the position are
+        // candidates of this pass anyway: an MNV spans it.)
+        std::vector<CandPtr> gapped_refs;
+        if (blocks_first) {
+            std::sort(gapped_now.begin(), gapped_now.end());
+            gapped_now.erase(std::unique(gapped_now.begin(), gapped_now.end()), gapped_now.end());
+            static const int32_t kNoSupport[3] = {0, 0, 0};
+            for (int32_t p : gapped_now) {
+                if (touched_refs.count(p)) { if (cand_support(*touched_refs[p]) == 0) gapped_refs.push_back(touched_refs[p]); continue; }
+                if (!h->cfg.include_reference_calls || p < 1 || p > h->ref_len || !std::binary_search(keys.begin(), keys.end(), block_key(h, p))) continue;
+                touched_refs[p] = arena.make(p, std::string(1, (char)h->h_ref[(size_t)p - 1]), std::string(1, (char)h->h_ref[(size_t)p - 1]), kNoSupport);
+                gapped_refs.push_back(touched_refs[p]);
+            }
         }
         // a failed MNV that is a forced allele is reported all the same (AlleleCaller.cs:98-107)
         if (have_forced)
@@ -1247,6 +1340,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
             if (a->category == PISCES_CAT_REFERENCE && cand_support(*a) == 0) continue;   // untouched: the tile kernels' record stands
             final_list.push_back(a);
         }
+        for (CandPtr a : gapped_refs) final_list.push_back(a);
     }
     // not a gVCF, forced alleles given: Reference candidates at the forced positions of the cleared blocks, with or without coverage
     // (RegionState.GetAllCandidates :393-450 with CreateIntervalsFromAllels); the candidate kernel makes their records from the counts
@@ -1263,7 +1357,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         }
     }
 
-    if (rows_missing) return fail(h, PISCES_E_INTERNAL, "flush: a candidate's counts were not among the rows fetched for the batch");
+    if (rows_missing || counts_missing) return fail(h, PISCES_E_INTERNAL, "flush: a candidate's counts were not among those made for the batch");
     phase(6);
     second_pass = mnv_mode;
     int32_t rc2 = device_pass(final_list);
@@ -1296,6 +1390,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         recs.push_back(r);
         called.push_back(*final_list[i]);
     }
+    if (rows_missing || counts_missing) return fail(h, PISCES_E_INTERNAL, "flush: a candidate's counts were not among those made for the batch");
     return PISCES_OK;
 }
 
@@ -1338,7 +1433,19 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
         // Reference records of call_blocks must see (AlleleCaller.cs:95, CoverageCalculator.cs:82-97)
         int64_t collapsed = 0;
         std::vector<PiscesCalledAllele> ref_overrides;
-        int32_t rc = call_spanning(h, keys, final_flush ? -1 : up_to_position, span_recs, span_cands, &called, &collapsed, ref_overrides);
+        // The tile kernels first when they are the fused kernel over a run of whole blocks: their launch leaves the folded counts of every
+        // locus for the candidate kernel (no second walk over the reads for point alleles, MNVs and deletions), and it runs while the host
+        // collects the candidates.  Otherwise (counts in HBM, NoiseModel.Window, an interval set, an observation log) the candidates go first,
+        // as they always did: the Reference records then see what gapped MNVs take.
+        CallBlocksInFlight blocks_st;
+        const bool blocks_first = fused_regular_applies(h, keys);
+        int32_t rc = PISCES_OK;
+        if (blocks_first) {
+            rc = call_blocks_enqueue(h, keys, true, -1, &blocks_st, true);
+            if (rc) return rc;
+        }
+        rc = call_spanning(h, keys, final_flush ? -1 : up_to_position, span_recs, span_cands, &called, &collapsed, ref_overrides, blocks_first && blocks_st.active);
+        h->fold.valid = false;
         h->pending_collapsed = collapsed;
         if (rc) return rc;
         h->pending_dropped = false;
@@ -1348,8 +1455,22 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
         const bool plain = span_recs.empty() && !diploid && h->forced.empty() && ref_overrides.empty();
         // the tile kernels' rows are read where the last kernel left them (pinned memory) unless a per-locus genotyper or forced alleles rework them
         const bool fast_merge = !plain && !diploid && h->forced.empty();
+        if (blocks_first) {
+            // (enqueued above; the candidate passes have waited for the stream more than once since: this wait is short)
+            if (blocks_st.active) {
+                PISCES_TIMED_WAIT(h, hipStreamSynchronize(h->stream));
+                h->h_meta_used = 0;
+                int32_t total = 0;
+                rc = call_blocks_finish(h, blocks_st, &total, &called, &h->pending_kept);
+                if (rc) return rc;
+                if (blocks_st.drop_now) h->pending_dropped = true;
+                if (plain || fast_merge) { h->pending_view = blocks_st.hrec; h->pending_view_n = (size_t)total; }
+                else point_recs.assign(blocks_st.hrec, blocks_st.hrec + total);
+            }
+        } else {
         rc = call_blocks(h, keys, point_recs, &called, true, &h->pending_dropped, &h->pending_kept, plain || fast_merge);
         if (rc) return rc;
+        }
         prof.reset();
         prof.reset(new HostTimer(h->prof_on ? &h->prof[8] : nullptr));
         if (fast_merge) {
