@@ -56,6 +56,15 @@ namespace Pisces.Hip
         public byte* DeletionDirections;   // 2 per CIGAR op: first / last deleted base of a D op in CigarDirections.Expand(), 255 = untracked
     }
 
+    [StructLayout(LayoutKind.Sequential)]
+    public struct PiscesGenotypeAllele   // one allele of a locus for pisces_hip_set_genotypes (the germline genotypers as a function)
+    {
+        public int Category, RefLen, AltLen, Support, Coverage, ReferenceSupport;
+        public long AlleleOffset;
+        public int Genotype, GenotypeQscore, PhaseSetIndex;
+        public byte MultiAllelic, Prune, Pad0, Pad1;
+    }
+
     [StructLayout(LayoutKind.Sequential, Size = 32)]
     public struct PiscesBgzfBlock
     {
@@ -178,6 +187,10 @@ namespace Pisces.Hip
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_bgzf_inflate(IntPtr handle, byte[] file, long nBytes, PiscesBgzfBlock[] blocks, long nBlocks, [Out] byte[] output, long outCapacity, int checkCrc, out float kernelMs);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_probe_read_bandwidth(IntPtr handle, long nBytes, int reps, out double gbPerSecond);
         // VCF body lines straight from the records (what VcfFileWriter.WriteListOfColocatedAlleles writes per allele, Pisces.IO/VcfFileWriter.cs:206-262)
+        /// the host half of IAlleleCaller.Call as functions: MnvReallocator.ReallocateFailedMnvs and the germline genotypers on alleles the caller brings
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_reallocate_failed_mnvs(PiscesCandidate[] failed, long nFailed, PiscesCandidate[] callable, long nCallable, byte[] alleles, long alleleBytes, int blockMaxPosition, [Out] PiscesCandidate[] callableOut, long callableCapacity, out long nCallableOut, [Out] PiscesCandidate[] outsideOut, long outsideCapacity, out long nOutsideOut, [Out] byte[] allelesOut, long alleleCapacity, out long alleleBytesOut);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_set_genotypes(ref PiscesHipConfig cfg, [In, Out] PiscesGenotypeAllele[] allelesOfOneLocus, int n, byte[] alleles, long alleleBytes);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_diploid_genotype_qscore(int genotype, int totalCoverage, int alleleSupport, int minQscore, int maxQscore);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_vcf_default_config(out PiscesVcfConfig cfg);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern long pisces_hip_format_vcf(ref PiscesVcfConfig cfg, [MarshalAs(UnmanagedType.LPStr)] string chrom, PiscesCalledAllele[] records, long n, int[] candIndex, PiscesCandidate[] cands, byte[] alleles, [Out] byte[] text, long capacity);
 

@@ -527,6 +527,39 @@ int64_t pisces_hip_find_candidates_device(PiscesHip* h, const PiscesReadBatch* b
                                           int32_t max_mnv_length, int32_t max_gap_between_mnv, PiscesCandidate* out, int64_t capacity,
                                           uint8_t* alleles, int64_t allele_capacity, int64_t* allele_bytes);
 
+/* ---- the host half of IAlleleCaller.Call as functions of their own (pure CPU) ------------------------------------------------------
+ * What pisces_hip_flush runs on the host between its device passes, callable on alleles the caller brings — the reference's own unit
+ * tests drive MnvReallocator and the genotypers this way (MNVReallocatorTests.cs, GenotypeCalculatorTest.cs), and so do this repository's
+ * (tests/test_product_goldens.py: the reference's known answers through the PRODUCT's code, not through the oracle's restatement).
+ *
+ * MnvReallocator.ReallocateFailedMnvs(failedMnvs, callableAlleles, blockMaxPos) (src/exe/Pisces/Logic/VariantCalling/MnvReallocator.cs:12-98):
+ * the support of MNVs that are not callable goes to the callable alleles inside them (longest first, then most support), what is left
+ * becomes smaller MNVs / SNVs, and — with block_max_position >= 0 — what lies past the block goes to `outside`.  An allele's
+ * AlleleSupport is the sum of support_by_dir (the product keeps no second number).  Candidates in, candidates out (same pool layout as
+ * pisces_hip_get_candidates); returns PISCES_E_BUFFER_TOO_SMALL with the three counts set when an output is short. */
+int32_t pisces_hip_reallocate_failed_mnvs(const PiscesCandidate* failed, int64_t n_failed, const PiscesCandidate* callable, int64_t n_callable,
+                                          const uint8_t* alleles, int64_t allele_bytes, int32_t block_max_position,
+                                          PiscesCandidate* callable_out, int64_t callable_capacity, int64_t* n_callable_out,
+                                          PiscesCandidate* outside_out, int64_t outside_capacity, int64_t* n_outside_out,
+                                          uint8_t* alleles_out, int64_t allele_capacity, int64_t* allele_bytes_out);
+/* The per-locus genotypers of the germline modes over the alleles of ONE locus (Reference row gone when a variant is there, rows in
+ * (ref, alt) order — what pisces_hip_flush hands them): DiploidThresholdingGenotyper.SetGenotypes
+ * (src/lib/Pisces.Genotyping/Thresholding/DiploidThresholdingGenotyper.cs:54-141) with cfg->ploidy == PISCES_PLOIDY_DIPLOID,
+ * HaploidGenotyper.SetGenotypes (Haploid/HaploidGenotyper.cs:36-83) with PISCES_PLOIDY_HAPLOID; thresholds, minimum depth (min_coverage)
+ * and the q-score range come from cfg.  Fills the result fields of every allele; returns the locus' genotype (PISCES_GT_*) or < 0. */
+typedef struct PiscesGenotypeAllele {
+    int32_t category;                 /* PISCES_CAT_* */
+    int32_t ref_len, alt_len;
+    int32_t support, coverage, reference_support;
+    int64_t allele_offset;            /* ref bytes then alt bytes in the allele pool */
+    int32_t genotype, genotype_qscore, phase_set_index;   /* results */
+    uint8_t multi_allelic, prune, pad[2];                 /* results: FilterType.MultiAllelicSite; the genotyper drops the allele */
+} PiscesGenotypeAllele;
+int32_t pisces_hip_set_genotypes(const PiscesHipConfig* cfg, PiscesGenotypeAllele* alleles_of_one_locus, int32_t n, const uint8_t* alleles,
+                                 int64_t allele_bytes);
+/* DiploidGenotypeQualityCalculator.Compute (Thresholding/DiploidGenotypeQualityCalculator.cs:17-103) for one allele */
+int32_t pisces_hip_diploid_genotype_qscore(int32_t genotype, int32_t total_coverage, int32_t allele_support, int32_t min_qscore, int32_t max_qscore);
+
 /* ---- VCF body lines (pure CPU) ---------------------------------------
  * What the writer needs of VcfWriterConfig (src/lib/Pisces.IO/VcfFileWriter.cs:264-330). */
 typedef struct PiscesVcfConfig {

@@ -265,6 +265,16 @@ class PiscesReadBatch(C.Structure):
     ]
 
 
+class PiscesGenotypeAllele(C.Structure):
+    _fields_ = [
+        ("category", C.c_int32), ("ref_len", C.c_int32), ("alt_len", C.c_int32),
+        ("support", C.c_int32), ("coverage", C.c_int32), ("reference_support", C.c_int32),
+        ("allele_offset", C.c_int64),
+        ("genotype", C.c_int32), ("genotype_qscore", C.c_int32), ("phase_set_index", C.c_int32),
+        ("multi_allelic", C.c_uint8), ("prune", C.c_uint8), ("pad", C.c_uint8 * 2),
+    ]
+
+
 class PiscesBgzfBlock(C.Structure):
     _fields_ = [
         ("in_offset", C.c_int64),

@@ -2264,3 +2264,98 @@ int32_t pisces_hip_stats(PiscesHip* h, int64_t out[4])
     });
 }
 
+
+// ---- the host half of IAlleleCaller.Call as functions of their own (pure CPU; include/pisces_hip.h) --------------------------------------
+int32_t pisces_hip_reallocate_failed_mnvs(const PiscesCandidate* failed, int64_t n_failed, const PiscesCandidate* callable, int64_t n_callable,
+                                          const uint8_t* alleles, int64_t allele_bytes, int32_t block_max_position,
+                                          PiscesCandidate* callable_out, int64_t callable_capacity, int64_t* n_callable_out,
+                                          PiscesCandidate* outside_out, int64_t outside_capacity, int64_t* n_outside_out,
+                                          uint8_t* alleles_out, int64_t allele_capacity, int64_t* allele_bytes_out)
+{
+    return abi_guard<int32_t>((PiscesHip*)nullptr, [&]() -> int32_t {
+    if (n_failed < 0 || n_callable < 0 || (n_failed > 0 && !failed) || (n_callable > 0 && !callable) || !n_callable_out || !n_outside_out || !allele_bytes_out ||
+        callable_capacity < 0 || outside_capacity < 0 || allele_capacity < 0)
+        return PISCES_E_INVALID_ARG;
+    // (categories as given: the reference's tests hand over alleles typed Reference that are MNVs by their strings; IsPotentialOverlap
+    // looks at the type, CreateVariant types what it makes)
+    auto load = [&](const PiscesCandidate* in, int64_t n, std::vector<HostCandidate>& out) -> bool {
+        out.resize((size_t)n);
+        for (int64_t i = 0; i < n; i++) {
+            const PiscesCandidate& c = in[i];
+            if (c.ref_len < 0 || c.alt_len < 0 || c.allele_offset < 0 || c.allele_offset + c.ref_len + c.alt_len > allele_bytes || (c.ref_len + c.alt_len > 0 && !alleles)) return false;
+            HostCandidate& h = out[(size_t)i];
+            h.position = c.position;
+            h.category = c.category;
+            h.ref.assign((const char*)alleles + c.allele_offset, (size_t)c.ref_len);
+            h.alt.assign((const char*)alleles + c.allele_offset + c.ref_len, (size_t)c.alt_len);
+            for (int d = 0; d < 3; d++) { h.support_by_dir[d] = c.support_by_dir[d]; h.well_anchored_by_dir[d] = c.well_anchored_by_dir[d]; }
+        }
+        return true;
+    };
+    std::vector<HostCandidate> f, c;
+    if (!load(failed, n_failed, f) || !load(callable, n_callable, c)) return PISCES_E_INVALID_ARG;
+    MnvArena arena;
+    std::vector<CandPtr> failed_p, callable_p, outside;
+    for (auto& x : f) failed_p.push_back(&x);
+    for (auto& x : c) callable_p.push_back(&x);
+    mnv_reallocate_failed(arena, failed_p, callable_p, block_max_position >= 0, block_max_position, outside);
+    int64_t bytes = 0;
+    for (CandPtr x : callable_p) bytes += (int64_t)(x->ref.size() + x->alt.size());
+    for (CandPtr x : outside) bytes += (int64_t)(x->ref.size() + x->alt.size());
+    *n_callable_out = (int64_t)callable_p.size();
+    *n_outside_out = (int64_t)outside.size();
+    *allele_bytes_out = bytes;
+    if ((int64_t)callable_p.size() > callable_capacity || (int64_t)outside.size() > outside_capacity || bytes > allele_capacity ||
+        (!callable_p.empty() && !callable_out) || (!outside.empty() && !outside_out) || (bytes > 0 && !alleles_out))
+        return PISCES_E_BUFFER_TOO_SMALL;
+    int64_t off = 0;
+    auto store = [&](const std::vector<CandPtr>& list, PiscesCandidate* out) {
+        for (size_t i = 0; i < list.size(); i++) {
+            const HostCandidate& x = *list[i];
+            PiscesCandidate& o = out[i];
+            std::memset(&o, 0, sizeof(o));
+            o.position = x.position; o.category = x.category;
+            o.ref_len = (int32_t)x.ref.size(); o.alt_len = (int32_t)x.alt.size();
+            for (int d = 0; d < 3; d++) { o.support_by_dir[d] = x.support_by_dir[d]; o.well_anchored_by_dir[d] = x.well_anchored_by_dir[d]; }
+            o.allele_offset = off;
+            std::memcpy(alleles_out + off, x.ref.data(), x.ref.size());
+            std::memcpy(alleles_out + off + x.ref.size(), x.alt.data(), x.alt.size());
+            off += (int64_t)(x.ref.size() + x.alt.size());
+        }
+    };
+    store(callable_p, callable_out);
+    store(outside, outside_out);
+    return PISCES_OK;
+    });
+}
+
+int32_t pisces_hip_set_genotypes(const PiscesHipConfig* cfg, PiscesGenotypeAllele* a, int32_t n, const uint8_t* alleles, int64_t allele_bytes)
+{
+    return abi_guard<int32_t>((PiscesHip*)nullptr, [&]() -> int32_t {
+    if (!cfg || n < 0 || (n > 0 && !a) || (cfg->ploidy != PISCES_PLOIDY_DIPLOID && cfg->ploidy != PISCES_PLOIDY_HAPLOID)) return PISCES_E_INVALID_ARG;
+    std::vector<DiploidAllele> at((size_t)n);
+    for (int32_t i = 0; i < n; i++) {
+        const PiscesGenotypeAllele& x = a[i];
+        if (x.ref_len < 0 || x.alt_len < 0 || x.allele_offset < 0 || x.allele_offset + x.ref_len + x.alt_len > allele_bytes || (x.ref_len + x.alt_len > 0 && !alleles)) return PISCES_E_INVALID_ARG;
+        DiploidAllele& d = at[(size_t)i];
+        d.category = x.category;
+        d.ref.assign((const char*)alleles + x.allele_offset, (size_t)x.ref_len);
+        d.alt.assign((const char*)alleles + x.allele_offset + x.ref_len, (size_t)x.alt_len);
+        d.support = x.support; d.coverage = x.coverage; d.ref_support = x.reference_support;
+    }
+    const int32_t gt = cfg->ploidy == PISCES_PLOIDY_HAPLOID
+                           ? haploid_set_genotypes(at, cfg->diploid_snv_params[0], cfg->diploid_snv_params[1], cfg->min_coverage, cfg->min_genotype_qscore, cfg->max_genotype_qscore)
+                           : diploid_set_genotypes(at, cfg->diploid_snv_params, cfg->diploid_indel_params, cfg->min_coverage, cfg->min_genotype_qscore, cfg->max_genotype_qscore);
+    for (int32_t i = 0; i < n; i++) {
+        const DiploidAllele& d = at[(size_t)i];
+        a[i].genotype = d.genotype; a[i].genotype_qscore = d.genotype_qscore; a[i].phase_set_index = d.phase_set_index;
+        a[i].multi_allelic = d.multi_allelic ? 1 : 0; a[i].prune = d.prune ? 1 : 0;
+    }
+    return gt;
+    });
+}
+
+int32_t pisces_hip_diploid_genotype_qscore(int32_t genotype, int32_t total_coverage, int32_t allele_support, int32_t min_qscore, int32_t max_qscore)
+{
+    return abi_guard<int32_t>((PiscesHip*)nullptr, [&]() -> int32_t { return diploid_genotype_qscore(genotype, total_coverage, allele_support, min_qscore, max_qscore); });
+}

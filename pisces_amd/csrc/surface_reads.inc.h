@@ -456,16 +456,20 @@ static int32_t consume_found(PiscesHip* h)
             h->split_stats[0] += (int64_t)misc[3];
         }
         h->pcie[2] += n_groups * (int64_t)sizeof(DevMerged) + h->found.pool_bytes;
+        // (few groups among many record slots once the plain SNV groups stay on the device: ordered by a sort of the groups, not by a pass over the slots)
         std::vector<int32_t>& order = h->found.order;
-        order.assign((size_t)h->found.n_slots, -1);
+        order.resize((size_t)n_groups);
         for (int64_t k = 0; k < n_groups; k++) {
             const int32_t first = groups[k].first;
-            if (first < 0 || first >= h->found.n_slots || order[(size_t)first] != -1) return fail(h, PISCES_E_DEVICE, "add_reads: the merged candidate records of the device are inconsistent");
-            order[(size_t)first] = (int32_t)k;
+            if (first < 0 || first >= h->found.n_slots) return fail(h, PISCES_E_DEVICE, "add_reads: the merged candidate records of the device are inconsistent");
+            order[(size_t)k] = (int32_t)k;
         }
-        for (int64_t i = 0; i < h->found.n_slots; i++) {
-            if (order[(size_t)i] < 0) continue;
-            const DevMerged& m = groups[order[(size_t)i]];
+        std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return groups[a].first < groups[b].first; });
+        for (int64_t k = 1; k < n_groups; k++)
+            if (groups[order[(size_t)k]].first == groups[order[(size_t)k - 1]].first) return fail(h, PISCES_E_DEVICE, "add_reads: the merged candidate records of the device are inconsistent");
+        for (int64_t oi = 0; oi < n_groups; oi++) {
+            const DevMerged& m = groups[order[(size_t)oi]];
+            const int64_t i = m.first;
             if (m.f.c.category == kFoundSpanMark) {   // the positions of an X operation: no candidate, dirty loci of their blocks (surface_flush.inc.h)
                 for (int32_t k = block_key(h, m.f.c.position); k <= block_key(h, m.f.c.position + m.f.c.length - 1); k++)
                     get_block(h, (k - 1) * h->cfg.block_size + 1)->x_spans.emplace_back(m.f.c.position, m.f.c.position + m.f.c.length - 1);
