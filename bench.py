@@ -370,6 +370,46 @@ def end_to_end_full(pileup, cfg, engine, torch):
     return out, roof
 
 
+def config3_sample(engine, torch, amps=200):
+    """BASELINE config 3's mix on a sample that finishes in seconds (200 amplicons = 30 000 loci x 2000x = 400 000 reads; SNVs + MNVs +
+    deletions + insertions, MNV calling on): the reads in DEVICE memory (pisces_hip_add_device_reads) -> records, one add + one flush, best of
+    three — the form `python bench.py --config 3` runs over all of the 1 M loci.  roofline: the path's algorithmic bytes (2 B per aligned
+    base + 64 B per record) over the wall clock of the pair."""
+    from pisces_amd import synth
+    seed, depth = 33, 2000
+    cfg3 = _abi_config(call_mnvs=1, max_mnv_length=3, max_gap_between_mnv=1)
+    n_loci = amps * synth.READ_LEN
+    ref3 = synth.reference_of(n_loci, seed, device="cuda")
+    p3 = synth.make_pileup(n_loci, depth, seed=seed, device="cuda", first_locus=0, total_loci=n_loci, with_tuples=False)
+    batch, planted = synth.mixed_reads(p3, seed)
+    dbatch = engine.DeviceReadBatch.from_host(batch, "cuda:0")
+    with engine.HipVariantCaller(cfg3) as c:
+        c.SetReference(ref3)
+        best, best_add, n_rec = None, None, 0
+        for rep in range(4):
+            if rep == 1:
+                c.HostTime(reset=True)
+                c.TransferBytes(reset=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            c.AddDeviceReads(dbatch)
+            t1 = time.perf_counter()
+            n_rec = len(c.CallView(None))
+            dt = time.perf_counter() - t0
+            if rep > 0 and (best is None or dt < best):
+                best, best_add = dt, t1 - t0
+        ht = c.HostTime(reset=True)
+        tb = c.TransferBytes(reset=True)
+    nbytes = 2.0 * batch.n_bases + 64.0 * n_rec
+    return {"bound": "hbm", "achieved": nbytes / best / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / best / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes": nbytes, "value": n_loci / best, "value_unit": "candidate loci/s", "seconds": best, "seconds_in_add": best_add,
+            "loci": n_loci, "depth": depth, "reads": int(batch.n_reads), "records": n_rec, "planted_events": len(planted),
+            "host_seconds_in_flush_per_flush": ht["host_ms_per_flush"] / 1e3, "pcie_bytes_per_flush": {k: v / max(ht["flushes"], 1) for k, v in tb.items()},
+            "what": "BASELINE config 3's mix, a 30 000-locus sample, reads in device memory -> records on the host: pisces_hip_add_device_reads + one "
+                    "pisces_hip_flush_view (device checks, read store, candidate discovery + merge, dirty loci, collapser / reallocator, call kernels); wall clock, "
+                    "not a per-kernel figure: profiles/r04_config3_kernel_stats.csv has those; all of config 3: python bench.py --config 3"}
+
+
 def from_large_bam(cfg, engine, reads=400_000, copies=9):
     """the BAM surface on a file of >= 256 MB: 3.6 M reads of 150 bases drawn from a random reference with 0.5 % wrong
     bases at ~450x (tools/bam_bench.make_bam), BGZF at zlib level 1 (1.0 GB inflated, ~265 MB compressed: position-sorted reads of one
@@ -489,8 +529,9 @@ def run_stream_config(args):
       3: 1 M loci x 2000x = 13.3 M reads, SNVs + MNVs (2-3 bases) + deletions (1-10) + insertions (1-6), -callmnvs true -maxmnvlength 3
          -maxgapbetweenmnv 1, gVCF;
       5: 100 000 loci x 5000x = 3.3 M reads, planted 0.5 % VAF SNVs, -minbq 30 (=> NL 30) -minvf 0.005 -sbfilter 0.5 -vqfilter 30, gVCF.
-    The amplicons are handed over in stretches (pisces_hip_add_reads, then pisces_hip_flush up to the stretch's last cleared position),
-    host reads in, host records out; making the synthetic reads (torch, on the device) is not timed.  N ranks: rank r takes the r-th
+    The amplicons are handed over in stretches (pisces_hip_add_device_reads — the reads lie in device memory when the timed region starts,
+    SURVEY 8d — then pisces_hip_flush_view up to the stretch's last cleared position), records out on the host; the same stretches from host
+    arrays (pisces_hip_add_reads, PCIe-inclusive) are timed beside it as `host_fed`; making the synthetic reads is not timed.  N ranks: rank r takes the r-th
     contiguous range of amplicons (amplicons do not overlap: no halo), totals all-reduced, `value` = loci / the slowest rank's time."""
     import numpy as np
     import torch
@@ -523,24 +564,41 @@ def run_stream_config(args):
     a_lo, a_hi = rank * n_amp_all // world, (rank + 1) * n_amp_all // world
     ref = synth.reference_of(n_loci_all, seed, device=f"cuda:{local_rank}")
     origin = synth.READ_LEN + 1
+    # Two handles over the same stretches: `c` takes the reads from device memory (pisces_hip_add_device_reads: the metric's form, SURVEY 8d —
+    # inputs resident in HBM when the timed region starts), `ch` from host arrays over PCIe (pisces_hip_add_reads: what a host that holds
+    # the reads pays; 2 bytes per base at the host link's rate bound it whatever the device does)
     elapsed, n_rec, n_reads, host = 0.0, 0, 0, None
-    with engine.HipVariantCaller(cfg, device=local_rank) as c:
+    elapsed_h, n_rec_h = 0.0, 0
+    n_bases = 0
+    with engine.HipVariantCaller(cfg, device=local_rank) as c, engine.HipVariantCaller(cfg, device=local_rank) as ch:
         c.SetReference(ref)
+        ch.SetReference(ref)
         for a0 in range(a_lo, a_hi, stretch):
             na = min(stretch, a_hi - a0)
             p = synth.make_pileup(na * synth.READ_LEN, depth, seed=seed, device=f"cuda:{local_rank}", first_locus=a0 * synth.READ_LEN, total_loci=n_loci_all,
                                   with_tuples=False, **synth_kw)
             batch = synth.mixed_reads(p, seed)[0] if args.config == 3 else synth.reads_of(p, na, first_amplicon=a0)
             n_reads += int(batch.n_reads)
+            n_bases += int(batch.n_bases)
+            up_to = origin + (a0 + na) * synth.READ_LEN - 1 if a0 + na < a_hi else None
+            dbatch = engine.DeviceReadBatch.from_host(batch, f"cuda:{local_rank}")
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
-            c.AddAlleleCounts(batch)
-            n_rec += len(c.CallView(origin + (a0 + na) * synth.READ_LEN - 1 if a0 + na < a_hi else None))
+            c.AddDeviceReads(dbatch)
+            n_rec += len(c.CallView(up_to))
             elapsed += time.perf_counter() - t0
+            del dbatch
+            t0 = time.perf_counter()
+            ch.AddAlleleCounts(batch)
+            n_rec_h += len(ch.CallView(up_to))
+            elapsed_h += time.perf_counter() - t0
             del p, batch
         stats = c.Stats()
         host = c.HostTime()
         pcie = c.TransferBytes()
+        host_h = ch.HostTime()
+        pcie_h = ch.TransferBytes()
+        assert ch.Stats() == stats and n_rec_h == n_rec
     loci_mine = (a_hi - a_lo) * synth.READ_LEN
     summary = torch.tensor([stats["TotalNumCalled"], stats["TotalNumCollapsed"], stats["reads"], stats["reads_skipped"], loci_mine, n_rec], dtype=torch.int64, device=dev)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -549,6 +607,8 @@ def run_stream_config(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
         loci = int(summary[4].item())
+        # the path's algorithmic bytes: 2 B per aligned base in, 64 B per record out
+        algo_bytes = 2.0 * n_bases + 64.0 * n_rec
         out = {"metric": f"candidate loci/s at {depth}x depth from reads (BASELINE config {args.config})", "value": loci / float(t.item()), "unit": "candidate loci/s",
                "n_gpus": world, "steps": 1, "warmup": 0, "ms_per_step": float(t.item()) * 1e3, "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": "int32 counts + f64 likelihoods", "data": "synthetic",
@@ -557,7 +617,15 @@ def run_stream_config(args):
                "totals": {"allelesCalled": int(summary[0].item()), "variantsCollapsed": int(summary[1].item()), "readsProcessed": int(summary[2].item()),
                           "readsSkipped": int(summary[3].item()), "records": int(summary[5].item())},
                "rank0": {"host_seconds_in_add_reads": host["add_reads_s"], "host_seconds_in_flushes": host["flush_s"], "of_those_waiting_for_the_device": host["flush_wait_s"],
-                         "flushes": host["flushes"], "pcie_bytes": pcie}}
+                         "flushes": host["flushes"], "pcie_bytes": pcie},
+               f"roofline_config{args.config}": {"bound": "hbm", "achieved": algo_bytes / elapsed / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                 "frac": algo_bytes / elapsed / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": algo_bytes,
+                                                 "seconds": elapsed, "what": "reads in device memory (2 B per aligned base) -> records (64 B each), wall clock of pisces_hip_add_device_reads + "
+                                                 "pisces_hip_flush_view over all stretches on rank 0: candidate discovery, merge, collapser / reallocator on the host and the call kernels "
+                                                 "included; per-kernel times: profiles/r04_config3_kernel_stats.csv"},
+               "host_fed": {"value": loci_mine / elapsed_h, "unit": "candidate loci/s (rank 0)", "seconds": elapsed_h, "host_seconds_in_add_reads": host_h["add_reads_s"],
+                            "host_seconds_in_flushes": host_h["flush_s"], "pcie_bytes": pcie_h,
+                            "what": "the same stretches from host arrays (pisces_hip_add_reads): the reads cross PCIe, 2 B per base"}}
         assert out["totals"]["readsProcessed"] == n_reads or use_dist
         print(json.dumps(out), flush=True)
     if use_dist:
@@ -861,6 +929,10 @@ def main():
                 out["end_to_end_full"], out["roofline_streaming"] = end_to_end_full(ring[0], cfg, engine, torch)
             except Exception as e:   # noqa: BLE001  (extra figures: they must not cost the bench line)
                 out["end_to_end_full"] = {"error": str(e)[:200]}
+            try:
+                out["roofline_config3"] = config3_sample(engine, torch)
+            except Exception as e:   # noqa: BLE001
+                out["roofline_config3"] = {"error": str(e)[:200]}
             if not args.no_large_bam:
                 try:
                     out["end_to_end_full"]["from_bam_bytes_large"] = from_large_bam(cfg, engine)

@@ -306,6 +306,7 @@ struct PiscesHip {
     SnvGroup* h_snv_sel = nullptr;            // pinned: {selected, kept} counts (16 bytes), then the first kSnvSpec selected groups
     DeviceBuf<uint32_t> d_dirty;
     std::vector<uint32_t> dirty_host;
+    std::vector<HostCandidate> split_selected;   // the SNV groups of the current batch's dirty loci (split_prepare -> call_spanning), by position
     uint32_t batch_seq = 0, host_seq = 0;     // arrival stamps: (batch_seq << 32) | record index, host-side additions behind the batch's records
     DeviceBuf<int32_t> d_folded;              // the folded counts the flush's tile kernel leaves for the candidate kernel (DeviceParams::folded_out)
     struct { bool valid = false; int32_t lo = 0, hi = 0; } fold;   // the positions d_folded holds (the tile kernels of this flush went first)
@@ -752,8 +753,8 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     if (!h) return PISCES_OK;
     if (h->prof_on) {
         static const char* names[12] = {"consume_found", "spanning: candidates of the batch", "spanning: counts to the host", "collapse", "device pass (MNVs)",
-                                        "reallocate", "device pass (all)", "call_blocks", "row merge / genotypers", "copy out + DoneProcessing", "", ""};
-        for (int i = 0; i < 10; i++) fprintf(stderr, "pisces_hip host profile: %-36s %9.3f ms\n", names[i], h->prof[i] * 1e3);
+                                        "reallocate", "device pass (all)", "call_blocks", "row merge / genotypers", "copy out + DoneProcessing", "split: dirty loci + SNV store", "  of reallocate: mnv_reallocate_failed"};
+        for (int i = 0; i < 12; i++) fprintf(stderr, "pisces_hip host profile: %-36s %9.3f ms\n", names[i], h->prof[i] * 1e3);
         if (h->mnv_split)
             fprintf(stderr, "pisces_hip split form: %lld SNV groups into the store, %lld taken by flushes (dirty loci), %lld dropped unseen, %lld sweeps\n",
                     (long long)h->split_stats[0], (long long)h->split_stats[1], (long long)h->split_stats[2], (long long)h->split_stats[3]);

@@ -555,21 +555,30 @@ void mnv_reallocate_failed(MnvArena& arena, const std::vector<CandPtr>& failed, 
     // the callable alleles by position (their places in `callable`, ascending): IsPotentialOverlap only looks at alleles that start on
     // the failed allele's few positions, and a batch of thirty blocks holds ~10^5 callable alleles (a scan of all of them per failed
     // allele made reallocation 52 of the 65 ms of such a flush)
+    // (a sorted array of (position, place) for the alleles there are at the start — thousands in a large batch, no allocation each —
+    // and a small map for the SNVs that BreakDownToSingleNucCalls adds on the way)
+    std::vector<std::pair<int32_t, uint32_t>> by_position(callable.size());
+    for (size_t i = 0; i < callable.size(); i++) by_position[i] = {callable[i]->position, (uint32_t)i};
+    std::sort(by_position.begin(), by_position.end());
     std::unordered_map<int32_t, std::vector<uint32_t>> at_position;
-    at_position.reserve(callable.size() * 2);
-    for (size_t i = 0; i < callable.size(); i++) at_position[callable[i]->position].push_back((uint32_t)i);
     std::vector<uint32_t> places;
+    std::vector<CandPtr> remainderAlleles, overlaps;   // (reused: a failed MNV is a handful of alleles, a batch hundreds of failed MNVs)
     for (CandPtr failedMnv : ordered) {
-        std::vector<CandPtr> remainderAlleles{failedMnv};
+        remainderAlleles.assign(1, failedMnv);
         while (!remainderAlleles.empty()) {
             CandPtr alleleToReassign = remainderAlleles.front();
             const int fl = (int)alleleToReassign->alt.size();
-            std::vector<CandPtr> overlaps;
+            overlaps.clear();
             places.clear();
-            for (int32_t q = alleleToReassign->position; q <= alleleToReassign->position + fl; q++) {
-                auto it = at_position.find(q);
-                if (it != at_position.end()) places.insert(places.end(), it->second.begin(), it->second.end());
+            {
+                auto lo = std::lower_bound(by_position.begin(), by_position.end(), std::make_pair(alleleToReassign->position, 0u));
+                for (; lo != by_position.end() && lo->first <= alleleToReassign->position + fl; ++lo) places.push_back(lo->second);
             }
+            if (!at_position.empty())
+                for (int32_t q = alleleToReassign->position; q <= alleleToReassign->position + fl; q++) {
+                    auto it = at_position.find(q);
+                    if (it != at_position.end()) places.insert(places.end(), it->second.begin(), it->second.end());
+                }
             std::sort(places.begin(), places.end());   // the order of `callable`: what the stable sort below keeps among equals
             for (uint32_t i : places) {   // IsPotentialOverlap :250-261
                 CandPtr c = callable[i];
@@ -773,6 +782,7 @@ static void split_restore(PiscesHip* h)
 static int32_t split_prepare(PiscesHip* h, const std::vector<int32_t>& keys, int32_t up_to_position)
 {
     split_restore(h);
+    h->split_selected.clear();
     if (!h->mnv_split) return PISCES_OK;
     h->P.refs_only = 0;
     if (keys.empty()) return PISCES_OK;
@@ -861,8 +871,17 @@ static int32_t split_prepare(PiscesHip* h, const std::vector<int32_t>& keys, int
         int32_t rcs = snv_store_sweep(h, any ? h->d_dirty.p : (const uint32_t*)nullptr, (int32_t)lo, (int32_t)n, (int32_t)std::min<int64_t>(hi, 0x7FFFFFFFll), selected);
         if (rcs) return rcs;
     }
+    // The groups of the batch's own blocks do not become block state: they are flushed with this batch, and call_spanning takes them from
+    // h->split_selected (position order, then order of arrival).  Only the few of held blocks (the AddCollapsable case) join their blocks.
+    h->split_selected.clear();
     if (!selected.empty()) {
+        std::sort(selected.begin(), selected.end(), [](const SnvGroup& a, const SnvGroup& b) {
+            if (a.position != b.position) return a.position < b.position;
+            if (a.batch != b.batch) return a.batch < b.batch;
+            return a.first < b.first;
+        });
         std::vector<int32_t> touched;
+        h->split_selected.reserve(selected.size());
         for (const SnvGroup& g : selected) {
             if (g.position < 1 || (int64_t)g.position > h->ref_len) continue;
             HostCandidate c;
@@ -873,6 +892,7 @@ static int32_t split_prepare(PiscesHip* h, const std::vector<int32_t>& keys, int
             for (int d = 0; d < 3; d++) { c.support_by_dir[d] = g.sup[d]; c.well_anchored_by_dir[d] = g.anch[d]; }
             c.stamp = ((uint64_t)g.batch << 32) | (uint64_t)g.first;
             c.from_reads = true;
+            if ((int64_t)g.position <= hi) { h->split_selected.push_back(std::move(c)); continue; }
             add_candidate(h, c);
             touched.push_back(block_key(h, g.position));
         }
@@ -925,7 +945,41 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
             if (h->mnv_split && candidate_is_plain_snv(h, c) && !split_dirty_at(h, c.position)) continue;
             work.push_back(c);
         }
-        std::stable_sort(work.begin() + (std::ptrdiff_t)first, work.end(), [](const HostCandidate& x, const HostCandidate& y) { return x.position < y.position; });
+        // the SNV groups of the block's dirty loci, taken from the device's store for this flush (split_prepare): they go where their
+        // arrival puts them among the block's candidates, and a group equal to a candidate that is there already is merged into it
+        // (RegionState.AddCandidate, RegionState.cs:114-137)
+        bool extra = false;
+        if (h->mnv_split && !h->split_selected.empty()) {
+            const int32_t b0 = (key - 1) * h->cfg.block_size + 1, b1 = key * h->cfg.block_size;
+            auto lo = std::lower_bound(h->split_selected.begin(), h->split_selected.end(), b0, [](const HostCandidate& c, int32_t p) { return c.position < p; });
+            for (; lo != h->split_selected.end() && lo->position <= b1; ++lo) { work.push_back(*lo); extra = true; }
+        }
+        if (!extra) {
+            std::stable_sort(work.begin() + (std::ptrdiff_t)first, work.end(), [](const HostCandidate& x, const HostCandidate& y) { return x.position < y.position; });
+        } else {
+            std::stable_sort(work.begin() + (std::ptrdiff_t)first, work.end(), [](const HostCandidate& x, const HostCandidate& y) {
+                return x.position != y.position ? x.position < y.position : x.stamp < y.stamp;
+            });
+            const bool track_open = h->cfg.collapse != 0;
+            size_t w = first;
+            for (size_t i = first; i < work.size(); i++) {
+                bool merged = false;
+                for (size_t j = w; j-- > first && work[j].position == work[i].position;) {
+                    HostCandidate& e = work[j];
+                    if (e.category == work[i].category && e.ref == work[i].ref && e.alt == work[i].alt &&
+                        (!track_open || (e.open_left == work[i].open_left && e.open_right == work[i].open_right))) {
+                        for (int d = 0; d < 3; d++) { e.support_by_dir[d] += work[i].support_by_dir[d]; e.well_anchored_by_dir[d] += work[i].well_anchored_by_dir[d]; }
+                        e.from_reads = e.from_reads && work[i].from_reads;
+                        merged = true;
+                        break;
+                    }
+                }
+                if (merged) continue;
+                if (w != i) work[w] = std::move(work[i]);
+                w++;
+            }
+            work.resize(w);
+        }
     }
     const int bs = h->cfg.block_size;
     // AddCollapsableFromOtherBlocks (RegionStateManager.cs:321-324, 441-457): when an allele of the cleared blocks reaches past the last
@@ -1295,7 +1349,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
                 ref_before.push_back({kv.second->support_by_dir[0], kv.second->support_by_dir[1], kv.second->support_by_dir[2]});
             }
             std::vector<CandPtr> outside;
-            mnv_reallocate_failed(arena, failed, callable_alleles, true, last_cleared, outside);
+            { HostTimer prof_r(h->prof_on ? &h->prof[11] : nullptr); mnv_reallocate_failed(arena, failed, callable_alleles, true, last_cleared, outside); }
             for (CandPtr o : outside)   // source.AddCandidates(leftovers.Select(AlleleHelper.Map)) :92-93
                 if (o->category != PISCES_CAT_REFERENCE && o->position > 0) {
                     HostCandidate c = *o;
@@ -1428,7 +1482,7 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
         std::vector<HostCandidate> span_cands;
         // MNV calling on, split form: the dirty loci of the batch, the SNV groups on them, the tile kernels' parameters for this flush
         struct SplitGuard { PiscesHip* h; ~SplitGuard() { split_restore(h); } } split_guard{h};
-        { int32_t rcs = split_prepare(h, keys, final_flush ? -1 : up_to_position); if (rcs) return rcs; }
+        { HostTimer prof_split(h->prof_on ? &h->prof[10] : nullptr); int32_t rcs = split_prepare(h, keys, final_flush ? -1 : up_to_position); if (rcs) return rcs; }
         // host-side candidates first: with MNV calling on they register the reference support that gapped MNVs take, which the
         // Reference records of call_blocks must see (AlleleCaller.cs:95, CoverageCalculator.cs:82-97)
         int64_t collapsed = 0;
