@@ -451,27 +451,15 @@ def _abi_config(**kw):
     return _abi.default_config(**kw)
 
 
-def run_config4(args):
-    """BASELINE config 4 as SURVEY 8d states it (30 M loci x 200x, 200 000 intervals on 24 contigs, SNV + indel, cut 8 ways by interval):
-    `python bench.py --config 4`.  One process: the eight shards run in turn on cuda:0 (per-shard loci/s printed; `value` = loci / the sum
-    of the shards' times: what ONE GPU does with the whole set).  Under torch.distributed.run with N ranks: rank r takes the shards
-    r, r + N, ... on its own GPU, the totals are all-reduced (RCCL) and `value` = loci / the slowest rank's time.  Timed: the streaming
-    surface per (contig, range) piece — set_reference, set_intervals, add_reads in stretches, flushes — host reads in, host records out;
-    making the synthetic contigs is not timed."""
+def config4_job(torch, dist, world, rank, local_rank, use_dist):
+    """BASELINE config 4 as SURVEY 8d states it (30 M loci x 200x, 200 000 intervals on 24 contigs, SNV + indel, cut 8 ways by interval).
+    Rank r of `world` takes the shards r, r + world, ... of the 8-way cut in turn on its own GPU (one process: all eight in turn on
+    cuda:0), the per-chromosome totals are all-reduced (RCCL) and the job's rate is loci / the slowest rank's time: STRONG scaling — the
+    job is the same whatever the number of GPUs.  Timed: the streaming surface per (contig, range) piece — set_reference, set_intervals,
+    add_reads in stretches, flushes — host reads in, host records out; making the synthetic contigs is not timed.  Returns the line (rank 0)."""
     import numpy as np
-    import torch
-    import torch.distributed as dist
     from pisces_amd import _abi, config4, engine
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_dist = world > 1
-    if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
     depth, n_shards = 200, 8
     sizes = config4.contig_intervals(200_000)
     cfg = _abi.default_config(emit_zero_coverage_refs=1)
@@ -500,24 +488,72 @@ def run_config4(args):
     elapsed = sum(t_shard.values())
     summary = torch.tensor(totals.tolist() + [sum(loci_shard.values())], dtype=torch.int64, device=dev)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    per_rank = torch.zeros(world, dtype=torch.float64, device=dev)
+    per_rank[rank] = sum(loci_shard.values()) / max(elapsed, 1e-9)
     if use_dist:
         dist.all_reduce(summary, op=dist.ReduceOp.SUM)   # the per-chromosome totals over the shards (RCCL over xGMI)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
+    # the same totals through the C ABI (pisces_hip_comm_* / pisces_hip_reduce_summary: RCCL bound by the library, what a C# host with one
+    # process per GPU calls); on a side thread with a time limit: a communicator that cannot be set up costs this field, not the line
+    c_abi = None
+    if use_dist and world > 1:
+        import threading
+        box = {}
+
+        def through_the_c_abi():
+            try:
+                with engine.HipVariantCaller(cfg, device=local_rank) as hc:
+                    ids = [engine.HipVariantCaller.comm_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(ids, src=0)
+                    hc.comm_init(ids[0], rank, world)
+                    red = hc.reduce_summary([int(x) for x in totals.tolist()])
+                    box["r"] = {"ok": red == [int(x) for x in summary[:4].tolist()], "summary": red}
+            except Exception as e:   # noqa: BLE001
+                box["r"] = {"ok": False, "error": str(e)[:200]}
+        th = threading.Thread(target=through_the_c_abi, daemon=True)
+        th.start()
+        th.join(60.0)
+        c_abi = box.get("r", {"ok": False, "error": "no answer within 60 s"})
+    if rank != 0:
+        return None
+    loci = int(summary[4].item())
+    out = {"metric": "candidate loci/s at 200x depth, interval-sharded (BASELINE config 4)", "value": loci / float(t.item()), "unit": "candidate loci/s",
+           "n_gpus": world, "steps": 1, "warmup": 0, "ms_per_step": float(t.item()) * 1e3, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "int32 counts + f64 likelihoods", "data": "synthetic",
+           "config": {"workload": "BASELINE config 4: 30 M loci x 200x over 200 000 intervals of 150 bp on 24 contigs, SNV + indel at 1/10 of config 3's "
+                                  "density, cut 8 ways by interval; streaming surface (host reads in, host records out), shards "
+                                  + ("in turn on one GPU" if world == 1 else f"over {world} GPUs"),
+                      "loci": loci, "reads": int(summary[2].item()), "intervals": 200_000, "contigs": 24, "shards": n_shards},
+           "totals": {"allelesCalled": int(summary[0].item()), "variantsCollapsed": int(summary[1].item()), "readsProcessed": int(summary[2].item()),
+                      "readsSkipped": int(summary[3].item())},
+           "loci_per_s_by_rank": [float(x) for x in per_rank.tolist()],
+           "rank0_seconds_inside_the_library": lib_time,
+           "shards_rank0": [{"shard": r, "pieces": len(shards[r]), "loci": loci_shard[r], "seconds": t_shard[r], "loci_per_s": loci_shard[r] / t_shard[r]}
+                            for r in mine]}
+    if c_abi is not None:
+        out["c_abi_reduce"] = c_abi
+    assert loci == 30_000_000 and out["totals"]["readsProcessed"] == 200_000 * depth
+    return out
+
+
+def run_config4(args):
+    """`python bench.py --config 4` (one process: the eight shards in turn on cuda:0; under torch.distributed.run with N ranks: spread over
+    the ranks' GPUs): see config4_job."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    use_dist = world > 1
+    if use_dist:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    out = config4_job(torch, dist, world, rank, local_rank, use_dist)
     if rank == 0:
-        loci = int(summary[4].item())
-        out = {"metric": "candidate loci/s at 200x depth, interval-sharded (BASELINE config 4)", "value": loci / float(t.item()), "unit": "candidate loci/s",
-               "n_gpus": world, "steps": 1, "warmup": 0, "ms_per_step": float(t.item()) * 1e3, "higher_is_better": True, "scaling": "strong",
-               "vs_baseline": None, "dtype": "int32 counts + f64 likelihoods", "data": "synthetic",
-               "config": {"workload": "BASELINE config 4: 30 M loci x 200x over 200 000 intervals of 150 bp on 24 contigs, SNV + indel at 1/10 of config 3's "
-                                      "density, cut 8 ways by interval; streaming surface (host reads in, host records out), shards "
-                                      + ("in turn on one GPU" if world == 1 else f"over {world} GPUs"),
-                          "loci": loci, "reads": int(summary[2].item()), "intervals": 200_000, "contigs": 24, "shards": n_shards},
-               "totals": {"allelesCalled": int(summary[0].item()), "variantsCollapsed": int(summary[1].item()), "readsProcessed": int(summary[2].item()),
-                          "readsSkipped": int(summary[3].item())},
-               "rank0_seconds_inside_the_library": lib_time,
-               "shards_rank0": [{"shard": r, "pieces": len(shards[r]), "loci": loci_shard[r], "seconds": t_shard[r], "loci_per_s": loci_shard[r] / t_shard[r]}
-                                for r in mine]}
-        assert loci == 30_000_000 and out["totals"]["readsProcessed"] == 200_000 * depth
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
@@ -855,6 +891,16 @@ def main():
         c_abi_hung = th.is_alive()
         c_abi_reduce = box.get("r", {"ok": False, "error": "no answer within 90 s"})
 
+    # ---- N > 1: BASELINE's multi-GPU configuration (config 4: 30 M loci x 200x cut 8 ways by interval, STRONG scaling) beside the
+    # weak-scaling `value` (which stays config 2 per GPU, so that the line's value means the same thing at every N): every rank takes its
+    # shards of the 8-way cut in turn, totals reduced.  Outside the timed region; BENCH_CONFIG4=0 skips it (it takes ~2 minutes / N). ----
+    config4_line = None
+    if world > 1 and os.environ.get("BENCH_CONFIG4", "1") != "0":
+        try:
+            config4_line = config4_job(torch, dist, world, rank, local_rank, use_dist)
+        except Exception as e:   # noqa: BLE001  (an extra figure: it must not cost the bench line)
+            config4_line = {"error": str(e)[:300]}
+
     if rank == 0:
         # roofline of the dominant (only) kernel: algorithmic bytes per launch / mean kernel duration from HIP
         # events recorded on the launch stream around every TIME_EVERY-th launch of the timed region
@@ -923,6 +969,8 @@ def main():
             out["shard_check"] = shard_check
         if c_abi_reduce is not None:
             out["c_abi_reduce"] = c_abi_reduce
+        if config4_line is not None:
+            out["config4_strong_scaling"] = config4_line
         if not args.no_end_to_end and world == 1:     # the drop-in boundary's own rates, rank 0 at N=1 only
             out["end_to_end"] = end_to_end(ring[0], cfg, engine)
             try:

@@ -2020,3 +2020,20 @@ def test_flush_views_hand_out_the_rows_the_copying_flushes_return(torch_cuda):
         assert got.tobytes() == want_recs.tobytes() and pair_alleles == want_alleles
         rc = _native.lib.pisces_hip_flush_end_view(c._h, C.byref(rows), C.byref(n), None, None, None, None, None)
         assert rc == _abi.E_STATE        # no flush_begin before it
+
+
+def test_summary_reduce_through_the_c_abi_on_two_devices(torch_cuda):
+    """pisces_hip_comm_init / pisces_hip_reduce_summary with one process per GPU (RCCL over xGMI, bound by the library): two ranks on two
+    devices must both get the sums of what they handed in.  Skipped on a one-GPU box — RCCL refuses two ranks on one device — so that the
+    first node with several GPUs that runs this suite is also the first to run that code (tools/reduce_check.py)."""
+    import os
+    import subprocess
+    import sys
+    if torch_cuda.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", os.path.join(root, "tools", "reduce_check.py")], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("reduce_check rank") == 2
