@@ -759,6 +759,18 @@ def main():
         if use_dist:
             dist.barrier()
 
+    # The K timed steps as ONE HIP graph (pisces_hip_call_tiles_graph_build: the K launches captured in order, replayed with one
+    # submission): the launches then follow each other at the device's pace — a launch call per step through Python leaves ~1.3 us between
+    # 38 us kernels.  Measured (round 4, K = 20): the device-side span per launch is the same 40.3 us either way (kernel 38.8 + the
+    # dispatch gap), and hipGraphLaunch's own host cost makes the wall clock 1 us per step WORSE than the plain loop — what K = 20 shows
+    # in ms_per_step is ~75 us of fixed host <-> device latency around the K launches (event records, the wake-up of the final wait, the
+    # totals' read-back), not launch gaps.  So the plain loop stays the default; BENCH_GRAPH_LAUNCHES=1 replays the graph instead.
+    def tile_batch(i):
+        p = ring[i % RING_BATCHES]
+        return (p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), p.ref_start, p.ref_len, records.data_ptr(), cap, tile_results.data_ptr())
+    use_graph = os.environ.get("BENCH_GRAPH_LAUNCHES") == "1"
+    graph_id = caller.call_tiles_graph_build([tile_batch(args.warmup + i) for i in range(args.steps)]) if use_graph else None
+
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize(dev)
@@ -769,12 +781,13 @@ def main():
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     caller.mark(0, stream.cuda_stream)     # HIP events on the stream the kernel is launched on (torch.cuda.Event would see torch's only)
-    for i in range(args.steps):
-        step(args.warmup + i)
+    if use_graph:
+        caller.call_tiles_graph_launch(graph_id, stream.cuda_stream)
+    else:
+        for i in range(args.steps):
+            step(args.warmup + i)
     caller.mark(1, stream.cuda_stream)
-    torch.cuda.synchronize(dev)
-    caller.synchronize()
-    totals = caller.device_totals()
+    totals = caller.device_totals()        # (waits for the device: hipDeviceSynchronize, then the totals of the K launches)
     summary = torch.tensor([totals["records"], totals["candidate_loci"], totals["called"], totals["tiles"]], dtype=torch.int64)
     if use_dist:
         summary = summary.to(dev)

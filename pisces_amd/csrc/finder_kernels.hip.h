@@ -93,6 +93,13 @@ struct WordBases {
     }
 };
 
+__device__ __forceinline__ uint32_t load_word(const uint8_t* p)   // four bytes at any address (unaligned global access is on)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
 __device__ __forceinline__ bool found_needs_pool(const FoundCandidate& c)
 {
     return c.category != PISCES_CAT_DELETION && c.category != kFoundSpanMark && c.length > kFoundInline;
@@ -231,6 +238,272 @@ __global__ __launch_bounds__(256) void find_emit_kernel(DevReadBatch b, const ui
         f.pool_offset = -1;
         out[slot] = f;
     }
+}
+
+// ---- the wave form of the walk (round 4) ------------------------------------------------------------------------------------------
+// One lane per read runs the M-operation state machine base by base: ~1.2 waves a SIMD, and a wave pays for every branch any of its 64
+// reads takes (106 + 119 us per 80 000 reads of BASELINE config 3's mix, whatever the memory system does).  But the state machine only
+// ever DOES something at an EVENT — a base that cannot be called (N, low quality, N in the reference) or a mismatch: ~3 of a read's 150
+// bases — and what it does between two events is a closed form of the number of matching bases between them (a pending variant grows by
+// at most MaxGapBetweenMNV matches, then closes).  So here a WAVE takes a read: lane l compares the four bases 4 l .. 4 l + 3 of an M
+// operation with the reference in one step (three 4-byte loads a lane for up to 256 bases), a ballot says which lanes hold an event,
+// and the state machine — wave-uniform, i.e. scalar code — hops from event to event.  Same candidates, same order, same records as
+// finder_walk.h's walk (the host form, and the oracle's restatement, check it: tests/test_gpu_parity.py).
+//   find_count_wave_kernel / find_emit_wave_kernel   kReadsPerWave consecutive reads a wave
+template <typename Emit>
+__device__ __forceinline__ void walk_match_op_wave(const ReadView& r, const walk::ReadFrame& f, const uint8_t* __restrict__ ref, int64_t ref_len,
+                                                   const FinderParams& P, int op_read0, int op_len, int op_ref0, int lane, Emit& emit)
+{
+    int run = 0, tail = 0;
+    bool open_left = false;
+    auto close = [&](int at, bool open_right) {   // finder_walk.h walk_match_op's close
+        int len = run;
+        if (tail >= 1) { len -= tail; open_right = false; }
+        if (len < 1) return;
+        const int start_read = op_read0 + at - run, start_ref = op_ref0 + at - run;
+        walk::finish_candidate(r, f, P, len > 1 ? PISCES_CAT_MNV : PISCES_CAT_SNV, start_ref + 1, start_ref, start_read, len, len, -1, open_left, open_right, emit);
+    };
+    int64_t lim = op_len;
+    if ((int64_t)r.read_len - op_read0 < lim) lim = (int64_t)r.read_len - op_read0;
+    if (ref_len - (int64_t)op_ref0 < lim) lim = ref_len - (int64_t)op_ref0;
+    const int walked = lim < 0 ? 0 : (int)lim;
+    int cur = 0;   // bases [0, cur) of the operation have been through the state machine
+    // the callable, matching bases [cur, upto): a pending variant takes them as trailing matches while ShouldBuildUpMNV lets it
+    // (run + 1 <= MaxSizeMNV, tail + 1 <= MaxGapBetweenMNV), the first one it cannot take closes it, and a match with nothing pending
+    // only clears open_left
+    auto matches_until = [&](int upto) {
+        int g = upto - cur;
+        if (g <= 0) return;
+        if (run > 0) {
+            while (g > 0 && P.call_mnvs && run + 1 <= P.max_mnv_length && tail + 1 <= P.max_gap) { run++; tail++; g--; }
+            if (g > 0) { close(upto - g, false); run = 0; tail = 0; }
+        }
+        if (g > 0) open_left = false;
+        cur = upto;
+    };
+    auto event = [&](int i, bool callable) {   // a base that cannot be called, or a callable mismatch (finder_walk.h's step on such a base)
+        matches_until(i);
+        const bool alone_on_last_base = i == op_len - 1 && run == 0;
+        const bool grows = callable && P.call_mnvs && run + 1 <= P.max_mnv_length && tail <= P.max_gap && !alone_on_last_base;
+        if (grows) { run++; tail = 0; }
+        else {
+            close(i, !callable);
+            run = callable ? 1 : 0;
+            tail = 0;
+            open_left = !callable;
+        }
+        cur = i + 1;
+    };
+    const uint8_t* const pb = r.bases + op_read0;
+    const uint8_t* const pq = r.quals + op_read0;
+    const uint8_t* const pf = ref + op_ref0;
+    for (int c0 = 0; c0 < walked; c0 += 256) {
+        const int i0 = c0 + 4 * lane;
+        uint32_t packed = 0;   // bit k: base i0 + k cannot be called; bit 4 + k: it can, and differs from the reference
+        if (i0 < walked) {
+            uint32_t bw, qw, fw;
+            if (walked >= 4) {   // a word that would reach past the operation's bases is taken 1-3 bytes early and shifted
+                const int oc = min(i0, walked - 4), sh = 8 * (i0 - oc);
+                bw = load_word(pb + oc) >> sh; qw = load_word(pq + oc) >> sh; fw = load_word(pf + oc) >> sh;
+            } else {
+                bw = qw = fw = 0;
+                for (int k = 0; k < walked - i0; k++) { bw |= (uint32_t)pb[i0 + k] << (8 * k); qw |= (uint32_t)pq[i0 + k] << (8 * k); fw |= (uint32_t)pf[i0 + k] << (8 * k); }
+            }
+            const int n_here = min(4, walked - i0);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint8_t rb = (uint8_t)(bw >> (8 * k)), fb = (uint8_t)(fw >> (8 * k)), q = (uint8_t)(qw >> (8 * k));
+                const bool callable = walk::is_acgt(rb) && walk::is_acgt(fb) && q >= P.min_bq;
+                if (k < n_here) packed |= !callable ? (1u << k) : (rb != fb ? (16u << k) : 0u);
+            }
+        }
+        unsigned long long ev = __ballot(packed != 0);
+        while (ev) {
+            const int L = __builtin_ctzll(ev);
+            ev &= ev - 1;
+            const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)packed, L);
+#pragma unroll 1
+            for (int k = 0; k < 4; k++)
+                if ((pk >> k) & 0x11u) event(c0 + 4 * L + k, !((pk >> k) & 1u));
+        }
+    }
+    matches_until(walked);
+    close(walked, false);
+}
+
+// ProcessCigarOps (finder_walk.h walk_read) with the M operations walked by the wave
+template <typename Emit>
+__device__ __forceinline__ void walk_read_wave(const ReadView& r, const uint8_t* __restrict__ ref, int64_t ref_len, const FinderParams& P, int lane, Emit& emit)
+{
+    const walk::ReadFrame f = walk::frame_of(r);
+    int in_read = 0, in_ref = r.position - 1;
+    for (int ci = 0; ci < r.n_cigar; ci++) {
+        const uint8_t t = r.cigar_op[ci];
+        const int len = (int)r.cigar_len[ci];
+        if (t == 'M') {
+            if (P.snvs_and_mnvs) walk_match_op_wave(r, f, ref, ref_len, P, in_read, len, in_ref, lane, emit);
+        } else if (t == 'I') {
+            const bool off_contig = (int64_t)in_ref - 1 >= ref_len || in_ref == 0;
+            if (!off_contig && in_read < r.read_len && in_read + len <= r.read_len && r.quals[in_read] >= P.min_bq)
+                walk::finish_candidate(r, f, P, PISCES_CAT_INSERTION, in_ref, in_ref - 1, in_read, len, len + 1, -1, false, false, emit);
+        } else if (t == 'D') {
+            bool flanks_ok = false;
+            if (r.read_len > 0) {
+                const int after = in_read < r.read_len ? r.quals[in_read] : r.quals[in_read - 1];
+                const int before = in_read > 0 ? r.quals[in_read - 1] : after;
+                flanks_ok = before >= P.min_bq && after >= P.min_bq;
+            }
+            if ((int64_t)in_ref + len < ref_len && in_ref >= 1 && flanks_ok)
+                walk::finish_candidate(r, f, P, PISCES_CAT_DELETION, in_ref, in_ref - 1, in_read, len, 1, ci, false, false, emit);
+        } else if (t == 'X' && P.mark_x_spans && len > 0) {
+            FoundCandidate c;
+            c.position = in_ref + 1; c.ref_index = in_ref; c.start_in_read = in_read; c.length = len;
+            c.category = kFoundSpanMark; c.dir = 0; c.well_anchored = c.open_left = c.open_right = 0;
+            c.pad[0] = c.pad[1] = c.pad[2] = 0;
+            emit(c);
+        }
+        if (walk::spans_read(t)) in_read += len;
+        if (walk::spans_ref(t)) in_ref += len;
+    }
+}
+
+constexpr int kReadsPerWave = 8;
+
+__global__ __launch_bounds__(256) void find_count_wave_kernel(DevReadBatch b, const uint8_t* __restrict__ del_dirs, const uint8_t* __restrict__ ref,
+                                                              int64_t ref_len, FinderParams P, int32_t* __restrict__ n_found, int32_t* __restrict__ n_pool)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    for (int k = 0; k < kReadsPerWave; k++) {
+        const int r = wave * kReadsPerWave + k;
+        if (r >= b.n_reads) return;
+        const ReadView v = dev_read_view(b, del_dirs, r);
+        int n = 0, bytes = 0;
+        auto count = [&](const FoundCandidate& c) {
+            if (c.position <= 0) return;
+            n++;
+            if (found_needs_pool(c)) bytes += c.length;
+        };
+        walk_read_wave(v, ref, ref_len, P, lane, count);
+        if (lane == 0) { n_found[r] = n; n_pool[r] = bytes; }
+    }
+}
+
+__global__ __launch_bounds__(256) void find_emit_wave_kernel(DevReadBatch b, const uint8_t* __restrict__ del_dirs, const uint8_t* __restrict__ ref,
+                                                             int64_t ref_len, FinderParams P, const int32_t* __restrict__ slot_first,
+                                                             const int32_t* __restrict__ pool_first, DevFound* __restrict__ out, uint8_t* __restrict__ pool,
+                                                             unsigned int* __restrict__ pool_cursor, int32_t pool_capacity, int32_t* __restrict__ overflow)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    for (int k = 0; k < kReadsPerWave; k++) {
+        const int r = wave * kReadsPerWave + k;
+        if (r >= b.n_reads) return;
+        const ReadView v = dev_read_view(b, del_dirs, r);
+        int slot = slot_first[r];
+        const int slot_end = slot_first[r + 1];
+        int pool_at = pool_first ? pool_first[r] : -1;
+        auto write = [&](const FoundCandidate& c) {   // (wave-uniform: every lane holds the same candidate; the lanes share the stores)
+            if (c.position <= 0) return;
+            if (slot >= slot_end) { if (lane == 0) atomicExch(overflow, 1); return; }
+            const int n_alt = (c.category == PISCES_CAT_DELETION || c.category == kFoundSpanMark) ? 0 : c.length;
+            const uint8_t* src = v.bases + c.start_in_read;
+            int pool_offset = -1;
+            if (n_alt > kFoundInline) {
+                int at;
+                if (pool_first) { at = pool_at; pool_at += n_alt; }
+                else {
+                    unsigned int got = 0;
+                    if (lane == 0) got = atomicAdd(pool_cursor, (unsigned int)n_alt);
+                    at = __builtin_amdgcn_readfirstlane((int)got);
+                }
+                if (at + n_alt <= pool_capacity) {
+                    for (int q = lane; q < n_alt; q += 64) pool[at + q] = src[q];
+                    pool_offset = at;
+                } else if (lane == 0) {
+                    atomicExch(overflow, 1);
+                }
+            }
+            // the record's 64 bytes: FoundCandidate (24), read, pool_offset, alt[32]: lane 0 the head, lanes 0-31 one ALT byte each
+            DevFound* const dst = out + slot;
+            if (lane == 0) {
+                dst->c = c;
+                dst->read = r;
+                dst->pool_offset = pool_offset;
+            }
+            if (lane < kFoundInline) dst->alt[lane] = (lane < n_alt && n_alt <= kFoundInline) ? src[lane] : (uint8_t)0;
+            slot++;
+        };
+        walk_read_wave(v, ref, ref_len, P, lane, write);
+        for (; slot < slot_end; slot++) {   // reserved, unused: a hole
+            DevFound* const dst = out + slot;
+            if (lane == 0) {
+                FoundCandidate hole = {};
+                hole.category = kFoundHole;
+                dst->c = hole;
+                dst->read = r;
+                dst->pool_offset = -1;
+            }
+            if (lane < kFoundInline) dst->alt[lane] = 0;
+        }
+    }
+}
+
+// Exclusive scans of two int32 arrays of any length by many workgroups, in three launches (block sums, their scan, the blocks): the
+// one-workgroup found_scan_kernel above takes 229 us for 400 000 reads — one workgroup's pace — where these take a few microseconds each.
+constexpr int kScanBlock = 8192;   // entries a workgroup of 1024 threads takes: eight a thread
+__global__ __launch_bounds__(1024) void scan_block_sums_kernel(const int32_t* __restrict__ a, const int32_t* __restrict__ b, int32_t n,
+                                                               long long* __restrict__ sums /* [2][blocks] */, int32_t n_blocks)
+{
+    __shared__ long long s_part[2][16];
+    const int base = blockIdx.x * kScanBlock, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    long long sa = 0, sb = 0;
+    for (int i = base + (int)threadIdx.x; i < min(base + kScanBlock, n); i += 1024) { sa += a[i]; sb += b[i]; }
+    for (int d = 32; d; d >>= 1) { sa += __shfl_xor(sa, d); sb += __shfl_xor(sb, d); }
+    if (lane == 0) { s_part[0][w] = sa; s_part[1][w] = sb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long ta = 0, tb = 0;
+        for (int k = 0; k < 16; k++) { ta += s_part[0][k]; tb += s_part[1][k]; }
+        sums[blockIdx.x] = ta;
+        sums[n_blocks + blockIdx.x] = tb;
+    }
+}
+__global__ __launch_bounds__(1024) void scan_block_offsets_kernel(long long* __restrict__ sums, int32_t n_blocks, long long* __restrict__ totals)
+{
+    // (one workgroup, two arrays of at most a few thousand block sums: thread t scans array t)
+    if (threadIdx.x < 2) {
+        long long* s = sums + (size_t)threadIdx.x * n_blocks;
+        long long acc = 0;
+        for (int i = 0; i < n_blocks; i++) { const long long v = s[i]; s[i] = acc; acc += v; }
+        totals[threadIdx.x] = acc;
+    }
+}
+__global__ __launch_bounds__(1024) void scan_apply_kernel(int32_t* __restrict__ a, int32_t* __restrict__ b, int32_t n, const long long* __restrict__ sums, int32_t n_blocks)
+{
+    __shared__ int s_wave[2][16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i0 = blockIdx.x * kScanBlock + (int)threadIdx.x * 8;
+    int va[8], vb[8], ta = 0, tb = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int xa = i0 + k < n ? a[i0 + k] : 0, xb = i0 + k < n ? b[i0 + k] : 0;
+        va[k] = ta; vb[k] = tb;
+        ta += xa; tb += xb;
+    }
+    int xa = ta, xb = tb;   // inclusive scan of the lanes' sums inside the wave
+    for (int d = 1; d < 64; d <<= 1) {
+        const int ya = __shfl_up(xa, d), yb = __shfl_up(xb, d);
+        if (lane >= d) { xa += ya; xb += yb; }
+    }
+    if (lane == 63) { s_wave[0][w] = xa; s_wave[1][w] = xb; }
+    __syncthreads();
+    int wa = 0, wb = 0;
+    for (int k = 0; k < w; k++) { wa += s_wave[0][k]; wb += s_wave[1][k]; }
+    const long long la = sums[blockIdx.x] + wa + xa - ta, lb = sums[n_blocks + blockIdx.x] + wb + xb - tb;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (i0 + k < n) { a[i0 + k] = (int32_t)(la + va[k]); b[i0 + k] = (int32_t)(lb + vb[k]); }
 }
 
 // ---- RegionState.AddCandidate for the records of one batch, on the device ------------------------------------------------------

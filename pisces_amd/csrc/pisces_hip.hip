@@ -142,6 +142,7 @@ struct PiscesHip {
     int64_t ring_used = 0;
     int64_t launches_seen = 0;
     DeviceBuf<unsigned long long> d_totals;
+    unsigned long long* h_totals = nullptr;   // pinned: pisces_hip_device_totals
     DeviceBuf<double> d_qlut;
     DeviceBuf<ulonglong2> d_bq_lut;   // [256] Math.Pow(10, -1 * (int)q / 10f) in fixed point (two 38-bit halves): what a base of quality q adds to the sums
     DeviceBuf<unsigned long long> d_sumq_fix;   // the cells' fixed-point accumulators (accumulate_tiles_kernel)
@@ -359,6 +360,8 @@ struct PiscesHip {
     std::vector<hipGraphExec_t> graphs;       // pisces_hip_call_tiles_graph_build
     std::vector<hipGraph_t> graph_defs;
     int store_waves = 0;                      // development: waves per tile of call_store_tiles_kernel (PISCES_HIP_STORE_WAVES; 0 = by launch size)
+    int finder_wave = 0;                      // PISCES_HIP_FINDER=wave: the candidate walk a wave a read (finder_kernels.hip.h; measured slower: default off)
+    DeviceBuf<long long> d_scan_sums;         // block sums of launch_found_scan
     int device_checks = -1;                   // PISCES_HIP_DEVICE_CHECKS: 1 every host batch is checked on the device (read_prepare_kernel), 0 none, -1 (default) from 65 536 reads up
     bool prep_map_clean = false;              // the block map of read_prepare_kernel is all zero
     DeviceBuf<uint32_t> d_prep_map;
@@ -658,6 +661,7 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         if (const char* v = getenv("PISCES_HIP_MNV_SPLIT")) h->mnv_split = h->mnv_split && atoi(v) != 0;
         if (const char* v = getenv("PISCES_HIP_STORE_SEAL_BYTES")) h->store_seal_bytes = (size_t)std::max(0ll, atoll(v));
         if (const char* v = getenv("PISCES_HIP_DEVICE_CHECKS")) h->device_checks = atoi(v) != 0 ? 1 : 0;
+        if (const char* v = getenv("PISCES_HIP_FINDER")) h->finder_wave = std::string(v) == "wave" ? 1 : 0;
     }
     {
         // MathOperations.QtoP(q) = Math.Pow(10, -1 * q / 10f) for every integer q-score the caller can produce
@@ -791,8 +795,10 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     h->found.done = nullptr;
     h->d_found.release(); h->d_found_pool.release(); h->d_found_slots.release(); h->d_found_pool_first.release();
     h->d_merge_tab.release(); h->d_merge_acc.release();
-    h->d_prep_map.release(); h->d_folded.release(); h->d_span_tiles.release();
+    h->d_scan_sums.release(); h->d_prep_map.release(); h->d_folded.release(); h->d_span_tiles.release();
     h->d_snv[0].release(); h->d_snv[1].release(); h->d_snv_n.release(); h->d_snv_sel.release(); h->d_dirty.release(); h->d_row_idx.release(); h->d_rows.release();
+    if (h->h_totals) (void)hipHostFree(h->h_totals);
+    h->h_totals = nullptr;
     if (h->h_snv_sel) (void)hipHostFree(h->h_snv_sel);
     h->h_snv_sel = nullptr;
     h->d_found_misc.release(); h->d_found_totals.release();

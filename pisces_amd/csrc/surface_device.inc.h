@@ -141,6 +141,9 @@ int32_t pisces_hip_call_tiles_graph_build(PiscesHip* h, const PiscesTileBatch* b
         if (graph) (void)hipGraphDestroy(graph);
         return fail(h, PISCES_E_DEVICE, std::string("call_tiles_graph_build: ") + hipGetErrorString(e));
     }
+    // (the executable graph's own upload now, not inside its first launch: a replay then costs what every later replay costs)
+    if (hipGraphUpload(exec, h->stream) == hipSuccess) (void)hipStreamSynchronize(h->stream);
+    else (void)hipGetLastError();
     h->graph_defs.push_back(graph);
     h->graphs.push_back(exec);
     *graph_id = (int32_t)h->graphs.size() - 1;
@@ -214,8 +217,12 @@ int32_t pisces_hip_device_totals(PiscesHip* h, int64_t out[4], int32_t reset)
     if (!h || !out) return PISCES_E_INVALID_ARG;
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     PISCES_HIP_CHECK(h, hipDeviceSynchronize());   // launches may sit on caller-supplied streams
-    std::vector<unsigned long long> host((size_t)kTotalShards * kTotalStride);
-    PISCES_HIP_CHECK(h, hipMemcpy(host.data(), h->d_totals.p, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    // (into pinned memory: a copy into pageable memory is staged by the runtime, 20-30 us for these 8 KB)
+    constexpr size_t kTotalsBytes = (size_t)kTotalShards * kTotalStride * sizeof(unsigned long long);
+    if (!h->h_totals) PISCES_HIP_CHECK(h, hipHostMalloc((void**)&h->h_totals, kTotalsBytes, hipHostMallocDefault));
+    unsigned long long* const host_p = h->h_totals;
+    PISCES_HIP_CHECK(h, hipMemcpy(host_p, h->d_totals.p, kTotalsBytes, hipMemcpyDeviceToHost));
+    struct { unsigned long long* p; size_t n; unsigned long long operator[](size_t i) const { return p[i]; } size_t size() const { return n; } } host = {host_p, (size_t)kTotalShards * kTotalStride};
     for (int i = 0; i < 4; i++) {
         out[i] = 0;
         for (int sh = 0; sh < kTotalShards; sh++) out[i] += (int64_t)host[sh * kTotalStride + i];

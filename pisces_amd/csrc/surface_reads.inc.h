@@ -330,6 +330,44 @@ static void add_forced_as_candidates(PiscesHip* h, int32_t up_to_position)
     }
 }
 
+// the exclusive scans of the per-read record / pool-byte counts (n entries each, the last one zero: it receives the total), totals[0..1] = the sums
+static int32_t launch_found_scan(PiscesHip* h, int32_t* a, int32_t* b, int32_t n, long long* d_totals)
+{
+    if (n <= 2 * kScanBlock) {
+        hipLaunchKernelGGL(found_scan_kernel, dim3(1), dim3(1024), 0, h->stream, a, b, n, d_totals);
+        return PISCES_OK;
+    }
+    const int32_t n_blocks = (n + kScanBlock - 1) / kScanBlock;
+    PISCES_HIP_CHECK(h, h->d_scan_sums.reserve((size_t)2 * n_blocks));
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)n_blocks), dim3(1024), 0, h->stream, (const int32_t*)a, (const int32_t*)b, n, h->d_scan_sums.p, n_blocks);
+    hipLaunchKernelGGL(scan_block_offsets_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_scan_sums.p, n_blocks, d_totals);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)n_blocks), dim3(1024), 0, h->stream, a, b, n, (const long long*)h->d_scan_sums.p, n_blocks);
+    return PISCES_OK;
+}
+// the count / emit passes of the candidate walk: a wave per read when the M operations are walked (finder_kernels.hip.h, the wave form),
+// a lane per read otherwise (insertions and deletions only: a read is a loop over its CIGAR) or when PISCES_HIP_FINDER=lane asks for it
+static void launch_find_count(PiscesHip* h, const DevReadBatch& db, const uint8_t* d_deldirs, const FinderParams& FP, int32_t nr, int32_t* n_found, int32_t* n_pool)
+{
+    if (FP.snvs_and_mnvs && h->finder_wave) {
+        const unsigned waves = (unsigned)((nr + kReadsPerWave - 1) / kReadsPerWave);
+        hipLaunchKernelGGL(find_count_wave_kernel, dim3((waves + 3) / 4), dim3(256), 0, h->stream, db, d_deldirs, (const uint8_t*)h->d_ref.p, h->ref_len, FP, n_found, n_pool);
+    } else {
+        hipLaunchKernelGGL(find_count_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, h->stream, db, d_deldirs, (const uint8_t*)h->d_ref.p, h->ref_len, FP, n_found, n_pool);
+    }
+}
+static void launch_find_emit(PiscesHip* h, const DevReadBatch& db, const uint8_t* d_deldirs, const FinderParams& FP, int32_t nr, const int32_t* d_slots,
+                             const int32_t* d_pool_first, DevFound* out, uint8_t* pool, unsigned int* misc, int32_t pool_capacity)
+{
+    if (FP.snvs_and_mnvs && h->finder_wave) {
+        const unsigned waves = (unsigned)((nr + kReadsPerWave - 1) / kReadsPerWave);
+        hipLaunchKernelGGL(find_emit_wave_kernel, dim3((waves + 3) / 4), dim3(256), 0, h->stream, db, d_deldirs, (const uint8_t*)h->d_ref.p, h->ref_len, FP, d_slots,
+                           d_pool_first, out, pool, misc, pool_capacity, (int32_t*)(misc + 1));
+    } else {
+        hipLaunchKernelGGL(find_emit_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, h->stream, db, d_deldirs, (const uint8_t*)h->d_ref.p, h->ref_len, FP, d_slots,
+                           d_pool_first, out, pool, misc, pool_capacity, (int32_t*)(misc + 1));
+    }
+}
+
 // Candidate discovery for a read batch that is on the device (find_count / found_scan / find_emit kernels), enqueued on the handle's
 // stream; its records come back into pinned memory and are merged by consume_found when they are needed.  d_slots: the record slots
 // the host reserved per read from the CIGARs (MNV calling off), found_slots / found_pool their totals.
@@ -345,7 +383,6 @@ static int32_t enqueue_candidate_discovery(PiscesHip* h, const DevReadBatch& db,
         h->host_seq = 0;
         h->found.batch = h->batch_seq;
         h->found.split = false;
-        const unsigned grid = (unsigned)((nr + 255) / 256);
         PISCES_HIP_CHECK(h, h->d_found_misc.reserve(4));
         PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_found_misc.p, 0, 4 * sizeof(unsigned int), h->stream));
         const int32_t* d_pool_first = nullptr;
@@ -356,10 +393,8 @@ static int32_t enqueue_candidate_discovery(PiscesHip* h, const DevReadBatch& db,
             PISCES_HIP_CHECK(h, h->d_found_totals.reserve(2));
             PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_found_slots.p + nr, 0, sizeof(int32_t), h->stream));
             PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_found_pool_first.p + nr, 0, sizeof(int32_t), h->stream));
-            hipLaunchKernelGGL(find_count_kernel, dim3(grid), dim3(256), 0, h->stream, db, d_deldirs, (const uint8_t*)h->d_ref.p, h->ref_len, FP,
-                               h->d_found_slots.p, h->d_found_pool_first.p);
-            hipLaunchKernelGGL(found_scan_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_found_slots.p, h->d_found_pool_first.p, nr + 1,
-                               h->d_found_totals.p);
+            launch_find_count(h, db, d_deldirs, FP, nr, h->d_found_slots.p, h->d_found_pool_first.p);
+            { int32_t rcs = launch_found_scan(h, h->d_found_slots.p, h->d_found_pool_first.p, nr + 1, h->d_found_totals.p); if (rcs) return rcs; }
             long long totals[2] = {0, 0};
             PISCES_HIP_CHECK(h, hipMemcpyAsync(totals, h->d_found_totals.p, sizeof(totals), hipMemcpyDeviceToHost, h->stream));
             PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
@@ -372,8 +407,7 @@ static int32_t enqueue_candidate_discovery(PiscesHip* h, const DevReadBatch& db,
         if (found_slots > 0) {
             PISCES_HIP_CHECK(h, h->d_found.reserve((size_t)found_slots));
             PISCES_HIP_CHECK(h, h->d_found_pool.reserve((size_t)found_pool + 16));
-            hipLaunchKernelGGL(find_emit_kernel, dim3(grid), dim3(256), 0, h->stream, db, d_deldirs, (const uint8_t*)h->d_ref.p, h->ref_len, FP, d_slots,
-                               d_pool_first, h->d_found.p, h->d_found_pool.p, h->d_found_misc.p, (int32_t)found_pool, (int32_t*)(h->d_found_misc.p + 1));
+            launch_find_emit(h, db, d_deldirs, FP, nr, d_slots, d_pool_first, h->d_found.p, h->d_found_pool.p, h->d_found_misc.p, (int32_t)found_pool);
             PISCES_HIP_CHECK(h, hipGetLastError());
             // records + pool + {cursor, overflow, merged groups} come back into pinned memory; consume_found waits for them when they are needed
             const bool merge = h->mnv_split || h->device_merge == 1 || (h->device_merge < 0 && found_slots >= 2048);
@@ -894,7 +928,6 @@ int64_t pisces_hip_find_candidates_device(PiscesHip* h, const PiscesReadBatch* b
     db.seq_offset = d_soff.p; db.bases = d_bases.p; db.quals = d_quals.p; db.dirs = batch->directions ? d_dirs.p : nullptr; db.n_reads = nr;
     const uint8_t* dd = batch->deletion_directions ? d_deldirs.p : nullptr;
     const FinderParams FP = {h->cfg.min_base_call_quality, PISCES_ANCHOR_SIZE, snvs_and_mnvs ? 1 : 0, call_mnvs ? 1 : 0, max_mnv_length, max_gap_between_mnv};
-    const unsigned grid = (unsigned)((nr + 255) / 256);
     PISCES_HIP_CHECK(h, d_cnt.reserve((size_t)nr + 1));
     PISCES_HIP_CHECK(h, d_pool_first.reserve((size_t)nr + 1));
     PISCES_HIP_CHECK(h, d_totals.reserve(2));
@@ -902,8 +935,8 @@ int64_t pisces_hip_find_candidates_device(PiscesHip* h, const PiscesReadBatch* b
     PISCES_HIP_CHECK(h, hipMemsetAsync(d_misc.p, 0, 4 * sizeof(unsigned int), h->stream));
     PISCES_HIP_CHECK(h, hipMemsetAsync(d_cnt.p + nr, 0, sizeof(int32_t), h->stream));
     PISCES_HIP_CHECK(h, hipMemsetAsync(d_pool_first.p + nr, 0, sizeof(int32_t), h->stream));
-    hipLaunchKernelGGL(find_count_kernel, dim3(grid), dim3(256), 0, h->stream, db, dd, (const uint8_t*)h->d_ref.p, h->ref_len, FP, d_cnt.p, d_pool_first.p);
-    hipLaunchKernelGGL(found_scan_kernel, dim3(1), dim3(1024), 0, h->stream, d_cnt.p, d_pool_first.p, nr + 1, d_totals.p);
+    launch_find_count(h, db, dd, FP, nr, d_cnt.p, d_pool_first.p);
+    { int32_t rcs = launch_found_scan(h, d_cnt.p, d_pool_first.p, nr + 1, d_totals.p); if (rcs) return rcs; }
     long long totals[2] = {0, 0};
     PISCES_HIP_CHECK(h, hipMemcpyAsync(totals, d_totals.p, sizeof(totals), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
@@ -911,8 +944,7 @@ int64_t pisces_hip_find_candidates_device(PiscesHip* h, const PiscesReadBatch* b
     if (totals[0] > 0) {
         PISCES_HIP_CHECK(h, d_out.reserve((size_t)totals[0]));
         PISCES_HIP_CHECK(h, d_pool.reserve((size_t)totals[1] + 16));
-        hipLaunchKernelGGL(find_emit_kernel, dim3(grid), dim3(256), 0, h->stream, db, dd, (const uint8_t*)h->d_ref.p, h->ref_len, FP, (const int32_t*)d_cnt.p,
-                           (const int32_t*)d_pool_first.p, d_out.p, d_pool.p, d_misc.p, (int32_t)totals[1], (int32_t*)(d_misc.p + 1));
+        launch_find_emit(h, db, dd, FP, nr, (const int32_t*)d_cnt.p, (const int32_t*)d_pool_first.p, d_out.p, d_pool.p, d_misc.p, (int32_t)totals[1]);
         PISCES_HIP_CHECK(h, hipGetLastError());
         std::vector<DevFound> recs((size_t)totals[0]);
         std::vector<uint8_t> pool((size_t)totals[1] + 1);

@@ -352,7 +352,7 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
         hipLaunchKernelGGL(check_directions_kernel, dim3((unsigned)std::min<size_t>((n_seq + 255) / 256, 4096)), dim3(256), 0, h->stream,
                            (const uint8_t*)(d + L.off_dirs), (int64_t)n_seq, B.d_first_error.p);
     if (count_indels)
-        hipLaunchKernelGGL(found_scan_kernel, dim3(1), dim3(1024), 0, h->stream, (int32_t*)(d + L.off_fslots), h->d_found_pool_first.p, nr + 1, h->d_found_totals.p);
+        { int32_t rcs = launch_found_scan(h, (int32_t*)(d + L.off_fslots), h->d_found_pool_first.p, nr + 1, h->d_found_totals.p); if (rcs) return rcs; }
     PISCES_HIP_CHECK(h, hipGetLastError());
     unsigned long long first_error = ~0ull;
     int32_t span[2] = {0x7FFFFFFF, 0};
