@@ -609,6 +609,10 @@ def run_stream_config(args):
     with engine.HipVariantCaller(cfg, device=local_rank) as c, engine.HipVariantCaller(cfg, device=local_rank) as ch:
         c.SetReference(ref)
         ch.SetReference(ref)
+        # SmallVariantCaller's order (SmallVariantCaller.cs:88-105): a read is added, THEN Call(its position - 1) clears what lies behind it.
+        # Stretch by stretch: the reads of stretch k + 1 are added, then the flush up to their first position - 1 takes stretch k — the device
+        # discovers the candidates of k + 1 while the host works on the flush of k.
+        prev_up_to = None
         for a0 in range(a_lo, a_hi, stretch):
             na = min(stretch, a_hi - a0)
             p = synth.make_pileup(na * synth.READ_LEN, depth, seed=seed, device=f"cuda:{local_rank}", first_locus=a0 * synth.READ_LEN, total_loci=n_loci_all,
@@ -616,19 +620,27 @@ def run_stream_config(args):
             batch = synth.mixed_reads(p, seed)[0] if args.config == 3 else synth.reads_of(p, na, first_amplicon=a0)
             n_reads += int(batch.n_reads)
             n_bases += int(batch.n_bases)
-            up_to = origin + (a0 + na) * synth.READ_LEN - 1 if a0 + na < a_hi else None
             dbatch = engine.DeviceReadBatch.from_host(batch, f"cuda:{local_rank}")
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             c.AddDeviceReads(dbatch)
-            n_rec += len(c.CallView(up_to))
+            if prev_up_to is not None:
+                n_rec += len(c.CallView(prev_up_to))
             elapsed += time.perf_counter() - t0
             del dbatch
             t0 = time.perf_counter()
             ch.AddAlleleCounts(batch)
-            n_rec_h += len(ch.CallView(up_to))
+            if prev_up_to is not None:
+                n_rec_h += len(ch.CallView(prev_up_to))
             elapsed_h += time.perf_counter() - t0
+            prev_up_to = origin + (a0 + na) * synth.READ_LEN - 1    # the next stretch's first position - 1
             del p, batch
+        t0 = time.perf_counter()
+        n_rec += len(c.CallView(None))
+        elapsed += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        n_rec_h += len(ch.CallView(None))
+        elapsed_h += time.perf_counter() - t0
         stats = c.Stats()
         host = c.HostTime()
         pcie = c.TransferBytes()

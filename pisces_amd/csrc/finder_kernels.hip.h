@@ -250,9 +250,22 @@ __global__ __launch_bounds__(256) void find_emit_kernel(DevReadBatch b, const ui
 // and the state machine — wave-uniform, i.e. scalar code — hops from event to event.  Same candidates, same order, same records as
 // finder_walk.h's walk (the host form, and the oracle's restatement, check it: tests/test_gpu_parity.py).
 //   find_count_wave_kernel / find_emit_wave_kernel   kReadsPerWave consecutive reads a wave
+struct ChunkWords { uint32_t b, q, f; };   // a lane's four bases, qualities and reference bases of a chunk (already shifted into place)
+// the lane's words of the first chunk of an operation of `walked` >= 4 bases (unconditional loads: a word that would reach past the
+// operation's bases is taken 1-3 bytes early and shifted; a lane past the operation's end loads its last word)
+__device__ __forceinline__ ChunkWords load_first_chunk(const uint8_t* pb, const uint8_t* pq, const uint8_t* pf, int walked, int lane)
+{
+    const int i0 = min(4 * lane, walked - 1);
+    const int oc = min(i0, walked - 4), sh = 8 * (i0 - oc);
+    ChunkWords w;
+    w.b = load_word(pb + oc) >> sh; w.q = load_word(pq + oc) >> sh; w.f = load_word(pf + oc) >> sh;
+    return w;
+}
+
 template <typename Emit>
 __device__ __forceinline__ void walk_match_op_wave(const ReadView& r, const walk::ReadFrame& f, const uint8_t* __restrict__ ref, int64_t ref_len,
-                                                   const FinderParams& P, int op_read0, int op_len, int op_ref0, int lane, Emit& emit)
+                                                   const FinderParams& P, int op_read0, int op_len, int op_ref0, int lane, Emit& emit,
+                                                   const ChunkWords* first_chunk = nullptr /* load_first_chunk's words, requested ahead */)
 {
     int run = 0, tail = 0;
     bool open_left = false;
@@ -302,7 +315,9 @@ __device__ __forceinline__ void walk_match_op_wave(const ReadView& r, const walk
         uint32_t packed = 0;   // bit k: base i0 + k cannot be called; bit 4 + k: it can, and differs from the reference
         if (i0 < walked) {
             uint32_t bw, qw, fw;
-            if (walked >= 4) {   // a word that would reach past the operation's bases is taken 1-3 bytes early and shifted
+            if (c0 == 0 && first_chunk) {
+                bw = first_chunk->b; qw = first_chunk->q; fw = first_chunk->f;
+            } else if (walked >= 4) {   // a word that would reach past the operation's bases is taken 1-3 bytes early and shifted
                 const int oc = min(i0, walked - 4), sh = 8 * (i0 - oc);
                 bw = load_word(pb + oc) >> sh; qw = load_word(pq + oc) >> sh; fw = load_word(pf + oc) >> sh;
             } else {
@@ -447,6 +462,132 @@ __global__ __launch_bounds__(256) void find_emit_wave_kernel(DevReadBatch b, con
             if (lane < kFoundInline) dst->alt[lane] = 0;
         }
     }
+}
+
+// The form that is used: a wave takes SIXTY-FOUR reads.  First every lane reads the descriptors of one of them (position, CIGAR, offsets:
+// the dependent scalar loads that made a read of the kernels above a chain of three memory round trips, here one pass for 64 reads);
+// then the reads are taken in order, their values handed to all lanes with v_readlane.  A read of one M operation — nearly all — has the
+// words of its bases requested while the read before it is walked (load_first_chunk: the round trip lies under the event loop of its
+// predecessor); anything else goes through walk_read_wave as it is.
+template <bool kEmit>
+__global__ __launch_bounds__(256) void find_batch_wave_kernel(DevReadBatch b, const uint8_t* __restrict__ del_dirs, const uint8_t* __restrict__ ref,
+                                                              int64_t ref_len, FinderParams P, int32_t* __restrict__ n_found, int32_t* __restrict__ n_pool,
+                                                              const int32_t* __restrict__ slot_first, const int32_t* __restrict__ pool_first,
+                                                              DevFound* __restrict__ out, uint8_t* __restrict__ pool, unsigned int* __restrict__ pool_cursor,
+                                                              int32_t pool_capacity, int32_t* __restrict__ overflow)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const int r_mine = wave * 64 + lane;
+    const bool valid = r_mine < b.n_reads;
+    // ---- the lanes' own reads
+    int pos = 0, c0 = 0, nc = 0, s0 = 0, n = 0, len0 = 0, rev = 0, slot0 = 0, slot1 = 0, pool0 = -1;
+    uint8_t op0 = 0;
+    if (valid) {
+        pos = b.position[r_mine];
+        c0 = b.cigar_offset[r_mine]; nc = b.cigar_offset[r_mine + 1] - c0;
+        s0 = b.seq_offset[r_mine]; n = b.seq_offset[r_mine + 1] - s0;
+        rev = b.flags[r_mine] & 1;
+        if (nc > 0) { op0 = b.cigar_op[c0]; len0 = (int)b.cigar_len[c0]; }
+        if (kEmit) { slot0 = slot_first[r_mine]; slot1 = slot_first[r_mine + 1]; pool0 = pool_first ? pool_first[r_mine] : -1; }
+    }
+    // the bases of the one M operation that lie on the read and on the contig (walk_match_op's `walked`)
+    long long lim = len0;
+    if ((long long)n < lim) lim = n;
+    if (ref_len - (long long)(pos - 1) < lim) lim = ref_len - (long long)(pos - 1);
+    const int walked = lim < 0 ? 0 : (int)lim;
+    const bool simple = valid && P.snvs_and_mnvs && nc == 1 && op0 == 'M' && walked >= 4 && pos >= 1;
+    const unsigned long long valid_mask = __ballot(valid), simple_mask = __ballot(simple);
+    int my_n = 0, my_bytes = 0;
+    auto issue = [&](int k) {   // the first chunk of (simple) read k
+        const int kp = __builtin_amdgcn_readlane(pos, k), ks = __builtin_amdgcn_readlane(s0, k), kw = __builtin_amdgcn_readlane(walked, k);
+        return load_first_chunk(b.bases + ks, b.quals + ks, ref + (kp - 1), kw, lane);
+    };
+    ChunkWords cur = {0, 0, 0};
+    if (simple_mask) cur = issue(__builtin_ctzll(simple_mask));
+    for (unsigned long long todo = valid_mask; todo; todo &= todo - 1) {
+        const int k = __builtin_ctzll(todo);
+        const int r = wave * 64 + k;
+        const bool k_simple = (simple_mask >> k) & 1ull;
+        // the next simple read's words: requested now, used when this read is done
+        const unsigned long long later = simple_mask & ~((2ull << k) - 1ull);
+        ChunkWords nxt = cur;
+        if (k_simple && later) nxt = issue(__builtin_ctzll(later));
+        __builtin_amdgcn_sched_barrier(0);
+        int cnt = 0, bytes = 0;
+        int slot = kEmit ? __builtin_amdgcn_readlane(slot0, k) : 0;
+        const int slot_end = kEmit ? __builtin_amdgcn_readlane(slot1, k) : 0;
+        int pool_at = kEmit ? __builtin_amdgcn_readlane(pool0, k) : -1;
+        ReadView v;
+        auto handle = [&](const FoundCandidate& c) {   // (wave-uniform)
+            if (c.position <= 0) return;
+            if (!kEmit) {
+                cnt++;
+                if (found_needs_pool(c)) bytes += c.length;
+                return;
+            }
+            if (slot >= slot_end) { if (lane == 0) atomicExch(overflow, 1); return; }
+            const int n_alt = (c.category == PISCES_CAT_DELETION || c.category == kFoundSpanMark) ? 0 : c.length;
+            const uint8_t* src = v.bases + c.start_in_read;
+            int pool_offset = -1;
+            if (n_alt > kFoundInline) {
+                int at;
+                if (pool_first) { at = pool_at; pool_at += n_alt; }
+                else {
+                    unsigned int got = 0;
+                    if (lane == 0) got = atomicAdd(pool_cursor, (unsigned int)n_alt);
+                    at = __builtin_amdgcn_readfirstlane((int)got);
+                }
+                if (at + n_alt <= pool_capacity) {
+                    for (int q = lane; q < n_alt; q += 64) pool[at + q] = src[q];
+                    pool_offset = at;
+                } else if (lane == 0) {
+                    atomicExch(overflow, 1);
+                }
+            }
+            DevFound* const dst = out + slot;
+            if (lane == 0) {
+                dst->c = c;
+                dst->read = r;
+                dst->pool_offset = pool_offset;
+            }
+            if (lane < kFoundInline) dst->alt[lane] = (lane < n_alt && n_alt <= kFoundInline) ? src[lane] : (uint8_t)0;
+            slot++;
+        };
+        if (k_simple) {
+            const int kp = __builtin_amdgcn_readlane(pos, k), ks = __builtin_amdgcn_readlane(s0, k), kn = __builtin_amdgcn_readlane(n, k);
+            const int kc = __builtin_amdgcn_readlane(c0, k), kl = __builtin_amdgcn_readlane(len0, k);
+            v.position = kp; v.n_cigar = 1; v.cigar_op = b.cigar_op + kc; v.cigar_len = b.cigar_len + kc; v.read_len = kn;
+            v.bases = b.bases + ks; v.quals = b.quals + ks; v.dirs = b.dirs ? b.dirs + ks : nullptr;
+            v.del_dirs = del_dirs ? del_dirs + 2 * (size_t)kc : nullptr;
+            v.is_reverse = __builtin_amdgcn_readlane(rev, k);
+            walk::ReadFrame f;   // frame_of for a read of one M operation
+            f.end_position = kp + kl - 1;
+            f.max_position = kl > 0 ? kp + kl - 1 : kp - 1;
+            f.first_op = f.last_op = 'M';
+            walk_match_op_wave(v, f, ref, ref_len, P, 0, kl, kp - 1, lane, handle, &cur);
+        } else {
+            v = dev_read_view(b, del_dirs, r);
+            walk_read_wave(v, ref, ref_len, P, lane, handle);
+        }
+        if (!kEmit) {
+            if (lane == k) { my_n = cnt; my_bytes = bytes; }
+        } else {
+            for (; slot < slot_end; slot++) {   // reserved, unused: a hole
+                DevFound* const dst = out + slot;
+                if (lane == 0) {
+                    FoundCandidate hole = {};
+                    hole.category = kFoundHole;
+                    dst->c = hole;
+                    dst->read = r;
+                    dst->pool_offset = -1;
+                }
+                if (lane < kFoundInline) dst->alt[lane] = 0;
+            }
+        }
+        if (k_simple) cur = nxt;
+    }
+    if (!kEmit && valid) { n_found[r_mine] = my_n; n_pool[r_mine] = my_bytes; }
 }
 
 // Exclusive scans of two int32 arrays of any length by many workgroups, in three launches (block sums, their scan, the blocks): the

@@ -293,7 +293,9 @@ struct PiscesHip {
         int64_t n_slots = 0, pool_bytes = 0;
         std::vector<int32_t> order;          // consume_found: group of each first-arrival record index
         uint32_t batch = 0;                  // the batch's sequence number (arrival stamps)
+        int32_t min_position = 0;            // lowest read position of the batch, 0 = unknown (a flush below it need not wait for the records)
         bool split = false;                  // the plain SNV groups went to the SNV store (misc[3] of them)
+        bool split_counted = false;          // ... and a sweep of the store has counted them since (snv_ub is exact: nothing to correct)
     } found;
 
     // MNV calling on, SPLIT FORM (surface_flush.inc.h): the fully anchored SNV groups of the read walk stay in device memory (the SNV store,
@@ -661,7 +663,7 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         if (const char* v = getenv("PISCES_HIP_MNV_SPLIT")) h->mnv_split = h->mnv_split && atoi(v) != 0;
         if (const char* v = getenv("PISCES_HIP_STORE_SEAL_BYTES")) h->store_seal_bytes = (size_t)std::max(0ll, atoll(v));
         if (const char* v = getenv("PISCES_HIP_DEVICE_CHECKS")) h->device_checks = atoi(v) != 0 ? 1 : 0;
-        if (const char* v = getenv("PISCES_HIP_FINDER")) h->finder_wave = std::string(v) == "wave" ? 1 : 0;
+        if (const char* v = getenv("PISCES_HIP_FINDER")) h->finder_wave = std::string(v) == "wave" ? 1 : std::string(v) == "batch" ? 2 : 0;
     }
     {
         // MathOperations.QtoP(q) = Math.Pow(10, -1 * q / 10f) for every integer q-score the caller can produce

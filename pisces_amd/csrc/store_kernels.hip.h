@@ -269,7 +269,7 @@ struct PrepareArgs {
     int32_t* n_found;                   // [n_reads + 1] (count_indels): candidate records / pool bytes of every read, scanned afterwards
     int32_t* n_pool;
     unsigned long long* first_error;    // read index * 8 + code of the first read that is refused (atomicMin; all ones: none)
-    int32_t* key_span;                  // [0] lowest, [1] highest block key touched
+    int32_t* key_span;                  // [0] lowest, [1] highest block key touched, [2] lowest read position
 };
 // bits [a, b] of the block map; a bit that is set already (seen through a load that goes past this XCD's L2, where a stale line would
 // show zero for the rest of the launch) costs no atomic: same-address atomics from eight XCDs serialise at 0.1-0.2 us each
@@ -291,10 +291,11 @@ __device__ __forceinline__ long long prep_shfl64(long long v, int src_lane)
 __global__ __launch_bounds__(256) void read_prepare_kernel(PrepareArgs A)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    int k_lo = 0x7FFFFFFF, k_hi = 0;
+    int k_lo = 0x7FFFFFFF, k_hi = 0, p_lo = 0x7FFFFFFF;
     int64_t run_a = 1, run_b = 0;   // the run of keys this read touches (empty)
     if (r < A.n_reads) {
         int code = 0;
+        p_lo = A.position[r];
         const int64_t c0 = A.cigar_offset[r], c1 = A.cigar_offset[r + 1], s0 = A.seq_offset[r], s1 = A.seq_offset[r + 1];
         const int32_t pos0 = A.position[r];
         const int64_t nc = c1 - c0, n = s1 - s0;
@@ -383,7 +384,9 @@ __global__ __launch_bounds__(256) void read_prepare_kernel(PrepareArgs A)
     for (int d = 32; d >= 1; d >>= 1) {
         k_lo = min(k_lo, __shfl_xor(k_lo, d, 64));
         k_hi = max(k_hi, __shfl_xor(k_hi, d, 64));
+        p_lo = min(p_lo, __shfl_xor(p_lo, d, 64));
     }
+    if ((threadIdx.x & 63) == 0 && p_lo < __hip_atomic_load(&A.key_span[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&A.key_span[2], p_lo);
     if ((threadIdx.x & 63) == 0 && k_hi > 0) {
         if (k_lo < __hip_atomic_load(&A.key_span[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&A.key_span[0], k_lo);
         if (k_hi > __hip_atomic_load(&A.key_span[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&A.key_span[1], k_hi);

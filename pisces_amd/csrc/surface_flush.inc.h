@@ -767,6 +767,7 @@ static int32_t snv_store_sweep(PiscesHip* h, const uint32_t* d_bm, int32_t bm_fi
     h->split_stats[3] += 1;
     h->snv_cur = o;
     h->snv_ub = (int64_t)n_kept;
+    if (h->found.in_flight && h->found.split) h->found.split_counted = true;   // (a batch whose records are still to be taken: its groups are in n_kept)
     return PISCES_OK;
 }
 
@@ -1461,7 +1462,11 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
     if (n_cand) *n_cand = 0;
     if (allele_bytes) *allele_bytes = 0;
     if (h->async.state != 0) return fail(h, PISCES_E_STATE, "flush: pisces_hip_flush_begin is waiting for its pisces_hip_flush_end");
-    { int32_t rcf = consume_found(h); if (rcf) return rcf; }
+    // The candidates of the last batch are waited for unless every read of it starts behind upTo: then none of them lies in a block this
+    // flush clears, nor among the candidates it may take from held blocks (SNVs / MNVs that end at or before upTo) — and a host that adds
+    // the next stretch of reads before it calls up to their first position (SmallVariantCaller's LastClearedPosition) has the device
+    // discover that stretch's candidates under this flush's host work.
+    if (!(up_to_position >= 0 && h->found.in_flight && h->found.min_position > up_to_position && !h->pending_valid)) { int32_t rcf = consume_found(h); if (rcf) return rcf; }
     const bool final_flush = up_to_position < 0;
     const bool replay = h->pending_valid && h->pending_up_to == up_to_position;
     if (!replay) {
@@ -1953,7 +1958,7 @@ int32_t pisces_hip_flush_begin(PiscesHip* h, int32_t up_to_position)
     struct InBegin { bool& f; explicit InBegin(bool& x) : f(x) { f = true; } ~InBegin() { f = false; } } in_begin(h->in_flush_begin);
     { int32_t rcp = refuse_while_batch_is_open(h, "flush_begin"); if (rcp) return rcp; }
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
-    { int32_t rcf = consume_found(h); if (rcf) return rcf; }
+    if (!(up_to_position >= 0 && h->found.in_flight && h->found.min_position > up_to_position)) { int32_t rcf = consume_found(h); if (rcf) return rcf; }
     const bool final_flush = up_to_position < 0;
     auto& A = h->async;
     // the batch GetCandidatesToProcess would build (as pisces_hip_flush_ex)

@@ -348,7 +348,10 @@ static int32_t launch_found_scan(PiscesHip* h, int32_t* a, int32_t* b, int32_t n
 // a lane per read otherwise (insertions and deletions only: a read is a loop over its CIGAR) or when PISCES_HIP_FINDER=lane asks for it
 static void launch_find_count(PiscesHip* h, const DevReadBatch& db, const uint8_t* d_deldirs, const FinderParams& FP, int32_t nr, int32_t* n_found, int32_t* n_pool)
 {
-    if (FP.snvs_and_mnvs && h->finder_wave) {
+    if (FP.snvs_and_mnvs && h->finder_wave == 2) {
+        hipLaunchKernelGGL(find_batch_wave_kernel<false>, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, h->stream, db, d_deldirs, (const uint8_t*)h->d_ref.p, h->ref_len, FP,
+                           n_found, n_pool, (const int32_t*)nullptr, (const int32_t*)nullptr, (DevFound*)nullptr, (uint8_t*)nullptr, (unsigned int*)nullptr, 0, (int32_t*)nullptr);
+    } else if (FP.snvs_and_mnvs && h->finder_wave) {
         const unsigned waves = (unsigned)((nr + kReadsPerWave - 1) / kReadsPerWave);
         hipLaunchKernelGGL(find_count_wave_kernel, dim3((waves + 3) / 4), dim3(256), 0, h->stream, db, d_deldirs, (const uint8_t*)h->d_ref.p, h->ref_len, FP, n_found, n_pool);
     } else {
@@ -358,7 +361,10 @@ static void launch_find_count(PiscesHip* h, const DevReadBatch& db, const uint8_
 static void launch_find_emit(PiscesHip* h, const DevReadBatch& db, const uint8_t* d_deldirs, const FinderParams& FP, int32_t nr, const int32_t* d_slots,
                              const int32_t* d_pool_first, DevFound* out, uint8_t* pool, unsigned int* misc, int32_t pool_capacity)
 {
-    if (FP.snvs_and_mnvs && h->finder_wave) {
+    if (FP.snvs_and_mnvs && h->finder_wave == 2) {
+        hipLaunchKernelGGL(find_batch_wave_kernel<true>, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, h->stream, db, d_deldirs, (const uint8_t*)h->d_ref.p, h->ref_len, FP,
+                           (int32_t*)nullptr, (int32_t*)nullptr, d_slots, d_pool_first, out, pool, misc, pool_capacity, (int32_t*)(misc + 1));
+    } else if (FP.snvs_and_mnvs && h->finder_wave) {
         const unsigned waves = (unsigned)((nr + kReadsPerWave - 1) / kReadsPerWave);
         hipLaunchKernelGGL(find_emit_wave_kernel, dim3((waves + 3) / 4), dim3(256), 0, h->stream, db, d_deldirs, (const uint8_t*)h->d_ref.p, h->ref_len, FP, d_slots,
                            d_pool_first, out, pool, misc, pool_capacity, (int32_t*)(misc + 1));
@@ -383,6 +389,8 @@ static int32_t enqueue_candidate_discovery(PiscesHip* h, const DevReadBatch& db,
         h->host_seq = 0;
         h->found.batch = h->batch_seq;
         h->found.split = false;
+        h->found.split_counted = false;
+        h->found.min_position = 0;
         PISCES_HIP_CHECK(h, h->d_found_misc.reserve(4));
         PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_found_misc.p, 0, 4 * sizeof(unsigned int), h->stream));
         const int32_t* d_pool_first = nullptr;
@@ -486,7 +494,7 @@ static int32_t consume_found(PiscesHip* h)
         if (n_groups > h->found.n_slots) return fail(h, PISCES_E_DEVICE, "add_reads: the merged candidate records of the device are inconsistent");
         if (h->found.split) {   // the plain SNV groups of the batch are in the SNV store: its size is exact again
             if ((int64_t)misc[3] + n_groups > h->found.n_slots) return fail(h, PISCES_E_DEVICE, "add_reads: the merged candidate records of the device are inconsistent");
-            h->snv_ub -= h->found.n_slots - (int64_t)misc[3];
+            if (!h->found.split_counted) h->snv_ub -= h->found.n_slots - (int64_t)misc[3];
             h->split_stats[0] += (int64_t)misc[3];
         }
         h->pcie[2] += n_groups * (int64_t)sizeof(DevMerged) + h->found.pool_bytes;

@@ -304,17 +304,18 @@ static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const Sto
 // touched blocks; then that span's bits).  found_slots / found_pool: the candidate-record slots (MNV calling off), scanned in place at
 // d + L.off_fslots.
 static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& L, int32_t nr, size_t n_cig, size_t n_seq, bool has_dirs, bool has_deldirs,
-                                   bool count_indels, int64_t* found_slots, int64_t* found_pool, std::vector<int32_t>& touched, int32_t* max_key)
+                                   bool count_indels, int64_t* found_slots, int64_t* found_pool, std::vector<int32_t>& touched, int32_t* max_key, int32_t* min_position)
 {
     *found_slots = *found_pool = 0;
     *max_key = 0;
+    *min_position = 0;
     touched.clear();
     const int32_t bs = h->cfg.block_size;
     const int64_t n_block_bits = (0x7FFFFFFFll + bs - 1) / bs + 2;
     if (n_block_bits > (1ll << 27)) return fail(h, PISCES_E_UNSUPPORTED, "add_reads: a batch on the device needs a block size of 16 positions or more");
     const size_t map_words = (size_t)((n_block_bits + 31) / 32);
     auto& B = h->bam;   // (the block map and the first-error word of the BAM surface: the same roles)
-    PISCES_HIP_CHECK(h, h->d_prep_map.reserve(map_words + 4));
+    PISCES_HIP_CHECK(h, h->d_prep_map.reserve(map_words + 8));
     PISCES_HIP_CHECK(h, B.d_first_error.reserve(1));
     PISCES_HIP_CHECK(h, B.d_totals64.reserve(8));
     PISCES_HIP_CHECK(h, h->d_found_pool_first.reserve((size_t)nr + 1));
@@ -325,7 +326,7 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
         PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_prep_map.p, 0, map_words * sizeof(uint32_t), h->stream));
         h->prep_map_clean = true;
     }
-    const int32_t span_init[2] = {0x7FFFFFFF, 0};
+    const int32_t span_init[3] = {0x7FFFFFFF, 0, 0x7FFFFFFF};
     { int32_t rcu = meta_upload(h, d_span, span_init, sizeof(span_init)); if (rcu) return rcu; }
     PISCES_HIP_CHECK(h, hipMemsetAsync(B.d_first_error.p, 0xFF, sizeof(unsigned long long), h->stream));
     PrepareArgs A;
@@ -355,7 +356,7 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
         { int32_t rcs = launch_found_scan(h, (int32_t*)(d + L.off_fslots), h->d_found_pool_first.p, nr + 1, h->d_found_totals.p); if (rcs) return rcs; }
     PISCES_HIP_CHECK(h, hipGetLastError());
     unsigned long long first_error = ~0ull;
-    int32_t span[2] = {0x7FFFFFFF, 0};
+    int32_t span[3] = {0x7FFFFFFF, 0, 0x7FFFFFFF};
     long long totals[2] = {0, 0};
     PISCES_HIP_CHECK(h, hipMemcpyAsync(&first_error, B.d_first_error.p, sizeof(first_error), hipMemcpyDeviceToHost, h->stream));
     PISCES_HIP_CHECK(h, hipMemcpyAsync(span, d_span, sizeof(span), hipMemcpyDeviceToHost, h->stream));
@@ -387,6 +388,7 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
     if (totals[0] > 0x7FFFFFF0ll || totals[1] > 0x7FFFFFF0ll) return fail(h, PISCES_E_INVALID_ARG, "add_reads: too many insertions / deletions in one batch");
     *found_slots = totals[0];
     *found_pool = totals[1];
+    *min_position = span[2] == 0x7FFFFFFF ? 0 : span[2];
     return PISCES_OK;
 }
 
@@ -395,7 +397,7 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
 // slots the host pass made (uploaded here), or nullptr when they were made on the device.
 static int32_t store_finish_add(PiscesHip* h, StorePlace& pl, int32_t rc, uint8_t* d, const StageLayout& L, int32_t nr, size_t n_cig, size_t n_seq, bool has_dirs,
                                 bool has_deldirs, bool find_on_device, int64_t found_slots, int64_t found_pool, const int32_t* fslots_host,
-                                const std::vector<int32_t>& touched, int32_t max_key)
+                                const std::vector<int32_t>& touched, int32_t max_key, int32_t min_position = 0)
 {
     const int32_t bs = h->cfg.block_size;
     DevReadBatch db;
@@ -422,6 +424,7 @@ static int32_t store_finish_add(PiscesHip* h, StorePlace& pl, int32_t rc, uint8_
         }
         if (rc == PISCES_OK)
             rc = enqueue_candidate_discovery(h, db, has_deldirs ? d + L.off_deldirs : nullptr, nr, (const int32_t*)(d + L.off_fslots), found_slots, found_pool);
+        h->found.min_position = min_position;   // (a flush up to a position below every read of this batch need not wait for its candidates)
     }
     { int32_t rcs = stage_release(h); if (rc == PISCES_OK) rc = rcs; }   // (transfers out of the pinned buffer may be in flight whatever happened after them)
     if (rc) {
@@ -478,13 +481,13 @@ static int32_t add_reads_store(PiscesHip* h, const PiscesReadBatch* batch)
     std::vector<int32_t>& touched = h->touched_keys;
     touched.clear();
     int64_t found_slots = 0, found_pool = 0;
-    int32_t max_key = 0;
+    int32_t max_key = 0, min_position = 0;
     // A large batch: the checks and the bookkeeping run on the device behind the upload (read_prepare_kernel) — a host pass over tens of
     // millions of CIGARs is a second of one core, longer than the transfer it used to hide under.  (PISCES_HIP_DEVICE_CHECKS=0 / 1 forces either.)
     const bool checked_on_device = h->device_checks == 1 || (h->device_checks < 0 && nr >= (1 << 16));
     if (checked_on_device) {
         if (rc == PISCES_OK) rc = store_device_checks(h, d, L, nr, n_cig, n_seq, batch->directions != nullptr, batch->deletion_directions != nullptr, count_indels,
-                                                      &found_slots, &found_pool, touched, &max_key);
+                                                      &found_slots, &found_pool, touched, &max_key, &min_position);
     } else {
     // ---- the pass over the CIGARs, under the transfer
     auto op_ref = [](uint8_t t) { return t == 'M' || t == 'D' || t == 'N' || t == '=' || t == 'X'; };
@@ -567,8 +570,12 @@ static int32_t add_reads_store(PiscesHip* h, const PiscesReadBatch* batch)
     fslots[(size_t)nr] = (int32_t)found_slots;
     if (rc == PISCES_OK && bad) rc = fail(h, PISCES_E_INVALID_ARG, bad);
     }   // (the host's pass over the CIGARs)
+    if (!checked_on_device && nr > 0) {
+        min_position = batch->position[0];
+        for (int32_t i = 1; i < nr; i++) min_position = std::min(min_position, batch->position[i]);
+    }
     return store_finish_add(h, pl, rc, d, L, nr, n_cig, n_seq, batch->directions != nullptr, batch->deletion_directions != nullptr, find_on_device, found_slots,
-                            found_pool, checked_on_device ? nullptr : fslots.data(), touched, max_key);
+                            found_pool, checked_on_device ? nullptr : fslots.data(), touched, max_key, min_position);
 }
 
 // pisces_hip_add_reads for a batch in device memory: its arrays are copied into the segment's blob (or, for a small batch, the staging
@@ -620,9 +627,9 @@ int32_t pisces_hip_add_device_reads(PiscesHip* h, const PiscesReadBatch* batch, 
     std::vector<int32_t>& touched = h->touched_keys;
     touched.clear();
     int64_t found_slots = 0, found_pool = 0;
-    int32_t max_key = 0;
-    if (rc == PISCES_OK) rc = store_device_checks(h, d, L, nr, n_cig, n_seq, has_dirs, has_deldirs, count_indels, &found_slots, &found_pool, touched, &max_key);
-    return store_finish_add(h, pl, rc, d, L, nr, n_cig, n_seq, has_dirs, has_deldirs, find_on_device, found_slots, found_pool, nullptr, touched, max_key);
+    int32_t max_key = 0, min_position = 0;
+    if (rc == PISCES_OK) rc = store_device_checks(h, d, L, nr, n_cig, n_seq, has_dirs, has_deldirs, count_indels, &found_slots, &found_pool, touched, &max_key, &min_position);
+    return store_finish_add(h, pl, rc, d, L, nr, n_cig, n_seq, has_dirs, has_deldirs, find_on_device, found_slots, found_pool, nullptr, touched, max_key, min_position);
     });
 }
 

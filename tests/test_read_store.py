@@ -476,3 +476,48 @@ def test_checks_on_the_device_refuse_what_the_host_pass_refuses(torch_cuda):
                 add(_abi.ReadBatch([{"pos": 996, "seq": "ACGTACGT", "cigar": [("M", 8)], "quals": [30] * 8, "reverse": True},
                                     {"pos": 5_000_001, "seq": "ACGT", "cigar": [("M", 4)], "quals": [30] * 4, "reverse": False}]))
                 assert c.GetCounts(996, 8).sum() == 8 and c.GetCounts(5_000_001, 4).sum() == 4 and c.Stats()["reads"] == 3
+
+
+@pytest.mark.parametrize("call_mnvs", [0, 1], ids=["snv_indel", "mnv"])
+def test_reads_added_ahead_of_the_flush_that_clears_what_lies_behind_them(torch_cuda, call_mnvs):
+    """SmallVariantCaller adds a read and THEN calls up to its position - 1 (SmallVariantCaller.cs:88-105).  Stretch by stretch that is:
+    add the reads of stretch k + 1, flush up to their first position - 1.  Such a flush does not wait for the candidates of the stretch
+    just added (every read of it starts behind upTo), so the device discovers them under the flush's host work — and the records must be
+    the ones the add-then-flush order gives: BASELINE config 3's mix (SNVs, MNVs, insertions, deletions at 2000x), six stretches."""
+    from pisces_amd import engine, synth
+    seed, depth, n_amp, per = 37, 1200, 24, 4
+    cfg = _abi.default_config(call_mnvs=call_mnvs, max_mnv_length=3, max_gap_between_mnv=1)
+    n_loci = n_amp * synth.READ_LEN
+    ref = synth.reference_of(n_loci, seed, device="cuda")
+    origin = synth.READ_LEN + 1
+    stretches = []
+    for a0 in range(0, n_amp, per):
+        p = synth.make_pileup(per * synth.READ_LEN, depth, seed=seed, device="cuda", first_locus=a0 * synth.READ_LEN, total_loci=n_loci, with_tuples=False)
+        stretches.append((synth.mixed_reads(p, seed)[0], origin + (a0 + per) * synth.READ_LEN - 1))
+
+    def run(ahead, device_fed):
+        recs, alleles = [], []
+        with engine.HipVariantCaller(cfg) as c:
+            c.SetReference(ref)
+            add = c.AddDeviceReads if device_fed else c.AddAlleleCounts
+            prev = None
+            for batch, up_to in stretches:
+                if not ahead and prev is not None:
+                    pass
+                add(batch)
+                if ahead:
+                    if prev is not None:
+                        r, a = c.CallWithAlleles(prev, capacity=1 << 15)
+                        recs.append(r); alleles += a
+                    prev = up_to
+                else:
+                    r, a = c.CallWithAlleles(up_to, capacity=1 << 15)
+                    recs.append(r); alleles += a
+            r, a = c.CallWithAlleles(None, capacity=1 << 15)
+            recs.append(r); alleles += a
+            return np.concatenate(recs), alleles, c.Stats()
+    want = run(False, False)
+    assert len(want[0]) >= n_loci
+    for ahead, device_fed in ((True, False), (True, True)):
+        got = run(ahead, device_fed)
+        assert got[0].tobytes() == want[0].tobytes() and got[1] == want[1] and got[2] == want[2], (ahead, device_fed)
