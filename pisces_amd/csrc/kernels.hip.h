@@ -1374,6 +1374,8 @@ __host__ __device__ inline int candidate_total_coverage(const DevCandidate& c, c
     return spanning_coverage(c, counts, expect_stitched).total;
 }
 
+enum { kSpanningEveryRecord = 0, kSpanningCallableRecords = 1, kSpanningFlagsOnly = 2 };   // call_spanning_kernel's `wanted`
+
 // IAlleleCaller's ProcessVariant + IsCallable for host-supplied candidates (one lane each): insertions / deletions always; with MNV
 // calling on also the SNV and MNV candidates of the read walk and the Reference alleles that MNV reallocation touched
 // (AlleleCaller.cs:60-141).  Point alleles (SNV, Reference) go through the tile kernels' own process_point_allele.
@@ -1381,12 +1383,21 @@ __global__ __launch_bounds__(64) void call_spanning_kernel(
     const DevCandidate* __restrict__ cands, int32_t n, const int32_t* __restrict__ counts_tensor, const uint8_t* __restrict__ alleles,
     const uint8_t* __restrict__ ref, int64_t ref_len /* ref[i] = position i+1 */, int32_t expect_stitched,
     PiscesCalledAllele* __restrict__ out, uint8_t* __restrict__ callable_out, DeviceParams P,
-    const double* __restrict__ sumq = nullptr /* NoiseModel.Window */, const int32_t* __restrict__ counts_folded = nullptr)
+    const double* __restrict__ sumq = nullptr /* NoiseModel.Window */, const int32_t* __restrict__ counts_folded = nullptr,
+    int32_t wanted = kSpanningEveryRecord)
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     const DevCandidate c = cands[i];
     const CountsView counts(counts_tensor, counts_folded);
+    // What the caller reads back: IsCallable alone (the MNV pass: a failed MNV goes to the reallocator with its candidate, not its record),
+    // or the records of the callable alleles (nothing looks at the record of an allele that is not callable unless it is a forced one).
+    // An allele stops at the first IsCallable test it fails then: most candidates of a deep batch are one- and two-read errors below the
+    // frequency threshold, and the q-score and strand-bias evaluations they would run are the long ones.
+    const bool flags_only = wanted == kSpanningFlagsOnly, every_record = wanted == kSpanningEveryRecord;
+    // the memo tables of the tile kernels' call phase (flat noise, Poisson / Extended strand bias), every entry requested up front; a
+    // miss takes the evaluation the table was filled with
+    const bool tabs = !sumq && tables_complete(P);
     if (c.category == PISCES_CAT_SNV || c.category == PISCES_CAT_REFERENCE) {
         // CalculateSinglePoint :49-98 over the anchor-resolved counts; AlleleSupport is the candidate's (AlleleHelper.Map)
         const bool isRef = c.category == PISCES_CAT_REFERENCE;
@@ -1420,9 +1431,27 @@ __global__ __launch_bounds__(64) void call_spanning_kernel(
                 for (int k = 0; k < 5; k++) sum += get_base_quality_sum(sumq, c.start_idx, cca[k], d, 0, -1, false);
             wlevel = window_level(sum, pc.total);
         }
-        const bool ok = process_point_allele<true, true>(pc, c.position, a, isRef, rt, ref, 0, ref_len, P, r, nullptr, 0, nullptr, sumq ? &wlevel : nullptr);
-        out[i] = r;
+        if (!tabs) {
+            const bool ok = process_point_allele<true, true>(pc, c.position, a, isRef, rt, ref, 0, ref_len, P, r, nullptr, 0, nullptr, sumq ? &wlevel : nullptr);
+            out[i] = r;
+            callable_out[i] = ok ? 1 : 0;
+            return;
+        }
+        bool ok = isRef || variant_passes_frequency(pc, P);
+        if (!ok && !every_record) { callable_out[i] = 0; return; }
+        const AlleleTables tb = request_allele_tables(isRef, pc.support, pc.total, pc.refsup, pc.cov, pc.sup, P);
+        int vq = 0;
+        if (pc.support > 0 && pc.total != 0 && !poisson_qscore_try(pc.support, pc.total, P, tb, vq)) vq = poisson_qscore(pc.support, pc.total, P);
+        if (!isRef && vq < P.min_vq) ok = false;
         callable_out[i] = ok ? 1 : 0;
+        if (flags_only || (!ok && !every_record)) return;
+        SbResult sb = {0.0, 0, 0, 0};
+        if (pc.support > 0 && !strand_bias_try(pc.cov, pc.sup, P, tb, sb.bias_score, sb.acceptable, sb.var_both, sb.cov_both))
+            sb = strand_bias<true>(pc.cov, pc.sup, P);
+        const GqPre g = {tb.gq_idx, tb.gq_cap};
+        if (!finish_allele<true>(pc, c.position, a, isRef, rt, vq, sb, ref, 0, ref_len, P, r, nullptr, 0, nullptr, &g))
+            finish_allele<false>(pc, c.position, a, isRef, rt, vq, sb, ref, 0, ref_len, P, r, nullptr, 0);
+        out[i] = r;
         return;
     }
     const int length = c.category == PISCES_CAT_INSERTION ? c.alt_len - 1 : c.category == PISCES_CAT_DELETION ? c.ref_len - 1 : c.alt_len;
@@ -1434,10 +1463,18 @@ __global__ __launch_bounds__(64) void call_spanning_kernel(
     int refsup = total - support;
     if (refsup < 0) refsup = 0;
 
+    // IsCallable (AlleleCaller.cs:236-258), the tests that precede the q-score
+    const float freq = frequency_f(support, total);
+    bool callable = true;
+    if (total < P.min_cov && !P.include_ref) callable = false;
+    else if (total != 0 && freq < P.min_freq) callable = false;
+    if (!callable && !every_record) { callable_out[i] = 0; return; }
+
     // ProcessVariant (AlleleCaller.cs:208-234)
+    AlleleTables tb;
+    if (tabs) tb = request_allele_tables(false, support, total, refsup, cov, c.sup, P);
     int vq = 0;
     int16_t noise_level = 0;   // NoiseLevelApplied: assigned with the q-score, i.e. for alleles with support
-    SbResult sb = {0.0, 0, 0, 0};
     if (support > 0) {
         noise_level = (int16_t)P.noise_level;
         if (sumq) {
@@ -1445,11 +1482,15 @@ __global__ __launch_bounds__(64) void call_spanning_kernel(
             noise_level = noise_level_field(level);
             if (total != 0 && level != kNoLevel) vq = poisson_qscore_e(support, total, window_err_of_level(level, P), P);
         } else if (total != 0) {
-            vq = poisson_qscore(support, total, P);
+            if (!(tabs && poisson_qscore_try(support, total, P, tb, vq))) vq = poisson_qscore(support, total, P);
         }
-        sb = strand_bias<true>(cov, c.sup, P);
     }
-    const float freq = frequency_f(support, total);
+    if (vq < P.min_vq) callable = false;
+    callable_out[i] = callable ? 1 : 0;
+    if (flags_only || (!callable && !every_record)) return;
+    SbResult sb = {0.0, 0, 0, 0};
+    if (support > 0 && !(tabs && strand_bias_try(cov, c.sup, P, tb, sb.bias_score, sb.acceptable, sb.var_both, sb.cov_both)))
+        sb = strand_bias<true>(cov, c.sup, P);
     uint32_t filters = 0;   // NumNoCalls stays 0 for spanning alleles -> FractionNoCalls 0
     if (P.low_depth_filter >= 0 && total < P.low_depth_filter) filters |= 1u << PISCES_FILTER_LOW_DEPTH;
     if (P.vq_filter >= 0 && vq < P.vq_filter && total != 0) filters |= 1u << PISCES_FILTER_LOW_VARIANT_QSCORE;
@@ -1474,13 +1515,9 @@ __global__ __launch_bounds__(64) void call_spanning_kernel(
         for (int k = 0; k < c.alt_len; k++)
             if (alleles[c.allele_off + c.ref_len + k] == 'N') filters |= 1u << PISCES_FILTER_STRAND_BIAS;
     }
-    bool callable = true;   // IsCallable (AlleleCaller.cs:236-258)
-    if (total < P.min_cov && !P.include_ref) callable = false;
-    else if (total != 0 && freq < P.min_freq) callable = false;
-    else if (vq < P.min_vq) callable = false;
-
     const int gt = somatic_genotype(false, total, support, refsup, P);
-    const int gq = somatic_gq(gt, vq, total, support, P);
+    int gq;
+    if (!(tabs && somatic_gq_try(gt, vq, total, support, P, tb.gq_idx, tb.gq_cap, gq))) gq = somatic_gq(gt, vq, total, support, P);
     if (P.low_gq_filter >= 0 && (float)gq < (float)P.low_gq_filter) filters |= 1u << PISCES_FILTER_LOW_GENOTYPE_QUALITY;
 
     PiscesCalledAllele r;
@@ -1499,7 +1536,6 @@ __global__ __launch_bounds__(64) void call_spanning_kernel(
     const int rt = allele_type_of_base(alleles[c.allele_off]);
     r.info = PISCES_INFO_PACK(gt, c.category, rt, PISCES_ALLELE_N, sb.acceptable, sb.var_both, sb.cov_both);
     out[i] = r;
-    callable_out[i] = callable ? 1 : 0;
 }
 
 }  // namespace pisces

@@ -1226,7 +1226,9 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
     std::vector<PiscesCalledAllele> raw;
     std::vector<uint8_t> callable;
     bool second_pass = false;   // MNV mode: the pass over every callable allele, after the MNV-only pass
-    auto device_pass = [&](const std::vector<const HostCandidate*>& list) -> int32_t {
+    // wanted: what the caller reads of the pass (call_spanning_kernel's kSpanning*): the records of alleles that are not callable only
+    // matter for forced alleles, and the MNV pass reads IsCallable alone
+    auto device_pass = [&](const std::vector<const HostCandidate*>& list, int32_t wanted) -> int32_t {
         std::vector<DevCandidate> dc(list.size());
         std::vector<uint8_t> pool;
         for (size_t i = 0; i < list.size(); i++) {
@@ -1251,10 +1253,10 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         { int32_t rcu = meta_upload(h, h->d_alleles.p, pool.data(), pool.size()); if (rcu) return rcu; }
         hipLaunchKernelGGL(call_spanning_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, h->d_cands.p, n, h->d_counts.p,
                            h->d_alleles.p, h->d_ref.p, h->ref_len, h->cfg.expect_stitched_reads, h->d_cand_records.p, h->d_cand_callable.p, h->P,
-                           window ? h->d_sumq.p : (const double*)nullptr, d_folded);
+                           window ? h->d_sumq.p : (const double*)nullptr, d_folded, wanted);
         PISCES_HIP_CHECK(h, hipGetLastError());
-        h->pcie[1] += (int64_t)(raw.size() * (sizeof(PiscesCalledAllele) + 1));
-        const size_t rec_bytes = raw.size() * sizeof(PiscesCalledAllele), need = rec_bytes + callable.size();
+        const size_t rec_bytes = wanted == kSpanningFlagsOnly ? 0 : raw.size() * sizeof(PiscesCalledAllele), need = rec_bytes + callable.size();
+        h->pcie[1] += (int64_t)need;
         if (need > h->h_cand_dl_cap) {
             if (h->h_cand_dl) (void)hipHostFree(h->h_cand_dl);
             h->h_cand_dl = nullptr;
@@ -1262,7 +1264,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
             PISCES_HIP_CHECK(h, hipHostMalloc((void**)&h->h_cand_dl, need + need / 2, hipHostMallocDefault));
             h->h_cand_dl_cap = need + need / 2;
         }
-        PISCES_HIP_CHECK(h, hipMemcpyAsync(h->h_cand_dl, h->d_cand_records.p, rec_bytes, hipMemcpyDeviceToHost, h->stream));
+        if (rec_bytes) PISCES_HIP_CHECK(h, hipMemcpyAsync(h->h_cand_dl, h->d_cand_records.p, rec_bytes, hipMemcpyDeviceToHost, h->stream));
         PISCES_HIP_CHECK(h, hipMemcpyAsync(h->h_cand_dl + rec_bytes, h->d_cand_callable.p, callable.size(), hipMemcpyDeviceToHost, h->stream));
         PISCES_TIMED_WAIT(h, hipStreamSynchronize(h->stream));
         std::memcpy(raw.data(), h->h_cand_dl, rec_bytes);
@@ -1290,7 +1292,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         std::vector<const HostCandidate*> mnvs;
         for (auto& c : work)
             if (c.category == PISCES_CAT_MNV) mnvs.push_back(&c);
-        int32_t rc1 = device_pass(mnvs);
+        int32_t rc1 = device_pass(mnvs, kSpanningFlagsOnly);
         if (rc1) return rc1;
         phase(5);
         std::vector<CandPtr> failed;
@@ -1415,7 +1417,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
     if (rows_missing || counts_missing) return fail(h, PISCES_E_INTERNAL, "flush: a candidate's counts were not among those made for the batch");
     phase(6);
     second_pass = mnv_mode;
-    int32_t rc2 = device_pass(final_list);
+    int32_t rc2 = device_pass(final_list, have_forced ? kSpanningEveryRecord : kSpanningCallableRecords);
     if (rc2) return rc2;
     for (size_t i = 0; i < final_list.size(); i++) {
         if (final_list[i]->category == PISCES_CAT_REFERENCE) {   // counted as called by the tile kernels already (gVCF)
