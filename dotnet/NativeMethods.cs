@@ -102,6 +102,7 @@ namespace Pisces.Hip
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_default_config(out PiscesHipConfig cfg);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_create(ref PiscesHipConfig cfg, int device, out IntPtr handle);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_destroy(IntPtr handle);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern long pisces_hip_trim_memory();
         /// the HIP devices of this process; job j of a -threadbychr run takes device j % count (HipFactory)
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_device_count();
         /// the positions this handle reports calls and totals for, when it is one interval shard of a chromosome (halo reads beyond it only feed the counts)

@@ -263,6 +263,10 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
  * a host gives job j the device j % count, handles on different devices share nothing. */
 int32_t pisces_hip_device_count(void);
 int32_t pisces_hip_destroy(PiscesHip* h);
+/* Device and pinned host memory of destroyed handles is kept for the handles that follow (a job per chromosome, or per interval range,
+ * makes and destroys one each: BaseGenomeProcessor.cs:40-90): up to PISCES_HIP_ALLOC_CACHE_MB of device memory per device (default
+ * 8192; 0 = keep nothing) and a quarter of that pinned.  This gives it all back; returns the bytes released. */
+int64_t pisces_hip_trim_memory(void);
 const char* pisces_hip_last_error(const PiscesHip* h);   /* h may be NULL: message of the last failed create */
 int32_t pisces_hip_abi_version(void);
 

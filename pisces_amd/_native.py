@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PISCES_HIP_LIB") or os.path.join(_HERE, "libpisceship.so")
 
 EXPORTS = [
-    "pisces_hip_abi_version", "pisces_hip_default_config", "pisces_hip_create", "pisces_hip_destroy",
+    "pisces_hip_abi_version", "pisces_hip_default_config", "pisces_hip_create", "pisces_hip_destroy", "pisces_hip_trim_memory",
     "pisces_hip_last_error", "pisces_hip_set_reference", "pisces_hip_set_intervals", "pisces_hip_add_reads", "pisces_hip_stage_reads", "pisces_hip_flush_begin", "pisces_hip_flush_end",
     "pisces_hip_add_observations", "pisces_hip_flush", "pisces_hip_get_counts", "pisces_hip_add_gapped_mnv_ref",
     "pisces_hip_get_candidates", "pisces_hip_stats", "pisces_hip_call_tiles", "pisces_hip_accumulate_tiles",
@@ -61,6 +61,7 @@ def _load():
         "pisces_hip_default_config": (i32, [P(_abi.PiscesHipConfig)]),
         "pisces_hip_create": (i32, [P(_abi.PiscesHipConfig), i32, P(vp)]),
         "pisces_hip_destroy": (i32, [vp]),
+        "pisces_hip_trim_memory": (C.c_int64, []),
         "pisces_hip_last_error": (C.c_char_p, [vp]),
         "pisces_hip_set_reference": (i32, [vp, vp, i64]),
         "pisces_hip_set_intervals": (i32, [vp, vp, vp, i32]),

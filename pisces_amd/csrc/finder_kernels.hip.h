@@ -100,11 +100,178 @@ __device__ __forceinline__ uint32_t load_word(const uint8_t* p)   // four bytes 
     return v;
 }
 
+// ---- the lane form, events first (round 4) -----------------------------------------------------------------------------------------
+// walk_match_op hands every base of an M operation to the state machine; with a lane a read a wave then pays, at every base, for whatever
+// any of its 64 reads does there — and with one base in a hundred a mismatch, some read closes a variant (Create + Annotate, the support
+// direction: a hundred instructions) at every second base.  But the state machine only DOES something at an event — a base that cannot be
+// called (N, low quality, N in the reference) or a callable mismatch — and between two events it is a closed form of the number of matches
+// (a pending variant takes at most MaxGapBetweenMNV of them, then closes).  So here a lane first CLASSIFIES 64 bases of its operation at
+// once, branch-free: twenty-four 8-byte loads issued together (bases, qualities, reference), four bases a step classified in SWAR form
+// (v_perm letter table: is it exactly A C G T; one subtraction for quality < minBQ; a byte-wise xor for the mismatch) into two 64-bit
+// masks.  Then it hops from event to event in a short loop that only advances (run, tail, open ends) and stops at a variant to emit;
+// the long code (walk::finish_candidate and the record) runs once per EMITTED variant of the slowest lane, not once per base at which
+// some lane emits.  Same candidates, same order, same records as walk::walk_match_op (tests/test_gpu_parity.py, tests/test_read_store.py
+// against the host form and the oracle).  min_bq <= 127 (a quality byte >= 128 is never low then); the byte-wise form serves the rest.
+__device__ __forceinline__ uint32_t swar_nonzero(uint32_t x) { return (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u; }   // bit 7 of every byte that is not 0
+__device__ __forceinline__ uint32_t swar_not_acgt(uint32_t w)
+{
+    // the letter the low three bits of a base stand for (A 1, C 3, T 4, G 7; anything else: a byte no base with those bits equals)
+    return swar_nonzero(w ^ __builtin_amdgcn_perm(0x47000054u, 0x43004101u, w & 0x07070707u));
+}
+__device__ __forceinline__ uint32_t swar_gather(uint32_t flags) { return (((flags >> 7) * 0x01020408u) >> 24) & 0xFu; }   // bit 7 of byte k -> bit k
+__device__ __forceinline__ unsigned long long load_u64_at(const uint8_t* p)   // eight bytes at any address (unaligned global access is on)
+{
+    unsigned long long v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
+template <typename Emit>
+__device__ __forceinline__ void walk_match_op_events(const ReadView& r, const walk::ReadFrame& f, const uint8_t* __restrict__ ref, int64_t ref_len,
+                                                     const FinderParams& P, int op_read0, int op_len, int op_ref0, Emit& emit)
+{
+    int run = 0, tail = 0;
+    bool open_left = false;
+    // a variant that is closed waits here for the long code
+    bool pend = false, p_ol = false, p_or = false;
+    int p_at = 0, p_run = 0, p_len = 0;
+    auto close = [&](int at, bool open_right) {   // walk::walk_match_op's close
+        int len = run;
+        if (tail >= 1) { len -= tail; open_right = false; }
+        if (len < 1) return;
+        pend = true; p_at = at; p_run = run; p_len = len; p_ol = open_left; p_or = open_right;
+    };
+    auto emit_pending = [&]() {
+        const int start_read = op_read0 + p_at - p_run, start_ref = op_ref0 + p_at - p_run;
+        walk::finish_candidate(r, f, P, p_len > 1 ? PISCES_CAT_MNV : PISCES_CAT_SNV, start_ref + 1, start_ref, start_read, p_len, p_len, -1, p_ol, p_or, emit);
+        pend = false;
+    };
+    int64_t lim = op_len;
+    if ((int64_t)r.read_len - op_read0 < lim) lim = (int64_t)r.read_len - op_read0;
+    if (ref_len - (int64_t)op_ref0 < lim) lim = ref_len - (int64_t)op_ref0;
+    const int walked = lim < 0 ? 0 : (int)lim;
+    int cur = 0;   // bases [0, cur) of the operation have been through the state machine
+    auto matches_until = [&](int upto) {   // the callable, matching bases [cur, upto) (walk_match_op_wave's, above)
+        int g = upto - cur;
+        if (g <= 0) return;
+        if (run > 0) {
+            if (P.call_mnvs) {
+                const int take = max(0, min(g, min(P.max_mnv_length - run, P.max_gap - tail)));
+                run += take; tail += take; g -= take;
+            }
+            if (g > 0) { close(upto - g, false); run = 0; tail = 0; }
+        }
+        if (g > 0) open_left = false;
+        cur = upto;
+    };
+    auto event = [&](int i, bool callable) {
+        matches_until(i);
+        const bool alone_on_last_base = i == op_len - 1 && run == 0;
+        const bool grows = callable && P.call_mnvs && run + 1 <= P.max_mnv_length && tail <= P.max_gap && !alone_on_last_base;
+        if (grows) { run++; tail = 0; }
+        else {
+            close(i, !callable);   // (nothing pending from matches_until then: it left run == 0, or it closed nothing)
+            run = callable ? 1 : 0;
+            tail = 0;
+            open_left = !callable;
+        }
+        cur = i + 1;
+    };
+    const uint8_t* const pb = r.bases + op_read0;
+    const uint8_t* const pq = r.quals + op_read0;
+    const uint8_t* const pf = ref + op_ref0;
+    const uint32_t qk4 = (0x7Fu + (uint32_t)min(max(P.min_bq, 0), 127)) * 0x01010101u;
+    for (int c0 = 0; c0 < walked; c0 += 64) {
+        const int n_here = min(64, walked - c0);
+        unsigned long long bw[8], qw[8], fw[8];
+        if (walked >= 8) {
+#pragma unroll
+            for (int w = 0; w < 8; w++) {   // (a word that would reach past the operation's bases is taken early and shifted; one wholly past it: anything)
+                const int o = c0 + 8 * w, oc = min(o, walked - 8), sh = 8 * min(o - oc, 7);
+                bw[w] = load_u64_at(pb + oc) >> sh;
+                qw[w] = load_u64_at(pq + oc) >> sh;
+                fw[w] = load_u64_at(pf + oc) >> sh;
+            }
+        } else {
+#pragma unroll
+            for (int w = 0; w < 8; w++) bw[w] = qw[w] = fw[w] = 0;
+            for (int k = 0; k < walked; k++) {
+                bw[0] |= (unsigned long long)pb[k] << (8 * k); qw[0] |= (unsigned long long)pq[k] << (8 * k); fw[0] |= (unsigned long long)pf[k] << (8 * k);
+            }
+        }
+        unsigned long long unc = 0, mis = 0;   // bit k: base c0 + k cannot be called / can, and differs from the reference
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                const uint32_t b4 = (uint32_t)(bw[w] >> (32 * hf)), q4 = (uint32_t)(qw[w] >> (32 * hf)), f4 = (uint32_t)(fw[w] >> (32 * hf));
+                const uint32_t low4 = ~q4 & (qk4 - (q4 & 0x7F7F7F7Fu)) & 0x80808080u;   // quality < minBQ
+                const uint32_t u4 = swar_not_acgt(b4) | swar_not_acgt(f4) | low4;
+                const uint32_t m4 = swar_nonzero(b4 ^ f4) & ~u4;
+                unc |= (unsigned long long)swar_gather(u4) << (8 * w + 4 * hf);
+                mis |= (unsigned long long)swar_gather(m4) << (8 * w + 4 * hf);
+            }
+        }
+        const unsigned long long here = n_here >= 64 ? ~0ull : ((1ull << n_here) - 1ull);
+        unc &= here;
+        unsigned long long ev = (unc | mis) & here;
+        for (;;) {
+            while (ev && !pend) {
+                const int k = __builtin_ctzll(ev);
+                ev &= ev - 1;
+                event(c0 + k, !((unc >> k) & 1ull));
+            }
+            if (!pend) break;
+            emit_pending();
+        }
+    }
+    matches_until(walked);
+    close(walked, false);
+    if (pend) emit_pending();
+}
+
+// ProcessCigarOps (finder_walk.h walk_read) with the M operations in the event form
+template <typename Emit>
+__device__ __forceinline__ void walk_read_events(const ReadView& r, const uint8_t* __restrict__ ref, int64_t ref_len, const FinderParams& P, Emit& emit)
+{
+    const walk::ReadFrame f = walk::frame_of(r);
+    int in_read = 0, in_ref = r.position - 1;
+    for (int ci = 0; ci < r.n_cigar; ci++) {
+        const uint8_t t = r.cigar_op[ci];
+        const int len = (int)r.cigar_len[ci];
+        if (t == 'M') {
+            if (P.snvs_and_mnvs) walk_match_op_events(r, f, ref, ref_len, P, in_read, len, in_ref, emit);
+        } else if (t == 'I') {
+            const bool off_contig = (int64_t)in_ref - 1 >= ref_len || in_ref == 0;
+            if (!off_contig && in_read < r.read_len && in_read + len <= r.read_len && r.quals[in_read] >= P.min_bq)
+                walk::finish_candidate(r, f, P, PISCES_CAT_INSERTION, in_ref, in_ref - 1, in_read, len, len + 1, -1, false, false, emit);
+        } else if (t == 'D') {
+            bool flanks_ok = false;
+            if (r.read_len > 0) {
+                const int after = in_read < r.read_len ? r.quals[in_read] : r.quals[in_read - 1];
+                const int before = in_read > 0 ? r.quals[in_read - 1] : after;
+                flanks_ok = before >= P.min_bq && after >= P.min_bq;
+            }
+            if ((int64_t)in_ref + len < ref_len && in_ref >= 1 && flanks_ok)
+                walk::finish_candidate(r, f, P, PISCES_CAT_DELETION, in_ref, in_ref - 1, in_read, len, 1, ci, false, false, emit);
+        } else if (t == 'X' && P.mark_x_spans && len > 0) {
+            FoundCandidate c;
+            c.position = in_ref + 1; c.ref_index = in_ref; c.start_in_read = in_read; c.length = len;
+            c.category = kFoundSpanMark; c.dir = 0; c.well_anchored = c.open_left = c.open_right = 0;
+            c.pad[0] = c.pad[1] = c.pad[2] = 0;
+            emit(c);
+        }
+        if (walk::spans_read(t)) in_read += len;
+        if (walk::spans_ref(t)) in_ref += len;
+    }
+}
+
 __device__ __forceinline__ bool found_needs_pool(const FoundCandidate& c)
 {
     return c.category != PISCES_CAT_DELETION && c.category != kFoundSpanMark && c.length > kFoundInline;
 }
 
+template <bool kEvents>   // the event form of the M-operation walk (above), or finder_walk.h's base by base
 __global__ __launch_bounds__(256) void find_count_kernel(DevReadBatch b, const uint8_t* __restrict__ del_dirs, const uint8_t* __restrict__ ref,
                                                          int64_t ref_len, FinderParams P, int32_t* __restrict__ n_found,
                                                          int32_t* __restrict__ n_pool)
@@ -118,7 +285,8 @@ __global__ __launch_bounds__(256) void find_count_kernel(DevReadBatch b, const u
         n++;
         if (found_needs_pool(c)) bytes += c.length;
     };
-    walk::walk_read<WordBases>(v, ref, ref_len, P, count);
+    if (kEvents) walk_read_events(v, ref, ref_len, P, count);
+    else walk::walk_read<WordBases>(v, ref, ref_len, P, count);
     n_found[r] = n;
     n_pool[r] = bytes;
 }
@@ -194,6 +362,7 @@ __global__ __launch_bounds__(1024) void found_scan_kernel(int32_t* __restrict__ 
 // slot_first[r] = first record slot of read r, slot_end = slot_first[r + 1] (host-made or scanned); pool_first[r] = first pool byte of
 // read r when the pool offsets were scanned (MNV calling on), else nullptr: long insertions then take pool bytes from a cursor
 // (rare: an insertion longer than kFoundInline bases).
+template <bool kEvents>
 __global__ __launch_bounds__(256) void find_emit_kernel(DevReadBatch b, const uint8_t* __restrict__ del_dirs, const uint8_t* __restrict__ ref,
                                                         int64_t ref_len, FinderParams P, const int32_t* __restrict__ slot_first,
                                                         const int32_t* __restrict__ pool_first, DevFound* __restrict__ out,
@@ -230,7 +399,8 @@ __global__ __launch_bounds__(256) void find_emit_kernel(DevReadBatch b, const ui
         for (int k = 0; k < kFoundInline; k++) f.alt[k] = (k < n_alt && n_alt <= kFoundInline) ? src[k] : (uint8_t)0;
         out[slot++] = f;
     };
-    walk::walk_read<WordBases>(v, ref, ref_len, P, write);
+    if (kEvents) walk_read_events(v, ref, ref_len, P, write);
+    else walk::walk_read<WordBases>(v, ref, ref_len, P, write);
     for (; slot < slot_end; slot++) {   // reserved, unused: a hole
         DevFound f = {};
         f.c.category = kFoundHole;

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <ctime>
 #include <map>
 #include <set>
@@ -55,6 +56,136 @@ struct BlockObs {   // the block's observations live in the device log (PiscesHi
     std::vector<std::pair<int32_t, int32_t>> x_spans;   // positions of the X operations of the block's reads (MNV calling on, split form): dirty loci
 };
 
+
+// ---- device / pinned memory kept across handles ------------------------------------------------------------------------------------
+// A caller that cuts a genome into pieces makes and destroys a handle per piece (one per chromosome in the reference,
+// BaseGenomeProcessor.cs:40-90; one per (contig, interval range) in BASELINE config 4): hipFree and hipHostFree synchronise the device
+// and unpin pages — 30 ms of a 75 ms piece were pisces_hip_destroy, 10 more the first touch of freshly pinned staging memory.  What a
+// handle held when it was destroyed is therefore kept (by device; up to PISCES_HIP_ALLOC_CACHE_MB of device memory, default 8192, and a
+// quarter of that pinned) and handed to the next allocation of about that size.  Only pisces_hip_destroy puts memory there — it has
+// waited for the handle's streams — a buffer that is outgrown in mid-life is freed for real, as before.  pisces_hip_trim_memory()
+// gives everything back.
+constexpr int kCacheDevices = 16;
+struct AllocCache {
+    std::mutex m;
+    std::multimap<size_t, void*> free_dev[kCacheDevices], free_host;
+    std::unordered_map<void*, std::pair<size_t, int>> live;   // every allocation made here: bytes, device (-1: pinned host)
+    size_t cached_dev[kCacheDevices] = {0}, cached_host = 0, limit_dev = 0, limit_host = 0;
+    bool configured = false;
+    void configure()
+    {
+        if (configured) return;
+        configured = true;
+        const char* e = getenv("PISCES_HIP_ALLOC_CACHE_MB");
+        const long long mb = e ? atoll(e) : 8192;
+        limit_dev = (size_t)std::max(0ll, mb) << 20;
+        limit_host = limit_dev / 4;
+    }
+};
+AllocCache& alloc_cache() { static AllocCache* c = new AllocCache(); return *c; }   // (never destroyed: a static's destructor would run after the runtime's)
+thread_local bool tl_keep_freed = false;   // pisces_hip_destroy, after it has waited for the handle's streams
+
+void* cache_take(std::multimap<size_t, void*>& m, size_t& cached, size_t bytes)
+{
+    auto it = m.lower_bound(bytes);
+    if (it == m.end() || it->first > bytes + bytes / 2 + ((size_t)1 << 20)) return nullptr;
+    void* p = it->second;
+    cached -= it->first;
+    m.erase(it);
+    return p;
+}
+size_t cache_drop(AllocCache& c, int device /* -1 host, -2 everything */)
+{
+    size_t freed = 0;
+    for (int d = 0; d < kCacheDevices; d++) {
+        if (device != -2 && device != d) continue;
+        for (auto& kv : c.free_dev[d]) { (void)hipFree(kv.second); c.live.erase(kv.second); freed += kv.first; }
+        c.free_dev[d].clear();
+        c.cached_dev[d] = 0;
+    }
+    if (device == -2 || device == -1) {
+        for (auto& kv : c.free_host) { (void)hipHostFree(kv.second); c.live.erase(kv.second); freed += kv.first; }
+        c.free_host.clear();
+        c.cached_host = 0;
+    }
+    return freed;
+}
+hipError_t dev_alloc(void** out, size_t bytes)
+{
+    AllocCache& c = alloc_cache();
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(c.m);
+    c.configure();
+    if (bytes == 0) bytes = 1;
+    if (dev >= 0 && dev < kCacheDevices) {
+        if (void* p = cache_take(c.free_dev[dev], c.cached_dev[dev], bytes)) { *out = p; return hipSuccess; }
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess && dev >= 0 && dev < kCacheDevices && !c.free_dev[dev].empty()) {   // out of memory with memory set aside: give it back, once more
+        (void)hipGetLastError();
+        (void)cache_drop(c, dev);
+        e = hipMalloc(out, bytes);
+    }
+    if (e == hipSuccess) c.live[*out] = {bytes, dev};
+    return e;
+}
+void dev_free(void* p)
+{
+    if (!p) return;
+    AllocCache& c = alloc_cache();
+    {
+        std::lock_guard<std::mutex> lock(c.m);
+        auto it = c.live.find(p);
+        if (it != c.live.end()) {
+            const size_t bytes = it->second.first;
+            const int dev = it->second.second;
+            if (tl_keep_freed && dev >= 0 && dev < kCacheDevices && c.cached_dev[dev] + bytes <= c.limit_dev) {
+                c.free_dev[dev].insert({bytes, p});
+                c.cached_dev[dev] += bytes;
+                return;
+            }
+            c.live.erase(it);
+        }
+    }
+    (void)hipFree(p);
+}
+hipError_t host_alloc(void** out, size_t bytes)
+{
+    AllocCache& c = alloc_cache();
+    std::lock_guard<std::mutex> lock(c.m);
+    c.configure();
+    if (bytes == 0) bytes = 1;
+    if (void* p = cache_take(c.free_host, c.cached_host, bytes)) { *out = p; return hipSuccess; }
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess && !c.free_host.empty()) {
+        (void)hipGetLastError();
+        (void)cache_drop(c, -1);
+        e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    }
+    if (e == hipSuccess) c.live[*out] = {bytes, -1};
+    return e;
+}
+void host_free(void* p)
+{
+    if (!p) return;
+    AllocCache& c = alloc_cache();
+    {
+        std::lock_guard<std::mutex> lock(c.m);
+        auto it = c.live.find(p);
+        if (it != c.live.end()) {
+            const size_t bytes = it->second.first;
+            if (tl_keep_freed && c.cached_host + bytes <= c.limit_host) {
+                c.free_host.insert({bytes, p});
+                c.cached_host += bytes;
+                return;
+            }
+            c.live.erase(it);
+        }
+    }
+    (void)hipHostFree(p);
+}
+
 template <typename T>
 struct DeviceBuf {
     T* p = nullptr;
@@ -66,11 +197,11 @@ struct DeviceBuf {
     hipError_t reserve(size_t n)
     {
         if (n <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
+        if (p) dev_free(p);
         p = nullptr;
         cap = 0;
         size_t want = n + n / 4 + 64;
-        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        hipError_t e = dev_alloc((void**)&p, want * sizeof(T));
         if (e == hipSuccess) cap = want;
         return e;
     }
@@ -81,20 +212,20 @@ struct DeviceBuf {
         T* old = p;
         size_t want = n + n / 2 + 1024;
         T* fresh = nullptr;
-        hipError_t e = hipMalloc((void**)&fresh, want * sizeof(T));
+        hipError_t e = dev_alloc((void**)&fresh, want * sizeof(T));
         if (e != hipSuccess) return e;
         if (old && n_keep > 0) {
             e = hipMemcpyAsync(fresh, old, std::min(n_keep, cap) * sizeof(T), hipMemcpyDeviceToDevice, stream);
             if (e == hipSuccess) e = hipStreamSynchronize(stream);
         }
-        if (old) (void)hipFree(old);
+        if (old) dev_free(old);
         p = fresh;
         cap = want;
         return e;
     }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p) dev_free(p);
         p = nullptr;
         cap = 0;
     }
@@ -362,8 +493,10 @@ struct PiscesHip {
     std::vector<hipGraphExec_t> graphs;       // pisces_hip_call_tiles_graph_build
     std::vector<hipGraph_t> graph_defs;
     int store_waves = 0;                      // development: waves per tile of call_store_tiles_kernel (PISCES_HIP_STORE_WAVES; 0 = by launch size)
-    int finder_wave = 0;                      // PISCES_HIP_FINDER=wave: the candidate walk a wave a read (finder_kernels.hip.h; measured slower: default off)
+    int finder_wave = 0;                      // PISCES_HIP_FINDER: the default is a lane a read, events first; =bases: a lane a read, base by base (round 3's);
+                                              // =wave / =batch: a wave for one / for 64 reads (finder_kernels.hip.h; measured slower)
     DeviceBuf<long long> d_scan_sums;         // block sums of launch_found_scan
+    bool merge_in_place = true;               // PISCES_HIP_MERGE_IN_PLACE=0: the candidate kernel's rows and the tile kernels' are merged into a vector of their own (the A / B of the tests)
     int device_checks = -1;                   // PISCES_HIP_DEVICE_CHECKS: 1 every host batch is checked on the device (read_prepare_kernel), 0 none, -1 (default) from 65 536 reads up
     bool prep_map_clean = false;              // the block map of read_prepare_kernel is all zero
     DeviceBuf<uint32_t> d_prep_map;
@@ -663,7 +796,8 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         if (const char* v = getenv("PISCES_HIP_MNV_SPLIT")) h->mnv_split = h->mnv_split && atoi(v) != 0;
         if (const char* v = getenv("PISCES_HIP_STORE_SEAL_BYTES")) h->store_seal_bytes = (size_t)std::max(0ll, atoll(v));
         if (const char* v = getenv("PISCES_HIP_DEVICE_CHECKS")) h->device_checks = atoi(v) != 0 ? 1 : 0;
-        if (const char* v = getenv("PISCES_HIP_FINDER")) h->finder_wave = std::string(v) == "wave" ? 1 : std::string(v) == "batch" ? 2 : 0;
+        if (const char* v = getenv("PISCES_HIP_MERGE_IN_PLACE")) h->merge_in_place = atoi(v) != 0;
+        if (const char* v = getenv("PISCES_HIP_FINDER")) h->finder_wave = std::string(v) == "wave" ? 1 : std::string(v) == "batch" ? 2 : std::string(v) == "bases" ? 3 : 0;
     }
     {
         // MathOperations.QtoP(q) = Math.Pow(10, -1 * q / 10f) for every integer q-score the caller can produce
@@ -753,6 +887,17 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
     });
 }
 
+int64_t pisces_hip_trim_memory(void)
+{
+    AllocCache& c = alloc_cache();
+    std::lock_guard<std::mutex> lock(c.m);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const size_t freed = cache_drop(c, -2);
+    (void)hipSetDevice(dev);
+    return (int64_t)freed;
+}
+
 int32_t pisces_hip_destroy(PiscesHip* h)
 {
     return abi_guard<int32_t>(h, [&]() -> int32_t {
@@ -766,8 +911,14 @@ int32_t pisces_hip_destroy(PiscesHip* h)
                     (long long)h->split_stats[0], (long long)h->split_stats[1], (long long)h->split_stats[2], (long long)h->split_stats[3]);
     }
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    bool idle = !h->stream || hipStreamSynchronize(h->stream) == hipSuccess;
+    for (int k = 0; k < PiscesHip::kLanes; k++)
+        if (h->lane[k] && hipStreamSynchronize(h->lane[k]) != hipSuccess) idle = false;
     (void)pisces_hip_comm_destroy(h);
+    struct KeepFreed {   // nothing of the handle is in flight: what it held may go to the next handle as it is
+        explicit KeepFreed(bool on) { tl_keep_freed = on; }
+        ~KeepFreed() { tl_keep_freed = false; }
+    } keep(idle);
     h->d_summary.release();
     h->d_ref.release(); h->d_tuples.release(); h->d_tiles.release(); h->d_tile_results.release();
     h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release(); h->d_totals.release(); h->d_qlut.release(); h->d_bq_lut.release(); h->d_sumq_fix.release(); h->d_sumq.release(); h->d_gq_tail.release(); h->d_vq_tab.release(); h->d_sb_tab.release(); h->d_sb0_tab.release(); h->d_gq_cap.release(); h->d_params.release(); h->d_offsets.release(); h->d_compact.release();
@@ -775,7 +926,7 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     h->d_log_n.release(); h->d_flags.release(); h->d_bucket.release(); h->d_total.release();
     for (auto& st : h->stage) {
         st.d.release();
-        if (st.h) (void)hipHostFree(st.h);
+        if (st.h) host_free(st.h);
         st.h = nullptr;
         if (st.done) (void)hipEventDestroy(st.done);
         st.done = nullptr;
@@ -783,15 +934,15 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     h->h_stage = nullptr;
     if (h->async.done) (void)hipEventDestroy(h->async.done);
     h->async.done = nullptr;
-    if (h->h_dl) (void)hipHostFree(h->h_dl);
+    if (h->h_dl) host_free(h->h_dl);
     h->h_dl = nullptr;
-    if (h->h_cand_dl) (void)hipHostFree(h->h_cand_dl);
+    if (h->h_cand_dl) host_free(h->h_cand_dl);
     h->h_cand_dl = nullptr;
-    if (h->h_meta) (void)hipHostFree(h->h_meta);
+    if (h->h_meta) host_free(h->h_meta);
     h->h_meta = nullptr;
-    if (h->h_counts) (void)hipHostFree(h->h_counts);
+    if (h->h_counts) host_free(h->h_counts);
     h->h_counts = nullptr;
-    if (h->found.h) (void)hipHostFree(h->found.h);
+    if (h->found.h) host_free(h->found.h);
     h->found.h = nullptr;
     if (h->found.done) (void)hipEventDestroy(h->found.done);
     h->found.done = nullptr;
@@ -799,9 +950,9 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     h->d_merge_tab.release(); h->d_merge_acc.release();
     h->d_scan_sums.release(); h->d_prep_map.release(); h->d_folded.release(); h->d_span_tiles.release();
     h->d_snv[0].release(); h->d_snv[1].release(); h->d_snv_n.release(); h->d_snv_sel.release(); h->d_dirty.release(); h->d_row_idx.release(); h->d_rows.release();
-    if (h->h_totals) (void)hipHostFree(h->h_totals);
+    if (h->h_totals) host_free(h->h_totals);
     h->h_totals = nullptr;
-    if (h->h_snv_sel) (void)hipHostFree(h->h_snv_sel);
+    if (h->h_snv_sel) host_free(h->h_snv_sel);
     h->h_snv_sel = nullptr;
     h->d_found_misc.release(); h->d_found_totals.release();
     h->d_cands.release(); h->d_alleles.release(); h->d_cand_records.release(); h->d_cand_callable.release();

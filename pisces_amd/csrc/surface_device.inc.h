@@ -219,7 +219,7 @@ int32_t pisces_hip_device_totals(PiscesHip* h, int64_t out[4], int32_t reset)
     PISCES_HIP_CHECK(h, hipDeviceSynchronize());   // launches may sit on caller-supplied streams
     // (into pinned memory: a copy into pageable memory is staged by the runtime, 20-30 us for these 8 KB)
     constexpr size_t kTotalsBytes = (size_t)kTotalShards * kTotalStride * sizeof(unsigned long long);
-    if (!h->h_totals) PISCES_HIP_CHECK(h, hipHostMalloc((void**)&h->h_totals, kTotalsBytes, hipHostMallocDefault));
+    if (!h->h_totals) PISCES_HIP_CHECK(h, host_alloc((void**)&h->h_totals, kTotalsBytes));
     unsigned long long* const host_p = h->h_totals;
     PISCES_HIP_CHECK(h, hipMemcpy(host_p, h->d_totals.p, kTotalsBytes, hipMemcpyDeviceToHost));
     struct { unsigned long long* p; size_t n; unsigned long long operator[](size_t i) const { return p[i]; } size_t size() const { return n; } } host = {host_p, (size_t)kTotalShards * kTotalStride};

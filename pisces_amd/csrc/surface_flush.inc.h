@@ -340,10 +340,10 @@ static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& key
     const size_t dl_bytes = (cap + 1) * sizeof(PiscesCalledAllele);
     if (dl_bytes > h->h_dl_cap) {
         if (h->async.state == 1) PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // (never: a flush in flight owns the buffer; flush_begin refuses)
-        if (h->h_dl) (void)hipHostFree(h->h_dl);
+        if (h->h_dl) host_free(h->h_dl);
         h->h_dl = nullptr;
         h->h_dl_cap = 0;
-        PISCES_HIP_CHECK(h, hipHostMalloc((void**)&h->h_dl, dl_bytes + dl_bytes / 2, hipHostMallocDefault));
+        PISCES_HIP_CHECK(h, host_alloc((void**)&h->h_dl, dl_bytes + dl_bytes / 2));
         h->h_dl_cap = dl_bytes + dl_bytes / 2;
     }
     // the pinned download buffer mirrors d_compact: a header slot {records, called, kept (8 bytes)}, then the records
@@ -739,7 +739,7 @@ static int32_t snv_store_sweep(PiscesHip* h, const uint32_t* d_bm, int32_t bm_fi
     const int c = h->snv_cur, o = c ^ 1;
     PISCES_HIP_CHECK(h, h->d_snv[o].reserve((size_t)h->snv_ub));
     PISCES_HIP_CHECK(h, h->d_snv_sel.reserve((size_t)h->snv_ub));
-    if (!h->h_snv_sel) PISCES_HIP_CHECK(h, hipHostMalloc((void**)&h->h_snv_sel, 16 + kSnvSpec * sizeof(SnvGroup), hipHostMallocDefault));
+    if (!h->h_snv_sel) PISCES_HIP_CHECK(h, host_alloc((void**)&h->h_snv_sel, 16 + kSnvSpec * sizeof(SnvGroup)));
     PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_snv_n.p + 2, 0, 2 * sizeof(unsigned int), h->stream));
     hipLaunchKernelGGL(snv_store_sweep_kernel, dim3((unsigned)((h->snv_ub + 255) / 256)), dim3(256), 0, h->stream, (const SnvGroup*)h->d_snv[c].p,
                        (const unsigned int*)(h->d_snv_n.p + c), d_bm, bm_first, bm_n, drop_hi, h->d_snv_sel.p, (uint32_t)std::min<size_t>(h->d_snv_sel.cap, 0xFFFFFFF0u),
@@ -1156,10 +1156,10 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         need.erase(std::unique(need.begin(), need.end()), need.end());
         const size_t n_rows = need.size(), n_counts = std::max<size_t>(n_rows, 1) * PISCES_COUNTS_PER_LOCUS;
         if (n_counts > h->h_counts_cap) {
-            if (h->h_counts) (void)hipHostFree(h->h_counts);
+            if (h->h_counts) host_free(h->h_counts);
             h->h_counts = nullptr;
             h->h_counts_cap = 0;
-            PISCES_HIP_CHECK(h, hipHostMalloc((void**)&h->h_counts, (n_counts + n_counts / 2) * sizeof(int32_t), hipHostMallocDefault));
+            PISCES_HIP_CHECK(h, host_alloc((void**)&h->h_counts, (n_counts + n_counts / 2) * sizeof(int32_t)));
             h->h_counts_cap = n_counts + n_counts / 2;
         }
         if (n_rows > 0) {
@@ -1258,10 +1258,10 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         const size_t rec_bytes = wanted == kSpanningFlagsOnly ? 0 : raw.size() * sizeof(PiscesCalledAllele), need = rec_bytes + callable.size();
         h->pcie[1] += (int64_t)need;
         if (need > h->h_cand_dl_cap) {
-            if (h->h_cand_dl) (void)hipHostFree(h->h_cand_dl);
+            if (h->h_cand_dl) host_free(h->h_cand_dl);
             h->h_cand_dl = nullptr;
             h->h_cand_dl_cap = 0;
-            PISCES_HIP_CHECK(h, hipHostMalloc((void**)&h->h_cand_dl, need + need / 2, hipHostMallocDefault));
+            PISCES_HIP_CHECK(h, host_alloc((void**)&h->h_cand_dl, need + need / 2));
             h->h_cand_dl_cap = need + need / 2;
         }
         if (rec_bytes) PISCES_HIP_CHECK(h, hipMemcpyAsync(h->h_cand_dl, h->d_cand_records.p, rec_bytes, hipMemcpyDeviceToHost, h->stream));
@@ -1584,6 +1584,55 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
             std::stable_sort(evs.begin(), evs.end(), [](const Ev& a, const Ev& b) { return a.idx != b.idx ? a.idx < b.idx : a.kind < b.kind; });
             h->pending.clear();
             h->pending_cand_index.clear();
+            // In place when the rows lie in the download buffer and it has room for the ones that join them: a row that comes in pushes the
+            // rows behind it one place along only until the Reference row of its position goes (the usual pair of events), so nearly all
+            // of the buffer stays where the kernel wrote it.  (A copy of every row into h->pending was 5 of the 7 ms a flush of 230 000
+            // loci of BASELINE config 4 spent on the host.)
+            const size_t room = h->h_dl_cap / sizeof(PiscesCalledAllele);
+            if (h->merge_in_place && h->h_dl && P == (const PiscesCalledAllele*)h->h_dl + 1 && room > 0 && np + rows.size() + 1 <= room) {
+                PiscesCalledAllele* const M = (PiscesCalledAllele*)h->h_dl + 1;
+                std::deque<PiscesCalledAllele> ahead;   // rows [cur, rp) of the input: read out of the way of the write cursor
+                size_t cur = 0, rp = 0, w = 0;          // next input row; first input row still in its place (>= cur); next output place (<= rp)
+                std::vector<std::pair<size_t, int32_t>> placed;
+                placed.reserve(rows.size());
+                auto emit = [&](const PiscesCalledAllele& row) {
+                    if (w == rp && rp < np) { ahead.push_back(M[rp]); rp++; }
+                    M[w++] = row;
+                };
+                auto skip_one = [&]() { if (!ahead.empty()) ahead.pop_front(); else rp++; cur++; };
+                auto copy_to = [&](size_t end) {
+                    while (cur < end && !ahead.empty()) {
+                        const PiscesCalledAllele row = ahead.front();
+                        ahead.pop_front();
+                        cur++;
+                        emit(row);
+                    }
+                    if (cur < end) {   // nothing read ahead: rp == cur, w <= cur
+                        const size_t n = end - cur;
+                        if (w != cur) std::memmove(M + w, M + cur, n * sizeof(PiscesCalledAllele));
+                        w += n;
+                        cur = rp = end;
+                    }
+                };
+                for (size_t e = 0; e < evs.size(); e++) {
+                    const Ev& ev = evs[e];
+                    copy_to(ev.idx);
+                    if (ev.kind == 0) { placed.push_back({w, ev.ci}); emit(*ev.row); continue; }
+                    if (cur != ev.idx) continue;                       // (the row is gone already: dropped and replaced at once)
+                    if (ev.kind == 2) {
+                        bool dropped = false;
+                        for (size_t q = e; q-- > 0 && evs[q].idx == ev.idx;) dropped = dropped || evs[q].kind == 1;
+                        if (!dropped) emit(*ev.row);
+                    }
+                    skip_one();
+                }
+                copy_to(np);
+                h->pending_view = M;
+                h->pending_view_n = w;
+                h->pending_cand_index.assign(w, -1);
+                for (auto& pl : placed) h->pending_cand_index[pl.first] = pl.second;
+                h->pending_cands = span_cands;
+            } else {
             h->pending.reserve(np + rows.size());
             h->pending_cand_index.reserve(np + rows.size());
             size_t cur = 0;
@@ -1611,6 +1660,7 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
             h->pending_view = nullptr;
             h->pending_view_n = 0;
             h->pending_cands = span_cands;
+            }
         } else {
         if (!ref_overrides.empty()) {   // Reference alleles that MNV reallocation added support to
             std::map<int32_t, const PiscesCalledAllele*> by_pos;

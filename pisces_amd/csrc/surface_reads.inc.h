@@ -42,10 +42,10 @@ static int32_t meta_upload(PiscesHip* h, void* dst, const void* src, size_t byte
         h->h_meta_used = 0;
         if (need > h->h_meta_cap) {
             const size_t want = std::max<size_t>(need * 2, (size_t)1 << 20);
-            if (h->h_meta) (void)hipHostFree(h->h_meta);
+            if (h->h_meta) host_free(h->h_meta);
             h->h_meta = nullptr;
             h->h_meta_cap = 0;
-            PISCES_HIP_CHECK(h, hipHostMalloc((void**)&h->h_meta, want, hipHostMallocDefault));
+            PISCES_HIP_CHECK(h, host_alloc((void**)&h->h_meta, want));
             h->h_meta_cap = want;
         }
     }
@@ -67,11 +67,11 @@ static int32_t stage_reserve(PiscesHip* h, size_t bytes, bool with_device_half =
         st.in_flight = false;
     }
     if (bytes > st.h_cap) {
-        if (st.h) (void)hipHostFree(st.h);
+        if (st.h) host_free(st.h);
         st.h = nullptr;
         st.h_cap = 0;
         const size_t want = bytes + bytes / 2 + 4096;
-        PISCES_HIP_CHECK(h, hipHostMalloc((void**)&st.h, want, hipHostMallocDefault));
+        PISCES_HIP_CHECK(h, host_alloc((void**)&st.h, want));
         st.h_cap = want;
     }
     if (with_device_half) PISCES_HIP_CHECK(h, st.d.reserve(bytes));
@@ -354,8 +354,10 @@ static void launch_find_count(PiscesHip* h, const DevReadBatch& db, const uint8_
     } else if (FP.snvs_and_mnvs && h->finder_wave) {
         const unsigned waves = (unsigned)((nr + kReadsPerWave - 1) / kReadsPerWave);
         hipLaunchKernelGGL(find_count_wave_kernel, dim3((waves + 3) / 4), dim3(256), 0, h->stream, db, d_deldirs, (const uint8_t*)h->d_ref.p, h->ref_len, FP, n_found, n_pool);
+    } else if (FP.snvs_and_mnvs && h->finder_wave != 3 && FP.min_bq <= 127) {
+        hipLaunchKernelGGL(find_count_kernel<true>, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, h->stream, db, d_deldirs, (const uint8_t*)h->d_ref.p, h->ref_len, FP, n_found, n_pool);
     } else {
-        hipLaunchKernelGGL(find_count_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, h->stream, db, d_deldirs, (const uint8_t*)h->d_ref.p, h->ref_len, FP, n_found, n_pool);
+        hipLaunchKernelGGL(find_count_kernel<false>, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, h->stream, db, d_deldirs, (const uint8_t*)h->d_ref.p, h->ref_len, FP, n_found, n_pool);
     }
 }
 static void launch_find_emit(PiscesHip* h, const DevReadBatch& db, const uint8_t* d_deldirs, const FinderParams& FP, int32_t nr, const int32_t* d_slots,
@@ -368,8 +370,11 @@ static void launch_find_emit(PiscesHip* h, const DevReadBatch& db, const uint8_t
         const unsigned waves = (unsigned)((nr + kReadsPerWave - 1) / kReadsPerWave);
         hipLaunchKernelGGL(find_emit_wave_kernel, dim3((waves + 3) / 4), dim3(256), 0, h->stream, db, d_deldirs, (const uint8_t*)h->d_ref.p, h->ref_len, FP, d_slots,
                            d_pool_first, out, pool, misc, pool_capacity, (int32_t*)(misc + 1));
+    } else if (FP.snvs_and_mnvs && h->finder_wave != 3 && FP.min_bq <= 127) {
+        hipLaunchKernelGGL(find_emit_kernel<true>, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, h->stream, db, d_deldirs, (const uint8_t*)h->d_ref.p, h->ref_len, FP, d_slots,
+                           d_pool_first, out, pool, misc, pool_capacity, (int32_t*)(misc + 1));
     } else {
-        hipLaunchKernelGGL(find_emit_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, h->stream, db, d_deldirs, (const uint8_t*)h->d_ref.p, h->ref_len, FP, d_slots,
+        hipLaunchKernelGGL(find_emit_kernel<false>, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, h->stream, db, d_deldirs, (const uint8_t*)h->d_ref.p, h->ref_len, FP, d_slots,
                            d_pool_first, out, pool, misc, pool_capacity, (int32_t*)(misc + 1));
     }
 }
@@ -422,10 +427,10 @@ static int32_t enqueue_candidate_discovery(PiscesHip* h, const DevReadBatch& db,
             const size_t rec_bytes = (size_t)found_slots * (merge ? sizeof(DevMerged) : sizeof(DevFound)), pool_al = ((size_t)found_pool + 15) & ~(size_t)15;
             const size_t need = rec_bytes + pool_al + 16;
             if (need > h->found.h_cap) {
-                if (h->found.h) (void)hipHostFree(h->found.h);
+                if (h->found.h) host_free(h->found.h);
                 h->found.h = nullptr;
                 h->found.h_cap = 0;
-                PISCES_HIP_CHECK(h, hipHostMalloc((void**)&h->found.h, need + need / 2, hipHostMallocDefault));
+                PISCES_HIP_CHECK(h, host_alloc((void**)&h->found.h, need + need / 2));
                 h->found.h_cap = need + need / 2;
             }
             if (!h->found.done) PISCES_HIP_CHECK(h, hipEventCreateWithFlags(&h->found.done, hipEventDisableTiming));

@@ -521,3 +521,46 @@ def test_reads_added_ahead_of_the_flush_that_clears_what_lies_behind_them(torch_
     for ahead, device_fed in ((True, False), (True, True)):
         got = run(ahead, device_fed)
         assert got[0].tobytes() == want[0].tobytes() and got[1] == want[1] and got[2] == want[2], (ahead, device_fed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gvcf", [1, 0], ids=["gvcf", "variants only"])
+def test_candidate_rows_merged_in_place_equal_the_rows_merged_by_copy(torch_cuda, gvcf):
+    """The rows of the candidate kernel (insertions, deletions) join the tile kernels' rows inside the pinned download buffer
+    (AlleleCaller.cs:146-147, :172-176: the Reference row of the position goes, the rows stay in position / ref / alt order); the A / B is
+    the merge into a vector of its own (PISCES_HIP_MERGE_IN_PLACE=0).  A gVCF (a Reference row goes for nearly every row that comes: the rows
+    shift by one for a position or two) and variants only (nothing goes: every row behind the first insertion moves), rows read as a view
+    and through the caller's arrays, a handle made from what the last one left behind (pisces_hip_trim_memory gives that back)."""
+    from pisces_amd import _native, engine, synth
+    seed, depth, n_amp = 41, 300, 40
+    cfg = _abi.default_config(emit_zero_coverage_refs=1) if gvcf else _abi.default_config(include_reference_calls=0)
+    n_loci = n_amp * synth.READ_LEN
+    ref = synth.reference_of(n_loci, seed, device="cuda")
+    p = synth.make_pileup(n_loci, depth, seed=seed, device="cuda", first_locus=0, total_loci=n_loci, with_tuples=False)
+    batch, planted = synth.mixed_reads(p, seed, kinds="DI")
+    out = {}
+    for in_place in (1, 0):
+        with env(PISCES_HIP_MERGE_IN_PLACE=in_place):
+            for how in ("view", "arrays"):
+                with engine.HipVariantCaller(cfg) as c:
+                    c.SetReference(ref)
+                    c.AddAlleleCounts(batch)
+                    rows = []
+                    alleles = []
+                    for up in (3000, None):
+                        if how == "view":
+                            rows.append(c.CallView(up).copy())
+                        else:
+                            r, a = c.CallWithAlleles(up, capacity=1 << 15)
+                            rows.append(r)
+                            alleles += a
+                    out[(in_place, how)] = (np.concatenate(rows), alleles, c.Stats())
+    want = out[(0, "arrays")]
+    cats = (want[0]["info"] >> 4) & 7
+    assert (cats == _abi.CAT_DELETION).sum() >= 3 and (cats == _abi.CAT_INSERTION).sum() >= 3 and len(want[1]) >= 6
+    assert gvcf == int((cats == _abi.CAT_REFERENCE).any())
+    for key, got in out.items():
+        assert got[0].tobytes() == want[0].tobytes() and got[2] == want[2], key
+        if key[1] == "arrays":
+            assert got[1] == want[1], key
+    assert _native.lib.pisces_hip_trim_memory() > 0 and _native.lib.pisces_hip_trim_memory() == 0
