@@ -98,11 +98,9 @@ def read_batch_range(arrays, i0, i1):
                                       cigar_len=cig_len[c0:c1], seq_offset=seq_off[i0:i1 + 1] - s0, bases=bases[s0:s1], quals=quals[s0:s1])
 
 
-def run_piece(engine, cfg, job, lo=None, hi=None, halo=synth.READ_LEN + 16, device=0, chunk_reads=400_000, with_alleles=True, keep_records=True):
-    """One (contig, owned range) job on one handle: set_reference, set_intervals (clipped to the range), the reads
-    shard.reads_for_shard gives it, one final flush.  lo / hi None: the whole contig.  Returns (records, alleles, stats, reads counted:
-    a read is counted by the piece that owns its start).  keep_records=False (bench.py): the rows are looked at where they lie
-    (pisces_hip_flush_view) and only counted — `records` is then {"n": rows, "loci": distinct positions}."""
+def piece_plan(job, lo=None, hi=None, halo=synth.READ_LEN + 16):
+    """What a (contig, owned range) piece is made of: the clipped intervals, the reads shard.reads_for_shard gives it ([i0, i1) of the
+    position-sorted reads) and how many of them it owns (a read is counted by the piece that owns its start)."""
     starts, ends = job["starts"], job["ends"]
     pos = job["arrays"][0].astype(np.int64)
     if lo is None:
@@ -110,6 +108,45 @@ def run_piece(engine, cfg, job, lo=None, hi=None, halo=synth.READ_LEN + 16, devi
     keep = (ends >= lo) & (starts <= hi)
     ivs = list(zip(np.maximum(starts[keep], lo).tolist(), np.minimum(ends[keep], hi).tolist()))
     idx, owner = shard.reads_for_shard(pos, job["read_end"], lo, hi, halo)
+    i0 = i1 = 0
+    if len(idx):
+        assert idx[-1] - idx[0] + 1 == len(idx)      # position-sorted reads: a contiguous range
+        i0, i1 = int(idx[0]), int(idx[-1]) + 1
+    return {"lo": lo, "hi": hi, "intervals": ivs, "i0": i0, "i1": i1, "pos": pos, "owned": int(owner.sum())}
+
+
+def device_arrays(job, device="cuda:0"):
+    """The contig's read arrays in device memory (torch tensors, the order of job["arrays"])."""
+    import torch
+    return [torch.from_numpy(np.ascontiguousarray(a if a.dtype != np.uint32 else a.view(np.int32))).to(device) for a in job["arrays"]]
+
+
+def device_chunks(engine, job, dev_arrays, plan, chunk_reads=400_000):
+    """The stretches of reads run_piece adds, as engine.DeviceReadBatch views of the contig's arrays in device memory (offsets rebased to
+    the stretch: two small tensors of their own)."""
+    pos, flags, cig_off, cig_op, cig_len, seq_off, bases, quals = dev_arrays
+    h_cig_off, h_seq_off = job["arrays"][2], job["arrays"][5]
+    out = []
+    for a in range(plan["i0"], plan["i1"], chunk_reads):
+        b = min(a + chunk_reads, plan["i1"])
+        c0, c1, s0, s1 = int(h_cig_off[a]), int(h_cig_off[b]), int(h_seq_off[a]), int(h_seq_off[b])
+        out.append(engine.DeviceReadBatch(pos[a:b], flags[a:b], cig_off[a:b + 1] - c0, cig_op[c0:c1], cig_len[c0:c1], seq_off[a:b + 1] - s0,
+                                          bases[s0:s1], quals[s0:s1], n_ops=c1 - c0, n_bases=s1 - s0))
+    if out:
+        out[0].synchronize()
+    return out
+
+
+def run_piece(engine, cfg, job, lo=None, hi=None, halo=synth.READ_LEN + 16, device=0, chunk_reads=400_000, with_alleles=True, keep_records=True,
+              plan=None, chunks=None):
+    """One (contig, owned range) job on one handle: set_reference, set_intervals (clipped to the range), the reads
+    shard.reads_for_shard gives it, one final flush.  lo / hi None: the whole contig.  Returns (records, alleles, stats, reads counted:
+    a read is counted by the piece that owns its start).  keep_records=False (bench.py): the rows are looked at where they lie
+    (pisces_hip_flush_view) and only counted — `records` is then {"n": rows, "loci": distinct positions}.  chunks (device_chunks of
+    `plan`): the reads are handed over in device memory (pisces_hip_add_device_reads) instead of from the host arrays."""
+    if plan is None:
+        plan = piece_plan(job, lo, hi, halo)
+    lo, hi, pos, i0, i1 = plan["lo"], plan["hi"], plan["pos"], plan["i0"], plan["i1"]
     recs, alleles = [], []
     n_rows = n_loci = 0
     last_position = [0]
@@ -126,23 +163,23 @@ def run_piece(engine, cfg, job, lo=None, hi=None, halo=synth.READ_LEN + 16, devi
     take = (lambda view: view.copy()) if keep_records else count
     with engine.HipVariantCaller(cfg, device=device) as c:
         c.SetReference(job["ref"])
-        c.SetIntervals(ivs)
+        c.SetIntervals(plan["intervals"])
         c.SetOwnedRange(lo, hi)
-        if len(idx):
-            assert idx[-1] - idx[0] + 1 == len(idx)      # position-sorted reads: a contiguous range
-            i0, i1 = int(idx[0]), int(idx[-1]) + 1
-            for a in range(i0, i1, chunk_reads):          # the streaming protocol: add a stretch of reads, call what lies behind them
-                b = min(a + chunk_reads, i1)
+        for k, a in enumerate(range(i0, i1, chunk_reads)):   # the streaming protocol: add a stretch of reads, call what lies behind them
+            b = min(a + chunk_reads, i1)
+            if chunks is not None:
+                c.AddDeviceReads(chunks[k])
+            else:
                 c.AddAlleleCounts(read_batch_range(job["arrays"], a, b))
-                if b < i1:
-                    r, al = c.CallWithAlleles(int(pos[b]) - 1, capacity=1 << 20) if with_alleles else (take(c.CallView(int(pos[b]) - 1)), [])
-                    recs.append(r)
-                    alleles += al
+            if b < i1:
+                r, al = c.CallWithAlleles(int(pos[b]) - 1, capacity=1 << 20) if with_alleles else (take(c.CallView(int(pos[b]) - 1)), [])
+                recs.append(r)
+                alleles += al
         r, al = c.CallWithAlleles(None, capacity=1 << 20) if with_alleles else (take(c.CallView(None)), [])   # (rows read in place; kept by copying them once)
         recs.append(r)
         alleles += al
         stats = c.Stats()
         stats["host_time"] = c.HostTime()
     if not keep_records:
-        return {"n": n_rows, "loci": n_loci}, alleles, stats, int(owner.sum())
-    return np.concatenate(recs), alleles, stats, int(owner.sum())
+        return {"n": n_rows, "loci": n_loci}, alleles, stats, plan["owned"]
+    return np.concatenate(recs), alleles, stats, plan["owned"]
