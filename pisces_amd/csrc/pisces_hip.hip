@@ -321,7 +321,7 @@ struct PiscesHip {
     int32_t own_lo = 1, own_hi = 0x7FFFFFFF;              // pisces_hip_set_owned_range
     int64_t stats[4] = {0, 0, 0, 0};      // called, collapsed, reads processed, reads skipped
     bool in_flush_begin = false;
-    double prof[12] = {0};                 // development (PISCES_HIP_HOST_PROFILE=1): host seconds by phase of a flush, printed when the handle goes
+    double prof[16] = {0};                 // development (PISCES_HIP_HOST_PROFILE=1): host seconds by phase of a flush, printed when the handle goes
     bool prof_on = false;
     int64_t pcie[4] = {0, 0, 0, 0};          // pisces_hip_transfer_bytes: H2D reads / file bytes, D2H records, D2H candidate records, D2H counts
     double host_time[4] = {0, 0, 0, 0};   // pisces_hip_host_time: seconds in add_reads, in flush, of that waiting for the device; flushes
@@ -427,6 +427,14 @@ struct PiscesHip {
         int32_t min_position = 0;            // lowest read position of the batch, 0 = unknown (a flush below it need not wait for the records)
         bool split = false;                  // the plain SNV groups went to the SNV store (misc[3] of them)
         bool split_counted = false;          // ... and a sweep of the store has counted them since (snv_ub is exact: nothing to correct)
+        // MNV calling on: the walk is counted at the add (find_count + scan), the records are written (find_emit, merge, gather) by the next
+        // entry that comes along — by then the totals that size their buffers have arrived and nobody waits for them
+        bool counted_only = false;
+        hipEvent_t counted = nullptr;
+        long long* h_totals = nullptr;       // pinned: {record slots, pool bytes}
+        DevReadBatch db;
+        const uint8_t* d_deldirs = nullptr;
+        int32_t nr = 0;
     } found;
 
     // MNV calling on, SPLIT FORM (surface_flush.inc.h): the fully anchored SNV groups of the read walk stay in device memory (the SNV store,
@@ -903,9 +911,10 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_OK;
     if (h->prof_on) {
-        static const char* names[12] = {"consume_found", "spanning: candidates of the batch", "spanning: counts to the host", "collapse", "device pass (MNVs)",
-                                        "reallocate", "device pass (all)", "call_blocks", "row merge / genotypers", "copy out + DoneProcessing", "split: dirty loci + SNV store", "  of reallocate: mnv_reallocate_failed"};
-        for (int i = 0; i < 12; i++) fprintf(stderr, "pisces_hip host profile: %-36s %9.3f ms\n", names[i], h->prof[i] * 1e3);
+        static const char* names[16] = {"consume_found", "spanning: candidates of the batch", "spanning: counts to the host", "collapse", "device pass (MNVs)",
+                                        "reallocate", "device pass (all)", "call_blocks", "row merge / genotypers", "copy out + DoneProcessing", "split: dirty loci + SNV store", "  of reallocate: mnv_reallocate_failed",
+                                        "add_device_reads: consume_found", "add_device_reads: copies + checks", "add_device_reads: shape + discovery + commit", "-"};
+        for (int i = 0; i < 15; i++) fprintf(stderr, "pisces_hip host profile: %-36s %9.3f ms\n", names[i], h->prof[i] * 1e3);
         if (h->mnv_split)
             fprintf(stderr, "pisces_hip split form: %lld SNV groups into the store, %lld taken by flushes (dirty loci), %lld dropped unseen, %lld sweeps\n",
                     (long long)h->split_stats[0], (long long)h->split_stats[1], (long long)h->split_stats[2], (long long)h->split_stats[3]);
@@ -946,6 +955,10 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     h->found.h = nullptr;
     if (h->found.done) (void)hipEventDestroy(h->found.done);
     h->found.done = nullptr;
+    if (h->found.counted) (void)hipEventDestroy(h->found.counted);
+    h->found.counted = nullptr;
+    if (h->found.h_totals) host_free(h->found.h_totals);
+    h->found.h_totals = nullptr;
     h->d_found.release(); h->d_found_pool.release(); h->d_found_slots.release(); h->d_found_pool_first.release();
     h->d_merge_tab.release(); h->d_merge_acc.release();
     h->d_scan_sums.release(); h->d_prep_map.release(); h->d_folded.release(); h->d_span_tiles.release();

@@ -139,6 +139,7 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
     return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (!file || n_bytes <= 0 || n_blocks <= 0 || !blocks) return fail(h, PISCES_E_INVALID_ARG, "bam_decode: bad arguments");
+    { int32_t rcd = finish_candidate_discovery(h); if (rcd) return rcd; }   // (the last batch's walk may still read the arrays this decode writes)
     h->bam.valid = false;
     h->bam.moved = false;
     h->bam.added = false;

@@ -1468,6 +1468,7 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
     // flush clears, nor among the candidates it may take from held blocks (SNVs / MNVs that end at or before upTo) — and a host that adds
     // the next stretch of reads before it calls up to their first position (SmallVariantCaller's LastClearedPosition) has the device
     // discover that stretch's candidates under this flush's host work.
+    { int32_t rcd = finish_candidate_discovery(h); if (rcd) return rcd; }   // (the records of the last batch's walk go on their way before this flush's kernels)
     if (!(up_to_position >= 0 && h->found.in_flight && h->found.min_position > up_to_position && !h->pending_valid)) { int32_t rcf = consume_found(h); if (rcf) return rcf; }
     const bool final_flush = up_to_position < 0;
     const bool replay = h->pending_valid && h->pending_up_to == up_to_position;
@@ -2010,6 +2011,7 @@ int32_t pisces_hip_flush_begin(PiscesHip* h, int32_t up_to_position)
     struct InBegin { bool& f; explicit InBegin(bool& x) : f(x) { f = true; } ~InBegin() { f = false; } } in_begin(h->in_flush_begin);
     { int32_t rcp = refuse_while_batch_is_open(h, "flush_begin"); if (rcp) return rcp; }
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    { int32_t rcd = finish_candidate_discovery(h); if (rcd) return rcd; }
     if (!(up_to_position >= 0 && h->found.in_flight && h->found.min_position > up_to_position)) { int32_t rcf = consume_found(h); if (rcf) return rcf; }
     const bool final_flush = up_to_position < 0;
     auto& A = h->async;

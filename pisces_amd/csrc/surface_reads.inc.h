@@ -382,41 +382,67 @@ static void launch_find_emit(PiscesHip* h, const DevReadBatch& db, const uint8_t
 // Candidate discovery for a read batch that is on the device (find_count / found_scan / find_emit kernels), enqueued on the handle's
 // stream; its records come back into pinned memory and are merged by consume_found when they are needed.  d_slots: the record slots
 // the host reserved per read from the CIGARs (MNV calling off), found_slots / found_pool their totals.
+static int32_t enqueue_found_records(PiscesHip* h, const DevReadBatch& db, const uint8_t* d_deldirs, int32_t nr, const FinderParams& FP, const int32_t* d_slots,
+                                     const int32_t* d_pool_first, int64_t found_slots, int64_t found_pool);
+static FinderParams finder_params(const PiscesHip* h)
+{
+    const FinderParams FP = {h->cfg.min_base_call_quality, PISCES_ANCHOR_SIZE, h->cfg.call_mnvs ? 1 : 0, h->cfg.call_mnvs ? 1 : 0, h->cfg.max_mnv_length,
+                             h->cfg.max_gap_between_mnv, h->mnv_split ? 1 : 0};
+    return FP;
+}
 static int32_t enqueue_candidate_discovery(PiscesHip* h, const DevReadBatch& db, const uint8_t* d_deldirs, int32_t nr, const int32_t* d_slots_in,
                                            int64_t found_slots, int64_t found_pool)
 {
-    const int32_t minBQ = h->cfg.min_base_call_quality;
-    const int32_t* d_slots = d_slots_in;
-        const FinderParams FP = {minBQ, PISCES_ANCHOR_SIZE, h->cfg.call_mnvs ? 1 : 0, h->cfg.call_mnvs ? 1 : 0, h->cfg.max_mnv_length,
-                                 h->cfg.max_gap_between_mnv, h->mnv_split ? 1 : 0};
-        // (arrival stamps: this batch's records come behind everything the host added so far)
-        h->batch_seq++;
-        h->host_seq = 0;
-        h->found.batch = h->batch_seq;
-        h->found.split = false;
-        h->found.split_counted = false;
-        h->found.min_position = 0;
-        PISCES_HIP_CHECK(h, h->d_found_misc.reserve(4));
-        PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_found_misc.p, 0, 4 * sizeof(unsigned int), h->stream));
-        const int32_t* d_pool_first = nullptr;
-        if (h->cfg.call_mnvs) {
-            // count, scan (one more element than reads: the last one receives the total), then size the record buffer
-            PISCES_HIP_CHECK(h, h->d_found_slots.reserve((size_t)nr + 1));
-            PISCES_HIP_CHECK(h, h->d_found_pool_first.reserve((size_t)nr + 1));
-            PISCES_HIP_CHECK(h, h->d_found_totals.reserve(2));
-            PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_found_slots.p + nr, 0, sizeof(int32_t), h->stream));
-            PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_found_pool_first.p + nr, 0, sizeof(int32_t), h->stream));
-            launch_find_count(h, db, d_deldirs, FP, nr, h->d_found_slots.p, h->d_found_pool_first.p);
-            { int32_t rcs = launch_found_scan(h, h->d_found_slots.p, h->d_found_pool_first.p, nr + 1, h->d_found_totals.p); if (rcs) return rcs; }
-            long long totals[2] = {0, 0};
-            PISCES_HIP_CHECK(h, hipMemcpyAsync(totals, h->d_found_totals.p, sizeof(totals), hipMemcpyDeviceToHost, h->stream));
-            PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
-            if (totals[0] > 0x7FFFFFF0ll || totals[1] > 0x7FFFFFF0ll) return fail(h, PISCES_E_INVALID_ARG, "add_reads: too many candidates in one batch");
-            found_slots = totals[0];
-            found_pool = totals[1];
-            d_slots = h->d_found_slots.p;
-            d_pool_first = h->d_found_pool_first.p;
-        }
+    const FinderParams FP = finder_params(h);
+    // (arrival stamps: this batch's records come behind everything the host added so far)
+    h->batch_seq++;
+    h->host_seq = 0;
+    h->found.batch = h->batch_seq;
+    h->found.split = false;
+    h->found.split_counted = false;
+    h->found.min_position = 0;
+    h->found.counted_only = false;
+    PISCES_HIP_CHECK(h, h->d_found_misc.reserve(4));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_found_misc.p, 0, 4 * sizeof(unsigned int), h->stream));
+    if (!h->cfg.call_mnvs) return enqueue_found_records(h, db, d_deldirs, nr, FP, d_slots_in, nullptr, found_slots, found_pool);
+    // count, scan (one more element than reads: the last one receives the total); the totals size the record buffers: they travel to pinned
+    // memory behind an event, and the second half (finish_candidate_discovery) is enqueued by whichever entry comes next — the batch's
+    // arrays stay where they are until then (a segment's blob; or the staging pair, which only the next add reuses, behind that half)
+    PISCES_HIP_CHECK(h, h->d_found_slots.reserve((size_t)nr + 1));
+    PISCES_HIP_CHECK(h, h->d_found_pool_first.reserve((size_t)nr + 1));
+    PISCES_HIP_CHECK(h, h->d_found_totals.reserve(2));
+    if (!h->found.h_totals) PISCES_HIP_CHECK(h, host_alloc((void**)&h->found.h_totals, 64));
+    if (!h->found.counted) PISCES_HIP_CHECK(h, hipEventCreateWithFlags(&h->found.counted, hipEventDisableTiming));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_found_slots.p + nr, 0, sizeof(int32_t), h->stream));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_found_pool_first.p + nr, 0, sizeof(int32_t), h->stream));
+    launch_find_count(h, db, d_deldirs, FP, nr, h->d_found_slots.p, h->d_found_pool_first.p);
+    { int32_t rcs = launch_found_scan(h, h->d_found_slots.p, h->d_found_pool_first.p, nr + 1, h->d_found_totals.p); if (rcs) return rcs; }
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(h->found.h_totals, h->d_found_totals.p, 2 * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    PISCES_HIP_CHECK(h, hipEventRecord(h->found.counted, h->stream));
+    h->found.db = db;
+    h->found.d_deldirs = d_deldirs;
+    h->found.nr = nr;
+    h->found.counted_only = true;
+    h->found.in_flight = true;
+    h->found.n_slots = 0;
+    h->found.pool_bytes = 0;
+    return PISCES_OK;
+}
+// the second half of a batch's candidate discovery (MNV calling on), if it is still to come
+static int32_t finish_candidate_discovery(PiscesHip* h)
+{
+    if (!h->found.counted_only) return PISCES_OK;
+    h->found.counted_only = false;
+    h->found.in_flight = false;
+    PISCES_TIMED_WAIT(h, hipEventSynchronize(h->found.counted));
+    const long long found_slots = h->found.h_totals[0], found_pool = h->found.h_totals[1];
+    if (found_slots > 0x7FFFFFF0ll || found_pool > 0x7FFFFFF0ll) return fail(h, PISCES_E_INVALID_ARG, "add_reads: too many candidates in one batch");
+    return enqueue_found_records(h, h->found.db, h->found.d_deldirs, h->found.nr, finder_params(h), h->d_found_slots.p, h->d_found_pool_first.p, found_slots, found_pool);
+}
+static int32_t enqueue_found_records(PiscesHip* h, const DevReadBatch& db, const uint8_t* d_deldirs, int32_t nr, const FinderParams& FP, const int32_t* d_slots,
+                                     const int32_t* d_pool_first, int64_t found_slots, int64_t found_pool)
+{
         if (found_slots > 0) {
             PISCES_HIP_CHECK(h, h->d_found.reserve((size_t)found_slots));
             PISCES_HIP_CHECK(h, h->d_found_pool.reserve((size_t)found_pool + 16));
@@ -455,7 +481,7 @@ static int32_t enqueue_candidate_discovery(PiscesHip* h, const DevReadBatch& db,
                     PISCES_HIP_CHECK(h, h->d_snv[h->snv_cur].grow_keep((size_t)(h->snv_ub + found_slots), (size_t)h->snv_ub, h->stream));
                     hipLaunchKernelGGL(found_gather_split_kernel, dim3(mgrid), dim3(256), 0, h->stream, (const DevFound*)h->d_found.p, (int32_t)found_slots,
                                        (const int32_t*)h->d_merge_acc.p, (DevMerged*)h->found.h, h->d_found_misc.p, h->d_snv[h->snv_cur].p,
-                                       h->d_snv_n.p + h->snv_cur, (uint32_t)std::min<size_t>(h->d_snv[h->snv_cur].cap, 0xFFFFFFF0u), h->batch_seq,
+                                       h->d_snv_n.p + h->snv_cur, (uint32_t)std::min<size_t>(h->d_snv[h->snv_cur].cap, 0xFFFFFFF0u), h->found.batch,
                                        h->cfg.collapse != 0 ? 1 : 0);
                     h->snv_ub += found_slots;   // (an upper bound until the batch's counts are in: consume_found)
                     h->found.split = true;
@@ -483,6 +509,7 @@ static int32_t enqueue_candidate_discovery(PiscesHip* h, const DevReadBatch& db,
 // IStateManager.AddCandidates (SmallVariantCaller.cs:92-96).  Called before anything that looks at the candidates.
 static int32_t consume_found(PiscesHip* h)
 {
+    { int32_t rcd = finish_candidate_discovery(h); if (rcd) return rcd; }
     if (!h->found.in_flight) return PISCES_OK;
     HostTimer prof(h->prof_on ? &h->prof[0] : nullptr);
     h->found.in_flight = false;
@@ -905,6 +932,7 @@ int64_t pisces_hip_find_candidates_device(PiscesHip* h, const PiscesReadBatch* b
     if (allele_bytes) *allele_bytes = 0;
     if (batch->n_reads == 0) return 0;
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    { int32_t rcd = finish_candidate_discovery(h); if (rcd) return rcd; }   // (this entry uses the discovery buffers)
     const int32_t nr = batch->n_reads;
     for (int32_t i = 0; i < nr; i++) {
         const ReadView r = read_view(batch, i);

@@ -594,7 +594,8 @@ int32_t pisces_hip_add_device_reads(PiscesHip* h, const PiscesReadBatch* batch, 
         return fail(h, PISCES_E_INVALID_ARG, "add_device_reads: malformed read batch");
     if (h->read_path != 1) return fail(h, PISCES_E_UNSUPPORTED, "add_device_reads: the observation-log chain (PISCES_HIP_READ_PATH=log) takes host batches only");
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
-    { int32_t rcf = consume_found(h); if (rcf) return rcf; }
+    { HostTimer prof_c(h->prof_on ? &h->prof[12] : nullptr); int32_t rcf = consume_found(h); if (rcf) return rcf; }
+    std::unique_ptr<HostTimer> prof_a(new HostTimer(h->prof_on ? &h->prof[13] : nullptr));
     const size_t n_cig = (size_t)n_cigar_ops, n_seq = (size_t)n_bases;
     const bool has_dirs = batch->directions != nullptr, has_deldirs = batch->deletion_directions != nullptr;
     const StageLayout L = stage_layout((size_t)nr, n_cig, n_seq, has_dirs, has_deldirs);
@@ -629,6 +630,7 @@ int32_t pisces_hip_add_device_reads(PiscesHip* h, const PiscesReadBatch* batch, 
     int64_t found_slots = 0, found_pool = 0;
     int32_t max_key = 0, min_position = 0;
     if (rc == PISCES_OK) rc = store_device_checks(h, d, L, nr, n_cig, n_seq, has_dirs, has_deldirs, count_indels, &found_slots, &found_pool, touched, &max_key, &min_position);
+    prof_a.reset(new HostTimer(h->prof_on ? &h->prof[14] : nullptr));
     return store_finish_add(h, pl, rc, d, L, nr, n_cig, n_seq, has_dirs, has_deldirs, find_on_device, found_slots, found_pool, nullptr, touched, max_key, min_position);
     });
 }

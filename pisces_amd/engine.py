@@ -643,8 +643,8 @@ def _candidate_dicts(cands, pool, n):
     for i in range(n):
         c = cands[i]
         o = c.allele_offset
-        out.append({"position": c.position, "category": c.category, "ref": bytes(pool[o: o + c.ref_len]).decode(),
-                    "alt": bytes(pool[o + c.ref_len: o + c.ref_len + c.alt_len]).decode(),
+        out.append({"position": c.position, "category": c.category, "ref": bytes(pool[o: o + c.ref_len]).decode("latin-1"),   # (inserted bases are whatever bytes the read holds)
+                    "alt": bytes(pool[o + c.ref_len: o + c.ref_len + c.alt_len]).decode("latin-1"),
                     "support_by_dir": list(c.support_by_dir), "well_anchored_by_dir": list(c.well_anchored_by_dir),
                     "open_left": bool(c.open_left), "open_right": bool(c.open_right)})
     return out

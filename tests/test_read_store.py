@@ -564,3 +564,36 @@ def test_candidate_rows_merged_in_place_equal_the_rows_merged_by_copy(torch_cuda
         if key[1] == "arrays":
             assert got[1] == want[1], key
     assert _native.lib.pisces_hip_trim_memory() > 0 and _native.lib.pisces_hip_trim_memory() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["events", "bases", "wave", "batch"])
+def test_every_form_of_the_candidate_walk_equals_the_host_walk(torch_cuda, form):
+    """ICandidateVariantFinder.FindCandidates (CandidateVariantFinder.cs:31-203) in the forms finder_kernels.hip.h holds — a lane a read
+    with the events first (the default), a lane a read base by base, a wave a read, a wave for 64 reads (PISCES_HIP_FINDER) — against the
+    host's base-by-base walk (pisces_hip_find_candidates, finder_walk.h): reads with any CIGAR, N bases, bytes that are no bases, low
+    qualities, qualities above 127, M operations shorter than a word and longer than a chunk of 64 bases, MNV limits from 1 to 6 bases
+    and gaps from 0 to 3."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(77)
+    ref = bytes(rng.choice(list(b"ACGTN"), 3000, p=[.245, .245, .245, .245, .02]).astype(np.uint8))
+    reads = random_reads(rng, 600, 1, 2600, exotic=True)
+    for i in range(60):   # long aligned runs that differ from the reference here and there (MNVs with gaps, runs that hit the length limit)
+        pos = int(rng.integers(1, 2500))
+        n = int(rng.integers(130, 400))
+        seq = bytearray(ref[pos - 1:pos - 1 + n])
+        for k in rng.integers(0, len(seq), 12):
+            for j in range(int(rng.integers(1, 5))):
+                if k + 2 * j < len(seq):
+                    seq[k + 2 * j] = int(rng.choice(list(b"ACGT")))
+        reads.append({"pos": pos, "cigar": [("M", len(seq))], "seq": bytes(seq), "quals": rng.choice([12, 30, 37], len(seq), p=[.05, .15, .8]).astype(np.uint8).tolist(),
+                      "reverse": bool(i % 2)})
+    reads.sort(key=lambda r: r["pos"])
+    batch = _abi.ReadBatch(reads)
+    with env(PISCES_HIP_FINDER=None if form == "events" else form):
+        with engine.HipVariantCaller(_abi.default_config()) as c:
+            c.SetReference(ref)
+            for call_mnvs, max_len, max_gap in [(0, 3, 1), (1, 3, 1), (1, 1, 0), (1, 6, 3), (1, 2, 2)]:
+                want = engine.find_candidates(batch, ref, 20, True, bool(call_mnvs), max_len, max_gap)
+                got = c.FindCandidates(batch, True, bool(call_mnvs), max_len, max_gap)
+                assert len(want) > 2000 and got == want, (form, call_mnvs, max_len, max_gap)
