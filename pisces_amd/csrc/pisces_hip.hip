@@ -274,6 +274,7 @@ struct PiscesHip {
     int64_t launches_seen = 0;
     DeviceBuf<unsigned long long> d_totals;
     unsigned long long* h_totals = nullptr;   // pinned: pisces_hip_device_totals
+    uint8_t* h_prep = nullptr;                // pinned: prepare_collect_kernel's PrepVerdict + the keys of the touched blocks
     DeviceBuf<double> d_qlut;
     DeviceBuf<ulonglong2> d_bq_lut;   // [256] Math.Pow(10, -1 * (int)q / 10f) in fixed point (two 38-bit halves): what a base of quality q adds to the sums
     DeviceBuf<unsigned long long> d_sumq_fix;   // the cells' fixed-point accumulators (accumulate_tiles_kernel)
@@ -965,6 +966,8 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     h->d_snv[0].release(); h->d_snv[1].release(); h->d_snv_n.release(); h->d_snv_sel.release(); h->d_dirty.release(); h->d_row_idx.release(); h->d_rows.release();
     if (h->h_totals) host_free(h->h_totals);
     h->h_totals = nullptr;
+    if (h->h_prep) host_free(h->h_prep);
+    h->h_prep = nullptr;
     if (h->h_snv_sel) host_free(h->h_snv_sel);
     h->h_snv_sel = nullptr;
     h->d_found_misc.release(); h->d_found_totals.release();

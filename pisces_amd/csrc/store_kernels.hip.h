@@ -400,6 +400,49 @@ __global__ __launch_bounds__(256) void check_directions_kernel(const uint8_t* __
     if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicMin(first_error, (unsigned long long)kPrepBadDirection);
 }
 
+// What the host needs of read_prepare_kernel's results, into pinned host memory as this kernel's own stores (one wait, no copy operations):
+// the verdict, the span of touched blocks, the totals of the candidate-record slots, and the keys of the touched blocks (any order) — whose
+// bits are cleared here for the next batch.  More touched blocks than `capacity`: nothing is cleared, the host reads the map's words itself.
+struct PrepVerdict {
+    unsigned long long first_error;
+    long long totals[2];
+    int32_t span[3];
+    int32_t n_keys;      // touched blocks (all of them, also beyond capacity)
+};
+static_assert(sizeof(PrepVerdict) == 40, "PrepVerdict layout");
+__global__ __launch_bounds__(256) void prepare_collect_kernel(uint32_t* __restrict__ block_bits, const int32_t* __restrict__ key_span,
+                                                              const unsigned long long* __restrict__ first_error, const long long* __restrict__ totals /* or nullptr */,
+                                                              PrepVerdict* __restrict__ out, int32_t* __restrict__ keys_out, int32_t capacity)
+{
+    __shared__ int s_n, s_at;
+    const int lo = key_span[0], hi = key_span[1];
+    if (threadIdx.x == 0) { s_n = 0; s_at = 0; }
+    __syncthreads();
+    const bool any = hi >= lo && hi > 0;
+    const int w0 = any ? lo >> 5 : 0, w1 = any ? hi >> 5 : -1;
+    int mine = 0;
+    for (int w = w0 + (int)threadIdx.x; w <= w1; w += 256) mine += __popc(block_bits[w]);
+    if (mine) atomicAdd(&s_n, mine);
+    __syncthreads();
+    const int n = s_n;
+    if (n <= capacity) {
+        for (int w = w0 + (int)threadIdx.x; w <= w1; w += 256) {
+            uint32_t bits = block_bits[w];
+            if (!bits) continue;
+            int at = atomicAdd(&s_at, __popc(bits));
+            for (; bits; bits &= bits - 1) keys_out[at++] = w * 32 + (int)__builtin_ctz(bits);
+            block_bits[w] = 0;
+        }
+    }
+    if (threadIdx.x == 0) {
+        out->first_error = *first_error;
+        out->totals[0] = totals ? totals[0] : 0;
+        out->totals[1] = totals ? totals[1] : 0;
+        out->span[0] = key_span[0]; out->span[1] = key_span[1]; out->span[2] = key_span[2];
+        out->n_keys = n;
+    }
+}
+
 // small batches: their bytes join the open segment (up to five ranges in one launch; byte-wise: destinations are not aligned)
 struct CopyRanges {
     uint8_t* dst[5];

@@ -355,17 +355,26 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
     if (count_indels)
         { int32_t rcs = launch_found_scan(h, (int32_t*)(d + L.off_fslots), h->d_found_pool_first.p, nr + 1, h->d_found_totals.p); if (rcs) return rcs; }
     PISCES_HIP_CHECK(h, hipGetLastError());
-    unsigned long long first_error = ~0ull;
-    int32_t span[3] = {0x7FFFFFFF, 0, 0x7FFFFFFF};
-    long long totals[2] = {0, 0};
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(&first_error, B.d_first_error.p, sizeof(first_error), hipMemcpyDeviceToHost, h->stream));
-    PISCES_HIP_CHECK(h, hipMemcpyAsync(span, d_span, sizeof(span), hipMemcpyDeviceToHost, h->stream));
-    if (count_indels) PISCES_HIP_CHECK(h, hipMemcpyAsync(totals, h->d_found_totals.p, sizeof(totals), hipMemcpyDeviceToHost, h->stream));
+    // verdict, span, totals and the touched blocks arrive in pinned memory as one kernel's stores: one wait
+    constexpr int32_t kPrepKeys = 8192;
+    if (!h->h_prep) PISCES_HIP_CHECK(h, host_alloc((void**)&h->h_prep, sizeof(PrepVerdict) + (size_t)kPrepKeys * sizeof(int32_t)));
+    PrepVerdict* const verdict = (PrepVerdict*)h->h_prep;
+    int32_t* const keys = (int32_t*)(h->h_prep + sizeof(PrepVerdict));
+    hipLaunchKernelGGL(prepare_collect_kernel, dim3(1), dim3(256), 0, h->stream, h->d_prep_map.p, (const int32_t*)d_span, (const unsigned long long*)B.d_first_error.p,
+                       count_indels ? (const long long*)h->d_found_totals.p : (const long long*)nullptr, verdict, keys, kPrepKeys);
+    PISCES_HIP_CHECK(h, hipGetLastError());
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     h->h_meta_used = 0;
-    // the touched blocks: the bits of [span[0], span[1]], which are cleared again behind the copy
-    std::vector<uint32_t> words;
-    if (span[1] >= span[0] && span[1] > 0) {
+    const unsigned long long first_error = verdict->first_error;
+    const int32_t span[3] = {verdict->span[0], verdict->span[1], verdict->span[2]};
+    const long long totals[2] = {verdict->totals[0], verdict->totals[1]};
+    if (verdict->n_keys <= kPrepKeys) {
+        touched.assign(keys, keys + verdict->n_keys);
+        std::sort(touched.begin(), touched.end());
+        if (!touched.empty()) *max_key = touched.back();
+    } else if (span[1] >= span[0] && span[1] > 0) {
+        // (more touched blocks than the kernel had room for: the bits of [span[0], span[1]], which are cleared again behind the copy)
+        std::vector<uint32_t> words;
         const size_t w0 = (size_t)span[0] >> 5, w1 = (size_t)span[1] >> 5;
         words.resize(w1 - w0 + 1);
         PISCES_HIP_CHECK(h, hipMemcpyAsync(words.data(), h->d_prep_map.p + w0, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));

@@ -98,7 +98,7 @@ def fasta_slice(path, start, end):
     return "".join(seq).upper()
 
 
-def extract(root, bam, chrom, fasta, window, offset, expected, dst_name, ref_literal=None):
+def extract(root, bam, chrom, fasta, window, offset, expected, dst_name, ref_literal=None, more=None):
     """Filters `chrom` alignments as AlignmentSource.ShouldSkipRead does and stores them with the reference window."""
     t = os.path.join(root, "src/test")
     refs, reads = read_bam(os.path.join(t, bam))
@@ -137,7 +137,7 @@ def extract(root, bam, chrom, fasta, window, offset, expected, dst_name, ref_lit
         dst, offset=np.int32(offset), ref_start=np.int32(window[0] - offset), ref=np.frombuffer(ref.encode(), dtype=np.uint8),
         position=position, flags=flags, cigar_offset=np.array(cig_off, dtype=np.int32), cigar_op=np.array(cig_op, dtype=np.uint8),
         cigar_len=np.array(cig_len, dtype=np.uint32), seq_offset=np.array(seq_off, dtype=np.int32), bases=np.concatenate(bases),
-        quals=np.concatenate(quals), expected_vcf=np.array(expected), n_skipped=np.int32(skipped))
+        quals=np.concatenate(quals), expected_vcf=np.array(expected), n_skipped=np.int32(skipped), **{k: np.array(v) for k, v in (more or {}).items()})
     cig = {}
     for r in keep:
         k = "".join(op for op, ln in r["cigar"])
@@ -193,6 +193,27 @@ def main(root):
     with open(os.path.join(t, "Pisces.Tests/TestData/Chr17again.expected.genome.vcf")) as f:
         expected += [l.rstrip("\r\n") for l in f if l.startswith("chr19\t3118942\t")]
     extract(root, "Pisces.Tests/TestData/Chr17Chr19.bam", "chr19", "SharedData/Genomes/chr19/chr19.fa", WINDOW, OFFSET, expected, "bam_chr19.npz")
+    # chr17 of the same BAM (IntervalTestingWithVcf :101-166, IntervalTestingWithMultipleSamples :168-300).  The runs' genome "fourChrs" is an
+    # index without its fasta in the reference's tree; the reference bases come from the REF column of the rows those runs wrote (every
+    # position the three VCFs cover: 7572952-7572990), N elsewhere — outside the intervals nothing is called, and with MNV calling off
+    # the only thing that looks at reference bases beside a called position is the RMxN filter, which does not apply to the one variant
+    # (its frequency 0.504 is above the filter's 0.35).
+    known = {}
+    sets = {}
+    for key, name, keep in (("expected_vcf", "Chr17again.expected.genome.vcf", lambda l: l.startswith("chr17\t")),
+                            ("expected_vcf_int", "Chr17Chr19.expected.genome.vcf", lambda l: l.startswith("chr17\t")),
+                            ("expected_vcf_variants", "Chr17Chr19.expected.vcf", lambda l: l.startswith("chr17\t"))):
+        with open(os.path.join(t, "Pisces.Tests/TestData", name)) as f:
+            sets[key] = [l.rstrip("\r\n") for l in f if keep(l)]
+        for l in sets[key]:
+            c = l.split("\t")
+            assert len(c[3]) == 1 and known.get(int(c[1]), c[3]) == c[3]
+            known[int(c[1])] = c[3]
+    assert sorted(known) == list(range(7572952, 7572991)) and [len(sets[k]) for k in ("expected_vcf", "expected_vcf_int", "expected_vcf_variants")] == [29, 11, 1]
+    off17, win17 = 7572000, (7572001, 7573200)
+    ref = "".join(known.get(p, "N") for p in range(win17[0], win17[1] + 1))
+    extract(root, "Pisces.Tests/TestData/Chr17Chr19.bam", "chr17", None, win17, off17, sets["expected_vcf"], "bam_chr17.npz", ref_literal=ref,
+            more={"expected_vcf_int": sets["expected_vcf_int"], "expected_vcf_variants": sets["expected_vcf_variants"]})
     rows = ["phix\t%s\t.\t%s\t%s\t%s\t%s\tDP=%s\tGT:GQ:AD:DP:VF:NL:SB\t%s" % r for r in PHIX_ROWS]
     extract(root, "SharedData/Bams/PhiX_S3.bam", "phix", "SharedData/Genomes/PhiX/WholeGenomeFasta/genome.fa", (1, 5386), 0, rows, "bam_phix.npz")
 

@@ -224,35 +224,46 @@ def test_bam_records_are_cut_on_the_device(name, chrom):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,bam", [("bam_phix", "PhiX_S3"), ("bam_small_s1", "small_S1")])
+@pytest.mark.parametrize("name,bam", [("bam_phix", "PhiX_S3"), ("bam_small_s1", "small_S1"), ("bam_chr19", "Sample_S1"), ("bam_chr19", "Chr17Chr19"),
+                                      ("bam_chr17_again", "Chr17Chr19"), ("bam_chr17_int", "Chr17Chr19"), ("bam_chr17_vcf", "Chr17Chr19"),
+                                      ("bam_edge_ins", "edgeIns_S2"), ("bam_edge_del", "edgeIndel_S2")])
 def test_bam_bytes_to_vcf_rows_without_the_reads_leaving_the_device(name, bam):
     """The whole upstream path on the device: compressed BAM bytes in (the only bulk PCIe traffic), BGZF inflate, records cut and
     decoded, read walk + candidate discovery straight from the decoded batch (pisces_hip_add_decoded_reads), calls, VCF text — the
-    body lines Pisces wrote for these BAMs, and the records of the host-fed path on the same reads."""
+    body lines Pisces wrote for these BAMs (every BAM of the reference's tests that has such rows beside it: tests/bam_fixtures.py), and the
+    records of the host-fed path on the same reads.  A BAM's positions are the chromosome's: the reference is the fixture's window behind
+    as many N as lie in front of it."""
     import torch
     assert torch.cuda.is_available()
     from pisces_amd import engine
     from tests import bam_fixtures
     case = bam_fixtures.CASES[name]
     z, batch = bam_fixtures.load(name)
-    assert int(z["offset"]) == 0
+    off = int(z["offset"])
     data = _FIXTURES[bam]
     refs, _ = _bam_reads_reference(data)
     cfg = _abi.default_config(**case["cfg"])
+    ref = np.concatenate([np.full(off + int(z["ref_start"]) - 1, ord("N"), dtype=np.uint8), z["ref"]])
     with engine.HipVariantCaller(cfg) as c:
-        c.SetReference(z["ref"])
+        c.SetReference(ref)
+        if case["intervals"]:
+            c.SetIntervals(case["intervals"])
         counts = c.bam_decode(data, refs.index(case["chrom"]))
         assert counts["reads"] == batch.n_reads
         c.AddDecodedReads()
         got, got_alleles = c.CallWithAlleles()
         stats = c.Stats()
-    with engine.HipVariantCaller(cfg) as c:
-        c.SetReference(z["ref"])
+    with engine.HipVariantCaller(cfg) as c:   # the host-fed path on the fixture's reads (positions relative to the fixture's offset)
+        c.SetReference(z["ref"] if int(z["ref_start"]) == 1 else np.concatenate([np.full(int(z["ref_start"]) - 1, ord("N"), dtype=np.uint8), z["ref"]]))
+        if case["intervals"]:
+            c.SetIntervals([(a - off, b - off) for a, b in case["intervals"]])
         c.AddAlleleCounts(batch)
         want, want_alleles = c.CallWithAlleles()
+    want = want.copy()
+    want["position"] += off
     assert got.tobytes() == want.tobytes() and got_alleles == want_alleles and stats["reads"] == batch.n_reads
     text = engine.format_vcf(case["chrom"], got, alleles=got_alleles, noise_level_from_records=1, **case["vcf"])
-    bam_fixtures.check_lines(case, text.rstrip("\n").split("\n") if text else [], [str(x) for x in z["expected_vcf"]])
+    bam_fixtures.check_lines(case, text.rstrip("\n").split("\n") if text else [], bam_fixtures.expected_lines(name, z))
 
 
 def _synthetic_bam(read_lens, header_text=b"@HD\tVN:1.6\n", seed=5):

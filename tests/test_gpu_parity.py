@@ -1004,7 +1004,7 @@ def test_streaming_mix_of_snvs_and_indels_across_blocks_matches_oracle(torch_cud
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["bam_chr19", "bam_phix", "bam_edge_ins", "bam_edge_del"])
+@pytest.mark.parametrize("name", ["bam_chr19", "bam_chr17_again", "bam_chr17_int", "bam_chr17_vcf", "bam_phix", "bam_edge_ins", "bam_edge_del"])
 def test_reference_bams_through_the_library_give_the_vcf_rows_pisces_wrote(torch_cuda, name):
     """End to end on the device: the reads of the reference's own test BAMs through the streaming surface (device read walk, finder,
     collapser, call kernels) and pisces_hip_format_vcf must reproduce the VCF body lines Pisces wrote for them byte for byte, and
@@ -1032,7 +1032,7 @@ def test_reference_bams_through_the_library_give_the_vcf_rows_pisces_wrote(torch
     got = got.copy()
     got["position"] += off
     text = engine.format_vcf(case["chrom"], got, alleles=got_alleles, noise_level_from_records=1, **case["vcf"])
-    bam_fixtures.check_lines(case, text.rstrip("\n").split("\n") if text else [], [str(x) for x in z["expected_vcf"]])
+    bam_fixtures.check_lines(case, text.rstrip("\n").split("\n") if text else [], bam_fixtures.expected_lines(name, z))
 
 
 def _mnv_reads(rng, ref, n_reads, read_len=100, region=(50, 1900), snv_rate=0.004):
@@ -1126,7 +1126,7 @@ def test_small_s1_bam_mnvs_through_the_library(torch_cuda):
     assert_records_match(got, exp)
     assert stats["TotalNumCalled"] == exp_called
     text = engine.format_vcf(case["chrom"], got, alleles=got_alleles)
-    bam_fixtures.check_lines(case, text.rstrip("\n").split("\n"), [str(x) for x in z["expected_vcf"]])
+    bam_fixtures.check_lines(case, text.rstrip("\n").split("\n"), bam_fixtures.expected_lines("bam_small_s1", z))
 
 
 @pytest.mark.gpu

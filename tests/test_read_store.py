@@ -597,3 +597,32 @@ def test_every_form_of_the_candidate_walk_equals_the_host_walk(torch_cuda, form)
                 want = engine.find_candidates(batch, ref, 20, True, bool(call_mnvs), max_len, max_gap)
                 got = c.FindCandidates(batch, True, bool(call_mnvs), max_len, max_gap)
                 assert len(want) > 2000 and got == want, (form, call_mnvs, max_len, max_gap)
+
+
+@pytest.mark.gpu
+def test_a_batch_that_touches_more_blocks_than_the_device_lists(torch_cuda):
+    """The touched blocks of a batch that was checked on the device come back as a list of keys the kernel writes (8 192 of them at most);
+    a batch that touches more makes the host read the block map's words itself.  9 000 reads, each in a block of its own, one of them
+    across a block edge: the same records and totals as with the host's pass over the CIGARs (RegionStateManager.cs:118-220, :385-391)."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(9)
+    n = 9000
+    ref = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n * 1000 + 2000)]
+    reads = []
+    for i in range(n):
+        pos = 1000 * i + (996 if i == 4000 else int(rng.integers(5, 900)))
+        seq = bytearray(ref[pos - 1:pos - 1 + 12].tobytes())
+        if i % 3 == 0:
+            seq[5] = ord("A") if seq[5] != ord("A") else ord("C")
+        reads.append({"pos": pos, "seq": bytes(seq), "cigar": [("M", 12)], "quals": [35] * 12, "reverse": bool(i & 1)})
+    batch = _abi.ReadBatch(reads)
+    cfg = _abi.default_config(min_coverage=1, include_reference_calls=0)
+    out = []
+    for checks in (1, 0):
+        with env(PISCES_HIP_DEVICE_CHECKS=checks):
+            with engine.HipVariantCaller(cfg) as c:
+                c.SetReference(ref)
+                c.AddAlleleCounts(batch)
+                out.append((c.Call(None, capacity=1 << 16), c.Stats()))
+    (got, gs), (want, ws) = out
+    assert len(want) == 3000 and got.tobytes() == want.tobytes() and gs == ws
