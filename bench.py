@@ -621,53 +621,53 @@ def run_stream_config(args):
     a_lo, a_hi = rank * n_amp_all // world, (rank + 1) * n_amp_all // world
     ref = synth.reference_of(n_loci_all, seed, device=f"cuda:{local_rank}")
     origin = synth.READ_LEN + 1
-    # Two handles over the same stretches: `c` takes the reads from device memory (pisces_hip_add_device_reads: the metric's form, SURVEY 8d —
-    # inputs resident in HBM when the timed region starts), `ch` from host arrays over PCIe (pisces_hip_add_reads: what a host that holds
-    # the reads pays; 2 bytes per base at the host link's rate bound it whatever the device does)
-    elapsed, n_rec, n_reads, host = 0.0, 0, 0, None
-    elapsed_h, n_rec_h = 0.0, 0
-    n_bases = 0
-    with engine.HipVariantCaller(cfg, device=local_rank) as c, engine.HipVariantCaller(cfg, device=local_rank) as ch:
-        c.SetReference(ref)
-        ch.SetReference(ref)
+    # The stretches are made first (the reads of all of them stay in device memory: 4 GB for config 3), then timed pass by pass, each pass
+    # on a handle of its own: three passes from device memory (pisces_hip_add_device_reads: the metric's form, SURVEY 8d — inputs resident
+    # in HBM when the timed region starts; `value` is their median: the path is bound by one host core, and a neighbour on the box shows),
+    # then one from host arrays over PCIe (pisces_hip_add_reads: what a host that holds the reads pays; 2 bytes per base at the host
+    # link's rate bound it whatever the device does).
+    stretches = []
+    n_reads = n_bases = 0
+    for a0 in range(a_lo, a_hi, stretch):
+        na = min(stretch, a_hi - a0)
+        p = synth.make_pileup(na * synth.READ_LEN, depth, seed=seed, device=f"cuda:{local_rank}", first_locus=a0 * synth.READ_LEN, total_loci=n_loci_all,
+                              with_tuples=False, **synth_kw)
+        batch = synth.mixed_reads(p, seed)[0] if args.config == 3 else synth.reads_of(p, na, first_amplicon=a0)
+        n_reads += int(batch.n_reads)
+        n_bases += int(batch.n_bases)
+        stretches.append((batch, engine.DeviceReadBatch.from_host(batch, f"cuda:{local_rank}"), origin + (a0 + na) * synth.READ_LEN - 1))   # (.., the next stretch's first position - 1)
+        del p
+    torch.cuda.synchronize(dev)
+
+    def one_pass(from_device):
         # SmallVariantCaller's order (SmallVariantCaller.cs:88-105): a read is added, THEN Call(its position - 1) clears what lies behind it.
         # Stretch by stretch: the reads of stretch k + 1 are added, then the flush up to their first position - 1 takes stretch k — the device
         # discovers the candidates of k + 1 while the host works on the flush of k.
-        prev_up_to = None
-        for a0 in range(a_lo, a_hi, stretch):
-            na = min(stretch, a_hi - a0)
-            p = synth.make_pileup(na * synth.READ_LEN, depth, seed=seed, device=f"cuda:{local_rank}", first_locus=a0 * synth.READ_LEN, total_loci=n_loci_all,
-                                  with_tuples=False, **synth_kw)
-            batch = synth.mixed_reads(p, seed)[0] if args.config == 3 else synth.reads_of(p, na, first_amplicon=a0)
-            n_reads += int(batch.n_reads)
-            n_bases += int(batch.n_bases)
-            dbatch = engine.DeviceReadBatch.from_host(batch, f"cuda:{local_rank}")
+        with engine.HipVariantCaller(cfg, device=local_rank) as c:
+            c.SetReference(ref)
             torch.cuda.synchronize(dev)
+            n_rec, prev_up_to = 0, None
             t0 = time.perf_counter()
-            c.AddDeviceReads(dbatch)
-            if prev_up_to is not None:
-                n_rec += len(c.CallView(prev_up_to))
-            elapsed += time.perf_counter() - t0
-            del dbatch
-            t0 = time.perf_counter()
-            ch.AddAlleleCounts(batch)
-            if prev_up_to is not None:
-                n_rec_h += len(ch.CallView(prev_up_to))
-            elapsed_h += time.perf_counter() - t0
-            prev_up_to = origin + (a0 + na) * synth.READ_LEN - 1    # the next stretch's first position - 1
-            del p, batch
-        t0 = time.perf_counter()
-        n_rec += len(c.CallView(None))
-        elapsed += time.perf_counter() - t0
-        t0 = time.perf_counter()
-        n_rec_h += len(ch.CallView(None))
-        elapsed_h += time.perf_counter() - t0
-        stats = c.Stats()
-        host = c.HostTime()
-        pcie = c.TransferBytes()
-        host_h = ch.HostTime()
-        pcie_h = ch.TransferBytes()
-        assert ch.Stats() == stats and n_rec_h == n_rec
+            for batch, dbatch, up_to in stretches:
+                if from_device:
+                    c.AddDeviceReads(dbatch)
+                else:
+                    c.AddAlleleCounts(batch)
+                if prev_up_to is not None:
+                    n_rec += len(c.CallView(prev_up_to))
+                prev_up_to = up_to
+            n_rec += len(c.CallView(None))
+            seconds = time.perf_counter() - t0
+            return seconds, n_rec, c.Stats(), c.HostTime(), c.TransferBytes()
+
+    passes = [one_pass(True) for _ in range(3)]
+    assert all(q[1:3] == passes[0][1:3] for q in passes)
+    passes.sort(key=lambda q: q[0])
+    elapsed, n_rec, stats, host, pcie = passes[1]
+    pass_seconds = [q[0] for q in passes]
+    elapsed_h, n_rec_h, stats_h, host_h, pcie_h = one_pass(False)
+    assert stats_h == stats and n_rec_h == n_rec
+    del stretches
     loci_mine = (a_hi - a_lo) * synth.READ_LEN
     summary = torch.tensor([stats["TotalNumCalled"], stats["TotalNumCollapsed"], stats["reads"], stats["reads_skipped"], loci_mine, n_rec], dtype=torch.int64, device=dev)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -686,7 +686,7 @@ def run_stream_config(args):
                "totals": {"allelesCalled": int(summary[0].item()), "variantsCollapsed": int(summary[1].item()), "readsProcessed": int(summary[2].item()),
                           "readsSkipped": int(summary[3].item()), "records": int(summary[5].item())},
                "rank0": {"host_seconds_in_add_reads": host["add_reads_s"], "host_seconds_in_flushes": host["flush_s"], "of_those_waiting_for_the_device": host["flush_wait_s"],
-                         "flushes": host["flushes"], "pcie_bytes": pcie},
+                         "flushes": host["flushes"], "pcie_bytes": pcie, "seconds_of_the_three_passes": pass_seconds, "value_is": "their median"},
                f"roofline_config{args.config}": {"bound": "hbm", "achieved": algo_bytes / elapsed / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                  "frac": algo_bytes / elapsed / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": algo_bytes,
                                                  "seconds": elapsed, "what": "reads in device memory (2 B per aligned base) -> records (64 B each), wall clock of pisces_hip_add_device_reads + "
