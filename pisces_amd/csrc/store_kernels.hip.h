@@ -808,6 +808,9 @@ __device__ __forceinline__ void walk_segment_fast(const SegmentView& G, int tile
 #if defined(PISCES_STORE_ABLATE) && PISCES_STORE_ABLATE == 3
                 S.bw[u] = load_u32_unaligned(bases + (at & ~3u));
                 S.qw[u] = load_u32_unaligned(quals + (at & ~3u));
+#elif defined(PISCES_STORE_ABLATE) && PISCES_STORE_ABLATE == 5
+                S.bw[u] = 0x41434754u ^ ((at & 1u) << 1);   // development ablation: no loads of bases / qualities (what is left is descriptors + arithmetic + LDS)
+                S.qw[u] = 0x25252525u + (at & 3u);
 #else
                 S.bw[u] = load_u32_unaligned(bases + at);
                 S.qw[u] = load_u32_unaligned(quals + at);
