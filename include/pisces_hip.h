@@ -149,7 +149,10 @@ typedef struct PiscesHipConfig {
                                          (AlleleCaller.cs:215-218, RegionStateManager.cs:191) */
     int32_t ploidy;                   /* PISCES_PLOIDY_SOMATIC (default), PISCES_PLOIDY_DIPLOID or PISCES_PLOIDY_HAPLOID: one genotype per locus from the
                                          variant frequencies, alleles beyond the ploidy pruned (DiploidThresholdingGenotyper.cs:54-141,
-                                         HaploidGenotyper.cs:36-83, which takes MinorVF / MajorVF from the SNV parameters below) */
+                                         HaploidGenotyper.cs:36-83, which takes MinorVF / MajorVF from the SNV parameters below).  Made on the
+                                         device over the tile kernels' record slots (pisces_hip_call_tiles*, and a flush whose rows are
+                                         the tile kernels' alone); by the host pass of the flush when rows of insertions / deletions / MNVs
+                                         or forced alleles join them.  Both are csrc/genotype_core.h */
     float   diploid_snv_params[3];    /* DiploidSNVThresholdingParameters {MinorVF, MajorVF, SumVFforMultiAllelicSite}: 0.20, 0.70, 0.80 */
     float   diploid_indel_params[3];  /* DiploidINDELThresholdingParameters, same defaults */
 } PiscesHipConfig;

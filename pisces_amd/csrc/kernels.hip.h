@@ -27,6 +27,7 @@
 #include <stdint.h>
 
 #include "device_math.hip.h"
+#include "genotype_core.h"
 
 namespace pisces {
 
@@ -1372,6 +1373,79 @@ __host__ __device__ inline int candidate_total_coverage(const DevCandidate& c, c
         return total;
     }
     return spanning_coverage(c, counts, expect_stitched).total;
+}
+
+// PloidyModel.DiploidByThresholding / Haploid over the tile kernels' record slots, lane = locus (AlleleCaller.ComputeGenotypeAndFilterAllele,
+// AlleleCaller.cs:143-177 with genotype_core.h): the rows of a locus are its valid slots — variants in rank order A C G T, which is their
+// (REF, ALT) order, or the one Reference row —, every kept row gets the locus genotype, its own genotype q-score, the LowGQ and
+// MultiAllelicSite filters and its phase-set index; rows beyond the ploidy lose their validity bit (the compaction that follows never
+// sees them).  TotalNumCalled counts callable alleles before this (AlleleCaller.cs:236-258): n_called stays.  The device-resident
+// surface (pisces_hip_call_tiles*) runs it behind every tile kernel of a diploid / haploid handle; a flush runs it when no row of the
+// candidate kernel and no forced allele joins the tile kernels' rows (then the host pass over the merged rows does the same: diploid.cpp).
+struct GenotypeParams {
+    int32_t ploidy;
+    float snv[3], indel[3];
+    int32_t min_depth, min_gq, max_gq, low_gq_filter;
+};
+__global__ __launch_bounds__(64) void genotype_loci_kernel(PiscesCalledAllele* __restrict__ records, PiscesTileResult* __restrict__ tile_results, int32_t n_tiles,
+                                                           GenotypeParams G, unsigned long long* __restrict__ totals)
+{
+    const int t = blockIdx.x;
+    if (t >= n_tiles) return;
+    const int l = threadIdx.x;
+    PiscesTileResult* const tr = &tile_results[t];
+    const uint32_t nib = (tr->valid[l >> 3] >> ((l & 7) * 4)) & 0xFu;
+    uint32_t keep = nib;
+    if (nib) {
+        PiscesCalledAllele* const rows = records + (int64_t)t * kSlotsPerTile + l * 4;
+        genotype::Allele a[4];
+        int slot[4], order[5], n = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (!((nib >> k) & 1u)) continue;
+            const PiscesCalledAllele& r = rows[k];
+            a[n].category = (int32_t)PISCES_INFO_CATEGORY(r.info);
+            a[n].support = r.allele_support; a[n].coverage = r.total_coverage; a[n].ref_support = r.reference_support;
+            a[n].genotype = 0; a[n].genotype_qscore = 0; a[n].phase_set_index = 0; a[n].multi_allelic = false; a[n].prune = false;
+            slot[n] = k;
+            n++;
+        }
+        auto before = [](int x, int y) { return x < y; };   // slot rank = ordinal order of the ALT base (one REF base a locus)
+        if (G.ploidy == PISCES_PLOIDY_HAPLOID) (void)genotype::haploid_set(a, n, order, G.snv[0], G.snv[1], G.min_depth, G.min_gq, G.max_gq, before);
+        else (void)genotype::diploid_set(a, n, order, G.snv, G.indel, G.min_depth, G.min_gq, G.max_gq, before);
+        for (int i = 0; i < n; i++) {
+            if (a[i].prune) { keep &= ~(1u << slot[i]); continue; }
+            PiscesCalledAllele& r = rows[slot[i]];
+            r.info = (uint16_t)((r.info & ~0xFu) | ((uint32_t)a[i].genotype & 0xFu));
+            r.genotype_qscore = (int16_t)a[i].genotype_qscore;
+            uint32_t fb = r.filter_bits & ~(1u << PISCES_FILTER_LOW_GENOTYPE_QUALITY) & 0x3FFFu;
+            if (a[i].multi_allelic) fb |= 1u << PISCES_FILTER_MULTI_ALLELIC_SITE;
+            if (G.low_gq_filter >= 0 && (float)a[i].genotype_qscore < (float)G.low_gq_filter) fb |= 1u << PISCES_FILTER_LOW_GENOTYPE_QUALITY;
+            fb |= (uint32_t)(a[i].phase_set_index & 3) << 14;
+            r.filter_bits = (uint16_t)fb;
+        }
+    }
+    int n_was = 0, n_now = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        n_was += __popcll(__ballot((nib >> k) & 1u));
+        n_now += __popcll(__ballot((keep >> k) & 1u));
+    }
+    const int loci_was = __popcll(__ballot(nib != 0)), loci_now = __popcll(__ballot(keep != 0));
+    uint32_t word = keep << ((l & 7) * 4);
+    word |= __shfl_xor(word, 1, 64);
+    word |= __shfl_xor(word, 2, 64);
+    word |= __shfl_xor(word, 4, 64);
+    if ((l & 7) == 0) tr->valid[l >> 3] = word;
+    if (l == 0) {
+        tr->n_records = n_now;
+        tr->n_candidate_loci = loci_now;
+        if (totals && (n_now != n_was || loci_now != loci_was)) {   // (the tile kernel has added its own counts: take back what went)
+            unsigned long long* tt = totals + (size_t)(t % kTotalShards) * kTotalStride;
+            atomicAdd(&tt[0], (unsigned long long)(long long)(n_now - n_was));
+            atomicAdd(&tt[1], (unsigned long long)(long long)(loci_now - loci_was));
+        }
+    }
 }
 
 enum { kSpanningEveryRecord = 0, kSpanningCallableRecords = 1, kSpanningFlagsOnly = 2 };   // call_spanning_kernel's `wanted`

@@ -505,6 +505,7 @@ struct PiscesHip {
     int finder_wave = 0;                      // PISCES_HIP_FINDER: the default is a lane a read, events first; =bases: a lane a read, base by base (round 3's);
                                               // =wave / =batch: a wave for one / for 64 reads (finder_kernels.hip.h; measured slower)
     DeviceBuf<long long> d_scan_sums;         // block sums of launch_found_scan
+    bool device_genotyper = true;             // PISCES_HIP_DEVICE_GENOTYPER=0: diploid / haploid genotypes are always the host pass of the flush (the A / B of the tests)
     bool merge_in_place = true;               // PISCES_HIP_MERGE_IN_PLACE=0: the candidate kernel's rows and the tile kernels' are merged into a vector of their own (the A / B of the tests)
     int device_checks = -1;                   // PISCES_HIP_DEVICE_CHECKS: 1 every host batch is checked on the device (read_prepare_kernel), 0 none, -1 (default) from 65 536 reads up
     bool prep_map_clean = false;              // the block map of read_prepare_kernel is all zero
@@ -806,6 +807,7 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         if (const char* v = getenv("PISCES_HIP_STORE_SEAL_BYTES")) h->store_seal_bytes = (size_t)std::max(0ll, atoll(v));
         if (const char* v = getenv("PISCES_HIP_DEVICE_CHECKS")) h->device_checks = atoi(v) != 0 ? 1 : 0;
         if (const char* v = getenv("PISCES_HIP_MERGE_IN_PLACE")) h->merge_in_place = atoi(v) != 0;
+        if (const char* v = getenv("PISCES_HIP_DEVICE_GENOTYPER")) h->device_genotyper = atoi(v) != 0;
         if (const char* v = getenv("PISCES_HIP_FINDER")) h->finder_wave = std::string(v) == "wave" ? 1 : std::string(v) == "batch" ? 2 : std::string(v) == "bases" ? 3 : 0;
     }
     {

@@ -16,8 +16,6 @@ int32_t pisces_hip_call_tiles(PiscesHip* h, const uint32_t* d_tuples, const Pisc
         return fail(h, PISCES_E_INVALID_ARG, "call_tiles: null device pointer");
     if ((int64_t)record_capacity < (int64_t)n_tiles * kSlotsPerTile)
         return fail(h, PISCES_E_BUFFER_TOO_SMALL, "call_tiles: the slot layout needs record_capacity >= 256 * n_tiles");
-    if (h->cfg.ploidy != PISCES_PLOIDY_SOMATIC)
-        return fail(h, PISCES_E_STATE, "call_tiles: diploid / haploid genotyping is a per-locus pass of pisces_hip_flush (streaming surface)");
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     // events only when asked for (pisces_hip_set_timing): an event record is a queue packet of its own, and two of them
@@ -31,6 +29,7 @@ int32_t pisces_hip_call_tiles(PiscesHip* h, const uint32_t* d_tuples, const Pisc
     }
     if (n_tiles > 0) {
         PISCES_HIP_CHECK(h, launch_call_tiles(h, s, d_tuples, d_tiles, n_tiles, d_ref_bases, ref_start_position, ref_length, d_records, d_tile_results, e0, e1));
+        if (germline(h)) launch_genotype_loci(h, s, d_records, d_tile_results, n_tiles);   // PloidyModel.DiploidByThresholding / Haploid: a pass over the slots
     } else if (e0) {
         PISCES_HIP_CHECK(h, hipEventRecord(e0, s));
         PISCES_HIP_CHECK(h, hipEventRecord(e1, s));
@@ -62,8 +61,6 @@ int32_t pisces_hip_call_tiles_batched(PiscesHip* h, const PiscesTileBatch* batch
     return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_E_INVALID_ARG;
     if (n_batches < 0 || (n_batches > 0 && !batches)) return fail(h, PISCES_E_INVALID_ARG, "call_tiles_batched: null batch list");
-    if (h->cfg.ploidy != PISCES_PLOIDY_SOMATIC)
-        return fail(h, PISCES_E_STATE, "call_tiles: diploid / haploid genotyping is a per-locus pass of pisces_hip_flush (streaming surface)");
     if (h->cfg.noise_model == PISCES_NOISE_WINDOW)
         return fail(h, PISCES_E_STATE, "call_tiles_batched: NoiseModel.Window calls through the handle's one counts tensor; use pisces_hip_call_tiles");
     for (int32_t i = 0; i < n_batches; i++) {
@@ -89,6 +86,7 @@ int32_t pisces_hip_call_tiles_batched(PiscesHip* h, const PiscesTileBatch* batch
         if (b.n_tiles == 0) continue;
         PISCES_HIP_CHECK(h, launch_call_tiles(h, h->lane[i % lanes], b.d_tuples, b.d_tiles, b.n_tiles, b.d_ref_bases, b.ref_start_position,
                                               b.ref_length, b.d_records, b.d_tile_results));
+        if (germline(h)) launch_genotype_loci(h, h->lane[i % lanes], b.d_records, b.d_tile_results, b.n_tiles);
     }
     PISCES_HIP_CHECK(h, hipGetLastError());
     return PISCES_OK;
@@ -102,8 +100,8 @@ int32_t pisces_hip_call_tiles_graph_build(PiscesHip* h, const PiscesTileBatch* b
     return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h || !graph_id) return PISCES_E_INVALID_ARG;
     if (n_batches <= 0 || !batches) return fail(h, PISCES_E_INVALID_ARG, "call_tiles_graph_build: null batch list");
-    if (h->cfg.ploidy != PISCES_PLOIDY_SOMATIC || h->cfg.noise_model == PISCES_NOISE_WINDOW)
-        return fail(h, PISCES_E_STATE, "call_tiles_graph_build: the somatic, NoiseModel.Flat configuration only (see pisces_hip_call_tiles)");
+    if (h->cfg.noise_model == PISCES_NOISE_WINDOW)
+        return fail(h, PISCES_E_STATE, "call_tiles_graph_build: NoiseModel.Flat only (see pisces_hip_call_tiles_batched)");
     for (int32_t i = 0; i < n_batches; i++) {
         const PiscesTileBatch& b = batches[i];
         if (b.n_tiles <= 0 || b.record_capacity < 0 || b.ref_length < 0 || !b.d_tiles || !b.d_ref_bases || !b.d_records || !b.d_tile_results)
@@ -130,6 +128,7 @@ int32_t pisces_hip_call_tiles_graph_build(PiscesHip* h, const PiscesTileBatch* b
         if (e == hipSuccess)
             e = launch_call_tiles(h, h->stream, b.d_tuples, b.d_tiles, b.n_tiles, b.d_ref_bases, b.ref_start_position, b.ref_length, b.d_records,
                                   b.d_tile_results);
+        if (e == hipSuccess && germline(h)) launch_genotype_loci(h, h->stream, b.d_records, b.d_tile_results, b.n_tiles);
         if (e == hipSuccess && e1) e = hipEventRecord(e1, h->stream);
     }
     const hipError_t ec = hipStreamEndCapture(h->stream, &graph);

@@ -217,6 +217,20 @@ static hipError_t launch_call_tiles(PiscesHip* h, hipStream_t s, const uint32_t*
     return hipSuccess;
 }
 
+// PloidyModel.DiploidByThresholding / Haploid over the record slots a tile kernel has just filled (genotype_loci_kernel), on stream s
+static void launch_genotype_loci(PiscesHip* h, hipStream_t s, PiscesCalledAllele* d_records, PiscesTileResult* d_tr, int32_t n_tiles)
+{
+    GenotypeParams G;
+    G.ploidy = h->cfg.ploidy;
+    for (int k = 0; k < 3; k++) { G.snv[k] = h->cfg.diploid_snv_params[k]; G.indel[k] = h->cfg.diploid_indel_params[k]; }
+    G.min_depth = h->cfg.min_coverage;
+    G.min_gq = h->cfg.min_genotype_qscore;
+    G.max_gq = h->cfg.max_genotype_qscore;
+    G.low_gq_filter = h->cfg.low_gq_filter;
+    if (n_tiles > 0) hipLaunchKernelGGL(genotype_loci_kernel, dim3((unsigned)n_tiles), dim3(64), 0, s, d_records, d_tr, n_tiles, G, h->P.totals);
+}
+static bool germline(const PiscesHip* h) { return h->cfg.ploidy == PISCES_PLOIDY_DIPLOID || h->cfg.ploidy == PISCES_PLOIDY_HAPLOID; }
+
 // scan + gather: d_out = called alleles in (position, allele) order, *d_count = how many
 static void launch_compaction(hipStream_t s, const PiscesCalledAllele* d_records, const PiscesTileResult* d_tr, int32_t n_tiles,
                               int32_t* d_offsets, PiscesCalledAllele* d_out, int32_t cap, int32_t* d_count, int32_t* d_called = nullptr)
@@ -238,7 +252,10 @@ struct CallBlocksInFlight {
 // hole_bound >= 0 (asynchronous flush): the compacted log is made hole_bound slots long (see enqueue_drop)
 // with_folded: the launch — when it is the fused kernel over a run of whole blocks — also leaves the folded counts of every locus it walks
 // in h->d_folded (h->fold says which positions), for the candidate kernel of the same flush
-static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& keys, bool with_drop, int64_t hole_bound, CallBlocksInFlight* st, bool with_folded = false)
+// genotype_on_device: a diploid / haploid handle's rows are genotyped where they lie (genotype_loci_kernel) before they are compacted:
+// the caller knows that no row of the candidate kernel and no forced allele joins them
+static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& keys, bool with_drop, int64_t hole_bound, CallBlocksInFlight* st, bool with_folded = false,
+                                   bool genotype_on_device = false)
 {
     *st = CallBlocksInFlight();
     h->fold.valid = false;
@@ -328,6 +345,7 @@ static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& key
                            h->d_tiles.p, n_tiles, h->d_ref.p, 1, h->ref_len, h->d_records.p, h->d_tile_results.p, h->P,
                            window ? h->d_sumq.p : (const double*)nullptr);
     }
+    if (genotype_on_device) launch_genotype_loci(h, h->stream, h->d_records.p, h->d_tile_results.p, n_tiles);
     // tiles were built in ascending position order: the ordered compaction is AlleleCaller.Call's (position, ref, alt) order.
     // The sorted records lie behind one header slot {records, called}.  A launch of up to 64 tiles (the blocks of one flush of the
     // streaming protocol) is compacted by one kernel that writes header and records into the pinned download buffer itself.
@@ -378,6 +396,7 @@ static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& key
 static bool fused_regular_applies(PiscesHip* h, const std::vector<int32_t>& keys)
 {
     if (keys.empty() || !h->d_ref.p || h->cfg.noise_model == PISCES_NOISE_WINDOW || h->read_path != 1 || h->log_ub != 0 || !h->intervals.empty()) return false;
+    if (germline(h)) return false;   // (whether the rows are genotyped on the device is only known once the candidates have been through)
     if (!(h->kernel_variant >= 2 && h->cfg.strand_bias_model != PISCES_SB_DIPLOID && h->cfg.min_base_call_quality <= 127)) return false;
     for (auto& kv : h->gapped_mnv_ref)
         if (std::binary_search(keys.begin(), keys.end(), block_key(h, kv.first))) return false;
@@ -407,12 +426,12 @@ static int32_t call_blocks_finish(PiscesHip* h, const CallBlocksInFlight& st, in
 // as_view: the records are not copied into `out`; h->pending_view points at them in the pinned download buffer (valid until the next
 // call_blocks)
 static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::vector<PiscesCalledAllele>& out, int64_t* n_called,
-                           bool with_drop = false, bool* dropped = nullptr, unsigned long long* kept = nullptr, bool as_view = false)
+                           bool with_drop = false, bool* dropped = nullptr, unsigned long long* kept = nullptr, bool as_view = false, bool genotype_on_device = false)
 {
     out.clear();   // (*n_called accumulates: the caller zeroes it)
     if (dropped) *dropped = false;
     CallBlocksInFlight st;
-    int32_t rc = call_blocks_enqueue(h, keys, with_drop, -1, &st);
+    int32_t rc = call_blocks_enqueue(h, keys, with_drop, -1, &st, false, genotype_on_device);
     if (rc || !st.active) return rc;
     PISCES_TIMED_WAIT(h, hipStreamSynchronize(h->stream));
     h->h_meta_used = 0;   // the stream is idle: nothing reads the arena any more
@@ -1512,7 +1531,9 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
         if (rc) return rc;
         h->pending_dropped = false;
         std::unique_ptr<HostTimer> prof(new HostTimer(h->prof_on ? &h->prof[7] : nullptr));
-        const bool diploid = h->cfg.ploidy == PISCES_PLOIDY_DIPLOID || h->cfg.ploidy == PISCES_PLOIDY_HAPLOID;   // per-locus genotypers
+        // per-locus genotypers: on the device, over the tile kernels' slots, when nothing joins their rows; else the host pass over the merged rows
+        const bool device_genotyper = germline(h) && h->device_genotyper && span_recs.empty() && h->forced.empty() && ref_overrides.empty();
+        const bool diploid = germline(h) && !device_genotyper;
         // nothing to merge into the tile kernels' records: they go from the download buffer straight to the caller
         const bool plain = span_recs.empty() && !diploid && h->forced.empty() && ref_overrides.empty();
         // the tile kernels' rows are read where the last kernel left them (pinned memory) unless a per-locus genotyper or forced alleles rework them
@@ -1530,7 +1551,7 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
                 else point_recs.assign(blocks_st.hrec, blocks_st.hrec + total);
             }
         } else {
-        rc = call_blocks(h, keys, point_recs, &called, true, &h->pending_dropped, &h->pending_kept, plain || fast_merge);
+        rc = call_blocks(h, keys, point_recs, &called, true, &h->pending_dropped, &h->pending_kept, plain || fast_merge, device_genotyper);
         if (rc) return rc;
         }
         prof.reset();

@@ -10,6 +10,7 @@ import pytest
 
 from pisces_amd import _abi
 from tests import orc
+from tests.test_read_store import env
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
@@ -1203,15 +1204,10 @@ def test_window_noise_model_matches_oracle(torch_cuda, call_mnvs):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sb_model,ploidy", [(1, 1), (2, 1), (1, 2)])   # Extended / Diploid strand bias; diploid, diploid, haploid genotyper
-def test_diploid_genotyping_matches_oracle(torch_cuda, sb_model, ploidy):
-    """SURVEY section 8 row f4: PloidyModel.DiploidByThresholding (one genotype per locus from the variant frequencies, alleles beyond
-    the ploidy pruned, diploid genotype q-scores, MultiAllelicSite / LowGQ filters, phase set index), PloidyModel.Haploid (hemizygous
-    calls, its own q-score) and the Diploid strand-bias model,
-    on germline-like reads: het and hom SNVs, a het deletion, a tri-allelic site, a 1/2 site, sub-threshold alleles, a shallow stretch.
-    Records, allele strings and TotalNumCalled against the oracle."""
-    from pisces_amd import engine
-    rng = np.random.default_rng(500 + sb_model)
+def _germline_reads(seed, with_deletion=True):
+    """Germline-like reads: het and hom SNVs, a het deletion (optional), a tri-allelic site, a 1/2 site, sub-threshold alleles, a shallow
+    stretch.  Returns (reference bytes, reads in position order)."""
+    rng = np.random.default_rng(seed)
     ref = bytearray(rng.choice(list(b"ACGT"), 1600).astype(np.uint8))
     def other(p, k=0):
         return [b for b in b"ACGT" if b != ref[p - 1]][k]
@@ -1243,13 +1239,25 @@ def test_diploid_genotyping_matches_oracle(torch_cuda, sb_model, ploidy):
             if rng.random() < 0.002:
                 seq[k] = int(rng.choice(list(b"ACGT")))
         ops, s = [("M", L)], bytes(seq).decode()
-        if start <= 720 and start + L > 745 and rng.random() < 0.45:   # a het deletion of 731..733
+        if with_deletion and start <= 720 and start + L > 745 and rng.random() < 0.45:   # a het deletion of 731..733
             k = 730 - start + 1
             ops = [("M", k), ("D", 3), ("M", L - k)]
             s = s[:k] + bytes(ref[start - 1 + k + 3: start - 1 + L + 3]).decode()
         reads.append({"pos": start, "cigar": ops, "seq": s, "quals": np.where(rng.random(L) < 0.02, 12, 37).astype(np.uint8).tolist(),
                       "reverse": bool(n % 2)})
     reads.sort(key=lambda r: r["pos"])
+    return ref, reads
+
+
+@pytest.mark.parametrize("sb_model,ploidy", [(1, 1), (2, 1), (1, 2)])   # Extended / Diploid strand bias; diploid, diploid, haploid genotyper
+def test_diploid_genotyping_matches_oracle(torch_cuda, sb_model, ploidy):
+    """SURVEY section 8 row f4: PloidyModel.DiploidByThresholding (one genotype per locus from the variant frequencies, alleles beyond
+    the ploidy pruned, diploid genotype q-scores, MultiAllelicSite / LowGQ filters, phase set index), PloidyModel.Haploid (hemizygous
+    calls, its own q-score) and the Diploid strand-bias model,
+    on germline-like reads: het and hom SNVs, a het deletion, a tri-allelic site, a 1/2 site, sub-threshold alleles, a shallow stretch.
+    Records, allele strings and TotalNumCalled against the oracle."""
+    from pisces_amd import engine
+    ref, reads = _germline_reads(500 + sb_model)
     batch = _abi.ReadBatch(reads)
     refa = np.frombuffer(bytes(ref), dtype=np.uint8)
     cfg = _abi.default_config(ploidy=ploidy, strand_bias_model=sb_model, min_frequency=0.2, variant_freq_filter=0.2, low_gq_filter=30,
@@ -1270,6 +1278,49 @@ def test_diploid_genotyping_matches_oracle(torch_cuda, sb_model, ploidy):
     assert got_alleles == exp_alleles
     assert_records_match(got, exp)
     assert stats["TotalNumCalled"] == exp_called
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ploidy", [1, 2], ids=["diploid", "haploid"])
+@pytest.mark.parametrize("gvcf", [1, 0], ids=["gvcf", "variants only"])
+def test_genotypes_made_on_the_device_equal_the_host_pass_and_the_oracle(torch_cuda, ploidy, gvcf):
+    """genotype_loci_kernel (lane = locus over the tile kernels' record slots: DiploidThresholdingGenotyper.cs:54-141, HaploidGenotyper.cs:36-83,
+    the genotype q-scores, LowGQ / MultiAllelicSite, alleles beyond the ploidy gone before the compaction) against the host pass of the
+    flush (PISCES_HIP_DEVICE_GENOTYPER=0: diploid.cpp over the downloaded rows — the same genotype_core.h) and the oracle: reads without
+    insertions / deletions, so that no candidate row joins the tile kernels' rows; block by block and in one flush; and through the
+    device-resident surface (pisces_hip_call_tiles + pisces_hip_compact_records on a diploid / haploid handle, which used to refuse)."""
+    from pisces_amd import engine, synth
+    torch = torch_cuda
+    ref, reads = _germline_reads(640 + ploidy, with_deletion=False)
+    batch = _abi.ReadBatch(reads)
+    refa = np.frombuffer(bytes(ref), dtype=np.uint8)
+    cfg = _abi.default_config(ploidy=ploidy, min_frequency=0.2, variant_freq_filter=0.2, low_gq_filter=30, max_genotype_qscore=1000,
+                              include_reference_calls=gvcf)
+    exp, exp_alleles, _, exp_called = orc.run_reads_full(batch, refa, 1, len(ref), cfg)
+    assert set(((exp["info"] >> 4) & 7).tolist()) <= {_abi.CAT_SNV, _abi.CAT_REFERENCE} and len(exp) > (1000 if gvcf else 5)
+    if ploidy == 1:
+        assert ((exp["filter_bits"] >> 8) & 1).any() and ((exp["filter_bits"] >> 14) == 2).any()   # a multi-allelic site, a second phase-set index
+    out = {}
+    for on_device in (1, 0):
+        with env(PISCES_HIP_DEVICE_GENOTYPER=on_device):
+            with engine.HipVariantCaller(cfg) as c:
+                c.SetReference(refa)
+                c.AddAlleleCounts(batch)
+                rows = [c.Call(up, capacity=1 << 14) for up in (1000, None)]
+                out[on_device] = (np.concatenate(rows), c.Stats())
+    assert out[1][0].tobytes() == out[0][0].tobytes() and out[1][1] == out[0][1]
+    assert_records_match(out[1][0], exp)
+    assert out[1][1]["TotalNumCalled"] == exp_called
+    # the device-resident surface on a pileup of its own: slots genotyped in place, pruned rows never compacted, totals taken back
+    p = synth.make_pileup(n_loci=1500, depth=120, seed=77 + ploidy, device="cuda", snv_every=4, snv_offset=1, vaf_range=(0.05, 0.99))
+    with engine.HipVariantCaller(cfg) as c:
+        got, tr = run_fused(torch, c, p, compact=True)
+        totals = c.device_totals()
+    pos, tup = synth.observations_of(p)
+    want, nloci = orc.run_observations(pos, tup, p.ref.cpu().numpy(), p.region_start, p.n_loci, cfg)
+    assert_records_match(got, want)
+    assert totals["records"] == len(want) and totals["candidate_loci"] == nloci == int(tr["n_candidate_loci"].sum())
+    assert len(set((want["info"] & 15).tolist())) >= 2 and len(want) > 100
 
 
 @pytest.mark.gpu
