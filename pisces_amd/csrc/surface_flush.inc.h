@@ -422,6 +422,18 @@ static int32_t call_blocks_finish(PiscesHip* h, const CallBlocksInFlight& st, in
     return PISCES_OK;
 }
 
+#ifdef PISCES_STORE_TIMING
+// development: the fused kernel's clock stamps (every tile's last record slot) to the file PISCES_HIP_DUMP_TILE_RESULTS names (tools/store_timing.py)
+static void dump_tile_stamps(PiscesHip* h)
+{
+    const char* path = getenv("PISCES_HIP_DUMP_TILE_RESULTS");
+    if (!path) return;
+    std::vector<PiscesCalledAllele> tr(h->d_tile_results.cap);
+    (void)hipMemcpy2D(tr.data(), sizeof(PiscesCalledAllele), h->d_records.p + (kSlotsPerTile - 1), (size_t)kSlotsPerTile * sizeof(PiscesCalledAllele),
+                      sizeof(PiscesCalledAllele), std::min(tr.size(), h->d_records.cap / kSlotsPerTile), hipMemcpyDeviceToHost);
+    if (FILE* fp = fopen(path, "wb")) { fwrite(tr.data(), sizeof(PiscesCalledAllele), tr.size(), fp); fclose(fp); }
+}
+#endif
 // device work of one flush: returns called alleles of `keys` sorted by (position, ref, alt)
 // as_view: the records are not copied into `out`; h->pending_view points at them in the pinned download buffer (valid until the next
 // call_blocks)
@@ -436,12 +448,7 @@ static int32_t call_blocks(PiscesHip* h, const std::vector<int32_t>& keys, std::
     PISCES_TIMED_WAIT(h, hipStreamSynchronize(h->stream));
     h->h_meta_used = 0;   // the stream is idle: nothing reads the arena any more
 #ifdef PISCES_STORE_TIMING
-    if (const char* path = getenv("PISCES_HIP_DUMP_TILE_RESULTS")) {   // development: the kernel's clock stamps (tools/store_timing.py)
-        std::vector<PiscesCalledAllele> tr(h->d_tile_results.cap);   // every tile's last record slot: the stamps
-        (void)hipMemcpy2D(tr.data(), sizeof(PiscesCalledAllele), h->d_records.p + (kSlotsPerTile - 1), (size_t)kSlotsPerTile * sizeof(PiscesCalledAllele),
-                          sizeof(PiscesCalledAllele), std::min(tr.size(), h->d_records.cap / kSlotsPerTile), hipMemcpyDeviceToHost);
-        if (FILE* fp = fopen(path, "wb")) { fwrite(tr.data(), sizeof(PiscesCalledAllele), tr.size(), fp); fclose(fp); }
-    }
+    dump_tile_stamps(h);
 #endif
     int32_t total = 0;
     rc = call_blocks_finish(h, st, &total, n_called, kept);
@@ -1543,6 +1550,9 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
             if (blocks_st.active) {
                 PISCES_TIMED_WAIT(h, hipStreamSynchronize(h->stream));
                 h->h_meta_used = 0;
+#ifdef PISCES_STORE_TIMING
+                dump_tile_stamps(h);
+#endif
                 int32_t total = 0;
                 rc = call_blocks_finish(h, blocks_st, &total, &called, &h->pending_kept);
                 if (rc) return rc;

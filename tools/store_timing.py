@@ -33,3 +33,12 @@ for lo, hi in ((0, 600), (600, 2000)):
 print("t(us)  searching  walking  calling")
 for g in np.arange(0, te.max() + 1, 4.0):
     print(f"{g:6.0f} {int(((t0 <= g) & (ts > g)).sum()):9d} {int(((ts <= g) & (tw > g)).sum()):8d} {int(((tw <= g) & (te > g)).sum()):8d}")
+# per CU (XCC id, SE / SH / CU bits of HW_ID): how much work it was dealt and when its last tile ended
+cu = (t[:, 6].astype(np.int64) & 0xF) * 4096 + ((t[:, 5].astype(np.int64) >> 8) & 0xFFF)
+ids = np.unique(cu)
+work = np.array([nreads[cu == i].sum() for i in ids])
+last = np.array([te[cu == i].max() for i in ids])
+ntile = np.array([(cu == i).sum() for i in ids])
+print(f"CUs seen {len(ids)}; tiles per CU min/p50/max {ntile.min()} {int(np.median(ntile))} {ntile.max()}; fragments per CU min/p10/p50/p90/max "
+      f"{np.round(np.percentile(work, [0, 10, 50, 90, 100]))}; max / mean {work.max() / work.mean():.2f}")
+print(f"last tile's end per CU us min/p10/p50/p90/max {np.round(np.percentile(last, [0, 10, 50, 90, 100]), 1)}; correlation(work, end) {np.corrcoef(work, last)[0, 1]:.2f}")
