@@ -667,6 +667,44 @@ def run_stream_config(args):
     pass_seconds = [q[0] for q in passes]
     elapsed_h, n_rec_h, stats_h, host_h, pcie_h = one_pass(False)
     assert stats_h == stats and n_rec_h == n_rec
+
+    def handles_in_parallel(n_threads):
+        # One handle is bound by ONE host core.  The reference runs a job per chromosome on a thread pool
+        # (BaseGenomeProcessor.cs:40-90, JobManager.cs:70-73): here n_threads handles, each over its own contiguous share of the stretches
+        # (amplicons do not overlap: the shares' records are the whole's), on n_threads host threads against the one GPU.
+        import threading
+        bounds = [len(stretches) * k // n_threads for k in range(n_threads + 1)]
+        handles = [engine.HipVariantCaller(cfg, device=local_rank) for _ in range(n_threads)]
+        for c in handles:
+            c.SetReference(ref)
+        torch.cuda.synchronize(dev)
+        rows, errors = [0] * n_threads, []
+
+        def work(k):
+            try:
+                c, prev = handles[k], None
+                for batch, dbatch, up_to in stretches[bounds[k]:bounds[k + 1]]:
+                    c.AddDeviceReads(dbatch)
+                    if prev is not None:
+                        rows[k] += len(c.CallView(prev))
+                    prev = up_to
+                rows[k] += len(c.CallView(None))
+            except Exception as e:   # noqa: BLE001
+                errors.append(repr(e))
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(n_threads)]
+        t0 = time.perf_counter()
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        seconds = time.perf_counter() - t0
+        for c in handles:
+            c.close()
+        assert not errors and sum(rows) == n_rec, (errors, sum(rows), n_rec)
+        return seconds
+    par = None
+    if world == 1 and args.config == 3 and len(stretches) >= 8:   # (config 5's 17 stretches are 5 ms of device work: nothing for threads to share)
+        par = {"threads": 4, "seconds": sorted(handles_in_parallel(4) for _ in range(3))[1]}
     del stretches
     loci_mine = (a_hi - a_lo) * synth.READ_LEN
     summary = torch.tensor([stats["TotalNumCalled"], stats["TotalNumCollapsed"], stats["reads"], stats["reads_skipped"], loci_mine, n_rec], dtype=torch.int64, device=dev)
@@ -695,6 +733,10 @@ def run_stream_config(args):
                "host_fed": {"value": loci_mine / elapsed_h, "unit": "candidate loci/s (rank 0)", "seconds": elapsed_h, "host_seconds_in_add_reads": host_h["add_reads_s"],
                             "host_seconds_in_flushes": host_h["flush_s"], "pcie_bytes": pcie_h,
                             "what": "the same stretches from host arrays (pisces_hip_add_reads): the reads cross PCIe, 2 B per base"}}
+        if par:
+            out["handles_in_parallel"] = {"threads": par["threads"], "value": loci / par["seconds"], "unit": "candidate loci/s", "seconds": par["seconds"],
+                                          "what": "the same stretches over four handles on four host threads, one GPU (median of three passes): a job per "
+                                                  "chromosome on a thread pool is the reference's own model; one handle is bound by one host core"}
         assert out["totals"]["readsProcessed"] == n_reads or use_dist
         print(json.dumps(out), flush=True)
     if use_dist:

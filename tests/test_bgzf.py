@@ -565,3 +565,41 @@ def test_stitched_reads_through_the_bam_surface(which):
         with engine.HipVariantCaller(cfg) as c:
             c.bam_decode(_bgzf_of(bytes(plain)), 0)
             assert c.bam_fetch_directions() is None
+
+
+@pytest.mark.gpu
+def test_a_second_decode_right_behind_an_add_does_not_disturb_the_first_batch_s_candidates():
+    """MNV calling on: the candidate walk of a batch is counted at the add and its records are written by the next entry
+    (finish_candidate_discovery) — from the arrays of the batch, which for a small decoded batch are the decode's own buffers.  A second
+    pisces_hip_bam_decode overwrites those: it must first let the pending half run.  Two small BAMs decoded and added back to back against
+    (a) the same with the candidates taken between them and (b) the reads of both files added from host arrays."""
+    import torch
+    assert torch.cuda.is_available()
+    rng = np.random.default_rng(3)
+    streams = [_synthetic_bam([120] * 400, seed=s) for s in (5, 6)]
+    files = [make_bgzf([st[i:i + 60000] for i in range(0, len(st), 60000)]) for st in streams]
+    ref = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 3000)]
+    cfg = _abi.default_config(call_mnvs=1, max_mnv_length=3, max_gap_between_mnv=1, min_base_call_quality=20)
+    outs = []
+    for how in ("back to back", "candidates taken in between", "host arrays"):
+        os.environ["PISCES_HIP_STORE_DIRECT_BYTES"] = str(1 << 40)   # every batch joins the open segment: its arrays stay the decode's
+        try:
+            c = engine.HipVariantCaller(cfg)
+        finally:
+            os.environ.pop("PISCES_HIP_STORE_DIRECT_BYTES", None)
+        if True:
+            with c:
+                c.SetReference(ref)
+                for data in files:
+                    c.bam_decode(data, 0)
+                    if how == "host arrays":
+                        c.AddAlleleCounts(_abi.ReadBatch.from_arrays(**c.bam_fetch()))
+                    else:
+                        c.AddDecodedReads()
+                        if how != "back to back":
+                            assert len(c.GetCandidates(None)) > 100
+                rows, alleles = c.CallWithAlleles(None, capacity=1 << 16)
+                outs.append((rows, alleles, c.Stats()))
+    assert len(outs[0][0]) > 1000 and len(outs[0][1]) > 0
+    for o in outs[1:]:
+        assert o[0].tobytes() == outs[0][0].tobytes() and o[1] == outs[0][1] and o[2] == outs[0][2]
