@@ -17,7 +17,8 @@
 // Reads of a segment are in position order (a BAM is); a tile's reads are then the index range [first read that can still reach the
 // tile, first read that starts behind it), found by a 64-ary search over the descriptors (every lane probes one: 2-4 dependent loads).
 // A segment that turned out not to be sorted (state[0]) is scanned in whole: slow, still exact.
-// A read of one aligned run (soft clips allowed: most reads) is taken sixteen lanes at a time, four bases a lane (walk_segment);
+// A read of one aligned run (soft clips allowed: most reads) is taken eight lanes at a time, eight bases a lane (walk_segment_fast; the
+// anchor-resolved walk_segment: sixteen lanes, four bases a lane);
 // reads with insertions, deletions or skips go through read_walk.h's per-base function (the walk the host form and the log path use).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -590,6 +591,12 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p)
     __builtin_memcpy(&v, p, 4);
     return v;
 }
+__device__ __forceinline__ unsigned long long load_u64_unaligned(const uint8_t* p)   // eight bytes at any address: one global_load_dwordx2
+{
+    unsigned long long v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
 __device__ __forceinline__ long long shfl64(long long v, int src_lane)
 {
     const int lo = __shfl((int)(v & 0xFFFFFFFFll), src_lane, 64);
@@ -737,8 +744,11 @@ __device__ __forceinline__ void walk_segment(const SegmentView& G, int tile_star
 //     AlleleType; a base that is not exactly that letter is an N (AlleleHelper.GetAlleleType, AlleleHelper.cs:13-32)
 //   * low quality: one subtraction on all four qualities (RegionStateManager.cs:179-181: quality < minBQ; minBQ <= 127 here)
 //   * on the read: one mask from the lane's first / last valid byte (v_bfm_b32), applied with v_bfi_b32
-// and an observation is then ONE v_perm_b32 (row byte and column byte -> LDS address) and one ds_add_u32.  Lane (g, j) adds its four
-// bytes in the order (s + g) & 3 (the word is rotated by 8 g once), so the 64 lanes of an instruction stand on 64 different loci.
+// and an observation is then ONE v_perm_b32 (row byte and column byte -> LDS address) and one ds_add_u32.  A lane holds EIGHT bases of a
+// fragment (round 4: one 8-byte load each of bases and qualities; eight fragments a step, sixteen a sub-chunk) and adds its bytes in the
+// order (s + g) & 7 (the eight row bytes are rotated by g bytes once), so the 64 lanes of an instruction stand on 64 different loci.
+// What bounds the kernel is the number of instructions a SIMD issues for its three waves: ~320 per 2 048 lane-bases,
+// of which the classification and the mask are per four bases whatever the width of the load.
 struct ReadTrim {   // a descriptor with the floor applied: what is left of the read, per lane of a 64-read block
     int32_t pos, end;     // first position still to count, one past the last
     uint32_t aoff;        // index of the base on `pos` in the segment's arrays, + kSegmentPad
@@ -758,16 +768,19 @@ __device__ __forceinline__ void walk_segment_fast(const SegmentView& G, int tile
 #ifdef PISCES_STORE_TIMING
     if (stamps) { stamps[0] = wall_clock64(); stamps[1] = hi - lo; }
 #endif
-    const int g = lane >> 4, j4 = (lane & 15) * 4;
-    const int lane_pos = tile_start + j4;
-    // byte s of colreg: LDS byte offset, inside a row, of the locus this lane stands on in step s (its byte (s + g) & 3);
-    // sel[s]: the v_perm selector that makes that step's LDS address out of the word of rows and colreg
-    uint32_t colreg = 0, sel[4];
+    // Eight fragments a step, eight bases a lane: lane (g, j) = (lane >> 3, lane & 7) holds, of fragment 8 u + g (u = 0, 1), the bases on the
+    // tile's loci 8 j .. 8 j + 7 (one 8-byte load each of bases and qualities: half the loads, shuffles and mask arithmetic per base of
+    // the four-base form this replaced).  A lane adds its eight bytes in the order (s + g) & 7, s = 0..7: in every step the 64 lanes stand
+    // on 64 different loci.  The eight row bytes are rotated right by g bytes once (v_alignbyte): byte s of the rotated pair IS step s's,
+    // and so is byte s of the column constants below; the v_perm selectors that make the LDS address are then compile-time constants.
+    const int g = lane >> 3, j8 = (lane & 7) * 8;
+    const int lane_pos = tile_start + j8;
+    uint32_t col_lo = 0, col_hi = 0;   // byte s: LDS byte offset, inside a row, of the locus this lane stands on in step s
 #pragma unroll
-    for (int st = 0; st < 4; st++) {
-        const int k = (st + g) & 3;
-        colreg |= (uint32_t)((j4 + k) * (int)sizeof(int)) << (8 * st);
-        sel[st] = 0x0C0C0000u | ((uint32_t)(4 + k) << 8) | (uint32_t)st;
+    for (int st = 0; st < 8; st++) {
+        const uint32_t c = (uint32_t)((j8 + ((st + g) & 7)) * (int)sizeof(int));
+        if (st < 4) col_lo |= c << (8 * st);
+        else col_hi |= c << (8 * (st - 4));
     }
     const uint32_t qk4 = (0x7Fu + min(min_bq, 127u)) * 0x01010101u;
     const uint8_t* const bases = G.bases - kSegmentPad;
@@ -776,7 +789,7 @@ __device__ __forceinline__ void walk_segment_fast(const SegmentView& G, int tile
     const int n_blocks = (hi - lo + 63) >> 6;
     const int my_blocks = (n_blocks - wid + n_waves - 1) / n_waves;
     if (my_blocks > 0) {
-        struct Sub { uint32_t bw[4], qw[4], dw[4], mask[4]; };
+        struct Sub { uint32_t bw[2][2], qw[2][2], dw[2][2], mask[2][2]; };   // [u][low / high four bases]
         auto block_base = [&](int b) { return lo + (wid + min(b, my_blocks - 1) * n_waves) * 64; };
         auto load_trim = [&](int b) {
             const int base = block_base(b), cnt = min(64, hi - base);
@@ -796,26 +809,33 @@ __device__ __forceinline__ void walk_segment_fast(const SegmentView& G, int tile
             const uint32_t live = f < my_blocks * 4 ? 0xFFFFFFFFu : 0u;
             const int q = f & 3;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int src = 16 * q + 4 * u + g;
+            for (int u = 0; u < 2; u++) {
+                const int src = 16 * q + 8 * u + g;
                 const int pos = __shfl(t.pos, src, 64), end = __shfl(t.end, src, 64);
                 const uint32_t aoff = (uint32_t)__shfl((int)t.aoff, src, 64);
                 const int da = pos - lane_pos, de = end - lane_pos;            // the lane's bytes a .. e - 1 are on the read
-                const int a = min(max(da, 0), 4), e = min(max(de, 0), 4);
-                const uint32_t width = (uint32_t)min((e - a) * 8, 31);         // (a full word: 31 bits; bit 31 is no row bit)
-                S.mask[u] = ((((1u << width) - 1u) << ((uint32_t)a * 8u)) & live);
-                const uint32_t at = aoff + (uint32_t)(a < e ? -da : 0);       // (a word that is not on the read at all: the read's first)
-#if defined(PISCES_STORE_ABLATE) && PISCES_STORE_ABLATE == 3
-                S.bw[u] = load_u32_unaligned(bases + (at & ~3u));
-                S.qw[u] = load_u32_unaligned(quals + (at & ~3u));
-#elif defined(PISCES_STORE_ABLATE) && PISCES_STORE_ABLATE == 5
-                S.bw[u] = 0x41434754u ^ ((at & 1u) << 1);   // development ablation: no loads of bases / qualities (what is left is descriptors + arithmetic + LDS)
-                S.qw[u] = 0x25252525u + (at & 3u);
+                const int a = min(max(da, 0), 8), e = min(max(de, 0), 8);
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) {
+                    const int ah = min(max(a - 4 * hf, 0), 4), eh = min(max(e - 4 * hf, 0), 4);
+                    const uint32_t width = (uint32_t)min((eh - ah) * 8, 31);   // (a full word: 31 bits; bit 31 is no row bit)
+                    S.mask[u][hf] = ((((1u << width) - 1u) << (((uint32_t)ah * 8u) & 31u)) & live);
+                }
+                const uint32_t at = aoff + (uint32_t)(a < e ? -da : 0);       // (eight bytes that are not on the read at all: the read's first)
+#if defined(PISCES_STORE_ABLATE) && PISCES_STORE_ABLATE == 5
+                S.bw[u][0] = 0x41434754u ^ ((at & 1u) << 1); S.bw[u][1] = 0x54474341u;   // development ablation: no loads of bases / qualities
+                S.qw[u][0] = 0x25252525u + (at & 3u); S.qw[u][1] = 0x25252525u;
 #else
-                S.bw[u] = load_u32_unaligned(bases + at);
-                S.qw[u] = load_u32_unaligned(quals + at);
+                const unsigned long long b8 = load_u64_unaligned(bases + at), q8 = load_u64_unaligned(quals + at);
+                S.bw[u][0] = (uint32_t)b8; S.bw[u][1] = (uint32_t)(b8 >> 32);
+                S.qw[u][0] = (uint32_t)q8; S.qw[u][1] = (uint32_t)(q8 >> 32);
 #endif
-                S.dw[u] = kDirs ? load_u32_unaligned(dirs + at) : (uint32_t)__shfl((int)t.dir4, src, 64);
+                if (kDirs) {
+                    const unsigned long long d8 = load_u64_unaligned(dirs + at);
+                    S.dw[u][0] = (uint32_t)d8; S.dw[u][1] = (uint32_t)(d8 >> 32);
+                } else {
+                    S.dw[u][0] = S.dw[u][1] = (uint32_t)__shfl((int)t.dir4, src, 64);
+                }
             }
         };
         // the rows of the four bases of a word.  Fast form: the letter the low three bits stand for (A C G T N) is taken at its word; a base
@@ -843,33 +863,52 @@ __device__ __forceinline__ void walk_segment_fast(const SegmentView& G, int tile
             return (mask & row4) | (~mask & 0x18181818u);
         };
         auto consume = [&](const Sub& S) {
-            uint32_t row4[4], other = 0;
+            uint32_t row4[2][2], other = 0;
 #pragma unroll
-            for (int u = 0; u < 4; u++) row4[u] = rows_of(S.bw[u], S.qw[u], S.dw[u], S.mask[u], other);
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) row4[u][hf] = rows_of(S.bw[u][hf], S.qw[u][hf], S.dw[u][hf], S.mask[u][hf], other);
             if (__builtin_expect(__ballot(other != 0) != 0ull, 0)) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) row4[u] = rows_of_exact(S.bw[u], S.qw[u], S.dw[u], S.mask[u]);
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int hf = 0; hf < 2; hf++) row4[u][hf] = rows_of_exact(S.bw[u][hf], S.qw[u][hf], S.dw[u][hf], S.mask[u][hf]);
             }
 #if defined(PISCES_STORE_ABLATE) && PISCES_STORE_ABLATE == 2
-            if ((row4[0] ^ row4[1] ^ row4[2] ^ row4[3]) == 0x12345u) *reinterpret_cast<volatile int*>(hbytes) = 1;   // development ablation: no histogram update
+            if ((row4[0][0] ^ row4[0][1] ^ row4[1][0] ^ row4[1][1]) == 0x12345u) *reinterpret_cast<volatile int*>(hbytes) = 1;   // development ablation: no histogram update
             return;
 #endif
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 2; u++) {
+                // the eight row bytes rotated right by g bytes: {hi, lo} >> 8 g for g < 4, the words swapped first for g >= 4
+                const uint32_t x = g < 4 ? row4[u][0] : row4[u][1], y = g < 4 ? row4[u][1] : row4[u][0];
+                const uint32_t lo8 = __builtin_amdgcn_alignbyte(y, x, (uint32_t)(g & 3)), hi8 = __builtin_amdgcn_alignbyte(x, y, (uint32_t)(g & 3));
 #pragma unroll
-                for (int st = 0; st < 4; st++) atomicAdd(reinterpret_cast<int*>(hbytes + __builtin_amdgcn_perm(row4[u], colreg, sel[st])), 1);
+                for (int st = 0; st < 4; st++)   // (row byte st and column byte st -> LDS address)
+                    atomicAdd(reinterpret_cast<int*>(hbytes + __builtin_amdgcn_perm(lo8, col_lo, 0x0C0C0000u | ((uint32_t)(4 + st) << 8) | (uint32_t)st)), 1);
+#pragma unroll
+                for (int st = 0; st < 4; st++)
+                    atomicAdd(reinterpret_cast<int*>(hbytes + __builtin_amdgcn_perm(hi8, col_hi, 0x0C0C0000u | ((uint32_t)(4 + st) << 8) | (uint32_t)st)), 1);
             }
         };
         const int n_f = my_blocks * 4;
         ReadTrim tc = load_trim(0), tn = load_trim(1);
         Sub A, B;
         issue(tc, 0, A);
+#ifdef PISCES_STORE_TIMING
+#define PISCES_TICK(k) { __builtin_amdgcn_sched_barrier(0); const long long now_ = clock64(); if (stamps) stamps[k] += now_ - tick_; tick_ = now_; __builtin_amdgcn_sched_barrier(0); }
+        long long tick_ = clock64();
+#else
+#define PISCES_TICK(k)
+#endif
         for (int f = 0; f < n_f; f += 2) {
             __builtin_amdgcn_sched_barrier(0);
             issue(tc, f + 1, B);                  // (same block as f: four sub-chunks a block)
             __builtin_amdgcn_sched_barrier(0);
+            PISCES_TICK(2)
             consume(A);
             __builtin_amdgcn_sched_barrier(0);
+            PISCES_TICK(3)
             const bool next_block = (f & 3) == 2;
             ReadTrim ta;
             ta.pos = next_block ? tn.pos : tc.pos;
@@ -877,11 +916,18 @@ __device__ __forceinline__ void walk_segment_fast(const SegmentView& G, int tile
             ta.aoff = next_block ? tn.aoff : tc.aoff;
             ta.dir4 = next_block ? tn.dir4 : tc.dir4;
             tn = load_trim(((f + 2) >> 2) + 1);   // (the same descriptors again three times out of four: straight-line code)
+            PISCES_TICK(4)
             issue(ta, f + 2, A);                  // (past the end: a repeat of the last sub-chunk with nothing valid)
             tc = ta;
             __builtin_amdgcn_sched_barrier(0);
+            PISCES_TICK(2)
             consume(B);
+            PISCES_TICK(3)
+#ifdef PISCES_STORE_TIMING
+            if (stamps) stamps[5] += 1;
+#endif
         }
+#undef PISCES_TICK
     }
     const int frag_bits = G.state[kStateFrags];
     // ---- the deletion fragments of the range (if the segment has any): lane = locus; a gap's positions count as deletions in the
@@ -988,7 +1034,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
     const PiscesTile tile = tiles ? tiles[t] : regular_tile(R, t);
 #ifdef PISCES_STORE_TIMING
     const long long tc0 = wall_clock64();   // 100 MHz, chip-global
-    long long stamps[2] = {0, 0};
+    long long stamps[6] = {0, 0, 0, 0, 0, 0};   // [2..5]: shader-clock cycles this wave spent issuing / consuming / trimming, loop iterations
 #endif
 #if defined(PISCES_STORE_ABLATE) && PISCES_STORE_ABLATE == 4
     if (tile.n_loci > 0) { if (threadIdx.x == 0) { tile_results[t].record_begin = 0; tile_results[t].n_records = 0; tile_results[t].n_called = 0; tile_results[t].n_candidate_loci = 0; } return; }   // development ablation: nothing
@@ -1052,6 +1098,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
         tr[2] = (int)(tc_walk & 0x3FFFFFFF);
         tr[3] = (int)(tc_end & 0x3FFFFFFF);
         tr[4] = (int)stamps[1];                     // reads in the tile's range
+        tr[7] = (int)stamps[2]; tr[8] = (int)stamps[3]; tr[9] = (int)stamps[4]; tr[10] = (int)stamps[5];   // wave 0: cycles issuing / consuming / trimming, iterations
         tr[5] = (int)__builtin_amdgcn_s_getreg(63492);    // HW_REG_HW_ID
         tr[6] = (int)__builtin_amdgcn_s_getreg(63508);    // HW_REG_XCC_ID
     }

@@ -42,3 +42,9 @@ ntile = np.array([(cu == i).sum() for i in ids])
 print(f"CUs seen {len(ids)}; tiles per CU min/p50/max {ntile.min()} {int(np.median(ntile))} {ntile.max()}; fragments per CU min/p10/p50/p90/max "
       f"{np.round(np.percentile(work, [0, 10, 50, 90, 100]))}; max / mean {work.max() / work.mean():.2f}")
 print(f"last tile's end per CU us min/p10/p50/p90/max {np.round(np.percentile(last, [0, 10, 50, 90, 100]), 1)}; correlation(work, end) {np.corrcoef(work, last)[0, 1]:.2f}")
+# wave 0 of every tile: shader-clock cycles of its walk loop by part
+it = np.maximum(t[:, 10].astype(np.int64), 1)
+for name, k in (("issue (shuffles, masks, loads sent)", 7), ("consume (wait for the loads, classify, ds_add)", 8), ("next block's descriptors + trim", 9)):
+    v = t[:, k].astype(np.int64)
+    print(f"{name:48s} cycles per iteration p10/p50/p90 {np.round(np.percentile(v / it, [10, 50, 90]))}; per tile p50 {np.percentile(v, 50):.0f}")
+print("iterations per wave p50", np.percentile(it, 50))
