@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpisceship.so")
 SOURCES = ["pisces_hip.hip", "expander.cpp", "finder.cpp", "vcf_format.cpp", "diploid.cpp"]
-HEADERS = ["kernels.hip.h", "stream_kernels.hip.h", "store_kernels.hip.h", "surface_store.inc.h", "finder_kernels.hip.h", "bgzf_kernels.hip.h", "bam_kernels.hip.h", "device_math.hip.h", "surface_reads.inc.h", "surface_flush.inc.h", "surface_device.inc.h", "surface_bam.inc.h", "surface_comm.inc.h", "expander.h", "read_walk.h", "finder.h", "finder_walk.h", "diploid.h", os.path.join("..", "..", "include", "pisces_hip.h")]
+HEADERS = ["kernels.hip.h", "stream_kernels.hip.h", "store_kernels.hip.h", "surface_store.inc.h", "finder_kernels.hip.h", "bgzf_kernels.hip.h", "bam_kernels.hip.h", "device_math.hip.h", "surface_reads.inc.h", "surface_flush.inc.h", "surface_device.inc.h", "surface_bam.inc.h", "surface_comm.inc.h", "expander.h", "read_walk.h", "finder.h", "finder_walk.h", "diploid.h", "genotype_core.h", os.path.join("..", "..", "include", "pisces_hip.h")]
 
 
 def hipcc_path():
