@@ -342,6 +342,27 @@ namespace Pisces.Hip
             return counts;
         }
 
+        /// The same over bytes that are not a managed array: a view of a memory-mapped BAM (HipBamSource) — no copy of the file on the
+        /// managed heap, no 2 GB limit of byte[].
+        public long[] AddBamBlocks(IntPtr file, long nBytes, int refId, ChrReference chrReference, int minMapQuality, bool skipDuplicates, bool onlyProperPairs)
+        {
+            if (!_referenceSet && chrReference != null)
+            {
+                var bytes = Encoding.ASCII.GetBytes(chrReference.Sequence);
+                NativeMethods.Check(_h, NativeMethods.pisces_hip_set_reference(_h, bytes, bytes.LongLength));
+                _referenceSet = true;
+            }
+            long inflated;
+            long nBlocks = NativeMethods.pisces_hip_bgzf_scan(file, nBytes, null, 0, out inflated);
+            if (nBlocks < 0) throw new System.IO.InvalidDataException("not a chain of BGZF blocks (" + nBlocks + ")");
+            var blocks = new PiscesBgzfBlock[Math.Max(1, nBlocks)];
+            nBlocks = NativeMethods.pisces_hip_bgzf_scan(file, nBytes, blocks, blocks.LongLength, out inflated);
+            var counts = new long[4];
+            NativeMethods.Check(_h, NativeMethods.pisces_hip_bam_decode(_h, file, nBytes, blocks, nBlocks, refId, minMapQuality, skipDuplicates ? 1 : 0, onlyProperPairs ? 1 : 0, counts));
+            NativeMethods.Check(_h, NativeMethods.pisces_hip_add_decoded_reads(_h));
+            return counts;
+        }
+
         /// one interval shard of a chromosome: calls and totals only inside [lo, hi] (the reads of the halo still feed the counts)
         public void SetOwnedRange(int lo, int hi) { NativeMethods.Check(_h, NativeMethods.pisces_hip_set_owned_range(_h, lo, hi)); }
 

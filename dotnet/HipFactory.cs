@@ -77,8 +77,9 @@ namespace Pisces.Hip
     }
 
     /// IAlignmentSource over the library's BAM surface: no Read ever reaches the managed side (HipFactory.CreateAlignmentSource).
-    /// The whole file is handed over and the library keeps the records of refId (a production reader would hand over the chromosome's
-    /// chunks from the .bai instead of the file).
+    /// The file is memory-mapped and handed over as it lies (no managed copy, no byte[] size limit; jobs of one process share the page
+    /// cache); the library keeps the records of refId.  Still per job: the whole file is inflated and cut to find one chromosome's
+    /// records — a production reader hands over the chromosome's chunks from the .bai, in position-ordered slices with a flush between them.
     internal sealed class HipBamSource : IAlignmentSource
     {
         private readonly Func<HipEngine> _engine; private readonly string _path; private readonly int _refId; private readonly ChrReference _chr;
@@ -90,13 +91,25 @@ namespace Pisces.Hip
             _engine = engine; _path = path; _refId = refId; _chr = chr; _minMapQuality = minMapQuality; _skipDuplicates = skipDuplicates;
             _onlyProperPairs = onlyProperPairs; SourceIsStitched = stitched; SourceIsCollapsed = collapsed;
         }
-        public Read GetNextRead()
+        public unsafe Read GetNextRead()
         {
             if (!_handedOver && _refId >= 0)
             {
                 _handedOver = true;
-                // {records of the chromosome, reads kept, bases, CIGAR operations}; the skipped reads are in HipEngine.Stats()[3]
-                _engine().AddBamBlocks(System.IO.File.ReadAllBytes(_path), _refId, _chr, _minMapQuality, _skipDuplicates, _onlyProperPairs);
+                long nBytes = new System.IO.FileInfo(_path).Length;
+                using (var map = System.IO.MemoryMappedFiles.MemoryMappedFile.CreateFromFile(_path, System.IO.FileMode.Open, null, 0,
+                                                                                             System.IO.MemoryMappedFiles.MemoryMappedFileAccess.Read))
+                using (var view = map.CreateViewAccessor(0, 0, System.IO.MemoryMappedFiles.MemoryMappedFileAccess.Read))
+                {
+                    byte* p = null;
+                    view.SafeMemoryMappedViewHandle.AcquirePointer(ref p);
+                    try
+                    {
+                        // {records of the chromosome, reads kept, bases, CIGAR operations}; the skipped reads are in HipEngine.Stats()[3]
+                        _engine().AddBamBlocks((IntPtr)(p + view.PointerOffset), nBytes, _refId, _chr, _minMapQuality, _skipDuplicates, _onlyProperPairs);
+                    }
+                    finally { view.SafeMemoryMappedViewHandle.ReleasePointer(); }
+                }
             }
             return null;   // end of file: SmallVariantCaller goes on to its final Call()
         }

@@ -185,6 +185,7 @@ namespace Pisces.Hip
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern long pisces_hip_expand_reads(ref PiscesReadBatch batch, int minBaseCallQuality, [Out] int[] positions, [Out] uint[] tuples, long capacity);
         // BGZF: the batched counterpart of Common.IO.SafeNativeMethods.UncompressBlock (FileCompression.cs:14-16)
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern long pisces_hip_bgzf_scan(byte[] file, long nBytes, [Out] PiscesBgzfBlock[] blocks, long capacity, out long inflatedBytes);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern long pisces_hip_bgzf_scan(IntPtr file, long nBytes, [Out] PiscesBgzfBlock[] blocks, long capacity, out long inflatedBytes);   // (a memory-mapped file)
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_bgzf_inflate(IntPtr handle, byte[] file, long nBytes, PiscesBgzfBlock[] blocks, long nBlocks, [Out] byte[] output, long outCapacity, int checkCrc, out float kernelMs);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_probe_read_bandwidth(IntPtr handle, long nBytes, int reps, out double gbPerSecond);
         // VCF body lines straight from the records (what VcfFileWriter.WriteListOfColocatedAlleles writes per allele, Pisces.IO/VcfFileWriter.cs:206-262)
