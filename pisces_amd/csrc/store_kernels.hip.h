@@ -813,15 +813,13 @@ __device__ __forceinline__ void walk_segment_fast(const SegmentView& G, int tile
                 const int src = 16 * q + 8 * u + g;
                 const int pos = __shfl(t.pos, src, 64), end = __shfl(t.end, src, 64);
                 const uint32_t aoff = (uint32_t)__shfl((int)t.aoff, src, 64);
-                const int da = pos - lane_pos, de = end - lane_pos;            // the lane's bytes a .. e - 1 are on the read
-                const int a = min(max(da, 0), 8), e = min(max(de, 0), 8);
-#pragma unroll
-                for (int hf = 0; hf < 2; hf++) {
-                    const int ah = min(max(a - 4 * hf, 0), 4), eh = min(max(e - 4 * hf, 0), 4);
-                    const uint32_t width = (uint32_t)min((eh - ah) * 8, 31);   // (a full word: 31 bits; bit 31 is no row bit)
-                    S.mask[u][hf] = ((((1u << width) - 1u) << (((uint32_t)ah * 8u) & 31u)) & live);
-                }
-                const uint32_t at = aoff + (uint32_t)(a < e ? -da : 0);       // (eight bytes that are not on the read at all: the read's first)
+                const int da = pos - lane_pos, de = end - lane_pos;            // the lane's bytes a .. e - 1 are on the read: a = clamp(da, 0, 8), e = clamp(de, 0, 8)
+                // as bit positions, capped at 63 (bit 63 is bit 7 of the last byte: no row bit): the mask is bits a8 .. e8 - 1 of the eight bytes
+                const uint32_t a8 = (uint32_t)min(min(max(da, 0), 8) * 8, 63), e8 = (uint32_t)min(min(max(de, 0), 8) * 8, 63) & live;   // (clamped before they are scaled: da is any int in an unsorted segment)
+                const unsigned long long m8 = ((1ull << e8) - 1ull) & ~((1ull << a8) - 1ull);
+                S.mask[u][0] = (uint32_t)m8;
+                S.mask[u][1] = (uint32_t)(m8 >> 32);
+                const uint32_t at = aoff + (uint32_t)(a8 < e8 ? -da : 0);     // (eight bytes that are not on the read at all: the read's first)
 #if defined(PISCES_STORE_ABLATE) && PISCES_STORE_ABLATE == 5
                 S.bw[u][0] = 0x41434754u ^ ((at & 1u) << 1); S.bw[u][1] = 0x54474341u;   // development ablation: no loads of bases / qualities
                 S.qw[u][0] = 0x25252525u + (at & 3u); S.qw[u][1] = 0x25252525u;
