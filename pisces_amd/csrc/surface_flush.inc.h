@@ -1529,7 +1529,12 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
         const bool blocks_first = fused_regular_applies(h, keys);
         int32_t rc = PISCES_OK;
         if (blocks_first) {
-            rc = call_blocks_enqueue(h, keys, true, -1, &blocks_st, true);
+            // (the folded counts only when a candidate can ask for them: 72 B a locus that an SNV-only flush need not write)
+            bool want_folded = h->mnv_split || !h->forced.empty();
+            if (!want_folded)
+                for (auto& kv : h->blocks)
+                    if (!kv.second.cands.empty()) { want_folded = true; break; }
+            rc = call_blocks_enqueue(h, keys, true, -1, &blocks_st, want_folded);
             if (rc) return rc;
         }
         rc = call_spanning(h, keys, final_flush ? -1 : up_to_position, span_recs, span_cands, &called, &collapsed, ref_overrides, blocks_first && blocks_st.active);
