@@ -254,12 +254,8 @@ __device__ __forceinline__ void walk_read_events(const ReadView& r, const uint8_
             }
             if ((int64_t)in_ref + len < ref_len && in_ref >= 1 && flanks_ok)
                 walk::finish_candidate(r, f, P, PISCES_CAT_DELETION, in_ref, in_ref - 1, in_read, len, 1, ci, false, false, emit);
-        } else if (t == 'X' && P.mark_x_spans && len > 0) {
-            FoundCandidate c;
-            c.position = in_ref + 1; c.ref_index = in_ref; c.start_in_read = in_read; c.length = len;
-            c.category = kFoundSpanMark; c.dir = 0; c.well_anchored = c.open_left = c.open_right = 0;
-            c.pad[0] = c.pad[1] = c.pad[2] = 0;
-            emit(c);
+        } else if ((t == 'X' || t == '=') && P.mark_x_spans && len > 0) {
+            walk::mark_unwalked_span(r, t, len, in_read, in_ref, ref, ref_len, emit);
         }
         if (walk::spans_read(t)) in_read += len;
         if (walk::spans_ref(t)) in_ref += len;
@@ -540,12 +536,8 @@ __device__ __forceinline__ void walk_read_wave(const ReadView& r, const uint8_t*
             }
             if ((int64_t)in_ref + len < ref_len && in_ref >= 1 && flanks_ok)
                 walk::finish_candidate(r, f, P, PISCES_CAT_DELETION, in_ref, in_ref - 1, in_read, len, 1, ci, false, false, emit);
-        } else if (t == 'X' && P.mark_x_spans && len > 0) {
-            FoundCandidate c;
-            c.position = in_ref + 1; c.ref_index = in_ref; c.start_in_read = in_read; c.length = len;
-            c.category = kFoundSpanMark; c.dir = 0; c.well_anchored = c.open_left = c.open_right = 0;
-            c.pad[0] = c.pad[1] = c.pad[2] = 0;
-            emit(c);
+        } else if ((t == 'X' || t == '=') && P.mark_x_spans && len > 0) {
+            walk::mark_unwalked_span(r, t, len, in_read, in_ref, ref, ref_len, emit);
         }
         if (walk::spans_read(t)) in_read += len;
         if (walk::spans_ref(t)) in_ref += len;

@@ -39,9 +39,9 @@ struct FinderParams {
     int32_t mark_x_spans;    // the streaming surface's split form of MNV calling: every X operation leaves a span mark (below)
 };
 
-// Not a candidate: the positions of an X operation (position, length).  ProcessCigarOps (:44-71) walks M operations only, so the bases of
-// an X operation are allele counts without SNV candidates; the flush takes the loci of such a span from the read walk's candidates
-// instead of from the counts (surface_flush.inc.h, the dirty loci).  '=' bases equal the reference: they make no candidate either way.
+// Not a candidate: the positions of an X operation, or of the differing bases of an = operation (position, length).  ProcessCigarOps
+// (:44-71) walks M operations only, so such bases are allele counts without SNV candidates; the flush takes the loci of such a span from
+// the read walk's candidates instead of from the counts (surface_flush.inc.h, the dirty loci).
 constexpr uint8_t kFoundSpanMark = 0x40;
 
 namespace walk {
@@ -208,6 +208,31 @@ PISCES_HD inline void walk_match_op(const ReadView& r, const ReadFrame& f, const
     close(walked, false);
 }
 
+// ProcessCigarOps walks M operations only (:44-71): the bases of an X operation — and those of an = operation that differ from the
+// reference after all (a CIGAR is not checked against the reference) — are allele counts that no SNV candidate stands for.  With
+// mark_x_spans the walk leaves a span mark over them (all of an X operation; from the first to the last differing base of an = operation).
+template <typename Emit>
+PISCES_HD inline void mark_unwalked_span(const ReadView& r, uint8_t t, int len, int in_read, int in_ref, const uint8_t* ref, int64_t ref_len, Emit& emit)
+{
+    int lo = 0, hi = len - 1;
+    if (t == '=') {
+        lo = -1;
+        for (int i = 0; i < len && in_read + i < r.read_len && (int64_t)in_ref + i < ref_len; i++)
+            if (r.bases[in_read + i] != ref[in_ref + i]) { if (lo < 0) lo = i; hi = i; }
+        if (lo < 0) return;
+    }
+    FoundCandidate c;
+    c.position = in_ref + lo + 1;
+    c.ref_index = in_ref + lo;
+    c.start_in_read = in_read + lo;
+    c.length = hi - lo + 1;
+    c.category = kFoundSpanMark;
+    c.dir = 0;
+    c.well_anchored = c.open_left = c.open_right = 0;
+    c.pad[0] = c.pad[1] = c.pad[2] = 0;
+    emit(c);
+}
+
 // ProcessCigarOps :36-83: every candidate of one read, in the reference's order of discovery
 template <typename Src = ByteBases, typename Emit>
 PISCES_HD inline void walk_read(const ReadView& r, const uint8_t* ref, int64_t ref_len, const FinderParams& P, Emit& emit)
@@ -233,18 +258,7 @@ PISCES_HD inline void walk_read(const ReadView& r, const uint8_t* ref, int64_t r
             if ((int64_t)in_ref + len < ref_len && in_ref >= 1 && flanks_ok)
                 finish_candidate(r, f, P, PISCES_CAT_DELETION, in_ref, in_ref - 1, in_read, len, 1, ci, false, false, emit);
         }
-        else if (t == 'X' && P.mark_x_spans && len > 0) {
-            FoundCandidate c;
-            c.position = in_ref + 1;
-            c.ref_index = in_ref;
-            c.start_in_read = in_read;
-            c.length = len;
-            c.category = kFoundSpanMark;
-            c.dir = 0;
-            c.well_anchored = c.open_left = c.open_right = 0;
-            c.pad[0] = c.pad[1] = c.pad[2] = 0;
-            emit(c);
-        }
+        else if ((t == 'X' || t == '=') && P.mark_x_spans && len > 0) mark_unwalked_span(r, t, len, in_read, in_ref, ref, ref_len, emit);
         if (spans_read(t)) in_read += len;
         if (spans_ref(t)) in_ref += len;
     }

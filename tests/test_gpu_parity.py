@@ -2088,3 +2088,62 @@ def test_summary_reduce_through_the_c_abi_on_two_devices(torch_cuda):
                         "--master-port", "29517", os.path.join(root, "tools", "reduce_check.py")], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("reduce_check rank") == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(20)))
+def test_split_form_equals_the_legacy_form_on_random_schedules(torch_cuda, seed):
+    """MNV calling on: the split form (plain SNV groups stay in the device's SNV store, the tile kernel calls SNVs from the counts off the
+    dirty loci: DESIGN section 8a) against the form in which every candidate group visits the host (PISCES_HIP_MNV_SPLIT=0) — AlleleCaller's
+    MNV pass, MnvReallocator and the all-alleles pass (AlleleCaller.cs:60-141) either way.  Random reads (planted MNVs, some gapped, SNVs
+    beside them, errors that make failing MNVs, low-quality bases that open candidates up, insertions / deletions, X and = operations),
+    reads added in batches that straddle the block edges, random flush schedules, collapser on / off, gVCF on / off, MNV limits, an
+    interval set or forced alleles now and then: records, allele strings and totals must be the same — and the oracle's, which runs the same
+    upTo schedule over all the reads (orc_run_reads_schedule; no interval sets there).  (An = operation over a base that differs from the
+    reference is such a case: an allele count no SNV candidate stands for, a span mark of the walk like the bases of an X operation.)"""
+    from pisces_amd import engine
+    rng = np.random.default_rng(9000 + seed)
+    ref = bytes(rng.choice(list(b"ACGT"), 4200).astype(np.uint8))
+    reads = _mnv_reads(rng, bytearray(ref), int(rng.integers(1500, 4000)), region=(50, 4000), snv_rate=float(rng.choice([0.002, 0.006])))
+    for i, r in enumerate(reads):   # a few reads whose M run is split in = / X operations (ProcessCigarOps walks M only)
+        if i % 37 == 0 and r["cigar"] == [("M", 100)]:
+            k = int(rng.integers(10, 80))
+            r["cigar"] = [("=", k), ("X", 2), ("M", 100 - k - 2)]
+    reads.sort(key=lambda r: r["pos"])
+    kw = dict(call_mnvs=1, max_mnv_length=int(rng.choice([2, 3, 5])), max_gap_between_mnv=int(rng.choice([0, 1, 2])), collapse=int(rng.integers(0, 2)),
+              include_reference_calls=int(rng.integers(0, 2)), min_frequency=float(rng.choice([0.01, 0.05])))
+    cfg = _abi.default_config(**kw)
+    intervals = [(200, 1700), (1900, 3100), (3300, 3900)] if seed % 4 == 1 else None
+    forced = [(1500, chr(ref[1499]), "A" if chr(ref[1499]) != "A" else "C"),
+              (2600, ref[2599:2601].decode(), "TT" if ref[2599] != ord("T") and ref[2600] != ord("T") else "GG" if ref[2599] != ord("G") and ref[2600] != ord("G") else "CC")] if seed % 4 == 2 else None
+    cuts = sorted(set(int(x) for x in rng.integers(0, len(reads), 4)) | {len(reads)})
+    ups = [int(x) for x in sorted(rng.integers(600, 3900, len(cuts) - 1))] + [None]
+    out, schedule = [], []
+    for split in (None, 0):
+        with env(PISCES_HIP_MNV_SPLIT=split):
+            with engine.HipVariantCaller(cfg) as c:
+                c.SetReference(ref)
+                if intervals:
+                    c.SetIntervals(intervals)
+                if forced:
+                    c.SetForcedAlleles(forced)
+                rows, alleles, a0 = [], [], 0
+                for cut, up in zip(cuts, ups):
+                    c.AddAlleleCounts(_abi.ReadBatch(reads[a0:cut]))
+                    a0 = cut
+                    if up is not None:
+                        up = min(up, reads[cut - 1]["pos"] - 1) if cut else up   # (Call(upTo) behind the last read added, as SmallVariantCaller)
+                        if split is None:
+                            schedule.append(up)
+                    r, a = c.CallWithAlleles(up, capacity=1 << 15)
+                    rows.append(r)
+                    alleles += a
+                out.append((np.concatenate(rows), alleles, c.Stats()))
+    (got, ga, gs), (want, wa, ws) = out
+    cats = set(((want["info"] >> 4) & 7).tolist())
+    assert _abi.CAT_MNV in cats and _abi.CAT_SNV in cats and len(want) > 50
+    assert got.tobytes() == want.tobytes() and ga == wa and gs == ws, (seed, kw)
+    if not intervals:
+        exp, exp_alleles, exp_called = orc.run_reads_schedule(_abi.ReadBatch(reads), np.frombuffer(ref, np.uint8), 1, len(ref), cfg, schedule, forced=forced or ())
+        assert ga == exp_alleles and gs["TotalNumCalled"] == exp_called
+        assert_records_match(got, exp)
