@@ -2147,3 +2147,68 @@ def test_split_form_equals_the_legacy_form_on_random_schedules(torch_cuda, seed)
         exp, exp_alleles, exp_called = orc.run_reads_schedule(_abi.ReadBatch(reads), np.frombuffer(ref, np.uint8), 1, len(ref), cfg, schedule, forced=forced or ())
         assert ga == exp_alleles and gs["TotalNumCalled"] == exp_called
         assert_records_match(got, exp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_every_switch_of_the_library_leaves_the_records_alone(torch_cuda, seed):
+    """The forms the library can take for the same work — rows merged in place or into a vector, a batch checked by the host's pass over
+    the CIGARs or on the device, candidates merged on the host or on the device, the candidate walk base by base or events first, the
+    germline genotypes by the kernel or by the host pass, every batch a segment of its own or appended to the open one, reads handed over
+    from host arrays or in device memory, the candidates looked at between an add and its flush — on random reads, random modes (MNV
+    calling, collapser, ploidy, gVCF, thresholds) and a random flush schedule: every form gives the records, allele strings and totals
+    of the default."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(7100 + seed)
+    ref = bytes(rng.choice(list(b"ACGT"), 3300).astype(np.uint8))
+    reads = _mnv_reads(rng, bytearray(ref), int(rng.integers(1200, 3000)), region=(50, 3100), snv_rate=float(rng.choice([0.002, 0.006])))
+    reads.sort(key=lambda r: r["pos"])
+    ploidy = int(rng.choice([0, 0, 0, 1, 2]))
+    kw = dict(call_mnvs=int(rng.integers(0, 2)), max_mnv_length=int(rng.choice([2, 3])), max_gap_between_mnv=int(rng.choice([0, 1])),
+              collapse=int(rng.integers(0, 2)), include_reference_calls=int(rng.integers(0, 2)), ploidy=ploidy,
+              min_frequency=0.2 if ploidy else float(rng.choice([0.01, 0.05])))
+    if ploidy:
+        kw.update(variant_freq_filter=0.2, low_gq_filter=30, max_genotype_qscore=1000)
+    cfg = _abi.default_config(**kw)
+    cuts = sorted(set(int(x) for x in rng.integers(1, len(reads), 3)) | {len(reads)})
+    ups = [int(x) for x in sorted(rng.integers(600, 3000, len(cuts) - 1))] + [None]
+
+    def run(environ, device_reads=False, peek=False):
+        with env(**environ):
+            with engine.HipVariantCaller(cfg) as c:
+                c.SetReference(ref)
+                rows, alleles, a0 = [], [], 0
+                for cut, up in zip(cuts, ups):
+                    batch = _abi.ReadBatch(reads[a0:cut])
+                    if device_reads:
+                        c.AddDeviceReads(engine.DeviceReadBatch.from_host(batch))
+                    else:
+                        c.AddAlleleCounts(batch)
+                    a0 = cut
+                    if peek:
+                        c.GetCandidates(None)
+                    if up is not None:
+                        up = min(up, reads[cut - 1]["pos"] - 1)
+                    r, a = c.CallWithAlleles(up, capacity=1 << 15)
+                    rows.append(r)
+                    alleles += a
+                return np.concatenate(rows), alleles, c.Stats()
+    want = run({})
+    assert len(want[0]) >= 1
+    schedule = [min(up, reads[cut - 1]["pos"] - 1) for cut, up in zip(cuts, ups) if up is not None]
+    exp, exp_alleles, exp_called = orc.run_reads_schedule(_abi.ReadBatch(reads), np.frombuffer(ref, np.uint8), 1, len(ref), cfg, schedule)
+    assert want[1] == exp_alleles and want[2]["TotalNumCalled"] == exp_called
+    assert_records_match(want[0], exp)
+    forms = {"rows merged by copy": dict(environ=dict(PISCES_HIP_MERGE_IN_PLACE=0)),
+             "checks on the device": dict(environ=dict(PISCES_HIP_DEVICE_CHECKS=1)),
+             "checks on the host": dict(environ=dict(PISCES_HIP_DEVICE_CHECKS=0)),
+             "candidates merged on the host": dict(environ=dict(PISCES_HIP_DEVICE_MERGE=0)),
+             "walk base by base": dict(environ=dict(PISCES_HIP_FINDER="bases")),
+             "genotypes by the host pass": dict(environ=dict(PISCES_HIP_DEVICE_GENOTYPER=0)),
+             "every batch its own segment": dict(environ=dict(PISCES_HIP_STORE_DIRECT_BYTES=0)),
+             "every batch appended": dict(environ=dict(PISCES_HIP_STORE_DIRECT_BYTES=1 << 40, PISCES_HIP_STORE_SEAL_BYTES=1 << 40)),
+             "reads in device memory": dict(environ={}, device_reads=True),
+             "candidates looked at after every add": dict(environ={}, peek=True)}
+    for name, how in forms.items():
+        got = run(**how)
+        assert got[0].tobytes() == want[0].tobytes() and got[1] == want[1] and got[2] == want[2], (seed, name, kw)
