@@ -306,10 +306,10 @@ __device__ __forceinline__ bool bam_keep(const uint8_t* __restrict__ rec, const 
 // what pisces_hip_add_reads's host pass takes from a read's CIGAR, for the kept reads of the decoded batch: log slots (one per reference
 // position the read spans: an upper bound of its observations), candidate-record slots (one per insertion / deletion), bytes of
 // insertions too long for a record
-struct BamCigarSums { long long ref_span; int read_span, indels, pool; };
+struct BamCigarSums { long long ref_span; int read_span, indels, pool; bool eqx; };
 __device__ __forceinline__ BamCigarSums bam_cigar_sums(const uint8_t* __restrict__ cig, int n_cigar)
 {
-    BamCigarSums t = {0, 0, 0, 0};
+    BamCigarSums t = {0, 0, 0, 0, false};
     for (int k = 0; k < n_cigar; k++) {
         const uint32_t v = (uint32_t)bam_le32(cig + 4 * k);
         const uint32_t op = v & 0xFu, len = v >> 4;
@@ -317,6 +317,7 @@ __device__ __forceinline__ BamCigarSums bam_cigar_sums(const uint8_t* __restrict
         if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) t.ref_span += (long long)len;   // M D N = X
         if (op == 1 || op == 2) t.indels++;
         if (op == 1 && len > (uint32_t)kFoundInline) t.pool += (int)len;
+        if (op == 7 || op == 8) t.eqx = true;
     }
     return t;
 }
@@ -360,7 +361,8 @@ __global__ __launch_bounds__(64) void bam_count_kernel(const uint8_t* __restrict
         if (bam_keep(rec, F)) {
             const int n_cigar = (int)bam_le16(rec + 12);
             int xd_len = 0;
-            if (!status[2] && bam_find_string_tag(bam_aux_of(rec), rec + bam_le32(rec - 4), 'X', 'D', &xd_len)) status[2] = 1;   // stitched reads: the batch gets per-base directions
+            // status[2]: bit 0 stitched reads (the batch gets per-base directions), bit 1 reads with X or = operations
+            if (!(status[2] & 1) && bam_find_string_tag(bam_aux_of(rec), rec + bam_le32(rec - 4), 'X', 'D', &xd_len)) atomicOr(&status[2], 1);
             reads++;
             ops += n_cigar;
             bases += bam_le32(rec + 16);
@@ -368,6 +370,7 @@ __global__ __launch_bounds__(64) void bam_count_kernel(const uint8_t* __restrict
             span += t.ref_span;
             indels += t.indels;
             pool += t.pool;
+            if (t.eqx && !(status[2] & 2)) atomicOr(&status[2], 2);
         } else if (bam_le32(rec) == F.ref_id) {
             skipped++;
         }

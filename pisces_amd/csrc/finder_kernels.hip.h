@@ -255,7 +255,7 @@ __device__ __forceinline__ void walk_read_events(const ReadView& r, const uint8_
             if ((int64_t)in_ref + len < ref_len && in_ref >= 1 && flanks_ok)
                 walk::finish_candidate(r, f, P, PISCES_CAT_DELETION, in_ref, in_ref - 1, in_read, len, 1, ci, false, false, emit);
         } else if ((t == 'X' || t == '=') && P.mark_x_spans && len > 0) {
-            walk::mark_unwalked_span(r, t, len, in_read, in_ref, ref, ref_len, emit);
+            walk::mark_unwalked_span(r, t, len, in_read, in_ref, ref, ref_len, P, emit);
         }
         if (walk::spans_read(t)) in_read += len;
         if (walk::spans_ref(t)) in_ref += len;
@@ -537,7 +537,7 @@ __device__ __forceinline__ void walk_read_wave(const ReadView& r, const uint8_t*
             if ((int64_t)in_ref + len < ref_len && in_ref >= 1 && flanks_ok)
                 walk::finish_candidate(r, f, P, PISCES_CAT_DELETION, in_ref, in_ref - 1, in_read, len, 1, ci, false, false, emit);
         } else if ((t == 'X' || t == '=') && P.mark_x_spans && len > 0) {
-            walk::mark_unwalked_span(r, t, len, in_read, in_ref, ref, ref_len, emit);
+            walk::mark_unwalked_span(r, t, len, in_read, in_ref, ref, ref_len, P, emit);
         }
         if (walk::spans_read(t)) in_read += len;
         if (walk::spans_ref(t)) in_ref += len;

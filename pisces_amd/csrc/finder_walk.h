@@ -36,13 +36,18 @@ struct FinderParams {
     int32_t min_bq, anchor_size;
     int32_t snvs_and_mnvs;   // walk the M operations (MNV calling on); off: insertions and deletions only
     int32_t call_mnvs, max_mnv_length, max_gap;
-    int32_t mark_x_spans;    // the streaming surface's split form of MNV calling: every X operation leaves a span mark (below)
+    int32_t mark_x_spans;    // what the X and = operations leave (below): 0 nothing, 1 a span mark an operation (the streaming surface's split form
+                             // of MNV calling), 2 a record for every base a walk of the operation would have made an SNV of (MNV calling off)
 };
 
 // Not a candidate: the positions of an X operation, or of the differing bases of an = operation (position, length).  ProcessCigarOps
 // (:44-71) walks M operations only, so such bases are allele counts without SNV candidates; the flush takes the loci of such a span from
 // the read walk's candidates instead of from the counts (surface_flush.inc.h, the dirty loci).
 constexpr uint8_t kFoundSpanMark = 0x40;
+// Not a candidate either: ONE base of an X or = operation that an M operation would have made an SNV candidate of (position, the read base,
+// its direction).  MNV calling off: SNVs are called from the allele counts, which hold such bases (AddAlleleCounts walks every operation
+// that spans read and reference) though no candidate stands for them; the flush takes them off the allele's support again.
+constexpr uint8_t kFoundUnwalked = 0x41;
 
 namespace walk {
 
@@ -210,10 +215,30 @@ PISCES_HD inline void walk_match_op(const ReadView& r, const ReadFrame& f, const
 
 // ProcessCigarOps walks M operations only (:44-71): the bases of an X operation — and those of an = operation that differ from the
 // reference after all (a CIGAR is not checked against the reference) — are allele counts that no SNV candidate stands for.  With
-// mark_x_spans the walk leaves a span mark over them (all of an X operation; from the first to the last differing base of an = operation).
+// mark_x_spans = 1 the walk leaves a span mark over them (all of an X operation; from the first to the last differing base of an = operation),
+// with mark_x_spans = 2 a kFoundUnwalked record for each of them that an M operation would have made an SNV candidate of.
 template <typename Emit>
-PISCES_HD inline void mark_unwalked_span(const ReadView& r, uint8_t t, int len, int in_read, int in_ref, const uint8_t* ref, int64_t ref_len, Emit& emit)
+PISCES_HD inline void mark_unwalked_span(const ReadView& r, uint8_t t, int len, int in_read, int in_ref, const uint8_t* ref, int64_t ref_len,
+                                         const FinderParams& P, Emit& emit)
 {
+    FoundCandidate c;
+    c.dir = 0;
+    c.well_anchored = c.open_left = c.open_right = 0;
+    c.pad[0] = c.pad[1] = c.pad[2] = 0;
+    if (P.mark_x_spans == 2) {   // the callable mismatches of the operation, one by one (walk_match_op's `callable && !matches`)
+        for (int i = 0; i < len && in_read + i < r.read_len && (int64_t)in_ref + i < ref_len; i++) {
+            const uint8_t rb = r.bases[in_read + i], fb = ref[in_ref + i];
+            if (rb == fb || !is_acgt(rb) || !is_acgt(fb) || r.quals[in_read + i] < P.min_bq) continue;
+            c.position = in_ref + i + 1;
+            c.ref_index = in_ref + i;
+            c.start_in_read = in_read + i;
+            c.length = 1;
+            c.category = kFoundUnwalked;
+            c.dir = (uint8_t)dir_of_base(r, in_read + i);
+            emit(c);
+        }
+        return;
+    }
     int lo = 0, hi = len - 1;
     if (t == '=') {
         lo = -1;
@@ -221,15 +246,11 @@ PISCES_HD inline void mark_unwalked_span(const ReadView& r, uint8_t t, int len, 
             if (r.bases[in_read + i] != ref[in_ref + i]) { if (lo < 0) lo = i; hi = i; }
         if (lo < 0) return;
     }
-    FoundCandidate c;
     c.position = in_ref + lo + 1;
     c.ref_index = in_ref + lo;
     c.start_in_read = in_read + lo;
     c.length = hi - lo + 1;
     c.category = kFoundSpanMark;
-    c.dir = 0;
-    c.well_anchored = c.open_left = c.open_right = 0;
-    c.pad[0] = c.pad[1] = c.pad[2] = 0;
     emit(c);
 }
 
@@ -258,7 +279,7 @@ PISCES_HD inline void walk_read(const ReadView& r, const uint8_t* ref, int64_t r
             if ((int64_t)in_ref + len < ref_len && in_ref >= 1 && flanks_ok)
                 finish_candidate(r, f, P, PISCES_CAT_DELETION, in_ref, in_ref - 1, in_read, len, 1, ci, false, false, emit);
         }
-        else if ((t == 'X' || t == '=') && P.mark_x_spans && len > 0) mark_unwalked_span(r, t, len, in_read, in_ref, ref, ref_len, emit);
+        else if ((t == 'X' || t == '=') && P.mark_x_spans && len > 0) mark_unwalked_span(r, t, len, in_read, in_ref, ref, ref_len, P, emit);
         if (spans_read(t)) in_read += len;
         if (spans_ref(t)) in_ref += len;
     }

@@ -54,6 +54,10 @@ struct BlockObs {   // the block's observations live in the device log (PiscesHi
     std::vector<uint32_t> cand_next;
     int32_t max_allele_endpoint = 0;   // RegionState.MaxAlleleEndpoint
     std::vector<std::pair<int32_t, int32_t>> x_spans;   // positions of the X operations of the block's reads (MNV calling on, split form): dirty loci
+    // MNV calling off: the bases of X and = operations that the allele counts hold and no SNV candidate stands for (finder_walk.h
+    // kFoundUnwalked), by (position, read base): the flush calls the SNVs of their loci from the counts LESS these (surface_flush.inc.h)
+    struct Unwalked { int32_t position; uint8_t alt; int32_t sup[3]; };
+    std::vector<Unwalked> unwalked;
 };
 
 
@@ -436,7 +440,9 @@ struct PiscesHip {
         DevReadBatch db;
         const uint8_t* d_deldirs = nullptr;
         int32_t nr = 0;
+        FinderParams fp = {};                // the walk's parameters (both halves)
     } found;
+    bool eqx_in_batch = false;               // the batch being added has X or = operations (set by its checks, read by enqueue_candidate_discovery)
 
     // MNV calling on, SPLIT FORM (surface_flush.inc.h): the fully anchored SNV groups of the read walk stay in device memory (the SNV store,
     // finder_kernels.hip.h) until their block is flushed; the tile kernels call SNVs from the allele counts everywhere but on the dirty loci
@@ -478,6 +484,7 @@ struct PiscesHip {
         DeviceBuf<int32_t> position, cigar_offset, seq_offset;
         DeviceBuf<uint8_t> flags, cigar_op, bases, quals, op_quality, read_quality, dirs, del_dirs;
         DeviceBuf<long long> d_totals64;
+        bool has_eqx = false;     // some read of the batch has an X or = operation
         bool has_dirs = false;    // some read of the batch carries an XD tag (a stitched read): `dirs` / `del_dirs` are made
         DeviceBuf<uint32_t> cigar_len;
         DeviceBuf<long long> d_slots;      // log slots of the reads (pisces_hip_add_decoded_reads)

@@ -294,6 +294,7 @@ __global__ __launch_bounds__(256) void read_prepare_kernel(PrepareArgs A)
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     int k_lo = 0x7FFFFFFF, k_hi = 0, p_lo = 0x7FFFFFFF;
     int64_t run_a = 1, run_b = 0;   // the run of keys this read touches (empty)
+    bool eqx = false;               // an X or = operation (MNV calling off: candidate discovery then walks them, surface_reads.inc.h)
     if (r < A.n_reads) {
         int code = 0;
         p_lo = A.position[r];
@@ -340,6 +341,7 @@ __global__ __launch_bounds__(256) void read_prepare_kernel(PrepareArgs A)
                 if (A.count_indels) {
                     if (t == 'I' || t == 'D') found++;
                     if (t == 'I' && len > 32u) pool += (int)len;   // (kFoundInline)
+                    if (t == 'X' || t == '=') eqx = true;
                 }
             }
             if (!code && nc > 0 && read_span != n) code = kPrepCigarMismatch;               // Read.ValidateCigar (Read.cs:603-605)
@@ -388,6 +390,7 @@ __global__ __launch_bounds__(256) void read_prepare_kernel(PrepareArgs A)
         p_lo = min(p_lo, __shfl_xor(p_lo, d, 64));
     }
     if ((threadIdx.x & 63) == 0 && p_lo < __hip_atomic_load(&A.key_span[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&A.key_span[2], p_lo);
+    if (__ballot(eqx) != 0ull && (threadIdx.x & 63) == 0 && !__hip_atomic_load(&A.key_span[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&A.key_span[3], 1);
     if ((threadIdx.x & 63) == 0 && k_hi > 0) {
         if (k_lo < __hip_atomic_load(&A.key_span[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&A.key_span[0], k_lo);
         if (k_hi > __hip_atomic_load(&A.key_span[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&A.key_span[1], k_hi);
@@ -409,8 +412,10 @@ struct PrepVerdict {
     long long totals[2];
     int32_t span[3];
     int32_t n_keys;      // touched blocks (all of them, also beyond capacity)
+    int32_t has_eqx;     // some read has an X or = operation
+    int32_t pad;
 };
-static_assert(sizeof(PrepVerdict) == 40, "PrepVerdict layout");
+static_assert(sizeof(PrepVerdict) == 48, "PrepVerdict layout");
 __global__ __launch_bounds__(256) void prepare_collect_kernel(uint32_t* __restrict__ block_bits, const int32_t* __restrict__ key_span,
                                                               const unsigned long long* __restrict__ first_error, const long long* __restrict__ totals /* or nullptr */,
                                                               PrepVerdict* __restrict__ out, int32_t* __restrict__ keys_out, int32_t capacity)
@@ -441,6 +446,8 @@ __global__ __launch_bounds__(256) void prepare_collect_kernel(uint32_t* __restri
         out->totals[1] = totals ? totals[1] : 0;
         out->span[0] = key_span[0]; out->span[1] = key_span[1]; out->span[2] = key_span[2];
         out->n_keys = n;
+        out->has_eqx = key_span[3];
+        out->pad = 0;
     }
 }
 

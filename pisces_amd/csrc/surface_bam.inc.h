@@ -240,7 +240,8 @@ int32_t pisces_hip_bam_decode(PiscesHip* h, const uint8_t* file, int64_t n_bytes
         if (totals64[k] > 0x7FFFFFF0ll || span_total < 0)
             return fail(h, PISCES_E_INVALID_ARG, "bam_decode: more than 2^31 reads, CIGAR operations, bases or candidate slots in one call: decode the file in regions");
     B.chain_mode = bstatus[3] != 0 ? 1 : 0;
-    B.has_dirs = bstatus[2] != 0;
+    B.has_dirs = (bstatus[2] & 1) != 0;
+    B.has_eqx = (bstatus[2] & 2) != 0;
     B.n_reads = totals[0]; B.n_ops = totals[1]; B.n_bases = totals[2];
     B.found_slots = totals[3]; B.found_pool = totals[4]; B.log_slots = span_total;
     B.n_skipped = 0;
@@ -373,6 +374,7 @@ int32_t pisces_hip_add_decoded_reads(PiscesHip* h)
     const bool find_on_device = !h->h_ref.empty();
     const int64_t found_slots = (find_on_device && !h->cfg.call_mnvs) ? B.found_slots : 0, found_pool = (find_on_device && !h->cfg.call_mnvs) ? B.found_pool : 0;
     if (found_slots > 0x7FFFFFF0ll || found_pool > 0x7FFFFFF0ll) return fail(h, PISCES_E_INVALID_ARG, "add_decoded_reads: too many insertions / deletions in one batch");
+    h->eqx_in_batch = find_on_device && !h->cfg.call_mnvs && B.has_eqx;
     // commit: the blocks the reads touch (GetBlock, RegionStateManager.cs:361-383) and the totals — only once the batch is in the store / the log
     // (a failed add leaves neither empty blocks nor readsProcessed / readsSkipped that pisces_hip_reduce_summary would add up)
     auto commit = [&]() {
@@ -398,7 +400,7 @@ int32_t pisces_hip_add_decoded_reads(PiscesHip* h)
     hipLaunchKernelGGL(expand_reads_kernel, dim3(expand_reads_grid(nr)), dim3(256), 0, h->stream, db, (const long long*)B.d_slots.p,
                        (long long)h->log_ub, h->cfg.min_base_call_quality, h->d_log_pos[c].p, h->d_log_tup[c].p, h->d_log_n.p + 2, expand_reads_per_wave(nr));
     PISCES_HIP_CHECK(h, hipGetLastError());
-    if (find_on_device && (h->cfg.call_mnvs || found_slots > 0)) {
+    if (find_on_device && (h->cfg.call_mnvs || found_slots > 0 || h->eqx_in_batch)) {
         int32_t rcd = enqueue_candidate_discovery(h, db, B.has_dirs ? B.del_dirs.p : nullptr, nr, (const int32_t*)B.d_fslots.p, found_slots, found_pool);
         if (rcd) return rcd;
     }

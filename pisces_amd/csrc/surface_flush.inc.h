@@ -810,14 +810,22 @@ static int32_t split_prepare(PiscesHip* h, const std::vector<int32_t>& keys, int
 {
     split_restore(h);
     h->split_selected.clear();
-    if (!h->mnv_split) return PISCES_OK;
+    // MNV calling off: the loci with bases of X / = operations that the allele counts hold and no SNV candidate stands for are dirty too
+    // (their SNVs are called by call_spanning, from the counts less those bases)
+    const bool unwalked_mode = !h->mnv_split && !h->cfg.call_mnvs;
+    if (!h->mnv_split && !unwalked_mode) return PISCES_OK;
+    if (unwalked_mode) {
+        bool some = false;
+        for (int32_t key : keys) some = some || !h->blocks[key].unwalked.empty();
+        if (!some) return PISCES_OK;
+    } else
     h->P.refs_only = 0;
     if (keys.empty()) return PISCES_OK;
     const int bs = h->cfg.block_size;
     const int64_t lo = (int64_t)(keys.front() - 1) * bs + 1, hi = (int64_t)keys.back() * bs;
     int64_t hi_bm = hi;
     bool add_collapsable = false;
-    if (up_to_position >= 0 && h->cfg.collapse) {   // (the condition of call_spanning's AddCollapsableFromOtherBlocks step)
+    if (up_to_position >= 0 && h->cfg.collapse && !unwalked_mode) {   // (the condition of call_spanning's AddCollapsableFromOtherBlocks step)
         int32_t max_endpoint = 0;
         for (int32_t key : keys) max_endpoint = std::max(max_endpoint, h->blocks[key].max_allele_endpoint);
         if ((int64_t)max_endpoint > hi) { add_collapsable = true; hi_bm = std::max<int64_t>(hi, up_to_position); }
@@ -860,7 +868,10 @@ static int32_t split_prepare(PiscesHip* h, const std::vector<int32_t>& keys, int
         mark(c.position, end);
         if (of_the_batch) carry(c.position, end);
     };
-    if (!h->forced.empty()) {
+    if (unwalked_mode) {
+        for (int32_t key : keys)
+            for (auto& u : h->blocks[key].unwalked) mark(u.position, u.position);
+    } else if (!h->forced.empty()) {
         mark(lo, hi);   // forced alleles: every candidate of the batch is an object on the host, as before
     } else {
         for (int32_t key : keys) {
@@ -1038,7 +1049,30 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
             }
         }
     }
-    if (work.empty()) return PISCES_OK;
+    // MNV calling off: the bases of X / = operations on the batch's loci that the allele counts hold and no SNV candidate stands for
+    // (ProcessCigarOps walks M operations only, CandidateVariantFinder.cs:44-71), by (position, read base).  The tile kernels leave the
+    // variants of those loci alone (split_prepare made them dirty); their SNV candidates are made here, after the collapser, with the
+    // support the read walk's candidates have: the allele counts less these bases.
+    std::vector<BlockObs::Unwalked> unw;
+    if (!mnv_mode) {
+        for (int32_t key : keys) {
+            const auto& u = h->blocks[key].unwalked;
+            unw.insert(unw.end(), u.begin(), u.end());
+        }
+        std::sort(unw.begin(), unw.end(), [](const BlockObs::Unwalked& a, const BlockObs::Unwalked& b) { return a.position != b.position ? a.position < b.position : a.alt < b.alt; });
+        size_t w = 0;
+        for (size_t i = 0; i < unw.size(); i++) {
+            if (w > 0 && unw[w - 1].position == unw[i].position && unw[w - 1].alt == unw[i].alt) { for (int d = 0; d < 3; d++) unw[w - 1].sup[d] += unw[i].sup[d]; continue; }
+            unw[w++] = unw[i];
+        }
+        unw.resize(w);
+    }
+    auto unwalked_of = [&](int32_t position, char alt, int d) -> int32_t {
+        auto it = std::lower_bound(unw.begin(), unw.end(), std::make_pair(position, (uint8_t)alt), [](const BlockObs::Unwalked& u, const std::pair<int32_t, uint8_t>& k) {
+            return u.position != k.first ? u.position < k.first : u.alt < k.second; });
+        return (it != unw.end() && it->position == position && it->alt == (uint8_t)alt) ? it->sup[d] : 0;
+    };
+    if (work.empty() && unw.empty()) return PISCES_OK;
     // start / end points (CoverageCalculator.Compute :27-41)
     auto endpoints = [](const HostCandidate& c, int32_t& sp, int32_t& ep) {
         if (c.category == PISCES_CAT_DELETION) { sp = c.position + 1; ep = c.position + (int32_t)c.ref.size() - 1; }
@@ -1071,6 +1105,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
     if (have_forced)
         for (int32_t p : h->forced_positions)
             if (std::binary_search(keys.begin(), keys.end(), block_key(h, p))) need(p, true);
+    for (auto& u : unw) need(u.position, true);
     phase(2);
     std::vector<PiscesTile> tiles;
     std::vector<int32_t> bkeys, tile_starts;
@@ -1178,6 +1213,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
                 for (int32_t p = sp; p <= ep; p++) want(p, true);
             else if (any_open || (have_forced && c.category == PISCES_CAT_SNV)) { want(sp, may_fold); want(ep, may_fold); }
         }
+        for (auto& u : unw) want(u.position, true);
         std::sort(need.begin(), need.end());
         need.erase(std::unique(need.begin(), need.end()), need.end());
         const size_t n_rows = need.size(), n_counts = std::max<size_t>(n_rows, 1) * PISCES_COUNTS_PER_LOCUS;
@@ -1214,6 +1250,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
             for (int d = 0; d < 3; d++) {
                 const int32_t* row = host_counts.data() + li * PISCES_COUNTS_PER_LOCUS + (at * 3 + d) * PISCES_NUM_ANCHORS;
                 for (int an = 0; an < PISCES_NUM_ANCHORS; an++) c.support_by_dir[d] += row[an];
+                c.support_by_dir[d] = std::max(0, c.support_by_dir[d] - unwalked_of(c.position, c.alt[0], d));   // (less what no candidate stands for)
             }
         }
     }
@@ -1245,8 +1282,49 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
                 w++;
             }
             work.resize(w);
-            if (work.empty()) return PISCES_OK;
+            if (work.empty() && unw.empty()) return PISCES_OK;
         }
+    }
+    if (!unw.empty()) {
+        // the SNV candidates of the loci with unwalked bases: what the reads show there (the counts) less those bases
+        static const char kAcgt[4] = {'A', 'C', 'G', 'T'};
+        const size_t n_before = work.size();
+        for (size_t i = 0; i < unw.size();) {
+            const int32_t p = unw[i].position;
+            while (i < unw.size() && unw[i].position == p) i++;
+            if (p < 1 || (int64_t)p > h->ref_len) continue;
+            const char rb = (char)h->h_ref[(size_t)p - 1];
+            const int64_t li = row_index(locus_index(p));
+            if (atype(rb) >= 4 || li < 0) continue;
+            for (char ab : kAcgt) {
+                if (ab == rb) continue;
+                bool there = false;   // (a forced SNV: it has taken its support above)
+                for (size_t k = 0; k < n_before && !there; k++)
+                    there = work[k].position == p && work[k].category == PISCES_CAT_SNV && work[k].alt.size() == 1 && work[k].alt[0] == ab;
+                if (there) continue;
+                HostCandidate c;
+                c.position = p;
+                c.category = PISCES_CAT_SNV;
+                c.ref.assign(1, rb);
+                c.alt.assign(1, ab);
+                int32_t total = 0;
+                for (int d = 0; d < 3; d++) {
+                    const int32_t* row = host_counts.data() + li * PISCES_COUNTS_PER_LOCUS + (atype(ab) * 3 + d) * PISCES_NUM_ANCHORS;
+                    int32_t n = 0;
+                    for (int an = 0; an < PISCES_NUM_ANCHORS; an++) n += row[an];
+                    n = std::max(0, n - unwalked_of(p, ab, d));
+                    c.support_by_dir[d] = c.well_anchored_by_dir[d] = n;
+                    total += n;
+                }
+                if (total <= 0) continue;   // no read walk made a candidate of this allele
+                c.stamp = next_host_stamp(h);
+                c.from_reads = true;
+                work.push_back(std::move(c));
+            }
+        }
+        if (work.size() != n_before)
+            std::stable_sort(work.begin(), work.end(), [](const HostCandidate& x, const HostCandidate& y) { return x.position < y.position; });
+        if (work.empty()) return PISCES_OK;
     }
     // one device pass over a list of candidates: records + IsCallable
     std::vector<PiscesCalledAllele> raw;
@@ -1455,7 +1533,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         const bool forced = have_forced && is_forced_allele(h, *final_list[i]);
         const bool reportable = callable[i] && inside_intervals(final_list[i]->position);
         if (callable[i] && owned(final_list[i]->position)) (*n_called) += forced ? 2 : 1;
-        if (forced && !mnv_mode && final_list[i]->category == PISCES_CAT_SNV && reportable) {   // MNV calling off: the tile kernels report it,
+        if (forced && !mnv_mode && final_list[i]->category == PISCES_CAT_SNV && reportable && !split_dirty_at(h, final_list[i]->position)) {   // MNV calling off: the tile kernels report it,
             (*n_called)--;                                                                        // and have counted it once
             continue;
         }
@@ -1533,7 +1611,7 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
             bool want_folded = h->mnv_split || !h->forced.empty();
             if (!want_folded)
                 for (auto& kv : h->blocks)
-                    if (!kv.second.cands.empty()) { want_folded = true; break; }
+                    if (!kv.second.cands.empty() || !kv.second.unwalked.empty()) { want_folded = true; break; }
             rc = call_blocks_enqueue(h, keys, true, -1, &blocks_st, want_folded);
             if (rc) return rc;
         }
@@ -2061,7 +2139,7 @@ int32_t pisces_hip_flush_begin(PiscesHip* h, int32_t up_to_position)
             if (!(final_flush || (int64_t)kv.first * h->cfg.block_size <= up_to_position)) continue;
             if (!final_flush && kv.second.max_allele_endpoint > up_to_position) break;
             keys.push_back(kv.first);
-            if (!kv.second.cands.empty() || !kv.second.x_spans.empty()) plain = false;
+            if (!kv.second.cands.empty() || !kv.second.x_spans.empty() || !kv.second.unwalked.empty()) plain = false;
         }
     // MNV calling on, split form: a batch without dirty loci is the tile kernels' alone (SNVs from the allele counts); off-interval loci are
     // dirty, and a store that has grown large is swept by a synchronous flush (the groups of flushed blocks leave it there)

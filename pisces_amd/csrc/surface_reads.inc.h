@@ -390,10 +390,17 @@ static FinderParams finder_params(const PiscesHip* h)
                              h->cfg.max_gap_between_mnv, h->mnv_split ? 1 : 0};
     return FP;
 }
+// h->eqx_in_batch: some read of the batch has an X or = operation.  With MNV calling off those bases are allele counts that no SNV candidate
+// stands for (ProcessCigarOps walks M operations only): the walk then leaves a record for each of them that an M operation would have
+// made a candidate of (finder_walk.h kFoundUnwalked), counted on the device like the walk of MNV calling on — the slots the caller
+// reserved from the CIGARs hold insertions and deletions only.
 static int32_t enqueue_candidate_discovery(PiscesHip* h, const DevReadBatch& db, const uint8_t* d_deldirs, int32_t nr, const int32_t* d_slots_in,
                                            int64_t found_slots, int64_t found_pool)
 {
-    const FinderParams FP = finder_params(h);
+    FinderParams FP = finder_params(h);
+    const bool unwalked = !h->cfg.call_mnvs && h->eqx_in_batch;
+    if (unwalked) FP.mark_x_spans = 2;
+    h->found.fp = FP;
     // (arrival stamps: this batch's records come behind everything the host added so far)
     h->batch_seq++;
     h->host_seq = 0;
@@ -404,7 +411,7 @@ static int32_t enqueue_candidate_discovery(PiscesHip* h, const DevReadBatch& db,
     h->found.counted_only = false;
     PISCES_HIP_CHECK(h, h->d_found_misc.reserve(4));
     PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_found_misc.p, 0, 4 * sizeof(unsigned int), h->stream));
-    if (!h->cfg.call_mnvs) return enqueue_found_records(h, db, d_deldirs, nr, FP, d_slots_in, nullptr, found_slots, found_pool);
+    if (!h->cfg.call_mnvs && !unwalked) return enqueue_found_records(h, db, d_deldirs, nr, FP, d_slots_in, nullptr, found_slots, found_pool);
     // count, scan (one more element than reads: the last one receives the total); the totals size the record buffers: they travel to pinned
     // memory behind an event, and the second half (finish_candidate_discovery) is enqueued by whichever entry comes next — the batch's
     // arrays stay where they are until then (a segment's blob; or the staging pair, which only the next add reuses, behind that half)
@@ -429,7 +436,7 @@ static int32_t enqueue_candidate_discovery(PiscesHip* h, const DevReadBatch& db,
     h->found.pool_bytes = 0;
     return PISCES_OK;
 }
-// the second half of a batch's candidate discovery (MNV calling on), if it is still to come
+// the second half of a batch's candidate discovery (MNV calling on; or off, over reads with X / = operations), if it is still to come
 static int32_t finish_candidate_discovery(PiscesHip* h)
 {
     if (!h->found.counted_only) return PISCES_OK;
@@ -438,7 +445,7 @@ static int32_t finish_candidate_discovery(PiscesHip* h)
     PISCES_TIMED_WAIT(h, hipEventSynchronize(h->found.counted));
     const long long found_slots = h->found.h_totals[0], found_pool = h->found.h_totals[1];
     if (found_slots > 0x7FFFFFF0ll || found_pool > 0x7FFFFFF0ll) return fail(h, PISCES_E_INVALID_ARG, "add_reads: too many candidates in one batch");
-    return enqueue_found_records(h, h->found.db, h->found.d_deldirs, h->found.nr, finder_params(h), h->d_found_slots.p, h->d_found_pool_first.p, found_slots, found_pool);
+    return enqueue_found_records(h, h->found.db, h->found.d_deldirs, h->found.nr, h->found.fp, h->d_found_slots.p, h->d_found_pool_first.p, found_slots, found_pool);
 }
 static int32_t enqueue_found_records(PiscesHip* h, const DevReadBatch& db, const uint8_t* d_deldirs, int32_t nr, const FinderParams& FP, const int32_t* d_slots,
                                      const int32_t* d_pool_first, int64_t found_slots, int64_t found_pool)
@@ -549,6 +556,10 @@ static int32_t consume_found(PiscesHip* h)
                     get_block(h, (k - 1) * h->cfg.block_size + 1)->x_spans.emplace_back(m.f.c.position, m.f.c.position + m.f.c.length - 1);
                 continue;
             }
+            if (m.f.c.category == kFoundUnwalked) {   // bases of X / = operations: no candidate, support the allele counts hold and the walk does not
+                get_block(h, m.f.c.position)->unwalked.push_back({m.f.c.position, m.f.alt[0], {m.sup[0], m.sup[1], m.sup[2]}});
+                continue;
+            }
             HostCandidate c = host_candidate_of(m.f.c, h->h_ref.data(), m.f.pool_offset >= 0 ? pool + m.f.pool_offset : m.f.alt);
             for (int d = 0; d < 3; d++) { c.support_by_dir[d] = m.sup[d]; c.well_anchored_by_dir[d] = m.anch[d]; }
             c.stamp = ((uint64_t)h->found.batch << 32) | (uint64_t)(uint32_t)i;
@@ -560,6 +571,12 @@ static int32_t consume_found(PiscesHip* h)
     for (int64_t i = 0; i < h->found.n_slots; i++) {
         const DevFound& f = recs[i];
         if (f.c.category == kFoundHole) continue;
+        if (f.c.category == kFoundUnwalked) {
+            BlockObs::Unwalked u = {f.c.position, f.alt[0], {0, 0, 0}};
+            if (f.c.dir < 3) u.sup[f.c.dir] = 1;
+            get_block(h, f.c.position)->unwalked.push_back(u);
+            continue;
+        }
         const uint8_t* bases = f.pool_offset >= 0 ? pool + f.pool_offset : f.alt;
         HostCandidate c = host_candidate_of(f.c, h->h_ref.data(), bases);
         c.stamp = ((uint64_t)h->found.batch << 32) | (uint64_t)(uint32_t)i;
@@ -758,6 +775,7 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
     std::vector<int32_t>& fslots = h->found_slots_host;
     fslots.assign((size_t)nr + 1, 0);
     int64_t found_slots = 0, found_pool = 0;
+    h->eqx_in_batch = false;
     for (int32_t i = 0; i < nr; i++) {
         ReadView r = read_view(batch, i);
         fslots[(size_t)i] = (int32_t)found_slots;
@@ -765,6 +783,7 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
             for (int c = 0; c < r.n_cigar; c++) {
                 if (r.cigar_op[c] == 'I' || r.cigar_op[c] == 'D') found_slots++;
                 if (r.cigar_op[c] == 'I' && r.cigar_len[c] > (uint32_t)kFoundInline) found_pool += r.cigar_len[c];
+                if (r.cigar_op[c] == 'X' || r.cigar_op[c] == '=') h->eqx_in_batch = true;
             }
         if (found_slots > 0x7FFFFFF0ll || found_pool > 0x7FFFFFF0ll) {
             (void)stage_release(h);   // (the batch's transfer is in flight out of the staging pair)
@@ -828,7 +847,7 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
     hipLaunchKernelGGL(expand_reads_kernel, dim3(expand_reads_grid(nr)), dim3(256), 0, h->stream, db, (const long long*)(d + off_slots), 0ll,
                        minBQ, h->d_log_pos[c].p, h->d_log_tup[c].p, h->d_log_n.p + 2, expand_reads_per_wave(nr));
     { hipError_t el = hipGetLastError(); if (el != hipSuccess) { (void)stage_release(h); return fail(h, PISCES_E_DEVICE, std::string("add_reads: ") + hipGetErrorString(el)); } }
-    if (find_on_device && (h->cfg.call_mnvs || found_slots > 0)) {
+    if (find_on_device && (h->cfg.call_mnvs || found_slots > 0 || h->eqx_in_batch)) {
         int32_t rcd = enqueue_candidate_discovery(h, db, batch->deletion_directions ? d + off_deldirs : nullptr, nr, (const int32_t*)(d + off_fslots),
                                                   found_slots, found_pool);
         if (rcd) { (void)stage_release(h); return rcd; }   // (transfers out of the staging pair are in flight)

@@ -326,7 +326,7 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
         PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_prep_map.p, 0, map_words * sizeof(uint32_t), h->stream));
         h->prep_map_clean = true;
     }
-    const int32_t span_init[3] = {0x7FFFFFFF, 0, 0x7FFFFFFF};
+    const int32_t span_init[4] = {0x7FFFFFFF, 0, 0x7FFFFFFF, 0};   // ([3]: some read has an X or = operation)
     { int32_t rcu = meta_upload(h, d_span, span_init, sizeof(span_init)); if (rcu) return rcu; }
     PISCES_HIP_CHECK(h, hipMemsetAsync(B.d_first_error.p, 0xFF, sizeof(unsigned long long), h->stream));
     PrepareArgs A;
@@ -367,6 +367,7 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
     h->h_meta_used = 0;
     const unsigned long long first_error = verdict->first_error;
     const int32_t span[3] = {verdict->span[0], verdict->span[1], verdict->span[2]};
+    h->eqx_in_batch = count_indels && verdict->has_eqx != 0;
     const long long totals[2] = {verdict->totals[0], verdict->totals[1]};
     if (verdict->n_keys <= kPrepKeys) {
         touched.assign(keys, keys + verdict->n_keys);
@@ -425,7 +426,7 @@ static int32_t store_finish_add(PiscesHip* h, StorePlace& pl, int32_t rc, uint8_
         rc = store_append_arrays(h, pl, A, nr, n_cig, n_seq);
     }
     // ICandidateVariantFinder.FindCandidates + IStateManager.AddCandidates (SmallVariantCaller.cs:92-96) on the device, on the batch as it lies there
-    if (rc == PISCES_OK && find_on_device && (h->cfg.call_mnvs || found_slots > 0)) {
+    if (rc == PISCES_OK && find_on_device && (h->cfg.call_mnvs || found_slots > 0 || h->eqx_in_batch)) {
         if (fslots_host) {
             std::memcpy(h->h_stage + L.off_fslots, fslots_host, ((size_t)nr + 1) * 4);
             hipError_t e = hipMemcpyAsync(d + L.off_fslots, h->h_stage + L.off_fslots, L.total - L.off_fslots, hipMemcpyHostToDevice, h->stream);
@@ -486,6 +487,7 @@ static int32_t add_reads_store(PiscesHip* h, const PiscesReadBatch* batch)
     rc = store_upload_batch(h, batch, L, nr, n_cig, n_seq, staged, d);
     const bool find_on_device = !h->h_ref.empty();   // without a reference only the IStateManager half (allele counts) runs
     const bool count_indels = find_on_device && !h->cfg.call_mnvs;
+    h->eqx_in_batch = false;
     std::vector<int32_t>& fslots = h->found_slots_host;
     std::vector<int32_t>& touched = h->touched_keys;
     touched.clear();
@@ -557,6 +559,7 @@ static int32_t add_reads_store(PiscesHip* h, const PiscesReadBatch* batch)
             if (count_indels) {
                 if (t == 'I' || t == 'D') found_slots++;
                 if (t == 'I' && len > (int64_t)kFoundInline) found_pool += len;
+                if (t == 'X' || t == '=') h->eqx_in_batch = true;
             }
             if (op_read(t) && op_ref(t) && len > 0) {
                 if (rp > last_mapped + 1 && ri < r.read_len && delq(ri)) touch(last_mapped + 1, rp - 1);
@@ -634,6 +637,7 @@ int32_t pisces_hip_add_device_reads(PiscesHip* h, const PiscesReadBatch* batch, 
     if (e != hipSuccess) rc = fail(h, PISCES_E_DEVICE, std::string("add_device_reads: ") + hipGetErrorString(e));
     const bool find_on_device = !h->h_ref.empty();
     const bool count_indels = find_on_device && !h->cfg.call_mnvs;
+    h->eqx_in_batch = false;
     std::vector<int32_t>& touched = h->touched_keys;
     touched.clear();
     int64_t found_slots = 0, found_pool = 0;
@@ -670,7 +674,7 @@ static int32_t add_decoded_reads_store(PiscesHip* h, int64_t found_slots, int64_
                                 B.seq_offset.p, (pl.direct ? g.bases.p : B.bases.p) + kSegmentPad, (pl.direct ? g.quals.p : B.quals.p) + kSegmentPad,
                                 B.has_dirs ? (pl.direct ? g.dirs.p : B.dirs.p) + kSegmentPad : nullptr};
     int32_t rc = store_append_arrays(h, pl, A, nr, n_cig, n_seq);
-    if (rc == PISCES_OK && find_on_device && (h->cfg.call_mnvs || found_slots > 0)) {
+    if (rc == PISCES_OK && find_on_device && (h->cfg.call_mnvs || found_slots > 0 || h->eqx_in_batch)) {
         DevReadBatch db;
         db.position = A.position; db.flags = A.flags; db.cigar_offset = A.cigar_offset; db.cigar_op = A.cigar_op; db.cigar_len = A.cigar_len;
         db.seq_offset = A.seq_offset; db.bases = A.bases; db.quals = A.quals; db.dirs = A.dirs; db.n_reads = nr;

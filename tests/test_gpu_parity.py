@@ -2118,6 +2118,15 @@ def test_split_form_equals_the_legacy_form_on_random_schedules(torch_cuda, seed)
               (2600, ref[2599:2601].decode(), "TT" if ref[2599] != ord("T") and ref[2600] != ord("T") else "GG" if ref[2599] != ord("G") and ref[2600] != ord("G") else "CC")] if seed % 4 == 2 else None
     cuts = sorted(set(int(x) for x in rng.integers(0, len(reads), 4)) | {len(reads)})
     ups = [int(x) for x in sorted(rng.integers(600, 3900, len(cuts) - 1))] + [None]
+    host_cands = None
+    if seed % 4 == 3:   # an SNV, an MNV and a deletion the host adds with support of their own
+        def other(p):
+            return "A" if ref[p - 1] != ord("A") else "C"
+        host_cands = [dict(position=3950, category=_abi.CAT_SNV, ref=chr(ref[3949]), alt=other(3950), support_by_dir=(3, 2, 0), well_anchored_by_dir=(3, 2, 0)),
+                      dict(position=3960, category=_abi.CAT_MNV, ref=ref[3959:3961].decode(), alt=other(3960) + other(3961), support_by_dir=(4, 4, 0),
+                           well_anchored_by_dir=(4, 4, 0)),
+                      dict(position=3970, category=_abi.CAT_DELETION, ref=ref[3969:3972].decode(), alt=chr(ref[3969]), support_by_dir=(5, 5, 0),
+                           well_anchored_by_dir=(5, 5, 0))]
     out, schedule = [], []
     for split in (None, 0):
         with env(PISCES_HIP_MNV_SPLIT=split):
@@ -2131,6 +2140,8 @@ def test_split_form_equals_the_legacy_form_on_random_schedules(torch_cuda, seed)
                 for cut, up in zip(cuts, ups):
                     c.AddAlleleCounts(_abi.ReadBatch(reads[a0:cut]))
                     a0 = cut
+                    if host_cands:   # IStateManager.AddCandidates from the host between the reads: their loci are the candidate kernel's
+                        c.AddCandidates(host_cands)
                     if up is not None:
                         up = min(up, reads[cut - 1]["pos"] - 1) if cut else up   # (Call(upTo) behind the last read added, as SmallVariantCaller)
                         if split is None:
@@ -2143,7 +2154,7 @@ def test_split_form_equals_the_legacy_form_on_random_schedules(torch_cuda, seed)
     cats = set(((want["info"] >> 4) & 7).tolist())
     assert _abi.CAT_MNV in cats and _abi.CAT_SNV in cats and len(want) > 50
     assert got.tobytes() == want.tobytes() and ga == wa and gs == ws, (seed, kw)
-    if not intervals:
+    if not intervals and not host_cands:
         exp, exp_alleles, exp_called = orc.run_reads_schedule(_abi.ReadBatch(reads), np.frombuffer(ref, np.uint8), 1, len(ref), cfg, schedule, forced=forced or ())
         assert ga == exp_alleles and gs["TotalNumCalled"] == exp_called
         assert_records_match(got, exp)
@@ -2157,15 +2168,19 @@ def test_every_switch_of_the_library_leaves_the_records_alone(torch_cuda, seed):
     germline genotypes by the kernel or by the host pass, every batch a segment of its own or appended to the open one, reads handed over
     from host arrays or in device memory, the candidates looked at between an add and its flush — on random reads, random modes (MNV
     calling, collapser, ploidy, gVCF, thresholds) and a random flush schedule: every form gives the records, allele strings and totals
-    of the default."""
+    of the default (and the default the oracle's)."""
     from pisces_amd import engine
     rng = np.random.default_rng(7100 + seed)
     ref = bytes(rng.choice(list(b"ACGT"), 3300).astype(np.uint8))
+    from tests.test_read_store import random_reads
     reads = _mnv_reads(rng, bytearray(ref), int(rng.integers(1200, 3000)), region=(50, 3100), snv_rate=float(rng.choice([0.002, 0.006])))
+    if seed % 3 == 0:   # reads with any CIGAR (clips, skips, pads, terminal deletions), N bases, stitched per-base directions
+        reads += random_reads(rng, 300, 60, 2900, exotic=False, sort=False)
     reads.sort(key=lambda r: r["pos"])
     ploidy = int(rng.choice([0, 0, 0, 1, 2]))
     kw = dict(call_mnvs=int(rng.integers(0, 2)), max_mnv_length=int(rng.choice([2, 3])), max_gap_between_mnv=int(rng.choice([0, 1])),
               collapse=int(rng.integers(0, 2)), include_reference_calls=int(rng.integers(0, 2)), ploidy=ploidy,
+              noise_model=int(rng.choice([0, 0, 1])), strand_bias_model=int(rng.choice([1, 1, 2])),
               min_frequency=0.2 if ploidy else float(rng.choice([0.01, 0.05])))
     if ploidy:
         kw.update(variant_freq_filter=0.2, low_gq_filter=30, max_genotype_qscore=1000)
@@ -2208,7 +2223,8 @@ def test_every_switch_of_the_library_leaves_the_records_alone(torch_cuda, seed):
              "every batch its own segment": dict(environ=dict(PISCES_HIP_STORE_DIRECT_BYTES=0)),
              "every batch appended": dict(environ=dict(PISCES_HIP_STORE_DIRECT_BYTES=1 << 40, PISCES_HIP_STORE_SEAL_BYTES=1 << 40)),
              "reads in device memory": dict(environ={}, device_reads=True),
-             "candidates looked at after every add": dict(environ={}, peek=True)}
+             "candidates looked at after every add": dict(environ={}, peek=True),
+             "every candidate group to the host": dict(environ=dict(PISCES_HIP_MNV_SPLIT=0))}
     for name, how in forms.items():
         got = run(**how)
         assert got[0].tobytes() == want[0].tobytes() and got[1] == want[1] and got[2] == want[2], (seed, name, kw)

@@ -626,3 +626,181 @@ def test_a_batch_that_touches_more_blocks_than_the_device_lists(torch_cuda):
                 out.append((c.Call(None, capacity=1 << 16), c.Stats()))
     (got, gs), (want, ws) = out
     assert len(want) == 3000 and got.tobytes() == want.tobytes() and gs == ws
+
+
+def _eqx_reads(rng, ref, n=2400, lo=60, hi=2900):
+    """Reads an aligner wrote with = and X operations (minimap2 --eqx) among reads with M operations, over shared mismatch sites: sites
+    only X operations show, sites both kinds of reads show, = operations whose bases differ from the reference after all, low qualities
+    and N bases under X, an insertion or a deletion between = runs."""
+    reads = []
+    for i in range(n):
+        pos = int(rng.integers(lo, hi))
+        ln = int(rng.integers(50, 140))
+        seq = bytearray(ref[pos - 1:pos - 1 + ln])
+        site = pos + 6 + (40 - (pos + 6)) % 61   # one shared site every 61 positions: the first one the read reaches
+        off = site - pos
+        kind = (site // 61) % 3             # 0: X reads only, 1: M reads only, 2: both
+        eqx = i % 2 == 0
+        mism = []
+        if 6 <= off < ln - 6 and rng.random() < 0.45 and (kind == 2 or (kind == 0) == eqx):
+            seq[off] = ord("ACGT"[("ACGT".index(chr(ref[site - 1])) + 1 + (i % 7 == 0)) % 4])
+            mism.append(off)
+        for k in range(ln):                 # sequencing errors
+            if rng.random() < 0.004 and k not in mism:
+                seq[k] = int(rng.choice(list(b"ACGTN")))
+                if seq[k] != ref[pos - 1 + k]:
+                    mism.append(k)
+        quals = rng.choice([12, 30, 38], ln, p=[.05, .3, .65]).astype(np.uint8)
+        if not eqx:
+            ops = [("M", ln)]
+        else:
+            hide = i % 10 == 0              # this read's = runs are not checked against the reference: a mismatch stays inside one
+            ops, run = [], 0
+            for k in range(ln):
+                if k in mism and not hide:
+                    if run:
+                        ops.append(("=", run))
+                    if ops and ops[-1][0] == "X":
+                        ops[-1] = ("X", ops[-1][1] + 1)
+                    else:
+                        ops.append(("X", 1))
+                    run = 0
+                else:
+                    run += 1
+            if run:
+                ops.append(("=", run))
+        seq = bytes(seq)
+        if i % 9 == 4 and ln > 40:          # an insertion / a deletion in the middle (of either kind of read)
+            cut, k = ln // 2, 1 + i % 3
+            head, tail, at = [], [], 0
+            for o, l in ops:
+                if at + l <= cut:
+                    head.append((o, l))
+                elif at >= cut:
+                    tail.append((o, l))
+                else:
+                    head.append((o, cut - at))
+                    tail.append((o, l - (cut - at)))
+                at += l
+            if i % 2:
+                seq = seq[:cut] + bytes(ref[pos - 1 + cut + k:pos - 1 + cut + k + (ln - cut)])
+                ops = head + [("D", k), ("M" if not eqx else "=", len(seq) - cut)]
+            else:
+                ins = bytes(rng.choice(list(b"ACGT"), k).astype(np.uint8))
+                seq = seq[:cut] + ins + seq[cut:]
+                quals = np.concatenate([quals[:cut], np.full(k, 35, np.uint8), quals[cut:]])
+                ops = head + [("I", k)] + tail
+        rl = sum(l for o, l in ops if o in "MIS=X")
+        reads.append({"pos": pos, "cigar": ops, "seq": seq[:rl], "quals": quals[:rl].tolist() + [30] * (rl - len(quals)), "reverse": bool(i % 3 == 0)})
+    reads.sort(key=lambda r: r["pos"])
+    return reads
+
+
+def _bam_of_reads(reads, chrom_len=1_000_000):
+    import struct
+    from tests.test_bgzf import _bgzf_of
+    hdr = b"BAM\x01" + struct.pack("<i", 0) + struct.pack("<i", 1) + struct.pack("<i", 5) + b"chr1\0" + struct.pack("<i", chrom_len)
+    code = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+    out = [hdr]
+    for i, r in enumerate(reads):
+        name = b"q%06d\0" % i
+        cig = b"".join(struct.pack("<I", (l << 4) | "MIDNSHP=X".index(o)) for o, l in r["cigar"])
+        seq = r["seq"].decode()
+        packed = bytearray((len(seq) + 1) // 2)
+        for k, ch in enumerate(seq):
+            packed[k >> 1] |= code[ch] << (4 if k % 2 == 0 else 0)
+        body = struct.pack("<iiBBHHHiiii", 0, r["pos"] - 1, len(name), 60, 0, len(r["cigar"]), 16 if r["reverse"] else 0, len(seq), -1, -1, 0)
+        body += name + cig + bytes(packed) + bytes(r["quals"])
+        out.append(struct.pack("<i", len(body)) + body)
+    return _bgzf_of(b"".join(out))
+
+
+@pytest.mark.parametrize("mode", ["somatic", "gvcf", "collapse", "diploid", "forced", "intervals", "window noise"])
+def test_bases_of_x_and_eq_operations_are_counts_without_candidates(torch_cuda, mode):
+    """ProcessCigarOps walks M, I and D operations only (CandidateVariantFinder.cs:36-83) while AddAlleleCounts counts every operation
+    that spans read and reference, = and X included (CigarExtensions.IsReadSpan / IsReferenceSpan): a mismatch under an X operation is
+    coverage and allele count, and no SNV candidate — the allele is called only where reads with M operations show it too, and then with
+    THEIR support.  MNV calling off, where the tile kernels call SNVs from the allele counts: the walk leaves a record for every such
+    base (finder_walk.h kFoundUnwalked), their loci are called from the counts less those bases (surface_flush.inc.h).  Through every
+    way reads come in — host arrays, device memory, the observation-log chain, BAM bytes — and against the oracle's schedule."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(4100)
+    ref = bytes(rng.choice(list(b"ACGT"), 3300).astype(np.uint8))
+    reads = _eqx_reads(rng, ref)
+    assert sum(any(o in "=X" for o, _ in r["cigar"]) for r in reads) > 500
+    kw = dict(call_mnvs=0, min_frequency=0.01, include_reference_calls=1 if mode in ("gvcf", "diploid", "forced") else 0, collapse=1 if mode == "collapse" else 0)
+    if mode == "diploid":
+        kw.update(ploidy=2, min_frequency=0.2, variant_freq_filter=0.2, low_gq_filter=30, max_genotype_qscore=1000)
+    if mode == "window noise":
+        kw.update(noise_model=1)
+    cfg = _abi.default_config(**kw)
+    sites = [p for p in range(100, 2900) if p % 61 == 40]
+    other = lambda p: "ACGT"[("ACGT".index(chr(ref[p - 1])) + 1) % 4]
+    forced = None
+    if mode == "forced":   # an allele only X operations show, one M and X reads show, one nobody shows
+        x_only, both = [p for p in sites if (p // 61) % 3 == 0], [p for p in sites if (p // 61) % 3 == 2]
+        forced = [(x_only[3], chr(ref[x_only[3] - 1]), other(x_only[3])), (both[5], chr(ref[both[5] - 1]), other(both[5])),
+                  (both[7] + 3, chr(ref[both[7] + 2]), other(both[7] + 3))]
+    intervals = [(300, 1000), (1500, 1620), (2000, 2700)] if mode == "intervals" else None
+    cuts = [600, 1300, 1800, len(reads)]
+    ups = [reads[c - 1]["pos"] - 1 for c in cuts[:-1]] + [None]
+
+    def run(environ, how="host"):
+        with env(**environ):
+            with engine.HipVariantCaller(cfg) as c:
+                c.SetReference(ref)
+                if intervals:
+                    c.SetIntervals(intervals)
+                if forced:
+                    c.SetForcedAlleles(forced)
+                rows, alleles, a0 = [], [], 0
+                for cut, up in zip(cuts, ups):
+                    part = reads[a0:cut]
+                    if how == "device":
+                        c.AddDeviceReads(engine.DeviceReadBatch.from_host(_abi.ReadBatch(part)))
+                    elif how == "bam":
+                        assert c.bam_decode(_bam_of_reads(part), 0)["reads"] == len(part)
+                        c.AddDecodedReads()
+                    else:
+                        c.AddAlleleCounts(_abi.ReadBatch(part))
+                    a0 = cut
+                    r, a = c.CallWithAlleles(up, capacity=1 << 15)
+                    rows.append(r)
+                    alleles += a
+                return np.concatenate(rows), alleles, c.Stats()["TotalNumCalled"]
+    want = run({})
+    if not intervals:
+        exp, exp_alleles, exp_called = orc.run_reads_schedule(_abi.ReadBatch(reads), np.frombuffer(ref, np.uint8), 1, len(ref), cfg, ups[:-1], forced=forced or ())
+        assert want[1] == exp_alleles and want[2] == exp_called
+        for f in ("position", "total_coverage", "allele_support", "reference_support", "num_no_calls", "coverage_by_dir", "support_by_dir", "filter_bits",
+                  "info", "variant_qscore", "genotype_qscore"):
+            assert (want[0][f] == exp[f]).all(), f
+    # what the test is about: no variant where only X operations show one, variants with the M reads' support where both do
+    called = {(int(r["position"]), a[1]): int(r["allele_support"]) for r, a in zip(want[0], want[1]) if a[1] != "." and len(a[0]) == 1 and len(a[1]) == 1
+              and not (r["filter_bits"] >> _abi.FILTER_FORCED_REPORT) & 1}
+    def shown_under(r, p):   # the operation under which read r shows other(p) at p with a quality that counts, or None
+        at, k = r["pos"], 0
+        for o, l in r["cigar"]:
+            if o in "M=X":
+                if at <= p < at + l:
+                    return o if r["seq"][k + p - at] == ord(other(p)) and r["quals"][k + p - at] >= 20 else None
+                at, k = at + l, k + l
+            elif o in "DN":
+                at += l
+            elif o in "IS":
+                k += l
+        return None
+    in_reads = lambda p, kinds: sum(1 for r in reads if (shown_under(r, p) or "-") in kinds)
+    inside = lambda p: not intervals or any(a <= p <= b for a, b in intervals)
+    x_sites = [p for p in sites if (p // 61) % 3 == 0 and in_reads(p, "=X") >= 6 and in_reads(p, "M") == 0]
+    both_sites = [p for p in sites if (p // 61) % 3 == 2 and in_reads(p, "M") >= 6 and in_reads(p, "=X") >= 6 and inside(p)]
+    assert len(x_sites) > 5 and len(both_sites) > 5
+    assert not any((p, other(p)) in called for p in x_sites)
+    if mode != "diploid":
+        assert all(called.get((p, other(p))) == in_reads(p, "M") for p in both_sites), [(p, called.get((p, other(p))), in_reads(p, "M")) for p in both_sites]
+    for name, environ, how in [("reads in device memory", {}, "device"), ("the observation-log chain", dict(PISCES_HIP_READ_PATH="log"), "host"),
+                               ("BAM bytes", {}, "bam"), ("BAM bytes, the log chain", dict(PISCES_HIP_READ_PATH="log"), "bam"),
+                               ("checks on the device", dict(PISCES_HIP_DEVICE_CHECKS=1), "host"), ("candidates merged on the host", dict(PISCES_HIP_DEVICE_MERGE=0), "host"),
+                               ("candidates merged on the device", dict(PISCES_HIP_DEVICE_MERGE=1), "host"), ("rows merged by copy", dict(PISCES_HIP_MERGE_IN_PLACE=0), "host")]:
+        got = run(environ, how)
+        assert got[0].tobytes() == want[0].tobytes() and got[1] == want[1] and got[2] == want[2], (mode, name)
