@@ -23,6 +23,9 @@ struct HostCandidate {
     // candidates in that order, RegionState.cs:104-123), and whether every read event behind the candidate came from the device's read walk
     uint64_t stamp = 0;
     bool from_reads = false;
+    // MNV calling off, a forced SNV: the support it took from the allele counts at a flush (surface_flush.inc.h) — taken back when the
+    // candidate returns to the state (a candidate of a held block that joined a batch for the collapser), where more reads may reach it
+    int32_t counted_by_dir[3] = {0, 0, 0};
 };
 
 // Appends the read's indel candidates. ref[i] is position i+1 of the chromosome (upper case).

@@ -447,6 +447,13 @@ struct PiscesHip {
     // MNV calling on, SPLIT FORM (surface_flush.inc.h): the fully anchored SNV groups of the read walk stay in device memory (the SNV store,
     // finder_kernels.hip.h) until their block is flushed; the tile kernels call SNVs from the allele counts everywhere but on the dirty loci
     bool mnv_split = false;
+    // The read walk makes the SNV candidates (its M-operation half runs): MNV calling on — or off with a collapser whose thresholds can keep
+    // an open-ended SNV and its twin apart (VariantCollapser.GetMatches: a match that is not the fully anchored twin must reach
+    // CollapseFreqThreshold and more than CollapseFreqRatioThreshold times the candidate's frequency).  Then two candidates of one allele
+    // are called on their own support each, which the allele counts do not know; with the default thresholds (0, 0.5) twins always join
+    // and the SNVs of MNV calling off are the allele counts (the tile kernels call them; a read that maps ONE base — an SNV open on both
+    // sides — is the exception that stays with the counts).
+    bool snv_walk = false;
     DeviceBuf<SnvGroup> d_snv[2];
     int snv_cur = 0;
     DeviceBuf<unsigned int> d_snv_n;          // [0], [1]: groups in d_snv[0] / [1]; [2], [3]: a sweep's {selected, kept}
@@ -809,7 +816,8 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         if (const char* v = getenv("PISCES_HIP_DEVICE_MERGE")) h->device_merge = atoi(v) != 0 ? 1 : 0;   // the A/B of tests/test_read_store.py
         // MNV calling on: the split form, unless the candidate records are asked to come back unmerged (PISCES_HIP_DEVICE_MERGE=0: the
         // earlier form, every candidate an object on the host, the tile kernels Reference records only) or PISCES_HIP_MNV_SPLIT=0
-        h->mnv_split = h->cfg.call_mnvs != 0 && h->device_merge != 0;
+        h->snv_walk = h->cfg.call_mnvs != 0 || (h->cfg.collapse != 0 && (h->cfg.collapse_freq_threshold > 0.0f || h->cfg.collapse_freq_ratio_threshold >= 1.0f));
+        h->mnv_split = h->snv_walk && h->device_merge != 0;
         if (const char* v = getenv("PISCES_HIP_MNV_SPLIT")) h->mnv_split = h->mnv_split && atoi(v) != 0;
         if (const char* v = getenv("PISCES_HIP_STORE_SEAL_BYTES")) h->store_seal_bytes = (size_t)std::max(0ll, atoll(v));
         if (const char* v = getenv("PISCES_HIP_DEVICE_CHECKS")) h->device_checks = atoi(v) != 0 ? 1 : 0;

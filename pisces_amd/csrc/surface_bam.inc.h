@@ -372,9 +372,9 @@ int32_t pisces_hip_add_decoded_reads(PiscesHip* h)
         }
     }
     const bool find_on_device = !h->h_ref.empty();
-    const int64_t found_slots = (find_on_device && !h->cfg.call_mnvs) ? B.found_slots : 0, found_pool = (find_on_device && !h->cfg.call_mnvs) ? B.found_pool : 0;
+    const int64_t found_slots = (find_on_device && !h->snv_walk) ? B.found_slots : 0, found_pool = (find_on_device && !h->snv_walk) ? B.found_pool : 0;
     if (found_slots > 0x7FFFFFF0ll || found_pool > 0x7FFFFFF0ll) return fail(h, PISCES_E_INVALID_ARG, "add_decoded_reads: too many insertions / deletions in one batch");
-    h->eqx_in_batch = find_on_device && !h->cfg.call_mnvs && B.has_eqx;
+    h->eqx_in_batch = find_on_device && !h->snv_walk && B.has_eqx;
     // commit: the blocks the reads touch (GetBlock, RegionStateManager.cs:361-383) and the totals — only once the batch is in the store / the log
     // (a failed add leaves neither empty blocks nor readsProcessed / readsSkipped that pisces_hip_reduce_summary would add up)
     auto commit = [&]() {
@@ -400,7 +400,7 @@ int32_t pisces_hip_add_decoded_reads(PiscesHip* h)
     hipLaunchKernelGGL(expand_reads_kernel, dim3(expand_reads_grid(nr)), dim3(256), 0, h->stream, db, (const long long*)B.d_slots.p,
                        (long long)h->log_ub, h->cfg.min_base_call_quality, h->d_log_pos[c].p, h->d_log_tup[c].p, h->d_log_n.p + 2, expand_reads_per_wave(nr));
     PISCES_HIP_CHECK(h, hipGetLastError());
-    if (find_on_device && (h->cfg.call_mnvs || found_slots > 0 || h->eqx_in_batch)) {
+    if (find_on_device && (h->snv_walk || found_slots > 0 || h->eqx_in_batch)) {
         int32_t rcd = enqueue_candidate_discovery(h, db, B.has_dirs ? B.del_dirs.p : nullptr, nr, (const int32_t*)B.d_fslots.p, found_slots, found_pool);
         if (rcd) return rcd;
     }

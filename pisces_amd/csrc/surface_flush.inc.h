@@ -804,7 +804,7 @@ static void split_restore(PiscesHip* h)
 {
     h->P.dirty_bits = nullptr;
     h->P.dirty_first = h->P.dirty_n = 0;
-    h->P.refs_only = h->cfg.call_mnvs ? 1 : 0;
+    h->P.refs_only = h->snv_walk ? 1 : 0;
 }
 static int32_t split_prepare(PiscesHip* h, const std::vector<int32_t>& keys, int32_t up_to_position)
 {
@@ -812,7 +812,7 @@ static int32_t split_prepare(PiscesHip* h, const std::vector<int32_t>& keys, int
     h->split_selected.clear();
     // MNV calling off: the loci with bases of X / = operations that the allele counts hold and no SNV candidate stands for are dirty too
     // (their SNVs are called by call_spanning, from the counts less those bases)
-    const bool unwalked_mode = !h->mnv_split && !h->cfg.call_mnvs;
+    const bool unwalked_mode = !h->snv_walk;
     if (!h->mnv_split && !unwalked_mode) return PISCES_OK;
     if (unwalked_mode) {
         bool some = false;
@@ -1054,10 +1054,21 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
     // variants of those loci alone (split_prepare made them dirty); their SNV candidates are made here, after the collapser, with the
     // support the read walk's candidates have: the allele counts less these bases.
     std::vector<BlockObs::Unwalked> unw;
-    if (!mnv_mode) {
+    if (!h->snv_walk) {
         for (int32_t key : keys) {
             const auto& u = h->blocks[key].unwalked;
             unw.insert(unw.end(), u.begin(), u.end());
+        }
+        if (max_cleared >= 0) {   // (SNV candidates of held blocks that joined the batch — forced ones: what the reads so far show at their positions)
+            std::vector<int32_t> seen;
+            for (auto& c : work) {
+                if (c.category != PISCES_CAT_SNV || c.position <= max_cleared || std::find(seen.begin(), seen.end(), c.position) != seen.end()) continue;
+                seen.push_back(c.position);
+                auto it = h->blocks.find(block_key(h, c.position));
+                if (it == h->blocks.end()) continue;
+                for (auto& u : it->second.unwalked)
+                    if (u.position == c.position) unw.push_back(u);
+            }
         }
         std::sort(unw.begin(), unw.end(), [](const BlockObs::Unwalked& a, const BlockObs::Unwalked& b) { return a.position != b.position ? a.position < b.position : a.alt < b.alt; });
         size_t w = 0;
@@ -1239,7 +1250,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         host_counts_p = h->h_counts;
     }
     struct { const int32_t* p; const int32_t* data() const { return p; } } host_counts = {host_counts_p};
-    if (!mnv_mode && have_forced) {
+    if (!h->snv_walk && have_forced) {
         // MNV calling off: SNV candidates are the allele counts and never reach the host, so a forced SNV (added without support) takes
         // the support the merged candidate of the reference has: the reads that show the base at or above the quality threshold
         for (auto& c : work) {
@@ -1251,6 +1262,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
                 const int32_t* row = host_counts.data() + li * PISCES_COUNTS_PER_LOCUS + (at * 3 + d) * PISCES_NUM_ANCHORS;
                 for (int an = 0; an < PISCES_NUM_ANCHORS; an++) c.support_by_dir[d] += row[an];
                 c.support_by_dir[d] = std::max(0, c.support_by_dir[d] - unwalked_of(c.position, c.alt[0], d));   // (less what no candidate stands for)
+                c.counted_by_dir[d] = c.support_by_dir[d];
             }
         }
     }
@@ -1274,6 +1286,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
             size_t w = 0;
             for (size_t i = 0; i < work.size(); i++) {
                 if (work[i].position > max_cleared && work[i].category != PISCES_CAT_REFERENCE) {
+                    for (int d = 0; d < 3; d++) { work[i].support_by_dir[d] -= work[i].counted_by_dir[d]; work[i].counted_by_dir[d] = 0; }   // (the allele counts are asked again when its block is flushed)
                     work[i].stamp = next_host_stamp(h);   // (AddCandidates appends it to its position's list again)
                     add_candidate(h, work[i]);
                     continue;
@@ -1292,7 +1305,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         for (size_t i = 0; i < unw.size();) {
             const int32_t p = unw[i].position;
             while (i < unw.size() && unw[i].position == p) i++;
-            if (p < 1 || (int64_t)p > h->ref_len) continue;
+            if (p < 1 || (int64_t)p > h->ref_len || !std::binary_search(keys.begin(), keys.end(), block_key(h, p))) continue;
             const char rb = (char)h->h_ref[(size_t)p - 1];
             const int64_t li = row_index(locus_index(p));
             if (atype(rb) >= 4 || li < 0) continue;
@@ -1533,7 +1546,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         const bool forced = have_forced && is_forced_allele(h, *final_list[i]);
         const bool reportable = callable[i] && inside_intervals(final_list[i]->position);
         if (callable[i] && owned(final_list[i]->position)) (*n_called) += forced ? 2 : 1;
-        if (forced && !mnv_mode && final_list[i]->category == PISCES_CAT_SNV && reportable && !split_dirty_at(h, final_list[i]->position)) {   // MNV calling off: the tile kernels report it,
+        if (forced && !h->snv_walk && final_list[i]->category == PISCES_CAT_SNV && reportable && !split_dirty_at(h, final_list[i]->position)) {   // MNV calling off: the tile kernels report it,
             (*n_called)--;                                                                        // and have counted it once
             continue;
         }

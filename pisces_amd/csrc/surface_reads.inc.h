@@ -386,7 +386,7 @@ static int32_t enqueue_found_records(PiscesHip* h, const DevReadBatch& db, const
                                      const int32_t* d_pool_first, int64_t found_slots, int64_t found_pool);
 static FinderParams finder_params(const PiscesHip* h)
 {
-    const FinderParams FP = {h->cfg.min_base_call_quality, PISCES_ANCHOR_SIZE, h->cfg.call_mnvs ? 1 : 0, h->cfg.call_mnvs ? 1 : 0, h->cfg.max_mnv_length,
+    const FinderParams FP = {h->cfg.min_base_call_quality, PISCES_ANCHOR_SIZE, h->snv_walk ? 1 : 0, h->cfg.call_mnvs ? 1 : 0, h->cfg.max_mnv_length,
                              h->cfg.max_gap_between_mnv, h->mnv_split ? 1 : 0};
     return FP;
 }
@@ -398,7 +398,7 @@ static int32_t enqueue_candidate_discovery(PiscesHip* h, const DevReadBatch& db,
                                            int64_t found_slots, int64_t found_pool)
 {
     FinderParams FP = finder_params(h);
-    const bool unwalked = !h->cfg.call_mnvs && h->eqx_in_batch;
+    const bool unwalked = !h->snv_walk && h->eqx_in_batch;
     if (unwalked) FP.mark_x_spans = 2;
     h->found.fp = FP;
     // (arrival stamps: this batch's records come behind everything the host added so far)
@@ -411,7 +411,7 @@ static int32_t enqueue_candidate_discovery(PiscesHip* h, const DevReadBatch& db,
     h->found.counted_only = false;
     PISCES_HIP_CHECK(h, h->d_found_misc.reserve(4));
     PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_found_misc.p, 0, 4 * sizeof(unsigned int), h->stream));
-    if (!h->cfg.call_mnvs && !unwalked) return enqueue_found_records(h, db, d_deldirs, nr, FP, d_slots_in, nullptr, found_slots, found_pool);
+    if (!h->snv_walk && !unwalked) return enqueue_found_records(h, db, d_deldirs, nr, FP, d_slots_in, nullptr, found_slots, found_pool);
     // count, scan (one more element than reads: the last one receives the total); the totals size the record buffers: they travel to pinned
     // memory behind an event, and the second half (finish_candidate_discovery) is enqueued by whichever entry comes next — the batch's
     // arrays stay where they are until then (a segment's blob; or the staging pair, which only the next add reuses, behind that half)
@@ -779,7 +779,7 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
     for (int32_t i = 0; i < nr; i++) {
         ReadView r = read_view(batch, i);
         fslots[(size_t)i] = (int32_t)found_slots;
-        if (find_on_device && !h->cfg.call_mnvs)
+        if (find_on_device && !h->snv_walk)
             for (int c = 0; c < r.n_cigar; c++) {
                 if (r.cigar_op[c] == 'I' || r.cigar_op[c] == 'D') found_slots++;
                 if (r.cigar_op[c] == 'I' && r.cigar_len[c] > (uint32_t)kFoundInline) found_pool += r.cigar_len[c];
@@ -847,7 +847,7 @@ int32_t pisces_hip_add_reads(PiscesHip* h, const PiscesReadBatch* batch)
     hipLaunchKernelGGL(expand_reads_kernel, dim3(expand_reads_grid(nr)), dim3(256), 0, h->stream, db, (const long long*)(d + off_slots), 0ll,
                        minBQ, h->d_log_pos[c].p, h->d_log_tup[c].p, h->d_log_n.p + 2, expand_reads_per_wave(nr));
     { hipError_t el = hipGetLastError(); if (el != hipSuccess) { (void)stage_release(h); return fail(h, PISCES_E_DEVICE, std::string("add_reads: ") + hipGetErrorString(el)); } }
-    if (find_on_device && (h->cfg.call_mnvs || found_slots > 0 || h->eqx_in_batch)) {
+    if (find_on_device && (h->snv_walk || found_slots > 0 || h->eqx_in_batch)) {
         int32_t rcd = enqueue_candidate_discovery(h, db, batch->deletion_directions ? d + off_deldirs : nullptr, nr, (const int32_t*)(d + off_fslots),
                                                   found_slots, found_pool);
         if (rcd) { (void)stage_release(h); return rcd; }   // (transfers out of the staging pair are in flight)

@@ -426,7 +426,7 @@ static int32_t store_finish_add(PiscesHip* h, StorePlace& pl, int32_t rc, uint8_
         rc = store_append_arrays(h, pl, A, nr, n_cig, n_seq);
     }
     // ICandidateVariantFinder.FindCandidates + IStateManager.AddCandidates (SmallVariantCaller.cs:92-96) on the device, on the batch as it lies there
-    if (rc == PISCES_OK && find_on_device && (h->cfg.call_mnvs || found_slots > 0 || h->eqx_in_batch)) {
+    if (rc == PISCES_OK && find_on_device && (h->snv_walk || found_slots > 0 || h->eqx_in_batch)) {
         if (fslots_host) {
             std::memcpy(h->h_stage + L.off_fslots, fslots_host, ((size_t)nr + 1) * 4);
             hipError_t e = hipMemcpyAsync(d + L.off_fslots, h->h_stage + L.off_fslots, L.total - L.off_fslots, hipMemcpyHostToDevice, h->stream);
@@ -486,7 +486,7 @@ static int32_t add_reads_store(PiscesHip* h, const PiscesReadBatch* batch)
     uint8_t* const d = pl.direct ? pl.seg->blob.p : D_STAGE(h);
     rc = store_upload_batch(h, batch, L, nr, n_cig, n_seq, staged, d);
     const bool find_on_device = !h->h_ref.empty();   // without a reference only the IStateManager half (allele counts) runs
-    const bool count_indels = find_on_device && !h->cfg.call_mnvs;
+    const bool count_indels = find_on_device && !h->snv_walk;
     h->eqx_in_batch = false;
     std::vector<int32_t>& fslots = h->found_slots_host;
     std::vector<int32_t>& touched = h->touched_keys;
@@ -532,6 +532,7 @@ static int32_t add_reads_store(PiscesHip* h, const PiscesReadBatch* batch)
             if (len != r.read_len) { bad = "add_reads: CIGAR does not match the read"; break; }   // Read.ValidateCigar (Read.cs:603-605)
             if ((int64_t)r.position + len > 0x7FFFFFFFll) { bad = "add_reads: read runs past position 2^31 - 1"; break; }
             if (len > 0) touch(r.position, r.position + len - 1);
+            if (count_indels && r.cigar_op[0] != 'M') h->eqx_in_batch = true;
             continue;
         }
         auto delq = [&](int idx) {   // CandidateVariantFinder.CheckDeletionQuality (CandidateVariantFinder.cs:294-320)
@@ -636,7 +637,7 @@ int32_t pisces_hip_add_device_reads(PiscesHip* h, const PiscesReadBatch* batch, 
     if (e == hipSuccess && has_deldirs) e = d2d(L.off_deldirs, batch->deletion_directions, 2 * n_cig);
     if (e != hipSuccess) rc = fail(h, PISCES_E_DEVICE, std::string("add_device_reads: ") + hipGetErrorString(e));
     const bool find_on_device = !h->h_ref.empty();
-    const bool count_indels = find_on_device && !h->cfg.call_mnvs;
+    const bool count_indels = find_on_device && !h->snv_walk;
     h->eqx_in_batch = false;
     std::vector<int32_t>& touched = h->touched_keys;
     touched.clear();
@@ -674,7 +675,7 @@ static int32_t add_decoded_reads_store(PiscesHip* h, int64_t found_slots, int64_
                                 B.seq_offset.p, (pl.direct ? g.bases.p : B.bases.p) + kSegmentPad, (pl.direct ? g.quals.p : B.quals.p) + kSegmentPad,
                                 B.has_dirs ? (pl.direct ? g.dirs.p : B.dirs.p) + kSegmentPad : nullptr};
     int32_t rc = store_append_arrays(h, pl, A, nr, n_cig, n_seq);
-    if (rc == PISCES_OK && find_on_device && (h->cfg.call_mnvs || found_slots > 0 || h->eqx_in_batch)) {
+    if (rc == PISCES_OK && find_on_device && (h->snv_walk || found_slots > 0 || h->eqx_in_batch)) {
         DevReadBatch db;
         db.position = A.position; db.flags = A.flags; db.cigar_offset = A.cigar_offset; db.cigar_op = A.cigar_op; db.cigar_len = A.cigar_len;
         db.seq_offset = A.seq_offset; db.bases = A.bases; db.quals = A.quals; db.dirs = A.dirs; db.n_reads = nr;

@@ -280,7 +280,7 @@ class HipVariantCaller:
                 else:
                     c = cands[ci]
                     o = c.allele_offset
-                    alleles.append((bytes(pool[o: o + c.ref_len]).decode(), bytes(pool[o + c.ref_len: o + c.ref_len + c.alt_len]).decode()))
+                    alleles.append((bytes(pool[o: o + c.ref_len]).decode("latin-1"), bytes(pool[o + c.ref_len: o + c.ref_len + c.alt_len]).decode("latin-1")))
             return recs, alleles
 
     def GetCandidates(self, upToPosition=None):
@@ -295,8 +295,8 @@ class HipVariantCaller:
         for i in range(n.value):
             c = cands[i]
             o = c.allele_offset
-            out.append({"position": c.position, "category": c.category, "ref": bytes(pool[o: o + c.ref_len]).decode(),
-                        "alt": bytes(pool[o + c.ref_len: o + c.ref_len + c.alt_len]).decode(),
+            out.append({"position": c.position, "category": c.category, "ref": bytes(pool[o: o + c.ref_len]).decode("latin-1"),
+                        "alt": bytes(pool[o + c.ref_len: o + c.ref_len + c.alt_len]).decode("latin-1"),
                         "support_by_dir": list(c.support_by_dir), "well_anchored_by_dir": list(c.well_anchored_by_dir),
                         "open_left": bool(c.open_left), "open_right": bool(c.open_right)})
         return out

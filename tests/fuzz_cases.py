@@ -1,0 +1,155 @@
+"""The fuzz of the streaming surface: the product (default form) against the oracle's block schedule over random reads, modes and flush
+schedules — every dimension at once (bases that are no A C G T N, any CIGAR, = and X operations, stitched directions, quality
+thresholds, block sizes, depth thresholds, filters, collapser thresholds, forced alleles, ploidy, noise model).  one(seed) runs a
+draw; tests/test_gpu_parity.py runs the seeds that once differed and a band of fresh ones, tools/fuzz_oracle.py any range:
+    python tools/fuzz_oracle.py [first_seed] [n_seeds]
+"""
+import os
+import sys
+
+import numpy as np
+
+from pisces_amd import _abi
+from tests import orc
+
+
+def one(seed, verbose=False):
+    from pisces_amd import engine
+    from tests.test_gpu_parity import _mnv_reads, INT_FIELDS
+    from tests.test_read_store import random_reads, _eqx_reads
+    rng = np.random.default_rng(990000 + seed)
+    L = int(rng.choice([2200, 3300, 5200]))
+    ref = bytearray(rng.choice(list(b"ACGT"), L).astype(np.uint8))
+    if seed % 5 == 1:   # stretches of N and a homopolymer / repeat (RMxN) in the reference
+        a = int(rng.integers(300, L - 400)); ref[a:a + int(rng.integers(1, 30))] = b"N" * 30
+        b = int(rng.integers(300, L - 400)); ref[b:b + 24] = b"ACACACACACACACACACACACAC"
+        c = int(rng.integers(300, L - 400)); ref[c:c + 14] = b"TTTTTTTTTTTTTT"
+    ref = bytes(ref[:L])
+    region = (50, L - 200)
+    reads = _mnv_reads(rng, bytearray(ref), int(rng.integers(600, 3000)), region=region, snv_rate=float(rng.choice([0.001, 0.004, 0.01])))
+    for r in reads:
+        r["seq"] = r["seq"].encode() if isinstance(r["seq"], str) else r["seq"]
+    kind = seed % 4
+    if kind == 1:
+        reads += random_reads(rng, int(rng.integers(50, 500)), 60, L - 400, exotic=bool(rng.integers(0, 2)), sort=False)
+    elif kind == 2:
+        reads += _eqx_reads(rng, ref.replace(b"N", b"A"), n=int(rng.integers(100, 900)), lo=60, hi=L - 400)
+    for r in reads:   # (a NUL ends the oracle's allele strings, which are C strings)
+        if b"\0" in r["seq"]:
+            r["seq"] = r["seq"].replace(b"\0", b".")
+    reads.sort(key=lambda r: r["pos"])
+    ploidy = int(rng.choice([0, 0, 0, 1, 2]))
+    kw = dict(call_mnvs=int(rng.integers(0, 2)), max_mnv_length=int(rng.choice([2, 3, 5])), max_gap_between_mnv=int(rng.choice([0, 1, 2])),
+              collapse=int(rng.integers(0, 2)), include_reference_calls=int(rng.integers(0, 2)), ploidy=ploidy,
+              noise_model=int(rng.choice([0, 0, 1])), strand_bias_model=int(rng.choice([1, 1, 2])),
+              min_frequency=0.2 if ploidy else float(rng.choice([0.005, 0.01, 0.05])),
+              min_base_call_quality=int(rng.choice([20, 20, 13, 30, 0])), block_size=int(rng.choice([1000, 1000, 500, 64, 4000])),
+              min_coverage=int(rng.choice([10, 1, 0, 50])), low_depth_filter=int(rng.choice([10, 30, -1])),
+              emit_zero_coverage_refs=int(rng.integers(0, 2)), filter_single_strand=int(rng.integers(0, 2)),
+              min_variant_qscore=int(rng.choice([20, 0, 40])), variant_qscore_filter=int(rng.choice([30, 20, 60])),
+              expect_stitched_reads=int(rng.choice([0, 0, 1])), collapse_freq_threshold=float(rng.choice([0.0, 0.02])),
+              collapse_freq_ratio_threshold=float(rng.choice([0.5, 0.2])), noise_level=int(rng.choice([20, 30])),
+              rmxn_min_repetitions=int(rng.choice([9, 4])))
+    if kw["block_size"] < 500:   # (the oracle emits zero-coverage rows over all of its region, the state manager over the blocks that exist)
+        kw["emit_zero_coverage_refs"] = 0
+    if kw["variant_qscore_filter"] < kw["min_variant_qscore"]:
+        kw["variant_qscore_filter"] = kw["min_variant_qscore"]
+    if kw["max_gap_between_mnv"] > kw["max_mnv_length"] - 2:
+        kw["max_gap_between_mnv"] = max(0, kw["max_mnv_length"] - 2)
+    if ploidy:
+        kw.update(variant_freq_filter=0.2, low_gq_filter=30, max_genotype_qscore=1000)
+    cfg = _abi.default_config(**kw)
+    forced = None
+    if seed % 3 == 2:
+        forced = []
+        for _ in range(int(rng.integers(1, 6))):
+            p = int(rng.integers(100, L - 300))
+            rb = chr(ref[p - 1])
+            if rb not in "ACGT":
+                continue
+            k = int(rng.integers(0, 4))
+            if k == 0:
+                forced.append((p, rb, "ACGT"[("ACGT".index(rb) + 1 + int(rng.integers(0, 3))) % 4]))
+            elif k == 1 and all(chr(x) in "ACGT" for x in ref[p - 1:p + 3]):
+                forced.append((p, ref[p - 1:p + 2].decode(), rb))
+            elif k == 2:
+                forced.append((p, rb, rb + "GT"))
+            elif all(chr(x) in "ACGT" for x in ref[p - 1:p + 1]):
+                forced.append((p, ref[p - 1:p + 1].decode(), "".join("ACGT"[("ACGT".index(chr(x)) + 2) % 4] for x in ref[p - 1:p + 1])))
+        forced = sorted(set(forced)) or None
+    n_cuts = int(rng.integers(1, 6))
+    cuts = sorted(set(int(x) for x in rng.integers(1, len(reads), n_cuts)) | {len(reads)})
+    ups = [int(x) for x in sorted(rng.integers(200, L - 200, len(cuts) - 1))] + [None]
+    rows, alleles, a0, schedule = [], [], 0, []
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(ref)
+        if forced:
+            c.SetForcedAlleles(forced)
+        for cut, up in zip(cuts, ups):
+            c.AddAlleleCounts(_abi.ReadBatch(reads[a0:cut]))
+            a0 = cut
+            if up is not None:
+                up = min(up, reads[cut - 1]["pos"] - 1)
+                schedule.append(up)
+            r, a = c.CallWithAlleles(up, capacity=1 << 16)
+            rows.append(r)
+            alleles += a
+        called = c.Stats()["TotalNumCalled"]
+    got = np.concatenate(rows)
+    # (the oracle's region: the blocks the reads touch — it emits zero-coverage reference rows over all of its region, the state manager
+    # only over blocks that exist)
+    bs = kw["block_size"]
+    reach = max(r["pos"] + sum(l for o, l in r["cigar"] if o in "MDN=X") - 1 for r in reads)
+    region = min(len(ref), (reach + bs - 1) // bs * bs)
+    exp, exp_alleles, exp_called = orc.run_reads_schedule(_abi.ReadBatch(reads), np.frombuffer(ref, np.uint8), 1, region, cfg, schedule, forced=forced or ())
+    why = None
+    if alleles != exp_alleles:
+        why = "alleles"
+        if verbose:
+            ga = set(zip(got["position"].tolist(), alleles)); ea = set(zip(exp["position"].tolist(), exp_alleles))
+            print("  only product:", sorted(ga - ea)[:10]); print("  only oracle:", sorted(ea - ga)[:10])
+            print("  cuts", cuts, "schedule", schedule, "read positions at cuts", [reads[c - 1]["pos"] for c in cuts])
+            for (p, (ra, aa)) in sorted((ga - ea) | (ea - ga))[:6]:
+                if len(ra) != 1 or len(aa) != 1:
+                    continue
+                shown = {}
+                for ri, r in enumerate(reads):
+                    at, k = r["pos"], 0
+                    for o, l in r["cigar"]:
+                        if o in "M=X":
+                            if at <= p < at + l and r["seq"][k + p - at] == ord(aa):
+                                key = (o, "q>=" if r["quals"][k + p - at] >= kw["min_base_call_quality"] else "q<", sum(1 for c in cuts if c <= ri))
+                                shown[key] = shown.get(key, 0) + 1
+                            at, k = at + l, k + l
+                        elif o in "DN":
+                            at += l
+                        elif o in "IS":
+                            k += l
+                print("   ", p, ra, aa, "shown as (op, quality, batch):", shown)
+    elif len(got) != len(exp):
+        why = "rows"
+    else:
+        for f in list(INT_FIELDS) + ["info", "variant_qscore", "genotype_qscore"]:
+            if not (got[f] == exp[f]).all():
+                why = f
+                if verbose:
+                    bad = np.nonzero((got[f] != exp[f]).reshape(len(got), -1).any(axis=1))[0][:5]
+                    for i in bad:
+                        print("  ", f, int(got["position"][i]), alleles[i], got[f][i], exp[f][i])
+                        p, aa = int(got["position"][i]), alleles[i][1]
+                        for ri, r in enumerate(reads):
+                            at, k = r["pos"], 0
+                            for ci, (o, l) in enumerate(r["cigar"]):
+                                if o in "M=X":
+                                    if at <= p < at + l and len(aa) == 1 and r["seq"][k + p - at] == ord(aa):
+                                        print("     read", ri, "pos", r["pos"], r["cigar"], "op", ci, "offset", p - at, "q", r["quals"][k + p - at],
+                                              "neighbours", r["seq"][max(0, k + p - at - 1):k + p - at + 2], r["quals"][max(0, k + p - at - 1):k + p - at + 2], ref[p - 2:p + 1])
+                                    at, k = at + l, k + l
+                                elif o in "DN":
+                                    at += l
+                                elif o in "IS":
+                                    k += l
+                break
+        if why is None and called != exp_called:
+            why = "TotalNumCalled %d != %d" % (called, exp_called)
+    return why, kw, len(got), forced

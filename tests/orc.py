@@ -372,7 +372,7 @@ def run_reads_full(batch, ref, region_start, region_loci, cfg):
     n = lib.orc_run_reads_full(C.byref(batch.c), refa.ctypes.data_as(C.POINTER(C.c_uint8)), len(refa), region_start,
                                region_loci, C.byref(cfg), out.ctypes.data, cap, C.byref(nloci), full, C.byref(total))
     assert n >= 0, n
-    return out[:n], [(full[i].ref.decode(), full[i].alt.decode()) for i in range(n)], nloci.value, total.value
+    return out[:n], [(full[i].ref.decode("latin-1"), full[i].alt.decode("latin-1")) for i in range(n)], nloci.value, total.value
 
 
 def run_reads_sharded(shards, ref, cfg, passes=1):
@@ -481,7 +481,7 @@ def run_reads_blocks(batch, ref, region_start, region_loci, cfg):
     n = lib.orc_run_reads_blocks(C.byref(batch.c), refa.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int64(len(refa)), C.c_int32(region_start),
                                  C.c_int32(region_loci), C.byref(cfg), C.c_void_p(out.ctypes.data), C.c_int64(cap), full, C.byref(total))
     assert n >= 0, n
-    return out[:n], [(full[i].ref.decode(), full[i].alt.decode()) for i in range(n)], total.value
+    return out[:n], [(full[i].ref.decode("latin-1"), full[i].alt.decode("latin-1")) for i in range(n)], total.value
 
 
 def run_reads_schedule(batch, ref, region_start, region_loci, cfg, up_to_positions, forced=()):
@@ -502,7 +502,7 @@ def run_reads_schedule(batch, ref, region_start, region_loci, cfg, up_to_positio
                                    C.c_int32(region_loci), C.byref(cfg), ups.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int32(len(ups)),
                                    fa, C.c_int32(len(forced)), C.c_void_p(out.ctypes.data), C.c_int64(cap), full, C.byref(total))
     assert n >= 0, n
-    return out[:n], [(full[i].ref.decode(), full[i].alt.decode()) for i in range(n)], total.value
+    return out[:n], [(full[i].ref.decode("latin-1"), full[i].alt.decode("latin-1")) for i in range(n)], total.value
 
 
 def diploid_locus_process(alleles):

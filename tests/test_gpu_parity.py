@@ -2228,3 +2228,20 @@ def test_every_switch_of_the_library_leaves_the_records_alone(torch_cuda, seed):
     for name, how in forms.items():
         got = run(**how)
         assert got[0].tobytes() == want[0].tobytes() and got[1] == want[1] and got[2] == want[2], (seed, name, kw)
+
+
+# seeds of tests/fuzz_cases.py whose records once differed from the oracle's (what each one found is in DESIGN.md section 5), then a band
+# of fresh ones
+FUZZ_SEEDS_THAT_ONCE_DIFFERED = [101, 213, 353, 369, 466, 1874, 1878, 6065]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", FUZZ_SEEDS_THAT_ONCE_DIFFERED + list(range(20000, 20040)))
+def test_streaming_surface_fuzz_against_the_oracle(torch_cuda, seed):
+    """One draw of tests/fuzz_cases.py: random reads (planted MNVs and SNVs, any CIGAR, = and X operations, bases that are no A C G T N,
+    stitched directions), random modes (MNV calling, collapser and its thresholds, ploidy, gVCF, zero-coverage rows, noise model,
+    strand-bias model, quality / depth / frequency thresholds, block size, RMxN, forced alleles) and a random flush schedule through the
+    streaming surface: records, allele strings and TotalNumCalled equal the oracle's run of the same schedule."""
+    from tests.fuzz_cases import one
+    why, kw, rows, forced = one(seed)
+    assert why is None, (seed, why, kw, forced)
