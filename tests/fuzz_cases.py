@@ -13,6 +13,18 @@ from pisces_amd import _abi
 from tests import orc
 
 
+FORMS = [("rows merged by copy", dict(PISCES_HIP_MERGE_IN_PLACE=0), "host"), ("checks on the device", dict(PISCES_HIP_DEVICE_CHECKS=1), "host"),
+         ("checks on the host", dict(PISCES_HIP_DEVICE_CHECKS=0), "host"), ("candidates merged on the host", dict(PISCES_HIP_DEVICE_MERGE=0), "host"),
+         ("candidates merged on the device", dict(PISCES_HIP_DEVICE_MERGE=1), "host"), ("walk base by base", dict(PISCES_HIP_FINDER="bases"), "host"),
+         ("walk a wave a read", dict(PISCES_HIP_FINDER="wave"), "host"), ("walk in batches", dict(PISCES_HIP_FINDER="batch"), "host"),
+         ("genotypes by the host pass", dict(PISCES_HIP_DEVICE_GENOTYPER=0), "host"), ("every batch its own segment", dict(PISCES_HIP_STORE_DIRECT_BYTES=0), "host"),
+         ("every batch appended", dict(PISCES_HIP_STORE_DIRECT_BYTES=1 << 40, PISCES_HIP_STORE_SEAL_BYTES=1 << 40), "host"),
+         ("reads in device memory", {}, "device"), ("candidates looked at after every add", {}, "peek"),
+         ("every candidate group to the host", dict(PISCES_HIP_MNV_SPLIT=0), "host"), ("the observation-log chain", dict(PISCES_HIP_READ_PATH="log"), "host"),
+         ("BAM bytes", {}, "bam"), ("BAM bytes, the log chain", dict(PISCES_HIP_READ_PATH="log"), "bam"),
+         ("reads in device memory, checks on the host's side of things off", dict(PISCES_HIP_DEVICE_MERGE=1), "device")]
+
+
 def one(seed, verbose=False):
     from pisces_amd import engine
     from tests.test_gpu_parity import _mnv_reads, INT_FIELDS
@@ -37,6 +49,14 @@ def one(seed, verbose=False):
     for r in reads:   # (a NUL ends the oracle's allele strings, which are C strings)
         if b"\0" in r["seq"]:
             r["seq"] = r["seq"].replace(b"\0", b".")
+    ext = seed >= 100000   # (and from 200 000: see FORMS)
+    # the wider draw: a deep pile (counts beyond the memo tables), more thresholds, candidates from the host
+    if ext and seed % 3 == 0:
+        a = int(rng.integers(200, L - 700))
+        pile = _mnv_reads(rng, bytearray(ref), int(rng.integers(800, 3500)), region=(a, a + int(rng.integers(200, 400))), snv_rate=0.002)
+        for r in pile:
+            r["seq"] = r["seq"].encode() if isinstance(r["seq"], str) else r["seq"]
+        reads += pile
     reads.sort(key=lambda r: r["pos"])
     ploidy = int(rng.choice([0, 0, 0, 1, 2]))
     kw = dict(call_mnvs=int(rng.integers(0, 2)), max_mnv_length=int(rng.choice([2, 3, 5])), max_gap_between_mnv=int(rng.choice([0, 1, 2])),
@@ -50,6 +70,17 @@ def one(seed, verbose=False):
               expect_stitched_reads=int(rng.choice([0, 0, 1])), collapse_freq_threshold=float(rng.choice([0.0, 0.02])),
               collapse_freq_ratio_threshold=float(rng.choice([0.5, 0.2])), noise_level=int(rng.choice([20, 30])),
               rmxn_min_repetitions=int(rng.choice([9, 4])))
+    if ext:
+        kw.update(strand_bias_threshold=float(rng.choice([0.5, 0.1, 0.9])), no_call_filter_threshold=float(rng.choice([0.6, 0.02, -1.0])),
+                  rmxn_max_repeat_length=int(rng.choice([5, 2, -1])), rmxn_frequency_limit=float(rng.choice([0.35, 1.0])),
+                  genotype_min_freq_filter=float(rng.choice([0.01, 0.05])), target_lod_frequency=float(rng.choice([0.01, 0.05])),
+                  min_genotype_qscore=int(rng.choice([0, 10])), max_variant_qscore=int(rng.choice([100, 60, 3000])),
+                  low_gq_filter=int(rng.choice([-1, 20, 50])))
+        if not ploidy:
+            kw.update(variant_freq_filter=float(rng.choice([0.01, 0.03, 0.1])), max_genotype_qscore=int(rng.choice([100, 40])))
+        else:
+            kw.update(diploid_snv_params=[float(x) for x in rng.choice([[0.20, 0.70, 0.80], [0.10, 0.60, 0.90]])],
+                      diploid_indel_params=[float(x) for x in rng.choice([[0.20, 0.70, 0.80], [0.15, 0.75, 0.85]])])
     if kw["block_size"] < 500:   # (the oracle emits zero-coverage rows over all of its region, the state manager over the blocks that exist)
         kw["emit_zero_coverage_refs"] = 0
     if kw["variant_qscore_filter"] < kw["min_variant_qscore"]:
@@ -81,20 +112,35 @@ def one(seed, verbose=False):
     cuts = sorted(set(int(x) for x in rng.integers(1, len(reads), n_cuts)) | {len(reads)})
     ups = [int(x) for x in sorted(rng.integers(200, L - 200, len(cuts) - 1))] + [None]
     rows, alleles, a0, schedule = [], [], 0, []
-    with engine.HipVariantCaller(cfg) as c:
-        c.SetReference(ref)
-        if forced:
-            c.SetForcedAlleles(forced)
-        for cut, up in zip(cuts, ups):
-            c.AddAlleleCounts(_abi.ReadBatch(reads[a0:cut]))
-            a0 = cut
-            if up is not None:
-                up = min(up, reads[cut - 1]["pos"] - 1)
-                schedule.append(up)
-            r, a = c.CallWithAlleles(up, capacity=1 << 16)
-            rows.append(r)
-            alleles += a
-        called = c.Stats()["TotalNumCalled"]
+    # seeds from 200 000: one of the forms the library can take for the same work (tests/test_gpu_parity.py, the switch test), drawn by the seed
+    form = FORMS[seed % len(FORMS)] if seed >= 200000 else ("default", {}, "host")
+    if form[2] == "bam" and any("dirs" in r or any(ch not in b"ACGTN" for ch in r["seq"]) or any(q > 93 for q in r["quals"]) for r in reads):
+        form = ("default", {}, "host")   # (per-base direction arrays and bases outside the BAM alphabet cannot be written into a BAM record)
+    from tests.test_read_store import env, _bam_of_reads
+    with env(**form[1]):
+        with engine.HipVariantCaller(cfg) as c:
+            c.SetReference(ref)
+            if forced:
+                c.SetForcedAlleles(forced)
+            for cut, up in zip(cuts, ups):
+                part = reads[a0:cut]
+                if form[2] == "device":
+                    c.AddDeviceReads(engine.DeviceReadBatch.from_host(_abi.ReadBatch(part)))
+                elif form[2] == "bam":
+                    assert c.bam_decode(_bam_of_reads(part), 0)["reads"] == len(part)
+                    c.AddDecodedReads()
+                else:
+                    c.AddAlleleCounts(_abi.ReadBatch(part))
+                a0 = cut
+                if form[2] == "peek":
+                    c.GetCandidates(None)
+                if up is not None:
+                    up = min(up, reads[cut - 1]["pos"] - 1)
+                    schedule.append(up)
+                r, a = c.CallWithAlleles(up, capacity=1 << 16)
+                rows.append(r)
+                alleles += a
+            called = c.Stats()["TotalNumCalled"]
     got = np.concatenate(rows)
     # (the oracle's region: the blocks the reads touch — it emits zero-coverage reference rows over all of its region, the state manager
     # only over blocks that exist)
@@ -152,4 +198,6 @@ def one(seed, verbose=False):
                 break
         if why is None and called != exp_called:
             why = "TotalNumCalled %d != %d" % (called, exp_called)
+    if why and form[0] != "default":
+        why = form[0] + ": " + why
     return why, kw, len(got), forced
