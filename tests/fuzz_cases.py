@@ -25,7 +25,7 @@ FORMS = [("rows merged by copy", dict(PISCES_HIP_MERGE_IN_PLACE=0), "host"), ("c
          ("reads in device memory, checks on the host's side of things off", dict(PISCES_HIP_DEVICE_MERGE=1), "device")]
 
 
-def one(seed, verbose=False):
+def one(seed, verbose=False, rows_too=False):
     from pisces_amd import engine
     from tests.test_gpu_parity import _mnv_reads, INT_FIELDS
     from tests.test_read_store import random_reads, _eqx_reads
@@ -81,6 +81,8 @@ def one(seed, verbose=False):
         else:
             kw.update(diploid_snv_params=[float(x) for x in rng.choice([[0.20, 0.70, 0.80], [0.10, 0.60, 0.90]])],
                       diploid_indel_params=[float(x) for x in rng.choice([[0.20, 0.70, 0.80], [0.15, 0.75, 0.85]])])
+    if seed >= 300000:   # (the interval draws, below: their expectation — the oracle's rows inside the intervals — holds with MNV calling off; a failed
+        kw["call_mnvs"] = 0   # MNV at an interval's edge is reallocated among the Reference candidates that exist, which are those inside)
     if kw["block_size"] < 500:   # (the oracle emits zero-coverage rows over all of its region, the state manager over the blocks that exist)
         kw["emit_zero_coverage_refs"] = 0
     if kw["variant_qscore_filter"] < kw["min_variant_qscore"]:
@@ -114,12 +116,28 @@ def one(seed, verbose=False):
     rows, alleles, a0, schedule = [], [], 0, []
     # seeds from 200 000: one of the forms the library can take for the same work (tests/test_gpu_parity.py, the switch test), drawn by the seed
     form = FORMS[seed % len(FORMS)] if seed >= 200000 else ("default", {}, "host")
+    from tests.test_read_store import env, _bam_of_reads
+    # seeds from 300 000: an interval set (ChrIntervalSet).  Reference candidates are made inside the intervals only and a callable allele
+    # outside them is counted and not reported (RegionState.cs:414-447, AlleleCaller.cs:260-263): the rows are the oracle's rows inside
+    intervals = None
+    if seed >= 300000:
+        form = FORMS[seed % len(FORMS)] if seed % 2 else ("default", {}, "host")
+        at, intervals = int(rng.integers(1, 400)), []
+        while at < L - 100:
+            b = at + int(rng.choice([0, 5, 40, 150, 700]))
+            intervals.append((at, min(b, L)))
+            at = b + int(rng.choice([1, 2, 30, 300, 900]))
+        if forced:   # (Factory.SelectForcedAllele keeps the forced alleles inside the intervals)
+            forced = [f for f in forced if any(a <= f[0] <= b for a, b in intervals)] or None
     if form[2] == "bam" and any("dirs" in r or any(ch not in b"ACGTN" for ch in r["seq"]) or any(q > 93 for q in r["quals"]) for r in reads):
         form = ("default", {}, "host")   # (per-base direction arrays and bases outside the BAM alphabet cannot be written into a BAM record)
-    from tests.test_read_store import env, _bam_of_reads
+    if os.environ.get("PISCES_FUZZ_FORM"):   # (development: any seed in a given form)
+        form = ("default", {}, "host") if os.environ["PISCES_FUZZ_FORM"] == "default" else [f for f in FORMS if f[0] == os.environ["PISCES_FUZZ_FORM"]][0]
     with env(**form[1]):
         with engine.HipVariantCaller(cfg) as c:
             c.SetReference(ref)
+            if intervals:
+                c.SetIntervals(intervals)
             if forced:
                 c.SetForcedAlleles(forced)
             for cut, up in zip(cuts, ups):
@@ -148,6 +166,11 @@ def one(seed, verbose=False):
     reach = max(r["pos"] + sum(l for o, l in r["cigar"] if o in "MDN=X") - 1 for r in reads)
     region = min(len(ref), (reach + bs - 1) // bs * bs)
     exp, exp_alleles, exp_called = orc.run_reads_schedule(_abi.ReadBatch(reads), np.frombuffer(ref, np.uint8), 1, region, cfg, schedule, forced=forced or ())
+    exp_all, exp_alleles_all = exp, exp_alleles
+    if intervals:
+        keep = np.array([any(a <= int(p) <= b for a, b in intervals) for p in exp["position"]], dtype=bool)
+        exp, exp_alleles = exp[keep], [x for x, k in zip(exp_alleles, keep) if k]
+        exp_called = called   # (what is counted outside the intervals is the callable alleles there: not compared)
     why = None
     if alleles != exp_alleles:
         why = "alleles"
@@ -200,4 +223,6 @@ def one(seed, verbose=False):
             why = "TotalNumCalled %d != %d" % (called, exp_called)
     if why and form[0] != "default":
         why = form[0] + ": " + why
+    if rows_too:
+        return why, kw, (got, alleles, exp_all, exp_alleles_all, intervals, form), forced
     return why, kw, len(got), forced
