@@ -226,3 +226,87 @@ def one(seed, verbose=False, rows_too=False):
     if rows_too:
         return why, kw, (got, alleles, exp_all, exp_alleles_all, intervals, form), forced
     return why, kw, len(got), forced
+
+
+def one_tuples(seed, verbose=False):
+    """The device-resident surface (pisces_hip_call_tiles: bucketed observation tuples -> records, BASELINE config 2's path): random
+    loci x depth, allele mix, qualities, directions and anchors, tile sizes and unaligned segments, a reference with N and homopolymers,
+    and every threshold of the configuration, against the oracle over the same observations.  Returns (why or None, overrides, rows)."""
+    import torch
+    from types import SimpleNamespace
+    from pisces_amd import engine
+    from tests.test_gpu_parity import run_fused, INT_FIELDS
+    rng = np.random.default_rng(770000 + seed)
+    n_loci, start = int(rng.integers(1, 700)), int(rng.choice([1, 11, 1000]))
+    ref = rng.choice(list(b"ACGT"), start - 1 + n_loci + 40).astype(np.uint8)
+    if seed % 3 == 0:
+        a = int(rng.integers(0, len(ref) - 30)); ref[a:a + int(rng.integers(1, 20))] = ord("N")
+        b = int(rng.integers(0, len(ref) - 30)); ref[b:b + 12] = ord("A"); ref[b + 12:b + 24] = ord("C")
+    depth = int(rng.choice([3, 30, 300, 1500, 6000 if n_loci < 120 else 300]))
+    n_obs = n_loci * depth
+    pos = rng.integers(start, start + n_loci, n_obs).astype(np.int32)
+    if seed % 4 == 1:   # zero-coverage loci and a wholly empty stretch
+        pos = pos[(pos % 7 != 3) & ((pos < start + n_loci // 3) | (pos >= start + n_loci // 3 + min(70, n_loci // 4)))]
+    refa = np.array([_abi.ALLELE_OF_BASE.get(chr(c), 4) for c in ref], np.int64)[pos - 1]
+    vaf = rng.choice([0.0, 0.002, 0.01, 0.05, 0.3, 0.6, 1.0], start + n_loci + 1)[pos]
+    alt = ((refa + 1 + rng.integers(0, 3, len(pos))) % 4)
+    allele = np.where(rng.random(len(pos)) < vaf, alt, refa)
+    noise = rng.random(len(pos))
+    allele = np.where(noise < 0.003, rng.integers(0, 4, len(pos)), allele)          # errors
+    allele = np.where((noise > 0.99) & (noise < 0.995), 4, allele)                   # N
+    allele = np.where(noise > 0.995, 5, allele)                                      # deletion
+    qual = np.where(allele == 5, 255, rng.choice([2, 19, 20, 30, 37, 41], len(pos), p=[.02, .03, .05, .1, .7, .1]))
+    dirs = rng.choice(3, len(pos), p=[.48, .48, .04]) if seed % 5 else rng.choice(3, len(pos), p=[.95, .03, .02])
+    tup = _abi.tuple_pack(np.zeros(len(pos), np.uint32), rng.integers(0, 11, len(pos)), dirs, allele, qual)
+    ploidy = int(rng.choice([0, 0, 0, 1, 2]))
+    kw = dict(include_reference_calls=int(rng.integers(0, 2)), ploidy=ploidy, strand_bias_model=int(rng.choice([1, 1, 2])),
+              min_frequency=0.2 if ploidy else float(rng.choice([0.005, 0.01, 0.05])), min_base_call_quality=int(rng.choice([20, 20, 13, 30, 0])),
+              min_coverage=int(rng.choice([10, 1, 0, 50])), low_depth_filter=int(rng.choice([10, 30, -1])), emit_zero_coverage_refs=int(rng.integers(0, 2)),
+              filter_single_strand=int(rng.integers(0, 2)), min_variant_qscore=int(rng.choice([20, 0, 40])), variant_qscore_filter=int(rng.choice([30, 20, 60])),
+              expect_stitched_reads=int(rng.choice([0, 0, 1])), noise_level=int(rng.choice([20, 30, 15])),
+              rmxn_min_repetitions=int(rng.choice([9, 4])), strand_bias_threshold=float(rng.choice([0.5, 0.1, 0.9])),
+              no_call_filter_threshold=float(rng.choice([0.6, 0.02, -1.0])), rmxn_max_repeat_length=int(rng.choice([5, 2, -1])),
+              rmxn_frequency_limit=float(rng.choice([0.35, 1.0])), genotype_min_freq_filter=float(rng.choice([0.01, 0.05])),
+              target_lod_frequency=float(rng.choice([0.01, 0.05])), min_genotype_qscore=int(rng.choice([0, 10])),
+              max_variant_qscore=int(rng.choice([100, 60, 3000])), low_gq_filter=int(rng.choice([-1, 20, 50])))
+    if kw["variant_qscore_filter"] < kw["min_variant_qscore"]:
+        kw["variant_qscore_filter"] = kw["min_variant_qscore"]
+    if ploidy:
+        kw.update(variant_freq_filter=0.2, low_gq_filter=30, max_genotype_qscore=1000,
+                  diploid_snv_params=[float(x) for x in rng.choice([[0.20, 0.70, 0.80], [0.10, 0.60, 0.90]])])
+    else:
+        kw.update(variant_freq_filter=float(rng.choice([0.01, 0.03, 0.1])), max_genotype_qscore=int(rng.choice([100, 40])))
+    cfg = _abi.default_config(**kw)
+    exp, _ = orc.run_observations(pos, tup, ref, start, n_loci, cfg)
+    tile = int(rng.choice([64, 64, 56, 33, 7]))
+    n_tiles = (n_loci + tile - 1) // tile
+    tiles = np.zeros(n_tiles, dtype=_abi.TILE_DTYPE)
+    pad = bool(rng.integers(0, 2))
+    segs, cursor = [np.full(1 if not pad else 4, _abi.TUPLE_PAD, np.uint32)], 1 if not pad else 4
+    for t in range(n_tiles):
+        l0, l1 = t * tile, min(n_loci, t * tile + tile)
+        m = (pos >= start + l0) & (pos < start + l1)
+        seg = _abi.tuple_with_locus(tup[m], pos[m] - (start + l0))
+        if pad and len(seg) % 4:
+            seg = np.concatenate([seg, np.full(4 - len(seg) % 4, _abi.TUPLE_PAD, np.uint32)])
+        tiles[t] = (start + l0, l1 - l0, cursor, cursor + len(seg))
+        segs.append(seg)
+        cursor += len(seg)
+    view = SimpleNamespace(tuples=torch.from_numpy(np.concatenate(segs).view(np.int32)).cuda(), tiles=torch.from_numpy(tiles.view(np.uint8)).cuda(),
+                           n_tiles=n_tiles, ref=torch.from_numpy(ref).cuda(), ref_len=len(ref))
+    with engine.HipVariantCaller(cfg) as caller:
+        got, _ = run_fused(torch, caller, view, compact=bool(seed % 2))
+    why = None
+    if len(got) != len(exp):
+        why = "rows %d != %d" % (len(got), len(exp))
+    else:
+        for f in list(INT_FIELDS) + ["info", "variant_qscore", "genotype_qscore"]:
+            if not (got[f] == exp[f]).all():
+                why = f
+                if verbose:
+                    for i in np.nonzero((got[f] != exp[f]).reshape(len(got), -1).any(axis=1))[0][:5]:
+                        print("  ", f, int(got["position"][i]), got[f][i], exp[f][i], "cov", int(got["total_coverage"][i]), "sup", int(got["allele_support"][i]))
+                break
+        if why is None and not np.allclose(got["strand_bias_score"], exp["strand_bias_score"], rtol=1e-9, atol=1e-12, equal_nan=True):
+            why = "strand_bias_score"
+    return why, kw, len(got)
