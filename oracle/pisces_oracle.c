@@ -755,6 +755,11 @@ struct OrcState {
     /* forced genotyping alleles (-forcedalleles): sorted by position; [0, n_forced_added) have been handed in as candidates */
     OrcCandidate* forced;
     int32_t n_forced, n_forced_added;
+    /* ChrIntervalSet (sorted, disjoint, inclusive), or none: Reference candidates are made inside it only (RegionState.cs:414-447) and a
+     * callable allele outside it is counted and not reported (AlleleCaller.ShouldReport :260-263).  None: the state's window is the interval. */
+    int32_t* iv_start;
+    int32_t* iv_end;
+    int32_t n_intervals;
 };
 
 OrcState* orc_state_create(int32_t start, int32_t n_loci, int32_t min_bq, int32_t num_anchor_types,
@@ -783,7 +788,34 @@ void orc_state_destroy(OrcState* s)
     free(s->counts); free(s->sumq); free(s->gapped); free(s->cand_head); free(s->cand_tail); free(s->cands);
     free(s->max_allele_endpoint);
     free(s->forced);
+    free(s->iv_start); free(s->iv_end);
     free(s);
+}
+
+void orc_set_intervals(OrcState* s, const int32_t* starts, const int32_t* ends, int32_t n)
+{
+    free(s->iv_start); free(s->iv_end);
+    s->iv_start = s->iv_end = NULL;
+    s->n_intervals = 0;
+    if (n <= 0) return;
+    s->iv_start = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+    s->iv_end = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+    memcpy(s->iv_start, starts, sizeof(int32_t) * (size_t)n);
+    memcpy(s->iv_end, ends, sizeof(int32_t) * (size_t)n);
+    s->n_intervals = n;
+}
+/* ChrIntervalSet.ContainsPosition; without an interval set every position of the window */
+static int inside_intervals(const OrcState* s, int32_t position)
+{
+    if (s->n_intervals == 0) return 1;
+    int lo = 0, hi = s->n_intervals - 1;
+    while (lo <= hi) {
+        const int m = (lo + hi) / 2;
+        if (position < s->iv_start[m]) hi = m - 1;
+        else if (position > s->iv_end[m]) lo = m + 1;
+        else return 1;
+    }
+    return 0;
 }
 
 const int32_t* orc_counts_ptr(const OrcState* s) { return s->counts; }
@@ -2091,8 +2123,8 @@ int64_t orc_call_candidates_max(OrcState* s, const OrcCandidate* list, int64_t n
         /* :109-131.  (ShouldReport: the window is the interval; forced alleles are inside the intervals by Factory.SelectForcedAllele.)
          * IsCallable runs once in each condition, and counts a callable forced allele twice in TotalNumCalled. */
         const int forced = s->n_forced > 0 && is_forced_allele(s, v);
-        if (forced && !is_callable(v, cfg, &totalNumCalled)) v->filters |= 1u << PISCES_FILTER_FORCED_REPORT;   /* IsForcedToReport */
-        if (is_callable(v, cfg, &totalNumCalled) || forced) called[n++] = *v;
+        if (forced && !(is_callable(v, cfg, &totalNumCalled) && inside_intervals(s, v->position))) v->filters |= 1u << PISCES_FILTER_FORCED_REPORT;   /* IsForcedToReport */
+        if ((is_callable(v, cfg, &totalNumCalled) && inside_intervals(s, v->position)) || forced) called[n++] = *v;   /* IsCallable && ShouldReport */
     }
     callable.n -= n_spiked;   /* (owned by failedMnvs) */
     {   /* free every object once */
@@ -2319,6 +2351,7 @@ int64_t orc_call_range_up_to(OrcState* s, const uint8_t* ref_bases, int64_t ref_
             int position = s->start_position + li;
             if (position < first_position || position > last_position) continue;
             if (position > ref_len) break;
+            if (!inside_intervals(s, position)) continue;
             if (refs_at_forced_only) {
                 int here = 0;
                 for (int f = 0; f < s->n_forced && !here; f++) here = s->forced[f].position == position;
@@ -2496,12 +2529,27 @@ int64_t orc_run_reads_blocks(const PiscesReadBatch* b, const uint8_t* ref_bases,
 /* SmallVariantCaller's loop with the reads given first and then a list of upToPosition values, the last batch being the final one
  * (GetCandidatesToProcess(null)): RegionStateManager.GetCandidatesToProcess :283-334 decides which blocks each batch clears.  Every
  * block of the window exists (the window is dense); a batch is skipped while upTo stays in the block of the previous call. */
+int64_t orc_run_reads_schedule_intervals(const PiscesReadBatch* b, const uint8_t* ref_bases, int64_t ref_len, int32_t region_start, int32_t region_loci,
+                                         const PiscesHipConfig* cfg, const int32_t* up_to_positions, int32_t n_up_to, const OrcCandidate* forced,
+                                         int32_t n_forced, const int32_t* iv_starts, const int32_t* iv_ends, int32_t n_intervals,
+                                         PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out, int64_t* total_num_called);
 int64_t orc_run_reads_schedule(const PiscesReadBatch* b, const uint8_t* ref_bases, int64_t ref_len, int32_t region_start, int32_t region_loci,
                                const PiscesHipConfig* cfg, const int32_t* up_to_positions, int32_t n_up_to, const OrcCandidate* forced,
                                int32_t n_forced, PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out, int64_t* total_num_called)
 {
+    return orc_run_reads_schedule_intervals(b, ref_bases, ref_len, region_start, region_loci, cfg, up_to_positions, n_up_to, forced, n_forced, NULL, NULL, 0,
+                                            out, capacity, full_out, total_num_called);
+}
+
+/* ... with a ChrIntervalSet (n_intervals inclusive ranges, sorted and disjoint; 0: none) */
+int64_t orc_run_reads_schedule_intervals(const PiscesReadBatch* b, const uint8_t* ref_bases, int64_t ref_len, int32_t region_start, int32_t region_loci,
+                                         const PiscesHipConfig* cfg, const int32_t* up_to_positions, int32_t n_up_to, const OrcCandidate* forced,
+                                         int32_t n_forced, const int32_t* iv_starts, const int32_t* iv_ends, int32_t n_intervals,
+                                         PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out, int64_t* total_num_called)
+{
     OrcState* s = orc_state_create(region_start, region_loci, cfg->min_base_call_quality, PISCES_ANCHOR_SIZE, cfg->collapse ? 1 : 0);
     orc_track_blocks(s, cfg->block_size);
+    orc_set_intervals(s, iv_starts, iv_ends, n_intervals);
     if (n_forced > 0) orc_set_forced_alleles(s, forced, n_forced);
     OrcCandidate cands[256];
     uint8_t* expanded = NULL;

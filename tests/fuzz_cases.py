@@ -81,8 +81,6 @@ def one(seed, verbose=False, rows_too=False):
         else:
             kw.update(diploid_snv_params=[float(x) for x in rng.choice([[0.20, 0.70, 0.80], [0.10, 0.60, 0.90]])],
                       diploid_indel_params=[float(x) for x in rng.choice([[0.20, 0.70, 0.80], [0.15, 0.75, 0.85]])])
-    if seed >= 300000:   # (the interval draws, below: their expectation — the oracle's rows inside the intervals — holds with MNV calling off; a failed
-        kw["call_mnvs"] = 0   # MNV at an interval's edge is reallocated among the Reference candidates that exist, which are those inside)
     if kw["block_size"] < 500:   # (the oracle emits zero-coverage rows over all of its region, the state manager over the blocks that exist)
         kw["emit_zero_coverage_refs"] = 0
     if kw["variant_qscore_filter"] < kw["min_variant_qscore"]:
@@ -117,8 +115,8 @@ def one(seed, verbose=False, rows_too=False):
     # seeds from 200 000: one of the forms the library can take for the same work (tests/test_gpu_parity.py, the switch test), drawn by the seed
     form = FORMS[seed % len(FORMS)] if seed >= 200000 else ("default", {}, "host")
     from tests.test_read_store import env, _bam_of_reads
-    # seeds from 300 000: an interval set (ChrIntervalSet).  Reference candidates are made inside the intervals only and a callable allele
-    # outside them is counted and not reported (RegionState.cs:414-447, AlleleCaller.cs:260-263): the rows are the oracle's rows inside
+    # seeds from 300 000: an interval set (ChrIntervalSet): Reference candidates inside the intervals only, a callable allele outside them
+    # counted and not reported (RegionState.cs:414-447, AlleleCaller.cs:260-263) — the oracle's schedule takes the set
     intervals = None
     if seed >= 300000:
         form = FORMS[seed % len(FORMS)] if seed % 2 else ("default", {}, "host")
@@ -165,12 +163,13 @@ def one(seed, verbose=False, rows_too=False):
     bs = kw["block_size"]
     reach = max(r["pos"] + sum(l for o, l in r["cigar"] if o in "MDN=X") - 1 for r in reads)
     region = min(len(ref), (reach + bs - 1) // bs * bs)
-    exp, exp_alleles, exp_called = orc.run_reads_schedule(_abi.ReadBatch(reads), np.frombuffer(ref, np.uint8), 1, region, cfg, schedule, forced=forced or ())
+    exp, exp_alleles, exp_called = orc.run_reads_schedule(_abi.ReadBatch(reads), np.frombuffer(ref, np.uint8), 1, region, cfg, schedule, forced=forced or (),
+                                                          intervals=intervals)
     exp_all, exp_alleles_all = exp, exp_alleles
-    if intervals:
-        keep = np.array([any(a <= int(p) <= b for a, b in intervals) for p in exp["position"]], dtype=bool)
-        exp, exp_alleles = exp[keep], [x for x, k in zip(exp_alleles, keep) if k]
-        exp_called = called   # (what is counted outside the intervals is the callable alleles there: not compared)
+    if intervals and not (kw["call_mnvs"] or (kw["collapse"] and (kw["collapse_freq_threshold"] > 0 or kw["collapse_freq_ratio_threshold"] >= 1))):
+        # MNV calling off, SNVs from the allele counts: the tile kernels run over the intervals only, so TotalNumCalled lacks the callable SNVs
+        # OUTSIDE them, which the reference counts and does not report; the rows are all there
+        exp_called = called
     why = None
     if alleles != exp_alleles:
         why = "alleles"

@@ -506,6 +506,25 @@ def test_reference_bams_give_the_vcf_rows_pisces_wrote(name):
     bam_fixtures.check_lines(case, lines, bam_fixtures.expected_lines(name, z))
 
 
+@pytest.mark.parametrize("name", ["bam_chr19", "bam_chr17_again", "bam_chr17_int", "bam_chr17_vcf"])
+def test_reference_bams_through_the_oracle_s_interval_set(name):
+    """The same rows from ONE run of the oracle's block schedule over the whole window with the run's ChrIntervalSet
+    (orc_run_reads_schedule_intervals: Reference candidates inside the intervals only, callable alleles outside them counted and not
+    reported) — what the GPU fuzz's interval draws are checked against, pinned here to the rows Pisces wrote."""
+    from pisces_amd import engine
+    from tests import bam_fixtures
+    case = bam_fixtures.CASES[name]
+    z, batch = bam_fixtures.load(name)
+    off = int(z["offset"])
+    cfg = _abi.default_config(**case["cfg"])
+    intervals = [(a - off, b - off) for a, b in case["intervals"]]
+    recs, alleles, _ = orc.run_reads_schedule(batch, z["ref"], 1, len(z["ref"]), cfg, [], intervals=intervals)
+    recs = recs.copy()
+    recs["position"] += off
+    text = engine.format_vcf(case["chrom"], recs, alleles=alleles, noise_level_from_records=1, **case["vcf"])
+    bam_fixtures.check_lines(case, text.rstrip("\n").split("\n") if text else [], bam_fixtures.expected_lines(name, z))
+
+
 # ---- MnvReallocator (SURVEY section 8 row f2) ------------------------------------------------------------------------------------
 def _norm(rows):
     return sorted((r["position"], r["ref"], r["alt"], r["support"], tuple(r["dirs"]), r["category"]) for r in rows)
