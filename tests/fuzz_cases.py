@@ -22,7 +22,8 @@ FORMS = [("rows merged by copy", dict(PISCES_HIP_MERGE_IN_PLACE=0), "host"), ("c
          ("reads in device memory", {}, "device"), ("candidates looked at after every add", {}, "peek"),
          ("every candidate group to the host", dict(PISCES_HIP_MNV_SPLIT=0), "host"), ("the observation-log chain", dict(PISCES_HIP_READ_PATH="log"), "host"),
          ("BAM bytes", {}, "bam"), ("BAM bytes, the log chain", dict(PISCES_HIP_READ_PATH="log"), "bam"),
-         ("reads in device memory, checks on the host's side of things off", dict(PISCES_HIP_DEVICE_MERGE=1), "device")]
+         ("reads in device memory, checks on the host's side of things off", dict(PISCES_HIP_DEVICE_MERGE=1), "device"),
+         ("the flush pair", {}, "pair"), ("the flush pair, the next batch added before the rows are taken", {}, "pair ahead")]
 
 
 def one(seed, verbose=False, rows_too=False):
@@ -138,6 +139,7 @@ def one(seed, verbose=False, rows_too=False):
                 c.SetIntervals(intervals)
             if forced:
                 c.SetForcedAlleles(forced)
+            pending = False
             for cut, up in zip(cuts, ups):
                 part = reads[a0:cut]
                 if form[2] == "device":
@@ -148,12 +150,28 @@ def one(seed, verbose=False, rows_too=False):
                 else:
                     c.AddAlleleCounts(_abi.ReadBatch(part))
                 a0 = cut
+                if pending:   # (the flush that was begun before this batch was added: its blocks lie below every read of the batch)
+                    r, a = c.CallEndWithAlleles(capacity=1 << 16)
+                    rows.append(r)
+                    alleles += a
+                    pending = False
                 if form[2] == "peek":
                     c.GetCandidates(None)
                 if up is not None:
                     up = min(up, reads[cut - 1]["pos"] - 1)
                     schedule.append(up)
-                r, a = c.CallWithAlleles(up, capacity=1 << 16)
+                if form[2] in ("pair", "pair ahead"):
+                    c.CallBegin(up)
+                    if form[2] == "pair ahead":
+                        pending = True
+                        continue
+                    r, a = c.CallEndWithAlleles(capacity=1 << 16)
+                else:
+                    r, a = c.CallWithAlleles(up, capacity=1 << 16)
+                rows.append(r)
+                alleles += a
+            if pending:
+                r, a = c.CallEndWithAlleles(capacity=1 << 16)
                 rows.append(r)
                 alleles += a
             called = c.Stats()["TotalNumCalled"]
