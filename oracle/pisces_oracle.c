@@ -2529,6 +2529,11 @@ int64_t orc_run_reads_blocks(const PiscesReadBatch* b, const uint8_t* ref_bases,
 /* SmallVariantCaller's loop with the reads given first and then a list of upToPosition values, the last batch being the final one
  * (GetCandidatesToProcess(null)): RegionStateManager.GetCandidatesToProcess :283-334 decides which blocks each batch clears.  Every
  * block of the window exists (the window is dense); a batch is skipped while upTo stays in the block of the previous call. */
+/* the candidates the next orc_run_reads_schedule* adds to its state before the schedule runs (a host's own AddCandidates); n = 0 clears */
+static const OrcCandidate* g_host_candidates = NULL;
+static int32_t g_host_candidates_n = 0;
+void orc_schedule_host_candidates(const OrcCandidate* list, int32_t n) { g_host_candidates = list; g_host_candidates_n = n; }
+
 int64_t orc_run_reads_schedule_intervals(const PiscesReadBatch* b, const uint8_t* ref_bases, int64_t ref_len, int32_t region_start, int32_t region_loci,
                                          const PiscesHipConfig* cfg, const int32_t* up_to_positions, int32_t n_up_to, const OrcCandidate* forced,
                                          int32_t n_forced, const int32_t* iv_starts, const int32_t* iv_ends, int32_t n_intervals,
@@ -2550,6 +2555,9 @@ int64_t orc_run_reads_schedule_intervals(const PiscesReadBatch* b, const uint8_t
     OrcState* s = orc_state_create(region_start, region_loci, cfg->min_base_call_quality, PISCES_ANCHOR_SIZE, cfg->collapse ? 1 : 0);
     orc_track_blocks(s, cfg->block_size);
     orc_set_intervals(s, iv_starts, iv_ends, n_intervals);
+    /* candidates the host hands in beside the reads' (IStateManager.AddCandidates, SmallVariantCaller.cs:92-96): orc_schedule_host_candidates */
+    for (int i = 0; i < g_host_candidates_n; i++)
+        if (g_host_candidates[i].position >= region_start && g_host_candidates[i].position < region_start + region_loci) orc_add_candidate(s, &g_host_candidates[i]);
     if (n_forced > 0) orc_set_forced_alleles(s, forced, n_forced);
     OrcCandidate cands[256];
     uint8_t* expanded = NULL;

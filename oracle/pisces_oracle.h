@@ -205,7 +205,8 @@ int64_t orc_run_reads_schedule_intervals(const PiscesReadBatch* batch, const uin
                                          const PiscesHipConfig* cfg, const int32_t* up_to_positions, int32_t n_up_to, const OrcCandidate* forced,
                                          int32_t n_forced, const int32_t* iv_starts, const int32_t* iv_ends, int32_t n_intervals,
                                          PiscesCalledAllele* out, int64_t capacity, OrcCalled* full_out, int64_t* total_num_called);
-void orc_set_intervals(OrcState* s, const int32_t* starts, const int32_t* ends, int32_t n);                  /* RegionStateManager.cs:283-334; forced alleles: SmallVariantCaller.cs:49-77,118-150 */
+void orc_set_intervals(OrcState* s, const int32_t* starts, const int32_t* ends, int32_t n);
+void orc_schedule_host_candidates(const OrcCandidate* list, int32_t n);   /* IStateManager.AddCandidates beside the reads', for the next orc_run_reads_schedule* (n = 0 clears) */                  /* RegionStateManager.cs:283-334; forced alleles: SmallVariantCaller.cs:49-77,118-150 */
 void    orc_diploid_locus_process(OrcCalled* alleles_at_position, int32_t n);             /* DiploidLocusProcessor.cs:13-52 */
 void    orc_set_forced_alleles(OrcState* s, const OrcCandidate* list, int32_t n);       /* Factory.cs:56-96,270-286 */
 void    orc_add_forced_as_candidates(OrcState* s, int32_t up_to_position);              /* SmallVariantCaller.cs:118-132 */

@@ -814,9 +814,16 @@ static int32_t split_prepare(PiscesHip* h, const std::vector<int32_t>& keys, int
     // (their SNVs are called by call_spanning, from the counts less those bases)
     const bool unwalked_mode = !h->snv_walk;
     if (!h->mnv_split && !unwalked_mode) return PISCES_OK;
+    // (and the loci of the SNV candidates the host handed in — pisces_hip_add_candidates: what the reads show joins them there)
+    // (a forced SNV nobody gave support stays where it was: the tile kernels report it when it is callable, call_spanning when it is not)
+    auto own_snv = [&](const HostCandidate& c) { return c.category == PISCES_CAT_SNV && (cand_support(c) > 0 || h->forced.empty() || !is_forced_allele(h, c)); };
     if (unwalked_mode) {
         bool some = false;
-        for (int32_t key : keys) some = some || !h->blocks[key].unwalked.empty();
+        for (int32_t key : keys) {
+            const BlockObs& b = h->blocks[key];
+            some = some || !b.unwalked.empty();
+            for (auto& c : b.cands) some = some || own_snv(c);
+        }
         if (!some) return PISCES_OK;
     } else
     h->P.refs_only = 0;
@@ -869,8 +876,11 @@ static int32_t split_prepare(PiscesHip* h, const std::vector<int32_t>& keys, int
         if (of_the_batch) carry(c.position, end);
     };
     if (unwalked_mode) {
-        for (int32_t key : keys)
+        for (int32_t key : keys) {
             for (auto& u : h->blocks[key].unwalked) mark(u.position, u.position);
+            for (auto& c : h->blocks[key].cands)
+                if (own_snv(c)) mark(c.position, c.position);
+        }
     } else if (!h->forced.empty()) {
         mark(lo, hi);   // forced alleles: every candidate of the batch is an object on the host, as before
     } else {
@@ -1059,6 +1069,9 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
             const auto& u = h->blocks[key].unwalked;
             unw.insert(unw.end(), u.begin(), u.end());
         }
+        for (auto& c : work)   // an SNV candidate the host handed in: its locus is dirty; the other bases of the locus are made below, from the counts
+            if (c.category == PISCES_CAT_SNV && split_dirty_at(h, c.position) && c.alt.size() == 1 && std::binary_search(keys.begin(), keys.end(), block_key(h, c.position)))
+                unw.push_back({c.position, (uint8_t)c.alt[0], {0, 0, 0}});
         if (max_cleared >= 0) {   // (SNV candidates of held blocks that joined the batch — forced ones: what the reads so far show at their positions)
             std::vector<int32_t> seen;
             for (auto& c : work) {
@@ -1222,7 +1235,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
             const bool may_fold = c.category != PISCES_CAT_INSERTION;
             if (mnv_mode && c.category == PISCES_CAT_MNV)
                 for (int32_t p = sp; p <= ep; p++) want(p, true);
-            else if (any_open || (have_forced && c.category == PISCES_CAT_SNV)) { want(sp, may_fold); want(ep, may_fold); }
+            else if (any_open || ((have_forced || !h->snv_walk) && c.category == PISCES_CAT_SNV)) { want(sp, may_fold); want(ep, may_fold); }
         }
         for (auto& u : unw) want(u.position, true);
         std::sort(need.begin(), need.end());
@@ -1250,19 +1263,21 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         host_counts_p = h->h_counts;
     }
     struct { const int32_t* p; const int32_t* data() const { return p; } } host_counts = {host_counts_p};
-    if (!h->snv_walk && have_forced) {
-        // MNV calling off: SNV candidates are the allele counts and never reach the host, so a forced SNV (added without support) takes
-        // the support the merged candidate of the reference has: the reads that show the base at or above the quality threshold
+    if (!h->snv_walk) {
+        // MNV calling off: the reads' SNV candidates are the allele counts and never reach the host, so an SNV candidate that IS an object
+        // here — a forced allele (added without support), one the host handed in (with its own) — takes the support the merged candidate of
+        // the reference has: the reads that show the base at or above the quality threshold join it
         for (auto& c : work) {
-            if (c.category != PISCES_CAT_SNV || cand_support(c) != 0 || !is_forced_allele(h, c)) continue;
+            if (c.category != PISCES_CAT_SNV || c.alt.size() != 1 || c.counted_by_dir[0] + c.counted_by_dir[1] + c.counted_by_dir[2] != 0) continue;
             const int64_t li = row_index(locus_index(c.position));
             const int at = atype(c.alt[0]);
             if (li < 0 || at >= 4) continue;
             for (int d = 0; d < 3; d++) {
                 const int32_t* row = host_counts.data() + li * PISCES_COUNTS_PER_LOCUS + (at * 3 + d) * PISCES_NUM_ANCHORS;
+                const int32_t own = c.support_by_dir[d];
                 for (int an = 0; an < PISCES_NUM_ANCHORS; an++) c.support_by_dir[d] += row[an];
-                c.support_by_dir[d] = std::max(0, c.support_by_dir[d] - unwalked_of(c.position, c.alt[0], d));   // (less what no candidate stands for)
-                c.counted_by_dir[d] = c.support_by_dir[d];
+                c.support_by_dir[d] = std::max(own, c.support_by_dir[d] - unwalked_of(c.position, c.alt[0], d));   // (less what no candidate stands for)
+                c.counted_by_dir[d] = c.support_by_dir[d] - own;
             }
         }
     }

@@ -132,6 +132,29 @@ def one(seed, verbose=False, rows_too=False):
         form = ("default", {}, "host")   # (per-base direction arrays and bases outside the BAM alphabet cannot be written into a BAM record)
     if os.environ.get("PISCES_FUZZ_FORM"):   # (development: any seed in a given form)
         form = ("default", {}, "host") if os.environ["PISCES_FUZZ_FORM"] == "default" else [f for f in FORMS if f[0] == os.environ["PISCES_FUZZ_FORM"]][0]
+    # seeds from 500 000: candidates the host hands in itself (IStateManager.AddCandidates) behind the last batch, beyond every flush of the
+    # schedule: an SNV, an insertion, a deletion and (MNV calling on) an MNV with support of their own, at positions reads cover
+    host_cands = []
+    if seed >= 500000:
+        hi_reads = max(r["pos"] for r in reads)
+        base = hi_reads + 2   # (every flush of the schedule lies below the last read's start)
+        other = lambda p: "ACGT"[("ACGT".index(chr(ref[p - 1])) + 1) % 4] if chr(ref[p - 1]) in "ACGT" else "A"
+        ok = lambda p, n: all(chr(x) in "ACGT" for x in ref[p - 1:p - 1 + n])
+        sup = lambda: tuple(int(x) for x in rng.integers(0, 6, 2)) + (0,)
+        p = base + int(rng.integers(0, 20))
+        if ok(p, 1):
+            s1 = sup(); host_cands.append(dict(position=p, category=_abi.CAT_SNV, ref=chr(ref[p - 1]), alt=other(p), support_by_dir=s1, well_anchored_by_dir=s1))
+        p = base + 25 + int(rng.integers(0, 10))
+        if ok(p, 1):
+            s1 = sup(); host_cands.append(dict(position=p, category=_abi.CAT_INSERTION, ref=chr(ref[p - 1]), alt=chr(ref[p - 1]) + "GT", support_by_dir=s1, well_anchored_by_dir=s1))
+        p = base + 40 + int(rng.integers(0, 10))
+        if ok(p, 4):
+            s1 = sup(); host_cands.append(dict(position=p, category=_abi.CAT_DELETION, ref=ref[p - 1:p + 2].decode(), alt=chr(ref[p - 1]), support_by_dir=s1, well_anchored_by_dir=s1))
+        p = base + 55 + int(rng.integers(0, 10))
+        if kw["call_mnvs"] and ok(p, 2):
+            s1 = sup(); host_cands.append(dict(position=p, category=_abi.CAT_MNV, ref=ref[p - 1:p + 1].decode(), alt=other(p) + other(p + 1), support_by_dir=s1, well_anchored_by_dir=s1))
+        if intervals:
+            host_cands = [h for h in host_cands if any(a <= h["position"] <= b for a, b in intervals)]
     with env(**form[1]):
         with engine.HipVariantCaller(cfg) as c:
             c.SetReference(ref)
@@ -150,6 +173,8 @@ def one(seed, verbose=False, rows_too=False):
                 else:
                     c.AddAlleleCounts(_abi.ReadBatch(part))
                 a0 = cut
+                if host_cands and cut == cuts[-1]:
+                    c.AddCandidates(host_cands)
                 if pending:   # (the flush that was begun before this batch was added: its blocks lie below every read of the batch)
                     r, a = c.CallEndWithAlleles(capacity=1 << 16)
                     rows.append(r)
@@ -182,7 +207,7 @@ def one(seed, verbose=False, rows_too=False):
     reach = max(r["pos"] + sum(l for o, l in r["cigar"] if o in "MDN=X") - 1 for r in reads)
     region = min(len(ref), (reach + bs - 1) // bs * bs)
     exp, exp_alleles, exp_called = orc.run_reads_schedule(_abi.ReadBatch(reads), np.frombuffer(ref, np.uint8), 1, region, cfg, schedule, forced=forced or (),
-                                                          intervals=intervals)
+                                                          intervals=intervals, host_candidates=host_cands)
     exp_all, exp_alleles_all = exp, exp_alleles
     if intervals and not (kw["call_mnvs"] or (kw["collapse"] and (kw["collapse_freq_threshold"] > 0 or kw["collapse_freq_ratio_threshold"] >= 1))):
         # MNV calling off, SNVs from the allele counts: the tile kernels run over the intervals only, so TotalNumCalled lacks the callable SNVs
@@ -194,6 +219,9 @@ def one(seed, verbose=False, rows_too=False):
         if verbose:
             ga = set(zip(got["position"].tolist(), alleles)); ea = set(zip(exp["position"].tolist(), exp_alleles))
             print("  only product:", sorted(ga - ea)[:10]); print("  only oracle:", sorted(ea - ga)[:10])
+            pa, ea_ = list(zip(got["position"].tolist(), alleles)), list(zip(exp["position"].tolist(), exp_alleles))
+            k = next((i for i in range(min(len(pa), len(ea_))) if pa[i] != ea_[i]), min(len(pa), len(ea_)))
+            print("  first difference at row", k, "product", pa[max(0, k - 2):k + 3], "oracle", ea_[max(0, k - 2):k + 3], "host candidates", host_cands, "forced", forced)
             print("  cuts", cuts, "schedule", schedule, "read positions at cuts", [reads[c - 1]["pos"] for c in cuts])
             for (p, (ra, aa)) in sorted((ga - ea) | (ea - ga))[:6]:
                 if len(ra) != 1 or len(aa) != 1:

@@ -484,10 +484,11 @@ def run_reads_blocks(batch, ref, region_start, region_loci, cfg):
     return out[:n], [(full[i].ref.decode("latin-1"), full[i].alt.decode("latin-1")) for i in range(n)], total.value
 
 
-def run_reads_schedule(batch, ref, region_start, region_loci, cfg, up_to_positions, forced=(), intervals=None):
+def run_reads_schedule(batch, ref, region_start, region_loci, cfg, up_to_positions, forced=(), intervals=None, host_candidates=()):
     """run_reads_full with GetCandidatesToProcess(upTo) for every upTo of the list and then the final batch (RegionStateManager.cs:283-334,
     with AddCollapsableFromOtherBlocks); forced = [(position, ref, alt)] forced genotyping alleles of the chromosome; intervals = the
-    ChrIntervalSet [(first, last)] (sorted, disjoint, inclusive) or None."""
+    ChrIntervalSet [(first, last)] (sorted, disjoint, inclusive) or None; host_candidates = candidate dicts (engine.AddCandidates' form) the
+    host hands in behind the reads."""
     refa = np.ascontiguousarray(ref, np.uint8)
     cap = region_loci * 5 + 16
     out = np.zeros(cap, dtype=_abi.CALLED_ALLELE_DTYPE)
@@ -500,11 +501,15 @@ def run_reads_schedule(batch, ref, region_start, region_loci, cfg, up_to_positio
     full = (OrcCalled * cap)()
     ivs = np.ascontiguousarray([a for a, _ in (intervals or [])], np.int32)
     ive = np.ascontiguousarray([b for _, b in (intervals or [])], np.int32)
+    hc = (OrcCandidate * max(len(host_candidates), 1))(*[make_candidate(d["position"], d["category"], d["ref"], d["alt"], d["support_by_dir"], d["well_anchored_by_dir"])
+                                                        for d in host_candidates])
+    lib.orc_schedule_host_candidates(hc, C.c_int32(len(host_candidates)))   # (IStateManager.AddCandidates behind the reads, before the schedule)
     lib.orc_run_reads_schedule_intervals.restype = C.c_int64
     n = lib.orc_run_reads_schedule_intervals(C.byref(batch.c), refa.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int64(len(refa)), C.c_int32(region_start),
                                              C.c_int32(region_loci), C.byref(cfg), ups.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int32(len(ups)),
                                              fa, C.c_int32(len(forced)), ivs.ctypes.data_as(C.POINTER(C.c_int32)), ive.ctypes.data_as(C.POINTER(C.c_int32)),
                                              C.c_int32(len(ivs)), C.c_void_p(out.ctypes.data), C.c_int64(cap), full, C.byref(total))
+    lib.orc_schedule_host_candidates(None, C.c_int32(0))
     assert n >= 0, n
     return out[:n], [(full[i].ref.decode("latin-1"), full[i].alt.decode("latin-1")) for i in range(n)], total.value
 
