@@ -82,6 +82,8 @@ def one(seed, verbose=False, rows_too=False):
         else:
             kw.update(diploid_snv_params=[float(x) for x in rng.choice([[0.20, 0.70, 0.80], [0.10, 0.60, 0.90]])],
                       diploid_indel_params=[float(x) for x in rng.choice([[0.20, 0.70, 0.80], [0.15, 0.75, 0.85]])])
+    if seed >= 600000:   # collapser thresholds that keep twins apart (the read walk makes the SNV candidates whatever MNV calling is: section 7)
+        kw.update(collapse=1, collapse_freq_threshold=float(rng.choice([0.0, 0.02, 0.1])), collapse_freq_ratio_threshold=float(rng.choice([1.0, 2.0, 0.5])))
     if kw["block_size"] < 500:   # (the oracle emits zero-coverage rows over all of its region, the state manager over the blocks that exist)
         kw["emit_zero_coverage_refs"] = 0
     if kw["variant_qscore_filter"] < kw["min_variant_qscore"]:

@@ -2236,7 +2236,7 @@ FUZZ_SEEDS_THAT_ONCE_DIFFERED = [101, 213, 353, 369, 466, 1874, 1878, 6065, 5001
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", FUZZ_SEEDS_THAT_ONCE_DIFFERED + list(range(20000, 20030)) + list(range(100000, 100020)) + list(range(200000, 200060)) + list(range(300000, 300030)) + list(range(500000, 500030)))
+@pytest.mark.parametrize("seed", FUZZ_SEEDS_THAT_ONCE_DIFFERED + list(range(20000, 20030)) + list(range(100000, 100020)) + list(range(200000, 200060)) + list(range(300000, 300030)) + list(range(500000, 500030)) + list(range(600000, 600020)))
 def test_streaming_surface_fuzz_against_the_oracle(torch_cuda, seed):
     """One draw of tests/fuzz_cases.py: random reads (planted MNVs and SNVs, any CIGAR, = and X operations, bases that are no A C G T N,
     stitched directions), random modes (MNV calling, collapser and its thresholds, ploidy, gVCF, zero-coverage rows, noise model,
@@ -2244,7 +2244,8 @@ def test_streaming_surface_fuzz_against_the_oracle(torch_cuda, seed):
     streaming surface: records, allele strings and TotalNumCalled equal the oracle's run of the same schedule.  Seeds from 100 000 add a
     deep pile (counts beyond the memo tables) and more thresholds; seeds from 200 000 run one of the twenty forms the library can take
     (fuzz_cases.FORMS: every environment switch, reads in device memory, the observation-log chain, BAM bytes), three draws each; seeds
-    from 300 000 an interval set (the oracle's schedule takes it); seeds from 500 000 candidates the host hands in itself."""
+    from 300 000 an interval set (the oracle's schedule takes it); seeds from 500 000 candidates the host hands in itself; seeds from 600 000 collapser thresholds
+    that keep an open-ended SNV and its twin apart."""
     from tests.fuzz_cases import one
     why, kw, rows, forced = one(seed)
     assert why is None, (seed, why, kw, forced)
