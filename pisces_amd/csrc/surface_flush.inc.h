@@ -800,6 +800,8 @@ static int32_t snv_store_sweep(PiscesHip* h, const uint32_t* d_bm, int32_t bm_fi
 // The dirty loci of the batch `keys` (and, when alleles of the cleared blocks reach past the last cleared position, of the held blocks up
 // to upTo whose candidates AddCollapsableFromOtherBlocks will bring in), as a bit map on host and device; the SNV groups on them join
 // their blocks' candidates; DeviceParams is set for the tile kernels of this flush.  split_restore() undoes the latter.
+// When the SNVs are the allele counts' (MNV calling off, PiscesHip::snv_walk false) the same bit map marks the few loci where they are
+// not: bases of X / = operations (BlockObs::unwalked) and SNV candidates the host handed in; call_spanning makes those loci's candidates.
 static void split_restore(PiscesHip* h)
 {
     h->P.dirty_bits = nullptr;
@@ -825,8 +827,9 @@ static int32_t split_prepare(PiscesHip* h, const std::vector<int32_t>& keys, int
             for (auto& c : b.cands) some = some || own_snv(c);
         }
         if (!some) return PISCES_OK;
-    } else
-    h->P.refs_only = 0;
+    } else {
+        h->P.refs_only = 0;
+    }
     if (keys.empty()) return PISCES_OK;
     const int bs = h->cfg.block_size;
     const int64_t lo = (int64_t)(keys.front() - 1) * bs + 1, hi = (int64_t)keys.back() * bs;
@@ -1317,6 +1320,9 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
         // the SNV candidates of the loci with unwalked bases: what the reads show there (the counts) less those bases
         static const char kAcgt[4] = {'A', 'C', 'G', 'T'};
         const size_t n_before = work.size();
+        std::unordered_set<uint64_t> snv_there;   // (position, base) of the SNV candidates that are objects already: forced alleles, the host's (support taken above)
+        for (auto& c : work)
+            if (c.category == PISCES_CAT_SNV && c.alt.size() == 1) snv_there.insert(((uint64_t)(uint32_t)c.position << 8) | (uint8_t)c.alt[0]);
         for (size_t i = 0; i < unw.size();) {
             const int32_t p = unw[i].position;
             while (i < unw.size() && unw[i].position == p) i++;
@@ -1326,10 +1332,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
             if (atype(rb) >= 4 || li < 0) continue;
             for (char ab : kAcgt) {
                 if (ab == rb) continue;
-                bool there = false;   // (a forced SNV: it has taken its support above)
-                for (size_t k = 0; k < n_before && !there; k++)
-                    there = work[k].position == p && work[k].category == PISCES_CAT_SNV && work[k].alt.size() == 1 && work[k].alt[0] == ab;
-                if (there) continue;
+                if (snv_there.count(((uint64_t)(uint32_t)p << 8) | (uint8_t)ab)) continue;
                 HostCandidate c;
                 c.position = p;
                 c.category = PISCES_CAT_SNV;
