@@ -2257,7 +2257,7 @@ def test_device_resident_surface_fuzz_against_the_oracle(torch_cuda, seed):
     """One draw of fuzz_cases.one_tuples: bucketed observation tuples (1 to 700 loci at 3x to 6000x, any allele mix, qualities, directions,
     tile sizes 7 to 64, padded or unaligned segments, N and homopolymers in the reference) and every threshold of the configuration
     through pisces_hip_call_tiles (slot layout or compacted): every field of every record equals the oracle's over the same observations
-    (12 600 draws were run beside the suite: tools/fuzz_oracle.py tuples first n)."""
+    (52 600 draws were run beside the suite: tools/fuzz_oracle.py tuples first n)."""
     from tests.fuzz_cases import one_tuples
     why, kw, rows = one_tuples(seed)
     assert why is None, (seed, why, kw)
