@@ -821,14 +821,23 @@ def main():
     torch.cuda.empty_cache()
     n_tiles = ring[0].n_tiles
     cap = n_tiles * _abi.SLOTS_PER_TILE   # slot layout (include/pisces_hip.h PiscesTileResult): no allocation atomics
-    records = torch.zeros(cap * 64, dtype=torch.uint8, device=dev)
-    tile_results = torch.zeros(n_tiles * _abi.TILE_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-    stream = torch.cuda.Stream(dev) if os.environ.get('BENCH_OWN_STREAM') else torch.cuda.current_stream(dev)
+    # Stream discipline: the launches go to the handle's own (non-blocking) stream, which does not order against torch's default (null)
+    # stream.  Every output buffer of this run — the pipelined figure's per-lane ones too — is therefore allocated and zero-filled HERE, on
+    # the handle's stream (engine.torch_stream(): an ExternalStream over pisces_hip_get_stream), and the device is synchronised once before
+    # the first launch; no torch allocation sits between two library calls below.
+    stream = caller.torch_stream()
+    with torch.cuda.stream(stream):
+        records = torch.zeros(cap * 64, dtype=torch.uint8, device=dev)
+        tile_results = torch.zeros(n_tiles * _abi.TILE_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        n_extra = 0 if args.no_pipelined else PIPELINE_STREAMS - 1
+        p_records = [records] + [torch.zeros_like(records) for _ in range(n_extra)]
+        p_results = [tile_results] + [torch.zeros_like(tile_results) for _ in range(n_extra)]
+    torch.cuda.synchronize(dev)
 
     def step(i):
         p = ring[i % RING_BATCHES]
         caller.call_tiles(p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), p.ref_start, p.ref_len,
-                          records.data_ptr(), cap, tile_results.data_ptr(), stream.cuda_stream)
+                          records.data_ptr(), cap, tile_results.data_ptr(), stream)
 
     def barrier():
         if use_dist:
@@ -855,13 +864,13 @@ def main():
     barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    caller.mark(0, stream.cuda_stream)     # HIP events on the stream the kernel is launched on (torch.cuda.Event would see torch's only)
+    caller.mark(0, stream)     # HIP events on the stream the kernel is launched on (torch.cuda.Event would see torch's only)
     if use_graph:
-        caller.call_tiles_graph_launch(graph_id, stream.cuda_stream)
+        caller.call_tiles_graph_launch(graph_id, stream)
     else:
         for i in range(args.steps):
             step(args.warmup + i)
-    caller.mark(1, stream.cuda_stream)
+    caller.mark(1, stream)
     totals = caller.device_totals()        # (waits for the device: hipDeviceSynchronize, then the totals of the K launches)
     summary = torch.tensor([totals["records"], totals["candidate_loci"], totals["called"], totals["tiles"]], dtype=torch.int64)
     if use_dist:
@@ -929,9 +938,7 @@ def main():
     if not args.no_pipelined:
         # pisces_hip_call_tiles_batched spreads the launches over the handle's own HIP streams ("lanes"); every batch in flight needs its
         # own output buffers
-        p_records = [records] + [torch.zeros_like(records) for _ in range(PIPELINE_STREAMS - 1)]
-        p_results = [tile_results] + [torch.zeros_like(tile_results) for _ in range(PIPELINE_STREAMS - 1)]
-
+        # (allocated with the other buffers in front of the first launch: see "Stream discipline" above)
         def pbatches(first, n):
             out = []
             for i in range(first, first + n):

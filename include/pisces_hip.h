@@ -505,6 +505,12 @@ int32_t pisces_hip_kernel_time(PiscesHip* h, double* total_ms, int64_t* launches
 int32_t pisces_hip_probe_read_bandwidth(PiscesHip* h, int64_t nbytes, int32_t reps, double* gb_per_s);
 /* waits for the handle's stream */
 int32_t pisces_hip_synchronize(PiscesHip* h);
+/* The handle's own stream (a hipStream_t), i.e. what a NULL `stream` argument of the calls above stands for.  It is created
+ * hipStreamNonBlocking: it does NOT order against HIP's null stream.  A host whose runtime fills or allocates-and-zeroes device
+ * buffers on the null stream (PyTorch's default stream is the null stream) must therefore either enqueue that work on this stream
+ * (torch.cuda.ExternalStream over the value returned here) or wait for it before handing the buffers to the library; passing its
+ * own null-stream handle (0) as `stream` selects THIS stream, not the null stream, and orders nothing. */
+int32_t pisces_hip_get_stream(PiscesHip* h, void** stream);
 /* duration of the most recent timed launch of the current window, in milliseconds (PISCES_E_STATE when timing is off) */
 int32_t pisces_hip_last_kernel_ms(PiscesHip* h, float* ms);
 

@@ -1073,6 +1073,15 @@ int32_t pisces_hip_synchronize(PiscesHip* h)
     });
 }
 
+int32_t pisces_hip_get_stream(PiscesHip* h, void** stream)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h || !stream) return PISCES_E_INVALID_ARG;
+    *stream = (void*)h->stream;
+    return PISCES_OK;
+    });
+}
+
 int32_t pisces_hip_last_kernel_ms(PiscesHip* h, float* ms)
 {
     return abi_guard<int32_t>(h, [&]() -> int32_t {

@@ -1599,12 +1599,13 @@ int32_t pisces_hip_flush_ex(PiscesHip* h, int32_t up_to_position, PiscesCalledAl
     if (n_cand) *n_cand = 0;
     if (allele_bytes) *allele_bytes = 0;
     if (h->async.state != 0) return fail(h, PISCES_E_STATE, "flush: pisces_hip_flush_begin is waiting for its pisces_hip_flush_end");
-    // The candidates of the last batch are waited for unless every read of it starts behind upTo: then none of them lies in a block this
-    // flush clears, nor among the candidates it may take from held blocks (SNVs / MNVs that end at or before upTo) — and a host that adds
+    // The candidates of the last batch are waited for unless every read of it starts MORE THAN ONE position behind upTo (a read whose first
+    // operation is I or D puts its candidate at position - 1: finder_walk.h, CandidateVariantFinder.cs:52-76): then none of them lies in a
+    // block this flush clears, nor among the candidates it may take from held blocks (SNVs / MNVs that end at or before upTo) — and a host that adds
     // the next stretch of reads before it calls up to their first position (SmallVariantCaller's LastClearedPosition) has the device
     // discover that stretch's candidates under this flush's host work.
     { int32_t rcd = finish_candidate_discovery(h); if (rcd) return rcd; }   // (the records of the last batch's walk go on their way before this flush's kernels)
-    if (!(up_to_position >= 0 && h->found.in_flight && h->found.min_position > up_to_position && !h->pending_valid)) { int32_t rcf = consume_found(h); if (rcf) return rcf; }
+    if (!(up_to_position >= 0 && h->found.in_flight && h->found.min_position - 1 > up_to_position && !h->pending_valid)) { int32_t rcf = consume_found(h); if (rcf) return rcf; }
     const bool final_flush = up_to_position < 0;
     const bool replay = h->pending_valid && h->pending_up_to == up_to_position;
     if (!replay) {
@@ -2157,7 +2158,7 @@ int32_t pisces_hip_flush_begin(PiscesHip* h, int32_t up_to_position)
     { int32_t rcp = refuse_while_batch_is_open(h, "flush_begin"); if (rcp) return rcp; }
     PISCES_HIP_CHECK(h, hipSetDevice(h->device));
     { int32_t rcd = finish_candidate_discovery(h); if (rcd) return rcd; }
-    if (!(up_to_position >= 0 && h->found.in_flight && h->found.min_position > up_to_position)) { int32_t rcf = consume_found(h); if (rcf) return rcf; }
+    if (!(up_to_position >= 0 && h->found.in_flight && h->found.min_position - 1 > up_to_position)) { int32_t rcf = consume_found(h); if (rcf) return rcf; }
     const bool final_flush = up_to_position < 0;
     auto& A = h->async;
     // the batch GetCandidatesToProcess would build (as pisces_hip_flush_ex)

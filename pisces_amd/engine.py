@@ -68,6 +68,7 @@ class HipVariantCaller:
     # ---- lifetime (C# IDisposable) ----
     def close(self):
         if getattr(self, "_h", None):
+            self._torch_stream = None   # (an ExternalStream over the handle's stream: dead with the handle)
             lib.pisces_hip_destroy(self._h)
             self._h = None
 
@@ -390,10 +391,39 @@ class HipVariantCaller:
         return {"h2d_reads": int(b[0]), "d2h_records": int(b[1]), "d2h_candidates": int(b[2]), "d2h_counts": int(b[3])}
 
     # ---- device-resident surface ----
+    def stream_handle(self):
+        """pisces_hip_get_stream: the handle's own hipStream_t as an int (what stream=None stands for in the calls below)."""
+        s = C.c_void_p()
+        _check(self._h, lib.pisces_hip_get_stream(self._h, C.byref(s)))
+        return int(s.value or 0)
+
+    def torch_stream(self):
+        """The handle's own stream as a torch.cuda.ExternalStream.  Tensors a torch host hands to the device-resident surface are
+        allocated / filled under `with torch.cuda.stream(caller.torch_stream()):` so that torch's fill kernels and the library's launches
+        sit in ONE queue: the handle's stream is hipStreamNonBlocking and does not order against torch's default (null) stream."""
+        ts = getattr(self, "_torch_stream", None)
+        if ts is None:
+            import torch
+            ts = self._torch_stream = torch.cuda.ExternalStream(self.stream_handle(), device=torch.device("cuda", self.device))
+        return ts
+
+    @staticmethod
+    def _stream_arg(stream):
+        """None = the handle's own stream (an explicit choice); a torch stream or a raw hipStream_t otherwise.  The null stream (0, e.g.
+        torch.cuda.current_stream().cuda_stream of a default torch context) is refused: the C ABI reads NULL as "the handle's stream", which
+        does not order against the null stream, so work torch queued there (a torch.zeros fill) would race the launch."""
+        if stream is None:
+            return None
+        raw = int(getattr(stream, "cuda_stream", stream))
+        if raw == 0:
+            raise ValueError("stream 0 is HIP's null stream, which the handle's non-blocking stream is not ordered against: pass None (the handle's "
+                             "own stream, after synchronizing your fills) or allocate under caller.torch_stream() and pass that")
+        return raw
+
     def call_tiles(self, d_tuples, d_tiles, n_tiles, d_ref, ref_start, ref_len, d_records, capacity, d_tile_results, stream=None):
         """All pointer arguments are raw device addresses (ints); capacity >= 256 * n_tiles record slots."""
         _check(self._h, lib.pisces_hip_call_tiles(self._h, d_tuples, d_tiles, n_tiles, d_ref, ref_start, ref_len,
-                                                  d_records, capacity, d_tile_results, stream))
+                                                  d_records, capacity, d_tile_results, self._stream_arg(stream)))
 
     def balanced_tile_loci(self, n_loci):
         """Tile size (<= 64) that gives every CU the same number of tiles for a launch over n_loci loci (pisces_hip_balanced_tile_loci)."""
@@ -407,7 +437,7 @@ class HipVariantCaller:
         for i, (tu, ti, n, rf, rs, rl, rec, cap, tr) in enumerate(batches):
             arr[i].d_tuples, arr[i].d_tiles, arr[i].n_tiles, arr[i].ref_start_position = tu, ti, n, rs
             arr[i].d_ref_bases, arr[i].ref_length, arr[i].d_records, arr[i].d_tile_results, arr[i].record_capacity = rf, rl, rec, tr, cap
-        _check(self._h, lib.pisces_hip_call_tiles_batched(self._h, arr, len(batches), stream))
+        _check(self._h, lib.pisces_hip_call_tiles_batched(self._h, arr, len(batches), self._stream_arg(stream)))
 
     def call_tiles_graph_build(self, batches):
         """pisces_hip_call_tiles_graph_build: the launches of `batches` (as call_tiles_batched takes them), in order, as one HIP graph."""
@@ -420,14 +450,14 @@ class HipVariantCaller:
         return gid.value
 
     def call_tiles_graph_launch(self, graph_id, stream=None):
-        _check(self._h, lib.pisces_hip_call_tiles_graph_launch(self._h, int(graph_id), stream))
+        _check(self._h, lib.pisces_hip_call_tiles_graph_launch(self._h, int(graph_id), self._stream_arg(stream)))
 
     def compact_records(self, d_records, d_tile_results, n_tiles, d_offsets, d_out, out_capacity, d_count, stream=None):
         _check(self._h, lib.pisces_hip_compact_records(self._h, d_records, d_tile_results, n_tiles, d_offsets, d_out,
-                                                       out_capacity, d_count, stream))
+                                                       out_capacity, d_count, self._stream_arg(stream)))
 
     def accumulate_tiles(self, d_tuples, d_tiles, n_tiles, d_counts, stream=None):
-        _check(self._h, lib.pisces_hip_accumulate_tiles(self._h, d_tuples, d_tiles, n_tiles, d_counts, stream))
+        _check(self._h, lib.pisces_hip_accumulate_tiles(self._h, d_tuples, d_tiles, n_tiles, d_counts, self._stream_arg(stream)))
 
     def device_totals(self, reset=False):
         """{records, candidate_loci, called (IAlleleCaller.TotalNumCalled), tiles} summed over call_tiles launches."""
@@ -437,7 +467,7 @@ class HipVariantCaller:
 
     def mark(self, which, stream=None):
         """pisces_hip_mark: an event on the launch stream in front of (0) / behind (1) a run of launches."""
-        _check(self._h, lib.pisces_hip_mark(self._h, int(which), stream))
+        _check(self._h, lib.pisces_hip_mark(self._h, int(which), self._stream_arg(stream)))
 
     def marked_ms(self):
         ms = C.c_float(0)

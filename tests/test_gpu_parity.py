@@ -51,23 +51,27 @@ def torch_cuda():
 
 def run_fused(torch, caller, p, compact=False, ref_start=1):
     """One pisces_hip_call_tiles launch on device-resident buffers; returns the called alleles in order.
-    compact=False: read the slot layout through the validity masks; compact=True: pisces_hip_compact_records."""
+    compact=False: read the slot layout through the validity masks; compact=True: pisces_hip_compact_records.
+    Stream discipline (the round-4 flake: three torch.zeros fills on torch's null stream landed AFTER gather_records_kernel had written the
+    count, because the handle's stream is non-blocking): EVERY buffer is allocated and filled on the handle's own stream
+    (engine.torch_stream(), an ExternalStream over pisces_hip_get_stream) before the first library call, the launches go to that same
+    stream, and the inputs torch made earlier on its default stream are waited for once.  One queue, no cross-stream ordering left."""
     dev = p.tuples.device
     cap = p.n_tiles * _abi.SLOTS_PER_TILE
-    recs = torch.zeros(cap * 64, dtype=torch.uint8, device=dev)
-    tres = torch.zeros(p.n_tiles * _abi.TILE_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    # torch's default stream has the null handle, which the library reads as "the handle's own (non-blocking) stream": the fills
-    # above must be complete before the launch or they race with the tile directory writes of the first workgroups
-    torch.cuda.synchronize()
-    caller.call_tiles(p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), ref_start, p.ref_len,
-                      recs.data_ptr(), cap, tres.data_ptr(), stream)
-    if compact:
-        out_d = torch.zeros(cap * 64, dtype=torch.uint8, device=dev)
+    ts = caller.torch_stream()
+    with torch.cuda.stream(ts):
+        recs = torch.zeros(cap * 64, dtype=torch.uint8, device=dev)
+        tres = torch.zeros(p.n_tiles * _abi.TILE_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        out_d = torch.zeros(cap * 64 if compact else 1, dtype=torch.uint8, device=dev)
         offs = torch.zeros(max(p.n_tiles, 1), dtype=torch.int32, device=dev)
         count = torch.zeros(1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()   # p.tuples / p.tiles / p.ref were made on torch's default stream
+    caller.call_tiles(p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), ref_start, p.ref_len,
+                      recs.data_ptr(), cap, tres.data_ptr(), ts)
+    if compact:
         caller.compact_records(recs.data_ptr(), tres.data_ptr(), p.n_tiles, offs.data_ptr(), out_d.data_ptr(), cap,
-                               count.data_ptr(), stream)
+                               count.data_ptr(), ts)
+    caller.synchronize()
     torch.cuda.synchronize()
     tr = tres.cpu().numpy().view(_abi.TILE_RESULT_DTYPE)
     bad = np.nonzero(tr["record_begin"] != np.arange(len(tr)) * _abi.SLOTS_PER_TILE)[0]
@@ -80,6 +84,39 @@ def run_fused(torch, caller, p, compact=False, ref_start=1):
     out = _abi.records_in_order(recs.cpu().numpy().view(_abi.CALLED_ALLELE_DTYPE), tr)
     assert len(out) == int(tr["n_records"].sum())
     return out, tr
+
+
+def test_compacted_launch_is_deterministic_over_three_hundred_runs(torch_cuda):
+    """Regression for the round-4 flake (GPUTEST_r04: `assert 0 == 313` in draw 9 of the device-resident fuzz, an 8-tile input): a
+    compacted launch on a tiny input, 300 times over with fresh buffers every time, each run's count, offsets and rows equal to the
+    first's.  With buffers filled on torch's null stream and launches on the handle's non-blocking stream, some of these lose the race."""
+    from pisces_amd import engine, synth
+    torch = torch_cuda
+    p = synth.make_pileup(n_loci=8 * 64, depth=40, seed=9, device="cuda")
+    assert p.n_tiles == 8
+    with engine.HipVariantCaller(_abi.default_config()) as caller:
+        want, tr0 = run_fused(torch, caller, p, compact=True)
+        assert len(want) > 8 * 64 - 1
+        for i in range(300):
+            got, tr = run_fused(torch, caller, p, compact=True)
+            assert got.tobytes() == want.tobytes() and tr.tobytes() == tr0.tobytes(), i
+
+
+def test_the_null_stream_is_refused_by_the_engine(torch_cuda):
+    """HIP's null stream (what torch.cuda.current_stream().cuda_stream is in a default torch context) is not a stream the library can
+    launch on -- the C ABI reads NULL as the handle's own stream -- so the engine makes the caller choose: None, or a real stream."""
+    from pisces_amd import engine
+    torch = torch_cuda
+    with engine.HipVariantCaller(_abi.default_config()) as caller:
+        assert caller.stream_handle() != 0 and caller.torch_stream().cuda_stream == caller.stream_handle()
+        if torch.cuda.current_stream().cuda_stream == 0:
+            with pytest.raises(ValueError, match="null stream"):
+                caller.mark(0, torch.cuda.current_stream())
+        with pytest.raises(ValueError, match="null stream"):
+            caller.call_tiles(0, 0, 0, 0, 1, 0, 0, 0, 0, 0)
+        caller.mark(0, None)
+        caller.mark(1, caller.torch_stream())
+        assert caller.marked_ms() >= 0.0
 
 
 @pytest.mark.parametrize("n_loci,depth,seed", [(1000, 500, 1), (777, 37, 2), (64, 5000, 3), (130, 1, 4), (2000, 200, 5)])

@@ -523,6 +523,45 @@ def test_reads_added_ahead_of_the_flush_that_clears_what_lies_behind_them(torch_
         assert got[0].tobytes() == want[0].tobytes() and got[1] == want[1] and got[2] == want[2], (ahead, device_fed)
 
 
+@pytest.mark.parametrize("lead", ["I", "D"])
+@pytest.mark.parametrize("device_fed", [False, True], ids=["host reads", "device reads"])
+def test_a_leading_indel_one_past_a_block_edge_is_waited_for(torch_cuda, lead, device_fed):
+    """A read whose first operation is I or D puts its candidate at position - 1 (CandidateVariantFinder.cs:52-76 through the walk's
+    `coordinate = in_ref`): with reads at 1001 that is position 1000, the last of block 1.  The flush up to 1000 that follows the add
+    (SmallVariantCaller.cs:88-105: add, then Call(position - 1)) must wait for that batch's candidates although every read of it starts
+    behind upTo — it skipped them while it compared the batch's lowest READ position with upTo, cleared block 1 without
+    the indel and re-created the block afterwards."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(77)
+    ref = rng.choice(np.frombuffer(b"ACGT", np.uint8), 2300)
+    seq_at = lambda p, n: bytes(ref[p - 1: p - 1 + n])
+    first = [dict(pos=int(p), cigar=[("M", 70)], seq=seq_at(int(p), 70), quals=bytes([35] * 70), reverse=bool(i & 1))
+             for i, p in enumerate(np.sort(rng.integers(905, 960, 60)))]
+    second = []
+    for i in range(60):
+        if i % 3 == 2:   # plain reads of the same stretch
+            second.append(dict(pos=1001 + i % 5, cigar=[("M", 70)], seq=seq_at(1001 + i % 5, 70), quals=bytes([35] * 70), reverse=bool(i & 1)))
+        elif lead == "I":
+            second.append(dict(pos=1001, cigar=[("I", 3), ("M", 67)], seq=b"TTG" + seq_at(1001, 67), quals=bytes([35] * 70), reverse=bool(i & 1)))
+        else:
+            second.append(dict(pos=1001, cigar=[("D", 2), ("M", 70)], seq=seq_at(1003, 70), quals=bytes([35] * 70), reverse=bool(i & 1)))
+    up_to = min(r["pos"] for r in second) - 1
+    cfg = _abi.default_config()
+    want, want_alleles, want_called = orc.run_reads_schedule(_abi.ReadBatch(first + second), ref, 1, len(ref), cfg, [up_to])
+    assert [int(r["position"]) for r, a in zip(want, want_alleles) if len(a[0]) != len(a[1])] == [1000], "the oracle calls the leading indel"
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(ref)
+        add = c.AddDeviceReads if device_fed else c.AddAlleleCounts
+        add(_abi.ReadBatch(first))
+        add(_abi.ReadBatch(second))
+        r1, a1 = c.CallWithAlleles(up_to)
+        r2, a2 = c.CallWithAlleles(None)
+        got, got_alleles = np.concatenate([r1, r2]), a1 + a2
+        assert got_alleles == want_alleles
+        assert got.tobytes() == want.tobytes()
+        assert c.Stats()["TotalNumCalled"] == want_called
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("gvcf", [1, 0], ids=["gvcf", "variants only"])
 def test_candidate_rows_merged_in_place_equal_the_rows_merged_by_copy(torch_cuda, gvcf):

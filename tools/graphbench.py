@@ -11,7 +11,8 @@ with engine.HipVariantCaller(_abi.default_config()) as c:
     ring = [synth.make_pileup(100_000, 500, seed=100 + b, device=dev, tile=tile) for b in range(4)]
     nt = ring[0].n_tiles; cap = nt * 256
     rec = torch.zeros(cap * 64, dtype=torch.uint8, device=dev); tr = torch.zeros(nt * 48, dtype=torch.uint8, device=dev)
-    st = torch.cuda.current_stream(dev).cuda_stream
+    st = None   # the handle's own stream (fills are synchronised before the first launch)
+    torch.cuda.synchronize()
     def batch(i):
         p = ring[i % 4]
         return (p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), p.ref_start, p.ref_len, rec.data_ptr(), cap, tr.data_ptr())

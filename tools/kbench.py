@@ -28,7 +28,7 @@ def main():
     cap = nt * 256
     rec = torch.zeros(cap * 64, dtype=torch.uint8, device=dev)
     tr = torch.zeros(nt * 48, dtype=torch.uint8, device=dev)
-    st = torch.cuda.current_stream(dev).cuda_stream
+    st = None   # the handle's own stream (fills are synchronised before the first launch)
     with engine.HipVariantCaller(_abi.default_config()) as c:
         def step(i):
             p = ring[i % a.ring]

@@ -15,7 +15,7 @@ with engine.HipVariantCaller(_abi.default_config()) as c:
     c.set_timing(True)
     torch.cuda.synchronize()
     for _ in range(3):
-        c.call_tiles(p.tuples.data_ptr(), p.tiles.data_ptr(), nt, p.ref.data_ptr(), 1, p.ref_len, rec.data_ptr(), cap, tr.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        c.call_tiles(p.tuples.data_ptr(), p.tiles.data_ptr(), nt, p.ref.data_ptr(), 1, p.ref_len, rec.data_ptr(), cap, tr.data_ptr(), None)
     torch.cuda.synchronize()
     ms = c.last_kernel_ms()
 t = tr.cpu().numpy().view(_abi.TILE_RESULT_DTYPE)

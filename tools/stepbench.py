@@ -40,15 +40,16 @@ def main():
         def run(n_streams, timing):
             streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
             if a.null_first:
-                streams[0] = torch.cuda.current_stream(dev)
+                streams[0] = None   # the handle's own stream
             recs = [torch.zeros(cap * 64, dtype=torch.uint8, device=dev) for _ in range(n_streams)]
             trs = [torch.zeros(nt * 48, dtype=torch.uint8, device=dev) for _ in range(n_streams)]
+            torch.cuda.synchronize()   # the fills sit on torch's null stream, the launches do not
 
             def step(i):
                 p = ring[i % a.ring]
                 s = i % n_streams
                 c.call_tiles(p.tuples.data_ptr(), p.tiles.data_ptr(), p.n_tiles, p.ref.data_ptr(), 1, p.ref_len,
-                             recs[s].data_ptr(), cap, trs[s].data_ptr(), streams[s].cuda_stream)
+                             recs[s].data_ptr(), cap, trs[s].data_ptr(), streams[s])
             c.set_timing(timing)
             for i in range(10):
                 step(i)
