@@ -247,12 +247,13 @@ struct DeviceBuf {
 struct ReadSegment {
     DeviceBuf<uint8_t> blob;
     DeviceBuf<uint8_t> bases, quals, dirs, cop;
+    DeviceBuf<uint8_t> codes;    // one byte per base: low-quality << 5 | AlleleType << 2, made when the batch joins (encode_rows: what the flush kernel walks)
     DeviceBuf<uint32_t> clen;
     DeviceBuf<ReadDesc> desc;
     DeviceBuf<ReadExt> ext;
     DeviceBuf<ReadDesc> frag;    // one per CIGAR operation: what the flush kernel walks
     int32_t* state = nullptr;    // its four state words on the device (a slot of PiscesHip::state_pool, zero when handed out)
-    const uint8_t *v_bases = nullptr, *v_quals = nullptr, *v_dirs = nullptr, *v_cop = nullptr;
+    const uint8_t *v_bases = nullptr, *v_quals = nullptr, *v_dirs = nullptr, *v_cop = nullptr, *v_codes = nullptr;
     const uint32_t* v_clen = nullptr;
     int64_t n_reads = 0, n_bases = 0, n_ops = 0;
     int64_t n_floored = 0, n_floored_ops = 0;   // reads / CIGAR operations that were there at the last flush ...

@@ -72,6 +72,7 @@ struct SegmentView {
     const ReadExt* ext;
     const uint8_t* bases;
     const uint8_t* quals;
+    const uint8_t* codes;         // per base: low-quality << 5 | AlleleType << 2 (encode_rows, made at add time: what the flush kernel walks)
     const uint8_t* dirs;          // per-base DirectionType of every read of the segment, or nullptr (direction = kDescReverse)
     const uint8_t* cigar_op;
     const uint32_t* cigar_len;
@@ -107,10 +108,58 @@ struct ShapeArgs {
     const uint8_t* dirs;
     int32_t min_bq;
     int32_t* state;
+    // the second role of the launch (workgroups [shape_blocks, gridDim.x)): the row codes of the batch's bases
+    const uint8_t* enc_bases;
+    const uint8_t* enc_quals;
+    uint8_t* enc_codes;
+    int64_t enc_n;
+    uint32_t enc_min_bq;   // <= 127
+    int32_t shape_blocks;
 };
+
+// ROW CODES.  What the flush kernel needs of a base is the row of the LDS histogram it counts in: low-quality << 5 | AlleleType << 2
+// (| direction, which the fragment or the segment's per-base directions add).  Both depend on the base, its quality and the handle's
+// minimum base-call quality only (AlleleHelper.GetAlleleType, AlleleHelper.cs:13-32: anything but A C G T is an N;
+// RegionStateManager.cs:179-181: quality < minBQ), so they are made ONCE, when the batch joins the store — a streaming pass at 16 bytes a
+// lane, every lane busy — instead of in every tile that walks the read (3.3 tiles of 64 loci for a read of 150 bases, at 71 % of the
+// lanes).  The flush then loads one byte per base instead of two and classifies nothing.
+__device__ __forceinline__ uint32_t row_codes_of(uint32_t bw, uint32_t qw, uint32_t qk4)
+{
+    const uint32_t idx4 = bw & 0x07070707u;
+    const uint32_t letter4 = __builtin_amdgcn_perm(0x47000054u, 0x43004101u, idx4);   // the letter the low three bits stand for: 1 A, 3 C, 4 T, 7 G
+    const uint32_t code4 = __builtin_amdgcn_perm(0x0410100Cu, 0x08100010u, idx4);     // its AlleleType << 2 (N for the rest)
+    const uint32_t x4 = bw ^ letter4;                                                   // a zero byte: the base IS that letter
+    const uint32_t nz = (((x4 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x4) & 0x80808080u;
+    const uint32_t nzff = (nz - (nz >> 7)) | nz;                                       // 0xFF where it is not
+    const uint32_t allele4 = (nzff & 0x10101010u) | (~nzff & code4);
+    // quality < minBQ: bit 7 of (0x7F + minBQ) - (q & 0x7F) is set iff (q & 0x7F) < minBQ; a quality >= 128 is never low
+    const uint32_t low4 = ~qw & (qk4 - (qw & 0x7F7F7F7Fu));
+    return ((low4 >> 2) & 0x20202020u) | allele4;
+}
+__device__ __forceinline__ void encode_rows(const ShapeArgs& A, int block, int n_blocks)
+{
+    const uint32_t qk4 = (0x7Fu + A.enc_min_bq) * 0x01010101u;
+    const int64_t n16 = A.enc_n >> 4;
+    for (int64_t i = (int64_t)block * 256 + threadIdx.x; i < n16; i += (int64_t)n_blocks * 256) {
+        uint32_t b[4], q[4], c[4];
+        __builtin_memcpy(b, A.enc_bases + 16 * i, 16);   // (any alignment: one global_load_dwordx4 each)
+        __builtin_memcpy(q, A.enc_quals + 16 * i, 16);
+#pragma unroll
+        for (int k = 0; k < 4; k++) c[k] = row_codes_of(b[k], q[k], qk4);
+        __builtin_memcpy(A.enc_codes + 16 * i, c, 16);
+    }
+    if (block == 0 && (int64_t)threadIdx.x < (A.enc_n & 15)) {   // the last bytes
+        const int64_t i = (n16 << 4) + threadIdx.x;
+        A.enc_codes[i] = (uint8_t)row_codes_of(A.enc_bases[i], A.enc_quals[i], qk4);
+    }
+}
 
 __global__ __launch_bounds__(256) void read_shape_kernel(ShapeArgs A)
 {
+    if ((int)blockIdx.x >= A.shape_blocks) {
+        encode_rows(A, (int)blockIdx.x - A.shape_blocks, (int)gridDim.x - A.shape_blocks);
+        return;
+    }
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     int reach = 0;
     bool unsorted = false, complex_read = false, generic_read = false, has_del = false;
@@ -744,26 +793,27 @@ __device__ __forceinline__ void walk_segment(const SegmentView& G, int tile_star
 
 // ---- the flush kernel's own form of the walk over simple reads -------------------------------------------------------------------
 // The general form above hands every base to a callback (18 VALU instructions a base with the histogram update of the call kernel:
-// 37.5 M a launch at BASELINE config 2, 4 cycles each — the kernel was VALU-bound at 3 x the tuple kernel's time).  Here the four
-// bases of a loaded word are classified TOGETHER into one byte each, the ROW of the histogram the base counts in:
-//     row = low-quality << 5 | allele << 2 | direction          (24 = a row nobody reads: the base is not on the read / below the floor)
-//   * allele: v_perm_b32 looks up, by the low three bits of every base, the letter those bits stand for (A C G T have 1 3 7 4) and its
-//     AlleleType; a base that is not exactly that letter is an N (AlleleHelper.GetAlleleType, AlleleHelper.cs:13-32)
-//   * low quality: one subtraction on all four qualities (RegionStateManager.cs:179-181: quality < minBQ; minBQ <= 127 here)
-//   * on the read: one mask from the lane's first / last valid byte (v_bfm_b32), applied with v_bfi_b32
-// and an observation is then ONE v_perm_b32 (row byte and column byte -> LDS address) and one ds_add_u32.  A lane holds EIGHT bases of a
-// fragment (round 4: one 8-byte load each of bases and qualities; eight fragments a step, sixteen a sub-chunk) and adds its bytes in the
-// order (s + g) & 7 (the eight row bytes are rotated by g bytes once), so the 64 lanes of an instruction stand on 64 different loci.
-// What bounds the kernel is the number of instructions a SIMD issues for its three waves: ~320 per 2 048 lane-bases,
-// of which the classification and the mask are per four bases whatever the width of the load.
+// 37.5 M a launch at BASELINE config 2, 4 cycles each — the kernel was VALU-bound at 3 x the tuple kernel's time).  Rounds 3-4 classified
+// four bases at once here (v_perm tables, 12.0 M VALU a launch); round 5 moved the classification to add time (encode_rows: one ROW CODE
+// per base, low-quality << 5 | allele << 2), so that what is left per lane and eight bases is
+//   * one 8-byte load of codes (bases and qualities are not read by the flush at all: half the bytes),
+//   * the on-the-read mask: first / last valid byte of the lane as two entries of a nine-entry LDS table of 64-bit masks (bytes >= a),
+//   * row = code | direction on the read, row 24 (a row nobody reads) elsewhere: v_or, v_bfi,
+//   * one v_perm_b32 (row byte and column byte -> LDS address) and one ds_add_u32 per base.
+// A lane holds EIGHT bases of a fragment (lane (g, j) = (lane >> 3, lane & 7): fragment g of the eight of a unit, the tile's loci
+// 8 j .. 8 j + 7) and adds its bytes in the order (s + rot) & 7, rot = (g + 4 (j >> 2)) & 7 (the eight row bytes are rotated by rot bytes
+// once): in every step the lanes of EACH 32-lane half — what a ds_add_u32 is serviced in — stand on 32 different banks (half 0: g = 0..3,
+// and g + 4 (j >> 2) takes eight different values for the eight lanes that share j & 3; rounds 3-4 rotated by g alone, which put lanes
+// j and j + 4 on one bank: 31 % of the kernel's LDS cycles were conflicts).
 struct ReadTrim {   // a descriptor with the floor applied: what is left of the read, per lane of a 64-read block
     int32_t pos, end;     // first position still to count, one past the last
     uint32_t aoff;        // index of the base on `pos` in the segment's arrays, + kSegmentPad
     uint32_t dir4;        // the read's direction in every byte
 };
+constexpr int kMaskTab = 9;   // s_masktab[a] = the bytes >= a of eight (a = 8: none)
 template <bool kDirs, typename OnObs>
 __device__ __forceinline__ void walk_segment_fast(const SegmentView& G, int tile_start, uint32_t min_bq, int lane, int wid, int n_waves, char* hbytes,
-                                                  OnObs on_obs, long long* stamps = nullptr /* development: PISCES_STORE_TIMING */)
+                                                  const unsigned long long* s_masktab, OnObs on_obs, long long* stamps = nullptr /* development: PISCES_STORE_TIMING */)
 {
     if (G.n_frags <= 0) return;
     const int tile_end = tile_start + kTile - 1;
@@ -775,33 +825,27 @@ __device__ __forceinline__ void walk_segment_fast(const SegmentView& G, int tile
 #ifdef PISCES_STORE_TIMING
     if (stamps) { stamps[0] = wall_clock64(); stamps[1] = hi - lo; }
 #endif
-    // Eight fragments a step, eight bases a lane: lane (g, j) = (lane >> 3, lane & 7) holds, of fragment 8 u + g (u = 0, 1), the bases on the
-    // tile's loci 8 j .. 8 j + 7 (one 8-byte load each of bases and qualities: half the loads, shuffles and mask arithmetic per base of
-    // the four-base form this replaced).  A lane adds its eight bytes in the order (s + g) & 7, s = 0..7: in every step the 64 lanes stand
-    // on 64 different loci.  The eight row bytes are rotated right by g bytes once (v_alignbyte): byte s of the rotated pair IS step s's,
-    // and so is byte s of the column constants below; the v_perm selectors that make the LDS address are then compile-time constants.
     const int g = lane >> 3, j8 = (lane & 7) * 8;
+    const int rot = (g + 4 * ((lane & 7) >> 2)) & 7;
     const int lane_pos = tile_start + j8;
     uint32_t col_lo = 0, col_hi = 0;   // byte s: LDS byte offset, inside a row, of the locus this lane stands on in step s
 #pragma unroll
     for (int st = 0; st < 8; st++) {
-        const uint32_t c = (uint32_t)((j8 + ((st + g) & 7)) * (int)sizeof(int));
+        const uint32_t c = (uint32_t)((j8 + ((st + rot) & 7)) * (int)sizeof(int));
         if (st < 4) col_lo |= c << (8 * st);
         else col_hi |= c << (8 * (st - 4));
     }
-    const uint32_t qk4 = (0x7Fu + min(min_bq, 127u)) * 0x01010101u;
-    const uint8_t* const bases = G.bases - kSegmentPad;
-    const uint8_t* const quals = G.quals - kSegmentPad;
+    const uint8_t* const codes = G.codes - kSegmentPad;
     const uint8_t* const dirs = kDirs ? G.dirs - kSegmentPad : nullptr;
     const int n_blocks = (hi - lo + 63) >> 6;
     const int my_blocks = (n_blocks - wid + n_waves - 1) / n_waves;
     if (my_blocks > 0) {
-        struct Sub { uint32_t bw[2][2], qw[2][2], dw[2][2], mask[2][2]; };   // [u][low / high four bases]
+        struct Unit { uint32_t cw[2], dw[2]; unsigned long long ma, me; };   // eight fragments: this lane's eight codes of one of them
         auto block_base = [&](int b) { return lo + (wid + min(b, my_blocks - 1) * n_waves) * 64; };
         auto load_trim = [&](int b) {
             const int base = block_base(b), cnt = min(64, hi - base);
             const ReadDesc d = G.frag[base + min(lane, cnt - 1)];
-            const int n = (lane < cnt && !(d.meta & kFragDeletion)) ? (int)(d.meta & kDescLenMask) : 0;
+            const int n = (b < my_blocks && lane < cnt && !(d.meta & kFragDeletion)) ? (int)(d.meta & kDescLenMask) : 0;
             const int floor_pos = base + lane < G.n_floored_frags ? G.floor : 0;
             const int first = d.pos0 + frag_delta(d.aoff);   // the fragment's first position
             ReadTrim t;
@@ -812,126 +856,93 @@ __device__ __forceinline__ void walk_segment_fast(const SegmentView& G, int tile
             t.dir4 = (d.meta & kDescReverse) ? (uint32_t)PISCES_DIR_REVERSE * 0x01010101u : (uint32_t)PISCES_DIR_FORWARD * 0x01010101u;
             return t;
         };
-        auto issue = [&](const ReadTrim& t, int f, Sub& S) {
-            const uint32_t live = f < my_blocks * 4 ? 0xFFFFFFFFu : 0u;
-            const int q = f & 3;
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int src = 16 * q + 8 * u + g;
-                const int pos = __shfl(t.pos, src, 64), end = __shfl(t.end, src, 64);
-                const uint32_t aoff = (uint32_t)__shfl((int)t.aoff, src, 64);
-                const int da = pos - lane_pos, de = end - lane_pos;            // the lane's bytes a .. e - 1 are on the read: a = clamp(da, 0, 8), e = clamp(de, 0, 8)
-                // as bit positions, capped at 63 (bit 63 is bit 7 of the last byte: no row bit): the mask is bits a8 .. e8 - 1 of the eight bytes
-                const uint32_t a8 = (uint32_t)min(min(max(da, 0), 8) * 8, 63), e8 = (uint32_t)min(min(max(de, 0), 8) * 8, 63) & live;   // (clamped before they are scaled: da is any int in an unsorted segment)
-                const unsigned long long m8 = ((1ull << e8) - 1ull) & ~((1ull << a8) - 1ull);
-                S.mask[u][0] = (uint32_t)m8;
-                S.mask[u][1] = (uint32_t)(m8 >> 32);
-                const uint32_t at = aoff + (uint32_t)(a8 < e8 ? -da : 0);     // (eight bytes that are not on the read at all: the read's first)
-#if defined(PISCES_STORE_ABLATE) && PISCES_STORE_ABLATE == 5
-                S.bw[u][0] = 0x41434754u ^ ((at & 1u) << 1); S.bw[u][1] = 0x54474341u;   // development ablation: no loads of bases / qualities
-                S.qw[u][0] = 0x25252525u + (at & 3u); S.qw[u][1] = 0x25252525u;
-#else
-                const unsigned long long b8 = load_u64_unaligned(bases + at), q8 = load_u64_unaligned(quals + at);
-                S.bw[u][0] = (uint32_t)b8; S.bw[u][1] = (uint32_t)(b8 >> 32);
-                S.qw[u][0] = (uint32_t)q8; S.qw[u][1] = (uint32_t)(q8 >> 32);
-#endif
-                if (kDirs) {
-                    const unsigned long long d8 = load_u64_unaligned(dirs + at);
-                    S.dw[u][0] = (uint32_t)d8; S.dw[u][1] = (uint32_t)(d8 >> 32);
-                } else {
-                    S.dw[u][0] = S.dw[u][1] = (uint32_t)__shfl((int)t.dir4, src, 64);
-                }
+        // Unit u = fragments 8 u + g of the block whose trims are t.  Its trim reaches the lanes by four ds_bpermute (`shuffle`), issued one
+        // step ahead of the arithmetic that uses them (`issue`: the mask-table reads and the load) so that they do not queue behind the
+        // eight ds_add of the unit consumed in between.
+        struct Pre { int pos, end; uint32_t aoff, dir4; };
+        auto shuffle = [&](const ReadTrim& t, int u, Pre& P) {
+            const int src = 8 * u + g;
+            P.pos = __shfl(t.pos, src, 64);
+            P.end = __shfl(t.end, src, 64);
+            P.aoff = (uint32_t)__shfl((int)t.aoff, src, 64);
+            P.dir4 = kDirs ? 0u : (uint32_t)__shfl((int)t.dir4, src, 64);
+        };
+        auto issue = [&](const Pre& P, Unit& U) {
+            const int da = P.pos - lane_pos, de = P.end - lane_pos;   // the lane's bytes a .. e - 1 are on the read: a = clamp(da, 0, 8), e = clamp(de, 0, 8)
+            const int a = min(max(da, 0), 8), e = min(max(de, 0), 8);
+            U.ma = s_masktab[a];
+            U.me = s_masktab[e];
+            const uint32_t at = P.aoff - (uint32_t)(a < e ? da : 0);   // (eight bytes that are not on the read at all: the read's first)
+            const unsigned long long c8 = load_u64_unaligned(codes + at);
+            U.cw[0] = (uint32_t)c8; U.cw[1] = (uint32_t)(c8 >> 32);
+            if (kDirs) {
+                const unsigned long long d8 = load_u64_unaligned(dirs + at);
+                U.dw[0] = (uint32_t)d8; U.dw[1] = (uint32_t)(d8 >> 32);
+            } else {
+                U.dw[0] = U.dw[1] = P.dir4;
             }
         };
-        // the rows of the four bases of a word.  Fast form: the letter the low three bits stand for (A C G T N) is taken at its word; a base
-        // that is none of these letters shows in `other` (returned or-ed over the words) and the exact form is taken then.
-        auto rows_of = [&](uint32_t bw, uint32_t qw, uint32_t dw, uint32_t mask, uint32_t& other) {
-            const uint32_t idx4 = bw & 0x07070707u;
-            const uint32_t letter4 = __builtin_amdgcn_perm(0x474E0054u, 0x43004101u, idx4);   // 1 A, 3 C, 4 T, 6 N, 7 G
-            const uint32_t code4 = __builtin_amdgcn_perm(0x0410100Cu, 0x08100010u, idx4);     // AlleleType << 2 (N for the rest)
-            other |= (bw ^ letter4) & mask;
-            // quality < minBQ: bit 7 of (0x7F + minBQ) - (q & 0x7F) is set iff (q & 0x7F) < minBQ; a quality >= 128 is never low
-            const uint32_t low4 = ~qw & (qk4 - (qw & 0x7F7F7F7Fu));
-            const uint32_t row4 = ((low4 >> 2) & 0x20202020u) | code4 | dw;
-            return (mask & row4) | (~mask & 0x18181818u);
-        };
-        auto rows_of_exact = [&](uint32_t bw, uint32_t qw, uint32_t dw, uint32_t mask) {   // any byte: what is not exactly A C G T is an N
-            const uint32_t idx4 = bw & 0x07070707u;
-            const uint32_t letter4 = __builtin_amdgcn_perm(0x47000054u, 0x43004101u, idx4);
-            const uint32_t code4 = __builtin_amdgcn_perm(0x0410100Cu, 0x08100010u, idx4);
-            const uint32_t x4 = bw ^ letter4;                                                   // a zero byte: the base IS that letter
-            const uint32_t nz = (((x4 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x4) & 0x80808080u;
-            const uint32_t nzff = (nz - (nz >> 7)) | nz;                                       // 0xFF where it is not
-            const uint32_t allele4 = (nzff & 0x10101010u) | (~nzff & code4);
-            const uint32_t low4 = ~qw & (qk4 - (qw & 0x7F7F7F7Fu));
-            const uint32_t row4 = ((low4 >> 2) & 0x20202020u) | allele4 | dw;
-            return (mask & row4) | (~mask & 0x18181818u);
-        };
-        auto consume = [&](const Sub& S) {
-            uint32_t row4[2][2], other = 0;
-#pragma unroll
-            for (int u = 0; u < 2; u++)
-#pragma unroll
-                for (int hf = 0; hf < 2; hf++) row4[u][hf] = rows_of(S.bw[u][hf], S.qw[u][hf], S.dw[u][hf], S.mask[u][hf], other);
-            if (__builtin_expect(__ballot(other != 0) != 0ull, 0)) {
-#pragma unroll
-                for (int u = 0; u < 2; u++)
-#pragma unroll
-                    for (int hf = 0; hf < 2; hf++) row4[u][hf] = rows_of_exact(S.bw[u][hf], S.qw[u][hf], S.dw[u][hf], S.mask[u][hf]);
-            }
+        auto consume = [&](const Unit& U) {
+            const unsigned long long m8 = U.ma & ~U.me;   // bytes a .. e - 1 (none when a >= e)
+            const uint32_t m0 = (uint32_t)m8, m1 = (uint32_t)(m8 >> 32);
+            const uint32_t r0 = (m0 & (U.cw[0] | U.dw[0])) | (~m0 & 0x18181818u), r1 = (m1 & (U.cw[1] | U.dw[1])) | (~m1 & 0x18181818u);
 #if defined(PISCES_STORE_ABLATE) && PISCES_STORE_ABLATE == 2
-            if ((row4[0][0] ^ row4[0][1] ^ row4[1][0] ^ row4[1][1]) == 0x12345u) *reinterpret_cast<volatile int*>(hbytes) = 1;   // development ablation: no histogram update
+            if ((r0 ^ r1) == 0x12345u) *reinterpret_cast<volatile int*>(hbytes) = 1;   // development ablation: no histogram update
             return;
 #endif
+            // the eight row bytes rotated right by rot bytes: {hi, lo} >> 8 rot for rot < 4, the words swapped first for rot >= 4
+            const uint32_t x = rot < 4 ? r0 : r1, y = rot < 4 ? r1 : r0;
+            const uint32_t lo8 = __builtin_amdgcn_alignbyte(y, x, (uint32_t)(rot & 3)), hi8 = __builtin_amdgcn_alignbyte(x, y, (uint32_t)(rot & 3));
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                // the eight row bytes rotated right by g bytes: {hi, lo} >> 8 g for g < 4, the words swapped first for g >= 4
-                const uint32_t x = g < 4 ? row4[u][0] : row4[u][1], y = g < 4 ? row4[u][1] : row4[u][0];
-                const uint32_t lo8 = __builtin_amdgcn_alignbyte(y, x, (uint32_t)(g & 3)), hi8 = __builtin_amdgcn_alignbyte(x, y, (uint32_t)(g & 3));
+            for (int st = 0; st < 4; st++)   // (row byte st and column byte st -> LDS address)
+                atomicAdd(reinterpret_cast<int*>(hbytes + __builtin_amdgcn_perm(lo8, col_lo, 0x0C0C0000u | ((uint32_t)(4 + st) << 8) | (uint32_t)st)), 1);
 #pragma unroll
-                for (int st = 0; st < 4; st++)   // (row byte st and column byte st -> LDS address)
-                    atomicAdd(reinterpret_cast<int*>(hbytes + __builtin_amdgcn_perm(lo8, col_lo, 0x0C0C0000u | ((uint32_t)(4 + st) << 8) | (uint32_t)st)), 1);
-#pragma unroll
-                for (int st = 0; st < 4; st++)
-                    atomicAdd(reinterpret_cast<int*>(hbytes + __builtin_amdgcn_perm(hi8, col_hi, 0x0C0C0000u | ((uint32_t)(4 + st) << 8) | (uint32_t)st)), 1);
-            }
+            for (int st = 0; st < 4; st++)
+                atomicAdd(reinterpret_cast<int*>(hbytes + __builtin_amdgcn_perm(hi8, col_hi, 0x0C0C0000u | ((uint32_t)(4 + st) << 8) | (uint32_t)st)), 1);
         };
-        const int n_f = my_blocks * 4;
-        ReadTrim tc = load_trim(0), tn = load_trim(1);
-        Sub A, B;
-        issue(tc, 0, A);
 #ifdef PISCES_STORE_TIMING
 #define PISCES_TICK(k) { __builtin_amdgcn_sched_barrier(0); const long long now_ = clock64(); if (stamps) stamps[k] += now_ - tick_; tick_ = now_; __builtin_amdgcn_sched_barrier(0); }
         long long tick_ = clock64();
 #else
 #define PISCES_TICK(k)
 #endif
-        for (int f = 0; f < n_f; f += 2) {
-            __builtin_amdgcn_sched_barrier(0);
-            issue(tc, f + 1, B);                  // (same block as f: four sub-chunks a block)
-            __builtin_amdgcn_sched_barrier(0);
+        // Four units in flight (a ring of four register sets, eight units a block of 64 fragments: straight-line code, every load
+        // unconditional — past the last block the last block's descriptors are taken once more with nothing on the read, and never consumed)
+        ReadTrim tc = load_trim(0), tn = load_trim(1);
+        Unit R0, R1, R2, R3;
+        Pre P, Pn;
+        shuffle(tc, 0, P); issue(P, R0);
+        shuffle(tc, 1, P); issue(P, R1);
+        shuffle(tc, 2, P); issue(P, R2);
+        shuffle(tc, 3, P); issue(P, R3);
+        shuffle(tc, 4, P);
+#define PISCES_STEP(T, U_NEXT, R)            \
+        __builtin_amdgcn_sched_barrier(0);   \
+        shuffle(T, U_NEXT, Pn);              \
+        __builtin_amdgcn_sched_barrier(0);   \
+        consume(R);                          \
+        __builtin_amdgcn_sched_barrier(0);   \
+        issue(P, R);                         \
+        P = Pn;
+        for (int b = 0; b < my_blocks; b++) {
+            PISCES_STEP(tc, 5, R0)   // R0: unit 0 consumed, unit 4 issued
+            PISCES_STEP(tc, 6, R1)
+            PISCES_STEP(tc, 7, R2)
+            PISCES_STEP(tn, 0, R3)
             PISCES_TICK(2)
-            consume(A);
-            __builtin_amdgcn_sched_barrier(0);
-            PISCES_TICK(3)
-            const bool next_block = (f & 3) == 2;
-            ReadTrim ta;
-            ta.pos = next_block ? tn.pos : tc.pos;
-            ta.end = next_block ? tn.end : tc.end;
-            ta.aoff = next_block ? tn.aoff : tc.aoff;
-            ta.dir4 = next_block ? tn.dir4 : tc.dir4;
-            tn = load_trim(((f + 2) >> 2) + 1);   // (the same descriptors again three times out of four: straight-line code)
+            tc = tn;
+            tn = load_trim(b + 2);
             PISCES_TICK(4)
-            issue(ta, f + 2, A);                  // (past the end: a repeat of the last sub-chunk with nothing valid)
-            tc = ta;
-            __builtin_amdgcn_sched_barrier(0);
-            PISCES_TICK(2)
-            consume(B);
+            PISCES_STEP(tc, 1, R0)   // R0: unit 4 consumed, the next block's unit 0 issued
+            PISCES_STEP(tc, 2, R1)
+            PISCES_STEP(tc, 3, R2)
+            PISCES_STEP(tc, 4, R3)
             PISCES_TICK(3)
 #ifdef PISCES_STORE_TIMING
             if (stamps) stamps[5] += 1;
 #endif
         }
+#undef PISCES_STEP
 #undef PISCES_TICK
     }
     const int frag_bits = G.state[kStateFrags];
@@ -1028,6 +1039,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
     __shared__ __attribute__((aligned(16))) int hist[2 * kWaveRegion];   // [region: quality-passing / low-quality][allele * 4 + direction][locus]
     __shared__ uint8_t s_refwin[kRefWin];
     __shared__ uint8_t s_vmask[kTile];
+    __shared__ unsigned long long s_masktab[kMaskTab + 1];
 
     if ((int)blockIdx.x >= n_tiles) return;
 #ifdef PISCES_STORE_NO_SWIZZLE
@@ -1051,6 +1063,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
             const int64_t ri = (int64_t)tile.start_position - kRefMargin + i - ref_start;
             s_refwin[i] = (ri >= 0 && ri < ref_len) ? ref[ri] : (uint8_t)0;
         }
+        if (threadIdx.x < kMaskTab) s_masktab[threadIdx.x] = threadIdx.x >= 8 ? 0ull : ~0ull << (8 * threadIdx.x);
         __syncthreads();
     }
     const uint32_t min_bq = (uint32_t)min(max(P.min_bq, 0), 127);   // (the host routes larger thresholds through the counts in HBM)
@@ -1073,11 +1086,11 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
     for (int sg = 0; sg < S.n_segments; sg++) {
         const SegmentView& G = S.seg[sg];
 #ifdef PISCES_STORE_TIMING
-        if (G.dirs) walk_segment_fast<true>(G, tile.start_position, min_bq, l, wid, NW, hbytes, on_obs, stamps);
-        else walk_segment_fast<false>(G, tile.start_position, min_bq, l, wid, NW, hbytes, on_obs, stamps);
+        if (G.dirs) walk_segment_fast<true>(G, tile.start_position, min_bq, l, wid, NW, hbytes, s_masktab, on_obs, stamps);
+        else walk_segment_fast<false>(G, tile.start_position, min_bq, l, wid, NW, hbytes, s_masktab, on_obs, stamps);
 #else
-        if (G.dirs) walk_segment_fast<true>(G, tile.start_position, min_bq, l, wid, NW, hbytes, on_obs);
-        else walk_segment_fast<false>(G, tile.start_position, min_bq, l, wid, NW, hbytes, on_obs);
+        if (G.dirs) walk_segment_fast<true>(G, tile.start_position, min_bq, l, wid, NW, hbytes, s_masktab, on_obs);
+        else walk_segment_fast<false>(G, tile.start_position, min_bq, l, wid, NW, hbytes, s_masktab, on_obs);
 #endif
     }
 #ifdef PISCES_STORE_TIMING

@@ -19,6 +19,7 @@ static void store_view(const PiscesHip* h, StoreView* V)
         v.ext = g.ext.p;
         v.bases = g.v_bases;
         v.quals = g.v_quals;
+        v.codes = g.v_codes;
         v.dirs = g.v_dirs;
         v.cigar_op = g.v_cop;
         v.cigar_len = g.v_clen;
@@ -69,7 +70,7 @@ static int32_t store_new_segment(PiscesHip* h, std::unique_ptr<ReadSegment>* out
     g->floor = 0;
     g->max_key = 0;
     g->open = false;
-    g->v_bases = g->v_quals = g->v_dirs = g->v_cop = nullptr;
+    g->v_bases = g->v_quals = g->v_dirs = g->v_cop = g->v_codes = nullptr;
     g->v_clen = nullptr;
     { int32_t rc = store_state_slot(h, &g->state); if (rc) return rc; }
     *out = std::move(g);
@@ -249,7 +250,9 @@ static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const Sto
         PISCES_HIP_CHECK(h, g.desc.reserve((size_t)nr));
         PISCES_HIP_CHECK(h, g.ext.reserve((size_t)nr));
         PISCES_HIP_CHECK(h, g.frag.reserve(n_cig + 1));
+        PISCES_HIP_CHECK(h, g.codes.reserve(n_seq + 2 * (size_t)kSegmentPad));
         g.v_bases = A.bases; g.v_quals = A.quals; g.v_dirs = A.dirs; g.v_cop = A.cigar_op; g.v_clen = A.cigar_len;
+        g.v_codes = g.codes.p + kSegmentPad;
         S.n0 = 0; S.base0 = 0; S.ops0 = 0;
     } else {
         const size_t nb = (size_t)g.n_bases, no = (size_t)g.n_ops, n0 = (size_t)g.n_reads;
@@ -259,6 +262,7 @@ static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const Sto
         PISCES_HIP_CHECK(h, g.frag.grow_keep(no + n_cig + 1, no, h->stream));
         PISCES_HIP_CHECK(h, g.bases.grow_keep(nb + n_seq + 2 * kPad, nb + kPad, h->stream));
         PISCES_HIP_CHECK(h, g.quals.grow_keep(nb + n_seq + 2 * kPad, nb + kPad, h->stream));
+        PISCES_HIP_CHECK(h, g.codes.grow_keep(nb + n_seq + 2 * kPad, nb + kPad, h->stream));
         PISCES_HIP_CHECK(h, g.cop.grow_keep(no + n_cig + 16, no, h->stream));
         PISCES_HIP_CHECK(h, g.clen.grow_keep(no + n_cig + 16, no, h->stream));
         const bool tracks = g.v_dirs != nullptr;
@@ -266,6 +270,7 @@ static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const Sto
         if (wants) PISCES_HIP_CHECK(h, g.dirs.grow_keep(std::max(g.bases.cap, nb + n_seq + 2 * kPad), tracks ? nb + kPad : 0, h->stream));
         g.v_bases = g.bases.p + kPad; g.v_quals = g.quals.p + kPad; g.v_cop = g.cop.p; g.v_clen = g.clen.p;
         g.v_dirs = wants ? g.dirs.p + kPad : nullptr;
+        g.v_codes = g.codes.p + kPad;
         uint8_t* const w_bases = g.bases.p + kPad;
         uint8_t* const w_quals = g.quals.p + kPad;
         uint8_t* const w_dirs = wants ? g.dirs.p + kPad : nullptr;
@@ -291,7 +296,16 @@ static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const Sto
     S.dirs = A.dirs;
     S.min_bq = h->cfg.min_base_call_quality;
     S.state = g.state;
-    hipLaunchKernelGGL(read_shape_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, h->stream, S);
+    // the row codes of the batch's bases (what the flush kernel walks instead of bases + qualities), in the same launch: the workgroups
+    // behind the shape's own
+    S.enc_bases = A.bases;
+    S.enc_quals = A.quals;
+    S.enc_codes = const_cast<uint8_t*>(g.v_codes) + S.base0;
+    S.enc_n = (int64_t)n_seq;
+    S.enc_min_bq = (uint32_t)std::min(std::max(h->cfg.min_base_call_quality, 0), 127);
+    S.shape_blocks = (nr + 255) / 256;
+    const unsigned enc_blocks = (unsigned)std::min<int64_t>(((int64_t)n_seq + 16 * 256 - 1) / (16 * 256), 8192);
+    hipLaunchKernelGGL(read_shape_kernel, dim3((unsigned)S.shape_blocks + enc_blocks), dim3(256), 0, h->stream, S);
     if (!pl.direct && !A.dirs && g.v_dirs)   // a batch without directions in a segment that tracks them
         hipLaunchKernelGGL(segment_fill_dirs_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, h->stream, (const ReadDesc*)g.desc.p,
                            (const ReadExt*)g.ext.p, S.n0, S.n0 + nr, const_cast<uint8_t*>(g.v_dirs));
