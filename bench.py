@@ -288,8 +288,9 @@ def end_to_end_full(pileup, cfg, engine, torch):
                     "traffic_from": traffic_run,
                     "kernel": "pisces::call_store_tiles_kernel", "kernel_ms": kernel_ms, "launches_timed": int(launches),
                     "algorithmic_bytes_per_launch": nbytes,
-                    "what": "reads in HBM (1 B base + 1 B quality per aligned base) -> LDS histogram -> 64-byte records, one launch per flush; "
-                            "the kernel is VALU-issue-bound (DESIGN.md section 3.10), not HBM-bound"}
+                    "what": "reads in HBM -> LDS histogram -> 64-byte records, one launch per flush.  Algorithmic bytes as SURVEY 8d counts them "
+                            "(2 B per aligned base: base + quality, + 64 B per record); since round 5 the kernel itself loads 1 B per base (the row code "
+                            "encode_rows made of base and quality when the batch was added) and is instruction-issue-bound (DESIGN.md section 3.10)"}
         per_block = [(a0, synth.reads_of(pileup, min(7, n_amp - a0), first_amplicon=pileup.first_amplicon + a0)) for a0 in range(0, n_amp, 7)]
         best = None
         for rep in range(3):

@@ -6,23 +6,25 @@
 // histogram the call phase reads (IStateManager.AddAlleleCounts, RegionStateManager.cs:118-220, then IAlleleCaller.Call): no
 // observation log (8 bytes per observation written, then read three more times), no bucketing passes.
 //
-//   read_shape_kernel          add time: one lane per read, CIGAR -> ReadDesc / ReadExt, sortedness and longest reach of the segment
+//   read_shape_kernel          add time: one lane per read, CIGAR -> ReadDesc / ReadExt, sortedness and longest reach of the segment;
+//                              the workgroups behind those: the batch's row codes (encode_rows: 2 B read, 1 B written per base)
 //   segment_copy_kernel        add time, small batches only: the batch's bytes appended to the open segment
 //   segment_fill_dirs_kernel   a batch without per-base directions joining a segment that tracks them
 //   call_store_tiles_kernel    THE FLUSH: per tile, reads (+ bucketed log tuples of pisces_hip_add_observations, if any) -> LDS
-//                              histogram -> call_phase_wave (kernels.hip.h): HBM traffic ~ 2 B / observation + 16 B / read and tile + 64 B / record
+//                              histogram -> call_phase_wave (kernels.hip.h): HBM traffic ~ 1 B / observation (its row code) + 16 B / fragment and tile + 64 B / record
 //   accumulate_store_tiles_kernel  the same walk into the anchor-resolved tensor int32[locus][6][3][11] (+ base-quality sums) for the
 //                              candidate kernel, the collapser, NoiseModel.Window and IAlleleSource.GetAlleleCount
 //
 // Reads of a segment are in position order (a BAM is); a tile's reads are then the index range [first read that can still reach the
 // tile, first read that starts behind it), found by a 64-ary search over the descriptors (every lane probes one: 2-4 dependent loads).
 // A segment that turned out not to be sorted (state[0]) is scanned in whole: slow, still exact.
-// A read of one aligned run (soft clips allowed: most reads) is taken eight lanes at a time, eight bases a lane (walk_segment_fast; the
-// anchor-resolved walk_segment: sixteen lanes, four bases a lane);
+// The flush kernel walks ROW CODES (one byte per base, made at add time: encode_rows) by (fragment, half-tile) PAIRS, four lanes and
+// eight bases a lane each (walk_segment_fast); the anchor-resolved walk_segment reads bases and qualities, sixteen lanes a fragment, four bases a lane;
 // reads with insertions, deletions or skips go through read_walk.h's per-base function (the walk the host form and the log path use).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "kernels.hip.h"
 #include "read_walk.h"
@@ -795,25 +797,36 @@ __device__ __forceinline__ void walk_segment(const SegmentView& G, int tile_star
 // The general form above hands every base to a callback (18 VALU instructions a base with the histogram update of the call kernel:
 // 37.5 M a launch at BASELINE config 2, 4 cycles each — the kernel was VALU-bound at 3 x the tuple kernel's time).  Rounds 3-4 classified
 // four bases at once here (v_perm tables, 12.0 M VALU a launch); round 5 moved the classification to add time (encode_rows: one ROW CODE
-// per base, low-quality << 5 | allele << 2), so that what is left per lane and eight bases is
-//   * one 8-byte load of codes (bases and qualities are not read by the flush at all: half the bytes),
-//   * the on-the-read mask: first / last valid byte of the lane as two entries of a nine-entry LDS table of 64-bit masks (bytes >= a),
-//   * row = code | direction on the read, row 24 (a row nobody reads) elsewhere: v_or, v_bfi,
-//   * one v_perm_b32 (row byte and column byte -> LDS address) and one ds_add_u32 per base.
-// A lane holds EIGHT bases of a fragment (lane (g, j) = (lane >> 3, lane & 7): fragment g of the eight of a unit, the tile's loci
-// 8 j .. 8 j + 7) and adds its bytes in the order (s + rot) & 7, rot = (g + 4 (j >> 2)) & 7 (the eight row bytes are rotated by rot bytes
-// once): in every step the lanes of EACH 32-lane half — what a ds_add_u32 is serviced in — stand on 32 different banks (half 0: g = 0..3,
-// and g + 4 (j >> 2) takes eight different values for the eight lanes that share j & 3; rounds 3-4 rotated by g alone, which put lanes
-// j and j + 4 on one bank: 31 % of the kernel's LDS cycles were conflicts).
-struct ReadTrim {   // a descriptor with the floor applied: what is left of the read, per lane of a 64-read block
-    int32_t pos, end;     // first position still to count, one past the last
-    uint32_t aoff;        // index of the base on `pos` in the segment's arrays, + kSegmentPad
-    uint32_t dir4;        // the read's direction in every byte
-};
-constexpr int kMaskTab = 9;   // s_masktab[a] = the bytes >= a of eight (a = 8: none)
+// per base, low-quality << 5 | allele << 2) and gives lanes only to the parts of fragments that lie on the tile:
+//   * PAIRS.  A wave takes 64 fragments with one 16-byte load per lane, applies the floor, and lists — in LDS, by two ballots and
+//     v_mbcnt, no scan — the (fragment, half of the tile) pairs that hold at least one base: first the fragments that reach the left 32
+//     loci, then those that reach the right 32.  A fragment that only brushes the tile, lies on one half of it (an amplicon's edge
+//     inside the tile: half of a tile's fragments end there, the other half start there) or is only in the range because its READ may
+//     reach the tile costs one pair or none, where rounds 3-4 gave every fragment of the range eight lanes (71 % of the lane-bases of
+//     BASELINE config 2 were on a read, and a tile that straddles two amplicons took twice the time of one inside an amplicon: the
+//     launch ended 19 us after its median tile).
+//   * UNITS.  Sixteen pairs a unit: lane (q, jj) = (lane >> 2, lane & 3) holds, of pair q, the eight bases on the loci 8 jj .. 8 jj + 7
+//     of the pair's half — one 8-byte load of codes (bases and qualities are not read by the flush at all: half the bytes), the
+//     on-the-read mask from two entries of a nine-entry LDS table of 64-bit masks (bytes >= a), row = code | direction on the read and
+//     row 24 (a row nobody reads) elsewhere, then one v_perm_b32 (row byte, column byte -> LDS address) and one ds_add_u32 per base.
+//   * BANKS.  A lane adds its eight bytes in the order (s + q) & 7 (the row bytes are rotated by q & 7 bytes once; selectors and column
+//     bytes are then per-lane constants, the half's 128-byte column offset is or-ed into the column bytes).  A ds_add_u32 is serviced
+//     in two halves of 32 lanes, bank = locus mod 32 = 8 jj + step byte whatever the half of the tile: the eight lanes of a half-wave
+//     that share jj hold q = 0..7 (8..15), eight different bytes — no two lanes of a half-wave on one bank, whatever the pairs.
+//     (Rounds 3-4: lanes j and j + 4 of a fragment shared a bank: 31 % of the kernel's LDS cycles were conflicts.)
+//   * Four units are in flight per wave (a ring of four register sets refilled in order), in GROUPS of four: a block of 64 fragments
+//     is one group (up to 64 pairs) or two; the loop body is straight-line code around one uniform branch (the second group), so the
+//     compiler counts its waits instead of draining the queue.  The pairs of block b + 1 are listed (into the other of two LDS lists)
+//     before block b's units are consumed — its first group is what block b's last group prefetches — from descriptors requested a
+//     block earlier.
+constexpr int kMaskTab = 81;       // s_masktab[9 a + e] = the bytes a .. e - 1 of eight (a, e = 0..8; none when a >= e)
+constexpr int kPairSlots = 128 + 32;   // a block's pairs (<= 64 left + 64 right, the right ones from a multiple of 16) + the filler behind both
+// a pair: x = first valid byte * 8 (bits 0-9, in loci of the tile x 8: 0..512) | one past the last * 8 (bits 10-19) | half (bit 20) |
+// direction (bits 21-22); y = index, in the segment's arrays (+ kSegmentPad), of the base that would stand on the tile's first locus
 template <bool kDirs, typename OnObs>
 __device__ __forceinline__ void walk_segment_fast(const SegmentView& G, int tile_start, uint32_t min_bq, int lane, int wid, int n_waves, char* hbytes,
-                                                  const unsigned long long* s_masktab, OnObs on_obs, long long* stamps = nullptr /* development: PISCES_STORE_TIMING */)
+                                                  const unsigned long long* s_masktab, uint2* pairs /* LDS, this wave's [kPairSlots] */, OnObs on_obs,
+                                                  long long* stamps = nullptr /* development: PISCES_STORE_TIMING */)
 {
     if (G.n_frags <= 0) return;
     const int tile_end = tile_start + kTile - 1;
@@ -825,125 +838,163 @@ __device__ __forceinline__ void walk_segment_fast(const SegmentView& G, int tile
 #ifdef PISCES_STORE_TIMING
     if (stamps) { stamps[0] = wall_clock64(); stamps[1] = hi - lo; }
 #endif
-    const int g = lane >> 3, j8 = (lane & 7) * 8;
-    const int rot = (g + 4 * ((lane & 7) >> 2)) & 7;
-    const int lane_pos = tile_start + j8;
-    uint32_t col_lo = 0, col_hi = 0;   // byte s: LDS byte offset, inside a row, of the locus this lane stands on in step s
+    const int q = lane >> 2, jj = lane & 3;
+    const int rot = q & 7;
+    // per-lane constants: the column bytes of the eight steps (byte s: LDS byte offset, inside a row, of the locus this lane stands on
+    // in step s) for a pair on the left / on the right half of the tile; the selectors that rotate the eight row bytes right by rot bytes
+    uint32_t col_lo_l = 0, col_hi_l = 0, rot_lo = 0, rot_hi = 0;
 #pragma unroll
     for (int st = 0; st < 8; st++) {
-        const uint32_t c = (uint32_t)((j8 + ((st + rot) & 7)) * (int)sizeof(int));
-        if (st < 4) col_lo |= c << (8 * st);
-        else col_hi |= c << (8 * (st - 4));
+        const uint32_t c = (uint32_t)((8 * jj + ((st + rot) & 7)) * (int)sizeof(int));
+        const uint32_t from = (uint32_t)((st + rot) & 7);   // v_perm_b32(r1, r0, .): 0-3 = bytes of r0, 4-7 = bytes of r1
+        if (st < 4) { col_lo_l |= c << (8 * st); rot_lo |= from << (8 * st); }
+        else { col_hi_l |= c << (8 * (st - 4)); rot_hi |= from << (8 * (st - 4)); }
     }
+    const uint32_t col_lo_r = col_lo_l | 0x80808080u, col_hi_r = col_hi_l | 0x80808080u;   // the right half's columns: + 128 bytes
+    const int rel8_l = 64 * jj, rel8_r = 64 * jj + 256;   // the lane's first locus in the tile, x 8
     const uint8_t* const codes = G.codes - kSegmentPad;
     const uint8_t* const dirs = kDirs ? G.dirs - kSegmentPad : nullptr;
+    const ReadDesc* const frag = G.frag;
+    const int seg_floor = G.floor, n_floored_frags = G.n_floored_frags;
     const int n_blocks = (hi - lo + 63) >> 6;
     const int my_blocks = (n_blocks - wid + n_waves - 1) / n_waves;
     if (my_blocks > 0) {
-        struct Unit { uint32_t cw[2], dw[2]; unsigned long long ma, me; };   // eight fragments: this lane's eight codes of one of them
+        struct Unit { uint32_t cw[2], dw[2], ex; unsigned long long m; };   // sixteen pairs of ONE half: this lane's eight codes of one of them
         auto block_base = [&](int b) { return lo + (wid + min(b, my_blocks - 1) * n_waves) * 64; };
-        auto load_trim = [&](int b) {
+        auto load_desc = [&](int b) {
+            const int base = block_base(b);
+            return frag[base + min(lane, min(64, hi - base) - 1)];
+        };
+        // The pairs of block b (descriptors d, lane = fragment; past the wave's last block: none) into `list`: the left-half pairs from
+        // entry 0, the right-half pairs from the next multiple of 16 (a unit's sixteen pairs are all on one half: which half is then
+        // uniform, and the lanes' constants are picked by a branch, not computed), filler behind both.  *units_l / *units: units of
+        // left pairs / units in all (<= 4 + 4).
+        auto list_pairs = [&](int b, const ReadDesc& d, uint2* list, int* units_l, int* units) {
             const int base = block_base(b), cnt = min(64, hi - base);
-            const ReadDesc d = G.frag[base + min(lane, cnt - 1)];
             const int n = (b < my_blocks && lane < cnt && !(d.meta & kFragDeletion)) ? (int)(d.meta & kDescLenMask) : 0;
-            const int floor_pos = base + lane < G.n_floored_frags ? G.floor : 0;
+            const int floor_pos = base + lane < n_floored_frags ? seg_floor : 0;
             const int first = d.pos0 + frag_delta(d.aoff);   // the fragment's first position
-            ReadTrim t;
-            t.pos = max(first, floor_pos);
-            const int cut = t.pos - first;                   // positions below the floor
-            t.end = t.pos + max(n - min(cut, n), 0);
-            t.aoff = (uint32_t)(d.aoff & kFragAoffMask) + (uint32_t)min(cut, n) + (uint32_t)kSegmentPad;
-            t.dir4 = (d.meta & kDescReverse) ? (uint32_t)PISCES_DIR_REVERSE * 0x01010101u : (uint32_t)PISCES_DIR_FORWARD * 0x01010101u;
-            return t;
+            const int pos = max(first, floor_pos);            // first position still to count
+            const int cut = min(pos - first, n);              // bases below the floor (pos - first >= 0)
+            const int end = pos + (n - cut);                  // one past the last
+            const uint32_t aoff = (uint32_t)(d.aoff & kFragAoffMask) + (uint32_t)cut + (uint32_t)kSegmentPad;   // index of the base on `pos`
+            const int pr = min(max(pos - tile_start, 0), kTile), er = min(max(end - tile_start, 0), kTile);     // (differences of positive ints: no overflow)
+            const bool left = pr < min(er, 32), right = max(pr, 32) < er;
+            const uint32_t dirbits = (d.meta & kDescReverse) ? (uint32_t)PISCES_DIR_REVERSE : (uint32_t)PISCES_DIR_FORWARD;
+            uint2 e;
+            e.x = (uint32_t)(pr * 8) | ((uint32_t)(er * 8) << 10) | (dirbits << 24);
+            e.y = aoff + (uint32_t)(tile_start - pos);        // (wraps when the read starts behind the tile's first locus: added back per lane)
+            const unsigned long long ml = __ballot(left), mr = __ballot(right);
+            const int nl = __popcll(ml), nr = __popcll(mr);
+            const int ul = (nl + 15) >> 4, ur = (nr + 15) >> 4;
+            const uint2 filler = make_uint2(0u, (uint32_t)kSegmentPad);   // a pair with nothing on the read
+            if (lane < 16) { list[nl + lane] = filler; list[16 * ul + nr + lane] = filler; }
+            if (left) list[__builtin_amdgcn_mbcnt_hi((uint32_t)(ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ml, 0u))] = e;
+            if (right) list[16 * ul + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mr >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mr, 0u))] = e;
+            __builtin_amdgcn_wave_barrier();                            // (the list is read by other lanes of this wave: LDS operations of a wave execute in order)
+            *units_l = ul;
+            *units = ul + ur;
         };
-        // Unit u = fragments 8 u + g of the block whose trims are t.  Its trim reaches the lanes by four ds_bpermute (`shuffle`), issued one
-        // step ahead of the arithmetic that uses them (`issue`: the mask-table reads and the load) so that they do not queue behind the
-        // eight ds_add of the unit consumed in between.
-        struct Pre { int pos, end; uint32_t aoff, dir4; };
-        auto shuffle = [&](const ReadTrim& t, int u, Pre& P) {
-            const int src = 8 * u + g;
-            P.pos = __shfl(t.pos, src, 64);
-            P.end = __shfl(t.end, src, 64);
-            P.aoff = (uint32_t)__shfl((int)t.aoff, src, 64);
-            P.dir4 = kDirs ? 0u : (uint32_t)__shfl((int)t.dir4, src, 64);
-        };
-        auto issue = [&](const Pre& P, Unit& U) {
-            const int da = P.pos - lane_pos, de = P.end - lane_pos;   // the lane's bytes a .. e - 1 are on the read: a = clamp(da, 0, 8), e = clamp(de, 0, 8)
-            const int a = min(max(da, 0), 8), e = min(max(de, 0), 8);
-            U.ma = s_masktab[a];
-            U.me = s_masktab[e];
-            const uint32_t at = P.aoff - (uint32_t)(a < e ? da : 0);   // (eight bytes that are not on the read at all: the read's first)
+        // A unit: the pair reaches its four lanes by one ds_read_b64 (the same address in all four: a broadcast), read for all eight units
+        // of a block before the first unit of the block before it is consumed (behind a consumed unit's eight ds_add it would wait for them).
+        // `live` (uniform): the unit holds pairs; else only its load is issued (the same memory operations on every path: the compiler's
+        // wait counts stay exact — a branch with a load on one side made it drain the queue at the join).
+        auto issue = [&](const uint2 e, Unit& U, bool live, auto right) {   // right: std::true_type / std::false_type (two copies of the code, each with its own lane constants)
+            uint32_t at = (uint32_t)kSegmentPad;
+            if (live) {
+                const int rel8 = decltype(right)::value ? rel8_r : rel8_l;
+                const int a8 = min(max((int)(e.x & 0x3FFu) - rel8, 0), 64), e8 = min(max((int)((e.x >> 10) & 0x3FFu) - rel8, 0), 64);   // the lane's bytes a .. e - 1 are on the read
+                U.m = *reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(s_masktab) + (a8 * 9 + e8));
+                at = e.y + (uint32_t)(rel8 >> 3);   // the byte on the lane's first locus (up to 7 before the read's first, 63 behind its last: kSegmentPad)
+                U.ex = e.x;
+            }
+#if defined(PISCES_STORE_ABLATE) && PISCES_STORE_ABLATE == 5
+            const unsigned long long c8 = 0x0004080C0004080Cull + (at & 1u);   // development ablation: no loads of codes
+#else
             const unsigned long long c8 = load_u64_unaligned(codes + at);
+#endif
             U.cw[0] = (uint32_t)c8; U.cw[1] = (uint32_t)(c8 >> 32);
             if (kDirs) {
                 const unsigned long long d8 = load_u64_unaligned(dirs + at);
                 U.dw[0] = (uint32_t)d8; U.dw[1] = (uint32_t)(d8 >> 32);
-            } else {
-                U.dw[0] = U.dw[1] = P.dir4;
             }
         };
-        auto consume = [&](const Unit& U) {
-            const unsigned long long m8 = U.ma & ~U.me;   // bytes a .. e - 1 (none when a >= e)
-            const uint32_t m0 = (uint32_t)m8, m1 = (uint32_t)(m8 >> 32);
-            const uint32_t r0 = (m0 & (U.cw[0] | U.dw[0])) | (~m0 & 0x18181818u), r1 = (m1 & (U.cw[1] | U.dw[1])) | (~m1 & 0x18181818u);
+        auto consume = [&](const Unit& U, auto right) {
+            const uint32_t m0 = (uint32_t)U.m, m1 = (uint32_t)(U.m >> 32);   // the lane's bytes on the read
+            const uint32_t d0 = kDirs ? U.dw[0] : __builtin_amdgcn_perm(U.ex, U.ex, 0x03030303u), d1 = kDirs ? U.dw[1] : d0;   // (the pair's direction in every byte)
+            const uint32_t r0 = (m0 & (U.cw[0] | d0)) | (~m0 & 0x18181818u), r1 = (m1 & (U.cw[1] | d1)) | (~m1 & 0x18181818u);
 #if defined(PISCES_STORE_ABLATE) && PISCES_STORE_ABLATE == 2
             if ((r0 ^ r1) == 0x12345u) *reinterpret_cast<volatile int*>(hbytes) = 1;   // development ablation: no histogram update
             return;
 #endif
-            // the eight row bytes rotated right by rot bytes: {hi, lo} >> 8 rot for rot < 4, the words swapped first for rot >= 4
-            const uint32_t x = rot < 4 ? r0 : r1, y = rot < 4 ? r1 : r0;
-            const uint32_t lo8 = __builtin_amdgcn_alignbyte(y, x, (uint32_t)(rot & 3)), hi8 = __builtin_amdgcn_alignbyte(x, y, (uint32_t)(rot & 3));
+            const uint32_t cl = decltype(right)::value ? col_lo_r : col_lo_l, ch = decltype(right)::value ? col_hi_r : col_hi_l;
+            const uint32_t lo8 = __builtin_amdgcn_perm(r1, r0, rot_lo), hi8 = __builtin_amdgcn_perm(r1, r0, rot_hi);   // the eight row bytes rotated right by rot bytes
 #pragma unroll
             for (int st = 0; st < 4; st++)   // (row byte st and column byte st -> LDS address)
-                atomicAdd(reinterpret_cast<int*>(hbytes + __builtin_amdgcn_perm(lo8, col_lo, 0x0C0C0000u | ((uint32_t)(4 + st) << 8) | (uint32_t)st)), 1);
+                atomicAdd(reinterpret_cast<int*>(hbytes + __builtin_amdgcn_perm(lo8, cl, 0x0C0C0000u | ((uint32_t)(4 + st) << 8) | (uint32_t)st)), 1);
 #pragma unroll
             for (int st = 0; st < 4; st++)
-                atomicAdd(reinterpret_cast<int*>(hbytes + __builtin_amdgcn_perm(hi8, col_hi, 0x0C0C0000u | ((uint32_t)(4 + st) << 8) | (uint32_t)st)), 1);
+                atomicAdd(reinterpret_cast<int*>(hbytes + __builtin_amdgcn_perm(hi8, ch, 0x0C0C0000u | ((uint32_t)(4 + st) << 8) | (uint32_t)st)), 1);
         };
+        // (uniform branches: the half picks lane constants, nothing is computed from it)
+#define PISCES_ISSUE(E, R, K, UL, UN) { if ((K) < (UL)) issue(E, R, true, std::false_type()); else issue(E, R, (K) < (UN), std::true_type()); }
+#define PISCES_CONSUME(R, K, UL, UN) { if ((K) < (UL)) consume(R, std::false_type()); else if ((K) < (UN)) consume(R, std::true_type()); }
+        // One step a block.  Invariant at the top of step b: A / B hold the units 0-3 / 4-7 of block b (loads in flight; ul_c of its un_c
+        // units are of left pairs), `raw` the descriptors of block b + 1, requested a step ago.  The step lists block b + 1, requests the
+        // descriptors of block b + 2, and issues block b + 1's units as it consumes block b's.
+        Unit A0, A1, A2, A3, B0, B1, B2, B3;
+        int ul_c, un_c;
+        list_pairs(0, load_desc(0), pairs, &ul_c, &un_c);
+        ReadDesc raw = load_desc(1);
+        {
+            const uint2* const at = pairs + q;
+            PISCES_ISSUE(at[0], A0, 0, ul_c, un_c) PISCES_ISSUE(at[16], A1, 1, ul_c, un_c) PISCES_ISSUE(at[32], A2, 2, ul_c, un_c) PISCES_ISSUE(at[48], A3, 3, ul_c, un_c)
+            PISCES_ISSUE(at[64], B0, 4, ul_c, un_c) PISCES_ISSUE(at[80], B1, 5, ul_c, un_c) PISCES_ISSUE(at[96], B2, 6, ul_c, un_c) PISCES_ISSUE(at[112], B3, 7, ul_c, un_c)
+        }
 #ifdef PISCES_STORE_TIMING
 #define PISCES_TICK(k) { __builtin_amdgcn_sched_barrier(0); const long long now_ = clock64(); if (stamps) stamps[k] += now_ - tick_; tick_ = now_; __builtin_amdgcn_sched_barrier(0); }
         long long tick_ = clock64();
 #else
 #define PISCES_TICK(k)
 #endif
-        // Four units in flight (a ring of four register sets, eight units a block of 64 fragments: straight-line code, every load
-        // unconditional — past the last block the last block's descriptors are taken once more with nothing on the read, and never consumed)
-        ReadTrim tc = load_trim(0), tn = load_trim(1);
-        Unit R0, R1, R2, R3;
-        Pre P, Pn;
-        shuffle(tc, 0, P); issue(P, R0);
-        shuffle(tc, 1, P); issue(P, R1);
-        shuffle(tc, 2, P); issue(P, R2);
-        shuffle(tc, 3, P); issue(P, R3);
-        shuffle(tc, 4, P);
-#define PISCES_STEP(T, U_NEXT, R)            \
-        __builtin_amdgcn_sched_barrier(0);   \
-        shuffle(T, U_NEXT, Pn);              \
-        __builtin_amdgcn_sched_barrier(0);   \
-        consume(R);                          \
-        __builtin_amdgcn_sched_barrier(0);   \
-        issue(P, R);                         \
-        P = Pn;
         for (int b = 0; b < my_blocks; b++) {
-            PISCES_STEP(tc, 5, R0)   // R0: unit 0 consumed, unit 4 issued
-            PISCES_STEP(tc, 6, R1)
-            PISCES_STEP(tc, 7, R2)
-            PISCES_STEP(tn, 0, R3)
+            int ul_n, un_n;
+            list_pairs(b + 1, raw, pairs, &ul_n, &un_n);
             PISCES_TICK(2)
-            tc = tn;
-            tn = load_trim(b + 2);
+            raw = load_desc(b + 2);
+            const uint2* const at = pairs + q;
+            const uint2 e0 = at[0], e1 = at[16], e2 = at[32], e3 = at[48], f0 = at[64], f1 = at[80], f2 = at[96], f3 = at[112];
+#ifdef PISCES_STORE_TIMING
+            if ((e0.x ^ e1.x ^ e2.x ^ e3.x ^ f0.x ^ f1.x ^ f2.x ^ f3.x) == 0xFFFFFFFFu) stamps[5] += 1;   // (the entries are in: the tick below sees the LDS round trip)
+#endif
             PISCES_TICK(4)
-            PISCES_STEP(tc, 1, R0)   // R0: unit 4 consumed, the next block's unit 0 issued
-            PISCES_STEP(tc, 2, R1)
-            PISCES_STEP(tc, 3, R2)
-            PISCES_STEP(tc, 4, R3)
+            __builtin_amdgcn_sched_barrier(0);
+            PISCES_CONSUME(A0, 0, ul_c, un_c) PISCES_ISSUE(e0, A0, 0, ul_n, un_n)
+            __builtin_amdgcn_sched_barrier(0);
+            PISCES_CONSUME(A1, 1, ul_c, un_c) PISCES_ISSUE(e1, A1, 1, ul_n, un_n)
+            __builtin_amdgcn_sched_barrier(0);
+            PISCES_CONSUME(A2, 2, ul_c, un_c) PISCES_ISSUE(e2, A2, 2, ul_n, un_n)
+            __builtin_amdgcn_sched_barrier(0);
+            PISCES_CONSUME(A3, 3, ul_c, un_c) PISCES_ISSUE(e3, A3, 3, ul_n, un_n)
+            __builtin_amdgcn_sched_barrier(0);
+            PISCES_CONSUME(B0, 4, ul_c, un_c) PISCES_ISSUE(f0, B0, 4, ul_n, un_n)
+            __builtin_amdgcn_sched_barrier(0);
+            PISCES_CONSUME(B1, 5, ul_c, un_c) PISCES_ISSUE(f1, B1, 5, ul_n, un_n)
+            __builtin_amdgcn_sched_barrier(0);
+            PISCES_CONSUME(B2, 6, ul_c, un_c) PISCES_ISSUE(f2, B2, 6, ul_n, un_n)
+            __builtin_amdgcn_sched_barrier(0);
+            PISCES_CONSUME(B3, 7, ul_c, un_c) PISCES_ISSUE(f3, B3, 7, ul_n, un_n)
+            __builtin_amdgcn_sched_barrier(0);
+            ul_c = ul_n;
+            un_c = un_n;
             PISCES_TICK(3)
 #ifdef PISCES_STORE_TIMING
             if (stamps) stamps[5] += 1;
 #endif
         }
-#undef PISCES_STEP
 #undef PISCES_TICK
+#undef PISCES_ISSUE
+#undef PISCES_CONSUME
     }
     const int frag_bits = G.state[kStateFrags];
     // ---- the deletion fragments of the range (if the segment has any): lane = locus; a gap's positions count as deletions in the
@@ -1039,7 +1090,8 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
     __shared__ __attribute__((aligned(16))) int hist[2 * kWaveRegion];   // [region: quality-passing / low-quality][allele * 4 + direction][locus]
     __shared__ uint8_t s_refwin[kRefWin];
     __shared__ uint8_t s_vmask[kTile];
-    __shared__ unsigned long long s_masktab[kMaskTab + 1];
+    __shared__ unsigned long long s_masktab[kMaskTab];
+    __shared__ uint2 s_pairs[NW][kPairSlots];
 
     if ((int)blockIdx.x >= n_tiles) return;
 #ifdef PISCES_STORE_NO_SWIZZLE
@@ -1063,7 +1115,11 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
             const int64_t ri = (int64_t)tile.start_position - kRefMargin + i - ref_start;
             s_refwin[i] = (ri >= 0 && ri < ref_len) ? ref[ri] : (uint8_t)0;
         }
-        if (threadIdx.x < kMaskTab) s_masktab[threadIdx.x] = threadIdx.x >= 8 ? 0ull : ~0ull << (8 * threadIdx.x);
+        for (int i = threadIdx.x; i < kMaskTab; i += 64 * NW) {
+            const int a = i / 9, e = i - 9 * a;
+            const unsigned long long ge_a = a >= 8 ? 0ull : ~0ull << (8 * a), ge_e = e >= 8 ? 0ull : ~0ull << (8 * e);
+            s_masktab[i] = ge_a & ~ge_e;
+        }
         __syncthreads();
     }
     const uint32_t min_bq = (uint32_t)min(max(P.min_bq, 0), 127);   // (the host routes larger thresholds through the counts in HBM)
@@ -1086,11 +1142,11 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
     for (int sg = 0; sg < S.n_segments; sg++) {
         const SegmentView& G = S.seg[sg];
 #ifdef PISCES_STORE_TIMING
-        if (G.dirs) walk_segment_fast<true>(G, tile.start_position, min_bq, l, wid, NW, hbytes, s_masktab, on_obs, stamps);
-        else walk_segment_fast<false>(G, tile.start_position, min_bq, l, wid, NW, hbytes, s_masktab, on_obs, stamps);
+        if (G.dirs) walk_segment_fast<true>(G, tile.start_position, min_bq, l, wid, NW, hbytes, s_masktab, s_pairs[wid], on_obs, stamps);
+        else walk_segment_fast<false>(G, tile.start_position, min_bq, l, wid, NW, hbytes, s_masktab, s_pairs[wid], on_obs, stamps);
 #else
-        if (G.dirs) walk_segment_fast<true>(G, tile.start_position, min_bq, l, wid, NW, hbytes, s_masktab, on_obs);
-        else walk_segment_fast<false>(G, tile.start_position, min_bq, l, wid, NW, hbytes, s_masktab, on_obs);
+        if (G.dirs) walk_segment_fast<true>(G, tile.start_position, min_bq, l, wid, NW, hbytes, s_masktab, s_pairs[wid], on_obs);
+        else walk_segment_fast<false>(G, tile.start_position, min_bq, l, wid, NW, hbytes, s_masktab, s_pairs[wid], on_obs);
 #endif
     }
 #ifdef PISCES_STORE_TIMING

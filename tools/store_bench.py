@@ -27,7 +27,10 @@ def main():
             t0 = time.perf_counter()
             c.AddAlleleCounts(whole)
             t1 = time.perf_counter()
-            recs = c.Call(None, capacity=4 * a.loci)
+            try:
+                recs = c.Call(None, capacity=4 * a.loci)
+            except Exception as e:   # (ablation builds make no usable records)
+                recs = []
             t2 = time.perf_counter()
             if best is None or t2 - t0 < best[0]:
                 best = (t2 - t0, t1 - t0, t2 - t1)

@@ -34,17 +34,20 @@ print("t(us)  searching  walking  calling")
 for g in np.arange(0, te.max() + 1, 4.0):
     print(f"{g:6.0f} {int(((t0 <= g) & (ts > g)).sum()):9d} {int(((ts <= g) & (tw > g)).sum()):8d} {int(((tw <= g) & (te > g)).sum()):8d}")
 # per CU (XCC id, SE / SH / CU bits of HW_ID): how much work it was dealt and when its last tile ended
-cu = (t[:, 6].astype(np.int64) & 0xF) * 4096 + ((t[:, 5].astype(np.int64) >> 8) & 0xFFF)
+cu = (t[:, 6].astype(np.int64) & 0xF) * 256 + ((t[:, 5].astype(np.int64) >> 8) & 0xFF)   # XCC_ID, HW_ID.cu_id[11:8] | sh_id[12] | se_id[15:13]
 ids = np.unique(cu)
 work = np.array([nreads[cu == i].sum() for i in ids])
 last = np.array([te[cu == i].max() for i in ids])
 ntile = np.array([(cu == i).sum() for i in ids])
 print(f"CUs seen {len(ids)}; tiles per CU min/p50/max {ntile.min()} {int(np.median(ntile))} {ntile.max()}; fragments per CU min/p10/p50/p90/max "
       f"{np.round(np.percentile(work, [0, 10, 50, 90, 100]))}; max / mean {work.max() / work.mean():.2f}")
+for k in sorted(set(ntile.tolist())):
+    m = ntile == k
+    print(f"  CUs with {k} tiles: {int(m.sum())}; their last end p50 {np.percentile(last[m], 50):.1f} max {last[m].max():.1f} us; fragments p50 {np.percentile(work[m], 50):.0f}")
 print(f"last tile's end per CU us min/p10/p50/p90/max {np.round(np.percentile(last, [0, 10, 50, 90, 100]), 1)}; correlation(work, end) {np.corrcoef(work, last)[0, 1]:.2f}")
 # wave 0 of every tile: shader-clock cycles of its walk loop by part
 it = np.maximum(t[:, 10].astype(np.int64), 1)
-for name, k in (("issue (shuffles, masks, loads sent)", 7), ("consume (wait for the loads, classify, ds_add)", 8), ("next block's descriptors + trim", 9)):
+for name, k in (("list the next block's pairs (waits for its descriptors)", 7), ("consume 8 units / issue 8 units", 8), ("read the 8 pair entries (LDS round trip)", 9)):
     v = t[:, k].astype(np.int64)
     print(f"{name:48s} cycles per iteration p10/p50/p90 {np.round(np.percentile(v / it, [10, 50, 90]))}; per tile p50 {np.percentile(v, 50):.0f}")
 print("iterations per wave p50", np.percentile(it, 50))
