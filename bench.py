@@ -121,6 +121,108 @@ def cpu_baseline(torch, pileup, cfg, budget_s=14.0):
     return single, multi
 
 
+def _bgzf_with_offsets(stream, block=0xFF00):
+    """BGZF of `stream` (DEFLATE level 1) + the start of every block in the file and in the stream: virtual offsets for a .bai."""
+    import struct
+    import zlib
+    out, file_at, stream_at = [], [], []
+    at = 0
+    for o in range(0, len(stream), block):
+        raw = stream[o:o + block]
+        co = zlib.compressobj(1, zlib.DEFLATED, -15)
+        body = co.compress(raw) + co.flush()
+        blk = (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(body) + 25) + body + struct.pack("<II", zlib.crc32(raw), len(raw)))
+        file_at.append(at)
+        stream_at.append(o)
+        out.append(blk)
+        at += len(blk)
+    out.append(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))   # the EOF block
+    return b"".join(out), file_at, stream_at
+
+
+def reference_csharp_baseline(pileup, cfg, n_amplicons=40, timeout_s=120):
+    """SURVEY 8d / BASELINE.md 3.2: when the box has a `dotnet` host AND PISCES_REF_DLL names a Pisces build, the reference C# itself is timed
+    on a bounded sample of the same reads (a synthetic BAM + .bai + genome folder written here; `dotnet Pisces.dll -bam .. -g .. -t 1`,
+    BaseApplication.cs:141-151 prints what it did; the wall clock of the process is what is reported).  Neither exists in the image this
+    was written in: the probe's outcome is part of the bench line either way, and the port stays the baseline then."""
+    import shutil
+    import struct
+    import subprocess
+    import tempfile
+    import numpy as np
+    from pisces_amd import synth
+    dotnet, dll = shutil.which("dotnet"), os.environ.get("PISCES_REF_DLL")
+    probe = {"dotnet": dotnet, "PISCES_REF_DLL": dll, "ran": False}
+    if not dotnet or not dll or not os.path.exists(dll):
+        probe["why"] = "no `dotnet` on PATH" if not dotnet else "PISCES_REF_DLL is not set" if not dll else "PISCES_REF_DLL does not exist"
+        return probe
+    try:
+        from tools.bam_bench import bam_of_read_batch
+        n_amp = min(n_amplicons, pileup.base.shape[0])
+        rb = synth.reads_of(pileup, n_amp)
+        ref = pileup.ref.cpu().numpy()
+        chrom_len = int(pileup.ref_start - 1 + len(ref))
+        stream = bam_of_read_batch(rb, chrom=b"chr1", chrom_len=chrom_len)
+        data, file_at, stream_at = _bgzf_with_offsets(stream)
+        # record starts in the stream -> virtual offsets; one chunk per bin, the linear index per 16 KiB window (SAM spec 5.2)
+        n = rb.n_reads
+        rec_len = (len(stream) - (12 + 4 + 5 + 4)) // max(n, 1)
+        starts = len(stream) - n * rec_len + np.arange(n + 1, dtype=np.int64) * rec_len
+        blk = np.searchsorted(np.asarray(stream_at), starts, side="right") - 1
+        voff = (np.asarray(file_at, dtype=np.int64)[blk] << 16) | (starts - np.asarray(stream_at, dtype=np.int64)[blk])
+        beg = np.asarray(rb.position, dtype=np.int64) - 1
+        end = beg + np.diff(np.asarray(rb.seq_offset))
+
+        def reg2bin(b, e):
+            e = e - 1
+            for shift, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+                if b >> shift == e >> shift:
+                    return base + (b >> shift)
+            return 0
+        bins = {}
+        for i in range(n):
+            k = reg2bin(int(beg[i]), int(end[i]))
+            lo, hi = bins.get(k, (int(voff[i]), int(voff[i + 1])))
+            bins[k] = (min(lo, int(voff[i])), max(hi, int(voff[i + 1])))
+        n_intv = int(end.max() >> 14) + 1
+        lin = np.zeros(n_intv, dtype=np.uint64)
+        for i in range(n):
+            for w in range(int(beg[i]) >> 14, (int(end[i]) - 1 >> 14) + 1):
+                if lin[w] == 0 or voff[i] < lin[w]:
+                    lin[w] = voff[i]
+        bai = b"BAI\x01" + struct.pack("<ii", 1, len(bins))
+        for k in sorted(bins):
+            bai += struct.pack("<IiQQ", k, 1, bins[k][0], bins[k][1])
+        bai += struct.pack("<i", n_intv) + lin.tobytes() + struct.pack("<Q", 0)
+        with tempfile.TemporaryDirectory() as tmp:
+            gdir = os.path.join(tmp, "genome")
+            os.mkdir(gdir)
+            seq = (b"N" * (pileup.ref_start - 1) + ref.tobytes()).decode()
+            with open(os.path.join(gdir, "genome.fa"), "w") as f:
+                f.write(">chr1\n" + "\n".join(seq[i:i + 60] for i in range(0, len(seq), 60)) + "\n")
+            with open(os.path.join(gdir, "genome.fa.fai"), "w") as f:
+                f.write(f"chr1\t{len(seq)}\t6\t60\t61\n")
+            with open(os.path.join(gdir, "GenomeSize.xml"), "w") as f:
+                f.write(f'<sequences genomeName="synthetic">\n  <chromosome fileName="genome.fa" contigName="chr1" totalBases="{len(seq)}" isCircular="false" '
+                        f'md5="00000000000000000000000000000000" ploidy="2" knownBases="{len(seq)}" />\n</sequences>')
+            bam = os.path.join(tmp, "sample.bam")
+            open(bam, "wb").write(data)
+            open(bam + ".bai", "wb").write(bai)
+            cmd = [dotnet, dll, "-bam", bam, "-g", gdir, "-t", "1", "-gvcf", "true", "-minbq", str(cfg.min_base_call_quality), "-OutFolder", os.path.join(tmp, "out")]
+            t0 = time.perf_counter()
+            run = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+            dt = time.perf_counter() - t0
+            n_loci = min(pileup.n_loci, n_amp * synth.READ_LEN)
+            probe.update(ran=run.returncode == 0, returncode=run.returncode, seconds=dt, command=" ".join(cmd[:2]) + " -bam <synthetic> -g <synthetic> -t 1 -gvcf true",
+                         stdout_tail=run.stdout[-300:], stderr_tail=run.stderr[-300:])
+            if run.returncode == 0:
+                probe["cpu_baseline"] = {"value": n_loci / dt, "unit": "candidate loci/s", "cores": 1, "kind": "reference",
+                                         "sample": f"first {n_loci} loci x {pileup.depth}x of batch 0 ({n} reads), dotnet Pisces.dll -t 1, process wall clock {dt:.1f} s (start-up included)"}
+    except Exception as e:   # noqa: BLE001  (a probe: it must not cost the bench line)
+        probe["why"] = "the reference run failed: " + str(e)[:300]
+    return probe
+
+
 def end_to_end(pileup, cfg, engine, loci=30_000):
     """the end-to-end rate of the drop-in boundary (the streaming surface the C# shim drives), host buffers in,
     called alleles out, H2D / D2H and every host pass included: reads of the first `loci` loci of batch 0 through
@@ -977,7 +1079,8 @@ def main():
                 dist.broadcast_object_list(ids, src=0)
                 caller.comm_init(ids[0], rank, world)
                 red = caller.reduce_summary([totals["records"], totals["candidate_loci"], totals["called"], totals["tiles"]])
-                box["r"] = {"ok": red == [int(x) for x in summary.tolist()], "summary": red}
+                box["r"] = {"ok": red == [int(x) for x in summary.tolist()], "summary": red, "ranks": caller.comm_ranks(),
+                            "library": engine.HipVariantCaller.comm_library()}
             except Exception as e:   # noqa: BLE001
                 box["r"] = {"ok": False, "error": str(e)[:200]}
 
@@ -1063,6 +1166,10 @@ def main():
                                 "note": "same steps over several HIP streams; not the contract's value, not a per-kernel roofline"}
         if shard_check is not None:
             out["shard_check"] = shard_check
+        # ranks that joined the collectives of this run: torch.distributed's process group (the timed region's reduce) and, N > 1, ncclCommCount
+        # of the communicator the library itself made through the C ABI (1 at N = 1: no communicator, the value is the 1-GPU path's)
+        out["rccl_ranks"] = {"torch_process_group": dist.get_world_size() if use_dist else 1,
+                             "c_abi_comm_count": (c_abi_reduce or {}).get("ranks", caller.comm_ranks() if world == 1 else None)}
         if c_abi_reduce is not None:
             out["c_abi_reduce"] = c_abi_reduce
         if config4_line is not None:
@@ -1084,6 +1191,11 @@ def main():
                     out["end_to_end_full"]["from_bam_bytes_large"] = {"error": str(e)[:200]}
         if not args.no_cpu_baseline and world == 1:   # timed on rank 0 at N=1 only
             out["cpu_baseline"], out["cpu_baseline_threads"] = cpu_baseline(torch, ring[0], cfg)
+            # the reference C# itself beside the port, when the box can run it: the probe's outcome is reported either way
+            out["cpu_baseline_reference"] = reference_csharp_baseline(ring[0], cfg)
+            if out["cpu_baseline_reference"].get("cpu_baseline"):
+                out["cpu_baseline_port"] = out["cpu_baseline"]
+                out["cpu_baseline"] = out["cpu_baseline_reference"]["cpu_baseline"]
         print(json.dumps(out), flush=True)
     if c_abi_hung:   # a side thread sits in a communicator that never came up: nothing more to do in this process
         sys.stdout.flush()

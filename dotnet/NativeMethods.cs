@@ -141,6 +141,8 @@ namespace Pisces.Hip
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_device_totals(IntPtr handle, [Out] long[] totals4, int reset);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_synchronize(IntPtr handle);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_get_stream(IntPtr handle, out IntPtr stream);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_comm_library([Out] byte[] text, int capacity);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_comm_ranks(IntPtr handle, out int ranks);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_get_counts(IntPtr handle, int startPosition, int n, [Out] int[] counts);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_add_gapped_mnv_ref(IntPtr handle, int[] positions, int[] counts, int n);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_get_gapped_mnv_ref(IntPtr handle, int position, out int count);

@@ -424,6 +424,13 @@ int32_t pisces_hip_comm_unique_id(uint8_t* id_out, int32_t capacity);
 int32_t pisces_hip_comm_init(PiscesHip* h, const uint8_t* id, int32_t rank, int32_t world);
 int32_t pisces_hip_reduce_summary(PiscesHip* h, int64_t inout[4]);
 int32_t pisces_hip_comm_destroy(PiscesHip* h);
+/* Which librccl the library binds, and how it found it — in this order, the first that applies deciding: (1) the file PISCES_HIP_RCCL_PATH
+ * names (an error naming it if it cannot be bound); (2) a librccl.so the process has mapped already (a PyTorch host brings its own under
+ * torch/lib: binding THAT copy keeps one RCCL per process); (3) librccl.so.1 / librccl.so on the loader's path, then /opt/rocm/lib.
+ * Writes "<source>: <path>" (source = PISCES_HIP_RCCL_PATH | mapped | default) and returns its length, or PISCES_E_DEVICE. */
+int32_t pisces_hip_comm_library(char* out, int32_t capacity);
+/* ncclCommCount of the handle's communicator (1 without one). */
+int32_t pisces_hip_comm_ranks(PiscesHip* h, int32_t* ranks);
 
 /* ---- device-resident surface (bench / multi-GPU shards) --------------------
  * All d_* pointers are device pointers on the handle's device; stream is a hipStream_t

@@ -927,6 +927,21 @@ __global__ __launch_bounds__(256) void build_gq_cap_kernel(int16_t* __restrict__
 }
 
 // streaming-read probe: the hot kernel's load pattern (non-temporal dwordx4, 8 per lane in flight) and nothing else
+// pisces_hip_device_totals: the running totals' shards added up into host-visible memory as this kernel's own stores (no copy operation,
+// one stream wait on the host), and cleared when asked to
+__global__ __launch_bounds__(64) void totals_collect_kernel(unsigned long long* __restrict__ shards, unsigned long long* __restrict__ out_host, int reset)
+{
+    const int l = threadIdx.x;
+    if (l < 4) {
+        unsigned long long v = 0;
+        for (int sh = 0; sh < kTotalShards; sh++) v += shards[sh * kTotalStride + l];
+        out_host[l] = v;
+    }
+    if (reset)
+        for (int i = l; i < kTotalShards * kTotalStride; i += 64) shards[i] = 0ull;
+    __threadfence_system();
+}
+
 __global__ __launch_bounds__(256) void read_probe_kernel(const u32x4* __restrict__ p, int64_t n4, uint32_t* __restrict__ sink)
 {
     uint32_t acc = 0;

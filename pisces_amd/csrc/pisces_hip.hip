@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <dlfcn.h>
+#include <link.h>
 
 #include <algorithm>
 #include <array>
@@ -280,6 +281,10 @@ struct PiscesHip {
     int64_t launches_seen = 0;
     DeviceBuf<unsigned long long> d_totals;
     unsigned long long* h_totals = nullptr;   // pinned: pisces_hip_device_totals
+    bool foreign_stream_used = false;         // a call_tiles launch went to a stream that is not the handle's since the last pisces_hip_device_totals
+    bool foreign_stream_ever = false;         // ... ever (pisces_hip_destroy)
+    bool poisoned = false;                    // the deferred half of a batch's candidate discovery failed after the batch was committed (finish_candidate_discovery)
+    std::string poison_why;
     uint8_t* h_prep = nullptr;                // pinned: prepare_collect_kernel's PrepVerdict + the keys of the touched blocks
     DeviceBuf<double> d_qlut;
     DeviceBuf<ulonglong2> d_bq_lut;   // [256] Math.Pow(10, -1 * (int)q / 10f) in fixed point (two 38-bit halves): what a base of quality q adds to the sums
@@ -943,6 +948,9 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     bool idle = !h->stream || hipStreamSynchronize(h->stream) == hipSuccess;
     for (int k = 0; k < PiscesHip::kLanes; k++)
         if (h->lane[k] && hipStreamSynchronize(h->lane[k]) != hipSuccess) idle = false;
+    // launches that went to a caller's stream may still read the handle's tables: the buffers only go to the cache (and so to the next
+    // handle) once the whole device is idle (hipFree used to wait implicitly; the cache does not)
+    if (h->foreign_stream_ever && hipDeviceSynchronize() != hipSuccess) idle = false;
     (void)pisces_hip_comm_destroy(h);
     struct KeepFreed {   // nothing of the handle is in flight: what it held may go to the next handle as it is
         explicit KeepFreed(bool on) { tl_keep_freed = on; }

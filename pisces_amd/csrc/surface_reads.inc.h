@@ -56,9 +56,13 @@ static int32_t meta_upload(PiscesHip* h, void* dst, const void* src, size_t byte
     return PISCES_OK;
 }
 
+static int32_t finish_candidate_discovery(PiscesHip* h);
 // next staging pair with room for `bytes`; waits only for the work that used THIS pair two calls ago
 static int32_t stage_reserve(PiscesHip* h, size_t bytes, bool with_device_half = true)
 {
+    // a deferred candidate walk (find_emit of the last batch, still to be enqueued) reads that batch's arrays where they lie — for a small
+    // batch in the device half of a staging pair, which two more reservations would overwrite or a growing reserve free: it goes first
+    { int32_t rcd = finish_candidate_discovery(h); if (rcd) return rcd; }
     h->stage_cur ^= 1;
     PiscesHip::Stage& st = h->stage[h->stage_cur];
     if (!st.done) PISCES_HIP_CHECK(h, hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
@@ -439,13 +443,22 @@ static int32_t enqueue_candidate_discovery(PiscesHip* h, const DevReadBatch& db,
 // the second half of a batch's candidate discovery (MNV calling on; or off, over reads with X / = operations), if it is still to come
 static int32_t finish_candidate_discovery(PiscesHip* h)
 {
+    // A failure here comes AFTER the batch's reads were committed (its counts are in the store, its candidates are not): the handle no
+    // longer holds what the reference's state manager would, and says so on every later call instead of calling without them.
+    if (h->poisoned) return fail(h, PISCES_E_STATE, "the candidates of an earlier batch were lost (" + h->poison_why + "): the handle's state is unusable, destroy it");
     if (!h->found.counted_only) return PISCES_OK;
     h->found.counted_only = false;
     h->found.in_flight = false;
     PISCES_TIMED_WAIT(h, hipEventSynchronize(h->found.counted));
     const long long found_slots = h->found.h_totals[0], found_pool = h->found.h_totals[1];
-    if (found_slots > 0x7FFFFFF0ll || found_pool > 0x7FFFFFF0ll) return fail(h, PISCES_E_INVALID_ARG, "add_reads: too many candidates in one batch");
-    return enqueue_found_records(h, h->found.db, h->found.d_deldirs, h->found.nr, h->found.fp, h->d_found_slots.p, h->d_found_pool_first.p, found_slots, found_pool);
+    int32_t rc = PISCES_OK;
+    if (found_slots > 0x7FFFFFF0ll || found_pool > 0x7FFFFFF0ll) rc = fail(h, PISCES_E_INVALID_ARG, "add_reads: too many candidates in one batch");
+    else rc = enqueue_found_records(h, h->found.db, h->found.d_deldirs, h->found.nr, h->found.fp, h->d_found_slots.p, h->d_found_pool_first.p, found_slots, found_pool);
+    if (rc) {
+        h->poisoned = true;
+        h->poison_why = h->err;
+    }
+    return rc;
 }
 static int32_t enqueue_found_records(PiscesHip* h, const DevReadBatch& db, const uint8_t* d_deldirs, int32_t nr, const FinderParams& FP, const int32_t* d_slots,
                                      const int32_t* d_pool_first, int64_t found_slots, int64_t found_pool)

@@ -345,6 +345,21 @@ class HipVariantCaller:
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         _check(self._h, lib.pisces_hip_comm_init(self._h, buf, int(rank), int(world)))
 
+    @staticmethod
+    def comm_library():
+        """pisces_hip_comm_library: '<source>: <path>' of the librccl the library binds (source = PISCES_HIP_RCCL_PATH | mapped | default)."""
+        buf = C.create_string_buffer(4096)
+        rc = lib.pisces_hip_comm_library(buf, len(buf))
+        if rc < 0:
+            raise PiscesHipError(rc, (lib.pisces_hip_last_error(None) or b"").decode(errors="replace"))
+        return buf.value.decode()
+
+    def comm_ranks(self):
+        """ncclCommCount of the handle's communicator (1 without one)."""
+        n = C.c_int32(0)
+        _check(self._h, lib.pisces_hip_comm_ranks(self._h, C.byref(n)))
+        return int(n.value)
+
     def reduce_summary(self, values):
         """In-place sum over the ranks of the int64[4] summary (identity without a communicator)."""
         v = (C.c_int64 * 4)(*[int(x) for x in values])

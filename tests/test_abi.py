@@ -166,3 +166,45 @@ def test_graft_entry_build_succeeds():
     """The driver's build check: __graft_entry__.build() compiles (or finds up to date) the HIP library and the oracle and imports the package."""
     import __graft_entry__ as g
     g.build()
+
+
+def _comm_library_in_a_fresh_process(prelude, env=None):
+    """pisces_hip_comm_library binds RCCL once per process: every case gets a process of its own."""
+    import subprocess
+    import sys
+    code = prelude + "\nfrom pisces_amd import engine\ntry:\n    print('OK ' + engine.HipVariantCaller.comm_library())\nexcept Exception as e:\n    print('ERR ' + str(e))\n"
+    e = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    e.pop("PISCES_HIP_RCCL_PATH", None)
+    e.update(env or {})
+    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith(("OK ", "ERR "))]
+    assert lines, (out.stdout[-500:], out.stderr[-500:])
+    return lines[-1]
+
+
+def test_rccl_lookup_order():
+    """surface_comm.inc.h binds RCCL at run time, in this order: PISCES_HIP_RCCL_PATH (and nothing else when it is set), a librccl.so the
+    process has mapped already (a PyTorch host's own copy: one RCCL per process), the loader's path / /opt/rocm/lib.  No GPU needed:
+    binding is dlopen + dlsym."""
+    import importlib.util
+    system = "/opt/rocm/lib/librccl.so"
+    if not os.path.exists(system):
+        import pytest
+        pytest.skip("no system RCCL in this image")
+    # 1. the environment decides, also when what it names cannot be loaded (no fall-through to another copy)
+    r = _comm_library_in_a_fresh_process("", {"PISCES_HIP_RCCL_PATH": "/nonexistent/librccl.so"})
+    assert r.startswith("ERR ") and "PISCES_HIP_RCCL_PATH=/nonexistent/librccl.so" in r, r
+    r = _comm_library_in_a_fresh_process("", {"PISCES_HIP_RCCL_PATH": system})
+    assert r == "OK PISCES_HIP_RCCL_PATH: " + system, r
+    # 2. a copy that is mapped already wins over the default names — and the environment wins over it
+    spec = importlib.util.find_spec("torch")
+    torch_rccl = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so") if spec and spec.origin else None
+    if torch_rccl and os.path.exists(torch_rccl):
+        prelude = "import ctypes\nfrom pisces_amd import _native\nctypes.CDLL(%r)" % torch_rccl
+        r = _comm_library_in_a_fresh_process(prelude)
+        assert r == "OK mapped: " + torch_rccl, r
+        r = _comm_library_in_a_fresh_process(prelude, {"PISCES_HIP_RCCL_PATH": system})
+        assert r == "OK PISCES_HIP_RCCL_PATH: " + system, r
+    # 3. nothing mapped, nothing named: the loader's path
+    r = _comm_library_in_a_fresh_process("")
+    assert r.startswith("OK default: "), r
