@@ -513,6 +513,74 @@ def config3_sample(engine, torch, amps=200):
                     "not a per-kernel figure: profiles/r04_config3_kernel_stats.csv has those; all of config 3: python bench.py --config 3"}
 
 
+def config5_sample(engine, torch, amps=40):
+    """BASELINE config 5's settings (0.5 % VAF SNVs at 5000x, -minbq 30 -minvf 0.005 -sbfilter 0.5 -vqfilter 30, gVCF) on a sample that
+    finishes in seconds (40 amplicons = 6 000 loci x 5000x = 200 000 reads): reads in DEVICE memory -> records, one add + one flush, best
+    of three — the form `python bench.py --config 5` runs over all 100 000 loci.  roofline: the path's algorithmic bytes (2 B per aligned
+    base + 64 B per record) over the wall clock of the pair."""
+    from pisces_amd import synth
+    seed, depth = 23, 5000
+    cfg5 = _abi_config(min_base_call_quality=30, noise_level=30, min_frequency=0.005, variant_freq_filter=0.005, genotype_min_freq_filter=0.005,
+                       target_lod_frequency=0.005, strand_bias_threshold=0.5, variant_qscore_filter=30)
+    n_loci = amps * synth.READ_LEN
+    ref5 = synth.reference_of(n_loci, seed, device="cuda")
+    p5 = synth.make_pileup(n_loci, depth, seed=seed, device="cuda", first_locus=0, total_loci=n_loci, with_tuples=False,
+                           vaf_range=(0.005, 0.005), snv_every=50, snv_offset=17, q_lo=12)
+    batch = synth.reads_of(p5, amps, first_amplicon=0)
+    dbatch = engine.DeviceReadBatch.from_host(batch, "cuda:0")
+    del p5
+    with engine.HipVariantCaller(cfg5) as c:
+        c.SetReference(ref5)
+        best, best_add, n_rec = None, None, 0
+        for rep in range(4):
+            if rep == 1:
+                c.HostTime(reset=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            c.AddDeviceReads(dbatch)
+            t1 = time.perf_counter()
+            n_rec = len(c.CallView(None))
+            dt = time.perf_counter() - t0
+            if rep > 0 and (best is None or dt < best):
+                best, best_add = dt, t1 - t0
+        ht = c.HostTime(reset=True)
+    nbytes = 2.0 * batch.n_bases + 64.0 * n_rec
+    return {"bound": "hbm", "achieved": nbytes / best / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / best / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes": nbytes, "value": n_loci / best, "value_unit": "candidate loci/s", "seconds": best, "seconds_in_add": best_add,
+            "loci": n_loci, "depth": depth, "reads": int(batch.n_reads), "records": n_rec, "host_seconds_in_flush_per_flush": ht["host_ms_per_flush"] / 1e3,
+            "what": "BASELINE config 5's settings, a 6 000-locus sample, reads in device memory -> records on the host: pisces_hip_add_device_reads + one "
+                    "pisces_hip_flush_view; wall clock of the pair, not a per-kernel figure; all of config 5: python bench.py --config 5"}
+
+
+def config4_sample(engine, torch, n_intervals=2000):
+    """BASELINE config 4's data (150 bp intervals 300 bp apart at 200x, SNVs + small insertions / deletions, interval set applied,
+    zero-coverage rows on) on ONE synthetic contig of 2 000 intervals = 300 000 loci (the whole job is 200 000 intervals on 24 contigs cut
+    8 ways: `python bench.py --config 4`, and `config4_strong_scaling` of a multi-GPU line): the contig's reads in device memory, the
+    streaming surface in stretches of 400 000 reads as pisces_amd.config4.run_piece drives it, records looked at in place; best of three."""
+    from pisces_amd import config4
+    cfg4 = _abi_config(emit_zero_coverage_refs=1)
+    job = config4.make_contig(0, n_intervals, depth=200, device="cuda:0")
+    dev_arrays = config4.device_arrays(job, "cuda:0")
+    plan = config4.piece_plan(job, None, None)
+    chunks = config4.device_chunks(engine, job, dev_arrays, plan)
+    best, recs, stats = None, None, None
+    for rep in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        recs, _, stats, owned = config4.run_piece(engine, cfg4, job, None, None, device=0, with_alleles=False, keep_records=False, plan=plan, chunks=chunks)
+        dt = time.perf_counter() - t0
+        if rep > 0 and (best is None or dt < best):
+            best = dt
+    n_bases = int(job["batch"].n_bases)
+    nbytes = 2.0 * n_bases + 64.0 * recs["n"]
+    return {"bound": "hbm", "achieved": nbytes / best / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / best / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes": nbytes, "value": recs["loci"] / best, "value_unit": "candidate loci/s", "seconds": best, "loci": recs["loci"], "depth": 200,
+            "intervals": n_intervals, "reads": int(job["batch"].n_reads), "records": recs["n"],
+            "host_seconds": {k: stats["host_time"][k] for k in ("add_reads_s", "flush_s", "flush_wait_s")},
+            "what": "BASELINE config 4's data on one contig of 2 000 intervals (300 000 loci x 200x), reads in device memory -> records read in place: "
+                    "set_reference + set_intervals + add_device_reads / flush_view in stretches on a handle made for the piece; wall clock per GPU"}
+
+
 def from_large_bam(cfg, engine, reads=400_000, copies=9):
     """the BAM surface on a file of >= 256 MB: 3.6 M reads of 150 bases drawn from a random reference with 0.5 % wrong
     bases at ~450x (tools/bam_bench.make_bam), BGZF at zlib level 1 (1.0 GB inflated, ~265 MB compressed: position-sorted reads of one
@@ -1180,10 +1248,11 @@ def main():
                 out["end_to_end_full"], out["roofline_streaming"] = end_to_end_full(ring[0], cfg, engine, torch)
             except Exception as e:   # noqa: BLE001  (extra figures: they must not cost the bench line)
                 out["end_to_end_full"] = {"error": str(e)[:200]}
-            try:
-                out["roofline_config3"] = config3_sample(engine, torch)
-            except Exception as e:   # noqa: BLE001
-                out["roofline_config3"] = {"error": str(e)[:200]}
+            for key, sample in (("roofline_config3", config3_sample), ("roofline_config5", config5_sample), ("roofline_config4", config4_sample)):
+                try:
+                    out[key] = sample(engine, torch)
+                except Exception as e:   # noqa: BLE001  (extra figures: they must not cost the bench line)
+                    out[key] = {"error": str(e)[:200]}
             if not args.no_large_bam:
                 try:
                     out["end_to_end_full"]["from_bam_bytes_large"] = from_large_bam(cfg, engine)
