@@ -513,9 +513,9 @@ def config3_sample(engine, torch, amps=200):
                     "not a per-kernel figure: profiles/r04_config3_kernel_stats.csv has those; all of config 3: python bench.py --config 3"}
 
 
-def config5_sample(engine, torch, amps=40):
+def config5_sample(engine, torch, amps=100):
     """BASELINE config 5's settings (0.5 % VAF SNVs at 5000x, -minbq 30 -minvf 0.005 -sbfilter 0.5 -vqfilter 30, gVCF) on a sample that
-    finishes in seconds (40 amplicons = 6 000 loci x 5000x = 200 000 reads): reads in DEVICE memory -> records, one add + one flush, best
+    finishes in seconds (100 amplicons = 15 000 loci x 5000x = 500 000 reads): reads in DEVICE memory -> records, one add + one flush, best
     of three — the form `python bench.py --config 5` runs over all 100 000 loci.  roofline: the path's algorithmic bytes (2 B per aligned
     base + 64 B per record) over the wall clock of the pair."""
     from pisces_amd import synth
@@ -548,7 +548,7 @@ def config5_sample(engine, torch, amps=40):
     return {"bound": "hbm", "achieved": nbytes / best / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / best / 1e9 / HBM_PEAK_GBS,
             "algorithmic_bytes": nbytes, "value": n_loci / best, "value_unit": "candidate loci/s", "seconds": best, "seconds_in_add": best_add,
             "loci": n_loci, "depth": depth, "reads": int(batch.n_reads), "records": n_rec, "host_seconds_in_flush_per_flush": ht["host_ms_per_flush"] / 1e3,
-            "what": "BASELINE config 5's settings, a 6 000-locus sample, reads in device memory -> records on the host: pisces_hip_add_device_reads + one "
+            "what": "BASELINE config 5's settings, a 15 000-locus sample, reads in device memory -> records on the host: pisces_hip_add_device_reads + one "
                     "pisces_hip_flush_view; wall clock of the pair, not a per-kernel figure; all of config 5: python bench.py --config 5"}
 
 
@@ -782,7 +782,7 @@ def run_stream_config(args):
         what = ("BASELINE config 3: 1 M loci x 2000x, SNV + MNV (2-3) + deletions (1-10) + insertions (1-6), MNV calling on, gVCF; "
                 "streaming surface from reads (device read store, device candidate discovery and merge, collapser, reallocator, candidate kernel)")
     else:
-        n_loci_all, depth, seed, stretch = 100_000, 5000, 23, 40
+        n_loci_all, depth, seed, stretch = 100_000, 5000, 23, 200   # (stretches of 1 M reads = 300 MB of bases + qualities: a flush of 30 000 loci fills the chip; 40 amplicons were 94 tiles)
         cfg = _abi.default_config(min_base_call_quality=30, noise_level=30, min_frequency=0.005, variant_freq_filter=0.005, genotype_min_freq_filter=0.005,
                                   target_lod_frequency=0.005, strand_bias_threshold=0.5, variant_qscore_filter=30)
         synth_kw = dict(vaf_range=(0.005, 0.005), snv_every=50, snv_offset=17, q_lo=12)

@@ -316,21 +316,27 @@ struct PrepareArgs {
     const uint8_t* del_dirs;            // two per CIGAR operation, or nullptr
     int32_t n_reads, min_bq, block_size, count_indels;
     int64_t n_ops_total, n_bases_total;
-    uint32_t* block_bits;               // bit k: block key k is touched
+    uint32_t* block_bits;               // bit k: block key k is touched; kPrepReplicas copies map_stride words apart (workgroup b writes copy b % kPrepReplicas)
     int64_t n_block_bits;
+    int64_t map_stride;
     int32_t* n_found;                   // [n_reads + 1] (count_indels): candidate records / pool bytes of every read, scanned afterwards
     int32_t* n_pool;
     unsigned long long* first_error;    // read index * 8 + code of the first read that is refused (atomicMin; all ones: none)
-    int32_t* key_span;                  // [0] lowest, [1] highest block key touched, [2] lowest read position
+    int32_t* key_span;                  // [0] lowest, [1] highest block key touched, [2] lowest read position, [3] X / = seen; kPrepReplicas copies of four
 };
+// Every wave of the launch starts with the same few words to set (reads come in position order: one or two block keys, one span), and an
+// atomic on ONE address costs ~15 ns however many XCDs ask: 3 128 waves of a 200 000-read batch spent 47 us on them.  The words are
+// kept in kPrepReplicas copies, a workgroup writes the copy of its index, prepare_collect_kernel folds the copies.
+constexpr int kPrepReplicas = 32;
 // bits [a, b] of the block map; a bit that is set already (seen through a load that goes past this XCD's L2, where a stale line would
 // show zero for the rest of the launch) costs no atomic: same-address atomics from eight XCDs serialise at 0.1-0.2 us each
 __device__ __forceinline__ void set_keys(const PrepareArgs& A, int64_t a, int64_t b)
 {
+    uint32_t* const map = A.block_bits + (int64_t)(blockIdx.x & (kPrepReplicas - 1)) * A.map_stride;
     for (int64_t k = a; k <= b; k++) {
         if (k >= A.n_block_bits) continue;   // (cannot be: the map covers every int32 position)
         const uint32_t bit = 1u << (k & 31);
-        uint32_t* const w = &A.block_bits[k >> 5];
+        uint32_t* const w = &map[k >> 5];
         if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(w, bit);
     }
 }
@@ -342,6 +348,13 @@ __device__ __forceinline__ long long prep_shfl64(long long v, int src_lane)
 }
 __global__ __launch_bounds__(256) void read_prepare_kernel(PrepareArgs A)
 {
+    // what the workgroup's waves found goes through LDS first: one lane of the workgroup touches the shared words (their loads go past the
+    // XCD's L2 and queue on one memory channel when every wave of a large batch asks: 68 us for 500 000 reads before)
+    constexpr int kRunSlots = 32;
+    __shared__ int s_klo, s_khi, s_plo, s_eqx, s_nruns;
+    __shared__ long long s_run_a[kRunSlots], s_run_b[kRunSlots];
+    if (threadIdx.x == 0) { s_klo = 0x7FFFFFFF; s_khi = 0; s_plo = 0x7FFFFFFF; s_eqx = 0; s_nruns = 0; }
+    __syncthreads();
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     int k_lo = 0x7FFFFFFF, k_hi = 0, p_lo = 0x7FFFFFFF;
     int64_t run_a = 1, run_b = 0;   // the run of keys this read touches (empty)
@@ -430,7 +443,11 @@ __global__ __launch_bounds__(256) void read_prepare_kernel(PrepareArgs A)
             const int l0 = __builtin_ctzll(todo);
             const long long a0 = prep_shfl64((long long)run_a, l0), b0 = prep_shfl64((long long)run_b, l0);
             const unsigned long long same = __ballot(run_b >= run_a && run_a == a0 && run_b == b0);
-            if (lane == l0) set_keys(A, a0, b0);
+            if (lane == l0) {
+                const int slot = atomicAdd(&s_nruns, 1);
+                if (slot < kRunSlots) { s_run_a[slot] = a0; s_run_b[slot] = b0; }
+                else set_keys(A, a0, b0);
+            }
             todo &= ~same;
         }
     }
@@ -440,11 +457,30 @@ __global__ __launch_bounds__(256) void read_prepare_kernel(PrepareArgs A)
         k_hi = max(k_hi, __shfl_xor(k_hi, d, 64));
         p_lo = min(p_lo, __shfl_xor(p_lo, d, 64));
     }
-    if ((threadIdx.x & 63) == 0 && p_lo < __hip_atomic_load(&A.key_span[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&A.key_span[2], p_lo);
-    if (__ballot(eqx) != 0ull && (threadIdx.x & 63) == 0 && !__hip_atomic_load(&A.key_span[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&A.key_span[3], 1);
-    if ((threadIdx.x & 63) == 0 && k_hi > 0) {
-        if (k_lo < __hip_atomic_load(&A.key_span[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&A.key_span[0], k_lo);
-        if (k_hi > __hip_atomic_load(&A.key_span[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&A.key_span[1], k_hi);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&s_plo, p_lo);
+        if (__ballot(eqx) != 0ull) s_eqx = 1;
+        if (k_hi > 0) { atomicMin(&s_klo, k_lo); atomicMax(&s_khi, k_hi); }
+    }
+    __syncthreads();
+    {   // the workgroup's distinct runs, each set once
+        const int n_runs = min(s_nruns, kRunSlots), t = threadIdx.x;
+        if (t < n_runs) {
+            bool seen = false;
+            for (int j = 0; j < t; j++) seen = seen || (s_run_a[j] == s_run_a[t] && s_run_b[j] == s_run_b[t]);
+            if (!seen) set_keys(A, s_run_a[t], s_run_b[t]);
+        }
+    }
+    if (threadIdx.x == 0) {
+        int32_t* const span = A.key_span + 4 * (int)(blockIdx.x & (kPrepReplicas - 1));
+        const int v0 = __hip_atomic_load(&span[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), v1 = __hip_atomic_load(&span[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                  v2 = __hip_atomic_load(&span[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), v3 = __hip_atomic_load(&span[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s_plo < v2) atomicMin(&span[2], s_plo);
+        if (s_eqx && !v3) atomicMax(&span[3], 1);
+        if (s_khi > 0) {
+            if (s_klo < v0) atomicMin(&span[0], s_klo);
+            if (s_khi > v1) atomicMax(&span[1], s_khi);
+        }
     }
 }
 // per-base directions: a value that is no DirectionType makes the batch unusable (add_reads: "CIGAR does not match the read")
@@ -467,18 +503,35 @@ struct PrepVerdict {
     int32_t pad;
 };
 static_assert(sizeof(PrepVerdict) == 48, "PrepVerdict layout");
-__global__ __launch_bounds__(256) void prepare_collect_kernel(uint32_t* __restrict__ block_bits, const int32_t* __restrict__ key_span,
+__global__ __launch_bounds__(256) void prepare_collect_kernel(uint32_t* __restrict__ block_bits, int64_t map_stride, const int32_t* __restrict__ key_span,
                                                               const unsigned long long* __restrict__ first_error, const long long* __restrict__ totals /* or nullptr */,
                                                               PrepVerdict* __restrict__ out, int32_t* __restrict__ keys_out, int32_t capacity)
 {
-    __shared__ int s_n, s_at;
-    const int lo = key_span[0], hi = key_span[1];
-    if (threadIdx.x == 0) { s_n = 0; s_at = 0; }
+    __shared__ int s_n, s_at, s_span[4];
+    if (threadIdx.x == 0) { s_n = 0; s_at = 0; s_span[0] = 0x7FFFFFFF; s_span[1] = 0; s_span[2] = 0x7FFFFFFF; s_span[3] = 0; }
     __syncthreads();
+    if (threadIdx.x < kPrepReplicas) {   // the copies of the span folded
+        const int32_t* sp = key_span + 4 * threadIdx.x;
+        atomicMin(&s_span[0], sp[0]); atomicMax(&s_span[1], sp[1]); atomicMin(&s_span[2], sp[2]); atomicMax(&s_span[3], sp[3]);
+    }
+    __syncthreads();
+    const int lo = s_span[0], hi = s_span[1];
     const bool any = hi >= lo && hi > 0;
     const int w0 = any ? lo >> 5 : 0, w1 = any ? hi >> 5 : -1;
+    // the copies of the map folded into copy 0 (the others cleared for the next batch)
     int mine = 0;
-    for (int w = w0 + (int)threadIdx.x; w <= w1; w += 256) mine += __popc(block_bits[w]);
+    for (int w = w0 + (int)threadIdx.x; w <= w1; w += 256) {
+        uint32_t v[kPrepReplicas], bits = 0;
+#pragma unroll
+        for (int r = 0; r < kPrepReplicas; r++) v[r] = block_bits[(int64_t)r * map_stride + w];   // (all the loads first: one round trip)
+#pragma unroll
+        for (int r = 0; r < kPrepReplicas; r++) bits |= v[r];
+#pragma unroll
+        for (int r = 1; r < kPrepReplicas; r++)
+            if (v[r]) block_bits[(int64_t)r * map_stride + w] = 0;
+        block_bits[w] = bits;
+        mine += __popc(bits);
+    }
     if (mine) atomicAdd(&s_n, mine);
     __syncthreads();
     const int n = s_n;
@@ -495,9 +548,9 @@ __global__ __launch_bounds__(256) void prepare_collect_kernel(uint32_t* __restri
         out->first_error = *first_error;
         out->totals[0] = totals ? totals[0] : 0;
         out->totals[1] = totals ? totals[1] : 0;
-        out->span[0] = key_span[0]; out->span[1] = key_span[1]; out->span[2] = key_span[2];
+        out->span[0] = s_span[0]; out->span[1] = s_span[1]; out->span[2] = s_span[2];
         out->n_keys = n;
-        out->has_eqx = key_span[3];
+        out->has_eqx = s_span[3];
         out->pad = 0;
     }
 }

@@ -329,18 +329,19 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
     if (n_block_bits > (1ll << 27)) return fail(h, PISCES_E_UNSUPPORTED, "add_reads: a batch on the device needs a block size of 16 positions or more");
     const size_t map_words = (size_t)((n_block_bits + 31) / 32);
     auto& B = h->bam;   // (the block map and the first-error word of the BAM surface: the same roles)
-    PISCES_HIP_CHECK(h, h->d_prep_map.reserve(map_words + 8));
+    PISCES_HIP_CHECK(h, h->d_prep_map.reserve(map_words * kPrepReplicas + 4 * kPrepReplicas));
     PISCES_HIP_CHECK(h, B.d_first_error.reserve(1));
     PISCES_HIP_CHECK(h, B.d_totals64.reserve(8));
     PISCES_HIP_CHECK(h, h->d_found_pool_first.reserve((size_t)nr + 1));
     PISCES_HIP_CHECK(h, h->d_found_totals.reserve(2));
-    int32_t* const d_span = (int32_t*)(h->d_prep_map.p + map_words);   // [0] lowest, [1] highest key
+    int32_t* const d_span = (int32_t*)(h->d_prep_map.p + map_words * kPrepReplicas);   // kPrepReplicas x {lowest key, highest key, lowest position, X / = seen}
     // (the map is zero outside the span of the last batch that used it: only that span is cleared again, below; first use: all of it)
     if (!h->prep_map_clean) {
-        PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_prep_map.p, 0, map_words * sizeof(uint32_t), h->stream));
+        PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_prep_map.p, 0, map_words * kPrepReplicas * sizeof(uint32_t), h->stream));
         h->prep_map_clean = true;
     }
-    const int32_t span_init[4] = {0x7FFFFFFF, 0, 0x7FFFFFFF, 0};   // ([3]: some read has an X or = operation)
+    int32_t span_init[4 * kPrepReplicas];   // ([3]: some read has an X or = operation)
+    for (int r = 0; r < kPrepReplicas; r++) { span_init[4 * r] = 0x7FFFFFFF; span_init[4 * r + 1] = 0; span_init[4 * r + 2] = 0x7FFFFFFF; span_init[4 * r + 3] = 0; }
     { int32_t rcu = meta_upload(h, d_span, span_init, sizeof(span_init)); if (rcu) return rcu; }
     PISCES_HIP_CHECK(h, hipMemsetAsync(B.d_first_error.p, 0xFF, sizeof(unsigned long long), h->stream));
     PrepareArgs A;
@@ -353,7 +354,7 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
     A.del_dirs = has_deldirs ? d + L.off_deldirs : nullptr;
     A.n_reads = nr; A.min_bq = h->cfg.min_base_call_quality; A.block_size = bs; A.count_indels = count_indels ? 1 : 0;
     A.n_ops_total = (int64_t)n_cig; A.n_bases_total = (int64_t)n_seq;
-    A.block_bits = h->d_prep_map.p; A.n_block_bits = n_block_bits;
+    A.block_bits = h->d_prep_map.p; A.n_block_bits = n_block_bits; A.map_stride = (int64_t)map_words;
     A.n_found = count_indels ? (int32_t*)(d + L.off_fslots) : nullptr;
     A.n_pool = count_indels ? h->d_found_pool_first.p : nullptr;
     A.first_error = B.d_first_error.p;
@@ -374,7 +375,7 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
     if (!h->h_prep) PISCES_HIP_CHECK(h, host_alloc((void**)&h->h_prep, sizeof(PrepVerdict) + (size_t)kPrepKeys * sizeof(int32_t)));
     PrepVerdict* const verdict = (PrepVerdict*)h->h_prep;
     int32_t* const keys = (int32_t*)(h->h_prep + sizeof(PrepVerdict));
-    hipLaunchKernelGGL(prepare_collect_kernel, dim3(1), dim3(256), 0, h->stream, h->d_prep_map.p, (const int32_t*)d_span, (const unsigned long long*)B.d_first_error.p,
+    hipLaunchKernelGGL(prepare_collect_kernel, dim3(1), dim3(256), 0, h->stream, h->d_prep_map.p, (int64_t)map_words, (const int32_t*)d_span, (const unsigned long long*)B.d_first_error.p,
                        count_indels ? (const long long*)h->d_found_totals.p : (const long long*)nullptr, verdict, keys, kPrepKeys);
     PISCES_HIP_CHECK(h, hipGetLastError());
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
