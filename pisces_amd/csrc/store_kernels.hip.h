@@ -457,9 +457,10 @@ __global__ __launch_bounds__(256) void read_prepare_kernel(PrepareArgs A)
         k_hi = max(k_hi, __shfl_xor(k_hi, d, 64));
         p_lo = min(p_lo, __shfl_xor(p_lo, d, 64));
     }
+    const bool any_eqx = __ballot(eqx) != 0ull;   // (all lanes: before the branch)
     if ((threadIdx.x & 63) == 0) {
         atomicMin(&s_plo, p_lo);
-        if (__ballot(eqx) != 0ull) s_eqx = 1;
+        if (any_eqx) s_eqx = 1;
         if (k_hi > 0) { atomicMin(&s_klo, k_lo); atomicMax(&s_khi, k_hi); }
     }
     __syncthreads();
