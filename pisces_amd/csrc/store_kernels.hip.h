@@ -570,6 +570,32 @@ __global__ __launch_bounds__(256) void segment_copy_kernel(CopyRanges C)
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < C.n[k]; i += stride) C.dst[k][i] = C.src[k][i];
 }
 
+// A batch handed over in device memory (pisces_hip_add_device_reads): its arrays copied into the store's layout by ONE launch — sixteen
+// bytes a lane at any alignment of source and destination (gfx950 runs with unaligned global access enabled), the ranges one after the
+// other over the whole grid.  (Ten hipMemcpyAsync cost ten stream operations: ~95 us for a batch of 500 000 reads, ~40 for one of 3 000.)
+struct CopyRanges16 {
+    uint8_t* dst[10];
+    const uint8_t* src[10];
+    int64_t n[10];
+};
+__global__ __launch_bounds__(256) void ranges_copy16_kernel(CopyRanges16 C)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll 1
+    for (int k = 0; k < 10; k++) {
+        const int64_t n = C.n[k], n16 = n >> 4;
+        if (n <= 0) continue;
+        const uint8_t* const src = C.src[k];
+        uint8_t* const dst = C.dst[k];
+        for (int64_t i = t; i < n16; i += stride) {
+            uint32_t v[4];
+            __builtin_memcpy(v, src + 16 * i, 16);
+            __builtin_memcpy(dst + 16 * i, v, 16);
+        }
+        if (t < (n & 15)) dst[(n16 << 4) + t] = src[(n16 << 4) + t];
+    }
+}
+
 // per-base directions of reads [r0, r1) of a segment from their flags: a batch without directions joining a segment that tracks them,
 // or the reads a segment held before its first batch with directions
 __global__ __launch_bounds__(256) void segment_fill_dirs_kernel(const ReadDesc* __restrict__ desc, const ReadExt* __restrict__ ext, int32_t r0, int32_t r1,

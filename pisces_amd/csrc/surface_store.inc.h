@@ -637,20 +637,27 @@ int32_t pisces_hip_add_device_reads(PiscesHip* h, const PiscesReadBatch* batch, 
     }
     if (rc) { store_unplace(h, pl); return rc; }
     uint8_t* const d = pl.direct ? pl.seg->blob.p : D_STAGE(h);
-    auto d2d = [&](size_t off, const void* src, size_t bytes) -> hipError_t {
-        return bytes ? hipMemcpyAsync(d + off, src, bytes, hipMemcpyDeviceToDevice, h->stream) : hipSuccess;
-    };
-    hipError_t e = d2d(L.off_pos, batch->position, (size_t)nr * 4);
-    if (e == hipSuccess) e = d2d(L.off_flags, batch->flags, (size_t)nr);
-    if (e == hipSuccess) e = d2d(L.off_coff, batch->cigar_offset, ((size_t)nr + 1) * 4);
-    if (e == hipSuccess) e = d2d(L.off_cop, batch->cigar_op, n_cig);
-    if (e == hipSuccess) e = d2d(L.off_clen, batch->cigar_len, n_cig * 4);
-    if (e == hipSuccess) e = d2d(L.off_soff, batch->seq_offset, ((size_t)nr + 1) * 4);
-    if (e == hipSuccess) e = d2d(L.off_bases, batch->bases, n_seq);
-    if (e == hipSuccess) e = d2d(L.off_quals, batch->quals, n_seq);
-    if (e == hipSuccess && has_dirs) e = d2d(L.off_dirs, batch->directions, n_seq);
-    if (e == hipSuccess && has_deldirs) e = d2d(L.off_deldirs, batch->deletion_directions, 2 * n_cig);
-    if (e != hipSuccess) rc = fail(h, PISCES_E_DEVICE, std::string("add_device_reads: ") + hipGetErrorString(e));
+    {   // the caller's arrays into the store's layout: one launch (ranges_copy16_kernel)
+        CopyRanges16 C;
+        std::memset(&C, 0, sizeof(C));
+        int k = 0;
+        auto range = [&](size_t off, const void* src, size_t bytes) { C.dst[k] = d + off; C.src[k] = (const uint8_t*)src; C.n[k] = (int64_t)bytes; k++; };
+        range(L.off_pos, batch->position, (size_t)nr * 4);
+        range(L.off_flags, batch->flags, (size_t)nr);
+        range(L.off_coff, batch->cigar_offset, ((size_t)nr + 1) * 4);
+        range(L.off_cop, batch->cigar_op, n_cig);
+        range(L.off_clen, batch->cigar_len, n_cig * 4);
+        range(L.off_soff, batch->seq_offset, ((size_t)nr + 1) * 4);
+        range(L.off_bases, batch->bases, n_seq);
+        range(L.off_quals, batch->quals, n_seq);
+        if (has_dirs) range(L.off_dirs, batch->directions, n_seq);
+        if (has_deldirs) range(L.off_deldirs, batch->deletion_directions, 2 * n_cig);
+        const int64_t most = std::max<int64_t>((int64_t)n_seq, (int64_t)nr * 4);
+        const unsigned grid = (unsigned)std::min<int64_t>(std::max<int64_t>((most / 16 + 255) / 256, 1), (int64_t)h->n_cus * 16);
+        hipLaunchKernelGGL(ranges_copy16_kernel, dim3(grid), dim3(256), 0, h->stream, C);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) rc = fail(h, PISCES_E_DEVICE, std::string("add_device_reads: ") + hipGetErrorString(e));
+    }
     const bool find_on_device = !h->h_ref.empty();
     const bool count_indels = find_on_device && !h->snv_walk;
     h->eqx_in_batch = false;

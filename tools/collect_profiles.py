@@ -28,7 +28,7 @@ def cat(names, out):
 
 
 cat(["pmc_FETCH_SIZE.txt", "pmc_WRITE_SIZE.txt", "pmc_sq_lds.txt", "pmc_sq_wave.txt"], "sq_counters.txt")
-cat(["pmc_store_fetch.txt", "pmc_store_write.txt", "pmc_store_sq.txt", "pmc_store_lds.txt"], "store_counters.txt")
+cat(["pmc_store_fetch.txt", "pmc_store_write.txt", "pmc_store_calib.txt", "pmc_store_sq.txt", "pmc_store_lds.txt"], "store_counters.txt")
 cat(["pmc_bgzf_mem.txt", "pmc_bgzf_sq.txt", "pmc_bgzf_lds.txt"], "bgzf_counters.txt")
 for name, out in (("hostfed.log", "streaming_bench.txt"), ("bam_bench.log", "bam_bench.txt")):
     p = os.path.join(src, name)

@@ -4,7 +4,7 @@
 # restricted to the hot kernel: the synthetic generator's thousands of small torch kernels are not instrumented), (4) SQ / LDS counters
 # of the hot kernel, (5) the streaming surface's and the BGZF / BAM kernels' statistics and counters.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r05}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
@@ -60,6 +60,8 @@ for path in store log; do
 done
 pmc store_fetch call_store_tiles FETCH_SIZE -- python tools/store_bench.py
 pmc store_write call_store_tiles WRITE_SIZE -- python tools/store_bench.py
+pmc store_calib call_store_tiles FETCH_SIZE -- python tools/store_traffic_calibration.py
+grep store_traffic_calibration $OUT/pmc_store_calib.log | tee -a $OUT/pmc_store_calib.txt
 pmc store_sq call_store_tiles SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -- python tools/store_bench.py
 pmc store_lds call_store_tiles SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU -- python tools/store_bench.py
 # BASELINE config 3's mix (2000x, SNV + insertion / deletion / MNV candidates), flushed block by block

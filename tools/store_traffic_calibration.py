@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Development: what FETCH_SIZE reports for call_store_tiles_kernel when no byte can be read twice — reads of 32 bases that each lie inside
-ONE 64-locus tile (so no two tiles share a read), a known byte count: 2 B per base + 16 B per fragment + the reference window.
+ONE 64-locus tile (so no two tiles share a read), a known byte count: 1 B per base (its row code: what the round-5 kernel loads) + 16 B per
+fragment + the reference window.
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --kernel-include-regex call_store_tiles ... -- python tools/store_traffic_calibration.py
-The counter / the known bytes is the factor for this kernel's access pattern (16 lanes x 4 B per read, any alignment); the same run with
+The counter / the known bytes is the factor for this kernel's access pattern (4 lanes x 8 B per pair, any alignment); the same run with
 reads of 150 bases (tools/store_bench.py) then says how many times a byte crosses HBM."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,5 +29,5 @@ with engine.HipVariantCaller(_abi.default_config()) as c:
     for rep in range(4):
         c.AddAlleleCounts(batch)
         recs = c.Call(None, capacity=1 << 18, reuse_buffer=True)
-print(f"store_traffic_calibration: {n} reads of {L} bases, each inside one tile: {2 * n * L / 1e6:.1f} MB of bases and qualities + {16 * n / 1e6:.1f} MB of fragments "
+print(f"store_traffic_calibration: {n} reads of {L} bases, each inside one tile: {n * L / 1e6:.1f} MB of row codes + {16 * n / 1e6:.1f} MB of fragments "
       f"+ {64 * len(recs) / 1e6:.1f} MB of records written; {len(recs)} records")
