@@ -392,6 +392,12 @@ int32_t pisces_hip_add_candidates(PiscesHip* h, const PiscesCandidate* cands, in
  * (RegionState.GetAllCandidates :393-450).  With the diploid model DiploidLocusProcessor's rules apply (PISCES_GT_OTHERS).  Call it
  * after pisces_hip_set_intervals and before the first flush. */
 int32_t pisces_hip_set_forced_alleles(PiscesHip* h, const PiscesCandidate* alleles_of, int64_t n, const uint8_t* alleles, int64_t allele_bytes);
+/* The chromosome's known (prior) variants: what Factory.cs:204 hands VariantCollapser (the priors file's insertions and MNVs, Factory.cs:378-395).
+ * With the collapser on, a candidate that equals one (position, reference allele, alternate allele, type) is anchored on both sides and
+ * preferred among the potential matches of an open-ended candidate (VariantCollapser.cs:16-24, 178-190, 216-218).  Same arguments as
+ * pisces_hip_set_forced_alleles (position, ref_len, alt_len, allele_offset of every entry; the rest is ignored); n = 0 clears.  Any time
+ * before the flush that should see them. */
+int32_t pisces_hip_set_known_variants(PiscesHip* h, const PiscesCandidate* variants, int64_t n, const uint8_t* alleles, int64_t allele_bytes);
 /* totals lines: {allelesCalled (IAlleleCaller.TotalNumCalled), variantsCollapsed, readsProcessed, readsSkipped}
  * (SmallVariantCaller.cs:114-115; readsSkipped = AlignmentSource's count of the reads ShouldSkipRead dropped, AlignmentsSource.cs:63,84-92:
  * the reads pisces_hip_bam_decode dropped from the batches that pisces_hip_add_decoded_reads added; reads a host hands over through

@@ -1707,13 +1707,21 @@ static float cand_frequency(const OrcCandidate* c, const OrcState* src, int cons
     return frequency_f(v.allele_support, v.total_coverage);
 }
 
-typedef struct { const OrcCandidate* c; float freq; int idx; } MatchRow;
+typedef struct { const OrcCandidate* c; float freq; int idx; int known; } MatchRow;
 
-/* IComparer<CandidateAllele>.Compare :214-244 (no known variants on this path) */
+/* the chromosome's known (prior) variants: Factory.cs:204 hands VariantCollapser the list of the priors file (Factory.cs:378-395); the
+ * next orc_collapse / schedule run annotates with them (AnnotateKnown :178-190); n = 0 clears */
+static const OrcCandidate* g_known = NULL;
+static int32_t g_known_n = 0;
+void orc_set_known_variants(const OrcCandidate* list, int32_t n) { g_known = list; g_known_n = n; }
+
+/* IComparer<CandidateAllele>.Compare :214-244 */
 static int match_cmp(const void* pa, const void* pb)
 {
     const MatchRow* a = (const MatchRow*)pa;
     const MatchRow* b = (const MatchRow*)pb;
+    if (a->known && !b->known) return -1;   /* return known one first :216-218 */
+    if (!a->known && b->known) return 1;
     const int fa = cand_fully_anchored(a->c), fb = cand_fully_anchored(b->c);
     if (fa && !fb) return -1;
     if (!fa && fb) return 1;
@@ -1756,6 +1764,13 @@ int32_t orc_collapse(OrcCandidate* cands, int32_t n, const OrcState* src, float 
     OrderRow* order = (OrderRow*)malloc(sizeof(OrderRow) * (size_t)(n > 0 ? n : 1));
     MatchRow* rows = (MatchRow*)malloc(sizeof(MatchRow) * (size_t)(n > 0 ? n : 1));
     int no = 0, collapsed = 0;
+    /* AnnotateKnown :178-190: a target that equals a known variant is known and anchored on both sides, whatever its reads said */
+    uint8_t* known = (uint8_t*)calloc((size_t)(n > 0 ? n : 1), 1);
+    for (int i = 0; i < n; i++) {
+        if (exclude_mnvs && cands[i].category == PISCES_CAT_MNV) continue;
+        for (int k = 0; k < g_known_n; k++)
+            if (candidate_equals(&cands[i], &g_known[k])) { known[i] = 1; cands[i].open_left = cands[i].open_right = 0; break; }
+    }
     for (int i = 0; i < n; i++) {
         const OrcCandidate* c = &cands[i];
         if (exclude_mnvs && c->category == PISCES_CAT_MNV) continue;
@@ -1774,6 +1789,7 @@ int32_t orc_collapse(OrcCandidate* cands, int32_t n, const OrcState* src, float 
             if (!can_collapse(toCollapse, &cands[j])) continue;
             rows[nm].c = &cands[j];
             rows[nm].idx = j;
+            rows[nm].known = known[j];
             rows[nm].freq = cand_frequency(&cands[j], src, consider_anchors, expect_stitched);
             nm++;
         }
@@ -1809,7 +1825,7 @@ int32_t orc_collapse(OrcCandidate* cands, int32_t n, const OrcState* src, float 
         if (!removed[i]) { if (w != i) cands[w] = cands[i]; w++; }
     if (n_collapsed) *n_collapsed = collapsed;
     if (n_added_back) *n_added_back = nab;
-    free(removed); free(order); free(rows);
+    free(removed); free(order); free(rows); free(known);
     return w;
 }
 

@@ -661,10 +661,18 @@ void mnv_reallocate_failed(MnvArena& arena, const std::vector<CandPtr>& failed, 
 // cands is edited in place; freq(c) = CalledAllele.Frequency of the candidate against the current counts
 extern "C++" {
 template <typename FreqFn>
-static int64_t collapse_candidates(std::vector<HostCandidate>& cands, float freq_threshold, float freq_ratio_threshold, FreqFn freq)
+static int64_t collapse_candidates(std::vector<HostCandidate>& cands, float freq_threshold, float freq_ratio_threshold, FreqFn freq,
+                                   const std::vector<HostCandidate>* known_variants = nullptr)
 {
     const size_t n = cands.size();
     std::vector<uint8_t> removed(n, 0);
+    // AnnotateKnown (VariantCollapser.cs:178-190): a candidate that equals a known (prior) variant of the chromosome is known, and anchored on
+    // both sides whatever its reads said
+    std::vector<uint8_t> known(n, 0);
+    if (known_variants && !known_variants->empty())
+        for (size_t i = 0; i < n; i++)
+            for (const HostCandidate& k : *known_variants)
+                if (cand_equals(cands[i], k)) { known[i] = 1; cands[i].open_left = cands[i].open_right = false; break; }
     std::vector<size_t> order;
     for (size_t i = 0; i < n; i++)
         if (cands[i].open_left || cands[i].open_right) order.push_back(i);
@@ -693,10 +701,11 @@ static int64_t collapse_candidates(std::vector<HostCandidate>& cands, float freq
             if (j != oi && !removed[j] && can_collapse(t, cands[j])) rows.push_back({j, freq(cands[j])});
         if (rows.empty()) continue;
         const float tf = freq(t);
-        // IComparer.Compare :214-244 (no known variants here); input order breaks the remaining ties
+        // IComparer.Compare :214-244; input order breaks the remaining ties
         std::stable_sort(rows.begin(), rows.end(), [&](const Row& x, const Row& y) {
             const HostCandidate& a = cands[x.idx];
             const HostCandidate& b = cands[y.idx];
+            if (known[x.idx] != known[y.idx]) return known[x.idx] != 0;   // "return known one first" :216-218
             if (cand_fully_anchored(a) != cand_fully_anchored(b)) return cand_fully_anchored(a);
             if (cand_length(a) != cand_length(b)) return cand_length(a) > cand_length(b);
             if (std::fabs(x.f - y.f) > 0.0f) return x.f > y.f;
@@ -1297,7 +1306,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
             if (total == 0) return 0.0f;                       // CalledAllele.Frequency (CalledAllele.cs:49-52)
             const float f = (float)support / (float)total;
             return f < 1.0f ? f : 1.0f;
-        });
+        }, &h->known_variants);
         // candidates past the last cleared position that could not be collapsed return to the state (VariantCollapser.cs:67-75): only the
         // ones AddCollapsableFromOtherBlocks brought in can lie there
         if (max_cleared >= 0) {

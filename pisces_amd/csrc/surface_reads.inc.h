@@ -320,6 +320,23 @@ int32_t pisces_hip_set_forced_alleles(PiscesHip* h, const PiscesCandidate* cands
     });
 }
 
+// The chromosome's known (prior) variants (Factory.cs:204, 378-395: the priors file's insertions and MNVs of this chromosome): the
+// collapser annotates the candidates that equal one (VariantCollapser.cs:16-24, 178-190) and prefers them among potential matches (:216-218).
+int32_t pisces_hip_set_known_variants(PiscesHip* h, const PiscesCandidate* cands, int64_t n, const uint8_t* alleles, int64_t allele_bytes)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    std::vector<HostCandidate> list;
+    int32_t rc = host_candidates_of(h, cands, n, alleles, allele_bytes, list, "set_known_variants");
+    if (rc) return rc;
+    for (auto& c : list)   // (CandidateAllele.Equals compares the type too: derived from the alleles as the reader of the priors file does)
+        c.category = (c.ref.size() == 1 && c.alt.size() == 1) ? PISCES_CAT_SNV : c.ref.size() == c.alt.size() ? PISCES_CAT_MNV
+                     : c.ref.size() > c.alt.size() ? PISCES_CAT_DELETION : PISCES_CAT_INSERTION;
+    h->known_variants = std::move(list);
+    return PISCES_OK;
+    });
+}
+
 // SmallVariantCaller.AddForcedAlleleAsCandidate :118-132, before GetCandidatesToProcess(upTo)
 static void add_forced_as_candidates(PiscesHip* h, int32_t up_to_position)
 {

@@ -331,6 +331,12 @@ class HipVariantCaller:
         arr, pool, nb = self._candidate_arrays(list(alleles))
         _check(self._h, lib.pisces_hip_set_forced_alleles(self._h, arr, len(alleles), pool.ctypes.data, nb))
 
+    def SetKnownVariants(self, variants):
+        """The chromosome's known (prior) variants, [(position, ref, alt)]: Factory.cs:204 hands them to VariantCollapser (AnnotateKnown,
+        VariantCollapser.cs:178-190).  [] clears."""
+        arr, pool, nb = self._candidate_arrays(list(variants))
+        _check(self._h, lib.pisces_hip_set_known_variants(self._h, arr, len(variants), pool.ctypes.data, nb))
+
     # ---- multi-GPU summary (one process per GPU): RCCL bound at run time by the library ----
     @staticmethod
     def comm_unique_id():

@@ -293,6 +293,15 @@ def call_candidates(state, cands, cfg, ref_bases=b""):
     return out[:n], [full[i] for i in range(n)], total.value
 
 
+def set_known_variants(variants):
+    """orc_set_known_variants: [(position, category, ref, alt)] the next collapse / schedule run annotates with; [] clears.  Returns the
+    ctypes array (keep it alive while it is set)."""
+    arr = (OrcCandidate * max(len(variants), 1))(*[make_candidate(p, cat, r, a) for (p, cat, r, a) in variants])
+    lib.orc_set_known_variants.restype = None
+    lib.orc_set_known_variants(arr if variants else None, C.c_int32(len(variants)))
+    return arr
+
+
 def collapse(state, cands, freq_threshold=0.0, freq_ratio_threshold=0.0, exclude_mnvs=False, consider_anchors=True, expect_stitched=False,
              max_cleared_position=None):
     """VariantCollapser.Collapse on a list of OrcCandidate; returns (collapsed list, TotalNumCollapsed, added back)."""

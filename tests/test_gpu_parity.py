@@ -987,6 +987,57 @@ def test_collapser_on_open_ended_indels_matches_oracle(torch_cuda):
     assert len(out[1][0]) <= len(out[0][0])
 
 
+def test_known_variants_steer_the_collapser_as_in_the_reference(torch_cuda):
+    """VariantCollapser.cs:16-24, 178-190, 216-218: a candidate that equals a known (prior) variant of the chromosome is anchored on both
+    sides and comes first among the potential matches of an open-ended candidate.  Two insertions behind one position, a long one and a
+    shorter one with the same first bases; reads that end inside the insertion match both and join the LONGER one — unless the shorter one
+    is known (pisces_hip_set_known_variants; the oracle: orc_set_known_variants).  Records, allele strings and totals against the oracle,
+    with and without."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(15)
+    ref = bytes(rng.choice(list(b"ACGT"), 700).astype(np.uint8))
+    P, LONG, SHORT = 300, b"ACGTTGCA", b"ACGTA"
+    reads = []
+
+    def add(pos, ops, seq, i):
+        reads.append({"pos": pos, "cigar": ops, "seq": seq.decode(), "quals": [37] * len(seq), "reverse": bool(i % 2)})
+
+    for i in range(80):
+        add(P - 70, [("M", 150)], ref[P - 71: P + 79], i)
+    for i in range(30):
+        add(P - 50, [("M", 51), ("I", len(LONG)), ("M", 60)], ref[P - 51: P] + LONG + ref[P: P + 60], i)
+    for i in range(20):
+        add(P - 50, [("M", 51), ("I", len(SHORT)), ("M", 60)], ref[P - 51: P] + SHORT + ref[P: P + 60], i)
+    for i in range(24):            # reads that end inside the insertion after ACG / ACGT: both insertions start that way
+        k = 3 + i % 2
+        add(P - 60, [("M", 61), ("I", k)], ref[P - 61: P] + LONG[:k], i)
+    batch = _abi.ReadBatch(reads)
+    refa = np.frombuffer(ref, dtype=np.uint8)
+    anchor = "%c" % ref[P - 1]
+    short_allele, long_allele = (anchor, anchor + SHORT.decode()), (anchor, anchor + LONG.decode())
+    cfg = _abi.default_config(collapse=1)
+    sup = {}
+    for known in ([], [(P, short_allele[0], short_allele[1])]):
+        keep = orc.set_known_variants([(p, _abi.CAT_INSERTION, r, a) for p, r, a in known])
+        try:
+            exp, exp_alleles, _, exp_called = orc.run_reads_full(batch, refa, 1, len(ref), cfg)
+        finally:
+            orc.set_known_variants([])
+        del keep
+        with engine.HipVariantCaller(cfg) as c:
+            c.SetReference(refa)
+            c.SetKnownVariants(known)
+            c.AddAlleleCounts(batch)
+            got, got_alleles = c.CallWithAlleles()
+            stats = c.Stats()
+        assert_records_match(got, exp)
+        assert got_alleles == exp_alleles
+        assert stats["TotalNumCalled"] == exp_called and stats["TotalNumCollapsed"] == 2   # (the two distinct open-ended candidates: ACG, ACGT)
+        sup[bool(known)] = {a: int(r["allele_support"]) for r, a in zip(got, got_alleles) if r["position"] == P and a in (short_allele, long_allele)}
+    assert sup[False] == {long_allele: 30 + 24, short_allele: 20}     # the open-ended reads join the longer insertion ...
+    assert sup[True] == {long_allele: 30, short_allele: 20 + 24}      # ... or the known one
+
+
 def test_streaming_mix_of_snvs_and_indels_across_blocks_matches_oracle(torch_cuda):
     """BASELINE config 3 / 4 in the small (without MNV calling): 12 000 loci x 120x in 80 amplicons over 13 blocks, sequencing errors,
     planted SNVs, and at ~every 1000th locus a deletion (1-10 bp) or an insertion (1-6 bp) in a third of the reads — some of them

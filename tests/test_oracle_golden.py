@@ -483,6 +483,37 @@ def test_variant_collapser_reference_cases(case):
     run(list(reversed(case["candidates"])))
 
 
+def test_variant_collapser_known_variants():
+    """VariantCollapser.cs:178-190 (AnnotateKnown) and :216-218 (Compare returns the known one first — VariantCollapserTests.cs:765-766: a
+    known candidate sorts before a fully anchored, longer, more frequent one).  On the mock allele source of the cases above."""
+    st = orc.State(1, 64)
+    for pos in range(1, 40):
+        for a in range(6):
+            for d in range(3):
+                for anchor in range(11):
+                    st.set_count(pos, a, d, anchor, 0)
+                st.set_count(pos, a, d, 5, 1)
+    ins = _CAT["Insertion"] if "Insertion" in _CAT else 1
+    def cands():
+        return [orc.make_candidate(10, ins, "A", "AACGTTGCA", support=(3, 0, 0)),                      # long, anchored
+                orc.make_candidate(10, ins, "A", "AACGTA", support=(2, 0, 0)),                         # short, anchored
+                orc.make_candidate(10, ins, "A", "AACG", support=(1, 0, 0), open_right=True)]          # ends inside the insertion: matches both
+    out, n, _ = orc.collapse(st, cands())
+    assert n == 1 and [(c.alt.decode(), sum(c.support_by_dir)) for c in out] == [("AACGTTGCA", 4), ("AACGTA", 2)]   # the longer one takes it
+    keep = orc.set_known_variants([(10, ins, "A", "AACGTA")])
+    try:
+        out, n, _ = orc.collapse(st, cands())
+        assert n == 1 and [(c.alt.decode(), sum(c.support_by_dir)) for c in out] == [("AACGTTGCA", 3), ("AACGTA", 3)]   # the known one does
+        # a candidate that IS a known variant is anchored on both sides (it is no longer collapsed away, others may join it)
+        mine = cands()
+        mine[1].open_left = 1
+        out, n, _ = orc.collapse(st, mine)
+        assert n == 1 and [(c.alt.decode(), sum(c.support_by_dir), c.open_left, c.open_right) for c in out] == [("AACGTTGCA", 3, 0, 0), ("AACGTA", 3, 0, 0)]
+    finally:
+        orc.set_known_variants([])
+    del keep
+
+
 # ---- end to end: the reference's own BAMs -> the VCF rows Pisces wrote for them -----------------------------------------------
 @pytest.mark.parametrize("name", ["bam_chr19", "bam_chr17_again", "bam_chr17_int", "bam_chr17_vcf", "bam_phix", "bam_edge_ins", "bam_edge_del", "bam_small_s1"])
 def test_reference_bams_give_the_vcf_rows_pisces_wrote(name):
