@@ -397,6 +397,12 @@ int32_t pisces_hip_set_forced_alleles(PiscesHip* h, const PiscesCandidate* allel
  * preferred among the potential matches of an open-ended candidate (VariantCollapser.cs:16-24, 178-190, 216-218).  Same arguments as
  * pisces_hip_set_forced_alleles (position, ref_len, alt_len, allele_offset of every entry; the rest is ignored); n = 0 clears.  Any time
  * before the flush that should see them. */
+/* IAlleleCaller.TotalNumCalled with an interval set and MNV calling off: AlleleCaller.Call counts in IsCallable, BEFORE ShouldReport
+ * (AlleleCaller.cs:109-131), so the reference's total includes the callable SNVs of loci OUTSIDE the intervals, which it does not report.
+ * By default the library evaluates the intervals' loci only (the total then counts the callable alleles inside them; every reported row
+ * is the reference's either way).  on != 0: every flush also runs its kernel over the off-interval loci of the flushed blocks, drops the
+ * records and adds their callable alleles — the reference's number, at the price of a second launch per flush (read store path only). */
+int32_t pisces_hip_set_exact_total_called(PiscesHip* h, int32_t on);
 int32_t pisces_hip_set_known_variants(PiscesHip* h, const PiscesCandidate* variants, int64_t n, const uint8_t* alleles, int64_t allele_bytes);
 /* totals lines: {allelesCalled (IAlleleCaller.TotalNumCalled), variantsCollapsed, readsProcessed, readsSkipped}
  * (SmallVariantCaller.cs:114-115; readsSkipped = AlignmentSource's count of the reads ShouldSkipRead dropped, AlignmentsSource.cs:63,84-92:

@@ -33,6 +33,7 @@ struct DeviceParams {
     const double* gq_tail;
     int32_t gq_tail_a, gq_tail_cov;
     int32_t refs_only;   // MNV calling on: SNV candidates come from the read walk, the tile kernels emit Reference records only
+    int32_t variants_only;   // a counting launch over loci OUTSIDE the interval set (pisces_hip_set_exact_total_called): no Reference records, the variants' IsCallable only
     // Memo tables of the call phase, all filled once per handle BY THE DEVICE with the very functions they stand in for
     // (build_call_tables_kernel), so a hit is bit-identical to the evaluation it replaces; `tab_cov` columns (coverage) each:
     //   vq_tab[k * tab_cov + cov]  = poisson_qscore(k, cov)                                    1 <= k < vq_tab_k   (NoiseModel.Flat)

@@ -752,7 +752,7 @@ __device__ __forceinline__ void call_phase_wave(const int* hist, const uint8_t* 
         // Reference candidate (RegionState.GetAllCandidates, RegionState.cs:414-447); written now, it only counts if no variant turns
         // out callable at the locus
         const PointCounts c = point_counts_of(lc, ref_a, true, rt, 0);
-        if (in_ref && P.include_ref && (P.emit_zero_cov || c.total + c.nocalls > 0)) {
+        if (in_ref && P.include_ref && !P.variants_only && (P.emit_zero_cov || c.total + c.nocalls > 0)) {
             ref_rank = (rt < 4) ? rank_of_allele(rt) : 0;
             ref_emitted = true;
             PiscesCalledAllele rec;

@@ -283,6 +283,15 @@ struct PiscesHip {
     unsigned long long* h_totals = nullptr;   // pinned: pisces_hip_device_totals
     bool foreign_stream_used = false;         // a call_tiles launch went to a stream that is not the handle's since the last pisces_hip_device_totals
     bool foreign_stream_ever = false;         // ... ever (pisces_hip_destroy)
+    // pisces_hip_set_exact_total_called: IAlleleCaller.TotalNumCalled with an interval set and MNV calling off counts the callable SNVs of the
+    // loci OUTSIDE the intervals too (AlleleCaller.cs:109-131: IsCallable counts, ShouldReport comes after): a second launch of the flush
+    // kernel over those loci of the flushed blocks, its records dropped, its n_called added
+    bool exact_total_called = false;
+    DeviceBuf<PiscesTile> d_tiles_x;
+    DeviceBuf<PiscesTileResult> d_tr_x;
+    DeviceBuf<PiscesCalledAllele> d_rec_x;
+    DeviceBuf<int32_t> d_cnt_x, d_off_x;
+    int32_t* h_cnt_x = nullptr;   // pinned: {records, called} of the counting launch
     bool poisoned = false;                    // the deferred half of a batch's candidate discovery failed after the batch was committed (finish_candidate_discovery)
     std::string poison_why;
     uint8_t* h_prep = nullptr;                // pinned: prepare_collect_kernel's PrepVerdict + the keys of the touched blocks
@@ -682,6 +691,7 @@ static DeviceParams make_params(const PiscesHipConfig& c)
     P.gq_tail_a = 0;
     P.gq_tail_cov = 0;
     P.refs_only = c.call_mnvs ? 1 : 0;
+    P.variants_only = 0;
     P.vq_tab = nullptr;
     P.sb_tab = nullptr;
     P.sb0_tab = nullptr;
@@ -993,6 +1003,7 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     h->d_scan_sums.release(); h->d_prep_map.release(); h->d_folded.release(); h->d_span_tiles.release();
     h->d_snv[0].release(); h->d_snv[1].release(); h->d_snv_n.release(); h->d_snv_sel.release(); h->d_dirty.release(); h->d_row_idx.release(); h->d_rows.release();
     if (h->h_totals) host_free(h->h_totals);
+    if (h->h_cnt_x) host_free(h->h_cnt_x);
     h->h_totals = nullptr;
     if (h->h_prep) host_free(h->h_prep);
     h->h_prep = nullptr;

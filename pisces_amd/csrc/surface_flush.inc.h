@@ -248,7 +248,59 @@ struct CallBlocksInFlight {
     int32_t* hdr = nullptr;
     PiscesCalledAllele* hrec = nullptr;
     size_t spec = 0;
+    const int32_t* extra = nullptr;   // {records, called} of the counting launch over the off-interval loci (exact TotalNumCalled), or nullptr
 };
+// pisces_hip_set_exact_total_called: the loci of `keys`' blocks that lie OUTSIDE the interval set, through the flush kernel once more with
+// DeviceParams::variants_only (no Reference records; variants exactly as inside the intervals: dirty loci are skipped there and counted by
+// the candidate path, as everywhere), the records dropped, the tiles' n_called summed into pinned memory behind the same wait.
+static int32_t enqueue_off_interval_count(PiscesHip* h, const std::vector<int32_t>& keys, CallBlocksInFlight* st)
+{
+    const int bs = h->cfg.block_size;
+    std::vector<PiscesTile> tiles;
+    auto add_range = [&](int32_t s, int32_t e) {
+        for (int32_t p = s; p <= e; p += kTile) {
+            PiscesTile t;
+            t.start_position = p;
+            t.n_loci = std::min<int32_t>(kTile, e - p + 1);
+            t.tuple_begin = t.tuple_end = 0;
+            tiles.push_back(t);
+        }
+    };
+    for (int32_t key : keys) {
+        const int32_t bstart = (key - 1) * bs + 1, bend = (int32_t)std::min<int64_t>((int64_t)key * bs, h->ref_len);
+        int32_t at = bstart;
+        auto it = std::lower_bound(h->intervals.begin(), h->intervals.end(), bstart, [](const std::pair<int32_t, int32_t>& iv, int32_t p) { return iv.second < p; });
+        for (; it != h->intervals.end() && it->first <= bend; ++it) {
+            if (it->first > at) add_range(at, std::min(it->first - 1, bend));
+            at = std::max(at, it->second + 1);
+        }
+        if (at <= bend) add_range(at, bend);
+    }
+    if (tiles.empty() || tiles.size() > (size_t)(0x7FFFFF00ll / kSlotsPerTile)) return PISCES_OK;
+    const int32_t n = (int32_t)tiles.size();
+    PISCES_HIP_CHECK(h, h->d_tiles_x.reserve(tiles.size()));
+    PISCES_HIP_CHECK(h, h->d_tr_x.reserve(tiles.size()));
+    PISCES_HIP_CHECK(h, h->d_rec_x.reserve(tiles.size() * kSlotsPerTile));
+    PISCES_HIP_CHECK(h, h->d_off_x.reserve(tiles.size()));
+    PISCES_HIP_CHECK(h, h->d_cnt_x.reserve(4));
+    if (!h->h_cnt_x) PISCES_HIP_CHECK(h, host_alloc((void**)&h->h_cnt_x, 64));
+    { int32_t rcu = meta_upload(h, h->d_tiles_x.p, tiles.data(), tiles.size() * sizeof(PiscesTile)); if (rcu) return rcu; }
+    const DeviceParams saved = h->P;
+    h->P.variants_only = 1;
+    h->P.totals = nullptr;
+    h->P.folded_out = nullptr;
+    h->P.folded_first = h->P.folded_n = 0;
+    const RegularTiles R = {0, bs, (bs + kTile - 1) / kTile, 0};
+    const hipError_t e = launch_call_store_tiles(h, h->stream, nullptr, h->d_tiles_x.p, R, n, h->d_ref.p, 1, h->ref_len, h->d_rec_x.p, h->d_tr_x.p);
+    h->P = saved;
+    PISCES_HIP_CHECK(h, e);
+    hipLaunchKernelGGL(scan_tile_counts_kernel, dim3(1), dim3(1024), 0, h->stream, (const PiscesTileResult*)h->d_tr_x.p, n, h->d_off_x.p, h->d_cnt_x.p, h->d_cnt_x.p + 1);
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    PISCES_HIP_CHECK(h, hipMemcpyAsync(h->h_cnt_x, h->d_cnt_x.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    st->extra = h->h_cnt_x;
+    return PISCES_OK;
+}
+
 // hole_bound >= 0 (asynchronous flush): the compacted log is made hole_bound slots long (see enqueue_drop)
 // with_folded: the launch — when it is the fused kernel over a run of whole blocks — also leaves the folded counts of every locus it walks
 // in h->d_folded (h->fold says which positions), for the candidate kernel of the same flush
@@ -389,6 +441,10 @@ static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& key
     st->hdr = hdr;
     st->hrec = hrec;
     st->spec = spec;
+    if (h->exact_total_called && fused && !regular && !h->intervals.empty() && !h->snv_walk && h->log_ub == 0) {
+        int32_t rcx = enqueue_off_interval_count(h, keys, st);
+        if (rcx) return rcx;
+    }
     return PISCES_OK;
 }
 // Does a flush of `keys` go through the fused kernel over a run of whole blocks (call_blocks_enqueue's `fused && regular`)?  Then its
@@ -413,6 +469,7 @@ static int32_t call_blocks_finish(PiscesHip* h, const CallBlocksInFlight& st, in
     *total = st.hdr[0];
     h->pcie[1] += (int64_t)*total * (int64_t)sizeof(PiscesCalledAllele) + 16;
     *n_called += st.hdr[1];
+    if (st.extra) *n_called += st.extra[1];   // callable SNVs of the loci outside the intervals (pisces_hip_set_exact_total_called)
     if (st.drop_now && kept) std::memcpy(kept, st.hdr + 2, sizeof(unsigned long long));
     if ((size_t)*total > st.spec) {
         PISCES_HIP_CHECK(h, hipMemcpyAsync(st.hrec + st.spec, h->d_compact.p + 1 + st.spec, ((size_t)*total - st.spec) * sizeof(PiscesCalledAllele),

@@ -320,6 +320,15 @@ int32_t pisces_hip_set_forced_alleles(PiscesHip* h, const PiscesCandidate* cands
     });
 }
 
+int32_t pisces_hip_set_exact_total_called(PiscesHip* h, int32_t on)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    h->exact_total_called = on != 0;
+    return PISCES_OK;
+    });
+}
+
 // The chromosome's known (prior) variants (Factory.cs:204, 378-395: the priors file's insertions and MNVs of this chromosome): the
 // collapser annotates the candidates that equal one (VariantCollapser.cs:16-24, 178-190) and prefers them among potential matches (:216-218).
 int32_t pisces_hip_set_known_variants(PiscesHip* h, const PiscesCandidate* cands, int64_t n, const uint8_t* alleles, int64_t allele_bytes)

@@ -331,6 +331,10 @@ class HipVariantCaller:
         arr, pool, nb = self._candidate_arrays(list(alleles))
         _check(self._h, lib.pisces_hip_set_forced_alleles(self._h, arr, len(alleles), pool.ctypes.data, nb))
 
+    def SetExactTotalNumCalled(self, on=True):
+        """pisces_hip_set_exact_total_called: TotalNumCalled also counts the callable SNVs outside the interval set (AlleleCaller.cs:109-131)."""
+        _check(self._h, lib.pisces_hip_set_exact_total_called(self._h, int(bool(on))))
+
     def SetKnownVariants(self, variants):
         """The chromosome's known (prior) variants, [(position, ref, alt)]: Factory.cs:204 hands them to VariantCollapser (AnnotateKnown,
         VariantCollapser.cs:178-190).  [] clears."""

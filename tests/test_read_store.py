@@ -562,6 +562,46 @@ def test_a_leading_indel_one_past_a_block_edge_is_waited_for(torch_cuda, lead, d
         assert c.Stats()["TotalNumCalled"] == want_called
 
 
+@pytest.mark.parametrize("gvcf", [1, 0], ids=["gvcf", "variants only"])
+def test_total_num_called_counts_the_callable_snvs_outside_the_intervals_when_asked(torch_cuda, gvcf):
+    """AlleleCaller.Call counts an allele in IsCallable, before ShouldReport (AlleleCaller.cs:109-131): with an interval set the reference's
+    TotalNumCalled includes the callable SNVs of loci the reads overhang the intervals by.  The library evaluates the intervals' loci only
+    unless pisces_hip_set_exact_total_called asks for the reference's number (a counting launch over the off-interval loci of the
+    flushed blocks).  Rows are the oracle's either way; the total is the oracle's with the switch on and smaller without."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(99)
+    ref = rng.choice(np.frombuffer(b"ACGT", np.uint8), 3300)
+    intervals = [(200, 420), (1100, 1180), (2050, 2300)]
+    reads = []
+    alt_of = {ord("A"): "C", ord("C"): "G", ord("G"): "T", ord("T"): "A"}
+    snv_at = set(range(150, 2400, 37))        # planted SNVs inside and outside the intervals
+    for i, start in enumerate(np.sort(rng.integers(100, 2350, 900))):
+        seq = bytearray(ref[start - 1: start - 1 + 100].tobytes())
+        if i % 2:
+            for p in range(start, start + 100):
+                if p in snv_at:
+                    seq[p - start] = ord(alt_of[seq[p - start]])
+        reads.append(dict(pos=int(start), cigar=[("M", 100)], seq=bytes(seq), quals=bytes([35] * 100), reverse=bool(i & 2)))
+    batch = _abi.ReadBatch(reads)
+    cfg = _abi.default_config(include_reference_calls=gvcf)
+    for schedule in ([], [1000, 2000]):
+        want, want_alleles, want_called = orc.run_reads_schedule(batch, ref, 1, len(ref), cfg, schedule, intervals=intervals)
+        totals = {}
+        for exact in (False, True):
+            with engine.HipVariantCaller(cfg) as c:
+                c.SetReference(ref)
+                c.SetIntervals(intervals)
+                c.SetExactTotalNumCalled(exact)
+                c.AddAlleleCounts(batch)
+                rows = [c.CallWithAlleles(up) for up in schedule] + [c.CallWithAlleles(None)]
+                got = np.concatenate([r for r, _ in rows])
+                got_alleles = [a for _, al in rows for a in al]
+                assert got_alleles == want_alleles and got.tobytes() == want.tobytes()
+                totals[exact] = c.Stats()["TotalNumCalled"]
+        assert totals[True] == want_called, (schedule, totals, want_called)
+        assert totals[False] < want_called
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("gvcf", [1, 0], ids=["gvcf", "variants only"])
 def test_candidate_rows_merged_in_place_equal_the_rows_merged_by_copy(torch_cuda, gvcf):
