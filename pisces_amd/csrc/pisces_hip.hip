@@ -292,6 +292,7 @@ struct PiscesHip {
     DeviceBuf<PiscesCalledAllele> d_rec_x;
     DeviceBuf<int32_t> d_cnt_x, d_off_x;
     int32_t* h_cnt_x = nullptr;   // pinned: {records, called} of the counting launch
+    bool tables_shareable = false;            // the memo tables are the default ones of the configuration: they outlive the handle (table_cache)
     bool poisoned = false;                    // the deferred half of a batch's candidate discovery failed after the batch was committed (finish_candidate_discovery)
     std::string poison_why;
     uint8_t* h_prep = nullptr;                // pinned: prepare_collect_kernel's PrepVerdict + the keys of the touched blocks
@@ -718,6 +719,39 @@ static R abi_guard(PiscesHip* h, F&& body)
     }
 }
 
+// The memo tables of the call phase depend on the configuration only (~22 MB, four kernels, ~0.6 ms of pisces_hip_create): a job per
+// chromosome or per interval range makes and destroys a handle (BaseGenomeProcessor.cs:40-90), so a destroyed handle leaves its tables
+// here and the next handle of the same configuration on the same device takes them over instead of building them again.
+namespace {
+struct TableSet {
+    PiscesHipConfig cfg;
+    int device = 0;
+    DeviceBuf<double> gq_tail, sb_tab, sb0_tab;
+    DeviceBuf<int16_t> vq_tab, gq_cap;
+};
+std::mutex g_tables_mu;
+std::vector<TableSet*>& table_cache() { static std::vector<TableSet*>* v = new std::vector<TableSet*>(); return *v; }   // (never destroyed: the HIP runtime may be gone by then)
+TableSet* take_tables(const PiscesHipConfig& cfg, int device)
+{
+    std::lock_guard<std::mutex> lock(g_tables_mu);
+    auto& v = table_cache();
+    for (size_t i = 0; i < v.size(); i++)
+        if (v[i]->device == device && std::memcmp(&v[i]->cfg, &cfg, sizeof(cfg)) == 0) {
+            TableSet* t = v[i];
+            v.erase(v.begin() + (std::ptrdiff_t)i);
+            return t;
+        }
+    return nullptr;
+}
+void leave_tables(TableSet* t)
+{
+    std::lock_guard<std::mutex> lock(g_tables_mu);
+    auto& v = table_cache();
+    v.push_back(t);
+    if (v.size() > 8) { delete v.front(); v.erase(v.begin()); }
+}
+}  // namespace
+
 extern "C" {
 
 int32_t pisces_hip_abi_version(void) { return PISCES_HIP_ABI_VERSION; }
@@ -871,7 +905,19 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         pisces_hip_destroy(h);
         return PISCES_E_DEVICE;
     }
-    if (!getenv("PISCES_HIP_NO_GQ_TABLE")) {
+    const bool tables_by_default = !getenv("PISCES_HIP_NO_GQ_TABLE") && !getenv("PISCES_HIP_NO_CALL_TABLES") && h->cfg.noise_model == PISCES_NOISE_FLAT &&
+                                   h->cfg.strand_bias_model != PISCES_SB_DIPLOID && h->cfg.max_variant_qscore <= 32767 && h->cfg.max_genotype_qscore <= 32767 &&
+                                   h->cfg.min_genotype_qscore >= -32768;
+    std::unique_ptr<TableSet> kept(tables_by_default ? take_tables(h->cfg, h->device) : nullptr);
+    if (kept) {   // the tables a destroyed handle of this configuration left (the sizes are the constants below)
+        h->d_gq_tail.swap(kept->gq_tail); h->d_vq_tab.swap(kept->vq_tab); h->d_sb_tab.swap(kept->sb_tab); h->d_sb0_tab.swap(kept->sb0_tab); h->d_gq_cap.swap(kept->gq_cap);
+        h->P.gq_tail = h->d_gq_tail.p; h->P.gq_tail_a = 32; h->P.gq_tail_cov = 8192;
+        h->P.vq_tab = h->d_vq_tab.p; h->P.sb_tab = h->d_sb_tab.p; h->P.sb0_tab = h->d_sb0_tab.p; h->P.gq_cap = h->d_gq_cap.p;
+        h->P.vq_tab_k = h->P.sb_tab_k = 256;
+        h->P.tab_cov = 8192;
+        h->tables_shareable = true;
+    }
+    if (!kept && !getenv("PISCES_HIP_NO_GQ_TABLE")) {
         // genotype-quality tail memo, evaluated on the device by the function it stands in for
         const int32_t n_a = 32, n_cov = 8192;
         if ((e = h->d_gq_tail.reserve((size_t)n_a * n_cov)) != hipSuccess) {
@@ -890,7 +936,7 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         h->P.gq_tail_a = n_a;
         h->P.gq_tail_cov = n_cov;
     }
-    if (!getenv("PISCES_HIP_NO_CALL_TABLES") && h->cfg.noise_model == PISCES_NOISE_FLAT && h->cfg.strand_bias_model != PISCES_SB_DIPLOID &&
+    if (!kept && !getenv("PISCES_HIP_NO_CALL_TABLES") && h->cfg.noise_model == PISCES_NOISE_FLAT && h->cfg.strand_bias_model != PISCES_SB_DIPLOID &&
         h->cfg.max_variant_qscore <= 32767 && h->cfg.max_genotype_qscore <= 32767 && h->cfg.min_genotype_qscore >= -32768) {
         // Memo tables of the streaming-rate kernel's call phase, filled by the device with the functions they stand in for
         // (bit-identical by construction): variant q-score and strand-bias tail by (support, coverage), the support-0 power by
@@ -920,6 +966,7 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         h->P.gq_cap = h->P.gq_tail ? h->d_gq_cap.p : nullptr;
         h->P.vq_tab_k = h->P.sb_tab_k = n_k;
         h->P.tab_cov = n_cov;
+        h->tables_shareable = tables_by_default && h->P.gq_tail != nullptr;
     }
     if ((e = h->d_params.reserve(1)) != hipSuccess || (e = hipMemcpy(h->d_params.p, &h->P, sizeof(DeviceParams), hipMemcpyHostToDevice)) != hipSuccess) {
         g_create_error = std::string("pisces_hip_create: ") + hipGetErrorString(e);
@@ -933,6 +980,11 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
 
 int64_t pisces_hip_trim_memory(void)
 {
+    {   // the memo tables kept for the next handle go too
+        std::lock_guard<std::mutex> lock(g_tables_mu);
+        for (TableSet* t : table_cache()) delete t;
+        table_cache().clear();
+    }
     AllocCache& c = alloc_cache();
     std::lock_guard<std::mutex> lock(c.m);
     int dev = 0;
@@ -967,6 +1019,13 @@ int32_t pisces_hip_destroy(PiscesHip* h)
         explicit KeepFreed(bool on) { tl_keep_freed = on; }
         ~KeepFreed() { tl_keep_freed = false; }
     } keep(idle);
+    if (idle && h->tables_shareable && h->d_vq_tab.p && h->d_gq_tail.p && h->d_gq_cap.p) {   // the next handle of this configuration takes them over
+        TableSet* t = new TableSet();
+        t->cfg = h->cfg;
+        t->device = h->device;
+        t->gq_tail.swap(h->d_gq_tail); t->vq_tab.swap(h->d_vq_tab); t->sb_tab.swap(h->d_sb_tab); t->sb0_tab.swap(h->d_sb0_tab); t->gq_cap.swap(h->d_gq_cap);
+        leave_tables(t);
+    }
     h->d_summary.release();
     h->d_ref.release(); h->d_tuples.release(); h->d_tiles.release(); h->d_tile_results.release();
     h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release(); h->d_totals.release(); h->d_qlut.release(); h->d_bq_lut.release(); h->d_sumq_fix.release(); h->d_sumq.release(); h->d_gq_tail.release(); h->d_vq_tab.release(); h->d_sb_tab.release(); h->d_sb0_tab.release(); h->d_gq_cap.release(); h->d_params.release(); h->d_offsets.release(); h->d_compact.release();
