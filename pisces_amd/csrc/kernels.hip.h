@@ -1146,29 +1146,37 @@ __global__ __launch_bounds__(1024) void scan_tile_counts_kernel(const PiscesTile
                                                                 int32_t* __restrict__ offsets, int32_t* __restrict__ total,
                                                                 int32_t* __restrict__ called_out /* optional */)
 {
-    __shared__ int s_part[1024];
-    __shared__ int s_carry;
+    __shared__ int s_wave[2][16];   // the sixteen waves' totals of a chunk of 1024 tiles (two sets: one barrier a chunk)
     __shared__ int s_called;
-    if (threadIdx.x == 0) { s_carry = 0; s_called = 0; }
-    __syncthreads();
+    if (threadIdx.x == 0) s_called = 0;
     int called = 0;   // IAlleleCaller.TotalNumCalled of the launch: total[1]
-    for (int base = 0; base < n_tiles; base += 1024) {
+    int carry = 0;    // records of the chunks before this one (the same in every thread)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int set = 0;
+    for (int base = 0; base < n_tiles; base += 1024, set ^= 1) {
         const int i = base + threadIdx.x;
         const int v = i < n_tiles ? tr[i].n_records : 0;
         if (i < n_tiles) called += tr[i].n_called;
-        s_part[threadIdx.x] = v;
-        __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {   // Hillis-Steele inclusive scan
-            int add = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
-            __syncthreads();
-            s_part[threadIdx.x] += add;
-            __syncthreads();
+        int x = v;   // inclusive scan inside the wave (shuffles), then the waves' totals through LDS
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
         }
-        if (i < n_tiles) offsets[i] = s_carry + s_part[threadIdx.x] - v;
+        if (lane == 63) s_wave[set][w] = x;
         __syncthreads();
-        if (threadIdx.x == 1023) s_carry += s_part[1023];
-        __syncthreads();
+        int before = 0, chunk = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int t = s_wave[set][k];
+            before += k < w ? t : 0;
+            chunk += t;
+        }
+        if (i < n_tiles) offsets[i] = carry + before + x - v;
+        carry += chunk;
     }
+    __syncthreads();
+    const int s_carry = carry;
     if (called) atomicAdd(&s_called, called);
     __syncthreads();
     if (threadIdx.x == 0) {
