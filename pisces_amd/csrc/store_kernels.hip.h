@@ -66,7 +66,7 @@ constexpr uint32_t kFragTerminal = 1u << 24;
 // second aligned run of 20M40000N30M)
 __host__ __device__ __forceinline__ int frag_delta(long long aoff) { return (int)((unsigned long long)aoff >> 48); }     // a deletion at the read's end / before its final soft clip: its positions count in anchor bin 10
 constexpr int kMaxSegments = 8;
-constexpr int kStateUnsorted = 0, kStateReach = 1, kStateComplex = 2, kStateFrags = 3;   // [kStateFrags]: bit 0 some read is kDescGeneric, bit 1 some deletion fragment
+constexpr int kStateUnsorted = 0, kStateReach = 1, kStateComplex = 2, kStateFrags = 3;   // [kStateFrags]: bit 0 some read is kDescGeneric, bit 1 some deletion fragment, bit 2 the position grid is not usable
 
 struct SegmentView {
     const ReadDesc* frag;         // one per CIGAR operation (see above)
@@ -84,7 +84,9 @@ struct SegmentView {
     int32_t n_floored;            // reads [0, n_floored) were there at the last flush: their positions below `floor` are counted already
     int32_t floor;
     int32_t n_frags, n_floored_frags;   // the same for the fragments
-    int32_t pad;
+    int32_t grid_n;               // cells of `grid` (0: none)
+    const int32_t* grid;          // grid[c - grid_base] = first fragment whose read starts at or behind position c << kGridShift (grid_fill_kernel), or nullptr
+    int32_t grid_base, pad2;
 };
 struct StoreView {
     SegmentView seg[kMaxSegments];
@@ -655,6 +657,89 @@ __device__ __forceinline__ void wave_lower_bound2(const ReadDesc* __restrict__ d
     *hi_out = __builtin_amdgcn_readlane(a, 32);
 }
 
+// THE POSITION GRID of a segment: grid[c - grid_base] = index of the first fragment whose READ starts at or behind position 8 c — a
+// lower bound per cell of 8 positions, written when a batch joins (one lane a read: the cells between the read before it and itself get
+// the read's first fragment; cells behind the last read keep their fill value, which is above every index).  A tile's search then starts
+// from two entries instead of the whole segment: one round for the entries, one for the fragments of a cell (wave_lower_bound2_hinted),
+// where the 32-ary search over the whole segment takes four dependent rounds of ~1.1 us each.
+constexpr int kGridShift = 3;   // cells of 8 positions
+constexpr int kGridBadBit = 4;       // state[kStateFrags]
+__global__ __launch_bounds__(256) void grid_fill_kernel(const ReadDesc* __restrict__ desc, const ReadExt* __restrict__ ext, int32_t n0, int32_t nr,
+                                                        int32_t* __restrict__ grid, int32_t grid_base, int32_t grid_n, int32_t* __restrict__ state)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nr) return;
+    const int i = n0 + r;
+    const long long p = desc[i].pos0;
+    const long long prev = i > 0 ? (long long)desc[i - 1].pos0 : ((long long)grid_base << kGridShift) - 1;
+    if (p <= prev) return;   // (the same position as the read before it; or out of order: the segment is then scanned, not searched)
+    const long long c0 = ((prev + (1ll << kGridShift)) >> kGridShift), c1 = p >> kGridShift;   // cells c with prev < (c << kGridShift) <= p (prev >= -1)
+    // a gap one lane should not fill (sparse reads: the segment goes without a grid); or outside the span the host sized the grid over (never expected)
+    if (c1 - c0 > 4096 || c1 - grid_base >= grid_n || c0 < grid_base) { atomicOr(&state[kStateFrags], kGridBadBit); return; }
+    const int f0 = (int)ext[i].cig_off;
+    for (long long c = c0; c <= c1; c++) {
+        const long long k = c - grid_base;
+        if (k >= 0 && k < grid_n) grid[k] = f0;
+    }
+}
+
+// One narrowing round of the hinted search with PER probes a lane (32 PER a half): the window [a, b] of the lane's half shrinks to one
+// step of it.  All of a lane's loads are issued before the first is used: one round trip.
+template <int PER>
+__device__ __forceinline__ void hinted_round(const ReadDesc* __restrict__ desc, int x, int half, int sub, bool more, int& a, int& b)
+{
+    const int step = max((b - a + 32 * PER - 1) / (32 * PER), 1);
+    long long idx[PER];
+    int v[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        idx[u] = (long long)a + (long long)(32 * u + sub + 1) * step - 1;
+        v[u] = (more && idx[u] < b) ? desc[idx[u]].pos0 : 0x7FFFFFFF;
+    }
+    int c = 0;
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const unsigned long long below = __ballot(more && idx[u] < b && v[u] < x);
+        c += __popc((unsigned int)(half ? (below >> 32) : (below & 0xFFFFFFFFull)));
+    }
+    const long long na = (long long)a + (long long)c * step;
+    const long long nb = na + step - 1;
+    if (more) {
+        a = (int)min(na, (long long)b);
+        b = (int)max(min(nb, (long long)b), (long long)a);
+    }
+}
+
+// Both ends of a tile's fragment range from the position grid: lanes 0-31 the low end, 32-63 the high end.  The bound for position x lies
+// between the entries of x's cell and of the next one; that window (the fragments of reads that start inside one cell: ~26 at 500x) is
+// narrowed with as many probes a lane as it takes to finish in one round (1, 2, 4 or 8: up to 256 fragments), more rounds behind that.
+__device__ __forceinline__ void wave_lower_bound2_hinted(const ReadDesc* __restrict__ desc, int n, int x_lo, int x_hi, int lane, const int32_t* __restrict__ grid,
+                                                         int grid_base, int grid_n, int* lo_out, int* hi_out)
+{
+    const int half = lane >> 5, sub = lane & 31;
+    const int x = half ? x_hi : x_lo;
+    const long long k = ((long long)max(x, 0) >> kGridShift) - grid_base;
+    int a, b;
+    if (k < 0) { a = 0; b = 0; }                       // before the segment's first read
+    else if (k >= grid_n) { a = n; b = n; }            // behind every cell a read starts in
+    else {
+        a = min(grid[k], n);
+        b = k + 1 < grid_n ? min(grid[k + 1], n) : n;
+        b = max(b, a);
+    }
+    bool more = b > a;
+    while (__ballot(more) != 0ull) {
+        const int w = max(__builtin_amdgcn_readlane(b - a, 0), __builtin_amdgcn_readlane(b - a, 32));
+        if (w <= 32) hinted_round<1>(desc, x, half, sub, more, a, b);
+        else if (w <= 64) hinted_round<2>(desc, x, half, sub, more, a, b);
+        else if (w <= 128) hinted_round<4>(desc, x, half, sub, more, a, b);
+        else hinted_round<8>(desc, x, half, sub, more, a, b);
+        more = b > a;
+    }
+    *lo_out = __builtin_amdgcn_readlane(a, 0);
+    *hi_out = __builtin_amdgcn_readlane(a, 32);
+}
+
 __device__ __forceinline__ long long readlane64(long long v, int lane_index)
 {
     const int lo = __builtin_amdgcn_readlane((int)(v & 0xFFFFFFFFll), lane_index);
@@ -914,7 +999,10 @@ __device__ __forceinline__ void walk_segment_fast(const SegmentView& G, int tile
     const int reach = G.state[kStateReach];
     const int x_lo = (int)max((long long)tile_start - reach + 1, -0x7FFFFFFFll), x_hi = tile_end == 0x7FFFFFFF ? 0x7FFFFFFF : tile_end + 1;
     int lo = 0, hi = G.n_frags;
-    if (sorted) wave_lower_bound2(G.frag, G.n_frags, x_lo, x_hi, lane, &lo, &hi);
+    if (sorted) {
+        if (G.grid && !(G.state[kStateFrags] & kGridBadBit)) wave_lower_bound2_hinted(G.frag, G.n_frags, x_lo, x_hi, lane, G.grid, G.grid_base, G.grid_n, &lo, &hi);
+        else wave_lower_bound2(G.frag, G.n_frags, x_lo, x_hi, lane, &lo, &hi);
+    }
 #ifdef PISCES_STORE_TIMING
     if (stamps) { stamps[0] = wall_clock64(); stamps[1] = hi - lo; }
 #endif

@@ -29,6 +29,9 @@ static void store_view(const PiscesHip* h, StoreView* V)
         v.floor = g.floor;
         v.n_frags = (int32_t)g.n_ops;
         v.n_floored_frags = (int32_t)g.n_floored_ops;
+        v.grid = g.grid_ok && g.grid_n > 0 ? g.grid.p : nullptr;
+        v.grid_base = (int32_t)g.grid_base;
+        v.grid_n = (int32_t)g.grid_n;
     }
     V->n_segments = n;
 }
@@ -70,6 +73,8 @@ static int32_t store_new_segment(PiscesHip* h, std::unique_ptr<ReadSegment>* out
     g->floor = 0;
     g->max_key = 0;
     g->open = false;
+    g->grid_ok = false;
+    g->grid_base = g->grid_n = 0;
     g->v_bases = g->v_quals = g->v_dirs = g->v_cop = g->v_codes = nullptr;
     g->v_clen = nullptr;
     { int32_t rc = store_state_slot(h, &g->state); if (rc) return rc; }
@@ -100,6 +105,8 @@ static int32_t store_commit_flush(PiscesHip* h, const std::vector<int32_t>& keys
             g.floor = 0;
             g.max_key = 0;
             g.v_dirs = nullptr;
+            g.grid_ok = false;
+            g.grid_base = g.grid_n = 0;
             { int32_t rc = store_state_slot(h, &g.state); if (rc) return rc; }
             i++;
         } else if (dead) {
@@ -235,7 +242,8 @@ struct StoreBatchArrays {
     const uint8_t* quals;
     const uint8_t* dirs;   // or nullptr
 };
-static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const StoreBatchArrays& A, int32_t nr, size_t n_cig, size_t n_seq)
+static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const StoreBatchArrays& A, int32_t nr, size_t n_cig, size_t n_seq,
+                                   int32_t min_position = 0 /* lowest read position of the batch, 0 = unknown */, int32_t max_key = 0 /* highest block a read touches */)
 {
     ReadSegment& g = *pl.seg;
     if (g.n_reads + nr > 0x7FFFFF00ll || g.n_ops + (int64_t)n_cig > 0x7FFFFF00ll) return fail(h, PISCES_E_INVALID_ARG, "add_reads: too many reads held at once");
@@ -306,6 +314,30 @@ static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const Sto
     S.shape_blocks = (nr + 255) / 256;
     const unsigned enc_blocks = (unsigned)std::min<int64_t>(((int64_t)n_seq + 16 * 256 - 1) / (16 * 256), 8192);
     hipLaunchKernelGGL(read_shape_kernel, dim3((unsigned)S.shape_blocks + enc_blocks), dim3(256), 0, h->stream, S);
+    {   // the position grid (what a tile's search starts from): extended over the batch's span, or given up for this segment
+        const bool first = g.n_reads == 0;
+        bool ok = min_position > 0 && (first || g.grid_ok);
+        int64_t base = g.grid_base, cells = g.grid_n;
+        if (ok) {
+            const int64_t c_lo = (int64_t)min_position >> kGridShift;
+            const int64_t c_hi = (std::min<int64_t>(((int64_t)max_key + 2) * h->cfg.block_size, 0x7FFFFFFFll) >> kGridShift) + 2;   // (past the last block a read of the batch touches)
+            if (first) { base = c_lo; cells = 0; }
+            // worth it for dense reads only: at most four cells a CIGAR operation held (500x of 150-base reads: one cell per ~26)
+            if (c_lo < base || c_hi - base + 1 > std::max<int64_t>(1ll << 16, 4 * (g.n_ops + (int64_t)n_cig))) ok = false;
+            else if (c_hi - base + 1 > cells) {
+                const int64_t want = c_hi - base + 1;
+                PISCES_HIP_CHECK(h, g.grid.grow_keep((size_t)want, (size_t)cells, h->stream));
+                PISCES_HIP_CHECK(h, hipMemsetAsync(g.grid.p + cells, 0x7F, (size_t)(want - cells) * sizeof(int32_t), h->stream));
+                cells = want;
+            }
+        }
+        g.grid_ok = ok;
+        g.grid_base = ok ? base : 0;
+        g.grid_n = ok ? cells : 0;
+        if (ok)
+            hipLaunchKernelGGL(grid_fill_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, h->stream, (const ReadDesc*)g.desc.p, (const ReadExt*)g.ext.p, S.n0, nr,
+                               g.grid.p, (int32_t)base, (int32_t)cells, g.state);
+    }
     if (!pl.direct && !A.dirs && g.v_dirs)   // a batch without directions in a segment that tracks them
         hipLaunchKernelGGL(segment_fill_dirs_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, h->stream, (const ReadDesc*)g.desc.p,
                            (const ReadExt*)g.ext.p, S.n0, S.n0 + nr, const_cast<uint8_t*>(g.v_dirs));
@@ -438,7 +470,7 @@ static int32_t store_finish_add(PiscesHip* h, StorePlace& pl, int32_t rc, uint8_
     db.n_reads = nr;
     if (rc == PISCES_OK) {
         const StoreBatchArrays A = {db.position, db.flags, db.cigar_offset, db.cigar_op, db.cigar_len, db.seq_offset, db.bases, db.quals, db.dirs};
-        rc = store_append_arrays(h, pl, A, nr, n_cig, n_seq);
+        rc = store_append_arrays(h, pl, A, nr, n_cig, n_seq, min_position, max_key);
     }
     // ICandidateVariantFinder.FindCandidates + IStateManager.AddCandidates (SmallVariantCaller.cs:92-96) on the device, on the batch as it lies there
     if (rc == PISCES_OK && find_on_device && (h->snv_walk || found_slots > 0 || h->eqx_in_batch)) {
