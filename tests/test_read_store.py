@@ -220,6 +220,36 @@ def test_any_cigar_through_the_fused_kernel_equals_the_log_chain(torch_cuda, mod
     assert (got["position"] > 70000).any()        # the far ends of the skipping reads were called
 
 
+@pytest.mark.parametrize("shape", ["clusters 20 000 apart", "clusters 50 000 apart", "second batch before the first", "a pile on one position",
+                                   "a pile, then a tail"])
+@pytest.mark.parametrize("mode", ["default", "every batch appended to the open segment"])
+def test_the_position_grid_finds_what_the_search_over_the_whole_segment_finds(torch_cuda, mode, shape):
+    """A tile's fragment range starts from the segment's position grid (grid_fill_kernel, wave_lower_bound2_hinted) where the segment
+    has one: records equal the log chain's when the reads lie in clusters with empty cells between them, when the gap between two
+    reads is wider than one lane fills (the segment then goes without a grid), when a later batch starts before the grid's first cell,
+    and when thousands of fragments share one cell (more than one narrowing round)."""
+    rng = np.random.default_rng(31)
+    ref = np.frombuffer(bytes(rng.choice(list(b"ACGT"), 120_000).astype(np.uint8)), dtype=np.uint8)
+    if shape.startswith("clusters"):
+        step = 20_000 if "20 000" in shape else 50_000
+        reads = []
+        for k in range(3):
+            reads += random_reads(rng, 500, 1000 + k * step, 1400 + k * step, with_dirs=False)
+        batches = [reads[:700], reads[700:]]
+    elif shape == "second batch before the first":
+        batches = [random_reads(rng, 600, 5000, 5600, with_dirs=False), random_reads(rng, 600, 3000, 5300, with_dirs=False)]
+    else:
+        pile = random_reads(rng, 3000, 2000, 2001, with_dirs=False)
+        tail = random_reads(rng, 400, 2001, 2300, with_dirs=False) if "tail" in shape else []
+        batches = [pile + tail]
+    cfg = _abi.default_config(min_coverage=1, low_depth_filter=1)
+    environ = dict(PISCES_HIP_READ_PATH=None, **STORE_MODES[mode])
+    got_r, got_a, stats = _schedule_run([_abi.ReadBatch(b) for b in batches], ref, cfg, [None] * len(batches), environ)
+    want_r, want_a, want_stats = _schedule_run([_abi.ReadBatch(b) for b in batches], ref, cfg, [None] * len(batches), dict(PISCES_HIP_READ_PATH="log"))
+    assert len(got_r) > 300
+    assert got_r.tobytes() == want_r.tobytes() and got_a == want_a and stats == want_stats
+
+
 @pytest.mark.parametrize("gap_op", ["N", "D"])
 def test_fragment_behind_a_gap_of_forty_thousand_positions(torch_cuda, gap_op):
     """A later fragment's offset from the read's position sits in the top 16 bits of the descriptor's signed 64-bit field: offsets of
