@@ -67,7 +67,8 @@ struct BlockObs {   // the block's observations live in the device log (PiscesHi
 // A caller that cuts a genome into pieces makes and destroys a handle per piece (one per chromosome in the reference,
 // BaseGenomeProcessor.cs:40-90; one per (contig, interval range) in BASELINE config 4): hipFree and hipHostFree synchronise the device
 // and unpin pages — 30 ms of a 75 ms piece were pisces_hip_destroy, 10 more the first touch of freshly pinned staging memory.  What a
-// handle held when it was destroyed is therefore kept (by device; up to PISCES_HIP_ALLOC_CACHE_MB of device memory, default 8192, and a
+// handle held when it was destroyed is therefore kept (by device; up to PISCES_HIP_ALLOC_CACHE_MB of device memory, default 8192 or a
+// sixteenth of the device's memory if that is less, and a
 // quarter of that pinned) and handed to the next allocation of about that size.  Only pisces_hip_destroy puts memory there — it has
 // waited for the handle's streams — a buffer that is outgrown in mid-life is freed for real, as before.  pisces_hip_trim_memory()
 // gives everything back.
@@ -83,7 +84,12 @@ struct AllocCache {
         if (configured) return;
         configured = true;
         const char* e = getenv("PISCES_HIP_ALLOC_CACHE_MB");
-        const long long mb = e ? atoll(e) : 8192;
+        long long mb = e ? atoll(e) : 8192;
+        if (!e) {   // the default never holds back more than a sixteenth of the device: processes that share a GPU cannot drop each other's caches
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) mb = std::min<long long>(mb, (long long)(total_b >> 24));
+            else (void)hipGetLastError();
+        }
         limit_dev = (size_t)std::max(0ll, mb) << 20;
         limit_host = limit_dev / 4;
     }

@@ -560,12 +560,14 @@ bool can_collapse(const HostCandidate& t, const HostCandidate& p)
 // ---- MnvReallocator (exe/Pisces/Logic/VariantCalling/MnvReallocator.cs:12-261) over heap HostCandidate objects; AlleleSupport is the
 // sum of support_by_dir throughout (AlleleHelper.Map and every CreateVariant on this path keep the two in step) ----
 using CandPtr = HostCandidate*;
-struct MnvArena {   // owns every object the reallocation creates
-    std::vector<std::unique_ptr<HostCandidate>> objs;
+struct MnvArena {   // owns every object the reallocation creates (in chunks: a flush of thirty blocks at 2000x makes ~5 000 of them)
+    static constexpr size_t kChunk = 512;
+    std::vector<std::unique_ptr<HostCandidate[]>> chunks;
+    size_t used = kChunk;
     CandPtr make(int32_t position, const std::string& alt, const std::string& ref, const int32_t* dirs)   // CreateVariant :151-168
     {
-        objs.emplace_back(new HostCandidate());
-        CandPtr v = objs.back().get();
+        if (used == kChunk) { chunks.emplace_back(new HostCandidate[kChunk]); used = 0; }
+        CandPtr v = &chunks.back()[used++];
         bool same = alt.size() == ref.size();
         for (size_t i = 0; same && i < alt.size(); i++) same = std::toupper((unsigned char)alt[i]) == std::toupper((unsigned char)ref[i]);
         v->category = same ? PISCES_CAT_REFERENCE : (alt.size() > 1 ? PISCES_CAT_MNV : PISCES_CAT_SNV);
@@ -639,11 +641,11 @@ void mnv_reallocate_failed(MnvArena& arena, const std::vector<CandPtr>& failed, 
     // the failed allele's few positions, and a batch of thirty blocks holds ~10^5 callable alleles (a scan of all of them per failed
     // allele made reallocation 52 of the 65 ms of such a flush)
     // (a sorted array of (position, place) for the alleles there are at the start — thousands in a large batch, no allocation each —
-    // and a small map for the SNVs that BreakDownToSingleNucCalls adds on the way)
+    // and a second one for the SNVs that BreakDownToSingleNucCalls adds on the way)
     std::vector<std::pair<int32_t, uint32_t>> by_position(callable.size());
     for (size_t i = 0; i < callable.size(); i++) by_position[i] = {callable[i]->position, (uint32_t)i};
     std::sort(by_position.begin(), by_position.end());
-    std::unordered_map<int32_t, std::vector<uint32_t>> at_position;
+    std::vector<std::pair<int32_t, uint32_t>> added;   // (position, place) of those, kept sorted: they arrive nearly in position order
     std::vector<uint32_t> places;
     std::vector<CandPtr> remainderAlleles, overlaps;   // (reused: a failed MNV is a handful of alleles, a batch hundreds of failed MNVs)
     for (CandPtr failedMnv : ordered) {
@@ -657,11 +659,10 @@ void mnv_reallocate_failed(MnvArena& arena, const std::vector<CandPtr>& failed, 
                 auto lo = std::lower_bound(by_position.begin(), by_position.end(), std::make_pair(alleleToReassign->position, 0u));
                 for (; lo != by_position.end() && lo->first <= alleleToReassign->position + fl; ++lo) places.push_back(lo->second);
             }
-            if (!at_position.empty())
-                for (int32_t q = alleleToReassign->position; q <= alleleToReassign->position + fl; q++) {
-                    auto it = at_position.find(q);
-                    if (it != at_position.end()) places.insert(places.end(), it->second.begin(), it->second.end());
-                }
+            if (!added.empty()) {
+                auto lo = std::lower_bound(added.begin(), added.end(), std::make_pair(alleleToReassign->position, 0u));
+                for (; lo != added.end() && lo->first <= alleleToReassign->position + fl; ++lo) places.push_back(lo->second);
+            }
             std::sort(places.begin(), places.end());   // the order of `callable`: what the stable sort below keeps among equals
             for (uint32_t i : places) {   // IsPotentialOverlap :250-261
                 CandPtr c = callable[i];
@@ -706,7 +707,11 @@ void mnv_reallocate_failed(MnvArena& arena, const std::vector<CandPtr>& failed, 
                                             alleleToReassign->support_by_dir);
                     if (sn->category == PISCES_CAT_REFERENCE) continue;
                     if (hasMax && sn->position > blockMaxPos) outsideThisBlock.push_back(sn);
-                    else { at_position[sn->position].push_back((uint32_t)callable.size()); callable.push_back(sn); }
+                    else {
+                        const std::pair<int32_t, uint32_t> e(sn->position, (uint32_t)callable.size());
+                        added.insert(std::upper_bound(added.begin(), added.end(), e), e);
+                        callable.push_back(sn);
+                    }
                 }
                 list_remove(remainderAlleles, alleleToReassign);
             }
