@@ -510,7 +510,7 @@ def config3_sample(engine, torch, amps=200):
             "host_seconds_in_flush_per_flush": ht["host_ms_per_flush"] / 1e3, "pcie_bytes_per_flush": {k: v / max(ht["flushes"], 1) for k, v in tb.items()},
             "what": "BASELINE config 3's mix, a 30 000-locus sample, reads in device memory -> records on the host: pisces_hip_add_device_reads + one "
                     "pisces_hip_flush_view (device checks, read store, candidate discovery + merge, dirty loci, collapser / reallocator, call kernels); wall clock, "
-                    "not a per-kernel figure: profiles/r04_config3_kernel_stats.csv has those; all of config 3: python bench.py --config 3"}
+                    "not a per-kernel figure: profiles/r05_config3_kernel_stats.csv has those; all of config 3: python bench.py --config 3"}
 
 
 def config5_sample(engine, torch, amps=100):
@@ -907,7 +907,7 @@ def run_stream_config(args):
                                                  "frac": algo_bytes / elapsed / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": algo_bytes,
                                                  "seconds": elapsed, "what": "reads in device memory (2 B per aligned base) -> records (64 B each), wall clock of pisces_hip_add_device_reads + "
                                                  "pisces_hip_flush_view over all stretches on rank 0: candidate discovery, merge, collapser / reallocator on the host and the call kernels "
-                                                 "included; per-kernel times: profiles/r04_config3_kernel_stats.csv"},
+                                                 "included; per-kernel times: profiles/r05_config3_kernel_stats.csv (config 3), profiles/r05_config5_kernel_stats.csv (config 5)"},
                "host_fed": {"value": loci_mine / elapsed_h, "unit": "candidate loci/s (rank 0)", "seconds": elapsed_h, "host_seconds_in_add_reads": host_h["add_reads_s"],
                             "host_seconds_in_flushes": host_h["flush_s"], "pcie_bytes": pcie_h,
                             "what": "the same stretches from host arrays (pisces_hip_add_reads): the reads cross PCIe, 2 B per base"}}

@@ -486,6 +486,7 @@ static int32_t store_finish_add(PiscesHip* h, StorePlace& pl, int32_t rc, uint8_
     { int32_t rcs = stage_release(h); if (rc == PISCES_OK) rc = rcs; }   // (transfers out of the pinned buffer may be in flight whatever happened after them)
     if (rc) {
         (void)hipStreamSynchronize(h->stream);
+        pl.seg->grid_ok = false;   // (the refused batch may have written cells of an open segment's position grid: the segment goes without)
         store_unplace(h, pl);
         return rc;
     }

@@ -11,7 +11,7 @@ dst = "profiles"
 plain = {"bench_n1.json": "bench_n1.json", "bench_kernel_stats.csv": "bench_kernel_stats.csv", "streaming_kernel_stats.csv": "streaming_kernel_stats.csv",
          "bam_kernel_stats.csv": "bam_kernel_stats.csv", "store_store_kernel_stats.csv": "store_store_kernel_stats.csv",
          "store_log_kernel_stats.csv": "store_log_kernel_stats.csv", "config3_kernel_stats.csv": "config3_blocks_kernel_stats.csv",
-         "config3_batch_kernel_stats.csv": "config3_kernel_stats.csv", "config3_full.json": "config3_full.json", "config5_full.json": "config5_full.json",
+         "config3_batch_kernel_stats.csv": "config3_kernel_stats.csv", "config3_full.json": "config3_full.json", "config5_full.json": "config5_full.json", "config5_kernel_stats.csv": "config5_kernel_stats.csv",
          "config4.json": "config4.json", "bench_n1_k20.json": "bench_n1_k20.json", "bench_n2_one_device_b.json": "bench_n2_one_device.json",
          "store_timing.txt": "store_timing.txt", "bgzf_bench.txt": "bgzf_bench.txt"}
 for a, b in plain.items():
@@ -38,7 +38,11 @@ for name, out in (("hostfed.log", "streaming_bench.txt"), ("bam_bench.log", "bam
 p = os.path.join(src, "gpu_suite_full.log")
 if os.path.exists(p):
     lines = [l for l in open(p) if ("passed" in l or "failed" in l or "FAILED" in l or "skipped" in l)]
-    open(os.path.join(dst, f"{tag}_gpu_suites.txt"), "w").writelines(["python -m pytest tests -m gpu -q  (one MI355X)\n"] + lines[-6:])
+    target = os.path.join(dst, f"{tag}_gpu_suites.txt")
+    if os.path.exists(target):   # the round's record of its suite runs is kept by hand: show the new run, leave the file
+        print("gpu suite of this run (add it to %s): %s" % (target, "".join(lines[-2:]).strip()))
+    else:
+        open(target, "w").writelines(["python -m pytest tests -m gpu -q  (one MI355X)\n"] + lines[-6:])
 if os.path.exists(os.path.join(src, "traffic.json")):
     shutil.copyfile(os.path.join(src, "traffic.json"), os.path.join(dst, "traffic.json"))
 print(sorted(f for f in os.listdir(dst) if f.startswith(tag)))
