@@ -131,6 +131,7 @@ namespace Pisces.Hip
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_set_forced_alleles(IntPtr handle, PiscesCandidate[] alleles_of, long n, byte[] alleles, long alleleBytes);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_set_exact_total_called(IntPtr handle, int on);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_set_known_variants(IntPtr handle, PiscesCandidate[] variants, long n, byte[] alleles, long alleleBytes);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_set_exclude_mnvs_from_collapsing(IntPtr handle, int on);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern long pisces_hip_find_indel_candidates(ref PiscesReadBatch batch, byte[] reference, long refLen, int minBaseCallQuality, [Out] PiscesCandidate[] cands, long capacity, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern long pisces_hip_find_candidates(ref PiscesReadBatch batch, byte[] reference, long refLen, int minBaseCallQuality, int snvsAndMnvs, int callMnvs, int maxMnvLength, int maxGapBetweenMnv, [Out] PiscesCandidate[] cands, long capacity, [Out] byte[] alleles, long alleleCapacity, out long alleleBytes);
         [StructLayout(LayoutKind.Sequential)]

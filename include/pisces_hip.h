@@ -404,6 +404,10 @@ int32_t pisces_hip_set_forced_alleles(PiscesHip* h, const PiscesCandidate* allel
  * records and adds their callable alleles — the reference's number, at the price of a second launch per flush (read store path only). */
 int32_t pisces_hip_set_exact_total_called(PiscesHip* h, int32_t on);
 int32_t pisces_hip_set_known_variants(PiscesHip* h, const PiscesCandidate* variants, int64_t n, const uint8_t* alleles, int64_t allele_bytes);
+/* PiscesApplicationOptions.ExcludeMNVsFromCollapsing (Options/PiscesApplicationOptions.cs:62; Factory.cs:204 hands it to VariantCollapser):
+ * on != 0: MNV candidates are left out of the collapser's targets (VariantCollapser.cs:33) — an open-ended MNV is not collapsed, and no
+ * open-ended SNV / MNV collapses INTO an MNV.  Off by default, as the option.  Any time before the flush that should see it. */
+int32_t pisces_hip_set_exclude_mnvs_from_collapsing(PiscesHip* h, int32_t on);
 /* totals lines: {allelesCalled (IAlleleCaller.TotalNumCalled), variantsCollapsed, readsProcessed, readsSkipped}
  * (SmallVariantCaller.cs:114-115; readsSkipped = AlignmentSource's count of the reads ShouldSkipRead dropped, AlignmentsSource.cs:63,84-92:
  * the reads pisces_hip_bam_decode dropped from the batches that pisces_hip_add_decoded_reads added; reads a host hands over through

@@ -1714,6 +1714,10 @@ typedef struct { const OrcCandidate* c; float freq; int idx; int known; } MatchR
 static const OrcCandidate* g_known = NULL;
 static int32_t g_known_n = 0;
 void orc_set_known_variants(const OrcCandidate* list, int32_t n) { g_known = list; g_known_n = n; }
+/* PiscesApplicationOptions.ExcludeMNVsFromCollapsing (Factory.cs:204 -> VariantCollapser's excludeMNVs, VariantCollapser.cs:33): what the
+ * schedule runs hand orc_collapse; 0 (the option's default) until set */
+static int32_t g_exclude_mnvs = 0;
+void orc_set_exclude_mnvs_from_collapsing(int32_t on) { g_exclude_mnvs = on != 0; }
 
 /* IComparer<CandidateAllele>.Compare :214-244 */
 static int match_cmp(const void* pa, const void* pb)
@@ -2353,7 +2357,7 @@ int64_t orc_call_range_up_to(OrcState* s, const uint8_t* ref_bases, int64_t ref_
     if (cfg->collapse) {   /* AlleleCaller.Call :50-58: candidates = _collapser.Collapse(batch.GetCandidates(), source, MaxClearedPosition) */
         OrcCandidate* back = from_other_blocks ? (OrcCandidate*)malloc(sizeof(OrcCandidate) * (size_t)(n > 0 ? n : 1)) : NULL;
         int32_t n_back = 0;
-        n = orc_collapse(list, (int32_t)n, s, cfg->collapse_freq_threshold, cfg->collapse_freq_ratio_threshold, 0, 1,
+        n = orc_collapse(list, (int32_t)n, s, cfg->collapse_freq_threshold, cfg->collapse_freq_ratio_threshold, g_exclude_mnvs, 1,
                          cfg->expect_stitched_reads, from_other_blocks ? last_position : -1, NULL, back, &n_back);
         for (int i = 0; i < n_back; i++) orc_add_candidate(s, &back[i]);   /* source.AddCandidates(notClearedVariants) :67-75 */
         free(back);

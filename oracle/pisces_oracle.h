@@ -147,6 +147,8 @@ int64_t orc_call_all(OrcState* s, const uint8_t* ref_bases, int64_t ref_len, con
  * returns the new count.  max_cleared_position < 0 = null. */
 /* the known (prior) variants the next orc_collapse / schedule run annotates with (VariantCollapser.cs:16-24, 178-190); n = 0 clears */
 void orc_set_known_variants(const OrcCandidate* list, int32_t n);
+/* ExcludeMNVsFromCollapsing for the schedule runs (VariantCollapser.cs:33; orc_collapse itself takes it as an argument) */
+void orc_set_exclude_mnvs_from_collapsing(int32_t on);
 int32_t orc_collapse(OrcCandidate* cands, int32_t n, const OrcState* src, float freq_threshold, float freq_ratio_threshold,
                      int32_t exclude_mnvs, int32_t consider_anchors, int32_t expect_stitched, int32_t max_cleared_position,
                      int32_t* n_collapsed, OrcCandidate* added_back, int32_t* n_added_back);

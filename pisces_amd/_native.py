@@ -22,7 +22,7 @@ EXPORTS = [
     "pisces_hip_balanced_tile_loci", "pisces_hip_bam_decode", "pisces_hip_bam_fetch", "pisces_hip_bam_chain_mode", "pisces_hip_add_decoded_reads", "pisces_hip_find_candidates_device", "pisces_hip_get_base_quality_sums", "pisces_hip_get_gapped_mnv_ref", "pisces_hip_comm_unique_id", "pisces_hip_comm_init", "pisces_hip_reduce_summary", "pisces_hip_comm_destroy",
     "pisces_hip_add_candidates", "pisces_hip_set_forced_alleles", "pisces_hip_host_time", "pisces_hip_set_owned_range", "pisces_hip_bam_fetch_directions", "pisces_hip_call_tiles_graph_build", "pisces_hip_call_tiles_graph_launch", "pisces_hip_mark", "pisces_hip_marked_ms",
     "pisces_hip_flush_end_ex", "pisces_hip_device_count", "pisces_hip_flush_view", "pisces_hip_flush_end_view", "pisces_hip_transfer_bytes",
-    "pisces_hip_add_device_reads", "pisces_hip_get_stream", "pisces_hip_comm_library", "pisces_hip_comm_ranks", "pisces_hip_set_known_variants", "pisces_hip_set_exact_total_called", "pisces_hip_reallocate_failed_mnvs", "pisces_hip_set_genotypes", "pisces_hip_diploid_genotype_qscore",
+    "pisces_hip_add_device_reads", "pisces_hip_get_stream", "pisces_hip_comm_library", "pisces_hip_comm_ranks", "pisces_hip_set_known_variants", "pisces_hip_set_exclude_mnvs_from_collapsing", "pisces_hip_set_exact_total_called", "pisces_hip_reallocate_failed_mnvs", "pisces_hip_set_genotypes", "pisces_hip_diploid_genotype_qscore",
 ]
 
 
@@ -100,6 +100,7 @@ def _load():
         "pisces_hip_add_candidates": (i32, [vp, vp, i64, vp, i64]),
         "pisces_hip_set_forced_alleles": (i32, [vp, vp, i64, vp, i64]),
         "pisces_hip_set_known_variants": (i32, [vp, vp, i64, vp, i64]),
+        "pisces_hip_set_exclude_mnvs_from_collapsing": (i32, [vp, i32]),
         "pisces_hip_set_exact_total_called": (i32, [vp, i32]),
         "pisces_hip_stats": (i32, [vp, P(i64)]),
         "pisces_hip_host_time": (i32, [vp, P(C.c_double), i32]),

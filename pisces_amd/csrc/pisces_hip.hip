@@ -343,6 +343,7 @@ struct PiscesHip {
     int32_t last_up_to_block_key = 0;
     std::unordered_map<int32_t, int32_t> gapped_mnv_ref;
     std::vector<HostCandidate> known_variants;   // the chromosome's known (prior) variants (pisces_hip_set_known_variants): the collapser's AnnotateKnown
+    bool exclude_mnvs_from_collapsing = false;   // PiscesApplicationOptions.ExcludeMNVsFromCollapsing (pisces_hip_set_exclude_mnvs_from_collapsing)
     // forced genotyping alleles of this chromosome (pisces_hip_set_forced_alleles), in position order; the first n_forced_added have
     // been handed to the state as candidates (SmallVariantCaller.AddForcedAlleleAsCandidate)
     std::vector<HostCandidate> forced;

@@ -724,20 +724,24 @@ void mnv_reallocate_failed(MnvArena& arena, const std::vector<CandPtr>& failed, 
 extern "C++" {
 template <typename FreqFn>
 static int64_t collapse_candidates(std::vector<HostCandidate>& cands, float freq_threshold, float freq_ratio_threshold, FreqFn freq,
-                                   const std::vector<HostCandidate>* known_variants = nullptr)
+                                   const std::vector<HostCandidate>* known_variants = nullptr, bool exclude_mnvs = false)
 {
     const size_t n = cands.size();
     std::vector<uint8_t> removed(n, 0);
+    // excludeMNVs (VariantCollapser.cs:33): MNV candidates are no targets — not annotated, not collapsed, nothing collapses into them
+    auto excluded = [&](size_t i) { return exclude_mnvs && cands[i].category == PISCES_CAT_MNV; };
     // AnnotateKnown (VariantCollapser.cs:178-190): a candidate that equals a known (prior) variant of the chromosome is known, and anchored on
     // both sides whatever its reads said
     std::vector<uint8_t> known(n, 0);
     if (known_variants && !known_variants->empty())
-        for (size_t i = 0; i < n; i++)
+        for (size_t i = 0; i < n; i++) {
+            if (excluded(i)) continue;
             for (const HostCandidate& k : *known_variants)
                 if (cand_equals(cands[i], k)) { known[i] = 1; cands[i].open_left = cands[i].open_right = false; break; }
+        }
     std::vector<size_t> order;
     for (size_t i = 0; i < n; i++)
-        if (cands[i].open_left || cands[i].open_right) order.push_back(i);
+        if (!excluded(i) && (cands[i].open_left || cands[i].open_right)) order.push_back(i);
     // OrderByDescending(Length).ThenByDescending(both open).ThenByDescending(either).ThenBy(ref).ThenBy(alt).ThenBy(Support)
     // .ThenBy(OpenOnRight).ThenBy(OpenOnLeft) :41-46
     std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) {
@@ -760,7 +764,7 @@ static int64_t collapse_candidates(std::vector<HostCandidate>& cands, float freq
         HostCandidate& t = cands[oi];
         rows.clear();
         for (size_t j = 0; j < n; j++)
-            if (j != oi && !removed[j] && can_collapse(t, cands[j])) rows.push_back({j, freq(cands[j])});
+            if (j != oi && !removed[j] && !excluded(j) && can_collapse(t, cands[j])) rows.push_back({j, freq(cands[j])});
         if (rows.empty()) continue;
         const float tf = freq(t);
         // IComparer.Compare :214-244; input order breaks the remaining ties
@@ -1368,7 +1372,7 @@ static int32_t call_spanning(PiscesHip* h, const std::vector<int32_t>& keys, int
             if (total == 0) return 0.0f;                       // CalledAllele.Frequency (CalledAllele.cs:49-52)
             const float f = (float)support / (float)total;
             return f < 1.0f ? f : 1.0f;
-        }, &h->known_variants);
+        }, &h->known_variants, h->exclude_mnvs_from_collapsing);
         // candidates past the last cleared position that could not be collapsed return to the state (VariantCollapser.cs:67-75): only the
         // ones AddCollapsableFromOtherBlocks brought in can lie there
         if (max_cleared >= 0) {

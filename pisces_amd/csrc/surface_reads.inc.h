@@ -346,6 +346,16 @@ int32_t pisces_hip_set_known_variants(PiscesHip* h, const PiscesCandidate* cands
     });
 }
 
+// PiscesApplicationOptions.ExcludeMNVsFromCollapsing (Options/PiscesApplicationOptions.cs:62 -> Factory.cs:204 -> VariantCollapser.cs:33)
+int32_t pisces_hip_set_exclude_mnvs_from_collapsing(PiscesHip* h, int32_t on)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    h->exclude_mnvs_from_collapsing = on != 0;
+    return PISCES_OK;
+    });
+}
+
 // SmallVariantCaller.AddForcedAlleleAsCandidate :118-132, before GetCandidatesToProcess(upTo)
 static void add_forced_as_candidates(PiscesHip* h, int32_t up_to_position)
 {

@@ -341,6 +341,10 @@ class HipVariantCaller:
         arr, pool, nb = self._candidate_arrays(list(variants))
         _check(self._h, lib.pisces_hip_set_known_variants(self._h, arr, len(variants), pool.ctypes.data, nb))
 
+    def SetExcludeMNVsFromCollapsing(self, on=True):
+        """PiscesApplicationOptions.ExcludeMNVsFromCollapsing (VariantCollapser.cs:33): MNV candidates are no targets of the collapser."""
+        _check(self._h, lib.pisces_hip_set_exclude_mnvs_from_collapsing(self._h, int(bool(on))))
+
     # ---- multi-GPU summary (one process per GPU): RCCL bound at run time by the library ----
     @staticmethod
     def comm_unique_id():

@@ -302,6 +302,12 @@ def set_known_variants(variants):
     return arr
 
 
+def set_exclude_mnvs_from_collapsing(on):
+    """orc_set_exclude_mnvs_from_collapsing: PiscesApplicationOptions.ExcludeMNVsFromCollapsing for the schedule runs."""
+    lib.orc_set_exclude_mnvs_from_collapsing.restype = None
+    lib.orc_set_exclude_mnvs_from_collapsing(C.c_int32(1 if on else 0))
+
+
 def collapse(state, cands, freq_threshold=0.0, freq_ratio_threshold=0.0, exclude_mnvs=False, consider_anchors=True, expect_stitched=False,
              max_cleared_position=None):
     """VariantCollapser.Collapse on a list of OrcCandidate; returns (collapsed list, TotalNumCollapsed, added back)."""

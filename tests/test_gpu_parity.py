@@ -1038,6 +1038,53 @@ def test_known_variants_steer_the_collapser_as_in_the_reference(torch_cuda):
     assert sup[True] == {long_allele: 30, short_allele: 20 + 24}      # ... or the known one
 
 
+def test_mnvs_can_be_left_out_of_the_collapser_as_in_the_reference(torch_cuda):
+    """PiscesApplicationOptions.ExcludeMNVsFromCollapsing (VariantCollapser.cs:33; VariantCollapserTests.cs:383-425 Collapse_IgnoreMNVs):
+    reads that carry a two-base MNV at P, P + 1, and reads that END on P with the MNV's first base — an SNV candidate that is open on the
+    right, which the collapser merges into the MNV (same position, the MNV's bases start with it) unless MNVs are left out of its
+    targets (pisces_hip_set_exclude_mnvs_from_collapsing; the oracle: orc_set_exclude_mnvs_from_collapsing).  Records, allele strings
+    and totals against the oracle, both ways."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(23)
+    ref = bytearray(rng.choice(list(b"ACGT"), 700).astype(np.uint8))
+    P = 300
+    ref[P - 1:P + 1] = b"AC"
+    ref = bytes(ref)
+    reads = []
+
+    def add(pos, seq, i):
+        reads.append({"pos": pos, "cigar": [("M", len(seq))], "seq": seq.decode(), "quals": [37] * len(seq), "reverse": bool(i % 2)})
+
+    for i in range(60):
+        add(P - 70, ref[P - 71: P + 79], i)
+    for i in range(30):            # the MNV AC > GT inside the read
+        add(P - 50, ref[P - 51: P - 1] + b"GT" + ref[P + 1: P + 70], i)
+    for i in range(20):            # reads that end on P with G: an SNV A > G that is open on the right
+        add(P - 80, ref[P - 81: P - 1] + b"G", i)
+    batch = _abi.ReadBatch(reads)
+    refa = np.frombuffer(ref, dtype=np.uint8)
+    cfg = _abi.default_config(call_mnvs=1, max_mnv_length=3, max_gap_between_mnv=1, collapse=1)
+    seen = {}
+    for exclude in (False, True):
+        orc.set_exclude_mnvs_from_collapsing(exclude)
+        try:
+            exp, exp_alleles, _, exp_called = orc.run_reads_full(batch, refa, 1, len(ref), cfg)
+        finally:
+            orc.set_exclude_mnvs_from_collapsing(False)
+        with engine.HipVariantCaller(cfg) as c:
+            c.SetReference(refa)
+            c.SetExcludeMNVsFromCollapsing(exclude)
+            c.AddAlleleCounts(batch)
+            got, got_alleles = c.CallWithAlleles()
+            stats = c.Stats()
+        assert_records_match(got, exp)
+        assert got_alleles == exp_alleles
+        assert stats["TotalNumCalled"] == exp_called
+        seen[exclude] = ({a: int(r["allele_support"]) for r, a in zip(got, got_alleles) if r["position"] == P and a != ("A", "A")}, stats["TotalNumCollapsed"])
+    assert seen[False] == ({("AC", "GT"): 30 + 20}, 1)                       # the open-ended SNV joins the MNV ...
+    assert seen[True] == ({("AC", "GT"): 30, ("A", "G"): 20}, 0)             # ... or stays a call of its own
+
+
 def test_streaming_mix_of_snvs_and_indels_across_blocks_matches_oracle(torch_cuda):
     """BASELINE config 3 / 4 in the small (without MNV calling): 12 000 loci x 120x in 80 amplicons over 13 blocks, sequencing errors,
     planted SNVs, and at ~every 1000th locus a deletion (1-10 bp) or an insertion (1-6 bp) in a third of the reads — some of them

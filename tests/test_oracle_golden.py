@@ -514,6 +514,29 @@ def test_variant_collapser_known_variants():
     del keep
 
 
+def test_variant_collapser_ignores_mnvs_when_asked():
+    """VariantCollapserTests.cs:383-425 (Collapse_IgnoreMNVs): with excludeMNVs the MNV AC>GT (open on the left, support 3047) stays as it
+    is and the SNV A>G that is open on both sides (30) joins the SNV A>G that is open on the left (16); without it
+    (Collapse_CandidateOrderIndependent :428-480) the one open on both sides joins the MNV (3077) and the other SNV keeps its 16.  On the
+    reference's mock allele source (every GetAlleleCount is 1, :948-949)."""
+    st = orc.State(1, 64)
+    for pos in range(1, 40):
+        for a in range(6):
+            for d in range(3):
+                for anchor in range(11):
+                    st.set_count(pos, a, d, anchor, 0)
+                st.set_count(pos, a, d, 5, 1)
+    mnv, snv = _CAT["Mnv"], _CAT["Snv"]
+    def cands():
+        return [orc.make_candidate(20, snv, "A", "G", support=(16, 0, 0), open_left=True),
+                orc.make_candidate(20, snv, "A", "G", support=(30, 0, 0), open_left=True, open_right=True),
+                orc.make_candidate(20, mnv, "AC", "GT", support=(3047, 0, 0), open_left=True)]
+    out, n, _ = orc.collapse(st, cands(), exclude_mnvs=True)
+    assert sorted((c.alt.decode(), sum(c.support_by_dir)) for c in out) == [("G", 16 + 30), ("GT", 3047)] and n == 1
+    out, n, _ = orc.collapse(st, cands(), exclude_mnvs=False)
+    assert sorted((c.alt.decode(), sum(c.support_by_dir)) for c in out) == [("G", 16), ("GT", 3047 + 30)] and n == 1
+
+
 # ---- end to end: the reference's own BAMs -> the VCF rows Pisces wrote for them -----------------------------------------------
 @pytest.mark.parametrize("name", ["bam_chr19", "bam_chr17_again", "bam_chr17_int", "bam_chr17_vcf", "bam_phix", "bam_edge_ins", "bam_edge_del", "bam_small_s1"])
 def test_reference_bams_give_the_vcf_rows_pisces_wrote(name):
