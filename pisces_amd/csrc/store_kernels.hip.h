@@ -657,29 +657,40 @@ __device__ __forceinline__ void wave_lower_bound2(const ReadDesc* __restrict__ d
     *hi_out = __builtin_amdgcn_readlane(a, 32);
 }
 
-// THE POSITION GRID of a segment: grid[c - grid_base] = index of the first fragment whose READ starts at or behind position 8 c — a
-// lower bound per cell of 8 positions, written when a batch joins (one lane a read: the cells between the read before it and itself get
-// the read's first fragment; cells behind the last read keep their fill value, which is above every index).  A tile's search then starts
-// from two entries instead of the whole segment: one round for the entries, one for the fragments of a cell (wave_lower_bound2_hinted),
-// where the 32-ary search over the whole segment takes four dependent rounds of ~1.1 us each.
-constexpr int kGridShift = 3;   // cells of 8 positions
+// THE POSITION GRID of a segment: grid[p - grid_base] = index of the first fragment whose READ starts at or behind position p, written
+// when a batch joins (one lane a read: the positions behind the read before it up to its own get the read's first fragment; positions
+// behind the last read keep their fill value, which is above every index).  A tile's fragment range is then two entries of it — one
+// round of two loads (wave_lower_bound2_hinted) where the 32-ary search over the whole segment takes four dependent rounds of ~1.1 us
+// each.  (Cells of 8 positions with a probe round over the fragments of a cell, the first form, cost a second round and, where hundreds
+// of reads start on one position — the first base of an amplicon —, a third: 7.6 us at the 90th percentile of tiles against 3.7.)
+constexpr int kGridShift = 0;   // positions a cell (1 << kGridShift): one — the entry IS the bound, no probe round behind it
 constexpr int kGridBadBit = 4;       // state[kStateFrags]
+constexpr int kGridGapCells = 65536; // the widest gap between two reads that is filled (a wave's work: 64 cells a store)
 __global__ __launch_bounds__(256) void grid_fill_kernel(const ReadDesc* __restrict__ desc, const ReadExt* __restrict__ ext, int32_t n0, int32_t nr,
                                                         int32_t* __restrict__ grid, int32_t grid_base, int32_t grid_n, int32_t* __restrict__ state)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nr) return;
-    const int i = n0 + r;
-    const long long p = desc[i].pos0;
-    const long long prev = i > 0 ? (long long)desc[i - 1].pos0 : ((long long)grid_base << kGridShift) - 1;
-    if (p <= prev) return;   // (the same position as the read before it; or out of order: the segment is then scanned, not searched)
-    const long long c0 = ((prev + (1ll << kGridShift)) >> kGridShift), c1 = p >> kGridShift;   // cells c with prev < (c << kGridShift) <= p (prev >= -1)
-    // a gap one lane should not fill (sparse reads: the segment goes without a grid); or outside the span the host sized the grid over (never expected)
-    if (c1 - c0 > 4096 || c1 - grid_base >= grid_n || c0 < grid_base) { atomicOr(&state[kStateFrags], kGridBadBit); return; }
-    const int f0 = (int)ext[i].cig_off;
-    for (long long c = c0; c <= c1; c++) {
-        const long long k = c - grid_base;
-        if (k >= 0 && k < grid_n) grid[k] = f0;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    int c0 = 0, c1 = -1, f0 = 0;   // this lane's read fills cells c0 .. c1 with f0 (none when the read starts where the one before it does)
+    if (r < nr) {
+        const int i = n0 + r;
+        const long long p = desc[i].pos0;
+        const long long prev = i > 0 ? (long long)desc[i - 1].pos0 : ((long long)grid_base << kGridShift) - 1;
+        if (p > prev) {   // (else: the same position as the read before it; or out of order: the segment is then scanned, not searched)
+            const long long a = ((prev + (1ll << kGridShift)) >> kGridShift), b = p >> kGridShift;   // cells c with prev < (c << kGridShift) <= p (prev >= -1)
+            // a gap wider than the grid is meant for (sparse reads: the segment goes without); or outside the span the host sized the grid
+            // over (never expected)
+            if (b - a > kGridGapCells || b - grid_base >= grid_n || a < grid_base) atomicOr(&state[kStateFrags], kGridBadBit);
+            else { c0 = (int)(a - grid_base); c1 = (int)(b - grid_base); f0 = (int)ext[i].cig_off; }
+        }
+    }
+    // a few cells: the lane's own stores; a gap (the positions between two amplicons: a thousand cells) is the whole wave's, 64 cells a store
+    const bool wide = c1 - c0 >= 16;
+    if (!wide)
+        for (int k = c0; k <= c1; k++) grid[k] = f0;
+    for (unsigned long long m = __ballot(wide); m != 0ull; m &= m - 1ull) {
+        const int src = __builtin_ctzll(m);
+        const int b0 = __builtin_amdgcn_readlane(c0, src), b1 = __builtin_amdgcn_readlane(c1, src), f = __builtin_amdgcn_readlane(f0, src);
+        for (int k = b0 + lane; k <= b1; k += 64) grid[k] = f;
     }
 }
 
@@ -711,8 +722,8 @@ __device__ __forceinline__ void hinted_round(const ReadDesc* __restrict__ desc, 
 }
 
 // Both ends of a tile's fragment range from the position grid: lanes 0-31 the low end, 32-63 the high end.  The bound for position x lies
-// between the entries of x's cell and of the next one; that window (the fragments of reads that start inside one cell: ~26 at 500x) is
-// narrowed with as many probes a lane as it takes to finish in one round (1, 2, 4 or 8: up to 256 fragments), more rounds behind that.
+// between the entries of x's cell and of the next one — with a cell a position (kGridShift 0) the entry itself; with wider cells that
+// window is narrowed with as many probes a lane as it takes to finish in one round (1, 2, 4 or 8: up to 256 fragments), more rounds behind that.
 __device__ __forceinline__ void wave_lower_bound2_hinted(const ReadDesc* __restrict__ desc, int n, int x_lo, int x_hi, int lane, const int32_t* __restrict__ grid,
                                                          int grid_base, int grid_n, int* lo_out, int* hi_out)
 {
@@ -724,8 +735,11 @@ __device__ __forceinline__ void wave_lower_bound2_hinted(const ReadDesc* __restr
     else if (k >= grid_n) { a = n; b = n; }            // behind every cell a read starts in
     else {
         a = min(grid[k], n);
-        b = k + 1 < grid_n ? min(grid[k + 1], n) : n;
-        b = max(b, a);
+        if (kGridShift == 0) b = a;                    // (a cell a position: the first fragment whose read starts at or behind x is the answer)
+        else {
+            b = k + 1 < grid_n ? min(grid[k + 1], n) : n;
+            b = max(b, a);
+        }
     }
     bool more = b > a;
     while (__ballot(more) != 0ull) {

@@ -322,8 +322,8 @@ static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const Sto
             const int64_t c_lo = (int64_t)min_position >> kGridShift;
             const int64_t c_hi = (std::min<int64_t>(((int64_t)max_key + 2) * h->cfg.block_size, 0x7FFFFFFFll) >> kGridShift) + 2;   // (past the last block a read of the batch touches)
             if (first) { base = c_lo; cells = 0; }
-            // worth it for dense reads only: at most four cells a CIGAR operation held (500x of 150-base reads: one cell per ~26)
-            if (c_lo < base || c_hi - base + 1 > std::max<int64_t>(1ll << 16, 4 * (g.n_ops + (int64_t)n_cig))) ok = false;
+            // worth it for dense reads only: at most sixteen cells a CIGAR operation held (500x of 150-base reads: a cell per ~3.3; 10x: one per 0.07)
+            if (c_lo < base || c_hi - base + 1 > std::max<int64_t>(1ll << 18, 16 * (g.n_ops + (int64_t)n_cig))) ok = false;
             else if (c_hi - base + 1 > cells) {
                 const int64_t want = c_hi - base + 1;
                 PISCES_HIP_CHECK(h, g.grid.grow_keep((size_t)want, (size_t)cells, h->stream));

@@ -220,18 +220,18 @@ def test_any_cigar_through_the_fused_kernel_equals_the_log_chain(torch_cuda, mod
     assert (got["position"] > 70000).any()        # the far ends of the skipping reads were called
 
 
-@pytest.mark.parametrize("shape", ["clusters 20 000 apart", "clusters 50 000 apart", "second batch before the first", "a pile on one position",
+@pytest.mark.parametrize("shape", ["clusters 8 000 apart", "clusters 20 000 apart", "clusters 70 000 apart", "second batch before the first", "a pile on one position",
                                    "a pile, then a tail"])
 @pytest.mark.parametrize("mode", ["default", "every batch appended to the open segment"])
 def test_the_position_grid_finds_what_the_search_over_the_whole_segment_finds(torch_cuda, mode, shape):
     """A tile's fragment range starts from the segment's position grid (grid_fill_kernel, wave_lower_bound2_hinted) where the segment
-    has one: records equal the log chain's when the reads lie in clusters with empty cells between them, when the gap between two
+    has one: records equal the log chain's when the reads lie in clusters with empty positions between them, when the gap between two
     reads is wider than one lane fills (the segment then goes without a grid), when a later batch starts before the grid's first cell,
     and when thousands of fragments share one cell (more than one narrowing round)."""
     rng = np.random.default_rng(31)
-    ref = np.frombuffer(bytes(rng.choice(list(b"ACGT"), 120_000).astype(np.uint8)), dtype=np.uint8)
+    ref = np.frombuffer(bytes(rng.choice(list(b"ACGT"), 160_000).astype(np.uint8)), dtype=np.uint8)
     if shape.startswith("clusters"):
-        step = 20_000 if "20 000" in shape else 50_000
+        step = int(shape.split()[1] + shape.split()[2])   # (8 000 and 20 000: a wave fills the gap; 70 000: wider than kGridGapCells, the segment goes without a grid)
         reads = []
         for k in range(3):
             reads += random_reads(rng, 500, 1000 + k * step, 1400 + k * step, with_dirs=False)
