@@ -85,7 +85,7 @@ struct SegmentView {
     int32_t floor;
     int32_t n_frags, n_floored_frags;   // the same for the fragments
     int32_t grid_n;               // cells of `grid` (0: none)
-    const int32_t* grid;          // grid[c - grid_base] = first fragment whose read starts at or behind position c << kGridShift (grid_fill_kernel), or nullptr
+    const int32_t* grid;          // grid[c - grid_base] = first fragment whose read starts at or behind position c (grid_fill_kernel), or nullptr
     int32_t grid_base, pad2;
 };
 struct StoreView {
@@ -663,7 +663,6 @@ __device__ __forceinline__ void wave_lower_bound2(const ReadDesc* __restrict__ d
 // round of two loads (wave_lower_bound2_hinted) where the 32-ary search over the whole segment takes four dependent rounds of ~1.1 us
 // each.  (Cells of 8 positions with a probe round over the fragments of a cell, the first form, cost a second round and, where hundreds
 // of reads start on one position — the first base of an amplicon —, a third: 7.6 us at the 90th percentile of tiles against 3.7.)
-constexpr int kGridShift = 0;   // positions a cell (1 << kGridShift): one — the entry IS the bound, no probe round behind it
 constexpr int kGridBadBit = 4;       // state[kStateFrags]
 constexpr int kGridGapCells = 65536; // the widest gap between two reads that is filled (a wave's work: 64 cells a store)
 __global__ __launch_bounds__(256) void grid_fill_kernel(const ReadDesc* __restrict__ desc, const ReadExt* __restrict__ ext, int32_t n0, int32_t nr,
@@ -674,9 +673,9 @@ __global__ __launch_bounds__(256) void grid_fill_kernel(const ReadDesc* __restri
     if (r < nr) {
         const int i = n0 + r;
         const long long p = desc[i].pos0;
-        const long long prev = i > 0 ? (long long)desc[i - 1].pos0 : ((long long)grid_base << kGridShift) - 1;
+        const long long prev = i > 0 ? (long long)desc[i - 1].pos0 : (long long)grid_base - 1;
         if (p > prev) {   // (else: the same position as the read before it; or out of order: the segment is then scanned, not searched)
-            const long long a = ((prev + (1ll << kGridShift)) >> kGridShift), b = p >> kGridShift;   // cells c with prev < (c << kGridShift) <= p (prev >= -1)
+            const long long a = prev + 1, b = p;   // the positions behind the read before it, up to its own
             // a gap wider than the grid is meant for (sparse reads: the segment goes without); or outside the span the host sized the grid
             // over (never expected)
             if (b - a > kGridGapCells || b - grid_base >= grid_n || a < grid_base) atomicOr(&state[kStateFrags], kGridBadBit);
@@ -694,62 +693,15 @@ __global__ __launch_bounds__(256) void grid_fill_kernel(const ReadDesc* __restri
     }
 }
 
-// One narrowing round of the hinted search with PER probes a lane (32 PER a half): the window [a, b] of the lane's half shrinks to one
-// step of it.  All of a lane's loads are issued before the first is used: one round trip.
-template <int PER>
-__device__ __forceinline__ void hinted_round(const ReadDesc* __restrict__ desc, int x, int half, int sub, bool more, int& a, int& b)
+// Both ends of a tile's fragment range from the position grid: the entry of x_lo and the entry of x_hi (lane 0 loads one, lane 32 the
+// other: one round trip).  A position before the grid's first is before every read (0), one behind its last behind every read (n).
+__device__ __forceinline__ void wave_lower_bound2_hinted(int n, int x_lo, int x_hi, int lane, const int32_t* __restrict__ grid, int grid_base, int grid_n,
+                                                         int* lo_out, int* hi_out)
 {
-    const int step = max((b - a + 32 * PER - 1) / (32 * PER), 1);
-    long long idx[PER];
-    int v[PER];
-#pragma unroll
-    for (int u = 0; u < PER; u++) {
-        idx[u] = (long long)a + (long long)(32 * u + sub + 1) * step - 1;
-        v[u] = (more && idx[u] < b) ? desc[idx[u]].pos0 : 0x7FFFFFFF;
-    }
-    int c = 0;
-#pragma unroll
-    for (int u = 0; u < PER; u++) {
-        const unsigned long long below = __ballot(more && idx[u] < b && v[u] < x);
-        c += __popc((unsigned int)(half ? (below >> 32) : (below & 0xFFFFFFFFull)));
-    }
-    const long long na = (long long)a + (long long)c * step;
-    const long long nb = na + step - 1;
-    if (more) {
-        a = (int)min(na, (long long)b);
-        b = (int)max(min(nb, (long long)b), (long long)a);
-    }
-}
-
-// Both ends of a tile's fragment range from the position grid: lanes 0-31 the low end, 32-63 the high end.  The bound for position x lies
-// between the entries of x's cell and of the next one — with a cell a position (kGridShift 0) the entry itself; with wider cells that
-// window is narrowed with as many probes a lane as it takes to finish in one round (1, 2, 4 or 8: up to 256 fragments), more rounds behind that.
-__device__ __forceinline__ void wave_lower_bound2_hinted(const ReadDesc* __restrict__ desc, int n, int x_lo, int x_hi, int lane, const int32_t* __restrict__ grid,
-                                                         int grid_base, int grid_n, int* lo_out, int* hi_out)
-{
-    const int half = lane >> 5, sub = lane & 31;
-    const int x = half ? x_hi : x_lo;
-    const long long k = ((long long)max(x, 0) >> kGridShift) - grid_base;
-    int a, b;
-    if (k < 0) { a = 0; b = 0; }                       // before the segment's first read
-    else if (k >= grid_n) { a = n; b = n; }            // behind every cell a read starts in
-    else {
-        a = min(grid[k], n);
-        if (kGridShift == 0) b = a;                    // (a cell a position: the first fragment whose read starts at or behind x is the answer)
-        else {
-            b = k + 1 < grid_n ? min(grid[k + 1], n) : n;
-            b = max(b, a);
-        }
-    }
-    bool more = b > a;
-    while (__ballot(more) != 0ull) {
-        const int w = max(__builtin_amdgcn_readlane(b - a, 0), __builtin_amdgcn_readlane(b - a, 32));
-        if (w <= 32) hinted_round<1>(desc, x, half, sub, more, a, b);
-        else if (w <= 64) hinted_round<2>(desc, x, half, sub, more, a, b);
-        else if (w <= 128) hinted_round<4>(desc, x, half, sub, more, a, b);
-        else hinted_round<8>(desc, x, half, sub, more, a, b);
-        more = b > a;
-    }
+    const int x = lane >> 5 ? x_hi : x_lo;
+    const long long k = (long long)max(x, 0) - grid_base;
+    int a = k < 0 ? 0 : n;
+    if (k >= 0 && k < grid_n) a = min(grid[k], n);
     *lo_out = __builtin_amdgcn_readlane(a, 0);
     *hi_out = __builtin_amdgcn_readlane(a, 32);
 }
@@ -1014,7 +966,7 @@ __device__ __forceinline__ void walk_segment_fast(const SegmentView& G, int tile
     const int x_lo = (int)max((long long)tile_start - reach + 1, -0x7FFFFFFFll), x_hi = tile_end == 0x7FFFFFFF ? 0x7FFFFFFF : tile_end + 1;
     int lo = 0, hi = G.n_frags;
     if (sorted) {
-        if (G.grid && !(G.state[kStateFrags] & kGridBadBit)) wave_lower_bound2_hinted(G.frag, G.n_frags, x_lo, x_hi, lane, G.grid, G.grid_base, G.grid_n, &lo, &hi);
+        if (G.grid && !(G.state[kStateFrags] & kGridBadBit)) wave_lower_bound2_hinted(G.n_frags, x_lo, x_hi, lane, G.grid, G.grid_base, G.grid_n, &lo, &hi);
         else wave_lower_bound2(G.frag, G.n_frags, x_lo, x_hi, lane, &lo, &hi);
     }
 #ifdef PISCES_STORE_TIMING

@@ -319,8 +319,8 @@ static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const Sto
         bool ok = min_position > 0 && (first || g.grid_ok);
         int64_t base = g.grid_base, cells = g.grid_n;
         if (ok) {
-            const int64_t c_lo = (int64_t)min_position >> kGridShift;
-            const int64_t c_hi = (std::min<int64_t>(((int64_t)max_key + 2) * h->cfg.block_size, 0x7FFFFFFFll) >> kGridShift) + 2;   // (past the last block a read of the batch touches)
+            const int64_t c_lo = (int64_t)min_position;
+            const int64_t c_hi = std::min<int64_t>(((int64_t)max_key + 2) * h->cfg.block_size + 2, 0x7FFFFFFFll);   // (past the last block a read of the batch touches)
             if (first) { base = c_lo; cells = 0; }
             // worth it for dense reads only: at most sixteen cells a CIGAR operation held (500x of 150-base reads: a cell per ~3.3; 10x: one per 0.07)
             if (c_lo < base || c_hi - base + 1 > std::max<int64_t>(1ll << 18, 16 * (g.n_ops + (int64_t)n_cig))) ok = false;
