@@ -259,7 +259,7 @@ struct ReadSegment {
     DeviceBuf<ReadDesc> desc;
     DeviceBuf<ReadExt> ext;
     DeviceBuf<ReadDesc> frag;    // one per CIGAR operation: what the flush kernel walks
-    DeviceBuf<int32_t> grid;     // the position grid (store_kernels.hip.h grid_fill_kernel): first fragment per position (cell) from cell grid_base on
+    DeviceBuf<int32_t> grid;     // the position grid (store_kernels.hip.h grid_cells): first fragment per position (cell) from cell grid_base on
     int64_t grid_base = 0, grid_n = 0;
     bool grid_ok = false;        // every batch so far could extend it (known first position, not before grid_base, a sane span)
     int32_t* state = nullptr;    // its four state words on the device (a slot of PiscesHip::state_pool, zero when handed out)

@@ -85,7 +85,7 @@ struct SegmentView {
     int32_t floor;
     int32_t n_frags, n_floored_frags;   // the same for the fragments
     int32_t grid_n;               // cells of `grid` (0: none)
-    const int32_t* grid;          // grid[c - grid_base] = first fragment whose read starts at or behind position c (grid_fill_kernel), or nullptr
+    const int32_t* grid;          // grid[c - grid_base] = first fragment whose read starts at or behind position c (grid_cells), or nullptr
     int32_t grid_base, pad2;
 };
 struct StoreView {
@@ -112,13 +112,16 @@ struct ShapeArgs {
     const uint8_t* dirs;
     int32_t min_bq;
     int32_t* state;
-    // the second role of the launch (workgroups [shape_blocks, gridDim.x)): the row codes of the batch's bases
+    // the second role of the launch (workgroups [shape_blocks, shape_blocks + enc_blocks)): the row codes of the batch's bases
     const uint8_t* enc_bases;
     const uint8_t* enc_quals;
     uint8_t* enc_codes;
     int64_t enc_n;
     uint32_t enc_min_bq;   // <= 127
-    int32_t shape_blocks;
+    int32_t shape_blocks, enc_blocks;
+    // the third role (the workgroups behind those, one lane a read; none when grid is nullptr): the segment's position grid
+    int32_t* grid;
+    int32_t grid_base, grid_n;
 };
 
 // ROW CODES.  What the flush kernel needs of a base is the row of the LDS histogram it counts in: low-quality << 5 | AlleleType << 2
@@ -158,10 +161,48 @@ __device__ __forceinline__ void encode_rows(const ShapeArgs& A, int block, int n
     }
 }
 
+// THE POSITION GRID of a segment: grid[p - grid_base] = index of the first fragment whose READ starts at or behind position p, written
+// when a batch joins (grid_cells, one lane a read: the positions behind the read before it up to its own get the read's first fragment; positions
+// behind the last read keep their fill value, which is above every index).  A tile's fragment range is then two entries of it — one
+// round of two loads (wave_lower_bound2_hinted) where the 32-ary search over the whole segment takes four dependent rounds of ~1.1 us
+// each.  (Cells of 8 positions with a probe round over the fragments of a cell, the first form, cost a second round and, where hundreds
+// of reads start on one position — the first base of an amplicon —, a third: 7.6 us at the 90th percentile of tiles against 3.7.)
+constexpr int kGridBadBit = 4;       // state[kStateFrags]
+constexpr int kGridGapCells = 65536; // the widest gap between two reads that is filled (a wave's work: 64 cells a store)
+// (the third role of read_shape_kernel's launch: the workgroups behind the row codes'; it reads the batch's own arrays — a read's first
+// fragment is its first CIGAR operation — and, for the read before the batch's first, the descriptor an earlier launch wrote)
+__device__ __forceinline__ void grid_cells(const ShapeArgs& A, int block)
+{
+    const int r = block * 256 + (int)threadIdx.x, lane = threadIdx.x & 63;
+    int c0 = 0, c1 = -1, f0 = 0;   // this lane's read fills cells c0 .. c1 with f0 (none when the read starts where the one before it does)
+    if (r < A.n_reads) {
+        const long long p = A.position[r];
+        const long long prev = r > 0 ? (long long)A.position[r - 1] : A.n0 > 0 ? (long long)A.desc[A.n0 - 1].pos0 : (long long)A.grid_base - 1;
+        if (p > prev) {   // (else: the same position as the read before it; or out of order: the segment is then scanned, not searched)
+            const long long a = prev + 1, b = p;   // the positions behind the read before it, up to its own
+            // a gap wider than the grid is meant for (sparse reads: the segment goes without); or outside the span the host sized the grid
+            // over (never expected)
+            if (b - a > kGridGapCells || b - A.grid_base >= A.grid_n || a < A.grid_base) atomicOr(&A.state[kStateFrags], kGridBadBit);
+            else { c0 = (int)(a - A.grid_base); c1 = (int)(b - A.grid_base); f0 = (int)(A.ops0 + A.cigar_offset[r]); }
+        }
+    }
+    // a few cells: the lane's own stores; a gap (the positions between two amplicons: a thousand cells) is the whole wave's, 64 cells a store
+    const bool wide = c1 - c0 >= 16;
+    if (!wide)
+        for (int k = c0; k <= c1; k++) A.grid[k] = f0;
+    for (unsigned long long m = __ballot(wide); m != 0ull; m &= m - 1ull) {
+        const int src = __builtin_ctzll(m);
+        const int b0 = __builtin_amdgcn_readlane(c0, src), b1 = __builtin_amdgcn_readlane(c1, src), f = __builtin_amdgcn_readlane(f0, src);
+        for (int k = b0 + lane; k <= b1; k += 64) A.grid[k] = f;
+    }
+}
+
 __global__ __launch_bounds__(256) void read_shape_kernel(ShapeArgs A)
 {
     if ((int)blockIdx.x >= A.shape_blocks) {
-        encode_rows(A, (int)blockIdx.x - A.shape_blocks, (int)gridDim.x - A.shape_blocks);
+        const int b = (int)blockIdx.x - A.shape_blocks;
+        if (b < A.enc_blocks) encode_rows(A, b, A.enc_blocks);
+        else grid_cells(A, b - A.enc_blocks);
         return;
     }
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -655,42 +696,6 @@ __device__ __forceinline__ void wave_lower_bound2(const ReadDesc* __restrict__ d
     }
     *lo_out = __builtin_amdgcn_readlane(a, 0);
     *hi_out = __builtin_amdgcn_readlane(a, 32);
-}
-
-// THE POSITION GRID of a segment: grid[p - grid_base] = index of the first fragment whose READ starts at or behind position p, written
-// when a batch joins (one lane a read: the positions behind the read before it up to its own get the read's first fragment; positions
-// behind the last read keep their fill value, which is above every index).  A tile's fragment range is then two entries of it — one
-// round of two loads (wave_lower_bound2_hinted) where the 32-ary search over the whole segment takes four dependent rounds of ~1.1 us
-// each.  (Cells of 8 positions with a probe round over the fragments of a cell, the first form, cost a second round and, where hundreds
-// of reads start on one position — the first base of an amplicon —, a third: 7.6 us at the 90th percentile of tiles against 3.7.)
-constexpr int kGridBadBit = 4;       // state[kStateFrags]
-constexpr int kGridGapCells = 65536; // the widest gap between two reads that is filled (a wave's work: 64 cells a store)
-__global__ __launch_bounds__(256) void grid_fill_kernel(const ReadDesc* __restrict__ desc, const ReadExt* __restrict__ ext, int32_t n0, int32_t nr,
-                                                        int32_t* __restrict__ grid, int32_t grid_base, int32_t grid_n, int32_t* __restrict__ state)
-{
-    const int r = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
-    int c0 = 0, c1 = -1, f0 = 0;   // this lane's read fills cells c0 .. c1 with f0 (none when the read starts where the one before it does)
-    if (r < nr) {
-        const int i = n0 + r;
-        const long long p = desc[i].pos0;
-        const long long prev = i > 0 ? (long long)desc[i - 1].pos0 : (long long)grid_base - 1;
-        if (p > prev) {   // (else: the same position as the read before it; or out of order: the segment is then scanned, not searched)
-            const long long a = prev + 1, b = p;   // the positions behind the read before it, up to its own
-            // a gap wider than the grid is meant for (sparse reads: the segment goes without); or outside the span the host sized the grid
-            // over (never expected)
-            if (b - a > kGridGapCells || b - grid_base >= grid_n || a < grid_base) atomicOr(&state[kStateFrags], kGridBadBit);
-            else { c0 = (int)(a - grid_base); c1 = (int)(b - grid_base); f0 = (int)ext[i].cig_off; }
-        }
-    }
-    // a few cells: the lane's own stores; a gap (the positions between two amplicons: a thousand cells) is the whole wave's, 64 cells a store
-    const bool wide = c1 - c0 >= 16;
-    if (!wide)
-        for (int k = c0; k <= c1; k++) grid[k] = f0;
-    for (unsigned long long m = __ballot(wide); m != 0ull; m &= m - 1ull) {
-        const int src = __builtin_ctzll(m);
-        const int b0 = __builtin_amdgcn_readlane(c0, src), b1 = __builtin_amdgcn_readlane(c1, src), f = __builtin_amdgcn_readlane(f0, src);
-        for (int k = b0 + lane; k <= b1; k += 64) grid[k] = f;
-    }
 }
 
 // Both ends of a tile's fragment range from the position grid: the entry of x_lo and the entry of x_hi (lane 0 loads one, lane 32 the

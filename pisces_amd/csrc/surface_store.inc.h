@@ -312,9 +312,10 @@ static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const Sto
     S.enc_n = (int64_t)n_seq;
     S.enc_min_bq = (uint32_t)std::min(std::max(h->cfg.min_base_call_quality, 0), 127);
     S.shape_blocks = (nr + 255) / 256;
-    const unsigned enc_blocks = (unsigned)std::min<int64_t>(((int64_t)n_seq + 16 * 256 - 1) / (16 * 256), 8192);
-    hipLaunchKernelGGL(read_shape_kernel, dim3((unsigned)S.shape_blocks + enc_blocks), dim3(256), 0, h->stream, S);
-    {   // the position grid (what a tile's search starts from): extended over the batch's span, or given up for this segment
+    S.enc_blocks = (int32_t)std::min<int64_t>(((int64_t)n_seq + 16 * 256 - 1) / (16 * 256), 8192);
+    S.grid = nullptr;
+    S.grid_base = S.grid_n = 0;
+    {   // the position grid (what gives a tile its fragment range): extended over the batch's span, or given up for this segment
         const bool first = g.n_reads == 0;
         bool ok = min_position > 0 && (first || g.grid_ok);
         int64_t base = g.grid_base, cells = g.grid_n;
@@ -334,10 +335,10 @@ static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const Sto
         g.grid_ok = ok;
         g.grid_base = ok ? base : 0;
         g.grid_n = ok ? cells : 0;
-        if (ok)
-            hipLaunchKernelGGL(grid_fill_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, h->stream, (const ReadDesc*)g.desc.p, (const ReadExt*)g.ext.p, S.n0, nr,
-                               g.grid.p, (int32_t)base, (int32_t)cells, g.state);
+        if (ok) { S.grid = g.grid.p; S.grid_base = (int32_t)base; S.grid_n = (int32_t)cells; }
     }
+    const unsigned grid_blocks = S.grid ? (unsigned)S.shape_blocks : 0u;
+    hipLaunchKernelGGL(read_shape_kernel, dim3((unsigned)S.shape_blocks + (unsigned)S.enc_blocks + grid_blocks), dim3(256), 0, h->stream, S);
     if (!pl.direct && !A.dirs && g.v_dirs)   // a batch without directions in a segment that tracks them
         hipLaunchKernelGGL(segment_fill_dirs_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, h->stream, (const ReadDesc*)g.desc.p,
                            (const ReadExt*)g.ext.p, S.n0, S.n0 + nr, const_cast<uint8_t*>(g.v_dirs));

@@ -224,7 +224,7 @@ def test_any_cigar_through_the_fused_kernel_equals_the_log_chain(torch_cuda, mod
                                    "a pile, then a tail"])
 @pytest.mark.parametrize("mode", ["default", "every batch appended to the open segment"])
 def test_the_position_grid_finds_what_the_search_over_the_whole_segment_finds(torch_cuda, mode, shape):
-    """A tile's fragment range starts from the segment's position grid (grid_fill_kernel, wave_lower_bound2_hinted) where the segment
+    """A tile's fragment range starts from the segment's position grid (grid_cells in read_shape_kernel's launch, wave_lower_bound2_hinted) where the segment
     has one: records equal the log chain's when the reads lie in clusters with empty positions between them, when the gap between two
     reads is wider than one lane fills (the segment then goes without a grid), when a later batch starts before the grid's first cell,
     and when thousands of fragments share one cell (more than one narrowing round)."""
