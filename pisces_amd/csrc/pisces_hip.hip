@@ -544,6 +544,9 @@ struct PiscesHip {
     std::vector<hipGraphExec_t> graphs;       // pisces_hip_call_tiles_graph_build
     std::vector<hipGraph_t> graph_defs;
     int store_waves = 0;                      // development: waves per tile of call_store_tiles_kernel (PISCES_HIP_STORE_WAVES; 0 = by launch size)
+    int tile_order = 2;                       // which tile a workgroup of call_store_tiles_kernel takes in a launch of several tiles a CU (PISCES_HIP_TILE_ORDER): 2 tiles
+                                              // traded by price inside small groups (exchanged_tile), 1 tile_order_kernel's order (a launch in front), 0 position order
+    DeviceBuf<int32_t> d_tile_order;
     int finder_wave = 0;                      // PISCES_HIP_FINDER: the default is a lane a read, events first; =bases: a lane a read, base by base (round 3's);
                                               // =wave / =batch: a wave for one / for 64 reads (finder_kernels.hip.h; measured slower)
     DeviceBuf<long long> d_scan_sums;         // block sums of launch_found_scan
@@ -875,6 +878,7 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         if (rp && std::string(rp) == "log") h->read_path = 0;
         if (const char* v = getenv("PISCES_HIP_STORE_DIRECT_BYTES")) h->store_direct_bytes = (size_t)std::max(0ll, atoll(v));
         if (const char* v = getenv("PISCES_HIP_STORE_WAVES")) h->store_waves = atoi(v);
+        if (const char* v = getenv("PISCES_HIP_TILE_ORDER")) h->tile_order = atoi(v);
         if (const char* v = getenv("PISCES_HIP_DEVICE_MERGE")) h->device_merge = atoi(v) != 0 ? 1 : 0;   // the A/B of tests/test_read_store.py
         // MNV calling on: the split form, unless the candidate records are asked to come back unmerged (PISCES_HIP_DEVICE_MERGE=0: the
         // earlier form, every candidate an object on the host, the tile kernels Reference records only) or PISCES_HIP_MNV_SPLIT=0
@@ -1038,7 +1042,7 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     }
     h->d_summary.release();
     h->d_ref.release(); h->d_tuples.release(); h->d_tiles.release(); h->d_tile_results.release();
-    h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release(); h->d_totals.release(); h->d_qlut.release(); h->d_bq_lut.release(); h->d_sumq_fix.release(); h->d_sumq.release(); h->d_gq_tail.release(); h->d_vq_tab.release(); h->d_sb_tab.release(); h->d_sb0_tab.release(); h->d_gq_cap.release(); h->d_params.release(); h->d_offsets.release(); h->d_compact.release();
+    h->d_records.release(); h->d_counts.release(); h->d_gapped.release(); h->d_count.release(); h->d_totals.release(); h->d_qlut.release(); h->d_bq_lut.release(); h->d_sumq_fix.release(); h->d_sumq.release(); h->d_gq_tail.release(); h->d_vq_tab.release(); h->d_sb_tab.release(); h->d_sb0_tab.release(); h->d_gq_cap.release(); h->d_params.release(); h->d_offsets.release(); h->d_compact.release(); h->d_tile_order.release();
     for (int i = 0; i < 2; i++) { h->d_log_pos[i].release(); h->d_log_tup[i].release(); }
     h->d_log_n.release(); h->d_flags.release(); h->d_bucket.release(); h->d_total.release();
     for (auto& st : h->stage) {

@@ -962,15 +962,17 @@ constexpr int kPairSlots = 128 + 32;   // a block's pairs (<= 64 left + 64 right
 template <bool kDirs, typename OnObs>
 __device__ __forceinline__ void walk_segment_fast(const SegmentView& G, int tile_start, uint32_t min_bq, int lane, int wid, int n_waves, char* hbytes,
                                                   const unsigned long long* s_masktab, uint2* pairs /* LDS, this wave's [kPairSlots] */, OnObs on_obs,
+                                                  int pre_lo /* >= 0: the tile's fragment range is known (exchanged_tile priced it) */, int pre_hi,
                                                   long long* stamps = nullptr /* development: PISCES_STORE_TIMING */)
 {
     if (G.n_frags <= 0) return;
     const int tile_end = tile_start + kTile - 1;
-    const bool sorted = G.state[kStateUnsorted] == 0;
+    const bool sorted = pre_lo >= 0 || G.state[kStateUnsorted] == 0;
     const int reach = G.state[kStateReach];
     const int x_lo = (int)max((long long)tile_start - reach + 1, -0x7FFFFFFFll), x_hi = tile_end == 0x7FFFFFFF ? 0x7FFFFFFF : tile_end + 1;
     int lo = 0, hi = G.n_frags;
-    if (sorted) {
+    if (pre_lo >= 0) { lo = pre_lo; hi = pre_hi; }
+    else if (sorted) {
         if (G.grid && !(G.state[kStateFrags] & kGridBadBit)) wave_lower_bound2_hinted(G.n_frags, x_lo, x_hi, lane, G.grid, G.grid_base, G.grid_n, &lo, &hi);
         else wave_lower_bound2(G.frag, G.n_frags, x_lo, x_hi, lane, &lo, &hi);
     }
@@ -1198,6 +1200,141 @@ __device__ __forceinline__ int xcd_tile_of_block(int b, int n)
     return x * q + min(x, rem) + j;
 }
 
+// THE ORDER OF A LAUNCH'S TILES (launches of several tiles a CU).  A launch ends with the CU that was dealt the most fragments: a tile
+// across two amplicons lists twice the fragments of one inside an amplicon, and with the tiles taken in position order the tiles one
+// CU is dealt lie a fixed distance apart — on a periodic panel they are all of one kind (config 2: 3 000 to 6 000 fragments a CU, mean
+// 4 400; the launch lasted as long as the 6 000).  tile_order_kernel prices every tile (the fragments in its range: the two grid
+// entries walk_segment_fast's search reads, + the bucketed tuples) and, inside each XCD's share of the tiles (xcd_tile_of_block: neighbours
+// stay on one L2), orders them by falling cost, the rounds of `cus` workgroups alternately forwards and backwards: the workgroups
+// of a round go to different CUs, so every CU gets one tile of every cost stratum.  order[b] = the tile of workgroup b.  Which tile a
+// workgroup takes changes no result (a tile's records lie in the tile's own slots).  Measured (config 2, 1 600 tiles, profiles/
+// r05_tile_order.txt): the flush kernel 32.0-32.7 us against 35.9-37.8 in position order (fragments of the fullest CU 5 000 against
+// 6 000) — and 8.6-9.6 us for this launch in front of it (two dependent round trips on an idle chip and the launch itself), so a
+// flush is slower by ~5 us: NOT the default (PISCES_HIP_TILE_ORDER=1 asks for it); the default is exchanged_tile below.
+__device__ __forceinline__ int tile_cost(const StoreView& S, const PiscesTile& tile)
+{
+    int cost = (int)min((long long)(tile.tuple_end - tile.tuple_begin) >> 4, 0x3FFFFFll);
+    const int tile_end = tile.start_position + kTile - 1;
+    for (int sg = 0; sg < S.n_segments; sg++) {
+        const SegmentView& G = S.seg[sg];
+        if (G.n_frags <= 0 || G.state[kStateUnsorted] != 0 || !G.grid || (G.state[kStateFrags] & kGridBadBit)) continue;   // (the same for every tile)
+        const int reach = G.state[kStateReach];
+        const int x_lo = (int)max((long long)tile.start_position - reach + 1, -0x7FFFFFFFll), x_hi = tile_end == 0x7FFFFFFF ? 0x7FFFFFFF : tile_end + 1;
+        int e[2];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; k2++) {
+            const long long k = (long long)max(k2 ? x_hi : x_lo, 0) - G.grid_base;
+            e[k2] = k < 0 ? 0 : G.n_frags;
+            if (k >= 0 && k < G.grid_n) e[k2] = min(G.grid[k], G.n_frags);
+        }
+        cost += min(max(e[1] - e[0], 0), 0x3FFFFF);
+    }
+    return cost;
+}
+constexpr int kTileFixedCost = 1264;   // a tile's search, pipeline fill / drain and call phase in units of one listed fragment (13.4 us against 10.6 ns, config 2)
+constexpr int kOrderCached = 2048;      // tiles of an XCD whose costs tile_order_kernel keeps in LDS (beyond: priced again in each pass)
+__global__ __launch_bounds__(256) void tile_order_kernel(StoreView S, const PiscesTile* __restrict__ tiles /* or nullptr: R */, RegularTiles R, int32_t n_tiles,
+                                                         int32_t cus /* CUs of an XCD */, int32_t* __restrict__ order)
+{
+    __shared__ int s_max, s_cnt[256], s_at[256], s_wave[4], s_cost[kOrderCached];
+    const int x = (int)blockIdx.x, q = n_tiles >> 3, rem = n_tiles & 7, tid = (int)threadIdx.x;
+    const int first = x * q + min(x, rem), cnt = q + (x < rem ? 1 : 0);
+    if (tid == 0) s_max = 1;
+    s_cnt[tid] = 0;
+    __syncthreads();
+    auto price = [&](int j) { return kTileFixedCost + tile_cost(S, tiles ? tiles[first + j] : regular_tile(R, first + j)); };
+    for (int j = tid; j < cnt; j += 256) {
+        const int c = price(j);
+        if (j < kOrderCached) s_cost[j] = c;
+        atomicMax(&s_max, c);
+    }
+    __syncthreads();
+    const long long mx = s_max;
+    auto bucket_of = [&](int j) { const int c = j < kOrderCached ? s_cost[j] : price(j); return 255 - (int)((long long)c * 255 / mx); };   // the dearest tiles first
+    for (int j = tid; j < cnt; j += 256) atomicAdd(&s_cnt[bucket_of(j)], 1);
+    __syncthreads();
+    {   // exclusive scan of the 256 bucket counts
+        const int v = s_cnt[tid];
+        int a = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(a, d); if ((tid & 63) >= d) a += u; }
+        if ((tid & 63) == 63) s_wave[tid >> 6] = a;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < (tid >> 6); w++) base += s_wave[w];
+        s_at[tid] = base + a - v;
+    }
+    __syncthreads();
+    // workgroup j of the XCD runs on CU j % cus (the dispatcher deals them in turn): the r CUs that get one tile more than the others take
+    // the cheapest tiles, the others share the dearest — each group by rounds that run alternately forwards and backwards
+    const int s = cnt / cus, r = cnt - s * cus, n6 = cus - r, n_top = s * n6;
+    for (int j = tid; j < cnt; j += 256) {
+        const int rank = atomicAdd(&s_at[bucket_of(j)], 1);
+        int k, c;
+        if (rank < n_top) { k = rank / n6; const int i = rank - k * n6; c = r + ((k & 1) ? n6 - 1 - i : i); }
+        else { const int rr = rank - n_top; k = rr / r; const int i = rr - k * r; c = (k & 1) ? r - 1 - i : i; }
+        order[(k * cus + c) * 8 + x] = first + j;
+    }
+}
+
+// A little of that without a launch in front: the workgroups of one round of an XCD trade tiles inside small groups.  Workgroup j of
+// an XCD runs on CU j % cus (the dispatcher deals them in turn), so the first r = cnt % cus CUs get one tile more than the others; each
+// of them forms a group with g - 1 of the others (g = cus / r, at most 8).  Every workgroup of a group prices the g tiles of the group
+// (the 2 g grid entries are one load instruction of the wave, lanes 0 .. g - 1 the low ends, 32 .. 32 + g - 1 the high ends: a tile's
+// start keeps its two dependent round trips, and the range of the tile taken goes to walk_segment_fast, which then has no search of
+// its own) and all come to the same ranking: the CU with the extra tile takes the cheapest, the others the rest, rotated by the round so
+// that over the rounds each CU gets every rank.  r = 0: groups of four, rotated.  Prices are the fragment counts of the first segment
+// (one segment is the rule); no usable grid there: position order.  (Groups over all rounds of their CUs — up to 32 tiles priced by
+// every workgroup, the dearest first on each CU — measured slower than position order: 38.6 against 36.0 us.)
+__device__ __forceinline__ int exchanged_tile(const StoreView& S, const PiscesTile* __restrict__ tiles, const RegularTiles& R, int n_tiles, int cus, int b, int lane,
+                                          int* pre_lo /* -1, or: the first segment's fragment range of the tile, both ends */, int* pre_hi)
+{
+    *pre_lo = -1;
+    *pre_hi = 0;
+    const int x = b & 7, j = b >> 3, q = n_tiles >> 3, rem = n_tiles & 7;
+    const int first = x * q + min(x, rem), cnt = q + (x < rem ? 1 : 0), own = first + j;
+    const int s = cnt / cus, r = cnt - s * cus, k = j / cus, c = j - k * cus;
+    if (k >= s || S.n_segments < 1) return own;   // (the last, partial round keeps its tiles)
+    int g, grp, m;
+    if (r > 0) {
+        g = min(cus / r, 8);
+        if (g < 2) return own;
+        if (c < r) { grp = c; m = 0; }
+        else { const int d = c - r; grp = d / (g - 1); m = 1 + d - grp * (g - 1); if (grp >= r) return own; }
+    } else {
+        g = 4; grp = c >> 2; m = c & 3;
+        if (grp * 4 + 4 > cus) return own;
+    }
+    const SegmentView& G = S.seg[0];
+    if (G.n_frags <= 0 || G.state[kStateUnsorted] != 0 || !G.grid || (G.state[kStateFrags] & kGridBadBit)) return own;
+    const int reach = G.state[kStateReach];
+    const int i = lane & 31;   // the member this lane prices
+    int a = 0, t_i = own;
+    if (i < g) {
+        const int c_i = r > 0 ? (i == 0 ? grp : r + grp * (g - 1) + i - 1) : grp * 4 + i;
+        t_i = first + k * cus + c_i;
+        const int start = tiles ? tiles[t_i].start_position : regular_tile(R, t_i).start_position;
+        const int tile_end = start + kTile - 1;
+        const int xq = (lane >> 5) ? (tile_end == 0x7FFFFFFF ? 0x7FFFFFFF : tile_end + 1) : (int)max((long long)start - reach + 1, -0x7FFFFFFFll);
+        const long long kk = (long long)max(xq, 0) - G.grid_base;
+        a = kk < 0 ? 0 : G.n_frags;
+        if (kk >= 0 && kk < G.grid_n) a = min(G.grid[kk], G.n_frags);
+    }
+    const int cost = __shfl_down(a, 32) - a;   // (lanes 0 .. g - 1)
+    int rank = 0;                               // by rising price
+    for (int u = 0; u < g; u++) {
+        const int cu = __builtin_amdgcn_readlane(cost, u);
+        rank += (cu < cost || (cu == cost && u < i)) ? 1 : 0;
+    }
+    const int want = r > 0 ? (m == 0 ? 0 : 1 + (m - 1 + k) % (g - 1)) : (m + k) & 3;
+    const unsigned long long hit = __ballot(lane < g && rank == want);
+    if (hit == 0ull) return own;
+    const int chosen = (int)__ffsll((long long)hit) - 1;
+    *pre_lo = __builtin_amdgcn_readlane(a, chosen);
+    *pre_hi = __builtin_amdgcn_readlane(a, chosen + 32);
+    return __builtin_amdgcn_readlane(t_i, chosen);
+}
+
 // byte offset of an allele's first row in a histogram region, by read base (AlleleHelper.GetAlleleType, AlleleHelper.cs:13-32:
 // anything but A, C, G, T is an N); row = allele * 4 + direction, 64 int32 columns a row
 __device__ __forceinline__ uint32_t allele_row_bytes(uint32_t c)
@@ -1223,7 +1360,7 @@ __device__ __forceinline__ uint32_t allele_row_bytes_of_base(uint32_t c)
 template <int NW>
 __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_OCC) void call_store_tiles_kernel(
     StoreView S, const uint32_t* __restrict__ tuples, const PiscesTile* __restrict__ tiles /* or nullptr: R */, RegularTiles R, int32_t n_tiles,
-    const uint8_t* __restrict__ ref, int32_t ref_start, int64_t ref_len, PiscesCalledAllele* __restrict__ records,
+    const int32_t* __restrict__ order /* tile_order_kernel's, or nullptr: position order */, int32_t trade_cus /* > 0: exchanged_tile */, const uint8_t* __restrict__ ref, int32_t ref_start, int64_t ref_len, PiscesCalledAllele* __restrict__ records,
     PiscesTileResult* __restrict__ tile_results, DeviceParams P, const DeviceParams* __restrict__ Pd)
 {
     __shared__ __attribute__((aligned(16))) int hist[2 * kWaveRegion];   // [region: quality-passing / low-quality][allele * 4 + direction][locus]
@@ -1233,10 +1370,12 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
     __shared__ uint2 s_pairs[NW][kPairSlots];
 
     if ((int)blockIdx.x >= n_tiles) return;
+    int pre_lo = -1, pre_hi = 0;
 #ifdef PISCES_STORE_NO_SWIZZLE
     const int t = (int)blockIdx.x;
 #else
-    const int t = xcd_tile_of_block((int)blockIdx.x, n_tiles);
+    const int t = order ? order[blockIdx.x] : trade_cus > 0 ? exchanged_tile(S, tiles, R, n_tiles, trade_cus, (int)blockIdx.x, (int)(threadIdx.x & 63), &pre_lo, &pre_hi)
+                                            : xcd_tile_of_block((int)blockIdx.x, n_tiles);
 #endif
     const int l = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const PiscesTile tile = tiles ? tiles[t] : regular_tile(R, t);
@@ -1281,11 +1420,11 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
     for (int sg = 0; sg < S.n_segments; sg++) {
         const SegmentView& G = S.seg[sg];
 #ifdef PISCES_STORE_TIMING
-        if (G.dirs) walk_segment_fast<true>(G, tile.start_position, min_bq, l, wid, NW, hbytes, s_masktab, s_pairs[wid], on_obs, stamps);
-        else walk_segment_fast<false>(G, tile.start_position, min_bq, l, wid, NW, hbytes, s_masktab, s_pairs[wid], on_obs, stamps);
+        if (G.dirs) walk_segment_fast<true>(G, tile.start_position, min_bq, l, wid, NW, hbytes, s_masktab, s_pairs[wid], on_obs, sg == 0 ? pre_lo : -1, pre_hi, stamps);
+        else walk_segment_fast<false>(G, tile.start_position, min_bq, l, wid, NW, hbytes, s_masktab, s_pairs[wid], on_obs, sg == 0 ? pre_lo : -1, pre_hi, stamps);
 #else
-        if (G.dirs) walk_segment_fast<true>(G, tile.start_position, min_bq, l, wid, NW, hbytes, s_masktab, s_pairs[wid], on_obs);
-        else walk_segment_fast<false>(G, tile.start_position, min_bq, l, wid, NW, hbytes, s_masktab, s_pairs[wid], on_obs);
+        if (G.dirs) walk_segment_fast<true>(G, tile.start_position, min_bq, l, wid, NW, hbytes, s_masktab, s_pairs[wid], on_obs, sg == 0 ? pre_lo : -1, pre_hi);
+        else walk_segment_fast<false>(G, tile.start_position, min_bq, l, wid, NW, hbytes, s_masktab, s_pairs[wid], on_obs, sg == 0 ? pre_lo : -1, pre_hi);
 #endif
     }
 #ifdef PISCES_STORE_TIMING
@@ -1314,6 +1453,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
         tr[7] = (int)stamps[2]; tr[8] = (int)stamps[3]; tr[9] = (int)stamps[4]; tr[10] = (int)stamps[5];   // wave 0: cycles issuing / consuming / trimming, iterations
         tr[5] = (int)__builtin_amdgcn_s_getreg(63492);    // HW_REG_HW_ID
         tr[6] = (int)__builtin_amdgcn_s_getreg(63508);    // HW_REG_XCC_ID
+        tr[11] = (int)blockIdx.x;
     }
 #endif
 }

@@ -762,8 +762,18 @@ static hipError_t launch_call_store_tiles(PiscesHip* h, hipStream_t s, const uin
     int nw = h->store_waves;
     if (nw == 0) nw = h->kernel_variant == 2 ? 1 : h->kernel_variant == 3 ? 2 : (int64_t)n_tiles * 4 <= (int64_t)h->n_cus ? 16 : (int64_t)n_tiles <= (int64_t)h->n_cus ? 8
                       : (int64_t)n_tiles * 4 <= (int64_t)h->n_cus * 12 ? 4 : (int64_t)n_tiles <= (int64_t)h->n_cus * 32 ? 2 : 1;
+    // several tiles a CU (store_kernels.hip.h): the workgroups trade tiles by price inside small groups (the default), or take them in
+    // tile_order_kernel's order (PISCES_HIP_TILE_ORDER=1: a launch in front), or in position order (=0)
+    const int32_t* order = nullptr;
+    int32_t trade_cus = 0;
+    if (h->tile_order == 2 && nw <= 2 && (int64_t)n_tiles >= 4 * (int64_t)h->n_cus && h->n_cus >= 8) trade_cus = (int32_t)(h->n_cus / 8);
+    if (h->tile_order == 1 && nw <= 2 && (int64_t)n_tiles >= 4 * (int64_t)h->n_cus && h->n_cus >= 8) {
+        if (h->d_tile_order.reserve((size_t)n_tiles) != hipSuccess) return hipErrorOutOfMemory;
+        hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(256), 0, s, V, d_tiles, R, n_tiles, (int32_t)(h->n_cus / 8), h->d_tile_order.p);
+        order = h->d_tile_order.p;
+    }
 #define PISCES_LAUNCH_STORE(NW)                                                                                                                     \
-    hipExtLaunchKernelGGL(call_store_tiles_kernel<NW>, dim3((unsigned)n_tiles), dim3(64 * NW), 0u, s, e0, e1, 0u, V, d_tuples, d_tiles, R, n_tiles, d_ref, \
+    hipExtLaunchKernelGGL(call_store_tiles_kernel<NW>, dim3((unsigned)n_tiles), dim3(64 * NW), 0u, s, e0, e1, 0u, V, d_tuples, d_tiles, R, n_tiles, order, trade_cus, d_ref, \
                           ref_start, ref_len, d_records, d_tr, h->P, (const DeviceParams*)h->d_params.p)
     if (nw >= 16) PISCES_LAUNCH_STORE(16);
     else if (nw >= 8) PISCES_LAUNCH_STORE(8);

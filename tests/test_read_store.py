@@ -299,6 +299,30 @@ def test_thresholds_the_fused_kernel_is_not_compiled_for(torch_cuda):
     assert (got["num_no_calls"] > 0).any() and (got["total_coverage"] > 0).any()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_loci,depth", [(100_000, 500), (128_000, 60), (70_000, 100)], ids=["config2_100kx500", "2048_tiles_x60", "1120_tiles_x100"])
+def test_whichever_tile_a_workgroup_takes_the_records_are_the_same(torch_cuda, n_loci, depth):
+    """A launch of several tiles a CU deals its tiles by price (store_kernels.hip.h: exchanged_tile inside call_store_tiles_kernel, the
+    default; tile_order_kernel in front of it, PISCES_HIP_TILE_ORDER=1): every tile must be taken exactly once, so the records of one
+    flush are the bytes of the launch in position order (PISCES_HIP_TILE_ORDER=0).  Sizes: some CUs with one tile more than the
+    others (1 600 and 1 120 tiles on 256 CUs) and none (2 048)."""
+    from pisces_amd import engine, synth
+    p = synth.make_pileup(n_loci=n_loci, depth=depth, seed=5)
+    ref = p.ref.cpu().numpy()
+    cfg = _abi.default_config()
+    whole = synth.reads_of(p, p.base.shape[0], first_amplicon=0)
+    out = {}
+    for order in ("0", "1", "2"):
+        with env(PISCES_HIP_TILE_ORDER=order):
+            with engine.HipVariantCaller(cfg) as c:
+                c.SetReference(ref)
+                c.AddAlleleCounts(whole)
+                out[order] = c.Call(None, capacity=2 * n_loci)
+    assert len(out["0"]) >= n_loci
+    assert out["1"].tobytes() == out["0"].tobytes()
+    assert out["2"].tobytes() == out["0"].tobytes()
+
+
 @pytest.mark.parametrize("n_loci,depth", [(100_000, 500)], ids=["config2_100kx500"])
 def test_config2_at_full_size_store_equals_log_chain_and_oracle_slice(torch_cuda, n_loci, depth):
     """BASELINE config 2 (100 000 loci x 500x, 333 500 reads) through pisces_hip_add_reads / pisces_hip_flush: the read store and the

@@ -51,3 +51,16 @@ for name, k in (("list the next block's pairs (waits for its descriptors)", 7), 
     v = t[:, k].astype(np.int64)
     print(f"{name:48s} cycles per iteration p10/p50/p90 {np.round(np.percentile(v / it, [10, 50, 90]))}; per tile p50 {np.percentile(v, 50):.0f}")
 print("iterations per wave p50", np.percentile(it, 50))
+# which CU a workgroup went to, in dispatch order (tr[11] = blockIdx.x): XCD = b & 7 by the round-robin of the dispatcher, then?
+if t.shape[1] > 11 and t[:, 11].max() > 0:
+    b = t[:, 11].astype(np.int64)
+    o = np.argsort(b)
+    xcc = (t[:, 6].astype(np.int64) & 0xF)[o]
+    print("XCC of blocks 0..15:", xcc[:16].tolist(), "; blocks whose XCC != b & 7:", int((xcc != (np.arange(len(o)) & 7)).sum()))
+    cu_o = cu[o]
+    for x in (0, 3):
+        seq = cu_o[x::8] & 0xFF
+        print(f"XCD {x}: CU field of its workgroups in order (first 72):", seq[:72].tolist())
+        per = 32
+        same = int((seq[per:2 * per] == seq[:per]).sum())
+        print(f"   second round of 32 on the same CUs as the first: {same} of 32")
