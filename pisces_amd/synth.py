@@ -68,10 +68,11 @@ def _chunk_generator(seed, chunk, dev):
 
 def make_pileup(n_loci, depth, seed=20260928, device="cpu", p_lowq=0.02, base_error=0.001, snv_every=100,
                 snv_offset=37, q_hi=37, q_lo=12, vaf_range=(0.02, 0.5), strand_range=(0.3, 0.7), flank=READ_LEN, tile=TILE,
-                first_locus=0, total_loci=None, with_tuples=True):
+                first_locus=0, total_loci=None, with_tuples=True, tile_plan=None):
     """Loci [first_locus, first_locus + n_loci) of a global pileup of `total_loci` loci (default: the whole pileup, n_loci from 0).
     `tile` = loci per tile of the bucketed tuple stream (<= 64; the kernels take any PiscesTile.n_loci <= 64).  Every chunk of
-    CHUNK_AMPLICONS amplicons has its own seeded stream: a range made on its own equals the same range of the whole."""
+    CHUNK_AMPLICONS amplicons has its own seeded stream: a range made on its own equals the same range of the whole.
+    `tile_plan` = [(tiles, loci per tile), ...] for the first tiles of the stream (the rest take `tile`): tiles of unequal size."""
     assert 1 <= tile <= TILE
     dev = torch.device(device)
     total_loci = first_locus + n_loci if total_loci is None else int(total_loci)
@@ -167,13 +168,21 @@ def make_pileup(n_loci, depth, seed=20260928, device="cpu", p_lowq=0.02, base_er
                       base=base, qual=qual, planted=np.nonzero((gl % snv_every) == snv_offset)[0], ref_start=ref_start,
                       first_locus=first_locus, first_amplicon=a0, total_loci=total_loci, flank=flank)
     # tile-bucketed tuple stream: tiles from locus 0 of this pileup; inside a tile read-major (each read's run of loci)
-    n_tiles = math.ceil(n_loci / tile)
+    edges = [0]
+    for cnt_, loci_ in (tile_plan or ()):
+        assert 1 <= loci_ <= TILE
+        for _ in range(cnt_):
+            if edges[-1] < n_loci:
+                edges.append(min(edges[-1] + loci_, n_loci))
+    while edges[-1] < n_loci:
+        edges.append(min(edges[-1] + tile, n_loci))
+    n_tiles = len(edges) - 1
     tiles = np.zeros(n_tiles, dtype=_abi.TILE_DTYPE)
     segs = []
     cursor = 0
     pad_val = torch.tensor([-1], device=dev, dtype=torch.int64)   # 0xFFFFFFFF after the int32 cast
     for t in range(n_tiles):
-        l0, l1 = t * tile, min(t * tile + tile, n_loci)            # loci of this pileup
+        l0, l1 = edges[t], edges[t + 1]                            # loci of this pileup
         g0, g1 = first_locus + l0, first_locus + l1               # global loci
         n_seg = 0
         for a in range(g0 // READ_LEN, (g1 - 1) // READ_LEN + 1):

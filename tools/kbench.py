@@ -16,11 +16,13 @@ def main():
     ap.add_argument("--ring", type=int, default=4)
     ap.add_argument("--tag", default="")
     ap.add_argument("--tile", type=int, default=64, help="loci per tile of the synthetic tuple stream")
+    ap.add_argument("--plan", default="", help="tiles of unequal size: '1536x58,256x43' = the first 1536 tiles of 58 loci, the next 256 of 43, the rest --tile")
     a = ap.parse_args()
+    plan = [(int(x.split("x")[0]), int(x.split("x")[1])) for x in a.plan.split(",") if x] or None
     import torch
     from pisces_amd import _abi, engine, synth
     dev = torch.device("cuda", 0)
-    ring = [synth.make_pileup(a.loci, a.depth, seed=100 + b, device=dev, tile=a.tile) for b in range(a.ring)]
+    ring = [synth.make_pileup(a.loci, a.depth, seed=100 + b, device=dev, tile=a.tile, tile_plan=plan) for b in range(a.ring)]
     for p in ring:
         p.base = p.qual = None
     torch.cuda.empty_cache()
@@ -45,7 +47,7 @@ def main():
         ms, n = c.kernel_time()
     k = ms / n
     nb = 4 * ring[0].n_obs + a.loci + 64 * a.loci
-    print(f"{a.tag or os.environ.get('PISCES_HIP_LIB', 'product')}: loci={a.loci} depth={a.depth} tile={a.tile} kernel={k*1e3:.1f} us  "
+    print(f"{a.tag or os.environ.get('PISCES_HIP_LIB', 'product')}: loci={a.loci} depth={a.depth} tile={a.tile} plan={a.plan or '-'} tiles={nt} kernel={k*1e3:.1f} us  "
           f"{nb / (k * 1e-3) / 1e9:.0f} GB/s algorithmic ({nb / (k * 1e-3) / 8e12 * 100:.1f}% of 8 TB/s)  "
           f"{a.loci / (k * 1e-3) / 1e9:.2f} G loci/s", flush=True)
 
