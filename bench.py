@@ -1049,10 +1049,9 @@ def main():
         for i in range(args.steps):
             step(args.warmup + i)
     caller.mark(1, stream)
-    totals = caller.device_totals()        # (waits for the device: hipDeviceSynchronize, then the totals of the K launches)
-    summary = torch.tensor([totals["records"], totals["candidate_loci"], totals["called"], totals["tiles"]], dtype=torch.int64)
+    totals = caller.device_totals()        # (waits for the K launches: their totals arrive in pinned memory behind them, one stream wait)
     if use_dist:
-        summary = summary.to(dev)
+        summary = torch.tensor([totals["records"], totals["candidate_loci"], totals["called"], totals["tiles"]], dtype=torch.int64).to(dev)
         shard.reduce_summary(summary)   # the per-chromosome summary reduce: one all-reduce(sum) of int64[4] (RCCL over xGMI)
         torch.cuda.synchronize(dev)
     barrier()
@@ -1078,6 +1077,8 @@ def main():
     assert int(tr["n_records"].sum()) * args.steps == totals["records"]
     assert int(tr["n_candidate_loci"].sum()) == my_loci, "every covered locus must be a candidate locus in gVCF mode"
 
+    if not use_dist:   # (one rank: the summary is this rank's totals; the tensor is made outside the timed region)
+        summary = torch.tensor([totals["records"], totals["candidate_loci"], totals["called"], totals["tiles"]], dtype=torch.int64)
     total_records, sum_loci = int(summary[0].item()), int(summary[1].item())
     assert sum_loci == total_loci * args.steps, (sum_loci, total_loci, args.steps)   # the shards cover the interval set exactly once
     value = sum_loci / elapsed
