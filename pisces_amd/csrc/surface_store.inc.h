@@ -766,7 +766,10 @@ static hipError_t launch_call_store_tiles(PiscesHip* h, hipStream_t s, const uin
     // tile_order_kernel's order (PISCES_HIP_TILE_ORDER=1: a launch in front), or in position order (=0)
     const int32_t* order = nullptr;
     int32_t trade_cus = 0;
-    if (h->tile_order == 2 && nw <= 2 && (int64_t)n_tiles >= 4 * (int64_t)h->n_cus && h->n_cus >= 8) trade_cus = (int32_t)(h->n_cus / 8);
+    // (from 4 to 8 tiles a CU: beyond, the CUs' shares even out by themselves and the trade's pricing only delays a tile's start —
+    // 3 200 / 4 688 / 9 376 tiles: 60.3 / 48.3 / 92.3 us in position order, 61.0 / 49.2 / 93.0 traded, profiles/r05_tile_order.txt)
+    if (h->tile_order == 2 && nw <= 2 && (int64_t)n_tiles >= 4 * (int64_t)h->n_cus && (int64_t)n_tiles <= 8 * (int64_t)h->n_cus && h->n_cus >= 8)
+        trade_cus = (int32_t)(h->n_cus / 8);
     if (h->tile_order == 1 && nw <= 2 && (int64_t)n_tiles >= 4 * (int64_t)h->n_cus && h->n_cus >= 8) {
         if (h->d_tile_order.reserve((size_t)n_tiles) != hipSuccess) return hipErrorOutOfMemory;
         hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(256), 0, s, V, d_tiles, R, n_tiles, (int32_t)(h->n_cus / 8), h->d_tile_order.p);
