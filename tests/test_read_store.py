@@ -300,12 +300,15 @@ def test_thresholds_the_fused_kernel_is_not_compiled_for(torch_cuda):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_loci,depth", [(100_000, 500), (128_000, 60), (70_000, 100)], ids=["config2_100kx500", "2048_tiles_x60", "1120_tiles_x100"])
+@pytest.mark.parametrize("n_loci,depth", [(100_000, 500), (128_000, 60), (70_000, 100), (65_000, 40), (120_000, 40), (85_000, 40), (112_000, 40)],
+                         ids=["config2_100kx500", "2048_tiles_x60", "1120_tiles_x100", "1040_tiles_groups_of_8", "1920_tiles_groups_of_2",
+                              "1360_tiles_groups_of_3_and_cus_left_over", "1792_tiles_no_cu_with_a_tile_more"])
 def test_whichever_tile_a_workgroup_takes_the_records_are_the_same(torch_cuda, n_loci, depth):
     """A launch of several tiles a CU deals its tiles by price (store_kernels.hip.h: exchanged_tile inside call_store_tiles_kernel, the
     default; tile_order_kernel in front of it, PISCES_HIP_TILE_ORDER=1): every tile must be taken exactly once, so the records of one
     flush are the bytes of the launch in position order (PISCES_HIP_TILE_ORDER=0).  Sizes: some CUs with one tile more than the
-    others (1 600 and 1 120 tiles on 256 CUs) and none (2 048)."""
+    others (1 600 and 1 120 tiles on 256 CUs: groups of four) and none (2 048, 1 792: groups of four, rotated); 2 / 16 / 10 of an XCD's 32
+    CUs with a tile more (1 040 / 1 920 / 1 360 tiles: groups of eight / two / three, the last with CUs that belong to no group)."""
     from pisces_amd import engine, synth
     p = synth.make_pileup(n_loci=n_loci, depth=depth, seed=5)
     ref = p.ref.cpu().numpy()
