@@ -547,6 +547,7 @@ struct PiscesHip {
     int tile_order = 2;                       // which tile a workgroup of call_store_tiles_kernel takes in a launch of several tiles a CU (PISCES_HIP_TILE_ORDER): 2 tiles
                                               // traded by price inside small groups (exchanged_tile), 1 tile_order_kernel's order (a launch in front), 0 position order
     DeviceBuf<int32_t> d_tile_order;
+    bool store_prio = true;                   // PISCES_HIP_STORE_PRIO=0: no issue priority for the walking waves of call_store_tiles_kernel (the A / B)
     int finder_wave = 0;                      // PISCES_HIP_FINDER: the default is a lane a read, events first; =bases: a lane a read, base by base (round 3's);
                                               // =wave / =batch: a wave for one / for 64 reads (finder_kernels.hip.h; measured slower)
     DeviceBuf<long long> d_scan_sums;         // block sums of launch_found_scan
@@ -879,6 +880,7 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         if (const char* v = getenv("PISCES_HIP_STORE_DIRECT_BYTES")) h->store_direct_bytes = (size_t)std::max(0ll, atoll(v));
         if (const char* v = getenv("PISCES_HIP_STORE_WAVES")) h->store_waves = atoi(v);
         if (const char* v = getenv("PISCES_HIP_TILE_ORDER")) h->tile_order = atoi(v);
+        if (const char* v = getenv("PISCES_HIP_STORE_PRIO")) h->store_prio = atoi(v) != 0;
         if (const char* v = getenv("PISCES_HIP_DEVICE_MERGE")) h->device_merge = atoi(v) != 0 ? 1 : 0;   // the A/B of tests/test_read_store.py
         // MNV calling on: the split form, unless the candidate records are asked to come back unmerged (PISCES_HIP_DEVICE_MERGE=0: the
         // earlier form, every candidate an object on the host, the tile kernels Reference records only) or PISCES_HIP_MNV_SPLIT=0

@@ -1360,7 +1360,7 @@ __device__ __forceinline__ uint32_t allele_row_bytes_of_base(uint32_t c)
 template <int NW>
 __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_OCC) void call_store_tiles_kernel(
     StoreView S, const uint32_t* __restrict__ tuples, const PiscesTile* __restrict__ tiles /* or nullptr: R */, RegularTiles R, int32_t n_tiles,
-    const int32_t* __restrict__ order /* tile_order_kernel's, or nullptr: position order */, int32_t trade_cus /* > 0: exchanged_tile */, const uint8_t* __restrict__ ref, int32_t ref_start, int64_t ref_len, PiscesCalledAllele* __restrict__ records,
+    const int32_t* __restrict__ order /* tile_order_kernel's, or nullptr: position order */, int32_t trade_cus /* > 0: exchanged_tile */, int32_t walk_prio, const uint8_t* __restrict__ ref, int32_t ref_start, int64_t ref_len, PiscesCalledAllele* __restrict__ records,
     PiscesTileResult* __restrict__ tile_results, DeviceParams P, const DeviceParams* __restrict__ Pd)
 {
     __shared__ __attribute__((aligned(16))) int hist[2 * kWaveRegion];   // [region: quality-passing / low-quality][allele * 4 + direction][locus]
@@ -1400,6 +1400,11 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
         }
         __syncthreads();
     }
+    // a launch whose workgroups are all resident at once: walking waves win the issue arbitration over waves in their call phase (as in
+    // call_tiles_wave_kernel) — the launch ends with the slowest tile, and a tile that still walks has its whole call phase ahead of it.
+    // Config 2, 1 600 tiles: 32.9-33.4 us against 35.5-37.4 (best launches 31.3-32.0 against 34.0-34.4); a launch of several rounds
+    // (4 688 tiles) loses 2.4 us with it, so the host asks for it in single-round launches only
+    if (walk_prio) __builtin_amdgcn_s_setprio(3);
     const uint32_t min_bq = (uint32_t)min(max(P.min_bq, 0), 127);   // (the host routes larger thresholds through the counts in HBM)
     char* const hbytes = reinterpret_cast<char*>(hist);
     constexpr uint32_t kRegionBytes = (uint32_t)(kWaveRegion * sizeof(int));
@@ -1436,6 +1441,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? PISCES_WAVE_OCC : PISCES_WAVE2_O
     return;
 #endif
     if (NW > 2 && wid != 0 && wid != NW - 1) return;
+    if (walk_prio) __builtin_amdgcn_s_setprio(0);
     call_phase_wave<(NW == 1 ? 1 : 2), HistLinear>(hist, s_refwin, s_vmask, tile, t, l, NW == 1 ? 0 : (wid == NW - 1 ? 1 : 0), ref, ref_start, ref_len, records, tile_results, P
 #ifdef PISCES_TIMING
                                     , 0ll, 0ll

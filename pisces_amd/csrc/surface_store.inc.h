@@ -775,8 +775,10 @@ static hipError_t launch_call_store_tiles(PiscesHip* h, hipStream_t s, const uin
         hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(256), 0, s, V, d_tiles, R, n_tiles, (int32_t)(h->n_cus / 8), h->d_tile_order.p);
         order = h->d_tile_order.p;
     }
+    // issue priority for walking waves: launches whose workgroups are all resident at once (8 tiles a CU at two waves a tile)
+    const int32_t walk_prio = (h->store_prio && nw == 2 && (int64_t)n_tiles <= 8 * (int64_t)h->n_cus) ? 1 : 0;
 #define PISCES_LAUNCH_STORE(NW)                                                                                                                     \
-    hipExtLaunchKernelGGL(call_store_tiles_kernel<NW>, dim3((unsigned)n_tiles), dim3(64 * NW), 0u, s, e0, e1, 0u, V, d_tuples, d_tiles, R, n_tiles, order, trade_cus, d_ref, \
+    hipExtLaunchKernelGGL(call_store_tiles_kernel<NW>, dim3((unsigned)n_tiles), dim3(64 * NW), 0u, s, e0, e1, 0u, V, d_tuples, d_tiles, R, n_tiles, order, trade_cus, walk_prio, d_ref, \
                           ref_start, ref_len, d_records, d_tr, h->P, (const DeviceParams*)h->d_params.p)
     if (nw >= 16) PISCES_LAUNCH_STORE(16);
     else if (nw >= 8) PISCES_LAUNCH_STORE(8);
