@@ -922,6 +922,39 @@ def run_stream_config(args):
         dist.destroy_process_group()
 
 
+def launch_ranks(args, argv, device_count=None, run=None):
+    """`python bench.py --gpus N` (N > 1) with no launcher around it starts its N ranks ITSELF: the same command line under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, one rank a GPU (the driver's own form;
+    under that launcher WORLD_SIZE is set and this returns None: the rank runs).  Fewer devices than ranks is an error, not a silent
+    one-rank run — unless PISCES_BENCH_ONE_DEVICE=1 (development: every rank on cuda:0, process group on gloo).  Returns None when this
+    process is to run the bench itself, else the exit status of the launcher.  `device_count` / `run` are the test's seams."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: the launcher's --nproc-per-node and --gpus must agree",
+                  file=sys.stderr)
+            return 2
+        return None
+    if device_count is None:
+        from pisces_amd import engine
+        device_count = engine.device_count
+    have = device_count()
+    if have < args.gpus and os.environ.get("PISCES_BENCH_ONE_DEVICE") != "1":
+        print(f"bench.py: --gpus {args.gpus} asked for, pisces_hip_device_count() = {have}: not enough MI355X devices on this node "
+              f"(PISCES_BENCH_ONE_DEVICE=1 runs the {args.gpus}-rank code path on one device for development; its numbers mean nothing)",
+              file=sys.stderr)
+        return 3
+    import socket
+    import subprocess
+    with socket.socket() as so:                                     # a free rendezvous port on the loopback
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    print("bench.py: starting " + str(args.gpus) + " ranks: " + " ".join(cmd), file=sys.stderr)
+    return (run or subprocess.call)(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -939,6 +972,9 @@ def main():
                     help="2 (default): the configuration the metric is quoted on; 3 / 5: BASELINE configs 3 / 5 as stated, from reads through the "
                          "streaming surface; 4: BASELINE config 4 as stated")
     args = ap.parse_args()
+    launched = launch_ranks(args, sys.argv[1:])
+    if launched is not None:
+        return launched
     if args.config == 4:
         return run_config4(args)
     if args.config in (3, 5):
@@ -970,8 +1006,6 @@ def main():
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-    if world != args.gpus and rank == 0:
-        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch N>1 with torch.distributed.run", file=sys.stderr)
 
     cfg = _abi.default_config()
     caller = engine.HipVariantCaller(cfg, device=local_rank)
@@ -1292,4 +1326,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

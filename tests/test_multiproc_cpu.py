@@ -169,3 +169,87 @@ def test_shards_with_halo_reads_reproduce_the_single_run():
         got.append(recs)
     assert counted == len(reads)
     assert np.concatenate(got).tobytes() == whole.tobytes()
+
+
+# ---- bench.py --gpus N starts its own ranks ----
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+class _Args:
+    def __init__(self, gpus):
+        self.gpus = gpus
+
+
+def test_bench_launcher_refuses_more_ranks_than_devices(monkeypatch, capsys):
+    """`python bench.py --gpus 2` on a box with one device exits non-zero with a message that names the count, instead of running one rank."""
+    bench = _bench_module()
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("PISCES_BENCH_ONE_DEVICE", raising=False)
+    started = []
+    rc = bench.launch_ranks(_Args(2), ["--gpus", "2"], device_count=lambda: 1, run=lambda cmd, env: started.append(cmd) or 0)
+    assert rc not in (None, 0) and not started
+    err = capsys.readouterr().err
+    assert "--gpus 2" in err and "pisces_hip_device_count() = 1" in err
+
+
+def test_bench_launcher_starts_one_rank_per_gpu(monkeypatch):
+    """With enough devices (or PISCES_BENCH_ONE_DEVICE=1) the command line is re-run under torch.distributed.run, N processes on the loopback."""
+    bench = _bench_module()
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    started = []
+
+    def run(cmd, env):
+        started.append((cmd, env))
+        return 0
+
+    assert bench.launch_ranks(_Args(4), ["--gpus", "4", "--steps", "5"], device_count=lambda: 8, run=run) == 0
+    cmd, env = started[0]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "5"]
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setenv("PISCES_BENCH_ONE_DEVICE", "1")
+    assert bench.launch_ranks(_Args(2), ["--gpus", "2"], device_count=lambda: 1, run=run) == 0 and len(started) == 2
+
+
+def test_bench_launcher_leaves_a_launched_rank_and_n1_alone(monkeypatch, capsys):
+    """N = 1 runs in this process as before; under a launcher (WORLD_SIZE set) the rank runs; a launcher that disagrees with --gpus is an error."""
+    bench = _bench_module()
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    boom = lambda *a, **k: (_ for _ in ()).throw(AssertionError("nothing may be started"))
+    assert bench.launch_ranks(_Args(1), [], device_count=boom, run=boom) is None
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    assert bench.launch_ranks(_Args(2), ["--gpus", "2"], device_count=boom, run=boom) is None
+    assert bench.launch_ranks(_Args(4), ["--gpus", "4"], device_count=boom, run=boom) == 2
+    assert "WORLD_SIZE=2" in capsys.readouterr().err
+
+
+def _spawned_rank_script():
+    return ("import os, sys, torch.distributed as dist\n"
+            "dist.init_process_group('gloo')\n"
+            "import torch\n"
+            "t = torch.tensor([dist.get_rank() + 1]); dist.all_reduce(t)\n"
+            "assert int(t) == sum(range(1, dist.get_world_size() + 1))\n"
+            "open(os.path.join(sys.argv[1], 'rank%d' % dist.get_rank()), 'w').write(str(int(t)))\n")
+
+
+def test_bench_launcher_command_brings_up_a_gloo_world_of_two(tmp_path, monkeypatch):
+    """The launcher's own command form (torch.distributed.run on 127.0.0.1 with a free port) brings up two ranks that find each other:
+    run here with a stand-in script in place of bench.py (whose ranks need a GPU each)."""
+    import subprocess
+    bench = _bench_module()
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    script = tmp_path / "rank.py"
+    script.write_text(_spawned_rank_script())
+
+    def run(cmd, env):
+        i = cmd.index(os.path.abspath(bench.__file__))
+        return subprocess.call(cmd[:i] + [str(script), str(tmp_path)], env=env, timeout=240)
+
+    assert bench.launch_ranks(_Args(2), ["--gpus", "2"], device_count=lambda: 2, run=run) == 0
+    assert (tmp_path / "rank0").read_text() == "3" and (tmp_path / "rank1").read_text() == "3"
