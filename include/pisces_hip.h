@@ -392,17 +392,21 @@ int32_t pisces_hip_add_candidates(PiscesHip* h, const PiscesCandidate* cands, in
  * (RegionState.GetAllCandidates :393-450).  With the diploid model DiploidLocusProcessor's rules apply (PISCES_GT_OTHERS).  Call it
  * after pisces_hip_set_intervals and before the first flush. */
 int32_t pisces_hip_set_forced_alleles(PiscesHip* h, const PiscesCandidate* alleles_of, int64_t n, const uint8_t* alleles, int64_t allele_bytes);
+/* IAlleleCaller.TotalNumCalled with an interval set and MNV calling off: AlleleCaller.Call counts in IsCallable, BEFORE ShouldReport
+ * (AlleleCaller.cs:109-131), so the reference's total includes the callable SNVs of loci OUTSIDE the intervals, which it does not report.
+ * By default the library evaluates the intervals' loci only (the total then counts the callable alleles inside them; every reported row
+ * is the reference's either way).  on != 0: every flush also runs its kernel over the off-interval loci of the flushed blocks, drops the
+ * records and adds their callable alleles — the reference's number, at the price of a second launch per flush.  With MNV calling on (or collapser
+ * thresholds that keep an open-ended SNV and its twin apart) the SNVs are candidates and the candidate path counts the callable ones outside the intervals itself (the switch changes
+ * nothing).  The counting launch is the read store's flush kernel: a flush of a configuration that kernel does not serve (NoiseModel.Window,
+ * the Diploid strand-bias model, a gapped-MNV reference count in the flushed blocks, the observation-log read path, minimum base quality
+ * above 127) fails with PISCES_E_UNSUPPORTED while the switch is on instead of reporting the smaller total. */
+int32_t pisces_hip_set_exact_total_called(PiscesHip* h, int32_t on);
 /* The chromosome's known (prior) variants: what Factory.cs:204 hands VariantCollapser (the priors file's insertions and MNVs, Factory.cs:378-395).
  * With the collapser on, a candidate that equals one (position, reference allele, alternate allele, type) is anchored on both sides and
  * preferred among the potential matches of an open-ended candidate (VariantCollapser.cs:16-24, 178-190, 216-218).  Same arguments as
  * pisces_hip_set_forced_alleles (position, ref_len, alt_len, allele_offset of every entry; the rest is ignored); n = 0 clears.  Any time
  * before the flush that should see them. */
-/* IAlleleCaller.TotalNumCalled with an interval set and MNV calling off: AlleleCaller.Call counts in IsCallable, BEFORE ShouldReport
- * (AlleleCaller.cs:109-131), so the reference's total includes the callable SNVs of loci OUTSIDE the intervals, which it does not report.
- * By default the library evaluates the intervals' loci only (the total then counts the callable alleles inside them; every reported row
- * is the reference's either way).  on != 0: every flush also runs its kernel over the off-interval loci of the flushed blocks, drops the
- * records and adds their callable alleles — the reference's number, at the price of a second launch per flush (read store path only). */
-int32_t pisces_hip_set_exact_total_called(PiscesHip* h, int32_t on);
 int32_t pisces_hip_set_known_variants(PiscesHip* h, const PiscesCandidate* variants, int64_t n, const uint8_t* alleles, int64_t allele_bytes);
 /* PiscesApplicationOptions.ExcludeMNVsFromCollapsing (Options/PiscesApplicationOptions.cs:62; Factory.cs:204 hands it to VariantCollapser):
  * on != 0: MNV candidates are left out of the collapser's targets (VariantCollapser.cs:33) — an open-ended MNV is not collapsed, and no

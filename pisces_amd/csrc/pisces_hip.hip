@@ -555,6 +555,7 @@ struct PiscesHip {
     bool merge_in_place = true;               // PISCES_HIP_MERGE_IN_PLACE=0: the candidate kernel's rows and the tile kernels' are merged into a vector of their own (the A / B of the tests)
     int device_checks = -1;                   // PISCES_HIP_DEVICE_CHECKS: 1 every host batch is checked on the device (read_prepare_kernel), 0 none, -1 (default) from 65 536 reads up
     bool prep_map_clean = false;              // the block map of read_prepare_kernel is all zero
+    size_t prep_map_copies = 0;               // copies the map is kept in (kPrepReplicas, or 1 when a small block size makes it large)
     DeviceBuf<uint32_t> d_prep_map;
 
     // device scratch, grow-only

@@ -276,7 +276,9 @@ static int32_t enqueue_off_interval_count(PiscesHip* h, const std::vector<int32_
         }
         if (at <= bend) add_range(at, bend);
     }
-    if (tiles.empty() || tiles.size() > (size_t)(0x7FFFFF00ll / kSlotsPerTile)) return PISCES_OK;
+    if (tiles.empty()) return PISCES_OK;
+    if (tiles.size() > (size_t)(0x7FFFFF00ll / kSlotsPerTile))
+        return fail(h, PISCES_E_UNSUPPORTED, "flush: pisces_hip_set_exact_total_called: more off-interval tiles in one flush than a launch's record slots hold (flush fewer blocks at a time)");
     const int32_t n = (int32_t)tiles.size();
     PISCES_HIP_CHECK(h, h->d_tiles_x.reserve(tiles.size()));
     PISCES_HIP_CHECK(h, h->d_tr_x.reserve(tiles.size()));
@@ -441,7 +443,15 @@ static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& key
     st->hdr = hdr;
     st->hrec = hrec;
     st->spec = spec;
-    if (h->exact_total_called && fused && !regular && !h->intervals.empty() && !h->snv_walk && h->log_ub == 0) {
+    // pisces_hip_set_exact_total_called: with an interval set and the SNVs taken from the allele counts (MNV calling and collapsing off:
+    // otherwise they are candidates, and the candidate path counts the callable ones outside the intervals itself) the off-interval loci
+    // get a counting launch of the flush kernel.  A configuration that kernel does not serve cannot give the reference's number: refused
+    // here, not answered with the smaller one.
+    if (h->exact_total_called && !h->intervals.empty() && !h->snv_walk) {
+        if (!(fused && h->log_ub == 0))
+            return fail(h, PISCES_E_UNSUPPORTED, "flush: pisces_hip_set_exact_total_called is on, but this configuration does not go through the read store's "
+                        "flush kernel (NoiseModel.Window, the Diploid strand-bias model, a gapped-MNV reference count in the flushed blocks, the "
+                        "observation-log read path or a base-quality threshold above 127): the off-interval total cannot be counted; switch it off");
         int32_t rcx = enqueue_off_interval_count(h, keys, st);
         if (rcx) return rcx;
     }
@@ -733,12 +743,20 @@ static int64_t collapse_candidates(std::vector<HostCandidate>& cands, float freq
     // AnnotateKnown (VariantCollapser.cs:178-190): a candidate that equals a known (prior) variant of the chromosome is known, and anchored on
     // both sides whatever its reads said
     std::vector<uint8_t> known(n, 0);
-    if (known_variants && !known_variants->empty())
+    if (known_variants && !known_variants->empty()) {
+        const bool sorted = std::is_sorted(known_variants->begin(), known_variants->end(),
+                                           [](const HostCandidate& a, const HostCandidate& b) { return a.position < b.position; });   // (pisces_hip_set_known_variants sorts)
         for (size_t i = 0; i < n; i++) {
             if (excluded(i)) continue;
-            for (const HostCandidate& k : *known_variants)
-                if (cand_equals(cands[i], k)) { known[i] = 1; cands[i].open_left = cands[i].open_right = false; break; }
+            auto k = known_variants->begin(), k_end = known_variants->end();
+            if (sorted) {   // the known variants at the candidate's own position only
+                k = std::lower_bound(k, k_end, cands[i].position, [](const HostCandidate& a, int32_t p) { return a.position < p; });
+                k_end = std::upper_bound(k, k_end, cands[i].position, [](int32_t p, const HostCandidate& a) { return p < a.position; });
+            }
+            for (; k != k_end; ++k)
+                if (cand_equals(cands[i], *k)) { known[i] = 1; cands[i].open_left = cands[i].open_right = false; break; }
         }
+    }
     std::vector<size_t> order;
     for (size_t i = 0; i < n; i++)
         if (!excluded(i) && (cands[i].open_left || cands[i].open_right)) order.push_back(i);

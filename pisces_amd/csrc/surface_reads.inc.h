@@ -341,6 +341,8 @@ int32_t pisces_hip_set_known_variants(PiscesHip* h, const PiscesCandidate* cands
     for (auto& c : list)   // (CandidateAllele.Equals compares the type too: derived from the alleles as the reader of the priors file does)
         c.category = (c.ref.size() == 1 && c.alt.size() == 1) ? PISCES_CAT_SNV : c.ref.size() == c.alt.size() ? PISCES_CAT_MNV
                      : c.ref.size() > c.alt.size() ? PISCES_CAT_DELETION : PISCES_CAT_INSERTION;
+    // (in position order: AnnotateKnown looks a candidate's position up instead of comparing it with every known variant)
+    std::stable_sort(list.begin(), list.end(), [](const HostCandidate& a, const HostCandidate& b) { return a.position < b.position; });
     h->known_variants = std::move(list);
     return PISCES_OK;
     });

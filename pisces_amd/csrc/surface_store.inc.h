@@ -331,6 +331,10 @@ static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const Sto
                 PISCES_HIP_CHECK(h, hipMemsetAsync(g.grid.p + cells, 0x7F, (size_t)(want - cells) * sizeof(int32_t), h->stream));
                 cells = want;
             }
+            // a batch that touches no block (every read soft-clipped away or without operations: max_key == 0, c_hi < base) leaves no cell; the
+            // next batch of the segment would fill from its own first read on and the cells in between would keep the fill value (a tile
+            // there would see an empty fragment range): such a segment goes without a grid
+            if (cells == 0) ok = false;
         }
         g.grid_ok = ok;
         g.grid_base = ok ? base : 0;
@@ -362,15 +366,22 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
     if (n_block_bits > (1ll << 27)) return fail(h, PISCES_E_UNSUPPORTED, "add_reads: a batch on the device needs a block size of 16 positions or more");
     const size_t map_words = (size_t)((n_block_bits + 31) / 32);
     auto& B = h->bam;   // (the block map and the first-error word of the BAM surface: the same roles)
-    PISCES_HIP_CHECK(h, h->d_prep_map.reserve(map_words * kPrepReplicas + 4 * kPrepReplicas));
+    // the map in kPrepReplicas copies (read_prepare_kernel: a workgroup sets bits in the copy of its index) while that stays small: 8.6 MB at
+    // the default block size of 1000; a small block size would make it hundreds of MB to clear and to fold, so from 32 MB on the copies
+    // alias one map (stride 0: the kernels are the same, the workgroups share the words again)
+    const size_t map_copies = map_words * kPrepReplicas * sizeof(uint32_t) > (32u << 20) ? 1 : (size_t)kPrepReplicas;
+    const size_t map_stride = map_copies == 1 ? 0 : map_words;
+    if (h->prep_map_copies != map_copies) h->prep_map_clean = false;
+    h->prep_map_copies = map_copies;
+    PISCES_HIP_CHECK(h, h->d_prep_map.reserve(map_words * map_copies + 4 * kPrepReplicas));
     PISCES_HIP_CHECK(h, B.d_first_error.reserve(1));
     PISCES_HIP_CHECK(h, B.d_totals64.reserve(8));
     PISCES_HIP_CHECK(h, h->d_found_pool_first.reserve((size_t)nr + 1));
     PISCES_HIP_CHECK(h, h->d_found_totals.reserve(2));
-    int32_t* const d_span = (int32_t*)(h->d_prep_map.p + map_words * kPrepReplicas);   // kPrepReplicas x {lowest key, highest key, lowest position, X / = seen}
+    int32_t* const d_span = (int32_t*)(h->d_prep_map.p + map_words * map_copies);   // kPrepReplicas x {lowest key, highest key, lowest position, X / = seen}
     // (the map is zero outside the span of the last batch that used it: only that span is cleared again, below; first use: all of it)
     if (!h->prep_map_clean) {
-        PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_prep_map.p, 0, map_words * kPrepReplicas * sizeof(uint32_t), h->stream));
+        PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_prep_map.p, 0, map_words * map_copies * sizeof(uint32_t), h->stream));
         h->prep_map_clean = true;
     }
     int32_t span_init[4 * kPrepReplicas];   // ([3]: some read has an X or = operation)
@@ -387,7 +398,7 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
     A.del_dirs = has_deldirs ? d + L.off_deldirs : nullptr;
     A.n_reads = nr; A.min_bq = h->cfg.min_base_call_quality; A.block_size = bs; A.count_indels = count_indels ? 1 : 0;
     A.n_ops_total = (int64_t)n_cig; A.n_bases_total = (int64_t)n_seq;
-    A.block_bits = h->d_prep_map.p; A.n_block_bits = n_block_bits; A.map_stride = (int64_t)map_words;
+    A.block_bits = h->d_prep_map.p; A.n_block_bits = n_block_bits; A.map_stride = (int64_t)map_stride;
     A.n_found = count_indels ? (int32_t*)(d + L.off_fslots) : nullptr;
     A.n_pool = count_indels ? h->d_found_pool_first.p : nullptr;
     A.first_error = B.d_first_error.p;
@@ -408,7 +419,7 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
     if (!h->h_prep) PISCES_HIP_CHECK(h, host_alloc((void**)&h->h_prep, sizeof(PrepVerdict) + (size_t)kPrepKeys * sizeof(int32_t)));
     PrepVerdict* const verdict = (PrepVerdict*)h->h_prep;
     int32_t* const keys = (int32_t*)(h->h_prep + sizeof(PrepVerdict));
-    hipLaunchKernelGGL(prepare_collect_kernel, dim3(1), dim3(256), 0, h->stream, h->d_prep_map.p, (int64_t)map_words, (const int32_t*)d_span, (const unsigned long long*)B.d_first_error.p,
+    hipLaunchKernelGGL(prepare_collect_kernel, dim3(1), dim3(256), 0, h->stream, h->d_prep_map.p, (int64_t)map_stride, (const int32_t*)d_span, (const unsigned long long*)B.d_first_error.p,
                        count_indels ? (const long long*)h->d_found_totals.p : (const long long*)nullptr, verdict, keys, kPrepKeys);
     PISCES_HIP_CHECK(h, hipGetLastError());
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));

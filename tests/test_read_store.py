@@ -940,3 +940,89 @@ def test_bases_of_x_and_eq_operations_are_counts_without_candidates(torch_cuda, 
                                ("candidates merged on the device", dict(PISCES_HIP_DEVICE_MERGE=1), "host"), ("rows merged by copy", dict(PISCES_HIP_MERGE_IN_PLACE=0), "host")]:
         got = run(environ, how)
         assert got[0].tobytes() == want[0].tobytes() and got[1] == want[1] and got[2] == want[2], (mode, name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("how", ["host reads", "device reads"])
+def test_a_first_batch_that_touches_no_block_leaves_the_segment_without_a_grid(torch_cuda, how):
+    """a segment's FIRST batch holds only reads that touch no block (soft clips from end to end), so it leaves no cell of the
+    position grid; the batch that joins the same open segment next must not find a grid whose first cells keep the fill value (a tile
+    there would see an empty fragment range and drop the reads over it).  Records == the log chain's, counts == the oracle's."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(5)
+    ref = np.frombuffer(bytes(rng.choice(list(b"ACGT"), 9000).astype(np.uint8)), dtype=np.uint8)
+    clipped = [{"pos": 5000 + i, "cigar": [("S", 30)], "seq": bytes(rng.choice(list(b"ACGT"), 30).astype(np.uint8)), "quals": [37] * 30,
+                "reverse": bool(i & 1)} for i in range(40)]
+    real = random_reads(rng, 1500, 5100, 6500, with_dirs=False)
+    cfg = _abi.default_config(min_coverage=1, low_depth_filter=1)
+    mode = STORE_MODES["every batch appended to the open segment"]
+
+    def run(environ):
+        with env(**environ):
+            with engine.HipVariantCaller(cfg) as c:
+                c.SetReference(ref)
+                add = c.AddDeviceReads if how == "device reads" else c.AddAlleleCounts
+                add(_abi.ReadBatch(clipped))
+                add(_abi.ReadBatch(real))
+                counts = c.GetCounts(5000, 2000)
+                r, a = c.CallWithAlleles(None, capacity=1 << 14)
+                return r, a, counts, c.Stats()
+    got = run(dict(PISCES_HIP_READ_PATH=None, **mode))
+    with env(PISCES_HIP_READ_PATH="log"):
+        with engine.HipVariantCaller(cfg) as c:
+            c.SetReference(ref)
+            c.AddAlleleCounts(_abi.ReadBatch(clipped))
+            c.AddAlleleCounts(_abi.ReadBatch(real))
+            want_r, want_a = c.CallWithAlleles(None, capacity=1 << 14)
+    exp = oracle_counts(clipped + real, 1, 9000)
+    np.testing.assert_array_equal(got[2].reshape(2000, -1), exp.reshape(9000, -1)[4999:6999])
+    assert len(want_r) > 1000 and got[0].tobytes() == want_r.tobytes() and got[1] == want_a
+
+
+@pytest.mark.gpu
+def test_exact_total_called_is_refused_where_it_cannot_be_counted(torch_cuda):
+    """pisces_hip_set_exact_total_called promises the reference's TotalNumCalled.  A configuration whose flush does not go
+    through the read store's flush kernel (here NoiseModel.Window and the Diploid strand-bias model) cannot run the counting launch over the
+    off-interval loci: the flush fails with PISCES_E_UNSUPPORTED instead of reporting the smaller total; with the switch off it runs."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(3)
+    ref = rng.choice(np.frombuffer(b"ACGT", np.uint8), 2300)
+    reads = [dict(pos=int(s), cigar=[("M", 60)], seq=ref[s - 1:s + 59].tobytes(), quals=bytes([35] * 60), reverse=bool(i & 1))
+             for i, s in enumerate(np.sort(rng.integers(50, 2100, 300)))]
+    for kw in (dict(noise_model=1), dict(strand_bias_model=_abi.SB_DIPLOID)):
+        cfg = _abi.default_config(**kw)
+        for exact in (True, False):
+            with engine.HipVariantCaller(cfg) as c:
+                c.SetReference(ref)
+                c.SetIntervals([(200, 700), (1200, 1500)])
+                c.SetExactTotalNumCalled(exact)
+                c.AddAlleleCounts(_abi.ReadBatch(reads))
+                if exact:
+                    with pytest.raises(engine.PiscesHipError) as e:
+                        c.CallWithAlleles(None)
+                    assert e.value.code == _abi.E_UNSUPPORTED and "exact_total_called" in e.value.message
+                else:
+                    rows, _ = c.CallWithAlleles(None)
+                    assert len(rows) > 0
+
+
+@pytest.mark.gpu
+def test_device_checks_with_a_small_block_size_share_one_block_map(torch_cuda):
+    """read_prepare_kernel's block map is kept in 32 copies while that is small; at a block size of 100 (86 MB of copies) the copies
+    alias one map.  Device-fed reads then give the records of host-fed reads, whose blocks the host's own pass over the CIGARs lists."""
+    from pisces_amd import engine
+    rng = np.random.default_rng(12)
+    ref = np.frombuffer(bytes(rng.choice(list(b"ACGT"), 5000).astype(np.uint8)), dtype=np.uint8)
+    reads = random_reads(rng, 1500, 30, 4500, with_dirs=False)
+    cfg = _abi.default_config(min_coverage=1, low_depth_filter=1, block_size=100)
+    out = {}
+    for how in ("host", "device"):
+        with env(PISCES_HIP_READ_PATH=None, PISCES_HIP_DEVICE_CHECKS=0):
+            with engine.HipVariantCaller(cfg) as c:
+                c.SetReference(ref)
+                recs = []
+                for part, up in ((reads[:800], reads[799]["pos"] - 1), (reads[800:], None)):
+                    (c.AddDeviceReads if how == "device" else c.AddAlleleCounts)(_abi.ReadBatch(part))
+                    recs.append(c.CallWithAlleles(up, capacity=1 << 15))
+                out[how] = (np.concatenate([r for r, _ in recs]).tobytes(), [a for _, al in recs for a in al], c.Stats())
+    assert out["host"] == out["device"] and len(out["host"][0]) > 64 * 3000
