@@ -1210,6 +1210,93 @@ __global__ __launch_bounds__(64) void gather_records_kernel(const PiscesCalledAl
     }
 }
 
+
+// The two launches above as ONE (large launches: the flush of many blocks, the device-resident surface): a workgroup takes sixteen tiles,
+// publishes the number of their records, finds the records of all tiles before its own by a decoupled look-back over the workgroups'
+// words (64 predecessors a round; a word = launch epoch << 34 | status << 32 | count, so words of earlier launches read as "not yet" and
+// nothing is cleared between launches), and copies its tiles' valid slots to their final places, a wave four tiles.  Workgroups are
+// dispatched in index order and wait for lower indices only.  The last workgroup writes the totals.
+constexpr int kCompactTiles = 16;
+__global__ __launch_bounds__(256) void compact_records_kernel(const PiscesCalledAllele* __restrict__ records, const PiscesTileResult* __restrict__ tr, int32_t n_tiles,
+                                                              unsigned long long* __restrict__ state, uint32_t epoch, PiscesCalledAllele* __restrict__ out, int32_t capacity,
+                                                              int32_t* __restrict__ total, int32_t* __restrict__ called_out /* optional */, int32_t* __restrict__ offsets /* optional */)
+{
+    __shared__ int s_excl, s_tile[kCompactTiles];
+    const int b = (int)blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t0 = b * kCompactTiles;
+    const unsigned long long tag = (unsigned long long)epoch << 34;
+    if (wave == 0) {
+        const int t = t0 + lane;
+        const int v = (lane < kCompactTiles && t < n_tiles) ? tr[t].n_records : 0;
+        int x = v;   // inclusive scan over the workgroup's tiles
+#pragma unroll
+        for (int d = 1; d < kCompactTiles; d <<= 1) {
+            const int y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        const int agg = __shfl(x, kCompactTiles - 1, 64);
+        if (lane < kCompactTiles) s_tile[lane] = x - v;
+        long long excl = 0;
+        if (b == 0) {
+            if (lane == 0) __hip_atomic_store(&state[0], tag | (2ull << 32) | (unsigned long long)(unsigned)agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(&state[b], tag | (1ull << 32) | (unsigned long long)(unsigned)agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int base = b - 1;
+            for (;;) {
+                const int idx = base - lane;
+                unsigned long long w = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (tag | (2ull << 32));
+                const int status = (w >> 34) == (unsigned long long)epoch ? (int)((w >> 32) & 3ull) : 0;
+                const unsigned long long none = __ballot(status == 0), incl = __ballot(status == 2);
+                const int first_incl = incl ? __builtin_ctzll(incl) : 64;
+                const unsigned long long upto = first_incl >= 63 ? ~0ull : ((2ull << first_incl) - 1ull);
+                if (none & upto) { __builtin_amdgcn_s_sleep(1); continue; }
+                int f = lane <= first_incl ? (int)(uint32_t)w : 0;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) f += __shfl_xor(f, d, 64);
+                excl += f;
+                if (first_incl < 64) break;
+                base -= 64;
+            }
+            if (lane == 0) __hip_atomic_store(&state[b], tag | (2ull << 32) | (unsigned long long)(unsigned)(excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            s_excl = (int)excl;
+            if (b == (int)gridDim.x - 1) *total = (int)excl + agg;
+        }
+    }
+    if (called_out && b == (int)gridDim.x - 1 && wave == 1) {   // IAlleleCaller.TotalNumCalled of the launch (the tiles' own counts: no other workgroup is waited for)
+        int called = 0;
+        for (int i = lane; i < n_tiles; i += 64) called += tr[i].n_called;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) called += __shfl_xor(called, d, 64);
+        if (lane == 0) *called_out = called;
+    }
+    __syncthreads();
+    const int excl = s_excl;
+#pragma unroll 1
+    for (int k = 0; k < kCompactTiles / 4; k++) {
+        const int j = wave * (kCompactTiles / 4) + k, t = t0 + j;
+        if (t >= n_tiles) break;
+        const int at = excl + s_tile[j];
+        if (offsets && lane == 0) offsets[t] = at;
+        const uint32_t nib = (tr[t].valid[lane >> 3] >> ((lane & 7) * 4)) & 0xFu;
+        int x = __popc(nib);
+        const int mine = x;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        int64_t dst = (int64_t)at + (x - mine);
+        const PiscesCalledAllele* src = records + (int64_t)tr[t].record_begin + lane * 4;
+        for (int q = 0; q < 4; q++) {
+            if (!(nib & (1u << q))) continue;
+            if (dst < capacity) copy_record(&out[dst], &src[q]);
+            dst++;
+        }
+    }
+}
+
 }  // namespace pisces
 
 // ==========================================================================================

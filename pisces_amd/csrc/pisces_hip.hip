@@ -304,7 +304,7 @@ struct PiscesHip {
     bool tables_shareable = false;            // the memo tables are the default ones of the configuration: they outlive the handle (table_cache)
     bool poisoned = false;                    // the deferred half of a batch's candidate discovery failed after the batch was committed (finish_candidate_discovery)
     std::string poison_why;
-    uint8_t* h_prep = nullptr;                // pinned: prepare_collect_kernel's PrepVerdict + the keys of the touched blocks
+    uint8_t* h_prep = nullptr;                // pinned: add_fused_kernel's PrepVerdict + the keys of the touched blocks
     DeviceBuf<double> d_qlut;
     DeviceBuf<ulonglong2> d_bq_lut;   // [256] Math.Pow(10, -1 * (int)q / 10f) in fixed point (two 38-bit halves): what a base of quality q adds to the sums
     DeviceBuf<unsigned long long> d_sumq_fix;   // the cells' fixed-point accumulators (accumulate_tiles_kernel)
@@ -553,10 +553,12 @@ struct PiscesHip {
     DeviceBuf<long long> d_scan_sums;         // block sums of launch_found_scan
     bool device_genotyper = true;             // PISCES_HIP_DEVICE_GENOTYPER=0: diploid / haploid genotypes are always the host pass of the flush (the A / B of the tests)
     bool merge_in_place = true;               // PISCES_HIP_MERGE_IN_PLACE=0: the candidate kernel's rows and the tile kernels' are merged into a vector of their own (the A / B of the tests)
-    int device_checks = -1;                   // PISCES_HIP_DEVICE_CHECKS: 1 every host batch is checked on the device (read_prepare_kernel), 0 none, -1 (default) from 65 536 reads up
-    bool prep_map_clean = false;              // the block map of read_prepare_kernel is all zero
+    int device_checks = -1;                   // PISCES_HIP_DEVICE_CHECKS: 1 every host batch is checked on the device (add_fused_kernel), 0 none, -1 (default) from 65 536 reads up
+    bool prep_map_clean = false;              // the block map of add_fused_kernel is all zero
     size_t prep_map_copies = 0;               // copies the map is kept in (kPrepReplicas, or 1 when a small block size makes it large)
     DeviceBuf<uint32_t> d_prep_map;
+    DeviceBuf<uint8_t> d_fused_words;         // add_fused_kernel's shared words (spans, first error, workgroups through, totals): set once, left clean by every launch
+    DeviceBuf<unsigned long long> d_fused_scan;   // its look-back words, zero between launches
 
     // device scratch, grow-only
     DeviceBuf<uint32_t> d_tuples;
@@ -1076,7 +1078,7 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     h->found.h_totals = nullptr;
     h->d_found.release(); h->d_found_pool.release(); h->d_found_slots.release(); h->d_found_pool_first.release();
     h->d_merge_tab.release(); h->d_merge_acc.release();
-    h->d_scan_sums.release(); h->d_prep_map.release(); h->d_folded.release(); h->d_span_tiles.release();
+    h->d_scan_sums.release(); h->d_prep_map.release(); h->d_fused_words.release(); h->d_fused_scan.release(); h->d_folded.release(); h->d_span_tiles.release();
     h->d_snv[0].release(); h->d_snv[1].release(); h->d_snv_n.release(); h->d_snv_sel.release(); h->d_dirty.release(); h->d_row_idx.release(); h->d_rows.release();
     if (h->h_totals) host_free(h->h_totals);
     if (h->h_cnt_x) host_free(h->h_cnt_x);

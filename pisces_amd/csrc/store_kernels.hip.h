@@ -197,18 +197,14 @@ __device__ __forceinline__ void grid_cells(const ShapeArgs& A, int block)
     }
 }
 
-__global__ __launch_bounds__(256) void read_shape_kernel(ShapeArgs A)
+// the shape role: reads [256 block, 256 block + 256), one lane each; `ok` false: the lane's read is not to be walked (refused by the checks
+// made in the same lane just before, add_fused_kernel)
+__device__ __forceinline__ void shape_reads(const ShapeArgs& A, const int block, const bool ok)
 {
-    if ((int)blockIdx.x >= A.shape_blocks) {
-        const int b = (int)blockIdx.x - A.shape_blocks;
-        if (b < A.enc_blocks) encode_rows(A, b, A.enc_blocks);
-        else grid_cells(A, b - A.enc_blocks);
-        return;
-    }
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = block * 256 + (int)threadIdx.x;
     int reach = 0;
     bool unsorted = false, complex_read = false, generic_read = false, has_del = false;
-    if (r < A.n_reads) {
+    if (r < A.n_reads && ok) {
         const int c0 = A.cigar_offset[r], nc = A.cigar_offset[r + 1] - c0;
         const int s0 = A.seq_offset[r], n = A.seq_offset[r + 1] - s0;
         const int32_t pos0 = A.position[r];
@@ -342,6 +338,16 @@ __global__ __launch_bounds__(256) void read_shape_kernel(ShapeArgs A)
         if (frag_bits & ~A.state[kStateFrags]) atomicOr(&A.state[kStateFrags], frag_bits);
     }
 }
+__global__ __launch_bounds__(256) void read_shape_kernel(ShapeArgs A)
+{
+    if ((int)blockIdx.x >= A.shape_blocks) {
+        const int b = (int)blockIdx.x - A.shape_blocks;
+        if (b < A.enc_blocks) encode_rows(A, b, A.enc_blocks);
+        else grid_cells(A, b - A.enc_blocks);
+        return;
+    }
+    shape_reads(A, (int)blockIdx.x, true);
+}
 
 // What pisces_hip_add_reads takes from a pass over the reads' CIGARs, for a batch that is in device memory (a batch handed over there,
 // pisces_hip_add_device_reads, or a large host batch behind its upload): the argument checks of the reference's walk (Read.ValidateCigar,
@@ -369,13 +375,13 @@ struct PrepareArgs {
 };
 // Every wave of the launch starts with the same few words to set (reads come in position order: one or two block keys, one span), and an
 // atomic on ONE address costs ~15 ns however many XCDs ask: 3 128 waves of a 200 000-read batch spent 47 us on them.  The words are
-// kept in kPrepReplicas copies, a workgroup writes the copy of its index, prepare_collect_kernel folds the copies.
+// kept in kPrepReplicas copies, a workgroup writes the copy of its index, prepare_collect folds the copies.
 constexpr int kPrepReplicas = 32;
 // bits [a, b] of the block map; a bit that is set already (seen through a load that goes past this XCD's L2, where a stale line would
 // show zero for the rest of the launch) costs no atomic: same-address atomics from eight XCDs serialise at 0.1-0.2 us each
 __device__ __forceinline__ void set_keys(const PrepareArgs& A, int64_t a, int64_t b)
 {
-    uint32_t* const map = A.block_bits + (int64_t)(blockIdx.x & (kPrepReplicas - 1)) * A.map_stride;
+    uint32_t* const map = A.block_bits + (int64_t)(blockIdx.x & (kPrepReplicas - 1)) * A.map_stride;   // (any copy will do: the launch's workgroup index)
     for (int64_t k = a; k <= b; k++) {
         if (k >= A.n_block_bits) continue;   // (cannot be: the map covers every int32 position)
         const uint32_t bit = 1u << (k & 31);
@@ -389,7 +395,9 @@ __device__ __forceinline__ long long prep_shfl64(long long v, int src_lane)
     const int hi = __shfl((int)(v >> 32), src_lane, 64);
     return ((long long)hi << 32) | (unsigned int)lo;
 }
-__global__ __launch_bounds__(256) void read_prepare_kernel(PrepareArgs A)
+// (a role of add_fused_kernel's launch, below; found_out / pool_out: the lane's read's candidate-record slots and pool bytes, 0 for a refused
+// read; ok_out: the lane holds a read that passed every check — only then may its CIGAR be walked again, read_shape)
+__device__ __forceinline__ void prepare_reads(const PrepareArgs& A, const int block, int& found_out, int& pool_out, bool& ok_out)
 {
     // what the workgroup's waves found goes through LDS first: one lane of the workgroup touches the shared words (their loads go past the
     // XCD's L2 and queue on one memory channel when every wave of a large batch asks: 68 us for 500 000 reads before)
@@ -398,7 +406,9 @@ __global__ __launch_bounds__(256) void read_prepare_kernel(PrepareArgs A)
     __shared__ long long s_run_a[kRunSlots], s_run_b[kRunSlots];
     if (threadIdx.x == 0) { s_klo = 0x7FFFFFFF; s_khi = 0; s_plo = 0x7FFFFFFF; s_eqx = 0; s_nruns = 0; }
     __syncthreads();
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = block * 256 + (int)threadIdx.x;
+    found_out = pool_out = 0;
+    ok_out = false;
     int k_lo = 0x7FFFFFFF, k_hi = 0, p_lo = 0x7FFFFFFF;
     int64_t run_a = 1, run_b = 0;   // the run of keys this read touches (empty)
     bool eqx = false;               // an X or = operation (MNV calling off: candidate discovery then walks them, surface_reads.inc.h)
@@ -476,7 +486,9 @@ __global__ __launch_bounds__(256) void read_prepare_kernel(PrepareArgs A)
                 }
             }
         }
-        if (A.n_found) { A.n_found[r] = code ? 0 : found; A.n_pool[r] = code ? 0 : pool; }
+        found_out = code ? 0 : found;
+        pool_out = code ? 0 : pool;
+        ok_out = code == 0;
         if (code) atomicMin(A.first_error, (unsigned long long)r * 8ull + (unsigned long long)code);
     }
     {   // the lanes' runs, each distinct one set by one lane (reads come in position order: a wave holds one or two)
@@ -516,7 +528,7 @@ __global__ __launch_bounds__(256) void read_prepare_kernel(PrepareArgs A)
         }
     }
     if (threadIdx.x == 0) {
-        int32_t* const span = A.key_span + 4 * (int)(blockIdx.x & (kPrepReplicas - 1));
+        int32_t* const span = A.key_span + 4 * (int)(block & (kPrepReplicas - 1));
         const int v0 = __hip_atomic_load(&span[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), v1 = __hip_atomic_load(&span[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                   v2 = __hip_atomic_load(&span[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), v3 = __hip_atomic_load(&span[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (s_plo < v2) atomicMin(&span[2], s_plo);
@@ -527,15 +539,7 @@ __global__ __launch_bounds__(256) void read_prepare_kernel(PrepareArgs A)
         }
     }
 }
-// per-base directions: a value that is no DirectionType makes the batch unusable (add_reads: "CIGAR does not match the read")
-__global__ __launch_bounds__(256) void check_directions_kernel(const uint8_t* __restrict__ dirs, int64_t n, unsigned long long* __restrict__ first_error)
-{
-    bool bad = false;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) bad = bad || dirs[i] > 2;
-    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicMin(first_error, (unsigned long long)kPrepBadDirection);
-}
-
-// What the host needs of read_prepare_kernel's results, into pinned host memory as this kernel's own stores (one wait, no copy operations):
+// What the host needs of prepare_reads' results, into pinned host memory as the launch's own stores (one wait, no copy operations):
 // the verdict, the span of touched blocks, the totals of the candidate-record slots, and the keys of the touched blocks (any order) — whose
 // bits are cleared here for the next batch.  More touched blocks than `capacity`: nothing is cleared, the host reads the map's words itself.
 struct PrepVerdict {
@@ -547,9 +551,10 @@ struct PrepVerdict {
     int32_t pad;
 };
 static_assert(sizeof(PrepVerdict) == 48, "PrepVerdict layout");
-__global__ __launch_bounds__(256) void prepare_collect_kernel(uint32_t* __restrict__ block_bits, int64_t map_stride, const int32_t* __restrict__ key_span,
-                                                              const unsigned long long* __restrict__ first_error, const long long* __restrict__ totals /* or nullptr */,
-                                                              PrepVerdict* __restrict__ out, int32_t* __restrict__ keys_out, int32_t capacity)
+// (run by the workgroup of add_fused_kernel's read role that finishes last, behind an agent-scope fence: every other workgroup's words are in)
+__device__ __forceinline__ void prepare_collect(uint32_t* __restrict__ block_bits, int64_t map_stride, int32_t* __restrict__ key_span,
+                                                unsigned long long* __restrict__ first_error, const long long* __restrict__ totals /* or nullptr */,
+                                                PrepVerdict* __restrict__ out, int32_t* __restrict__ keys_out, int32_t capacity)
 {
     __shared__ int s_n, s_at, s_span[4];
     if (threadIdx.x == 0) { s_n = 0; s_at = 0; s_span[0] = 0x7FFFFFFF; s_span[1] = 0; s_span[2] = 0x7FFFFFFF; s_span[3] = 0; }
@@ -599,6 +604,187 @@ __global__ __launch_bounds__(256) void prepare_collect_kernel(uint32_t* __restri
     }
 }
 
+// the small arrays of a batch handed over in device memory, copied into the store's layout by add_fused_kernel's misc role: sixteen bytes
+// a lane at any alignment of source and destination (gfx950 runs with unaligned global access enabled)
+struct CopyRanges16 {
+    uint8_t* dst[10];
+    const uint8_t* src[10];
+    int64_t n[10];
+};
+// ---- ONE LAUNCH PER ADD of a batch that lies in device memory (pisces_hip_add_device_reads, or a large host batch behind its upload) ----
+// What used to be seven launches and three memsets (ranges_copy16 | read_prepare | check_directions | scan_block_sums | scan_block_offsets |
+// scan_apply | prepare_collect, then read_shape behind the host's wait) — four streaming passes over the batch — is one launch that reads
+// the batch ONCE.  Roles by workgroup index:
+//   [0, read_blocks)            one lane a read: the checks and the bookkeeping (prepare_reads), the candidate-record slots scanned in the
+//                               same launch (a decoupled look-back over the workgroups' sums: no scan kernels), and — a batch that becomes
+//                               a segment of its own — descriptors and fragments from the same lane (shape_reads).  The workgroup that
+//                               finishes last folds the copies of the block map and writes the verdict into pinned host memory
+//                               (prepare_collect), then leaves every shared word as the next launch expects it: no memsets.
+//   [.., + stream_blocks)       bases and qualities (and per-base directions), sixteen bytes a lane: loaded once, stored into the store's
+//                               own arrays (a batch handed over in the caller's memory), encoded into row codes (encode_rows' arithmetic), the directions checked
+//   [.., + misc_blocks)         the batch's small arrays into the store's layout (positions, flags, offsets, CIGARs, deletion directions)
+struct AddFusedArgs {
+    PrepareArgs P;              // (reads the batch where it lies NOW: the caller's arrays when the batch is being copied)
+    ShapeArgs S;                // shape role (do_shape) — reads the same arrays; S.enc_* unused here
+    int32_t do_shape;
+    int32_t read_blocks, stream_blocks, misc_blocks;
+    const uint8_t* s_bases;     // stream role: sources
+    const uint8_t* s_quals;
+    const uint8_t* s_dirs;      // or nullptr
+    uint8_t* d_bases;           // copies (nullptr: the batch is where it stays)
+    uint8_t* d_quals;
+    uint8_t* d_dirs;
+    uint8_t* d_codes;           // row codes (nullptr: made later, read_shape_kernel's encode role)
+    int64_t n_seq;
+    uint32_t enc_min_bq;        // <= 127
+    CopyRanges16 C;             // misc role
+    unsigned long long* scan_state;   // [read_blocks], zero between launches: status << 62 | pool bytes << 31 | records
+    unsigned int* done;               // zero between launches: read workgroups that are through
+    long long* totals;                // [2]: records, pool bytes of the batch
+    PrepVerdict* verdict;             // pinned host memory
+    int32_t* keys_out;
+    int32_t capacity;
+};
+constexpr unsigned long long kScanAggregate = 1ull << 62, kScanInclusive = 2ull << 62, kScanField = 0x7FFFFFFFull;
+
+__global__ __launch_bounds__(256) void add_fused_kernel(AddFusedArgs A)
+{
+    const int b = (int)blockIdx.x;
+    __shared__ int s_wf[4], s_wp[4], s_excl[2], s_last;
+    if (b >= A.read_blocks) {
+        const int sb = b - A.read_blocks;
+        if (sb < A.stream_blocks) {
+            // ---- stream role
+            const uint32_t qk4 = (0x7Fu + A.enc_min_bq) * 0x01010101u;
+            const int64_t n16 = A.n_seq >> 4;
+            bool bad_dir = false;
+            for (int64_t i = (int64_t)sb * 256 + threadIdx.x; i < n16; i += (int64_t)A.stream_blocks * 256) {
+                uint32_t bw[4], qw[4], c[4];
+                __builtin_memcpy(bw, A.s_bases + 16 * i, 16);
+                __builtin_memcpy(qw, A.s_quals + 16 * i, 16);
+                if (A.s_dirs) {
+                    uint32_t dw[4];
+                    __builtin_memcpy(dw, A.s_dirs + 16 * i, 16);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) bad_dir = bad_dir || ((dw[k] + 0x7D7D7D7Du) | dw[k]) & 0x80808080u;   // some byte > 2
+                    if (A.d_dirs) __builtin_memcpy(A.d_dirs + 16 * i, dw, 16);
+                }
+                if (A.d_bases) {
+                    __builtin_memcpy(A.d_bases + 16 * i, bw, 16);
+                    __builtin_memcpy(A.d_quals + 16 * i, qw, 16);
+                }
+                if (A.d_codes) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) c[k] = row_codes_of(bw[k], qw[k], qk4);
+                    __builtin_memcpy(A.d_codes + 16 * i, c, 16);
+                }
+            }
+            if (sb == 0 && (int64_t)threadIdx.x < (A.n_seq & 15)) {   // the last bytes
+                const int64_t i = (n16 << 4) + threadIdx.x;
+                const uint8_t bb = A.s_bases[i], qq = A.s_quals[i];
+                if (A.s_dirs) { const uint8_t dd = A.s_dirs[i]; bad_dir = bad_dir || dd > 2; if (A.d_dirs) A.d_dirs[i] = dd; }
+                if (A.d_bases) { A.d_bases[i] = bb; A.d_quals[i] = qq; }
+                if (A.d_codes) A.d_codes[i] = (uint8_t)row_codes_of(bb, qq, qk4);
+            }
+            if (__ballot(bad_dir) != 0ull && (threadIdx.x & 63) == 0) atomicMin(A.P.first_error, (unsigned long long)kPrepBadDirection);
+        } else {
+            // ---- misc role: the small arrays, sixteen bytes a lane, one range after the other over this role's workgroups
+            const int64_t stride = (int64_t)A.misc_blocks * 256, t = (int64_t)(sb - A.stream_blocks) * 256 + threadIdx.x;
+#pragma unroll 1
+            for (int k = 0; k < 10; k++) {
+                const int64_t n = A.C.n[k], n16 = n >> 4;
+                if (n <= 0) continue;
+                const uint8_t* const src = A.C.src[k];
+                uint8_t* const dst = A.C.dst[k];
+                for (int64_t i = t; i < n16; i += stride) {
+                    uint32_t v[4];
+                    __builtin_memcpy(v, src + 16 * i, 16);
+                    __builtin_memcpy(dst + 16 * i, v, 16);
+                }
+                if (t < (n & 15)) dst[(n16 << 4) + t] = src[(n16 << 4) + t];
+            }
+        }
+    } else {
+    // ---- read role
+    int found, pool;
+    bool ok;
+    prepare_reads(A.P, b, found, pool, ok);
+    if (A.do_shape) shape_reads(A.S, b, ok);
+    // the candidate-record slots: exclusive scan over the batch's reads, in this launch
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl_f = found, incl_p = pool;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int uf = __shfl_up(incl_f, d, 64), up = __shfl_up(incl_p, d, 64);
+        if (lane >= d) { incl_f += uf; incl_p += up; }
+    }
+    if (lane == 63) { s_wf[wave] = incl_f; s_wp[wave] = incl_p; }
+    __syncthreads();
+    int off_f = 0, off_p = 0, agg_f = 0, agg_p = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (w < wave) { off_f += s_wf[w]; off_p += s_wp[w]; }
+        agg_f += s_wf[w]; agg_p += s_wp[w];
+    }
+    if (wave == 0) {
+        const unsigned long long mine = ((unsigned long long)(unsigned)agg_p << 31) | (unsigned long long)(unsigned)agg_f;
+        long long excl_f = 0, excl_p = 0;
+        if (b == 0) {
+            if (lane == 0) __hip_atomic_store(&A.scan_state[0], kScanInclusive | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(&A.scan_state[b], kScanAggregate | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int base = b - 1;   // lane l looks at workgroup base - l
+            for (;;) {
+                const int idx = base - lane;
+                const unsigned long long w = idx >= 0 ? __hip_atomic_load(&A.scan_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kScanInclusive;
+                const unsigned long long none = __ballot((w >> 62) == 0ull), incl = __ballot((w >> 62) == 2ull);
+                const int first_incl = incl ? __builtin_ctzll(incl) : 64;
+                const unsigned long long upto = first_incl >= 63 ? ~0ull : ((2ull << first_incl) - 1ull);   // lanes 0 .. first_incl
+                if (none & upto) { __builtin_amdgcn_s_sleep(1); continue; }   // a workgroup in between has not published yet
+                int f = (lane <= first_incl) ? (int)(w & kScanField) : 0, p = (lane <= first_incl) ? (int)((w >> 31) & kScanField) : 0;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) { f += __shfl_xor(f, d, 64); p += __shfl_xor(p, d, 64); }
+                excl_f += f; excl_p += p;
+                if (first_incl < 64) break;
+                base -= 64;
+            }
+            if (lane == 0)
+                __hip_atomic_store(&A.scan_state[b], kScanInclusive | ((unsigned long long)(excl_p + agg_p) << 31) | (unsigned long long)(excl_f + agg_f), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            s_excl[0] = (int)excl_f; s_excl[1] = (int)excl_p;
+            if (b == A.read_blocks - 1) { A.totals[0] = excl_f + agg_f; A.totals[1] = excl_p + agg_p; }
+        }
+    }
+    __syncthreads();
+    if (A.P.n_found) {
+        const int r = b * 256 + (int)threadIdx.x;
+        if (r < A.P.n_reads) {
+            A.P.n_found[r] = s_excl[0] + off_f + incl_f - found;
+            A.P.n_pool[r] = s_excl[1] + off_p + incl_p - pool;
+        }
+        if (b == A.read_blocks - 1 && threadIdx.x == 0) { A.P.n_found[A.P.n_reads] = s_excl[0] + agg_f; A.P.n_pool[A.P.n_reads] = s_excl[1] + agg_p; }
+    }
+    }
+    // the workgroup of the launch (any role) that is through last collects: every thread's stores are out (fence), then the count
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(A.done, 1u) == gridDim.x - 1u ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    prepare_collect(A.P.block_bits, A.P.map_stride, A.P.key_span, A.P.first_error, A.totals, A.verdict, A.keys_out, A.capacity);
+    __syncthreads();
+    // the shared words as the next launch expects them
+    for (int i = threadIdx.x; i < A.read_blocks; i += 256) A.scan_state[i] = 0ull;
+    if (threadIdx.x < kPrepReplicas) {
+        int32_t* const sp = A.P.key_span + 4 * threadIdx.x;
+        sp[0] = 0x7FFFFFFF; sp[1] = 0; sp[2] = 0x7FFFFFFF; sp[3] = 0;
+    }
+    if (threadIdx.x == 0) { *A.done = 0u; *A.P.first_error = ~0ull; }
+}
+
 // small batches: their bytes join the open segment (up to five ranges in one launch; byte-wise: destinations are not aligned)
 struct CopyRanges {
     uint8_t* dst[5];
@@ -611,32 +797,6 @@ __global__ __launch_bounds__(256) void segment_copy_kernel(CopyRanges C)
 #pragma unroll
     for (int k = 0; k < 5; k++)
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < C.n[k]; i += stride) C.dst[k][i] = C.src[k][i];
-}
-
-// A batch handed over in device memory (pisces_hip_add_device_reads): its arrays copied into the store's layout by ONE launch — sixteen
-// bytes a lane at any alignment of source and destination (gfx950 runs with unaligned global access enabled), the ranges one after the
-// other over the whole grid.  (Ten hipMemcpyAsync cost ten stream operations: ~95 us for a batch of 500 000 reads, ~40 for one of 3 000.)
-struct CopyRanges16 {
-    uint8_t* dst[10];
-    const uint8_t* src[10];
-    int64_t n[10];
-};
-__global__ __launch_bounds__(256) void ranges_copy16_kernel(CopyRanges16 C)
-{
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-#pragma unroll 1
-    for (int k = 0; k < 10; k++) {
-        const int64_t n = C.n[k], n16 = n >> 4;
-        if (n <= 0) continue;
-        const uint8_t* const src = C.src[k];
-        uint8_t* const dst = C.dst[k];
-        for (int64_t i = t; i < n16; i += stride) {
-            uint32_t v[4];
-            __builtin_memcpy(v, src + 16 * i, 16);
-            __builtin_memcpy(dst + 16 * i, v, 16);
-        }
-        if (t < (n & 15)) dst[(n16 << 4) + t] = src[(n16 << 4) + t];
-    }
 }
 
 // per-base directions of reads [r0, r1) of a segment from their flags: a batch without directions joining a segment that tracks them,

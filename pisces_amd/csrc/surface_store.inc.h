@@ -242,8 +242,11 @@ struct StoreBatchArrays {
     const uint8_t* quals;
     const uint8_t* dirs;   // or nullptr
 };
-static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const StoreBatchArrays& A, int32_t nr, size_t n_cig, size_t n_seq,
-                                   int32_t min_position = 0 /* lowest read position of the batch, 0 = unknown */, int32_t max_key = 0 /* highest block a read touches */)
+// Two halves.  store_shape_begin: room in the segment (and, for a batch that joins the open segment, its bytes copied there), the arguments of
+// the shape / row-code roles filled in.  store_shape_launch: the position grid sized from what the checks reported, then read_shape_kernel
+// with the roles that are still to run (`shaped`: descriptors, fragments and row codes were made by add_fused_kernel already — the grid
+// role alone is left).  store_append_arrays is both in turn.
+static int32_t store_shape_begin(PiscesHip* h, const StorePlace& pl, const StoreBatchArrays& A, int32_t nr, size_t n_cig, size_t n_seq, ShapeArgs* S_out)
 {
     ReadSegment& g = *pl.seg;
     if (g.n_reads + nr > 0x7FFFFF00ll || g.n_ops + (int64_t)n_cig > 0x7FFFFF00ll) return fail(h, PISCES_E_INVALID_ARG, "add_reads: too many reads held at once");
@@ -315,6 +318,13 @@ static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const Sto
     S.enc_blocks = (int32_t)std::min<int64_t>(((int64_t)n_seq + 16 * 256 - 1) / (16 * 256), 8192);
     S.grid = nullptr;
     S.grid_base = S.grid_n = 0;
+    *S_out = S;
+    return PISCES_OK;
+}
+static int32_t store_shape_launch(PiscesHip* h, const StorePlace& pl, ShapeArgs S, bool batch_has_dirs, int32_t nr, size_t n_cig, int32_t min_position, int32_t max_key, bool shaped)
+{
+    ReadSegment& g = *pl.seg;
+    if (shaped) S.shape_blocks = S.enc_blocks = 0;
     {   // the position grid (what gives a tile its fragment range): extended over the batch's span, or given up for this segment
         const bool first = g.n_reads == 0;
         bool ok = min_position > 0 && (first || g.grid_ok);
@@ -341,93 +351,143 @@ static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const Sto
         g.grid_n = ok ? cells : 0;
         if (ok) { S.grid = g.grid.p; S.grid_base = (int32_t)base; S.grid_n = (int32_t)cells; }
     }
-    const unsigned grid_blocks = S.grid ? (unsigned)S.shape_blocks : 0u;
-    hipLaunchKernelGGL(read_shape_kernel, dim3((unsigned)S.shape_blocks + (unsigned)S.enc_blocks + grid_blocks), dim3(256), 0, h->stream, S);
-    if (!pl.direct && !A.dirs && g.v_dirs)   // a batch without directions in a segment that tracks them
+    const unsigned grid_blocks = S.grid ? (unsigned)((nr + 255) / 256) : 0u;
+    const unsigned n_blocks = (unsigned)S.shape_blocks + (unsigned)S.enc_blocks + grid_blocks;
+    if (n_blocks) hipLaunchKernelGGL(read_shape_kernel, dim3(n_blocks), dim3(256), 0, h->stream, S);
+    if (!pl.direct && !batch_has_dirs && g.v_dirs)   // a batch without directions in a segment that tracks them
         hipLaunchKernelGGL(segment_fill_dirs_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, h->stream, (const ReadDesc*)g.desc.p,
                            (const ReadExt*)g.ext.p, S.n0, S.n0 + nr, const_cast<uint8_t*>(g.v_dirs));
     PISCES_HIP_CHECK(h, hipGetLastError());
     return PISCES_OK;
 }
+static int32_t store_append_arrays(PiscesHip* h, const StorePlace& pl, const StoreBatchArrays& A, int32_t nr, size_t n_cig, size_t n_seq,
+                                   int32_t min_position = 0 /* lowest read position of the batch, 0 = unknown */, int32_t max_key = 0 /* highest block a read touches */)
+{
+    ShapeArgs S;
+    { int32_t rc = store_shape_begin(h, pl, A, nr, n_cig, n_seq, &S); if (rc) return rc; }
+    return store_shape_launch(h, pl, S, A.dirs != nullptr, nr, n_cig, min_position, max_key, false);
+}
 
-// The checks and the bookkeeping of a batch whose arrays lie on the device at d (laid out by L), made THERE (read_prepare_kernel): what
-// add_reads_store's host pass over the CIGARs makes for a batch that came from the host.  Two small waits (the verdict and the span of
-// touched blocks; then that span's bits).  found_slots / found_pool: the candidate-record slots (MNV calling off), scanned in place at
-// d + L.off_fslots.
+// The checks and the bookkeeping of a batch that lies in device memory, made THERE, in ONE launch (add_fused_kernel, store_kernels.hip.h):
+// what add_reads_store's host pass over the CIGARs makes for a batch that came from the host.  `src` (or nullptr): the caller's device
+// arrays — the launch then also copies them into the store's layout at d (laid out by L), reading bases and qualities once; otherwise the
+// batch lies at d already (a host batch behind its upload).  `shape` (or nullptr; a batch that becomes a segment of its own): descriptors,
+// fragments and row codes are made by the same launch (store_shape_begin filled the arguments).  One wait: the verdict, the span, the
+// totals and the touched blocks arrive in pinned memory as the launch's own stores.  found_slots / found_pool: the candidate-record slots
+// (MNV calling off), scanned by the launch itself, at d + L.off_fslots.
 static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& L, int32_t nr, size_t n_cig, size_t n_seq, bool has_dirs, bool has_deldirs,
-                                   bool count_indels, int64_t* found_slots, int64_t* found_pool, std::vector<int32_t>& touched, int32_t* max_key, int32_t* min_position)
+                                   bool count_indels, int64_t* found_slots, int64_t* found_pool, std::vector<int32_t>& touched, int32_t* max_key, int32_t* min_position,
+                                   const PiscesReadBatch* src = nullptr, const ShapeArgs* shape = nullptr)
 {
     *found_slots = *found_pool = 0;
     *max_key = 0;
     *min_position = 0;
     touched.clear();
+    if (nr <= 0) return PISCES_OK;
     const int32_t bs = h->cfg.block_size;
     const int64_t n_block_bits = (0x7FFFFFFFll + bs - 1) / bs + 2;
     if (n_block_bits > (1ll << 27)) return fail(h, PISCES_E_UNSUPPORTED, "add_reads: a batch on the device needs a block size of 16 positions or more");
     const size_t map_words = (size_t)((n_block_bits + 31) / 32);
-    auto& B = h->bam;   // (the block map and the first-error word of the BAM surface: the same roles)
-    // the map in kPrepReplicas copies (read_prepare_kernel: a workgroup sets bits in the copy of its index) while that stays small: 8.6 MB at
+    // the map in kPrepReplicas copies (prepare_reads: a workgroup sets bits in the copy of its index) while that stays small: 8.6 MB at
     // the default block size of 1000; a small block size would make it hundreds of MB to clear and to fold, so from 32 MB on the copies
     // alias one map (stride 0: the kernels are the same, the workgroups share the words again)
     const size_t map_copies = map_words * kPrepReplicas * sizeof(uint32_t) > (32u << 20) ? 1 : (size_t)kPrepReplicas;
     const size_t map_stride = map_copies == 1 ? 0 : map_words;
     if (h->prep_map_copies != map_copies) h->prep_map_clean = false;
     h->prep_map_copies = map_copies;
-    PISCES_HIP_CHECK(h, h->d_prep_map.reserve(map_words * map_copies + 4 * kPrepReplicas));
-    PISCES_HIP_CHECK(h, B.d_first_error.reserve(1));
-    PISCES_HIP_CHECK(h, B.d_totals64.reserve(8));
+    { const size_t before = h->d_prep_map.cap; PISCES_HIP_CHECK(h, h->d_prep_map.reserve(map_words * map_copies)); if (h->d_prep_map.cap != before) h->prep_map_clean = false; }
     PISCES_HIP_CHECK(h, h->d_found_pool_first.reserve((size_t)nr + 1));
-    PISCES_HIP_CHECK(h, h->d_found_totals.reserve(2));
-    int32_t* const d_span = (int32_t*)(h->d_prep_map.p + map_words * map_copies);   // kPrepReplicas x {lowest key, highest key, lowest position, X / = seen}
-    // (the map is zero outside the span of the last batch that used it: only that span is cleared again, below; first use: all of it)
+    // (the map is zero outside the span of the last batch that used it, and the collecting workgroup clears that: first use: all of it)
     if (!h->prep_map_clean) {
         PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_prep_map.p, 0, map_words * map_copies * sizeof(uint32_t), h->stream));
         h->prep_map_clean = true;
     }
-    int32_t span_init[4 * kPrepReplicas];   // ([3]: some read has an X or = operation)
-    for (int r = 0; r < kPrepReplicas; r++) { span_init[4 * r] = 0x7FFFFFFF; span_init[4 * r + 1] = 0; span_init[4 * r + 2] = 0x7FFFFFFF; span_init[4 * r + 3] = 0; }
-    { int32_t rcu = meta_upload(h, d_span, span_init, sizeof(span_init)); if (rcu) return rcu; }
-    PISCES_HIP_CHECK(h, hipMemsetAsync(B.d_first_error.p, 0xFF, sizeof(unsigned long long), h->stream));
-    PrepareArgs A;
-    A.position = (const int32_t*)(d + L.off_pos);
-    A.cigar_offset = (const int32_t*)(d + L.off_coff);
-    A.cigar_op = d + L.off_cop;
-    A.cigar_len = (const uint32_t*)(d + L.off_clen);
-    A.seq_offset = (const int32_t*)(d + L.off_soff);
-    A.quals = d + L.off_quals;
-    A.del_dirs = has_deldirs ? d + L.off_deldirs : nullptr;
+    // the launch's shared words — kPrepReplicas x {lowest key, highest key, lowest position, X / = seen}, the first-error word, the count of
+    // workgroups that are through, the totals — are set once: the collecting workgroup of every launch leaves them as the next one expects
+    constexpr size_t kWordsSpan = 0, kWordsError = 4 * kPrepReplicas * sizeof(int32_t), kWordsDone = kWordsError + 8, kWordsTotals = kWordsDone + 8, kWordsBytes = kWordsTotals + 16;
+    if (!h->d_fused_words.p) {
+        PISCES_HIP_CHECK(h, h->d_fused_words.reserve(kWordsBytes));
+        uint8_t init[kWordsBytes];
+        std::memset(init, 0, sizeof(init));
+        int32_t* sp = (int32_t*)init;
+        for (int r = 0; r < kPrepReplicas; r++) { sp[4 * r] = 0x7FFFFFFF; sp[4 * r + 1] = 0; sp[4 * r + 2] = 0x7FFFFFFF; sp[4 * r + 3] = 0; }
+        std::memset(init + kWordsError, 0xFF, 8);
+        { int32_t rcu = meta_upload(h, h->d_fused_words.p, init, sizeof(init)); if (rcu) return rcu; }
+    }
+    const int32_t read_blocks = (nr + 255) / 256;
+    {   // the look-back's words: zero between launches (cleared by the collecting workgroup); a new buffer starts zeroed
+        const size_t before = h->d_fused_scan.cap;
+        PISCES_HIP_CHECK(h, h->d_fused_scan.reserve((size_t)read_blocks + 1));
+        if (h->d_fused_scan.cap != before) PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_fused_scan.p, 0, h->d_fused_scan.cap * sizeof(unsigned long long), h->stream));
+    }
+    constexpr int32_t kPrepKeys = 8192;
+    if (!h->h_prep) PISCES_HIP_CHECK(h, host_alloc((void**)&h->h_prep, sizeof(PrepVerdict) + (size_t)kPrepKeys * sizeof(int32_t)));
+    PrepVerdict* const verdict = (PrepVerdict*)h->h_prep;
+    int32_t* const keys = (int32_t*)(h->h_prep + sizeof(PrepVerdict));
+    AddFusedArgs F;
+    std::memset(&F, 0, sizeof(F));
+    PrepareArgs& A = F.P;
+    // (the checks read the batch where it lies when the launch starts: the caller's arrays while the copy is being made)
+    A.position = src ? src->position : (const int32_t*)(d + L.off_pos);
+    A.cigar_offset = src ? src->cigar_offset : (const int32_t*)(d + L.off_coff);
+    A.cigar_op = src ? src->cigar_op : d + L.off_cop;
+    A.cigar_len = src ? src->cigar_len : (const uint32_t*)(d + L.off_clen);
+    A.seq_offset = src ? src->seq_offset : (const int32_t*)(d + L.off_soff);
+    A.quals = src ? src->quals : d + L.off_quals;
+    A.del_dirs = has_deldirs ? (src ? src->deletion_directions : d + L.off_deldirs) : nullptr;
     A.n_reads = nr; A.min_bq = h->cfg.min_base_call_quality; A.block_size = bs; A.count_indels = count_indels ? 1 : 0;
     A.n_ops_total = (int64_t)n_cig; A.n_bases_total = (int64_t)n_seq;
     A.block_bits = h->d_prep_map.p; A.n_block_bits = n_block_bits; A.map_stride = (int64_t)map_stride;
     A.n_found = count_indels ? (int32_t*)(d + L.off_fslots) : nullptr;
     A.n_pool = count_indels ? h->d_found_pool_first.p : nullptr;
-    A.first_error = B.d_first_error.p;
-    A.key_span = d_span;
-    if (count_indels) {
-        PISCES_HIP_CHECK(h, hipMemsetAsync(d + L.off_fslots + (size_t)nr * 4, 0, sizeof(int32_t), h->stream));
-        PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_found_pool_first.p + nr, 0, sizeof(int32_t), h->stream));
+    A.first_error = (unsigned long long*)(h->d_fused_words.p + kWordsError);
+    A.key_span = (int32_t*)(h->d_fused_words.p + kWordsSpan);
+    if (shape) {
+        F.S = *shape;
+        F.do_shape = 1;
+        if (src) {   // (the shape role walks the same arrays as the checks)
+            F.S.position = src->position; F.S.flags = src->flags; F.S.cigar_offset = src->cigar_offset; F.S.cigar_op = src->cigar_op; F.S.cigar_len = src->cigar_len;
+            F.S.seq_offset = src->seq_offset; F.S.quals = src->quals; F.S.dirs = has_dirs ? src->directions : nullptr;
+        }
+        F.d_codes = shape->enc_codes;
     }
-    hipLaunchKernelGGL(read_prepare_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, h->stream, A);
-    if (has_dirs && n_seq > 0)
-        hipLaunchKernelGGL(check_directions_kernel, dim3((unsigned)std::min<size_t>((n_seq + 255) / 256, 4096)), dim3(256), 0, h->stream,
-                           (const uint8_t*)(d + L.off_dirs), (int64_t)n_seq, B.d_first_error.p);
-    if (count_indels)
-        { int32_t rcs = launch_found_scan(h, (int32_t*)(d + L.off_fslots), h->d_found_pool_first.p, nr + 1, h->d_found_totals.p); if (rcs) return rcs; }
-    PISCES_HIP_CHECK(h, hipGetLastError());
-    // verdict, span, totals and the touched blocks arrive in pinned memory as one kernel's stores: one wait
-    constexpr int32_t kPrepKeys = 8192;
-    if (!h->h_prep) PISCES_HIP_CHECK(h, host_alloc((void**)&h->h_prep, sizeof(PrepVerdict) + (size_t)kPrepKeys * sizeof(int32_t)));
-    PrepVerdict* const verdict = (PrepVerdict*)h->h_prep;
-    int32_t* const keys = (int32_t*)(h->h_prep + sizeof(PrepVerdict));
-    hipLaunchKernelGGL(prepare_collect_kernel, dim3(1), dim3(256), 0, h->stream, h->d_prep_map.p, (int64_t)map_stride, (const int32_t*)d_span, (const unsigned long long*)B.d_first_error.p,
-                       count_indels ? (const long long*)h->d_found_totals.p : (const long long*)nullptr, verdict, keys, kPrepKeys);
+    F.s_bases = src ? src->bases : d + L.off_bases;
+    F.s_quals = src ? src->quals : d + L.off_quals;
+    F.s_dirs = has_dirs ? (src ? src->directions : d + L.off_dirs) : nullptr;
+    if (src) { F.d_bases = d + L.off_bases; F.d_quals = d + L.off_quals; F.d_dirs = has_dirs ? d + L.off_dirs : nullptr; }
+    F.n_seq = (int64_t)n_seq;
+    F.enc_min_bq = (uint32_t)std::min(std::max(h->cfg.min_base_call_quality, 0), 127);
+    int64_t misc_bytes = 0;
+    if (src) {
+        int k = 0;
+        auto range = [&](size_t off, const void* from, size_t bytes) { F.C.dst[k] = d + off; F.C.src[k] = (const uint8_t*)from; F.C.n[k] = (int64_t)bytes; misc_bytes = std::max<int64_t>(misc_bytes, (int64_t)bytes); k++; };
+        range(L.off_pos, src->position, (size_t)nr * 4);
+        range(L.off_flags, src->flags, (size_t)nr);
+        range(L.off_coff, src->cigar_offset, ((size_t)nr + 1) * 4);
+        range(L.off_cop, src->cigar_op, n_cig);
+        range(L.off_clen, src->cigar_len, n_cig * 4);
+        range(L.off_soff, src->seq_offset, ((size_t)nr + 1) * 4);
+        if (has_deldirs) range(L.off_deldirs, src->deletion_directions, 2 * n_cig);
+    }
+    F.read_blocks = read_blocks;
+    // the stream role runs when there is something to copy, to encode or to check
+    const bool stream = n_seq > 0 && (src || F.d_codes || has_dirs);
+    F.stream_blocks = stream ? (int32_t)std::min<int64_t>(((int64_t)n_seq + 16 * 256 - 1) / (16 * 256), 8192) : 0;
+    F.misc_blocks = src ? (int32_t)std::min<int64_t>(std::max<int64_t>((misc_bytes / 16 + 255) / 256, 1), 64) : 0;
+    F.scan_state = h->d_fused_scan.p;
+    F.done = (unsigned int*)(h->d_fused_words.p + kWordsDone);
+    F.totals = (long long*)(h->d_fused_words.p + kWordsTotals);
+    F.verdict = verdict;
+    F.keys_out = keys;
+    F.capacity = kPrepKeys;
+    hipLaunchKernelGGL(add_fused_kernel, dim3((unsigned)(F.read_blocks + F.stream_blocks + F.misc_blocks)), dim3(256), 0, h->stream, F);
     PISCES_HIP_CHECK(h, hipGetLastError());
     PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     h->h_meta_used = 0;
     const unsigned long long first_error = verdict->first_error;
     const int32_t span[3] = {verdict->span[0], verdict->span[1], verdict->span[2]};
     h->eqx_in_batch = count_indels && verdict->has_eqx != 0;
-    const long long totals[2] = {verdict->totals[0], verdict->totals[1]};
+    const long long totals[2] = {count_indels ? verdict->totals[0] : 0, count_indels ? verdict->totals[1] : 0};
     if (verdict->n_keys <= kPrepKeys) {
         touched.assign(keys, keys + verdict->n_keys);
         std::sort(touched.begin(), touched.end());
@@ -466,7 +526,7 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
 // slots the host pass made (uploaded here), or nullptr when they were made on the device.
 static int32_t store_finish_add(PiscesHip* h, StorePlace& pl, int32_t rc, uint8_t* d, const StageLayout& L, int32_t nr, size_t n_cig, size_t n_seq, bool has_dirs,
                                 bool has_deldirs, bool find_on_device, int64_t found_slots, int64_t found_pool, const int32_t* fslots_host,
-                                const std::vector<int32_t>& touched, int32_t max_key, int32_t min_position = 0)
+                                const std::vector<int32_t>& touched, int32_t max_key, int32_t min_position = 0, const ShapeArgs* shaped = nullptr /* add_fused_kernel made them */)
 {
     const int32_t bs = h->cfg.block_size;
     DevReadBatch db;
@@ -482,7 +542,8 @@ static int32_t store_finish_add(PiscesHip* h, StorePlace& pl, int32_t rc, uint8_
     db.n_reads = nr;
     if (rc == PISCES_OK) {
         const StoreBatchArrays A = {db.position, db.flags, db.cigar_offset, db.cigar_op, db.cigar_len, db.seq_offset, db.bases, db.quals, db.dirs};
-        rc = store_append_arrays(h, pl, A, nr, n_cig, n_seq, min_position, max_key);
+        if (shaped) rc = store_shape_launch(h, pl, *shaped, A.dirs != nullptr, nr, n_cig, min_position, max_key, true);   // (the position grid is all that is left)
+        else rc = store_append_arrays(h, pl, A, nr, n_cig, n_seq, min_position, max_key);
     }
     // ICandidateVariantFinder.FindCandidates + IStateManager.AddCandidates (SmallVariantCaller.cs:92-96) on the device, on the batch as it lies there
     if (rc == PISCES_OK && find_on_device && (h->snv_walk || found_slots > 0 || h->eqx_in_batch)) {
@@ -553,12 +614,21 @@ static int32_t add_reads_store(PiscesHip* h, const PiscesReadBatch* batch)
     touched.clear();
     int64_t found_slots = 0, found_pool = 0;
     int32_t max_key = 0, min_position = 0;
-    // A large batch: the checks and the bookkeeping run on the device behind the upload (read_prepare_kernel) — a host pass over tens of
+    // A large batch: the checks and the bookkeeping run on the device behind the upload (add_fused_kernel) — a host pass over tens of
     // millions of CIGARs is a second of one core, longer than the transfer it used to hide under.  (PISCES_HIP_DEVICE_CHECKS=0 / 1 forces either.)
     const bool checked_on_device = h->device_checks == 1 || (h->device_checks < 0 && nr >= (1 << 16));
+    ShapeArgs shape;
+    bool shaped = false;
     if (checked_on_device) {
+        // a batch that becomes a segment of its own: descriptors, fragments and row codes in the same launch as the checks
+        if (rc == PISCES_OK && pl.direct) {
+            const StoreBatchArrays A = {(const int32_t*)(d + L.off_pos), d + L.off_flags, (const int32_t*)(d + L.off_coff), d + L.off_cop, (const uint32_t*)(d + L.off_clen),
+                                        (const int32_t*)(d + L.off_soff), d + L.off_bases, d + L.off_quals, batch->directions ? d + L.off_dirs : nullptr};
+            rc = store_shape_begin(h, pl, A, nr, n_cig, n_seq, &shape);
+            shaped = rc == PISCES_OK;
+        }
         if (rc == PISCES_OK) rc = store_device_checks(h, d, L, nr, n_cig, n_seq, batch->directions != nullptr, batch->deletion_directions != nullptr, count_indels,
-                                                      &found_slots, &found_pool, touched, &max_key, &min_position);
+                                                      &found_slots, &found_pool, touched, &max_key, &min_position, nullptr, shaped ? &shape : nullptr);
     } else {
     // ---- the pass over the CIGARs, under the transfer
     auto op_ref = [](uint8_t t) { return t == 'M' || t == 'D' || t == 'N' || t == '=' || t == 'X'; };
@@ -648,7 +718,7 @@ static int32_t add_reads_store(PiscesHip* h, const PiscesReadBatch* batch)
         for (int32_t i = 1; i < nr; i++) min_position = std::min(min_position, batch->position[i]);
     }
     return store_finish_add(h, pl, rc, d, L, nr, n_cig, n_seq, batch->directions != nullptr, batch->deletion_directions != nullptr, find_on_device, found_slots,
-                            found_pool, checked_on_device ? nullptr : fslots.data(), touched, max_key, min_position);
+                            found_pool, checked_on_device ? nullptr : fslots.data(), touched, max_key, min_position, shaped ? &shape : nullptr);
 }
 
 // pisces_hip_add_reads for a batch in device memory: its arrays are copied into the segment's blob (or, for a small batch, the staging
@@ -682,27 +752,6 @@ int32_t pisces_hip_add_device_reads(PiscesHip* h, const PiscesReadBatch* batch, 
     }
     if (rc) { store_unplace(h, pl); return rc; }
     uint8_t* const d = pl.direct ? pl.seg->blob.p : D_STAGE(h);
-    {   // the caller's arrays into the store's layout: one launch (ranges_copy16_kernel)
-        CopyRanges16 C;
-        std::memset(&C, 0, sizeof(C));
-        int k = 0;
-        auto range = [&](size_t off, const void* src, size_t bytes) { C.dst[k] = d + off; C.src[k] = (const uint8_t*)src; C.n[k] = (int64_t)bytes; k++; };
-        range(L.off_pos, batch->position, (size_t)nr * 4);
-        range(L.off_flags, batch->flags, (size_t)nr);
-        range(L.off_coff, batch->cigar_offset, ((size_t)nr + 1) * 4);
-        range(L.off_cop, batch->cigar_op, n_cig);
-        range(L.off_clen, batch->cigar_len, n_cig * 4);
-        range(L.off_soff, batch->seq_offset, ((size_t)nr + 1) * 4);
-        range(L.off_bases, batch->bases, n_seq);
-        range(L.off_quals, batch->quals, n_seq);
-        if (has_dirs) range(L.off_dirs, batch->directions, n_seq);
-        if (has_deldirs) range(L.off_deldirs, batch->deletion_directions, 2 * n_cig);
-        const int64_t most = std::max<int64_t>((int64_t)n_seq, (int64_t)nr * 4);
-        const unsigned grid = (unsigned)std::min<int64_t>(std::max<int64_t>((most / 16 + 255) / 256, 1), (int64_t)h->n_cus * 16);
-        hipLaunchKernelGGL(ranges_copy16_kernel, dim3(grid), dim3(256), 0, h->stream, C);
-        const hipError_t e = hipGetLastError();
-        if (e != hipSuccess) rc = fail(h, PISCES_E_DEVICE, std::string("add_device_reads: ") + hipGetErrorString(e));
-    }
     const bool find_on_device = !h->h_ref.empty();
     const bool count_indels = find_on_device && !h->snv_walk;
     h->eqx_in_batch = false;
@@ -710,9 +759,21 @@ int32_t pisces_hip_add_device_reads(PiscesHip* h, const PiscesReadBatch* batch, 
     touched.clear();
     int64_t found_slots = 0, found_pool = 0;
     int32_t max_key = 0, min_position = 0;
-    if (rc == PISCES_OK) rc = store_device_checks(h, d, L, nr, n_cig, n_seq, has_dirs, has_deldirs, count_indels, &found_slots, &found_pool, touched, &max_key, &min_position);
+    // ONE launch: the caller's arrays into the store's layout, the checks, the candidate-record slots and — a batch that becomes a segment of
+    // its own — descriptors, fragments and row codes, the batch read once (add_fused_kernel)
+    ShapeArgs shape;
+    bool shaped = false;
+    if (rc == PISCES_OK && pl.direct) {
+        const StoreBatchArrays A = {(const int32_t*)(d + L.off_pos), d + L.off_flags, (const int32_t*)(d + L.off_coff), d + L.off_cop, (const uint32_t*)(d + L.off_clen),
+                                    (const int32_t*)(d + L.off_soff), d + L.off_bases, d + L.off_quals, has_dirs ? d + L.off_dirs : nullptr};
+        rc = store_shape_begin(h, pl, A, nr, n_cig, n_seq, &shape);
+        shaped = rc == PISCES_OK;
+    }
+    if (rc == PISCES_OK) rc = store_device_checks(h, d, L, nr, n_cig, n_seq, has_dirs, has_deldirs, count_indels, &found_slots, &found_pool, touched, &max_key, &min_position,
+                                                  batch, shaped ? &shape : nullptr);
     prof_a.reset(new HostTimer(h->prof_on ? &h->prof[14] : nullptr));
-    return store_finish_add(h, pl, rc, d, L, nr, n_cig, n_seq, has_dirs, has_deldirs, find_on_device, found_slots, found_pool, nullptr, touched, max_key, min_position);
+    return store_finish_add(h, pl, rc, d, L, nr, n_cig, n_seq, has_dirs, has_deldirs, find_on_device, found_slots, found_pool, nullptr, touched, max_key, min_position,
+                            shaped ? &shape : nullptr);
     });
 }
 
