@@ -180,6 +180,8 @@ namespace Pisces.Hip
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_set_timing(IntPtr handle, int everyNth);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_last_kernel_ms(IntPtr handle, out float ms);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_kernel_time(IntPtr handle, out double totalMs, out long launches);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_set_chain_timing(IntPtr handle, int enable);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_chain_time(IntPtr handle, [Out] double[] outMs);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_mark(IntPtr handle, int which, IntPtr stream);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_marked_ms(IntPtr handle, out float ms);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int pisces_hip_balanced_tile_loci(IntPtr handle, long nLoci);

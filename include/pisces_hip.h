@@ -527,6 +527,15 @@ int32_t pisces_hip_mark(PiscesHip* h, int32_t which, void* stream);
 int32_t pisces_hip_marked_ms(PiscesHip* h, float* ms);
 /* Sum of the timed kernel durations (ms) and number of timed launches since set_timing(n). Waits for them. */
 int32_t pisces_hip_kernel_time(PiscesHip* h, double* total_ms, int64_t* launches);
+/* The device time of the streaming surface's chain reads -> records (bench.py's roofline_chain).  enable != 0: every
+ * pisces_hip_add_device_reads records an event on the handle's stream before the first thing it enqueues and one behind the last, every
+ * flush one in front of its first kernel and one behind the kernel that leaves the compacted records in HBM (the transfer to the host
+ * follows that event).  pisces_hip_chain_time waits for the last add's and the last flush's events: out_ms[0] = the add's span
+ * (IStateManager.AddAlleleCounts + ICandidateVariantFinder.FindCandidates of the batch, RegionStateManager.cs:118-220,
+ * CandidateVariantFinder.cs:36-83), out_ms[1] = the flush's (GetCandidatesToProcess + IAlleleCaller.Call); PISCES_E_STATE when either has
+ * not happened since timing was switched on. */
+int32_t pisces_hip_set_chain_timing(PiscesHip* h, int32_t enable);
+int32_t pisces_hip_chain_time(PiscesHip* h, double out_ms[2]);
 /* Streaming-read bandwidth of the handle's device, GB/s: best of `reps` timed passes of a kernel that only reads `nbytes`
  * with the hot kernel's load pattern.  Reported beside the spec peak in bench.py; allocates and frees nbytes. */
 int32_t pisces_hip_probe_read_bandwidth(PiscesHip* h, int64_t nbytes, int32_t reps, double* gb_per_s);

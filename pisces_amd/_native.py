@@ -16,7 +16,7 @@ EXPORTS = [
     "pisces_hip_add_observations", "pisces_hip_flush", "pisces_hip_get_counts", "pisces_hip_add_gapped_mnv_ref",
     "pisces_hip_get_candidates", "pisces_hip_stats", "pisces_hip_call_tiles", "pisces_hip_accumulate_tiles",
     "pisces_hip_synchronize", "pisces_hip_last_kernel_ms", "pisces_hip_expand_reads", "pisces_hip_device_totals",
-    "pisces_hip_set_timing", "pisces_hip_kernel_time", "pisces_hip_flush_ex", "pisces_hip_probe_read_bandwidth",
+    "pisces_hip_set_timing", "pisces_hip_kernel_time", "pisces_hip_set_chain_timing", "pisces_hip_chain_time", "pisces_hip_flush_ex", "pisces_hip_probe_read_bandwidth",
     "pisces_hip_vcf_default_config", "pisces_hip_format_vcf", "pisces_hip_format_vcf_padded", "pisces_hip_find_candidates", "pisces_hip_call_tiles_batched",
     "pisces_hip_find_indel_candidates", "pisces_hip_compact_records", "pisces_hip_bgzf_scan", "pisces_hip_bgzf_inflate",
     "pisces_hip_balanced_tile_loci", "pisces_hip_bam_decode", "pisces_hip_bam_fetch", "pisces_hip_bam_chain_mode", "pisces_hip_add_decoded_reads", "pisces_hip_find_candidates_device", "pisces_hip_get_base_quality_sums", "pisces_hip_get_gapped_mnv_ref", "pisces_hip_comm_unique_id", "pisces_hip_comm_init", "pisces_hip_reduce_summary", "pisces_hip_comm_destroy",
@@ -126,6 +126,8 @@ def _load():
         "pisces_hip_device_totals": (i32, [vp, P(i64), i32]),
         "pisces_hip_set_timing": (i32, [vp, i32]),
         "pisces_hip_kernel_time": (i32, [vp, P(C.c_double), P(i64)]),
+        "pisces_hip_set_chain_timing": (i32, [vp, i32]),
+        "pisces_hip_chain_time": (i32, [vp, P(C.c_double)]),
         "pisces_hip_probe_read_bandwidth": (i32, [vp, i64, i32, P(C.c_double)]),
         "pisces_hip_vcf_default_config": (i32, [P(_abi.PiscesVcfConfig)]),
         "pisces_hip_format_vcf": (i64, [P(_abi.PiscesVcfConfig), C.c_char_p, vp, i64, vp, vp, vp, vp, i64]),

@@ -1211,6 +1211,55 @@ __global__ __launch_bounds__(64) void gather_records_kernel(const PiscesCalledAl
 }
 
 
+// The two launches above as ONE for launches of up to kGatherDirectTiles tiles (the flush of a batch: BASELINE config 2 is 1 563-1 786): the
+// directory is a few KB that stay in L2, so a tile's wave simply ADDS UP the record counts of the tiles before it — lane i takes tiles i,
+// i + 64, ... (28 independent loads a lane for the last tile of 1 786) — while its own validity mask is on the way: two dependent round
+// trips (directory, records) where scan + gather took four and a launch gap.  The last tile's wave writes the totals.
+constexpr int kGatherDirectTiles = 4096;
+__global__ __launch_bounds__(64) void gather_direct_kernel(const PiscesCalledAllele* __restrict__ records, const PiscesTileResult* __restrict__ tr, int32_t n_tiles,
+                                                           int32_t* __restrict__ offsets /* optional */, PiscesCalledAllele* __restrict__ out, int32_t capacity,
+                                                           int32_t* __restrict__ total, int32_t* __restrict__ called_out /* optional */)
+{
+    const int t = blockIdx.x, l = threadIdx.x;
+    if (t >= n_tiles) return;
+    const uint32_t nib = (tr[t].valid[l >> 3] >> ((l & 7) * 4)) & 0xFu;
+    const int32_t begin = tr[t].record_begin;
+    const bool last = t == n_tiles - 1;
+    int before = 0, called = 0;
+    for (int i0 = 0; i0 < t; i0 += 64 * 32) {   // 32 independent loads a lane a round: one round trip up to 2 048 tiles (the loop's round trips are what the kernel costs)
+        int v[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++) v[k] = tr[min(i0 + 64 * k + l, t - 1)].n_records;
+#pragma unroll
+        for (int k = 0; k < 32; k++) before += i0 + 64 * k + l < t ? v[k] : 0;
+    }
+    if (last && called_out)   // IAlleleCaller.TotalNumCalled of the launch (one wave of the launch)
+        for (int i = l; i < t; i += 64) called += tr[i].n_called;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { before += __shfl_xor(before, d, 64); called += __shfl_xor(called, d, 64); }
+    if (l == 0) {
+        if (offsets) offsets[t] = before;
+        if (last) {
+            *total = before + tr[t].n_records;
+            if (called_out) *called_out = called + tr[t].n_called;
+        }
+    }
+    int x = __popc(nib);
+    const int mine = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d, 64);
+        if (l >= d) x += y;
+    }
+    int64_t dst = (int64_t)before + (x - mine);
+    const PiscesCalledAllele* src = records + (int64_t)begin + l * 4;
+    for (int k = 0; k < 4; k++) {
+        if (!(nib & (1u << k))) continue;
+        if (dst < capacity) copy_record(&out[dst], &src[k]);
+        dst++;
+    }
+}
+
 // The two launches above as ONE (large launches: the flush of many blocks, the device-resident surface): a workgroup takes sixteen tiles,
 // publishes the number of their records, finds the records of all tiles before its own by a decoupled look-back over the workgroups'
 // words (64 predecessors a round; a word = launch epoch << 34 | status << 32 | count, so words of earlier launches read as "not yet" and

@@ -21,6 +21,7 @@
 #include <set>
 #include <string>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -286,6 +287,12 @@ struct PiscesHip {
     // per-launch timing window (pisces_hip_set_timing / pisces_hip_kernel_time)
     std::vector<hipEvent_t> ring;   // pairs: [2i] start, [2i+1] stop
     int32_t timing = 0;        // 0 = off (no events are recorded), n > 0 = every n-th launch is bracketed by events
+    // pisces_hip_set_chain_timing / pisces_hip_chain_time: the device time of reads -> records, as two spans on the handle's stream — [0, 1]
+    // around everything an add of reads enqueues, [2, 3] from a flush's first kernel to its compacted records in HBM (the transfer to the
+    // host comes behind [3])
+    bool chain_timing = false;
+    hipEvent_t ev_chain[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool chain_have[2] = {false, false};
     int64_t ring_used = 0;
     int64_t launches_seen = 0;
     DeviceBuf<unsigned long long> d_totals;
@@ -559,6 +566,13 @@ struct PiscesHip {
     DeviceBuf<uint32_t> d_prep_map;
     DeviceBuf<uint8_t> d_fused_words;         // add_fused_kernel's shared words (spans, first error, workgroups through, totals): set once, left clean by every launch
     DeviceBuf<unsigned long long> d_fused_scan;   // its look-back words, zero between launches
+    DeviceBuf<unsigned long long> d_compact_state;   // compact_records_kernel's look-back words (epoch-tagged: never cleared between launches)
+    uint32_t compact_epoch = 0;
+    struct DeferredGrid { ShapeArgs S; unsigned blocks; };
+    std::vector<DeferredGrid> deferred_grid;  // grid roles of read_shape_kernel kept back until something reads or changes a grid (store_run_deferred)
+    bool defer_grid = true;                   // PISCES_HIP_DEFER_GRID=0: enqueued by the add itself (the A / B)
+    int32_t fused_seq = 0;                    // add_fused_kernel launches of this handle (the word the host polls for the verdict)
+    int32_t compact_mode = 0;                 // PISCES_HIP_COMPACT: 0 = one launch (direct sums / look-back by size), 2 = "two" (scan + gather), 3 = "lookback" always
 
     // device scratch, grow-only
     DeviceBuf<uint32_t> d_tuples;
@@ -641,7 +655,7 @@ static hipError_t ensure_quality_lut(PiscesHip* h)
 }
 
 // tuples of `n_tiles` tiles -> anchor-resolved counts in d_counts (and, with_sums, the base-quality sums in d_sumq), on stream s
-static void store_view(const PiscesHip* h, StoreView* V);
+static void store_view(PiscesHip* h, StoreView* V);
 // with_store: the reads of the handle's read store are walked as well (the streaming surface; the device-resident surface passes false)
 static hipError_t accumulate_tiles(PiscesHip* h, hipStream_t s, const uint32_t* d_tuples, const PiscesTile* d_tiles, int32_t n_tiles, bool with_sums,
                                    bool with_store = false)
@@ -892,6 +906,8 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         if (const char* v = getenv("PISCES_HIP_MNV_SPLIT")) h->mnv_split = h->mnv_split && atoi(v) != 0;
         if (const char* v = getenv("PISCES_HIP_STORE_SEAL_BYTES")) h->store_seal_bytes = (size_t)std::max(0ll, atoll(v));
         if (const char* v = getenv("PISCES_HIP_DEVICE_CHECKS")) h->device_checks = atoi(v) != 0 ? 1 : 0;
+        if (const char* v = getenv("PISCES_HIP_DEFER_GRID")) h->defer_grid = atoi(v) != 0;
+        if (const char* v = getenv("PISCES_HIP_COMPACT")) h->compact_mode = std::string(v) == "two" ? 2 : std::string(v) == "lookback" ? 3 : 0;
         if (const char* v = getenv("PISCES_HIP_MERGE_IN_PLACE")) h->merge_in_place = atoi(v) != 0;
         if (const char* v = getenv("PISCES_HIP_DEVICE_GENOTYPER")) h->device_genotyper = atoi(v) != 0;
         if (const char* v = getenv("PISCES_HIP_FINDER")) h->finder_wave = std::string(v) == "wave" ? 1 : std::string(v) == "batch" ? 2 : std::string(v) == "bases" ? 3 : 0;
@@ -1078,7 +1094,7 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     h->found.h_totals = nullptr;
     h->d_found.release(); h->d_found_pool.release(); h->d_found_slots.release(); h->d_found_pool_first.release();
     h->d_merge_tab.release(); h->d_merge_acc.release();
-    h->d_scan_sums.release(); h->d_prep_map.release(); h->d_fused_words.release(); h->d_fused_scan.release(); h->d_folded.release(); h->d_span_tiles.release();
+    h->d_scan_sums.release(); h->d_prep_map.release(); h->d_fused_words.release(); h->d_fused_scan.release(); h->d_compact_state.release(); h->d_folded.release(); h->d_span_tiles.release();
     h->d_snv[0].release(); h->d_snv[1].release(); h->d_snv_n.release(); h->d_snv_sel.release(); h->d_dirty.release(); h->d_row_idx.release(); h->d_rows.release();
     if (h->h_totals) host_free(h->h_totals);
     if (h->h_cnt_x) host_free(h->h_cnt_x);
@@ -1095,6 +1111,7 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     for (hipGraphExec_t g : h->graphs) (void)hipGraphExecDestroy(g);
     for (hipGraph_t g : h->graph_defs) (void)hipGraphDestroy(g);
     for (hipEvent_t ev : h->ring) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : h->ev_chain) if (ev) (void)hipEventDestroy(ev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (int k = 0; k < PiscesHip::kLanes; k++)

@@ -30,6 +30,12 @@
 #include "read_walk.h"
 #include "stream_kernels.hip.h"
 
+#ifndef PISCES_ADD_OCC
+#define PISCES_ADD_OCC 6      // waves a SIMD of add_fused_kernel: 1 303 read workgroups of a 333 500-read batch are resident at once (5.1 waves a SIMD)
+#endif
+#ifndef PISCES_ADD_ABLATE
+#define PISCES_ADD_ABLATE 0   // (development: ablations of add_fused_kernel, tools/add_ablate.sh)
+#endif
 namespace pisces {
 
 struct ReadDesc {       // 16 bytes, one per read, in position order
@@ -195,6 +201,16 @@ __device__ __forceinline__ void grid_cells(const ShapeArgs& A, int block)
         const int b0 = __builtin_amdgcn_readlane(c0, src), b1 = __builtin_amdgcn_readlane(c1, src), f = __builtin_amdgcn_readlane(f0, src);
         for (int k = b0 + lane; k <= b1; k += 64) A.grid[k] = f;
     }
+    // the cells behind the batch's last read, to the grid's end: above every fragment index (no memset of the cells a batch adds; an
+    // out-of-order batch leaves the grid unused)
+    if (block == (A.n_reads - 1) / 256) {
+        const int last_lane = (A.n_reads - 1) & 255;
+        if ((int)(threadIdx.x >> 6) == (last_lane >> 6)) {
+            const long long p_last = A.position[A.n_reads - 1];
+            const long long from = max(p_last + 1 - (long long)A.grid_base, 0ll);
+            for (long long k = from + lane; k < (long long)A.grid_n; k += 64) A.grid[k] = 0x7F7F7F7F;
+        }
+    }
 }
 
 // the shape role: reads [256 block, 256 block + 256), one lane each; `ok` false: the lane's read is not to be walked (refused by the checks
@@ -330,7 +346,7 @@ __device__ __forceinline__ void shape_reads(const ShapeArgs& A, const int block,
     for (int d = 32; d >= 1; d >>= 1) reach = max(reach, __shfl_xor(reach, d, 64));
     const bool any_unsorted = __ballot(unsorted) != 0ull, any_complex = __ballot(complex_read) != 0ull;
     const int frag_bits = (__ballot(generic_read) != 0ull ? 1 : 0) | (__ballot(has_del) != 0ull ? 2 : 0);
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0 && PISCES_ADD_ABLATE != 9) {
         // (plain reads first: same-address atomics from the whole chip are what they cost, and after the first few waves none is needed)
         if (reach > A.state[kStateReach]) atomicMax(&A.state[kStateReach], reach);
         if (any_unsorted && A.state[kStateUnsorted] == 0) atomicOr(&A.state[kStateUnsorted], 1);
@@ -381,12 +397,17 @@ constexpr int kPrepReplicas = 32;
 // show zero for the rest of the launch) costs no atomic: same-address atomics from eight XCDs serialise at 0.1-0.2 us each
 __device__ __forceinline__ void set_keys(const PrepareArgs& A, int64_t a, int64_t b)
 {
+#if PISCES_ADD_ABLATE == 7
+    return;
+#endif
     uint32_t* const map = A.block_bits + (int64_t)(blockIdx.x & (kPrepReplicas - 1)) * A.map_stride;   // (any copy will do: the launch's workgroup index)
     for (int64_t k = a; k <= b; k++) {
         if (k >= A.n_block_bits) continue;   // (cannot be: the map covers every int32 position)
         const uint32_t bit = 1u << (k & 31);
         uint32_t* const w = &map[k >> 5];
-        if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(w, bit);
+        // (no look before the atomic: a workgroup sets each of its distinct runs once, a launch a few atomics per word and copy — and a load
+        // that must go past the L2 to see the others' bits is a round trip of its own in every workgroup's chain)
+        (void)__hip_atomic_fetch_or(w, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 __device__ __forceinline__ long long prep_shfl64(long long v, int src_lane)
@@ -527,15 +548,14 @@ __device__ __forceinline__ void prepare_reads(const PrepareArgs& A, const int bl
             if (!seen) set_keys(A, s_run_a[t], s_run_b[t]);
         }
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && PISCES_ADD_ABLATE != 8) {
         int32_t* const span = A.key_span + 4 * (int)(block & (kPrepReplicas - 1));
-        const int v0 = __hip_atomic_load(&span[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), v1 = __hip_atomic_load(&span[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                  v2 = __hip_atomic_load(&span[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), v3 = __hip_atomic_load(&span[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (s_plo < v2) atomicMin(&span[2], s_plo);
-        if (s_eqx && !v3) atomicMax(&span[3], 1);
+        // (no look before the atomics either: four of them a workgroup on the copy of its index, none waited for)
+        (void)__hip_atomic_fetch_min(&span[2], s_plo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s_eqx) (void)__hip_atomic_fetch_max(&span[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (s_khi > 0) {
-            if (s_klo < v0) atomicMin(&span[0], s_klo);
-            if (s_khi > v1) atomicMax(&span[1], s_khi);
+            (void)__hip_atomic_fetch_min(&span[0], s_klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_max(&span[1], s_khi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -548,7 +568,7 @@ struct PrepVerdict {
     int32_t span[3];
     int32_t n_keys;      // touched blocks (all of them, also beyond capacity)
     int32_t has_eqx;     // some read has an X or = operation
-    int32_t pad;
+    int32_t ready;       // the launch's sequence number, stored last (system-scope release): the host may poll it instead of waiting for the stream
 };
 static_assert(sizeof(PrepVerdict) == 48, "PrepVerdict layout");
 // (run by the workgroup of add_fused_kernel's read role that finishes last, behind an agent-scope fence: every other workgroup's words are in)
@@ -600,7 +620,6 @@ __device__ __forceinline__ void prepare_collect(uint32_t* __restrict__ block_bit
         out->span[0] = s_span[0]; out->span[1] = s_span[1]; out->span[2] = s_span[2];
         out->n_keys = n;
         out->has_eqx = s_span[3];
-        out->pad = 0;
     }
 }
 
@@ -639,15 +658,17 @@ struct AddFusedArgs {
     uint32_t enc_min_bq;        // <= 127
     CopyRanges16 C;             // misc role
     unsigned long long* scan_state;   // [read_blocks], zero between launches: status << 62 | pool bytes << 31 | records
-    unsigned int* done;               // zero between launches: read workgroups that are through
+    unsigned int* done;               // [1 + kPrepReplicas], zero between launches: [1 + c] read workgroups of index class c that are through, [0] classes that are
     long long* totals;                // [2]: records, pool bytes of the batch
     PrepVerdict* verdict;             // pinned host memory
     int32_t* keys_out;
     int32_t capacity;
+    int32_t* bad_direction;           // pinned host memory, zero at launch: set by the stream role when a per-base direction is none of 0 / 1 / 2
+    int32_t seq;                      // this launch's number (nonzero): verdict->ready
 };
 constexpr unsigned long long kScanAggregate = 1ull << 62, kScanInclusive = 2ull << 62, kScanField = 0x7FFFFFFFull;
 
-__global__ __launch_bounds__(256) void add_fused_kernel(AddFusedArgs A)
+__global__ __launch_bounds__(256, PISCES_ADD_OCC) void add_fused_kernel(AddFusedArgs A)
 {
     const int b = (int)blockIdx.x;
     __shared__ int s_wf[4], s_wp[4], s_excl[2], s_last;
@@ -655,6 +676,9 @@ __global__ __launch_bounds__(256) void add_fused_kernel(AddFusedArgs A)
         const int sb = b - A.read_blocks;
         if (sb < A.stream_blocks) {
             // ---- stream role
+#if PISCES_ADD_ABLATE == 1
+            return;
+#endif
             const uint32_t qk4 = (0x7Fu + A.enc_min_bq) * 0x01010101u;
             const int64_t n16 = A.n_seq >> 4;
             bool bad_dir = false;
@@ -669,10 +693,16 @@ __global__ __launch_bounds__(256) void add_fused_kernel(AddFusedArgs A)
                     for (int k = 0; k < 4; k++) bad_dir = bad_dir || ((dw[k] + 0x7D7D7D7Du) | dw[k]) & 0x80808080u;   // some byte > 2
                     if (A.d_dirs) __builtin_memcpy(A.d_dirs + 16 * i, dw, 16);
                 }
+#if PISCES_ADD_ABLATE == 5
+                if (bw[0] == 0x12345678u && qw[1] == 0x9ABCDEF0u) __builtin_memcpy(A.d_codes + 16 * i, bw, 16);
+                continue;
+#endif
+#if PISCES_ADD_ABLATE != 4
                 if (A.d_bases) {
                     __builtin_memcpy(A.d_bases + 16 * i, bw, 16);
                     __builtin_memcpy(A.d_quals + 16 * i, qw, 16);
                 }
+#endif
                 if (A.d_codes) {
 #pragma unroll
                     for (int k = 0; k < 4; k++) c[k] = row_codes_of(bw[k], qw[k], qk4);
@@ -686,7 +716,7 @@ __global__ __launch_bounds__(256) void add_fused_kernel(AddFusedArgs A)
                 if (A.d_bases) { A.d_bases[i] = bb; A.d_quals[i] = qq; }
                 if (A.d_codes) A.d_codes[i] = (uint8_t)row_codes_of(bb, qq, qk4);
             }
-            if (__ballot(bad_dir) != 0ull && (threadIdx.x & 63) == 0) atomicMin(A.P.first_error, (unsigned long long)kPrepBadDirection);
+            if (__ballot(bad_dir) != 0ull && (threadIdx.x & 63) == 0) __hip_atomic_store(A.bad_direction, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         } else {
             // ---- misc role: the small arrays, sixteen bytes a lane, one range after the other over this role's workgroups
             const int64_t stride = (int64_t)A.misc_blocks * 256, t = (int64_t)(sb - A.stream_blocks) * 256 + threadIdx.x;
@@ -704,12 +734,22 @@ __global__ __launch_bounds__(256) void add_fused_kernel(AddFusedArgs A)
                 if (t < (n & 15)) dst[(n16 << 4) + t] = src[(n16 << 4) + t];
             }
         }
-    } else {
+        // (the streaming roles leave nothing the collecting workgroup reads: no fence, no count — a release fence here is a write-back of the
+        // XCD's whole L2, and 8 000 workgroups x 4 waves of them made the launch 1.2 ms where its bytes take 45 us)
+        return;
+    }
     // ---- read role
+    {
     int found, pool;
     bool ok;
+#if PISCES_ADD_ABLATE == 6
+    found = pool = 0; ok = true;
+#else
     prepare_reads(A.P, b, found, pool, ok);
+#endif
+#if PISCES_ADD_ABLATE != 2
     if (A.do_shape) shape_reads(A.S, b, ok);
+#endif
     // the candidate-record slots: exclusive scan over the batch's reads, in this launch
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int incl_f = found, incl_p = pool;
@@ -734,6 +774,9 @@ __global__ __launch_bounds__(256) void add_fused_kernel(AddFusedArgs A)
         } else {
             if (lane == 0) __hip_atomic_store(&A.scan_state[b], kScanAggregate | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int base = b - 1;   // lane l looks at workgroup base - l
+#if PISCES_ADD_ABLATE == 3
+            base = -1000000;
+#endif
             for (;;) {
                 const int idx = base - lane;
                 const unsigned long long w = idx >= 0 ? __hip_atomic_load(&A.scan_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kScanInclusive;
@@ -754,7 +797,10 @@ __global__ __launch_bounds__(256) void add_fused_kernel(AddFusedArgs A)
         }
         if (lane == 0) {
             s_excl[0] = (int)excl_f; s_excl[1] = (int)excl_p;
-            if (b == A.read_blocks - 1) { A.totals[0] = excl_f + agg_f; A.totals[1] = excl_p + agg_p; }
+            if (b == A.read_blocks - 1) {
+                __hip_atomic_store(&A.totals[0], excl_f + agg_f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&A.totals[1], excl_p + agg_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     __syncthreads();
@@ -767,13 +813,30 @@ __global__ __launch_bounds__(256) void add_fused_kernel(AddFusedArgs A)
         if (b == A.read_blocks - 1 && threadIdx.x == 0) { A.P.n_found[A.P.n_reads] = s_excl[0] + agg_f; A.P.n_pool[A.P.n_reads] = s_excl[1] + agg_p; }
     }
     }
-    // the workgroup of the launch (any role) that is through last collects: every thread's stores are out (fence), then the count
-    __threadfence();
+    // The read workgroup that is through last collects.  What it reads of the others — block map, spans, first error, totals — was written
+    // with agent-scope atomics, which are performed past the XCDs' L2s, and the barrier's s_waitcnt vmcnt(0) has every wave's atomics
+    // acknowledged before thread 0 counts the workgroup in: the count is a RELAXED atomic.  (A release there is a write-back of the XCD's
+    // whole L2 — while the stream role fills it — per read workgroup: 60 us of the launch's 127; a fence in every wave of every role: 1.2 ms.)
+    // The collector's acquire (an invalidate, no write-back) makes its plain loads miss the L2.
+#if PISCES_ADD_ABLATE == 10
+    return;
+#endif
     __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(A.done, 1u) == gridDim.x - 1u ? 1 : 0;
+    if (threadIdx.x == 0) {
+        // counted in two levels — kPrepReplicas counters by workgroup index, then one for the counters that are full — so that no word sees
+        // more than read_blocks / 32 (+ 32) atomics: same-address atomics from eight XCDs are served one at a time, ~0.1 us each
+        const unsigned cls = (unsigned)b & (kPrepReplicas - 1u);
+        const unsigned members = ((unsigned)A.read_blocks - cls + kPrepReplicas - 1u) / kPrepReplicas;
+        int last = 0;
+        if (__hip_atomic_fetch_add(&A.done[1 + cls], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u) {
+            const unsigned classes = min((unsigned)A.read_blocks, (unsigned)kPrepReplicas);
+            last = __hip_atomic_fetch_add(&A.done[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == classes - 1u;
+        }
+        s_last = last;
+    }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     prepare_collect(A.P.block_bits, A.P.map_stride, A.P.key_span, A.P.first_error, A.totals, A.verdict, A.keys_out, A.capacity);
     __syncthreads();
     // the shared words as the next launch expects them
@@ -782,7 +845,13 @@ __global__ __launch_bounds__(256) void add_fused_kernel(AddFusedArgs A)
         int32_t* const sp = A.P.key_span + 4 * threadIdx.x;
         sp[0] = 0x7FFFFFFF; sp[1] = 0; sp[2] = 0x7FFFFFFF; sp[3] = 0;
     }
-    if (threadIdx.x == 0) { *A.done = 0u; *A.P.first_error = ~0ull; }
+    if (threadIdx.x <= kPrepReplicas) A.done[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) *A.P.first_error = ~0ull;
+    // the word the host polls, behind every thread's stores to the host's memory (verdict, keys) and to the shared words (the host may
+    // enqueue the next launch as soon as it has seen it: stream order puts that launch behind the end of this one)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&A.verdict->ready, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // small batches: their bytes join the open segment (up to five ranges in one launch; byte-wise: destinations are not aligned)

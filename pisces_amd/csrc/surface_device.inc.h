@@ -179,7 +179,7 @@ int32_t pisces_hip_compact_records(PiscesHip* h, const PiscesCalledAllele* d_rec
         PISCES_HIP_CHECK(h, hipMemsetAsync(d_count, 0, sizeof(int32_t), s));
         return PISCES_OK;
     }
-    launch_compaction(s, d_records, d_tile_results, n_tiles, d_offsets, d_out, out_capacity, d_count);
+    { int32_t rcc = launch_compaction(h, s, d_records, d_tile_results, n_tiles, d_offsets, d_out, out_capacity, d_count); if (rcc) return rcc; }
     PISCES_HIP_CHECK(h, hipGetLastError());
     return PISCES_OK;
     });
@@ -291,6 +291,37 @@ int32_t pisces_hip_kernel_time(PiscesHip* h, double* total_ms, int64_t* launches
     }
     *total_ms = sum;
     *launches = n;
+    return PISCES_OK;
+    });
+}
+
+int32_t pisces_hip_set_chain_timing(PiscesHip* h, int32_t enable)
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h) return PISCES_E_INVALID_ARG;
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    if (enable)
+        for (auto& ev : h->ev_chain)
+            if (!ev) PISCES_HIP_CHECK(h, hipEventCreate(&ev));
+    h->chain_timing = enable != 0;
+    h->chain_have[0] = h->chain_have[1] = false;
+    return PISCES_OK;
+    });
+}
+
+int32_t pisces_hip_chain_time(PiscesHip* h, double out_ms[2])
+{
+    return abi_guard<int32_t>(h, [&]() -> int32_t {
+    if (!h || !out_ms) return PISCES_E_INVALID_ARG;
+    if (!h->chain_timing || !h->chain_have[0] || !h->chain_have[1])
+        return fail(h, PISCES_E_STATE, "chain_time: no timed add_device_reads + flush pair (pisces_hip_set_chain_timing first)");
+    PISCES_HIP_CHECK(h, hipSetDevice(h->device));
+    for (int k = 0; k < 2; k++) {
+        float ms = 0.f;
+        PISCES_HIP_CHECK(h, hipEventSynchronize(h->ev_chain[2 * k + 1]));
+        PISCES_HIP_CHECK(h, hipEventElapsedTime(&ms, h->ev_chain[2 * k], h->ev_chain[2 * k + 1]));
+        out_ms[k] = ms;
+    }
     return PISCES_OK;
     });
 }

@@ -232,11 +232,37 @@ static void launch_genotype_loci(PiscesHip* h, hipStream_t s, PiscesCalledAllele
 static bool germline(const PiscesHip* h) { return h->cfg.ploidy == PISCES_PLOIDY_DIPLOID || h->cfg.ploidy == PISCES_PLOIDY_HAPLOID; }
 
 // scan + gather: d_out = called alleles in (position, allele) order, *d_count = how many
-static void launch_compaction(hipStream_t s, const PiscesCalledAllele* d_records, const PiscesTileResult* d_tr, int32_t n_tiles,
-                              int32_t* d_offsets, PiscesCalledAllele* d_out, int32_t cap, int32_t* d_count, int32_t* d_called = nullptr)
+// ONE launch: gather_direct_kernel up to kGatherDirectTiles tiles (a tile's wave adds up the counts before it), compact_records_kernel beyond
+// (a decoupled look-back over the workgroups of sixteen tiles; its words carry the launch's epoch, so nothing is cleared between launches).
+// PISCES_HIP_COMPACT=two: the scan + gather pair they replace (the A / B).
+static int32_t launch_compaction(PiscesHip* h, hipStream_t s, const PiscesCalledAllele* d_records, const PiscesTileResult* d_tr, int32_t n_tiles,
+                                 int32_t* d_offsets, PiscesCalledAllele* d_out, int32_t cap, int32_t* d_count, int32_t* d_called = nullptr)
 {
-    hipLaunchKernelGGL(scan_tile_counts_kernel, dim3(1), dim3(1024), 0, s, d_tr, n_tiles, d_offsets, d_count, d_called);
-    hipLaunchKernelGGL(gather_records_kernel, dim3((unsigned)n_tiles), dim3(64), 0, s, d_records, d_tr, n_tiles, d_offsets, d_out, cap);
+    // (the look-back's words belong to the handle: launches on a caller's stream may overlap each other, and two launches sharing the words
+    // would wait for each other's epochs for ever — those take the stateless pair)
+    if (h->compact_mode == 2 || (n_tiles > kGatherDirectTiles && s != h->stream)) {
+        hipLaunchKernelGGL(scan_tile_counts_kernel, dim3(1), dim3(1024), 0, s, d_tr, n_tiles, d_offsets, d_count, d_called);
+        hipLaunchKernelGGL(gather_records_kernel, dim3((unsigned)n_tiles), dim3(64), 0, s, d_records, d_tr, n_tiles, d_offsets, d_out, cap);
+        return PISCES_OK;
+    }
+    if (n_tiles <= kGatherDirectTiles && h->compact_mode != 3) {
+        hipLaunchKernelGGL(gather_direct_kernel, dim3((unsigned)n_tiles), dim3(64), 0, s, d_records, d_tr, n_tiles, d_offsets, d_out, cap, d_count, d_called);
+        return PISCES_OK;
+    }
+    const size_t groups = ((size_t)n_tiles + kCompactTiles - 1) / kCompactTiles;
+    {   // the look-back's words: a new buffer starts zeroed (epoch 0 is never used); the epoch wraps after 2^30 launches: cleared again then
+        const size_t before = h->d_compact_state.cap;
+        PISCES_HIP_CHECK(h, h->d_compact_state.reserve(groups));
+        if (h->d_compact_state.cap != before || h->compact_epoch >= (1u << 30) - 1u) {
+            // (launches of earlier epochs on other streams are not waited for: a buffer only grows under the stream it is used on — the handle's)
+            PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_compact_state.p, 0, h->d_compact_state.cap * sizeof(unsigned long long), s));
+            h->compact_epoch = 0;
+        }
+    }
+    const uint32_t epoch = ++h->compact_epoch;
+    hipLaunchKernelGGL(compact_records_kernel, dim3((unsigned)groups), dim3(256), 0, s, d_records, d_tr, n_tiles, h->d_compact_state.p, epoch, d_out, cap, d_count, d_called,
+                       d_offsets);
+    return PISCES_OK;
 }
 
 // device work of one flush: returns called alleles of `keys` sorted by (position, ref, alt)
@@ -353,6 +379,7 @@ static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& key
     PISCES_HIP_CHECK(h, h->d_records.reserve(cap));
     PISCES_HIP_CHECK(h, h->d_compact.reserve(cap + 1));   // ([0]: the header of a small launch's compaction)
     PISCES_HIP_CHECK(h, h->d_offsets.reserve((size_t)n_tiles));
+    if (h->chain_timing) { h->chain_have[1] = false; PISCES_HIP_CHECK(h, hipEventRecord(h->ev_chain[2], h->stream)); }
 
     std::vector<uint32_t> g;
     if (fused) {
@@ -426,8 +453,9 @@ static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& key
         hipLaunchKernelGGL(compact_small_kernel, dim3((unsigned)n_tiles), dim3(64), 0, h->stream, (const PiscesCalledAllele*)h->d_records.p,
                            (const PiscesTileResult*)h->d_tile_results.p, n_tiles, (PiscesCalledAllele*)h->h_dl, (int32_t)cap);
     } else {
-        launch_compaction(h->stream, h->d_records.p, h->d_tile_results.p, n_tiles, h->d_offsets.p, h->d_compact.p + 1, (int32_t)cap, h->d_count.p,
-                          h->d_count.p + 1);
+        { int32_t rcc = launch_compaction(h, h->stream, h->d_records.p, h->d_tile_results.p, n_tiles, h->d_offsets.p, h->d_compact.p + 1, (int32_t)cap, h->d_count.p,
+                                          h->d_count.p + 1); if (rcc) return rcc; }
+        if (h->chain_timing) { PISCES_HIP_CHECK(h, hipEventRecord(h->ev_chain[3], h->stream)); h->chain_have[1] = true; }
         PISCES_HIP_CHECK(h, hipMemcpyAsync(hdr, h->d_count.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         PISCES_HIP_CHECK(h, hipMemcpyAsync(hrec, h->d_compact.p + 1, spec * sizeof(PiscesCalledAllele), hipMemcpyDeviceToHost, h->stream));
     }

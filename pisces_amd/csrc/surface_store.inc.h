@@ -6,8 +6,22 @@
 // counted already: DoneProcessing, RegionStateManager.cs:336-353, is a floor, not a compaction) and the highest block any of its reads
 // touches (the segment goes when no block up to it is left).
 
-static void store_view(const PiscesHip* h, StoreView* V)
+// The position grid of a batch whose descriptors, fragments and row codes add_fused_kernel made is all that is left of its add once the
+// verdict is in — and a launch enqueued THEN starts 20-25 us after the kernel before it ended (the host's turn in between), with the device
+// idle.  It is kept back and enqueued in front of whatever reads or changes a grid next: the flush's kernel (store_view), the next add
+// (store_shape_launch), a failed add's clean-up.  Stream order does the rest.
+static int32_t store_run_deferred(PiscesHip* h)
 {
+    if (h->deferred_grid.empty()) return PISCES_OK;
+    for (auto& d : h->deferred_grid) hipLaunchKernelGGL(read_shape_kernel, dim3(d.blocks), dim3(256), 0, h->stream, d.S);
+    h->deferred_grid.clear();
+    PISCES_HIP_CHECK(h, hipGetLastError());
+    return PISCES_OK;
+}
+
+static void store_view(PiscesHip* h, StoreView* V)
+{
+    (void)store_run_deferred(h);   // (a launch error stays with the stream: the kernel that follows reports it)
     std::memset(V, 0, sizeof(*V));
     int n = 0;
     for (auto& sp : h->segments) {
@@ -325,6 +339,7 @@ static int32_t store_shape_launch(PiscesHip* h, const StorePlace& pl, ShapeArgs 
 {
     ReadSegment& g = *pl.seg;
     if (shaped) S.shape_blocks = S.enc_blocks = 0;
+    { int32_t rcd = store_run_deferred(h); if (rcd) return rcd; }   // (grids of earlier batches: this one's may be an extension of theirs, and may move)
     {   // the position grid (what gives a tile its fragment range): extended over the batch's span, or given up for this segment
         const bool first = g.n_reads == 0;
         bool ok = min_position > 0 && (first || g.grid_ok);
@@ -337,8 +352,9 @@ static int32_t store_shape_launch(PiscesHip* h, const StorePlace& pl, ShapeArgs 
             if (c_lo < base || c_hi - base + 1 > std::max<int64_t>(1ll << 18, 16 * (g.n_ops + (int64_t)n_cig))) ok = false;
             else if (c_hi - base + 1 > cells) {
                 const int64_t want = c_hi - base + 1;
+                // (the new cells need no fill: the batch's first read fills from the read before it up to its own position, its last read
+                // from its own position to the grid's end — grid_cells)
                 PISCES_HIP_CHECK(h, g.grid.grow_keep((size_t)want, (size_t)cells, h->stream));
-                PISCES_HIP_CHECK(h, hipMemsetAsync(g.grid.p + cells, 0x7F, (size_t)(want - cells) * sizeof(int32_t), h->stream));
                 cells = want;
             }
             // a batch that touches no block (every read soft-clipped away or without operations: max_key == 0, c_hi < base) leaves no cell; the
@@ -353,7 +369,8 @@ static int32_t store_shape_launch(PiscesHip* h, const StorePlace& pl, ShapeArgs 
     }
     const unsigned grid_blocks = S.grid ? (unsigned)((nr + 255) / 256) : 0u;
     const unsigned n_blocks = (unsigned)S.shape_blocks + (unsigned)S.enc_blocks + grid_blocks;
-    if (n_blocks) hipLaunchKernelGGL(read_shape_kernel, dim3(n_blocks), dim3(256), 0, h->stream, S);
+    if (n_blocks && shaped && h->defer_grid) h->deferred_grid.push_back({S, n_blocks});   // (the grid role alone: enqueued with what comes next)
+    else if (n_blocks) hipLaunchKernelGGL(read_shape_kernel, dim3(n_blocks), dim3(256), 0, h->stream, S);
     if (!pl.direct && !batch_has_dirs && g.v_dirs)   // a batch without directions in a segment that tracks them
         hipLaunchKernelGGL(segment_fill_dirs_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, h->stream, (const ReadDesc*)g.desc.p,
                            (const ReadExt*)g.ext.p, S.n0, S.n0 + nr, const_cast<uint8_t*>(g.v_dirs));
@@ -404,7 +421,7 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
     }
     // the launch's shared words — kPrepReplicas x {lowest key, highest key, lowest position, X / = seen}, the first-error word, the count of
     // workgroups that are through, the totals — are set once: the collecting workgroup of every launch leaves them as the next one expects
-    constexpr size_t kWordsSpan = 0, kWordsError = 4 * kPrepReplicas * sizeof(int32_t), kWordsDone = kWordsError + 8, kWordsTotals = kWordsDone + 8, kWordsBytes = kWordsTotals + 16;
+    constexpr size_t kWordsSpan = 0, kWordsError = 4 * kPrepReplicas * sizeof(int32_t), kWordsDone = kWordsError + 8, kWordsTotals = kWordsDone + 8 * ((1 + kPrepReplicas) * 4 / 8 + 1), kWordsBytes = kWordsTotals + 16;
     if (!h->d_fused_words.p) {
         PISCES_HIP_CHECK(h, h->d_fused_words.reserve(kWordsBytes));
         uint8_t init[kWordsBytes];
@@ -421,9 +438,11 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
         if (h->d_fused_scan.cap != before) PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_fused_scan.p, 0, h->d_fused_scan.cap * sizeof(unsigned long long), h->stream));
     }
     constexpr int32_t kPrepKeys = 8192;
-    if (!h->h_prep) PISCES_HIP_CHECK(h, host_alloc((void**)&h->h_prep, sizeof(PrepVerdict) + (size_t)kPrepKeys * sizeof(int32_t)));
+    if (!h->h_prep) PISCES_HIP_CHECK(h, host_alloc((void**)&h->h_prep, sizeof(PrepVerdict) + (size_t)kPrepKeys * sizeof(int32_t) + 16));
     PrepVerdict* const verdict = (PrepVerdict*)h->h_prep;
     int32_t* const keys = (int32_t*)(h->h_prep + sizeof(PrepVerdict));
+    int32_t* const bad_direction = keys + kPrepKeys;   // (set by the launch's stream role, which no other workgroup waits for)
+    *bad_direction = 0;
     AddFusedArgs F;
     std::memset(&F, 0, sizeof(F));
     PrepareArgs& A = F.P;
@@ -480,11 +499,31 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
     F.verdict = verdict;
     F.keys_out = keys;
     F.capacity = kPrepKeys;
+    F.bad_direction = bad_direction;
+    if (++h->fused_seq <= 0) h->fused_seq = 1;
+    F.seq = h->fused_seq;
+    verdict->ready = 0;
+    // (pisces_hip_set_chain_timing: the add's device time starts with its first kernel — what the host does before it is not the device's)
+    if (h->chain_timing && src) { h->chain_have[0] = false; PISCES_HIP_CHECK(h, hipEventRecord(h->ev_chain[0], h->stream)); }
     hipLaunchKernelGGL(add_fused_kernel, dim3((unsigned)(F.read_blocks + F.stream_blocks + F.misc_blocks)), dim3(256), 0, h->stream, F);
     PISCES_HIP_CHECK(h, hipGetLastError());
-    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    {   // The one wait of an add.  The collecting workgroup stores the launch's number behind the verdict: polling that word in pinned memory
+        // sees it ~2 us after the store, where hipStreamSynchronize's wake-up takes 15-25 us during which the device has nothing to do (the
+        // position grid and candidate discovery are enqueued behind the verdict).  The stream's other work is ordered by the stream itself.
+        // A launch that never reports (a device fault) falls back to the stream's own wait and error after 0.2 s.
+        const volatile int32_t* const ready = &verdict->ready;
+        const auto t0 = std::chrono::steady_clock::now();
+        bool seen = false;
+        // (per-base directions are checked by the stream role, which the verdict does not wait for: such a batch waits for the whole launch)
+        for (int64_t spin = 0; !has_dirs && !(seen = (*ready == F.seq)); spin++) {
+            if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+            __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (!seen) PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    }
     h->h_meta_used = 0;
-    const unsigned long long first_error = verdict->first_error;
+    const unsigned long long first_error = std::min<unsigned long long>(verdict->first_error, *bad_direction ? (unsigned long long)kPrepBadDirection : ~0ull);
     const int32_t span[3] = {verdict->span[0], verdict->span[1], verdict->span[2]};
     h->eqx_in_batch = count_indels && verdict->has_eqx != 0;
     const long long totals[2] = {count_indels ? verdict->totals[0] : 0, count_indels ? verdict->totals[1] : 0};
@@ -558,6 +597,7 @@ static int32_t store_finish_add(PiscesHip* h, StorePlace& pl, int32_t rc, uint8_
     }
     { int32_t rcs = stage_release(h); if (rc == PISCES_OK) rc = rcs; }   // (transfers out of the pinned buffer may be in flight whatever happened after them)
     if (rc) {
+        (void)store_run_deferred(h);   // (before the segment's buffers can go)
         (void)hipStreamSynchronize(h->stream);
         pl.seg->grid_ok = false;   // (the refused batch may have written cells of an open segment's position grid: the segment goes without)
         store_unplace(h, pl);
@@ -572,6 +612,7 @@ static int32_t store_finish_add(PiscesHip* h, StorePlace& pl, int32_t rc, uint8_
     store_maybe_seal(h, &g);
     for (int32_t k : touched) (void)get_block(h, (k - 1) * bs + 1);
     h->stats[2] += nr;
+    if (h->chain_timing) { PISCES_HIP_CHECK(h, hipEventRecord(h->ev_chain[1], h->stream)); h->chain_have[0] = true; }
     return PISCES_OK;
 }
 

@@ -281,14 +281,14 @@ class HipVariantCaller:
                 continue
             _check(self._h, rc)
             recs = out[: n.value]
-            alleles = []
-            for r, ci in zip(recs, idx[: n.value]):
-                if ci < 0:
-                    alleles.append((_abi.BASE_OF_ALLELE[_abi.info_ref(r["info"])], _abi.BASE_OF_ALLELE[_abi.info_alt(r["info"])]))
-                else:
-                    c = cands[ci]
-                    o = c.allele_offset
-                    alleles.append((bytes(pool[o: o + c.ref_len]).decode("latin-1"), bytes(pool[o + c.ref_len: o + c.ref_len + c.alt_len]).decode("latin-1")))
+            # (point rows in one pass over the array; only the rows that stand on a candidate are looked up one by one)
+            letters = np.array(list(_abi.BASE_OF_ALLELE) + ["?", "?"])
+            info = recs["info"].astype(np.int64)
+            alleles = list(zip(letters[_abi.info_ref(info)].tolist(), letters[_abi.info_alt(info)].tolist()))
+            for i in np.nonzero(idx[: n.value] >= 0)[0].tolist():
+                c = cands[idx[i]]
+                o = c.allele_offset
+                alleles[i] = (bytes(pool[o: o + c.ref_len]).decode("latin-1"), bytes(pool[o + c.ref_len: o + c.ref_len + c.alt_len]).decode("latin-1"))
             return recs, alleles
 
     def GetCandidates(self, upToPosition=None):
@@ -519,6 +519,16 @@ class HipVariantCaller:
         ms, n = C.c_double(0), C.c_int64(0)
         _check(self._h, lib.pisces_hip_kernel_time(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def SetChainTiming(self, enable=True):
+        """pisces_hip_set_chain_timing: events around what AddDeviceReads enqueues and around a flush's kernels (up to the compacted records)."""
+        _check(self._h, lib.pisces_hip_set_chain_timing(self._h, int(bool(enable))))
+
+    def ChainTime(self):
+        """(add_ms, flush_ms) of the last AddDeviceReads and the last flush since SetChainTiming(True): device time by HIP events."""
+        out = (C.c_double * 2)()
+        _check(self._h, lib.pisces_hip_chain_time(self._h, out))
+        return out[0], out[1]
 
     def probe_read_bandwidth(self, nbytes=1 << 30, reps=6):
         """GB/s of a plain streaming read on this device (context for the roofline fraction)."""

@@ -255,20 +255,22 @@ def reads_of(p, n_amplicons=None, first_amplicon=None):
         seq_offset=np.array(seq_off, dtype=np.int32), bases=np.concatenate(bases), quals=np.concatenate(quals))
 
 
-def observations_of(p, n_tiles=None):
-    """(positions, tuples) numpy arrays of the first `n_tiles` tiles, padding removed, tile order kept."""
+def observations_of(p, n_tiles=None, first_tile=0):
+    """(positions, tuples) numpy arrays of `n_tiles` tiles from `first_tile` on (default: the first `n_tiles`), padding removed, tile
+    order kept."""
     tiles = p.tiles.cpu().numpy().view(_abi.TILE_DTYPE)
-    nt = p.n_tiles if n_tiles is None else min(p.n_tiles, n_tiles)
-    hi = int(tiles[nt - 1]["tuple_end"]) if nt > 0 else 0   # only the tiles asked for leave the device
-    tup = p.tuples[:hi].cpu().numpy().view(np.uint32)
+    first_tile = max(0, min(int(first_tile), p.n_tiles))
+    nt = p.n_tiles if n_tiles is None else min(p.n_tiles, first_tile + n_tiles)
+    if nt <= first_tile:
+        return np.zeros(0, np.int32), np.zeros(0, np.uint32)
+    lo, hi = int(tiles[first_tile]["tuple_begin"]), int(tiles[nt - 1]["tuple_end"])   # only the tiles asked for leave the device
+    tup = p.tuples[lo:hi].cpu().numpy().view(np.uint32)
     pos_out, tup_out = [], []
-    for t in range(nt):
-        b, e = int(tiles[t]["tuple_begin"]), int(tiles[t]["tuple_end"])
+    for t in range(first_tile, nt):
+        b, e = int(tiles[t]["tuple_begin"]) - lo, int(tiles[t]["tuple_end"]) - lo
         seg = tup[b:e]
         pos_out.append((tiles[t]["start_position"] + _abi.tuple_fields(seg)[0]).astype(np.int32))
         tup_out.append(seg)
-    if not pos_out:
-        return np.zeros(0, np.int32), np.zeros(0, np.uint32)
     return np.concatenate(pos_out), np.concatenate(tup_out)
 
 

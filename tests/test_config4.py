@@ -21,6 +21,37 @@ def torch_cuda():
     return torch
 
 
+def _oracle_windows(config4, cfg, job, got, got_alleles, cuts, chunk_reads=400_000, n_random=4):
+    """1000-locus blocks of a contig's (sharded, concatenated) output against the oracle, records and allele strings: the block every
+    shard cut falls in front of, the block a stretch of reads ends in (where run_piece's flush cuts the run), the contig's last block
+    and a few seeded anywhere.  The oracle runs the reads of the block and its two neighbours (interval set and the whole contig's
+    flush schedule as far as it falls there); the middle block is compared.  Returns the number of blocks checked."""
+    from tests import orc
+    from tests.test_gpu_parity import assert_records_match
+    pos = job["arrays"][0].astype(np.int64)
+    ups_all = [int(pos[b]) - 1 for b in range(chunk_reads, len(pos), chunk_reads)]
+    last_position = int(job["ends"][-1])
+    last_block = (last_position - 1) // 1000
+    blocks = {last_block, 1} | {(lo - 1) // 1000 for lo in cuts} | {(lo - 2) // 1000 for lo in cuts} | {(u - 1) // 1000 for u in ups_all[:2]}
+    rng = np.random.default_rng(100 + job["contig"])
+    while len(blocks) < len(cuts) * 2 + 2 + min(len(ups_all), 2) + n_random:
+        blocks.add(int(rng.integers(1, last_block)))
+    blocks = sorted(b for b in blocks if 1 <= b <= last_block)
+    for k in blocks:
+        lo, hi = (k - 1) * 1000 + 1, min((k + 2) * 1000, len(job["ref"]))
+        i0, i1 = int(np.searchsorted(pos, lo - 2 * config4.INTERVAL)), int(np.searchsorted(pos, hi + 1))   # (no read is two intervals long)
+        batch = config4.read_batch_range(job["arrays"], i0, i1)
+        keep = (job["ends"] >= lo) & (job["starts"] <= hi)
+        ivs = list(zip(np.maximum(job["starts"][keep], lo).tolist(), np.minimum(job["ends"][keep], hi).tolist()))
+        exp, exp_alleles, _ = orc.run_reads_schedule(batch, job["ref"], lo, hi - lo + 1, cfg, [u for u in ups_all if lo <= u <= hi], intervals=ivs)
+        sel = (exp["position"] > k * 1000) & (exp["position"] <= (k + 1) * 1000)
+        g0, g1 = np.searchsorted(got["position"], [k * 1000 + 1, (k + 1) * 1000 + 1])
+        assert g1 - g0 == int(sel.sum()) > 0, (job["contig"], k, int(g0), int(g1), int(sel.sum()))
+        assert_records_match(got[g0:g1], exp[sel])
+        assert got_alleles[g0:g1] == [x for x, s_ in zip(exp_alleles, sel) if s_], (job["contig"], k)
+    return len(blocks)
+
+
 def test_config4_as_stated_eight_shards_in_turn_on_one_gpu(torch_cuda):
     from pisces_amd import config4, engine
     depth, world = 200, 8
@@ -38,7 +69,7 @@ def test_config4_as_stated_eight_shards_in_turn_on_one_gpu(torch_cuda):
     verify = set(cut_contigs[:2] + cut_contigs[-1:])
     shard_loci = np.zeros(world, dtype=np.int64)
     totals = np.zeros(4, dtype=np.int64)
-    n_reads_total = n_loci_total = 0
+    n_reads_total = n_loci_total = checked_blocks = 0
     for c, n_iv in enumerate(sizes):
         job = config4.make_contig(c, n_iv, depth=depth)
         n_reads_total += job["batch"].n_reads
@@ -74,8 +105,10 @@ def test_config4_as_stated_eight_shards_in_turn_on_one_gpu(torch_cuda):
             whole, whole_alleles, wstats, _ = config4.run_piece(engine, cfg, job)
             assert got.tobytes() == whole.tobytes() and got_alleles == whole_alleles, c
             assert called == wstats["TotalNumCalled"] and wstats["reads"] == job["batch"].n_reads
+            checked_blocks += _oracle_windows(config4, cfg, job, got, got_alleles, [lo for _, lo, _ in pieces_of[c][1:]])
         del job, got
     assert n_loci_total == 30_000_000 and n_reads_total == 200_000 * depth
+    assert checked_blocks >= 16                                                   # blocks held to the oracle, record for record
     assert totals[2] == n_reads_total and totals[3] == 0
     assert shard_loci.sum() == n_loci_total and shard_loci.min() > 0.8 * shard_loci.mean()   # the cut is balanced
 

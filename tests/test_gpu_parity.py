@@ -410,6 +410,30 @@ def test_error_paths(torch_cuda):
 
 
 # ---------------------------------------------------------------- BASELINE sizes: size-independent properties
+
+def assert_random_windows_match_oracle(p, got, cfg, n_windows=16, window_loci=1000, seed=7):
+    """Seeded random windows of one 1000-locus block each over the WHOLE launch — always the first and the last block, the rest anywhere
+    (tiles late in a multi-round launch, the far end of the position range) — compared record for record with the oracle run on those
+    tiles' observations (a tile's records depend on its own observations only).  Returns the loci checked."""
+    from pisces_amd import synth
+    tiles = p.tiles.cpu().numpy().view(_abi.TILE_DTYPE)
+    per = max(1, min(p.n_tiles, -(-window_loci // max(int(tiles[0]["n_loci"]), 1))))
+    rng = np.random.default_rng(seed)
+    firsts = {0, p.n_tiles - per}
+    while len(firsts) < min(n_windows, p.n_tiles - per + 1):
+        firsts.add(int(rng.integers(0, p.n_tiles - per + 1)))
+    ref = p.ref.cpu().numpy()
+    checked = 0
+    for t0 in sorted(firsts):
+        start = int(tiles[t0]["start_position"])
+        n = int(tiles[t0 + per - 1]["start_position"] + tiles[t0 + per - 1]["n_loci"]) - start
+        pos, tup = synth.observations_of(p, per, first_tile=t0)
+        exp, _ = orc.run_observations(pos, tup, ref, start, n, cfg)
+        lo, hi = np.searchsorted(got["position"], [start, start + n])
+        assert_records_match(got[lo:hi], exp)
+        checked += n
+    return checked
+
 def test_full_size_properties_config2(torch_cuda):
     """100k loci x 500x (BASELINE config 2): exact depth everywhere, one candidate locus per locus, linearity
     (two launches over halves == one launch), idempotence (same launch twice), a sampled slice against the oracle."""
@@ -433,6 +457,8 @@ def test_full_size_properties_config2(torch_cuda):
     pos, tup = synth.observations_of(p, n_t)
     exp, _ = orc.run_observations(pos, tup, p.ref.cpu().numpy(), p.region_start, n_t * 64, cfg)
     assert_records_match(got[got["position"] < p.region_start + n_t * 64], exp)
+    # and sixteen random 1000-locus windows over the whole launch (the last block among them) against the oracle
+    assert assert_random_windows_match_oracle(p, got, cfg) >= 16_000
 
 
 @pytest.mark.gpu
@@ -471,6 +497,8 @@ def test_full_size_properties_other_baseline_configs(torch_cuda, n_loci, depth, 
     pos, tup = synth.observations_of(p, n_t)
     exp, _ = orc.run_observations(pos, tup, p.ref.cpu().numpy(), p.region_start, n_t * 64, cfg)
     assert_records_match(got[got["position"] < p.region_start + n_t * 64], exp)
+    # sixteen random 1000-locus windows over the whole launch — the last block, tiles of late rounds, the far end of the position range
+    assert assert_random_windows_match_oracle(p, got, cfg) >= 16_000
     del p
     torch.cuda.empty_cache()
 
@@ -853,6 +881,7 @@ def test_full_size_config3_mix_through_the_streaming_surface(torch_cuda, n_loci,
         assert head_alleles == [x for x, k in zip(exp_alleles, keep) if k]
         assert_records_match(head, exp[keep])
         recs.append(head)
+        got_alleles = list(head_alleles)
         for a0 in range(14, n_amp, chunk):
             na = min(chunk, n_amp - a0)
             p = synth.make_pileup(na * synth.READ_LEN, depth, seed=seed, device="cuda", first_locus=a0 * synth.READ_LEN, total_loci=n_loci,
@@ -861,13 +890,44 @@ def test_full_size_config3_mix_through_the_streaming_surface(torch_cuda, n_loci,
             planted += pl
             n_reads += batch.n_reads
             c.AddAlleleCounts(batch)
-            recs.append(c.Call(origin + a0 * synth.READ_LEN - 1, capacity=1 << 19))
+            r, a = c.CallWithAlleles(origin + a0 * synth.READ_LEN - 1, capacity=1 << 19)
+            recs.append(r)
+            got_alleles += a
             del p, batch
-        recs.append(c.Call(None, capacity=1 << 19))
+        r, a = c.CallWithAlleles(None, capacity=1 << 19)
+        recs.append(r)
+        got_alleles += a
         stats = c.Stats()
     got = np.concatenate(recs)
-    assert stats["reads"] == n_reads
+    assert stats["reads"] == n_reads and len(got_alleles) == len(got)
     assert (np.diff(got["position"]) >= 0).all()
+    # ---- sixteen 1000-locus blocks anywhere in the run against the oracle: the last block, the blocks that hold a stretch boundary (where
+    # one add_reads ended and the next began, and a flush cut the run), blocks late in the position range.  The oracle runs the reads of
+    # the block and of its two neighbours through the flushes of the product's own schedule that fall there; the middle block is compared,
+    # records and allele strings.
+    ref_np = ref.cpu().numpy() if hasattr(ref, "cpu") else np.asarray(ref)
+    ups_all = [origin + a0 * synth.READ_LEN - 1 for a0 in range(14, n_amp, chunk)]
+    last_position = origin + n_loci - 1
+    last_block = (last_position - 1) // 1000
+    blocks = {last_block, 3}
+    if len(ups_all) > 1:
+        blocks |= {(ups_all[1] - 1) // 1000, (ups_all[len(ups_all) // 2] - 1) // 1000, (ups_all[-1] - 1) // 1000}
+    rng = np.random.default_rng(11)
+    while len(blocks) < min(16, last_block - 2):
+        blocks.add(int(rng.integers(3, last_block)))
+    for k in sorted(blocks):
+        lo, hi = (k - 1) * 1000 + 1, min((k + 2) * 1000, last_position)
+        a_lo, a_hi = max(0, (lo - origin) // synth.READ_LEN), min(n_amp, -(-(hi + 1 - origin) // synth.READ_LEN))
+        p = synth.make_pileup((a_hi - a_lo) * synth.READ_LEN, depth, seed=seed, device="cuda", first_locus=a_lo * synth.READ_LEN, total_loci=n_loci,
+                              with_tuples=False)
+        batch, _ = synth.mixed_reads(p, seed)
+        exp, exp_alleles, _ = orc.run_reads_schedule(batch, ref_np, lo, hi - lo + 1, cfg, [u for u in ups_all if lo <= u <= hi])
+        sel = (exp["position"] > k * 1000) & (exp["position"] <= (k + 1) * 1000)
+        g0, g1 = np.searchsorted(got["position"], [k * 1000 + 1, (k + 1) * 1000 + 1])
+        assert g1 - g0 == int(sel.sum()) >= min(1000, last_position - k * 1000), (k, g0, g1, int(sel.sum()))
+        assert_records_match(got[g0:g1], exp[sel])
+        assert got_alleles[g0:g1] == [x for x, s_ in zip(exp_alleles, sel) if s_], k
+        del p, batch
     cats = (got["info"] >> 4) & 7
     point = (cats == _abi.CAT_SNV) | (cats == _abi.CAT_REFERENCE)
     assert ((got["total_coverage"] + got["num_no_calls"])[point] == depth).all()
