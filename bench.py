@@ -340,6 +340,48 @@ def end_to_end(pileup, cfg, engine, loci=30_000):
     return out
 
 
+def chain_roofline(pileup, cfg, engine, torch, reps=10):
+    """`roofline_chain`: the DEVICE time of reads in HBM -> records in HBM through the streaming surface, on all of the configuration the
+    metric is quoted on (BASELINE config 2, batch 0: 333 500 reads): pisces_hip_add_device_reads (the caller's arrays into the store, the
+    checks, descriptors / fragments / row codes: one launch) + pisces_hip_flush_view (position grid, the flush's kernel, the ordered
+    compaction), each span by two HIP events on the handle's stream (pisces_hip_set_chain_timing): from the first kernel an entry point
+    enqueues to the last — the host's turns inside a span count, the records' transfer to the host (behind the last event) does not.
+    Algorithmic bytes as SURVEY 8d counts the path (2 B per aligned base + 64 B per record).  Reference: what one AddAlleleCounts +
+    FindCandidates per read and one GetCandidatesToProcess + Call do (RegionStateManager.cs:118-220, CandidateVariantFinder.cs:36-83)."""
+    from pisces_amd import synth
+    ref = pileup.ref.cpu().numpy()
+    n_amp = pileup.base.shape[0]
+    whole = synth.reads_of(pileup, n_amp, first_amplicon=pileup.first_amplicon)
+    d = engine.DeviceReadBatch.from_host(whole, "cuda:0")
+    spans, walls, n_rec = [], [], 0
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(ref)
+        c.SetChainTiming(True)
+        for rep in range(reps + 2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            c.AddDeviceReads(d)
+            n_rec = len(c.CallView(None))
+            dt = time.perf_counter() - t0
+            if rep >= 2:
+                spans.append(c.ChainTime())
+                walls.append(dt)
+        c.SetChainTiming(False)
+    nbytes = 2.0 * int(whole.n_bases) + 64.0 * n_rec
+    add_ms = sum(a for a, _ in spans) / len(spans)
+    flush_ms = sum(f for _, f in spans) / len(spans)
+    chain_ms = add_ms + flush_ms
+    best = min(a + f for a, f in spans)
+    achieved = nbytes / (chain_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "chain_ms": chain_ms, "add_device_reads_ms": add_ms, "flush_view_ms": flush_ms, "best_chain_ms": best, "pairs_timed": len(spans),
+            "algorithmic_bytes_per_batch": nbytes, "reads": int(whole.n_reads), "records": n_rec, "loci": pileup.n_loci,
+            "wall_clock_ms_per_pair": sum(walls) / len(walls) * 1e3,
+            "what": "device time (HIP events on the handle's stream, mean of the timed pairs) of pisces_hip_add_device_reads + pisces_hip_flush_view on "
+                    "BASELINE config 2's batch: reads in HBM -> compacted records in HBM; the D2H transfer of the records and the host's work outside "
+                    "the two spans are in wall_clock_ms_per_pair only"}
+
+
 def end_to_end_full(pileup, cfg, engine, torch):
     """The streaming surface on ALL of the configuration the metric is quoted on (BASELINE config 2: 100 000 loci x 500x = 333 500 reads
     of batch 0), not a 30 000-locus sample: in one add_reads + flush, and block by block as SmallVariantCaller drives it
@@ -1298,6 +1340,10 @@ def main():
                 out["end_to_end_full"], out["roofline_streaming"] = end_to_end_full(ring[0], cfg, engine, torch)
             except Exception as e:   # noqa: BLE001  (extra figures: they must not cost the bench line)
                 out["end_to_end_full"] = {"error": str(e)[:200]}
+            try:
+                out["roofline_chain"] = chain_roofline(ring[0], cfg, engine, torch)
+            except Exception as e:   # noqa: BLE001  (extra figures: they must not cost the bench line)
+                out["roofline_chain"] = {"error": str(e)[:200]}
             for key, sample in (("roofline_config3", config3_sample), ("roofline_config5", config5_sample), ("roofline_config4", config4_sample)):
                 try:
                     out[key] = sample(engine, torch)

@@ -33,6 +33,11 @@
 #ifndef PISCES_ADD_OCC
 #define PISCES_ADD_OCC 6      // waves a SIMD of add_fused_kernel: 1 303 read workgroups of a 333 500-read batch are resident at once (5.1 waves a SIMD)
 #endif
+#ifdef PISCES_ADD_STAMPS   // development: when the roles of add_fused_kernel start and end (wall_clock64, 10 ns), min / max over workgroups
+#define PISCES_STAMP(k, is_max) do { if (threadIdx.x == 0) A.stamps[(long long)blockIdx.x * 8 + ((k) == 0 ? 2 : (k) == 1 ? 3 : (k) - 2)] = (long long)wall_clock64(); } while (0)
+#else
+#define PISCES_STAMP(k, is_max) do { } while (0)
+#endif
 #ifndef PISCES_ADD_ABLATE
 #define PISCES_ADD_ABLATE 0   // (development: ablations of add_fused_kernel, tools/add_ablate.sh)
 #endif
@@ -395,12 +400,12 @@ struct PrepareArgs {
 constexpr int kPrepReplicas = 32;
 // bits [a, b] of the block map; a bit that is set already (seen through a load that goes past this XCD's L2, where a stale line would
 // show zero for the rest of the launch) costs no atomic: same-address atomics from eight XCDs serialise at 0.1-0.2 us each
-__device__ __forceinline__ void set_keys(const PrepareArgs& A, int64_t a, int64_t b)
+__device__ __forceinline__ void set_keys(const PrepareArgs& A, int replica, int64_t a, int64_t b)
 {
 #if PISCES_ADD_ABLATE == 7
     return;
 #endif
-    uint32_t* const map = A.block_bits + (int64_t)(blockIdx.x & (kPrepReplicas - 1)) * A.map_stride;   // (any copy will do: the launch's workgroup index)
+    uint32_t* const map = A.block_bits + (int64_t)(replica & (kPrepReplicas - 1)) * A.map_stride;   // (any copy will do: the read workgroup's index)
     for (int64_t k = a; k <= b; k++) {
         if (k >= A.n_block_bits) continue;   // (cannot be: the map covers every int32 position)
         const uint32_t bit = 1u << (k & 31);
@@ -459,7 +464,7 @@ __device__ __forceinline__ void prepare_reads(const PrepareArgs& A, const int bl
                 const int64_t a = (from + A.block_size - 1) / A.block_size, b = (to + A.block_size - 1) / A.block_size;   // GetBlockKey
                 if (run_b < run_a) { run_a = a; run_b = b; }
                 else if (a <= run_b + 1 && b >= run_a - 1) { run_a = min(run_a, a); run_b = max(run_b, b); }
-                else { set_keys(A, run_a, run_b); run_a = a; run_b = b; }
+                else { set_keys(A, block, run_a, run_b); run_a = a; run_b = b; }
                 k_lo = min(k_lo, (int)a);
                 k_hi = max(k_hi, (int)min(b, (int64_t)0x7FFFFFFF));
             };
@@ -522,7 +527,7 @@ __device__ __forceinline__ void prepare_reads(const PrepareArgs& A, const int bl
             if (lane == l0) {
                 const int slot = atomicAdd(&s_nruns, 1);
                 if (slot < kRunSlots) { s_run_a[slot] = a0; s_run_b[slot] = b0; }
-                else set_keys(A, a0, b0);
+                else set_keys(A, block, a0, b0);
             }
             todo &= ~same;
         }
@@ -545,7 +550,7 @@ __device__ __forceinline__ void prepare_reads(const PrepareArgs& A, const int bl
         if (t < n_runs) {
             bool seen = false;
             for (int j = 0; j < t; j++) seen = seen || (s_run_a[j] == s_run_a[t] && s_run_b[j] == s_run_b[t]);
-            if (!seen) set_keys(A, s_run_a[t], s_run_b[t]);
+            if (!seen) set_keys(A, block, s_run_a[t], s_run_b[t]);
         }
     }
     if (threadIdx.x == 0 && PISCES_ADD_ABLATE != 8) {
@@ -571,17 +576,30 @@ struct PrepVerdict {
     int32_t ready;       // the launch's sequence number, stored last (system-scope release): the host may poll it instead of waiting for the stream
 };
 static_assert(sizeof(PrepVerdict) == 48, "PrepVerdict layout");
-// (run by the workgroup of add_fused_kernel's read role that finishes last, behind an agent-scope fence: every other workgroup's words are in)
+// (run by the read workgroup of add_fused_kernel that is counted in last.  It runs while the streaming role has the memory system full — a
+// round trip is 4-5 us then — so it is written for few of them: every word of the other workgroups is read with an agent-scope atomic
+// load (it sees their agent-scope atomics without a fence; an acquire fence is an L2 invalidate in front of every load), two rounds of
+// independent loads; what goes to the host goes as system-scope stores, acknowledged (s_waitcnt) before the word the host polls is
+// stored — no release fence: that is a write-back of the XCD's L2, full of the streaming role's lines.  First form: 38 us; the launch
+// ended with it.)
 __device__ __forceinline__ void prepare_collect(uint32_t* __restrict__ block_bits, int64_t map_stride, int32_t* __restrict__ key_span,
-                                                unsigned long long* __restrict__ first_error, const long long* __restrict__ totals /* or nullptr */,
+                                                unsigned long long* __restrict__ first_error, long long* __restrict__ totals,
                                                 PrepVerdict* __restrict__ out, int32_t* __restrict__ keys_out, int32_t capacity)
 {
     __shared__ int s_n, s_at, s_span[4];
+    __shared__ unsigned long long s_err;
+    __shared__ long long s_tot[2];
     if (threadIdx.x == 0) { s_n = 0; s_at = 0; s_span[0] = 0x7FFFFFFF; s_span[1] = 0; s_span[2] = 0x7FFFFFFF; s_span[3] = 0; }
     __syncthreads();
     if (threadIdx.x < kPrepReplicas) {   // the copies of the span folded
-        const int32_t* sp = key_span + 4 * threadIdx.x;
-        atomicMin(&s_span[0], sp[0]); atomicMax(&s_span[1], sp[1]); atomicMin(&s_span[2], sp[2]); atomicMax(&s_span[3], sp[3]);
+        int32_t* const sp = key_span + 4 * threadIdx.x;
+        const int v0 = __hip_atomic_load(&sp[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), v1 = __hip_atomic_load(&sp[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                  v2 = __hip_atomic_load(&sp[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), v3 = __hip_atomic_load(&sp[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicMin(&s_span[0], v0); atomicMax(&s_span[1], v1); atomicMin(&s_span[2], v2); atomicMax(&s_span[3], v3);
+    } else if (threadIdx.x == 64) {      // (another wave: the same round trip)
+        s_err = __hip_atomic_load(first_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_tot[0] = __hip_atomic_load(&totals[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_tot[1] = __hip_atomic_load(&totals[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     const int lo = s_span[0], hi = s_span[1];
@@ -592,12 +610,12 @@ __device__ __forceinline__ void prepare_collect(uint32_t* __restrict__ block_bit
     for (int w = w0 + (int)threadIdx.x; w <= w1; w += 256) {
         uint32_t v[kPrepReplicas], bits = 0;
 #pragma unroll
-        for (int r = 0; r < kPrepReplicas; r++) v[r] = block_bits[(int64_t)r * map_stride + w];   // (all the loads first: one round trip)
+        for (int r = 0; r < kPrepReplicas; r++) v[r] = __hip_atomic_load(&block_bits[(int64_t)r * map_stride + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (all the loads first: one round trip)
 #pragma unroll
         for (int r = 0; r < kPrepReplicas; r++) bits |= v[r];
 #pragma unroll
         for (int r = 1; r < kPrepReplicas; r++)
-            if (v[r]) block_bits[(int64_t)r * map_stride + w] = 0;
+            if (v[r] && map_stride) block_bits[(int64_t)r * map_stride + w] = 0;
         block_bits[w] = bits;
         mine += __popc(bits);
     }
@@ -606,20 +624,22 @@ __device__ __forceinline__ void prepare_collect(uint32_t* __restrict__ block_bit
     const int n = s_n;
     if (n <= capacity) {
         for (int w = w0 + (int)threadIdx.x; w <= w1; w += 256) {
-            uint32_t bits = block_bits[w];
+            uint32_t bits = block_bits[w];   // (this thread's own store of the pass above)
             if (!bits) continue;
             int at = atomicAdd(&s_at, __popc(bits));
-            for (; bits; bits &= bits - 1) keys_out[at++] = w * 32 + (int)__builtin_ctz(bits);
+            for (; bits; bits &= bits - 1) __hip_atomic_store(&keys_out[at++], w * 32 + (int)__builtin_ctz(bits), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             block_bits[w] = 0;
         }
     }
     if (threadIdx.x == 0) {
-        out->first_error = *first_error;
-        out->totals[0] = totals ? totals[0] : 0;
-        out->totals[1] = totals ? totals[1] : 0;
-        out->span[0] = s_span[0]; out->span[1] = s_span[1]; out->span[2] = s_span[2];
-        out->n_keys = n;
-        out->has_eqx = s_span[3];
+        __hip_atomic_store(&out->first_error, s_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&out->totals[0], s_tot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&out->totals[1], s_tot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&out->span[0], s_span[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&out->span[1], s_span[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&out->span[2], s_span[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&out->n_keys, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&out->has_eqx, s_span[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -647,6 +667,7 @@ struct AddFusedArgs {
     ShapeArgs S;                // shape role (do_shape) — reads the same arrays; S.enc_* unused here
     int32_t do_shape;
     int32_t read_blocks, stream_blocks, misc_blocks;
+    int32_t role_stride;        // every role_stride-th workgroup of the launch is a read workgroup (>= 1), until there are read_blocks of them
     const uint8_t* s_bases;     // stream role: sources
     const uint8_t* s_quals;
     const uint8_t* s_dirs;      // or nullptr
@@ -665,48 +686,77 @@ struct AddFusedArgs {
     int32_t capacity;
     int32_t* bad_direction;           // pinned host memory, zero at launch: set by the stream role when a per-base direction is none of 0 / 1 / 2
     int32_t seq;                      // this launch's number (nonzero): verdict->ready
+    long long* stamps;                // development (PISCES_ADD_STAMPS): [16]
 };
+constexpr int kScanDirectBlocks = 4096;   // read workgroups up to which the candidate-slot scan adds up the words before its own (beyond: look-back)
 constexpr unsigned long long kScanAggregate = 1ull << 62, kScanInclusive = 2ull << 62, kScanField = 0x7FFFFFFFull;
 
 __global__ __launch_bounds__(256, PISCES_ADD_OCC) void add_fused_kernel(AddFusedArgs A)
 {
-    const int b = (int)blockIdx.x;
+    // Roles by workgroup index, INTERLEAVED: every role_stride-th workgroup is a read workgroup (in index order, which is dispatch order:
+    // the look-back waits for lower read indices only), the others stream.  With the read workgroups in front they took the chip's slots
+    // first and the streaming — the launch's bytes — started when they were through: the two latencies added up (62-73 us for 45 us of bytes).
+    // (in units of eight consecutive workgroups — one per XCD: a stride of single workgroups that shares a factor with eight puts the read
+    // role on some XCDs only, 129 us at a stride of four)
+    const int raw = (int)blockIdx.x;
+    const int unit = raw >> 3, in_unit = raw & 7;
+    const int uq = unit / A.role_stride;
+    const bool read_unit = unit - uq * A.role_stride == 0;
+    const int reads_before = min(A.read_blocks, ((unit + A.role_stride - 1) / A.role_stride) * 8 + (read_unit ? in_unit : 0));
+    const bool read_role = read_unit && uq * 8 + in_unit < A.read_blocks;
+    const int b = read_role ? uq * 8 + in_unit : raw - reads_before;   // the index inside its role(s)
     __shared__ int s_wf[4], s_wp[4], s_excl[2], s_last;
-    if (b >= A.read_blocks) {
-        const int sb = b - A.read_blocks;
+    if (!read_role) {
+        const int sb = b;
         if (sb < A.stream_blocks) {
             // ---- stream role
 #if PISCES_ADD_ABLATE == 1
             return;
 #endif
+            PISCES_STAMP(0, false);
             const uint32_t qk4 = (0x7Fu + A.enc_min_bq) * 0x01010101u;
             const int64_t n16 = A.n_seq >> 4;
             bool bad_dir = false;
-            for (int64_t i = (int64_t)sb * 256 + threadIdx.x; i < n16; i += (int64_t)A.stream_blocks * 256) {
-                uint32_t bw[4], qw[4], c[4];
-                __builtin_memcpy(bw, A.s_bases + 16 * i, 16);
-                __builtin_memcpy(qw, A.s_quals + 16 * i, 16);
-                if (A.s_dirs) {
-                    uint32_t dw[4];
-                    __builtin_memcpy(dw, A.s_dirs + 16 * i, 16);
+            // kStreamPieces sixteen-byte pieces of bases and of qualities a lane, ALL REQUESTED BEFORE THE FIRST IS USED: 8 KB a wave in flight.
+            // While the read role holds most of the chip's wave slots (its workgroups are the launch's first: ~35 us of round trips, little
+            // traffic) only 3-4 streaming waves a CU run; with one piece in flight each they moved a fifth of what the memory system takes and
+            // the launch's bytes waited for the read role to end (stream role through at 61 us, of which the first 35 at a fifth of the rate).
+            constexpr int kStreamPieces = 4;
+            for (int64_t i0 = (int64_t)sb * (256 * kStreamPieces); i0 < n16; i0 += (int64_t)A.stream_blocks * (256 * kStreamPieces)) {
+                uint32_t bw[kStreamPieces][4], qw[kStreamPieces][4];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) bad_dir = bad_dir || ((dw[k] + 0x7D7D7D7Du) | dw[k]) & 0x80808080u;   // some byte > 2
-                    if (A.d_dirs) __builtin_memcpy(A.d_dirs + 16 * i, dw, 16);
+                for (int p = 0; p < kStreamPieces; p++) {
+                    const int64_t i = min(i0 + p * 256 + (int64_t)threadIdx.x, n16 - 1);   // (clamped: the load is unconditional, the stores are not)
+                    __builtin_memcpy(bw[p], A.s_bases + 16 * i, 16);
+                    __builtin_memcpy(qw[p], A.s_quals + 16 * i, 16);
                 }
+#pragma unroll
+                for (int p = 0; p < kStreamPieces; p++) {
+                    const int64_t i = i0 + p * 256 + (int64_t)threadIdx.x;
+                    if (i >= n16) continue;
+                    if (A.s_dirs) {   // (stitched reads' per-base directions: rare, fetched here)
+                        uint32_t dw[4];
+                        __builtin_memcpy(dw, A.s_dirs + 16 * i, 16);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) bad_dir = bad_dir || ((dw[k] + 0x7D7D7D7Du) | dw[k]) & 0x80808080u;   // some byte > 2
+                        if (A.d_dirs) __builtin_memcpy(A.d_dirs + 16 * i, dw, 16);
+                    }
 #if PISCES_ADD_ABLATE == 5
-                if (bw[0] == 0x12345678u && qw[1] == 0x9ABCDEF0u) __builtin_memcpy(A.d_codes + 16 * i, bw, 16);
-                continue;
+                    if (bw[p][0] == 0x12345678u && qw[p][1] == 0x9ABCDEF0u) __builtin_memcpy(A.d_codes + 16 * i, bw[p], 16);
+                    continue;
 #endif
 #if PISCES_ADD_ABLATE != 4
-                if (A.d_bases) {
-                    __builtin_memcpy(A.d_bases + 16 * i, bw, 16);
-                    __builtin_memcpy(A.d_quals + 16 * i, qw, 16);
-                }
+                    if (A.d_bases) {
+                        __builtin_memcpy(A.d_bases + 16 * i, bw[p], 16);
+                        __builtin_memcpy(A.d_quals + 16 * i, qw[p], 16);
+                    }
 #endif
-                if (A.d_codes) {
+                    if (A.d_codes) {
+                        uint32_t c[4];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) c[k] = row_codes_of(bw[k], qw[k], qk4);
-                    __builtin_memcpy(A.d_codes + 16 * i, c, 16);
+                        for (int k = 0; k < 4; k++) c[k] = row_codes_of(bw[p][k], qw[p][k], qk4);
+                        __builtin_memcpy(A.d_codes + 16 * i, c, 16);
+                    }
                 }
             }
             if (sb == 0 && (int64_t)threadIdx.x < (A.n_seq & 15)) {   // the last bytes
@@ -717,6 +767,7 @@ __global__ __launch_bounds__(256, PISCES_ADD_OCC) void add_fused_kernel(AddFused
                 if (A.d_codes) A.d_codes[i] = (uint8_t)row_codes_of(bb, qq, qk4);
             }
             if (__ballot(bad_dir) != 0ull && (threadIdx.x & 63) == 0) __hip_atomic_store(A.bad_direction, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            PISCES_STAMP(1, true);
         } else {
             // ---- misc role: the small arrays, sixteen bytes a lane, one range after the other over this role's workgroups
             const int64_t stride = (int64_t)A.misc_blocks * 256, t = (int64_t)(sb - A.stream_blocks) * 256 + threadIdx.x;
@@ -742,14 +793,18 @@ __global__ __launch_bounds__(256, PISCES_ADD_OCC) void add_fused_kernel(AddFused
     {
     int found, pool;
     bool ok;
+    PISCES_STAMP(2, false);
+    PISCES_STAMP(3, true);
 #if PISCES_ADD_ABLATE == 6
     found = pool = 0; ok = true;
 #else
     prepare_reads(A.P, b, found, pool, ok);
 #endif
+    PISCES_STAMP(4, true);
 #if PISCES_ADD_ABLATE != 2
     if (A.do_shape) shape_reads(A.S, b, ok);
 #endif
+    PISCES_STAMP(5, true);
     // the candidate-record slots: exclusive scan over the batch's reads, in this launch
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int incl_f = found, incl_p = pool;
@@ -769,7 +824,32 @@ __global__ __launch_bounds__(256, PISCES_ADD_OCC) void add_fused_kernel(AddFused
     if (wave == 0) {
         const unsigned long long mine = ((unsigned long long)(unsigned)agg_p << 31) | (unsigned long long)(unsigned)agg_f;
         long long excl_f = 0, excl_p = 0;
-        if (b == 0) {
+        if (A.read_blocks <= kScanDirectBlocks) {
+            // The read workgroups of a launch are resident together and reach this point together, so a look-back finds no inclusive word
+            // near by and walks — 64 workgroups a round trip, the inclusive words coming to meet it at the same pace: ~10 dependent round
+            // trips for workgroup 1 300, the launch's critical path.  Up to kScanDirectBlocks workgroups every one simply ADDS UP the
+            // words before its own (lane i takes words i, i + 64, ...: 21 independent loads a lane for the last of 1 303), waiting only
+            // for words that are not published yet: one round trip.
+            if (lane == 0) __hip_atomic_store(&A.scan_state[b], kScanAggregate | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i0 = 0; i0 < b; i0 += 64 * 16) {
+                unsigned long long w[16];
+                for (;;) {
+                    bool all = true;
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        const int idx = i0 + 64 * k + lane;
+                        w[k] = idx < b ? __hip_atomic_load(&A.scan_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kScanAggregate;
+                        all = all && (w[k] >> 62) != 0ull;
+                    }
+                    if (__ballot(!all) == 0ull) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+#pragma unroll
+                for (int k = 0; k < 16; k++) { excl_f += (long long)(w[k] & kScanField); excl_p += (long long)((w[k] >> 31) & kScanField); }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { excl_f += __shfl_xor(excl_f, d, 64); excl_p += __shfl_xor(excl_p, d, 64); }
+        } else if (b == 0) {
             if (lane == 0) __hip_atomic_store(&A.scan_state[0], kScanInclusive | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             if (lane == 0) __hip_atomic_store(&A.scan_state[b], kScanAggregate | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -804,6 +884,7 @@ __global__ __launch_bounds__(256, PISCES_ADD_OCC) void add_fused_kernel(AddFused
         }
     }
     __syncthreads();
+    PISCES_STAMP(6, true);
     if (A.P.n_found) {
         const int r = b * 256 + (int)threadIdx.x;
         if (r < A.P.n_reads) {
@@ -817,7 +898,7 @@ __global__ __launch_bounds__(256, PISCES_ADD_OCC) void add_fused_kernel(AddFused
     // with agent-scope atomics, which are performed past the XCDs' L2s, and the barrier's s_waitcnt vmcnt(0) has every wave's atomics
     // acknowledged before thread 0 counts the workgroup in: the count is a RELAXED atomic.  (A release there is a write-back of the XCD's
     // whole L2 — while the stream role fills it — per read workgroup: 60 us of the launch's 127; a fence in every wave of every role: 1.2 ms.)
-    // The collector's acquire (an invalidate, no write-back) makes its plain loads miss the L2.
+    // The collector reads with agent-scope atomic loads.
 #if PISCES_ADD_ABLATE == 10
     return;
 #endif
@@ -835,11 +916,11 @@ __global__ __launch_bounds__(256, PISCES_ADD_OCC) void add_fused_kernel(AddFused
         s_last = last;
     }
     __syncthreads();
+    PISCES_STAMP(7, true);
     if (!s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     prepare_collect(A.P.block_bits, A.P.map_stride, A.P.key_span, A.P.first_error, A.totals, A.verdict, A.keys_out, A.capacity);
     __syncthreads();
-    // the shared words as the next launch expects them
+    // the shared words as the next launch expects them (plain stores: the next launch starts behind the end of this one)
     for (int i = threadIdx.x; i < A.read_blocks; i += 256) A.scan_state[i] = 0ull;
     if (threadIdx.x < kPrepReplicas) {
         int32_t* const sp = A.P.key_span + 4 * threadIdx.x;
@@ -847,11 +928,11 @@ __global__ __launch_bounds__(256, PISCES_ADD_OCC) void add_fused_kernel(AddFused
     }
     if (threadIdx.x <= kPrepReplicas) A.done[threadIdx.x] = 0u;
     if (threadIdx.x == 0) *A.P.first_error = ~0ull;
-    // the word the host polls, behind every thread's stores to the host's memory (verdict, keys) and to the shared words (the host may
-    // enqueue the next launch as soon as it has seen it: stream order puts that launch behind the end of this one)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    // the word the host polls, behind every thread's stores to the host's memory (verdict, keys): the barrier's workgroup-scope fence has
+    // each wave wait for its stores' acknowledgements (s_waitcnt vmcnt(0)); device-to-host writes arrive in the order they were acknowledged in
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(&A.verdict->ready, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    PISCES_STAMP(8, true);
+    if (threadIdx.x == 0) __hip_atomic_store(&A.verdict->ready, A.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // small batches: their bytes join the open segment (up to five ranges in one launch; byte-wise: destinations are not aligned)

@@ -491,8 +491,12 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
     F.read_blocks = read_blocks;
     // the stream role runs when there is something to copy, to encode or to check
     const bool stream = n_seq > 0 && (src || F.d_codes || has_dirs);
-    F.stream_blocks = stream ? (int32_t)std::min<int64_t>(((int64_t)n_seq + 16 * 256 - 1) / (16 * 256), 8192) : 0;
+    // (four sixteen-byte pieces of each array a lane a trip — add_fused_kernel's kStreamPieces — and every lane the same number of trips)
+    F.stream_blocks = stream ? (int32_t)std::min<int64_t>(((int64_t)n_seq + 4 * 16 * 256 - 1) / (4 * 16 * 256), 16384) : 0;
     F.misc_blocks = src ? (int32_t)std::min<int64_t>(std::max<int64_t>((misc_bytes / 16 + 255) / 256, 1), 64) : 0;
+    // (1: the read workgroups in front.  Measured, XCD-aware, on config 2's batch: every 2nd / 3rd / 4th / 8th unit of eight workgroups a read
+    // unit: 96 / 95 / 115 / 106 us against 83 with the read role in front; PISCES_HIP_ROLE_STRIDE for the A / B)
+    F.role_stride = std::max<int32_t>(1, std::min<int32_t>(h->role_stride, (F.read_blocks + F.stream_blocks + F.misc_blocks) / std::max((F.read_blocks + 7) / 8 * 8, 1)));
     F.scan_state = h->d_fused_scan.p;
     F.done = (unsigned int*)(h->d_fused_words.p + kWordsDone);
     F.totals = (long long*)(h->d_fused_words.p + kWordsTotals);
@@ -503,6 +507,13 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
     if (++h->fused_seq <= 0) h->fused_seq = 1;
     F.seq = h->fused_seq;
     verdict->ready = 0;
+#ifdef PISCES_ADD_STAMPS
+    const size_t n_wg = (size_t)(F.read_blocks + F.stream_blocks + F.misc_blocks);
+    PISCES_HIP_CHECK(h, h->d_add_stamps.reserve(n_wg * 8));
+    PISCES_HIP_CHECK(h, hipMemsetAsync(h->d_add_stamps.p, 0, n_wg * 8 * sizeof(long long), h->stream));
+    PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    F.stamps = h->d_add_stamps.p;
+#endif
     // (pisces_hip_set_chain_timing: the add's device time starts with its first kernel — what the host does before it is not the device's)
     if (h->chain_timing && src) { h->chain_have[0] = false; PISCES_HIP_CHECK(h, hipEventRecord(h->ev_chain[0], h->stream)); }
     hipLaunchKernelGGL(add_fused_kernel, dim3((unsigned)(F.read_blocks + F.stream_blocks + F.misc_blocks)), dim3(256), 0, h->stream, F);
@@ -522,6 +533,31 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
         std::atomic_thread_fence(std::memory_order_acquire);
         if (!seen) PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     }
+#ifdef PISCES_ADD_STAMPS
+    {   // slots of a workgroup: read role [0] start, [2] prepare done, [3] shape done, [4] scan done, [5] counted, [6] collector done; stream role [2] start, [3] end
+        std::vector<long long> st(n_wg * 8);
+        PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+        PISCES_HIP_CHECK(h, hipMemcpy(st.data(), h->d_add_stamps.p, st.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        long long t0 = 0x7FFFFFFFFFFFFFFFll;
+        for (size_t w = 0; w < n_wg; w++) for (int k : {0, 2}) if (st[w * 8 + k]) t0 = std::min(t0, st[w * 8 + k]);
+        double rs_min = 1e9, rs_max = 0, prep = 0, shape = 0, scan = 0, counted = 0, coll = 0, ss_min = 1e9, ss_max = 0, se_max = 0, dur_r = 0, dur_s = 0;
+        int nr_ = 0, ns_ = 0;
+        for (size_t w = 0; w < n_wg; w++) {
+            const long long* q = &st[w * 8];
+            auto us = [&](int k) { return (double)(q[k] - t0) / 100.0; };
+            if (q[0]) {   // a read workgroup
+                rs_min = std::min(rs_min, us(0)); rs_max = std::max(rs_max, us(0)); prep = std::max(prep, us(2)); shape = std::max(shape, us(3));
+                scan = std::max(scan, us(4)); if (q[5]) counted = std::max(counted, us(5)); if (q[6]) coll = us(6);
+                dur_r += us(q[5] ? 5 : 4) - us(0); nr_++;
+            } else if (q[2]) {
+                ss_min = std::min(ss_min, us(2)); ss_max = std::max(ss_max, us(2)); se_max = std::max(se_max, us(3)); dur_s += us(3) - us(2); ns_++;
+            }
+        }
+        fprintf(stderr, "add_fused stamps (us from the first start): read role: starts %.1f .. %.1f, last prepare done %.1f, shape %.1f, scan %.1f, counted %.1f, collector done %.1f, "
+                "mean workgroup %.1f us (%d) | stream role: starts %.1f .. %.1f, last end %.1f, mean workgroup %.1f us (%d)\n",
+                rs_min, rs_max, prep, shape, scan, counted, coll, dur_r / std::max(nr_, 1), nr_, ss_min, ss_max, se_max, dur_s / std::max(ns_, 1), ns_);
+    }
+#endif
     h->h_meta_used = 0;
     const unsigned long long first_error = std::min<unsigned long long>(verdict->first_error, *bad_direction ? (unsigned long long)kPrepBadDirection : ~0ull);
     const int32_t span[3] = {verdict->span[0], verdict->span[1], verdict->span[2]};
@@ -603,6 +639,8 @@ static int32_t store_finish_add(PiscesHip* h, StorePlace& pl, int32_t rc, uint8_
         store_unplace(h, pl);
         return rc;
     }
+    // (pisces_hip_set_chain_timing: behind the last thing the add enqueues; what follows is the host's bookkeeping)
+    if (h->chain_timing) { PISCES_HIP_CHECK(h, hipEventRecord(h->ev_chain[1], h->stream)); h->chain_have[0] = true; }
     // ---- commit
     ReadSegment& g = *pl.seg;
     g.n_reads += nr;
@@ -612,7 +650,6 @@ static int32_t store_finish_add(PiscesHip* h, StorePlace& pl, int32_t rc, uint8_
     store_maybe_seal(h, &g);
     for (int32_t k : touched) (void)get_block(h, (k - 1) * bs + 1);
     h->stats[2] += nr;
-    if (h->chain_timing) { PISCES_HIP_CHECK(h, hipEventRecord(h->ev_chain[1], h->stream)); h->chain_have[0] = true; }
     return PISCES_OK;
 }
 
