@@ -1487,17 +1487,19 @@ __device__ __forceinline__ void walk_store(const StoreView& S, int tile_start, i
     }
 }
 
-// The tiles of a run of consecutive blocks with no interval clipping, by value: tile t is the (t % tiles_per_block)-th 64-locus tile of
+// The tiles of a run of consecutive blocks with no interval clipping, by value: tile t is the (t % tiles_per_block)-th tile_loci-locus tile of
 // block first_key + t / tiles_per_block (GetBlockKey grid, RegionStateManager.cs:385-391).  A flush of such a run uploads no geometry.
 struct RegularTiles {
-    int32_t first_key, block_size, tiles_per_block, pad;
+    int32_t first_key, block_size, tiles_per_block;
+    int32_t tile_loci;   // loci a tile (<= 64; 0 = 64): tiles_per_block = ceil(block_size / tile_loci), a block's last tile takes what is left
 };
 __device__ __forceinline__ PiscesTile regular_tile(const RegularTiles& R, int t)
 {
     const int b = t / R.tiles_per_block, i = t - b * R.tiles_per_block;
+    const int step = R.tile_loci > 0 ? R.tile_loci : kTile;
     PiscesTile tile;
-    tile.start_position = (R.first_key - 1 + b) * R.block_size + 1 + i * kTile;
-    tile.n_loci = min(kTile, R.block_size - i * kTile);
+    tile.start_position = (R.first_key - 1 + b) * R.block_size + 1 + i * step;
+    tile.n_loci = min(step, R.block_size - i * step);
     tile.tuple_begin = tile.tuple_end = 0;
     return tile;
 }

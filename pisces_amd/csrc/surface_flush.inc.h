@@ -355,13 +355,22 @@ static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& key
     // A run of consecutive blocks that no interval set clips, nothing in the observation log: the tile geometry goes to the kernel by
     // value (RegularTiles) — no geometry is made on the host and none uploaded
     const int bs = h->cfg.block_size;
-    const int tiles_per_block = (bs + kTile - 1) / kTile;
+    int tiles_per_block = (bs + kTile - 1) / kTile;
     const bool regular = fused && h->log_ub == 0 && h->intervals.empty() && (int64_t)keys.back() - keys.front() + 1 == (int64_t)keys.size() &&
                          (int64_t)keys.size() * tiles_per_block < 0x7FFFFF00ll / kSlotsPerTile;
+    // The tiles of a regular run may be of any size up to 64 (RegularTiles::tile_loci).  A launch ends with the CU that was dealt the most
+    // loci — ceil(tiles / CUs) tiles — and 100 blocks on 256 CUs put 7 x 64 = 448 loci on 64 CUs with tiles of 64 but 7 x 59 = 413 with
+    // tiles of 59; measured (round 6, config 2's flush, tools/tile_loci_ab.sh): 64 -> 50.8-51.3 us for the flush's span, 59 -> 51.4,
+    // 56 / 60 / 62 -> 54.5 / 53.2 / 53.8: the trade of tiles inside the kernel has taken that imbalance already.  64 stays; PISCES_HIP_TILE_LOCI forces a size.
+    int tile_loci = kTile;
+    if (regular && h->tile_loci > 0 && h->tile_loci < kTile && (int64_t)keys.size() * ((bs + h->tile_loci - 1) / h->tile_loci) < 0x7FFFFF00ll / kSlotsPerTile) {
+        tile_loci = h->tile_loci;
+        tiles_per_block = (bs + tile_loci - 1) / tile_loci;
+    }
     std::vector<PiscesTile> tiles;
     int32_t n_tiles = 0;
     int64_t n_loci_total = 0;
-    RegularTiles R = {0, bs, tiles_per_block, 0};
+    RegularTiles R = {0, bs, tiles_per_block, tile_loci};
     if (regular) {
         R.first_key = keys.front();
         n_tiles = (int32_t)(keys.size() * (size_t)tiles_per_block);
@@ -452,6 +461,7 @@ static int32_t call_blocks_enqueue(PiscesHip* h, const std::vector<int32_t>& key
         // straight into the pinned buffer (host memory the device can write): the kernel's stores are the transfer
         hipLaunchKernelGGL(compact_small_kernel, dim3((unsigned)n_tiles), dim3(64), 0, h->stream, (const PiscesCalledAllele*)h->d_records.p,
                            (const PiscesTileResult*)h->d_tile_results.p, n_tiles, (PiscesCalledAllele*)h->h_dl, (int32_t)cap);
+        if (h->chain_timing) { PISCES_HIP_CHECK(h, hipEventRecord(h->ev_chain[3], h->stream)); h->chain_have[1] = true; }
     } else {
         { int32_t rcc = launch_compaction(h, h->stream, h->d_records.p, h->d_tile_results.p, n_tiles, h->d_offsets.p, h->d_compact.p + 1, (int32_t)cap, h->d_count.p,
                                           h->d_count.p + 1); if (rcc) return rcc; }

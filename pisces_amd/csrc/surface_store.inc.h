@@ -910,7 +910,7 @@ static hipError_t launch_call_store_tiles(PiscesHip* h, hipStream_t s, const uin
     store_view(h, &V);
     // waves per tile: enough of them that a small launch still puts its reads on many SIMDs (see the kernel)
     int nw = h->store_waves;
-    if (nw == 0) nw = h->kernel_variant == 2 ? 1 : h->kernel_variant == 3 ? 2 : (int64_t)n_tiles * 4 <= (int64_t)h->n_cus ? 16 : (int64_t)n_tiles <= (int64_t)h->n_cus ? 8
+    if (nw == 0) nw = h->kernel_variant == 2 ? 1 : h->kernel_variant == 3 ? 2 : (int64_t)n_tiles <= (int64_t)h->n_cus ? 16 /* (a tile a CU at most: all sixteen waves; 235 tiles at 5000x: 69 us against 74 with eight) */
                       : (int64_t)n_tiles * 4 <= (int64_t)h->n_cus * 12 ? 4 : (int64_t)n_tiles <= (int64_t)h->n_cus * 32 ? 2 : 1;
     // several tiles a CU (store_kernels.hip.h): the workgroups trade tiles by price inside small groups (the default), or take them in
     // tile_order_kernel's order (PISCES_HIP_TILE_ORDER=1: a launch in front), or in position order (=0)

@@ -102,6 +102,64 @@ def test_compacted_launch_is_deterministic_over_three_hundred_runs(torch_cuda):
             assert got.tobytes() == want.tobytes() and tr.tobytes() == tr0.tobytes(), i
 
 
+@pytest.mark.parametrize("n_loci,depth", [(3 * 64, 30), (1786 * 56, 12), (4700 * 64, 6)], ids=["3_tiles", "1786_tiles", "4700_tiles"])
+def test_the_three_forms_of_the_ordered_compaction_give_the_same_rows(torch_cuda, monkeypatch, n_loci, depth):
+    """pisces_hip_compact_records is ONE launch since round 6 — up to 4 096 tiles a tile's wave adds up the record counts of the tiles
+    before it (gather_direct_kernel), beyond them a decoupled look-back over workgroups of sixteen tiles (compact_records_kernel) — where it
+    was a scan launch and a gather launch (PISCES_HIP_COMPACT=two, kept for the A / B).  The three forms (the look-back forced on the small
+    launches too) must write the same count, the same offsets and the same rows, launch after launch on one handle (the look-back's words
+    carry the launch's number: nothing is cleared in between), and equal the rows read through the validity masks."""
+    from pisces_amd import engine, synth
+    torch = torch_cuda
+    p = synth.make_pileup(n_loci=n_loci, depth=depth, seed=21, device="cuda")
+    cfg = _abi.default_config()
+    rows = {}
+    for mode in ("", "two", "lookback"):
+        if mode:
+            monkeypatch.setenv("PISCES_HIP_COMPACT", mode)
+        else:
+            monkeypatch.delenv("PISCES_HIP_COMPACT", raising=False)
+        with engine.HipVariantCaller(cfg) as caller:
+            plain, tr0 = run_fused(torch, caller, p)
+            for launch in range(3):
+                got, tr = run_fused(torch, caller, p, compact=True)
+                assert got.tobytes() == plain.tobytes() and tr.tobytes() == tr0.tobytes(), (mode, launch)
+            rows[mode] = plain.tobytes()
+    assert rows[""] == rows["two"] == rows["lookback"] and len(rows[""]) >= 64 * n_loci
+
+
+def test_chain_timing_brackets_an_add_of_device_reads_and_a_flush(torch_cuda):
+    """pisces_hip_set_chain_timing / pisces_hip_chain_time (bench.py's roofline_chain): refused before an add + flush pair has run with timing
+    on; afterwards two positive spans; the rows are the rows of an untimed handle."""
+    from pisces_amd import engine, synth
+    p = synth.make_pileup(n_loci=3000, depth=60, seed=5, device="cuda", with_tuples=False)
+    batch = synth.reads_of(p, p.base.shape[0], first_amplicon=0)
+    d = engine.DeviceReadBatch.from_host(batch, "cuda:0")
+    ref = p.ref.cpu().numpy()
+    cfg = _abi.default_config()
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(ref)
+        c.AddDeviceReads(d)
+        want = c.Call(None)
+    with engine.HipVariantCaller(cfg) as c:
+        c.SetReference(ref)
+        with pytest.raises(engine.PiscesHipError) as e:
+            c.ChainTime()
+        assert e.value.code == _abi.E_STATE
+        c.SetChainTiming(True)
+        with pytest.raises(engine.PiscesHipError):
+            c.ChainTime()
+        for _ in range(2):
+            c.AddDeviceReads(d)
+            got = c.Call(None)
+            add_ms, flush_ms = c.ChainTime()
+            assert 0.0 < add_ms < 100.0 and 0.0 < flush_ms < 100.0
+            assert got.tobytes() == want.tobytes()
+        c.SetChainTiming(False)
+        with pytest.raises(engine.PiscesHipError):
+            c.ChainTime()
+
+
 def test_the_null_stream_is_refused_by_the_engine(torch_cuda):
     """HIP's null stream (what torch.cuda.current_stream().cuda_stream is in a default torch context) is not a stream the library can
     launch on -- the C ABI reads NULL as the handle's own stream -- so the engine makes the caller choose: None, or a real stream."""

@@ -326,6 +326,36 @@ def test_whichever_tile_a_workgroup_takes_the_records_are_the_same(torch_cuda, n
     assert out["2"].tobytes() == out["0"].tobytes()
 
 
+def test_tiles_of_any_size_and_switches_of_the_add_give_the_same_records(torch_cuda):
+    """The tiles of a flush over whole blocks are described by value (RegularTiles) and may be of any size up to 64
+    (PISCES_HIP_TILE_LOCI: 59 -> 17 tiles a block, 48 -> 21, 33 -> 31; the default 64 -> 16): a tile's records depend on its loci only, so
+    the compacted rows of the flush are the same bytes.  The same for the switches round 6 added to the add of a batch in device memory:
+    the position grid enqueued by the add itself (PISCES_HIP_DEFER_GRID=0) and the read role spread between the streaming workgroups
+    (PISCES_HIP_ROLE_STRIDE=3)."""
+    from pisces_amd import engine, synth
+    p = synth.make_pileup(n_loci=40_000, depth=80, seed=17, device="cuda", with_tuples=False)
+    ref = p.ref.cpu().numpy()
+    cfg = _abi.default_config()
+    whole = synth.reads_of(p, p.base.shape[0], first_amplicon=0)
+    d = engine.DeviceReadBatch.from_host(whole, "cuda:0")
+    out = {}
+    for label, kw in (("default", {}), ("59", dict(PISCES_HIP_TILE_LOCI="59")), ("48", dict(PISCES_HIP_TILE_LOCI="48")), ("33", dict(PISCES_HIP_TILE_LOCI="33")),
+                      ("grid_in_the_add", dict(PISCES_HIP_DEFER_GRID="0")), ("stride_3", dict(PISCES_HIP_ROLE_STRIDE="3"))):
+        with env(**kw):
+            with engine.HipVariantCaller(cfg) as c:
+                c.SetReference(ref)
+                c.AddDeviceReads(d)
+                first = c.Call(20_000, capacity=80_000)      # (a flush, an add behind it, the final flush: the grid of the second batch extends the first's)
+                out[label] = np.concatenate([first, c.Call(None, capacity=80_000)])
+    assert len(out["default"]) >= 40_000
+    for label, rows in out.items():
+        assert rows.tobytes() == out["default"].tobytes(), label
+    with engine.HipVariantCaller(cfg) as c:   # and the host-fed add gives them too
+        c.SetReference(ref)
+        c.AddAlleleCounts(whole)
+        assert c.Call(None, capacity=80_000).tobytes() == out["default"].tobytes()
+
+
 @pytest.mark.parametrize("n_loci,depth", [(100_000, 500)], ids=["config2_100kx500"])
 def test_config2_at_full_size_store_equals_log_chain_and_oracle_slice(torch_cuda, n_loci, depth):
     """BASELINE config 2 (100 000 loci x 500x, 333 500 reads) through pisces_hip_add_reads / pisces_hip_flush: the read store and the
