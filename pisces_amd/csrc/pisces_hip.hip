@@ -361,7 +361,7 @@ struct PiscesHip {
     int32_t own_lo = 1, own_hi = 0x7FFFFFFF;              // pisces_hip_set_owned_range
     int64_t stats[4] = {0, 0, 0, 0};      // called, collapsed, reads processed, reads skipped
     bool in_flush_begin = false;
-    double prof[16] = {0};                 // development (PISCES_HIP_HOST_PROFILE=1): host seconds by phase of a flush, printed when the handle goes
+    double prof[24] = {0};                 // development (PISCES_HIP_HOST_PROFILE=1): host seconds by phase of a flush, printed when the handle goes
     bool prof_on = false;
     int64_t pcie[4] = {0, 0, 0, 0};          // pisces_hip_transfer_bytes: H2D reads / file bytes, D2H records, D2H candidate records, D2H counts
     double host_time[4] = {0, 0, 0, 0};   // pisces_hip_host_time: seconds in add_reads, in flush, of that waiting for the device; flushes
@@ -1041,10 +1041,11 @@ int32_t pisces_hip_destroy(PiscesHip* h)
     return abi_guard<int32_t>(h, [&]() -> int32_t {
     if (!h) return PISCES_OK;
     if (h->prof_on) {
-        static const char* names[16] = {"consume_found", "spanning: candidates of the batch", "spanning: counts to the host", "collapse", "device pass (MNVs)",
+        static const char* names[19] = {"consume_found", "spanning: candidates of the batch", "spanning: counts to the host", "collapse", "device pass (MNVs)",
                                         "reallocate", "device pass (all)", "call_blocks", "row merge / genotypers", "copy out + DoneProcessing", "split: dirty loci + SNV store", "  of reallocate: mnv_reallocate_failed",
-                                        "add_device_reads: consume_found", "add_device_reads: copies + checks", "add_device_reads: shape + discovery + commit", "-"};
-        for (int i = 0; i < 15; i++) fprintf(stderr, "pisces_hip host profile: %-36s %9.3f ms\n", names[i], h->prof[i] * 1e3);
+                                        "add_device_reads: consume_found", "add_device_reads: copies + checks", "add_device_reads: shape + discovery + commit",
+                                        "add_reads: place + reserve", "add_reads: staging + upload", "add_reads: pass over the CIGARs", "add_reads: launches + commit"};
+        for (int i = 0; i < 19; i++) fprintf(stderr, "pisces_hip host profile: %-36s %9.3f ms\n", names[i], h->prof[i] * 1e3);
         if (h->mnv_split)
             fprintf(stderr, "pisces_hip split form: %lld SNV groups into the store, %lld taken by flushes (dirty loci), %lld dropped unseen, %lld sweeps\n",
                     (long long)h->split_stats[0], (long long)h->split_stats[1], (long long)h->split_stats[2], (long long)h->split_stats[3]);
