@@ -143,12 +143,15 @@ def device_chunks(engine, job, dev_arrays, plan, chunk_reads=400_000):
 
 
 def run_piece(engine, cfg, job, lo=None, hi=None, halo=synth.READ_LEN + 16, device=0, chunk_reads=400_000, with_alleles=True, keep_records=True,
-              plan=None, chunks=None, count_loci=True):
+              plan=None, chunks=None, count_loci=True, caller=None):
     """One (contig, owned range) job on one handle: set_reference, set_intervals (clipped to the range), the reads
     shard.reads_for_shard gives it, one final flush.  lo / hi None: the whole contig.  Returns (records, alleles, stats, reads counted:
     a read is counted by the piece that owns its start).  keep_records=False (bench.py): the rows are looked at where they lie
     (pisces_hip_flush_view) and only counted — `records` is then {"n": rows, "loci": distinct positions}.  chunks (device_chunks of
-    `plan`): the reads are handed over in device memory (pisces_hip_add_device_reads) instead of from the host arrays."""
+    `plan`): the reads are handed over in device memory (pisces_hip_add_device_reads) instead of from the host arrays.  caller (an
+    engine.HipVariantCaller that has the contig's reference already): the piece runs on that handle — one handle per contig, as the
+    reference has one SmallVariantCaller per chromosome job (Factory.cs:253-269), its pieces in turn: intervals and owned range are set per
+    piece, a final flush leaves the handle empty for the next; the stats returned are the piece's own (differences)."""
     if plan is None:
         plan = piece_plan(job, lo, hi, halo)
     lo, hi, pos, i0, i1 = plan["lo"], plan["hi"], plan["pos"], plan["i0"], plan["i1"]
@@ -168,8 +171,14 @@ def run_piece(engine, cfg, job, lo=None, hi=None, halo=synth.READ_LEN + 16, devi
         return view[:0]
 
     take = (lambda view: view.copy()) if keep_records else count
-    with engine.HipVariantCaller(cfg, device=device) as c:
-        c.SetReference(job["ref"])
+    import contextlib
+    own = caller is None
+    with (engine.HipVariantCaller(cfg, device=device) if own else contextlib.nullcontext(caller)) as c:
+        before = None if own else c.Stats()
+        if own:
+            c.SetReference(job["ref"])
+        else:
+            c.HostTime(reset=True)
         c.SetIntervals(plan["intervals"])
         c.SetOwnedRange(lo, hi)
         for k, a in enumerate(range(i0, i1, chunk_reads)):   # the streaming protocol: add a stretch of reads, call what lies behind them
@@ -186,6 +195,8 @@ def run_piece(engine, cfg, job, lo=None, hi=None, halo=synth.READ_LEN + 16, devi
         recs.append(r)
         alleles += al
         stats = c.Stats()
+        if before is not None:
+            stats = {k: (v - before[k] if isinstance(v, (int, np.integer)) and k in before else v) for k, v in stats.items()}
         stats["host_time"] = c.HostTime()
     if not keep_records:
         return {"n": n_rows, "loci": n_loci}, alleles, stats, plan["owned"]

@@ -124,3 +124,21 @@ def test_run_piece_counts_rows_in_place_as_it_would_keep_them(torch_cuda):
     assert counted == {"n": len(recs), "loci": len(np.unique(recs["position"]))} and len(recs) >= 400 * config4.INTERVAL
     assert owned == owned2 == job["batch"].n_reads
     assert {k: v for k, v in stats.items() if k != "host_time"} == {k: v for k, v in stats2.items() if k != "host_time"}
+
+
+def test_the_pieces_of_a_contig_on_one_handle_give_what_handles_of_their_own_give(torch_cuda):
+    """One handle per contig, its (contig, range) pieces run on it in turn (config4.run_piece(caller=...): intervals and owned range set per
+    piece, every piece ended by a final flush that leaves the handle empty) — what bench.py --config 4 times — against a handle per piece:
+    the same records, allele strings and per-piece stats; and the contig's handle takes the whole contig afterwards as a fresh one does."""
+    from pisces_amd import config4, engine
+    cfg = _abi.default_config(emit_zero_coverage_refs=1)
+    job = config4.make_contig(7, 500, depth=50)
+    cuts = [(None, None), (1, 40_000), (40_001, 93_000), (93_001, len(job["ref"]))]
+    fresh = [config4.run_piece(engine, cfg, job, lo, hi, chunk_reads=6000) for lo, hi in cuts]
+    with engine.HipVariantCaller(cfg) as contig_caller:
+        contig_caller.SetReference(job["ref"])
+        for (lo, hi), want in list(zip(cuts, fresh))[1:] + [(cuts[0], fresh[0])]:
+            recs, alleles, stats, owned = config4.run_piece(engine, cfg, job, lo, hi, chunk_reads=6000, caller=contig_caller)
+            assert recs.tobytes() == want[0].tobytes() and alleles == want[1] and owned == want[3], (lo, hi)
+            assert {k: v for k, v in stats.items() if k != "host_time"} == {k: v for k, v in want[2].items() if k != "host_time"}, (lo, hi)
+    assert np.concatenate([f[0] for f in fresh[1:]]).tobytes() == fresh[0][0].tobytes()
