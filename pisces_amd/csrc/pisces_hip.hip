@@ -571,6 +571,7 @@ struct PiscesHip {
     struct DeferredGrid { ShapeArgs S; unsigned blocks; };
     std::vector<DeferredGrid> deferred_grid;  // grid roles of read_shape_kernel kept back until something reads or changes a grid (store_run_deferred)
     int32_t tile_loci = 0;                    // PISCES_HIP_TILE_LOCI: loci a tile of a regular flush (development; 0 = 64)
+    int32_t stream_wgs_per_cu = 0;            // add_fused_kernel: > 0 = that many persistent stream workgroups a CU in front of the read role (PISCES_HIP_STREAM_WGS_PER_CU)
     int32_t role_stride = 1;                  // add_fused_kernel: every n-th workgroup at the front of the launch is a read workgroup (PISCES_HIP_ROLE_STRIDE)
     bool defer_grid = true;                   // PISCES_HIP_DEFER_GRID=0: enqueued by the add itself (the A / B)
 #ifdef PISCES_ADD_STAMPS
@@ -912,6 +913,7 @@ int32_t pisces_hip_create(const PiscesHipConfig* cfg, int32_t device, PiscesHip*
         if (const char* v = getenv("PISCES_HIP_STORE_SEAL_BYTES")) h->store_seal_bytes = (size_t)std::max(0ll, atoll(v));
         if (const char* v = getenv("PISCES_HIP_DEVICE_CHECKS")) h->device_checks = atoi(v) != 0 ? 1 : 0;
         if (const char* v = getenv("PISCES_HIP_TILE_LOCI")) h->tile_loci = atoi(v);
+        if (const char* v = getenv("PISCES_HIP_STREAM_WGS_PER_CU")) h->stream_wgs_per_cu = std::max(0, atoi(v));
         if (const char* v = getenv("PISCES_HIP_ROLE_STRIDE")) h->role_stride = std::max(1, atoi(v));
         if (const char* v = getenv("PISCES_HIP_DEFER_GRID")) h->defer_grid = atoi(v) != 0;
         if (const char* v = getenv("PISCES_HIP_COMPACT")) h->compact_mode = std::string(v) == "two" ? 2 : std::string(v) == "lookback" ? 3 : 0;

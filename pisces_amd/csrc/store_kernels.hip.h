@@ -667,7 +667,8 @@ struct AddFusedArgs {
     ShapeArgs S;                // shape role (do_shape) — reads the same arrays; S.enc_* unused here
     int32_t do_shape;
     int32_t read_blocks, stream_blocks, misc_blocks;
-    int32_t role_stride;        // every role_stride-th workgroup of the launch is a read workgroup (>= 1), until there are read_blocks of them
+    int32_t role_stride;        // every role_stride-th unit of eight workgroups is a read unit (>= 1), until there are read_blocks read workgroups
+    int32_t stream_first;       // != 0: the stream and misc workgroups are the launch's first, the read workgroups follow
     const uint8_t* s_bases;     // stream role: sources
     const uint8_t* s_quals;
     const uint8_t* s_dirs;      // or nullptr
@@ -693,18 +694,26 @@ constexpr unsigned long long kScanAggregate = 1ull << 62, kScanInclusive = 2ull 
 
 __global__ __launch_bounds__(256, PISCES_ADD_OCC) void add_fused_kernel(AddFusedArgs A)
 {
-    // Roles by workgroup index, INTERLEAVED: every role_stride-th workgroup is a read workgroup (in index order, which is dispatch order:
-    // the look-back waits for lower read indices only), the others stream.  With the read workgroups in front they took the chip's slots
-    // first and the streaming — the launch's bytes — started when they were through: the two latencies added up (62-73 us for 45 us of bytes).
-    // (in units of eight consecutive workgroups — one per XCD: a stride of single workgroups that shares a factor with eight puts the read
-    // role on some XCDs only, 129 us at a stride of four)
+    // Roles by workgroup index.  stream_first > 0: the launch's FIRST workgroups are the stream (and misc) role — a few persistent ones a CU
+    // that walk the batch's bytes from the launch's first microsecond to its last with 8 KB a wave in flight — and the read workgroups
+    // follow in index order (which is dispatch order: their scan waits for lower read indices only) into the slots that are left.  With the
+    // read role in front (stream_first == 0; every role_stride-th unit of eight workgroups — one per XCD — a read unit, until there are
+    // read_blocks of them) its workgroups take 85 % of the chip's wave slots for ~35 us of round trips and the launch's bytes wait for them.
     const int raw = (int)blockIdx.x;
-    const int unit = raw >> 3, in_unit = raw & 7;
-    const int uq = unit / A.role_stride;
-    const bool read_unit = unit - uq * A.role_stride == 0;
-    const int reads_before = min(A.read_blocks, ((unit + A.role_stride - 1) / A.role_stride) * 8 + (read_unit ? in_unit : 0));
-    const bool read_role = read_unit && uq * 8 + in_unit < A.read_blocks;
-    const int b = read_role ? uq * 8 + in_unit : raw - reads_before;   // the index inside its role(s)
+    bool read_role;
+    int b;   // the index inside its role(s)
+    if (A.stream_first) {
+        const int front = A.stream_blocks + A.misc_blocks;
+        read_role = raw >= front;
+        b = read_role ? raw - front : raw;
+    } else {
+        const int unit = raw >> 3, in_unit = raw & 7;
+        const int uq = unit / A.role_stride;
+        const bool read_unit = unit - uq * A.role_stride == 0;
+        const int reads_before = min(A.read_blocks, ((unit + A.role_stride - 1) / A.role_stride) * 8 + (read_unit ? in_unit : 0));
+        read_role = read_unit && uq * 8 + in_unit < A.read_blocks;
+        b = read_role ? uq * 8 + in_unit : raw - reads_before;
+    }
     __shared__ int s_wf[4], s_wp[4], s_excl[2], s_last;
     if (!read_role) {
         const int sb = b;

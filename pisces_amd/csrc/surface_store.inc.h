@@ -493,6 +493,12 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
     const bool stream = n_seq > 0 && (src || F.d_codes || has_dirs);
     // (four sixteen-byte pieces of each array a lane a trip — add_fused_kernel's kStreamPieces — and every lane the same number of trips)
     F.stream_blocks = stream ? (int32_t)std::min<int64_t>(((int64_t)n_seq + 4 * 16 * 256 - 1) / (4 * 16 * 256), 16384) : 0;
+    // PISCES_HIP_STREAM_WGS_PER_CU = k > 0: at most k x CUs persistent stream workgroups, in FRONT of the read workgroups (add_fused_kernel)
+    F.stream_first = 0;
+    if (h->stream_wgs_per_cu > 0 && F.stream_blocks > 0) {
+        F.stream_blocks = (int32_t)std::min<int64_t>(F.stream_blocks, (int64_t)h->stream_wgs_per_cu * h->n_cus);
+        F.stream_first = 1;
+    }
     F.misc_blocks = src ? (int32_t)std::min<int64_t>(std::max<int64_t>((misc_bytes / 16 + 255) / 256, 1), 64) : 0;
     // (1: the read workgroups in front.  Measured, XCD-aware, on config 2's batch: every 2nd / 3rd / 4th / 8th unit of eight workgroups a read
     // unit: 96 / 95 / 115 / 106 us against 83 with the read role in front; PISCES_HIP_ROLE_STRIDE for the A / B)
