@@ -5,7 +5,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 src = os.path.join("gpurun_out", tag)
 dst = "profiles"
 plain = {"bench_n1.json": "bench_n1.json", "bench_kernel_stats.csv": "bench_kernel_stats.csv", "streaming_kernel_stats.csv": "streaming_kernel_stats.csv",
@@ -13,7 +13,8 @@ plain = {"bench_n1.json": "bench_n1.json", "bench_kernel_stats.csv": "bench_kern
          "store_log_kernel_stats.csv": "store_log_kernel_stats.csv", "config3_kernel_stats.csv": "config3_blocks_kernel_stats.csv",
          "config3_batch_kernel_stats.csv": "config3_kernel_stats.csv", "config3_full.json": "config3_full.json", "config5_full.json": "config5_full.json", "config5_kernel_stats.csv": "config5_kernel_stats.csv",
          "config4.json": "config4.json", "bench_n1_k20.json": "bench_n1_k20.json", "bench_n2_one_device_b.json": "bench_n2_one_device.json",
-         "store_timing.txt": "store_timing.txt", "bgzf_bench.txt": "bgzf_bench.txt"}
+         "store_timing.txt": "store_timing.txt", "bgzf_bench.txt": "bgzf_bench.txt", "chain2_kernel_stats.csv": "chain_config2_kernel_stats.csv",
+         "chain5_kernel_stats.csv": "chain_config5_kernel_stats.csv", "chain.txt": "chain_bench.txt", "pair_bench.txt": "pair_bench.txt"}
 for a, b in plain.items():
     if os.path.exists(os.path.join(src, a)):
         shutil.copyfile(os.path.join(src, a), os.path.join(dst, f"{tag}_{b}"))
@@ -30,6 +31,7 @@ def cat(names, out):
 cat(["pmc_FETCH_SIZE.txt", "pmc_WRITE_SIZE.txt", "pmc_sq_lds.txt", "pmc_sq_wave.txt"], "sq_counters.txt")
 cat(["pmc_store_fetch.txt", "pmc_store_write.txt", "pmc_store_calib.txt", "pmc_store_sq.txt", "pmc_store_lds.txt"], "store_counters.txt")
 cat(["pmc_bgzf_mem.txt", "pmc_bgzf_sq.txt", "pmc_bgzf_lds.txt"], "bgzf_counters.txt")
+cat(["pmc_chain_fetch.txt", "pmc_chain_write.txt"], "chain_counters.txt")
 for name, out in (("hostfed.log", "streaming_bench.txt"), ("bam_bench.log", "bam_bench.txt")):
     p = os.path.join(src, name)
     if os.path.exists(p):

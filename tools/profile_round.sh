@@ -4,7 +4,7 @@
 # restricted to the hot kernel: the synthetic generator's thousands of small torch kernels are not instrumented), (4) SQ / LDS counters
 # of the hot kernel, (5) the streaming surface's and the BGZF / BAM kernels' statistics and counters.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
@@ -68,6 +68,16 @@ pmc store_lds call_store_tiles SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_L
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_c3 -o s -- python tools/config3_host_profile.py 40 > $OUT/config3.log 2>&1
 find /tmp/prof_${TAG}_c3 -name "*kernel_stats.csv" -exec cp {} $OUT/config3_kernel_stats.csv \;
 grep "rep 2" $OUT/config3.log
+# the device chain reads in HBM -> records in HBM (bench.py's roofline_chain): un-profiled spans by events, then the kernels under rocprofv3
+for cfgname in "2 --loci 100000 --depth 500" "5 --loci 15000 --depth 5000 --minbq 30"; do
+  set -- $cfgname; n=$1; shift
+  timeout 300 python tools/chain_bench.py "$@" 2>&1 | grep chain_bench | tee -a $OUT/chain.txt
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_chain$n -o s -- python tools/chain_bench.py "$@" > $OUT/chain${n}_prof.log 2>&1
+  find /tmp/prof_${TAG}_chain$n -name "*kernel_stats.csv" -exec cp {} $OUT/chain${n}_kernel_stats.csv \;
+done
+timeout 300 python tools/pair_bench.py 2>&1 | grep pair_bench | tee $OUT/pair_bench.txt
+pmc chain_fetch add_fused FETCH_SIZE -- python tools/chain_bench.py --reps 4
+pmc chain_write add_fused WRITE_SIZE -- python tools/chain_bench.py --reps 4
 # HBM traffic of the hot kernel per launch, for bench.py's roofline.traffic: FETCH_SIZE / WRITE_SIZE come in KiB; on gfx950 FETCH_SIZE
 # reports half the bytes of a wide coalesced streaming read (16 B per lane: this kernel's loads), so it is doubled (MI355X_MICROARCH.md, HBM)
 python - $OUT $TAG <<'PY'
