@@ -692,31 +692,12 @@ struct AddFusedArgs {
 constexpr int kScanDirectBlocks = 4096;   // read workgroups up to which the candidate-slot scan adds up the words before its own (beyond: look-back)
 constexpr unsigned long long kScanAggregate = 1ull << 62, kScanInclusive = 2ull << 62, kScanField = 0x7FFFFFFFull;
 
-__global__ __launch_bounds__(256, PISCES_ADD_OCC) void add_fused_kernel(AddFusedArgs A)
+// the stream and misc roles of an add's launch: workgroup sb of stream_blocks + misc_blocks (add_fused_kernel's workgroups that are not
+// read workgroups.  As a launch of their own on a second stream beside the read role's — the two roles want different register budgets, and
+// in one kernel every wave is given the larger — the two launches did not run side by side but one after the other: 98-107 us for the
+// add's span against 84-86, profiles/r06_add_fused.txt)
+__device__ __forceinline__ void add_stream_roles(const AddFusedArgs& A, const int sb)
 {
-    // Roles by workgroup index.  stream_first > 0: the launch's FIRST workgroups are the stream (and misc) role — a few persistent ones a CU
-    // that walk the batch's bytes from the launch's first microsecond to its last with 8 KB a wave in flight — and the read workgroups
-    // follow in index order (which is dispatch order: their scan waits for lower read indices only) into the slots that are left.  With the
-    // read role in front (stream_first == 0; every role_stride-th unit of eight workgroups — one per XCD — a read unit, until there are
-    // read_blocks of them) its workgroups take 85 % of the chip's wave slots for ~35 us of round trips and the launch's bytes wait for them.
-    const int raw = (int)blockIdx.x;
-    bool read_role;
-    int b;   // the index inside its role(s)
-    if (A.stream_first) {
-        const int front = A.stream_blocks + A.misc_blocks;
-        read_role = raw >= front;
-        b = read_role ? raw - front : raw;
-    } else {
-        const int unit = raw >> 3, in_unit = raw & 7;
-        const int uq = unit / A.role_stride;
-        const bool read_unit = unit - uq * A.role_stride == 0;
-        const int reads_before = min(A.read_blocks, ((unit + A.role_stride - 1) / A.role_stride) * 8 + (read_unit ? in_unit : 0));
-        read_role = read_unit && uq * 8 + in_unit < A.read_blocks;
-        b = read_role ? uq * 8 + in_unit : raw - reads_before;
-    }
-    __shared__ int s_wf[4], s_wp[4], s_excl[2], s_last;
-    if (!read_role) {
-        const int sb = b;
         if (sb < A.stream_blocks) {
             // ---- stream role
 #if PISCES_ADD_ABLATE == 1
@@ -794,6 +775,32 @@ __global__ __launch_bounds__(256, PISCES_ADD_OCC) void add_fused_kernel(AddFused
                 if (t < (n & 15)) dst[(n16 << 4) + t] = src[(n16 << 4) + t];
             }
         }
+}
+__global__ __launch_bounds__(256, PISCES_ADD_OCC) void add_fused_kernel(AddFusedArgs A)
+{
+    // Roles by workgroup index.  stream_first > 0: the launch's FIRST workgroups are the stream (and misc) role — a few persistent ones a CU
+    // that walk the batch's bytes from the launch's first microsecond to its last with 8 KB a wave in flight — and the read workgroups
+    // follow in index order (which is dispatch order: their scan waits for lower read indices only) into the slots that are left.  With the
+    // read role in front (stream_first == 0; every role_stride-th unit of eight workgroups — one per XCD — a read unit, until there are
+    // read_blocks of them) its workgroups take 85 % of the chip's wave slots for ~35 us of round trips and the launch's bytes wait for them.
+    const int raw = (int)blockIdx.x;
+    bool read_role;
+    int b;   // the index inside its role(s)
+    if (A.stream_first) {
+        const int front = A.stream_blocks + A.misc_blocks;
+        read_role = raw >= front;
+        b = read_role ? raw - front : raw;
+    } else {
+        const int unit = raw >> 3, in_unit = raw & 7;
+        const int uq = unit / A.role_stride;
+        const bool read_unit = unit - uq * A.role_stride == 0;
+        const int reads_before = min(A.read_blocks, ((unit + A.role_stride - 1) / A.role_stride) * 8 + (read_unit ? in_unit : 0));
+        read_role = read_unit && uq * 8 + in_unit < A.read_blocks;
+        b = read_role ? uq * 8 + in_unit : raw - reads_before;
+    }
+    __shared__ int s_wf[4], s_wp[4], s_excl[2], s_last;
+    if (!read_role) {
+        add_stream_roles(A, b);
         // (the streaming roles leave nothing the collecting workgroup reads: no fence, no count — a release fence here is a write-back of the
         // XCD's whole L2, and 8 000 workgroups x 4 waves of them made the launch 1.2 ms where its bytes take 45 us)
         return;

@@ -537,7 +537,11 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
             __builtin_ia32_pause();
         }
         std::atomic_thread_fence(std::memory_order_acquire);
-        if (!seen) PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+        if (!seen) {
+            PISCES_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+            // (the launch is over: its verdict is there, or the launch is broken — never a verdict of an earlier launch)
+            if (*ready != F.seq) return fail(h, PISCES_E_DEVICE, "add_reads: the launch that checks the batch ended without its verdict");
+        }
     }
 #ifdef PISCES_ADD_STAMPS
     {   // slots of a workgroup: read role [0] start, [2] prepare done, [3] shape done, [4] scan done, [5] counted, [6] collector done; stream role [2] start, [3] end
