@@ -373,7 +373,19 @@ def chain_roofline(pileup, cfg, engine, torch, reps=10):
     chain_ms = add_ms + flush_ms
     best = min(a + f for a, f in spans)
     achieved = nbytes / (chain_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+    traffic, traffic_run = None, None
+    try:   # separate rocprofv3 --pmc passes over tools/chain_bench.py (the same pair), tools/profile_round.sh
+        from pisces_amd import build as native_build
+        whole_file = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        tj = whole_file.get("chain", {})
+        if tj.get("loci") == pileup.n_loci and tj.get("depth") == pileup.depth:
+            if whole_file.get("source_hash") == native_build.source_hash():   # (collected on these kernels)
+                traffic, traffic_run = tj.get("hbm_bytes_per_batch"), tj.get("run")
+            else:
+                traffic_run = "stale: profiles/traffic.json was collected on other sources (%s)" % tj.get("run")
+    except Exception:   # noqa: BLE001
+        pass
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_from": traffic_run,
             "chain_ms": chain_ms, "add_device_reads_ms": add_ms, "flush_view_ms": flush_ms, "best_chain_ms": best, "pairs_timed": len(spans),
             "algorithmic_bytes_per_batch": nbytes, "reads": int(whole.n_reads), "records": n_rec, "loci": pileup.n_loci,
             "wall_clock_ms_per_pair": sum(walls) / len(walls) * 1e3,

@@ -521,7 +521,9 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
     F.stamps = h->d_add_stamps.p;
 #endif
     // (pisces_hip_set_chain_timing: the add's device time starts with its first kernel — what the host does before it is not the device's)
-    if (h->chain_timing && src) { h->chain_have[0] = false; PISCES_HIP_CHECK(h, hipEventRecord(h->ev_chain[0], h->stream)); }
+    h->chain_have[0] = false;
+    h->chain_add_open = false;
+    if (h->chain_timing && src) { PISCES_HIP_CHECK(h, hipEventRecord(h->ev_chain[0], h->stream)); h->chain_add_open = true; }
     hipLaunchKernelGGL(add_fused_kernel, dim3((unsigned)(F.read_blocks + F.stream_blocks + F.misc_blocks)), dim3(256), 0, h->stream, F);
     PISCES_HIP_CHECK(h, hipGetLastError());
     {   // The one wait of an add.  The collecting workgroup stores the launch's number behind the verdict: polling that word in pinned memory
@@ -650,7 +652,8 @@ static int32_t store_finish_add(PiscesHip* h, StorePlace& pl, int32_t rc, uint8_
         return rc;
     }
     // (pisces_hip_set_chain_timing: behind the last thing the add enqueues; what follows is the host's bookkeeping)
-    if (h->chain_timing) { PISCES_HIP_CHECK(h, hipEventRecord(h->ev_chain[1], h->stream)); h->chain_have[0] = true; }
+    if (h->chain_timing && h->chain_add_open) { PISCES_HIP_CHECK(h, hipEventRecord(h->ev_chain[1], h->stream)); h->chain_have[0] = true; }
+    h->chain_add_open = false;
     // ---- commit
     ReadSegment& g = *pl.seg;
     g.n_reads += nr;

@@ -109,6 +109,21 @@ if f and w:
     if sf and sw:   # tools/store_bench.py's one-batch flush of the same configuration (4 B / lane loads: the same x 2, tools/fetch_calibration.py)
         t["streaming"] = {"kernel": "pisces::call_store_tiles_kernel<2>", "loci": t["loci"], "depth": t["depth"], "fetch_size_kib_raw": sf, "fetch_correction": corr,
                           "write_size_kib_raw": sw, "hbm_bytes_per_launch": sf * 1024 * corr + sw * 1024, "run": t["run"] + " (pmc_store_fetch / pmc_store_write over tools/store_bench.py)"}
+    cf, cw = None, None
+    for name, key in (("chain_fetch", "FETCH_SIZE"), ("chain_write", "WRITE_SIZE")):
+        try:
+            for ln in open(f"{out}/pmc_{name}.txt"):
+                m = re.search(r"add_fused\S* " + key + r" mean per dispatch ([0-9.e+]+)", ln)
+                if m:
+                    cf, cw = (float(m.group(1)), cw) if key == "FETCH_SIZE" else (cf, float(m.group(1)))
+        except OSError:
+            pass
+    if cf and cw and "streaming" in t:   # the chain of roofline_chain: the add's launch + the flush's kernel + the compaction's 64 B a record in and out
+        add_bytes = cf * 1024 * corr + cw * 1024
+        t["chain"] = {"kernels": "pisces::add_fused_kernel + pisces::call_store_tiles_kernel<2> + pisces::gather_direct_kernel", "loci": t["loci"], "depth": t["depth"],
+                      "add_fused_fetch_size_kib_raw": cf, "add_fused_write_size_kib_raw": cw, "fetch_correction": corr, "add_fused_hbm_bytes": add_bytes,
+                      "hbm_bytes_per_batch": add_bytes + t["streaming"]["hbm_bytes_per_launch"] + 2 * 64.0 * t["loci"],
+                      "run": t["run"] + " (pmc_chain_fetch / pmc_chain_write over tools/chain_bench.py; the flush kernel's as `streaming`; the compaction counted at 64 B a record in and out)"}
     json.dump(t, open(f"{out}/traffic.json", "w"), indent=1)
     print("traffic.json:", t["hbm_bytes_per_launch"], "bytes per launch; algorithmic", line["roofline"]["algorithmic_bytes_per_launch"])
 PY
