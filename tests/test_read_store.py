@@ -565,6 +565,46 @@ def test_checks_on_the_device_refuse_what_the_host_pass_refuses(torch_cuda):
                 assert c.GetCounts(996, 8).sum() == 8 and c.GetCounts(5_000_001, 4).sum() == 4 and c.Stats()["reads"] == 3
 
 
+@pytest.mark.parametrize("how", ["device", "host_pass", "host_checked_on_the_device"])
+def test_one_bad_read_in_a_large_plain_batch_is_found_on_every_path(torch_cuda, how):
+    """70 000 plain <8>M reads — a batch that becomes a segment of its own (one launch makes its checks, descriptors, fragments and row
+    codes: add_fused_kernel) and, from the host, a batch the bulk loops of add_reads establish as plain — with ONE bad read somewhere:
+    a position of 0 in the middle, a CIGAR one base short near the end, a per-base direction of 3 in the batch's last bytes (checked by
+    the stream role, whose verdict the host waits for apart).  Every path refuses the batch with the reference's message and leaves the
+    handle as it was; the good batch then goes in and is counted."""
+    from pisces_amd import engine
+    n, L = 70_000, 8
+    pos = (20 + 2 * np.arange(n)).astype(np.int32)
+
+    def batch(bad=None):
+        position, clen = pos.copy(), np.full(n, L, np.uint32)
+        dirs = None
+        if bad == "position":
+            position[n // 2] = 0
+        elif bad == "cigar":
+            clen[n - 7] = L - 1
+        elif bad == "direction":
+            dirs = np.zeros(n * L, np.uint8)
+            dirs[n * L - 3] = 3
+        return _abi.ReadBatch.from_arrays(position, np.zeros(n, np.uint8), np.arange(n + 1, dtype=np.int32), np.full(n, ord("M"), np.uint8), clen,
+                                          L * np.arange(n + 1, dtype=np.int32), np.tile(np.frombuffer(b"ACGTACGT", np.uint8), n), np.full(n * L, 30, np.uint8),
+                                          directions=dirs)
+    kw = {"device": {}, "host_pass": dict(PISCES_HIP_DEVICE_CHECKS="0"), "host_checked_on_the_device": dict(PISCES_HIP_DEVICE_CHECKS="1")}[how]
+    with env(PISCES_HIP_READ_PATH=None, **kw):
+        with engine.HipVariantCaller() as c:
+            add = (lambda b: c.AddDeviceReads(engine.DeviceReadBatch.from_host(b, "cuda:0"))) if how == "device" else c.AddAlleleCounts
+            for bad, needle in (("position", "greater than 0"), ("cigar", "CIGAR does not match"), ("direction", "CIGAR does not match")):
+                before = c.Stats()
+                with pytest.raises(engine.PiscesHipError) as e:
+                    add(batch(bad))
+                assert e.value.code == _abi.E_INVALID_ARG and needle in e.value.message, (how, bad, e.value.message)
+                assert c.Stats() == before and c.GetCounts(20, 8).sum() == 0
+            add(batch())
+            assert c.Stats()["reads"] == n
+            counts = c.GetCounts(int(pos[n // 2]), 2)
+            assert counts.sum() == 2 * (L // 2)      # (reads two positions apart, eight bases long: four cover a position)
+
+
 @pytest.mark.parametrize("call_mnvs", [0, 1], ids=["snv_indel", "mnv"])
 def test_reads_added_ahead_of_the_flush_that_clears_what_lies_behind_them(torch_cuda, call_mnvs):
     """SmallVariantCaller adds a read and THEN calls up to its position - 1 (SmallVariantCaller.cs:88-105).  Stretch by stretch that is:
