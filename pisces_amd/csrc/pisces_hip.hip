@@ -293,6 +293,7 @@ struct PiscesHip {
     bool chain_timing = false;
     hipEvent_t ev_chain[4] = {nullptr, nullptr, nullptr, nullptr};
     bool chain_have[2] = {false, false};
+    bool chain_enqueued_since = false;        // ... and something was enqueued behind the span's provisional end (recorded behind the add's launch)
     bool chain_add_open = false;              // the add in progress recorded its first event (a batch in device memory)
     int64_t ring_used = 0;
     int64_t launches_seen = 0;

@@ -370,7 +370,8 @@ static int32_t store_shape_launch(PiscesHip* h, const StorePlace& pl, ShapeArgs 
     const unsigned grid_blocks = S.grid ? (unsigned)((nr + 255) / 256) : 0u;
     const unsigned n_blocks = (unsigned)S.shape_blocks + (unsigned)S.enc_blocks + grid_blocks;
     if (n_blocks && shaped && h->defer_grid) h->deferred_grid.push_back({S, n_blocks});   // (the grid role alone: enqueued with what comes next)
-    else if (n_blocks) hipLaunchKernelGGL(read_shape_kernel, dim3(n_blocks), dim3(256), 0, h->stream, S);
+    else if (n_blocks) { hipLaunchKernelGGL(read_shape_kernel, dim3(n_blocks), dim3(256), 0, h->stream, S); h->chain_enqueued_since = true; }
+    if (!pl.direct && !batch_has_dirs && g.v_dirs) h->chain_enqueued_since = true;
     if (!pl.direct && !batch_has_dirs && g.v_dirs)   // a batch without directions in a segment that tracks them
         hipLaunchKernelGGL(segment_fill_dirs_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, h->stream, (const ReadDesc*)g.desc.p,
                            (const ReadExt*)g.ext.p, S.n0, S.n0 + nr, const_cast<uint8_t*>(g.v_dirs));
@@ -526,6 +527,9 @@ static int32_t store_device_checks(PiscesHip* h, uint8_t* d, const StageLayout& 
     if (h->chain_timing && src) { PISCES_HIP_CHECK(h, hipEventRecord(h->ev_chain[0], h->stream)); h->chain_add_open = true; }
     hipLaunchKernelGGL(add_fused_kernel, dim3((unsigned)(F.read_blocks + F.stream_blocks + F.misc_blocks)), dim3(256), 0, h->stream, F);
     PISCES_HIP_CHECK(h, hipGetLastError());
+    // (the span's end goes in behind the launch at once: an event recorded after the verdict has come back would count the host's turn as
+    // the device's; whatever the add enqueues later — candidate discovery, a grid that is not kept back — records it again, behind itself)
+    if (h->chain_add_open) { PISCES_HIP_CHECK(h, hipEventRecord(h->ev_chain[1], h->stream)); h->chain_enqueued_since = false; }
     {   // The one wait of an add.  The collecting workgroup stores the launch's number behind the verdict: polling that word in pinned memory
         // sees it ~2 us after the store, where hipStreamSynchronize's wake-up takes 15-25 us during which the device has nothing to do (the
         // position grid and candidate discovery are enqueued behind the verdict).  The stream's other work is ordered by the stream itself.
@@ -639,6 +643,7 @@ static int32_t store_finish_add(PiscesHip* h, StorePlace& pl, int32_t rc, uint8_
             hipError_t e = hipMemcpyAsync(d + L.off_fslots, h->h_stage + L.off_fslots, L.total - L.off_fslots, hipMemcpyHostToDevice, h->stream);
             if (e != hipSuccess) rc = fail(h, PISCES_E_DEVICE, std::string("add_reads: ") + hipGetErrorString(e));
         }
+        h->chain_enqueued_since = true;
         if (rc == PISCES_OK)
             rc = enqueue_candidate_discovery(h, db, has_deldirs ? d + L.off_deldirs : nullptr, nr, (const int32_t*)(d + L.off_fslots), found_slots, found_pool);
         h->found.min_position = min_position;   // (a flush up to a position below every read of this batch need not wait for its candidates)
@@ -652,7 +657,10 @@ static int32_t store_finish_add(PiscesHip* h, StorePlace& pl, int32_t rc, uint8_
         return rc;
     }
     // (pisces_hip_set_chain_timing: behind the last thing the add enqueues; what follows is the host's bookkeeping)
-    if (h->chain_timing && h->chain_add_open) { PISCES_HIP_CHECK(h, hipEventRecord(h->ev_chain[1], h->stream)); h->chain_have[0] = true; }
+    if (h->chain_timing && h->chain_add_open) {
+        if (h->chain_enqueued_since) PISCES_HIP_CHECK(h, hipEventRecord(h->ev_chain[1], h->stream));
+        h->chain_have[0] = true;
+    }
     h->chain_add_open = false;
     // ---- commit
     ReadSegment& g = *pl.seg;
