@@ -76,6 +76,76 @@ def test_mathnet_restatement_against_scipy():
         assert orc.lib.orc_poisson_cdf(k, lam) == pytest.approx(float(sp.pdtr(k, lam)), rel=1e-10)
 
 
+def test_mathnet_restatement_on_dense_grids_against_scipy():
+    """The MathNet.Numerics 4.5.1 functions of the hot path (VariantQualityCalculator.cs:36-47: Poisson.CumulativeDistribution and
+    ProbabilityLn; StrandBiasCalculator.cs:164 / the diploid q-scores: BetaRegularized) are restated from their published algorithms
+    (the package is not under /root/reference) and the reference's own tests pin them at some twenty values; this holds the
+    restatement to an INDEPENDENT implementation (scipy's cephes / boost routines) on dense grids of the arguments the path produces —
+    supports up to 600, coverages up to 20 000, noise levels 20-40 — and the variant q-score itself, end to end, to the reference's formula
+    evaluated through scipy's survival function: the north star's own tolerance (+-1 Phred) may be used at rounding edges, nowhere else."""
+    sp = pytest.importorskip("scipy.special")
+    st = pytest.importorskip("scipy.stats")
+    L = orc.lib
+    # regularized lower incomplete gamma P(a, x)
+    worst = 0.0
+    for a in (1, 2, 3, 5, 8, 13, 25, 50, 99, 100, 101, 250, 500, 699, 700, 701, 1000, 2500, 5000, 10000):
+        for f in (0.01, 0.1, 0.5, 0.8, 0.95, 1.0, 1.05, 1.25, 2.0, 4.0):
+            x = a * f
+            want = float(sp.gammainc(a, x))
+            got = L.orc_mathnet_gamma_lower_regularized(float(a), float(x))
+            if want > 1e-290:
+                worst = max(worst, abs(got - want) / want)
+            else:
+                assert got < 1e-280
+    assert worst < 2e-10, worst
+    # ln Gamma
+    for z in np.concatenate([np.logspace(-1, 5, 240), np.arange(1, 700, 7.0)]):
+        assert L.orc_mathnet_gamma_ln(float(z)) == pytest.approx(float(sp.gammaln(z)), rel=2e-13, abs=2e-13), z
+    # Poisson: MathNet's CDF and ln PMF, and the repository's own Poisson.Cdf (stats/Poisson.cs:26-128)
+    for lam in (0.05, 0.5, 1.0, 2.5, 5.0, 10.0, 20.0, 50.0, 100.0, 200.0, 500.0):
+        ks = np.unique(np.concatenate([np.arange(0, 40), np.linspace(0, 3 * lam + 60, 60).astype(int)]))
+        for k in ks:
+            want = float(st.poisson.cdf(int(k), lam))
+            if want > 1e-280:
+                assert L.orc_mathnet_poisson_cdf(lam, float(k)) == pytest.approx(want, rel=5e-10), (lam, k)
+                own = L.orc_poisson_cdf(float(k), lam)
+                assert own == -1.0 or own == pytest.approx(want, rel=5e-9), (lam, k, own, want)   # (-1: the reference's "did not converge")
+            assert L.orc_mathnet_poisson_ln_pmf(lam, int(k)) == pytest.approx(float(st.poisson.logpmf(int(k), lam)), rel=1e-11, abs=1e-11), (lam, k)
+    # regularized incomplete beta (Binomial.CumulativeDistribution of the Diploid strand-bias model and the diploid q-scores)
+    if hasattr(L, "orc_mathnet_beta_regularized"):
+        L.orc_mathnet_beta_regularized.restype = C.c_double
+        L.orc_mathnet_beta_regularized.argtypes = [C.c_double, C.c_double, C.c_double]
+        for a in (0.5, 1, 2, 5, 20, 100, 500, 2000):
+            for b in (0.5, 1, 3, 10, 50, 400, 3000):
+                for x in (0.001, 0.02, 0.2, 0.5, 0.8, 0.98, 0.999):
+                    want = float(sp.betainc(a, b, x))
+                    if 1e-280 < want:
+                        assert L.orc_mathnet_beta_regularized(float(a), float(b), float(x)) == pytest.approx(want, rel=2e-9), (a, b, x)
+    # the variant q-score end to end: Q = round(min(maxQ, -10 log10(1 - CDF(k - 1; cov * 10^(-NL / 10))))) (VariantQualityCalculator.cs:27-65)
+    rng = np.random.default_rng(20260930)
+    n, off, edge = 0, 0, 0
+    for nl in (20, 30, 40):
+        cov = np.unique(np.concatenate([np.arange(1, 60), rng.integers(60, 20_001, 700)]))
+        for c in cov:
+            lam = float(c) * 10.0 ** (-nl / 10.0)
+            ks = np.unique(np.concatenate([np.arange(1, min(int(c), 12) + 1), rng.integers(1, min(int(c), 600) + 1, 12)]))
+            logsf = st.poisson.logsf(ks - 1, lam)
+            for k, ls in zip(ks, logsf):
+                raw = -10.0 * float(ls) / np.log(10.0)
+                # (the reference forms 1 - CDF in double precision: below p ~ 1e-12 its q-score is the cancellation's — 149 where the exact
+                # tail gives 166 at support 10 of coverage 10 — which the restatement follows operation by operation and which only MathNet's
+                # own bits, pinned by the reference's tables above, can check; the default cap of the q-score is 100)
+                if not np.isfinite(raw) or raw > 120.0:
+                    continue
+                got = L.orc_poisson_qscore(int(k), int(c), nl, 1 << 30)
+                want = int(np.rint(max(raw, 0.0)))
+                n += 1
+                if got != want:
+                    off += 1
+                    assert abs(got - want) <= 1 and abs(raw - np.floor(raw) - 0.5) < 1e-6, (k, c, nl, got, raw)   # a rounding edge, nothing else
+    assert n > 8_000 and off <= n // 2000, (n, off)
+
+
 # ---------------------------------------------------------------- strand bias
 def test_strand_bias_somatic_rows():
     g = load("strand_bias.json")
