@@ -106,7 +106,7 @@ def piece_plan(job, lo=None, hi=None, halo=synth.READ_LEN + 16):
     if lo is None:
         lo, hi = 1, len(job["ref"])
     keep = (ends >= lo) & (starts <= hi)
-    ivs = list(zip(np.maximum(starts[keep], lo).tolist(), np.minimum(ends[keep], hi).tolist()))
+    ivs = np.stack([np.maximum(starts[keep], lo), np.minimum(ends[keep], hi)], axis=1).astype(np.int32)   # (n, 2): first, last position
     idx, owner = shard.reads_for_shard(pos, job["read_end"], lo, hi, halo)
     i0 = i1 = 0
     if len(idx):
@@ -117,7 +117,8 @@ def piece_plan(job, lo=None, hi=None, halo=synth.READ_LEN + 16):
 
 def plan_loci(plan):
     """Positions of the piece's clipped intervals: with zero-coverage reference rows on (config 4's setting) every one of them has a row."""
-    return int(sum(e - s + 1 for s, e in plan["intervals"]))
+    iv = np.asarray(plan["intervals"], dtype=np.int64).reshape(-1, 2)
+    return int((iv[:, 1] - iv[:, 0] + 1).sum())
 
 
 def device_arrays(job, device="cuda:0"):

@@ -106,8 +106,8 @@ class HipVariantCaller:
 
     def SetIntervals(self, intervals):
         """ChrIntervalSet (sorted, disjoint, inclusive)."""
-        s = np.array([a for a, _ in intervals], dtype=np.int32)
-        e = np.array([b for _, b in intervals], dtype=np.int32)
+        iv = np.asarray(intervals, dtype=np.int32).reshape(-1, 2)   # (pairs, or an (n, 2) array: 16 000 tuples taken apart in Python were 2 ms a call)
+        s, e = np.ascontiguousarray(iv[:, 0]), np.ascontiguousarray(iv[:, 1])
         _check(self._h, lib.pisces_hip_set_intervals(self._h, s.ctypes.data, e.ctypes.data, len(s)))
 
     def SetOwnedRange(self, lo, hi):
